@@ -1,0 +1,166 @@
+/*
+ * xevd_hip.h - C ABI of the MI355X (gfx950) per-CU reconstruction backend for an MPEG-5 EVC decoder.
+ *
+ * This is the drop-in boundary: plain C, plain pointers and sizes, no C++/torch types.  Every entry point
+ * replaces one coarse slot of the reference decoder's function table (all citations are relative to the
+ * reference tree mpeg5/xevd v0.7.0):
+ *
+ *   xgpu_open / xgpu_close        <- xevd_platform_init / xevd_platform_deinit  src_base/xevd.c:2074-2163
+ *                                    (the `void *pf` "platform specific data" slot, src_base/xevd_def.h:1452-1470)
+ *   xgpu_pic_alloc / xgpu_pic_free<- PICBUF_ALLOCATOR.fn_alloc / fn_free         src_base/xevd_def.h:684-705
+ *   xgpu_frame_begin              <- slice_init + refp set-up                    src_base/xevd.c:378-405,1871-1903
+ *   xgpu_batch_create/_recon      <- body of xevd_ctu_row_rec_mt -> xevd_recon_unit
+ *                                                                                 src_base/xevd.c:1470-1526, 678-756
+ *                                    (xevd_sub_block_itdq, xevd_mc, xevd_recon_yuv, xevd_set_dec_info)
+ *   xgpu_deblock                  <- ctx->fn_deblock (xevd_deblock)              src_base/xevd.c:1116-1243,1909-1976
+ *   xgpu_pad                      <- ctx->fn_picbuf_expand                       src_base/xevd_util.c:365-427
+ *   xgpu_pic_download             <- xevd_pull (picture hand-off)                src_base/xevd.c:2042-2071
+ *
+ * plus fine-grained shims with the reference's per-block function-table signatures
+ * (XEVD_MC_L / XEVD_MC_C src_base/xevd_mc.h:47-49, XEVD_ITXB src_base/xevd_def.h:360, fn_recon :1466)
+ * so parity tests can drive one block exactly like the reference tables are driven: xgpu_test_*.
+ *
+ * Conventions (same as the reference's): every function returns XGPU_OK (0) or a negative error code with
+ * the numeric values of XEVD_ERR_* (inc/xevd.h:48-77); nothing throws; no global state - one xgpu_ctx per
+ * decoder instance, one HIP stream per ctx; a ctx is thread-compatible, not thread-safe.  All sample
+ * storage is 16-bit (`pel` = s16, src_base/xevd_port.h:51) also for 8-bit streams.
+ */
+#ifndef XEVD_HIP_H
+#define XEVD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XGPU_OK                    0
+#define XGPU_ERR                  (-1)    /* XEVD_ERR                      */
+#define XGPU_ERR_INVALID_ARGUMENT (-101)  /* XEVD_ERR_INVALID_ARGUMENT     */
+#define XGPU_ERR_OUT_OF_MEMORY    (-102)  /* XEVD_ERR_OUT_OF_MEMORY        */
+#define XGPU_ERR_UNSUPPORTED      (-105)  /* XEVD_ERR_UNSUPPORTED          */
+#define XGPU_ERR_UNEXPECTED       (-106)  /* XEVD_ERR_UNEXPECTED (HIP errors map here) */
+
+#define XGPU_MAX_REFS   17      /* XEVD_MAX_NUM_REF_PICS, src_base/xevd_def.h */
+#define XGPU_PAD_L      144     /* PIC_PAD_SIZE_L = MAX_CU_SIZE + 16, src_base/xevd_def.h:211 */
+#define XGPU_PAD_C      72      /* PIC_PAD_SIZE_C, :212 */
+
+/* prediction modes, numeric values of MODE_* in src_base/xevd_def.h:284-287 */
+#define XGPU_MODE_INTRA 0
+#define XGPU_MODE_INTER 1
+#define XGPU_MODE_SKIP  2
+#define XGPU_MODE_DIR   3
+
+typedef struct xgpu_ctx    xgpu_ctx;     /* one decoder instance on one GPU          */
+typedef struct xgpu_dbatch xgpu_dbatch;  /* a CU batch resident in HBM               */
+
+/* Sequence-level parameters: the SPS fields that change arithmetic on this path. */
+typedef struct xgpu_seq_params {
+    int device;               /* HIP device ordinal                                              */
+    int width, height;        /* luma picture size in samples (ctx->w, ctx->h); multiples of 8  */
+    int bit_depth_luma;       /* sps->bit_depth_luma_minus8 + 8   (8..12)                        */
+    int bit_depth_chroma;     /* sps->bit_depth_chroma_minus8 + 8                                */
+    int chroma_format_idc;    /* 1 (4:2:0) is implemented                                        */
+    int log2_ctu;             /* ctx->log2_max_cuwh: 6 Baseline (xevd.c:249-252), 5..7 Main      */
+    int tool_iqt;             /* sps->tool_iqt  : 16-bit two-stage transform + scale table ..72  */
+    int tool_admvp;           /* sps->tool_admvp: Main 8-tap luma / 4-tap chroma tables          */
+    int tool_addb;            /* sps->tool_addb : ADDB deblocking (else baseline filter)         */
+    int tool_alf;             /* sps->tool_alf                                                   */
+    int max_pics;             /* picture slots to make available (DPB + current), <= 34          */
+    /* chroma QP mapping tables (xevd_qp_chroma_dynamic[0..1][-qpBdOffsetC .. 57], xevd_tbl.c:359-426);
+       entry [c][qp + 6*(bit_depth_chroma-8)]; NULL = the default static table                        */
+    const int8_t *chroma_qp_table[2];
+} xgpu_seq_params;
+
+/* Per-picture parameters: what slice_init / the slice header contribute to this path. */
+typedef struct xgpu_frame_params {
+    int pic;                               /* destination picture slot                                   */
+    int poc;                               /* ctx->poc.poc_val                                           */
+    int num_refp[2];                       /* ctx->dpm.num_refp[list]                                    */
+    int refp_pic[XGPU_MAX_REFS][2];        /* picture slot of ctx->refp[idx][list].pic                   */
+    int refp_poc[XGPU_MAX_REFS][2];        /* ctx->refp[idx][list].pic->poc                              */
+    int qp_u_offset, qp_v_offset;          /* sh.qp_u_offset / sh.qp_v_offset (pic_qp_*_offset)          */
+    int deblock_alpha_offset, deblock_beta_offset;  /* sh_deblock_alpha/beta_offset (ADDB only)          */
+} xgpu_frame_params;
+
+/*
+ * One batch of decoded CUs (one tile or one picture), structure-of-arrays, in decode order, grouped by CTU.
+ * It is the post-entropy-decode record set of XEVD_CU_DATA (src_base/xevd_def.h:1145-1190) after MV
+ * derivation (xevd.c:705-728), flattened per leaf CU.  Coefficients are stored CU-contiguous exactly as
+ * coef_rect_to_series produces them (xevd.c:640-676): for a CU, the coded components in the order Y, U, V,
+ * each `w*h` (luma) / `(w/2)*(h/2)` (chroma) s16 values, row-major; an un-coded component occupies nothing.
+ */
+typedef struct xgpu_cu_batch {
+    int             n_cu;
+    const uint16_t *x, *y;        /* [n_cu] top-left luma sample                                          */
+    const uint8_t  *log2w, *log2h;/* [n_cu] 2..6 (7 with Main CTU 128)                                    */
+    const uint8_t  *pred_mode;    /* [n_cu] XGPU_MODE_*; SKIP/DIR are inter CUs (MVs already derived)     */
+    const int8_t   *refi;         /* [n_cu][2]  reference index per list, <0 = unused                     */
+    const int16_t  *mv;           /* [n_cu][2][2] quarter-pel (list, x/y), unclipped                      */
+    const uint8_t  *qp;           /* [n_cu][3]  core->qp_y/qp_u/qp_v: dequant QPs incl. 6*(bd-8)          */
+    const uint8_t  *cbf;          /* [n_cu]  bit c set = component c has coefficients (is_coef[c])        */
+    const uint8_t  *ipm;          /* [n_cu][2] intra luma / chroma mode (intra CUs)                       */
+    const uint32_t *coef_off;     /* [n_cu]  offset (in s16 units) of the CU's first coefficient          */
+    const int16_t  *coef;         /* [n_coef] coefficient arena                                           */
+    size_t          n_coef;
+    int             n_ctu;
+    const uint32_t *ctu_cu_start; /* [n_ctu+1] first CU of every CTU in raster CTU order                  */
+} xgpu_cu_batch;
+
+/* ------------------------------------------------------------------ lifetime ---------------------- */
+int  xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out);
+void xgpu_close(xgpu_ctx *ctx);
+int  xgpu_sync(xgpu_ctx *ctx);                         /* wait for everything enqueued on the ctx stream */
+const char *xgpu_last_error(const xgpu_ctx *ctx);
+const char *xgpu_version(void);
+
+/* ------------------------------------------------------------------ pictures ---------------------- */
+int  xgpu_pic_alloc(xgpu_ctx *ctx);                    /* -> slot >= 0, or error                          */
+int  xgpu_pic_free(xgpu_ctx *ctx, int pic);
+/* planes point at the first ACTIVE sample (XEVD_PIC.y/u/v); strides in samples.  Upload does not pad.   */
+int  xgpu_pic_upload(xgpu_ctx *ctx, int pic, const int16_t *y, int s_y, const int16_t *u, const int16_t *v, int s_c);
+int  xgpu_pic_download(xgpu_ctx *ctx, int pic, int16_t *y, int s_y, int16_t *u, int16_t *v, int s_c);
+/* whole padded buffers (XEVD_PIC.buf_y/u/v layout: stride = w + 2*pad, rows = h + 2*pad), for tests.     */
+int  xgpu_pic_download_padded(xgpu_ctx *ctx, int pic, int16_t *buf_y, int16_t *buf_u, int16_t *buf_v);
+int  xgpu_pic_upload_padded(xgpu_ctx *ctx, int pic, const int16_t *buf_y, const int16_t *buf_u, const int16_t *buf_v);
+
+/* ------------------------------------------------------------------ per picture ------------------- */
+int  xgpu_frame_begin(xgpu_ctx *ctx, const xgpu_frame_params *fp);
+/* copy a batch into HBM (pinned staging + async H2D) and build its device work lists */
+int  xgpu_batch_create(xgpu_ctx *ctx, const xgpu_cu_batch *b, xgpu_dbatch **out);
+void xgpu_batch_destroy(xgpu_ctx *ctx, xgpu_dbatch *db);
+/* dequant + inverse transform of every coded TB, then MC + residual add + clip of every inter CU, and the
+   SCU map update (xevd_set_dec_info) the in-loop filters read.  Asynchronous on the ctx stream.          */
+int  xgpu_batch_recon(xgpu_ctx *ctx, xgpu_dbatch *db);
+/* both deblocking passes over the current picture (vertical edges, then horizontal edges)               */
+int  xgpu_deblock(xgpu_ctx *ctx);
+/* replicate the picture border into the 144/72-sample padding                                            */
+int  xgpu_pad(xgpu_ctx *ctx);
+int  xgpu_frame_end(xgpu_ctx *ctx);
+
+/* ------------------------------------------------------------------ measurement ------------------- */
+/* Kernel families timed with HIP events on the ctx stream (the stream the kernels are launched on).      */
+enum { XGPU_K_ITDQ = 0, XGPU_K_INTER = 1, XGPU_K_DBK_V = 2, XGPU_K_DBK_H = 3, XGPU_K_PAD = 4, XGPU_K_INTRA = 5,
+       XGPU_K_ALF = 6, XGPU_K_COUNT = 8 };
+int  xgpu_timing_enable(xgpu_ctx *ctx, int on);
+int  xgpu_timing_reset(xgpu_ctx *ctx);
+/* resolves pending events (synchronises) and returns accumulated milliseconds and launch counts          */
+int  xgpu_timing_get(xgpu_ctx *ctx, double ms[XGPU_K_COUNT], long long launches[XGPU_K_COUNT]);
+/* plain device-to-device copy bandwidth (bytes read + written per second) - the "measured roofline"      */
+int  xgpu_measure_copy_bw(xgpu_ctx *ctx, size_t bytes, int iters, double *gbps);
+
+/* ------------------------------------------------------------------ fine-grained test shims ------- */
+/* Host buffers in, host buffers out, one block per call, reference function-table signatures.
+   `ref` points INTO a host plane that has at least the filter margin around the addressed window.       */
+int xgpu_test_mc_l(xgpu_ctx *ctx, const int16_t *ref_plane, int plane_w, int plane_h, int ref_x, int ref_y,
+                   int has_dx, int has_dy, int gmv_x, int gmv_y, int16_t *pred, int w, int h, int bit_depth);
+int xgpu_test_mc_c(xgpu_ctx *ctx, const int16_t *ref_plane, int plane_w, int plane_h, int ref_x, int ref_y,
+                   int has_dx, int has_dy, int gmv_x, int gmv_y, int16_t *pred, int w, int h, int bit_depth);
+/* dequant + 2-D inverse transform of n blocks of one size, in place (xevd_itdq, src_base/xevd_itdq.c:494) */
+int xgpu_test_itdq(xgpu_ctx *ctx, int16_t *coef, int n_blocks, int log2w, int log2h, const uint8_t *qp, int bit_depth);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XEVD_HIP_H */

@@ -1,0 +1,223 @@
+/*
+ * ref_harness.c - OUR driver around the REAL reference functions (test infrastructure only).
+ *
+ * Compiled by oracle/Makefile.ref against the reference's headers where they lie (/root/reference) and linked
+ * to oracle/_ref/libxevd_ref.so; the output (oracle/_ref/libref_harness.so) exists only in the development
+ * container and travels to the GPU box as a prebuilt .so.  No reference source is copied: this file only
+ * fills the reference's own structs (XEVD_CTX / XEVD_CORE / XEVD_PIC / XEVD_REFP) from our batch format and
+ * calls the reference's exported functions, so that picture-level golden outputs are computed by reference
+ * arithmetic:
+ *   xevd_sub_block_itdq   src_base/xevd_itdq.c:544      xevdm_sub_block_itdq  src_main/xevdm_itdq.c:790
+ *   xevd_mc               src_base/xevd_mc.c:469        xevdm_mc              src_main/xevdm_mc.c:1860
+ *   xevd_recon            src_base/xevd_recon.c:35      xevd_set_dec_info     src_base/xevd_util.c:1574
+ *   xevd_deblock_cu_ver / _hor  src_base/xevd_df.c:385 / :291
+ *   xevd_picbuf_lc_expand src_base/xevd_util.c:420
+ * The loop structure mirrors xevd_recon_unit (src_base/xevd.c:678-756) and the two deblocking passes
+ * (src_base/xevd.c:1116-1243).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "xevdm_def.h"
+#include "xevdm_mc.h"
+#include "xevdm_itdq.h"
+#include "xevd_oracle.h"
+
+/* reference tables selected like xevd_platform_init does (src_base/xevd.c:2074-2149) */
+static void select_tables(XEVD_CTX *ctx, int simd)
+{
+    /* the interpolation-table pointers are process globals (xevd_mc.c:137-138) that only xevdm_mc rewrites
+       (xevdm_mc.c:1914-1924); start every picture from their initial Baseline value */
+    tbl_mc_l_coeff = xevd_tbl_mc_l_coeff;
+    tbl_mc_c_coeff = xevd_tbl_mc_c_coeff;
+    if (simd) {
+        xevd_func_mc_l = xevd_tbl_mc_l_avx;
+        xevd_func_mc_c = xevd_tbl_mc_c_avx;
+        xevd_func_average_no_clip = &xevd_average_16b_no_clip_sse;
+        ctx->fn_itxb = &xevd_tbl_itxb_avx;
+        ctx->fn_recon = &xevd_recon_avx;
+        ctx->fn_dbk = &xevd_tbl_dbk_sse;
+        ctx->fn_dbk_chroma = &xevd_tbl_dbk_chroma_sse;
+        xevdm_fn_itx = &xevdm_tbl_itx_avx;
+    } else {
+        xevd_func_mc_l = xevd_tbl_mc_l;
+        xevd_func_mc_c = xevd_tbl_mc_c;
+        xevd_func_average_no_clip = &xevd_average_16b_no_clip;
+        ctx->fn_itxb = &xevd_tbl_itxb;
+        ctx->fn_recon = &xevd_recon;
+        ctx->fn_dbk = &xevd_tbl_dbk;
+        ctx->fn_dbk_chroma = &xevd_tbl_dbk_chroma;
+        xevdm_fn_itx = &xevdm_tbl_itx;
+    }
+}
+
+typedef struct {
+    XEVD_CTX  *ctx;
+    XEVD_CORE *core;
+    XEVD_SPS   sps;
+    XEVD_PIC   cur;
+    XEVD_PIC   rpic[XGPU_MAX_REFS][2];
+    u8        *map_tidx;
+    s8        *map_ipm;
+    u32       *map_cu_mode;
+} harness;
+
+static void fill_pic(XEVD_PIC *p, const orc_pic *o, const xgpu_seq_params *sp)
+{
+    memset(p, 0, sizeof(*p));
+    p->y = o->y; p->u = o->u; p->v = o->v;
+    p->s_l = o->s_l; p->s_c = o->s_c;
+    p->w_l = sp->width; p->h_l = sp->height; p->w_c = sp->width >> 1; p->h_c = sp->height >> 1;
+    p->pad_l = XGPU_PAD_L; p->pad_c = XGPU_PAD_C;
+    p->poc = o->poc;
+}
+
+static harness *harness_new(const xgpu_seq_params *sp, const orc_frame *fr, orc_maps *m, int simd)
+{
+    harness *h = (harness *)calloc(1, sizeof(harness));
+    int i, l, n = m->w_scu * m->h_scu;
+    h->ctx = (XEVD_CTX *)calloc(1, sizeof(XEVDM_CTX));     /* XEVDM_CTX begins with XEVD_CTX bctx */
+    h->core = (XEVD_CORE *)calloc(1, sizeof(XEVDM_CORE));
+    h->map_tidx = (u8 *)calloc(n, 1);
+    h->map_ipm = (s8 *)calloc(n, 1);
+    h->map_cu_mode = (u32 *)calloc(n, sizeof(u32));
+    h->sps.bit_depth_luma_minus8 = sp->bit_depth_luma - 8;
+    h->sps.bit_depth_chroma_minus8 = sp->bit_depth_chroma - 8;
+    h->sps.chroma_format_idc = sp->chroma_format_idc;
+    h->ctx->sps = &h->sps;
+    h->ctx->w = sp->width; h->ctx->h = sp->height;
+    h->ctx->w_scu = m->w_scu; h->ctx->h_scu = m->h_scu; h->ctx->f_scu = n;
+    h->ctx->map_scu = m->map_scu;
+    h->ctx->map_refi = (s8 (*)[REFP_NUM])m->map_refi;
+    h->ctx->map_mv = (s16 (*)[REFP_NUM][MV_D])m->map_mv;
+    h->ctx->map_tidx = h->map_tidx;
+    h->ctx->map_ipm = h->map_ipm;
+    h->ctx->map_cu_mode = h->map_cu_mode;
+    h->ctx->slice_num = 0;
+    fill_pic(&h->cur, &fr->cur, sp);
+    h->cur.pic_qp_u_offset = fr->qp_u_offset;
+    h->cur.pic_qp_v_offset = fr->qp_v_offset;
+    h->ctx->pic = &h->cur;
+    for (i = 0; i < XGPU_MAX_REFS; i++) for (l = 0; l < 2; l++) {
+        fill_pic(&h->rpic[i][l], &fr->refp[i][l], sp);
+        h->ctx->refp[i][l].pic = &h->rpic[i][l];
+        h->ctx->refp[i][l].poc = fr->refp[i][l].poc;
+    }
+    select_tables(h->ctx, simd);
+    /* chroma QP mapping exactly as sequence_init sets it up (src_base/xevd.c:347-358) */
+    xevd_set_chroma_qp_tbl_loc(sp->bit_depth_luma);
+    if (sp->chroma_qp_table[0] && sp->chroma_qp_table[1]) {
+        const int boff = 6 * (sp->bit_depth_chroma - 8);
+        for (i = -boff; i <= 57; i++) {
+            xevd_qp_chroma_dynamic[0][i] = sp->chroma_qp_table[0][i + boff];
+            xevd_qp_chroma_dynamic[1][i] = sp->chroma_qp_table[1][i + boff];
+        }
+    } else {
+        for (i = 0; i < XEVD_MAX_QP_TABLE_SIZE; i++) {
+            xevd_qp_chroma_dynamic[0][i] = xevd_tbl_qp_chroma_adjust_base[i];
+            xevd_qp_chroma_dynamic[1][i] = xevd_tbl_qp_chroma_adjust_base[i];
+        }
+    }
+    return h;
+}
+
+static void harness_free(harness *h)
+{
+    free(h->map_tidx); free(h->map_ipm); free(h->map_cu_mode); free(h->core); free(h->ctx); free(h);
+}
+
+int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *m,
+                     int16_t *resid_out, int simd)
+{
+    harness *hn = harness_new(sp, fr, m, simd);
+    XEVD_CTX *ctx = hn->ctx; XEVD_CORE *core = hn->core;
+    XEVDM_CORE *mcore = (XEVDM_CORE *)core;
+    const int main_path = sp->tool_admvp || sp->tool_iqt;
+    int i, c;
+
+    for (i = 0; i < b->n_cu; i++) {
+        const int x = b->x[i], y = b->y[i], lw = b->log2w[i], lh = b->log2h[i], w = 1 << lw, h = 1 << lh;
+        size_t off = b->coef_off[i], o = off;
+        core->log2_cuw = lw; core->log2_cuh = lh; core->cuw = w; core->cuh = h;
+        core->x_scu = x >> 2; core->y_scu = y >> 2;
+        core->scup = core->x_scu + core->y_scu * ctx->w_scu;
+        core->pred_mode = b->pred_mode[i];
+        core->qp_y = b->qp[i * 3]; core->qp_u = b->qp[i * 3 + 1]; core->qp_v = b->qp[i * 3 + 2];
+        core->qp = core->qp_y - 6 * (sp->bit_depth_luma - 8);
+        core->ipm[0] = b->ipm ? b->ipm[i * 2] : 0; core->ipm[1] = b->ipm ? b->ipm[i * 2 + 1] : 0;
+        memset(core->is_coef_sub, 0, sizeof(core->is_coef_sub));
+        for (c = 0; c < 3; c++) {
+            const int n = c ? (w >> 1) * (h >> 1) : w * h;
+            core->is_coef[c] = (b->cbf[i] >> c) & 1;
+            core->is_coef_sub[c][0] = core->is_coef[c];
+            if (core->is_coef[c]) { memcpy(core->coef[c], b->coef + o, sizeof(s16) * n); o += n; }
+        }
+        if (b->pred_mode[i] == XGPU_MODE_INTRA) {
+            core->refi[0] = core->refi[1] = -1;
+            memset(core->mv, 0, sizeof(core->mv));
+        } else {
+            core->refi[0] = b->refi[i * 2]; core->refi[1] = b->refi[i * 2 + 1];
+            memcpy(core->mv, &b->mv[i * 4], sizeof(s16) * 4);
+        }
+        /* inverse quantisation + transform: xevd.c:694-698 (xevd_lc_itdq) */
+        if (main_path)
+            xevdm_sub_block_itdq(ctx, core->coef, lw, lh, core->qp_y, core->qp_u, core->qp_v, core->is_coef, core->is_coef_sub,
+                                 sp->tool_iqt, 0, 0, 0, sp->bit_depth_luma, sp->chroma_format_idc);
+        else
+            xevd_sub_block_itdq(ctx, core->coef, lw, lh, core->qp_y, core->qp_u, core->qp_v, core->is_coef, core->is_coef_sub,
+                                sp->bit_depth_luma, sp->chroma_format_idc);
+        if (resid_out) {
+            o = off;
+            for (c = 0; c < 3; c++) {
+                const int n = c ? (w >> 1) * (h >> 1) : w * h;
+                if (core->is_coef[c]) { memcpy(resid_out + o, core->coef[c], sizeof(s16) * n); o += n; }
+            }
+        }
+        if (b->pred_mode[i] != XGPU_MODE_INTRA) {
+            /* prediction: xevd.c:725-726 / xevdm.c:1311-1316 (DMVR off) */
+            if (main_path) {
+                u8 dmvr_flag = 0;
+                xevdm_mc(x, y, ctx->w, ctx->h, w, h, core->refi, core->mv, ctx->refp, core->pred, fr->cur.poc,
+                         mcore->dmvr_template, mcore->dmvr_ref_pred_interpolated, mcore->dmvr_half_pred_interpolated, 0,
+                         mcore->dmvr_padding_buf, &dmvr_flag, mcore->dmvr_mv, sp->tool_admvp,
+                         sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
+            } else {
+                xevd_mc(x, y, ctx->w, ctx->h, w, h, core->refi, core->mv, ctx->refp, core->pred, fr->cur.poc,
+                        sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
+            }
+            /* reconstruction: xevd_recon_yuv, xevd_recon.c:70-92 */
+            xevd_recon_yuv(ctx, core, x, y, w, h);
+        }
+        xevd_set_dec_info(ctx, core);
+        {   /* MCU_SET_COD over the CU, xevd.c:746-754 */
+            int r, q;
+            for (r = 0; r < h >> 2; r++) for (q = 0; q < w >> 2; q++)
+                MCU_SET_COD(ctx->map_scu[core->scup + r * ctx->w_scu + q]);
+        }
+    }
+    harness_free(hn);
+    return 0;
+}
+
+int refh_deblock_baseline(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *m, int simd)
+{
+    harness *hn = harness_new(sp, fr, m, simd);
+    XEVD_CTX *ctx = hn->ctx;
+    int i, k;
+    /* vertical edges, then horizontal edges; COD cleared before each pass (xevd.c:1179-1188, 1221-1227);
+       leaf CUs visited in decode order as deblock_tree does (xevd.c:1057-1114) */
+    for (k = 0; k < (int)ctx->f_scu; k++) MCU_CLR_COD(ctx->map_scu[k]);
+    for (i = 0; i < b->n_cu; i++)
+        xevd_deblock_cu_ver(ctx, ctx->pic, b->x[i], b->y[i], 1 << b->log2w[i], 1 << b->log2h[i], 0);
+    for (k = 0; k < (int)ctx->f_scu; k++) MCU_CLR_COD(ctx->map_scu[k]);
+    for (i = 0; i < b->n_cu; i++)
+        xevd_deblock_cu_hor(ctx, ctx->pic, b->x[i], b->y[i], 1 << b->log2w[i], 1 << b->log2h[i], 0);
+    harness_free(hn);
+    return 0;
+}
+
+void refh_pad(const xgpu_seq_params *sp, const orc_pic *p)
+{
+    XEVD_PIC pic;
+    fill_pic(&pic, p, sp);
+    xevd_picbuf_lc_expand(&pic, XGPU_PAD_L, XGPU_PAD_C);
+}

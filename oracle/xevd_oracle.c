@@ -1,0 +1,520 @@
+/*
+ * xevd_oracle.c - plain-C CPU restatement of the reference's per-CU reconstruction path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see xevd_oracle.h).  Parity status: PINNED against the reference built in
+ * oracle/_ref (tests/test_oracle_vs_ref.py) and against tests/golden/*.npz.
+ *
+ * Written from the reference's behaviour, not copied from it: FIRs are generic tap loops, the inverse
+ * transform is an exact integer matrix product with tables generated from the closed form, the deblocking
+ * driver walks the CU list.  Every function names the reference lines it must agree with bit for bit.
+ */
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include "xevd_oracle.h"
+
+#define CLIP3(lo, hi, v) ((v) < (lo) ? (lo) : ((v) > (hi) ? (hi) : (v)))
+#define MAX_CU 128
+#define ORC_PI 3.14159265358979323846
+
+/* ------------------------------------------------------------------------------------------------
+ * interpolation filter tables.  Baseline: src_base/xevd_mc.c:80-134 (only phases 0,4,8,12 / 0,4,..,28 are
+ * populated).  Main (sps_admvp_flag): src_main/xevdm_mc.c:121-175, 16 luma / 32 chroma phases.
+ * ---------------------------------------------------------------------------------------------- */
+static const int16_t k_luma_base[4][8] = {          /* phase = row*4 */
+    { 0, 0,   0, 64,  0,   0, 0, 0 },
+    { 0, 1,  -5, 52, 20,  -5, 1, 0 },
+    { 0, 2, -10, 40, 40, -10, 2, 0 },
+    { 0, 1,  -5, 20, 52,  -5, 1, 0 },
+};
+static const int16_t k_chroma_base[8][4] = {        /* phase = row*4 */
+    {  0, 64,  0,  0 }, { -2, 58, 10, -2 }, { -4, 52, 20, -4 }, { -6, 46, 30, -6 },
+    { -8, 40, 40, -8 }, { -6, 30, 46, -6 }, { -4, 20, 52, -4 }, { -2, 10, 58, -2 },
+};
+static const int16_t k_luma_main[16][8] = {
+    {  0, 0,   0, 64,  0,   0,  0,  0 }, {  0, 1,  -3, 63,  4,  -2,  1,  0 },
+    { -1, 2,  -5, 62,  8,  -3,  1,  0 }, { -1, 3,  -8, 60, 13,  -4,  1,  0 },
+    { -1, 4, -10, 58, 17,  -5,  1,  0 }, { -1, 4, -11, 52, 26,  -8,  3, -1 },
+    { -1, 3,  -9, 47, 31, -10,  4, -1 }, { -1, 4, -11, 45, 34, -10,  4, -1 },
+    { -1, 4, -11, 40, 40, -11,  4, -1 }, { -1, 4, -10, 34, 45, -11,  4, -1 },
+    { -1, 4, -10, 31, 47,  -9,  3, -1 }, { -1, 3,  -8, 26, 52, -11,  4, -1 },
+    {  0, 1,  -5, 17, 58, -10,  4, -1 }, {  0, 1,  -4, 13, 60,  -8,  3, -1 },
+    {  0, 1,  -3,  8, 62,  -5,  2, -1 }, {  0, 1,  -2,  4, 63,  -3,  1,  0 },
+};
+static const int16_t k_chroma_main[32][4] = {
+    {  0, 64,  0,  0 }, { -1, 63,  2,  0 }, { -2, 62,  4,  0 }, { -2, 60,  7, -1 },
+    { -2, 58, 10, -2 }, { -3, 57, 12, -2 }, { -4, 56, 14, -2 }, { -4, 55, 15, -2 },
+    { -4, 54, 16, -2 }, { -5, 53, 18, -2 }, { -6, 52, 20, -2 }, { -6, 49, 24, -3 },
+    { -6, 46, 28, -4 }, { -5, 44, 29, -4 }, { -4, 42, 30, -4 }, { -4, 39, 33, -4 },
+    { -4, 36, 36, -4 }, { -4, 33, 39, -4 }, { -4, 30, 42, -4 }, { -4, 29, 44, -5 },
+    { -4, 28, 46, -6 }, { -3, 24, 49, -6 }, { -2, 20, 52, -6 }, { -2, 18, 53, -5 },
+    { -2, 16, 54, -4 }, { -2, 15, 55, -4 }, { -2, 14, 56, -4 }, { -2, 12, 57, -3 },
+    { -2, 10, 58, -2 }, { -1,  7, 60, -2 }, {  0,  4, 62, -2 }, {  0,  2, 63, -1 },
+};
+
+static void luma_taps(int phase, int admvp, int16_t t[8])
+{
+    int k;
+    if (admvp) { for (k = 0; k < 8; k++) t[k] = k_luma_main[phase][k]; return; }
+    /* baseline table rows other than 0,4,8,12 are all-zero (xevd_mc.c:83-97) */
+    for (k = 0; k < 8; k++) t[k] = (phase & 3) ? 0 : k_luma_base[phase >> 2][k];
+}
+static void chroma_taps(int phase, int admvp, int16_t t[4])
+{
+    int k;
+    if (admvp) { for (k = 0; k < 4; k++) t[k] = k_chroma_main[phase][k]; return; }
+    for (k = 0; k < 4; k++) t[k] = (phase & 3) ? 0 : k_chroma_base[phase >> 2][k];
+}
+
+/*
+ * Generic separable FIR with the reference's four rounding regimes (ntap = 8 luma / 4 chroma):
+ *   00: copy                                              xevd_mc.c:169-188 / 290-309
+ *   n0: (sum) >> 6, no rounding offset, clip              :190-212 / 311-333   (MAC_SFT_N0 6, MAC_ADD_N0 0, xevd_mc.h:34-38)
+ *   0n: same, vertical                                    :215-237 / 335-358
+ *   nn: stage1 (sum) >> min(4,bd-8) stored as s16 (wraps), stage2 (sum + 2^(s2-1)) >> s2, s2 = max(8,20-bd), clip
+ *                                                         :240-284 / 360-408
+ * prec = fractional bits of gmv (4 luma, 5 chroma).
+ */
+static void fir_block(const int16_t *ref, int gmv_x, int gmv_y, int s_ref, int s_pred, int16_t *pred, int w, int h,
+                      int bd, int has_dx, int has_dy, int ntap, int prec, const int16_t *tx, const int16_t *ty)
+{
+    const int half = ntap / 2 - 1;              /* 3 luma, 1 chroma */
+    const int ix = gmv_x >> prec, iy = gmv_y >> prec;
+    const int maxv = (1 << bd) - 1;
+    int i, j, k;
+
+    if (!has_dx && !has_dy) {
+        const int16_t *r = ref + iy * s_ref + ix;
+        for (i = 0; i < h; i++) for (j = 0; j < w; j++) pred[i * s_pred + j] = r[i * s_ref + j];
+    } else if (has_dx && !has_dy) {
+        const int16_t *r = ref + iy * s_ref + ix - half;
+        for (i = 0; i < h; i++) for (j = 0; j < w; j++) {
+            int32_t s = 0;
+            for (k = 0; k < ntap; k++) s += tx[k] * r[i * s_ref + j + k];
+            s >>= 6;
+            pred[i * s_pred + j] = (int16_t)CLIP3(0, maxv, s);
+        }
+    } else if (!has_dx && has_dy) {
+        const int16_t *r = ref + (iy - half) * s_ref + ix;
+        for (i = 0; i < h; i++) for (j = 0; j < w; j++) {
+            int32_t s = 0;
+            for (k = 0; k < ntap; k++) s += ty[k] * r[(i + k) * s_ref + j];
+            s >>= 6;
+            pred[i * s_pred + j] = (int16_t)CLIP3(0, maxv, s);
+        }
+    } else {
+        const int16_t *r = ref + (iy - half) * s_ref + ix - half;
+        const int shift1 = bd - 8 < 4 ? bd - 8 : 4;
+        const int shift2 = 20 - bd > 8 ? 20 - bd : 8;
+        const int32_t off2 = 1 << (shift2 - 1);
+        int16_t *tmp = (int16_t *)malloc(sizeof(int16_t) * (size_t)(h + ntap - 1) * w);
+        for (i = 0; i < h + ntap - 1; i++) for (j = 0; j < w; j++) {
+            int32_t s = 0;
+            for (k = 0; k < ntap; k++) s += tx[k] * r[i * s_ref + j + k];
+            tmp[i * w + j] = (int16_t)(s >> shift1);          /* s16 store: wraps like the reference's buffer */
+        }
+        for (i = 0; i < h; i++) for (j = 0; j < w; j++) {
+            int32_t s = 0;
+            for (k = 0; k < ntap; k++) s += ty[k] * tmp[(i + k) * w + j];
+            s = (s + off2) >> shift2;
+            pred[i * s_pred + j] = (int16_t)CLIP3(0, maxv, s);
+        }
+        free(tmp);
+    }
+}
+
+void orc_mc_l(const int16_t *ref, int gmv_x, int gmv_y, int s_ref, int s_pred, int16_t *pred, int w, int h,
+              int bit_depth, int has_dx, int has_dy, int admvp)
+{
+    int16_t tx[8], ty[8];
+    luma_taps(gmv_x & 15, admvp, tx);
+    luma_taps(gmv_y & 15, admvp, ty);
+    fir_block(ref, gmv_x, gmv_y, s_ref, s_pred, pred, w, h, bit_depth, has_dx, has_dy, 8, 4, tx, ty);
+}
+
+void orc_mc_c(const int16_t *ref, int gmv_x, int gmv_y, int s_ref, int s_pred, int16_t *pred, int w, int h,
+              int bit_depth, int has_dx, int has_dy, int admvp)
+{
+    int16_t tx[4], ty[4];
+    chroma_taps(gmv_x & 31, admvp, tx);
+    chroma_taps(gmv_y & 31, admvp, ty);
+    fir_block(ref, gmv_x, gmv_y, s_ref, s_pred, pred, w, h, bit_depth, has_dx, has_dy, 4, 5, tx, ty);
+}
+
+/* xevd_mv_clip, src_base/xevd_mc.c:435-467: block start clipped to [-128, pic-1+128] in quarter-pel units */
+static void mv_clip(int x, int y, int pic_w, int pic_h, int w, int h, const int8_t refi[2], const int16_t mv[2][2], int16_t mv_t[2][2])
+{
+    const int min_x = -(MAX_CU << 2), min_y = -(MAX_CU << 2);
+    const int max_x = (pic_w - 1 + MAX_CU) << 2, max_y = (pic_h - 1 + MAX_CU) << 2;
+    int l;
+    x <<= 2; y <<= 2; w <<= 2; h <<= 2;
+    for (l = 0; l < 2; l++) {
+        mv_t[l][0] = mv[l][0]; mv_t[l][1] = mv[l][1];
+        if (refi[l] < 0) continue;
+        if (x + mv[l][0] < min_x) mv_t[l][0] = (int16_t)(min_x - x);
+        if (y + mv[l][1] < min_y) mv_t[l][1] = (int16_t)(min_y - y);
+        if (x + mv[l][0] + w - 4 > max_x) mv_t[l][0] = (int16_t)(max_x - x - w + 4);
+        if (y + mv[l][1] + h - 4 > max_y) mv_t[l][1] = (int16_t)(max_y - y - h + 4);
+    }
+}
+
+int orc_mc_cu(const xgpu_seq_params *sp, const orc_frame *fr, int x, int y, int w, int h,
+              const int8_t refi[2], const int16_t mv[2][2], int16_t *pred0[3], int16_t *pred1[3])
+{
+    int16_t mv_t[2][2];
+    int16_t **dst[2] = { pred0, pred1 };
+    int bidx = 0, l, i;
+    const int wc = w >> 1, hc = h >> 1;      /* 4:2:0 */
+
+    mv_clip(x, y, sp->width, sp->height, w, h, refi, mv, mv_t);
+
+    for (l = 0; l < 2; l++) {
+        const orc_pic *rp;
+        int gx, gy, ldx, ldy, cdx, cdy;
+        if (refi[l] < 0) continue;
+        if (l == 1 && refi[0] >= 0) {
+            /* identical-motion early-out, xevd_mc.c:512-519 (POC equality of the two reference pictures and
+               equality of the CLIPPED vectors) */
+            if (fr->refp[refi[0]][0].poc == fr->refp[refi[1]][1].poc &&
+                mv_t[0][0] == mv_t[1][0] && mv_t[0][1] == mv_t[1][1]) break;
+        }
+        rp = &fr->refp[refi[l]][l];
+        gx = ((x << 2) + mv_t[l][0]) << 2;      /* 1/16-pel luma units, xevd_mc.c:498-502 */
+        gy = ((y << 2) + mv_t[l][1]) << 2;
+        /* filter variant from the UNCLIPPED vector (xevd_mc.h:61-74): any of the low 4 (luma) / 5 (chroma)
+           bits of mv<<2 set */
+        ldx = ((mv[l][0] << 2) & 15) != 0;  ldy = ((mv[l][1] << 2) & 15) != 0;
+        cdx = ((mv[l][0] << 2) & 31) != 0;  cdy = ((mv[l][1] << 2) & 31) != 0;
+        orc_mc_l(rp->y, gx, gy, rp->s_l, w, dst[bidx][0], w, h, sp->bit_depth_luma, ldx, ldy, sp->tool_admvp);
+        orc_mc_c(rp->u, gx, gy, rp->s_c, wc, dst[bidx][1], wc, hc, sp->bit_depth_chroma, cdx, cdy, sp->tool_admvp);
+        orc_mc_c(rp->v, gx, gy, rp->s_c, wc, dst[bidx][2], wc, hc, sp->bit_depth_chroma, cdx, cdy, sp->tool_admvp);
+        bidx++;
+    }
+    if (bidx == 2) {
+        /* xevd_average_16b_no_clip, xevd_mc.c:145-167: average of the two already-clipped predictions */
+        for (i = 0; i < w * h; i++)   pred0[0][i] = (int16_t)((pred0[0][i] + pred1[0][i] + 1) >> 1);
+        for (i = 0; i < wc * hc; i++) pred0[1][i] = (int16_t)((pred0[1][i] + pred1[1][i] + 1) >> 1);
+        for (i = 0; i < wc * hc; i++) pred0[2][i] = (int16_t)((pred0[2][i] + pred1[2][i] + 1) >> 1);
+    }
+    return bidx;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * inverse transform.  xevd_tbl_tm{2..64} (src_base/xevd_tbl.c:89-243) equal
+ * round(64*sqrt(2)*cos((2n+1)k*pi/2N)) with row 0 = 64 (checked entry-by-entry against the reference's
+ * exported tables in tests/test_oracle_vs_ref.py); the partial butterflies of xevd_itdq.c:48-461 are an
+ * evaluation order of the plain products dst[n] = sum_k tm[k][n]*src[k] and exact in integers.
+ * ---------------------------------------------------------------------------------------------- */
+static int8_t g_tm[7][64 * 64];
+static int g_tm_ready = 0;
+static void tm_init(void)
+{
+    int l, k, n;
+    if (g_tm_ready) return;
+    for (l = 1; l <= 6; l++) {
+        const int N = 1 << l;
+        for (k = 0; k < N; k++) for (n = 0; n < N; n++) {
+            double v = k == 0 ? 64.0 : 64.0 * sqrt(2.0) * cos((2 * n + 1) * k * ORC_PI / (2.0 * N));
+            g_tm[l][k * N + n] = (int8_t)(v >= 0 ? floor(v + 0.5) : -floor(-v + 0.5));
+        }
+    }
+    g_tm_ready = 1;
+}
+const int8_t *orc_tm(int log2n) { tm_init(); return g_tm[log2n]; }
+
+/* first stage: columns, s16 -> s32, no shift, output transposed (dst[j*N+n]); xevd_itx_pb*b step 0 */
+void orc_itx_pass0(const int16_t *src, int32_t *dst, int log2n, int line)
+{
+    const int N = 1 << log2n; const int8_t *tm = orc_tm(log2n);
+    int j, n, k;
+    for (j = 0; j < line; j++) for (n = 0; n < N; n++) {
+        int64_t s = 0;
+        for (k = 0; k < N; k++) s += (int64_t)tm[k * N + n] * src[k * line + j];
+        if (s > 2147483647LL) s = 2147483647LL;             /* ITX_CLIP_32, xevd_itdq.c:41-45 */
+        if (s < -2147483647LL - 1) s = -2147483647LL - 1;
+        dst[j * N + n] = (int32_t)s;
+    }
+}
+/* second stage: s32 -> s16, (sum + 2^(shift-1)) >> shift, clip to s16; xevd_itx_pb*b step 1 */
+void orc_itx_pass1(const int32_t *src, int16_t *dst, int log2n, int line, int shift)
+{
+    const int N = 1 << log2n; const int8_t *tm = orc_tm(log2n);
+    const int64_t add = shift == 0 ? 0 : (int64_t)1 << (shift - 1);
+    int j, n, k;
+    for (j = 0; j < line; j++) for (n = 0; n < N; n++) {
+        int64_t s = 0;
+        for (k = 0; k < N; k++) s += (int64_t)tm[k * N + n] * src[k * line + j];
+        s = (s + add) >> shift;
+        dst[j * N + n] = (int16_t)CLIP3(-32768, 32767, s);
+    }
+}
+/* IQT stage (src_main/xevdm_itdq.c:423-706): s16 -> s16 with rounding shift and clip after every stage, 32-bit sums */
+static void itx_iqt(const int16_t *src, int16_t *dst, int log2n, int line, int shift)
+{
+    const int N = 1 << log2n; const int8_t *tm = orc_tm(log2n);
+    const int32_t add = shift == 0 ? 0 : 1 << (shift - 1);
+    int j, n, k;
+    for (j = 0; j < line; j++) for (n = 0; n < N; n++) {
+        int32_t s = 0;
+        for (k = 0; k < N; k++) s += tm[k * N + n] * src[k * line + j];
+        s = (s + add) >> shift;
+        dst[j * N + n] = (int16_t)CLIP3(-32768, 32767, s);
+    }
+}
+
+void orc_itdq(int16_t *coef, int log2w, int log2h, int qp, int bit_depth, int iqt)
+{
+    /* scale tables xevd_tbl_dq_scale / _b, src_base/xevd_tbl.c:255-256; selection xevdm_itdq.c:848-855, xevd_itdq.c:594 */
+    static const int scale_main[6] = { 40, 45, 51, 57, 64, 72 };
+    static const int scale_base[6] = { 40, 45, 51, 57, 64, 71 };
+    const int n = 1 << (log2w + log2h);
+    const int scale = (iqt ? scale_main : scale_base)[qp % 6] << (qp / 6);
+    const int odd = (log2w + log2h) & 1;
+    /* xevd_itdq.c:511-515: tr_shift = 15 - bd - log2_size; shift = 20 - 14 - tr_shift (+8 non-square) */
+    const int tr_shift = 15 - bit_depth - ((log2w + log2h) >> 1);
+    const int shift = 20 - 14 - tr_shift + (odd ? 8 : 0);
+    const int64_t offset = shift == 0 ? 0 : (int64_t)1 << (shift - 1);
+    const int64_t mul = (int64_t)scale * (odd ? 181 : 1);
+    int i;
+    for (i = 0; i < n; i++) {                                   /* xevd_dquant, xevd_itdq.c:480-492 */
+        int64_t lev = (coef[i] * mul + offset) >> shift;
+        coef[i] = (int16_t)CLIP3(-32768, 32767, lev);
+    }
+    if (iqt) {                                                  /* xevdm_itrans, xevdm_itdq.c:708-716 */
+        int16_t *t = (int16_t *)malloc(sizeof(int16_t) * n);
+        itx_iqt(coef, t, log2h, 1 << log2w, 7);
+        itx_iqt(t, coef, log2w, 1 << log2h, 12 - (bit_depth - 8));
+        free(t);
+    } else {                                                    /* xevd_itrans, xevd_itdq.c:473-478 */
+        int32_t *t = (int32_t *)malloc(sizeof(int32_t) * n);
+        orc_itx_pass0(coef, t, log2h, 1 << log2w);
+        orc_itx_pass1(t, coef, log2w, 1 << log2h, 7 + 12 - (bit_depth - 8));
+        free(t);
+    }
+}
+
+void orc_recon(const int16_t *coef, const int16_t *pred, int is_coef, int cuw, int cuh, int s_rec, int16_t *rec, int bit_depth)
+{
+    const int maxv = (1 << bit_depth) - 1;
+    int i, j;
+    for (i = 0; i < cuh; i++) for (j = 0; j < cuw; j++) {
+        /* the sum is formed in 16 bits and wraps (s16 t0, xevd_recon.c:39,60) */
+        int16_t t = is_coef ? (int16_t)(coef[i * cuw + j] + pred[i * cuw + j]) : pred[i * cuw + j];
+        rec[i * s_rec + j] = (int16_t)CLIP3(0, maxv, t);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * baseline deblocking, one 4-sample (luma) / 2-sample (chroma) edge segment.  src_base/xevd_df.c:96-289.
+ * is_ver: filter ACROSS a vertical edge (samples along a row, step 1), else across a horizontal edge.
+ * ---------------------------------------------------------------------------------------------- */
+static void dbk_line(int16_t *p, int step, int st, int maxv, int luma)
+{
+    int16_t A = p[-2 * step], B = p[-step], C = p[0], D = p[step];
+    int16_t d = (int16_t)((A - (B << 2) + (C << 2) - D) / 8);     /* C division: toward zero */
+    int16_t abs_d = (int16_t)(d < 0 ? -d : d);
+    int16_t t16 = (int16_t)((abs_d - st) << 1); if (t16 < 0) t16 = 0;
+    int16_t clip = (int16_t)(abs_d - t16);     if (clip < 0) clip = 0;
+    int16_t d1 = (int16_t)(d < 0 ? -clip : clip);
+    B = (int16_t)(B + d1); C = (int16_t)(C - d1);
+    if (luma) {
+        int16_t c2 = (int16_t)(clip >> 1);
+        int16_t d2 = (int16_t)CLIP3(-c2, c2, (A - D) / 4);
+        A = (int16_t)(A - d2); D = (int16_t)(D + d2);
+        p[-2 * step] = (int16_t)CLIP3(0, maxv, A);
+        p[step]      = (int16_t)CLIP3(0, maxv, D);
+    }
+    p[-step] = (int16_t)CLIP3(0, maxv, B);
+    p[0]     = (int16_t)CLIP3(0, maxv, C);
+}
+void orc_dbk_luma(int16_t *buf, int st, int stride, int bit_depth, int is_ver)
+{
+    int i; const int maxv = (1 << bit_depth) - 1;
+    for (i = 0; i < 4; i++) dbk_line(is_ver ? buf + i * stride : buf + i, is_ver ? 1 : stride, st, maxv, 1);
+}
+void orc_dbk_chroma(int16_t *u, int16_t *v, int st_u, int st_v, int stride, int bit_depth, int is_ver)
+{
+    int i; const int maxv = (1 << bit_depth) - 1;
+    for (i = 0; i < 2; i++) {
+        if (st_u) dbk_line(is_ver ? u + i * stride : u + i, is_ver ? 1 : stride, st_u, maxv, 0);
+        if (st_v) dbk_line(is_ver ? v + i * stride : v + i, is_ver ? 1 : stride, st_v, maxv, 0);
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * picture level
+ * ---------------------------------------------------------------------------------------------- */
+#define MCU_IF(m)   (((m) >> 15) & 1)
+#define MCU_QP(m)   (((m) >> 16) & 0x7F)
+#define MCU_CBFL(m) (((m) >> 24) & 1)
+#define MCU_COD(m)  (((m) >> 31) & 1)
+
+/* xevd_set_dec_info (src_base/xevd_util.c:1574-1660): every SCU of the CU receives intra flag (bit 15), QP
+   (bits 16-22, core->qp = qp_y - 6*(bd-8)), skip flag (23), luma cbf (24), COD (31), refi and mv. */
+static void set_dec_info(const xgpu_seq_params *sp, const xgpu_cu_batch *b, int i, orc_maps *m)
+{
+    const int xs = b->x[i] >> 2, ys = b->y[i] >> 2, ws = (1 << b->log2w[i]) >> 2, hs = (1 << b->log2h[i]) >> 2;
+    const int intra = b->pred_mode[i] == XGPU_MODE_INTRA;
+    const uint32_t qp = (uint32_t)(b->qp[i * 3] - 6 * (sp->bit_depth_luma - 8)) & 0x7F;
+    uint32_t v = (qp << 16) | ((uint32_t)intra << 15) | (1u << 31);
+    int r, c;
+    if (b->pred_mode[i] == XGPU_MODE_SKIP) v |= 1u << 23;
+    if (b->cbf[i] & 1) v |= 1u << 24;
+    for (r = 0; r < hs; r++) for (c = 0; c < ws; c++) {
+        const int k = (ys + r) * m->w_scu + xs + c;
+        m->map_scu[k] = v;
+        if (intra) {
+            m->map_refi[k * 2] = m->map_refi[k * 2 + 1] = -1;
+            memset(&m->map_mv[k * 4], 0, 4 * sizeof(int16_t));
+        } else {
+            m->map_refi[k * 2] = b->refi[i * 2]; m->map_refi[k * 2 + 1] = b->refi[i * 2 + 1];
+            memcpy(&m->map_mv[k * 4], &b->mv[i * 4], 4 * sizeof(int16_t));
+        }
+    }
+}
+
+int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *maps, int16_t *resid_out)
+{
+    int16_t *pred[2][3], *res;
+    int i, c, l;
+    for (l = 0; l < 2; l++) for (c = 0; c < 3; c++) pred[l][c] = (int16_t *)malloc(sizeof(int16_t) * MAX_CU * MAX_CU);
+    res = (int16_t *)malloc(sizeof(int16_t) * MAX_CU * MAX_CU);
+
+    for (i = 0; i < b->n_cu; i++) {
+        const int x = b->x[i], y = b->y[i], lw = b->log2w[i], lh = b->log2h[i], w = 1 << lw, h = 1 << lh;
+        size_t off = b->coef_off[i];
+        const int inter = b->pred_mode[i] != XGPU_MODE_INTRA;
+        if (inter)
+            orc_mc_cu(sp, fr, x, y, w, h, &b->refi[i * 2], (const int16_t (*)[2])&b->mv[i * 4], pred[0], pred[1]);
+        for (c = 0; c < 3; c++) {
+            const int cw = c ? w >> 1 : w, ch = c ? h >> 1 : h, clw = c ? lw - 1 : lw, clh = c ? lh - 1 : lh;
+            const int coded = (b->cbf[i] >> c) & 1;
+            int16_t *plane = c == 0 ? fr->cur.y : (c == 1 ? fr->cur.u : fr->cur.v);
+            const int s = c ? fr->cur.s_c : fr->cur.s_l;
+            if (coded) {
+                /* xevd_sub_block_itdq (xevd_itdq.c:544-621): the LUMA bit depth is used for all components
+                   (xevd.c:441-442); TBs are at most 64 wide so a CU <= 64 is one TB per component */
+                memcpy(res, b->coef + off, sizeof(int16_t) * cw * ch);
+                orc_itdq(res, clw, clh, b->qp[i * 3 + c], sp->bit_depth_luma, sp->tool_iqt);
+                if (resid_out) memcpy(resid_out + off, res, sizeof(int16_t) * cw * ch);
+                off += (size_t)cw * ch;
+            }
+            if (inter)      /* xevd_recon_yuv passes the luma bit depth for chroma too, xevd_recon.c:75-90 */
+                orc_recon(res, pred[0][c], coded, cw, ch, s, plane + (c ? (y >> 1) * s + (x >> 1) : y * s + x), sp->bit_depth_luma);
+        }
+        if (maps) set_dec_info(sp, b, i, maps);
+    }
+    for (l = 0; l < 2; l++) for (c = 0; c < 3; c++) free(pred[l][c]);
+    free(res);
+    return 0;
+}
+
+/* xevd_tbl_df_st, src_base/xevd_tbl.c:306-324 (filter strength by edge class and QP) */
+static const uint8_t k_df_st[4][52] = {
+    { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,1,1,1,1,1,2,2,2,2,2,3,3,3,4,4,4,5,5,6,6,7,8,9,10,11,12,12,12,12,12 },
+    { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,1,2,2,2,3,3,3,4,4,5,5,6,7,8, 9,10,11,11,11,11,11 },
+    { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,2,2,2,3,3,4,4,5,6,7, 8, 9,10,10,10,10,10 },
+    { 0 },
+};
+/* xevd_tbl_qp_chroma_adjust_base, src_base/xevd_tbl.c:345-354 (Baseline default chroma QP mapping) */
+static const int8_t k_chroma_qp_base[58] = {
+     0,  1,  2,  3,  4,  5,  6,  7,  8,  9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19,
+    20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 29, 30, 31, 32, 32, 33, 33, 34, 34,
+    35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 39, 39, 40, 40, 40, 41, 41, 41 };
+const int8_t *orc_default_chroma_qp_table(void) { return k_chroma_qp_base; }
+
+/* get_tbl_qp_to_st, src_base/xevd_df.c:34-94: edge class 0 intra, 1 luma cbf, 2 motion differs, 3 none */
+static int edge_class(const orc_maps *m, int k0, int k1)
+{
+    const uint32_t m0 = m->map_scu[k0], m1 = m->map_scu[k1];
+    const int8_t *r0 = &m->map_refi[k0 * 2], *r1 = &m->map_refi[k1 * 2];
+    int mv0[2][2], mv1[2][2], l, d;
+    if (MCU_IF(m0) || MCU_IF(m1)) return 0;
+    if (MCU_CBFL(m0) || MCU_CBFL(m1)) return 1;
+    for (l = 0; l < 2; l++) for (d = 0; d < 2; d++) {
+        mv0[l][d] = r0[l] >= 0 ? m->map_mv[k0 * 4 + l * 2 + d] : 0;
+        mv1[l][d] = r1[l] >= 0 ? m->map_mv[k1 * 4 + l * 2 + d] : 0;
+    }
+    if (r0[0] == r1[0] && r0[1] == r1[1])
+        return (abs(mv0[0][0] - mv1[0][0]) >= 4 || abs(mv0[0][1] - mv1[0][1]) >= 4 ||
+                abs(mv0[1][0] - mv1[1][0]) >= 4 || abs(mv0[1][1] - mv1[1][1]) >= 4) ? 2 : 3;
+    if (r0[0] == r1[1] && r0[1] == r1[0])
+        return (abs(mv0[0][0] - mv1[1][0]) >= 4 || abs(mv0[0][1] - mv1[1][1]) >= 4 ||
+                abs(mv0[1][0] - mv1[0][0]) >= 4 || abs(mv0[1][1] - mv1[0][1]) >= 4) ? 2 : 3;
+    return 2;
+}
+
+/* xevd_qp_chroma_dynamic[c][clip(-6*(bdc-8), 57, qp)] (xevd_df.c:362-365).  A caller-supplied table starts at
+   qp = -6*(bdc-8); the default is the Baseline static table with the identity extension below 0 that
+   xevd_set_chroma_qp_tbl_loc builds (xevd_tbl.c:364-372).  The strength-table index is clamped to 0..51: the
+   reference reads out of bounds there (xevd_tbl_df_st rows are 52 long), conformant streams never do. */
+static int chroma_qp(const xgpu_seq_params *sp, int c, int qp)
+{
+    const int boff = 6 * (sp->bit_depth_chroma - 8);
+    int v;
+    qp = CLIP3(-boff, 57, qp);
+    if (sp->chroma_qp_table[c]) v = sp->chroma_qp_table[c][qp + boff];
+    else v = qp < 0 ? qp : k_chroma_qp_base[qp];
+    return CLIP3(0, 51, v);
+}
+
+/* one 4-sample luma edge segment + its chroma, between SCU kq (right/below, supplies the QP) and SCU kp.
+   xevd_df.c:343-371 (hor) / :442-476 (ver) */
+static void dbk_segment(const xgpu_seq_params *sp, const orc_frame *fr, const orc_maps *m, int kq, int kp,
+                        int x_pel, int y_pel, int is_ver)
+{
+    const int cls = edge_class(m, kq, kp);
+    const int qp = MCU_QP(m->map_scu[kq]);
+    const int bdl = sp->bit_depth_luma, bdc = sp->bit_depth_chroma;
+    const int st = k_df_st[cls][qp] << (bdl - 8);
+    int st_u, st_v;
+    if (st) orc_dbk_luma(fr->cur.y + y_pel * fr->cur.s_l + x_pel, st, fr->cur.s_l, bdl, is_ver);
+    st_u = k_df_st[cls][chroma_qp(sp, 0, qp + fr->qp_u_offset)] << (bdc - 8);
+    st_v = k_df_st[cls][chroma_qp(sp, 1, qp + fr->qp_v_offset)] << (bdc - 8);
+    if (st_u || st_v) {
+        const int off = (y_pel >> 1) * fr->cur.s_c + (x_pel >> 1);
+        orc_dbk_chroma(fr->cur.u + off, fr->cur.v + off, st_u, st_v, fr->cur.s_c, bdc, is_ver);
+    }
+}
+
+int orc_deblock_baseline(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *m)
+{
+    const int ws = m->w_scu;
+    int i, r, c, k;
+    /* pass 1: vertical edges (xevd.c:1190-1210 with is_hor_edge=0 -> xevd_deblock_cu_ver, xevd_df.c:385-546).
+       COD is cleared, CUs are visited in decode order; the left edge is filtered when the left neighbour is
+       already visited, the right edge when the right neighbour is (never the case in quad-tree z-order). */
+    for (k = 0; k < ws * m->h_scu; k++) m->map_scu[k] &= 0x7FFFFFFFu;
+    for (i = 0; i < b->n_cu; i++) {
+        const int x = b->x[i], y = b->y[i], w = 1 << b->log2w[i], h = 1 << b->log2h[i];
+        const int t = (x >> 2) + (y >> 2) * ws;
+        if (x > 0 && MCU_COD(m->map_scu[t - 1]))
+            for (r = 0; r < h >> 2; r++) dbk_segment(sp, fr, m, t + r * ws, t + r * ws - 1, x, y + 4 * r, 1);
+        if (x + w < sp->width && MCU_COD(m->map_scu[t + (w >> 2)]))
+            for (r = 0; r < h >> 2; r++) dbk_segment(sp, fr, m, t + r * ws + (w >> 2), t + r * ws + (w >> 2) - 1, x + w, y + 4 * r, 1);
+        for (r = 0; r < h >> 2; r++) for (c = 0; c < w >> 2; c++) m->map_scu[t + r * ws + c] |= 1u << 31;
+    }
+    /* pass 2: horizontal edges (xevd_deblock_cu_hor, xevd_df.c:291-383): top edge of every CU below row 0 */
+    for (i = 0; i < b->n_cu; i++) {
+        const int x = b->x[i], y = b->y[i], w = 1 << b->log2w[i];
+        const int t = (x >> 2) + (y >> 2) * ws;
+        if (y > 0)
+            for (c = 0; c < w >> 2; c++) dbk_segment(sp, fr, m, t + c, t + c - ws, x + 4 * c, y, 0);
+    }
+    return 0;
+}
+
+void orc_pad(const xgpu_seq_params *sp, const orc_pic *p)
+{
+    int c, i, j;
+    for (c = 0; c < 3; c++) {
+        int16_t *a = c == 0 ? p->y : (c == 1 ? p->u : p->v);
+        const int s = c ? p->s_c : p->s_l, w = c ? sp->width >> 1 : sp->width, h = c ? sp->height >> 1 : sp->height;
+        const int e = c ? XGPU_PAD_C : XGPU_PAD_L;
+        for (i = 0; i < h; i++) for (j = 0; j < e; j++) { a[i * s - e + j] = a[i * s]; a[i * s + w + j] = a[i * s + w - 1]; }
+        for (i = 0; i < e; i++) {
+            memcpy(a - e - (i + 1) * s, a - e, sizeof(int16_t) * s);
+            memcpy(a - e + (h + i) * s, a - e + (h - 1) * s, sizeof(int16_t) * s);
+        }
+    }
+}

@@ -1,0 +1,159 @@
+"""Test-side loader for the CPU oracle (oracle/liboracle.so) and, when present, the reference harness
+(oracle/_ref/libref_harness.so = OUR driver around the real reference functions).  Test infrastructure only."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from xevd_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
+REF_SO = os.path.join(ORACLE_DIR, "_ref", "libxevd_ref.so")
+HARNESS_SO = os.path.join(ORACLE_DIR, "_ref", "libref_harness.so")
+
+
+class OrcPic(C.Structure):
+    _fields_ = [("y", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("s_l", C.c_int), ("s_c", C.c_int), ("poc", C.c_int)]
+
+
+class OrcMaps(C.Structure):
+    _fields_ = [("map_scu", C.c_void_p), ("map_refi", C.c_void_p), ("map_mv", C.c_void_p), ("w_scu", C.c_int), ("h_scu", C.c_int)]
+
+
+class OrcFrame(C.Structure):
+    _fields_ = [("cur", OrcPic), ("refp", (OrcPic * 2) * abi.XGPU_MAX_REFS), ("qp_u_offset", C.c_int), ("qp_v_offset", C.c_int)]
+
+
+def build_oracle():
+    if (not os.path.exists(ORACLE_SO) or
+            os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(os.path.join(ORACLE_DIR, f)) for f in ("xevd_oracle.c", "xevd_oracle.h"))):
+        subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+
+
+_oracle = None
+_harness = None
+_ref = None
+
+
+def oracle():
+    global _oracle
+    if _oracle is None:
+        build_oracle()
+        lib = C.CDLL(ORACLE_SO)
+        lib.orc_mc_l.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.c_void_p] + [C.c_int] * 6
+        lib.orc_mc_c.argtypes = lib.orc_mc_l.argtypes
+        lib.orc_itdq.argtypes = [C.c_void_p] + [C.c_int] * 5
+        lib.orc_tm.restype = C.POINTER(C.c_int8)
+        lib.orc_tm.argtypes = [C.c_int]
+        lib.orc_recon.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        lib.orc_dbk_luma.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.orc_dbk_chroma.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.orc_recon_batch.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_void_p]
+        lib.orc_deblock_baseline.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps)]
+        lib.orc_pad.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcPic)]
+        _oracle = lib
+    return _oracle
+
+
+def have_ref():
+    return os.path.exists(REF_SO) and os.path.exists(HARNESS_SO)
+
+
+def ref():
+    """The real reference library (exported per-block functions)."""
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(REF_SO, mode=C.RTLD_GLOBAL)
+    return _ref
+
+
+def harness():
+    global _harness
+    if _harness is None:
+        ref()
+        lib = C.CDLL(HARNESS_SO)
+        lib.refh_recon_batch.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_void_p, C.c_int]
+        lib.refh_deblock_baseline.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_int]
+        lib.refh_pad.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcPic)]
+        _harness = lib
+    return _harness
+
+
+class Picture:
+    """Padded planar 4:2:0 s16 picture with the reference's buffer geometry (stride = w + 2*pad)."""
+
+    def __init__(self, width, height, poc=0, planes=None, fill=None):
+        self.w, self.h, self.poc = width, height, poc
+        self.bufs = []
+        for c in range(3):
+            pw, ph, pad = (width, height, abi.PAD_L) if c == 0 else (width // 2, height // 2, abi.PAD_C)
+            b = np.zeros((ph + 2 * pad, pw + 2 * pad), np.int16)
+            if fill is not None:
+                b[:] = fill
+            if planes is not None:
+                b[pad:pad + ph, pad:pad + pw] = planes[c]
+            self.bufs.append(b)
+
+    def pad_of(self, c):
+        return abi.PAD_L if c == 0 else abi.PAD_C
+
+    def active(self, c):
+        pad = self.pad_of(c)
+        ph, pw = (self.h, self.w) if c == 0 else (self.h // 2, self.w // 2)
+        return self.bufs[c][pad:pad + ph, pad:pad + pw]
+
+    def stride(self, c):
+        return self.bufs[c].shape[1]
+
+    def origin_ptr(self, c):
+        pad = self.pad_of(c)
+        return self.bufs[c].ctypes.data + 2 * (pad * self.stride(c) + pad)
+
+    def orc(self):
+        p = OrcPic()
+        p.y, p.u, p.v = self.origin_ptr(0), self.origin_ptr(1), self.origin_ptr(2)
+        p.s_l, p.s_c, p.poc = self.stride(0), self.stride(1), self.poc
+        return p
+
+    def copy(self):
+        q = Picture(self.w, self.h, self.poc)
+        for c in range(3):
+            q.bufs[c][:] = self.bufs[c]
+        return q
+
+    def pad_numpy(self):
+        """border replication (numpy restatement, used to prepare reference pictures in tests)."""
+        for c in range(3):
+            pad = self.pad_of(c)
+            a = self.active(c)
+            self.bufs[c][:] = np.pad(a, pad, mode="edge")
+
+
+class Maps:
+    def __init__(self, width, height):
+        self.w_scu, self.h_scu = (width + 3) // 4, (height + 3) // 4
+        n = self.w_scu * self.h_scu
+        self.map_scu = np.zeros(n, np.uint32)
+        self.map_refi = np.full((n, 2), -1, np.int8)
+        self.map_mv = np.zeros((n, 2, 2), np.int16)
+
+    def orc(self):
+        m = OrcMaps()
+        m.map_scu, m.map_refi, m.map_mv = self.map_scu.ctypes.data, self.map_refi.ctypes.data, self.map_mv.ctypes.data
+        m.w_scu, m.h_scu = self.w_scu, self.h_scu
+        return m
+
+
+def make_frame(cur, refs, qp_u_offset=0, qp_v_offset=0):
+    """refs: {(idx, list): Picture}"""
+    fr = OrcFrame()
+    fr.cur = cur.orc()
+    dummy = cur.orc()
+    for i in range(abi.XGPU_MAX_REFS):
+        for l in range(2):
+            fr.refp[i][l] = refs[(i, l)].orc() if (i, l) in refs else dummy
+    fr.qp_u_offset, fr.qp_v_offset = qp_u_offset, qp_v_offset
+    return fr

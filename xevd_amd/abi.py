@@ -1,0 +1,146 @@
+"""ctypes view of include/xevd_hip.h - struct layouts and the loader for the product library.
+
+Plumbing only: the product is xevd_amd/libxevd_hip.so (hand-written HIP for gfx950 behind a C ABI).  This
+module never falls back to a CPU path: if the shared library is missing, `load()` raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libxevd_hip.so")
+
+XGPU_MAX_REFS = 17
+PAD_L, PAD_C = 144, 72
+MODE_INTRA, MODE_INTER, MODE_SKIP, MODE_DIR = 0, 1, 2, 3
+K_NAMES = ["itdq", "inter", "dbk_v", "dbk_h", "pad", "intra", "alf", "rsvd"]
+K_COUNT = 8
+
+
+class SeqParams(C.Structure):
+    _fields_ = [
+        ("device", C.c_int), ("width", C.c_int), ("height", C.c_int),
+        ("bit_depth_luma", C.c_int), ("bit_depth_chroma", C.c_int), ("chroma_format_idc", C.c_int),
+        ("log2_ctu", C.c_int), ("tool_iqt", C.c_int), ("tool_admvp", C.c_int), ("tool_addb", C.c_int),
+        ("tool_alf", C.c_int), ("max_pics", C.c_int),
+        ("chroma_qp_table", C.POINTER(C.c_int8) * 2),
+    ]
+
+
+class FrameParams(C.Structure):
+    _fields_ = [
+        ("pic", C.c_int), ("poc", C.c_int), ("num_refp", C.c_int * 2),
+        ("refp_pic", (C.c_int * 2) * XGPU_MAX_REFS), ("refp_poc", (C.c_int * 2) * XGPU_MAX_REFS),
+        ("qp_u_offset", C.c_int), ("qp_v_offset", C.c_int),
+        ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int),
+    ]
+
+
+class CuBatch(C.Structure):
+    _fields_ = [
+        ("n_cu", C.c_int),
+        ("x", C.POINTER(C.c_uint16)), ("y", C.POINTER(C.c_uint16)),
+        ("log2w", C.POINTER(C.c_uint8)), ("log2h", C.POINTER(C.c_uint8)),
+        ("pred_mode", C.POINTER(C.c_uint8)),
+        ("refi", C.POINTER(C.c_int8)), ("mv", C.POINTER(C.c_int16)),
+        ("qp", C.POINTER(C.c_uint8)), ("cbf", C.POINTER(C.c_uint8)), ("ipm", C.POINTER(C.c_uint8)),
+        ("coef_off", C.POINTER(C.c_uint32)), ("coef", C.POINTER(C.c_int16)), ("n_coef", C.c_size_t),
+        ("n_ctu", C.c_int), ("ctu_cu_start", C.POINTER(C.c_uint32)),
+    ]
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def make_cu_batch(b):
+    """dict of numpy arrays (see synth.gen_frame) -> (CuBatch, keepalive)."""
+    keep = {
+        "x": np.ascontiguousarray(b["x"], np.uint16), "y": np.ascontiguousarray(b["y"], np.uint16),
+        "log2w": np.ascontiguousarray(b["log2w"], np.uint8), "log2h": np.ascontiguousarray(b["log2h"], np.uint8),
+        "pred_mode": np.ascontiguousarray(b["pred_mode"], np.uint8),
+        "refi": np.ascontiguousarray(b["refi"], np.int8), "mv": np.ascontiguousarray(b["mv"], np.int16),
+        "qp": np.ascontiguousarray(b["qp"], np.uint8), "cbf": np.ascontiguousarray(b["cbf"], np.uint8),
+        "ipm": np.ascontiguousarray(b["ipm"], np.uint8),
+        "coef_off": np.ascontiguousarray(b["coef_off"], np.uint32),
+        "coef": np.ascontiguousarray(b["coef"], np.int16),
+        "ctu_cu_start": np.ascontiguousarray(b["ctu_cu_start"], np.uint32),
+    }
+    cb = CuBatch()
+    cb.n_cu = len(keep["x"])
+    cb.x, cb.y = _ptr(keep["x"], C.c_uint16), _ptr(keep["y"], C.c_uint16)
+    cb.log2w, cb.log2h = _ptr(keep["log2w"], C.c_uint8), _ptr(keep["log2h"], C.c_uint8)
+    cb.pred_mode = _ptr(keep["pred_mode"], C.c_uint8)
+    cb.refi, cb.mv = _ptr(keep["refi"], C.c_int8), _ptr(keep["mv"], C.c_int16)
+    cb.qp, cb.cbf, cb.ipm = _ptr(keep["qp"], C.c_uint8), _ptr(keep["cbf"], C.c_uint8), _ptr(keep["ipm"], C.c_uint8)
+    cb.coef_off, cb.coef = _ptr(keep["coef_off"], C.c_uint32), _ptr(keep["coef"], C.c_int16)
+    cb.n_coef = len(keep["coef"])
+    cb.n_ctu = len(keep["ctu_cu_start"]) - 1
+    cb.ctu_cu_start = _ptr(keep["ctu_cu_start"], C.c_uint32)
+    return cb, keep
+
+
+def make_seq_params(width, height, bit_depth=8, log2_ctu=6, device=0, iqt=0, admvp=0, addb=0, alf=0, max_pics=4,
+                    bit_depth_chroma=None):
+    sp = SeqParams()
+    sp.device, sp.width, sp.height = device, width, height
+    sp.bit_depth_luma = bit_depth
+    sp.bit_depth_chroma = bit_depth if bit_depth_chroma is None else bit_depth_chroma
+    sp.chroma_format_idc = 1
+    sp.log2_ctu = log2_ctu
+    sp.tool_iqt, sp.tool_admvp, sp.tool_addb, sp.tool_alf = iqt, admvp, addb, alf
+    sp.max_pics = max_pics
+    return sp
+
+
+_EXPORTS = {
+    # name: (restype, argtypes)
+    "xgpu_open": (C.c_int, [C.POINTER(SeqParams), C.POINTER(C.c_void_p)]),
+    "xgpu_close": (None, [C.c_void_p]),
+    "xgpu_sync": (C.c_int, [C.c_void_p]),
+    "xgpu_last_error": (C.c_char_p, [C.c_void_p]),
+    "xgpu_version": (C.c_char_p, []),
+    "xgpu_pic_alloc": (C.c_int, [C.c_void_p]),
+    "xgpu_pic_free": (C.c_int, [C.c_void_p, C.c_int]),
+    "xgpu_pic_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "xgpu_pic_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "xgpu_pic_download_padded": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "xgpu_pic_upload_padded": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "xgpu_frame_begin": (C.c_int, [C.c_void_p, C.POINTER(FrameParams)]),
+    "xgpu_batch_create": (C.c_int, [C.c_void_p, C.POINTER(CuBatch), C.POINTER(C.c_void_p)]),
+    "xgpu_batch_destroy": (None, [C.c_void_p, C.c_void_p]),
+    "xgpu_batch_recon": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "xgpu_deblock": (C.c_int, [C.c_void_p]),
+    "xgpu_pad": (C.c_int, [C.c_void_p]),
+    "xgpu_frame_end": (C.c_int, [C.c_void_p]),
+    "xgpu_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "xgpu_timing_reset": (C.c_int, [C.c_void_p]),
+    "xgpu_timing_get": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    "xgpu_measure_copy_bw": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
+    "xgpu_test_mc_l": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p] + [C.c_int] * 3),
+    "xgpu_test_mc_c": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p] + [C.c_int] * 3),
+    "xgpu_test_itdq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
+}
+
+_lib = None
+
+
+def exported_names():
+    return sorted(_EXPORTS)
+
+
+def load():
+    """Load the product library.  Fails loudly when it has not been built - there is no CPU fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  xevd_amd has no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _EXPORTS.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib

@@ -1,0 +1,192 @@
+"""Seeded synthetic CU-batch streams.
+
+The reference ships no bitstreams and no encoder, so the path's input - the per-CU records that entropy
+decoding and MV derivation produce (XEVD_CU_DATA, src_base/xevd_def.h:1145-1190) - is generated directly:
+a quad-tree per 64x64 CTU (boundary CUs forced to split, xevd.c:918-1017 behaviour), inter / intra mode,
+reference indices, quarter-pel MVs with all four sub-pel classes and a share of vectors that point outside
+the picture (MV-clip path), per-CU QP, coded-block flags and sparse low-frequency coefficient blocks.
+Everything is numpy-vectorised so that 8K pictures (about 2 M SCUs) generate in well under a second.
+"""
+import numpy as np
+
+from .abi import MODE_INTER, MODE_INTRA
+
+
+def _morton(xs, ys):
+    """z-order key of SCU coordinates inside a CTU (4 bits each is enough for 128/4 = 32 -> use 5)."""
+    k = np.zeros(xs.shape, np.int64)
+    for b in range(5):
+        k |= ((xs >> b) & 1) << (2 * b)
+        k |= ((ys >> b) & 1) << (2 * b + 1)
+    return k
+
+
+def gen_partition(rng, width, height, log2_ctu=6, split_prob=0.5, min_log2=2):
+    """Quad-tree leaf CUs of one picture in decode order (CTU raster, z-order inside a CTU)."""
+    ctu = 1 << log2_ctu
+    w_ctu, h_ctu = (width + ctu - 1) // ctu, (height + ctu - 1) // ctu
+    gx, gy = np.meshgrid(np.arange(w_ctu) * ctu, np.arange(h_ctu) * ctu)
+    x, y = gx.ravel().astype(np.int64), gy.ravel().astype(np.int64)
+    size = ctu
+    leaves = []
+    while True:
+        inside = (x < width) & (y < height)
+        x, y = x[inside], y[inside]
+        crosses = (x + size > width) | (y + size > height)
+        if size > (1 << min_log2):
+            split = crosses | (rng.random(x.shape) < split_prob)
+        else:
+            split = np.zeros(x.shape, bool)
+            assert not crosses.any(), "picture size must be a multiple of the minimum CU size"
+        leaves.append((x[~split], y[~split], np.full((~split).sum(), size)))
+        if not split.any():
+            break
+        half = size // 2
+        px, py = x[split], y[split]
+        x = np.concatenate([px, px + half, px, px + half])
+        y = np.concatenate([py, py, py + half, py + half])
+        size = half
+    x = np.concatenate([l[0] for l in leaves])
+    y = np.concatenate([l[1] for l in leaves])
+    s = np.concatenate([l[2] for l in leaves])
+    ctu_idx = (y >> log2_ctu) * w_ctu + (x >> log2_ctu)
+    key = ctu_idx * (1 << 12) + _morton((x & (ctu - 1)) >> 2, (y & (ctu - 1)) >> 2)
+    order = np.argsort(key, kind="stable")
+    x, y, s, ctu_idx = x[order], y[order], s[order], ctu_idx[order]
+    start = np.searchsorted(ctu_idx, np.arange(w_ctu * h_ctu + 1)).astype(np.uint32)
+    log2s = np.log2(s).astype(np.uint8)
+    return x.astype(np.uint16), y.astype(np.uint16), log2s, log2s.copy(), start
+
+
+def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_frac=0.0, coded_frac=0.6,
+              n_refs=(1, 0), qp_range=(22, 37), mv_sigma_px=8.0, oob_frac=0.05, split_prob=0.5,
+              chroma_qp_table=None, max_level=24, amp=2.0):
+    """One picture's CU batch as a dict of numpy arrays (layout of xgpu_cu_batch, include/xevd_hip.h)."""
+    x, y, l2w, l2h, start = gen_partition(rng, width, height, log2_ctu, split_prob)
+    n = len(x)
+    w = (1 << l2w.astype(np.int64))
+    h = (1 << l2h.astype(np.int64))
+
+    pred_mode = np.where(rng.random(n) < inter_frac, MODE_INTER, MODE_INTRA).astype(np.uint8)
+    inter = pred_mode != MODE_INTRA
+
+    # reference indices: uni L0, uni L1 or bi
+    refi = np.full((n, 2), -1, np.int8)
+    has_l1 = n_refs[1] > 0
+    bi = inter & has_l1 & (rng.random(n) < bi_frac)
+    use_l1_only = inter & has_l1 & ~bi & (rng.random(n) < 0.3)
+    l0 = inter & ~use_l1_only
+    refi[l0, 0] = rng.integers(0, max(n_refs[0], 1), l0.sum())
+    l1 = bi | use_l1_only
+    if has_l1:
+        refi[l1, 1] = rng.integers(0, n_refs[1], l1.sum())
+
+    # motion vectors: quarter-pel, 25% each of integer / H-only / V-only / 2-D phase, some far outside
+    mv = np.zeros((n, 2, 2), np.int16)
+    for lst in range(2):
+        ipart = np.round(rng.normal(0, mv_sigma_px, (n, 2))).astype(np.int64)
+        cls = rng.integers(0, 4, n)
+        frac = rng.integers(1, 4, (n, 2))
+        frac[:, 0] *= ((cls == 1) | (cls == 3))
+        frac[:, 1] *= ((cls == 2) | (cls == 3))
+        v = ipart * 4 + frac
+        oob = rng.random(n) < oob_frac
+        far = rng.integers(-(max(width, height) + 300), max(width, height) + 300, (n, 2)) * 4 + rng.integers(0, 4, (n, 2))
+        v[oob] = far[oob]
+        v = np.clip(v, -32768, 32767)
+        mv[:, lst, :] = np.where((refi[:, lst] >= 0)[:, None], v, 0)
+
+    # QPs: per-CU luma QP (sequence range), chroma through the mapping table, +6*(bd-8) like core->qp_*
+    qp_y = rng.integers(qp_range[0], qp_range[1] + 1, n)
+    tbl = np.asarray(chroma_qp_table if chroma_qp_table is not None else DEFAULT_CHROMA_QP_BASE, np.int64)
+    qp_c = tbl[np.clip(qp_y, 0, 57)]
+    boff = 6 * (bit_depth - 8)
+    qp = np.stack([qp_y + boff, qp_c + boff, qp_c + boff], 1).astype(np.uint8)
+
+    # coded block flags
+    coded = rng.random(n) < coded_frac
+    cbf = np.zeros(n, np.uint8)
+    cbf |= (coded & (rng.random(n) < 0.9)).astype(np.uint8)
+    cbf |= (coded & (rng.random(n) < 0.5)).astype(np.uint8) << 1
+    cbf |= (coded & (rng.random(n) < 0.5)).astype(np.uint8) << 2
+
+    # coefficient arena: CU-contiguous, components in Y,U,V order, coded ones only
+    area_y = w * h
+    area_c = area_y // 4
+    sizes = np.stack([area_y * (cbf & 1), area_c * ((cbf >> 1) & 1), area_c * ((cbf >> 2) & 1)], 1)
+    cu_size = sizes.sum(1)
+    coef_off = np.concatenate([[0], np.cumsum(cu_size)[:-1]]).astype(np.int64)
+    n_coef = int(cu_size.sum())
+    coef = np.zeros(max(n_coef, 1), np.int16)
+    # transform-block table (cu, comp) -> offset, w, h
+    tb_off, tb_w, tb_h, tb_qp = [], [], [], []
+    run = coef_off.copy()
+    for c in range(3):
+        m = ((cbf >> c) & 1).astype(bool)
+        tb_off.append(run[m])
+        tb_w.append((w[m] >> (1 if c else 0)))
+        tb_h.append((h[m] >> (1 if c else 0)))
+        tb_qp.append(qp[m, c].astype(np.int64))
+        run = run + sizes[:, c]
+    tb_off, tb_w, tb_h, tb_qp = (np.concatenate(v) for v in (tb_off, tb_w, tb_h, tb_qp))
+    # level cap per block: keep the dequantised magnitude near the sample range (amp * 2^bd) like a real
+    # encoder's output, which is also the range where the reference's C and SIMD paths agree;
+    # amp=None leaves levels uncapped (stress cases, compared against the normative C path only)
+    if amp is not None and len(tb_off):
+        l2 = np.log2(tb_w).astype(np.int64) + np.log2(tb_h).astype(np.int64)
+        odd = l2 & 1
+        shift = 6 - (15 - bit_depth - (l2 >> 1)) + 8 * odd
+        gain = (np.array([40, 45, 51, 57, 64, 71])[tb_qp % 6] << (tb_qp // 6)) * np.where(odd, 181, 1) / (2.0 ** shift)
+        tb_cap = np.clip(np.floor(amp * (1 << bit_depth) / gain), 1, max_level).astype(np.int64)
+    else:
+        tb_cap = np.full(len(tb_off), max_level, np.int64)
+    if len(tb_off):
+        nnz = np.minimum(1 + rng.geometric(0.25, len(tb_off)), 24)
+        tb = np.repeat(np.arange(len(tb_off)), nnz)
+        # positions: concentrated at low frequencies, occasionally anywhere in the block
+        fx = np.abs(rng.normal(0, 1.0, len(tb))) * tb_w[tb] / 5.0
+        fy = np.abs(rng.normal(0, 1.0, len(tb))) * tb_h[tb] / 5.0
+        anywhere = rng.random(len(tb)) < 0.05
+        fx = np.where(anywhere, rng.random(len(tb)) * tb_w[tb], fx)
+        fy = np.where(anywhere, rng.random(len(tb)) * tb_h[tb], fy)
+        # 64-point dimensions carry coefficients only in their first 32 positions (the range real streams use;
+        # the reference's AVX 64-point IQT stage drops the rest while its C version does not)
+        px = np.minimum(fx.astype(np.int64), np.minimum(tb_w[tb], 32) - 1)
+        py = np.minimum(fy.astype(np.int64), np.minimum(tb_h[tb], 32) - 1)
+        lev = np.round(rng.laplace(0, 2.0, len(tb))).astype(np.int64)
+        lev[lev == 0] = 1
+        lev = np.clip(lev, -tb_cap[tb], tb_cap[tb])
+        coef[tb_off[tb] + py * tb_w[tb] + px] = lev
+        # the first coefficient of every coded block is DC-ish and non-zero
+        dc = np.round(rng.laplace(0, 6.0, len(tb_off))).astype(np.int64)
+        dc[dc == 0] = 1
+        coef[tb_off] = np.clip(dc, -tb_cap, tb_cap)
+
+    ipm = np.zeros((n, 2), np.uint8)
+    ipm[:, 0] = rng.integers(0, 5, n)
+    return {
+        "x": x, "y": y, "log2w": l2w, "log2h": l2h, "pred_mode": pred_mode, "refi": refi, "mv": mv, "qp": qp,
+        "cbf": cbf, "ipm": ipm, "coef_off": coef_off.astype(np.uint32), "coef": coef[:max(n_coef, 1)],
+        "ctu_cu_start": start, "n_coef": n_coef,
+    }
+
+
+# xevd_tbl_qp_chroma_adjust_base (src_base/xevd_tbl.c:345-354): the Baseline default chroma QP mapping, a
+# constant of the MPEG-5 EVC specification.
+DEFAULT_CHROMA_QP_BASE = [
+    0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19,
+    20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 29, 30, 31, 32, 32, 33, 33, 34, 34,
+    35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 39, 39, 40, 40, 40, 41, 41, 41]
+
+
+def gen_picture(rng, width, height, bit_depth=8, smooth=True):
+    """A synthetic reference picture (active area only): smooth gradients + texture + noise, 4:2:0."""
+    maxv = (1 << bit_depth) - 1
+    planes = []
+    for (pw, ph) in ((width, height), (width // 2, height // 2), (width // 2, height // 2)):
+        yy, xx = np.mgrid[0:ph, 0:pw]
+        base = 0.5 + 0.25 * np.sin(xx / (17.0 + 13 * rng.random())) * np.cos(yy / (11.0 + 9 * rng.random()))
+        base += 0.15 * np.sin((xx + 2 * yy) / (5.0 + 4 * rng.random()))
+        base += rng.normal(0, 0.06, (ph, pw))
+        planes.append(np.clip(np.round(base * maxv), 0, maxv).astype(np.int16))
+    return planes
