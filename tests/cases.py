@@ -1,0 +1,97 @@
+"""Shared picture-level test cases: build seeded inputs once, run them through the oracle, the real reference
+(oracle/_ref harness) or the HIP backend (C ABI), and return comparable outputs."""
+import ctypes as C
+import zlib
+
+import numpy as np
+
+import oracle_lib as ol
+from xevd_amd import abi, synth
+
+# name, w, h, bd, admvp, iqt, n_refs, bi_frac
+CASES = [
+    ("base_p_8b", 208, 120, 8, 0, 0, (1, 0), 0.0),
+    ("base_b_8b", 136, 72, 8, 0, 0, (2, 2), 0.5),
+    ("base_p_10b", 144, 88, 10, 0, 0, (2, 0), 0.0),
+    ("main_b_10b", 200, 136, 10, 1, 1, (2, 2), 0.5),
+    ("main_admvp_only", 128, 64, 8, 1, 0, (1, 1), 0.4),
+    ("main_iqt_only", 128, 72, 10, 0, 1, (1, 1), 0.4),
+]
+POCS = [[4, 0, 2], [12, 16, 4]]      # L1 idx 2 has the POC of L0 idx 0 -> identical-motion candidates exist
+CUR_POC = 8
+QP_OFFSETS = (1, -2)
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, seed=0, inter_frac=0.9, split_prob=0.5, qp_range=(20, 45),
+               amp=2.0, oob_frac=0.1):
+    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000 + seed)
+    refs = {}
+    for l in range(2):
+        for i in range(n_refs[l]):
+            pic = ol.Picture(w, h, POCS[l][i], synth.gen_picture(rng, w, h, bd))
+            pic.pad_numpy()
+            refs[(i, l)] = pic
+    batch = synth.gen_frame(rng, w, h, bd, inter_frac=inter_frac, bi_frac=bi_frac, n_refs=n_refs, oob_frac=oob_frac,
+                            qp_range=qp_range, split_prob=split_prob, amp=amp)
+    if n_refs[0] and n_refs[1]:      # force some identical-motion bi CUs
+        sel = (batch["refi"][:, 0] >= 0) & (batch["refi"][:, 1] >= 0)
+        idx = np.nonzero(sel)[0][::3]
+        batch["mv"][idx, 1] = batch["mv"][idx, 0]
+    return {"name": name, "w": w, "h": h, "bd": bd, "admvp": admvp, "iqt": iqt, "refs": refs, "batch": batch}
+
+
+def _start_picture(case):
+    """Intra CUs are not reconstructed on this path: start from a deterministic mid-grey picture."""
+    cur = ol.Picture(case["w"], case["h"], CUR_POC)
+    for c in range(3):
+        cur.bufs[c][:] = 1 << (case["bd"] - 1)
+    return cur
+
+
+def run_cpu(engine, case, deblock=True, simd=0, pad=True):
+    """engine 'oracle' (oracle/liboracle.so) or 'ref' (the real reference through oracle/_ref). -> (final, pre-deblock, maps, resid)"""
+    sp = abi.make_seq_params(case["w"], case["h"], case["bd"], iqt=case["iqt"], admvp=case["admvp"])
+    cb, keep = abi.make_cu_batch(case["batch"])
+    cur = _start_picture(case)
+    maps = ol.Maps(case["w"], case["h"])
+    fr = ol.make_frame(cur, case["refs"], *QP_OFFSETS)
+    m = maps.orc()
+    resid = np.zeros(max(case["batch"]["n_coef"], 1), np.int16)
+    if engine == "oracle":
+        o = ol.oracle()
+        o.orc_recon_batch(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), _p(resid))
+        pre = cur.copy()
+        if deblock:
+            o.orc_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m))
+        if pad:
+            o.orc_pad(C.byref(sp), C.byref(fr.cur))
+    else:
+        hn = ol.harness()
+        hn.refh_recon_batch(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), _p(resid), simd)
+        pre = cur.copy()
+        if deblock:
+            hn.refh_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), simd)
+        if pad:
+            hn.refh_pad(C.byref(sp), C.byref(fr.cur))
+    return cur, pre, maps, resid
+
+
+def run_gpu(case, deblock=True, pad=True):
+    """The HIP backend through the C ABI. -> list of padded planes (reference buffer geometry)"""
+    from xevd_amd.decoder import XgpuDecoder
+    with XgpuDecoder(case["w"], case["h"], case["bd"], iqt=case["iqt"], admvp=case["admvp"], max_pics=8) as dec:
+        slots = {}
+        for key, pic in case["refs"].items():
+            s = dec.pic_alloc()
+            dec.pic_upload_padded(s, pic.bufs)
+            slots[key] = (s, pic.poc)
+        cur = dec.pic_alloc()
+        dec.pic_upload_padded(cur, _start_picture(case).bufs)
+        hb = dec.batch_create(case["batch"])
+        dec.decode_picture(cur, CUR_POC, slots, hb, deblock=deblock, pad=pad, qp_u_offset=QP_OFFSETS[0], qp_v_offset=QP_OFFSETS[1])
+        dec.sync()
+        return dec.pic_download_padded(cur)

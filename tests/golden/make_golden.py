@@ -1,0 +1,135 @@
+#!/usr/bin/env python3
+"""Generates the golden vectors under tests/golden/ FROM THE REFERENCE ITSELF.
+
+Run in the development container only (needs oracle/_ref, i.e. /root/reference compiled by oracle/Makefile.ref):
+    python tests/golden/make_golden.py
+Every expected output below is produced by the reference's own code - the exported per-block functions of
+libxevd_ref.so (plain-C tables, which are normative) and, at picture level, the reference's
+xevd_sub_block_itdq / xevd_mc / xevdm_mc / xevd_recon / xevd_set_dec_info / xevd_deblock_cu_* / picbuf expand
+driven by oracle/ref_harness.c.  The files hold inputs AND expected outputs (data only), so the tests that
+consume them (tests/test_golden.py on CPU, tests/test_gpu_parity.py on the MI355X) never need the reference.
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+import cases  # noqa: E402
+import oracle_lib as ol  # noqa: E402
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def golden_mc(lib):
+    names = {(0, 0): "00", (1, 0): "n0", (0, 1): "0n", (1, 1): "nn"}
+    rng = np.random.default_rng(2024)
+    out = {}
+    recs, preds = [], []
+    for bd in (8, 10):
+        plane = rng.integers(0, 1 << bd, (96, 160)).astype(np.int16)
+        out[f"plane_bd{bd}"] = plane
+        for admvp in (0, 1):
+            lp = C.c_void_p.in_dll(lib, "tbl_mc_l_coeff")
+            cp = C.c_void_p.in_dll(lib, "tbl_mc_c_coeff")
+            lp.value = C.addressof((C.c_int16 * 128).in_dll(lib, "tbl_mc_l_coeff_main" if admvp else "xevd_tbl_mc_l_coeff"))
+            cp.value = C.addressof((C.c_int16 * 128).in_dll(lib, "tbl_mc_c_coeff_main" if admvp else "xevd_tbl_mc_c_coeff"))
+            for luma in (1, 0):
+                for has_dx in (0, 1):
+                    for has_dy in (0, 1):
+                        for trial in range(6):
+                            lo = 2 if luma else 1
+                            w = 1 << int(rng.integers(lo, 7))
+                            h = 1 << int(rng.integers(lo, 7))
+                            prec = 4 if luma else 5
+                            step = 1 if (admvp and trial % 2) else 4
+                            fx = int(rng.integers(0, (1 << prec) // step)) * step
+                            fy = int(rng.integers(0, (1 << prec) // step)) * step
+                            ix, iy = int(rng.integers(6, 160 - 12 - w)), int(rng.integers(6, 96 - 12 - h))
+                            gx, gy = (ix << prec) + fx, (iy << prec) + fy
+                            a = np.zeros((h, w), np.int16)
+                            fn = getattr(lib, f"xevd_mc_{'l' if luma else 'c'}_{names[(has_dx, has_dy)]}")
+                            fn(_p(plane), gx, gy, plane.shape[1], w, _p(a), w, h, bd)
+                            recs.append((bd, admvp, luma, has_dx, has_dy, w, h, gx, gy, sum(p.size for p in preds)))
+                            preds.append(a.ravel())
+    out["recs"] = np.array(recs, np.int64)
+    out["pred"] = np.concatenate(preds)
+    np.savez_compressed(os.path.join(HERE, "blocks_mc.npz"), **out)
+    print("blocks_mc.npz:", len(recs), "blocks")
+
+
+def golden_itdq(lib):
+    rng = np.random.default_rng(77)
+    itxb = (C.c_void_p * 6).in_dll(lib, "xevd_tbl_itxb")
+    itx = (C.c_void_p * 6).in_dll(lib, "xevdm_tbl_itx")
+    f_itxb = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int)
+    f_itx = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int)
+    lib.xevd_dquant.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_uint8]
+    recs, cin, cout = [], [], []
+    for iqt in (0, 1):
+        for bd in (8, 10):
+            for log2w in range(1, 7):
+                for log2h in range(1, 7):
+                    w, h = 1 << log2w, 1 << log2h
+                    for trial in range(3):
+                        qp = int(rng.integers(10, 46)) + 6 * (bd - 8)
+                        tbl = [40, 45, 51, 57, 64, 72] if iqt else [40, 45, 51, 57, 64, 71]
+                        scale = tbl[qp % 6] << (qp // 6)
+                        shift = 20 - 14 - (15 - bd - ((log2w + log2h) >> 1)) + (8 if (log2w + log2h) & 1 else 0)
+                        offset = 0 if shift == 0 else 1 << (shift - 1)
+                        ns = 181 if (log2w + log2h) & 1 else 1
+                        cap = max(1, int(2.0 * (1 << bd) / (scale * ns / 2.0 ** shift)))
+                        coef = np.zeros((h, w), np.int16)
+                        nnz = int(rng.integers(1, max(2, min(w * h // 4, 40))))
+                        ys = rng.integers(0, min(h, 32), nnz)          # 64-point dims: first 32 positions only
+                        xs = rng.integers(0, min(w, 32), nnz)
+                        coef[ys, xs] = rng.integers(-cap, cap + 1, nnz)
+                        a = coef.copy()
+                        lib.xevd_dquant(_p(a), log2w, log2h, scale, offset, shift)
+                        if iqt:
+                            t = np.zeros(w * h, np.int16)
+                            f_itx(itx[log2h - 1])(_p(a), _p(t), 7, w)
+                            f_itx(itx[log2w - 1])(_p(t), _p(a), 12 - (bd - 8), h)
+                        else:
+                            t = np.zeros(w * h, np.int32)
+                            f_itxb(itxb[log2h - 1])(_p(a), _p(t), 0, w, 0)
+                            f_itxb(itxb[log2w - 1])(_p(t), _p(a), 7 + 12 - (bd - 8), h, 1)
+                        recs.append((iqt, bd, log2w, log2h, qp, sum(c.size for c in cin)))
+                        cin.append(coef.ravel())
+                        cout.append(a.ravel())
+    np.savez_compressed(os.path.join(HERE, "blocks_itdq.npz"), recs=np.array(recs, np.int64), coef=np.concatenate(cin),
+                        resid=np.concatenate(cout))
+    print("blocks_itdq.npz:", len(recs), "blocks")
+
+
+def golden_pictures():
+    for case in cases.CASES:
+        cs = cases.build_case(*case)
+        final, pre, maps, resid = cases.run_cpu("ref", cs)
+        d = {"params": np.array(case[1:6], np.int64), "n_refs": np.array(case[6], np.int64)}
+        for (i, l), pic in cs["refs"].items():
+            for c in range(3):
+                d[f"ref_{i}_{l}_{c}"] = pic.active(c)
+            d[f"refpoc_{i}_{l}"] = np.array(pic.poc)
+        for k, v in cs["batch"].items():
+            d["b_" + k] = np.asarray(v)
+        for c in range(3):
+            d[f"out_{c}"] = final.bufs[c]
+            d[f"pre_{c}"] = pre.active(c)
+        d["resid"] = resid
+        d["map_scu"] = maps.map_scu & 0x7FFFFFFF
+        np.savez_compressed(os.path.join(HERE, f"pic_{case[0]}.npz"), **d)
+        print(f"pic_{case[0]}.npz")
+
+
+if __name__ == "__main__":
+    assert ol.have_ref(), "oracle/_ref is not built: run `make -C oracle -f Makefile.ref` in the development container"
+    lib = ol.ref()
+    golden_mc(lib)
+    golden_itdq(lib)
+    golden_pictures()

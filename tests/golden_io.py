@@ -1,0 +1,26 @@
+"""Loads the committed golden vectors (tests/golden/*.npz: inputs + outputs produced by the reference)."""
+import os
+
+import numpy as np
+
+import oracle_lib as ol
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+PICTURE_CASES = ["base_p_8b", "base_b_8b", "base_p_10b", "main_b_10b", "main_admvp_only", "main_iqt_only"]
+
+
+def load_picture_case(name):
+    d = np.load(os.path.join(GOLDEN, f"pic_{name}.npz"))
+    w, h, bd, admvp, iqt = (int(v) for v in d["params"])
+    refs = {}
+    for l in range(2):
+        for i in range(int(d["n_refs"][l])):
+            pic = ol.Picture(w, h, int(d[f"refpoc_{i}_{l}"]), [d[f"ref_{i}_{l}_{c}"] for c in range(3)])
+            pic.pad_numpy()
+            refs[(i, l)] = pic
+    batch = {k[2:]: d[k] for k in d.files if k.startswith("b_")}
+    batch["n_coef"] = int(batch["n_coef"])
+    case = {"name": name, "w": w, "h": h, "bd": bd, "admvp": admvp, "iqt": iqt, "refs": refs, "batch": batch}
+    expect = {"out": [d[f"out_{c}"] for c in range(3)], "pre": [d[f"pre_{c}"] for c in range(3)], "resid": d["resid"],
+              "map_scu": d["map_scu"]}
+    return case, expect

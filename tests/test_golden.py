@@ -1,0 +1,65 @@
+"""CPU suite: the oracle reproduces the committed golden vectors (which the reference produced)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import golden_io
+import oracle_lib as ol
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_golden_mc_blocks_oracle():
+    d = np.load(os.path.join(golden_io.GOLDEN, "blocks_mc.npz"))
+    orc = ol.oracle()
+    for bd, admvp, luma, has_dx, has_dy, w, h, gx, gy, off in d["recs"]:
+        plane = d[f"plane_bd{bd}"]
+        out = np.zeros((h, w), np.int16)
+        (orc.orc_mc_l if luma else orc.orc_mc_c)(_p(plane), int(gx), int(gy), plane.shape[1], int(w), _p(out), int(w), int(h), int(bd),
+                                                int(has_dx), int(has_dy), int(admvp))
+        assert np.array_equal(out.ravel(), d["pred"][off:off + w * h]), (bd, admvp, luma, has_dx, has_dy, w, h)
+
+
+def test_golden_itdq_blocks_oracle():
+    d = np.load(os.path.join(golden_io.GOLDEN, "blocks_itdq.npz"))
+    orc = ol.oracle()
+    for iqt, bd, log2w, log2h, qp, off in d["recs"]:
+        n = 1 << (log2w + log2h)
+        c = d["coef"][off:off + n].copy()
+        orc.orc_itdq(_p(c), int(log2w), int(log2h), int(qp), int(bd), int(iqt))
+        assert np.array_equal(c, d["resid"][off:off + n]), (iqt, bd, log2w, log2h, qp)
+
+
+@pytest.mark.parametrize("name", golden_io.PICTURE_CASES)
+def test_golden_pictures_oracle(name):
+    case, exp = golden_io.load_picture_case(name)
+    final, pre, maps, resid = cases.run_cpu("oracle", case)
+    assert np.array_equal(resid, exp["resid"])
+    for c in range(3):
+        assert np.array_equal(pre.active(c), exp["pre"][c]), f"recon plane {c}"
+        assert np.array_equal(final.bufs[c], exp["out"][c]), f"final plane {c}"
+    assert np.array_equal(maps.map_scu & 0x7FFFFFFF, exp["map_scu"])
+
+
+def test_synthetic_generator_is_deterministic_and_well_formed():
+    from xevd_amd import synth
+    a = synth.gen_frame(np.random.default_rng(5), 200, 136, 10, inter_frac=0.8, bi_frac=0.4, n_refs=(2, 2))
+    b = synth.gen_frame(np.random.default_rng(5), 200, 136, 10, inter_frac=0.8, bi_frac=0.4, n_refs=(2, 2))
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    # CUs tile the picture exactly once
+    cover = np.zeros((136 // 4, 200 // 4), np.int32)
+    for x, y, lw, lh in zip(a["x"], a["y"], a["log2w"], a["log2h"]):
+        cover[y // 4:(y + (1 << lh)) // 4, x // 4:(x + (1 << lw)) // 4] += 1
+    assert (cover == 1).all()
+    # CTU grouping
+    st = a["ctu_cu_start"]
+    assert st[0] == 0 and st[-1] == len(a["x"]) and (np.diff(st.astype(np.int64)) > 0).all()
+    for i in range(len(st) - 1):
+        xs, ys = a["x"][st[i]:st[i + 1]], a["y"][st[i]:st[i + 1]]
+        assert len(set(zip((xs // 64).tolist(), (ys // 64).tolist()))) == 1

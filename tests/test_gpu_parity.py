@@ -1,0 +1,133 @@
+"""GPU suite (run with -m gpu on an MI355X): the HIP backend, driven through the C ABI, against
+  (1) the committed golden vectors the reference produced (tests/golden/*.npz),
+  (2) the CPU oracle on further seeded inputs incl. extreme partitions and out-of-range stress levels,
+  (3) size-independent properties at BASELINE.json's full picture sizes.
+Bar: bit-exact (integer path)."""
+import os
+
+import numpy as np
+import pytest
+
+import cases
+import golden_io
+from xevd_amd import abi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def decs():
+    from xevd_amd.decoder import XgpuDecoder
+    d = {(admvp, iqt): XgpuDecoder(64, 64, 8, admvp=admvp, iqt=iqt, max_pics=2) for admvp in (0, 1) for iqt in (0, 1)}
+    yield d
+    for v in d.values():
+        v.close()
+
+
+def test_native_library_is_loaded():
+    lib = abi.load()
+    assert lib.xgpu_version().startswith(b"xevd_amd")
+    maps = open("/proc/self/maps").read()
+    assert "libxevd_hip.so" in maps
+
+
+def test_gpu_mc_blocks_golden(decs):
+    d = np.load(os.path.join(golden_io.GOLDEN, "blocks_mc.npz"))
+    for bd, admvp, luma, has_dx, has_dy, w, h, gx, gy, off in d["recs"]:
+        plane = d[f"plane_bd{bd}"]
+        out = decs[(int(admvp), 0)].test_mc(plane, 0, 0, int(has_dx), int(has_dy), int(gx), int(gy), int(w), int(h), int(bd), bool(luma))
+        assert np.array_equal(out.ravel(), d["pred"][off:off + w * h]), (bd, admvp, luma, has_dx, has_dy, w, h, gx, gy)
+
+
+def test_gpu_itdq_blocks_golden(decs):
+    d = np.load(os.path.join(golden_io.GOLDEN, "blocks_itdq.npz"))
+    for iqt, bd, log2w, log2h, qp, off in d["recs"]:
+        n = 1 << (log2w + log2h)
+        out = decs[(0, int(iqt))].test_itdq(d["coef"][off:off + n], int(log2w), int(log2h), [int(qp)], int(bd))
+        assert np.array_equal(out, d["resid"][off:off + n]), (iqt, bd, log2w, log2h, qp)
+
+
+def test_gpu_itdq_many_blocks_per_wave(decs):
+    """several TBs share a wave (64/W per wave): every block of a batch must come out like its golden twin"""
+    d = np.load(os.path.join(golden_io.GOLDEN, "blocks_itdq.npz"))
+    recs = [r for r in d["recs"] if r[0] == 0 and r[1] == 8 and r[2] == 2 and r[3] == 3]
+    coef = np.concatenate([d["coef"][r[5]:r[5] + 32] for r in recs] * 7)
+    exp = np.concatenate([d["resid"][r[5]:r[5] + 32] for r in recs] * 7)
+    qp = [int(r[4]) for r in recs] * 7
+    out = decs[(0, 0)].test_itdq(coef, 2, 3, qp, 8)
+    assert np.array_equal(out, exp)
+
+
+@pytest.mark.parametrize("name", golden_io.PICTURE_CASES)
+def test_gpu_pictures_golden(name):
+    case, exp = golden_io.load_picture_case(name)
+    pre = cases.run_gpu(case, deblock=False, pad=False)
+    for c in range(3):
+        pad = abi.PAD_L if c == 0 else abi.PAD_C
+        got = pre[c][pad:-pad, pad:-pad]
+        assert np.array_equal(got, exp["pre"][c]), f"recon plane {c}: {np.argwhere(got != exp['pre'][c])[:4]}"
+    out = cases.run_gpu(case)
+    for c in range(3):
+        assert np.array_equal(out[c], exp["out"][c]), f"final plane {c}: {np.argwhere(out[c] != exp['out'][c])[:4]}"
+
+
+RANDOM = [
+    # name, w, h, bd, admvp, iqt, n_refs, bi_frac, kwargs
+    ("rnd_a", 264, 136, 8, 0, 0, (2, 1), 0.3, {}),
+    ("rnd_b", 72, 200, 10, 1, 1, (2, 2), 0.6, {}),
+    ("all_4x4", 136, 72, 8, 0, 0, (1, 1), 0.3, {"split_prob": 1.0, "qp_range": (30, 50)}),
+    ("all_64", 192, 128, 8, 0, 0, (1, 1), 0.3, {"split_prob": 0.0, "qp_range": (30, 50)}),
+    ("all_inter_oob", 128, 128, 10, 1, 0, (1, 1), 0.5, {"inter_frac": 1.0, "oob_frac": 0.6}),
+    ("stress_levels", 128, 72, 8, 0, 0, (1, 0), 0.0, {"amp": 40.0}),
+    ("stress_levels_iqt", 128, 72, 10, 0, 1, (1, 0), 0.0, {"amp": 40.0}),
+    ("tiny", 8, 8, 8, 0, 0, (1, 0), 0.0, {}),
+]
+
+
+@pytest.mark.parametrize("spec", RANDOM, ids=[s[0] for s in RANDOM])
+def test_gpu_vs_oracle_random(spec):
+    *case, kw = spec
+    for seed in range(2):
+        cs = cases.build_case(*case, seed=seed, **kw)
+        ref, _, _, _ = cases.run_cpu("oracle", cs)
+        out = cases.run_gpu(cs)
+        for c in range(3):
+            assert np.array_equal(out[c], ref.bufs[c]), f"{spec[0]} seed {seed} plane {c}: {np.argwhere(out[c] != ref.bufs[c])[:4]}"
+
+
+@pytest.mark.parametrize("size", [(1920, 1080), (3840, 2160)], ids=["1080p", "4k"])
+def test_gpu_full_size_vs_oracle(size):
+    """BASELINE.json picture sizes, whole pipeline, against the oracle (a few seconds of CPU)."""
+    w, h = size
+    cs = cases.build_case("full", w, h, 8, 0, 0, (1, 0), 0.0, seed=w, inter_frac=0.95)
+    ref, _, _, _ = cases.run_cpu("oracle", cs)
+    out = cases.run_gpu(cs)
+    for c in range(3):
+        assert np.array_equal(out[c], ref.bufs[c]), f"plane {c}"
+
+
+def test_gpu_8k_properties():
+    """8K (7680x4320): identity property - zero motion, no residual, deblocking off: the picture equals its
+    reference, padding included; and the run is deterministic."""
+    from xevd_amd.decoder import XgpuDecoder
+    w, h, bd = 7680, 4320, 10
+    rng = np.random.default_rng(8)
+    planes = synth.gen_picture(rng, w, h, bd)
+    batch = synth.gen_frame(rng, w, h, bd, inter_frac=1.0, coded_frac=0.0, mv_sigma_px=0.0, oob_frac=0.0)
+    batch["mv"][:] = 0
+    with XgpuDecoder(w, h, bd, max_pics=3) as dec:
+        r = dec.pic_alloc()
+        dec.pic_upload(r, planes)
+        dec.frame_begin(r, 0, {})
+        dec.pad()
+        dec.frame_end()
+        cur = dec.pic_alloc()
+        hb = dec.batch_create(batch)
+        dec.decode_picture(cur, 1, {(0, 0): (r, 0)}, hb, deblock=False)
+        a = dec.pic_download_padded(cur)
+        b = dec.pic_download_padded(r)
+        for c in range(3):
+            assert np.array_equal(a[c], b[c])
+            pad = abi.PAD_L if c == 0 else abi.PAD_C
+            assert np.array_equal(a[c][pad:-pad, pad:-pad], planes[c])
+            assert np.array_equal(a[c], np.pad(planes[c], pad, mode="edge"))

@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
-from xevd_amd import abi, synth
+from xevd_amd import abi, synth  # noqa: F401
 
 pytestmark = pytest.mark.ref
 
@@ -172,67 +172,14 @@ def test_deblock_segments():
                 assert np.array_equal(au, bu) and np.array_equal(av, bv)
 
 
-CASES = [
-    # name, w, h, bd, admvp, iqt, n_refs, bi_frac
-    ("base_p_8b", 208, 120, 8, 0, 0, (1, 0), 0.0),
-    ("base_b_8b", 136, 72, 8, 0, 0, (2, 2), 0.5),
-    ("base_p_10b", 144, 88, 10, 0, 0, (2, 0), 0.0),
-    ("main_b_10b", 200, 136, 10, 1, 1, (2, 2), 0.5),
-    ("main_admvp_only", 128, 64, 8, 1, 0, (1, 1), 0.4),
-    ("main_iqt_only", 128, 72, 10, 0, 1, (1, 1), 0.4),
-]
+import cases
 
 
-def run_case(engine, name, w, h, bd, admvp, iqt, n_refs, bi_frac, seed=0, deblock=True, simd=0, inter_frac=0.9):
-    """engine: 'oracle' or 'ref'. returns (picture, maps, resid)"""
-    rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000 + seed)
-    sp = abi.make_seq_params(w, h, bd, iqt=iqt, admvp=admvp)
-    refs = {}
-    poc = 8
-    pocs = [[4, 0, 2], [12, 16, 4]]      # L1 idx2 has the same POC as L0 idx0 -> identical-motion candidates
-    for l in range(2):
-        for i in range(n_refs[l]):
-            pic = ol.Picture(w, h, pocs[l][i], synth.gen_picture(rng, w, h, bd))
-            pic.pad_numpy()
-            refs[(i, l)] = pic
-    batch = synth.gen_frame(rng, w, h, bd, inter_frac=inter_frac, bi_frac=bi_frac, n_refs=n_refs, oob_frac=0.1,
-                            qp_range=(20, 45))
-    # force some identical-motion bi CUs
-    if n_refs[0] and n_refs[1]:
-        sel = (batch["refi"][:, 0] >= 0) & (batch["refi"][:, 1] >= 0)
-        idx = np.nonzero(sel)[0][::3]
-        batch["mv"][idx, 1] = batch["mv"][idx, 0]
-    cb, keep = abi.make_cu_batch(batch)
-    cur = ol.Picture(w, h, poc, fill=0)
-    # intra CUs are not reconstructed on this path: give them deterministic content so deblocking has input
-    cur.bufs[0][:] = 1 << (bd - 1)
-    cur.bufs[1][:] = 1 << (bd - 1)
-    cur.bufs[2][:] = 1 << (bd - 1)
-    maps = ol.Maps(w, h)
-    fr = ol.make_frame(cur, refs, qp_u_offset=1, qp_v_offset=-2)
-    m = maps.orc()
-    resid = np.zeros(max(batch["n_coef"], 1), np.int16)
-    if engine == "oracle":
-        o = ol.oracle()
-        o.orc_recon_batch(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), _p(resid))
-        pre = cur.copy()
-        if deblock:
-            o.orc_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m))
-        o.orc_pad(C.byref(sp), C.byref(fr.cur))
-    else:
-        hn = ol.harness()
-        hn.refh_recon_batch(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), _p(resid), simd)
-        pre = cur.copy()
-        if deblock:
-            hn.refh_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), simd)
-        hn.refh_pad(C.byref(sp), C.byref(fr.cur))
-    return cur, pre, maps, resid
-
-
-@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("case", cases.CASES, ids=[c[0] for c in cases.CASES])
 def test_picture_level_oracle_equals_reference(case):
-    a, a_pre, ma, ra = run_case("oracle", *case)
-    b, b_pre, mb, rb = run_case("ref", *case)
+    cs = cases.build_case(*case)
+    a, a_pre, ma, ra = cases.run_cpu("oracle", cs)
+    b, b_pre, mb, rb = cases.run_cpu("ref", cs)
     assert np.array_equal(ra, rb), "residual arena"
     for c in range(3):
         assert np.array_equal(a_pre.active(c), b_pre.active(c)), f"recon plane {c}"
@@ -242,8 +189,20 @@ def test_picture_level_oracle_equals_reference(case):
         assert np.array_equal(a.bufs[c], b.bufs[c]), f"deblocked+padded plane {c}"
     # the reference's AVX/SSE tables give the same picture on these conformant-range inputs (all-inter: the
     # SIMD recon kernels scribble past narrow blocks, which a real decode repairs with the next CU)
-    c0, _, _, r0 = run_case("ref", *case, simd=0, inter_frac=1.0)
-    s0, _, _, r1 = run_case("ref", *case, simd=1, inter_frac=1.0)
+    cs1 = cases.build_case(*case, inter_frac=1.0)
+    c0, _, _, r0 = cases.run_cpu("ref", cs1, simd=0)
+    s0, _, _, r1 = cases.run_cpu("ref", cs1, simd=1)
     assert np.array_equal(r0, r1), "simd residual"
     for c in range(3):
         assert np.array_equal(s0.bufs[c], c0.bufs[c]), f"simd plane {c}"
+
+
+@pytest.mark.parametrize("split_prob", [0.0, 1.0])
+def test_picture_level_extreme_partitions(split_prob):
+    """all-64x64 CUs and all-4x4 CUs (the longest chroma deblocking dependency chains)"""
+    cs = cases.build_case("extreme", 136, 72, 8, 0, 0, (1, 1), 0.3, seed=int(split_prob), split_prob=split_prob, qp_range=(30, 50))
+    a, _, _, ra = cases.run_cpu("oracle", cs)
+    b, _, _, rb = cases.run_cpu("ref", cs)
+    assert np.array_equal(ra, rb)
+    for c in range(3):
+        assert np.array_equal(a.bufs[c], b.bufs[c])

@@ -1,0 +1,406 @@
+// k_inter.hip - motion compensation + residual add + clip + SCU-map update for every inter CU of a picture.
+//
+// Replaces, per picture, the reference's per-CU sequence  xevd_mc -> xevd_recon_yuv -> xevd_set_dec_info
+// (src_base/xevd.c:725-754, xevd_mc.c:469-557, xevd_recon.c:35-92, xevd_util.c:1574-1660).
+//
+// MI355X mapping (not a translation of the per-CU C/AVX loops):
+//   * one 256-thread workgroup per 64x64 luma region, one LANE per 4x4 SCU (+ its two 2x2 chroma blocks).  MC is
+//     a per-sample function of the covering CU's motion, so an SCU can be predicted independently of the CU it
+//     belongs to: every lane runs the same straight-line code whatever the CU sizes are (no size classes, no
+//     divergence on block shape), and the 16 lanes of an SCU row store 128 contiguous bytes per picture row.
+//   * the lane finds its CU by scanning the CTU's CU list, staged once per workgroup in LDS as one packed
+//     geometry word per CU (broadcast reads); the 32-byte CU record is then fetched with two 16-byte loads.
+//   * the 11x11 (luma) / 5x5 (chroma) reference windows are read straight from HBM/L2 with 16-byte loads at the
+//     2-byte-aligned sample address (gfx950 runs in unaligned-access mode); neighbouring lanes share the halo
+//     through the vector L1, workgroups are mapped to XCDs in contiguous bands so vertical halos share an L2.
+//   * FIRs run on packed s16 pairs with v_dot2c_i32_i16 (two taps per instruction); the four rounding regimes of
+//     the reference (copy / H-only / V-only / 2-D) are one code path with per-lane tap vectors, shifts and
+//     offsets, so lanes with different sub-pel classes do not diverge.
+//   * no MFMA: these are 4/8-tap integer FIRs, bounded by load/issue rate and HBM, not by dense contraction.
+#include "xgpu_internal.h"
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+struct __attribute__((packed, aligned(2))) U32x4u { uint32_t a, b, c, d; };
+struct __attribute__((packed, aligned(2))) U32x2u { uint32_t a, b; };
+struct __attribute__((packed, aligned(2))) U32x1u { uint32_t a; };
+
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b), c, false);
+}
+__device__ __forceinline__ uint32_t hi_lo(uint32_t hi, uint32_t lo)   // (lo.hi16, hi.lo16): samples 2m+1, 2m+2
+{
+    return __builtin_amdgcn_alignbit(hi, lo, 16);
+}
+__device__ __forceinline__ uint32_t pack2(int lo, int hi)               // two s32 -> packed (lo16, hi16), wraps
+{
+    return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
+}
+__device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
+
+// Interpolation taps as packed s16 pairs.  Luma rows: phase (1/16 pel) -> 4 dwords; chroma: phase (1/32) -> 2 dwords.
+// Baseline tables: src_base/xevd_mc.c:80-134 (phases 0,4,8,12 / 0,4,..,28); Main (sps_admvp_flag):
+// src_main/xevdm_mc.c:121-175.  Entry [.][16] / [.][32] is the identity (tap 3 / tap 1 = 1) used when a
+// direction is not filtered.
+#define PK(a, b) ((uint32_t)(uint16_t)(int16_t)(a) | ((uint32_t)(uint16_t)(int16_t)(b) << 16))
+#define L8(a, b, c, d, e, f, g, h) { PK(a, b), PK(c, d), PK(e, f), PK(g, h) }
+#define C4(a, b, c, d) { PK(a, b), PK(c, d) }
+__constant__ uint32_t k_luma_taps[2][17][4] = {
+    { L8(0,0,0,64,0,0,0,0), L8(0,0,0,0,0,0,0,0), L8(0,0,0,0,0,0,0,0), L8(0,0,0,0,0,0,0,0),
+      L8(0,1,-5,52,20,-5,1,0), L8(0,0,0,0,0,0,0,0), L8(0,0,0,0,0,0,0,0), L8(0,0,0,0,0,0,0,0),
+      L8(0,2,-10,40,40,-10,2,0), L8(0,0,0,0,0,0,0,0), L8(0,0,0,0,0,0,0,0), L8(0,0,0,0,0,0,0,0),
+      L8(0,1,-5,20,52,-5,1,0), L8(0,0,0,0,0,0,0,0), L8(0,0,0,0,0,0,0,0), L8(0,0,0,0,0,0,0,0),
+      L8(0,0,0,1,0,0,0,0) },
+    { L8(0,0,0,64,0,0,0,0), L8(0,1,-3,63,4,-2,1,0), L8(-1,2,-5,62,8,-3,1,0), L8(-1,3,-8,60,13,-4,1,0),
+      L8(-1,4,-10,58,17,-5,1,0), L8(-1,4,-11,52,26,-8,3,-1), L8(-1,3,-9,47,31,-10,4,-1), L8(-1,4,-11,45,34,-10,4,-1),
+      L8(-1,4,-11,40,40,-11,4,-1), L8(-1,4,-10,34,45,-11,4,-1), L8(-1,4,-10,31,47,-9,3,-1), L8(-1,3,-8,26,52,-11,4,-1),
+      L8(0,1,-5,17,58,-10,4,-1), L8(0,1,-4,13,60,-8,3,-1), L8(0,1,-3,8,62,-5,2,-1), L8(0,1,-2,4,63,-3,1,0),
+      L8(0,0,0,1,0,0,0,0) },
+};
+__constant__ uint32_t k_chroma_taps[2][33][2] = {
+    { C4(0,64,0,0), C4(0,0,0,0), C4(0,0,0,0), C4(0,0,0,0), C4(-2,58,10,-2), C4(0,0,0,0), C4(0,0,0,0), C4(0,0,0,0),
+      C4(-4,52,20,-4), C4(0,0,0,0), C4(0,0,0,0), C4(0,0,0,0), C4(-6,46,30,-6), C4(0,0,0,0), C4(0,0,0,0), C4(0,0,0,0),
+      C4(-8,40,40,-8), C4(0,0,0,0), C4(0,0,0,0), C4(0,0,0,0), C4(-6,30,46,-6), C4(0,0,0,0), C4(0,0,0,0), C4(0,0,0,0),
+      C4(-4,20,52,-4), C4(0,0,0,0), C4(0,0,0,0), C4(0,0,0,0), C4(-2,10,58,-2), C4(0,0,0,0), C4(0,0,0,0), C4(0,0,0,0),
+      C4(0,1,0,0) },
+    { C4(0,64,0,0), C4(-1,63,2,0), C4(-2,62,4,0), C4(-2,60,7,-1), C4(-2,58,10,-2), C4(-3,57,12,-2), C4(-4,56,14,-2), C4(-4,55,15,-2),
+      C4(-4,54,16,-2), C4(-5,53,18,-2), C4(-6,52,20,-2), C4(-6,49,24,-3), C4(-6,46,28,-4), C4(-5,44,29,-4), C4(-4,42,30,-4), C4(-4,39,33,-4),
+      C4(-4,36,36,-4), C4(-4,33,39,-4), C4(-4,30,42,-4), C4(-4,29,44,-5), C4(-4,28,46,-6), C4(-3,24,49,-6), C4(-2,20,52,-6), C4(-2,18,53,-5),
+      C4(-2,16,54,-4), C4(-2,15,55,-4), C4(-2,14,56,-4), C4(-2,12,57,-3), C4(-2,10,58,-2), C4(-1,7,60,-2), C4(0,4,62,-2), C4(0,2,63,-1),
+      C4(0,1,0,0) },
+};
+
+// Per-lane description of one separable interpolation in the reference's four rounding regimes
+// (xevd_mc.c:169-288 / :290-408, shifts xevd_mc.h:34-38):
+//   stage 1: t = (sum_h) >> sh1, clipped to [0,max] only in the H-only regime, then truncated to s16
+//   stage 2: out = clip((sum_v + off2) >> sh2)
+struct Regime { int sh1, clip1, sh2, off2; };
+__device__ __forceinline__ Regime regime(int has_dx, int has_dy, int bd)
+{
+    Regime r;
+    const int shift1 = min(4, bd - 8), shift2 = max(8, 20 - bd);
+    r.sh1   = has_dx ? (has_dy ? shift1 : 6) : 0;
+    r.clip1 = has_dx && !has_dy;
+    r.sh2   = has_dy ? (has_dx ? shift2 : 6) : 0;
+    r.off2  = (has_dy && has_dx) ? (1 << (shift2 - 1)) : 0;
+    return r;
+}
+
+// 4x4 luma prediction of one SCU.  `p` = reference sample at (block x - 3, block y - 3).
+// out[r] = packed (c0,c1),(c2,c3) as two dwords per row -> o[r*2+0], o[r*2+1]; values are clipped s16.
+__device__ __forceinline__ void mc_luma_4x4(const int16_t *p, int s, const uint32_t ch[4], const uint32_t cv[4],
+                                            Regime rg, int maxv, uint32_t o[8])
+{
+    int acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[r][c] = rg.off2;
+    int tp[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 11; j++) {
+        const U32x4u a = *(const U32x4u *)(p + j * s);
+        const U32x2u b = *(const U32x2u *)(p + j * s + 8);
+        const uint32_t D0 = a.a, D1 = a.b, D2 = a.c, D3 = a.d, D4 = b.a, D5 = b.b;
+        const uint32_t Q0 = hi_lo(D1, D0), Q1 = hi_lo(D2, D1), Q2 = hi_lo(D3, D2), Q3 = hi_lo(D4, D3), Q4 = hi_lo(D5, D4);
+        int t[4];
+        t[0] = dot2(ch[3], D3, dot2(ch[2], D2, dot2(ch[1], D1, dot2(ch[0], D0, 0))));
+        t[2] = dot2(ch[3], D4, dot2(ch[2], D3, dot2(ch[1], D2, dot2(ch[0], D1, 0))));
+        t[1] = dot2(ch[3], Q3, dot2(ch[2], Q2, dot2(ch[1], Q1, dot2(ch[0], Q0, 0))));
+        t[3] = dot2(ch[3], Q4, dot2(ch[2], Q3, dot2(ch[1], Q2, dot2(ch[0], Q1, 0))));
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            t[c] >>= rg.sh1;
+            if (rg.clip1) t[c] = clip3(0, maxv, t[c]);
+        }
+        if (j > 0) {
+            // row pair (j-1, j) feeds output row r with tap pair (j-1-r)/2 when j-1-r is even and in 0..6
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t pr = pack2(tp[c], t[c]);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int d = j - 1 - r;
+                    if (d >= 0 && d <= 6 && (d & 1) == 0) acc[r][c] = dot2(cv[d >> 1], pr, acc[r][c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) tp[c] = t[c];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int v[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) v[c] = clip3(0, maxv, acc[r][c] >> rg.sh2);
+        o[r * 2 + 0] = pack2(v[0], v[1]);
+        o[r * 2 + 1] = pack2(v[2], v[3]);
+    }
+}
+
+// 2x2 chroma prediction of one SCU.  `p` = reference sample at (block x - 1, block y - 1).  o[r] = packed row r.
+__device__ __forceinline__ void mc_chroma_2x2(const int16_t *p, int s, const uint32_t ch[2], const uint32_t cv[2],
+                                              Regime rg, int maxv, uint32_t o[2])
+{
+    int acc[2][2] = {{rg.off2, rg.off2}, {rg.off2, rg.off2}};
+    int tp[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const U32x2u a = *(const U32x2u *)(p + j * s);
+        const U32x1u b = *(const U32x1u *)(p + j * s + 4);
+        const uint32_t D0 = a.a, D1 = a.b, D2 = b.a;
+        const uint32_t Q0 = hi_lo(D1, D0), Q1 = hi_lo(D2, D1);
+        int t[2];
+        t[0] = dot2(ch[1], D1, dot2(ch[0], D0, 0));
+        t[1] = dot2(ch[1], Q1, dot2(ch[0], Q0, 0));
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            t[c] >>= rg.sh1;
+            if (rg.clip1) t[c] = clip3(0, maxv, t[c]);
+        }
+        if (j > 0) {
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const uint32_t pr = pack2(tp[c], t[c]);
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const int d = j - 1 - r;
+                    if (d >= 0 && d <= 2 && (d & 1) == 0) acc[r][c] = dot2(cv[d >> 1], pr, acc[r][c]);
+                }
+            }
+        }
+        tp[0] = t[0]; tp[1] = t[1];
+    }
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+        o[r] = pack2(clip3(0, maxv, acc[r][0] >> rg.sh2), clip3(0, maxv, acc[r][1] >> rg.sh2));
+}
+
+// (p0 + p1 + 1) >> 1 on packed non-negative s16 pairs (xevd_average_16b_no_clip, xevd_mc.c:145-167)
+__device__ __forceinline__ uint32_t avg2(uint32_t a, uint32_t b)
+{
+    const uint32_t lo = ((a & 0xFFFFu) + (b & 0xFFFFu) + 1u) >> 1;
+    const uint32_t hi = ((a >> 16) + (b >> 16) + 1u) >> 1;
+    return lo | (hi << 16);
+}
+// rec = clip(0, max, (s16)(res + pred)) on packed pairs: the 16-bit sum wraps (xevd_recon.c:39,60)
+__device__ __forceinline__ uint32_t recon2(uint32_t pred, uint32_t res, int maxv)
+{
+    const int lo = (int)(int16_t)((pred & 0xFFFFu) + (res & 0xFFFFu));
+    const int hi = (int)(int16_t)((pred >> 16) + (res >> 16));
+    return pack2(clip3(0, maxv, lo), clip3(0, maxv, hi));
+}
+
+#define MAX_CU_PER_CTU 1024
+
+__global__ __launch_bounds__(256) void k_inter(const InterArgs a)
+{
+    __shared__ uint32_t s_geo[MAX_CU_PER_CTU];
+
+    // XCD-aware mapping: workgroup b runs on XCD b % 8; give every XCD a contiguous band of regions so that
+    // vertically adjacent regions (which share reference halos) hit the same L2.
+    const int per = (a.n_regions + 7) >> 3;
+    const int region = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (region >= a.n_regions) return;
+    const int rx = region % a.regions_x, ry = region / a.regions_x;
+    const int ctu_sz = 1 << a.log2_ctu;
+    const int ctu_x = (rx << 6) >> a.log2_ctu, ctu_y = (ry << 6) >> a.log2_ctu;
+    const int ctu = ctu_y * a.w_ctu + ctu_x;
+    const int first = a.ctu_cu_start[ctu];
+    const int n = min((int)a.ctu_cu_start[ctu + 1] - first, MAX_CU_PER_CTU);
+    const int t = threadIdx.x;
+
+    for (int i = t; i < n; i += 256) {
+        const uint2 g = *(const uint2 *)&a.cus[first + i];        // x, y, log2w, log2h, ...
+        const int x = g.x & 0xFFFF, y = g.x >> 16, lw = g.y & 0xFF, lh = (g.y >> 8) & 0xFF;
+        s_geo[i] = (uint32_t)((x & (ctu_sz - 1)) >> 2) | ((uint32_t)((y & (ctu_sz - 1)) >> 2) << 5) |
+                   ((uint32_t)(((1 << lw) >> 2) - 1) << 10) | ((uint32_t)(((1 << lh) >> 2) - 1) << 15);
+    }
+    __syncthreads();
+
+    const int sx = (rx << 4) + (t & 15), sy = (ry << 4) + (t >> 4);      // SCU coordinates in the picture
+    const bool active = sx < (a.pic_w >> 2) && sy < (a.pic_h >> 2);
+    const int rsx = sx - ((ctu_x << a.log2_ctu) >> 2), rsy = sy - ((ctu_y << a.log2_ctu) >> 2);
+    int found = -1;
+    for (int i = 0; i < n; i++) {
+        const uint32_t g = s_geo[i];
+        const bool hit = (uint32_t)(rsx - (int)(g & 31)) <= ((g >> 10) & 31) && (uint32_t)(rsy - (int)((g >> 5) & 31)) <= ((g >> 15) & 31);
+        if (hit && found < 0) found = i;
+        if (__ballot(active && found < 0) == 0) break;
+    }
+    if (!active || found < 0) return;
+
+    const uint4 r0 = ((const uint4 *)&a.cus[first + found])[0];
+    const uint4 r1 = ((const uint4 *)&a.cus[first + found])[1];
+    const int cu_x = r0.x & 0xFFFF, cu_y = r0.x >> 16;
+    const int lw = r0.y & 0xFF, lh = (r0.y >> 8) & 0xFF, pred_mode = (r0.y >> 16) & 0xFF, cbf = r0.y >> 24;
+    const int refi0 = (int)(int8_t)(r0.z & 0xFF), refi1 = (int)(int8_t)((r0.z >> 8) & 0xFF), qp_map = (r0.z >> 16) & 0xFF;
+    const uint32_t coef_off = r0.w;
+    const int cw = 1 << lw, chh = 1 << lh;
+    const int x = sx << 2, y = sy << 2;
+    const bool intra = pred_mode == XGPU_MODE_INTRA;
+
+    // ---- SCU map update (xevd_set_dec_info): intra flag, QP, skip flag, luma cbf, COD + CU-edge flags ----
+    {
+        uint32_t m = ((uint32_t)qp_map << 16) | ((uint32_t)intra << 15) | (1u << 31);
+        if (pred_mode == XGPU_MODE_SKIP) m |= 1u << 23;
+        if (cbf & 1) m |= 1u << 24;
+        if (x == cu_x) m |= SCU_EDGE_L;
+        if (y == cu_y) m |= SCU_EDGE_T;
+        uint4 rec;
+        rec.x = m;
+        rec.y = intra ? 0x0000FFFFu : (r0.z & 0xFFFFu);
+        rec.z = intra ? 0u : r1.x;
+        rec.w = intra ? 0u : r1.y;
+        *(uint4 *)&a.maps[sy * a.w_scu + sx] = rec;
+    }
+    if (intra) return;
+
+    // ---- motion: clip like xevd_mv_clip (xevd_mc.c:435-467), variant from the UNCLIPPED vector ----
+    const int maxl = (1 << a.bd_l) - 1, maxc = (1 << a.bd_c) - 1;
+    uint32_t pl[8], pu[2], pv[2];
+    int nl = 0;
+    int16_t mvt[2][2];
+    const int mvs[2][2] = { { (int)(int16_t)(r1.x & 0xFFFF), (int)(int16_t)(r1.x >> 16) },
+                            { (int)(int16_t)(r1.y & 0xFFFF), (int)(int16_t)(r1.y >> 16) } };
+    const int refis[2] = { refi0, refi1 };
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        int mx = mvs[l][0], my = mvs[l][1];
+        const int qx = cu_x << 2, qy = cu_y << 2, qw = cw << 2, qh = chh << 2;
+        const int min_c = -(128 << 2), max_x = (a.pic_w - 1 + 128) << 2, max_y = (a.pic_h - 1 + 128) << 2;
+        if (qx + mvs[l][0] < min_c) mx = min_c - qx;
+        if (qy + mvs[l][1] < min_c) my = min_c - qy;
+        if (qx + mvs[l][0] + qw - 4 > max_x) mx = max_x - qx - qw + 4;
+        if (qy + mvs[l][1] + qh - 4 > max_y) my = max_y - qy - qh + 4;
+        mvt[l][0] = (int16_t)mx; mvt[l][1] = (int16_t)my;
+    }
+    bool use[2] = { refi0 >= 0, refi1 >= 0 };
+    if (use[0] && use[1] && a.refp[refi0][0].poc == a.refp[refi1][1].poc && mvt[0][0] == mvt[1][0] && mvt[0][1] == mvt[1][1])
+        use[1] = false;                                               // identical motion, xevd_mc.c:512-519
+
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        if (!use[l]) continue;
+        const RefEntry re = a.refp[refis[l]][l];
+        const int mvx = mvs[l][0], mvy = mvs[l][1];
+        // luma: quarter-pel position of this SCU = (x<<2) + clipped mv; phase in 1/16 = (pos&3)<<2
+        const int px = (x << 2) + mvt[l][0], py = (y << 2) + mvt[l][1];
+        const int ldx = (mvx & 3) != 0, ldy = (mvy & 3) != 0;
+        const int cdx = (mvx & 7) != 0, cdy = (mvy & 7) != 0;
+        uint32_t ch[4], cv[4], o[8], ou[2], ov[2];
+        {
+            const uint32_t *th = k_luma_taps[a.admvp][ldx ? ((px & 3) << 2) : 16];
+            const uint32_t *tv = k_luma_taps[a.admvp][ldy ? ((py & 3) << 2) : 16];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { ch[k] = th[k]; cv[k] = tv[k]; }
+            const int16_t *p = re.y + ((py >> 2) - 3) * a.s_l + (px >> 2) - 3;
+            mc_luma_4x4(p, a.s_l, ch, cv, regime(ldx, ldy, a.bd_l), maxl, o);
+        }
+        {
+            // chroma: 1/8-pel position (x<<2)+mv in luma quarter-pel == chroma eighth-pel; phase in 1/32 = (pos&7)<<2
+            const uint32_t *th = k_chroma_taps[a.admvp][cdx ? ((px & 7) << 2) : 32];
+            const uint32_t *tv = k_chroma_taps[a.admvp][cdy ? ((py & 7) << 2) : 32];
+            uint32_t c2h[2] = { th[0], th[1] }, c2v[2] = { tv[0], tv[1] };
+            const int off = ((py >> 3) - 1) * a.s_c + (px >> 3) - 1;
+            const Regime rg = regime(cdx, cdy, a.bd_c);
+            mc_chroma_2x2(re.u + off, a.s_c, c2h, c2v, rg, maxc, ou);
+            mc_chroma_2x2(re.v + off, a.s_c, c2h, c2v, rg, maxc, ov);
+        }
+        if (nl == 0) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) pl[k] = o[k];
+            pu[0] = ou[0]; pu[1] = ou[1]; pv[0] = ov[0]; pv[1] = ov[1];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 8; k++) pl[k] = avg2(pl[k], o[k]);
+            pu[0] = avg2(pu[0], ou[0]); pu[1] = avg2(pu[1], ou[1]);
+            pv[0] = avg2(pv[0], ov[0]); pv[1] = avg2(pv[1], ov[1]);
+        }
+        nl++;
+    }
+    if (nl == 0) return;     // inter CU without a valid reference: nothing predicted (does not occur in valid streams)
+
+    // ---- residual add + clip (xevd_recon.c:35-71; the LUMA bit depth clips all three components, :75-90) ----
+    const int lx = x - cu_x, ly = y - cu_y;
+    uint32_t off = coef_off;
+    if (cbf & 1) {
+        const int16_t *r = a.resid + off + ly * cw + lx;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint2 v = *(const uint2 *)(r + k * cw);
+            pl[k * 2 + 0] = recon2(pl[k * 2 + 0], v.x, maxl);
+            pl[k * 2 + 1] = recon2(pl[k * 2 + 1], v.y, maxl);
+        }
+        off += cw * chh;
+    }
+    const int cwc = cw >> 1;
+    if (cbf & 2) {
+        const int16_t *r = a.resid + off + (ly >> 1) * cwc + (lx >> 1);
+        pu[0] = recon2(pu[0], *(const uint32_t *)r, maxl);
+        pu[1] = recon2(pu[1], *(const uint32_t *)(r + cwc), maxl);
+        off += cwc * (chh >> 1);
+    }
+    if (cbf & 4) {
+        const int16_t *r = a.resid + off + (ly >> 1) * cwc + (lx >> 1);
+        pv[0] = recon2(pv[0], *(const uint32_t *)r, maxl);
+        pv[1] = recon2(pv[1], *(const uint32_t *)(r + cwc), maxl);
+    }
+
+    int16_t *dy = a.cur_y + y * a.s_l + x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) *(uint2 *)(dy + k * a.s_l) = make_uint2(pl[k * 2], pl[k * 2 + 1]);
+    const int coff = (y >> 1) * a.s_c + (x >> 1);
+    *(uint32_t *)(a.cur_u + coff) = pu[0];
+    *(uint32_t *)(a.cur_u + coff + a.s_c) = pu[1];
+    *(uint32_t *)(a.cur_v + coff) = pv[0];
+    *(uint32_t *)(a.cur_v + coff + a.s_c) = pv[1];
+}
+
+void launch_inter(xgpu_ctx *c, const InterArgs &a)
+{
+    const int blocks = ((a.n_regions + 7) >> 3) << 3;
+    hipLaunchKernelGGL(k_inter, dim3(blocks), dim3(256), 0, c->stream, a);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fine-grained shim: one block through the same device functions with the reference's XEVD_MC_L / XEVD_MC_C
+// call shape (xevd_mc.h:47-49).  One lane per 4x4 (luma) / 2x2 (chroma) sub-block.
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_test_mc(const int16_t *plane, int stride, int ref_x, int ref_y, int has_dx, int has_dy, int gmv_x, int gmv_y,
+                          int16_t *pred, int w, int h, int bd, int luma, int admvp)
+{
+    const int bs = luma ? 4 : 2;
+    const int nbx = w / bs, nby = h / bs;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbx * nby) return;
+    const int bx = (i % nbx) * bs, by = (i / nbx) * bs;
+    const int maxv = (1 << bd) - 1;
+    const int16_t *ref = plane + ref_y * stride + ref_x;
+    if (luma) {
+        const uint32_t *th = k_luma_taps[admvp][has_dx ? (gmv_x & 15) : 16], *tv = k_luma_taps[admvp][has_dy ? (gmv_y & 15) : 16];
+        uint32_t ch[4] = { th[0], th[1], th[2], th[3] }, cv[4] = { tv[0], tv[1], tv[2], tv[3] }, o[8];
+        const int16_t *p = ref + ((gmv_y >> 4) - 3 + by) * stride + (gmv_x >> 4) - 3 + bx;
+        mc_luma_4x4(p, stride, ch, cv, regime(has_dx, has_dy, bd), maxv, o);
+        for (int r = 0; r < 4; r++) {
+            *(uint32_t *)(pred + (by + r) * w + bx) = o[r * 2];
+            *(uint32_t *)(pred + (by + r) * w + bx + 2) = o[r * 2 + 1];
+        }
+    } else {
+        const uint32_t *th = k_chroma_taps[admvp][has_dx ? (gmv_x & 31) : 32], *tv = k_chroma_taps[admvp][has_dy ? (gmv_y & 31) : 32];
+        uint32_t ch[2] = { th[0], th[1] }, cv[2] = { tv[0], tv[1] }, o[2];
+        const int16_t *p = ref + ((gmv_y >> 5) - 1 + by) * stride + (gmv_x >> 5) - 1 + bx;
+        mc_chroma_2x2(p, stride, ch, cv, regime(has_dx, has_dy, bd), maxv, o);
+        *(uint32_t *)(pred + by * w + bx) = o[0];
+        *(uint32_t *)(pred + (by + 1) * w + bx) = o[1];
+    }
+}
+
+void launch_test_mc(xgpu_ctx *c, const int16_t *plane, int stride, int ref_x, int ref_y, int has_dx, int has_dy,
+                    int gmv_x, int gmv_y, int16_t *pred, int w, int h, int bd, int luma)
+{
+    const int bs = luma ? 4 : 2;
+    const int n = (w / bs) * (h / bs);
+    hipLaunchKernelGGL(k_test_mc, dim3((n + 63) / 64), dim3(64), 0, c->stream, plane, stride, ref_x, ref_y, has_dx, has_dy,
+                       gmv_x, gmv_y, pred, w, h, bd, luma, c->sp.tool_admvp);
+}

@@ -1,0 +1,535 @@
+// xgpu_api.hip - the C ABI of include/xevd_hip.h: context, device pictures, batch builder, launch sequencing,
+// HIP-event kernel timing.  Host-side code only; kernels live in k_*.hip.
+#include <math.h>
+#include <stdlib.h>
+#include <algorithm>
+#include "xgpu_internal.h"
+
+#define HIPCHK(c, expr)                                                                                         \
+    do {                                                                                                        \
+        hipError_t e_ = (expr);                                                                                 \
+        if (e_ != hipSuccess) {                                                                                 \
+            snprintf((c)->err, sizeof((c)->err), "%s:%d %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(e_)); \
+            return XGPU_ERR_UNEXPECTED;                                                                         \
+        }                                                                                                       \
+    } while (0)
+#define ARGCHK(c, cond)                                                                                         \
+    do {                                                                                                        \
+        if (!(cond)) {                                                                                          \
+            if (c) snprintf((c)->err, sizeof((c)->err), "%s:%d invalid argument: %s", __FILE__, __LINE__, #cond); \
+            return XGPU_ERR_INVALID_ARGUMENT;                                                                   \
+        }                                                                                                       \
+    } while (0)
+
+// xevd_tbl_df_st (src_base/xevd_tbl.c:306-324): deblocking strength by edge class and QP - a table of the
+// MPEG-5 EVC specification.
+static const uint8_t k_df_st[4][52] = {
+    { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,1,1,1,1,1,2,2,2,2,2,3,3,3,4,4,4,5,5,6,6,7,8,9,10,11,12,12,12,12,12 },
+    { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,1,2,2,2,3,3,3,4,4,5,5,6,7,8, 9,10,11,11,11,11,11 },
+    { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,2,2,2,3,3,4,4,5,6,7, 8, 9,10,10,10,10,10 },
+    { 0 },
+};
+// xevd_tbl_qp_chroma_adjust_base (src_base/xevd_tbl.c:345-354): default Baseline chroma QP mapping.
+static const int8_t k_chroma_qp_base[58] = {
+     0,  1,  2,  3,  4,  5,  6,  7,  8,  9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19,
+    20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 29, 30, 31, 32, 32, 33, 33, 34, 34,
+    35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 39, 39, 40, 40, 40, 41, 41, 41 };
+
+static int align_up(int v, int a) { return (v + a - 1) / a * a; }
+
+const char *xgpu_version(void) { return "xevd_amd 0.1 (gfx950)"; }
+const char *xgpu_last_error(const xgpu_ctx *c) { return c ? c->err : "null ctx"; }
+
+// ------------------------------------------------------------------------------------------------ timing
+static void time_begin(xgpu_ctx *c, int k, hipEvent_t *a, hipEvent_t *b)
+{
+    if (!c->timing) return;
+    auto get = [&]() {
+        hipEvent_t e;
+        if (!c->ev_pool.empty()) { e = c->ev_pool.back(); c->ev_pool.pop_back(); }
+        else (void)hipEventCreate(&e);
+        return e;
+    };
+    *a = get(); *b = get();
+    (void)hipEventRecord(*a, c->stream);
+    (void)k;
+}
+static void time_end(xgpu_ctx *c, int k, hipEvent_t a, hipEvent_t b)
+{
+    if (!c->timing) return;
+    (void)hipEventRecord(b, c->stream);
+    c->ev_pending.push_back({ a, b, k });
+}
+#define TIMED(c, k, stmt)                      \
+    do {                                       \
+        hipEvent_t ta_ = 0, tb_ = 0;           \
+        time_begin(c, k, &ta_, &tb_);          \
+        stmt;                                  \
+        time_end(c, k, ta_, tb_);              \
+    } while (0)
+
+int xgpu_timing_enable(xgpu_ctx *c, int on) { ARGCHK(c, c != NULL); c->timing = on; return XGPU_OK; }
+int xgpu_timing_reset(xgpu_ctx *c)
+{
+    ARGCHK(c, c != NULL);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto &e : c->ev_pending) { c->ev_pool.push_back(e.a); c->ev_pool.push_back(e.b); }
+    c->ev_pending.clear();
+    memset(c->t_ms, 0, sizeof(c->t_ms));
+    memset(c->t_n, 0, sizeof(c->t_n));
+    return XGPU_OK;
+}
+int xgpu_timing_get(xgpu_ctx *c, double ms[XGPU_K_COUNT], long long n[XGPU_K_COUNT])
+{
+    ARGCHK(c, c != NULL);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (auto &e : c->ev_pending) {
+        float t = 0;
+        HIPCHK(c, hipEventElapsedTime(&t, e.a, e.b));
+        c->t_ms[e.k] += t; c->t_n[e.k]++;
+        c->ev_pool.push_back(e.a); c->ev_pool.push_back(e.b);
+    }
+    c->ev_pending.clear();
+    for (int i = 0; i < XGPU_K_COUNT; i++) { ms[i] = c->t_ms[i]; n[i] = c->t_n[i]; }
+    return XGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ lifetime
+static void init_transform_tables(xgpu_ctx *c)
+{
+    // xevd_tbl_tm2..64 (src_base/xevd_tbl.c:89-243) = round(64*sqrt(2)*cos((2n+1)k*pi/2N)), row 0 = 64; checked
+    // entry by entry against the reference's tables in tests/test_oracle_vs_ref.py (same closed form as the oracle)
+    static int tm[5460];
+    int o = 0;
+    for (int l = 1; l <= 6; l++) {
+        const int N = 1 << l;
+        for (int k = 0; k < N; k++)
+            for (int n = 0; n < N; n++) {
+                const double v = k == 0 ? 64.0 : 64.0 * sqrt(2.0) * cos((2 * n + 1) * k * 3.14159265358979323846 / (2.0 * N));
+                tm[o++] = (int)(v >= 0 ? floor(v + 0.5) : -floor(-v + 0.5));
+            }
+    }
+    upload_transform_tables(tm, c->stream);
+}
+
+int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
+{
+    if (!sp || !out) return XGPU_ERR_INVALID_ARGUMENT;
+    *out = NULL;
+    if (sp->chroma_format_idc != 1) return XGPU_ERR_UNSUPPORTED;
+    if (sp->width <= 0 || sp->height <= 0 || (sp->width & 7) || (sp->height & 7)) return XGPU_ERR_INVALID_ARGUMENT;
+    if (sp->bit_depth_luma < 8 || sp->bit_depth_luma > 12 || sp->bit_depth_chroma < 8 || sp->bit_depth_chroma > 12) return XGPU_ERR_UNSUPPORTED;
+    if (sp->log2_ctu < 5 || sp->log2_ctu > 7) return XGPU_ERR_INVALID_ARGUMENT;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || sp->device < 0 || sp->device >= ndev) return XGPU_ERR_UNEXPECTED;
+
+    xgpu_ctx *c = new xgpu_ctx();
+    c->sp = *sp;
+    c->sp.chroma_qp_table[0] = c->sp.chroma_qp_table[1] = NULL;
+    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->stream = 0;
+    memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_n, 0, sizeof(c->t_n));
+    // chroma QP mapping: caller table starts at qp = -6*(bdc-8); default = Baseline static table with the
+    // identity extension below 0 (xevd_set_chroma_qp_tbl_loc, xevd_tbl.c:364-372)
+    const int boff = 6 * (sp->bit_depth_chroma - 8);
+    for (int t = 0; t < 2; t++)
+        for (int q = -boff; q <= 57; q++)
+            c->chroma_qp[t][q + boff] = sp->chroma_qp_table[t] ? sp->chroma_qp_table[t][q + boff] : (int8_t)(q < 0 ? q : k_chroma_qp_base[q]);
+
+    auto fail = [&](int code) { xgpu_close(c); return code; };
+    if (hipSetDevice(sp->device) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+
+    c->w_scu = sp->width >> 2; c->h_scu = sp->height >> 2;
+    const int ctu = 1 << sp->log2_ctu;
+    c->w_ctu = (sp->width + ctu - 1) / ctu; c->h_ctu = (sp->height + ctu - 1) / ctu;
+    c->s_l = align_up(XGPU_MARGIN_L + sp->width + XGPU_PAD_L, 64);
+    c->s_c = align_up(XGPU_MARGIN_C + (sp->width >> 1) + XGPU_PAD_C, 64);
+    c->rows_l = sp->height + 2 * XGPU_PAD_L;
+    c->rows_c = (sp->height >> 1) + 2 * XGPU_PAD_C;
+    c->off_u = (size_t)c->s_l * c->rows_l;
+    c->off_v = c->off_u + (size_t)c->s_c * c->rows_c;
+    c->pic_elems = c->off_v + (size_t)c->s_c * c->rows_c + 64;   // +64: slack for the 16-byte window over-read of the last row
+
+    if (hipMalloc((void **)&c->d_maps, sizeof(ScuRec) * (size_t)c->w_scu * c->h_scu) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
+    if (hipMemsetAsync(c->d_maps, 0, sizeof(ScuRec) * (size_t)c->w_scu * c->h_scu, c->stream) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+    init_transform_tables(c);
+    // slot 0 of `pics` is the private scratch picture of the deblocking passes
+    c->pics.resize(1 + std::max(1, std::min(sp->max_pics, 34)));
+    for (auto &p : c->pics) { p.base = NULL; p.used = 0; }
+    {
+        DevPic &p = c->pics[0];
+        if (hipMalloc((void **)&p.base, c->pic_elems * sizeof(int16_t)) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
+        (void)hipMemsetAsync(p.base, 0, c->pic_elems * sizeof(int16_t), c->stream);
+        p.s_l = c->s_l; p.s_c = c->s_c; p.used = 1;
+        p.y = p.base + (size_t)XGPU_PAD_L * c->s_l + XGPU_MARGIN_L;
+        p.u = p.base + c->off_u + (size_t)XGPU_PAD_C * c->s_c + XGPU_MARGIN_C;
+        p.v = p.base + c->off_v + (size_t)XGPU_PAD_C * c->s_c + XGPU_MARGIN_C;
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+    *out = c;
+    return XGPU_OK;
+}
+
+void xgpu_close(xgpu_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->sp.device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &p : c->pics) if (p.base) (void)hipFree(p.base);
+    if (c->d_maps) (void)hipFree(c->d_maps);
+    for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int xgpu_sync(xgpu_ctx *c)
+{
+    ARGCHK(c, c != NULL);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return XGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ pictures
+static bool valid_pic(const xgpu_ctx *c, int pic) { return pic >= 0 && pic + 1 < (int)c->pics.size() && c->pics[pic + 1].used; }
+static DevPic &dpic(xgpu_ctx *c, int pic) { return c->pics[pic + 1]; }
+
+int xgpu_pic_alloc(xgpu_ctx *c)
+{
+    ARGCHK(c, c != NULL);
+    HIPCHK(c, hipSetDevice(c->sp.device));
+    for (size_t i = 1; i < c->pics.size(); i++) {
+        DevPic &p = c->pics[i];
+        if (p.used) continue;
+        if (!p.base) {
+            if (hipMalloc((void **)&p.base, c->pic_elems * sizeof(int16_t)) != hipSuccess) {
+                snprintf(c->err, sizeof(c->err), "hipMalloc of a %zu-byte picture failed", c->pic_elems * sizeof(int16_t));
+                return XGPU_ERR_OUT_OF_MEMORY;
+            }
+            HIPCHK(c, hipMemsetAsync(p.base, 0, c->pic_elems * sizeof(int16_t), c->stream));
+        }
+        p.s_l = c->s_l; p.s_c = c->s_c;
+        p.y = p.base + (size_t)XGPU_PAD_L * c->s_l + XGPU_MARGIN_L;
+        p.u = p.base + c->off_u + (size_t)XGPU_PAD_C * c->s_c + XGPU_MARGIN_C;
+        p.v = p.base + c->off_v + (size_t)XGPU_PAD_C * c->s_c + XGPU_MARGIN_C;
+        p.used = 1;
+        return (int)i - 1;
+    }
+    snprintf(c->err, sizeof(c->err), "no free picture slot (max_pics=%d)", c->sp.max_pics);
+    return XGPU_ERR_OUT_OF_MEMORY;
+}
+
+int xgpu_pic_free(xgpu_ctx *c, int pic)
+{
+    ARGCHK(c, c != NULL);
+    ARGCHK(c, valid_pic(c, pic));
+    dpic(c, pic).used = 0;          // memory is kept for reuse (a DPB recycles its buffers, xevd_picman.c)
+    return XGPU_OK;
+}
+
+static int copy_planes(xgpu_ctx *c, int pic, int16_t *y, int s_y, int16_t *u, int16_t *v, int s_c, int ext_l, int ext_c, bool up)
+{
+    // ext_*: how many samples of padding around the active area take part (0 = active area only)
+    DevPic &p = dpic(c, pic);
+    int16_t *host[3] = { y, u, v };
+    int16_t *dev[3] = { p.y, p.u, p.v };
+    for (int i = 0; i < 3; i++) {
+        const int e = i ? ext_c : ext_l, hs = i ? s_c : s_y, ds = i ? p.s_c : p.s_l;
+        const int w = (i ? c->sp.width >> 1 : c->sp.width) + 2 * e, h = (i ? c->sp.height >> 1 : c->sp.height) + 2 * e;
+        int16_t *d = dev[i] - (size_t)e * ds - e;
+        if (up) HIPCHK(c, hipMemcpy2DAsync(d, ds * 2, host[i], hs * 2, w * 2, h, hipMemcpyHostToDevice, c->stream));
+        else    HIPCHK(c, hipMemcpy2DAsync(host[i], hs * 2, d, ds * 2, w * 2, h, hipMemcpyDeviceToHost, c->stream));
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return XGPU_OK;
+}
+
+int xgpu_pic_upload(xgpu_ctx *c, int pic, const int16_t *y, int s_y, const int16_t *u, const int16_t *v, int s_c)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, valid_pic(c, pic)); ARGCHK(c, y && u && v && s_y >= c->sp.width && s_c >= c->sp.width / 2);
+    return copy_planes(c, pic, (int16_t *)y, s_y, (int16_t *)u, (int16_t *)v, s_c, 0, 0, true);
+}
+int xgpu_pic_download(xgpu_ctx *c, int pic, int16_t *y, int s_y, int16_t *u, int16_t *v, int s_c)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, valid_pic(c, pic)); ARGCHK(c, y && u && v && s_y >= c->sp.width && s_c >= c->sp.width / 2);
+    return copy_planes(c, pic, y, s_y, u, v, s_c, 0, 0, false);
+}
+int xgpu_pic_download_padded(xgpu_ctx *c, int pic, int16_t *by, int16_t *bu, int16_t *bv)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, valid_pic(c, pic)); ARGCHK(c, by && bu && bv);
+    return copy_planes(c, pic, by, c->sp.width + 2 * XGPU_PAD_L, bu, bv, (c->sp.width >> 1) + 2 * XGPU_PAD_C, XGPU_PAD_L, XGPU_PAD_C, false);
+}
+int xgpu_pic_upload_padded(xgpu_ctx *c, int pic, const int16_t *by, const int16_t *bu, const int16_t *bv)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, valid_pic(c, pic)); ARGCHK(c, by && bu && bv);
+    return copy_planes(c, pic, (int16_t *)by, c->sp.width + 2 * XGPU_PAD_L, (int16_t *)bu, (int16_t *)bv,
+                       (c->sp.width >> 1) + 2 * XGPU_PAD_C, XGPU_PAD_L, XGPU_PAD_C, true);
+}
+
+// ------------------------------------------------------------------------------------------------ per picture
+int xgpu_frame_begin(xgpu_ctx *c, const xgpu_frame_params *fp)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, fp != NULL); ARGCHK(c, valid_pic(c, fp->pic));
+    for (int l = 0; l < 2; l++) {
+        ARGCHK(c, fp->num_refp[l] >= 0 && fp->num_refp[l] <= XGPU_MAX_REFS);
+        for (int i = 0; i < fp->num_refp[l]; i++) ARGCHK(c, valid_pic(c, fp->refp_pic[i][l]));
+    }
+    c->fp = *fp;
+    c->have_frame = 1;
+    return XGPU_OK;
+}
+
+int xgpu_frame_end(xgpu_ctx *c)
+{
+    ARGCHK(c, c != NULL);
+    c->have_frame = 0;
+    return XGPU_OK;
+}
+
+// The batch builder: SoA batch of the ABI -> 32-byte CU records, the TB list sorted by size class and the
+// wave work items of the itdq kernel, written into ONE pinned staging block and sent with one async copy per
+// array.  (xevd_ctu_row_rec_mt's per-CU cu_init + coef_rect_to_series, xevd.c:567-676, become this pass.)
+int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, b != NULL && out != NULL);
+    *out = NULL;
+    ARGCHK(c, b->n_cu >= 0 && b->n_ctu == c->w_ctu * c->h_ctu);
+    ARGCHK(c, b->n_cu == 0 || (b->x && b->y && b->log2w && b->log2h && b->pred_mode && b->refi && b->mv && b->qp && b->cbf && b->coef_off));
+    ARGCHK(c, b->ctu_cu_start != NULL && (b->n_coef == 0 || b->coef != NULL));
+    HIPCHK(c, hipSetDevice(c->sp.device));
+    const int n = b->n_cu;
+    const int bdoff = 6 * (c->sp.bit_depth_luma - 8);
+
+    // pass 1: validate + count TBs per size class
+    int cls_count[64] = { 0 };
+    for (int i = 0; i < n; i++) {
+        const int lw = b->log2w[i], lh = b->log2h[i];
+        ARGCHK(c, lw >= 2 && lw <= 6 && lh >= 2 && lh <= 6);         // CUs above 64 (Main CTU 128) are a later row
+        ARGCHK(c, b->x[i] + (1 << lw) <= c->sp.width && b->y[i] + (1 << lh) <= c->sp.height && !(b->x[i] & 3) && !(b->y[i] & 3));
+        if (b->pred_mode[i] != XGPU_MODE_INTRA) ARGCHK(c, b->refi[i * 2] < XGPU_MAX_REFS && b->refi[i * 2 + 1] < XGPU_MAX_REFS);
+        size_t need = 0;
+        for (int k = 0; k < 3; k++)
+            if ((b->cbf[i] >> k) & 1) { cls_count[(k ? lw - 1 : lw) * 8 + (k ? lh - 1 : lh)]++; need += (size_t)(1 << (lw + lh)) >> (k ? 2 : 0); }
+        ARGCHK(c, (size_t)b->coef_off[i] + need <= b->n_coef);
+    }
+    int cls_first[64], n_tb = 0, n_waves = 0;
+    for (int k = 0; k < 64; k++) {
+        cls_first[k] = n_tb; n_tb += cls_count[k];
+        if (cls_count[k]) { const int per = 64 >> (k >> 3); n_waves += (cls_count[k] + per - 1) / per; }
+    }
+
+    xgpu_dbatch *db = new xgpu_dbatch();
+    memset(db, 0, sizeof(*db));
+    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef;
+    const size_t sz_cus = sizeof(CuRec) * (size_t)std::max(n, 1), sz_ctu = sizeof(uint32_t) * (size_t)(b->n_ctu + 1);
+    const size_t sz_tbs = sizeof(TbRec) * (size_t)std::max(n_tb, 1), sz_wv = sizeof(TbWave) * (size_t)std::max(n_waves, 1);
+    const size_t sz_coef = sizeof(int16_t) * std::max(b->n_coef, (size_t)8);
+    const size_t o_cus = 0, o_ctu = o_cus + align_up((int)sz_cus, 256), o_tbs = o_ctu + align_up((int)sz_ctu, 256);
+    const size_t o_wv = o_tbs + align_up((int)sz_tbs, 256), o_coef = o_wv + align_up((int)sz_wv, 256);
+    db->stage_bytes = o_coef + sz_coef;
+    auto fail = [&](int code) { xgpu_batch_destroy(c, db); return code; };
+    if (hipHostMalloc(&db->h_stage, db->stage_bytes, hipHostMallocDefault) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
+    uint8_t *hs = (uint8_t *)db->h_stage;
+    CuRec *cus = (CuRec *)(hs + o_cus);
+    TbRec *tbs = (TbRec *)(hs + o_tbs);
+    TbWave *wv = (TbWave *)(hs + o_wv);
+
+    // pass 2: records + TB scatter into class order
+    int cls_fill[64];
+    memcpy(cls_fill, cls_first, sizeof(cls_fill));
+    for (int i = 0; i < n; i++) {
+        CuRec &r = cus[i];
+        memset(&r, 0, sizeof(r));
+        r.x = b->x[i]; r.y = b->y[i]; r.log2w = b->log2w[i]; r.log2h = b->log2h[i];
+        r.pred_mode = b->pred_mode[i]; r.cbf = b->cbf[i] & 7;
+        r.refi[0] = b->refi[i * 2]; r.refi[1] = b->refi[i * 2 + 1];
+        r.qp_map = (uint8_t)((b->qp[i * 3] - bdoff) & 0x7F);
+        r.coef_off = b->coef_off[i];
+        memcpy(r.mv, &b->mv[i * 4], sizeof(r.mv));
+        r.qp[0] = b->qp[i * 3]; r.qp[1] = b->qp[i * 3 + 1]; r.qp[2] = b->qp[i * 3 + 2];
+        if (b->ipm) { r.ipm[0] = b->ipm[i * 2]; r.ipm[1] = b->ipm[i * 2 + 1]; }
+        uint32_t off = r.coef_off;
+        for (int k = 0; k < 3; k++) {
+            if (!((r.cbf >> k) & 1)) continue;
+            const int lw = k ? r.log2w - 1 : r.log2w, lh = k ? r.log2h - 1 : r.log2h;
+            TbRec &t = tbs[cls_fill[lw * 8 + lh]++];
+            t.off = off; t.log2w = (uint8_t)lw; t.log2h = (uint8_t)lh; t.qp = r.qp[k]; t.rsvd = 0;
+            off += 1u << (lw + lh);
+        }
+    }
+    int w = 0;
+    for (int k = 0; k < 64; k++) {
+        if (!cls_count[k]) continue;
+        const int per = 64 >> (k >> 3);
+        for (int f = 0; f < cls_count[k]; f += per) {
+            wv[w].first = cls_first[k] + f; wv[w].count = (uint16_t)std::min(per, cls_count[k] - f);
+            wv[w].log2w = (uint8_t)(k >> 3); wv[w].log2h = (uint8_t)(k & 7); w++;
+        }
+    }
+    memcpy(hs + o_ctu, b->ctu_cu_start, sz_ctu);
+    if (b->n_coef) memcpy(hs + o_coef, b->coef, sizeof(int16_t) * b->n_coef);
+
+    if (hipMalloc((void **)&db->d_cus, sz_cus) != hipSuccess || hipMalloc((void **)&db->d_ctu_start, sz_ctu) != hipSuccess ||
+        hipMalloc((void **)&db->d_tbs, sz_tbs) != hipSuccess || hipMalloc((void **)&db->d_waves, sz_wv) != hipSuccess ||
+        hipMalloc((void **)&db->d_coef, sz_coef) != hipSuccess || hipMalloc((void **)&db->d_resid, sz_coef) != hipSuccess)
+        return fail(XGPU_ERR_OUT_OF_MEMORY);
+    hipError_t e = hipMemcpyAsync(db->d_cus, hs + o_cus, sz_cus, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(db->d_ctu_start, hs + o_ctu, sz_ctu, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(db->d_tbs, hs + o_tbs, sz_tbs, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(db->d_waves, hs + o_wv, sz_wv, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(db->d_coef, hs + o_coef, sz_coef, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(db->d_resid, 0, sz_coef, c->stream);
+    if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "batch upload: %s", hipGetErrorString(e)); return fail(XGPU_ERR_UNEXPECTED); }
+    *out = db;
+    return XGPU_OK;
+}
+
+void xgpu_batch_destroy(xgpu_ctx *c, xgpu_dbatch *db)
+{
+    if (!db) return;
+    if (c && c->stream) (void)hipStreamSynchronize(c->stream);
+    if (db->d_cus) (void)hipFree(db->d_cus);
+    if (db->d_ctu_start) (void)hipFree(db->d_ctu_start);
+    if (db->d_tbs) (void)hipFree(db->d_tbs);
+    if (db->d_waves) (void)hipFree(db->d_waves);
+    if (db->d_coef) (void)hipFree(db->d_coef);
+    if (db->d_resid) (void)hipFree(db->d_resid);
+    if (db->h_stage) (void)hipHostFree(db->h_stage);
+    delete db;
+}
+
+int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, db != NULL); ARGCHK(c, c->have_frame);
+    ItdqArgs ia;
+    ia.coef = db->d_coef; ia.resid = db->d_resid; ia.tbs = db->d_tbs; ia.waves = db->d_waves; ia.n_waves = db->n_waves;
+    ia.bd = c->sp.bit_depth_luma;      // the LUMA depth drives dequant/transform shifts of all components (xevd.c:441-442)
+    ia.iqt = c->sp.tool_iqt;
+    TIMED(c, XGPU_K_ITDQ, launch_itdq(c, ia));
+
+    InterArgs a;
+    memset(&a, 0, sizeof(a));
+    DevPic &cur = dpic(c, c->fp.pic);
+    a.cur_y = cur.y; a.cur_u = cur.u; a.cur_v = cur.v;
+    a.s_l = c->s_l; a.s_c = c->s_c; a.pic_w = c->sp.width; a.pic_h = c->sp.height;
+    a.bd_l = c->sp.bit_depth_luma; a.bd_c = c->sp.bit_depth_chroma;
+    a.log2_ctu = c->sp.log2_ctu; a.w_ctu = c->w_ctu;
+    a.regions_x = (c->sp.width + 63) >> 6;
+    a.n_regions = a.regions_x * ((c->sp.height + 63) >> 6);
+    a.admvp = c->sp.tool_admvp ? 1 : 0;
+    a.cus = db->d_cus; a.ctu_cu_start = db->d_ctu_start; a.resid = db->d_resid;
+    a.maps = c->d_maps; a.w_scu = c->w_scu;
+    for (int l = 0; l < 2; l++)
+        for (int i = 0; i < XGPU_MAX_REFS; i++) {
+            const DevPic &rp = i < c->fp.num_refp[l] ? dpic(c, c->fp.refp_pic[i][l]) : cur;
+            a.refp[i][l].y = rp.y; a.refp[i][l].u = rp.u; a.refp[i][l].v = rp.v;
+            a.refp[i][l].poc = i < c->fp.num_refp[l] ? c->fp.refp_poc[i][l] : 0;
+        }
+    TIMED(c, XGPU_K_INTER, launch_inter(c, a));
+    HIPCHK(c, hipGetLastError());
+    return XGPU_OK;
+}
+
+int xgpu_deblock(xgpu_ctx *c)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, c->have_frame);
+    if (c->sp.tool_addb) { snprintf(c->err, sizeof(c->err), "ADDB deblocking is not implemented yet"); return XGPU_ERR_UNSUPPORTED; }
+    DbkArgs a;
+    memset(&a, 0, sizeof(a));
+    a.s_l = c->s_l; a.s_c = c->s_c; a.pic_w = c->sp.width; a.pic_h = c->sp.height; a.w_scu = c->w_scu; a.h_scu = c->h_scu;
+    a.bd_l = c->sp.bit_depth_luma; a.bd_c = c->sp.bit_depth_chroma; a.maps = c->d_maps;
+    // strength LUT: xevd_df.c:347-365 with the table index clamped to 0..51 (see oracle chroma_qp())
+    const int boff = 6 * (c->sp.bit_depth_chroma - 8);
+    for (int cls = 0; cls < 4; cls++)
+        for (int qp = 0; qp < 64; qp++) {
+            a.st[0][cls][qp] = (uint8_t)(k_df_st[cls][std::min(qp, 51)] << (c->sp.bit_depth_luma - 8));
+            for (int t = 0; t < 2; t++) {
+                const int q = std::min(std::max(qp + (t ? c->fp.qp_v_offset : c->fp.qp_u_offset), -boff), 57);
+                const int v = std::min(std::max((int)c->chroma_qp[t][q + boff], 0), 51);
+                a.st[1 + t][cls][qp] = (uint8_t)(k_df_st[cls][v] << (c->sp.bit_depth_chroma - 8));
+            }
+        }
+    DevPic &cur = dpic(c, c->fp.pic);
+    TIMED(c, XGPU_K_DBK_V, launch_dbk(c, a, 0, cur, c->pics[0]));
+    TIMED(c, XGPU_K_DBK_H, launch_dbk(c, a, 1, c->pics[0], cur));
+    HIPCHK(c, hipGetLastError());
+    return XGPU_OK;
+}
+
+int xgpu_pad(xgpu_ctx *c)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, c->have_frame);
+    TIMED(c, XGPU_K_PAD, launch_pad(c, dpic(c, c->fp.pic)));
+    HIPCHK(c, hipGetLastError());
+    return XGPU_OK;
+}
+
+int xgpu_measure_copy_bw(xgpu_ctx *c, size_t bytes, int iters, double *gbps)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, gbps != NULL && iters > 0 && bytes >= (1u << 20));
+    void *a = NULL, *b = NULL;
+    bytes &= ~(size_t)15;
+    if (hipMalloc(&a, bytes) != hipSuccess || hipMalloc(&b, bytes) != hipSuccess) { if (a) (void)hipFree(a); return XGPU_ERR_OUT_OF_MEMORY; }
+    (void)hipMemsetAsync(a, 1, bytes, c->stream);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    launch_copy_bw(c, a, b, bytes);                       // warm-up
+    (void)hipEventRecord(e0, c->stream);
+    for (int i = 0; i < iters; i++) launch_copy_bw(c, (i & 1) ? b : a, (i & 1) ? a : b, bytes);
+    (void)hipEventRecord(e1, c->stream);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    (void)hipFree(a); (void)hipFree(b);
+    if (e != hipSuccess || ms <= 0) return XGPU_ERR_UNEXPECTED;
+    *gbps = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;
+    return XGPU_OK;
+}
+
+// ------------------------------------------------------------------------------------------------ test shims
+static int test_mc(xgpu_ctx *c, const int16_t *plane, int pw, int ph, int ref_x, int ref_y, int has_dx, int has_dy,
+                   int gmv_x, int gmv_y, int16_t *pred, int w, int h, int bd, int luma)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, plane && pred && pw > 0 && ph > 0 && w > 0 && h > 0);
+    ARGCHK(c, luma ? ((w & 3) == 0 && (h & 3) == 0) : ((w & 1) == 0 && (h & 1) == 0));
+    int16_t *dp = NULL, *dq = NULL;
+    const size_t pb = sizeof(int16_t) * (size_t)pw * ph + 64, qb = sizeof(int16_t) * (size_t)w * h;
+    HIPCHK(c, hipMalloc((void **)&dp, pb));
+    HIPCHK(c, hipMalloc((void **)&dq, qb));
+    HIPCHK(c, hipMemcpyAsync(dp, plane, pb - 64, hipMemcpyHostToDevice, c->stream));
+    launch_test_mc(c, dp, pw, ref_x, ref_y, has_dx, has_dy, gmv_x, gmv_y, dq, w, h, bd, luma);
+    HIPCHK(c, hipMemcpyAsync(pred, dq, qb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(dp); (void)hipFree(dq);
+    return XGPU_OK;
+}
+int xgpu_test_mc_l(xgpu_ctx *c, const int16_t *plane, int pw, int ph, int ref_x, int ref_y, int has_dx, int has_dy,
+                   int gmv_x, int gmv_y, int16_t *pred, int w, int h, int bd)
+{ return test_mc(c, plane, pw, ph, ref_x, ref_y, has_dx, has_dy, gmv_x, gmv_y, pred, w, h, bd, 1); }
+int xgpu_test_mc_c(xgpu_ctx *c, const int16_t *plane, int pw, int ph, int ref_x, int ref_y, int has_dx, int has_dy,
+                   int gmv_x, int gmv_y, int16_t *pred, int w, int h, int bd)
+{ return test_mc(c, plane, pw, ph, ref_x, ref_y, has_dx, has_dy, gmv_x, gmv_y, pred, w, h, bd, 0); }
+
+int xgpu_test_itdq(xgpu_ctx *c, int16_t *coef, int n_blocks, int log2w, int log2h, const uint8_t *qp, int bit_depth)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, coef && qp && n_blocks > 0 && log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6);
+    const size_t per = (size_t)1 << (log2w + log2h), nb = per * n_blocks * sizeof(int16_t);
+    std::vector<TbRec> tbs(n_blocks);
+    std::vector<TbWave> wv;
+    for (int i = 0; i < n_blocks; i++) { tbs[i].off = (uint32_t)(per * i); tbs[i].log2w = (uint8_t)log2w; tbs[i].log2h = (uint8_t)log2h; tbs[i].qp = qp[i]; tbs[i].rsvd = 0; }
+    const int pw = 64 >> log2w;
+    for (int f = 0; f < n_blocks; f += pw) wv.push_back({ (uint32_t)f, (uint16_t)std::min(pw, n_blocks - f), (uint8_t)log2w, (uint8_t)log2h });
+    int16_t *dc = NULL, *dr = NULL; TbRec *dt = NULL; TbWave *dw = NULL;
+    HIPCHK(c, hipMalloc((void **)&dc, nb)); HIPCHK(c, hipMalloc((void **)&dr, nb));
+    HIPCHK(c, hipMalloc((void **)&dt, sizeof(TbRec) * tbs.size())); HIPCHK(c, hipMalloc((void **)&dw, sizeof(TbWave) * wv.size()));
+    HIPCHK(c, hipMemcpyAsync(dc, coef, nb, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dt, tbs.data(), sizeof(TbRec) * tbs.size(), hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(dw, wv.data(), sizeof(TbWave) * wv.size(), hipMemcpyHostToDevice, c->stream));
+    ItdqArgs ia; ia.coef = dc; ia.resid = dr; ia.tbs = dt; ia.waves = dw; ia.n_waves = (int)wv.size(); ia.bd = bit_depth; ia.iqt = c->sp.tool_iqt;
+    launch_itdq(c, ia);
+    HIPCHK(c, hipMemcpyAsync(coef, dr, nb, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(dc); (void)hipFree(dr); (void)hipFree(dt); (void)hipFree(dw);
+    return XGPU_OK;
+}

@@ -1,0 +1,147 @@
+// xgpu_internal.h - device-side record formats and the context of the MI355X reconstruction backend.
+// Everything here is private to xevd_amd/csrc; the public boundary is include/xevd_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <vector>
+#include "../../include/xevd_hip.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// Device picture.  16-bit planar 4:2:0 like the reference's XEVD_PIC (src_base/xevd_def.h:630-679), but with a
+// geometry chosen for HBM: the first active sample of every row is 256-byte aligned (left margin 192 luma /
+// 128 chroma samples >= the reference's 144 / 72 padding) and the row stride is a multiple of 64 samples, so
+// that a wave's 128-byte row segments never straddle more cache lines than necessary.
+// ---------------------------------------------------------------------------------------------------------
+#define XGPU_MARGIN_L 192
+#define XGPU_MARGIN_C 128
+
+struct DevPic {
+    int16_t *base;        // one allocation: Y, U, V padded planes
+    int16_t *y, *u, *v;   // first active sample of each plane
+    int      s_l, s_c;    // strides in samples
+    int      used;
+};
+
+// Per-CU record on the device: 32 bytes, read as two 16-byte loads.  Built on the host from the SoA batch of the
+// ABI because every consumer (inter kernel, map update, TB list) needs all fields of a CU together.
+struct __attribute__((aligned(16))) CuRec {
+    uint16_t x, y;            // luma sample position
+    uint8_t  log2w, log2h;
+    uint8_t  pred_mode;       // XGPU_MODE_*
+    uint8_t  cbf;             // bit c: component c coded
+    int8_t   refi[2];
+    uint8_t  qp_map;          // core->qp = qp_y - 6*(bd-8): the QP stored in map_scu (xevd_util.c:1626)
+    uint8_t  rsvd;
+    uint32_t coef_off;        // offset of the CU's residual block in the arena (s16 units)
+    int16_t  mv[2][2];        // unclipped quarter-pel
+    uint8_t  qp[3];           // dequant QPs
+    uint8_t  ipm[2];
+    uint8_t  pad[3];
+};
+static_assert(sizeof(CuRec) == 32, "CuRec must be 32 bytes");
+
+// SCU map record: the reference's map_scu / map_refi / map_mv (xevd_def.h:372-438) fused into one 16-byte
+// element so that a deblocking lane fetches a neighbour with one load.
+struct __attribute__((aligned(16))) ScuRec {
+    uint32_t scu;             // bit 15 intra, 16-22 QP, 23 skip, 24 luma cbf, 31 COD; bits 8/9: left/top CU edge
+    int8_t   refi[2];
+    uint16_t rsvd;
+    int16_t  mv[2][2];
+};
+static_assert(sizeof(ScuRec) == 16, "ScuRec must be 16 bytes");
+#define SCU_EDGE_L (1u << 8)      // the SCU's left edge is a CU boundary  (free bits 7:14 of map_scu)
+#define SCU_EDGE_T (1u << 9)      // the SCU's top edge is a CU boundary
+
+// One coded transform block for the dequant + inverse-transform kernel.
+struct TbRec {
+    uint32_t off;             // arena offset (s16 units)
+    uint8_t  log2w, log2h, qp, rsvd;
+};
+// One wave of the itdq kernel: `count` consecutive TbRecs of one size class.
+struct TbWave {
+    uint32_t first;
+    uint16_t count;
+    uint8_t  log2w, log2h;
+};
+
+struct RefEntry { const int16_t *y, *u, *v; int poc; int pad; };
+
+// Kernel arguments of the inter reconstruction kernel (passed by value).
+struct InterArgs {
+    int16_t *cur_y, *cur_u, *cur_v;
+    int      s_l, s_c;                 // all pictures of a ctx share the geometry
+    int      pic_w, pic_h;
+    int      bd_l, bd_c;
+    int      log2_ctu, w_ctu;
+    int      n_regions, regions_x;     // 64x64 luma regions
+    int      admvp;
+    const CuRec    *cus;
+    const uint32_t *ctu_cu_start;
+    const int16_t  *resid;
+    ScuRec  *maps;
+    int      w_scu;
+    RefEntry refp[XGPU_MAX_REFS][2];
+};
+
+struct ItdqArgs {
+    const int16_t *coef;
+    int16_t       *resid;
+    const TbRec   *tbs;
+    const TbWave  *waves;
+    int            n_waves;
+    int            bd;
+    int            iqt;
+};
+
+struct DbkArgs {
+    int      s_l, s_c;
+    int      pic_w, pic_h, w_scu, h_scu;
+    int      bd_l, bd_c;
+    const ScuRec *maps;
+    uint8_t  st[3][4][64];             // strength by component, edge class, map QP (host-built from xevd_tbl_df_st)
+};
+
+struct xgpu_dbatch {
+    int        n_cu, n_ctu, n_tb, n_waves;
+    size_t     n_coef;
+    CuRec     *d_cus;
+    uint32_t  *d_ctu_start;
+    int16_t   *d_coef, *d_resid;
+    TbRec     *d_tbs;
+    TbWave    *d_waves;
+    void      *h_stage;               // pinned staging block
+    size_t     stage_bytes;
+};
+
+struct xgpu_ctx {
+    xgpu_seq_params sp;
+    int8_t          chroma_qp[2][96];  // [c][qp + 6*(bdc-8)]
+    hipStream_t     stream;
+    int             w_scu, h_scu, w_ctu, h_ctu;
+    int             s_l, s_c, rows_l, rows_c;
+    size_t          pic_elems, off_u, off_v;
+    std::vector<DevPic> pics;
+    ScuRec         *d_maps;
+    xgpu_frame_params fp;
+    int             have_frame;
+    // timing
+    int             timing;
+    struct Ev { hipEvent_t a, b; int k; };
+    std::vector<Ev> ev_pending;
+    std::vector<hipEvent_t> ev_pool;
+    double          t_ms[XGPU_K_COUNT];
+    long long       t_n[XGPU_K_COUNT];
+    char            err[256];
+};
+
+// kernel launchers (one per .hip file)
+void launch_itdq(xgpu_ctx *c, const ItdqArgs &a);
+void launch_inter(xgpu_ctx *c, const InterArgs &a);
+void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst);
+void upload_transform_tables(const int *tm, hipStream_t s);
+void launch_pad(xgpu_ctx *c, const DevPic &p);
+void launch_copy_bw(xgpu_ctx *c, const void *src, void *dst, size_t bytes);
+void launch_test_mc(xgpu_ctx *c, const int16_t *plane, int stride, int ref_x, int ref_y, int has_dx, int has_dy,
+                    int gmv_x, int gmv_y, int16_t *pred, int w, int h, int bd, int luma);

@@ -1,0 +1,168 @@
+"""Host-side mirror of the reference's coarse decode sequence for the reconstruction path, over the C ABI.
+
+Mirrors, per picture, what xevd_dec_nalu does after entropy decoding (src_base/xevd.c:1890-1983):
+    slice/refp set-up -> recon of every CU -> deblock (vertical edges, then horizontal) -> picbuf_expand -> DPB
+Plumbing only (ctypes + numpy); all arithmetic happens in xevd_amd/libxevd_hip.so.  There is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import abi
+
+
+class XgpuError(RuntimeError):
+    pass
+
+
+class XgpuDecoder:
+    def __init__(self, width, height, bit_depth=8, device=0, log2_ctu=6, iqt=0, admvp=0, addb=0, alf=0, max_pics=6,
+                 bit_depth_chroma=None, chroma_qp_tables=None):
+        self.lib = abi.load()
+        self.sp = abi.make_seq_params(width, height, bit_depth, log2_ctu, device, iqt, admvp, addb, alf, max_pics,
+                                      bit_depth_chroma)
+        self._tables = None
+        if chroma_qp_tables is not None:
+            self._tables = [np.ascontiguousarray(t, np.int8) for t in chroma_qp_tables]
+            for i in range(2):
+                self.sp.chroma_qp_table[i] = self._tables[i].ctypes.data_as(C.POINTER(C.c_int8))
+        self.ctx = C.c_void_p()
+        rc = self.lib.xgpu_open(C.byref(self.sp), C.byref(self.ctx))
+        if rc != 0:
+            raise XgpuError(f"xgpu_open failed: {rc}")
+        self.width, self.height, self.bit_depth = width, height, bit_depth
+        self._batches = []
+
+    # -- helpers -------------------------------------------------------------------------------------
+    def _chk(self, rc, what):
+        if rc < 0:
+            raise XgpuError(f"{what} failed: {rc}: {self.lib.xgpu_last_error(self.ctx).decode()}")
+        return rc
+
+    def close(self):
+        if self.ctx:
+            for b in self._batches:
+                self.lib.xgpu_batch_destroy(self.ctx, b)
+            self._batches = []
+            self.lib.xgpu_close(self.ctx)
+            self.ctx = C.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def sync(self):
+        self._chk(self.lib.xgpu_sync(self.ctx), "xgpu_sync")
+
+    # -- pictures ------------------------------------------------------------------------------------
+    def pic_alloc(self):
+        return self._chk(self.lib.xgpu_pic_alloc(self.ctx), "xgpu_pic_alloc")
+
+    def pic_free(self, pic):
+        self._chk(self.lib.xgpu_pic_free(self.ctx, pic), "xgpu_pic_free")
+
+    def pic_upload(self, pic, planes):
+        y, u, v = (np.ascontiguousarray(p, np.int16) for p in planes)
+        self._chk(self.lib.xgpu_pic_upload(self.ctx, pic, y.ctypes.data, y.shape[1], u.ctypes.data, v.ctypes.data, u.shape[1]),
+                  "xgpu_pic_upload")
+
+    def pic_download(self, pic):
+        y = np.zeros((self.height, self.width), np.int16)
+        u = np.zeros((self.height // 2, self.width // 2), np.int16)
+        v = np.zeros_like(u)
+        self._chk(self.lib.xgpu_pic_download(self.ctx, pic, y.ctypes.data, self.width, u.ctypes.data, v.ctypes.data, self.width // 2),
+                  "xgpu_pic_download")
+        return [y, u, v]
+
+    def pic_upload_padded(self, pic, bufs):
+        y, u, v = (np.ascontiguousarray(p, np.int16) for p in bufs)
+        self._chk(self.lib.xgpu_pic_upload_padded(self.ctx, pic, y.ctypes.data, u.ctypes.data, v.ctypes.data), "xgpu_pic_upload_padded")
+
+    def pic_download_padded(self, pic):
+        y = np.zeros((self.height + 2 * abi.PAD_L, self.width + 2 * abi.PAD_L), np.int16)
+        u = np.zeros((self.height // 2 + 2 * abi.PAD_C, self.width // 2 + 2 * abi.PAD_C), np.int16)
+        v = np.zeros_like(u)
+        self._chk(self.lib.xgpu_pic_download_padded(self.ctx, pic, y.ctypes.data, u.ctypes.data, v.ctypes.data), "xgpu_pic_download_padded")
+        return [y, u, v]
+
+    # -- per picture ---------------------------------------------------------------------------------
+    def frame_begin(self, pic, poc, refs, qp_u_offset=0, qp_v_offset=0):
+        """refs: {(idx, list): (pic_slot, poc)}"""
+        fp = abi.FrameParams()
+        fp.pic, fp.poc = pic, poc
+        for l in range(2):
+            idxs = [i for (i, ll) in refs if ll == l]
+            fp.num_refp[l] = (max(idxs) + 1) if idxs else 0
+        for (i, l), (slot, rpoc) in refs.items():
+            fp.refp_pic[i][l] = slot
+            fp.refp_poc[i][l] = rpoc
+        fp.qp_u_offset, fp.qp_v_offset = qp_u_offset, qp_v_offset
+        self._chk(self.lib.xgpu_frame_begin(self.ctx, C.byref(fp)), "xgpu_frame_begin")
+
+    def batch_create(self, batch):
+        cb, keep = abi.make_cu_batch(batch)
+        h = C.c_void_p()
+        self._chk(self.lib.xgpu_batch_create(self.ctx, C.byref(cb), C.byref(h)), "xgpu_batch_create")
+        self._batches.append(h)
+        return h
+
+    def batch_destroy(self, h):
+        self._batches = [b for b in self._batches if b.value != h.value]
+        self.lib.xgpu_batch_destroy(self.ctx, h)
+
+    def batch_recon(self, h):
+        self._chk(self.lib.xgpu_batch_recon(self.ctx, h), "xgpu_batch_recon")
+
+    def deblock(self):
+        self._chk(self.lib.xgpu_deblock(self.ctx), "xgpu_deblock")
+
+    def pad(self):
+        self._chk(self.lib.xgpu_pad(self.ctx), "xgpu_pad")
+
+    def frame_end(self):
+        self._chk(self.lib.xgpu_frame_end(self.ctx), "xgpu_frame_end")
+
+    def decode_picture(self, pic, poc, refs, batch_handle, deblock=True, pad=True, qp_u_offset=0, qp_v_offset=0):
+        """The coarse sequence of xevd_dec_nalu for one picture (src_base/xevd.c:1905-1983)."""
+        self.frame_begin(pic, poc, refs, qp_u_offset, qp_v_offset)
+        self.batch_recon(batch_handle)
+        if deblock:
+            self.deblock()
+        if pad:
+            self.pad()
+        self.frame_end()
+
+    # -- measurement ---------------------------------------------------------------------------------
+    def timing_enable(self, on=True):
+        self._chk(self.lib.xgpu_timing_enable(self.ctx, 1 if on else 0), "xgpu_timing_enable")
+
+    def timing_reset(self):
+        self._chk(self.lib.xgpu_timing_reset(self.ctx), "xgpu_timing_reset")
+
+    def timing_get(self):
+        ms = (C.c_double * abi.K_COUNT)()
+        n = (C.c_longlong * abi.K_COUNT)()
+        self._chk(self.lib.xgpu_timing_get(self.ctx, ms, n), "xgpu_timing_get")
+        return {abi.K_NAMES[i]: (ms[i], n[i]) for i in range(abi.K_COUNT)}
+
+    def measure_copy_bw(self, nbytes=1 << 30, iters=10):
+        g = C.c_double()
+        self._chk(self.lib.xgpu_measure_copy_bw(self.ctx, nbytes, iters, C.byref(g)), "xgpu_measure_copy_bw")
+        return g.value
+
+    # -- fine-grained shims --------------------------------------------------------------------------
+    def test_mc(self, plane, ref_x, ref_y, has_dx, has_dy, gmv_x, gmv_y, w, h, bit_depth, luma=True):
+        plane = np.ascontiguousarray(plane, np.int16)
+        pred = np.zeros((h, w), np.int16)
+        fn = self.lib.xgpu_test_mc_l if luma else self.lib.xgpu_test_mc_c
+        self._chk(fn(self.ctx, plane.ctypes.data, plane.shape[1], plane.shape[0], ref_x, ref_y, has_dx, has_dy, gmv_x, gmv_y,
+                     pred.ctypes.data, w, h, bit_depth), "xgpu_test_mc")
+        return pred
+
+    def test_itdq(self, coef, log2w, log2h, qp, bit_depth):
+        coef = np.ascontiguousarray(coef, np.int16).copy()
+        qp = np.ascontiguousarray(qp, np.uint8)
+        self._chk(self.lib.xgpu_test_itdq(self.ctx, coef.ctypes.data, len(qp), log2w, log2h, qp.ctypes.data, bit_depth), "xgpu_test_itdq")
+        return coef
