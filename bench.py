@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py - frames/s of the MI355X reconstruction backend on BASELINE.json's workload, with the roofline of the
+dominant kernel and a CPU baseline.
+
+A "step" is one picture through the whole hot path: dequant + inverse transform of every coded TB, MC + residual
+add + clip of every CU, both deblocking passes and border padding - i.e. everything xevd_dec_nalu does after
+entropy decoding (src_base/xevd.c:1905-1983).  Pictures chain like an IPPP stream: picture k is predicted from
+picture k-1 (DPB ping-pong), so steps are serially dependent exactly like a real decode.  The CU batches (the
+post-entropy records) are resident in HBM before the timed region starts; H2D of the batches is reported
+separately as `pcie_inclusive_fps`.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20            # single GPU
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # one rank per GPU
+
+With N > 1 every rank decodes its own independent stream (streams/GOPs shard across GPUs with a host
+work queue and no collective), so scaling is "weak" and value = N x frames / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # BASELINE.json configs[1]: Baseline profile, 1080p, 8 bit, IPPP, one reference
+    "cfg2_base_1080p_8b_ippp": dict(w=1920, h=1080, bd=8, admvp=0, iqt=0, n_refs=(1, 0), bi_frac=0.0),
+    "base_4k_8b_ippp": dict(w=3840, h=2160, bd=8, admvp=0, iqt=0, n_refs=(1, 0), bi_frac=0.0),
+    "base_8k_10b_ippp": dict(w=7680, h=4320, bd=10, admvp=0, iqt=0, n_refs=(1, 0), bi_frac=0.0),
+}
+HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+
+
+def algorithmic_bytes(batch, w, h):
+    """SURVEY 8(d) per-sample byte counts applied to the actual batch (2 B/sample, halo re-reads not credited)."""
+    cw = (1 << batch["log2w"].astype(np.int64))
+    ch = (1 << batch["log2h"].astype(np.int64))
+    samples = cw * ch * 3 // 2
+    inter = batch["pred_mode"] != 0
+    lists = (batch["refi"] >= 0).sum(1)
+    coded = np.zeros(len(cw), np.int64)
+    for c in range(3):
+        coded += ((batch["cbf"] >> c) & 1) * (cw * ch >> (2 if c else 0))
+    b_inter = int((samples[inter] * (2 * lists[inter] + 2)).sum() + 2 * coded[inter].sum())
+    b_itdq = int(4 * coded.sum())
+    s_pic = w * h * 3 // 2
+    return {"inter": b_inter, "itdq": b_itdq, "dbk_v": 4 * s_pic, "dbk_h": 4 * s_pic}
+
+
+def make_stream(wl, seed, n_batches):
+    from xevd_amd import synth
+    rng = np.random.default_rng(seed)
+    first = synth.gen_picture(rng, wl["w"], wl["h"], wl["bd"])
+    batches = [synth.gen_frame(rng, wl["w"], wl["h"], wl["bd"], inter_frac=1.0, bi_frac=wl["bi_frac"], coded_frac=0.6,
+                               n_refs=wl["n_refs"], qp_range=(22, 37), mv_sigma_px=8.0, oob_frac=0.05)
+               for _ in range(n_batches)]
+    return first, batches
+
+
+def cpu_baseline(wl, first, batch, budget_s=15.0):
+    """The CPU side of the comparison on this host: the reference's own functions (AVX2 tables, one thread)
+    through oracle/_ref when that was built in the development container, else the plain-C oracle port."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+    import oracle_lib as ol
+    from xevd_amd import abi
+    sp = abi.make_seq_params(wl["w"], wl["h"], wl["bd"], iqt=wl["iqt"], admvp=wl["admvp"])
+    cb, keep = abi.make_cu_batch(batch)
+    ref = ol.Picture(wl["w"], wl["h"], 0, first)
+    ref.pad_numpy()
+    cur = ol.Picture(wl["w"], wl["h"], 1)
+    maps = ol.Maps(wl["w"], wl["h"])
+    m = maps.orc()
+    kind = "reference" if ol.have_ref() else "port"
+    n, t0 = 0, time.perf_counter()
+    while True:
+        fr = ol.make_frame(cur, {(0, 0): ref})
+        if kind == "reference":
+            hn = ol.harness()
+            hn.refh_recon_batch(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), None, 1)
+            hn.refh_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), 1)
+            hn.refh_pad(C.byref(sp), C.byref(fr.cur))
+        else:
+            o = ol.oracle()
+            o.orc_recon_batch(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), None)
+            o.orc_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m))
+            o.orc_pad(C.byref(sp), C.byref(fr.cur))
+        ref, cur = cur, ref
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt > budget_s or n >= 64:
+            break
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": kind,
+            "sample": f"{n} pictures of the same {wl['w']}x{wl['h']} workload (recon + deblock + pad), single thread, "
+                      + ("reference functions with its AVX2/SSE tables via oracle/_ref" if kind == "reference" else "plain-C oracle port")}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default="cfg2_base_1080p_8b_ippp", choices=sorted(WORKLOADS))
+    ap.add_argument("--batches", type=int, default=8, help="distinct pictures' CU batches kept resident and cycled")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    from xevd_amd.decoder import XgpuDecoder
+    wl = WORKLOADS[args.workload]
+    first, batches = make_stream(wl, 1000 + rank, args.batches)
+    dec = XgpuDecoder(wl["w"], wl["h"], wl["bd"], device=local_rank, iqt=wl["iqt"], admvp=wl["admvp"], max_pics=4)
+    slots = [dec.pic_alloc(), dec.pic_alloc()]
+    dec.pic_upload(slots[0], first)
+    dec.frame_begin(slots[0], 0, {})
+    dec.pad()
+    dec.frame_end()
+    t_up = time.perf_counter()
+    handles = [dec.batch_create(b) for b in batches]
+    dec.sync()
+    t_up = (time.perf_counter() - t_up) / len(batches)
+
+    def step(k):
+        cur, ref = slots[(k + 1) & 1], slots[k & 1]
+        dec.decode_picture(cur, k + 1, {(0, 0): (ref, k)}, handles[k % len(handles)])
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dec.sync()
+
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-kernel durations with HIP events on the stream the kernels are launched on, same workload and steps
+    dec.timing_enable(True)
+    dec.timing_reset()
+    for k in range(args.steps):
+        step(args.warmup + args.steps + k)
+    tim = dec.timing_get()
+    dec.timing_enable(False)
+
+    if rank == 0:
+        ab = [algorithmic_bytes(b, wl["w"], wl["h"]) for b in batches]
+        kernels = {}
+        for name in ("itdq", "inter", "dbk_v", "dbk_h", "pad"):
+            ms, n = tim[name]
+            if n:
+                kernels[name] = {"avg_us": round(1e3 * ms / n, 2), "launches": int(n)}
+        dom = max(("itdq", "inter", "dbk_v", "dbk_h"), key=lambda k: tim[k][0])
+        bytes_per_launch = float(np.mean([a[dom] for a in ab]))
+        avg_s = tim[dom][0] / max(tim[dom][1], 1) * 1e-3
+        achieved = bytes_per_launch / avg_s / 1e9
+        try:
+            copy_bw = dec.measure_copy_bw(1 << 30, 10)
+        except Exception:
+            copy_bw = None
+        total_alg = float(np.mean([sum(a.values()) for a in ab]))
+        kern_s = sum(tim[k][0] for k in ("itdq", "inter", "dbk_v", "dbk_h", "pad")) * 1e-3 / args.steps
+        out = {
+            "metric": "frames/sec (bit-exact YUV) + achieved HBM GB/s",
+            "value": round(world * args.steps / dt, 2),
+            "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "s16", "data": "synthetic",
+            "config": {"workload": args.workload, "width": wl["w"], "height": wl["h"], "bit_depth": wl["bd"],
+                       "stream": "IPPP, 1 reference, 100% inter CUs (GPU intra prediction is a later row), 60% coded, "
+                                 "deblock on, quad-tree 64..4", "batches_resident": len(batches),
+                       "parallelism": f"{world} independent stream(s), one per GPU"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 2),
+                         "measured_copy_bw_gbps": None if copy_bw is None else round(copy_bw, 1),
+                         "frac_of_measured_copy_bw": None if not copy_bw else round(achieved / copy_bw, 4)},
+            "kernels": kernels,
+            "whole_frame": {"algorithmic_bytes": int(total_alg), "kernel_us": round(kern_s * 1e6, 2),
+                            "achieved_gbps": round(total_alg / kern_s / 1e9, 1)},
+            "pcie_inclusive_fps": round(1.0 / (dt / args.steps + t_up), 2),
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(wl, first, batches[0])
+        print(json.dumps(out))
+    barrier()
+    dec.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

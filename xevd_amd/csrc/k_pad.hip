@@ -21,11 +21,11 @@ __global__ __launch_bounds__(256) void k_pad(const PadArgs p)
     const int mr = s - ml - w;
     const int16_t lv = src[0], rv = src[w - 1];
     const uint32_t l2 = (uint16_t)lv * 0x10001u, r2 = (uint16_t)rv * 0x10001u;
-    // margins (both are even-sized and 4-byte aligned: w, ml, s are multiples of 8)
+    // margins (even-sized and 4-byte aligned: luma w % 8 == 0, chroma w % 4 == 0, ml and s multiples of 64)
     for (int i = threadIdx.x; i < ml / 2; i += 256) ((uint32_t *)(dst - ml))[i] = l2;
     for (int i = threadIdx.x; i < mr / 2; i += 256) ((uint32_t *)(dst + w))[i] = r2;
     if (r != rs)
-        for (int i = threadIdx.x; i < w / 8; i += 256) ((uint4 *)dst)[i] = ((const uint4 *)src)[i];
+        for (int i = threadIdx.x; i < w / 4; i += 256) ((uint2 *)dst)[i] = ((const uint2 *)src)[i];   // w % 4 == 0 (chroma of w % 8 == 0)
 }
 
 void launch_pad(xgpu_ctx *c, const DevPic &pic)
