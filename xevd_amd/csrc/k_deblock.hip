@@ -24,6 +24,8 @@
 //     are staged in LDS.
 #include "xgpu_internal.h"
 
+struct __attribute__((packed, aligned(4))) U32x4a4 { uint32_t a, b, c, d; };   // 16-byte load at 4-byte alignment
+
 __device__ __forceinline__ int clip3i(int lo, int hi, int v) { return min(max(v, lo), hi); }
 
 // get_tbl_qp_to_st, xevd_df.c:34-94.  q = record of the right/below SCU, p = left/above.
@@ -96,33 +98,59 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
     const int k0 = sy * a.w_scu + sx;
     const int maxl = (1 << a.bd_l) - 1, maxc = (1 << a.bd_c) - 1;
 
+    // ---- everything this lane can need is requested up front (one memory round trip): the three SCU records,
+    //      the luma window and the chroma windows of both planes; decisions come afterwards ----
     const uint4 rq = maps[k0];
+    const uint4 rp = maps[pos > 0 ? k0 - step : k0];
+    const uint4 rn = maps[pos + 1 < npos ? k0 + step : k0];
+    const int x = sx << 2, y = sy << 2, cx = sx << 1, cy = sy << 1;
+    U32x4a4 lrow[4];       // DIR 0: rows y..y+3, samples x-2..x+5
+    uint2   lcol[8];       // DIR 1: rows y-2..y+5, samples x..x+3
+    int cs[2][2][6];       // chroma [plane][line][A B C D | C' D' of the next edge]: 6 samples along the filtering axis from -2
+    if (DIR == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) lrow[r] = *(const U32x4a4 *)(sy_ + (y + r) * a.s_l + x - 2);
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+            for (int ln = 0; ln < 2; ln++) {
+                const U32x4a4 v = *(const U32x4a4 *)((pl ? sv_ : su_) + (cy + ln) * a.s_c + cx - 2);
+                cs[pl][ln][0] = (int16_t)(v.a & 0xFFFF); cs[pl][ln][1] = (int16_t)(v.a >> 16);
+                cs[pl][ln][2] = (int16_t)(v.b & 0xFFFF); cs[pl][ln][3] = (int16_t)(v.b >> 16);
+                cs[pl][ln][4] = (int16_t)(v.c & 0xFFFF); cs[pl][ln][5] = (int16_t)(v.c >> 16);
+            }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) lcol[r] = *(const uint2 *)(sy_ + (y - 2 + r) * a.s_l + x);
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                const uint32_t v = *(const uint32_t *)((pl ? sv_ : su_) + (cy - 2 + r) * a.s_c + cx);
+                cs[pl][0][r] = (int16_t)(v & 0xFFFF); cs[pl][1][r] = (int16_t)(v >> 16);
+            }
+    }
+
     // edge on this SCU's left/top side, and the edge on the far side (belongs to the next SCU)
     int st_this[3] = {0, 0, 0}, st_next[3] = {0, 0, 0};
-    uint4 rp = rq;
     if (pos > 0 && (rq.x & eflag)) {
-        rp = maps[k0 - step];
         const int cls = edge_class(rq, rp), qp = (rq.x >> 16) & 0x7F;
 #pragma unroll
         for (int c = 0; c < 3; c++) st_this[c] = s_st[(c * 4 + cls) * 64 + (qp & 63)];
     }
-    if (pos + 1 < npos) {
-        const uint4 rn = maps[k0 + step];
-        if (rn.x & eflag) {
-            const int cls = edge_class(rn, rq), qp = (rn.x >> 16) & 0x7F;
+    if (pos + 1 < npos && (rn.x & eflag)) {
+        const int cls = edge_class(rn, rq), qp = (rn.x >> 16) & 0x7F;
 #pragma unroll
-            for (int c = 0; c < 3; c++) st_next[c] = s_st[(c * 4 + cls) * 64 + (qp & 63)];
-        }
+        for (int c = 0; c < 3; c++) st_next[c] = s_st[(c * 4 + cls) * 64 + (qp & 63)];
     }
 
     // ------------------------------------------------ luma -----------------------------------------------
-    const int x = sx << 2, y = sy << 2;
     if (DIR == 0) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const uint4 v = *(const uint4 *)(sy_ + (y + r) * a.s_l + x - 2);          // samples x-2 .. x+5
-            int s[8] = { (int16_t)(v.x & 0xFFFF), (int16_t)(v.x >> 16), (int16_t)(v.y & 0xFFFF), (int16_t)(v.y >> 16),
-                         (int16_t)(v.z & 0xFFFF), (int16_t)(v.z >> 16), (int16_t)(v.w & 0xFFFF), (int16_t)(v.w >> 16) };
+            const U32x4a4 v = lrow[r];
+            int s[8] = { (int16_t)(v.a & 0xFFFF), (int16_t)(v.a >> 16), (int16_t)(v.b & 0xFFFF), (int16_t)(v.b >> 16),
+                         (int16_t)(v.c & 0xFFFF), (int16_t)(v.c >> 16), (int16_t)(v.d & 0xFFFF), (int16_t)(v.d >> 16) };
             if (st_this[0]) { const Line4 o = filt_luma({ s[0], s[1], s[2], s[3] }, st_this[0], maxl); s[2] = o.C; s[3] = o.D; }
             if (st_next[0]) { const Line4 o = filt_luma({ s[4], s[5], s[6], s[7] }, st_next[0], maxl); s[4] = o.A; s[5] = o.B; }
             uint2 w;
@@ -131,82 +159,93 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
             *(uint2 *)(dy_ + (y + r) * a.s_l + x) = w;
         }
     } else {
-        uint2 rows[8];
-#pragma unroll
-        for (int r = 0; r < 8; r++) rows[r] = *(const uint2 *)(sy_ + (y - 2 + r) * a.s_l + x);     // rows y-2 .. y+5
 #pragma unroll
         for (int c = 0; c < 4; c++) {
             int s[8];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
-                const uint32_t d = (c < 2) ? rows[r].x : rows[r].y;
+                const uint32_t d = (c < 2) ? lcol[r].x : lcol[r].y;
                 s[r] = (c & 1) ? (int16_t)(d >> 16) : (int16_t)(d & 0xFFFF);
             }
             if (st_this[0]) { const Line4 o = filt_luma({ s[0], s[1], s[2], s[3] }, st_this[0], maxl); s[2] = o.C; s[3] = o.D; }
             if (st_next[0]) { const Line4 o = filt_luma({ s[4], s[5], s[6], s[7] }, st_next[0], maxl); s[4] = o.A; s[5] = o.B; }
 #pragma unroll
             for (int r = 2; r < 6; r++) {
-                uint32_t &d = (c < 2) ? rows[r].x : rows[r].y;
+                uint32_t &d = (c < 2) ? lcol[r].x : lcol[r].y;
                 d = (c & 1) ? ((d & 0xFFFFu) | ((uint32_t)(uint16_t)s[r] << 16)) : ((d & 0xFFFF0000u) | (uint32_t)(uint16_t)s[r]);
             }
         }
 #pragma unroll
-        for (int r = 2; r < 6; r++) *(uint2 *)(dy_ + (y - 2 + r) * a.s_l + x) = rows[r];
+        for (int r = 2; r < 6; r++) *(uint2 *)(dy_ + (y - 2 + r) * a.s_l + x) = lcol[r];
     }
 
     // ------------------------------------------------ chroma ---------------------------------------------
     // The SCU owns chroma samples (cx..cx+1, cy..cy+1).  Along the filtering axis, sample 0 is C' of this SCU's
     // edge and sample 1 is B' of the next SCU's edge; both need the final value of the sample two positions
     // before the edge (A), i.e. the C' of the previous edge when that edge is active.
-    const int cx = sx << 1, cy = sy << 1;
     const int alongc = DIR == 0 ? 1 : a.s_c, acrossc = DIR == 0 ? a.s_c : 1;
+    int outc[2][2][2];     // [plane][line][sample along the axis]
 #pragma unroll
     for (int pl = 0; pl < 2; pl++) {
-        const int16_t *src = (pl == 0 ? su_ : sv_) + cy * a.s_c + cx;
-        int16_t *dst = (pl == 0 ? du_ : dv_) + cy * a.s_c + cx;
         const int stt = st_this[1 + pl], stn = st_next[1 + pl];
+        // head of the chain of consecutive active edges that ends at this SCU's edge (xevd_df.c:238-289 order
+        // dependence); identical for both lines of the SCU.  Rare (runs of 4-wide / 4-tall CUs), so the extra
+        // records and samples are fetched inside the loop.
+        int head = pos;
+        if (stt) {
+            int kk = k0;
+            uint4 cur = rp;                                  // record of SCU head-1
+            while (head - 1 > 0) {
+                if (!(cur.x & eflag)) break;
+                const uint4 prv = maps[kk - 2 * step];
+                const int cls = edge_class(cur, prv), qp = (cur.x >> 16) & 0x7F;
+                if (s_st[((1 + pl) * 4 + cls) * 64 + (qp & 63)] == 0) break;
+                head--; kk -= step; cur = prv;
+            }
+        }
 #pragma unroll
         for (int ln = 0; ln < 2; ln++) {
-            const int16_t *p = src + ln * acrossc;          // p[k*alongc], k = -2..3 around this SCU's edge
-            int o0 = p[0], o1 = p[alongc];
-            int a_in = p[-2 * alongc];
+            const int *s = cs[pl][ln];
+            int o0 = s[2], o1 = s[3], a_in = s[0];
             if (stt) {
-                // walk back to the head of the chain of active edges (xevd_df.c:238-289 order dependence)
-                int head = pos;
-                int kk = k0;
-                uint4 cur = rp;                              // record of SCU pos-1
-                while (head - 1 > 0) {
-                    if (!(cur.x & eflag)) break;
-                    const uint4 prv = maps[kk - 2 * step];
-                    const int cls = edge_class(cur, prv), qp = (cur.x >> 16) & 0x7F;
-                    if (s_st[((1 + pl) * 4 + cls) * 64 + (qp & 63)] == 0) break;
-                    head--; kk -= step; cur = prv;
+                if (head < pos) {
+                    // recompute the chain forward from its head using ORIGINAL samples
+                    const int16_t *p = (pl ? sv_ : su_) + cy * a.s_c + cx + ln * acrossc;
+                    int prevC = 0;
+                    for (int e = head; e < pos; e++) {
+                        const int rel = (e - pos) * 2;                   // chroma offset of edge e relative to this edge
+                        const int ke = k0 + (e - pos) * step;
+                        const uint4 q = maps[ke], pp = maps[ke - step];
+                        const int cls = edge_class(q, pp), qp = (q.x >> 16) & 0x7F;
+                        const int st = s_st[((1 + pl) * 4 + cls) * 64 + (qp & 63)];
+                        const int A = (e == head) ? p[(rel - 2) * alongc] : prevC;
+                        int Bo, Co;
+                        filt_chroma(A, p[(rel - 1) * alongc], p[rel * alongc], p[(rel + 1) * alongc], st, maxc, Bo, Co);
+                        prevC = Co;
+                    }
+                    a_in = prevC;
                 }
-                // recompute the chain forward from its head using original samples
-                int prevC = 0;
-                for (int e = head; e < pos; e++) {
-                    const int rel = (e - pos) * 2;                       // chroma offset of edge e relative to this edge
-                    const int ke = k0 + (e - pos) * step;
-                    const uint4 q = maps[ke], pp = maps[ke - step];
-                    const int cls = edge_class(q, pp), qp = (q.x >> 16) & 0x7F;
-                    const int st = s_st[((1 + pl) * 4 + cls) * 64 + (qp & 63)];
-                    const int A = (e == head) ? p[(rel - 2) * alongc] : prevC;
-                    int Bo, Co;
-                    filt_chroma(A, p[(rel - 1) * alongc], p[rel * alongc], p[(rel + 1) * alongc], st, maxc, Bo, Co);
-                    prevC = Co;
-                }
-                if (head < pos) a_in = prevC;
                 int Bo, Co;
-                filt_chroma(a_in, p[-alongc], p[0], p[alongc], stt, maxc, Bo, Co);
+                filt_chroma(a_in, s[1], s[2], s[3], stt, maxc, Bo, Co);
                 o0 = Co;
             }
             if (stn) {
                 int Bo, Co;
-                filt_chroma(o0, p[alongc], p[2 * alongc], p[3 * alongc], stn, maxc, Bo, Co);
+                filt_chroma(o0, s[3], s[4], s[5], stn, maxc, Bo, Co);
                 o1 = Bo;
             }
-            dst[ln * acrossc] = (int16_t)o0;
-            dst[ln * acrossc + alongc] = (int16_t)o1;
+            outc[pl][ln][0] = o0; outc[pl][ln][1] = o1;
+        }
+    }
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++) {
+        int16_t *dst = (pl ? dv_ : du_) + cy * a.s_c + cx;
+        if (DIR == 0) {      // line = row, samples along x: one dword per row
+            *(uint32_t *)dst = (uint32_t)(uint16_t)outc[pl][0][0] | ((uint32_t)(uint16_t)outc[pl][0][1] << 16);
+            *(uint32_t *)(dst + a.s_c) = (uint32_t)(uint16_t)outc[pl][1][0] | ((uint32_t)(uint16_t)outc[pl][1][1] << 16);
+        } else {             // line = column, samples along y: row cy holds sample 0 of both columns
+            *(uint32_t *)dst = (uint32_t)(uint16_t)outc[pl][0][0] | ((uint32_t)(uint16_t)outc[pl][1][0] << 16);
+            *(uint32_t *)(dst + a.s_c) = (uint32_t)(uint16_t)outc[pl][0][1] | ((uint32_t)(uint16_t)outc[pl][1][1] << 16);
         }
     }
 }

@@ -3,139 +3,221 @@
 // Replaces xevd_sub_block_itdq -> xevd_itdq -> xevd_dquant + xevd_itrans (src_base/xevd_itdq.c:473-621) and the
 // IQT variant xevdm_itdq / xevdm_itrans (src_main/xevdm_itdq.c:708-788).
 //
-// MI355X mapping: the host sorts the picture's TBs by size class and cuts them into wave-sized work items
-// (TbWave).  One 64-lane workgroup per item:
-//   stage 1 (vertical):   lane = one COLUMN of one TB (64/W TBs side by side), coefficient rows streamed from
-//                         HBM with coalesced loads, dequantised on the fly, accumulated against transform-matrix
-//                         rows held in SGPRs (uniform scalar loads from constant memory); all-zero coefficient
-//                         rows are skipped wave-uniformly (ballot) - most high-frequency rows are zero;
-//   transpose through LDS (row stride H+1 dwords: conflict-free for both the column writes and the row reads);
-//   stage 2 (horizontal): lane = one ROW of one TB, 16 outputs at a time, 64-bit accumulation in the
-//                         non-IQT path exactly like the reference's s64 sums, packed 16-byte stores.
-// The butterflies of the reference are an evaluation order of exact integer dot products; a direct product
-// with the same matrices is bit-identical (tests/test_oracle_vs_ref.py pins the matrices and the arithmetic).
-// No MFMA: north_star scopes these as integer butterflies; the kernel is bound by issue rate on large TBs and
-// by HBM on small ones.
+// MI355X mapping: the host sorts the picture's TBs by size class and cuts them into 256-thread work items
+// (TbWave = a group of G same-size TBs, 4096 samples for everything up to 64x64).  Inside a workgroup
+//   stage 1 (vertical):   lane = one COLUMN of one TB, wave = one chunk of 16 output rows, so the transform
+//                         matrix entries a wave needs are wave-uniform and live in SGPRs (scalar loads from
+//                         constant memory, packed as s16 row PAIRS); two taps per v_dot2c_i32_i16; coefficient
+//                         row pairs that are zero across the whole wave are skipped (ballot) - most
+//                         high-frequency rows are; dequantisation (s64 like xevd_dquant) happens on the fly;
+//   transpose through LDS as packed s16 (row stride W/2+1 dwords: conflict-free column writes and row reads);
+//   stage 2 (horizontal): lane = one ROW of one TB, wave = one chunk of 16 output columns.  The reference's
+//                         non-IQT path keeps a 32-bit intermediate and a 64-bit sum: the intermediate t
+//                         (|t| < 2^28) is split exactly into t = hi*2^15 + lo with both halves in s16 range,
+//                         two dot2 chains accumulate sum(tm*hi) and sum(tm*lo) in 32 bits without overflow and
+//                         the 64-bit value hi*2^15+lo is formed once per output - bit-identical to the s64 sum.
+//                         IQT keeps a clipped s16 intermediate, one chain.
+// The reference's partial butterflies are an evaluation order of exact integer dot products; a direct product
+// with the same matrices is bit-identical (matrices and arithmetic pinned in tests/test_oracle_vs_ref.py).
+// No MFMA (north_star: integer butterflies, not dense contractions); bound by VALU issue on 32/64-point TBs
+// and by HBM on small ones.
 #include "xgpu_internal.h"
 
-// transform matrices xevd_tbl_tm2..64 as int32, row-major [k][n], filled by the host from the closed form
-// round(64*sqrt(2)*cos((2n+1)k*pi/2N)) (row 0 = 64), see xgpu_api.hip:init_transform_tables
-__constant__ int k_tm[5460];
-__host__ __device__ constexpr int tm_base(int log2n) { return log2n == 1 ? 0 : log2n == 2 ? 4 : log2n == 3 ? 20 : log2n == 4 ? 84 : log2n == 5 ? 340 : 1364; }
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+// transform matrices xevd_tbl_tm2..64 packed as row pairs: entry [k2][n] = (tm[2*k2][n], tm[2*k2+1][n]) as two s16;
+// filled by the host from the closed form (xgpu_api.hip:init_transform_tables).  Offsets: N*N/2 dwords per size.
+__constant__ uint32_t k_tmp[2730];
+__host__ __device__ constexpr int tmp_base(int log2n) { return log2n == 1 ? 0 : log2n == 2 ? 2 : log2n == 3 ? 10 : log2n == 4 ? 42 : log2n == 5 ? 170 : 682; }
 
 void upload_transform_tables(const int *tm, hipStream_t s)
 {
-    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(k_tm), tm, sizeof(int) * 5460, 0, hipMemcpyHostToDevice, s);
+    // tm: int32 row-major matrices 2,4,..,64 back to back (5460 entries)
+    static uint32_t packed[2730];
+    int src = 0;
+    for (int l = 1; l <= 6; l++) {
+        const int N = 1 << l, dst = tmp_base(l);
+        for (int k2 = 0; k2 < N / 2; k2++)
+            for (int n = 0; n < N; n++)
+                packed[dst + k2 * N + n] = (uint32_t)(uint16_t)(int16_t)tm[src + (2 * k2) * N + n] |
+                                           ((uint32_t)(uint16_t)(int16_t)tm[src + (2 * k2 + 1) * N + n] << 16);
+        src += N * N;
+    }
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(k_tmp), packed, sizeof(packed), 0, hipMemcpyHostToDevice, s);
+    (void)hipStreamSynchronize(s);
 }
 
 __device__ __forceinline__ int clip16(int v) { return min(max(v, -32768), 32767); }
+__device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
+{
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b), c, false);
+}
+
+// geometry of a size class, shared with the host-side batch builder (xgpu_api.hip)
+__host__ __device__ constexpr int itdq_group(int lw, int lh)
+{
+    const int W = 1 << lw, H = 1 << lh;
+    const int l1 = W * (H > 16 ? H / 16 : 1), l2 = H * (W > 16 ? W / 16 : 1);
+    return 256 / (l1 > l2 ? l1 : l2);
+}
+int itdq_group_size(int lw, int lh) { return itdq_group(lw, lh); }
+
+#define ITDQ_PLANES_DWORDS 4608  // max over size classes of 2 planes x G*H*(W/2+1) dwords (16x16: 2*2304)
+#define ITDQ_LDS_DWORDS (ITDQ_PLANES_DWORDS + 2048)   // + 4096 dequantised s16 coefficients
 
 template <int LW, int LH>
-__device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, int *lds)
+__device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, uint32_t *lds)
 {
     constexpr int W = 1 << LW, H = 1 << LH;
-    constexpr int P = 64 / W;                       // TBs per wave (W <= 64)
-    constexpr int LS = H + 1;                       // LDS row stride in dwords
-    const int lane = threadIdx.x;
-    const int *tmh = k_tm + tm_base(LH);
-    const int *tmw = k_tm + tm_base(LW);
+    constexpr int N1 = H > 16 ? 16 : H, C1 = H / N1;          // stage-1 outputs per lane, chunks
+    constexpr int N2 = W > 16 ? 16 : W, C2 = W / N2;
+    constexpr int G = itdq_group(LW, LH);
+    constexpr int RS = W / 2 + 1;                              // LDS row stride in dwords (s16 pairs), odd
+    constexpr int PLANE = G * H * RS;                          // dwords per intermediate plane
+    constexpr bool UNI1 = (G * W) % 64 == 0, UNI2 = (G * H) % 64 == 0;
+    static_assert(2 * PLANE <= ITDQ_PLANES_DWORDS && G * W * H <= 4096, "LDS budget");
+    const int t = threadIdx.x;
+    const uint32_t *tmh = k_tmp + tmp_base(LH);
+    const uint32_t *tmw = k_tmp + tmp_base(LW);
+    int16_t *ldsh = (int16_t *)lds;                            // plane 0: hi (or the IQT intermediate), plane 1: lo
+    int16_t *ldsl = (int16_t *)(lds + PLANE);
+    uint32_t *ldsc = lds + ITDQ_PLANES_DWORDS;                 // dequantised coefficients, [p][row][col] s16
 
-    // ------------------------------------------------ stage 1: columns ------------------------------------
+    // ------------------------------------------------ stage 0: load + dequantise ---------------------------
+    // all coefficients of the G blocks in one coalesced sweep (one memory round trip for the whole work item),
+    // dequantised once (xevd_dquant, xevd_itdq.c:480-492; shift/offset :511-515; scale tables xevd_tbl.c:255-256:
+    // {..,72} with tool_iqt, {..,71} without) and parked in LDS as s16
     {
-        const int p = lane >> LW, j = lane & (W - 1);
-        const bool valid = p < wv.count;
-        const TbRec tb = a.tbs[wv.first + (valid ? p : 0)];
-        // xevd_itdq.c:511-515 / xevd_dquant :480-492
-        const int qp = tb.qp;
-        const int sidx = qp % 6;
-        // xevd_tbl_dq_scale {..,72} with tool_iqt, xevd_tbl_dq_scale_b {..,71} without (xevd_tbl.c:255-256)
-        const int sbase = sidx == 0 ? 40 : sidx == 1 ? 45 : sidx == 2 ? 51 : sidx == 3 ? 57 : sidx == 4 ? 64 : (a.iqt ? 72 : 71);
-        const int scale = sbase << (qp / 6);
+        constexpr int S = W * H, UN = S >= 8 ? 8 : 4;           // samples per load unit
         constexpr int odd = (LW + LH) & 1;
         const int shift = 20 - 14 - (15 - a.bd - ((LW + LH) >> 1)) + (odd ? 8 : 0);
         const long long offset = shift == 0 ? 0 : 1ll << (shift - 1);
-        const long long mul = (long long)scale * (odd ? 181 : 1);
-        const int16_t *src = a.coef + tb.off + j;
-
-        int acc[H];
+        for (int u = t; u < G * S / UN; u += 256) {
+            const int p = (u * UN) / S, o = (u * UN) % S;
+            if (p >= wv.count) break;
+            const TbRec tb = a.tbs[wv.first + p];
+            const int qp = tb.qp, sidx = qp % 6;
+            const int sbase = sidx == 0 ? 40 : sidx == 1 ? 45 : sidx == 2 ? 51 : sidx == 3 ? 57 : sidx == 4 ? 64 : (a.iqt ? 72 : 71);
+            const long long mul = (long long)(sbase << (qp / 6)) * (odd ? 181 : 1);
+            uint32_t raw[UN / 2];
+            if constexpr (UN == 8) { const uint4 v = *(const uint4 *)(a.coef + tb.off + o); raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w; }
+            else { const uint2 v = *(const uint2 *)(a.coef + tb.off + o); raw[0] = v.x; raw[1] = v.y; }
 #pragma unroll
-        for (int n = 0; n < H; n++) acc[n] = 0;
-        for (int k = 0; k < H; k++) {
-            int c = valid ? (int)src[k * W] : 0;
-            if (__ballot(c != 0) == 0) continue;                       // whole coefficient row zero in this wave
-            long long lev = ((long long)c * mul + offset) >> shift;
-            const int v = (int)min(max(lev, -32768ll), 32767ll);
+            for (int i = 0; i < UN / 2; i++) {
+                if (raw[i] == 0) continue;
+                const int c0 = (int16_t)(raw[i] & 0xFFFF), c1 = (int16_t)(raw[i] >> 16);
+                const long long l0 = ((long long)c0 * mul + offset) >> shift, l1 = ((long long)c1 * mul + offset) >> shift;
+                const int v0 = (int)min(max(l0, -32768ll), 32767ll), v1 = (int)min(max(l1, -32768ll), 32767ll);
+                raw[i] = (uint32_t)(uint16_t)v0 | ((uint32_t)(uint16_t)v1 << 16);
+            }
 #pragma unroll
-            for (int n = 0; n < H; n++) acc[n] = (__mul24(tmh[k * H + n], v) + acc[n]);   // |tm|<=90, |v|<2^15: exact in 24x24
+            for (int i = 0; i < UN / 2; i++) ldsc[(p * S + o) / 2 + i] = raw[i];
         }
-        int *dst = lds + lane * LS;
+    }
+    __syncthreads();
+
+    // ------------------------------------------------ stage 1: columns ------------------------------------
+    if (t < G * W * C1) {
+        const int idx = t % (G * W);
+        int chunk = t / (G * W);
+        if (UNI1) chunk = __builtin_amdgcn_readfirstlane(chunk);
+        const int p = idx >> LW, j = idx & (W - 1);
+        const bool valid = p < wv.count;
+        const int16_t *src = (const int16_t *)ldsc + p * (W * H) + j;
+
+        int acc[N1];
 #pragma unroll
-        for (int n = 0; n < H; n++) dst[n] = a.iqt ? clip16((acc[n] + 64) >> 7) : acc[n];
+        for (int n = 0; n < N1; n++) acc[n] = 0;
+        for (int k2 = 0; k2 < H / 2; k2++) {
+            const uint32_t vp = valid ? ((uint32_t)(uint16_t)src[(2 * k2) * W] | ((uint32_t)(uint16_t)src[(2 * k2 + 1) * W] << 16)) : 0u;
+            if (__ballot(vp != 0) == 0) continue;              // both coefficient rows zero across this wave
+            const uint32_t *row = tmh + k2 * H + chunk * N1;
+#pragma unroll
+            for (int n = 0; n < N1; n++) acc[n] = dot2(row[n], vp, acc[n]);
+        }
+        // transposed store: element [p][row = chunk*N1+n][col = j]
+        const int base = (p * H + chunk * N1) * (2 * RS) + j;
+        if (a.iqt) {
+#pragma unroll
+            for (int n = 0; n < N1; n++) ldsh[base + n * (2 * RS)] = (int16_t)clip16((acc[n] + 64) >> 7);   // xevdm_itdq.c ITX_SHIFT1 = 7
+        } else {
+#pragma unroll
+            for (int n = 0; n < N1; n++) {
+                ldsh[base + n * (2 * RS)] = (int16_t)(acc[n] >> 15);          // |acc| < 2^28 -> hi in s16 range
+                ldsl[base + n * (2 * RS)] = (int16_t)(acc[n] & 0x7FFF);
+            }
+        }
     }
     __syncthreads();
 
     // ------------------------------------------------ stage 2: rows ---------------------------------------
-    constexpr int NC = W < 16 ? W : 16;             // outputs per chunk
-    const int shift2 = a.iqt ? 12 - (a.bd - 8) : 7 + 12 - (a.bd - 8);
-    for (int ri = lane; ri < P * H; ri += 64) {
-        const int p = ri >> LH, r = ri & (H - 1);
-        if (p >= wv.count) break;
+    if (t < G * H * C2) {
+        const int idx = t % (G * H);
+        int chunk = t / (G * H);
+        if (UNI2) chunk = __builtin_amdgcn_readfirstlane(chunk);
+        const int p = idx >> LH, r = idx & (H - 1);
+        if (p >= wv.count) return;
         const TbRec tb = a.tbs[wv.first + p];
-        const int *in = lds + (p * W) * LS + r;
-        int16_t *out = a.resid + tb.off + r * W;
-#pragma unroll 1
-        for (int n0 = 0; n0 < W; n0 += NC) {
-            int res[NC];
-            if (a.iqt) {
-                int s[NC];
+        const int shift2 = a.iqt ? 12 - (a.bd - 8) : 7 + 12 - (a.bd - 8);
+        const uint32_t *inh = lds + (p * H + r) * RS;
+        const uint32_t *inl = inh + PLANE;
+        int res[N2];
+        if (a.iqt) {
+            int s[N2];
 #pragma unroll
-                for (int n = 0; n < NC; n++) s[n] = 1 << (shift2 - 1);
-                for (int k = 0; k < W; k++) {
-                    const int v = in[k * LS];
+            for (int n = 0; n < N2; n++) s[n] = 1 << (shift2 - 1);
+            for (int k2 = 0; k2 < W / 2; k2++) {
+                const uint32_t vp = inh[k2];
+                if (__ballot(vp != 0) == 0) continue;
+                const uint32_t *row = tmw + k2 * W + chunk * N2;
 #pragma unroll
-                    for (int n = 0; n < NC; n++) s[n] = (__mul24(tmw[k * W + n0 + n], v) + s[n]);
-                }
-#pragma unroll
-                for (int n = 0; n < NC; n++) res[n] = clip16(s[n] >> shift2);
-            } else {
-                long long s[NC];
-#pragma unroll
-                for (int n = 0; n < NC; n++) s[n] = 1ll << (shift2 - 1);
-                for (int k = 0; k < W; k++) {
-                    const int v = in[k * LS];
-#pragma unroll
-                    for (int n = 0; n < NC; n++) s[n] += (long long)tmw[k * W + n0 + n] * v;
-                }
-#pragma unroll
-                for (int n = 0; n < NC; n++) res[n] = (int)min(max(s[n] >> shift2, -32768ll), 32767ll);
+                for (int n = 0; n < N2; n++) s[n] = dot2(row[n], vp, s[n]);
             }
-            if constexpr (NC >= 8) {
 #pragma unroll
-                for (int n = 0; n < NC; n += 8) {
-                    uint4 v;
-                    v.x = (uint32_t)(uint16_t)res[n + 0] | ((uint32_t)(uint16_t)res[n + 1] << 16);
-                    v.y = (uint32_t)(uint16_t)res[n + 2] | ((uint32_t)(uint16_t)res[n + 3] << 16);
-                    v.z = (uint32_t)(uint16_t)res[n + 4] | ((uint32_t)(uint16_t)res[n + 5] << 16);
-                    v.w = (uint32_t)(uint16_t)res[n + 6] | ((uint32_t)(uint16_t)res[n + 7] << 16);
-                    *(uint4 *)(out + n0 + n) = v;
-                }
-            } else if constexpr (NC == 4) {
-                uint2 v;
-                v.x = (uint32_t)(uint16_t)res[0] | ((uint32_t)(uint16_t)res[1] << 16);
-                v.y = (uint32_t)(uint16_t)res[2] | ((uint32_t)(uint16_t)res[3] << 16);
-                *(uint2 *)(out + n0) = v;
-            } else {
-                *(uint32_t *)(out + n0) = (uint32_t)(uint16_t)res[0] | ((uint32_t)(uint16_t)res[1] << 16);
+            for (int n = 0; n < N2; n++) res[n] = clip16(s[n] >> shift2);
+        } else {
+            int sh[N2], sl[N2];
+#pragma unroll
+            for (int n = 0; n < N2; n++) { sh[n] = 0; sl[n] = 0; }
+            for (int k2 = 0; k2 < W / 2; k2++) {
+                const uint32_t vh = inh[k2], vl = inl[k2];
+                if (__ballot((vh | vl) != 0) == 0) continue;
+                const uint32_t *row = tmw + k2 * W + chunk * N2;
+#pragma unroll
+                for (int n = 0; n < N2; n++) { sh[n] = dot2(row[n], vh, sh[n]); sl[n] = dot2(row[n], vl, sl[n]); }
             }
+            const long long add = 1ll << (shift2 - 1);
+#pragma unroll
+            for (int n = 0; n < N2; n++) {
+                const long long s = (long long)sh[n] * 32768 + sl[n] + add;     // == the reference's s64 sum + rounding offset
+                res[n] = (int)min(max(s >> shift2, -32768ll), 32767ll);
+            }
+        }
+        int16_t *out = a.resid + tb.off + r * W + chunk * N2;
+        if constexpr (N2 >= 8) {
+#pragma unroll
+            for (int n = 0; n < N2; n += 8) {
+                uint4 v;
+                v.x = (uint32_t)(uint16_t)res[n + 0] | ((uint32_t)(uint16_t)res[n + 1] << 16);
+                v.y = (uint32_t)(uint16_t)res[n + 2] | ((uint32_t)(uint16_t)res[n + 3] << 16);
+                v.z = (uint32_t)(uint16_t)res[n + 4] | ((uint32_t)(uint16_t)res[n + 5] << 16);
+                v.w = (uint32_t)(uint16_t)res[n + 6] | ((uint32_t)(uint16_t)res[n + 7] << 16);
+                *(uint4 *)(out + n) = v;
+            }
+        } else if constexpr (N2 == 4) {
+            uint2 v;
+            v.x = (uint32_t)(uint16_t)res[0] | ((uint32_t)(uint16_t)res[1] << 16);
+            v.y = (uint32_t)(uint16_t)res[2] | ((uint32_t)(uint16_t)res[3] << 16);
+            *(uint2 *)out = v;
+        } else {
+            *(uint32_t *)out = (uint32_t)(uint16_t)res[0] | ((uint32_t)(uint16_t)res[1] << 16);
         }
     }
 }
 
-#define ITDQ_MAX_LDS_INTS (64 * 65)
-
-__global__ __launch_bounds__(64) void k_itdq(const ItdqArgs a)
+__global__ __launch_bounds__(256) void k_itdq(const ItdqArgs a)
 {
-    __shared__ int lds[ITDQ_MAX_LDS_INTS];
+    __shared__ uint32_t lds[ITDQ_LDS_DWORDS];
     const int wi = blockIdx.x;
     if (wi >= a.n_waves) return;
     const TbWave wv = a.waves[wi];
@@ -150,5 +232,5 @@ __global__ __launch_bounds__(64) void k_itdq(const ItdqArgs a)
 void launch_itdq(xgpu_ctx *c, const ItdqArgs &a)
 {
     if (a.n_waves <= 0) return;
-    hipLaunchKernelGGL(k_itdq, dim3(a.n_waves), dim3(64), 0, c->stream, a);
+    hipLaunchKernelGGL(k_itdq, dim3(a.n_waves), dim3(256), 0, c->stream, a);
 }

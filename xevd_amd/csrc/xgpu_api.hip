@@ -315,7 +315,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     int cls_first[64], n_tb = 0, n_waves = 0;
     for (int k = 0; k < 64; k++) {
         cls_first[k] = n_tb; n_tb += cls_count[k];
-        if (cls_count[k]) { const int per = 64 >> (k >> 3); n_waves += (cls_count[k] + per - 1) / per; }
+        if (cls_count[k]) { const int per = itdq_group_size(k >> 3, k & 7); n_waves += (cls_count[k] + per - 1) / per; }
     }
 
     xgpu_dbatch *db = new xgpu_dbatch();
@@ -360,7 +360,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     int w = 0;
     for (int k = 0; k < 64; k++) {
         if (!cls_count[k]) continue;
-        const int per = 64 >> (k >> 3);
+        const int per = itdq_group_size(k >> 3, k & 7);
         for (int f = 0; f < cls_count[k]; f += per) {
             wv[w].first = cls_first[k] + f; wv[w].count = (uint16_t)std::min(per, cls_count[k] - f);
             wv[w].log2w = (uint8_t)(k >> 3); wv[w].log2h = (uint8_t)(k & 7); w++;
@@ -518,7 +518,7 @@ int xgpu_test_itdq(xgpu_ctx *c, int16_t *coef, int n_blocks, int log2w, int log2
     std::vector<TbRec> tbs(n_blocks);
     std::vector<TbWave> wv;
     for (int i = 0; i < n_blocks; i++) { tbs[i].off = (uint32_t)(per * i); tbs[i].log2w = (uint8_t)log2w; tbs[i].log2h = (uint8_t)log2h; tbs[i].qp = qp[i]; tbs[i].rsvd = 0; }
-    const int pw = 64 >> log2w;
+    const int pw = itdq_group_size(log2w, log2h);
     for (int f = 0; f < n_blocks; f += pw) wv.push_back({ (uint32_t)f, (uint16_t)std::min(pw, n_blocks - f), (uint8_t)log2w, (uint8_t)log2h });
     int16_t *dc = NULL, *dr = NULL; TbRec *dt = NULL; TbWave *dw = NULL;
     HIPCHK(c, hipMalloc((void **)&dc, nb)); HIPCHK(c, hipMalloc((void **)&dr, nb));

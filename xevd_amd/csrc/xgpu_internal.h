@@ -59,7 +59,7 @@ struct TbRec {
     uint32_t off;             // arena offset (s16 units)
     uint8_t  log2w, log2h, qp, rsvd;
 };
-// One wave of the itdq kernel: `count` consecutive TbRecs of one size class.
+// One 256-thread work item of the itdq kernel: `count` consecutive TbRecs of one size class.
 struct TbWave {
     uint32_t first;
     uint16_t count;
@@ -141,6 +141,7 @@ void launch_itdq(xgpu_ctx *c, const ItdqArgs &a);
 void launch_inter(xgpu_ctx *c, const InterArgs &a);
 void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst);
 void upload_transform_tables(const int *tm, hipStream_t s);
+int  itdq_group_size(int log2w, int log2h);     // TBs of one size class per 256-thread work item
 void launch_pad(xgpu_ctx *c, const DevPic &p);
 void launch_copy_bw(xgpu_ctx *c, const void *src, void *dst, size_t bytes);
 void launch_test_mc(xgpu_ctx *c, const int16_t *plane, int stride, int ref_x, int ref_y, int has_dx, int has_dy,
