@@ -82,6 +82,10 @@ typedef struct xgpu_frame_params {
     int refp_poc[XGPU_MAX_REFS][2];        /* ctx->refp[idx][list].pic->poc                              */
     int qp_u_offset, qp_v_offset;          /* sh.qp_u_offset / sh.qp_v_offset (pic_qp_*_offset)          */
     int deblock_alpha_offset, deblock_beta_offset;  /* sh_deblock_alpha/beta_offset (ADDB only)          */
+    /* which in-loop filters WILL run on this picture (sh.deblocking_filter_on, sh.alf_on).  The filters work
+       out of place between the DPB slot and a private scratch picture; knowing the plan up front lets
+       reconstruction start in the buffer from which the last filter lands in the DPB slot without a copy.  */
+    int deblock_on, alf_on;
 } xgpu_frame_params;
 
 /*

@@ -20,6 +20,7 @@
 #include "xevdm_def.h"
 #include "xevdm_mc.h"
 #include "xevdm_itdq.h"
+#include "xevdm_df.h"
 #include "xevd_oracle.h"
 
 /* reference tables selected like xevd_platform_init does (src_base/xevd.c:2074-2149) */
@@ -98,8 +99,14 @@ static harness *harness_new(const xgpu_seq_params *sp, const orc_frame *fr, orc_
     h->cur.pic_qp_v_offset = fr->qp_v_offset;
     h->ctx->pic = &h->cur;
     for (i = 0; i < XGPU_MAX_REFS; i++) for (l = 0; l < 2; l++) {
+        int i2, l2, found = 0;
         fill_pic(&h->rpic[i][l], &fr->refp[i][l], sp);
         h->ctx->refp[i][l].pic = &h->rpic[i][l];
+        /* one XEVD_PIC per distinct picture: ADDB's get_bs compares reference pictures by pointer (xevdm_df.c:461-464) */
+        for (i2 = 0; i2 <= i && !found; i2++) for (l2 = 0; l2 < 2 && !found; l2++) {
+            if (i2 == i && l2 >= l) break;
+            if (fr->refp[i2][l2].y == fr->refp[i][l].y) { h->ctx->refp[i][l].pic = h->ctx->refp[i2][l2].pic; found = 1; }
+        }
         h->ctx->refp[i][l].poc = fr->refp[i][l].poc;
     }
     select_tables(h->ctx, simd);
@@ -211,6 +218,35 @@ int refh_deblock_baseline(const xgpu_seq_params *sp, const orc_frame *fr, const 
     for (k = 0; k < (int)ctx->f_scu; k++) MCU_CLR_COD(ctx->map_scu[k]);
     for (i = 0; i < b->n_cu; i++)
         xevd_deblock_cu_hor(ctx, ctx->pic, b->x[i], b->y[i], 1 << b->log2w[i], 1 << b->log2h[i], 0);
+    harness_free(hn);
+    return 0;
+}
+
+/* ADDB: xevdm_deblock_cu_ver / _hor (src_main/xevdm_df.c:1137-1168) over the leaf CUs in decode order, vertical edges
+   first (is_hor_edge = 0), COD cleared before each pass - the loop of src_main/xevdm.c:3152-3205 / deblock_tree :1935-2040 */
+int refh_deblock_addb(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *m, int alpha_off, int beta_off)
+{
+    harness *hn = harness_new(sp, fr, m, 0);
+    XEVD_CTX *ctx = hn->ctx;
+    XEVDM_CTX *mctx = (XEVDM_CTX *)ctx;
+    const TREE_CONS tc = { FALSE, TREE_LC, eAll };
+    u8 *map_ats = (u8 *)calloc(ctx->f_scu, 1);
+    int i, k;
+    hn->sps.tool_addb = 1;
+    ctx->pic->pic_deblock_alpha_offset = alpha_off;
+    ctx->pic->pic_deblock_beta_offset = beta_off;
+    (void)mctx;
+    for (k = 0; k < (int)ctx->f_scu; k++) MCU_CLR_COD(ctx->map_scu[k]);
+    for (i = 0; i < b->n_cu; i++)
+        xevdm_deblock_cu_ver(ctx, ctx->pic, b->x[i], b->y[i], 1 << b->log2w[i], 1 << b->log2h[i], ctx->map_scu, ctx->map_refi, ctx->map_mv,
+                             ctx->w_scu, sp->log2_ctu, ctx->map_cu_mode, ctx->refp, 0, tc, ctx->map_tidx, 0, 1, map_ats,
+                             sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
+    for (k = 0; k < (int)ctx->f_scu; k++) MCU_CLR_COD(ctx->map_scu[k]);
+    for (i = 0; i < b->n_cu; i++)
+        xevdm_deblock_cu_hor(ctx, ctx->pic, b->x[i], b->y[i], 1 << b->log2w[i], 1 << b->log2h[i], ctx->map_scu, ctx->map_refi, ctx->map_mv,
+                             ctx->w_scu, sp->log2_ctu, ctx->refp, 0, tc, ctx->map_tidx, 0, 1, map_ats,
+                             sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
+    free(map_ats);
     harness_free(hn);
     return 0;
 }

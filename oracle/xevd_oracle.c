@@ -504,6 +504,162 @@ int orc_deblock_baseline(const xgpu_seq_params *sp, const orc_frame *fr, const x
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * ADDB deblocking (Main profile, sps->tool_addb).  src_main/xevdm_df.c:361-1135.
+ * Tables ALPHA_TABLE / BETA_TABLE / CLIP_TAB: src_main/xevdm_tbl.c:377-379 (constants of the EVC specification).
+ * ---------------------------------------------------------------------------------------------- */
+static const uint8_t k_addb_alpha[52] = { 0,0,0,0,0,0,0,0,0,0,0,0, 0,0,0,0,4,4,5,6, 7,8,9,10,12,13,15,17, 20,22,25,28,32,36,40,45,
+    50,56,63,71,80,90,101,113, 127,144,162,182,203,226,255,255 };
+static const uint8_t k_addb_beta[52] = { 0,0,0,0,0,0,0,0,0,0,0,0, 0,0,0,0,2,2,2,3, 3,3,3,4,4,4,6,6, 7,7,8,8,9,9,10,10,
+    11,11,12,12,13,13,14,14, 15,15,16,16,17,17,18,18 };
+static const uint8_t k_addb_clip[52][5] = {
+    {0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},
+    {0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},
+    {0,0,0,0,0},{0,0,0,1,1},{0,0,0,1,1},{0,0,0,1,1},{0,0,0,1,1},{0,0,1,1,1},{0,0,1,1,1},{0,1,1,1,1},
+    {0,1,1,1,1},{0,1,1,1,1},{0,1,1,1,1},{0,1,1,2,2},{0,1,1,2,2},{0,1,1,2,2},{0,1,1,2,2},{0,1,2,3,3},
+    {0,1,2,3,3},{0,2,2,3,3},{0,2,2,4,4},{0,2,3,4,4},{0,2,3,4,4},{0,3,3,5,5},{0,3,4,6,6},{0,3,4,6,6},
+    {0,4,5,7,7},{0,4,5,8,8},{0,4,6,9,9},{0,5,7,10,10},{0,6,8,11,11},{0,6,8,13,13},{0,7,10,14,14},{0,8,11,16,16},
+    {0,9,12,18,18},{0,10,13,20,20},{0,11,15,23,23},{0,13,17,25,25} };
+
+/* get_bs, xevdm_df.c:361-513.  k0 = current (right/below) SCU, k1 = neighbour; (x0,y0),(x1,y1) their sample positions.
+   Reference pictures are compared by identity (XEVD_PIC pointers) - here by their luma plane pointer. */
+static int addb_bs(const xgpu_seq_params *sp, const orc_frame *fr, const orc_maps *m, int k0, int x0, int y0, int k1, int x1, int y1)
+{
+    const uint32_t m0 = m->map_scu[k0], m1 = m->map_scu[k1];
+    const int intra = MCU_IF(m0) || MCU_IF(m1);
+    const int lg = sp->log2_ctu;
+    const int8_t *r0 = &m->map_refi[k0 * 2], *r1 = &m->map_refi[k1 * 2];
+    const int16_t *p0[2], *p1[2];
+    int mv0[2][2], mv1[2][2], l, d;
+    if (intra && ((x0 >> lg) != (x1 >> lg) || (y0 >> lg) != (y1 >> lg))) return 4;
+    if (intra) return 3;
+    if (MCU_CBFL(m0) || MCU_CBFL(m1)) return 2;
+    for (l = 0; l < 2; l++) {
+        p0[l] = r0[l] >= 0 ? fr->refp[r0[l]][l].y : NULL;
+        p1[l] = r1[l] >= 0 ? fr->refp[r1[l]][l].y : NULL;
+        for (d = 0; d < 2; d++) {
+            mv0[l][d] = r0[l] >= 0 ? m->map_mv[k0 * 4 + l * 2 + d] : 0;
+            mv1[l][d] = r1[l] >= 0 ? m->map_mv[k1 * 4 + l * 2 + d] : 0;
+        }
+    }
+#define MVSAME(a, b) (abs((a)[0] - (b)[0]) < 4 && abs((a)[1] - (b)[1]) < 4)
+    if ((p0[0] == p1[0] && p0[1] == p1[1]) || (p0[0] == p1[1] && p0[1] == p1[0])) {
+        if (p0[0] == p0[1])
+            return (MVSAME(mv0[0], mv1[0]) && MVSAME(mv0[1], mv1[1]) && MVSAME(mv0[0], mv1[1]) && MVSAME(mv0[1], mv1[0])) ? 0 : 1;
+        if (p0[0] == p1[0] && p0[1] == p1[1])
+            return (MVSAME(mv0[0], mv1[0]) && MVSAME(mv0[1], mv1[1])) ? 0 : 1;
+        return (MVSAME(mv0[0], mv1[1]) && MVSAME(mv0[1], mv1[0])) ? 0 : 1;
+    }
+    return 1;
+#undef MVSAME
+}
+
+/* deblock_scu_line_luma, xevdm_df.c:584-709.  p[i] = buf[-(i+1)*step], q[i] = buf[i*step] */
+static void addb_line_luma(int16_t *buf, int step, int bs, int alpha, int beta, int c1, int bd)
+{
+    const int maxv = (1 << bd) - 1;
+    int16_t p[4], q[4], po[4], qo[4];
+    int i, ap, aq;
+    for (i = 0; i < 4; i++) { q[i] = buf[i * step]; p[i] = buf[-(i + 1) * step]; po[i] = p[i]; qo[i] = q[i]; }
+    if (!(bs && abs(p[0] - q[0]) < alpha && abs(p[1] - p[0]) < beta && abs(q[1] - q[0]) < beta)) return;
+    ap = abs(p[0] - p[2]) < beta;
+    aq = abs(q[0] - q[2]) < beta;
+    if (bs == 4) {
+        const int strong = abs(p[0] - q[0]) < ((alpha >> 2) + 2);
+        if (ap && strong) {
+            po[0] = (int16_t)((p[2] + 2 * (p[1] + p[0] + q[0]) + q[1] + 4) >> 3);
+            po[1] = (int16_t)((p[2] + p[1] + p[0] + q[0] + 2) >> 2);
+            po[2] = (int16_t)((2 * p[3] + 3 * p[2] + p[1] + p[0] + q[0] + 4) >> 3);
+        } else po[0] = (int16_t)((2 * p[1] + p[0] + q[1] + 2) >> 2);
+        if (aq && strong) {
+            qo[0] = (int16_t)((q[2] + 2 * (q[1] + q[0] + p[0]) + p[1] + 4) >> 3);
+            qo[1] = (int16_t)((q[2] + q[1] + q[0] + p[0] + 2) >> 2);
+            qo[2] = (int16_t)((2 * q[3] + 3 * q[2] + q[1] + q[0] + p[0] + 4) >> 3);
+        } else qo[0] = (int16_t)((2 * q[1] + q[0] + p[1] + 2) >> 2);
+    } else {
+        const int c0 = (uint8_t)(c1 + ((ap + aq) << (bd - 9 > 0 ? bd - 9 : 0)));
+        const int d0 = CLIP3(-c0, c0, (4 * (q[0] - p[0]) + p[1] - q[1] + 4) >> 3);
+        po[0] = (int16_t)CLIP3(0, maxv, p[0] + d0);
+        qo[0] = (int16_t)CLIP3(0, maxv, q[0] - d0);
+        if (ap) po[1] = (int16_t)(p[1] + CLIP3(-c1, c1, (((p[2] + p[0] + q[0]) * 3) - 8 * p[1] - q[1]) >> 4));
+        if (aq) qo[1] = (int16_t)(q[1] + CLIP3(-c1, c1, (((q[2] + q[0] + p[0]) * 3) - 8 * q[1] - p[1]) >> 4));
+    }
+    for (i = 0; i < 4; i++) { buf[i * step] = (int16_t)CLIP3(0, maxv, qo[i]); buf[-(i + 1) * step] = (int16_t)CLIP3(0, maxv, po[i]); }
+}
+/* deblock_scu_line_chroma, xevdm_df.c:710-781 */
+static void addb_line_chroma(int16_t *buf, int step, int bs, int alpha, int beta, int c0, int bd)
+{
+    const int maxv = (1 << bd) - 1;
+    const int16_t p0 = buf[-step], p1 = buf[-2 * step], q0 = buf[0], q1 = buf[step];
+    int po = p0, qo = q0;
+    if (!(bs && abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta)) return;
+    if (bs == 4) {
+        po = (2 * p1 + p0 + q1 + 2) >> 2;
+        qo = (2 * q1 + q0 + p1 + 2) >> 2;
+    } else {
+        const int d0 = CLIP3(-c0, c0, (4 * (q0 - p0) + p1 - q1 + 4) >> 3);
+        po = CLIP3(0, maxv, p0 + d0);
+        qo = CLIP3(0, maxv, q0 - d0);
+    }
+    buf[-step] = (int16_t)CLIP3(0, maxv, po); buf[0] = (int16_t)CLIP3(0, maxv, qo);
+    buf[-2 * step] = (int16_t)CLIP3(0, maxv, p1); buf[step] = (int16_t)CLIP3(0, maxv, q1);
+}
+
+/* one 4-sample segment of an 8x8-grid edge: deblock_addb_cu_hor (xevdm_df.c:893-944) / deblock_addb_cu_ver_yuv (:947-1034).
+   get_index() takes its arguments as u8 (xevdm_df.c:356-359): offsets and negative chroma QPs wrap like there. */
+static int addb_index(int qp, int offset) { return CLIP3(0, 51, (int)(uint8_t)qp + (int)(uint8_t)offset); }
+static void addb_segment(const xgpu_seq_params *sp, const orc_frame *fr, const orc_maps *m, int kq, int kp,
+                         int x_pel, int y_pel, int is_ver, int alpha_off, int beta_off)
+{
+    const int bdl = sp->bit_depth_luma, bdc = sp->bit_depth_chroma, scale = bdl - 8;
+    const int bs = is_ver ? addb_bs(sp, fr, m, kq, x_pel, y_pel, kp, x_pel - 1, y_pel) : addb_bs(sp, fr, m, kq, x_pel, y_pel, kp, x_pel, y_pel - 1);
+    const int qp = (MCU_QP(m->map_scu[kq]) + MCU_QP(m->map_scu[kp]) + 1) >> 1;
+    int ia = addb_index(qp, alpha_off), ib = addb_index(qp, beta_off);
+    int alpha = k_addb_alpha[ia] << scale, beta = (uint8_t)(k_addb_beta[ib] << scale);
+    int c1 = (uint8_t)(k_addb_clip[ia][bs] << (bdl - 9 > 0 ? bdl - 9 : 0));
+    int i, c;
+    int16_t *y = fr->cur.y + y_pel * fr->cur.s_l + x_pel;
+    for (i = 0; i < 4; i++)
+        addb_line_luma(is_ver ? y + i * fr->cur.s_l : y + i, is_ver ? 1 : fr->cur.s_l, bs, alpha, beta, c1, bdl);
+    for (c = 0; c < 2; c++) {
+        int16_t *pl = (c ? fr->cur.v : fr->cur.u) + (y_pel >> 1) * fr->cur.s_c + (x_pel >> 1);
+        const int boff = 6 * (bdc - 8);
+        int q = CLIP3(-boff, 57, qp + (c ? fr->qp_v_offset : fr->qp_u_offset));
+        int qc = sp->chroma_qp_table[c] ? sp->chroma_qp_table[c][q + boff] : (q < 0 ? q : k_chroma_qp_base[q]);
+        int c0;
+        ia = addb_index(qc, alpha_off); ib = addb_index(qc, beta_off);
+        alpha = k_addb_alpha[ia] << scale;                    /* luma bit depth scales chroma too, xevdm_df.c:926-927 */
+        beta = (uint8_t)(k_addb_beta[ib] << scale);
+        c0 = (uint8_t)((k_addb_clip[ia][bs] + 1) << (bdc - 9 > 0 ? bdc - 9 : 0));
+        for (i = 0; i < 2; i++)
+            addb_line_chroma(is_ver ? pl + i * fr->cur.s_c : pl + i, is_ver ? 1 : fr->cur.s_c, bs, alpha, beta, c0, bdc);
+    }
+}
+
+int orc_deblock_addb(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *m, int alpha_off, int beta_off)
+{
+    const int ws = m->w_scu;
+    int i, r, c, k;
+    /* vertical edges on the 8x8 luma grid (deblock_addb_cu_ver, xevdm_df.c:1036-1135), then horizontal (:835-945) */
+    for (k = 0; k < ws * m->h_scu; k++) m->map_scu[k] &= 0x7FFFFFFFu;
+    for (i = 0; i < b->n_cu; i++) {
+        const int x = b->x[i], y = b->y[i], w = 1 << b->log2w[i], h = 1 << b->log2h[i];
+        const int t = (x >> 2) + (y >> 2) * ws;
+        if ((x & 7) == 0 && x > 0 && MCU_COD(m->map_scu[t - 1]))
+            for (r = 0; r < h >> 2; r++) addb_segment(sp, fr, m, t + r * ws, t + r * ws - 1, x, y + 4 * r, 1, alpha_off, beta_off);
+        if (((x + w) & 7) == 0 && x + w < sp->width && MCU_COD(m->map_scu[t + (w >> 2)]))
+            for (r = 0; r < h >> 2; r++) addb_segment(sp, fr, m, t + r * ws + (w >> 2), t + r * ws + (w >> 2) - 1, x + w, y + 4 * r, 1, alpha_off, beta_off);
+        for (r = 0; r < h >> 2; r++) for (c = 0; c < w >> 2; c++) m->map_scu[t + r * ws + c] |= 1u << 31;
+    }
+    for (i = 0; i < b->n_cu; i++) {
+        const int x = b->x[i], y = b->y[i], w = 1 << b->log2w[i];
+        const int t = (x >> 2) + (y >> 2) * ws;
+        if ((y & 7) == 0 && y > 0)
+            for (c = 0; c < w >> 2; c++) addb_segment(sp, fr, m, t + c, t + c - ws, x + 4 * c, y, 0, alpha_off, beta_off);
+    }
+    return 0;
+}
+
 void orc_pad(const xgpu_seq_params *sp, const orc_pic *p)
 {
     int c, i, j;

@@ -16,6 +16,9 @@ CASES = [
     ("main_b_10b", 200, 136, 10, 1, 1, (2, 2), 0.5),
     ("main_admvp_only", 128, 64, 8, 1, 0, (1, 1), 0.4),
     ("main_iqt_only", 128, 72, 10, 0, 1, (1, 1), 0.4),
+    # Main-profile in-loop filters: (..., tools)
+    ("main_addb_10b", 200, 136, 10, 1, 1, (2, 2), 0.5, {"addb": 1}),
+    ("main_addb_8b_shared_refs", 136, 136, 8, 1, 1, (3, 3), 0.6, {"addb": 1}),
 ]
 POCS = [[4, 0, 2], [12, 16, 4]]      # L1 idx 2 has the POC of L0 idx 0 -> identical-motion candidates exist
 CUR_POC = 8
@@ -26,8 +29,9 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, seed=0, inter_frac=0.9, split_prob=0.5, qp_range=(20, 45),
+def build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, tools=None, seed=0, inter_frac=0.9, split_prob=0.5, qp_range=(20, 45),
                amp=2.0, oob_frac=0.1):
+    tools = dict(tools or {})
     rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000 + seed)
     refs = {}
     for l in range(2):
@@ -35,13 +39,17 @@ def build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, seed=0, inter_frac=0
             pic = ol.Picture(w, h, POCS[l][i], synth.gen_picture(rng, w, h, bd))
             pic.pad_numpy()
             refs[(i, l)] = pic
+    if (2, 1) in refs and (0, 0) in refs:
+        refs[(2, 1)] = refs[(0, 0)]      # the same picture in both lists (same POC 4): ADDB compares pictures, not indices
     batch = synth.gen_frame(rng, w, h, bd, inter_frac=inter_frac, bi_frac=bi_frac, n_refs=n_refs, oob_frac=oob_frac,
                             qp_range=qp_range, split_prob=split_prob, amp=amp)
     if n_refs[0] and n_refs[1]:      # force some identical-motion bi CUs
         sel = (batch["refi"][:, 0] >= 0) & (batch["refi"][:, 1] >= 0)
         idx = np.nonzero(sel)[0][::3]
         batch["mv"][idx, 1] = batch["mv"][idx, 0]
-    return {"name": name, "w": w, "h": h, "bd": bd, "admvp": admvp, "iqt": iqt, "refs": refs, "batch": batch}
+    return {"name": name, "w": w, "h": h, "bd": bd, "admvp": admvp, "iqt": iqt, "refs": refs, "batch": batch,
+            "addb": int(tools.get("addb", 0)), "alf": int(tools.get("alf", 0)),
+            "alpha_off": int(tools.get("alpha_off", 0)), "beta_off": int(tools.get("beta_off", 0))}
 
 
 def _start_picture(case):
@@ -54,7 +62,8 @@ def _start_picture(case):
 
 def run_cpu(engine, case, deblock=True, simd=0, pad=True):
     """engine 'oracle' (oracle/liboracle.so) or 'ref' (the real reference through oracle/_ref). -> (final, pre-deblock, maps, resid)"""
-    sp = abi.make_seq_params(case["w"], case["h"], case["bd"], iqt=case["iqt"], admvp=case["admvp"])
+    sp = abi.make_seq_params(case["w"], case["h"], case["bd"], iqt=case["iqt"], admvp=case["admvp"], addb=case.get("addb", 0),
+                             alf=case.get("alf", 0))
     cb, keep = abi.make_cu_batch(case["batch"])
     cur = _start_picture(case)
     maps = ol.Maps(case["w"], case["h"])
@@ -65,7 +74,9 @@ def run_cpu(engine, case, deblock=True, simd=0, pad=True):
         o = ol.oracle()
         o.orc_recon_batch(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), _p(resid))
         pre = cur.copy()
-        if deblock:
+        if deblock and case.get("addb"):
+            o.orc_deblock_addb(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), case["alpha_off"], case["beta_off"])
+        elif deblock:
             o.orc_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m))
         if pad:
             o.orc_pad(C.byref(sp), C.byref(fr.cur))
@@ -73,7 +84,9 @@ def run_cpu(engine, case, deblock=True, simd=0, pad=True):
         hn = ol.harness()
         hn.refh_recon_batch(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), _p(resid), simd)
         pre = cur.copy()
-        if deblock:
+        if deblock and case.get("addb"):
+            hn.refh_deblock_addb(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), case["alpha_off"], case["beta_off"])
+        elif deblock:
             hn.refh_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), simd)
         if pad:
             hn.refh_pad(C.byref(sp), C.byref(fr.cur))
@@ -83,15 +96,18 @@ def run_cpu(engine, case, deblock=True, simd=0, pad=True):
 def run_gpu(case, deblock=True, pad=True):
     """The HIP backend through the C ABI. -> list of padded planes (reference buffer geometry)"""
     from xevd_amd.decoder import XgpuDecoder
-    with XgpuDecoder(case["w"], case["h"], case["bd"], iqt=case["iqt"], admvp=case["admvp"], max_pics=8) as dec:
-        slots = {}
+    with XgpuDecoder(case["w"], case["h"], case["bd"], iqt=case["iqt"], admvp=case["admvp"], addb=case.get("addb", 0),
+                     alf=case.get("alf", 0), max_pics=8) as dec:
+        slots, by_obj = {}, {}
         for key, pic in case["refs"].items():
-            s = dec.pic_alloc()
-            dec.pic_upload_padded(s, pic.bufs)
-            slots[key] = (s, pic.poc)
+            if id(pic) not in by_obj:            # one device picture per distinct picture
+                by_obj[id(pic)] = dec.pic_alloc()
+                dec.pic_upload_padded(by_obj[id(pic)], pic.bufs)
+            slots[key] = (by_obj[id(pic)], pic.poc)
         cur = dec.pic_alloc()
         dec.pic_upload_padded(cur, _start_picture(case).bufs)
         hb = dec.batch_create(case["batch"])
-        dec.decode_picture(cur, CUR_POC, slots, hb, deblock=deblock, pad=pad, qp_u_offset=QP_OFFSETS[0], qp_v_offset=QP_OFFSETS[1])
+        dec.decode_picture(cur, CUR_POC, slots, hb, deblock=deblock, pad=pad, qp_u_offset=QP_OFFSETS[0], qp_v_offset=QP_OFFSETS[1],
+                           alpha_off=case.get("alpha_off", 0), beta_off=case.get("beta_off", 0))
         dec.sync()
         return dec.pic_download_padded(cur)

@@ -111,8 +111,14 @@ def golden_pictures():
     for case in cases.CASES:
         cs = cases.build_case(*case)
         final, pre, maps, resid = cases.run_cpu("ref", cs)
-        d = {"params": np.array(case[1:6], np.int64), "n_refs": np.array(case[6], np.int64)}
+        d = {"params": np.array(case[1:6], np.int64), "n_refs": np.array(case[6], np.int64),
+             "tools": np.array([cs["addb"], cs["alf"], cs["alpha_off"], cs["beta_off"]], np.int64)}
+        seen = {}
         for (i, l), pic in cs["refs"].items():
+            if id(pic) in seen:                       # the same picture in another list slot: store an alias
+                d[f"refalias_{i}_{l}"] = np.array(seen[id(pic)], np.int64)
+                continue
+            seen[id(pic)] = (i, l)
             for c in range(3):
                 d[f"ref_{i}_{l}_{c}"] = pic.active(c)
             d[f"refpoc_{i}_{l}"] = np.array(pic.poc)

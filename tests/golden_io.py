@@ -6,7 +6,8 @@ import numpy as np
 import oracle_lib as ol
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-PICTURE_CASES = ["base_p_8b", "base_b_8b", "base_p_10b", "main_b_10b", "main_admvp_only", "main_iqt_only"]
+PICTURE_CASES = ["base_p_8b", "base_b_8b", "base_p_10b", "main_b_10b", "main_admvp_only", "main_iqt_only",
+                 "main_addb_10b", "main_addb_8b_shared_refs"]
 
 
 def load_picture_case(name):
@@ -15,12 +16,20 @@ def load_picture_case(name):
     refs = {}
     for l in range(2):
         for i in range(int(d["n_refs"][l])):
+            if f"refalias_{i}_{l}" in d.files:
+                continue
             pic = ol.Picture(w, h, int(d[f"refpoc_{i}_{l}"]), [d[f"ref_{i}_{l}_{c}"] for c in range(3)])
             pic.pad_numpy()
             refs[(i, l)] = pic
+    for l in range(2):
+        for i in range(int(d["n_refs"][l])):
+            if f"refalias_{i}_{l}" in d.files:
+                refs[(i, l)] = refs[tuple(int(v) for v in d[f"refalias_{i}_{l}"])]
+    tools = [int(v) for v in d["tools"]] if "tools" in d.files else [0, 0, 0, 0]
     batch = {k[2:]: d[k] for k in d.files if k.startswith("b_")}
     batch["n_coef"] = int(batch["n_coef"])
-    case = {"name": name, "w": w, "h": h, "bd": bd, "admvp": admvp, "iqt": iqt, "refs": refs, "batch": batch}
+    case = {"name": name, "w": w, "h": h, "bd": bd, "admvp": admvp, "iqt": iqt, "refs": refs, "batch": batch,
+            "addb": tools[0], "alf": tools[1], "alpha_off": tools[2], "beta_off": tools[3]}
     expect = {"out": [d[f"out_{c}"] for c in range(3)], "pre": [d[f"pre_{c}"] for c in range(3)], "resid": d["resid"],
               "map_scu": d["map_scu"]}
     return case, expect

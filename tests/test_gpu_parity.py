@@ -88,7 +88,7 @@ RANDOM = [
 def test_gpu_vs_oracle_random(spec):
     *case, kw = spec
     for seed in range(2):
-        cs = cases.build_case(*case, seed=seed, **kw)
+        cs = cases.build_case(*case[:8], case[8] if len(case) > 8 else None, seed=seed, **kw)
         ref, _, _, _ = cases.run_cpu("oracle", cs)
         out = cases.run_gpu(cs)
         for c in range(3):
@@ -99,7 +99,7 @@ def test_gpu_vs_oracle_random(spec):
 def test_gpu_full_size_vs_oracle(size):
     """BASELINE.json picture sizes, whole pipeline, against the oracle (a few seconds of CPU)."""
     w, h = size
-    cs = cases.build_case("full", w, h, 8, 0, 0, (1, 0), 0.0, seed=w, inter_frac=0.95)
+    cs = cases.build_case("full", w, h, 8, 0, 0, (1, 0), 0.0, None, seed=w, inter_frac=0.95)
     ref, _, _, _ = cases.run_cpu("oracle", cs)
     out = cases.run_gpu(cs)
     for c in range(3):

@@ -189,6 +189,8 @@ def test_picture_level_oracle_equals_reference(case):
         assert np.array_equal(a.bufs[c], b.bufs[c]), f"deblocked+padded plane {c}"
     # the reference's AVX/SSE tables give the same picture on these conformant-range inputs (all-inter: the
     # SIMD recon kernels scribble past narrow blocks, which a real decode repairs with the next CU)
+    if cs["addb"]:
+        return      # ADDB is scalar C only in the reference
     cs1 = cases.build_case(*case, inter_frac=1.0)
     c0, _, _, r0 = cases.run_cpu("ref", cs1, simd=0)
     s0, _, _, r1 = cases.run_cpu("ref", cs1, simd=1)
@@ -200,9 +202,20 @@ def test_picture_level_oracle_equals_reference(case):
 @pytest.mark.parametrize("split_prob", [0.0, 1.0])
 def test_picture_level_extreme_partitions(split_prob):
     """all-64x64 CUs and all-4x4 CUs (the longest chroma deblocking dependency chains)"""
-    cs = cases.build_case("extreme", 136, 72, 8, 0, 0, (1, 1), 0.3, seed=int(split_prob), split_prob=split_prob, qp_range=(30, 50))
+    cs = cases.build_case("extreme", 136, 72, 8, 0, 0, (1, 1), 0.3, None, seed=int(split_prob), split_prob=split_prob, qp_range=(30, 50))
     a, _, _, ra = cases.run_cpu("oracle", cs)
     b, _, _, rb = cases.run_cpu("ref", cs)
     assert np.array_equal(ra, rb)
     for c in range(3):
         assert np.array_equal(a.bufs[c], b.bufs[c])
+
+
+@pytest.mark.parametrize("offs", [(0, 0), (6, -4), (-6, 5)])
+def test_addb_with_slice_offsets_and_high_qp(offs):
+    """alpha/beta offsets go through get_index()'s u8 arguments (negative ones saturate the index); QP up to 51"""
+    cs = cases.build_case("addb_offs", 136, 72, 10, 1, 1, (2, 2), 0.5, {"addb": 1, "alpha_off": offs[0], "beta_off": offs[1]},
+                          seed=offs[0] + 7, qp_range=(30, 51))
+    a, _, _, _ = cases.run_cpu("oracle", cs)
+    b, _, _, _ = cases.run_cpu("ref", cs)
+    for c in range(3):
+        assert np.array_equal(a.bufs[c], b.bufs[c]), f"plane {c}"

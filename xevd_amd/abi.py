@@ -34,6 +34,7 @@ class FrameParams(C.Structure):
         ("refp_pic", (C.c_int * 2) * XGPU_MAX_REFS), ("refp_poc", (C.c_int * 2) * XGPU_MAX_REFS),
         ("qp_u_offset", C.c_int), ("qp_v_offset", C.c_int),
         ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int),
+        ("deblock_on", C.c_int), ("alf_on", C.c_int),
     ]
 
 

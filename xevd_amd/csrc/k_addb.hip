@@ -1,0 +1,238 @@
+// k_addb.hip - ADDB deblocking (Main profile, sps->tool_addb), vertical-edge pass and horizontal-edge pass.
+//
+// Replaces xevdm_deblock -> deblock_tree -> xevdm_deblock_cu_ver / _hor -> deblock_addb_cu_* -> deblock_scu_line_*
+// (src_main/xevdm.c:1935-2103, src_main/xevdm_df.c:361-1135).  Semantics reproduced: only CU edges on the 8x8 luma
+// grid; boundary strength 0..4 from intra / CTU crossing / luma cbf / reference PICTURES + MVs (get_bs); QP =
+// average of both sides; alpha/beta/clip tables indexed through get_index()'s u8 arguments; luma strong (bS 4)
+// and normal filters over 3 samples per side, chroma over 1; all vertical edges before all horizontal ones.
+//
+// MI355X mapping - same order-free out-of-place scheme as the baseline filter (k_deblock.hip): each pass reads
+// SRC and writes DST, one LANE per 4x4 SCU writes exactly its own 16 luma + 2x4 chroma samples.  Grid edges are 8
+// samples apart and touch 3 samples per side, so edges never interact: the SCU left of / above an edge is its P
+// side, the SCU right of / below it its Q side; both lanes load the same aligned 8-sample window across the
+// edge, evaluate the same line filter and keep their half.  All loads (two SCU records, luma and chroma windows)
+// are issued before any decision, the decisions are lane-local integer tests, tables sit in LDS.
+#include "xgpu_internal.h"
+
+struct __attribute__((packed, aligned(8))) U32x4a8 { uint32_t a, b, c, d; };
+struct __attribute__((packed, aligned(4))) U32x2a4 { uint32_t a, b; };
+
+__device__ __forceinline__ int clip3a(int lo, int hi, int v) { return min(max(v, lo), hi); }
+
+// ALPHA_TABLE / BETA_TABLE / CLIP_TAB (src_main/xevdm_tbl.c:377-379) - tables of the EVC specification
+__constant__ uint8_t k_alpha[52] = { 0,0,0,0,0,0,0,0,0,0,0,0, 0,0,0,0,4,4,5,6, 7,8,9,10,12,13,15,17, 20,22,25,28,32,36,40,45,
+    50,56,63,71,80,90,101,113, 127,144,162,182,203,226,255,255 };
+__constant__ uint8_t k_beta[52] = { 0,0,0,0,0,0,0,0,0,0,0,0, 0,0,0,0,2,2,2,3, 3,3,3,4,4,4,6,6, 7,7,8,8,9,9,10,10,
+    11,11,12,12,13,13,14,14, 15,15,16,16,17,17,18,18 };
+__constant__ uint8_t k_clip[52][5] = {
+    {0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},
+    {0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},
+    {0,0,0,0,0},{0,0,0,1,1},{0,0,0,1,1},{0,0,0,1,1},{0,0,0,1,1},{0,0,1,1,1},{0,0,1,1,1},{0,1,1,1,1},
+    {0,1,1,1,1},{0,1,1,1,1},{0,1,1,1,1},{0,1,1,2,2},{0,1,1,2,2},{0,1,1,2,2},{0,1,1,2,2},{0,1,2,3,3},
+    {0,1,2,3,3},{0,2,2,3,3},{0,2,2,4,4},{0,2,3,4,4},{0,2,3,4,4},{0,3,3,5,5},{0,3,4,6,6},{0,3,4,6,6},
+    {0,4,5,7,7},{0,4,5,8,8},{0,4,6,9,9},{0,5,7,10,10},{0,6,8,11,11},{0,6,8,13,13},{0,7,10,14,14},{0,8,11,16,16},
+    {0,9,12,18,18},{0,10,13,20,20},{0,11,15,23,23},{0,13,17,25,25} };
+
+// get_bs, xevdm_df.c:361-513.  q = record of the right/below SCU, p = left/above; cross_ctu: the edge lies on a CTU boundary.
+__device__ __forceinline__ int addb_bs(const uint4 q, const uint4 p, bool cross_ctu, const uint8_t *pic_id)
+{
+    const bool intra = ((q.x | p.x) >> 15) & 1;
+    if (intra) return cross_ctu ? 4 : 3;
+    if (((q.x | p.x) >> 24) & 1) return 2;
+    const int q0 = (int8_t)(q.y & 0xFF), q1 = (int8_t)((q.y >> 8) & 0xFF), p0 = (int8_t)(p.y & 0xFF), p1 = (int8_t)((p.y >> 8) & 0xFF);
+    // reference pictures by identity (XEVD_PIC pointers in the reference): device picture slot, 255 = none
+    const int Q0 = q0 >= 0 ? pic_id[q0 * 2] : 255, Q1 = q1 >= 0 ? pic_id[q1 * 2 + 1] : 255;
+    const int P0 = p0 >= 0 ? pic_id[p0 * 2] : 255, P1 = p1 >= 0 ? pic_id[p1 * 2 + 1] : 255;
+    const int qm[2][2] = { { q0 >= 0 ? (int16_t)(q.z & 0xFFFF) : 0, q0 >= 0 ? (int16_t)(q.z >> 16) : 0 },
+                           { q1 >= 0 ? (int16_t)(q.w & 0xFFFF) : 0, q1 >= 0 ? (int16_t)(q.w >> 16) : 0 } };
+    const int pm[2][2] = { { p0 >= 0 ? (int16_t)(p.z & 0xFFFF) : 0, p0 >= 0 ? (int16_t)(p.z >> 16) : 0 },
+                           { p1 >= 0 ? (int16_t)(p.w & 0xFFFF) : 0, p1 >= 0 ? (int16_t)(p.w >> 16) : 0 } };
+#define MVSAME(a, b) (abs((a)[0] - (b)[0]) < 4 && abs((a)[1] - (b)[1]) < 4)
+    if ((Q0 == P0 && Q1 == P1) || (Q0 == P1 && Q1 == P0)) {
+        if (Q0 == Q1) return (MVSAME(qm[0], pm[0]) && MVSAME(qm[1], pm[1]) && MVSAME(qm[0], pm[1]) && MVSAME(qm[1], pm[0])) ? 0 : 1;
+        if (Q0 == P0 && Q1 == P1) return (MVSAME(qm[0], pm[0]) && MVSAME(qm[1], pm[1])) ? 0 : 1;
+        return (MVSAME(qm[0], pm[1]) && MVSAME(qm[1], pm[0])) ? 0 : 1;
+    }
+    return 1;
+#undef MVSAME
+}
+
+// deblock_scu_line_luma, xevdm_df.c:584-709.  s[0..3] = p3 p2 p1 p0, s[4..7] = q0 q1 q2 q3; in place.
+__device__ __forceinline__ void addb_line_luma(int s[8], int bs, int alpha, int beta, int c1, int bd, int maxv)
+{
+    const int p0 = s[3], p1 = s[2], p2 = s[1], p3 = s[0], q0 = s[4], q1 = s[5], q2 = s[6], q3 = s[7];
+    if (!(bs && abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta)) return;
+    const int ap = abs(p0 - p2) < beta, aq = abs(q0 - q2) < beta;
+    int po0 = p0, po1 = p1, po2 = p2, qo0 = q0, qo1 = q1, qo2 = q2;
+    if (bs == 4) {
+        const bool strong = abs(p0 - q0) < ((alpha >> 2) + 2);
+        if (ap && strong) {
+            po0 = (p2 + 2 * (p1 + p0 + q0) + q1 + 4) >> 3;
+            po1 = (p2 + p1 + p0 + q0 + 2) >> 2;
+            po2 = (2 * p3 + 3 * p2 + p1 + p0 + q0 + 4) >> 3;
+        } else po0 = (2 * p1 + p0 + q1 + 2) >> 2;
+        if (aq && strong) {
+            qo0 = (q2 + 2 * (q1 + q0 + p0) + p1 + 4) >> 3;
+            qo1 = (q2 + q1 + q0 + p0 + 2) >> 2;
+            qo2 = (2 * q3 + 3 * q2 + q1 + q0 + p0 + 4) >> 3;
+        } else qo0 = (2 * q1 + q0 + p1 + 2) >> 2;
+    } else {
+        const int c0 = (c1 + ((ap + aq) << max(0, bd - 9))) & 0xFF;          // u8 c0, xevdm_df.c:650
+        const int d0 = clip3a(-c0, c0, (4 * (q0 - p0) + p1 - q1 + 4) >> 3);
+        po0 = clip3a(0, maxv, p0 + d0);
+        qo0 = clip3a(0, maxv, q0 - d0);
+        if (ap) po1 = p1 + clip3a(-c1, c1, (((p2 + p0 + q0) * 3) - 8 * p1 - q1) >> 4);
+        if (aq) qo1 = q1 + clip3a(-c1, c1, (((q2 + q0 + p0) * 3) - 8 * q1 - p1) >> 4);
+    }
+    s[3] = clip3a(0, maxv, (int)(int16_t)po0); s[2] = clip3a(0, maxv, (int)(int16_t)po1); s[1] = clip3a(0, maxv, (int)(int16_t)po2);
+    s[4] = clip3a(0, maxv, (int)(int16_t)qo0); s[5] = clip3a(0, maxv, (int)(int16_t)qo1); s[6] = clip3a(0, maxv, (int)(int16_t)qo2);
+}
+// deblock_scu_line_chroma, xevdm_df.c:710-781.  s = p1 p0 q0 q1; only p0, q0 change.
+__device__ __forceinline__ void addb_line_chroma(int s[4], int bs, int alpha, int beta, int c0, int maxv)
+{
+    const int p1 = s[0], p0 = s[1], q0 = s[2], q1 = s[3];
+    if (!(bs && abs(p0 - q0) < alpha && abs(p1 - p0) < beta && abs(q1 - q0) < beta)) return;
+    if (bs == 4) {
+        s[1] = clip3a(0, maxv, (2 * p1 + p0 + q1 + 2) >> 2);
+        s[2] = clip3a(0, maxv, (2 * q1 + q0 + p1 + 2) >> 2);
+    } else {
+        const int d0 = clip3a(-c0, c0, (4 * (q0 - p0) + p1 - q1 + 4) >> 3);
+        s[1] = clip3a(0, maxv, p0 + d0);
+        s[2] = clip3a(0, maxv, q0 - d0);
+    }
+}
+
+__device__ __forceinline__ int addb_index(int qp, int offset) { return clip3a(0, 51, (qp & 0xFF) + (offset & 0xFF)); }   // u8 arguments
+
+template <int DIR>
+__global__ __launch_bounds__(256) void k_addb(const AddbArgs a, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
+                                              const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_,
+                                              int16_t *__restrict__ dv_)
+{
+    __shared__ uint8_t s_alpha[52], s_beta[52], s_clip[52 * 5], s_pic[XGPU_MAX_REFS * 2];
+    __shared__ int8_t s_cqp[2 * 96];
+    for (int i = threadIdx.x; i < 52; i += 256) { s_alpha[i] = k_alpha[i]; s_beta[i] = k_beta[i]; }
+    for (int i = threadIdx.x; i < 260; i += 256) s_clip[i] = ((const uint8_t *)k_clip)[i];
+    for (int i = threadIdx.x; i < XGPU_MAX_REFS * 2; i += 256) s_pic[i] = a.pic_id[i];
+    for (int i = threadIdx.x; i < 192; i += 256) s_cqp[i] = a.chroma_qp[i];
+    __syncthreads();
+
+    const int tiles_x = (a.w_scu + 15) >> 4;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int sx = (tx << 4) + (threadIdx.x & 15), sy = (ty << 4) + (threadIdx.x >> 4);
+    if (sx >= a.w_scu || sy >= a.h_scu) return;
+    const int step = DIR == 0 ? 1 : a.w_scu;
+    const int pos = DIR == 0 ? sx : sy, npos = DIR == 0 ? a.w_scu : a.h_scu;
+    const uint32_t eflag = DIR == 0 ? SCU_EDGE_L : SCU_EDGE_T;
+    const uint4 *maps = (const uint4 *)a.maps;
+    const int odd = pos & 1;                        // odd SCU = P side of the grid edge at pos+1, even SCU = Q side of the edge at pos
+    const int eq = pos + odd;                       // SCU index (along the axis) of the edge's Q side
+    const bool in_range = eq > 0 && eq < npos;
+    const int k0 = sy * a.w_scu + sx;
+    const int kq = in_range ? k0 + odd * step : k0, kp = in_range ? kq - step : k0;
+    const int maxl = (1 << a.bd_l) - 1, maxc = (1 << a.bd_c) - 1;
+
+    // ---- all loads first ----
+    const uint4 rq = maps[kq], rp = maps[kp];
+    const int x = sx << 2, y = sy << 2, cx = sx << 1, cy = sy << 1;
+    const int xe = DIR == 0 ? (eq << 2) : x, ye = DIR == 0 ? y : (eq << 2);        // luma position of the edge segment (Q side origin)
+    int L[4][8];          // 4 lines x (p3 p2 p1 p0 q0 q1 q2 q3)
+    int Cc[2][2][4];      // [plane][line][p1 p0 q0 q1]
+    if (DIR == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const U32x4a8 v = *(const U32x4a8 *)(sy_ + (y + r) * a.s_l + xe - 4);
+            L[r][0] = (int16_t)(v.a & 0xFFFF); L[r][1] = (int16_t)(v.a >> 16); L[r][2] = (int16_t)(v.b & 0xFFFF); L[r][3] = (int16_t)(v.b >> 16);
+            L[r][4] = (int16_t)(v.c & 0xFFFF); L[r][5] = (int16_t)(v.c >> 16); L[r][6] = (int16_t)(v.d & 0xFFFF); L[r][7] = (int16_t)(v.d >> 16);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const U32x2a4 v = *(const U32x2a4 *)((pl ? sv_ : su_) + (cy + r) * a.s_c + (xe >> 1) - 2);
+                Cc[pl][r][0] = (int16_t)(v.a & 0xFFFF); Cc[pl][r][1] = (int16_t)(v.a >> 16);
+                Cc[pl][r][2] = (int16_t)(v.b & 0xFFFF); Cc[pl][r][3] = (int16_t)(v.b >> 16);
+            }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const uint2 v = *(const uint2 *)(sy_ + (ye - 4 + r) * a.s_l + x);
+            L[0][r] = (int16_t)(v.x & 0xFFFF); L[1][r] = (int16_t)(v.x >> 16); L[2][r] = (int16_t)(v.y & 0xFFFF); L[3][r] = (int16_t)(v.y >> 16);
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const uint32_t v = *(const uint32_t *)((pl ? sv_ : su_) + ((ye >> 1) - 2 + r) * a.s_c + cx);
+                Cc[pl][0][r] = (int16_t)(v & 0xFFFF); Cc[pl][1][r] = (int16_t)(v >> 16);
+            }
+    }
+
+    // ---- decisions (deblock_addb_cu_hor :893-944 / deblock_addb_cu_ver_yuv :947-1034) ----
+    if (in_range && (rq.x & eflag)) {
+        const int epos = eq << 2;
+        const bool cross = (epos & ((1 << a.log2_ctu) - 1)) == 0;
+        const int bs = addb_bs(rq, rp, cross, s_pic);
+        const int qp = (((rq.x >> 16) & 0x7F) + ((rp.x >> 16) & 0x7F) + 1) >> 1;
+        const int scale = a.bd_l - 8;
+        {
+            const int ia = addb_index(qp, a.alpha_off), ib = addb_index(qp, a.beta_off);
+            const int alpha = s_alpha[ia] << scale, beta = (s_beta[ib] << scale) & 0xFF;
+            const int c1 = (s_clip[ia * 5 + bs] << max(0, a.bd_l - 9)) & 0xFF;
+#pragma unroll
+            for (int r = 0; r < 4; r++) addb_line_luma(L[r], bs, alpha, beta, c1, a.bd_l, maxl);
+        }
+        const int boff = 6 * (a.bd_c - 8);
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++) {
+            const int q = clip3a(-boff, 57, qp + (pl ? a.qp_v_off : a.qp_u_off));
+            const int qc = s_cqp[pl * 96 + q + boff];
+            const int ia = addb_index(qc, a.alpha_off), ib = addb_index(qc, a.beta_off);
+            const int alpha = s_alpha[ia] << scale, beta = (s_beta[ib] << scale) & 0xFF;      // luma depth scales chroma too (:926-927)
+            const int c0 = ((s_clip[ia * 5 + bs] + 1) << max(0, a.bd_c - 9)) & 0xFF;
+#pragma unroll
+            for (int r = 0; r < 2; r++) addb_line_chroma(Cc[pl][r], bs, alpha, beta, c0, maxc);
+        }
+    }
+
+    // ---- every lane writes its own SCU: the P half (odd) or the Q half (even) of the window ----
+    const int h0 = odd ? 0 : 4;
+    if (DIR == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            uint2 w;
+            w.x = (uint32_t)(uint16_t)L[r][h0 + 0] | ((uint32_t)(uint16_t)L[r][h0 + 1] << 16);
+            w.y = (uint32_t)(uint16_t)L[r][h0 + 2] | ((uint32_t)(uint16_t)L[r][h0 + 3] << 16);
+            *(uint2 *)(dy_ + (y + r) * a.s_l + x) = w;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+                *(uint32_t *)((pl ? dv_ : du_) + (cy + r) * a.s_c + cx) =
+                    (uint32_t)(uint16_t)Cc[pl][r][odd ? 0 : 2] | ((uint32_t)(uint16_t)Cc[pl][r][odd ? 1 : 3] << 16);
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            uint2 w;
+            w.x = (uint32_t)(uint16_t)L[0][h0 + r] | ((uint32_t)(uint16_t)L[1][h0 + r] << 16);
+            w.y = (uint32_t)(uint16_t)L[2][h0 + r] | ((uint32_t)(uint16_t)L[3][h0 + r] << 16);
+            *(uint2 *)(dy_ + (y + r) * a.s_l + x) = w;
+        }
+#pragma unroll
+        for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+                *(uint32_t *)((pl ? dv_ : du_) + (cy + r) * a.s_c + cx) =
+                    (uint32_t)(uint16_t)Cc[pl][0][(odd ? 0 : 2) + r] | ((uint32_t)(uint16_t)Cc[pl][1][(odd ? 0 : 2) + r] << 16);
+    }
+}
+
+void launch_addb(xgpu_ctx *c, const AddbArgs &a, int dir, const DevPic &src, const DevPic &dst)
+{
+    const int tiles = ((a.w_scu + 15) >> 4) * ((a.h_scu + 15) >> 4);
+    if (dir == 0)
+        hipLaunchKernelGGL(k_addb<0>, dim3(tiles), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
+    else
+        hipLaunchKernelGGL(k_addb<1>, dim3(tiles), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
+}

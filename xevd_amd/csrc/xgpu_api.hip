@@ -276,6 +276,7 @@ int xgpu_frame_begin(xgpu_ctx *c, const xgpu_frame_params *fp)
     }
     c->fp = *fp;
     c->have_frame = 1;
+    c->where = 0;
     return XGPU_OK;
 }
 
@@ -283,6 +284,12 @@ int xgpu_frame_end(xgpu_ctx *c)
 {
     ARGCHK(c, c != NULL);
     c->have_frame = 0;
+    if (c->where != 0) {
+        snprintf(c->err, sizeof(c->err), "frame_end: the in-loop filters announced in xgpu_frame_params (deblock_on=%d alf_on=%d) were not all run",
+                 c->fp.deblock_on, c->fp.alf_on);
+        c->where = 0;
+        return XGPU_ERR_UNEXPECTED;
+    }
     return XGPU_OK;
 }
 
@@ -409,7 +416,10 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
 
     InterArgs a;
     memset(&a, 0, sizeof(a));
-    DevPic &cur = dpic(c, c->fp.pic);
+    // out-of-place filter chain: 2 passes of deblocking + 1 of ALF must end in the DPB slot -> start in the scratch
+    // picture when the number of passes is odd
+    c->where = (2 * (c->fp.deblock_on ? 1 : 0) + (c->fp.alf_on ? 1 : 0)) & 1;
+    DevPic &cur = c->where ? c->pics[0] : dpic(c, c->fp.pic);
     a.cur_y = cur.y; a.cur_u = cur.u; a.cur_v = cur.v;
     a.s_l = c->s_l; a.s_c = c->s_c; a.pic_w = c->sp.width; a.pic_h = c->sp.height;
     a.bd_l = c->sp.bit_depth_luma; a.bd_c = c->sp.bit_depth_chroma;
@@ -421,7 +431,7 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
     a.maps = c->d_maps; a.w_scu = c->w_scu;
     for (int l = 0; l < 2; l++)
         for (int i = 0; i < XGPU_MAX_REFS; i++) {
-            const DevPic &rp = i < c->fp.num_refp[l] ? dpic(c, c->fp.refp_pic[i][l]) : cur;
+            const DevPic &rp = i < c->fp.num_refp[l] ? dpic(c, c->fp.refp_pic[i][l]) : dpic(c, c->fp.pic);
             a.refp[i][l].y = rp.y; a.refp[i][l].u = rp.u; a.refp[i][l].v = rp.v;
             a.refp[i][l].poc = i < c->fp.num_refp[l] ? c->fp.refp_poc[i][l] : 0;
         }
@@ -432,33 +442,47 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
 
 int xgpu_deblock(xgpu_ctx *c)
 {
-    ARGCHK(c, c != NULL); ARGCHK(c, c->have_frame);
-    if (c->sp.tool_addb) { snprintf(c->err, sizeof(c->err), "ADDB deblocking is not implemented yet"); return XGPU_ERR_UNSUPPORTED; }
-    DbkArgs a;
-    memset(&a, 0, sizeof(a));
-    a.s_l = c->s_l; a.s_c = c->s_c; a.pic_w = c->sp.width; a.pic_h = c->sp.height; a.w_scu = c->w_scu; a.h_scu = c->h_scu;
-    a.bd_l = c->sp.bit_depth_luma; a.bd_c = c->sp.bit_depth_chroma; a.maps = c->d_maps;
-    // strength LUT: xevd_df.c:347-365 with the table index clamped to 0..51 (see oracle chroma_qp())
+    ARGCHK(c, c != NULL); ARGCHK(c, c->have_frame); ARGCHK(c, c->fp.deblock_on);
+    DevPic &slot = dpic(c, c->fp.pic), &scratch = c->pics[0];
+    DevPic &first = c->where ? scratch : slot, &second = c->where ? slot : scratch;      // first -> second -> first
     const int boff = 6 * (c->sp.bit_depth_chroma - 8);
-    for (int cls = 0; cls < 4; cls++)
-        for (int qp = 0; qp < 64; qp++) {
-            a.st[0][cls][qp] = (uint8_t)(k_df_st[cls][std::min(qp, 51)] << (c->sp.bit_depth_luma - 8));
-            for (int t = 0; t < 2; t++) {
-                const int q = std::min(std::max(qp + (t ? c->fp.qp_v_offset : c->fp.qp_u_offset), -boff), 57);
-                const int v = std::min(std::max((int)c->chroma_qp[t][q + boff], 0), 51);
-                a.st[1 + t][cls][qp] = (uint8_t)(k_df_st[cls][v] << (c->sp.bit_depth_chroma - 8));
+    if (c->sp.tool_addb) {
+        AddbArgs a;
+        memset(&a, 0, sizeof(a));
+        a.s_l = c->s_l; a.s_c = c->s_c; a.w_scu = c->w_scu; a.h_scu = c->h_scu;
+        a.bd_l = c->sp.bit_depth_luma; a.bd_c = c->sp.bit_depth_chroma; a.log2_ctu = c->sp.log2_ctu;
+        a.alpha_off = c->fp.deblock_alpha_offset; a.beta_off = c->fp.deblock_beta_offset;
+        a.qp_u_off = c->fp.qp_u_offset; a.qp_v_off = c->fp.qp_v_offset; a.maps = c->d_maps;
+        memcpy(a.chroma_qp, c->chroma_qp, sizeof(a.chroma_qp));
+        for (int l = 0; l < 2; l++)
+            for (int i = 0; i < XGPU_MAX_REFS; i++) a.pic_id[i * 2 + l] = i < c->fp.num_refp[l] ? (uint8_t)c->fp.refp_pic[i][l] : 255;
+        TIMED(c, XGPU_K_DBK_V, launch_addb(c, a, 0, first, second));
+        TIMED(c, XGPU_K_DBK_H, launch_addb(c, a, 1, second, first));
+    } else {
+        DbkArgs a;
+        memset(&a, 0, sizeof(a));
+        a.s_l = c->s_l; a.s_c = c->s_c; a.pic_w = c->sp.width; a.pic_h = c->sp.height; a.w_scu = c->w_scu; a.h_scu = c->h_scu;
+        a.bd_l = c->sp.bit_depth_luma; a.bd_c = c->sp.bit_depth_chroma; a.maps = c->d_maps;
+        // strength LUT: xevd_df.c:347-365 with the table index clamped to 0..51 (see oracle chroma_qp())
+        for (int cls = 0; cls < 4; cls++)
+            for (int qp = 0; qp < 64; qp++) {
+                a.st[0][cls][qp] = (uint8_t)(k_df_st[cls][std::min(qp, 51)] << (c->sp.bit_depth_luma - 8));
+                for (int t = 0; t < 2; t++) {
+                    const int q = std::min(std::max(qp + (t ? c->fp.qp_v_offset : c->fp.qp_u_offset), -boff), 57);
+                    const int v = std::min(std::max((int)c->chroma_qp[t][q + boff], 0), 51);
+                    a.st[1 + t][cls][qp] = (uint8_t)(k_df_st[cls][v] << (c->sp.bit_depth_chroma - 8));
+                }
             }
-        }
-    DevPic &cur = dpic(c, c->fp.pic);
-    TIMED(c, XGPU_K_DBK_V, launch_dbk(c, a, 0, cur, c->pics[0]));
-    TIMED(c, XGPU_K_DBK_H, launch_dbk(c, a, 1, c->pics[0], cur));
+        TIMED(c, XGPU_K_DBK_V, launch_dbk(c, a, 0, first, second));
+        TIMED(c, XGPU_K_DBK_H, launch_dbk(c, a, 1, second, first));
+    }
     HIPCHK(c, hipGetLastError());
     return XGPU_OK;
 }
 
 int xgpu_pad(xgpu_ctx *c)
 {
-    ARGCHK(c, c != NULL); ARGCHK(c, c->have_frame);
+    ARGCHK(c, c != NULL); ARGCHK(c, c->have_frame); ARGCHK(c, c->where == 0);
     TIMED(c, XGPU_K_PAD, launch_pad(c, dpic(c, c->fp.pic)));
     HIPCHK(c, hipGetLastError());
     return XGPU_OK;

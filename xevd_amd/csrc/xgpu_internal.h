@@ -103,6 +103,16 @@ struct DbkArgs {
     uint8_t  st[3][4][64];             // strength by component, edge class, map QP (host-built from xevd_tbl_df_st)
 };
 
+struct AddbArgs {
+    int      s_l, s_c;
+    int      w_scu, h_scu;
+    int      bd_l, bd_c, log2_ctu;
+    int      alpha_off, beta_off, qp_u_off, qp_v_off;
+    const ScuRec *maps;
+    int8_t   chroma_qp[2 * 96];        // [c][qp + 6*(bdc-8)]
+    uint8_t  pic_id[XGPU_MAX_REFS * 2];// picture slot of refp[idx][list], 255 = none
+};
+
 struct xgpu_dbatch {
     int        n_cu, n_ctu, n_tb, n_waves;
     size_t     n_coef;
@@ -126,6 +136,7 @@ struct xgpu_ctx {
     ScuRec         *d_maps;
     xgpu_frame_params fp;
     int             have_frame;
+    int             where;             // 0: the picture being built lives in its DPB slot, 1: in the scratch picture
     // timing
     int             timing;
     struct Ev { hipEvent_t a, b; int k; };
@@ -142,6 +153,7 @@ void launch_inter(xgpu_ctx *c, const InterArgs &a);
 void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst);
 void upload_transform_tables(const int *tm, hipStream_t s);
 int  itdq_group_size(int log2w, int log2h);     // TBs of one size class per 256-thread work item
+void launch_addb(xgpu_ctx *c, const AddbArgs &a, int dir, const DevPic &src, const DevPic &dst);
 void launch_pad(xgpu_ctx *c, const DevPic &p);
 void launch_copy_bw(xgpu_ctx *c, const void *src, void *dst, size_t bytes);
 void launch_test_mc(xgpu_ctx *c, const int16_t *plane, int stride, int ref_x, int ref_y, int has_dx, int has_dy,

@@ -88,7 +88,7 @@ class XgpuDecoder:
         return [y, u, v]
 
     # -- per picture ---------------------------------------------------------------------------------
-    def frame_begin(self, pic, poc, refs, qp_u_offset=0, qp_v_offset=0):
+    def frame_begin(self, pic, poc, refs, qp_u_offset=0, qp_v_offset=0, deblock_on=0, alf_on=0, alpha_off=0, beta_off=0):
         """refs: {(idx, list): (pic_slot, poc)}"""
         fp = abi.FrameParams()
         fp.pic, fp.poc = pic, poc
@@ -99,6 +99,8 @@ class XgpuDecoder:
             fp.refp_pic[i][l] = slot
             fp.refp_poc[i][l] = rpoc
         fp.qp_u_offset, fp.qp_v_offset = qp_u_offset, qp_v_offset
+        fp.deblock_alpha_offset, fp.deblock_beta_offset = alpha_off, beta_off
+        fp.deblock_on, fp.alf_on = int(deblock_on), int(alf_on)
         self._chk(self.lib.xgpu_frame_begin(self.ctx, C.byref(fp)), "xgpu_frame_begin")
 
     def batch_create(self, batch):
@@ -124,12 +126,16 @@ class XgpuDecoder:
     def frame_end(self):
         self._chk(self.lib.xgpu_frame_end(self.ctx), "xgpu_frame_end")
 
-    def decode_picture(self, pic, poc, refs, batch_handle, deblock=True, pad=True, qp_u_offset=0, qp_v_offset=0):
-        """The coarse sequence of xevd_dec_nalu for one picture (src_base/xevd.c:1905-1983)."""
-        self.frame_begin(pic, poc, refs, qp_u_offset, qp_v_offset)
+    def decode_picture(self, pic, poc, refs, batch_handle, deblock=True, pad=True, qp_u_offset=0, qp_v_offset=0,
+                       alpha_off=0, beta_off=0, alf=None):
+        """The coarse sequence of xevd_dec_nalu for one picture (src_base/xevd.c:1905-1983, src_main/xevdm.c:3136-3219)."""
+        self.frame_begin(pic, poc, refs, qp_u_offset, qp_v_offset, deblock_on=deblock, alf_on=alf is not None,
+                         alpha_off=alpha_off, beta_off=beta_off)
         self.batch_recon(batch_handle)
         if deblock:
             self.deblock()
+        if alf is not None:
+            self.alf(alf)
         if pad:
             self.pad()
         self.frame_end()
