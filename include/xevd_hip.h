@@ -13,6 +13,7 @@
  *                                                                                 src_base/xevd.c:1470-1526, 678-756
  *                                    (xevd_sub_block_itdq, xevd_mc, xevd_recon_yuv, xevd_set_dec_info)
  *   xgpu_deblock                  <- ctx->fn_deblock (xevd_deblock)              src_base/xevd.c:1116-1243,1909-1976
+ *   xgpu_alf                      <- mctx->fn_alf (xevd_alf -> alf_process)      src_main/xevdm.c:2105, xevdm_alf.c:901-1249
  *   xgpu_pad                      <- ctx->fn_picbuf_expand                       src_base/xevd_util.c:365-427
  *   xgpu_pic_download             <- xevd_pull (picture hand-off)                src_base/xevd.c:2042-2071
  *
@@ -88,6 +89,16 @@ typedef struct xgpu_frame_params {
     int deblock_on, alf_on;
 } xgpu_frame_params;
 
+/* Adaptive loop filter parameters of one picture: what alf_process has after alf_recon_coef
+   (src_main/xevdm_alf.c:700-794, 1167-1195) - coefficient reconstruction from the APS stays on the host. */
+typedef struct xgpu_alf_params {
+    int            enable[3];     /* alf_slice_param.enable_flag[Y, U, V]                                    */
+    const int16_t *luma_coef;     /* alf->coef_final: [25 classes][13] 7x7-diamond coefficients              */
+    const int16_t *chroma_coef;   /* alf_slice_param.chroma_coef: [7] 5x5-diamond coefficients               */
+    const uint8_t *ctb_flag;      /* alf_ctb_flag of the luma plane, [n_ctu] raster; NULL = every CTU on     */
+    int            across_tiles;  /* pps.loop_filter_across_tiles_enabled_flag (changes right/bottom borders) */
+} xgpu_alf_params;
+
 /*
  * One batch of decoded CUs (one tile or one picture), structure-of-arrays, in decode order, grouped by CTU.
  * It is the post-entropy-decode record set of XEVD_CU_DATA (src_base/xevd_def.h:1145-1190) after MV
@@ -139,6 +150,8 @@ void xgpu_batch_destroy(xgpu_ctx *ctx, xgpu_dbatch *db);
 int  xgpu_batch_recon(xgpu_ctx *ctx, xgpu_dbatch *db);
 /* both deblocking passes over the current picture (vertical edges, then horizontal edges)               */
 int  xgpu_deblock(xgpu_ctx *ctx);
+/* adaptive loop filter: 4x4 block classification + 7x7 luma / 5x5 chroma diamond filters (ctx->fn_alf)    */
+int  xgpu_alf(xgpu_ctx *ctx, const xgpu_alf_params *ap);
 /* replicate the picture border into the 144/72-sample padding                                            */
 int  xgpu_pad(xgpu_ctx *ctx);
 int  xgpu_frame_end(xgpu_ctx *ctx);

@@ -21,6 +21,7 @@
 #include "xevdm_mc.h"
 #include "xevdm_itdq.h"
 #include "xevdm_df.h"
+#include "xevdm_alf.h"
 #include "xevd_oracle.h"
 
 /* reference tables selected like xevd_platform_init does (src_base/xevd.c:2074-2149) */
@@ -248,6 +249,60 @@ int refh_deblock_addb(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu
                              sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
     free(map_ats);
     harness_free(hn);
+    return 0;
+}
+
+/* ALF: the reference's alf_process_tile (src_main/xevdm_alf.c:901-1165: copy + extend, per-CTU halo buffer,
+   alf_derive_classification, alf_filter_blk_7 / _5) on a single-tile picture, with the final coefficients
+   (alf->coef_final, what alf_recon_coef :700-794 produces) supplied by the caller.  The argument record of
+   alf_process_tile is private to xevdm_alf.c (:796-803); this mirrors its five fields for the call. */
+typedef struct { ADAPTIVE_LOOP_FILTER *alf; CODING_STRUCTURE *cs; ALF_SLICE_PARAM *alf_slice_param; int tile_idx; int tsk_num; } alf_tile_arg;
+extern int alf_process_tile(void *arg);
+
+int refh_alf(const xgpu_seq_params *sp, const orc_pic *pic, const xgpu_alf_params *ap)
+{
+    XEVD_CTX *ctx = (XEVD_CTX *)calloc(1, sizeof(XEVDM_CTX));
+    XEVD_SPS sps;
+    XEVD_PIC p;
+    XEVD_TILE tile;
+    CODING_STRUCTURE cs;
+    ALF_SLICE_PARAM *asp = (ALF_SLICE_PARAM *)calloc(1, sizeof(ALF_SLICE_PARAM));
+    ADAPTIVE_LOOP_FILTER *alf = new_alf(sp->bit_depth_luma);
+    const int ctu = 1 << sp->log2_ctu;
+    const int w_lcu = (sp->width + ctu - 1) / ctu, h_lcu = (sp->height + ctu - 1) / ctu, f_lcu = w_lcu * h_lcu;
+    u8 *flags = (u8 *)calloc(3 * f_lcu, 1);
+    alf_tile_arg arg;
+    int i, c;
+
+    memset(&sps, 0, sizeof(sps)); memset(&tile, 0, sizeof(tile));
+    sps.chroma_format_idc = sp->chroma_format_idc;
+    sps.pic_width_in_luma_samples = sp->width; sps.pic_height_in_luma_samples = sp->height;
+    ctx->sps = &sps;
+    ctx->w = sp->width; ctx->h = sp->height;
+    ctx->w_scu = sp->width >> 2; ctx->h_scu = sp->height >> 2;
+    ctx->log2_max_cuwh = sp->log2_ctu; ctx->max_cuwh = ctu;
+    ctx->w_lcu = w_lcu; ctx->h_lcu = h_lcu; ctx->f_lcu = f_lcu;
+    ctx->pps.num_tile_columns_minus1 = 0;
+    ctx->pps.loop_filter_across_tiles_enabled_flag = ap->across_tiles;
+    tile.ctba_rs_first = 0; tile.w_ctb = w_lcu; tile.h_ctb = h_lcu; tile.f_ctb = f_lcu;
+    ctx->tile = &tile;
+    fill_pic(&p, pic, sp);
+    cs.ctx = ctx; cs.pic = &p; cs.temp_stride = 0; cs.pic_stride = 0;
+
+    xevd_alf_create(alf, sp->width, sp->height, ctu, ctu, 5, sp->chroma_format_idc, sp->bit_depth_luma);
+    memcpy(alf->coef_final, ap->luma_coef, sizeof(short) * 25 * 13);
+    memcpy(asp->chroma_coef, ap->chroma_coef, sizeof(short) * 7);
+    for (c = 0; c < 3; c++) {
+        asp->enable_flag[c] = ap->enable[c];
+        for (i = 0; i < f_lcu; i++) flags[c * f_lcu + i] = ap->enable[c] ? ((c == 0 && ap->ctb_flag) ? ap->ctb_flag[i] : 1) : 0;
+        alf->ctu_enable_flag[c] = flags + c * f_lcu;      /* alf_process :1181-1184 */
+    }
+    asp->alf_ctb_flag = flags;
+    arg.alf = alf; arg.cs = &cs; arg.alf_slice_param = asp; arg.tile_idx = 0; arg.tsk_num = 0;
+    alf_process_tile(&arg);
+
+    xevd_alf_destroy(alf); delete_alf(alf);
+    free(flags); free(asp); free(ctx);
     return 0;
 }
 

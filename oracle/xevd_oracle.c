@@ -660,6 +660,133 @@ int orc_deblock_addb(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
     return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Adaptive loop filter.  src_main/xevdm_alf.c.
+ * The reference filters CTU by CTU from a copy of the deblocked picture that is replicate-extended by 3 samples
+ * (alf_copy_and_extend_tile :805-842).  Every CTU gets a private (W+6)x(H+6) window (alf_process_tile :1000-1052):
+ *   - its own rows take their left/right halo from the copy when that side is "available", else by mirroring
+ *     around the CTU edge without repeating the edge sample;
+ *   - the 3 rows above/below are copied WHOLE (halo columns included) from the copy when available - so next to a
+ *     picture's left/right border those corner samples are the copy's replicate extension, not mirrored ones -
+ *     else they mirror the window's own rows (which already carry their halos).
+ * Availability = not on the tile (picture) border; with pps.loop_filter_across_tiles_enabled_flag the test is
+ * made against pic_width-1 / pic_height-1 (:990-999), which makes the right and bottom picture borders count as
+ * available (they then read the replicate extension).
+ * ---------------------------------------------------------------------------------------------- */
+static int16_t *alf_ctu_window(const int16_t *a, int s, int pw, int ph, int x0, int y0, int cw, int ch,
+                               int aL, int aR, int aT, int aB, int *ws_out)
+{
+    const int m = 3, ws = cw + 2 * m;
+    int16_t *buf = (int16_t *)malloc(sizeof(int16_t) * (size_t)ws * (ch + 2 * m));
+    int16_t *o = buf + m * ws + m;
+    int r, c;
+#define PIC(yy, xx) a[CLIP3(0, ph - 1, (yy)) * s + CLIP3(0, pw - 1, (xx))]        /* the replicate-extended copy */
+    for (r = 0; r < ch; r++) for (c = -m; c < cw + m; c++) {
+        int xx = x0 + c;
+        if (c < 0 && !aL) xx = x0 - c;
+        if (c >= cw && !aR) xx = x0 + cw - 1 - (c - cw + 1);
+        o[r * ws + c] = PIC(y0 + r, xx);
+    }
+    for (r = 1; r <= m; r++) for (c = -m; c < cw + m; c++) {
+        o[-r * ws + c] = aT ? PIC(y0 - r, x0 + c) : o[r * ws + c];
+        o[(ch - 1 + r) * ws + c] = aB ? PIC(y0 + ch - 1 + r, x0 + c) : o[(ch - 1 - r) * ws + c];
+    }
+#undef PIC
+    *ws_out = ws;
+    return o;
+}
+
+/* alf_derive_classification_blk, xevdm_alf.c:38-208: class (0..24) and transpose index (0..3) of the 4x4 block at (bx,by) */
+static void alf_classify(const int16_t *o, int es, int bx, int by, int bd, int *cls, int *tr)
+{
+    static const int th[16] = { 0, 1, 2, 2, 2, 2, 2, 3, 3, 3, 3, 3, 3, 3, 3, 4 };
+    static const int trans_tbl[8] = { 0, 1, 0, 2, 2, 3, 1, 3 };
+    int sv = 0, sh = 0, sd0 = 0, sd1 = 0, r, c;
+    int hv1, hv0, d1, d0, dir_hv, dir_d, hvd1, hvd0, main_dir, sec_dir, act, ci, strength = 0;
+    for (r = by - 2; r < by + 6; r++) for (c = bx - 2; c < bx + 6; c++) {
+        const int16_t *p = o + r * es + c;
+        const int16_t p2 = (int16_t)(p[0] << 1);
+        sv  += abs(p2 - p[-es] - p[es]);
+        sh  += abs(p2 - p[1] - p[-1]);
+        sd0 += abs(p2 - p[-es - 1] - p[es + 1]);
+        sd1 += abs(p2 - p[es - 1] - p[-es + 1]);
+    }
+    act = (int16_t)CLIP3(0, 15, (sv + sh) >> (bd - 2));
+    ci = th[act];
+    if (sv > sh) { hv1 = sv; hv0 = sh; dir_hv = 1; } else { hv1 = sh; hv0 = sv; dir_hv = 3; }
+    if (sd0 > sd1) { d1 = sd0; d0 = sd1; dir_d = 0; } else { d1 = sd1; d0 = sd0; dir_d = 2; }
+    if (d1 * hv0 > hv1 * d0) { hvd1 = d1; hvd0 = d0; main_dir = dir_d; sec_dir = dir_hv; }
+    else { hvd1 = hv1; hvd0 = hv0; main_dir = dir_hv; sec_dir = dir_d; }
+    if (hvd1 > 2 * hvd0) strength = 1;
+    if (hvd1 * 2 > 9 * hvd0) strength = 2;
+    if (strength) ci += (((main_dir & 1) << 1) + strength) * 5;
+    *cls = ci; *tr = trans_tbl[main_dir * 2 + (sec_dir >> 1)];
+}
+
+int orc_alf(const xgpu_seq_params *sp, const orc_pic *pic, const xgpu_alf_params *ap)
+{
+    /* coefficient order per transpose index, xevdm_alf.c:268-273 */
+    static const int l[4][13] = {
+        { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12 }, { 9, 4, 10, 8, 1, 5, 11, 7, 3, 0, 2, 6, 12 },
+        { 0, 3, 2, 1, 8, 7, 6, 5, 4, 9, 10, 11, 12 }, { 9, 8, 10, 4, 3, 7, 11, 5, 1, 0, 2, 6, 12 } };
+    const int w = sp->width, h = sp->height, ctu = 1 << sp->log2_ctu, w_ctu = (w + ctu - 1) / ctu;
+    const int maxv = (1 << sp->bit_depth_luma) - 1;          /* one bit depth for all clip ranges, xevd_alf_init :431-437 */
+    int16_t *copy[3];
+    int c, x0, y0, i;
+    if (!ap->enable[0] && !ap->enable[1] && !ap->enable[2]) return 0;
+    for (c = 0; c < 3; c++) {                                 /* the pre-filter copy every CTU reads from */
+        const int pw = c ? w >> 1 : w, ph = c ? h >> 1 : h, s = c ? pic->s_c : pic->s_l;
+        const int16_t *pl = c == 0 ? pic->y : (c == 1 ? pic->u : pic->v);
+        int y;
+        copy[c] = (int16_t *)malloc(sizeof(int16_t) * (size_t)pw * ph);
+        for (y = 0; y < ph; y++) memcpy(copy[c] + (size_t)y * pw, pl + (size_t)y * s, sizeof(int16_t) * pw);
+    }
+    for (y0 = 0; y0 < h; y0 += ctu) for (x0 = 0; x0 < w; x0 += ctu) {
+        const int cw = x0 + ctu > w ? w - x0 : ctu, ch = y0 + ctu > h ? h - y0 : ctu;
+        const int aL = x0 != 0, aT = y0 != 0;
+        const int aR = ap->across_tiles ? 1 : (x0 + cw != w), aB = ap->across_tiles ? 1 : (y0 + ch != h);
+        const int ctu_idx = (y0 >> sp->log2_ctu) * w_ctu + (x0 >> sp->log2_ctu);
+        int ws, x, y;
+        if (ap->enable[0] && (!ap->ctb_flag || ap->ctb_flag[ctu_idx])) {
+            int16_t *o = alf_ctu_window(copy[0], w, w, h, x0, y0, cw, ch, aL, aR, aT, aB, &ws);
+            for (y = 0; y < ch; y += 4) for (x = 0; x < cw; x += 4) {
+                int cls, tr, ii, jj;
+                int16_t f[13];
+                alf_classify(o, ws, x, y, sp->bit_depth_luma, &cls, &tr);
+                for (i = 0; i < 13; i++) f[i] = ap->luma_coef[cls * 13 + l[tr][i]];
+                for (ii = 0; ii < 4; ii++) for (jj = 0; jj < 4; jj++) {             /* alf_filter_blk_7, :210-337 */
+                    const int16_t *p = o + (y + ii) * ws + x + jj;
+                    int sum = f[0] * (p[3 * ws] + p[-3 * ws])
+                            + f[1] * (p[2 * ws + 1] + p[-2 * ws - 1]) + f[2] * (p[2 * ws] + p[-2 * ws]) + f[3] * (p[2 * ws - 1] + p[-2 * ws + 1])
+                            + f[4] * (p[ws + 2] + p[-ws - 2]) + f[5] * (p[ws + 1] + p[-ws - 1]) + f[6] * (p[ws] + p[-ws])
+                            + f[7] * (p[ws - 1] + p[-ws + 1]) + f[8] * (p[ws - 2] + p[-ws + 2])
+                            + f[9] * (p[3] + p[-3]) + f[10] * (p[2] + p[-2]) + f[11] * (p[1] + p[-1]) + f[12] * p[0];
+                    sum = (sum + 256) >> 9;
+                    pic->y[(y0 + y + ii) * pic->s_l + x0 + x + jj] = (int16_t)CLIP3(0, maxv, sum);
+                }
+            }
+            free(o - 3 * ws - 3);
+        }
+        for (c = 1; c < 3; c++) {
+            int16_t *pl = c == 1 ? pic->u : pic->v;
+            const int16_t *f = ap->chroma_coef;
+            int16_t *o;
+            if (!ap->enable[c]) continue;
+            o = alf_ctu_window(copy[c], w >> 1, w >> 1, h >> 1, x0 >> 1, y0 >> 1, cw >> 1, ch >> 1, aL, aR, aT, aB, &ws);
+            for (y = 0; y < ch >> 1; y++) for (x = 0; x < cw >> 1; x++) {          /* alf_filter_blk_5, :339-429 */
+                const int16_t *p = o + y * ws + x;
+                int sum = f[0] * (p[2 * ws] + p[-2 * ws]) + f[1] * (p[ws + 1] + p[-ws - 1]) + f[2] * (p[ws] + p[-ws]) + f[3] * (p[ws - 1] + p[-ws + 1])
+                        + f[4] * (p[2] + p[-2]) + f[5] * (p[1] + p[-1]) + f[6] * p[0];
+                sum = (sum + 256) >> 9;
+                pl[((y0 >> 1) + y) * pic->s_c + (x0 >> 1) + x] = (int16_t)CLIP3(0, maxv, sum);
+            }
+            free(o - 3 * ws - 3);
+        }
+    }
+    for (c = 0; c < 3; c++) free(copy[c]);
+    return 0;
+}
+
 void orc_pad(const xgpu_seq_params *sp, const orc_pic *p)
 {
     int c, i, j;

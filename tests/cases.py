@@ -19,6 +19,9 @@ CASES = [
     # Main-profile in-loop filters: (..., tools)
     ("main_addb_10b", 200, 136, 10, 1, 1, (2, 2), 0.5, {"addb": 1}),
     ("main_addb_8b_shared_refs", 136, 136, 8, 1, 1, (3, 3), 0.6, {"addb": 1}),
+    ("main_alf_10b", 200, 136, 10, 1, 1, (2, 2), 0.5, {"addb": 1, "alf": 1, "inter_frac": 1.0}),
+    ("main_alf_8b_across_tiles", 136, 72, 8, 1, 1, (1, 1), 0.4, {"addb": 1, "alf": 1, "across_tiles": 1, "inter_frac": 1.0}),
+    ("main_alf_only_luma", 72, 136, 10, 1, 1, (1, 0), 0.0, {"alf": 1, "alf_enable": (1, 0, 0), "inter_frac": 1.0, "no_deblock": 1}),
 ]
 POCS = [[4, 0, 2], [12, 16, 4]]      # L1 idx 2 has the POC of L0 idx 0 -> identical-motion candidates exist
 CUR_POC = 8
@@ -32,6 +35,7 @@ def _p(a):
 def build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, tools=None, seed=0, inter_frac=0.9, split_prob=0.5, qp_range=(20, 45),
                amp=2.0, oob_frac=0.1):
     tools = dict(tools or {})
+    inter_frac = tools.get("inter_frac", inter_frac)
     rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000 + seed)
     refs = {}
     for l in range(2):
@@ -47,7 +51,13 @@ def build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, tools=None, seed=0, 
         sel = (batch["refi"][:, 0] >= 0) & (batch["refi"][:, 1] >= 0)
         idx = np.nonzero(sel)[0][::3]
         batch["mv"][idx, 1] = batch["mv"][idx, 0]
+    alf_params = None
+    if tools.get("alf"):
+        n_ctu = ((w + 63) // 64) * ((h + 63) // 64)
+        alf_params = synth.gen_alf_params(rng, n_ctu, across_tiles=int(tools.get("across_tiles", 0)),
+                                          enable=tools.get("alf_enable", (1, 1, 1)))
     return {"name": name, "w": w, "h": h, "bd": bd, "admvp": admvp, "iqt": iqt, "refs": refs, "batch": batch,
+            "alf_params": alf_params, "no_deblock": int(tools.get("no_deblock", 0)),
             "addb": int(tools.get("addb", 0)), "alf": int(tools.get("alf", 0)),
             "alpha_off": int(tools.get("alpha_off", 0)), "beta_off": int(tools.get("beta_off", 0))}
 
@@ -70,6 +80,10 @@ def run_cpu(engine, case, deblock=True, simd=0, pad=True):
     fr = ol.make_frame(cur, case["refs"], *QP_OFFSETS)
     m = maps.orc()
     resid = np.zeros(max(case["batch"]["n_coef"], 1), np.int16)
+    deblock = deblock and not case.get("no_deblock")
+    ap = keep_ap = None
+    if case.get("alf_params") is not None:
+        ap, keep_ap = abi.make_alf_params(case["alf_params"])
     if engine == "oracle":
         o = ol.oracle()
         o.orc_recon_batch(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), _p(resid))
@@ -78,6 +92,8 @@ def run_cpu(engine, case, deblock=True, simd=0, pad=True):
             o.orc_deblock_addb(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), case["alpha_off"], case["beta_off"])
         elif deblock:
             o.orc_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m))
+        if ap is not None:
+            o.orc_alf(C.byref(sp), C.byref(fr.cur), C.byref(ap))
         if pad:
             o.orc_pad(C.byref(sp), C.byref(fr.cur))
     else:
@@ -88,12 +104,14 @@ def run_cpu(engine, case, deblock=True, simd=0, pad=True):
             hn.refh_deblock_addb(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), case["alpha_off"], case["beta_off"])
         elif deblock:
             hn.refh_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), simd)
+        if ap is not None:
+            hn.refh_alf(C.byref(sp), C.byref(fr.cur), C.byref(ap))
         if pad:
             hn.refh_pad(C.byref(sp), C.byref(fr.cur))
     return cur, pre, maps, resid
 
 
-def run_gpu(case, deblock=True, pad=True):
+def run_gpu(case, deblock=True, pad=True, alf=True):
     """The HIP backend through the C ABI. -> list of padded planes (reference buffer geometry)"""
     from xevd_amd.decoder import XgpuDecoder
     with XgpuDecoder(case["w"], case["h"], case["bd"], iqt=case["iqt"], admvp=case["admvp"], addb=case.get("addb", 0),
@@ -107,7 +125,8 @@ def run_gpu(case, deblock=True, pad=True):
         cur = dec.pic_alloc()
         dec.pic_upload_padded(cur, _start_picture(case).bufs)
         hb = dec.batch_create(case["batch"])
-        dec.decode_picture(cur, CUR_POC, slots, hb, deblock=deblock, pad=pad, qp_u_offset=QP_OFFSETS[0], qp_v_offset=QP_OFFSETS[1],
-                           alpha_off=case.get("alpha_off", 0), beta_off=case.get("beta_off", 0))
+        dec.decode_picture(cur, CUR_POC, slots, hb, deblock=deblock and not case.get("no_deblock"), pad=pad,
+                           qp_u_offset=QP_OFFSETS[0], qp_v_offset=QP_OFFSETS[1],
+                           alpha_off=case.get("alpha_off", 0), beta_off=case.get("beta_off", 0), alf=case.get("alf_params") if alf else None)
         dec.sync()
         return dec.pic_download_padded(cur)

@@ -112,7 +112,12 @@ def golden_pictures():
         cs = cases.build_case(*case)
         final, pre, maps, resid = cases.run_cpu("ref", cs)
         d = {"params": np.array(case[1:6], np.int64), "n_refs": np.array(case[6], np.int64),
-             "tools": np.array([cs["addb"], cs["alf"], cs["alpha_off"], cs["beta_off"]], np.int64)}
+             "tools": np.array([cs["addb"], cs["alf"], cs["alpha_off"], cs["beta_off"], cs["no_deblock"]], np.int64)}
+        if cs["alf_params"] is not None:
+            ap = cs["alf_params"]
+            d["alf_enable"] = np.array(ap["enable"], np.int64)
+            d["alf_luma_coef"], d["alf_chroma_coef"], d["alf_ctb_flag"] = ap["luma_coef"], ap["chroma_coef"], ap["ctb_flag"]
+            d["alf_across_tiles"] = np.array(ap["across_tiles"], np.int64)
         seen = {}
         for (i, l), pic in cs["refs"].items():
             if id(pic) in seen:                       # the same picture in another list slot: store an alias

@@ -54,6 +54,7 @@ def oracle():
         lib.orc_recon_batch.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_void_p]
         lib.orc_deblock_baseline.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps)]
         lib.orc_deblock_addb.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_int, C.c_int]
+        lib.orc_alf.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcPic), C.POINTER(abi.AlfParams)]
         lib.orc_pad.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcPic)]
         _oracle = lib
     return _oracle
@@ -79,6 +80,7 @@ def harness():
         lib.refh_recon_batch.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_void_p, C.c_int]
         lib.refh_deblock_baseline.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_int]
         lib.refh_deblock_addb.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_int, C.c_int]
+        lib.refh_alf.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcPic), C.POINTER(abi.AlfParams)]
         lib.refh_pad.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcPic)]
         _harness = lib
     return _harness

@@ -51,6 +51,27 @@ class CuBatch(C.Structure):
     ]
 
 
+class AlfParams(C.Structure):
+    _fields_ = [("enable", C.c_int * 3), ("luma_coef", C.POINTER(C.c_int16)), ("chroma_coef", C.POINTER(C.c_int16)),
+                ("ctb_flag", C.POINTER(C.c_uint8)), ("across_tiles", C.c_int)]
+
+
+def make_alf_params(d):
+    """{'enable': (y,u,v), 'luma_coef': [25][13], 'chroma_coef': [7], 'ctb_flag': [n_ctu] or None, 'across_tiles': 0/1}"""
+    keep = {"luma": np.ascontiguousarray(d["luma_coef"], np.int16).reshape(25 * 13),
+            "chroma": np.ascontiguousarray(d["chroma_coef"], np.int16).reshape(7),
+            "flag": None if d.get("ctb_flag") is None else np.ascontiguousarray(d["ctb_flag"], np.uint8)}
+    ap = AlfParams()
+    for i in range(3):
+        ap.enable[i] = int(d["enable"][i])
+    ap.luma_coef = keep["luma"].ctypes.data_as(C.POINTER(C.c_int16))
+    ap.chroma_coef = keep["chroma"].ctypes.data_as(C.POINTER(C.c_int16))
+    if keep["flag"] is not None:
+        ap.ctb_flag = keep["flag"].ctypes.data_as(C.POINTER(C.c_uint8))
+    ap.across_tiles = int(d.get("across_tiles", 0))
+    return ap, keep
+
+
 def _ptr(a, ctype):
     return a.ctypes.data_as(C.POINTER(ctype))
 
@@ -113,6 +134,7 @@ _EXPORTS = {
     "xgpu_batch_destroy": (None, [C.c_void_p, C.c_void_p]),
     "xgpu_batch_recon": (C.c_int, [C.c_void_p, C.c_void_p]),
     "xgpu_deblock": (C.c_int, [C.c_void_p]),
+    "xgpu_alf": (C.c_int, [C.c_void_p, C.POINTER(AlfParams)]),
     "xgpu_pad": (C.c_int, [C.c_void_p]),
     "xgpu_frame_end": (C.c_int, [C.c_void_p]),
     "xgpu_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -1,0 +1,232 @@
+// k_alf.hip - adaptive loop filter (Main profile, sps->tool_alf): 4x4 block classification, 7x7-diamond luma filter,
+// 5x5-diamond chroma filter.
+//
+// Replaces xevd_alf -> call_dec_alf_process_aps -> alf_process -> alf_process_tile -> alf_derive_classification_blk /
+// alf_filter_blk_7 / alf_filter_blk_5 (src_main/xevdm.c:2105, src_main/xevdm_alf.c:38-429, 901-1249).  Coefficient
+// reconstruction from the APS (alf_recon_coef :700-794) stays on the host; the kernel receives coef_final.
+//
+// Semantics reproduced: every sample is filtered from the PRE-filter picture; a CTU's 3-sample halo follows the
+// reference's per-CTU window rules (own rows mirror at unavailable left/right borders; the rows above/below are
+// taken whole from the replicate-extended copy when available - so corner samples next to a picture side border
+// are replicated, not mirrored - else mirror the window's own rows; with loop_filter_across_tiles the right and
+// bottom picture borders count as available).  Class = f(sum of |Laplacians| V,H,D0,D1 over the 8x8 window around
+// the 4x4 block, activity), transpose index from the dominant directions, 25 classes x 13 coefficients.
+//
+// MI355X mapping: out of place (SRC -> DST) like the deblocking passes; one 256-thread workgroup per 64x64 luma
+// tile stages the tile + halo of all three planes in LDS (interior by 8-byte coalesced loads, the halo ring through
+// the border rule), then one LANE per 4x4 SCU classifies its block with packed-s16 arithmetic (two samples per
+// v_pk_* op, row sums via v_dot2 with a ones vector), fetches its 13 coefficients from an LDS copy of the filter
+// set and filters its 16 luma + 2x4 chroma samples.  LDS rows are read as aligned 8-byte pieces.
+#include "xgpu_internal.h"
+
+typedef short v2s __attribute__((ext_vector_type(2)));
+
+#define LROWS 70
+#define LSTR  72          // luma LDS row stride in s16: window col c (-3..66) at index c+4
+#define CROWS 36
+#define CSTR  40          // chroma: window col c (-2..33) at index c+4 (keeps the 8-byte interior pieces aligned)
+
+struct CtuRect { int x0, y0, cw, ch, aL, aR, aT, aB; };
+
+// sample of the reference's per-CTU window at absolute plane position (y,x)  (alf_process_tile :1000-1052)
+__device__ __forceinline__ int alf_fetch(const int16_t *__restrict__ p, int s, int pw, int ph, const CtuRect k, int y, int x)
+{
+    int yy = y, xx = x;
+    if (y < k.y0 && !k.aT) yy = 2 * k.y0 - y;
+    else if (y >= k.y0 + k.ch && !k.aB) yy = 2 * (k.y0 + k.ch - 1) - y;
+    if (yy >= k.y0 && yy < k.y0 + k.ch) {
+        if (x < k.x0 && !k.aL) xx = 2 * k.x0 - x;
+        else if (x >= k.x0 + k.cw && !k.aR) xx = 2 * (k.x0 + k.cw - 1) - x;
+    }
+    yy = min(max(yy, 0), ph - 1); xx = min(max(xx, 0), pw - 1);           // the copy's replicate extension
+    return p[yy * s + xx];
+}
+
+// stage a T x T tile (+H halo) of one plane into LDS.  lds index of window (r,c) = (r+H)*STR + c + OFF
+template <int T, int H, int STR, int OFF>
+__device__ __forceinline__ void alf_stage(int16_t *lds, const int16_t *__restrict__ p, int s, int pw, int ph, const CtuRect k,
+                                          int tx0, int ty0, int t0, int nthr)
+{
+    // interior: T rows x T/4 pieces of 4 samples.  Pieces inside the CTU are rule-free 8-byte copies; when the CTU is
+    // cut by the picture border, the part of the tile beyond it belongs to the window's halo and goes through the rule
+    for (int i = t0; i < T * (T / 4); i += nthr) {
+        const int r = i / (T / 4), c4 = (i % (T / 4)) * 4;
+        if (ty0 + r < k.y0 + k.ch && tx0 + c4 + 3 < k.x0 + k.cw) {
+            const uint2 v = *(const uint2 *)(p + (ty0 + r) * s + tx0 + c4);
+            *(uint2 *)(lds + (r + H) * STR + c4 + OFF) = v;
+        } else if (ty0 + r < k.y0 + k.ch + H && tx0 + c4 < k.x0 + k.cw + H) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) lds[(r + H) * STR + c4 + e + OFF] = (int16_t)alf_fetch(p, s, pw, ph, k, ty0 + r, tx0 + c4 + e);
+        }
+    }
+    // halo ring through the window rule
+    constexpr int RING = (T + 2 * H) * (T + 2 * H) - T * T;
+    for (int i = t0; i < RING; i += nthr) {
+        int r, c;
+        if (i < H * (T + 2 * H)) { r = i / (T + 2 * H) - H; c = i % (T + 2 * H) - H; }
+        else if (i < 2 * H * (T + 2 * H)) { const int j = i - H * (T + 2 * H); r = T + j / (T + 2 * H); c = j % (T + 2 * H) - H; }
+        else { const int j = i - 2 * H * (T + 2 * H); r = j / (2 * H); const int q = j % (2 * H); c = q < H ? q - H : T + q - H; }
+        lds[(r + H) * STR + c + OFF] = (int16_t)alf_fetch(p, s, pw, ph, k, ty0 + r, tx0 + c);
+    }
+}
+
+__constant__ uint8_t k_alf_perm[4][13] = {      // coefficient order per transpose index, xevdm_alf.c:268-273
+    { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12 }, { 9, 4, 10, 8, 1, 5, 11, 7, 3, 0, 2, 6, 12 },
+    { 0, 3, 2, 1, 8, 7, 6, 5, 4, 9, 10, 11, 12 }, { 9, 8, 10, 4, 3, 7, 11, 5, 1, 0, 2, 6, 12 } };
+
+__device__ __forceinline__ v2s asv(uint32_t x) { return __builtin_bit_cast(v2s, x); }
+__device__ __forceinline__ uint32_t asu(v2s x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ v2s vabs(v2s x) { const v2s z = {0, 0}; const v2s n = z - x; return __builtin_elementwise_max(x, n); }
+__device__ __forceinline__ int hsum(v2s x, int acc) { const v2s one = {1, 1}; return __builtin_amdgcn_sdot2(x, one, acc, false); }
+
+__global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
+                                             const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_,
+                                             int16_t *__restrict__ dv_)
+{
+    __shared__ __attribute__((aligned(16))) int16_t l_y[LROWS * LSTR];
+    __shared__ __attribute__((aligned(16))) int16_t l_c[2][CROWS * CSTR];
+    __shared__ int16_t l_coef[25 * 13 + 7];
+
+    const int tiles_x = (a.pic_w + 63) >> 6;
+    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int tx0 = tx << 6, ty0 = ty << 6;
+    const int t = threadIdx.x;
+    // the CTU this tile belongs to and its border availability (alf_process_tile :984-999)
+    CtuRect k;
+    const int ctu = 1 << a.log2_ctu;
+    k.x0 = tx0 & ~(ctu - 1); k.y0 = ty0 & ~(ctu - 1);
+    k.cw = min(ctu, a.pic_w - k.x0); k.ch = min(ctu, a.pic_h - k.y0);
+    k.aL = k.x0 != 0; k.aT = k.y0 != 0;
+    k.aR = a.across_tiles ? 1 : (k.x0 + k.cw != a.pic_w);
+    k.aB = a.across_tiles ? 1 : (k.y0 + k.ch != a.pic_h);
+    const int ctu_idx = (k.y0 >> a.log2_ctu) * a.w_ctu + (k.x0 >> a.log2_ctu);
+    const bool luma_on = a.enable[0] && (a.ctb_flag == nullptr || a.ctb_flag[ctu_idx] != 0);
+
+    for (int i = t; i < 25 * 13 + 7; i += 256) l_coef[i] = a.coef[i];
+    if (luma_on) alf_stage<64, 3, LSTR, 4>(l_y, sy_, a.s_l, a.pic_w, a.pic_h, k, tx0, ty0, t, 256);
+    {
+        CtuRect kc = k;
+        kc.x0 >>= 1; kc.y0 >>= 1; kc.cw >>= 1; kc.ch >>= 1;
+        if (a.enable[1]) alf_stage<32, 2, CSTR, 4>(l_c[0], su_, a.s_c, a.pic_w >> 1, a.pic_h >> 1, kc, tx0 >> 1, ty0 >> 1, t, 256);
+        if (a.enable[2]) alf_stage<32, 2, CSTR, 4>(l_c[1], sv_, a.s_c, a.pic_w >> 1, a.pic_h >> 1, kc, tx0 >> 1, ty0 >> 1, t, 256);
+    }
+    __syncthreads();
+
+    const int lx = t & 15, ly = t >> 4;
+    const int x = tx0 + (lx << 2), y = ty0 + (ly << 2);
+    if (x >= a.pic_w || y >= a.pic_h) return;
+    const int maxv = (1 << a.bd) - 1;
+
+    // ------------------------------------------------ luma -----------------------------------------------
+    if (luma_on) {
+        // window rows -3..6, each 12 samples (cols -4..7) as 6 dwords; col j sits at sample j+4
+        uint32_t W[10][6];
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const uint2 *row = (const uint2 *)(l_y + ((ly << 2) + i) * LSTR + (lx << 2));
+            const uint2 v0 = row[0], v1 = row[1], v2 = row[2];
+            W[i][0] = v0.x; W[i][1] = v0.y; W[i][2] = v1.x; W[i][3] = v1.y; W[i][4] = v2.x; W[i][5] = v2.y;
+        }
+        // classification: sums of |Laplacian| over window rows -2..5 (W rows 1..8) and cols -2..5 (dwords 1..4)
+        int sv = 0, sh = 0, sd0 = 0, sd1 = 0;
+#pragma unroll
+        for (int i = 1; i <= 8; i++) {
+#pragma unroll
+            for (int d = 1; d <= 4; d++) {
+                const v2s c2 = asv(W[i][d]) + asv(W[i][d]);
+                const v2s up = asv(W[i - 1][d]), dn = asv(W[i + 1][d]);
+                const v2s l0 = asv(__builtin_amdgcn_alignbit(W[i][d], W[i][d - 1], 16)), r0 = asv(__builtin_amdgcn_alignbit(W[i][d + 1], W[i][d], 16));
+                const v2s lu = asv(__builtin_amdgcn_alignbit(W[i - 1][d], W[i - 1][d - 1], 16)), ru = asv(__builtin_amdgcn_alignbit(W[i - 1][d + 1], W[i - 1][d], 16));
+                const v2s ld = asv(__builtin_amdgcn_alignbit(W[i + 1][d], W[i + 1][d - 1], 16)), rd = asv(__builtin_amdgcn_alignbit(W[i + 1][d + 1], W[i + 1][d], 16));
+                sv = hsum(vabs(c2 - up - dn), sv);
+                sh = hsum(vabs(c2 - l0 - r0), sh);
+                sd0 = hsum(vabs(c2 - lu - rd), sd0);
+                sd1 = hsum(vabs(c2 - ld - ru), sd1);
+            }
+        }
+        int cls, tr;
+        {
+            const int act = min(max((sv + sh) >> (a.bd - 2), 0), 15);
+            cls = (0x4333333332222210ull >> (act * 4)) & 0xF;                 // th[16] = {0,1,2,2,2,2,2,3,3,3,3,3,3,3,3,4}
+            int hv1, hv0, d1, d0, dir_hv, dir_d, hvd1, hvd0, main_dir, sec_dir;
+            if (sv > sh) { hv1 = sv; hv0 = sh; dir_hv = 1; } else { hv1 = sh; hv0 = sv; dir_hv = 3; }
+            if (sd0 > sd1) { d1 = sd0; d0 = sd1; dir_d = 0; } else { d1 = sd1; d0 = sd0; dir_d = 2; }
+            if (d1 * hv0 > hv1 * d0) { hvd1 = d1; hvd0 = d0; main_dir = dir_d; sec_dir = dir_hv; }
+            else { hvd1 = hv1; hvd0 = hv0; main_dir = dir_hv; sec_dir = dir_d; }
+            int strength = 0;
+            if (hvd1 > 2 * hvd0) strength = 1;
+            if (hvd1 * 2 > 9 * hvd0) strength = 2;
+            if (strength) cls += (((main_dir & 1) << 1) + strength) * 5;
+            tr = (0x31322010u >> ((main_dir * 2 + (sec_dir >> 1)) * 4)) & 0xF;  // trans_tbl = {0,1,0,2,2,3,1,3}
+        }
+        int f[13];
+#pragma unroll
+        for (int i = 0; i < 13; i++) f[i] = l_coef[cls * 13 + k_alf_perm[tr][i]];
+
+        // S(i, j): window row i (-3..6), col j (-3..6)
+#define S(i, j) ((int)(int16_t)(W[(i) + 3][((j) + 4) >> 1] >> ((((j) + 4) & 1) * 16)))
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) {
+            int o[4];
+#pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                int sum = f[0] * (S(ii + 3, jj) + S(ii - 3, jj))
+                        + f[1] * (S(ii + 2, jj + 1) + S(ii - 2, jj - 1)) + f[2] * (S(ii + 2, jj) + S(ii - 2, jj)) + f[3] * (S(ii + 2, jj - 1) + S(ii - 2, jj + 1))
+                        + f[4] * (S(ii + 1, jj + 2) + S(ii - 1, jj - 2)) + f[5] * (S(ii + 1, jj + 1) + S(ii - 1, jj - 1)) + f[6] * (S(ii + 1, jj) + S(ii - 1, jj))
+                        + f[7] * (S(ii + 1, jj - 1) + S(ii - 1, jj + 1)) + f[8] * (S(ii + 1, jj - 2) + S(ii - 1, jj + 2))
+                        + f[9] * (S(ii, jj + 3) + S(ii, jj - 3)) + f[10] * (S(ii, jj + 2) + S(ii, jj - 2)) + f[11] * (S(ii, jj + 1) + S(ii, jj - 1))
+                        + f[12] * S(ii, jj);
+                o[jj] = min(max((sum + 256) >> 9, 0), maxv);
+            }
+            uint2 w;
+            w.x = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
+            w.y = (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
+            *(uint2 *)(dy_ + (y + ii) * a.s_l + x) = w;
+        }
+#undef S
+    } else {
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) *(uint2 *)(dy_ + (y + ii) * a.s_l + x) = *(const uint2 *)(sy_ + (y + ii) * a.s_l + x);
+    }
+
+    // ------------------------------------------------ chroma ---------------------------------------------
+    const int cx = x >> 1, cy = y >> 1;
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++) {
+        const int16_t *src = pl ? sv_ : su_;
+        int16_t *dst = pl ? dv_ : du_;
+        if (!a.enable[1 + pl]) {
+            *(uint32_t *)(dst + cy * a.s_c + cx) = *(const uint32_t *)(src + cy * a.s_c + cx);
+            *(uint32_t *)(dst + (cy + 1) * a.s_c + cx) = *(const uint32_t *)(src + (cy + 1) * a.s_c + cx);
+            continue;
+        }
+        // window rows -2..3, cols -2..3 -> 3 dwords per row; col j at sample j+2
+        uint32_t C[6][3];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const uint32_t *row = (const uint32_t *)(l_c[pl] + ((ly << 1) + i) * CSTR + (lx << 1) + 2);
+            C[i][0] = row[0]; C[i][1] = row[1]; C[i][2] = row[2];
+        }
+        const int16_t *f = l_coef + 325;
+#define SC(i, j) ((int)(int16_t)(C[(i) + 2][((j) + 2) >> 1] >> ((((j) + 2) & 1) * 16)))
+#pragma unroll
+        for (int ii = 0; ii < 2; ii++) {
+            int o[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                int sum = f[0] * (SC(ii + 2, jj) + SC(ii - 2, jj)) + f[1] * (SC(ii + 1, jj + 1) + SC(ii - 1, jj - 1)) + f[2] * (SC(ii + 1, jj) + SC(ii - 1, jj))
+                        + f[3] * (SC(ii + 1, jj - 1) + SC(ii - 1, jj + 1)) + f[4] * (SC(ii, jj + 2) + SC(ii, jj - 2)) + f[5] * (SC(ii, jj + 1) + SC(ii, jj - 1))
+                        + f[6] * SC(ii, jj);
+                o[jj] = min(max((sum + 256) >> 9, 0), maxv);
+            }
+            *(uint32_t *)(dst + (cy + ii) * a.s_c + cx) = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
+        }
+#undef SC
+    }
+}
+
+void launch_alf(xgpu_ctx *c, const AlfArgs &a, const DevPic &src, const DevPic &dst)
+{
+    const int tiles = ((a.pic_w + 63) >> 6) * ((a.pic_h + 63) >> 6);
+    hipLaunchKernelGGL(k_alf, dim3(tiles), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
+}

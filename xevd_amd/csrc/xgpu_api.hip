@@ -126,7 +126,7 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     xgpu_ctx *c = new xgpu_ctx();
     c->sp = *sp;
     c->sp.chroma_qp_table[0] = c->sp.chroma_qp_table[1] = NULL;
-    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->stream = 0;
+    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_ctb_flag = NULL; c->stream = 0; c->where = 0;
     memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_n, 0, sizeof(c->t_n));
     // chroma QP mapping: caller table starts at qp = -6*(bdc-8); default = Baseline static table with the
     // identity extension below 0 (xevd_set_chroma_qp_tbl_loc, xevd_tbl.c:364-372)
@@ -152,6 +152,7 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
 
     if (hipMalloc((void **)&c->d_maps, sizeof(ScuRec) * (size_t)c->w_scu * c->h_scu) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
     if (hipMemsetAsync(c->d_maps, 0, sizeof(ScuRec) * (size_t)c->w_scu * c->h_scu, c->stream) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+    if (hipMalloc((void **)&c->d_ctb_flag, (size_t)c->w_ctu * c->h_ctu + 16) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
     init_transform_tables(c);
     // slot 0 of `pics` is the private scratch picture of the deblocking passes
     c->pics.resize(1 + std::max(1, std::min(sp->max_pics, 34)));
@@ -177,6 +178,7 @@ void xgpu_close(xgpu_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &p : c->pics) if (p.base) (void)hipFree(p.base);
     if (c->d_maps) (void)hipFree(c->d_maps);
+    if (c->d_ctb_flag) (void)hipFree(c->d_ctb_flag);
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -476,6 +478,29 @@ int xgpu_deblock(xgpu_ctx *c)
         TIMED(c, XGPU_K_DBK_V, launch_dbk(c, a, 0, first, second));
         TIMED(c, XGPU_K_DBK_H, launch_dbk(c, a, 1, second, first));
     }
+    HIPCHK(c, hipGetLastError());
+    return XGPU_OK;
+}
+
+int xgpu_alf(xgpu_ctx *c, const xgpu_alf_params *ap)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, c->have_frame); ARGCHK(c, c->fp.alf_on); ARGCHK(c, ap != NULL && c->where == 1);
+    ARGCHK(c, (!ap->enable[0] || ap->luma_coef) && ((!ap->enable[1] && !ap->enable[2]) || ap->chroma_coef));
+    AlfArgs a;
+    memset(&a, 0, sizeof(a));
+    a.s_l = c->s_l; a.s_c = c->s_c; a.pic_w = c->sp.width; a.pic_h = c->sp.height;
+    a.bd = c->sp.bit_depth_luma;           // one bit depth for classification and all clip ranges (xevd_alf_init, xevdm_alf.c:431-437)
+    a.log2_ctu = c->sp.log2_ctu; a.w_ctu = c->w_ctu; a.across_tiles = ap->across_tiles ? 1 : 0;
+    for (int i = 0; i < 3; i++) a.enable[i] = ap->enable[i] ? 1 : 0;
+    if (ap->luma_coef) memcpy(a.coef, ap->luma_coef, sizeof(int16_t) * 325);
+    if (ap->chroma_coef) memcpy(a.coef + 325, ap->chroma_coef, sizeof(int16_t) * 7);
+    if (ap->ctb_flag && ap->enable[0]) {
+        HIPCHK(c, hipMemcpyAsync(c->d_ctb_flag, ap->ctb_flag, (size_t)c->w_ctu * c->h_ctu, hipMemcpyHostToDevice, c->stream));
+        a.ctb_flag = c->d_ctb_flag;
+    }
+    // the filter chain is planned so that ALF reads the scratch picture and lands in the DPB slot
+    TIMED(c, XGPU_K_ALF, launch_alf(c, a, c->pics[0], dpic(c, c->fp.pic)));
+    c->where = 0;
     HIPCHK(c, hipGetLastError());
     return XGPU_OK;
 }

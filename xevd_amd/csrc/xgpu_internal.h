@@ -113,6 +113,13 @@ struct AddbArgs {
     uint8_t  pic_id[XGPU_MAX_REFS * 2];// picture slot of refp[idx][list], 255 = none
 };
 
+struct AlfArgs {
+    int      s_l, s_c, pic_w, pic_h, bd, log2_ctu, w_ctu, across_tiles;
+    int      enable[3];
+    const uint8_t *ctb_flag;           // device, [n_ctu] or null
+    int16_t  coef[25 * 13 + 7];        // coef_final followed by the chroma filter
+};
+
 struct xgpu_dbatch {
     int        n_cu, n_ctu, n_tb, n_waves;
     size_t     n_coef;
@@ -134,6 +141,7 @@ struct xgpu_ctx {
     size_t          pic_elems, off_u, off_v;
     std::vector<DevPic> pics;
     ScuRec         *d_maps;
+    uint8_t        *d_ctb_flag;       // ALF luma CTB flags of the current picture
     xgpu_frame_params fp;
     int             have_frame;
     int             where;             // 0: the picture being built lives in its DPB slot, 1: in the scratch picture
@@ -154,6 +162,7 @@ void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const
 void upload_transform_tables(const int *tm, hipStream_t s);
 int  itdq_group_size(int log2w, int log2h);     // TBs of one size class per 256-thread work item
 void launch_addb(xgpu_ctx *c, const AddbArgs &a, int dir, const DevPic &src, const DevPic &dst);
+void launch_alf(xgpu_ctx *c, const AlfArgs &a, const DevPic &src, const DevPic &dst);
 void launch_pad(xgpu_ctx *c, const DevPic &p);
 void launch_copy_bw(xgpu_ctx *c, const void *src, void *dst, size_t bytes);
 void launch_test_mc(xgpu_ctx *c, const int16_t *plane, int stride, int ref_x, int ref_y, int has_dx, int has_dy,

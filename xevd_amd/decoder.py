@@ -120,6 +120,10 @@ class XgpuDecoder:
     def deblock(self):
         self._chk(self.lib.xgpu_deblock(self.ctx), "xgpu_deblock")
 
+    def alf(self, params):
+        ap, keep = abi.make_alf_params(params)
+        self._chk(self.lib.xgpu_alf(self.ctx, C.byref(ap)), "xgpu_alf")
+
     def pad(self):
         self._chk(self.lib.xgpu_pad(self.ctx), "xgpu_pad")
 

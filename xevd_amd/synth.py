@@ -190,3 +190,16 @@ def gen_picture(rng, width, height, bit_depth=8, smooth=True):
         base += rng.normal(0, 0.06, (ph, pw))
         planes.append(np.clip(np.round(base * maxv), 0, maxv).astype(np.int16))
     return planes
+
+
+def gen_alf_params(rng, n_ctu, across_tiles=0, ctb_on_frac=0.8, enable=(1, 1, 1), strength=40):
+    """Random ALF parameters in the form alf_recon_coef leaves them (src_main/xevdm_alf.c:700-794): 25 luma filters
+    of 13 coefficients and one chroma filter of 7, each with unity gain at 9 fractional bits (the centre tap is
+    512 minus twice the sum of the others)."""
+    luma = rng.integers(-strength, strength + 1, (25, 13)).astype(np.int64)
+    luma[:, 12] = 512 - 2 * luma[:, :12].sum(1)
+    chroma = rng.integers(-strength, strength + 1, 7).astype(np.int64)
+    chroma[6] = 512 - 2 * chroma[:6].sum()
+    flag = (rng.random(n_ctu) < ctb_on_frac).astype(np.uint8)
+    return {"enable": tuple(enable), "luma_coef": luma.astype(np.int16), "chroma_coef": chroma.astype(np.int16),
+            "ctb_flag": flag, "across_tiles": across_tiles}
