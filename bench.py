@@ -28,10 +28,14 @@ sys.path.insert(0, ROOT)
 
 WORKLOADS = {
     # BASELINE.json configs[1]: Baseline profile, 1080p, 8 bit, IPPP, one reference
-    "cfg2_base_1080p_8b_ippp": dict(w=1920, h=1080, bd=8, admvp=0, iqt=0, n_refs=(1, 0), bi_frac=0.0),
-    "base_4k_8b_ippp": dict(w=3840, h=2160, bd=8, admvp=0, iqt=0, n_refs=(1, 0), bi_frac=0.0),
-    "base_8k_10b_ippp": dict(w=7680, h=4320, bd=10, admvp=0, iqt=0, n_refs=(1, 0), bi_frac=0.0),
+    "cfg2_base_1080p_8b_ippp": dict(w=1920, h=1080, bd=8, admvp=0, iqt=0, addb=0, alf=0, n_refs=(1, 0), bi_frac=0.0),
+    "base_8k_10b_ippp": dict(w=7680, h=4320, bd=10, admvp=0, iqt=0, addb=0, alf=0, n_refs=(1, 0), bi_frac=0.0),
+    # configs[2]: Main profile 4K 10 bit, two reference lists, 50% bi-prediction, 8-tap MC tables, IQT, ADDB, ALF
+    "cfg3_main_4k_10b_ra": dict(w=3840, h=2160, bd=10, admvp=1, iqt=1, addb=1, alf=1, n_refs=(1, 1), bi_frac=0.5),
+    # configs[3]: the same at 8K - the configuration the metric (fps + HBM GB/s at 4K/8K) is quoted on
+    "cfg4_main_8k_10b_ra": dict(w=7680, h=4320, bd=10, admvp=1, iqt=1, addb=1, alf=1, n_refs=(1, 1), bi_frac=0.5),
 }
+DEFAULT_WORKLOAD = "cfg4_main_8k_10b_ra"
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -48,64 +52,83 @@ def algorithmic_bytes(batch, w, h):
     b_inter = int((samples[inter] * (2 * lists[inter] + 2)).sum() + 2 * coded[inter].sum())
     b_itdq = int(4 * coded.sum())
     s_pic = w * h * 3 // 2
-    return {"inter": b_inter, "itdq": b_itdq, "dbk_v": 4 * s_pic, "dbk_h": 4 * s_pic}
+    return {"inter": b_inter, "itdq": b_itdq, "dbk_v": 4 * s_pic, "dbk_h": 4 * s_pic, "alf": 4 * s_pic}
 
 
 def make_stream(wl, seed, n_batches):
     from xevd_amd import synth
     rng = np.random.default_rng(seed)
-    first = synth.gen_picture(rng, wl["w"], wl["h"], wl["bd"])
+    first = [synth.gen_picture(rng, wl["w"], wl["h"], wl["bd"]) for _ in range(2)]
     batches = [synth.gen_frame(rng, wl["w"], wl["h"], wl["bd"], inter_frac=1.0, bi_frac=wl["bi_frac"], coded_frac=0.6,
                                n_refs=wl["n_refs"], qp_range=(22, 37), mv_sigma_px=8.0, oob_frac=0.05)
                for _ in range(n_batches)]
-    return first, batches
+    n_ctu = ((wl["w"] + 63) // 64) * ((wl["h"] + 63) // 64)
+    alf = synth.gen_alf_params(rng, n_ctu, ctb_on_frac=1.0) if wl["alf"] else None     # all CTUs on
+    return first, batches, alf
 
 
-def cpu_baseline(wl, first, batch, budget_s=15.0):
+def cpu_baseline(wl, first, batch, alf, budget_s=15.0):
     """The CPU side of the comparison on this host: the reference's own functions (AVX2 tables, one thread)
     through oracle/_ref when that was built in the development container, else the plain-C oracle port."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import ctypes as C
     import oracle_lib as ol
     from xevd_amd import abi
-    sp = abi.make_seq_params(wl["w"], wl["h"], wl["bd"], iqt=wl["iqt"], admvp=wl["admvp"])
+    sp = abi.make_seq_params(wl["w"], wl["h"], wl["bd"], iqt=wl["iqt"], admvp=wl["admvp"], addb=wl["addb"], alf=wl["alf"])
     cb, keep = abi.make_cu_batch(batch)
-    ref = ol.Picture(wl["w"], wl["h"], 0, first)
+    ref = ol.Picture(wl["w"], wl["h"], 0, first[0])
     ref.pad_numpy()
+    ref2 = ol.Picture(wl["w"], wl["h"], -1, first[1])
+    ref2.pad_numpy()
     cur = ol.Picture(wl["w"], wl["h"], 1)
+    ap = keep_ap = None
+    if alf is not None:
+        ap, keep_ap = abi.make_alf_params(alf)
     maps = ol.Maps(wl["w"], wl["h"])
     m = maps.orc()
     kind = "reference" if ol.have_ref() else "port"
     n, t0 = 0, time.perf_counter()
     while True:
-        fr = ol.make_frame(cur, {(0, 0): ref})
+        fr = ol.make_frame(cur, {(0, 0): ref, (0, 1): ref2})
         if kind == "reference":
             hn = ol.harness()
             hn.refh_recon_batch(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), None, 1)
-            hn.refh_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), 1)
+            if wl["addb"]:
+                hn.refh_deblock_addb(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), 0, 0)
+            else:
+                hn.refh_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), 1)
+            if ap is not None:
+                hn.refh_alf(C.byref(sp), C.byref(fr.cur), C.byref(ap))
             hn.refh_pad(C.byref(sp), C.byref(fr.cur))
         else:
             o = ol.oracle()
             o.orc_recon_batch(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), None)
-            o.orc_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m))
+            if wl["addb"]:
+                o.orc_deblock_addb(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), 0, 0)
+            else:
+                o.orc_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m))
+            if ap is not None:
+                o.orc_alf(C.byref(sp), C.byref(fr.cur), C.byref(ap))
             o.orc_pad(C.byref(sp), C.byref(fr.cur))
-        ref, cur = cur, ref
+        ref2, ref, cur = ref, cur, ref2
         n += 1
         dt = time.perf_counter() - t0
         if dt > budget_s or n >= 64:
             break
     return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": kind,
-            "sample": f"{n} pictures of the same {wl['w']}x{wl['h']} workload (recon + deblock + pad), single thread, "
-                      + ("reference functions with its AVX2/SSE tables via oracle/_ref" if kind == "reference" else "plain-C oracle port")}
+            "sample": f"{n} pictures of the same {wl['w']}x{wl['h']} workload (recon + deblock" + (" + ALF" if alf is not None else "")
+                      + " + pad), single thread, "
+                      + ("the reference's own functions (AVX2/SSE tables where it has them; ADDB and ALF are scalar C there) via oracle/_ref"
+                         if kind == "reference" else "plain-C oracle port")}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
-    ap.add_argument("--workload", default="cfg2_base_1080p_8b_ippp", choices=sorted(WORKLOADS))
-    ap.add_argument("--batches", type=int, default=8, help="distinct pictures' CU batches kept resident and cycled")
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--batches", type=int, default=4, help="distinct pictures' CU batches kept resident and cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -122,21 +145,29 @@ def main():
 
     from xevd_amd.decoder import XgpuDecoder
     wl = WORKLOADS[args.workload]
-    first, batches = make_stream(wl, 1000 + rank, args.batches)
-    dec = XgpuDecoder(wl["w"], wl["h"], wl["bd"], device=local_rank, iqt=wl["iqt"], admvp=wl["admvp"], max_pics=4)
-    slots = [dec.pic_alloc(), dec.pic_alloc()]
-    dec.pic_upload(slots[0], first)
-    dec.frame_begin(slots[0], 0, {})
-    dec.pad()
-    dec.frame_end()
+    first, batches, alf = make_stream(wl, 1000 + rank, args.batches)
+    dec = XgpuDecoder(wl["w"], wl["h"], wl["bd"], device=local_rank, iqt=wl["iqt"], admvp=wl["admvp"], addb=wl["addb"],
+                      alf=wl["alf"], max_pics=4)
+    slots = [dec.pic_alloc(), dec.pic_alloc(), dec.pic_alloc()]
+    for i in range(2):
+        dec.pic_upload(slots[i], first[i])
+        dec.frame_begin(slots[i], i - 1, {})
+        dec.pad()
+        dec.frame_end()
     t_up = time.perf_counter()
     handles = [dec.batch_create(b) for b in batches]
     dec.sync()
     t_up = (time.perf_counter() - t_up) / len(batches)
 
+    two_lists = wl["n_refs"][1] > 0
+
     def step(k):
-        cur, ref = slots[(k + 1) & 1], slots[k & 1]
-        dec.decode_picture(cur, k + 1, {(0, 0): (ref, k)}, handles[k % len(handles)])
+        # picture k+1 is predicted from picture k (list 0) and, with two lists, picture k-1 (list 1): a 3-slot DPB ring
+        cur, ref0, ref1 = slots[(k + 2) % 3], slots[(k + 1) % 3], slots[k % 3]
+        refs = {(0, 0): (ref0, k)}
+        if two_lists:
+            refs[(0, 1)] = (ref1, k - 1)
+        dec.decode_picture(cur, k + 1, refs, handles[k % len(handles)], alf=alf)
 
     def barrier():
         if dist is not None:
@@ -168,11 +199,11 @@ def main():
     if rank == 0:
         ab = [algorithmic_bytes(b, wl["w"], wl["h"]) for b in batches]
         kernels = {}
-        for name in ("itdq", "inter", "dbk_v", "dbk_h", "pad"):
+        for name in ("itdq", "inter", "dbk_v", "dbk_h", "alf", "pad"):
             ms, n = tim[name]
             if n:
                 kernels[name] = {"avg_us": round(1e3 * ms / n, 2), "launches": int(n)}
-        dom = max(("itdq", "inter", "dbk_v", "dbk_h"), key=lambda k: tim[k][0])
+        dom = max(("itdq", "inter", "dbk_v", "dbk_h", "alf"), key=lambda k: tim[k][0])
         bytes_per_launch = float(np.mean([a[dom] for a in ab]))
         avg_s = tim[dom][0] / max(tim[dom][1], 1) * 1e-3
         achieved = bytes_per_launch / avg_s / 1e9
@@ -180,8 +211,15 @@ def main():
             copy_bw = dec.measure_copy_bw(1 << 30, 10)
         except Exception:
             copy_bw = None
-        total_alg = float(np.mean([sum(a.values()) for a in ab]))
-        kern_s = sum(tim[k][0] for k in ("itdq", "inter", "dbk_v", "dbk_h", "pad")) * 1e-3 / args.steps
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
+            if pmc["workload"] == args.workload:
+                traffic = pmc["kernels"][dom]["traffic_bytes"]       # from the committed rocprofv3 --pmc passes
+        except Exception:
+            traffic = None
+        total_alg = float(np.mean([sum(v for k, v in a.items() if k != "alf" or wl["alf"]) for a in ab]))
+        kern_s = sum(tim[k][0] for k in ("itdq", "inter", "dbk_v", "dbk_h", "alf", "pad")) * 1e-3 / args.steps
         out = {
             "metric": "frames/sec (bit-exact YUV) + achieved HBM GB/s",
             "value": round(world * args.steps / dt, 2),
@@ -191,11 +229,13 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "s16", "data": "synthetic",
             "config": {"workload": args.workload, "width": wl["w"], "height": wl["h"], "bit_depth": wl["bd"],
-                       "stream": "IPPP, 1 reference, 100% inter CUs (GPU intra prediction is a later row), 60% coded, "
-                                 "deblock on, quad-tree 64..4", "batches_resident": len(batches),
+                       "profile": "Main (admvp 8-tap MC, IQT, ADDB, ALF on every CTU)" if wl["addb"] else "Baseline",
+                       "stream": ("2 reference lists, 50% bi-predicted CUs" if two_lists else "IPPP, 1 reference")
+                                 + ", 100% inter CUs (GPU intra prediction is a later row), 60% coded, deblock on, quad-tree 64..4",
+                       "batches_resident": len(batches),
                        "parallelism": f"{world} independent stream(s), one per GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 2),
                          "measured_copy_bw_gbps": None if copy_bw is None else round(copy_bw, 1),
                          "frac_of_measured_copy_bw": None if not copy_bw else round(achieved / copy_bw, 4)},
@@ -205,7 +245,7 @@ def main():
             "pcie_inclusive_fps": round(1.0 / (dt / args.steps + t_up), 2),
         }
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(wl, first, batches[0])
+            out["cpu_baseline"] = cpu_baseline(wl, first, batches[0], alf)
         print(json.dumps(out))
     barrier()
     dec.close()
