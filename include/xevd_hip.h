@@ -115,6 +115,9 @@ typedef struct xgpu_cu_batch {
     const int16_t  *mv;           /* [n_cu][2][2] quarter-pel (list, x/y), unclipped                      */
     const uint8_t  *qp;           /* [n_cu][3]  core->qp_y/qp_u/qp_v: dequant QPs incl. 6*(bd-8)          */
     const uint8_t  *cbf;          /* [n_cu]  bit c set = component c has coefficients (is_coef[c])        */
+    const uint16_t *cbf_sub;      /* [n_cu] or NULL: for CUs wider/taller than 64, bit (4*c + sb) = nnz_sub[c][sb]
+                                     of the 64x64 sub-blocks sb = (j<<1)|i (xevd_itdq.c:544-621); NULL = every
+                                     sub-block of a coded component is coded                                */
     const uint8_t  *ipm;          /* [n_cu][2] intra luma / chroma mode (intra CUs)                       */
     const uint32_t *coef_off;     /* [n_cu]  offset (in s16 units) of the CU's first coefficient          */
     const int16_t  *coef;         /* [n_coef] coefficient arena                                           */

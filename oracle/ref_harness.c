@@ -155,8 +155,14 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
         memset(core->is_coef_sub, 0, sizeof(core->is_coef_sub));
         for (c = 0; c < 3; c++) {
             const int n = c ? (w >> 1) * (h >> 1) : w * h;
+            int sb;
             core->is_coef[c] = (b->cbf[i] >> c) & 1;
-            core->is_coef_sub[c][0] = core->is_coef[c];
+            /* nnz_sub of the 64x64 sub-blocks, (j<<1)|i; a CU <= 64 only has sub-block 0 */
+            for (sb = 0; sb < 4; sb++) {
+                const int exists = (sb & 1) < (lw > 6 ? 2 : 1) && (sb >> 1) < (lh > 6 ? 2 : 1);
+                core->is_coef_sub[c][sb] = core->is_coef[c] && exists &&
+                    ((lw <= 6 && lh <= 6) || !b->cbf_sub || ((b->cbf_sub[i] >> (4 * c + sb)) & 1));
+            }
             if (core->is_coef[c]) { memcpy(core->coef[c], b->coef + o, sizeof(s16) * n); o += n; }
         }
         if (b->pred_mode[i] == XGPU_MODE_INTRA) {
@@ -238,15 +244,23 @@ int refh_deblock_addb(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu
     ctx->pic->pic_deblock_beta_offset = beta_off;
     (void)mctx;
     for (k = 0; k < (int)ctx->f_scu; k++) MCU_CLR_COD(ctx->map_scu[k]);
-    for (i = 0; i < b->n_cu; i++)
-        xevdm_deblock_cu_ver(ctx, ctx->pic, b->x[i], b->y[i], 1 << b->log2w[i], 1 << b->log2h[i], ctx->map_scu, ctx->map_refi, ctx->map_mv,
-                             ctx->w_scu, sp->log2_ctu, ctx->map_cu_mode, ctx->refp, 0, tc, ctx->map_tidx, 0, 1, map_ats,
-                             sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
+    for (i = 0; i < b->n_cu; i++) {      /* CUs above 64 go in as two halves, deblock_tree xevdm.c:2017-2037 */
+        const int cw = 1 << b->log2w[i];
+        int hx;
+        for (hx = 0; hx < cw; hx += 64)
+            xevdm_deblock_cu_ver(ctx, ctx->pic, b->x[i] + hx, b->y[i], cw > 64 ? 64 : cw, 1 << b->log2h[i], ctx->map_scu, ctx->map_refi, ctx->map_mv,
+                                 ctx->w_scu, sp->log2_ctu, ctx->map_cu_mode, ctx->refp, 0, tc, ctx->map_tidx, 0, 1, map_ats,
+                                 sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
+    }
     for (k = 0; k < (int)ctx->f_scu; k++) MCU_CLR_COD(ctx->map_scu[k]);
-    for (i = 0; i < b->n_cu; i++)
-        xevdm_deblock_cu_hor(ctx, ctx->pic, b->x[i], b->y[i], 1 << b->log2w[i], 1 << b->log2h[i], ctx->map_scu, ctx->map_refi, ctx->map_mv,
-                             ctx->w_scu, sp->log2_ctu, ctx->refp, 0, tc, ctx->map_tidx, 0, 1, map_ats,
-                             sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
+    for (i = 0; i < b->n_cu; i++) {
+        const int ch = 1 << b->log2h[i];
+        int hy;
+        for (hy = 0; hy < ch; hy += 64)
+            xevdm_deblock_cu_hor(ctx, ctx->pic, b->x[i], b->y[i] + hy, 1 << b->log2w[i], ch > 64 ? 64 : ch, ctx->map_scu, ctx->map_refi, ctx->map_mv,
+                                 ctx->w_scu, sp->log2_ctu, ctx->refp, 0, tc, ctx->map_tidx, 0, 1, map_ats,
+                                 sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
+    }
     free(map_ats);
     harness_free(hn);
     return 0;

@@ -359,7 +359,8 @@ static void set_dec_info(const xgpu_seq_params *sp, const xgpu_cu_batch *b, int 
     uint32_t v = (qp << 16) | ((uint32_t)intra << 15) | (1u << 31);
     int r, c;
     if (b->pred_mode[i] == XGPU_MODE_SKIP) v |= 1u << 23;
-    if (b->cbf[i] & 1) v |= 1u << 24;
+    /* the luma cbf flag of the map is is_coef_sub[Y_C][0] (xevd_util.c:1615): for a CU above 64 only its first 64x64 sub-block counts */
+    if ((b->cbf[i] & 1) && (!(b->log2w[i] > 6 || b->log2h[i] > 6) || !b->cbf_sub || (b->cbf_sub[i] & 1))) v |= 1u << 24;
     for (r = 0; r < hs; r++) for (c = 0; c < ws; c++) {
         const int k = (ys + r) * m->w_scu + xs + c;
         m->map_scu[k] = v;
@@ -393,9 +394,25 @@ int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_c
             const int s = c ? fr->cur.s_c : fr->cur.s_l;
             if (coded) {
                 /* xevd_sub_block_itdq (xevd_itdq.c:544-621): the LUMA bit depth is used for all components
-                   (xevd.c:441-442); TBs are at most 64 wide so a CU <= 64 is one TB per component */
+                   (xevd.c:441-442); TBs are at most 64x64: a larger CU is transformed as 64x64 (chroma 32x32)
+                   sub-blocks sb = (j<<1)|i that are copied out of and back into the CU-strided block */
+                const int tlw = clw > (c ? 5 : 6) ? (c ? 5 : 6) : clw, tlh = clh > (c ? 5 : 6) ? (c ? 5 : 6) : clh;
+                const int nsx = 1 << (clw - tlw), nsy = 1 << (clh - tlh), tw = 1 << tlw, th = 1 << tlh;
+                int si, sj, r;
                 memcpy(res, b->coef + off, sizeof(int16_t) * cw * ch);
-                orc_itdq(res, clw, clh, b->qp[i * 3 + c], sp->bit_depth_luma, sp->tool_iqt);
+                for (sj = 0; sj < nsy; sj++) for (si = 0; si < nsx; si++) {
+                    const int sb = (sj << 1) | si;
+                    int16_t *blk = res + sj * th * cw + si * tw;
+                    if (nsx * nsy > 1 && b->cbf_sub && !((b->cbf_sub[i] >> (4 * c + sb)) & 1)) continue;
+                    if (nsx * nsy == 1) { orc_itdq(res, tlw, tlh, b->qp[i * 3 + c], sp->bit_depth_luma, sp->tool_iqt); continue; }
+                    {
+                        int16_t *tmp = (int16_t *)malloc(sizeof(int16_t) * tw * th);
+                        for (r = 0; r < th; r++) memcpy(tmp + r * tw, blk + r * cw, sizeof(int16_t) * tw);
+                        orc_itdq(tmp, tlw, tlh, b->qp[i * 3 + c], sp->bit_depth_luma, sp->tool_iqt);
+                        for (r = 0; r < th; r++) memcpy(blk + r * cw, tmp + r * tw, sizeof(int16_t) * tw);
+                        free(tmp);
+                    }
+                }
                 if (resid_out) memcpy(resid_out + off, res, sizeof(int16_t) * cw * ch);
                 off += (size_t)cw * ch;
             }
@@ -642,20 +659,30 @@ int orc_deblock_addb(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
     int i, r, c, k;
     /* vertical edges on the 8x8 luma grid (deblock_addb_cu_ver, xevdm_df.c:1036-1135), then horizontal (:835-945) */
     for (k = 0; k < ws * m->h_scu; k++) m->map_scu[k] &= 0x7FFFFFFFu;
+    /* a CU wider (taller) than 64 is passed to the CU filter as two 64-sample halves (deblock_tree, xevdm.c:1989-2037),
+       which makes its inner 64-sample boundary an edge */
     for (i = 0; i < b->n_cu; i++) {
-        const int x = b->x[i], y = b->y[i], w = 1 << b->log2w[i], h = 1 << b->log2h[i];
-        const int t = (x >> 2) + (y >> 2) * ws;
-        if ((x & 7) == 0 && x > 0 && MCU_COD(m->map_scu[t - 1]))
-            for (r = 0; r < h >> 2; r++) addb_segment(sp, fr, m, t + r * ws, t + r * ws - 1, x, y + 4 * r, 1, alpha_off, beta_off);
-        if (((x + w) & 7) == 0 && x + w < sp->width && MCU_COD(m->map_scu[t + (w >> 2)]))
-            for (r = 0; r < h >> 2; r++) addb_segment(sp, fr, m, t + r * ws + (w >> 2), t + r * ws + (w >> 2) - 1, x + w, y + 4 * r, 1, alpha_off, beta_off);
-        for (r = 0; r < h >> 2; r++) for (c = 0; c < w >> 2; c++) m->map_scu[t + r * ws + c] |= 1u << 31;
+        const int cx = b->x[i], y = b->y[i], cw = 1 << b->log2w[i], h = 1 << b->log2h[i];
+        int hx;
+        for (hx = 0; hx < cw; hx += 64) {
+            const int x = cx + hx, w = cw > 64 ? 64 : cw;
+            const int t = (x >> 2) + (y >> 2) * ws;
+            if ((x & 7) == 0 && x > 0 && MCU_COD(m->map_scu[t - 1]))
+                for (r = 0; r < h >> 2; r++) addb_segment(sp, fr, m, t + r * ws, t + r * ws - 1, x, y + 4 * r, 1, alpha_off, beta_off);
+            if (((x + w) & 7) == 0 && x + w < sp->width && MCU_COD(m->map_scu[t + (w >> 2)]))
+                for (r = 0; r < h >> 2; r++) addb_segment(sp, fr, m, t + r * ws + (w >> 2), t + r * ws + (w >> 2) - 1, x + w, y + 4 * r, 1, alpha_off, beta_off);
+            for (r = 0; r < h >> 2; r++) for (c = 0; c < w >> 2; c++) m->map_scu[t + r * ws + c] |= 1u << 31;
+        }
     }
     for (i = 0; i < b->n_cu; i++) {
-        const int x = b->x[i], y = b->y[i], w = 1 << b->log2w[i];
-        const int t = (x >> 2) + (y >> 2) * ws;
-        if ((y & 7) == 0 && y > 0)
-            for (c = 0; c < w >> 2; c++) addb_segment(sp, fr, m, t + c, t + c - ws, x + 4 * c, y, 0, alpha_off, beta_off);
+        const int x = b->x[i], cy = b->y[i], w = 1 << b->log2w[i], ch = 1 << b->log2h[i];
+        int hy;
+        for (hy = 0; hy < ch; hy += 64) {
+            const int y = cy + hy;
+            const int t = (x >> 2) + (y >> 2) * ws;
+            if ((y & 7) == 0 && y > 0)
+                for (c = 0; c < w >> 2; c++) addb_segment(sp, fr, m, t + c, t + c - ws, x + 4 * c, y, 0, alpha_off, beta_off);
+        }
     }
     return 0;
 }

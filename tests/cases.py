@@ -22,6 +22,9 @@ CASES = [
     ("main_alf_10b", 200, 136, 10, 1, 1, (2, 2), 0.5, {"addb": 1, "alf": 1, "inter_frac": 1.0}),
     ("main_alf_8b_across_tiles", 136, 72, 8, 1, 1, (1, 1), 0.4, {"addb": 1, "alf": 1, "across_tiles": 1, "inter_frac": 1.0}),
     ("main_alf_only_luma", 72, 136, 10, 1, 1, (1, 0), 0.0, {"alf": 1, "alf_enable": (1, 0, 0), "inter_frac": 1.0, "no_deblock": 1}),
+    # CTU 128: CUs up to 128x128 (four 64x64 sub-TBs), deblocking of the inner 64-sample boundaries, ALF CTU rules
+    ("main_ctu128_10b", 264, 200, 10, 1, 1, (2, 2), 0.5, {"addb": 1, "alf": 1, "inter_frac": 1.0, "log2_ctu": 7, "split_prob": 0.25}),
+    ("main_ctu128_8b_noiqt", 256, 128, 8, 1, 0, (1, 1), 0.4, {"addb": 1, "log2_ctu": 7, "split_prob": 0.2}),
 ]
 POCS = [[4, 0, 2], [12, 16, 4]]      # L1 idx 2 has the POC of L0 idx 0 -> identical-motion candidates exist
 CUR_POC = 8
@@ -36,6 +39,8 @@ def build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, tools=None, seed=0, 
                amp=2.0, oob_frac=0.1):
     tools = dict(tools or {})
     inter_frac = tools.get("inter_frac", inter_frac)
+    split_prob = tools.get("split_prob", split_prob)
+    log2_ctu = int(tools.get("log2_ctu", 6))
     rng = np.random.default_rng(zlib.crc32(name.encode()) % 1000 + seed)
     refs = {}
     for l in range(2):
@@ -45,7 +50,7 @@ def build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, tools=None, seed=0, 
             refs[(i, l)] = pic
     if (2, 1) in refs and (0, 0) in refs:
         refs[(2, 1)] = refs[(0, 0)]      # the same picture in both lists (same POC 4): ADDB compares pictures, not indices
-    batch = synth.gen_frame(rng, w, h, bd, inter_frac=inter_frac, bi_frac=bi_frac, n_refs=n_refs, oob_frac=oob_frac,
+    batch = synth.gen_frame(rng, w, h, bd, log2_ctu=log2_ctu, inter_frac=inter_frac, bi_frac=bi_frac, n_refs=n_refs, oob_frac=oob_frac,
                             qp_range=qp_range, split_prob=split_prob, amp=amp)
     if n_refs[0] and n_refs[1]:      # force some identical-motion bi CUs
         sel = (batch["refi"][:, 0] >= 0) & (batch["refi"][:, 1] >= 0)
@@ -53,11 +58,12 @@ def build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, tools=None, seed=0, 
         batch["mv"][idx, 1] = batch["mv"][idx, 0]
     alf_params = None
     if tools.get("alf"):
-        n_ctu = ((w + 63) // 64) * ((h + 63) // 64)
+        ctu = 1 << log2_ctu
+        n_ctu = ((w + ctu - 1) // ctu) * ((h + ctu - 1) // ctu)
         alf_params = synth.gen_alf_params(rng, n_ctu, across_tiles=int(tools.get("across_tiles", 0)),
                                           enable=tools.get("alf_enable", (1, 1, 1)))
     return {"name": name, "w": w, "h": h, "bd": bd, "admvp": admvp, "iqt": iqt, "refs": refs, "batch": batch,
-            "alf_params": alf_params, "no_deblock": int(tools.get("no_deblock", 0)),
+            "alf_params": alf_params, "no_deblock": int(tools.get("no_deblock", 0)), "log2_ctu": log2_ctu,
             "addb": int(tools.get("addb", 0)), "alf": int(tools.get("alf", 0)),
             "alpha_off": int(tools.get("alpha_off", 0)), "beta_off": int(tools.get("beta_off", 0))}
 
@@ -72,8 +78,8 @@ def _start_picture(case):
 
 def run_cpu(engine, case, deblock=True, simd=0, pad=True):
     """engine 'oracle' (oracle/liboracle.so) or 'ref' (the real reference through oracle/_ref). -> (final, pre-deblock, maps, resid)"""
-    sp = abi.make_seq_params(case["w"], case["h"], case["bd"], iqt=case["iqt"], admvp=case["admvp"], addb=case.get("addb", 0),
-                             alf=case.get("alf", 0))
+    sp = abi.make_seq_params(case["w"], case["h"], case["bd"], log2_ctu=case.get("log2_ctu", 6), iqt=case["iqt"], admvp=case["admvp"],
+                             addb=case.get("addb", 0), alf=case.get("alf", 0))
     cb, keep = abi.make_cu_batch(case["batch"])
     cur = _start_picture(case)
     maps = ol.Maps(case["w"], case["h"])
@@ -114,8 +120,8 @@ def run_cpu(engine, case, deblock=True, simd=0, pad=True):
 def run_gpu(case, deblock=True, pad=True, alf=True):
     """The HIP backend through the C ABI. -> list of padded planes (reference buffer geometry)"""
     from xevd_amd.decoder import XgpuDecoder
-    with XgpuDecoder(case["w"], case["h"], case["bd"], iqt=case["iqt"], admvp=case["admvp"], addb=case.get("addb", 0),
-                     alf=case.get("alf", 0), max_pics=8) as dec:
+    with XgpuDecoder(case["w"], case["h"], case["bd"], log2_ctu=case.get("log2_ctu", 6), iqt=case["iqt"], admvp=case["admvp"],
+                     addb=case.get("addb", 0), alf=case.get("alf", 0), max_pics=8) as dec:
         slots, by_obj = {}, {}
         for key, pic in case["refs"].items():
             if id(pic) not in by_obj:            # one device picture per distinct picture

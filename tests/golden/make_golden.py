@@ -112,7 +112,7 @@ def golden_pictures():
         cs = cases.build_case(*case)
         final, pre, maps, resid = cases.run_cpu("ref", cs)
         d = {"params": np.array(case[1:6], np.int64), "n_refs": np.array(case[6], np.int64),
-             "tools": np.array([cs["addb"], cs["alf"], cs["alpha_off"], cs["beta_off"], cs["no_deblock"]], np.int64)}
+             "tools": np.array([cs["addb"], cs["alf"], cs["alpha_off"], cs["beta_off"], cs["no_deblock"], cs["log2_ctu"]], np.int64)}
         if cs["alf_params"] is not None:
             ap = cs["alf_params"]
             d["alf_enable"] = np.array(ap["enable"], np.int64)
@@ -128,7 +128,8 @@ def golden_pictures():
                 d[f"ref_{i}_{l}_{c}"] = pic.active(c)
             d[f"refpoc_{i}_{l}"] = np.array(pic.poc)
         for k, v in cs["batch"].items():
-            d["b_" + k] = np.asarray(v)
+            if v is not None:
+                d["b_" + k] = np.asarray(v)
         for c in range(3):
             d[f"out_{c}"] = final.bufs[c]
             d[f"pre_{c}"] = pre.active(c)

@@ -7,7 +7,8 @@ import oracle_lib as ol
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 PICTURE_CASES = ["base_p_8b", "base_b_8b", "base_p_10b", "main_b_10b", "main_admvp_only", "main_iqt_only",
-                 "main_addb_10b", "main_addb_8b_shared_refs", "main_alf_10b", "main_alf_8b_across_tiles", "main_alf_only_luma"]
+                 "main_addb_10b", "main_addb_8b_shared_refs", "main_alf_10b", "main_alf_8b_across_tiles", "main_alf_only_luma",
+                 "main_ctu128_10b", "main_ctu128_8b_noiqt"]
 
 
 def load_picture_case(name):
@@ -25,15 +26,17 @@ def load_picture_case(name):
         for i in range(int(d["n_refs"][l])):
             if f"refalias_{i}_{l}" in d.files:
                 refs[(i, l)] = refs[tuple(int(v) for v in d[f"refalias_{i}_{l}"])]
-    tools = ([int(v) for v in d["tools"]] + [0] * 5)[:5] if "tools" in d.files else [0, 0, 0, 0, 0]
+    tools = [int(v) for v in d["tools"]] if "tools" in d.files else []
+    tools = (tools + [0, 0, 0, 0, 0, 6][len(tools):])[:6]
     alf_params = None
     if "alf_enable" in d.files:
         alf_params = {"enable": tuple(int(v) for v in d["alf_enable"]), "luma_coef": d["alf_luma_coef"], "chroma_coef": d["alf_chroma_coef"],
                       "ctb_flag": d["alf_ctb_flag"], "across_tiles": int(d["alf_across_tiles"])}
     batch = {k[2:]: d[k] for k in d.files if k.startswith("b_")}
     batch["n_coef"] = int(batch["n_coef"])
+    batch.setdefault("cbf_sub", None)
     case = {"name": name, "w": w, "h": h, "bd": bd, "admvp": admvp, "iqt": iqt, "refs": refs, "batch": batch,
-            "addb": tools[0], "alf": tools[1], "alpha_off": tools[2], "beta_off": tools[3], "no_deblock": tools[4],
+            "addb": tools[0], "alf": tools[1], "alpha_off": tools[2], "beta_off": tools[3], "no_deblock": tools[4], "log2_ctu": tools[5],
             "alf_params": alf_params}
     expect = {"out": [d[f"out_{c}"] for c in range(3)], "pre": [d[f"pre_{c}"] for c in range(3)], "resid": d["resid"],
               "map_scu": d["map_scu"]}

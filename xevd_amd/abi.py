@@ -45,7 +45,7 @@ class CuBatch(C.Structure):
         ("log2w", C.POINTER(C.c_uint8)), ("log2h", C.POINTER(C.c_uint8)),
         ("pred_mode", C.POINTER(C.c_uint8)),
         ("refi", C.POINTER(C.c_int8)), ("mv", C.POINTER(C.c_int16)),
-        ("qp", C.POINTER(C.c_uint8)), ("cbf", C.POINTER(C.c_uint8)), ("ipm", C.POINTER(C.c_uint8)),
+        ("qp", C.POINTER(C.c_uint8)), ("cbf", C.POINTER(C.c_uint8)), ("cbf_sub", C.POINTER(C.c_uint16)), ("ipm", C.POINTER(C.c_uint8)),
         ("coef_off", C.POINTER(C.c_uint32)), ("coef", C.POINTER(C.c_int16)), ("n_coef", C.c_size_t),
         ("n_ctu", C.c_int), ("ctu_cu_start", C.POINTER(C.c_uint32)),
     ]
@@ -85,6 +85,7 @@ def make_cu_batch(b):
         "refi": np.ascontiguousarray(b["refi"], np.int8), "mv": np.ascontiguousarray(b["mv"], np.int16),
         "qp": np.ascontiguousarray(b["qp"], np.uint8), "cbf": np.ascontiguousarray(b["cbf"], np.uint8),
         "ipm": np.ascontiguousarray(b["ipm"], np.uint8),
+        "cbf_sub": None if b.get("cbf_sub") is None else np.ascontiguousarray(b["cbf_sub"], np.uint16),
         "coef_off": np.ascontiguousarray(b["coef_off"], np.uint32),
         "coef": np.ascontiguousarray(b["coef"], np.int16),
         "ctu_cu_start": np.ascontiguousarray(b["ctu_cu_start"], np.uint32),
@@ -96,6 +97,8 @@ def make_cu_batch(b):
     cb.pred_mode = _ptr(keep["pred_mode"], C.c_uint8)
     cb.refi, cb.mv = _ptr(keep["refi"], C.c_int8), _ptr(keep["mv"], C.c_int16)
     cb.qp, cb.cbf, cb.ipm = _ptr(keep["qp"], C.c_uint8), _ptr(keep["cbf"], C.c_uint8), _ptr(keep["ipm"], C.c_uint8)
+    if keep["cbf_sub"] is not None:
+        cb.cbf_sub = _ptr(keep["cbf_sub"], C.c_uint16)
     cb.coef_off, cb.coef = _ptr(keep["coef_off"], C.c_uint32), _ptr(keep["coef"], C.c_int16)
     cb.n_coef = len(keep["coef"])
     cb.n_ctu = len(keep["ctu_cu_start"]) - 1

@@ -28,6 +28,18 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
 {
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b), c, false);
 }
+__device__ __forceinline__ int dot2z(uint32_t a, uint32_t b)       // first tap pair of a chain: VOP3P form with a literal 0 addend
+{                                                                  // (the builtin picks v_dot2c, which needs a v_mov 0 first)
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ int dot2a(uint32_t a, uint32_t b, int c)   // VOP3P form, addend not tied to the destination
+{
+    int r;
+    asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 __device__ __forceinline__ uint32_t hi_lo(uint32_t hi, uint32_t lo)   // (lo.hi16, hi.lo16): samples 2m+1, 2m+2
 {
     return __builtin_amdgcn_alignbit(hi, lo, 16);
@@ -36,7 +48,12 @@ __device__ __forceinline__ uint32_t pack2(int lo, int hi)               // two s
 {
     return __builtin_amdgcn_perm((uint32_t)hi, (uint32_t)lo, 0x05040100u);
 }
-__device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
+__device__ __forceinline__ int clip3(int lo, int hi, int v)
+{
+    int r;                                   // one v_med3_i32 instead of v_max + v_min (the kernel is VALU-issue bound)
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(v), "v"(lo), "v"(hi));
+    return r;
+}
 
 // Interpolation taps as packed s16 pairs.  Luma rows: phase (1/16 pel) -> 4 dwords; chroma: phase (1/32) -> 2 dwords.
 // Baseline tables: src_base/xevd_mc.c:80-134 (phases 0,4,8,12 / 0,4,..,28); Main (sps_admvp_flag):
@@ -74,13 +91,14 @@ __constant__ uint32_t k_chroma_taps[2][33][2] = {
 // (xevd_mc.c:169-288 / :290-408, shifts xevd_mc.h:34-38):
 //   stage 1: t = (sum_h) >> sh1, clipped to [0,max] only in the H-only regime, then truncated to s16
 //   stage 2: out = clip((sum_v + off2) >> sh2)
-struct Regime { int sh1, clip1, sh2, off2; };
+struct Regime { int sh1, lo1, hi1, sh2, off2; };     // stage-1 clamp bounds: [0,max] in the H-only regime, else the whole s32 range
 __device__ __forceinline__ Regime regime(int has_dx, int has_dy, int bd)
 {
     Regime r;
     const int shift1 = min(4, bd - 8), shift2 = max(8, 20 - bd);
     r.sh1   = has_dx ? (has_dy ? shift1 : 6) : 0;
-    r.clip1 = has_dx && !has_dy;
+    r.lo1   = (has_dx && !has_dy) ? 0 : (int)0x80000000;
+    r.hi1   = (has_dx && !has_dy) ? (1 << bd) - 1 : 0x7FFFFFFF;
     r.sh2   = has_dy ? (has_dx ? shift2 : 6) : 0;
     r.off2  = (has_dy && has_dx) ? (1 << (shift2 - 1)) : 0;
     return r;
@@ -92,10 +110,6 @@ __device__ __forceinline__ void mc_luma_4x4(const int16_t *p, int s, const uint3
                                             Regime rg, int maxv, uint32_t o[8])
 {
     int acc[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; r++)
-#pragma unroll
-        for (int c = 0; c < 4; c++) acc[r][c] = rg.off2;
     int tp[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int j = 0; j < 11; j++) {
@@ -104,15 +118,12 @@ __device__ __forceinline__ void mc_luma_4x4(const int16_t *p, int s, const uint3
         const uint32_t D0 = a.a, D1 = a.b, D2 = a.c, D3 = a.d, D4 = b.a, D5 = b.b;
         const uint32_t Q0 = hi_lo(D1, D0), Q1 = hi_lo(D2, D1), Q2 = hi_lo(D3, D2), Q3 = hi_lo(D4, D3), Q4 = hi_lo(D5, D4);
         int t[4];
-        t[0] = dot2(ch[3], D3, dot2(ch[2], D2, dot2(ch[1], D1, dot2(ch[0], D0, 0))));
-        t[2] = dot2(ch[3], D4, dot2(ch[2], D3, dot2(ch[1], D2, dot2(ch[0], D1, 0))));
-        t[1] = dot2(ch[3], Q3, dot2(ch[2], Q2, dot2(ch[1], Q1, dot2(ch[0], Q0, 0))));
-        t[3] = dot2(ch[3], Q4, dot2(ch[2], Q3, dot2(ch[1], Q2, dot2(ch[0], Q1, 0))));
+        t[0] = dot2(ch[3], D3, dot2(ch[2], D2, dot2(ch[1], D1, dot2z(ch[0], D0))));
+        t[2] = dot2(ch[3], D4, dot2(ch[2], D3, dot2(ch[1], D2, dot2z(ch[0], D1))));
+        t[1] = dot2(ch[3], Q3, dot2(ch[2], Q2, dot2(ch[1], Q1, dot2z(ch[0], Q0))));
+        t[3] = dot2(ch[3], Q4, dot2(ch[2], Q3, dot2(ch[1], Q2, dot2z(ch[0], Q1))));
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            t[c] >>= rg.sh1;
-            if (rg.clip1) t[c] = clip3(0, maxv, t[c]);
-        }
+        for (int c = 0; c < 4; c++) t[c] = clip3(rg.lo1, rg.hi1, t[c] >> rg.sh1);
         if (j > 0) {
             // row pair (j-1, j) feeds output row r with tap pair (j-1-r)/2 when j-1-r is even and in 0..6
 #pragma unroll
@@ -121,7 +132,8 @@ __device__ __forceinline__ void mc_luma_4x4(const int16_t *p, int s, const uint3
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int d = j - 1 - r;
-                    if (d >= 0 && d <= 6 && (d & 1) == 0) acc[r][c] = dot2(cv[d >> 1], pr, acc[r][c]);
+                    if (d == 0) acc[r][c] = dot2a(cv[0], pr, rg.off2);          // first tap pair carries the rounding offset
+                    else if (d > 0 && d <= 6 && (d & 1) == 0) acc[r][c] = dot2(cv[d >> 1], pr, acc[r][c]);
                 }
             }
         }
@@ -142,7 +154,7 @@ __device__ __forceinline__ void mc_luma_4x4(const int16_t *p, int s, const uint3
 __device__ __forceinline__ void mc_chroma_2x2(const int16_t *p, int s, const uint32_t ch[2], const uint32_t cv[2],
                                               Regime rg, int maxv, uint32_t o[2])
 {
-    int acc[2][2] = {{rg.off2, rg.off2}, {rg.off2, rg.off2}};
+    int acc[2][2];
     int tp[2] = {0, 0};
 #pragma unroll
     for (int j = 0; j < 5; j++) {
@@ -151,13 +163,10 @@ __device__ __forceinline__ void mc_chroma_2x2(const int16_t *p, int s, const uin
         const uint32_t D0 = a.a, D1 = a.b, D2 = b.a;
         const uint32_t Q0 = hi_lo(D1, D0), Q1 = hi_lo(D2, D1);
         int t[2];
-        t[0] = dot2(ch[1], D1, dot2(ch[0], D0, 0));
-        t[1] = dot2(ch[1], Q1, dot2(ch[0], Q0, 0));
+        t[0] = dot2(ch[1], D1, dot2z(ch[0], D0));
+        t[1] = dot2(ch[1], Q1, dot2z(ch[0], Q0));
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-            t[c] >>= rg.sh1;
-            if (rg.clip1) t[c] = clip3(0, maxv, t[c]);
-        }
+        for (int c = 0; c < 2; c++) t[c] = clip3(rg.lo1, rg.hi1, t[c] >> rg.sh1);
         if (j > 0) {
 #pragma unroll
             for (int c = 0; c < 2; c++) {
@@ -165,7 +174,8 @@ __device__ __forceinline__ void mc_chroma_2x2(const int16_t *p, int s, const uin
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
                     const int d = j - 1 - r;
-                    if (d >= 0 && d <= 2 && (d & 1) == 0) acc[r][c] = dot2(cv[d >> 1], pr, acc[r][c]);
+                    if (d == 0) acc[r][c] = dot2a(cv[0], pr, rg.off2);
+                    else if (d == 2) acc[r][c] = dot2(cv[1], pr, acc[r][c]);
                 }
             }
         }
@@ -244,9 +254,10 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     {
         uint32_t m = ((uint32_t)qp_map << 16) | ((uint32_t)intra << 15) | (1u << 31);
         if (pred_mode == XGPU_MODE_SKIP) m |= 1u << 23;
-        if (cbf & 1) m |= 1u << 24;
-        if (x == cu_x) m |= SCU_EDGE_L;
-        if (y == cu_y) m |= SCU_EDGE_T;
+        if ((r0.z >> 24) & 1) m |= 1u << 24;          // CuRec.map_cbf
+        // CU boundary, or the 64-sample transform boundary inside a wider CU (deblock_tree splits those, xevdm.c:1989-2037)
+        if (((x - cu_x) & 63) == 0) m |= SCU_EDGE_L;
+        if (((y - cu_y) & 63) == 0) m |= SCU_EDGE_T;
         uint4 rec;
         rec.x = m;
         rec.y = intra ? 0x0000FFFFu : (r0.z & 0xFFFFu);

@@ -99,9 +99,11 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
             const int qp = tb.qp, sidx = qp % 6;
             const int sbase = sidx == 0 ? 40 : sidx == 1 ? 45 : sidx == 2 ? 51 : sidx == 3 ? 57 : sidx == 4 ? 64 : (a.iqt ? 72 : 71);
             const long long mul = (long long)(sbase << (qp / 6)) * (odd ? 181 : 1);
+            // row-major TB with row stride 2^log2s (a sub-block of a >64 CU keeps the CU's stride, xevd_itdq.c:573-584)
+            const int16_t *src = a.coef + tb.off + ((o >> LW) << tb.log2s) + (o & (W - 1));
             uint32_t raw[UN / 2];
-            if constexpr (UN == 8) { const uint4 v = *(const uint4 *)(a.coef + tb.off + o); raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w; }
-            else { const uint2 v = *(const uint2 *)(a.coef + tb.off + o); raw[0] = v.x; raw[1] = v.y; }
+            if constexpr (UN == 8) { const uint4 v = *(const uint4 *)src; raw[0] = v.x; raw[1] = v.y; raw[2] = v.z; raw[3] = v.w; }
+            else { const uint2 v = *(const uint2 *)src; raw[0] = v.x; raw[1] = v.y; }
 #pragma unroll
             for (int i = 0; i < UN / 2; i++) {
                 if (raw[i] == 0) continue;
@@ -193,7 +195,7 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
                 res[n] = (int)min(max(s >> shift2, -32768ll), 32767ll);
             }
         }
-        int16_t *out = a.resid + tb.off + r * W + chunk * N2;
+        int16_t *out = a.resid + tb.off + (r << tb.log2s) + chunk * N2;
         if constexpr (N2 >= 8) {
 #pragma unroll
             for (int n = 0; n < N2; n += 8) {

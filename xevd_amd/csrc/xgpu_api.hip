@@ -313,12 +313,22 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     int cls_count[64] = { 0 };
     for (int i = 0; i < n; i++) {
         const int lw = b->log2w[i], lh = b->log2h[i];
-        ARGCHK(c, lw >= 2 && lw <= 6 && lh >= 2 && lh <= 6);         // CUs above 64 (Main CTU 128) are a later row
+        ARGCHK(c, lw >= 2 && lw <= 7 && lh >= 2 && lh <= 7 && lw <= c->sp.log2_ctu && lh <= c->sp.log2_ctu);
         ARGCHK(c, b->x[i] + (1 << lw) <= c->sp.width && b->y[i] + (1 << lh) <= c->sp.height && !(b->x[i] & 3) && !(b->y[i] & 3));
         if (b->pred_mode[i] != XGPU_MODE_INTRA) ARGCHK(c, b->refi[i * 2] < XGPU_MAX_REFS && b->refi[i * 2 + 1] < XGPU_MAX_REFS);
         size_t need = 0;
-        for (int k = 0; k < 3; k++)
-            if ((b->cbf[i] >> k) & 1) { cls_count[(k ? lw - 1 : lw) * 8 + (k ? lh - 1 : lh)]++; need += (size_t)(1 << (lw + lh)) >> (k ? 2 : 0); }
+        for (int k = 0; k < 3; k++) {
+            if (!((b->cbf[i] >> k) & 1)) continue;
+            // TBs are at most 64 wide/tall: a larger CU is cut into 64x64 (chroma 32x32) sub-blocks (xevd_itdq.c:544-621)
+            const int tw = std::min(lw, 6) - (k ? 1 : 0), th = std::min(lh, 6) - (k ? 1 : 0);
+            const int nsx = lw > 6 ? 2 : 1, nsy = lh > 6 ? 2 : 1;
+            for (int sb = 0; sb < 4; sb++) {
+                if ((sb & 1) >= nsx || (sb >> 1) >= nsy) continue;
+                if (nsx * nsy > 1 && b->cbf_sub && !((b->cbf_sub[i] >> (4 * k + sb)) & 1)) continue;
+                cls_count[tw * 8 + th]++;
+            }
+            need += (size_t)(1 << (lw + lh)) >> (k ? 2 : 0);
+        }
         ARGCHK(c, (size_t)b->coef_off[i] + need <= b->n_coef);
     }
     int cls_first[64], n_tb = 0, n_waves = 0;
@@ -353,6 +363,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         r.pred_mode = b->pred_mode[i]; r.cbf = b->cbf[i] & 7;
         r.refi[0] = b->refi[i * 2]; r.refi[1] = b->refi[i * 2 + 1];
         r.qp_map = (uint8_t)((b->qp[i * 3] - bdoff) & 0x7F);
+        r.map_cbf = (uint8_t)((r.cbf & 1) && (!(r.log2w > 6 || r.log2h > 6) || !b->cbf_sub || (b->cbf_sub[i] & 1)));
         r.coef_off = b->coef_off[i];
         memcpy(r.mv, &b->mv[i * 4], sizeof(r.mv));
         r.qp[0] = b->qp[i * 3]; r.qp[1] = b->qp[i * 3 + 1]; r.qp[2] = b->qp[i * 3 + 2];
@@ -360,10 +371,18 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         uint32_t off = r.coef_off;
         for (int k = 0; k < 3; k++) {
             if (!((r.cbf >> k) & 1)) continue;
-            const int lw = k ? r.log2w - 1 : r.log2w, lh = k ? r.log2h - 1 : r.log2h;
-            TbRec &t = tbs[cls_fill[lw * 8 + lh]++];
-            t.off = off; t.log2w = (uint8_t)lw; t.log2h = (uint8_t)lh; t.qp = r.qp[k]; t.rsvd = 0;
-            off += 1u << (lw + lh);
+            const int cl = k ? r.log2w - 1 : r.log2w, chh = k ? r.log2h - 1 : r.log2h;        // component block of the CU
+            const int tw = std::min((int)r.log2w, 6) - (k ? 1 : 0), th = std::min((int)r.log2h, 6) - (k ? 1 : 0);
+            const int nsx = r.log2w > 6 ? 2 : 1, nsy = r.log2h > 6 ? 2 : 1;
+            for (int sb = 0; sb < 4; sb++) {
+                const int si = sb & 1, sj = sb >> 1;
+                if (si >= nsx || sj >= nsy) continue;
+                if (nsx * nsy > 1 && b->cbf_sub && !((b->cbf_sub[i] >> (4 * k + sb)) & 1)) continue;
+                TbRec &t = tbs[cls_fill[tw * 8 + th]++];
+                t.off = off + ((uint32_t)sj << (th + cl)) + ((uint32_t)si << tw);
+                t.log2w = (uint8_t)tw; t.log2h = (uint8_t)th; t.qp = r.qp[k]; t.log2s = (uint8_t)cl;
+            }
+            off += 1u << (cl + chh);
         }
     }
     int w = 0;
@@ -566,7 +585,7 @@ int xgpu_test_itdq(xgpu_ctx *c, int16_t *coef, int n_blocks, int log2w, int log2
     const size_t per = (size_t)1 << (log2w + log2h), nb = per * n_blocks * sizeof(int16_t);
     std::vector<TbRec> tbs(n_blocks);
     std::vector<TbWave> wv;
-    for (int i = 0; i < n_blocks; i++) { tbs[i].off = (uint32_t)(per * i); tbs[i].log2w = (uint8_t)log2w; tbs[i].log2h = (uint8_t)log2h; tbs[i].qp = qp[i]; tbs[i].rsvd = 0; }
+    for (int i = 0; i < n_blocks; i++) { tbs[i].off = (uint32_t)(per * i); tbs[i].log2w = (uint8_t)log2w; tbs[i].log2h = (uint8_t)log2h; tbs[i].qp = qp[i]; tbs[i].log2s = (uint8_t)log2w; }
     const int pw = itdq_group_size(log2w, log2h);
     for (int f = 0; f < n_blocks; f += pw) wv.push_back({ (uint32_t)f, (uint16_t)std::min(pw, n_blocks - f), (uint8_t)log2w, (uint8_t)log2h });
     int16_t *dc = NULL, *dr = NULL; TbRec *dt = NULL; TbWave *dw = NULL;

@@ -33,7 +33,7 @@ struct __attribute__((aligned(16))) CuRec {
     uint8_t  cbf;             // bit c: component c coded
     int8_t   refi[2];
     uint8_t  qp_map;          // core->qp = qp_y - 6*(bd-8): the QP stored in map_scu (xevd_util.c:1626)
-    uint8_t  rsvd;
+    uint8_t  map_cbf;         // luma cbf bit of the SCU map = is_coef_sub[Y_C][0] (xevd_util.c:1615)
     uint32_t coef_off;        // offset of the CU's residual block in the arena (s16 units)
     int16_t  mv[2][2];        // unclipped quarter-pel
     uint8_t  qp[3];           // dequant QPs
@@ -56,8 +56,9 @@ static_assert(sizeof(ScuRec) == 16, "ScuRec must be 16 bytes");
 
 // One coded transform block for the dequant + inverse-transform kernel.
 struct TbRec {
-    uint32_t off;             // arena offset (s16 units)
-    uint8_t  log2w, log2h, qp, rsvd;
+    uint32_t off;             // arena offset (s16 units) of the TB's first coefficient
+    uint8_t  log2w, log2h, qp;
+    uint8_t  log2s;           // log2 of the row stride: = log2w, or log2 of the CU width for a 64x64 sub-block of a larger CU
 };
 // One 256-thread work item of the itdq kernel: `count` consecutive TbRecs of one size class.
 struct TbWave {

@@ -118,17 +118,37 @@ def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_fr
     coef_off = np.concatenate([[0], np.cumsum(cu_size)[:-1]]).astype(np.int64)
     n_coef = int(cu_size.sum())
     coef = np.zeros(max(n_coef, 1), np.int16)
-    # transform-block table (cu, comp) -> offset, w, h
-    tb_off, tb_w, tb_h, tb_qp = [], [], [], []
+    # transform-block table: one entry per coded TB.  TBs are at most 64x64 (chroma 32x32): a larger CU carries up to
+    # four sub-blocks sb = (j<<1)|i inside its CU-strided coefficient block (xevd_itdq.c:544-621), each with its own
+    # coded flag (cbf_sub bit 4*c+sb)
+    big = (l2w > 6) | (l2h > 6)
+    cbf_sub = np.zeros(n, np.uint16)
+    if big.any():
+        sub = rng.integers(1, 16, (n, 3)).astype(np.uint16)          # at least one coded sub-block per coded component
+        exists = np.zeros((n, 4), bool)
+        for sb in range(4):
+            exists[:, sb] = ((sb & 1) < np.where(l2w > 6, 2, 1)) & ((sb >> 1) < np.where(l2h > 6, 2, 1))
+        emask = (exists * (1 << np.arange(4))).sum(1).astype(np.uint16)
+        for c in range(3):
+            v = sub[:, c] & emask
+            v = np.where(v == 0, emask & (~emask + 1), v)              # keep the lowest existing one if the draw missed
+            cbf_sub |= (np.where(((cbf >> c) & 1).astype(bool), v, 0).astype(np.uint16) << (4 * c))
+        cbf_sub = np.where(big, cbf_sub, 0).astype(np.uint16)
+    tb_off, tb_w, tb_h, tb_qp, tb_stride = [], [], [], [], []
     run = coef_off.copy()
     for c in range(3):
-        m = ((cbf >> c) & 1).astype(bool)
-        tb_off.append(run[m])
-        tb_w.append((w[m] >> (1 if c else 0)))
-        tb_h.append((h[m] >> (1 if c else 0)))
-        tb_qp.append(qp[m, c].astype(np.int64))
+        cw_c, ch_c = (w >> (1 if c else 0)), (h >> (1 if c else 0))
+        tw = np.minimum(cw_c, 32 if c else 64)
+        th = np.minimum(ch_c, 32 if c else 64)
+        for sb in range(4):
+            si, sj = sb & 1, sb >> 1
+            m = ((cbf >> c) & 1).astype(bool) & (si * tw < cw_c) & (sj * th < ch_c)
+            m &= ~big | (((cbf_sub >> (4 * c + sb)) & 1).astype(bool))
+            tb_off.append((run + sj * th * cw_c + si * tw)[m])
+            tb_w.append(tw[m]); tb_h.append(th[m]); tb_stride.append(cw_c[m])
+            tb_qp.append(qp[m, c].astype(np.int64))
         run = run + sizes[:, c]
-    tb_off, tb_w, tb_h, tb_qp = (np.concatenate(v) for v in (tb_off, tb_w, tb_h, tb_qp))
+    tb_off, tb_w, tb_h, tb_qp, tb_stride = (np.concatenate(v) for v in (tb_off, tb_w, tb_h, tb_qp, tb_stride))
     # level cap per block: keep the dequantised magnitude near the sample range (amp * 2^bd) like a real
     # encoder's output, which is also the range where the reference's C and SIMD paths agree;
     # amp=None leaves levels uncapped (stress cases, compared against the normative C path only)
@@ -156,7 +176,7 @@ def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_fr
         lev = np.round(rng.laplace(0, 2.0, len(tb))).astype(np.int64)
         lev[lev == 0] = 1
         lev = np.clip(lev, -tb_cap[tb], tb_cap[tb])
-        coef[tb_off[tb] + py * tb_w[tb] + px] = lev
+        coef[tb_off[tb] + py * tb_stride[tb] + px] = lev
         # the first coefficient of every coded block is DC-ish and non-zero
         dc = np.round(rng.laplace(0, 6.0, len(tb_off))).astype(np.int64)
         dc[dc == 0] = 1
@@ -166,7 +186,7 @@ def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_fr
     ipm[:, 0] = rng.integers(0, 5, n)
     return {
         "x": x, "y": y, "log2w": l2w, "log2h": l2h, "pred_mode": pred_mode, "refi": refi, "mv": mv, "qp": qp,
-        "cbf": cbf, "ipm": ipm, "coef_off": coef_off.astype(np.uint32), "coef": coef[:max(n_coef, 1)],
+        "cbf": cbf, "cbf_sub": cbf_sub if big.any() else None, "ipm": ipm, "coef_off": coef_off.astype(np.uint32), "coef": coef[:max(n_coef, 1)],
         "ctu_cu_start": start, "n_coef": n_coef,
     }
 
