@@ -119,6 +119,8 @@ typedef struct xgpu_cu_batch {
                                      of the 64x64 sub-blocks sb = (j<<1)|i (xevd_itdq.c:544-621); NULL = every
                                      sub-block of a coded component is coded                                */
     const uint8_t  *ipm;          /* [n_cu][2] intra luma / chroma mode (intra CUs)                       */
+    const uint8_t  *ats;          /* [n_cu] or NULL: bit 0 = ats_intra_cu, bit 1 = ats_intra_mode_v, bit 2 = ats_intra_mode_h
+                                     (0 = DST-VII, 1 = DCT-VIII; luma TB of intra CUs, xevdm.c:602, xevdm_itdq.c:406-421)   */
     const uint32_t *coef_off;     /* [n_cu]  offset (in s16 units) of the CU's first coefficient          */
     const int16_t  *coef;         /* [n_coef] coefficient arena                                           */
     size_t          n_coef;
@@ -177,6 +179,8 @@ int xgpu_test_mc_l(xgpu_ctx *ctx, const int16_t *ref_plane, int plane_w, int pla
                    int has_dx, int has_dy, int gmv_x, int gmv_y, int16_t *pred, int w, int h, int bit_depth);
 int xgpu_test_mc_c(xgpu_ctx *ctx, const int16_t *ref_plane, int plane_w, int plane_h, int ref_x, int ref_y,
                    int has_dx, int has_dy, int gmv_x, int gmv_y, int16_t *pred, int w, int h, int bit_depth);
+/* residual arena of a batch after xgpu_batch_recon (what xevd_sub_block_itdq leaves in core->coef), n_coef s16   */
+int xgpu_test_batch_resid(xgpu_ctx *ctx, xgpu_dbatch *db, int16_t *resid);
 /* dequant + 2-D inverse transform of n blocks of one size, in place (xevd_itdq, src_base/xevd_itdq.c:494) */
 int xgpu_test_itdq(xgpu_ctx *ctx, int16_t *coef, int n_blocks, int log2w, int log2h, const uint8_t *qp, int bit_depth);
 

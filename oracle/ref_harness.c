@@ -50,6 +50,10 @@ static void select_tables(XEVD_CTX *ctx, int simd)
         ctx->fn_dbk_chroma = &xevd_tbl_dbk_chroma;
         xevdm_fn_itx = &xevdm_tbl_itx;
     }
+    /* ATS: matrices and the function table, as xevd_create does (src_main/xevdm.c:3441, 3581-3582) */
+    xevdm_init_multi_tbl();
+    xevd_init_multi_inv_tbl();
+    xevd_func_itrans = xevdm_itrans_map_tbl;
 }
 
 typedef struct {
@@ -139,7 +143,7 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
     harness *hn = harness_new(sp, fr, m, simd);
     XEVD_CTX *ctx = hn->ctx; XEVD_CORE *core = hn->core;
     XEVDM_CORE *mcore = (XEVDM_CORE *)core;
-    const int main_path = sp->tool_admvp || sp->tool_iqt;
+    const int main_path = sp->tool_admvp || sp->tool_iqt || b->ats != NULL;
     int i, c;
 
     for (i = 0; i < b->n_cu; i++) {
@@ -173,9 +177,11 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
             memcpy(core->mv, &b->mv[i * 4], sizeof(s16) * 4);
         }
         /* inverse quantisation + transform: xevd.c:694-698 (xevd_lc_itdq) */
-        if (main_path)
+        if (main_path) {
+            const int a = (b->ats && b->pred_mode[i] == XGPU_MODE_INTRA) ? b->ats[i] : 0;      /* xevdm.c:602 */
             xevdm_sub_block_itdq(ctx, core->coef, lw, lh, core->qp_y, core->qp_u, core->qp_v, core->is_coef, core->is_coef_sub,
-                                 sp->tool_iqt, 0, 0, 0, sp->bit_depth_luma, sp->chroma_format_idc);
+                                 sp->tool_iqt, a & 1, (u8)((((a >> 2) & 1) << 1) | ((a >> 1) & 1)), 0, sp->bit_depth_luma, sp->chroma_format_idc);
+        }
         else
             xevd_sub_block_itdq(ctx, core->coef, lw, lh, core->qp_y, core->qp_u, core->qp_v, core->is_coef, core->is_coef_sub,
                                 sp->bit_depth_luma, sp->chroma_format_idc);

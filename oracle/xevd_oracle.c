@@ -293,6 +293,85 @@ void orc_itdq(int16_t *coef, int log2w, int log2h, int qp, int bit_depth, int iq
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * ATS: DST-VII / DCT-VIII.  Matrices built like xevdm_init_multi_tbl (src_main/xevdm_itdq.c:81-119):
+ *   DCT8[k][n] = (s16)(64*sqrt(N) * cos(pi(k+.5)(n+.5)/(N+.5)) * sqrt(2/(N+.5)) +- .5), DST7 with sin(pi(k+.5)(n+1)/(N+.5)),
+ * in double precision.  type index: DCT8 = 0, DST7 = 1 (enum in xevdm_def.h).  Checked against the reference's
+ * tables in tests/test_oracle_vs_ref.py.
+ * ---------------------------------------------------------------------------------------------- */
+static int16_t g_ats[2][6][32 * 32];
+static int g_ats_ready = 0;
+const int16_t *orc_ats_tm(int type, int log2n)
+{
+    if (!g_ats_ready) {
+        int l, k, n;
+        for (l = 1; l <= 5; l++) {
+            const int N = 1 << l;
+            const double s = sqrt((double)N) * 64;
+            for (k = 0; k < N; k++) for (n = 0; n < N; n++) {
+                double v = cos(ORC_PI * (k + 0.5) * (n + 0.5) / (N + 0.5)) * sqrt(2.0 / (N + 0.5));
+                g_ats[0][l][k * N + n] = (int16_t)(s * v + (v > 0 ? 0.5 : -0.5));
+                v = sin(ORC_PI * (k + 0.5) * (n + 1) / (N + 0.5)) * sqrt(2.0 / (N + 0.5));
+                g_ats[1][l][k * N + n] = (int16_t)(s * v + (v > 0 ? 0.5 : -0.5));
+            }
+        }
+        g_ats_ready = 1;
+    }
+    return g_ats[type][log2n];
+}
+/* one ATS stage: out[j*N + n] = clip16((sum_k tm[k][n]*src[k*line+j] + rnd) >> shift).  The 4-point kernels of the
+   reference use a factorised form built from three entries of the first matrix row (xevdm_itdq.c:163-190, 284-312):
+   the products below are that form written as a 4x4 matrix. */
+static void ats_stage(const int16_t *src, int16_t *dst, int type, int log2n, int line, int shift)
+{
+    const int N = 1 << log2n;
+    const int16_t *tm = orc_ats_tm(type, log2n);
+    int16_t e4[16];
+    int j, n, k;
+    if (N == 4) {
+        const int a = tm[0], b = tm[1], c = tm[2], d = tm[3];
+        if (type == 1) {   /* DST7_B4 */
+            const int16_t m[16] = { (int16_t)a, (int16_t)b, (int16_t)c, (int16_t)(b + a),   (int16_t)c, (int16_t)c, 0, (int16_t)-c,
+                                    (int16_t)(a + b), (int16_t)-a, (int16_t)-c, (int16_t)b,  (int16_t)b, (int16_t)-(b + a), (int16_t)c, (int16_t)-a };
+            memcpy(e4, m, sizeof(m));
+        } else {           /* DCT8_B4 */
+            const int16_t m[16] = { (int16_t)(d + c), (int16_t)b, (int16_t)c, (int16_t)d,   (int16_t)b, 0, (int16_t)-b, (int16_t)-b,
+                                    (int16_t)c, (int16_t)-b, (int16_t)-d, (int16_t)(d + c),  (int16_t)d, (int16_t)-b, (int16_t)(d + c), (int16_t)-c };
+            memcpy(e4, m, sizeof(m));
+        }
+        tm = e4;           /* e4[k*4+n]: coefficient k -> output n */
+    }
+    for (j = 0; j < line; j++) for (n = 0; n < N; n++) {
+        int32_t s = 0;
+        for (k = 0; k < N; k++) s += tm[k * N + n] * src[k * line + j];
+        s = (s + (1 << (shift - 1))) >> shift;
+        dst[j * N + n] = (int16_t)CLIP3(-32768, 32767, s);
+    }
+}
+
+void orc_itdq_ats(int16_t *coef, int log2w, int log2h, int qp, int bit_depth, int iqt, int tr_v, int tr_h)
+{
+    static const int scale_main[6] = { 40, 45, 51, 57, 64, 72 };
+    static const int scale_base[6] = { 40, 45, 51, 57, 64, 71 };
+    const int n = 1 << (log2w + log2h);
+    const int scale = (iqt ? scale_main : scale_base)[qp % 6] << (qp / 6);
+    const int odd = (log2w + log2h) & 1;
+    const int shift = 20 - 14 - (15 - bit_depth - ((log2w + log2h) >> 1)) + (odd ? 8 : 0);
+    const int64_t offset = shift == 0 ? 0 : (int64_t)1 << (shift - 1);
+    const int64_t mul = (int64_t)scale * (odd ? 181 : 1);
+    int16_t *t = (int16_t *)malloc(sizeof(int16_t) * n);
+    int i;
+    for (i = 0; i < n; i++) {
+        int64_t lev = (coef[i] * mul + offset) >> shift;
+        coef[i] = (int16_t)CLIP3(-32768, 32767, lev);
+    }
+    /* xevdm_it_MxN_ats_intra, xevdm_itdq.c:406-421: shift_1st = 7, shift_2nd = 6 + 15 - 1 - bit_depth; type index DST7 = 1 - tr, i.e.
+       xevd_tbl_tr_subset_intra = { DST7, DCT8 } (xevdm_tbl.c:51) maps tr 0 -> DST7, 1 -> DCT8 */
+    ats_stage(coef, t, tr_v ? 0 : 1, log2h, 1 << log2w, 7);
+    ats_stage(t, coef, tr_h ? 0 : 1, log2w, 1 << log2h, 20 - bit_depth);
+    free(t);
+}
+
 void orc_recon(const int16_t *coef, const int16_t *pred, int is_coef, int cuw, int cuh, int s_rec, int16_t *rec, int bit_depth)
 {
     const int maxv = (1 << bit_depth) - 1;
@@ -404,7 +483,14 @@ int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_c
                     const int sb = (sj << 1) | si;
                     int16_t *blk = res + sj * th * cw + si * tw;
                     if (nsx * nsy > 1 && b->cbf_sub && !((b->cbf_sub[i] >> (4 * c + sb)) & 1)) continue;
-                    if (nsx * nsy == 1) { orc_itdq(res, tlw, tlh, b->qp[i * 3 + c], sp->bit_depth_luma, sp->tool_iqt); continue; }
+                    if (nsx * nsy == 1) {
+                        const int a = b->ats ? b->ats[i] : 0;
+                        if (c == 0 && (a & 1) && !inter)      /* ats_intra_cu: luma TB of an intra CU, xevdm_itdq.c:820-829 */
+                            orc_itdq_ats(res, tlw, tlh, b->qp[i * 3 + c], sp->bit_depth_luma, sp->tool_iqt, (a >> 1) & 1, (a >> 2) & 1);
+                        else
+                            orc_itdq(res, tlw, tlh, b->qp[i * 3 + c], sp->bit_depth_luma, sp->tool_iqt);
+                        continue;
+                    }
                     {
                         int16_t *tmp = (int16_t *)malloc(sizeof(int16_t) * tw * th);
                         for (r = 0; r < th; r++) memcpy(tmp + r * tw, blk + r * cw, sizeof(int16_t) * tw);

@@ -25,6 +25,9 @@ CASES = [
     # CTU 128: CUs up to 128x128 (four 64x64 sub-TBs), deblocking of the inner 64-sample boundaries, ALF CTU rules
     ("main_ctu128_10b", 264, 200, 10, 1, 1, (2, 2), 0.5, {"addb": 1, "alf": 1, "inter_frac": 1.0, "log2_ctu": 7, "split_prob": 0.25}),
     ("main_ctu128_8b_noiqt", 256, 128, 8, 1, 0, (1, 1), 0.4, {"addb": 1, "log2_ctu": 7, "split_prob": 0.2}),
+    # ATS: DST-VII / DCT-VIII luma transforms of intra CUs (checked through the residual arena)
+    ("main_ats_10b", 136, 136, 10, 1, 1, (1, 1), 0.3, {"addb": 1, "inter_frac": 0.5, "ats_frac": 0.7}),
+    ("main_ats_8b_noiqt", 128, 72, 8, 1, 0, (1, 0), 0.0, {"inter_frac": 0.4, "ats_frac": 0.8, "split_prob": 0.7}),
 ]
 POCS = [[4, 0, 2], [12, 16, 4]]      # L1 idx 2 has the POC of L0 idx 0 -> identical-motion candidates exist
 CUR_POC = 8
@@ -50,7 +53,7 @@ def build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, tools=None, seed=0, 
             refs[(i, l)] = pic
     if (2, 1) in refs and (0, 0) in refs:
         refs[(2, 1)] = refs[(0, 0)]      # the same picture in both lists (same POC 4): ADDB compares pictures, not indices
-    batch = synth.gen_frame(rng, w, h, bd, log2_ctu=log2_ctu, inter_frac=inter_frac, bi_frac=bi_frac, n_refs=n_refs, oob_frac=oob_frac,
+    batch = synth.gen_frame(rng, w, h, bd, log2_ctu=log2_ctu, ats_frac=float(tools.get("ats_frac", 0.0)), inter_frac=inter_frac, bi_frac=bi_frac, n_refs=n_refs, oob_frac=oob_frac,
                             qp_range=qp_range, split_prob=split_prob, amp=amp)
     if n_refs[0] and n_refs[1]:      # force some identical-motion bi CUs
         sel = (batch["refi"][:, 0] >= 0) & (batch["refi"][:, 1] >= 0)
@@ -117,7 +120,7 @@ def run_cpu(engine, case, deblock=True, simd=0, pad=True):
     return cur, pre, maps, resid
 
 
-def run_gpu(case, deblock=True, pad=True, alf=True):
+def run_gpu(case, deblock=True, pad=True, alf=True, resid=False):
     """The HIP backend through the C ABI. -> list of padded planes (reference buffer geometry)"""
     from xevd_amd.decoder import XgpuDecoder
     with XgpuDecoder(case["w"], case["h"], case["bd"], log2_ctu=case.get("log2_ctu", 6), iqt=case["iqt"], admvp=case["admvp"],
@@ -135,4 +138,6 @@ def run_gpu(case, deblock=True, pad=True, alf=True):
                            qp_u_offset=QP_OFFSETS[0], qp_v_offset=QP_OFFSETS[1],
                            alpha_off=case.get("alpha_off", 0), beta_off=case.get("beta_off", 0), alf=case.get("alf_params") if alf else None)
         dec.sync()
+        if resid:
+            return dec.pic_download_padded(cur), dec.batch_resid(hb, case["batch"]["n_coef"])
         return dec.pic_download_padded(cur)

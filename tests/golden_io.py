@@ -8,7 +8,7 @@ import oracle_lib as ol
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 PICTURE_CASES = ["base_p_8b", "base_b_8b", "base_p_10b", "main_b_10b", "main_admvp_only", "main_iqt_only",
                  "main_addb_10b", "main_addb_8b_shared_refs", "main_alf_10b", "main_alf_8b_across_tiles", "main_alf_only_luma",
-                 "main_ctu128_10b", "main_ctu128_8b_noiqt"]
+                 "main_ctu128_10b", "main_ctu128_8b_noiqt", "main_ats_10b", "main_ats_8b_noiqt"]
 
 
 def load_picture_case(name):
@@ -35,6 +35,7 @@ def load_picture_case(name):
     batch = {k[2:]: d[k] for k in d.files if k.startswith("b_")}
     batch["n_coef"] = int(batch["n_coef"])
     batch.setdefault("cbf_sub", None)
+    batch.setdefault("ats", None)
     case = {"name": name, "w": w, "h": h, "bd": bd, "admvp": admvp, "iqt": iqt, "refs": refs, "batch": batch,
             "addb": tools[0], "alf": tools[1], "alpha_off": tools[2], "beta_off": tools[3], "no_deblock": tools[4], "log2_ctu": tools[5],
             "alf_params": alf_params}

@@ -66,7 +66,8 @@ def test_gpu_pictures_golden(name):
         pad = abi.PAD_L if c == 0 else abi.PAD_C
         got = pre[c][pad:-pad, pad:-pad]
         assert np.array_equal(got, exp["pre"][c]), f"recon plane {c}: {np.argwhere(got != exp['pre'][c])[:4]}"
-    out = cases.run_gpu(case)
+    out, resid = cases.run_gpu(case, resid=True)
+    assert np.array_equal(resid[:len(exp["resid"])], exp["resid"]), "residual arena (dequant + inverse transform of every coded TB, intra CUs included)"
     for c in range(3):
         assert np.array_equal(out[c], exp["out"][c]), f"final plane {c}: {np.argwhere(out[c] != exp['out'][c])[:4]}"
 

@@ -30,6 +30,19 @@ def test_transform_tables_match_reference():
         assert np.array_equal(t_ref, t_orc), f"tm{n}"
 
 
+def test_ats_tables_match_reference():
+    import ctypes as C
+    lib, orc = ol.ref(), ol.oracle()
+    lib.xevdm_init_multi_tbl()
+    orc.orc_ats_tm.restype = C.POINTER(C.c_int16)
+    orc.orc_ats_tm.argtypes = [C.c_int, C.c_int]
+    for l in range(2, 6):
+        n = 1 << l
+        t_ref = np.frombuffer((C.c_int16 * (2 * n * n)).in_dll(lib, f"xevd_tbl_tr{n}"), np.int16).reshape(2, n * n)
+        for typ in (0, 1):
+            assert np.array_equal(t_ref[typ], np.ctypeslib.as_array(orc.orc_ats_tm(typ, l), (n * n,))), (n, typ)
+
+
 def _set_mc_tables(lib, admvp):
     lp = C.c_void_p.in_dll(lib, "tbl_mc_l_coeff")
     cp = C.c_void_p.in_dll(lib, "tbl_mc_c_coeff")
@@ -191,7 +204,9 @@ def test_picture_level_oracle_equals_reference(case):
     # SIMD recon kernels scribble past narrow blocks, which a real decode repairs with the next CU)
     if cs["addb"]:
         return      # ADDB is scalar C only in the reference
-    cs1 = cases.build_case(*case, inter_frac=1.0)
+    tools1 = dict(case[8]) if len(case) > 8 else {}
+    tools1["inter_frac"] = 1.0
+    cs1 = cases.build_case(*case[:8], tools1)
     c0, _, _, r0 = cases.run_cpu("ref", cs1, simd=0)
     s0, _, _, r1 = cases.run_cpu("ref", cs1, simd=1)
     assert np.array_equal(r0, r1), "simd residual"

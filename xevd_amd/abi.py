@@ -45,7 +45,7 @@ class CuBatch(C.Structure):
         ("log2w", C.POINTER(C.c_uint8)), ("log2h", C.POINTER(C.c_uint8)),
         ("pred_mode", C.POINTER(C.c_uint8)),
         ("refi", C.POINTER(C.c_int8)), ("mv", C.POINTER(C.c_int16)),
-        ("qp", C.POINTER(C.c_uint8)), ("cbf", C.POINTER(C.c_uint8)), ("cbf_sub", C.POINTER(C.c_uint16)), ("ipm", C.POINTER(C.c_uint8)),
+        ("qp", C.POINTER(C.c_uint8)), ("cbf", C.POINTER(C.c_uint8)), ("cbf_sub", C.POINTER(C.c_uint16)), ("ipm", C.POINTER(C.c_uint8)), ("ats", C.POINTER(C.c_uint8)),
         ("coef_off", C.POINTER(C.c_uint32)), ("coef", C.POINTER(C.c_int16)), ("n_coef", C.c_size_t),
         ("n_ctu", C.c_int), ("ctu_cu_start", C.POINTER(C.c_uint32)),
     ]
@@ -86,6 +86,7 @@ def make_cu_batch(b):
         "qp": np.ascontiguousarray(b["qp"], np.uint8), "cbf": np.ascontiguousarray(b["cbf"], np.uint8),
         "ipm": np.ascontiguousarray(b["ipm"], np.uint8),
         "cbf_sub": None if b.get("cbf_sub") is None else np.ascontiguousarray(b["cbf_sub"], np.uint16),
+        "ats": None if b.get("ats") is None else np.ascontiguousarray(b["ats"], np.uint8),
         "coef_off": np.ascontiguousarray(b["coef_off"], np.uint32),
         "coef": np.ascontiguousarray(b["coef"], np.int16),
         "ctu_cu_start": np.ascontiguousarray(b["ctu_cu_start"], np.uint32),
@@ -99,6 +100,8 @@ def make_cu_batch(b):
     cb.qp, cb.cbf, cb.ipm = _ptr(keep["qp"], C.c_uint8), _ptr(keep["cbf"], C.c_uint8), _ptr(keep["ipm"], C.c_uint8)
     if keep["cbf_sub"] is not None:
         cb.cbf_sub = _ptr(keep["cbf_sub"], C.c_uint16)
+    if keep["ats"] is not None:
+        cb.ats = _ptr(keep["ats"], C.c_uint8)
     cb.coef_off, cb.coef = _ptr(keep["coef_off"], C.c_uint32), _ptr(keep["coef"], C.c_int16)
     cb.n_coef = len(keep["coef"])
     cb.n_ctu = len(keep["ctu_cu_start"]) - 1
@@ -146,6 +149,7 @@ _EXPORTS = {
     "xgpu_measure_copy_bw": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "xgpu_test_mc_l": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p] + [C.c_int] * 3),
     "xgpu_test_mc_c": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p] + [C.c_int] * 3),
+    "xgpu_test_batch_resid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "xgpu_test_itdq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
 }
 

@@ -30,8 +30,27 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 __constant__ uint32_t k_tmp[2730];
 __host__ __device__ constexpr int tmp_base(int log2n) { return log2n == 1 ? 0 : log2n == 2 ? 2 : log2n == 3 ? 10 : log2n == 4 ? 42 : log2n == 5 ? 170 : 682; }
 
-void upload_transform_tables(const int *tm, hipStream_t s)
+// ATS matrices, same packing, [type DST7=0 / DCT8=1][size 4,8,16,32]: offsets 8, 32, 128, 512 dwords per size.
+// The 4-point entries hold the 4x4 matrices equivalent to the reference's factorised kernels (xevdm_itdq.c:163-190, 284-312).
+__constant__ uint32_t k_atsp[2][680];
+__host__ __device__ constexpr int atsp_base(int log2n) { return log2n == 2 ? 0 : log2n == 3 ? 8 : log2n == 4 ? 40 : 168; }
+
+void upload_transform_tables(const int *tm, const int16_t *ats, hipStream_t s)
 {
+    // ats: [type DST7=0/DCT8=1][log2n 2..5] row-major s16 matrices M[k][n] back to back (16+64+256+1024 per type)
+    static uint32_t apk[2][680];
+    for (int t = 0; t < 2; t++) {
+        int src = 0;
+        for (int l = 2; l <= 5; l++) {
+            const int N = 1 << l, dst = atsp_base(l);
+            for (int k2 = 0; k2 < N / 2; k2++)
+                for (int n = 0; n < N; n++)
+                    apk[t][dst + k2 * N + n] = (uint32_t)(uint16_t)ats[t * 1360 + src + (2 * k2) * N + n] |
+                                               ((uint32_t)(uint16_t)ats[t * 1360 + src + (2 * k2 + 1) * N + n] << 16);
+            src += N * N;
+        }
+    }
+    (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(k_atsp), apk, sizeof(apk), 0, hipMemcpyHostToDevice, s);
     // tm: int32 row-major matrices 2,4,..,64 back to back (5460 entries)
     static uint32_t packed[2730];
     int src = 0;
@@ -77,8 +96,10 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
     constexpr bool UNI1 = (G * W) % 64 == 0, UNI2 = (G * H) % 64 == 0;
     static_assert(2 * PLANE <= ITDQ_PLANES_DWORDS && G * W * H <= 4096, "LDS budget");
     const int t = threadIdx.x;
-    const uint32_t *tmh = k_tmp + tmp_base(LH);
-    const uint32_t *tmw = k_tmp + tmp_base(LW);
+    // wave-uniform matrix choice: DCT-II, or for ATS work items (4..32 only) DST-VII / DCT-VIII
+    const uint32_t *tmh = (wv.tr_v == TR_DCT2 || LH < 2 || LH > 5) ? k_tmp + tmp_base(LH) : k_atsp[wv.tr_v - 1] + atsp_base(LH);
+    const uint32_t *tmw = (wv.tr_h == TR_DCT2 || LW < 2 || LW > 5) ? k_tmp + tmp_base(LW) : k_atsp[wv.tr_h - 1] + atsp_base(LW);
+    const bool s16_mid = a.iqt || wv.tr_v != TR_DCT2 || wv.tr_h != TR_DCT2;    // ATS keeps a clipped s16 intermediate like IQT (:406-421)
     int16_t *ldsh = (int16_t *)lds;                            // plane 0: hi (or the IQT intermediate), plane 1: lo
     int16_t *ldsl = (int16_t *)(lds + PLANE);
     uint32_t *ldsc = lds + ITDQ_PLANES_DWORDS;                 // dequantised coefficients, [p][row][col] s16
@@ -139,7 +160,7 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
         }
         // transposed store: element [p][row = chunk*N1+n][col = j]
         const int base = (p * H + chunk * N1) * (2 * RS) + j;
-        if (a.iqt) {
+        if (s16_mid) {
 #pragma unroll
             for (int n = 0; n < N1; n++) ldsh[base + n * (2 * RS)] = (int16_t)clip16((acc[n] + 64) >> 7);   // xevdm_itdq.c ITX_SHIFT1 = 7
         } else {
@@ -160,11 +181,11 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
         const int p = idx >> LH, r = idx & (H - 1);
         if (p >= wv.count) return;
         const TbRec tb = a.tbs[wv.first + p];
-        const int shift2 = a.iqt ? 12 - (a.bd - 8) : 7 + 12 - (a.bd - 8);
+        const int shift2 = s16_mid ? 12 - (a.bd - 8) : 7 + 12 - (a.bd - 8);
         const uint32_t *inh = lds + (p * H + r) * RS;
         const uint32_t *inl = inh + PLANE;
         int res[N2];
-        if (a.iqt) {
+        if (s16_mid) {
             int s[N2];
 #pragma unroll
             for (int n = 0; n < N2; n++) s[n] = 1 << (shift2 - 1);

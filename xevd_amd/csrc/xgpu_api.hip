@@ -109,7 +109,32 @@ static void init_transform_tables(xgpu_ctx *c)
                 tm[o++] = (int)(v >= 0 ? floor(v + 0.5) : -floor(-v + 0.5));
             }
     }
-    upload_transform_tables(tm, c->stream);
+    // ATS matrices exactly as xevdm_init_multi_tbl builds them in double precision (src_main/xevdm_itdq.c:81-119); the
+    // 4-point kernels of the reference are factorised around three entries of the first row (:163-190, :284-312) -
+    // the equivalent 4x4 matrices are stored instead.  Order: [DST7, DCT8][4, 8, 16, 32], M[k][n].
+    static int16_t ats[2 * 1360];
+    for (int t = 0; t < 2; t++) {
+        int q = t * 1360;
+        for (int l = 2; l <= 5; l++) {
+            const int N = 1 << l;
+            const double sc = sqrt((double)N) * 64;
+            int16_t m[32 * 32];
+            for (int k = 0; k < N; k++)
+                for (int n = 0; n < N; n++) {
+                    const double v = t == 0 ? sin(3.14159265358979323846 * (k + 0.5) * (n + 1) / (N + 0.5)) * sqrt(2.0 / (N + 0.5))
+                                            : cos(3.14159265358979323846 * (k + 0.5) * (n + 0.5) / (N + 0.5)) * sqrt(2.0 / (N + 0.5));
+                    m[k * N + n] = (int16_t)(sc * v + (v > 0 ? 0.5 : -0.5));
+                }
+            if (N == 4) {
+                const int a = m[0], b = m[1], cc = m[2], d = m[3];
+                const int e7[16] = { a, b, cc, b + a,  cc, cc, 0, -cc,  a + b, -a, -cc, b,  b, -(b + a), cc, -a };
+                const int e8[16] = { d + cc, b, cc, d,  b, 0, -b, -b,  cc, -b, -d, d + cc,  d, -b, d + cc, -cc };
+                for (int i = 0; i < 16; i++) m[i] = (int16_t)(t == 0 ? e7[i] : e8[i]);
+            }
+            for (int i = 0; i < N * N; i++) ats[q++] = m[i];
+        }
+    }
+    upload_transform_tables(tm, ats, c->stream);
 }
 
 int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
@@ -310,7 +335,14 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     const int bdoff = 6 * (c->sp.bit_depth_luma - 8);
 
     // pass 1: validate + count TBs per size class
-    int cls_count[64] = { 0 };
+    // size class = (log2w, log2h) x (vertical, horizontal) transform kind; ATS kinds only occur for intra luma TBs
+    enum { NCLS = 64 * 9 };
+    int cls_count[NCLS] = { 0 };
+    auto tr_code = [&](int i, int k) -> int {
+        if (k != 0 || !b->ats || !(b->ats[i] & 1) || b->pred_mode[i] != XGPU_MODE_INTRA) return 0;
+        const int tv = (b->ats[i] >> 1) & 1 ? TR_DCT8 : TR_DST7, th = (b->ats[i] >> 2) & 1 ? TR_DCT8 : TR_DST7;
+        return tv * 3 + th;
+    };
     for (int i = 0; i < n; i++) {
         const int lw = b->log2w[i], lh = b->log2h[i];
         ARGCHK(c, lw >= 2 && lw <= 7 && lh >= 2 && lh <= 7 && lw <= c->sp.log2_ctu && lh <= c->sp.log2_ctu);
@@ -325,16 +357,16 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
             for (int sb = 0; sb < 4; sb++) {
                 if ((sb & 1) >= nsx || (sb >> 1) >= nsy) continue;
                 if (nsx * nsy > 1 && b->cbf_sub && !((b->cbf_sub[i] >> (4 * k + sb)) & 1)) continue;
-                cls_count[tw * 8 + th]++;
+                cls_count[tr_code(i, k) * 64 + tw * 8 + th]++;
             }
             need += (size_t)(1 << (lw + lh)) >> (k ? 2 : 0);
         }
         ARGCHK(c, (size_t)b->coef_off[i] + need <= b->n_coef);
     }
-    int cls_first[64], n_tb = 0, n_waves = 0;
-    for (int k = 0; k < 64; k++) {
+    int cls_first[NCLS], n_tb = 0, n_waves = 0;
+    for (int k = 0; k < NCLS; k++) {
         cls_first[k] = n_tb; n_tb += cls_count[k];
-        if (cls_count[k]) { const int per = itdq_group_size(k >> 3, k & 7); n_waves += (cls_count[k] + per - 1) / per; }
+        if (cls_count[k]) { const int per = itdq_group_size((k & 63) >> 3, k & 7); n_waves += (cls_count[k] + per - 1) / per; }
     }
 
     xgpu_dbatch *db = new xgpu_dbatch();
@@ -354,7 +386,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     TbWave *wv = (TbWave *)(hs + o_wv);
 
     // pass 2: records + TB scatter into class order
-    int cls_fill[64];
+    int cls_fill[NCLS];
     memcpy(cls_fill, cls_first, sizeof(cls_fill));
     for (int i = 0; i < n; i++) {
         CuRec &r = cus[i];
@@ -378,7 +410,8 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
                 const int si = sb & 1, sj = sb >> 1;
                 if (si >= nsx || sj >= nsy) continue;
                 if (nsx * nsy > 1 && b->cbf_sub && !((b->cbf_sub[i] >> (4 * k + sb)) & 1)) continue;
-                TbRec &t = tbs[cls_fill[tw * 8 + th]++];
+                ARGCHK(c, tr_code(i, k) == 0 || (tw >= 2 && tw <= 5 && th >= 2 && th <= 5));      // ATS exists for 4..32 only
+                TbRec &t = tbs[cls_fill[tr_code(i, k) * 64 + tw * 8 + th]++];
                 t.off = off + ((uint32_t)sj << (th + cl)) + ((uint32_t)si << tw);
                 t.log2w = (uint8_t)tw; t.log2h = (uint8_t)th; t.qp = r.qp[k]; t.log2s = (uint8_t)cl;
             }
@@ -386,12 +419,13 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         }
     }
     int w = 0;
-    for (int k = 0; k < 64; k++) {
+    for (int k = 0; k < NCLS; k++) {
         if (!cls_count[k]) continue;
-        const int per = itdq_group_size(k >> 3, k & 7);
+        const int per = itdq_group_size((k & 63) >> 3, k & 7);
         for (int f = 0; f < cls_count[k]; f += per) {
             wv[w].first = cls_first[k] + f; wv[w].count = (uint16_t)std::min(per, cls_count[k] - f);
-            wv[w].log2w = (uint8_t)(k >> 3); wv[w].log2h = (uint8_t)(k & 7); w++;
+            wv[w].log2w = (uint8_t)((k & 63) >> 3); wv[w].log2h = (uint8_t)(k & 7);
+            wv[w].tr_v = (uint8_t)((k >> 6) / 3); wv[w].tr_h = (uint8_t)((k >> 6) % 3); wv[w].pad[0] = wv[w].pad[1] = 0; w++;
         }
     }
     memcpy(hs + o_ctu, b->ctu_cu_start, sz_ctu);
@@ -579,6 +613,14 @@ int xgpu_test_mc_c(xgpu_ctx *c, const int16_t *plane, int pw, int ph, int ref_x,
                    int gmv_x, int gmv_y, int16_t *pred, int w, int h, int bd)
 { return test_mc(c, plane, pw, ph, ref_x, ref_y, has_dx, has_dy, gmv_x, gmv_y, pred, w, h, bd, 0); }
 
+int xgpu_test_batch_resid(xgpu_ctx *c, xgpu_dbatch *db, int16_t *resid)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, db != NULL && resid != NULL);
+    if (db->n_coef) HIPCHK(c, hipMemcpyAsync(resid, db->d_resid, sizeof(int16_t) * db->n_coef, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return XGPU_OK;
+}
+
 int xgpu_test_itdq(xgpu_ctx *c, int16_t *coef, int n_blocks, int log2w, int log2h, const uint8_t *qp, int bit_depth)
 {
     ARGCHK(c, c != NULL); ARGCHK(c, coef && qp && n_blocks > 0 && log2w >= 1 && log2w <= 6 && log2h >= 1 && log2h <= 6);
@@ -587,7 +629,7 @@ int xgpu_test_itdq(xgpu_ctx *c, int16_t *coef, int n_blocks, int log2w, int log2
     std::vector<TbWave> wv;
     for (int i = 0; i < n_blocks; i++) { tbs[i].off = (uint32_t)(per * i); tbs[i].log2w = (uint8_t)log2w; tbs[i].log2h = (uint8_t)log2h; tbs[i].qp = qp[i]; tbs[i].log2s = (uint8_t)log2w; }
     const int pw = itdq_group_size(log2w, log2h);
-    for (int f = 0; f < n_blocks; f += pw) wv.push_back({ (uint32_t)f, (uint16_t)std::min(pw, n_blocks - f), (uint8_t)log2w, (uint8_t)log2h });
+    for (int f = 0; f < n_blocks; f += pw) wv.push_back({ (uint32_t)f, (uint16_t)std::min(pw, n_blocks - f), (uint8_t)log2w, (uint8_t)log2h, 0, 0, { 0, 0 } });
     int16_t *dc = NULL, *dr = NULL; TbRec *dt = NULL; TbWave *dw = NULL;
     HIPCHK(c, hipMalloc((void **)&dc, nb)); HIPCHK(c, hipMalloc((void **)&dr, nb));
     HIPCHK(c, hipMalloc((void **)&dt, sizeof(TbRec) * tbs.size())); HIPCHK(c, hipMalloc((void **)&dw, sizeof(TbWave) * wv.size()));

@@ -60,11 +60,17 @@ struct TbRec {
     uint8_t  log2w, log2h, qp;
     uint8_t  log2s;           // log2 of the row stride: = log2w, or log2 of the CU width for a 64x64 sub-block of a larger CU
 };
+// transform kinds of a work item (wave-uniform): 0 = DCT-II, 1 = DST-VII, 2 = DCT-VIII (ATS, src_main/xevdm_itdq.c:163-421)
+#define TR_DCT2 0
+#define TR_DST7 1
+#define TR_DCT8 2
 // One 256-thread work item of the itdq kernel: `count` consecutive TbRecs of one size class.
 struct TbWave {
     uint32_t first;
     uint16_t count;
     uint8_t  log2w, log2h;
+    uint8_t  tr_v, tr_h;      // TR_* of the vertical (first) and horizontal (second) stage
+    uint8_t  pad[2];
 };
 
 struct RefEntry { const int16_t *y, *u, *v; int poc; int pad; };
@@ -160,7 +166,7 @@ struct xgpu_ctx {
 void launch_itdq(xgpu_ctx *c, const ItdqArgs &a);
 void launch_inter(xgpu_ctx *c, const InterArgs &a);
 void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst);
-void upload_transform_tables(const int *tm, hipStream_t s);
+void upload_transform_tables(const int *tm, const int16_t *ats, hipStream_t s);
 int  itdq_group_size(int log2w, int log2h);     // TBs of one size class per 256-thread work item
 void launch_addb(xgpu_ctx *c, const AddbArgs &a, int dir, const DevPic &src, const DevPic &dst);
 void launch_alf(xgpu_ctx *c, const AlfArgs &a, const DevPic &src, const DevPic &dst);

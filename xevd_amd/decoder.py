@@ -110,6 +110,11 @@ class XgpuDecoder:
         self._batches.append(h)
         return h
 
+    def batch_resid(self, h, n_coef):
+        out = np.zeros(max(n_coef, 1), np.int16)
+        self._chk(self.lib.xgpu_test_batch_resid(self.ctx, h, out.ctypes.data), "xgpu_test_batch_resid")
+        return out
+
     def batch_destroy(self, h):
         self._batches = [b for b in self._batches if b.value != h.value]
         self.lib.xgpu_batch_destroy(self.ctx, h)

@@ -60,7 +60,7 @@ def gen_partition(rng, width, height, log2_ctu=6, split_prob=0.5, min_log2=2):
 
 def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_frac=0.0, coded_frac=0.6,
               n_refs=(1, 0), qp_range=(22, 37), mv_sigma_px=8.0, oob_frac=0.05, split_prob=0.5,
-              chroma_qp_table=None, max_level=24, amp=2.0):
+              chroma_qp_table=None, max_level=24, amp=2.0, ats_frac=0.0):
     """One picture's CU batch as a dict of numpy arrays (layout of xgpu_cu_batch, include/xevd_hip.h)."""
     x, y, l2w, l2h, start = gen_partition(rng, width, height, log2_ctu, split_prob)
     n = len(x)
@@ -182,11 +182,16 @@ def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_fr
         dc[dc == 0] = 1
         coef[tb_off] = np.clip(dc, -tb_cap, tb_cap)
 
+    # ATS (Main): intra CUs up to 32x32 may code their luma TB with DST-VII / DCT-VIII (bit0 on, bit1 v type, bit2 h type)
+    ats = None
+    if ats_frac > 0:
+        on = (~inter) & (l2w <= 5) & (l2h <= 5) & (rng.random(n) < ats_frac)
+        ats = (on.astype(np.uint8) | (rng.integers(0, 4, n).astype(np.uint8) << 1) * on).astype(np.uint8)
     ipm = np.zeros((n, 2), np.uint8)
     ipm[:, 0] = rng.integers(0, 5, n)
     return {
         "x": x, "y": y, "log2w": l2w, "log2h": l2h, "pred_mode": pred_mode, "refi": refi, "mv": mv, "qp": qp,
-        "cbf": cbf, "cbf_sub": cbf_sub if big.any() else None, "ipm": ipm, "coef_off": coef_off.astype(np.uint32), "coef": coef[:max(n_coef, 1)],
+        "cbf": cbf, "cbf_sub": cbf_sub if big.any() else None, "ats": ats, "ipm": ipm, "coef_off": coef_off.astype(np.uint32), "coef": coef[:max(n_coef, 1)],
         "ctu_cu_start": start, "n_coef": n_coef,
     }
 
