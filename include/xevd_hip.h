@@ -121,6 +121,10 @@ typedef struct xgpu_cu_batch {
     const uint8_t  *ipm;          /* [n_cu][2] intra luma / chroma mode (intra CUs)                       */
     const uint8_t  *ats;          /* [n_cu] or NULL: bit 0 = ats_intra_cu, bit 1 = ats_intra_mode_v, bit 2 = ats_intra_mode_h
                                      (0 = DST-VII, 1 = DCT-VIII; luma TB of intra CUs, xevdm.c:602, xevdm_itdq.c:406-421)   */
+    const uint8_t  *ats_inter;    /* [n_cu] or NULL: ats_inter_info of inter CUs = idx | pos << 4 (src_main/xevdm_def.h:232-236):
+                                     idx 1/3 = left|right half/quarter-width TU, 2/4 = top|bottom half/quarter-height TU, pos 0 =
+                                     first part coded, 1 = last part.  The CU's coefficient blocks then have the TU size
+                                     (xevdm_get_tu_size, xevdm_util.c:3585-3608) for all three components          */
     const uint32_t *coef_off;     /* [n_cu]  offset (in s16 units) of the CU's first coefficient          */
     const int16_t  *coef;         /* [n_coef] coefficient arena                                           */
     size_t          n_coef;

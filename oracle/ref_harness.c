@@ -143,7 +143,7 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
     harness *hn = harness_new(sp, fr, m, simd);
     XEVD_CTX *ctx = hn->ctx; XEVD_CORE *core = hn->core;
     XEVDM_CORE *mcore = (XEVDM_CORE *)core;
-    const int main_path = sp->tool_admvp || sp->tool_iqt || b->ats != NULL;
+    const int main_path = sp->tool_admvp || sp->tool_iqt || b->ats != NULL || b->ats_inter != NULL;
     int i, c;
 
     for (i = 0; i < b->n_cu; i++) {
@@ -157,8 +157,11 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
         core->qp = core->qp_y - 6 * (sp->bit_depth_luma - 8);
         core->ipm[0] = b->ipm ? b->ipm[i * 2] : 0; core->ipm[1] = b->ipm ? b->ipm[i * 2 + 1] : 0;
         memset(core->is_coef_sub, 0, sizeof(core->is_coef_sub));
+        const u8 ai = (b->ats_inter && b->pred_mode[i] != XGPU_MODE_INTRA) ? b->ats_inter[i] : 0;
+        int tuw = w, tuh = h;
+        if (ai) { int lt_w, lt_h; xevdm_get_tu_size(ai, lw, lh, &lt_w, &lt_h); tuw = 1 << lt_w; tuh = 1 << lt_h; }
         for (c = 0; c < 3; c++) {
-            const int n = c ? (w >> 1) * (h >> 1) : w * h;
+            const int n = c ? (tuw >> 1) * (tuh >> 1) : tuw * tuh;
             int sb;
             core->is_coef[c] = (b->cbf[i] >> c) & 1;
             /* nnz_sub of the 64x64 sub-blocks, (j<<1)|i; a CU <= 64 only has sub-block 0 */
@@ -180,7 +183,7 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
         if (main_path) {
             const int a = (b->ats && b->pred_mode[i] == XGPU_MODE_INTRA) ? b->ats[i] : 0;      /* xevdm.c:602 */
             xevdm_sub_block_itdq(ctx, core->coef, lw, lh, core->qp_y, core->qp_u, core->qp_v, core->is_coef, core->is_coef_sub,
-                                 sp->tool_iqt, a & 1, (u8)((((a >> 2) & 1) << 1) | ((a >> 1) & 1)), 0, sp->bit_depth_luma, sp->chroma_format_idc);
+                                 sp->tool_iqt, a & 1, (u8)((((a >> 2) & 1) << 1) | ((a >> 1) & 1)), ai, sp->bit_depth_luma, sp->chroma_format_idc);
         }
         else
             xevd_sub_block_itdq(ctx, core->coef, lw, lh, core->qp_y, core->qp_u, core->qp_v, core->is_coef, core->is_coef_sub,
@@ -188,7 +191,7 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
         if (resid_out) {
             o = off;
             for (c = 0; c < 3; c++) {
-                const int n = c ? (w >> 1) * (h >> 1) : w * h;
+                const int n = c ? (tuw >> 1) * (tuh >> 1) : tuw * tuh;
                 if (core->is_coef[c]) { memcpy(resid_out + o, core->coef[c], sizeof(s16) * n); o += n; }
             }
         }
@@ -204,10 +207,19 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
                 xevd_mc(x, y, ctx->w, ctx->h, w, h, core->refi, core->mv, ctx->refp, core->pred, fr->cur.poc,
                         sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
             }
-            /* reconstruction: xevd_recon_yuv, xevd_recon.c:70-92 */
-            xevd_recon_yuv(ctx, core, x, y, w, h);
+            /* reconstruction: xevd_recon_yuv, xevd_recon.c:70-92; with ATS-inter the Main profile's own (xevdm.c:1379) */
+            if (ai) {
+                TREE_CONS tc = { 0, TREE_LC, eAll };
+                xevdm_recon_yuv(x, y, w, h, core->coef, core->pred[0], core->is_coef, ctx->pic, ai, tc, sp->bit_depth_luma, sp->chroma_format_idc);
+            } else
+                xevd_recon_yuv(ctx, core, x, y, w, h);
         }
         xevd_set_dec_info(ctx, core);
+        if (ai) {      /* xevdm_set_dec_info's ATS-inter tail (xevdm_util.c:4321, :4375) */
+            int r, q;
+            xevdm_set_cu_cbf_flags((u8)core->is_coef[Y_C], ai, lw, lh, ctx->map_scu + core->scup, ctx->w_scu);
+            if (m->map_ats) for (r = 0; r < h >> 2; r++) for (q = 0; q < w >> 2; q++) m->map_ats[core->scup + r * ctx->w_scu + q] = ai;
+        }
         {   /* MCU_SET_COD over the CU, xevd.c:746-754 */
             int r, q;
             for (r = 0; r < h >> 2; r++) for (q = 0; q < w >> 2; q++)
@@ -218,8 +230,12 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
     return 0;
 }
 
+static int deblock_main(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *m, int addb, int alpha_off, int beta_off);
+
 int refh_deblock_baseline(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *m, int simd)
 {
+    /* a Main-profile stream without ADDB runs the Main library's own copy of this filter through the same deblock_tree */
+    if (sp->tool_admvp || sp->tool_iqt || sp->log2_ctu > 6 || b->ats || b->ats_inter) return deblock_main(sp, fr, b, m, 0, 0, 0);
     harness *hn = harness_new(sp, fr, m, simd);
     XEVD_CTX *ctx = hn->ctx;
     int i, k;
@@ -239,13 +255,19 @@ int refh_deblock_baseline(const xgpu_seq_params *sp, const orc_frame *fr, const 
    first (is_hor_edge = 0), COD cleared before each pass - the loop of src_main/xevdm.c:3152-3205 / deblock_tree :1935-2040 */
 int refh_deblock_addb(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *m, int alpha_off, int beta_off)
 {
+    return deblock_main(sp, fr, b, m, 1, alpha_off, beta_off);
+}
+
+static int deblock_main(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *m, int addb, int alpha_off, int beta_off)
+{
     harness *hn = harness_new(sp, fr, m, 0);
     XEVD_CTX *ctx = hn->ctx;
     XEVDM_CTX *mctx = (XEVDM_CTX *)ctx;
     const TREE_CONS tc = { FALSE, TREE_LC, eAll };
     u8 *map_ats = (u8 *)calloc(ctx->f_scu, 1);
+    if (m->map_ats) memcpy(map_ats, m->map_ats, ctx->f_scu);
     int i, k;
-    hn->sps.tool_addb = 1;
+    hn->sps.tool_addb = addb;
     ctx->pic->pic_deblock_alpha_offset = alpha_off;
     ctx->pic->pic_deblock_beta_offset = beta_off;
     (void)mctx;
@@ -255,7 +277,7 @@ int refh_deblock_addb(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu
         int hx;
         for (hx = 0; hx < cw; hx += 64)
             xevdm_deblock_cu_ver(ctx, ctx->pic, b->x[i] + hx, b->y[i], cw > 64 ? 64 : cw, 1 << b->log2h[i], ctx->map_scu, ctx->map_refi, ctx->map_mv,
-                                 ctx->w_scu, sp->log2_ctu, ctx->map_cu_mode, ctx->refp, 0, tc, ctx->map_tidx, 0, 1, map_ats,
+                                 ctx->w_scu, sp->log2_ctu, ctx->map_cu_mode, ctx->refp, 0, tc, ctx->map_tidx, 0, addb, map_ats,
                                  sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
     }
     for (k = 0; k < (int)ctx->f_scu; k++) MCU_CLR_COD(ctx->map_scu[k]);
@@ -264,7 +286,7 @@ int refh_deblock_addb(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu
         int hy;
         for (hy = 0; hy < ch; hy += 64)
             xevdm_deblock_cu_hor(ctx, ctx->pic, b->x[i], b->y[i] + hy, 1 << b->log2w[i], ch > 64 ? 64 : ch, ctx->map_scu, ctx->map_refi, ctx->map_mv,
-                                 ctx->w_scu, sp->log2_ctu, ctx->refp, 0, tc, ctx->map_tidx, 0, 1, map_ats,
+                                 ctx->w_scu, sp->log2_ctu, ctx->refp, 0, tc, ctx->map_tidx, 0, addb, map_ats,
                                  sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
     }
     free(map_ats);

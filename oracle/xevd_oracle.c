@@ -428,6 +428,17 @@ void orc_dbk_chroma(int16_t *u, int16_t *v, int st_u, int st_v, int stride, int 
 #define MCU_CBFL(m) (((m) >> 24) & 1)
 #define MCU_COD(m)  (((m) >> 31) & 1)
 
+/* ATS-inter TU of a CU: size (xevdm_get_tu_size, src_main/xevdm_util.c:3585-3608) and offset (get_tu_pos_offset :3610-3634) in
+   luma samples; info = idx | pos<<4, idx 1/3 vertical split half/quarter width, 2/4 horizontal split */
+static void ats_inter_tu(int info, int w, int h, int *tx, int *ty, int *tw, int *th)
+{
+    const int idx = info & 15, pos = (info >> 4) & 15;
+    *tx = 0; *ty = 0; *tw = w; *th = h;
+    if (idx == 0) return;
+    if (idx == 2 || idx == 4) { *th = idx == 4 ? h / 4 : h / 2; *ty = pos ? h - *th : 0; }
+    else { *tw = idx == 3 ? w / 4 : w / 2; *tx = pos ? w - *tw : 0; }
+}
+
 /* xevd_set_dec_info (src_base/xevd_util.c:1574-1660): every SCU of the CU receives intra flag (bit 15), QP
    (bits 16-22, core->qp = qp_y - 6*(bd-8)), skip flag (23), luma cbf (24), COD (31), refi and mv. */
 static void set_dec_info(const xgpu_seq_params *sp, const xgpu_cu_batch *b, int i, orc_maps *m)
@@ -440,9 +451,17 @@ static void set_dec_info(const xgpu_seq_params *sp, const xgpu_cu_batch *b, int 
     if (b->pred_mode[i] == XGPU_MODE_SKIP) v |= 1u << 23;
     /* the luma cbf flag of the map is is_coef_sub[Y_C][0] (xevd_util.c:1615): for a CU above 64 only its first 64x64 sub-block counts */
     if ((b->cbf[i] & 1) && (!(b->log2w[i] > 6 || b->log2h[i] > 6) || !b->cbf_sub || (b->cbf_sub[i] & 1))) v |= 1u << 24;
+    const int ai = (!intra && b->ats_inter) ? b->ats_inter[i] : 0;
+    int tx = 0, ty = 0, tw = 0, th = 0;
+    if (ai) ats_inter_tu(ai, ws * 4, hs * 4, &tx, &ty, &tw, &th);
     for (r = 0; r < hs; r++) for (c = 0; c < ws; c++) {
         const int k = (ys + r) * m->w_scu + xs + c;
         m->map_scu[k] = v;
+        if (ai) {      /* xevdm_set_cu_cbf_flags (xevdm_util.c:3670-3712): luma cbf only on the coded part */
+            m->map_scu[k] &= ~(1u << 24);
+            if ((b->cbf[i] & 1) && c * 4 >= tx && c * 4 < tx + tw && r * 4 >= ty && r * 4 < ty + th) m->map_scu[k] |= 1u << 24;
+        }
+        if (m->map_ats) m->map_ats[k] = (uint8_t)ai;
         if (intra) {
             m->map_refi[k * 2] = m->map_refi[k * 2 + 1] = -1;
             memset(&m->map_mv[k * 4], 0, 4 * sizeof(int16_t));
@@ -466,7 +485,39 @@ int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_c
         const int inter = b->pred_mode[i] != XGPU_MODE_INTRA;
         if (inter)
             orc_mc_cu(sp, fr, x, y, w, h, &b->refi[i * 2], (const int16_t (*)[2])&b->mv[i * 4], pred[0], pred[1]);
-        for (c = 0; c < 3; c++) {
+        const int ai = (inter && b->ats_inter) ? b->ats_inter[i] : 0;
+        for (c = 0; c < 3 && ai; c++) {
+            /* ATS-inter (xevdm_sub_block_itdq :808-816, xevdm_recon :62-112): one TU of half/quarter size per component, luma
+               with DST-VII/DCT-VIII when the CU is at most 32x32 (xevdm_get_ats_inter_trs, xevdm_util.c:3636-3668), residual
+               added only inside the TU */
+            const int cw = c ? w >> 1 : w, ch = c ? h >> 1 : h;
+            const int coded = (b->cbf[i] >> c) & 1;
+            int16_t *plane = c == 0 ? fr->cur.y : (c == 1 ? fr->cur.u : fr->cur.v);
+            const int s = c ? fr->cur.s_c : fr->cur.s_l;
+            int16_t *rec = plane + (c ? (y >> 1) * s + (x >> 1) : y * s + x);
+            int tx, ty, tw, th, r, q;
+            ats_inter_tu(ai, cw, ch, &tx, &ty, &tw, &th);
+            if (coded) {
+                int l2w = 0, l2h = 0;
+                while ((1 << l2w) < tw) l2w++;
+                while ((1 << l2h) < th) l2h++;
+                memcpy(res, b->coef + off, sizeof(int16_t) * tw * th);
+                if (c == 0 && lw <= 5 && lh <= 5) {
+                    const int idx = ai & 15, pos = (ai >> 4) & 15, hor = idx == 2 || idx == 4;
+                    const int t_h = hor ? 0 : (pos == 0), t_v = hor ? (pos == 0) : 0;      /* 1 = DCT-VIII, 0 = DST-VII */
+                    orc_itdq_ats(res, l2w, l2h, b->qp[i * 3], sp->bit_depth_luma, sp->tool_iqt, t_v, t_h);
+                } else
+                    orc_itdq(res, l2w, l2h, b->qp[i * 3 + c], sp->bit_depth_luma, sp->tool_iqt);
+                if (resid_out) memcpy(resid_out + off, res, sizeof(int16_t) * tw * th);
+                off += (size_t)tw * th;
+            }
+            for (r = 0; r < ch; r++) for (q = 0; q < cw; q++) {
+                const int in = coded && q >= tx && q < tx + tw && r >= ty && r < ty + th;
+                const int16_t t = (int16_t)((in ? res[(r - ty) * tw + (q - tx)] : 0) + pred[0][c][r * cw + q]);
+                rec[r * s + q] = (int16_t)CLIP3(0, (1 << sp->bit_depth_luma) - 1, t);
+            }
+        }
+        for (c = 0; c < 3 && !ai; c++) {
             const int cw = c ? w >> 1 : w, ch = c ? h >> 1 : h, clw = c ? lw - 1 : lw, clh = c ? lh - 1 : lh;
             const int coded = (b->cbf[i] >> c) & 1;
             int16_t *plane = c == 0 ? fr->cur.y : (c == 1 ? fr->cur.u : fr->cur.v);
@@ -589,20 +640,27 @@ int orc_deblock_baseline(const xgpu_seq_params *sp, const orc_frame *fr, const x
        already visited, the right edge when the right neighbour is (never the case in quad-tree z-order). */
     for (k = 0; k < ws * m->h_scu; k++) m->map_scu[k] &= 0x7FFFFFFFu;
     for (i = 0; i < b->n_cu; i++) {
-        const int x = b->x[i], y = b->y[i], w = 1 << b->log2w[i], h = 1 << b->log2h[i];
-        const int t = (x >> 2) + (y >> 2) * ws;
-        if (x > 0 && MCU_COD(m->map_scu[t - 1]))
-            for (r = 0; r < h >> 2; r++) dbk_segment(sp, fr, m, t + r * ws, t + r * ws - 1, x, y + 4 * r, 1);
-        if (x + w < sp->width && MCU_COD(m->map_scu[t + (w >> 2)]))
-            for (r = 0; r < h >> 2; r++) dbk_segment(sp, fr, m, t + r * ws + (w >> 2), t + r * ws + (w >> 2) - 1, x + w, y + 4 * r, 1);
-        for (r = 0; r < h >> 2; r++) for (c = 0; c < w >> 2; c++) m->map_scu[t + r * ws + c] |= 1u << 31;
+        /* a CU wider than 64 is filtered as two halves, each like a CU of its own (deblock_tree, src_main/xevdm.c:2017-2037) */
+        const int cw = 1 << b->log2w[i], y = b->y[i], w = cw > 64 ? 64 : cw, h = 1 << b->log2h[i];
+        int x;
+        for (x = b->x[i]; x < b->x[i] + cw; x += 64) {
+            const int t = (x >> 2) + (y >> 2) * ws;
+            if (x > 0 && MCU_COD(m->map_scu[t - 1]))
+                for (r = 0; r < h >> 2; r++) dbk_segment(sp, fr, m, t + r * ws, t + r * ws - 1, x, y + 4 * r, 1);
+            if (x + w < sp->width && MCU_COD(m->map_scu[t + (w >> 2)]))
+                for (r = 0; r < h >> 2; r++) dbk_segment(sp, fr, m, t + r * ws + (w >> 2), t + r * ws + (w >> 2) - 1, x + w, y + 4 * r, 1);
+            for (r = 0; r < h >> 2; r++) for (c = 0; c < w >> 2; c++) m->map_scu[t + r * ws + c] |= 1u << 31;
+        }
     }
-    /* pass 2: horizontal edges (xevd_deblock_cu_hor, xevd_df.c:291-383): top edge of every CU below row 0 */
+    /* pass 2: horizontal edges (xevd_deblock_cu_hor, xevd_df.c:291-383): top edge of every CU (or 64-row half) below row 0 */
     for (i = 0; i < b->n_cu; i++) {
-        const int x = b->x[i], y = b->y[i], w = 1 << b->log2w[i];
-        const int t = (x >> 2) + (y >> 2) * ws;
-        if (y > 0)
-            for (c = 0; c < w >> 2; c++) dbk_segment(sp, fr, m, t + c, t + c - ws, x + 4 * c, y, 0);
+        const int x = b->x[i], w = 1 << b->log2w[i], ch = 1 << b->log2h[i];
+        int y;
+        for (y = b->y[i]; y < b->y[i] + ch; y += 64) {
+            const int t = (x >> 2) + (y >> 2) * ws;
+            if (y > 0)
+                for (c = 0; c < w >> 2; c++) dbk_segment(sp, fr, m, t + c, t + c - ws, x + 4 * c, y, 0);
+        }
     }
     return 0;
 }
@@ -636,7 +694,7 @@ static int addb_bs(const xgpu_seq_params *sp, const orc_frame *fr, const orc_map
     int mv0[2][2], mv1[2][2], l, d;
     if (intra && ((x0 >> lg) != (x1 >> lg) || (y0 >> lg) != (y1 >> lg))) return 4;
     if (intra) return 3;
-    if (MCU_CBFL(m0) || MCU_CBFL(m1)) return 2;
+    if (MCU_CBFL(m0) || MCU_CBFL(m1) || (m->map_ats && (m->map_ats[k0] || m->map_ats[k1]))) return 2;     /* ats_present, xevdm_df.c:415 */
     for (l = 0; l < 2; l++) {
         p0[l] = r0[l] >= 0 ? fr->refp[r0[l]][l].y : NULL;
         p1[l] = r1[l] >= 0 ? fr->refp[r1[l]][l].y : NULL;

@@ -28,6 +28,16 @@ CASES = [
     # ATS: DST-VII / DCT-VIII luma transforms of intra CUs (checked through the residual arena)
     ("main_ats_10b", 136, 136, 10, 1, 1, (1, 1), 0.3, {"addb": 1, "inter_frac": 0.5, "ats_frac": 0.7}),
     ("main_ats_8b_noiqt", 128, 72, 8, 1, 0, (1, 0), 0.0, {"inter_frac": 0.4, "ats_frac": 0.8, "split_prob": 0.7}),
+    # ATS-inter: half/quarter-size TU of an inter CU, residual placed at one end, luma cbf and bS on the coded part only
+    ("main_atsinter_10b", 200, 136, 10, 1, 1, (2, 2), 0.5, {"addb": 1, "inter_frac": 1.0, "ats_inter_frac": 1.0, "split_prob": 0.4, "coded_frac": 0.85}),
+    ("main_atsinter_8b_mixed", 136, 136, 8, 1, 1, (1, 1), 0.3, {"addb": 1, "inter_frac": 0.8, "ats_frac": 0.5, "ats_inter_frac": 0.6, "split_prob": 0.35}),
+    ("main_atsinter_noaddb", 128, 72, 10, 1, 0, (1, 0), 0.0, {"inter_frac": 1.0, "ats_inter_frac": 0.8}),
+    # BTT: binary / ternary splits -> non-square CUs (4x16 ... 128x32), edges off the 8x8 ADDB grid, all tools together
+    ("main_btt_10b", 200, 136, 10, 1, 1, (2, 2), 0.5, {"addb": 1, "alf": 1, "btt_frac": 0.7, "ats_inter_frac": 0.6, "inter_frac": 1.0, "coded_frac": 0.8}),
+    ("main_btt_ctu128_8b", 264, 200, 8, 1, 1, (1, 1), 0.4, {"addb": 1, "log2_ctu": 7, "btt_frac": 0.7, "split_prob": 0.45, "ats_inter_frac": 0.5}),
+    ("main_btt_noaddb_8b", 136, 72, 8, 1, 0, (1, 0), 0.0, {"btt_frac": 0.8, "split_prob": 0.6}),
+    # CTU 128 without ADDB: the Main library's copy of the Baseline filter, CUs above 64 filtered as two halves
+    ("main_ctu128_noaddb_8b", 264, 264, 8, 1, 0, (1, 1), 0.3, {"log2_ctu": 7, "btt_frac": 0.6, "ats_inter_frac": 0.5, "split_prob": 0.3}),
 ]
 POCS = [[4, 0, 2], [12, 16, 4]]      # L1 idx 2 has the POC of L0 idx 0 -> identical-motion candidates exist
 CUR_POC = 8
@@ -53,8 +63,8 @@ def build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, tools=None, seed=0, 
             refs[(i, l)] = pic
     if (2, 1) in refs and (0, 0) in refs:
         refs[(2, 1)] = refs[(0, 0)]      # the same picture in both lists (same POC 4): ADDB compares pictures, not indices
-    batch = synth.gen_frame(rng, w, h, bd, log2_ctu=log2_ctu, ats_frac=float(tools.get("ats_frac", 0.0)), inter_frac=inter_frac, bi_frac=bi_frac, n_refs=n_refs, oob_frac=oob_frac,
-                            qp_range=qp_range, split_prob=split_prob, amp=amp)
+    batch = synth.gen_frame(rng, w, h, bd, log2_ctu=log2_ctu, ats_frac=float(tools.get("ats_frac", 0.0)), ats_inter_frac=float(tools.get("ats_inter_frac", 0.0)), btt_frac=float(tools.get("btt_frac", 0.0)), inter_frac=inter_frac, bi_frac=bi_frac, n_refs=n_refs, oob_frac=oob_frac,
+                            qp_range=qp_range, split_prob=split_prob, amp=amp, coded_frac=float(tools.get("coded_frac", 0.6)))
     if n_refs[0] and n_refs[1]:      # force some identical-motion bi CUs
         sel = (batch["refi"][:, 0] >= 0) & (batch["refi"][:, 1] >= 0)
         idx = np.nonzero(sel)[0][::3]

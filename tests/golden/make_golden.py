@@ -107,8 +107,10 @@ def golden_itdq(lib):
     print("blocks_itdq.npz:", len(recs), "blocks")
 
 
-def golden_pictures():
+def golden_pictures(only=None):
     for case in cases.CASES:
+        if only and case[0] not in only:
+            continue
         cs = cases.build_case(*case)
         final, pre, maps, resid = cases.run_cpu("ref", cs)
         d = {"params": np.array(case[1:6], np.int64), "n_refs": np.array(case[6], np.int64),
@@ -142,6 +144,10 @@ def golden_pictures():
 if __name__ == "__main__":
     assert ol.have_ref(), "oracle/_ref is not built: run `make -C oracle -f Makefile.ref` in the development container"
     lib = ol.ref()
-    golden_mc(lib)
-    golden_itdq(lib)
-    golden_pictures()
+    import sys
+    if len(sys.argv) > 1:                 # python make_golden.py <picture case> ... : only (re)generate those
+        golden_pictures(set(sys.argv[1:]))
+    else:
+        golden_mc(lib)
+        golden_itdq(lib)
+        golden_pictures()

@@ -8,7 +8,9 @@ import oracle_lib as ol
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 PICTURE_CASES = ["base_p_8b", "base_b_8b", "base_p_10b", "main_b_10b", "main_admvp_only", "main_iqt_only",
                  "main_addb_10b", "main_addb_8b_shared_refs", "main_alf_10b", "main_alf_8b_across_tiles", "main_alf_only_luma",
-                 "main_ctu128_10b", "main_ctu128_8b_noiqt", "main_ats_10b", "main_ats_8b_noiqt"]
+                 "main_ctu128_10b", "main_ctu128_8b_noiqt", "main_ats_10b", "main_ats_8b_noiqt",
+                 "main_atsinter_10b", "main_atsinter_8b_mixed", "main_atsinter_noaddb",
+                 "main_btt_10b", "main_btt_ctu128_8b", "main_btt_noaddb_8b", "main_ctu128_noaddb_8b"]
 
 
 def load_picture_case(name):
@@ -36,6 +38,7 @@ def load_picture_case(name):
     batch["n_coef"] = int(batch["n_coef"])
     batch.setdefault("cbf_sub", None)
     batch.setdefault("ats", None)
+    batch.setdefault("ats_inter", None)
     case = {"name": name, "w": w, "h": h, "bd": bd, "admvp": admvp, "iqt": iqt, "refs": refs, "batch": batch,
             "addb": tools[0], "alf": tools[1], "alpha_off": tools[2], "beta_off": tools[3], "no_deblock": tools[4], "log2_ctu": tools[5],
             "alf_params": alf_params}

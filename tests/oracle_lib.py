@@ -20,7 +20,7 @@ class OrcPic(C.Structure):
 
 
 class OrcMaps(C.Structure):
-    _fields_ = [("map_scu", C.c_void_p), ("map_refi", C.c_void_p), ("map_mv", C.c_void_p), ("w_scu", C.c_int), ("h_scu", C.c_int)]
+    _fields_ = [("map_scu", C.c_void_p), ("map_refi", C.c_void_p), ("map_mv", C.c_void_p), ("map_ats", C.c_void_p), ("w_scu", C.c_int), ("h_scu", C.c_int)]
 
 
 class OrcFrame(C.Structure):
@@ -143,10 +143,12 @@ class Maps:
         self.map_scu = np.zeros(n, np.uint32)
         self.map_refi = np.full((n, 2), -1, np.int8)
         self.map_mv = np.zeros((n, 2, 2), np.int16)
+        self.map_ats = np.zeros(n, np.uint8)
 
     def orc(self):
         m = OrcMaps()
         m.map_scu, m.map_refi, m.map_mv = self.map_scu.ctypes.data, self.map_refi.ctypes.data, self.map_mv.ctypes.data
+        m.map_ats = self.map_ats.ctypes.data
         m.w_scu, m.h_scu = self.w_scu, self.h_scu
         return m
 

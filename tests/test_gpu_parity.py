@@ -82,14 +82,18 @@ RANDOM = [
     ("stress_levels", 128, 72, 8, 0, 0, (1, 0), 0.0, {"amp": 40.0}),
     ("stress_levels_iqt", 128, 72, 10, 0, 1, (1, 0), 0.0, {"amp": 40.0}),
     ("tiny", 8, 8, 8, 0, 0, (1, 0), 0.0, {}),
+    ("btt_all_tools", 328, 200, 10, 1, 1, (2, 2), 0.5, {"inter_frac": 1.0, "tools": {"addb": 1, "alf": 1, "btt_frac": 0.8, "ats_inter_frac": 0.7, "coded_frac": 0.8}}),
+    ("btt_ctu128_base_dbk", 264, 264, 8, 1, 0, (1, 1), 0.3, {"tools": {"log2_ctu": 7, "btt_frac": 0.8, "ats_inter_frac": 0.5}}),
 ]
 
 
 @pytest.mark.parametrize("spec", RANDOM, ids=[s[0] for s in RANDOM])
 def test_gpu_vs_oracle_random(spec):
     *case, kw = spec
+    kw = dict(kw)
+    tools = kw.pop("tools", None)
     for seed in range(2):
-        cs = cases.build_case(*case[:8], case[8] if len(case) > 8 else None, seed=seed, **kw)
+        cs = cases.build_case(*case[:8], tools, seed=seed, **kw)
         ref, _, _, _ = cases.run_cpu("oracle", cs)
         out = cases.run_gpu(cs)
         for c in range(3):

@@ -45,7 +45,7 @@ class CuBatch(C.Structure):
         ("log2w", C.POINTER(C.c_uint8)), ("log2h", C.POINTER(C.c_uint8)),
         ("pred_mode", C.POINTER(C.c_uint8)),
         ("refi", C.POINTER(C.c_int8)), ("mv", C.POINTER(C.c_int16)),
-        ("qp", C.POINTER(C.c_uint8)), ("cbf", C.POINTER(C.c_uint8)), ("cbf_sub", C.POINTER(C.c_uint16)), ("ipm", C.POINTER(C.c_uint8)), ("ats", C.POINTER(C.c_uint8)),
+        ("qp", C.POINTER(C.c_uint8)), ("cbf", C.POINTER(C.c_uint8)), ("cbf_sub", C.POINTER(C.c_uint16)), ("ipm", C.POINTER(C.c_uint8)), ("ats", C.POINTER(C.c_uint8)), ("ats_inter", C.POINTER(C.c_uint8)),
         ("coef_off", C.POINTER(C.c_uint32)), ("coef", C.POINTER(C.c_int16)), ("n_coef", C.c_size_t),
         ("n_ctu", C.c_int), ("ctu_cu_start", C.POINTER(C.c_uint32)),
     ]
@@ -87,6 +87,7 @@ def make_cu_batch(b):
         "ipm": np.ascontiguousarray(b["ipm"], np.uint8),
         "cbf_sub": None if b.get("cbf_sub") is None else np.ascontiguousarray(b["cbf_sub"], np.uint16),
         "ats": None if b.get("ats") is None else np.ascontiguousarray(b["ats"], np.uint8),
+        "ats_inter": None if b.get("ats_inter") is None else np.ascontiguousarray(b["ats_inter"], np.uint8),
         "coef_off": np.ascontiguousarray(b["coef_off"], np.uint32),
         "coef": np.ascontiguousarray(b["coef"], np.int16),
         "ctu_cu_start": np.ascontiguousarray(b["ctu_cu_start"], np.uint32),
@@ -102,6 +103,8 @@ def make_cu_batch(b):
         cb.cbf_sub = _ptr(keep["cbf_sub"], C.c_uint16)
     if keep["ats"] is not None:
         cb.ats = _ptr(keep["ats"], C.c_uint8)
+    if keep["ats_inter"] is not None:
+        cb.ats_inter = _ptr(keep["ats_inter"], C.c_uint8)
     cb.coef_off, cb.coef = _ptr(keep["coef_off"], C.c_uint32), _ptr(keep["coef"], C.c_int16)
     cb.n_coef = len(keep["coef"])
     cb.n_ctu = len(keep["ctu_cu_start"]) - 1

@@ -249,18 +249,29 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     const int cw = 1 << lw, chh = 1 << lh;
     const int x = sx << 2, y = sy << 2;
     const bool intra = pred_mode == XGPU_MODE_INTRA;
+    // ATS-inter: the coded TU is one half/quarter of the CU at its start or end (xevdm_get_tu_size / get_tu_pos_offset,
+    // src_main/xevdm_util.c:3585-3634); residual and luma cbf exist only there (xevdm_recon.c:62-112, xevdm_util.c:3670-3712)
+    const int ai = intra ? 0 : (int)((r1.w >> 8) & 0xFF);
+    int tu_x = 0, tu_y = 0, tu_w = cw, tu_h = chh;
+    if (ai) {
+        const int idx = ai & 15, pos = ai >> 4;
+        if (idx == 2 || idx == 4) { tu_h = chh >> (idx == 4 ? 2 : 1); tu_y = pos ? chh - tu_h : 0; }
+        else                      { tu_w = cw >> (idx == 3 ? 2 : 1);  tu_x = pos ? cw - tu_w : 0; }
+    }
+    const int lx = x - cu_x - tu_x, ly = y - cu_y - tu_y;                 // position inside the TU
+    const bool in_tu = (uint32_t)lx < (uint32_t)tu_w && (uint32_t)ly < (uint32_t)tu_h;
 
     // ---- SCU map update (xevd_set_dec_info): intra flag, QP, skip flag, luma cbf, COD + CU-edge flags ----
     {
         uint32_t m = ((uint32_t)qp_map << 16) | ((uint32_t)intra << 15) | (1u << 31);
         if (pred_mode == XGPU_MODE_SKIP) m |= 1u << 23;
-        if ((r0.z >> 24) & 1) m |= 1u << 24;          // CuRec.map_cbf
+        if (((r0.z >> 24) & 1) && in_tu) m |= 1u << 24;          // CuRec.map_cbf
         // CU boundary, or the 64-sample transform boundary inside a wider CU (deblock_tree splits those, xevdm.c:1989-2037)
         if (((x - cu_x) & 63) == 0) m |= SCU_EDGE_L;
         if (((y - cu_y) & 63) == 0) m |= SCU_EDGE_T;
         uint4 rec;
         rec.x = m;
-        rec.y = intra ? 0x0000FFFFu : (r0.z & 0xFFFFu);
+        rec.y = intra ? 0x0000FFFFu : ((r0.z & 0xFFFFu) | ((uint32_t)ai << 16));
         rec.z = intra ? 0u : r1.x;
         rec.w = intra ? 0u : r1.y;
         *(uint4 *)&a.maps[sy * a.w_scu + sx] = rec;
@@ -333,26 +344,27 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     if (nl == 0) return;     // inter CU without a valid reference: nothing predicted (does not occur in valid streams)
 
     // ---- residual add + clip (xevd_recon.c:35-71; the LUMA bit depth clips all three components, :75-90) ----
-    const int lx = x - cu_x, ly = y - cu_y;
     uint32_t off = coef_off;
     if (cbf & 1) {
-        const int16_t *r = a.resid + off + ly * cw + lx;
+        const int16_t *r = a.resid + off + ly * tu_w + lx;
+        if (in_tu) {
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const uint2 v = *(const uint2 *)(r + k * cw);
-            pl[k * 2 + 0] = recon2(pl[k * 2 + 0], v.x, maxl);
-            pl[k * 2 + 1] = recon2(pl[k * 2 + 1], v.y, maxl);
+            for (int k = 0; k < 4; k++) {
+                const uint2 v = *(const uint2 *)(r + k * tu_w);
+                pl[k * 2 + 0] = recon2(pl[k * 2 + 0], v.x, maxl);
+                pl[k * 2 + 1] = recon2(pl[k * 2 + 1], v.y, maxl);
+            }
         }
-        off += cw * chh;
+        off += tu_w * tu_h;
     }
-    const int cwc = cw >> 1;
-    if (cbf & 2) {
+    const int cwc = tu_w >> 1;
+    if ((cbf & 2) && in_tu) {
         const int16_t *r = a.resid + off + (ly >> 1) * cwc + (lx >> 1);
         pu[0] = recon2(pu[0], *(const uint32_t *)r, maxl);
         pu[1] = recon2(pu[1], *(const uint32_t *)(r + cwc), maxl);
-        off += cwc * (chh >> 1);
     }
-    if (cbf & 4) {
+    if (cbf & 2) off += cwc * (tu_h >> 1);
+    if ((cbf & 4) && in_tu) {
         const int16_t *r = a.resid + off + (ly >> 1) * cwc + (lx >> 1);
         pv[0] = recon2(pv[0], *(const uint32_t *)r, maxl);
         pv[1] = recon2(pv[1], *(const uint32_t *)(r + cwc), maxl);

@@ -338,28 +338,53 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     // size class = (log2w, log2h) x (vertical, horizontal) transform kind; ATS kinds only occur for intra luma TBs
     enum { NCLS = 64 * 9 };
     int cls_count[NCLS] = { 0 };
+    auto ats_inter_of = [&](int i) -> int { return (b->ats_inter && b->pred_mode[i] != XGPU_MODE_INTRA) ? b->ats_inter[i] : 0; };
     auto tr_code = [&](int i, int k) -> int {
-        if (k != 0 || !b->ats || !(b->ats[i] & 1) || b->pred_mode[i] != XGPU_MODE_INTRA) return 0;
+        if (k != 0) return 0;
+        if (const int ai = ats_inter_of(i)) {
+            // xevdm_get_ats_inter_trs (src_main/xevdm_util.c:3636-3668): DST-VII across the split, DCT-VIII along it for the
+            // first part / DST-VII for the last; CUs wider or taller than 32 keep DCT-II
+            if (b->log2w[i] > 5 || b->log2h[i] > 5) return 0;
+            const int idx = ai & 15, pos = ai >> 4, hor = idx == 2 || idx == 4;
+            const int tv = hor ? (pos == 0 ? TR_DCT8 : TR_DST7) : TR_DST7, th = hor ? TR_DST7 : (pos == 0 ? TR_DCT8 : TR_DST7);
+            return tv * 3 + th;
+        }
+        if (!b->ats || !(b->ats[i] & 1) || b->pred_mode[i] != XGPU_MODE_INTRA) return 0;
         const int tv = (b->ats[i] >> 1) & 1 ? TR_DCT8 : TR_DST7, th = (b->ats[i] >> 2) & 1 ? TR_DCT8 : TR_DST7;
         return tv * 3 + th;
+    };
+    // luma log2 size of the CU's coefficient block: the CU, or the ATS-inter TU (xevdm_get_tu_size, xevdm_util.c:3585-3608)
+    auto blk_log2 = [&](int i, int &bw, int &bh) {
+        bw = b->log2w[i]; bh = b->log2h[i];
+        const int idx = ats_inter_of(i) & 15;
+        if (idx == 1 || idx == 3) bw -= idx == 3 ? 2 : 1;
+        if (idx == 2 || idx == 4) bh -= idx == 4 ? 2 : 1;
     };
     for (int i = 0; i < n; i++) {
         const int lw = b->log2w[i], lh = b->log2h[i];
         ARGCHK(c, lw >= 2 && lw <= 7 && lh >= 2 && lh <= 7 && lw <= c->sp.log2_ctu && lh <= c->sp.log2_ctu);
         ARGCHK(c, b->x[i] + (1 << lw) <= c->sp.width && b->y[i] + (1 << lh) <= c->sp.height && !(b->x[i] & 3) && !(b->y[i] & 3));
         if (b->pred_mode[i] != XGPU_MODE_INTRA) ARGCHK(c, b->refi[i * 2] < XGPU_MAX_REFS && b->refi[i * 2 + 1] < XGPU_MAX_REFS);
+        if (const int ai = ats_inter_of(i)) {
+            // availability as xevdm_check_ats_inter_info_coded (xevdm_util.c:3565-3583): CU <= 64, split dimension >= 8 (>= 16 for quarters)
+            const int idx = ai & 15, pos = ai >> 4;
+            ARGCHK(c, idx >= 1 && idx <= 4 && pos <= 1 && lw <= 6 && lh <= 6);
+            ARGCHK(c, ((idx == 1 || idx == 3) ? lw : lh) >= (idx >= 3 ? 4 : 3));
+        }
         size_t need = 0;
+        int bw, bh;
+        blk_log2(i, bw, bh);
         for (int k = 0; k < 3; k++) {
             if (!((b->cbf[i] >> k) & 1)) continue;
             // TBs are at most 64 wide/tall: a larger CU is cut into 64x64 (chroma 32x32) sub-blocks (xevd_itdq.c:544-621)
-            const int tw = std::min(lw, 6) - (k ? 1 : 0), th = std::min(lh, 6) - (k ? 1 : 0);
+            const int tw = std::min(bw, 6) - (k ? 1 : 0), th = std::min(bh, 6) - (k ? 1 : 0);
             const int nsx = lw > 6 ? 2 : 1, nsy = lh > 6 ? 2 : 1;
             for (int sb = 0; sb < 4; sb++) {
                 if ((sb & 1) >= nsx || (sb >> 1) >= nsy) continue;
                 if (nsx * nsy > 1 && b->cbf_sub && !((b->cbf_sub[i] >> (4 * k + sb)) & 1)) continue;
                 cls_count[tr_code(i, k) * 64 + tw * 8 + th]++;
             }
-            need += (size_t)(1 << (lw + lh)) >> (k ? 2 : 0);
+            need += (size_t)(1 << (bw + bh)) >> (k ? 2 : 0);
         }
         ARGCHK(c, (size_t)b->coef_off[i] + need <= b->n_coef);
     }
@@ -400,11 +425,14 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         memcpy(r.mv, &b->mv[i * 4], sizeof(r.mv));
         r.qp[0] = b->qp[i * 3]; r.qp[1] = b->qp[i * 3 + 1]; r.qp[2] = b->qp[i * 3 + 2];
         if (b->ipm) { r.ipm[0] = b->ipm[i * 2]; r.ipm[1] = b->ipm[i * 2 + 1]; }
+        r.ats_inter = (uint8_t)ats_inter_of(i);
+        int bw, bh;
+        blk_log2(i, bw, bh);
         uint32_t off = r.coef_off;
         for (int k = 0; k < 3; k++) {
             if (!((r.cbf >> k) & 1)) continue;
-            const int cl = k ? r.log2w - 1 : r.log2w, chh = k ? r.log2h - 1 : r.log2h;        // component block of the CU
-            const int tw = std::min((int)r.log2w, 6) - (k ? 1 : 0), th = std::min((int)r.log2h, 6) - (k ? 1 : 0);
+            const int cl = k ? bw - 1 : bw, chh = k ? bh - 1 : bh;        // component block of the CU
+            const int tw = std::min(bw, 6) - (k ? 1 : 0), th = std::min(bh, 6) - (k ? 1 : 0);
             const int nsx = r.log2w > 6 ? 2 : 1, nsy = r.log2h > 6 ? 2 : 1;
             for (int sb = 0; sb < 4; sb++) {
                 const int si = sb & 1, sj = sb >> 1;

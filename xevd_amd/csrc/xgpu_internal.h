@@ -38,7 +38,8 @@ struct __attribute__((aligned(16))) CuRec {
     int16_t  mv[2][2];        // unclipped quarter-pel
     uint8_t  qp[3];           // dequant QPs
     uint8_t  ipm[2];
-    uint8_t  pad[3];
+    uint8_t  ats_inter;       // ats_inter_info of an inter CU (idx | pos << 4), 0 = whole-CU transform
+    uint8_t  pad[2];
 };
 static_assert(sizeof(CuRec) == 32, "CuRec must be 32 bytes");
 
@@ -47,7 +48,7 @@ static_assert(sizeof(CuRec) == 32, "CuRec must be 32 bytes");
 struct __attribute__((aligned(16))) ScuRec {
     uint32_t scu;             // bit 15 intra, 16-22 QP, 23 skip, 24 luma cbf, 31 COD; bits 8/9: left/top CU edge
     int8_t   refi[2];
-    uint16_t rsvd;
+    uint16_t ats_inter;       // mctx->map_ats_inter of the SCU (ADDB: non-zero on either side of an edge -> bS 2)
     int16_t  mv[2][2];
 };
 static_assert(sizeof(ScuRec) == 16, "ScuRec must be 16 bytes");

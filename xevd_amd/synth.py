@@ -58,11 +58,89 @@ def gen_partition(rng, width, height, log2_ctu=6, split_prob=0.5, min_log2=2):
     return x.astype(np.uint16), y.astype(np.uint16), log2s, log2s.copy(), start
 
 
+def gen_partition_btt(rng, width, height, log2_ctu=6, split_prob=0.5, btt_frac=0.6, min_log2=2, max_ratio=4):
+    """Leaf CUs of a quad + binary + ternary split tree (the Main profile's BTT, split modes of src_base/xevd_def.h:776-785)
+    in decode order: children of a node are visited first-to-last, so the order key is the path of child indices."""
+    ctu = 1 << log2_ctu
+    mn = 1 << min_log2
+    w_ctu, h_ctu = (width + ctu - 1) // ctu, (height + ctu - 1) // ctu
+    gx, gy = np.meshgrid(np.arange(w_ctu) * ctu, np.arange(h_ctu) * ctu)
+    x, y = gx.ravel().astype(np.int64), gy.ravel().astype(np.int64)
+    w = np.full(x.shape, ctu, np.int64)
+    h = w.copy()
+    key = np.arange(len(x), dtype=np.int64)                 # CTU raster index, then 2 bits per tree level
+    depth = np.zeros(len(x), np.int64)
+    MAXD = 12
+    leaves = []
+    while len(x):
+        inside = (x < width) & (y < height)
+        x, y, w, h, key, depth = (v[inside] for v in (x, y, w, h, key, depth))
+        cx, cy = x + w > width, y + h > height
+        # candidate modes: 0 none, 1 quad, 2 binary ver, 3 binary hor, 4 ternary ver, 5 ternary hor
+        avail = np.stack([~(cx | cy),
+                          (w == h) & (w > mn),
+                          (w > mn) & (h <= max_ratio * (w // 2)),
+                          (h > mn) & (w <= max_ratio * (h // 2)),
+                          (w >= 4 * mn) & (h <= max_ratio * (w // 4)) & ~(cx | cy),
+                          (h >= 4 * mn) & (w <= max_ratio * (h // 4)) & ~(cx | cy)], 1)
+        # a node crossing the picture border must split towards the border
+        forced_v = cx & ~cy & (w > mn)
+        forced_h = cy & ~cx & (h > mn)
+        avail[forced_v] &= np.array([0, 1, 1, 0, 0, 0], bool)
+        avail[forced_h] &= np.array([0, 1, 0, 1, 0, 0], bool)
+        avail[forced_v, 2] = True
+        avail[forced_h, 3] = True
+        both = cx & cy
+        avail[both] &= np.array([0, 1, 1, 1, 0, 0], bool)
+        avail[both & (w >= h) & (w > mn), 2] = True
+        avail[both & (h > w), 3] = True
+        weight = np.array([0.0, 1.0 - btt_frac, btt_frac / 3, btt_frac / 3, btt_frac / 6, btt_frac / 6])
+        score = rng.random(avail.shape) * weight * avail
+        mode = np.where(score.max(1) > 0, score.argmax(1), 0)
+        stay = avail[:, 0] & ((rng.random(len(x)) >= split_prob) | (mode == 0))
+        mode = np.where(stay, 0, mode)
+        assert (avail[np.arange(len(x)), mode]).all(), "picture size must be a multiple of the minimum CU size"
+        lf = mode == 0
+        leaves.append((x[lf], y[lf], w[lf], h[lf], key[lf] << (2 * (MAXD - depth[lf]))))
+        nx, ny, nw, nh, nk, nd = [], [], [], [], [], []
+
+        def child(m, i, dx, dy, cw, ch):
+            nx.append(x[m] + dx); ny.append(y[m] + dy); nw.append(cw); nh.append(ch)
+            nk.append(key[m] * 4 + i); nd.append(depth[m] + 1)
+        m = mode == 1
+        for i in range(4):
+            child(m, i, (i & 1) * (w[m] // 2), (i >> 1) * (h[m] // 2), w[m] // 2, h[m] // 2)
+        m = mode == 2
+        for i in range(2):
+            child(m, i, i * (w[m] // 2), 0 * w[m], w[m] // 2, h[m])
+        m = mode == 3
+        for i in range(2):
+            child(m, i, 0 * w[m], i * (h[m] // 2), w[m], h[m] // 2)
+        m = mode == 4
+        for i, (o, f) in enumerate(((0, 4), (1, 2), (3, 4))):
+            child(m, i, o * (w[m] // 4), 0 * w[m], w[m] // f, h[m])
+        m = mode == 5
+        for i, (o, f) in enumerate(((0, 4), (1, 2), (3, 4))):
+            child(m, i, 0 * w[m], o * (h[m] // 4), w[m], h[m] // f)
+        x, y, w, h, key, depth = (np.concatenate(v) for v in (nx, ny, nw, nh, nk, nd))
+        assert len(depth) == 0 or depth.max() <= MAXD
+    x, y, w, h, key = (np.concatenate([l[i] for l in leaves]) for i in range(5))
+    order = np.argsort(key, kind="stable")
+    x, y, w, h, key = x[order], y[order], w[order], h[order], key[order]
+    ctu_idx = (y >> log2_ctu) * w_ctu + (x >> log2_ctu)
+    assert (np.diff(ctu_idx) >= 0).all()
+    start = np.searchsorted(ctu_idx, np.arange(w_ctu * h_ctu + 1)).astype(np.uint32)
+    return x.astype(np.uint16), y.astype(np.uint16), np.log2(w).astype(np.uint8), np.log2(h).astype(np.uint8), start
+
+
 def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_frac=0.0, coded_frac=0.6,
               n_refs=(1, 0), qp_range=(22, 37), mv_sigma_px=8.0, oob_frac=0.05, split_prob=0.5,
-              chroma_qp_table=None, max_level=24, amp=2.0, ats_frac=0.0):
+              chroma_qp_table=None, max_level=24, amp=2.0, ats_frac=0.0, ats_inter_frac=0.0, btt_frac=0.0):
     """One picture's CU batch as a dict of numpy arrays (layout of xgpu_cu_batch, include/xevd_hip.h)."""
-    x, y, l2w, l2h, start = gen_partition(rng, width, height, log2_ctu, split_prob)
+    if btt_frac > 0:
+        x, y, l2w, l2h, start = gen_partition_btt(rng, width, height, log2_ctu, split_prob, btt_frac)
+    else:
+        x, y, l2w, l2h, start = gen_partition(rng, width, height, log2_ctu, split_prob)
     n = len(x)
     w = (1 << l2w.astype(np.int64))
     h = (1 << l2h.astype(np.int64))
@@ -110,8 +188,22 @@ def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_fr
     cbf |= (coded & (rng.random(n) < 0.5)).astype(np.uint8) << 1
     cbf |= (coded & (rng.random(n) < 0.5)).astype(np.uint8) << 2
 
+    # ATS-inter (Main): a coded inter CU of 8..64 may code one half/quarter TU (xevdm_check_ats_inter_info_coded,
+    # src_main/xevdm_util.c:3565-3583); ats_inter_info = idx | pos << 4, idx 1/3 vertical split, 2/4 horizontal split
+    ats_inter = None
+    tu_w, tu_h = w.copy(), h.copy()
+    if ats_inter_frac > 0:
+        ok = inter & (cbf != 0) & (l2w <= 6) & (l2h <= 6) & (rng.random(n) < ats_inter_frac)
+        avail = np.stack([w >= 8, h >= 8, w >= 16, h >= 16], 1) & ok[:, None]       # idx 1, 2, 3, 4
+        pick = rng.random((n, 4)) * avail
+        idx = np.where(avail.any(1), pick.argmax(1) + 1, 0)
+        pos = rng.integers(0, 2, n)
+        ats_inter = np.where(idx > 0, idx | (pos << 4), 0).astype(np.uint8)
+        tu_w = np.where(idx == 1, w // 2, np.where(idx == 3, w // 4, w))
+        tu_h = np.where(idx == 2, h // 2, np.where(idx == 4, h // 4, h))
+
     # coefficient arena: CU-contiguous, components in Y,U,V order, coded ones only
-    area_y = w * h
+    area_y = tu_w * tu_h
     area_c = area_y // 4
     sizes = np.stack([area_y * (cbf & 1), area_c * ((cbf >> 1) & 1), area_c * ((cbf >> 2) & 1)], 1)
     cu_size = sizes.sum(1)
@@ -137,7 +229,7 @@ def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_fr
     tb_off, tb_w, tb_h, tb_qp, tb_stride = [], [], [], [], []
     run = coef_off.copy()
     for c in range(3):
-        cw_c, ch_c = (w >> (1 if c else 0)), (h >> (1 if c else 0))
+        cw_c, ch_c = (tu_w >> (1 if c else 0)), (tu_h >> (1 if c else 0))
         tw = np.minimum(cw_c, 32 if c else 64)
         th = np.minimum(ch_c, 32 if c else 64)
         for sb in range(4):
@@ -191,7 +283,7 @@ def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_fr
     ipm[:, 0] = rng.integers(0, 5, n)
     return {
         "x": x, "y": y, "log2w": l2w, "log2h": l2h, "pred_mode": pred_mode, "refi": refi, "mv": mv, "qp": qp,
-        "cbf": cbf, "cbf_sub": cbf_sub if big.any() else None, "ats": ats, "ipm": ipm, "coef_off": coef_off.astype(np.uint32), "coef": coef[:max(n_coef, 1)],
+        "cbf": cbf, "cbf_sub": cbf_sub if big.any() else None, "ats": ats, "ats_inter": ats_inter, "ipm": ipm, "coef_off": coef_off.astype(np.uint32), "coef": coef[:max(n_coef, 1)],
         "ctu_cu_start": start, "n_coef": n_coef,
     }
 
