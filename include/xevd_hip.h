@@ -118,7 +118,8 @@ typedef struct xgpu_cu_batch {
     const uint16_t *cbf_sub;      /* [n_cu] or NULL: for CUs wider/taller than 64, bit (4*c + sb) = nnz_sub[c][sb]
                                      of the 64x64 sub-blocks sb = (j<<1)|i (xevd_itdq.c:544-621); NULL = every
                                      sub-block of a coded component is coded                                */
-    const uint8_t  *ipm;          /* [n_cu][2] intra luma / chroma mode (intra CUs)                       */
+    const uint8_t  *ipm;          /* [n_cu][2] intra luma / chroma mode of intra CUs (core->ipm[0..1]): IPD_DC_B 0, HOR 1, VER 2,
+                                     UL 3, UR 4 (src_base/xevd_def.h:332-342); NULL = DC                      */
     const uint8_t  *ats;          /* [n_cu] or NULL: bit 0 = ats_intra_cu, bit 1 = ats_intra_mode_v, bit 2 = ats_intra_mode_h
                                      (0 = DST-VII, 1 = DCT-VIII; luma TB of intra CUs, xevdm.c:602, xevdm_itdq.c:406-421)   */
     const uint8_t  *ats_inter;    /* [n_cu] or NULL: ats_inter_info of inter CUs = idx | pos << 4 (src_main/xevdm_def.h:232-236):
@@ -130,6 +131,8 @@ typedef struct xgpu_cu_batch {
     size_t          n_coef;
     int             n_ctu;
     const uint32_t *ctu_cu_start; /* [n_ctu+1] first CU of every CTU in raster CTU order                  */
+    int             constrained_intra_pred;   /* pps.constrained_intra_pred_flag: intra CUs only predict from intra neighbours
+                                                 (xevd_get_nbr_b, src_base/xevd_ipred.c:47,61,77)          */
 } xgpu_cu_batch;
 
 /* ------------------------------------------------------------------ lifetime ---------------------- */

@@ -195,7 +195,25 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
                 if (core->is_coef[c]) { memcpy(resid_out + o, core->coef[c], sizeof(s16) * n); o += n; }
             }
         }
-        if (b->pred_mode[i] != XGPU_MODE_INTRA) {
+        if (b->pred_mode[i] == XGPU_MODE_INTRA) {
+            /* xevd_recon_unit's intra branch (xevd.c:731-741; Main with tool_eipd = 0: xevdm.c:1346-1381): availability from the
+               COD flags set so far, neighbour samples, the Baseline predictors, then the same reconstruction */
+            int xx = x, yy = y, ww = w, hh = h;
+            ctx->pps.constrained_intra_pred_flag = b->constrained_intra_pred;
+            core->avail_lr = xevd_check_nev_avail(core->x_scu, core->y_scu, w, h, ctx->w_scu, ctx->h_scu, ctx->map_scu, ctx->map_tidx);
+            core->avail_cu = xevd_get_avail_intra(core->x_scu, core->y_scu, ctx->w_scu, ctx->h_scu, core->scup, lw, lh, ctx->map_scu, ctx->map_tidx);
+            for (c = 0; c < 3; c++) {
+                pel *plane = c == 0 ? ctx->pic->y : (c == 1 ? ctx->pic->u : ctx->pic->v);
+                const int s = c ? ctx->pic->s_c : ctx->pic->s_l;
+                if (c == 1) { xx >>= 1; yy >>= 1; ww >>= 1; hh >>= 1; }
+                xevd_get_nbr_b(xx, yy, ww, hh, plane + yy * s + xx, s, core->avail_cu, core->nb, core->scup, ctx->map_scu, ctx->w_scu, ctx->h_scu,
+                               c, b->constrained_intra_pred, ctx->map_tidx, sp->bit_depth_luma, sp->chroma_format_idc);
+            }
+            xevd_ipred_b(core->nb[0][0] + 2, core->nb[0][1] + h, core->nb[0][2] + 2, core->avail_lr, core->pred[0][Y_C], core->ipm[0], w, h);
+            xevd_ipred_uv_b(core->nb[1][0] + 2, core->nb[1][1] + (h >> 1), core->nb[1][2] + 2, core->avail_lr, core->pred[0][U_C], core->ipm[1], core->ipm[0], w >> 1, h >> 1);
+            xevd_ipred_uv_b(core->nb[2][0] + 2, core->nb[2][1] + (h >> 1), core->nb[2][2] + 2, core->avail_lr, core->pred[0][V_C], core->ipm[1], core->ipm[0], w >> 1, h >> 1);
+            xevd_recon_yuv(ctx, core, x, y, w, h);
+        } else {
             /* prediction: xevd.c:725-726 / xevdm.c:1311-1316 (DMVR off) */
             if (main_path) {
                 u8 dmvr_flag = 0;

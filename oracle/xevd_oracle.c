@@ -472,6 +472,59 @@ static void set_dec_info(const xgpu_seq_params *sp, const xgpu_cu_batch *b, int 
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Intra prediction, Baseline modes (also what the Main profile runs with sps->tool_eipd = 0, src_main/xevdm.c:1368-1381).
+ * ---------------------------------------------------------------------------------------------- */
+/* xevd_get_nbr_b (src_base/xevd_ipred.c:33-94): neighbour samples of one component.  `up` and `left` point at index 0 and
+   are valid from -1 to cw+ch-1.  A 4x4-luma unit (2x2 chroma) of the row above / column to the left is taken from the picture
+   when its SCU is inside the picture and already reconstructed (COD, bit 31 of map_scu) - and intra-coded under
+   constrained_intra_pred -, else it is the mid value of the LUMA bit depth (xevd.c:455-473 passes it for all components). */
+static void intra_neighbours(const xgpu_seq_params *sp, const orc_maps *m, const int16_t *src, int s, int x_scu, int y_scu,
+                             int cw, int ch, int unit, int constrained, int16_t *up, int16_t *left)
+{
+    const int scuw = cw / unit, scuh = ch / unit, ws = m->w_scu, scup = x_scu + y_scu * ws;
+    const int16_t mid = (int16_t)(1 << (sp->bit_depth_luma - 1));
+    int i, j;
+#define NB_OK(k) (MCU_COD(m->map_scu[k]) && (!constrained || MCU_IF(m->map_scu[k])))
+    up[-1] = (x_scu > 0 && y_scu > 0 && NB_OK(scup - ws - 1)) ? src[-s - 1] : mid;      /* AVAIL_UP_LE, xevd_util.c:722-725 */
+    for (i = 0; i < scuw + scuh; i++) {
+        const int ok = y_scu > 0 && x_scu + i < ws && NB_OK(scup - ws + i);
+        for (j = 0; j < unit; j++) up[i * unit + j] = ok ? src[-s + i * unit + j] : mid;
+    }
+    for (i = 0; i < scuh + scuw; i++) {
+        const int ok = x_scu > 0 && y_scu + i < m->h_scu && NB_OK(scup - 1 + i * ws);
+        for (j = 0; j < unit; j++) left[i * unit + j] = ok ? src[(i * unit + j) * s - 1] : mid;
+    }
+    left[-1] = up[-1];
+#undef NB_OK
+}
+
+/* xevd_ipred_b / xevd_ipred_uv_b (xevd_ipred.c:625-676): IPD_DC_B 0, HOR 1, VER 2, UL 3, UR 4 for luma and chroma alike */
+static void intra_predict(const int16_t *left, const int16_t *up, int16_t *dst, int mode, int w, int h)
+{
+    int i, j;
+    switch (mode) {
+    case 2: for (i = 0; i < h; i++) for (j = 0; j < w; j++) dst[i * w + j] = up[j]; break;                 /* :112-124 */
+    case 1: for (i = 0; i < h; i++) for (j = 0; j < w; j++) dst[i * w + j] = left[i]; break;               /* :96-108 */
+    case 0: {                                                                                              /* ipred_dc_b :149-164 */
+        int dc = 0, lw = 0;
+        while ((1 << lw) < w) lw++;
+        for (i = 0; i < h; i++) dc += left[i];
+        for (j = 0; j < w; j++) dc += up[j];
+        dc = (dc + w) >> (lw + 1);                   /* the width alone sets rounding and shift, also for non-square blocks */
+        for (i = 0; i < w * h; i++) dst[i] = (int16_t)dc;
+        break; }
+    case 3:                                                                                                /* ipred_ul :587-609 */
+        for (i = 0; i < h; i++) for (j = 0; j < w; j++)
+            dst[i * w + j] = i > j ? left[i - j - 1] : (i == j ? up[-1] : up[j - i - 1]);
+        break;
+    case 4:                                                                                                /* ipred_ur :611-622 */
+        for (i = 0; i < h; i++) for (j = 0; j < w; j++) dst[i * w + j] = (int16_t)((up[i + j + 1] + left[i + j + 1]) >> 1);
+        break;
+    default: break;
+    }
+}
+
 int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *maps, int16_t *resid_out)
 {
     int16_t *pred[2][3], *res;
@@ -485,6 +538,16 @@ int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_c
         const int inter = b->pred_mode[i] != XGPU_MODE_INTRA;
         if (inter)
             orc_mc_cu(sp, fr, x, y, w, h, &b->refi[i * 2], (const int16_t (*)[2])&b->mv[i * 4], pred[0], pred[1]);
+        else if (maps) {      /* xevd_recon_unit's intra branch, xevd.c:731-741 (availability needs the SCU map) */
+            int16_t nb_up[2 * MAX_CU + 8], nb_le[2 * MAX_CU + 8];
+            for (c = 0; c < 3; c++) {
+                const int cw = c ? w >> 1 : w, ch = c ? h >> 1 : h, s = c ? fr->cur.s_c : fr->cur.s_l;
+                const int16_t *plane = c == 0 ? fr->cur.y : (c == 1 ? fr->cur.u : fr->cur.v);
+                intra_neighbours(sp, maps, plane + (c ? (y >> 1) * s + (x >> 1) : y * s + x), s, x >> 2, y >> 2, cw, ch, c ? 2 : 4,
+                                 b->constrained_intra_pred, nb_up + 4, nb_le + 4);
+                intra_predict(nb_le + 4, nb_up + 4, pred[0][c], b->ipm ? b->ipm[i * 2 + (c ? 1 : 0)] : 0, cw, ch);
+            }
+        }
         const int ai = (inter && b->ats_inter) ? b->ats_inter[i] : 0;
         for (c = 0; c < 3 && ai; c++) {
             /* ATS-inter (xevdm_sub_block_itdq :808-816, xevdm_recon :62-112): one TU of half/quarter size per component, luma
@@ -553,7 +616,7 @@ int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_c
                 if (resid_out) memcpy(resid_out + off, res, sizeof(int16_t) * cw * ch);
                 off += (size_t)cw * ch;
             }
-            if (inter)      /* xevd_recon_yuv passes the luma bit depth for chroma too, xevd_recon.c:75-90 */
+            if (inter || maps)      /* xevd_recon_yuv passes the luma bit depth for chroma too, xevd_recon.c:75-90 */
                 orc_recon(res, pred[0][c], coded, cw, ch, s, plane + (c ? (y >> 1) * s + (x >> 1) : y * s + x), sp->bit_depth_luma);
         }
         if (maps) set_dec_info(sp, b, i, maps);

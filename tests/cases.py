@@ -36,6 +36,11 @@ CASES = [
     ("main_btt_10b", 200, 136, 10, 1, 1, (2, 2), 0.5, {"addb": 1, "alf": 1, "btt_frac": 0.7, "ats_inter_frac": 0.6, "inter_frac": 1.0, "coded_frac": 0.8}),
     ("main_btt_ctu128_8b", 264, 200, 8, 1, 1, (1, 1), 0.4, {"addb": 1, "log2_ctu": 7, "btt_frac": 0.7, "split_prob": 0.45, "ats_inter_frac": 0.5}),
     ("main_btt_noaddb_8b", 136, 72, 8, 1, 0, (1, 0), 0.0, {"btt_frac": 0.8, "split_prob": 0.6}),
+    # intra prediction (Baseline modes; Main runs the same ones with tool_eipd = 0): all-intra pictures, constrained intra
+    ("base_i_8b", 136, 120, 8, 0, 0, (1, 0), 0.0, {"inter_frac": 0.0}),
+    ("base_p_constrained_intra_10b", 144, 88, 10, 0, 0, (1, 0), 0.0, {"inter_frac": 0.5, "constrained_intra": 1}),
+    ("main_i_btt_10b", 200, 136, 10, 1, 1, (1, 0), 0.0, {"inter_frac": 0.0, "btt_frac": 0.7, "addb": 1, "alf": 1, "ats_frac": 0.5}),
+    ("main_b_ctu128_intra_mix_8b", 264, 200, 8, 1, 1, (1, 1), 0.4, {"inter_frac": 0.6, "log2_ctu": 7, "btt_frac": 0.5, "split_prob": 0.4, "addb": 1, "alf": 1, "ats_frac": 0.4, "ats_inter_frac": 0.4}),
     # CTU 128 without ADDB: the Main library's copy of the Baseline filter, CUs above 64 filtered as two halves
     ("main_ctu128_noaddb_8b", 264, 264, 8, 1, 0, (1, 1), 0.3, {"log2_ctu": 7, "btt_frac": 0.6, "ats_inter_frac": 0.5, "split_prob": 0.3}),
 ]
@@ -65,6 +70,7 @@ def build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, tools=None, seed=0, 
         refs[(2, 1)] = refs[(0, 0)]      # the same picture in both lists (same POC 4): ADDB compares pictures, not indices
     batch = synth.gen_frame(rng, w, h, bd, log2_ctu=log2_ctu, ats_frac=float(tools.get("ats_frac", 0.0)), ats_inter_frac=float(tools.get("ats_inter_frac", 0.0)), btt_frac=float(tools.get("btt_frac", 0.0)), inter_frac=inter_frac, bi_frac=bi_frac, n_refs=n_refs, oob_frac=oob_frac,
                             qp_range=qp_range, split_prob=split_prob, amp=amp, coded_frac=float(tools.get("coded_frac", 0.6)))
+    batch["constrained_intra_pred"] = int(tools.get("constrained_intra", 0))
     if n_refs[0] and n_refs[1]:      # force some identical-motion bi CUs
         sel = (batch["refi"][:, 0] >= 0) & (batch["refi"][:, 1] >= 0)
         idx = np.nonzero(sel)[0][::3]

@@ -10,7 +10,8 @@ PICTURE_CASES = ["base_p_8b", "base_b_8b", "base_p_10b", "main_b_10b", "main_adm
                  "main_addb_10b", "main_addb_8b_shared_refs", "main_alf_10b", "main_alf_8b_across_tiles", "main_alf_only_luma",
                  "main_ctu128_10b", "main_ctu128_8b_noiqt", "main_ats_10b", "main_ats_8b_noiqt",
                  "main_atsinter_10b", "main_atsinter_8b_mixed", "main_atsinter_noaddb",
-                 "main_btt_10b", "main_btt_ctu128_8b", "main_btt_noaddb_8b", "main_ctu128_noaddb_8b"]
+                 "main_btt_10b", "main_btt_ctu128_8b", "main_btt_noaddb_8b", "main_ctu128_noaddb_8b",
+                 "base_i_8b", "base_p_constrained_intra_10b", "main_i_btt_10b", "main_b_ctu128_intra_mix_8b"]
 
 
 def load_picture_case(name):
@@ -36,6 +37,7 @@ def load_picture_case(name):
                       "ctb_flag": d["alf_ctb_flag"], "across_tiles": int(d["alf_across_tiles"])}
     batch = {k[2:]: d[k] for k in d.files if k.startswith("b_")}
     batch["n_coef"] = int(batch["n_coef"])
+    batch["constrained_intra_pred"] = int(batch.get("constrained_intra_pred", 0))
     batch.setdefault("cbf_sub", None)
     batch.setdefault("ats", None)
     batch.setdefault("ats_inter", None)

@@ -47,7 +47,7 @@ class CuBatch(C.Structure):
         ("refi", C.POINTER(C.c_int8)), ("mv", C.POINTER(C.c_int16)),
         ("qp", C.POINTER(C.c_uint8)), ("cbf", C.POINTER(C.c_uint8)), ("cbf_sub", C.POINTER(C.c_uint16)), ("ipm", C.POINTER(C.c_uint8)), ("ats", C.POINTER(C.c_uint8)), ("ats_inter", C.POINTER(C.c_uint8)),
         ("coef_off", C.POINTER(C.c_uint32)), ("coef", C.POINTER(C.c_int16)), ("n_coef", C.c_size_t),
-        ("n_ctu", C.c_int), ("ctu_cu_start", C.POINTER(C.c_uint32)),
+        ("n_ctu", C.c_int), ("ctu_cu_start", C.POINTER(C.c_uint32)), ("constrained_intra_pred", C.c_int),
     ]
 
 
@@ -109,6 +109,7 @@ def make_cu_batch(b):
     cb.n_coef = len(keep["coef"])
     cb.n_ctu = len(keep["ctu_cu_start"]) - 1
     cb.ctu_cu_start = _ptr(keep["ctu_cu_start"], C.c_uint32)
+    cb.constrained_intra_pred = int(b.get("constrained_intra_pred", 0) or 0)
     return cb, keep
 
 

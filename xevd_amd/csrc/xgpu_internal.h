@@ -93,6 +93,23 @@ struct InterArgs {
     RefEntry refp[XGPU_MAX_REFS][2];
 };
 
+// One intra CU of a picture, in dependency-level order.  Availability = the reference's COD flags at the CU's turn
+// (xevd_get_nbr_b, src_base/xevd_ipred.c:47-92): bit k of `up` / `le` = the k-th 4-luma-sample unit of the row above /
+// the column to the left (cw/4 + ch/4 units each) comes from the picture, else it is mid grey.
+struct IntraRec {
+    uint32_t cu;              // index into the CU records
+    uint32_t flags;           // bit 0: the up-left sample is available
+    uint64_t up, le;
+};
+struct IntraArgs {
+    int16_t *cur_y, *cur_u, *cur_v;
+    int      s_l, s_c;
+    int      bd_l;
+    const CuRec    *cus;
+    const IntraRec *list;
+    const int16_t  *resid;
+};
+
 struct ItdqArgs {
     const int16_t *coef;
     int16_t       *resid;
@@ -136,6 +153,9 @@ struct xgpu_dbatch {
     int16_t   *d_coef, *d_resid;
     TbRec     *d_tbs;
     TbWave    *d_waves;
+    IntraRec  *d_intra;               // intra CUs sorted by dependency level
+    int        n_intra, n_levels;
+    int       *level_first;           // host: [n_levels + 1] ranges of d_intra
     void      *h_stage;               // pinned staging block
     size_t     stage_bytes;
 };
@@ -166,6 +186,7 @@ struct xgpu_ctx {
 // kernel launchers (one per .hip file)
 void launch_itdq(xgpu_ctx *c, const ItdqArgs &a);
 void launch_inter(xgpu_ctx *c, const InterArgs &a);
+void launch_intra(xgpu_ctx *c, const IntraArgs &a, int first, int count);
 void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst);
 void upload_transform_tables(const int *tm, const int16_t *ats, hipStream_t s);
 int  itdq_group_size(int log2w, int log2h);     // TBs of one size class per 256-thread work item

@@ -281,6 +281,8 @@ def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_fr
         ats = (on.astype(np.uint8) | (rng.integers(0, 4, n).astype(np.uint8) << 1) * on).astype(np.uint8)
     ipm = np.zeros((n, 2), np.uint8)
     ipm[:, 0] = rng.integers(0, 5, n)
+    # the Baseline syntax has no chroma mode of its own (core->ipm[1] = luma mode, xevd_eco.c:1154); a few CUs differ anyway
+    ipm[:, 1] = np.where(rng.random(n) < 0.8, ipm[:, 0], rng.integers(0, 5, n))
     return {
         "x": x, "y": y, "log2w": l2w, "log2h": l2h, "pred_mode": pred_mode, "refi": refi, "mv": mv, "qp": qp,
         "cbf": cbf, "cbf_sub": cbf_sub if big.any() else None, "ats": ats, "ats_inter": ats_inter, "ipm": ipm, "coef_off": coef_off.astype(np.uint32), "coef": coef[:max(n_coef, 1)],
