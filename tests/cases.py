@@ -136,7 +136,7 @@ def run_cpu(engine, case, deblock=True, simd=0, pad=True):
     return cur, pre, maps, resid
 
 
-def run_gpu(case, deblock=True, pad=True, alf=True, resid=False):
+def run_gpu(case, deblock=True, pad=True, alf=True, resid=False, repeat=1):
     """The HIP backend through the C ABI. -> list of padded planes (reference buffer geometry)"""
     from xevd_amd.decoder import XgpuDecoder
     with XgpuDecoder(case["w"], case["h"], case["bd"], log2_ctu=case.get("log2_ctu", 6), iqt=case["iqt"], admvp=case["admvp"],
@@ -150,6 +150,10 @@ def run_gpu(case, deblock=True, pad=True, alf=True, resid=False):
         cur = dec.pic_alloc()
         dec.pic_upload_padded(cur, _start_picture(case).bufs)
         hb = dec.batch_create(case["batch"])
+        for _ in range(repeat - 1):      # the same resident batch decoded again into the same slot (exercises per-batch device state)
+            dec.decode_picture(cur, CUR_POC, slots, hb, deblock=deblock and not case.get("no_deblock"), pad=pad,
+                               qp_u_offset=QP_OFFSETS[0], qp_v_offset=QP_OFFSETS[1],
+                               alpha_off=case.get("alpha_off", 0), beta_off=case.get("beta_off", 0), alf=case.get("alf_params") if alf else None)
         dec.decode_picture(cur, CUR_POC, slots, hb, deblock=deblock and not case.get("no_deblock"), pad=pad,
                            qp_u_offset=QP_OFFSETS[0], qp_v_offset=QP_OFFSETS[1],
                            alpha_off=case.get("alpha_off", 0), beta_off=case.get("beta_off", 0), alf=case.get("alf_params") if alf else None)

@@ -111,6 +111,16 @@ def test_gpu_full_size_vs_oracle(size):
         assert np.array_equal(out[c], ref.bufs[c]), f"plane {c}"
 
 
+def test_gpu_all_intra_1080p_vs_oracle():
+    """BASELINE.json configs[0] shape (Baseline 1080p I-only): every CU intra, dependency chains a thousand CUs deep
+    through the data-flow kernel; the resident batch is decoded three times (epoch-valued done flags, running ticket counter)."""
+    cs = cases.build_case("intra1080", 1920, 1080, 8, 0, 0, (1, 0), 0.0, {"inter_frac": 0.0}, seed=3)
+    ref, _, _, _ = cases.run_cpu("oracle", cs)
+    out = cases.run_gpu(cs, repeat=3)
+    for c in range(3):
+        assert np.array_equal(out[c], ref.bufs[c]), f"plane {c}"
+
+
 def test_gpu_8k_properties():
     """8K (7680x4320): identity property - zero motion, no residual, deblocking off: the picture equals its
     reference, padding included; and the run is deterministic."""

@@ -7,8 +7,12 @@
 // An intra CU predicts from reconstructed samples of CUs decoded before it, so intra CUs form a dependency graph
 // on top of the inter CUs (which k_inter finishes first).  The batch builder (host) derives, per intra CU, which
 // 4-sample units of the row above / the column to the left exist "already reconstructed" in decode order
-// (= the reference's COD flags at that CU's turn) and the CU's level = 1 + max level of the intra CUs it reads;
-// one launch of this kernel handles all CUs of one level - CUs of a level are independent by construction.
+// (= the reference's COD flags at that CU's turn), the list of intra CUs it reads from, and sorts the CUs
+// topologically (by level = 1 + max level of the intra CUs read).
+//
+// Two launches per picture: level 1 (no intra neighbour; the bulk of the intra CUs of a P/B picture) as a plain kernel,
+// all deeper levels as ONE data-flow kernel (a launch per level would cost ~15 us each, and an all-intra picture has
+// ~10^3 levels) - see k_intra<DEP> below.
 //
 // MI355X mapping: one wavefront (= one 64-thread workgroup) per CU.  The neighbour arrays of the three components
 // are staged once in LDS (unavailable units -> mid grey of the LUMA bit depth, xevd.c:455-473), DC sums are wave
@@ -28,104 +32,243 @@ __device__ __forceinline__ uint32_t recon2i(uint32_t pred, uint32_t res, int max
     return pack2i(clip3i(0, maxv, lo), clip3i(0, maxv, hi));
 }
 
-// one predicted sample at (j, i) of a w-wide block; up/left are LDS arrays whose element [0] is index -1
-__device__ __forceinline__ int ipred_sample(const int16_t *up, const int16_t *le, int mode, int dc, int i, int j)
+// Neighbour samples of one component in LDS, laid out along the block's "diagonal axis":
+//   nb[NB_C0 - 1 - k] = left[k],  nb[NB_C0] = up[-1],  nb[NB_C0 + 1 + k] = up[k]   (k = 0 .. w+h-1)
+//   nb[NB_UR + k] = (up[k] + left[k]) >> 1  (only filled for IPD_UR_B),  nb[NB_DC] = the DC value (only for IPD_DC_B).
+// Every Baseline predictor (IPD_DC_B 0, HOR 1, VER 2, UL 3, UR 4; src_base/xevd_ipred.c:96-164, 587-622) of a 4x4 (2x2) block
+// then reads at most 7 (3) CONSECUTIVE entries: HOR left[i], VER up[j], UL nb[NB_C0 + j - i], UR nb[NB_UR + i + j + 1].
+#define NB_DC 0
+#define NB_C0 261            // odd: up[k] pairs (k even) are 4-byte aligned
+#define NB_UR 520
+#define NB_LEN (NB_UR + 256)
+
+// N consecutive neighbour entries for the block at (lx, ly): v[k]; the sample at row r, column q is v[sel(mode, r, q)]
+template <int N>
+__device__ __forceinline__ void nb_fetch(const int16_t *nb, int mode, int lx, int ly, int v[N])
 {
-    switch (mode) {
-    case 0:  return dc;                                                              // IPD_DC_B
-    case 1:  return le[1 + i];                                                       // IPD_HOR_B
-    case 2:  return up[1 + j];                                                       // IPD_VER_B
-    case 3:  return i > j ? le[i - j] : (i == j ? up[0] : up[j - i]);                // IPD_UL_B: le[i-j-1] / up[-1] / up[j-i-1]
-    default: return (up[2 + i + j] + le[2 + i + j]) >> 1;                            // IPD_UR_B: index i+j+1
-    }
+    int base = NB_DC, step = 0;
+    if (mode == 1) { base = NB_C0 - 1 - ly; step = -1; }
+    if (mode == 2) { base = NB_C0 + 1 + lx; step = 1; }
+    if (mode == 3) { base = NB_C0 + lx - ly - (N >> 1); step = 1; }
+    if (mode == 4) { base = NB_UR + lx + ly + 1; step = 1; }
+#pragma unroll
+    for (int k = 0; k < N; k++) v[k] = (uint16_t)nb[base + step * k];
+}
+__device__ __forceinline__ int nb_sel(int mode, int r, int q, int half)      // compile-time r, q; mode is wave-uniform
+{
+    return mode == 1 ? r : mode == 2 ? q : mode == 3 ? half + q - r : mode == 4 ? r + q : 0;
 }
 
-__global__ __launch_bounds__(64) void k_intra(const IntraArgs a, int first)
+// Samples that other workgroups of the SAME launch wrote (or will read) move with agent-scope relaxed atomics, i.e. plain
+// loads/stores with the sc1 bit: coherent across the XCD L2s without the bulk write-back / invalidate an agent-scope fence costs.
+__device__ __forceinline__ uint32_t ld_coherent(const int16_t *p)      // p 4-byte aligned
 {
-    __shared__ int16_t s_up[3][NB_MAX], s_le[3][NB_MAX];
-    const int t = threadIdx.x;
-    const IntraRec ir = a.list[first + blockIdx.x];
-    const uint4 r0 = ((const uint4 *)&a.cus[ir.cu])[0];
-    const uint4 r1 = ((const uint4 *)&a.cus[ir.cu])[1];
-    const int cu_x = r0.x & 0xFFFF, cu_y = r0.x >> 16;
-    const int lw = r0.y & 0xFF, lh = (r0.y >> 8) & 0xFF, cbf = r0.y >> 24;
-    const uint32_t coef_off = r0.w;
-    const int cw = 1 << lw, chh = 1 << lh;
-    const int mode_l = (r1.z >> 24) & 0xFF, mode_c = r1.w & 0xFF;                    // CuRec.ipm[0], ipm[1]
+    return __hip_atomic_load((uint32_t *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_coherent(int16_t *p, uint32_t v)
+{
+    __hip_atomic_store((uint32_t *)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_coherent2(int16_t *p, uint32_t lo, uint32_t hi)      // p 8-byte aligned
+{
+    __hip_atomic_store((uint64_t *)p, (uint64_t)lo | ((uint64_t)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+#define INTRA_WAVES 4        // waves (= CUs in flight) per workgroup; INTRA_CHUNK (xgpu_internal.h) list positions per workgroup, interleaved
+
+__device__ __forceinline__ void wave_lds_sync()      // LDS traffic of one wave is processed in order: only the compiler needs the fence
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+
+// DEP = false: the CUs of level 1 (no intra CU among their neighbours) - independent, plain accesses, static assignment.
+// DEP = true : all deeper levels in ONE launch.  Workgroups draw chunks of list positions from a ticket counter, so every
+//              lower position is already running or finished whatever order the dispatcher picks; a wave waits on the done
+//              flags of the CUs it reads from.  Samples move with sc1 accesses (coherent across the XCD L2s), flags hold the
+//              launch's epoch (no reset between pictures).  There are no workgroup barriers: a wave may wait for a flag that
+//              another wave of its own workgroup sets.
+template <bool DEP>
+__global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
+{
+    __shared__ __attribute__((aligned(16))) int16_t s_nb[INTRA_WAVES][3][NB_LEN];
+    __shared__ uint32_t s_chunk;
+    const int t = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    uint32_t chunk = blockIdx.x;
+    if (DEP) {
+        if (threadIdx.x == 0) s_chunk = atomicAdd(&a.done[a.n_intra], 1u) - a.ticket_base;
+        __syncthreads();                                             // the only workgroup barrier, before any wave can wait
+        chunk = s_chunk;
+    }
+    int16_t (*nb)[NB_LEN] = s_nb[wv];
     const int mid = 1 << (a.bd_l - 1);
     const int maxv = (1 << a.bd_l) - 1;
 
-    // ---- neighbour staging (xevd_get_nbr_b): element e of a side belongs to unit e / unit_size ----
-#pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const int16_t *plane = c == 0 ? a.cur_y : (c == 1 ? a.cur_u : a.cur_v);
-        const int s = c ? a.s_c : a.s_l, sh = c ? 1 : 0, ush = c ? 1 : 2;
-        const int16_t *org = plane + (cu_y >> sh) * s + (cu_x >> sh);
-        const int n = (cw + chh) >> sh;
-        for (int e = t; e < n; e += 64) {
-            const int k = e >> ush;
-            s_up[c][1 + e] = ((ir.up >> k) & 1) ? org[-s + e] : (int16_t)mid;
-            s_le[c][1 + e] = ((ir.le >> k) & 1) ? org[e * s - 1] : (int16_t)mid;
-        }
-        if (t == 0) {
-            const int16_t ul = (ir.flags & 1) ? org[-s - 1] : (int16_t)mid;
-            s_up[c][0] = ul; s_le[c][0] = ul;
-        }
-    }
-    __syncthreads();
+    constexpr int PER_WG = DEP ? INTRA_CHUNK : INTRA_WAVES;         // independent CUs: one per wave, as many workgroups as it takes
+    for (int it = 0; it < PER_WG / INTRA_WAVES; it++) {
+        const uint32_t item = a.first + chunk * PER_WG + it * INTRA_WAVES + wv;
+        if (item >= (uint32_t)(a.first + a.count)) break;
+        const uint4 *rec = (const uint4 *)&a.list[item];
+        const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+        const uint32_t avail_ul = uni(q0.y) & 1;
+        const uint64_t avail_up = (uint64_t)uni(q0.z) | ((uint64_t)uni(q0.w) << 32), avail_le = (uint64_t)uni(q1.x) | ((uint64_t)uni(q1.y) << 32);
+        const uint32_t dep_first = uni(q1.z), dep_count = uni(q1.w);
+        const uint32_t g = uni(q2.x), m = uni(q2.y), ipm = uni(q2.z), coef_off = uni(q2.w);
+        const int cu_x = g & 0xFFFF, cu_y = g >> 16;
+        const int lw = m & 0xFF, lh = (m >> 8) & 0xFF, cbf = (m >> 16) & 0xFF;
+        const int mode_l = ipm & 0xFF, mode_c = (ipm >> 8) & 0xFF;
+        const int cw = 1 << lw, chh = 1 << lh;
+        const int scuw = cw >> 2, nscu = scuw * (chh >> 2);
+        const int cwc = cw >> 1;
+        const uint32_t off_u = coef_off + ((cbf & 1) ? (uint32_t)(cw * chh) : 0u);
+        const uint32_t off_v = off_u + ((cbf & 2) ? (uint32_t)(cwc * (chh >> 1)) : 0u);
 
-    // ---- DC values (ipred_dc_b): (sum of h left + w up samples + w) >> (log2 w + 1) ----
-    int dc[3] = { 0, 0, 0 };
+        // the residual of the lane's first SCU does not depend on any neighbour: fetch it before waiting
+        uint2 rl[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
+        uint32_t rc[2][2] = { { 0, 0 }, { 0, 0 } };
+        auto fetch_resid = [&](int lx, int ly) {
+            if (cbf & 1)
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-        const int w = c ? cw >> 1 : cw, h = c ? chh >> 1 : chh;
-        int acc = 0;
-        for (int e = t; e < w + h; e += 64) acc += e < h ? s_le[c][1 + e] : s_up[c][1 + e - h];
+                for (int r = 0; r < 4; r++) rl[r] = *(const uint2 *)(a.resid + coef_off + (ly + r) * cw + lx);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        dc[c] = (acc + w) >> ((c ? lw - 1 : lw) + 1);
-    }
+            for (int c = 1; c < 3; c++)
+                if ((cbf >> c) & 1)
+#pragma unroll
+                    for (int r = 0; r < 2; r++) rc[c - 1][r] = *(const uint32_t *)(a.resid + (c == 1 ? off_u : off_v) + ((ly >> 1) + r) * cwc + (lx >> 1));
+        };
+        if (t < nscu) fetch_resid((t % scuw) << 2, (t / scuw) << 2);
 
-    // ---- prediction + reconstruction, one 4x4 SCU per lane and step ----
-    const int scuw = cw >> 2, nscu = scuw * (chh >> 2);
-    const int cwc = cw >> 1;
-    const uint32_t off_u = coef_off + ((cbf & 1) ? (uint32_t)(cw * chh) : 0u);
-    const uint32_t off_v = off_u + ((cbf & 2) ? (uint32_t)(cwc * (chh >> 1)) : 0u);
-    for (int sidx = t; sidx < nscu; sidx += 64) {
-        const int lx = (sidx % scuw) << 2, ly = (sidx / scuw) << 2;
-        const int x = cu_x + lx, y = cu_y + ly;
-        int16_t *dy = a.cur_y + y * a.s_l + x;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            int p[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) p[q] = ipred_sample(s_up[0], s_le[0], mode_l, dc[0], ly + r, lx + q);
-            uint32_t v0 = pack2i(p[0], p[1]), v1 = pack2i(p[2], p[3]);
-            if (cbf & 1) {
-                const uint2 rs = *(const uint2 *)(a.resid + coef_off + (ly + r) * cw + lx);
-                v0 = recon2i(v0, rs.x, maxv); v1 = recon2i(v1, rs.y, maxv);
+        if (DEP) {      // wait until the intra CUs this one reads from have published their samples
+            for (uint32_t d = t; d < dep_count; d += 64) {
+                const uint32_t j = a.deps[dep_first + d];
+                while (__hip_atomic_load(&a.done[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != a.epoch) __builtin_amdgcn_s_sleep(1);
             }
-            *(uint2 *)(dy + r * a.s_l) = make_uint2(v0, v1);
+            wave_lds_sync();
+            asm volatile("" ::: "memory");
         }
-        const int coff = (y >> 1) * a.s_c + (x >> 1);
+
+        // ---- neighbour staging (xevd_get_nbr_b): sample e of a side belongs to unit e / unit_size.  All loads of the first round
+        //      (covers CUs up to w + h = 128) are issued before any LDS store so that they overlap ----
+        uint32_t v_up[3], v_le[3][2], v_ul[3];
 #pragma unroll
-        for (int c = 1; c < 3; c++) {
-            int16_t *d = (c == 1 ? a.cur_u : a.cur_v) + coff;
-            const bool coded = (cbf >> c) & 1;
-            const int16_t *rs = a.resid + (c == 1 ? off_u : off_v) + (ly >> 1) * cwc + (lx >> 1);
+        for (int c = 0; c < 3; c++) {
+            const int16_t *plane = c == 0 ? a.cur_y : (c == 1 ? a.cur_u : a.cur_v);
+            const int s = c ? a.s_c : a.s_l, sh = c ? 1 : 0, ush = c ? 1 : 2;
+            const int16_t *org = plane + (cu_y >> sh) * s + (cu_x >> sh);
+            const int n = (cw + chh) >> sh;
+            const int e = 2 * t;
+            v_up[c] = (uint32_t)mid * 0x10001u;
+            if (e < n && ((avail_up >> (e >> ush)) & 1)) v_up[c] = DEP ? ld_coherent(org - s + e) : *(const uint32_t *)(org - s + e);
 #pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const int p0 = ipred_sample(s_up[c], s_le[c], mode_c, dc[c], (ly >> 1) + r, (lx >> 1));
-                const int p1 = ipred_sample(s_up[c], s_le[c], mode_c, dc[c], (ly >> 1) + r, (lx >> 1) + 1);
-                uint32_t v = pack2i(p0, p1);
-                if (coded) v = recon2i(v, *(const uint32_t *)(rs + r * cwc), maxv);      // the luma depth clips chroma too (xevd_recon.c:75-90)
-                *(uint32_t *)(d + r * a.s_c) = v;
+            for (int k = 0; k < 2; k++) {
+                const int el = t + 64 * k;
+                v_le[c][k] = (uint32_t)mid;
+                if (el < n && ((avail_le >> (el >> ush)) & 1)) v_le[c][k] = DEP ? (ld_coherent(org + el * s - 2) >> 16) : (uint32_t)(uint16_t)org[el * s - 1];
+            }
+            v_ul[c] = (uint32_t)mid;
+            if (t == 0 && avail_ul) v_ul[c] = DEP ? (ld_coherent(org - s - 2) >> 16) : (uint32_t)(uint16_t)org[-s - 1];
+        }
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int sh = c ? 1 : 0, n = (cw + chh) >> sh;
+            if (2 * t < n) *(uint32_t *)&nb[c][NB_C0 + 1 + 2 * t] = v_up[c];
+            if (t < n) nb[c][NB_C0 - 1 - t] = (int16_t)v_le[c][0];
+            if (t + 64 < n) nb[c][NB_C0 - 1 - (t + 64)] = (int16_t)v_le[c][1];
+            if (t == 0) nb[c][NB_C0] = (int16_t)v_ul[c];
+        }
+        if (cw + chh > 128) {                                        // the rest of the largest CUs (luma only can exceed one round)
+            const int16_t *org = a.cur_y + cu_y * a.s_l + cu_x;
+            const int n = cw + chh;
+            for (int e = 2 * t + 128; e < n; e += 128)
+                *(uint32_t *)&nb[0][NB_C0 + 1 + e] = ((avail_up >> (e >> 2)) & 1) ? (DEP ? ld_coherent(org - a.s_l + e) : *(const uint32_t *)(org - a.s_l + e))
+                                                                            : ((uint32_t)mid * 0x10001u);
+            for (int e = t + 128; e < n; e += 64)
+                nb[0][NB_C0 - 1 - e] = ((avail_le >> (e >> 2)) & 1) ? (DEP ? (int16_t)(ld_coherent(org + e * a.s_l - 2) >> 16) : org[e * a.s_l - 1]) : (int16_t)mid;
+        }
+        wave_lds_sync();
+
+        // ---- DC values (ipred_dc_b): (sum of h left + w up samples + w) >> (log2 w + 1) ----
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const int mode = c ? mode_c : mode_l;                    // wave-uniform
+            const int w = c ? cw >> 1 : cw, h = c ? chh >> 1 : chh;
+            if (mode == 0) {
+                int acc = 0;
+                for (int e = t; e < w + h; e += 64) acc += e < h ? nb[c][NB_C0 - 1 - e] : nb[c][NB_C0 + 1 + e - h];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+                if (t == 0) nb[c][NB_DC] = (int16_t)((acc + w) >> ((c ? lw - 1 : lw) + 1));
+            } else if (mode == 4) {
+                for (int e = t; e < w + h; e += 64) nb[c][NB_UR + e] = (int16_t)((nb[c][NB_C0 + 1 + e] + nb[c][NB_C0 - 1 - e]) >> 1);
             }
         }
+        wave_lds_sync();
+        // ---- prediction + reconstruction, one 4x4 SCU per lane and step ----
+        for (int sidx = t; sidx < nscu; sidx += 64) {
+            const int lx = (sidx % scuw) << 2, ly = (sidx / scuw) << 2;
+            const int x = cu_x + lx, y = cu_y + ly;
+            if (sidx != t) fetch_resid(lx, ly);                      // later rounds of a CU above 32x32
+            // all LDS reads of the SCU first (one wait), then the arithmetic, then the stores
+            int vl[7], vc[2][3];
+            nb_fetch<7>(nb[0], mode_l, lx, ly, vl);
+            nb_fetch<3>(nb[1], mode_c, lx >> 1, ly >> 1, vc[0]);
+            nb_fetch<3>(nb[2], mode_c, lx >> 1, ly >> 1, vc[1]);
+            int pl[4][4], pc[2][2][2];
+#pragma unroll
+            for (int md = 0; md < 5; md++) {                         // uniform: one of the five register shuffles runs
+                if (md == mode_l)
+#pragma unroll
+                    for (int r = 0; r < 4; r++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) pl[r][q] = vl[nb_sel(md, r, q, 3)];
+                if (md == mode_c)
+#pragma unroll
+                    for (int c = 0; c < 2; c++)
+#pragma unroll
+                        for (int r = 0; r < 2; r++)
+#pragma unroll
+                            for (int q = 0; q < 2; q++) pc[c][r][q] = vc[c][nb_sel(md, r, q, 1)];
+            }
+            int16_t *dy = a.cur_y + y * a.s_l + x;
+            uint32_t ol[4][2], oc[2][2];
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                ol[r][0] = pack2i(pl[r][0], pl[r][1]); ol[r][1] = pack2i(pl[r][2], pl[r][3]);
+                if (cbf & 1) { ol[r][0] = recon2i(ol[r][0], rl[r].x, maxv); ol[r][1] = recon2i(ol[r][1], rl[r].y, maxv); }
+            }
+#pragma unroll
+            for (int c = 1; c < 3; c++)
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    oc[c - 1][r] = pack2i(pc[c - 1][r][0], pc[c - 1][r][1]);
+                    if ((cbf >> c) & 1) oc[c - 1][r] = recon2i(oc[c - 1][r], rc[c - 1][r], maxv);   // the luma depth clips chroma too (xevd_recon.c:75-90)
+                }
+            const int coff = (y >> 1) * a.s_c + (x >> 1);
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                if (DEP) st_coherent2(dy + r * a.s_l, ol[r][0], ol[r][1]); else *(uint2 *)(dy + r * a.s_l) = make_uint2(ol[r][0], ol[r][1]);
+#pragma unroll
+            for (int c = 1; c < 3; c++) {
+                int16_t *d = (c == 1 ? a.cur_u : a.cur_v) + coff;
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+                    if (DEP) st_coherent(d + r * a.s_c, oc[c - 1][r]); else *(uint32_t *)(d + r * a.s_c) = oc[c - 1][r];
+            }
+        }
+        if (DEP) {      // publish: the wave's sc1 stores have reached the coherence point once vmcnt drains; then the done flag
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (t == 0) __hip_atomic_store(&a.done[item], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        wave_lds_sync();                                             // the next CU of this wave reuses the LDS arrays
     }
 }
 
-void launch_intra(xgpu_ctx *c, const IntraArgs &a, int first, int count)
+void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep)
 {
-    hipLaunchKernelGGL(k_intra, dim3(count), dim3(64), 0, c->stream, a, first);
+    const int per = dep ? INTRA_CHUNK : INTRA_WAVES;
+    const int blocks = (a.count + per - 1) / per;
+    if (dep) hipLaunchKernelGGL(k_intra<true>, dim3(blocks), dim3(64 * INTRA_WAVES), 0, c->stream, a);
+    else     hipLaunchKernelGGL(k_intra<false>, dim3(blocks), dim3(64 * INTRA_WAVES), 0, c->stream, a);
 }

@@ -320,10 +320,12 @@ int xgpu_frame_end(xgpu_ctx *c)
     return XGPU_OK;
 }
 
-// Intra CUs: availability masks + dependency levels, sorted by level.  An SCU map of "CU index in decode order" stands in
-// for the reference's COD flags: a neighbouring SCU is reconstructed at CU i's turn iff its CU index is below i
-// (xevd_recon_unit sets COD CU by CU, xevd.c:744-754; xevd_get_avail_intra, xevd_util.c:689-745; single tile/slice).
-static int build_intra_list(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch *db, IntraRec *out)
+// Intra CUs: availability masks, dependency lists and levels.  An SCU map of "CU index in decode order" stands in for the
+// reference's COD flags: a neighbouring SCU is reconstructed at CU i's turn iff its CU index is below i (xevd_recon_unit
+// sets COD CU by CU, xevd.c:744-754; xevd_get_avail_intra, xevd_util.c:689-745; single tile/slice).  The list is sorted by
+// level (1 + the highest level among the intra CUs read), which is a topological order: every dependency sits earlier.
+struct IntraPlan { std::vector<IntraRec> recs; std::vector<uint32_t> deps; int n_levels, n_level1; };
+static void build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &plan)
 {
     const int n = b->n_cu, ws = c->w_scu, hs = c->h_scu;
     const uint32_t NONE = 0xFFFFFFFFu;
@@ -334,40 +336,63 @@ static int build_intra_list(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch *db
         for (int r = 0; r < h; r++) std::fill_n(owner.begin() + (size_t)(ys + r) * ws + xs, w, (uint32_t)i);
     }
     const bool constrained = b->constrained_intra_pred != 0;
-    std::vector<IntraRec> recs;
-    recs.reserve(db->n_intra);
+    std::vector<IntraRec> recs;                 // decode order; dep lists hold CU indices until the sort below
+    std::vector<uint32_t> deps;
     int max_level = 0;
     for (int i = 0; i < n; i++) {
         if (b->pred_mode[i] != XGPU_MODE_INTRA) continue;
         const int xs = b->x[i] >> 2, ys = b->y[i] >> 2, units = ((1 << b->log2w[i]) + (1 << b->log2h[i])) >> 2;
-        IntraRec r = { (uint32_t)i, 0u, 0ull, 0ull };
+        IntraRec r;
+        memset(&r, 0, sizeof(r));
+        r.cu = (uint32_t)i; r.dep_first = (uint32_t)deps.size();
+        r.x = b->x[i]; r.y = b->y[i]; r.log2w = b->log2w[i]; r.log2h = b->log2h[i]; r.cbf = b->cbf[i] & 7;
+        if (b->ipm) { r.ipm[0] = b->ipm[i * 2]; r.ipm[1] = b->ipm[i * 2 + 1]; }
+        r.coef_off = b->coef_off[i];
         int lv = 0;
+        uint32_t last = NONE;
         auto ok = [&](int sx, int sy) -> bool {
             const uint32_t j = owner[(size_t)sy * ws + sx];
             if (j >= (uint32_t)i) return false;                                            // not reconstructed yet (or nothing there)
-            if (constrained && b->pred_mode[j] != XGPU_MODE_INTRA) return false;         // constrained_intra_pred: intra neighbours only
+            const bool j_intra = b->pred_mode[j] == XGPU_MODE_INTRA;
+            if (constrained && !j_intra) return false;                                     // constrained_intra_pred: intra neighbours only
+            if (j_intra && j != last) {                                                    // inter CUs are complete before the intra kernel starts
+                bool seen = false;
+                for (size_t d = r.dep_first; d < deps.size() && !seen; d++) seen = deps[d] == j;
+                if (!seen) deps.push_back(j);
+                last = j;
+            }
             lv = std::max(lv, level[j]);
             return true;
         };
         if (xs > 0 && ys > 0 && ok(xs - 1, ys - 1)) r.flags |= 1u;
-        for (int k = 0; k < units; k++) {
+        for (int k = 0; k < units; k++)
             if (ys > 0 && xs + k < ws && ok(xs + k, ys - 1)) r.up |= 1ull << k;
+        for (int k = 0; k < units; k++)
             if (xs > 0 && ys + k < hs && ok(xs - 1, ys + k)) r.le |= 1ull << k;
-        }
+        r.dep_count = (uint32_t)deps.size() - r.dep_first;
         level[i] = lv + 1;
         max_level = std::max(max_level, lv + 1);
         recs.push_back(r);
     }
-    // counting sort by level
-    db->n_levels = max_level;
-    db->level_first = (int *)calloc((size_t)max_level + 2, sizeof(int));
-    if (!db->level_first) return XGPU_ERR_OUT_OF_MEMORY;
-    for (const IntraRec &r : recs) db->level_first[level[r.cu] + 1]++;       // slot l+1 counts level l (levels start at 1)
-    for (int l = 1; l <= max_level + 1; l++) db->level_first[l] += db->level_first[l - 1];
-    std::vector<int> fill(db->level_first, db->level_first + max_level + 1);
-    for (const IntraRec &r : recs) out[fill[level[r.cu]]++] = r;
-    // level l (1-based) occupies [level_first[l], level_first[l + 1])
-    return XGPU_OK;
+    // counting sort by level (levels are 1-based), then dependency CU indices -> list positions
+    std::vector<int> first((size_t)max_level + 2, 0);
+    for (const IntraRec &r : recs) first[level[r.cu] + 1]++;
+    for (int l = 1; l <= max_level + 1; l++) first[l] += first[l - 1];
+    std::vector<uint32_t> pos((size_t)n, NONE);
+    plan.recs.resize(recs.size());
+    for (const IntraRec &r : recs) { pos[r.cu] = (uint32_t)first[level[r.cu]]; plan.recs[first[level[r.cu]]++] = r; }
+    for (uint32_t &d : deps) d = pos[d];
+    plan.deps.swap(deps);
+    plan.n_levels = max_level;
+    plan.n_level1 = 0;
+    for (const IntraRec &r : plan.recs) plan.n_level1 += level[r.cu] == 1;
+    // level-1 CUs are finished by their own launch before the data-flow launch starts: drop them from the waiting lists
+    for (IntraRec &r : plan.recs) {
+        uint32_t k = r.dep_first;
+        for (uint32_t d = r.dep_first; d < r.dep_first + r.dep_count; d++)
+            if (plan.deps[d] >= (uint32_t)plan.n_level1) plan.deps[k++] = plan.deps[d];
+        r.dep_count = k - r.dep_first;
+    }
 }
 
 // The batch builder: SoA batch of the ABI -> 32-byte CU records, the TB list sorted by size class and the
@@ -444,19 +469,24 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         if (cls_count[k]) { const int per = itdq_group_size((k & 63) >> 3, k & 7); n_waves += (cls_count[k] + per - 1) / per; }
     }
 
-    int n_intra = 0;
-    for (int i = 0; i < n; i++) n_intra += b->pred_mode[i] == XGPU_MODE_INTRA;
+    IntraPlan plan;
+    plan.n_levels = 0; plan.n_level1 = 0;
+    bool any_intra = false;
+    for (int i = 0; i < n && !any_intra; i++) any_intra = b->pred_mode[i] == XGPU_MODE_INTRA;
+    if (any_intra) build_intra_plan(c, b, plan);
+    const int n_intra = (int)plan.recs.size(), n_deps = (int)plan.deps.size();
 
     xgpu_dbatch *db = new xgpu_dbatch();
     memset(db, 0, sizeof(*db));
-    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra;
+    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1;
     const size_t sz_cus = sizeof(CuRec) * (size_t)std::max(n, 1), sz_ctu = sizeof(uint32_t) * (size_t)(b->n_ctu + 1);
     const size_t sz_tbs = sizeof(TbRec) * (size_t)std::max(n_tb, 1), sz_wv = sizeof(TbWave) * (size_t)std::max(n_waves, 1);
     const size_t sz_coef = sizeof(int16_t) * std::max(b->n_coef, (size_t)8);
     const size_t o_cus = 0, o_ctu = o_cus + align_up((int)sz_cus, 256), o_tbs = o_ctu + align_up((int)sz_ctu, 256);
     const size_t sz_intra = sizeof(IntraRec) * (size_t)std::max(n_intra, 1);
     const size_t o_wv = o_tbs + align_up((int)sz_tbs, 256), o_intra = o_wv + align_up((int)sz_wv, 256);
-    const size_t o_coef = o_intra + align_up((int)sz_intra, 256);
+    const size_t sz_deps = sizeof(uint32_t) * (size_t)std::max(n_deps, 1);
+    const size_t o_deps = o_intra + align_up((int)sz_intra, 256), o_coef = o_deps + align_up((int)sz_deps, 256);
     db->stage_bytes = o_coef + sz_coef;
     auto fail = [&](int code) { xgpu_batch_destroy(c, db); return code; };
     if (hipHostMalloc(&db->h_stage, db->stage_bytes, hipHostMallocDefault) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
@@ -513,15 +543,14 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     }
     memcpy(hs + o_ctu, b->ctu_cu_start, sz_ctu);
     if (b->n_coef) memcpy(hs + o_coef, b->coef, sizeof(int16_t) * b->n_coef);
-    if (n_intra) {
-        const int code = build_intra_list(c, b, db, (IntraRec *)(hs + o_intra));
-        if (code != XGPU_OK) return fail(code);
-    }
+    if (n_intra) memcpy(hs + o_intra, plan.recs.data(), sizeof(IntraRec) * (size_t)n_intra);
+    if (n_deps) memcpy(hs + o_deps, plan.deps.data(), sizeof(uint32_t) * (size_t)n_deps);
 
     if (hipMalloc((void **)&db->d_cus, sz_cus) != hipSuccess || hipMalloc((void **)&db->d_ctu_start, sz_ctu) != hipSuccess ||
         hipMalloc((void **)&db->d_tbs, sz_tbs) != hipSuccess || hipMalloc((void **)&db->d_waves, sz_wv) != hipSuccess ||
         hipMalloc((void **)&db->d_coef, sz_coef) != hipSuccess || hipMalloc((void **)&db->d_resid, sz_coef) != hipSuccess ||
-        hipMalloc((void **)&db->d_intra, sz_intra) != hipSuccess)
+        hipMalloc((void **)&db->d_intra, sz_intra) != hipSuccess || hipMalloc((void **)&db->d_intra_deps, sz_deps) != hipSuccess ||
+        hipMalloc((void **)&db->d_intra_done, sizeof(uint32_t) * ((size_t)n_intra + 1)) != hipSuccess)
         return fail(XGPU_ERR_OUT_OF_MEMORY);
     hipError_t e = hipMemcpyAsync(db->d_cus, hs + o_cus, sz_cus, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(db->d_ctu_start, hs + o_ctu, sz_ctu, hipMemcpyHostToDevice, c->stream);
@@ -529,6 +558,8 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     if (e == hipSuccess) e = hipMemcpyAsync(db->d_waves, hs + o_wv, sz_wv, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(db->d_coef, hs + o_coef, sz_coef, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess && n_intra) e = hipMemcpyAsync(db->d_intra, hs + o_intra, sz_intra, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess && n_deps) e = hipMemcpyAsync(db->d_intra_deps, hs + o_deps, sz_deps, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(db->d_intra_done, 0, sizeof(uint32_t) * ((size_t)n_intra + 1), c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(db->d_resid, 0, sz_coef, c->stream);
     if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "batch upload: %s", hipGetErrorString(e)); return fail(XGPU_ERR_UNEXPECTED); }
     *out = db;
@@ -546,7 +577,8 @@ void xgpu_batch_destroy(xgpu_ctx *c, xgpu_dbatch *db)
     if (db->d_coef) (void)hipFree(db->d_coef);
     if (db->d_resid) (void)hipFree(db->d_resid);
     if (db->d_intra) (void)hipFree(db->d_intra);
-    free(db->level_first);
+    if (db->d_intra_deps) (void)hipFree(db->d_intra_deps);
+    if (db->d_intra_done) (void)hipFree(db->d_intra_done);
     if (db->h_stage) (void)hipHostFree(db->h_stage);
     delete db;
 }
@@ -583,13 +615,19 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
         }
     TIMED(c, XGPU_K_INTER, launch_inter(c, a));
     if (db->n_intra) {
-        // intra CUs, one launch per dependency level (kernel boundaries order the levels and publish their samples)
+        // intra CUs: level 1 as a plain launch, all deeper levels as one data-flow launch (k_intra.hip)
         IntraArgs ta;
         ta.cur_y = cur.y; ta.cur_u = cur.u; ta.cur_v = cur.v; ta.s_l = c->s_l; ta.s_c = c->s_c; ta.bd_l = c->sp.bit_depth_luma;
-        ta.cus = db->d_cus; ta.list = db->d_intra; ta.resid = db->d_resid;
+        ta.cus = db->d_cus; ta.list = db->d_intra; ta.deps = db->d_intra_deps; ta.resid = db->d_resid;
+        ta.done = db->d_intra_done; ta.n_intra = db->n_intra;
+        ta.epoch = ++db->intra_epoch;                      // flags are compared against the epoch: no reset between pictures
+        ta.ticket_base = db->intra_tickets;                // the counter keeps running: a launch draws one ticket per workgroup
+        const int n_dep = db->n_intra - db->n_intra_l1;
         TIMED(c, XGPU_K_INTRA, {
-            for (int l = 1; l <= db->n_levels; l++)
-                launch_intra(c, ta, db->level_first[l], db->level_first[l + 1] - db->level_first[l]);
+            ta.first = 0; ta.count = db->n_intra_l1;
+            if (ta.count) launch_intra(c, ta, false);
+            ta.first = db->n_intra_l1; ta.count = n_dep;
+            if (ta.count) { launch_intra(c, ta, true); db->intra_tickets += (uint32_t)((n_dep + INTRA_CHUNK - 1) / INTRA_CHUNK); }
         });
     }
     HIPCHK(c, hipGetLastError());

@@ -96,18 +96,30 @@ struct InterArgs {
 // One intra CU of a picture, in dependency-level order.  Availability = the reference's COD flags at the CU's turn
 // (xevd_get_nbr_b, src_base/xevd_ipred.c:47-92): bit k of `up` / `le` = the k-th 4-luma-sample unit of the row above /
 // the column to the left (cw/4 + ch/4 units each) comes from the picture, else it is mid grey.
-struct IntraRec {
+struct __attribute__((aligned(16))) IntraRec {
     uint32_t cu;              // index into the CU records
     uint32_t flags;           // bit 0: the up-left sample is available
     uint64_t up, le;
+    uint32_t dep_first, dep_count;   // range of the dependency list: positions (in this list) of the intra CUs it reads from
+    uint16_t x, y;            // the CU fields the kernel needs, copied here so that one record fetch starts the work
+    uint8_t  log2w, log2h, cbf, pad0;
+    uint8_t  ipm[2], pad1[2];
+    uint32_t coef_off;
 };
+static_assert(sizeof(IntraRec) == 48, "IntraRec must be 48 bytes");
+#define INTRA_CHUNK 8         // list positions one workgroup of the data-flow intra kernel handles (4 waves x 2)
 struct IntraArgs {
     int16_t *cur_y, *cur_u, *cur_v;
     int      s_l, s_c;
     int      bd_l;
     const CuRec    *cus;
     const IntraRec *list;
+    const uint32_t *deps;
     const int16_t  *resid;
+    uint32_t *done;           // [n_intra] = epoch once the CU's samples are published; [n_intra] (one past) = the ticket counter
+    uint32_t  epoch, ticket_base;
+    int       n_intra;        // list length (the ticket counter sits at done[n_intra])
+    int       first, count;   // the list range this launch covers
 };
 
 struct ItdqArgs {
@@ -154,8 +166,10 @@ struct xgpu_dbatch {
     TbRec     *d_tbs;
     TbWave    *d_waves;
     IntraRec  *d_intra;               // intra CUs sorted by dependency level
-    int        n_intra, n_levels;
-    int       *level_first;           // host: [n_levels + 1] ranges of d_intra
+    uint32_t  *d_intra_deps;          // dependency lists (positions in d_intra)
+    uint32_t  *d_intra_done;          // [n_intra] done epochs + [1] ticket counter
+    int        n_intra, n_levels, n_intra_deps, n_intra_l1;      // n_intra_l1: CUs of level 1 (head of the list)
+    uint32_t   intra_epoch, intra_tickets;
     void      *h_stage;               // pinned staging block
     size_t     stage_bytes;
 };
@@ -186,7 +200,7 @@ struct xgpu_ctx {
 // kernel launchers (one per .hip file)
 void launch_itdq(xgpu_ctx *c, const ItdqArgs &a);
 void launch_inter(xgpu_ctx *c, const InterArgs &a);
-void launch_intra(xgpu_ctx *c, const IntraArgs &a, int first, int count);
+void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep);
 void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst);
 void upload_transform_tables(const int *tm, const int16_t *ats, hipStream_t s);
 int  itdq_group_size(int log2w, int log2h);     // TBs of one size class per 256-thread work item
