@@ -225,17 +225,10 @@ __device__ __forceinline__ uint32_t recon2(uint32_t pred, uint32_t res, int maxv
 
 #define MAX_CU_PER_CTU 1024
 #define INTER_STRIP 16
-#define LDS_CU 256
 
 __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
 {
-    // Everything a lane looks up by a data-dependent index lives in LDS: the per-wave critical path is then LDS -> LDS -> LDS
-    // -> reference samples, instead of a chain of dependent global loads (the kernel is latency-bound, not bandwidth-bound).
     __shared__ uint32_t s_geo[MAX_CU_PER_CTU];
-    __shared__ uint4    s_cu[LDS_CU][2];                    // CU records of the CTU (the first LDS_CU of them)
-    __shared__ uint4    s_ref[XGPU_MAX_REFS * 2][2];        // RefEntry [idx][list]
-    __shared__ uint4    s_ltap[17];                         // luma taps of this sequence's table, [16] = identity
-    __shared__ uint2    s_ctap[33];
 
     // XCD-aware mapping: workgroup b runs on XCD b % 8; give every XCD a contiguous band of regions so that
     // vertically adjacent regions (which share reference halos) hit the same L2.
@@ -254,18 +247,8 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     const int n = min((int)a.ctu_cu_start[ctu + 1] - first, MAX_CU_PER_CTU);
     const int t = threadIdx.x;
 
-    if (t < XGPU_MAX_REFS * 2) {
-        const uint4 *re = (const uint4 *)&a.refp[t >> 1][t & 1];
-        s_ref[t][0] = re[0]; s_ref[t][1] = re[1];
-    } else if (t >= 64 && t < 64 + 17) {
-        s_ltap[t - 64] = *(const uint4 *)k_luma_taps[a.admvp][t - 64];
-    } else if (t >= 128 && t < 128 + 33) {
-        s_ctap[t - 128] = *(const uint2 *)k_chroma_taps[a.admvp][t - 128];
-    }
     for (int i = t; i < n; i += 256) {
-        const uint4 c0 = ((const uint4 *)&a.cus[first + i])[0];       // x, y, log2w, log2h, ...
-        if (i < LDS_CU) { s_cu[i][0] = c0; s_cu[i][1] = ((const uint4 *)&a.cus[first + i])[1]; }
-        const uint2 g = make_uint2(c0.x, c0.y);
+        const uint2 g = *(const uint2 *)&a.cus[first + i];        // x, y, log2w, log2h, ...
         const int x = g.x & 0xFFFF, y = g.x >> 16, lw = g.y & 0xFF, lh = (g.y >> 8) & 0xFF;
         s_geo[i] = (uint32_t)((x & (ctu_sz - 1)) >> 2) | ((uint32_t)((y & (ctu_sz - 1)) >> 2) << 5) |
                    ((uint32_t)(((1 << lw) >> 2) - 1) << 10) | ((uint32_t)(((1 << lh) >> 2) - 1) << 15);
@@ -286,9 +269,8 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     }
     if (!active || found < 0) return;
 
-    uint4 r0, r1;
-    if (found < LDS_CU) { r0 = s_cu[found][0]; r1 = s_cu[found][1]; }
-    else { r0 = ((const uint4 *)&a.cus[first + found])[0]; r1 = ((const uint4 *)&a.cus[first + found])[1]; }
+    const uint4 r0 = ((const uint4 *)&a.cus[first + found])[0];
+    const uint4 r1 = ((const uint4 *)&a.cus[first + found])[1];
     const int cu_x = r0.x & 0xFFFF, cu_y = r0.x >> 16;
     const int lw = r0.y & 0xFF, lh = (r0.y >> 8) & 0xFF, pred_mode = (r0.y >> 16) & 0xFF, cbf = r0.y >> 24;
     const int refi0 = (int)(int8_t)(r0.z & 0xFF), refi1 = (int)(int8_t)((r0.z >> 8) & 0xFF), qp_map = (r0.z >> 16) & 0xFF;
@@ -345,18 +327,13 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
         mvt[l][0] = (int16_t)mx; mvt[l][1] = (int16_t)my;
     }
     bool use[2] = { refi0 >= 0, refi1 >= 0 };
-    if (use[0] && use[1] && s_ref[refi0 * 2][1].z == s_ref[refi1 * 2 + 1][1].z && mvt[0][0] == mvt[1][0] && mvt[0][1] == mvt[1][1])
+    if (use[0] && use[1] && a.refp[refi0][0].poc == a.refp[refi1][1].poc && mvt[0][0] == mvt[1][0] && mvt[0][1] == mvt[1][1])
         use[1] = false;                                               // identical motion, xevd_mc.c:512-519
 
 #pragma unroll
     for (int l = 0; l < 2; l++) {
         if (!use[l]) continue;
-        RefEntry re;
-        {
-            const uint4 e0 = s_ref[refis[l] * 2 + l][0], e1 = s_ref[refis[l] * 2 + l][1];
-            re.y = (const int16_t *)(((uint64_t)e0.y << 32) | e0.x); re.u = (const int16_t *)(((uint64_t)e0.w << 32) | e0.z);
-            re.v = (const int16_t *)(((uint64_t)e1.y << 32) | e1.x); re.poc = (int)e1.z;
-        }
+        const RefEntry re = a.refp[refis[l]][l];
         const int mvx = mvs[l][0], mvy = mvs[l][1];
         // luma: quarter-pel position of this SCU = (x<<2) + clipped mv; phase in 1/16 = (pos&3)<<2
         const int px = (x << 2) + mvt[l][0], py = (y << 2) + mvt[l][1];
@@ -364,21 +341,24 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
         const int cdx = (mvx & 7) != 0, cdy = (mvy & 7) != 0;
         uint32_t ch[4], cv[4], o[8], ou[2], ov[2];
         {
-            const uint4 th = s_ltap[ldx ? ((px & 3) << 2) : 16], tv = s_ltap[ldy ? ((py & 3) << 2) : 16];
-            ch[0] = th.x; ch[1] = th.y; ch[2] = th.z; ch[3] = th.w; cv[0] = tv.x; cv[1] = tv.y; cv[2] = tv.z; cv[3] = tv.w;
+            const uint32_t *th = k_luma_taps[a.admvp][ldx ? ((px & 3) << 2) : 16];
+            const uint32_t *tv = k_luma_taps[a.admvp][ldy ? ((py & 3) << 2) : 16];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { ch[k] = th[k]; cv[k] = tv[k]; }
             const int16_t *p = re.y + ((py >> 2) - 3) * a.s_l + (px >> 2) - 3;
             const Regime rg = regime(ldx, ldy, a.bd_l);
-            const bool wh = __ballot(ldx) != 0, wvv = __ballot(ldy) != 0;      // over the lanes that run this list
+            const bool wh = __ballot(ldx) != 0, wvv = false;      // EXPERIMENT
             if (wh) { if (wvv) mc_luma_4x4<true, true>(p, a.s_l, ch, cv, rg, maxl, o); else mc_luma_4x4<true, false>(p, a.s_l, ch, cv, rg, maxl, o); }
             else    { if (wvv) mc_luma_4x4<false, true>(p, a.s_l, ch, cv, rg, maxl, o); else mc_luma_4x4<false, false>(p, a.s_l, ch, cv, rg, maxl, o); }
         }
         {
             // chroma: 1/8-pel position (x<<2)+mv in luma quarter-pel == chroma eighth-pel; phase in 1/32 = (pos&7)<<2
-            const uint2 th = s_ctap[cdx ? ((px & 7) << 2) : 32], tv = s_ctap[cdy ? ((py & 7) << 2) : 32];
-            uint32_t c2h[2] = { th.x, th.y }, c2v[2] = { tv.x, tv.y };
+            const uint32_t *th = k_chroma_taps[a.admvp][cdx ? ((px & 7) << 2) : 32];
+            const uint32_t *tv = k_chroma_taps[a.admvp][cdy ? ((py & 7) << 2) : 32];
+            uint32_t c2h[2] = { th[0], th[1] }, c2v[2] = { tv[0], tv[1] };
             const int off = ((py >> 3) - 1) * a.s_c + (px >> 3) - 1;
             const Regime rg = regime(cdx, cdy, a.bd_c);
-            const bool wh = __ballot(cdx) != 0, wvv = __ballot(cdy) != 0;
+            const bool wh = __ballot(cdx) != 0, wvv = false;
 #define MC_C(H, V) do { mc_chroma_2x2<H, V>(re.u + off, a.s_c, c2h, c2v, rg, maxc, ou); mc_chroma_2x2<H, V>(re.v + off, a.s_c, c2h, c2v, rg, maxc, ov); } while (0)
             if (wh) { if (wvv) MC_C(true, true); else MC_C(true, false); }
             else    { if (wvv) MC_C(false, true); else MC_C(false, false); }
