@@ -205,6 +205,8 @@ def main():
             ms, n = tim[name]
             if n:
                 kernels[name] = {"avg_us": round(1e3 * ms / n, 2), "launches": int(n)}
+        # the dominant kernel by time; k_intra is a dependency-chain (latency) kernel in two launches and is reported in
+        # `kernels` but not priced against the HBM roofline
         dom = max(("itdq", "inter", "dbk_v", "dbk_h", "alf"), key=lambda k: tim[k][0])
         bytes_per_launch = float(np.mean([a[dom] for a in ab]))
         avg_s = tim[dom][0] / max(tim[dom][1], 1) * 1e-3
