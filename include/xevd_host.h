@@ -1,0 +1,78 @@
+/*
+ * xevd_host.h - C ABI of the host front end that sits before the GPU path: an MPEG-5 EVC (Baseline profile) bitstream
+ * parser that turns `.evc` NAL units into the CU batches of include/xevd_hip.h, and a bitstream writer for synthetic
+ * CU batches (test/bench streams the reference decoder can decode too).
+ *
+ * What it mirrors in the reference (mpeg5/xevd v0.7.0), re-designed around the batch hand-over:
+ *   parser : xevd_dec_nalu (src_base/xevd.c:1786-2024): xevd_eco_nalu/sps/pps/sh (xevd_eco.c:1178-1581), POC derivation
+ *            (xevd_util.c:429-467), reference list set-up without RPL (xevd_picman.c:68-110,291-437), tile entropy decoding
+ *            (xevd_tile_eco xevd.c:1408-1468, xevd_eco_cu xevd_eco.c:1048-1176, coefficients :343-395, SBAC :35-165),
+ *            motion derivation (xevd.c:476-566, xevd_util.c:469-566,632-687), QP derivation (xevd_eco.c:640-668).
+ *   writer : the inverse syntax (this tree has no encoder; the arithmetic encoder is the mirror of xevd_sbac_decode_bin).
+ * Wire format: 4-byte big-endian NAL length prefix (XEVD_NAL_UNIT_LENGTH_BYTE, inc/xevd.h:133; app/xevd_app.c:52-107),
+ * 2-byte NAL header (xevd_eco.c:1178-1209).
+ *
+ * Scope: Baseline profile, 4:2:0, one tile and one slice per picture, I and P slices (sps->tool_* all 0).
+ * Conventions as xevd_hip.h: 0 / negative XEVD_ERR_* codes, nothing throws, one object per stream.
+ */
+#ifndef XEVD_HOST_H
+#define XEVD_HOST_H
+
+#include "xevd_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XHOST_ERR_MALFORMED (-202)      /* XEVD_ERR_MALFORMED_BITSTREAM */
+
+#define XHOST_SLICE_B 0                 /* XEVD_ST_B / _P / _I, inc/xevd.h:181-183 */
+#define XHOST_SLICE_P 1
+#define XHOST_SLICE_I 2
+
+typedef struct xhost_parser xhost_parser;
+typedef struct xhost_writer xhost_writer;
+
+/* One decoded-syntax picture: everything xgpu_frame_begin + xgpu_batch_create need, plus DPB bookkeeping by POC.
+   The arrays behind `batch` belong to the parser and stay valid until the next xhost_parser_next / close. */
+typedef struct xhost_picture {
+    int width, height, bit_depth_luma, bit_depth_chroma;
+    int poc, temporal_id, slice_type, is_idr;
+    int is_ref;                            /* the picture stays in the DPB as a reference (ctx->slice_ref_flag)         */
+    int num_refp[2];
+    int refp_poc[XGPU_MAX_REFS][2];        /* POC of ctx->refp[idx][list]: the caller maps POC -> picture slot           */
+    int slice_qp, qp_u_offset, qp_v_offset;
+    int deblock_on;
+    int n_release;                         /* reference pictures unmarked before this one was stored (pic_marking_no_rpl) */
+    int release_poc[32];
+    xgpu_cu_batch batch;
+} xhost_picture;
+
+xhost_parser *xhost_parser_open(const uint8_t *bytes, size_t size);
+/* 1: `out` holds the next picture in decoding order; 0: end of stream; < 0: error */
+int  xhost_parser_next(xhost_parser *p, xhost_picture *out);
+const char *xhost_parser_error(const xhost_parser *p);
+void xhost_parser_close(xhost_parser *p);
+
+typedef struct xhost_stream_params {
+    int width, height;                     /* multiples of 8                                                        */
+    int bit_depth;                         /* luma = chroma                                                         */
+    int max_num_ref_pics;                  /* sps->max_num_ref_pics                                                 */
+    int qp_u_offset, qp_v_offset;          /* sh.qp_u_offset / qp_v_offset                                          */
+    int deblock_on;                        /* sh.deblocking_filter_on                                               */
+    int cu_qp_delta;                       /* pps.cu_qp_delta_enabled_flag: per-CU QPs of coded CUs are transmitted  */
+} xhost_stream_params;
+
+xhost_writer *xhost_writer_open(const xhost_stream_params *sp);
+/* Appends one picture (SPS + PPS first when it is the first).  `b`: leaf CUs of a quad tree (64..4) in decode order with the
+   fields of xgpu_cu_batch; per CU the writer keeps pred_mode (INTRA / INTER / SKIP), refi[0], mv[0] (INTER; a SKIP CU takes
+   the motion of a predictor), qp[0] (luma dequant QP incl. 6*(bd-8), used when the CU has coefficients and cu_qp_delta is on),
+   cbf, ipm[0], coefficients.  idr != 0 forces an IDR picture with an I slice. */
+int  xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type, int slice_qp, const xgpu_cu_batch *b);
+int  xhost_writer_bytes(xhost_writer *w, const uint8_t **bytes, size_t *size);
+void xhost_writer_close(xhost_writer *w);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -141,13 +141,31 @@ def golden_pictures(only=None):
         print(f"pic_{case[0]}.npz")
 
 
+def golden_streams():
+    import stream_util as su
+    for name, (w, h, n, kw) in {"ippp_8b": (208, 120, 5, dict(max_refs=2)), "ippp_10b_offsets": (144, 88, 4, dict(bit_depth=10, qp_offsets=(1, -2))),
+                                "idr_period_skip": (72, 136, 6, dict(max_refs=4, skip_frac=0.4, idr_period=4))}.items():
+        data = su.make_stream(w, h, n, seed=len(name) * 13 + n, **kw)
+        ref = su.decode_reference(data, w, h)
+        assert len(ref) == n
+        d = {"bytes": np.frombuffer(data, np.uint8), "n": np.array(n), "size": np.array([w, h])}
+        for k in range(n):
+            for c in range(3):
+                d[f"p{k}_{c}"] = ref[k][c]
+        np.savez_compressed(os.path.join(HERE, f"stream_{name}.npz"), **d)
+        print(f"stream_{name}.npz", len(data), "bytes,", n, "pictures")
+
+
 if __name__ == "__main__":
     assert ol.have_ref(), "oracle/_ref is not built: run `make -C oracle -f Makefile.ref` in the development container"
     lib = ol.ref()
     import sys
-    if len(sys.argv) > 1:                 # python make_golden.py <picture case> ... : only (re)generate those
+    if len(sys.argv) > 1 and sys.argv[1] == "streams":
+        golden_streams()
+    elif len(sys.argv) > 1:               # python make_golden.py <picture case> ... : only (re)generate those
         golden_pictures(set(sys.argv[1:]))
     else:
         golden_mc(lib)
         golden_itdq(lib)
         golden_pictures()
+        golden_streams()

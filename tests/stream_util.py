@@ -1,0 +1,113 @@
+"""Frame-level test helpers: synthetic EVC Baseline streams, decoded (a) by the REAL reference decoder through its public API
+(oracle/_ref/libref_decode.so), (b) by our parser + the CPU oracle, (c) by our parser + the HIP backend."""
+import ctypes as C
+import os
+
+import numpy as np
+
+import oracle_lib as ol
+from xevd_amd import abi, stream, synth
+
+REF_DECODE = os.path.join(ol.ORACLE_DIR, "_ref", "ref_decode")
+
+
+def have_ref_decoder():
+    return os.path.exists(REF_DECODE)
+
+
+def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_frac=0.15, inter_frac=0.85, deblock=True, qp_offsets=(0, 0),
+                cu_qp_delta=True, split_prob=0.5, idr_period=0):
+    """-> bytes.  Picture 0 is an IDR; the others are P pictures over synthetic CU batches (quad tree 64..4)."""
+    rng = np.random.default_rng(seed)
+    w = stream.StreamWriter(width, height, bit_depth, max_refs, qp_offsets[0], qp_offsets[1], deblock, cu_qp_delta)
+    try:
+        for k in range(n_pics):
+            idr = k == 0 or (idr_period and k % idr_period == 0)
+            n_refs_now = 1 if idr else min(max_refs, (k % idr_period) if idr_period else k, 4)
+            b = synth.gen_frame(rng, width, height, bit_depth, inter_frac=0.0 if idr else inter_frac, n_refs=(max(n_refs_now, 1), 0),
+                                split_prob=split_prob, coded_frac=0.6, max_level=6, amp=1.0)
+            if not idr:
+                inter = b["pred_mode"] == 1
+                b["pred_mode"] = np.where(inter & (rng.random(len(inter)) < skip_frac), 2, b["pred_mode"]).astype(np.uint8)
+            w.add_picture(b, stream.SLICE_I if idr else stream.SLICE_P, slice_qp=int(rng.integers(24, 40)), idr=idr)
+        return w.bytes()
+    finally:
+        w.close()
+
+
+def decode_reference(data, width, height, max_pics=64, threads=1):
+    """The reference decoder's output pictures (output order) as lists of [Y, U, V] int16 arrays; one process per decode."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "s.evc"), os.path.join(td, "s.raw")
+        with open(fin, "wb") as f:
+            f.write(data)
+        r = subprocess.run([REF_DECODE, fin, fout, str(width), str(height), str(threads)], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        if r.returncode != 0:
+            raise RuntimeError(f"reference decoder failed ({r.returncode}): {r.stderr.decode()[-300:]}")
+        n = int(r.stderr.decode().split()[-2])
+        out = np.fromfile(fout, np.int16)
+    elems = width * height * 3 // 2
+    pics = []
+    for k in range(min(n, max_pics, len(out) // elems)):
+        p = out[k * elems:(k + 1) * elems]
+        pics.append([p[:width * height].reshape(height, width).copy(),
+                     p[width * height:width * height * 5 // 4].reshape(height // 2, width // 2).copy(),
+                     p[width * height * 5 // 4:].reshape(height // 2, width // 2).copy()])
+    return pics
+
+
+def decode_oracle(data):
+    """Our parser + the CPU oracle (oracle/liboracle.so). -> pictures in POC order."""
+    o = ol.oracle()
+    dpb, out = {}, {}
+    for p in stream.parse_stream(data):
+        w, h, bd = p["width"], p["height"], p["bit_depth"]
+        sp = abi.make_seq_params(w, h, bd)
+        cb, keep = abi.make_cu_batch(p["batch"])
+        cur = ol.Picture(w, h, p["poc"])
+        refs = {(i, 0): dpb[poc] for i, poc in enumerate(p["refs"][0])}
+        fr = ol.make_frame(cur, refs, p["qp_u_offset"], p["qp_v_offset"])
+        maps = ol.Maps(w, h)
+        m = maps.orc()
+        o.orc_recon_batch(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), None)
+        if p["deblock_on"]:
+            o.orc_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m))
+        o.orc_pad(C.byref(sp), C.byref(fr.cur))
+        if p["is_idr"]:
+            dpb.clear()
+        for poc in p["release"]:
+            dpb.pop(poc, None)
+        dpb[p["poc"]] = cur
+        out[(len([k for k in out if k[1] >= 0]), p["poc"])] = [cur.active(c).copy() for c in range(3)]
+    return [v for _, v in sorted(out.items(), key=lambda kv: kv[0][0])]
+
+
+def decode_gpu(data):
+    """Our parser + the HIP backend through the C ABI. -> pictures in decoding order (= output order for IPPP)."""
+    from xevd_amd.decoder import XgpuDecoder
+    pics = stream.parse_stream(data)
+    if not pics:
+        return []
+    w, h, bd = pics[0]["width"], pics[0]["height"], pics[0]["bit_depth"]
+    out = []
+    with XgpuDecoder(w, h, bd, max_pics=8) as dec:
+        slots, free = {}, [dec.pic_alloc() for _ in range(7)]
+        for p in pics:
+            if p["is_idr"]:
+                free.extend(slots.values()); slots.clear()
+            for poc in p["release"]:
+                if poc in slots:
+                    free.append(slots.pop(poc))
+            cur = free.pop()
+            refs = {(i, 0): (slots[poc], poc) for i, poc in enumerate(p["refs"][0])}
+            hb = dec.batch_create(p["batch"])
+            dec.decode_picture(cur, p["poc"], refs, hb, deblock=p["deblock_on"], pad=True, qp_u_offset=p["qp_u_offset"], qp_v_offset=p["qp_v_offset"])
+            dec.sync()
+            planes = dec.pic_download_padded(cur)
+            out.append([planes[c][(abi.PAD_L if c == 0 else abi.PAD_C):-(abi.PAD_L if c == 0 else abi.PAD_C),
+                                  (abi.PAD_L if c == 0 else abi.PAD_C):-(abi.PAD_L if c == 0 else abi.PAD_C)].copy() for c in range(3)])
+            dec.batch_destroy(hb)
+            slots[p["poc"]] = cur
+    return out

@@ -1,0 +1,84 @@
+"""Frame-level parity on real bitstreams: synthetic EVC Baseline streams written by our writer are decoded by
+the REAL reference decoder through its public API (xevd_create / xevd_decode / xevd_pull, oracle/_ref) and by our parser + the
+CPU oracle; every output picture must be identical.  Also pins the committed golden streams (tests/golden/stream_*.npz)."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import golden_io
+import stream_util as su
+from xevd_amd import stream
+
+CONFIGS = [
+    # w, h, pictures, kwargs
+    (64, 64, 2, dict(split_prob=0.9)),
+    (136, 72, 4, dict()),
+    (208, 120, 6, dict(max_refs=2)),
+    (144, 88, 5, dict(bit_depth=10, qp_offsets=(1, -2))),
+    (72, 136, 7, dict(max_refs=4, skip_frac=0.4, idr_period=4)),
+    (136, 136, 3, dict(deblock=False, cu_qp_delta=False)),
+    (200, 72, 4, dict(inter_frac=0.5, split_prob=0.7)),
+]
+
+
+@pytest.mark.ref
+@pytest.mark.parametrize("cfg", CONFIGS, ids=[f"{c[0]}x{c[1]}x{c[2]}" for c in CONFIGS])
+def test_stream_reference_decoder_equals_parser_plus_oracle(cfg):
+    if not su.have_ref_decoder():
+        pytest.skip("oracle/_ref is not built")
+    w, h, n, kw = cfg
+    data = su.make_stream(w, h, n, seed=w * 7 + n, **kw)
+    ref = su.decode_reference(data, w, h)
+    ours = su.decode_oracle(data)
+    assert len(ref) == n and len(ours) == n
+    for k in range(n):
+        for c in range(3):
+            assert np.array_equal(ref[k][c], ours[k][c]), f"picture {k} plane {c}: {np.argwhere(ref[k][c] != ours[k][c])[:4]}"
+
+
+@pytest.mark.ref
+def test_stream_reference_decoder_threads_agree():
+    if not su.have_ref_decoder():
+        pytest.skip("oracle/_ref is not built")
+    # (the reference's row threading needs at least as many CTU rows as threads: with more threads than rows it leaves CTU rows
+    #  unreconstructed - a finding, not a requirement - so the multi-threaded CPU baseline is only used on tall enough pictures)
+    data = su.make_stream(136, 328, 4, seed=5)
+    a = su.decode_reference(data, 136, 328, threads=1)
+    b = su.decode_reference(data, 136, 328, threads=4)
+    assert all(np.array_equal(a[k][c], b[k][c]) for k in range(4) for c in range(3))
+
+
+def test_writer_is_deterministic_and_parser_round_trips():
+    data = su.make_stream(136, 72, 3, seed=11)
+    assert data == su.make_stream(136, 72, 3, seed=11)
+    pics = stream.parse_stream(data)
+    assert [p["poc"] for p in pics] == [0, 1, 2] and pics[0]["is_idr"] and pics[1]["refs"][0] == [0]
+    # every CU of every picture lies inside the picture and the CTU index is consistent
+    for p in pics:
+        b = p["batch"]
+        assert (b["x"].astype(int) + (1 << b["log2w"].astype(int)) <= 136).all() and (b["y"].astype(int) + (1 << b["log2h"].astype(int)) <= 72).all()
+        assert b["ctu_cu_start"][-1] == len(b["x"])
+        area = ((1 << b["log2w"].astype(np.int64)) * (1 << b["log2h"].astype(np.int64))).sum()
+        assert area == 136 * 72
+
+
+def test_parser_rejects_garbage():
+    data = bytearray(su.make_stream(64, 64, 2, seed=3))
+    with pytest.raises(RuntimeError):
+        stream.parse_stream(bytes(data[:-3]))             # truncated last NAL
+    data[4] ^= 0x80                                        # forbidden_zero_bit of the first NAL header
+    with pytest.raises(RuntimeError):
+        stream.parse_stream(bytes(data))
+
+
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(golden_io.GOLDEN, "stream_*.npz"))), ids=os.path.basename)
+def test_golden_streams_parser_plus_oracle(path):
+    """committed streams + the reference decoder's pictures (made by tests/golden/make_golden.py with oracle/_ref)"""
+    d = np.load(path)
+    ours = su.decode_oracle(d["bytes"].tobytes())
+    assert len(ours) == int(d["n"])
+    for k in range(len(ours)):
+        for c in range(3):
+            assert np.array_equal(ours[k][c], d[f"p{k}_{c}"]), f"picture {k} plane {c}"

@@ -1,0 +1,816 @@
+// evc_host.cc - MPEG-5 EVC Baseline-profile bitstream parser (-> CU batches for the GPU path) and writer (<- synthetic CU
+// batches), see include/xevd_host.h.  Plain C++ (no HIP): it is the serial, bit-level host half of the decoder.
+//
+// Design (not the reference's): the CU-level syntax is written ONCE as a template over a "coder" that is either the
+// arithmetic decoder or the arithmetic encoder - every syntax element is `v = c.bin(v, model)` - so the writer and the parser
+// cannot drift apart; the reference decoder itself (oracle/_ref) is what pins them to the standard in tests.  A picture is
+// parsed CU by CU in ONE pass (entropy decoding + motion/QP derivation + map update), straight into the structure-of-arrays
+// batch that xgpu_batch_create takes; the reference's two passes over XEVD_CU_DATA (xevd_tile_eco, then xevd_ctu_row_rec_mt)
+// see the same neighbour state because both walk the CUs in the same order and "reconstructed" (COD) == "already parsed".
+#include "../../include/xevd_host.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ bit I/O
+struct BitWriter {
+    std::vector<uint8_t> buf;
+    uint32_t acc = 0;
+    int n = 0;
+    void put1(int b) { acc = (acc << 1) | (uint32_t)(b & 1); if (++n == 8) { buf.push_back((uint8_t)acc); acc = 0; n = 0; } }
+    void put(uint32_t v, int len) { for (int i = len - 1; i >= 0; i--) put1((int)((v >> i) & 1)); }
+    void ue(uint32_t v) { const uint64_t x = (uint64_t)v + 1; int len = 0; while ((x >> len) > 1) len++; for (int i = 0; i < len; i++) put1(0); for (int i = len; i >= 0; i--) put1((int)((x >> i) & 1)); }
+    void se(int v) { ue(v > 0 ? (uint32_t)(2 * v - 1) : (uint32_t)(-2 * v)); }      // xevd_bsr_read_se, xevd_bsr.c:322-328
+    void align_zero() { while (n) put1(0); }
+};
+struct BitReader {
+    const uint8_t *p = nullptr;
+    size_t size = 0, pos = 0;       // pos in bits
+    bool overrun = false;
+    int get1() { if (pos >= size * 8) { overrun = true; return 0; } const int b = (p[pos >> 3] >> (7 - (pos & 7))) & 1; pos++; return b; }
+    uint32_t get(int len) { uint32_t v = 0; for (int i = 0; i < len; i++) v = (v << 1) | (uint32_t)get1(); return v; }
+    uint32_t ue() { int z = 0; while (!get1()) { if (++z > 32 || overrun) { overrun = true; return 0; } } uint64_t v = 1; for (int i = 0; i < z; i++) v = (v << 1) | (uint64_t)get1(); return (uint32_t)(v - 1); }
+    int se() { const uint32_t k = ue(); return (k & 1) ? (int)((k + 1) >> 1) : -(int)(k >> 1); }
+    bool aligned() const { return (pos & 7) == 0; }
+};
+
+// ------------------------------------------------------------------------------------------------ arithmetic coder
+// Context model = (state << 1) | mps, state 9 bits, initial 512 = state 256 (p = 1/2) - xevd_eco.c:35-87, xevd_def.h:76
+typedef uint16_t Model;
+static inline void model_update(Model &m, bool lps)
+{
+    int state = m >> 1, mps = m & 1;
+    if (lps) { state = state + ((512 - state + 16) >> 5); if (state > 256) { mps = 1 - mps; state = 512 - state; } }
+    else state = state - ((state + 16) >> 5);
+    m = (Model)((state << 1) | mps);
+}
+static inline uint32_t lps_range(Model m, uint32_t range) { const uint32_t l = ((uint32_t)(m >> 1) * range) >> 9; return l < 437 ? 437 : l; }
+
+struct Dec {      // xevd_sbac_decode_bin / sbac_decode_bin_ep / xevd_sbac_decode_bin_trm, xevd_eco.c:35-165
+    BitReader *br;
+    uint32_t range, value;
+    void start() { range = 16384; value = 0; for (int i = 0; i < 14; i++) value = ((value << 1) | (uint32_t)br->get1()) & 0xFFFF; }
+    int bin(int, Model &m)
+    {
+        const int mps = m & 1;
+        const uint32_t lps = lps_range(m, range);
+        int b = mps;
+        range -= lps;
+        if (value >= range) { b = 1 - mps; value -= range; range = lps; model_update(m, true); }
+        else model_update(m, false);
+        while (range < 8192) { range <<= 1; value = ((value << 1) | (uint32_t)br->get1()) & 0xFFFF; }
+        return b;
+    }
+    int ep(int)
+    {
+        int b = 0;
+        range >>= 1;
+        if (value >= range) { b = 1; value -= range; }
+        range <<= 1;
+        value = ((value << 1) | (uint32_t)br->get1()) & 0xFFFF;
+        return b;
+    }
+    int tile_end()      // terminating bin, then zero bits up to the byte boundary and zero words up to the end (xevd_eco.c:100-140,1683-1695)
+    {
+        range--;
+        if (value < range) return 0;
+        while (!br->aligned()) if (br->get1()) return -1;
+        return 1;
+    }
+};
+struct Enc {      // the mirror image: MPS takes the lower part of the interval, carries resolved with outstanding bits
+    BitWriter *bw;
+    uint32_t low = 0, range = 16384;
+    int outstanding = 0;
+    bool first = true;
+    void start() { low = 0; range = 16384; outstanding = 0; first = true; }
+    void emit(int b) { if (first) first = false; else bw->put1(b); while (outstanding) { bw->put1(!b); outstanding--; } }
+    void shift_out()
+    {
+        if (low < 8192) emit(0);
+        else if (low >= 16384) { low -= 16384; emit(1); }
+        else { low -= 8192; outstanding++; }
+        low <<= 1;
+    }
+    int bin(int v, Model &m)
+    {
+        const int mps = m & 1;
+        const uint32_t lps = lps_range(m, range);
+        range -= lps;
+        if ((v & 1) != mps) { low += range; range = lps; model_update(m, true); }
+        else model_update(m, false);
+        while (range < 8192) { shift_out(); range <<= 1; }
+        return v & 1;
+    }
+    int ep(int v)
+    {
+        const uint32_t half = range >> 1;
+        if (v & 1) low += half;
+        shift_out();
+        range = half << 1;
+        return v & 1;
+    }
+    int tile_end()
+    {
+        range--;
+        low += range;                               // the top unit of the interval: the decoder sees value >= range
+        emit((int)((low >> 14) & 1));
+        for (int i = 13; i >= 0; i--) bw->put1((int)((low >> i) & 1));
+        bw->align_zero();
+        return 1;
+    }
+};
+
+// Symbol binarisations shared by both coders (xevd_eco.c:167-258, 452-489)
+template <class C> static int sym_unary(C &c, int v, Model *m, int num_ctx)       // sbac_read_unary_sym
+{
+    int sym = 0, ctx = 0;
+    if (!c.bin(v > 0, m[0])) return 0;
+    for (;;) {
+        if (ctx < num_ctx - 1) ctx++;
+        sym++;
+        if (!c.bin(v > sym, m[ctx])) break;
+    }
+    return sym;
+}
+template <class C> static int sym_trunc_unary(C &c, int v, Model *m, int num_ctx, int max_num)      // sbac_read_truncate_unary_sym
+{
+    int i = 0;
+    if (max_num > 1)
+        for (; i < max_num - 1; ++i)
+            if (!c.bin(v > i, m[i > num_ctx - 1 ? num_ctx - 1 : i])) break;
+    return i;
+}
+template <class C> static int sym_abs_mvd(C &c, int v, Model &m)      // xevd_eco_abs_mvd: 1 = zero; else (len-1) zeros + 1, then len suffix bits
+{
+    if (c.bin(v == 0, m)) return 0;
+    int len_v = 0;
+    while (((v + 1) >> (len_v + 1)) > 0) len_v++;            // floor(log2(v + 1)) on the encoder side
+    int len = 0, code;
+    do { code = len == 0 ? c.bin(len + 1 == len_v, m) : c.ep(len + 1 == len_v); len++; } while (!code);
+    int val = (1 << len) - 1;
+    const int suffix = v + 1 - (1 << len_v);
+    while (len != 0) { len--; val += c.ep((suffix >> len) & 1) << len; }
+    return val;
+}
+
+struct Models {
+    Model split[1], run[24], last[2], level[24], cbf_luma[1], cbf_cb[1], cbf_cr[1], cbf_all[1], pred_mode[3], direct[1], inter_dir[2],
+          intra_dir[2], mvp_idx[3], mvd[1], refi[2], dqp[1], skip[2];
+    void reset() { Model *p = (Model *)this; for (size_t i = 0; i < sizeof(Models) / sizeof(Model); i++) p[i] = 512; }     // PROB_INIT, xevd_eco.c:769-803
+};
+
+// ------------------------------------------------------------------------------------------------ constants of the standard
+// most-probable-mode code numbers by (left mode + 1, upper mode + 1), 0 = not intra/available: xevd_tbl_mpm, xevd_tbl.c:46-54
+static const uint8_t k_mpm[6][6][5] = {
+    { { 0, 2, 3, 1, 4 }, { 0, 2, 1, 3, 4 }, { 0, 2, 1, 3, 4 }, { 1, 2, 0, 3, 4 }, { 0, 2, 1, 3, 4 }, { 0, 1, 2, 3, 4 } },
+    { { 1, 0, 2, 3, 4 }, { 0, 1, 2, 3, 4 }, { 0, 1, 2, 3, 4 }, { 1, 2, 0, 3, 4 }, { 0, 1, 3, 2, 4 }, { 0, 2, 1, 4, 3 } },
+    { { 1, 0, 2, 3, 4 }, { 1, 0, 2, 3, 4 }, { 1, 0, 2, 3, 4 }, { 2, 0, 1, 3, 4 }, { 1, 0, 3, 2, 4 }, { 0, 1, 2, 4, 3 } },
+    { { 1, 0, 2, 3, 4 }, { 0, 2, 1, 3, 4 }, { 1, 0, 2, 3, 4 }, { 1, 2, 0, 3, 4 }, { 0, 1, 2, 3, 4 }, { 0, 2, 1, 4, 3 } },
+    { { 0, 1, 2, 3, 4 }, { 0, 3, 2, 1, 4 }, { 1, 0, 2, 3, 4 }, { 1, 2, 0, 3, 4 }, { 1, 2, 3, 0, 4 }, { 0, 2, 1, 4, 3 } },
+    { { 0, 1, 2, 3, 4 }, { 0, 1, 2, 4, 3 }, { 0, 1, 2, 4, 3 }, { 0, 2, 1, 4, 3 }, { 0, 1, 2, 3, 4 }, { 0, 1, 2, 4, 3 } } };
+// default chroma QP mapping: xevd_tbl_qp_chroma_adjust_base, xevd_tbl.c:345-354
+static const int8_t k_chroma_qp[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
+    29, 29, 30, 31, 32, 32, 33, 33, 34, 34, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 39, 39, 40, 40, 40, 41, 41, 41 };
+
+// zig-zag scan of a w x h block (init_scan, xevd_util.c:1004-1047): anti-diagonals, odd ones top-right -> bottom-left
+static void make_zigzag(std::vector<uint16_t> &scan, int w, int h)
+{
+    scan.resize((size_t)w * h);
+    int pos = 0;
+    scan[pos++] = 0;
+    for (int l = 1; l < w + h - 1; l++) {
+        if (l & 1) { int x = std::min(l, w - 1), y = std::max(0, l - (w - 1)); while (x >= 0 && y < h) { scan[pos++] = (uint16_t)(y * w + x); x--; y++; } }
+        else       { int y = std::min(l, h - 1), x = std::max(0, l - (h - 1)); while (y >= 0 && x < w) { scan[pos++] = (uint16_t)(y * w + x); x++; y--; } }
+    }
+}
+
+enum { MODE_INTRA = XGPU_MODE_INTRA, MODE_INTER = XGPU_MODE_INTER, MODE_SKIP = XGPU_MODE_SKIP };
+
+// ------------------------------------------------------------------------------------------------ stream / picture state
+struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, log2_ref_gap = 0, max_num_ref_pics = 1; };
+struct Pps { int constrained_intra = 0, cu_qp_delta = 0; };
+struct Slice { int type = XHOST_SLICE_I, qp = 32, qp_u_offset = 0, qp_v_offset = 0, deblock = 1; };
+
+struct RefPic {          // what a decoded picture leaves behind for later pictures (XEVD_PIC map_mv / list_poc, xevd_picman.c:213-221)
+    int poc = 0, tid = 0;
+    std::vector<int16_t> mv0;        // [f_scu][2]: list-0 motion of every SCU (refp.map_mv[scup][REFP_0])
+};
+
+struct Cu {
+    int x, y, log2w, log2h;
+    int mode;                        // MODE_INTRA / MODE_INTER / MODE_SKIP
+    int refi[2], mvp_idx[2];
+    int16_t mvd[2][2], mv[2][2];
+    int ipm, cbf[3], qp;
+};
+
+struct Picture {         // SCU maps of the picture being parsed / written (ctx->map_scu, map_ipm, map_mv, map_refi; cod_eco)
+    int w_scu = 0, h_scu = 0;
+    std::vector<uint8_t> cod, intra;
+    std::vector<int8_t> ipm;
+    std::vector<int16_t> mv;         // [f_scu][2][2]
+    std::vector<int8_t> refi;        // [f_scu][2]
+    void reset(int w, int h)
+    {
+        w_scu = w >> 2; h_scu = h >> 2;
+        const size_t f = (size_t)w_scu * h_scu;
+        cod.assign(f, 0); intra.assign(f, 0); ipm.assign(f, 0); mv.assign(f * 4, 0); refi.assign(f * 2, -1);
+    }
+};
+
+struct Batch {           // the xgpu_cu_batch under construction
+    std::vector<uint16_t> x, y;
+    std::vector<uint8_t> log2w, log2h, pred_mode, qp, cbf, ipm;
+    std::vector<int8_t> refi;
+    std::vector<int16_t> mv, coef;
+    std::vector<uint32_t> coef_off, ctu_start;
+    void clear() { x.clear(); y.clear(); log2w.clear(); log2h.clear(); pred_mode.clear(); qp.clear(); cbf.clear(); ipm.clear(); refi.clear(); mv.clear(); coef.clear(); coef_off.clear(); ctu_start.clear(); }
+};
+
+struct Stream {          // everything both directions share
+    Sps sps;
+    Pps pps;
+    Slice sh;
+    Picture pic;
+    Models models;
+    std::vector<RefPic> dpb;         // reference pictures in coding order (pm->pic[] restricted to IS_REF)
+    std::vector<const RefPic *> refp[2];
+    int poc = 0, prev_poc = 0, last_intra_poc = 0, qp_prev = 0;
+    bool have_sps = false, have_pps = false;
+    std::vector<uint16_t> scan[6][6];      // zig-zag tables by log2 size - 1
+
+    Stream() { for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) make_zigzag(scan[a][b], 2 << a, 2 << b); }
+
+    // reference lists without RPL for temporal layer 0 (xevd_picman_refp_init, xevd_picman.c:291-437): all reference pictures by
+    // descending POC, those before the current picture (and not before the last intra picture), at most max_num_ref_pics
+    void build_ref_lists()
+    {
+        refp[0].clear(); refp[1].clear();
+        if (sh.type == XHOST_SLICE_I) return;
+        std::vector<const RefPic *> sorted;
+        for (const RefPic &r : dpb) sorted.push_back(&r);
+        std::sort(sorted.begin(), sorted.end(), [](const RefPic *a, const RefPic *b) { return a->poc > b->poc; });
+        for (const RefPic *r : sorted) {
+            if ((int)refp[0].size() >= sps.max_num_ref_pics) break;
+            if (poc >= last_intra_poc && r->poc < last_intra_poc) continue;
+            if (r->poc < poc) refp[0].push_back(r);
+        }
+    }
+    // picture marking + insertion (xevd_picman_put_pic / pic_marking_no_rpl, xevd_picman.c:68-110,462-509); released POCs reported
+    void store_picture(bool idr, std::vector<int> &released)
+    {
+        if (idr) { for (const RefPic &r : dpb) released.push_back(r.poc); dpb.clear(); }
+        else {
+            const int gap = 1 << sps.log2_ref_gap;
+            for (size_t i = 0; i < dpb.size();) {
+                if (dpb[i].tid > 0 || (i > 0 && gap > 0 && dpb[i].poc % gap != 0)) { released.push_back(dpb[i].poc); dpb.erase(dpb.begin() + (long)i); }
+                else i++;
+            }
+            while (dpb.size() >= 5) { released.push_back(dpb[0].poc); dpb.erase(dpb.begin()); }      // XEVD_MAX_NUM_ACTIVE_REF_FRAME
+        }
+        RefPic r;
+        r.poc = poc; r.tid = 0;
+        const size_t f = (size_t)pic.w_scu * pic.h_scu;
+        r.mv0.resize(f * 2);
+        for (size_t k = 0; k < f; k++) { r.mv0[k * 2] = pic.mv[k * 4]; r.mv0[k * 2 + 1] = pic.mv[k * 4 + 1]; }
+        dpb.push_back(std::move(r));
+    }
+
+    // motion vector predictor candidates of one list (xevd_get_motion, xevd_util.c:469-515; availability xevd_get_avail_inter :632-687):
+    // left, up, up-right neighbour SCU (1,1 when not available) and the co-located list-0 motion of reference 0 of that list
+    void mvp_candidates(const Cu &cu, int lidx, int16_t cand[4][2]) const
+    {
+        const int xs = cu.x >> 2, ys = cu.y >> 2, scuw = (1 << cu.log2w) >> 2, ws = pic.w_scu;
+        const int scup = ys * ws + xs;
+        auto take = [&](int k, bool ok, int s) {
+            cand[k][0] = ok ? pic.mv[(size_t)s * 4 + lidx * 2] : (int16_t)1;
+            cand[k][1] = ok ? pic.mv[(size_t)s * 4 + lidx * 2 + 1] : (int16_t)1;
+        };
+        take(0, xs > 0 && !pic.intra[scup - 1] && pic.cod[scup - 1], scup - 1);
+        take(1, ys > 0 && !pic.intra[scup - ws], scup - ws);
+        take(2, ys > 0 && xs + scuw < ws && pic.cod[scup - ws + scuw] && !pic.intra[scup - ws + scuw], scup - ws + scuw);
+        const RefPic *col = refp[lidx].empty() ? nullptr : refp[lidx][0];
+        cand[3][0] = col ? col->mv0[(size_t)scup * 2] : (int16_t)0;
+        cand[3][1] = col ? col->mv0[(size_t)scup * 2 + 1] : (int16_t)0;
+    }
+    // code-number table of the luma intra mode (xevd_get_mpm_b, xevd_ipred.c:678-692): neighbours count when intra and already parsed
+    const uint8_t *mpm_list(const Cu &cu) const
+    {
+        const int xs = cu.x >> 2, ys = cu.y >> 2, ws = pic.w_scu, scup = ys * ws + xs;
+        int l = 0, u = 0;
+        if (xs > 0 && pic.intra[scup - 1] && pic.cod[scup - 1]) l = pic.ipm[scup - 1] + 1;
+        if (ys > 0 && pic.intra[scup - ws] && pic.cod[scup - ws]) u = pic.ipm[scup - ws] + 1;
+        return k_mpm[l][u];
+    }
+    void chroma_qps(int qp, int &qp_u, int &qp_v) const      // xevd_eco.c:663-666
+    {
+        const int off = 6 * (sps.bd_c - 8);
+        const int iu = std::min(std::max(qp + sh.qp_u_offset, -off), 57), iv = std::min(std::max(qp + sh.qp_v_offset, -off), 57);
+        qp_u = (iu >= 0 ? k_chroma_qp[iu] : 0) + off;         // entries below 0 of the default table are zero-initialised storage
+        qp_v = (iv >= 0 ? k_chroma_qp[iv] : 0) + off;
+    }
+    // SCU maps after a CU (xevd_set_dec_info, xevd_util.c:1574-1660; cod_eco xevd.c:797-803)
+    void commit(const Cu &cu)
+    {
+        const int xs = cu.x >> 2, ys = cu.y >> 2, w = (1 << cu.log2w) >> 2, h = (1 << cu.log2h) >> 2;
+        for (int r = 0; r < h; r++) for (int c = 0; c < w; c++) {
+            const size_t k = (size_t)(ys + r) * pic.w_scu + xs + c;
+            pic.cod[k] = 1; pic.intra[k] = cu.mode == MODE_INTRA; pic.ipm[k] = (int8_t)cu.ipm;
+            for (int l = 0; l < 2; l++) { pic.refi[k * 2 + l] = (int8_t)cu.refi[l]; pic.mv[k * 4 + l * 2] = cu.mv[l][0]; pic.mv[k * 4 + l * 2 + 1] = cu.mv[l][1]; }
+        }
+    }
+
+    // ---- coefficient block, run-length coding in zig-zag order (xevd_eco_run_length_cc, xevd_eco.c:343-395) ----
+    template <class C> void code_coefs(C &c, int16_t *coef, int log2w, int log2h, int chroma, bool enc)
+    {
+        const std::vector<uint16_t> &sc = scan[log2w - 1][log2h - 1];
+        const int n = 1 << (log2w + log2h), t0 = chroma ? 2 : 0;
+        int pos = 0;
+        for (;;) {
+            int run = 0, level = 1, sign = 0, last = 1;
+            if (enc) {
+                while (pos + run < n && coef[sc[pos + run]] == 0) run++;
+                const int v = coef[sc[pos + run]];
+                level = v < 0 ? -v : v; sign = v < 0;
+                for (int q = pos + run + 1; q < n; q++) if (coef[sc[q]]) { last = 0; break; }
+            }
+            run = sym_unary(c, run, models.run + t0, 2);
+            if (!enc) for (int i = pos; i < pos + run && i < n; i++) coef[sc[i]] = 0;
+            pos += run;
+            if (pos >= n) return;                                   // malformed input; the caller checks the reader's overrun flag
+            level = sym_unary(c, level - 1, models.level + t0, 2) + 1;
+            sign = c.ep(sign);
+            if (!enc) coef[sc[pos]] = (int16_t)(sign ? -level : level);
+            if (pos >= n - 1) break;
+            pos++;
+            last = c.bin(last, models.last[chroma ? 1 : 0]);
+            if (last) break;
+        }
+    }
+
+    // ---- one CU: syntax (xevd_eco_cu, xevd_eco.c:1048-1176; cbf :260-341; coefficients/QP :593-767) + derivations ----
+    // enc: `cu` and `coef` carry the wanted values (mv of an INTER CU is met through mvd, a SKIP CU takes its predictor's motion);
+    // dec: they are filled.  coef[c]: w*h (w/2*h/2) values of component c, zero-initialised by the caller when decoding.
+    template <class C> void code_cu(C &c, Cu &cu, int16_t *coef[3], bool enc)
+    {
+        const bool inter_slice = sh.type != XHOST_SLICE_I;
+        int skip = 0;
+        if (inter_slice) skip = c.bin(cu.mode == MODE_SKIP, models.skip[0]);
+        if (!enc) { cu.mode = skip ? MODE_SKIP : MODE_INTRA; cu.refi[0] = cu.refi[1] = -1; memset(cu.mv, 0, sizeof(cu.mv)); memset(cu.mvd, 0, sizeof(cu.mvd));
+                    cu.mvp_idx[0] = cu.mvp_idx[1] = 0; cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0; cu.ipm = 0; }
+        int16_t cand[4][2];
+        if (skip) {
+            // the motion of candidate mvp_idx, reference 0 (xevd_get_skip_motion, xevd.c:502-531)
+            cu.mvp_idx[0] = sym_trunc_unary(c, cu.mvp_idx[0], models.mvp_idx, 3, 4);
+            mvp_candidates(cu, 0, cand);
+            cu.refi[0] = 0; cu.refi[1] = -1;
+            cu.mv[0][0] = cand[cu.mvp_idx[0]][0]; cu.mv[0][1] = cand[cu.mvp_idx[0]][1]; cu.mv[1][0] = cu.mv[1][1] = 0;
+            cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0;
+            cu.qp = qp_prev;                                         // xevd_eco.c:1091-1115 (cu_qp_delta on: previous QP; off: slice QP = the same)
+            return;
+        }
+        int intra = 1;
+        if (inter_slice) intra = c.bin(cu.mode == MODE_INTRA, models.pred_mode[0]);
+        if (!enc) cu.mode = intra ? MODE_INTRA : MODE_INTER;
+        if (!intra) {
+            // P slice: list 0 only (inter_dir = PRED_L0): ref index, predictor index, mvd (xevd_eco.c:1134-1146); mv = mvp + mvd (xevd.c:533-556)
+            const int nref = (int)refp[0].size();
+            if (nref > 1) {                                          // xevd_eco_refi, xevd_eco.c:409-436
+                int r = cu.refi[0], v = 0;
+                if (c.bin(r > 0, models.refi[0])) {
+                    v = 1;
+                    if (nref > 2 && c.bin(r > 1, models.refi[1])) {
+                        v = 2;
+                        for (; v < nref - 1; v++) if (!c.ep(r > v)) break;
+                    }
+                }
+                cu.refi[0] = v;
+            } else cu.refi[0] = 0;
+            cu.refi[1] = -1;
+            mvp_candidates(cu, 0, cand);
+            if (enc) {                                               // cheapest predictor
+                int best = 0, cost = 1 << 30;
+                for (int k = 0; k < 4; k++) { const int d = abs(cu.mv[0][0] - cand[k][0]) + abs(cu.mv[0][1] - cand[k][1]); if (d < cost) { cost = d; best = k; } }
+                cu.mvp_idx[0] = best;
+                cu.mvd[0][0] = (int16_t)(cu.mv[0][0] - cand[best][0]); cu.mvd[0][1] = (int16_t)(cu.mv[0][1] - cand[best][1]);
+            }
+            cu.mvp_idx[0] = sym_trunc_unary(c, cu.mvp_idx[0], models.mvp_idx, 3, 4);
+            for (int d = 0; d < 2; d++) {                            // xevd_eco_get_mvd, xevd_eco.c:491-536
+                const int v = cu.mvd[0][d], a = sym_abs_mvd(c, v < 0 ? -v : v, models.mvd[0]);
+                int s = v < 0;
+                if (a) s = c.ep(s);
+                cu.mvd[0][d] = (int16_t)(s ? -a : a);
+            }
+            cu.mv[0][0] = (int16_t)(cand[cu.mvp_idx[0]][0] + cu.mvd[0][0]); cu.mv[0][1] = (int16_t)(cand[cu.mvp_idx[0]][1] + cu.mvd[0][1]);
+            cu.mv[1][0] = cu.mv[1][1] = 0;
+        } else {
+            const uint8_t *mpm = mpm_list(cu);                       // xevd_eco_intra_dir_b, xevd_eco.c:826-846: the code number is sent
+            const int code = sym_unary(c, mpm[cu.ipm], models.intra_dir, 2);
+            if (!enc) for (int i = 0; i < 5; i++) if (mpm[i] == code) cu.ipm = i;
+        }
+        // coded block flags (eco_cbf, xevd_eco.c:260-341), CU <= 64: no sub-blocks
+        bool all_zero = false;
+        if (!intra) {
+            const int any = c.bin((cu.cbf[0] | cu.cbf[1] | cu.cbf[2]) != 0, models.cbf_all[0]);
+            if (!any) { cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0; all_zero = true; }
+            else {
+                cu.cbf[1] = c.bin(cu.cbf[1], models.cbf_cb[0]);
+                cu.cbf[2] = c.bin(cu.cbf[2], models.cbf_cr[0]);
+                if (cu.cbf[1] + cu.cbf[2] == 0) cu.cbf[0] = 1;
+                else cu.cbf[0] = c.bin(cu.cbf[0], models.cbf_luma[0]);
+            }
+        } else {
+            cu.cbf[1] = c.bin(cu.cbf[1], models.cbf_cb[0]);
+            cu.cbf[2] = c.bin(cu.cbf[2], models.cbf_cr[0]);
+            cu.cbf[0] = c.bin(cu.cbf[0], models.cbf_luma[0]);
+        }
+        // QP (xevd_eco.c:640-668, xevd_eco_dqp :460-479): a delta only when the CU has coefficients
+        if (!all_zero && pps.cu_qp_delta && (cu.cbf[0] || cu.cbf[1] || cu.cbf[2])) {
+            int dqp = 0;
+            if (enc) { dqp = cu.qp - qp_prev; while (dqp > 25) dqp -= 52; while (dqp < -26) dqp += 52; }
+            const int a = sym_unary(c, dqp < 0 ? -dqp : dqp, models.dqp, 1);
+            int s = dqp < 0;
+            if (a) s = c.ep(s);
+            dqp = s ? -a : a;
+            cu.qp = (qp_prev + dqp + 52) % 52;
+            qp_prev = cu.qp;
+        } else cu.qp = qp_prev;
+        if (all_zero) return;
+        for (int k = 0; k < 3; k++)
+            if (cu.cbf[k]) code_coefs(c, coef[k], cu.log2w - (k ? 1 : 0), cu.log2h - (k ? 1 : 0), k != 0, enc);
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ NAL plumbing
+enum { NUT_NONIDR = 0, NUT_IDR = 1, NUT_SPS = 24, NUT_PPS = 25, NUT_SEI = 28 };
+
+static void write_nal(std::vector<uint8_t> &out, int nut, int tid, const BitWriter &payload)
+{
+    const uint32_t len = (uint32_t)payload.buf.size() + 2;
+    for (int i = 3; i >= 0; i--) out.push_back((uint8_t)(len >> (8 * i)));
+    const uint32_t hdr = ((uint32_t)(nut + 1) << 9) | ((uint32_t)tid << 6);      // 1 zero bit, type + 1 (6), tid (3), 5 reserved zero bits, 1 extension bit
+    out.push_back((uint8_t)(hdr >> 8)); out.push_back((uint8_t)hdr);
+    out.insert(out.end(), payload.buf.begin(), payload.buf.end());
+}
+
+}   // namespace
+
+// =============================================================================================================== parser
+struct xhost_parser {
+    std::vector<uint8_t> data;
+    size_t pos = 0;
+    Stream st;
+    Batch batch;
+    std::string err;
+    std::vector<int16_t> blk[3];
+    int fail(const char *m) { err = m; return XHOST_ERR_MALFORMED; }
+
+    int parse_sps(BitReader &br)
+    {
+        Sps &s = st.sps;
+        br.ue();                                         // sps_seq_parameter_set_id
+        const int profile = (int)br.get(8);
+        if (profile != 0 && profile != 2) return fail("not a Baseline-profile stream");
+        br.get(8); br.get(32); br.get(32);               // level, toolset_idc_h/l
+        if (br.ue() != 1) return fail("only 4:2:0 is supported");
+        s.width = (int)br.ue(); s.height = (int)br.ue();
+        s.bd_l = (int)br.ue() + 8; s.bd_c = (int)br.ue() + 8;
+        int tools = 0;
+        for (int i = 0; i < 13; i++) { const int f = br.get1(); if (i != 11) tools |= f; (void)f; }      // btt suco admvp eipd cm_init iqt addb alf htdf rpl pocs dquant dra
+        if (tools) return fail("Main-profile tools are not supported by this front end");
+        s.log2_sub_gop = (int)br.ue();                   // tool_rpl = tool_pocs = 0
+        if (s.log2_sub_gop == 0) s.log2_ref_gap = (int)br.ue();
+        else return fail("temporal layers (sub-GOP > 1) are not supported yet");
+        s.max_num_ref_pics = (int)br.ue();
+        if (br.get1()) { br.ue(); br.ue(); br.ue(); br.ue(); }      // cropping offsets (output cropping is the caller's business)
+        if (br.get1()) return fail("chroma QP tables in the SPS are not supported yet");
+        if (br.get1()) return fail("VUI is not supported yet");
+        if (br.overrun || (s.width & 7) || (s.height & 7) || s.width <= 0 || s.height <= 0) return fail("bad SPS");
+        st.have_sps = true;
+        return XGPU_OK;
+    }
+    int parse_pps(BitReader &br)
+    {
+        br.ue(); br.ue(); br.ue(); br.ue(); br.ue();     // pps id, sps id, num_ref_idx_default_active_minus1[2], additional_lt_poc_lsb_len
+        br.get1();                                       // rpl1_idx_present_flag
+        if (!br.get1()) return fail("multiple tiles are not supported");
+        br.ue(); br.get1(); br.get1(); br.get1();        // tile_id_len_minus1, explicit_tile_id, pic_dra_enabled, arbitrary_slice_present
+        st.pps.constrained_intra = br.get1();
+        st.pps.cu_qp_delta = br.get1();
+        if (st.pps.cu_qp_delta) br.ue();                 // cu_qp_delta_area
+        if (br.overrun) return fail("bad PPS");
+        st.have_pps = true;
+        return XGPU_OK;
+    }
+    int parse_slice(BitReader &br, int nut, int tid, xhost_picture *out)
+    {
+        if (!st.have_sps || !st.have_pps) return fail("slice before SPS/PPS");
+        if (tid != 0) return fail("temporal layers are not supported yet");
+        Slice &sh = st.sh;
+        br.ue();                                         // slice_pic_parameter_set_id; single tile: no tile ids
+        sh.type = (int)br.ue();
+        if (sh.type == XHOST_SLICE_B) return fail("B slices are not supported yet");
+        if (nut == NUT_IDR) br.get1();                   // no_output_of_prior_pics_flag
+        if (sh.type != XHOST_SLICE_I && br.get1()) br.ue();      // num_ref_idx_active override (unused by the Baseline decoder, xevd_eco.c:409)
+        sh.deblock = br.get1();
+        sh.qp = (int)br.get(6);
+        sh.qp_u_offset = br.se(); sh.qp_v_offset = br.se();
+        while (!br.aligned()) if (br.get1()) return fail("slice header alignment");
+        if (br.overrun || sh.qp > 51) return fail("bad slice header");
+        // POC (xevd.c:1846-1861, xevd_poc_derivation with sub-GOP length 1): IDR 0, else previous + 1
+        if (nut == NUT_IDR) { st.poc = 0; st.prev_poc = 0; } else { st.poc = st.prev_poc + 1; st.prev_poc = st.poc; }
+        if (sh.type == XHOST_SLICE_I) st.last_intra_poc = st.poc;
+        st.build_ref_lists();
+        if (sh.type != XHOST_SLICE_I && st.refp[0].empty()) return fail("P slice without a reference picture");
+        st.pic.reset(st.sps.width, st.sps.height);
+        st.models.reset();
+        st.qp_prev = sh.qp;
+
+        // ---- tile data (xevd_tile_eco, xevd.c:1408-1468) ----
+        Dec dec;
+        dec.br = &br;
+        dec.start();
+        batch.clear();
+        const int W = st.sps.width, H = st.sps.height, w_ctu = (W + 63) >> 6, h_ctu = (H + 63) >> 6;
+        for (int k = 0; k < 3; k++) blk[k].assign(64 * 64, 0);
+        for (int cy = 0; cy < h_ctu; cy++) for (int cx = 0; cx < w_ctu; cx++) {
+            batch.ctu_start.push_back((uint32_t)batch.x.size());
+            const int rc = parse_tree(dec, cx << 6, cy << 6, 6);
+            if (rc != XGPU_OK) return rc;
+            if (br.overrun) return fail("slice data ends early");
+        }
+        batch.ctu_start.push_back((uint32_t)batch.x.size());
+        if (dec.tile_end() != 1) return fail("missing end-of-tile flag");
+
+        // ---- hand-over ----
+        memset(out, 0, sizeof(*out));
+        out->width = W; out->height = H; out->bit_depth_luma = st.sps.bd_l; out->bit_depth_chroma = st.sps.bd_c;
+        out->poc = st.poc; out->temporal_id = tid; out->slice_type = sh.type; out->is_idr = nut == NUT_IDR; out->is_ref = 1;
+        out->num_refp[0] = (int)st.refp[0].size();
+        for (size_t i = 0; i < st.refp[0].size(); i++) out->refp_poc[i][0] = st.refp[0][i]->poc;
+        out->slice_qp = sh.qp; out->qp_u_offset = sh.qp_u_offset; out->qp_v_offset = sh.qp_v_offset; out->deblock_on = sh.deblock;
+        std::vector<int> released;
+        st.store_picture(nut == NUT_IDR, released);
+        out->n_release = (int)std::min(released.size(), (size_t)32);
+        for (int i = 0; i < out->n_release; i++) out->release_poc[i] = released[(size_t)i];
+        xgpu_cu_batch &b = out->batch;
+        b.n_cu = (int)batch.x.size();
+        b.x = batch.x.data(); b.y = batch.y.data(); b.log2w = batch.log2w.data(); b.log2h = batch.log2h.data();
+        b.pred_mode = batch.pred_mode.data(); b.refi = batch.refi.data(); b.mv = batch.mv.data(); b.qp = batch.qp.data();
+        b.cbf = batch.cbf.data(); b.ipm = batch.ipm.data(); b.coef_off = batch.coef_off.data();
+        if (batch.coef.empty()) batch.coef.push_back(0);
+        b.coef = batch.coef.data(); b.n_coef = batch.x.empty() ? 0 : n_coef;
+        b.n_ctu = w_ctu * h_ctu; b.ctu_cu_start = batch.ctu_start.data();
+        b.constrained_intra_pred = st.pps.constrained_intra;
+        return 1;
+    }
+    size_t n_coef = 0;
+
+    // quad tree of one CTU (xevd_entropy_decode_tree, xevd.c:928-999; xevd_eco_split_mode, xevd_eco.c:985-999): a split flag for
+    // every node above 4x4 whose top-left corner is inside the picture, also when the node crosses the picture border
+    int parse_tree(Dec &dec, int x, int y, int log2s)
+    {
+        const int s = 1 << log2s;
+        int split = 0;
+        if (s > 4 && !(s < 8)) split = dec.bin(0, st.models.split[0]);
+        if (split) {
+            const int h = s >> 1;
+            for (int i = 0; i < 4; i++) {
+                const int nx = x + (i & 1) * h, ny = y + (i >> 1) * h;
+                if (nx < st.sps.width && ny < st.sps.height) { const int rc = parse_tree(dec, nx, ny, log2s - 1); if (rc != XGPU_OK) return rc; }
+            }
+            return XGPU_OK;
+        }
+        if (x + s > st.sps.width || y + s > st.sps.height) return fail("a CU crosses the picture border");
+        Cu cu;
+        memset(&cu, 0, sizeof(cu));
+        cu.x = x; cu.y = y; cu.log2w = cu.log2h = log2s;
+        int16_t *coef[3] = { blk[0].data(), blk[1].data(), blk[2].data() };
+        memset(coef[0], 0, sizeof(int16_t) << (2 * log2s));
+        memset(coef[1], 0, sizeof(int16_t) << (2 * log2s - 2));
+        memset(coef[2], 0, sizeof(int16_t) << (2 * log2s - 2));
+        st.code_cu(dec, cu, coef, false);
+        st.commit(cu);
+        // append to the batch
+        if (batch.x.empty()) n_coef = 0;
+        batch.x.push_back((uint16_t)x); batch.y.push_back((uint16_t)y); batch.log2w.push_back((uint8_t)log2s); batch.log2h.push_back((uint8_t)log2s);
+        batch.pred_mode.push_back((uint8_t)cu.mode);
+        batch.refi.push_back((int8_t)cu.refi[0]); batch.refi.push_back((int8_t)cu.refi[1]);
+        for (int l = 0; l < 2; l++) { batch.mv.push_back(cu.mv[l][0]); batch.mv.push_back(cu.mv[l][1]); }
+        int qp_u, qp_v;
+        st.chroma_qps(cu.qp, qp_u, qp_v);
+        batch.qp.push_back((uint8_t)(cu.qp + 6 * (st.sps.bd_l - 8))); batch.qp.push_back((uint8_t)qp_u); batch.qp.push_back((uint8_t)qp_v);
+        batch.cbf.push_back((uint8_t)(cu.cbf[0] | (cu.cbf[1] << 1) | (cu.cbf[2] << 2)));
+        batch.ipm.push_back((uint8_t)cu.ipm); batch.ipm.push_back((uint8_t)cu.ipm);            // chroma mode = luma mode, xevd_eco.c:1154
+        batch.coef_off.push_back((uint32_t)n_coef);
+        for (int k = 0; k < 3; k++)
+            if (cu.cbf[k]) {
+                const size_t n = (size_t)1 << (2 * log2s - (k ? 2 : 0));
+                batch.coef.insert(batch.coef.end(), coef[k], coef[k] + n);
+                n_coef += n;
+            }
+        return XGPU_OK;
+    }
+};
+
+extern "C" xhost_parser *xhost_parser_open(const uint8_t *bytes, size_t size)
+{
+    if (!bytes) return nullptr;
+    xhost_parser *p = new xhost_parser();
+    p->data.assign(bytes, bytes + size);
+    return p;
+}
+extern "C" const char *xhost_parser_error(const xhost_parser *p) { return p ? p->err.c_str() : "null parser"; }
+extern "C" void xhost_parser_close(xhost_parser *p) { delete p; }
+
+extern "C" int xhost_parser_next(xhost_parser *p, xhost_picture *out)
+{
+    if (!p || !out) return XGPU_ERR_INVALID_ARGUMENT;
+    while (p->pos + 4 <= p->data.size()) {
+        const uint8_t *d = p->data.data() + p->pos;
+        const size_t len = ((size_t)d[0] << 24) | ((size_t)d[1] << 16) | ((size_t)d[2] << 8) | d[3];
+        if (len < 2 || p->pos + 4 + len > p->data.size()) return p->fail("bad NAL length");
+        BitReader br;
+        br.p = d + 4; br.size = len;
+        p->pos += 4 + len;
+        if (br.get1()) return p->fail("forbidden_zero_bit");
+        const int nut = (int)br.get(6) - 1, tid = (int)br.get(3);
+        if (br.get(5) != 0 || br.get1() != 0) return p->fail("reserved NAL header bits");
+        int rc = XGPU_OK;
+        if (nut == NUT_SPS) rc = p->parse_sps(br);
+        else if (nut == NUT_PPS) rc = p->parse_pps(br);
+        else if (nut == NUT_IDR || nut == NUT_NONIDR) return p->parse_slice(br, nut, tid, out);
+        else if (nut == NUT_SEI) rc = XGPU_OK;          // picture signatures are checked by the caller against its own output if wanted
+        else return p->fail("unsupported NAL unit type");
+        if (rc != XGPU_OK) return rc;
+    }
+    return 0;
+}
+
+// =============================================================================================================== writer
+struct xhost_writer {
+    xhost_stream_params sp;
+    Stream st;
+    std::vector<uint8_t> out;
+    int n_pics = 0;
+
+    void write_sps()
+    {
+        BitWriter bw;
+        bw.ue(0); bw.put(0, 8); bw.put(0, 8); bw.put(0, 32); bw.put(0, 32);       // id, profile Baseline, level, toolset
+        bw.ue(1); bw.ue((uint32_t)sp.width); bw.ue((uint32_t)sp.height);
+        bw.ue((uint32_t)(sp.bit_depth - 8)); bw.ue((uint32_t)(sp.bit_depth - 8));
+        for (int i = 0; i < 13; i++) bw.put1(i == 11 ? (sp.cu_qp_delta ? 1 : 0) : 0);       // all tools off; dquant_flag with cu_qp_delta
+        bw.ue(0); bw.ue(0);                              // log2_sub_gop_length = 0, log2_ref_pic_gap_length = 0
+        bw.ue((uint32_t)sp.max_num_ref_pics);
+        bw.put1(0); bw.put1(0); bw.put1(0);              // no cropping, default chroma QP table, no VUI
+        bw.align_zero();
+        write_nal(out, NUT_SPS, 0, bw);
+    }
+    void write_pps()
+    {
+        BitWriter bw;
+        bw.ue(0); bw.ue(0); bw.ue(0); bw.ue(0); bw.ue(0);
+        bw.put1(0); bw.put1(1); bw.ue(0); bw.put1(0); bw.put1(0); bw.put1(0);
+        bw.put1(0);                                      // constrained_intra_pred_flag
+        bw.put1(sp.cu_qp_delta ? 1 : 0);
+        if (sp.cu_qp_delta) bw.ue(0);
+        bw.align_zero();
+        write_nal(out, NUT_PPS, 0, bw);
+    }
+};
+
+extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
+{
+    if (!sp || sp->width <= 0 || sp->height <= 0 || (sp->width & 7) || (sp->height & 7) || sp->bit_depth < 8 || sp->bit_depth > 12) return nullptr;
+    xhost_writer *w = new xhost_writer();
+    w->sp = *sp;
+    Sps &s = w->st.sps;
+    s.width = sp->width; s.height = sp->height; s.bd_l = s.bd_c = sp->bit_depth; s.max_num_ref_pics = sp->max_num_ref_pics;
+    w->st.pps.cu_qp_delta = sp->cu_qp_delta;
+    return w;
+}
+extern "C" void xhost_writer_close(xhost_writer *w) { delete w; }
+extern "C" int xhost_writer_bytes(xhost_writer *w, const uint8_t **bytes, size_t *size)
+{
+    if (!w || !bytes || !size) return XGPU_ERR_INVALID_ARGUMENT;
+    *bytes = w->out.data(); *size = w->out.size();
+    return XGPU_OK;
+}
+
+namespace {
+struct TreeWriter {
+    xhost_writer *w;
+    const xgpu_cu_batch *b;
+    Enc *enc;
+    std::vector<int> leaf;        // CU index by SCU position of its top-left corner, -1 elsewhere
+    int bd_off;
+    int error = 0;
+    void node(int x, int y, int log2s)
+    {
+        Stream &st = w->st;
+        const int s = 1 << log2s, ws = st.pic.w_scu;
+        const int i = (x < st.sps.width && y < st.sps.height) ? leaf[(size_t)(y >> 2) * ws + (x >> 2)] : -1;
+        const bool is_leaf = i >= 0 && b->log2w[i] == log2s;
+        if (s >= 8) enc->bin(!is_leaf, st.models.split[0]);
+        else if (!is_leaf) { error = 1; return; }
+        if (!is_leaf) {
+            const int h = s >> 1;
+            for (int q = 0; q < 4; q++) {
+                const int nx = x + (q & 1) * h, ny = y + (q >> 1) * h;
+                if (nx < st.sps.width && ny < st.sps.height) node(nx, ny, log2s - 1);
+            }
+            return;
+        }
+        Cu cu;
+        memset(&cu, 0, sizeof(cu));
+        cu.x = x; cu.y = y; cu.log2w = cu.log2h = log2s;
+        cu.mode = b->pred_mode[i] == XGPU_MODE_INTRA ? MODE_INTRA : (b->pred_mode[i] == XGPU_MODE_SKIP ? MODE_SKIP : MODE_INTER);
+        if (st.sh.type == XHOST_SLICE_I) cu.mode = MODE_INTRA;
+        cu.refi[0] = std::max(0, std::min((int)b->refi[i * 2], (int)st.refp[0].size() - 1)); cu.refi[1] = -1;
+        cu.mv[0][0] = b->mv[i * 4]; cu.mv[0][1] = b->mv[i * 4 + 1];
+        cu.mvp_idx[0] = (x >> 2) & 3;                                  // a SKIP CU: some predictor
+        cu.ipm = b->ipm ? b->ipm[i * 2] % 5 : 0;
+        cu.qp = std::min(std::max((int)b->qp[i * 3] - bd_off, 0), 51);
+        for (int k = 0; k < 3; k++) cu.cbf[k] = cu.mode == MODE_SKIP ? 0 : (b->cbf[i] >> k) & 1;
+        // coefficient blocks: a coded component needs at least one non-zero value to be representable
+        std::vector<int16_t> blk[3];
+        int16_t *coef[3];
+        size_t off = b->coef_off[i];
+        for (int k = 0; k < 3; k++) {
+            const size_t n = (size_t)1 << (2 * log2s - (k ? 2 : 0));
+            blk[k].assign(n, 0);
+            if ((b->cbf[i] >> k) & 1) {
+                blk[k].assign(b->coef + off, b->coef + off + n);
+                off += n;
+                bool nz = false;
+                for (int16_t v : blk[k]) nz |= v != 0;
+                if (!nz) cu.cbf[k] = 0;
+            }
+            coef[k] = blk[k].data();
+        }
+        if (cu.mode == MODE_INTER && !(cu.cbf[0] | cu.cbf[1] | cu.cbf[2])) { /* all-zero flag path */ }
+        else if (cu.mode == MODE_INTER && cu.cbf[1] + cu.cbf[2] == 0) cu.cbf[0] = 1;      // implied luma cbf needs a luma coefficient
+        if (cu.mode == MODE_INTER && cu.cbf[0]) { bool nz = false; for (int16_t v : blk[0]) nz |= v != 0; if (!nz) blk[0][0] = 1; }
+        st.code_cu(*enc, cu, coef, true);
+        st.commit(cu);
+    }
+};
+}
+
+extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type, int slice_qp, const xgpu_cu_batch *b)
+{
+    if (!w || !b || slice_qp < 0 || slice_qp > 51) return XGPU_ERR_INVALID_ARGUMENT;
+    Stream &st = w->st;
+    if (w->n_pics == 0) { idr = 1; w->write_sps(); w->write_pps(); }
+    if (idr) slice_type = XHOST_SLICE_I;
+    if (slice_type == XHOST_SLICE_B) return XGPU_ERR_UNSUPPORTED;
+    st.sh.type = slice_type; st.sh.qp = slice_qp; st.sh.qp_u_offset = w->sp.qp_u_offset; st.sh.qp_v_offset = w->sp.qp_v_offset;
+    st.sh.deblock = w->sp.deblock_on ? 1 : 0;
+    if (idr) { st.poc = 0; st.prev_poc = 0; } else { st.poc = st.prev_poc + 1; st.prev_poc = st.poc; }
+    if (slice_type == XHOST_SLICE_I) st.last_intra_poc = st.poc;
+    st.build_ref_lists();
+    if (slice_type != XHOST_SLICE_I && st.refp[0].empty()) return XGPU_ERR_INVALID_ARGUMENT;
+
+    BitWriter bw;
+    bw.ue(0);                                            // slice_pic_parameter_set_id
+    bw.ue((uint32_t)slice_type);
+    if (idr) bw.put1(0);                                 // no_output_of_prior_pics_flag
+    if (slice_type != XHOST_SLICE_I) bw.put1(0);         // num_ref_idx_active_override_flag
+    bw.put1(st.sh.deblock);
+    bw.put((uint32_t)slice_qp, 6);
+    bw.se(st.sh.qp_u_offset); bw.se(st.sh.qp_v_offset);
+    bw.align_zero();
+
+    st.pic.reset(st.sps.width, st.sps.height);
+    st.models.reset();
+    st.qp_prev = slice_qp;
+    Enc enc;
+    enc.bw = &bw;
+    enc.start();
+    TreeWriter tw;
+    tw.w = w; tw.b = b; tw.enc = &enc; tw.bd_off = 6 * (st.sps.bd_l - 8);
+    tw.leaf.assign((size_t)st.pic.w_scu * st.pic.h_scu, -1);
+    for (int i = 0; i < b->n_cu; i++) {
+        if (b->log2w[i] != b->log2h[i] || b->log2w[i] < 2 || b->log2w[i] > 6 || b->x[i] + (1 << b->log2w[i]) > st.sps.width ||
+            b->y[i] + (1 << b->log2h[i]) > st.sps.height || (b->x[i] & ((1 << b->log2w[i]) - 1)) || (b->y[i] & ((1 << b->log2h[i]) - 1)))
+            return XGPU_ERR_INVALID_ARGUMENT;
+        tw.leaf[(size_t)(b->y[i] >> 2) * st.pic.w_scu + (b->x[i] >> 2)] = i;
+    }
+    const int w_ctu = (st.sps.width + 63) >> 6, h_ctu = (st.sps.height + 63) >> 6;
+    for (int cy = 0; cy < h_ctu; cy++) for (int cx = 0; cx < w_ctu; cx++) tw.node(cx << 6, cy << 6, 6);
+    if (tw.error) return XGPU_ERR_INVALID_ARGUMENT;
+    enc.tile_end();
+    write_nal(w->out, idr ? NUT_IDR : NUT_NONIDR, 0, bw);
+    std::vector<int> released;
+    st.store_picture(idr != 0, released);
+    w->n_pics++;
+    return XGPU_OK;
+}

@@ -1,0 +1,116 @@
+"""ctypes plumbing for the host front end (xevd_amd/libxevd_host.so, include/xevd_host.h): an EVC Baseline bitstream
+writer for synthetic CU batches and the parser that turns a .evc byte string back into CU batches + picture parameters.
+No arithmetic here."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_SO = os.path.join(_HERE, "libxevd_host.so")
+SLICE_B, SLICE_P, SLICE_I = 0, 1, 2
+
+
+class StreamParams(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("max_num_ref_pics", C.c_int),
+                ("qp_u_offset", C.c_int), ("qp_v_offset", C.c_int), ("deblock_on", C.c_int), ("cu_qp_delta", C.c_int)]
+
+
+class HostPicture(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth_luma", C.c_int), ("bit_depth_chroma", C.c_int),
+                ("poc", C.c_int), ("temporal_id", C.c_int), ("slice_type", C.c_int), ("is_idr", C.c_int), ("is_ref", C.c_int),
+                ("num_refp", C.c_int * 2), ("refp_poc", (C.c_int * 2) * abi.XGPU_MAX_REFS),
+                ("slice_qp", C.c_int), ("qp_u_offset", C.c_int), ("qp_v_offset", C.c_int), ("deblock_on", C.c_int),
+                ("n_release", C.c_int), ("release_poc", C.c_int * 32), ("batch", abi.CuBatch)]
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HOST_SO):
+            raise RuntimeError(f"{HOST_SO} is missing: build it with `make -C xevd_amd/host` (or __graft_entry__.build())")
+        lib = C.CDLL(HOST_SO)
+        lib.xhost_parser_open.restype = C.c_void_p
+        lib.xhost_parser_open.argtypes = [C.c_void_p, C.c_size_t]
+        lib.xhost_parser_next.argtypes = [C.c_void_p, C.POINTER(HostPicture)]
+        lib.xhost_parser_error.restype = C.c_char_p
+        lib.xhost_parser_error.argtypes = [C.c_void_p]
+        lib.xhost_parser_close.argtypes = [C.c_void_p]
+        lib.xhost_writer_open.restype = C.c_void_p
+        lib.xhost_writer_open.argtypes = [C.POINTER(StreamParams)]
+        lib.xhost_writer_add_picture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(abi.CuBatch)]
+        lib.xhost_writer_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+        lib.xhost_writer_close.argtypes = [C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+class StreamWriter:
+    def __init__(self, width, height, bit_depth=8, max_num_ref_pics=1, qp_u_offset=0, qp_v_offset=0, deblock=True, cu_qp_delta=True):
+        self.lib = load()
+        sp = StreamParams(width, height, bit_depth, max_num_ref_pics, qp_u_offset, qp_v_offset, int(deblock), int(cu_qp_delta))
+        self.h = self.lib.xhost_writer_open(C.byref(sp))
+        if not self.h:
+            raise ValueError("xhost_writer_open: bad stream parameters")
+
+    def add_picture(self, batch, slice_type=SLICE_P, slice_qp=32, idr=False):
+        cb, keep = abi.make_cu_batch(batch)
+        rc = self.lib.xhost_writer_add_picture(self.h, int(idr), slice_type, slice_qp, C.byref(cb))
+        if rc != 0:
+            raise RuntimeError(f"xhost_writer_add_picture -> {rc}")
+
+    def bytes(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self.lib.xhost_writer_bytes(self.h, C.byref(p), C.byref(n))
+        return C.string_at(p, n.value)
+
+    def close(self):
+        if self.h:
+            self.lib.xhost_writer_close(self.h)
+            self.h = None
+
+
+def _arr(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+def parse_stream(data):
+    """-> list of pictures in decoding order: dict(params..., batch=dict of numpy arrays in the layout of synth.gen_frame)"""
+    lib = load()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    h = lib.xhost_parser_open(buf, len(data))
+    pics = []
+    try:
+        while True:
+            hp = HostPicture()
+            rc = lib.xhost_parser_next(h, C.byref(hp))
+            if rc == 0:
+                break
+            if rc < 0:
+                raise RuntimeError(f"xhost_parser_next -> {rc}: {lib.xhost_parser_error(h).decode()}")
+            b, n = hp.batch, hp.batch.n_cu
+            batch = {
+                "x": _arr(b.x, n, np.uint16), "y": _arr(b.y, n, np.uint16), "log2w": _arr(b.log2w, n, np.uint8), "log2h": _arr(b.log2h, n, np.uint8),
+                "pred_mode": _arr(b.pred_mode, n, np.uint8), "refi": _arr(b.refi, n * 2, np.int8).reshape(n, 2),
+                "mv": _arr(b.mv, n * 4, np.int16).reshape(n, 2, 2), "qp": _arr(b.qp, n * 3, np.uint8).reshape(n, 3),
+                "cbf": _arr(b.cbf, n, np.uint8), "cbf_sub": None, "ats": None, "ats_inter": None, "ipm": _arr(b.ipm, n * 2, np.uint8).reshape(n, 2),
+                "coef_off": _arr(b.coef_off, n, np.uint32), "coef": _arr(b.coef, max(b.n_coef, 1), np.int16), "n_coef": int(b.n_coef),
+                "ctu_cu_start": _arr(b.ctu_cu_start, b.n_ctu + 1, np.uint32), "constrained_intra_pred": int(b.constrained_intra_pred),
+            }
+            pics.append({
+                "width": hp.width, "height": hp.height, "bit_depth": hp.bit_depth_luma, "poc": hp.poc, "slice_type": hp.slice_type,
+                "is_idr": bool(hp.is_idr), "is_ref": bool(hp.is_ref),
+                "refs": [[hp.refp_poc[i][l] for i in range(hp.num_refp[l])] for l in range(2)],
+                "slice_qp": hp.slice_qp, "qp_u_offset": hp.qp_u_offset, "qp_v_offset": hp.qp_v_offset, "deblock_on": bool(hp.deblock_on),
+                "release": [hp.release_poc[i] for i in range(hp.n_release)], "batch": batch,
+            })
+    finally:
+        lib.xhost_parser_close(h)
+    return pics
