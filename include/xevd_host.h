@@ -12,7 +12,8 @@
  * Wire format: 4-byte big-endian NAL length prefix (XEVD_NAL_UNIT_LENGTH_BYTE, inc/xevd.h:133; app/xevd_app.c:52-107),
  * 2-byte NAL header (xevd_eco.c:1178-1209).
  *
- * Scope: Baseline profile, 4:2:0, one tile and one slice per picture, I and P slices (sps->tool_* all 0).
+ * Scope: Baseline profile, 4:2:0, one tile and one slice per picture, I / P / B slices incl. temporal layers (hierarchical
+ * sub-GOPs), sps->tool_* all 0.
  * Conventions as xevd_hip.h: 0 / negative XEVD_ERR_* codes, nothing throws, one object per stream.
  */
 #ifndef XEVD_HOST_H
@@ -58,6 +59,8 @@ typedef struct xhost_stream_params {
     int width, height;                     /* multiples of 8                                                        */
     int bit_depth;                         /* luma = chroma                                                         */
     int max_num_ref_pics;                  /* sps->max_num_ref_pics                                                 */
+    int log2_sub_gop_length;               /* sps->log2_sub_gop_length: 0 = low delay; n = hierarchical sub-GOPs of 2^n pictures
+                                              (decoding order per sub-GOP: temporal ids 0, 1, 2, 2, 3, 3, 3, 3, ...)  */
     int qp_u_offset, qp_v_offset;          /* sh.qp_u_offset / qp_v_offset                                          */
     int deblock_on;                        /* sh.deblocking_filter_on                                               */
     int cu_qp_delta;                       /* pps.cu_qp_delta_enabled_flag: per-CU QPs of coded CUs are transmitted  */
@@ -65,10 +68,11 @@ typedef struct xhost_stream_params {
 
 xhost_writer *xhost_writer_open(const xhost_stream_params *sp);
 /* Appends one picture (SPS + PPS first when it is the first).  `b`: leaf CUs of a quad tree (64..4) in decode order with the
-   fields of xgpu_cu_batch; per CU the writer keeps pred_mode (INTRA / INTER / SKIP), refi[0], mv[0] (INTER; a SKIP CU takes
-   the motion of a predictor), qp[0] (luma dequant QP incl. 6*(bd-8), used when the CU has coefficients and cu_qp_delta is on),
-   cbf, ipm[0], coefficients.  idr != 0 forces an IDR picture with an I slice. */
-int  xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type, int slice_qp, const xgpu_cu_batch *b);
+   fields of xgpu_cu_batch; per CU the writer keeps pred_mode (INTRA / INTER / SKIP / DIR), refi and mv of the lists in use
+   (INTER: refi[l] >= 0 selects the lists, indices are clamped to the actual list sizes; SKIP / DIR CUs take derived motion),
+   qp[0] (luma dequant QP incl. 6*(bd-8), used when the CU has coefficients and cu_qp_delta is on), cbf, ipm[0], coefficients.
+   idr != 0 forces an IDR picture with an I slice.  temporal_id: nuh_temporal_id (0 for low-delay streams). */
+int  xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type, int slice_qp, int temporal_id, const xgpu_cu_batch *b);
 int  xhost_writer_bytes(xhost_writer *w, const uint8_t **bytes, size_t *size);
 void xhost_writer_close(xhost_writer *w);
 

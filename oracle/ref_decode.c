@@ -22,7 +22,7 @@ int refd_decode(const uint8_t *bytes, size_t size, int threads, int16_t *out, in
     XEVD_STAT stat;
     XEVD_IMGB *imgb;
     size_t pos = 0;
-    int n = 0, ret, bumping = 0;
+    int n = 0, ret, bumping = 0, idle = 0;
     const size_t pic_elems = (size_t)w * h * 3 / 2;
 
     memset(&cdsc, 0, sizeof(cdsc));
@@ -48,7 +48,10 @@ int refd_decode(const uint8_t *bytes, size_t size, int threads, int16_t *out, in
         ret = xevd_pull(id, &imgb);
         if (ret == XEVD_ERR_UNEXPECTED) break;                 /* bumping completed */
         if (XEVD_FAILED(ret)) { xevd_delete(id); return -4000 + ret; }
+        /* a stream that ends inside a sub-GOP leaves pictures the reference never outputs (it waits for the missing POC for ever) */
+        if (bumping && !imgb && ++idle > 64) break;
         if (imgb) {
+            idle = 0;
             if (n < max_pics) {
                 int16_t *dst = out + (size_t)n * pic_elems;
                 int c, r;

@@ -144,7 +144,9 @@ def golden_pictures(only=None):
 def golden_streams():
     import stream_util as su
     for name, (w, h, n, kw) in {"ippp_8b": (208, 120, 5, dict(max_refs=2)), "ippp_10b_offsets": (144, 88, 4, dict(bit_depth=10, qp_offsets=(1, -2))),
-                                "idr_period_skip": (72, 136, 6, dict(max_refs=4, skip_frac=0.4, idr_period=4))}.items():
+                                "idr_period_skip": (72, 136, 6, dict(max_refs=4, skip_frac=0.4, idr_period=4)),
+                                "hier_b_gop4": (208, 120, 9, dict(log2_sub_gop=2, max_refs=2)),
+                                "hier_b_gop8_10b": (136, 136, 9, dict(log2_sub_gop=3, max_refs=3, bit_depth=10, direct_frac=0.3))}.items():
         data = su.make_stream(w, h, n, seed=len(name) * 13 + n, **kw)
         ref = su.decode_reference(data, w, h)
         assert len(ref) == n

@@ -15,21 +15,40 @@ def have_ref_decoder():
     return os.path.exists(REF_DECODE)
 
 
+def gop_tids(log2_sub_gop):
+    """temporal ids of one sub-GOP in decoding order: 0, 1, 2, 2, 3, 3, 3, 3, ... (xevd_poc_derivation's expected order)"""
+    tids = [0]
+    for t in range(1, log2_sub_gop + 1):
+        tids += [t] * (1 << (t - 1))
+    return tids
+
+
 def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_frac=0.15, inter_frac=0.85, deblock=True, qp_offsets=(0, 0),
-                cu_qp_delta=True, split_prob=0.5, idr_period=0):
-    """-> bytes.  Picture 0 is an IDR; the others are P pictures over synthetic CU batches (quad tree 64..4)."""
+                cu_qp_delta=True, split_prob=0.5, idr_period=0, log2_sub_gop=0, bi_frac=0.5, direct_frac=0.1):
+    """-> bytes.  Picture 0 is an IDR.  log2_sub_gop = 0: IPPP; n: hierarchical sub-GOPs of 2^n pictures, the layer-0 picture of
+    each a P picture, the others B pictures (bi-prediction, temporal direct and two-list skip CUs)."""
     rng = np.random.default_rng(seed)
-    w = stream.StreamWriter(width, height, bit_depth, max_refs, qp_offsets[0], qp_offsets[1], deblock, cu_qp_delta)
+    w = stream.StreamWriter(width, height, bit_depth, max_refs, qp_offsets[0], qp_offsets[1], deblock, cu_qp_delta, log2_sub_gop)
+    tids = gop_tids(log2_sub_gop)
     try:
+        since_idr = 0
         for k in range(n_pics):
             idr = k == 0 or (idr_period and k % idr_period == 0)
-            n_refs_now = 1 if idr else min(max_refs, (k % idr_period) if idr_period else k, 4)
-            b = synth.gen_frame(rng, width, height, bit_depth, inter_frac=0.0 if idr else inter_frac, n_refs=(max(n_refs_now, 1), 0),
-                                split_prob=split_prob, coded_frac=0.6, max_level=6, amp=1.0)
+            if idr:
+                since_idr = 0
+            tid = 0 if idr else tids[(since_idr - 1) % len(tids)]
+            is_b = (not idr) and tid > 0
+            b = synth.gen_frame(rng, width, height, bit_depth, inter_frac=0.0 if idr else inter_frac, n_refs=(max_refs, max_refs if is_b else 0),
+                                bi_frac=bi_frac if is_b else 0.0, split_prob=split_prob, coded_frac=0.6, max_level=6, amp=1.0)
             if not idr:
                 inter = b["pred_mode"] == 1
-                b["pred_mode"] = np.where(inter & (rng.random(len(inter)) < skip_frac), 2, b["pred_mode"]).astype(np.uint8)
-            w.add_picture(b, stream.SLICE_I if idr else stream.SLICE_P, slice_qp=int(rng.integers(24, 40)), idr=idr)
+                r = rng.random(len(inter))
+                b["pred_mode"] = np.where(inter & (r < skip_frac), 2, b["pred_mode"]).astype(np.uint8)
+                if is_b:
+                    b["pred_mode"] = np.where(inter & (r >= skip_frac) & (r < skip_frac + direct_frac), 3, b["pred_mode"]).astype(np.uint8)
+            w.add_picture(b, stream.SLICE_I if idr else (stream.SLICE_B if is_b else stream.SLICE_P), slice_qp=int(rng.integers(24, 40)), idr=idr,
+                          temporal_id=tid)
+            since_idr += 1
         return w.bytes()
     finally:
         w.close()
@@ -58,16 +77,26 @@ def decode_reference(data, width, height, max_pics=64, threads=1):
     return pics
 
 
+def _output_order(pics):
+    """decoding order -> output order: ascending POC inside every IDR period (what xevd_pull's bumping produces)"""
+    out, epoch = [], -1
+    for p, planes in pics:
+        if p["is_idr"]:
+            epoch += 1
+        out.append(((epoch, p["poc"]), planes))
+    return [v for _, v in sorted(out, key=lambda kv: kv[0])]
+
+
 def decode_oracle(data):
-    """Our parser + the CPU oracle (oracle/liboracle.so). -> pictures in POC order."""
+    """Our parser + the CPU oracle (oracle/liboracle.so). -> pictures in output order."""
     o = ol.oracle()
-    dpb, out = {}, {}
+    dpb, out = {}, []
     for p in stream.parse_stream(data):
         w, h, bd = p["width"], p["height"], p["bit_depth"]
         sp = abi.make_seq_params(w, h, bd)
         cb, keep = abi.make_cu_batch(p["batch"])
         cur = ol.Picture(w, h, p["poc"])
-        refs = {(i, 0): dpb[poc] for i, poc in enumerate(p["refs"][0])}
+        refs = {(i, l): dpb[poc] for l in range(2) for i, poc in enumerate(p["refs"][l])}
         fr = ol.make_frame(cur, refs, p["qp_u_offset"], p["qp_v_offset"])
         maps = ol.Maps(w, h)
         m = maps.orc()
@@ -79,35 +108,39 @@ def decode_oracle(data):
             dpb.clear()
         for poc in p["release"]:
             dpb.pop(poc, None)
-        dpb[p["poc"]] = cur
-        out[(len([k for k in out if k[1] >= 0]), p["poc"])] = [cur.active(c).copy() for c in range(3)]
-    return [v for _, v in sorted(out.items(), key=lambda kv: kv[0][0])]
+        if p["is_ref"]:
+            dpb[p["poc"]] = cur
+        out.append((p, [cur.active(c).copy() for c in range(3)]))
+    return _output_order(out)
 
 
 def decode_gpu(data):
-    """Our parser + the HIP backend through the C ABI. -> pictures in decoding order (= output order for IPPP)."""
+    """Our parser + the HIP backend through the C ABI. -> pictures in output order."""
     from xevd_amd.decoder import XgpuDecoder
     pics = stream.parse_stream(data)
     if not pics:
         return []
     w, h, bd = pics[0]["width"], pics[0]["height"], pics[0]["bit_depth"]
     out = []
-    with XgpuDecoder(w, h, bd, max_pics=8) as dec:
-        slots, free = {}, [dec.pic_alloc() for _ in range(7)]
+    with XgpuDecoder(w, h, bd, max_pics=12) as dec:
+        slots, free = {}, [dec.pic_alloc() for _ in range(10)]
         for p in pics:
             if p["is_idr"]:
                 free.extend(slots.values()); slots.clear()
-            for poc in p["release"]:
-                if poc in slots:
-                    free.append(slots.pop(poc))
             cur = free.pop()
-            refs = {(i, 0): (slots[poc], poc) for i, poc in enumerate(p["refs"][0])}
+            refs = {(i, l): (slots[poc], poc) for l in range(2) for i, poc in enumerate(p["refs"][l])}
             hb = dec.batch_create(p["batch"])
             dec.decode_picture(cur, p["poc"], refs, hb, deblock=p["deblock_on"], pad=True, qp_u_offset=p["qp_u_offset"], qp_v_offset=p["qp_v_offset"])
             dec.sync()
             planes = dec.pic_download_padded(cur)
-            out.append([planes[c][(abi.PAD_L if c == 0 else abi.PAD_C):-(abi.PAD_L if c == 0 else abi.PAD_C),
-                                  (abi.PAD_L if c == 0 else abi.PAD_C):-(abi.PAD_L if c == 0 else abi.PAD_C)].copy() for c in range(3)])
+            pad = (abi.PAD_L, abi.PAD_C, abi.PAD_C)
+            out.append((p, [planes[c][pad[c]:-pad[c], pad[c]:-pad[c]].copy() for c in range(3)]))
             dec.batch_destroy(hb)
-            slots[p["poc"]] = cur
-    return out
+            for poc in p["release"]:          # unmarked when THIS picture is stored (it may still have referenced them)
+                if poc in slots:
+                    free.append(slots.pop(poc))
+            if p["is_ref"]:
+                slots[p["poc"]] = cur
+            else:
+                free.append(cur)
+    return _output_order(out)

@@ -20,6 +20,12 @@ CONFIGS = [
     (72, 136, 7, dict(max_refs=4, skip_frac=0.4, idr_period=4)),
     (136, 136, 3, dict(deblock=False, cu_qp_delta=False)),
     (200, 72, 4, dict(inter_frac=0.5, split_prob=0.7)),
+    # hierarchical sub-GOPs (temporal layers): B slices with bi-prediction, temporal direct mode, two-list skip; whole sub-GOPs only -
+    # the reference never outputs the pictures of a sub-GOP whose lower POCs are missing
+    (136, 72, 7, dict(log2_sub_gop=1, max_refs=2)),
+    (208, 120, 9, dict(log2_sub_gop=2, max_refs=2)),
+    (144, 136, 17, dict(log2_sub_gop=3, max_refs=3, bit_depth=10)),
+    (136, 136, 9, dict(log2_sub_gop=2, max_refs=4, direct_frac=0.4, skip_frac=0.3)),
 ]
 
 

@@ -200,12 +200,14 @@ struct Slice { int type = XHOST_SLICE_I, qp = 32, qp_u_offset = 0, qp_v_offset =
 
 struct RefPic {          // what a decoded picture leaves behind for later pictures (XEVD_PIC map_mv / list_poc, xevd_picman.c:213-221)
     int poc = 0, tid = 0;
+    int list0_poc = 0;               // POC of reference 0 of ITS list 0 (pic->list_poc[0]); temporal direct mode scales by it
     std::vector<int16_t> mv0;        // [f_scu][2]: list-0 motion of every SCU (refp.map_mv[scup][REFP_0])
 };
 
 struct Cu {
     int x, y, log2w, log2h;
     int mode;                        // MODE_INTRA / MODE_INTER / MODE_SKIP
+    int direct;                      // B slices: temporal direct mode (inter_dir = PRED_DIR), no motion syntax
     int refi[2], mvp_idx[2];
     int16_t mvd[2][2], mv[2][2];
     int ipm, cbf[3], qp;
@@ -242,32 +244,70 @@ struct Stream {          // everything both directions share
     Models models;
     std::vector<RefPic> dpb;         // reference pictures in coding order (pm->pic[] restricted to IS_REF)
     std::vector<const RefPic *> refp[2];
-    int poc = 0, prev_poc = 0, last_intra_poc = 0, qp_prev = 0;
+    int poc = 0, prev_poc = 0, prev_doc_offset = -1, tid = 0, last_intra_poc = 0, qp_prev = 0, stale_list0_poc = 0;
     bool have_sps = false, have_pps = false;
     std::vector<uint16_t> scan[6][6];      // zig-zag tables by log2 size - 1
 
     Stream() { for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) make_zigzag(scan[a][b], 2 << a, 2 << b); }
 
-    // reference lists without RPL for temporal layer 0 (xevd_picman_refp_init, xevd_picman.c:291-437): all reference pictures by
-    // descending POC, those before the current picture (and not before the last intra picture), at most max_num_ref_pics
+    // POC of the next picture (xevd.c:1846-1861, xevd_poc_derivation xevd_util.c:429-467)
+    void derive_poc(bool idr, int t)
+    {
+        tid = t;
+        if (idr) { poc = 0; prev_doc_offset = -1; prev_poc = 0; return; }
+        const int sub = 1 << sps.log2_sub_gop;
+        if (t == 0) { poc = prev_poc + sub; prev_doc_offset = 0; prev_poc = poc; return; }
+        auto ilog2 = [](int v) { int l = 0; while ((v >> (l + 1)) > 0) l++; return l; };
+        int doc = (prev_doc_offset + 1) % sub, expected = 0;
+        if (doc == 0) prev_poc += sub; else expected = 1 + ilog2(doc);
+        for (int guard = 0; t != expected && guard < 4 * sub; guard++) { doc = (doc + 1) % sub; expected = doc == 0 ? 0 : 1 + ilog2(doc); }
+        poc = prev_poc + (int)(sub * ((2.0 * doc + 1) / (double)(1 << t) - 2));
+        prev_doc_offset = doc;
+    }
+    bool is_ref_picture() const { return tid == 0 || tid < sps.log2_sub_gop; }      // ctx->slice_ref_flag, xevd.c:1853
+
+    // reference lists without RPL (xevd_picman_refp_init, xevd_picman.c:291-437) over the reference pictures by descending POC
     void build_ref_lists()
     {
         refp[0].clear(); refp[1].clear();
         if (sh.type == XHOST_SLICE_I) return;
-        std::vector<const RefPic *> sorted;
-        for (const RefPic &r : dpb) sorted.push_back(&r);
-        std::sort(sorted.begin(), sorted.end(), [](const RefPic *a, const RefPic *b) { return a->poc > b->poc; });
-        for (const RefPic *r : sorted) {
-            if ((int)refp[0].size() >= sps.max_num_ref_pics) break;
-            if (poc >= last_intra_poc && r->poc < last_intra_poc) continue;
-            if (r->poc < poc) refp[0].push_back(r);
+        std::vector<const RefPic *> ref;
+        for (const RefPic &r : dpb) ref.push_back(&r);
+        std::stable_sort(ref.begin(), ref.end(), [](const RefPic *a, const RefPic *b) { return a->poc > b->poc; });
+        const int maxn = sps.max_num_ref_pics, n = (int)ref.size();
+        auto old = [&](const RefPic *r) { return poc >= last_intra_poc && r->poc < last_intra_poc; };
+        if (sh.type == XHOST_SLICE_P) {
+            for (int i = 0; i < n && (int)refp[0].size() < maxn; i++) {
+                const RefPic *r = ref[i];
+                if (tid > 0) {
+                    if (tid == 1) { if (r->poc < poc && r->tid <= tid) refp[0].push_back(r); }
+                    else if (r->poc < poc && refp[0].empty()) refp[0].push_back(r);
+                    else if (!refp[0].empty() && r->poc < poc && r->tid <= 1) refp[0].push_back(r);
+                } else {
+                    if (old(r)) continue;
+                    if (r->poc < poc) refp[0].push_back(r);
+                }
+            }
+            return;
+        }
+        // B: nearest pictures first, each step allowed one temporal layer further down than the picture just taken
+        for (int l = 0; l < 2; l++) {
+            for (int pass = 0; pass < 2; pass++) {
+                int next_layer = std::max(tid - 1, 0);
+                const bool backward = (l == 0) == (pass == 0);             // list 0: earlier pictures first; list 1: later pictures first
+                for (int k = 0; k < n && (int)refp[l].size() < maxn; k++) {
+                    const RefPic *r = backward ? ref[k] : ref[n - 1 - k];
+                    if (old(r)) continue;
+                    if ((backward ? r->poc < poc : r->poc > poc) && r->tid <= next_layer) { refp[l].push_back(r); next_layer = std::max(r->tid - 1, 0); }
+                }
+            }
         }
     }
     // picture marking + insertion (xevd_picman_put_pic / pic_marking_no_rpl, xevd_picman.c:68-110,462-509); released POCs reported
     void store_picture(bool idr, std::vector<int> &released)
     {
         if (idr) { for (const RefPic &r : dpb) released.push_back(r.poc); dpb.clear(); }
-        else {
+        else if (tid == 0) {
             const int gap = 1 << sps.log2_ref_gap;
             for (size_t i = 0; i < dpb.size();) {
                 if (dpb[i].tid > 0 || (i > 0 && gap > 0 && dpb[i].poc % gap != 0)) { released.push_back(dpb[i].poc); dpb.erase(dpb.begin() + (long)i); }
@@ -275,8 +315,11 @@ struct Stream {          // everything both directions share
             }
             while (dpb.size() >= 5) { released.push_back(dpb[0].poc); dpb.erase(dpb.begin()); }      // XEVD_MAX_NUM_ACTIVE_REF_FRAME
         }
+        // pic->list_poc[0] = POC of refp[0][REFP_0]; an I slice leaves num_refp untouched, so the previous picture's value stays
+        if (sh.type != XHOST_SLICE_I) stale_list0_poc = refp[0].empty() ? 0 : refp[0][0]->poc;
+        if (!is_ref_picture()) return;
         RefPic r;
-        r.poc = poc; r.tid = 0;
+        r.poc = poc; r.tid = tid; r.list0_poc = stale_list0_poc;
         const size_t f = (size_t)pic.w_scu * pic.h_scu;
         r.mv0.resize(f * 2);
         for (size_t k = 0; k < f; k++) { r.mv0[k * 2] = pic.mv[k * 4]; r.mv0[k * 2 + 1] = pic.mv[k * 4 + 1]; }
@@ -299,6 +342,20 @@ struct Stream {          // everything both directions share
         const RefPic *col = refp[lidx].empty() ? nullptr : refp[lidx][0];
         cand[3][0] = col ? col->mv0[(size_t)scup * 2] : (int16_t)0;
         cand[3][1] = col ? col->mv0[(size_t)scup * 2 + 1] : (int16_t)0;
+    }
+    // temporal direct motion of a B CU (xevd_get_mv_dir, xevd_util.c:540-566; call site xevd.c:713-717): the list-0 motion the
+    // co-located picture (reference 0 of list 1) stored at the CU's bottom-right SCU, scaled by POC distances (C division)
+    void direct_motion(Cu &cu) const
+    {
+        const int ws = pic.w_scu, scup = (cu.y >> 2) * ws + (cu.x >> 2);
+        const int c_scu = scup + (((1 << cu.log2w) >> 2) - 1) + (((1 << cu.log2h) >> 2) - 1) * ws;
+        const RefPic *r0 = refp[0][0], *col = refp[1][0];
+        const int mvx = col->mv0[(size_t)c_scu * 2], mvy = col->mv0[(size_t)c_scu * 2 + 1];
+        const int dco = col->poc - col->list0_poc, d0 = poc - r0->poc, d1 = col->poc - poc;
+        cu.refi[0] = cu.refi[1] = 0;
+        if (dco == 0) { memset(cu.mv, 0, sizeof(cu.mv)); return; }
+        cu.mv[0][0] = (int16_t)(d0 * mvx / dco); cu.mv[0][1] = (int16_t)(d0 * mvy / dco);
+        cu.mv[1][0] = (int16_t)(-d1 * mvx / dco); cu.mv[1][1] = (int16_t)(-d1 * mvy / dco);
     }
     // code-number table of the luma intra mode (xevd_get_mpm_b, xevd_ipred.c:678-692): neighbours count when intra and already parsed
     const uint8_t *mpm_list(const Cu &cu) const
@@ -366,50 +423,65 @@ struct Stream {          // everything both directions share
         if (!enc) { cu.mode = skip ? MODE_SKIP : MODE_INTRA; cu.refi[0] = cu.refi[1] = -1; memset(cu.mv, 0, sizeof(cu.mv)); memset(cu.mvd, 0, sizeof(cu.mvd));
                     cu.mvp_idx[0] = cu.mvp_idx[1] = 0; cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0; cu.ipm = 0; }
         int16_t cand[4][2];
+        const int n_lists = sh.type == XHOST_SLICE_B ? 2 : 1;
         if (skip) {
-            // the motion of candidate mvp_idx, reference 0 (xevd_get_skip_motion, xevd.c:502-531)
-            cu.mvp_idx[0] = sym_trunc_unary(c, cu.mvp_idx[0], models.mvp_idx, 3, 4);
-            mvp_candidates(cu, 0, cand);
-            cu.refi[0] = 0; cu.refi[1] = -1;
-            cu.mv[0][0] = cand[cu.mvp_idx[0]][0]; cu.mv[0][1] = cand[cu.mvp_idx[0]][1]; cu.mv[1][0] = cu.mv[1][1] = 0;
+            // the motion of candidate mvp_idx of every list, reference 0 (xevd_get_skip_motion, xevd.c:502-531; syntax xevd_eco.c:1079-1085)
+            for (int l = 0; l < n_lists; l++) cu.mvp_idx[l] = sym_trunc_unary(c, cu.mvp_idx[l], models.mvp_idx, 3, 4);
+            cu.refi[1] = -1; cu.mv[1][0] = cu.mv[1][1] = 0;
+            for (int l = 0; l < n_lists; l++) {
+                mvp_candidates(cu, l, cand);
+                cu.refi[l] = 0; cu.mv[l][0] = cand[cu.mvp_idx[l]][0]; cu.mv[l][1] = cand[cu.mvp_idx[l]][1];
+            }
             cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0;
             cu.qp = qp_prev;                                         // xevd_eco.c:1091-1115 (cu_qp_delta on: previous QP; off: slice QP = the same)
             return;
         }
         int intra = 1;
         if (inter_slice) intra = c.bin(cu.mode == MODE_INTRA, models.pred_mode[0]);
-        if (!enc) cu.mode = intra ? MODE_INTRA : MODE_INTER;
+        if (!enc) { cu.mode = intra ? MODE_INTRA : MODE_INTER; cu.direct = 0; }
         if (!intra) {
-            // P slice: list 0 only (inter_dir = PRED_L0): ref index, predictor index, mvd (xevd_eco.c:1134-1146); mv = mvp + mvd (xevd.c:533-556)
-            const int nref = (int)refp[0].size();
-            if (nref > 1) {                                          // xevd_eco_refi, xevd_eco.c:409-436
-                int r = cu.refi[0], v = 0;
-                if (c.bin(r > 0, models.refi[0])) {
-                    v = 1;
-                    if (nref > 2 && c.bin(r > 1, models.refi[1])) {
-                        v = 2;
-                        for (; v < nref - 1; v++) if (!c.ep(r > v)) break;
-                    }
+            // xevd_eco.c:1120-1148: B: direct_mode_flag, else inter_pred_idc; per list in use: ref index, predictor index, mvd; mv = mvp + mvd (xevd.c:533-556)
+            int dir = 0;                                             // PRED_L0 0, PRED_L1 1, PRED_BI 2
+            if (n_lists == 2) cu.direct = c.bin(cu.direct, models.direct[0]);
+            if (cu.direct) direct_motion(cu);
+            else {
+                if (n_lists == 2) {
+                    if (enc) dir = (cu.refi[0] >= 0 && cu.refi[1] >= 0) ? 2 : (cu.refi[1] >= 0 ? 1 : 0);
+                    if (!c.bin(dir != 2, models.inter_dir[0])) dir = 2;
+                    else dir = c.bin(dir == 1, models.inter_dir[1]) ? 1 : 0;
                 }
-                cu.refi[0] = v;
-            } else cu.refi[0] = 0;
-            cu.refi[1] = -1;
-            mvp_candidates(cu, 0, cand);
-            if (enc) {                                               // cheapest predictor
-                int best = 0, cost = 1 << 30;
-                for (int k = 0; k < 4; k++) { const int d = abs(cu.mv[0][0] - cand[k][0]) + abs(cu.mv[0][1] - cand[k][1]); if (d < cost) { cost = d; best = k; } }
-                cu.mvp_idx[0] = best;
-                cu.mvd[0][0] = (int16_t)(cu.mv[0][0] - cand[best][0]); cu.mvd[0][1] = (int16_t)(cu.mv[0][1] - cand[best][1]);
+                for (int l = 0; l < 2; l++) {
+                    if (!(((dir + 1) >> l) & 1)) { cu.refi[l] = -1; cu.mv[l][0] = cu.mv[l][1] = 0; continue; }
+                    const int nref = (int)refp[l].size();
+                    if (nref > 1) {                                  // xevd_eco_refi, xevd_eco.c:409-436
+                        const int r = cu.refi[l];
+                        int v = 0;
+                        if (c.bin(r > 0, models.refi[0])) {
+                            v = 1;
+                            if (nref > 2 && c.bin(r > 1, models.refi[1])) {
+                                v = 2;
+                                for (; v < nref - 1; v++) if (!c.ep(r > v)) break;
+                            }
+                        }
+                        cu.refi[l] = v;
+                    } else cu.refi[l] = 0;
+                    mvp_candidates(cu, l, cand);
+                    if (enc) {                                       // cheapest predictor
+                        int best = 0, cost = 1 << 30;
+                        for (int k = 0; k < 4; k++) { const int d = abs(cu.mv[l][0] - cand[k][0]) + abs(cu.mv[l][1] - cand[k][1]); if (d < cost) { cost = d; best = k; } }
+                        cu.mvp_idx[l] = best;
+                        cu.mvd[l][0] = (int16_t)(cu.mv[l][0] - cand[best][0]); cu.mvd[l][1] = (int16_t)(cu.mv[l][1] - cand[best][1]);
+                    }
+                    cu.mvp_idx[l] = sym_trunc_unary(c, cu.mvp_idx[l], models.mvp_idx, 3, 4);
+                    for (int d = 0; d < 2; d++) {                    // xevd_eco_get_mvd, xevd_eco.c:491-536
+                        const int v = cu.mvd[l][d], a = sym_abs_mvd(c, v < 0 ? -v : v, models.mvd[0]);
+                        int sg = v < 0;
+                        if (a) sg = c.ep(sg);
+                        cu.mvd[l][d] = (int16_t)(sg ? -a : a);
+                    }
+                    cu.mv[l][0] = (int16_t)(cand[cu.mvp_idx[l]][0] + cu.mvd[l][0]); cu.mv[l][1] = (int16_t)(cand[cu.mvp_idx[l]][1] + cu.mvd[l][1]);
+                }
             }
-            cu.mvp_idx[0] = sym_trunc_unary(c, cu.mvp_idx[0], models.mvp_idx, 3, 4);
-            for (int d = 0; d < 2; d++) {                            // xevd_eco_get_mvd, xevd_eco.c:491-536
-                const int v = cu.mvd[0][d], a = sym_abs_mvd(c, v < 0 ? -v : v, models.mvd[0]);
-                int s = v < 0;
-                if (a) s = c.ep(s);
-                cu.mvd[0][d] = (int16_t)(s ? -a : a);
-            }
-            cu.mv[0][0] = (int16_t)(cand[cu.mvp_idx[0]][0] + cu.mvd[0][0]); cu.mv[0][1] = (int16_t)(cand[cu.mvp_idx[0]][1] + cu.mvd[0][1]);
-            cu.mv[1][0] = cu.mv[1][1] = 0;
         } else {
             const uint8_t *mpm = mpm_list(cu);                       // xevd_eco_intra_dir_b, xevd_eco.c:826-846: the code number is sent
             const int code = sym_unary(c, mpm[cu.ipm], models.intra_dir, 2);
@@ -487,7 +559,7 @@ struct xhost_parser {
         if (tools) return fail("Main-profile tools are not supported by this front end");
         s.log2_sub_gop = (int)br.ue();                   // tool_rpl = tool_pocs = 0
         if (s.log2_sub_gop == 0) s.log2_ref_gap = (int)br.ue();
-        else return fail("temporal layers (sub-GOP > 1) are not supported yet");
+        if (s.log2_sub_gop > 5) return fail("bad SPS");
         s.max_num_ref_pics = (int)br.ue();
         if (br.get1()) { br.ue(); br.ue(); br.ue(); br.ue(); }      // cropping offsets (output cropping is the caller's business)
         if (br.get1()) return fail("chroma QP tables in the SPS are not supported yet");
@@ -512,23 +584,22 @@ struct xhost_parser {
     int parse_slice(BitReader &br, int nut, int tid, xhost_picture *out)
     {
         if (!st.have_sps || !st.have_pps) return fail("slice before SPS/PPS");
-        if (tid != 0) return fail("temporal layers are not supported yet");
         Slice &sh = st.sh;
         br.ue();                                         // slice_pic_parameter_set_id; single tile: no tile ids
         sh.type = (int)br.ue();
-        if (sh.type == XHOST_SLICE_B) return fail("B slices are not supported yet");
+        if (sh.type < 0 || sh.type > 2) return fail("bad slice type");
         if (nut == NUT_IDR) br.get1();                   // no_output_of_prior_pics_flag
-        if (sh.type != XHOST_SLICE_I && br.get1()) br.ue();      // num_ref_idx_active override (unused by the Baseline decoder, xevd_eco.c:409)
+        if (sh.type != XHOST_SLICE_I && br.get1()) { br.ue(); if (sh.type == XHOST_SLICE_B) br.ue(); }      // num_ref_idx_active override (unused by the Baseline decoder, xevd_eco.c:409)
         sh.deblock = br.get1();
         sh.qp = (int)br.get(6);
         sh.qp_u_offset = br.se(); sh.qp_v_offset = br.se();
         while (!br.aligned()) if (br.get1()) return fail("slice header alignment");
         if (br.overrun || sh.qp > 51) return fail("bad slice header");
-        // POC (xevd.c:1846-1861, xevd_poc_derivation with sub-GOP length 1): IDR 0, else previous + 1
-        if (nut == NUT_IDR) { st.poc = 0; st.prev_poc = 0; } else { st.poc = st.prev_poc + 1; st.prev_poc = st.poc; }
+        st.derive_poc(nut == NUT_IDR, tid);
         if (sh.type == XHOST_SLICE_I) st.last_intra_poc = st.poc;
         st.build_ref_lists();
-        if (sh.type != XHOST_SLICE_I && st.refp[0].empty()) return fail("P slice without a reference picture");
+        if (sh.type != XHOST_SLICE_I && st.refp[0].empty()) return fail("P/B slice without a reference picture");
+        if (sh.type == XHOST_SLICE_B && st.refp[1].empty()) return fail("B slice without a list-1 reference picture");
         st.pic.reset(st.sps.width, st.sps.height);
         st.models.reset();
         st.qp_prev = sh.qp;
@@ -552,9 +623,11 @@ struct xhost_parser {
         // ---- hand-over ----
         memset(out, 0, sizeof(*out));
         out->width = W; out->height = H; out->bit_depth_luma = st.sps.bd_l; out->bit_depth_chroma = st.sps.bd_c;
-        out->poc = st.poc; out->temporal_id = tid; out->slice_type = sh.type; out->is_idr = nut == NUT_IDR; out->is_ref = 1;
-        out->num_refp[0] = (int)st.refp[0].size();
-        for (size_t i = 0; i < st.refp[0].size(); i++) out->refp_poc[i][0] = st.refp[0][i]->poc;
+        out->poc = st.poc; out->temporal_id = tid; out->slice_type = sh.type; out->is_idr = nut == NUT_IDR; out->is_ref = st.is_ref_picture();
+        for (int l = 0; l < 2; l++) {
+            out->num_refp[l] = (int)st.refp[l].size();
+            for (size_t i = 0; i < st.refp[l].size(); i++) out->refp_poc[i][l] = st.refp[l][i]->poc;
+        }
         out->slice_qp = sh.qp; out->qp_u_offset = sh.qp_u_offset; out->qp_v_offset = sh.qp_v_offset; out->deblock_on = sh.deblock;
         std::vector<int> released;
         st.store_picture(nut == NUT_IDR, released);
@@ -668,7 +741,8 @@ struct xhost_writer {
         bw.ue(1); bw.ue((uint32_t)sp.width); bw.ue((uint32_t)sp.height);
         bw.ue((uint32_t)(sp.bit_depth - 8)); bw.ue((uint32_t)(sp.bit_depth - 8));
         for (int i = 0; i < 13; i++) bw.put1(i == 11 ? (sp.cu_qp_delta ? 1 : 0) : 0);       // all tools off; dquant_flag with cu_qp_delta
-        bw.ue(0); bw.ue(0);                              // log2_sub_gop_length = 0, log2_ref_pic_gap_length = 0
+        bw.ue((uint32_t)sp.log2_sub_gop_length);
+        if (sp.log2_sub_gop_length == 0) bw.ue(0);      // log2_ref_pic_gap_length
         bw.ue((uint32_t)sp.max_num_ref_pics);
         bw.put1(0); bw.put1(0); bw.put1(0);              // no cropping, default chroma QP table, no VUI
         bw.align_zero();
@@ -689,11 +763,13 @@ struct xhost_writer {
 
 extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
 {
-    if (!sp || sp->width <= 0 || sp->height <= 0 || (sp->width & 7) || (sp->height & 7) || sp->bit_depth < 8 || sp->bit_depth > 12) return nullptr;
+    if (!sp || sp->width <= 0 || sp->height <= 0 || (sp->width & 7) || (sp->height & 7) || sp->bit_depth < 8 || sp->bit_depth > 12 ||
+        sp->log2_sub_gop_length < 0 || sp->log2_sub_gop_length > 5 || sp->max_num_ref_pics < 1) return nullptr;
     xhost_writer *w = new xhost_writer();
     w->sp = *sp;
     Sps &s = w->st.sps;
     s.width = sp->width; s.height = sp->height; s.bd_l = s.bd_c = sp->bit_depth; s.max_num_ref_pics = sp->max_num_ref_pics;
+    s.log2_sub_gop = sp->log2_sub_gop_length;
     w->st.pps.cu_qp_delta = sp->cu_qp_delta;
     return w;
 }
@@ -734,9 +810,15 @@ struct TreeWriter {
         cu.x = x; cu.y = y; cu.log2w = cu.log2h = log2s;
         cu.mode = b->pred_mode[i] == XGPU_MODE_INTRA ? MODE_INTRA : (b->pred_mode[i] == XGPU_MODE_SKIP ? MODE_SKIP : MODE_INTER);
         if (st.sh.type == XHOST_SLICE_I) cu.mode = MODE_INTRA;
-        cu.refi[0] = std::max(0, std::min((int)b->refi[i * 2], (int)st.refp[0].size() - 1)); cu.refi[1] = -1;
-        cu.mv[0][0] = b->mv[i * 4]; cu.mv[0][1] = b->mv[i * 4 + 1];
-        cu.mvp_idx[0] = (x >> 2) & 3;                                  // a SKIP CU: some predictor
+        cu.direct = st.sh.type == XHOST_SLICE_B && b->pred_mode[i] == XGPU_MODE_DIR;
+        for (int l = 0; l < 2; l++) {
+            const int nref = (int)st.refp[l].size();
+            cu.refi[l] = (b->refi[i * 2 + l] < 0 || nref == 0) ? -1 : std::min((int)b->refi[i * 2 + l], nref - 1);
+            cu.mv[l][0] = b->mv[i * 4 + l * 2]; cu.mv[l][1] = b->mv[i * 4 + l * 2 + 1];
+        }
+        if (cu.mode == MODE_INTER && cu.refi[0] < 0 && cu.refi[1] < 0) cu.refi[0] = 0;
+        if (st.sh.type == XHOST_SLICE_P) { cu.refi[1] = -1; if (cu.refi[0] < 0) cu.refi[0] = 0; }
+        cu.mvp_idx[0] = (x >> 2) & 3; cu.mvp_idx[1] = (y >> 2) & 3;   // a SKIP CU: some predictor per list
         cu.ipm = b->ipm ? b->ipm[i * 2] % 5 : 0;
         cu.qp = std::min(std::max((int)b->qp[i * 3] - bd_off, 0), 51);
         for (int k = 0; k < 3; k++) cu.cbf[k] = cu.mode == MODE_SKIP ? 0 : (b->cbf[i] >> k) & 1;
@@ -765,19 +847,20 @@ struct TreeWriter {
 };
 }
 
-extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type, int slice_qp, const xgpu_cu_batch *b)
+extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type, int slice_qp, int temporal_id, const xgpu_cu_batch *b)
 {
-    if (!w || !b || slice_qp < 0 || slice_qp > 51) return XGPU_ERR_INVALID_ARGUMENT;
+    if (!w || !b || slice_qp < 0 || slice_qp > 51 || temporal_id < 0 || temporal_id > w->sp.log2_sub_gop_length) return XGPU_ERR_INVALID_ARGUMENT;
     Stream &st = w->st;
     if (w->n_pics == 0) { idr = 1; w->write_sps(); w->write_pps(); }
-    if (idr) slice_type = XHOST_SLICE_I;
-    if (slice_type == XHOST_SLICE_B) return XGPU_ERR_UNSUPPORTED;
+    if (idr) { slice_type = XHOST_SLICE_I; temporal_id = 0; }
+    if (slice_type < 0 || slice_type > 2) return XGPU_ERR_INVALID_ARGUMENT;
     st.sh.type = slice_type; st.sh.qp = slice_qp; st.sh.qp_u_offset = w->sp.qp_u_offset; st.sh.qp_v_offset = w->sp.qp_v_offset;
     st.sh.deblock = w->sp.deblock_on ? 1 : 0;
-    if (idr) { st.poc = 0; st.prev_poc = 0; } else { st.poc = st.prev_poc + 1; st.prev_poc = st.poc; }
+    st.derive_poc(idr != 0, temporal_id);
     if (slice_type == XHOST_SLICE_I) st.last_intra_poc = st.poc;
     st.build_ref_lists();
     if (slice_type != XHOST_SLICE_I && st.refp[0].empty()) return XGPU_ERR_INVALID_ARGUMENT;
+    if (slice_type == XHOST_SLICE_B && st.refp[1].empty()) return XGPU_ERR_INVALID_ARGUMENT;
 
     BitWriter bw;
     bw.ue(0);                                            // slice_pic_parameter_set_id
@@ -808,7 +891,7 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
     for (int cy = 0; cy < h_ctu; cy++) for (int cx = 0; cx < w_ctu; cx++) tw.node(cx << 6, cy << 6, 6);
     if (tw.error) return XGPU_ERR_INVALID_ARGUMENT;
     enc.tile_end();
-    write_nal(w->out, idr ? NUT_IDR : NUT_NONIDR, 0, bw);
+    write_nal(w->out, idr ? NUT_IDR : NUT_NONIDR, temporal_id, bw);
     std::vector<int> released;
     st.store_picture(idr != 0, released);
     w->n_pics++;

@@ -14,7 +14,7 @@ SLICE_B, SLICE_P, SLICE_I = 0, 1, 2
 
 
 class StreamParams(C.Structure):
-    _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("max_num_ref_pics", C.c_int),
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("max_num_ref_pics", C.c_int), ("log2_sub_gop_length", C.c_int),
                 ("qp_u_offset", C.c_int), ("qp_v_offset", C.c_int), ("deblock_on", C.c_int), ("cu_qp_delta", C.c_int)]
 
 
@@ -43,7 +43,7 @@ def load():
         lib.xhost_parser_close.argtypes = [C.c_void_p]
         lib.xhost_writer_open.restype = C.c_void_p
         lib.xhost_writer_open.argtypes = [C.POINTER(StreamParams)]
-        lib.xhost_writer_add_picture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(abi.CuBatch)]
+        lib.xhost_writer_add_picture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.CuBatch)]
         lib.xhost_writer_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         lib.xhost_writer_close.argtypes = [C.c_void_p]
         _lib = lib
@@ -51,16 +51,17 @@ def load():
 
 
 class StreamWriter:
-    def __init__(self, width, height, bit_depth=8, max_num_ref_pics=1, qp_u_offset=0, qp_v_offset=0, deblock=True, cu_qp_delta=True):
+    def __init__(self, width, height, bit_depth=8, max_num_ref_pics=1, qp_u_offset=0, qp_v_offset=0, deblock=True, cu_qp_delta=True,
+                 log2_sub_gop=0):
         self.lib = load()
-        sp = StreamParams(width, height, bit_depth, max_num_ref_pics, qp_u_offset, qp_v_offset, int(deblock), int(cu_qp_delta))
+        sp = StreamParams(width, height, bit_depth, max_num_ref_pics, log2_sub_gop, qp_u_offset, qp_v_offset, int(deblock), int(cu_qp_delta))
         self.h = self.lib.xhost_writer_open(C.byref(sp))
         if not self.h:
             raise ValueError("xhost_writer_open: bad stream parameters")
 
-    def add_picture(self, batch, slice_type=SLICE_P, slice_qp=32, idr=False):
+    def add_picture(self, batch, slice_type=SLICE_P, slice_qp=32, idr=False, temporal_id=0):
         cb, keep = abi.make_cu_batch(batch)
-        rc = self.lib.xhost_writer_add_picture(self.h, int(idr), slice_type, slice_qp, C.byref(cb))
+        rc = self.lib.xhost_writer_add_picture(self.h, int(idr), slice_type, slice_qp, temporal_id, C.byref(cb))
         if rc != 0:
             raise RuntimeError(f"xhost_writer_add_picture -> {rc}")
 
@@ -105,7 +106,7 @@ def parse_stream(data):
                 "ctu_cu_start": _arr(b.ctu_cu_start, b.n_ctu + 1, np.uint32), "constrained_intra_pred": int(b.constrained_intra_pred),
             }
             pics.append({
-                "width": hp.width, "height": hp.height, "bit_depth": hp.bit_depth_luma, "poc": hp.poc, "slice_type": hp.slice_type,
+                "width": hp.width, "height": hp.height, "bit_depth": hp.bit_depth_luma, "poc": hp.poc, "temporal_id": hp.temporal_id, "slice_type": hp.slice_type,
                 "is_idr": bool(hp.is_idr), "is_ref": bool(hp.is_ref),
                 "refs": [[hp.refp_poc[i][l] for i in range(hp.num_refp[l])] for l in range(2)],
                 "slice_qp": hp.slice_qp, "qp_u_offset": hp.qp_u_offset, "qp_v_offset": hp.qp_v_offset, "deblock_on": bool(hp.deblock_on),
