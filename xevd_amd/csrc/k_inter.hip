@@ -231,7 +231,6 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
 {
     // Everything a lane looks up by a data-dependent index lives in LDS: the per-wave critical path is then LDS -> LDS -> LDS
     // -> reference samples, instead of a chain of dependent global loads (the kernel is latency-bound, not bandwidth-bound).
-    __shared__ uint32_t s_geo[MAX_CU_PER_CTU];
     __shared__ uint4    s_cu[LDS_CU][2];                    // CU records of the CTU (the first LDS_CU of them)
     __shared__ uint4    s_ref[XGPU_MAX_REFS * 2][2];        // RefEntry [idx][list]
     __shared__ uint4    s_ltap[17];                         // luma taps of this sequence's table, [16] = identity
@@ -247,7 +246,6 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     const int strip = k / per_strip, ks = k - strip * per_strip;
     const int rx = strip * INTER_STRIP + ks % INTER_STRIP, ry = (blockIdx.x & 7) * band_rows + ks / INTER_STRIP;
     if (rx >= a.regions_x || ry >= regions_y) return;
-    const int ctu_sz = 1 << a.log2_ctu;
     const int ctu_x = (rx << 6) >> a.log2_ctu, ctu_y = (ry << 6) >> a.log2_ctu;
     const int ctu = ctu_y * a.w_ctu + ctu_x;
     const int first = a.ctu_cu_start[ctu];
@@ -262,13 +260,8 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     } else if (t >= 128 && t < 128 + 33) {
         s_ctap[t - 128] = *(const uint2 *)k_chroma_taps[a.admvp][t - 128];
     }
-    for (int i = t; i < n; i += 256) {
-        const uint4 c0 = ((const uint4 *)&a.cus[first + i])[0];       // x, y, log2w, log2h, ...
-        if (i < LDS_CU) { s_cu[i][0] = c0; s_cu[i][1] = ((const uint4 *)&a.cus[first + i])[1]; }
-        const uint2 g = make_uint2(c0.x, c0.y);
-        const int x = g.x & 0xFFFF, y = g.x >> 16, lw = g.y & 0xFF, lh = (g.y >> 8) & 0xFF;
-        s_geo[i] = (uint32_t)((x & (ctu_sz - 1)) >> 2) | ((uint32_t)((y & (ctu_sz - 1)) >> 2) << 5) |
-                   ((uint32_t)(((1 << lw) >> 2) - 1) << 10) | ((uint32_t)(((1 << lh) >> 2) - 1) << 15);
+    for (int i = t; i < min(n, LDS_CU); i += 256) {
+        s_cu[i][0] = ((const uint4 *)&a.cus[first + i])[0]; s_cu[i][1] = ((const uint4 *)&a.cus[first + i])[1];
     }
     __syncthreads();
 
@@ -276,15 +269,10 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     // with one motion class (the MC variants below are chosen per wave)
     const int sx = (rx << 4) + ((t >> 6 & 1) << 3) + (t & 7), sy = (ry << 4) + ((t >> 7) << 3) + ((t >> 3) & 7);
     const bool active = sx < (a.pic_w >> 2) && sy < (a.pic_h >> 2);
-    const int rsx = sx - ((ctu_x << a.log2_ctu) >> 2), rsy = sy - ((ctu_y << a.log2_ctu) >> 2);
-    int found = -1;
-    for (int i = 0; i < n; i++) {
-        const uint32_t g = s_geo[i];
-        const bool hit = (uint32_t)(rsx - (int)(g & 31)) <= ((g >> 10) & 31) && (uint32_t)(rsy - (int)((g >> 5) & 31)) <= ((g >> 15) & 31);
-        if (hit && found < 0) found = i;
-        if (__ballot(active && found < 0) == 0) break;
-    }
-    if (!active || found < 0) return;
+    if (!active) return;
+    // the covering CU: painted per picture by k_paint (a per-lane scan of the CTU's CU list cost ~30 us of this kernel at 8K)
+    const int found = a.owner[sy * a.w_scu + sx];
+    if (found >= n) return;
 
     uint4 r0, r1;
     if (found < LDS_CU) { r0 = s_cu[found][0]; r1 = s_cu[found][1]; }
@@ -435,8 +423,27 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     *(uint32_t *)(a.cur_v + coff + a.s_c) = pv[1];
 }
 
+// SCU -> CU map of one picture: one thread per CU writes the CU's index (inside its CTU's list) over the SCUs it covers.
+// CUs tile the picture, so every entry is written exactly once and the map needs no clearing.
+__global__ __launch_bounds__(256) void k_paint(const InterArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= a.n_cu) return;
+    const uint2 g = *(const uint2 *)&a.cus[i];
+    const int x = g.x & 0xFFFF, y = g.x >> 16, ws = (1 << (g.y & 0xFF)) >> 2, hs = (1 << ((g.y >> 8) & 0xFF)) >> 2;
+    const int ctu = (y >> a.log2_ctu) * a.w_ctu + (x >> a.log2_ctu);
+    const uint16_t idx = (uint16_t)(i - (int)a.ctu_cu_start[ctu]);
+    uint16_t *o = a.owner + (y >> 2) * a.w_scu + (x >> 2);
+    const uint32_t v2 = (uint32_t)idx * 0x10001u;
+    for (int r = 0; r < hs; r++, o += a.w_scu) {
+        if (ws == 1) o[0] = idx;
+        else for (int q = 0; q < ws; q += 2) *(uint32_t *)(o + q) = v2;      // CUs wider than 4 start at even SCU columns
+    }
+}
+
 void launch_inter(xgpu_ctx *c, const InterArgs &a)
 {
+    if (a.n_cu) hipLaunchKernelGGL(k_paint, dim3((a.n_cu + 255) / 256), dim3(256), 0, c->stream, a);
     const int regions_y = a.n_regions / a.regions_x, band_rows = (regions_y + 7) >> 3;
     const int strips = (a.regions_x + INTER_STRIP - 1) / INTER_STRIP;
     const int blocks = strips * INTER_STRIP * band_rows * 8;

@@ -151,7 +151,7 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     xgpu_ctx *c = new xgpu_ctx();
     c->sp = *sp;
     c->sp.chroma_qp_table[0] = c->sp.chroma_qp_table[1] = NULL;
-    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_ctb_flag = NULL; c->stream = 0; c->where = 0;
+    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_owner = NULL; c->d_ctb_flag = NULL; c->stream = 0; c->where = 0;
     memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_n, 0, sizeof(c->t_n));
     // chroma QP mapping: caller table starts at qp = -6*(bdc-8); default = Baseline static table with the
     // identity extension below 0 (xevd_set_chroma_qp_tbl_loc, xevd_tbl.c:364-372)
@@ -177,6 +177,8 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
 
     if (hipMalloc((void **)&c->d_maps, sizeof(ScuRec) * (size_t)c->w_scu * c->h_scu) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
     if (hipMemsetAsync(c->d_maps, 0, sizeof(ScuRec) * (size_t)c->w_scu * c->h_scu, c->stream) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+    if (hipMalloc((void **)&c->d_owner, sizeof(uint16_t) * ((size_t)c->w_scu * c->h_scu + 8)) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
+    if (hipMemsetAsync(c->d_owner, 0xFF, sizeof(uint16_t) * ((size_t)c->w_scu * c->h_scu + 8), c->stream) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     if (hipMalloc((void **)&c->d_ctb_flag, (size_t)c->w_ctu * c->h_ctu + 16) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
     init_transform_tables(c);
     // slot 0 of `pics` is the private scratch picture of the deblocking passes
@@ -203,6 +205,7 @@ void xgpu_close(xgpu_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &p : c->pics) if (p.base) (void)hipFree(p.base);
     if (c->d_maps) (void)hipFree(c->d_maps);
+    if (c->d_owner) (void)hipFree(c->d_owner);
     if (c->d_ctb_flag) (void)hipFree(c->d_ctb_flag);
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
@@ -350,11 +353,26 @@ static void build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         r.coef_off = b->coef_off[i];
         int lv = 0;
         uint32_t last = NONE;
+        // which neighbour units the CU's predictors actually read (xevd_ipred.c:96-164,587-622): only those create a dependency;
+        // the others are still fetched by the kernel (availability is about COD flags, not about use) but their values are ignored
+        const int wu = (1 << b->log2w[i]) >> 2, hu = (1 << b->log2h[i]) >> 2;
+        bool need_ul = false;
+        int need_up = 0, need_le = 0;                                                      // number of leading units read on each side
+        for (int k = 0; k < 2; k++) {
+            const int m = r.ipm[k];
+            if (m == 0) { need_up = std::max(need_up, wu); need_le = std::max(need_le, hu); }
+            else if (m == 1) need_le = std::max(need_le, hu);
+            else if (m == 2) need_up = std::max(need_up, wu);
+            else if (m == 3) { need_up = std::max(need_up, wu); need_le = std::max(need_le, hu); need_ul = true; }
+            else { need_up = units; need_le = units; }
+        }
+        bool used = true;
         auto ok = [&](int sx, int sy) -> bool {
             const uint32_t j = owner[(size_t)sy * ws + sx];
             if (j >= (uint32_t)i) return false;                                            // not reconstructed yet (or nothing there)
             const bool j_intra = b->pred_mode[j] == XGPU_MODE_INTRA;
             if (constrained && !j_intra) return false;                                     // constrained_intra_pred: intra neighbours only
+            if (!used) return true;
             if (j_intra && j != last) {                                                    // inter CUs are complete before the intra kernel starts
                 bool seen = false;
                 for (size_t d = r.dep_first; d < deps.size() && !seen; d++) seen = deps[d] == j;
@@ -364,11 +382,16 @@ static void build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
             lv = std::max(lv, level[j]);
             return true;
         };
+        used = need_ul;
         if (xs > 0 && ys > 0 && ok(xs - 1, ys - 1)) r.flags |= 1u;
-        for (int k = 0; k < units; k++)
+        for (int k = 0; k < units; k++) {
+            used = k < need_up;
             if (ys > 0 && xs + k < ws && ok(xs + k, ys - 1)) r.up |= 1ull << k;
-        for (int k = 0; k < units; k++)
+        }
+        for (int k = 0; k < units; k++) {
+            used = k < need_le;
             if (xs > 0 && ys + k < hs && ok(xs - 1, ys + k)) r.le |= 1ull << k;
+        }
         r.dep_count = (uint32_t)deps.size() - r.dep_first;
         level[i] = lv + 1;
         max_level = std::max(max_level, lv + 1);
@@ -606,7 +629,7 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
     a.n_regions = a.regions_x * ((c->sp.height + 63) >> 6);
     a.admvp = c->sp.tool_admvp ? 1 : 0;
     a.cus = db->d_cus; a.ctu_cu_start = db->d_ctu_start; a.resid = db->d_resid;
-    a.maps = c->d_maps; a.w_scu = c->w_scu;
+    a.maps = c->d_maps; a.w_scu = c->w_scu; a.owner = c->d_owner; a.n_cu = db->n_cu;
     for (int l = 0; l < 2; l++)
         for (int i = 0; i < XGPU_MAX_REFS; i++) {
             const DevPic &rp = i < c->fp.num_refp[l] ? dpic(c, c->fp.refp_pic[i][l]) : dpic(c, c->fp.pic);

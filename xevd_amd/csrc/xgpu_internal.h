@@ -90,6 +90,8 @@ struct InterArgs {
     const int16_t  *resid;
     ScuRec  *maps;
     int      w_scu;
+    uint16_t *owner;                   // [w_scu * h_scu] index (inside its CTU's list) of the CU covering each SCU, written by k_paint
+    int      n_cu;
     RefEntry refp[XGPU_MAX_REFS][2];
 };
 
@@ -183,6 +185,7 @@ struct xgpu_ctx {
     size_t          pic_elems, off_u, off_v;
     std::vector<DevPic> pics;
     ScuRec         *d_maps;
+    uint16_t       *d_owner;          // SCU -> CU index inside the CTU, rebuilt per picture by k_paint
     uint8_t        *d_ctb_flag;       // ALF luma CTB flags of the current picture
     xgpu_frame_params fp;
     int             have_frame;
@@ -199,7 +202,7 @@ struct xgpu_ctx {
 
 // kernel launchers (one per .hip file)
 void launch_itdq(xgpu_ctx *c, const ItdqArgs &a);
-void launch_inter(xgpu_ctx *c, const InterArgs &a);
+void launch_inter(xgpu_ctx *c, const InterArgs &a);      // k_paint + k_inter
 void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep);
 void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst);
 void upload_transform_tables(const int *tm, const int16_t *ats, hipStream_t s);
