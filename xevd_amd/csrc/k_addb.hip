@@ -6,12 +6,13 @@
 // average of both sides; alpha/beta/clip tables indexed through get_index()'s u8 arguments; luma strong (bS 4)
 // and normal filters over 3 samples per side, chroma over 1; all vertical edges before all horizontal ones.
 //
-// MI355X mapping - same order-free out-of-place scheme as the baseline filter (k_deblock.hip): each pass reads
-// SRC and writes DST, one LANE per 4x4 SCU writes exactly its own 16 luma + 2x4 chroma samples.  Grid edges are 8
-// samples apart and touch 3 samples per side, so edges never interact: the SCU left of / above an edge is its P
-// side, the SCU right of / below it its Q side; both lanes load the same aligned 8-sample window across the
-// edge, evaluate the same line filter and keep their half.  All loads (two SCU records, luma and chroma windows)
-// are issued before any decision, the decisions are lane-local integer tests, tables sit in LDS.
+// MI355X mapping - order-free and out of place like the baseline filter (k_deblock.hip): each pass reads SRC and writes
+// DST.  Grid edges are 8 samples apart and touch 3 samples per side, so edges never interact and the 8-sample windows
+// centred on the grid lines tile the picture: one LANE per 4-sample edge SEGMENT owns the SCU on either side (P = left /
+// above, Q = right / below), loads the aligned 8x4 (4x8) luma and 4x2 (2x4) chroma windows once, filters and writes both
+// halves - every sample is read once and written once, no filter is evaluated twice.  The columns (rows) of SCUs next to
+// the picture border belong to "edges" 0 and w_scu (h_scu), which only copy their inner half.  All loads (two SCU
+// records, luma and chroma windows) are issued before any decision; decisions are lane-local integer tests, tables in LDS.
 #include "xgpu_internal.h"
 
 struct __attribute__((packed, aligned(8))) U32x4a8 { uint32_t a, b, c, d; };
@@ -117,25 +118,25 @@ __global__ __launch_bounds__(256) void k_addb(const AddbArgs a, const int16_t *_
     for (int i = threadIdx.x; i < 192; i += 256) s_cqp[i] = a.chroma_qp[i];
     __syncthreads();
 
-    const int tiles_x = (a.w_scu + 15) >> 4;
+    // lane -> edge segment: along the filtered axis the lane index counts grid lines (every second SCU position), across it SCUs
+    const int n_ex = DIR == 0 ? (a.w_scu >> 1) + 1 : a.w_scu, n_ey = DIR == 0 ? a.h_scu : (a.h_scu >> 1) + 1;
+    const int tiles_x = (n_ex + 15) >> 4;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int sx = (tx << 4) + (threadIdx.x & 15), sy = (ty << 4) + (threadIdx.x >> 4);
-    if (sx >= a.w_scu || sy >= a.h_scu) return;
+    const int ex = (tx << 4) + (threadIdx.x & 15), ey = (ty << 4) + (threadIdx.x >> 4);
+    if (ex >= n_ex || ey >= n_ey) return;
+    const int sx = DIR == 0 ? ex << 1 : ex, sy = DIR == 0 ? ey : ey << 1;                 // the Q-side SCU (may lie one past the picture)
     const int step = DIR == 0 ? 1 : a.w_scu;
-    const int pos = DIR == 0 ? sx : sy, npos = DIR == 0 ? a.w_scu : a.h_scu;
+    const int eq = DIR == 0 ? sx : sy, npos = DIR == 0 ? a.w_scu : a.h_scu;
     const uint32_t eflag = DIR == 0 ? SCU_EDGE_L : SCU_EDGE_T;
     const uint4 *maps = (const uint4 *)a.maps;
-    const int odd = pos & 1;                        // odd SCU = P side of the grid edge at pos+1, even SCU = Q side of the edge at pos
-    const int eq = pos + odd;                       // SCU index (along the axis) of the edge's Q side
-    const bool in_range = eq > 0 && eq < npos;
-    const int k0 = sy * a.w_scu + sx;
-    const int kq = in_range ? k0 + odd * step : k0, kp = in_range ? kq - step : k0;
+    const bool has_p = eq > 0, has_q = eq < npos, in_range = has_p && has_q;
+    const int kq = in_range ? sy * a.w_scu + sx : 0, kp = in_range ? kq - step : 0;
     const int maxl = (1 << a.bd_l) - 1, maxc = (1 << a.bd_c) - 1;
 
     // ---- all loads first ----
     const uint4 rq = maps[kq], rp = maps[kp];
     const int x = sx << 2, y = sy << 2, cx = sx << 1, cy = sy << 1;
-    const int xe = DIR == 0 ? (eq << 2) : x, ye = DIR == 0 ? y : (eq << 2);        // luma position of the edge segment (Q side origin)
+    const int xe = x, ye = y;                          // luma position of the edge segment (Q side origin)
     int L[4][8];          // 4 lines x (p3 p2 p1 p0 q0 q1 q2 q3)
     int Cc[2][2][4];      // [plane][line][p1 p0 q0 q1]
     if (DIR == 0) {
@@ -195,42 +196,44 @@ __global__ __launch_bounds__(256) void k_addb(const AddbArgs a, const int16_t *_
         }
     }
 
-    // ---- every lane writes its own SCU: the P half (odd) or the Q half (even) of the window ----
-    const int h0 = odd ? 0 : 4;
+    // ---- both halves of the window: P (the SCU before the grid line) and Q, each if inside the picture ----
+#define PK2(lo, hi) ((uint32_t)(uint16_t)(lo) | ((uint32_t)(uint16_t)(hi) << 16))
     if (DIR == 0) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            uint2 w;
-            w.x = (uint32_t)(uint16_t)L[r][h0 + 0] | ((uint32_t)(uint16_t)L[r][h0 + 1] << 16);
-            w.y = (uint32_t)(uint16_t)L[r][h0 + 2] | ((uint32_t)(uint16_t)L[r][h0 + 3] << 16);
-            *(uint2 *)(dy_ + (y + r) * a.s_l + x) = w;
+            int16_t *d = dy_ + (y + r) * a.s_l + x;
+            if (has_p) *(uint2 *)(d - 4) = make_uint2(PK2(L[r][0], L[r][1]), PK2(L[r][2], L[r][3]));
+            if (has_q) *(uint2 *)d = make_uint2(PK2(L[r][4], L[r][5]), PK2(L[r][6], L[r][7]));
         }
 #pragma unroll
         for (int pl = 0; pl < 2; pl++)
 #pragma unroll
-            for (int r = 0; r < 2; r++)
-                *(uint32_t *)((pl ? dv_ : du_) + (cy + r) * a.s_c + cx) =
-                    (uint32_t)(uint16_t)Cc[pl][r][odd ? 0 : 2] | ((uint32_t)(uint16_t)Cc[pl][r][odd ? 1 : 3] << 16);
+            for (int r = 0; r < 2; r++) {
+                int16_t *d = (pl ? dv_ : du_) + (cy + r) * a.s_c + cx;
+                if (has_p) *(uint32_t *)(d - 2) = PK2(Cc[pl][r][0], Cc[pl][r][1]);
+                if (has_q) *(uint32_t *)d = PK2(Cc[pl][r][2], Cc[pl][r][3]);
+            }
     } else {
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            uint2 w;
-            w.x = (uint32_t)(uint16_t)L[0][h0 + r] | ((uint32_t)(uint16_t)L[1][h0 + r] << 16);
-            w.y = (uint32_t)(uint16_t)L[2][h0 + r] | ((uint32_t)(uint16_t)L[3][h0 + r] << 16);
-            *(uint2 *)(dy_ + (y + r) * a.s_l + x) = w;
+        for (int r = 0; r < 8; r++) {
+            if (r < 4 ? !has_p : !has_q) continue;
+            *(uint2 *)(dy_ + (y - 4 + r) * a.s_l + x) = make_uint2(PK2(L[0][r], L[1][r]), PK2(L[2][r], L[3][r]));
         }
 #pragma unroll
         for (int pl = 0; pl < 2; pl++)
 #pragma unroll
-            for (int r = 0; r < 2; r++)
-                *(uint32_t *)((pl ? dv_ : du_) + (cy + r) * a.s_c + cx) =
-                    (uint32_t)(uint16_t)Cc[pl][0][(odd ? 0 : 2) + r] | ((uint32_t)(uint16_t)Cc[pl][1][(odd ? 0 : 2) + r] << 16);
+            for (int r = 0; r < 4; r++) {
+                if (r < 2 ? !has_p : !has_q) continue;
+                *(uint32_t *)((pl ? dv_ : du_) + (cy - 2 + r) * a.s_c + cx) = PK2(Cc[pl][0][r], Cc[pl][1][r]);
+            }
     }
+#undef PK2
 }
 
 void launch_addb(xgpu_ctx *c, const AddbArgs &a, int dir, const DevPic &src, const DevPic &dst)
 {
-    const int tiles = ((a.w_scu + 15) >> 4) * ((a.h_scu + 15) >> 4);
+    const int n_ex = dir == 0 ? (a.w_scu >> 1) + 1 : a.w_scu, n_ey = dir == 0 ? a.h_scu : (a.h_scu >> 1) + 1;
+    const int tiles = ((n_ex + 15) >> 4) * ((n_ey + 15) >> 4);
     if (dir == 0)
         hipLaunchKernelGGL(k_addb<0>, dim3(tiles), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
     else
