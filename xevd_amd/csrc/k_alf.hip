@@ -24,6 +24,7 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 #define LROWS 70
 #define LSTR  72          // luma LDS row stride in s16: window col c (-3..66) at index c+4
 #define CROWS 36
+#define SSTR  40          // sub-block sums row stride (u16); sub-block col c (-1..32) at index c+2 (own pairs 4-byte aligned)
 #define CSTR  40          // chroma: window col c (-2..33) at index c+4 (keeps the 8-byte interior pieces aligned)
 
 struct CtuRect { int x0, y0, cw, ch, aL, aR, aT, aB; };
@@ -86,6 +87,8 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
     __shared__ __attribute__((aligned(16))) int16_t l_y[LROWS * LSTR];
     __shared__ __attribute__((aligned(16))) int16_t l_c[2][CROWS * CSTR];
     __shared__ int16_t l_coef[25 * 13 + 7];
+    // sums of |Laplacian| over the 2x2 sub-blocks of the tile + one ring: [direction V, H, D0, D1][sub-block row -1..32][col -1..32]
+    __shared__ __attribute__((aligned(16))) uint16_t l_lap[4][34][SSTR];
 
     const int tiles_x = (a.pic_w + 63) >> 6;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
@@ -114,36 +117,87 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
 
     const int lx = t & 15, ly = t >> 4;
     const int x = tx0 + (lx << 2), y = ty0 + (ly << 2);
-    if (x >= a.pic_w || y >= a.pic_h) return;
+    const bool inside = x < a.pic_w && y < a.pic_h;
     const int maxv = (1 << a.bd) - 1;
 
     // ------------------------------------------------ luma -----------------------------------------------
+    // window rows -3..6, each 12 samples (cols -4..7) as 6 dwords; col j sits at sample j+4
+    uint32_t W[10][6];
     if (luma_on) {
-        // window rows -3..6, each 12 samples (cols -4..7) as 6 dwords; col j sits at sample j+4
-        uint32_t W[10][6];
 #pragma unroll
         for (int i = 0; i < 10; i++) {
             const uint2 *row = (const uint2 *)(l_y + ((ly << 2) + i) * LSTR + (lx << 2));
             const uint2 v0 = row[0], v1 = row[1], v2 = row[2];
             W[i][0] = v0.x; W[i][1] = v0.y; W[i][2] = v1.x; W[i][3] = v1.y; W[i][4] = v2.x; W[i][5] = v2.y;
         }
-        // classification: sums of |Laplacian| over window rows -2..5 (W rows 1..8) and cols -2..5 (dwords 1..4)
-        int sv = 0, sh = 0, sd0 = 0, sd1 = 0;
+        // Classification, phase 1 (alf_derive_classification_blk :38-208): the reference sums |Laplacian| (vertical, horizontal, two
+        // diagonals) over the 8x8 window around a 4x4 block.  Windows of neighbouring blocks overlap, so every lane computes the
+        // Laplacians of its OWN 16 positions once, reduced to its four 2x2 sub-blocks, and shares them through LDS; the window sum
+        // is then 16 sub-block sums (phase 2).  Packed-s16 arithmetic; a sub-block sum is at most 4 * 2 * (2^bd - 1): fits u16 up to 12 bit.
 #pragma unroll
-        for (int i = 1; i <= 8; i++) {
+        for (int sr = 0; sr < 2; sr++) {
+            int acc[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
 #pragma unroll
-            for (int d = 1; d <= 4; d++) {
-                const v2s c2 = asv(W[i][d]) + asv(W[i][d]);
-                const v2s up = asv(W[i - 1][d]), dn = asv(W[i + 1][d]);
-                const v2s l0 = asv(__builtin_amdgcn_alignbit(W[i][d], W[i][d - 1], 16)), r0 = asv(__builtin_amdgcn_alignbit(W[i][d + 1], W[i][d], 16));
-                const v2s lu = asv(__builtin_amdgcn_alignbit(W[i - 1][d], W[i - 1][d - 1], 16)), ru = asv(__builtin_amdgcn_alignbit(W[i - 1][d + 1], W[i - 1][d], 16));
-                const v2s ld = asv(__builtin_amdgcn_alignbit(W[i + 1][d], W[i + 1][d - 1], 16)), rd = asv(__builtin_amdgcn_alignbit(W[i + 1][d + 1], W[i + 1][d], 16));
-                sv = hsum(vabs(c2 - up - dn), sv);
-                sh = hsum(vabs(c2 - l0 - r0), sh);
-                sd0 = hsum(vabs(c2 - lu - rd), sd0);
-                sd1 = hsum(vabs(c2 - ld - ru), sd1);
+            for (int rr = 0; rr < 2; rr++) {
+                const int i = 3 + sr * 2 + rr;
+#pragma unroll
+                for (int sc = 0; sc < 2; sc++) {
+                    const int d = 2 + sc;
+                    const v2s c2 = asv(W[i][d]) + asv(W[i][d]);
+                    const v2s up = asv(W[i - 1][d]), dn = asv(W[i + 1][d]);
+                    const v2s l0 = asv(__builtin_amdgcn_alignbit(W[i][d], W[i][d - 1], 16)), r0 = asv(__builtin_amdgcn_alignbit(W[i][d + 1], W[i][d], 16));
+                    const v2s lu = asv(__builtin_amdgcn_alignbit(W[i - 1][d], W[i - 1][d - 1], 16)), ru = asv(__builtin_amdgcn_alignbit(W[i - 1][d + 1], W[i - 1][d], 16));
+                    const v2s ld = asv(__builtin_amdgcn_alignbit(W[i + 1][d], W[i + 1][d - 1], 16)), rd = asv(__builtin_amdgcn_alignbit(W[i + 1][d + 1], W[i + 1][d], 16));
+                    acc[sc][0] = hsum(vabs(c2 - up - dn), acc[sc][0]);
+                    acc[sc][1] = hsum(vabs(c2 - l0 - r0), acc[sc][1]);
+                    acc[sc][2] = hsum(vabs(c2 - lu - rd), acc[sc][2]);
+                    acc[sc][3] = hsum(vabs(c2 - ld - ru), acc[sc][3]);
+                }
             }
+#pragma unroll
+            for (int dir = 0; dir < 4; dir++)
+                *(uint32_t *)&l_lap[dir][(ly << 1) + sr + 1][(lx << 1) + 2] = (uint32_t)acc[0][dir] | ((uint32_t)acc[1][dir] << 16);
         }
+        // the ring of sub-blocks around the tile (window rows/cols -2..-1 and 64..65): 132 of them, one per lane
+        if (t < 132) {
+            int sr, sc;                                           // sub-block coordinates -1..32
+            if (t < 34) { sr = -1; sc = t - 1; } else if (t < 68) { sr = 32; sc = t - 35; } else if (t < 100) { sr = t - 68; sc = -1; } else { sr = t - 100; sc = 32; }
+            int acc[4] = { 0, 0, 0, 0 };
+#pragma unroll
+            for (int rr = 0; rr < 2; rr++)
+#pragma unroll
+                for (int cc = 0; cc < 2; cc++) {
+                    const int16_t *p = l_y + (sr * 2 + rr + 3) * LSTR + sc * 2 + cc + 4;
+                    const int c2 = 2 * p[0];
+                    acc[0] += abs(c2 - p[-LSTR] - p[LSTR]);
+                    acc[1] += abs(c2 - p[-1] - p[1]);
+                    acc[2] += abs(c2 - p[-LSTR - 1] - p[LSTR + 1]);
+                    acc[3] += abs(c2 - p[LSTR - 1] - p[-LSTR + 1]);
+                }
+#pragma unroll
+            for (int dir = 0; dir < 4; dir++) l_lap[dir][sr + 1][sc + 2] = (uint16_t)acc[dir];
+        }
+    }
+    __syncthreads();
+    if (!inside) return;
+
+    if (luma_on) {
+        // phase 2: the 8x8 window = sub-block rows 2*ly-1 .. 2*ly+2, cols 2*lx-1 .. 2*lx+2
+        int sum[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int dir = 0; dir < 4; dir++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                // cols 2*lx-1 .. 2*lx+2 sit at u16 index 2*lx+1 .. 2*lx+4: three aligned pairs, the outer ones half used
+                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+                const uint32_t *row = (const uint32_t *)&l_lap[dir][(ly << 1) + r][lx << 1];
+                uint32_t acc = (uint32_t)sum[dir];
+                acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, row[0]), (us2){0, 1}, acc, false);
+                acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, row[1]), (us2){1, 1}, acc, false);
+                acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, row[2]), (us2){1, 0}, acc, false);
+                sum[dir] = (int)acc;
+            }
+        const int sv = sum[0], sh = sum[1], sd0 = sum[2], sd1 = sum[3];
         int cls, tr;
         {
             const int act = min(max((sv + sh) >> (a.bd - 2), 0), 15);
