@@ -115,32 +115,6 @@ def decode_oracle(data):
 
 
 def decode_gpu(data):
-    """Our parser + the HIP backend through the C ABI. -> pictures in output order."""
-    from xevd_amd.decoder import XgpuDecoder
-    pics = stream.parse_stream(data)
-    if not pics:
-        return []
-    w, h, bd = pics[0]["width"], pics[0]["height"], pics[0]["bit_depth"]
-    out = []
-    with XgpuDecoder(w, h, bd, max_pics=12) as dec:
-        slots, free = {}, [dec.pic_alloc() for _ in range(10)]
-        for p in pics:
-            if p["is_idr"]:
-                free.extend(slots.values()); slots.clear()
-            cur = free.pop()
-            refs = {(i, l): (slots[poc], poc) for l in range(2) for i, poc in enumerate(p["refs"][l])}
-            hb = dec.batch_create(p["batch"])
-            dec.decode_picture(cur, p["poc"], refs, hb, deblock=p["deblock_on"], pad=True, qp_u_offset=p["qp_u_offset"], qp_v_offset=p["qp_v_offset"])
-            dec.sync()
-            planes = dec.pic_download_padded(cur)
-            pad = (abi.PAD_L, abi.PAD_C, abi.PAD_C)
-            out.append((p, [planes[c][pad[c]:-pad[c], pad[c]:-pad[c]].copy() for c in range(3)]))
-            dec.batch_destroy(hb)
-            for poc in p["release"]:          # unmarked when THIS picture is stored (it may still have referenced them)
-                if poc in slots:
-                    free.append(slots.pop(poc))
-            if p["is_ref"]:
-                slots[p["poc"]] = cur
-            else:
-                free.append(cur)
-    return _output_order(out)
+    """Our parser + the HIP backend through the two C ABIs (xevd_amd/player.py). -> pictures in output order."""
+    from xevd_amd.player import StreamDecoder
+    return [planes for _, planes in StreamDecoder(data).output_order()]

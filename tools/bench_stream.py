@@ -50,6 +50,12 @@ def main():
                 t_gpu = time.perf_counter() - t0
         out["batches_to_gpu_fps"] = round(n / t_gpu, 1)
         out["parse_plus_gpu_sequential_fps"] = round(n / (t_gpu + n / out["parser_fps"]), 1)
+        from xevd_amd.player import StreamDecoder
+        for rep in range(2):
+            t0 = time.perf_counter()
+            cnt = sum(1 for _ in StreamDecoder(data).pictures(download=False))
+            t_pipe = time.perf_counter() - t0
+        out["pipelined_fps"] = round(cnt / t_pipe, 1)      # parser thread one picture ahead of the GPU loop (xevd_amd/player.py)
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_decode")
     if os.path.exists(ref):
         with tempfile.TemporaryDirectory() as td:

@@ -82,12 +82,12 @@ def _arr(ptr, n, dtype):
     return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
 
 
-def parse_stream(data):
-    """-> list of pictures in decoding order: dict(params..., batch=dict of numpy arrays in the layout of synth.gen_frame)"""
+def iter_stream(data):
+    """generator over the pictures of a .evc byte string in decoding order: dict(params..., batch=dict of numpy arrays in the
+    layout of synth.gen_frame).  The C parser runs inside each next() with the GIL released (ctypes)."""
     lib = load()
     buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
     h = lib.xhost_parser_open(buf, len(data))
-    pics = []
     try:
         while True:
             hp = HostPicture()
@@ -105,13 +105,17 @@ def parse_stream(data):
                 "coef_off": _arr(b.coef_off, n, np.uint32), "coef": _arr(b.coef, max(b.n_coef, 1), np.int16), "n_coef": int(b.n_coef),
                 "ctu_cu_start": _arr(b.ctu_cu_start, b.n_ctu + 1, np.uint32), "constrained_intra_pred": int(b.constrained_intra_pred),
             }
-            pics.append({
+            yield {
                 "width": hp.width, "height": hp.height, "bit_depth": hp.bit_depth_luma, "poc": hp.poc, "temporal_id": hp.temporal_id, "slice_type": hp.slice_type,
                 "is_idr": bool(hp.is_idr), "is_ref": bool(hp.is_ref),
                 "refs": [[hp.refp_poc[i][l] for i in range(hp.num_refp[l])] for l in range(2)],
                 "slice_qp": hp.slice_qp, "qp_u_offset": hp.qp_u_offset, "qp_v_offset": hp.qp_v_offset, "deblock_on": bool(hp.deblock_on),
                 "release": [hp.release_poc[i] for i in range(hp.n_release)], "batch": batch,
-            })
+            }
     finally:
         lib.xhost_parser_close(h)
-    return pics
+
+
+def parse_stream(data):
+    """-> list of the pictures of iter_stream(data)"""
+    return list(iter_stream(data))
