@@ -248,7 +248,7 @@ def main():
                             "achieved_gbps": round(total_alg / kern_s / 1e9, 1)},
             "pcie_inclusive_fps": round(1.0 / (dt / args.steps + t_up), 2),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(wl, first, batches[0], alf)
         print(json.dumps(out))
     barrier()
