@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
-"""End-to-end numbers on a REAL bitstream (BASELINE.json configs[1] shape: Baseline 1080p 8-bit IPPP): our writer makes the
+"""(test-side tool: it runs the reference decoder from oracle/_ref, which only tests/ may touch)
+End-to-end numbers on a REAL bitstream (BASELINE.json configs[1] shape: Baseline 1080p 8-bit IPPP): our writer makes the
 stream, then (a) the host parser alone, (b) parser -> batch upload -> HIP kernels, sequentially, one picture at a time
 (nothing overlapped yet), (c) the reference decoder itself (oracle/_ref/ref_decode, its public API, -m N threads) on the same
-bytes.  Prints one JSON line.  usage: python tools/bench_stream.py [--pics 30] [--width 1920 --height 1080]"""
+bytes.  Prints one JSON line.  usage: python tests/tools/bench_stream.py [--pics 30] [--width 1920 --height 1080]"""
 import argparse
 import json
 import os
@@ -11,7 +12,7 @@ import sys
 import tempfile
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 

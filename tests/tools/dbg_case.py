@@ -1,7 +1,7 @@
 """debug helper: run one picture case on the GPU stage by stage against the oracle and print the first differences"""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import cases, golden_io
 from xevd_amd import abi
