@@ -70,7 +70,8 @@ typedef struct xgpu_seq_params {
     int tool_alf;             /* sps->tool_alf                                                   */
     int max_pics;             /* picture slots to make available (DPB + current), <= 34          */
     /* chroma QP mapping tables (xevd_qp_chroma_dynamic[0..1][-qpBdOffsetC .. 57], xevd_tbl.c:359-426);
-       entry [c][qp + 6*(bit_depth_chroma-8)]; NULL = the default static table                        */
+       entry [c][qp + 6*(bit_depth_chroma-8)]; NULL = the sequence default: xevd_tbl_qp_chroma_adjust_base, or
+       _main when tool_iqt is on (src_main/xevdm.c:471-479)                                            */
     const int8_t *chroma_qp_table[2];
 } xgpu_seq_params;
 

@@ -12,8 +12,10 @@
  * Wire format: 4-byte big-endian NAL length prefix (XEVD_NAL_UNIT_LENGTH_BYTE, inc/xevd.h:133; app/xevd_app.c:52-107),
  * 2-byte NAL header (xevd_eco.c:1178-1209).
  *
- * Scope: Baseline profile, 4:2:0, one tile and one slice per picture, I / P / B slices incl. temporal layers (hierarchical
- * sub-GOPs), sps->tool_* all 0.
+ * Scope: Baseline profile, and Main-profile streams that switch on only tools of the back half - sps->tool_iqt, tool_ats,
+ * tool_addb (syntax of src_main/xevdm_eco.c: SPS :1847-2004, slice header :2510-2800, ATS flags :128-190,354-393,902-934) -
+ * with every other Main tool off (the CU syntax is then the Baseline one); 4:2:0, one tile and one slice per picture,
+ * I / P / B slices incl. temporal layers (hierarchical sub-GOPs).
  * Conventions as xevd_hip.h: 0 / negative XEVD_ERR_* codes, nothing throws, one object per stream.
  */
 #ifndef XEVD_HOST_H
@@ -44,6 +46,9 @@ typedef struct xhost_picture {
     int refp_poc[XGPU_MAX_REFS][2];        /* POC of ctx->refp[idx][list]: the caller maps POC -> picture slot           */
     int slice_qp, qp_u_offset, qp_v_offset;
     int deblock_on;
+    int profile_main;                      /* 1: Main-profile stream (sps->profile_idc)                                   */
+    int tool_iqt, tool_ats, tool_addb;     /* sps->tool_* flags that change arithmetic on the GPU path                      */
+    int deblock_alpha_offset, deblock_beta_offset;      /* sh.sh_deblock_alpha/beta_offset (ADDB)                          */
     int n_release;                         /* reference pictures unmarked before this one was stored (pic_marking_no_rpl) */
     int release_poc[32];
     xgpu_cu_batch batch;
@@ -64,13 +69,18 @@ typedef struct xhost_stream_params {
     int qp_u_offset, qp_v_offset;          /* sh.qp_u_offset / qp_v_offset                                          */
     int deblock_on;                        /* sh.deblocking_filter_on                                               */
     int cu_qp_delta;                       /* pps.cu_qp_delta_enabled_flag: per-CU QPs of coded CUs are transmitted  */
+    int profile_main;                      /* 1: Main profile (needed for any of the tools below)                    */
+    int tool_iqt, tool_ats, tool_addb;     /* sps->tool_iqt / tool_ats (needs iqt) / tool_addb                       */
+    int deblock_alpha_offset, deblock_beta_offset;      /* slice-level ADDB offsets                                   */
 } xhost_stream_params;
 
 xhost_writer *xhost_writer_open(const xhost_stream_params *sp);
 /* Appends one picture (SPS + PPS first when it is the first).  `b`: leaf CUs of a quad tree (64..4) in decode order with the
    fields of xgpu_cu_batch; per CU the writer keeps pred_mode (INTRA / INTER / SKIP / DIR), refi and mv of the lists in use
    (INTER: refi[l] >= 0 selects the lists, indices are clamped to the actual list sizes; SKIP / DIR CUs take derived motion),
-   qp[0] (luma dequant QP incl. 6*(bd-8), used when the CU has coefficients and cu_qp_delta is on), cbf, ipm[0], coefficients.
+   qp[0] (luma dequant QP incl. 6*(bd-8), used when the CU has coefficients and cu_qp_delta is on), cbf, ipm[0], coefficients,
+   and with tool_ats: ats (intra CUs up to 32x32 with luma coefficients) and ats_inter (inter CUs; dropped when the shape does
+   not allow the split; the coefficient blocks then have the TU size).
    idr != 0 forces an IDR picture with an I slice.  temporal_id: nuh_temporal_id (0 for low-delay streams). */
 int  xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type, int slice_qp, int temporal_id, const xgpu_cu_batch *b);
 int  xhost_writer_bytes(xhost_writer *w, const uint8_t **bytes, size_t *size);

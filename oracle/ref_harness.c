@@ -125,8 +125,9 @@ static harness *harness_new(const xgpu_seq_params *sp, const orc_frame *fr, orc_
         }
     } else {
         for (i = 0; i < XEVD_MAX_QP_TABLE_SIZE; i++) {
-            xevd_qp_chroma_dynamic[0][i] = xevd_tbl_qp_chroma_adjust_base[i];
-            xevd_qp_chroma_dynamic[1][i] = xevd_tbl_qp_chroma_adjust_base[i];
+            /* the sequence default: the Main table with tool_iqt, else the Baseline one (xevdm.c:471-479) */
+            xevd_qp_chroma_dynamic[0][i] = sp->tool_iqt ? xevd_tbl_qp_chroma_adjust_main[i] : xevd_tbl_qp_chroma_adjust_base[i];
+            xevd_qp_chroma_dynamic[1][i] = xevd_qp_chroma_dynamic[0][i];
         }
     }
     return h;

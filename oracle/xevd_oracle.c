@@ -634,6 +634,9 @@ static const uint8_t k_df_st[4][52] = {
     { 0 },
 };
 /* xevd_tbl_qp_chroma_adjust_base, src_base/xevd_tbl.c:345-354 (Baseline default chroma QP mapping) */
+/* xevd_tbl_qp_chroma_adjust_main, xevd_tbl.c:334-342: the default mapping when sps->tool_iqt is on (src_main/xevdm.c:471-479) */
+static const int8_t k_chroma_qp_main[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
+    29, 30, 31, 32, 33, 34, 35, 36, 37, 37, 38, 39, 40, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54 };
 static const int8_t k_chroma_qp_base[58] = {
      0,  1,  2,  3,  4,  5,  6,  7,  8,  9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19,
     20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 29, 30, 31, 32, 32, 33, 33, 34, 34,
@@ -671,7 +674,7 @@ static int chroma_qp(const xgpu_seq_params *sp, int c, int qp)
     int v;
     qp = CLIP3(-boff, 57, qp);
     if (sp->chroma_qp_table[c]) v = sp->chroma_qp_table[c][qp + boff];
-    else v = qp < 0 ? qp : k_chroma_qp_base[qp];
+    else v = qp < 0 ? qp : (sp->tool_iqt ? k_chroma_qp_main[qp] : k_chroma_qp_base[qp]);
     return CLIP3(0, 51, v);
 }
 
@@ -849,7 +852,7 @@ static void addb_segment(const xgpu_seq_params *sp, const orc_frame *fr, const o
         int16_t *pl = (c ? fr->cur.v : fr->cur.u) + (y_pel >> 1) * fr->cur.s_c + (x_pel >> 1);
         const int boff = 6 * (bdc - 8);
         int q = CLIP3(-boff, 57, qp + (c ? fr->qp_v_offset : fr->qp_u_offset));
-        int qc = sp->chroma_qp_table[c] ? sp->chroma_qp_table[c][q + boff] : (q < 0 ? q : k_chroma_qp_base[q]);
+        int qc = sp->chroma_qp_table[c] ? sp->chroma_qp_table[c][q + boff] : (q < 0 ? q : (sp->tool_iqt ? k_chroma_qp_main[q] : k_chroma_qp_base[q]));
         int c0;
         ia = addb_index(qc, alpha_off); ib = addb_index(qc, beta_off);
         alpha = k_addb_alpha[ia] << scale;                    /* luma bit depth scales chroma too, xevdm_df.c:926-927 */

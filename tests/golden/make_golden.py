@@ -146,9 +146,11 @@ def golden_streams():
     for name, (w, h, n, kw) in {"ippp_8b": (208, 120, 5, dict(max_refs=2)), "ippp_10b_offsets": (144, 88, 4, dict(bit_depth=10, qp_offsets=(1, -2))),
                                 "idr_period_skip": (72, 136, 6, dict(max_refs=4, skip_frac=0.4, idr_period=4)),
                                 "hier_b_gop4": (208, 120, 9, dict(log2_sub_gop=2, max_refs=2)),
-                                "hier_b_gop8_10b": (136, 136, 9, dict(log2_sub_gop=3, max_refs=3, bit_depth=10, direct_frac=0.3))}.items():
+                                "hier_b_gop8_10b": (136, 136, 9, dict(log2_sub_gop=3, max_refs=3, bit_depth=10, direct_frac=0.3)),
+                                "main_iqt_ats_addb_10b": (144, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, log2_sub_gop=2, max_refs=2, bit_depth=10, addb_offsets=(1, -2))),
+                                "main_iqt_addb_8b": (208, 120, 5, dict(main=True, iqt=True, addb=True, max_refs=2))}.items():
         data = su.make_stream(w, h, n, seed=len(name) * 13 + n, **kw)
-        ref = su.decode_reference(data, w, h)
+        ref = su.decode_reference(data, w, h, main=bool(kw.get("main")))
         assert len(ref) == n
         d = {"bytes": np.frombuffer(data, np.uint8), "n": np.array(n), "size": np.array([w, h])}
         for k in range(n):

@@ -24,11 +24,13 @@ def gop_tids(log2_sub_gop):
 
 
 def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_frac=0.15, inter_frac=0.85, deblock=True, qp_offsets=(0, 0),
-                cu_qp_delta=True, split_prob=0.5, idr_period=0, log2_sub_gop=0, bi_frac=0.5, direct_frac=0.1):
+                cu_qp_delta=True, split_prob=0.5, idr_period=0, log2_sub_gop=0, bi_frac=0.5, direct_frac=0.1,
+                main=False, iqt=False, ats=False, addb=False, addb_offsets=(0, 0)):
     """-> bytes.  Picture 0 is an IDR.  log2_sub_gop = 0: IPPP; n: hierarchical sub-GOPs of 2^n pictures, the layer-0 picture of
     each a P picture, the others B pictures (bi-prediction, temporal direct and two-list skip CUs)."""
     rng = np.random.default_rng(seed)
-    w = stream.StreamWriter(width, height, bit_depth, max_refs, qp_offsets[0], qp_offsets[1], deblock, cu_qp_delta, log2_sub_gop)
+    w = stream.StreamWriter(width, height, bit_depth, max_refs, qp_offsets[0], qp_offsets[1], deblock, cu_qp_delta, log2_sub_gop,
+                            main=main, iqt=iqt, ats=ats, addb=addb, alpha_off=addb_offsets[0], beta_off=addb_offsets[1])
     tids = gop_tids(log2_sub_gop)
     try:
         since_idr = 0
@@ -39,7 +41,8 @@ def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_fra
             tid = 0 if idr else tids[(since_idr - 1) % len(tids)]
             is_b = (not idr) and tid > 0
             b = synth.gen_frame(rng, width, height, bit_depth, inter_frac=0.0 if idr else inter_frac, n_refs=(max_refs, max_refs if is_b else 0),
-                                bi_frac=bi_frac if is_b else 0.0, split_prob=split_prob, coded_frac=0.6, max_level=6, amp=1.0)
+                                bi_frac=bi_frac if is_b else 0.0, split_prob=split_prob, coded_frac=0.6, max_level=6, amp=1.0,
+                                ats_frac=0.5 if ats else 0.0, ats_inter_frac=0.5 if ats else 0.0)
             if not idr:
                 inter = b["pred_mode"] == 1
                 r = rng.random(len(inter))
@@ -54,7 +57,7 @@ def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_fra
         w.close()
 
 
-def decode_reference(data, width, height, max_pics=64, threads=1):
+def decode_reference(data, width, height, max_pics=64, threads=1, main=False):
     """The reference decoder's output pictures (output order) as lists of [Y, U, V] int16 arrays; one process per decode."""
     import subprocess
     import tempfile
@@ -62,7 +65,8 @@ def decode_reference(data, width, height, max_pics=64, threads=1):
         fin, fout = os.path.join(td, "s.evc"), os.path.join(td, "s.raw")
         with open(fin, "wb") as f:
             f.write(data)
-        r = subprocess.run([REF_DECODE, fin, fout, str(width), str(height), str(threads)], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+        r = subprocess.run([REF_DECODE + ("_main" if main else ""), fin, fout, str(width), str(height), str(threads)],
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
         if r.returncode != 0:
             raise RuntimeError(f"reference decoder failed ({r.returncode}): {r.stderr.decode()[-300:]}")
         n = int(r.stderr.decode().split()[-2])
@@ -93,7 +97,7 @@ def decode_oracle(data):
     dpb, out = {}, []
     for p in stream.parse_stream(data):
         w, h, bd = p["width"], p["height"], p["bit_depth"]
-        sp = abi.make_seq_params(w, h, bd)
+        sp = abi.make_seq_params(w, h, bd, iqt=p["iqt"], addb=p["addb"])
         cb, keep = abi.make_cu_batch(p["batch"])
         cur = ol.Picture(w, h, p["poc"])
         refs = {(i, l): dpb[poc] for l in range(2) for i, poc in enumerate(p["refs"][l])}
@@ -101,7 +105,9 @@ def decode_oracle(data):
         maps = ol.Maps(w, h)
         m = maps.orc()
         o.orc_recon_batch(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), None)
-        if p["deblock_on"]:
+        if p["deblock_on"] and p["addb"]:
+            o.orc_deblock_addb(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), p["alpha_off"], p["beta_off"])
+        elif p["deblock_on"]:
             o.orc_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m))
         o.orc_pad(C.byref(sp), C.byref(fr.cur))
         if p["is_idr"]:

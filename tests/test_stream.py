@@ -26,6 +26,14 @@ CONFIGS = [
     (208, 120, 9, dict(log2_sub_gop=2, max_refs=2)),
     (144, 136, 17, dict(log2_sub_gop=3, max_refs=3, bit_depth=10)),
     (136, 136, 9, dict(log2_sub_gop=2, max_refs=4, direct_frac=0.4, skip_frac=0.3)),
+    # Main profile with the tools of the back half switched on - decoded by the reference's MAIN-profile library: frame-level parity of
+    # IQT (incl. its chroma QP mapping default), ATS-intra / ATS-inter syntax and transforms, ADDB with slice offsets
+    (136, 72, 3, dict(main=True)),
+    (136, 72, 4, dict(main=True, iqt=True)),
+    (136, 72, 4, dict(main=True, addb=True)),
+    (208, 120, 5, dict(main=True, iqt=True, addb=True, addb_offsets=(2, -1), max_refs=2)),
+    (136, 136, 5, dict(main=True, iqt=True, ats=True, addb=True)),
+    (144, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, log2_sub_gop=2, max_refs=2, bit_depth=10)),
 ]
 
 
@@ -36,9 +44,12 @@ def test_stream_reference_decoder_equals_parser_plus_oracle(cfg):
         pytest.skip("oracle/_ref is not built")
     w, h, n, kw = cfg
     data = su.make_stream(w, h, n, seed=w * 7 + n, **kw)
-    ref = su.decode_reference(data, w, h)
+    ref = su.decode_reference(data, w, h, main=bool(kw.get("main")))
     ours = su.decode_oracle(data)
     assert len(ref) == n and len(ours) == n
+    if kw.get("ats"):      # the stream really carries both kinds of ATS CUs
+        pics = stream.parse_stream(data)
+        assert sum(int((p["batch"]["ats"] & 1).sum()) for p in pics) > 0 and sum(int((p["batch"]["ats_inter"] != 0).sum()) for p in pics) > 0
     for k in range(n):
         for c in range(3):
             assert np.array_equal(ref[k][c], ours[k][c]), f"picture {k} plane {c}: {np.argwhere(ref[k][c] != ours[k][c])[:4]}"

@@ -30,6 +30,9 @@ static const uint8_t k_df_st[4][52] = {
     { 0 },
 };
 // xevd_tbl_qp_chroma_adjust_base (src_base/xevd_tbl.c:345-354): default Baseline chroma QP mapping.
+// ... and xevd_tbl_qp_chroma_adjust_main (xevd_tbl.c:334-342): the default when sps->tool_iqt is on (xevdm.c:471-479)
+static const int8_t k_chroma_qp_main[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
+    29, 30, 31, 32, 33, 34, 35, 36, 37, 37, 38, 39, 40, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54 };
 static const int8_t k_chroma_qp_base[58] = {
      0,  1,  2,  3,  4,  5,  6,  7,  8,  9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19,
     20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 29, 30, 31, 32, 32, 33, 33, 34, 34,
@@ -158,7 +161,7 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     const int boff = 6 * (sp->bit_depth_chroma - 8);
     for (int t = 0; t < 2; t++)
         for (int q = -boff; q <= 57; q++)
-            c->chroma_qp[t][q + boff] = sp->chroma_qp_table[t] ? sp->chroma_qp_table[t][q + boff] : (int8_t)(q < 0 ? q : k_chroma_qp_base[q]);
+            c->chroma_qp[t][q + boff] = sp->chroma_qp_table[t] ? sp->chroma_qp_table[t][q + boff] : (int8_t)(q < 0 ? q : (sp->tool_iqt ? k_chroma_qp_main[q] : k_chroma_qp_base[q]));
 
     auto fail = [&](int code) { xgpu_close(c); return code; };
     if (hipSetDevice(sp->device) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);

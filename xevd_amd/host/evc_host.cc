@@ -162,7 +162,8 @@ template <class C> static int sym_abs_mvd(C &c, int v, Model &m)      // xevd_ec
 
 struct Models {
     Model split[1], run[24], last[2], level[24], cbf_luma[1], cbf_cb[1], cbf_cr[1], cbf_all[1], pred_mode[3], direct[1], inter_dir[2],
-          intra_dir[2], mvp_idx[3], mvd[1], refi[2], dqp[1], skip[2];
+          intra_dir[2], mvp_idx[3], mvd[1], refi[2], dqp[1], skip[2],
+          ats_mode[1], ats_inter_flag[2], ats_inter_quad[1], ats_inter_hor[3], ats_inter_pos[1];      // Main: xevd_def.h:559-563
     void reset() { Model *p = (Model *)this; for (size_t i = 0; i < sizeof(Models) / sizeof(Model); i++) p[i] = 512; }     // PROB_INIT, xevd_eco.c:769-803
 };
 
@@ -179,6 +180,10 @@ static const uint8_t k_mpm[6][6][5] = {
 static const int8_t k_chroma_qp[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
     29, 29, 30, 31, 32, 32, 33, 33, 34, 34, 35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 39, 39, 40, 40, 40, 41, 41, 41 };
 
+// ... and with sps->tool_iqt: xevd_tbl_qp_chroma_adjust_main, xevd_tbl.c:334-342 (src_main/xevdm.c:471-479)
+static const int8_t k_chroma_qp_main[58] = { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29,
+    29, 30, 31, 32, 33, 34, 35, 36, 37, 37, 38, 39, 40, 40, 41, 42, 43, 44, 45, 46, 47, 48, 49, 50, 51, 52, 53, 54 };
+
 // zig-zag scan of a w x h block (init_scan, xevd_util.c:1004-1047): anti-diagonals, odd ones top-right -> bottom-left
 static void make_zigzag(std::vector<uint16_t> &scan, int w, int h)
 {
@@ -194,9 +199,10 @@ static void make_zigzag(std::vector<uint16_t> &scan, int w, int h)
 enum { MODE_INTRA = XGPU_MODE_INTRA, MODE_INTER = XGPU_MODE_INTER, MODE_SKIP = XGPU_MODE_SKIP };
 
 // ------------------------------------------------------------------------------------------------ stream / picture state
-struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, log2_ref_gap = 0, max_num_ref_pics = 1; };
+struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, log2_ref_gap = 0, max_num_ref_pics = 1;
+             int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0; };
 struct Pps { int constrained_intra = 0, cu_qp_delta = 0; };
-struct Slice { int type = XHOST_SLICE_I, qp = 32, qp_u_offset = 0, qp_v_offset = 0, deblock = 1; };
+struct Slice { int type = XHOST_SLICE_I, qp = 32, qp_u_offset = 0, qp_v_offset = 0, deblock = 1, alpha_off = 0, beta_off = 0; };
 
 struct RefPic {          // what a decoded picture leaves behind for later pictures (XEVD_PIC map_mv / list_poc, xevd_picman.c:213-221)
     int poc = 0, tid = 0;
@@ -211,6 +217,8 @@ struct Cu {
     int refi[2], mvp_idx[2];
     int16_t mvd[2][2], mv[2][2];
     int ipm, cbf[3], qp;
+    int ats;                         // bit 0 ats_intra_cu, bit 1 ats_intra_mode_v, bit 2 ats_intra_mode_h (layout of xgpu_cu_batch.ats)
+    int ats_inter;                   // ats_inter_info: idx | pos << 4
 };
 
 struct Picture {         // SCU maps of the picture being parsed / written (ctx->map_scu, map_ipm, map_mv, map_refi; cod_eco)
@@ -229,11 +237,11 @@ struct Picture {         // SCU maps of the picture being parsed / written (ctx-
 
 struct Batch {           // the xgpu_cu_batch under construction
     std::vector<uint16_t> x, y;
-    std::vector<uint8_t> log2w, log2h, pred_mode, qp, cbf, ipm;
+    std::vector<uint8_t> log2w, log2h, pred_mode, qp, cbf, ipm, ats, ats_inter;
     std::vector<int8_t> refi;
     std::vector<int16_t> mv, coef;
     std::vector<uint32_t> coef_off, ctu_start;
-    void clear() { x.clear(); y.clear(); log2w.clear(); log2h.clear(); pred_mode.clear(); qp.clear(); cbf.clear(); ipm.clear(); refi.clear(); mv.clear(); coef.clear(); coef_off.clear(); ctu_start.clear(); }
+    void clear() { x.clear(); y.clear(); log2w.clear(); log2h.clear(); pred_mode.clear(); qp.clear(); cbf.clear(); ipm.clear(); ats.clear(); ats_inter.clear(); refi.clear(); mv.clear(); coef.clear(); coef_off.clear(); ctu_start.clear(); }
 };
 
 struct Stream {          // everything both directions share
@@ -370,8 +378,9 @@ struct Stream {          // everything both directions share
     {
         const int off = 6 * (sps.bd_c - 8);
         const int iu = std::min(std::max(qp + sh.qp_u_offset, -off), 57), iv = std::min(std::max(qp + sh.qp_v_offset, -off), 57);
-        qp_u = (iu >= 0 ? k_chroma_qp[iu] : 0) + off;         // entries below 0 of the default table are zero-initialised storage
-        qp_v = (iv >= 0 ? k_chroma_qp[iv] : 0) + off;
+        const int8_t *tbl = sps.tool_iqt ? k_chroma_qp_main : k_chroma_qp;
+        qp_u = (iu >= 0 ? tbl[iu] : 0) + off;                 // entries below 0 of the default table are zero-initialised storage
+        qp_v = (iv >= 0 ? tbl[iv] : 0) + off;
     }
     // SCU maps after a CU (xevd_set_dec_info, xevd_util.c:1574-1660; cod_eco xevd.c:797-803)
     void commit(const Cu &cu)
@@ -421,7 +430,7 @@ struct Stream {          // everything both directions share
         int skip = 0;
         if (inter_slice) skip = c.bin(cu.mode == MODE_SKIP, models.skip[0]);
         if (!enc) { cu.mode = skip ? MODE_SKIP : MODE_INTRA; cu.refi[0] = cu.refi[1] = -1; memset(cu.mv, 0, sizeof(cu.mv)); memset(cu.mvd, 0, sizeof(cu.mvd));
-                    cu.mvp_idx[0] = cu.mvp_idx[1] = 0; cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0; cu.ipm = 0; }
+                    cu.mvp_idx[0] = cu.mvp_idx[1] = 0; cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0; cu.ipm = 0; cu.ats = cu.ats_inter = 0; }
         int16_t cand[4][2];
         const int n_lists = sh.type == XHOST_SLICE_B ? 2 : 1;
         if (skip) {
@@ -515,8 +524,38 @@ struct Stream {          // everything both directions share
             qp_prev = cu.qp;
         } else cu.qp = qp_prev;
         if (all_zero) return;
+        // Main, tool_ats (xevdm_eco_coef, xevdm_eco.c:902-934): transform selection of intra luma blocks up to 32x32, sub-block
+        // transform of inter CUs (the coefficient blocks of all components then have the TU size, xevdm_eco_xcoef :697-703)
+        int tlw = cu.log2w, tlh = cu.log2h;
+        if (sps.tool_ats) {
+            if (intra && cu.cbf[0] && cu.log2w <= 5 && cu.log2h <= 5) {
+                int on = c.ep(cu.ats & 1), mh = 0, mv = 0;
+                if (on) { mh = c.bin((cu.ats >> 2) & 1, models.ats_mode[0]); mv = c.bin((cu.ats >> 1) & 1, models.ats_mode[0]); }
+                cu.ats = on | (mv << 1) | (mh << 2);
+            } else cu.ats = 0;
+            const int w = 1 << cu.log2w, h = 1 << cu.log2h;
+            const int avail = (intra || w > 64 || h > 64) ? 0 : ((w >= 8) | ((h >= 8) << 1) | ((w >= 16) << 2) | ((h >= 16) << 3));      // xevdm_util.c:3565-3583
+            cu.ats_inter = avail ? code_ats_inter(c, cu.ats_inter, avail) : 0;
+            const int idx = cu.ats_inter & 15;
+            if (idx == 1 || idx == 3) tlw -= idx == 3 ? 2 : 1;
+            if (idx == 2 || idx == 4) tlh -= idx == 4 ? 2 : 1;
+        }
         for (int k = 0; k < 3; k++)
-            if (cu.cbf[k]) code_coefs(c, coef[k], cu.log2w - (k ? 1 : 0), cu.log2h - (k ? 1 : 0), k != 0, enc);
+            if (cu.cbf[k]) code_coefs(c, coef[k], tlw - (k ? 1 : 0), tlh - (k ? 1 : 0), k != 0, enc);
+    }
+
+    // ats_inter_info syntax (xevdm_eco_ats_inter_info, xevdm_eco.c:128-190; contexts 0 without cm_init)
+    template <class C> int code_ats_inter(C &c, int info, int avail)
+    {
+        const int mv_ = avail & 1, mh_ = (avail >> 1) & 1, vq = (avail >> 2) & 1, hq = (avail >> 3) & 1;
+        if (!c.bin(info != 0, models.ats_inter_flag[0])) return 0;
+        const int idx = info & 15;
+        int quad = idx >= 3, hor = idx == 2 || idx == 4, pos = (info >> 4) & 1;
+        if ((vq || hq) && (mv_ || mh_)) quad = c.bin(quad, models.ats_inter_quad[0]); else quad = 0;
+        if ((quad && vq && hq) || (!quad && mv_ && mh_)) hor = c.bin(hor, models.ats_inter_hor[0]);
+        else hor = (quad && hq) || (!quad && mh_);
+        pos = c.bin(pos, models.ats_inter_pos[0]);
+        return ((quad ? 2 : 0) + (hor ? 1 : 0) + 1) | (pos << 4);
     }
 };
 
@@ -548,15 +587,34 @@ struct xhost_parser {
     {
         Sps &s = st.sps;
         br.ue();                                         // sps_seq_parameter_set_id
-        const int profile = (int)br.get(8);
-        if (profile != 0 && profile != 2) return fail("not a Baseline-profile stream");
+        const int profile = (int)br.get(8);              // 0 Baseline, 1 Main, 2/3 still picture
+        if (profile < 0 || profile > 3) return fail("unknown profile");
+        s.profile_main = profile == 1 || profile == 3;
         br.get(8); br.get(32); br.get(32);               // level, toolset_idc_h/l
         if (br.ue() != 1) return fail("only 4:2:0 is supported");
         s.width = (int)br.ue(); s.height = (int)br.ue();
         s.bd_l = (int)br.ue() + 8; s.bd_c = (int)br.ue() + 8;
-        int tools = 0;
-        for (int i = 0; i < 13; i++) { const int f = br.get1(); if (i != 11) tools |= f; (void)f; }      // btt suco admvp eipd cm_init iqt addb alf htdf rpl pocs dquant dra
-        if (tools) return fail("Main-profile tools are not supported by this front end");
+        int unsupported = 0, rpl = 0, pocs = 0;
+        s.tool_iqt = s.tool_ats = s.tool_addb = 0;
+        if (!s.profile_main) {
+            for (int i = 0; i < 13; i++) { const int f = br.get1(); if (i != 11) unsupported |= f; }      // btt suco admvp eipd cm_init iqt addb alf htdf rpl pocs dquant dra
+        } else {                                          // xevdm_eco_sps, xevdm_eco.c:1863-1937: sub-flags follow their tool flag
+            unsupported |= br.get1();                    // sps_btt_flag
+            unsupported |= br.get1();                    // sps_suco_flag
+            unsupported |= br.get1();                    // tool_admvp
+            unsupported |= br.get1();                    // tool_eipd
+            unsupported |= br.get1();                    // tool_cm_init
+            s.tool_iqt = br.get1();
+            if (s.tool_iqt) s.tool_ats = br.get1();
+            s.tool_addb = br.get1();
+            unsupported |= br.get1();                    // tool_alf
+            unsupported |= br.get1();                    // tool_htdf
+            rpl = br.get1(); pocs = br.get1();
+            unsupported |= rpl | pocs;
+            br.get1();                                   // dquant_flag (only matters with cu_qp_delta_area handling; plain dqp otherwise)
+            unsupported |= br.get1();                    // tool_dra
+        }
+        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, admvp, eipd, cm_init, alf, htdf, rpl, pocs, dra)");
         s.log2_sub_gop = (int)br.ue();                   // tool_rpl = tool_pocs = 0
         if (s.log2_sub_gop == 0) s.log2_ref_gap = (int)br.ue();
         if (s.log2_sub_gop > 5) return fail("bad SPS");
@@ -591,6 +649,8 @@ struct xhost_parser {
         if (nut == NUT_IDR) br.get1();                   // no_output_of_prior_pics_flag
         if (sh.type != XHOST_SLICE_I && br.get1()) { br.ue(); if (sh.type == XHOST_SLICE_B) br.ue(); }      // num_ref_idx_active override (unused by the Baseline decoder, xevd_eco.c:409)
         sh.deblock = br.get1();
+        sh.alpha_off = sh.beta_off = 0;
+        if (sh.deblock && st.sps.tool_addb) { sh.alpha_off = br.se(); sh.beta_off = br.se(); }      // xevdm_eco.c:2767-2772
         sh.qp = (int)br.get(6);
         sh.qp_u_offset = br.se(); sh.qp_v_offset = br.se();
         while (!br.aligned()) if (br.get1()) return fail("slice header alignment");
@@ -629,6 +689,8 @@ struct xhost_parser {
             for (size_t i = 0; i < st.refp[l].size(); i++) out->refp_poc[i][l] = st.refp[l][i]->poc;
         }
         out->slice_qp = sh.qp; out->qp_u_offset = sh.qp_u_offset; out->qp_v_offset = sh.qp_v_offset; out->deblock_on = sh.deblock;
+        out->profile_main = st.sps.profile_main; out->tool_iqt = st.sps.tool_iqt; out->tool_ats = st.sps.tool_ats; out->tool_addb = st.sps.tool_addb;
+        out->deblock_alpha_offset = sh.alpha_off; out->deblock_beta_offset = sh.beta_off;
         std::vector<int> released;
         st.store_picture(nut == NUT_IDR, released);
         out->n_release = (int)std::min(released.size(), (size_t)32);
@@ -638,6 +700,7 @@ struct xhost_parser {
         b.x = batch.x.data(); b.y = batch.y.data(); b.log2w = batch.log2w.data(); b.log2h = batch.log2h.data();
         b.pred_mode = batch.pred_mode.data(); b.refi = batch.refi.data(); b.mv = batch.mv.data(); b.qp = batch.qp.data();
         b.cbf = batch.cbf.data(); b.ipm = batch.ipm.data(); b.coef_off = batch.coef_off.data();
+        if (st.sps.tool_ats) { b.ats = batch.ats.data(); b.ats_inter = batch.ats_inter.data(); }
         if (batch.coef.empty()) batch.coef.push_back(0);
         b.coef = batch.coef.data(); b.n_coef = batch.x.empty() ? 0 : n_coef;
         b.n_ctu = w_ctu * h_ctu; b.ctu_cu_start = batch.ctu_start.data();
@@ -682,10 +745,12 @@ struct xhost_parser {
         batch.qp.push_back((uint8_t)(cu.qp + 6 * (st.sps.bd_l - 8))); batch.qp.push_back((uint8_t)qp_u); batch.qp.push_back((uint8_t)qp_v);
         batch.cbf.push_back((uint8_t)(cu.cbf[0] | (cu.cbf[1] << 1) | (cu.cbf[2] << 2)));
         batch.ipm.push_back((uint8_t)cu.ipm); batch.ipm.push_back((uint8_t)cu.ipm);            // chroma mode = luma mode, xevd_eco.c:1154
+        batch.ats.push_back((uint8_t)cu.ats); batch.ats_inter.push_back((uint8_t)cu.ats_inter);
         batch.coef_off.push_back((uint32_t)n_coef);
+        const int tu_shift = (cu.ats_inter & 15) == 0 ? 0 : (((cu.ats_inter & 15) >= 3) ? 2 : 1);      // the TU is 1/2 or 1/4 of the CU
         for (int k = 0; k < 3; k++)
             if (cu.cbf[k]) {
-                const size_t n = (size_t)1 << (2 * log2s - (k ? 2 : 0));
+                const size_t n = (size_t)1 << (2 * log2s - (k ? 2 : 0) - tu_shift);
                 batch.coef.insert(batch.coef.end(), coef[k], coef[k] + n);
                 n_coef += n;
             }
@@ -737,10 +802,17 @@ struct xhost_writer {
     void write_sps()
     {
         BitWriter bw;
-        bw.ue(0); bw.put(0, 8); bw.put(0, 8); bw.put(0, 32); bw.put(0, 32);       // id, profile Baseline, level, toolset
+        bw.ue(0); bw.put(sp.profile_main ? 1 : 0, 8); bw.put(0, 8); bw.put(0, 32); bw.put(0, 32);       // id, profile, level, toolset
         bw.ue(1); bw.ue((uint32_t)sp.width); bw.ue((uint32_t)sp.height);
         bw.ue((uint32_t)(sp.bit_depth - 8)); bw.ue((uint32_t)(sp.bit_depth - 8));
-        for (int i = 0; i < 13; i++) bw.put1(i == 11 ? (sp.cu_qp_delta ? 1 : 0) : 0);       // all tools off; dquant_flag with cu_qp_delta
+        if (!sp.profile_main) for (int i = 0; i < 13; i++) bw.put1(i == 11 ? (sp.cu_qp_delta ? 1 : 0) : 0);       // all tools off; dquant_flag with cu_qp_delta
+        else {
+            for (int i = 0; i < 5; i++) bw.put1(0);      // btt suco admvp eipd cm_init
+            bw.put1(sp.tool_iqt ? 1 : 0);
+            if (sp.tool_iqt) bw.put1(sp.tool_ats ? 1 : 0);
+            bw.put1(sp.tool_addb ? 1 : 0);
+            for (int i = 0; i < 6; i++) bw.put1(0);      // alf htdf rpl pocs dquant dra
+        }
         bw.ue((uint32_t)sp.log2_sub_gop_length);
         if (sp.log2_sub_gop_length == 0) bw.ue(0);      // log2_ref_pic_gap_length
         bw.ue((uint32_t)sp.max_num_ref_pics);
@@ -770,6 +842,9 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     Sps &s = w->st.sps;
     s.width = sp->width; s.height = sp->height; s.bd_l = s.bd_c = sp->bit_depth; s.max_num_ref_pics = sp->max_num_ref_pics;
     s.log2_sub_gop = sp->log2_sub_gop_length;
+    s.profile_main = sp->profile_main ? 1 : 0;
+    s.tool_iqt = s.profile_main && sp->tool_iqt; s.tool_ats = s.tool_iqt && sp->tool_ats; s.tool_addb = s.profile_main && sp->tool_addb;
+    w->sp.tool_iqt = s.tool_iqt; w->sp.tool_ats = s.tool_ats; w->sp.tool_addb = s.tool_addb;
     w->st.pps.cu_qp_delta = sp->cu_qp_delta;
     return w;
 }
@@ -822,12 +897,19 @@ struct TreeWriter {
         cu.ipm = b->ipm ? b->ipm[i * 2] % 5 : 0;
         cu.qp = std::min(std::max((int)b->qp[i * 3] - bd_off, 0), 51);
         for (int k = 0; k < 3; k++) cu.cbf[k] = cu.mode == MODE_SKIP ? 0 : (b->cbf[i] >> k) & 1;
+        cu.ats = (st.sps.tool_ats && b->ats && cu.mode == MODE_INTRA) ? b->ats[i] & 7 : 0;
+        cu.ats_inter = 0;
+        if (st.sps.tool_ats && b->ats_inter && cu.mode == MODE_INTER && !cu.direct) {
+            const int info = b->ats_inter[i], idx = info & 15, dim = (idx == 1 || idx == 3) ? s : s;      // square CUs: both dimensions = s
+            if (idx >= 1 && idx <= 4 && dim >= (idx >= 3 ? 16 : 8) && s <= 64) cu.ats_inter = info & 0x1F;
+        }
+        const int tu_shift = (cu.ats_inter & 15) == 0 ? 0 : (((cu.ats_inter & 15) >= 3) ? 2 : 1);
         // coefficient blocks: a coded component needs at least one non-zero value to be representable
         std::vector<int16_t> blk[3];
         int16_t *coef[3];
         size_t off = b->coef_off[i];
         for (int k = 0; k < 3; k++) {
-            const size_t n = (size_t)1 << (2 * log2s - (k ? 2 : 0));
+            const size_t n = (size_t)1 << (2 * log2s - (k ? 2 : 0) - tu_shift);
             blk[k].assign(n, 0);
             if ((b->cbf[i] >> k) & 1) {
                 blk[k].assign(b->coef + off, b->coef + off + n);
@@ -868,6 +950,8 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
     if (idr) bw.put1(0);                                 // no_output_of_prior_pics_flag
     if (slice_type != XHOST_SLICE_I) bw.put1(0);         // num_ref_idx_active_override_flag
     bw.put1(st.sh.deblock);
+    st.sh.alpha_off = st.sps.tool_addb ? w->sp.deblock_alpha_offset : 0; st.sh.beta_off = st.sps.tool_addb ? w->sp.deblock_beta_offset : 0;
+    if (st.sh.deblock && st.sps.tool_addb) { bw.se(st.sh.alpha_off); bw.se(st.sh.beta_off); }
     bw.put((uint32_t)slice_qp, 6);
     bw.se(st.sh.qp_u_offset); bw.se(st.sh.qp_v_offset);
     bw.align_zero();

@@ -15,7 +15,9 @@ SLICE_B, SLICE_P, SLICE_I = 0, 1, 2
 
 class StreamParams(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("max_num_ref_pics", C.c_int), ("log2_sub_gop_length", C.c_int),
-                ("qp_u_offset", C.c_int), ("qp_v_offset", C.c_int), ("deblock_on", C.c_int), ("cu_qp_delta", C.c_int)]
+                ("qp_u_offset", C.c_int), ("qp_v_offset", C.c_int), ("deblock_on", C.c_int), ("cu_qp_delta", C.c_int),
+                ("profile_main", C.c_int), ("tool_iqt", C.c_int), ("tool_ats", C.c_int), ("tool_addb", C.c_int),
+                ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int)]
 
 
 class HostPicture(C.Structure):
@@ -23,6 +25,8 @@ class HostPicture(C.Structure):
                 ("poc", C.c_int), ("temporal_id", C.c_int), ("slice_type", C.c_int), ("is_idr", C.c_int), ("is_ref", C.c_int),
                 ("num_refp", C.c_int * 2), ("refp_poc", (C.c_int * 2) * abi.XGPU_MAX_REFS),
                 ("slice_qp", C.c_int), ("qp_u_offset", C.c_int), ("qp_v_offset", C.c_int), ("deblock_on", C.c_int),
+                ("profile_main", C.c_int), ("tool_iqt", C.c_int), ("tool_ats", C.c_int), ("tool_addb", C.c_int),
+                ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int),
                 ("n_release", C.c_int), ("release_poc", C.c_int * 32), ("batch", abi.CuBatch)]
 
 
@@ -52,9 +56,10 @@ def load():
 
 class StreamWriter:
     def __init__(self, width, height, bit_depth=8, max_num_ref_pics=1, qp_u_offset=0, qp_v_offset=0, deblock=True, cu_qp_delta=True,
-                 log2_sub_gop=0):
+                 log2_sub_gop=0, main=False, iqt=False, ats=False, addb=False, alpha_off=0, beta_off=0):
         self.lib = load()
-        sp = StreamParams(width, height, bit_depth, max_num_ref_pics, log2_sub_gop, qp_u_offset, qp_v_offset, int(deblock), int(cu_qp_delta))
+        sp = StreamParams(width, height, bit_depth, max_num_ref_pics, log2_sub_gop, qp_u_offset, qp_v_offset, int(deblock), int(cu_qp_delta),
+                          int(main), int(iqt), int(ats), int(addb), alpha_off, beta_off)
         self.h = self.lib.xhost_writer_open(C.byref(sp))
         if not self.h:
             raise ValueError("xhost_writer_open: bad stream parameters")
@@ -101,7 +106,8 @@ def iter_stream(data):
                 "x": _arr(b.x, n, np.uint16), "y": _arr(b.y, n, np.uint16), "log2w": _arr(b.log2w, n, np.uint8), "log2h": _arr(b.log2h, n, np.uint8),
                 "pred_mode": _arr(b.pred_mode, n, np.uint8), "refi": _arr(b.refi, n * 2, np.int8).reshape(n, 2),
                 "mv": _arr(b.mv, n * 4, np.int16).reshape(n, 2, 2), "qp": _arr(b.qp, n * 3, np.uint8).reshape(n, 3),
-                "cbf": _arr(b.cbf, n, np.uint8), "cbf_sub": None, "ats": None, "ats_inter": None, "ipm": _arr(b.ipm, n * 2, np.uint8).reshape(n, 2),
+                "cbf": _arr(b.cbf, n, np.uint8), "cbf_sub": None, "ats": _arr(b.ats, n, np.uint8) if b.ats else None,
+                "ats_inter": _arr(b.ats_inter, n, np.uint8) if b.ats_inter else None, "ipm": _arr(b.ipm, n * 2, np.uint8).reshape(n, 2),
                 "coef_off": _arr(b.coef_off, n, np.uint32), "coef": _arr(b.coef, max(b.n_coef, 1), np.int16), "n_coef": int(b.n_coef),
                 "ctu_cu_start": _arr(b.ctu_cu_start, b.n_ctu + 1, np.uint32), "constrained_intra_pred": int(b.constrained_intra_pred),
             }
@@ -110,6 +116,8 @@ def iter_stream(data):
                 "is_idr": bool(hp.is_idr), "is_ref": bool(hp.is_ref),
                 "refs": [[hp.refp_poc[i][l] for i in range(hp.num_refp[l])] for l in range(2)],
                 "slice_qp": hp.slice_qp, "qp_u_offset": hp.qp_u_offset, "qp_v_offset": hp.qp_v_offset, "deblock_on": bool(hp.deblock_on),
+                "main": bool(hp.profile_main), "iqt": hp.tool_iqt, "ats": hp.tool_ats, "addb": hp.tool_addb,
+                "alpha_off": hp.deblock_alpha_offset, "beta_off": hp.deblock_beta_offset,
                 "release": [hp.release_poc[i] for i in range(hp.n_release)], "batch": batch,
             }
     finally:
