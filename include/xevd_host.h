@@ -14,7 +14,9 @@
  *
  * Scope: Baseline profile, and Main-profile streams that switch on only tools of the back half - sps->tool_iqt, tool_ats,
  * tool_addb (syntax of src_main/xevdm_eco.c: SPS :1847-2004, slice header :2510-2800, ATS flags :128-190,354-393,902-934) -
- * with every other Main tool off (the CU syntax is then the Baseline one); 4:2:0, one tile and one slice per picture,
+ * and tool_alf (APS NAL units :2082-2135,2376-2477, coefficient syntax :2154-2318, slice-level parameters :2479-2657, per-CTU flags
+ * src_main/xevdm.c:2411-2418; coefficient reconstruction alf_recon_coef src_main/xevdm_alf.c:700-794; fixed filter sets are not
+ * supported yet) - with every other Main tool off (the CU syntax is then the Baseline one); 4:2:0, one tile and one slice per picture,
  * I / P / B slices incl. temporal layers (hierarchical sub-GOPs).
  * Conventions as xevd_hip.h: 0 / negative XEVD_ERR_* codes, nothing throws, one object per stream.
  */
@@ -49,6 +51,9 @@ typedef struct xhost_picture {
     int profile_main;                      /* 1: Main-profile stream (sps->profile_idc)                                   */
     int tool_iqt, tool_ats, tool_addb;     /* sps->tool_* flags that change arithmetic on the GPU path                      */
     int deblock_alpha_offset, deblock_beta_offset;      /* sh.sh_deblock_alpha/beta_offset (ADDB)                          */
+    int tool_alf;
+    int alf_on;                            /* sh.alf_on: `alf` below is what xgpu_alf takes (final coefficients, CTB flags)      */
+    xgpu_alf_params alf;
     int n_release;                         /* reference pictures unmarked before this one was stored (pic_marking_no_rpl) */
     int release_poc[32];
     xgpu_cu_batch batch;
@@ -72,9 +77,31 @@ typedef struct xhost_stream_params {
     int profile_main;                      /* 1: Main profile (needed for any of the tools below)                    */
     int tool_iqt, tool_ats, tool_addb;     /* sps->tool_iqt / tool_ats (needs iqt) / tool_addb                       */
     int deblock_alpha_offset, deblock_beta_offset;      /* slice-level ADDB offsets                                   */
+    int tool_alf;                          /* sps->tool_alf                                                          */
 } xhost_stream_params;
 
+/* ALF parameter set as it is coded in an APS NAL unit (XEVD_ALF_SLICE_PARAM after xevdm_eco_alf_aps_param), no fixed filters */
+typedef struct xhost_alf_aps {
+    int aps_id;                            /* 0..31                                                                 */
+    int luma_present, chroma_present;      /* alf_luma_filter_signal_flag / alf_chroma_filter_signal_flag            */
+    int luma_type_7x7;                     /* alf_luma_type_flag: 0 = 5x5 diamond (6 coded coefficients), 1 = 7x7 (12) */
+    int num_luma_filters;                  /* 1..25                                                                 */
+    uint8_t delta_idx[25];                 /* filter of every class                                                 */
+    int coef_delta_flag, pred_mode_flag;
+    uint8_t filter_coef_flag[25];          /* with coef_delta_flag: which filters carry coefficients                */
+    int16_t luma_coef[25][12];             /* coded values (differences with pred_mode_flag)                        */
+    int16_t chroma_coef[6];
+} xhost_alf_aps;
+/* slice-level ALF parameters of the NEXT picture (sh.alf_on, aps ids, CTB map) */
+typedef struct xhost_slice_alf {
+    int alf_on, aps_id_y, aps_id_ch, chroma_idc;      /* chroma_idc: bit 0 Cb, bit 1 Cr                              */
+    int ctb_map;                           /* alf_sh_param.is_ctb_alf_on: per-CTU luma flags are coded              */
+    const uint8_t *ctb_flag;               /* [n_ctu], used with ctb_map                                            */
+} xhost_slice_alf;
+
 xhost_writer *xhost_writer_open(const xhost_stream_params *sp);
+int  xhost_writer_add_alf_aps(xhost_writer *w, const xhost_alf_aps *aps);       /* appends an APS NAL unit (needs tool_alf)    */
+int  xhost_writer_set_slice_alf(xhost_writer *w, const xhost_slice_alf *sa);    /* for the next xhost_writer_add_picture       */
 /* Appends one picture (SPS + PPS first when it is the first).  `b`: leaf CUs of a quad tree (64..4) in decode order with the
    fields of xgpu_cu_batch; per CU the writer keeps pred_mode (INTRA / INTER / SKIP / DIR), refi and mv of the lists in use
    (INTER: refi[l] >= 0 selects the lists, indices are clamped to the actual list sizes; SKIP / DIR CUs take derived motion),

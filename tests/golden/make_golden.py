@@ -148,7 +148,9 @@ def golden_streams():
                                 "hier_b_gop4": (208, 120, 9, dict(log2_sub_gop=2, max_refs=2)),
                                 "hier_b_gop8_10b": (136, 136, 9, dict(log2_sub_gop=3, max_refs=3, bit_depth=10, direct_frac=0.3)),
                                 "main_iqt_ats_addb_10b": (144, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, log2_sub_gop=2, max_refs=2, bit_depth=10, addb_offsets=(1, -2))),
-                                "main_iqt_addb_8b": (208, 120, 5, dict(main=True, iqt=True, addb=True, max_refs=2))}.items():
+                                "main_iqt_addb_8b": (208, 120, 5, dict(main=True, iqt=True, addb=True, max_refs=2)),
+                                "main_all_tools_10b": (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, log2_sub_gop=2, max_refs=2, bit_depth=10)),
+                                "main_alf_addb_8b": (264, 136, 6, dict(main=True, alf=True, addb=True))}.items():
         data = su.make_stream(w, h, n, seed=len(name) * 13 + n, **kw)
         ref = su.decode_reference(data, w, h, main=bool(kw.get("main")))
         assert len(ref) == n

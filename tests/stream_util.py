@@ -25,12 +25,13 @@ def gop_tids(log2_sub_gop):
 
 def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_frac=0.15, inter_frac=0.85, deblock=True, qp_offsets=(0, 0),
                 cu_qp_delta=True, split_prob=0.5, idr_period=0, log2_sub_gop=0, bi_frac=0.5, direct_frac=0.1,
-                main=False, iqt=False, ats=False, addb=False, addb_offsets=(0, 0)):
+                main=False, iqt=False, ats=False, addb=False, addb_offsets=(0, 0), alf=False):
     """-> bytes.  Picture 0 is an IDR.  log2_sub_gop = 0: IPPP; n: hierarchical sub-GOPs of 2^n pictures, the layer-0 picture of
     each a P picture, the others B pictures (bi-prediction, temporal direct and two-list skip CUs)."""
     rng = np.random.default_rng(seed)
     w = stream.StreamWriter(width, height, bit_depth, max_refs, qp_offsets[0], qp_offsets[1], deblock, cu_qp_delta, log2_sub_gop,
-                            main=main, iqt=iqt, ats=ats, addb=addb, alpha_off=addb_offsets[0], beta_off=addb_offsets[1])
+                            main=main, iqt=iqt, ats=ats, addb=addb, alpha_off=addb_offsets[0], beta_off=addb_offsets[1], alf=alf)
+    n_ctu = ((width + 63) // 64) * ((height + 63) // 64)
     tids = gop_tids(log2_sub_gop)
     try:
         since_idr = 0
@@ -48,7 +49,22 @@ def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_fra
                 r = rng.random(len(inter))
                 b["pred_mode"] = np.where(inter & (r < skip_frac), 2, b["pred_mode"]).astype(np.uint8)
                 if is_b:
-                    b["pred_mode"] = np.where(inter & (r >= skip_frac) & (r < skip_frac + direct_frac), 3, b["pred_mode"]).astype(np.uint8)
+                    # (not the CUs that carry an ATS-inter TU: the writer drops ATS-inter of a direct-mode CU, the TU-sized coefficient
+                    #  block would be read as a CU-sized one, and 64-point blocks with coefficients past position 32 hit the reference's
+                    #  AVX-vs-C difference)
+                    plain = np.ones(len(inter), bool) if b.get("ats_inter") is None else (b["ats_inter"] == 0)
+                    b["pred_mode"] = np.where(inter & plain & (r >= skip_frac) & (r < skip_frac + direct_frac), 3, b["pred_mode"]).astype(np.uint8)
+            if alf:      # a fresh parameter set every other picture (different shapes of the syntax), per-CTU flags, some pictures without ALF / map
+                if k % 2 == 0:
+                    nf = int(rng.integers(1, 6))
+                    t7 = bool(rng.integers(0, 2))
+                    w.add_alf_aps(k % 32, luma=rng.integers(-12, 13, (nf, 12 if t7 else 6)), chroma=rng.integers(-10, 11, 6), type7=t7,
+                                  delta_idx=rng.integers(0, nf, 25), coef_delta_flag=int(nf > 1 and rng.random() < 0.4),
+                                  pred_mode_flag=int(rng.random() < 0.5), filter_coef_flag=np.maximum(rng.integers(0, 2, 25), np.arange(25) == 0))
+                    last_aps = k % 32
+                mode = k % 5
+                w.set_slice_alf(mode != 3, last_aps, last_aps, chroma_idc=int(rng.integers(0, 4)),
+                                ctb_flag=None if mode == 4 else (rng.random(n_ctu) < 0.7).astype(np.uint8))
             w.add_picture(b, stream.SLICE_I if idr else (stream.SLICE_B if is_b else stream.SLICE_P), slice_qp=int(rng.integers(24, 40)), idr=idr,
                           temporal_id=tid)
             since_idr += 1
@@ -97,7 +113,7 @@ def decode_oracle(data):
     dpb, out = {}, []
     for p in stream.parse_stream(data):
         w, h, bd = p["width"], p["height"], p["bit_depth"]
-        sp = abi.make_seq_params(w, h, bd, iqt=p["iqt"], addb=p["addb"])
+        sp = abi.make_seq_params(w, h, bd, iqt=p["iqt"], addb=p["addb"], alf=p["tool_alf"])
         cb, keep = abi.make_cu_batch(p["batch"])
         cur = ol.Picture(w, h, p["poc"])
         refs = {(i, l): dpb[poc] for l in range(2) for i, poc in enumerate(p["refs"][l])}
@@ -109,6 +125,9 @@ def decode_oracle(data):
             o.orc_deblock_addb(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), p["alpha_off"], p["beta_off"])
         elif p["deblock_on"]:
             o.orc_deblock_baseline(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m))
+        if p["alf"] is not None:
+            ap, keep_ap = abi.make_alf_params(p["alf"])
+            o.orc_alf(C.byref(sp), C.byref(fr.cur), C.byref(ap))
         o.orc_pad(C.byref(sp), C.byref(fr.cur))
         if p["is_idr"]:
             dpb.clear()

@@ -34,6 +34,11 @@ CONFIGS = [
     (208, 120, 5, dict(main=True, iqt=True, addb=True, addb_offsets=(2, -1), max_refs=2)),
     (136, 136, 5, dict(main=True, iqt=True, ats=True, addb=True)),
     (144, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, log2_sub_gop=2, max_refs=2, bit_depth=10)),
+    # ... and ALF: parameter sets in APS NAL units (5x5 / 7x7 luma shapes, merged classes, delta / prediction coding, chroma filter),
+    # slice-level switches, per-CTU map or none, pictures without ALF in between
+    (136, 72, 4, dict(main=True, alf=True)),
+    (264, 136, 11, dict(main=True, alf=True, addb=True)),
+    (144, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, log2_sub_gop=2, max_refs=2, bit_depth=10)),
 ]
 
 

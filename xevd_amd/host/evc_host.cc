@@ -163,7 +163,8 @@ template <class C> static int sym_abs_mvd(C &c, int v, Model &m)      // xevd_ec
 struct Models {
     Model split[1], run[24], last[2], level[24], cbf_luma[1], cbf_cb[1], cbf_cr[1], cbf_all[1], pred_mode[3], direct[1], inter_dir[2],
           intra_dir[2], mvp_idx[3], mvd[1], refi[2], dqp[1], skip[2],
-          ats_mode[1], ats_inter_flag[2], ats_inter_quad[1], ats_inter_hor[3], ats_inter_pos[1];      // Main: xevd_def.h:559-563
+          ats_mode[1], ats_inter_flag[2], ats_inter_quad[1], ats_inter_hor[3], ats_inter_pos[1],      // Main: xevd_def.h:559-563
+          alf_ctb[1];
     void reset() { Model *p = (Model *)this; for (size_t i = 0; i < sizeof(Models) / sizeof(Model); i++) p[i] = 512; }     // PROB_INIT, xevd_eco.c:769-803
 };
 
@@ -200,9 +201,43 @@ enum { MODE_INTRA = XGPU_MODE_INTRA, MODE_INTER = XGPU_MODE_INTER, MODE_SKIP = X
 
 // ------------------------------------------------------------------------------------------------ stream / picture state
 struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, log2_ref_gap = 0, max_num_ref_pics = 1;
-             int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0; };
+             int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0, tool_alf = 0; };
 struct Pps { int constrained_intra = 0, cu_qp_delta = 0; };
-struct Slice { int type = XHOST_SLICE_I, qp = 32, qp_u_offset = 0, qp_v_offset = 0, deblock = 1, alpha_off = 0, beta_off = 0; };
+struct Slice { int type = XHOST_SLICE_I, qp = 32, qp_u_offset = 0, qp_v_offset = 0, deblock = 1, alpha_off = 0, beta_off = 0;
+               int alf_on = 0, aps_id_y = 0, aps_id_ch = 0, alf_chroma_idc = 0, alf_ctb_map = 0; };
+
+// ---- ALF parameter sets (XEVD_ALF_SLICE_PARAM / ac_alf_line_buf[32], src_main/xevdm_alf.c:587-698) ----
+// zig-zag position of the coded coefficients inside the 13-tap (7x7 diamond) layout and Exp-Golomb order class of each coefficient
+// (pattern_to_large_filter5/7, golombIdx5/7: constants of the EVC specification, src_main/xevdm_alf.h:165-194)
+static const int k_alf_to_large[2][13] = { { 0, 0, 1, 0, 0, 2, 3, 4, 0, 0, 5, 6, 7 }, { 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13 } };
+static const int k_alf_golomb_idx[2][13] = { { 0, 0, 1, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0 }, { 0, 0, 1, 0, 0, 1, 2, 1, 0, 0, 1, 2, 0 } };
+struct AlfAps {
+    bool valid = false;
+    int luma_present = 0, chroma_present = 0, type7 = 0, num_filters = 1, coef_delta_flag = 0, pred_mode_flag = 0;
+    uint8_t delta_idx[25] = { 0 }, filter_coef_flag[25] = { 0 };
+    int16_t luma[25][13] = { { 0 } }, chroma[7] = { 0 };
+};
+// alfGolombDecode / its inverse (xevdm_eco.c:2154-2187): q zeros, a one, q + k suffix bits, sign bit (1 = positive) for non-zero values
+static int alf_golomb_read(BitReader &br, int k, bool is_signed)
+{
+    int q = 0;
+    while (!br.get1()) { if (++q > 24 || br.overrun) { br.overrun = true; return 0; } }
+    int v = ((1 << q) - 1) << k;
+    if (q + k > 0) v += (int)br.get(q + k);
+    if (is_signed && v != 0) v = br.get1() ? v : -v;
+    return v;
+}
+static void alf_golomb_write(BitWriter &bw, int v, int k, bool is_signed)
+{
+    const int a = v < 0 ? -v : v;
+    int q = 0;
+    while (a >= (((1 << (q + 1)) - 1) << k)) q++;
+    for (int i = 0; i < q; i++) bw.put1(0);
+    bw.put1(1);
+    if (q + k > 0) bw.put((uint32_t)(a - (((1 << q) - 1) << k)), q + k);
+    if (is_signed && a != 0) bw.put1(v > 0);
+}
+static int ilog2i(int v) { int l = 0; while ((v >> (l + 1)) > 0) l++; return l; }
 
 struct RefPic {          // what a decoded picture leaves behind for later pictures (XEVD_PIC map_mv / list_poc, xevd_picman.c:213-221)
     int poc = 0, tid = 0;
@@ -255,6 +290,84 @@ struct Stream {          // everything both directions share
     int poc = 0, prev_poc = 0, prev_doc_offset = -1, tid = 0, last_intra_poc = 0, qp_prev = 0, stale_list0_poc = 0;
     bool have_sps = false, have_pps = false;
     std::vector<uint16_t> scan[6][6];      // zig-zag tables by log2 size - 1
+    AlfAps alf_aps[32];
+    std::vector<uint8_t> alf_ctb_flag;     // luma CTB flags: all on at the start of a picture (xevdm.c:3001-3005), coded ones overwrite (:2411-2418)
+    int16_t alf_luma_final[25][13], alf_chroma_final[7];
+
+    // what alf_process hands to the filter (alf_load_paramline_from_aps_buffer2 + alf_recon_coef, xevdm_alf.c:682-794)
+    bool alf_finalise()
+    {
+        const AlfAps &y = alf_aps[sh.aps_id_y & 31];
+        if (!y.valid || !y.luma_present) return false;
+        int16_t coef[25][13];
+        memcpy(coef, y.luma, sizeof(coef));
+        const int ncm1 = y.type7 ? 12 : 6;
+        if (y.pred_mode_flag)
+            for (int i = 1; i < y.num_filters; i++) for (int j = 0; j < ncm1; j++) coef[i][j] = (int16_t)(coef[i][j] + coef[i - 1][j]);
+        for (int c = 0; c < 25; c++) {
+            int sum = 0;
+            for (int i = 0; i < 12; i++) {
+                const int pos = k_alf_to_large[y.type7][i];
+                alf_luma_final[c][i] = pos > 0 ? coef[y.delta_idx[c]][pos - 1] : (int16_t)0;
+                sum += alf_luma_final[c][i] << 1;
+            }
+            alf_luma_final[c][12] = (int16_t)(512 - sum);
+        }
+        memset(alf_chroma_final, 0, sizeof(alf_chroma_final));
+        if (sh.alf_chroma_idc) {
+            const AlfAps &ch = alf_aps[sh.aps_id_ch & 31];
+            if (!ch.valid || !ch.chroma_present) return false;
+            int sum = 0;
+            for (int i = 0; i < 6; i++) { alf_chroma_final[i] = ch.chroma[i]; sum += ch.chroma[i] << 1; }
+            alf_chroma_final[6] = (int16_t)(512 - sum);
+        }
+        return true;
+    }
+    // APS payload after aps_id / aps_type (xevdm_eco_alf_aps_param + xevdm_eco_alf_filter), reading or writing
+    template <bool WR> bool alf_aps_syntax(BitReader *br, BitWriter *bw, AlfAps &a)
+    {
+        auto bit = [&](int v) -> int { if (WR) { bw->put1(v); return v & 1; } return br->get1(); };
+        auto ue = [&](int v) -> int { if (WR) { bw->ue((uint32_t)v); return v; } return (int)br->ue(); };
+        auto gol = [&](int v, int k, bool sg) -> int { if (WR) { alf_golomb_write(*bw, v, k, sg); return v; } return alf_golomb_read(*br, k, sg); };
+        a.luma_present = bit(a.luma_present);
+        a.chroma_present = bit(a.chroma_present);
+        for (int pass = 0; pass < 2; pass++) {
+            const bool chroma = pass == 1;
+            if (chroma ? !a.chroma_present : !a.luma_present) continue;
+            int type7 = 0;
+            if (!chroma) {
+                a.num_filters = ue(a.num_filters - 1) + 1;
+                if (a.num_filters < 1 || a.num_filters > 25) return false;
+                a.type7 = bit(a.type7);
+                if (a.num_filters > 1) {
+                    const int nb = ilog2i(a.num_filters - 1) + 1;
+                    for (int c = 0; c < 25; c++) {
+                        if (WR) bw->put(a.delta_idx[c], nb); else a.delta_idx[c] = (uint8_t)br->get(nb);
+                        if (a.delta_idx[c] >= a.num_filters) return false;
+                    }
+                } else memset(a.delta_idx, 0, sizeof(a.delta_idx));
+                if (gol(0, 0, false) != 0) return false;                  // alf_luma_fixed_filter_usage_pattern: fixed filter sets are not supported
+                a.coef_delta_flag = bit(a.coef_delta_flag);
+                a.pred_mode_flag = (!a.coef_delta_flag && a.num_filters > 1) ? bit(a.pred_mode_flag) : 0;
+                type7 = a.type7;
+            }
+            int kmin = ue(0 + (WR ? alf_kmin_minus1 : 0)) + 1, ktab[3];
+            if (kmin > 7) return false;
+            for (int i = 0; i < (type7 ? 3 : 2); i++) { ktab[i] = kmin + bit(0); kmin = ktab[i]; }
+            const int nf = chroma ? 1 : a.num_filters, nc = type7 ? 12 : 6;
+            if (!chroma) {
+                if (a.coef_delta_flag) for (int f = 0; f < nf; f++) a.filter_coef_flag[f] = (uint8_t)bit(a.filter_coef_flag[f]);
+                else memset(a.filter_coef_flag, 1, sizeof(a.filter_coef_flag));
+            }
+            for (int f = 0; f < nf; f++) {
+                int16_t *dst = chroma ? a.chroma : a.luma[f];
+                if (!chroma && !a.filter_coef_flag[f]) { memset(dst, 0, sizeof(int16_t) * 13); continue; }
+                for (int i = 0; i < nc; i++) dst[i] = (int16_t)gol(dst[i], ktab[k_alf_golomb_idx[type7][i]], true);
+            }
+        }
+        return WR || !br->overrun;
+    }
+    int alf_kmin_minus1 = 0;
 
     Stream() { for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) make_zigzag(scan[a][b], 2 << a, 2 << b); }
 
@@ -595,7 +708,7 @@ struct xhost_parser {
         s.width = (int)br.ue(); s.height = (int)br.ue();
         s.bd_l = (int)br.ue() + 8; s.bd_c = (int)br.ue() + 8;
         int unsupported = 0, rpl = 0, pocs = 0;
-        s.tool_iqt = s.tool_ats = s.tool_addb = 0;
+        s.tool_iqt = s.tool_ats = s.tool_addb = s.tool_alf = 0;
         if (!s.profile_main) {
             for (int i = 0; i < 13; i++) { const int f = br.get1(); if (i != 11) unsupported |= f; }      // btt suco admvp eipd cm_init iqt addb alf htdf rpl pocs dquant dra
         } else {                                          // xevdm_eco_sps, xevdm_eco.c:1863-1937: sub-flags follow their tool flag
@@ -607,14 +720,14 @@ struct xhost_parser {
             s.tool_iqt = br.get1();
             if (s.tool_iqt) s.tool_ats = br.get1();
             s.tool_addb = br.get1();
-            unsupported |= br.get1();                    // tool_alf
+            s.tool_alf = br.get1();
             unsupported |= br.get1();                    // tool_htdf
             rpl = br.get1(); pocs = br.get1();
             unsupported |= rpl | pocs;
             br.get1();                                   // dquant_flag (only matters with cu_qp_delta_area handling; plain dqp otherwise)
             unsupported |= br.get1();                    // tool_dra
         }
-        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, admvp, eipd, cm_init, alf, htdf, rpl, pocs, dra)");
+        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, admvp, eipd, cm_init, htdf, rpl, pocs, dra)");
         s.log2_sub_gop = (int)br.ue();                   // tool_rpl = tool_pocs = 0
         if (s.log2_sub_gop == 0) s.log2_ref_gap = (int)br.ue();
         if (s.log2_sub_gop > 5) return fail("bad SPS");
@@ -647,6 +760,16 @@ struct xhost_parser {
         sh.type = (int)br.ue();
         if (sh.type < 0 || sh.type > 2) return fail("bad slice type");
         if (nut == NUT_IDR) br.get1();                   // no_output_of_prior_pics_flag
+        sh.alf_on = sh.alf_chroma_idc = sh.alf_ctb_map = 0;
+        if (st.sps.tool_alf) {                           // xevdm_eco.c:2608-2657 (4:2:0)
+            sh.alf_on = br.get1();
+            if (sh.alf_on) {
+                sh.aps_id_y = (int)br.get(5);
+                sh.alf_ctb_map = br.get1();
+                sh.alf_chroma_idc = (int)br.get(2);
+                if (sh.alf_chroma_idc) sh.aps_id_ch = (int)br.get(5);
+            }
+        }
         if (sh.type != XHOST_SLICE_I && br.get1()) { br.ue(); if (sh.type == XHOST_SLICE_B) br.ue(); }      // num_ref_idx_active override (unused by the Baseline decoder, xevd_eco.c:409)
         sh.deblock = br.get1();
         sh.alpha_off = sh.beta_off = 0;
@@ -670,9 +793,11 @@ struct xhost_parser {
         dec.start();
         batch.clear();
         const int W = st.sps.width, H = st.sps.height, w_ctu = (W + 63) >> 6, h_ctu = (H + 63) >> 6;
+        st.alf_ctb_flag.assign((size_t)w_ctu * h_ctu, 1);
         for (int k = 0; k < 3; k++) blk[k].assign(64 * 64, 0);
         for (int cy = 0; cy < h_ctu; cy++) for (int cx = 0; cx < w_ctu; cx++) {
             batch.ctu_start.push_back((uint32_t)batch.x.size());
+            if (sh.alf_on && sh.alf_ctb_map) st.alf_ctb_flag[(size_t)cy * w_ctu + cx] = (uint8_t)dec.bin(0, st.models.alf_ctb[0]);      // xevdm.c:2411-2418
             const int rc = parse_tree(dec, cx << 6, cy << 6, 6);
             if (rc != XGPU_OK) return rc;
             if (br.overrun) return fail("slice data ends early");
@@ -691,6 +816,13 @@ struct xhost_parser {
         out->slice_qp = sh.qp; out->qp_u_offset = sh.qp_u_offset; out->qp_v_offset = sh.qp_v_offset; out->deblock_on = sh.deblock;
         out->profile_main = st.sps.profile_main; out->tool_iqt = st.sps.tool_iqt; out->tool_ats = st.sps.tool_ats; out->tool_addb = st.sps.tool_addb;
         out->deblock_alpha_offset = sh.alpha_off; out->deblock_beta_offset = sh.beta_off;
+        out->tool_alf = st.sps.tool_alf; out->alf_on = sh.alf_on;
+        if (sh.alf_on) {
+            if (!st.alf_finalise()) return fail("slice refers to an ALF parameter set that was not sent");
+            out->alf.enable[0] = 1; out->alf.enable[1] = sh.alf_chroma_idc & 1; out->alf.enable[2] = (sh.alf_chroma_idc >> 1) & 1;
+            out->alf.luma_coef = &st.alf_luma_final[0][0]; out->alf.chroma_coef = st.alf_chroma_final;
+            out->alf.ctb_flag = st.alf_ctb_flag.data(); out->alf.across_tiles = 0;
+        }
         std::vector<int> released;
         st.store_picture(nut == NUT_IDR, released);
         out->n_release = (int)std::min(released.size(), (size_t)32);
@@ -785,6 +917,14 @@ extern "C" int xhost_parser_next(xhost_parser *p, xhost_picture *out)
         if (nut == NUT_SPS) rc = p->parse_sps(br);
         else if (nut == NUT_PPS) rc = p->parse_pps(br);
         else if (nut == NUT_IDR || nut == NUT_NONIDR) return p->parse_slice(br, nut, tid, out);
+        else if (nut == 26) {                            // APS (xevdm_eco_aps_gen, xevdm_eco.c:2082-2135)
+            const int id = (int)br.get(5), type = (int)br.get(3);
+            if (type != 0) return p->fail("only ALF parameter sets (APS type 0) are supported");
+            AlfAps a;
+            if (!p->st.alf_aps_syntax<false>(&br, nullptr, a)) return p->fail("bad or unsupported ALF APS (fixed filter sets are not supported)");
+            a.valid = true;
+            p->st.alf_aps[id] = a;
+        }
         else if (nut == NUT_SEI) rc = XGPU_OK;          // picture signatures are checked by the caller against its own output if wanted
         else return p->fail("unsupported NAL unit type");
         if (rc != XGPU_OK) return rc;
@@ -798,6 +938,9 @@ struct xhost_writer {
     Stream st;
     std::vector<uint8_t> out;
     int n_pics = 0;
+    bool headers_done = false;
+    xhost_slice_alf next_alf = { 0, 0, 0, 0, 0, nullptr };
+    std::vector<uint8_t> next_alf_ctb;
 
     void write_sps()
     {
@@ -811,7 +954,8 @@ struct xhost_writer {
             bw.put1(sp.tool_iqt ? 1 : 0);
             if (sp.tool_iqt) bw.put1(sp.tool_ats ? 1 : 0);
             bw.put1(sp.tool_addb ? 1 : 0);
-            for (int i = 0; i < 6; i++) bw.put1(0);      // alf htdf rpl pocs dquant dra
+            bw.put1(sp.tool_alf ? 1 : 0);
+            for (int i = 0; i < 5; i++) bw.put1(0);      // htdf rpl pocs dquant dra
         }
         bw.ue((uint32_t)sp.log2_sub_gop_length);
         if (sp.log2_sub_gop_length == 0) bw.ue(0);      // log2_ref_pic_gap_length
@@ -844,11 +988,50 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     s.log2_sub_gop = sp->log2_sub_gop_length;
     s.profile_main = sp->profile_main ? 1 : 0;
     s.tool_iqt = s.profile_main && sp->tool_iqt; s.tool_ats = s.tool_iqt && sp->tool_ats; s.tool_addb = s.profile_main && sp->tool_addb;
-    w->sp.tool_iqt = s.tool_iqt; w->sp.tool_ats = s.tool_ats; w->sp.tool_addb = s.tool_addb;
+    s.tool_alf = s.profile_main && sp->tool_alf;
+    w->sp.tool_iqt = s.tool_iqt; w->sp.tool_ats = s.tool_ats; w->sp.tool_addb = s.tool_addb; w->sp.tool_alf = s.tool_alf;
     w->st.pps.cu_qp_delta = sp->cu_qp_delta;
     return w;
 }
 extern "C" void xhost_writer_close(xhost_writer *w) { delete w; }
+extern "C" int xhost_writer_set_slice_alf(xhost_writer *w, const xhost_slice_alf *sa)
+{
+    if (!w || !sa) return XGPU_ERR_INVALID_ARGUMENT;
+    w->next_alf = *sa;
+    w->next_alf_ctb.clear();
+    const size_t n_ctu = (size_t)((w->sp.width + 63) >> 6) * (size_t)((w->sp.height + 63) >> 6);
+    if (sa->ctb_flag) w->next_alf_ctb.assign(sa->ctb_flag, sa->ctb_flag + n_ctu);
+    w->next_alf.ctb_flag = nullptr;
+    return XGPU_OK;
+}
+extern "C" int xhost_writer_add_alf_aps(xhost_writer *w, const xhost_alf_aps *in)
+{
+    if (!w || !in || !w->st.sps.tool_alf || in->aps_id < 0 || in->aps_id > 31 || in->num_luma_filters < 1 || in->num_luma_filters > 25) return XGPU_ERR_INVALID_ARGUMENT;
+    if (w->n_pics == 0 && w->out.empty()) { w->write_sps(); w->write_pps(); w->headers_done = true; }
+    AlfAps a;
+    a.valid = true;
+    a.luma_present = in->luma_present != 0; a.chroma_present = in->chroma_present != 0; a.type7 = in->luma_type_7x7 != 0;
+    a.num_filters = in->num_luma_filters; a.coef_delta_flag = in->coef_delta_flag != 0; a.pred_mode_flag = in->pred_mode_flag != 0;
+    for (int c = 0; c < 25; c++) { a.delta_idx[c] = (uint8_t)(in->delta_idx[c] % a.num_filters); a.filter_coef_flag[c] = in->filter_coef_flag[c] != 0; }
+    for (int f = 0; f < 25; f++) for (int i = 0; i < 12; i++) a.luma[f][i] = in->luma_coef[f][i];
+    for (int i = 0; i < 6; i++) a.chroma[i] = in->chroma_coef[i];
+    BitWriter bw;
+    bw.put((uint32_t)in->aps_id, 5); bw.put(0, 3);
+    AlfAps coded = a;
+    if (!w->st.alf_aps_syntax<true>(nullptr, &bw, coded)) return XGPU_ERR_INVALID_ARGUMENT;
+    bw.put1(0);                                          // aps_extension_flag
+    bw.align_zero();
+    write_nal(w->out, 26, 0, bw);
+    // keep what a decoder will hold after parsing (filters without coefficients are zero, flags normalised)
+    BitReader br;
+    br.p = bw.buf.data(); br.size = bw.buf.size();
+    br.get(8);
+    AlfAps parsed;
+    w->st.alf_aps_syntax<false>(&br, nullptr, parsed);
+    parsed.valid = true;
+    w->st.alf_aps[in->aps_id] = parsed;
+    return XGPU_OK;
+}
 extern "C" int xhost_writer_bytes(xhost_writer *w, const uint8_t **bytes, size_t *size)
 {
     if (!w || !bytes || !size) return XGPU_ERR_INVALID_ARGUMENT;
@@ -933,7 +1116,7 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
 {
     if (!w || !b || slice_qp < 0 || slice_qp > 51 || temporal_id < 0 || temporal_id > w->sp.log2_sub_gop_length) return XGPU_ERR_INVALID_ARGUMENT;
     Stream &st = w->st;
-    if (w->n_pics == 0) { idr = 1; w->write_sps(); w->write_pps(); }
+    if (w->n_pics == 0) { idr = 1; if (!w->headers_done) { w->write_sps(); w->write_pps(); w->headers_done = true; } }
     if (idr) { slice_type = XHOST_SLICE_I; temporal_id = 0; }
     if (slice_type < 0 || slice_type > 2) return XGPU_ERR_INVALID_ARGUMENT;
     st.sh.type = slice_type; st.sh.qp = slice_qp; st.sh.qp_u_offset = w->sp.qp_u_offset; st.sh.qp_v_offset = w->sp.qp_v_offset;
@@ -948,6 +1131,20 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
     bw.ue(0);                                            // slice_pic_parameter_set_id
     bw.ue((uint32_t)slice_type);
     if (idr) bw.put1(0);                                 // no_output_of_prior_pics_flag
+    const int w_ctu = (st.sps.width + 63) >> 6, h_ctu = (st.sps.height + 63) >> 6;
+    st.alf_ctb_flag.assign((size_t)w_ctu * h_ctu, 1);
+    if (st.sps.tool_alf) {
+        st.sh.alf_on = w->next_alf.alf_on ? 1 : 0; st.sh.aps_id_y = w->next_alf.aps_id_y & 31; st.sh.aps_id_ch = w->next_alf.aps_id_ch & 31;
+        st.sh.alf_chroma_idc = w->next_alf.chroma_idc & 3; st.sh.alf_ctb_map = w->next_alf.ctb_map ? 1 : 0;
+        if (st.sh.alf_on && (!st.alf_aps[st.sh.aps_id_y].valid || !st.alf_aps[st.sh.aps_id_y].luma_present ||
+                             (st.sh.alf_chroma_idc && (!st.alf_aps[st.sh.aps_id_ch].valid || !st.alf_aps[st.sh.aps_id_ch].chroma_present))))
+            return XGPU_ERR_INVALID_ARGUMENT;
+        bw.put1(st.sh.alf_on);
+        if (st.sh.alf_on) {
+            bw.put((uint32_t)st.sh.aps_id_y, 5); bw.put1(st.sh.alf_ctb_map); bw.put((uint32_t)st.sh.alf_chroma_idc, 2);
+            if (st.sh.alf_chroma_idc) bw.put((uint32_t)st.sh.aps_id_ch, 5);
+        }
+    } else st.sh.alf_on = 0;
     if (slice_type != XHOST_SLICE_I) bw.put1(0);         // num_ref_idx_active_override_flag
     bw.put1(st.sh.deblock);
     st.sh.alpha_off = st.sps.tool_addb ? w->sp.deblock_alpha_offset : 0; st.sh.beta_off = st.sps.tool_addb ? w->sp.deblock_beta_offset : 0;
@@ -971,8 +1168,14 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
             return XGPU_ERR_INVALID_ARGUMENT;
         tw.leaf[(size_t)(b->y[i] >> 2) * st.pic.w_scu + (b->x[i] >> 2)] = i;
     }
-    const int w_ctu = (st.sps.width + 63) >> 6, h_ctu = (st.sps.height + 63) >> 6;
-    for (int cy = 0; cy < h_ctu; cy++) for (int cx = 0; cx < w_ctu; cx++) tw.node(cx << 6, cy << 6, 6);
+    for (int cy = 0; cy < h_ctu; cy++) for (int cx = 0; cx < w_ctu; cx++) {
+        if (st.sh.alf_on && st.sh.alf_ctb_map) {
+            const int f = w->next_alf_ctb.empty() ? 1 : (w->next_alf_ctb[(size_t)cy * w_ctu + cx] != 0);
+            enc.bin(f, st.models.alf_ctb[0]);
+            st.alf_ctb_flag[(size_t)cy * w_ctu + cx] = (uint8_t)f;
+        }
+        tw.node(cx << 6, cy << 6, 6);
+    }
     if (tw.error) return XGPU_ERR_INVALID_ARGUMENT;
     enc.tile_end();
     write_nal(w->out, idr ? NUT_IDR : NUT_NONIDR, temporal_id, bw);

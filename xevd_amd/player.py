@@ -35,7 +35,7 @@ class StreamDecoder:
                 if isinstance(p, Exception):
                     raise p
                 if dec is None:
-                    dec = XgpuDecoder(p["width"], p["height"], p["bit_depth"], device=self.device, iqt=p["iqt"], addb=p["addb"], max_pics=12)
+                    dec = XgpuDecoder(p["width"], p["height"], p["bit_depth"], device=self.device, iqt=p["iqt"], addb=p["addb"], alf=p["tool_alf"], max_pics=12)
                     free = [dec.pic_alloc() for _ in range(10)]
                 if p["is_idr"]:
                     free.extend(slots.values()); slots.clear()
@@ -43,7 +43,7 @@ class StreamDecoder:
                 refs = {(i, l): (slots[poc], poc) for l in range(2) for i, poc in enumerate(p["refs"][l])}
                 hb = dec.batch_create(p["batch"])
                 dec.decode_picture(cur, p["poc"], refs, hb, deblock=p["deblock_on"], pad=True, qp_u_offset=p["qp_u_offset"], qp_v_offset=p["qp_v_offset"],
-                                   alpha_off=p["alpha_off"], beta_off=p["beta_off"])
+                                   alpha_off=p["alpha_off"], beta_off=p["beta_off"], alf=p["alf"])
                 planes = None
                 if download:
                     planes = dec.pic_download(cur)

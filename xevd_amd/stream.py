@@ -17,7 +17,18 @@ class StreamParams(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("max_num_ref_pics", C.c_int), ("log2_sub_gop_length", C.c_int),
                 ("qp_u_offset", C.c_int), ("qp_v_offset", C.c_int), ("deblock_on", C.c_int), ("cu_qp_delta", C.c_int),
                 ("profile_main", C.c_int), ("tool_iqt", C.c_int), ("tool_ats", C.c_int), ("tool_addb", C.c_int),
-                ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int)]
+                ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int), ("tool_alf", C.c_int)]
+
+
+class AlfAps(C.Structure):
+    _fields_ = [("aps_id", C.c_int), ("luma_present", C.c_int), ("chroma_present", C.c_int), ("luma_type_7x7", C.c_int),
+                ("num_luma_filters", C.c_int), ("delta_idx", C.c_uint8 * 25), ("coef_delta_flag", C.c_int), ("pred_mode_flag", C.c_int),
+                ("filter_coef_flag", C.c_uint8 * 25), ("luma_coef", (C.c_int16 * 12) * 25), ("chroma_coef", C.c_int16 * 6)]
+
+
+class SliceAlf(C.Structure):
+    _fields_ = [("alf_on", C.c_int), ("aps_id_y", C.c_int), ("aps_id_ch", C.c_int), ("chroma_idc", C.c_int), ("ctb_map", C.c_int),
+                ("ctb_flag", C.POINTER(C.c_uint8))]
 
 
 class HostPicture(C.Structure):
@@ -27,6 +38,7 @@ class HostPicture(C.Structure):
                 ("slice_qp", C.c_int), ("qp_u_offset", C.c_int), ("qp_v_offset", C.c_int), ("deblock_on", C.c_int),
                 ("profile_main", C.c_int), ("tool_iqt", C.c_int), ("tool_ats", C.c_int), ("tool_addb", C.c_int),
                 ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int),
+                ("tool_alf", C.c_int), ("alf_on", C.c_int), ("alf", abi.AlfParams),
                 ("n_release", C.c_int), ("release_poc", C.c_int * 32), ("batch", abi.CuBatch)]
 
 
@@ -50,16 +62,18 @@ def load():
         lib.xhost_writer_add_picture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.CuBatch)]
         lib.xhost_writer_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         lib.xhost_writer_close.argtypes = [C.c_void_p]
+        lib.xhost_writer_add_alf_aps.argtypes = [C.c_void_p, C.POINTER(AlfAps)]
+        lib.xhost_writer_set_slice_alf.argtypes = [C.c_void_p, C.POINTER(SliceAlf)]
         _lib = lib
     return _lib
 
 
 class StreamWriter:
     def __init__(self, width, height, bit_depth=8, max_num_ref_pics=1, qp_u_offset=0, qp_v_offset=0, deblock=True, cu_qp_delta=True,
-                 log2_sub_gop=0, main=False, iqt=False, ats=False, addb=False, alpha_off=0, beta_off=0):
+                 log2_sub_gop=0, main=False, iqt=False, ats=False, addb=False, alpha_off=0, beta_off=0, alf=False):
         self.lib = load()
         sp = StreamParams(width, height, bit_depth, max_num_ref_pics, log2_sub_gop, qp_u_offset, qp_v_offset, int(deblock), int(cu_qp_delta),
-                          int(main), int(iqt), int(ats), int(addb), alpha_off, beta_off)
+                          int(main), int(iqt), int(ats), int(addb), alpha_off, beta_off, int(alf))
         self.h = self.lib.xhost_writer_open(C.byref(sp))
         if not self.h:
             raise ValueError("xhost_writer_open: bad stream parameters")
@@ -69,6 +83,36 @@ class StreamWriter:
         rc = self.lib.xhost_writer_add_picture(self.h, int(idr), slice_type, slice_qp, temporal_id, C.byref(cb))
         if rc != 0:
             raise RuntimeError(f"xhost_writer_add_picture -> {rc}")
+
+    def add_alf_aps(self, aps_id, luma=None, chroma=None, type7=True, delta_idx=None, coef_delta_flag=0, pred_mode_flag=0, filter_coef_flag=None):
+        """luma: [n_filters][12 or 6] coded coefficient values or None; chroma: [6] or None"""
+        a = AlfAps()
+        a.aps_id, a.luma_present, a.chroma_present, a.luma_type_7x7 = aps_id, int(luma is not None), int(chroma is not None), int(type7)
+        a.num_luma_filters = 1 if luma is None else len(luma)
+        a.coef_delta_flag, a.pred_mode_flag = int(coef_delta_flag), int(pred_mode_flag)
+        for c in range(25):
+            a.delta_idx[c] = 0 if delta_idx is None else int(delta_idx[c])
+            a.filter_coef_flag[c] = 1 if filter_coef_flag is None else int(filter_coef_flag[c])
+        if luma is not None:
+            for f, row in enumerate(luma):
+                for i, v in enumerate(row):
+                    a.luma_coef[f][i] = int(v)
+        if chroma is not None:
+            for i, v in enumerate(chroma):
+                a.chroma_coef[i] = int(v)
+        rc = self.lib.xhost_writer_add_alf_aps(self.h, C.byref(a))
+        if rc != 0:
+            raise RuntimeError(f"xhost_writer_add_alf_aps -> {rc}")
+
+    def set_slice_alf(self, alf_on, aps_id_y=0, aps_id_ch=0, chroma_idc=0, ctb_flag=None):
+        sa = SliceAlf(int(alf_on), aps_id_y, aps_id_ch, chroma_idc, int(ctb_flag is not None), None)
+        keep = None
+        if ctb_flag is not None:
+            keep = np.ascontiguousarray(ctb_flag, np.uint8)
+            sa.ctb_flag = keep.ctypes.data_as(C.POINTER(C.c_uint8))
+        rc = self.lib.xhost_writer_set_slice_alf(self.h, C.byref(sa))
+        if rc != 0:
+            raise RuntimeError(f"xhost_writer_set_slice_alf -> {rc}")
 
     def bytes(self):
         p, n = C.c_void_p(), C.c_size_t()
@@ -117,7 +161,10 @@ def iter_stream(data):
                 "refs": [[hp.refp_poc[i][l] for i in range(hp.num_refp[l])] for l in range(2)],
                 "slice_qp": hp.slice_qp, "qp_u_offset": hp.qp_u_offset, "qp_v_offset": hp.qp_v_offset, "deblock_on": bool(hp.deblock_on),
                 "main": bool(hp.profile_main), "iqt": hp.tool_iqt, "ats": hp.tool_ats, "addb": hp.tool_addb,
-                "alpha_off": hp.deblock_alpha_offset, "beta_off": hp.deblock_beta_offset,
+                "alpha_off": hp.deblock_alpha_offset, "beta_off": hp.deblock_beta_offset, "tool_alf": hp.tool_alf,
+                "alf": None if not hp.alf_on else {
+                    "enable": tuple(hp.alf.enable[i] for i in range(3)), "luma_coef": _arr(hp.alf.luma_coef, 25 * 13, np.int16).reshape(25, 13),
+                    "chroma_coef": _arr(hp.alf.chroma_coef, 7, np.int16), "ctb_flag": _arr(hp.alf.ctb_flag, b.n_ctu, np.uint8), "across_tiles": 0},
                 "release": [hp.release_poc[i] for i in range(hp.n_release)], "batch": batch,
             }
     finally:
