@@ -208,6 +208,182 @@ __device__ __forceinline__ void mc_chroma_2x2(const int16_t *p, int s, const uin
         o[r] = pack2(clip3(0, maxv, V ? acc[r][0] >> rg.sh2 : acc[r][0]), clip3(0, maxv, V ? acc[r][1] >> rg.sh2 : acc[r][1]));
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Wave-uniform motion (every SCU of a wave's 32x32 tile belongs to one CU - three quarters of the samples of a typical
+// picture): the separable filter runs as a tile through the wave's own LDS instead of per lane.  The 39x39 reference window
+// is fetched ONCE with 16-byte loads (the per-lane path fetches 11 rows x 24 bytes per SCU: 5x the vector-memory
+// instructions, which bound that path), the horizontal pass produces each of the 39x32 intermediate values once
+// (per lane: 11 rows for 4 output rows), and the vertical pass reads 11 rows x 8 bytes per lane from LDS.  Same integer
+// arithmetic and rounding regimes as mc_luma_4x4 / mc_chroma_2x2, only the work is shared between the lanes.
+// LDS accesses of one wave execute in order, so no workgroup barrier is involved - only compiler ordering.
+// ---------------------------------------------------------------------------------------------------------
+#define UW_STRIDE 48                 // luma window row stride in samples: 96 B, 16-byte aligned chunk stores
+#define UI_STRIDE 40                 // intermediate rows: 80 B = 20 banks, so the 8 x 4 SCUs of a half wave hit 64 different banks
+#define UC_STRIDE 24                 // chroma rows (window and intermediate): 12 banks, conflict-free for the 64 lanes' dword reads
+#define UNI_W_SAMPLES (39 * UW_STRIDE)
+#define UNI_SAMPLES   (UNI_W_SAMPLES + 39 * UI_STRIDE)
+
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// p = reference sample at (tile x - 3, tile y - 3); lane l owns the SCU (l & 7, l >> 3) of the tile.  o[] as mc_luma_4x4.
+// The fetch is split from the filtering so that a wave has the windows of both lists (and its residual) in flight at once.
+struct TileFetch { uint4 y[4]; uint2 c[3]; };
+__device__ __forceinline__ void tile_fetch(const int16_t *p, int s, const int16_t *pu, const int16_t *pv, int sc, int lane, TileFetch &f)
+{
+#pragma unroll
+    for (int it = 0; it < 4; it++) {                                // luma window: 39 rows x 5 chunks of 8 samples
+        const int c = lane + 64 * it, row = (c * 205) >> 10, k = c - row * 5;            // c / 5 for c < 256
+        if (c < 195) { const U32x4u q = *(const U32x4u *)(p + row * s + 8 * k); f.y[it] = make_uint4(q.a, q.b, q.c, q.d); }
+    }
+#pragma unroll
+    for (int it = 0; it < 3; it++) {                                // chroma windows: 2 planes x 19 rows x 5 chunks of 4 samples
+        const int c = lane + 64 * it, pl = c >= 95, cc = c - 95 * pl, row = (cc * 205) >> 10, k = cc - row * 5;
+        if (c < 190) { const U32x2u q = *(const U32x2u *)((pl ? pv : pu) + row * sc + 4 * k); f.c[it] = make_uint2(q.a, q.b); }
+    }
+}
+
+template <bool H, bool V>
+__device__ __forceinline__ void mc_luma_tile(const uint4 v[4], const uint32_t ch[4], const uint32_t cv[4], Regime rg, int maxv,
+                                             int16_t *W, int16_t *I, int lane, uint32_t o[8])
+{
+#pragma unroll
+    for (int it = 0; it < 4; it++) {
+        const int c = lane + 64 * it, row = (c * 205) >> 10, k = c - row * 5;
+        if (c < 195) *(uint4 *)(W + row * UW_STRIDE + 8 * k) = v[it];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 5; it++) {                                // horizontal pass: 39 rows x 8 groups of 4 columns
+        const int idx = lane + 64 * it, row = idx >> 3, g = idx & 7;
+        if (idx < 312) {
+            const uint2 *w = (const uint2 *)(W + row * UW_STRIDE + 4 * g);
+            const uint2 a = w[0], b = w[1], c = w[2];
+            const uint32_t D0 = a.x, D1 = a.y, D2 = b.x, D3 = b.y, D4 = c.x, D5 = c.y;
+            uint2 r;
+            if (H) {
+                const uint32_t Q0 = hi_lo(D1, D0), Q1 = hi_lo(D2, D1), Q2 = hi_lo(D3, D2), Q3 = hi_lo(D4, D3), Q4 = hi_lo(D5, D4);
+                int t[4];
+                t[0] = dot2(ch[3], D3, dot2(ch[2], D2, dot2(ch[1], D1, dot2z(ch[0], D0))));
+                t[2] = dot2(ch[3], D4, dot2(ch[2], D3, dot2(ch[1], D2, dot2z(ch[0], D1))));
+                t[1] = dot2(ch[3], Q3, dot2(ch[2], Q2, dot2(ch[1], Q1, dot2z(ch[0], Q0))));
+                t[3] = dot2(ch[3], Q4, dot2(ch[2], Q3, dot2(ch[1], Q2, dot2z(ch[0], Q1))));
+#pragma unroll
+                for (int q = 0; q < 4; q++) { t[q] >>= rg.sh1; if (!V) t[q] = clip3(0, maxv, t[q]); }
+                r = make_uint2(pack2(t[0], t[1]), pack2(t[2], t[3]));
+            } else {
+                r = make_uint2(hi_lo(D2, D1), hi_lo(D3, D2));       // samples 3..6 of the window
+            }
+            *(uint2 *)(I + row * UI_STRIDE + 4 * g) = r;
+        }
+    }
+    wave_lds_sync();
+    const int16_t *base = I + ((lane >> 3) << 2) * UI_STRIDE + ((lane & 7) << 2);
+    if (!V) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { const uint2 q = *(const uint2 *)(base + (r + 3) * UI_STRIDE); o[r * 2] = q.x; o[r * 2 + 1] = q.y; }
+    } else {
+        uint2 q[11];
+#pragma unroll
+        for (int j = 0; j < 11; j++) q[j] = *(const uint2 *)(base + j * UI_STRIDE);
+        int acc[4][4];
+#pragma unroll
+        for (int j = 1; j < 11; j++) {
+            const uint32_t pr[4] = { __builtin_amdgcn_perm(q[j].x, q[j - 1].x, 0x05040100u), __builtin_amdgcn_perm(q[j].x, q[j - 1].x, 0x07060302u),
+                                     __builtin_amdgcn_perm(q[j].y, q[j - 1].y, 0x05040100u), __builtin_amdgcn_perm(q[j].y, q[j - 1].y, 0x07060302u) };
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int d = j - 1 - r;
+                    if (d == 0) acc[r][c] = dot2a(cv[0], pr[c], rg.off2);
+                    else if (d > 0 && d <= 6 && (d & 1) == 0) acc[r][c] = dot2(cv[d >> 1], pr[c], acc[r][c]);
+                }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int v[4];
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[c] = clip3(0, maxv, acc[r][c] >> rg.sh2);
+            o[r * 2 + 0] = pack2(v[0], v[1]);
+            o[r * 2 + 1] = pack2(v[2], v[3]);
+        }
+    }
+    wave_lds_sync();
+}
+
+// Both chroma planes of the tile (16x16 each).  pu / pv = reference sample at (tile x - 1, tile y - 1) of the plane.
+template <bool H, bool V>
+__device__ __forceinline__ void mc_chroma_tile(const uint2 v[3], const uint32_t ch[2], const uint32_t cv[2],
+                                               Regime rg, int maxv, int16_t *W, int16_t *I, int lane, uint32_t ou[2], uint32_t ov[2])
+{
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+        const int c = lane + 64 * it, pl = c >= 95, cc = c - 95 * pl, row = (cc * 205) >> 10, k = cc - row * 5;
+        if (c < 190) *(uint2 *)(W + (pl * 19 + row) * UC_STRIDE + 4 * k) = v[it];
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int it = 0; it < 3; it++) {                                // horizontal pass: 2 x 19 rows x 4 groups of 4 columns
+        const int idx = lane + 64 * it, prow = idx >> 2, g = idx & 3;
+        if (idx < 152) {
+            const uint2 *w = (const uint2 *)(W + prow * UC_STRIDE + 4 * g);
+            const uint2 a = w[0], b = w[1];
+            const uint32_t D0 = a.x, D1 = a.y, D2 = b.x, D3 = b.y;
+            const uint32_t Q0 = hi_lo(D1, D0), Q1 = hi_lo(D2, D1);
+            uint2 r;
+            if (H) {
+                const uint32_t Q2 = hi_lo(D3, D2);
+                int t[4];
+                t[0] = dot2(ch[1], D1, dot2z(ch[0], D0));
+                t[1] = dot2(ch[1], Q1, dot2z(ch[0], Q0));
+                t[2] = dot2(ch[1], D2, dot2z(ch[0], D1));
+                t[3] = dot2(ch[1], Q2, dot2z(ch[0], Q1));
+#pragma unroll
+                for (int q = 0; q < 4; q++) { t[q] >>= rg.sh1; if (!V) t[q] = clip3(0, maxv, t[q]); }
+                r = make_uint2(pack2(t[0], t[1]), pack2(t[2], t[3]));
+            } else {
+                r = make_uint2(Q0, Q1);                             // samples 1..4
+            }
+            *(uint2 *)(I + prow * UC_STRIDE + 4 * g) = r;
+        }
+    }
+    wave_lds_sync();
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++) {
+        const int16_t *base = I + (pl * 19 + ((lane >> 3) << 1)) * UC_STRIDE + ((lane & 7) << 1);
+        uint32_t *o = pl ? ov : ou;
+        if (!V) {
+            o[0] = *(const uint32_t *)(base + UC_STRIDE); o[1] = *(const uint32_t *)(base + 2 * UC_STRIDE);
+        } else {
+            uint32_t q[5];
+#pragma unroll
+            for (int j = 0; j < 5; j++) q[j] = *(const uint32_t *)(base + j * UC_STRIDE);
+            int acc[2][2];
+#pragma unroll
+            for (int j = 1; j < 5; j++) {
+                const uint32_t pr[2] = { __builtin_amdgcn_perm(q[j], q[j - 1], 0x05040100u), __builtin_amdgcn_perm(q[j], q[j - 1], 0x07060302u) };
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const int d = j - 1 - r;
+                        if (d == 0) acc[r][c] = dot2a(cv[0], pr[c], rg.off2);
+                        else if (d == 2) acc[r][c] = dot2(cv[1], pr[c], acc[r][c]);
+                    }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+                o[r] = pack2(clip3(0, maxv, acc[r][0] >> rg.sh2), clip3(0, maxv, acc[r][1] >> rg.sh2));
+        }
+    }
+    wave_lds_sync();
+}
+
 // (p0 + p1 + 1) >> 1 on packed non-negative s16 pairs (xevd_average_16b_no_clip, xevd_mc.c:145-167)
 __device__ __forceinline__ uint32_t avg2(uint32_t a, uint32_t b)
 {
@@ -235,6 +411,7 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     __shared__ uint4    s_ref[XGPU_MAX_REFS * 2][2];        // RefEntry [idx][list]
     __shared__ uint4    s_ltap[17];                         // luma taps of this sequence's table, [16] = identity
     __shared__ uint2    s_ctap[33];
+    __shared__ __attribute__((aligned(16))) int16_t s_tile[4][UNI_SAMPLES];      // per wave: window + intermediate of the tile path
 
     // XCD-aware mapping: workgroup b runs on XCD b % 8; give every XCD a contiguous band of regions so that
     // vertically adjacent regions (which share reference halos) hit the same L2.
@@ -251,6 +428,13 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     const int first = a.ctu_cu_start[ctu];
     const int n = min((int)a.ctu_cu_start[ctu + 1] - first, MAX_CU_PER_CTU);
     const int t = threadIdx.x;
+    // SCU coordinates in the picture: a wave covers 8x8 SCUs (32x32 samples), so that CUs of 32x32 and above fill whole waves
+    // with one motion class (the MC variants below are chosen per wave)
+    const int sx = (rx << 4) + ((t >> 6 & 1) << 3) + (t & 7), sy = (ry << 4) + ((t >> 7) << 3) + ((t >> 3) & 7);
+    const bool active = sx < (a.pic_w >> 2) && sy < (a.pic_h >> 2);
+    // the covering CU: painted per picture by k_paint (a per-lane scan of the CTU's CU list cost ~30 us of this kernel at 8K).
+    // Fetched before the staging below: the kernel is bound by its chain of dependent memory round trips, not by bandwidth.
+    const int found = active ? (int)a.owner[sy * a.w_scu + sx] : 0xFFFF;
 
     if (t < XGPU_MAX_REFS * 2) {
         const uint4 *re = (const uint4 *)&a.refp[t >> 1][t & 1];
@@ -265,14 +449,7 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     }
     __syncthreads();
 
-    // SCU coordinates in the picture: a wave covers 8x8 SCUs (32x32 samples), so that CUs of 32x32 and above fill whole waves
-    // with one motion class (the MC variants below are chosen per wave)
-    const int sx = (rx << 4) + ((t >> 6 & 1) << 3) + (t & 7), sy = (ry << 4) + ((t >> 7) << 3) + ((t >> 3) & 7);
-    const bool active = sx < (a.pic_w >> 2) && sy < (a.pic_h >> 2);
-    if (!active) return;
-    // the covering CU: painted per picture by k_paint (a per-lane scan of the CTU's CU list cost ~30 us of this kernel at 8K)
-    const int found = a.owner[sy * a.w_scu + sx];
-    if (found >= n) return;
+    if (!active || found >= n) return;
 
     uint4 r0, r1;
     if (found < LDS_CU) { r0 = s_cu[found][0]; r1 = s_cu[found][1]; }
@@ -336,6 +513,83 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     if (use[0] && use[1] && s_ref[refi0 * 2][1].z == s_ref[refi1 * 2 + 1][1].z && mvt[0][0] == mvt[1][0] && mvt[0][1] == mvt[1][1])
         use[1] = false;                                               // identical motion, xevd_mc.c:512-519
 
+    // residual of this SCU (zero where nothing is coded); the tile path issues the loads before the filtering
+    uint32_t rl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ru[2] = {0, 0}, rv[2] = {0, 0};
+    auto load_resid = [&]() {
+        if (!in_tu) return;
+        uint32_t off = coef_off;
+        const int cwc = tu_w >> 1;
+        if (cbf & 1) {
+            const int16_t *r = a.resid + off + ly * tu_w + lx;
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const uint2 v = *(const uint2 *)(r + k * tu_w); rl[k * 2] = v.x; rl[k * 2 + 1] = v.y; }
+            off += tu_w * tu_h;
+        }
+        if (cbf & 2) {
+            const int16_t *r = a.resid + off + (ly >> 1) * cwc + (lx >> 1);
+            ru[0] = *(const uint32_t *)r; ru[1] = *(const uint32_t *)(r + cwc);
+            off += cwc * (tu_h >> 1);
+        }
+        if (cbf & 4) {
+            const int16_t *r = a.resid + off + (ly >> 1) * cwc + (lx >> 1);
+            rv[0] = *(const uint32_t *)r; rv[1] = *(const uint32_t *)(r + cwc);
+        }
+    };
+    // every lane of the wave alive and in the same CU: tile path
+    const bool uni = __ballot(1) == ~0ull && __ballot(found == __builtin_amdgcn_readfirstlane(found)) == ~0ull;
+    if (uni) {
+        const int lane = t & 63;
+        int16_t *W = s_tile[t >> 6], *I = W + UNI_W_SAMPLES;
+        const int wx = __builtin_amdgcn_readfirstlane(x), wy = __builtin_amdgcn_readfirstlane(y);
+        TileFetch tf[2];
+        int tpx[2], tpy[2], tmx[2], tmy[2];
+#pragma unroll
+        for (int l = 0; l < 2; l++) {                               // all the windows first ...
+            if (!__builtin_amdgcn_readfirstlane((int)use[l])) continue;
+            const int ri = __builtin_amdgcn_readfirstlane(refis[l] * 2 + l);
+            const uint4 e0 = s_ref[ri][0], e1 = s_ref[ri][1];
+            const int16_t *ry_ = (const int16_t *)(((uint64_t)e0.y << 32) | e0.x), *ru_ = (const int16_t *)(((uint64_t)e0.w << 32) | e0.z);
+            const int16_t *rv_ = (const int16_t *)(((uint64_t)e1.y << 32) | e1.x);
+            tmx[l] = __builtin_amdgcn_readfirstlane(mvs[l][0]); tmy[l] = __builtin_amdgcn_readfirstlane(mvs[l][1]);
+            const int px = tpx[l] = (wx << 2) + __builtin_amdgcn_readfirstlane((int)mvt[l][0]);
+            const int py = tpy[l] = (wy << 2) + __builtin_amdgcn_readfirstlane((int)mvt[l][1]);
+            const int off = ((py >> 3) - 1) * a.s_c + (px >> 3) - 1;
+            tile_fetch(ry_ + ((py >> 2) - 3) * a.s_l + (px >> 2) - 3, a.s_l, ru_ + off, rv_ + off, a.s_c, lane, tf[l]);
+        }
+        load_resid();                                               // ... and the residual, then the filtering
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+            if (!__builtin_amdgcn_readfirstlane((int)use[l])) continue;
+            const int mvx = tmx[l], mvy = tmy[l], px = tpx[l], py = tpy[l];
+            const int ldx = (mvx & 3) != 0, ldy = (mvy & 3) != 0, cdx = (mvx & 7) != 0, cdy = (mvy & 7) != 0;
+            uint32_t o[8], ou[2], ov[2];
+            {
+                const uint4 th = s_ltap[ldx ? ((px & 3) << 2) : 16], tv = s_ltap[ldy ? ((py & 3) << 2) : 16];
+                const uint32_t ch[4] = { th.x, th.y, th.z, th.w }, cv[4] = { tv.x, tv.y, tv.z, tv.w };
+                const Regime rg = regime(ldx, ldy, a.bd_l);
+                if (ldx) { if (ldy) mc_luma_tile<true, true>(tf[l].y, ch, cv, rg, maxl, W, I, lane, o); else mc_luma_tile<true, false>(tf[l].y, ch, cv, rg, maxl, W, I, lane, o); }
+                else     { if (ldy) mc_luma_tile<false, true>(tf[l].y, ch, cv, rg, maxl, W, I, lane, o); else mc_luma_tile<false, false>(tf[l].y, ch, cv, rg, maxl, W, I, lane, o); }
+            }
+            {
+                const uint2 th = s_ctap[cdx ? ((px & 7) << 2) : 32], tv = s_ctap[cdy ? ((py & 7) << 2) : 32];
+                const uint32_t c2h[2] = { th.x, th.y }, c2v[2] = { tv.x, tv.y };
+                const Regime rg = regime(cdx, cdy, a.bd_c);
+                if (cdx) { if (cdy) mc_chroma_tile<true, true>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, ou, ov); else mc_chroma_tile<true, false>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, ou, ov); }
+                else     { if (cdy) mc_chroma_tile<false, true>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, ou, ov); else mc_chroma_tile<false, false>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, ou, ov); }
+            }
+            if (nl == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) pl[k] = o[k];
+                pu[0] = ou[0]; pu[1] = ou[1]; pv[0] = ov[0]; pv[1] = ov[1];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) pl[k] = avg2(pl[k], o[k]);
+                pu[0] = avg2(pu[0], ou[0]); pu[1] = avg2(pu[1], ou[1]);
+                pv[0] = avg2(pv[0], ov[0]); pv[1] = avg2(pv[1], ov[1]);
+            }
+            nl++;
+        }
+    } else
 #pragma unroll
     for (int l = 0; l < 2; l++) {
         if (!use[l]) continue;
@@ -387,31 +641,13 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     if (nl == 0) return;     // inter CU without a valid reference: nothing predicted (does not occur in valid streams)
 
     // ---- residual add + clip (xevd_recon.c:35-71; the LUMA bit depth clips all three components, :75-90) ----
-    uint32_t off = coef_off;
+    if (!uni) load_resid();
     if (cbf & 1) {
-        const int16_t *r = a.resid + off + ly * tu_w + lx;
-        if (in_tu) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint2 v = *(const uint2 *)(r + k * tu_w);
-                pl[k * 2 + 0] = recon2(pl[k * 2 + 0], v.x, maxl);
-                pl[k * 2 + 1] = recon2(pl[k * 2 + 1], v.y, maxl);
-            }
-        }
-        off += tu_w * tu_h;
+        for (int k = 0; k < 8; k++) pl[k] = recon2(pl[k], rl[k], maxl);
     }
-    const int cwc = tu_w >> 1;
-    if ((cbf & 2) && in_tu) {
-        const int16_t *r = a.resid + off + (ly >> 1) * cwc + (lx >> 1);
-        pu[0] = recon2(pu[0], *(const uint32_t *)r, maxl);
-        pu[1] = recon2(pu[1], *(const uint32_t *)(r + cwc), maxl);
-    }
-    if (cbf & 2) off += cwc * (tu_h >> 1);
-    if ((cbf & 4) && in_tu) {
-        const int16_t *r = a.resid + off + (ly >> 1) * cwc + (lx >> 1);
-        pv[0] = recon2(pv[0], *(const uint32_t *)r, maxl);
-        pv[1] = recon2(pv[1], *(const uint32_t *)(r + cwc), maxl);
-    }
+    if (cbf & 2) { pu[0] = recon2(pu[0], ru[0], maxl); pu[1] = recon2(pu[1], ru[1], maxl); }
+    if (cbf & 4) { pv[0] = recon2(pv[0], rv[0], maxl); pv[1] = recon2(pv[1], rv[1], maxl); }
 
     int16_t *dy = a.cur_y + y * a.s_l + x;
 #pragma unroll

@@ -135,12 +135,12 @@ def gen_partition_btt(rng, width, height, log2_ctu=6, split_prob=0.5, btt_frac=0
 
 def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_frac=0.0, coded_frac=0.6,
               n_refs=(1, 0), qp_range=(22, 37), mv_sigma_px=8.0, oob_frac=0.05, split_prob=0.5,
-              chroma_qp_table=None, max_level=24, amp=2.0, ats_frac=0.0, ats_inter_frac=0.0, btt_frac=0.0):
+              chroma_qp_table=None, max_level=24, amp=2.0, ats_frac=0.0, ats_inter_frac=0.0, btt_frac=0.0, min_log2=2):
     """One picture's CU batch as a dict of numpy arrays (layout of xgpu_cu_batch, include/xevd_hip.h)."""
     if btt_frac > 0:
         x, y, l2w, l2h, start = gen_partition_btt(rng, width, height, log2_ctu, split_prob, btt_frac)
     else:
-        x, y, l2w, l2h, start = gen_partition(rng, width, height, log2_ctu, split_prob)
+        x, y, l2w, l2h, start = gen_partition(rng, width, height, log2_ctu, split_prob, min_log2)
     n = len(x)
     w = (1 << l2w.astype(np.int64))
     h = (1 << l2h.astype(np.int64))
