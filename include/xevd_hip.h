@@ -16,6 +16,8 @@
  *   xgpu_alf                      <- mctx->fn_alf (xevd_alf -> alf_process)      src_main/xevdm.c:2105, xevdm_alf.c:901-1249
  *   xgpu_pad                      <- ctx->fn_picbuf_expand                       src_base/xevd_util.c:365-427
  *   xgpu_pic_download             <- xevd_pull (picture hand-off)                src_base/xevd.c:2042-2071
+ *   xgpu_pic_output               <- xevd_pull + the application's imgb_cpy_codec_to_out (crop fields xevd.c:2058-2069,
+ *                                    bit-depth conversions app/xevd_app_util.h:441-552,656-700)
  *
  * plus fine-grained shims with the reference's per-block function-table signatures
  * (XEVD_MC_L / XEVD_MC_C src_base/xevd_mc.h:47-49, XEVD_ITXB src_base/xevd_def.h:360, fn_recon :1466)
@@ -149,6 +151,14 @@ int  xgpu_pic_free(xgpu_ctx *ctx, int pic);
 /* planes point at the first ACTIVE sample (XEVD_PIC.y/u/v); strides in samples.  Upload does not pad.   */
 int  xgpu_pic_upload(xgpu_ctx *ctx, int pic, const int16_t *y, int s_y, const int16_t *u, const int16_t *v, int s_c);
 int  xgpu_pic_download(xgpu_ctx *ctx, int pic, int16_t *y, int s_y, int16_t *u, int16_t *v, int s_c);
+/* The output side in one call: the active area minus a conformance-window crop (luma samples, even: sps picture_crop_*_offset
+   as xevd_pull reports them), converted to out_bit_depth - 8: one byte per sample, (v + round) >> shift clipped to 255;
+   below the coding depth: the same rounding shift clipped to the range, 16 bit; above: v << shift; equal: copy - and packed
+   as Y, U, V planes back to back without row padding (the bytes imgb_write puts in a .yuv file).  Crop, conversion and
+   packing run on the device; `dst` (host, >= xgpu_pic_output_size() bytes) receives one contiguous copy.  Blocking. */
+size_t xgpu_pic_output_size(const xgpu_ctx *ctx, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b);   /* 0: invalid */
+int  xgpu_pic_output(xgpu_ctx *ctx, int pic, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b,
+                     void *dst, size_t dst_size);
 /* whole padded buffers (XEVD_PIC.buf_y/u/v layout: stride = w + 2*pad, rows = h + 2*pad), for tests.     */
 int  xgpu_pic_download_padded(xgpu_ctx *ctx, int pic, int16_t *buf_y, int16_t *buf_u, int16_t *buf_v);
 int  xgpu_pic_upload_padded(xgpu_ctx *ctx, int pic, const int16_t *buf_y, const int16_t *buf_u, const int16_t *buf_v);

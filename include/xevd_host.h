@@ -54,6 +54,8 @@ typedef struct xhost_picture {
     int tool_alf;
     int alf_on;                            /* sh.alf_on: `alf` below is what xgpu_alf takes (final coefficients, CTB flags)      */
     xgpu_alf_params alf;
+    int has_md5;                           /* a picture-signature SEI follows the slice: MD5 of every plane's 16-bit samples    */
+    uint8_t md5[3][16];                    /*   (xevd_eco_sei xevd_eco.c:1617-1678, xevd_md5_imgb xevd_util.c:985-1002)          */
     int n_release;                         /* reference pictures unmarked before this one was stored (pic_marking_no_rpl) */
     int release_poc[32];
     xgpu_cu_batch batch;
@@ -110,6 +112,10 @@ int  xhost_writer_set_slice_alf(xhost_writer *w, const xhost_slice_alf *sa);    
    not allow the split; the coefficient blocks then have the TU size).
    idr != 0 forces an IDR picture with an I slice.  temporal_id: nuh_temporal_id (0 for low-delay streams). */
 int  xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type, int slice_qp, int temporal_id, const xgpu_cu_batch *b);
+/* Appends a picture-signature SEI NAL unit (payload type 0x10) for the picture added last: the MD5 digests of its decoded Y, U, V
+   planes (16-bit little-endian samples, rows without padding).  The reference decoder verifies them when
+   XEVD_CFG_SET_USE_PIC_SIGNATURE is set (src_base/xevd.c:2010-2026) - the MD5 round trip of SURVEY 8c. */
+int  xhost_writer_add_md5_sei(xhost_writer *w, const uint8_t md5[3][16]);
 int  xhost_writer_bytes(xhost_writer *w, const uint8_t **bytes, size_t *size);
 void xhost_writer_close(xhost_writer *w);
 

@@ -29,6 +29,10 @@ int refd_decode(const uint8_t *bytes, size_t size, int threads, int16_t *out, in
     cdsc.threads = threads;
     id = xevd_create(&cdsc, &ret);
     if (!id) return -1000 + ret;
+    {   /* picture-signature SEIs are VERIFIED (app/xevd_app.c:177-182): a stream that carries our MD5s makes the reference check them */
+        int on = 1, sz = sizeof(int);
+        (void)xevd_config(id, XEVD_CFG_SET_USE_PIC_SIGNATURE, &on, &sz);
+    }
     for (;;) {
         memset(&stat, 0, sizeof(stat));
         stat.fnum = -1;

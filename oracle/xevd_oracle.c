@@ -1038,3 +1038,30 @@ void orc_pad(const xgpu_seq_params *sp, const orc_pic *p)
         }
     }
 }
+
+/* app/xevd_app_util.h:665-708: dst 8 bit -> imgb_conv_shift_right_8b (:464-494); same depth -> plane copy; lower ->
+   imgb_conv_shift_right (:519-552); higher -> imgb_conv_shift_left (:495-517) */
+void orc_output_convert(const int16_t *src, int stride, int w, int h, int src_bd, int dst_bd, void *dst)
+{
+    int i, j;
+    uint8_t *d8 = (uint8_t *)dst;
+    uint16_t *d16 = (uint16_t *)dst;
+    for (i = 0; i < h; i++) {
+        const int16_t *s = src + (size_t)i * stride;
+        for (j = 0; j < w; j++) {
+            if (dst_bd == 8) {
+                const int shift = src_bd - 8, add = shift ? 1 << (shift - 1) : 0;
+                int t = (s[j] + add) >> shift;
+                d8[(size_t)i * w + j] = (uint8_t)(t < 0 ? 0 : (t > 255 ? 255 : t));
+            } else if (dst_bd == src_bd) {
+                d16[(size_t)i * w + j] = (uint16_t)s[j];
+            } else if (dst_bd < src_bd) {
+                const int shift = src_bd - dst_bd, add = 1 << (shift - 1), maxv = (1 << dst_bd) - 1;
+                int t = ((uint16_t)s[j] + add) >> shift;
+                d16[(size_t)i * w + j] = (uint16_t)(t < 0 ? 0 : (t > maxv ? maxv : t));
+            } else {
+                d16[(size_t)i * w + j] = (uint16_t)((uint16_t)s[j] << (dst_bd - src_bd));
+            }
+        }
+    }
+}

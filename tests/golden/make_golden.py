@@ -141,7 +141,7 @@ def golden_pictures(only=None):
         print(f"pic_{case[0]}.npz")
 
 
-def golden_streams():
+def golden_streams(only=()):
     import stream_util as su
     for name, (w, h, n, kw) in {"ippp_8b": (208, 120, 5, dict(max_refs=2)), "ippp_10b_offsets": (144, 88, 4, dict(bit_depth=10, qp_offsets=(1, -2))),
                                 "idr_period_skip": (72, 136, 6, dict(max_refs=4, skip_frac=0.4, idr_period=4)),
@@ -150,7 +150,13 @@ def golden_streams():
                                 "main_iqt_ats_addb_10b": (144, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, log2_sub_gop=2, max_refs=2, bit_depth=10, addb_offsets=(1, -2))),
                                 "main_iqt_addb_8b": (208, 120, 5, dict(main=True, iqt=True, addb=True, max_refs=2)),
                                 "main_all_tools_10b": (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, log2_sub_gop=2, max_refs=2, bit_depth=10)),
-                                "main_alf_addb_8b": (264, 136, 6, dict(main=True, alf=True, addb=True))}.items():
+                                "main_alf_addb_8b": (264, 136, 6, dict(main=True, alf=True, addb=True)),
+                                # every picture followed by a picture-signature SEI (MD5s of the oracle's reconstruction, VERIFIED by the
+                                # reference decoder while it produced the pictures below)
+                                "signed_hier_b_8b": (136, 120, 5, dict(log2_sub_gop=2, max_refs=2, sign=True)),
+                                "signed_main_alf_10b": (136, 72, 4, dict(main=True, iqt=True, addb=True, alf=True, bit_depth=10, sign=True))}.items():
+        if only and name not in only:
+            continue
         data = su.make_stream(w, h, n, seed=len(name) * 13 + n, **kw)
         ref = su.decode_reference(data, w, h, main=bool(kw.get("main")))
         assert len(ref) == n
@@ -167,7 +173,7 @@ if __name__ == "__main__":
     lib = ol.ref()
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "streams":
-        golden_streams()
+        golden_streams(sys.argv[2:])
     elif len(sys.argv) > 1:               # python make_golden.py <picture case> ... : only (re)generate those
         golden_pictures(set(sys.argv[1:]))
     else:

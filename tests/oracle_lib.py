@@ -56,8 +56,42 @@ def oracle():
         lib.orc_deblock_addb.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_int, C.c_int]
         lib.orc_alf.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcPic), C.POINTER(abi.AlfParams)]
         lib.orc_pad.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcPic)]
+        lib.orc_output_convert.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        lib.orc_output_convert.restype = None
         _oracle = lib
     return _oracle
+
+
+REF_OUTPUT_SO = os.path.join(ORACLE_DIR, "_ref", "libref_output.so")
+_ref_output = None
+
+
+def output_convert(planes, src_bd, dst_bd, crop=(0, 0, 0, 0)):
+    """Oracle: cropped + converted picture as the bytes of one .yuv frame (orc_output_convert per plane)."""
+    cl, cr, ct, cb = crop
+    out = []
+    for i, p in enumerate(planes):
+        sh = 1 if i else 0
+        p = np.ascontiguousarray(p, np.int16)
+        h, w = p.shape
+        x0, y0, w2, h2 = cl >> sh, ct >> sh, w - ((cl + cr) >> sh), h - ((ct + cb) >> sh)
+        dst = np.zeros(w2 * h2 * (1 if dst_bd == 8 else 2), np.uint8)
+        oracle().orc_output_convert(p.ctypes.data + 2 * (y0 * w + x0), w, w2, h2, src_bd, dst_bd, dst.ctypes.data)
+        out.append(dst)
+    return np.concatenate(out)
+
+
+def ref_output_convert(planes, src_bd, dst_bd):
+    """The reference application's imgb_cpy_codec_to_out through oracle/ref_output.c (no crop: the app does not crop)."""
+    global _ref_output
+    if _ref_output is None:
+        _ref_output = C.CDLL(REF_OUTPUT_SO)
+        _ref_output.refh_output_convert.argtypes = [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_void_p]
+    y, u, v = (np.ascontiguousarray(p, np.int16) for p in planes)
+    h, w = y.shape
+    dst = np.zeros((w * h + 2 * (w // 2) * (h // 2)) * (1 if dst_bd == 8 else 2), np.uint8)
+    _ref_output.refh_output_convert(y.ctypes.data, u.ctypes.data, v.ctypes.data, w, h, src_bd, dst_bd, dst.ctypes.data)
+    return dst
 
 
 def have_ref():

@@ -25,9 +25,10 @@ def gop_tids(log2_sub_gop):
 
 def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_frac=0.15, inter_frac=0.85, deblock=True, qp_offsets=(0, 0),
                 cu_qp_delta=True, split_prob=0.5, idr_period=0, log2_sub_gop=0, bi_frac=0.5, direct_frac=0.1,
-                main=False, iqt=False, ats=False, addb=False, addb_offsets=(0, 0), alf=False):
+                main=False, iqt=False, ats=False, addb=False, addb_offsets=(0, 0), alf=False, sign=False):
     """-> bytes.  Picture 0 is an IDR.  log2_sub_gop = 0: IPPP; n: hierarchical sub-GOPs of 2^n pictures, the layer-0 picture of
-    each a P picture, the others B pictures (bi-prediction, temporal direct and two-list skip CUs)."""
+    each a P picture, the others B pictures (bi-prediction, temporal direct and two-list skip CUs).
+    sign: every picture is followed by a picture-signature SEI with the MD5s of the ORACLE's reconstruction of the stream so far."""
     rng = np.random.default_rng(seed)
     w = stream.StreamWriter(width, height, bit_depth, max_refs, qp_offsets[0], qp_offsets[1], deblock, cu_qp_delta, log2_sub_gop,
                             main=main, iqt=iqt, ats=ats, addb=addb, alpha_off=addb_offsets[0], beta_off=addb_offsets[1], alf=alf)
@@ -67,6 +68,8 @@ def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_fra
                                 ctb_flag=None if mode == 4 else (rng.random(n_ctu) < 0.7).astype(np.uint8))
             w.add_picture(b, stream.SLICE_I if idr else (stream.SLICE_B if is_b else stream.SLICE_P), slice_qp=int(rng.integers(24, 40)), idr=idr,
                           temporal_id=tid)
+            if sign:
+                w.add_md5_sei(decode_oracle(w.bytes(), order="decoding")[-1])
             since_idr += 1
         return w.bytes()
     finally:
@@ -107,8 +110,8 @@ def _output_order(pics):
     return [v for _, v in sorted(out, key=lambda kv: kv[0])]
 
 
-def decode_oracle(data):
-    """Our parser + the CPU oracle (oracle/liboracle.so). -> pictures in output order."""
+def decode_oracle(data, order="output"):
+    """Our parser + the CPU oracle (oracle/liboracle.so). -> pictures in output (or decoding) order."""
     o = ol.oracle()
     dpb, out = {}, []
     for p in stream.parse_stream(data):
@@ -136,10 +139,12 @@ def decode_oracle(data):
         if p["is_ref"]:
             dpb[p["poc"]] = cur
         out.append((p, [cur.active(c).copy() for c in range(3)]))
+    if order == "decoding":
+        return [planes for _, planes in out]
     return _output_order(out)
 
 
-def decode_gpu(data):
+def decode_gpu(data, verify_md5=False):
     """Our parser + the HIP backend through the two C ABIs (xevd_amd/player.py). -> pictures in output order."""
     from xevd_amd.player import StreamDecoder
-    return [planes for _, planes in StreamDecoder(data).output_order()]
+    return [planes for _, planes in StreamDecoder(data, verify_md5=verify_md5).output_order()]

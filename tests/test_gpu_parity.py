@@ -126,7 +126,7 @@ def test_gpu_golden_streams(path):
     """real bitstreams: committed .evc bytes -> our parser -> HIP backend == the pictures the reference decoder produced"""
     import stream_util as su
     d = np.load(path)
-    ours = su.decode_gpu(d["bytes"].tobytes())
+    ours = su.decode_gpu(d["bytes"].tobytes(), verify_md5=True)      # signed streams: the player checks the MD5 SEIs as well
     assert len(ours) == int(d["n"])
     for k in range(len(ours)):
         for c in range(3):
@@ -169,3 +169,39 @@ def test_gpu_8k_properties():
             pad = abi.PAD_L if c == 0 else abi.PAD_C
             assert np.array_equal(a[c][pad:-pad, pad:-pad], planes[c])
             assert np.array_equal(a[c], np.pad(planes[c], pad, mode="edge"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("src_bd,dst_bd,crop", [(10, 8, (0, 0, 0, 0)), (10, 8, (2, 6, 4, 2)), (8, 8, (0, 0, 0, 0)), (8, 10, (0, 2, 0, 0)),
+                                                (10, 10, (4, 0, 2, 6)), (12, 10, (0, 0, 0, 0)), (12, 8, (2, 2, 2, 2)), (10, 12, (0, 0, 0, 0))])
+def test_gpu_output_conversion(src_bd, dst_bd, crop):
+    """xgpu_pic_output (device crop + bit-depth conversion + packing) == the oracle's restatement of the application's
+    imgb_cpy_codec_to_out, extremes included; the oracle is pinned to the real function in test_oracle_vs_ref.py."""
+    from xevd_amd.decoder import XgpuDecoder
+    import oracle_lib as ol
+    rng = np.random.default_rng(src_bd * 100 + dst_bd)
+    w, h = 136, 72
+    planes = [rng.integers(0, 1 << src_bd, (h >> (i > 0), w >> (i > 0))).astype(np.int16) for i in range(3)]
+    planes[0][0, :4] = [0, (1 << src_bd) - 1, (1 << src_bd) - 2, 1]
+    dec = XgpuDecoder(w, h, src_bd, device=0)
+    try:
+        pic = dec.pic_alloc()
+        dec.pic_upload(pic, planes)
+        got = dec.pic_output(pic, dst_bd, crop)
+    finally:
+        dec.close()
+    assert np.array_equal(got, ol.output_convert(planes, src_bd, dst_bd, crop))
+
+
+@pytest.mark.gpu
+def test_gpu_output_rejects_bad_crop():
+    from xevd_amd.decoder import XgpuDecoder
+    dec = XgpuDecoder(64, 64, 8, device=0)
+    try:
+        pic = dec.pic_alloc()
+        with pytest.raises(ValueError):
+            dec.pic_output(pic, 8, (1, 0, 0, 0))          # odd crop
+        with pytest.raises(ValueError):
+            dec.pic_output(pic, 8, (32, 32, 0, 0))        # nothing left
+    finally:
+        dec.close()

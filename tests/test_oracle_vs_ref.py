@@ -6,6 +6,7 @@ the survey found them identical).  Picture level: oracle/ref_harness.c drives th
 xevd_sub_block_itdq / xevd_mc / xevd_recon / xevd_deblock_cu_* over the same CU batch.
 """
 import ctypes as C
+import os
 import zlib
 
 import numpy as np
@@ -234,3 +235,16 @@ def test_addb_with_slice_offsets_and_high_qp(offs):
     b, _, _, _ = cases.run_cpu("ref", cs)
     for c in range(3):
         assert np.array_equal(a.bufs[c], b.bufs[c]), f"plane {c}"
+
+
+@pytest.mark.parametrize("src_bd,dst_bd", [(10, 8), (8, 8), (8, 10), (10, 10), (12, 10), (12, 8), (10, 12)])
+def test_output_conversion(src_bd, dst_bd):
+    """orc_output_convert == the application's imgb_cpy_codec_to_out (app/xevd_app_util.h:665-708) on whole pictures,
+    extremes included."""
+    if not os.path.exists(ol.REF_OUTPUT_SO):
+        pytest.skip("oracle/_ref/libref_output.so not built")
+    rng = np.random.default_rng(src_bd * 16 + dst_bd)
+    w, h = 72, 40
+    planes = [rng.integers(0, 1 << src_bd, (h >> (i > 0), w >> (i > 0))).astype(np.int16) for i in range(3)]
+    planes[0][0, :4] = [0, (1 << src_bd) - 1, (1 << src_bd) - 2, 1]
+    assert np.array_equal(ol.output_convert(planes, src_bd, dst_bd), ol.ref_output_convert(planes, src_bd, dst_bd))

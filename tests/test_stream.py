@@ -104,3 +104,27 @@ def test_golden_streams_parser_plus_oracle(path):
     for k in range(len(ours)):
         for c in range(3):
             assert np.array_equal(ours[k][c], d[f"p{k}_{c}"]), f"picture {k} plane {c}"
+
+
+@pytest.mark.parametrize("kw", [dict(log2_sub_gop=2, max_refs=2), dict(main=True, iqt=True, addb=True, alf=True, bit_depth=10)],
+                         ids=["base_hier_b", "main_alf_addb_10b"])
+def test_md5_sei_round_trip(kw):
+    """The MD5 round trip: the writer signs every picture with the MD5s of the oracle's reconstruction; the REFERENCE
+    decoder, told to verify signatures (XEVD_CFG_SET_USE_PIC_SIGNATURE), accepts the stream - and rejects it once a digest is
+    damaged (XEVD_ERR_BAD_CRC).  Our parser hands the digests out with the picture."""
+    if not su.have_ref_decoder():
+        pytest.skip("oracle/_ref/ref_decode not built")
+    main = kw.get("main", False)
+    data = su.make_stream(136, 72, 5, seed=77, sign=True, **kw)
+    pics = stream.parse_stream(data)
+    assert all(p["md5"] is not None for p in pics)
+    ref = su.decode_reference(data, 136, 72, main=main)              # raises if the reference's own MD5 check fails
+    ora = su.decode_oracle(data)
+    assert len(ref) == len(ora) == 5
+    for a, b in zip(ref, ora):
+        for c in range(3):
+            assert np.array_equal(a[c], b[c])
+    bad = bytearray(data)
+    bad[len(bad) - 3] ^= 0x40                                          # inside the last SEI's V-plane digest
+    with pytest.raises(RuntimeError):
+        su.decode_reference(bytes(bad), 136, 72, main=main)

@@ -6,8 +6,6 @@ import os
 import sys
 import time
 
-import numpy as np
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from xevd_amd.player import StreamDecoder      # noqa: E402
 
@@ -21,21 +19,13 @@ def main():
     args = ap.parse_args()
     data = open(args.input, "rb").read()
     t0 = time.perf_counter()
-    pics = StreamDecoder(data, device=args.device).output_order()
+    # crop-free output like the reference application; bit-depth conversion and plane packing run on the device (xgpu_pic_output)
+    pics = StreamDecoder(data, device=args.device).output_order(output_bit_depth=args.output_bit_depth)
     dt = time.perf_counter() - t0
     if args.output:
         with open(args.output, "wb") as f:
-            for p, planes in pics:
-                bd_in = p["bit_depth"]
-                bd_out = args.output_bit_depth or bd_in
-                for pl in planes:
-                    v = pl.astype(np.int32)
-                    if bd_out < bd_in:      # rounding down-conversion, as the reference's imgb_cpy_conv_rec (app/xevd_app_util.h) does
-                        sh = bd_in - bd_out
-                        v = np.clip((v + (1 << (sh - 1))) >> sh, 0, (1 << bd_out) - 1)
-                    elif bd_out > bd_in:
-                        v = v << (bd_out - bd_in)
-                    f.write(v.astype(np.uint8 if bd_out == 8 else "<u2").tobytes())
+            for _, frame in pics:
+                f.write(frame.tobytes())
     print(f"{len(pics)} pictures, {len(pics) / dt:.1f} pictures/s (parse + upload + kernels + download)", file=sys.stderr)
 
 

@@ -137,6 +137,8 @@ _EXPORTS = {
     "xgpu_pic_free": (C.c_int, [C.c_void_p, C.c_int]),
     "xgpu_pic_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "xgpu_pic_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
+    "xgpu_pic_output_size": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "xgpu_pic_output": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "xgpu_pic_download_padded": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "xgpu_pic_upload_padded": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "xgpu_frame_begin": (C.c_int, [C.c_void_p, C.POINTER(FrameParams)]),

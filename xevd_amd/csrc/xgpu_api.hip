@@ -154,7 +154,7 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     xgpu_ctx *c = new xgpu_ctx();
     c->sp = *sp;
     c->sp.chroma_qp_table[0] = c->sp.chroma_qp_table[1] = NULL;
-    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_owner = NULL; c->d_ctb_flag = NULL; c->stream = 0; c->where = 0;
+    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_owner = NULL; c->d_out = NULL; c->out_cap = 0; c->d_ctb_flag = NULL; c->stream = 0; c->where = 0;
     memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_n, 0, sizeof(c->t_n));
     // chroma QP mapping: caller table starts at qp = -6*(bdc-8); default = Baseline static table with the
     // identity extension below 0 (xevd_set_chroma_qp_tbl_loc, xevd_tbl.c:364-372)
@@ -209,6 +209,7 @@ void xgpu_close(xgpu_ctx *c)
     for (auto &p : c->pics) if (p.base) (void)hipFree(p.base);
     if (c->d_maps) (void)hipFree(c->d_maps);
     if (c->d_owner) (void)hipFree(c->d_owner);
+    if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_ctb_flag) (void)hipFree(c->d_ctb_flag);
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
@@ -297,6 +298,35 @@ int xgpu_pic_upload_padded(xgpu_ctx *c, int pic, const int16_t *by, const int16_
     ARGCHK(c, c != NULL); ARGCHK(c, valid_pic(c, pic)); ARGCHK(c, by && bu && bv);
     return copy_planes(c, pic, (int16_t *)by, c->sp.width + 2 * XGPU_PAD_L, (int16_t *)bu, (int16_t *)bv,
                        (c->sp.width >> 1) + 2 * XGPU_PAD_C, XGPU_PAD_L, XGPU_PAD_C, true);
+}
+
+static bool valid_output(const xgpu_ctx *c, int out_bd, int cl, int cr, int ct, int cb)
+{
+    return out_bd >= 8 && out_bd <= 16 && cl >= 0 && cr >= 0 && ct >= 0 && cb >= 0 && !((cl | cr | ct | cb) & 1) &&
+           cl + cr < c->sp.width && ct + cb < c->sp.height;
+}
+size_t xgpu_pic_output_size(const xgpu_ctx *c, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b)
+{
+    if (!c || !valid_output(c, out_bit_depth, crop_l, crop_r, crop_t, crop_b)) return 0;
+    const size_t w = c->sp.width - crop_l - crop_r, h = c->sp.height - crop_t - crop_b;
+    return (w * h + 2 * (w >> 1) * (h >> 1)) * (out_bit_depth == 8 ? 1 : 2);
+}
+int xgpu_pic_output(xgpu_ctx *c, int pic, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b, void *dst, size_t dst_size)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, valid_pic(c, pic)); ARGCHK(c, dst != NULL);
+    ARGCHK(c, valid_output(c, out_bit_depth, crop_l, crop_r, crop_t, crop_b));
+    const size_t need = xgpu_pic_output_size(c, out_bit_depth, crop_l, crop_r, crop_t, crop_b);
+    ARGCHK(c, dst_size >= need);
+    if (c->out_cap < need) {
+        if (c->d_out) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_out); c->d_out = NULL; c->out_cap = 0; }
+        if (hipMalloc((void **)&c->d_out, need) != hipSuccess) { snprintf(c->err, sizeof(c->err), "pic_output: cannot allocate the %zu-byte staging buffer", need); return XGPU_ERR_OUT_OF_MEMORY; }
+        c->out_cap = need;
+    }
+    launch_output(c, dpic(c, pic), out_bit_depth, crop_l, crop_r, crop_t, crop_b, c->d_out);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(dst, c->d_out, need, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return XGPU_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ per picture

@@ -76,6 +76,17 @@ class XgpuDecoder:
                   "xgpu_pic_download")
         return [y, u, v]
 
+    def pic_output(self, pic, out_bit_depth=0, crop=(0, 0, 0, 0)):
+        """The picture as the bytes of a .yuv file frame (Y, U, V planes, tight rows): converted to `out_bit_depth` (0 = the coding
+        depth; 8 -> one byte per sample) and cropped by (left, right, top, bottom) luma samples on the device (xgpu_pic_output)."""
+        bd = out_bit_depth or self.bit_depth
+        n = self.lib.xgpu_pic_output_size(self.ctx, bd, *crop)
+        if n == 0:
+            raise ValueError(f"invalid output format: bit depth {bd}, crop {crop}")
+        out = np.empty(n, np.uint8)
+        self._chk(self.lib.xgpu_pic_output(self.ctx, pic, bd, *crop, out.ctypes.data, n), "xgpu_pic_output")
+        return out
+
     def pic_upload_padded(self, pic, bufs):
         y, u, v = (np.ascontiguousarray(p, np.int16) for p in bufs)
         self._chk(self.lib.xgpu_pic_upload_padded(self.ctx, pic, y.ctypes.data, u.ctypes.data, v.ctypes.data), "xgpu_pic_upload_padded")

@@ -696,6 +696,22 @@ struct xhost_parser {
     std::vector<int16_t> blk[3];
     int fail(const char *m) { err = m; return XHOST_ERR_MALFORMED; }
 
+    // A picture-signature SEI directly after the slice NAL belongs to that picture (xevd_dec_nalu checks it against ctx->pic,
+    // src_base/xevd.c:2010-2026).  Payload (xevd_eco_sei, xevd_eco.c:1617-1678): type 0x10, size 16, then 16 bytes PER PLANE.
+    void attach_signature(xhost_picture *out)
+    {
+        out->has_md5 = 0;
+        if (pos + 6 > data.size()) return;
+        const uint8_t *d = data.data() + pos;
+        const size_t len = ((size_t)d[0] << 24) | ((size_t)d[1] << 16) | ((size_t)d[2] << 8) | d[3];
+        if (len < 2 + 2 + 48 || pos + 4 + len > data.size()) return;
+        if ((((d[4] << 8 | d[5]) >> 9) & 63) - 1 != NUT_SEI) return;
+        if (d[6] != 0x10 || d[7] != 16) return;
+        memcpy(out->md5, d + 8, 48);
+        out->has_md5 = 1;
+        pos += 4 + len;
+    }
+
     int parse_sps(BitReader &br)
     {
         Sps &s = st.sps;
@@ -916,7 +932,11 @@ extern "C" int xhost_parser_next(xhost_parser *p, xhost_picture *out)
         int rc = XGPU_OK;
         if (nut == NUT_SPS) rc = p->parse_sps(br);
         else if (nut == NUT_PPS) rc = p->parse_pps(br);
-        else if (nut == NUT_IDR || nut == NUT_NONIDR) return p->parse_slice(br, nut, tid, out);
+        else if (nut == NUT_IDR || nut == NUT_NONIDR) {
+            rc = p->parse_slice(br, nut, tid, out);
+            if (rc == 1) p->attach_signature(out);
+            return rc;
+        }
         else if (nut == 26) {                            // APS (xevdm_eco_aps_gen, xevdm_eco.c:2082-2135)
             const int id = (int)br.get(5), type = (int)br.get(3);
             if (type != 0) return p->fail("only ALF parameter sets (APS type 0) are supported");
@@ -937,7 +957,7 @@ struct xhost_writer {
     xhost_stream_params sp;
     Stream st;
     std::vector<uint8_t> out;
-    int n_pics = 0;
+    int n_pics = 0, last_tid = 0;
     bool headers_done = false;
     xhost_slice_alf next_alf = { 0, 0, 0, 0, 0, nullptr };
     std::vector<uint8_t> next_alf_ctb;
@@ -1032,6 +1052,17 @@ extern "C" int xhost_writer_add_alf_aps(xhost_writer *w, const xhost_alf_aps *in
     w->st.alf_aps[in->aps_id] = parsed;
     return XGPU_OK;
 }
+extern "C" int xhost_writer_add_md5_sei(xhost_writer *w, const uint8_t md5[3][16])
+{
+    if (!w || !md5 || w->n_pics == 0) return XGPU_ERR_INVALID_ARGUMENT;
+    BitWriter bw;
+    bw.put(0x10, 8); bw.put(16, 8);
+    for (int c = 0; c < 3; c++) for (int i = 0; i < 16; i++) bw.put(md5[c][i], 8);
+    bw.put(0x80, 8);                                      // rbsp trailing bits
+    write_nal(w->out, NUT_SEI, w->last_tid, bw);
+    return XGPU_OK;
+}
+
 extern "C" int xhost_writer_bytes(xhost_writer *w, const uint8_t **bytes, size_t *size)
 {
     if (!w || !bytes || !size) return XGPU_ERR_INVALID_ARGUMENT;
@@ -1179,6 +1210,7 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
     if (tw.error) return XGPU_ERR_INVALID_ARGUMENT;
     enc.tile_end();
     write_nal(w->out, idr ? NUT_IDR : NUT_NONIDR, temporal_id, bw);
+    w->last_tid = temporal_id;
     std::vector<int> released;
     st.store_picture(idr != 0, released);
     w->n_pics++;

@@ -10,8 +10,10 @@ from .decoder import XgpuDecoder
 
 
 class StreamDecoder:
-    def __init__(self, data, device=0, prefetch=2):
-        self.data, self.device, self.prefetch = data, device, prefetch
+    def __init__(self, data, device=0, prefetch=2, verify_md5=False):
+        """verify_md5: check downloaded pictures against the stream's picture-signature SEIs (the reference's
+        XEVD_CFG_SET_USE_PIC_SIGNATURE), raising on a mismatch"""
+        self.data, self.device, self.prefetch, self.verify_md5 = data, device, prefetch, verify_md5
 
     def _producer(self, q):
         try:
@@ -21,8 +23,16 @@ class StreamDecoder:
         except Exception as e:      # surfaced in the consumer thread
             q.put(e)
 
-    def pictures(self, download=True):
-        """generator of (params, planes or None) in DECODING order; planes = [Y, U, V] int16 arrays of the active area"""
+    @staticmethod
+    def signature_ok(p, planes):
+        """the stream's picture-signature SEI (MD5 per plane over 16-bit samples, xevd_picbuf_check_signature) against decoded planes"""
+        import hashlib
+        import numpy as np
+        return all(hashlib.md5(np.ascontiguousarray(pl, "<i2").tobytes()).digest() == p["md5"][c] for c, pl in enumerate(planes))
+
+    def pictures(self, download=True, output_bit_depth=None):
+        """generator of (params, planes or None) in DECODING order; planes = [Y, U, V] int16 arrays of the active area, or - with
+        output_bit_depth (0 = the coding depth) - the bytes of one .yuv frame, converted and packed on the device"""
         q = queue.Queue(maxsize=self.prefetch)
         th = threading.Thread(target=self._producer, args=(q,), daemon=True)
         th.start()
@@ -45,8 +55,12 @@ class StreamDecoder:
                 dec.decode_picture(cur, p["poc"], refs, hb, deblock=p["deblock_on"], pad=True, qp_u_offset=p["qp_u_offset"], qp_v_offset=p["qp_v_offset"],
                                    alpha_off=p["alpha_off"], beta_off=p["beta_off"], alf=p["alf"])
                 planes = None
-                if download:
+                if download and output_bit_depth is not None:
+                    planes = dec.pic_output(cur, output_bit_depth)
+                elif download:
                     planes = dec.pic_download(cur)
+                    if self.verify_md5 and p["md5"] is not None and not self.signature_ok(p, planes):
+                        raise RuntimeError(f"picture signature mismatch at POC {p['poc']} (XEVD_ERR_BAD_CRC)")
                 else:
                     dec.sync()
                 dec.batch_destroy(hb)
@@ -62,10 +76,10 @@ class StreamDecoder:
             if dec is not None:
                 dec.close()
 
-    def output_order(self):
+    def output_order(self, output_bit_depth=None):
         """all pictures in output order (ascending POC inside every IDR period), as xevd_pull's bumping delivers them"""
         out, epoch = [], -1
-        for p, planes in self.pictures():
+        for p, planes in self.pictures(output_bit_depth=output_bit_depth):
             if p["is_idr"]:
                 epoch += 1
             out.append(((epoch, p["poc"]), p, planes))

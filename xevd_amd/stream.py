@@ -39,6 +39,7 @@ class HostPicture(C.Structure):
                 ("profile_main", C.c_int), ("tool_iqt", C.c_int), ("tool_ats", C.c_int), ("tool_addb", C.c_int),
                 ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int),
                 ("tool_alf", C.c_int), ("alf_on", C.c_int), ("alf", abi.AlfParams),
+                ("has_md5", C.c_int), ("md5", (C.c_uint8 * 16) * 3),
                 ("n_release", C.c_int), ("release_poc", C.c_int * 32), ("batch", abi.CuBatch)]
 
 
@@ -63,6 +64,7 @@ def load():
         lib.xhost_writer_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         lib.xhost_writer_close.argtypes = [C.c_void_p]
         lib.xhost_writer_add_alf_aps.argtypes = [C.c_void_p, C.POINTER(AlfAps)]
+        lib.xhost_writer_add_md5_sei.argtypes = [C.c_void_p, C.c_void_p]
         lib.xhost_writer_set_slice_alf.argtypes = [C.c_void_p, C.POINTER(SliceAlf)]
         _lib = lib
     return _lib
@@ -113,6 +115,17 @@ class StreamWriter:
         rc = self.lib.xhost_writer_set_slice_alf(self.h, C.byref(sa))
         if rc != 0:
             raise RuntimeError(f"xhost_writer_set_slice_alf -> {rc}")
+
+    def add_md5_sei(self, planes):
+        """picture-signature SEI for the picture added last; planes = its decoded [Y, U, V] (the MD5 runs over 16-bit LE samples)"""
+        import hashlib
+        md5 = ((C.c_uint8 * 16) * 3)()
+        for c, pl in enumerate(planes):
+            for i, v in enumerate(hashlib.md5(np.ascontiguousarray(pl, "<i2").tobytes()).digest()):
+                md5[c][i] = v
+        rc = self.lib.xhost_writer_add_md5_sei(self.h, md5)
+        if rc != 0:
+            raise RuntimeError(f"xhost_writer_add_md5_sei -> {rc}")
 
     def bytes(self):
         p, n = C.c_void_p(), C.c_size_t()
@@ -165,6 +178,7 @@ def iter_stream(data):
                 "alf": None if not hp.alf_on else {
                     "enable": tuple(hp.alf.enable[i] for i in range(3)), "luma_coef": _arr(hp.alf.luma_coef, 25 * 13, np.int16).reshape(25, 13),
                     "chroma_coef": _arr(hp.alf.chroma_coef, 7, np.int16), "ctb_flag": _arr(hp.alf.ctb_flag, b.n_ctu, np.uint8), "across_tiles": 0},
+                "md5": [bytes(hp.md5[c]) for c in range(3)] if hp.has_md5 else None,
                 "release": [hp.release_poc[i] for i in range(hp.n_release)], "batch": batch,
             }
     finally:
