@@ -155,9 +155,17 @@ int  xgpu_pic_download(xgpu_ctx *ctx, int pic, int16_t *y, int s_y, int16_t *u, 
    as xevd_pull reports them), converted to out_bit_depth - 8: one byte per sample, (v + round) >> shift clipped to 255;
    below the coding depth: the same rounding shift clipped to the range, 16 bit; above: v << shift; equal: copy - and packed
    as Y, U, V planes back to back without row padding (the bytes imgb_write puts in a .yuv file).  Crop, conversion and
-   packing run on the device; `dst` (host, >= xgpu_pic_output_size() bytes) receives one contiguous copy.  Blocking. */
+   packing run on the device; `dst` (host, >= xgpu_pic_output_size() bytes) receives one contiguous copy.  Blocking.
+   `dra` (NULL = none): the DRA post-filter xevd_pull applies to its copy of the picture when sps->tool_dra and the PPS names a
+   DRA parameter set (xevd_apply_filter, src_main/xevdm.c:3305-3349): the inverse-mapping tables of DRA_CONTROL after xevd_init_dra
+   (the table construction stays host code), applied before the conversion - Cb and Cr scaled around 512 by a factor looked up
+   with the UNMAPPED luma sample at (2y, 2x), then luma through its table (xevdm_dra.c:272-355); 4:2:0 at up to 10 bit. */
+typedef struct xgpu_dra_luts {
+    const int32_t *luma_inv_scale_lut;         /* [1024]  DRA_CONTROL.luma_inv_scale_lut          */
+    const int32_t *chroma_inv_scale_lut[2];    /* [1024]  DRA_CONTROL.int_chroma_inv_scale_lut[c] */
+} xgpu_dra_luts;
 size_t xgpu_pic_output_size(const xgpu_ctx *ctx, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b);   /* 0: invalid */
-int  xgpu_pic_output(xgpu_ctx *ctx, int pic, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b,
+int  xgpu_pic_output(xgpu_ctx *ctx, int pic, const xgpu_dra_luts *dra, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b,
                      void *dst, size_t dst_size);
 /* whole padded buffers (XEVD_PIC.buf_y/u/v layout: stride = w + 2*pad, rows = h + 2*pad), for tests.     */
 int  xgpu_pic_download_padded(xgpu_ctx *ctx, int pic, int16_t *buf_y, int16_t *buf_u, int16_t *buf_v);

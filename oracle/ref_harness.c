@@ -22,6 +22,7 @@
 #include "xevdm_itdq.h"
 #include "xevdm_df.h"
 #include "xevdm_alf.h"
+#include "xevdm_dra.h"
 #include "xevd_oracle.h"
 
 /* reference tables selected like xevd_platform_init does (src_base/xevd.c:2074-2149) */
@@ -372,4 +373,42 @@ void refh_pad(const xgpu_seq_params *sp, const orc_pic *p)
     XEVD_PIC pic;
     fill_pic(&pic, p, sp);
     xevd_picbuf_lc_expand(&pic, XGPU_PAD_L, XGPU_PAD_C);
+}
+
+/* DRA (the post-filter xevd_pull applies to a COPY of the picture, src_main/xevdm.c:3305-3385): the real LUT construction
+   (xevd_init_dra, xevdm_dra.c:263-270) from signalled parameters, and the real sample processing (chroma planes first - they read
+   the unmapped luma - then luma, :272-355) on tight 16-bit planes.  luts: [3][1024] = luma_inv_scale_lut, int_chroma_inv_scale_lut[0..1] */
+int refh_dra(int bit_depth, int table_idx, int num_ranges, const int *in_ranges, const int *scale_values, int cb_scale, int cr_scale,
+             int16_t *y, int16_t *u, int16_t *v, int w, int h, int32_t *luts)
+{
+    static DRA_CONTROL dc;
+    XEVD_IMGB im;
+    int i;
+    /* the chroma QP mapping xevd_correct_local_chroma_scale reads: the Main sequence default, as sequence_init leaves it (xevdm.c:471-479) */
+    xevd_set_chroma_qp_tbl_loc(bit_depth);
+    for (i = 0; i < XEVD_MAX_QP_TABLE_SIZE; i++)
+        xevd_qp_chroma_dynamic[0][i] = xevd_qp_chroma_dynamic[1][i] = xevd_tbl_qp_chroma_adjust_main[i];
+    memset(&dc, 0, sizeof(dc));
+    dc.signalled_dra.signal_dra_flag = 1;
+    dc.signalled_dra.dra_table_idx = table_idx;
+    dc.signalled_dra.num_ranges = num_ranges;
+    dc.signalled_dra.dra_descriptor1 = 4; dc.signalled_dra.dra_descriptor2 = 9;
+    dc.signalled_dra.dra_cb_scale_value = cb_scale; dc.signalled_dra.dra_cr_scale_value = cr_scale;
+    for (i = 0; i <= num_ranges; i++) dc.signalled_dra.in_ranges[i] = in_ranges[i];
+    for (i = 0; i < num_ranges; i++) dc.signalled_dra.dra_scale_value[i] = scale_values[i];
+    xevd_init_dra(&dc, bit_depth);
+    for (i = 0; i < DRA_LUT_MAXSIZE; i++) {
+        luts[i] = dc.luma_inv_scale_lut[i];
+        luts[DRA_LUT_MAXSIZE + i] = dc.int_chroma_inv_scale_lut[0][i];
+        luts[2 * DRA_LUT_MAXSIZE + i] = dc.int_chroma_inv_scale_lut[1][i];
+    }
+    if (!y) return 0;
+    memset(&im, 0, sizeof(im));
+    im.np = 3;
+    im.a[0] = y; im.a[1] = u; im.a[2] = v;
+    for (i = 0; i < 3; i++) { im.w[i] = i ? w >> 1 : w; im.h[i] = i ? h >> 1 : h; im.s[i] = im.w[i] * 2; }
+    xevd_apply_dra_chroma_plane(&im, &im, &dc, 1, TRUE);
+    xevd_apply_dra_chroma_plane(&im, &im, &dc, 2, TRUE);
+    xevd_apply_dra_luma_plane(&im, &im, &dc, 0, TRUE);
+    return 0;
 }

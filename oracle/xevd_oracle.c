@@ -1065,3 +1065,25 @@ void orc_output_convert(const int16_t *src, int stride, int w, int h, int src_bd
         }
     }
 }
+
+/* src_main/xevdm_dra.c:301-355 (chroma: |v - 512| * scale(luma) + 256 >> 9, sign restored, + 512; the luma index is clamped at 0
+   only) then :272-299 (luma: table look-up).  Results are stored as shorts without clipping, as the reference does. */
+void orc_dra_apply(int16_t *y, int16_t *u, int16_t *v, int w, int h, const int32_t *luma_inv, const int32_t *cb_inv, const int32_t *cr_inv)
+{
+    int c, j, k;
+    for (c = 1; c < 3; c++) {
+        int16_t *pl = c == 1 ? u : v;
+        const int32_t *lut = c == 1 ? cb_inv : cr_inv;
+        for (j = 0; j < h / 2; j++)
+            for (k = 0; k < w / 2; k++) {
+                int ref = y[(size_t)(2 * j) * w + 2 * k];
+                int sv = pl[(size_t)j * (w / 2) + k] - 512, off = sv < 0 ? -sv : sv;
+                if (ref < 0) ref = 0;
+                off = (off * lut[ref] + (1 << 8)) >> 9;
+                if (sv < 0) off = -off;
+                pl[(size_t)j * (w / 2) + k] = (int16_t)(512 + off);
+            }
+    }
+    for (j = 0; j < h; j++)
+        for (k = 0; k < w; k++) y[(size_t)j * w + k] = (int16_t)luma_inv[y[(size_t)j * w + k]];
+}

@@ -168,10 +168,32 @@ def golden_streams(only=()):
         print(f"stream_{name}.npz", len(data), "bytes,", n, "pictures")
 
 
+def golden_dra():
+    """DRA tables from the reference's xevd_init_dra + pictures through the reference's DRA and output conversion"""
+    d = {}
+    rng = np.random.default_rng(99)
+    w, h = 136, 72
+    planes = [rng.integers(0, 1024, (h >> (i > 0), w >> (i > 0))).astype(np.int16) for i in range(3)]
+    planes[0][0, :4] = [0, 1023, 1, 1022]
+    planes[1][0, :4] = [0, 1023, 512, 511]
+    for c in range(3):
+        d[f"in_{c}"] = planes[c]
+    for name in sorted(ol.DRA_SETS):
+        luts, out = ol.ref_dra(name, 10, planes)
+        d[f"{name}_luts"] = np.stack(luts)
+        d[f"{name}_out8"] = ol.ref_output_convert(out, 10, 8)
+        d[f"{name}_out10"] = ol.ref_output_convert(out, 10, 10)
+    np.savez_compressed(os.path.join(HERE, "dra.npz"), **d)
+    print("dra.npz")
+
+
 if __name__ == "__main__":
     assert ol.have_ref(), "oracle/_ref is not built: run `make -C oracle -f Makefile.ref` in the development container"
     lib = ol.ref()
     import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "dra":
+        golden_dra()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "streams":
         golden_streams(sys.argv[2:])
     elif len(sys.argv) > 1:               # python make_golden.py <picture case> ... : only (re)generate those

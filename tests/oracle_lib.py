@@ -58,6 +58,8 @@ def oracle():
         lib.orc_pad.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcPic)]
         lib.orc_output_convert.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]
         lib.orc_output_convert.restype = None
+        lib.orc_dra_apply.argtypes = [C.c_void_p] * 3 + [C.c_int] * 2 + [C.c_void_p] * 3
+        lib.orc_dra_apply.restype = None
         _oracle = lib
     return _oracle
 
@@ -94,6 +96,41 @@ def ref_output_convert(planes, src_bd, dst_bd):
     return dst
 
 
+# DRA parameter sets (what a DRA APS signals: xevdm_eco_dra_aps_param, src_main/xevdm_eco.c:2319-2375) used by the DRA tests;
+# table index 58 takes the direct chroma-scale branch of xevd_correct_local_chroma_scale, the others the QP-table one
+DRA_SETS = {
+    "three_ranges_idx58": dict(table_idx=58, in_ranges=[64, 300, 600, 940], scales=[600, 512, 400], cb=520, cr=500),
+    "five_ranges_idx40": dict(table_idx=40, in_ranges=[16, 200, 420, 610, 800, 1000], scales=[700, 560, 512, 470, 380], cb=512, cr=540),
+    "one_range_idx30": dict(table_idx=30, in_ranges=[1, 1023], scales=[512], cb=480, cr=512),
+}
+
+
+def ref_dra(name, bit_depth=10, planes=None):
+    """The reference's xevd_init_dra tables for a parameter set -> (luma_inv, cb_inv, cr_inv); with planes: also the pictures after
+    the real xevd_apply_dra_chroma_plane x2 + xevd_apply_dra_luma_plane (tight int16 planes, modified copies returned)."""
+    d = DRA_SETS[name]
+    luts = np.zeros((3, 1024), np.int32)
+    ir, sc = np.array(d["in_ranges"], np.int32), np.array(d["scales"], np.int32)
+    out = None
+    if planes is None:
+        harness().refh_dra(bit_depth, d["table_idx"], len(sc), ir.ctypes.data, sc.ctypes.data, d["cb"], d["cr"], None, None, None, 0, 0, luts.ctypes.data)
+    else:
+        out = [np.ascontiguousarray(p, np.int16).copy() for p in planes]
+        h, w = out[0].shape
+        harness().refh_dra(bit_depth, d["table_idx"], len(sc), ir.ctypes.data, sc.ctypes.data, d["cb"], d["cr"],
+                           out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, w, h, luts.ctypes.data)
+    return (luts[0].copy(), luts[1].copy(), luts[2].copy()), out
+
+
+def dra_apply(planes, luts):
+    """Oracle: DRA sample processing on copies of tight planes."""
+    out = [np.ascontiguousarray(p, np.int16).copy() for p in planes]
+    h, w = out[0].shape
+    l = [np.ascontiguousarray(t, np.int32) for t in luts]
+    oracle().orc_dra_apply(out[0].ctypes.data, out[1].ctypes.data, out[2].ctypes.data, w, h, l[0].ctypes.data, l[1].ctypes.data, l[2].ctypes.data)
+    return out
+
+
 def have_ref():
     return os.path.exists(REF_SO) and os.path.exists(HARNESS_SO)
 
@@ -116,6 +153,7 @@ def harness():
         lib.refh_deblock_addb.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_int, C.c_int]
         lib.refh_alf.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcPic), C.POINTER(abi.AlfParams)]
         lib.refh_pad.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcPic)]
+        lib.refh_dra.argtypes = [C.c_int] * 3 + [C.c_void_p] * 2 + [C.c_int] * 2 + [C.c_void_p] * 3 + [C.c_int] * 2 + [C.c_void_p]
         _harness = lib
     return _harness
 

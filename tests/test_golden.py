@@ -63,3 +63,14 @@ def test_synthetic_generator_is_deterministic_and_well_formed():
     for i in range(len(st) - 1):
         xs, ys = a["x"][st[i]:st[i + 1]], a["y"][st[i]:st[i + 1]]
         assert len(set(zip((xs // 64).tolist(), (ys // 64).tolist()))) == 1
+
+
+def test_dra_golden():
+    """oracle DRA + output conversion == the reference's output committed in tests/golden/dra.npz (runs without the reference)"""
+    import oracle_lib as ol
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dra.npz"))
+    planes = [d[f"in_{c}"] for c in range(3)]
+    for name in ol.DRA_SETS:
+        mapped = ol.dra_apply(planes, d[f"{name}_luts"])
+        assert np.array_equal(ol.output_convert(mapped, 10, 8), d[f"{name}_out8"])
+        assert np.array_equal(ol.output_convert(mapped, 10, 10), d[f"{name}_out10"])

@@ -205,3 +205,30 @@ def test_gpu_output_rejects_bad_crop():
             dec.pic_output(pic, 8, (32, 32, 0, 0))        # nothing left
     finally:
         dec.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["three_ranges_idx58", "five_ranges_idx40", "one_range_idx30"])
+def test_gpu_dra_output(name):
+    """xgpu_pic_output with DRA tables == the reference's own output (golden: xevd_init_dra tables, xevd_apply_dra_* and
+    imgb_cpy_codec_to_out run in the development container) and == the oracle, with and without crop."""
+    from xevd_amd.decoder import XgpuDecoder
+    import oracle_lib as ol
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dra.npz"))
+    planes = [d[f"in_{c}"] for c in range(3)]
+    luts = d[f"{name}_luts"]
+    h, w = planes[0].shape
+    dec = XgpuDecoder(w, h, 10, device=0)
+    try:
+        pic = dec.pic_alloc()
+        dec.pic_upload(pic, planes)
+        out8, out10 = dec.pic_output(pic, 8, dra=luts), dec.pic_output(pic, 10, dra=luts)
+        crop = (4, 2, 2, 6)
+        out_crop = dec.pic_output(pic, 8, crop, dra=luts)
+        plain = dec.pic_output(pic, 10)
+    finally:
+        dec.close()
+    assert np.array_equal(out8, d[f"{name}_out8"]) and np.array_equal(out10, d[f"{name}_out10"])
+    mapped = ol.dra_apply(planes, luts)
+    assert np.array_equal(out_crop, ol.output_convert(mapped, 10, 8, crop))
+    assert np.array_equal(plain, ol.output_convert(planes, 10, 10))      # and without tables the picture is untouched

@@ -248,3 +248,19 @@ def test_output_conversion(src_bd, dst_bd):
     planes = [rng.integers(0, 1 << src_bd, (h >> (i > 0), w >> (i > 0))).astype(np.int16) for i in range(3)]
     planes[0][0, :4] = [0, (1 << src_bd) - 1, (1 << src_bd) - 2, 1]
     assert np.array_equal(ol.output_convert(planes, src_bd, dst_bd), ol.ref_output_convert(planes, src_bd, dst_bd))
+
+
+@pytest.mark.parametrize("name", sorted(ol.DRA_SETS))
+def test_dra_apply(name):
+    """orc_dra_apply == the reference's DRA sample processing (xevdm_dra.c:272-355, order of xevd_apply_filter) with the tables the
+    real xevd_init_dra builds from the signalled parameters; the tables themselves become a golden fixture for the GPU test."""
+    rng = np.random.default_rng(len(name))
+    w, h = 72, 40
+    planes = [rng.integers(0, 1024, (h >> (i > 0), w >> (i > 0))).astype(np.int16) for i in range(3)]
+    planes[0][0, :4] = [0, 1023, 1, 1022]
+    planes[1][0, :4] = [0, 1023, 512, 511]
+    luts, ref = ol.ref_dra(name, 10, planes)
+    ours = ol.dra_apply(planes, luts)
+    for c in range(3):
+        assert np.array_equal(ours[c], ref[c]), f"plane {c}"
+    assert not np.array_equal(ours[0], planes[0]) and not np.array_equal(ours[1], planes[1])     # the filter does something

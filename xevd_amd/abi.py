@@ -28,6 +28,10 @@ class SeqParams(C.Structure):
     ]
 
 
+class DraLuts(C.Structure):
+    _fields_ = [("luma_inv_scale_lut", C.c_void_p), ("chroma_inv_scale_lut", C.c_void_p * 2)]
+
+
 class FrameParams(C.Structure):
     _fields_ = [
         ("pic", C.c_int), ("poc", C.c_int), ("num_refp", C.c_int * 2),
@@ -138,7 +142,7 @@ _EXPORTS = {
     "xgpu_pic_upload": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "xgpu_pic_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "xgpu_pic_output_size": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
-    "xgpu_pic_output": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "xgpu_pic_output": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "xgpu_pic_download_padded": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "xgpu_pic_upload_padded": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "xgpu_frame_begin": (C.c_int, [C.c_void_p, C.POINTER(FrameParams)]),

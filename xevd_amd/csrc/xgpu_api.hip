@@ -154,7 +154,7 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     xgpu_ctx *c = new xgpu_ctx();
     c->sp = *sp;
     c->sp.chroma_qp_table[0] = c->sp.chroma_qp_table[1] = NULL;
-    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_owner = NULL; c->d_out = NULL; c->out_cap = 0; c->d_ctb_flag = NULL; c->stream = 0; c->where = 0;
+    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_owner = NULL; c->d_out = NULL; c->d_dra = NULL; c->out_cap = 0; c->d_ctb_flag = NULL; c->stream = 0; c->where = 0;
     memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_n, 0, sizeof(c->t_n));
     // chroma QP mapping: caller table starts at qp = -6*(bdc-8); default = Baseline static table with the
     // identity extension below 0 (xevd_set_chroma_qp_tbl_loc, xevd_tbl.c:364-372)
@@ -210,6 +210,7 @@ void xgpu_close(xgpu_ctx *c)
     if (c->d_maps) (void)hipFree(c->d_maps);
     if (c->d_owner) (void)hipFree(c->d_owner);
     if (c->d_out) (void)hipFree(c->d_out);
+    if (c->d_dra) (void)hipFree(c->d_dra);
     if (c->d_ctb_flag) (void)hipFree(c->d_ctb_flag);
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
@@ -311,18 +312,25 @@ size_t xgpu_pic_output_size(const xgpu_ctx *c, int out_bit_depth, int crop_l, in
     const size_t w = c->sp.width - crop_l - crop_r, h = c->sp.height - crop_t - crop_b;
     return (w * h + 2 * (w >> 1) * (h >> 1)) * (out_bit_depth == 8 ? 1 : 2);
 }
-int xgpu_pic_output(xgpu_ctx *c, int pic, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b, void *dst, size_t dst_size)
+int xgpu_pic_output(xgpu_ctx *c, int pic, const xgpu_dra_luts *dra, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b, void *dst, size_t dst_size)
 {
     ARGCHK(c, c != NULL); ARGCHK(c, valid_pic(c, pic)); ARGCHK(c, dst != NULL);
     ARGCHK(c, valid_output(c, out_bit_depth, crop_l, crop_r, crop_t, crop_b));
     const size_t need = xgpu_pic_output_size(c, out_bit_depth, crop_l, crop_r, crop_t, crop_b);
     ARGCHK(c, dst_size >= need);
     if (c->out_cap < need) {
-        if (c->d_out) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_out); c->d_out = NULL; c->out_cap = 0; }
+        if (c->d_out) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_out); c->d_out = NULL; c->d_dra = NULL; c->out_cap = 0; }
         if (hipMalloc((void **)&c->d_out, need) != hipSuccess) { snprintf(c->err, sizeof(c->err), "pic_output: cannot allocate the %zu-byte staging buffer", need); return XGPU_ERR_OUT_OF_MEMORY; }
         c->out_cap = need;
     }
-    launch_output(c, dpic(c, pic), out_bit_depth, crop_l, crop_r, crop_t, crop_b, c->d_out);
+    if (dra) {
+        ARGCHK(c, dra->luma_inv_scale_lut && dra->chroma_inv_scale_lut[0] && dra->chroma_inv_scale_lut[1]);
+        ARGCHK(c, c->sp.bit_depth_luma <= 10);                         // the tables have 1024 entries (DRA_LUT_MAXSIZE)
+        if (!c->d_dra && hipMalloc((void **)&c->d_dra, sizeof(int32_t) * 3 * 1024) != hipSuccess) { snprintf(c->err, sizeof(c->err), "pic_output: cannot allocate the DRA tables"); return XGPU_ERR_OUT_OF_MEMORY; }
+        const int32_t *src[3] = { dra->luma_inv_scale_lut, dra->chroma_inv_scale_lut[0], dra->chroma_inv_scale_lut[1] };
+        for (int i = 0; i < 3; i++) HIPCHK(c, hipMemcpyAsync(c->d_dra + 1024 * i, src[i], sizeof(int32_t) * 1024, hipMemcpyHostToDevice, c->stream));
+    }
+    launch_output(c, dpic(c, pic), dra ? c->d_dra : NULL, out_bit_depth, crop_l, crop_r, crop_t, crop_b, c->d_out);
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipMemcpyAsync(dst, c->d_out, need, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));

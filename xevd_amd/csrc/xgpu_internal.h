@@ -188,6 +188,7 @@ struct xgpu_ctx {
     uint16_t       *d_owner;          // SCU -> CU index inside the CTU, rebuilt per picture by k_paint
     uint8_t        *d_ctb_flag;       // ALF luma CTB flags of the current picture
     uint8_t        *d_out;            // packed output picture (xgpu_pic_output), grown on demand
+    int32_t        *d_dra;            // [3][1024] DRA inverse tables of the current output call
     size_t          out_cap;
     xgpu_frame_params fp;
     int             have_frame;
@@ -213,6 +214,6 @@ void launch_addb(xgpu_ctx *c, const AddbArgs &a, int dir, const DevPic &src, con
 void launch_alf(xgpu_ctx *c, const AlfArgs &a, const DevPic &src, const DevPic &dst);
 void launch_pad(xgpu_ctx *c, const DevPic &p);
 void launch_copy_bw(xgpu_ctx *c, const void *src, void *dst, size_t bytes);
-void launch_output(xgpu_ctx *c, const DevPic &pic, int out_bd, int crop_l, int crop_r, int crop_t, int crop_b, uint8_t *d_dst);
+void launch_output(xgpu_ctx *c, const DevPic &pic, const int32_t *d_dra, int out_bd, int crop_l, int crop_r, int crop_t, int crop_b, uint8_t *d_dst);
 void launch_test_mc(xgpu_ctx *c, const int16_t *plane, int stride, int ref_x, int ref_y, int has_dx, int has_dy,
                     int gmv_x, int gmv_y, int16_t *pred, int w, int h, int bd, int luma);

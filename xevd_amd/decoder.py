@@ -76,15 +76,24 @@ class XgpuDecoder:
                   "xgpu_pic_download")
         return [y, u, v]
 
-    def pic_output(self, pic, out_bit_depth=0, crop=(0, 0, 0, 0)):
+    def pic_output(self, pic, out_bit_depth=0, crop=(0, 0, 0, 0), dra=None):
         """The picture as the bytes of a .yuv file frame (Y, U, V planes, tight rows): converted to `out_bit_depth` (0 = the coding
-        depth; 8 -> one byte per sample) and cropped by (left, right, top, bottom) luma samples on the device (xgpu_pic_output)."""
+        depth; 8 -> one byte per sample) and cropped by (left, right, top, bottom) luma samples on the device (xgpu_pic_output).
+        dra: (luma_inv_scale_lut, cb_inv_scale_lut, cr_inv_scale_lut), 1024 int32 each - the DRA post-filter's tables."""
         bd = out_bit_depth or self.bit_depth
         n = self.lib.xgpu_pic_output_size(self.ctx, bd, *crop)
         if n == 0:
             raise ValueError(f"invalid output format: bit depth {bd}, crop {crop}")
         out = np.empty(n, np.uint8)
-        self._chk(self.lib.xgpu_pic_output(self.ctx, pic, bd, *crop, out.ctypes.data, n), "xgpu_pic_output")
+        dl, keep = None, None
+        if dra is not None:
+            keep = [np.ascontiguousarray(t, np.int32) for t in dra]
+            assert all(t.size == 1024 for t in keep)
+            d = abi.DraLuts()
+            d.luma_inv_scale_lut = keep[0].ctypes.data
+            d.chroma_inv_scale_lut[0], d.chroma_inv_scale_lut[1] = keep[1].ctypes.data, keep[2].ctypes.data
+            dl = C.byref(d)
+        self._chk(self.lib.xgpu_pic_output(self.ctx, pic, dl, bd, *crop, out.ctypes.data, n), "xgpu_pic_output")
         return out
 
     def pic_upload_padded(self, pic, bufs):
