@@ -33,4 +33,5 @@ for name, sp, ml in cases:
         out[f"{name}_{tag}"] = round(1e3 * tim["inter"][0] / tim["inter"][1], 1)
         print(name, tag, "n_cu", len(b["x"]), "inter_us", out[f"{name}_{tag}"], flush=True)
         dec.batch_destroy(h)
-json.dump(out, open("gpurun_out/exp_inter.json", "w"))
+os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "exp_inter.json"), "w"))

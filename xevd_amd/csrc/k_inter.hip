@@ -544,6 +544,7 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
         TileFetch tf[2];
         int tpx[2], tpy[2], tmx[2], tmy[2];
 #pragma unroll
+
         for (int l = 0; l < 2; l++) {                               // all the windows first ...
             if (!__builtin_amdgcn_readfirstlane((int)use[l])) continue;
             const int ri = __builtin_amdgcn_readfirstlane(refis[l] * 2 + l);
@@ -589,7 +590,8 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
             }
             nl++;
         }
-    } else
+    } else {
+    load_resid();
 #pragma unroll
     for (int l = 0; l < 2; l++) {
         if (!use[l]) continue;
@@ -638,10 +640,10 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
         }
         nl++;
     }
+    }
     if (nl == 0) return;     // inter CU without a valid reference: nothing predicted (does not occur in valid streams)
 
     // ---- residual add + clip (xevd_recon.c:35-71; the LUMA bit depth clips all three components, :75-90) ----
-    if (!uni) load_resid();
     if (cbf & 1) {
 #pragma unroll
         for (int k = 0; k < 8; k++) pl[k] = recon2(pl[k], rl[k], maxl);
