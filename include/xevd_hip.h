@@ -75,6 +75,8 @@ typedef struct xgpu_seq_params {
        entry [c][qp + 6*(bit_depth_chroma-8)]; NULL = the sequence default: xevd_tbl_qp_chroma_adjust_base, or
        _main when tool_iqt is on (src_main/xevdm.c:471-479)                                            */
     const int8_t *chroma_qp_table[2];
+    int tool_eipd;            /* sps->tool_eipd : 33 luma / 5 chroma intra modes, neighbour padding of xevdm_get_nbr; batch.ipm then
+                                 holds core->ipm[0] (IPD_DC 0, PLN 1, BI 2, angular 3..32) and core->ipm[1] (DM 0, BI 1, DC 2, HOR 3, VER 4) */
 } xgpu_seq_params;
 
 /* Per-picture parameters: what slice_init / the slice header contribute to this path. */

@@ -22,6 +22,7 @@
 #include "xevdm_itdq.h"
 #include "xevdm_df.h"
 #include "xevdm_alf.h"
+#include "xevdm_ipred.h"
 #include "xevdm_dra.h"
 #include "xevd_oracle.h"
 
@@ -208,12 +209,22 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
                 pel *plane = c == 0 ? ctx->pic->y : (c == 1 ? ctx->pic->u : ctx->pic->v);
                 const int s = c ? ctx->pic->s_c : ctx->pic->s_l;
                 if (c == 1) { xx >>= 1; yy >>= 1; ww >>= 1; hh >>= 1; }
-                xevd_get_nbr_b(xx, yy, ww, hh, plane + yy * s + xx, s, core->avail_cu, core->nb, core->scup, ctx->map_scu, ctx->w_scu, ctx->h_scu,
-                               c, b->constrained_intra_pred, ctx->map_tidx, sp->bit_depth_luma, sp->chroma_format_idc);
+                if (sp->tool_eipd)      /* get_nbr_yuv, xevdm.c:605-655 */
+                    xevdm_get_nbr(xx, yy, ww, hh, plane + yy * s + xx, s, core->avail_cu, core->nb, core->scup, ctx->map_scu, ctx->w_scu, ctx->h_scu,
+                                  c, b->constrained_intra_pred, ctx->map_tidx, sp->bit_depth_luma, sp->chroma_format_idc);
+                else
+                    xevd_get_nbr_b(xx, yy, ww, hh, plane + yy * s + xx, s, core->avail_cu, core->nb, core->scup, ctx->map_scu, ctx->w_scu, ctx->h_scu,
+                                   c, b->constrained_intra_pred, ctx->map_tidx, sp->bit_depth_luma, sp->chroma_format_idc);
             }
-            xevd_ipred_b(core->nb[0][0] + 2, core->nb[0][1] + h, core->nb[0][2] + 2, core->avail_lr, core->pred[0][Y_C], core->ipm[0], w, h);
-            xevd_ipred_uv_b(core->nb[1][0] + 2, core->nb[1][1] + (h >> 1), core->nb[1][2] + 2, core->avail_lr, core->pred[0][U_C], core->ipm[1], core->ipm[0], w >> 1, h >> 1);
-            xevd_ipred_uv_b(core->nb[2][0] + 2, core->nb[2][1] + (h >> 1), core->nb[2][2] + 2, core->avail_lr, core->pred[0][V_C], core->ipm[1], core->ipm[0], w >> 1, h >> 1);
+            if (sp->tool_eipd) {        /* xevdm.c:1352-1360 */
+                xevdm_ipred(core->nb[0][0] + 2, core->nb[0][1] + h, core->nb[0][2] + 2, core->avail_lr, core->pred[0][Y_C], core->ipm[0], w, h, sp->bit_depth_luma);
+                xevdm_ipred_uv(core->nb[1][0] + 2, core->nb[1][1] + (h >> 1), core->nb[1][2] + 2, core->avail_lr, core->pred[0][U_C], core->ipm[1], core->ipm[0], w >> 1, h >> 1, sp->bit_depth_chroma);
+                xevdm_ipred_uv(core->nb[2][0] + 2, core->nb[2][1] + (h >> 1), core->nb[2][2] + 2, core->avail_lr, core->pred[0][V_C], core->ipm[1], core->ipm[0], w >> 1, h >> 1, sp->bit_depth_chroma);
+            } else {
+                xevd_ipred_b(core->nb[0][0] + 2, core->nb[0][1] + h, core->nb[0][2] + 2, core->avail_lr, core->pred[0][Y_C], core->ipm[0], w, h);
+                xevd_ipred_uv_b(core->nb[1][0] + 2, core->nb[1][1] + (h >> 1), core->nb[1][2] + 2, core->avail_lr, core->pred[0][U_C], core->ipm[1], core->ipm[0], w >> 1, h >> 1);
+                xevd_ipred_uv_b(core->nb[2][0] + 2, core->nb[2][1] + (h >> 1), core->nb[2][2] + 2, core->avail_lr, core->pred[0][V_C], core->ipm[1], core->ipm[0], w >> 1, h >> 1);
+            }
             xevd_recon_yuv(ctx, core, x, y, w, h);
         } else {
             /* prediction: xevd.c:725-726 / xevdm.c:1311-1316 (DMVR off) */

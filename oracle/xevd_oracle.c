@@ -525,6 +525,132 @@ static void intra_predict(const int16_t *left, const int16_t *up, int16_t *dst, 
     }
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Intra prediction with sps->tool_eipd (Main): 33 luma modes (DC 0, planar 1, bilinear 2, 30 angular with VER 12 / HOR 24) and
+ * 5 chroma modes (DM 0, BI 1, DC 2, HOR 3, VER 4), for blocks without right-hand neighbours (SUCO off: avail_lr LR_00 / LR_10).
+ * ---------------------------------------------------------------------------------------------- */
+/* xevdm_get_nbr (src_main/xevdm_ipred.c:39-148): as intra_neighbours, but an unavailable unit REPEATS the sample before it
+   (towards the corner) instead of the mid value, and an unavailable corner takes up[0]. */
+static void intra_neighbours_eipd(const xgpu_seq_params *sp, const orc_maps *m, const int16_t *src, int s, int x_scu, int y_scu,
+                                  int cw, int ch, int unit, int constrained, int16_t *up, int16_t *left)
+{
+    const int scuw = cw / unit, scuh = ch / unit, ws = m->w_scu, scup = x_scu + y_scu * ws;
+    int i, j;
+#define NB_OK(k) (MCU_COD(m->map_scu[k]) && (!constrained || MCU_IF(m->map_scu[k])))
+    const int ul_ok = x_scu > 0 && y_scu > 0 && NB_OK(scup - ws - 1);
+    up[-1] = ul_ok ? src[-s - 1] : (int16_t)(1 << (sp->bit_depth_luma - 1));      /* the mid value only feeds the repetition below */
+    for (i = 0; i < scuw + scuh; i++) {
+        const int ok = y_scu > 0 && x_scu + i < ws && NB_OK(scup - ws + i);
+        for (j = 0; j < unit; j++) up[i * unit + j] = ok ? src[-s + i * unit + j] : up[i * unit - 1];
+    }
+    if (!ul_ok) up[-1] = up[0];                      /* :80-99: the part left of up[0] repeats up[0] when its unit is unavailable */
+    left[-1] = up[-1];
+    for (i = 0; i < scuh + scuw; i++) {
+        const int ok = x_scu > 0 && y_scu + i < m->h_scu && NB_OK(scup - 1 + i * ws);
+        for (j = 0; j < unit; j++) left[i * unit + j] = ok ? src[(i * unit + j) * s - 1] : left[i * unit - 1];
+    }
+#undef NB_OK
+}
+
+static int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
+static const int k_inv_size[8] = { 2048, 1365, 819, 455, 241, 124, 63, 32 };      /* 4096 / (2^k + 1), xevd_ipred.c:122 */
+
+/* slopes of the angular modes in 1/1024: { dx per dy, dy per dx } (xevd_tbl_ipred_dxdy, xevd_tbl.c:294-304) */
+static void ang_slopes(int mode, int *dx, int *dy)
+{
+    static const int t[9] = { 2816, 2048, 1408, 1024, 744, 512, 372, 256, 128 };       /* modes 3..11 dx; mirrored for the rest */
+    static const int u[11] = { 128, 256, 372, 512, 744, 1024, 1408, 2048, 2816, 4096, 8192 };
+    if (mode >= 3 && mode <= 11)       { *dx = t[mode - 3]; *dy = u[mode - 1]; }
+    else if (mode >= 13 && mode <= 23) { *dx = u[mode - 13]; *dy = u[23 - mode]; }
+    else if (mode >= 25 && mode <= 32) { *dx = u[35 - mode]; *dy = u[mode - 25]; }
+    else                               { *dx = 0; *dy = 0; }
+}
+
+/* ipred_ang_val (xevd_ipred.c:377-569) without the right-neighbour branches: a 4-tap interpolation { 32-o, 64-o, 32+o, o } / 128
+   between reference positions clamped to [-1, w+h-1] */
+static int ang_sample(const int16_t *left, const int16_t *up, int mode, int i, int j, int w, int h, int maxv)
+{
+    int dx, dy, o, p, dir;
+    const int16_t *ref;
+    ang_slopes(mode, &dx, &dy);
+    if (mode < 12) {                       /* from the row above, leaning right */
+        const int t = (j + 1) * dx;
+        p = i + (t >> 10); o = (t >> 5) - ((t >> 10) << 5); ref = up; dir = 1;
+    } else if (mode > 24) {                /* from the left column, leaning down */
+        const int t = (i + 1) * dy;
+        p = j + (t >> 10); o = (t >> 5) - ((t >> 10) << 5); ref = left; dir = 1;
+    } else {                               /* between vertical and horizontal: from above or from the left, leaning back */
+        const int ty = (i + 1) * dy;
+        if (j < (ty >> 10)) {
+            const int tx = (j + 1) * dx;
+            p = i - (tx >> 10); o = (tx >> 5) - ((tx >> 10) << 5); ref = up;
+        } else {
+            p = j - (ty >> 10); o = (ty >> 5) - ((ty >> 10) << 5); ref = left;
+        }
+        dir = -1;
+    }
+    {
+        const int hi = w + h - 1;
+#define CL(v) ((v) < -1 ? -1 : ((v) > hi ? hi : (v)))
+        const int v = (ref[CL(p - dir)] * (32 - o) + ref[CL(p)] * (64 - o) + ref[CL(p + dir)] * (32 + o) + ref[CL(p + 2 * dir)] * o + 64) >> 7;
+#undef CL
+        return v < 0 ? 0 : (v > maxv ? maxv : v);
+    }
+}
+
+/* xevdm_ipred / xevdm_ipred_uv (src_main/xevdm_ipred.c:241-305) for avail_lr without a right side.  `mode` is a LUMA mode number. */
+static void intra_predict_eipd(const int16_t *left, const int16_t *up, int16_t *dst, int mode, int w, int h, int bit_depth)
+{
+    const int lw = ilog2(w), lh = ilog2(h), maxv = (1 << bit_depth) - 1;
+    int i, j;
+    if (mode == 12) { for (j = 0; j < h; j++) for (i = 0; i < w; i++) dst[j * w + i] = up[i]; return; }            /* xevd_ipred_vert */
+    if (mode == 24) { for (j = 0; j < h; j++) for (i = 0; i < w; i++) dst[j * w + i] = left[j]; return; }          /* xevdm_ipred_hor :153-196 */
+    if (mode == 0) {                                                                                            /* xevdm_ipred_dc :198-229, xevd_get_dc */
+        int dc = 0;
+        for (j = 0; j < h; j++) dc += left[j];
+        for (i = 0; i < w; i++) dc += up[i];
+        dc = ((dc + ((w + h) >> 1)) * k_inv_size[lw > lh ? lw - lh : lh - lw]) >> ((lw < lh ? lw : lh) + 12);
+        for (i = 0; i < w * h; i++) dst[i] = (int16_t)dc;
+        return;
+    }
+    if (mode == 1) {                                                                                            /* xevd_ipred_plane :163-249 */
+        static const int mult[6] = { 13, 17, 5, 11, 23, 47 }, shift[6] = { 7, 10, 11, 15, 19, 23 };
+        const int w2 = w >> 1, h2 = h >> 1, iw = lw < 2 ? 0 : lw - 2, ih = lh < 2 ? 0 : lh - 2;
+        int ch_ = 0, cv = 0, a, b, c, base;
+        for (i = 1; i <= w2; i++) ch_ += i * (up[w2 - 1 + i] - up[w2 - 1 - i]);
+        for (j = 1; j <= h2; j++) cv += j * (left[h2 - 1 + j] - left[h2 - 1 - j]);
+        a = (left[h - 1] + up[w - 1]) << 4;
+        b = ((ch_ << 5) * mult[iw] + (1 << (shift[iw] - 1))) >> shift[iw];
+        c = ((cv << 5) * mult[ih] + (1 << (shift[ih] - 1))) >> shift[ih];
+        base = a - (h2 - 1) * c - (w2 - 1) * b + 16;
+        for (j = 0; j < h; j++) for (i = 0; i < w; i++) {
+            const int v = (base + j * c + i * b) >> 5;
+            dst[j * w + i] = (int16_t)(v < 0 ? 0 : (v > maxv ? maxv : v));
+        }
+        return;
+    }
+    if (mode == 2) {                                                                                            /* xevd_ipred_bi :251-369, last branch */
+        static const int wc_tbl[6] = { -1, 341, 205, 114, 60, 31 };
+        const int a = up[w], b = left[h], ms = lw < lh ? lw : lh;
+        const int c = w == h ? (a + b + 1) >> 1 : (((a << lw) + (b << lh)) * wc_tbl[lw > lh ? lw - lh : lh - lw] + (1 << (ms + 9))) >> (ms + 10);
+        const int wt = (c << 1) - a - b;
+        for (j = 0; j < h; j++) for (i = 0; i < w; i++) {
+            const int px = (left[j] << lw) + (i + 1) * (a - left[j]);
+            const int py = (up[i] << lh) + (j + 1) * (b - up[i]);
+            const int v = ((px << lh) + (py << lw) + i * j * wt + (1 << (lw + lh))) >> (lw + lh + 1);
+            dst[j * w + i] = (int16_t)(v < 0 ? 0 : (v > maxv ? maxv : v));
+        }
+        return;
+    }
+    for (j = 0; j < h; j++) for (i = 0; i < w; i++) dst[j * w + i] = (int16_t)ang_sample(left, up, mode, i, j, w, h, maxv);
+}
+/* chroma mode -> the luma-numbered predictor to run (xevdm_ipred_uv :267-305; DM follows the luma mode) */
+static int eipd_chroma_mode(int ipm_c, int ipm_l)
+{
+    static const int direct[5] = { -1, 2, 0, 24, 12 };      /* BI_C 1, DC_C 2, HOR_C 3, VER_C 4 */
+    return ipm_c == 0 ? ipm_l : direct[ipm_c];
+}
+
 int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *maps, int16_t *resid_out)
 {
     int16_t *pred[2][3], *res;
@@ -543,6 +669,14 @@ int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_c
             for (c = 0; c < 3; c++) {
                 const int cw = c ? w >> 1 : w, ch = c ? h >> 1 : h, s = c ? fr->cur.s_c : fr->cur.s_l;
                 const int16_t *plane = c == 0 ? fr->cur.y : (c == 1 ? fr->cur.u : fr->cur.v);
+                if (sp->tool_eipd) {
+                    const int ml = b->ipm ? b->ipm[i * 2] : 0, mc = b->ipm ? b->ipm[i * 2 + 1] : 0;
+                    intra_neighbours_eipd(sp, maps, plane + (c ? (y >> 1) * s + (x >> 1) : y * s + x), s, x >> 2, y >> 2, cw, ch, c ? 2 : 4,
+                                          b->constrained_intra_pred, nb_up + 4, nb_le + 4);
+                    intra_predict_eipd(nb_le + 4, nb_up + 4, pred[0][c], c ? eipd_chroma_mode(mc, ml) : ml, cw, ch,
+                                       c ? sp->bit_depth_chroma : sp->bit_depth_luma);
+                    continue;
+                }
                 intra_neighbours(sp, maps, plane + (c ? (y >> 1) * s + (x >> 1) : y * s + x), s, x >> 2, y >> 2, cw, ch, c ? 2 : 4,
                                  b->constrained_intra_pred, nb_up + 4, nb_le + 4);
                 intra_predict(nb_le + 4, nb_up + 4, pred[0][c], b->ipm ? b->ipm[i * 2 + (c ? 1 : 0)] : 0, cw, ch);

@@ -41,6 +41,11 @@ CASES = [
     ("base_p_constrained_intra_10b", 144, 88, 10, 0, 0, (1, 0), 0.0, {"inter_frac": 0.5, "constrained_intra": 1}),
     ("main_i_btt_10b", 200, 136, 10, 1, 1, (1, 0), 0.0, {"inter_frac": 0.0, "btt_frac": 0.7, "addb": 1, "alf": 1, "ats_frac": 0.5}),
     ("main_b_ctu128_intra_mix_8b", 264, 200, 8, 1, 1, (1, 1), 0.4, {"inter_frac": 0.6, "log2_ctu": 7, "btt_frac": 0.5, "split_prob": 0.4, "addb": 1, "alf": 1, "ats_frac": 0.4, "ats_inter_frac": 0.4}),
+    # sps->tool_eipd: 33 luma / 5 chroma intra modes, neighbour padding by repetition (xevdm_get_nbr)
+    ("main_eipd_i_10b", 136, 120, 10, 1, 1, (1, 0), 0.0, {"inter_frac": 0.0, "eipd": 1, "addb": 1}),
+    ("main_eipd_i_btt_8b", 200, 136, 8, 1, 1, (1, 0), 0.0, {"inter_frac": 0.0, "eipd": 1, "btt_frac": 0.7, "split_prob": 0.6}),
+    ("main_eipd_b_ctu128_constrained_10b", 264, 200, 10, 1, 1, (1, 1), 0.4, {"inter_frac": 0.5, "eipd": 1, "log2_ctu": 7, "btt_frac": 0.5, "split_prob": 0.4,
+                                                                             "addb": 1, "alf": 1, "constrained_intra": 1, "ats_frac": 0.4}),
     # CTU 128 without ADDB: the Main library's copy of the Baseline filter, CUs above 64 filtered as two halves
     ("main_ctu128_noaddb_8b", 264, 264, 8, 1, 0, (1, 1), 0.3, {"log2_ctu": 7, "btt_frac": 0.6, "ats_inter_frac": 0.5, "split_prob": 0.3}),
 ]
@@ -69,7 +74,7 @@ def build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, tools=None, seed=0, 
     if (2, 1) in refs and (0, 0) in refs:
         refs[(2, 1)] = refs[(0, 0)]      # the same picture in both lists (same POC 4): ADDB compares pictures, not indices
     batch = synth.gen_frame(rng, w, h, bd, log2_ctu=log2_ctu, ats_frac=float(tools.get("ats_frac", 0.0)), ats_inter_frac=float(tools.get("ats_inter_frac", 0.0)), btt_frac=float(tools.get("btt_frac", 0.0)), inter_frac=inter_frac, bi_frac=bi_frac, n_refs=n_refs, oob_frac=oob_frac,
-                            qp_range=qp_range, split_prob=split_prob, amp=amp, coded_frac=float(tools.get("coded_frac", 0.6)))
+                            qp_range=qp_range, split_prob=split_prob, amp=amp, coded_frac=float(tools.get("coded_frac", 0.6)), eipd=bool(tools.get("eipd", 0)))
     batch["constrained_intra_pred"] = int(tools.get("constrained_intra", 0))
     if n_refs[0] and n_refs[1]:      # force some identical-motion bi CUs
         sel = (batch["refi"][:, 0] >= 0) & (batch["refi"][:, 1] >= 0)
@@ -83,7 +88,7 @@ def build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, tools=None, seed=0, 
                                           enable=tools.get("alf_enable", (1, 1, 1)))
     return {"name": name, "w": w, "h": h, "bd": bd, "admvp": admvp, "iqt": iqt, "refs": refs, "batch": batch,
             "alf_params": alf_params, "no_deblock": int(tools.get("no_deblock", 0)), "log2_ctu": log2_ctu,
-            "addb": int(tools.get("addb", 0)), "alf": int(tools.get("alf", 0)),
+            "addb": int(tools.get("addb", 0)), "alf": int(tools.get("alf", 0)), "eipd": int(tools.get("eipd", 0)),
             "alpha_off": int(tools.get("alpha_off", 0)), "beta_off": int(tools.get("beta_off", 0))}
 
 
@@ -98,7 +103,7 @@ def _start_picture(case):
 def run_cpu(engine, case, deblock=True, simd=0, pad=True):
     """engine 'oracle' (oracle/liboracle.so) or 'ref' (the real reference through oracle/_ref). -> (final, pre-deblock, maps, resid)"""
     sp = abi.make_seq_params(case["w"], case["h"], case["bd"], log2_ctu=case.get("log2_ctu", 6), iqt=case["iqt"], admvp=case["admvp"],
-                             addb=case.get("addb", 0), alf=case.get("alf", 0))
+                             addb=case.get("addb", 0), alf=case.get("alf", 0), eipd=case.get("eipd", 0))
     cb, keep = abi.make_cu_batch(case["batch"])
     cur = _start_picture(case)
     maps = ol.Maps(case["w"], case["h"])
@@ -140,7 +145,7 @@ def run_gpu(case, deblock=True, pad=True, alf=True, resid=False, repeat=1):
     """The HIP backend through the C ABI. -> list of padded planes (reference buffer geometry)"""
     from xevd_amd.decoder import XgpuDecoder
     with XgpuDecoder(case["w"], case["h"], case["bd"], log2_ctu=case.get("log2_ctu", 6), iqt=case["iqt"], admvp=case["admvp"],
-                     addb=case.get("addb", 0), alf=case.get("alf", 0), max_pics=8) as dec:
+                     addb=case.get("addb", 0), alf=case.get("alf", 0), eipd=case.get("eipd", 0), max_pics=8) as dec:
         slots, by_obj = {}, {}
         for key, pic in case["refs"].items():
             if id(pic) not in by_obj:            # one device picture per distinct picture

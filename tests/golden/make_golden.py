@@ -114,7 +114,7 @@ def golden_pictures(only=None):
         cs = cases.build_case(*case)
         final, pre, maps, resid = cases.run_cpu("ref", cs)
         d = {"params": np.array(case[1:6], np.int64), "n_refs": np.array(case[6], np.int64),
-             "tools": np.array([cs["addb"], cs["alf"], cs["alpha_off"], cs["beta_off"], cs["no_deblock"], cs["log2_ctu"]], np.int64)}
+             "tools": np.array([cs["addb"], cs["alf"], cs["alpha_off"], cs["beta_off"], cs["no_deblock"], cs["log2_ctu"], cs.get("eipd", 0)], np.int64)}
         if cs["alf_params"] is not None:
             ap = cs["alf_params"]
             d["alf_enable"] = np.array(ap["enable"], np.int64)

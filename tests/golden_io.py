@@ -11,7 +11,8 @@ PICTURE_CASES = ["base_p_8b", "base_b_8b", "base_p_10b", "main_b_10b", "main_adm
                  "main_ctu128_10b", "main_ctu128_8b_noiqt", "main_ats_10b", "main_ats_8b_noiqt",
                  "main_atsinter_10b", "main_atsinter_8b_mixed", "main_atsinter_noaddb",
                  "main_btt_10b", "main_btt_ctu128_8b", "main_btt_noaddb_8b", "main_ctu128_noaddb_8b",
-                 "base_i_8b", "base_p_constrained_intra_10b", "main_i_btt_10b", "main_b_ctu128_intra_mix_8b"]
+                 "base_i_8b", "base_p_constrained_intra_10b", "main_i_btt_10b", "main_b_ctu128_intra_mix_8b",
+                 "main_eipd_i_10b", "main_eipd_i_btt_8b", "main_eipd_b_ctu128_constrained_10b"]
 
 
 def load_picture_case(name):
@@ -30,7 +31,7 @@ def load_picture_case(name):
             if f"refalias_{i}_{l}" in d.files:
                 refs[(i, l)] = refs[tuple(int(v) for v in d[f"refalias_{i}_{l}"])]
     tools = [int(v) for v in d["tools"]] if "tools" in d.files else []
-    tools = (tools + [0, 0, 0, 0, 0, 6][len(tools):])[:6]
+    tools = (tools + [0, 0, 0, 0, 0, 6, 0][len(tools):])[:7]
     alf_params = None
     if "alf_enable" in d.files:
         alf_params = {"enable": tuple(int(v) for v in d["alf_enable"]), "luma_coef": d["alf_luma_coef"], "chroma_coef": d["alf_chroma_coef"],
@@ -43,7 +44,7 @@ def load_picture_case(name):
     batch.setdefault("ats_inter", None)
     case = {"name": name, "w": w, "h": h, "bd": bd, "admvp": admvp, "iqt": iqt, "refs": refs, "batch": batch,
             "addb": tools[0], "alf": tools[1], "alpha_off": tools[2], "beta_off": tools[3], "no_deblock": tools[4], "log2_ctu": tools[5],
-            "alf_params": alf_params}
+            "eipd": tools[6], "alf_params": alf_params}
     expect = {"out": [d[f"out_{c}"] for c in range(3)], "pre": [d[f"pre_{c}"] for c in range(3)], "resid": d["resid"],
               "map_scu": d["map_scu"]}
     return case, expect

@@ -25,6 +25,7 @@ class SeqParams(C.Structure):
         ("log2_ctu", C.c_int), ("tool_iqt", C.c_int), ("tool_admvp", C.c_int), ("tool_addb", C.c_int),
         ("tool_alf", C.c_int), ("max_pics", C.c_int),
         ("chroma_qp_table", C.POINTER(C.c_int8) * 2),
+        ("tool_eipd", C.c_int),
     ]
 
 
@@ -118,7 +119,7 @@ def make_cu_batch(b):
 
 
 def make_seq_params(width, height, bit_depth=8, log2_ctu=6, device=0, iqt=0, admvp=0, addb=0, alf=0, max_pics=4,
-                    bit_depth_chroma=None):
+                    bit_depth_chroma=None, eipd=0):
     sp = SeqParams()
     sp.device, sp.width, sp.height = device, width, height
     sp.bit_depth_luma = bit_depth
@@ -127,6 +128,7 @@ def make_seq_params(width, height, bit_depth=8, log2_ctu=6, device=0, iqt=0, adm
     sp.log2_ctu = log2_ctu
     sp.tool_iqt, sp.tool_admvp, sp.tool_addb, sp.tool_alf = iqt, admvp, addb, alf
     sp.max_pics = max_pics
+    sp.tool_eipd = eipd
     return sp
 
 

@@ -74,6 +74,102 @@ __device__ __forceinline__ void st_coherent2(int16_t *p, uint32_t lo, uint32_t h
     __hip_atomic_store((uint64_t *)p, (uint64_t)lo | ((uint64_t)hi << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// sps->tool_eipd (Main): 33 luma modes - DC 0, planar 1, bilinear 2, angular 3..32 with VER 12 / HOR 24 - and chroma DM / BI / DC /
+// HOR / VER (xevdm_ipred / xevdm_ipred_uv, src_main/xevdm_ipred.c:241-305; predictors src_base/xevd_ipred.c:110-585), for blocks
+// without right-hand neighbours (SUCO off).  The neighbour arrays follow xevdm_get_nbr (xevdm_ipred.c:39-148): an unavailable
+// unit REPEATS the sample before it (towards the corner; the mid value only where nothing precedes), an unavailable corner takes
+// up[0].  Every predictor is a function of (i, j) and the arrays, so a lane evaluates its 4x4 (2x2) samples independently.
+// ---------------------------------------------------------------------------------------------------------
+struct EipdPlan { int mode, p0, p1, p2; };      // wave-uniform: DC p0 = value; planar p0 = base, p1 = b, p2 = c; bilinear p0 = a, p1 = b, p2 = wt; angular p0 = dx, p1 = dy
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ void ang_slopes(int mode, int &dx, int &dy)      // xevd_tbl_ipred_dxdy (xevd_tbl.c:294-304): slopes in 1/1024
+{
+    const int u[11] = { 128, 256, 372, 512, 744, 1024, 1408, 2048, 2816, 4096, 8192 };
+    int a = 0, b = 0;
+    if (mode >= 3 && mode <= 11)       { a = 11 - mode; b = mode - 1; }
+    else if (mode >= 13 && mode <= 23) { a = mode - 13; b = 23 - mode; }
+    else if (mode >= 25 && mode <= 32) { a = 35 - mode; b = mode - 25; }
+    dx = 0; dy = 0;
+#pragma unroll
+    for (int k = 0; k < 11; k++) { if (k == a) dx = u[k]; if (k == b) dy = u[k]; }
+}
+// mode: a LUMA mode number (chroma modes are mapped by the caller); A = the component's neighbour array; all lanes take part
+__device__ __forceinline__ EipdPlan eipd_plan(const int16_t *A, int mode, int w, int h, int lw, int lh, int t)
+{
+    EipdPlan k = { mode, 0, 0, 0 };
+    const int16_t *up = A + NB_C0 + 1;
+    if (mode == 0) {                                   // xevdm_ipred_dc + xevd_get_dc (xevd_ipred.c:124-144): 4096 / (2^k + 1) scaling of non-square sums
+        const int inv[8] = { 2048, 1365, 819, 455, 241, 124, 63, 32 };
+        int acc = 0;
+        for (int e = t; e < w + h; e += 64) acc += e < h ? A[NB_C0 - 1 - e] : up[e - h];
+        const int asp = lw > lh ? lw - lh : lh - lw;
+        int m = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (q == asp) m = inv[q];
+        k.p0 = ((wave_sum(acc) + ((w + h) >> 1)) * m) >> (min(lw, lh) + 12);
+    } else if (mode == 1) {                            // xevd_ipred_plane (:163-249), left-neighbour branch
+        const int mult[6] = { 13, 17, 5, 11, 23, 47 }, shift[6] = { 7, 10, 11, 15, 19, 23 };
+        const int w2 = w >> 1, h2 = h >> 1, iw = max(lw - 2, 0), ih = max(lh - 2, 0);
+        int ch = 0, cv = 0;
+        for (int x = 1 + t; x <= w2; x += 64) ch += x * (up[w2 - 1 + x] - up[w2 - 1 - x]);
+        for (int y = 1 + t; y <= h2; y += 64) cv += y * (A[NB_C0 - 1 - (h2 - 1 + y)] - A[NB_C0 - 1 - (h2 - 1 - y)]);
+        ch = wave_sum(ch); cv = wave_sum(cv);
+        int mh = 0, sh = 0, mv = 0, sv = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) { if (q == iw) { mh = mult[q]; sh = shift[q]; } if (q == ih) { mv = mult[q]; sv = shift[q]; } }
+        const int a = (A[NB_C0 - 1 - (h - 1)] + up[w - 1]) << 4;
+        k.p1 = ((ch << 5) * mh + (1 << (sh - 1))) >> sh;
+        k.p2 = ((cv << 5) * mv + (1 << (sv - 1))) >> sv;
+        k.p0 = a - (h2 - 1) * k.p2 - (w2 - 1) * k.p1 + 16;
+    } else if (mode == 2) {                            // xevd_ipred_bi (:251-369), left-neighbour branch
+        const int wc_tbl[6] = { -1, 341, 205, 114, 60, 31 };
+        const int a = up[w], b = A[NB_C0 - 1 - h], ms = min(lw, lh), asp = lw > lh ? lw - lh : lh - lw;
+        int wc = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) if (q == asp) wc = wc_tbl[q];
+        const int c = w == h ? (a + b + 1) >> 1 : (((a << lw) + (b << lh)) * wc + (1 << (ms + 9))) >> (ms + 10);
+        k.p0 = a; k.p1 = b; k.p2 = (c << 1) - a - b;
+    } else if (mode != 12 && mode != 24) {
+        ang_slopes(mode, k.p0, k.p1);
+    }
+    return k;
+}
+// the predicted sample at column i, row j (ipred_ang_val :377-569 for the angular modes: 4 taps { 32-o, 64-o, 32+o, o } / 128 between
+// reference positions clamped to [-1, w+h-1]; up[p] = A[NB_C0 + 1 + p], left[p] = A[NB_C0 - 1 - p], both with p = -1 at the corner)
+__device__ __forceinline__ int eipd_sample(const int16_t *A, const EipdPlan &k, int i, int j, int w, int h, int lw, int lh, int maxv)
+{
+    const int mode = k.mode;
+    if (mode == 12) return A[NB_C0 + 1 + i];
+    if (mode == 24) return A[NB_C0 - 1 - j];
+    if (mode == 0) return k.p0;
+    if (mode == 1) return clip3i(0, maxv, (k.p0 + j * k.p2 + i * k.p1) >> 5);
+    if (mode == 2) {
+        const int le = A[NB_C0 - 1 - j], u = A[NB_C0 + 1 + i];
+        const int px = (le << lw) + (i + 1) * (k.p0 - le), py = (u << lh) + (j + 1) * (k.p1 - u);
+        return clip3i(0, maxv, ((px << lh) + (py << lw) + i * j * k.p2 + (1 << (lw + lh))) >> (lw + lh + 1));
+    }
+    int p, o, sgn, dir;                                // reference = A[NB_C0 + sgn * (1 + position)]
+    if (mode < 12)      { const int tt = (j + 1) * k.p0; p = i + (tt >> 10); o = (tt >> 5) & 31; sgn = 1; dir = 1; }
+    else if (mode > 24) { const int tt = (i + 1) * k.p1; p = j + (tt >> 10); o = (tt >> 5) & 31; sgn = -1; dir = 1; }
+    else {
+        const int ty = (i + 1) * k.p1;
+        if (j < (ty >> 10)) { const int tx = (j + 1) * k.p0; p = i - (tx >> 10); o = (tx >> 5) & 31; sgn = 1; }
+        else                { p = j - (ty >> 10); o = (ty >> 5) & 31; sgn = -1; }
+        dir = -1;
+    }
+    const int hi = w + h - 1;
+    const int r0 = A[NB_C0 + sgn * (1 + clip3i(-1, hi, p - dir))], r1 = A[NB_C0 + sgn * (1 + clip3i(-1, hi, p))];
+    const int r2 = A[NB_C0 + sgn * (1 + clip3i(-1, hi, p + dir))], r3 = A[NB_C0 + sgn * (1 + clip3i(-1, hi, p + 2 * dir))];
+    return clip3i(0, maxv, (r0 * (32 - o) + r1 * (64 - o) + r2 * (32 + o) + r3 * o + 64) >> 7);
+}
+
 #define INTRA_WAVES 4        // waves (= CUs in flight) per workgroup; INTRA_CHUNK (xgpu_internal.h) list positions per workgroup, interleaved
 
 __device__ __forceinline__ void wave_lds_sync()      // LDS traffic of one wave is processed in order: only the compiler needs the fence
@@ -90,7 +186,7 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 //              flags of the CUs it reads from.  Samples move with sc1 accesses (coherent across the XCD L2s), flags hold the
 //              launch's epoch (no reset between pictures).  There are no workgroup barriers: a wave may wait for a flag that
 //              another wave of its own workgroup sets.
-template <bool DEP>
+template <bool DEP, bool EIPD>
 __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 {
     __shared__ __attribute__((aligned(16))) int16_t s_nb[INTRA_WAVES][3][NB_LEN];
@@ -151,6 +247,39 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 
         // ---- neighbour staging (xevd_get_nbr_b): sample e of a side belongs to unit e / unit_size.  All loads of the first round
         //      (covers CUs up to w + h = 128) are issued before any LDS store so that they overlap ----
+        if (EIPD) {
+            // xevdm_get_nbr: an unavailable unit repeats the last sample of the nearest available unit before it (the mid value when
+            // there is none above; the corner when there is none to the left); every element is one load at a computed position
+            auto ld1 = [&](const int16_t *p) -> int {
+                if (!DEP) return (int)(uint16_t)*p;
+                const uintptr_t q = (uintptr_t)p;
+                const uint32_t d = ld_coherent((const int16_t *)(q & ~(uintptr_t)3));
+                return (int)((q & 2) ? d >> 16 : d & 0xFFFFu);
+            };
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const int16_t *plane = c == 0 ? a.cur_y : (c == 1 ? a.cur_u : a.cur_v);
+                const int s = c ? a.s_c : a.s_l, sh = c ? 1 : 0, ush = c ? 1 : 2, usz = c ? 2 : 4;
+                const int16_t *org = plane + (cu_y >> sh) * s + (cu_x >> sh);
+                const int n = (cw + chh) >> sh;
+                const int corner_pre = avail_ul ? ld1(org - s - 1) : mid;
+                const int corner = avail_ul ? corner_pre : ((avail_up & 1) ? ld1(org - s) : mid);
+                for (int e = t; e < n; e += 64) {
+                    const int u = e >> ush;
+                    const uint64_t below_up = avail_up & ((1ull << u) - 1), below_le = avail_le & ((1ull << u) - 1);
+                    int v;
+                    if ((avail_up >> u) & 1) v = ld1(org - s + e);
+                    else if (below_up)       v = ld1(org - s + (63 - __clzll((long long)below_up)) * usz + usz - 1);
+                    else                     v = corner_pre;
+                    nb[c][NB_C0 + 1 + e] = (int16_t)v;
+                    if ((avail_le >> u) & 1) v = ld1(org + e * s - 1);
+                    else if (below_le)       v = ld1(org + ((63 - __clzll((long long)below_le)) * usz + usz - 1) * s - 1);
+                    else                     v = corner;
+                    nb[c][NB_C0 - 1 - e] = (int16_t)v;
+                }
+                if (t == 0) nb[c][NB_C0] = (int16_t)corner;
+            }
+        } else {
         uint32_t v_up[3], v_le[3][2], v_ul[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -187,8 +316,17 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
             for (int e = t + 128; e < n; e += 64)
                 nb[0][NB_C0 - 1 - e] = ((avail_le >> (e >> 2)) & 1) ? (DEP ? (int16_t)(ld_coherent(org + e * a.s_l - 2) >> 16) : org[e * a.s_l - 1]) : (int16_t)mid;
         }
+        }
         wave_lds_sync();
 
+        EipdPlan plan[3];
+        if (EIPD) {
+            // chroma mode -> the luma-numbered predictor (xevdm_ipred_uv :267-305): DM follows the luma mode, then BI / DC / HOR / VER
+            const int mc = mode_c == 0 ? mode_l : (mode_c == 1 ? 2 : mode_c == 2 ? 0 : mode_c == 3 ? 24 : 12);
+            plan[0] = eipd_plan(nb[0], mode_l, cw, chh, lw, lh, t);
+            plan[1] = eipd_plan(nb[1], mc, cw >> 1, chh >> 1, lw - 1, lh - 1, t);
+            plan[2] = eipd_plan(nb[2], mc, cw >> 1, chh >> 1, lw - 1, lh - 1, t);
+        } else {
         // ---- DC values (ipred_dc_b): (sum of h left + w up samples + w) >> (log2 w + 1) ----
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -204,18 +342,33 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
                 for (int e = t; e < w + h; e += 64) nb[c][NB_UR + e] = (int16_t)((nb[c][NB_C0 + 1 + e] + nb[c][NB_C0 - 1 - e]) >> 1);
             }
         }
+        }
         wave_lds_sync();
         // ---- prediction + reconstruction, one 4x4 SCU per lane and step ----
         for (int sidx = t; sidx < nscu; sidx += 64) {
             const int lx = (sidx % scuw) << 2, ly = (sidx / scuw) << 2;
             const int x = cu_x + lx, y = cu_y + ly;
             if (sidx != t) fetch_resid(lx, ly);                      // later rounds of a CU above 32x32
+            int pl[4][4], pc[2][2][2];
+            if (EIPD) {
+                const int maxc = (1 << a.bd_c) - 1;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) pl[r][q] = eipd_sample(nb[0], plan[0], lx + q, ly + r, cw, chh, lw, lh, maxv);
+#pragma unroll
+                for (int c = 0; c < 2; c++)
+#pragma unroll
+                    for (int r = 0; r < 2; r++)
+#pragma unroll
+                        for (int q = 0; q < 2; q++)
+                            pc[c][r][q] = eipd_sample(nb[1 + c], plan[1 + c], (lx >> 1) + q, (ly >> 1) + r, cw >> 1, chh >> 1, lw - 1, lh - 1, maxc);
+            } else {
             // all LDS reads of the SCU first (one wait), then the arithmetic, then the stores
             int vl[7], vc[2][3];
             nb_fetch<7>(nb[0], mode_l, lx, ly, vl);
             nb_fetch<3>(nb[1], mode_c, lx >> 1, ly >> 1, vc[0]);
             nb_fetch<3>(nb[2], mode_c, lx >> 1, ly >> 1, vc[1]);
-            int pl[4][4], pc[2][2][2];
 #pragma unroll
             for (int md = 0; md < 5; md++) {                         // uniform: one of the five register shuffles runs
                 if (md == mode_l)
@@ -230,6 +383,7 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
                         for (int r = 0; r < 2; r++)
 #pragma unroll
                             for (int q = 0; q < 2; q++) pc[c][r][q] = vc[c][nb_sel(md, r, q, 1)];
+            }
             }
             int16_t *dy = a.cur_y + y * a.s_l + x;
             uint32_t ol[4][2], oc[2][2];
@@ -269,6 +423,11 @@ void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep)
 {
     const int per = dep ? INTRA_CHUNK : INTRA_WAVES;
     const int blocks = (a.count + per - 1) / per;
-    if (dep) hipLaunchKernelGGL(k_intra<true>, dim3(blocks), dim3(64 * INTRA_WAVES), 0, c->stream, a);
-    else     hipLaunchKernelGGL(k_intra<false>, dim3(blocks), dim3(64 * INTRA_WAVES), 0, c->stream, a);
+    if (c->sp.tool_eipd) {
+        if (dep) hipLaunchKernelGGL((k_intra<true, true>), dim3(blocks), dim3(64 * INTRA_WAVES), 0, c->stream, a);
+        else     hipLaunchKernelGGL((k_intra<false, true>), dim3(blocks), dim3(64 * INTRA_WAVES), 0, c->stream, a);
+    } else {
+        if (dep) hipLaunchKernelGGL((k_intra<true, false>), dim3(blocks), dim3(64 * INTRA_WAVES), 0, c->stream, a);
+        else     hipLaunchKernelGGL((k_intra<false, false>), dim3(blocks), dim3(64 * INTRA_WAVES), 0, c->stream, a);
+    }
 }

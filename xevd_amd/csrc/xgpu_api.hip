@@ -399,7 +399,8 @@ static void build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         const int wu = (1 << b->log2w[i]) >> 2, hu = (1 << b->log2h[i]) >> 2;
         bool need_ul = false;
         int need_up = 0, need_le = 0;                                                      // number of leading units read on each side
-        for (int k = 0; k < 2; k++) {
+        if (c->sp.tool_eipd) { need_up = need_le = units; need_ul = true; }            // EIPD modes: planar / bilinear / angular read both whole sides
+        else for (int k = 0; k < 2; k++) {
             const int m = r.ipm[k];
             if (m == 0) { need_up = std::max(need_up, wu); need_le = std::max(need_le, hu); }
             else if (m == 1) need_le = std::max(need_le, hu);
@@ -681,7 +682,7 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
     if (db->n_intra) {
         // intra CUs: level 1 as a plain launch, all deeper levels as one data-flow launch (k_intra.hip)
         IntraArgs ta;
-        ta.cur_y = cur.y; ta.cur_u = cur.u; ta.cur_v = cur.v; ta.s_l = c->s_l; ta.s_c = c->s_c; ta.bd_l = c->sp.bit_depth_luma;
+        ta.cur_y = cur.y; ta.cur_u = cur.u; ta.cur_v = cur.v; ta.s_l = c->s_l; ta.s_c = c->s_c; ta.bd_l = c->sp.bit_depth_luma; ta.bd_c = c->sp.bit_depth_chroma;
         ta.cus = db->d_cus; ta.list = db->d_intra; ta.deps = db->d_intra_deps; ta.resid = db->d_resid;
         ta.done = db->d_intra_done; ta.n_intra = db->n_intra;
         ta.epoch = ++db->intra_epoch;                      // flags are compared against the epoch: no reset between pictures

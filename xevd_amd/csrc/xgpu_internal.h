@@ -113,7 +113,7 @@ static_assert(sizeof(IntraRec) == 48, "IntraRec must be 48 bytes");
 struct IntraArgs {
     int16_t *cur_y, *cur_u, *cur_v;
     int      s_l, s_c;
-    int      bd_l;
+    int      bd_l, bd_c;
     const CuRec    *cus;
     const IntraRec *list;
     const uint32_t *deps;

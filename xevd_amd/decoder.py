@@ -17,10 +17,10 @@ class XgpuError(RuntimeError):
 
 class XgpuDecoder:
     def __init__(self, width, height, bit_depth=8, device=0, log2_ctu=6, iqt=0, admvp=0, addb=0, alf=0, max_pics=6,
-                 bit_depth_chroma=None, chroma_qp_tables=None):
+                 bit_depth_chroma=None, chroma_qp_tables=None, eipd=0):
         self.lib = abi.load()
         self.sp = abi.make_seq_params(width, height, bit_depth, log2_ctu, device, iqt, admvp, addb, alf, max_pics,
-                                      bit_depth_chroma)
+                                      bit_depth_chroma, eipd)
         self._tables = None
         if chroma_qp_tables is not None:
             self._tables = [np.ascontiguousarray(t, np.int8) for t in chroma_qp_tables]

@@ -135,7 +135,7 @@ def gen_partition_btt(rng, width, height, log2_ctu=6, split_prob=0.5, btt_frac=0
 
 def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_frac=0.0, coded_frac=0.6,
               n_refs=(1, 0), qp_range=(22, 37), mv_sigma_px=8.0, oob_frac=0.05, split_prob=0.5,
-              chroma_qp_table=None, max_level=24, amp=2.0, ats_frac=0.0, ats_inter_frac=0.0, btt_frac=0.0, min_log2=2):
+              chroma_qp_table=None, max_level=24, amp=2.0, ats_frac=0.0, ats_inter_frac=0.0, btt_frac=0.0, min_log2=2, eipd=False):
     """One picture's CU batch as a dict of numpy arrays (layout of xgpu_cu_batch, include/xevd_hip.h)."""
     if btt_frac > 0:
         x, y, l2w, l2h, start = gen_partition_btt(rng, width, height, log2_ctu, split_prob, btt_frac)
@@ -283,6 +283,9 @@ def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_fr
     ipm[:, 0] = rng.integers(0, 5, n)
     # the Baseline syntax has no chroma mode of its own (core->ipm[1] = luma mode, xevd_eco.c:1154); a few CUs differ anyway
     ipm[:, 1] = np.where(rng.random(n) < 0.8, ipm[:, 0], rng.integers(0, 5, n))
+    if eipd:      # sps->tool_eipd: 33 luma modes (DC, planar, bilinear, angular), chroma DM / BI / DC / HOR / VER
+        ipm[:, 0] = np.where(rng.random(n) < 0.25, rng.integers(0, 3, n), rng.integers(0, 33, n))
+        ipm[:, 1] = rng.integers(0, 5, n)
     return {
         "x": x, "y": y, "log2w": l2w, "log2h": l2h, "pred_mode": pred_mode, "refi": refi, "mv": mv, "qp": qp,
         "cbf": cbf, "cbf_sub": cbf_sub if big.any() else None, "ats": ats, "ats_inter": ats_inter, "ipm": ipm, "coef_off": coef_off.astype(np.uint32), "coef": coef[:max(n_coef, 1)],
