@@ -14,6 +14,7 @@
  *
  * Scope: Baseline profile, and Main-profile streams that switch on only tools of the back half - sps->tool_iqt, tool_ats,
  * tool_addb (syntax of src_main/xevdm_eco.c: SPS :1847-2004, slice header :2510-2800, ATS flags :128-190,354-393,902-934) -
+ * tool_eipd (intra mode syntax src_base/xevd_eco.c:842-910, most-probable-mode lists src_main/xevdm_ipred.c:320-767)
  * and tool_alf (APS NAL units :2082-2135,2376-2477, coefficient syntax :2154-2318, slice-level parameters :2479-2657, per-CTU flags
  * src_main/xevdm.c:2411-2418; coefficient reconstruction alf_recon_coef src_main/xevdm_alf.c:700-794; fixed filter sets are not
  * supported yet) - with every other Main tool off (the CU syntax is then the Baseline one); 4:2:0, one tile and one slice per picture,
@@ -52,6 +53,7 @@ typedef struct xhost_picture {
     int tool_iqt, tool_ats, tool_addb;     /* sps->tool_* flags that change arithmetic on the GPU path                      */
     int deblock_alpha_offset, deblock_beta_offset;      /* sh.sh_deblock_alpha/beta_offset (ADDB)                          */
     int tool_alf;
+    int tool_eipd;                         /* sps->tool_eipd: batch.ipm holds Main mode numbers, xgpu_seq_params.tool_eipd must be set      */
     int alf_on;                            /* sh.alf_on: `alf` below is what xgpu_alf takes (final coefficients, CTB flags)      */
     xgpu_alf_params alf;
     int has_md5;                           /* a picture-signature SEI follows the slice: MD5 of every plane's 16-bit samples    */
@@ -80,6 +82,8 @@ typedef struct xhost_stream_params {
     int tool_iqt, tool_ats, tool_addb;     /* sps->tool_iqt / tool_ats (needs iqt) / tool_addb                       */
     int deblock_alpha_offset, deblock_beta_offset;      /* slice-level ADDB offsets                                   */
     int tool_alf;                          /* sps->tool_alf                                                          */
+    int tool_eipd;                         /* sps->tool_eipd: ipm[0] = luma mode 0..32, ipm[1] = chroma mode 0..4 (a chroma mode equal to what DM
+                                              stands for is written as DM)                                            */
 } xhost_stream_params;
 
 /* ALF parameter set as it is coded in an APS NAL unit (XEVD_ALF_SLICE_PARAM after xevdm_eco_alf_aps_param), no fixed filters */

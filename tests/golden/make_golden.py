@@ -153,6 +153,8 @@ def golden_streams(only=()):
                                 "main_alf_addb_8b": (264, 136, 6, dict(main=True, alf=True, addb=True)),
                                 # every picture followed by a picture-signature SEI (MD5s of the oracle's reconstruction, VERIFIED by the
                                 # reference decoder while it produced the pictures below)
+                                "main_eipd_i_8b": (136, 120, 2, dict(main=True, eipd=True, idr_period=1, split_prob=0.7)),
+                                "main_eipd_all_tools_10b": (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, inter_frac=0.5, log2_sub_gop=2, max_refs=2, bit_depth=10)),
                                 "signed_hier_b_8b": (136, 120, 5, dict(log2_sub_gop=2, max_refs=2, sign=True)),
                                 "signed_main_alf_10b": (136, 72, 4, dict(main=True, iqt=True, addb=True, alf=True, bit_depth=10, sign=True))}.items():
         if only and name not in only:

@@ -25,13 +25,13 @@ def gop_tids(log2_sub_gop):
 
 def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_frac=0.15, inter_frac=0.85, deblock=True, qp_offsets=(0, 0),
                 cu_qp_delta=True, split_prob=0.5, idr_period=0, log2_sub_gop=0, bi_frac=0.5, direct_frac=0.1,
-                main=False, iqt=False, ats=False, addb=False, addb_offsets=(0, 0), alf=False, sign=False):
+                main=False, iqt=False, ats=False, addb=False, addb_offsets=(0, 0), alf=False, sign=False, eipd=False):
     """-> bytes.  Picture 0 is an IDR.  log2_sub_gop = 0: IPPP; n: hierarchical sub-GOPs of 2^n pictures, the layer-0 picture of
     each a P picture, the others B pictures (bi-prediction, temporal direct and two-list skip CUs).
     sign: every picture is followed by a picture-signature SEI with the MD5s of the ORACLE's reconstruction of the stream so far."""
     rng = np.random.default_rng(seed)
     w = stream.StreamWriter(width, height, bit_depth, max_refs, qp_offsets[0], qp_offsets[1], deblock, cu_qp_delta, log2_sub_gop,
-                            main=main, iqt=iqt, ats=ats, addb=addb, alpha_off=addb_offsets[0], beta_off=addb_offsets[1], alf=alf)
+                            main=main, iqt=iqt, ats=ats, addb=addb, alpha_off=addb_offsets[0], beta_off=addb_offsets[1], alf=alf, eipd=eipd)
     n_ctu = ((width + 63) // 64) * ((height + 63) // 64)
     tids = gop_tids(log2_sub_gop)
     try:
@@ -44,7 +44,7 @@ def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_fra
             is_b = (not idr) and tid > 0
             b = synth.gen_frame(rng, width, height, bit_depth, inter_frac=0.0 if idr else inter_frac, n_refs=(max_refs, max_refs if is_b else 0),
                                 bi_frac=bi_frac if is_b else 0.0, split_prob=split_prob, coded_frac=0.6, max_level=6, amp=1.0,
-                                ats_frac=0.5 if ats else 0.0, ats_inter_frac=0.5 if ats else 0.0)
+                                ats_frac=0.5 if ats else 0.0, ats_inter_frac=0.5 if ats else 0.0, eipd=eipd)
             if not idr:
                 inter = b["pred_mode"] == 1
                 r = rng.random(len(inter))
@@ -116,7 +116,7 @@ def decode_oracle(data, order="output"):
     dpb, out = {}, []
     for p in stream.parse_stream(data):
         w, h, bd = p["width"], p["height"], p["bit_depth"]
-        sp = abi.make_seq_params(w, h, bd, iqt=p["iqt"], addb=p["addb"], alf=p["tool_alf"])
+        sp = abi.make_seq_params(w, h, bd, iqt=p["iqt"], addb=p["addb"], alf=p["tool_alf"], eipd=p["eipd"])
         cb, keep = abi.make_cu_batch(p["batch"])
         cur = ol.Picture(w, h, p["poc"])
         refs = {(i, l): dpb[poc] for l in range(2) for i, poc in enumerate(p["refs"][l])}

@@ -39,6 +39,10 @@ CONFIGS = [
     (136, 72, 4, dict(main=True, alf=True)),
     (264, 136, 11, dict(main=True, alf=True, addb=True)),
     (144, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, log2_sub_gop=2, max_refs=2, bit_depth=10)),
+    # ... and EIPD: 33 luma / 5 chroma intra modes with their most-probable-mode syntax, all-intra and mixed pictures
+    (136, 72, 2, dict(main=True, eipd=True, idr_period=1, split_prob=0.8)),
+    (200, 136, 5, dict(main=True, eipd=True, inter_frac=0.4, max_refs=2)),
+    (144, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, inter_frac=0.5, log2_sub_gop=2, max_refs=2, bit_depth=10)),
 ]
 
 
@@ -55,6 +59,10 @@ def test_stream_reference_decoder_equals_parser_plus_oracle(cfg):
     if kw.get("ats"):      # the stream really carries both kinds of ATS CUs
         pics = stream.parse_stream(data)
         assert sum(int((p["batch"]["ats"] & 1).sum()) for p in pics) > 0 and sum(int((p["batch"]["ats_inter"] != 0).sum()) for p in pics) > 0
+    if kw.get("eipd"):     # angular luma modes and all five chroma modes occur
+        pics = stream.parse_stream(data)
+        intra = np.concatenate([p["batch"]["ipm"][p["batch"]["pred_mode"] == 0] for p in pics])
+        assert len(set(intra[:, 0].tolist())) > 20 and set(intra[:, 1].tolist()) == {0, 1, 2, 3, 4}
     for k in range(n):
         for c in range(3):
             assert np.array_equal(ref[k][c], ours[k][c]), f"picture {k} plane {c}: {np.argwhere(ref[k][c] != ours[k][c])[:4]}"

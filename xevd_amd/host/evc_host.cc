@@ -160,11 +160,26 @@ template <class C> static int sym_abs_mvd(C &c, int v, Model &m)      // xevd_ec
     return val;
 }
 
+template <class C> static int sym_unary_ep(C &c, int v, int max_val)                 // sbac_read_unary_sym_ep, xevd_eco.c:166-189
+{
+    if (!c.ep(v > 0)) return 0;
+    int sym = 0, counter = 1, t;
+    do { t = counter == max_val ? 0 : c.ep(v > sym + 1); counter++; sym++; } while (t);
+    return sym;
+}
+template <class C> static int sym_bits_ep(C &c, int v, int n)                         // sbac_decode_bins_ep: most significant bin first
+{
+    int r = 0;
+    for (int i = n - 1; i >= 0; i--) r = (r << 1) | c.ep((v >> i) & 1);
+    return r;
+}
+
 struct Models {
     Model split[1], run[24], last[2], level[24], cbf_luma[1], cbf_cb[1], cbf_cr[1], cbf_all[1], pred_mode[3], direct[1], inter_dir[2],
           intra_dir[2], mvp_idx[3], mvd[1], refi[2], dqp[1], skip[2],
           ats_mode[1], ats_inter_flag[2], ats_inter_quad[1], ats_inter_hor[3], ats_inter_pos[1],      // Main: xevd_def.h:559-563
-          alf_ctb[1];
+          alf_ctb[1],
+          ipm_mpm_flag[1], ipm_mpm_idx[1], ipm_chroma[1];                                            // tool_eipd: xevd_def.h intra_luma_pred_mpm_flag / _idx, intra_chroma_pred_mode
     void reset() { Model *p = (Model *)this; for (size_t i = 0; i < sizeof(Models) / sizeof(Model); i++) p[i] = 512; }     // PROB_INIT, xevd_eco.c:769-803
 };
 
@@ -201,7 +216,7 @@ enum { MODE_INTRA = XGPU_MODE_INTRA, MODE_INTER = XGPU_MODE_INTER, MODE_SKIP = X
 
 // ------------------------------------------------------------------------------------------------ stream / picture state
 struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, log2_ref_gap = 0, max_num_ref_pics = 1;
-             int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0, tool_alf = 0; };
+             int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0, tool_alf = 0, tool_eipd = 0; };
 struct Pps { int constrained_intra = 0, cu_qp_delta = 0; };
 struct Slice { int type = XHOST_SLICE_I, qp = 32, qp_u_offset = 0, qp_v_offset = 0, deblock = 1, alpha_off = 0, beta_off = 0;
                int alf_on = 0, aps_id_y = 0, aps_id_ch = 0, alf_chroma_idc = 0, alf_ctb_map = 0; };
@@ -251,7 +266,7 @@ struct Cu {
     int direct;                      // B slices: temporal direct mode (inter_dir = PRED_DIR), no motion syntax
     int refi[2], mvp_idx[2];
     int16_t mvd[2][2], mv[2][2];
-    int ipm, cbf[3], qp;
+    int ipm, ipm_c, cbf[3], qp;       // ipm_c: chroma mode with tool_eipd (DM 0, BI 1, DC 2, HOR 3, VER 4)
     int ats;                         // bit 0 ats_intra_cu, bit 1 ats_intra_mode_v, bit 2 ats_intra_mode_h (layout of xgpu_cu_batch.ats)
     int ats_inter;                   // ats_inter_info: idx | pos << 4
 };
@@ -487,6 +502,55 @@ struct Stream {          // everything both directions share
         if (ys > 0 && pic.intra[scup - ws] && pic.cod[scup - ws]) u = pic.ipm[scup - ws] + 1;
         return k_mpm[l][u];
     }
+    // tool_eipd: the two most probable modes, eight "extended" ones and the ordering of all 33 (xevdm_get_mpm, src_main/xevdm_ipred.c:
+    // 320-767) for a CU whose right-hand neighbour is not coded yet - always the case without SUCO, which this front end rejects.
+    void eipd_mpm(const Cu &cu, int mpm[2], int ext[8], int pims[33]) const
+    {
+        enum { DC = 0, PLN = 1, BI = 2, VER = 12, HOR = 24, DIA_R = 18, DIA_L = 6, DIA_U = 30, CNT = 33 };
+        const int xs = cu.x >> 2, ys = cu.y >> 2, ws = pic.w_scu, scup = ys * ws + xs;
+        int l = DC, u = DC;
+        if (xs > 0 && pic.intra[scup - 1] && pic.cod[scup - 1]) l = pic.ipm[scup - 1];
+        if (ys > 0 && pic.intra[scup - ws] && pic.cod[scup - ws]) u = pic.ipm[scup - ws];
+        mpm[0] = std::min(l, u); mpm[1] = std::max(l, u);
+        if (mpm[0] == mpm[1]) { mpm[0] = DC; mpm[1] = mpm[1] == DC ? BI : mpm[1]; }
+        const int m0 = mpm[0], m1 = mpm[1];
+        if (m1 < 3) {                                         // two non-angular modes: the third one, then the main directions
+            const int e[8] = { m0 == DC ? (m1 == BI ? PLN : BI) : DC, VER, HOR, DIA_R, DIA_L, DIA_U, VER + 4, HOR - 4 };
+            memcpy(ext, e, sizeof(e));
+        } else if (m0 < 3) {                                  // one angular mode: the other non-angular ones, then its neighbourhood
+            ext[0] = m0 == PLN ? BI : (m0 == BI ? DC : BI);
+            ext[1] = m0 == PLN ? DC : PLN;
+            if (m1 > CNT - 3)  { const int e[6] = { m1 == CNT - 1 ? CNT - 2 : CNT - 1, CNT - 3, CNT - 4, CNT - 5, HOR, DIA_R }; memcpy(ext + 2, e, sizeof(e)); }
+            else if (m1 < 5)   { const int e[6] = { m1 == 3 ? 4 : 3, 5, 6, 7, VER, DIA_R }; memcpy(ext + 2, e, sizeof(e)); }
+            else {
+                ext[2] = m1 + 2; ext[3] = m1 - 2; ext[4] = m1 + 1; ext[5] = m1 - 1;
+                if (m1 <= 23 && m1 >= 13) { ext[6] = m1 - 5; ext[7] = m1 + 5; }
+                else { ext[6] = m1 > 23 ? m1 - 5 : m1 + 5; ext[7] = m1 > 23 ? m1 - 10 : m1 + 10; }
+            }
+        } else {                                              // two angular modes: their neighbours and means, then the main directions
+            int list[15] = { (m0 == 3 || m0 == 4) ? m0 + 1 : m0 - 2, m0 == CNT - 2 ? m0 - 1 : m0 + 2, m1 == 4 ? m1 + 1 : m1 - 2,
+                             (m1 == CNT - 1 || m1 == CNT - 2) ? m1 - 1 : m1 + 2, (m0 + m1 + 1) >> 1, 0, 0,
+                             VER, HOR, DIA_R, PLN, DIA_L, DIA_U, VER + 4, HOR - 4 };
+            list[5] = (list[4] + m0 + 1) >> 1; list[6] = (list[4] + m1 + 1) >> 1;
+            ext[0] = BI; ext[1] = DC;
+            int n = 2;
+            for (int i = 0; i < 15 && n < 8; i++) {
+                bool dup = list[i] == m0 || list[i] == m1;
+                for (int j = 0; j < n && !dup; j++) dup = list[i] == ext[j];
+                if (!dup) ext[n++] = list[i];
+            }
+        }
+        // the order of all modes: the two, the eight, then a fixed list (intra_mode_list, xevdm_ipred.c:307-318), duplicates dropped
+        static const int k_default[33] = { DC, BI, VER, PLN, HOR, VER - 1, VER + 1, VER - 2, VER + 2, VER - 3, VER + 3, HOR - 1, HOR + 1, HOR - 2, HOR + 2,
+                                           HOR - 3, HOR + 3, DIA_R, DIA_L, DIA_L - 3, DIA_L - 2, DIA_L - 1, DIA_U, DIA_U + 1, DIA_U + 2, VER + 5, VER + 4,
+                                           HOR - 4, HOR - 5, VER - 5, VER - 4, HOR + 5, HOR + 4 };
+        bool in[33] = { false };
+        int n = 0;
+        auto add = [&](int m) { if (m >= 0 && m < 33 && !in[m]) { in[m] = true; pims[n++] = m; } };
+        add(m0); add(m1);
+        for (int i = 0; i < 8; i++) add(ext[i]);
+        for (int i = 0; i < 33; i++) add(k_default[i]);
+    }
     void chroma_qps(int qp, int &qp_u, int &qp_v) const      // xevd_eco.c:663-666
     {
         const int off = 6 * (sps.bd_c - 8);
@@ -543,7 +607,7 @@ struct Stream {          // everything both directions share
         int skip = 0;
         if (inter_slice) skip = c.bin(cu.mode == MODE_SKIP, models.skip[0]);
         if (!enc) { cu.mode = skip ? MODE_SKIP : MODE_INTRA; cu.refi[0] = cu.refi[1] = -1; memset(cu.mv, 0, sizeof(cu.mv)); memset(cu.mvd, 0, sizeof(cu.mvd));
-                    cu.mvp_idx[0] = cu.mvp_idx[1] = 0; cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0; cu.ipm = 0; cu.ats = cu.ats_inter = 0; }
+                    cu.mvp_idx[0] = cu.mvp_idx[1] = 0; cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0; cu.ipm = cu.ipm_c = 0; cu.ats = cu.ats_inter = 0; }
         int16_t cand[4][2];
         const int n_lists = sh.type == XHOST_SLICE_B ? 2 : 1;
         if (skip) {
@@ -603,6 +667,37 @@ struct Stream {          // everything both directions share
                     }
                     cu.mv[l][0] = (int16_t)(cand[cu.mvp_idx[l]][0] + cu.mvd[l][0]); cu.mv[l][1] = (int16_t)(cand[cu.mvp_idx[l]][1] + cu.mvd[l][1]);
                 }
+            }
+        } else if (sps.tool_eipd) {
+            // xevd_eco_intra_dir (xevd_eco.c:842-879): one of the 2 most probable modes, one of the 8 extended ones (bypass), or the index
+            // among the remaining 23 in truncated binary (4 or 5 bypass bins)
+            int mpm[2], ext[8], pims[33];
+            eipd_mpm(cu, mpm, ext, pims);
+            int pos = 0;
+            while (enc && pos < 33 && pims[pos] != cu.ipm) pos++;
+            const int in_mpm = enc ? (cu.ipm == mpm[0] || cu.ipm == mpm[1]) : 0;
+            if (c.bin(in_mpm, models.ipm_mpm_flag[0])) {
+                cu.ipm = mpm[c.bin(cu.ipm == mpm[1], models.ipm_mpm_idx[0])];
+            } else {
+                int ei = 0;
+                while (enc && ei < 8 && ext[ei] != cu.ipm) ei++;
+                if (c.ep(enc ? ei < 8 : 0)) {
+                    cu.ipm = ext[sym_bits_ep(c, ei & 7, 3)];
+                } else {
+                    const int rem = pos - 10;                        // 23 symbols: 9 with 4 bins, 14 with 5
+                    int v = sym_bits_ep(c, rem < 9 ? rem : (rem + 9) >> 1, 4);
+                    if (v >= 9) v = ((v << 1) | c.ep((rem + 9) & 1)) - 9;
+                    cu.ipm = pims[10 + std::min(v, 22)];
+                }
+            }
+            // xevd_eco_intra_dir_c (:881-910): DM, or one of the other modes - the one DM stands for (a luma DC / BI / HOR / VER) is skipped
+            const int lc = cu.ipm == 12 ? 4 : cu.ipm == 24 ? 3 : cu.ipm == 0 ? 2 : cu.ipm == 2 ? 1 : 0;
+            if (enc && lc && cu.ipm_c == lc) cu.ipm_c = 0;
+            if (c.bin(cu.ipm_c == 0, models.ipm_chroma[0])) cu.ipm_c = 0;
+            else {
+                int v = sym_unary_ep(c, (lc && cu.ipm_c > lc ? cu.ipm_c - 1 : cu.ipm_c) - 1, 4) + 1;
+                if (lc && v >= lc) v++;
+                cu.ipm_c = std::min(v, 4);
             }
         } else {
             const uint8_t *mpm = mpm_list(cu);                       // xevd_eco_intra_dir_b, xevd_eco.c:826-846: the code number is sent
@@ -724,14 +819,15 @@ struct xhost_parser {
         s.width = (int)br.ue(); s.height = (int)br.ue();
         s.bd_l = (int)br.ue() + 8; s.bd_c = (int)br.ue() + 8;
         int unsupported = 0, rpl = 0, pocs = 0;
-        s.tool_iqt = s.tool_ats = s.tool_addb = s.tool_alf = 0;
+        s.tool_iqt = s.tool_ats = s.tool_addb = s.tool_alf = s.tool_eipd = 0;
         if (!s.profile_main) {
             for (int i = 0; i < 13; i++) { const int f = br.get1(); if (i != 11) unsupported |= f; }      // btt suco admvp eipd cm_init iqt addb alf htdf rpl pocs dquant dra
         } else {                                          // xevdm_eco_sps, xevdm_eco.c:1863-1937: sub-flags follow their tool flag
             unsupported |= br.get1();                    // sps_btt_flag
             unsupported |= br.get1();                    // sps_suco_flag
             unsupported |= br.get1();                    // tool_admvp
-            unsupported |= br.get1();                    // tool_eipd
+            s.tool_eipd = br.get1();
+            if (s.tool_eipd) unsupported |= br.get1();   // ibc_flag
             unsupported |= br.get1();                    // tool_cm_init
             s.tool_iqt = br.get1();
             if (s.tool_iqt) s.tool_ats = br.get1();
@@ -743,7 +839,7 @@ struct xhost_parser {
             br.get1();                                   // dquant_flag (only matters with cu_qp_delta_area handling; plain dqp otherwise)
             unsupported |= br.get1();                    // tool_dra
         }
-        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, admvp, eipd, cm_init, htdf, rpl, pocs, dra)");
+        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, admvp, ibc, cm_init, htdf, rpl, pocs, dra)");
         s.log2_sub_gop = (int)br.ue();                   // tool_rpl = tool_pocs = 0
         if (s.log2_sub_gop == 0) s.log2_ref_gap = (int)br.ue();
         if (s.log2_sub_gop > 5) return fail("bad SPS");
@@ -832,7 +928,7 @@ struct xhost_parser {
         out->slice_qp = sh.qp; out->qp_u_offset = sh.qp_u_offset; out->qp_v_offset = sh.qp_v_offset; out->deblock_on = sh.deblock;
         out->profile_main = st.sps.profile_main; out->tool_iqt = st.sps.tool_iqt; out->tool_ats = st.sps.tool_ats; out->tool_addb = st.sps.tool_addb;
         out->deblock_alpha_offset = sh.alpha_off; out->deblock_beta_offset = sh.beta_off;
-        out->tool_alf = st.sps.tool_alf; out->alf_on = sh.alf_on;
+        out->tool_alf = st.sps.tool_alf; out->alf_on = sh.alf_on; out->tool_eipd = st.sps.tool_eipd;
         if (sh.alf_on) {
             if (!st.alf_finalise()) return fail("slice refers to an ALF parameter set that was not sent");
             out->alf.enable[0] = 1; out->alf.enable[1] = sh.alf_chroma_idc & 1; out->alf.enable[2] = (sh.alf_chroma_idc >> 1) & 1;
@@ -892,7 +988,7 @@ struct xhost_parser {
         st.chroma_qps(cu.qp, qp_u, qp_v);
         batch.qp.push_back((uint8_t)(cu.qp + 6 * (st.sps.bd_l - 8))); batch.qp.push_back((uint8_t)qp_u); batch.qp.push_back((uint8_t)qp_v);
         batch.cbf.push_back((uint8_t)(cu.cbf[0] | (cu.cbf[1] << 1) | (cu.cbf[2] << 2)));
-        batch.ipm.push_back((uint8_t)cu.ipm); batch.ipm.push_back((uint8_t)cu.ipm);            // chroma mode = luma mode, xevd_eco.c:1154
+        batch.ipm.push_back((uint8_t)cu.ipm); batch.ipm.push_back((uint8_t)(st.sps.tool_eipd ? cu.ipm_c : cu.ipm));      // Baseline: chroma mode = luma mode, xevd_eco.c:1154
         batch.ats.push_back((uint8_t)cu.ats); batch.ats_inter.push_back((uint8_t)cu.ats_inter);
         batch.coef_off.push_back((uint32_t)n_coef);
         const int tu_shift = (cu.ats_inter & 15) == 0 ? 0 : (((cu.ats_inter & 15) >= 3) ? 2 : 1);      // the TU is 1/2 or 1/4 of the CU
@@ -970,7 +1066,10 @@ struct xhost_writer {
         bw.ue((uint32_t)(sp.bit_depth - 8)); bw.ue((uint32_t)(sp.bit_depth - 8));
         if (!sp.profile_main) for (int i = 0; i < 13; i++) bw.put1(i == 11 ? (sp.cu_qp_delta ? 1 : 0) : 0);       // all tools off; dquant_flag with cu_qp_delta
         else {
-            for (int i = 0; i < 5; i++) bw.put1(0);      // btt suco admvp eipd cm_init
+            for (int i = 0; i < 3; i++) bw.put1(0);      // btt suco admvp
+            bw.put1(sp.tool_eipd ? 1 : 0);
+            if (sp.tool_eipd) bw.put1(0);                // ibc_flag
+            bw.put1(0);                                  // cm_init
             bw.put1(sp.tool_iqt ? 1 : 0);
             if (sp.tool_iqt) bw.put1(sp.tool_ats ? 1 : 0);
             bw.put1(sp.tool_addb ? 1 : 0);
@@ -1009,7 +1108,8 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     s.profile_main = sp->profile_main ? 1 : 0;
     s.tool_iqt = s.profile_main && sp->tool_iqt; s.tool_ats = s.tool_iqt && sp->tool_ats; s.tool_addb = s.profile_main && sp->tool_addb;
     s.tool_alf = s.profile_main && sp->tool_alf;
-    w->sp.tool_iqt = s.tool_iqt; w->sp.tool_ats = s.tool_ats; w->sp.tool_addb = s.tool_addb; w->sp.tool_alf = s.tool_alf;
+    s.tool_eipd = s.profile_main && sp->tool_eipd;
+    w->sp.tool_iqt = s.tool_iqt; w->sp.tool_ats = s.tool_ats; w->sp.tool_addb = s.tool_addb; w->sp.tool_alf = s.tool_alf; w->sp.tool_eipd = s.tool_eipd;
     w->st.pps.cu_qp_delta = sp->cu_qp_delta;
     return w;
 }
@@ -1108,7 +1208,8 @@ struct TreeWriter {
         if (cu.mode == MODE_INTER && cu.refi[0] < 0 && cu.refi[1] < 0) cu.refi[0] = 0;
         if (st.sh.type == XHOST_SLICE_P) { cu.refi[1] = -1; if (cu.refi[0] < 0) cu.refi[0] = 0; }
         cu.mvp_idx[0] = (x >> 2) & 3; cu.mvp_idx[1] = (y >> 2) & 3;   // a SKIP CU: some predictor per list
-        cu.ipm = b->ipm ? b->ipm[i * 2] % 5 : 0;
+        cu.ipm = b->ipm ? b->ipm[i * 2] % (st.sps.tool_eipd ? 33 : 5) : 0;
+        cu.ipm_c = (b->ipm && st.sps.tool_eipd) ? b->ipm[i * 2 + 1] % 5 : 0;
         cu.qp = std::min(std::max((int)b->qp[i * 3] - bd_off, 0), 51);
         for (int k = 0; k < 3; k++) cu.cbf[k] = cu.mode == MODE_SKIP ? 0 : (b->cbf[i] >> k) & 1;
         cu.ats = (st.sps.tool_ats && b->ats && cu.mode == MODE_INTRA) ? b->ats[i] & 7 : 0;

@@ -45,7 +45,7 @@ class StreamDecoder:
                 if isinstance(p, Exception):
                     raise p
                 if dec is None:
-                    dec = XgpuDecoder(p["width"], p["height"], p["bit_depth"], device=self.device, iqt=p["iqt"], addb=p["addb"], alf=p["tool_alf"], max_pics=12)
+                    dec = XgpuDecoder(p["width"], p["height"], p["bit_depth"], device=self.device, iqt=p["iqt"], addb=p["addb"], alf=p["tool_alf"], eipd=p["eipd"], max_pics=12)
                     free = [dec.pic_alloc() for _ in range(10)]
                 if p["is_idr"]:
                     free.extend(slots.values()); slots.clear()
