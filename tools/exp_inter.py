@@ -19,6 +19,8 @@ for name, sp, ml in cases:
     if name not in sel:
         continue
     for tag, kw in (("bi50", dict(bi_frac=0.5)), ("uni", dict(bi_frac=0.0)), ("zero_mv", dict(bi_frac=0.0, mv_sigma_px=0.0, oob_frac=0.0))):
+        if os.environ.get("EXP_TAGS") and tag not in os.environ["EXP_TAGS"].split(","):
+            continue
         b = synth.gen_frame(rng, W, H, BD, inter_frac=1.0, coded_frac=0.6, n_refs=(1, 1), split_prob=sp, min_log2=ml, **kw)
         h = dec.batch_create(b)
         def step(k):
