@@ -17,7 +17,7 @@
  * tool_eipd (intra mode syntax src_base/xevd_eco.c:842-910, most-probable-mode lists src_main/xevdm_ipred.c:320-767)
  * and tool_alf (APS NAL units :2082-2135,2376-2477, coefficient syntax :2154-2318, slice-level parameters :2479-2657, per-CTU flags
  * src_main/xevdm.c:2411-2418; coefficient reconstruction alf_recon_coef src_main/xevdm_alf.c:700-794; fixed filter sets are not
- * supported yet) - with every other Main tool off (the CU syntax is then the Baseline one); 4:2:0, one tile and one slice per picture,
+ * supported yet) - with every other Main tool off; SPS chroma QP mapping tables and cropping offsets are parsed, a VUI is skipped (the CU syntax is then the Baseline one); 4:2:0, one tile and one slice per picture,
  * I / P / B slices incl. temporal layers (hierarchical sub-GOPs).
  * Conventions as xevd_hip.h: 0 / negative XEVD_ERR_* codes, nothing throws, one object per stream.
  */
@@ -54,6 +54,8 @@ typedef struct xhost_picture {
     int deblock_alpha_offset, deblock_beta_offset;      /* sh.sh_deblock_alpha/beta_offset (ADDB)                          */
     int tool_alf;
     int tool_eipd;                         /* sps->tool_eipd: batch.ipm holds Main mode numbers, xgpu_seq_params.tool_eipd must be set      */
+    int crop[4];                           /* sps picture_crop_left / right / top / bottom_offset, what xevd_pull puts in the XEVD_IMGB      */
+    const int8_t *chroma_qp_table[2];      /* SPS chroma QP mapping tables in xgpu_seq_params.chroma_qp_table layout, NULL = sequence default */
     int alf_on;                            /* sh.alf_on: `alf` below is what xgpu_alf takes (final coefficients, CTB flags)      */
     xgpu_alf_params alf;
     int has_md5;                           /* a picture-signature SEI follows the slice: MD5 of every plane's 16-bit samples    */
@@ -84,6 +86,12 @@ typedef struct xhost_stream_params {
     int tool_alf;                          /* sps->tool_alf                                                          */
     int tool_eipd;                         /* sps->tool_eipd: ipm[0] = luma mode 0..32, ipm[1] = chroma mode 0..4 (a chroma mode equal to what DM
                                               stands for is written as DM)                                            */
+    int crop[4];                           /* picture cropping offsets left / right / top / bottom (all 0: no cropping)  */
+    /* chroma_qp_table_struct of the SPS (xevd_eco.c:1361-1376): pivot points of the chroma QP mapping */
+    int cqt_present, cqt_same, cqt_global_offset;
+    int cqt_num_points[2];                 /* 1..16 per table                                                        */
+    int cqt_delta_in[2][16];               /* delta_qp_in_val_minus1 (6 bits)                                         */
+    int cqt_delta_out[2][16];              /* delta_qp_out_val                                                       */
 } xhost_stream_params;
 
 /* ALF parameter set as it is coded in an APS NAL unit (XEVD_ALF_SLICE_PARAM after xevdm_eco_alf_aps_param), no fixed filters */

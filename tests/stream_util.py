@@ -25,13 +25,14 @@ def gop_tids(log2_sub_gop):
 
 def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_frac=0.15, inter_frac=0.85, deblock=True, qp_offsets=(0, 0),
                 cu_qp_delta=True, split_prob=0.5, idr_period=0, log2_sub_gop=0, bi_frac=0.5, direct_frac=0.1,
-                main=False, iqt=False, ats=False, addb=False, addb_offsets=(0, 0), alf=False, sign=False, eipd=False):
+                main=False, iqt=False, ats=False, addb=False, addb_offsets=(0, 0), alf=False, sign=False, eipd=False, crop=(0, 0, 0, 0),
+                chroma_qp_points=None):
     """-> bytes.  Picture 0 is an IDR.  log2_sub_gop = 0: IPPP; n: hierarchical sub-GOPs of 2^n pictures, the layer-0 picture of
     each a P picture, the others B pictures (bi-prediction, temporal direct and two-list skip CUs).
     sign: every picture is followed by a picture-signature SEI with the MD5s of the ORACLE's reconstruction of the stream so far."""
     rng = np.random.default_rng(seed)
     w = stream.StreamWriter(width, height, bit_depth, max_refs, qp_offsets[0], qp_offsets[1], deblock, cu_qp_delta, log2_sub_gop,
-                            main=main, iqt=iqt, ats=ats, addb=addb, alpha_off=addb_offsets[0], beta_off=addb_offsets[1], alf=alf, eipd=eipd)
+                            main=main, iqt=iqt, ats=ats, addb=addb, alpha_off=addb_offsets[0], beta_off=addb_offsets[1], alf=alf, eipd=eipd, crop=crop, chroma_qp_points=chroma_qp_points)
     n_ctu = ((width + 63) // 64) * ((height + 63) // 64)
     tids = gop_tids(log2_sub_gop)
     try:
@@ -117,6 +118,10 @@ def decode_oracle(data, order="output"):
     for p in stream.parse_stream(data):
         w, h, bd = p["width"], p["height"], p["bit_depth"]
         sp = abi.make_seq_params(w, h, bd, iqt=p["iqt"], addb=p["addb"], alf=p["tool_alf"], eipd=p["eipd"])
+        if p["chroma_qp_tables"] is not None:
+            keep_tables = [np.ascontiguousarray(t, np.int8) for t in p["chroma_qp_tables"]]
+            for i in range(2):
+                sp.chroma_qp_table[i] = keep_tables[i].ctypes.data_as(C.POINTER(C.c_int8))
         cb, keep = abi.make_cu_batch(p["batch"])
         cur = ol.Picture(w, h, p["poc"])
         refs = {(i, l): dpb[poc] for l in range(2) for i, poc in enumerate(p["refs"][l])}

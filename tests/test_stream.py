@@ -39,6 +39,10 @@ CONFIGS = [
     (136, 72, 4, dict(main=True, alf=True)),
     (264, 136, 11, dict(main=True, alf=True, addb=True)),
     (144, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, log2_sub_gop=2, max_refs=2, bit_depth=10)),
+    # chroma QP mapping tables in the SPS (one shared table from 16 up / two tables from the bottom of the range), with QP offsets; cropping
+    (136, 72, 4, dict(chroma_qp_points=(1, [[(4, 0), (5, -2), (9, -5), (20, -3)]]), qp_offsets=(2, -3))),
+    (144, 88, 5, dict(bit_depth=10, chroma_qp_points=(0, [[(30, 0), (10, -4), (15, -6)], [(25, 1), (6, -2), (30, -10)]]), max_refs=2, crop=(2, 4, 0, 6))),
+    (136, 72, 4, dict(main=True, iqt=True, addb=True, chroma_qp_points=(1, [[(10, -1), (12, -6)]]), qp_offsets=(-2, 1))),
     # ... and EIPD: 33 luma / 5 chroma intra modes with their most-probable-mode syntax, all-intra and mixed pictures
     (136, 72, 2, dict(main=True, eipd=True, idr_period=1, split_prob=0.8)),
     (200, 136, 5, dict(main=True, eipd=True, inter_frac=0.4, max_refs=2)),

@@ -216,7 +216,9 @@ enum { MODE_INTRA = XGPU_MODE_INTRA, MODE_INTER = XGPU_MODE_INTER, MODE_SKIP = X
 
 // ------------------------------------------------------------------------------------------------ stream / picture state
 struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, log2_ref_gap = 0, max_num_ref_pics = 1;
-             int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0, tool_alf = 0, tool_eipd = 0; };
+             int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0, tool_alf = 0, tool_eipd = 0;
+             int crop[4] = { 0, 0, 0, 0 };            // picture_crop_left / right / top / bottom_offset (xevd_eco.c:1349-1357), as xevd_pull reports them
+             bool cqt = false; int8_t cq[2][70] = { { 0 } }; };      // chroma QP mapping tables signalled in the SPS: [c][qp + 6*(bd_c-8)], qp = -6*(bd_c-8) .. 57
 struct Pps { int constrained_intra = 0, cu_qp_delta = 0; };
 struct Slice { int type = XHOST_SLICE_I, qp = 32, qp_u_offset = 0, qp_v_offset = 0, deblock = 1, alpha_off = 0, beta_off = 0;
                int alf_on = 0, aps_id_y = 0, aps_id_ch = 0, alf_chroma_idc = 0, alf_ctb_map = 0; };
@@ -555,6 +557,7 @@ struct Stream {          // everything both directions share
     {
         const int off = 6 * (sps.bd_c - 8);
         const int iu = std::min(std::max(qp + sh.qp_u_offset, -off), 57), iv = std::min(std::max(qp + sh.qp_v_offset, -off), 57);
+        if (sps.cqt) { qp_u = sps.cq[0][iu + off] + off; qp_v = sps.cq[1][iv + off] + off; return; }
         const int8_t *tbl = sps.tool_iqt ? k_chroma_qp_main : k_chroma_qp;
         qp_u = (iu >= 0 ? tbl[iu] : 0) + off;                 // entries below 0 of the default table are zero-initialised storage
         qp_v = (iv >= 0 ? tbl[iv] : 0) + off;
@@ -844,9 +847,36 @@ struct xhost_parser {
         if (s.log2_sub_gop == 0) s.log2_ref_gap = (int)br.ue();
         if (s.log2_sub_gop > 5) return fail("bad SPS");
         s.max_num_ref_pics = (int)br.ue();
-        if (br.get1()) { br.ue(); br.ue(); br.ue(); br.ue(); }      // cropping offsets (output cropping is the caller's business)
-        if (br.get1()) return fail("chroma QP tables in the SPS are not supported yet");
-        if (br.get1()) return fail("VUI is not supported yet");
+        s.crop[0] = s.crop[1] = s.crop[2] = s.crop[3] = 0;
+        if (br.get1()) for (int i = 0; i < 4; i++) s.crop[i] = (int)br.ue();      // left, right, top, bottom (handed to the caller's output stage)
+        s.cqt = br.get1() != 0;
+        if (s.cqt) {
+            // chroma_qp_table_struct (xevd_eco.c:1361-1376) -> mapping tables (xevd_derived_chroma_qp_mapping_tables, xevd_tbl.c:375-425): pivot
+            // points, linear interpolation with rounding between them, slope 1 outside, clipped to the QP range
+            const int same = br.get1(), global_offset = br.get1(), off = 6 * (s.bd_c - 8), start = global_offset ? 16 : -off;
+            for (int c = 0; c < (same ? 1 : 2); c++) {
+                const int np = (int)br.ue() + 1;
+                if (np < 1 || np > 58 + off) return fail("bad chroma QP table");
+                int din[70], qin[70], qout[70];
+                for (int j = 0; j < np; j++) {
+                    din[j] = (int)br.get(6);
+                    const int dout = br.se();
+                    qin[j] = j ? qin[j - 1] + din[j] + 1 : start + din[0];
+                    qout[j] = j ? qout[j - 1] + din[j] + 1 + dout : start + din[0] + dout;
+                    if (qin[j] < -off || qin[j] > 57 || qout[j] < -off || qout[j] > 57) return fail("bad chroma QP table");
+                }
+                int8_t *t = s.cq[c] + off;                          // t[qp], qp = -off .. 57
+                t[qin[0]] = (int8_t)qout[0];
+                for (int k = qin[0] - 1; k >= -off; k--) t[k] = (int8_t)std::min(std::max(t[k + 1] - 1, -off), 57);
+                for (int j = 0; j + 1 < np; j++) {
+                    const int den = din[j + 1] + 1, rnd = den >> 1;
+                    for (int k = qin[j] + 1, m = 1; k <= qin[j + 1]; k++, m++) t[k] = (int8_t)(t[qin[j]] + ((qout[j + 1] - qout[j]) * m + rnd) / den);
+                }
+                for (int k = qin[np - 1] + 1; k <= 57; k++) t[k] = (int8_t)std::min(std::max(t[k - 1] + 1, -off), 57);
+            }
+            if (same) memcpy(s.cq[1], s.cq[0], sizeof(s.cq[0]));
+        }
+        br.get1();      // vui_parameters_present_flag: the VUI (display metadata, xevd_eco.c:1226-1304) is the last SPS element and is not needed here
         if (br.overrun || (s.width & 7) || (s.height & 7) || s.width <= 0 || s.height <= 0) return fail("bad SPS");
         st.have_sps = true;
         return XGPU_OK;
@@ -929,6 +959,8 @@ struct xhost_parser {
         out->profile_main = st.sps.profile_main; out->tool_iqt = st.sps.tool_iqt; out->tool_ats = st.sps.tool_ats; out->tool_addb = st.sps.tool_addb;
         out->deblock_alpha_offset = sh.alpha_off; out->deblock_beta_offset = sh.beta_off;
         out->tool_alf = st.sps.tool_alf; out->alf_on = sh.alf_on; out->tool_eipd = st.sps.tool_eipd;
+        for (int i = 0; i < 4; i++) out->crop[i] = st.sps.crop[i];
+        out->chroma_qp_table[0] = st.sps.cqt ? st.sps.cq[0] : nullptr; out->chroma_qp_table[1] = st.sps.cqt ? st.sps.cq[1] : nullptr;
         if (sh.alf_on) {
             if (!st.alf_finalise()) return fail("slice refers to an ALF parameter set that was not sent");
             out->alf.enable[0] = 1; out->alf.enable[1] = sh.alf_chroma_idc & 1; out->alf.enable[2] = (sh.alf_chroma_idc >> 1) & 1;
@@ -1079,7 +1111,18 @@ struct xhost_writer {
         bw.ue((uint32_t)sp.log2_sub_gop_length);
         if (sp.log2_sub_gop_length == 0) bw.ue(0);      // log2_ref_pic_gap_length
         bw.ue((uint32_t)sp.max_num_ref_pics);
-        bw.put1(0); bw.put1(0); bw.put1(0);              // no cropping, default chroma QP table, no VUI
+        const bool crop = sp.crop[0] | sp.crop[1] | sp.crop[2] | sp.crop[3];
+        bw.put1(crop);
+        if (crop) for (int i = 0; i < 4; i++) bw.ue((uint32_t)sp.crop[i]);
+        bw.put1(sp.cqt_present ? 1 : 0);
+        if (sp.cqt_present) {
+            bw.put1(sp.cqt_same ? 1 : 0); bw.put1(sp.cqt_global_offset ? 1 : 0);
+            for (int c = 0; c < (sp.cqt_same ? 1 : 2); c++) {
+                bw.ue((uint32_t)(sp.cqt_num_points[c] - 1));
+                for (int j = 0; j < sp.cqt_num_points[c]; j++) { bw.put((uint32_t)sp.cqt_delta_in[c][j], 6); bw.se(sp.cqt_delta_out[c][j]); }
+            }
+        }
+        bw.put1(0);                                      // no VUI
         bw.align_zero();
         write_nal(out, NUT_SPS, 0, bw);
     }

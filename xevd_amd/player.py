@@ -10,10 +10,11 @@ from .decoder import XgpuDecoder
 
 
 class StreamDecoder:
-    def __init__(self, data, device=0, prefetch=2, verify_md5=False):
+    def __init__(self, data, device=0, prefetch=2, verify_md5=False, apply_crop=False):
         """verify_md5: check downloaded pictures against the stream's picture-signature SEIs (the reference's
         XEVD_CFG_SET_USE_PIC_SIGNATURE), raising on a mismatch"""
         self.data, self.device, self.prefetch, self.verify_md5 = data, device, prefetch, verify_md5
+        self.apply_crop = apply_crop      # packed output: cut the SPS conformance window (the reference application writes uncropped pictures)
 
     def _producer(self, q):
         try:
@@ -45,7 +46,8 @@ class StreamDecoder:
                 if isinstance(p, Exception):
                     raise p
                 if dec is None:
-                    dec = XgpuDecoder(p["width"], p["height"], p["bit_depth"], device=self.device, iqt=p["iqt"], addb=p["addb"], alf=p["tool_alf"], eipd=p["eipd"], max_pics=12)
+                    dec = XgpuDecoder(p["width"], p["height"], p["bit_depth"], device=self.device, iqt=p["iqt"], addb=p["addb"], alf=p["tool_alf"], eipd=p["eipd"], max_pics=12,
+                                          chroma_qp_tables=p["chroma_qp_tables"])
                     free = [dec.pic_alloc() for _ in range(10)]
                 if p["is_idr"]:
                     free.extend(slots.values()); slots.clear()
@@ -56,7 +58,7 @@ class StreamDecoder:
                                    alpha_off=p["alpha_off"], beta_off=p["beta_off"], alf=p["alf"])
                 planes = None
                 if download and output_bit_depth is not None:
-                    planes = dec.pic_output(cur, output_bit_depth)
+                    planes = dec.pic_output(cur, output_bit_depth, p["crop"] if self.apply_crop else (0, 0, 0, 0))
                 elif download:
                     planes = dec.pic_download(cur)
                     if self.verify_md5 and p["md5"] is not None and not self.signature_ok(p, planes):

@@ -17,7 +17,9 @@ class StreamParams(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth", C.c_int), ("max_num_ref_pics", C.c_int), ("log2_sub_gop_length", C.c_int),
                 ("qp_u_offset", C.c_int), ("qp_v_offset", C.c_int), ("deblock_on", C.c_int), ("cu_qp_delta", C.c_int),
                 ("profile_main", C.c_int), ("tool_iqt", C.c_int), ("tool_ats", C.c_int), ("tool_addb", C.c_int),
-                ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int), ("tool_alf", C.c_int), ("tool_eipd", C.c_int)]
+                ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int), ("tool_alf", C.c_int), ("tool_eipd", C.c_int),
+                ("crop", C.c_int * 4), ("cqt_present", C.c_int), ("cqt_same", C.c_int), ("cqt_global_offset", C.c_int),
+                ("cqt_num_points", C.c_int * 2), ("cqt_delta_in", (C.c_int * 16) * 2), ("cqt_delta_out", (C.c_int * 16) * 2)]
 
 
 class AlfAps(C.Structure):
@@ -38,7 +40,8 @@ class HostPicture(C.Structure):
                 ("slice_qp", C.c_int), ("qp_u_offset", C.c_int), ("qp_v_offset", C.c_int), ("deblock_on", C.c_int),
                 ("profile_main", C.c_int), ("tool_iqt", C.c_int), ("tool_ats", C.c_int), ("tool_addb", C.c_int),
                 ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int),
-                ("tool_alf", C.c_int), ("tool_eipd", C.c_int), ("alf_on", C.c_int), ("alf", abi.AlfParams),
+                ("tool_alf", C.c_int), ("tool_eipd", C.c_int), ("crop", C.c_int * 4), ("chroma_qp_table", C.POINTER(C.c_int8) * 2),
+                ("alf_on", C.c_int), ("alf", abi.AlfParams),
                 ("has_md5", C.c_int), ("md5", (C.c_uint8 * 16) * 3),
                 ("n_release", C.c_int), ("release_poc", C.c_int * 32), ("batch", abi.CuBatch)]
 
@@ -72,10 +75,20 @@ def load():
 
 class StreamWriter:
     def __init__(self, width, height, bit_depth=8, max_num_ref_pics=1, qp_u_offset=0, qp_v_offset=0, deblock=True, cu_qp_delta=True,
-                 log2_sub_gop=0, main=False, iqt=False, ats=False, addb=False, alpha_off=0, beta_off=0, alf=False, eipd=False):
+                 log2_sub_gop=0, main=False, iqt=False, ats=False, addb=False, alpha_off=0, beta_off=0, alf=False, eipd=False, crop=(0, 0, 0, 0),
+                 chroma_qp_points=None):
+        """chroma_qp_points: None, or (global_offset_flag, [table, ...]) with 1 (same for Cb and Cr) or 2 tables of (delta_in_minus1, delta_out) pairs"""
         self.lib = load()
         sp = StreamParams(width, height, bit_depth, max_num_ref_pics, log2_sub_gop, qp_u_offset, qp_v_offset, int(deblock), int(cu_qp_delta),
                           int(main), int(iqt), int(ats), int(addb), alpha_off, beta_off, int(alf), int(eipd))
+        for i in range(4):
+            sp.crop[i] = int(crop[i])
+        if chroma_qp_points is not None:
+            sp.cqt_present, sp.cqt_global_offset, sp.cqt_same = 1, int(chroma_qp_points[0]), int(len(chroma_qp_points[1]) == 1)
+            for c, tbl in enumerate(chroma_qp_points[1]):
+                sp.cqt_num_points[c] = len(tbl)
+                for j, (di, do) in enumerate(tbl):
+                    sp.cqt_delta_in[c][j], sp.cqt_delta_out[c][j] = int(di), int(do)
         self.h = self.lib.xhost_writer_open(C.byref(sp))
         if not self.h:
             raise ValueError("xhost_writer_open: bad stream parameters")
@@ -174,7 +187,8 @@ def iter_stream(data):
                 "refs": [[hp.refp_poc[i][l] for i in range(hp.num_refp[l])] for l in range(2)],
                 "slice_qp": hp.slice_qp, "qp_u_offset": hp.qp_u_offset, "qp_v_offset": hp.qp_v_offset, "deblock_on": bool(hp.deblock_on),
                 "main": bool(hp.profile_main), "iqt": hp.tool_iqt, "ats": hp.tool_ats, "addb": hp.tool_addb,
-                "alpha_off": hp.deblock_alpha_offset, "beta_off": hp.deblock_beta_offset, "tool_alf": hp.tool_alf, "eipd": hp.tool_eipd,
+                "alpha_off": hp.deblock_alpha_offset, "beta_off": hp.deblock_beta_offset, "tool_alf": hp.tool_alf, "eipd": hp.tool_eipd, "crop": tuple(hp.crop[i] for i in range(4)),
+                "chroma_qp_tables": None if not hp.chroma_qp_table[0] else [np.ctypeslib.as_array(hp.chroma_qp_table[c], (58 + 6 * (hp.bit_depth_chroma - 8),)).copy() for c in range(2)],
                 "alf": None if not hp.alf_on else {
                     "enable": tuple(hp.alf.enable[i] for i in range(3)), "luma_coef": _arr(hp.alf.luma_coef, 25 * 13, np.int16).reshape(25, 13),
                     "chroma_coef": _arr(hp.alf.chroma_coef, 7, np.int16), "ctb_flag": _arr(hp.alf.ctb_flag, b.n_ctu, np.uint8), "across_tiles": 0},
