@@ -232,3 +232,19 @@ def test_gpu_dra_output(name):
     mapped = ol.dra_apply(planes, luts)
     assert np.array_equal(out_crop, ol.output_convert(mapped, 10, 8, crop))
     assert np.array_equal(plain, ol.output_convert(planes, 10, 10))      # and without tables the picture is untouched
+
+
+@pytest.mark.gpu
+def test_gpu_stream_cropped_8bit_output():
+    """a stream with SPS chroma QP tables and a conformance window: player output with the crop applied and 10 -> 8 bit conversion on
+    the device == oracle pictures through the oracle's conversion"""
+    import stream_util as su
+    import oracle_lib as ol
+    from xevd_amd.player import StreamDecoder
+    d = np.load(os.path.join(golden_io.GOLDEN, "stream_cqt_crop_10b.npz"))
+    data = d["bytes"].tobytes()
+    frames = [f for _, f in StreamDecoder(data, apply_crop=True).output_order(output_bit_depth=8)]
+    assert len(frames) == int(d["n"])
+    for k, f in enumerate(frames):
+        ref = [d[f"p{k}_{c}"] for c in range(3)]
+        assert np.array_equal(f, ol.output_convert(ref, 10, 8, (2, 4, 0, 6))), f"picture {k}"
