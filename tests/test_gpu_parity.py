@@ -248,3 +248,31 @@ def test_gpu_stream_cropped_8bit_output():
     for k, f in enumerate(frames):
         ref = [d[f"p{k}_{c}"] for c in range(3)]
         assert np.array_equal(f, ol.output_convert(ref, 10, 8, (2, 4, 0, 6))), f"picture {k}"
+
+
+@pytest.mark.gpu
+def test_gpu_decoder_survives_mutated_streams():
+    """damaged streams that still parse reach the backend: every call returns (pictures or an error), the device stays usable and a
+    clean stream decodes bit-exactly afterwards"""
+    import glob
+    import stream_util as su
+    from xevd_amd.player import StreamDecoder
+    rng = np.random.default_rng(7)
+    paths = sorted(glob.glob(os.path.join(golden_io.GOLDEN, "stream_*.npz")))
+    seeds = [np.load(p)["bytes"].tobytes() for p in paths]
+    decoded = failed = 0
+    for it in range(48):
+        data = bytearray(seeds[it % len(seeds)])
+        for _ in range(int(rng.integers(1, 3))):
+            pos = int(rng.integers(len(data) // 4, len(data)))
+            data[pos] ^= 1 << int(rng.integers(0, 8))
+        try:
+            decoded += len(StreamDecoder(bytes(data)).output_order())
+        except Exception:
+            failed += 1
+    assert decoded > 0
+    d = np.load(paths[0])
+    ours = su.decode_gpu(d["bytes"].tobytes())
+    for k in range(len(ours)):
+        for c in range(3):
+            assert np.array_equal(ours[k][c], d[f"p{k}_{c}"])

@@ -470,6 +470,8 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     ARGCHK(c, b->n_cu >= 0 && b->n_ctu == c->w_ctu * c->h_ctu);
     ARGCHK(c, b->n_cu == 0 || (b->x && b->y && b->log2w && b->log2h && b->pred_mode && b->refi && b->mv && b->qp && b->cbf && b->coef_off));
     ARGCHK(c, b->ctu_cu_start != NULL && (b->n_coef == 0 || b->coef != NULL));
+    ARGCHK(c, b->ctu_cu_start[0] == 0 && b->ctu_cu_start[b->n_ctu] == (uint32_t)b->n_cu);      // the kernels index the CU records through it
+    for (int k = 0; k < b->n_ctu; k++) ARGCHK(c, b->ctu_cu_start[k] <= b->ctu_cu_start[k + 1]);
     HIPCHK(c, hipSetDevice(c->sp.device));
     const int n = b->n_cu;
     const int bdoff = 6 * (c->sp.bit_depth_luma - 8);
@@ -505,6 +507,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         ARGCHK(c, lw >= 2 && lw <= 7 && lh >= 2 && lh <= 7 && lw <= c->sp.log2_ctu && lh <= c->sp.log2_ctu);
         ARGCHK(c, b->x[i] + (1 << lw) <= c->sp.width && b->y[i] + (1 << lh) <= c->sp.height && !(b->x[i] & 3) && !(b->y[i] & 3));
         if (b->pred_mode[i] != XGPU_MODE_INTRA) ARGCHK(c, b->refi[i * 2] < XGPU_MAX_REFS && b->refi[i * 2 + 1] < XGPU_MAX_REFS);
+        ARGCHK(c, b->qp[i * 3] < 96 && b->qp[i * 3 + 1] < 96 && b->qp[i * 3 + 2] < 96);                     // 0..51 + 6 * (bit depth - 8)
         if (const int ai = ats_inter_of(i)) {
             // availability as xevdm_check_ats_inter_info_coded (xevdm_util.c:3565-3583): CU <= 64, split dimension >= 8 (>= 16 for quarters)
             const int idx = ai & 15, pos = ai >> 4;

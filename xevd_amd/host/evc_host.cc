@@ -136,6 +136,7 @@ template <class C> static int sym_unary(C &c, int v, Model *m, int num_ctx)     
         if (ctx < num_ctx - 1) ctx++;
         sym++;
         if (!c.bin(v > sym, m[ctx])) break;
+        if (sym >= 0x7FFF) break;                   // no valid symbol is longer (levels are s16, runs below 4096): malformed input ends here
     }
     return sym;
 }
@@ -153,7 +154,7 @@ template <class C> static int sym_abs_mvd(C &c, int v, Model &m)      // xevd_ec
     int len_v = 0;
     while (((v + 1) >> (len_v + 1)) > 0) len_v++;            // floor(log2(v + 1)) on the encoder side
     int len = 0, code;
-    do { code = len == 0 ? c.bin(len + 1 == len_v, m) : c.ep(len + 1 == len_v); len++; } while (!code);
+    do { code = len == 0 ? c.bin(len + 1 == len_v, m) : c.ep(len + 1 == len_v); len++; } while (!code && len < 24);      // a valid |mvd| has at most 16 prefix bins
     int val = (1 << len) - 1;
     const int suffix = v + 1 - (1 << len_v);
     while (len != 0) { len--; val += c.ep((suffix >> len) & 1) << len; }
@@ -326,7 +327,7 @@ struct Stream {          // everything both directions share
             for (int i = 0; i < 12; i++) {
                 const int pos = k_alf_to_large[y.type7][i];
                 alf_luma_final[c][i] = pos > 0 ? coef[y.delta_idx[c]][pos - 1] : (int16_t)0;
-                sum += alf_luma_final[c][i] << 1;
+                sum += alf_luma_final[c][i] * 2;
             }
             alf_luma_final[c][12] = (int16_t)(512 - sum);
         }
@@ -335,7 +336,7 @@ struct Stream {          // everything both directions share
             const AlfAps &ch = alf_aps[sh.aps_id_ch & 31];
             if (!ch.valid || !ch.chroma_present) return false;
             int sum = 0;
-            for (int i = 0; i < 6; i++) { alf_chroma_final[i] = ch.chroma[i]; sum += ch.chroma[i] << 1; }
+            for (int i = 0; i < 6; i++) { alf_chroma_final[i] = ch.chroma[i]; sum += ch.chroma[i] * 2; }
             alf_chroma_final[6] = (int16_t)(512 - sum);
         }
         return true;
@@ -877,7 +878,8 @@ struct xhost_parser {
             if (same) memcpy(s.cq[1], s.cq[0], sizeof(s.cq[0]));
         }
         br.get1();      // vui_parameters_present_flag: the VUI (display metadata, xevd_eco.c:1226-1304) is the last SPS element and is not needed here
-        if (br.overrun || (s.width & 7) || (s.height & 7) || s.width <= 0 || s.height <= 0) return fail("bad SPS");
+        if (br.overrun || (s.width & 7) || (s.height & 7) || s.width <= 0 || s.height <= 0 || s.width > 16384 || s.height > 16384 ||
+            s.bd_l < 8 || s.bd_l > 12 || s.bd_c < 8 || s.bd_c > 12 || s.max_num_ref_pics < 0 || s.max_num_ref_pics > 21) return fail("bad SPS");
         st.have_sps = true;
         return XGPU_OK;
     }
