@@ -124,6 +124,53 @@ def cpu_baseline(wl, first, batch, alf, budget_s=15.0):
                          if kind == "reference" else "plain-C oracle port")}
 
 
+def reference_decoder_leg(wl, budget_s=25.0):
+    """The reference DECODER itself (its public API through oracle/_ref/ref_decode, -m 1 and -m 8 threads) on a real bitstream of the same
+    shape, written by this repository's front end: entropy decoding included, i.e. what a user of xevd_app runs on this host.  The front
+    end writes P pictures with one reference, and of the Main tools IQT / ADDB / ALF - not the 8-tap tables and bi-prediction of the GPU
+    workload - so for the Main workloads this is a lower bound of the reference's work per picture."""
+    import subprocess
+    import tempfile
+    from xevd_amd import stream, synth
+    main_profile = bool(wl["addb"] or wl["iqt"] or wl["alf"])
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_decode_main" if main_profile else "ref_decode")
+    if not os.path.exists(exe):
+        return None
+    w, h, bd = wl["w"], wl["h"], wl["bd"]
+    n = 30 if w * h <= 1920 * 1088 else (8 if w * h <= 3840 * 2176 else 3)
+    rng = np.random.default_rng(77)
+    wr = stream.StreamWriter(w, h, bd, 1, main=main_profile, iqt=bool(wl["iqt"]), addb=bool(wl["addb"]), alf=bool(wl["alf"]))
+    try:
+        if wl["alf"]:
+            wr.add_alf_aps(0, luma=rng.integers(-12, 13, (5, 12)), chroma=rng.integers(-10, 11, 6), type7=True, delta_idx=rng.integers(0, 5, 25))
+        for k in range(n):
+            b = synth.gen_frame(rng, w, h, bd, inter_frac=0.0 if k == 0 else 0.9, n_refs=(1, 0), bi_frac=0.0, coded_frac=0.6, max_level=6, amp=1.0)
+            if wl["alf"]:
+                wr.set_slice_alf(True, 0, 0, chroma_idc=3)
+            wr.add_picture(b, stream.SLICE_I if k == 0 else stream.SLICE_P, slice_qp=30, idr=k == 0)
+        data = wr.bytes()
+    finally:
+        wr.close()
+    fps, t0 = {}, time.perf_counter()
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "s.evc")
+        with open(path, "wb") as f:
+            f.write(data)
+        for threads in (1, 8):
+            if time.perf_counter() - t0 > budget_s:
+                break
+            r = subprocess.run([exe, path, "-", str(w), str(h), str(threads)], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=120)
+            if r.returncode != 0:
+                return {"error": r.stderr.decode()[-200:]}
+            pics, secs = r.stderr.decode().split()[-2:]
+            fps[str(threads)] = round(int(pics) / float(secs), 2)
+    return {"frames_per_s_by_threads": fps, "host_cores": os.cpu_count(),
+            "stream": f"{n} pictures (1 I + {n - 1} P, one reference), {w}x{h} {bd}-bit, {len(data)} bytes, "
+                      + ("Main profile: IQT, ADDB, ALF" if main_profile else "Baseline profile") + ", written by xevd_amd/host",
+            "what": "xevd_create / xevd_decode / xevd_pull of the reference library built in oracle/_ref (entropy decoding + reconstruction), "
+                    "threads = XEVD_CDSC.threads"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -250,6 +297,12 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
             out["cpu_baseline"] = cpu_baseline(wl, first, batches[0], alf)
+            try:
+                rd = reference_decoder_leg(wl)
+            except Exception as e:                      # the checker's leg must not take the measurement down
+                rd = {"error": repr(e)[:200]}
+            if rd is not None:
+                out["cpu_baseline"]["reference_decoder"] = rd
         print(json.dumps(out))
     barrier()
     dec.close()
