@@ -208,6 +208,8 @@ void xgpu_close(xgpu_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto &p : c->pics) if (p.base) (void)hipFree(p.base);
     if (c->d_maps) (void)hipFree(c->d_maps);
+    for (BatchBlock &k : c->pool) { (void)hipFree(k.d_base); (void)hipHostFree(k.h_stage); (void)hipEventDestroy(k.uploaded); }
+    c->pool.clear();
     if (c->d_owner) (void)hipFree(c->d_owner);
     if (c->d_out) (void)hipFree(c->d_out);
     if (c->d_dra) (void)hipFree(c->d_dra);
@@ -557,7 +559,30 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     const size_t o_deps = o_intra + align_up((int)sz_intra, 256), o_coef = o_deps + align_up((int)sz_deps, 256);
     db->stage_bytes = o_coef + sz_coef;
     auto fail = [&](int code) { xgpu_batch_destroy(c, db); return code; };
-    if (hipHostMalloc(&db->h_stage, db->stage_bytes, hipHostMallocDefault) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
+    // device layout: the uploaded arrays at the staging offsets, then the residual arena and the intra done flags
+    const size_t sz_done = sizeof(uint32_t) * ((size_t)n_intra + 1);
+    const size_t o_resid = align_up((int)(o_coef + sz_coef), 256), o_done = o_resid + align_up((int)sz_coef, 256);
+    const size_t d_need = o_done + align_up((int)sz_done, 256);
+    {
+        // a pooled block that is large enough (the smallest such), else a new one
+        int best = -1;
+        for (size_t k = 0; k < c->pool.size(); k++)
+            if (c->pool[k].d_cap >= d_need && c->pool[k].h_cap >= db->stage_bytes && (best < 0 || c->pool[k].d_cap < c->pool[best].d_cap)) best = (int)k;
+        if (best >= 0) {
+            db->blk = c->pool[best];
+            c->pool.erase(c->pool.begin() + best);
+            if (hipEventSynchronize(db->blk.uploaded) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);      // its staging block may still feed an upload
+        } else {
+            memset(&db->blk, 0, sizeof(db->blk));
+            const size_t d_cap = d_need + d_need / 4, h_cap = db->stage_bytes + db->stage_bytes / 4;             // headroom: pictures of a stream vary
+            if (hipMalloc((void **)&db->blk.d_base, d_cap) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
+            db->blk.d_cap = d_cap;
+            if (hipHostMalloc(&db->blk.h_stage, h_cap, hipHostMallocDefault) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
+            db->blk.h_cap = h_cap;
+            if (hipEventCreateWithFlags(&db->blk.uploaded, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+        }
+    }
+    db->h_stage = db->blk.h_stage;
     uint8_t *hs = (uint8_t *)db->h_stage;
     CuRec *cus = (CuRec *)(hs + o_cus);
     TbRec *tbs = (TbRec *)(hs + o_tbs);
@@ -614,20 +639,14 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     if (n_intra) memcpy(hs + o_intra, plan.recs.data(), sizeof(IntraRec) * (size_t)n_intra);
     if (n_deps) memcpy(hs + o_deps, plan.deps.data(), sizeof(uint32_t) * (size_t)n_deps);
 
-    if (hipMalloc((void **)&db->d_cus, sz_cus) != hipSuccess || hipMalloc((void **)&db->d_ctu_start, sz_ctu) != hipSuccess ||
-        hipMalloc((void **)&db->d_tbs, sz_tbs) != hipSuccess || hipMalloc((void **)&db->d_waves, sz_wv) != hipSuccess ||
-        hipMalloc((void **)&db->d_coef, sz_coef) != hipSuccess || hipMalloc((void **)&db->d_resid, sz_coef) != hipSuccess ||
-        hipMalloc((void **)&db->d_intra, sz_intra) != hipSuccess || hipMalloc((void **)&db->d_intra_deps, sz_deps) != hipSuccess ||
-        hipMalloc((void **)&db->d_intra_done, sizeof(uint32_t) * ((size_t)n_intra + 1)) != hipSuccess)
-        return fail(XGPU_ERR_OUT_OF_MEMORY);
-    hipError_t e = hipMemcpyAsync(db->d_cus, hs + o_cus, sz_cus, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(db->d_ctu_start, hs + o_ctu, sz_ctu, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(db->d_tbs, hs + o_tbs, sz_tbs, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(db->d_waves, hs + o_wv, sz_wv, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(db->d_coef, hs + o_coef, sz_coef, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && n_intra) e = hipMemcpyAsync(db->d_intra, hs + o_intra, sz_intra, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess && n_deps) e = hipMemcpyAsync(db->d_intra_deps, hs + o_deps, sz_deps, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(db->d_intra_done, 0, sizeof(uint32_t) * ((size_t)n_intra + 1), c->stream);
+    uint8_t *dbase = db->blk.d_base;
+    db->d_cus = (CuRec *)(dbase + o_cus); db->d_ctu_start = (uint32_t *)(dbase + o_ctu); db->d_tbs = (TbRec *)(dbase + o_tbs);
+    db->d_waves = (TbWave *)(dbase + o_wv); db->d_intra = (IntraRec *)(dbase + o_intra); db->d_intra_deps = (uint32_t *)(dbase + o_deps);
+    db->d_coef = (int16_t *)(dbase + o_coef); db->d_resid = (int16_t *)(dbase + o_resid); db->d_intra_done = (uint32_t *)(dbase + o_done);
+    // one copy: the staging block has the device layout
+    hipError_t e = hipMemcpyAsync(dbase, hs, db->stage_bytes, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(db->blk.uploaded, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(db->d_intra_done, 0, sz_done, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(db->d_resid, 0, sz_coef, c->stream);
     if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "batch upload: %s", hipGetErrorString(e)); return fail(XGPU_ERR_UNEXPECTED); }
     *out = db;
@@ -637,17 +656,15 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
 void xgpu_batch_destroy(xgpu_ctx *c, xgpu_dbatch *db)
 {
     if (!db) return;
-    if (c && c->stream) (void)hipStreamSynchronize(c->stream);
-    if (db->d_cus) (void)hipFree(db->d_cus);
-    if (db->d_ctu_start) (void)hipFree(db->d_ctu_start);
-    if (db->d_tbs) (void)hipFree(db->d_tbs);
-    if (db->d_waves) (void)hipFree(db->d_waves);
-    if (db->d_coef) (void)hipFree(db->d_coef);
-    if (db->d_resid) (void)hipFree(db->d_resid);
-    if (db->d_intra) (void)hipFree(db->d_intra);
-    if (db->d_intra_deps) (void)hipFree(db->d_intra_deps);
-    if (db->d_intra_done) (void)hipFree(db->d_intra_done);
-    if (db->h_stage) (void)hipHostFree(db->h_stage);
+    // No synchronisation: kernels still queued on the context's stream keep reading the block, and whoever reuses it writes it through the
+    // same stream (ordered behind them); only the staging block is touched by the host, guarded by the `uploaded` event.
+    if (db->blk.d_base && db->blk.h_stage && db->blk.uploaded && c) c->pool.push_back(db->blk);
+    else {
+        if (c && c->stream) (void)hipStreamSynchronize(c->stream);
+        if (db->blk.d_base) (void)hipFree(db->blk.d_base);
+        if (db->blk.h_stage) (void)hipHostFree(db->blk.h_stage);
+        if (db->blk.uploaded) (void)hipEventDestroy(db->blk.uploaded);
+    }
     delete db;
 }
 

@@ -159,7 +159,13 @@ struct AlfArgs {
     int16_t  coef[25 * 13 + 7];        // coef_final followed by the chroma filter
 };
 
+// One device block + one pinned staging block of a batch.  xgpu_batch_destroy returns them to the context's pool instead of freeing:
+// hipMalloc / hipFree / hipHostMalloc synchronise the device and serialise across the threads of a process, which capped many-stream
+// decoding on one GPU (tools/bench_multistream.py) and cost a stream synchronisation per picture.
+struct BatchBlock { uint8_t *d_base; size_t d_cap; void *h_stage; size_t h_cap; hipEvent_t uploaded; };
+
 struct xgpu_dbatch {
+    BatchBlock blk;
     int        n_cu, n_ctu, n_tb, n_waves;
     size_t     n_coef;
     CuRec     *d_cus;
@@ -187,6 +193,7 @@ struct xgpu_ctx {
     ScuRec         *d_maps;
     uint16_t       *d_owner;          // SCU -> CU index inside the CTU, rebuilt per picture by k_paint
     uint8_t        *d_ctb_flag;       // ALF luma CTB flags of the current picture
+    std::vector<BatchBlock> pool;     // blocks of destroyed batches, reused by later ones of the same stream (same HIP stream -> ordered)
     uint8_t        *d_out;            // packed output picture (xgpu_pic_output), grown on demand
     int32_t        *d_dra;            // [3][1024] DRA inverse tables of the current output call
     size_t          out_cap;
