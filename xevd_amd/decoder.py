@@ -130,6 +130,13 @@ class XgpuDecoder:
         self._batches.append(h)
         return h
 
+    def batch_create_from_struct(self, cu_batch):
+        """xgpu_batch_create on a filled abi.CuBatch (e.g. the one inside the host parser's xhost_picture): no numpy round trip"""
+        h = C.c_void_p()
+        self._chk(self.lib.xgpu_batch_create(self.ctx, C.byref(cu_batch), C.byref(h)), "xgpu_batch_create")
+        self._batches.append(h)
+        return h
+
     def batch_resid(self, h, n_coef):
         out = np.zeros(max(n_coef, 1), np.int16)
         self._chk(self.lib.xgpu_test_batch_resid(self.ctx, h, out.ctypes.data), "xgpu_test_batch_resid")

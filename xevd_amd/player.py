@@ -14,11 +14,20 @@ class StreamDecoder:
         """verify_md5: check downloaded pictures against the stream's picture-signature SEIs (the reference's
         XEVD_CFG_SET_USE_PIC_SIGNATURE), raising on a mismatch"""
         self.data, self.device, self.prefetch, self.verify_md5 = data, device, prefetch, verify_md5
+        self._lock, self._dec = threading.Lock(), None
         self.apply_crop = apply_crop      # packed output: cut the SPS conformance window (the reference application writes uncropped pictures)
 
     def _producer(self, q):
+        """parser thread: entropy decoding, and - zero-copy, while the parser's arrays are valid - the hand-over of every picture's CU batch to
+        the backend (builder + upload into pooled buffers).  The backend context is not thread-safe: calls on it are serialised by self._lock."""
+        def to_device(p, cu_batch):
+            with self._lock:
+                if self._dec is None:
+                    self._dec = XgpuDecoder(p["width"], p["height"], p["bit_depth"], device=self.device, iqt=p["iqt"], addb=p["addb"], alf=p["tool_alf"],
+                                            eipd=p["eipd"], max_pics=12, chroma_qp_tables=p["chroma_qp_tables"])
+                return self._dec.batch_create_from_struct(cu_batch)
         try:
-            for p in stream.iter_stream(self.data):
+            for p in stream.iter_stream(self.data, consume_batch=to_device):
                 q.put(p)
             q.put(None)
         except Exception as e:      # surfaced in the consumer thread
@@ -37,7 +46,34 @@ class StreamDecoder:
         q = queue.Queue(maxsize=self.prefetch)
         th = threading.Thread(target=self._producer, args=(q,), daemon=True)
         th.start()
-        dec, slots, free = None, {}, []
+        slots, free = {}, []
+
+        def decode(p):
+            dec, hb = self._dec, p["batch"]
+            if p["is_idr"]:
+                free.extend(slots.values()); slots.clear()
+            cur = free.pop()
+            refs = {(i, l): (slots[poc], poc) for l in range(2) for i, poc in enumerate(p["refs"][l])}
+            with self._lock:
+                dec.decode_picture(cur, p["poc"], refs, hb, deblock=p["deblock_on"], pad=True, qp_u_offset=p["qp_u_offset"], qp_v_offset=p["qp_v_offset"],
+                                   alpha_off=p["alpha_off"], beta_off=p["beta_off"], alf=p["alf"])
+                dec.batch_destroy(hb)          # back to the pool; queued kernels keep reading it (same HIP stream)
+            planes = None
+            if download and output_bit_depth is not None:
+                planes = dec.pic_output(cur, output_bit_depth, p["crop"] if self.apply_crop else (0, 0, 0, 0))
+            elif download:
+                planes = dec.pic_download(cur)
+                if self.verify_md5 and p["md5"] is not None and not self.signature_ok(p, planes):
+                    raise RuntimeError(f"picture signature mismatch at POC {p['poc']} (XEVD_ERR_BAD_CRC)")
+            for poc in p["release"]:      # unmarked when THIS picture is stored (it may still have referenced them)
+                if poc in slots:
+                    free.append(slots.pop(poc))
+            if p["is_ref"]:
+                slots[p["poc"]] = cur
+            else:
+                free.append(cur)
+            return planes
+
         try:
             while True:
                 p = q.get()
@@ -45,38 +81,22 @@ class StreamDecoder:
                     break
                 if isinstance(p, Exception):
                     raise p
-                if dec is None:
-                    dec = XgpuDecoder(p["width"], p["height"], p["bit_depth"], device=self.device, iqt=p["iqt"], addb=p["addb"], alf=p["tool_alf"], eipd=p["eipd"], max_pics=12,
-                                          chroma_qp_tables=p["chroma_qp_tables"])
-                    free = [dec.pic_alloc() for _ in range(10)]
-                if p["is_idr"]:
-                    free.extend(slots.values()); slots.clear()
-                cur = free.pop()
-                refs = {(i, l): (slots[poc], poc) for l in range(2) for i, poc in enumerate(p["refs"][l])}
-                hb = dec.batch_create(p["batch"])
-                dec.decode_picture(cur, p["poc"], refs, hb, deblock=p["deblock_on"], pad=True, qp_u_offset=p["qp_u_offset"], qp_v_offset=p["qp_v_offset"],
-                                   alpha_off=p["alpha_off"], beta_off=p["beta_off"], alf=p["alf"])
-                planes = None
-                if download and output_bit_depth is not None:
-                    planes = dec.pic_output(cur, output_bit_depth, p["crop"] if self.apply_crop else (0, 0, 0, 0))
-                elif download:
-                    planes = dec.pic_download(cur)
-                    if self.verify_md5 and p["md5"] is not None and not self.signature_ok(p, planes):
-                        raise RuntimeError(f"picture signature mismatch at POC {p['poc']} (XEVD_ERR_BAD_CRC)")
-                else:
-                    dec.sync()
-                dec.batch_destroy(hb)
-                for poc in p["release"]:      # unmarked when THIS picture is stored (it may still have referenced them)
-                    if poc in slots:
-                        free.append(slots.pop(poc))
-                if p["is_ref"]:
-                    slots[p["poc"]] = cur
-                else:
-                    free.append(cur)
-                yield p, planes
+                if not free and not slots:
+                    with self._lock:
+                        free = [self._dec.pic_alloc() for _ in range(10)]
+                yield p, decode(p)
+            if self._dec is not None and not download:
+                self._dec.sync()
         finally:
-            if dec is not None:
-                dec.close()
+            # let the parser thread finish (it may be inside a backend call), then release the device
+            while th.is_alive():
+                try:
+                    q.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            if self._dec is not None:
+                self._dec.close()
+                self._dec = None
 
     def output_order(self, output_bit_depth=None):
         """all pictures in output order (ascending POC inside every IDR period), as xevd_pull's bumping delivers them"""

@@ -157,9 +157,11 @@ def _arr(ptr, n, dtype):
     return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
 
 
-def iter_stream(data):
+def iter_stream(data, consume_batch=None):
     """generator over the pictures of a .evc byte string in decoding order: dict(params..., batch=dict of numpy arrays in the
-    layout of synth.gen_frame).  The C parser runs inside each next() with the GIL released (ctypes)."""
+    layout of synth.gen_frame).  The C parser runs inside each next() with the GIL released (ctypes).
+    consume_batch(params, cu_batch_struct): zero-copy hand-over - called while the parser's arrays are valid (before the next picture
+    is parsed) with the xgpu_cu_batch the parser filled; its return value becomes params["batch"] (e.g. a device batch handle)."""
     lib = load()
     buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
     h = lib.xhost_parser_open(buf, len(data))
@@ -172,7 +174,7 @@ def iter_stream(data):
             if rc < 0:
                 raise RuntimeError(f"xhost_parser_next -> {rc}: {lib.xhost_parser_error(h).decode()}")
             b, n = hp.batch, hp.batch.n_cu
-            batch = {
+            batch = None if consume_batch is not None else {
                 "x": _arr(b.x, n, np.uint16), "y": _arr(b.y, n, np.uint16), "log2w": _arr(b.log2w, n, np.uint8), "log2h": _arr(b.log2h, n, np.uint8),
                 "pred_mode": _arr(b.pred_mode, n, np.uint8), "refi": _arr(b.refi, n * 2, np.int8).reshape(n, 2),
                 "mv": _arr(b.mv, n * 4, np.int16).reshape(n, 2, 2), "qp": _arr(b.qp, n * 3, np.uint8).reshape(n, 3),
@@ -181,7 +183,7 @@ def iter_stream(data):
                 "coef_off": _arr(b.coef_off, n, np.uint32), "coef": _arr(b.coef, max(b.n_coef, 1), np.int16), "n_coef": int(b.n_coef),
                 "ctu_cu_start": _arr(b.ctu_cu_start, b.n_ctu + 1, np.uint32), "constrained_intra_pred": int(b.constrained_intra_pred),
             }
-            yield {
+            params = {
                 "width": hp.width, "height": hp.height, "bit_depth": hp.bit_depth_luma, "poc": hp.poc, "temporal_id": hp.temporal_id, "slice_type": hp.slice_type,
                 "is_idr": bool(hp.is_idr), "is_ref": bool(hp.is_ref),
                 "refs": [[hp.refp_poc[i][l] for i in range(hp.num_refp[l])] for l in range(2)],
@@ -195,6 +197,9 @@ def iter_stream(data):
                 "md5": [bytes(hp.md5[c]) for c in range(3)] if hp.has_md5 else None,
                 "release": [hp.release_poc[i] for i in range(hp.n_release)], "batch": batch,
             }
+            if consume_batch is not None:
+                params["batch"] = consume_batch(params, hp.batch)
+            yield params
     finally:
         lib.xhost_parser_close(h)
 
