@@ -175,8 +175,11 @@ int  xgpu_pic_upload_padded(xgpu_ctx *ctx, int pic, const int16_t *buf_y, const 
 
 /* ------------------------------------------------------------------ per picture ------------------- */
 int  xgpu_frame_begin(xgpu_ctx *ctx, const xgpu_frame_params *fp);
-/* copy a batch into HBM (pinned staging + async H2D) and build its device work lists */
+/* copy a batch into HBM (one pinned staging block + one async H2D copy) and build its device work lists.  The arrays behind `b`
+   are read before the call returns.  Device and staging blocks come from a per-context pool: no allocation in steady state. */
 int  xgpu_batch_create(xgpu_ctx *ctx, const xgpu_cu_batch *b, xgpu_dbatch **out);
+/* returns the batch's blocks to the pool.  Does not wait for the device: it may follow xgpu_batch_recon immediately (kernels already
+   queued keep their data - later batches of this context are written through the same HIP stream, behind them). */
 void xgpu_batch_destroy(xgpu_ctx *ctx, xgpu_dbatch *db);
 /* dequant + inverse transform of every coded TB, then MC + residual add + clip of every inter CU, and the
    SCU map update (xevd_set_dec_info) the in-loop filters read.  Asynchronous on the ctx stream.          */
