@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
     const uint4 rq = maps[k0];
     const uint4 rp = maps[pos > 0 ? k0 - step : k0];
     const uint4 rn = maps[pos + 1 < npos ? k0 + step : k0];
+    const uint4 rpp = maps[pos > 1 ? k0 - 2 * step : k0];    // two back: the first link of a chroma dependency chain (below) without a second round trip
     const int x = sx << 2, y = sy << 2, cx = sx << 1, cy = sy << 1;
     U32x4a4 lrow[4];       // DIR 0: rows y..y+3, samples x-2..x+5
     uint2   lcol[8];       // DIR 1: rows y-2..y+5, samples x..x+3
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
             uint4 cur = rp;                                  // record of SCU head-1
             while (head - 1 > 0) {
                 if (!(cur.x & eflag)) break;
-                const uint4 prv = maps[kk - 2 * step];
+                const uint4 prv = kk == k0 ? rpp : maps[kk - 2 * step];
                 const int cls = edge_class(cur, prv), qp = (cur.x >> 16) & 0x7F;
                 if (s_st[((1 + pl) * 4 + cls) * 64 + (qp & 63)] == 0) break;
                 head--; kk -= step; cur = prv;
