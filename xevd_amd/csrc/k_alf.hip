@@ -78,6 +78,9 @@ __constant__ uint8_t k_alf_perm[4][13] = {      // coefficient order per transpo
 __device__ __forceinline__ v2s asv(uint32_t x) { return __builtin_bit_cast(v2s, x); }
 __device__ __forceinline__ uint32_t asu(v2s x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ v2s vabs(v2s x) { const v2s z = {0, 0}; const v2s n = z - x; return __builtin_elementwise_max(x, n); }
+// D = S0.i16 * S1.i16 + S2.i32 on the low / high half of a packed pair: two neighbouring output samples share every packed pair sum
+__device__ __forceinline__ int mad_lo(uint32_t ps, int f, int acc) { int r; asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(ps), "v"(f), "v"(acc)); return r; }
+__device__ __forceinline__ int mad_hi(uint32_t ps, int f, int acc) { int r; asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(ps), "v"(f), "v"(acc)); return r; }
 __device__ __forceinline__ int hsum(v2s x, int acc) { const v2s one = {1, 1}; return __builtin_amdgcn_sdot2(x, one, acc, false); }
 
 __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
@@ -217,27 +220,33 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
 #pragma unroll
         for (int i = 0; i < 13; i++) f[i] = l_coef[cls * 13 + k_alf_perm[tr][i]];
 
-        // S(i, j): window row i (-3..6), col j (-3..6)
-#define S(i, j) ((int)(int16_t)(W[(i) + 3][((j) + 4) >> 1] >> ((((j) + 4) & 1) * 16)))
+        // The filter of alf_filter_blk_7 (xevdm_alf.c:210-337): sum_k f[k] * (S(i+dy_k, j+dx_k) + S(i-dy_k, j-dx_k)) + f[12] * S(i, j), + 256 >> 9.
+        // Two neighbouring outputs (j, j+1) at a time: their symmetric sample pairs are PACKED pairs of the window - P(i, c) = (S(i, c),
+        // S(i, c+1)), a window dword or one v_alignbit - so one v_pk_add_i16 makes both pair sums (<= 2 * 4095, exact in s16) and two
+        // v_mad_i32_i16 (low / high half) accumulate them: 38 VALU per output pair instead of ~100 with scalar extracts.
+#define P(i, c) ((((c) + 4) & 1) ? __builtin_amdgcn_alignbit(W[(i) + 3][(((c) + 4) >> 1) + 1], W[(i) + 3][((c) + 4) >> 1], 16) : W[(i) + 3][((c) + 4) >> 1])
+#define TAP(k, i1, c1, i2, c2) do { const uint32_t ps_ = __builtin_bit_cast(uint32_t, asv(P(i1, c1)) + asv(P(i2, c2))); a0 = mad_lo(ps_, f[k], a0); a1 = mad_hi(ps_, f[k], a1); } while (0)
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) {
             int o[4];
 #pragma unroll
-            for (int jj = 0; jj < 4; jj++) {
-                int sum = f[0] * (S(ii + 3, jj) + S(ii - 3, jj))
-                        + f[1] * (S(ii + 2, jj + 1) + S(ii - 2, jj - 1)) + f[2] * (S(ii + 2, jj) + S(ii - 2, jj)) + f[3] * (S(ii + 2, jj - 1) + S(ii - 2, jj + 1))
-                        + f[4] * (S(ii + 1, jj + 2) + S(ii - 1, jj - 2)) + f[5] * (S(ii + 1, jj + 1) + S(ii - 1, jj - 1)) + f[6] * (S(ii + 1, jj) + S(ii - 1, jj))
-                        + f[7] * (S(ii + 1, jj - 1) + S(ii - 1, jj + 1)) + f[8] * (S(ii + 1, jj - 2) + S(ii - 1, jj + 2))
-                        + f[9] * (S(ii, jj + 3) + S(ii, jj - 3)) + f[10] * (S(ii, jj + 2) + S(ii, jj - 2)) + f[11] * (S(ii, jj + 1) + S(ii, jj - 1))
-                        + f[12] * S(ii, jj);
-                o[jj] = min(max((sum + 256) >> 9, 0), maxv);
+            for (int jj = 0; jj < 4; jj += 2) {
+                int a0 = 256, a1 = 256;
+                TAP(0, ii + 3, jj, ii - 3, jj);
+                TAP(1, ii + 2, jj + 1, ii - 2, jj - 1); TAP(2, ii + 2, jj, ii - 2, jj); TAP(3, ii + 2, jj - 1, ii - 2, jj + 1);
+                TAP(4, ii + 1, jj + 2, ii - 1, jj - 2); TAP(5, ii + 1, jj + 1, ii - 1, jj - 1); TAP(6, ii + 1, jj, ii - 1, jj);
+                TAP(7, ii + 1, jj - 1, ii - 1, jj + 1); TAP(8, ii + 1, jj - 2, ii - 1, jj + 2);
+                TAP(9, ii, jj + 3, ii, jj - 3); TAP(10, ii, jj + 2, ii, jj - 2); TAP(11, ii, jj + 1, ii, jj - 1);
+                { const uint32_t c_ = P(ii, jj); a0 = mad_lo(c_, f[12], a0); a1 = mad_hi(c_, f[12], a1); }
+                o[jj] = min(max(a0 >> 9, 0), maxv); o[jj + 1] = min(max(a1 >> 9, 0), maxv);
             }
             uint2 w;
             w.x = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
             w.y = (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
             *(uint2 *)(dy_ + (y + ii) * a.s_l + x) = w;
         }
-#undef S
+#undef TAP
+#undef P
     } else {
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) *(uint2 *)(dy_ + (y + ii) * a.s_l + x) = *(const uint2 *)(sy_ + (y + ii) * a.s_l + x);
@@ -262,20 +271,19 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
             C[i][0] = row[0]; C[i][1] = row[1]; C[i][2] = row[2];
         }
         const int16_t *f = l_coef + 325;
-#define SC(i, j) ((int)(int16_t)(C[(i) + 2][((j) + 2) >> 1] >> ((((j) + 2) & 1) * 16)))
+        // alf_filter_blk_5 (xevdm_alf.c:339-429), the same way: the SCU's two outputs of a row are one packed pair
+#define PC(i, c) ((((c) + 2) & 1) ? __builtin_amdgcn_alignbit(C[(i) + 2][(((c) + 2) >> 1) + 1], C[(i) + 2][((c) + 2) >> 1], 16) : C[(i) + 2][((c) + 2) >> 1])
+#define TAPC(k, i1, c1, i2, c2) do { const uint32_t ps_ = __builtin_bit_cast(uint32_t, asv(PC(i1, c1)) + asv(PC(i2, c2))); a0 = mad_lo(ps_, f[k], a0); a1 = mad_hi(ps_, f[k], a1); } while (0)
 #pragma unroll
         for (int ii = 0; ii < 2; ii++) {
-            int o[2];
-#pragma unroll
-            for (int jj = 0; jj < 2; jj++) {
-                int sum = f[0] * (SC(ii + 2, jj) + SC(ii - 2, jj)) + f[1] * (SC(ii + 1, jj + 1) + SC(ii - 1, jj - 1)) + f[2] * (SC(ii + 1, jj) + SC(ii - 1, jj))
-                        + f[3] * (SC(ii + 1, jj - 1) + SC(ii - 1, jj + 1)) + f[4] * (SC(ii, jj + 2) + SC(ii, jj - 2)) + f[5] * (SC(ii, jj + 1) + SC(ii, jj - 1))
-                        + f[6] * SC(ii, jj);
-                o[jj] = min(max((sum + 256) >> 9, 0), maxv);
-            }
-            *(uint32_t *)(dst + (cy + ii) * a.s_c + cx) = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
+            int a0 = 256, a1 = 256;
+            TAPC(0, ii + 2, 0, ii - 2, 0); TAPC(1, ii + 1, 1, ii - 1, -1); TAPC(2, ii + 1, 0, ii - 1, 0); TAPC(3, ii + 1, -1, ii - 1, 1);
+            TAPC(4, ii, 2, ii, -2); TAPC(5, ii, 1, ii, -1);
+            { const uint32_t c_ = PC(ii, 0); a0 = mad_lo(c_, f[6], a0); a1 = mad_hi(c_, f[6], a1); }
+            *(uint32_t *)(dst + (cy + ii) * a.s_c + cx) = (uint32_t)(uint16_t)min(max(a0 >> 9, 0), maxv) | ((uint32_t)(uint16_t)min(max(a1 >> 9, 0), maxv) << 16);
         }
-#undef SC
+#undef TAPC
+#undef PC
     }
 }
 
