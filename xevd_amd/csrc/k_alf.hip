@@ -48,6 +48,19 @@ template <int T, int H, int STR, int OFF>
 __device__ __forceinline__ void alf_stage(int16_t *lds, const int16_t *__restrict__ p, int s, int pw, int ph, const CtuRect k,
                                           int tx0, int ty0, int t0, int nthr)
 {
+    // fast path (every tile that touches neither the picture border nor an unavailable CTU side - almost all of them): the window rule
+    // does nothing, so the tile AND its halo are 8-byte copies of (T + 2H) rows x (T + 8) / 4 pieces (cols -4 .. T+3, window cols -H .. T+H-1 inside)
+    static_assert(OFF == 4 && STR == T + 8, "the fast path copies whole LDS rows");
+    const bool plain = (k.aL || tx0 > k.x0) && (k.aR || tx0 + T < k.x0 + k.cw) && (k.aT || ty0 > k.y0) && (k.aB || ty0 + T < k.y0 + k.ch) &&
+                       tx0 >= 4 && tx0 + T + 4 <= pw && ty0 >= H && ty0 + T + H <= ph;
+    if (plain) {
+        constexpr int PCS = (T + 8) / 4;
+        for (int i = t0; i < (T + 2 * H) * PCS; i += nthr) {
+            const int r = i / PCS, c4 = (i % PCS) * 4;
+            *(uint2 *)(lds + r * STR + c4) = *(const uint2 *)(p + (ty0 - H + r) * s + tx0 - 4 + c4);
+        }
+        return;
+    }
     // interior: T rows x T/4 pieces of 4 samples.  Pieces inside the CTU are rule-free 8-byte copies; when the CTU is
     // cut by the picture border, the part of the tile beyond it belongs to the window's halo and goes through the rule
     for (int i = t0; i < T * (T / 4); i += nthr) {
