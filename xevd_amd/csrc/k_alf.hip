@@ -229,9 +229,11 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
             if (strength) cls += (((main_dir & 1) << 1) + strength) * 5;
             tr = (0x31322010u >> ((main_dir * 2 + (sec_dir >> 1)) * 4)) & 0xF;  // trans_tbl = {0,1,0,2,2,3,1,3}
         }
+        // coefficient order of the block's transpose index (k_alf_perm) as 13 nibbles of one constant: selects instead of per-lane table loads
+        const uint64_t pk = tr == 0 ? 0xcba9876543210ull : tr == 1 ? 0xc62037b518a49ull : tr == 2 ? 0xcba9456781230ull : 0xc62015b734a89ull;
         int f[13];
 #pragma unroll
-        for (int i = 0; i < 13; i++) f[i] = l_coef[cls * 13 + k_alf_perm[tr][i]];
+        for (int i = 0; i < 13; i++) f[i] = l_coef[cls * 13 + (int)((pk >> (4 * i)) & 15)];
 
         // The filter of alf_filter_blk_7 (xevdm_alf.c:210-337): sum_k f[k] * (S(i+dy_k, j+dx_k) + S(i-dy_k, j-dx_k)) + f[12] * S(i, j), + 256 >> 9.
         // Two neighbouring outputs (j, j+1) at a time: their symmetric sample pairs are PACKED pairs of the window - P(i, c) = (S(i, c),
