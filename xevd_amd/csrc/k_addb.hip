@@ -120,9 +120,11 @@ __global__ __launch_bounds__(256) void k_addb(const AddbArgs a, const int16_t *_
 
     // lane -> edge segment: along the filtered axis the lane index counts grid lines (every second SCU position), across it SCUs
     const int n_ex = DIR == 0 ? (a.w_scu >> 1) + 1 : a.w_scu, n_ey = DIR == 0 ? a.h_scu : (a.h_scu >> 1) + 1;
-    const int tiles_x = (n_ex + 15) >> 4;
+    // a wave = 64 neighbouring segments of one grid row: its loads and stores are 512-byte to 1-KB runs of a picture row (a 16 x 16 lane
+    // tile made them 128-byte pieces of 16 rows: 17 % slower at 8K)
+    const int tiles_x = (n_ex + 63) >> 6;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int ex = (tx << 4) + (threadIdx.x & 15), ey = (ty << 4) + (threadIdx.x >> 4);
+    const int ex = (tx << 6) + (threadIdx.x & 63), ey = (ty << 2) + (threadIdx.x >> 6);
     if (ex >= n_ex || ey >= n_ey) return;
     const int sx = DIR == 0 ? ex << 1 : ex, sy = DIR == 0 ? ey : ey << 1;                 // the Q-side SCU (may lie one past the picture)
     const int step = DIR == 0 ? 1 : a.w_scu;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void k_addb(const AddbArgs a, const int16_t *_
 void launch_addb(xgpu_ctx *c, const AddbArgs &a, int dir, const DevPic &src, const DevPic &dst)
 {
     const int n_ex = dir == 0 ? (a.w_scu >> 1) + 1 : a.w_scu, n_ey = dir == 0 ? a.h_scu : (a.h_scu >> 1) + 1;
-    const int tiles = ((n_ex + 15) >> 4) * ((n_ey + 15) >> 4);
+    const int tiles = ((n_ex + 63) >> 6) * ((n_ey + 3) >> 2);
     if (dir == 0)
         hipLaunchKernelGGL(k_addb<0>, dim3(tiles), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
     else

@@ -85,10 +85,12 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
     for (int i = threadIdx.x; i < 3 * 4 * 64 / 4; i += 256) ((uint32_t *)s_st)[i] = ((const uint32_t *)a.st)[i];
     __syncthreads();
 
-    // 16x16 SCU tile per workgroup (64x64 luma), lanes row-major inside the tile
-    const int tiles_x = (a.w_scu + 15) >> 4;
+    // vertical edges: a wave = 64 neighbouring SCUs of one SCU row (512-byte runs of a picture row), 4 such rows per workgroup - 8 % faster at
+    // 8K than a 16 x 16 lane tile; horizontal edges (8 rows of 8 bytes per lane) measured the other way round and keep the square tile
+    const int LW = DIR == 0 ? 6 : 4, LH = 8 - LW;
+    const int tiles_x = (a.w_scu + (1 << LW) - 1) >> LW;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int sx = (tx << 4) + (threadIdx.x & 15), sy = (ty << 4) + (threadIdx.x >> 4);
+    const int sx = (tx << LW) + (threadIdx.x & ((1 << LW) - 1)), sy = (ty << LH) + (threadIdx.x >> LW);
     if (sx >= a.w_scu || sy >= a.h_scu) return;
     const int step = DIR == 0 ? 1 : a.w_scu;                 // SCU-map step along the filtering axis
     const int pos = DIR == 0 ? sx : sy;                      // coordinate along the filtering axis
@@ -253,7 +255,7 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
 
 void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst)
 {
-    const int tiles = ((a.w_scu + 15) >> 4) * ((a.h_scu + 15) >> 4);
+    const int tiles = dir == 0 ? ((a.w_scu + 63) >> 6) * ((a.h_scu + 3) >> 2) : ((a.w_scu + 15) >> 4) * ((a.h_scu + 15) >> 4);
     if (dir == 0)
         hipLaunchKernelGGL(k_dbk<0>, dim3(tiles), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
     else
