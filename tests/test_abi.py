@@ -56,3 +56,14 @@ def test_no_cpu_fallback_in_product_package():
             if f.endswith((".py", ".hip", ".h", ".c", ".cpp")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "liboracle" not in txt and "xevd_oracle" not in txt and "oracle_lib" not in txt, f
+
+
+def test_plain_c_example_is_built():
+    """examples/evc_decode (plain C over include/xevd_host.h + include/xevd_hip.h) links against both libraries; without arguments it only
+    prints its usage (no GPU needed)"""
+    import subprocess
+    exe = os.path.join(ROOT, "examples", "evc_decode")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
+    r = subprocess.run([exe], stderr=subprocess.PIPE, timeout=30)
+    assert r.returncode == 2 and b"usage" in r.stderr

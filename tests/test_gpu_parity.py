@@ -276,3 +276,22 @@ def test_gpu_decoder_survives_mutated_streams():
     for k in range(len(ours)):
         for c in range(3):
             assert np.array_equal(ours[k][c], d[f"p{k}_{c}"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["hier_b_gop4", "main_eipd_all_tools_10b", "cqt_crop_10b", "idr_period_skip"])
+def test_gpu_plain_c_decoder(name, tmp_path):
+    """examples/evc_decode - a decoder in plain C on the two C ABIs, no Python in the loop - writes the reference decoder's pictures"""
+    import subprocess
+    exe = os.path.normpath(os.path.join(golden_io.GOLDEN, "..", "..", "examples", "evc_decode"))
+    assert os.path.exists(exe), "examples/evc_decode is not built (python -c 'import __graft_entry__ as g; g.build()')"
+    d = np.load(os.path.join(golden_io.GOLDEN, f"stream_{name}.npz"))
+    src, dst = tmp_path / "s.evc", tmp_path / "s.yuv"
+    src.write_bytes(d["bytes"].tobytes())
+    r = subprocess.run([exe, str(src), str(dst)], stderr=subprocess.PIPE, timeout=120)
+    assert r.returncode == 0, r.stderr.decode()[-300:]
+    w, h = (int(v) for v in d["size"])
+    ten_bit = int(d["p0_0"].max()) > 255 or "10b" in name
+    got = np.fromfile(dst, "<u2" if ten_bit else np.uint8)
+    expect = np.concatenate([d[f"p{k}_{c}"].ravel() for k in range(int(d["n"])) for c in range(3)])
+    assert got.size == expect.size and np.array_equal(got.astype(np.int32), expect.astype(np.int32))
