@@ -170,7 +170,10 @@ __device__ __forceinline__ int eipd_sample(const int16_t *A, const EipdPlan &k, 
     return clip3i(0, maxv, (r0 * (32 - o) + r1 * (64 - o) + r2 * (32 + o) + r3 * o + 64) >> 7);
 }
 
-#define INTRA_WAVES 4        // waves (= CUs in flight) per workgroup; INTRA_CHUNK (xgpu_internal.h) list positions per workgroup, interleaved
+// waves (= CUs in flight) per workgroup = INTRA_CHUNK list positions per ticket.  Measured at 8K (chunk, waves): (8, 4) 81 us, (4, 4) 72, (2, 2) 83,
+// (1, 1) 106, (8, 8) 68, (12, 12) 69, (16, 16) 70: one pass per workgroup (no CU waits behind another one of its workgroup) and few tickets
+// (the counter is one contended atomic)
+#define INTRA_WAVES 8
 
 __device__ __forceinline__ void wave_lds_sync()      // LDS traffic of one wave is processed in order: only the compiler needs the fence
 {

@@ -109,7 +109,7 @@ struct __attribute__((aligned(16))) IntraRec {
     uint32_t coef_off;
 };
 static_assert(sizeof(IntraRec) == 48, "IntraRec must be 48 bytes");
-#define INTRA_CHUNK 8         // list positions one workgroup of the data-flow intra kernel handles (4 waves x 2)
+#define INTRA_CHUNK 8         // list positions one workgroup of the data-flow intra kernel handles = its 8 waves, one CU each
 struct IntraArgs {
     int16_t *cur_y, *cur_u, *cur_v;
     int      s_l, s_c;
