@@ -68,6 +68,10 @@ typedef struct xhost_picture {
 xhost_parser *xhost_parser_open(const uint8_t *bytes, size_t size);
 /* 1: `out` holds the next picture in decoding order; 0: end of stream; < 0: error */
 int  xhost_parser_next(xhost_parser *p, xhost_picture *out);
+/* The same parser fed one NAL unit at a time (2-byte NAL header + payload, no length prefix - what xevd_decode receives):
+   1: `out` holds a picture (has_md5 is 0: a signature SEI arrives as its own NAL unit); 0: consumed; < 0: error */
+xhost_parser *xhost_parser_open_nal(void);
+int  xhost_parser_nal(xhost_parser *p, const uint8_t *nal, size_t size, xhost_picture *out);
 const char *xhost_parser_error(const xhost_parser *p);
 void xhost_parser_close(xhost_parser *p);
 

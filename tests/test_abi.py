@@ -67,3 +67,13 @@ def test_plain_c_example_is_built():
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples")])
     r = subprocess.run([exe], stderr=subprocess.PIPE, timeout=30)
     assert r.returncode == 2 and b"usage" in r.stderr
+
+
+def test_public_api_library_exports_the_reference_entry_points():
+    """libxevd_amd_api.so (xevd_amd/compat, built where the reference's public header is) exports the six functions of inc/xevd.h:369-374"""
+    lib_path = os.path.join(ROOT, "xevd_amd", "libxevd_amd_api.so")
+    if not os.path.exists(lib_path):
+        pytest.skip("libxevd_amd_api.so is built only in the development container")
+    lib = C.CDLL(lib_path)
+    for name in ("xevd_create", "xevd_delete", "xevd_decode", "xevd_pull", "xevd_config", "xevd_info"):
+        assert hasattr(lib, name), name

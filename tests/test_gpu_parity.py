@@ -295,3 +295,46 @@ def test_gpu_plain_c_decoder(name, tmp_path):
     got = np.fromfile(dst, "<u2" if ten_bit else np.uint8)
     expect = np.concatenate([d[f"p{k}_{c}"].ravel() for k in range(int(d["n"])) for c in range(3)])
     assert got.size == expect.size and np.array_equal(got.astype(np.int32), expect.astype(np.int32))
+
+
+APP_ON_HIP = os.path.normpath(os.path.join(golden_io.GOLDEN, "..", "..", "oracle", "_ref", "xevd_app_on_hip"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,args", [("hier_b_gop8_10b", ["--output-bit-depth", "10"]), ("main_eipd_all_tools_10b", ["--output-bit-depth", "10"]),
+                                       ("main_all_tools_10b", []), ("signed_main_alf_10b", ["-s", "--output-bit-depth", "10"])])
+def test_gpu_reference_application_on_our_api(name, args, tmp_path):
+    """The reference's OWN sample application (app/xevd_app.c, compiled from its source where it lies) linked against libxevd_amd_api.so - this
+    repository's implementation of the public xevd_create / xevd_decode / xevd_pull API - instead of libxevd: it decodes the golden streams on
+    the GPU and writes the reference decoder's pictures (16-bit copy, or its own 10 -> 8 bit conversion), and verifies the MD5 SEIs with -s."""
+    import subprocess
+    import oracle_lib as ol
+    if not os.path.exists(APP_ON_HIP):
+        pytest.skip("oracle/_ref/xevd_app_on_hip is built only where the reference sources are (development container)")
+    d = np.load(os.path.join(golden_io.GOLDEN, f"stream_{name}.npz"))
+    src, dst = tmp_path / "s.evc", tmp_path / "s.yuv"
+    src.write_bytes(d["bytes"].tobytes())
+    r = subprocess.run([APP_ON_HIP, "-i", str(src), "-o", str(dst)] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode == 0, r.stdout.decode()[-400:]
+    pics = [[d[f"p{k}_{c}"] for c in range(3)] for k in range(int(d["n"]))]
+    if "--output-bit-depth" in args:
+        got = np.fromfile(dst, "<u2")
+        expect = np.concatenate([p.ravel() for pic in pics for p in pic]).astype(np.uint16)
+    else:
+        got = np.fromfile(dst, np.uint8)
+        expect = np.concatenate([ol.output_convert(pic, 10, 8) for pic in pics])
+    assert got.size == expect.size and np.array_equal(got, expect)
+
+
+@pytest.mark.gpu
+def test_gpu_reference_application_rejects_bad_signature(tmp_path):
+    import subprocess
+    if not os.path.exists(APP_ON_HIP):
+        pytest.skip("oracle/_ref/xevd_app_on_hip is not built")
+    d = np.load(os.path.join(golden_io.GOLDEN, "stream_signed_main_alf_10b.npz"))
+    bad = bytearray(d["bytes"].tobytes())
+    bad[len(bad) - 3] ^= 0x40                          # inside the last SEI's V-plane digest
+    src = tmp_path / "s.evc"
+    src.write_bytes(bytes(bad))
+    r = subprocess.run([APP_ON_HIP, "-i", str(src), "-s"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode != 0 and b"MD5 check mismatch" in r.stdout

@@ -1046,6 +1046,35 @@ extern "C" xhost_parser *xhost_parser_open(const uint8_t *bytes, size_t size)
 extern "C" const char *xhost_parser_error(const xhost_parser *p) { return p ? p->err.c_str() : "null parser"; }
 extern "C" void xhost_parser_close(xhost_parser *p) { delete p; }
 
+// one NAL unit (2-byte header + payload, no length prefix): 1 = `out` holds a picture, 0 = consumed without a picture, < 0 error
+static int parser_nal(xhost_parser *p, const uint8_t *nal, size_t len, xhost_picture *out, bool peek_signature)
+{
+    if (len < 2) return p->fail("bad NAL length");
+    BitReader br;
+    br.p = nal; br.size = len;
+    if (br.get1()) return p->fail("forbidden_zero_bit");
+    const int nut = (int)br.get(6) - 1, tid = (int)br.get(3);
+    if (br.get(5) != 0 || br.get1() != 0) return p->fail("reserved NAL header bits");
+    if (nut == NUT_SPS) return p->parse_sps(br);
+    if (nut == NUT_PPS) return p->parse_pps(br);
+    if (nut == NUT_IDR || nut == NUT_NONIDR) {
+        const int rc = p->parse_slice(br, nut, tid, out);
+        if (rc == 1) { out->has_md5 = 0; if (peek_signature) p->attach_signature(out); }
+        return rc;
+    }
+    if (nut == 26) {                                     // APS (xevdm_eco_aps_gen, xevdm_eco.c:2082-2135)
+        const int id = (int)br.get(5), type = (int)br.get(3);
+        if (type != 0) return p->fail("only ALF parameter sets (APS type 0) are supported");
+        AlfAps a;
+        if (!p->st.alf_aps_syntax<false>(&br, nullptr, a)) return p->fail("bad or unsupported ALF APS (fixed filter sets are not supported)");
+        a.valid = true;
+        p->st.alf_aps[id] = a;
+        return XGPU_OK;
+    }
+    if (nut == NUT_SEI || nut == 27) return XGPU_OK;     // SEI (picture signatures are the caller's to check), filler data
+    return p->fail("unsupported NAL unit type");
+}
+
 extern "C" int xhost_parser_next(xhost_parser *p, xhost_picture *out)
 {
     if (!p || !out) return XGPU_ERR_INVALID_ARGUMENT;
@@ -1053,33 +1082,19 @@ extern "C" int xhost_parser_next(xhost_parser *p, xhost_picture *out)
         const uint8_t *d = p->data.data() + p->pos;
         const size_t len = ((size_t)d[0] << 24) | ((size_t)d[1] << 16) | ((size_t)d[2] << 8) | d[3];
         if (len < 2 || p->pos + 4 + len > p->data.size()) return p->fail("bad NAL length");
-        BitReader br;
-        br.p = d + 4; br.size = len;
         p->pos += 4 + len;
-        if (br.get1()) return p->fail("forbidden_zero_bit");
-        const int nut = (int)br.get(6) - 1, tid = (int)br.get(3);
-        if (br.get(5) != 0 || br.get1() != 0) return p->fail("reserved NAL header bits");
-        int rc = XGPU_OK;
-        if (nut == NUT_SPS) rc = p->parse_sps(br);
-        else if (nut == NUT_PPS) rc = p->parse_pps(br);
-        else if (nut == NUT_IDR || nut == NUT_NONIDR) {
-            rc = p->parse_slice(br, nut, tid, out);
-            if (rc == 1) p->attach_signature(out);
-            return rc;
-        }
-        else if (nut == 26) {                            // APS (xevdm_eco_aps_gen, xevdm_eco.c:2082-2135)
-            const int id = (int)br.get(5), type = (int)br.get(3);
-            if (type != 0) return p->fail("only ALF parameter sets (APS type 0) are supported");
-            AlfAps a;
-            if (!p->st.alf_aps_syntax<false>(&br, nullptr, a)) return p->fail("bad or unsupported ALF APS (fixed filter sets are not supported)");
-            a.valid = true;
-            p->st.alf_aps[id] = a;
-        }
-        else if (nut == NUT_SEI) rc = XGPU_OK;          // picture signatures are checked by the caller against its own output if wanted
-        else return p->fail("unsupported NAL unit type");
+        const int rc = parser_nal(p, d + 4, len, out, true);
         if (rc != XGPU_OK) return rc;
     }
     return 0;
+}
+
+// NAL-at-a-time interface (what xevd_decode takes: one NAL unit without its length prefix, src_base/xevd.c:1786-2024)
+extern "C" xhost_parser *xhost_parser_open_nal(void) { return new xhost_parser(); }
+extern "C" int xhost_parser_nal(xhost_parser *p, const uint8_t *nal, size_t size, xhost_picture *out)
+{
+    if (!p || !nal || !out) return XGPU_ERR_INVALID_ARGUMENT;
+    return parser_nal(p, nal, size, out, false);
 }
 
 // =============================================================================================================== writer
