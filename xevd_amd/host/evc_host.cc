@@ -840,10 +840,10 @@ struct xhost_parser {
             unsupported |= br.get1();                    // tool_htdf
             rpl = br.get1(); pocs = br.get1();
             unsupported |= rpl | pocs;
-            br.get1();                                   // dquant_flag (only matters with cu_qp_delta_area handling; plain dqp otherwise)
+            unsupported |= br.get1();                    // dquant_flag: the Main decoder then codes QP deltas per cu_qp_delta_area (xevdm_eco.c), not per CU
             unsupported |= br.get1();                    // tool_dra
         }
-        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, admvp, ibc, cm_init, htdf, rpl, pocs, dra)");
+        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, admvp, ibc, cm_init, htdf, rpl, pocs, dquant in Main, dra)");
         s.log2_sub_gop = (int)br.ue();                   // tool_rpl = tool_pocs = 0
         if (s.log2_sub_gop == 0) s.log2_ref_gap = (int)br.ue();
         if (s.log2_sub_gop > 5) return fail("bad SPS");
