@@ -100,7 +100,8 @@ int main(int argc, char **argv)
             outs = (out_t *)realloc(outs, sizeof(out_t) * (cap / frame_bytes));
             if (!frames || !outs) return 1;
         }
-        CHECK(xgpu_pic_output(g, cur, NULL, out_bd_arg ? out_bd_arg : p.bit_depth_luma, 0, 0, 0, 0, frames + (size_t)n_pics * frame_bytes, frame_bytes));
+        xgpu_dra_luts dra = { p.dra_lut[0], { p.dra_lut[1], p.dra_lut[2] } };          /* the DRA post-filter, when the PPS switches it on */
+        CHECK(xgpu_pic_output(g, cur, p.dra_lut[0] ? &dra : NULL, out_bd_arg ? out_bd_arg : p.bit_depth_luma, 0, 0, 0, 0, frames + (size_t)n_pics * frame_bytes, frame_bytes));
         outs[n_pics].epoch = epoch; outs[n_pics].poc = p.poc; outs[n_pics].off = (size_t)n_pics * frame_bytes;
         n_pics++;
 

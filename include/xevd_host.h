@@ -15,6 +15,7 @@
  * Scope: Baseline profile, and Main-profile streams that switch on only tools of the back half - sps->tool_iqt, tool_ats,
  * tool_addb (syntax of src_main/xevdm_eco.c: SPS :1847-2004, slice header :2510-2800, ATS flags :128-190,354-393,902-934) -
  * tool_eipd (intra mode syntax src_base/xevd_eco.c:842-910, most-probable-mode lists src_main/xevdm_ipred.c:320-767)
+ * tool_dra (DRA APS NAL units src_main/xevdm_eco.c:2319-2375, PPS switch :2054-2060, table construction src_main/xevdm_dra.c:39-270)
  * and tool_alf (APS NAL units :2082-2135,2376-2477, coefficient syntax :2154-2318, slice-level parameters :2479-2657, per-CTU flags
  * src_main/xevdm.c:2411-2418; coefficient reconstruction alf_recon_coef src_main/xevdm_alf.c:700-794; fixed filter sets are not
  * supported yet) - with every other Main tool off; SPS chroma QP mapping tables and cropping offsets are parsed, a VUI is skipped (the CU syntax is then the Baseline one); 4:2:0, one tile and one slice per picture,
@@ -56,6 +57,8 @@ typedef struct xhost_picture {
     int tool_eipd;                         /* sps->tool_eipd: batch.ipm holds Main mode numbers, xgpu_seq_params.tool_eipd must be set      */
     int crop[4];                           /* sps picture_crop_left / right / top / bottom_offset, what xevd_pull puts in the XEVD_IMGB      */
     const int8_t *chroma_qp_table[2];      /* SPS chroma QP mapping tables in xgpu_seq_params.chroma_qp_table layout, NULL = sequence default */
+    const int32_t *dra_lut[3];             /* sps->tool_dra + pps.pic_dra_enabled_flag: the tables xgpu_pic_output takes (xgpu_dra_luts: luma, Cb, Cr; 1024
+                                              entries each), built as xevd_init_dra does from the DRA parameter set; NULL: no DRA for this picture  */
     int alf_on;                            /* sh.alf_on: `alf` below is what xgpu_alf takes (final coefficients, CTB flags)      */
     xgpu_alf_params alf;
     int has_md5;                           /* a picture-signature SEI follows the slice: MD5 of every plane's 16-bit samples    */
@@ -91,6 +94,7 @@ typedef struct xhost_stream_params {
     int tool_eipd;                         /* sps->tool_eipd: ipm[0] = luma mode 0..32, ipm[1] = chroma mode 0..4 (a chroma mode equal to what DM
                                               stands for is written as DM)                                            */
     int crop[4];                           /* picture cropping offsets left / right / top / bottom (all 0: no cropping)  */
+    int tool_dra, dra_aps_id;              /* sps->tool_dra; the PPS then switches DRA on for every picture with this parameter set id */
     /* chroma_qp_table_struct of the SPS (xevd_eco.c:1361-1376): pivot points of the chroma QP mapping */
     int cqt_present, cqt_same, cqt_global_offset;
     int cqt_num_points[2];                 /* 1..16 per table                                                        */
@@ -110,6 +114,15 @@ typedef struct xhost_alf_aps {
     int16_t luma_coef[25][12];             /* coded values (differences with pred_mode_flag)                        */
     int16_t chroma_coef[6];
 } xhost_alf_aps;
+/* DRA parameter set as an APS NAL unit of type 1 carries it (SIG_PARAM_DRA, src_main/xevdm_dra.h:76-89; descriptors 4.9 fixed point) */
+typedef struct xhost_dra_aps {
+    int aps_id;                            /* 0..31                                                                  */
+    int num_ranges;                        /* 1..32                                                                  */
+    int in_ranges[33];                     /* luma range borders, increasing, in_ranges[0] >= 1, steps <= 1023          */
+    int scale[32];                         /* dra_scale_value per range, 4.9 fixed point (512 = 1.0)                  */
+    int cb_scale, cr_scale;                /* dra_cb_scale_value / dra_cr_scale_value                                 */
+    int table_idx;                         /* dra_table_idx 0..58 (58: chroma scales taken as they are)               */
+} xhost_dra_aps;
 /* slice-level ALF parameters of the NEXT picture (sh.alf_on, aps ids, CTB map) */
 typedef struct xhost_slice_alf {
     int alf_on, aps_id_y, aps_id_ch, chroma_idc;      /* chroma_idc: bit 0 Cb, bit 1 Cr                              */
@@ -118,6 +131,7 @@ typedef struct xhost_slice_alf {
 } xhost_slice_alf;
 
 xhost_writer *xhost_writer_open(const xhost_stream_params *sp);
+int  xhost_writer_add_dra_aps(xhost_writer *w, const xhost_dra_aps *aps);       /* appends a DRA APS NAL unit (needs tool_dra), before the pictures */
 int  xhost_writer_add_alf_aps(xhost_writer *w, const xhost_alf_aps *aps);       /* appends an APS NAL unit (needs tool_alf)    */
 int  xhost_writer_set_slice_alf(xhost_writer *w, const xhost_slice_alf *sa);    /* for the next xhost_writer_add_picture       */
 /* Appends one picture (SPS + PPS first when it is the first).  `b`: leaf CUs of a quad tree (64..4) in decode order with the

@@ -154,6 +154,7 @@ def golden_streams(only=()):
                                 # every picture followed by a picture-signature SEI (MD5s of the oracle's reconstruction, VERIFIED by the
                                 # reference decoder while it produced the pictures below)
                                 "cqt_crop_10b": (144, 88, 5, dict(bit_depth=10, chroma_qp_points=(0, [[(30, 0), (10, -4), (15, -6)], [(25, 1), (6, -2), (30, -10)]]), max_refs=2, crop=(2, 4, 0, 6), qp_offsets=(1, -1))),
+                                "main_dra_10b": (144, 88, 5, dict(main=True, iqt=True, bit_depth=10, dra="five_ranges_idx40", addb=True, log2_sub_gop=2, max_refs=2)),
                                 "main_eipd_i_8b": (136, 120, 2, dict(main=True, eipd=True, idr_period=1, split_prob=0.7)),
                                 "main_eipd_all_tools_10b": (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, inter_frac=0.5, log2_sub_gop=2, max_refs=2, bit_depth=10)),
                                 "signed_hier_b_8b": (136, 120, 5, dict(log2_sub_gop=2, max_refs=2, sign=True)),

@@ -26,16 +26,20 @@ def gop_tids(log2_sub_gop):
 def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_frac=0.15, inter_frac=0.85, deblock=True, qp_offsets=(0, 0),
                 cu_qp_delta=True, split_prob=0.5, idr_period=0, log2_sub_gop=0, bi_frac=0.5, direct_frac=0.1,
                 main=False, iqt=False, ats=False, addb=False, addb_offsets=(0, 0), alf=False, sign=False, eipd=False, crop=(0, 0, 0, 0),
-                chroma_qp_points=None):
+                chroma_qp_points=None, dra=None):
     """-> bytes.  Picture 0 is an IDR.  log2_sub_gop = 0: IPPP; n: hierarchical sub-GOPs of 2^n pictures, the layer-0 picture of
     each a P picture, the others B pictures (bi-prediction, temporal direct and two-list skip CUs).
     sign: every picture is followed by a picture-signature SEI with the MD5s of the ORACLE's reconstruction of the stream so far."""
     rng = np.random.default_rng(seed)
     w = stream.StreamWriter(width, height, bit_depth, max_refs, qp_offsets[0], qp_offsets[1], deblock, cu_qp_delta, log2_sub_gop,
-                            main=main, iqt=iqt, ats=ats, addb=addb, alpha_off=addb_offsets[0], beta_off=addb_offsets[1], alf=alf, eipd=eipd, crop=crop, chroma_qp_points=chroma_qp_points)
+                            main=main, iqt=iqt, ats=ats, addb=addb, alpha_off=addb_offsets[0], beta_off=addb_offsets[1], alf=alf, eipd=eipd, crop=crop, chroma_qp_points=chroma_qp_points,
+                            dra_aps_id=None if dra is None else 3)
     n_ctu = ((width + 63) // 64) * ((height + 63) // 64)
     tids = gop_tids(log2_sub_gop)
     try:
+        if dra is not None:      # one of oracle_lib.DRA_SETS: the PPS switches DRA on for every picture with parameter set 3
+            d = ol.DRA_SETS[dra]
+            w.add_dra_aps(3, d["in_ranges"], d["scales"], d["cb"], d["cr"], d["table_idx"])
         since_idr = 0
         for k in range(n_pics):
             idr = k == 0 or (idr_period and k % idr_period == 0)
@@ -143,7 +147,10 @@ def decode_oracle(data, order="output"):
             dpb.pop(poc, None)
         if p["is_ref"]:
             dpb[p["poc"]] = cur
-        out.append((p, [cur.active(c).copy() for c in range(3)]))
+        planes = [cur.active(c).copy() for c in range(3)]
+        if p["dra"] is not None:      # the post-filter runs on the OUTPUT copy only (xevd_pull), references stay unmapped
+            planes = ol.dra_apply(planes, p["dra"])
+        out.append((p, planes))
     if order == "decoding":
         return [planes for _, planes in out]
     return _output_order(out)

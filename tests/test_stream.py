@@ -43,6 +43,10 @@ CONFIGS = [
     (136, 72, 4, dict(chroma_qp_points=(1, [[(4, 0), (5, -2), (9, -5), (20, -3)]]), qp_offsets=(2, -3))),
     (144, 88, 5, dict(bit_depth=10, chroma_qp_points=(0, [[(30, 0), (10, -4), (15, -6)], [(25, 1), (6, -2), (30, -10)]]), max_refs=2, crop=(2, 4, 0, 6))),
     (136, 72, 4, dict(main=True, iqt=True, addb=True, chroma_qp_points=(1, [[(10, -1), (12, -6)]]), qp_offsets=(-2, 1))),
+    # DRA: parameter sets in APS NAL units of type 1, switched on by the PPS; the reference applies the post-filter when it outputs a picture
+    (136, 72, 4, dict(main=True, iqt=True, bit_depth=10, dra="three_ranges_idx58", max_refs=2)),
+    (144, 88, 5, dict(main=True, bit_depth=10, dra="five_ranges_idx40", addb=True, log2_sub_gop=2, max_refs=2)),
+    (136, 72, 3, dict(main=True, iqt=True, bit_depth=10, dra="one_range_idx30", chroma_qp_points=(1, [[(10, -1), (12, -6)]]), qp_offsets=(-2, 1))),
     # ... and EIPD: 33 luma / 5 chroma intra modes with their most-probable-mode syntax, all-intra and mixed pictures
     (136, 72, 2, dict(main=True, eipd=True, idr_period=1, split_prob=0.8)),
     (200, 136, 5, dict(main=True, eipd=True, inter_frac=0.4, max_refs=2)),

@@ -164,7 +164,13 @@ int decode_picture(Decoder *d, const xhost_picture &p, Image **out)
     g.pdata[0] = im;
     if (p.crop[0] | p.crop[1] | p.crop[2] | p.crop[3]) { g.crop_idx = 1; g.crop_l = p.crop[0]; g.crop_r = p.crop[1]; g.crop_t = p.crop[2]; g.crop_b = p.crop[3]; }
     g.imgb_active_aps_id = -1;
-    rc = xgpu_pic_download(d->g, cur, pl[0], w, pl[1], pl[2], w / 2);
+    if (p.dra_lut[0] && p.bit_depth_luma > 8) {
+        // xevd_pull_frm hands out a DRA-mapped COPY of the picture (src_main/xevdm.c:3376-3383): the output kernel applies the tables and packs the
+        // planes exactly in this image's layout (16-bit samples, tight rows)
+        const xgpu_dra_luts dra = { p.dra_lut[0], { p.dra_lut[1], p.dra_lut[2] } };
+        rc = xgpu_pic_output(d->g, cur, &dra, p.bit_depth_luma, 0, 0, 0, 0, im->mem.data(), im->mem.size() * sizeof(int16_t));
+    } else
+        rc = xgpu_pic_download(d->g, cur, pl[0], w, pl[1], pl[2], w / 2);
     if (rc < 0) { delete im; return rc; }
 
     for (int r = 0; r < p.n_release; r++)

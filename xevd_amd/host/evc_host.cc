@@ -217,10 +217,10 @@ enum { MODE_INTRA = XGPU_MODE_INTRA, MODE_INTER = XGPU_MODE_INTER, MODE_SKIP = X
 
 // ------------------------------------------------------------------------------------------------ stream / picture state
 struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, log2_ref_gap = 0, max_num_ref_pics = 1;
-             int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0, tool_alf = 0, tool_eipd = 0;
+             int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0, tool_alf = 0, tool_eipd = 0, tool_dra = 0;
              int crop[4] = { 0, 0, 0, 0 };            // picture_crop_left / right / top / bottom_offset (xevd_eco.c:1349-1357), as xevd_pull reports them
              bool cqt = false; int8_t cq[2][70] = { { 0 } }; };      // chroma QP mapping tables signalled in the SPS: [c][qp + 6*(bd_c-8)], qp = -6*(bd_c-8) .. 57
-struct Pps { int constrained_intra = 0, cu_qp_delta = 0; };
+struct Pps { int constrained_intra = 0, cu_qp_delta = 0, dra_on = 0, dra_aps_id = 0; };
 struct Slice { int type = XHOST_SLICE_I, qp = 32, qp_u_offset = 0, qp_v_offset = 0, deblock = 1, alpha_off = 0, beta_off = 0;
                int alf_on = 0, aps_id_y = 0, aps_id_ch = 0, alf_chroma_idc = 0, alf_ctb_map = 0; };
 
@@ -297,6 +297,83 @@ struct Batch {           // the xgpu_cu_batch under construction
     void clear() { x.clear(); y.clear(); log2w.clear(); log2h.clear(); pred_mode.clear(); qp.clear(); cbf.clear(); ipm.clear(); ats.clear(); ats_inter.clear(); refi.clear(); mv.clear(); coef.clear(); coef_off.clear(); ctu_start.clear(); }
 };
 
+// ---- DRA parameter sets (APS type 1, SIG_PARAM_DRA) and the inverse-mapping tables the output stage applies (src_main/xevdm_dra.c) ----
+struct DraAps { bool valid = false; int num_ranges = 0, in_ranges[33] = { 0 }, scale[32] = { 0 }, cb_scale = 0, cr_scale = 0, table_idx = 0; };
+// approximations of log / exp at 9 fractional bits used by the chroma scale correction (constants of the specification, src_main/xevdm_tbl.c:410-421)
+static const int k_dra_log_tbl[55] = { 0, 1, 1, 1, 1, 1, 2, 2, 3, 4, 4, 6, 7, 9, 11, 14, 18, 23, 29, 36, 45, 57, 72, 91, 114, 144, 181, 228, 287, 362, 456, 575, 724, 912, 1149,
+                                       1448, 1825, 2299, 2896, 3649, 4598, 5793, 7298, 9195, 11585, 14596, 18390, 23170, 29193, 36781, 46341, 58386, 73562, 92682, 116772 };
+static const int k_dra_exp_tbl[25] = { 128, 144, 161, 181, 203, 228, 256, 287, 322, 362, 406, 456, 512, 574, 645, 724, 812, 912, 1024, 1149, 1290, 1448, 1625, 1825, 2048 };
+static int dra_range_idx(int sample, const int *ranges, int n)           // xevd_get_dra_range_idx_gen: first i with sample < ranges[i + 1], else n - 1
+{
+    for (int i = 0; i < n - 1; i++) if (sample < ranges[i + 1]) return i;
+    return n - 1;
+}
+// luts: [3][1024] = luma_inv_scale_lut, int_chroma_inv_scale_lut[Cb], [Cr] of DRA_CONTROL after xevd_init_dra (xevdm_dra.c:39-270).
+// cq[c] + off = the sequence's chroma QP mapping (xevd_qp_chroma_dynamic[c]), indexable from -off.
+static void dra_build_luts(const DraAps &a, int bd, const int8_t *cq_u, const int8_t *cq_v, int off, int32_t *luts)
+{
+    const int n = a.num_ranges;
+    int out[34] = { 0 }, inv_scale[32], inv_off[32], cinv[2][32];
+    for (int i = 1; i <= n; i++) out[i] = out[i - 1] + (a.in_ranges[i] - a.in_ranges[i - 1]) * a.scale[i - 1];       // xevd_construct_dra
+    for (int i = 0; i < n; i++) {
+        const int sc = a.scale[i] ? a.scale[i] : 1;
+        inv_scale[i] = ((1 << 18) + (sc >> 1)) / sc;
+        inv_off[i] = (int)((((int64_t)a.in_ranges[i + 1] << 18) - (int64_t)out[i + 1] * inv_scale[i] + (1 << 8)) >> 9);
+    }
+    for (int i = 0; i <= n; i++) out[i] = (out[i] + (1 << 8)) >> 9;
+    auto scaled_qp = [&](int ch, int qp) { qp = std::min(std::max(qp, -off), 57); return (int)(ch == 1 ? cq_u : cq_v)[qp]; };   // xevd_get_scaled_chroma_qp2
+    for (int i = 0; i < n; i++)
+        for (int ch = 1; ch <= 2; ch++) {                            // xevd_correct_local_chroma_scale (:83-163)
+            const int base = ch == 1 ? a.cb_scale : a.cr_scale;
+            int cs;
+            if (a.table_idx == 58) cs = base;
+            else {
+                const int scale_dra = base * a.scale[i];
+                const int shift1 = a.table_idx - scaled_qp(ch, a.table_idx);
+                const int s9 = (scale_dra + (1 << 8)) >> 9;
+                const int idx = dra_range_idx(s9, k_dra_log_tbl, 54);
+                const int num = s9 - k_dra_log_tbl[idx], den = k_dra_log_tbl[idx + 1] - k_dra_log_tbl[idx];
+                int qp_int = 2 * idx - 60, qp_frac = 0;
+                if (num == 0) qp_int -= 1;
+                else { qp_frac = 512 * (num << 1) / den; qp_int += qp_frac / 512; qp_frac = 512 - (qp_frac % 512); }
+                const int local_qp = a.table_idx - qp_int;
+                const int q0 = scaled_qp(ch, std::min(std::max(local_qp, -off), 57)), q1 = scaled_qp(ch, std::min(std::max(local_qp + 1, -off), 57));
+                const int dec = (q1 - q0) * qp_frac;
+                int frac_adj = qp_frac - dec % 512;
+                int shift = (local_qp - q0 - (dec >> 9)) - shift1;
+                if (frac_adj < 0) { shift -= 1; frac_adj += 512; }
+                const int sc = std::min(std::max(shift, -12), 12);
+                const int e0 = k_dra_exp_tbl[sc + 12];
+                const int de = shift >= 0 ? k_dra_exp_tbl[std::min(std::max(shift + 1, -12), 12) + 12] - e0 : e0 - k_dra_exp_tbl[std::min(std::max(shift - 1, -12), 12) + 12];
+                const int out_scale = e0 + ((de * frac_adj + (1 << 8)) >> 9);
+                cs = (int)(((int64_t)scale_dra * out_scale + (1 << 17)) >> 18);
+            }
+            if (cs == 0) cs = 1;
+            cinv[ch - 1][i] = ((1 << 18) + (cs >> 1)) / cs;          // xevd_compensate_chroma_shift_table
+        }
+    for (int v = 0; v < 1024; v++) {                                 // xevd_build_dra_luma_lut
+        const int r = dra_range_idx(v, out, n);
+        luts[v] = std::min(std::max((inv_off[r] + v * inv_scale[r] + (1 << 8)) >> 9, 0), 1023);
+    }
+    for (int ch = 0; ch < 2; ch++) {                                 // xevd_build_dra_chroma_lut
+        int r2[35] = { 0 }, msc[34], mof[34];
+        r2[0] = out[0];
+        for (int i = 1; i <= n; i++) r2[i] = (out[i - 1] + out[i]) / 2;
+        msc[0] = 0; mof[0] = cinv[ch][0];
+        for (int i = 1; i < n; i++) {
+            const int delta = r2[i + 1] - r2[i];
+            mof[i] = cinv[ch][i - 1];
+            msc[i] = delta ? (((cinv[ch][i] - mof[i]) << bd) + (delta >> 1)) / delta : 0;
+        }
+        msc[n] = 0; mof[n] = cinv[ch][n - 1];
+        for (int v = 0; v < 1024; v++) {
+            int r = n;                                               // (the reference scans n + 1 ranges; past the last pivot the index is n)
+            for (int i = 0; i < n; i++) if (v < r2[i + 1]) { r = i; break; }
+            luts[(1 + ch) * 1024 + v] = mof[r] + ((msc[r] * (v - r2[r]) + (1 << (bd - 1))) >> bd);
+        }
+    }
+}
+
 struct Stream {          // everything both directions share
     Sps sps;
     Pps pps;
@@ -309,6 +386,8 @@ struct Stream {          // everything both directions share
     bool have_sps = false, have_pps = false;
     std::vector<uint16_t> scan[6][6];      // zig-zag tables by log2 size - 1
     AlfAps alf_aps[32];
+    DraAps dra_aps[32];
+    int32_t dra_luts[3 * 1024];            // of the current picture (when the PPS switches DRA on)
     std::vector<uint8_t> alf_ctb_flag;     // luma CTB flags: all on at the start of a picture (xevdm.c:3001-3005), coded ones overwrite (:2411-2418)
     int16_t alf_luma_final[25][13], alf_chroma_final[7];
 
@@ -823,7 +902,7 @@ struct xhost_parser {
         s.width = (int)br.ue(); s.height = (int)br.ue();
         s.bd_l = (int)br.ue() + 8; s.bd_c = (int)br.ue() + 8;
         int unsupported = 0, rpl = 0, pocs = 0;
-        s.tool_iqt = s.tool_ats = s.tool_addb = s.tool_alf = s.tool_eipd = 0;
+        s.tool_iqt = s.tool_ats = s.tool_addb = s.tool_alf = s.tool_eipd = s.tool_dra = 0;
         if (!s.profile_main) {
             for (int i = 0; i < 13; i++) { const int f = br.get1(); if (i != 11) unsupported |= f; }      // btt suco admvp eipd cm_init iqt addb alf htdf rpl pocs dquant dra
         } else {                                          // xevdm_eco_sps, xevdm_eco.c:1863-1937: sub-flags follow their tool flag
@@ -841,9 +920,9 @@ struct xhost_parser {
             rpl = br.get1(); pocs = br.get1();
             unsupported |= rpl | pocs;
             unsupported |= br.get1();                    // dquant_flag: the Main decoder then codes QP deltas per cu_qp_delta_area (xevdm_eco.c), not per CU
-            unsupported |= br.get1();                    // tool_dra
+            s.tool_dra = br.get1();
         }
-        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, admvp, ibc, cm_init, htdf, rpl, pocs, dquant in Main, dra)");
+        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, admvp, ibc, cm_init, htdf, rpl, pocs, dquant in Main)");
         s.log2_sub_gop = (int)br.ue();                   // tool_rpl = tool_pocs = 0
         if (s.log2_sub_gop == 0) s.log2_ref_gap = (int)br.ue();
         if (s.log2_sub_gop > 5) return fail("bad SPS");
@@ -888,7 +967,10 @@ struct xhost_parser {
         br.ue(); br.ue(); br.ue(); br.ue(); br.ue();     // pps id, sps id, num_ref_idx_default_active_minus1[2], additional_lt_poc_lsb_len
         br.get1();                                       // rpl1_idx_present_flag
         if (!br.get1()) return fail("multiple tiles are not supported");
-        br.ue(); br.get1(); br.get1(); br.get1();        // tile_id_len_minus1, explicit_tile_id, pic_dra_enabled, arbitrary_slice_present
+        br.ue(); br.get1();                              // tile_id_len_minus1, explicit_tile_id
+        st.pps.dra_on = br.get1();                       // pic_dra_enabled_flag, pic_dra_aps_id (xevdm_eco.c:2054-2060)
+        if (st.pps.dra_on) st.pps.dra_aps_id = (int)br.get(5);
+        br.get1();                                       // arbitrary_slice_present
         st.pps.constrained_intra = br.get1();
         st.pps.cu_qp_delta = br.get1();
         if (st.pps.cu_qp_delta) br.ue();                 // cu_qp_delta_area
@@ -961,6 +1043,21 @@ struct xhost_parser {
         out->profile_main = st.sps.profile_main; out->tool_iqt = st.sps.tool_iqt; out->tool_ats = st.sps.tool_ats; out->tool_addb = st.sps.tool_addb;
         out->deblock_alpha_offset = sh.alpha_off; out->deblock_beta_offset = sh.beta_off;
         out->tool_alf = st.sps.tool_alf; out->alf_on = sh.alf_on; out->tool_eipd = st.sps.tool_eipd;
+        out->dra_lut[0] = out->dra_lut[1] = out->dra_lut[2] = nullptr;
+        if (st.sps.tool_dra && st.pps.dra_on) {          // what xevd_pull applies to its copy of this picture (xevd_apply_filter, xevdm.c:3305-3349)
+            const DraAps &d = st.dra_aps[st.pps.dra_aps_id & 31];
+            if (!d.valid) return fail("the PPS names a DRA parameter set that was not sent");
+            if (st.sps.bd_l > 10) return fail("DRA tables cover 10 bits");
+            const int off = 6 * (st.sps.bd_c - 8);
+            int8_t dflt[2][70];
+            const int8_t *cq[2];
+            for (int c = 0; c < 2; c++) {
+                if (st.sps.cqt) cq[c] = st.sps.cq[c] + off;
+                else { for (int q = -off; q <= 57; q++) dflt[c][q + off] = q >= 0 ? (st.sps.tool_iqt ? k_chroma_qp_main : k_chroma_qp)[q] : 0; cq[c] = dflt[c] + off; }
+            }
+            dra_build_luts(d, st.sps.bd_l, cq[0], cq[1], off, st.dra_luts);
+            for (int c = 0; c < 3; c++) out->dra_lut[c] = st.dra_luts + 1024 * c;
+        }
         for (int i = 0; i < 4; i++) out->crop[i] = st.sps.crop[i];
         out->chroma_qp_table[0] = st.sps.cqt ? st.sps.cq[0] : nullptr; out->chroma_qp_table[1] = st.sps.cqt ? st.sps.cq[1] : nullptr;
         if (sh.alf_on) {
@@ -1064,7 +1161,27 @@ static int parser_nal(xhost_parser *p, const uint8_t *nal, size_t len, xhost_pic
     }
     if (nut == 26) {                                     // APS (xevdm_eco_aps_gen, xevdm_eco.c:2082-2135)
         const int id = (int)br.get(5), type = (int)br.get(3);
-        if (type != 0) return p->fail("only ALF parameter sets (APS type 0) are supported");
+        if (type == 1) {                                 // DRA parameters (xevdm_eco_dra_aps_param, :2319-2375)
+            if (!p->st.have_sps) return p->fail("DRA APS before the SPS");
+            DraAps d;
+            if (br.get(4) != 4 || br.get(4) != 9) return p->fail("unsupported DRA descriptors");
+            d.num_ranges = (int)br.ue() + 1;
+            if (d.num_ranges > 32) return p->fail("bad DRA APS");
+            const int equal = br.get1(), sh = std::max(0, p->st.sps.bd_l - 10);
+            d.in_ranges[0] = (int)br.get(10) << sh;
+            int delta[32];
+            if (equal) delta[0] = (int)br.get(10);
+            else for (int i = 0; i < d.num_ranges; i++) delta[i] = (int)br.get(10);
+            for (int i = 0; i < d.num_ranges; i++) d.scale[i] = (int)br.get(13);
+            d.cb_scale = (int)br.get(13); d.cr_scale = (int)br.get(13);
+            d.table_idx = (int)br.ue();
+            for (int i = 1; i <= d.num_ranges; i++) d.in_ranges[i] = d.in_ranges[i - 1] + (delta[equal ? 0 : i - 1] << sh);
+            if (br.overrun || d.table_idx > 58) return p->fail("bad DRA APS");
+            d.valid = true;
+            p->st.dra_aps[id] = d;
+            return XGPU_OK;
+        }
+        if (type != 0) return p->fail("unknown APS type");
         AlfAps a;
         if (!p->st.alf_aps_syntax<false>(&br, nullptr, a)) return p->fail("bad or unsupported ALF APS (fixed filter sets are not supported)");
         a.valid = true;
@@ -1123,7 +1240,8 @@ struct xhost_writer {
             if (sp.tool_iqt) bw.put1(sp.tool_ats ? 1 : 0);
             bw.put1(sp.tool_addb ? 1 : 0);
             bw.put1(sp.tool_alf ? 1 : 0);
-            for (int i = 0; i < 5; i++) bw.put1(0);      // htdf rpl pocs dquant dra
+            for (int i = 0; i < 4; i++) bw.put1(0);      // htdf rpl pocs dquant
+            bw.put1(sp.tool_dra ? 1 : 0);
         }
         bw.ue((uint32_t)sp.log2_sub_gop_length);
         if (sp.log2_sub_gop_length == 0) bw.ue(0);      // log2_ref_pic_gap_length
@@ -1147,7 +1265,10 @@ struct xhost_writer {
     {
         BitWriter bw;
         bw.ue(0); bw.ue(0); bw.ue(0); bw.ue(0); bw.ue(0);
-        bw.put1(0); bw.put1(1); bw.ue(0); bw.put1(0); bw.put1(0); bw.put1(0);
+        bw.put1(0); bw.put1(1); bw.ue(0); bw.put1(0);    // rpl1_idx_present, single_tile_in_pic, tile_id_len_minus1, explicit_tile_id
+        bw.put1(sp.tool_dra ? 1 : 0);                    // pic_dra_enabled_flag
+        if (sp.tool_dra) bw.put((uint32_t)sp.dra_aps_id, 5);
+        bw.put1(0);                                      // arbitrary_slice_present
         bw.put1(0);                                      // constrained_intra_pred_flag
         bw.put1(sp.cu_qp_delta ? 1 : 0);
         if (sp.cu_qp_delta) bw.ue(0);
@@ -1170,6 +1291,7 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     s.tool_alf = s.profile_main && sp->tool_alf;
     s.tool_eipd = s.profile_main && sp->tool_eipd;
     w->sp.tool_iqt = s.tool_iqt; w->sp.tool_ats = s.tool_ats; w->sp.tool_addb = s.tool_addb; w->sp.tool_alf = s.tool_alf; w->sp.tool_eipd = s.tool_eipd;
+    w->sp.tool_dra = s.profile_main && sp->tool_dra; s.tool_dra = w->sp.tool_dra;
     w->st.pps.cu_qp_delta = sp->cu_qp_delta;
     return w;
 }
@@ -1182,6 +1304,25 @@ extern "C" int xhost_writer_set_slice_alf(xhost_writer *w, const xhost_slice_alf
     const size_t n_ctu = (size_t)((w->sp.width + 63) >> 6) * (size_t)((w->sp.height + 63) >> 6);
     if (sa->ctb_flag) w->next_alf_ctb.assign(sa->ctb_flag, sa->ctb_flag + n_ctu);
     w->next_alf.ctb_flag = nullptr;
+    return XGPU_OK;
+}
+extern "C" int xhost_writer_add_dra_aps(xhost_writer *w, const xhost_dra_aps *in)
+{
+    if (!w || !in || !w->sp.tool_dra || in->aps_id < 0 || in->aps_id > 31 || in->num_ranges < 1 || in->num_ranges > 32) return XGPU_ERR_INVALID_ARGUMENT;
+    if (w->n_pics == 0 && w->out.empty()) { w->write_sps(); w->write_pps(); w->headers_done = true; }
+    BitWriter bw;
+    bw.put((uint32_t)in->aps_id, 5); bw.put(1, 3);
+    bw.put(4, 4); bw.put(9, 4);
+    bw.ue((uint32_t)(in->num_ranges - 1));
+    bw.put1(0);                                          // dra_equal_ranges_flag
+    bw.put((uint32_t)in->in_ranges[0], 10);
+    for (int i = 0; i < in->num_ranges; i++) bw.put((uint32_t)(in->in_ranges[i + 1] - in->in_ranges[i]), 10);
+    for (int i = 0; i < in->num_ranges; i++) bw.put((uint32_t)in->scale[i], 13);
+    bw.put((uint32_t)in->cb_scale, 13); bw.put((uint32_t)in->cr_scale, 13);
+    bw.ue((uint32_t)in->table_idx);
+    bw.put1(0);                                          // aps_extension_flag
+    bw.align_zero();
+    write_nal(w->out, 26, 0, bw);
     return XGPU_OK;
 }
 extern "C" int xhost_writer_add_alf_aps(xhost_writer *w, const xhost_alf_aps *in)

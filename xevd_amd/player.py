@@ -60,7 +60,14 @@ class StreamDecoder:
                 dec.batch_destroy(hb)          # back to the pool; queued kernels keep reading it (same HIP stream)
             planes = None
             if download and output_bit_depth is not None:
-                planes = dec.pic_output(cur, output_bit_depth, p["crop"] if self.apply_crop else (0, 0, 0, 0))
+                planes = dec.pic_output(cur, output_bit_depth, p["crop"] if self.apply_crop else (0, 0, 0, 0), dra=p["dra"])
+            elif download and p["dra"] is not None:      # the DRA post-filter belongs to the output: planes through the output kernel
+                import numpy as np
+                w, h = p["width"], p["height"]
+                flat = dec.pic_output(cur, max(p["bit_depth"], 9), dra=p["dra"]).view("<u2").astype(np.int16) if p["bit_depth"] > 8 else None
+                if flat is None:
+                    raise RuntimeError("DRA on 8-bit pictures: use output_bit_depth")
+                planes = [flat[:w * h].reshape(h, w), flat[w * h:w * h * 5 // 4].reshape(h // 2, w // 2), flat[w * h * 5 // 4:].reshape(h // 2, w // 2)]
             elif download:
                 planes = dec.pic_download(cur)
                 if self.verify_md5 and p["md5"] is not None and not self.signature_ok(p, planes):

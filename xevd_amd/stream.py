@@ -18,7 +18,7 @@ class StreamParams(C.Structure):
                 ("qp_u_offset", C.c_int), ("qp_v_offset", C.c_int), ("deblock_on", C.c_int), ("cu_qp_delta", C.c_int),
                 ("profile_main", C.c_int), ("tool_iqt", C.c_int), ("tool_ats", C.c_int), ("tool_addb", C.c_int),
                 ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int), ("tool_alf", C.c_int), ("tool_eipd", C.c_int),
-                ("crop", C.c_int * 4), ("cqt_present", C.c_int), ("cqt_same", C.c_int), ("cqt_global_offset", C.c_int),
+                ("crop", C.c_int * 4), ("tool_dra", C.c_int), ("dra_aps_id", C.c_int), ("cqt_present", C.c_int), ("cqt_same", C.c_int), ("cqt_global_offset", C.c_int),
                 ("cqt_num_points", C.c_int * 2), ("cqt_delta_in", (C.c_int * 16) * 2), ("cqt_delta_out", (C.c_int * 16) * 2)]
 
 
@@ -33,6 +33,11 @@ class SliceAlf(C.Structure):
                 ("ctb_flag", C.POINTER(C.c_uint8))]
 
 
+class DraAps(C.Structure):
+    _fields_ = [("aps_id", C.c_int), ("num_ranges", C.c_int), ("in_ranges", C.c_int * 33), ("scale", C.c_int * 32), ("cb_scale", C.c_int),
+                ("cr_scale", C.c_int), ("table_idx", C.c_int)]
+
+
 class HostPicture(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("bit_depth_luma", C.c_int), ("bit_depth_chroma", C.c_int),
                 ("poc", C.c_int), ("temporal_id", C.c_int), ("slice_type", C.c_int), ("is_idr", C.c_int), ("is_ref", C.c_int),
@@ -41,6 +46,7 @@ class HostPicture(C.Structure):
                 ("profile_main", C.c_int), ("tool_iqt", C.c_int), ("tool_ats", C.c_int), ("tool_addb", C.c_int),
                 ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int),
                 ("tool_alf", C.c_int), ("tool_eipd", C.c_int), ("crop", C.c_int * 4), ("chroma_qp_table", C.POINTER(C.c_int8) * 2),
+                ("dra_lut", C.POINTER(C.c_int32) * 3),
                 ("alf_on", C.c_int), ("alf", abi.AlfParams),
                 ("has_md5", C.c_int), ("md5", (C.c_uint8 * 16) * 3),
                 ("n_release", C.c_int), ("release_poc", C.c_int * 32), ("batch", abi.CuBatch)]
@@ -67,6 +73,7 @@ def load():
         lib.xhost_writer_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
         lib.xhost_writer_close.argtypes = [C.c_void_p]
         lib.xhost_writer_add_alf_aps.argtypes = [C.c_void_p, C.POINTER(AlfAps)]
+        lib.xhost_writer_add_dra_aps.argtypes = [C.c_void_p, C.POINTER(DraAps)]
         lib.xhost_writer_add_md5_sei.argtypes = [C.c_void_p, C.c_void_p]
         lib.xhost_writer_set_slice_alf.argtypes = [C.c_void_p, C.POINTER(SliceAlf)]
         _lib = lib
@@ -76,13 +83,15 @@ def load():
 class StreamWriter:
     def __init__(self, width, height, bit_depth=8, max_num_ref_pics=1, qp_u_offset=0, qp_v_offset=0, deblock=True, cu_qp_delta=True,
                  log2_sub_gop=0, main=False, iqt=False, ats=False, addb=False, alpha_off=0, beta_off=0, alf=False, eipd=False, crop=(0, 0, 0, 0),
-                 chroma_qp_points=None):
+                 chroma_qp_points=None, dra_aps_id=None):
         """chroma_qp_points: None, or (global_offset_flag, [table, ...]) with 1 (same for Cb and Cr) or 2 tables of (delta_in_minus1, delta_out) pairs"""
         self.lib = load()
         sp = StreamParams(width, height, bit_depth, max_num_ref_pics, log2_sub_gop, qp_u_offset, qp_v_offset, int(deblock), int(cu_qp_delta),
                           int(main), int(iqt), int(ats), int(addb), alpha_off, beta_off, int(alf), int(eipd))
         for i in range(4):
             sp.crop[i] = int(crop[i])
+        if dra_aps_id is not None:
+            sp.tool_dra, sp.dra_aps_id = 1, int(dra_aps_id)
         if chroma_qp_points is not None:
             sp.cqt_present, sp.cqt_global_offset, sp.cqt_same = 1, int(chroma_qp_points[0]), int(len(chroma_qp_points[1]) == 1)
             for c, tbl in enumerate(chroma_qp_points[1]):
@@ -98,6 +107,18 @@ class StreamWriter:
         rc = self.lib.xhost_writer_add_picture(self.h, int(idr), slice_type, slice_qp, temporal_id, C.byref(cb))
         if rc != 0:
             raise RuntimeError(f"xhost_writer_add_picture -> {rc}")
+
+    def add_dra_aps(self, aps_id, in_ranges, scales, cb_scale, cr_scale, table_idx):
+        """DRA parameter set (APS type 1): range borders, 4.9 fixed-point scales per range, chroma scales, dra_table_idx"""
+        a = DraAps()
+        a.aps_id, a.num_ranges, a.cb_scale, a.cr_scale, a.table_idx = aps_id, len(scales), int(cb_scale), int(cr_scale), int(table_idx)
+        for i, v in enumerate(in_ranges):
+            a.in_ranges[i] = int(v)
+        for i, v in enumerate(scales):
+            a.scale[i] = int(v)
+        rc = self.lib.xhost_writer_add_dra_aps(self.h, C.byref(a))
+        if rc != 0:
+            raise RuntimeError(f"xhost_writer_add_dra_aps -> {rc}")
 
     def add_alf_aps(self, aps_id, luma=None, chroma=None, type7=True, delta_idx=None, coef_delta_flag=0, pred_mode_flag=0, filter_coef_flag=None):
         """luma: [n_filters][12 or 6] coded coefficient values or None; chroma: [6] or None"""
@@ -190,6 +211,7 @@ def iter_stream(data, consume_batch=None):
                 "slice_qp": hp.slice_qp, "qp_u_offset": hp.qp_u_offset, "qp_v_offset": hp.qp_v_offset, "deblock_on": bool(hp.deblock_on),
                 "main": bool(hp.profile_main), "iqt": hp.tool_iqt, "ats": hp.tool_ats, "addb": hp.tool_addb,
                 "alpha_off": hp.deblock_alpha_offset, "beta_off": hp.deblock_beta_offset, "tool_alf": hp.tool_alf, "eipd": hp.tool_eipd, "crop": tuple(hp.crop[i] for i in range(4)),
+                "dra": None if not hp.dra_lut[0] else [np.ctypeslib.as_array(hp.dra_lut[c], (1024,)).copy() for c in range(3)],
                 "chroma_qp_tables": None if not hp.chroma_qp_table[0] else [np.ctypeslib.as_array(hp.chroma_qp_table[c], (58 + 6 * (hp.bit_depth_chroma - 8),)).copy() for c in range(2)],
                 "alf": None if not hp.alf_on else {
                     "enable": tuple(hp.alf.enable[i] for i in range(3)), "luma_coef": _arr(hp.alf.luma_coef, 25 * 13, np.int16).reshape(25, 13),
