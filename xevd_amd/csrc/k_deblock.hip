@@ -25,6 +25,8 @@
 #include "xgpu_internal.h"
 
 struct __attribute__((packed, aligned(4))) U32x4a4 { uint32_t a, b, c, d; };   // 16-byte load at 4-byte alignment
+struct __attribute__((packed, aligned(4))) U32x2a4 { uint32_t a, b; };         // 8 bytes at 4-byte alignment
+struct __attribute__((packed, aligned(2))) U32x1a2 { uint32_t a; };            // 4 bytes at 2-byte alignment (gfx950: unaligned-access mode)
 
 __device__ __forceinline__ int clip3i(int lo, int hi, int v) { return min(max(v, lo), hi); }
 
@@ -75,7 +77,10 @@ __device__ __forceinline__ void filt_chroma(int A, int B, int C, int D, int st, 
     Co = clip3i(0, maxv, C - d1);
 }
 
-// DIR 0: vertical edges (filter along x), DIR 1: horizontal edges (filter along y)
+// DIR 0: vertical edges (filter along x), DIR 1: horizontal edges (filter along y).
+// One lane per 4-sample edge segment - the left / top edge of SCU (sx, sy), grid lines one past the picture included.  The lane owns what its
+// edge can change: luma [e-2, e+2) and chroma [e/2-1, e/2+1) along the filtered axis, 4 (2) lines across; these windows tile the picture, so
+// every sample is written exactly once, each filter is evaluated once, and the window is a single 8-byte (4-byte) load per line.
 template <int DIR>
 __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
                                              const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_,
@@ -85,115 +90,97 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
     for (int i = threadIdx.x; i < 3 * 4 * 64 / 4; i += 256) ((uint32_t *)s_st)[i] = ((const uint32_t *)a.st)[i];
     __syncthreads();
 
-    // vertical edges: a wave = 64 neighbouring SCUs of one SCU row (512-byte runs of a picture row), 4 such rows per workgroup - 8 % faster at
-    // 8K than a 16 x 16 lane tile; horizontal edges (8 rows of 8 bytes per lane) measured the other way round and keep the square tile
+    // vertical edges: a wave = 64 neighbouring segments of one SCU row (512-byte runs of a picture row), 4 such rows per workgroup;
+    // horizontal edges keep a 16 x 16 lane tile (measured: the wide mapping is slower there)
+    const int n_ex = DIR == 0 ? a.w_scu + 1 : a.w_scu, n_ey = DIR == 0 ? a.h_scu : a.h_scu + 1;
     const int LW = DIR == 0 ? 6 : 4, LH = 8 - LW;
-    const int tiles_x = (a.w_scu + (1 << LW) - 1) >> LW;
+    const int tiles_x = (n_ex + (1 << LW) - 1) >> LW;
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int sx = (tx << LW) + (threadIdx.x & ((1 << LW) - 1)), sy = (ty << LH) + (threadIdx.x >> LW);
-    if (sx >= a.w_scu || sy >= a.h_scu) return;
+    if (sx >= n_ex || sy >= n_ey) return;
     const int step = DIR == 0 ? 1 : a.w_scu;                 // SCU-map step along the filtering axis
-    const int pos = DIR == 0 ? sx : sy;                      // coordinate along the filtering axis
-    const int npos = DIR == 0 ? a.w_scu : a.h_scu;
+    const int pos = DIR == 0 ? sx : sy, npos = DIR == 0 ? a.w_scu : a.h_scu;
     const uint32_t eflag = DIR == 0 ? SCU_EDGE_L : SCU_EDGE_T;
     const uint4 *maps = (const uint4 *)a.maps;
-    const int k0 = sy * a.w_scu + sx;
+    const bool has_p = pos > 0, has_q = pos < npos, in_range = has_p && has_q;
+    const int k0 = in_range ? sy * a.w_scu + sx : 0;
     const int maxl = (1 << a.bd_l) - 1, maxc = (1 << a.bd_c) - 1;
 
-    // ---- everything this lane can need is requested up front (one memory round trip): the three SCU records,
-    //      the luma window and the chroma windows of both planes; decisions come afterwards ----
-    const uint4 rq = maps[k0];
-    const uint4 rp = maps[pos > 0 ? k0 - step : k0];
-    const uint4 rn = maps[pos + 1 < npos ? k0 + step : k0];
-    const uint4 rpp = maps[pos > 1 ? k0 - 2 * step : k0];    // two back: the first link of a chroma dependency chain (below) without a second round trip
+    // ---- all loads first: the two SCU records (+ the one before: first link of a chroma chain), the luma and chroma windows ----
+    const uint4 rq = maps[k0], rp = maps[in_range ? k0 - step : 0], rpp = maps[in_range && pos > 1 ? k0 - 2 * step : 0];
     const int x = sx << 2, y = sy << 2, cx = sx << 1, cy = sy << 1;
-    U32x4a4 lrow[4];       // DIR 0: rows y..y+3, samples x-2..x+5
-    uint2   lcol[8];       // DIR 1: rows y-2..y+5, samples x..x+3
-    int cs[2][2][6];       // chroma [plane][line][A B C D | C' D' of the next edge]: 6 samples along the filtering axis from -2
+    int L[4][4];           // luma [line][A B C D]
+    int Cw[2][2][4];       // chroma [plane][line][A B C D]
     if (DIR == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; r++) lrow[r] = *(const U32x4a4 *)(sy_ + (y + r) * a.s_l + x - 2);
+        for (int r = 0; r < 4; r++) {
+            const U32x2a4 q = *(const U32x2a4 *)(sy_ + (y + r) * a.s_l + x - 2);
+            const uint32_t d0 = q.a, d1 = q.b;
+            L[r][0] = (int16_t)(d0 & 0xFFFF); L[r][1] = (int16_t)(d0 >> 16); L[r][2] = (int16_t)(d1 & 0xFFFF); L[r][3] = (int16_t)(d1 >> 16);
+        }
 #pragma unroll
         for (int pl = 0; pl < 2; pl++)
 #pragma unroll
             for (int ln = 0; ln < 2; ln++) {
-                const U32x4a4 v = *(const U32x4a4 *)((pl ? sv_ : su_) + (cy + ln) * a.s_c + cx - 2);
-                cs[pl][ln][0] = (int16_t)(v.a & 0xFFFF); cs[pl][ln][1] = (int16_t)(v.a >> 16);
-                cs[pl][ln][2] = (int16_t)(v.b & 0xFFFF); cs[pl][ln][3] = (int16_t)(v.b >> 16);
-                cs[pl][ln][4] = (int16_t)(v.c & 0xFFFF); cs[pl][ln][5] = (int16_t)(v.c >> 16);
+                const U32x2a4 q = *(const U32x2a4 *)((pl ? sv_ : su_) + (cy + ln) * a.s_c + cx - 2);
+                const uint32_t d0 = q.a, d1 = q.b;
+                Cw[pl][ln][0] = (int16_t)(d0 & 0xFFFF); Cw[pl][ln][1] = (int16_t)(d0 >> 16); Cw[pl][ln][2] = (int16_t)(d1 & 0xFFFF); Cw[pl][ln][3] = (int16_t)(d1 >> 16);
             }
     } else {
 #pragma unroll
-        for (int r = 0; r < 8; r++) lcol[r] = *(const uint2 *)(sy_ + (y - 2 + r) * a.s_l + x);
+        for (int r = 0; r < 4; r++) {
+            const uint2 v = *(const uint2 *)(sy_ + (y - 2 + r) * a.s_l + x);
+            L[0][r] = (int16_t)(v.x & 0xFFFF); L[1][r] = (int16_t)(v.x >> 16); L[2][r] = (int16_t)(v.y & 0xFFFF); L[3][r] = (int16_t)(v.y >> 16);
+        }
 #pragma unroll
         for (int pl = 0; pl < 2; pl++)
 #pragma unroll
-            for (int r = 0; r < 6; r++) {
+            for (int r = 0; r < 4; r++) {
                 const uint32_t v = *(const uint32_t *)((pl ? sv_ : su_) + (cy - 2 + r) * a.s_c + cx);
-                cs[pl][0][r] = (int16_t)(v & 0xFFFF); cs[pl][1][r] = (int16_t)(v >> 16);
+                Cw[pl][0][r] = (int16_t)(v & 0xFFFF); Cw[pl][1][r] = (int16_t)(v >> 16);
             }
     }
 
-    // edge on this SCU's left/top side, and the edge on the far side (belongs to the next SCU)
-    int st_this[3] = {0, 0, 0}, st_next[3] = {0, 0, 0};
-    if (pos > 0 && (rq.x & eflag)) {
+    int st[3] = {0, 0, 0};
+    if (in_range && (rq.x & eflag)) {
         const int cls = edge_class(rq, rp), qp = (rq.x >> 16) & 0x7F;
 #pragma unroll
-        for (int c = 0; c < 3; c++) st_this[c] = s_st[(c * 4 + cls) * 64 + (qp & 63)];
-    }
-    if (pos + 1 < npos && (rn.x & eflag)) {
-        const int cls = edge_class(rn, rq), qp = (rn.x >> 16) & 0x7F;
-#pragma unroll
-        for (int c = 0; c < 3; c++) st_next[c] = s_st[(c * 4 + cls) * 64 + (qp & 63)];
+        for (int c = 0; c < 3; c++) st[c] = s_st[(c * 4 + cls) * 64 + (qp & 63)];
     }
 
     // ------------------------------------------------ luma -----------------------------------------------
+    if (st[0]) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const Line4 o = filt_luma({ L[r][0], L[r][1], L[r][2], L[r][3] }, st[0], maxl);
+            L[r][0] = o.A; L[r][1] = o.B; L[r][2] = o.C; L[r][3] = o.D;
+        }
+    }
+#define PK2(lo, hi) ((uint32_t)(uint16_t)(lo) | ((uint32_t)(uint16_t)(hi) << 16))
     if (DIR == 0) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-            const U32x4a4 v = lrow[r];
-            int s[8] = { (int16_t)(v.a & 0xFFFF), (int16_t)(v.a >> 16), (int16_t)(v.b & 0xFFFF), (int16_t)(v.b >> 16),
-                         (int16_t)(v.c & 0xFFFF), (int16_t)(v.c >> 16), (int16_t)(v.d & 0xFFFF), (int16_t)(v.d >> 16) };
-            if (st_this[0]) { const Line4 o = filt_luma({ s[0], s[1], s[2], s[3] }, st_this[0], maxl); s[2] = o.C; s[3] = o.D; }
-            if (st_next[0]) { const Line4 o = filt_luma({ s[4], s[5], s[6], s[7] }, st_next[0], maxl); s[4] = o.A; s[5] = o.B; }
-            uint2 w;
-            w.x = (uint32_t)(uint16_t)s[2] | ((uint32_t)(uint16_t)s[3] << 16);
-            w.y = (uint32_t)(uint16_t)s[4] | ((uint32_t)(uint16_t)s[5] << 16);
-            *(uint2 *)(dy_ + (y + r) * a.s_l + x) = w;
+            int16_t *d = dy_ + (y + r) * a.s_l + x;
+            if (in_range) { U32x2a4 w = { PK2(L[r][0], L[r][1]), PK2(L[r][2], L[r][3]) }; *(U32x2a4 *)(d - 2) = w; }
+            else if (has_p) *(uint32_t *)(d - 2) = PK2(L[r][0], L[r][1]);
+            else if (has_q) *(uint32_t *)d = PK2(L[r][2], L[r][3]);
         }
     } else {
 #pragma unroll
-        for (int c = 0; c < 4; c++) {
-            int s[8];
-#pragma unroll
-            for (int r = 0; r < 8; r++) {
-                const uint32_t d = (c < 2) ? lcol[r].x : lcol[r].y;
-                s[r] = (c & 1) ? (int16_t)(d >> 16) : (int16_t)(d & 0xFFFF);
-            }
-            if (st_this[0]) { const Line4 o = filt_luma({ s[0], s[1], s[2], s[3] }, st_this[0], maxl); s[2] = o.C; s[3] = o.D; }
-            if (st_next[0]) { const Line4 o = filt_luma({ s[4], s[5], s[6], s[7] }, st_next[0], maxl); s[4] = o.A; s[5] = o.B; }
-#pragma unroll
-            for (int r = 2; r < 6; r++) {
-                uint32_t &d = (c < 2) ? lcol[r].x : lcol[r].y;
-                d = (c & 1) ? ((d & 0xFFFFu) | ((uint32_t)(uint16_t)s[r] << 16)) : ((d & 0xFFFF0000u) | (uint32_t)(uint16_t)s[r]);
-            }
+        for (int r = 0; r < 4; r++) {
+            if (r < 2 ? !has_p : !has_q) continue;
+            *(uint2 *)(dy_ + (y - 2 + r) * a.s_l + x) = make_uint2(PK2(L[0][r], L[1][r]), PK2(L[2][r], L[3][r]));
         }
-#pragma unroll
-        for (int r = 2; r < 6; r++) *(uint2 *)(dy_ + (y - 2 + r) * a.s_l + x) = lcol[r];
     }
 
     // ------------------------------------------------ chroma ---------------------------------------------
-    // The SCU owns chroma samples (cx..cx+1, cy..cy+1).  Along the filtering axis, sample 0 is C' of this SCU's
-    // edge and sample 1 is B' of the next SCU's edge; both need the final value of the sample two positions
-    // before the edge (A), i.e. the C' of the previous edge when that edge is active.
+    // Edges 2 chroma samples apart are applied in increasing coordinate order (xevd_df.c:238-289): this edge's A is the C' of the previous
+    // edge when that one is active.  The lane walks back to the head of the chain of consecutive active edges and recomputes it forward
+    // from the ORIGINAL samples (chains are as long as a run of 4-wide CUs; every lane stays independent).
     const int alongc = DIR == 0 ? 1 : a.s_c, acrossc = DIR == 0 ? a.s_c : 1;
-    int outc[2][2][2];     // [plane][line][sample along the axis]
 #pragma unroll
     for (int pl = 0; pl < 2; pl++) {
-        const int stt = st_this[1 + pl], stn = st_next[1 + pl];
-        // head of the chain of consecutive active edges that ends at this SCU's edge (xevd_df.c:238-289 order
-        // dependence); identical for both lines of the SCU.  Rare (runs of 4-wide / 4-tall CUs), so the extra
-        // records and samples are fetched inside the loop.
+        const int stt = st[1 + pl];
         int head = pos;
         if (stt) {
             int kk = k0;
@@ -208,54 +195,49 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
         }
 #pragma unroll
         for (int ln = 0; ln < 2; ln++) {
-            const int *s = cs[pl][ln];
-            int o0 = s[2], o1 = s[3], a_in = s[0];
-            if (stt) {
-                if (head < pos) {
-                    // recompute the chain forward from its head using ORIGINAL samples
-                    const int16_t *p = (pl ? sv_ : su_) + cy * a.s_c + cx + ln * acrossc;
-                    int prevC = 0;
-                    for (int e = head; e < pos; e++) {
-                        const int rel = (e - pos) * 2;                   // chroma offset of edge e relative to this edge
-                        const int ke = k0 + (e - pos) * step;
-                        const uint4 q = maps[ke], pp = maps[ke - step];
-                        const int cls = edge_class(q, pp), qp = (q.x >> 16) & 0x7F;
-                        const int st = s_st[((1 + pl) * 4 + cls) * 64 + (qp & 63)];
-                        const int A = (e == head) ? p[(rel - 2) * alongc] : prevC;
-                        int Bo, Co;
-                        filt_chroma(A, p[(rel - 1) * alongc], p[rel * alongc], p[(rel + 1) * alongc], st, maxc, Bo, Co);
-                        prevC = Co;
-                    }
-                    a_in = prevC;
+            int *s = Cw[pl][ln];
+            if (!stt) continue;
+            int a_in = s[0];
+            if (head < pos) {
+                const int16_t *p = (pl ? sv_ : su_) + cy * a.s_c + cx + ln * acrossc;
+                int prevC = 0;
+                for (int e = head; e < pos; e++) {
+                    const int rel = (e - pos) * 2;                   // chroma offset of edge e relative to this edge
+                    const int ke = k0 + (e - pos) * step;
+                    const uint4 q = maps[ke], pp = maps[ke - step];
+                    const int cls = edge_class(q, pp), qp = (q.x >> 16) & 0x7F;
+                    const int ste = s_st[((1 + pl) * 4 + cls) * 64 + (qp & 63)];
+                    const int A = (e == head) ? p[(rel - 2) * alongc] : prevC;
+                    int Bo, Co;
+                    filt_chroma(A, p[(rel - 1) * alongc], p[rel * alongc], p[(rel + 1) * alongc], ste, maxc, Bo, Co);
+                    prevC = Co;
                 }
-                int Bo, Co;
-                filt_chroma(a_in, s[1], s[2], s[3], stt, maxc, Bo, Co);
-                o0 = Co;
+                a_in = prevC;
             }
-            if (stn) {
-                int Bo, Co;
-                filt_chroma(o0, s[3], s[4], s[5], stn, maxc, Bo, Co);
-                o1 = Bo;
-            }
-            outc[pl][ln][0] = o0; outc[pl][ln][1] = o1;
+            int Bo, Co;
+            filt_chroma(a_in, s[1], s[2], s[3], stt, maxc, Bo, Co);
+            s[1] = Bo; s[2] = Co;
         }
-    }
-#pragma unroll
-    for (int pl = 0; pl < 2; pl++) {
         int16_t *dst = (pl ? dv_ : du_) + cy * a.s_c + cx;
-        if (DIR == 0) {      // line = row, samples along x: one dword per row
-            *(uint32_t *)dst = (uint32_t)(uint16_t)outc[pl][0][0] | ((uint32_t)(uint16_t)outc[pl][0][1] << 16);
-            *(uint32_t *)(dst + a.s_c) = (uint32_t)(uint16_t)outc[pl][1][0] | ((uint32_t)(uint16_t)outc[pl][1][1] << 16);
-        } else {             // line = column, samples along y: row cy holds sample 0 of both columns
-            *(uint32_t *)dst = (uint32_t)(uint16_t)outc[pl][0][0] | ((uint32_t)(uint16_t)outc[pl][1][0] << 16);
-            *(uint32_t *)(dst + a.s_c) = (uint32_t)(uint16_t)outc[pl][0][1] | ((uint32_t)(uint16_t)outc[pl][1][1] << 16);
+        if (DIR == 0) {      // line = row: B' at cx - 1, C' at cx
+#pragma unroll
+            for (int ln = 0; ln < 2; ln++) {
+                if (in_range) { U32x1a2 w = { PK2(Cw[pl][ln][1], Cw[pl][ln][2]) }; *(U32x1a2 *)(dst + ln * a.s_c - 1) = w; }
+                else if (has_p) dst[ln * a.s_c - 1] = (int16_t)Cw[pl][ln][1];
+                else if (has_q) dst[ln * a.s_c] = (int16_t)Cw[pl][ln][2];
+            }
+        } else {             // line = column: row cy - 1 holds B' of both columns, row cy their C'
+            if (has_p) *(uint32_t *)(dst - a.s_c) = PK2(Cw[pl][0][1], Cw[pl][1][1]);
+            if (has_q) *(uint32_t *)dst = PK2(Cw[pl][0][2], Cw[pl][1][2]);
         }
     }
+#undef PK2
 }
 
 void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst)
 {
-    const int tiles = dir == 0 ? ((a.w_scu + 63) >> 6) * ((a.h_scu + 3) >> 2) : ((a.w_scu + 15) >> 4) * ((a.h_scu + 15) >> 4);
+    const int n_ex = dir == 0 ? a.w_scu + 1 : a.w_scu, n_ey = dir == 0 ? a.h_scu : a.h_scu + 1;
+    const int tiles = dir == 0 ? ((n_ex + 63) >> 6) * ((n_ey + 3) >> 2) : ((n_ex + 15) >> 4) * ((n_ey + 15) >> 4);
     if (dir == 0)
         hipLaunchKernelGGL(k_dbk<0>, dim3(tiles), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
     else
