@@ -11,10 +11,9 @@
 //   * each pass reads picture SRC and writes picture DST (recon -> scratch -> DPB picture); every sample is
 //     written exactly once, so nothing depends on workgroup order and a pass moves 2 B in + 2 B out per sample,
 //     exactly the reference's in-place traffic;
-//   * one LANE per 4x4 SCU produces all 16 luma + 2x(2x2) chroma samples of its SCU.  The samples of an SCU are
-//     touched by two edges: its own left/top edge (C,D side) and the next SCU's edge (A,B side), so the lane
-//     evaluates both filters and keeps its half - twice the trivial ALU work in exchange for zero write
-//     conflicts and fully coalesced 128-byte row segments per 16 lanes;
+//   * one LANE per 4-sample edge segment (the left / top edge of an SCU, the grid line one past the picture included) owns what that
+//     edge can change - luma [e-2, e+2), chroma [e/2-1, e/2+1) along the filtered axis; the windows tile the picture: no write
+//     conflicts, each filter evaluated once (the first version gave a lane its SCU and made it evaluate both edges touching it);
 //   * the chroma order dependence (edge k needs the C' sample of edge k-1 when that edge is active) is resolved
 //     per lane by walking back to the head of the dependency chain and recomputing it forward in registers from
 //     the ORIGINAL samples - chains are as long as a run of 4-wide CUs (typically 1-3), and every lane stays
