@@ -8,8 +8,10 @@
 //     a per-sample function of the covering CU's motion, so an SCU can be predicted independently of the CU it
 //     belongs to: every lane runs the same straight-line code whatever the CU sizes are (no size classes, no
 //     divergence on block shape), and the 16 lanes of an SCU row store 128 contiguous bytes per picture row.
-//   * the lane finds its CU by scanning the CTU's CU list, staged once per workgroup in LDS as one packed
-//     geometry word per CU (broadcast reads); the 32-byte CU record is then fetched with two 16-byte loads.
+//   * the covering CU comes from a per-picture SCU -> CU owner map that k_paint (one thread per CU) writes first; the CTU's CU records, the
+//     reference table and the tap tables are staged once per workgroup in LDS, so a lane's chain is owner -> LDS -> reference samples;
+//   * a wave whose 32x32 tile lies inside ONE CU takes the tile path instead: window fetched once into the wave's own LDS, shared
+//     horizontal pass, vertical pass from LDS (mc_luma_tile / mc_chroma_tile below);
 //   * the 11x11 (luma) / 5x5 (chroma) reference windows are read straight from HBM/L2 with 16-byte loads at the
 //     2-byte-aligned sample address (gfx950 runs in unaligned-access mode); neighbouring lanes share the halo
 //     through the vector L1, workgroups are mapped to XCDs in contiguous bands so vertical halos share an L2.
