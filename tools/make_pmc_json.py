@@ -8,7 +8,7 @@ import json
 import sys
 
 NAMES = {"k_inter": "inter", "k_alf": "alf", "k_addb<0>": "dbk_v", "k_addb<1>": "dbk_h", "k_dbk<0>": "dbk_v", "k_dbk<1>": "dbk_h",
-         "k_itdq": "itdq", "k_intra<false>": "intra", "k_intra<true>": "intra", "k_pad": "pad"}
+         "k_itdq": "itdq", "k_intra<false, false>": "intra", "k_intra<true, false>": "intra", "k_intra<false, true>": "intra", "k_intra<true, true>": "intra", "k_pad": "pad"}
 
 
 def load(path):
