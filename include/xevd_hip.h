@@ -138,6 +138,11 @@ typedef struct xgpu_cu_batch {
     const uint32_t *ctu_cu_start; /* [n_ctu+1] first CU of every CTU in raster CTU order                  */
     int             constrained_intra_pred;   /* pps.constrained_intra_pred_flag: intra CUs only predict from intra neighbours
                                                  (xevd_get_nbr_b, src_base/xevd_ipred.c:47,61,77)          */
+    /* affine motion (Main, sps->tool_affine; xevdm_affine_mc, src_main/xevdm_mc.c:2606): both NULL = no affine CU in the batch */
+    const uint8_t  *affine;       /* [n_cu] or NULL: 0 = translational, 2 / 3 = control points of an inter CU (mcore->affine_flag + 1);
+                                     CUs of at least 8x8.  `mv` of such a CU is only stored for a list it does not use          */
+    const int16_t  *affine_mv;    /* [n_cu][2][3][2] quarter-pel control-point vectors mcore->affine_mv[list][vertex][x/y]
+                                     (top-left, top-right, bottom-left; the third ignored with 2 control points)              */
 } xgpu_cu_batch;
 
 /* ------------------------------------------------------------------ lifetime ---------------------- */

@@ -146,9 +146,20 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
     harness *hn = harness_new(sp, fr, m, simd);
     XEVD_CTX *ctx = hn->ctx; XEVD_CORE *core = hn->core;
     XEVDM_CORE *mcore = (XEVDM_CORE *)core;
-    const int main_path = sp->tool_admvp || sp->tool_iqt || b->ats != NULL || b->ats_inter != NULL;
+    const int main_path = sp->tool_admvp || sp->tool_iqt || b->ats != NULL || b->ats_inter != NULL || b->affine != NULL;
     int i, c;
 
+    if (b->affine) {
+        /* xevdm_affine_mc reads the interpolation tables through the process-global pointers that only xevdm_mc sets (xevdm_mc.c:1914-1924): it
+           works with whatever the last regular inter CU of the process left there (a stream whose first inter CU is affine gets the Baseline
+           table, whose rows for the sixteenth-sample phases are empty).  The batch semantics are those of the steady state: let one regular
+           CU go first. */
+        s8 refi0[2] = { -1, -1 }; s16 mv0[2][2] = { { 0, 0 }, { 0, 0 } }; u8 dmvr_flag = 0;
+        refi0[ctx->refp[0][0].pic ? 0 : 1] = 0;
+        xevdm_mc(0, 0, ctx->w, ctx->h, 4, 4, refi0, mv0, ctx->refp, core->pred, fr->cur.poc, mcore->dmvr_template, mcore->dmvr_ref_pred_interpolated,
+                 mcore->dmvr_half_pred_interpolated, 0, mcore->dmvr_padding_buf, &dmvr_flag, mcore->dmvr_mv, sp->tool_admvp,
+                 sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
+    }
     for (i = 0; i < b->n_cu; i++) {
         const int x = b->x[i], y = b->y[i], lw = b->log2w[i], lh = b->log2h[i], w = 1 << lw, h = 1 << lh;
         size_t off = b->coef_off[i], o = off;
@@ -227,8 +238,19 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
             }
             xevd_recon_yuv(ctx, core, x, y, w, h);
         } else {
-            /* prediction: xevd.c:725-726 / xevdm.c:1311-1316 (DMVR off) */
-            if (main_path) {
+            /* prediction: xevd.c:725-726 / xevdm.c:1311-1316 (DMVR off); affine CUs xevdm.c:1290-1295 */
+            const int vn = b->affine ? b->affine[i] : 0;
+            if (vn) {
+                int l, v;
+                mcore->affine_flag = (u8)(vn - 1);
+                memset(mcore->affine_mv, 0, sizeof(mcore->affine_mv));
+                for (l = 0; l < 2; l++) for (v = 0; v < 3; v++) {
+                    mcore->affine_mv[l][v][MV_X] = b->affine_mv[i * 12 + l * 6 + v * 2];
+                    mcore->affine_mv[l][v][MV_Y] = b->affine_mv[i * 12 + l * 6 + v * 2 + 1];
+                }
+                xevdm_affine_mc(x, y, ctx->w, ctx->h, w, h, core->refi, mcore->affine_mv, ctx->refp, core->pred, vn, core->eif_tmp_buffer,
+                                sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
+            } else if (main_path) {
                 u8 dmvr_flag = 0;
                 xevdm_mc(x, y, ctx->w, ctx->h, w, h, core->refi, core->mv, ctx->refp, core->pred, fr->cur.poc,
                          mcore->dmvr_template, mcore->dmvr_ref_pred_interpolated, mcore->dmvr_half_pred_interpolated, 0,
@@ -246,6 +268,8 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
                 xevd_recon_yuv(ctx, core, x, y, w, h);
         }
         xevd_set_dec_info(ctx, core);
+        if (b->affine && b->affine[i] && b->pred_mode[i] != XGPU_MODE_INTRA)      /* xevdm_set_dec_info's affine tail, xevdm_util.c:4378-4381 */
+            xevdm_set_affine_mvf(ctx, core);
         if (ai) {      /* xevdm_set_dec_info's ATS-inter tail (xevdm_util.c:4321, :4375) */
             int r, q;
             xevdm_set_cu_cbf_flags((u8)core->is_coef[Y_C], ai, lw, lh, ctx->map_scu + core->scup, ctx->w_scu);

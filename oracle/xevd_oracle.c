@@ -651,6 +651,218 @@ static int eipd_chroma_mode(int ipm_c, int ipm_l)
     return ipm_c == 0 ? ipm_l : direct[ipm_c];
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * Affine motion compensation (Main, sps->tool_affine): xevdm_affine_mc, src_main/xevdm_mc.c:2606-2685.
+ * Control-point vectors are quarter-pel; the model is kept at 2 + 7 fractional bits.
+ * ---------------------------------------------------------------------------------------------- */
+#define AFF_BIT 7                 /* MAX_CU_LOG2 */
+#define AFF_MAX_CU 128
+static int aff_round(int v, int shift) { return (v + (1 << (shift - 1)) - (v >= 0)) >> shift; }     /* xevdm_mv_rounding_s32, xevdm_util.c:1857-1868 */
+static int aff_clip18(int v) { return CLIP3(-(1 << 17), (1 << 17) - 1, v); }
+
+/* the four model deltas: xevdm_mc.c:2294-2306 (== xevdm_util.c:1891-1903) */
+static void aff_deltas(const int16_t mv[3][2], int lw, int lh, int vn, int dh[2], int dv[2])
+{
+    dh[0] = ((mv[1][0] - mv[0][0]) * (1 << AFF_BIT)) >> lw;
+    dh[1] = ((mv[1][1] - mv[0][1]) * (1 << AFF_BIT)) >> lw;
+    if (vn == 3) {
+        dv[0] = ((mv[2][0] - mv[0][0]) * (1 << AFF_BIT)) >> lh;
+        dv[1] = ((mv[2][1] - mv[0][1]) * (1 << AFF_BIT)) >> lh;
+    } else { dv[0] = -dh[1]; dv[1] = dh[0]; }
+}
+
+/* xevdm_check_eif_applicability_uni, xevdm_util.c:2073-2097 (bounding box of a 4x4 sub-block :2041-2060, fetched lines :2062-2071) */
+static int aff_eif_applicable(const int dh[2], const int dv[2], int *mem_band)
+{
+    const int P = 2 + AFF_BIT, one = 1 << P;
+    int cx[4], cy[4], k, mx, nx, my, ny;
+    cx[0] = 0; cx[1] = 5 * (dh[0] + one); cx[2] = 5 * dv[0]; cx[3] = cx[1] + cx[2];
+    cy[0] = 0; cy[1] = 5 * dh[1]; cy[2] = 5 * (dv[1] + one); cy[3] = cy[1] + cy[2];
+    mx = nx = my = ny = 0;
+    for (k = 1; k < 4; k++) { if (cx[k] > mx) mx = cx[k]; if (cx[k] < nx) nx = cx[k]; if (cy[k] > my) my = cy[k]; if (cy[k] < ny) ny = cy[k]; }
+    *mem_band = (((mx - nx + one - 1) >> P) + 2) * (((my - ny + one - 1) >> P) + 2) <= 72;
+    if (dv[1] < -one) return 0;
+    if (((dv[1] > 0 ? dv[1] : 0) + abs(dh[1])) * 5 > (1 << P)) return 0;
+    return 1;
+}
+
+/* xevdm_derive_affine_subblock_size_bi, xevdm_util.c:1870-1945 */
+static void aff_subblock(const int16_t mv[2][3][2], const int8_t refi[2], int lw, int lh, int vn, int *sub_w, int *sub_h, int *mem_band)
+{
+    static const int lut[4] = { 32, 16, 8, 8 };
+    const int cuw = 1 << lw, cuh = 1 << lh;
+    int l, apply = 1, mb = 1;
+    *sub_w = cuw; *sub_h = cuh;
+    for (l = 0; l < 2; l++) {
+        int dh[2], dv[2], wx, wy, w, h;
+        if (refi[l] < 0) continue;
+        aff_deltas(mv[l], lw, lh, vn, dh, dv);
+        wx = abs(dh[0]) > abs(dh[1]) ? abs(dh[0]) : abs(dh[1]);
+        wy = abs(dv[0]) > abs(dv[1]) ? abs(dv[0]) : abs(dv[1]);
+        w = wx > 4 ? 4 : (wx == 0 ? cuw : lut[wx - 1]);
+        h = wy > 4 ? 4 : (wy == 0 ? cuh : lut[wy - 1]);
+        if (w < *sub_w) *sub_w = w;
+        if (h < *sub_h) *sub_h = h;
+    }
+    for (l = 0; l < 2 && apply; l++) {      /* xevdm_check_eif_applicability_bi, :2099-2125: stops at the first list that fails */
+        int dh[2], dv[2], m;
+        if (refi[l] < 0) continue;
+        aff_deltas(mv[l], lw, lh, vn, dh, dv);
+        if (!aff_eif_applicable(dh, dv, &m)) apply = 0;
+        mb &= m;
+    }
+    if (!apply) { if (*sub_w < 8) *sub_w = 8; if (*sub_h < 8) *sub_h = 8; }
+    if (mem_band) *mem_band = mb;
+}
+
+/* eif_derive_mv_clip_range, xevdm_mc.c:2108-2150: 1/32-sample units */
+static void aff_eif_range(int x, int y, int lw, int lh, const int dh[2], const int dv[2], const int mv_scale[2], int pic_w, int pic_h,
+                          int range_clip, int max_mv[2], int min_mv[2])
+{
+    static const int spread[5] = { 128, 256, 544, 1120, 2272 };
+    const int cuw = 1 << lw, cuh = 1 << lh;
+    const int max_pic[2] = { (pic_w + AFF_MAX_CU - x - cuw - 1) * 32, (pic_h + AFF_MAX_CU - y - cuh - 1) * 32 };
+    const int min_pic[2] = { (-x - AFF_MAX_CU) * 32, (-y - AFF_MAX_CU) * 32 };
+    int c;
+    for (c = 0; c < 2; c++) {
+        if (!range_clip) { max_mv[c] = max_pic[c]; min_mv[c] = min_pic[c]; }
+        else {
+            const int centre = aff_round(mv_scale[c] + dh[c] * (cuw >> 1) + dv[c] * (cuh >> 1), 4);
+            const int sp = spread[(c == 0 ? lw : lh) - 3];
+            min_mv[c] = centre - sp; max_mv[c] = centre + sp;
+            if (min_mv[c] < min_pic[c]) { min_mv[c] = min_pic[c]; max_mv[c] = max_pic[c] < min_pic[c] + 2 * sp ? max_pic[c] : min_pic[c] + 2 * sp; }
+            else if (max_mv[c] > max_pic[c]) { max_mv[c] = max_pic[c]; min_mv[c] = min_pic[c] > max_pic[c] - 2 * sp ? min_pic[c] : max_pic[c] - 2 * sp; }
+        }
+        max_mv[c] = aff_clip18(max_mv[c]); min_mv[c] = aff_clip18(min_mv[c]);
+    }
+}
+
+/* xevdm_eif_mc, xevdm_mc.c:2543-2604: per-sample bilinear fetch at the model's vector (1/32 sample, clamped to the range -
+   xevdm_eif_bilinear_clip :2456-2499; the no-clip variant is the same when no vector leaves the range), then the 3-tap
+   [-1 10 -1] enhancement filter in both directions (xevdm_eif_filter :2428-2454).  Intermediates are `pel` (s16). */
+static void aff_eif(int bw, int bh, int x, int y, const int mv_scale[2], const int dh[2], const int dv[2], const int max_mv_[2], const int min_mv_[2],
+                    const int16_t *ref, int s_ref, int16_t *dst, int s_dst, int bd, int chroma)
+{
+    int mv0[2] = { mv_scale[0], mv_scale[1] }, mx[2] = { max_mv_[0], max_mv_[1] }, mn[2] = { min_mv_[0], min_mv_[1] };
+    const int shift1 = bd - 8 < 4 ? bd - 8 : 4, shift2 = 20 - bd > 8 ? 20 - bd : 8, off2 = 1 << (shift2 - 1);
+    const int sh2 = bd + 5 - 16 > 0 ? bd + 5 - 16 : 0, sh3 = 6 - sh2;
+    const int of2 = sh2 ? 1 << (sh2 - 1) : 0, of3 = 1 << (sh3 - 1);      /* sh2 = 0: the reference's 1 << -1 drops out of the s16 store */
+    const int ts = bw + 2;
+    int16_t *tmp = (int16_t *)malloc(sizeof(int16_t) * (size_t)ts * (bh + 2));
+    int px, py;
+    if (chroma) { mv0[0] >>= 1; mv0[1] >>= 1; mx[0] >>= 1; mx[1] >>= 1; mn[0] >>= 1; mn[1] >>= 1; x >>= 1; y >>= 1; }
+    ref += y * s_ref + x;
+    for (py = -1; py <= bh; py++) for (px = -1; px <= bw; px++) {
+        int vx = (mv0[0] + px * dh[0] + py * dv[0]) >> 4, vy = (mv0[1] + px * dh[1] + py * dv[1]) >> 4;
+        const int16_t *r;
+        int fx, fy, s1, s2;
+        vx = vx < mn[0] ? mn[0] : (vx > mx[0] ? mx[0] : vx);
+        vy = vy < mn[1] ? mn[1] : (vy > mx[1] ? mx[1] : vy);
+        r = ref + (py + (vy >> 5)) * s_ref + px + (vx >> 5);
+        fx = vx & 31; fy = vy & 31;
+        s1 = (int16_t)(((64 - 2 * fx) * r[0] + 2 * fx * r[1]) >> shift1);
+        s2 = (int16_t)(((64 - 2 * fx) * r[s_ref] + 2 * fx * r[s_ref + 1]) >> shift1);
+        tmp[(py + 1) * ts + px + 1] = (int16_t)(((64 - 2 * fy) * s1 + 2 * fy * s2 + off2) >> shift2);
+    }
+    for (py = 0; py < bh + 2; py++) {       /* in place, left to right: every read still sees the unfiltered neighbours */
+        int16_t *t = tmp + py * ts;
+        for (px = 0; px < bw; px++) t[px] = (int16_t)((-t[px] + t[px + 1] * 10 - t[px + 2] + of2) >> sh2);
+    }
+    for (py = 0; py < bh; py++) for (px = 0; px < bw; px++) {
+        const int16_t *t = tmp + (py + 1) * ts + px;
+        const int16_t res = (int16_t)((-t[-ts] + t[0] * 10 - t[ts] + of3) >> sh3);
+        dst[py * s_dst + px] = (int16_t)CLIP3(0, (1 << bd) - 1, res);
+    }
+    free(tmp);
+}
+
+/* one list: xevdm_affine_mc_lc, xevdm_mc.c:2259-2391 */
+static void aff_mc_list(const xgpu_seq_params *sp, const orc_pic *rp, int x, int y, int lw, int lh, const int16_t mv[3][2], int vn,
+                        int sub_w, int sub_h, int mem_band, int16_t *pred[3])
+{
+    const int cuw = 1 << lw, cuh = 1 << lh, wc = cuw >> 1;
+    const int mv_scale[2] = { mv[0][0] * (1 << AFF_BIT), mv[0][1] * (1 << AFF_BIT) };
+    int dh[2], dv[2], w, h;
+    aff_deltas(mv, lw, lh, vn, dh, dv);
+    if (sub_w < 8 || sub_h < 8) {
+        int mx[2], mn[2];
+        aff_eif_range(x, y, lw, lh, dh, dv, mv_scale, sp->width, sp->height, !mem_band, mx, mn);
+        aff_eif(cuw, cuh, x, y, mv_scale, dh, dv, mx, mn, rp->y, rp->s_l, pred[0], cuw, sp->bit_depth_luma, 0);
+        aff_eif(cuw >> 1, cuh >> 1, x, y, mv_scale, dh, dv, mx, mn, rp->u, rp->s_c, pred[1], wc, sp->bit_depth_chroma, 1);
+        aff_eif(cuw >> 1, cuh >> 1, x, y, mv_scale, dh, dv, mx, mn, rp->v, rp->s_c, pred[2], wc, sp->bit_depth_chroma, 1);
+        return;
+    }
+    {
+        /* sub-block translation.  As the reference has it (:2352-2353) the sub-block's position does not enter the vector: every
+           sub-block of the CU moves with the vector at the centre of the FIRST one. */
+        const int hor_max = (sp->width + AFF_MAX_CU - x - cuw) * 16, ver_max = (sp->height + AFF_MAX_CU - y - cuh) * 16;
+        const int hor_min = (-AFF_MAX_CU - x) * 16, ver_min = (-AFF_MAX_CU - y) * 16;
+        const int ox = aff_clip18(aff_round(mv_scale[0] + dh[0] * (sub_w >> 1) + dv[0] * (sub_h >> 1), 5));
+        const int oy = aff_clip18(aff_round(mv_scale[1] + dh[1] * (sub_w >> 1) + dv[1] * (sub_h >> 1), 5));
+        const int cx = ox < hor_min ? hor_min : (ox > hor_max ? hor_max : ox), cy = oy < ver_min ? ver_min : (oy > ver_max ? ver_max : oy);
+        for (h = 0; h < cuh; h += sub_h) for (w = 0; w < cuw; w += sub_w) {
+            const int gx = (x + w) * 16 + cx, gy = (y + h) * 16 + cy;
+            orc_mc_l(rp->y, gx, gy, rp->s_l, cuw, pred[0] + h * cuw + w, sub_w, sub_h, sp->bit_depth_luma, (ox & 15) != 0, (oy & 15) != 0, sp->tool_admvp);
+            orc_mc_c(rp->u, gx, gy, rp->s_c, wc, pred[1] + (h >> 1) * wc + (w >> 1), sub_w >> 1, sub_h >> 1, sp->bit_depth_chroma, (ox & 31) != 0, (oy & 31) != 0, sp->tool_admvp);
+            orc_mc_c(rp->v, gx, gy, rp->s_c, wc, pred[2] + (h >> 1) * wc + (w >> 1), sub_w >> 1, sub_h >> 1, sp->bit_depth_chroma, (ox & 31) != 0, (oy & 31) != 0, sp->tool_admvp);
+        }
+    }
+}
+
+int orc_affine_mc_cu(const xgpu_seq_params *sp, const orc_frame *fr, int x, int y, int lw, int lh, const int8_t refi[2],
+                     const int16_t mv[2][3][2], int vn, int16_t *pred0[3], int16_t *pred1[3])
+{
+    int16_t **dst[2] = { pred0, pred1 };
+    const int w = 1 << lw, h = 1 << lh;
+    int sub_w, sub_h, mem_band, l, bidx = 0, i;
+    aff_subblock(mv, refi, lw, lh, vn, &sub_w, &sub_h, &mem_band);
+    for (l = 0; l < 2; l++) {
+        if (refi[l] < 0) continue;
+        aff_mc_list(sp, &fr->refp[refi[l]][l], x, y, lw, lh, mv[l], vn, sub_w, sub_h, mem_band, dst[bidx]);
+        bidx++;
+    }
+    if (bidx == 2) {      /* :2649-2683; no identical-motion shortcut here */
+        for (i = 0; i < w * h; i++) pred0[0][i] = (int16_t)((pred0[0][i] + pred1[0][i] + 1) >> 1);
+        for (i = 0; i < (w >> 1) * (h >> 1); i++) {
+            pred0[1][i] = (int16_t)((pred0[1][i] + pred1[1][i] + 1) >> 1);
+            pred0[2][i] = (int16_t)((pred0[2][i] + pred1[2][i] + 1) >> 1);
+        }
+    }
+    return bidx;
+}
+
+/* xevdm_set_affine_mvf, xevdm_util.c:4095-4190: the vectors the in-loop filters (and later pictures) see - one per sub-block,
+   the control points themselves at the CU's corners */
+static void affine_set_mvf(const xgpu_cu_batch *b, int i, orc_maps *m)
+{
+    const int lw = b->log2w[i], lh = b->log2h[i], w_cu = (1 << lw) >> 2, h_cu = (1 << lh) >> 2, vn = b->affine[i];
+    const int16_t (*mv)[3][2] = (const int16_t (*)[3][2])&b->affine_mv[i * 12];
+    const int scup = (b->y[i] >> 2) * m->w_scu + (b->x[i] >> 2);
+    int sub_w, sub_h, l, h, w, yy, xx;
+    aff_subblock(mv, &b->refi[i * 2], lw, lh, vn, &sub_w, &sub_h, NULL);
+    for (l = 0; l < 2; l++) {
+        int dh[2], dv[2];
+        if (b->refi[i * 2 + l] < 0) continue;
+        aff_deltas(mv[l], lw, lh, vn, dh, dv);
+        for (h = 0; h < h_cu; h += sub_h >> 2) for (w = 0; w < w_cu; w += sub_w >> 2) {
+            int vx, vy;
+            if (w == 0 && h == 0) { vx = mv[l][0][0]; vy = mv[l][0][1]; }
+            else if (w + (sub_w >> 2) == w_cu && h == 0) { vx = mv[l][1][0]; vy = mv[l][1][1]; }
+            else if (w == 0 && h + (sub_h >> 2) == h_cu && vn == 3) { vx = mv[l][2][0]; vy = mv[l][2][1]; }
+            else {
+                const int px = (w << 2) + (sub_w >> 1), py = (h << 2) + (sub_h >> 1);
+                vx = aff_clip18(aff_round(mv[l][0][0] * (1 << AFF_BIT) + dh[0] * px + dv[0] * py, 5)) >> 2;
+                vy = aff_clip18(aff_round(mv[l][0][1] * (1 << AFF_BIT) + dh[1] * px + dv[1] * py, 5)) >> 2;
+            }
+            for (yy = h; yy < h + (sub_h >> 2); yy++) for (xx = w; xx < w + (sub_w >> 2); xx++) {
+                m->map_mv[(scup + yy * m->w_scu + xx) * 4 + l * 2 + 0] = (int16_t)vx;
+                m->map_mv[(scup + yy * m->w_scu + xx) * 4 + l * 2 + 1] = (int16_t)vy;
+            }
+        }
+    }
+}
+
+
 int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *maps, int16_t *resid_out)
 {
     int16_t *pred[2][3], *res;
@@ -662,7 +874,9 @@ int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_c
         const int x = b->x[i], y = b->y[i], lw = b->log2w[i], lh = b->log2h[i], w = 1 << lw, h = 1 << lh;
         size_t off = b->coef_off[i];
         const int inter = b->pred_mode[i] != XGPU_MODE_INTRA;
-        if (inter)
+        if (inter && b->affine && b->affine[i])
+            orc_affine_mc_cu(sp, fr, x, y, lw, lh, &b->refi[i * 2], (const int16_t (*)[3][2])&b->affine_mv[i * 12], b->affine[i], pred[0], pred[1]);
+        else if (inter)
             orc_mc_cu(sp, fr, x, y, w, h, &b->refi[i * 2], (const int16_t (*)[2])&b->mv[i * 4], pred[0], pred[1]);
         else if (maps) {      /* xevd_recon_unit's intra branch, xevd.c:731-741 (availability needs the SCU map) */
             int16_t nb_up[2 * MAX_CU + 8], nb_le[2 * MAX_CU + 8];
@@ -754,6 +968,7 @@ int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_c
                 orc_recon(res, pred[0][c], coded, cw, ch, s, plane + (c ? (y >> 1) * s + (x >> 1) : y * s + x), sp->bit_depth_luma);
         }
         if (maps) set_dec_info(sp, b, i, maps);
+        if (maps && inter && b->affine && b->affine[i]) affine_set_mvf(b, i, maps);
     }
     for (l = 0; l < 2; l++) for (c = 0; c < 3; c++) free(pred[l][c]);
     free(res);

@@ -53,6 +53,7 @@ class CuBatch(C.Structure):
         ("qp", C.POINTER(C.c_uint8)), ("cbf", C.POINTER(C.c_uint8)), ("cbf_sub", C.POINTER(C.c_uint16)), ("ipm", C.POINTER(C.c_uint8)), ("ats", C.POINTER(C.c_uint8)), ("ats_inter", C.POINTER(C.c_uint8)),
         ("coef_off", C.POINTER(C.c_uint32)), ("coef", C.POINTER(C.c_int16)), ("n_coef", C.c_size_t),
         ("n_ctu", C.c_int), ("ctu_cu_start", C.POINTER(C.c_uint32)), ("constrained_intra_pred", C.c_int),
+        ("affine", C.POINTER(C.c_uint8)), ("affine_mv", C.POINTER(C.c_int16)),
     ]
 
 
@@ -93,6 +94,8 @@ def make_cu_batch(b):
         "cbf_sub": None if b.get("cbf_sub") is None else np.ascontiguousarray(b["cbf_sub"], np.uint16),
         "ats": None if b.get("ats") is None else np.ascontiguousarray(b["ats"], np.uint8),
         "ats_inter": None if b.get("ats_inter") is None else np.ascontiguousarray(b["ats_inter"], np.uint8),
+        "affine": None if b.get("affine") is None else np.ascontiguousarray(b["affine"], np.uint8),
+        "affine_mv": None if b.get("affine") is None else np.ascontiguousarray(b["affine_mv"], np.int16),
         "coef_off": np.ascontiguousarray(b["coef_off"], np.uint32),
         "coef": np.ascontiguousarray(b["coef"], np.int16),
         "ctu_cu_start": np.ascontiguousarray(b["ctu_cu_start"], np.uint32),
@@ -110,6 +113,8 @@ def make_cu_batch(b):
         cb.ats = _ptr(keep["ats"], C.c_uint8)
     if keep["ats_inter"] is not None:
         cb.ats_inter = _ptr(keep["ats_inter"], C.c_uint8)
+    if keep["affine"] is not None:
+        cb.affine, cb.affine_mv = _ptr(keep["affine"], C.c_uint8), _ptr(keep["affine_mv"], C.c_int16)
     cb.coef_off, cb.coef = _ptr(keep["coef_off"], C.c_uint32), _ptr(keep["coef"], C.c_int16)
     cb.n_coef = len(keep["coef"])
     cb.n_ctu = len(keep["ctu_cu_start"]) - 1

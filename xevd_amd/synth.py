@@ -301,6 +301,28 @@ DEFAULT_CHROMA_QP_BASE = [
     35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 39, 39, 40, 40, 40, 41, 41, 41]
 
 
+def add_affine(rng, batch, frac=0.5):
+    """Turn a share of the inter CUs of at least 8x8 into affine CUs (Main, xevdm_affine_mc): 2 or 3 control points, the first = the CU's vector,
+    the others a few quarter-pel steps away so that every branch occurs - no spread (the whole CU as one block), spreads of a sample across the CU
+    (32/16/8-sample sub-blocks), stronger ones (per-sample interpolation, EIF), and rotations/shears too strong for EIF (8x8 sub-blocks)."""
+    n = len(batch["x"])
+    inter = batch["pred_mode"] != MODE_INTRA
+    ok = inter & (batch["log2w"] >= 3) & (batch["log2h"] >= 3) & (rng.random(n) < frac)
+    aff = np.where(ok, rng.integers(2, 4, n), 0).astype(np.uint8)
+    cp = np.zeros((n, 2, 3, 2), np.int64)
+    scale = np.array([0, 1, 2, 3, 6, 12, 24, 60, 160])[rng.integers(0, 9, n)]
+    for lst in range(2):
+        base = batch["mv"][:, lst, :].astype(np.int64)
+        cp[:, lst, 0] = base
+        for v in (1, 2):
+            d = rng.integers(-1, 2, (n, 2)) * scale[:, None] + rng.integers(-1, 2, (n, 2)) * (scale[:, None] // 3)
+            cp[:, lst, v] = base + d
+        cp[:, lst] *= (batch["refi"][:, lst] >= 0)[:, None, None]
+    batch["affine"] = aff
+    batch["affine_mv"] = (np.clip(cp, -32768, 32767) * (aff != 0)[:, None, None, None]).astype(np.int16)
+    return batch
+
+
 def gen_picture(rng, width, height, bit_depth=8, smooth=True):
     """A synthetic reference picture (active area only): smooth gradients + texture + noise, 4:2:0."""
     maxv = (1 << bit_depth) - 1
