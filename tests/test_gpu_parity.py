@@ -84,6 +84,9 @@ RANDOM = [
     ("tiny", 8, 8, 8, 0, 0, (1, 0), 0.0, {}),
     ("btt_all_tools", 328, 200, 10, 1, 1, (2, 2), 0.5, {"inter_frac": 1.0, "tools": {"addb": 1, "alf": 1, "btt_frac": 0.8, "ats_inter_frac": 0.7, "coded_frac": 0.8}}),
     ("btt_ctu128_base_dbk", 264, 264, 8, 1, 0, (1, 1), 0.3, {"tools": {"log2_ctu": 7, "btt_frac": 0.8, "ats_inter_frac": 0.5}}),
+    ("affine_all_tools", 328, 200, 10, 1, 1, (2, 2), 0.5, {"inter_frac": 0.9, "oob_frac": 0.3, "tools": {"addb": 1, "alf": 1, "btt_frac": 0.5, "ats_inter_frac": 0.5, "affine_frac": 0.9,
+                                                                                                     "split_prob": 0.3, "log2_ctu": 7, "coded_frac": 0.8}}),
+    ("affine_small_8b", 72, 136, 8, 1, 0, (1, 1), 0.4, {"inter_frac": 1.0, "oob_frac": 0.5, "tools": {"affine_frac": 1.0, "split_prob": 0.6}}),
 ]
 
 

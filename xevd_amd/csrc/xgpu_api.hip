@@ -504,6 +504,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         if (idx == 1 || idx == 3) bw -= idx == 3 ? 2 : 1;
         if (idx == 2 || idx == 4) bh -= idx == 4 ? 2 : 1;
     };
+    int n_aff = 0, n_aff_items = 0;
     for (int i = 0; i < n; i++) {
         const int lw = b->log2w[i], lh = b->log2h[i];
         ARGCHK(c, lw >= 2 && lw <= 7 && lh >= 2 && lh <= 7 && lw <= c->sp.log2_ctu && lh <= c->sp.log2_ctu);
@@ -515,6 +516,12 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
             const int idx = ai & 15, pos = ai >> 4;
             ARGCHK(c, idx >= 1 && idx <= 4 && pos <= 1 && lw <= 6 && lh <= 6);
             ARGCHK(c, ((idx == 1 || idx == 3) ? lw : lh) >= (idx >= 3 ? 4 : 3));
+        }
+        if (b->affine && b->affine[i]) {
+            // affine CUs exist from 8x8 (xevdm_eco.c:1529), with 2 or 3 control points and at least one reference
+            ARGCHK(c, b->affine_mv != NULL && (b->affine[i] == 2 || b->affine[i] == 3) && b->pred_mode[i] != XGPU_MODE_INTRA);
+            ARGCHK(c, lw >= 3 && lh >= 3 && (b->refi[i * 2] >= 0 || b->refi[i * 2 + 1] >= 0));
+            n_aff++; n_aff_items += ((1 << lw) + 31) / 32 * (((1 << lh) + 31) / 32);
         }
         size_t need = 0;
         int bw, bh;
@@ -548,7 +555,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
 
     xgpu_dbatch *db = new xgpu_dbatch();
     memset(db, 0, sizeof(*db));
-    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1;
+    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_aff_items = n_aff_items;
     const size_t sz_cus = sizeof(CuRec) * (size_t)std::max(n, 1), sz_ctu = sizeof(uint32_t) * (size_t)(b->n_ctu + 1);
     const size_t sz_tbs = sizeof(TbRec) * (size_t)std::max(n_tb, 1), sz_wv = sizeof(TbWave) * (size_t)std::max(n_waves, 1);
     const size_t sz_coef = sizeof(int16_t) * std::max(b->n_coef, (size_t)8);
@@ -556,7 +563,9 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     const size_t sz_intra = sizeof(IntraRec) * (size_t)std::max(n_intra, 1);
     const size_t o_wv = o_tbs + align_up((int)sz_tbs, 256), o_intra = o_wv + align_up((int)sz_wv, 256);
     const size_t sz_deps = sizeof(uint32_t) * (size_t)std::max(n_deps, 1);
-    const size_t o_deps = o_intra + align_up((int)sz_intra, 256), o_coef = o_deps + align_up((int)sz_deps, 256);
+    const size_t sz_aff = sizeof(AffItem) * (size_t)std::max(n_aff_items, 1), sz_cpmv = sizeof(int16_t) * 12 * (size_t)std::max(n_aff, 1);
+    const size_t o_deps = o_intra + align_up((int)sz_intra, 256), o_aff = o_deps + align_up((int)sz_deps, 256);
+    const size_t o_cpmv = o_aff + align_up((int)sz_aff, 256), o_coef = o_cpmv + align_up((int)sz_cpmv, 256);
     db->stage_bytes = o_coef + sz_coef;
     auto fail = [&](int code) { xgpu_batch_destroy(c, db); return code; };
     // device layout: the uploaded arrays at the staging offsets, then the residual arena and the intra done flags
@@ -588,12 +597,26 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     TbRec *tbs = (TbRec *)(hs + o_tbs);
     TbWave *wv = (TbWave *)(hs + o_wv);
 
+    AffItem *aff_items = (AffItem *)(hs + o_aff);
+    int16_t *cpmv = (int16_t *)(hs + o_cpmv);
+    int aff_fill = 0, item_fill = 0;
+
     // pass 2: records + TB scatter into class order
     int cls_fill[NCLS];
     memcpy(cls_fill, cls_first, sizeof(cls_fill));
     for (int i = 0; i < n; i++) {
         CuRec &r = cus[i];
         memset(&r, 0, sizeof(r));
+        if (b->affine && b->affine[i]) {
+            r.affine = b->affine[i];
+            memcpy(cpmv + (size_t)aff_fill * 12, b->affine_mv + (size_t)i * 12, sizeof(int16_t) * 12);
+            for (int ty = 0; ty < (1 << b->log2h[i]); ty += 32)
+                for (int tx = 0; tx < (1 << b->log2w[i]); tx += 32) {
+                    AffItem &it = aff_items[item_fill++];
+                    it.cu = (uint32_t)i; it.aff = (uint32_t)aff_fill; it.tx = (uint16_t)tx; it.ty = (uint16_t)ty; it.pad = 0;
+                }
+            aff_fill++;
+        }
         r.x = b->x[i]; r.y = b->y[i]; r.log2w = b->log2w[i]; r.log2h = b->log2h[i];
         r.pred_mode = b->pred_mode[i]; r.cbf = b->cbf[i] & 7;
         r.refi[0] = b->refi[i * 2]; r.refi[1] = b->refi[i * 2 + 1];
@@ -642,6 +665,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     uint8_t *dbase = db->blk.d_base;
     db->d_cus = (CuRec *)(dbase + o_cus); db->d_ctu_start = (uint32_t *)(dbase + o_ctu); db->d_tbs = (TbRec *)(dbase + o_tbs);
     db->d_waves = (TbWave *)(dbase + o_wv); db->d_intra = (IntraRec *)(dbase + o_intra); db->d_intra_deps = (uint32_t *)(dbase + o_deps);
+    db->d_aff_items = (AffItem *)(dbase + o_aff); db->d_cpmv = (int16_t *)(dbase + o_cpmv);
     db->d_coef = (int16_t *)(dbase + o_coef); db->d_resid = (int16_t *)(dbase + o_resid); db->d_intra_done = (uint32_t *)(dbase + o_done);
     // one copy: the staging block has the device layout
     hipError_t e = hipMemcpyAsync(dbase, hs, db->stage_bytes, hipMemcpyHostToDevice, c->stream);
@@ -699,6 +723,16 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
             a.refp[i][l].poc = i < c->fp.num_refp[l] ? c->fp.refp_poc[i][l] : 0;
         }
     TIMED(c, XGPU_K_INTER, launch_inter(c, a));
+    if (db->n_aff_items) {
+        AffineArgs f;
+        memset(&f, 0, sizeof(f));
+        f.cur_y = cur.y; f.cur_u = cur.u; f.cur_v = cur.v; f.s_l = c->s_l; f.s_c = c->s_c; f.pic_w = c->sp.width; f.pic_h = c->sp.height;
+        f.bd_l = c->sp.bit_depth_luma; f.bd_c = c->sp.bit_depth_chroma; f.admvp = a.admvp;
+        f.cus = db->d_cus; f.cpmv = db->d_cpmv; f.items = db->d_aff_items; f.n_items = db->n_aff_items;
+        f.resid = db->d_resid; f.maps = c->d_maps; f.w_scu = c->w_scu;
+        memcpy(f.refp, a.refp, sizeof(f.refp));
+        TIMED(c, XGPU_K_INTER, launch_affine(c, f));
+    }
     if (db->n_intra) {
         // intra CUs: level 1 as a plain launch, all deeper levels as one data-flow launch (k_intra.hip)
         IntraArgs ta;

@@ -39,7 +39,8 @@ struct __attribute__((aligned(16))) CuRec {
     uint8_t  qp[3];           // dequant QPs
     uint8_t  ipm[2];
     uint8_t  ats_inter;       // ats_inter_info of an inter CU (idx | pos << 4), 0 = whole-CU transform
-    uint8_t  pad[2];
+    uint8_t  affine;          // 0, or the number of control points (2 / 3) of an affine CU: predicted by k_affine, not k_inter
+    uint8_t  pad;
 };
 static_assert(sizeof(CuRec) == 32, "CuRec must be 32 bytes");
 
@@ -92,6 +93,25 @@ struct InterArgs {
     int      w_scu;
     uint16_t *owner;                   // [w_scu * h_scu] index (inside its CTU's list) of the CU covering each SCU, written by k_paint
     int      n_cu;
+    RefEntry refp[XGPU_MAX_REFS][2];
+};
+
+// Affine CUs (k_affine.hip): one work item per tile of at most 32x32 luma samples of an affine CU.
+struct AffItem { uint32_t cu, aff; uint16_t tx, ty; uint32_t pad; };      // CU record index, index into the control-point array, tile origin in the CU
+static_assert(sizeof(AffItem) == 16, "AffItem must be 16 bytes");
+struct AffineArgs {
+    int16_t *cur_y, *cur_u, *cur_v;
+    int      s_l, s_c;
+    int      pic_w, pic_h;
+    int      bd_l, bd_c;
+    int      admvp;
+    const CuRec   *cus;
+    const int16_t *cpmv;               // [n_affine][2][3][2] quarter-pel control points
+    const AffItem *items;
+    int      n_items;
+    const int16_t *resid;
+    ScuRec  *maps;
+    int      w_scu;
     RefEntry refp[XGPU_MAX_REFS][2];
 };
 
@@ -173,6 +193,9 @@ struct xgpu_dbatch {
     int16_t   *d_coef, *d_resid;
     TbRec     *d_tbs;
     TbWave    *d_waves;
+    AffItem   *d_aff_items;           // tiles of the affine CUs
+    int16_t   *d_cpmv;
+    int        n_aff_items;
     IntraRec  *d_intra;               // intra CUs sorted by dependency level
     uint32_t  *d_intra_deps;          // dependency lists (positions in d_intra)
     uint32_t  *d_intra_done;          // [n_intra] done epochs + [1] ticket counter
@@ -214,6 +237,7 @@ struct xgpu_ctx {
 void launch_itdq(xgpu_ctx *c, const ItdqArgs &a);
 void launch_inter(xgpu_ctx *c, const InterArgs &a);      // k_paint + k_inter
 void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep);
+void launch_affine(xgpu_ctx *c, const AffineArgs &a);
 void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst);
 void upload_transform_tables(const int *tm, const int16_t *ats, hipStream_t s);
 int  itdq_group_size(int log2w, int log2h);     // TBs of one size class per 256-thread work item
