@@ -54,6 +54,7 @@ extern "C" {
 #define XGPU_MODE_INTER 1
 #define XGPU_MODE_SKIP  2
 #define XGPU_MODE_DIR   3
+#define XGPU_MODE_IBC   6      /* intra block copy (Main, sps->ibc_flag): mv[0] = whole-sample block vector into the current picture, refi unused */
 
 typedef struct xgpu_ctx    xgpu_ctx;     /* one decoder instance on one GPU          */
 typedef struct xgpu_dbatch xgpu_dbatch;  /* a CU batch resident in HBM               */

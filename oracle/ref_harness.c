@@ -171,7 +171,8 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
         core->qp = core->qp_y - 6 * (sp->bit_depth_luma - 8);
         core->ipm[0] = b->ipm ? b->ipm[i * 2] : 0; core->ipm[1] = b->ipm ? b->ipm[i * 2 + 1] : 0;
         memset(core->is_coef_sub, 0, sizeof(core->is_coef_sub));
-        const u8 ai = (b->ats_inter && b->pred_mode[i] != XGPU_MODE_INTRA) ? b->ats_inter[i] : 0;
+        const int ibc = b->pred_mode[i] == XGPU_MODE_IBC;
+        const u8 ai = (b->ats_inter && b->pred_mode[i] != XGPU_MODE_INTRA && !ibc) ? b->ats_inter[i] : 0;
         int tuw = w, tuh = h;
         if (ai) { int lt_w, lt_h; xevdm_get_tu_size(ai, lw, lh, &lt_w, &lt_h); tuw = 1 << lt_w; tuh = 1 << lt_h; }
         for (c = 0; c < 3; c++) {
@@ -238,9 +239,14 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
             }
             xevd_recon_yuv(ctx, core, x, y, w, h);
         } else {
-            /* prediction: xevd.c:725-726 / xevdm.c:1311-1316 (DMVR off); affine CUs xevdm.c:1290-1295 */
+            /* prediction: xevd.c:725-726 / xevdm.c:1311-1316 (DMVR off); affine CUs xevdm.c:1290-1295; IBC xevdm.c:1263-1268 */
             const int vn = b->affine ? b->affine[i] : 0;
-            if (vn) {
+            if (ibc) {
+                TREE_CONS tc = { 0, TREE_LC, eAll };
+                core->refi[0] = core->refi[1] = -1;
+                core->mv[1][0] = core->mv[1][1] = 0;
+                xevdm_IBC_mc(x, y, lw, lh, core->mv[0], ctx->pic, core->pred[0], tc, sp->chroma_format_idc);
+            } else if (vn) {
                 int l, v;
                 mcore->affine_flag = (u8)(vn - 1);
                 memset(mcore->affine_mv, 0, sizeof(mcore->affine_mv));
@@ -268,6 +274,12 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
                 xevd_recon_yuv(ctx, core, x, y, w, h);
         }
         xevd_set_dec_info(ctx, core);
+        {   /* xevdm_set_dec_info's IBC flag (xevdm_util.c:4289-4296) */
+            int r, q;
+            for (r = 0; r < h >> 2; r++) for (q = 0; q < w >> 2; q++) {
+                if (ibc) MCU_SET_IBC(ctx->map_scu[core->scup + r * ctx->w_scu + q]); else MCU_CLR_IBC(ctx->map_scu[core->scup + r * ctx->w_scu + q]);
+            }
+        }
         if (b->affine && b->affine[i] && b->pred_mode[i] != XGPU_MODE_INTRA)      /* xevdm_set_dec_info's affine tail, xevdm_util.c:4378-4381 */
             xevdm_set_affine_mvf(ctx, core);
         if (ai) {      /* xevdm_set_dec_info's ATS-inter tail (xevdm_util.c:4321, :4375) */

@@ -426,6 +426,7 @@ void orc_dbk_chroma(int16_t *u, int16_t *v, int st_u, int st_v, int stride, int 
 #define MCU_IF(m)   (((m) >> 15) & 1)
 #define MCU_QP(m)   (((m) >> 16) & 0x7F)
 #define MCU_CBFL(m) (((m) >> 24) & 1)
+#define MCU_IBC(m)  (((m) >> 26) & 1)      /* src_main/xevdm_def.h:325-329 */
 #define MCU_COD(m)  (((m) >> 31) & 1)
 
 /* ATS-inter TU of a CU: size (xevdm_get_tu_size, src_main/xevdm_util.c:3585-3608) and offset (get_tu_pos_offset :3610-3634) in
@@ -449,9 +450,10 @@ static void set_dec_info(const xgpu_seq_params *sp, const xgpu_cu_batch *b, int 
     uint32_t v = (qp << 16) | ((uint32_t)intra << 15) | (1u << 31);
     int r, c;
     if (b->pred_mode[i] == XGPU_MODE_SKIP) v |= 1u << 23;
+    if (b->pred_mode[i] == XGPU_MODE_IBC) v |= 1u << 26;      /* xevdm_set_dec_info, xevdm_util.c:4289-4296 */
     /* the luma cbf flag of the map is is_coef_sub[Y_C][0] (xevd_util.c:1615): for a CU above 64 only its first 64x64 sub-block counts */
     if ((b->cbf[i] & 1) && (!(b->log2w[i] > 6 || b->log2h[i] > 6) || !b->cbf_sub || (b->cbf_sub[i] & 1))) v |= 1u << 24;
-    const int ai = (!intra && b->ats_inter) ? b->ats_inter[i] : 0;
+    const int ai = (!intra && b->pred_mode[i] != XGPU_MODE_IBC && b->ats_inter) ? b->ats_inter[i] : 0;
     int tx = 0, ty = 0, tw = 0, th = 0;
     if (ai) ats_inter_tu(ai, ws * 4, hs * 4, &tx, &ty, &tw, &th);
     for (r = 0; r < hs; r++) for (c = 0; c < ws; c++) {
@@ -465,6 +467,10 @@ static void set_dec_info(const xgpu_seq_params *sp, const xgpu_cu_batch *b, int 
         if (intra) {
             m->map_refi[k * 2] = m->map_refi[k * 2 + 1] = -1;
             memset(&m->map_mv[k * 4], 0, 4 * sizeof(int16_t));
+        } else if (b->pred_mode[i] == XGPU_MODE_IBC) {      /* refi -1 / -1, the block vector in list 0 (xevdm.c:1098-1110); the filters never look at it */
+            m->map_refi[k * 2] = m->map_refi[k * 2 + 1] = -1;
+            memset(&m->map_mv[k * 4], 0, 4 * sizeof(int16_t));
+            memcpy(&m->map_mv[k * 4], &b->mv[i * 4], 2 * sizeof(int16_t));
         } else {
             m->map_refi[k * 2] = b->refi[i * 2]; m->map_refi[k * 2 + 1] = b->refi[i * 2 + 1];
             memcpy(&m->map_mv[k * 4], &b->mv[i * 4], 4 * sizeof(int16_t));
@@ -874,7 +880,17 @@ int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_c
         const int x = b->x[i], y = b->y[i], lw = b->log2w[i], lh = b->log2h[i], w = 1 << lw, h = 1 << lh;
         size_t off = b->coef_off[i];
         const int inter = b->pred_mode[i] != XGPU_MODE_INTRA;
-        if (inter && b->affine && b->affine[i])
+        if (b->pred_mode[i] == XGPU_MODE_IBC) {
+            /* xevdm_IBC_mc, xevdm_mc.c:2040-2106: a copy out of the CURRENT picture (reconstructed, not yet filtered) at the whole-sample block
+               vector mv[0]; chroma at the halved vector */
+            const int bx = b->mv[i * 4], by = b->mv[i * 4 + 1];
+            int r;
+            for (r = 0; r < h; r++) memcpy(pred[0][0] + r * w, fr->cur.y + (y + by + r) * fr->cur.s_l + x + bx, sizeof(int16_t) * w);
+            for (r = 0; r < h >> 1; r++) {
+                memcpy(pred[0][1] + r * (w >> 1), fr->cur.u + ((y >> 1) + (by >> 1) + r) * fr->cur.s_c + (x >> 1) + (bx >> 1), sizeof(int16_t) * (w >> 1));
+                memcpy(pred[0][2] + r * (w >> 1), fr->cur.v + ((y >> 1) + (by >> 1) + r) * fr->cur.s_c + (x >> 1) + (bx >> 1), sizeof(int16_t) * (w >> 1));
+            }
+        } else if (inter && b->affine && b->affine[i])
             orc_affine_mc_cu(sp, fr, x, y, lw, lh, &b->refi[i * 2], (const int16_t (*)[3][2])&b->affine_mv[i * 12], b->affine[i], pred[0], pred[1]);
         else if (inter)
             orc_mc_cu(sp, fr, x, y, w, h, &b->refi[i * 2], (const int16_t (*)[2])&b->mv[i * 4], pred[0], pred[1]);
@@ -896,7 +912,7 @@ int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_c
                 intra_predict(nb_le + 4, nb_up + 4, pred[0][c], b->ipm ? b->ipm[i * 2 + (c ? 1 : 0)] : 0, cw, ch);
             }
         }
-        const int ai = (inter && b->ats_inter) ? b->ats_inter[i] : 0;
+        const int ai = (inter && b->pred_mode[i] != XGPU_MODE_IBC && b->ats_inter) ? b->ats_inter[i] : 0;      /* no ATS for IBC, xevdm.c:602 */
         for (c = 0; c < 3 && ai; c++) {
             /* ATS-inter (xevdm_sub_block_itdq :808-816, xevdm_recon :62-112): one TU of half/quarter size per component, luma
                with DST-VII/DCT-VIII when the CU is at most 32x32 (xevdm_get_ats_inter_trs, xevdm_util.c:3636-3668), residual
@@ -1000,6 +1016,7 @@ static int edge_class(const orc_maps *m, int k0, int k1)
     int mv0[2][2], mv1[2][2], l, d;
     if (MCU_IF(m0) || MCU_IF(m1)) return 0;
     if (MCU_CBFL(m0) || MCU_CBFL(m1)) return 1;
+    if (MCU_IBC(m0) || MCU_IBC(m1)) return 2;      /* the Main library's copy, xevdm_df.c:52-55 */
     for (l = 0; l < 2; l++) for (d = 0; d < 2; d++) {
         mv0[l][d] = r0[l] >= 0 ? m->map_mv[k0 * 4 + l * 2 + d] : 0;
         mv1[l][d] = r1[l] >= 0 ? m->map_mv[k1 * 4 + l * 2 + d] : 0;
@@ -1109,6 +1126,7 @@ static int addb_bs(const xgpu_seq_params *sp, const orc_frame *fr, const orc_map
     int mv0[2][2], mv1[2][2], l, d;
     if (intra && ((x0 >> lg) != (x1 >> lg) || (y0 >> lg) != (y1 >> lg))) return 4;
     if (intra) return 3;
+    if (MCU_IBC(m0) || MCU_IBC(m1)) return 3;      /* xevdm_df.c:411-414 */
     if (MCU_CBFL(m0) || MCU_CBFL(m1) || (m->map_ats && (m->map_ats[k0] || m->map_ats[k1]))) return 2;     /* ats_present, xevdm_df.c:415 */
     for (l = 0; l < 2; l++) {
         p0[l] = r0[l] >= 0 ? fr->refp[r0[l]][l].y : NULL;

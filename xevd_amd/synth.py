@@ -323,6 +323,50 @@ def add_affine(rng, batch, frac=0.5):
     return batch
 
 
+MODE_IBC = 6
+
+
+def add_ibc(rng, batch, width, height, log2_ctu=6, frac=0.3):
+    """Turn a share of the CUs into intra-block-copy CUs (Main, xevdm_IBC_mc): pred_mode 6, mv[0] = a whole-sample block vector into the part of
+    the CURRENT picture that is already reconstructed when the CU's turn comes - CTU rows above, CTUs to the left in the same row, or an earlier,
+    larger CU of the same CTU (decoding order = batch order).  Odd vectors included (chroma uses the halved vector)."""
+    n = len(batch["x"])
+    S = 1 << log2_ctu
+    x, y = batch["x"].astype(np.int64), batch["y"].astype(np.int64)
+    w, h = 1 << batch["log2w"].astype(np.int64), 1 << batch["log2h"].astype(np.int64)
+    ctu = (y // S) * ((width + S - 1) // S) + x // S
+    ai = batch.get("ats_inter")
+    aff = batch.get("affine")
+    pick = rng.random(n) < frac
+    for i in range(n):
+        if not pick[i] or (ai is not None and ai[i]) or (w[i] > 64 or h[i] > 64):
+            continue
+        opts = []
+        cy0, cx0 = (y[i] // S) * S, (x[i] // S) * S
+        if cy0 >= h[i]:
+            opts.append((0, width - w[i], 0, cy0 - h[i]))
+        if cx0 >= w[i]:
+            opts.append((0, cx0 - w[i], cy0, min(cy0 + S, height) - h[i]))
+        same = np.nonzero((ctu[:i] == ctu[i]) & (w[:i] >= w[i]) & (h[:i] >= h[i]))[0]
+        if len(same):
+            j = int(same[rng.integers(0, len(same))])
+            opts.append((x[j], x[j] + w[j] - w[i], y[j], y[j] + h[j] - h[i]))
+        if not opts:
+            continue
+        x0, x1, y0, y1 = opts[rng.integers(0, len(opts))]
+        sx, sy = int(rng.integers(x0, x1 + 1)), int(rng.integers(y0, y1 + 1))
+        batch["pred_mode"][i] = MODE_IBC
+        batch["refi"][i] = -1
+        batch["mv"][i] = 0
+        batch["mv"][i, 0] = (sx - x[i], sy - y[i])
+        if batch.get("ats") is not None:
+            batch["ats"][i] = 0
+        if aff is not None:
+            aff[i] = 0
+            batch["affine_mv"][i] = 0
+    return batch
+
+
 def gen_picture(rng, width, height, bit_depth=8, smooth=True):
     """A synthetic reference picture (active area only): smooth gradients + texture + noise, 4:2:0."""
     maxv = (1 << bit_depth) - 1
