@@ -13,7 +13,8 @@ PICTURE_CASES = ["base_p_8b", "base_b_8b", "base_p_10b", "main_b_10b", "main_adm
                  "main_btt_10b", "main_btt_ctu128_8b", "main_btt_noaddb_8b", "main_ctu128_noaddb_8b",
                  "base_i_8b", "base_p_constrained_intra_10b", "main_i_btt_10b", "main_b_ctu128_intra_mix_8b",
                  "main_eipd_i_10b", "main_eipd_i_btt_8b", "main_eipd_b_ctu128_constrained_10b",
-                 "main_affine_b_10b", "main_affine_p_8b_atsinter", "main_affine_b_ctu128_10b"]
+                 "main_affine_b_10b", "main_affine_p_8b_atsinter", "main_affine_b_ctu128_10b",
+                 "main_ibc_i_10b", "main_ibc_b_8b_noaddb", "main_ibc_p_ctu128_eipd_10b"]
 
 
 def load_picture_case(name):

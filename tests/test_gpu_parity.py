@@ -87,6 +87,10 @@ RANDOM = [
     ("affine_all_tools", 328, 200, 10, 1, 1, (2, 2), 0.5, {"inter_frac": 0.9, "oob_frac": 0.3, "tools": {"addb": 1, "alf": 1, "btt_frac": 0.5, "ats_inter_frac": 0.5, "affine_frac": 0.9,
                                                                                                      "split_prob": 0.3, "log2_ctu": 7, "coded_frac": 0.8}}),
     ("affine_small_8b", 72, 136, 8, 1, 0, (1, 1), 0.4, {"inter_frac": 1.0, "oob_frac": 0.5, "tools": {"affine_frac": 1.0, "split_prob": 0.6}}),
+    ("ibc_chains", 328, 200, 10, 1, 1, (1, 1), 0.4, {"inter_frac": 0.2, "tools": {"addb": 1, "alf": 1, "ibc_frac": 0.7, "btt_frac": 0.5, "split_prob": 0.6}}),
+    ("ibc_all_tools_ctu128", 264, 264, 8, 1, 1, (2, 2), 0.5, {"inter_frac": 0.6, "tools": {"addb": 1, "ibc_frac": 0.4, "log2_ctu": 7, "eipd": 1, "affine_frac": 0.5, "ats_frac": 0.4,
+                                                                                       "ats_inter_frac": 0.4, "btt_frac": 0.5, "split_prob": 0.45}}),
+    ("ibc_base_dbk", 136, 72, 8, 1, 0, (1, 0), 0.0, {"inter_frac": 0.3, "tools": {"ibc_frac": 0.6, "split_prob": 0.7}}),
 ]
 
 
@@ -118,6 +122,17 @@ def test_gpu_all_intra_1080p_vs_oracle():
     """BASELINE.json configs[0] shape (Baseline 1080p I-only): every CU intra, dependency chains a thousand CUs deep
     through the data-flow kernel; the resident batch is decoded three times (epoch-valued done flags, running ticket counter)."""
     cs = cases.build_case("intra1080", 1920, 1080, 8, 0, 0, (1, 0), 0.0, {"inter_frac": 0.0}, seed=3)
+    ref, _, _, _ = cases.run_cpu("oracle", cs)
+    out = cases.run_gpu(cs, repeat=3)
+    for c in range(3):
+        assert np.array_equal(out[c], ref.bufs[c]), f"plane {c}"
+
+
+def test_gpu_ibc_intra_1080p_vs_oracle():
+    """a 1080p picture of intra and intra-block-copy CUs only (Main, EIPD, ADDB): IBC CUs wait for the CUs under their source block, intra CUs for
+    their neighbours - one dependency graph through the data-flow kernel; decoded three times from the resident batch"""
+    cs = cases.build_case("ibc1080", 1920, 1080, 10, 1, 1, (1, 0), 0.0, {"inter_frac": 0.0, "ibc_frac": 0.5, "eipd": 1, "addb": 1, "split_prob": 0.55}, seed=5)
+    assert (cs["batch"]["pred_mode"] == 6).sum() > 2000
     ref, _, _, _ = cases.run_cpu("oracle", cs)
     out = cases.run_gpu(cs, repeat=3)
     for c in range(3):

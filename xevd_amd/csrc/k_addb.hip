@@ -39,6 +39,7 @@ __device__ __forceinline__ int addb_bs(const uint4 q, const uint4 p, bool cross_
 {
     const bool intra = ((q.x | p.x) >> 15) & 1;
     if (intra) return cross_ctu ? 4 : 3;
+    if (((q.x | p.x) >> 26) & 1) return 3;                 // IBC on either side (xevdm_df.c:411-414)
     if ((((q.x | p.x) >> 24) & 1) || ((q.y | p.y) >> 16)) return 2;      // luma cbf, or ATS-inter on either side (ats_present, xevdm_df.c:415)
     const int q0 = (int8_t)(q.y & 0xFF), q1 = (int8_t)((q.y >> 8) & 0xFF), p0 = (int8_t)(p.y & 0xFF), p1 = (int8_t)((p.y >> 8) & 0xFF);
     // reference pictures by identity (XEVD_PIC pointers in the reference): device picture slot, 255 = none

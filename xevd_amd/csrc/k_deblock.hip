@@ -34,6 +34,7 @@ __device__ __forceinline__ int edge_class(const uint4 q, const uint4 p)
 {
     if (((q.x | p.x) >> 15) & 1) return 0;
     if (((q.x | p.x) >> 24) & 1) return 1;
+    if (((q.x | p.x) >> 26) & 1) return 2;                 // IBC on either side: the Main library's copy of the filter (xevdm_df.c:52-55)
     const int q0 = (int8_t)(q.y & 0xFF), q1 = (int8_t)((q.y >> 8) & 0xFF), p0 = (int8_t)(p.y & 0xFF), p1 = (int8_t)((p.y >> 8) & 0xFF);
     const int qm[2][2] = { { q0 >= 0 ? (int16_t)(q.z & 0xFFFF) : 0, q0 >= 0 ? (int16_t)(q.z >> 16) : 0 },
                            { q1 >= 0 ? (int16_t)(q.w & 0xFFFF) : 0, q1 >= 0 ? (int16_t)(q.w >> 16) : 0 } };

@@ -263,7 +263,7 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     const bool intra = pred_mode == XGPU_MODE_INTRA;
     // ATS-inter: the coded TU is one half/quarter of the CU at its start or end (xevdm_get_tu_size / get_tu_pos_offset,
     // src_main/xevdm_util.c:3585-3634); residual and luma cbf exist only there (xevdm_recon.c:62-112, xevdm_util.c:3670-3712)
-    const int ai = intra ? 0 : (int)((r1.w >> 8) & 0xFF);
+    const int ai = (intra || pred_mode == XGPU_MODE_IBC) ? 0 : (int)((r1.w >> 8) & 0xFF);
     int tu_x = 0, tu_y = 0, tu_w = cw, tu_h = chh;
     if (ai) {
         const int idx = ai & 15, pos = ai >> 4;
@@ -277,18 +277,20 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     {
         uint32_t m = ((uint32_t)qp_map << 16) | ((uint32_t)intra << 15) | (1u << 31);
         if (pred_mode == XGPU_MODE_SKIP) m |= 1u << 23;
+        const bool ibc = pred_mode == XGPU_MODE_IBC;
+        if (ibc) m |= 1u << 26;                                  // MCU_SET_IBC (xevdm_def.h:325)
         if (((r0.z >> 24) & 1) && in_tu) m |= 1u << 24;          // CuRec.map_cbf
         // CU boundary, or the 64-sample transform boundary inside a wider CU (deblock_tree splits those, xevdm.c:1989-2037)
         if (((x - cu_x) & 63) == 0) m |= SCU_EDGE_L;
         if (((y - cu_y) & 63) == 0) m |= SCU_EDGE_T;
         uint4 rec;
         rec.x = m;
-        rec.y = intra ? 0x0000FFFFu : ((r0.z & 0xFFFFu) | ((uint32_t)ai << 16));
-        rec.z = intra ? 0u : r1.x;
-        rec.w = intra ? 0u : r1.y;
+        rec.y = (intra || ibc) ? 0x0000FFFFu : ((r0.z & 0xFFFFu) | ((uint32_t)ai << 16));
+        rec.z = intra ? 0u : r1.x;                               // IBC keeps its block vector in list 0 (xevdm.c:1098-1110)
+        rec.w = (intra || ibc) ? 0u : r1.y;
         *(uint4 *)&a.maps[sy * a.w_scu + sx] = rec;
     }
-    if (intra || ((r1.w >> 16) & 0xFF)) return;          // affine CUs: samples and sub-block vectors come from k_affine
+    if (intra || pred_mode == XGPU_MODE_IBC || ((r1.w >> 16) & 0xFF)) return;   // IBC CUs are reconstructed with the intra CUs (k_intra); affine CUs: samples and sub-block vectors come from k_affine
 
     // ---- motion: clip like xevd_mv_clip (xevd_mc.c:435-467), variant from the UNCLIPPED vector ----
     const int maxl = (1 << a.bd_l) - 1, maxc = (1 << a.bd_c) - 1;

@@ -189,7 +189,7 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 //              flags of the CUs it reads from.  Samples move with sc1 accesses (coherent across the XCD L2s), flags hold the
 //              launch's epoch (no reset between pictures).  There are no workgroup barriers: a wave may wait for a flag that
 //              another wave of its own workgroup sets.
-template <bool DEP, bool EIPD>
+template <bool DEP, bool EIPD, bool IBC>
 __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 {
     __shared__ __attribute__((aligned(16))) int16_t s_nb[INTRA_WAVES][3][NB_LEN];
@@ -212,7 +212,13 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
         const uint4 *rec = (const uint4 *)&a.list[item];
         const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
         const uint32_t avail_ul = uni(q0.y) & 1;
-        const uint64_t avail_up = (uint64_t)uni(q0.z) | ((uint64_t)uni(q0.w) << 32), avail_le = (uint64_t)uni(q1.x) | ((uint64_t)uni(q1.y) << 32);
+        const uint64_t avail_up = (uint64_t)uni(q0.z) | ((uint64_t)uni(q0.w) << 32);
+        uint64_t avail_le = (uint64_t)uni(q1.x) | ((uint64_t)uni(q1.y) << 32);
+        // intra block copy (batches that have such CUs run the IBC instantiation): the record's `le` word carries the block vector, there are no
+        // neighbour samples to stage (the masks are empty), and the SCU loop below copies instead of predicting
+        const bool ibc_cu = IBC && ((uni(q0.y) >> 1) & 1);
+        const int bvx = (int)(int16_t)(avail_le & 0xFFFF), bvy = (int)(int16_t)((avail_le >> 16) & 0xFFFF);
+        if (ibc_cu) avail_le = 0;
         const uint32_t dep_first = uni(q1.z), dep_count = uni(q1.w);
         const uint32_t g = uni(q2.x), m = uni(q2.y), ipm = uni(q2.z), coef_off = uni(q2.w);
         const int cu_x = g & 0xFFFF, cu_y = g >> 16;
@@ -353,7 +359,30 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
             const int x = cu_x + lx, y = cu_y + ly;
             if (sidx != t) fetch_resid(lx, ly);                      // later rounds of a CU above 32x32
             int pl[4][4], pc[2][2][2];
-            if (EIPD) {
+            if (IBC && ibc_cu) {
+                // xevdm_IBC_mc (xevdm_mc.c:2040-2106): the block at the whole-sample vector in the current picture, chroma at the halved vector.
+                // Aligned dword loads (coherent ones inside the data-flow launch: the source may have been written by this launch) + a parity shift
+                auto ldw = [&](const int16_t *p) -> uint32_t { return DEP ? ld_coherent(p) : *(const uint32_t *)p; };
+                const int sxl = x + bvx, syl = y + bvy, ol_ = sxl & 1;
+                const int16_t *src = a.cur_y + syl * a.s_l + (sxl - ol_);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t d0 = ldw(src + r * a.s_l), d1 = ldw(src + r * a.s_l + 2), d2 = ol_ ? ldw(src + r * a.s_l + 4) : 0u;
+                    const uint32_t o0 = ol_ ? (d0 >> 16) | (d1 << 16) : d0, o1 = ol_ ? (d1 >> 16) | (d2 << 16) : d1;
+                    pl[r][0] = (int)(o0 & 0xFFFF); pl[r][1] = (int)(o0 >> 16); pl[r][2] = (int)(o1 & 0xFFFF); pl[r][3] = (int)(o1 >> 16);
+                }
+                const int sxc = (x >> 1) + (bvx >> 1), syc = (y >> 1) + (bvy >> 1), oc_ = sxc & 1;
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const int16_t *sc = (c == 0 ? a.cur_u : a.cur_v) + syc * a.s_c + (sxc - oc_);
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const uint32_t d0 = ldw(sc + r * a.s_c), d1 = oc_ ? ldw(sc + r * a.s_c + 2) : 0u;
+                        const uint32_t o0 = oc_ ? (d0 >> 16) | (d1 << 16) : d0;
+                        pc[c][r][0] = (int)(o0 & 0xFFFF); pc[c][r][1] = (int)(o0 >> 16);
+                    }
+                }
+            } else if (EIPD) {
                 const int maxc = (1 << a.bd_c) - 1;
 #pragma unroll
                 for (int r = 0; r < 4; r++)
@@ -422,15 +451,18 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
     }
 }
 
-void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep)
+void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc)
 {
     const int per = dep ? INTRA_CHUNK : INTRA_WAVES;
     const int blocks = (a.count + per - 1) / per;
-    if (c->sp.tool_eipd) {
-        if (dep) hipLaunchKernelGGL((k_intra<true, true>), dim3(blocks), dim3(64 * INTRA_WAVES), 0, c->stream, a);
-        else     hipLaunchKernelGGL((k_intra<false, true>), dim3(blocks), dim3(64 * INTRA_WAVES), 0, c->stream, a);
+    const dim3 g(blocks), b(64 * INTRA_WAVES);
+#define LAUNCH(D, E, I) hipLaunchKernelGGL((k_intra<D, E, I>), g, b, 0, c->stream, a)
+    if (ibc) {      // pictures with intra-block-copy CUs: the instantiation that knows the copy path
+        if (c->sp.tool_eipd) { if (dep) LAUNCH(true, true, true); else LAUNCH(false, true, true); }
+        else                 { if (dep) LAUNCH(true, false, true); else LAUNCH(false, false, true); }
     } else {
-        if (dep) hipLaunchKernelGGL((k_intra<true, false>), dim3(blocks), dim3(64 * INTRA_WAVES), 0, c->stream, a);
-        else     hipLaunchKernelGGL((k_intra<false, false>), dim3(blocks), dim3(64 * INTRA_WAVES), 0, c->stream, a);
+        if (c->sp.tool_eipd) { if (dep) LAUNCH(true, true, false); else LAUNCH(false, true, false); }
+        else                 { if (dep) LAUNCH(true, false, false); else LAUNCH(false, false, false); }
     }
+#undef LAUNCH
 }

@@ -370,9 +370,10 @@ int xgpu_frame_end(xgpu_ctx *c)
 // reference's COD flags: a neighbouring SCU is reconstructed at CU i's turn iff its CU index is below i (xevd_recon_unit
 // sets COD CU by CU, xevd.c:744-754; xevd_get_avail_intra, xevd_util.c:689-745; single tile/slice).  The list is sorted by
 // level (1 + the highest level among the intra CUs read), which is a topological order: every dependency sits earlier.
-struct IntraPlan { std::vector<IntraRec> recs; std::vector<uint32_t> deps; int n_levels, n_level1; };
-static void build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &plan)
+struct IntraPlan { std::vector<IntraRec> recs; std::vector<uint32_t> deps; int n_levels, n_level1; bool has_ibc; };
+static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &plan)
 {
+    auto ordered = [&](uint32_t j) -> bool { return b->pred_mode[j] == XGPU_MODE_INTRA || b->pred_mode[j] == XGPU_MODE_IBC; };
     const int n = b->n_cu, ws = c->w_scu, hs = c->h_scu;
     const uint32_t NONE = 0xFFFFFFFFu;
     std::vector<uint32_t> owner((size_t)ws * hs, NONE);
@@ -386,7 +387,7 @@ static void build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     std::vector<uint32_t> deps;
     int max_level = 0;
     for (int i = 0; i < n; i++) {
-        if (b->pred_mode[i] != XGPU_MODE_INTRA) continue;
+        if (!ordered((uint32_t)i)) continue;
         const int xs = b->x[i] >> 2, ys = b->y[i] >> 2, units = ((1 << b->log2w[i]) + (1 << b->log2h[i])) >> 2;
         IntraRec r;
         memset(&r, 0, sizeof(r));
@@ -396,6 +397,32 @@ static void build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         r.coef_off = b->coef_off[i];
         int lv = 0;
         uint32_t last = NONE;
+        if (b->pred_mode[i] == XGPU_MODE_IBC) {
+            // intra block copy: the CU waits for the intra / IBC CUs under its source block - the luma block at the vector plus, for an odd
+            // vector, the sample column / row before it that the halved chroma vector reaches; all of it must precede the CU in decoding order
+            const int bvx = b->mv[i * 4], bvy = b->mv[i * 4 + 1], w = 1 << b->log2w[i], h = 1 << b->log2h[i];
+            const int x0 = b->x[i] + (bvx & ~1), x1 = b->x[i] + bvx + w - 1, y0 = b->y[i] + (bvy & ~1), y1 = b->y[i] + bvy + h - 1;
+            r.ipm[0] = r.ipm[1] = 0;
+            r.flags = 2u; r.le = (uint64_t)(uint16_t)bvx | ((uint64_t)(uint16_t)bvy << 16);
+            for (int sy = y0 >> 2; sy <= y1 >> 2; sy++)
+                for (int sx = x0 >> 2; sx <= x1 >> 2; sx++) {
+                    const uint32_t j = owner[(size_t)sy * ws + sx];
+                    if (j >= (uint32_t)i) return false;
+                    if (ordered(j) && j != last) {
+                        bool seen = false;
+                        for (size_t d = r.dep_first; d < deps.size() && !seen; d++) seen = deps[d] == j;
+                        if (!seen) deps.push_back(j);
+                        last = j;
+                    }
+                    lv = std::max(lv, level[j]);
+                }
+            r.dep_count = (uint32_t)deps.size() - r.dep_first;
+            level[i] = lv + 1;
+            max_level = std::max(max_level, lv + 1);
+            recs.push_back(r);
+            plan.has_ibc = true;
+            continue;
+        }
         // which neighbour units the CU's predictors actually read (xevd_ipred.c:96-164,587-622): only those create a dependency;
         // the others are still fetched by the kernel (availability is about COD flags, not about use) but their values are ignored
         const int wu = (1 << b->log2w[i]) >> 2, hu = (1 << b->log2h[i]) >> 2;
@@ -417,7 +444,7 @@ static void build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
             const bool j_intra = b->pred_mode[j] == XGPU_MODE_INTRA;
             if (constrained && !j_intra) return false;                                     // constrained_intra_pred: intra neighbours only
             if (!used) return true;
-            if (j_intra && j != last) {                                                    // inter CUs are complete before the intra kernel starts
+            if (ordered(j) && j != last) {                                                 // inter CUs are complete before the intra kernel starts
                 bool seen = false;
                 for (size_t d = r.dep_first; d < deps.size() && !seen; d++) seen = deps[d] == j;
                 if (!seen) deps.push_back(j);
@@ -460,6 +487,7 @@ static void build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
             if (plan.deps[d] >= (uint32_t)plan.n_level1) plan.deps[k++] = plan.deps[d];
         r.dep_count = k - r.dep_first;
     }
+    return true;
 }
 
 // The batch builder: SoA batch of the ABI -> 32-byte CU records, the TB list sorted by size class and the
@@ -482,7 +510,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     // size class = (log2w, log2h) x (vertical, horizontal) transform kind; ATS kinds only occur for intra luma TBs
     enum { NCLS = 64 * 9 };
     int cls_count[NCLS] = { 0 };
-    auto ats_inter_of = [&](int i) -> int { return (b->ats_inter && b->pred_mode[i] != XGPU_MODE_INTRA) ? b->ats_inter[i] : 0; };
+    auto ats_inter_of = [&](int i) -> int { return (b->ats_inter && b->pred_mode[i] != XGPU_MODE_INTRA && b->pred_mode[i] != XGPU_MODE_IBC) ? b->ats_inter[i] : 0; };
     auto tr_code = [&](int i, int k) -> int {
         if (k != 0) return 0;
         if (const int ai = ats_inter_of(i)) {
@@ -509,7 +537,14 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         const int lw = b->log2w[i], lh = b->log2h[i];
         ARGCHK(c, lw >= 2 && lw <= 7 && lh >= 2 && lh <= 7 && lw <= c->sp.log2_ctu && lh <= c->sp.log2_ctu);
         ARGCHK(c, b->x[i] + (1 << lw) <= c->sp.width && b->y[i] + (1 << lh) <= c->sp.height && !(b->x[i] & 3) && !(b->y[i] & 3));
-        if (b->pred_mode[i] != XGPU_MODE_INTRA) ARGCHK(c, b->refi[i * 2] < XGPU_MAX_REFS && b->refi[i * 2 + 1] < XGPU_MAX_REFS);
+        ARGCHK(c, b->pred_mode[i] <= XGPU_MODE_DIR || b->pred_mode[i] == XGPU_MODE_IBC);
+        if (b->pred_mode[i] == XGPU_MODE_IBC) {
+            // the source block (and the chroma block at the halved vector) inside the active picture; that it is reconstructed before the CU is
+            // checked by the dependency plan below
+            const int bvx = b->mv[i * 4], bvy = b->mv[i * 4 + 1];
+            ARGCHK(c, b->x[i] + (bvx & ~1) >= 0 && b->y[i] + (bvy & ~1) >= 0 && b->x[i] + bvx + (1 << lw) <= c->sp.width && b->y[i] + bvy + (1 << lh) <= c->sp.height);
+            ARGCHK(c, !(b->affine && b->affine[i]));
+        } else if (b->pred_mode[i] != XGPU_MODE_INTRA) ARGCHK(c, b->refi[i * 2] < XGPU_MAX_REFS && b->refi[i * 2 + 1] < XGPU_MAX_REFS);
         ARGCHK(c, b->qp[i * 3] < 96 && b->qp[i * 3 + 1] < 96 && b->qp[i * 3 + 2] < 96);                     // 0..51 + 6 * (bit depth - 8)
         if (const int ai = ats_inter_of(i)) {
             // availability as xevdm_check_ats_inter_info_coded (xevdm_util.c:3565-3583): CU <= 64, split dimension >= 8 (>= 16 for quarters)
@@ -549,13 +584,14 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     IntraPlan plan;
     plan.n_levels = 0; plan.n_level1 = 0;
     bool any_intra = false;
-    for (int i = 0; i < n && !any_intra; i++) any_intra = b->pred_mode[i] == XGPU_MODE_INTRA;
-    if (any_intra) build_intra_plan(c, b, plan);
+    plan.has_ibc = false;
+    for (int i = 0; i < n && !any_intra; i++) any_intra = b->pred_mode[i] == XGPU_MODE_INTRA || b->pred_mode[i] == XGPU_MODE_IBC;
+    if (any_intra) ARGCHK(c, build_intra_plan(c, b, plan));      // false: an IBC source block that is not reconstructed before its CU
     const int n_intra = (int)plan.recs.size(), n_deps = (int)plan.deps.size();
 
     xgpu_dbatch *db = new xgpu_dbatch();
     memset(db, 0, sizeof(*db));
-    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_aff_items = n_aff_items;
+    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_aff_items = n_aff_items; db->has_ibc = plan.has_ibc ? 1 : 0;
     const size_t sz_cus = sizeof(CuRec) * (size_t)std::max(n, 1), sz_ctu = sizeof(uint32_t) * (size_t)(b->n_ctu + 1);
     const size_t sz_tbs = sizeof(TbRec) * (size_t)std::max(n_tb, 1), sz_wv = sizeof(TbWave) * (size_t)std::max(n_waves, 1);
     const size_t sz_coef = sizeof(int16_t) * std::max(b->n_coef, (size_t)8);
@@ -744,9 +780,9 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
         const int n_dep = db->n_intra - db->n_intra_l1;
         TIMED(c, XGPU_K_INTRA, {
             ta.first = 0; ta.count = db->n_intra_l1;
-            if (ta.count) launch_intra(c, ta, false);
+            if (ta.count) launch_intra(c, ta, false, db->has_ibc != 0);
             ta.first = db->n_intra_l1; ta.count = n_dep;
-            if (ta.count) { launch_intra(c, ta, true); db->intra_tickets += (uint32_t)((n_dep + INTRA_CHUNK - 1) / INTRA_CHUNK); }
+            if (ta.count) { launch_intra(c, ta, true, db->has_ibc != 0); db->intra_tickets += (uint32_t)((n_dep + INTRA_CHUNK - 1) / INTRA_CHUNK); }
         });
     }
     HIPCHK(c, hipGetLastError());

@@ -306,7 +306,7 @@ def add_affine(rng, batch, frac=0.5):
     the others a few quarter-pel steps away so that every branch occurs - no spread (the whole CU as one block), spreads of a sample across the CU
     (32/16/8-sample sub-blocks), stronger ones (per-sample interpolation, EIF), and rotations/shears too strong for EIF (8x8 sub-blocks)."""
     n = len(batch["x"])
-    inter = batch["pred_mode"] != MODE_INTRA
+    inter = (batch["pred_mode"] != MODE_INTRA) & (batch["pred_mode"] != 6)      # not intra, not intra block copy
     ok = inter & (batch["log2w"] >= 3) & (batch["log2h"] >= 3) & (rng.random(n) < frac)
     aff = np.where(ok, rng.integers(2, 4, n), 0).astype(np.uint8)
     cp = np.zeros((n, 2, 3, 2), np.int64)
