@@ -34,6 +34,8 @@ WORKLOADS = {
     "cfg3_main_4k_10b_ra": dict(w=3840, h=2160, bd=10, admvp=1, iqt=1, addb=1, alf=1, n_refs=(1, 1), bi_frac=0.5),
     # configs[3]: the same at 8K - the configuration the metric (fps + HBM GB/s at 4K/8K) is quoted on
     "cfg4_main_8k_10b_ra": dict(w=7680, h=4320, bd=10, admvp=1, iqt=1, addb=1, alf=1, n_refs=(1, 1), bi_frac=0.5),
+    # not a BASELINE config: cfg4 with 30 % of the inter CUs of 8x8 and above affine (2 / 3 control points; sub-block translation and EIF) - k_affine's cost
+    "main_8k_10b_ra_affine30": dict(w=7680, h=4320, bd=10, admvp=1, iqt=1, addb=1, alf=1, n_refs=(1, 1), bi_frac=0.5, affine_frac=0.3),
 }
 DEFAULT_WORKLOAD = "cfg4_main_8k_10b_ra"
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -63,6 +65,9 @@ def make_stream(wl, seed, n_batches):
     batches = [synth.gen_frame(rng, wl["w"], wl["h"], wl["bd"], inter_frac=0.9, bi_frac=wl["bi_frac"], coded_frac=0.6,
                                n_refs=wl["n_refs"], qp_range=(22, 37), mv_sigma_px=8.0, oob_frac=0.05)
                for _ in range(n_batches)]
+    if wl.get("affine_frac"):
+        for b in batches:
+            synth.add_affine(rng, b, wl["affine_frac"])
     n_ctu = ((wl["w"] + 63) // 64) * ((wl["h"] + 63) // 64)
     alf = synth.gen_alf_params(rng, n_ctu, ctb_on_frac=1.0) if wl["alf"] else None     # all CTUs on
     return first, batches, alf
@@ -253,7 +258,7 @@ def main():
     if rank == 0:
         ab = [algorithmic_bytes(b, wl["w"], wl["h"]) for b in batches]
         kernels = {}
-        for name in ("itdq", "inter", "intra", "dbk_v", "dbk_h", "alf", "pad"):
+        for name in ("itdq", "inter", "affine", "intra", "dbk_v", "dbk_h", "alf", "pad"):
             ms, n = tim[name]
             if n:
                 kernels[name] = {"avg_us": round(1e3 * ms / n, 2), "launches": int(n)}
@@ -275,7 +280,7 @@ def main():
         except Exception:
             traffic = None
         total_alg = float(np.mean([sum(v for k, v in a.items() if k != "alf" or wl["alf"]) for a in ab]))
-        kern_s = sum(tim[k][0] for k in ("itdq", "inter", "intra", "dbk_v", "dbk_h", "alf", "pad")) * 1e-3 / args.steps
+        kern_s = sum(tim[k][0] for k in ("itdq", "inter", "affine", "intra", "dbk_v", "dbk_h", "alf", "pad")) * 1e-3 / args.steps
         out = {
             "metric": "frames/sec (bit-exact YUV) + achieved HBM GB/s",
             "value": round(world * args.steps / dt, 2),

@@ -201,7 +201,7 @@ int  xgpu_frame_end(xgpu_ctx *ctx);
 /* ------------------------------------------------------------------ measurement ------------------- */
 /* Kernel families timed with HIP events on the ctx stream (the stream the kernels are launched on).      */
 enum { XGPU_K_ITDQ = 0, XGPU_K_INTER = 1, XGPU_K_DBK_V = 2, XGPU_K_DBK_H = 3, XGPU_K_PAD = 4, XGPU_K_INTRA = 5,
-       XGPU_K_ALF = 6, XGPU_K_COUNT = 8 };
+       XGPU_K_ALF = 6, XGPU_K_AFFINE = 7, XGPU_K_COUNT = 8 };
 int  xgpu_timing_enable(xgpu_ctx *ctx, int on);
 int  xgpu_timing_reset(xgpu_ctx *ctx);
 /* resolves pending events (synchronises) and returns accumulated milliseconds and launch counts          */

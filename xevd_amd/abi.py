@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libxevd_hip.so")
 XGPU_MAX_REFS = 17
 PAD_L, PAD_C = 144, 72
 MODE_INTRA, MODE_INTER, MODE_SKIP, MODE_DIR = 0, 1, 2, 3
-K_NAMES = ["itdq", "inter", "dbk_v", "dbk_h", "pad", "intra", "alf", "rsvd"]
+K_NAMES = ["itdq", "inter", "dbk_v", "dbk_h", "pad", "intra", "alf", "affine"]
 K_COUNT = 8
 
 

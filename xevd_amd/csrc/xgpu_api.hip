@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include "xgpu_internal.h"
+#include "affine_model.h"
 
 #define HIPCHK(c, expr)                                                                                         \
     do {                                                                                                        \
@@ -532,7 +533,16 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         if (idx == 1 || idx == 3) bw -= idx == 3 ? 2 : 1;
         if (idx == 2 || idx == 4) bh -= idx == 4 ? 2 : 1;
     };
-    int n_aff = 0, n_aff_items = 0;
+    int n_aff = 0, n_aff_eif = 0, n_aff_sub = 0;
+    // the branch xevdm_affine_mc takes for CU i (EIF when a sub-block would be smaller than 8 samples): the kernels' own code, affine_model.h
+    auto affine_is_eif = [&](const xgpu_cu_batch *bb, int i) -> bool {
+        const bool use[2] = { bb->refi[i * 2] >= 0, bb->refi[i * 2 + 1] >= 0 };
+        AffModel md[2];
+        for (int l = 0; l < 2; l++) md[l] = aff_model(bb->affine_mv + (size_t)i * 12 + l * 6, bb->log2w[i], bb->log2h[i], bb->affine[i]);
+        int sw, sh; bool mb;
+        aff_subblock(md, use, bb->log2w[i], bb->log2h[i], sw, sh, mb);
+        return sw < 8 || sh < 8;
+    };
     for (int i = 0; i < n; i++) {
         const int lw = b->log2w[i], lh = b->log2h[i];
         ARGCHK(c, lw >= 2 && lw <= 7 && lh >= 2 && lh <= 7 && lw <= c->sp.log2_ctu && lh <= c->sp.log2_ctu);
@@ -556,7 +566,9 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
             // affine CUs exist from 8x8 (xevdm_eco.c:1529), with 2 or 3 control points and at least one reference
             ARGCHK(c, b->affine_mv != NULL && (b->affine[i] == 2 || b->affine[i] == 3) && b->pred_mode[i] != XGPU_MODE_INTRA);
             ARGCHK(c, lw >= 3 && lh >= 3 && (b->refi[i * 2] >= 0 || b->refi[i * 2 + 1] >= 0));
-            n_aff++; n_aff_items += ((1 << lw) + 31) / 32 * (((1 << lh) + 31) / 32);
+            n_aff++;
+            if (affine_is_eif(b, i)) n_aff_eif += ((1 << lw) + 15) / 16 * (((1 << lh) + 15) / 16);
+            else                     n_aff_sub += ((1 << lw) + 31) / 32 * (((1 << lh) + 31) / 32);
         }
         size_t need = 0;
         int bw, bh;
@@ -591,7 +603,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
 
     xgpu_dbatch *db = new xgpu_dbatch();
     memset(db, 0, sizeof(*db));
-    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_aff_items = n_aff_items; db->has_ibc = plan.has_ibc ? 1 : 0;
+    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->has_ibc = plan.has_ibc ? 1 : 0;
     const size_t sz_cus = sizeof(CuRec) * (size_t)std::max(n, 1), sz_ctu = sizeof(uint32_t) * (size_t)(b->n_ctu + 1);
     const size_t sz_tbs = sizeof(TbRec) * (size_t)std::max(n_tb, 1), sz_wv = sizeof(TbWave) * (size_t)std::max(n_waves, 1);
     const size_t sz_coef = sizeof(int16_t) * std::max(b->n_coef, (size_t)8);
@@ -599,7 +611,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     const size_t sz_intra = sizeof(IntraRec) * (size_t)std::max(n_intra, 1);
     const size_t o_wv = o_tbs + align_up((int)sz_tbs, 256), o_intra = o_wv + align_up((int)sz_wv, 256);
     const size_t sz_deps = sizeof(uint32_t) * (size_t)std::max(n_deps, 1);
-    const size_t sz_aff = sizeof(AffItem) * (size_t)std::max(n_aff_items, 1), sz_cpmv = sizeof(int16_t) * 12 * (size_t)std::max(n_aff, 1);
+    const size_t sz_aff = sizeof(AffItem) * (size_t)std::max(n_aff_eif + n_aff_sub, 1), sz_cpmv = sizeof(int16_t) * 12 * (size_t)std::max(n_aff, 1);
     const size_t o_deps = o_intra + align_up((int)sz_intra, 256), o_aff = o_deps + align_up((int)sz_deps, 256);
     const size_t o_cpmv = o_aff + align_up((int)sz_aff, 256), o_coef = o_cpmv + align_up((int)sz_cpmv, 256);
     db->stage_bytes = o_coef + sz_coef;
@@ -635,7 +647,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
 
     AffItem *aff_items = (AffItem *)(hs + o_aff);
     int16_t *cpmv = (int16_t *)(hs + o_cpmv);
-    int aff_fill = 0, item_fill = 0;
+    int aff_fill = 0, eif_fill = 0, sub_fill = n_aff_eif;
 
     // pass 2: records + TB scatter into class order
     int cls_fill[NCLS];
@@ -646,9 +658,11 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         if (b->affine && b->affine[i]) {
             r.affine = b->affine[i];
             memcpy(cpmv + (size_t)aff_fill * 12, b->affine_mv + (size_t)i * 12, sizeof(int16_t) * 12);
-            for (int ty = 0; ty < (1 << b->log2h[i]); ty += 32)
-                for (int tx = 0; tx < (1 << b->log2w[i]); tx += 32) {
-                    AffItem &it = aff_items[item_fill++];
+            const bool eif = affine_is_eif(b, i);
+            const int step = eif ? 16 : 32;
+            for (int ty = 0; ty < (1 << b->log2h[i]); ty += step)
+                for (int tx = 0; tx < (1 << b->log2w[i]); tx += step) {
+                    AffItem &it = aff_items[eif ? eif_fill++ : sub_fill++];
                     it.cu = (uint32_t)i; it.aff = (uint32_t)aff_fill; it.tx = (uint16_t)tx; it.ty = (uint16_t)ty; it.pad = 0;
                 }
             aff_fill++;
@@ -759,15 +773,15 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
             a.refp[i][l].poc = i < c->fp.num_refp[l] ? c->fp.refp_poc[i][l] : 0;
         }
     TIMED(c, XGPU_K_INTER, launch_inter(c, a));
-    if (db->n_aff_items) {
+    if (db->n_aff_eif + db->n_aff_sub) {
         AffineArgs f;
         memset(&f, 0, sizeof(f));
         f.cur_y = cur.y; f.cur_u = cur.u; f.cur_v = cur.v; f.s_l = c->s_l; f.s_c = c->s_c; f.pic_w = c->sp.width; f.pic_h = c->sp.height;
         f.bd_l = c->sp.bit_depth_luma; f.bd_c = c->sp.bit_depth_chroma; f.admvp = a.admvp;
-        f.cus = db->d_cus; f.cpmv = db->d_cpmv; f.items = db->d_aff_items; f.n_items = db->n_aff_items;
+        f.cus = db->d_cus; f.cpmv = db->d_cpmv; f.items = db->d_aff_items; f.n_eif = db->n_aff_eif; f.n_sub = db->n_aff_sub;
         f.resid = db->d_resid; f.maps = c->d_maps; f.w_scu = c->w_scu;
         memcpy(f.refp, a.refp, sizeof(f.refp));
-        TIMED(c, XGPU_K_INTER, launch_affine(c, f));
+        TIMED(c, XGPU_K_AFFINE, launch_affine(c, f));
     }
     if (db->n_intra) {
         // intra CUs: level 1 as a plain launch, all deeper levels as one data-flow launch (k_intra.hip)

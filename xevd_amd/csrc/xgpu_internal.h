@@ -96,7 +96,7 @@ struct InterArgs {
     RefEntry refp[XGPU_MAX_REFS][2];
 };
 
-// Affine CUs (k_affine.hip): one work item per tile of at most 32x32 luma samples of an affine CU.
+// Affine CUs (k_affine.hip): one work item per tile of an affine CU - 16x16 luma samples in the EIF branch, 32x32 in the translation branch.
 struct AffItem { uint32_t cu, aff; uint16_t tx, ty; uint32_t pad; };      // CU record index, index into the control-point array, tile origin in the CU
 static_assert(sizeof(AffItem) == 16, "AffItem must be 16 bytes");
 struct AffineArgs {
@@ -107,8 +107,8 @@ struct AffineArgs {
     int      admvp;
     const CuRec   *cus;
     const int16_t *cpmv;               // [n_affine][2][3][2] quarter-pel control points
-    const AffItem *items;
-    int      n_items;
+    const AffItem *items;              // the EIF tiles (16x16), then the sub-block-translation tiles (32x32)
+    int      n_eif, n_sub;
     const int16_t *resid;
     ScuRec  *maps;
     int      w_scu;
@@ -195,7 +195,7 @@ struct xgpu_dbatch {
     TbWave    *d_waves;
     AffItem   *d_aff_items;           // tiles of the affine CUs
     int16_t   *d_cpmv;
-    int        n_aff_items;
+    int        n_aff_eif, n_aff_sub;
     IntraRec  *d_intra;               // intra CUs sorted by dependency level
     uint32_t  *d_intra_deps;          // dependency lists (positions in d_intra)
     uint32_t  *d_intra_done;          // [n_intra] done epochs + [1] ticket counter
