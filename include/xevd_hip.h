@@ -144,6 +144,10 @@ typedef struct xgpu_cu_batch {
                                      CUs of at least 8x8.  `mv` of such a CU is only stored for a list it does not use          */
     const int16_t  *affine_mv;    /* [n_cu][2][3][2] quarter-pel control-point vectors mcore->affine_mv[list][vertex][x/y]
                                      (top-left, top-right, bottom-left; the third ignored with 2 control points)              */
+    int             htdf_slice_qp;/* 0 = no HTDF.  With sps->tool_htdf: ctx->sh.qp of the picture's slice - the Hadamard-domain filter
+                                     (xevdm_htdf, src_main/xevdm_recon.c:153-385) then runs on the luma block of every intra CU and every
+                                     inter CU with luma coefficients right after its reconstruction, reading one sample of border from
+                                     the CUs reconstructed before it (xevdm.c:1381-1392; a slice QP up to 17 switches it off)          */
 } xgpu_cu_batch;
 
 /* ------------------------------------------------------------------ lifetime ---------------------- */

@@ -146,7 +146,7 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
     harness *hn = harness_new(sp, fr, m, simd);
     XEVD_CTX *ctx = hn->ctx; XEVD_CORE *core = hn->core;
     XEVDM_CORE *mcore = (XEVDM_CORE *)core;
-    const int main_path = sp->tool_admvp || sp->tool_iqt || b->ats != NULL || b->ats_inter != NULL || b->affine != NULL;
+    const int main_path = sp->tool_admvp || sp->tool_iqt || b->ats != NULL || b->ats_inter != NULL || b->affine != NULL || b->htdf_slice_qp != 0;
     int i, c;
 
     if (b->affine) {
@@ -272,6 +272,13 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
                 xevdm_recon_yuv(x, y, w, h, core->coef, core->pred[0], core->is_coef, ctx->pic, ai, tc, sp->bit_depth_luma, sp->chroma_format_idc);
             } else
                 xevd_recon_yuv(ctx, core, x, y, w, h);
+        }
+        if (b->htdf_slice_qp && !ibc && (core->is_coef[Y_C] || b->pred_mode[i] == XGPU_MODE_INTRA)) {      /* xevdm.c:1381-1392 */
+            const u16 avail_cu = xevd_get_avail_intra(core->x_scu, core->y_scu, ctx->w_scu, ctx->h_scu, core->scup, lw, lh, ctx->map_scu, ctx->map_tidx);
+            const int cif = b->pred_mode[i] == XGPU_MODE_INTRA && b->constrained_intra_pred;
+            pel *rec = ctx->pic->y + y * ctx->pic->s_l + x;
+            xevdm_htdf(rec, b->htdf_slice_qp, w, h, ctx->pic->s_l, b->pred_mode[i] == XGPU_MODE_INTRA, rec, ctx->pic->s_l, avail_cu, core->scup,
+                       ctx->w_scu, ctx->h_scu, ctx->map_scu, cif, sp->bit_depth_luma);
         }
         xevd_set_dec_info(ctx, core);
         {   /* xevdm_set_dec_info's IBC flag (xevdm_util.c:4289-4296) */

@@ -869,6 +869,94 @@ static void affine_set_mvf(const xgpu_cu_batch *b, int i, orc_maps *m)
 }
 
 
+/* ------------------------------------------------------------------------------------------------
+ * HTDF, the Hadamard transform domain filter (Main, sps->tool_htdf): xevdm_htdf, src_main/xevdm_recon.c:153-385, called per CU right after
+ * its reconstruction (xevdm.c:1381-1392).  Luma only.
+ * ---------------------------------------------------------------------------------------------- */
+static const uint8_t k_htdf_thr_log2[5] = { 6, 7, 7, 8, 8 };
+static const uint8_t k_htdf_tbl[5][16] = {
+    { 0, 0, 2,  6, 10, 14, 19, 23, 28, 32,  36,  41,  45,  49,  53,  57 },
+    { 0, 0, 5, 12, 20, 29, 38, 47, 56, 65,  73,  82,  90,  98, 107, 115 },
+    { 0, 0, 1,  4,  9, 16, 24, 32, 41, 50,  59,  68,  77,  86,  94, 103 },
+    { 0, 0, 3,  9, 19, 32, 47, 64, 81, 99, 117, 135, 154, 179, 205, 230 },
+    { 0, 0, 0,  2,  6, 11, 18, 27, 38, 51,  64,  96, 128, 160, 192, 224 },
+};
+/* read_table (:176-189): small coefficients go through the table, large ones pass */
+static int htdf_lut(int z, const uint8_t *tbl, int thr, int shift, int rnd)
+{
+    const int a = z < 0 ? -z : z;
+    const int v = a < thr ? tbl[((a + rnd) & thr) >> shift] : a;      /* (a + rnd) & thr: the reference's index mask, kept as it is */
+    return z < 0 ? -v : v;
+}
+/* xevd_get_avail_intra, src_base/xevd_util.c:689-745 (one tile): bit 0 up, 1 left, 3 right, 5 up-left, 6 up-right, 7 low-left, 8 low-right */
+static int avail_intra(const orc_maps *m, int xs, int ys, int scuw, int scuh)
+{
+    const int k = ys * m->w_scu + xs;
+    int av = 0;
+    if (xs > 0 && MCU_COD(m->map_scu[k - 1])) {
+        av |= 1 << 1;
+        if (ys + scuh + scuw - 1 < m->h_scu && MCU_COD(m->map_scu[k + m->w_scu * (scuw + scuh) - m->w_scu - 1])) av |= 1 << 7;
+    }
+    if (ys > 0) {
+        av |= 1 << 0;
+        if (xs > 0 && MCU_COD(m->map_scu[k - m->w_scu - 1])) av |= 1 << 5;
+        if (xs + scuw < m->w_scu && MCU_COD(m->map_scu[k - m->w_scu + scuw])) av |= 1 << 6;
+    }
+    if (xs + scuw < m->w_scu && MCU_COD(m->map_scu[k + scuw])) {
+        av |= 1 << 3;
+        if (ys + scuh + scuw - 1 < m->h_scu && MCU_COD(m->map_scu[k + m->w_scu * (scuw + scuh - 1) + scuw])) av |= 1 << 8;
+    }
+    return av;
+}
+static void orc_htdf(int16_t *rec, int s, int w, int h, int qp, int intra, const orc_maps *m, int xs, int ys, int constrained, int bd)
+{
+    const int we = w + 2, he = h + 2, k = ys * m->w_scu + xs;
+    const int mn = w < h ? w : h, mxs = w > h ? w : h;
+    int16_t *tb, *acc;
+    int av, i, r, c, idx, thr_log2, shift, rnd, thr;
+    /* xevdm_htdf_skip_condition (:270-297) */
+    if (qp <= 17 || w * h < 64 || mxs >= 128) return;
+    if (!intra) { if (mn >= 32) return; }
+    else if (w == h && mn >= 32) qp -= 8;
+    av = avail_intra(m, xs, ys, w >> 2, h >> 2);
+    tb = (int16_t *)malloc(sizeof(int16_t) * we * he);
+    acc = (int16_t *)calloc((size_t)we * he, sizeof(int16_t));
+    for (i = 0; i < h; i++) memcpy(tb + (i + 1) * we + 1, rec + i * s, sizeof(int16_t) * w);
+    /* one sample of border: the neighbour's reconstruction where it exists (and is intra under constrained intra prediction), else the CU's own edge */
+    for (i = 0; i < h; i++) {
+        tb[(i + 1) * we] = ((av >> 1) & 1) && (!constrained || MCU_IF(m->map_scu[k - 1 + (i >> 2) * m->w_scu])) ? rec[i * s - 1] : rec[i * s];
+        tb[(i + 1) * we + we - 1] = ((av >> 3) & 1) && (!constrained || MCU_IF(m->map_scu[k + (w >> 2) + (i >> 2) * m->w_scu])) ? rec[i * s + w] : rec[i * s + w - 1];
+    }
+    for (i = 0; i < w; i++) {
+        tb[i + 1] = (av & 1) && (!constrained || MCU_IF(m->map_scu[k - m->w_scu + (i >> 2)])) ? rec[i - s] : rec[i];
+        tb[(he - 1) * we + i + 1] = rec[(h - 1) * s + i];
+    }
+    tb[0] = ((av >> 5) & 1) ? rec[-1 - s] : rec[0];
+    tb[we - 1] = ((av >> 6) & 1) ? rec[w - s] : rec[w - 1];
+    tb[we * (he - 1)] = ((av >> 7) & 1) ? rec[-1 + h * s] : rec[(h - 1) * s];
+    tb[we - 1 + we * (he - 1)] = ((av >> 8) & 1) ? rec[w + h * s] : rec[w - 1 + (h - 1) * s];
+    /* filter_block_luma (:252-268) + xevdm_htdf_filter_block (:201-250): every 2x2 window, Hadamard, table on the three AC terms, back,
+       accumulated into the four samples; a sample is final once its fourth window has gone by */
+    idx = (qp - 20 + 4) >> 3; idx = idx < 0 ? 0 : (idx > 4 ? 4 : idx);
+    thr_log2 = k_htdf_thr_log2[idx]; shift = thr_log2 - 4; rnd = (1 << shift) >> 1; thr = (1 << thr_log2) - (1 << shift);
+    for (r = 0; r < he - 1; r++) for (c = 0; c < we - 1; c++) {
+        int16_t *in = tb + r * we + c, *out = acc + r * we + c;
+        const int x0 = in[0], x1 = in[1], x2 = in[we], x3 = in[we + 1];
+        const int y0 = x0 + x2, y1 = x1 + x3, y2 = x0 - x2, y3 = x1 - x3;
+        const int z0 = y0 + y1, z1 = htdf_lut(y0 - y1, k_htdf_tbl[idx], thr, shift, rnd), z2 = htdf_lut(y2 + y3, k_htdf_tbl[idx], thr, shift, rnd),
+                  z3 = htdf_lut(y2 - y3, k_htdf_tbl[idx], thr, shift, rnd);
+        const int i0 = z0 + z2, i1 = z1 + z3, i2 = z0 - z2, i3 = z1 - z3;
+        out[0] = (int16_t)(out[0] + ((i0 + i1) >> 2));
+        out[1] = (int16_t)(out[1] + ((i0 - i1) >> 2));
+        out[we] = (int16_t)(out[we] + ((i2 + i3) >> 2));
+        out[we + 1] = (int16_t)(out[we + 1] + ((i2 - i3) >> 2));
+        in[0] = (int16_t)CLIP3(0, (1 << bd) - 1, (out[0] + 2) >> 2);
+    }
+    for (i = 0; i < h; i++) memcpy(rec + i * s, tb + (i + 1) * we + 1, sizeof(int16_t) * w);
+    free(tb); free(acc);
+}
+
+
 int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *maps, int16_t *resid_out)
 {
     int16_t *pred[2][3], *res;
@@ -983,6 +1071,9 @@ int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_c
             if (inter || maps)      /* xevd_recon_yuv passes the luma bit depth for chroma too, xevd_recon.c:75-90 */
                 orc_recon(res, pred[0][c], coded, cw, ch, s, plane + (c ? (y >> 1) * s + (x >> 1) : y * s + x), sp->bit_depth_luma);
         }
+        if (maps && b->htdf_slice_qp && b->pred_mode[i] != XGPU_MODE_IBC && ((b->cbf[i] & 1) || !inter))      /* xevdm.c:1381-1392 */
+            orc_htdf(fr->cur.y + y * fr->cur.s_l + x, fr->cur.s_l, w, h, b->htdf_slice_qp, !inter, maps, x >> 2, y >> 2, !inter && b->constrained_intra_pred,
+                     sp->bit_depth_luma);
         if (maps) set_dec_info(sp, b, i, maps);
         if (maps && inter && b->affine && b->affine[i]) affine_set_mvf(b, i, maps);
     }

@@ -56,6 +56,11 @@ CASES = [
     ("main_ibc_b_8b_noaddb", 136, 136, 8, 1, 1, (1, 1), 0.4, {"inter_frac": 0.5, "ibc_frac": 0.4, "btt_frac": 0.5, "ats_frac": 0.4, "ats_inter_frac": 0.4}),
     ("main_ibc_p_ctu128_eipd_10b", 264, 200, 10, 1, 1, (1, 0), 0.0, {"addb": 1, "alf": 1, "inter_frac": 0.4, "ibc_frac": 0.4, "log2_ctu": 7, "split_prob": 0.4, "eipd": 1,
                                                                     "btt_frac": 0.4, "affine_frac": 0.4, "constrained_intra": 1}),
+    # HTDF (sps->tool_htdf): every intra CU and every coded inter CU filtered right after its reconstruction, borders from the CUs before it
+    ("main_htdf_b_10b", 200, 136, 10, 1, 1, (1, 1), 0.4, {"addb": 1, "inter_frac": 0.7, "htdf_qp": 32, "coded_frac": 0.8}),
+    ("main_htdf_i_8b_constrained", 136, 136, 8, 1, 1, (1, 0), 0.0, {"inter_frac": 0.3, "htdf_qp": 24, "constrained_intra": 1, "btt_frac": 0.5, "split_prob": 0.4, "eipd": 1}),
+    ("main_htdf_p_ctu128_10b", 264, 200, 10, 1, 1, (2, 0), 0.0, {"addb": 1, "alf": 1, "inter_frac": 0.8, "htdf_qp": 45, "log2_ctu": 7, "split_prob": 0.4, "btt_frac": 0.4,
+                                                                "ats_inter_frac": 0.4, "affine_frac": 0.3, "ibc_frac": 0.15, "coded_frac": 0.8}),
     # CTU 128 without ADDB: the Main library's copy of the Baseline filter, CUs above 64 filtered as two halves
     ("main_ctu128_noaddb_8b", 264, 264, 8, 1, 0, (1, 1), 0.3, {"log2_ctu": 7, "btt_frac": 0.6, "ats_inter_frac": 0.5, "split_prob": 0.3}),
 ]
@@ -86,6 +91,8 @@ def build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, tools=None, seed=0, 
     batch = synth.gen_frame(rng, w, h, bd, log2_ctu=log2_ctu, ats_frac=float(tools.get("ats_frac", 0.0)), ats_inter_frac=float(tools.get("ats_inter_frac", 0.0)), btt_frac=float(tools.get("btt_frac", 0.0)), inter_frac=inter_frac, bi_frac=bi_frac, n_refs=n_refs, oob_frac=oob_frac,
                             qp_range=qp_range, split_prob=split_prob, amp=amp, coded_frac=float(tools.get("coded_frac", 0.6)), eipd=bool(tools.get("eipd", 0)))
     batch["constrained_intra_pred"] = int(tools.get("constrained_intra", 0))
+    if tools.get("htdf_qp"):
+        batch["htdf_slice_qp"] = int(tools["htdf_qp"])
     if tools.get("ibc_frac"):
         synth.add_ibc(np.random.default_rng(8000 + seed), batch, w, h, log2_ctu, float(tools["ibc_frac"]))
     if tools.get("affine_frac"):

@@ -53,7 +53,7 @@ class CuBatch(C.Structure):
         ("qp", C.POINTER(C.c_uint8)), ("cbf", C.POINTER(C.c_uint8)), ("cbf_sub", C.POINTER(C.c_uint16)), ("ipm", C.POINTER(C.c_uint8)), ("ats", C.POINTER(C.c_uint8)), ("ats_inter", C.POINTER(C.c_uint8)),
         ("coef_off", C.POINTER(C.c_uint32)), ("coef", C.POINTER(C.c_int16)), ("n_coef", C.c_size_t),
         ("n_ctu", C.c_int), ("ctu_cu_start", C.POINTER(C.c_uint32)), ("constrained_intra_pred", C.c_int),
-        ("affine", C.POINTER(C.c_uint8)), ("affine_mv", C.POINTER(C.c_int16)),
+        ("affine", C.POINTER(C.c_uint8)), ("affine_mv", C.POINTER(C.c_int16)), ("htdf_slice_qp", C.c_int),
     ]
 
 
@@ -120,6 +120,7 @@ def make_cu_batch(b):
     cb.n_ctu = len(keep["ctu_cu_start"]) - 1
     cb.ctu_cu_start = _ptr(keep["ctu_cu_start"], C.c_uint32)
     cb.constrained_intra_pred = int(b.get("constrained_intra_pred", 0) or 0)
+    cb.htdf_slice_qp = int(b.get("htdf_slice_qp", 0) or 0)
     return cb, keep
 
 
