@@ -35,6 +35,9 @@ WORKLOADS = {
     # configs[3]: the same at 8K - the configuration the metric (fps + HBM GB/s at 4K/8K) is quoted on
     "cfg4_main_8k_10b_ra": dict(w=7680, h=4320, bd=10, admvp=1, iqt=1, addb=1, alf=1, n_refs=(1, 1), bi_frac=0.5),
     # not a BASELINE config: cfg4 with 30 % of the inter CUs of 8x8 and above affine (2 / 3 control points; sub-block translation and EIF) - k_affine's cost
+    # not a BASELINE config either: cfg4 with HTDF on (slice QP 32) - every coded inter CU of a filterable size and every intra CU becomes a node of the
+    # data-flow kernel, which is where the time goes (kernels["intra"])
+    "main_8k_10b_ra_htdf": dict(w=7680, h=4320, bd=10, admvp=1, iqt=1, addb=1, alf=1, n_refs=(1, 1), bi_frac=0.5, htdf_qp=32),
     "main_8k_10b_ra_affine30": dict(w=7680, h=4320, bd=10, admvp=1, iqt=1, addb=1, alf=1, n_refs=(1, 1), bi_frac=0.5, affine_frac=0.3),
 }
 DEFAULT_WORKLOAD = "cfg4_main_8k_10b_ra"
@@ -65,6 +68,9 @@ def make_stream(wl, seed, n_batches):
     batches = [synth.gen_frame(rng, wl["w"], wl["h"], wl["bd"], inter_frac=0.9, bi_frac=wl["bi_frac"], coded_frac=0.6,
                                n_refs=wl["n_refs"], qp_range=(22, 37), mv_sigma_px=8.0, oob_frac=0.05)
                for _ in range(n_batches)]
+    if wl.get("htdf_qp"):
+        for b in batches:
+            b["htdf_slice_qp"] = wl["htdf_qp"]
     if wl.get("affine_frac"):
         for b in batches:
             synth.add_affine(rng, b, wl["affine_frac"])

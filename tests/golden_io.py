@@ -14,7 +14,8 @@ PICTURE_CASES = ["base_p_8b", "base_b_8b", "base_p_10b", "main_b_10b", "main_adm
                  "base_i_8b", "base_p_constrained_intra_10b", "main_i_btt_10b", "main_b_ctu128_intra_mix_8b",
                  "main_eipd_i_10b", "main_eipd_i_btt_8b", "main_eipd_b_ctu128_constrained_10b",
                  "main_affine_b_10b", "main_affine_p_8b_atsinter", "main_affine_b_ctu128_10b",
-                 "main_ibc_i_10b", "main_ibc_b_8b_noaddb", "main_ibc_p_ctu128_eipd_10b"]
+                 "main_ibc_i_10b", "main_ibc_b_8b_noaddb", "main_ibc_p_ctu128_eipd_10b",
+                 "main_htdf_b_10b", "main_htdf_i_8b_constrained", "main_htdf_p_ctu128_10b"]
 
 
 def load_picture_case(name):
@@ -41,6 +42,7 @@ def load_picture_case(name):
     batch = {k[2:]: d[k] for k in d.files if k.startswith("b_")}
     batch["n_coef"] = int(batch["n_coef"])
     batch["constrained_intra_pred"] = int(batch.get("constrained_intra_pred", 0))
+    batch["htdf_slice_qp"] = int(batch.get("htdf_slice_qp", 0))
     batch.setdefault("cbf_sub", None)
     batch.setdefault("ats", None)
     batch.setdefault("ats_inter", None)

@@ -91,6 +91,11 @@ RANDOM = [
     ("ibc_all_tools_ctu128", 264, 264, 8, 1, 1, (2, 2), 0.5, {"inter_frac": 0.6, "tools": {"addb": 1, "ibc_frac": 0.4, "log2_ctu": 7, "eipd": 1, "affine_frac": 0.5, "ats_frac": 0.4,
                                                                                        "ats_inter_frac": 0.4, "btt_frac": 0.5, "split_prob": 0.45}}),
     ("ibc_base_dbk", 136, 72, 8, 1, 0, (1, 0), 0.0, {"inter_frac": 0.3, "tools": {"ibc_frac": 0.6, "split_prob": 0.7}}),
+    ("htdf_b", 328, 200, 10, 1, 1, (2, 2), 0.5, {"inter_frac": 0.8, "tools": {"addb": 1, "alf": 1, "htdf_qp": 30, "coded_frac": 0.9, "split_prob": 0.45, "btt_frac": 0.5}}),
+    ("htdf_all_tools_ctu128", 264, 264, 8, 1, 1, (1, 1), 0.4, {"inter_frac": 0.6, "tools": {"addb": 1, "htdf_qp": 40, "log2_ctu": 7, "eipd": 1, "affine_frac": 0.4, "ats_frac": 0.4, "ibc_frac": 0.2,
+                                                                                        "ats_inter_frac": 0.4, "btt_frac": 0.5, "split_prob": 0.4, "coded_frac": 0.8, "constrained_intra": 1}}),
+    ("htdf_i_qp20", 136, 72, 8, 1, 0, (1, 0), 0.0, {"inter_frac": 0.0, "tools": {"htdf_qp": 20, "split_prob": 0.5}}),
+    ("htdf_off_by_qp", 136, 72, 8, 1, 0, (1, 0), 0.0, {"inter_frac": 0.5, "tools": {"htdf_qp": 17}}),
 ]
 
 
@@ -133,6 +138,16 @@ def test_gpu_ibc_intra_1080p_vs_oracle():
     their neighbours - one dependency graph through the data-flow kernel; decoded three times from the resident batch"""
     cs = cases.build_case("ibc1080", 1920, 1080, 10, 1, 1, (1, 0), 0.0, {"inter_frac": 0.0, "ibc_frac": 0.5, "eipd": 1, "addb": 1, "split_prob": 0.55}, seed=5)
     assert (cs["batch"]["pred_mode"] == 6).sum() > 2000
+    ref, _, _, _ = cases.run_cpu("oracle", cs)
+    out = cases.run_gpu(cs, repeat=3)
+    for c in range(3):
+        assert np.array_equal(out[c], ref.bufs[c]), f"plane {c}"
+
+
+def test_gpu_htdf_1080p_vs_oracle():
+    """a 1080p B picture with HTDF: every intra CU and every coded inter CU of a filterable size is a node of the dependency graph (each reads the
+    final border samples of the CUs before it) - tens of thousands of nodes through the data-flow kernel; decoded three times from the resident batch"""
+    cs = cases.build_case("htdf1080", 1920, 1080, 10, 1, 1, (1, 1), 0.4, {"inter_frac": 0.85, "htdf_qp": 34, "addb": 1, "coded_frac": 0.8, "split_prob": 0.5}, seed=6)
     ref, _, _, _ = cases.run_cpu("oracle", cs)
     out = cases.run_gpu(cs, repeat=3)
     for c in range(3):

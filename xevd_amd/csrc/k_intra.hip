@@ -189,9 +189,21 @@ __device__ __forceinline__ uint32_t uni(uint32_t v) { return (uint32_t)__builtin
 //              flags of the CUs it reads from.  Samples move with sc1 accesses (coherent across the XCD L2s), flags hold the
 //              launch's epoch (no reset between pictures).  There are no workgroup barriers: a wave may wait for a flag that
 //              another wave of its own workgroup sets.
-template <bool DEP, bool EIPD, bool IBC>
+// HTDF tables (xevdm_recon.c:163-174)
+__constant__ uint8_t k_htdf_tbl[5][16] = {
+    { 0, 0, 2,  6, 10, 14, 19, 23, 28, 32,  36,  41,  45,  49,  53,  57 },
+    { 0, 0, 5, 12, 20, 29, 38, 47, 56, 65,  73,  82,  90,  98, 107, 115 },
+    { 0, 0, 1,  4,  9, 16, 24, 32, 41, 50,  59,  68,  77,  86,  94, 103 },
+    { 0, 0, 3,  9, 19, 32, 47, 64, 81, 99, 117, 135, 154, 179, 205, 230 },
+    { 0, 0, 0,  2,  6, 11, 18, 27, 38, 51,  64,  96, 128, 160, 192, 224 },
+};
+#define HTDF_EXT (66 * 66)           // a filtered CU is at most 64 x 64 (xevdm_htdf_skip_condition): the block plus one sample of border
+
+template <bool DEP, bool EIPD, bool IBC, bool HTDF>
 __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 {
+    __shared__ int16_t s_htdf[HTDF ? INTRA_WAVES : 1][HTDF ? HTDF_EXT : 1];      // 70 KB: this instantiation runs one workgroup per CU
+    __shared__ int     s_lut[HTDF ? INTRA_WAVES : 1][16];
     __shared__ __attribute__((aligned(16))) int16_t s_nb[INTRA_WAVES][3][NB_LEN];
     __shared__ uint32_t s_chunk;
     const int t = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -214,11 +226,14 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
         const uint32_t avail_ul = uni(q0.y) & 1;
         const uint64_t avail_up = (uint64_t)uni(q0.z) | ((uint64_t)uni(q0.w) << 32);
         uint64_t avail_le = (uint64_t)uni(q1.x) | ((uint64_t)uni(q1.y) << 32);
+        const uint64_t avail_le_raw = avail_le;
         // intra block copy (batches that have such CUs run the IBC instantiation): the record's `le` word carries the block vector, there are no
         // neighbour samples to stage (the masks are empty), and the SCU loop below copies instead of predicting
         const bool ibc_cu = IBC && ((uni(q0.y) >> 1) & 1);
         const int bvx = (int)(int16_t)(avail_le & 0xFFFF), bvy = (int)(int16_t)((avail_le >> 16) & 0xFFFF);
         if (ibc_cu) avail_le = 0;
+        const uint32_t nflags = uni(q0.y);
+        const bool htdf_cu = HTDF && ((nflags >> 2) & 1), htdf_only = HTDF && ((nflags >> 3) & 1);
         const uint32_t dep_first = uni(q1.z), dep_count = uni(q1.w);
         const uint32_t g = uni(q2.x), m = uni(q2.y), ipm = uni(q2.z), coef_off = uni(q2.w);
         const int cu_x = g & 0xFFFF, cu_y = g >> 16;
@@ -354,7 +369,7 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
         }
         wave_lds_sync();
         // ---- prediction + reconstruction, one 4x4 SCU per lane and step ----
-        for (int sidx = t; sidx < nscu; sidx += 64) {
+        for (int sidx = t; sidx < (htdf_only ? 0 : nscu); sidx += 64) {
             const int lx = (sidx % scuw) << 2, ly = (sidx / scuw) << 2;
             const int x = cu_x + lx, y = cu_y + ly;
             if (sidx != t) fetch_resid(lx, ly);                      // later rounds of a CU above 32x32
@@ -443,6 +458,79 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
                     if (DEP) st_coherent(d + r * a.s_c, oc[c - 1][r]); else *(uint32_t *)(d + r * a.s_c) = oc[c - 1][r];
             }
         }
+        if (HTDF && htdf_cu) {
+            // ---- HTDF (xevdm_htdf, xevdm_recon.c:153-385): the CU's luma block with one sample of border in LDS, then every sample from the four
+            //      2x2 windows that hold it: Hadamard, table on the three AC terms, back, (sum of the four quarters + 2) >> 2 ----
+            const uint32_t av = (nflags >> 8) & 0x1FF;
+            const bool cmask = (nflags >> 4) & 1;                     // constrained intra prediction: border units only from intra neighbours
+            const int tidx = (nflags >> 20) & 7;
+            const int thr_log2 = tidx == 0 ? 6 : (tidx < 3 ? 7 : 8), shift = thr_log2 - 4, rnd = (1 << shift) >> 1, thr = (1 << thr_log2) - (1 << shift);
+            int16_t *tb = s_htdf[wv];
+            const int we = cw + 2, he = chh + 2;
+            int16_t *org = a.cur_y + cu_y * a.s_l + cu_x;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the wave's own stores of the prediction pass
+            auto ldw = [&](const int16_t *p) -> uint32_t { return DEP ? ld_coherent(p) : *(const uint32_t *)p; };
+            auto ld1s = [&](const int16_t *p) -> int {
+                const uintptr_t q = (uintptr_t)p;
+                const uint32_t d = ldw((const int16_t *)(q & ~(uintptr_t)3));
+                return (int)((q & 2) ? d >> 16 : d & 0xFFFFu);
+            };
+            if (t < 16) s_lut[wv][t] = k_htdf_tbl[tidx][t];
+            for (int i = t; i < (cw >> 1) * chh; i += 64) {
+                const int r = i >> (lw - 1), c = (i & ((cw >> 1) - 1)) << 1;
+                const uint32_t d = ldw(org + r * a.s_l + c);
+                tb[(r + 1) * we + c + 1] = (int16_t)(d & 0xFFFF); tb[(r + 1) * we + c + 2] = (int16_t)(d >> 16);
+            }
+            for (int i = t; i < chh; i += 64) {
+                const bool ok_l = ((av >> 1) & 1) && (!cmask || ((avail_le_raw >> (i >> 2)) & 1));
+                tb[(i + 1) * we] = (int16_t)ld1s(org + i * a.s_l + (ok_l ? -1 : 0));
+                tb[(i + 1) * we + we - 1] = (int16_t)ld1s(org + i * a.s_l + (((av >> 3) & 1) ? cw : cw - 1));
+            }
+            for (int i = t; i < cw; i += 64) {
+                const bool ok_u = (av & 1) && (!cmask || ((avail_up >> (i >> 2)) & 1));
+                tb[i + 1] = (int16_t)ld1s(org + i - (ok_u ? a.s_l : 0));
+                tb[(he - 1) * we + i + 1] = (int16_t)ld1s(org + (chh - 1) * a.s_l + i);
+            }
+            if (t == 0) tb[0] = (int16_t)ld1s(((av >> 5) & 1) ? org - 1 - a.s_l : org);
+            if (t == 1) tb[we - 1] = (int16_t)ld1s(((av >> 6) & 1) ? org + cw - a.s_l : org + cw - 1);
+            if (t == 2) tb[we * (he - 1)] = (int16_t)ld1s(((av >> 7) & 1) ? org - 1 + chh * a.s_l : org + (chh - 1) * a.s_l);
+            if (t == 3) tb[we - 1 + we * (he - 1)] = (int16_t)ld1s(((av >> 8) & 1) ? org + cw + chh * a.s_l : org + cw - 1 + (chh - 1) * a.s_l);
+            wave_lds_sync();
+            const int *lut = s_lut[wv];
+            auto lutf = [&](int z) -> int {                           // read_table (:176-189)
+                const int ab = z < 0 ? -z : z;
+                const int v = ab < thr ? lut[((ab + rnd) & thr) >> shift] : ab;
+                return z < 0 ? -v : v;
+            };
+            for (int i = t; i < (cw >> 1) * chh; i += 64) {
+                const int r = i >> (lw - 1), c = (i & ((cw >> 1) - 1)) << 1;          // output samples (r, c) and (r, c + 1) = ext (r + 1, c + 1), (r + 1, c + 2)
+                int p[3][4];
+#pragma unroll
+                for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+                    for (int cc = 0; cc < 4; cc++) p[rr][cc] = tb[(r + rr) * we + c + cc];
+                int acc[2] = { 0, 0 };
+#pragma unroll
+                for (int wr = 0; wr < 2; wr++)
+#pragma unroll
+                    for (int wc = 0; wc < 3; wc++) {                   // window with its top-left sample at ext (r + wr, c + wc)
+                        const int x0 = p[wr][wc], x1 = p[wr][wc + 1], x2 = p[wr + 1][wc], x3 = p[wr + 1][wc + 1];
+                        const int y0 = x0 + x2, y1 = x1 + x3, y2 = x0 - x2, y3 = x1 - x3;
+                        const int z0 = y0 + y1, z1 = lutf(y0 - y1), z2 = lutf(y2 + y3), z3 = lutf(y2 - y3);
+                        const int i0 = z0 + z2, i1 = z1 + z3, i2 = z0 - z2, i3 = z1 - z3;
+                        // the sample at ext (r + 1, c + 1 + e) sits in this window at row 1 - wr, column 1 + e - wc
+#pragma unroll
+                        for (int e = 0; e < 2; e++) {
+                            const int col = 1 + e - wc;
+                            if (col < 0 || col > 1) continue;
+                            const int v = wr == 0 ? (col == 0 ? i2 + i3 : i2 - i3) : (col == 0 ? i0 + i1 : i0 - i1);
+                            acc[e] += v >> 2;
+                        }
+                    }
+                const int o0 = clip3i(0, maxv, ((int)(int16_t)acc[0] + 2) >> 2), o1 = clip3i(0, maxv, ((int)(int16_t)acc[1] + 2) >> 2);
+                if (DEP) st_coherent(org + r * a.s_l + c, pack2i(o0, o1)); else *(uint32_t *)(org + r * a.s_l + c) = pack2i(o0, o1);
+            }
+        }
         if (DEP) {      // publish: the wave's sc1 stores have reached the coherence point once vmcnt drains; then the done flag
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (t == 0) __hip_atomic_store(&a.done[item], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -451,18 +539,21 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
     }
 }
 
-void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc)
+void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf)
 {
     const int per = dep ? INTRA_CHUNK : INTRA_WAVES;
     const int blocks = (a.count + per - 1) / per;
     const dim3 g(blocks), b(64 * INTRA_WAVES);
-#define LAUNCH(D, E, I) hipLaunchKernelGGL((k_intra<D, E, I>), g, b, 0, c->stream, a)
-    if (ibc) {      // pictures with intra-block-copy CUs: the instantiation that knows the copy path
-        if (c->sp.tool_eipd) { if (dep) LAUNCH(true, true, true); else LAUNCH(false, true, true); }
-        else                 { if (dep) LAUNCH(true, false, true); else LAUNCH(false, false, true); }
+#define LAUNCH(D, E, I, H) hipLaunchKernelGGL((k_intra<D, E, I, H>), g, b, 0, c->stream, a)
+    if (htdf) {     // pictures with HTDF nodes (they use the IBC-capable instantiation)
+        if (c->sp.tool_eipd) { if (dep) LAUNCH(true, true, true, true); else LAUNCH(false, true, true, true); }
+        else                 { if (dep) LAUNCH(true, false, true, true); else LAUNCH(false, false, true, true); }
+    } else if (ibc) {      // pictures with intra-block-copy CUs: the instantiation that knows the copy path
+        if (c->sp.tool_eipd) { if (dep) LAUNCH(true, true, true, false); else LAUNCH(false, true, true, false); }
+        else                 { if (dep) LAUNCH(true, false, true, false); else LAUNCH(false, false, true, false); }
     } else {
-        if (c->sp.tool_eipd) { if (dep) LAUNCH(true, true, false); else LAUNCH(false, true, false); }
-        else                 { if (dep) LAUNCH(true, false, false); else LAUNCH(false, false, false); }
+        if (c->sp.tool_eipd) { if (dep) LAUNCH(true, true, false, false); else LAUNCH(false, true, false, false); }
+        else                 { if (dep) LAUNCH(true, false, false, false); else LAUNCH(false, false, false, false); }
     }
 #undef LAUNCH
 }

@@ -371,10 +371,22 @@ int xgpu_frame_end(xgpu_ctx *c)
 // reference's COD flags: a neighbouring SCU is reconstructed at CU i's turn iff its CU index is below i (xevd_recon_unit
 // sets COD CU by CU, xevd.c:744-754; xevd_get_avail_intra, xevd_util.c:689-745; single tile/slice).  The list is sorted by
 // level (1 + the highest level among the intra CUs read), which is a topological order: every dependency sits earlier.
-struct IntraPlan { std::vector<IntraRec> recs; std::vector<uint32_t> deps; int n_levels, n_level1; bool has_ibc; };
+struct IntraPlan { std::vector<IntraRec> recs; std::vector<uint32_t> deps; int n_levels, n_level1; bool has_ibc, has_htdf; };
 static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &plan)
 {
-    auto ordered = [&](uint32_t j) -> bool { return b->pred_mode[j] == XGPU_MODE_INTRA || b->pred_mode[j] == XGPU_MODE_IBC; };
+    // HTDF (xevdm.c:1381-1392 with xevdm_htdf_skip_condition, xevdm_recon.c:270-297): which CUs are filtered right after their reconstruction, and with
+    // which of the five tables.  Such a CU - inter ones included - reads the final samples of the CUs before it and is read by the ones after it:
+    // it becomes a node of the dependency graph next to the intra and IBC CUs
+    const int hqp = b->htdf_slice_qp;
+    auto htdf_idx = [&](uint32_t j) -> int {       // -1: not filtered
+        const bool intra = b->pred_mode[j] == XGPU_MODE_INTRA;
+        if (hqp <= 17 || b->pred_mode[j] == XGPU_MODE_IBC || !((b->cbf[j] & 1) || intra)) return -1;
+        const int w = 1 << b->log2w[j], h = 1 << b->log2h[j], mn = std::min(w, h), mx = std::max(w, h);
+        if (w * h < 64 || mx >= 128 || (!intra && mn >= 32)) return -1;
+        const int qp = hqp - ((intra && w == h && mn >= 32) ? 8 : 0);
+        return std::min(std::max((qp - 20 + 4) >> 3, 0), 4);
+    };
+    auto ordered = [&](uint32_t j) -> bool { return b->pred_mode[j] == XGPU_MODE_INTRA || b->pred_mode[j] == XGPU_MODE_IBC || htdf_idx(j) >= 0; };
     const int n = b->n_cu, ws = c->w_scu, hs = c->h_scu;
     const uint32_t NONE = 0xFFFFFFFFu;
     std::vector<uint32_t> owner((size_t)ws * hs, NONE);
@@ -398,6 +410,61 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         r.coef_off = b->coef_off[i];
         int lv = 0;
         uint32_t last = NONE;
+        const int hidx = htdf_idx((uint32_t)i);
+        const bool h_intra = b->pred_mode[i] == XGPU_MODE_INTRA;
+        // the border samples the filter reads (xevdm_htdf, xevdm_recon.c:299-385) with the availability of xevd_get_avail_intra (xevd_util.c:689-745):
+        // "reconstructed" = earlier in decoding order
+        auto add_htdf = [&](IntraRec &r) -> bool {
+            const int scuw = (1 << b->log2w[i]) >> 2, scuh = (1 << b->log2h[i]) >> 2;
+            auto cod = [&](int sx, int sy) -> bool { return owner[(size_t)sy * ws + sx] < (uint32_t)i; };
+            auto dep = [&](int sx, int sy) {
+                const uint32_t j = owner[(size_t)sy * ws + sx];
+                if (j >= (uint32_t)i) return;                       // not reconstructed yet: the reference reads what is there, so do we
+                if (ordered(j)) {
+                    bool seen = false;
+                    for (size_t d = r.dep_first; d < deps.size() && !seen; d++) seen = deps[d] == j;
+                    if (!seen) deps.push_back(j);
+                }
+                lv = std::max(lv, level[j]);
+            };
+            uint32_t av = 0;
+            if (xs > 0 && cod(xs - 1, ys)) {
+                av |= 1u << 1;
+                if (ys + scuh + scuw - 1 < hs && cod(xs - 1, ys + scuh + scuw - 1)) av |= 1u << 7;
+            }
+            if (ys > 0) {
+                av |= 1u << 0;
+                if (xs > 0 && cod(xs - 1, ys - 1)) av |= 1u << 5;
+                if (xs + scuw < ws && cod(xs + scuw, ys - 1)) av |= 1u << 6;
+            }
+            if (xs + scuw < ws && cod(xs + scuw, ys)) {
+                av |= 1u << 3;
+                if (ys + scuh + scuw - 1 < hs && cod(xs + scuw, ys + scuh + scuw - 1)) av |= 1u << 8;
+            }
+            if ((av & 8u) && h_intra && constrained) return false;      // a right neighbour under constrained intra prediction: no per-unit mask for it
+            if (av & 2u)  for (int k = 0; k < scuh; k++) dep(xs - 1, ys + k);
+            if (av & 1u)  for (int k = 0; k < scuw; k++) dep(xs + k, ys - 1);
+            if (av & 8u)  for (int k = 0; k < scuh; k++) dep(xs + scuw, ys + k);
+            if (av & 32u) dep(xs - 1, ys - 1);
+            if (av & 64u) dep(xs + scuw, ys - 1);
+            if ((av & 128u) && ys + scuh < hs) dep(xs - 1, ys + scuh);
+            if ((av & 256u) && ys + scuh < hs) dep(xs + scuw, ys + scuh);
+            r.flags |= 4u | (av << 8) | ((uint32_t)hidx << 20) | ((h_intra && constrained) ? 16u : 0u);
+            return true;
+        };
+        if (!h_intra && b->pred_mode[i] != XGPU_MODE_IBC) {
+            // an inter CU that is only here for its filter: k_inter / k_affine have reconstructed it, the node filters it in place
+            r.cbf = 0; r.ipm[0] = r.ipm[1] = 0;
+            r.flags = 8u;
+            if (!add_htdf(r)) return false;
+            r.dep_count = (uint32_t)deps.size() - r.dep_first;
+            level[i] = lv + 1;
+            max_level = std::max(max_level, lv + 1);
+            recs.push_back(r);
+            plan.has_ibc = true;                 // the instantiation with the extra node kinds
+            plan.has_htdf = true;
+            continue;
+        }
         if (b->pred_mode[i] == XGPU_MODE_IBC) {
             // intra block copy: the CU waits for the intra / IBC CUs under its source block - the luma block at the vector plus, for an odd
             // vector, the sample column / row before it that the halved chroma vector reaches; all of it must precede the CU in decoding order
@@ -464,6 +531,7 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
             used = k < need_le;
             if (xs > 0 && ys + k < hs && ok(xs - 1, ys + k)) r.le |= 1ull << k;
         }
+        if (hidx >= 0) { used = true; if (!add_htdf(r)) return false; plan.has_htdf = true; plan.has_ibc = true; }
         r.dep_count = (uint32_t)deps.size() - r.dep_first;
         level[i] = lv + 1;
         max_level = std::max(max_level, lv + 1);
@@ -501,6 +569,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     ARGCHK(c, b->n_cu >= 0 && b->n_ctu == c->w_ctu * c->h_ctu);
     ARGCHK(c, b->n_cu == 0 || (b->x && b->y && b->log2w && b->log2h && b->pred_mode && b->refi && b->mv && b->qp && b->cbf && b->coef_off));
     ARGCHK(c, b->ctu_cu_start != NULL && (b->n_coef == 0 || b->coef != NULL));
+    ARGCHK(c, b->htdf_slice_qp >= 0 && b->htdf_slice_qp <= 51);
     ARGCHK(c, b->ctu_cu_start[0] == 0 && b->ctu_cu_start[b->n_ctu] == (uint32_t)b->n_cu);      // the kernels index the CU records through it
     for (int k = 0; k < b->n_ctu; k++) ARGCHK(c, b->ctu_cu_start[k] <= b->ctu_cu_start[k + 1]);
     HIPCHK(c, hipSetDevice(c->sp.device));
@@ -596,14 +665,14 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     IntraPlan plan;
     plan.n_levels = 0; plan.n_level1 = 0;
     bool any_intra = false;
-    plan.has_ibc = false;
-    for (int i = 0; i < n && !any_intra; i++) any_intra = b->pred_mode[i] == XGPU_MODE_INTRA || b->pred_mode[i] == XGPU_MODE_IBC;
+    plan.has_ibc = false; plan.has_htdf = false;
+    for (int i = 0; i < n && !any_intra; i++) any_intra = b->pred_mode[i] == XGPU_MODE_INTRA || b->pred_mode[i] == XGPU_MODE_IBC || (b->htdf_slice_qp > 17 && (b->cbf[i] & 1));
     if (any_intra) ARGCHK(c, build_intra_plan(c, b, plan));      // false: an IBC source block that is not reconstructed before its CU
     const int n_intra = (int)plan.recs.size(), n_deps = (int)plan.deps.size();
 
     xgpu_dbatch *db = new xgpu_dbatch();
     memset(db, 0, sizeof(*db));
-    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->has_ibc = plan.has_ibc ? 1 : 0;
+    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->has_ibc = plan.has_ibc ? 1 : 0; db->has_htdf = plan.has_htdf ? 1 : 0;
     const size_t sz_cus = sizeof(CuRec) * (size_t)std::max(n, 1), sz_ctu = sizeof(uint32_t) * (size_t)(b->n_ctu + 1);
     const size_t sz_tbs = sizeof(TbRec) * (size_t)std::max(n_tb, 1), sz_wv = sizeof(TbWave) * (size_t)std::max(n_waves, 1);
     const size_t sz_coef = sizeof(int16_t) * std::max(b->n_coef, (size_t)8);
@@ -794,9 +863,9 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
         const int n_dep = db->n_intra - db->n_intra_l1;
         TIMED(c, XGPU_K_INTRA, {
             ta.first = 0; ta.count = db->n_intra_l1;
-            if (ta.count) launch_intra(c, ta, false, db->has_ibc != 0);
+            if (ta.count) launch_intra(c, ta, false, db->has_ibc != 0, db->has_htdf != 0);
             ta.first = db->n_intra_l1; ta.count = n_dep;
-            if (ta.count) { launch_intra(c, ta, true, db->has_ibc != 0); db->intra_tickets += (uint32_t)((n_dep + INTRA_CHUNK - 1) / INTRA_CHUNK); }
+            if (ta.count) { launch_intra(c, ta, true, db->has_ibc != 0, db->has_htdf != 0); db->intra_tickets += (uint32_t)((n_dep + INTRA_CHUNK - 1) / INTRA_CHUNK); }
         });
     }
     HIPCHK(c, hipGetLastError());

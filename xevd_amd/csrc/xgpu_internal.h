@@ -120,7 +120,9 @@ struct AffineArgs {
 // the column to the left (cw/4 + ch/4 units each) comes from the picture, else it is mid grey.
 struct __attribute__((aligned(16))) IntraRec {
     uint32_t cu;              // index into the CU records
-    uint32_t flags;           // bit 0: the up-left sample is available; bit 1: an intra-block-copy CU (then `le` = block vector x | y << 16, `up` = 0)
+    uint32_t flags;           // bit 0: the up-left sample is available; bit 1: an intra-block-copy CU (then `le` = block vector x | y << 16, `up` = 0);
+                              // bit 2: HTDF runs on the CU, bit 3: and nothing else (an inter CU), bit 4: under constrained intra prediction (the up / le masks
+                              // pick the border units), bits 8-16: xevd_get_avail_intra's bits 0-8, bits 20-22: table
     uint64_t up, le;
     uint32_t dep_first, dep_count;   // range of the dependency list: positions (in this list) of the intra CUs it reads from
     uint16_t x, y;            // the CU fields the kernel needs, copied here so that one record fetch starts the work
@@ -199,7 +201,7 @@ struct xgpu_dbatch {
     IntraRec  *d_intra;               // intra CUs sorted by dependency level
     uint32_t  *d_intra_deps;          // dependency lists (positions in d_intra)
     uint32_t  *d_intra_done;          // [n_intra] done epochs + [1] ticket counter
-    int        has_ibc;               // the intra list holds intra-block-copy CUs
+    int        has_ibc, has_htdf;     // the intra list holds intra-block-copy CUs / HTDF nodes
     int        n_intra, n_levels, n_intra_deps, n_intra_l1;      // n_intra_l1: CUs of level 1 (head of the list)
     uint32_t   intra_epoch, intra_tickets;
     void      *h_stage;               // pinned staging block
@@ -237,7 +239,7 @@ struct xgpu_ctx {
 // kernel launchers (one per .hip file)
 void launch_itdq(xgpu_ctx *c, const ItdqArgs &a);
 void launch_inter(xgpu_ctx *c, const InterArgs &a);      // k_paint + k_inter
-void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc);
+void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf);
 void launch_affine(xgpu_ctx *c, const AffineArgs &a);
 void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst);
 void upload_transform_tables(const int *tm, const int16_t *ats, hipStream_t s);
