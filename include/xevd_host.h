@@ -100,6 +100,7 @@ typedef struct xhost_stream_params {
     int cqt_num_points[2];                 /* 1..16 per table                                                        */
     int cqt_delta_in[2][16];               /* delta_qp_in_val_minus1 (6 bits)                                         */
     int cqt_delta_out[2][16];              /* delta_qp_out_val                                                       */
+    int tool_htdf;                         /* sps->tool_htdf: no CU syntax of its own; the parser hands the slice QP to the backend (batch.htdf_slice_qp) */
 } xhost_stream_params;
 
 /* ALF parameter set as it is coded in an APS NAL unit (XEVD_ALF_SLICE_PARAM after xevdm_eco_alf_aps_param), no fixed filters */

@@ -157,6 +157,8 @@ def golden_streams(only=()):
                                 "main_dra_10b": (144, 88, 5, dict(main=True, iqt=True, bit_depth=10, dra="five_ranges_idx40", addb=True, log2_sub_gop=2, max_refs=2)),
                                 "main_eipd_i_8b": (136, 120, 2, dict(main=True, eipd=True, idr_period=1, split_prob=0.7)),
                                 "main_eipd_all_tools_10b": (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, inter_frac=0.5, log2_sub_gop=2, max_refs=2, bit_depth=10)),
+                                "main_htdf_all_tools_10b": (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, inter_frac=0.6, log2_sub_gop=2, max_refs=2, bit_depth=10)),
+                                "main_htdf_8b": (136, 72, 4, dict(main=True, htdf=True, inter_frac=0.6, max_refs=2)),
                                 "signed_hier_b_8b": (136, 120, 5, dict(log2_sub_gop=2, max_refs=2, sign=True)),
                                 "signed_main_alf_10b": (136, 72, 4, dict(main=True, iqt=True, addb=True, alf=True, bit_depth=10, sign=True))}.items():
         if only and name not in only:

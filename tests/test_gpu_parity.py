@@ -300,10 +300,11 @@ def test_gpu_decoder_survives_mutated_streams():
             pos = int(rng.integers(len(data) // 4, len(data)))
             data[pos] ^= 1 << int(rng.integers(0, 8))
         try:
-            decoded += len(StreamDecoder(bytes(data)).output_order())
+            for _pic in StreamDecoder(bytes(data)).pictures(download=True):      # pictures in front of the damage still reach the backend
+                decoded += 1
         except Exception:
             failed += 1
-    assert decoded > 0
+    assert decoded > 0 and failed > 0
     d = np.load(paths[0])
     ours = su.decode_gpu(d["bytes"].tobytes())
     for k in range(len(ours)):
@@ -312,7 +313,7 @@ def test_gpu_decoder_survives_mutated_streams():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["hier_b_gop4", "main_eipd_all_tools_10b", "cqt_crop_10b", "idr_period_skip", "main_dra_10b"])
+@pytest.mark.parametrize("name", ["hier_b_gop4", "main_eipd_all_tools_10b", "cqt_crop_10b", "idr_period_skip", "main_dra_10b", "main_htdf_all_tools_10b"])
 def test_gpu_plain_c_decoder(name, tmp_path):
     """examples/evc_decode - a decoder in plain C on the two C ABIs, no Python in the loop - writes the reference decoder's pictures"""
     import subprocess
@@ -336,7 +337,7 @@ APP_ON_HIP = os.path.normpath(os.path.join(golden_io.GOLDEN, "..", "..", "oracle
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,args", [("hier_b_gop8_10b", ["--output-bit-depth", "10"]), ("main_eipd_all_tools_10b", ["--output-bit-depth", "10"]),
                                        ("main_all_tools_10b", []), ("signed_main_alf_10b", ["-s", "--output-bit-depth", "10"]),
-                                       ("main_dra_10b", ["--output-bit-depth", "10"])])
+                                       ("main_dra_10b", ["--output-bit-depth", "10"]), ("main_htdf_all_tools_10b", ["--output-bit-depth", "10"])])
 def test_gpu_reference_application_on_our_api(name, args, tmp_path):
     """The reference's OWN sample application (app/xevd_app.c, compiled from its source where it lies) linked against libxevd_amd_api.so - this
     repository's implementation of the public xevd_create / xevd_decode / xevd_pull API - instead of libxevd: it decodes the golden streams on

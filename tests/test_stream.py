@@ -51,6 +51,9 @@ CONFIGS = [
     (136, 72, 2, dict(main=True, eipd=True, idr_period=1, split_prob=0.8)),
     (200, 136, 5, dict(main=True, eipd=True, inter_frac=0.4, max_refs=2)),
     (144, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, inter_frac=0.5, log2_sub_gop=2, max_refs=2, bit_depth=10)),
+    # tool_htdf: every intra CU and every coded inter CU is filtered after its reconstruction - the real decoder against parser + oracle
+    (136, 72, 3, dict(main=True, htdf=True, inter_frac=0.6)),
+    (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, inter_frac=0.6, log2_sub_gop=2, max_refs=2, bit_depth=10)),
 ]
 
 

@@ -217,7 +217,7 @@ enum { MODE_INTRA = XGPU_MODE_INTRA, MODE_INTER = XGPU_MODE_INTER, MODE_SKIP = X
 
 // ------------------------------------------------------------------------------------------------ stream / picture state
 struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, log2_ref_gap = 0, max_num_ref_pics = 1;
-             int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0, tool_alf = 0, tool_eipd = 0, tool_dra = 0;
+             int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0, tool_alf = 0, tool_eipd = 0, tool_dra = 0, tool_htdf = 0;
              int crop[4] = { 0, 0, 0, 0 };            // picture_crop_left / right / top / bottom_offset (xevd_eco.c:1349-1357), as xevd_pull reports them
              bool cqt = false; int8_t cq[2][70] = { { 0 } }; };      // chroma QP mapping tables signalled in the SPS: [c][qp + 6*(bd_c-8)], qp = -6*(bd_c-8) .. 57
 struct Pps { int constrained_intra = 0, cu_qp_delta = 0, dra_on = 0, dra_aps_id = 0; };
@@ -902,7 +902,7 @@ struct xhost_parser {
         s.width = (int)br.ue(); s.height = (int)br.ue();
         s.bd_l = (int)br.ue() + 8; s.bd_c = (int)br.ue() + 8;
         int unsupported = 0, rpl = 0, pocs = 0;
-        s.tool_iqt = s.tool_ats = s.tool_addb = s.tool_alf = s.tool_eipd = s.tool_dra = 0;
+        s.tool_iqt = s.tool_ats = s.tool_addb = s.tool_alf = s.tool_eipd = s.tool_dra = s.tool_htdf = 0;
         if (!s.profile_main) {
             for (int i = 0; i < 13; i++) { const int f = br.get1(); if (i != 11) unsupported |= f; }      // btt suco admvp eipd cm_init iqt addb alf htdf rpl pocs dquant dra
         } else {                                          // xevdm_eco_sps, xevdm_eco.c:1863-1937: sub-flags follow their tool flag
@@ -916,13 +916,13 @@ struct xhost_parser {
             if (s.tool_iqt) s.tool_ats = br.get1();
             s.tool_addb = br.get1();
             s.tool_alf = br.get1();
-            unsupported |= br.get1();                    // tool_htdf
+            s.tool_htdf = br.get1();                     // no syntax of its own: the backend filters with the slice QP (xevdm.c:1381-1392)
             rpl = br.get1(); pocs = br.get1();
             unsupported |= rpl | pocs;
             unsupported |= br.get1();                    // dquant_flag: the Main decoder then codes QP deltas per cu_qp_delta_area (xevdm_eco.c), not per CU
             s.tool_dra = br.get1();
         }
-        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, admvp, ibc, cm_init, htdf, rpl, pocs, dquant in Main)");
+        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, admvp, ibc, cm_init, rpl, pocs, dquant in Main)");
         s.log2_sub_gop = (int)br.ue();                   // tool_rpl = tool_pocs = 0
         if (s.log2_sub_gop == 0) s.log2_ref_gap = (int)br.ue();
         if (s.log2_sub_gop > 5) return fail("bad SPS");
@@ -1080,6 +1080,7 @@ struct xhost_parser {
         b.coef = batch.coef.data(); b.n_coef = batch.x.empty() ? 0 : n_coef;
         b.n_ctu = w_ctu * h_ctu; b.ctu_cu_start = batch.ctu_start.data();
         b.constrained_intra_pred = st.pps.constrained_intra;
+        b.htdf_slice_qp = st.sps.tool_htdf ? sh.qp : 0;
         return 1;
     }
     size_t n_coef = 0;
@@ -1240,7 +1241,8 @@ struct xhost_writer {
             if (sp.tool_iqt) bw.put1(sp.tool_ats ? 1 : 0);
             bw.put1(sp.tool_addb ? 1 : 0);
             bw.put1(sp.tool_alf ? 1 : 0);
-            for (int i = 0; i < 4; i++) bw.put1(0);      // htdf rpl pocs dquant
+            bw.put1(sp.tool_htdf ? 1 : 0);
+            for (int i = 0; i < 3; i++) bw.put1(0);      // rpl pocs dquant
             bw.put1(sp.tool_dra ? 1 : 0);
         }
         bw.ue((uint32_t)sp.log2_sub_gop_length);
@@ -1292,6 +1294,7 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     s.tool_eipd = s.profile_main && sp->tool_eipd;
     w->sp.tool_iqt = s.tool_iqt; w->sp.tool_ats = s.tool_ats; w->sp.tool_addb = s.tool_addb; w->sp.tool_alf = s.tool_alf; w->sp.tool_eipd = s.tool_eipd;
     w->sp.tool_dra = s.profile_main && sp->tool_dra; s.tool_dra = w->sp.tool_dra;
+    w->sp.tool_htdf = s.profile_main && sp->tool_htdf; s.tool_htdf = w->sp.tool_htdf;
     w->st.pps.cu_qp_delta = sp->cu_qp_delta;
     return w;
 }

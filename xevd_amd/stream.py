@@ -19,7 +19,7 @@ class StreamParams(C.Structure):
                 ("profile_main", C.c_int), ("tool_iqt", C.c_int), ("tool_ats", C.c_int), ("tool_addb", C.c_int),
                 ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int), ("tool_alf", C.c_int), ("tool_eipd", C.c_int),
                 ("crop", C.c_int * 4), ("tool_dra", C.c_int), ("dra_aps_id", C.c_int), ("cqt_present", C.c_int), ("cqt_same", C.c_int), ("cqt_global_offset", C.c_int),
-                ("cqt_num_points", C.c_int * 2), ("cqt_delta_in", (C.c_int * 16) * 2), ("cqt_delta_out", (C.c_int * 16) * 2)]
+                ("cqt_num_points", C.c_int * 2), ("cqt_delta_in", (C.c_int * 16) * 2), ("cqt_delta_out", (C.c_int * 16) * 2), ("tool_htdf", C.c_int)]
 
 
 class AlfAps(C.Structure):
@@ -83,13 +83,14 @@ def load():
 class StreamWriter:
     def __init__(self, width, height, bit_depth=8, max_num_ref_pics=1, qp_u_offset=0, qp_v_offset=0, deblock=True, cu_qp_delta=True,
                  log2_sub_gop=0, main=False, iqt=False, ats=False, addb=False, alpha_off=0, beta_off=0, alf=False, eipd=False, crop=(0, 0, 0, 0),
-                 chroma_qp_points=None, dra_aps_id=None):
+                 chroma_qp_points=None, dra_aps_id=None, htdf=False):
         """chroma_qp_points: None, or (global_offset_flag, [table, ...]) with 1 (same for Cb and Cr) or 2 tables of (delta_in_minus1, delta_out) pairs"""
         self.lib = load()
         sp = StreamParams(width, height, bit_depth, max_num_ref_pics, log2_sub_gop, qp_u_offset, qp_v_offset, int(deblock), int(cu_qp_delta),
                           int(main), int(iqt), int(ats), int(addb), alpha_off, beta_off, int(alf), int(eipd))
         for i in range(4):
             sp.crop[i] = int(crop[i])
+        sp.tool_htdf = int(htdf)
         if dra_aps_id is not None:
             sp.tool_dra, sp.dra_aps_id = 1, int(dra_aps_id)
         if chroma_qp_points is not None:
@@ -202,7 +203,7 @@ def iter_stream(data, consume_batch=None):
                 "cbf": _arr(b.cbf, n, np.uint8), "cbf_sub": None, "ats": _arr(b.ats, n, np.uint8) if b.ats else None,
                 "ats_inter": _arr(b.ats_inter, n, np.uint8) if b.ats_inter else None, "ipm": _arr(b.ipm, n * 2, np.uint8).reshape(n, 2),
                 "coef_off": _arr(b.coef_off, n, np.uint32), "coef": _arr(b.coef, max(b.n_coef, 1), np.int16), "n_coef": int(b.n_coef),
-                "ctu_cu_start": _arr(b.ctu_cu_start, b.n_ctu + 1, np.uint32), "constrained_intra_pred": int(b.constrained_intra_pred),
+                "ctu_cu_start": _arr(b.ctu_cu_start, b.n_ctu + 1, np.uint32), "constrained_intra_pred": int(b.constrained_intra_pred), "htdf_slice_qp": int(b.htdf_slice_qp),
             }
             params = {
                 "width": hp.width, "height": hp.height, "bit_depth": hp.bit_depth_luma, "poc": hp.poc, "temporal_id": hp.temporal_id, "slice_type": hp.slice_type,
