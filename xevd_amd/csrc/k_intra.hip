@@ -202,9 +202,11 @@ __constant__ uint8_t k_htdf_tbl[5][16] = {
 template <bool DEP, bool EIPD, bool IBC, bool HTDF>
 __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 {
-    __shared__ int16_t s_htdf[HTDF ? INTRA_WAVES : 1][HTDF ? HTDF_EXT : 1];      // 70 KB: this instantiation runs one workgroup per CU
     __shared__ int     s_lut[HTDF ? INTRA_WAVES : 1][16];
-    __shared__ __attribute__((aligned(16))) int16_t s_nb[INTRA_WAVES][3][NB_LEN];
+    // per wave: the neighbour arrays of the prediction pass; the HTDF instantiation lays its 66 x 66 block over them afterwards (70 KB per workgroup:
+    // two workgroups per CU)
+    constexpr int WAVE_LDS = (HTDF && HTDF_EXT > 3 * NB_LEN) ? HTDF_EXT : 3 * NB_LEN;
+    __shared__ __attribute__((aligned(16))) int16_t s_nb[INTRA_WAVES][WAVE_LDS];
     __shared__ uint32_t s_chunk;
     const int t = threadIdx.x & 63, wv = threadIdx.x >> 6;
     uint32_t chunk = blockIdx.x;
@@ -213,7 +215,7 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
         __syncthreads();                                             // the only workgroup barrier, before any wave can wait
         chunk = s_chunk;
     }
-    int16_t (*nb)[NB_LEN] = s_nb[wv];
+    int16_t (*nb)[NB_LEN] = (int16_t (*)[NB_LEN])s_nb[wv];
     const int mid = 1 << (a.bd_l - 1);
     const int maxv = (1 << a.bd_l) - 1;
 
@@ -465,7 +467,8 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
             const bool cmask = (nflags >> 4) & 1;                     // constrained intra prediction: border units only from intra neighbours
             const int tidx = (nflags >> 20) & 7;
             const int thr_log2 = tidx == 0 ? 6 : (tidx < 3 ? 7 : 8), shift = thr_log2 - 4, rnd = (1 << shift) >> 1, thr = (1 << thr_log2) - (1 << shift);
-            int16_t *tb = s_htdf[wv];
+            int16_t *tb = s_nb[wv];
+            wave_lds_sync();                                          // the prediction pass is done with the neighbour arrays
             const int we = cw + 2, he = chh + 2;
             int16_t *org = a.cur_y + cu_y * a.s_l + cu_x;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the wave's own stores of the prediction pass
