@@ -7,15 +7,15 @@ import csv
 import json
 import sys
 
-NAMES = {"k_inter": "inter", "k_alf": "alf", "k_addb<0>": "dbk_v", "k_addb<1>": "dbk_h", "k_dbk<0>": "dbk_v", "k_dbk<1>": "dbk_h",
-         "k_itdq": "itdq", "k_intra<false, false>": "intra", "k_intra<true, false>": "intra", "k_intra<false, true>": "intra", "k_intra<true, true>": "intra", "k_pad": "pad"}
+NAMES = {"k_inter(": "inter", "k_alf(": "alf", "k_addb<0>(": "dbk_v", "k_addb<1>(": "dbk_h", "k_dbk<0>(": "dbk_v", "k_dbk<1>(": "dbk_h",
+         "k_itdq(": "itdq", "k_intra<": "intra", "k_affine_": "affine", "k_pad(": "pad"}
 
 
 def load(path):
     out = {}
     for r in csv.DictReader(open(path)):
         for k, v in NAMES.items():
-            if k + "(" in r["kernel"]:
+            if k in r["kernel"]:
                 out[v] = out.get(v, 0.0) + float(r["avg"])
     return out
 
