@@ -144,6 +144,40 @@ def test_gpu_ibc_intra_1080p_vs_oracle():
         assert np.array_equal(out[c], ref.bufs[c]), f"plane {c}"
 
 
+def test_gpu_batch_rejects_malformed_tool_fields():
+    """xgpu_batch_create validates what the Main-tool fields claim: an error code (never a crash), and the context keeps working"""
+    from xevd_amd.decoder import XgpuDecoder, XgpuError
+    cs = cases.build_case("reject", 136, 72, 10, 1, 1, (1, 1), 0.4, {"inter_frac": 0.7, "affine_frac": 0.6, "ibc_frac": 0.3, "addb": 1}, seed=2)
+    good = cs["batch"]
+    ibc = np.nonzero(good["pred_mode"] == 6)[0]
+    aff = np.nonzero(good["affine"] != 0)[0]
+    assert len(ibc) and len(aff)
+
+    def variant(fn):
+        b = {k: (v.copy() if isinstance(v, np.ndarray) else v) for k, v in good.items()}
+        fn(b)
+        return b
+    bad = [
+        variant(lambda b: b["mv"].__setitem__((ibc[0], 0), (-4000, 0))),                          # IBC source left of the picture
+        variant(lambda b: b["mv"].__setitem__((ibc[0], 0), (0, 0))),                              # IBC source = the CU itself: not reconstructed before it
+        variant(lambda b: b["mv"].__setitem__((ibc[-1], 0), (0, 64))),                            # IBC source below: later in decoding order (or outside)
+        variant(lambda b: b["affine"].__setitem__(aff[0], 5)),                                    # control-point count
+        variant(lambda b: b["refi"].__setitem__(aff[0], (-1, -1))),                               # affine CU without a reference
+        variant(lambda b: b["affine"].__setitem__(np.nonzero(b["pred_mode"] == 0)[0][0], 2)),     # affine intra CU
+        variant(lambda b: b.__setitem__("htdf_slice_qp", 77)),                                    # slice QP range
+        variant(lambda b: b["pred_mode"].__setitem__(aff[0], 5)),                                 # unknown prediction mode
+    ]
+    dec = XgpuDecoder(cs["w"], cs["h"], cs["bd"], iqt=1, admvp=1, addb=1)
+    for k, b in enumerate(bad):
+        with pytest.raises(XgpuError):
+            dec.batch_create(b)
+    dec.close() if hasattr(dec, "close") else None
+    ref, _, _, _ = cases.run_cpu("oracle", cs)
+    out = cases.run_gpu(cs)
+    for c in range(3):
+        assert np.array_equal(out[c], ref.bufs[c])
+
+
 def test_gpu_htdf_1080p_vs_oracle():
     """a 1080p B picture with HTDF: every intra CU and every coded inter CU of a filterable size is a node of the dependency graph (each reads the
     final border samples of the CUs before it) - tens of thousands of nodes through the data-flow kernel; decoded three times from the resident batch"""

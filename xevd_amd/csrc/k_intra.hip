@@ -1,4 +1,4 @@
-// k_intra.hip - intra prediction (Baseline modes) + residual add + clip for the intra CUs of one dependency level.
+// k_intra.hip - the order-dependent part of a picture: intra prediction + residual add + clip of the intra CUs, intra block copy, HTDF.
 //
 // Replaces the intra branch of xevd_recon_unit (src_base/xevd.c:731-741): xevd_get_avail_intra + xevd_get_nbr_b
 // (src_base/xevd_ipred.c:33-94), xevd_ipred_b / xevd_ipred_uv_b (:96-164, 587-676) and xevd_recon_yuv.  The Main
@@ -14,7 +14,12 @@
 // all deeper levels as ONE data-flow kernel (a launch per level would cost ~15 us each, and an all-intra picture has
 // ~10^3 levels) - see k_intra<DEP> below.
 //
-// MI355X mapping: one wavefront (= one 64-thread workgroup) per CU.  The neighbour arrays of the three components
+// The same graph carries the other order-dependent Main tools as extra node kinds (template parameters, so pictures without them run the lean
+// instantiations): EIPD's 33 luma / 5 chroma predictors (k_intra<., EIPD>), intra block copy (<., ., IBC>: xevdm_IBC_mc, src_main/xevdm_mc.c:2040-2106 -
+// the node waits for the CUs under its source block and copies instead of predicting) and HTDF (<., ., ., HTDF>: xevdm_htdf, src_main/xevdm_recon.c:
+// 153-385 - a filter stage after the prediction pass, and filter-only nodes for the inter CUs it applies to).
+//
+// MI355X mapping: one wavefront per CU, eight independent waves per workgroup.  The neighbour arrays of the three components
 // are staged once in LDS (unavailable units -> mid grey of the LUMA bit depth, xevd.c:455-473), DC sums are wave
 // reductions, then every lane predicts whole 4x4 SCUs (+ their 2x2 chroma blocks) exactly like k_inter's lanes
 // reconstruct theirs, so residual addressing and stores are shared idioms.  HBM-bound integer work: no MFMA.
