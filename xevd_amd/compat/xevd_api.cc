@@ -118,8 +118,11 @@ int decode_picture(Decoder *d, const xhost_picture &p, Image **out)
         d->epoch++;
     }
     if (d->free_pic.empty()) return XEVD_ERR_UNEXPECTED;
+    for (int l = 0; l < 2; l++) if (p.num_refp[l] < 0 || p.num_refp[l] > XGPU_MAX_REFS) return XEVD_ERR_MALFORMED_BITSTREAM;
     const int cur = d->free_pic.back();
     d->free_pic.pop_back();
+    // every failure below hands the slot back: a damaged picture must not cost the decoder a picture buffer
+    struct SlotGuard { Decoder *d; int pic; bool keep; ~SlotGuard() { if (!keep) d->free_pic.push_back(pic); } } guard = { d, cur, false };
     xgpu_frame_params fp;
     memset(&fp, 0, sizeof(fp));
     fp.pic = cur; fp.poc = p.poc;
@@ -175,8 +178,7 @@ int decode_picture(Decoder *d, const xhost_picture &p, Image **out)
 
     for (int r = 0; r < p.n_release; r++)
         for (Slot &k : d->dpb) if (k.in_use && k.poc == p.release_poc[r]) { d->free_pic.push_back(k.pic); k.in_use = 0; }
-    if (p.is_ref) { for (Slot &k : d->dpb) if (!k.in_use) { k.in_use = 1; k.poc = p.poc; k.pic = cur; break; } }
-    else d->free_pic.push_back(cur);
+    if (p.is_ref) { for (Slot &k : d->dpb) if (!k.in_use) { k.in_use = 1; k.poc = p.poc; k.pic = cur; guard.keep = true; break; } }
     *out = im;
     return XEVD_OK;
 }

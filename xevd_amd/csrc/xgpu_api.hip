@@ -322,7 +322,7 @@ int xgpu_pic_output(xgpu_ctx *c, int pic, const xgpu_dra_luts *dra, int out_bit_
     const size_t need = xgpu_pic_output_size(c, out_bit_depth, crop_l, crop_r, crop_t, crop_b);
     ARGCHK(c, dst_size >= need);
     if (c->out_cap < need) {
-        if (c->d_out) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_out); c->d_out = NULL; c->d_dra = NULL; c->out_cap = 0; }
+        if (c->d_out) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_out); c->d_out = NULL; c->out_cap = 0; }
         if (hipMalloc((void **)&c->d_out, need) != hipSuccess) { snprintf(c->err, sizeof(c->err), "pic_output: cannot allocate the %zu-byte staging buffer", need); return XGPU_ERR_OUT_OF_MEMORY; }
         c->out_cap = need;
     }
@@ -650,6 +650,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
             for (int sb = 0; sb < 4; sb++) {
                 if ((sb & 1) >= nsx || (sb >> 1) >= nsy) continue;
                 if (nsx * nsy > 1 && b->cbf_sub && !((b->cbf_sub[i] >> (4 * k + sb)) & 1)) continue;
+                ARGCHK(c, tr_code(i, k) == 0 || (tw >= 2 && tw <= 5 && th >= 2 && th <= 5));      // ATS exists for 4..32 only (checked before anything is allocated)
                 cls_count[tr_code(i, k) * 64 + tw * 8 + th]++;
             }
             need += (size_t)(1 << (bw + bh)) >> (k ? 2 : 0);
@@ -758,7 +759,6 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
                 const int si = sb & 1, sj = sb >> 1;
                 if (si >= nsx || sj >= nsy) continue;
                 if (nsx * nsy > 1 && b->cbf_sub && !((b->cbf_sub[i] >> (4 * k + sb)) & 1)) continue;
-                ARGCHK(c, tr_code(i, k) == 0 || (tw >= 2 && tw <= 5 && th >= 2 && th <= 5));      // ATS exists for 4..32 only
                 TbRec &t = tbs[cls_fill[tr_code(i, k) * 64 + tw * 8 + th]++];
                 t.off = off + ((uint32_t)sj << (th + cl)) + ((uint32_t)si << tw);
                 t.log2w = (uint8_t)tw; t.log2h = (uint8_t)th; t.qp = r.qp[k]; t.log2s = (uint8_t)cl;

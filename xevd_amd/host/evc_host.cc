@@ -219,7 +219,7 @@ enum { MODE_INTRA = XGPU_MODE_INTRA, MODE_INTER = XGPU_MODE_INTER, MODE_SKIP = X
 struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, log2_ref_gap = 0, max_num_ref_pics = 1;
              int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0, tool_alf = 0, tool_eipd = 0, tool_dra = 0, tool_htdf = 0;
              int crop[4] = { 0, 0, 0, 0 };            // picture_crop_left / right / top / bottom_offset (xevd_eco.c:1349-1357), as xevd_pull reports them
-             bool cqt = false; int8_t cq[2][70] = { { 0 } }; };      // chroma QP mapping tables signalled in the SPS: [c][qp + 6*(bd_c-8)], qp = -6*(bd_c-8) .. 57
+             bool cqt = false; int8_t cq[2][96] = { { 0 } }; };      // chroma QP mapping tables signalled in the SPS: [c][qp + 6*(bd_c-8)], qp = -6*(bd_c-8) .. 57
 struct Pps { int constrained_intra = 0, cu_qp_delta = 0, dra_on = 0, dra_aps_id = 0; };
 struct Slice { int type = XHOST_SLICE_I, qp = 32, qp_u_offset = 0, qp_v_offset = 0, deblock = 1, alpha_off = 0, beta_off = 0;
                int alf_on = 0, aps_id_y = 0, aps_id_ch = 0, alf_chroma_idc = 0, alf_ctb_map = 0; };
@@ -383,7 +383,7 @@ struct Stream {          // everything both directions share
     std::vector<RefPic> dpb;         // reference pictures in coding order (pm->pic[] restricted to IS_REF)
     std::vector<const RefPic *> refp[2];
     int poc = 0, prev_poc = 0, prev_doc_offset = -1, tid = 0, last_intra_poc = 0, qp_prev = 0, stale_list0_poc = 0;
-    bool have_sps = false, have_pps = false;
+    bool have_sps = false, have_pps = false, need_idr = false;
     std::vector<uint16_t> scan[6][6];      // zig-zag tables by log2 size - 1
     AlfAps alf_aps[32];
     DraAps dra_aps[32];
@@ -536,6 +536,8 @@ struct Stream {          // everything both directions share
         // pic->list_poc[0] = POC of refp[0][REFP_0]; an I slice leaves num_refp untouched, so the previous picture's value stays
         if (sh.type != XHOST_SLICE_I) stale_list0_poc = refp[0].empty() ? 0 : refp[0][0]->poc;
         if (!is_ref_picture()) return;
+        // bound on a damaged stream that keeps sending tid > 0 reference pictures without a tid-0 picture between them
+        while (dpb.size() >= 32) { released.push_back(dpb[0].poc); dpb.erase(dpb.begin()); }
         RefPic r;
         r.poc = poc; r.tid = tid; r.list0_poc = stale_list0_poc;
         const size_t f = (size_t)pic.w_scu * pic.h_scu;
@@ -892,7 +894,8 @@ struct xhost_parser {
 
     int parse_sps(BitReader &br)
     {
-        Sps &s = st.sps;
+        Sps tmp = st.sps;                                // parsed into a copy and committed on success only: a damaged SPS leaves the active one intact
+        Sps &s = tmp;
         br.ue();                                         // sps_seq_parameter_set_id
         const int profile = (int)br.get(8);              // 0 Baseline, 1 Main, 2/3 still picture
         if (profile < 0 || profile > 3) return fail("unknown profile");
@@ -901,6 +904,9 @@ struct xhost_parser {
         if (br.ue() != 1) return fail("only 4:2:0 is supported");
         s.width = (int)br.ue(); s.height = (int)br.ue();
         s.bd_l = (int)br.ue() + 8; s.bd_c = (int)br.ue() + 8;
+        // range checks before anything is sized or indexed by these fields (the chroma QP table below is)
+        if (br.overrun || (s.width & 7) || (s.height & 7) || s.width <= 0 || s.height <= 0 || s.width > 16384 || s.height > 16384 ||
+            s.bd_l < 8 || s.bd_l > 12 || s.bd_c < 8 || s.bd_c > 12) return fail("bad SPS");
         int unsupported = 0, rpl = 0, pocs = 0;
         s.tool_iqt = s.tool_ats = s.tool_addb = s.tool_alf = s.tool_eipd = s.tool_dra = s.tool_htdf = 0;
         if (!s.profile_main) {
@@ -937,7 +943,7 @@ struct xhost_parser {
             for (int c = 0; c < (same ? 1 : 2); c++) {
                 const int np = (int)br.ue() + 1;
                 if (np < 1 || np > 58 + off) return fail("bad chroma QP table");
-                int din[70], qin[70], qout[70];
+                int din[96], qin[96], qout[96];                      // np <= 58 + 24
                 for (int j = 0; j < np; j++) {
                     din[j] = (int)br.get(6);
                     const int dout = br.se();
@@ -958,7 +964,14 @@ struct xhost_parser {
         }
         br.get1();      // vui_parameters_present_flag: the VUI (display metadata, xevd_eco.c:1226-1304) is the last SPS element and is not needed here
         if (br.overrun || (s.width & 7) || (s.height & 7) || s.width <= 0 || s.height <= 0 || s.width > 16384 || s.height > 16384 ||
-            s.bd_l < 8 || s.bd_l > 12 || s.bd_c < 8 || s.bd_c > 12 || s.max_num_ref_pics < 0 || s.max_num_ref_pics > 21) return fail("bad SPS");
+            s.bd_l < 8 || s.bd_l > 12 || s.bd_c < 8 || s.bd_c > 12 || s.max_num_ref_pics < 0 || s.max_num_ref_pics > XGPU_MAX_REFS) return fail("bad SPS");
+        // a new geometry / bit depth invalidates every stored picture (their motion fields have the old SCU grid): drop the DPB and take
+        // nothing but an IDR picture until one arrives
+        if (st.have_sps && (s.width != st.sps.width || s.height != st.sps.height || s.bd_l != st.sps.bd_l || s.bd_c != st.sps.bd_c)) {
+            st.dpb.clear(); st.refp[0].clear(); st.refp[1].clear();
+            st.need_idr = true;
+        }
+        st.sps = s;
         st.have_sps = true;
         return XGPU_OK;
     }
@@ -981,6 +994,8 @@ struct xhost_parser {
     int parse_slice(BitReader &br, int nut, int tid, xhost_picture *out)
     {
         if (!st.have_sps || !st.have_pps) return fail("slice before SPS/PPS");
+        if (st.need_idr && nut != NUT_IDR) return fail("the sequence parameters changed: waiting for an IDR picture");
+        st.need_idr = false;
         Slice &sh = st.sh;
         br.ue();                                         // slice_pic_parameter_set_id; single tile: no tile ids
         sh.type = (int)br.ue();
@@ -1009,6 +1024,9 @@ struct xhost_parser {
         st.build_ref_lists();
         if (sh.type != XHOST_SLICE_I && st.refp[0].empty()) return fail("P/B slice without a reference picture");
         if (sh.type == XHOST_SLICE_B && st.refp[1].empty()) return fail("B slice without a list-1 reference picture");
+        for (int l = 0; l < 2; l++)
+            for (const RefPic *r : st.refp[l])
+                if (r->mv0.size() != (size_t)(st.sps.width >> 2) * (st.sps.height >> 2) * 2) return fail("reference picture of another geometry");
         st.pic.reset(st.sps.width, st.sps.height);
         st.models.reset();
         st.qp_prev = sh.qp;
@@ -1049,7 +1067,7 @@ struct xhost_parser {
             if (!d.valid) return fail("the PPS names a DRA parameter set that was not sent");
             if (st.sps.bd_l > 10) return fail("DRA tables cover 10 bits");
             const int off = 6 * (st.sps.bd_c - 8);
-            int8_t dflt[2][70];
+            int8_t dflt[2][96];
             const int8_t *cq[2];
             for (int c = 0; c < 2; c++) {
                 if (st.sps.cqt) cq[c] = st.sps.cq[c] + off;

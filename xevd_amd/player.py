@@ -17,6 +17,8 @@ class StreamDecoder:
         self._lock, self._dec = threading.Lock(), None
         self.apply_crop = apply_crop      # packed output: cut the SPS conformance window (the reference application writes uncropped pictures)
 
+    N_SLOTS = 33      # the parser keeps at most 32 reference pictures (+ the current one): a slot is always free
+
     def _producer(self, q):
         """parser thread: entropy decoding, and - zero-copy, while the parser's arrays are valid - the hand-over of every picture's CU batch to
         the backend (builder + upload into pooled buffers).  The backend context is not thread-safe: calls on it are serialised by self._lock."""
@@ -24,7 +26,7 @@ class StreamDecoder:
             with self._lock:
                 if self._dec is None:
                     self._dec = XgpuDecoder(p["width"], p["height"], p["bit_depth"], device=self.device, iqt=p["iqt"], addb=p["addb"], alf=p["tool_alf"],
-                                            eipd=p["eipd"], max_pics=12, chroma_qp_tables=p["chroma_qp_tables"])
+                                            eipd=p["eipd"], max_pics=34, chroma_qp_tables=p["chroma_qp_tables"], bit_depth_chroma=p["bit_depth_chroma"])
                 return self._dec.batch_create_from_struct(cu_batch)
         try:
             for p in stream.iter_stream(self.data, consume_batch=to_device):
@@ -90,7 +92,7 @@ class StreamDecoder:
                     raise p
                 if not free and not slots:
                     with self._lock:
-                        free = [self._dec.pic_alloc() for _ in range(10)]
+                        free = [self._dec.pic_alloc() for _ in range(self.N_SLOTS)]
                 yield p, decode(p)
             if self._dec is not None and not download:
                 self._dec.sync()

@@ -206,7 +206,7 @@ def iter_stream(data, consume_batch=None):
                 "ctu_cu_start": _arr(b.ctu_cu_start, b.n_ctu + 1, np.uint32), "constrained_intra_pred": int(b.constrained_intra_pred), "htdf_slice_qp": int(b.htdf_slice_qp),
             }
             params = {
-                "width": hp.width, "height": hp.height, "bit_depth": hp.bit_depth_luma, "poc": hp.poc, "temporal_id": hp.temporal_id, "slice_type": hp.slice_type,
+                "width": hp.width, "height": hp.height, "bit_depth": hp.bit_depth_luma, "bit_depth_chroma": hp.bit_depth_chroma, "poc": hp.poc, "temporal_id": hp.temporal_id, "slice_type": hp.slice_type,
                 "is_idr": bool(hp.is_idr), "is_ref": bool(hp.is_ref),
                 "refs": [[hp.refp_poc[i][l] for i in range(hp.num_refp[l])] for l in range(2)],
                 "slice_qp": hp.slice_qp, "qp_u_offset": hp.qp_u_offset, "qp_v_offset": hp.qp_v_offset, "deblock_on": bool(hp.deblock_on),
