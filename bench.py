@@ -123,12 +123,14 @@ def cpu_baseline(wl, first, batch, alf, budget_s=15.0):
             if ap is not None:
                 o.orc_alf(C.byref(sp), C.byref(fr.cur), C.byref(ap))
             o.orc_pad(C.byref(sp), C.byref(fr.cur))
+        if n == 0:
+            first_out = [b.copy() for b in cur.bufs]      # padded planes of the first picture: what the GPU's picture is compared with
         ref2, ref, cur = ref, cur, ref2
         n += 1
         dt = time.perf_counter() - t0
         if dt > budget_s or n >= 64:
             break
-    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": kind,
+    return first_out, {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": kind,
             "sample": f"{n} pictures of the same {wl['w']}x{wl['h']} workload (recon + deblock" + (" + ALF" if alf is not None else "")
                       + " + pad), single thread, "
                       + ("the reference's own functions (AVX2/SSE tables where it has them; ADDB and ALF are scalar C there) via oracle/_ref"
@@ -226,6 +228,16 @@ def main():
 
     two_lists = wl["n_refs"][1] > 0
 
+    # self-check, outside the timed region: the first batch decoded from the two start pictures exactly as the CPU leg does it
+    # (src_main/xevdm.c:3136-3219: recon, deblock, ALF, pad); compared plane by plane, padding included, further down
+    gpu_check = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        refs = {(0, 0): (slots[0], 0)}
+        if two_lists:
+            refs[(0, 1)] = (slots[1], -1)
+        dec.decode_picture(slots[2], 1, refs, handles[0], alf=alf)
+        gpu_check = dec.pic_download_padded(slots[2])
+
     def step(k):
         # picture k+1 is predicted from picture k (list 0) and, with two lists, picture k-1 (list 1): a 3-slot DPB ring
         cur, ref0, ref1 = slots[(k + 2) % 3], slots[(k + 1) % 3], slots[k % 3]
@@ -312,7 +324,10 @@ def main():
             "pcie_inclusive_fps": round(1.0 / (dt / args.steps + t_up), 2),
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
-            out["cpu_baseline"] = cpu_baseline(wl, first, batches[0], alf)
+            cpu_pic, out["cpu_baseline"] = cpu_baseline(wl, first, batches[0], alf)
+            out["bit_exact"] = bool(all(np.array_equal(gpu_check[c], cpu_pic[c]) for c in range(3)))
+            out["bit_exact_what"] = (f"picture 1 of the benchmarked stream ({wl['w']}x{wl['h']}, padded planes) on the GPU == the same batch through "
+                                     + ("the reference's functions (oracle/_ref)" if out["cpu_baseline"]["kind"] == "reference" else "the CPU oracle"))
             try:
                 rd = reference_decoder_leg(wl)
             except Exception as e:                      # the checker's leg must not take the measurement down

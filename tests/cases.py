@@ -187,3 +187,17 @@ def run_gpu(case, deblock=True, pad=True, alf=True, resid=False, repeat=1):
         if resid:
             return dec.pic_download_padded(cur), dec.batch_resid(hb, case["batch"]["n_coef"])
         return dec.pic_download_padded(cur)
+
+
+def bench_case(name, seed=1000):
+    """bench.py's workload `name` (same generator, same seed as rank 0 of the benchmark) as a picture-level test case"""
+    import bench
+    wl = bench.WORKLOADS[name]
+    first, batches, alf = bench.make_stream(wl, seed, 1)
+    refs = {}
+    for l in range(1 + (wl["n_refs"][1] > 0)):
+        pic = ol.Picture(wl["w"], wl["h"], POCS[l][0], first[l])
+        pic.pad_numpy()
+        refs[(0, l)] = pic
+    return {"name": name, "w": wl["w"], "h": wl["h"], "bd": wl["bd"], "admvp": wl["admvp"], "iqt": wl["iqt"], "refs": refs, "batch": batches[0],
+            "alf_params": alf, "no_deblock": 0, "log2_ctu": 6, "addb": wl["addb"], "alf": wl["alf"], "eipd": 0, "alpha_off": 0, "beta_off": 0}

@@ -407,3 +407,17 @@ def test_gpu_reference_application_rejects_bad_signature(tmp_path):
     src.write_bytes(bytes(bad))
     r = subprocess.run([APP_ON_HIP, "-i", str(src), "-s"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
     assert r.returncode != 0 and b"MD5 check mismatch" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["cfg2_base_1080p_8b_ippp", "cfg3_main_4k_10b_ra", "cfg4_main_8k_10b_ra"])
+def test_gpu_bench_workload_vs_oracle(name):
+    """The configurations the metric is quoted on, at size: the exact CU batch, reference pictures and ALF parameters bench.py times (Main 10 bit,
+    admvp 8-tap tables, IQT, ADDB, ALF on every CTU, two lists, 50 % bi-prediction at 3840x2160 and 7680x4320; Baseline 1080p) through the whole
+    pipeline against the oracle - XCD band / strip mapping, 32-bit arena offsets at 55 M coefficients, ALF at 120 x 68 CTUs included
+    (src_main/xevdm.c:3136-3219)."""
+    cs = cases.bench_case(name)
+    ref, _, _, _ = cases.run_cpu("oracle", cs)
+    out = cases.run_gpu(cs)
+    for c in range(3):
+        assert np.array_equal(out[c], ref.bufs[c]), f"{name} plane {c}: {np.argwhere(out[c] != ref.bufs[c])[:4]}"

@@ -215,6 +215,17 @@ def test_picture_level_oracle_equals_reference(case):
         assert np.array_equal(s0.bufs[c], c0.bufs[c]), f"simd plane {c}"
 
 
+def test_bench_workload_4k_oracle_equals_reference():
+    """the oracle pinned at size on the benchmark's own Main 4K batch (10 bit, admvp tables, IQT, ADDB, ALF, two lists): the picture the
+    reference's functions produce; the 8K batch of the same generator is compared on the GPU box (bench.py's bit_exact field)"""
+    cs = cases.bench_case("cfg3_main_4k_10b_ra")
+    a, _, _, ra = cases.run_cpu("oracle", cs)
+    b, _, _, rb = cases.run_cpu("ref", cs)
+    assert np.array_equal(ra, rb)
+    for c in range(3):
+        assert np.array_equal(a.bufs[c], b.bufs[c])
+
+
 @pytest.mark.parametrize("split_prob", [0.0, 1.0])
 def test_picture_level_extreme_partitions(split_prob):
     """all-64x64 CUs and all-4x4 CUs (the longest chroma deblocking dependency chains)"""
