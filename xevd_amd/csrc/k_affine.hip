@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void k_affine_sub(const AffineArgs a)
         uint32_t ch[4], cv[4], o[8], c2h[2], c2v[2], ou[2], ov[2];
         const uint4 lth = s_ltap[ldx ? (gx & 15) : 16], ltv = s_ltap[ldy ? (gy & 15) : 16];
         ch[0] = lth.x; ch[1] = lth.y; ch[2] = lth.z; ch[3] = lth.w; cv[0] = ltv.x; cv[1] = ltv.y; cv[2] = ltv.z; cv[3] = ltv.w;
-        const int16_t *p = re.y + ((gy >> 4) - 3) * a.s_l + (gx >> 4) - 3;
+        const gs16 p = (gs16)re.y + ((gy >> 4) - 3) * a.s_l + (gx >> 4) - 3;
         const Regime rg = regime(ldx, ldy, a.bd_l);
         if (ldx) { if (ldy) mc_luma_4x4<true, true>(p, a.s_l, ch, cv, rg, maxl, o); else mc_luma_4x4<true, false>(p, a.s_l, ch, cv, rg, maxl, o); }
         else     { if (ldy) mc_luma_4x4<false, true>(p, a.s_l, ch, cv, rg, maxl, o); else mc_luma_4x4<false, false>(p, a.s_l, ch, cv, rg, maxl, o); }
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void k_affine_sub(const AffineArgs a)
         c2h[0] = cth.x; c2h[1] = cth.y; c2v[0] = ctv.x; c2v[1] = ctv.y;
         const int off = ((gy >> 5) - 1) * a.s_c + (gx >> 5) - 1;
         const Regime rc = regime(cdx, cdy, a.bd_c);
-#define MC_C(H, V) do { mc_chroma_2x2<H, V>(re.u + off, a.s_c, c2h, c2v, rc, maxc, ou); mc_chroma_2x2<H, V>(re.v + off, a.s_c, c2h, c2v, rc, maxc, ov); } while (0)
+#define MC_C(H, V) do { mc_chroma_2x2<H, V>((gs16)re.u + off, a.s_c, c2h, c2v, rc, maxc, ou); mc_chroma_2x2<H, V>((gs16)re.v + off, a.s_c, c2h, c2v, rc, maxc, ov); } while (0)
         if (cdx) { if (cdy) MC_C(true, true); else MC_C(true, false); }
         else     { if (cdy) MC_C(false, true); else MC_C(false, false); }
 #undef MC_C

@@ -48,17 +48,17 @@ __device__ __forceinline__ void wave_lds_sync()
 // p = reference sample at (tile x - 3, tile y - 3); lane l owns the SCU (l & 7, l >> 3) of the tile.  o[] as mc_luma_4x4.
 // The fetch is split from the filtering so that a wave has the windows of both lists (and its residual) in flight at once.
 struct TileFetch { uint4 y[4]; uint2 c[3]; };
-__device__ __forceinline__ void tile_fetch(const int16_t *p, int s, const int16_t *pu, const int16_t *pv, int sc, int lane, TileFetch &f)
+__device__ __forceinline__ void tile_fetch(gs16 p, int s, gs16 pu, gs16 pv, int sc, int lane, TileFetch &f)
 {
 #pragma unroll
     for (int it = 0; it < 4; it++) {                                // luma window: 39 rows x 5 chunks of 8 samples
         const int c = lane + 64 * it, row = (c * 205) >> 10, k = c - row * 5;            // c / 5 for c < 256
-        if (c < 195) { const U32x4u q = *(const U32x4u *)(p + row * s + 8 * k); f.y[it] = make_uint4(q.a, q.b, q.c, q.d); }
+        if (c < 195) f.y[it] = gload16(p + row * s + 8 * k);
     }
 #pragma unroll
     for (int it = 0; it < 3; it++) {                                // chroma windows: 2 planes x 19 rows x 5 chunks of 4 samples
         const int c = lane + 64 * it, pl = c >= 95, cc = c - 95 * pl, row = (cc * 205) >> 10, k = cc - row * 5;
-        if (c < 190) { const U32x2u q = *(const U32x2u *)((pl ? pv : pu) + row * sc + 4 * k); f.c[it] = make_uint2(q.a, q.b); }
+        if (c < 190) f.c[it] = gload8((pl ? pv : pu) + row * sc + 4 * k);
     }
 }
 
@@ -351,8 +351,7 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
             if (!__builtin_amdgcn_readfirstlane((int)use[l])) continue;
             const int ri = __builtin_amdgcn_readfirstlane(refis[l] * 2 + l);
             const uint4 e0 = s_ref[ri][0], e1 = s_ref[ri][1];
-            const int16_t *ry_ = (const int16_t *)(((uint64_t)e0.y << 32) | e0.x), *ru_ = (const int16_t *)(((uint64_t)e0.w << 32) | e0.z);
-            const int16_t *rv_ = (const int16_t *)(((uint64_t)e1.y << 32) | e1.x);
+            const gs16 ry_ = (gs16)(((uint64_t)e0.y << 32) | e0.x), ru_ = (gs16)(((uint64_t)e0.w << 32) | e0.z), rv_ = (gs16)(((uint64_t)e1.y << 32) | e1.x);
             tmx[l] = __builtin_amdgcn_readfirstlane(mvs[l][0]); tmy[l] = __builtin_amdgcn_readfirstlane(mvs[l][1]);
             const int px = tpx[l] = (wx << 2) + __builtin_amdgcn_readfirstlane((int)mvt[l][0]);
             const int py = tpy[l] = (wy << 2) + __builtin_amdgcn_readfirstlane((int)mvt[l][1]);
@@ -412,7 +411,7 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
         {
             const uint4 th = s_ltap[ldx ? ((px & 3) << 2) : 16], tv = s_ltap[ldy ? ((py & 3) << 2) : 16];
             ch[0] = th.x; ch[1] = th.y; ch[2] = th.z; ch[3] = th.w; cv[0] = tv.x; cv[1] = tv.y; cv[2] = tv.z; cv[3] = tv.w;
-            const int16_t *p = re.y + ((py >> 2) - 3) * a.s_l + (px >> 2) - 3;
+            const gs16 p = (gs16)re.y + ((py >> 2) - 3) * a.s_l + (px >> 2) - 3;
             const Regime rg = regime(ldx, ldy, a.bd_l);
             const bool wh = __ballot(ldx) != 0, wvv = __ballot(ldy) != 0;      // over the lanes that run this list
             if (wh) { if (wvv) mc_luma_4x4<true, true>(p, a.s_l, ch, cv, rg, maxl, o); else mc_luma_4x4<true, false>(p, a.s_l, ch, cv, rg, maxl, o); }
@@ -425,7 +424,7 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
             const int off = ((py >> 3) - 1) * a.s_c + (px >> 3) - 1;
             const Regime rg = regime(cdx, cdy, a.bd_c);
             const bool wh = __ballot(cdx) != 0, wvv = __ballot(cdy) != 0;
-#define MC_C(H, V) do { mc_chroma_2x2<H, V>(re.u + off, a.s_c, c2h, c2v, rg, maxc, ou); mc_chroma_2x2<H, V>(re.v + off, a.s_c, c2h, c2v, rg, maxc, ov); } while (0)
+#define MC_C(H, V) do { mc_chroma_2x2<H, V>((gs16)re.u + off, a.s_c, c2h, c2v, rg, maxc, ou); mc_chroma_2x2<H, V>((gs16)re.v + off, a.s_c, c2h, c2v, rg, maxc, ov); } while (0)
             if (wh) { if (wvv) MC_C(true, true); else MC_C(true, false); }
             else    { if (wvv) MC_C(false, true); else MC_C(false, false); }
 #undef MC_C
@@ -507,7 +506,7 @@ __global__ void k_test_mc(const int16_t *plane, int stride, int ref_x, int ref_y
     if (luma) {
         const uint32_t *th = k_luma_taps[admvp][has_dx ? (gmv_x & 15) : 16], *tv = k_luma_taps[admvp][has_dy ? (gmv_y & 15) : 16];
         uint32_t ch[4] = { th[0], th[1], th[2], th[3] }, cv[4] = { tv[0], tv[1], tv[2], tv[3] }, o[8];
-        const int16_t *p = ref + ((gmv_y >> 4) - 3 + by) * stride + (gmv_x >> 4) - 3 + bx;
+        const gs16 p = (gs16)ref + ((gmv_y >> 4) - 3 + by) * stride + (gmv_x >> 4) - 3 + bx;
         if (has_dx) { if (has_dy) mc_luma_4x4<true, true>(p, stride, ch, cv, regime(has_dx, has_dy, bd), maxv, o); else mc_luma_4x4<true, false>(p, stride, ch, cv, regime(has_dx, has_dy, bd), maxv, o); }
         else        { if (has_dy) mc_luma_4x4<false, true>(p, stride, ch, cv, regime(has_dx, has_dy, bd), maxv, o); else mc_luma_4x4<false, false>(p, stride, ch, cv, regime(has_dx, has_dy, bd), maxv, o); }
         for (int r = 0; r < 4; r++) {
@@ -517,7 +516,7 @@ __global__ void k_test_mc(const int16_t *plane, int stride, int ref_x, int ref_y
     } else {
         const uint32_t *th = k_chroma_taps[admvp][has_dx ? (gmv_x & 31) : 32], *tv = k_chroma_taps[admvp][has_dy ? (gmv_y & 31) : 32];
         uint32_t ch[2] = { th[0], th[1] }, cv[2] = { tv[0], tv[1] }, o[2];
-        const int16_t *p = ref + ((gmv_y >> 5) - 1 + by) * stride + (gmv_x >> 5) - 1 + bx;
+        const gs16 p = (gs16)ref + ((gmv_y >> 5) - 1 + by) * stride + (gmv_x >> 5) - 1 + bx;
         if (has_dx) { if (has_dy) mc_chroma_2x2<true, true>(p, stride, ch, cv, regime(has_dx, has_dy, bd), maxv, o); else mc_chroma_2x2<true, false>(p, stride, ch, cv, regime(has_dx, has_dy, bd), maxv, o); }
         else        { if (has_dy) mc_chroma_2x2<false, true>(p, stride, ch, cv, regime(has_dx, has_dy, bd), maxv, o); else mc_chroma_2x2<false, false>(p, stride, ch, cv, regime(has_dx, has_dy, bd), maxv, o); }
         *(uint32_t *)(pred + by * w + bx) = o[0];

@@ -7,6 +7,19 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 struct __attribute__((packed, aligned(2))) U32x4u { uint32_t a, b, c, d; };
 struct __attribute__((packed, aligned(2))) U32x2u { uint32_t a, b; };
 struct __attribute__((packed, aligned(2))) U32x1u { uint32_t a; };
+// Reference samples are read through GLOBAL pointers (address space 1): a pointer rebuilt from a 64-bit value (the reference table in LDS) is
+// otherwise a generic one and every load a flat_load - which also counts on the LDS counter, so each LDS wait of the filter passes would wait
+// for all the window and residual loads still in flight.
+#define GAS __attribute__((address_space(1)))
+typedef const GAS int16_t *gs16;
+typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
+typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
+typedef v4u32 __attribute__((aligned(2))) v4u32_u;          // 16 / 8 / 4 bytes at a 2-byte aligned sample address (gfx950 unaligned-access mode)
+typedef v2u32 __attribute__((aligned(2))) v2u32_u;
+typedef uint32_t __attribute__((aligned(2))) u32_u;
+__device__ __forceinline__ uint4 gload16(gs16 p) { const v4u32 v = *(const GAS v4u32_u *)p; return make_uint4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ uint2 gload8(gs16 p) { const v2u32 v = *(const GAS v2u32_u *)p; return make_uint2(v.x, v.y); }
+__device__ __forceinline__ uint32_t gload4(gs16 p) { return *(const GAS u32_u *)p; }
 
 __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
 {
@@ -94,7 +107,7 @@ __device__ __forceinline__ Regime regime(int has_dx, int has_dy, int bd)
 // touched (a lane's identity vertical tap would select exactly row r+3 and add nothing), without H the row is the samples
 // themselves.  The results are those of the full path with identity taps - the variants only skip work that cancels.
 template <bool H, bool V>
-__device__ __forceinline__ void mc_luma_4x4(const int16_t *p, int s, const uint32_t ch[4], const uint32_t cv[4],
+__device__ __forceinline__ void mc_luma_4x4(gs16 p, int s, const uint32_t ch[4], const uint32_t cv[4],
                                             Regime rg, int maxv, uint32_t o[8])
 {
     int acc[4][4];
@@ -103,9 +116,9 @@ __device__ __forceinline__ void mc_luma_4x4(const int16_t *p, int s, const uint3
     for (int j = V ? 0 : 3; j < (V ? 11 : 7); j++) {
         int t[4];
         if (H) {
-            const U32x4u a = *(const U32x4u *)(p + j * s);
-            const U32x2u b = *(const U32x2u *)(p + j * s + 8);
-            const uint32_t D0 = a.a, D1 = a.b, D2 = a.c, D3 = a.d, D4 = b.a, D5 = b.b;
+            const uint4 a = gload16(p + j * s);
+            const uint2 b = gload8(p + j * s + 8);
+            const uint32_t D0 = a.x, D1 = a.y, D2 = a.z, D3 = a.w, D4 = b.x, D5 = b.y;
             const uint32_t Q0 = hi_lo(D1, D0), Q1 = hi_lo(D2, D1), Q2 = hi_lo(D3, D2), Q3 = hi_lo(D4, D3), Q4 = hi_lo(D5, D4);
             t[0] = dot2(ch[3], D3, dot2(ch[2], D2, dot2(ch[1], D1, dot2z(ch[0], D0))));
             t[2] = dot2(ch[3], D4, dot2(ch[2], D3, dot2(ch[1], D2, dot2z(ch[0], D1))));
@@ -114,9 +127,9 @@ __device__ __forceinline__ void mc_luma_4x4(const int16_t *p, int s, const uint3
 #pragma unroll
             for (int c = 0; c < 4; c++) t[c] = clip3(rg.lo1, rg.hi1, t[c] >> rg.sh1);
         } else {
-            const U32x2u a = *(const U32x2u *)(p + j * s + 3);      // no lane filters horizontally: samples 3..6 of the window
-            t[0] = (int)(int16_t)(a.a & 0xFFFF); t[1] = (int)(int16_t)(a.a >> 16);
-            t[2] = (int)(int16_t)(a.b & 0xFFFF); t[3] = (int)(int16_t)(a.b >> 16);
+            const uint2 a = gload8(p + j * s + 3);      // no lane filters horizontally: samples 3..6 of the window
+            t[0] = (int)(int16_t)(a.x & 0xFFFF); t[1] = (int)(int16_t)(a.x >> 16);
+            t[2] = (int)(int16_t)(a.y & 0xFFFF); t[3] = (int)(int16_t)(a.y >> 16);
         }
         if (!V) {
 #pragma unroll
@@ -151,7 +164,7 @@ __device__ __forceinline__ void mc_luma_4x4(const int16_t *p, int s, const uint3
 
 // 2x2 chroma prediction of one SCU.  `p` = reference sample at (block x - 1, block y - 1).  o[r] = packed row r.
 template <bool H, bool V>
-__device__ __forceinline__ void mc_chroma_2x2(const int16_t *p, int s, const uint32_t ch[2], const uint32_t cv[2],
+__device__ __forceinline__ void mc_chroma_2x2(gs16 p, int s, const uint32_t ch[2], const uint32_t cv[2],
                                               Regime rg, int maxv, uint32_t o[2])
 {
     int acc[2][2];
@@ -160,17 +173,16 @@ __device__ __forceinline__ void mc_chroma_2x2(const int16_t *p, int s, const uin
     for (int j = V ? 0 : 1; j < (V ? 5 : 3); j++) {
         int t[2];
         if (H) {
-            const U32x2u a = *(const U32x2u *)(p + j * s);
-            const U32x1u b = *(const U32x1u *)(p + j * s + 4);
-            const uint32_t D0 = a.a, D1 = a.b, D2 = b.a;
+            const uint2 a = gload8(p + j * s);
+            const uint32_t D0 = a.x, D1 = a.y, D2 = gload4(p + j * s + 4);
             const uint32_t Q0 = hi_lo(D1, D0), Q1 = hi_lo(D2, D1);
             t[0] = dot2(ch[1], D1, dot2z(ch[0], D0));
             t[1] = dot2(ch[1], Q1, dot2z(ch[0], Q0));
 #pragma unroll
             for (int c = 0; c < 2; c++) t[c] = clip3(rg.lo1, rg.hi1, t[c] >> rg.sh1);
         } else {
-            const U32x1u a = *(const U32x1u *)(p + j * s + 1);
-            t[0] = (int)(int16_t)(a.a & 0xFFFF); t[1] = (int)(int16_t)(a.a >> 16);
+            const uint32_t a = gload4(p + j * s + 1);
+            t[0] = (int)(int16_t)(a & 0xFFFF); t[1] = (int)(int16_t)(a >> 16);
         }
         if (!V) { acc[j - 1][0] = t[0]; acc[j - 1][1] = t[1]; continue; }
         if (j > 0) {
