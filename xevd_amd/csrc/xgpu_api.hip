@@ -602,23 +602,6 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         if (idx == 1 || idx == 3) bw -= idx == 3 ? 2 : 1;
         if (idx == 2 || idx == 4) bh -= idx == 4 ? 2 : 1;
     };
-    // k_mc work lists: pieces (CUs cut to at most 32x32) counted per (band of CTU rows, lists used, piece shape)
-    const int mc_band_h = MC_BAND_ROWS << c->sp.log2_ctu, mc_bands = (c->sp.height + mc_band_h - 1) / mc_band_h;
-    std::vector<int> mc_count((size_t)mc_bands * 64, 0);
-    // piece shape of CU i (log2): CUs of 8x8 and above are cut into SQUARES of 8, 16 or 32 (the cooperative classes of k_mc), CUs with a side
-    // of 4 into rectangles of at most 32
-    auto mc_piece = [&](int i, int &plw, int &plh) {
-        const int lw = b->log2w[i], lh = b->log2h[i];
-        if (lw >= 3 && lh >= 3) plw = plh = std::min(std::min(lw, lh), 5);
-        else { plw = std::min(lw, 5); plh = std::min(lh, 5); }
-    };
-    auto mc_key = [&](int i) -> int {
-        const bool plain_inter = b->pred_mode[i] != XGPU_MODE_INTRA && b->pred_mode[i] != XGPU_MODE_IBC && !(b->affine && b->affine[i]);
-        const int lists = plain_inter ? ((b->refi[i * 2] >= 0 ? 1 : 0) | (b->refi[i * 2 + 1] >= 0 ? 2 : 0)) : 0;     // 0: the SCU map only
-        int plw, plh;
-        mc_piece(i, plw, plh);
-        return ((b->y[i] / mc_band_h) * 4 + lists) * 16 + (plw - 2) * 4 + (plh - 2);
-    };
     int n_aff = 0, n_aff_eif = 0, n_aff_sub = 0;
     // the branch xevdm_affine_mc takes for CU i (EIF when a sub-block would be smaller than 8 samples): the kernels' own code, affine_model.h
     auto affine_is_eif = [&](const xgpu_cu_batch *bb, int i) -> bool {
@@ -673,18 +656,6 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
             need += (size_t)(1 << (bw + bh)) >> (k ? 2 : 0);
         }
         ARGCHK(c, (size_t)b->coef_off[i] + need <= b->n_coef);
-        {
-            int plw, plh;
-            mc_piece(i, plw, plh);
-            mc_count[mc_key(i)] += 1 << ((lw - plw) + (lh - plh));
-        }
-    }
-    std::vector<int> mc_first(mc_count.size());
-    int n_mc_items = 0, n_mc_waves = 0;
-    for (size_t k = 0; k < mc_count.size(); k++) {
-        mc_first[k] = n_mc_items; n_mc_items += mc_count[k];
-        const int per = 64 >> (((int)(k >> 2) & 3) + ((int)k & 3));                 // pieces of this shape per 64-lane wave
-        n_mc_waves += (mc_count[k] + per - 1) / per;
     }
     int cls_first[NCLS], n_tb = 0, n_waves = 0;
     for (int k = 0; k < NCLS; k++) {
@@ -702,7 +673,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
 
     xgpu_dbatch *db = new xgpu_dbatch();
     memset(db, 0, sizeof(*db));
-    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->n_mc_items = n_mc_items; db->n_mc_waves = n_mc_waves; db->has_ibc = plan.has_ibc ? 1 : 0; db->has_htdf = plan.has_htdf ? 1 : 0;
+    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->has_ibc = plan.has_ibc ? 1 : 0; db->has_htdf = plan.has_htdf ? 1 : 0;
     const size_t sz_cus = sizeof(CuRec) * (size_t)std::max(n, 1), sz_ctu = sizeof(uint32_t) * (size_t)(b->n_ctu + 1);
     const size_t sz_tbs = sizeof(TbRec) * (size_t)std::max(n_tb, 1), sz_wv = sizeof(TbWave) * (size_t)std::max(n_waves, 1);
     const size_t sz_coef = sizeof(int16_t) * std::max(b->n_coef, (size_t)8);
@@ -712,9 +683,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     const size_t sz_deps = sizeof(uint32_t) * (size_t)std::max(n_deps, 1);
     const size_t sz_aff = sizeof(AffItem) * (size_t)std::max(n_aff_eif + n_aff_sub, 1), sz_cpmv = sizeof(int16_t) * 12 * (size_t)std::max(n_aff, 1);
     const size_t o_deps = o_intra + align_up((int)sz_intra, 256), o_aff = o_deps + align_up((int)sz_deps, 256);
-    const size_t sz_mci = sizeof(McItem) * (size_t)std::max(n_mc_items, 1), sz_mcw = sizeof(McWave) * (size_t)std::max(n_mc_waves, 1);
-    const size_t o_cpmv = o_aff + align_up((int)sz_aff, 256), o_mci = o_cpmv + align_up((int)sz_cpmv, 256);
-    const size_t o_mcw = o_mci + align_up((int)sz_mci, 256), o_coef = o_mcw + align_up((int)sz_mcw, 256);
+    const size_t o_cpmv = o_aff + align_up((int)sz_aff, 256), o_coef = o_cpmv + align_up((int)sz_cpmv, 256);
     db->stage_bytes = o_coef + sz_coef;
     auto fail = [&](int code) { xgpu_batch_destroy(c, db); return code; };
     // device layout: the uploaded arrays at the staging offsets, then the residual arena and the intra done flags
@@ -749,9 +718,6 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     AffItem *aff_items = (AffItem *)(hs + o_aff);
     int16_t *cpmv = (int16_t *)(hs + o_cpmv);
     int aff_fill = 0, eif_fill = 0, sub_fill = n_aff_eif;
-    McItem *mc_items = (McItem *)(hs + o_mci);
-    McWave *mc_waves = (McWave *)(hs + o_mcw);
-    std::vector<int> mc_fill(mc_first);
 
     // pass 2: records + TB scatter into class order
     int cls_fill[NCLS];
@@ -770,16 +736,6 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
                     it.cu = (uint32_t)i; it.aff = (uint32_t)aff_fill; it.tx = (uint16_t)tx; it.ty = (uint16_t)ty; it.pad = 0;
                 }
             aff_fill++;
-        }
-        {
-            int plw, plh;
-            mc_piece(i, plw, plh);
-            const int key = mc_key(i);
-            for (int oy = 0; oy < (1 << b->log2h[i]); oy += 1 << plh)
-                for (int ox = 0; ox < (1 << b->log2w[i]); ox += 1 << plw) {
-                    McItem &it = mc_items[mc_fill[key]++];
-                    it.cu = (uint32_t)i; it.ox = (uint8_t)(ox >> 2); it.oy = (uint8_t)(oy >> 2); it.pad = 0;
-                }
         }
         r.x = b->x[i]; r.y = b->y[i]; r.log2w = b->log2w[i]; r.log2h = b->log2h[i];
         r.pred_mode = b->pred_mode[i]; r.cbf = b->cbf[i] & 7;
@@ -820,17 +776,6 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
             wv[w].tr_v = (uint8_t)((k >> 6) / 3); wv[w].tr_h = (uint8_t)((k >> 6) % 3); wv[w].pad[0] = wv[w].pad[1] = 0; w++;
         }
     }
-    {
-        int mw = 0;
-        for (size_t k = 0; k < mc_count.size(); k++) {
-            const int plw = 2 + ((int)(k >> 2) & 3), plh = 2 + ((int)k & 3), per = 64 >> (plw + plh - 4);
-            for (int f = 0; f < mc_count[k]; f += per) {
-                McWave &m = mc_waves[mw++];
-                m.first = (uint32_t)(mc_first[k] + f); m.n = (uint8_t)std::min(per, mc_count[k] - f);
-                m.lw = (uint8_t)plw; m.lh = (uint8_t)plh; m.lists = (uint8_t)((k >> 4) & 3);
-            }
-        }
-    }
     memcpy(hs + o_ctu, b->ctu_cu_start, sz_ctu);
     if (b->n_coef) memcpy(hs + o_coef, b->coef, sizeof(int16_t) * b->n_coef);
     if (n_intra) memcpy(hs + o_intra, plan.recs.data(), sizeof(IntraRec) * (size_t)n_intra);
@@ -840,7 +785,6 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     db->d_cus = (CuRec *)(dbase + o_cus); db->d_ctu_start = (uint32_t *)(dbase + o_ctu); db->d_tbs = (TbRec *)(dbase + o_tbs);
     db->d_waves = (TbWave *)(dbase + o_wv); db->d_intra = (IntraRec *)(dbase + o_intra); db->d_intra_deps = (uint32_t *)(dbase + o_deps);
     db->d_aff_items = (AffItem *)(dbase + o_aff); db->d_cpmv = (int16_t *)(dbase + o_cpmv);
-    db->d_mc_items = (McItem *)(dbase + o_mci); db->d_mc_waves = (McWave *)(dbase + o_mcw);
     db->d_coef = (int16_t *)(dbase + o_coef); db->d_resid = (int16_t *)(dbase + o_resid); db->d_intra_done = (uint32_t *)(dbase + o_done);
     // one copy: the staging block has the device layout
     hipError_t e = hipMemcpyAsync(dbase, hs, db->stage_bytes, hipMemcpyHostToDevice, c->stream);
@@ -891,16 +835,13 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
     a.admvp = c->sp.tool_admvp ? 1 : 0;
     a.cus = db->d_cus; a.ctu_cu_start = db->d_ctu_start; a.resid = db->d_resid;
     a.maps = c->d_maps; a.w_scu = c->w_scu; a.owner = c->d_owner; a.n_cu = db->n_cu;
-    a.items = db->d_mc_items; a.waves = db->d_mc_waves; a.n_waves = db->n_mc_waves;
     for (int l = 0; l < 2; l++)
         for (int i = 0; i < XGPU_MAX_REFS; i++) {
             const DevPic &rp = i < c->fp.num_refp[l] ? dpic(c, c->fp.refp_pic[i][l]) : dpic(c, c->fp.pic);
             a.refp[i][l].y = rp.y; a.refp[i][l].u = rp.u; a.refp[i][l].v = rp.v;
             a.refp[i][l].poc = i < c->fp.num_refp[l] ? c->fp.refp_poc[i][l] : 0;
         }
-    static const bool old_inter = getenv("XGPU_OLD_INTER") != NULL;      // development switch while the two kernels are compared
-    if (old_inter) TIMED(c, XGPU_K_INTER, launch_inter(c, a));
-    else TIMED(c, XGPU_K_INTER, launch_mc(c, a));
+    TIMED(c, XGPU_K_INTER, launch_inter(c, a));
     if (db->n_aff_eif + db->n_aff_sub) {
         AffineArgs f;
         memset(&f, 0, sizeof(f));

@@ -77,14 +77,6 @@ struct TbWave {
 
 struct RefEntry { const int16_t *y, *u, *v; int poc; int pad; };
 
-// Work lists of the inter reconstruction kernel (k_mc.hip), built by the host batch builder.  A PIECE is a CU cut to at most 32x32 luma
-// samples; pieces are sorted by (band of CTU rows, class) where class = reference lists used x piece shape, so that every wave runs 64 lanes
-// (one per 4x4 SCU) of identical control flow: 64 / ((w/4)*(h/4)) pieces of one shape per wave.
-struct McItem { uint32_t cu; uint8_t ox, oy; uint16_t pad; };           // CU record index, piece origin inside the CU in 4-sample units
-struct McWave { uint32_t first; uint8_t n, lw, lh, lists; };            // first item, item count, log2 piece size (2..5), bit 0 / 1: list 0 / 1 (0 = SCU map only)
-static_assert(sizeof(McItem) == 8 && sizeof(McWave) == 8, "work list records are 8 bytes");
-#define MC_BAND_ROWS 2                // CTU rows per band of the work list order
-
 // Kernel arguments of the inter reconstruction kernel (passed by value).
 struct InterArgs {
     int16_t *cur_y, *cur_u, *cur_v;
@@ -101,9 +93,6 @@ struct InterArgs {
     int      w_scu;
     uint16_t *owner;                   // [w_scu * h_scu] index (inside its CTU's list) of the CU covering each SCU, written by k_paint
     int      n_cu;
-    const McItem *items;               // k_mc work lists
-    const McWave *waves;
-    int      n_waves;
     RefEntry refp[XGPU_MAX_REFS][2];
 };
 
@@ -206,9 +195,6 @@ struct xgpu_dbatch {
     int16_t   *d_coef, *d_resid;
     TbRec     *d_tbs;
     TbWave    *d_waves;
-    McItem    *d_mc_items;            // pieces of all CUs in (band, class) order
-    McWave    *d_mc_waves;
-    int        n_mc_items, n_mc_waves;
     AffItem   *d_aff_items;           // tiles of the affine CUs
     int16_t   *d_cpmv;
     int        n_aff_eif, n_aff_sub;
@@ -252,8 +238,7 @@ struct xgpu_ctx {
 
 // kernel launchers (one per .hip file)
 void launch_itdq(xgpu_ctx *c, const ItdqArgs &a);
-void launch_inter(xgpu_ctx *c, const InterArgs &a);      // k_paint + k_inter (region-ordered kernel of round 1)
-void launch_mc(xgpu_ctx *c, const InterArgs &a);         // k_mc: class-sorted work lists
+void launch_inter(xgpu_ctx *c, const InterArgs &a);      // k_paint + k_inter
 void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf);
 void launch_affine(xgpu_ctx *c, const AffineArgs &a);
 void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst);
