@@ -157,6 +157,12 @@ int  xgpu_sync(xgpu_ctx *ctx);                         /* wait for everything en
 const char *xgpu_last_error(const xgpu_ctx *ctx);
 const char *xgpu_version(void);
 
+/* Pinned host memory for the arrays a batch points at (north_star: "batches decoded CUs per tile into pinned SoA buffers"): a coefficient
+   arena inside such a range is sent to the device straight from the caller's buffer, everything else through the context's staging
+   blocks.  The range must stay untouched until xgpu_batch_wait_upload() of the batch that points into it has returned.            */
+int  xgpu_host_alloc(xgpu_ctx *ctx, size_t bytes, void **out);
+void xgpu_host_free(xgpu_ctx *ctx, void *p);
+
 /* ------------------------------------------------------------------ pictures ---------------------- */
 int  xgpu_pic_alloc(xgpu_ctx *ctx);                    /* -> slot >= 0, or error                          */
 int  xgpu_pic_free(xgpu_ctx *ctx, int pic);
@@ -179,6 +185,13 @@ typedef struct xgpu_dra_luts {
 size_t xgpu_pic_output_size(const xgpu_ctx *ctx, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b);   /* 0: invalid */
 int  xgpu_pic_output(xgpu_ctx *ctx, int pic, const xgpu_dra_luts *dra, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b,
                      void *dst, size_t dst_size);
+/* The same in two halves, for a decode loop that overlaps the output of picture k with the kernels of picture k+1: _async queues the
+   conversion behind the picture's kernels and the copy to `dst` (pinned memory for a truly asynchronous copy) on the context's download
+   stream and returns a ticket; _wait blocks until `dst` holds the picture.  At most two outputs are in flight (a third call waits for the
+   first); the picture slot may be decoded into again as soon as _async has returned.                                                   */
+int  xgpu_pic_output_async(xgpu_ctx *ctx, int pic, const xgpu_dra_luts *dra, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b,
+                           void *dst, size_t dst_size, int *ticket);
+int  xgpu_pic_output_wait(xgpu_ctx *ctx, int ticket);
 /* whole padded buffers (XEVD_PIC.buf_y/u/v layout: stride = w + 2*pad, rows = h + 2*pad), for tests.     */
 int  xgpu_pic_download_padded(xgpu_ctx *ctx, int pic, int16_t *buf_y, int16_t *buf_u, int16_t *buf_v);
 int  xgpu_pic_upload_padded(xgpu_ctx *ctx, int pic, const int16_t *buf_y, const int16_t *buf_u, const int16_t *buf_v);
@@ -188,6 +201,10 @@ int  xgpu_frame_begin(xgpu_ctx *ctx, const xgpu_frame_params *fp);
 /* copy a batch into HBM (one pinned staging block + one async H2D copy) and build its device work lists.  The arrays behind `b`
    are read before the call returns.  Device and staging blocks come from a per-context pool: no allocation in steady state. */
 int  xgpu_batch_create(xgpu_ctx *ctx, const xgpu_cu_batch *b, xgpu_dbatch **out);
+/* xgpu_batch_create / xgpu_batch_destroy are the two entry points that may run on ANOTHER thread than the one driving the context (a builder
+   thread preparing picture k+1 while picture k is being launched): the upload goes through the context's own upload stream, and
+   xgpu_batch_recon makes the kernels wait for it.  xgpu_batch_wait_upload blocks until the batch's arrays have left host memory.        */
+int  xgpu_batch_wait_upload(xgpu_ctx *ctx, xgpu_dbatch *db);
 /* returns the batch's blocks to the pool.  Does not wait for the device: it may follow xgpu_batch_recon immediately (kernels already
    queued keep their data - later batches of this context are written through the same HIP stream, behind them). */
 void xgpu_batch_destroy(xgpu_ctx *ctx, xgpu_dbatch *db);

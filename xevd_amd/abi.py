@@ -151,6 +151,11 @@ _EXPORTS = {
     "xgpu_pic_download": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "xgpu_pic_output_size": (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "xgpu_pic_output": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
+    "xgpu_pic_output_async": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "xgpu_pic_output_wait": (C.c_int, [C.c_void_p, C.c_int]),
+    "xgpu_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "xgpu_host_free": (None, [C.c_void_p, C.c_void_p]),
+    "xgpu_batch_wait_upload": (C.c_int, [C.c_void_p, C.c_void_p]),
     "xgpu_pic_download_padded": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "xgpu_pic_upload_padded": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "xgpu_frame_begin": (C.c_int, [C.c_void_p, C.POINTER(FrameParams)]),

@@ -155,7 +155,9 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     xgpu_ctx *c = new xgpu_ctx();
     c->sp = *sp;
     c->sp.chroma_qp_table[0] = c->sp.chroma_qp_table[1] = NULL;
-    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_owner = NULL; c->d_out = NULL; c->d_dra = NULL; c->out_cap = 0; c->d_ctb_flag = NULL; c->stream = 0; c->where = 0;
+    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_owner = NULL; c->d_dra = NULL; c->d_ctb_flag = NULL; c->stream = 0; c->up_stream = 0; c->down_stream = 0; c->where = 0;
+    for (int i = 0; i < 2; i++) { c->d_out[i] = NULL; c->out_caps[i] = 0; c->out_ready[i] = c->out_done[i] = 0; c->out_busy[i] = 0; }
+    c->out_next = 0;
     memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_n, 0, sizeof(c->t_n));
     // chroma QP mapping: caller table starts at qp = -6*(bdc-8); default = Baseline static table with the
     // identity extension below 0 (xevd_set_chroma_qp_tbl_loc, xevd_tbl.c:364-372)
@@ -167,6 +169,11 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     auto fail = [&](int code) { xgpu_close(c); return code; };
     if (hipSetDevice(sp->device) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+    if (hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+    if (hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+    for (int i = 0; i < 2; i++)
+        if (hipEventCreateWithFlags(&c->out_ready[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->out_done[i], hipEventDisableTiming) != hipSuccess)
+            return fail(XGPU_ERR_UNEXPECTED);
 
     c->w_scu = sp->width >> 2; c->h_scu = sp->height >> 2;
     const int ctu = 1 << sp->log2_ctu;
@@ -207,25 +214,54 @@ void xgpu_close(xgpu_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->sp.device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
+    if (c->down_stream) (void)hipStreamSynchronize(c->down_stream);
     for (auto &p : c->pics) if (p.base) (void)hipFree(p.base);
     if (c->d_maps) (void)hipFree(c->d_maps);
-    for (BatchBlock &k : c->pool) { (void)hipFree(k.d_base); (void)hipHostFree(k.h_stage); (void)hipEventDestroy(k.uploaded); }
+    for (BatchBlock &k : c->pool) { (void)hipFree(k.d_base); (void)hipHostFree(k.h_stage); (void)hipEventDestroy(k.uploaded); (void)hipEventDestroy(k.done); }
+    for (auto &h : c->pinned) (void)hipHostFree(h.p);
+    c->pinned.clear();
     c->pool.clear();
     if (c->d_owner) (void)hipFree(c->d_owner);
-    if (c->d_out) (void)hipFree(c->d_out);
+    for (int i = 0; i < 2; i++) { if (c->d_out[i]) (void)hipFree(c->d_out[i]); if (c->out_ready[i]) (void)hipEventDestroy(c->out_ready[i]); if (c->out_done[i]) (void)hipEventDestroy(c->out_done[i]); }
     if (c->d_dra) (void)hipFree(c->d_dra);
     if (c->d_ctb_flag) (void)hipFree(c->d_ctb_flag);
     for (auto &e : c->ev_pending) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto &e : c->ev_pool) (void)hipEventDestroy(e);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
+    if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
     delete c;
 }
 
 int xgpu_sync(xgpu_ctx *c)
 {
     ARGCHK(c, c != NULL);
+    HIPCHK(c, hipStreamSynchronize(c->up_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->down_stream));
     return XGPU_OK;
+}
+
+// pinned host memory for the arrays a batch points at: xgpu_batch_create sends a coefficient arena inside such a range straight from the caller's buffer
+int xgpu_host_alloc(xgpu_ctx *c, size_t bytes, void **out)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, out != NULL && bytes > 0);
+    *out = NULL;
+    HIPCHK(c, hipSetDevice(c->sp.device));
+    void *p = NULL;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) { snprintf(c->err, sizeof(c->err), "host_alloc: cannot pin %zu bytes", bytes); return XGPU_ERR_OUT_OF_MEMORY; }
+    std::lock_guard<std::mutex> g(c->pool_mu);
+    c->pinned.push_back({ (uint8_t *)p, bytes });
+    *out = p;
+    return XGPU_OK;
+}
+void xgpu_host_free(xgpu_ctx *c, void *p)
+{
+    if (!c || !p) return;
+    std::lock_guard<std::mutex> g(c->pool_mu);
+    for (size_t i = 0; i < c->pinned.size(); i++)
+        if (c->pinned[i].p == (uint8_t *)p) { (void)hipHostFree(p); c->pinned.erase(c->pinned.begin() + (long)i); return; }
 }
 
 // ------------------------------------------------------------------------------------------------ pictures
@@ -315,16 +351,19 @@ size_t xgpu_pic_output_size(const xgpu_ctx *c, int out_bit_depth, int crop_l, in
     const size_t w = c->sp.width - crop_l - crop_r, h = c->sp.height - crop_t - crop_b;
     return (w * h + 2 * (w >> 1) * (h >> 1)) * (out_bit_depth == 8 ? 1 : 2);
 }
-int xgpu_pic_output(xgpu_ctx *c, int pic, const xgpu_dra_luts *dra, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b, void *dst, size_t dst_size)
+int xgpu_pic_output_async(xgpu_ctx *c, int pic, const xgpu_dra_luts *dra, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b, void *dst, size_t dst_size,
+                          int *ticket)
 {
-    ARGCHK(c, c != NULL); ARGCHK(c, valid_pic(c, pic)); ARGCHK(c, dst != NULL);
+    ARGCHK(c, c != NULL); ARGCHK(c, valid_pic(c, pic)); ARGCHK(c, dst != NULL && ticket != NULL);
     ARGCHK(c, valid_output(c, out_bit_depth, crop_l, crop_r, crop_t, crop_b));
     const size_t need = xgpu_pic_output_size(c, out_bit_depth, crop_l, crop_r, crop_t, crop_b);
     ARGCHK(c, dst_size >= need);
-    if (c->out_cap < need) {
-        if (c->d_out) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_out); c->d_out = NULL; c->out_cap = 0; }
-        if (hipMalloc((void **)&c->d_out, need) != hipSuccess) { snprintf(c->err, sizeof(c->err), "pic_output: cannot allocate the %zu-byte staging buffer", need); return XGPU_ERR_OUT_OF_MEMORY; }
-        c->out_cap = need;
+    const int k = c->out_next;
+    if (c->out_busy[k]) { HIPCHK(c, hipEventSynchronize(c->out_done[k])); c->out_busy[k] = 0; }      // two outputs in flight at most
+    if (c->out_caps[k] < need) {
+        if (c->d_out[k]) { HIPCHK(c, hipStreamSynchronize(c->stream)); (void)hipFree(c->d_out[k]); c->d_out[k] = NULL; c->out_caps[k] = 0; }
+        if (hipMalloc((void **)&c->d_out[k], need) != hipSuccess) { snprintf(c->err, sizeof(c->err), "pic_output: cannot allocate the %zu-byte staging buffer", need); return XGPU_ERR_OUT_OF_MEMORY; }
+        c->out_caps[k] = need;
     }
     if (dra) {
         ARGCHK(c, dra->luma_inv_scale_lut && dra->chroma_inv_scale_lut[0] && dra->chroma_inv_scale_lut[1]);
@@ -333,11 +372,30 @@ int xgpu_pic_output(xgpu_ctx *c, int pic, const xgpu_dra_luts *dra, int out_bit_
         const int32_t *src[3] = { dra->luma_inv_scale_lut, dra->chroma_inv_scale_lut[0], dra->chroma_inv_scale_lut[1] };
         for (int i = 0; i < 3; i++) HIPCHK(c, hipMemcpyAsync(c->d_dra + 1024 * i, src[i], sizeof(int32_t) * 1024, hipMemcpyHostToDevice, c->stream));
     }
-    launch_output(c, dpic(c, pic), dra ? c->d_dra : NULL, out_bit_depth, crop_l, crop_r, crop_t, crop_b, c->d_out);
+    // conversion + packing behind the picture's kernels on their stream; the copy to the host on the download stream behind an event, so it
+    // overlaps the kernels of the next picture
+    launch_output(c, dpic(c, pic), dra ? c->d_dra : NULL, out_bit_depth, crop_l, crop_r, crop_t, crop_b, c->d_out[k]);
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipMemcpyAsync(dst, c->d_out, need, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipEventRecord(c->out_ready[k], c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->down_stream, c->out_ready[k], 0));
+    HIPCHK(c, hipMemcpyAsync(dst, c->d_out[k], need, hipMemcpyDeviceToHost, c->down_stream));
+    HIPCHK(c, hipEventRecord(c->out_done[k], c->down_stream));
+    c->out_busy[k] = 1;
+    c->out_next = k ^ 1;
+    *ticket = k;
     return XGPU_OK;
+}
+int xgpu_pic_output_wait(xgpu_ctx *c, int ticket)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, ticket == 0 || ticket == 1);
+    if (c->out_busy[ticket]) { HIPCHK(c, hipEventSynchronize(c->out_done[ticket])); c->out_busy[ticket] = 0; }
+    return XGPU_OK;
+}
+int xgpu_pic_output(xgpu_ctx *c, int pic, const xgpu_dra_luts *dra, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b, void *dst, size_t dst_size)
+{
+    int ticket = 0;
+    const int rc = xgpu_pic_output_async(c, pic, dra, out_bit_depth, crop_l, crop_r, crop_t, crop_b, dst, dst_size, &ticket);
+    return rc < 0 ? rc : xgpu_pic_output_wait(c, ticket);
 }
 
 // ------------------------------------------------------------------------------------------------ per picture
@@ -690,15 +748,23 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     const size_t sz_done = sizeof(uint32_t) * ((size_t)n_intra + 1);
     const size_t o_resid = align_up((int)(o_coef + sz_coef), 256), o_done = o_resid + align_up((int)sz_coef, 256);
     const size_t d_need = o_done + align_up((int)sz_done, 256);
+    // is the coefficient arena inside a range from xgpu_host_alloc?  Then it is sent from where it lies (no staging copy of the largest array)
+    bool coef_pinned = false;
     {
         // a pooled block that is large enough (the smallest such), else a new one
         int best = -1;
-        for (size_t k = 0; k < c->pool.size(); k++)
-            if (c->pool[k].d_cap >= d_need && c->pool[k].h_cap >= db->stage_bytes && (best < 0 || c->pool[k].d_cap < c->pool[best].d_cap)) best = (int)k;
+        {
+            std::lock_guard<std::mutex> g(c->pool_mu);
+            for (const auto &h : c->pinned)
+                if ((const uint8_t *)b->coef >= h.p && (const uint8_t *)(b->coef + b->n_coef) <= h.p + h.n) coef_pinned = b->n_coef != 0;
+            for (size_t k = 0; k < c->pool.size(); k++)
+                if (c->pool[k].d_cap >= d_need && c->pool[k].h_cap >= db->stage_bytes && (best < 0 || c->pool[k].d_cap < c->pool[best].d_cap)) best = (int)k;
+            if (best >= 0) { db->blk = c->pool[best]; c->pool.erase(c->pool.begin() + best); }
+        }
         if (best >= 0) {
-            db->blk = c->pool[best];
-            c->pool.erase(c->pool.begin() + best);
             if (hipEventSynchronize(db->blk.uploaded) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);      // its staging block may still feed an upload
+            // ... and its device block the kernels of the batch that had it before: the upload stream waits for them
+            if (hipStreamWaitEvent(c->up_stream, db->blk.done, 0) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
         } else {
             memset(&db->blk, 0, sizeof(db->blk));
             const size_t d_cap = d_need + d_need / 4, h_cap = db->stage_bytes + db->stage_bytes / 4;             // headroom: pictures of a stream vary
@@ -707,6 +773,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
             if (hipHostMalloc(&db->blk.h_stage, h_cap, hipHostMallocDefault) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
             db->blk.h_cap = h_cap;
             if (hipEventCreateWithFlags(&db->blk.uploaded, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+            if (hipEventCreateWithFlags(&db->blk.done, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
         }
     }
     db->h_stage = db->blk.h_stage;
@@ -777,7 +844,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         }
     }
     memcpy(hs + o_ctu, b->ctu_cu_start, sz_ctu);
-    if (b->n_coef) memcpy(hs + o_coef, b->coef, sizeof(int16_t) * b->n_coef);
+    if (b->n_coef && !coef_pinned) memcpy(hs + o_coef, b->coef, sizeof(int16_t) * b->n_coef);
     if (n_intra) memcpy(hs + o_intra, plan.recs.data(), sizeof(IntraRec) * (size_t)n_intra);
     if (n_deps) memcpy(hs + o_deps, plan.deps.data(), sizeof(uint32_t) * (size_t)n_deps);
 
@@ -786,11 +853,13 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     db->d_waves = (TbWave *)(dbase + o_wv); db->d_intra = (IntraRec *)(dbase + o_intra); db->d_intra_deps = (uint32_t *)(dbase + o_deps);
     db->d_aff_items = (AffItem *)(dbase + o_aff); db->d_cpmv = (int16_t *)(dbase + o_cpmv);
     db->d_coef = (int16_t *)(dbase + o_coef); db->d_resid = (int16_t *)(dbase + o_resid); db->d_intra_done = (uint32_t *)(dbase + o_done);
-    // one copy: the staging block has the device layout
-    hipError_t e = hipMemcpyAsync(dbase, hs, db->stage_bytes, hipMemcpyHostToDevice, c->stream);
-    if (e == hipSuccess) e = hipEventRecord(db->blk.uploaded, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(db->d_intra_done, 0, sz_done, c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(db->d_resid, 0, sz_coef, c->stream);
+    // one copy: the staging block has the device layout (a pinned coefficient arena goes from the caller's buffer).  On the upload stream: the
+    // copy overlaps the kernels of the pictures before; xgpu_batch_recon makes the kernel stream wait for `uploaded`
+    hipError_t e = hipMemcpyAsync(dbase, hs, coef_pinned ? o_coef : db->stage_bytes, hipMemcpyHostToDevice, c->up_stream);
+    if (e == hipSuccess && coef_pinned) e = hipMemcpyAsync(dbase + o_coef, b->coef, sizeof(int16_t) * b->n_coef, hipMemcpyHostToDevice, c->up_stream);
+    if (e == hipSuccess) e = hipMemsetAsync(db->d_intra_done, 0, sz_done, c->up_stream);
+    if (e == hipSuccess) e = hipMemsetAsync(db->d_resid, 0, sz_coef, c->up_stream);
+    if (e == hipSuccess) e = hipEventRecord(db->blk.uploaded, c->up_stream);
     if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "batch upload: %s", hipGetErrorString(e)); return fail(XGPU_ERR_UNEXPECTED); }
     *out = db;
     return XGPU_OK;
@@ -799,14 +868,15 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
 void xgpu_batch_destroy(xgpu_ctx *c, xgpu_dbatch *db)
 {
     if (!db) return;
-    // No synchronisation: kernels still queued on the context's stream keep reading the block, and whoever reuses it writes it through the
-    // same stream (ordered behind them); only the staging block is touched by the host, guarded by the `uploaded` event.
-    if (db->blk.d_base && db->blk.h_stage && db->blk.uploaded && c) c->pool.push_back(db->blk);
+    // No synchronisation: kernels still queued on the context's stream keep reading the block; whoever reuses it makes the upload stream wait
+    // for the `done` event those kernels signal, and the host waits for `uploaded` before it touches the staging block.
+    if (db->blk.d_base && db->blk.h_stage && db->blk.uploaded && db->blk.done && c) { std::lock_guard<std::mutex> g(c->pool_mu); c->pool.push_back(db->blk); }
     else {
         if (c && c->stream) (void)hipStreamSynchronize(c->stream);
         if (db->blk.d_base) (void)hipFree(db->blk.d_base);
         if (db->blk.h_stage) (void)hipHostFree(db->blk.h_stage);
         if (db->blk.uploaded) (void)hipEventDestroy(db->blk.uploaded);
+        if (db->blk.done) (void)hipEventDestroy(db->blk.done);
     }
     delete db;
 }
@@ -814,6 +884,7 @@ void xgpu_batch_destroy(xgpu_ctx *c, xgpu_dbatch *db)
 int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
 {
     ARGCHK(c, c != NULL); ARGCHK(c, db != NULL); ARGCHK(c, c->have_frame);
+    HIPCHK(c, hipStreamWaitEvent(c->stream, db->blk.uploaded, 0));       // the batch's arrays come through the upload stream
     ItdqArgs ia;
     ia.coef = db->d_coef; ia.resid = db->d_resid; ia.tbs = db->d_tbs; ia.waves = db->d_waves; ia.n_waves = db->n_waves;
     ia.bd = c->sp.bit_depth_luma;      // the LUMA depth drives dequant/transform shifts of all components (xevd.c:441-442)
@@ -869,6 +940,14 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
         });
     }
     HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(db->blk.done, c->stream));                  // the block may be overwritten by a later batch after this point
+    return XGPU_OK;
+}
+
+int xgpu_batch_wait_upload(xgpu_ctx *c, xgpu_dbatch *db)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, db != NULL);
+    HIPCHK(c, hipEventSynchronize(db->blk.uploaded));
     return XGPU_OK;
 }
 

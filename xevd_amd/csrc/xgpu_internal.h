@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <mutex>
 #include <vector>
 #include "../../include/xevd_hip.h"
 
@@ -184,7 +185,7 @@ struct AlfArgs {
 // One device block + one pinned staging block of a batch.  xgpu_batch_destroy returns them to the context's pool instead of freeing:
 // hipMalloc / hipFree / hipHostMalloc synchronise the device and serialise across the threads of a process, which capped many-stream
 // decoding on one GPU (tools/bench_multistream.py) and cost a stream synchronisation per picture.
-struct BatchBlock { uint8_t *d_base; size_t d_cap; void *h_stage; size_t h_cap; hipEvent_t uploaded; };
+struct BatchBlock { uint8_t *d_base; size_t d_cap; void *h_stage; size_t h_cap; hipEvent_t uploaded, done; };      // uploaded: the H2D copies have left the host memory; done: the reconstruction kernels have read the block
 
 struct xgpu_dbatch {
     BatchBlock blk;
@@ -211,7 +212,11 @@ struct xgpu_dbatch {
 struct xgpu_ctx {
     xgpu_seq_params sp;
     int8_t          chroma_qp[2][96];  // [c][qp + 6*(bdc-8)]
-    hipStream_t     stream;
+    hipStream_t     stream;            // kernels
+    hipStream_t     up_stream, down_stream;      // batch uploads / output downloads: their own DMA queues, ordered against the kernels by events
+    std::mutex      pool_mu;           // xgpu_batch_create / _destroy may run on a builder thread next to the thread that drives the context
+    struct HostRange { uint8_t *p; size_t n; };
+    std::vector<HostRange> pinned;     // xgpu_host_alloc'ed ranges: batch arrays inside them are sent without a staging copy
     int             w_scu, h_scu, w_ctu, h_ctu;
     int             s_l, s_c, rows_l, rows_c;
     size_t          pic_elems, off_u, off_v;
@@ -220,9 +225,11 @@ struct xgpu_ctx {
     uint16_t       *d_owner;          // SCU -> CU index inside the CTU, rebuilt per picture by k_paint
     uint8_t        *d_ctb_flag;       // ALF luma CTB flags of the current picture
     std::vector<BatchBlock> pool;     // blocks of destroyed batches, reused by later ones of the same stream (same HIP stream -> ordered)
-    uint8_t        *d_out;            // packed output picture (xgpu_pic_output), grown on demand
+    uint8_t        *d_out[2];         // packed output pictures (xgpu_pic_output): two in flight, grown on demand
+    size_t          out_caps[2];
+    hipEvent_t      out_ready[2], out_done[2];      // conversion kernel finished (kernel stream) / copy to the host finished (download stream)
+    int             out_busy[2], out_next;
     int32_t        *d_dra;            // [3][1024] DRA inverse tables of the current output call
-    size_t          out_cap;
     xgpu_frame_params fp;
     int             have_frame;
     int             where;             // 0: the picture being built lives in its DPB slot, 1: in the scratch picture

@@ -96,6 +96,25 @@ class XgpuDecoder:
         self._chk(self.lib.xgpu_pic_output(self.ctx, pic, dl, bd, *crop, out.ctypes.data, n), "xgpu_pic_output")
         return out
 
+    def host_alloc(self, nbytes, dtype=np.uint8):
+        """pinned host memory from the backend as a numpy array (freed with the decoder): for coefficient arenas and output buffers"""
+        p = C.c_void_p()
+        self._chk(self.lib.xgpu_host_alloc(self.ctx, nbytes, C.byref(p)), "xgpu_host_alloc")
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (nbytes,)).view(dtype)
+
+    def pic_output_async(self, pic, out, out_bit_depth=0, crop=(0, 0, 0, 0)):
+        """queue conversion + packing + the copy into `out` (uint8 array, pinned for a truly asynchronous copy) -> ticket for pic_output_wait"""
+        t = C.c_int()
+        self._chk(self.lib.xgpu_pic_output_async(self.ctx, pic, None, out_bit_depth or self.bit_depth, *crop, out.ctypes.data, out.nbytes, C.byref(t)),
+                  "xgpu_pic_output_async")
+        return t.value
+
+    def pic_output_wait(self, ticket):
+        self._chk(self.lib.xgpu_pic_output_wait(self.ctx, ticket), "xgpu_pic_output_wait")
+
+    def batch_wait_upload(self, h):
+        self._chk(self.lib.xgpu_batch_wait_upload(self.ctx, h), "xgpu_batch_wait_upload")
+
     def pic_upload_padded(self, pic, bufs):
         y, u, v = (np.ascontiguousarray(p, np.int16) for p in bufs)
         self._chk(self.lib.xgpu_pic_upload_padded(self.ctx, pic, y.ctypes.data, u.ctypes.data, v.ctypes.data), "xgpu_pic_upload_padded")
