@@ -12,8 +12,9 @@ separately as `pcie_inclusive_fps`.
     python bench.py --gpus 1 --steps 200 --warmup 20            # single GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # one rank per GPU
 
-With N > 1 every rank decodes its own independent stream (streams/GOPs shard across GPUs with a host
-work queue and no collective), so scaling is "weak" and value = N x frames / max-over-ranks time.
+With N > 1 the workload is BASELINE.json configs[4]: independent 4K Main streams cut into GOP-sized jobs that the ranks draw from one
+host work queue (streams/GOPs shard across GPUs, no collective, no RCCL); N x steps pictures in total, so scaling is "weak"
+and value = N x steps / max-over-ranks time; per-rank picture counts and rates are in `per_rank`.
 """
 import argparse
 import json
@@ -32,6 +33,9 @@ WORKLOADS = {
     "base_8k_10b_ippp": dict(w=7680, h=4320, bd=10, admvp=0, iqt=0, addb=0, alf=0, n_refs=(1, 0), bi_frac=0.0),
     # configs[2]: Main profile 4K 10 bit, two reference lists, 50% bi-prediction, 8-tap MC tables, IQT, ADDB, ALF
     "cfg3_main_4k_10b_ra": dict(w=3840, h=2160, bd=10, admvp=1, iqt=1, addb=1, alf=1, n_refs=(1, 1), bi_frac=0.5),
+    # configs[4]: independent 4K Main streams sharded over the GPUs of the node through a host work queue (the default with --gpus N > 1):
+    # the same stream shape as configs[2], cut into jobs of GOP_PICTURES pictures that the ranks draw from one queue
+    "cfg5_main_4k_10b_ra_streams": dict(w=3840, h=2160, bd=10, admvp=1, iqt=1, addb=1, alf=1, n_refs=(1, 1), bi_frac=0.5),
     # configs[3]: the same at 8K - the configuration the metric (fps + HBM GB/s at 4K/8K) is quoted on
     "cfg4_main_8k_10b_ra": dict(w=7680, h=4320, bd=10, admvp=1, iqt=1, addb=1, alf=1, n_refs=(1, 1), bi_frac=0.5),
     # not a BASELINE config: cfg4 with 30 % of the inter CUs of 8x8 and above affine (2 / 3 control points; sub-block translation and EIF) - k_affine's cost
@@ -41,6 +45,8 @@ WORKLOADS = {
     "main_8k_10b_ra_affine30": dict(w=7680, h=4320, bd=10, admvp=1, iqt=1, addb=1, alf=1, n_refs=(1, 1), bi_frac=0.5, affine_frac=0.3),
 }
 DEFAULT_WORKLOAD = "cfg4_main_8k_10b_ra"
+DEFAULT_WORKLOAD_MULTI = "cfg5_main_4k_10b_ra_streams"
+GOP_PICTURES = 8            # pictures per job of the multi-GPU work queue (one closed GOP)
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
@@ -255,7 +261,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help=f"default: {DEFAULT_WORKLOAD} on one GPU, {DEFAULT_WORKLOAD_MULTI} with --gpus N > 1")
     ap.add_argument("--batches", type=int, default=4, help="distinct pictures' CU batches kept resident and cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -265,10 +272,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    if args.workload is None:
+        args.workload = DEFAULT_WORKLOAD_MULTI if world > 1 else DEFAULT_WORKLOAD
     if world > 1:
+        # the ranks exchange no picture data (streams / GOPs are independent): the process group only carries the job counter of
+        # the work queue (rendezvous store), the barriers and the final accounting - gloo on the host, no RCCL communicator is created
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("gloo")
+    local_rank %= max(torch.cuda.device_count(), 1)       # more ranks than devices (a one-GPU box exercising the N > 1 path): they share
     torch.cuda.set_device(local_rank)
 
     from xevd_amd.decoder import XgpuDecoder
@@ -321,15 +333,40 @@ def main():
     for k in range(args.warmup):
         step(k)
     barrier()
+    per_rank = None
     t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if dist is None:
+        for k in range(args.steps):
+            step(args.warmup + k)
+        barrier()
+        dt = time.perf_counter() - t0
+    else:
+        # world x steps pictures in jobs of GOP_PICTURES, drawn by the ranks from one queue (xevd_amd/workqueue.py: a counter in the
+        # rendezvous store): a rank that is done asks for the next job, nobody waits for a fixed share
+        from xevd_amd import workqueue
+        import torch.distributed.distributed_c10d as c10d
+        n_jobs = (world * args.steps + GOP_PICTURES - 1) // GOP_PICTURES
+        q = workqueue.TicketQueue(c10d._get_default_store(), n_jobs, key="xevd_amd/bench_jobs")
+        mine, k = 0, args.warmup
+        while True:
+            j = q.next()
+            if j is None:
+                break
+            n = min(GOP_PICTURES, world * args.steps - j * GOP_PICTURES)
+            for _ in range(n):
+                step(k)
+                k += 1
+            mine += n
+        torch.cuda.synchronize()
+        dec.sync()
+        my_dt = time.perf_counter() - t0
+        barrier()
+        t = torch.tensor([my_dt], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        g = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(g, torch.tensor([float(mine), my_dt], dtype=torch.float64))
+        per_rank = [{"rank": r, "pictures": int(v[0].item()), "fps": round(float(v[0].item()) / max(float(v[1].item()), 1e-9), 2)} for r, v in enumerate(g)]
 
     # per-kernel durations with HIP events on the stream the kernels are launched on, same workload and steps
     dec.timing_enable(True)
@@ -345,7 +382,7 @@ def main():
     handles = []
     e2e = end_to_end_leg(dec, wl, batches, alf, slots, max(args.steps // 2, 10), 4)
     if dist is not None:
-        t = torch.tensor([e2e["ms_per_picture"]], dtype=torch.float64, device="cuda")
+        t = torch.tensor([e2e["ms_per_picture"]], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         e2e["fps"] = round(world * 1e3 / float(t.item()), 2)
 
@@ -388,7 +425,8 @@ def main():
                        "stream": ("2 reference lists, 50% bi-predicted CUs" if two_lists else "IPPP, 1 reference")
                                  + ", 90% inter / 10% intra CUs (5 Baseline modes), 60% coded, deblock on, quad-tree 64..4",
                        "batches_resident": len(batches),
-                       "parallelism": f"{world} independent stream(s), one per GPU"},
+                       "parallelism": (f"{world} ranks, one GPU each, drawing jobs of {GOP_PICTURES} pictures (closed GOPs of independent streams) from one host work "
+                                       "queue; no collective on the data path" if world > 1 else "1 stream on 1 GPU")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 2),
@@ -399,6 +437,7 @@ def main():
                             "achieved_gbps": round(total_alg / kern_s / 1e9, 1)},
             # `value` above is the rate with the CU batches resident in HBM (the benchmark contract's definition); the rate of the whole
             # span host batches -> host YUV, transfers and the host batch builder inside the timed region, is end_to_end_fps
+            "per_rank": per_rank,
             "kernel_only_fps": round(world * args.steps / dt, 2),
             "end_to_end_fps": e2e["fps"],
             "end_to_end": e2e,

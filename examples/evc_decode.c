@@ -1,23 +1,45 @@
 /*
- * evc_decode.c - a complete decoder in plain C on the two C ABIs of this repository (no Python, no reference code):
+ * evc_decode.c - a complete decoder in plain C on the C ABIs of this repository (no Python, no reference code):
  *   include/xevd_host.h  bitstream -> per-picture CU batches + DPB bookkeeping by POC      (libxevd_host.so, host only)
  *   include/xevd_hip.h   CU batches -> pictures on the MI355X                              (libxevd_hip.so)
+ *   include/xevd_wq.h    closed GOPs of all inputs -> the GPUs of the node                 (libxevd_host.so)
  * It is the loop xevd_app runs around xevd_decode / xevd_pull (app/xevd_app.c:455-640), with the pictures living in HBM: parse a picture,
  * map its reference POCs to device picture slots, reconstruct + filter + pad it, release the pictures the stream unmarked, write the
- * output in POC order inside every IDR period (what xevd_pull's bumping yields).
- * usage: evc_decode in.evc out.yuv [output_bit_depth]        (0 / omitted: the coding bit depth; 8: one byte per sample)
+ * output in POC order inside every IDR period (what xevd_pull's bumping yields).  The output of picture k (conversion, packing, download)
+ * overlaps the kernels of picture k + 1 (xgpu_pic_output_async).
+ * With --gpus N every input is cut into closed GOPs (IDR to IDR: independent units) and the GOPs of all inputs go through one
+ * host work queue to N worker threads, one per device, each with its own context and DPB; every GOP lands at its own offset of its output
+ * file.  No collective, no RCCL: there is nothing to exchange.
+ * usage: evc_decode [--gpus N] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
+ *        evc_decode in.evc out.yuv D                                               (the round-1 form)
  * build: oracle-free; see examples/Makefile.
  */
+#define _XOPEN_SOURCE 700
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
+#include <fcntl.h>
 #include "xevd_host.h"
+#include "xevd_wq.h"
 
-#define MAX_SLOTS 24
-#define CHECK(call) do { int rc_ = (call); if (rc_ < 0) { fprintf(stderr, "%s -> %d (%s)\n", #call, rc_, g ? xgpu_last_error(g) : ""); return 1; } } while (0)
+#define MAX_SLOTS 33             /* the parser keeps at most 32 reference pictures + the current one */
+#define MAX_STREAMS 64
+#define MAX_GOPS 4096
+#define CHECK(call) do { int rc_ = (call); if (rc_ < 0) { fprintf(stderr, "%s -> %d (%s)\n", #call, rc_, w->g ? xgpu_last_error(w->g) : ""); return rc_; } } while (0)
 
 typedef struct { int poc, pic, in_use; } slot_t;                 /* DPB: POC -> device picture slot */
-typedef struct { int epoch, poc; size_t off; } out_t;              /* one output picture: position in the staging file */
+typedef struct { int epoch, poc; size_t off; } out_t;              /* one output picture: position in the unit's buffer */
+typedef struct { const uint8_t *bytes; size_t size; int fd; int out_bd; } stream_t;
+typedef struct {                                                    /* one worker = one device */
+    int device;
+    xgpu_ctx *g;
+    xgpu_seq_params sp;
+    int slots[MAX_SLOTS];
+    const stream_t *streams;
+    long pictures;
+} worker_t;
 
 static int cmp_out(const void *a, const void *b)
 {
@@ -25,23 +47,30 @@ static int cmp_out(const void *a, const void *b)
     return x->epoch != y->epoch ? x->epoch - y->epoch : x->poc - y->poc;
 }
 
-int main(int argc, char **argv)
+/* the worker's context fits the stream of this picture?  Else (re)open it: one context per sequence, reused by every unit of it */
+static int worker_context(worker_t *w, const xhost_picture *p)
 {
-    if (argc < 3) { fprintf(stderr, "usage: %s in.evc out.yuv [output_bit_depth]\n", argv[0]); return 2; }
-    const int out_bd_arg = argc > 3 ? atoi(argv[3]) : 0;
-    FILE *f = fopen(argv[1], "rb");
-    if (!f) { perror(argv[1]); return 2; }
-    fseek(f, 0, SEEK_END);
-    const long size = ftell(f);
-    fseek(f, 0, SEEK_SET);
-    uint8_t *bytes = (uint8_t *)malloc((size_t)size);
-    if (fread(bytes, 1, (size_t)size, f) != (size_t)size) return 2;
-    fclose(f);
+    xgpu_seq_params sp;
+    memset(&sp, 0, sizeof(sp));
+    sp.device = w->device; sp.width = p->width; sp.height = p->height;
+    sp.bit_depth_luma = p->bit_depth_luma; sp.bit_depth_chroma = p->bit_depth_chroma; sp.chroma_format_idc = 1; sp.log2_ctu = 6;
+    sp.tool_iqt = p->tool_iqt; sp.tool_addb = p->tool_addb; sp.tool_alf = p->tool_alf; sp.tool_eipd = p->tool_eipd;
+    sp.max_pics = MAX_SLOTS + 1;
+    if (w->g && !p->chroma_qp_table[0] && !memcmp(&sp, &w->sp, sizeof(sp))) return 0;
+    if (w->g) { xgpu_close(w->g); w->g = NULL; }
+    w->sp = sp;                                                     /* compared without the table pointers */
+    sp.chroma_qp_table[0] = p->chroma_qp_table[0]; sp.chroma_qp_table[1] = p->chroma_qp_table[1];
+    CHECK(xgpu_open(&sp, &w->g));
+    for (int i = 0; i < MAX_SLOTS; i++) { w->slots[i] = xgpu_pic_alloc(w->g); if (w->slots[i] < 0) return w->slots[i]; }
+    return 0;
+}
 
-    xhost_parser *ps = xhost_parser_open(bytes, (size_t)size);
-    xgpu_ctx *g = NULL;
+/* Decode `bytes` (parameter sets + one or more GOPs) on the worker's device -> packed pictures in output order (malloc'ed) */
+static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_bd_arg, uint8_t **frames_out, int *n_out, size_t *frame_bytes_out)
+{
+    xhost_parser *ps = xhost_parser_open(bytes, size);
     slot_t dpb[MAX_SLOTS];
-    int free_pic[MAX_SLOTS], n_free = 0, n_pics = 0, epoch = -1, rc;
+    int free_pic[MAX_SLOTS], n_free = 0, n_pics = 0, epoch = -1, rc, have_ctx = 0, ticket = -1;
     out_t *outs = NULL;
     uint8_t *frames = NULL;                                         /* decoded pictures in decoding order, packed */
     size_t frame_bytes = 0, cap = 0;
@@ -49,23 +78,17 @@ int main(int argc, char **argv)
     memset(dpb, 0, sizeof(dpb));
 
     while ((rc = xhost_parser_next(ps, &p)) == 1) {
-        if (!g) {                                                    /* first picture: the sequence parameters are known */
-            xgpu_seq_params sp;
-            memset(&sp, 0, sizeof(sp));
-            sp.device = 0; sp.width = p.width; sp.height = p.height;
-            sp.bit_depth_luma = p.bit_depth_luma; sp.bit_depth_chroma = p.bit_depth_chroma; sp.chroma_format_idc = 1; sp.log2_ctu = 6;
-            sp.tool_iqt = p.tool_iqt; sp.tool_addb = p.tool_addb; sp.tool_alf = p.tool_alf; sp.tool_eipd = p.tool_eipd;
-            sp.max_pics = MAX_SLOTS + 2;
-            sp.chroma_qp_table[0] = p.chroma_qp_table[0]; sp.chroma_qp_table[1] = p.chroma_qp_table[1];
-            CHECK(xgpu_open(&sp, &g));
-            for (int i = 0; i < MAX_SLOTS; i++) { const int id = xgpu_pic_alloc(g); if (id < 0) return 1; free_pic[n_free++] = id; }
-            frame_bytes = xgpu_pic_output_size(g, out_bd_arg ? out_bd_arg : p.bit_depth_luma, 0, 0, 0, 0);
+        if (!have_ctx) {                                             /* first picture: the sequence parameters are known */
+            CHECK(worker_context(w, &p));
+            for (int i = 0; i < MAX_SLOTS; i++) free_pic[n_free++] = w->slots[i];
+            frame_bytes = xgpu_pic_output_size(w->g, out_bd_arg ? out_bd_arg : p.bit_depth_luma, 0, 0, 0, 0);
+            have_ctx = 1;
         }
         if (p.is_idr) {                                              /* an IDR empties the DPB */
             for (int i = 0; i < MAX_SLOTS; i++) if (dpb[i].in_use) { free_pic[n_free++] = dpb[i].pic; dpb[i].in_use = 0; }
             epoch++;
         }
-        if (n_free == 0) { fprintf(stderr, "DPB overflow\n"); return 1; }
+        if (n_free == 0) { fprintf(stderr, "DPB overflow\n"); return -1; }
         const int cur = free_pic[--n_free];
 
         xgpu_frame_params fp;
@@ -76,7 +99,7 @@ int main(int argc, char **argv)
             for (int i = 0; i < p.num_refp[l]; i++) {
                 int s = -1;
                 for (int k = 0; k < MAX_SLOTS; k++) if (dpb[k].in_use && dpb[k].poc == p.refp_poc[i][l]) s = dpb[k].pic;
-                if (s < 0) { fprintf(stderr, "reference POC %d is not in the DPB\n", p.refp_poc[i][l]); return 1; }
+                if (s < 0) { fprintf(stderr, "reference POC %d is not in the DPB\n", p.refp_poc[i][l]); return -1; }
                 fp.refp_pic[i][l] = s; fp.refp_poc[i][l] = p.refp_poc[i][l];
             }
         }
@@ -85,23 +108,29 @@ int main(int argc, char **argv)
         fp.deblock_on = p.deblock_on; fp.alf_on = p.alf_on;
 
         xgpu_dbatch *db = NULL;
-        CHECK(xgpu_batch_create(g, &p.batch, &db));                 /* the parser's arrays are consumed before the call returns */
-        CHECK(xgpu_frame_begin(g, &fp));
-        CHECK(xgpu_batch_recon(g, db));
-        if (p.deblock_on) CHECK(xgpu_deblock(g));
-        if (p.alf_on) CHECK(xgpu_alf(g, &p.alf));
-        CHECK(xgpu_pad(g));
-        CHECK(xgpu_frame_end(g));
-        xgpu_batch_destroy(g, db);
+        CHECK(xgpu_batch_create(w->g, &p.batch, &db));              /* the parser's arrays are consumed before the call returns */
+        CHECK(xgpu_frame_begin(w->g, &fp));
+        CHECK(xgpu_batch_recon(w->g, db));
+        if (p.deblock_on) CHECK(xgpu_deblock(w->g));
+        if (p.alf_on) CHECK(xgpu_alf(w->g, &p.alf));
+        CHECK(xgpu_pad(w->g));
+        CHECK(xgpu_frame_end(w->g));
+        xgpu_batch_destroy(w->g, db);
 
         if ((size_t)(n_pics + 1) * frame_bytes > cap) {
+            if (ticket >= 0) { CHECK(xgpu_pic_output_wait(w->g, ticket)); ticket = -1; }      /* the buffer moves: no copy may be in flight */
             cap = cap ? cap * 2 : 16 * frame_bytes;
             frames = (uint8_t *)realloc(frames, cap);
             outs = (out_t *)realloc(outs, sizeof(out_t) * (cap / frame_bytes));
-            if (!frames || !outs) return 1;
+            if (!frames || !outs) return -1;
         }
-        xgpu_dra_luts dra = { p.dra_lut[0], { p.dra_lut[1], p.dra_lut[2] } };          /* the DRA post-filter, when the PPS switches it on */
-        CHECK(xgpu_pic_output(g, cur, p.dra_lut[0] ? &dra : NULL, out_bd_arg ? out_bd_arg : p.bit_depth_luma, 0, 0, 0, 0, frames + (size_t)n_pics * frame_bytes, frame_bytes));
+        /* output of this picture behind its kernels, overlapping the parsing and the kernels of the next one; the DRA post-filter, when the
+           PPS switches it on, is part of it */
+        xgpu_dra_luts dra = { p.dra_lut[0], { p.dra_lut[1], p.dra_lut[2] } };
+        const int prev = ticket;
+        CHECK(xgpu_pic_output_async(w->g, cur, p.dra_lut[0] ? &dra : NULL, out_bd_arg ? out_bd_arg : p.bit_depth_luma, 0, 0, 0, 0,
+                                    frames + (size_t)n_pics * frame_bytes, frame_bytes, &ticket));
+        if (prev >= 0 && prev != ticket) CHECK(xgpu_pic_output_wait(w->g, prev));
         outs[n_pics].epoch = epoch; outs[n_pics].poc = p.poc; outs[n_pics].off = (size_t)n_pics * frame_bytes;
         n_pics++;
 
@@ -112,16 +141,120 @@ int main(int argc, char **argv)
             for (int k = 0; k < MAX_SLOTS; k++) if (!dpb[k].in_use) { dpb[k].in_use = 1; dpb[k].poc = p.poc; dpb[k].pic = cur; break; }
         } else free_pic[n_free++] = cur;
     }
-    if (rc < 0) { fprintf(stderr, "parser: %s\n", xhost_parser_error(ps)); return 1; }
+    if (rc < 0) { fprintf(stderr, "parser: %s\n", xhost_parser_error(ps)); xhost_parser_close(ps); return rc; }
+    xhost_parser_close(ps);
+    if (w->g) CHECK(xgpu_sync(w->g));                               /* the last outputs have landed */
 
     qsort(outs, (size_t)n_pics, sizeof(out_t), cmp_out);            /* output order: ascending POC inside every IDR period */
-    f = fopen(argv[2], "wb");
-    if (!f) { perror(argv[2]); return 2; }
-    for (int i = 0; i < n_pics; i++) fwrite(frames + outs[i].off, 1, frame_bytes, f);
-    fclose(f);
-    fprintf(stderr, "%d pictures\n", n_pics);
-    xhost_parser_close(ps);
-    if (g) xgpu_close(g);
-    free(frames); free(outs); free(bytes);
+    uint8_t *sorted = (uint8_t *)malloc((size_t)(n_pics ? n_pics : 1) * (frame_bytes ? frame_bytes : 1));
+    if (!sorted) return -1;
+    for (int i = 0; i < n_pics; i++) memcpy(sorted + (size_t)i * frame_bytes, frames + outs[i].off, frame_bytes);
+    free(frames); free(outs);
+    *frames_out = sorted; *n_out = n_pics; *frame_bytes_out = frame_bytes;
+    return 0;
+}
+
+/* ---- work queue callbacks: one worker per device ---- */
+static void *worker_init(int device, void *user)
+{
+    worker_t *w = (worker_t *)calloc(1, sizeof(worker_t));
+    if (!w) return NULL;
+    w->device = device; w->streams = (const stream_t *)user;
+    /* is the device there?  A worker without one leaves the queue to the others instead of failing their jobs */
+    xgpu_seq_params sp;
+    xgpu_ctx *probe = NULL;
+    memset(&sp, 0, sizeof(sp));
+    sp.device = device; sp.width = 64; sp.height = 64; sp.bit_depth_luma = sp.bit_depth_chroma = 8; sp.chroma_format_idc = 1; sp.log2_ctu = 6; sp.max_pics = 1;
+    if (xgpu_open(&sp, &probe) < 0) { fprintf(stderr, "device %d is not usable: its jobs go to the other workers\n", device); free(w); return NULL; }
+    xgpu_close(probe);
+    return w;
+}
+static int worker_job(void *state, const xwq_job *job)
+{
+    worker_t *w = (worker_t *)state;
+    const stream_t *s = &w->streams[job->stream];
+    const size_t cap = (size_t)job->offset + (size_t)job->size + 16;
+    uint8_t *unit = (uint8_t *)malloc(cap), *frames = NULL;
+    int n = 0;
+    size_t frame_bytes = 0;
+    if (!unit) return -1;
+    const size_t len = xwq_unit_bytes(s->bytes, s->size, job, unit, cap);
+    int rc = len ? decode_unit(w, unit, len, s->out_bd, &frames, &n, &frame_bytes) : -1;
+    free(unit);
+    if (rc < 0) return rc;
+    if (n != job->n_pictures) { fprintf(stderr, "stream %d unit %d: %d pictures decoded, %d expected\n", job->stream, job->unit, n, job->n_pictures); rc = -1; }
+    else if (n && pwrite(s->fd, frames, (size_t)n * frame_bytes, (off_t)((size_t)job->first_picture * frame_bytes)) != (ssize_t)((size_t)n * frame_bytes)) { perror("pwrite"); rc = -1; }
+    free(frames);
+    w->pictures += n;
+    return rc;
+}
+static void worker_fini(void *state)
+{
+    worker_t *w = (worker_t *)state;
+    if (w->g) xgpu_close(w->g);
+    free(w);
+}
+
+int main(int argc, char **argv)
+{
+    int gpus = 1, out_bd = 0, a = 1;
+    while (a < argc && argv[a][0] == '-' && argv[a][1] == '-') {
+        if (!strcmp(argv[a], "--gpus") && a + 1 < argc) { gpus = atoi(argv[a + 1]); a += 2; }
+        else if (!strcmp(argv[a], "--bd") && a + 1 < argc) { out_bd = atoi(argv[a + 1]); a += 2; }
+        else break;
+    }
+    int n_pos = argc - a;
+    if (n_pos == 3 && strspn(argv[a + 2], "0123456789") == strlen(argv[a + 2])) { out_bd = atoi(argv[a + 2]); n_pos = 2; }      /* in out D */
+    if (n_pos < 2 || (n_pos & 1) || gpus < 1 || gpus > 64 || n_pos / 2 > MAX_STREAMS) {
+        fprintf(stderr, "usage: %s [--gpus N] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]\n", argv[0]);
+        return 2;
+    }
+    static stream_t streams[MAX_STREAMS];
+    static xwq_job jobs[MAX_GOPS];
+    const int n_streams = n_pos / 2;
+    xwq *q = xwq_create();
+    if (!q) return 1;
+    long total_pictures = 0;
+    int n_jobs = 0;
+    for (int s = 0; s < n_streams; s++) {
+        FILE *f = fopen(argv[a + 2 * s], "rb");
+        if (!f) { perror(argv[a + 2 * s]); return 2; }
+        fseek(f, 0, SEEK_END);
+        const long size = ftell(f);
+        fseek(f, 0, SEEK_SET);
+        uint8_t *bytes = (uint8_t *)malloc((size_t)size + 1);
+        if (!bytes || fread(bytes, 1, (size_t)size, f) != (size_t)size) return 2;
+        fclose(f);
+        streams[s].bytes = bytes; streams[s].size = (size_t)size; streams[s].out_bd = out_bd;
+        streams[s].fd = open(argv[a + 2 * s + 1], O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (streams[s].fd < 0) { perror(argv[a + 2 * s + 1]); return 2; }
+        /* one job per closed GOP with several devices, the whole stream as one job with one (no parameter sets to re-parse) */
+        int n = xwq_split_gops(bytes, (size_t)size, s, jobs, MAX_GOPS);
+        if (n < 0) { fprintf(stderr, "%s: damaged NAL length prefix\n", argv[a + 2 * s]); return 1; }
+        if (n == 0) continue;                                       /* no picture: an empty output file */
+        if (gpus == 1) {
+            int pics = 0;
+            for (int k = 0; k < n; k++) pics += jobs[k].n_pictures;
+            jobs[0].size = (size_t)size - jobs[0].offset; jobs[0].n_pictures = pics;
+            n = 1;
+        }
+        for (int k = 0; k < n; k++) { xwq_push(q, &jobs[k]); total_pictures += jobs[k].n_pictures; }
+        n_jobs += n;
+    }
+    xwq_close(q);
+    int devices[64], done[64];
+    for (int i = 0; i < gpus; i++) devices[i] = i;
+    struct timespec t0, t1;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    const int rc = xwq_run(q, devices, gpus, worker_init, worker_job, worker_fini, streams, done);
+    clock_gettime(CLOCK_MONOTONIC, &t1);
+    const double secs = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+    for (int s = 0; s < n_streams; s++) { close(streams[s].fd); free((void *)streams[s].bytes); }
+    xwq_destroy(q);
+    if (rc < 0) { fprintf(stderr, "decoding failed: %d\n", rc); return 1; }
+    fprintf(stderr, "%ld pictures\n", total_pictures);
+    fprintf(stderr, "%d stream(s), %d job(s) on %d device(s):", n_streams, n_jobs, gpus);
+    for (int i = 0; i < gpus; i++) fprintf(stderr, " %d", done[i]);
+    fprintf(stderr, " jobs; %.3f s, %.2f pictures/s (device start-up, parsing and output included)\n", secs, secs > 0 ? (double)total_pictures / secs : 0.0);
     return 0;
 }

@@ -29,6 +29,19 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), name
 
 
+def test_host_library_exports_every_declared_symbol():
+    """include/xevd_host.h (parser / writer) and include/xevd_wq.h (multi-GPU work queue) -> libxevd_host.so"""
+    lib = C.CDLL(os.path.join(ROOT, "xevd_amd", "libxevd_host.so"))
+    for header, prefix in (("xevd_host.h", "xhost_"), ("xevd_wq.h", "xwq_")):
+        src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", header)).read(), flags=re.S)
+        names = sorted(set(re.findall(r"\b(%s[a-z0-9_]+)\s*\(" % prefix, src)))
+        assert len(names) >= 5, header
+        for name in names:
+            if name.endswith("_fn"):
+                continue                      # callback types
+            assert hasattr(lib, name), name
+
+
 def test_struct_sizes_match_header():
     # computed by hand from include/xevd_hip.h (LP64)
     assert C.sizeof(abi.SeqParams) == 12 * 4 + 2 * 8 + 8          # ... + tool_eipd + tail padding

@@ -421,3 +421,26 @@ def test_gpu_bench_workload_vs_oracle(name):
     out = cases.run_gpu(cs)
     for c in range(3):
         assert np.array_equal(out[c], ref.bufs[c]), f"{name} plane {c}: {np.argwhere(out[c] != ref.bufs[c])[:4]}"
+
+
+@pytest.mark.gpu
+def test_gpu_plain_c_decoder_work_queue(tmp_path):
+    """examples/evc_decode --gpus 2 on two inputs: every input is cut into closed GOPs, the GOPs of both go through the C work queue
+    (include/xevd_wq.h) to one worker thread per device - on a one-GPU box the second worker finds no device and leaves its share to the
+    first - and every GOP lands at its own offset of its output file: the reference decoder's pictures, byte for byte"""
+    import subprocess
+    exe = os.path.normpath(os.path.join(golden_io.GOLDEN, "..", "..", "examples", "evc_decode"))
+    names = ["idr_period_skip", "hier_b_gop4"]
+    cmd, expect = [exe, "--gpus", "2"], []
+    for name in names:
+        d = np.load(os.path.join(golden_io.GOLDEN, f"stream_{name}.npz"))
+        src, dst = tmp_path / f"{name}.evc", tmp_path / f"{name}.yuv"
+        src.write_bytes(d["bytes"].tobytes())
+        cmd += [str(src), str(dst)]
+        expect.append((dst, np.concatenate([d[f"p{k}_{c}"].ravel() for k in range(int(d["n"])) for c in range(3)])))
+    r = subprocess.run(cmd, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-400:]
+    assert b"2 stream(s)" in r.stderr
+    for dst, want in expect:
+        got = np.fromfile(dst, np.uint8)
+        assert got.size == want.size and np.array_equal(got.astype(np.int32), want.astype(np.int32)), dst
