@@ -106,8 +106,14 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
     // sums of |Laplacian| over the 2x2 sub-blocks of the tile + one ring: [direction V, H, D0, D1][sub-block row -1..32][col -1..32]
     __shared__ __attribute__((aligned(16))) uint16_t l_lap[4][34][SSTR];
 
-    const int tiles_x = (a.pic_w + 63) >> 6;
-    const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    // XCD-aware mapping: workgroup b runs on XCD b % 8 and every XCD has its own L2.  A tile reads its neighbours' edge samples as halo (the 8-byte
+    // pieces at cols -4 and 64 sit in the cache lines of the tiles to the left and right, 3 rows above / below in those of the tiles there), so
+    // with tiles handed out round-robin every line was fetched from HBM by up to three XCDs: 331 MB read per 8K picture for 126 MB of window
+    // (TCC_EA0_RDREQ_128B, profiles/round2_*).  Each XCD now takes a contiguous eighth of the raster tile order: neighbours share an L2.
+    const int tiles_x = (a.pic_w + 63) >> 6, n_tiles = tiles_x * ((a.pic_h + 63) >> 6);
+    const int tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (tile >= n_tiles) return;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tx0 = tx << 6, ty0 = ty << 6;
     const int t = threadIdx.x;
     // the CTU this tile belongs to and its border availability (alf_process_tile :984-999)
@@ -305,5 +311,5 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
 void launch_alf(xgpu_ctx *c, const AlfArgs &a, const DevPic &src, const DevPic &dst)
 {
     const int tiles = ((a.pic_w + 63) >> 6) * ((a.pic_h + 63) >> 6);
-    hipLaunchKernelGGL(k_alf, dim3(tiles), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
+    hipLaunchKernelGGL(k_alf, dim3(((tiles + 7) >> 3) << 3), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
 }

@@ -213,16 +213,17 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     __shared__ uint2    s_ctap[33];
     __shared__ __attribute__((aligned(16))) int16_t s_tile[4][UNI_SAMPLES];      // per wave: window + intermediate of the tile path
 
-    // XCD-aware mapping: workgroup b runs on XCD b % 8; give every XCD a contiguous band of regions so that
-    // vertically adjacent regions (which share reference halos) hit the same L2.
-    // Inside a band the regions are walked in strips INTER_STRIP wide, so that the ~100 workgroups an XCD has in flight
-    // form a compact patch whose vertical halos are still in that L2 when the row below is processed.
+    // XCD-aware mapping: workgroup b runs on XCD b % 8 and every XCD has its own L2.  The regions are ordered in vertical strips INTER_STRIP wide
+    // (row-major inside a strip) and every XCD takes a contiguous eighth of that order - about one strip: the ~100 workgroups it has in flight
+    // form a compact patch whose vertical halos are still in its L2 when the row below is processed, and all XCDs get the same number of regions
+    // (bands of whole region rows left the last XCD with 5 of 68 rows at 8K: the kernel ran at the pace of the 9-row bands).
     const int regions_y = a.n_regions / a.regions_x;
-    const int band_rows = (regions_y + 7) >> 3;
-    const int k = blockIdx.x >> 3, per_strip = INTER_STRIP * band_rows;
-    const int strip = k / per_strip, ks = k - strip * per_strip;
-    const int rx = strip * INTER_STRIP + ks % INTER_STRIP, ry = (blockIdx.x & 7) * band_rows + ks / INTER_STRIP;
-    if (rx >= a.regions_x || ry >= regions_y) return;
+    const int idx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (idx >= a.n_regions) return;
+    const int per_strip = INTER_STRIP * regions_y;
+    const int strip = idx / per_strip, ks = idx - strip * per_strip;
+    const int sw = min(INTER_STRIP, a.regions_x - strip * INTER_STRIP);       // the last strip may be narrower
+    const int ry = ks / sw, rx = strip * INTER_STRIP + (ks - ry * sw);
     const int ctu_x = (rx << 6) >> a.log2_ctu, ctu_y = (ry << 6) >> a.log2_ctu;
     const int ctu = ctu_y * a.w_ctu + ctu_x;
     const int first = a.ctu_cu_start[ctu];
@@ -483,10 +484,7 @@ __global__ __launch_bounds__(256) void k_paint(const InterArgs a)
 void launch_inter(xgpu_ctx *c, const InterArgs &a)
 {
     if (a.n_cu) hipLaunchKernelGGL(k_paint, dim3((a.n_cu + 255) / 256), dim3(256), 0, c->stream, a);
-    const int regions_y = a.n_regions / a.regions_x, band_rows = (regions_y + 7) >> 3;
-    const int strips = (a.regions_x + INTER_STRIP - 1) / INTER_STRIP;
-    const int blocks = strips * INTER_STRIP * band_rows * 8;
-    hipLaunchKernelGGL(k_inter, dim3(blocks), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_inter, dim3(((a.n_regions + 7) >> 3) << 3), dim3(256), 0, c->stream, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
