@@ -143,51 +143,77 @@ def cpu_baseline(wl, first, batch, alf, budget_s=15.0):
                          if kind == "reference" else "plain-C oracle port")}
 
 
-def reference_decoder_leg(wl, budget_s=25.0):
-    """The reference DECODER itself (its public API through oracle/_ref/ref_decode, -m 1 and -m 8 threads) on a real bitstream of the same
-    shape, written by this repository's front end: entropy decoding included, i.e. what a user of xevd_app runs on this host.  The front
-    end writes P pictures with one reference, and of the Main tools IQT / ADDB / ALF - not the 8-tap tables and bi-prediction of the GPU
-    workload - so for the Main workloads this is a lower bound of the reference's work per picture."""
+def reference_decoder_leg(wl, budget_s=40.0):
+    """Real-bitstream decode, .evc -> .yuv, of a stream of the workload's shape written by this repository's front end (closed GOPs; P
+    pictures with one reference, and of the Main tools IQT / ADDB / ALF - not the 8-tap tables and bi-prediction of the GPU workload):
+    the reference DECODER itself (its public API through oracle/_ref/ref_decode, -m 1 and -m 8 threads, entropy decoding included - what a
+    user of xevd_app runs on this host) next to examples/evc_decode (plain C on this repository's C ABIs: 8 parser workers feeding one GPU
+    through the GOP work queue), outputs compared byte for byte."""
+    import hashlib
     import subprocess
     import tempfile
     from xevd_amd import stream, synth
     main_profile = bool(wl["addb"] or wl["iqt"] or wl["alf"])
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_decode_main" if main_profile else "ref_decode")
+    ours = os.path.join(ROOT, "examples", "evc_decode")
     if not os.path.exists(exe):
         return None
     w, h, bd = wl["w"], wl["h"], wl["bd"]
-    n = 30 if w * h <= 1920 * 1088 else (8 if w * h <= 3840 * 2176 else 3)
+    n, gop = (40, 5) if w * h <= 1920 * 1088 else ((16, 2) if w * h <= 3840 * 2176 else (8, 1))
     rng = np.random.default_rng(77)
     wr = stream.StreamWriter(w, h, bd, 1, main=main_profile, iqt=bool(wl["iqt"]), addb=bool(wl["addb"]), alf=bool(wl["alf"]))
     try:
         if wl["alf"]:
             wr.add_alf_aps(0, luma=rng.integers(-12, 13, (5, 12)), chroma=rng.integers(-10, 11, 6), type7=True, delta_idx=rng.integers(0, 5, 25))
         for k in range(n):
-            b = synth.gen_frame(rng, w, h, bd, inter_frac=0.0 if k == 0 else 0.9, n_refs=(1, 0), bi_frac=0.0, coded_frac=0.6, max_level=6, amp=1.0)
+            idr = k % gop == 0
+            b = synth.gen_frame(rng, w, h, bd, inter_frac=0.0 if idr else 0.9, n_refs=(1, 0), bi_frac=0.0, coded_frac=0.6, max_level=6, amp=1.0)
             if wl["alf"]:
                 wr.set_slice_alf(True, 0, 0, chroma_idc=3)
-            wr.add_picture(b, stream.SLICE_I if k == 0 else stream.SLICE_P, slice_qp=30, idr=k == 0)
+            wr.add_picture(b, stream.SLICE_I if idr else stream.SLICE_P, slice_qp=30, idr=idr)
         data = wr.bytes()
     finally:
         wr.close()
-    fps, t0 = {}, time.perf_counter()
+
+    def md5(path):
+        hh = hashlib.md5()
+        with open(path, "rb") as f:
+            for blk in iter(lambda: f.read(1 << 24), b""):
+                hh.update(blk)
+        return hh.hexdigest()
+    fps, sums, t0, gpu = {}, set(), time.perf_counter(), None
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "s.evc")
         with open(path, "wb") as f:
             f.write(data)
+        if os.path.exists(ours):
+            dst = os.path.join(td, "ours.yuv")
+            r = subprocess.run([ours, "--workers", "8", path, dst], stderr=subprocess.PIPE, timeout=300)
+            if r.returncode == 0:
+                txt = r.stderr.decode()
+                gpu = {"decode_only_fps": float(txt.split("slowest worker)")[1].split("s,")[1].split("pictures/s")[0]), "parser_workers": 8}
+                if bd > 8:
+                    sums.add(md5(dst))          # 16-bit samples like the reference driver's output
+            else:
+                gpu = {"error": r.stderr.decode()[-200:]}
         for threads in (1, 8):
             if time.perf_counter() - t0 > budget_s:
                 break
-            r = subprocess.run([exe, path, "-", str(w), str(h), str(threads)], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=120)
+            dst = os.path.join(td, "ref.raw")
+            r = subprocess.run([exe, path, dst, str(w), str(h), str(threads)], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=300)
             if r.returncode != 0:
                 return {"error": r.stderr.decode()[-200:]}
             pics, secs = r.stderr.decode().split()[-2:]
             fps[str(threads)] = round(int(pics) / float(secs), 2)
-    return {"frames_per_s_by_threads": fps, "host_cores": os.cpu_count(),
-            "stream": f"{n} pictures (1 I + {n - 1} P, one reference), {w}x{h} {bd}-bit, {len(data)} bytes, "
+            if bd > 8:
+                sums.add(md5(dst))
+    return {"frames_per_s_by_threads": fps, "host_cores": os.cpu_count(), "evc_decode_on_gpu": gpu,
+            "bit_exact": (len(sums) == 1) if bd > 8 and gpu and "error" not in gpu else None,
+            "stream": f"{n} pictures in closed GOPs of {gop} (I + P, one reference), {w}x{h} {bd}-bit, {len(data)} bytes, "
                       + ("Main profile: IQT, ADDB, ALF" if main_profile else "Baseline profile") + ", written by xevd_amd/host",
             "what": "xevd_create / xevd_decode / xevd_pull of the reference library built in oracle/_ref (entropy decoding + reconstruction), "
-                    "threads = XEVD_CDSC.threads"}
+                    "threads = XEVD_CDSC.threads; evc_decode_on_gpu: examples/evc_decode --workers 8 on the same bytes, decode-only rate of the slowest "
+                    "worker (parsing + kernels + output, the span the reference application times)"}
 
 
 def end_to_end_leg(dec, wl, batches, alf, slots, steps, warmup, builders=int(os.environ.get('XEVD_BENCH_BUILDERS', '4')), depth=int(os.environ.get('XEVD_BENCH_DEPTH', '5'))):

@@ -10,7 +10,10 @@
  * With --gpus N every input is cut into closed GOPs (IDR to IDR: independent units) and the GOPs of all inputs go through one
  * host work queue to N worker threads, one per device, each with its own context and DPB; every GOP lands at its own offset of its output
  * file.  No collective, no RCCL: there is nothing to exchange.
- * usage: evc_decode [--gpus N] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
+ * --workers W puts W worker threads (each with its own parser, context and DPB) on every device: one stream's entropy decoding is a serial
+ * chain on one host core (an 8K picture takes tens of milliseconds to parse, its kernels half a millisecond), so a GPU is fed by parsing
+ * several GOPs at once.
+ * usage: evc_decode [--gpus N] [--workers W] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
  *        evc_decode in.evc out.yuv D                                               (the round-1 form)
  * build: oracle-free; see examples/Makefile.
  */
@@ -36,10 +39,18 @@ typedef struct {                                                    /* one worke
     int device;
     xgpu_ctx *g;
     xgpu_seq_params sp;
-    int slots[MAX_SLOTS];
+    int slots[MAX_SLOTS], n_slots;                                  /* device pictures allocated so far (on demand) */
     const stream_t *streams;
     long pictures;
+    double busy_s, setup_s;                                         /* time inside the units / inside context creation and picture allocation */
 } worker_t;
+
+static double now_s(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
 
 static int cmp_out(const void *a, const void *b)
 {
@@ -57,38 +68,52 @@ static int worker_context(worker_t *w, const xhost_picture *p)
     sp.tool_iqt = p->tool_iqt; sp.tool_addb = p->tool_addb; sp.tool_alf = p->tool_alf; sp.tool_eipd = p->tool_eipd;
     sp.max_pics = MAX_SLOTS + 1;
     if (w->g && !p->chroma_qp_table[0] && !memcmp(&sp, &w->sp, sizeof(sp))) return 0;
+    const double t0 = now_s();
     if (w->g) { xgpu_close(w->g); w->g = NULL; }
     w->sp = sp;                                                     /* compared without the table pointers */
+    w->n_slots = 0;
     sp.chroma_qp_table[0] = p->chroma_qp_table[0]; sp.chroma_qp_table[1] = p->chroma_qp_table[1];
     CHECK(xgpu_open(&sp, &w->g));
-    for (int i = 0; i < MAX_SLOTS; i++) { w->slots[i] = xgpu_pic_alloc(w->g); if (w->slots[i] < 0) return w->slots[i]; }
+    w->setup_s += now_s() - t0;
     return 0;
 }
 
 /* Decode `bytes` (parameter sets + one or more GOPs) on the worker's device -> packed pictures in output order (malloc'ed) */
-static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_bd_arg, uint8_t **frames_out, int *n_out, size_t *frame_bytes_out)
+static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_bd_arg, int expected, uint8_t **frames_out, out_t **outs_out, int *n_out, size_t *frame_bytes_out, int *pinned_out)
 {
     xhost_parser *ps = xhost_parser_open(bytes, size);
     slot_t dpb[MAX_SLOTS];
-    int free_pic[MAX_SLOTS], n_free = 0, n_pics = 0, epoch = -1, rc, have_ctx = 0, ticket = -1;
-    out_t *outs = NULL;
-    uint8_t *frames = NULL;                                         /* decoded pictures in decoding order, packed */
-    size_t frame_bytes = 0, cap = 0;
+    int free_pic[MAX_SLOTS], n_free = 0, n_pics = 0, epoch = -1, rc, have_ctx = 0, ticket = -1, pinned = 0;
+    out_t *outs = (out_t *)malloc(sizeof(out_t) * (size_t)(expected > 0 ? expected : 1));
+    uint8_t *frames = NULL;                                         /* decoded pictures in decoding order, packed: pinned memory, so that the */
+    size_t frame_bytes = 0;                                         /* download of picture k runs while picture k + 1 is parsed and launched     */
+    if (!outs) return -1;
     xhost_picture p;
     memset(dpb, 0, sizeof(dpb));
 
     while ((rc = xhost_parser_next(ps, &p)) == 1) {
         if (!have_ctx) {                                             /* first picture: the sequence parameters are known */
             CHECK(worker_context(w, &p));
-            for (int i = 0; i < MAX_SLOTS; i++) free_pic[n_free++] = w->slots[i];
+            for (int i = 0; i < w->n_slots; i++) free_pic[n_free++] = w->slots[i];
             frame_bytes = xgpu_pic_output_size(w->g, out_bd_arg ? out_bd_arg : p.bit_depth_luma, 0, 0, 0, 0);
+            void *pin = NULL;
+            if (xgpu_host_alloc(w->g, (size_t)(expected > 0 ? expected : 1) * frame_bytes, &pin) == 0) { frames = (uint8_t *)pin; pinned = 1; }
+            else frames = (uint8_t *)malloc((size_t)(expected > 0 ? expected : 1) * frame_bytes);       /* pageable: the copies block, the result is the same */
+            if (!frames) return -1;
             have_ctx = 1;
         }
         if (p.is_idr) {                                              /* an IDR empties the DPB */
             for (int i = 0; i < MAX_SLOTS; i++) if (dpb[i].in_use) { free_pic[n_free++] = dpb[i].pic; dpb[i].in_use = 0; }
             epoch++;
         }
-        if (n_free == 0) { fprintf(stderr, "DPB overflow\n"); return -1; }
+        if (n_free == 0) {                                           /* device pictures are allocated when the stream first needs them */
+            if (w->n_slots == MAX_SLOTS) { fprintf(stderr, "DPB overflow\n"); return -1; }
+            const double t0 = now_s();
+            const int id = xgpu_pic_alloc(w->g);
+            if (id < 0) return id;
+            w->setup_s += now_s() - t0;
+            w->slots[w->n_slots++] = id; free_pic[n_free++] = id;
+        }
         const int cur = free_pic[--n_free];
 
         xgpu_frame_params fp;
@@ -117,13 +142,7 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
         CHECK(xgpu_frame_end(w->g));
         xgpu_batch_destroy(w->g, db);
 
-        if ((size_t)(n_pics + 1) * frame_bytes > cap) {
-            if (ticket >= 0) { CHECK(xgpu_pic_output_wait(w->g, ticket)); ticket = -1; }      /* the buffer moves: no copy may be in flight */
-            cap = cap ? cap * 2 : 16 * frame_bytes;
-            frames = (uint8_t *)realloc(frames, cap);
-            outs = (out_t *)realloc(outs, sizeof(out_t) * (cap / frame_bytes));
-            if (!frames || !outs) return -1;
-        }
+        if (n_pics >= expected) { fprintf(stderr, "more pictures than slice NAL units\n"); return -1; }
         /* output of this picture behind its kernels, overlapping the parsing and the kernels of the next one; the DRA post-filter, when the
            PPS switches it on, is part of it */
         xgpu_dra_luts dra = { p.dra_lut[0], { p.dra_lut[1], p.dra_lut[2] } };
@@ -146,11 +165,7 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
     if (w->g) CHECK(xgpu_sync(w->g));                               /* the last outputs have landed */
 
     qsort(outs, (size_t)n_pics, sizeof(out_t), cmp_out);            /* output order: ascending POC inside every IDR period */
-    uint8_t *sorted = (uint8_t *)malloc((size_t)(n_pics ? n_pics : 1) * (frame_bytes ? frame_bytes : 1));
-    if (!sorted) return -1;
-    for (int i = 0; i < n_pics; i++) memcpy(sorted + (size_t)i * frame_bytes, frames + outs[i].off, frame_bytes);
-    free(frames); free(outs);
-    *frames_out = sorted; *n_out = n_pics; *frame_bytes_out = frame_bytes;
+    *frames_out = frames; *outs_out = outs; *n_out = n_pics; *frame_bytes_out = frame_bytes; *pinned_out = pinned;
     return 0;
 }
 
@@ -175,38 +190,48 @@ static int worker_job(void *state, const xwq_job *job)
     const stream_t *s = &w->streams[job->stream];
     const size_t cap = (size_t)job->offset + (size_t)job->size + 16;
     uint8_t *unit = (uint8_t *)malloc(cap), *frames = NULL;
-    int n = 0;
+    out_t *outs = NULL;
+    int n = 0, pinned = 0;
     size_t frame_bytes = 0;
     if (!unit) return -1;
     const size_t len = xwq_unit_bytes(s->bytes, s->size, job, unit, cap);
-    int rc = len ? decode_unit(w, unit, len, s->out_bd, &frames, &n, &frame_bytes) : -1;
+    const double t0 = now_s();
+    int rc = len ? decode_unit(w, unit, len, s->out_bd, job->n_pictures, &frames, &outs, &n, &frame_bytes, &pinned) : -1;
+    w->busy_s += now_s() - t0;
     free(unit);
     if (rc < 0) return rc;
     if (n != job->n_pictures) { fprintf(stderr, "stream %d unit %d: %d pictures decoded, %d expected\n", job->stream, job->unit, n, job->n_pictures); rc = -1; }
-    else if (n && pwrite(s->fd, frames, (size_t)n * frame_bytes, (off_t)((size_t)job->first_picture * frame_bytes)) != (ssize_t)((size_t)n * frame_bytes)) { perror("pwrite"); rc = -1; }
-    free(frames);
+    else
+        for (int i = 0; i < n && rc >= 0; i++)                       /* picture by picture, in output order, at the unit's place in the file */
+            if (pwrite(s->fd, frames + outs[i].off, frame_bytes, (off_t)((size_t)(job->first_picture + i) * frame_bytes)) != (ssize_t)frame_bytes) { perror("pwrite"); rc = -1; }
+    if (pinned) xgpu_host_free(w->g, frames); else free(frames);
+    free(outs);
     w->pictures += n;
     return rc;
 }
+static double g_busy[64], g_setup[64];
+static int g_workers;
 static void worker_fini(void *state)
 {
     worker_t *w = (worker_t *)state;
+    { const int k = __sync_fetch_and_add(&g_workers, 1); g_busy[k & 63] = w->busy_s - w->setup_s; g_setup[k & 63] = w->setup_s; }
     if (w->g) xgpu_close(w->g);
     free(w);
 }
 
 int main(int argc, char **argv)
 {
-    int gpus = 1, out_bd = 0, a = 1;
+    int gpus = 1, workers = 1, out_bd = 0, a = 1;
     while (a < argc && argv[a][0] == '-' && argv[a][1] == '-') {
         if (!strcmp(argv[a], "--gpus") && a + 1 < argc) { gpus = atoi(argv[a + 1]); a += 2; }
+        else if (!strcmp(argv[a], "--workers") && a + 1 < argc) { workers = atoi(argv[a + 1]); a += 2; }
         else if (!strcmp(argv[a], "--bd") && a + 1 < argc) { out_bd = atoi(argv[a + 1]); a += 2; }
         else break;
     }
     int n_pos = argc - a;
     if (n_pos == 3 && strspn(argv[a + 2], "0123456789") == strlen(argv[a + 2])) { out_bd = atoi(argv[a + 2]); n_pos = 2; }      /* in out D */
-    if (n_pos < 2 || (n_pos & 1) || gpus < 1 || gpus > 64 || n_pos / 2 > MAX_STREAMS) {
-        fprintf(stderr, "usage: %s [--gpus N] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]\n", argv[0]);
+    if (n_pos < 2 || (n_pos & 1) || gpus < 1 || workers < 1 || gpus * workers > 64 || n_pos / 2 > MAX_STREAMS) {
+        fprintf(stderr, "usage: %s [--gpus N] [--workers W] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]\n", argv[0]);
         return 2;
     }
     static stream_t streams[MAX_STREAMS];
@@ -228,22 +253,17 @@ int main(int argc, char **argv)
         streams[s].bytes = bytes; streams[s].size = (size_t)size; streams[s].out_bd = out_bd;
         streams[s].fd = open(argv[a + 2 * s + 1], O_WRONLY | O_CREAT | O_TRUNC, 0644);
         if (streams[s].fd < 0) { perror(argv[a + 2 * s + 1]); return 2; }
-        /* one job per closed GOP with several devices, the whole stream as one job with one (no parameter sets to re-parse) */
+        /* one job per closed GOP: the unit of the queue, and the bound on the pinned output buffer of a worker */
         int n = xwq_split_gops(bytes, (size_t)size, s, jobs, MAX_GOPS);
         if (n < 0) { fprintf(stderr, "%s: damaged NAL length prefix\n", argv[a + 2 * s]); return 1; }
         if (n == 0) continue;                                       /* no picture: an empty output file */
-        if (gpus == 1) {
-            int pics = 0;
-            for (int k = 0; k < n; k++) pics += jobs[k].n_pictures;
-            jobs[0].size = (size_t)size - jobs[0].offset; jobs[0].n_pictures = pics;
-            n = 1;
-        }
         for (int k = 0; k < n; k++) { xwq_push(q, &jobs[k]); total_pictures += jobs[k].n_pictures; }
         n_jobs += n;
     }
     xwq_close(q);
     int devices[64], done[64];
-    for (int i = 0; i < gpus; i++) devices[i] = i;
+    gpus *= workers;                                                /* worker i runs on device i / workers */
+    for (int i = 0; i < gpus; i++) devices[i] = i / workers;
     struct timespec t0, t1;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     const int rc = xwq_run(q, devices, gpus, worker_init, worker_job, worker_fini, streams, done);
@@ -253,8 +273,12 @@ int main(int argc, char **argv)
     xwq_destroy(q);
     if (rc < 0) { fprintf(stderr, "decoding failed: %d\n", rc); return 1; }
     fprintf(stderr, "%ld pictures\n", total_pictures);
-    fprintf(stderr, "%d stream(s), %d job(s) on %d device(s):", n_streams, n_jobs, gpus);
+    fprintf(stderr, "%d stream(s), %d job(s) on %d worker(s), %d per device:", n_streams, n_jobs, gpus, workers);
     for (int i = 0; i < gpus; i++) fprintf(stderr, " %d", done[i]);
-    fprintf(stderr, " jobs; %.3f s, %.2f pictures/s (device start-up, parsing and output included)\n", secs, secs > 0 ? (double)total_pictures / secs : 0.0);
+    double busy = 0, setup = 0;
+    for (int i = 0; i < g_workers && i < 64; i++) { if (g_busy[i] > busy) busy = g_busy[i]; if (g_setup[i] > setup) setup = g_setup[i]; }
+    fprintf(stderr, " jobs; %.3f s wall (device start-up included), %.2f pictures/s; decoding alone (parsing + kernels + output, the span xevd_app times: "
+            "app/xevd_app.c:492-501,612-624; slowest worker) %.3f s, %.2f pictures/s; context + picture allocation %.3f s\n",
+            secs, secs > 0 ? (double)total_pictures / secs : 0.0, busy, busy > 0 ? (double)total_pictures / busy : 0.0, setup);
     return 0;
 }
