@@ -144,6 +144,12 @@ typedef struct xgpu_cu_batch {
                                      CUs of at least 8x8.  `mv` of such a CU is only stored for a list it does not use          */
     const int16_t  *affine_mv;    /* [n_cu][2][3][2] quarter-pel control-point vectors mcore->affine_mv[list][vertex][x/y]
                                      (top-left, top-right, bottom-left; the third ignored with 2 control points)              */
+    const uint8_t  *dmvr;         /* [n_cu] or NULL: 1 = the CU's merge mode allows decoder-side motion vector refinement (sps->tool_dmvr and mcore->dmvr_enable:
+                                     a skip CU without MMVD or a direct-mode CU, not affine; src_main/xevdm.c:1272-1288).  The backend applies the
+                                     remaining conditions of xevdm_mc (two references at equal POC distances on either side of the picture, at least
+                                     8x8, src_main/xevdm_mc.c:1895-1911) and refines per 16x16 sub-block (processDMVR :1647-1829).  The SCU map the
+                                     deblocking filter reads keeps the UNREFINED vectors (map_unrefined_mv, xevdm.c:2009-2041); the refined ones
+                                     come back through xgpu_batch_dmvr_mvs for the host's temporal motion prediction                              */
     int             htdf_slice_qp;/* 0 = no HTDF.  With sps->tool_htdf: ctx->sh.qp of the picture's slice - the Hadamard-domain filter
                                      (xevdm_htdf, src_main/xevdm_recon.c:153-385) then runs on the luma block of every intra CU and every
                                      inter CU with luma coefficients right after its reconstruction, reading one sample of border from
@@ -205,6 +211,11 @@ int  xgpu_batch_create(xgpu_ctx *ctx, const xgpu_cu_batch *b, xgpu_dbatch **out)
    thread preparing picture k+1 while picture k is being launched): the upload goes through the context's own upload stream, and
    xgpu_batch_recon makes the kernels wait for it.  xgpu_batch_wait_upload blocks until the batch's arrays have left host memory.        */
 int  xgpu_batch_wait_upload(xgpu_ctx *ctx, xgpu_dbatch *db);
+/* DMVR: the vectors the decoder stores for temporal prediction (map_mv / dmvr_mv, src_main/xevdm_mc.c:1783-1797, xevdm.c:1553-1563) after
+   xgpu_batch_recon: for every CU of the batch with the dmvr flag, two references and at least 8x8 samples - in batch order, its 16x16
+   sub-blocks in raster order - mv[list][x/y] in quarter samples: refined where the refinement ran, the CU's own otherwise.  `n` = capacity of
+   `mv` in sub-blocks; returns the number of sub-blocks (also with mv = NULL), or a negative error.  Blocking.                                 */
+int  xgpu_batch_dmvr_mvs(xgpu_ctx *ctx, xgpu_dbatch *db, int16_t *mv, int n);
 /* returns the batch's blocks to the pool.  Does not wait for the device: it may follow xgpu_batch_recon immediately (kernels already
    queued keep their data - later batches of this context are written through the same HIP stream, behind them). */
 void xgpu_batch_destroy(xgpu_ctx *ctx, xgpu_dbatch *db);
@@ -222,7 +233,7 @@ int  xgpu_frame_end(xgpu_ctx *ctx);
 /* ------------------------------------------------------------------ measurement ------------------- */
 /* Kernel families timed with HIP events on the ctx stream (the stream the kernels are launched on).      */
 enum { XGPU_K_ITDQ = 0, XGPU_K_INTER = 1, XGPU_K_DBK_V = 2, XGPU_K_DBK_H = 3, XGPU_K_PAD = 4, XGPU_K_INTRA = 5,
-       XGPU_K_ALF = 6, XGPU_K_AFFINE = 7, XGPU_K_COUNT = 8 };
+       XGPU_K_ALF = 6, XGPU_K_AFFINE = 7, XGPU_K_DMVR = 8, XGPU_K_COUNT = 9 };
 int  xgpu_timing_enable(xgpu_ctx *ctx, int on);
 int  xgpu_timing_reset(xgpu_ctx *ctx);
 /* resolves pending events (synchronises) and returns accumulated milliseconds and launch counts          */

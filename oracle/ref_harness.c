@@ -42,6 +42,7 @@ static void select_tables(XEVD_CTX *ctx, int simd)
         ctx->fn_dbk = &xevd_tbl_dbk_sse;
         ctx->fn_dbk_chroma = &xevd_tbl_dbk_chroma_sse;
         xevdm_fn_itx = &xevdm_tbl_itx_avx;
+        xevdm_func_dmvr_mc_l = xevdm_tbl_dmvr_mc_l_sse; xevdm_func_dmvr_mc_c = xevdm_tbl_dmvr_mc_c_sse; xevdm_func_bl_mc_l = xevdm_tbl_bl_mc_l_sse;      /* xevdm.c:3415-3417 */
     } else {
         xevd_func_mc_l = xevd_tbl_mc_l;
         xevd_func_mc_c = xevd_tbl_mc_c;
@@ -51,6 +52,7 @@ static void select_tables(XEVD_CTX *ctx, int simd)
         ctx->fn_dbk = &xevd_tbl_dbk;
         ctx->fn_dbk_chroma = &xevd_tbl_dbk_chroma;
         xevdm_fn_itx = &xevdm_tbl_itx;
+        xevdm_func_dmvr_mc_l = xevdm_tbl_dmvr_mc_l; xevdm_func_dmvr_mc_c = xevdm_tbl_dmvr_mc_c; xevdm_func_bl_mc_l = xevdm_tbl_bl_mc_l;                  /* xevdm.c:3443-3445 */
     }
     /* ATS: matrices and the function table, as xevd_create does (src_main/xevdm.c:3441, 3581-3582) */
     xevdm_init_multi_tbl();
@@ -140,13 +142,22 @@ static void harness_free(harness *h)
     free(h->map_tidx); free(h->map_ipm); free(h->map_cu_mode); free(h->core); free(h->ctx); free(h);
 }
 
+int refh_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *m,
+                        int16_t *resid_out, int simd, int16_t *dmvr_mv_out);
 int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *m,
                      int16_t *resid_out, int simd)
 {
+    return refh_recon_batch_ex(sp, fr, b, m, resid_out, simd, NULL);
+}
+/* dmvr_mv_out: as orc_recon_batch_ex - what xevdm_mc leaves in mcore->dmvr_mv (refined) / core->mv (not refined) for the DMVR candidates */
+int refh_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *m,
+                        int16_t *resid_out, int simd, int16_t *dmvr_mv_out)
+{
+    size_t dmvr_n = 0;
     harness *hn = harness_new(sp, fr, m, simd);
     XEVD_CTX *ctx = hn->ctx; XEVD_CORE *core = hn->core;
     XEVDM_CORE *mcore = (XEVDM_CORE *)core;
-    const int main_path = sp->tool_admvp || sp->tool_iqt || b->ats != NULL || b->ats_inter != NULL || b->affine != NULL || b->htdf_slice_qp != 0;
+    const int main_path = sp->tool_admvp || sp->tool_iqt || b->ats != NULL || b->ats_inter != NULL || b->affine != NULL || b->htdf_slice_qp != 0 || b->dmvr != NULL;
     int i, c;
 
     if (b->affine) {
@@ -257,11 +268,24 @@ int refh_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
                 xevdm_affine_mc(x, y, ctx->w, ctx->h, w, h, core->refi, mcore->affine_mv, ctx->refp, core->pred, vn, core->eif_tmp_buffer,
                                 sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
             } else if (main_path) {
+                /* xevdm.c:1326-1331: apply_DMVR = (mcore->dmvr_enable == 1) && sps->tool_dmvr - the batch's flag */
                 u8 dmvr_flag = 0;
+                const int cand = b->dmvr && b->dmvr[i];
                 xevdm_mc(x, y, ctx->w, ctx->h, w, h, core->refi, core->mv, ctx->refp, core->pred, fr->cur.poc,
-                         mcore->dmvr_template, mcore->dmvr_ref_pred_interpolated, mcore->dmvr_half_pred_interpolated, 0,
+                         mcore->dmvr_template, mcore->dmvr_ref_pred_interpolated, mcore->dmvr_half_pred_interpolated, cand,
                          mcore->dmvr_padding_buf, &dmvr_flag, mcore->dmvr_mv, sp->tool_admvp,
                          sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
+                if (cand && core->refi[0] >= 0 && core->refi[1] >= 0 && w >= 8 && h >= 8) {
+                    /* dmvr_mv is indexed by SCU inside the CU (:1783-1797): one entry per 16x16 sub-block, raster order */
+                    const int dx = w < 16 ? w : 16, dy = h < 16 ? h : 16;
+                    int sx, sy;
+                    for (sy = 0; sy < h; sy += dy) for (sx = 0; sx < w; sx += dx, dmvr_n++) {
+                        const int idx = (sx >> 2) + (sy >> 2) * (w >> 2);
+                        if (!dmvr_mv_out) continue;
+                        if (dmvr_flag) memcpy(dmvr_mv_out + dmvr_n * 4, mcore->dmvr_mv[idx], 4 * sizeof(s16));
+                        else memcpy(dmvr_mv_out + dmvr_n * 4, core->mv, 4 * sizeof(s16));
+                    }
+                }
             } else {
                 xevd_mc(x, y, ctx->w, ctx->h, w, h, core->refi, core->mv, ctx->refp, core->pred, fr->cur.poc,
                         sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);

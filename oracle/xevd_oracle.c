@@ -479,6 +479,160 @@ static void set_dec_info(const xgpu_seq_params *sp, const xgpu_cu_batch *b, int 
 }
 
 /* ------------------------------------------------------------------------------------------------
+ * DMVR (Main, sps->tool_dmvr): decoder-side refinement of the two vectors of a merge-mode bi-predicted CU whose references lie at equal
+ * distances on either side of the picture (xevdm_mc, src_main/xevdm_mc.c:1860-2038; processDMVR :1647-1829).  Per 16x16 sub-block: bilinear
+ * pre-interpolation of both lists two samples wider than the block, up to two rounds of a 5-point SAD search with mirrored offsets
+ * (xevd_DMVR_refine :1293-1339), a parametric sub-sample step from the last round's cross of costs (xevd_SubPelErrorSrfc :1373-1427),
+ * then the real 8 / 4-tap interpolation at the refined sixteenth-sample vector out of a window fetched at the STARTING vector and
+ * replicate-padded by 2 / 1 samples (prefetch_for_mc :1481-1544, final_paddedMC_forDMVR :1548-1644).
+ * ---------------------------------------------------------------------------------------------- */
+static int dmvr_clip_one(int x, int y, int pic_w, int pic_h, int w, int h, const int16_t mv[2], int16_t mv_t[2])      /* :939-980 */
+{
+    const int min_c = -(MAX_CU << 2), max_x = (pic_w - 1 + MAX_CU) << 2, max_y = (pic_h - 1 + MAX_CU) << 2;
+    int clip = 0;
+    x <<= 2; y <<= 2; w <<= 2; h <<= 2;
+    mv_t[0] = mv[0]; mv_t[1] = mv[1];
+    if (x + mv[0] < min_c) { clip = 1; mv_t[0] = (int16_t)(min_c - x); }
+    if (y + mv[1] < min_c) { clip = 1; mv_t[1] = (int16_t)(min_c - y); }
+    if (x + mv[0] + w - 4 > max_x) { clip = 1; mv_t[0] = (int16_t)(max_x - x - w + 4); }
+    if (y + mv[1] + h - 4 > max_y) { clip = 1; mv_t[1] = (int16_t)(max_y - y - h + 4); }
+    return clip;
+}
+static int dmvr_cost(int w, int h, const int16_t *a, const int16_t *b, int s)      /* xevd_DMVR_cost :1270-1291 */
+{
+    int sad = 0, i, j;
+    for (i = 0; i < h; i++) for (j = 0; j < w; j++) sad += abs(a[i * s + j] - b[i * s + j]);
+    return sad;
+}
+static int dmvr_div_q7(int64_t n, int64_t d)      /* div_for_maxq7 :1341-1372: three bits of n / d */
+{
+    int sign = 0, q = 0;
+    if (n < 0) { sign = 1; n = -n; }
+    d <<= 3;
+    if (n >= d) { n -= d; q++; }
+    q <<= 1; d >>= 1;
+    if (n >= d) { n -= d; q++; }
+    q <<= 1;
+    if (n >= (d >> 1)) q++;
+    return sign ? -q : q;
+}
+/* refined[k][list][x/y]: the vectors of sub-block k (raster order inside the CU) in QUARTER samples, what the decoder stores for temporal
+   prediction (dmvr_mv, :1783-1797).  pred0 / pred1: the two predictions, not yet averaged. */
+static void dmvr_process(const xgpu_seq_params *sp, const orc_frame *fr, int x, int y, int w, int h, const int8_t refi[2], const int16_t mv[2][2],
+                         int16_t *pred0[3], int16_t *pred1[3], int16_t (*refined)[2][2])
+{
+    enum { IT = 2, BOTTOM = 0, TOP, RIGHT, LEFT, DIAG, CENTER = 8 };
+    const int stride = w + 2 * IT, dx = w < 16 ? w : 16, dy = h < 16 ? h : 16, bd = sp->bit_depth_luma;
+    int16_t start[2][2], *bl[2], **dst[2] = { pred0, pred1 };
+    int l, sx, sy, num = 0;
+    mv_clip(x, y, sp->width, sp->height, w, h, refi, mv, start);
+    for (l = 0; l < 2; l++) {
+        /* xevdm_bl_mc_l (:358-486): (w + 4) x (h + 4) samples from two samples up-left of the starting position, 2-tap { 64 - 4p, 4p } in the
+           regimes of the long filters */
+        const orc_pic *rp = &fr->refp[refi[l]][l];
+        const int gx = ((x << 2) + start[l][0] - (IT << 2)) << 2, gy = ((y << 2) + start[l][1] - (IT << 2)) << 2;
+        const int16_t tx[2] = { (int16_t)(64 - 4 * (gx & 15)), (int16_t)(4 * (gx & 15)) }, ty[2] = { (int16_t)(64 - 4 * (gy & 15)), (int16_t)(4 * (gy & 15)) };
+        bl[l] = (int16_t *)malloc(sizeof(int16_t) * (size_t)stride * (h + 2 * IT));
+        fir_block(rp->y, gx, gy, rp->s_l, stride, bl[l], w + 2 * IT, h + 2 * IT, bd, (gx & 15) != 0, (gy & 15) != 0, 2, 4, tx, ty);
+    }
+    for (sy = 0; sy < h; sy += dy) for (sx = 0; sx < w; sx += dx, num++) {
+        const int16_t *c0 = bl[0] + (IT + sy) * stride + IT + sx, *c1 = bl[1] + (IT + sy) * stride + IT + sx;
+        int tot[2] = { 0, 0 }, not_zero = 1, min_cost = 0, cost[9], i, k;
+        int32_t ref16[2][2];
+        for (k = 0; k < 9; k++) cost[k] = 0x7FFFFFFF;
+        for (i = 0; i < IT; i++) {
+            const int16_t *a0 = c0 + tot[0] + tot[1] * stride, *a1 = c1 - (tot[0] + tot[1] * stride);
+            int ox[5] = { 0, 0, 1, -1, 0 }, oy[5] = { 1, -1, 0, 0, 0 }, d[2] = { 0, 0 }, idx;
+            for (k = 0; k < 9; k++) cost[k] = 0x7FFFFFFF;
+            if (i == 0) min_cost = dmvr_cost(dx, dy, a0, a1, stride);
+            if ((i > 0 && min_cost == 0) || (i == 0 && min_cost < dx * dy)) { not_zero = 0; break; }
+            cost[CENTER] = min_cost;
+            for (idx = BOTTOM; idx <= DIAG; idx++) {      /* xevd_DMVR_refine: below, above, right, left, then the diagonal between the better two */
+                const int c = dmvr_cost(dx, dy, a0 + ox[idx] + oy[idx] * stride, a1 - ox[idx] - oy[idx] * stride, stride);
+                cost[idx] = c;
+                if (idx == LEFT) { ox[DIAG] = cost[RIGHT] <= cost[LEFT] ? 1 : -1; oy[DIAG] = cost[BOTTOM] <= cost[TOP] ? 1 : -1; }
+                if (c < min_cost) { min_cost = c; d[0] = ox[idx]; d[1] = oy[idx]; }
+            }
+            if (d[0] == 0 && d[1] == 0) break;
+            tot[0] += d[0]; tot[1] += d[1];
+        }
+        tot[0] <<= 4; tot[1] <<= 4;
+        if (not_zero && min_cost == cost[CENTER]) {      /* the centre of the last round won: parametric error surface through its cross */
+            const int sb[5] = { cost[CENTER], cost[LEFT], cost[TOP], cost[RIGHT], cost[BOTTOM] };
+            int a;
+            for (a = 0; a < 2; a++) {
+                const int64_t nu = (int64_t)((sb[1 + a] - sb[3 + a]) << 4), de = (int64_t)(sb[1 + a] + sb[3 + a] - (sb[0] << 1));
+                if (de != 0) tot[a] += (sb[1 + a] != sb[0] && sb[3 + a] != sb[0]) ? dmvr_div_q7(nu, de) : (sb[1 + a] == sb[0] ? -8 : 8);
+            }
+        }
+        for (l = 0; l < 2; l++) {
+            ref16[l][0] = (start[l][0] << 2) + (l ? -tot[0] : tot[0]);
+            ref16[l][1] = (start[l][1] << 2) + (l ? -tot[1] : tot[1]);
+            refined[num][l][0] = (int16_t)(ref16[l][0] >> 2); refined[num][l][1] = (int16_t)(ref16[l][1] >> 2);
+        }
+        /* final prediction of the sub-block: the long filters at the refined vector, reading the window of the starting vector */
+        for (l = 0; l < 2; l++) {
+            const orc_pic *rp = &fr->refp[refi[l]][l];
+            const int px = x + sx, py = y + sy;
+            const int16_t tq[2] = { (int16_t)(ref16[l][0] >> 2), (int16_t)(ref16[l][1] >> 2) };
+            int16_t mvc[2];
+            const int clip = dmvr_clip_one(px, py, sp->width, sp->height, dx, dy, tq, mvc);
+            const int gx = (px << 4) + (clip ? mvc[0] << 2 : ref16[l][0]), gy = (py << 4) + (clip ? mvc[1] << 2 : ref16[l][1]);
+            const int wx = ((((px << 2) + start[l][0]) << 2) >> 4) - 3, wy = ((((py << 2) + start[l][1]) << 2) >> 4) - 3;      /* window origin (luma) */
+            const int dlx = (clip ? mvc[0] >> 2 : ref16[l][0] >> 4) - (start[l][0] >> 2), dly = (clip ? mvc[1] >> 2 : ref16[l][1] >> 4) - (start[l][1] >> 2);
+            const int dcx = (clip ? mvc[0] >> 3 : ref16[l][0] >> 5) - (start[l][0] >> 3), dcy = (clip ? mvc[1] >> 3 : ref16[l][1] >> 5) - (start[l][1] >> 3);
+            int16_t buf[(16 + 7 + 4) * (16 + 7 + 4)], tx[8], ty[8];
+            int r, c, comp;
+            /* luma: (dx + 7) x (dy + 7) window, 2 samples of replicate padding = clamped indexing */
+            for (r = 0; r < dy + 11; r++) for (c = 0; c < dx + 11; c++) {
+                const int rr = r - 2 < 0 ? 0 : (r - 2 > dy + 6 ? dy + 6 : r - 2), cc = c - 2 < 0 ? 0 : (c - 2 > dx + 6 ? dx + 6 : c - 2);
+                buf[r * (dx + 11) + c] = rp->y[(wy + rr) * rp->s_l + wx + cc];
+            }
+            luma_taps(gx & 15, sp->tool_admvp, tx); luma_taps(gy & 15, sp->tool_admvp, ty);
+            fir_block(buf + (2 + 3 + dly) * (dx + 11) + 2 + 3 + dlx, gx & 15, gy & 15, dx + 11, w, dst[l][0] + sy * w + sx, dx, dy, bd,
+                      (gx & 15) != 0, (gy & 15) != 0, 8, 4, tx, ty);
+            /* chroma: (dx/2 + 3) x (dy/2 + 3) window at the starting vector's chroma position, 1 sample of padding */
+            for (comp = 1; comp < 3; comp++) {
+                const int16_t *plane = comp == 1 ? rp->u : rp->v;
+                const int cx0 = ((((px << 2) + start[l][0]) << 2) >> 5) - 1, cy0 = ((((py << 2) + start[l][1]) << 2) >> 5) - 1, cw = dx >> 1, ch = dy >> 1;
+                int16_t tcx[4], tcy[4];
+                for (r = 0; r < ch + 5; r++) for (c = 0; c < cw + 5; c++) {
+                    const int rr = r - 1 < 0 ? 0 : (r - 1 > ch + 2 ? ch + 2 : r - 1), cc = c - 1 < 0 ? 0 : (c - 1 > cw + 2 ? cw + 2 : c - 1);
+                    buf[r * (cw + 5) + c] = plane[(cy0 + rr) * rp->s_c + cx0 + cc];
+                }
+                chroma_taps(gx & 31, sp->tool_admvp, tcx); chroma_taps(gy & 31, sp->tool_admvp, tcy);
+                fir_block(buf + (1 + 1 + dcy) * (cw + 5) + 1 + 1 + dcx, gx & 31, gy & 31, cw + 5, w >> 1, dst[l][comp] + (sy >> 1) * (w >> 1) + (sx >> 1), cw, ch,
+                          sp->bit_depth_chroma, (gx & 31) != 0, (gy & 31) != 0, 4, 5, tcx, tcy);
+            }
+        }
+    }
+    free(bl[0]); free(bl[1]);
+}
+
+/* xevdm_mc with apply_DMVR (:1860-2038): the conditions that are left when the CU's merge mode allows the refinement; 1 = refined (both predictions
+   made and averaged into pred0), 0 = the caller predicts the CU the ordinary way */
+int orc_dmvr_cu(const xgpu_seq_params *sp, const orc_frame *fr, int x, int y, int w, int h, const int8_t refi[2], const int16_t mv[2][2],
+                int16_t *pred0[3], int16_t *pred1[3], int16_t (*refined)[2][2])
+{
+    int16_t mv_t[2][2];
+    int i;
+    if (refi[0] < 0 || refi[1] < 0 || w < 8 || h < 8) return 0;
+    {
+        const int poc_c = fr->cur.poc, poc0 = fr->refp[refi[0]][0].poc, poc1 = fr->refp[refi[1]][1].poc;
+        if (!((poc_c - poc0) * (poc_c - poc1) < 0 && abs(poc_c - poc0) == abs(poc_c - poc1))) return 0;
+        mv_clip(x, y, sp->width, sp->height, w, h, refi, mv, mv_t);
+        if (poc0 == poc1 && mv_t[0][0] == mv_t[1][0] && mv_t[0][1] == mv_t[1][1]) return 0;
+    }
+    dmvr_process(sp, fr, x, y, w, h, refi, mv, pred0, pred1, refined);
+    for (i = 0; i < w * h; i++) pred0[0][i] = (int16_t)((pred0[0][i] + pred1[0][i] + 1) >> 1);
+    for (i = 0; i < (w >> 1) * (h >> 1); i++) {
+        pred0[1][i] = (int16_t)((pred0[1][i] + pred1[1][i] + 1) >> 1);
+        pred0[2][i] = (int16_t)((pred0[2][i] + pred1[2][i] + 1) >> 1);
+    }
+    return 1;
+}
+
+/* ------------------------------------------------------------------------------------------------
  * Intra prediction, Baseline modes (also what the Main profile runs with sps->tool_eipd = 0, src_main/xevdm.c:1368-1381).
  * ---------------------------------------------------------------------------------------------- */
 /* xevd_get_nbr_b (src_base/xevd_ipred.c:33-94): neighbour samples of one component.  `up` and `left` point at index 0 and
@@ -959,8 +1113,17 @@ static void orc_htdf(int16_t *rec, int s, int w, int h, int qp, int intra, const
 
 int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *maps, int16_t *resid_out)
 {
+    return orc_recon_batch_ex(sp, fr, b, maps, resid_out, NULL);
+}
+
+/* dmvr_mv_out (or NULL): for every CU of the batch that carries the DMVR flag, has two references and is at least 8x8 - in batch order, its 16x16
+   sub-blocks in raster order - the vectors [list][x/y] in quarter samples the decoder keeps for temporal prediction: refined where the
+   refinement ran, the CU's own where its conditions failed (xgpu_batch_dmvr_mvs returns the same array) */
+int orc_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_cu_batch *b, orc_maps *maps, int16_t *resid_out, int16_t *dmvr_mv_out)
+{
     int16_t *pred[2][3], *res;
     int i, c, l;
+    size_t dmvr_n = 0;
     for (l = 0; l < 2; l++) for (c = 0; c < 3; c++) pred[l][c] = (int16_t *)malloc(sizeof(int16_t) * MAX_CU * MAX_CU);
     res = (int16_t *)malloc(sizeof(int16_t) * MAX_CU * MAX_CU);
 
@@ -980,8 +1143,19 @@ int orc_recon_batch(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_c
             }
         } else if (inter && b->affine && b->affine[i])
             orc_affine_mc_cu(sp, fr, x, y, lw, lh, &b->refi[i * 2], (const int16_t (*)[3][2])&b->affine_mv[i * 12], b->affine[i], pred[0], pred[1]);
-        else if (inter)
-            orc_mc_cu(sp, fr, x, y, w, h, &b->refi[i * 2], (const int16_t (*)[2])&b->mv[i * 4], pred[0], pred[1]);
+        else if (inter) {
+            int done = 0;
+            if (b->dmvr && b->dmvr[i] && b->refi[i * 2] >= 0 && b->refi[i * 2 + 1] >= 0 && w >= 8 && h >= 8) {
+                int16_t refined[64][2][2];
+                const int nsub = (w > 16 ? w / 16 : 1) * (h > 16 ? h / 16 : 1);
+                int k;
+                done = orc_dmvr_cu(sp, fr, x, y, w, h, &b->refi[i * 2], (const int16_t (*)[2])&b->mv[i * 4], pred[0], pred[1], refined);
+                for (k = 0; k < nsub && dmvr_mv_out; k++)
+                    memcpy(dmvr_mv_out + (dmvr_n + (size_t)k) * 4, done ? &refined[k][0][0] : &b->mv[i * 4], 4 * sizeof(int16_t));
+                dmvr_n += (size_t)nsub;
+            }
+            if (!done) orc_mc_cu(sp, fr, x, y, w, h, &b->refi[i * 2], (const int16_t (*)[2])&b->mv[i * 4], pred[0], pred[1]);
+        }
         else if (maps) {      /* xevd_recon_unit's intra branch, xevd.c:731-741 (availability needs the SCU map) */
             int16_t nb_up[2 * MAX_CU + 8], nb_le[2 * MAX_CU + 8];
             for (c = 0; c < 3; c++) {

@@ -61,6 +61,11 @@ CASES = [
     ("main_htdf_i_8b_constrained", 136, 136, 8, 1, 1, (1, 0), 0.0, {"inter_frac": 0.3, "htdf_qp": 24, "constrained_intra": 1, "btt_frac": 0.5, "split_prob": 0.4, "eipd": 1}),
     ("main_htdf_p_ctu128_10b", 264, 200, 10, 1, 1, (2, 0), 0.0, {"addb": 1, "alf": 1, "inter_frac": 0.8, "htdf_qp": 45, "log2_ctu": 7, "split_prob": 0.4, "btt_frac": 0.4,
                                                                 "ats_inter_frac": 0.4, "affine_frac": 0.3, "ibc_frac": 0.15, "coded_frac": 0.8}),
+    # DMVR (sps->tool_dmvr): merge-mode bi-predicted CUs refined per 16x16 sub-block when their references are POC-symmetric (lists (0,0) and (1,1) of
+    # POCS are, the mixed pairs are not: those CUs take the ordinary path with the flag set)
+    ("main_dmvr_b_10b", 200, 136, 10, 1, 1, (2, 2), 0.8, {"addb": 1, "inter_frac": 1.0, "dmvr_frac": 0.8, "split_prob": 0.35}),
+    ("main_dmvr_b_8b_ctu128_mixed", 264, 200, 8, 1, 1, (2, 2), 0.7, {"addb": 1, "alf": 1, "inter_frac": 0.85, "dmvr_frac": 0.7, "log2_ctu": 7, "split_prob": 0.3, "btt_frac": 0.4,
+                                                                     "ats_inter_frac": 0.3, "affine_frac": 0.2}),
     # CTU 128 without ADDB: the Main library's copy of the Baseline filter, CUs above 64 filtered as two halves
     ("main_ctu128_noaddb_8b", 264, 264, 8, 1, 0, (1, 1), 0.3, {"log2_ctu": 7, "btt_frac": 0.6, "ats_inter_frac": 0.5, "split_prob": 0.3}),
 ]
@@ -97,6 +102,8 @@ def build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, tools=None, seed=0, 
         synth.add_ibc(np.random.default_rng(8000 + seed), batch, w, h, log2_ctu, float(tools["ibc_frac"]))
     if tools.get("affine_frac"):
         synth.add_affine(np.random.default_rng(7000 + seed), batch, float(tools["affine_frac"]))
+    if tools.get("dmvr_frac"):
+        synth.add_dmvr(np.random.default_rng(9000 + seed), batch, float(tools["dmvr_frac"]))
     if n_refs[0] and n_refs[1]:      # force some identical-motion bi CUs
         sel = (batch["refi"][:, 0] >= 0) & (batch["refi"][:, 1] >= 0)
         idx = np.nonzero(sel)[0][::3]
@@ -162,7 +169,25 @@ def run_cpu(engine, case, deblock=True, simd=0, pad=True):
     return cur, pre, maps, resid
 
 
-def run_gpu(case, deblock=True, pad=True, alf=True, resid=False, repeat=1):
+def dmvr_mvs(engine, case):
+    """the vectors kept for temporal prediction of the batch's DMVR candidates ([n_sub_blocks][list][x/y], quarter samples) after the
+    reconstruction of `case` by the oracle or the reference (xevdm_mc's dmvr_mv / core->mv)"""
+    sp = abi.make_seq_params(case["w"], case["h"], case["bd"], log2_ctu=case.get("log2_ctu", 6), iqt=case["iqt"], admvp=case["admvp"],
+                             addb=case.get("addb", 0), alf=case.get("alf", 0), eipd=case.get("eipd", 0))
+    cb, keep = abi.make_cu_batch(case["batch"])
+    cur = _start_picture(case)
+    maps = ol.Maps(case["w"], case["h"])
+    fr = ol.make_frame(cur, case["refs"], *QP_OFFSETS)
+    m = maps.orc()
+    out = np.full((1 << 16, 2, 2), -32768, np.int16)
+    if engine == "oracle":
+        ol.oracle().orc_recon_batch_ex(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), None, _p(out))
+    else:
+        ol.harness().refh_recon_batch_ex(C.byref(sp), C.byref(fr), C.byref(cb), C.byref(m), None, 0, _p(out))
+    return out[:int((out[:, 0, 0] != -32768).sum())].copy()
+
+
+def run_gpu(case, deblock=True, pad=True, alf=True, resid=False, repeat=1, dmvr=False):
     """The HIP backend through the C ABI. -> list of padded planes (reference buffer geometry)"""
     from xevd_amd.decoder import XgpuDecoder
     with XgpuDecoder(case["w"], case["h"], case["bd"], log2_ctu=case.get("log2_ctu", 6), iqt=case["iqt"], admvp=case["admvp"],
@@ -184,6 +209,8 @@ def run_gpu(case, deblock=True, pad=True, alf=True, resid=False, repeat=1):
                            qp_u_offset=QP_OFFSETS[0], qp_v_offset=QP_OFFSETS[1],
                            alpha_off=case.get("alpha_off", 0), beta_off=case.get("beta_off", 0), alf=case.get("alf_params") if alf else None)
         dec.sync()
+        if dmvr:
+            return dec.pic_download_padded(cur), dec.batch_dmvr_mvs(hb)
         if resid:
             return dec.pic_download_padded(cur), dec.batch_resid(hb, case["batch"]["n_coef"])
         return dec.pic_download_padded(cur)

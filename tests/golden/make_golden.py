@@ -136,6 +136,8 @@ def golden_pictures(only=None):
             d[f"out_{c}"] = final.bufs[c]
             d[f"pre_{c}"] = pre.active(c)
         d["resid"] = resid
+        if cs["batch"].get("dmvr") is not None:      # what xevdm_mc leaves for temporal prediction: refined / unrefined vectors of the DMVR candidates
+            d["dmvr_mv"] = cases.dmvr_mvs("ref", cs)
         d["map_scu"] = maps.map_scu & 0x7FFFFFFF
         np.savez_compressed(os.path.join(HERE, f"pic_{case[0]}.npz"), **d)
         print(f"pic_{case[0]}.npz")

@@ -15,7 +15,7 @@ PICTURE_CASES = ["base_p_8b", "base_b_8b", "base_p_10b", "main_b_10b", "main_adm
                  "main_eipd_i_10b", "main_eipd_i_btt_8b", "main_eipd_b_ctu128_constrained_10b",
                  "main_affine_b_10b", "main_affine_p_8b_atsinter", "main_affine_b_ctu128_10b",
                  "main_ibc_i_10b", "main_ibc_b_8b_noaddb", "main_ibc_p_ctu128_eipd_10b",
-                 "main_htdf_b_10b", "main_htdf_i_8b_constrained", "main_htdf_p_ctu128_10b"]
+                 "main_htdf_b_10b", "main_htdf_i_8b_constrained", "main_htdf_p_ctu128_10b", "main_dmvr_b_10b", "main_dmvr_b_8b_ctu128_mixed"]
 
 
 def load_picture_case(name):
@@ -50,5 +50,5 @@ def load_picture_case(name):
             "addb": tools[0], "alf": tools[1], "alpha_off": tools[2], "beta_off": tools[3], "no_deblock": tools[4], "log2_ctu": tools[5],
             "eipd": tools[6], "alf_params": alf_params}
     expect = {"out": [d[f"out_{c}"] for c in range(3)], "pre": [d[f"pre_{c}"] for c in range(3)], "resid": d["resid"],
-              "map_scu": d["map_scu"]}
+              "map_scu": d["map_scu"], "dmvr_mv": d["dmvr_mv"] if "dmvr_mv" in d.files else None}
     return case, expect

@@ -52,6 +52,7 @@ def oracle():
         lib.orc_dbk_luma.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         lib.orc_dbk_chroma.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         lib.orc_recon_batch.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_void_p]
+        lib.orc_recon_batch_ex.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_void_p, C.c_void_p]
         lib.orc_deblock_baseline.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps)]
         lib.orc_deblock_addb.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_int, C.c_int]
         lib.orc_alf.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcPic), C.POINTER(abi.AlfParams)]
@@ -149,6 +150,7 @@ def harness():
         ref()
         lib = C.CDLL(HARNESS_SO)
         lib.refh_recon_batch.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_void_p, C.c_int]
+        lib.refh_recon_batch_ex.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_void_p, C.c_int, C.c_void_p]
         lib.refh_deblock_baseline.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_int]
         lib.refh_deblock_addb.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcFrame), C.POINTER(abi.CuBatch), C.POINTER(OrcMaps), C.c_int, C.c_int]
         lib.refh_alf.argtypes = [C.POINTER(abi.SeqParams), C.POINTER(OrcPic), C.POINTER(abi.AlfParams)]

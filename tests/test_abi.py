@@ -46,7 +46,7 @@ def test_struct_sizes_match_header():
     # computed by hand from include/xevd_hip.h (LP64)
     assert C.sizeof(abi.SeqParams) == 12 * 4 + 2 * 8 + 8          # ... + tool_eipd + tail padding
     assert C.sizeof(abi.FrameParams) == (4 + 2 * 17 * 2 + 4 + 2) * 4
-    assert C.sizeof(abi.CuBatch) == 8 + 15 * 8 + 8 + 8 + 8 + 8 + 16 + 8
+    assert C.sizeof(abi.CuBatch) == 8 + 15 * 8 + 8 + 8 + 8 + 8 + 16 + 8 + 8          # ... + dmvr
 
 
 def test_argument_errors_without_gpu():

@@ -70,6 +70,9 @@ def test_gpu_pictures_golden(name):
     assert np.array_equal(resid[:len(exp["resid"])], exp["resid"]), "residual arena (dequant + inverse transform of every coded TB, intra CUs included)"
     for c in range(3):
         assert np.array_equal(out[c], exp["out"][c]), f"final plane {c}: {np.argwhere(out[c] != exp['out'][c])[:4]}"
+    if exp["dmvr_mv"] is not None:      # the vectors the reference keeps for temporal prediction (refined where DMVR ran)
+        _, mvs = cases.run_gpu(case, dmvr=True)
+        assert np.array_equal(mvs, exp["dmvr_mv"]), f"DMVR vectors: {np.argwhere(mvs != exp['dmvr_mv'])[:4]}"
 
 
 RANDOM = [
@@ -95,6 +98,9 @@ RANDOM = [
     ("htdf_all_tools_ctu128", 264, 264, 8, 1, 1, (1, 1), 0.4, {"inter_frac": 0.6, "tools": {"addb": 1, "htdf_qp": 40, "log2_ctu": 7, "eipd": 1, "affine_frac": 0.4, "ats_frac": 0.4, "ibc_frac": 0.2,
                                                                                         "ats_inter_frac": 0.4, "btt_frac": 0.5, "split_prob": 0.4, "coded_frac": 0.8, "constrained_intra": 1}}),
     ("htdf_i_qp20", 136, 72, 8, 1, 0, (1, 0), 0.0, {"inter_frac": 0.0, "tools": {"htdf_qp": 20, "split_prob": 0.5}}),
+    ("dmvr_all_tools", 328, 200, 10, 1, 1, (2, 2), 0.8, {"inter_frac": 0.9, "oob_frac": 0.2, "tools": {"addb": 1, "alf": 1, "dmvr_frac": 0.8, "btt_frac": 0.5, "ats_inter_frac": 0.5, "coded_frac": 0.8,
+                                                                                                   "split_prob": 0.35, "affine_frac": 0.2}}),
+    ("dmvr_big_cus_8b", 264, 264, 8, 1, 0, (2, 2), 0.9, {"inter_frac": 1.0, "tools": {"dmvr_frac": 1.0, "log2_ctu": 7, "split_prob": 0.15}}),
     ("htdf_off_by_qp", 136, 72, 8, 1, 0, (1, 0), 0.0, {"inter_frac": 0.5, "tools": {"htdf_qp": 17}}),
 ]
 

@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(HERE, "libxevd_hip.so")
 XGPU_MAX_REFS = 17
 PAD_L, PAD_C = 144, 72
 MODE_INTRA, MODE_INTER, MODE_SKIP, MODE_DIR = 0, 1, 2, 3
-K_NAMES = ["itdq", "inter", "dbk_v", "dbk_h", "pad", "intra", "alf", "affine"]
-K_COUNT = 8
+K_NAMES = ["itdq", "inter", "dbk_v", "dbk_h", "pad", "intra", "alf", "affine", "dmvr"]
+K_COUNT = 9
 
 
 class SeqParams(C.Structure):
@@ -53,7 +53,7 @@ class CuBatch(C.Structure):
         ("qp", C.POINTER(C.c_uint8)), ("cbf", C.POINTER(C.c_uint8)), ("cbf_sub", C.POINTER(C.c_uint16)), ("ipm", C.POINTER(C.c_uint8)), ("ats", C.POINTER(C.c_uint8)), ("ats_inter", C.POINTER(C.c_uint8)),
         ("coef_off", C.POINTER(C.c_uint32)), ("coef", C.POINTER(C.c_int16)), ("n_coef", C.c_size_t),
         ("n_ctu", C.c_int), ("ctu_cu_start", C.POINTER(C.c_uint32)), ("constrained_intra_pred", C.c_int),
-        ("affine", C.POINTER(C.c_uint8)), ("affine_mv", C.POINTER(C.c_int16)), ("htdf_slice_qp", C.c_int),
+        ("affine", C.POINTER(C.c_uint8)), ("affine_mv", C.POINTER(C.c_int16)), ("dmvr", C.POINTER(C.c_uint8)), ("htdf_slice_qp", C.c_int),
     ]
 
 
@@ -96,6 +96,7 @@ def make_cu_batch(b):
         "ats_inter": None if b.get("ats_inter") is None else np.ascontiguousarray(b["ats_inter"], np.uint8),
         "affine": None if b.get("affine") is None else np.ascontiguousarray(b["affine"], np.uint8),
         "affine_mv": None if b.get("affine") is None else np.ascontiguousarray(b["affine_mv"], np.int16),
+        "dmvr": None if b.get("dmvr") is None else np.ascontiguousarray(b["dmvr"], np.uint8),
         "coef_off": np.ascontiguousarray(b["coef_off"], np.uint32),
         "coef": np.ascontiguousarray(b["coef"], np.int16),
         "ctu_cu_start": np.ascontiguousarray(b["ctu_cu_start"], np.uint32),
@@ -115,6 +116,8 @@ def make_cu_batch(b):
         cb.ats_inter = _ptr(keep["ats_inter"], C.c_uint8)
     if keep["affine"] is not None:
         cb.affine, cb.affine_mv = _ptr(keep["affine"], C.c_uint8), _ptr(keep["affine_mv"], C.c_int16)
+    if keep["dmvr"] is not None:
+        cb.dmvr = _ptr(keep["dmvr"], C.c_uint8)
     cb.coef_off, cb.coef = _ptr(keep["coef_off"], C.c_uint32), _ptr(keep["coef"], C.c_int16)
     cb.n_coef = len(keep["coef"])
     cb.n_ctu = len(keep["ctu_cu_start"]) - 1
@@ -156,6 +159,7 @@ _EXPORTS = {
     "xgpu_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "xgpu_host_free": (None, [C.c_void_p, C.c_void_p]),
     "xgpu_batch_wait_upload": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "xgpu_batch_dmvr_mvs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     "xgpu_pic_download_padded": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "xgpu_pic_upload_padded": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "xgpu_frame_begin": (C.c_int, [C.c_void_p, C.POINTER(FrameParams)]),

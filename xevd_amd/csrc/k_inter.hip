@@ -315,6 +315,8 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     bool use[2] = { refi0 >= 0, refi1 >= 0 };
     if (use[0] && use[1] && s_ref[refi0 * 2][1].z == s_ref[refi1 * 2 + 1][1].z && mvt[0][0] == mvt[1][0] && mvt[0][1] == mvt[1][1])
         use[1] = false;                                               // identical motion, xevd_mc.c:512-519
+    // a DMVR candidate whose references are POC-symmetric is refined and predicted by k_dmvr (its map record, with the unrefined vectors, is written)
+    if ((r1.w >> 24) && dmvr_applies(a.cur_poc, (int)s_ref[refi0 * 2][1].z, (int)s_ref[refi1 * 2 + 1][1].z)) return;
 
     // residual of this SCU (zero where nothing is coded); the tile path issues the loads before the filtering
     uint32_t rl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ru[2] = {0, 0}, rv[2] = {0, 0};

@@ -84,6 +84,14 @@ static __constant__ uint32_t k_chroma_taps[2][33][2] = {
       C4(0,1,0,0) },
 };
 
+// The conditions of xevdm_mc's apply_DMVR that depend on the picture (src_main/xevdm_mc.c:1895-1911): the two references at equal POC distances
+// on either side of the current picture (which also rules out the identical-motion case).  The static ones - merge mode, two references, at
+// least 8x8 - are CuRec.dmvr.  k_inter (skips the CU's samples) and k_dmvr (predicts them) both call this.
+__device__ __forceinline__ bool dmvr_applies(int poc_c, int poc0, int poc1)
+{
+    return (poc_c - poc0) * (poc_c - poc1) < 0 && abs(poc_c - poc0) == abs(poc_c - poc1);
+}
+
 // Per-lane description of one separable interpolation in the reference's four rounding regimes
 // (xevd_mc.c:169-288 / :290-408, shifts xevd_mc.h:34-38):
 //   stage 1: t = (sum_h) >> sh1, clipped to [0,max] only in the H-only regime, then truncated to s16

@@ -660,7 +660,12 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         if (idx == 1 || idx == 3) bw -= idx == 3 ? 2 : 1;
         if (idx == 2 || idx == 4) bh -= idx == 4 ? 2 : 1;
     };
-    int n_aff = 0, n_aff_eif = 0, n_aff_sub = 0;
+    int n_aff = 0, n_aff_eif = 0, n_aff_sub = 0, n_dmvr = 0;
+    // DMVR candidates the backend can refine: flagged, plain inter, two references, at least 8x8 (the POC test happens on the device)
+    auto dmvr_cand = [&](int i) -> bool {
+        return b->dmvr && b->dmvr[i] && b->pred_mode[i] != XGPU_MODE_INTRA && b->pred_mode[i] != XGPU_MODE_IBC && !(b->affine && b->affine[i]) &&
+               b->refi[i * 2] >= 0 && b->refi[i * 2 + 1] >= 0 && b->log2w[i] >= 3 && b->log2h[i] >= 3;
+    };
     // the branch xevdm_affine_mc takes for CU i (EIF when a sub-block would be smaller than 8 samples): the kernels' own code, affine_model.h
     auto affine_is_eif = [&](const xgpu_cu_batch *bb, int i) -> bool {
         const bool use[2] = { bb->refi[i * 2] >= 0, bb->refi[i * 2 + 1] >= 0 };
@@ -697,6 +702,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
             if (affine_is_eif(b, i)) n_aff_eif += ((1 << lw) + 15) / 16 * (((1 << lh) + 15) / 16);
             else                     n_aff_sub += ((1 << lw) + 31) / 32 * (((1 << lh) + 31) / 32);
         }
+        if (dmvr_cand(i)) n_dmvr += (lw > 4 ? 1 << (lw - 4) : 1) * (lh > 4 ? 1 << (lh - 4) : 1);
         size_t need = 0;
         int bw, bh;
         blk_log2(i, bw, bh);
@@ -731,7 +737,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
 
     xgpu_dbatch *db = new xgpu_dbatch();
     memset(db, 0, sizeof(*db));
-    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->has_ibc = plan.has_ibc ? 1 : 0; db->has_htdf = plan.has_htdf ? 1 : 0;
+    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->n_dmvr = n_dmvr; db->has_ibc = plan.has_ibc ? 1 : 0; db->has_htdf = plan.has_htdf ? 1 : 0;
     const size_t sz_cus = sizeof(CuRec) * (size_t)std::max(n, 1), sz_ctu = sizeof(uint32_t) * (size_t)(b->n_ctu + 1);
     const size_t sz_tbs = sizeof(TbRec) * (size_t)std::max(n_tb, 1), sz_wv = sizeof(TbWave) * (size_t)std::max(n_waves, 1);
     const size_t sz_coef = sizeof(int16_t) * std::max(b->n_coef, (size_t)8);
@@ -741,13 +747,15 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     const size_t sz_deps = sizeof(uint32_t) * (size_t)std::max(n_deps, 1);
     const size_t sz_aff = sizeof(AffItem) * (size_t)std::max(n_aff_eif + n_aff_sub, 1), sz_cpmv = sizeof(int16_t) * 12 * (size_t)std::max(n_aff, 1);
     const size_t o_deps = o_intra + align_up((int)sz_intra, 256), o_aff = o_deps + align_up((int)sz_deps, 256);
-    const size_t o_cpmv = o_aff + align_up((int)sz_aff, 256), o_coef = o_cpmv + align_up((int)sz_cpmv, 256);
+    const size_t sz_dmvr = sizeof(DmvrItem) * (size_t)std::max(n_dmvr, 1);
+    const size_t o_cpmv = o_aff + align_up((int)sz_aff, 256), o_dmvr = o_cpmv + align_up((int)sz_cpmv, 256), o_coef = o_dmvr + align_up((int)sz_dmvr, 256);
     db->stage_bytes = o_coef + sz_coef;
     auto fail = [&](int code) { xgpu_batch_destroy(c, db); return code; };
     // device layout: the uploaded arrays at the staging offsets, then the residual arena and the intra done flags
     const size_t sz_done = sizeof(uint32_t) * ((size_t)n_intra + 1);
     const size_t o_resid = align_up((int)(o_coef + sz_coef), 256), o_done = o_resid + align_up((int)sz_coef, 256);
-    const size_t d_need = o_done + align_up((int)sz_done, 256);
+    const size_t o_dmv = o_done + align_up((int)sz_done, 256);
+    const size_t d_need = o_dmv + align_up((int)(sizeof(int16_t) * 4 * (size_t)std::max(n_dmvr, 1)), 256);
     // is the coefficient arena inside a range from xgpu_host_alloc?  Then it is sent from where it lies (no staging copy of the largest array)
     bool coef_pinned = false;
     {
@@ -784,7 +792,8 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
 
     AffItem *aff_items = (AffItem *)(hs + o_aff);
     int16_t *cpmv = (int16_t *)(hs + o_cpmv);
-    int aff_fill = 0, eif_fill = 0, sub_fill = n_aff_eif;
+    int aff_fill = 0, eif_fill = 0, sub_fill = n_aff_eif, dmvr_fill = 0;
+    DmvrItem *dmvr_items = (DmvrItem *)(hs + o_dmvr);
 
     // pass 2: records + TB scatter into class order
     int cls_fill[NCLS];
@@ -814,6 +823,15 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         r.qp[0] = b->qp[i * 3]; r.qp[1] = b->qp[i * 3 + 1]; r.qp[2] = b->qp[i * 3 + 2];
         if (b->ipm) { r.ipm[0] = b->ipm[i * 2]; r.ipm[1] = b->ipm[i * 2 + 1]; }
         r.ats_inter = (uint8_t)ats_inter_of(i);
+        if (dmvr_cand(i)) {
+            r.dmvr = 1;
+            const int dxs = std::min(1 << b->log2w[i], 16), dys = std::min(1 << b->log2h[i], 16);
+            for (int sy = 0; sy < (1 << b->log2h[i]); sy += dys)
+                for (int sx = 0; sx < (1 << b->log2w[i]); sx += dxs) {
+                    DmvrItem &it = dmvr_items[dmvr_fill++];
+                    it.cu = (uint32_t)i; it.sx = (uint8_t)(sx >> 2); it.sy = (uint8_t)(sy >> 2); it.pad = 0;
+                }
+        }
         int bw, bh;
         blk_log2(i, bw, bh);
         uint32_t off = r.coef_off;
@@ -852,6 +870,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     db->d_cus = (CuRec *)(dbase + o_cus); db->d_ctu_start = (uint32_t *)(dbase + o_ctu); db->d_tbs = (TbRec *)(dbase + o_tbs);
     db->d_waves = (TbWave *)(dbase + o_wv); db->d_intra = (IntraRec *)(dbase + o_intra); db->d_intra_deps = (uint32_t *)(dbase + o_deps);
     db->d_aff_items = (AffItem *)(dbase + o_aff); db->d_cpmv = (int16_t *)(dbase + o_cpmv);
+    db->d_dmvr_items = (DmvrItem *)(dbase + o_dmvr); db->d_dmvr_mv = (int16_t *)(dbase + o_dmv);
     db->d_coef = (int16_t *)(dbase + o_coef); db->d_resid = (int16_t *)(dbase + o_resid); db->d_intra_done = (uint32_t *)(dbase + o_done);
     // one copy: the staging block has the device layout (a pinned coefficient arena goes from the caller's buffer).  On the upload stream: the
     // copy overlaps the kernels of the pictures before; xgpu_batch_recon makes the kernel stream wait for `uploaded`
@@ -905,7 +924,7 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
     a.n_regions = a.regions_x * ((c->sp.height + 63) >> 6);
     a.admvp = c->sp.tool_admvp ? 1 : 0;
     a.cus = db->d_cus; a.ctu_cu_start = db->d_ctu_start; a.resid = db->d_resid;
-    a.maps = c->d_maps; a.w_scu = c->w_scu; a.owner = c->d_owner; a.n_cu = db->n_cu;
+    a.maps = c->d_maps; a.w_scu = c->w_scu; a.owner = c->d_owner; a.n_cu = db->n_cu; a.cur_poc = c->fp.poc;
     for (int l = 0; l < 2; l++)
         for (int i = 0; i < XGPU_MAX_REFS; i++) {
             const DevPic &rp = i < c->fp.num_refp[l] ? dpic(c, c->fp.refp_pic[i][l]) : dpic(c, c->fp.pic);
@@ -913,6 +932,15 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
             a.refp[i][l].poc = i < c->fp.num_refp[l] ? c->fp.refp_poc[i][l] : 0;
         }
     TIMED(c, XGPU_K_INTER, launch_inter(c, a));
+    if (db->n_dmvr) {
+        DmvrArgs d;
+        memset(&d, 0, sizeof(d));
+        d.cur_y = cur.y; d.cur_u = cur.u; d.cur_v = cur.v; d.s_l = c->s_l; d.s_c = c->s_c; d.pic_w = c->sp.width; d.pic_h = c->sp.height;
+        d.bd_l = c->sp.bit_depth_luma; d.bd_c = c->sp.bit_depth_chroma; d.admvp = a.admvp; d.cur_poc = c->fp.poc;
+        d.cus = db->d_cus; d.items = db->d_dmvr_items; d.n_items = db->n_dmvr; d.resid = db->d_resid; d.out_mv = db->d_dmvr_mv;
+        memcpy(d.refp, a.refp, sizeof(d.refp));
+        TIMED(c, XGPU_K_DMVR, launch_dmvr(c, d));
+    }
     if (db->n_aff_eif + db->n_aff_sub) {
         AffineArgs f;
         memset(&f, 0, sizeof(f));
@@ -942,6 +970,17 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
     HIPCHK(c, hipGetLastError());
     HIPCHK(c, hipEventRecord(db->blk.done, c->stream));                  // the block may be overwritten by a later batch after this point
     return XGPU_OK;
+}
+
+int xgpu_batch_dmvr_mvs(xgpu_ctx *c, xgpu_dbatch *db, int16_t *mv, int n)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, db != NULL && n >= 0);
+    if (mv && db->n_dmvr) {
+        ARGCHK(c, n >= db->n_dmvr);
+        HIPCHK(c, hipMemcpyAsync(mv, db->d_dmvr_mv, sizeof(int16_t) * 4 * (size_t)db->n_dmvr, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    return db->n_dmvr;
 }
 
 int xgpu_batch_wait_upload(xgpu_ctx *c, xgpu_dbatch *db)

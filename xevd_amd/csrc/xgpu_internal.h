@@ -41,7 +41,7 @@ struct __attribute__((aligned(16))) CuRec {
     uint8_t  ipm[2];
     uint8_t  ats_inter;       // ats_inter_info of an inter CU (idx | pos << 4), 0 = whole-CU transform
     uint8_t  affine;          // 0, or the number of control points (2 / 3) of an affine CU: predicted by k_affine, not k_inter
-    uint8_t  pad;
+    uint8_t  dmvr;            // 1: a DMVR candidate with two references and at least 8x8 samples - predicted by k_dmvr when the picture's POCs allow (else k_inter)
 };
 static_assert(sizeof(CuRec) == 32, "CuRec must be 32 bytes");
 
@@ -94,6 +94,23 @@ struct InterArgs {
     int      w_scu;
     uint16_t *owner;                   // [w_scu * h_scu] index (inside its CTU's list) of the CU covering each SCU, written by k_paint
     int      n_cu;
+    int      cur_poc;                  // POC of the picture being decoded (DMVR's distance test)
+    RefEntry refp[XGPU_MAX_REFS][2];
+};
+
+// DMVR (k_dmvr.hip): one work item per 16x16 (or smaller) sub-block of a candidate CU
+struct DmvrItem { uint32_t cu; uint8_t sx, sy; uint16_t pad; };          // CU record index, sub-block origin inside the CU in 4-sample units
+struct DmvrArgs {
+    int16_t *cur_y, *cur_u, *cur_v;
+    int      s_l, s_c;
+    int      pic_w, pic_h;
+    int      bd_l, bd_c;
+    int      admvp, cur_poc;
+    const CuRec    *cus;
+    const DmvrItem *items;
+    int      n_items;
+    const int16_t  *resid;
+    int16_t *out_mv;                   // [n_items][2][2] quarter-sample vectors kept for temporal prediction
     RefEntry refp[XGPU_MAX_REFS][2];
 };
 
@@ -196,6 +213,9 @@ struct xgpu_dbatch {
     int16_t   *d_coef, *d_resid;
     TbRec     *d_tbs;
     TbWave    *d_waves;
+    DmvrItem  *d_dmvr_items;          // sub-blocks of the DMVR candidates
+    int16_t   *d_dmvr_mv;             // their vectors after xgpu_batch_recon
+    int        n_dmvr;
     AffItem   *d_aff_items;           // tiles of the affine CUs
     int16_t   *d_cpmv;
     int        n_aff_eif, n_aff_sub;
@@ -248,6 +268,7 @@ void launch_itdq(xgpu_ctx *c, const ItdqArgs &a);
 void launch_inter(xgpu_ctx *c, const InterArgs &a);      // k_paint + k_inter
 void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf);
 void launch_affine(xgpu_ctx *c, const AffineArgs &a);
+void launch_dmvr(xgpu_ctx *c, const DmvrArgs &a);
 void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst);
 void upload_transform_tables(const int *tm, const int16_t *ats, hipStream_t s);
 int  itdq_group_size(int log2w, int log2h);     // TBs of one size class per 256-thread work item

@@ -112,6 +112,13 @@ class XgpuDecoder:
     def pic_output_wait(self, ticket):
         self._chk(self.lib.xgpu_pic_output_wait(self.ctx, ticket), "xgpu_pic_output_wait")
 
+    def batch_dmvr_mvs(self, h):
+        """the vectors kept for temporal prediction of the batch's DMVR candidates after batch_recon: [n_sub_blocks][list][x/y], quarter samples"""
+        n = self._chk(self.lib.xgpu_batch_dmvr_mvs(self.ctx, h, None, 0), "xgpu_batch_dmvr_mvs")
+        out = np.zeros((max(n, 1), 2, 2), np.int16)
+        self._chk(self.lib.xgpu_batch_dmvr_mvs(self.ctx, h, out.ctypes.data, n), "xgpu_batch_dmvr_mvs")
+        return out[:n]
+
     def batch_wait_upload(self, h):
         self._chk(self.lib.xgpu_batch_wait_upload(self.ctx, h), "xgpu_batch_wait_upload")
 

@@ -323,6 +323,25 @@ def add_affine(rng, batch, frac=0.5):
     return batch
 
 
+def add_dmvr(rng, batch, frac=0.6, mirror_frac=0.5):
+    """Flag a share of the plain inter CUs as DMVR candidates (merge-mode CUs of a stream with sps->tool_dmvr: xgpu_cu_batch.dmvr).  Most of them
+    bi-predicted and at least 8x8 (the backend refines those whose two references lie at equal POC distances on either side of the picture),
+    some not - the flag alone must not change them.  The flagged bi-predicted CUs get moderate vectors (inside the picture + margin), `mirror_frac`
+    of them list-1 vectors that mirror list 0 up to a sample or two - the situation the refinement is for."""
+    n = len(batch["x"])
+    aff = batch.get("affine")
+    plain = (batch["pred_mode"] != MODE_INTRA) & (batch["pred_mode"] != 6) & ((aff == 0) if aff is not None else True)
+    flag = plain & (rng.random(n) < frac)
+    bi = flag & (batch["refi"][:, 0] >= 0) & (batch["refi"][:, 1] >= 0)
+    mv = batch["mv"].astype(np.int64)
+    mv[bi] = np.clip(mv[bi], -96, 96)
+    mir = bi & (rng.random(n) < mirror_frac)
+    mv[mir, 1] = -mv[mir, 0] + rng.integers(-6, 7, (int(mir.sum()), 2))
+    batch["mv"] = mv.astype(np.int16)
+    batch["dmvr"] = flag.astype(np.uint8)
+    return batch
+
+
 MODE_IBC = 6
 
 
