@@ -13,6 +13,16 @@
 #include <string.h>
 #include "xevd.h"
 
+#ifdef REFD_HIP
+/* ref_binding.c: the MI355X backend installed behind the reference decoder's function-table slots */
+int refb_install(void *id);
+int refb_failed(void *id);
+void refb_uninstall(void *id);
+#define REFD_DELETE(id) do { refb_uninstall(id); xevd_delete(id); } while (0)
+#else
+#define REFD_DELETE(id) xevd_delete(id)
+#endif
+
 /* out: [max_pics][h*w + 2*(h/2)*(w/2)] s16, Y then U then V per picture; returns the number of pictures or a negative error */
 int refd_decode(const uint8_t *bytes, size_t size, int threads, int16_t *out, int max_pics, int w, int h)
 {
@@ -29,6 +39,9 @@ int refd_decode(const uint8_t *bytes, size_t size, int threads, int16_t *out, in
     cdsc.threads = threads;
     id = xevd_create(&cdsc, &ret);
     if (!id) return -1000 + ret;
+#ifdef REFD_HIP
+    if (refb_install(id)) { xevd_delete(id); return -1001; }
+#endif
     {   /* picture-signature SEIs are VERIFIED (app/xevd_app.c:177-182): a stream that carries our MD5s makes the reference check them */
         int on = 1, sz = sizeof(int);
         (void)xevd_config(id, XEVD_CFG_SET_USE_PIC_SIGNATURE, &on, &sz);
@@ -39,19 +52,19 @@ int refd_decode(const uint8_t *bytes, size_t size, int threads, int16_t *out, in
         if (!bumping) {
             if (pos + 4 > size) { bumping = 1; continue; }
             const size_t len = ((size_t)bytes[pos] << 24) | ((size_t)bytes[pos + 1] << 16) | ((size_t)bytes[pos + 2] << 8) | bytes[pos + 3];
-            if (pos + 4 + len > size) { xevd_delete(id); return -2; }
+            if (pos + 4 + len > size) { REFD_DELETE(id); return -2; }
             memset(&bitb, 0, sizeof(bitb));
             bitb.addr = (void *)(bytes + pos + 4);
             bitb.ssize = (int)len;
             pos += 4 + len;
             ret = xevd_decode(id, &bitb, &stat);
-            if (XEVD_FAILED(ret)) { xevd_delete(id); return -3000 + ret; }
+            if (XEVD_FAILED(ret)) { REFD_DELETE(id); return -3000 + ret; }
         }
         if (stat.fnum < 0 && !bumping) continue;
         imgb = NULL;
         ret = xevd_pull(id, &imgb);
         if (ret == XEVD_ERR_UNEXPECTED) break;                 /* bumping completed */
-        if (XEVD_FAILED(ret)) { xevd_delete(id); return -4000 + ret; }
+        if (XEVD_FAILED(ret)) { REFD_DELETE(id); return -4000 + ret; }
         /* a stream that ends inside a sub-GOP leaves pictures the reference never outputs (it waits for the missing POC for ever) */
         if (bumping && !imgb && ++idle > 64) break;
         if (imgb) {
@@ -70,7 +83,10 @@ int refd_decode(const uint8_t *bytes, size_t size, int threads, int16_t *out, in
             imgb->release(imgb);
         }
     }
-    xevd_delete(id);
+#ifdef REFD_HIP
+    if (refb_failed(id)) n = -5000;
+#endif
+    REFD_DELETE(id);
     return n;
 }
 

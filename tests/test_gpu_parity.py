@@ -401,6 +401,35 @@ def test_gpu_reference_application_on_our_api(name, args, tmp_path):
     assert got.size == expect.size and np.array_equal(got, expect)
 
 
+REF_DECODE_HIP = os.path.normpath(os.path.join(golden_io.GOLDEN, "..", "..", "oracle", "_ref", "ref_decode_hip"))
+# the Main-profile streams: the reference's Main library itself does not survive the Baseline ones (its entropy pass writes past ctx->cod_eco,
+# src_main/xevdm.c:1450-1455, on CTU rows that cross the picture's bottom edge) - those are the Baseline library's, tests/test_stream.py
+STREAM_NAMES = sorted(f[len("stream_"):-len(".npz")] for f in os.listdir(golden_io.GOLDEN) if f.startswith("stream_") and f.endswith(".npz") and "main_" in f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", STREAM_NAMES)
+def test_gpu_reference_parser_feeds_hip_backend(name, tmp_path):
+    """INTEGRATION.md section 4 as a program: the reference decoder itself (Main library objects; oracle/ref_binding.c compiles its xevdm.c with
+    the backend installed in ctx->fn_dec_slice / fn_deblock / fn_alf / fn_picbuf_expand) - its NAL / parameter-set / slice-header / SBAC / CU
+    parser, motion derivation, DPB and xevd_pull run unchanged, every picture is reconstructed and filtered by libxevd_hip.so - on every golden
+    stream: the reference's pictures, sample for sample (and, where the stream carries MD5 SEIs, verified by the reference's own check)."""
+    import subprocess
+    if not os.path.exists(REF_DECODE_HIP):
+        pytest.skip("oracle/_ref/ref_decode_hip is built only where the reference sources are (development container)")
+    d = np.load(os.path.join(golden_io.GOLDEN, f"stream_{name}.npz"))
+    src, dst = tmp_path / "s.evc", tmp_path / "s.raw"
+    src.write_bytes(d["bytes"].tobytes())
+    h, w = d["p0_0"].shape
+    r = subprocess.run([REF_DECODE_HIP, str(src), str(dst), str(w), str(h), "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode == 0, r.stdout.decode()[-400:]
+    n = int(d["n"])
+    assert int(r.stdout.split()[-2]) == n
+    got = np.fromfile(dst, "<i2")
+    expect = np.concatenate([d[f"p{k}_{c}"].ravel() for k in range(min(n, 64)) for c in range(3)]).astype(np.int16)
+    assert got.size == expect.size and np.array_equal(got, expect)
+
+
 @pytest.mark.gpu
 def test_gpu_reference_application_rejects_bad_signature(tmp_path):
     import subprocess
