@@ -47,30 +47,26 @@ __device__ __forceinline__ void wave_lds_sync()
 
 // p = reference sample at (tile x - 3, tile y - 3); lane l owns the SCU (l & 7, l >> 3) of the tile.  o[] as mc_luma_4x4.
 // The fetch is split from the filtering so that a wave has the windows of both lists (and its residual) in flight at once.
-struct TileFetch { uint4 y[4]; uint2 c[3]; };
-__device__ __forceinline__ void tile_fetch(gs16 p, int s, gs16 pu, gs16 pv, int sc, int lane, TileFetch &f)
+struct TileFetch { uint4 y[4]; uint4 c[2]; };
+// a lane's chunk of the tile windows: offsets into the reference plane (samples) and into the wave's LDS window.  Luma: 12 rows x 5 chunks of
+// 8 samples per pass (lanes 60..63 idle), four passes cover the 39 rows; chroma: 19 rows x 3 chunks per plane (lanes 57..63 idle).  The offsets
+// depend on the lane alone: computed once per kernel, every pass adds a constant.
+struct LaneMap { int gy, ly, gc, lc; };
+__device__ __forceinline__ void tile_fetch(gs16 p, int s, gs16 pu, gs16 pv, int lane, const LaneMap fm, TileFetch &f)
 {
 #pragma unroll
-    for (int it = 0; it < 4; it++) {                                // luma window: 39 rows x 5 chunks of 8 samples
-        const int c = lane + 64 * it, row = (c * 205) >> 10, k = c - row * 5;            // c / 5 for c < 256
-        if (c < 195) f.y[it] = gload16(p + row * s + 8 * k);
-    }
-#pragma unroll
-    for (int it = 0; it < 3; it++) {                                // chroma windows: 2 planes x 19 rows x 5 chunks of 4 samples
-        const int c = lane + 64 * it, pl = c >= 95, cc = c - 95 * pl, row = (cc * 205) >> 10, k = cc - row * 5;
-        if (c < 190) f.c[it] = gload8((pl ? pv : pu) + row * sc + 4 * k);
-    }
+    for (int it = 0; it < 4; it++)
+        if (lane < (it < 3 ? 60 : 15)) f.y[it] = gload16(p + fm.gy + 12 * it * s);
+    if (lane < 57) { f.c[0] = gload16(pu + fm.gc); f.c[1] = gload16(pv + fm.gc); }
 }
 
 template <bool H, bool V>
 __device__ __forceinline__ void mc_luma_tile(const uint4 v[4], const uint32_t ch[4], const uint32_t cv[4], Regime rg, int maxv,
-                                             int16_t *W, int16_t *I, int lane, uint32_t o[8])
+                                             int16_t *W, int16_t *I, int lane, const LaneMap fm, uint32_t o[8])
 {
 #pragma unroll
-    for (int it = 0; it < 4; it++) {
-        const int c = lane + 64 * it, row = (c * 205) >> 10, k = c - row * 5;
-        if (c < 195) *(uint4 *)(W + row * UW_STRIDE + 8 * k) = v[it];
-    }
+    for (int it = 0; it < 4; it++)
+        if (lane < (it < 3 ? 60 : 15)) *(uint4 *)(W + fm.ly + 12 * it * UW_STRIDE) = v[it];
     wave_lds_sync();
 #pragma unroll
     for (int it = 0; it < 5; it++) {                                // horizontal pass: 39 rows x 8 groups of 4 columns
@@ -133,14 +129,10 @@ __device__ __forceinline__ void mc_luma_tile(const uint4 v[4], const uint32_t ch
 
 // Both chroma planes of the tile (16x16 each).  pu / pv = reference sample at (tile x - 1, tile y - 1) of the plane.
 template <bool H, bool V>
-__device__ __forceinline__ void mc_chroma_tile(const uint2 v[3], const uint32_t ch[2], const uint32_t cv[2],
-                                               Regime rg, int maxv, int16_t *W, int16_t *I, int lane, uint32_t ou[2], uint32_t ov[2])
+__device__ __forceinline__ void mc_chroma_tile(const uint4 v[2], const uint32_t ch[2], const uint32_t cv[2],
+                                               Regime rg, int maxv, int16_t *W, int16_t *I, int lane, const LaneMap fm, uint32_t ou[2], uint32_t ov[2])
 {
-#pragma unroll
-    for (int it = 0; it < 3; it++) {
-        const int c = lane + 64 * it, pl = c >= 95, cc = c - 95 * pl, row = (cc * 205) >> 10, k = cc - row * 5;
-        if (c < 190) *(uint2 *)(W + (pl * 19 + row) * UC_STRIDE + 4 * k) = v[it];
-    }
+    if (lane < 57) { *(uint4 *)(W + fm.lc) = v[0]; *(uint4 *)(W + 19 * UC_STRIDE + fm.lc) = v[1]; }
     wave_lds_sync();
 #pragma unroll
     for (int it = 0; it < 3; it++) {                                // horizontal pass: 2 x 19 rows x 4 groups of 4 columns
@@ -199,62 +191,23 @@ __device__ __forceinline__ void mc_chroma_tile(const uint2 v[3], const uint32_t 
     wave_lds_sync();
 }
 
-#define MAX_CU_PER_CTU 1024
 #define INTER_STRIP 16
-#define LDS_CU 256
+#define OWNER_NONE 0xFFFFFFFFu
 
-__global__ __launch_bounds__(256) void k_inter(const InterArgs a)
+// One 32x32 tile (one wave): the SCU map records, and for plain inter CUs prediction + residual + store.  UNI: the whole tile lies in one CU -
+// the CU record is made wave-uniform (scalar registers: its decoding, the vector clipping and every branch on it run on the scalar unit) and
+// the filters run as a tile through the wave's LDS; otherwise every lane works on the CU that covers its SCU.
+// Returns whether the lane has samples to store: pl / pu / pv = its 4x4 luma and 2x2 + 2x2 chroma samples (the caller stores them AFTER it has taken
+// the prefetched records of the next tile out of their registers: stores and loads share one counter, and a wait behind the stores would be a
+// wait for their acknowledgement - a memory round trip per tile).
+template <bool UNI>
+__device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r1, bool lane_ok, int sx, int sy, int lane, int16_t *W, const LaneMap fm,
+                                           const uint4 (*s_ref)[2], const uint4 *s_ltap, const uint2 *s_ctap, uint32_t pl[8], uint32_t pu[2], uint32_t pv[2])
 {
-    // Everything a lane looks up by a data-dependent index lives in LDS: the per-wave critical path is then LDS -> LDS -> LDS
-    // -> reference samples, instead of a chain of dependent global loads (the kernel is latency-bound, not bandwidth-bound).
-    __shared__ uint4    s_cu[LDS_CU][2];                    // CU records of the CTU (the first LDS_CU of them)
-    __shared__ uint4    s_ref[XGPU_MAX_REFS * 2][2];        // RefEntry [idx][list]
-    __shared__ uint4    s_ltap[17];                         // luma taps of this sequence's table, [16] = identity
-    __shared__ uint2    s_ctap[33];
-    __shared__ __attribute__((aligned(16))) int16_t s_tile[4][UNI_SAMPLES];      // per wave: window + intermediate of the tile path
-
-    // XCD-aware mapping: workgroup b runs on XCD b % 8 and every XCD has its own L2.  The regions are ordered in vertical strips INTER_STRIP wide
-    // (row-major inside a strip) and every XCD takes a contiguous eighth of that order - about one strip: the ~100 workgroups it has in flight
-    // form a compact patch whose vertical halos are still in its L2 when the row below is processed, and all XCDs get the same number of regions
-    // (bands of whole region rows left the last XCD with 5 of 68 rows at 8K: the kernel ran at the pace of the 9-row bands).
-    const int regions_y = a.n_regions / a.regions_x;
-    const int idx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    if (idx >= a.n_regions) return;
-    const int per_strip = INTER_STRIP * regions_y;
-    const int strip = idx / per_strip, ks = idx - strip * per_strip;
-    const int sw = min(INTER_STRIP, a.regions_x - strip * INTER_STRIP);       // the last strip may be narrower
-    const int ry = ks / sw, rx = strip * INTER_STRIP + (ks - ry * sw);
-    const int ctu_x = (rx << 6) >> a.log2_ctu, ctu_y = (ry << 6) >> a.log2_ctu;
-    const int ctu = ctu_y * a.w_ctu + ctu_x;
-    const int first = a.ctu_cu_start[ctu];
-    const int n = min((int)a.ctu_cu_start[ctu + 1] - first, MAX_CU_PER_CTU);
-    const int t = threadIdx.x;
-    // SCU coordinates in the picture: a wave covers 8x8 SCUs (32x32 samples), so that CUs of 32x32 and above fill whole waves
-    // with one motion class (the MC variants below are chosen per wave)
-    const int sx = (rx << 4) + ((t >> 6 & 1) << 3) + (t & 7), sy = (ry << 4) + ((t >> 7) << 3) + ((t >> 3) & 7);
-    const bool active = sx < (a.pic_w >> 2) && sy < (a.pic_h >> 2);
-    // the covering CU: painted per picture by k_paint (a per-lane scan of the CTU's CU list cost ~30 us of this kernel at 8K).
-    // Fetched before the staging below: the kernel is bound by its chain of dependent memory round trips, not by bandwidth.
-    const int found = active ? (int)a.owner[sy * a.w_scu + sx] : 0xFFFF;
-
-    if (t < XGPU_MAX_REFS * 2) {
-        const uint4 *re = (const uint4 *)&a.refp[t >> 1][t & 1];
-        s_ref[t][0] = re[0]; s_ref[t][1] = re[1];
-    } else if (t >= 64 && t < 64 + 17) {
-        s_ltap[t - 64] = *(const uint4 *)k_luma_taps[a.admvp][t - 64];
-    } else if (t >= 128 && t < 128 + 33) {
-        s_ctap[t - 128] = *(const uint2 *)k_chroma_taps[a.admvp][t - 128];
-    }
-    for (int i = t; i < min(n, LDS_CU); i += 256) {
-        s_cu[i][0] = ((const uint4 *)&a.cus[first + i])[0]; s_cu[i][1] = ((const uint4 *)&a.cus[first + i])[1];
-    }
-    __syncthreads();
-
-    if (!active || found >= n) return;
-
-    uint4 r0, r1;
-    if (found < LDS_CU) { r0 = s_cu[found][0]; r1 = s_cu[found][1]; }
-    else { r0 = ((const uint4 *)&a.cus[first + found])[0]; r1 = ((const uint4 *)&a.cus[first + found])[1]; }
+    if (UNI) {
+        r0.x = __builtin_amdgcn_readfirstlane(r0.x); r0.y = __builtin_amdgcn_readfirstlane(r0.y); r0.z = __builtin_amdgcn_readfirstlane(r0.z); r0.w = __builtin_amdgcn_readfirstlane(r0.w);
+        r1.x = __builtin_amdgcn_readfirstlane(r1.x); r1.y = __builtin_amdgcn_readfirstlane(r1.y); r1.z = __builtin_amdgcn_readfirstlane(r1.z); r1.w = __builtin_amdgcn_readfirstlane(r1.w);
+    } else if (!lane_ok) return false;
     const int cu_x = r0.x & 0xFFFF, cu_y = r0.x >> 16;
     const int lw = r0.y & 0xFF, lh = (r0.y >> 8) & 0xFF, pred_mode = (r0.y >> 16) & 0xFF, cbf = r0.y >> 24;
     const int refi0 = (int)(int8_t)(r0.z & 0xFF), refi1 = (int)(int8_t)((r0.z >> 8) & 0xFF), qp_map = (r0.z >> 16) & 0xFF;
@@ -291,13 +244,12 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
         rec.w = (intra || ibc) ? 0u : r1.y;
         *(uint4 *)&a.maps[sy * a.w_scu + sx] = rec;
     }
-    if (intra || pred_mode == XGPU_MODE_IBC || ((r1.w >> 16) & 0xFF)) return;   // IBC CUs are reconstructed with the intra CUs (k_intra); affine CUs: samples and sub-block vectors come from k_affine
+    if (intra || pred_mode == XGPU_MODE_IBC || ((r1.w >> 16) & 0xFF)) return false;   // IBC CUs are reconstructed with the intra CUs (k_intra); affine CUs: samples and sub-block vectors come from k_affine
 
     // ---- motion: clip like xevd_mv_clip (xevd_mc.c:435-467), variant from the UNCLIPPED vector ----
     const int maxl = (1 << a.bd_l) - 1, maxc = (1 << a.bd_c) - 1;
-    uint32_t pl[8], pu[2], pv[2];
     int nl = 0;
-    int16_t mvt[2][2];
+    int mvt[2][2];
     const int mvs[2][2] = { { (int)(int16_t)(r1.x & 0xFFFF), (int)(int16_t)(r1.x >> 16) },
                             { (int)(int16_t)(r1.y & 0xFFFF), (int)(int16_t)(r1.y >> 16) } };
     const int refis[2] = { refi0, refi1 };
@@ -310,15 +262,17 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
         if (qy + mvs[l][1] < min_c) my = min_c - qy;
         if (qx + mvs[l][0] + qw - 4 > max_x) mx = max_x - qx - qw + 4;
         if (qy + mvs[l][1] + qh - 4 > max_y) my = max_y - qy - qh + 4;
-        mvt[l][0] = (int16_t)mx; mvt[l][1] = (int16_t)my;
+        mvt[l][0] = (int)(int16_t)mx; mvt[l][1] = (int)(int16_t)my;
     }
     bool use[2] = { refi0 >= 0, refi1 >= 0 };
-    if (use[0] && use[1] && s_ref[refi0 * 2][1].z == s_ref[refi1 * 2 + 1][1].z && mvt[0][0] == mvt[1][0] && mvt[0][1] == mvt[1][1])
+    // POC of the two references (0 when the list is unused: the tests below look at them only with both lists in use)
+    const int poc0 = use[0] ? (int)s_ref[refi0 * 2][1].z : 0, poc1 = use[1] ? (int)s_ref[refi1 * 2 + 1][1].z : 0;
+    if (use[0] && use[1] && poc0 == poc1 && mvt[0][0] == mvt[1][0] && mvt[0][1] == mvt[1][1])
         use[1] = false;                                               // identical motion, xevd_mc.c:512-519
     // a DMVR candidate whose references are POC-symmetric is refined and predicted by k_dmvr (its map record, with the unrefined vectors, is written)
-    if ((r1.w >> 24) && dmvr_applies(a.cur_poc, (int)s_ref[refi0 * 2][1].z, (int)s_ref[refi1 * 2 + 1][1].z)) return;
+    if ((r1.w >> 24) && dmvr_applies(a.cur_poc, poc0, poc1)) return false;
 
-    // residual of this SCU (zero where nothing is coded); the tile path issues the loads before the filtering
+    // residual of this SCU (zero where nothing is coded); the loads are issued before the filtering
     uint32_t rl[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ru[2] = {0, 0}, rv[2] = {0, 0};
     auto load_resid = [&]() {
         if (!in_tu) return;
@@ -340,47 +294,39 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
             rv[0] = *(const uint32_t *)r; rv[1] = *(const uint32_t *)(r + cwc);
         }
     };
-    // every lane of the wave alive and in the same CU: tile path
-    const bool uni = __ballot(1) == ~0ull && __ballot(found == __builtin_amdgcn_readfirstlane(found)) == ~0ull;
-    if (uni) {
-        const int lane = t & 63;
-        int16_t *W = s_tile[t >> 6], *I = W + UNI_W_SAMPLES;
+    if (UNI) {
+        int16_t *I = W + UNI_W_SAMPLES;
         const int wx = __builtin_amdgcn_readfirstlane(x), wy = __builtin_amdgcn_readfirstlane(y);
         TileFetch tf[2];
-        int tpx[2], tpy[2], tmx[2], tmy[2];
 #pragma unroll
-
         for (int l = 0; l < 2; l++) {                               // all the windows first ...
-            if (!__builtin_amdgcn_readfirstlane((int)use[l])) continue;
-            const int ri = __builtin_amdgcn_readfirstlane(refis[l] * 2 + l);
-            const uint4 e0 = s_ref[ri][0], e1 = s_ref[ri][1];
+            if (!use[l]) continue;
+            const uint4 e0 = s_ref[refis[l] * 2 + l][0], e1 = s_ref[refis[l] * 2 + l][1];
             const gs16 ry_ = (gs16)(((uint64_t)e0.y << 32) | e0.x), ru_ = (gs16)(((uint64_t)e0.w << 32) | e0.z), rv_ = (gs16)(((uint64_t)e1.y << 32) | e1.x);
-            tmx[l] = __builtin_amdgcn_readfirstlane(mvs[l][0]); tmy[l] = __builtin_amdgcn_readfirstlane(mvs[l][1]);
-            const int px = tpx[l] = (wx << 2) + __builtin_amdgcn_readfirstlane((int)mvt[l][0]);
-            const int py = tpy[l] = (wy << 2) + __builtin_amdgcn_readfirstlane((int)mvt[l][1]);
+            const int px = (wx << 2) + mvt[l][0], py = (wy << 2) + mvt[l][1];
             const int off = ((py >> 3) - 1) * a.s_c + (px >> 3) - 1;
-            tile_fetch(ry_ + ((py >> 2) - 3) * a.s_l + (px >> 2) - 3, a.s_l, ru_ + off, rv_ + off, a.s_c, lane, tf[l]);
+            tile_fetch(ry_ + ((py >> 2) - 3) * a.s_l + (px >> 2) - 3, a.s_l, ru_ + off, rv_ + off, lane, fm, tf[l]);
         }
         load_resid();                                               // ... and the residual, then the filtering
 #pragma unroll
         for (int l = 0; l < 2; l++) {
-            if (!__builtin_amdgcn_readfirstlane((int)use[l])) continue;
-            const int mvx = tmx[l], mvy = tmy[l], px = tpx[l], py = tpy[l];
+            if (!use[l]) continue;
+            const int mvx = mvs[l][0], mvy = mvs[l][1], px = (wx << 2) + mvt[l][0], py = (wy << 2) + mvt[l][1];
             const int ldx = (mvx & 3) != 0, ldy = (mvy & 3) != 0, cdx = (mvx & 7) != 0, cdy = (mvy & 7) != 0;
             uint32_t o[8], ou[2], ov[2];
             {
                 const uint4 th = s_ltap[ldx ? ((px & 3) << 2) : 16], tv = s_ltap[ldy ? ((py & 3) << 2) : 16];
                 const uint32_t ch[4] = { th.x, th.y, th.z, th.w }, cv[4] = { tv.x, tv.y, tv.z, tv.w };
                 const Regime rg = regime(ldx, ldy, a.bd_l);
-                if (ldx) { if (ldy) mc_luma_tile<true, true>(tf[l].y, ch, cv, rg, maxl, W, I, lane, o); else mc_luma_tile<true, false>(tf[l].y, ch, cv, rg, maxl, W, I, lane, o); }
-                else     { if (ldy) mc_luma_tile<false, true>(tf[l].y, ch, cv, rg, maxl, W, I, lane, o); else mc_luma_tile<false, false>(tf[l].y, ch, cv, rg, maxl, W, I, lane, o); }
+                if (ldx) { if (ldy) mc_luma_tile<true, true>(tf[l].y, ch, cv, rg, maxl, W, I, lane, fm, o); else mc_luma_tile<true, false>(tf[l].y, ch, cv, rg, maxl, W, I, lane, fm, o); }
+                else     { if (ldy) mc_luma_tile<false, true>(tf[l].y, ch, cv, rg, maxl, W, I, lane, fm, o); else mc_luma_tile<false, false>(tf[l].y, ch, cv, rg, maxl, W, I, lane, fm, o); }
             }
             {
                 const uint2 th = s_ctap[cdx ? ((px & 7) << 2) : 32], tv = s_ctap[cdy ? ((py & 7) << 2) : 32];
                 const uint32_t c2h[2] = { th.x, th.y }, c2v[2] = { tv.x, tv.y };
                 const Regime rg = regime(cdx, cdy, a.bd_c);
-                if (cdx) { if (cdy) mc_chroma_tile<true, true>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, ou, ov); else mc_chroma_tile<true, false>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, ou, ov); }
-                else     { if (cdy) mc_chroma_tile<false, true>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, ou, ov); else mc_chroma_tile<false, false>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, ou, ov); }
+                if (cdx) { if (cdy) mc_chroma_tile<true, true>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, fm, ou, ov); else mc_chroma_tile<true, false>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, fm, ou, ov); }
+                else     { if (cdy) mc_chroma_tile<false, true>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, fm, ou, ov); else mc_chroma_tile<false, false>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, fm, ou, ov); }
             }
             if (nl == 0) {
 #pragma unroll
@@ -395,57 +341,53 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
             nl++;
         }
     } else {
-    load_resid();
+        load_resid();
 #pragma unroll
-    for (int l = 0; l < 2; l++) {
-        if (!use[l]) continue;
-        RefEntry re;
-        {
+        for (int l = 0; l < 2; l++) {
+            if (!use[l]) continue;
             const uint4 e0 = s_ref[refis[l] * 2 + l][0], e1 = s_ref[refis[l] * 2 + l][1];
-            re.y = (const int16_t *)(((uint64_t)e0.y << 32) | e0.x); re.u = (const int16_t *)(((uint64_t)e0.w << 32) | e0.z);
-            re.v = (const int16_t *)(((uint64_t)e1.y << 32) | e1.x); re.poc = (int)e1.z;
-        }
-        const int mvx = mvs[l][0], mvy = mvs[l][1];
-        // luma: quarter-pel position of this SCU = (x<<2) + clipped mv; phase in 1/16 = (pos&3)<<2
-        const int px = (x << 2) + mvt[l][0], py = (y << 2) + mvt[l][1];
-        const int ldx = (mvx & 3) != 0, ldy = (mvy & 3) != 0;
-        const int cdx = (mvx & 7) != 0, cdy = (mvy & 7) != 0;
-        uint32_t ch[4], cv[4], o[8], ou[2], ov[2];
-        {
-            const uint4 th = s_ltap[ldx ? ((px & 3) << 2) : 16], tv = s_ltap[ldy ? ((py & 3) << 2) : 16];
-            ch[0] = th.x; ch[1] = th.y; ch[2] = th.z; ch[3] = th.w; cv[0] = tv.x; cv[1] = tv.y; cv[2] = tv.z; cv[3] = tv.w;
-            const gs16 p = (gs16)re.y + ((py >> 2) - 3) * a.s_l + (px >> 2) - 3;
-            const Regime rg = regime(ldx, ldy, a.bd_l);
-            const bool wh = __ballot(ldx) != 0, wvv = __ballot(ldy) != 0;      // over the lanes that run this list
-            if (wh) { if (wvv) mc_luma_4x4<true, true>(p, a.s_l, ch, cv, rg, maxl, o); else mc_luma_4x4<true, false>(p, a.s_l, ch, cv, rg, maxl, o); }
-            else    { if (wvv) mc_luma_4x4<false, true>(p, a.s_l, ch, cv, rg, maxl, o); else mc_luma_4x4<false, false>(p, a.s_l, ch, cv, rg, maxl, o); }
-        }
-        {
-            // chroma: 1/8-pel position (x<<2)+mv in luma quarter-pel == chroma eighth-pel; phase in 1/32 = (pos&7)<<2
-            const uint2 th = s_ctap[cdx ? ((px & 7) << 2) : 32], tv = s_ctap[cdy ? ((py & 7) << 2) : 32];
-            uint32_t c2h[2] = { th.x, th.y }, c2v[2] = { tv.x, tv.y };
-            const int off = ((py >> 3) - 1) * a.s_c + (px >> 3) - 1;
-            const Regime rg = regime(cdx, cdy, a.bd_c);
-            const bool wh = __ballot(cdx) != 0, wvv = __ballot(cdy) != 0;
-#define MC_C(H, V) do { mc_chroma_2x2<H, V>((gs16)re.u + off, a.s_c, c2h, c2v, rg, maxc, ou); mc_chroma_2x2<H, V>((gs16)re.v + off, a.s_c, c2h, c2v, rg, maxc, ov); } while (0)
-            if (wh) { if (wvv) MC_C(true, true); else MC_C(true, false); }
-            else    { if (wvv) MC_C(false, true); else MC_C(false, false); }
+            const gs16 ry_ = (gs16)(((uint64_t)e0.y << 32) | e0.x), ru_ = (gs16)(((uint64_t)e0.w << 32) | e0.z), rv_ = (gs16)(((uint64_t)e1.y << 32) | e1.x);
+            const int mvx = mvs[l][0], mvy = mvs[l][1];
+            // luma: quarter-pel position of this SCU = (x<<2) + clipped mv; phase in 1/16 = (pos&3)<<2
+            const int px = (x << 2) + mvt[l][0], py = (y << 2) + mvt[l][1];
+            const int ldx = (mvx & 3) != 0, ldy = (mvy & 3) != 0;
+            const int cdx = (mvx & 7) != 0, cdy = (mvy & 7) != 0;
+            uint32_t ch[4], cv[4], o[8], ou[2], ov[2];
+            {
+                const uint4 th = s_ltap[ldx ? ((px & 3) << 2) : 16], tv = s_ltap[ldy ? ((py & 3) << 2) : 16];
+                ch[0] = th.x; ch[1] = th.y; ch[2] = th.z; ch[3] = th.w; cv[0] = tv.x; cv[1] = tv.y; cv[2] = tv.z; cv[3] = tv.w;
+                const gs16 p = ry_ + ((py >> 2) - 3) * a.s_l + (px >> 2) - 3;
+                const Regime rg = regime(ldx, ldy, a.bd_l);
+                const bool wh = __ballot(ldx) != 0, wvv = __ballot(ldy) != 0;      // over the lanes that run this list
+                if (wh) { if (wvv) mc_luma_4x4<true, true>(p, a.s_l, ch, cv, rg, maxl, o); else mc_luma_4x4<true, false>(p, a.s_l, ch, cv, rg, maxl, o); }
+                else    { if (wvv) mc_luma_4x4<false, true>(p, a.s_l, ch, cv, rg, maxl, o); else mc_luma_4x4<false, false>(p, a.s_l, ch, cv, rg, maxl, o); }
+            }
+            {
+                // chroma: 1/8-pel position (x<<2)+mv in luma quarter-pel == chroma eighth-pel; phase in 1/32 = (pos&7)<<2
+                const uint2 th = s_ctap[cdx ? ((px & 7) << 2) : 32], tv = s_ctap[cdy ? ((py & 7) << 2) : 32];
+                uint32_t c2h[2] = { th.x, th.y }, c2v[2] = { tv.x, tv.y };
+                const int off = ((py >> 3) - 1) * a.s_c + (px >> 3) - 1;
+                const Regime rg = regime(cdx, cdy, a.bd_c);
+                const bool wh = __ballot(cdx) != 0, wvv = __ballot(cdy) != 0;
+#define MC_C(H, V) do { mc_chroma_2x2<H, V>(ru_ + off, a.s_c, c2h, c2v, rg, maxc, ou); mc_chroma_2x2<H, V>(rv_ + off, a.s_c, c2h, c2v, rg, maxc, ov); } while (0)
+                if (wh) { if (wvv) MC_C(true, true); else MC_C(true, false); }
+                else    { if (wvv) MC_C(false, true); else MC_C(false, false); }
 #undef MC_C
-        }
-        if (nl == 0) {
+            }
+            if (nl == 0) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) pl[k] = o[k];
-            pu[0] = ou[0]; pu[1] = ou[1]; pv[0] = ov[0]; pv[1] = ov[1];
-        } else {
+                for (int k = 0; k < 8; k++) pl[k] = o[k];
+                pu[0] = ou[0]; pu[1] = ou[1]; pv[0] = ov[0]; pv[1] = ov[1];
+            } else {
 #pragma unroll
-            for (int k = 0; k < 8; k++) pl[k] = avg2(pl[k], o[k]);
-            pu[0] = avg2(pu[0], ou[0]); pu[1] = avg2(pu[1], ou[1]);
-            pv[0] = avg2(pv[0], ov[0]); pv[1] = avg2(pv[1], ov[1]);
+                for (int k = 0; k < 8; k++) pl[k] = avg2(pl[k], o[k]);
+                pu[0] = avg2(pu[0], ou[0]); pu[1] = avg2(pu[1], ou[1]);
+                pv[0] = avg2(pv[0], ov[0]); pv[1] = avg2(pv[1], ov[1]);
+            }
+            nl++;
         }
-        nl++;
     }
-    }
-    if (nl == 0) return;     // inter CU without a valid reference: nothing predicted (does not occur in valid streams)
+    if (nl == 0) return false;     // inter CU without a valid reference: nothing predicted (does not occur in valid streams)
 
     // ---- residual add + clip (xevd_recon.c:35-71; the LUMA bit depth clips all three components, :75-90) ----
     if (cbf & 1) {
@@ -455,37 +397,75 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     if (cbf & 2) { pu[0] = recon2(pu[0], ru[0], maxl); pu[1] = recon2(pu[1], ru[1], maxl); }
     if (cbf & 4) { pv[0] = recon2(pv[0], rv[0], maxl); pv[1] = recon2(pv[1], rv[1], maxl); }
 
-    int16_t *dy = a.cur_y + y * a.s_l + x;
-#pragma unroll
-    for (int k = 0; k < 4; k++) *(uint2 *)(dy + k * a.s_l) = make_uint2(pl[k * 2], pl[k * 2 + 1]);
-    const int coff = (y >> 1) * a.s_c + (x >> 1);
-    *(uint32_t *)(a.cur_u + coff) = pu[0];
-    *(uint32_t *)(a.cur_u + coff + a.s_c) = pu[1];
-    *(uint32_t *)(a.cur_v + coff) = pv[0];
-    *(uint32_t *)(a.cur_v + coff + a.s_c) = pv[1];
+    return true;
 }
 
-// SCU -> CU map of one picture: one thread per CU writes the CU's index (inside its CTU's list) over the SCUs it covers.
-// CUs tile the picture, so every entry is written exactly once and the map needs no clearing.
-__global__ __launch_bounds__(256) void k_paint(const InterArgs a)
+// One workgroup per 64x64 region, one wave per 32x32 tile, no barrier after the tables are staged: every wave walks its own chain owner entry ->
+// CU record -> reference windows.  The host paints the owner map (xgpu_batch_create), so there is no k_paint and no per-CTU staging of CU records.
+// (A persistent variant that kept the first links of the next tiles in flight was measured slower: the prefetch registers pushed the kernel into
+// scratch and its 53 KB of code out of the instruction cache; DESIGN.md.)
+__global__ __launch_bounds__(256) void k_inter(const InterArgs a)
 {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= a.n_cu) return;
-    const uint2 g = *(const uint2 *)&a.cus[i];
-    const int x = g.x & 0xFFFF, y = g.x >> 16, ws = (1 << (g.y & 0xFF)) >> 2, hs = (1 << ((g.y >> 8) & 0xFF)) >> 2;
-    const int ctu = (y >> a.log2_ctu) * a.w_ctu + (x >> a.log2_ctu);
-    const uint16_t idx = (uint16_t)(i - (int)a.ctu_cu_start[ctu]);
-    uint16_t *o = a.owner + (y >> 2) * a.w_scu + (x >> 2);
-    const uint32_t v2 = (uint32_t)idx * 0x10001u;
-    for (int r = 0; r < hs; r++, o += a.w_scu) {
-        if (ws == 1) o[0] = idx;
-        else for (int q = 0; q < ws; q += 2) *(uint32_t *)(o + q) = v2;      // CUs wider than 4 start at even SCU columns
+    __shared__ uint4    s_ref[XGPU_MAX_REFS * 2][2];        // RefEntry [idx][list]
+    __shared__ uint4    s_ltap[17];                         // luma taps of this sequence's table, [16] = identity
+    __shared__ uint2    s_ctap[33];
+    __shared__ __attribute__((aligned(16))) int16_t s_tile[4][UNI_SAMPLES];      // per wave: window + intermediate of the tile path
+    // XCD-aware mapping: workgroup b runs on XCD b % 8 and every XCD has its own L2.  The regions are ordered in vertical strips INTER_STRIP wide
+    // (row-major inside a strip) and every XCD takes a contiguous eighth of that order - about one strip: the ~100 workgroups it has in flight
+    // form a compact patch whose vertical halos are still in its L2 when the row below is processed, and all XCDs get the same number of regions.
+    const int idx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (idx >= a.n_regions) return;
+    const int regions_y = a.n_regions / a.regions_x, per_strip = INTER_STRIP * regions_y;
+    const int strip = idx / per_strip, ks = idx - strip * per_strip;
+    const int sw = min(INTER_STRIP, a.regions_x - strip * INTER_STRIP);       // the last strip may be narrower
+    const int ry = ks / sw, rx = strip * INTER_STRIP + (ks - ry * sw);
+    const int t = threadIdx.x, lane = t & 63;
+    // SCU coordinates in the picture: a wave covers 8x8 SCUs (32x32 samples), so that CUs of 32x32 and above fill whole waves
+    const int sx = (rx << 4) + ((t >> 6 & 1) << 3) + (lane & 7), sy = (ry << 4) + ((t >> 7) << 3) + (lane >> 3);
+    const bool active = sx < (a.pic_w >> 2) && sy < (a.pic_h >> 2);
+    // the first link of the chain goes out before the tables are staged
+    const uint32_t own = active ? a.owner[sy * a.w_scu + sx] : OWNER_NONE;
+    if (t < XGPU_MAX_REFS * 2) {
+        const uint4 *re = (const uint4 *)&a.refp[t >> 1][t & 1];
+        s_ref[t][0] = re[0]; s_ref[t][1] = re[1];
+    } else if (t >= 64 && t < 64 + 17) {
+        s_ltap[t - 64] = *(const uint4 *)k_luma_taps[a.admvp][t - 64];
+    } else if (t >= 128 && t < 128 + 33) {
+        s_ctap[t - 128] = *(const uint2 *)k_chroma_taps[a.admvp][t - 128];
+    }
+    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+    const bool ok = own < (uint32_t)a.n_cu;                    // unowned (another tile's SCU) or not an index of this batch
+    if (ok) { c0 = ((const uint4 *)&a.cus[own])[0]; c1 = ((const uint4 *)&a.cus[own])[1]; }
+    __syncthreads();
+
+    int16_t *W = s_tile[t >> 6];
+    LaneMap fm;
+    {
+        const int row0 = (lane * 205) >> 10, k = lane - row0 * 5;         // luma window: 12 rows x 5 chunks of 8 samples per pass (lanes 60..63 idle)
+        fm.gy = row0 * a.s_l + 8 * k; fm.ly = row0 * UW_STRIDE + 8 * k;
+        const int cr = (lane * 171) >> 9, ck = lane - cr * 3;              // chroma windows: 19 rows x 3 chunks of 8 samples per plane (lanes 57..63 idle)
+        fm.gc = cr * a.s_c + 8 * ck; fm.lc = cr * UC_STRIDE + 8 * ck;
+    }
+    const bool uni = __ballot(ok) == ~0ull && __ballot(own == __builtin_amdgcn_readfirstlane(own)) == ~0ull;
+    uint32_t pl[8], pu[2], pv[2];
+    bool st;
+    if (uni) st = inter_tile<true>(a, c0, c1, true, sx, sy, lane, W, fm, s_ref, s_ltap, s_ctap, pl, pu, pv);
+    else     st = inter_tile<false>(a, c0, c1, ok, sx, sy, lane, W, fm, s_ref, s_ltap, s_ctap, pl, pu, pv);
+    if (st) {
+        const int x = sx << 2, y = sy << 2;
+        int16_t *dy = a.cur_y + y * a.s_l + x;
+#pragma unroll
+        for (int k = 0; k < 4; k++) *(uint2 *)(dy + k * a.s_l) = make_uint2(pl[k * 2], pl[k * 2 + 1]);
+        const int coff = (y >> 1) * a.s_c + (x >> 1);
+        *(uint32_t *)(a.cur_u + coff) = pu[0];
+        *(uint32_t *)(a.cur_u + coff + a.s_c) = pu[1];
+        *(uint32_t *)(a.cur_v + coff) = pv[0];
+        *(uint32_t *)(a.cur_v + coff + a.s_c) = pv[1];
     }
 }
 
 void launch_inter(xgpu_ctx *c, const InterArgs &a)
 {
-    if (a.n_cu) hipLaunchKernelGGL(k_paint, dim3((a.n_cu + 255) / 256), dim3(256), 0, c->stream, a);
     hipLaunchKernelGGL(k_inter, dim3(((a.n_regions + 7) >> 3) << 3), dim3(256), 0, c->stream, a);
 }
 

@@ -212,17 +212,17 @@ __device__ __forceinline__ void mc_chroma_2x2(gs16 p, int s, const uint32_t ch[2
         o[r] = pack2(clip3(0, maxv, V ? acc[r][0] >> rg.sh2 : acc[r][0]), clip3(0, maxv, V ? acc[r][1] >> rg.sh2 : acc[r][1]));
 }
 
-// (p0 + p1 + 1) >> 1 on packed non-negative s16 pairs (xevd_average_16b_no_clip, xevd_mc.c:145-167)
+// (p0 + p1 + 1) >> 1 on packed non-negative s16 pairs (xevd_average_16b_no_clip, xevd_mc.c:145-167): packed 16-bit adds, the sums stay below 2^16
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t avg2(uint32_t a, uint32_t b)
 {
-    const uint32_t lo = ((a & 0xFFFFu) + (b & 0xFFFFu) + 1u) >> 1;
-    const uint32_t hi = ((a >> 16) + (b >> 16) + 1u) >> 1;
-    return lo | (hi << 16);
+    const v2us r = (__builtin_bit_cast(v2us, a) + __builtin_bit_cast(v2us, b) + (v2us)(1)) >> (v2us)(1);
+    return __builtin_bit_cast(uint32_t, r);
 }
 // rec = clip(0, max, (s16)(res + pred)) on packed pairs: the 16-bit sum wraps (xevd_recon.c:39,60)
 __device__ __forceinline__ uint32_t recon2(uint32_t pred, uint32_t res, int maxv)
 {
-    const int lo = (int)(int16_t)((pred & 0xFFFFu) + (res & 0xFFFFu));
-    const int hi = (int)(int16_t)((pred >> 16) + (res >> 16));
-    return pack2(clip3(0, maxv, lo), clip3(0, maxv, hi));
+    const v2s sum = __builtin_bit_cast(v2s, pred) + __builtin_bit_cast(v2s, res);
+    const v2s r = __builtin_elementwise_min(__builtin_elementwise_max(sum, (v2s)(0)), (v2s)((short)maxv));
+    return __builtin_bit_cast(uint32_t, r);
 }

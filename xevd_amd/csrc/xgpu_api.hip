@@ -155,7 +155,7 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     xgpu_ctx *c = new xgpu_ctx();
     c->sp = *sp;
     c->sp.chroma_qp_table[0] = c->sp.chroma_qp_table[1] = NULL;
-    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_owner = NULL; c->d_dra = NULL; c->d_ctb_flag = NULL; c->stream = 0; c->up_stream = 0; c->down_stream = 0; c->where = 0;
+    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_dra = NULL; c->d_ctb_flag = NULL; c->stream = 0; c->up_stream = 0; c->down_stream = 0; c->where = 0;
     for (int i = 0; i < 2; i++) { c->d_out[i] = NULL; c->out_caps[i] = 0; c->out_ready[i] = c->out_done[i] = 0; c->out_busy[i] = 0; }
     c->out_next = 0;
     memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_n, 0, sizeof(c->t_n));
@@ -188,8 +188,6 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
 
     if (hipMalloc((void **)&c->d_maps, sizeof(ScuRec) * (size_t)c->w_scu * c->h_scu) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
     if (hipMemsetAsync(c->d_maps, 0, sizeof(ScuRec) * (size_t)c->w_scu * c->h_scu, c->stream) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
-    if (hipMalloc((void **)&c->d_owner, sizeof(uint16_t) * ((size_t)c->w_scu * c->h_scu + 8)) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
-    if (hipMemsetAsync(c->d_owner, 0xFF, sizeof(uint16_t) * ((size_t)c->w_scu * c->h_scu + 8), c->stream) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     if (hipMalloc((void **)&c->d_ctb_flag, (size_t)c->w_ctu * c->h_ctu + 16) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
     init_transform_tables(c);
     // slot 0 of `pics` is the private scratch picture of the deblocking passes
@@ -222,7 +220,6 @@ void xgpu_close(xgpu_ctx *c)
     for (auto &h : c->pinned) (void)hipHostFree(h.p);
     c->pinned.clear();
     c->pool.clear();
-    if (c->d_owner) (void)hipFree(c->d_owner);
     for (int i = 0; i < 2; i++) { if (c->d_out[i]) (void)hipFree(c->d_out[i]); if (c->out_ready[i]) (void)hipEventDestroy(c->out_ready[i]); if (c->out_done[i]) (void)hipEventDestroy(c->out_done[i]); }
     if (c->d_dra) (void)hipFree(c->d_dra);
     if (c->d_ctb_flag) (void)hipFree(c->d_ctb_flag);
@@ -748,7 +745,9 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     const size_t sz_aff = sizeof(AffItem) * (size_t)std::max(n_aff_eif + n_aff_sub, 1), sz_cpmv = sizeof(int16_t) * 12 * (size_t)std::max(n_aff, 1);
     const size_t o_deps = o_intra + align_up((int)sz_intra, 256), o_aff = o_deps + align_up((int)sz_deps, 256);
     const size_t sz_dmvr = sizeof(DmvrItem) * (size_t)std::max(n_dmvr, 1);
-    const size_t o_cpmv = o_aff + align_up((int)sz_aff, 256), o_dmvr = o_cpmv + align_up((int)sz_cpmv, 256), o_coef = o_dmvr + align_up((int)sz_dmvr, 256);
+    const size_t sz_own = sizeof(uint32_t) * (size_t)c->w_scu * c->h_scu;
+    const size_t o_cpmv = o_aff + align_up((int)sz_aff, 256), o_dmvr = o_cpmv + align_up((int)sz_cpmv, 256), o_own = o_dmvr + align_up((int)sz_dmvr, 256);
+    const size_t o_coef = o_own + align_up((int)sz_own, 256);
     db->stage_bytes = o_coef + sz_coef;
     auto fail = [&](int code) { xgpu_batch_destroy(c, db); return code; };
     // device layout: the uploaded arrays at the staging offsets, then the residual arena and the intra done flags
@@ -794,6 +793,21 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     int16_t *cpmv = (int16_t *)(hs + o_cpmv);
     int aff_fill = 0, eif_fill = 0, sub_fill = n_aff_eif, dmvr_fill = 0;
     DmvrItem *dmvr_items = (DmvrItem *)(hs + o_dmvr);
+    // SCU -> CU map of the picture (k_inter's lanes find their CU through it); SCUs outside the batch - another tile's - stay unowned.  Painted in
+    // ordinary memory (short row fills) and copied into the pinned block in one piece
+    {
+        static thread_local std::vector<uint32_t> own;
+        own.resize((size_t)c->w_scu * c->h_scu);
+        size_t covered = 0;
+        for (int i = 0; i < n; i++) covered += (size_t)1 << (b->log2w[i] + b->log2h[i] - 4);
+        if (covered != own.size()) std::fill(own.begin(), own.end(), 0xFFFFFFFFu);
+        for (int i = 0; i < n; i++) {
+            const int ws = (1 << b->log2w[i]) >> 2, hh = (1 << b->log2h[i]) >> 2;
+            uint32_t *o = own.data() + (size_t)(b->y[i] >> 2) * c->w_scu + (b->x[i] >> 2);
+            for (int r = 0; r < hh; r++, o += c->w_scu) std::fill_n(o, ws, (uint32_t)i);
+        }
+        memcpy(hs + o_own, own.data(), sz_own);
+    }
 
     // pass 2: records + TB scatter into class order
     int cls_fill[NCLS];
@@ -870,7 +884,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     db->d_cus = (CuRec *)(dbase + o_cus); db->d_ctu_start = (uint32_t *)(dbase + o_ctu); db->d_tbs = (TbRec *)(dbase + o_tbs);
     db->d_waves = (TbWave *)(dbase + o_wv); db->d_intra = (IntraRec *)(dbase + o_intra); db->d_intra_deps = (uint32_t *)(dbase + o_deps);
     db->d_aff_items = (AffItem *)(dbase + o_aff); db->d_cpmv = (int16_t *)(dbase + o_cpmv);
-    db->d_dmvr_items = (DmvrItem *)(dbase + o_dmvr); db->d_dmvr_mv = (int16_t *)(dbase + o_dmv);
+    db->d_dmvr_items = (DmvrItem *)(dbase + o_dmvr); db->d_dmvr_mv = (int16_t *)(dbase + o_dmv); db->d_owner = (uint32_t *)(dbase + o_own);
     db->d_coef = (int16_t *)(dbase + o_coef); db->d_resid = (int16_t *)(dbase + o_resid); db->d_intra_done = (uint32_t *)(dbase + o_done);
     // one copy: the staging block has the device layout (a pinned coefficient arena goes from the caller's buffer).  On the upload stream: the
     // copy overlaps the kernels of the pictures before; xgpu_batch_recon makes the kernel stream wait for `uploaded`
@@ -919,12 +933,11 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
     a.cur_y = cur.y; a.cur_u = cur.u; a.cur_v = cur.v;
     a.s_l = c->s_l; a.s_c = c->s_c; a.pic_w = c->sp.width; a.pic_h = c->sp.height;
     a.bd_l = c->sp.bit_depth_luma; a.bd_c = c->sp.bit_depth_chroma;
-    a.log2_ctu = c->sp.log2_ctu; a.w_ctu = c->w_ctu;
     a.regions_x = (c->sp.width + 63) >> 6;
     a.n_regions = a.regions_x * ((c->sp.height + 63) >> 6);
     a.admvp = c->sp.tool_admvp ? 1 : 0;
-    a.cus = db->d_cus; a.ctu_cu_start = db->d_ctu_start; a.resid = db->d_resid;
-    a.maps = c->d_maps; a.w_scu = c->w_scu; a.owner = c->d_owner; a.n_cu = db->n_cu; a.cur_poc = c->fp.poc;
+    a.cus = db->d_cus; a.resid = db->d_resid;
+    a.maps = c->d_maps; a.w_scu = c->w_scu; a.owner = db->d_owner; a.n_cu = db->n_cu; a.cur_poc = c->fp.poc;
     for (int l = 0; l < 2; l++)
         for (int i = 0; i < XGPU_MAX_REFS; i++) {
             const DevPic &rp = i < c->fp.num_refp[l] ? dpic(c, c->fp.refp_pic[i][l]) : dpic(c, c->fp.pic);

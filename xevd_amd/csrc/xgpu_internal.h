@@ -84,15 +84,13 @@ struct InterArgs {
     int      s_l, s_c;                 // all pictures of a ctx share the geometry
     int      pic_w, pic_h;
     int      bd_l, bd_c;
-    int      log2_ctu, w_ctu;
     int      n_regions, regions_x;     // 64x64 luma regions
     int      admvp;
     const CuRec    *cus;
-    const uint32_t *ctu_cu_start;
     const int16_t  *resid;
     ScuRec  *maps;
     int      w_scu;
-    uint16_t *owner;                   // [w_scu * h_scu] index (inside its CTU's list) of the CU covering each SCU, written by k_paint
+    const uint32_t *owner;             // [w_scu * h_scu] batch index of the CU covering each SCU (0xFFFFFFFF: none), painted by xgpu_batch_create
     int      n_cu;
     int      cur_poc;                  // POC of the picture being decoded (DMVR's distance test)
     RefEntry refp[XGPU_MAX_REFS][2];
@@ -210,6 +208,7 @@ struct xgpu_dbatch {
     size_t     n_coef;
     CuRec     *d_cus;
     uint32_t  *d_ctu_start;
+    uint32_t  *d_owner;               // SCU -> CU index of the batch, over the whole picture
     int16_t   *d_coef, *d_resid;
     TbRec     *d_tbs;
     TbWave    *d_waves;
@@ -242,7 +241,6 @@ struct xgpu_ctx {
     size_t          pic_elems, off_u, off_v;
     std::vector<DevPic> pics;
     ScuRec         *d_maps;
-    uint16_t       *d_owner;          // SCU -> CU index inside the CTU, rebuilt per picture by k_paint
     uint8_t        *d_ctb_flag;       // ALF luma CTB flags of the current picture
     std::vector<BatchBlock> pool;     // blocks of destroyed batches, reused by later ones of the same stream (same HIP stream -> ordered)
     uint8_t        *d_out[2];         // packed output pictures (xgpu_pic_output): two in flight, grown on demand
@@ -265,7 +263,7 @@ struct xgpu_ctx {
 
 // kernel launchers (one per .hip file)
 void launch_itdq(xgpu_ctx *c, const ItdqArgs &a);
-void launch_inter(xgpu_ctx *c, const InterArgs &a);      // k_paint + k_inter
+void launch_inter(xgpu_ctx *c, const InterArgs &a);
 void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf);
 void launch_affine(xgpu_ctx *c, const AffineArgs &a);
 void launch_dmvr(xgpu_ctx *c, const DmvrArgs &a);
