@@ -43,6 +43,9 @@ WORKLOADS = {
     # data-flow kernel, which is where the time goes (kernels["intra"])
     "main_8k_10b_ra_htdf": dict(w=7680, h=4320, bd=10, admvp=1, iqt=1, addb=1, alf=1, n_refs=(1, 1), bi_frac=0.5, htdf_qp=32),
     "main_8k_10b_ra_affine30": dict(w=7680, h=4320, bd=10, admvp=1, iqt=1, addb=1, alf=1, n_refs=(1, 1), bi_frac=0.5, affine_frac=0.3),
+    # nor this one: cfg4 as a hierarchical-B picture (list 1 = the picture AFTER it in output order) with 60 % of the plain inter CUs in merge mode
+    # (xgpu_cu_batch.dmvr): the bi-predicted ones of 8x8 and above are refined and predicted by k_dmvr (kernels["dmvr"]), k_inter leaves them out
+    "main_8k_10b_ra_dmvr": dict(w=7680, h=4320, bd=10, admvp=1, iqt=1, addb=1, alf=1, n_refs=(1, 1), bi_frac=0.5, dmvr_frac=0.6),
 }
 DEFAULT_WORKLOAD = "cfg4_main_8k_10b_ra"
 DEFAULT_WORKLOAD_MULTI = "cfg5_main_4k_10b_ra_streams"
@@ -80,6 +83,9 @@ def make_stream(wl, seed, n_batches):
     if wl.get("affine_frac"):
         for b in batches:
             synth.add_affine(rng, b, wl["affine_frac"])
+    if wl.get("dmvr_frac"):
+        for b in batches:
+            synth.add_dmvr(rng, b, wl["dmvr_frac"])
     n_ctu = ((wl["w"] + 63) // 64) * ((wl["h"] + 63) // 64)
     alf = synth.gen_alf_params(rng, n_ctu, ctb_on_frac=1.0) if wl["alf"] else None     # all CTUs on
     return first, batches, alf
@@ -347,7 +353,7 @@ def main():
         cur, ref0, ref1 = slots[(k + 2) % 3], slots[(k + 1) % 3], slots[k % 3]
         refs = {(0, 0): (ref0, k)}
         if two_lists:
-            refs[(0, 1)] = (ref1, k - 1)
+            refs[(0, 1)] = (ref1, k + 2 if wl.get("dmvr_frac") else k - 1)      # DMVR: a B picture between its two references
         dec.decode_picture(cur, k + 1, refs, handles[k % len(handles)], alf=alf)
 
     def barrier():
@@ -415,7 +421,7 @@ def main():
     if rank == 0:
         ab = [algorithmic_bytes(b, wl["w"], wl["h"]) for b in batches]
         kernels = {}
-        for name in ("itdq", "inter", "affine", "intra", "dbk_v", "dbk_h", "alf", "pad"):
+        for name in ("itdq", "inter", "dmvr", "affine", "intra", "dbk_v", "dbk_h", "alf", "pad"):
             ms, n = tim[name]
             if n:
                 kernels[name] = {"avg_us": round(1e3 * ms / n, 2), "launches": int(n)}
@@ -437,7 +443,7 @@ def main():
         except Exception:
             traffic = None
         total_alg = float(np.mean([sum(v for k, v in a.items() if k != "alf" or wl["alf"]) for a in ab]))
-        kern_s = sum(tim[k][0] for k in ("itdq", "inter", "affine", "intra", "dbk_v", "dbk_h", "alf", "pad")) * 1e-3 / args.steps
+        kern_s = sum(tim[k][0] for k in ("itdq", "inter", "dmvr", "affine", "intra", "dbk_v", "dbk_h", "alf", "pad")) * 1e-3 / args.steps
         out = {
             "metric": "frames/sec (bit-exact YUV) + achieved HBM GB/s",
             "value": round(world * args.steps / dt, 2),

@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
-"""profiles/latest_pmc.json from the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KB per dispatch).
-usage: make_pmc_json.py <workload> <fetch.csv> <write.csv> <out.json>
-gfx950 correction (MI355X_MICROARCH.md, HBM/rocprofv3 section; confirmed here on k_copy: 524300 KB counted for a 1 GiB read):
-FETCH_SIZE tallies 16-B/lane reads at half -> doubled; WRITE_SIZE is exact."""
+"""profiles/latest_pmc.json from rocprofv3 --pmc passes (one pass per counter group, no tracing).
+usage: make_pmc_json.py <workload> <rdreq.csv> <wrreq.csv> <out.json> [<fetch_size.csv> <write_size.csv>]
+
+HBM traffic per dispatch from the L2 <-> fabric REQUEST counters, which carry their size:
+    read bytes  = 128 * TCC_EA0_RDREQ_128B + 64 * TCC_EA0_RDREQ_64B + 32 * TCC_EA0_RDREQ_32B      (the three classes partition TCC_EA0_RDREQ)
+    write bytes =  64 * TCC_EA0_WRREQ_64B + 32 * (TCC_EA0_WRREQ - TCC_EA0_WRREQ_64B)
+Checked on the runtime's own copy kernel in the same passes: one 8K 10-bit picture (99 532 800 B) counts 777 600 x 128 B read, 1 555 200 x 64 B
+written - exact.  FETCH_SIZE / WRITE_SIZE (the guide's method: KB per dispatch, FETCH_SIZE doubled on gfx950 because 128-byte requests are
+tallied at 64) are kept next to it when their passes are given: FETCH_SIZE x 2 over-counts kernels that issue 64-byte requests (it doubles those
+too), which is where round 1's "2.16x" ALF traffic came from."""
 import csv
 import json
 import sys
 
 NAMES = {"k_inter(": "inter", "k_alf(": "alf", "k_addb<0>(": "dbk_v", "k_addb<1>(": "dbk_h", "k_dbk<0>(": "dbk_v", "k_dbk<1>(": "dbk_h",
-         "k_itdq(": "itdq", "k_intra<": "intra", "k_affine_": "affine", "k_pad(": "pad"}
+         "k_itdq(": "itdq", "k_intra<": "intra", "k_affine_": "affine", "k_pad(": "pad", "k_dmvr(": "dmvr"}
 
 
 def load(path):
@@ -16,17 +22,30 @@ def load(path):
     for r in csv.DictReader(open(path)):
         for k, v in NAMES.items():
             if k in r["kernel"]:
-                out[v] = out.get(v, 0.0) + float(r["avg"])
+                d = out.setdefault(v, {})
+                d[r["counter"]] = d.get(r["counter"], 0.0) + float(r["avg"])
     return out
 
 
 def main():
-    wl, fpath, wpath, opath = sys.argv[1:5]
-    f, w = load(fpath), load(wpath)
-    kern = {k: {"fetch_kb": round(f.get(k, 0.0), 1), "write_kb": round(w.get(k, 0.0), 1),
-                "traffic_bytes": int((2.0 * f.get(k, 0.0) + w.get(k, 0.0)) * 1024)} for k in sorted(set(f) | set(w))}
-    json.dump({"workload": wl, "source": f"{fpath} + {wpath} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)",
-               "correction": "FETCH_SIZE doubled (gfx950: 16-B/lane reads tallied at half, confirmed on k_copy: 524300 KB for 1 GiB); WRITE_SIZE as is",
+    wl, rpath, wpath, opath = sys.argv[1:5]
+    rd, wr = load(rpath), load(wpath)
+    fs = load(sys.argv[5]) if len(sys.argv) > 6 else {}
+    ws = load(sys.argv[6]) if len(sys.argv) > 6 else {}
+    kern = {}
+    for k in sorted(set(rd) | set(wr)):
+        r, w = rd.get(k, {}), wr.get(k, {})
+        rb = 128 * r.get("TCC_EA0_RDREQ_128B_sum", 0) + 64 * r.get("TCC_EA0_RDREQ_64B_sum", 0) + 32 * r.get("TCC_EA0_RDREQ_32B_sum", 0)
+        wb = 64 * w.get("TCC_EA0_WRREQ_64B_sum", 0) + 32 * (w.get("TCC_EA0_WRREQ_sum", 0) - w.get("TCC_EA0_WRREQ_64B_sum", 0))
+        kern[k] = {"read_bytes": int(rb), "write_bytes": int(wb), "traffic_bytes": int(rb + wb)}
+        if k in fs or k in ws:
+            f, wv = fs.get(k, {}).get("FETCH_SIZE", 0.0), ws.get(k, {}).get("WRITE_SIZE", 0.0)
+            kern[k]["fetch_size_kb"] = round(f, 1)
+            kern[k]["write_size_kb"] = round(wv, 1)
+            kern[k]["traffic_bytes_fetch_size_method"] = int((2.0 * f + wv) * 1024)
+    json.dump({"workload": wl, "source": f"{rpath} + {wpath} (rocprofv3 --pmc, separate passes, no tracing)",
+               "method": "read = 128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B, write = 64*WRREQ_64B + 32*(WRREQ - WRREQ_64B); traffic_bytes_fetch_size_method = "
+                         "(2*FETCH_SIZE + WRITE_SIZE) KB, the guide's gfx950 correction, for comparison",
                "kernels": kern}, open(opath, "w"), indent=1)
     print(json.dumps(kern, indent=1))
 
