@@ -101,6 +101,8 @@ typedef struct xhost_stream_params {
     int cqt_delta_in[2][16];               /* delta_qp_in_val_minus1 (6 bits)                                         */
     int cqt_delta_out[2][16];              /* delta_qp_out_val                                                       */
     int tool_htdf;                         /* sps->tool_htdf: no CU syntax of its own; the parser hands the slice QP to the backend (batch.htdf_slice_qp) */
+    int ibc_log_max_size;                  /* 0: sps->ibc_flag off.  2..7 (needs tool_eipd): intra block copy for CUs up to 2^n samples - a CU of the batch with
+                                              pred_mode XGPU_MODE_IBC is written with ibc_flag and its block vector mv[0] (xevdm_eco.c:1401-1438, 1789-1800)  */
 } xhost_stream_params;
 
 /* ALF parameter set as it is coded in an APS NAL unit (XEVD_ALF_SLICE_PARAM after xevdm_eco_alf_aps_param), no fixed filters */

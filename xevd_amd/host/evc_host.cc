@@ -180,6 +180,7 @@ struct Models {
           intra_dir[2], mvp_idx[3], mvd[1], refi[2], dqp[1], skip[2],
           ats_mode[1], ats_inter_flag[2], ats_inter_quad[1], ats_inter_hor[3], ats_inter_pos[1],      // Main: xevd_def.h:559-563
           alf_ctb[1],
+          ibc_flag[2],                                                                               // sps->ibc_flag: xevd_def.h:485
           ipm_mpm_flag[1], ipm_mpm_idx[1], ipm_chroma[1];                                            // tool_eipd: xevd_def.h intra_luma_pred_mpm_flag / _idx, intra_chroma_pred_mode
     void reset() { Model *p = (Model *)this; for (size_t i = 0; i < sizeof(Models) / sizeof(Model); i++) p[i] = 512; }     // PROB_INIT, xevd_eco.c:769-803
 };
@@ -213,11 +214,12 @@ static void make_zigzag(std::vector<uint16_t> &scan, int w, int h)
     }
 }
 
-enum { MODE_INTRA = XGPU_MODE_INTRA, MODE_INTER = XGPU_MODE_INTER, MODE_SKIP = XGPU_MODE_SKIP };
+enum { MODE_INTRA = XGPU_MODE_INTRA, MODE_INTER = XGPU_MODE_INTER, MODE_SKIP = XGPU_MODE_SKIP, MODE_IBC = XGPU_MODE_IBC };
 
 // ------------------------------------------------------------------------------------------------ stream / picture state
 struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, log2_ref_gap = 0, max_num_ref_pics = 1;
              int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0, tool_alf = 0, tool_eipd = 0, tool_dra = 0, tool_htdf = 0;
+             int ibc = 0, ibc_log_max = 0;            // sps->ibc_flag, sps->ibc_log_max_size (log2 of the largest IBC CU; xevdm_eco.c:1890-1898)
              int crop[4] = { 0, 0, 0, 0 };            // picture_crop_left / right / top / bottom_offset (xevd_eco.c:1349-1357), as xevd_pull reports them
              bool cqt = false; int8_t cq[2][96] = { { 0 } }; };      // chroma QP mapping tables signalled in the SPS: [c][qp + 6*(bd_c-8)], qp = -6*(bd_c-8) .. 57
 struct Pps { int constrained_intra = 0, cu_qp_delta = 0, dra_on = 0, dra_aps_id = 0; };
@@ -265,7 +267,7 @@ struct RefPic {          // what a decoded picture leaves behind for later pictu
 
 struct Cu {
     int x, y, log2w, log2h;
-    int mode;                        // MODE_INTRA / MODE_INTER / MODE_SKIP
+    int mode;                        // MODE_INTRA / MODE_INTER / MODE_SKIP / MODE_IBC (mv[0] = the block vector, whole samples)
     int direct;                      // B slices: temporal direct mode (inter_dir = PRED_DIR), no motion syntax
     int refi[2], mvp_idx[2];
     int16_t mvd[2][2], mv[2][2];
@@ -276,7 +278,7 @@ struct Cu {
 
 struct Picture {         // SCU maps of the picture being parsed / written (ctx->map_scu, map_ipm, map_mv, map_refi; cod_eco)
     int w_scu = 0, h_scu = 0;
-    std::vector<uint8_t> cod, intra;
+    std::vector<uint8_t> cod, intra, ibc;      // ibc: MCU_GET_IBC
     std::vector<int8_t> ipm;
     std::vector<int16_t> mv;         // [f_scu][2][2]
     std::vector<int8_t> refi;        // [f_scu][2]
@@ -284,7 +286,7 @@ struct Picture {         // SCU maps of the picture being parsed / written (ctx-
     {
         w_scu = w >> 2; h_scu = h >> 2;
         const size_t f = (size_t)w_scu * h_scu;
-        cod.assign(f, 0); intra.assign(f, 0); ipm.assign(f, 0); mv.assign(f * 4, 0); refi.assign(f * 2, -1);
+        cod.assign(f, 0); intra.assign(f, 0); ibc.assign(f, 0); ipm.assign(f, 0); mv.assign(f * 4, 0); refi.assign(f * 2, -1);
     }
 };
 
@@ -556,8 +558,10 @@ struct Stream {          // everything both directions share
             cand[k][0] = ok ? pic.mv[(size_t)s * 4 + lidx * 2] : (int16_t)1;
             cand[k][1] = ok ? pic.mv[(size_t)s * 4 + lidx * 2 + 1] : (int16_t)1;
         };
-        take(0, xs > 0 && !pic.intra[scup - 1] && pic.cod[scup - 1], scup - 1);
-        take(1, ys > 0 && !pic.intra[scup - ws], scup - ws);
+        // an intra-block-copy neighbour does not count on the left and above - but does above-right, where the Main library's availability test
+        // only asks "coded and not intra" (xevdm_get_avail_inter, xevdm_util.c:1468-1503): its stored vector is the block vector (list 1: zero)
+        take(0, xs > 0 && !pic.intra[scup - 1] && pic.cod[scup - 1] && !pic.ibc[scup - 1], scup - 1);
+        take(1, ys > 0 && !pic.intra[scup - ws] && !pic.ibc[scup - ws], scup - ws);
         take(2, ys > 0 && xs + scuw < ws && pic.cod[scup - ws + scuw] && !pic.intra[scup - ws + scuw], scup - ws + scuw);
         const RefPic *col = refp[lidx].empty() ? nullptr : refp[lidx][0];
         cand[3][0] = col ? col->mv0[(size_t)scup * 2] : (int16_t)0;
@@ -650,7 +654,7 @@ struct Stream {          // everything both directions share
         const int xs = cu.x >> 2, ys = cu.y >> 2, w = (1 << cu.log2w) >> 2, h = (1 << cu.log2h) >> 2;
         for (int r = 0; r < h; r++) for (int c = 0; c < w; c++) {
             const size_t k = (size_t)(ys + r) * pic.w_scu + xs + c;
-            pic.cod[k] = 1; pic.intra[k] = cu.mode == MODE_INTRA; pic.ipm[k] = (int8_t)cu.ipm;
+            pic.cod[k] = 1; pic.intra[k] = cu.mode == MODE_INTRA; pic.ibc[k] = cu.mode == MODE_IBC; pic.ipm[k] = (int8_t)cu.ipm;
             for (int l = 0; l < 2; l++) { pic.refi[k * 2 + l] = (int8_t)cu.refi[l]; pic.mv[k * 4 + l * 2] = cu.mv[l][0]; pic.mv[k * 4 + l * 2 + 1] = cu.mv[l][1]; }
         }
     }
@@ -709,8 +713,23 @@ struct Stream {          // everything both directions share
         }
         int intra = 1;
         if (inter_slice) intra = c.bin(cu.mode == MODE_INTRA, models.pred_mode[0]);
-        if (!enc) { cu.mode = intra ? MODE_INTRA : MODE_INTER; cu.direct = 0; }
-        if (!intra) {
+        // xevdm_eco_pred_mode (xevdm_eco.c:1401-1438): with sps->ibc_flag every CU up to the IBC size limit that is not already known to be
+        // intra-predicted carries ibc_flag - in I slices all of them (mode constraint eOnlyIntra: no pred_mode_flag); context 0 without cm_init
+        int ibc = 0;
+        if (sps.ibc && cu.log2w <= sps.ibc_log_max && cu.log2h <= sps.ibc_log_max && !(inter_slice && intra))
+            ibc = c.bin(cu.mode == MODE_IBC, models.ibc_flag[0]);
+        if (!enc) { cu.mode = ibc ? MODE_IBC : intra ? MODE_INTRA : MODE_INTER; cu.direct = 0; }
+        if (ibc) {
+            // the block vector itself is sent as a motion vector difference (xevdm_eco.c:1789-1800); no references, no predictor
+            intra = 0;
+            cu.refi[0] = cu.refi[1] = -1; cu.mv[1][0] = cu.mv[1][1] = 0; cu.direct = 0;
+            for (int d = 0; d < 2; d++) {
+                const int v = cu.mv[0][d], a = sym_abs_mvd(c, v < 0 ? -v : v, models.mvd[0]);
+                int sg = v < 0;
+                if (a) sg = c.ep(sg);
+                cu.mv[0][d] = (int16_t)(sg ? -a : a);
+            }
+        } else if (!intra) {
             // xevd_eco.c:1120-1148: B: direct_mode_flag, else inter_pred_idc; per list in use: ref index, predictor index, mvd; mv = mvp + mvd (xevd.c:533-556)
             int dir = 0;                                             // PRED_L0 0, PRED_L1 1, PRED_BI 2
             if (n_lists == 2) cu.direct = c.bin(cu.direct, models.direct[0]);
@@ -827,7 +846,7 @@ struct Stream {          // everything both directions share
                 cu.ats = on | (mv << 1) | (mh << 2);
             } else cu.ats = 0;
             const int w = 1 << cu.log2w, h = 1 << cu.log2h;
-            const int avail = (intra || w > 64 || h > 64) ? 0 : ((w >= 8) | ((h >= 8) << 1) | ((w >= 16) << 2) | ((h >= 16) << 3));      // xevdm_util.c:3565-3583
+            const int avail = (intra || ibc || w > 64 || h > 64) ? 0 : ((w >= 8) | ((h >= 8) << 1) | ((w >= 16) << 2) | ((h >= 16) << 3));      // xevdm_util.c:3565-3583
             cu.ats_inter = avail ? code_ats_inter(c, cu.ats_inter, avail) : 0;
             const int idx = cu.ats_inter & 15;
             if (idx == 1 || idx == 3) tlw -= idx == 3 ? 2 : 1;
@@ -916,7 +935,8 @@ struct xhost_parser {
             unsupported |= br.get1();                    // sps_suco_flag
             unsupported |= br.get1();                    // tool_admvp
             s.tool_eipd = br.get1();
-            if (s.tool_eipd) unsupported |= br.get1();   // ibc_flag
+            s.ibc = s.ibc_log_max = 0;
+            if (s.tool_eipd && (s.ibc = br.get1())) { s.ibc_log_max = (int)br.ue() + 2; if (s.ibc_log_max > 7) return fail("bad SPS"); }
             unsupported |= br.get1();                    // tool_cm_init
             s.tool_iqt = br.get1();
             if (s.tool_iqt) s.tool_ats = br.get1();
@@ -928,7 +948,7 @@ struct xhost_parser {
             unsupported |= br.get1();                    // dquant_flag: the Main decoder then codes QP deltas per cu_qp_delta_area (xevdm_eco.c), not per CU
             s.tool_dra = br.get1();
         }
-        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, admvp, ibc, cm_init, rpl, pocs, dquant in Main)");
+        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, admvp, cm_init, rpl, pocs, dquant in Main)");
         s.log2_sub_gop = (int)br.ue();                   // tool_rpl = tool_pocs = 0
         if (s.log2_sub_gop == 0) s.log2_ref_gap = (int)br.ue();
         if (s.log2_sub_gop > 5) return fail("bad SPS");
@@ -1253,7 +1273,7 @@ struct xhost_writer {
         else {
             for (int i = 0; i < 3; i++) bw.put1(0);      // btt suco admvp
             bw.put1(sp.tool_eipd ? 1 : 0);
-            if (sp.tool_eipd) bw.put1(0);                // ibc_flag
+            if (sp.tool_eipd) { bw.put1(sp.ibc_log_max_size ? 1 : 0); if (sp.ibc_log_max_size) bw.ue((uint32_t)(sp.ibc_log_max_size - 2)); }      // ibc_flag, ibc_log_max_size - 2
             bw.put1(0);                                  // cm_init
             bw.put1(sp.tool_iqt ? 1 : 0);
             if (sp.tool_iqt) bw.put1(sp.tool_ats ? 1 : 0);
@@ -1313,6 +1333,8 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     w->sp.tool_iqt = s.tool_iqt; w->sp.tool_ats = s.tool_ats; w->sp.tool_addb = s.tool_addb; w->sp.tool_alf = s.tool_alf; w->sp.tool_eipd = s.tool_eipd;
     w->sp.tool_dra = s.profile_main && sp->tool_dra; s.tool_dra = w->sp.tool_dra;
     w->sp.tool_htdf = s.profile_main && sp->tool_htdf; s.tool_htdf = w->sp.tool_htdf;
+    w->sp.ibc_log_max_size = (s.tool_eipd && sp->ibc_log_max_size >= 2 && sp->ibc_log_max_size <= 7) ? sp->ibc_log_max_size : 0;
+    s.ibc = w->sp.ibc_log_max_size != 0; s.ibc_log_max = w->sp.ibc_log_max_size;
     w->st.pps.cu_qp_delta = sp->cu_qp_delta;
     return w;
 }
@@ -1420,7 +1442,9 @@ struct TreeWriter {
         memset(&cu, 0, sizeof(cu));
         cu.x = x; cu.y = y; cu.log2w = cu.log2h = log2s;
         cu.mode = b->pred_mode[i] == XGPU_MODE_INTRA ? MODE_INTRA : (b->pred_mode[i] == XGPU_MODE_SKIP ? MODE_SKIP : MODE_INTER);
+        const bool ibc = b->pred_mode[i] == XGPU_MODE_IBC && st.sps.ibc && log2s <= st.sps.ibc_log_max;
         if (st.sh.type == XHOST_SLICE_I) cu.mode = MODE_INTRA;
+        if (ibc) cu.mode = MODE_IBC;
         cu.direct = st.sh.type == XHOST_SLICE_B && b->pred_mode[i] == XGPU_MODE_DIR;
         for (int l = 0; l < 2; l++) {
             const int nref = (int)st.refp[l].size();
@@ -1429,6 +1453,7 @@ struct TreeWriter {
         }
         if (cu.mode == MODE_INTER && cu.refi[0] < 0 && cu.refi[1] < 0) cu.refi[0] = 0;
         if (st.sh.type == XHOST_SLICE_P) { cu.refi[1] = -1; if (cu.refi[0] < 0) cu.refi[0] = 0; }
+        if (ibc) { cu.refi[0] = cu.refi[1] = -1; cu.mv[1][0] = cu.mv[1][1] = 0; }
         cu.mvp_idx[0] = (x >> 2) & 3; cu.mvp_idx[1] = (y >> 2) & 3;   // a SKIP CU: some predictor per list
         cu.ipm = b->ipm ? b->ipm[i * 2] % (st.sps.tool_eipd ? 33 : 5) : 0;
         cu.ipm_c = (b->ipm && st.sps.tool_eipd) ? b->ipm[i * 2 + 1] % 5 : 0;
@@ -1457,9 +1482,10 @@ struct TreeWriter {
             }
             coef[k] = blk[k].data();
         }
-        if (cu.mode == MODE_INTER && !(cu.cbf[0] | cu.cbf[1] | cu.cbf[2])) { /* all-zero flag path */ }
-        else if (cu.mode == MODE_INTER && cu.cbf[1] + cu.cbf[2] == 0) cu.cbf[0] = 1;      // implied luma cbf needs a luma coefficient
-        if (cu.mode == MODE_INTER && cu.cbf[0]) { bool nz = false; for (int16_t v : blk[0]) nz |= v != 0; if (!nz) blk[0][0] = 1; }
+        const bool cbf_all_path = cu.mode == MODE_INTER || cu.mode == MODE_IBC;          // eco_cbf's non-intra branch
+        if (cbf_all_path && !(cu.cbf[0] | cu.cbf[1] | cu.cbf[2])) { /* all-zero flag path */ }
+        else if (cbf_all_path && cu.cbf[1] + cu.cbf[2] == 0) cu.cbf[0] = 1;      // implied luma cbf needs a luma coefficient
+        if (cbf_all_path && cu.cbf[0]) { bool nz = false; for (int16_t v : blk[0]) nz |= v != 0; if (!nz) blk[0][0] = 1; }
         st.code_cu(*enc, cu, coef, true);
         st.commit(cu);
     }

@@ -345,7 +345,7 @@ def add_dmvr(rng, batch, frac=0.6, mirror_frac=0.5):
 MODE_IBC = 6
 
 
-def add_ibc(rng, batch, width, height, log2_ctu=6, frac=0.3):
+def add_ibc(rng, batch, width, height, log2_ctu=6, frac=0.3, max_log2=6):
     """Turn a share of the CUs into intra-block-copy CUs (Main, xevdm_IBC_mc): pred_mode 6, mv[0] = a whole-sample block vector into the part of
     the CURRENT picture that is already reconstructed when the CU's turn comes - CTU rows above, CTUs to the left in the same row, or an earlier,
     larger CU of the same CTU (decoding order = batch order).  Odd vectors included (chroma uses the halved vector)."""
@@ -358,7 +358,7 @@ def add_ibc(rng, batch, width, height, log2_ctu=6, frac=0.3):
     aff = batch.get("affine")
     pick = rng.random(n) < frac
     for i in range(n):
-        if not pick[i] or (ai is not None and ai[i]) or (w[i] > 64 or h[i] > 64):
+        if not pick[i] or (ai is not None and ai[i]) or (w[i] > (1 << max_log2) or h[i] > (1 << max_log2)):
             continue
         opts = []
         cy0, cx0 = (y[i] // S) * S, (x[i] // S) * S
