@@ -249,6 +249,13 @@ int xgpu_test_mc_l(xgpu_ctx *ctx, const int16_t *ref_plane, int plane_w, int pla
 int xgpu_test_mc_c(xgpu_ctx *ctx, const int16_t *ref_plane, int plane_w, int plane_h, int ref_x, int ref_y,
                    int has_dx, int has_dy, int gmv_x, int gmv_y, int16_t *pred, int w, int h, int bit_depth);
 /* residual arena of a batch after xgpu_batch_recon (what xevd_sub_block_itdq leaves in core->coef), n_coef s16   */
+/* fn_recon (src_base/xevd_def.h:1466; xevd_recon, xevd_recon.c:35-71): rec[cuh][s_rec] = clip(pred + coef) or pred, through the kernels' residual add */
+int xgpu_test_recon(xgpu_ctx *ctx, const int16_t *coef, const int16_t *pred, int is_coef, int cuw, int cuh, int s_rec, int16_t *rec, int bit_depth);
+/* fn_dbk / fn_dbk_chroma (XEVD_DBK / XEVD_DBK_CH, src_base/xevd_def.h:363-364; deblock_scu_hor / _ver[_chroma], xevd_df.c:96-289): ONE 4-sample (chroma:
+   2-sample) edge segment of a host plane of pw x ph samples through the kernels' line filters, in place; (x, y) = first sample on the far side of the
+   edge, hor = the edge is horizontal, st = the strength from xevd_tbl_df_st (0 leaves a chroma plane untouched) */
+int xgpu_test_dbk(xgpu_ctx *ctx, int16_t *plane, int pw, int ph, int x, int y, int st, int hor, int bit_depth);
+int xgpu_test_dbk_chroma(xgpu_ctx *ctx, int16_t *u, int16_t *v, int pw, int ph, int x, int y, int st_u, int st_v, int hor, int bit_depth);
 int xgpu_test_batch_resid(xgpu_ctx *ctx, xgpu_dbatch *db, int16_t *resid);
 /* dequant + 2-D inverse transform of n blocks of one size, in place (xevd_itdq, src_base/xevd_itdq.c:494) */
 int xgpu_test_itdq(xgpu_ctx *ctx, int16_t *coef, int n_blocks, int log2w, int log2h, const uint8_t *qp, int bit_depth);

@@ -105,7 +105,7 @@ typedef struct xhost_stream_params {
                                               pred_mode XGPU_MODE_IBC is written with ibc_flag and its block vector mv[0] (xevdm_eco.c:1401-1438, 1789-1800)  */
 } xhost_stream_params;
 
-/* ALF parameter set as it is coded in an APS NAL unit (XEVD_ALF_SLICE_PARAM after xevdm_eco_alf_aps_param), no fixed filters */
+/* ALF parameter set as it is coded in an APS NAL unit (XEVD_ALF_SLICE_PARAM after xevdm_eco_alf_aps_param) */
 typedef struct xhost_alf_aps {
     int aps_id;                            /* 0..31                                                                 */
     int luma_present, chroma_present;      /* alf_luma_filter_signal_flag / alf_chroma_filter_signal_flag            */
@@ -116,6 +116,10 @@ typedef struct xhost_alf_aps {
     uint8_t filter_coef_flag[25];          /* with coef_delta_flag: which filters carry coefficients                */
     int16_t luma_coef[25][12];             /* coded values (differences with pred_mode_flag)                        */
     int16_t chroma_coef[6];
+    /* fixed filter sets (alf_luma_fixed_filter_usage_pattern, xevdm_eco.c:2436-2466): 0 = none, 1 = every class starts from one of its 16 fixed
+       filters, 2 = the classes flagged in fixed_filter_usage; fixed_filter_idx 0..15 selects the filter (alf_class_to_filter_mapping) */
+    int fixed_filter_pattern;
+    uint8_t fixed_filter_usage[25], fixed_filter_idx[25];
 } xhost_alf_aps;
 /* DRA parameter set as an APS NAL unit of type 1 carries it (SIG_PARAM_DRA, src_main/xevdm_dra.h:76-89; descriptors 4.9 fixed point) */
 typedef struct xhost_dra_aps {

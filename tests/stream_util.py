@@ -26,7 +26,7 @@ def gop_tids(log2_sub_gop):
 def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_frac=0.15, inter_frac=0.85, deblock=True, qp_offsets=(0, 0),
                 cu_qp_delta=True, split_prob=0.5, idr_period=0, log2_sub_gop=0, bi_frac=0.5, direct_frac=0.1,
                 main=False, iqt=False, ats=False, addb=False, addb_offsets=(0, 0), alf=False, sign=False, eipd=False, crop=(0, 0, 0, 0),
-                chroma_qp_points=None, dra=None, htdf=False, ibc_log_max=0, ibc_frac=0.25):
+                chroma_qp_points=None, dra=None, htdf=False, ibc_log_max=0, ibc_frac=0.25, alf_fixed=False):
     """-> bytes.  Picture 0 is an IDR.  log2_sub_gop = 0: IPPP; n: hierarchical sub-GOPs of 2^n pictures, the layer-0 picture of
     each a P picture, the others B pictures (bi-prediction, temporal direct and two-list skip CUs).
     sign: every picture is followed by a picture-signature SEI with the MD5s of the ORACLE's reconstruction of the stream so far."""
@@ -68,7 +68,8 @@ def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_fra
                     t7 = bool(rng.integers(0, 2))
                     w.add_alf_aps(k % 32, luma=rng.integers(-12, 13, (nf, 12 if t7 else 6)), chroma=rng.integers(-10, 11, 6), type7=t7,
                                   delta_idx=rng.integers(0, nf, 25), coef_delta_flag=int(nf > 1 and rng.random() < 0.4),
-                                  pred_mode_flag=int(rng.random() < 0.5), filter_coef_flag=np.maximum(rng.integers(0, 2, 25), np.arange(25) == 0))
+                                  pred_mode_flag=int(rng.random() < 0.5), filter_coef_flag=np.maximum(rng.integers(0, 2, 25), np.arange(25) == 0),
+                                  fixed_pattern=(k // 2) % 3 if alf_fixed else 0, fixed_usage=rng.integers(0, 2, 25), fixed_idx=rng.integers(0, 16, 25))
                     last_aps = k % 32
                 mode = k % 5
                 w.set_slice_alf(mode != 3, last_aps, last_aps, chroma_idc=int(rng.integers(0, 4)),

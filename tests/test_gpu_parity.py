@@ -47,6 +47,39 @@ def test_gpu_itdq_blocks_golden(decs):
         assert np.array_equal(out, d["resid"][off:off + n]), (iqt, bd, log2w, log2h, qp)
 
 
+def test_gpu_fine_grained_recon_and_deblock_shims(decs):
+    """The remaining per-block slots of the reference's function table - fn_recon, fn_dbk[HOR / VER], fn_dbk_chroma[HOR / VER] (src_base/xevd_def.h:
+    363-364, 1466-1468) - through the kernels' own residual add and line filters, against the oracle's xevd_recon / deblock_scu_* (which
+    tests/test_oracle_vs_ref.py pins to the reference's functions): sums that wrap in s16, strengths 0..12 scaled by the bit depth."""
+    import ctypes as C
+    import oracle_lib as ol
+    orc = ol.oracle()
+    dec = decs[(0, 0)]
+    rng = np.random.default_rng(31)
+    for bd in (8, 10):
+        for is_coef in (0, 1):
+            for (w, h) in ((16, 8), (4, 4), (64, 32), (2, 2)):
+                pred = rng.integers(0, 1 << bd, (h, w)).astype(np.int16)
+                coef = rng.integers(-32768, 32768, (h, w)).astype(np.int16)
+                exp = rng.integers(0, 100, (h, w + 24)).astype(np.int16)
+                got = dec.test_recon(coef, pred, is_coef, exp, bd)
+                orc.orc_recon(coef.ctypes.data, pred.ctypes.data, is_coef, w, h, w + 24, exp.ctypes.data, bd)
+                assert np.array_equal(got, exp), (bd, is_coef, w, h)
+        for trial in range(60):
+            st = int(rng.integers(1, 13)) << (bd - 8)
+            base = rng.integers(0, 1 << bd)
+            blk = np.clip(base + rng.integers(-40, 41, (12, 12)) * (1 << (bd - 8)), 0, (1 << bd) - 1).astype(np.int16)
+            for is_ver in (0, 1):
+                exp = blk.copy()
+                orc.orc_dbk_luma(C.c_void_p(exp.ctypes.data + 2 * (4 * 12 + 4)), st, 12, bd, is_ver)
+                assert np.array_equal(dec.test_dbk(blk, 4, 4, st, not is_ver, bd), exp), (bd, st, is_ver)
+                eu, ev = blk.copy(), blk.T.copy()
+                st_u, st_v = int(rng.integers(0, 13)) << (bd - 8), int(rng.integers(0, 13)) << (bd - 8)
+                orc.orc_dbk_chroma(C.c_void_p(eu.ctypes.data + 2 * (4 * 12 + 4)), C.c_void_p(ev.ctypes.data + 2 * (4 * 12 + 4)), st_u, st_v, 12, bd, is_ver)
+                gu, gv = dec.test_dbk(blk, 4, 4, st_u, not is_ver, bd, plane_v=blk.T.copy(), st_v=st_v)
+                assert np.array_equal(gu, eu) and np.array_equal(gv, ev), (bd, st_u, st_v, is_ver)
+
+
 def test_gpu_itdq_many_blocks_per_wave(decs):
     """several TBs share a wave (64/W per wave): every block of a batch must come out like its golden twin"""
     d = np.load(os.path.join(golden_io.GOLDEN, "blocks_itdq.npz"))

@@ -54,6 +54,9 @@ CONFIGS = [
     # tool_htdf: every intra CU and every coded inter CU is filtered after its reconstruction - the real decoder against parser + oracle
     (136, 72, 3, dict(main=True, htdf=True, inter_frac=0.6)),
     (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, inter_frac=0.6, log2_sub_gop=2, max_refs=2, bit_depth=10)),
+    # ALF parameter sets that start from the standard's fixed filters (usage pattern 1: every class, 2: flagged classes; 4-bit set index per class)
+    (264, 136, 8, dict(main=True, alf=True, addb=True, alf_fixed=True)),
+    (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, alf_fixed=True, log2_sub_gop=2, max_refs=2, bit_depth=10)),
     # sps->ibc_flag: ibc_flag + block-vector syntax in I / P / B slices (size limits 8 .. 64), the above-right neighbour quirk of the Main library's
     # predictor availability included (an IBC CU above-right lends its block vector as a motion vector predictor, xevdm_util.c:1499-1503)
     (136, 72, 3, dict(main=True, eipd=True, ibc_log_max=4, idr_period=1)),

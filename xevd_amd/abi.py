@@ -177,6 +177,9 @@ _EXPORTS = {
     "xgpu_test_mc_l": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p] + [C.c_int] * 3),
     "xgpu_test_mc_c": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p] + [C.c_int] * 3),
     "xgpu_test_batch_resid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "xgpu_test_recon": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int]),
+    "xgpu_test_dbk": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 7),
+    "xgpu_test_dbk_chroma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8),
     "xgpu_test_itdq": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]),
 }
 

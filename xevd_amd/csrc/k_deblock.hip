@@ -243,3 +243,33 @@ void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const
     else
         hipLaunchKernelGGL(k_dbk<1>, dim3(tiles), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// fine-grained shims: one edge segment through the kernels' own line filters with the call shape of the reference's
+// XEVD_DBK / XEVD_DBK_CH table entries (src_base/xevd_def.h:363-364; deblock_scu_hor / _ver[_chroma], xevd_df.c:96-289).
+// `buf` = the first sample on the far side of the edge; hor: the edge is horizontal (the filter runs down a column).
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_test_dbk(int16_t *buf, int16_t *buf_v, int st, int st_v, int stride, int bd, int hor, int chroma)
+{
+    const int i = threadIdx.x, maxv = (1 << bd) - 1;
+    const int step = hor ? stride : 1, line = hor ? 1 : stride;              // along the filter / from line to line
+    if (!chroma) {
+        if (i >= 4) return;
+        int16_t *p = buf + i * line;
+        const Line4 o = filt_luma(Line4{ p[-2 * step], p[-step], p[0], p[step] }, st, maxv);
+        p[-2 * step] = (int16_t)o.A; p[-step] = (int16_t)o.B; p[0] = (int16_t)o.C; p[step] = (int16_t)o.D;
+    } else {
+        if (i >= 4) return;                                                   // lanes 0,1: Cb; 2,3: Cr
+        int16_t *p = (i < 2 ? buf : buf_v) + (i & 1) * line;
+        const int s = i < 2 ? st : st_v;
+        if (!s) return;
+        int B, C;
+        filt_chroma(p[-2 * step], p[-step], p[0], p[step], s, maxv, B, C);
+        p[-step] = (int16_t)B; p[0] = (int16_t)C;
+    }
+}
+void launch_test_dbk(xgpu_ctx *c, int16_t *buf, int16_t *buf_v, int st, int st_v, int stride, int bd, int hor, int chroma)
+{
+    hipLaunchKernelGGL(k_test_dbk, dim3(1), dim3(64), 0, c->stream, buf, buf_v, st, st_v, stride, bd, hor, chroma);
+}
+

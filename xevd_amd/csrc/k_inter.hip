@@ -512,3 +512,21 @@ void launch_test_mc(xgpu_ctx *c, const int16_t *plane, int stride, int ref_x, in
     hipLaunchKernelGGL(k_test_mc, dim3((n + 63) / 64), dim3(64), 0, c->stream, plane, stride, ref_x, ref_y, has_dx, has_dy,
                        gmv_x, gmv_y, pred, w, h, bd, luma, c->sp.tool_admvp);
 }
+
+// fn_recon's call shape (src_base/xevd_def.h:1466, xevd_recon, xevd_recon.c:35-71) on the kernels' packed residual add: rec = clip(pred + coef)
+// with the 16-bit wrap of the reference's s16 sum, or the prediction itself when the block has no coefficients.  One lane per sample pair.
+__global__ void k_test_recon(const int16_t *coef, const int16_t *pred, int is_coef, int cuw, int cuh, int16_t *rec, int s_rec, int bd)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, pw = cuw >> 1;
+    if (i >= pw * cuh) return;
+    const int y = i / pw, x = (i - y * pw) * 2;
+    const uint32_t p = *(const uint32_t *)(pred + y * cuw + x);
+    const uint32_t r = is_coef ? recon2(p, *(const uint32_t *)(coef + y * cuw + x), (1 << bd) - 1) : p;
+    rec[y * s_rec + x] = (int16_t)(r & 0xFFFF); rec[y * s_rec + x + 1] = (int16_t)(r >> 16);
+}
+void launch_test_recon(xgpu_ctx *c, const int16_t *coef, const int16_t *pred, int is_coef, int cuw, int cuh, int16_t *rec, int s_rec, int bd)
+{
+    const int n = (cuw >> 1) * cuh;
+    hipLaunchKernelGGL(k_test_recon, dim3((n + 63) / 64), dim3(64), 0, c->stream, coef, pred, is_coef, cuw, cuh, rec, s_rec, bd);
+}
+

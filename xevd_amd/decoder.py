@@ -229,6 +229,25 @@ class XgpuDecoder:
                      pred.ctypes.data, w, h, bit_depth), "xgpu_test_mc")
         return pred
 
+    def test_recon(self, coef, pred, is_coef, rec, bit_depth):
+        """fn_recon's shape: coef / pred [cuh][cuw], rec [cuh][s_rec] (only its first cuw columns are written) -> rec"""
+        coef, pred = np.ascontiguousarray(coef, np.int16), np.ascontiguousarray(pred, np.int16)
+        rec = np.ascontiguousarray(rec, np.int16).copy()
+        self._chk(self.lib.xgpu_test_recon(self.ctx, coef.ctypes.data, pred.ctypes.data, int(is_coef), pred.shape[1], pred.shape[0], rec.shape[1],
+                                           rec.ctypes.data, bit_depth), "xgpu_test_recon")
+        return rec
+
+    def test_dbk(self, plane, x, y, st, hor, bit_depth, plane_v=None, st_v=0):
+        """fn_dbk / fn_dbk_chroma's shape on one edge segment of a small plane (both chroma planes when plane_v is given) -> filtered plane(s)"""
+        plane = np.ascontiguousarray(plane, np.int16).copy()
+        if plane_v is None:
+            self._chk(self.lib.xgpu_test_dbk(self.ctx, plane.ctypes.data, plane.shape[1], plane.shape[0], x, y, st, int(hor), bit_depth), "xgpu_test_dbk")
+            return plane
+        plane_v = np.ascontiguousarray(plane_v, np.int16).copy()
+        self._chk(self.lib.xgpu_test_dbk_chroma(self.ctx, plane.ctypes.data, plane_v.ctypes.data, plane.shape[1], plane.shape[0], x, y, st, st_v, int(hor),
+                                                bit_depth), "xgpu_test_dbk_chroma")
+        return plane, plane_v
+
     def test_itdq(self, coef, log2w, log2h, qp, bit_depth):
         coef = np.ascontiguousarray(coef, np.int16).copy()
         qp = np.ascontiguousarray(qp, np.uint8)

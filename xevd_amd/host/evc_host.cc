@@ -8,6 +8,7 @@
 // batch that xgpu_batch_create takes; the reference's two passes over XEVD_CU_DATA (xevd_tile_eco, then xevd_ctu_row_rec_mt)
 // see the same neighbour state because both walk the CUs in the same order and "reconstructed" (COD) == "already parsed".
 #include "../../include/xevd_host.h"
+#include "alf_fixed_tables.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -235,6 +236,8 @@ struct AlfAps {
     bool valid = false;
     int luma_present = 0, chroma_present = 0, type7 = 0, num_filters = 1, coef_delta_flag = 0, pred_mode_flag = 0;
     uint8_t delta_idx[25] = { 0 }, filter_coef_flag[25] = { 0 };
+    int fixed_pattern = 0;                                        // alf_luma_fixed_filter_usage_pattern: 0 none, 1 every class, 2 per-class flags
+    uint8_t fixed_usage[25] = { 0 }, fixed_idx[25] = { 0 };      // which classes start from a fixed filter, and which of the class's 16
     int16_t luma[25][13] = { { 0 } }, chroma[7] = { 0 };
 };
 // alfGolombDecode / its inverse (xevdm_eco.c:2154-2187): q zeros, a one, q + k suffix bits, sign bit (1 = positive) for non-zero values
@@ -407,7 +410,9 @@ struct Stream {          // everything both directions share
             int sum = 0;
             for (int i = 0; i < 12; i++) {
                 const int pos = k_alf_to_large[y.type7][i];
-                alf_luma_final[c][i] = pos > 0 ? coef[y.delta_idx[c]][pos - 1] : (int16_t)0;
+                // the class's fixed filter (one of the 16 its class may use), plus the coded coefficient (alf_recon_coef, xevdm_alf.c:724-752)
+                const int fixed = y.fixed_usage[c] ? k_alf_fixed_coef[k_alf_class_to_fixed[c][y.fixed_idx[c] & 15]][i] : 0;
+                alf_luma_final[c][i] = (int16_t)(fixed + (pos > 0 ? coef[y.delta_idx[c]][pos - 1] : 0));
                 sum += alf_luma_final[c][i] * 2;
             }
             alf_luma_final[c][12] = (int16_t)(512 - sum);
@@ -445,7 +450,14 @@ struct Stream {          // everything both directions share
                         if (a.delta_idx[c] >= a.num_filters) return false;
                     }
                 } else memset(a.delta_idx, 0, sizeof(a.delta_idx));
-                if (gol(0, 0, false) != 0) return false;                  // alf_luma_fixed_filter_usage_pattern: fixed filter sets are not supported
+                // fixed filter sets (xevdm_eco.c:2436-2466): pattern, per-class usage flags with pattern 2, a 4-bit set index per using class
+                a.fixed_pattern = gol(a.fixed_pattern, 0, false);
+                if (a.fixed_pattern < 0 || a.fixed_pattern > 2) return false;
+                for (int c = 0; c < 25; c++) a.fixed_usage[c] = (uint8_t)(a.fixed_pattern == 2 ? bit(a.fixed_usage[c]) : a.fixed_pattern == 1);
+                for (int c = 0; c < 25; c++) {
+                    if (!a.fixed_usage[c]) { a.fixed_idx[c] = 0; continue; }
+                    if (WR) bw->put(a.fixed_idx[c] & 15, 4); else a.fixed_idx[c] = (uint8_t)br->get(4);
+                }
                 a.coef_delta_flag = bit(a.coef_delta_flag);
                 a.pred_mode_flag = (!a.coef_delta_flag && a.num_filters > 1) ? bit(a.pred_mode_flag) : 0;
                 type7 = a.type7;
@@ -1222,7 +1234,7 @@ static int parser_nal(xhost_parser *p, const uint8_t *nal, size_t len, xhost_pic
         }
         if (type != 0) return p->fail("unknown APS type");
         AlfAps a;
-        if (!p->st.alf_aps_syntax<false>(&br, nullptr, a)) return p->fail("bad or unsupported ALF APS (fixed filter sets are not supported)");
+        if (!p->st.alf_aps_syntax<false>(&br, nullptr, a)) return p->fail("bad ALF APS");
         a.valid = true;
         p->st.alf_aps[id] = a;
         return XGPU_OK;
@@ -1379,6 +1391,8 @@ extern "C" int xhost_writer_add_alf_aps(xhost_writer *w, const xhost_alf_aps *in
     for (int c = 0; c < 25; c++) { a.delta_idx[c] = (uint8_t)(in->delta_idx[c] % a.num_filters); a.filter_coef_flag[c] = in->filter_coef_flag[c] != 0; }
     for (int f = 0; f < 25; f++) for (int i = 0; i < 12; i++) a.luma[f][i] = in->luma_coef[f][i];
     for (int i = 0; i < 6; i++) a.chroma[i] = in->chroma_coef[i];
+    a.fixed_pattern = in->fixed_filter_pattern < 0 || in->fixed_filter_pattern > 2 ? 0 : in->fixed_filter_pattern;
+    for (int c = 0; c < 25; c++) { a.fixed_usage[c] = (uint8_t)(a.fixed_pattern == 1 || (a.fixed_pattern == 2 && in->fixed_filter_usage[c])); a.fixed_idx[c] = (uint8_t)(in->fixed_filter_idx[c] & 15); }
     BitWriter bw;
     bw.put((uint32_t)in->aps_id, 5); bw.put(0, 3);
     AlfAps coded = a;

@@ -25,7 +25,8 @@ class StreamParams(C.Structure):
 class AlfAps(C.Structure):
     _fields_ = [("aps_id", C.c_int), ("luma_present", C.c_int), ("chroma_present", C.c_int), ("luma_type_7x7", C.c_int),
                 ("num_luma_filters", C.c_int), ("delta_idx", C.c_uint8 * 25), ("coef_delta_flag", C.c_int), ("pred_mode_flag", C.c_int),
-                ("filter_coef_flag", C.c_uint8 * 25), ("luma_coef", (C.c_int16 * 12) * 25), ("chroma_coef", C.c_int16 * 6)]
+                ("filter_coef_flag", C.c_uint8 * 25), ("luma_coef", (C.c_int16 * 12) * 25), ("chroma_coef", C.c_int16 * 6),
+                ("fixed_filter_pattern", C.c_int), ("fixed_filter_usage", C.c_uint8 * 25), ("fixed_filter_idx", C.c_uint8 * 25)]
 
 
 class SliceAlf(C.Structure):
@@ -122,8 +123,9 @@ class StreamWriter:
         if rc != 0:
             raise RuntimeError(f"xhost_writer_add_dra_aps -> {rc}")
 
-    def add_alf_aps(self, aps_id, luma=None, chroma=None, type7=True, delta_idx=None, coef_delta_flag=0, pred_mode_flag=0, filter_coef_flag=None):
-        """luma: [n_filters][12 or 6] coded coefficient values or None; chroma: [6] or None"""
+    def add_alf_aps(self, aps_id, luma=None, chroma=None, type7=True, delta_idx=None, coef_delta_flag=0, pred_mode_flag=0, filter_coef_flag=None,
+                    fixed_pattern=0, fixed_usage=None, fixed_idx=None):
+        """luma: [n_filters][12 or 6] coded coefficient values or None; chroma: [6] or None; fixed_pattern 0 / 1 / 2 with per-class usage flags and set indices 0..15"""
         a = AlfAps()
         a.aps_id, a.luma_present, a.chroma_present, a.luma_type_7x7 = aps_id, int(luma is not None), int(chroma is not None), int(type7)
         a.num_luma_filters = 1 if luma is None else len(luma)
@@ -131,6 +133,10 @@ class StreamWriter:
         for c in range(25):
             a.delta_idx[c] = 0 if delta_idx is None else int(delta_idx[c])
             a.filter_coef_flag[c] = 1 if filter_coef_flag is None else int(filter_coef_flag[c])
+        a.fixed_filter_pattern = int(fixed_pattern)
+        for c in range(25):
+            a.fixed_filter_usage[c] = 0 if fixed_usage is None else int(fixed_usage[c])
+            a.fixed_filter_idx[c] = 0 if fixed_idx is None else int(fixed_idx[c])
         if luma is not None:
             for f, row in enumerate(luma):
                 for i, v in enumerate(row):
