@@ -65,7 +65,7 @@ static int worker_context(worker_t *w, const xhost_picture *p)
     memset(&sp, 0, sizeof(sp));
     sp.device = w->device; sp.width = p->width; sp.height = p->height;
     sp.bit_depth_luma = p->bit_depth_luma; sp.bit_depth_chroma = p->bit_depth_chroma; sp.chroma_format_idc = 1; sp.log2_ctu = 6;
-    sp.tool_iqt = p->tool_iqt; sp.tool_addb = p->tool_addb; sp.tool_alf = p->tool_alf; sp.tool_eipd = p->tool_eipd;
+    sp.tool_iqt = p->tool_iqt; sp.tool_addb = p->tool_addb; sp.tool_alf = p->tool_alf; sp.tool_eipd = p->tool_eipd; sp.tool_admvp = p->tool_admvp;
     sp.max_pics = MAX_SLOTS + 1;
     if (w->g && !p->chroma_qp_table[0] && !memcmp(&sp, &w->sp, sizeof(sp))) return 0;
     const double t0 = now_s();

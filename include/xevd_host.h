@@ -55,6 +55,7 @@ typedef struct xhost_picture {
     int deblock_alpha_offset, deblock_beta_offset;      /* sh.sh_deblock_alpha/beta_offset (ADDB)                          */
     int tool_alf;
     int tool_eipd;                         /* sps->tool_eipd: batch.ipm holds Main mode numbers, xgpu_seq_params.tool_eipd must be set      */
+    int tool_admvp;                        /* sps->tool_admvp: xgpu_seq_params.tool_admvp must be set (Main interpolation tables)            */
     int crop[4];                           /* sps picture_crop_left / right / top / bottom_offset, what xevd_pull puts in the XEVD_IMGB      */
     const int8_t *chroma_qp_table[2];      /* SPS chroma QP mapping tables in xgpu_seq_params.chroma_qp_table layout, NULL = sequence default */
     const int32_t *dra_lut[3];             /* sps->tool_dra + pps.pic_dra_enabled_flag: the tables xgpu_pic_output takes (xgpu_dra_luts: luma, Cb, Cr; 1024
@@ -101,6 +102,8 @@ typedef struct xhost_stream_params {
     int cqt_delta_in[2][16];               /* delta_qp_in_val_minus1 (6 bits)                                         */
     int cqt_delta_out[2][16];              /* delta_qp_out_val                                                       */
     int tool_htdf;                         /* sps->tool_htdf: no CU syntax of its own; the parser hands the slice QP to the backend (batch.htdf_slice_qp) */
+    int tool_admvp;                        /* sps->tool_admvp: skip and merge-mode CUs take one of up to six merge candidates, explicitly coded motion uses the
+                                              resolution-indexed predictor and bi_idx (xevdm_eco.c:1519-1726); the backend then interpolates with the Main 8-tap tables */
     int ibc_log_max_size;                  /* 0: sps->ibc_flag off.  2..7 (needs tool_eipd): intra block copy for CUs up to 2^n samples - a CU of the batch with
                                               pred_mode XGPU_MODE_IBC is written with ibc_flag and its block vector mv[0] (xevdm_eco.c:1401-1438, 1789-1800)  */
 } xhost_stream_params;

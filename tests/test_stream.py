@@ -54,6 +54,13 @@ CONFIGS = [
     # tool_htdf: every intra CU and every coded inter CU is filtered after its reconstruction - the real decoder against parser + oracle
     (136, 72, 3, dict(main=True, htdf=True, inter_frac=0.6)),
     (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, inter_frac=0.6, log2_sub_gop=2, max_refs=2, bit_depth=10)),
+    # sps->tool_admvp: merge candidates (spatial, temporal with POC scaling and the picture-border clip, combined bi-predictive, zero) for skip and
+    # merge-mode CUs, the resolution-indexed predictor + bi_idx for explicitly coded motion, intra-only 4x4 CUs, Main interpolation tables
+    (136, 72, 3, dict(main=True, admvp=True, inter_frac=0.8, max_refs=1)),
+    (136, 136, 8, dict(main=True, admvp=True, inter_frac=0.9, max_refs=4)),
+    (200, 136, 9, dict(main=True, admvp=True, inter_frac=0.8, max_refs=2, log2_sub_gop=2)),
+    (264, 136, 17, dict(main=True, admvp=True, inter_frac=0.9, max_refs=3, log2_sub_gop=3, bit_depth=10, direct_frac=0.3, skip_frac=0.3)),
+    (200, 136, 9, dict(main=True, admvp=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=5, inter_frac=0.7, max_refs=2, log2_sub_gop=2, bit_depth=10)),
     # ALF parameter sets that start from the standard's fixed filters (usage pattern 1: every class, 2: flagged classes; 4-bit set index per class)
     (264, 136, 8, dict(main=True, alf=True, addb=True, alf_fixed=True)),
     (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, alf_fixed=True, log2_sub_gop=2, max_refs=2, bit_depth=10)),

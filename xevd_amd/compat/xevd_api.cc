@@ -106,7 +106,7 @@ int decode_picture(Decoder *d, const xhost_picture &p, Image **out)
         memset(&sp, 0, sizeof(sp));
         sp.width = p.width; sp.height = p.height; sp.bit_depth_luma = p.bit_depth_luma; sp.bit_depth_chroma = p.bit_depth_chroma;
         sp.chroma_format_idc = 1; sp.log2_ctu = 6; sp.max_pics = MAX_SLOTS + 2;
-        sp.tool_iqt = p.tool_iqt; sp.tool_addb = p.tool_addb; sp.tool_alf = p.tool_alf; sp.tool_eipd = p.tool_eipd;
+        sp.tool_iqt = p.tool_iqt; sp.tool_addb = p.tool_addb; sp.tool_alf = p.tool_alf; sp.tool_eipd = p.tool_eipd; sp.tool_admvp = p.tool_admvp;
         sp.chroma_qp_table[0] = p.chroma_qp_table[0]; sp.chroma_qp_table[1] = p.chroma_qp_table[1];
         int rc = xgpu_open(&sp, &d->g);
         if (rc < 0) return rc;

@@ -181,6 +181,7 @@ struct Models {
           intra_dir[2], mvp_idx[3], mvd[1], refi[2], dqp[1], skip[2],
           ats_mode[1], ats_inter_flag[2], ats_inter_quad[1], ats_inter_hor[3], ats_inter_pos[1],      // Main: xevd_def.h:559-563
           alf_ctb[1],
+          merge_mode[1], merge_idx[5], bi_idx[2],                                                      // tool_admvp: xevd_def.h:461-465
           ibc_flag[2],                                                                               // sps->ibc_flag: xevd_def.h:485
           ipm_mpm_flag[1], ipm_mpm_idx[1], ipm_chroma[1];                                            // tool_eipd: xevd_def.h intra_luma_pred_mpm_flag / _idx, intra_chroma_pred_mode
     void reset() { Model *p = (Model *)this; for (size_t i = 0; i < sizeof(Models) / sizeof(Model); i++) p[i] = 512; }     // PROB_INIT, xevd_eco.c:769-803
@@ -220,12 +221,14 @@ enum { MODE_INTRA = XGPU_MODE_INTRA, MODE_INTER = XGPU_MODE_INTER, MODE_SKIP = X
 // ------------------------------------------------------------------------------------------------ stream / picture state
 struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, log2_ref_gap = 0, max_num_ref_pics = 1;
              int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0, tool_alf = 0, tool_eipd = 0, tool_dra = 0, tool_htdf = 0;
+             int tool_admvp = 0;                     // sps->tool_admvp: merge / resolution-indexed predictors instead of the Baseline candidate lists, 8-tap MC tables
              int ibc = 0, ibc_log_max = 0;            // sps->ibc_flag, sps->ibc_log_max_size (log2 of the largest IBC CU; xevdm_eco.c:1890-1898)
              int crop[4] = { 0, 0, 0, 0 };            // picture_crop_left / right / top / bottom_offset (xevd_eco.c:1349-1357), as xevd_pull reports them
              bool cqt = false; int8_t cq[2][96] = { { 0 } }; };      // chroma QP mapping tables signalled in the SPS: [c][qp + 6*(bd_c-8)], qp = -6*(bd_c-8) .. 57
 struct Pps { int constrained_intra = 0, cu_qp_delta = 0, dra_on = 0, dra_aps_id = 0; };
 struct Slice { int type = XHOST_SLICE_I, qp = 32, qp_u_offset = 0, qp_v_offset = 0, deblock = 1, alpha_off = 0, beta_off = 0;
-               int alf_on = 0, aps_id_y = 0, aps_id_ch = 0, alf_chroma_idc = 0, alf_ctb_map = 0; };
+               int alf_on = 0, aps_id_y = 0, aps_id_ch = 0, alf_chroma_idc = 0, alf_ctb_map = 0;
+               int tmvp_assigned = 0, col_list = 0, col_src_list = 0, col_ref = 0; };      // temporal_mvp_asigned_flag + collocated_* (tool_admvp, xevdm_eco.c:2748-2760)
 
 // ---- ALF parameter sets (XEVD_ALF_SLICE_PARAM / ac_alf_line_buf[32], src_main/xevdm_alf.c:587-698) ----
 // zig-zag position of the coded coefficients inside the 13-tap (7x7 diamond) layout and Exp-Golomb order class of each coefficient
@@ -266,6 +269,9 @@ struct RefPic {          // what a decoded picture leaves behind for later pictu
     int poc = 0, tid = 0;
     int list0_poc = 0;               // POC of reference 0 of ITS list 0 (pic->list_poc[0]); temporal direct mode scales by it
     std::vector<int16_t> mv0;        // [f_scu][2]: list-0 motion of every SCU (refp.map_mv[scup][REFP_0])
+    std::vector<int16_t> mv;         // [f_scu][2][2] and
+    std::vector<int8_t> refi;        // [f_scu][2]: both lists (tool_admvp's temporal candidates read them)
+    int list_poc[16] = { 0 };        // pic->list_poc[]: POCs of ITS list-0 references (indexed by reference indices of EITHER list, xevdm_util.c:3760-3761)
 };
 
 struct Cu {
@@ -388,6 +394,7 @@ struct Stream {          // everything both directions share
     std::vector<RefPic> dpb;         // reference pictures in coding order (pm->pic[] restricted to IS_REF)
     std::vector<const RefPic *> refp[2];
     int poc = 0, prev_poc = 0, prev_doc_offset = -1, tid = 0, last_intra_poc = 0, qp_prev = 0, stale_list0_poc = 0;
+    int stale_list_poc[16] = { 0 };      // list_poc[] entries past a picture's own list keep what earlier pictures wrote
     bool have_sps = false, have_pps = false, need_idr = false;
     std::vector<uint16_t> scan[6][6];      // zig-zag tables by log2 size - 1
     AlfAps alf_aps[32];
@@ -538,6 +545,12 @@ struct Stream {          // everything both directions share
     // picture marking + insertion (xevd_picman_put_pic / pic_marking_no_rpl, xevd_picman.c:68-110,462-509); released POCs reported
     void store_picture(bool idr, std::vector<int> &released)
     {
+        // pic->list_poc[i] = POC of refp[i][REFP_0] (xevd_picman.c:213-221); an I slice leaves num_refp untouched, so the previous picture's values stay.
+        // Taken BEFORE the DPB below is edited: refp[] points into it
+        if (sh.type != XHOST_SLICE_I) {
+            stale_list0_poc = refp[0].empty() ? 0 : refp[0][0]->poc;
+            for (size_t i = 0; i < refp[0].size() && i < 16; i++) stale_list_poc[i] = refp[0][i]->poc;
+        }
         if (idr) { for (const RefPic &r : dpb) released.push_back(r.poc); dpb.clear(); }
         else if (tid == 0) {
             const int gap = 1 << sps.log2_ref_gap;
@@ -547,8 +560,6 @@ struct Stream {          // everything both directions share
             }
             while (dpb.size() >= 5) { released.push_back(dpb[0].poc); dpb.erase(dpb.begin()); }      // XEVD_MAX_NUM_ACTIVE_REF_FRAME
         }
-        // pic->list_poc[0] = POC of refp[0][REFP_0]; an I slice leaves num_refp untouched, so the previous picture's value stays
-        if (sh.type != XHOST_SLICE_I) stale_list0_poc = refp[0].empty() ? 0 : refp[0][0]->poc;
         if (!is_ref_picture()) return;
         // bound on a damaged stream that keeps sending tid > 0 reference pictures without a tid-0 picture between them
         while (dpb.size() >= 32) { released.push_back(dpb[0].poc); dpb.erase(dpb.begin()); }
@@ -557,6 +568,7 @@ struct Stream {          // everything both directions share
         const size_t f = (size_t)pic.w_scu * pic.h_scu;
         r.mv0.resize(f * 2);
         for (size_t k = 0; k < f; k++) { r.mv0[k * 2] = pic.mv[k * 4]; r.mv0[k * 2 + 1] = pic.mv[k * 4 + 1]; }
+        if (sps.tool_admvp) { r.mv = pic.mv; r.refi = pic.refi; memcpy(r.list_poc, stale_list_poc, sizeof(r.list_poc)); }
         dpb.push_back(std::move(r));
     }
 
@@ -579,6 +591,172 @@ struct Stream {          // everything both directions share
         cand[3][0] = col ? col->mv0[(size_t)scup * 2] : (int16_t)0;
         cand[3][1] = col ? col->mv0[(size_t)scup * 2 + 1] : (int16_t)0;
     }
+    // ------------------------------------------------------------------------------------------------------------------------------
+    // Main profile, sps->tool_admvp: merge candidates (skip and merge-mode CUs) and the predictor of explicitly coded motion.
+    // No SUCO here, so the right-hand neighbours are never decoded before the CU: the avail_lr LR_10 / LR_00 branch of the reference.
+    // ------------------------------------------------------------------------------------------------------------------------------
+    struct Motion { int8_t refi[2]; int16_t mv[2][2]; };
+    bool bi_applicable(const Cu &cu) const { return sh.type == XHOST_SLICE_B && (1 << cu.log2w) + (1 << cu.log2h) > 12; }      // xevdm_check_bi_applicability, xevdm_util.c:1083-1096
+    // the five spatial neighbours H, D, E, I, A (xevdm_check_motion_availability, xevdm_util.c:594-748, last branch): decoded, inter, not IBC
+    void adm_neighbours(const Cu &cu, int neb[5], bool valid[5]) const
+    {
+        const int ws = pic.w_scu, hs = pic.h_scu, xs = cu.x >> 2, ys = cu.y >> 2, scuw = (1 << cu.log2w) >> 2, scuh = (1 << cu.log2h) >> 2, scup = ys * ws + xs;
+        neb[0] = scup + (scuh - 1) * ws - 1; neb[1] = scup - ws + scuw - 1; neb[2] = scup - ws + scuw; neb[3] = scup + scuh * ws - 1; neb[4] = scup - ws - 1;
+        const bool in[5] = { xs > 0, ys > 0, ys > 0 && xs + scuw < ws, ys + scuh < hs && xs > 0, ys > 0 && xs > 0 };
+        for (int k = 0; k < 5; k++) valid[k] = in[k] && pic.cod[neb[k]] && !pic.intra[neb[k]] && !pic.ibc[neb[k]];
+    }
+    static void scale_mv(int ratio, const int16_t in[2], int16_t out[2])      // scaling_mv, xevdm_util.c:180-190 (MVP_SCALING_PRECISION 5)
+    {
+        for (int d = 0; d < 2; d++) {
+            int t = in[d] * ratio;
+            t = t == 0 ? 0 : t > 0 ? (t + 16) >> 5 : -((-t + 16) >> 5);
+            out[d] = (int16_t)std::min(std::max(t, -32768), 32767);
+        }
+    }
+    // temporal candidate from the collocated picture at SCU `scu_col` (xevdm_get_mv_collocated, xevdm_util.c:3729-3818): 0 none, bit 0 list 0, bit 1 list 1
+    int collocated(const Cu &cu, int scu_col, int16_t mvp[2][2]) const
+    {
+        int list = sh.type == XHOST_SLICE_P ? 0 : 1, ref = 0, src = 0;
+        if (sh.tmvp_assigned) { list = sh.col_list; ref = sh.col_ref; src = sh.col_src_list; }
+        memset(mvp, 0, sizeof(int16_t) * 4);
+        if (ref >= (int)refp[list].size()) return 0;
+        const RefPic *col = refp[list][ref];
+        if (col->refi.empty()) return 0;
+        const int dpoc[2] = { refp[0].empty() ? 0 : poc - refp[0][0]->poc, refp[1].empty() ? 0 : poc - refp[1][0]->poc };
+        int have[2] = { 0, 0 };
+        if (!sh.tmvp_assigned) {
+            for (int l = 0; l < 2; l++) {
+                const int r = col->refi[(size_t)scu_col * 2 + l];
+                if (r < 0 || r >= 16) continue;
+                const int dco = col->poc - col->list_poc[r];
+                if (dco == 0) continue;
+                have[l] = 1;
+                scale_mv((dpoc[l] << 5) / dco, &col->mv[(size_t)scu_col * 4 + l * 2], mvp[l]);
+            }
+        } else {
+            const int r = col->refi[(size_t)scu_col * 2 + src];
+            const int dco = (r >= 0 && r < 16) ? col->poc - col->list_poc[r] : 0;
+            if (dco != 0) {
+                have[0] = have[1] = 1;
+                for (int l = 0; l < 2; l++) scale_mv((dpoc[l] << 5) / dco, &col->mv[(size_t)scu_col * 4 + src * 2], mvp[l]);
+            }
+        }
+        // xevdm_clip_mv_pic (xevdm_util.c:1409-1421) at the CU's position - samples and quarter samples mixed exactly like the reference does
+        const int x = cu.x, y = cu.y, max_x = 144 + (pic.w_scu << 2) - 1, max_y = 144 + (pic.h_scu << 2) - 1, mn = -144;      // PIC_PAD_SIZE_L = MAX_CU_SIZE + 16
+        for (int l = 0; l < 2; l++) { if (x + mvp[l][0] < mn) mvp[l][0] = (int16_t)-(x + mn); }
+        for (int l = 0; l < 2; l++) { if (y + mvp[l][1] < mn) mvp[l][1] = (int16_t)-(y + mn); }
+        for (int l = 0; l < 2; l++) { if (x + mvp[l][0] > max_x) mvp[l][0] = (int16_t)(max_x - x); }
+        for (int l = 0; l < 2; l++) { if (y + mvp[l][1] > max_y) mvp[l][1] = (int16_t)(max_y - y); }
+        return have[0] | (have[1] << 1);
+    }
+    // xevdm_get_motion_merge_main (xevdm_util.c:1169-1391) without the history candidates (sps->tool_hmvp off): up to 6 candidates (4 for CUs of 32 samples)
+    void merge_candidates(const Cu &cu, Motion cand[6]) const
+    {
+        const int ws = pic.w_scu, hs = pic.h_scu, xs = cu.x >> 2, ys = cu.y >> 2, cuw = 1 << cu.log2w, cuh = 1 << cu.log2h, scup = ys * ws + xs;
+        const int max_n = cuw * cuh <= 32 ? 4 : 6;
+        const bool is_b = sh.type == XHOST_SLICE_B, bi = bi_applicable(cu);
+        for (int k = 0; k < 6; k++) { cand[k].refi[0] = cand[k].refi[1] = -1; memset(cand[k].mv, 0, sizeof(cand[k].mv)); }
+        int cnt = 0;
+        auto insert = [&](const int8_t r[2], const int16_t *mv) {       // xevdm_get_merge_insert_mv + check_redundancy
+            Motion &d = cand[cnt];
+            d.refi[0] = r[0] >= 0 ? r[0] : (int8_t)-1; d.mv[0][0] = mv[0]; d.mv[0][1] = mv[1];
+            if (is_b) {
+                if (r[0] >= 0 && !bi) { d.refi[1] = -1; d.mv[1][0] = d.mv[1][1] = 0; }
+                else { d.refi[1] = r[1] >= 0 ? r[1] : (int8_t)-1; d.mv[1][0] = mv[2]; d.mv[1][1] = mv[3]; }
+            }
+            bool dup = false;
+            for (int i = cnt - 1; i >= 0 && !dup; i--)
+                dup = d.refi[0] == cand[i].refi[0] && d.mv[0][0] == cand[i].mv[0][0] && d.mv[0][1] == cand[i].mv[0][1] &&
+                      (!is_b || (d.refi[1] == cand[i].refi[1] && d.mv[1][0] == cand[i].mv[1][0] && d.mv[1][1] == cand[i].mv[1][1]));
+            if (!dup) cnt++;
+            return !dup;
+        };
+        int neb[5]; bool valid[5];
+        adm_neighbours(cu, neb, valid);
+        for (int k = 0; k < 5; k++) {
+            if (valid[k]) insert(&pic.refi[(size_t)neb[k] * 2], &pic.mv[(size_t)neb[k] * 4]);
+            if (cnt == max_n - 1) break;
+        }
+        // temporal: the centre of the CU on the 8x8 grid, else below, else to the right (inside the CTU row / column)
+        bool tmvp_added = false;
+        auto temporal = [&](int scu_col) -> bool {      // true: candidate list complete
+            int16_t t[2][2];
+            const int av = collocated(cu, scu_col, t);
+            if (!av) return false;
+            const int8_t r[2] = { (int8_t)((av & 1) ? 0 : -1), (int8_t)((av & 2) ? 0 : -1) };
+            tmvp_added = insert(r, &t[0][0]);
+            return cnt >= max_n;
+        };
+        if (temporal(((xs + (cuw >> 3)) >> 1 << 1) + ((ys + (cuh >> 3)) >> 1 << 1) * ws)) return;
+        const int xe = xs + (cuw >> 2) - 1, ye = ys + (cuh >> 2) - 1;
+        if (!tmvp_added && ye + 1 < hs && ((ye + 1) << 2 >> 6) == (ye << 2 >> 6))
+            if (temporal(((ye + 1) >> 1 << 1) * ws + (xe >> 1 << 1))) return;
+        if (!tmvp_added && xe + 1 < ws && ((xe + 1) << 2 >> 6) == (xe << 2 >> 6))
+            if (temporal((ye >> 1 << 1) * ws + ((xe + 1) >> 1 << 1))) return;
+        if (bi) {       // combinations of the list-0 part of one candidate with the list-1 part of another
+            static const int p0[20] = { 0, 1, 0, 2, 1, 2, 0, 3, 1, 3, 2, 3, 0, 4, 1, 4, 2, 4, 3, 4 }, p1[20] = { 1, 0, 2, 0, 2, 1, 3, 0, 3, 1, 3, 2, 4, 0, 4, 1, 4, 2, 4, 3 };
+            const int cur = cnt;
+            for (int i = 0; i < cur * (cur - 1) && cnt != max_n; i++) {
+                const Motion a = cand[p0[i]], b = cand[p1[i]];
+                if (a.refi[0] >= 0 && b.refi[1] >= 0) {
+                    cand[cnt].refi[0] = a.refi[0]; cand[cnt].mv[0][0] = a.mv[0][0]; cand[cnt].mv[0][1] = a.mv[0][1];
+                    cand[cnt].refi[1] = b.refi[1]; cand[cnt].mv[1][0] = b.mv[1][0]; cand[cnt].mv[1][1] = b.mv[1][1];
+                    cnt++;
+                }
+            }
+            if (cnt == max_n) return;
+        }
+        for (int k = cnt; k < max_n; k++) { cand[k].refi[0] = 0; cand[k].refi[1] = bi ? 0 : -1; memset(cand[k].mv, 0, sizeof(cand[k].mv)); }
+        (void)scup;
+    }
+    // skip / merge-mode motion = candidate `idx` (xevd_get_skip_motion / xevd_get_direct_motion, xevdm.c:800-883); entries past the list stay "no reference, zero"
+    void merge_motion(Cu &cu, int idx) const
+    {
+        Motion cand[6];
+        merge_candidates(cu, cand);
+        const Motion &m = cand[std::min(std::max(idx, 0), 5)];
+        cu.refi[0] = m.refi[0]; cu.mv[0][0] = m.mv[0][0]; cu.mv[0][1] = m.mv[0][1];
+        if (sh.type == XHOST_SLICE_P) { cu.refi[1] = -1; cu.mv[1][0] = cu.mv[1][1] = 0; }
+        else { cu.refi[1] = m.refi[1]; cu.mv[1][0] = m.mv[1][0]; cu.mv[1][1] = m.mv[1][1]; }
+    }
+    // the fallback motion of a list among the first two neighbours (xevdm_get_default_motion, xevdm_util.c:783-867, no history): the one with `cur_refi`, else any
+    void default_motion(const int neb[5], const bool valid[5], int cur_refi, int l, int &refi, int16_t mv[2]) const
+    {
+        refi = 0; mv[0] = mv[1] = 0;
+        for (int pass = 0; pass < 2; pass++)
+            for (int k = 0; k < 2; k++) {
+                if (!valid[k]) continue;
+                const int r = pic.refi[(size_t)neb[k] * 2 + l];
+                if (r >= 0 && (pass == 1 || r == cur_refi)) { refi = r; mv[0] = pic.mv[(size_t)neb[k] * 4 + l * 2]; mv[1] = pic.mv[(size_t)neb[k] * 4 + l * 2 + 1]; return; }
+            }
+    }
+    // reference index of a list of a bi-predicted CU that does not code it (bi_idx FL0 / FL1: xevdm_get_first_refi, xevdm_util.c:750-781), resolution index 0
+    int first_refi(const Cu &cu, int l) const
+    {
+        int neb[5], dref; bool valid[5]; int16_t dmv[2];
+        adm_neighbours(cu, neb, valid);
+        default_motion(neb, valid, 0, l, dref, dmv);
+        if (valid[0] && pic.refi[(size_t)neb[0] * 2 + l] >= 0) return pic.refi[(size_t)neb[0] * 2 + l];
+        return dref;
+    }
+    // the predictor of explicitly coded motion at resolution index 0 (xevdm_get_motion_from_mvr, xevdm_util.c:869-951): neighbour H, scaled to the
+    // CU's reference when it points elsewhere, else the fallback motion
+    void mvr_predictor(const Cu &cu, int l, int cur_refi, int16_t mvp[2]) const
+    {
+        int neb[5], dref; bool valid[5]; int16_t dmv[2];
+        adm_neighbours(cu, neb, valid);
+        default_motion(neb, valid, cur_refi, l, dref, dmv);
+        const int n = (int)refp[l].size(), pc = refp[l][std::min(std::max(cur_refi, 0), n - 1)]->poc;
+        auto ratio = [&](int r) -> int { const int t0 = poc - refp[l][std::min(std::max(r, 0), n - 1)]->poc; return t0 ? ((poc - pc) << 5) / t0 : 0; };
+        int r = valid[0] ? (int)pic.refi[(size_t)neb[0] * 2 + l] : -1;
+        if (r >= 0) {
+            const int16_t *m = &pic.mv[(size_t)neb[0] * 4 + l * 2];
+            if (r == cur_refi) { mvp[0] = m[0]; mvp[1] = m[1]; } else scale_mv(ratio(r), m, mvp);
+        } else {
+            if (dref == cur_refi) { mvp[0] = dmv[0]; mvp[1] = dmv[1]; } else scale_mv(ratio(dref), dmv, mvp);
+        }
+    }
+
     // temporal direct motion of a B CU (xevd_get_mv_dir, xevd_util.c:540-566; call site xevd.c:713-717): the list-0 motion the
     // co-located picture (reference 0 of list 1) stored at the CU's bottom-right SCU, scaled by POC distances (C division)
     void direct_motion(Cu &cu) const
@@ -704,13 +882,22 @@ struct Stream {          // everything both directions share
     // dec: they are filled.  coef[c]: w*h (w/2*h/2) values of component c, zero-initialised by the caller when decoding.
     template <class C> void code_cu(C &c, Cu &cu, int16_t *coef[3], bool enc)
     {
-        const bool inter_slice = sh.type != XHOST_SLICE_I;
+        // mode constraint eOnlyIntra: I slices, and with tool_admvp every 4x4 CU (xevdm.c:1838-1843) - no skip flag, no pred_mode_flag
+        const bool inter_slice = sh.type != XHOST_SLICE_I && !(sps.tool_admvp && cu.log2w == 2 && cu.log2h == 2);
         int skip = 0;
         if (inter_slice) skip = c.bin(cu.mode == MODE_SKIP, models.skip[0]);
         if (!enc) { cu.mode = skip ? MODE_SKIP : MODE_INTRA; cu.refi[0] = cu.refi[1] = -1; memset(cu.mv, 0, sizeof(cu.mv)); memset(cu.mvd, 0, sizeof(cu.mvd));
                     cu.mvp_idx[0] = cu.mvp_idx[1] = 0; cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0; cu.ipm = cu.ipm_c = 0; cu.ats = cu.ats_inter = 0; }
         int16_t cand[4][2];
         const int n_lists = sh.type == XHOST_SLICE_B ? 2 : 1;
+        if (skip && sps.tool_admvp) {
+            // Main: one merge index, truncated unary over five contexts (xevdm_eco_merge_idx, xevdm_eco.c:731-744; call site :1550-1551)
+            cu.mvp_idx[0] = cu.mvp_idx[1] = sym_trunc_unary(c, cu.mvp_idx[0], models.merge_idx, 5, 6);
+            merge_motion(cu, cu.mvp_idx[0]);
+            cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0;
+            cu.qp = qp_prev;
+            return;
+        }
         if (skip) {
             // the motion of candidate mvp_idx of every list, reference 0 (xevd_get_skip_motion, xevd.c:502-531; syntax xevd_eco.c:1079-1085)
             for (int l = 0; l < n_lists; l++) cu.mvp_idx[l] = sym_trunc_unary(c, cu.mvp_idx[l], models.mvp_idx, 3, 4);
@@ -740,6 +927,63 @@ struct Stream {          // everything both directions share
                 int sg = v < 0;
                 if (a) sg = c.ep(sg);
                 cu.mv[0][d] = (int16_t)(sg ? -a : a);
+            }
+        } else if (!intra && sps.tool_admvp) {
+            // xevdm_eco.c:1595-1726 with the sub-tools off: merge_mode_flag (the CU takes a merge candidate: pred_mode MODE_DIR), else
+            // inter_pred_idc (no bi-prediction for CUs of 4x4 / 4x8 / 8x4), bi_idx of a bi-predicted CU (normal / list 0 / list 1 without a
+            // coded difference; the latter two also derive their reference indices), per list reference index and vector difference.
+            // The predictor is the resolution-indexed one (index 0 without AMVR): mv = predictor + mvd (xevd_get_inter_motion, xevdm.c:885-932)
+            cu.direct = c.bin(cu.direct, models.merge_mode[0]);
+            if (cu.direct) {
+                cu.mvp_idx[0] = cu.mvp_idx[1] = sym_trunc_unary(c, cu.mvp_idx[0], models.merge_idx, 5, 6);
+                merge_motion(cu, cu.mvp_idx[0]);
+            } else {
+                int dir = 0;
+                if (n_lists == 2) {
+                    if (enc) dir = (cu.refi[0] >= 0 && cu.refi[1] >= 0 && bi_applicable(cu)) ? 2 : ((cu.refi[1] >= 0 && cu.refi[0] < 0) ? 1 : 0);
+                    int not_bi = 1;
+                    if (bi_applicable(cu)) not_bi = c.bin(dir != 2, models.inter_dir[0]);
+                    if (!not_bi) dir = 2;
+                    else dir = c.bin(dir == 1, models.inter_dir[1]) ? 1 : 0;
+                }
+                int bi_idx = 0;                                      // BI_NON 0, BI_NORMAL 1, BI_FL0 2, BI_FL1 3
+                if (dir == 2) {
+                    if (enc) bi_idx = 1 + ((cu.x >> 2) + (cu.y >> 2) * 3) % 7 % 3;      // a spread of the three kinds over the picture
+                    const int v = bi_idx - 1;
+                    if (c.bin(v == 0, models.bi_idx[0])) bi_idx = 1;
+                    else bi_idx = c.bin(v == 1, models.bi_idx[1]) ? 2 : 3;
+                }
+                for (int l = 0; l < 2; l++) {
+                    if (!(((dir + 1) >> l) & 1)) { cu.refi[l] = -1; cu.mv[l][0] = cu.mv[l][1] = 0; continue; }
+                    const int nref = (int)refp[l].size();
+                    if (bi_idx != 2 && bi_idx != 3) {
+                        if (nref > 1) {                              // xevd_eco_refi, xevd_eco.c:409-436
+                            const int r = std::min(std::max(cu.refi[l], 0), nref - 1);
+                            int v = 0;
+                            if (c.bin(r > 0, models.refi[0])) {
+                                v = 1;
+                                if (nref > 2 && c.bin(r > 1, models.refi[1])) {
+                                    v = 2;
+                                    for (; v < nref - 1; v++) if (!c.ep(r > v)) break;
+                                }
+                            }
+                            cu.refi[l] = v;
+                        } else cu.refi[l] = 0;
+                    } else cu.refi[l] = first_refi(cu, l);
+                    int16_t mvp[2];
+                    mvr_predictor(cu, l, cu.refi[l], mvp);
+                    if (bi_idx == 2 + l) cu.mvd[l][0] = cu.mvd[l][1] = 0;
+                    else {
+                        if (enc) { cu.mvd[l][0] = (int16_t)(cu.mv[l][0] - mvp[0]); cu.mvd[l][1] = (int16_t)(cu.mv[l][1] - mvp[1]); }
+                        for (int d = 0; d < 2; d++) {                // xevd_eco_get_mvd, xevd_eco.c:491-536
+                            const int v = cu.mvd[l][d], a = sym_abs_mvd(c, v < 0 ? -v : v, models.mvd[0]);
+                            int sg = v < 0;
+                            if (a) sg = c.ep(sg);
+                            cu.mvd[l][d] = (int16_t)(sg ? -a : a);
+                        }
+                    }
+                    cu.mv[l][0] = (int16_t)(mvp[0] + cu.mvd[l][0]); cu.mv[l][1] = (int16_t)(mvp[1] + cu.mvd[l][1]);
+                }
             }
         } else if (!intra) {
             // xevd_eco.c:1120-1148: B: direct_mode_flag, else inter_pred_idc; per list in use: ref index, predictor index, mvd; mv = mvp + mvd (xevd.c:533-556)
@@ -823,7 +1067,9 @@ struct Stream {          // everything both directions share
         // coded block flags (eco_cbf, xevd_eco.c:260-341), CU <= 64: no sub-blocks
         bool all_zero = false;
         if (!intra) {
-            const int any = c.bin((cu.cbf[0] | cu.cbf[1] | cu.cbf[2]) != 0, models.cbf_all[0]);
+            // a merge-mode CU (MODE_DIR with tool_admvp) has coefficients by definition - without them it would be a skip CU: no cbf_all (xevdm_eco.c:831)
+            const bool merge_cu = sps.tool_admvp && cu.direct && cu.mode == MODE_INTER;
+            const int any = merge_cu ? 1 : c.bin((cu.cbf[0] | cu.cbf[1] | cu.cbf[2]) != 0, models.cbf_all[0]);
             if (!any) { cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0; all_zero = true; }
             else {
                 cu.cbf[1] = c.bin(cu.cbf[1], models.cbf_cb[0]);
@@ -945,7 +1191,8 @@ struct xhost_parser {
         } else {                                          // xevdm_eco_sps, xevdm_eco.c:1863-1937: sub-flags follow their tool flag
             unsupported |= br.get1();                    // sps_btt_flag
             unsupported |= br.get1();                    // sps_suco_flag
-            unsupported |= br.get1();                    // tool_admvp
+            s.tool_admvp = br.get1();
+            if (s.tool_admvp) for (int i = 0; i < 5; i++) unsupported |= br.get1();      // tool_affine, tool_amvr, tool_dmvr, tool_mmvd, tool_hmvp
             s.tool_eipd = br.get1();
             s.ibc = s.ibc_log_max = 0;
             if (s.tool_eipd && (s.ibc = br.get1())) { s.ibc_log_max = (int)br.ue() + 2; if (s.ibc_log_max > 7) return fail("bad SPS"); }
@@ -960,7 +1207,7 @@ struct xhost_parser {
             unsupported |= br.get1();                    // dquant_flag: the Main decoder then codes QP deltas per cu_qp_delta_area (xevdm_eco.c), not per CU
             s.tool_dra = br.get1();
         }
-        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, admvp, cm_init, rpl, pocs, dquant in Main)");
+        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, affine, amvr, dmvr, mmvd, hmvp, cm_init, rpl, pocs, dquant in Main)");
         s.log2_sub_gop = (int)br.ue();                   // tool_rpl = tool_pocs = 0
         if (s.log2_sub_gop == 0) s.log2_ref_gap = (int)br.ue();
         if (s.log2_sub_gop > 5) return fail("bad SPS");
@@ -1044,6 +1291,11 @@ struct xhost_parser {
             }
         }
         if (sh.type != XHOST_SLICE_I && br.get1()) { br.ue(); if (sh.type == XHOST_SLICE_B) br.ue(); }      // num_ref_idx_active override (unused by the Baseline decoder, xevd_eco.c:409)
+        sh.tmvp_assigned = sh.col_list = sh.col_src_list = sh.col_ref = 0;
+        if (sh.type != XHOST_SLICE_I && st.sps.tool_admvp && (sh.tmvp_assigned = br.get1())) {                // xevdm_eco.c:2748-2760
+            if (sh.type == XHOST_SLICE_B) { sh.col_list = br.get1(); sh.col_src_list = br.get1(); }
+            sh.col_ref = br.get1();
+        }
         sh.deblock = br.get1();
         sh.alpha_off = sh.beta_off = 0;
         if (sh.deblock && st.sps.tool_addb) { sh.alpha_off = br.se(); sh.beta_off = br.se(); }      // xevdm_eco.c:2767-2772
@@ -1092,7 +1344,7 @@ struct xhost_parser {
         out->slice_qp = sh.qp; out->qp_u_offset = sh.qp_u_offset; out->qp_v_offset = sh.qp_v_offset; out->deblock_on = sh.deblock;
         out->profile_main = st.sps.profile_main; out->tool_iqt = st.sps.tool_iqt; out->tool_ats = st.sps.tool_ats; out->tool_addb = st.sps.tool_addb;
         out->deblock_alpha_offset = sh.alpha_off; out->deblock_beta_offset = sh.beta_off;
-        out->tool_alf = st.sps.tool_alf; out->alf_on = sh.alf_on; out->tool_eipd = st.sps.tool_eipd;
+        out->tool_alf = st.sps.tool_alf; out->alf_on = sh.alf_on; out->tool_eipd = st.sps.tool_eipd; out->tool_admvp = st.sps.tool_admvp;
         out->dra_lut[0] = out->dra_lut[1] = out->dra_lut[2] = nullptr;
         if (st.sps.tool_dra && st.pps.dra_on) {          // what xevd_pull applies to its copy of this picture (xevd_apply_filter, xevdm.c:3305-3349)
             const DraAps &d = st.dra_aps[st.pps.dra_aps_id & 31];
@@ -1283,7 +1535,9 @@ struct xhost_writer {
         bw.ue((uint32_t)(sp.bit_depth - 8)); bw.ue((uint32_t)(sp.bit_depth - 8));
         if (!sp.profile_main) for (int i = 0; i < 13; i++) bw.put1(i == 11 ? (sp.cu_qp_delta ? 1 : 0) : 0);       // all tools off; dquant_flag with cu_qp_delta
         else {
-            for (int i = 0; i < 3; i++) bw.put1(0);      // btt suco admvp
+            bw.put1(0); bw.put1(0);                      // btt suco
+            bw.put1(sp.tool_admvp ? 1 : 0);
+            if (sp.tool_admvp) for (int i = 0; i < 5; i++) bw.put1(0);      // affine amvr dmvr mmvd hmvp
             bw.put1(sp.tool_eipd ? 1 : 0);
             if (sp.tool_eipd) { bw.put1(sp.ibc_log_max_size ? 1 : 0); if (sp.ibc_log_max_size) bw.ue((uint32_t)(sp.ibc_log_max_size - 2)); }      // ibc_flag, ibc_log_max_size - 2
             bw.put1(0);                                  // cm_init
@@ -1345,6 +1599,7 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     w->sp.tool_iqt = s.tool_iqt; w->sp.tool_ats = s.tool_ats; w->sp.tool_addb = s.tool_addb; w->sp.tool_alf = s.tool_alf; w->sp.tool_eipd = s.tool_eipd;
     w->sp.tool_dra = s.profile_main && sp->tool_dra; s.tool_dra = w->sp.tool_dra;
     w->sp.tool_htdf = s.profile_main && sp->tool_htdf; s.tool_htdf = w->sp.tool_htdf;
+    w->sp.tool_admvp = s.profile_main && sp->tool_admvp; s.tool_admvp = w->sp.tool_admvp;
     w->sp.ibc_log_max_size = (s.tool_eipd && sp->ibc_log_max_size >= 2 && sp->ibc_log_max_size <= 7) ? sp->ibc_log_max_size : 0;
     s.ibc = w->sp.ibc_log_max_size != 0; s.ibc_log_max = w->sp.ibc_log_max_size;
     w->st.pps.cu_qp_delta = sp->cu_qp_delta;
@@ -1457,9 +1712,9 @@ struct TreeWriter {
         cu.x = x; cu.y = y; cu.log2w = cu.log2h = log2s;
         cu.mode = b->pred_mode[i] == XGPU_MODE_INTRA ? MODE_INTRA : (b->pred_mode[i] == XGPU_MODE_SKIP ? MODE_SKIP : MODE_INTER);
         const bool ibc = b->pred_mode[i] == XGPU_MODE_IBC && st.sps.ibc && log2s <= st.sps.ibc_log_max;
-        if (st.sh.type == XHOST_SLICE_I) cu.mode = MODE_INTRA;
+        if (st.sh.type == XHOST_SLICE_I || (st.sps.tool_admvp && log2s == 2)) cu.mode = MODE_INTRA;
         if (ibc) cu.mode = MODE_IBC;
-        cu.direct = st.sh.type == XHOST_SLICE_B && b->pred_mode[i] == XGPU_MODE_DIR;
+        cu.direct = (st.sh.type == XHOST_SLICE_B || (st.sps.tool_admvp && st.sh.type == XHOST_SLICE_P)) && b->pred_mode[i] == XGPU_MODE_DIR;
         for (int l = 0; l < 2; l++) {
             const int nref = (int)st.refp[l].size();
             cu.refi[l] = (b->refi[i * 2 + l] < 0 || nref == 0) ? -1 : std::min((int)b->refi[i * 2 + l], nref - 1);
@@ -1469,6 +1724,7 @@ struct TreeWriter {
         if (st.sh.type == XHOST_SLICE_P) { cu.refi[1] = -1; if (cu.refi[0] < 0) cu.refi[0] = 0; }
         if (ibc) { cu.refi[0] = cu.refi[1] = -1; cu.mv[1][0] = cu.mv[1][1] = 0; }
         cu.mvp_idx[0] = (x >> 2) & 3; cu.mvp_idx[1] = (y >> 2) & 3;   // a SKIP CU: some predictor per list
+        if (st.sps.tool_admvp) cu.mvp_idx[0] = cu.mvp_idx[1] = ((x >> 2) + 2 * (y >> 2)) % 6;      // ... or one of the six merge candidates (also of a merge-mode CU)
         cu.ipm = b->ipm ? b->ipm[i * 2] % (st.sps.tool_eipd ? 33 : 5) : 0;
         cu.ipm_c = (b->ipm && st.sps.tool_eipd) ? b->ipm[i * 2 + 1] % 5 : 0;
         cu.qp = std::min(std::max((int)b->qp[i * 3] - bd_off, 0), 51);
@@ -1496,6 +1752,7 @@ struct TreeWriter {
             }
             coef[k] = blk[k].data();
         }
+        if (st.sps.tool_admvp && cu.mode == MODE_INTER && cu.direct && !(cu.cbf[0] | cu.cbf[1] | cu.cbf[2])) { cu.mode = MODE_SKIP; cu.direct = 0; }      // merge mode without coefficients IS skip
         const bool cbf_all_path = cu.mode == MODE_INTER || cu.mode == MODE_IBC;          // eco_cbf's non-intra branch
         if (cbf_all_path && !(cu.cbf[0] | cu.cbf[1] | cu.cbf[2])) { /* all-zero flag path */ }
         else if (cbf_all_path && cu.cbf[1] + cu.cbf[2] == 0) cu.cbf[0] = 1;      // implied luma cbf needs a luma coefficient
@@ -1540,6 +1797,8 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
         }
     } else st.sh.alf_on = 0;
     if (slice_type != XHOST_SLICE_I) bw.put1(0);         // num_ref_idx_active_override_flag
+    st.sh.tmvp_assigned = st.sh.col_list = st.sh.col_src_list = st.sh.col_ref = 0;
+    if (slice_type != XHOST_SLICE_I && st.sps.tool_admvp) bw.put1(0);      // temporal_mvp_asigned_flag: the collocated picture is reference 0 of list 1 (P: list 0)
     bw.put1(st.sh.deblock);
     st.sh.alpha_off = st.sps.tool_addb ? w->sp.deblock_alpha_offset : 0; st.sh.beta_off = st.sps.tool_addb ? w->sp.deblock_beta_offset : 0;
     if (st.sh.deblock && st.sps.tool_addb) { bw.se(st.sh.alpha_off); bw.se(st.sh.beta_off); }

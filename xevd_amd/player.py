@@ -25,7 +25,7 @@ class StreamDecoder:
         def to_device(p, cu_batch):
             with self._lock:
                 if self._dec is None:
-                    self._dec = XgpuDecoder(p["width"], p["height"], p["bit_depth"], device=self.device, iqt=p["iqt"], addb=p["addb"], alf=p["tool_alf"],
+                    self._dec = XgpuDecoder(p["width"], p["height"], p["bit_depth"], device=self.device, iqt=p["iqt"], admvp=p["admvp"], addb=p["addb"], alf=p["tool_alf"],
                                             eipd=p["eipd"], max_pics=34, chroma_qp_tables=p["chroma_qp_tables"], bit_depth_chroma=p["bit_depth_chroma"])
                 return self._dec.batch_create_from_struct(cu_batch)
         try:

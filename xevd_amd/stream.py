@@ -19,7 +19,7 @@ class StreamParams(C.Structure):
                 ("profile_main", C.c_int), ("tool_iqt", C.c_int), ("tool_ats", C.c_int), ("tool_addb", C.c_int),
                 ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int), ("tool_alf", C.c_int), ("tool_eipd", C.c_int),
                 ("crop", C.c_int * 4), ("tool_dra", C.c_int), ("dra_aps_id", C.c_int), ("cqt_present", C.c_int), ("cqt_same", C.c_int), ("cqt_global_offset", C.c_int),
-                ("cqt_num_points", C.c_int * 2), ("cqt_delta_in", (C.c_int * 16) * 2), ("cqt_delta_out", (C.c_int * 16) * 2), ("tool_htdf", C.c_int), ("ibc_log_max_size", C.c_int)]
+                ("cqt_num_points", C.c_int * 2), ("cqt_delta_in", (C.c_int * 16) * 2), ("cqt_delta_out", (C.c_int * 16) * 2), ("tool_htdf", C.c_int), ("tool_admvp", C.c_int), ("ibc_log_max_size", C.c_int)]
 
 
 class AlfAps(C.Structure):
@@ -46,7 +46,7 @@ class HostPicture(C.Structure):
                 ("slice_qp", C.c_int), ("qp_u_offset", C.c_int), ("qp_v_offset", C.c_int), ("deblock_on", C.c_int),
                 ("profile_main", C.c_int), ("tool_iqt", C.c_int), ("tool_ats", C.c_int), ("tool_addb", C.c_int),
                 ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int),
-                ("tool_alf", C.c_int), ("tool_eipd", C.c_int), ("crop", C.c_int * 4), ("chroma_qp_table", C.POINTER(C.c_int8) * 2),
+                ("tool_alf", C.c_int), ("tool_eipd", C.c_int), ("tool_admvp", C.c_int), ("crop", C.c_int * 4), ("chroma_qp_table", C.POINTER(C.c_int8) * 2),
                 ("dra_lut", C.POINTER(C.c_int32) * 3),
                 ("alf_on", C.c_int), ("alf", abi.AlfParams),
                 ("has_md5", C.c_int), ("md5", (C.c_uint8 * 16) * 3),
@@ -84,7 +84,7 @@ def load():
 class StreamWriter:
     def __init__(self, width, height, bit_depth=8, max_num_ref_pics=1, qp_u_offset=0, qp_v_offset=0, deblock=True, cu_qp_delta=True,
                  log2_sub_gop=0, main=False, iqt=False, ats=False, addb=False, alpha_off=0, beta_off=0, alf=False, eipd=False, crop=(0, 0, 0, 0),
-                 chroma_qp_points=None, dra_aps_id=None, htdf=False, ibc_log_max=0):
+                 chroma_qp_points=None, dra_aps_id=None, htdf=False, ibc_log_max=0, admvp=False):
         """chroma_qp_points: None, or (global_offset_flag, [table, ...]) with 1 (same for Cb and Cr) or 2 tables of (delta_in_minus1, delta_out) pairs"""
         self.lib = load()
         sp = StreamParams(width, height, bit_depth, max_num_ref_pics, log2_sub_gop, qp_u_offset, qp_v_offset, int(deblock), int(cu_qp_delta),
@@ -93,6 +93,7 @@ class StreamWriter:
             sp.crop[i] = int(crop[i])
         sp.tool_htdf = int(htdf)
         sp.ibc_log_max_size = int(ibc_log_max)
+        sp.tool_admvp = int(admvp)
         if dra_aps_id is not None:
             sp.tool_dra, sp.dra_aps_id = 1, int(dra_aps_id)
         if chroma_qp_points is not None:
@@ -218,7 +219,7 @@ def iter_stream(data, consume_batch=None):
                 "refs": [[hp.refp_poc[i][l] for i in range(hp.num_refp[l])] for l in range(2)],
                 "slice_qp": hp.slice_qp, "qp_u_offset": hp.qp_u_offset, "qp_v_offset": hp.qp_v_offset, "deblock_on": bool(hp.deblock_on),
                 "main": bool(hp.profile_main), "iqt": hp.tool_iqt, "ats": hp.tool_ats, "addb": hp.tool_addb,
-                "alpha_off": hp.deblock_alpha_offset, "beta_off": hp.deblock_beta_offset, "tool_alf": hp.tool_alf, "eipd": hp.tool_eipd, "crop": tuple(hp.crop[i] for i in range(4)),
+                "alpha_off": hp.deblock_alpha_offset, "beta_off": hp.deblock_beta_offset, "tool_alf": hp.tool_alf, "eipd": hp.tool_eipd, "admvp": hp.tool_admvp, "crop": tuple(hp.crop[i] for i in range(4)),
                 "dra": None if not hp.dra_lut[0] else [np.ctypeslib.as_array(hp.dra_lut[c], (1024,)).copy() for c in range(3)],
                 "chroma_qp_tables": None if not hp.chroma_qp_table[0] else [np.ctypeslib.as_array(hp.chroma_qp_table[c], (58 + 6 * (hp.bit_depth_chroma - 8),)).copy() for c in range(2)],
                 "alf": None if not hp.alf_on else {
