@@ -104,6 +104,8 @@ typedef struct xhost_stream_params {
     int tool_htdf;                         /* sps->tool_htdf: no CU syntax of its own; the parser hands the slice QP to the backend (batch.htdf_slice_qp) */
     int tool_admvp;                        /* sps->tool_admvp: skip and merge-mode CUs take one of up to six merge candidates, explicitly coded motion uses the
                                               resolution-indexed predictor and bi_idx (xevdm_eco.c:1519-1726); the backend then interpolates with the Main 8-tap tables */
+    int tool_amvr, tool_hmvp;              /* sub-tools of tool_admvp: sps->tool_amvr (mvr_idx: vector differences on a half / 1 / 2 / 4 sample grid, predictor position
+                                              coupled with the index), sps->tool_hmvp (history-based merge candidates and fallback predictors)  */
     int ibc_log_max_size;                  /* 0: sps->ibc_flag off.  2..7 (needs tool_eipd): intra block copy for CUs up to 2^n samples - a CU of the batch with
                                               pred_mode XGPU_MODE_IBC is written with ibc_flag and its block vector mv[0] (xevdm_eco.c:1401-1438, 1789-1800)  */
 } xhost_stream_params;

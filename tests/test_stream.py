@@ -61,6 +61,11 @@ CONFIGS = [
     (200, 136, 9, dict(main=True, admvp=True, inter_frac=0.8, max_refs=2, log2_sub_gop=2)),
     (264, 136, 17, dict(main=True, admvp=True, inter_frac=0.9, max_refs=3, log2_sub_gop=3, bit_depth=10, direct_frac=0.3, skip_frac=0.3)),
     (200, 136, 9, dict(main=True, admvp=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=5, inter_frac=0.7, max_refs=2, log2_sub_gop=2, bit_depth=10)),
+    # ... with sps->tool_hmvp (history candidates in the merge list and the fallback predictor, reset per CTU row) and sps->tool_amvr (mvr_idx: coarser
+    # vector grids, the predictor's neighbour position coupled with the index)
+    (200, 136, 9, dict(main=True, admvp=True, hmvp=True, inter_frac=0.9, max_refs=2, log2_sub_gop=2)),
+    (200, 136, 4, dict(main=True, admvp=True, amvr=True, inter_frac=0.9, max_refs=2)),
+    (264, 136, 9, dict(main=True, admvp=True, amvr=True, hmvp=True, iqt=True, addb=True, alf=True, inter_frac=0.9, max_refs=3, log2_sub_gop=3, bit_depth=10)),
     # ALF parameter sets that start from the standard's fixed filters (usage pattern 1: every class, 2: flagged classes; 4-bit set index per class)
     (264, 136, 8, dict(main=True, alf=True, addb=True, alf_fixed=True)),
     (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, alf_fixed=True, log2_sub_gop=2, max_refs=2, bit_depth=10)),

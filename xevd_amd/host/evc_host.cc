@@ -181,6 +181,7 @@ struct Models {
           intra_dir[2], mvp_idx[3], mvd[1], refi[2], dqp[1], skip[2],
           ats_mode[1], ats_inter_flag[2], ats_inter_quad[1], ats_inter_hor[3], ats_inter_pos[1],      // Main: xevd_def.h:559-563
           alf_ctb[1],
+          mvr_idx[4],                                                                                // tool_amvr: xevd_def.h:493
           merge_mode[1], merge_idx[5], bi_idx[2],                                                      // tool_admvp: xevd_def.h:461-465
           ibc_flag[2],                                                                               // sps->ibc_flag: xevd_def.h:485
           ipm_mpm_flag[1], ipm_mpm_idx[1], ipm_chroma[1];                                            // tool_eipd: xevd_def.h intra_luma_pred_mpm_flag / _idx, intra_chroma_pred_mode
@@ -221,6 +222,7 @@ enum { MODE_INTRA = XGPU_MODE_INTRA, MODE_INTER = XGPU_MODE_INTER, MODE_SKIP = X
 // ------------------------------------------------------------------------------------------------ stream / picture state
 struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, log2_ref_gap = 0, max_num_ref_pics = 1;
              int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0, tool_alf = 0, tool_eipd = 0, tool_dra = 0, tool_htdf = 0;
+             int tool_amvr = 0, tool_hmvp = 0;       // sub-tools of tool_admvp: adaptive vector resolution (mvr_idx), history-based candidates
              int tool_admvp = 0;                     // sps->tool_admvp: merge / resolution-indexed predictors instead of the Baseline candidate lists, 8-tap MC tables
              int ibc = 0, ibc_log_max = 0;            // sps->ibc_flag, sps->ibc_log_max_size (log2 of the largest IBC CU; xevdm_eco.c:1890-1898)
              int crop[4] = { 0, 0, 0, 0 };            // picture_crop_left / right / top / bottom_offset (xevd_eco.c:1349-1357), as xevd_pull reports them
@@ -596,6 +598,17 @@ struct Stream {          // everything both directions share
     // No SUCO here, so the right-hand neighbours are never decoded before the CU: the avail_lr LR_10 / LR_00 branch of the reference.
     // ------------------------------------------------------------------------------------------------------------------------------
     struct Motion { int8_t refi[2]; int16_t mv[2][2]; };
+    // sps->tool_hmvp: the motion of the last 23 inter CUs of the CTU row (XEVD_HISTORY_BUFFER; xevdm_hmvp_init at the start of every CTU row,
+    // xevdm.c:553-566, 2499-2503; update_history_buffer_parse_affine after every inter CU, :657-778)
+    Motion hist[23];
+    int hist_cnt = 0;
+    void history_reset() { hist_cnt = 0; for (Motion &m : hist) { m.refi[0] = m.refi[1] = -1; memset(m.mv, 0, sizeof(m.mv)); } }
+    void history_push(const Cu &cu)
+    {
+        if (hist_cnt == 23) { for (int i = 1; i < 23; i++) hist[i - 1] = hist[i]; hist_cnt = 22; }
+        Motion &m = hist[hist_cnt++];
+        for (int l = 0; l < 2; l++) { m.refi[l] = (int8_t)cu.refi[l]; m.mv[l][0] = cu.mv[l][0]; m.mv[l][1] = cu.mv[l][1]; }
+    }
     bool bi_applicable(const Cu &cu) const { return sh.type == XHOST_SLICE_B && (1 << cu.log2w) + (1 << cu.log2h) > 12; }      // xevdm_check_bi_applicability, xevdm_util.c:1083-1096
     // the five spatial neighbours H, D, E, I, A (xevdm_check_motion_availability, xevdm_util.c:594-748, last branch): decoded, inter, not IBC
     void adm_neighbours(const Cu &cu, int neb[5], bool valid[5]) const
@@ -693,6 +706,11 @@ struct Stream {          // everything both directions share
             if (temporal(((ye + 1) >> 1 << 1) * ws + (xe >> 1 << 1))) return;
         if (!tmvp_added && xe + 1 < ws && ((xe + 1) << 2 >> 6) == (xe << 2 >> 6))
             if (temporal((ye >> 1 << 1) * ws + ((xe + 1) >> 1 << 1))) return;
+        // every fourth entry of the history, newest first (with tool_hmvp off the buffer is empty)
+        for (int k = 3; k <= std::min(hist_cnt, max_n == 4 ? 15 : 23); k += 4) {
+            insert(hist[hist_cnt - k].refi, &hist[hist_cnt - k].mv[0][0]);
+            if (cnt >= max_n) return;
+        }
         if (bi) {       // combinations of the list-0 part of one candidate with the list-1 part of another
             static const int p0[20] = { 0, 1, 0, 2, 1, 2, 0, 3, 1, 3, 2, 3, 0, 4, 1, 4, 2, 4, 3, 4 }, p1[20] = { 1, 0, 2, 0, 2, 1, 3, 0, 3, 1, 3, 2, 4, 0, 4, 1, 4, 2, 4, 3 };
             const int cur = cnt;
@@ -729,32 +747,40 @@ struct Stream {          // everything both directions share
                 const int r = pic.refi[(size_t)neb[k] * 2 + l];
                 if (r >= 0 && (pass == 1 || r == cur_refi)) { refi = r; mv[0] = pic.mv[(size_t)neb[k] * 4 + l * 2]; mv[1] = pic.mv[(size_t)neb[k] * 4 + l * 2 + 1]; return; }
             }
+        if (!sps.tool_hmvp) return;
+        for (int pass = 0; pass < 2; pass++)                       // ... then the four newest history entries the same way
+            for (int k = 1; k <= std::min(hist_cnt, 4); k++) {
+                const int r = hist[hist_cnt - k].refi[l];
+                if (r >= 0 && (pass == 1 || r == cur_refi)) { refi = r; mv[0] = hist[hist_cnt - k].mv[l][0]; mv[1] = hist[hist_cnt - k].mv[l][1]; return; }
+            }
     }
     // reference index of a list of a bi-predicted CU that does not code it (bi_idx FL0 / FL1: xevdm_get_first_refi, xevdm_util.c:750-781), resolution index 0
-    int first_refi(const Cu &cu, int l) const
+    int first_refi(const Cu &cu, int l, int mvr) const
     {
         int neb[5], dref; bool valid[5]; int16_t dmv[2];
         adm_neighbours(cu, neb, valid);
         default_motion(neb, valid, 0, l, dref, dmv);
-        if (valid[0] && pic.refi[(size_t)neb[0] * 2 + l] >= 0) return pic.refi[(size_t)neb[0] * 2 + l];
+        if (valid[mvr] && pic.refi[(size_t)neb[mvr] * 2 + l] >= 0) return pic.refi[(size_t)neb[mvr] * 2 + l];      // the neighbour position is coupled with the resolution index
         return dref;
     }
     // the predictor of explicitly coded motion at resolution index 0 (xevdm_get_motion_from_mvr, xevdm_util.c:869-951): neighbour H, scaled to the
     // CU's reference when it points elsewhere, else the fallback motion
-    void mvr_predictor(const Cu &cu, int l, int cur_refi, int16_t mvp[2]) const
+    void mvr_predictor(const Cu &cu, int l, int cur_refi, int mvr, int16_t mvp[2]) const
     {
         int neb[5], dref; bool valid[5]; int16_t dmv[2];
         adm_neighbours(cu, neb, valid);
         default_motion(neb, valid, cur_refi, l, dref, dmv);
         const int n = (int)refp[l].size(), pc = refp[l][std::min(std::max(cur_refi, 0), n - 1)]->poc;
         auto ratio = [&](int r) -> int { const int t0 = poc - refp[l][std::min(std::max(r, 0), n - 1)]->poc; return t0 ? ((poc - pc) << 5) / t0 : 0; };
-        int r = valid[0] ? (int)pic.refi[(size_t)neb[0] * 2 + l] : -1;
+        int r = valid[mvr] ? (int)pic.refi[(size_t)neb[mvr] * 2 + l] : -1;
         if (r >= 0) {
-            const int16_t *m = &pic.mv[(size_t)neb[0] * 4 + l * 2];
+            const int16_t *m = &pic.mv[(size_t)neb[mvr] * 4 + l * 2];
             if (r == cur_refi) { mvp[0] = m[0]; mvp[1] = m[1]; } else scale_mv(ratio(r), m, mvp);
         } else {
             if (dref == cur_refi) { mvp[0] = dmv[0]; mvp[1] = dmv[1]; } else scale_mv(ratio(dref), dmv, mvp);
         }
+        const int rnd = mvr > 0 ? 1 << (mvr - 1) : 0;             // the predictor on the grid of the resolution, rounded away from zero at the half
+        for (int d = 0; d < 2; d++) mvp[d] = (int16_t)(mvp[d] >= 0 ? ((mvp[d] + rnd) >> mvr) << mvr : -(((-mvp[d] + rnd) >> mvr) << mvr));
     }
 
     // temporal direct motion of a B CU (xevd_get_mv_dir, xevd_util.c:540-566; call site xevd.c:713-717): the list-0 motion the
@@ -841,6 +867,7 @@ struct Stream {          // everything both directions share
     // SCU maps after a CU (xevd_set_dec_info, xevd_util.c:1574-1660; cod_eco xevd.c:797-803)
     void commit(const Cu &cu)
     {
+        if (sps.tool_hmvp && (cu.mode == MODE_INTER || cu.mode == MODE_SKIP)) history_push(cu);
         const int xs = cu.x >> 2, ys = cu.y >> 2, w = (1 << cu.log2w) >> 2, h = (1 << cu.log2h) >> 2;
         for (int r = 0; r < h; r++) for (int c = 0; c < w; c++) {
             const size_t k = (size_t)(ys + r) * pic.w_scu + xs + c;
@@ -933,7 +960,12 @@ struct Stream {          // everything both directions share
             // inter_pred_idc (no bi-prediction for CUs of 4x4 / 4x8 / 8x4), bi_idx of a bi-predicted CU (normal / list 0 / list 1 without a
             // coded difference; the latter two also derive their reference indices), per list reference index and vector difference.
             // The predictor is the resolution-indexed one (index 0 without AMVR): mv = predictor + mvd (xevd_get_inter_motion, xevdm.c:885-932)
-            cu.direct = c.bin(cu.direct, models.merge_mode[0]);
+            int mvr = 0;                                             // xevdm_eco_mvr_idx (xevdm_eco.c:814-817): quarter, half, 1, 2, 4 samples
+            if (sps.tool_amvr) {
+                if (enc) mvr = cu.direct ? 0 : ((cu.x >> 3) * 5 + (cu.y >> 3) * 3) % 11 % 5 * (((cu.x ^ cu.y) >> 2) & 1);      // about every second coded vector on a coarser grid
+                mvr = sym_trunc_unary(c, mvr, models.mvr_idx, 4, 5);
+            }
+            cu.direct = mvr == 0 ? c.bin(cu.direct, models.merge_mode[0]) : 0;
             if (cu.direct) {
                 cu.mvp_idx[0] = cu.mvp_idx[1] = sym_trunc_unary(c, cu.mvp_idx[0], models.merge_idx, 5, 6);
                 merge_motion(cu, cu.mvp_idx[0]);
@@ -969,12 +1001,12 @@ struct Stream {          // everything both directions share
                             }
                             cu.refi[l] = v;
                         } else cu.refi[l] = 0;
-                    } else cu.refi[l] = first_refi(cu, l);
+                    } else cu.refi[l] = first_refi(cu, l, mvr);
                     int16_t mvp[2];
-                    mvr_predictor(cu, l, cu.refi[l], mvp);
+                    mvr_predictor(cu, l, cu.refi[l], mvr, mvp);
                     if (bi_idx == 2 + l) cu.mvd[l][0] = cu.mvd[l][1] = 0;
                     else {
-                        if (enc) { cu.mvd[l][0] = (int16_t)(cu.mv[l][0] - mvp[0]); cu.mvd[l][1] = (int16_t)(cu.mv[l][1] - mvp[1]); }
+                        if (enc) { cu.mvd[l][0] = (int16_t)((cu.mv[l][0] - mvp[0]) >> mvr); cu.mvd[l][1] = (int16_t)((cu.mv[l][1] - mvp[1]) >> mvr); }
                         for (int d = 0; d < 2; d++) {                // xevd_eco_get_mvd, xevd_eco.c:491-536
                             const int v = cu.mvd[l][d], a = sym_abs_mvd(c, v < 0 ? -v : v, models.mvd[0]);
                             int sg = v < 0;
@@ -982,7 +1014,7 @@ struct Stream {          // everything both directions share
                             cu.mvd[l][d] = (int16_t)(sg ? -a : a);
                         }
                     }
-                    cu.mv[l][0] = (int16_t)(mvp[0] + cu.mvd[l][0]); cu.mv[l][1] = (int16_t)(mvp[1] + cu.mvd[l][1]);
+                    cu.mv[l][0] = (int16_t)(mvp[0] + (cu.mvd[l][0] << mvr)); cu.mv[l][1] = (int16_t)(mvp[1] + (cu.mvd[l][1] << mvr));
                 }
             }
         } else if (!intra) {
@@ -1192,7 +1224,8 @@ struct xhost_parser {
             unsupported |= br.get1();                    // sps_btt_flag
             unsupported |= br.get1();                    // sps_suco_flag
             s.tool_admvp = br.get1();
-            if (s.tool_admvp) for (int i = 0; i < 5; i++) unsupported |= br.get1();      // tool_affine, tool_amvr, tool_dmvr, tool_mmvd, tool_hmvp
+            s.tool_amvr = s.tool_hmvp = 0;
+            if (s.tool_admvp) { unsupported |= br.get1(); s.tool_amvr = br.get1(); unsupported |= br.get1(); unsupported |= br.get1(); s.tool_hmvp = br.get1(); }      // tool_affine, tool_amvr, tool_dmvr, tool_mmvd, tool_hmvp
             s.tool_eipd = br.get1();
             s.ibc = s.ibc_log_max = 0;
             if (s.tool_eipd && (s.ibc = br.get1())) { s.ibc_log_max = (int)br.ue() + 2; if (s.ibc_log_max > 7) return fail("bad SPS"); }
@@ -1207,7 +1240,7 @@ struct xhost_parser {
             unsupported |= br.get1();                    // dquant_flag: the Main decoder then codes QP deltas per cu_qp_delta_area (xevdm_eco.c), not per CU
             s.tool_dra = br.get1();
         }
-        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, affine, amvr, dmvr, mmvd, hmvp, cm_init, rpl, pocs, dquant in Main)");
+        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, affine, dmvr, mmvd, cm_init, rpl, pocs, dquant in Main)");
         s.log2_sub_gop = (int)br.ue();                   // tool_rpl = tool_pocs = 0
         if (s.log2_sub_gop == 0) s.log2_ref_gap = (int)br.ue();
         if (s.log2_sub_gop > 5) return fail("bad SPS");
@@ -1324,6 +1357,7 @@ struct xhost_parser {
         st.alf_ctb_flag.assign((size_t)w_ctu * h_ctu, 1);
         for (int k = 0; k < 3; k++) blk[k].assign(64 * 64, 0);
         for (int cy = 0; cy < h_ctu; cy++) for (int cx = 0; cx < w_ctu; cx++) {
+            if (cx == 0) st.history_reset();
             batch.ctu_start.push_back((uint32_t)batch.x.size());
             if (sh.alf_on && sh.alf_ctb_map) st.alf_ctb_flag[(size_t)cy * w_ctu + cx] = (uint8_t)dec.bin(0, st.models.alf_ctb[0]);      // xevdm.c:2411-2418
             const int rc = parse_tree(dec, cx << 6, cy << 6, 6);
@@ -1537,7 +1571,7 @@ struct xhost_writer {
         else {
             bw.put1(0); bw.put1(0);                      // btt suco
             bw.put1(sp.tool_admvp ? 1 : 0);
-            if (sp.tool_admvp) for (int i = 0; i < 5; i++) bw.put1(0);      // affine amvr dmvr mmvd hmvp
+            if (sp.tool_admvp) { bw.put1(0); bw.put1(sp.tool_amvr ? 1 : 0); bw.put1(0); bw.put1(0); bw.put1(sp.tool_hmvp ? 1 : 0); }      // affine amvr dmvr mmvd hmvp
             bw.put1(sp.tool_eipd ? 1 : 0);
             if (sp.tool_eipd) { bw.put1(sp.ibc_log_max_size ? 1 : 0); if (sp.ibc_log_max_size) bw.ue((uint32_t)(sp.ibc_log_max_size - 2)); }      // ibc_flag, ibc_log_max_size - 2
             bw.put1(0);                                  // cm_init
@@ -1600,6 +1634,8 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     w->sp.tool_dra = s.profile_main && sp->tool_dra; s.tool_dra = w->sp.tool_dra;
     w->sp.tool_htdf = s.profile_main && sp->tool_htdf; s.tool_htdf = w->sp.tool_htdf;
     w->sp.tool_admvp = s.profile_main && sp->tool_admvp; s.tool_admvp = w->sp.tool_admvp;
+    w->sp.tool_amvr = s.tool_admvp && sp->tool_amvr; s.tool_amvr = w->sp.tool_amvr;
+    w->sp.tool_hmvp = s.tool_admvp && sp->tool_hmvp; s.tool_hmvp = w->sp.tool_hmvp;
     w->sp.ibc_log_max_size = (s.tool_eipd && sp->ibc_log_max_size >= 2 && sp->ibc_log_max_size <= 7) ? sp->ibc_log_max_size : 0;
     s.ibc = w->sp.ibc_log_max_size != 0; s.ibc_log_max = w->sp.ibc_log_max_size;
     w->st.pps.cu_qp_delta = sp->cu_qp_delta;
@@ -1822,6 +1858,7 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
         tw.leaf[(size_t)(b->y[i] >> 2) * st.pic.w_scu + (b->x[i] >> 2)] = i;
     }
     for (int cy = 0; cy < h_ctu; cy++) for (int cx = 0; cx < w_ctu; cx++) {
+        if (cx == 0) st.history_reset();
         if (st.sh.alf_on && st.sh.alf_ctb_map) {
             const int f = w->next_alf_ctb.empty() ? 1 : (w->next_alf_ctb[(size_t)cy * w_ctu + cx] != 0);
             enc.bin(f, st.models.alf_ctb[0]);
