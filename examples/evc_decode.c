@@ -140,6 +140,14 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
         if (p.alf_on) CHECK(xgpu_alf(w->g, &p.alf));
         CHECK(xgpu_pad(w->g));
         CHECK(xgpu_frame_end(w->g));
+        if (p.n_dmvr_sub > 0) {
+            /* sps->tool_dmvr: the refined vectors of this picture go back to the parser before it parses the next one (temporal merge candidates) */
+            int16_t *mv = (int16_t *)malloc(sizeof(int16_t) * 4 * (size_t)p.n_dmvr_sub);
+            const int got = mv ? xgpu_batch_dmvr_mvs(w->g, db, mv, p.n_dmvr_sub) : -1;
+            const int fed = got == p.n_dmvr_sub ? xhost_parser_set_dmvr_mvs(ps, mv, got) : -1;
+            free(mv);
+            if (fed < 0) { fprintf(stderr, "DMVR vectors: backend %d, parser %d (%s)\n", got, fed, xhost_parser_error(ps)); xgpu_batch_destroy(w->g, db); return -1; }
+        }
         xgpu_batch_destroy(w->g, db);
 
         if (n_pics >= expected) { fprintf(stderr, "more pictures than slice NAL units\n"); return -1; }

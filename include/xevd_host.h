@@ -64,6 +64,8 @@ typedef struct xhost_picture {
     xgpu_alf_params alf;
     int has_md5;                           /* a picture-signature SEI follows the slice: MD5 of every plane's 16-bit samples    */
     uint8_t md5[3][16];                    /*   (xevd_eco_sei xevd_eco.c:1617-1678, xevd_md5_imgb xevd_util.c:985-1002)          */
+    int n_dmvr_sub;                        /* sps->tool_dmvr: the number of sub-blocks xgpu_batch_dmvr_mvs reports for this picture's batch (batch.dmvr flags the
+                                              merge-mode CUs); their vectors must come back through xhost_parser_set_dmvr_mvs before the next picture is parsed */
     int n_release;                         /* reference pictures unmarked before this one was stored (pic_marking_no_rpl) */
     int release_poc[32];
     xgpu_cu_batch batch;
@@ -72,6 +74,10 @@ typedef struct xhost_picture {
 xhost_parser *xhost_parser_open(const uint8_t *bytes, size_t size);
 /* 1: `out` holds the next picture in decoding order; 0: end of stream; < 0: error */
 int  xhost_parser_next(xhost_parser *p, xhost_picture *out);
+/* sps->tool_dmvr: the vectors xgpu_batch_dmvr_mvs returned for the picture the parser handed out last ([n_sub][list][x/y], n_sub = its n_dmvr_sub): the
+   parser stores them with the picture, where the temporal merge candidates of later pictures read them (the reference's map_mv holds the REFINED
+   vectors, src_main/xevdm_util.c:4327-4338).  0, or < 0 on a count mismatch.  Not needed for pictures with n_dmvr_sub == 0. */
+int  xhost_parser_set_dmvr_mvs(xhost_parser *p, const int16_t *mv, int n_sub);
 /* The same parser fed one NAL unit at a time (2-byte NAL header + payload, no length prefix - what xevd_decode receives):
    1: `out` holds a picture (has_md5 is 0: a signature SEI arrives as its own NAL unit); 0: consumed; < 0: error */
 xhost_parser *xhost_parser_open_nal(void);
@@ -104,6 +110,7 @@ typedef struct xhost_stream_params {
     int tool_htdf;                         /* sps->tool_htdf: no CU syntax of its own; the parser hands the slice QP to the backend (batch.htdf_slice_qp) */
     int tool_admvp;                        /* sps->tool_admvp: skip and merge-mode CUs take one of up to six merge candidates, explicitly coded motion uses the
                                               resolution-indexed predictor and bi_idx (xevdm_eco.c:1519-1726); the backend then interpolates with the Main 8-tap tables */
+    int tool_dmvr;                         /* sub-tool of tool_admvp: sps->tool_dmvr - skip and merge-mode CUs are flagged for decoder-side refinement */
     int tool_amvr, tool_hmvp;              /* sub-tools of tool_admvp: sps->tool_amvr (mvr_idx: vector differences on a half / 1 / 2 / 4 sample grid, predictor position
                                               coupled with the index), sps->tool_hmvp (history-based merge candidates and fallback predictors)  */
     int ibc_log_max_size;                  /* 0: sps->ibc_flag off.  2..7 (needs tool_eipd): intra block copy for CUs up to 2^n samples - a CU of the batch with

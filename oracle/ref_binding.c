@@ -24,7 +24,8 @@
  * objects in the link, oracle/Makefile.ref: libxevd_ref_hip.so) - the way ref_harness.c reaches static helpers; no reference source is copied.
  * The recursion over the split tree below is OUR walk over the reference's exported helpers (xevd_get_split_mode,
  * xevd_split_get_part_structure, xevdm_get_suco_flag, xevdm_split_get_suco_order, xevd_derive_mode_cons).
- * Limits (asserted): one tile per picture, 4:2:0.
+ * Limits (asserted): one tile per picture, 4:2:0, no local dual tree, not tool_dmvr together with tool_hmvp (the history would need refined vectors
+ * while the picture is still being parsed).
  */
 #include "xevdm.c"
 #include "xevdm_alf.c"
@@ -238,6 +239,9 @@ static int hip_dec_slice(XEVD_CTX *ctx, XEVD_CORE *core)
     xgpu_dbatch *db = NULL;
     int ret, l, i, cx, cy;
     if (ctx->num_tiles_in_slice != 1 || ctx->w_tile * ctx->h_tile != 1 || ctx->sps->chroma_format_idc != 1) return XEVD_ERR_UNSUPPORTED;
+    /* DMVR + HMVP: xevdm_set_dec_info leaves the refined vector of the first sub-block in core->mv (xevdm_util.c:4384-4387), which the history buffer then
+       takes (xevdm.c:1335-1342) - the next CUs' candidates would need the refinement result before the batch has run */
+    if (ctx->sps->tool_dmvr && ctx->sps->tool_hmvp) return XEVD_ERR_UNSUPPORTED;
     if (!s->g && (ret = hip_open(ctx)) < 0) return ret;
 
     /* entropy decoding of the tile, exactly as xevdm_dec_slice sets it up for its first worker (xevdm.c:2640-2663) */

@@ -154,6 +154,7 @@ int refh_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xg
                         int16_t *resid_out, int simd, int16_t *dmvr_mv_out)
 {
     size_t dmvr_n = 0;
+    int dmvr_applied = 0;
     harness *hn = harness_new(sp, fr, m, simd);
     XEVD_CTX *ctx = hn->ctx; XEVD_CORE *core = hn->core;
     XEVDM_CORE *mcore = (XEVDM_CORE *)core;
@@ -174,6 +175,7 @@ int refh_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xg
     for (i = 0; i < b->n_cu; i++) {
         const int x = b->x[i], y = b->y[i], lw = b->log2w[i], lh = b->log2h[i], w = 1 << lw, h = 1 << lh;
         size_t off = b->coef_off[i], o = off;
+        dmvr_applied = 0;
         core->log2_cuw = lw; core->log2_cuh = lh; core->cuw = w; core->cuh = h;
         core->x_scu = x >> 2; core->y_scu = y >> 2;
         core->scup = core->x_scu + core->y_scu * ctx->w_scu;
@@ -275,6 +277,7 @@ int refh_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xg
                          mcore->dmvr_template, mcore->dmvr_ref_pred_interpolated, mcore->dmvr_half_pred_interpolated, cand,
                          mcore->dmvr_padding_buf, &dmvr_flag, mcore->dmvr_mv, sp->tool_admvp,
                          sp->bit_depth_luma, sp->bit_depth_chroma, sp->chroma_format_idc);
+                dmvr_applied = dmvr_flag;
                 if (cand && core->refi[0] >= 0 && core->refi[1] >= 0 && w >= 8 && h >= 8) {
                     /* dmvr_mv is indexed by SCU inside the CU (:1783-1797): one entry per 16x16 sub-block, raster order */
                     const int dx = w < 16 ? w : 16, dy = h < 16 ? h : 16;
@@ -305,6 +308,13 @@ int refh_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xg
                        ctx->w_scu, ctx->h_scu, ctx->map_scu, cif, sp->bit_depth_luma);
         }
         xevd_set_dec_info(ctx, core);
+        if (dmvr_applied && !sp->tool_addb) {
+            /* xevdm_set_dec_info stores dmvr_mv in ctx->map_mv (xevdm_util.c:4327-4332), and that is the array the Main library's baseline deblocking
+               filter reads (xevdm_df.c:118,209; the ADDB filter gets map_unrefined_mv): one map here, holding what the sequence's filter reads */
+            int r, q;
+            for (r = 0; r < h >> 2; r++) for (q = 0; q < w >> 2; q++)
+                memcpy(ctx->map_mv[core->scup + r * ctx->w_scu + q], mcore->dmvr_mv[r * (w >> 2) + q], 4 * sizeof(s16));
+        }
         {   /* xevdm_set_dec_info's IBC flag (xevdm_util.c:4289-4296) */
             int r, q;
             for (r = 0; r < h >> 2; r++) for (q = 0; q < w >> 2; q++) {

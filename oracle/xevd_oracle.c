@@ -1124,6 +1124,8 @@ int orc_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xgp
     int16_t *pred[2][3], *res;
     int i, c, l;
     size_t dmvr_n = 0;
+    int16_t refined[64][2][2];
+    int dmvr_done = 0;
     for (l = 0; l < 2; l++) for (c = 0; c < 3; c++) pred[l][c] = (int16_t *)malloc(sizeof(int16_t) * MAX_CU * MAX_CU);
     res = (int16_t *)malloc(sizeof(int16_t) * MAX_CU * MAX_CU);
 
@@ -1145,14 +1147,15 @@ int orc_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xgp
             orc_affine_mc_cu(sp, fr, x, y, lw, lh, &b->refi[i * 2], (const int16_t (*)[3][2])&b->affine_mv[i * 12], b->affine[i], pred[0], pred[1]);
         else if (inter) {
             int done = 0;
+            dmvr_done = 0;
             if (b->dmvr && b->dmvr[i] && b->refi[i * 2] >= 0 && b->refi[i * 2 + 1] >= 0 && w >= 8 && h >= 8) {
-                int16_t refined[64][2][2];
                 const int nsub = (w > 16 ? w / 16 : 1) * (h > 16 ? h / 16 : 1);
                 int k;
                 done = orc_dmvr_cu(sp, fr, x, y, w, h, &b->refi[i * 2], (const int16_t (*)[2])&b->mv[i * 4], pred[0], pred[1], refined);
                 for (k = 0; k < nsub && dmvr_mv_out; k++)
                     memcpy(dmvr_mv_out + (dmvr_n + (size_t)k) * 4, done ? &refined[k][0][0] : &b->mv[i * 4], 4 * sizeof(int16_t));
                 dmvr_n += (size_t)nsub;
+                dmvr_done = done;
             }
             if (!done) orc_mc_cu(sp, fr, x, y, w, h, &b->refi[i * 2], (const int16_t (*)[2])&b->mv[i * 4], pred[0], pred[1]);
         }
@@ -1249,6 +1252,17 @@ int orc_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xgp
             orc_htdf(fr->cur.y + y * fr->cur.s_l + x, fr->cur.s_l, w, h, b->htdf_slice_qp, !inter, maps, x >> 2, y >> 2, !inter && b->constrained_intra_pred,
                      sp->bit_depth_luma);
         if (maps) set_dec_info(sp, b, i, maps);
+        if (maps && inter && dmvr_done && !sp->tool_addb) {
+            /* The SCU map after a refined CU.  xevdm_set_dec_info keeps both sets of vectors (map_mv refined, map_unrefined_mv not, xevdm_util.c:
+               4327-4338); the ADDB filter is handed the unrefined ones (xevdm.c:2009-2041) - but the Main library's copy of the BASELINE filter reads
+               ctx->map_mv itself (xevdm_df.c:118,209): with sps->tool_addb off the deblocking filter sees the REFINED vectors.  This map exists for
+               the filters only, so it holds what the filter of the sequence reads. */
+            const int dx = w < 16 ? w : 16, dy = h < 16 ? h : 16;
+            int sx, sy, u, v, k = 0;
+            for (sy = 0; sy < h; sy += dy) for (sx = 0; sx < w; sx += dx, k++)
+                for (v = 0; v < dy >> 2; v++) for (u = 0; u < dx >> 2; u++)
+                    memcpy(&maps->map_mv[((size_t)(((y + sy) >> 2) + v) * maps->w_scu + ((x + sx) >> 2) + u) * 4], &refined[k][0][0], 4 * sizeof(int16_t));
+        }
         if (maps && inter && b->affine && b->affine[i]) affine_set_mvf(b, i, maps);
     }
     for (l = 0; l < 2; l++) for (c = 0; c < 3; c++) free(pred[l][c]);

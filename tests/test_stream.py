@@ -66,6 +66,12 @@ CONFIGS = [
     (200, 136, 9, dict(main=True, admvp=True, hmvp=True, inter_frac=0.9, max_refs=2, log2_sub_gop=2)),
     (200, 136, 4, dict(main=True, admvp=True, amvr=True, inter_frac=0.9, max_refs=2)),
     (264, 136, 9, dict(main=True, admvp=True, amvr=True, hmvp=True, iqt=True, addb=True, alf=True, inter_frac=0.9, max_refs=3, log2_sub_gop=3, bit_depth=10)),
+    # ... and sps->tool_dmvr: skip / merge-mode CUs refined by the backend; the refined vectors come back to the parser (xhost_parser_set_dmvr_mvs)
+    # for the temporal candidates of later pictures, the baseline deblocking filter sees the refined vectors, ADDB the unrefined ones
+    (200, 136, 9, dict(main=True, admvp=True, dmvr=True, inter_frac=0.9, max_refs=2, log2_sub_gop=2, skip_frac=0.3, direct_frac=0.3)),
+    (136, 136, 6, dict(main=True, admvp=True, dmvr=True, inter_frac=0.9, max_refs=2, skip_frac=0.3, direct_frac=0.3)),
+    (264, 136, 17, dict(main=True, admvp=True, dmvr=True, amvr=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=4, inter_frac=0.9, max_refs=3,
+                        log2_sub_gop=3, bit_depth=10, skip_frac=0.3, direct_frac=0.3)),
     # ALF parameter sets that start from the standard's fixed filters (usage pattern 1: every class, 2: flagged classes; 4-bit set index per class)
     (264, 136, 8, dict(main=True, alf=True, addb=True, alf_fixed=True)),
     (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, alf_fixed=True, log2_sub_gop=2, max_refs=2, bit_depth=10)),

@@ -146,6 +146,12 @@ int decode_picture(Decoder *d, const xhost_picture &p, Image **out)
     if (rc >= 0 && p.alf_on) rc = xgpu_alf(d->g, &p.alf);
     if (rc >= 0) rc = xgpu_pad(d->g);
     if (rc >= 0) rc = xgpu_frame_end(d->g);
+    if (rc >= 0 && p.n_dmvr_sub > 0) {      // sps->tool_dmvr: this picture's refined vectors, for the temporal candidates of the pictures to come
+        std::vector<int16_t> mv((size_t)p.n_dmvr_sub * 4);
+        rc = xgpu_batch_dmvr_mvs(d->g, db, mv.data(), p.n_dmvr_sub);
+        if (rc == p.n_dmvr_sub) rc = xhost_parser_set_dmvr_mvs(d->ps, mv.data(), p.n_dmvr_sub);
+        else if (rc >= 0) rc = XGPU_ERR_UNEXPECTED;
+    }
     if (db) xgpu_batch_destroy(d->g, db);
     if (rc < 0) return rc;
 

@@ -149,6 +149,14 @@ __global__ __launch_bounds__(256) void k_dmvr(const DmvrArgs a)
 #pragma unroll
     for (int l = 0; l < 2; l++) { r16[l][0] = (st[l][0] << 2) + (l ? -tot[0] : tot[0]); r16[l][1] = (st[l][1] << 2) + (l ? -tot[1] : tot[1]); }
     if (lane < 4) out_mv[lane] = (int16_t)(r16[lane >> 1][lane & 1] >> 2);
+    // The deblocking filter's view of a refined CU: ADDB is handed the UNREFINED vectors (map_unrefined_mv, xevdm.c:2009-2041 - what k_inter wrote),
+    // the Main library's copy of the baseline filter reads ctx->map_mv, which holds the refined ones (xevdm_df.c:118,209; xevdm_util.c:4327-4332)
+    if (a.refined_to_map && lane < (dx >> 2) * (dy >> 2)) {
+        const int u = lane % (dx >> 2), v = lane / (dx >> 2);
+        ScuRec *m = a.maps + ((py >> 2) + v) * a.w_scu + (px >> 2) + u;
+        *(uint2 *)&m->mv[0][0] = make_uint2((uint32_t)(uint16_t)(r16[0][0] >> 2) | ((uint32_t)(uint16_t)(r16[0][1] >> 2) << 16),
+                                            (uint32_t)(uint16_t)(r16[1][0] >> 2) | ((uint32_t)(uint16_t)(r16[1][1] >> 2) << 16));
+    }
 
     // ---- the refined prediction: lane = 4 luma samples of a row (lanes below dx*dy/4) and one chroma sample per plane (lanes below dx*dy/4) ----
     const int nl4 = (dx * dy) >> 2, nc = (dx >> 1) * (dy >> 1);

@@ -950,7 +950,7 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
         memset(&d, 0, sizeof(d));
         d.cur_y = cur.y; d.cur_u = cur.u; d.cur_v = cur.v; d.s_l = c->s_l; d.s_c = c->s_c; d.pic_w = c->sp.width; d.pic_h = c->sp.height;
         d.bd_l = c->sp.bit_depth_luma; d.bd_c = c->sp.bit_depth_chroma; d.admvp = a.admvp; d.cur_poc = c->fp.poc;
-        d.cus = db->d_cus; d.items = db->d_dmvr_items; d.n_items = db->n_dmvr; d.resid = db->d_resid; d.out_mv = db->d_dmvr_mv;
+        d.cus = db->d_cus; d.items = db->d_dmvr_items; d.n_items = db->n_dmvr; d.resid = db->d_resid; d.out_mv = db->d_dmvr_mv; d.maps = c->d_maps; d.w_scu = c->w_scu; d.refined_to_map = c->sp.tool_addb ? 0 : 1;
         memcpy(d.refp, a.refp, sizeof(d.refp));
         TIMED(c, XGPU_K_DMVR, launch_dmvr(c, d));
     }

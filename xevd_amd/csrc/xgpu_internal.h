@@ -109,6 +109,8 @@ struct DmvrArgs {
     int      n_items;
     const int16_t  *resid;
     int16_t *out_mv;                   // [n_items][2][2] quarter-sample vectors kept for temporal prediction
+    ScuRec  *maps;                     // the SCU map the deblocking filter reads, and
+    int      w_scu, refined_to_map;    // whether it gets the refined vectors (baseline filter of the Main library) or keeps the unrefined ones (ADDB)
     RefEntry refp[XGPU_MAX_REFS][2];
 };
 

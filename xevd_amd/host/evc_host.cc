@@ -222,6 +222,7 @@ enum { MODE_INTRA = XGPU_MODE_INTRA, MODE_INTER = XGPU_MODE_INTER, MODE_SKIP = X
 // ------------------------------------------------------------------------------------------------ stream / picture state
 struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, log2_ref_gap = 0, max_num_ref_pics = 1;
              int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0, tool_alf = 0, tool_eipd = 0, tool_dra = 0, tool_htdf = 0;
+             int tool_dmvr = 0;                      // sps->tool_dmvr: merge-mode motion is refined by the backend (no syntax of its own)
              int tool_amvr = 0, tool_hmvp = 0;       // sub-tools of tool_admvp: adaptive vector resolution (mvr_idx), history-based candidates
              int tool_admvp = 0;                     // sps->tool_admvp: merge / resolution-indexed predictors instead of the Baseline candidate lists, 8-tap MC tables
              int ibc = 0, ibc_log_max = 0;            // sps->ibc_flag, sps->ibc_log_max_size (log2 of the largest IBC CU; xevdm_eco.c:1890-1898)
@@ -285,6 +286,7 @@ struct Cu {
     int ipm, ipm_c, cbf[3], qp;       // ipm_c: chroma mode with tool_eipd (DM 0, BI 1, DC 2, HOR 3, VER 4)
     int ats;                         // bit 0 ats_intra_cu, bit 1 ats_intra_mode_v, bit 2 ats_intra_mode_h (layout of xgpu_cu_batch.ats)
     int ats_inter;                   // ats_inter_info: idx | pos << 4
+    int dmvr;                        // tool_dmvr and a skip / merge-mode CU: mcore->dmvr_enable (xevdm.c:1272-1288)
 };
 
 struct Picture {         // SCU maps of the picture being parsed / written (ctx->map_scu, map_ipm, map_mv, map_refi; cod_eco)
@@ -303,11 +305,11 @@ struct Picture {         // SCU maps of the picture being parsed / written (ctx-
 
 struct Batch {           // the xgpu_cu_batch under construction
     std::vector<uint16_t> x, y;
-    std::vector<uint8_t> log2w, log2h, pred_mode, qp, cbf, ipm, ats, ats_inter;
+    std::vector<uint8_t> log2w, log2h, pred_mode, qp, cbf, ipm, ats, ats_inter, dmvr;
     std::vector<int8_t> refi;
     std::vector<int16_t> mv, coef;
     std::vector<uint32_t> coef_off, ctu_start;
-    void clear() { x.clear(); y.clear(); log2w.clear(); log2h.clear(); pred_mode.clear(); qp.clear(); cbf.clear(); ipm.clear(); ats.clear(); ats_inter.clear(); refi.clear(); mv.clear(); coef.clear(); coef_off.clear(); ctu_start.clear(); }
+    void clear() { x.clear(); y.clear(); log2w.clear(); log2h.clear(); pred_mode.clear(); qp.clear(); cbf.clear(); ipm.clear(); ats.clear(); ats_inter.clear(); dmvr.clear(); refi.clear(); mv.clear(); coef.clear(); coef_off.clear(); ctu_start.clear(); }
 };
 
 // ---- DRA parameter sets (APS type 1, SIG_PARAM_DRA) and the inverse-mapping tables the output stage applies (src_main/xevdm_dra.c) ----
@@ -914,13 +916,14 @@ struct Stream {          // everything both directions share
         int skip = 0;
         if (inter_slice) skip = c.bin(cu.mode == MODE_SKIP, models.skip[0]);
         if (!enc) { cu.mode = skip ? MODE_SKIP : MODE_INTRA; cu.refi[0] = cu.refi[1] = -1; memset(cu.mv, 0, sizeof(cu.mv)); memset(cu.mvd, 0, sizeof(cu.mvd));
-                    cu.mvp_idx[0] = cu.mvp_idx[1] = 0; cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0; cu.ipm = cu.ipm_c = 0; cu.ats = cu.ats_inter = 0; }
+                    cu.mvp_idx[0] = cu.mvp_idx[1] = 0; cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0; cu.ipm = cu.ipm_c = 0; cu.ats = cu.ats_inter = 0; cu.dmvr = 0; }
         int16_t cand[4][2];
         const int n_lists = sh.type == XHOST_SLICE_B ? 2 : 1;
         if (skip && sps.tool_admvp) {
             // Main: one merge index, truncated unary over five contexts (xevdm_eco_merge_idx, xevdm_eco.c:731-744; call site :1550-1551)
             cu.mvp_idx[0] = cu.mvp_idx[1] = sym_trunc_unary(c, cu.mvp_idx[0], models.merge_idx, 5, 6);
             merge_motion(cu, cu.mvp_idx[0]);
+            cu.dmvr = sps.tool_dmvr;
             cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0;
             cu.qp = qp_prev;
             return;
@@ -969,6 +972,7 @@ struct Stream {          // everything both directions share
             if (cu.direct) {
                 cu.mvp_idx[0] = cu.mvp_idx[1] = sym_trunc_unary(c, cu.mvp_idx[0], models.merge_idx, 5, 6);
                 merge_motion(cu, cu.mvp_idx[0]);
+                cu.dmvr = sps.tool_dmvr;
             } else {
                 int dir = 0;
                 if (n_lists == 2) {
@@ -1224,8 +1228,8 @@ struct xhost_parser {
             unsupported |= br.get1();                    // sps_btt_flag
             unsupported |= br.get1();                    // sps_suco_flag
             s.tool_admvp = br.get1();
-            s.tool_amvr = s.tool_hmvp = 0;
-            if (s.tool_admvp) { unsupported |= br.get1(); s.tool_amvr = br.get1(); unsupported |= br.get1(); unsupported |= br.get1(); s.tool_hmvp = br.get1(); }      // tool_affine, tool_amvr, tool_dmvr, tool_mmvd, tool_hmvp
+            s.tool_amvr = s.tool_hmvp = s.tool_dmvr = 0;
+            if (s.tool_admvp) { unsupported |= br.get1(); s.tool_amvr = br.get1(); s.tool_dmvr = br.get1(); unsupported |= br.get1(); s.tool_hmvp = br.get1(); }      // tool_affine, tool_amvr, tool_dmvr, tool_mmvd, tool_hmvp
             s.tool_eipd = br.get1();
             s.ibc = s.ibc_log_max = 0;
             if (s.tool_eipd && (s.ibc = br.get1())) { s.ibc_log_max = (int)br.ue() + 2; if (s.ibc_log_max > 7) return fail("bad SPS"); }
@@ -1240,7 +1244,11 @@ struct xhost_parser {
             unsupported |= br.get1();                    // dquant_flag: the Main decoder then codes QP deltas per cu_qp_delta_area (xevdm_eco.c), not per CU
             s.tool_dra = br.get1();
         }
-        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, affine, dmvr, mmvd, cm_init, rpl, pocs, dquant in Main)");
+        // tool_dmvr with tool_hmvp: xevdm_set_dec_info ends by copying map_mv[first SCU] - the REFINED vector of the CU's first sub-block - back into
+        // core->mv (xevdm_util.c:4384-4387), and that is what the history buffer then receives (xevdm.c:1335-1342): the merge candidates of the NEXT CUs of
+        // the same picture depend on the refinement search, i.e. on reference SAMPLES.  A front end that hands whole pictures to the backend cannot follow that.
+        if (s.tool_dmvr && s.tool_hmvp) return fail("tool_dmvr together with tool_hmvp: the history candidates depend on refined vectors inside the picture (not supported)");
+        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, affine, mmvd, cm_init, rpl, pocs, dquant in Main)");
         s.log2_sub_gop = (int)br.ue();                   // tool_rpl = tool_pocs = 0
         if (s.log2_sub_gop == 0) s.log2_ref_gap = (int)br.ue();
         if (s.log2_sub_gop > 5) return fail("bad SPS");
@@ -1417,7 +1425,39 @@ struct xhost_parser {
         b.n_ctu = w_ctu * h_ctu; b.ctu_cu_start = batch.ctu_start.data();
         b.constrained_intra_pred = st.pps.constrained_intra;
         b.htdf_slice_qp = st.sps.tool_htdf ? sh.qp : 0;
+        // sps->tool_dmvr: the merge-mode flags, and how many 16x16 sub-blocks of candidates (flag, two references, at least 8x8 - the order of
+        // xgpu_batch_dmvr_mvs) the backend will report vectors for; they go back in through xhost_parser_set_dmvr_mvs before the next picture
+        out->n_dmvr_sub = 0;
+        last_poc = st.poc; last_stored = st.is_ref_picture();
+        if (st.sps.tool_dmvr) {
+            b.dmvr = batch.dmvr.data();
+            for (int i = 0; i < b.n_cu; i++)
+                if (batch.dmvr[(size_t)i] && batch.refi[(size_t)i * 2] >= 0 && batch.refi[(size_t)i * 2 + 1] >= 0 && batch.log2w[(size_t)i] >= 3 && batch.log2h[(size_t)i] >= 3)
+                    out->n_dmvr_sub += (batch.log2w[(size_t)i] > 4 ? 1 << (batch.log2w[(size_t)i] - 4) : 1) * (batch.log2h[(size_t)i] > 4 ? 1 << (batch.log2h[(size_t)i] - 4) : 1);
+        }
+        last_n_dmvr = out->n_dmvr_sub;
         return 1;
+    }
+    int last_poc = 0, last_n_dmvr = 0;
+    bool last_stored = false;
+    // the refined vectors of the picture just handed out: what the reference keeps in map_mv for the temporal candidates of later pictures
+    // (dmvr_mv -> map_mv, src_main/xevdm_util.c:4327-4338); the picture's own CUs, the history and the deblocking filter use the unrefined ones
+    int set_dmvr_mvs(const int16_t *mv, int n)
+    {
+        if (n != last_n_dmvr || (n > 0 && !mv)) return fail("xhost_parser_set_dmvr_mvs: not the sub-block count of the last picture");
+        if (!last_stored || n == 0) return 0;
+        RefPic *r = nullptr;
+        for (RefPic &q : st.dpb) if (q.poc == last_poc) r = &q;
+        if (!r || r->mv.empty()) return 0;
+        const int ws = st.sps.width >> 2;
+        for (size_t i = 0; i < batch.x.size(); i++) {
+            if (!(batch.dmvr[i] && batch.refi[i * 2] >= 0 && batch.refi[i * 2 + 1] >= 0 && batch.log2w[i] >= 3 && batch.log2h[i] >= 3)) continue;
+            const int w = 1 << batch.log2w[i], h = 1 << batch.log2h[i], dx = std::min(w, 16), dy = std::min(h, 16);
+            for (int sy = 0; sy < h; sy += dy) for (int sx = 0; sx < w; sx += dx, mv += 4)
+                for (int v = 0; v < dy >> 2; v++) for (int u = 0; u < dx >> 2; u++)
+                    memcpy(&r->mv[((size_t)((batch.y[i] + sy) >> 2) + v) * ws * 4 + ((size_t)((batch.x[i] + sx) >> 2) + u) * 4], mv, sizeof(int16_t) * 4);
+        }
+        return 0;
     }
     size_t n_coef = 0;
 
@@ -1457,7 +1497,7 @@ struct xhost_parser {
         batch.qp.push_back((uint8_t)(cu.qp + 6 * (st.sps.bd_l - 8))); batch.qp.push_back((uint8_t)qp_u); batch.qp.push_back((uint8_t)qp_v);
         batch.cbf.push_back((uint8_t)(cu.cbf[0] | (cu.cbf[1] << 1) | (cu.cbf[2] << 2)));
         batch.ipm.push_back((uint8_t)cu.ipm); batch.ipm.push_back((uint8_t)(st.sps.tool_eipd ? cu.ipm_c : cu.ipm));      // Baseline: chroma mode = luma mode, xevd_eco.c:1154
-        batch.ats.push_back((uint8_t)cu.ats); batch.ats_inter.push_back((uint8_t)cu.ats_inter);
+        batch.ats.push_back((uint8_t)cu.ats); batch.ats_inter.push_back((uint8_t)cu.ats_inter); batch.dmvr.push_back((uint8_t)cu.dmvr);
         batch.coef_off.push_back((uint32_t)n_coef);
         const int tu_shift = (cu.ats_inter & 15) == 0 ? 0 : (((cu.ats_inter & 15) >= 3) ? 2 : 1);      // the TU is 1/2 or 1/4 of the CU
         for (int k = 0; k < 3; k++)
@@ -1477,6 +1517,7 @@ extern "C" xhost_parser *xhost_parser_open(const uint8_t *bytes, size_t size)
     p->data.assign(bytes, bytes + size);
     return p;
 }
+extern "C" int xhost_parser_set_dmvr_mvs(xhost_parser *p, const int16_t *mv, int n_sub) { return p ? p->set_dmvr_mvs(mv, n_sub) : XHOST_ERR_MALFORMED; }
 extern "C" const char *xhost_parser_error(const xhost_parser *p) { return p ? p->err.c_str() : "null parser"; }
 extern "C" void xhost_parser_close(xhost_parser *p) { delete p; }
 
@@ -1571,7 +1612,7 @@ struct xhost_writer {
         else {
             bw.put1(0); bw.put1(0);                      // btt suco
             bw.put1(sp.tool_admvp ? 1 : 0);
-            if (sp.tool_admvp) { bw.put1(0); bw.put1(sp.tool_amvr ? 1 : 0); bw.put1(0); bw.put1(0); bw.put1(sp.tool_hmvp ? 1 : 0); }      // affine amvr dmvr mmvd hmvp
+            if (sp.tool_admvp) { bw.put1(0); bw.put1(sp.tool_amvr ? 1 : 0); bw.put1(sp.tool_dmvr ? 1 : 0); bw.put1(0); bw.put1(sp.tool_hmvp ? 1 : 0); }      // affine amvr dmvr mmvd hmvp
             bw.put1(sp.tool_eipd ? 1 : 0);
             if (sp.tool_eipd) { bw.put1(sp.ibc_log_max_size ? 1 : 0); if (sp.ibc_log_max_size) bw.ue((uint32_t)(sp.ibc_log_max_size - 2)); }      // ibc_flag, ibc_log_max_size - 2
             bw.put1(0);                                  // cm_init
@@ -1636,6 +1677,7 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     w->sp.tool_admvp = s.profile_main && sp->tool_admvp; s.tool_admvp = w->sp.tool_admvp;
     w->sp.tool_amvr = s.tool_admvp && sp->tool_amvr; s.tool_amvr = w->sp.tool_amvr;
     w->sp.tool_hmvp = s.tool_admvp && sp->tool_hmvp; s.tool_hmvp = w->sp.tool_hmvp;
+    w->sp.tool_dmvr = s.tool_admvp && sp->tool_dmvr && !s.tool_hmvp; s.tool_dmvr = w->sp.tool_dmvr;      // not with tool_hmvp (see the parser)
     w->sp.ibc_log_max_size = (s.tool_eipd && sp->ibc_log_max_size >= 2 && sp->ibc_log_max_size <= 7) ? sp->ibc_log_max_size : 0;
     s.ibc = w->sp.ibc_log_max_size != 0; s.ibc_log_max = w->sp.ibc_log_max_size;
     w->st.pps.cu_qp_delta = sp->cu_qp_delta;

@@ -14,7 +14,7 @@ class StreamDecoder:
         """verify_md5: check downloaded pictures against the stream's picture-signature SEIs (the reference's
         XEVD_CFG_SET_USE_PIC_SIGNATURE), raising on a mismatch"""
         self.data, self.device, self.prefetch, self.verify_md5 = data, device, prefetch, verify_md5
-        self._lock, self._dec = threading.Lock(), None
+        self._lock, self._dec, self._abort = threading.Lock(), None, False
         self.apply_crop = apply_crop      # packed output: cut the SPS conformance window (the reference application writes uncropped pictures)
 
     N_SLOTS = 33      # the parser keeps at most 32 reference pictures (+ the current one): a slot is always free
@@ -30,7 +30,16 @@ class StreamDecoder:
                 return self._dec.batch_create_from_struct(cu_batch)
         try:
             for p in stream.iter_stream(self.data, consume_batch=to_device):
+                if p["n_dmvr_sub"]:
+                    p["_dmvr"] = [threading.Event(), None]
                 q.put(p)
+                if p["n_dmvr_sub"]:
+                    # sps->tool_dmvr: the temporal candidates of later pictures read this picture's REFINED vectors - the parser waits for the
+                    # backend's (xgpu_batch_dmvr_mvs, fetched by the consumer right after the picture's kernels were queued)
+                    while not p["_dmvr"][0].wait(0.05):
+                        if self._abort:
+                            return
+                    p["dmvr_feedback"](p["_dmvr"][1])
             q.put(None)
         except Exception as e:      # surfaced in the consumer thread
             q.put(e)
@@ -59,6 +68,9 @@ class StreamDecoder:
             with self._lock:
                 dec.decode_picture(cur, p["poc"], refs, hb, deblock=p["deblock_on"], pad=True, qp_u_offset=p["qp_u_offset"], qp_v_offset=p["qp_v_offset"],
                                    alpha_off=p["alpha_off"], beta_off=p["beta_off"], alf=p["alf"])
+                if p["n_dmvr_sub"]:
+                    p["_dmvr"][1] = dec.batch_dmvr_mvs(hb)
+                    p["_dmvr"][0].set()
                 dec.batch_destroy(hb)          # back to the pool; queued kernels keep reading it (same HIP stream)
             planes = None
             if download and output_bit_depth is not None:
@@ -98,6 +110,7 @@ class StreamDecoder:
                 self._dec.sync()
         finally:
             # let the parser thread finish (it may be inside a backend call), then release the device
+            self._abort = True
             while th.is_alive():
                 try:
                     q.get(timeout=0.05)

@@ -19,7 +19,7 @@ class StreamParams(C.Structure):
                 ("profile_main", C.c_int), ("tool_iqt", C.c_int), ("tool_ats", C.c_int), ("tool_addb", C.c_int),
                 ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int), ("tool_alf", C.c_int), ("tool_eipd", C.c_int),
                 ("crop", C.c_int * 4), ("tool_dra", C.c_int), ("dra_aps_id", C.c_int), ("cqt_present", C.c_int), ("cqt_same", C.c_int), ("cqt_global_offset", C.c_int),
-                ("cqt_num_points", C.c_int * 2), ("cqt_delta_in", (C.c_int * 16) * 2), ("cqt_delta_out", (C.c_int * 16) * 2), ("tool_htdf", C.c_int), ("tool_admvp", C.c_int), ("tool_amvr", C.c_int), ("tool_hmvp", C.c_int), ("ibc_log_max_size", C.c_int)]
+                ("cqt_num_points", C.c_int * 2), ("cqt_delta_in", (C.c_int * 16) * 2), ("cqt_delta_out", (C.c_int * 16) * 2), ("tool_htdf", C.c_int), ("tool_admvp", C.c_int), ("tool_dmvr", C.c_int), ("tool_amvr", C.c_int), ("tool_hmvp", C.c_int), ("ibc_log_max_size", C.c_int)]
 
 
 class AlfAps(C.Structure):
@@ -50,7 +50,7 @@ class HostPicture(C.Structure):
                 ("dra_lut", C.POINTER(C.c_int32) * 3),
                 ("alf_on", C.c_int), ("alf", abi.AlfParams),
                 ("has_md5", C.c_int), ("md5", (C.c_uint8 * 16) * 3),
-                ("n_release", C.c_int), ("release_poc", C.c_int * 32), ("batch", abi.CuBatch)]
+                ("n_dmvr_sub", C.c_int), ("n_release", C.c_int), ("release_poc", C.c_int * 32), ("batch", abi.CuBatch)]
 
 
 _lib = None
@@ -68,6 +68,7 @@ def load():
         lib.xhost_parser_error.restype = C.c_char_p
         lib.xhost_parser_error.argtypes = [C.c_void_p]
         lib.xhost_parser_close.argtypes = [C.c_void_p]
+        lib.xhost_parser_set_dmvr_mvs.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         lib.xhost_writer_open.restype = C.c_void_p
         lib.xhost_writer_open.argtypes = [C.POINTER(StreamParams)]
         lib.xhost_writer_add_picture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.CuBatch)]
@@ -84,7 +85,7 @@ def load():
 class StreamWriter:
     def __init__(self, width, height, bit_depth=8, max_num_ref_pics=1, qp_u_offset=0, qp_v_offset=0, deblock=True, cu_qp_delta=True,
                  log2_sub_gop=0, main=False, iqt=False, ats=False, addb=False, alpha_off=0, beta_off=0, alf=False, eipd=False, crop=(0, 0, 0, 0),
-                 chroma_qp_points=None, dra_aps_id=None, htdf=False, ibc_log_max=0, admvp=False, amvr=False, hmvp=False):
+                 chroma_qp_points=None, dra_aps_id=None, htdf=False, ibc_log_max=0, admvp=False, amvr=False, hmvp=False, dmvr=False):
         """chroma_qp_points: None, or (global_offset_flag, [table, ...]) with 1 (same for Cb and Cr) or 2 tables of (delta_in_minus1, delta_out) pairs"""
         self.lib = load()
         sp = StreamParams(width, height, bit_depth, max_num_ref_pics, log2_sub_gop, qp_u_offset, qp_v_offset, int(deblock), int(cu_qp_delta),
@@ -94,7 +95,7 @@ class StreamWriter:
         sp.tool_htdf = int(htdf)
         sp.ibc_log_max_size = int(ibc_log_max)
         sp.tool_admvp = int(admvp)
-        sp.tool_amvr, sp.tool_hmvp = int(amvr), int(hmvp)
+        sp.tool_amvr, sp.tool_hmvp, sp.tool_dmvr = int(amvr), int(hmvp), int(dmvr)
         if dra_aps_id is not None:
             sp.tool_dra, sp.dra_aps_id = 1, int(dra_aps_id)
         if chroma_qp_points is not None:
@@ -188,6 +189,15 @@ def _arr(ptr, n, dtype):
     return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
 
 
+def _feedback(lib, h):
+    def feed(mv):
+        mv = np.ascontiguousarray(mv, np.int16)
+        rc = lib.xhost_parser_set_dmvr_mvs(h, mv.ctypes.data, int(mv.size // 4))
+        if rc < 0:
+            raise RuntimeError(f"xhost_parser_set_dmvr_mvs -> {rc}: {lib.xhost_parser_error(h).decode()}")
+    return feed
+
+
 def iter_stream(data, consume_batch=None):
     """generator over the pictures of a .evc byte string in decoding order: dict(params..., batch=dict of numpy arrays in the
     layout of synth.gen_frame).  The C parser runs inside each next() with the GIL released (ctypes).
@@ -213,6 +223,7 @@ def iter_stream(data, consume_batch=None):
                 "ats_inter": _arr(b.ats_inter, n, np.uint8) if b.ats_inter else None, "ipm": _arr(b.ipm, n * 2, np.uint8).reshape(n, 2),
                 "coef_off": _arr(b.coef_off, n, np.uint32), "coef": _arr(b.coef, max(b.n_coef, 1), np.int16), "n_coef": int(b.n_coef),
                 "ctu_cu_start": _arr(b.ctu_cu_start, b.n_ctu + 1, np.uint32), "constrained_intra_pred": int(b.constrained_intra_pred), "htdf_slice_qp": int(b.htdf_slice_qp),
+                "dmvr": _arr(b.dmvr, n, np.uint8) if b.dmvr else None,
             }
             params = {
                 "width": hp.width, "height": hp.height, "bit_depth": hp.bit_depth_luma, "bit_depth_chroma": hp.bit_depth_chroma, "poc": hp.poc, "temporal_id": hp.temporal_id, "slice_type": hp.slice_type,
@@ -228,6 +239,9 @@ def iter_stream(data, consume_batch=None):
                     "chroma_coef": _arr(hp.alf.chroma_coef, 7, np.int16), "ctb_flag": _arr(hp.alf.ctb_flag, b.n_ctu, np.uint8), "across_tiles": 0},
                 "md5": [bytes(hp.md5[c]) for c in range(3)] if hp.has_md5 else None,
                 "release": [hp.release_poc[i] for i in range(hp.n_release)], "batch": batch,
+                # sps->tool_dmvr: the number of sub-blocks whose vectors (xgpu_batch_dmvr_mvs / the oracle's dmvr_mv_out) must be handed to
+                # dmvr_feedback() before the generator is advanced - the temporal candidates of later pictures read them
+                "n_dmvr_sub": int(hp.n_dmvr_sub), "dmvr_feedback": _feedback(lib, h),
             }
             if consume_batch is not None:
                 params["batch"] = consume_batch(params, hp.batch)
