@@ -12,14 +12,17 @@
  * Wire format: 4-byte big-endian NAL length prefix (XEVD_NAL_UNIT_LENGTH_BYTE, inc/xevd.h:133; app/xevd_app.c:52-107),
  * 2-byte NAL header (xevd_eco.c:1178-1209).
  *
- * Scope: Baseline profile, and Main-profile streams that switch on only tools of the back half - sps->tool_iqt, tool_ats,
- * tool_addb (syntax of src_main/xevdm_eco.c: SPS :1847-2004, slice header :2510-2800, ATS flags :128-190,354-393,902-934) -
- * tool_eipd (intra mode syntax src_base/xevd_eco.c:842-910, most-probable-mode lists src_main/xevdm_ipred.c:320-767)
- * tool_dra (DRA APS NAL units src_main/xevdm_eco.c:2319-2375, PPS switch :2054-2060, table construction src_main/xevdm_dra.c:39-270)
- * and tool_alf (APS NAL units :2082-2135,2376-2477, coefficient syntax :2154-2318, slice-level parameters :2479-2657, per-CTU flags
- * src_main/xevdm.c:2411-2418; coefficient reconstruction alf_recon_coef src_main/xevdm_alf.c:700-794; fixed filter sets are not
- * supported yet) - with every other Main tool off; SPS chroma QP mapping tables and cropping offsets are parsed, a VUI is skipped (the CU syntax is then the Baseline one); 4:2:0, one tile and one slice per picture,
- * I / P / B slices incl. temporal layers (hierarchical sub-GOPs).
+ * Scope: Baseline profile, and Main-profile streams with any of - sps->tool_iqt, tool_ats, tool_addb (syntax of src_main/xevdm_eco.c: SPS :1847-2004,
+ * slice header :2510-2800, ATS flags :128-190,354-393,902-934), tool_eipd (intra mode syntax src_base/xevd_eco.c:842-910, most-probable-mode lists
+ * src_main/xevdm_ipred.c:320-767), ibc_flag (ibc_flag + block vector per CU, xevdm_eco.c:1401-1438,1789-1800), tool_htdf, tool_dra (DRA APS NAL units
+ * :2319-2375, PPS switch :2054-2060, table construction src_main/xevdm_dra.c:39-270), tool_alf (APS NAL units :2082-2135,2376-2477 with the fixed
+ * filter sets, coefficient syntax :2154-2318, slice-level parameters :2479-2657, per-CTU flags src_main/xevdm.c:2411-2418, alf_recon_coef
+ * src_main/xevdm_alf.c:700-794), and tool_admvp with its sub-tools tool_amvr, tool_hmvp and tool_dmvr: merge_idx / merge_mode_flag / mvr_idx / bi_idx
+ * syntax (xevdm_eco.c:1519-1726), merge candidates incl. the temporal and history ones (src_main/xevdm_util.c:594-1391,3729-3818), the resolution-indexed
+ * predictor (:750-951), intra-only 4x4 CUs; tool_dmvr needs the backend's refined vectors back per picture (xhost_parser_set_dmvr_mvs) and is refused
+ * together with tool_hmvp.  Not parsed: sps_btt_flag / sps_suco_flag (split syntax), tool_affine, tool_mmvd, tool_cm_init (and ADCC),
+ * tool_rpl / tool_pocs, dquant.  SPS chroma QP mapping tables and cropping offsets are parsed, a VUI is skipped; 4:2:0, one tile and one slice per
+ * picture, I / P / B slices incl. temporal layers (hierarchical sub-GOPs).
  * Conventions as xevd_hip.h: 0 / negative XEVD_ERR_* codes, nothing throws, one object per stream.
  */
 #ifndef XEVD_HOST_H
