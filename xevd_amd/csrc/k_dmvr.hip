@@ -18,8 +18,10 @@
 #include "mc_filters.h"
 
 #define DM_BL   20            // bilinear block: (16 + 4)^2
-#define DM_WL   23            // luma window: (16 + 7)^2
-#define DM_WC   11            // chroma window: (8 + 3)^2 per plane
+#define DM_RS   24            // row stride of the staged windows: three 16-byte chunks (the 21 / 23 samples a 16-wide sub-block needs per row)
+#define DM_CS   16            // row stride of a chroma window: two chunks (11 samples)
+#define DM_WIN  (23 * DM_RS + 2 * 11 * DM_CS)      // luma + two chroma windows of the final prediction; the two 21-row search windows (2 x 21 x 24) use the same space
+#define DM_STAGE (2 * 21 * DM_RS > DM_WIN ? 2 * 21 * DM_RS : DM_WIN)
 
 __device__ __forceinline__ void dm_sync()
 {
@@ -47,55 +49,69 @@ __device__ __forceinline__ int dm_div_q7(long long n, long long d)      // div_f
 }
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
-__global__ __launch_bounds__(256) void k_dmvr(const DmvrArgs a)
+struct DmvrCu {        // the wave-uniform state of one sub-block
+    int cu_x, cu_y, cw, chh, cbf, px, py, ats;
+    uint32_t coef_off;
+    int st[2][2], mvu[2][2];
+    const int16_t *ry[2], *ru[2], *rv[2];      // the two references' planes (fields, not RefEntry copies: those went through scratch)
+    int rpoc[2];
+};
+
+__device__ __forceinline__ void dmvr_unpack(const DmvrArgs &a, const uint4 r0, const uint4 r1, int isx, int isy, DmvrCu &u)
 {
-    __shared__ int16_t s_bl[4][2][DM_BL * DM_BL];
-    __shared__ int16_t s_win[4][DM_WL * DM_WL + 2 * DM_WC * DM_WC];
-    __shared__ int16_t s_tmp[4][DM_WL * 16];
-    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int item = blockIdx.x * 4 + wv;
-    if (item >= a.n_items) return;
-    const DmvrItem it = a.items[item];
-    const uint4 r0 = ((const uint4 *)&a.cus[it.cu])[0], r1 = ((const uint4 *)&a.cus[it.cu])[1];
-    const int cu_x = r0.x & 0xFFFF, cu_y = r0.x >> 16, cw = 1 << (r0.y & 0xFF), chh = 1 << ((r0.y >> 8) & 0xFF), cbf = r0.y >> 24;
+    u.cu_x = r0.x & 0xFFFF; u.cu_y = r0.x >> 16; u.cw = 1 << (r0.y & 0xFF); u.chh = 1 << ((r0.y >> 8) & 0xFF); u.cbf = r0.y >> 24;
     const int refi[2] = { (int)(int8_t)(r0.z & 0xFF), (int)(int8_t)((r0.z >> 8) & 0xFF) };
-    const uint32_t coef_off = r0.w;
-    const int mvu[2][2] = { { (int)(int16_t)(r1.x & 0xFFFF), (int)(int16_t)(r1.x >> 16) }, { (int)(int16_t)(r1.y & 0xFFFF), (int)(int16_t)(r1.y >> 16) } };
-    const int dx = min(cw, 16), dy = min(chh, 16), px = cu_x + it.sx * 4, py = cu_y + it.sy * 4;
+    u.coef_off = r0.w; u.ats = (int)((r1.w >> 8) & 0xFF);
+    u.mvu[0][0] = (int)(int16_t)(r1.x & 0xFFFF); u.mvu[0][1] = (int)(int16_t)(r1.x >> 16); u.mvu[1][0] = (int)(int16_t)(r1.y & 0xFFFF); u.mvu[1][1] = (int)(int16_t)(r1.y >> 16);
+    u.px = u.cu_x + isx * 4; u.py = u.cu_y + isy * 4;
     // starting vectors: the CU's, clipped like xevd_mv_clip (mv_clip, xevdm_mc.c:1831-1858)
-    int st[2][2];
     {
         const int min_c = -(128 << 2), max_x = (a.pic_w - 1 + 128) << 2, max_y = (a.pic_h - 1 + 128) << 2;
 #pragma unroll
         for (int l = 0; l < 2; l++) {
-            int mx = mvu[l][0], my = mvu[l][1];
-            if ((cu_x << 2) + mvu[l][0] < min_c) mx = min_c - (cu_x << 2);
-            if ((cu_y << 2) + mvu[l][1] < min_c) my = min_c - (cu_y << 2);
-            if ((cu_x << 2) + mvu[l][0] + (cw << 2) - 4 > max_x) mx = max_x - (cu_x << 2) - (cw << 2) + 4;
-            if ((cu_y << 2) + mvu[l][1] + (chh << 2) - 4 > max_y) my = max_y - (cu_y << 2) - (chh << 2) + 4;
-            st[l][0] = mx; st[l][1] = my;
+            int mx = u.mvu[l][0], my = u.mvu[l][1];
+            if ((u.cu_x << 2) + u.mvu[l][0] < min_c) mx = min_c - (u.cu_x << 2);
+            if ((u.cu_y << 2) + u.mvu[l][1] < min_c) my = min_c - (u.cu_y << 2);
+            if ((u.cu_x << 2) + u.mvu[l][0] + (u.cw << 2) - 4 > max_x) mx = max_x - (u.cu_x << 2) - (u.cw << 2) + 4;
+            if ((u.cu_y << 2) + u.mvu[l][1] + (u.chh << 2) - 4 > max_y) my = max_y - (u.cu_y << 2) - (u.chh << 2) + 4;
+            u.st[l][0] = mx; u.st[l][1] = my;
         }
     }
-    const RefEntry re[2] = { a.refp[refi[0]][0], a.refp[refi[1]][1] };
-    int16_t *out_mv = a.out_mv + (size_t)item * 4;
-    if (!dmvr_applies(a.cur_poc, re[0].poc, re[1].poc)) {
-        // the CU was predicted by k_inter; the vector kept for temporal prediction is its own
-        if (lane < 4) out_mv[lane] = (int16_t)mvu[lane >> 1][lane & 1];
-        return;
-    }
+#pragma unroll
+    for (int l = 0; l < 2; l++) { const RefEntry &e = a.refp[refi[l]][l]; u.ry[l] = e.y; u.ru[l] = e.u; u.rv[l] = e.v; u.rpoc[l] = e.poc; }
+}
+
+// One sub-block of DX x DY luma samples (8 or 16 each way: compile-time, so that every index split below is a shift or a multiplication by a constant).
+// Every global read of a phase is ONE sweep of 16-byte loads into the wave's LDS (rows of three / two chunks); the filters then run out of LDS.
+template <int DX, int DY>
+__device__ __forceinline__ void dmvr_block(const DmvrArgs &a, const uint4 r0, const uint4 r1, int isx, int isy, int16_t *BL, int16_t *W, int16_t *T, int16_t *out_mv, int lane)
+{
+    DmvrCu u;
+    dmvr_unpack(a, r0, r1, isx, isy, u);
+    constexpr int CH = DX == 16 ? 3 : 2;                       // 16-byte chunks per staged luma row
     const int bd = a.bd_l, maxl = (1 << a.bd_l) - 1, maxc = (1 << a.bd_c) - 1;
     const int sh1 = min(4, bd - 8), sh2 = max(8, 20 - bd), off2 = 1 << (sh2 - 1);
 
-    // ---- bilinear blocks of the sub-block + 2 samples around it, both lists ----
+    // ---- search windows: (DY + 5) rows x (DX + 5) samples of both lists at the (clipped) starting vector, then the bilinear blocks ----
+    int bfx[2], bfy[2];
 #pragma unroll
     for (int l = 0; l < 2; l++) {
-        const int gx = ((cu_x << 2) + st[l][0] - 8) << 2, gy = ((cu_y << 2) + st[l][1] - 8) << 2;      // sixteenth samples of the CU block's corner
-        const int fx = gx & 15, fy = gy & 15, c0 = 64 - 4 * fx, c1 = 4 * fx, d0 = 64 - 4 * fy, d1 = 4 * fy;
-        const gs16 src = (gs16)re[l].y + ((gy >> 4) + it.sy * 4) * a.s_l + (gx >> 4) + it.sx * 4;
-        for (int i = lane; i < (dy + 4) * (dx + 4); i += 64) {
-            const int r = i / (dx + 4), c = i - r * (dx + 4);
-            const gs16 p = src + r * a.s_l + c;
-            const int A = p[0], B = p[1], Cc = p[a.s_l], D = p[a.s_l + 1];
+        const int gx = ((u.cu_x << 2) + u.st[l][0] - 8) << 2, gy = ((u.cu_y << 2) + u.st[l][1] - 8) << 2;      // sixteenth samples of the CU block's corner
+        bfx[l] = gx & 15; bfy[l] = gy & 15;
+        const gs16 src = (gs16)u.ry[l] + ((gy >> 4) + (u.py - u.cu_y)) * a.s_l + (gx >> 4) + (u.px - u.cu_x);
+        for (int i = lane; i < (DY + 5) * CH; i += 64) {
+            const int r = i / CH, k = i - r * CH;
+            *(uint4 *)(W + l * 21 * DM_RS + r * DM_RS + 8 * k) = gload16(src + r * a.s_l + 8 * k);
+        }
+    }
+    dm_sync();
+#pragma unroll
+    for (int l = 0; l < 2; l++) {
+        const int fx = bfx[l], fy = bfy[l], c0 = 64 - 4 * fx, c1 = 4 * fx, d0 = 64 - 4 * fy, d1 = 4 * fy;
+        const int16_t *R = W + l * 21 * DM_RS;
+        for (int i = lane; i < (DY + 4) * (DX + 4); i += 64) {
+            const int r = i / (DX + 4), c = i - r * (DX + 4);
+            const int A = R[r * DM_RS + c], B = R[r * DM_RS + c + 1], Cc = R[(r + 1) * DM_RS + c], D = R[(r + 1) * DM_RS + c + 1];
             int v;
             if (!fx && !fy) v = A;
             else if (fx && !fy) v = clampi((c0 * A + c1 * B) >> 6, 0, maxl);
@@ -104,7 +120,7 @@ __global__ __launch_bounds__(256) void k_dmvr(const DmvrArgs a)
                 const int t0 = (int)(int16_t)((c0 * A + c1 * B) >> sh1), t1 = (int)(int16_t)((c0 * Cc + c1 * D) >> sh1);
                 v = clampi((d0 * t0 + d1 * t1 + off2) >> sh2, 0, maxl);
             }
-            s_bl[wv][l][r * DM_BL + c] = (int16_t)v;
+            BL[l * DM_BL * DM_BL + r * DM_BL + c] = (int16_t)v;
         }
     }
     dm_sync();
@@ -112,33 +128,33 @@ __global__ __launch_bounds__(256) void k_dmvr(const DmvrArgs a)
     // ---- the search: list 0 at +offset against list 1 at -offset ----
     auto cost_at = [&](int ox, int oy) -> int {
         int s = 0;
-        for (int i = lane; i < dx * dy; i += 64) {
-            const int r = i / dx, c = i - r * dx;
-            s += abs((int)s_bl[wv][0][(2 + oy + r) * DM_BL + 2 + ox + c] - (int)s_bl[wv][1][(2 - oy + r) * DM_BL + 2 - ox + c]);
+#pragma unroll
+        for (int i0 = 0; i0 < DX * DY; i0 += 64) {
+            const int i = i0 + lane, r = i / DX, c = i - r * DX;
+            s += abs((int)BL[(2 + oy + r) * DM_BL + 2 + ox + c] - (int)BL[DM_BL * DM_BL + (2 - oy + r) * DM_BL + 2 - ox + c]);
         }
         return wave_sum(s);
     };
-    enum { BOTTOM = 0, TOP, RIGHT, LEFT, DIAG, CENTER = 8 };
-    int tot[2] = { 0, 0 }, not_zero = 1, min_cost = 0, cost[9];
-    for (int k = 0; k < 9; k++) cost[k] = 0x7FFFFFFF;
+    int tot[2] = { 0, 0 }, not_zero = 1, min_cost = 0;
+    int cB = 0x7FFFFFFF, cT = 0x7FFFFFFF, cR = 0x7FFFFFFF, cL = 0x7FFFFFFF, cC = 0x7FFFFFFF;      // bottom, top, right, left, centre of the last round
     for (int i = 0; i < 2; i++) {
-        int ox[5] = { 0, 0, 1, -1, 0 }, oy[5] = { 1, -1, 0, 0, 0 }, d[2] = { 0, 0 };
-        for (int k = 0; k < 9; k++) cost[k] = 0x7FFFFFFF;
+        int d[2] = { 0, 0 };
         if (i == 0) min_cost = cost_at(0, 0);
-        if ((i > 0 && min_cost == 0) || (i == 0 && min_cost < dx * dy)) { not_zero = 0; break; }
-        cost[CENTER] = min_cost;
-        for (int idx = BOTTOM; idx <= DIAG; idx++) {
-            const int c = cost_at(tot[0] + ox[idx], tot[1] + oy[idx]);
-            cost[idx] = c;
-            if (idx == LEFT) { ox[DIAG] = cost[RIGHT] <= cost[LEFT] ? 1 : -1; oy[DIAG] = cost[BOTTOM] <= cost[TOP] ? 1 : -1; }
-            if (c < min_cost) { min_cost = c; d[0] = ox[idx]; d[1] = oy[idx]; }
-        }
+        if ((i > 0 && min_cost == 0) || (i == 0 && min_cost < DX * DY)) { not_zero = 0; break; }
+        cC = min_cost;
+        cB = cost_at(tot[0], tot[1] + 1); if (cB < min_cost) { min_cost = cB; d[0] = 0; d[1] = 1; }
+        cT = cost_at(tot[0], tot[1] - 1); if (cT < min_cost) { min_cost = cT; d[0] = 0; d[1] = -1; }
+        cR = cost_at(tot[0] + 1, tot[1]); if (cR < min_cost) { min_cost = cR; d[0] = 1; d[1] = 0; }
+        cL = cost_at(tot[0] - 1, tot[1]); if (cL < min_cost) { min_cost = cL; d[0] = -1; d[1] = 0; }
+        const int dgx = cR <= cL ? 1 : -1, dgy = cB <= cT ? 1 : -1;
+        const int cD = cost_at(tot[0] + dgx, tot[1] + dgy); if (cD < min_cost) { min_cost = cD; d[0] = dgx; d[1] = dgy; }
         if (d[0] == 0 && d[1] == 0) break;
         tot[0] += d[0]; tot[1] += d[1];
+        if (i == 0) { cB = cT = cR = cL = cC = 0x7FFFFFFF; }      // the costs of a round are only meaningful around ITS centre
     }
     tot[0] <<= 4; tot[1] <<= 4;
-    if (not_zero && min_cost == cost[CENTER]) {
-        const int sb[5] = { cost[CENTER], cost[LEFT], cost[TOP], cost[RIGHT], cost[BOTTOM] };
+    if (not_zero && min_cost == cC) {
+        const int sb[5] = { cC, cL, cT, cR, cB };
 #pragma unroll
         for (int ax = 0; ax < 2; ax++) {
             const long long nu = (long long)((sb[1 + ax] - sb[3 + ax]) << 4), de = (long long)(sb[1 + ax] + sb[3 + ax] - (sb[0] << 1));
@@ -147,78 +163,79 @@ __global__ __launch_bounds__(256) void k_dmvr(const DmvrArgs a)
     }
     int r16[2][2];
 #pragma unroll
-    for (int l = 0; l < 2; l++) { r16[l][0] = (st[l][0] << 2) + (l ? -tot[0] : tot[0]); r16[l][1] = (st[l][1] << 2) + (l ? -tot[1] : tot[1]); }
-    if (lane < 4) out_mv[lane] = (int16_t)(r16[lane >> 1][lane & 1] >> 2);
+    for (int l = 0; l < 2; l++) { r16[l][0] = (u.st[l][0] << 2) + (l ? -tot[0] : tot[0]); r16[l][1] = (u.st[l][1] << 2) + (l ? -tot[1] : tot[1]); }
+    if (lane < 4) out_mv[lane] = (int16_t)((lane == 0 ? r16[0][0] : lane == 1 ? r16[0][1] : lane == 2 ? r16[1][0] : r16[1][1]) >> 2);      // selects: an array indexed by the lane would live in scratch
     // The deblocking filter's view of a refined CU: ADDB is handed the UNREFINED vectors (map_unrefined_mv, xevdm.c:2009-2041 - what k_inter wrote),
     // the Main library's copy of the baseline filter reads ctx->map_mv, which holds the refined ones (xevdm_df.c:118,209; xevdm_util.c:4327-4332)
-    if (a.refined_to_map && lane < (dx >> 2) * (dy >> 2)) {
-        const int u = lane % (dx >> 2), v = lane / (dx >> 2);
-        ScuRec *m = a.maps + ((py >> 2) + v) * a.w_scu + (px >> 2) + u;
+    if (a.refined_to_map && lane < (DX >> 2) * (DY >> 2)) {
+        const int uu = lane % (DX >> 2), vv = lane / (DX >> 2);
+        ScuRec *m = a.maps + ((u.py >> 2) + vv) * a.w_scu + (u.px >> 2) + uu;
         *(uint2 *)&m->mv[0][0] = make_uint2((uint32_t)(uint16_t)(r16[0][0] >> 2) | ((uint32_t)(uint16_t)(r16[0][1] >> 2) << 16),
                                             (uint32_t)(uint16_t)(r16[1][0] >> 2) | ((uint32_t)(uint16_t)(r16[1][1] >> 2) << 16));
     }
 
-    // ---- the refined prediction: lane = 4 luma samples of a row (lanes below dx*dy/4) and one chroma sample per plane (lanes below dx*dy/4) ----
-    const int nl4 = (dx * dy) >> 2, nc = (dx >> 1) * (dy >> 1);
-    const int lr = (lane * 4) / dx, lc = (lane * 4) - lr * dx;                    // luma row / first column inside the sub-block
-    const int cr = lane / (dx >> 1), cc = lane - cr * (dx >> 1);                  // chroma row / column
+    // ---- the refined prediction: lane = 4 luma samples of a row (lanes below DX*DY/4) and one chroma sample per plane (lanes below DX*DY/4) ----
+    constexpr int NL4 = (DX * DY) >> 2, NC = (DX >> 1) * (DY >> 1), WCW = (DX >> 1) + 3, WCH = (DY >> 1) + 3;
+    const int lr = (lane * 4) / DX, lc = (lane * 4) - lr * DX;                    // luma row / first column inside the sub-block
+    const int cr = lane / (DX >> 1), cc = lane - cr * (DX >> 1);                  // chroma row / column
     int accl[4] = { 0, 0, 0, 0 }, accu = 0, accv = 0;
-    int16_t *W = s_win[wv], *T = s_tmp[wv];
 #pragma unroll
     for (int l = 0; l < 2; l++) {
         // clip of the refined vector at the sub-block (mv_clip_only_one_ref_dmvr :939-980)
         int tq[2] = { (int)(int16_t)(r16[l][0] >> 2), (int)(int16_t)(r16[l][1] >> 2) }, mc[2] = { tq[0], tq[1] }, clip = 0;
         {
             const int min_c = -(128 << 2), max_x = (a.pic_w - 1 + 128) << 2, max_y = (a.pic_h - 1 + 128) << 2;
-            if ((px << 2) + tq[0] < min_c) { clip = 1; mc[0] = min_c - (px << 2); }
-            if ((py << 2) + tq[1] < min_c) { clip = 1; mc[1] = min_c - (py << 2); }
-            if ((px << 2) + tq[0] + (dx << 2) - 4 > max_x) { clip = 1; mc[0] = max_x - (px << 2) - (dx << 2) + 4; }
-            if ((py << 2) + tq[1] + (dy << 2) - 4 > max_y) { clip = 1; mc[1] = max_y - (py << 2) - (dy << 2) + 4; }
+            if ((u.px << 2) + tq[0] < min_c) { clip = 1; mc[0] = min_c - (u.px << 2); }
+            if ((u.py << 2) + tq[1] < min_c) { clip = 1; mc[1] = min_c - (u.py << 2); }
+            if ((u.px << 2) + tq[0] + (DX << 2) - 4 > max_x) { clip = 1; mc[0] = max_x - (u.px << 2) - (DX << 2) + 4; }
+            if ((u.py << 2) + tq[1] + (DY << 2) - 4 > max_y) { clip = 1; mc[1] = max_y - (u.py << 2) - (DY << 2) + 4; }
             mc[0] = (int)(int16_t)mc[0]; mc[1] = (int)(int16_t)mc[1];
         }
-        const int gx = (px << 4) + (clip ? mc[0] << 2 : r16[l][0]), gy = (py << 4) + (clip ? mc[1] << 2 : r16[l][1]);
-        const int dlx = (clip ? mc[0] >> 2 : r16[l][0] >> 4) - (st[l][0] >> 2), dly = (clip ? mc[1] >> 2 : r16[l][1] >> 4) - (st[l][1] >> 2);
-        const int dcx = (clip ? mc[0] >> 3 : r16[l][0] >> 5) - (st[l][0] >> 3), dcy = (clip ? mc[1] >> 3 : r16[l][1] >> 5) - (st[l][1] >> 3);
-        // windows at the STARTING vector: luma (dx + 7) x (dy + 7) from 3 samples up-left, chroma (dx/2 + 3) x (dy/2 + 3) from 1 sample up-left
-        const int q16x = ((px << 2) + st[l][0]) << 2, q16y = ((py << 2) + st[l][1]) << 2;
+        const int gx = (u.px << 4) + (clip ? mc[0] << 2 : r16[l][0]), gy = (u.py << 4) + (clip ? mc[1] << 2 : r16[l][1]);
+        const int dlx = (clip ? mc[0] >> 2 : r16[l][0] >> 4) - (u.st[l][0] >> 2), dly = (clip ? mc[1] >> 2 : r16[l][1] >> 4) - (u.st[l][1] >> 2);
+        const int dcx = (clip ? mc[0] >> 3 : r16[l][0] >> 5) - (u.st[l][0] >> 3), dcy = (clip ? mc[1] >> 3 : r16[l][1] >> 5) - (u.st[l][1] >> 3);
+        // windows at the STARTING vector: luma (DX + 7) x (DY + 7) from 3 samples up-left, chroma (DX/2 + 3) x (DY/2 + 3) from 1 sample up-left
+        const int q16x = ((u.px << 2) + u.st[l][0]) << 2, q16y = ((u.py << 2) + u.st[l][1]) << 2;
         {
-            const gs16 sy_ = (gs16)re[l].y + ((q16y >> 4) - 3) * a.s_l + (q16x >> 4) - 3;
-            for (int i = lane; i < (dy + 7) * (dx + 7); i += 64) { const int r = i / (dx + 7), c = i - r * (dx + 7); W[r * DM_WL + c] = sy_[r * a.s_l + c]; }
-            const int co = ((q16y >> 5) - 1) * a.s_c + (q16x >> 5) - 1, wcw = (dx >> 1) + 3, wch = (dy >> 1) + 3;
-            const gs16 su_ = (gs16)re[l].u + co, sv_ = (gs16)re[l].v + co;
-            for (int i = lane; i < 2 * wch * wcw; i += 64) {
-                const int pl = i >= wch * wcw, j = i - pl * wch * wcw, r = j / wcw, c = j - r * wcw;
-                W[DM_WL * DM_WL + pl * DM_WC * DM_WC + r * DM_WC + c] = (pl ? sv_ : su_)[r * a.s_c + c];
+            const gs16 sy_ = (gs16)u.ry[l] + ((q16y >> 4) - 3) * a.s_l + (q16x >> 4) - 3;
+            for (int i = lane; i < (DY + 7) * CH; i += 64) { const int r = i / CH, k = i - r * CH; *(uint4 *)(W + r * DM_RS + 8 * k) = gload16(sy_ + r * a.s_l + 8 * k); }
+            const int co = ((q16y >> 5) - 1) * a.s_c + (q16x >> 5) - 1;
+            const gs16 su_ = (gs16)u.ru[l] + co, sv_ = (gs16)u.rv[l] + co;
+            for (int i = lane; i < 2 * WCH * 2; i += 64) {      // two planes x rows x two chunks
+                const int pl = i >= WCH * 2, j = i - pl * WCH * 2, r = j >> 1, k = j & 1;
+                *(uint4 *)(W + 23 * DM_RS + pl * 11 * DM_CS + r * DM_CS + 8 * k) = gload16((pl ? sv_ : su_) + r * a.s_c + 8 * k);
             }
         }
         dm_sync();
         // luma: horizontal pass over every window row (the rows of the padding are copies of window rows), then vertical
         {
             const int fx = gx & 15, fy = gy & 15;
-            const uint32_t *th = k_luma_taps[a.admvp][fx], *tv = k_luma_taps[a.admvp][fy];
-            for (int i = lane; i < (dy + 7) * dx; i += 64) {
-                const int r = i / dx, j = i - r * dx;
-                int v;
-                if (!fx) v = W[r * DM_WL + clampi(3 + dlx + j, 0, dx + 6)];
-                else {
-                    int s = 0;
+            int th[8], tv[8];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) s += (int)(int16_t)(th[k >> 1] >> ((k & 1) * 16)) * (int)W[r * DM_WL + clampi(dlx + j + k, 0, dx + 6)];
-                    v = fy ? (int)(int16_t)(s >> sh1) : clampi(s >> 6, 0, maxl);
+            for (int k = 0; k < 8; k++) { th[k] = (int)(int16_t)(k_luma_taps[a.admvp][fx][k >> 1] >> ((k & 1) * 16)); tv[k] = (int)(int16_t)(k_luma_taps[a.admvp][fy][k >> 1] >> ((k & 1) * 16)); }
+            for (int i = lane; i < (DY + 7) * DX; i += 64) {
+                const int r = i / DX, j = i - r * DX;
+                int v;
+                if (!fx) v = W[r * DM_RS + clampi(3 + dlx + j, 0, DX + 6)];
+                else {
+                    int sacc = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) sacc += th[k] * (int)W[r * DM_RS + clampi(dlx + j + k, 0, DX + 6)];
+                    v = fy ? (int)(int16_t)(sacc >> sh1) : clampi(sacc >> 6, 0, maxl);
                 }
                 T[r * 16 + j] = (int16_t)v;
             }
             dm_sync();
-            if (lane < nl4) {
+            if (lane < NL4) {
 #pragma unroll
                 for (int e = 0; e < 4; e++) {
                     int v;
-                    if (!fy) v = T[clampi(3 + dly + lr, 0, dy + 6) * 16 + lc + e];
+                    if (!fy) v = T[clampi(3 + dly + lr, 0, DY + 6) * 16 + lc + e];
                     else {
-                        int s = 0;
+                        int sacc = 0;
 #pragma unroll
-                        for (int k = 0; k < 8; k++) s += (int)(int16_t)(tv[k >> 1] >> ((k & 1) * 16)) * (int)T[clampi(dly + lr + k, 0, dy + 6) * 16 + lc + e];
-                        v = fx ? clampi((s + off2) >> sh2, 0, maxl) : clampi(s >> 6, 0, maxl);
+                        for (int k = 0; k < 8; k++) sacc += tv[k] * (int)T[clampi(dly + lr + k, 0, DY + 6) * 16 + lc + e];
+                        v = fx ? clampi((sacc + off2) >> sh2, 0, maxl) : clampi(sacc >> 6, 0, maxl);
                     }
                     accl[e] = l ? (accl[e] + v + 1) >> 1 : v;
                 }
@@ -227,34 +244,37 @@ __global__ __launch_bounds__(256) void k_dmvr(const DmvrArgs a)
         }
         // chroma, both planes: the same with the 4-tap tables at the thirty-second-sample phase
         {
-            const int fx = gx & 31, fy = gy & 31, wcw = (dx >> 1) + 3, wch = (dy >> 1) + 3, cwd = dx >> 1;
-            const uint32_t *th = k_chroma_taps[a.admvp][fx], *tv = k_chroma_taps[a.admvp][fy];
-            const int shc1 = min(4, a.bd_c - 8), shc2 = max(8, 20 - a.bd_c), offc2 = 1 << (shc2 - 1);
-            for (int i = lane; i < 2 * wch * cwd; i += 64) {
-                const int pl = i >= wch * cwd, q = i - pl * wch * cwd, r = q / cwd, j = q - r * cwd;
-                const int16_t *Wc = W + DM_WL * DM_WL + pl * DM_WC * DM_WC;
-                int v;
-                if (!fx) v = Wc[r * DM_WC + clampi(1 + dcx + j, 0, wcw - 1)];
-                else {
-                    int s = 0;
+            const int fx = gx & 31, fy = gy & 31;
+            constexpr int CWD = DX >> 1;
+            int th[4], tv[4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) s += (int)(int16_t)(th[k >> 1] >> ((k & 1) * 16)) * (int)Wc[r * DM_WC + clampi(dcx + j + k, 0, wcw - 1)];
-                    v = fy ? (int)(int16_t)(s >> shc1) : clampi(s >> 6, 0, maxc);
+            for (int k = 0; k < 4; k++) { th[k] = (int)(int16_t)(k_chroma_taps[a.admvp][fx][k >> 1] >> ((k & 1) * 16)); tv[k] = (int)(int16_t)(k_chroma_taps[a.admvp][fy][k >> 1] >> ((k & 1) * 16)); }
+            const int shc1 = min(4, a.bd_c - 8), shc2 = max(8, 20 - a.bd_c), offc2 = 1 << (shc2 - 1);
+            for (int i = lane; i < 2 * WCH * CWD; i += 64) {
+                const int pl = i >= WCH * CWD, q = i - pl * WCH * CWD, r = q / CWD, j = q - r * CWD;
+                const int16_t *Wc = W + 23 * DM_RS + pl * 11 * DM_CS;
+                int v;
+                if (!fx) v = Wc[r * DM_CS + clampi(1 + dcx + j, 0, WCW - 1)];
+                else {
+                    int sacc = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) sacc += th[k] * (int)Wc[r * DM_CS + clampi(dcx + j + k, 0, WCW - 1)];
+                    v = fy ? (int)(int16_t)(sacc >> shc1) : clampi(sacc >> 6, 0, maxc);
                 }
-                T[pl * DM_WC * 8 + r * 8 + j] = (int16_t)v;
+                T[pl * 11 * 8 + r * 8 + j] = (int16_t)v;
             }
             dm_sync();
-            if (lane < nc) {
+            if (lane < NC) {
 #pragma unroll
                 for (int pl = 0; pl < 2; pl++) {
-                    const int16_t *Tc = T + pl * DM_WC * 8;
+                    const int16_t *Tc = T + pl * 11 * 8;
                     int v;
-                    if (!fy) v = Tc[clampi(1 + dcy + cr, 0, wch - 1) * 8 + cc];
+                    if (!fy) v = Tc[clampi(1 + dcy + cr, 0, WCH - 1) * 8 + cc];
                     else {
-                        int s = 0;
+                        int sacc = 0;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) s += (int)(int16_t)(tv[k >> 1] >> ((k & 1) * 16)) * (int)Tc[clampi(dcy + cr + k, 0, wch - 1) * 8 + cc];
-                        v = fx ? clampi((s + offc2) >> shc2, 0, maxc) : clampi(s >> 6, 0, maxc);
+                        for (int k = 0; k < 4; k++) sacc += tv[k] * (int)Tc[clampi(dcy + cr + k, 0, WCH - 1) * 8 + cc];
+                        v = fx ? clampi((sacc + offc2) >> shc2, 0, maxc) : clampi(sacc >> 6, 0, maxc);
                     }
                     if (pl) accv = l ? (accv + v + 1) >> 1 : v; else accu = l ? (accu + v + 1) >> 1 : v;
                 }
@@ -264,35 +284,61 @@ __global__ __launch_bounds__(256) void k_dmvr(const DmvrArgs a)
     }
 
     // ---- residual add + clip (xevd_recon.c:35-71; the LUMA bit depth clips all three components) and the stores ----
-    const int ai = (int)((r1.w >> 8) & 0xFF);
-    int tu_x = 0, tu_y = 0, tu_w = cw, tu_h = chh;
-    if (ai) {      // ATS-inter: the coded TU is one half / quarter of the CU at its start or end (xevdm_util.c:3585-3634)
-        const int idx = ai & 15, pos = ai >> 4;
-        if (idx == 2 || idx == 4) { tu_h = chh >> (idx == 4 ? 2 : 1); tu_y = pos ? chh - tu_h : 0; }
-        else                      { tu_w = cw >> (idx == 3 ? 2 : 1);  tu_x = pos ? cw - tu_w : 0; }
+    int tu_x = 0, tu_y = 0, tu_w = u.cw, tu_h = u.chh;
+    if (u.ats) {      // ATS-inter: the coded TU is one half / quarter of the CU at its start or end (xevdm_util.c:3585-3634)
+        const int idx = u.ats & 15, pos = u.ats >> 4;
+        if (idx == 2 || idx == 4) { tu_h = u.chh >> (idx == 4 ? 2 : 1); tu_y = pos ? u.chh - tu_h : 0; }
+        else                      { tu_w = u.cw >> (idx == 3 ? 2 : 1);  tu_x = pos ? u.cw - tu_w : 0; }
     }
-    const int cwc = tu_w >> 1;
-    const uint32_t off_u = coef_off + ((cbf & 1) ? tu_w * tu_h : 0), off_v = off_u + ((cbf & 2) ? cwc * (tu_h >> 1) : 0);
-    if (lane < nl4) {
-        const int x = px + lc, y = py + lr, lx = x - cu_x - tu_x, ly = y - cu_y - tu_y;
+    const int cwc = tu_w >> 1, cbf = u.cbf;
+    const uint32_t off_u = u.coef_off + ((cbf & 1) ? tu_w * tu_h : 0), off_v = off_u + ((cbf & 2) ? cwc * (tu_h >> 1) : 0);
+    if (lane < NL4) {
+        const int x = u.px + lc, y = u.py + lr, lx = x - u.cu_x - tu_x, ly = y - u.cu_y - tu_y;
         int o[4];
 #pragma unroll
         for (int e = 0; e < 4; e++) {
             o[e] = accl[e];
             if ((cbf & 1) && (uint32_t)(lx + e) < (uint32_t)tu_w && (uint32_t)ly < (uint32_t)tu_h)
-                o[e] = clampi((int)(int16_t)(a.resid[coef_off + ly * tu_w + lx + e] + o[e]), 0, maxl);
+                o[e] = clampi((int)(int16_t)(a.resid[u.coef_off + ly * tu_w + lx + e] + o[e]), 0, maxl);
         }
         *(uint2 *)(a.cur_y + y * a.s_l + x) = make_uint2((uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16), (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16));
     }
-    if (lane < nc) {
-        const int xc = (px >> 1) + cc, yc = (py >> 1) + cr, lxc = xc - ((cu_x + tu_x) >> 1), lyc = yc - ((cu_y + tu_y) >> 1);
+    if (lane < NC) {
+        const int xc = (u.px >> 1) + cc, yc = (u.py >> 1) + cr, lxc = xc - ((u.cu_x + tu_x) >> 1), lyc = yc - ((u.cu_y + tu_y) >> 1);
         const bool in_tu = (uint32_t)lxc < (uint32_t)cwc && (uint32_t)lyc < (uint32_t)(tu_h >> 1);
-        int u = accu, v = accv;
-        if ((cbf & 2) && in_tu) u = clampi((int)(int16_t)(a.resid[off_u + lyc * cwc + lxc] + u), 0, maxl);
-        if ((cbf & 4) && in_tu) v = clampi((int)(int16_t)(a.resid[off_v + lyc * cwc + lxc] + v), 0, maxl);
-        a.cur_u[yc * a.s_c + xc] = (int16_t)u;
-        a.cur_v[yc * a.s_c + xc] = (int16_t)v;
+        int uu = accu, vv = accv;
+        if ((cbf & 2) && in_tu) uu = clampi((int)(int16_t)(a.resid[off_u + lyc * cwc + lxc] + uu), 0, maxl);
+        if ((cbf & 4) && in_tu) vv = clampi((int)(int16_t)(a.resid[off_v + lyc * cwc + lxc] + vv), 0, maxl);
+        a.cur_u[yc * a.s_c + xc] = (int16_t)uu;
+        a.cur_v[yc * a.s_c + xc] = (int16_t)vv;
     }
+}
+
+__global__ __launch_bounds__(256) void k_dmvr(const DmvrArgs a)
+{
+    __shared__ __attribute__((aligned(16))) int16_t s_bl[4][2 * DM_BL * DM_BL];
+    __shared__ __attribute__((aligned(16))) int16_t s_win[4][DM_STAGE];
+    __shared__ __attribute__((aligned(16))) int16_t s_tmp[4][23 * 16];
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wv);
+    if (item >= a.n_items) return;
+    const DmvrItem it = a.items[item];
+    uint4 r0 = ((const uint4 *)&a.cus[it.cu])[0], r1 = ((const uint4 *)&a.cus[it.cu])[1];
+    // one item per wave: everything below is wave-uniform - in scalar registers (and the reference table is indexed in the kernel arguments, not in a scratch copy)
+    r0.x = __builtin_amdgcn_readfirstlane(r0.x); r0.y = __builtin_amdgcn_readfirstlane(r0.y); r0.z = __builtin_amdgcn_readfirstlane(r0.z); r0.w = __builtin_amdgcn_readfirstlane(r0.w);
+    r1.x = __builtin_amdgcn_readfirstlane(r1.x); r1.y = __builtin_amdgcn_readfirstlane(r1.y); r1.w = __builtin_amdgcn_readfirstlane(r1.w);
+    const int isx = __builtin_amdgcn_readfirstlane((int)it.sx), isy = __builtin_amdgcn_readfirstlane((int)it.sy);
+    const int refi0 = (int)(int8_t)(r0.z & 0xFF), refi1 = (int)(int8_t)((r0.z >> 8) & 0xFF), cw = 1 << (r0.y & 0xFF), chh = 1 << ((r0.y >> 8) & 0xFF);
+    int16_t *out_mv = a.out_mv + (size_t)item * 4;
+    if (!dmvr_applies(a.cur_poc, a.refp[refi0][0].poc, a.refp[refi1][1].poc)) {
+        // the CU was predicted by k_inter; the vector kept for temporal prediction is its own
+        if (lane < 4) out_mv[lane] = (int16_t)((lane & 2 ? r1.y : r1.x) >> ((lane & 1) * 16));
+        return;
+    }
+    int16_t *BL = s_bl[wv], *W = s_win[wv], *T = s_tmp[wv];
+    const bool w16 = cw >= 16, h16 = chh >= 16;
+    if (w16) { if (h16) dmvr_block<16, 16>(a, r0, r1, isx, isy, BL, W, T, out_mv, lane); else dmvr_block<16, 8>(a, r0, r1, isx, isy, BL, W, T, out_mv, lane); }
+    else     { if (h16) dmvr_block<8, 16>(a, r0, r1, isx, isy, BL, W, T, out_mv, lane);  else dmvr_block<8, 8>(a, r0, r1, isx, isy, BL, W, T, out_mv, lane); }
 }
 
 void launch_dmvr(xgpu_ctx *c, const DmvrArgs &a)
