@@ -17,10 +17,10 @@
  * src_main/xevdm_ipred.c:320-767), ibc_flag (ibc_flag + block vector per CU, xevdm_eco.c:1401-1438,1789-1800), tool_htdf, tool_dra (DRA APS NAL units
  * :2319-2375, PPS switch :2054-2060, table construction src_main/xevdm_dra.c:39-270), tool_alf (APS NAL units :2082-2135,2376-2477 with the fixed
  * filter sets, coefficient syntax :2154-2318, slice-level parameters :2479-2657, per-CTU flags src_main/xevdm.c:2411-2418, alf_recon_coef
- * src_main/xevdm_alf.c:700-794), and tool_admvp with its sub-tools tool_amvr, tool_hmvp and tool_dmvr: merge_idx / merge_mode_flag / mvr_idx / bi_idx
- * syntax (xevdm_eco.c:1519-1726), merge candidates incl. the temporal and history ones (src_main/xevdm_util.c:594-1391,3729-3818), the resolution-indexed
+ * src_main/xevdm_alf.c:700-794), and tool_admvp with its sub-tools tool_amvr, tool_hmvp, tool_mmvd and tool_dmvr: merge_idx / merge_mode_flag / mvr_idx /
+ * bi_idx / mmvd_flag + mmvd data syntax (xevdm_eco.c:767-812,1519-1726), merge with vector difference (src_main/xevdm_util.c:191-592,4682-4716), merge candidates incl. the temporal and history ones (src_main/xevdm_util.c:594-1391,3729-3818), the resolution-indexed
  * predictor (:750-951), intra-only 4x4 CUs; tool_dmvr needs the backend's refined vectors back per picture (xhost_parser_set_dmvr_mvs) and is refused
- * together with tool_hmvp.  Not parsed: sps_btt_flag / sps_suco_flag (split syntax), tool_affine, tool_mmvd, tool_cm_init (and ADCC),
+ * together with tool_hmvp or tool_mmvd.  Not parsed: sps_btt_flag / sps_suco_flag (split syntax), tool_affine, tool_cm_init (and ADCC),
  * tool_rpl / tool_pocs, dquant.  SPS chroma QP mapping tables and cropping offsets are parsed, a VUI is skipped; 4:2:0, one tile and one slice per
  * picture, I / P / B slices incl. temporal layers (hierarchical sub-GOPs).
  * Conventions as xevd_hip.h: 0 / negative XEVD_ERR_* codes, nothing throws, one object per stream.
@@ -113,6 +113,7 @@ typedef struct xhost_stream_params {
     int tool_htdf;                         /* sps->tool_htdf: no CU syntax of its own; the parser hands the slice QP to the backend (batch.htdf_slice_qp) */
     int tool_admvp;                        /* sps->tool_admvp: skip and merge-mode CUs take one of up to six merge candidates, explicitly coded motion uses the
                                               resolution-indexed predictor and bi_idx (xevdm_eco.c:1519-1726); the backend then interpolates with the Main 8-tap tables */
+    int tool_mmvd;                         /* sub-tool of tool_admvp: sps->tool_mmvd - a share of the skip / merge-mode CUs is written as merge with vector difference */
     int tool_dmvr;                         /* sub-tool of tool_admvp: sps->tool_dmvr - skip and merge-mode CUs are flagged for decoder-side refinement */
     int tool_amvr, tool_hmvp;              /* sub-tools of tool_admvp: sps->tool_amvr (mvr_idx: vector differences on a half / 1 / 2 / 4 sample grid, predictor position
                                               coupled with the index), sps->tool_hmvp (history-based merge candidates and fallback predictors)  */

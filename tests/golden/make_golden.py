@@ -170,6 +170,8 @@ def golden_streams(only=()):
                                 "main_dmvr_b_8b": (200, 136, 9, dict(main=True, admvp=True, dmvr=True, inter_frac=0.9, max_refs=2, log2_sub_gop=2, skip_frac=0.3, direct_frac=0.3)),
                                 "main_dmvr_all_tools_10b": (264, 136, 17, dict(main=True, admvp=True, dmvr=True, amvr=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=4,
                                                                                inter_frac=0.9, max_refs=3, log2_sub_gop=3, bit_depth=10, skip_frac=0.3, direct_frac=0.3)),
+                                "main_mmvd_all_tools_10b": (264, 136, 17, dict(main=True, admvp=True, mmvd=True, amvr=True, hmvp=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True,
+                                                                               ibc_log_max=5, inter_frac=0.9, skip_frac=0.35, direct_frac=0.3, max_refs=3, log2_sub_gop=3, bit_depth=10)),
                                 "main_alf_fixed_8b": (264, 136, 8, dict(main=True, alf=True, addb=True, alf_fixed=True)),
                                 "main_ibc_i_8b": (136, 72, 3, dict(main=True, eipd=True, ibc_log_max=4, ibc_frac=0.4, idr_period=1)),
                                 "main_ibc_all_tools_10b": (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=5, inter_frac=0.5, log2_sub_gop=2, max_refs=2, bit_depth=10))}.items():

@@ -72,6 +72,12 @@ CONFIGS = [
     (136, 136, 6, dict(main=True, admvp=True, dmvr=True, inter_frac=0.9, max_refs=2, skip_frac=0.3, direct_frac=0.3)),
     (264, 136, 17, dict(main=True, admvp=True, dmvr=True, amvr=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=4, inter_frac=0.9, max_refs=3,
                         log2_sub_gop=3, bit_depth=10, skip_frac=0.3, direct_frac=0.3)),
+    # ... and sps->tool_mmvd: merge with vector difference (group / base candidate / distance / direction syntax, the three prediction types per
+    # group with mirrored and POC-scaled vectors, the P-slice variants for 1, 2 and more references)
+    (200, 136, 4, dict(main=True, admvp=True, mmvd=True, inter_frac=0.9, skip_frac=0.35, direct_frac=0.3, max_refs=1)),
+    (136, 136, 8, dict(main=True, admvp=True, mmvd=True, inter_frac=0.9, skip_frac=0.35, direct_frac=0.3, max_refs=4)),
+    (264, 136, 17, dict(main=True, admvp=True, mmvd=True, amvr=True, hmvp=True, iqt=True, addb=True, alf=True, inter_frac=0.9, skip_frac=0.35, direct_frac=0.3, max_refs=3,
+                        log2_sub_gop=3, bit_depth=10)),
     # ALF parameter sets that start from the standard's fixed filters (usage pattern 1: every class, 2: flagged classes; 4-bit set index per class)
     (264, 136, 8, dict(main=True, alf=True, addb=True, alf_fixed=True)),
     (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, alf_fixed=True, log2_sub_gop=2, max_refs=2, bit_depth=10)),

@@ -181,6 +181,7 @@ struct Models {
           intra_dir[2], mvp_idx[3], mvd[1], refi[2], dqp[1], skip[2],
           ats_mode[1], ats_inter_flag[2], ats_inter_quad[1], ats_inter_hor[3], ats_inter_pos[1],      // Main: xevd_def.h:559-563
           alf_ctb[1],
+          mmvd_flag[1], mmvd_merge_idx[3], mmvd_dist_idx[7], mmvd_dir_idx[2], mmvd_group_idx[2],           // tool_mmvd: xevd_def.h:478-482
           mvr_idx[4],                                                                                // tool_amvr: xevd_def.h:493
           merge_mode[1], merge_idx[5], bi_idx[2],                                                      // tool_admvp: xevd_def.h:461-465
           ibc_flag[2],                                                                               // sps->ibc_flag: xevd_def.h:485
@@ -222,6 +223,7 @@ enum { MODE_INTRA = XGPU_MODE_INTRA, MODE_INTER = XGPU_MODE_INTER, MODE_SKIP = X
 // ------------------------------------------------------------------------------------------------ stream / picture state
 struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, log2_ref_gap = 0, max_num_ref_pics = 1;
              int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0, tool_alf = 0, tool_eipd = 0, tool_dra = 0, tool_htdf = 0;
+             int tool_mmvd = 0;                      // sps->tool_mmvd: merge with vector difference (a base candidate plus one of 32 offsets)
              int tool_dmvr = 0;                      // sps->tool_dmvr: merge-mode motion is refined by the backend (no syntax of its own)
              int tool_amvr = 0, tool_hmvp = 0;       // sub-tools of tool_admvp: adaptive vector resolution (mvr_idx), history-based candidates
              int tool_admvp = 0;                     // sps->tool_admvp: merge / resolution-indexed predictors instead of the Baseline candidate lists, 8-tap MC tables
@@ -231,6 +233,7 @@ struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, lo
 struct Pps { int constrained_intra = 0, cu_qp_delta = 0, dra_on = 0, dra_aps_id = 0; };
 struct Slice { int type = XHOST_SLICE_I, qp = 32, qp_u_offset = 0, qp_v_offset = 0, deblock = 1, alpha_off = 0, beta_off = 0;
                int alf_on = 0, aps_id_y = 0, aps_id_ch = 0, alf_chroma_idc = 0, alf_ctb_map = 0;
+               int mmvd_group = 0;                                                         // mmvd_group_enable_flag (tool_mmvd, xevdm_eco.c:2592-2599)
                int tmvp_assigned = 0, col_list = 0, col_src_list = 0, col_ref = 0; };      // temporal_mvp_asigned_flag + collocated_* (tool_admvp, xevdm_eco.c:2748-2760)
 
 // ---- ALF parameter sets (XEVD_ALF_SLICE_PARAM / ac_alf_line_buf[32], src_main/xevdm_alf.c:587-698) ----
@@ -286,6 +289,7 @@ struct Cu {
     int ipm, ipm_c, cbf[3], qp;       // ipm_c: chroma mode with tool_eipd (DM 0, BI 1, DC 2, HOR 3, VER 4)
     int ats;                         // bit 0 ats_intra_cu, bit 1 ats_intra_mode_v, bit 2 ats_intra_mode_h (layout of xgpu_cu_batch.ats)
     int ats_inter;                   // ats_inter_info: idx | pos << 4
+    int mmvd, mmvd_idx;              // mmvd_flag; group << 7 | base candidate << 5 | distance << 2 | direction
     int dmvr;                        // tool_dmvr and a skip / merge-mode CU: mcore->dmvr_enable (xevdm.c:1272-1288)
 };
 
@@ -729,6 +733,87 @@ struct Stream {          // everything both directions share
         for (int k = cnt; k < max_n; k++) { cand[k].refi[0] = 0; cand[k].refi[1] = bi ? 0 : -1; memset(cand[k].mv, 0, sizeof(cand[k].mv)); }
         (void)scup;
     }
+    // mmvd_group_idx (only with the slice's group flag and above 32 samples), mmvd_merge_idx, mmvd_distance_idx, mmvd_direction_idx (xevdm_eco_mmvd_data, xevdm_eco.c:767-812)
+    template <class C> void code_mmvd_idx(C &c, Cu &cu)
+    {
+        int grp = cu.mmvd_idx >> 7, base = (cu.mmvd_idx >> 5) & 3, dist = (cu.mmvd_idx >> 2) & 7, dir = cu.mmvd_idx & 3;
+        if (sh.mmvd_group && (1 << (cu.log2w + cu.log2h)) > 32) {
+            if (c.bin(grp > 0, models.mmvd_group_idx[0])) grp = 1 + c.bin(grp > 1, models.mmvd_group_idx[1]); else grp = 0;
+        } else grp = 0;
+        base = sym_trunc_unary(c, base, models.mmvd_merge_idx, 3, 4);
+        dist = sym_trunc_unary(c, dist, models.mmvd_dist_idx, 7, 8);
+        dir = (c.bin(dir >> 1, models.mmvd_dir_idx[0]) << 1) | c.bin(dir & 1, models.mmvd_dir_idx[1]);
+        cu.mmvd_idx = (grp << 7) | (base << 5) | (dist << 2) | dir;
+    }
+    // merge with vector difference (xevdm_get_mmvd_motion, xevdm_util.c:4682-4716; xevdm_get_mmvd_mvp_list :191-592, for ONE index): base candidate
+    // `base` of the merge list, turned into the prediction type of its group (bi-predictive / list 0 / list 1, the missing list mirrored and scaled by
+    // POC distance; P slices: the same, another or a third reference), plus an offset of 1 .. 128 quarter samples in one of four directions, scaled
+    // between the lists by their POC distances and mirrored when the references lie on either side
+    void mmvd_motion(Cu &cu) const
+    {
+        Motion cand[6];
+        merge_candidates(cu, cand);
+        const int grp = cu.mmvd_idx >> 7, base = (cu.mmvd_idx >> 5) & 3, kk = cu.mmvd_idx & 31;
+        const bool is_b = sh.type == XHOST_SLICE_B, small = (1 << (cu.log2w + cu.log2h)) <= 32;
+        auto rpoc = [&](int l, int r) -> int { return (r >= 0 && r < (int)refp[l].size()) ? refp[l][(size_t)r]->poc : 0; };      // REF_SET
+        auto scaled = [&](int w, int v, int sg) -> int { return std::min(std::max(sg * ((abs(w * v) + 16) >> 5), -32768), 32767); };
+        // base_mv_t: the candidate (P slices take list 1 of candidate 0: unused), types per group
+        int t[2][3] = { { cand[base].mv[0][0], cand[base].mv[0][1], cand[base].refi[0] },
+                        { is_b ? cand[base].mv[1][0] : cand[0].mv[1][0], is_b ? cand[base].mv[1][1] : cand[0].mv[1][1], is_b ? cand[base].refi[1] : cand[0].refi[1] } };
+        int b[2][3] = { { t[0][0], t[0][1], t[0][2] }, { t[1][0], t[1][1], t[1][2] } };      // base_mv: starts as the candidate
+        int pm[3][3] = { { 0 } }, type[3];
+        const int n0 = (int)refp[0].size(), n1 = (int)refp[1].size();
+        if (t[0][2] >= 0 && t[1][2] >= 0) { type[0] = 0; type[1] = 1; type[2] = 2; }
+        else if (t[0][2] >= 0) {
+            if (!is_b) {
+                type[0] = type[1] = type[2] = 1;
+                pm[0][2] = t[0][2];
+                pm[1][2] = n0 == 1 ? t[0][2] : !t[0][2];
+                pm[2][2] = n0 < 3 ? t[0][2] : (t[0][2] < 2 ? 2 : 1);
+                pm[0][0] = t[0][0]; pm[0][1] = t[0][1];
+                if (n0 == 1) { pm[1][0] = t[0][0] + 3; pm[1][1] = t[0][1]; pm[2][0] = t[0][0] - 3; pm[2][1] = t[0][1]; }
+                else {
+                    for (int g = 1; g <= (n0 == 2 ? 1 : 2); g++) {
+                        const int w = ((poc - rpoc(0, pm[0][2])) << 5) / (poc - rpoc(0, pm[g][2]));
+                        pm[g][0] = scaled(w, t[0][0], 1); pm[g][1] = scaled(w, t[0][1], 1);
+                    }
+                    if (n0 == 2) { pm[2][0] = t[0][0] - 3; pm[2][1] = t[0][1]; }
+                }
+            } else {
+                type[0] = 1; type[1] = 0; type[2] = 2;
+                const int p0 = rpoc(0, t[0][2]);
+                t[1][2] = (n1 > 1 && rpoc(1, 1) - poc == poc - p0) ? 1 : 0;
+                const int w = ((poc - rpoc(1, t[1][2])) << 5) / (poc - p0);
+                t[1][0] = scaled(w, t[0][0], w * t[0][0] < 0 ? -1 : 1); t[1][1] = scaled(w, t[0][1], w * t[0][1] < 0 ? -1 : 1);
+            }
+        } else if (t[1][2] >= 0) {
+            type[0] = 2; type[1] = 0; type[2] = 1;
+            const int p1 = rpoc(1, t[1][2]);
+            t[0][2] = (n0 > 1 && rpoc(0, 1) - poc == poc - p1) ? 1 : 0;
+            const int w = ((poc - rpoc(0, t[0][2])) << 5) / (poc - p1);
+            t[0][0] = scaled(w, t[1][0], w * t[1][0] < 0 ? -1 : 1); t[0][1] = scaled(w, t[1][1], w * t[1][1] < 0 ? -1 : 1);
+        } else type[0] = type[1] = type[2] = 3;
+        if (small) type[0] = 1;
+        switch (type[grp]) {
+        case 0: for (int l = 0; l < 2; l++) for (int d = 0; d < 3; d++) b[l][d] = t[l][d]; break;
+        case 1: if (!is_b) { b[0][0] = pm[grp][0]; b[0][1] = pm[grp][1]; b[0][2] = pm[grp][2]; } else { b[0][0] = t[0][0]; b[0][1] = t[0][1]; b[0][2] = t[0][2]; } b[1][2] = -1; break;
+        case 2: b[0][2] = -1; b[1][0] = t[1][0]; b[1][1] = t[1][1]; b[1][2] = t[1][2]; break;
+        default: b[0][2] = b[1][2] = -1; break;
+        }
+        const int r0 = b[0][2], r1 = b[1][2], step = 1 << (kk >> 2);
+        int sign = 1, d0 = step, d1 = step;
+        if (r0 != -1 && r1 != -1) {
+            const int p0 = rpoc(0, r0), p1 = rpoc(1, r1);
+            if (is_b && (p0 - poc) * (poc - p1) > 0) sign = -1;
+            if (abs(p1 - poc) >= abs(p0 - poc)) d0 = std::min(std::max((((abs(p0 - poc) << 5) / abs(p1 - poc)) * step + 16) >> 5, -32768), 32767);
+            else d1 = std::min(std::max((((abs(p1 - poc) << 5) / abs(p0 - poc)) * step + 16) >> 5, -32768), 32767);
+        }
+        const int dir = kk & 3, s0 = (dir & 1) ? -d0 : d0, s1 = ((dir & 1) ? -d1 : d1) * sign;
+        const int real[2][2] = { { b[0][0] + (dir < 2 ? s0 : 0), b[0][1] + (dir < 2 ? 0 : s0) }, { b[1][0] + (dir < 2 ? s1 : 0), b[1][1] + (dir < 2 ? 0 : s1) } };
+        cu.refi[0] = r0; cu.mv[0][0] = (int16_t)real[0][0]; cu.mv[0][1] = (int16_t)real[0][1];
+        if (is_b) { cu.refi[1] = r1; cu.mv[1][0] = (int16_t)real[1][0]; cu.mv[1][1] = (int16_t)real[1][1]; }
+        else { cu.refi[1] = -1; cu.mv[1][0] = cu.mv[1][1] = 0; }
+    }
     // skip / merge-mode motion = candidate `idx` (xevd_get_skip_motion / xevd_get_direct_motion, xevdm.c:800-883); entries past the list stay "no reference, zero"
     void merge_motion(Cu &cu, int idx) const
     {
@@ -916,14 +1001,18 @@ struct Stream {          // everything both directions share
         int skip = 0;
         if (inter_slice) skip = c.bin(cu.mode == MODE_SKIP, models.skip[0]);
         if (!enc) { cu.mode = skip ? MODE_SKIP : MODE_INTRA; cu.refi[0] = cu.refi[1] = -1; memset(cu.mv, 0, sizeof(cu.mv)); memset(cu.mvd, 0, sizeof(cu.mvd));
-                    cu.mvp_idx[0] = cu.mvp_idx[1] = 0; cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0; cu.ipm = cu.ipm_c = 0; cu.ats = cu.ats_inter = 0; cu.dmvr = 0; }
+                    cu.mvp_idx[0] = cu.mvp_idx[1] = 0; cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0; cu.ipm = cu.ipm_c = 0; cu.ats = cu.ats_inter = 0; cu.dmvr = 0; cu.mmvd = cu.mmvd_idx = 0; }
         int16_t cand[4][2];
         const int n_lists = sh.type == XHOST_SLICE_B ? 2 : 1;
         if (skip && sps.tool_admvp) {
             // Main: one merge index, truncated unary over five contexts (xevdm_eco_merge_idx, xevdm_eco.c:731-744; call site :1550-1551)
-            cu.mvp_idx[0] = cu.mvp_idx[1] = sym_trunc_unary(c, cu.mvp_idx[0], models.merge_idx, 5, 6);
-            merge_motion(cu, cu.mvp_idx[0]);
-            cu.dmvr = sps.tool_dmvr;
+            if (sps.tool_mmvd) cu.mmvd = c.bin(cu.mmvd, models.mmvd_flag[0]);
+            if (cu.mmvd) { code_mmvd_idx(c, cu); mmvd_motion(cu); }
+            else {
+                cu.mvp_idx[0] = cu.mvp_idx[1] = sym_trunc_unary(c, cu.mvp_idx[0], models.merge_idx, 5, 6);
+                merge_motion(cu, cu.mvp_idx[0]);
+                cu.dmvr = sps.tool_dmvr;
+            }
             cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0;
             cu.qp = qp_prev;
             return;
@@ -970,9 +1059,13 @@ struct Stream {          // everything both directions share
             }
             cu.direct = mvr == 0 ? c.bin(cu.direct, models.merge_mode[0]) : 0;
             if (cu.direct) {
-                cu.mvp_idx[0] = cu.mvp_idx[1] = sym_trunc_unary(c, cu.mvp_idx[0], models.merge_idx, 5, 6);
-                merge_motion(cu, cu.mvp_idx[0]);
-                cu.dmvr = sps.tool_dmvr;
+                if (sps.tool_mmvd) cu.mmvd = c.bin(cu.mmvd, models.mmvd_flag[0]);
+                if (cu.mmvd) { code_mmvd_idx(c, cu); mmvd_motion(cu); }
+                else {
+                    cu.mvp_idx[0] = cu.mvp_idx[1] = sym_trunc_unary(c, cu.mvp_idx[0], models.merge_idx, 5, 6);
+                    merge_motion(cu, cu.mvp_idx[0]);
+                    cu.dmvr = sps.tool_dmvr;
+                }
             } else {
                 int dir = 0;
                 if (n_lists == 2) {
@@ -1228,8 +1321,8 @@ struct xhost_parser {
             unsupported |= br.get1();                    // sps_btt_flag
             unsupported |= br.get1();                    // sps_suco_flag
             s.tool_admvp = br.get1();
-            s.tool_amvr = s.tool_hmvp = s.tool_dmvr = 0;
-            if (s.tool_admvp) { unsupported |= br.get1(); s.tool_amvr = br.get1(); s.tool_dmvr = br.get1(); unsupported |= br.get1(); s.tool_hmvp = br.get1(); }      // tool_affine, tool_amvr, tool_dmvr, tool_mmvd, tool_hmvp
+            s.tool_amvr = s.tool_hmvp = s.tool_dmvr = s.tool_mmvd = 0;
+            if (s.tool_admvp) { unsupported |= br.get1(); s.tool_amvr = br.get1(); s.tool_dmvr = br.get1(); s.tool_mmvd = br.get1(); s.tool_hmvp = br.get1(); }      // tool_affine, tool_amvr, tool_dmvr, tool_mmvd, tool_hmvp
             s.tool_eipd = br.get1();
             s.ibc = s.ibc_log_max = 0;
             if (s.tool_eipd && (s.ibc = br.get1())) { s.ibc_log_max = (int)br.ue() + 2; if (s.ibc_log_max > 7) return fail("bad SPS"); }
@@ -1247,8 +1340,11 @@ struct xhost_parser {
         // tool_dmvr with tool_hmvp: xevdm_set_dec_info ends by copying map_mv[first SCU] - the REFINED vector of the CU's first sub-block - back into
         // core->mv (xevdm_util.c:4384-4387), and that is what the history buffer then receives (xevdm.c:1335-1342): the merge candidates of the NEXT CUs of
         // the same picture depend on the refinement search, i.e. on reference SAMPLES.  A front end that hands whole pictures to the backend cannot follow that.
+        // ... and tool_mmvd builds its base candidates from ctx->map_mv, the REFINED vectors of refined neighbours (xevdm_get_mmvd_mvp_list passes no
+        // unrefined map, xevdm_util.c:246-247): the same dependency
+        if (s.tool_dmvr && s.tool_mmvd) return fail("tool_dmvr together with tool_mmvd: the base candidates depend on refined vectors inside the picture (not supported)");
         if (s.tool_dmvr && s.tool_hmvp) return fail("tool_dmvr together with tool_hmvp: the history candidates depend on refined vectors inside the picture (not supported)");
-        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, affine, mmvd, cm_init, rpl, pocs, dquant in Main)");
+        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, affine, cm_init, rpl, pocs, dquant in Main)");
         s.log2_sub_gop = (int)br.ue();                   // tool_rpl = tool_pocs = 0
         if (s.log2_sub_gop == 0) s.log2_ref_gap = (int)br.ue();
         if (s.log2_sub_gop > 5) return fail("bad SPS");
@@ -1321,6 +1417,7 @@ struct xhost_parser {
         sh.type = (int)br.ue();
         if (sh.type < 0 || sh.type > 2) return fail("bad slice type");
         if (nut == NUT_IDR) br.get1();                   // no_output_of_prior_pics_flag
+        sh.mmvd_group = (st.sps.tool_mmvd && sh.type != XHOST_SLICE_I) ? br.get1() : 0;
         sh.alf_on = sh.alf_chroma_idc = sh.alf_ctb_map = 0;
         if (st.sps.tool_alf) {                           // xevdm_eco.c:2608-2657 (4:2:0)
             sh.alf_on = br.get1();
@@ -1612,7 +1709,7 @@ struct xhost_writer {
         else {
             bw.put1(0); bw.put1(0);                      // btt suco
             bw.put1(sp.tool_admvp ? 1 : 0);
-            if (sp.tool_admvp) { bw.put1(0); bw.put1(sp.tool_amvr ? 1 : 0); bw.put1(sp.tool_dmvr ? 1 : 0); bw.put1(0); bw.put1(sp.tool_hmvp ? 1 : 0); }      // affine amvr dmvr mmvd hmvp
+            if (sp.tool_admvp) { bw.put1(0); bw.put1(sp.tool_amvr ? 1 : 0); bw.put1(sp.tool_dmvr ? 1 : 0); bw.put1(sp.tool_mmvd ? 1 : 0); bw.put1(sp.tool_hmvp ? 1 : 0); }      // affine amvr dmvr mmvd hmvp
             bw.put1(sp.tool_eipd ? 1 : 0);
             if (sp.tool_eipd) { bw.put1(sp.ibc_log_max_size ? 1 : 0); if (sp.ibc_log_max_size) bw.ue((uint32_t)(sp.ibc_log_max_size - 2)); }      // ibc_flag, ibc_log_max_size - 2
             bw.put1(0);                                  // cm_init
@@ -1677,7 +1774,8 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     w->sp.tool_admvp = s.profile_main && sp->tool_admvp; s.tool_admvp = w->sp.tool_admvp;
     w->sp.tool_amvr = s.tool_admvp && sp->tool_amvr; s.tool_amvr = w->sp.tool_amvr;
     w->sp.tool_hmvp = s.tool_admvp && sp->tool_hmvp; s.tool_hmvp = w->sp.tool_hmvp;
-    w->sp.tool_dmvr = s.tool_admvp && sp->tool_dmvr && !s.tool_hmvp; s.tool_dmvr = w->sp.tool_dmvr;      // not with tool_hmvp (see the parser)
+    w->sp.tool_mmvd = s.tool_admvp && sp->tool_mmvd; s.tool_mmvd = w->sp.tool_mmvd;
+    w->sp.tool_dmvr = s.tool_admvp && sp->tool_dmvr && !s.tool_hmvp && !s.tool_mmvd; s.tool_dmvr = w->sp.tool_dmvr;      // not with tool_hmvp (see the parser)
     w->sp.ibc_log_max_size = (s.tool_eipd && sp->ibc_log_max_size >= 2 && sp->ibc_log_max_size <= 7) ? sp->ibc_log_max_size : 0;
     s.ibc = w->sp.ibc_log_max_size != 0; s.ibc_log_max = w->sp.ibc_log_max_size;
     w->st.pps.cu_qp_delta = sp->cu_qp_delta;
@@ -1802,7 +1900,8 @@ struct TreeWriter {
         if (st.sh.type == XHOST_SLICE_P) { cu.refi[1] = -1; if (cu.refi[0] < 0) cu.refi[0] = 0; }
         if (ibc) { cu.refi[0] = cu.refi[1] = -1; cu.mv[1][0] = cu.mv[1][1] = 0; }
         cu.mvp_idx[0] = (x >> 2) & 3; cu.mvp_idx[1] = (y >> 2) & 3;   // a SKIP CU: some predictor per list
-        if (st.sps.tool_admvp) cu.mvp_idx[0] = cu.mvp_idx[1] = ((x >> 2) + 2 * (y >> 2)) % 6;      // ... or one of the six merge candidates (also of a merge-mode CU)
+        if (st.sps.tool_admvp) cu.mvp_idx[0] = cu.mvp_idx[1] = ((x >> 2) + 2 * (y >> 2)) % 6;
+        if (st.sps.tool_mmvd && ((x >> 3) + (y >> 2)) % 3 == 0) { cu.mmvd = 1; cu.mmvd_idx = ((x >> 2) * 37 + (y >> 2) * 101 + i) % 384; }      // a third of the skip / merge-mode CUs: any group, base, distance, direction      // ... or one of the six merge candidates (also of a merge-mode CU)
         cu.ipm = b->ipm ? b->ipm[i * 2] % (st.sps.tool_eipd ? 33 : 5) : 0;
         cu.ipm_c = (b->ipm && st.sps.tool_eipd) ? b->ipm[i * 2 + 1] % 5 : 0;
         cu.qp = std::min(std::max((int)b->qp[i * 3] - bd_off, 0), 51);
@@ -1860,6 +1959,8 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
     bw.ue(0);                                            // slice_pic_parameter_set_id
     bw.ue((uint32_t)slice_type);
     if (idr) bw.put1(0);                                 // no_output_of_prior_pics_flag
+    st.sh.mmvd_group = (st.sps.tool_mmvd && slice_type != XHOST_SLICE_I) ? (w->n_pics & 1) : 0;      // every other picture with the candidate groups
+    if (st.sps.tool_mmvd && slice_type != XHOST_SLICE_I) bw.put1(st.sh.mmvd_group);
     const int w_ctu = (st.sps.width + 63) >> 6, h_ctu = (st.sps.height + 63) >> 6;
     st.alf_ctb_flag.assign((size_t)w_ctu * h_ctu, 1);
     if (st.sps.tool_alf) {
