@@ -95,6 +95,19 @@ typedef struct xgpu_frame_params {
     int deblock_on, alf_on;
 } xgpu_frame_params;
 
+/* Tile grid of a picture: the PPS tile syntax after set_tile_info (src_main/xevdm.c:2162-2330).  Tiles are rectangles of CTUs; a CU
+   sees no neighbour in another tile (intra prediction, HTDF border, motion candidates), and the in-loop filters treat tile borders
+   as loop_filter_across_tiles says: the deblocking filters leave edges on a tile border alone when it is 0 (xevdm_df.c:142, 233,
+   274), the ALF windows end at the tile - mirrored when 0, replicated when 1 (alf_process_tile, xevdm_alf.c:901-1160).            */
+#define XGPU_MAX_TILE_COLS 20      /* MAX_NUM_TILES_COL / MAX_NUM_TILES_ROW, src_base/xevd_def.h */
+#define XGPU_MAX_TILE_ROWS 22
+typedef struct xgpu_tile_grid {
+    int n_cols, n_rows;
+    int col_bd[XGPU_MAX_TILE_COLS + 1];      /* first CTU column of every tile column; col_bd[n_cols] = CTUs per picture row */
+    int row_bd[XGPU_MAX_TILE_ROWS + 1];
+    int loop_filter_across_tiles;            /* pps.loop_filter_across_tiles_enabled_flag */
+} xgpu_tile_grid;
+
 /* Adaptive loop filter parameters of one picture: what alf_process has after alf_recon_coef
    (src_main/xevdm_alf.c:700-794, 1167-1195) - coefficient reconstruction from the APS stays on the host. */
 typedef struct xgpu_alf_params {
@@ -103,6 +116,7 @@ typedef struct xgpu_alf_params {
     const int16_t *chroma_coef;   /* alf_slice_param.chroma_coef: [7] 5x5-diamond coefficients               */
     const uint8_t *ctb_flag;      /* alf_ctb_flag of the luma plane, [n_ctu] raster; NULL = every CTU on     */
     int            across_tiles;  /* pps.loop_filter_across_tiles_enabled_flag (changes right/bottom borders) */
+    const xgpu_tile_grid *tiles;  /* NULL = one tile; else its loop_filter_across_tiles must equal across_tiles */
 } xgpu_alf_params;
 
 /*
@@ -136,7 +150,7 @@ typedef struct xgpu_cu_batch {
     const int16_t  *coef;         /* [n_coef] coefficient arena                                           */
     size_t          n_coef;
     int             n_ctu;
-    const uint32_t *ctu_cu_start; /* [n_ctu+1] first CU of every CTU in raster CTU order                  */
+    const uint32_t *ctu_cu_start; /* [n_ctu+1] first CU of every CTU in CTU decode order (raster; with tiles: tile by tile) */
     int             constrained_intra_pred;   /* pps.constrained_intra_pred_flag: intra CUs only predict from intra neighbours
                                                  (xevd_get_nbr_b, src_base/xevd_ipred.c:47,61,77)          */
     /* affine motion (Main, sps->tool_affine; xevdm_affine_mc, src_main/xevdm_mc.c:2606): both NULL = no affine CU in the batch */
@@ -154,6 +168,8 @@ typedef struct xgpu_cu_batch {
                                      (xevdm_htdf, src_main/xevdm_recon.c:153-385) then runs on the luma block of every intra CU and every
                                      inter CU with luma coefficients right after its reconstruction, reading one sample of border from
                                      the CUs reconstructed before it (xevdm.c:1381-1392; a slice QP up to 17 switches it off)          */
+    const xgpu_tile_grid *tiles;  /* NULL = one tile.  Else the CUs come tile by tile (tiles in raster order, CTUs in raster order inside a
+                                     tile - xevdm_dec_slice, src_main/xevdm.c:2614-2718) and neighbours in another tile are unavailable   */
 } xgpu_cu_batch;
 
 /* ------------------------------------------------------------------ lifetime ---------------------- */

@@ -21,8 +21,8 @@
  * bi_idx / mmvd_flag + mmvd data syntax (xevdm_eco.c:767-812,1519-1726), merge with vector difference (src_main/xevdm_util.c:191-592,4682-4716), merge candidates incl. the temporal and history ones (src_main/xevdm_util.c:594-1391,3729-3818), the resolution-indexed
  * predictor (:750-951), intra-only 4x4 CUs; tool_dmvr needs the backend's refined vectors back per picture (xhost_parser_set_dmvr_mvs) and is refused
  * together with tool_hmvp or tool_mmvd.  Not parsed: sps_btt_flag / sps_suco_flag (split syntax), tool_affine, tool_cm_init (and ADCC),
- * tool_rpl / tool_pocs, dquant.  SPS chroma QP mapping tables and cropping offsets are parsed, a VUI is skipped; 4:2:0, one tile and one slice per
- * picture, I / P / B slices incl. temporal layers (hierarchical sub-GOPs).
+ * tool_rpl / tool_pocs, dquant.  SPS chroma QP mapping tables and cropping offsets are parsed, a VUI is skipped; 4:2:0, one slice per picture (with all of its
+ * tiles - uniform or explicit PPS tile grids, entry points in the slice header; explicit tile ids and arbitrary slices are refused), I / P / B slices incl. temporal layers (hierarchical sub-GOPs).
  * Conventions as xevd_hip.h: 0 / negative XEVD_ERR_* codes, nothing throws, one object per stream.
  */
 #ifndef XEVD_HOST_H
@@ -119,6 +119,13 @@ typedef struct xhost_stream_params {
                                               coupled with the index), sps->tool_hmvp (history-based merge candidates and fallback predictors)  */
     int ibc_log_max_size;                  /* 0: sps->ibc_flag off.  2..7 (needs tool_eipd): intra block copy for CUs up to 2^n samples - a CU of the batch with
                                               pred_mode XGPU_MODE_IBC is written with ibc_flag and its block vector mv[0] (xevdm_eco.c:1401-1438, 1789-1800)  */
+    /* tiles (Main profile; PPS syntax xevdm_eco.c:2019-2052): tile_cols x tile_rows tiles per picture (0 / 1: one tile), one slice with all of them.
+       tile_col_w[0] == 0: uniform spacing; else the widths / heights in CTUs of all but the last column / row.  The batch handed to
+       xhost_writer_add_picture stays in raster CTU order; the writer codes the CTUs tile by tile.  No IBC CUs with tiles (their block
+       vectors would have to respect the tile decode order). */
+    int tile_cols, tile_rows;
+    int tile_col_w[XGPU_MAX_TILE_COLS], tile_row_h[XGPU_MAX_TILE_ROWS];
+    int loop_filter_across_tiles;          /* pps.loop_filter_across_tiles_enabled_flag */
 } xhost_stream_params;
 
 /* ALF parameter set as it is coded in an APS NAL unit (XEVD_ALF_SLICE_PARAM after xevdm_eco_alf_aps_param) */

@@ -24,7 +24,7 @@
  * objects in the link, oracle/Makefile.ref: libxevd_ref_hip.so) - the way ref_harness.c reaches static helpers; no reference source is copied.
  * The recursion over the split tree below is OUR walk over the reference's exported helpers (xevd_get_split_mode,
  * xevd_split_get_part_structure, xevdm_get_suco_flag, xevdm_split_get_suco_order, xevd_derive_mode_cons).
- * Limits (asserted): one tile per picture, 4:2:0, no local dual tree, not tool_dmvr together with tool_hmvp (the history would need refined vectors
+ * Limits (asserted): one slice per picture (any tile grid), 4:2:0, no local dual tree, not tool_dmvr together with tool_hmvp (the history would need refined vectors
  * while the picture is still being parsed).
  */
 #include "xevdm.c"
@@ -57,6 +57,7 @@ typedef struct {
     void *coef; rb_vec coef_v;
     int any_affine, any_dmvr, any_ats, any_ats_inter;
     int failed;
+    xgpu_tile_grid grid;
 } rb_state;
 
 static rb_state *rb_of(XEVD_CTX *ctx) { return (rb_state *)ctx->pf; }
@@ -228,6 +229,18 @@ static int hip_open(XEVD_CTX *ctx)
 }
 
 /* ctx->fn_dec_slice */
+/* ctx->tile[] (set_tile_info, xevdm.c:2162-2330) as the backend's tile grid; NULL for one tile */
+static const xgpu_tile_grid *hip_tile_grid(XEVD_CTX *ctx, xgpu_tile_grid *g)
+{
+    int i;
+    if (ctx->w_tile * ctx->h_tile <= 1) return NULL;
+    memset(g, 0, sizeof(*g));
+    g->n_cols = ctx->w_tile; g->n_rows = ctx->h_tile; g->loop_filter_across_tiles = ctx->pps.loop_filter_across_tiles_enabled_flag;
+    for (i = 0; i < g->n_cols; i++) g->col_bd[i + 1] = g->col_bd[i] + ctx->tile[i].w_ctb;
+    for (i = 0; i < g->n_rows; i++) g->row_bd[i + 1] = g->row_bd[i] + ctx->tile[i * ctx->w_tile].h_ctb;
+    return g;
+}
+
 static int hip_dec_slice(XEVD_CTX *ctx, XEVD_CORE *core)
 {
     rb_state *s = rb_of(ctx);
@@ -238,37 +251,57 @@ static int hip_dec_slice(XEVD_CTX *ctx, XEVD_CORE *core)
     xgpu_frame_params fp;
     xgpu_dbatch *db = NULL;
     int ret, l, i, cx, cy;
-    if (ctx->num_tiles_in_slice != 1 || ctx->w_tile * ctx->h_tile != 1 || ctx->sps->chroma_format_idc != 1) return XEVD_ERR_UNSUPPORTED;
+    XEVD_BSR bs0;
+    XEVD_SBAC sbac0;
+    int t, n_ctu = 0;
+    /* one slice per picture with all of its tiles in raster order (what set_tile_info derives for first_tile_id 0 / last_tile_id count - 1) */
+    if (ctx->num_tiles_in_slice != ctx->w_tile * ctx->h_tile || ctx->sh.arbitrary_slice_flag || ctx->sps->chroma_format_idc != 1) return XEVD_ERR_UNSUPPORTED;
+    for (t = 0; t < ctx->num_tiles_in_slice; t++) if (ctx->tile_in_slice[t] != t) return XEVD_ERR_UNSUPPORTED;
     /* DMVR + HMVP: xevdm_set_dec_info leaves the refined vector of the first sub-block in core->mv (xevdm_util.c:4384-4387), which the history buffer then
        takes (xevdm.c:1335-1342) - the next CUs' candidates would need the refinement result before the batch has run */
     if (ctx->sps->tool_dmvr && ctx->sps->tool_hmvp) return XEVD_ERR_UNSUPPORTED;
     if (!s->g && (ret = hip_open(ctx)) < 0) return ret;
 
-    /* entropy decoding of the tile, exactly as xevdm_dec_slice sets it up for its first worker (xevdm.c:2640-2663) */
-    ctx->sh.qp_prev_eco = ctx->sh.qp;
-    xevd_mcpy(cm, core, sizeof(XEVD_CORE));
-    cm->ctx = ctx; cm->bs = &ctx->bs_mt[0]; cm->sbac = &ctx->sbac_dec_mt[0]; cm->tile_num = ctx->tile_in_slice[0]; cm->thread_idx = 0;
-    tile = &ctx->tile[cm->tile_num];
-    tile->qp_prev_eco = ctx->sh.qp; tile->qp = ctx->sh.qp;
-    xevd_mcpy(cm->bs, &ctx->bs, sizeof(XEVD_BSR));
-    xevd_mcpy(cm->sbac, GET_SBAC_DEC(&ctx->bs), sizeof(XEVD_SBAC));
-    SET_SBAC_DEC(cm->bs, cm->sbac);
-    xevd_mset((void *)ctx->sync_row, 0, tile->h_ctb * sizeof(ctx->sync_row[0]));
-    (void)xevd_tile_eco(cm);                                           /* xevd_tile_mt does not look at its status in this configuration either (xevdm.c:2573-2574) */
-
-    /* the CUs of the picture in decoding order -> one batch */
     s->n_cu = 0; s->coef_v.n = 0; s->any_affine = s->any_dmvr = s->any_ats = s->any_ats_inter = 0; s->failed = 0; s->deblocked = 0;
     s->ctu_start = realloc(s->ctu_start, sizeof(uint32_t) * (size_t)(ctx->f_lcu + 1));
-    for (cy = 0; cy < ctx->h_lcu; cy++) for (cx = 0; cx < ctx->w_lcu; cx++) {
-        cm->x_lcu = cx; cm->y_lcu = cy; cm->lcu_num = cy * ctx->w_lcu + cx;
-        cm->x_pel = cx << ctx->log2_max_cuwh; cm->y_pel = cy << ctx->log2_max_cuwh;
-        if (ctx->sps->tool_hmvp && cx == 0 && xevdm_hmvp_init(cm) != XEVD_OK) return XEVD_ERR;      /* xevdm.c:2499-2503 */
-        s->ctu_start[cm->lcu_num] = (uint32_t)s->n_cu;
-        hip_recon_tree(ctx, cm, cm->x_pel, cm->y_pel, ctx->max_cuwh, ctx->max_cuwh, 0, 0, (TREE_CONS_NEW) { TREE_LC, eAll });
-        if (s->failed) return XEVD_ERR_UNSUPPORTED;
+    ctx->sh.qp_prev_eco = ctx->sh.qp;
+    xevd_mcpy(&bs0, &ctx->bs, sizeof(XEVD_BSR));                        /* the reader right behind the slice header: where the first tile starts */
+    xevd_mcpy(&sbac0, GET_SBAC_DEC(&ctx->bs), sizeof(XEVD_SBAC));
+    for (t = 0; t < ctx->num_tiles_in_slice; t++) {
+        /* entropy decoding of one tile, as xevdm_dec_slice sets its worker up (xevdm.c:2640-2680): own reader + arithmetic decoder at the tile's
+           entry point - the sum of the slice header's entry_point_offset_minus1 + 1 of the tiles before it, in bytes from the first tile */
+        int x0, x1, y1;
+        xevd_mcpy(cm, core, sizeof(XEVD_CORE));
+        cm->ctx = ctx; cm->bs = &ctx->bs_mt[0]; cm->sbac = &ctx->sbac_dec_mt[0]; cm->tile_num = t; cm->thread_idx = 0;
+        tile = &ctx->tile[t];
+        tile->qp_prev_eco = ctx->sh.qp; tile->qp = ctx->sh.qp;
+        xevd_mcpy(cm->bs, &bs0, sizeof(XEVD_BSR));
+        xevd_mcpy(cm->sbac, &sbac0, sizeof(XEVD_SBAC));
+        SET_SBAC_DEC(cm->bs, cm->sbac);
+        if (t > 0) {
+            int off = 0;
+            for (i = 0; i < t; i++) off += ctx->sh.entry_point_offset_minus1[i] + 1;
+            cm->bs->cur = bs0.cur - (bs0.leftbits >> 3) + off;          /* bytes the reader has fetched but not consumed lie before bs0.cur */
+            cm->bs->leftbits = 0; cm->bs->code = 0;
+            if (cm->bs->cur > cm->bs->end) return XEVD_ERR_MALFORMED_BITSTREAM;
+        }
+        xevd_mset((void *)ctx->sync_row, 0, ctx->h_lcu * sizeof(ctx->sync_row[0]));
+        (void)xevd_tile_eco(cm);                                       /* xevd_tile_mt does not look at its status in this configuration either (xevdm.c:2573-2574) */
+
+        /* the CUs of the tile in decoding order, appended to the picture's batch */
+        x0 = tile->ctba_rs_first % ctx->w_lcu; cy = tile->ctba_rs_first / ctx->w_lcu;
+        x1 = x0 + tile->w_ctb; y1 = cy + tile->h_ctb;
+        for (; cy < y1; cy++) for (cx = x0; cx < x1; cx++) {
+            cm->x_lcu = cx; cm->y_lcu = cy; cm->lcu_num = cy * ctx->w_lcu + cx;
+            cm->x_pel = cx << ctx->log2_max_cuwh; cm->y_pel = cy << ctx->log2_max_cuwh;
+            if (ctx->sps->tool_hmvp && cx == x0 && xevdm_hmvp_init(cm) != XEVD_OK) return XEVD_ERR;      /* xevdm.c:2499-2503 */
+            s->ctu_start[n_ctu++] = (uint32_t)s->n_cu;
+            hip_recon_tree(ctx, cm, cm->x_pel, cm->y_pel, ctx->max_cuwh, ctx->max_cuwh, 0, 0, (TREE_CONS_NEW) { TREE_LC, eAll });
+            if (s->failed) return XEVD_ERR_UNSUPPORTED;
+        }
+        ctx->num_ctb -= tile->w_ctb * tile->h_ctb;                    /* xevdm.c:2693-2697 */
     }
     s->ctu_start[ctx->f_lcu] = (uint32_t)s->n_cu;
-    ctx->num_ctb -= tile->w_ctb * tile->h_ctb;                        /* xevdm.c:2693-2697 */
     xevd_mcpy(&ctx->bs, cm->bs, sizeof(XEVD_BSR));                      /* :2707-2711 */
     xevd_mcpy(&ctx->sbac_dec, cm->sbac, sizeof(XEVD_SBAC));
 
@@ -282,6 +315,7 @@ static int hip_dec_slice(XEVD_CTX *ctx, XEVD_CORE *core)
     if (s->any_affine) { b.affine = s->affine; b.affine_mv = s->affine_mv; }
     if (s->any_dmvr) b.dmvr = s->dmvr;
     b.htdf_slice_qp = ctx->sps->tool_htdf ? ctx->sh.qp : 0;
+    b.tiles = hip_tile_grid(ctx, &s->grid);
 
     memset(&fp, 0, sizeof(fp));
     fp.pic = rb_slot(s, ctx->pic); fp.poc = ctx->poc.poc_val;
@@ -349,6 +383,7 @@ static int hip_alf(XEVD_CTX *ctx, XEVD_PIC *pic)
     xp.luma_coef = alf->coef_final; xp.chroma_coef = ap.chroma_coef;
     xp.ctb_flag = ap.alf_ctb_flag;                                     /* the luma flags: the first f_lcu entries */
     xp.across_tiles = ctx->pps.loop_filter_across_tiles_enabled_flag;
+    xp.tiles = hip_tile_grid(ctx, &s->grid);
     ret = xgpu_alf(s->g, &xp);
     free(ap.alf_ctb_flag);
     return ret < 0 ? XEVD_ERR : XEVD_OK;

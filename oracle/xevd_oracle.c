@@ -639,13 +639,28 @@ int orc_dmvr_cu(const xgpu_seq_params *sp, const orc_frame *fr, int x, int y, in
    are valid from -1 to cw+ch-1.  A 4x4-luma unit (2x2 chroma) of the row above / column to the left is taken from the picture
    when its SCU is inside the picture and already reconstructed (COD, bit 31 of map_scu) - and intra-coded under
    constrained_intra_pred -, else it is the mid value of the LUMA bit depth (xevd.c:455-473 passes it for all components). */
+#define TILE_SAME(m, a, b) (!(m)->map_tidx || (m)->map_tidx[a] == (m)->map_tidx[b])      /* map_tidx[curr] == map_tidx[neighbour] in all of the reference's availability tests */
+/* ctx->map_tidx (set_tile_info, src_main/xevdm.c:2300-2330) from the batch's tile grid; NULL for one tile.  The caller frees it. */
+static uint8_t *tile_map(const xgpu_tile_grid *g, int w_scu, int h_scu)
+{
+    uint8_t *t;
+    int i, j, y;
+    if (!g || g->n_cols * g->n_rows <= 1) return NULL;
+    t = (uint8_t *)calloc((size_t)w_scu * h_scu, 1);
+    for (j = 0; j < g->n_rows; j++) for (i = 0; i < g->n_cols; i++)
+        for (y = g->row_bd[j] * 16; y < g->row_bd[j + 1] * 16 && y < h_scu; y++) {
+            const int x0 = g->col_bd[i] * 16, x1 = g->col_bd[i + 1] * 16 < w_scu ? g->col_bd[i + 1] * 16 : w_scu;
+            memset(t + (size_t)y * w_scu + x0, j * g->n_cols + i, (size_t)(x1 - x0));
+        }
+    return t;
+}
 static void intra_neighbours(const xgpu_seq_params *sp, const orc_maps *m, const int16_t *src, int s, int x_scu, int y_scu,
                              int cw, int ch, int unit, int constrained, int16_t *up, int16_t *left)
 {
     const int scuw = cw / unit, scuh = ch / unit, ws = m->w_scu, scup = x_scu + y_scu * ws;
     const int16_t mid = (int16_t)(1 << (sp->bit_depth_luma - 1));
     int i, j;
-#define NB_OK(k) (MCU_COD(m->map_scu[k]) && (!constrained || MCU_IF(m->map_scu[k])))
+#define NB_OK(k) (MCU_COD(m->map_scu[k]) && (!constrained || MCU_IF(m->map_scu[k])) && TILE_SAME(m, scup, k))
     up[-1] = (x_scu > 0 && y_scu > 0 && NB_OK(scup - ws - 1)) ? src[-s - 1] : mid;      /* AVAIL_UP_LE, xevd_util.c:722-725 */
     for (i = 0; i < scuw + scuh; i++) {
         const int ok = y_scu > 0 && x_scu + i < ws && NB_OK(scup - ws + i);
@@ -696,7 +711,7 @@ static void intra_neighbours_eipd(const xgpu_seq_params *sp, const orc_maps *m, 
 {
     const int scuw = cw / unit, scuh = ch / unit, ws = m->w_scu, scup = x_scu + y_scu * ws;
     int i, j;
-#define NB_OK(k) (MCU_COD(m->map_scu[k]) && (!constrained || MCU_IF(m->map_scu[k])))
+#define NB_OK(k) (MCU_COD(m->map_scu[k]) && (!constrained || MCU_IF(m->map_scu[k])) && TILE_SAME(m, scup, k))
     const int ul_ok = x_scu > 0 && y_scu > 0 && NB_OK(scup - ws - 1);
     up[-1] = ul_ok ? src[-s - 1] : (int16_t)(1 << (sp->bit_depth_luma - 1));      /* the mid value only feeds the repetition below */
     for (i = 0; i < scuw + scuh; i++) {
@@ -1042,24 +1057,26 @@ static int htdf_lut(int z, const uint8_t *tbl, int thr, int shift, int rnd)
     const int v = a < thr ? tbl[((a + rnd) & thr) >> shift] : a;      /* (a + rnd) & thr: the reference's index mask, kept as it is */
     return z < 0 ? -v : v;
 }
-/* xevd_get_avail_intra, src_base/xevd_util.c:689-745 (one tile): bit 0 up, 1 left, 3 right, 5 up-left, 6 up-right, 7 low-left, 8 low-right */
+/* xevd_get_avail_intra, src_base/xevd_util.c:689-745: bit 0 up, 1 left, 3 right, 5 up-left, 6 up-right, 7 low-left, 8 low-right */
 static int avail_intra(const orc_maps *m, int xs, int ys, int scuw, int scuh)
 {
     const int k = ys * m->w_scu + xs;
     int av = 0;
-    if (xs > 0 && MCU_COD(m->map_scu[k - 1])) {
+#define AV_OK(n) (MCU_COD(m->map_scu[n]) && TILE_SAME(m, k, n))
+    if (xs > 0 && AV_OK(k - 1)) {
         av |= 1 << 1;
-        if (ys + scuh + scuw - 1 < m->h_scu && MCU_COD(m->map_scu[k + m->w_scu * (scuw + scuh) - m->w_scu - 1])) av |= 1 << 7;
+        if (ys + scuh + scuw - 1 < m->h_scu && AV_OK(k + m->w_scu * (scuw + scuh) - m->w_scu - 1)) av |= 1 << 7;
     }
     if (ys > 0) {
-        av |= 1 << 0;
-        if (xs > 0 && MCU_COD(m->map_scu[k - m->w_scu - 1])) av |= 1 << 5;
-        if (xs + scuw < m->w_scu && MCU_COD(m->map_scu[k - m->w_scu + scuw])) av |= 1 << 6;
+        if (TILE_SAME(m, k, k - m->w_scu)) av |= 1 << 0;
+        if (xs > 0 && AV_OK(k - m->w_scu - 1)) av |= 1 << 5;
+        if (xs + scuw < m->w_scu && AV_OK(k - m->w_scu + scuw)) av |= 1 << 6;
     }
-    if (xs + scuw < m->w_scu && MCU_COD(m->map_scu[k + scuw])) {
+    if (xs + scuw < m->w_scu && AV_OK(k + scuw)) {
         av |= 1 << 3;
-        if (ys + scuh + scuw - 1 < m->h_scu && MCU_COD(m->map_scu[k + m->w_scu * (scuw + scuh - 1) + scuw])) av |= 1 << 8;
+        if (ys + scuh + scuw - 1 < m->h_scu && AV_OK(k + m->w_scu * (scuw + scuh - 1) + scuw)) av |= 1 << 8;
     }
+#undef AV_OK
     return av;
 }
 static void orc_htdf(int16_t *rec, int s, int w, int h, int qp, int intra, const orc_maps *m, int xs, int ys, int constrained, int bd)
@@ -1126,6 +1143,8 @@ int orc_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xgp
     size_t dmvr_n = 0;
     int16_t refined[64][2][2];
     int dmvr_done = 0;
+    uint8_t *tmap = maps ? tile_map(b->tiles, maps->w_scu, maps->h_scu) : NULL;
+    if (maps) maps->map_tidx = tmap;
     for (l = 0; l < 2; l++) for (c = 0; c < 3; c++) pred[l][c] = (int16_t *)malloc(sizeof(int16_t) * MAX_CU * MAX_CU);
     res = (int16_t *)malloc(sizeof(int16_t) * MAX_CU * MAX_CU);
 
@@ -1267,6 +1286,8 @@ int orc_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xgp
     }
     for (l = 0; l < 2; l++) for (c = 0; c < 3; c++) free(pred[l][c]);
     free(res);
+    if (maps) maps->map_tidx = NULL;
+    free(tmap);
     return 0;
 }
 
@@ -1346,6 +1367,9 @@ int orc_deblock_baseline(const xgpu_seq_params *sp, const orc_frame *fr, const x
 {
     const int ws = m->w_scu;
     int i, r, c, k;
+    /* edges on a tile border are left alone unless pps.loop_filter_across_tiles_enabled_flag (no_boundary, src_main/xevdm_df.c:142, 233, 274) */
+    uint8_t *tmap = (b->tiles && !b->tiles->loop_filter_across_tiles) ? tile_map(b->tiles, m->w_scu, m->h_scu) : NULL;
+#define TB_OK(p, q) (!tmap || tmap[p] == tmap[q])
     /* pass 1: vertical edges (xevd.c:1190-1210 with is_hor_edge=0 -> xevd_deblock_cu_ver, xevd_df.c:385-546).
        COD is cleared, CUs are visited in decode order; the left edge is filtered when the left neighbour is
        already visited, the right edge when the right neighbour is (never the case in quad-tree z-order). */
@@ -1356,9 +1380,9 @@ int orc_deblock_baseline(const xgpu_seq_params *sp, const orc_frame *fr, const x
         int x;
         for (x = b->x[i]; x < b->x[i] + cw; x += 64) {
             const int t = (x >> 2) + (y >> 2) * ws;
-            if (x > 0 && MCU_COD(m->map_scu[t - 1]))
+            if (x > 0 && MCU_COD(m->map_scu[t - 1]) && TB_OK(t, t - 1))
                 for (r = 0; r < h >> 2; r++) dbk_segment(sp, fr, m, t + r * ws, t + r * ws - 1, x, y + 4 * r, 1);
-            if (x + w < sp->width && MCU_COD(m->map_scu[t + (w >> 2)]))
+            if (x + w < sp->width && MCU_COD(m->map_scu[t + (w >> 2)]) && TB_OK(t, t + (w >> 2)))
                 for (r = 0; r < h >> 2; r++) dbk_segment(sp, fr, m, t + r * ws + (w >> 2), t + r * ws + (w >> 2) - 1, x + w, y + 4 * r, 1);
             for (r = 0; r < h >> 2; r++) for (c = 0; c < w >> 2; c++) m->map_scu[t + r * ws + c] |= 1u << 31;
         }
@@ -1369,10 +1393,11 @@ int orc_deblock_baseline(const xgpu_seq_params *sp, const orc_frame *fr, const x
         int y;
         for (y = b->y[i]; y < b->y[i] + ch; y += 64) {
             const int t = (x >> 2) + (y >> 2) * ws;
-            if (y > 0)
+            if (y > 0 && TB_OK(t, t - ws))
                 for (c = 0; c < w >> 2; c++) dbk_segment(sp, fr, m, t + c, t + c - ws, x + 4 * c, y, 0);
         }
     }
+    free(tmap);
     return 0;
 }
 
@@ -1513,6 +1538,7 @@ int orc_deblock_addb(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
 {
     const int ws = m->w_scu;
     int i, r, c, k;
+    uint8_t *tmap = (b->tiles && !b->tiles->loop_filter_across_tiles) ? tile_map(b->tiles, m->w_scu, m->h_scu) : NULL;      /* xevdm_df.c:877, 1088, 1106 */
     /* vertical edges on the 8x8 luma grid (deblock_addb_cu_ver, xevdm_df.c:1036-1135), then horizontal (:835-945) */
     for (k = 0; k < ws * m->h_scu; k++) m->map_scu[k] &= 0x7FFFFFFFu;
     /* a CU wider (taller) than 64 is passed to the CU filter as two 64-sample halves (deblock_tree, xevdm.c:1989-2037),
@@ -1523,9 +1549,9 @@ int orc_deblock_addb(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
         for (hx = 0; hx < cw; hx += 64) {
             const int x = cx + hx, w = cw > 64 ? 64 : cw;
             const int t = (x >> 2) + (y >> 2) * ws;
-            if ((x & 7) == 0 && x > 0 && MCU_COD(m->map_scu[t - 1]))
+            if ((x & 7) == 0 && x > 0 && MCU_COD(m->map_scu[t - 1]) && TB_OK(t, t - 1))
                 for (r = 0; r < h >> 2; r++) addb_segment(sp, fr, m, t + r * ws, t + r * ws - 1, x, y + 4 * r, 1, alpha_off, beta_off);
-            if (((x + w) & 7) == 0 && x + w < sp->width && MCU_COD(m->map_scu[t + (w >> 2)]))
+            if (((x + w) & 7) == 0 && x + w < sp->width && MCU_COD(m->map_scu[t + (w >> 2)]) && TB_OK(t, t + (w >> 2)))
                 for (r = 0; r < h >> 2; r++) addb_segment(sp, fr, m, t + r * ws + (w >> 2), t + r * ws + (w >> 2) - 1, x + w, y + 4 * r, 1, alpha_off, beta_off);
             for (r = 0; r < h >> 2; r++) for (c = 0; c < w >> 2; c++) m->map_scu[t + r * ws + c] |= 1u << 31;
         }
@@ -1536,11 +1562,13 @@ int orc_deblock_addb(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
         for (hy = 0; hy < ch; hy += 64) {
             const int y = cy + hy;
             const int t = (x >> 2) + (y >> 2) * ws;
-            if ((y & 7) == 0 && y > 0)
+            if ((y & 7) == 0 && y > 0 && TB_OK(t, t - ws))
                 for (c = 0; c < w >> 2; c++) addb_segment(sp, fr, m, t + c, t + c - ws, x + 4 * c, y, 0, alpha_off, beta_off);
         }
     }
+    free(tmap);
     return 0;
+#undef TB_OK
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1555,15 +1583,18 @@ int orc_deblock_addb(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
  * Availability = not on the tile (picture) border; with pps.loop_filter_across_tiles_enabled_flag the test is
  * made against pic_width-1 / pic_height-1 (:990-999), which makes the right and bottom picture borders count as
  * available (they then read the replicate extension).
+ * Several tiles: every tile has its OWN replicate-extended copy (alf_process_tile copies w_tile x h_tile samples to a
+ * private place of the temporary picture, :934-967), so "available" at a tile border inside the picture means the
+ * replicated edge of the CTU's tile, never the neighbouring tile's samples - the clamp below is to the tile [tx0,tx1) x [ty0,ty1).
  * ---------------------------------------------------------------------------------------------- */
-static int16_t *alf_ctu_window(const int16_t *a, int s, int pw, int ph, int x0, int y0, int cw, int ch,
+static int16_t *alf_ctu_window(const int16_t *a, int s, int tx0, int tx1, int ty0, int ty1, int x0, int y0, int cw, int ch,
                                int aL, int aR, int aT, int aB, int *ws_out)
 {
     const int m = 3, ws = cw + 2 * m;
     int16_t *buf = (int16_t *)malloc(sizeof(int16_t) * (size_t)ws * (ch + 2 * m));
     int16_t *o = buf + m * ws + m;
     int r, c;
-#define PIC(yy, xx) a[CLIP3(0, ph - 1, (yy)) * s + CLIP3(0, pw - 1, (xx))]        /* the replicate-extended copy */
+#define PIC(yy, xx) a[CLIP3(ty0, ty1 - 1, (yy)) * s + CLIP3(tx0, tx1 - 1, (xx))]        /* the tile's replicate-extended copy */
     for (r = 0; r < ch; r++) for (c = -m; c < cw + m; c++) {
         int xx = x0 + c;
         if (c < 0 && !aL) xx = x0 - c;
@@ -1626,12 +1657,23 @@ int orc_alf(const xgpu_seq_params *sp, const orc_pic *pic, const xgpu_alf_params
     }
     for (y0 = 0; y0 < h; y0 += ctu) for (x0 = 0; x0 < w; x0 += ctu) {
         const int cw = x0 + ctu > w ? w - x0 : ctu, ch = y0 + ctu > h ? h - y0 : ctu;
-        const int aL = x0 != 0, aT = y0 != 0;
-        const int aR = ap->across_tiles ? 1 : (x0 + cw != w), aB = ap->across_tiles ? 1 : (y0 + ch != h);
+        /* the CTU's tile in luma samples (one tile: the picture) */
+        int tx0 = 0, tx1 = w, ty0 = 0, ty1 = h, aL, aR, aT, aB;
+        if (ap->tiles) {
+            const xgpu_tile_grid *g = ap->tiles;
+            int t;
+            for (t = 0; t < g->n_cols; t++) if ((x0 >> sp->log2_ctu) >= g->col_bd[t] && (x0 >> sp->log2_ctu) < g->col_bd[t + 1]) { tx0 = g->col_bd[t] << sp->log2_ctu; tx1 = g->col_bd[t + 1] << sp->log2_ctu; }
+            for (t = 0; t < g->n_rows; t++) if ((y0 >> sp->log2_ctu) >= g->row_bd[t] && (y0 >> sp->log2_ctu) < g->row_bd[t + 1]) { ty0 = g->row_bd[t] << sp->log2_ctu; ty1 = g->row_bd[t + 1] << sp->log2_ctu; }
+            if (tx1 > w) tx1 = w;
+            if (ty1 > h) ty1 = h;
+        }
+        /* tile_boundary_check against the tile, or - across tiles - against (0, pic_w - 1, 0, pic_h - 1) (:990-999) */
+        aL = ap->across_tiles ? x0 != 0 : x0 != tx0; aT = ap->across_tiles ? y0 != 0 : y0 != ty0;
+        aR = ap->across_tiles ? 1 : (x0 + cw != tx1); aB = ap->across_tiles ? 1 : (y0 + ch != ty1);
         const int ctu_idx = (y0 >> sp->log2_ctu) * w_ctu + (x0 >> sp->log2_ctu);
         int ws, x, y;
         if (ap->enable[0] && (!ap->ctb_flag || ap->ctb_flag[ctu_idx])) {
-            int16_t *o = alf_ctu_window(copy[0], w, w, h, x0, y0, cw, ch, aL, aR, aT, aB, &ws);
+            int16_t *o = alf_ctu_window(copy[0], w, tx0, tx1, ty0, ty1, x0, y0, cw, ch, aL, aR, aT, aB, &ws);
             for (y = 0; y < ch; y += 4) for (x = 0; x < cw; x += 4) {
                 int cls, tr, ii, jj;
                 int16_t f[13];
@@ -1655,7 +1697,7 @@ int orc_alf(const xgpu_seq_params *sp, const orc_pic *pic, const xgpu_alf_params
             const int16_t *f = ap->chroma_coef;
             int16_t *o;
             if (!ap->enable[c]) continue;
-            o = alf_ctu_window(copy[c], w >> 1, w >> 1, h >> 1, x0 >> 1, y0 >> 1, cw >> 1, ch >> 1, aL, aR, aT, aB, &ws);
+            o = alf_ctu_window(copy[c], w >> 1, tx0 >> 1, tx1 >> 1, ty0 >> 1, ty1 >> 1, x0 >> 1, y0 >> 1, cw >> 1, ch >> 1, aL, aR, aT, aB, &ws);
             for (y = 0; y < ch >> 1; y++) for (x = 0; x < cw >> 1; x++) {          /* alf_filter_blk_5, :339-429 */
                 const int16_t *p = o + y * ws + x;
                 int sum = f[0] * (p[2 * ws] + p[-2 * ws]) + f[1] * (p[ws + 1] + p[-ws - 1]) + f[2] * (p[ws] + p[-ws]) + f[3] * (p[ws - 1] + p[-ws + 1])

@@ -35,6 +35,7 @@ typedef struct orc_maps {
     int16_t  *map_mv;      /* [w_scu*h_scu][2][2] */
     uint8_t  *map_ats;     /* [w_scu*h_scu] mctx->map_ats_inter (src_main/xevdm_util.c:4321), may be NULL */
     int       w_scu, h_scu;
+    const uint8_t *map_tidx; /* [w_scu*h_scu] ctx->map_tidx or NULL: orc_recon_batch_ex fills it in for its own use from batch->tiles */
 } orc_maps;
 
 typedef struct orc_frame {

@@ -172,6 +172,13 @@ def golden_streams(only=()):
                                                                                inter_frac=0.9, max_refs=3, log2_sub_gop=3, bit_depth=10, skip_frac=0.3, direct_frac=0.3)),
                                 "main_mmvd_all_tools_10b": (264, 136, 17, dict(main=True, admvp=True, mmvd=True, amvr=True, hmvp=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True,
                                                                                ibc_log_max=5, inter_frac=0.9, skip_frac=0.35, direct_frac=0.3, max_refs=3, log2_sub_gop=3, bit_depth=10)),
+                                # several tiles per picture: without / with filtering across the tile borders, uniform and explicit grids
+                                "main_tiles_2x2_dbk_8b": (256, 192, 4, dict(main=True, tiles=(2, 2, 0), max_refs=2)),
+                                "main_tiles_3x2_all_tools_10b": (320, 200, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, alf_fixed=True, eipd=True, htdf=True, admvp=True, amvr=True, hmvp=True,
+                                                                                   mmvd=True, log2_sub_gop=2, max_refs=2, bit_depth=10, tiles=(3, 2, 0))),
+                                "main_tiles_across_dmvr_8b": (392, 264, 9, dict(main=True, iqt=True, addb=True, alf=True, eipd=True, htdf=True, admvp=True, dmvr=True, log2_sub_gop=2, max_refs=2,
+                                                                                tiles=(2, 3, 1))),
+                                "main_tiles_explicit_10b": (512, 320, 5, dict(main=True, iqt=True, addb=True, alf=True, eipd=True, admvp=True, bit_depth=10, tiles=(3, 3, 0, (1, 5), (2, 1)))),
                                 "main_alf_fixed_8b": (264, 136, 8, dict(main=True, alf=True, addb=True, alf_fixed=True)),
                                 "main_ibc_i_8b": (136, 72, 3, dict(main=True, eipd=True, ibc_log_max=4, ibc_frac=0.4, idr_period=1)),
                                 "main_ibc_all_tools_10b": (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=5, inter_frac=0.5, log2_sub_gop=2, max_refs=2, bit_depth=10))}.items():

@@ -20,7 +20,7 @@ class OrcPic(C.Structure):
 
 
 class OrcMaps(C.Structure):
-    _fields_ = [("map_scu", C.c_void_p), ("map_refi", C.c_void_p), ("map_mv", C.c_void_p), ("map_ats", C.c_void_p), ("w_scu", C.c_int), ("h_scu", C.c_int)]
+    _fields_ = [("map_scu", C.c_void_p), ("map_refi", C.c_void_p), ("map_mv", C.c_void_p), ("map_ats", C.c_void_p), ("w_scu", C.c_int), ("h_scu", C.c_int), ("map_tidx", C.c_void_p)]
 
 
 class OrcFrame(C.Structure):

@@ -86,6 +86,18 @@ CONFIGS = [
     (136, 72, 3, dict(main=True, eipd=True, ibc_log_max=4, idr_period=1)),
     (264, 136, 6, dict(main=True, eipd=True, addb=True, ibc_log_max=3, ibc_frac=0.6, inter_frac=0.5)),
     (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=6, inter_frac=0.5, log2_sub_gop=3, max_refs=2, bit_depth=10)),
+    # several tiles per picture (PPS grid uniform / explicit, one slice with entry points): every tile its own arithmetic-coder run, no neighbour
+    # across a tile border (intra samples, HTDF border, motion candidates, most probable modes), the history reset per tile CTU row, deblocking with
+    # and without loop_filter_across_tiles, the ALF windows ending at the tile (mirrored / replicated)
+    (256, 192, 3, dict(main=True, iqt=True, tiles=(2, 2, 1))),
+    (256, 256, 4, dict(main=True, tiles=(4, 4, 0))),
+    (320, 200, 4, dict(main=True, iqt=True, addb=True, alf=True, eipd=True, bit_depth=10, tiles=(3, 2, 0))),
+    (392, 264, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, alf_fixed=True, eipd=True, htdf=True, admvp=True, amvr=True, hmvp=True, mmvd=True, log2_sub_gop=2, max_refs=2,
+                       tiles=(2, 3, 1))),
+    (384, 256, 9, dict(main=True, iqt=True, addb=True, alf=True, eipd=True, admvp=True, dmvr=True, log2_sub_gop=2, max_refs=2, bit_depth=10, tiles=(2, 2, 0))),
+    (512, 320, 5, dict(main=True, iqt=True, addb=True, alf=True, eipd=True, admvp=True, bit_depth=10, tiles=(3, 3, 0, (1, 5), (2, 1)))),
+    (712, 72, 4, dict(main=True, iqt=True, alf=True, addb=True, tiles=(7, 1, 0))),
+    (200, 328, 4, dict(main=True, iqt=True, alf=True, tiles=(1, 5, 1))),
 ]
 
 

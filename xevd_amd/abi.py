@@ -43,6 +43,30 @@ class FrameParams(C.Structure):
     ]
 
 
+XGPU_MAX_TILE_COLS, XGPU_MAX_TILE_ROWS = 20, 22
+
+
+class TileGrid(C.Structure):
+    _fields_ = [("n_cols", C.c_int), ("n_rows", C.c_int), ("col_bd", C.c_int * (XGPU_MAX_TILE_COLS + 1)), ("row_bd", C.c_int * (XGPU_MAX_TILE_ROWS + 1)),
+                ("loop_filter_across_tiles", C.c_int)]
+
+
+def make_tile_grid(d):
+    """{'col_bd': [...], 'row_bd': [...], 'across': 0/1} (borders in CTUs, first 0, last = CTUs per row / column) -> TileGrid"""
+    g = TileGrid()
+    g.n_cols, g.n_rows = len(d["col_bd"]) - 1, len(d["row_bd"]) - 1
+    for i, v in enumerate(d["col_bd"]):
+        g.col_bd[i] = int(v)
+    for i, v in enumerate(d["row_bd"]):
+        g.row_bd[i] = int(v)
+    g.loop_filter_across_tiles = int(d.get("across", 0))
+    return g
+
+
+def tile_grid_dict(g):
+    return {"col_bd": [g.col_bd[i] for i in range(g.n_cols + 1)], "row_bd": [g.row_bd[i] for i in range(g.n_rows + 1)], "across": int(g.loop_filter_across_tiles)}
+
+
 class CuBatch(C.Structure):
     _fields_ = [
         ("n_cu", C.c_int),
@@ -54,12 +78,13 @@ class CuBatch(C.Structure):
         ("coef_off", C.POINTER(C.c_uint32)), ("coef", C.POINTER(C.c_int16)), ("n_coef", C.c_size_t),
         ("n_ctu", C.c_int), ("ctu_cu_start", C.POINTER(C.c_uint32)), ("constrained_intra_pred", C.c_int),
         ("affine", C.POINTER(C.c_uint8)), ("affine_mv", C.POINTER(C.c_int16)), ("dmvr", C.POINTER(C.c_uint8)), ("htdf_slice_qp", C.c_int),
+        ("tiles", C.POINTER(TileGrid)),
     ]
 
 
 class AlfParams(C.Structure):
     _fields_ = [("enable", C.c_int * 3), ("luma_coef", C.POINTER(C.c_int16)), ("chroma_coef", C.POINTER(C.c_int16)),
-                ("ctb_flag", C.POINTER(C.c_uint8)), ("across_tiles", C.c_int)]
+                ("ctb_flag", C.POINTER(C.c_uint8)), ("across_tiles", C.c_int), ("tiles", C.POINTER(TileGrid))]
 
 
 def make_alf_params(d):
@@ -75,6 +100,9 @@ def make_alf_params(d):
     if keep["flag"] is not None:
         ap.ctb_flag = keep["flag"].ctypes.data_as(C.POINTER(C.c_uint8))
     ap.across_tiles = int(d.get("across_tiles", 0))
+    if d.get("tiles") is not None:
+        keep["tiles"] = make_tile_grid(d["tiles"])
+        ap.tiles = C.pointer(keep["tiles"])
     return ap, keep
 
 
@@ -124,6 +152,9 @@ def make_cu_batch(b):
     cb.ctu_cu_start = _ptr(keep["ctu_cu_start"], C.c_uint32)
     cb.constrained_intra_pred = int(b.get("constrained_intra_pred", 0) or 0)
     cb.htdf_slice_qp = int(b.get("htdf_slice_qp", 0) or 0)
+    if b.get("tiles") is not None:
+        keep["tiles"] = make_tile_grid(b["tiles"])
+        cb.tiles = C.pointer(keep["tiles"])
     return cb, keep
 
 

@@ -173,7 +173,10 @@ __global__ __launch_bounds__(256) void k_addb(const AddbArgs a, const int16_t *_
     }
 
     // ---- decisions (deblock_addb_cu_hor :893-944 / deblock_addb_cu_ver_yuv :947-1034) ----
-    if (in_range && (rq.x & eflag)) {
+    // an edge on a tile border stays as it is unless the PPS filters across tiles (no_boundary, src_main/xevdm_df.c:877, 1088, 1106)
+    const int ctu_sh = a.log2_ctu - 2;
+    const bool tile_edge = (eq & ((1 << ctu_sh) - 1)) == 0 && (DIR == 0 ? a.no_filter.col_start((eq >> ctu_sh) & 255) : a.no_filter.row_start((eq >> ctu_sh) & 255));
+    if (in_range && (rq.x & eflag) && !tile_edge) {
         const int epos = eq << 2;
         const bool cross = (epos & ((1 << a.log2_ctu) - 1)) == 0;
         const int bs = addb_bs(rq, rp, cross, s_pic);

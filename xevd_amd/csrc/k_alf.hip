@@ -9,7 +9,9 @@
 // reference's per-CTU window rules (own rows mirror at unavailable left/right borders; the rows above/below are
 // taken whole from the replicate-extended copy when available - so corner samples next to a picture side border
 // are replicated, not mirrored - else mirror the window's own rows; with loop_filter_across_tiles the right and
-// bottom picture borders count as available).  Class = f(sum of |Laplacians| V,H,D0,D1 over the 8x8 window around
+// bottom picture borders count as available).  With several tiles every tile is filtered from its OWN replicate-extended copy
+// (alf_process_tile :934-967): the windows of a CTU end at its tile - "available" across a tile border means the tile's
+// replicated edge, "not available" (loop_filter_across_tiles = 0) the mirrored window, never the neighbouring tile's samples.  Class = f(sum of |Laplacians| V,H,D0,D1 over the 8x8 window around
 // the 4x4 block, activity), transpose index from the dominant directions, 25 classes x 13 coefficients.
 //
 // MI355X mapping: out of place (SRC -> DST) like the deblocking passes; one 256-thread workgroup per 64x64 luma
@@ -27,10 +29,10 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 #define SSTR  40          // sub-block sums row stride (u16); sub-block col c (-1..32) at index c+2 (own pairs 4-byte aligned)
 #define CSTR  40          // chroma: window col c (-2..33) at index c+4 (keeps the 8-byte interior pieces aligned)
 
-struct CtuRect { int x0, y0, cw, ch, aL, aR, aT, aB; };
+struct CtuRect { int x0, y0, cw, ch, aL, aR, aT, aB; int tx0, tx1, ty0, ty1; };      // the CTU, its border availability, its tile [tx0,tx1) x [ty0,ty1)
 
 // sample of the reference's per-CTU window at absolute plane position (y,x)  (alf_process_tile :1000-1052)
-__device__ __forceinline__ int alf_fetch(const int16_t *__restrict__ p, int s, int pw, int ph, const CtuRect k, int y, int x)
+__device__ __forceinline__ int alf_fetch(const int16_t *__restrict__ p, int s, const CtuRect k, int y, int x)
 {
     int yy = y, xx = x;
     if (y < k.y0 && !k.aT) yy = 2 * k.y0 - y;
@@ -39,20 +41,20 @@ __device__ __forceinline__ int alf_fetch(const int16_t *__restrict__ p, int s, i
         if (x < k.x0 && !k.aL) xx = 2 * k.x0 - x;
         else if (x >= k.x0 + k.cw && !k.aR) xx = 2 * (k.x0 + k.cw - 1) - x;
     }
-    yy = min(max(yy, 0), ph - 1); xx = min(max(xx, 0), pw - 1);           // the copy's replicate extension
+    yy = min(max(yy, k.ty0), k.ty1 - 1); xx = min(max(xx, k.tx0), k.tx1 - 1);           // the replicate extension of the tile's copy
     return p[yy * s + xx];
 }
 
 // stage a T x T tile (+H halo) of one plane into LDS.  lds index of window (r,c) = (r+H)*STR + c + OFF
 template <int T, int H, int STR, int OFF>
-__device__ __forceinline__ void alf_stage(int16_t *lds, const int16_t *__restrict__ p, int s, int pw, int ph, const CtuRect k,
+__device__ __forceinline__ void alf_stage(int16_t *lds, const int16_t *__restrict__ p, int s, const CtuRect k,
                                           int tx0, int ty0, int t0, int nthr)
 {
     // fast path (every tile that touches neither the picture border nor an unavailable CTU side - almost all of them): the window rule
     // does nothing, so the tile AND its halo are 8-byte copies of (T + 2H) rows x (T + 8) / 4 pieces (cols -4 .. T+3, window cols -H .. T+H-1 inside)
     static_assert(OFF == 4 && STR == T + 8, "the fast path copies whole LDS rows");
     const bool plain = (k.aL || tx0 > k.x0) && (k.aR || tx0 + T < k.x0 + k.cw) && (k.aT || ty0 > k.y0) && (k.aB || ty0 + T < k.y0 + k.ch) &&
-                       tx0 >= 4 && tx0 + T + 4 <= pw && ty0 >= H && ty0 + T + H <= ph;
+                       tx0 - H >= k.tx0 && tx0 + T + H <= k.tx1 && ty0 - H >= k.ty0 && ty0 + T + H <= k.ty1;
     if (plain) {
         constexpr int PCS = (T + 8) / 4;
         for (int i = t0; i < (T + 2 * H) * PCS; i += nthr) {
@@ -70,7 +72,7 @@ __device__ __forceinline__ void alf_stage(int16_t *lds, const int16_t *__restric
             *(uint2 *)(lds + (r + H) * STR + c4 + OFF) = v;
         } else if (ty0 + r < k.y0 + k.ch + H && tx0 + c4 < k.x0 + k.cw + H) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) lds[(r + H) * STR + c4 + e + OFF] = (int16_t)alf_fetch(p, s, pw, ph, k, ty0 + r, tx0 + c4 + e);
+            for (int e = 0; e < 4; e++) lds[(r + H) * STR + c4 + e + OFF] = (int16_t)alf_fetch(p, s, k, ty0 + r, tx0 + c4 + e);
         }
     }
     // halo ring through the window rule
@@ -80,7 +82,7 @@ __device__ __forceinline__ void alf_stage(int16_t *lds, const int16_t *__restric
         if (i < H * (T + 2 * H)) { r = i / (T + 2 * H) - H; c = i % (T + 2 * H) - H; }
         else if (i < 2 * H * (T + 2 * H)) { const int j = i - H * (T + 2 * H); r = T + j / (T + 2 * H); c = j % (T + 2 * H) - H; }
         else { const int j = i - 2 * H * (T + 2 * H); r = j / (2 * H); const int q = j % (2 * H); c = q < H ? q - H : T + q - H; }
-        lds[(r + H) * STR + c + OFF] = (int16_t)alf_fetch(p, s, pw, ph, k, ty0 + r, tx0 + c);
+        lds[(r + H) * STR + c + OFF] = (int16_t)alf_fetch(p, s, k, ty0 + r, tx0 + c);
     }
 }
 
@@ -121,19 +123,25 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
     const int ctu = 1 << a.log2_ctu;
     k.x0 = tx0 & ~(ctu - 1); k.y0 = ty0 & ~(ctu - 1);
     k.cw = min(ctu, a.pic_w - k.x0); k.ch = min(ctu, a.pic_h - k.y0);
-    k.aL = k.x0 != 0; k.aT = k.y0 != 0;
-    k.aR = a.across_tiles ? 1 : (k.x0 + k.cw != a.pic_w);
-    k.aB = a.across_tiles ? 1 : (k.y0 + k.ch != a.pic_h);
+    {
+        const int cx = k.x0 >> a.log2_ctu, cy = k.y0 >> a.log2_ctu, h_ctu = (a.pic_h + ctu - 1) >> a.log2_ctu;
+        k.tx0 = TileMask::tile_first(a.tiles.vb, cx) << a.log2_ctu; k.tx1 = min(TileMask::tile_end(a.tiles.vb, cx, a.w_ctu) << a.log2_ctu, a.pic_w);
+        k.ty0 = TileMask::tile_first(a.tiles.hb, cy) << a.log2_ctu; k.ty1 = min(TileMask::tile_end(a.tiles.hb, cy, h_ctu) << a.log2_ctu, a.pic_h);
+    }
+    // tile_boundary_check against the tile, or - across tiles - against (0, pic_w - 1, 0, pic_h - 1) (:990-999)
+    k.aL = a.across_tiles ? k.x0 != 0 : k.x0 != k.tx0; k.aT = a.across_tiles ? k.y0 != 0 : k.y0 != k.ty0;
+    k.aR = a.across_tiles ? 1 : (k.x0 + k.cw != k.tx1);
+    k.aB = a.across_tiles ? 1 : (k.y0 + k.ch != k.ty1);
     const int ctu_idx = (k.y0 >> a.log2_ctu) * a.w_ctu + (k.x0 >> a.log2_ctu);
     const bool luma_on = a.enable[0] && (a.ctb_flag == nullptr || a.ctb_flag[ctu_idx] != 0);
 
     for (int i = t; i < 25 * 13 + 7; i += 256) l_coef[i] = a.coef[i];
-    if (luma_on) alf_stage<64, 3, LSTR, 4>(l_y, sy_, a.s_l, a.pic_w, a.pic_h, k, tx0, ty0, t, 256);
+    if (luma_on) alf_stage<64, 3, LSTR, 4>(l_y, sy_, a.s_l, k, tx0, ty0, t, 256);
     {
         CtuRect kc = k;
-        kc.x0 >>= 1; kc.y0 >>= 1; kc.cw >>= 1; kc.ch >>= 1;
-        if (a.enable[1]) alf_stage<32, 2, CSTR, 4>(l_c[0], su_, a.s_c, a.pic_w >> 1, a.pic_h >> 1, kc, tx0 >> 1, ty0 >> 1, t, 256);
-        if (a.enable[2]) alf_stage<32, 2, CSTR, 4>(l_c[1], sv_, a.s_c, a.pic_w >> 1, a.pic_h >> 1, kc, tx0 >> 1, ty0 >> 1, t, 256);
+        kc.x0 >>= 1; kc.y0 >>= 1; kc.cw >>= 1; kc.ch >>= 1; kc.tx0 >>= 1; kc.tx1 >>= 1; kc.ty0 >>= 1; kc.ty1 >>= 1;
+        if (a.enable[1]) alf_stage<32, 2, CSTR, 4>(l_c[0], su_, a.s_c, kc, tx0 >> 1, ty0 >> 1, t, 256);
+        if (a.enable[2]) alf_stage<32, 2, CSTR, 4>(l_c[1], sv_, a.s_c, kc, tx0 >> 1, ty0 >> 1, t, 256);
     }
     __syncthreads();
 

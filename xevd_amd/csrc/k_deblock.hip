@@ -142,7 +142,11 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
     }
 
     int st[3] = {0, 0, 0};
-    if (in_range && (rq.x & eflag)) {
+    // an edge on a tile border stays as it is unless the PPS filters across tiles (no_boundary, src_main/xevdm_df.c:142, 233, 274)
+    auto on_tile_border = [&](int e) -> bool {
+        return (e & ((1 << a.ctu_sh) - 1)) == 0 && (DIR == 0 ? a.no_filter.col_start((e >> a.ctu_sh) & 255) : a.no_filter.row_start((e >> a.ctu_sh) & 255));
+    };
+    if (in_range && (rq.x & eflag) && !on_tile_border(pos)) {
         const int cls = edge_class(rq, rp), qp = (rq.x >> 16) & 0x7F;
 #pragma unroll
         for (int c = 0; c < 3; c++) st[c] = s_st[(c * 4 + cls) * 64 + (qp & 63)];
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
             int kk = k0;
             uint4 cur = rp;                                  // record of SCU head-1
             while (head - 1 > 0) {
-                if (!(cur.x & eflag)) break;
+                if (!(cur.x & eflag) || on_tile_border(head - 1)) break;
                 const uint4 prv = kk == k0 ? rpp : maps[kk - 2 * step];
                 const int cls = edge_class(cur, prv), qp = (cur.x >> 16) & 0x7F;
                 if (s_st[((1 + pl) * 4 + cls) * 64 + (qp & 63)] == 0) break;

@@ -450,6 +450,16 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         const int xs = b->x[i] >> 2, ys = b->y[i] >> 2, w = (1 << b->log2w[i]) >> 2, h = (1 << b->log2h[i]) >> 2;
         for (int r = 0; r < h; r++) std::fill_n(owner.begin() + (size_t)(ys + r) * ws + xs, w, (uint32_t)i);
     }
+    // tiles: a neighbour in another tile is not available (map_tidx[curr] == map_tidx[neighbour] in xevd_get_avail_intra, xevd_get_nbr_b, xevdm_get_nbr)
+    const int ctu_sh = c->sp.log2_ctu - 2;
+    std::vector<uint8_t> ctu_tile;
+    if (b->tiles) {
+        ctu_tile.assign((size_t)c->w_ctu * c->h_ctu, 0);
+        for (int tj = 0; tj < b->tiles->n_rows; tj++) for (int ti = 0; ti < b->tiles->n_cols; ti++)
+            for (int cy = b->tiles->row_bd[tj]; cy < b->tiles->row_bd[tj + 1]; cy++)
+                for (int cx = b->tiles->col_bd[ti]; cx < b->tiles->col_bd[ti + 1]; cx++) ctu_tile[(size_t)cy * c->w_ctu + cx] = (uint8_t)(tj * b->tiles->n_cols + ti);
+    }
+    auto tile_of = [&](int sx, int sy) -> int { return ctu_tile.empty() ? 0 : ctu_tile[(size_t)(sy >> ctu_sh) * c->w_ctu + (sx >> ctu_sh)]; };
     const bool constrained = b->constrained_intra_pred != 0;
     std::vector<IntraRec> recs;                 // decode order; dep lists hold CU indices until the sort below
     std::vector<uint32_t> deps;
@@ -467,11 +477,12 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         uint32_t last = NONE;
         const int hidx = htdf_idx((uint32_t)i);
         const bool h_intra = b->pred_mode[i] == XGPU_MODE_INTRA;
+        const int my_tile = tile_of(xs, ys);
         // the border samples the filter reads (xevdm_htdf, xevdm_recon.c:299-385) with the availability of xevd_get_avail_intra (xevd_util.c:689-745):
         // "reconstructed" = earlier in decoding order
         auto add_htdf = [&](IntraRec &r) -> bool {
             const int scuw = (1 << b->log2w[i]) >> 2, scuh = (1 << b->log2h[i]) >> 2;
-            auto cod = [&](int sx, int sy) -> bool { return owner[(size_t)sy * ws + sx] < (uint32_t)i; };
+            auto cod = [&](int sx, int sy) -> bool { return owner[(size_t)sy * ws + sx] < (uint32_t)i && tile_of(sx, sy) == my_tile; };
             auto dep = [&](int sx, int sy) {
                 const uint32_t j = owner[(size_t)sy * ws + sx];
                 if (j >= (uint32_t)i) return;                       // not reconstructed yet: the reference reads what is there, so do we
@@ -488,7 +499,7 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
                 if (ys + scuh + scuw - 1 < hs && cod(xs - 1, ys + scuh + scuw - 1)) av |= 1u << 7;
             }
             if (ys > 0) {
-                av |= 1u << 0;
+                if (tile_of(xs, ys - 1) == my_tile) av |= 1u << 0;
                 if (xs > 0 && cod(xs - 1, ys - 1)) av |= 1u << 5;
                 if (xs + scuw < ws && cod(xs + scuw, ys - 1)) av |= 1u << 6;
             }
@@ -563,7 +574,7 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         bool used = true;
         auto ok = [&](int sx, int sy) -> bool {
             const uint32_t j = owner[(size_t)sy * ws + sx];
-            if (j >= (uint32_t)i) return false;                                            // not reconstructed yet (or nothing there)
+            if (j >= (uint32_t)i || tile_of(sx, sy) != my_tile) return false;              // not reconstructed yet (or nothing there), or in another tile
             const bool j_intra = b->pred_mode[j] == XGPU_MODE_INTRA;
             if (constrained && !j_intra) return false;                                     // constrained_intra_pred: intra neighbours only
             if (!used) return true;
@@ -614,6 +625,20 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     return true;
 }
 
+// xgpu_tile_grid -> TileMask; false: not a partition of the picture's CTU grid
+static bool tile_mask(const xgpu_ctx *c, const xgpu_tile_grid *g, TileMask &m)
+{
+    memset(&m, 0, sizeof(m));
+    if (!g) return true;
+    if (g->n_cols < 1 || g->n_cols > XGPU_MAX_TILE_COLS || g->n_rows < 1 || g->n_rows > XGPU_MAX_TILE_ROWS || c->w_ctu > 256 || c->h_ctu > 256) return false;
+    if (g->col_bd[0] != 0 || g->row_bd[0] != 0 || g->col_bd[g->n_cols] != c->w_ctu || g->row_bd[g->n_rows] != c->h_ctu) return false;
+    for (int i = 0; i < g->n_cols; i++) if (g->col_bd[i + 1] <= g->col_bd[i]) return false;
+    for (int j = 0; j < g->n_rows; j++) if (g->row_bd[j + 1] <= g->row_bd[j]) return false;
+    for (int i = 1; i < g->n_cols; i++) m.vb[g->col_bd[i] >> 5] |= 1u << (g->col_bd[i] & 31);
+    for (int j = 1; j < g->n_rows; j++) m.hb[g->row_bd[j] >> 5] |= 1u << (g->row_bd[j] & 31);
+    return true;
+}
+
 // The batch builder: SoA batch of the ABI -> 32-byte CU records, the TB list sorted by size class and the
 // wave work items of the itdq kernel, written into ONE pinned staging block and sent with one async copy per
 // array.  (xevd_ctu_row_rec_mt's per-CU cu_init + coef_rect_to_series, xevd.c:567-676, become this pass.)
@@ -627,6 +652,8 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     ARGCHK(c, b->htdf_slice_qp >= 0 && b->htdf_slice_qp <= 51);
     ARGCHK(c, b->ctu_cu_start[0] == 0 && b->ctu_cu_start[b->n_ctu] == (uint32_t)b->n_cu);      // the kernels index the CU records through it
     for (int k = 0; k < b->n_ctu; k++) ARGCHK(c, b->ctu_cu_start[k] <= b->ctu_cu_start[k + 1]);
+    TileMask tmask;
+    ARGCHK(c, tile_mask(c, b->tiles, tmask));
     HIPCHK(c, hipSetDevice(c->sp.device));
     const int n = b->n_cu;
     const int bdoff = 6 * (c->sp.bit_depth_luma - 8);
@@ -735,6 +762,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     xgpu_dbatch *db = new xgpu_dbatch();
     memset(db, 0, sizeof(*db));
     db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->n_dmvr = n_dmvr; db->has_ibc = plan.has_ibc ? 1 : 0; db->has_htdf = plan.has_htdf ? 1 : 0;
+    db->tile_starts = tmask; db->tiles_across = b->tiles ? (b->tiles->loop_filter_across_tiles ? 1 : 0) : 1;
     const size_t sz_cus = sizeof(CuRec) * (size_t)std::max(n, 1), sz_ctu = sizeof(uint32_t) * (size_t)(b->n_ctu + 1);
     const size_t sz_tbs = sizeof(TbRec) * (size_t)std::max(n_tb, 1), sz_wv = sizeof(TbWave) * (size_t)std::max(n_waves, 1);
     const size_t sz_coef = sizeof(int16_t) * std::max(b->n_coef, (size_t)8);
@@ -918,6 +946,7 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
 {
     ARGCHK(c, c != NULL); ARGCHK(c, db != NULL); ARGCHK(c, c->have_frame);
     HIPCHK(c, hipStreamWaitEvent(c->stream, db->blk.uploaded, 0));       // the batch's arrays come through the upload stream
+    if (db->tiles_across) memset(&c->no_dbk, 0, sizeof(c->no_dbk)); else c->no_dbk = db->tile_starts;
     ItdqArgs ia;
     ia.coef = db->d_coef; ia.resid = db->d_resid; ia.tbs = db->d_tbs; ia.waves = db->d_waves; ia.n_waves = db->n_waves;
     ia.bd = c->sp.bit_depth_luma;      // the LUMA depth drives dequant/transform shifts of all components (xevd.c:441-442)
@@ -1015,7 +1044,7 @@ int xgpu_deblock(xgpu_ctx *c)
         a.s_l = c->s_l; a.s_c = c->s_c; a.w_scu = c->w_scu; a.h_scu = c->h_scu;
         a.bd_l = c->sp.bit_depth_luma; a.bd_c = c->sp.bit_depth_chroma; a.log2_ctu = c->sp.log2_ctu;
         a.alpha_off = c->fp.deblock_alpha_offset; a.beta_off = c->fp.deblock_beta_offset;
-        a.qp_u_off = c->fp.qp_u_offset; a.qp_v_off = c->fp.qp_v_offset; a.maps = c->d_maps;
+        a.qp_u_off = c->fp.qp_u_offset; a.qp_v_off = c->fp.qp_v_offset; a.maps = c->d_maps; a.no_filter = c->no_dbk;
         memcpy(a.chroma_qp, c->chroma_qp, sizeof(a.chroma_qp));
         for (int l = 0; l < 2; l++)
             for (int i = 0; i < XGPU_MAX_REFS; i++) a.pic_id[i * 2 + l] = i < c->fp.num_refp[l] ? (uint8_t)c->fp.refp_pic[i][l] : 255;
@@ -1025,7 +1054,7 @@ int xgpu_deblock(xgpu_ctx *c)
         DbkArgs a;
         memset(&a, 0, sizeof(a));
         a.s_l = c->s_l; a.s_c = c->s_c; a.pic_w = c->sp.width; a.pic_h = c->sp.height; a.w_scu = c->w_scu; a.h_scu = c->h_scu;
-        a.bd_l = c->sp.bit_depth_luma; a.bd_c = c->sp.bit_depth_chroma; a.maps = c->d_maps;
+        a.bd_l = c->sp.bit_depth_luma; a.bd_c = c->sp.bit_depth_chroma; a.maps = c->d_maps; a.ctu_sh = c->sp.log2_ctu - 2; a.no_filter = c->no_dbk;
         // strength LUT: xevd_df.c:347-365 with the table index clamped to 0..51 (see oracle chroma_qp())
         for (int cls = 0; cls < 4; cls++)
             for (int qp = 0; qp < 64; qp++) {
@@ -1052,6 +1081,8 @@ int xgpu_alf(xgpu_ctx *c, const xgpu_alf_params *ap)
     a.s_l = c->s_l; a.s_c = c->s_c; a.pic_w = c->sp.width; a.pic_h = c->sp.height;
     a.bd = c->sp.bit_depth_luma;           // one bit depth for classification and all clip ranges (xevd_alf_init, xevdm_alf.c:431-437)
     a.log2_ctu = c->sp.log2_ctu; a.w_ctu = c->w_ctu; a.across_tiles = ap->across_tiles ? 1 : 0;
+    ARGCHK(c, tile_mask(c, ap->tiles, a.tiles));
+    ARGCHK(c, !ap->tiles || (ap->tiles->loop_filter_across_tiles != 0) == (ap->across_tiles != 0));
     for (int i = 0; i < 3; i++) a.enable[i] = ap->enable[i] ? 1 : 0;
     if (ap->luma_coef) memcpy(a.coef, ap->luma_coef, sizeof(int16_t) * 325);
     if (ap->chroma_coef) memcpy(a.coef + 325, ap->chroma_coef, sizeof(int16_t) * 7);

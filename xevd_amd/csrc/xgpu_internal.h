@@ -174,10 +174,38 @@ struct ItdqArgs {
     int            iqt;
 };
 
+// Tile borders of a picture as bit masks over CTU columns / rows: bit i set = a tile starts at CTU column (row) i > 0.  All zero for one tile.
+struct TileMask {
+    uint32_t vb[8], hb[8];             // pictures up to 16384 samples = 256 CTUs of 64
+    __host__ __device__ bool col_start(int ctu_x) const { return (vb[ctu_x >> 5] >> (ctu_x & 31)) & 1; }
+    __host__ __device__ bool row_start(int ctu_y) const { return (hb[ctu_y >> 5] >> (ctu_y & 31)) & 1; }
+    // first CTU column / row of the tile that holds CTU i, and one past its last (n = CTUs per picture row / column)
+    __host__ __device__ static int tile_first(const uint32_t *m, int i)
+    {
+        for (int w = i >> 5; w >= 0; w--) {
+            uint32_t v = m[w];
+            if (w == (i >> 5)) v &= 0xFFFFFFFFu >> (31 - (i & 31));
+            if (v) return (w << 5) + 31 - __builtin_clz(v);
+        }
+        return 0;
+    }
+    __host__ __device__ static int tile_end(const uint32_t *m, int i, int n)
+    {
+        for (int w = (i + 1) >> 5; w < 8; w++) {
+            uint32_t v = m[w];
+            if (w == ((i + 1) >> 5)) v &= 0xFFFFFFFFu << ((i + 1) & 31);
+            if (v) { const int e = (w << 5) + __builtin_ctz(v); return e < n ? e : n; }
+        }
+        return n;
+    }
+};
+
 struct DbkArgs {
     int      s_l, s_c;
     int      pic_w, pic_h, w_scu, h_scu;
     int      bd_l, bd_c;
+    int      ctu_sh;                   // SCUs per CTU = 1 << ctu_sh
+    TileMask no_filter;                // tile borders the filter must leave alone (loop_filter_across_tiles = 0; else all zero)
     const ScuRec *maps;
     uint8_t  st[3][4][64];             // strength by component, edge class, map QP (host-built from xevd_tbl_df_st)
 };
@@ -187,6 +215,7 @@ struct AddbArgs {
     int      w_scu, h_scu;
     int      bd_l, bd_c, log2_ctu;
     int      alpha_off, beta_off, qp_u_off, qp_v_off;
+    TileMask no_filter;                // as in DbkArgs
     const ScuRec *maps;
     int8_t   chroma_qp[2 * 96];        // [c][qp + 6*(bdc-8)]
     uint8_t  pic_id[XGPU_MAX_REFS * 2];// picture slot of refp[idx][list], 255 = none
@@ -194,6 +223,7 @@ struct AddbArgs {
 
 struct AlfArgs {
     int      s_l, s_c, pic_w, pic_h, bd, log2_ctu, w_ctu, across_tiles;
+    TileMask tiles;                    // tile starts: a CTU's windows end at its tile (alf_process_tile)
     int      enable[3];
     const uint8_t *ctb_flag;           // device, [n_ctu] or null
     int16_t  coef[25 * 13 + 7];        // coef_final followed by the chroma filter
@@ -224,6 +254,8 @@ struct xgpu_dbatch {
     uint32_t  *d_intra_deps;          // dependency lists (positions in d_intra)
     uint32_t  *d_intra_done;          // [n_intra] done epochs + [1] ticket counter
     int        has_ibc, has_htdf;     // the intra list holds intra-block-copy CUs / HTDF nodes
+    TileMask   tile_starts;           // of the batch's tile grid (zero: one tile)
+    int        tiles_across;          // its loop_filter_across_tiles
     int        n_intra, n_levels, n_intra_deps, n_intra_l1;      // n_intra_l1: CUs of level 1 (head of the list)
     uint32_t   intra_epoch, intra_tickets;
     void      *h_stage;               // pinned staging block
@@ -252,6 +284,7 @@ struct xgpu_ctx {
     int32_t        *d_dra;            // [3][1024] DRA inverse tables of the current output call
     xgpu_frame_params fp;
     int             have_frame;
+    TileMask        no_dbk;            // tile borders the deblocking of the current picture leaves alone (set by xgpu_batch_recon)
     int             where;             // 0: the picture being built lives in its DPB slot, 1: in the scratch picture
     // timing
     int             timing;

@@ -230,7 +230,10 @@ struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, lo
              int ibc = 0, ibc_log_max = 0;            // sps->ibc_flag, sps->ibc_log_max_size (log2 of the largest IBC CU; xevdm_eco.c:1890-1898)
              int crop[4] = { 0, 0, 0, 0 };            // picture_crop_left / right / top / bottom_offset (xevd_eco.c:1349-1357), as xevd_pull reports them
              bool cqt = false; int8_t cq[2][96] = { { 0 } }; };      // chroma QP mapping tables signalled in the SPS: [c][qp + 6*(bd_c-8)], qp = -6*(bd_c-8) .. 57
-struct Pps { int constrained_intra = 0, cu_qp_delta = 0, dra_on = 0, dra_aps_id = 0; };
+struct Pps { int constrained_intra = 0, cu_qp_delta = 0, dra_on = 0, dra_aps_id = 0;
+             // tiles (xevdm_eco_pps, xevdm_eco.c:2019-2052): a grid of CTU columns x rows, uniform or with explicit sizes
+             int tile_cols = 1, tile_rows = 1, tile_uniform = 1, across_tiles = 0, offset_bits = 1, id_bits = 1, arbitrary_slices = 0;
+             int tile_col_w[XGPU_MAX_TILE_COLS] = { 0 }, tile_row_h[XGPU_MAX_TILE_ROWS] = { 0 }; };
 struct Slice { int type = XHOST_SLICE_I, qp = 32, qp_u_offset = 0, qp_v_offset = 0, deblock = 1, alpha_off = 0, beta_off = 0;
                int alf_on = 0, aps_id_y = 0, aps_id_ch = 0, alf_chroma_idc = 0, alf_ctb_map = 0;
                int mmvd_group = 0;                                                         // mmvd_group_enable_flag (tool_mmvd, xevdm_eco.c:2592-2599)
@@ -296,6 +299,8 @@ struct Cu {
 struct Picture {         // SCU maps of the picture being parsed / written (ctx->map_scu, map_ipm, map_mv, map_refi; cod_eco)
     int w_scu = 0, h_scu = 0;
     std::vector<uint8_t> cod, intra, ibc;      // ibc: MCU_GET_IBC
+    std::vector<uint8_t> tidx;       // ctx->map_tidx: the tile of every SCU (empty: one tile) - neighbours in another tile are not available
+    bool same_tile(int a, int b) const { return tidx.empty() || tidx[(size_t)a] == tidx[(size_t)b]; }
     std::vector<int8_t> ipm;
     std::vector<int16_t> mv;         // [f_scu][2][2]
     std::vector<int8_t> refi;        // [f_scu][2]
@@ -303,7 +308,7 @@ struct Picture {         // SCU maps of the picture being parsed / written (ctx-
     {
         w_scu = w >> 2; h_scu = h >> 2;
         const size_t f = (size_t)w_scu * h_scu;
-        cod.assign(f, 0); intra.assign(f, 0); ibc.assign(f, 0); ipm.assign(f, 0); mv.assign(f * 4, 0); refi.assign(f * 2, -1);
+        cod.assign(f, 0); intra.assign(f, 0); ibc.assign(f, 0); ipm.assign(f, 0); mv.assign(f * 4, 0); refi.assign(f * 2, -1); tidx.clear();
     }
 };
 
@@ -410,6 +415,35 @@ struct Stream {          // everything both directions share
     int32_t dra_luts[3 * 1024];            // of the current picture (when the PPS switches DRA on)
     std::vector<uint8_t> alf_ctb_flag;     // luma CTB flags: all on at the start of a picture (xevdm.c:3001-3005), coded ones overwrite (:2411-2418)
     int16_t alf_luma_final[25][13], alf_chroma_final[7];
+    xgpu_tile_grid grid;                   // tiles of the current picture (set_tile_info, src_main/xevdm.c:2162-2330)
+
+    // tile grid of the current picture from the PPS, and the SCU -> tile map (after pic.reset); false: the PPS does not fit the picture
+    bool setup_tiles()
+    {
+        const int w_ctu = (sps.width + 63) >> 6, h_ctu = (sps.height + 63) >> 6;
+        memset(&grid, 0, sizeof(grid));
+        grid.n_cols = pps.tile_cols; grid.n_rows = pps.tile_rows; grid.loop_filter_across_tiles = pps.across_tiles;
+        if (grid.n_cols > w_ctu || grid.n_rows > h_ctu) return false;
+        for (int i = 0; i < grid.n_cols; i++) {
+            const int wd = pps.tile_uniform ? ((i + 1) * w_ctu) / grid.n_cols - (i * w_ctu) / grid.n_cols : i + 1 < grid.n_cols ? pps.tile_col_w[i] : w_ctu - grid.col_bd[i];
+            if (wd < 1) return false;
+            grid.col_bd[i + 1] = grid.col_bd[i] + wd;
+        }
+        for (int j = 0; j < grid.n_rows; j++) {
+            const int ht = pps.tile_uniform ? ((j + 1) * h_ctu) / grid.n_rows - (j * h_ctu) / grid.n_rows : j + 1 < grid.n_rows ? pps.tile_row_h[j] : h_ctu - grid.row_bd[j];
+            if (ht < 1) return false;
+            grid.row_bd[j + 1] = grid.row_bd[j] + ht;
+        }
+        if (grid.col_bd[grid.n_cols] != w_ctu || grid.row_bd[grid.n_rows] != h_ctu) return false;
+        pic.tidx.clear();
+        if (grid.n_cols * grid.n_rows > 1) {
+            pic.tidx.assign((size_t)pic.w_scu * pic.h_scu, 0);
+            for (int j = 0; j < grid.n_rows; j++) for (int i = 0; i < grid.n_cols; i++)
+                for (int y = grid.row_bd[j] * 16; y < std::min(grid.row_bd[j + 1] * 16, pic.h_scu); y++)
+                    memset(&pic.tidx[(size_t)y * pic.w_scu + grid.col_bd[i] * 16], j * grid.n_cols + i, (size_t)(std::min(grid.col_bd[i + 1] * 16, pic.w_scu) - grid.col_bd[i] * 16));
+        }
+        return true;
+    }
 
     // what alf_process hands to the filter (alf_load_paramline_from_aps_buffer2 + alf_recon_coef, xevdm_alf.c:682-794)
     bool alf_finalise()
@@ -592,9 +626,9 @@ struct Stream {          // everything both directions share
         };
         // an intra-block-copy neighbour does not count on the left and above - but does above-right, where the Main library's availability test
         // only asks "coded and not intra" (xevdm_get_avail_inter, xevdm_util.c:1468-1503): its stored vector is the block vector (list 1: zero)
-        take(0, xs > 0 && !pic.intra[scup - 1] && pic.cod[scup - 1] && !pic.ibc[scup - 1], scup - 1);
-        take(1, ys > 0 && !pic.intra[scup - ws] && !pic.ibc[scup - ws], scup - ws);
-        take(2, ys > 0 && xs + scuw < ws && pic.cod[scup - ws + scuw] && !pic.intra[scup - ws + scuw], scup - ws + scuw);
+        take(0, xs > 0 && !pic.intra[scup - 1] && pic.cod[scup - 1] && !pic.ibc[scup - 1] && pic.same_tile(scup, scup - 1), scup - 1);
+        take(1, ys > 0 && !pic.intra[scup - ws] && !pic.ibc[scup - ws] && pic.same_tile(scup, scup - ws), scup - ws);
+        take(2, ys > 0 && xs + scuw < ws && pic.cod[scup - ws + scuw] && !pic.intra[scup - ws + scuw] && pic.same_tile(scup, scup - ws + scuw), scup - ws + scuw);
         const RefPic *col = refp[lidx].empty() ? nullptr : refp[lidx][0];
         cand[3][0] = col ? col->mv0[(size_t)scup * 2] : (int16_t)0;
         cand[3][1] = col ? col->mv0[(size_t)scup * 2 + 1] : (int16_t)0;
@@ -622,7 +656,7 @@ struct Stream {          // everything both directions share
         const int ws = pic.w_scu, hs = pic.h_scu, xs = cu.x >> 2, ys = cu.y >> 2, scuw = (1 << cu.log2w) >> 2, scuh = (1 << cu.log2h) >> 2, scup = ys * ws + xs;
         neb[0] = scup + (scuh - 1) * ws - 1; neb[1] = scup - ws + scuw - 1; neb[2] = scup - ws + scuw; neb[3] = scup + scuh * ws - 1; neb[4] = scup - ws - 1;
         const bool in[5] = { xs > 0, ys > 0, ys > 0 && xs + scuw < ws, ys + scuh < hs && xs > 0, ys > 0 && xs > 0 };
-        for (int k = 0; k < 5; k++) valid[k] = in[k] && pic.cod[neb[k]] && !pic.intra[neb[k]] && !pic.ibc[neb[k]];
+        for (int k = 0; k < 5; k++) valid[k] = in[k] && pic.cod[neb[k]] && !pic.intra[neb[k]] && !pic.ibc[neb[k]] && pic.same_tile(scup, neb[k]);
     }
     static void scale_mv(int ratio, const int16_t in[2], int16_t out[2])      // scaling_mv, xevdm_util.c:180-190 (MVP_SCALING_PRECISION 5)
     {
@@ -889,8 +923,8 @@ struct Stream {          // everything both directions share
     {
         const int xs = cu.x >> 2, ys = cu.y >> 2, ws = pic.w_scu, scup = ys * ws + xs;
         int l = 0, u = 0;
-        if (xs > 0 && pic.intra[scup - 1] && pic.cod[scup - 1]) l = pic.ipm[scup - 1] + 1;
-        if (ys > 0 && pic.intra[scup - ws] && pic.cod[scup - ws]) u = pic.ipm[scup - ws] + 1;
+        if (xs > 0 && pic.intra[scup - 1] && pic.cod[scup - 1] && pic.same_tile(scup, scup - 1)) l = pic.ipm[scup - 1] + 1;
+        if (ys > 0 && pic.intra[scup - ws] && pic.cod[scup - ws] && pic.same_tile(scup, scup - ws)) u = pic.ipm[scup - ws] + 1;
         return k_mpm[l][u];
     }
     // tool_eipd: the two most probable modes, eight "extended" ones and the ordering of all 33 (xevdm_get_mpm, src_main/xevdm_ipred.c:
@@ -900,8 +934,8 @@ struct Stream {          // everything both directions share
         enum { DC = 0, PLN = 1, BI = 2, VER = 12, HOR = 24, DIA_R = 18, DIA_L = 6, DIA_U = 30, CNT = 33 };
         const int xs = cu.x >> 2, ys = cu.y >> 2, ws = pic.w_scu, scup = ys * ws + xs;
         int l = DC, u = DC;
-        if (xs > 0 && pic.intra[scup - 1] && pic.cod[scup - 1]) l = pic.ipm[scup - 1];
-        if (ys > 0 && pic.intra[scup - ws] && pic.cod[scup - ws]) u = pic.ipm[scup - ws];
+        if (xs > 0 && pic.intra[scup - 1] && pic.cod[scup - 1] && pic.same_tile(scup, scup - 1)) l = pic.ipm[scup - 1];
+        if (ys > 0 && pic.intra[scup - ws] && pic.cod[scup - ws] && pic.same_tile(scup, scup - ws)) u = pic.ipm[scup - ws];
         mpm[0] = std::min(l, u); mpm[1] = std::max(l, u);
         if (mpm[0] == mpm[1]) { mpm[0] = DC; mpm[1] = mpm[1] == DC ? BI : mpm[1]; }
         const int m0 = mpm[0], m1 = mpm[1];
@@ -1395,11 +1429,26 @@ struct xhost_parser {
     {
         br.ue(); br.ue(); br.ue(); br.ue(); br.ue();     // pps id, sps id, num_ref_idx_default_active_minus1[2], additional_lt_poc_lsb_len
         br.get1();                                       // rpl1_idx_present_flag
-        if (!br.get1()) return fail("multiple tiles are not supported");
-        br.ue(); br.get1();                              // tile_id_len_minus1, explicit_tile_id
+        Pps &q = st.pps;
+        q.tile_cols = q.tile_rows = q.tile_uniform = 1; q.across_tiles = 0;      // one tile: the flag is not sent and reads as 0
+        if (!br.get1()) {                                // single_tile_in_pic_flag == 0 (xevdm_eco.c:2021-2039)
+            q.tile_cols = (int)br.ue() + 1; q.tile_rows = (int)br.ue() + 1;
+            if (br.overrun || q.tile_cols > XGPU_MAX_TILE_COLS || q.tile_rows > XGPU_MAX_TILE_ROWS) return fail("bad PPS: tile grid");
+            q.tile_uniform = br.get1();
+            if (!q.tile_uniform) {
+                for (int i = 0; i + 1 < q.tile_cols; i++) q.tile_col_w[i] = (int)br.ue() + 1;
+                for (int i = 0; i + 1 < q.tile_rows; i++) q.tile_row_h[i] = (int)br.ue() + 1;
+            }
+            q.across_tiles = br.get1();
+            q.offset_bits = (int)br.ue() + 1;
+            if (q.offset_bits > 32) return fail("bad PPS: tile_offset_lens_minus1");
+        }
+        q.id_bits = (int)br.ue() + 1;                    // tile_id_len_minus1
+        if (q.id_bits > 15) return fail("bad PPS: tile_id_len_minus1");
+        if (br.get1()) return fail("explicit tile ids are not supported");
         st.pps.dra_on = br.get1();                       // pic_dra_enabled_flag, pic_dra_aps_id (xevdm_eco.c:2054-2060)
         if (st.pps.dra_on) st.pps.dra_aps_id = (int)br.get(5);
-        br.get1();                                       // arbitrary_slice_present
+        q.arbitrary_slices = br.get1();                  // arbitrary_slice_present_flag
         st.pps.constrained_intra = br.get1();
         st.pps.cu_qp_delta = br.get1();
         if (st.pps.cu_qp_delta) br.ue();                 // cu_qp_delta_area
@@ -1413,7 +1462,15 @@ struct xhost_parser {
         if (st.need_idr && nut != NUT_IDR) return fail("the sequence parameters changed: waiting for an IDR picture");
         st.need_idr = false;
         Slice &sh = st.sh;
-        br.ue();                                         // slice_pic_parameter_set_id; single tile: no tile ids
+        br.ue();                                         // slice_pic_parameter_set_id
+        const int n_tiles = st.pps.tile_cols * st.pps.tile_rows;
+        if (n_tiles > 1 && !st.sps.profile_main) return fail("tiles in a Baseline stream are not supported");
+        if (n_tiles > 1) {                               // xevdm_eco.c:2520-2550: this front end takes ONE slice per picture, all tiles in raster order
+            const int single = br.get1(), first = (int)br.get(st.pps.id_bits);
+            if (single || first != 0) return fail("several slices per picture are not supported");
+            if (st.pps.arbitrary_slices && br.get1()) return fail("arbitrary slices are not supported");
+            if ((int)br.get(st.pps.id_bits) != n_tiles - 1) return fail("several slices per picture are not supported");
+        }
         sh.type = (int)br.ue();
         if (sh.type < 0 || sh.type > 2) return fail("bad slice type");
         if (nut == NUT_IDR) br.get1();                   // no_output_of_prior_pics_flag
@@ -1439,6 +1496,8 @@ struct xhost_parser {
         if (sh.deblock && st.sps.tool_addb) { sh.alpha_off = br.se(); sh.beta_off = br.se(); }      // xevdm_eco.c:2767-2772
         sh.qp = (int)br.get(6);
         sh.qp_u_offset = br.se(); sh.qp_v_offset = br.se();
+        std::vector<size_t> tile_size((size_t)n_tiles, 0);      // entry_point_offset_minus1 + 1: bytes of every tile but the last (xevdm_eco.c:2789-2795)
+        for (int i = 0; i + 1 < n_tiles; i++) tile_size[(size_t)i] = (size_t)br.get(st.pps.offset_bits) + 1;
         while (!br.aligned()) if (br.get1()) return fail("slice header alignment");
         if (br.overrun || sh.qp > 51) return fail("bad slice header");
         st.derive_poc(nut == NUT_IDR, tid);
@@ -1450,27 +1509,36 @@ struct xhost_parser {
             for (const RefPic *r : st.refp[l])
                 if (r->mv0.size() != (size_t)(st.sps.width >> 2) * (st.sps.height >> 2) * 2) return fail("reference picture of another geometry");
         st.pic.reset(st.sps.width, st.sps.height);
-        st.models.reset();
-        st.qp_prev = sh.qp;
+        if (!st.setup_tiles()) return fail("the tile grid of the PPS does not fit the picture");
 
-        // ---- tile data (xevd_tile_eco, xevd.c:1408-1468) ----
-        Dec dec;
-        dec.br = &br;
-        dec.start();
+        // ---- tile data (xevdm_dec_slice + xevd_tile_eco, src_main/xevdm.c:2363-2461, 2614-2718): every tile is its own arithmetic-coder
+        //      run - contexts, QP predictor and motion history start afresh - at the byte offset the slice header gave ----
         batch.clear();
         const int W = st.sps.width, H = st.sps.height, w_ctu = (W + 63) >> 6, h_ctu = (H + 63) >> 6;
         st.alf_ctb_flag.assign((size_t)w_ctu * h_ctu, 1);
         for (int k = 0; k < 3; k++) blk[k].assign(64 * 64, 0);
-        for (int cy = 0; cy < h_ctu; cy++) for (int cx = 0; cx < w_ctu; cx++) {
-            if (cx == 0) st.history_reset();
-            batch.ctu_start.push_back((uint32_t)batch.x.size());
-            if (sh.alf_on && sh.alf_ctb_map) st.alf_ctb_flag[(size_t)cy * w_ctu + cx] = (uint8_t)dec.bin(0, st.models.alf_ctb[0]);      // xevdm.c:2411-2418
-            const int rc = parse_tree(dec, cx << 6, cy << 6, 6);
-            if (rc != XGPU_OK) return rc;
-            if (br.overrun) return fail("slice data ends early");
+        size_t tile_pos = br.pos;
+        for (int t = 0; t < n_tiles; t++) {
+            const int tc = t % st.grid.n_cols, tr = t / st.grid.n_cols;
+            br.pos = tile_pos;
+            if (br.pos > br.size * 8) return fail("tile entry point past the end of the slice");
+            st.models.reset();
+            st.qp_prev = sh.qp;
+            Dec dec;
+            dec.br = &br;
+            dec.start();
+            for (int cy = st.grid.row_bd[tr]; cy < st.grid.row_bd[tr + 1]; cy++) for (int cx = st.grid.col_bd[tc]; cx < st.grid.col_bd[tc + 1]; cx++) {
+                if (cx == st.grid.col_bd[tc]) st.history_reset();
+                batch.ctu_start.push_back((uint32_t)batch.x.size());
+                if (sh.alf_on && sh.alf_ctb_map) st.alf_ctb_flag[(size_t)cy * w_ctu + cx] = (uint8_t)dec.bin(0, st.models.alf_ctb[0]);      // xevdm.c:2411-2418
+                const int rc = parse_tree(dec, cx << 6, cy << 6, 6);
+                if (rc != XGPU_OK) return rc;
+                if (br.overrun) return fail("slice data ends early");
+            }
+            if (dec.tile_end() != 1) return fail("missing end-of-tile flag");
+            tile_pos += tile_size[(size_t)t] * 8;
         }
         batch.ctu_start.push_back((uint32_t)batch.x.size());
-        if (dec.tile_end() != 1) return fail("missing end-of-tile flag");
 
         // ---- hand-over ----
         memset(out, 0, sizeof(*out));
@@ -1505,7 +1573,7 @@ struct xhost_parser {
             if (!st.alf_finalise()) return fail("slice refers to an ALF parameter set that was not sent");
             out->alf.enable[0] = 1; out->alf.enable[1] = sh.alf_chroma_idc & 1; out->alf.enable[2] = (sh.alf_chroma_idc >> 1) & 1;
             out->alf.luma_coef = &st.alf_luma_final[0][0]; out->alf.chroma_coef = st.alf_chroma_final;
-            out->alf.ctb_flag = st.alf_ctb_flag.data(); out->alf.across_tiles = 0;
+            out->alf.ctb_flag = st.alf_ctb_flag.data(); out->alf.across_tiles = st.pps.across_tiles; out->alf.tiles = n_tiles > 1 ? &st.grid : nullptr;
         }
         std::vector<int> released;
         st.store_picture(nut == NUT_IDR, released);
@@ -1521,6 +1589,7 @@ struct xhost_parser {
         b.coef = batch.coef.data(); b.n_coef = batch.x.empty() ? 0 : n_coef;
         b.n_ctu = w_ctu * h_ctu; b.ctu_cu_start = batch.ctu_start.data();
         b.constrained_intra_pred = st.pps.constrained_intra;
+        b.tiles = n_tiles > 1 ? &st.grid : nullptr;
         b.htdf_slice_qp = st.sps.tool_htdf ? sh.qp : 0;
         // sps->tool_dmvr: the merge-mode flags, and how many 16x16 sub-blocks of candidates (flag, two references, at least 8x8 - the order of
         // xgpu_batch_dmvr_mvs) the backend will report vectors for; they go back in through xhost_parser_set_dmvr_mvs before the next picture
@@ -1743,7 +1812,18 @@ struct xhost_writer {
     {
         BitWriter bw;
         bw.ue(0); bw.ue(0); bw.ue(0); bw.ue(0); bw.ue(0);
-        bw.put1(0); bw.put1(1); bw.ue(0); bw.put1(0);    // rpl1_idx_present, single_tile_in_pic, tile_id_len_minus1, explicit_tile_id
+        bw.put1(0);                                      // rpl1_idx_present_flag
+        const Pps &q = st.pps;
+        bw.put1(q.tile_cols * q.tile_rows == 1);         // single_tile_in_pic_flag
+        if (q.tile_cols * q.tile_rows > 1) {
+            bw.ue((uint32_t)q.tile_cols - 1); bw.ue((uint32_t)q.tile_rows - 1); bw.put1(q.tile_uniform);
+            if (!q.tile_uniform) {
+                for (int i = 0; i + 1 < q.tile_cols; i++) bw.ue((uint32_t)q.tile_col_w[i] - 1);
+                for (int i = 0; i + 1 < q.tile_rows; i++) bw.ue((uint32_t)q.tile_row_h[i] - 1);
+            }
+            bw.put1(q.across_tiles); bw.ue((uint32_t)q.offset_bits - 1);
+        }
+        bw.ue((uint32_t)q.id_bits - 1); bw.put1(0);      // tile_id_len_minus1, explicit_tile_id_flag
         bw.put1(sp.tool_dra ? 1 : 0);                    // pic_dra_enabled_flag
         if (sp.tool_dra) bw.put((uint32_t)sp.dra_aps_id, 5);
         bw.put1(0);                                      // arbitrary_slice_present
@@ -1778,6 +1858,19 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     w->sp.tool_dmvr = s.tool_admvp && sp->tool_dmvr && !s.tool_hmvp && !s.tool_mmvd; s.tool_dmvr = w->sp.tool_dmvr;      // not with tool_hmvp (see the parser)
     w->sp.ibc_log_max_size = (s.tool_eipd && sp->ibc_log_max_size >= 2 && sp->ibc_log_max_size <= 7) ? sp->ibc_log_max_size : 0;
     s.ibc = w->sp.ibc_log_max_size != 0; s.ibc_log_max = w->sp.ibc_log_max_size;
+    {
+        Pps &q = w->st.pps;
+        const int w_ctu = (sp->width + 63) >> 6, h_ctu = (sp->height + 63) >> 6;
+        q.tile_cols = std::max(sp->tile_cols, 1); q.tile_rows = std::max(sp->tile_rows, 1);
+        if (!s.profile_main || q.tile_cols > std::min(w_ctu, XGPU_MAX_TILE_COLS) || q.tile_rows > std::min(h_ctu, XGPU_MAX_TILE_ROWS)) q.tile_cols = q.tile_rows = 1;
+        q.tile_uniform = sp->tile_col_w[0] == 0;
+        for (int i = 0; i < XGPU_MAX_TILE_COLS; i++) q.tile_col_w[i] = sp->tile_col_w[i];
+        for (int i = 0; i < XGPU_MAX_TILE_ROWS; i++) q.tile_row_h[i] = sp->tile_row_h[i];
+        const int n = q.tile_cols * q.tile_rows;
+        q.across_tiles = n > 1 && sp->loop_filter_across_tiles; q.offset_bits = 24; q.id_bits = 1;
+        while ((1 << q.id_bits) < n) q.id_bits++;
+        w->sp.tile_cols = q.tile_cols; w->sp.tile_rows = q.tile_rows;
+    }
     w->st.pps.cu_qp_delta = sp->cu_qp_delta;
     return w;
 }
@@ -1957,6 +2050,8 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
 
     BitWriter bw;
     bw.ue(0);                                            // slice_pic_parameter_set_id
+    const int n_tiles = st.pps.tile_cols * st.pps.tile_rows;
+    if (n_tiles > 1) { bw.put1(0); bw.put(0, st.pps.id_bits); bw.put((uint32_t)n_tiles - 1, st.pps.id_bits); }      // one slice with every tile: first / last_tile_id
     bw.ue((uint32_t)slice_type);
     if (idr) bw.put1(0);                                 // no_output_of_prior_pics_flag
     st.sh.mmvd_group = (st.sps.tool_mmvd && slice_type != XHOST_SLICE_I) ? (w->n_pics & 1) : 0;      // every other picture with the candidate groups
@@ -1983,16 +2078,11 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
     if (st.sh.deblock && st.sps.tool_addb) { bw.se(st.sh.alpha_off); bw.se(st.sh.beta_off); }
     bw.put((uint32_t)slice_qp, 6);
     bw.se(st.sh.qp_u_offset); bw.se(st.sh.qp_v_offset);
-    bw.align_zero();
 
     st.pic.reset(st.sps.width, st.sps.height);
-    st.models.reset();
-    st.qp_prev = slice_qp;
-    Enc enc;
-    enc.bw = &bw;
-    enc.start();
+    if (!st.setup_tiles()) return XGPU_ERR_INVALID_ARGUMENT;
     TreeWriter tw;
-    tw.w = w; tw.b = b; tw.enc = &enc; tw.bd_off = 6 * (st.sps.bd_l - 8);
+    tw.w = w; tw.b = b; tw.bd_off = 6 * (st.sps.bd_l - 8);
     tw.leaf.assign((size_t)st.pic.w_scu * st.pic.h_scu, -1);
     for (int i = 0; i < b->n_cu; i++) {
         if (b->log2w[i] != b->log2h[i] || b->log2w[i] < 2 || b->log2w[i] > 6 || b->x[i] + (1 << b->log2w[i]) > st.sps.width ||
@@ -2000,17 +2090,36 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
             return XGPU_ERR_INVALID_ARGUMENT;
         tw.leaf[(size_t)(b->y[i] >> 2) * st.pic.w_scu + (b->x[i] >> 2)] = i;
     }
-    for (int cy = 0; cy < h_ctu; cy++) for (int cx = 0; cx < w_ctu; cx++) {
-        if (cx == 0) st.history_reset();
-        if (st.sh.alf_on && st.sh.alf_ctb_map) {
-            const int f = w->next_alf_ctb.empty() ? 1 : (w->next_alf_ctb[(size_t)cy * w_ctu + cx] != 0);
-            enc.bin(f, st.models.alf_ctb[0]);
-            st.alf_ctb_flag[(size_t)cy * w_ctu + cx] = (uint8_t)f;
+    // every tile is its own arithmetic-coder run (contexts, QP predictor, motion history); the header carries the byte sizes of all but the last
+    std::vector<BitWriter> tile_bits((size_t)n_tiles);
+    for (int t = 0; t < n_tiles; t++) {
+        const int tc = t % st.grid.n_cols, tr = t / st.grid.n_cols;
+        st.models.reset();
+        st.qp_prev = slice_qp;
+        Enc enc;
+        enc.bw = &tile_bits[(size_t)t];
+        enc.start();
+        tw.enc = &enc;
+        for (int cy = st.grid.row_bd[tr]; cy < st.grid.row_bd[tr + 1]; cy++) for (int cx = st.grid.col_bd[tc]; cx < st.grid.col_bd[tc + 1]; cx++) {
+            if (cx == st.grid.col_bd[tc]) st.history_reset();
+            if (st.sh.alf_on && st.sh.alf_ctb_map) {
+                const int f = w->next_alf_ctb.empty() ? 1 : (w->next_alf_ctb[(size_t)cy * w_ctu + cx] != 0);
+                enc.bin(f, st.models.alf_ctb[0]);
+                st.alf_ctb_flag[(size_t)cy * w_ctu + cx] = (uint8_t)f;
+            }
+            tw.node(cx << 6, cy << 6, 6);
         }
-        tw.node(cx << 6, cy << 6, 6);
+        if (tw.error) return XGPU_ERR_INVALID_ARGUMENT;
+        enc.tile_end();
+        // the reference steps to a tile in 4-byte words from the word its reader stands in (xevdm.c:2665-2678): an entry offset shorter than that breaks it
+        while (t + 1 < n_tiles && tile_bits[(size_t)t].buf.size() < 8) tile_bits[(size_t)t].buf.push_back(0);
     }
-    if (tw.error) return XGPU_ERR_INVALID_ARGUMENT;
-    enc.tile_end();
+    for (int t = 0; t + 1 < n_tiles; t++) {
+        if (st.pps.offset_bits < 32 && (tile_bits[(size_t)t].buf.size() - 1) >> st.pps.offset_bits) return XGPU_ERR_UNSUPPORTED;
+        bw.put((uint32_t)tile_bits[(size_t)t].buf.size() - 1, st.pps.offset_bits);      // entry_point_offset_minus1
+    }
+    bw.align_zero();
+    for (int t = 0; t < n_tiles; t++) bw.buf.insert(bw.buf.end(), tile_bits[(size_t)t].buf.begin(), tile_bits[(size_t)t].buf.end());
     write_nal(w->out, idr ? NUT_IDR : NUT_NONIDR, temporal_id, bw);
     w->last_tid = temporal_id;
     std::vector<int> released;

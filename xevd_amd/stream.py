@@ -19,7 +19,9 @@ class StreamParams(C.Structure):
                 ("profile_main", C.c_int), ("tool_iqt", C.c_int), ("tool_ats", C.c_int), ("tool_addb", C.c_int),
                 ("deblock_alpha_offset", C.c_int), ("deblock_beta_offset", C.c_int), ("tool_alf", C.c_int), ("tool_eipd", C.c_int),
                 ("crop", C.c_int * 4), ("tool_dra", C.c_int), ("dra_aps_id", C.c_int), ("cqt_present", C.c_int), ("cqt_same", C.c_int), ("cqt_global_offset", C.c_int),
-                ("cqt_num_points", C.c_int * 2), ("cqt_delta_in", (C.c_int * 16) * 2), ("cqt_delta_out", (C.c_int * 16) * 2), ("tool_htdf", C.c_int), ("tool_admvp", C.c_int), ("tool_mmvd", C.c_int), ("tool_dmvr", C.c_int), ("tool_amvr", C.c_int), ("tool_hmvp", C.c_int), ("ibc_log_max_size", C.c_int)]
+                ("cqt_num_points", C.c_int * 2), ("cqt_delta_in", (C.c_int * 16) * 2), ("cqt_delta_out", (C.c_int * 16) * 2), ("tool_htdf", C.c_int), ("tool_admvp", C.c_int), ("tool_mmvd", C.c_int), ("tool_dmvr", C.c_int), ("tool_amvr", C.c_int), ("tool_hmvp", C.c_int), ("ibc_log_max_size", C.c_int),
+                ("tile_cols", C.c_int), ("tile_rows", C.c_int), ("tile_col_w", C.c_int * abi.XGPU_MAX_TILE_COLS), ("tile_row_h", C.c_int * abi.XGPU_MAX_TILE_ROWS),
+                ("loop_filter_across_tiles", C.c_int)]
 
 
 class AlfAps(C.Structure):
@@ -85,7 +87,8 @@ def load():
 class StreamWriter:
     def __init__(self, width, height, bit_depth=8, max_num_ref_pics=1, qp_u_offset=0, qp_v_offset=0, deblock=True, cu_qp_delta=True,
                  log2_sub_gop=0, main=False, iqt=False, ats=False, addb=False, alpha_off=0, beta_off=0, alf=False, eipd=False, crop=(0, 0, 0, 0),
-                 chroma_qp_points=None, dra_aps_id=None, htdf=False, ibc_log_max=0, admvp=False, amvr=False, hmvp=False, dmvr=False, mmvd=False):
+                 chroma_qp_points=None, dra_aps_id=None, htdf=False, ibc_log_max=0, admvp=False, amvr=False, hmvp=False, dmvr=False, mmvd=False,
+                 tiles=None):
         """chroma_qp_points: None, or (global_offset_flag, [table, ...]) with 1 (same for Cb and Cr) or 2 tables of (delta_in_minus1, delta_out) pairs"""
         self.lib = load()
         sp = StreamParams(width, height, bit_depth, max_num_ref_pics, log2_sub_gop, qp_u_offset, qp_v_offset, int(deblock), int(cu_qp_delta),
@@ -94,6 +97,13 @@ class StreamWriter:
             sp.crop[i] = int(crop[i])
         sp.tool_htdf = int(htdf)
         sp.ibc_log_max_size = int(ibc_log_max)
+        if tiles is not None:      # (cols, rows, across) or (cols, rows, across, col widths, row heights) - sizes in CTUs of all but the last column / row
+            sp.tile_cols, sp.tile_rows, sp.loop_filter_across_tiles = int(tiles[0]), int(tiles[1]), int(tiles[2])
+            if len(tiles) > 3:
+                for i, v in enumerate(tiles[3]):
+                    sp.tile_col_w[i] = int(v)
+                for i, v in enumerate(tiles[4]):
+                    sp.tile_row_h[i] = int(v)
         sp.tool_admvp = int(admvp)
         sp.tool_amvr, sp.tool_hmvp, sp.tool_dmvr, sp.tool_mmvd = int(amvr), int(hmvp), int(dmvr), int(mmvd)
         if dra_aps_id is not None:
@@ -224,6 +234,7 @@ def iter_stream(data, consume_batch=None):
                 "coef_off": _arr(b.coef_off, n, np.uint32), "coef": _arr(b.coef, max(b.n_coef, 1), np.int16), "n_coef": int(b.n_coef),
                 "ctu_cu_start": _arr(b.ctu_cu_start, b.n_ctu + 1, np.uint32), "constrained_intra_pred": int(b.constrained_intra_pred), "htdf_slice_qp": int(b.htdf_slice_qp),
                 "dmvr": _arr(b.dmvr, n, np.uint8) if b.dmvr else None,
+                "tiles": abi.tile_grid_dict(b.tiles.contents) if b.tiles else None,
             }
             params = {
                 "width": hp.width, "height": hp.height, "bit_depth": hp.bit_depth_luma, "bit_depth_chroma": hp.bit_depth_chroma, "poc": hp.poc, "temporal_id": hp.temporal_id, "slice_type": hp.slice_type,
@@ -236,7 +247,8 @@ def iter_stream(data, consume_batch=None):
                 "chroma_qp_tables": None if not hp.chroma_qp_table[0] else [np.ctypeslib.as_array(hp.chroma_qp_table[c], (58 + 6 * (hp.bit_depth_chroma - 8),)).copy() for c in range(2)],
                 "alf": None if not hp.alf_on else {
                     "enable": tuple(hp.alf.enable[i] for i in range(3)), "luma_coef": _arr(hp.alf.luma_coef, 25 * 13, np.int16).reshape(25, 13),
-                    "chroma_coef": _arr(hp.alf.chroma_coef, 7, np.int16), "ctb_flag": _arr(hp.alf.ctb_flag, b.n_ctu, np.uint8), "across_tiles": 0},
+                    "chroma_coef": _arr(hp.alf.chroma_coef, 7, np.int16), "ctb_flag": _arr(hp.alf.ctb_flag, b.n_ctu, np.uint8), "across_tiles": int(hp.alf.across_tiles),
+                    "tiles": abi.tile_grid_dict(hp.alf.tiles.contents) if hp.alf.tiles else None},
                 "md5": [bytes(hp.md5[c]) for c in range(3)] if hp.has_md5 else None,
                 "release": [hp.release_poc[i] for i in range(hp.n_release)], "batch": batch,
                 # sps->tool_dmvr: the number of sub-blocks whose vectors (xgpu_batch_dmvr_mvs / the oracle's dmvr_mv_out) must be handed to
