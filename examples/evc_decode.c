@@ -13,7 +13,8 @@
  * --workers W puts W worker threads (each with its own parser, context and DPB) on every device: one stream's entropy decoding is a serial
  * chain on one host core (an 8K picture takes tens of milliseconds to parse, its kernels half a millisecond), so a GPU is fed by parsing
  * several GOPs at once.
- * usage: evc_decode [--gpus N] [--workers W] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
+ * --tile-threads T lets every worker's parser use T threads for the tiles of one picture (xhost_parser_set_threads).
+ * usage: evc_decode [--gpus N] [--workers W] [--tile-threads T] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
  *        evc_decode in.evc out.yuv D                                               (the round-1 form)
  * build: oracle-free; see examples/Makefile.
  */
@@ -78,11 +79,13 @@ static int worker_context(worker_t *w, const xhost_picture *p)
     return 0;
 }
 
+static int g_tile_threads = 1;
 /* Decode `bytes` (parameter sets + one or more GOPs) on the worker's device -> packed pictures in output order (malloc'ed) */
 static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_bd_arg, int expected, uint8_t **frames_out, out_t **outs_out, int *n_out, size_t *frame_bytes_out, int *pinned_out)
 {
     xhost_parser *ps = xhost_parser_open(bytes, size);
     slot_t dpb[MAX_SLOTS];
+    if (ps && g_tile_threads > 1) xhost_parser_set_threads(ps, g_tile_threads);      /* the tiles of a picture on parallel host threads */
     int free_pic[MAX_SLOTS], n_free = 0, n_pics = 0, epoch = -1, rc, have_ctx = 0, ticket = -1, pinned = 0;
     out_t *outs = (out_t *)malloc(sizeof(out_t) * (size_t)(expected > 0 ? expected : 1));
     uint8_t *frames = NULL;                                         /* decoded pictures in decoding order, packed: pinned memory, so that the */
@@ -234,12 +237,13 @@ int main(int argc, char **argv)
         if (!strcmp(argv[a], "--gpus") && a + 1 < argc) { gpus = atoi(argv[a + 1]); a += 2; }
         else if (!strcmp(argv[a], "--workers") && a + 1 < argc) { workers = atoi(argv[a + 1]); a += 2; }
         else if (!strcmp(argv[a], "--bd") && a + 1 < argc) { out_bd = atoi(argv[a + 1]); a += 2; }
+        else if (!strcmp(argv[a], "--tile-threads") && a + 1 < argc) { g_tile_threads = atoi(argv[a + 1]); a += 2; }
         else break;
     }
     int n_pos = argc - a;
     if (n_pos == 3 && strspn(argv[a + 2], "0123456789") == strlen(argv[a + 2])) { out_bd = atoi(argv[a + 2]); n_pos = 2; }      /* in out D */
     if (n_pos < 2 || (n_pos & 1) || gpus < 1 || workers < 1 || gpus * workers > 64 || n_pos / 2 > MAX_STREAMS) {
-        fprintf(stderr, "usage: %s [--gpus N] [--workers W] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]\n", argv[0]);
+        fprintf(stderr, "usage: %s [--gpus N] [--workers W] [--tile-threads T] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]\n", argv[0]);
         return 2;
     }
     static stream_t streams[MAX_STREAMS];

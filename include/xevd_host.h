@@ -86,6 +86,10 @@ int  xhost_parser_set_dmvr_mvs(xhost_parser *p, const int16_t *mv, int n_sub);
 xhost_parser *xhost_parser_open_nal(void);
 int  xhost_parser_nal(xhost_parser *p, const uint8_t *nal, size_t size, xhost_picture *out);
 const char *xhost_parser_error(const xhost_parser *p);
+/* Host threads the parser may use for ONE picture (default 1): the tiles of a picture are independent arithmetic-coder runs and are parsed
+   in parallel, tile by tile off a shared counter - what xevdm_dec_slice does with the reference's thread pool (src_main/xevdm.c:2640-2690).
+   Pictures with one tile are not affected.  The batch handed out is the same for every thread count. */
+int  xhost_parser_set_threads(xhost_parser *p, int n_threads);
 void xhost_parser_close(xhost_parser *p);
 
 typedef struct xhost_stream_params {

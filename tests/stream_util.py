@@ -165,7 +165,7 @@ def decode_oracle(data, order="output"):
     return _output_order(out)
 
 
-def decode_gpu(data, verify_md5=False):
+def decode_gpu(data, verify_md5=False, parser_threads=1):
     """Our parser + the HIP backend through the two C ABIs (xevd_amd/player.py). -> pictures in output order."""
     from xevd_amd.player import StreamDecoder
-    return [planes for _, planes in StreamDecoder(data, verify_md5=verify_md5).output_order()]
+    return [planes for _, planes in StreamDecoder(data, verify_md5=verify_md5, parser_threads=parser_threads).output_order()]

@@ -239,6 +239,17 @@ def test_gpu_golden_streams(path):
             assert np.array_equal(ours[k][c], d[f"p{k}_{c}"]), f"picture {k} plane {c}"
 
 
+def test_gpu_tiles_parsed_on_threads():
+    """a tiled golden stream with the tiles of every picture parsed by four host threads: still the reference decoder's pictures"""
+    import stream_util as su
+    d = np.load(os.path.join(golden_io.GOLDEN, "stream_main_tiles_3x2_all_tools_10b.npz"))
+    ours = su.decode_gpu(d["bytes"].tobytes(), parser_threads=4)
+    assert len(ours) == int(d["n"])
+    for k in range(len(ours)):
+        for c in range(3):
+            assert np.array_equal(ours[k][c], d[f"p{k}_{c}"]), f"picture {k} plane {c}"
+
+
 def test_gpu_stream_1080p_vs_oracle():
     """BASELINE.json configs[1] shape as a real stream: 1080p Baseline IPPP written, parsed, decoded on the GPU and by the oracle"""
     import stream_util as su

@@ -135,6 +135,21 @@ def test_stream_reference_decoder_threads_agree():
     assert all(np.array_equal(a[k][c], b[k][c]) for k in range(4) for c in range(3))
 
 
+def test_tiles_parse_the_same_on_any_number_of_threads():
+    """xhost_parser_set_threads: the tiles of a picture are parsed by parallel host threads; the batch (CU order tile by tile, coefficient offsets,
+    CTU starts, the grid) does not depend on the thread count"""
+    data = su.make_stream(392, 264, 5, seed=6, main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, admvp=True, amvr=True, hmvp=True, mmvd=True, log2_sub_gop=2, max_refs=2,
+                          tiles=(3, 3, 1))
+    one, many = stream.parse_stream(data), stream.parse_stream(data, threads=5)
+    assert len(one) == len(many) == 5 and one[0]["batch"]["tiles"]["col_bd"] == [0, 2, 4, 7]
+    for p, q in zip(one, many):
+        assert p["poc"] == q["poc"]
+        for k, v in p["batch"].items():
+            assert np.array_equal(v, q["batch"][k]) if isinstance(v, np.ndarray) else v == q["batch"][k], k
+        # tile by tile: the CTU starts rise through the whole batch and every CU lies in the tile its CTU belongs to
+        assert (np.diff(p["batch"]["ctu_cu_start"].astype(np.int64)) >= 0).all()
+
+
 def test_writer_is_deterministic_and_parser_round_trips():
     data = su.make_stream(136, 72, 3, seed=11)
     assert data == su.make_stream(136, 72, 3, seed=11)

@@ -34,27 +34,33 @@ def main():
     ap.add_argument("--sizes", default="1080p,4k,8k")
     ap.add_argument("--workers", default="1,4,8")
     ap.add_argument("--bit-depth", type=int, default=10)
+    ap.add_argument("--tiles", default="", help="CxR: tile grid of every picture (tiles parse on parallel host threads, see --tile-threads)")
+    ap.add_argument("--tile-threads", default="1", help="comma list: parser threads per picture; every --workers value is run with each")
     args = ap.parse_args()
     import stream_util as su
     exe = os.path.join(ROOT, "examples", "evc_decode")
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_decode_main")
     out = {"host_cores": os.cpu_count(), "what": "examples/evc_decode (C, .evc -> .yuv; decode_only = parsing + kernels + output of the slowest worker, the span the reference application times; process_wall adds process and device start-up) vs the reference "
            "decoder's public API on the same bytes; Main profile (IQT, ADDB, ALF), P pictures, closed GOPs", "sizes": {}}
+    tiles = tuple(int(v) for v in args.tiles.split("x")) + (0,) if args.tiles else None
+    if tiles:
+        out["tiles"] = args.tiles
     with tempfile.TemporaryDirectory() as td:
         for name in args.sizes.split(","):
             w, h, n, gop = SIZES[name]
             t0 = time.perf_counter()
             data = su.make_stream(w, h, n, bit_depth=args.bit_depth, seed=5, max_refs=1, inter_frac=0.9, skip_frac=0.15, idr_period=gop,
-                                  main=True, iqt=True, addb=True, alf=True)
+                                  main=True, iqt=True, addb=True, alf=True, tiles=tiles)
             src = os.path.join(td, f"{name}.evc")
             open(src, "wb").write(data)
             r = {"stream": f"{w}x{h} {args.bit_depth}-bit, {n} pictures in GOPs of {gop}, {len(data)} bytes ({8 * len(data) / n / 1e6:.2f} Mbit/picture)",
                  "writer_s": round(time.perf_counter() - t0, 1), "evc_decode_fps": {}, "reference_fps": {}}
             sums = set()
-            for wk in [int(v) for v in args.workers.split(",")]:
+            for wk, tt in [(int(v), int(u)) for v in args.workers.split(",") for u in args.tile_threads.split(",")]:
                 dst = os.path.join(td, f"{name}_{wk}.yuv")
                 t0 = time.perf_counter()
-                p = subprocess.run([exe, "--workers", str(wk), src, dst], stderr=subprocess.PIPE, timeout=1200)
+                p = subprocess.run([exe, "--workers", str(wk), "--tile-threads", str(tt), src, dst], stderr=subprocess.PIPE, timeout=1200)
+                wk = f"{wk}x{tt}" if tiles else wk
                 dt = time.perf_counter() - t0
                 if p.returncode != 0:
                     r["evc_decode_fps"][str(wk)] = "error: " + p.stderr.decode()[-200:]

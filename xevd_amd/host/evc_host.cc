@@ -11,6 +11,9 @@
 #include "alf_fixed_tables.h"
 
 #include <algorithm>
+#include <atomic>
+#include <memory>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -403,10 +406,9 @@ struct Stream {          // everything both directions share
     Pps pps;
     Slice sh;
     Picture pic;
-    Models models;
     std::vector<RefPic> dpb;         // reference pictures in coding order (pm->pic[] restricted to IS_REF)
     std::vector<const RefPic *> refp[2];
-    int poc = 0, prev_poc = 0, prev_doc_offset = -1, tid = 0, last_intra_poc = 0, qp_prev = 0, stale_list0_poc = 0;
+    int poc = 0, prev_poc = 0, prev_doc_offset = -1, tid = 0, last_intra_poc = 0, stale_list0_poc = 0;
     int stale_list_poc[16] = { 0 };      // list_poc[] entries past a picture's own list keep what earlier pictures wrote
     bool have_sps = false, have_pps = false, need_idr = false;
     std::vector<uint16_t> scan[6][6];      // zig-zag tables by log2 size - 1
@@ -613,6 +615,24 @@ struct Stream {          // everything both directions share
         if (sps.tool_admvp) { r.mv = pic.mv; r.refi = pic.refi; memcpy(r.list_poc, stale_list_poc, sizeof(r.list_poc)); }
         dpb.push_back(std::move(r));
     }
+
+};
+
+// The part of the front end that works inside ONE tile: CU syntax in both directions, motion derivation, the SCU maps of the tile's CUs.
+// Everything a tile changes while it is coded lives here (context models, QP predictor, motion history) or in the tile's own region of the
+// picture maps, so the tiles of a picture can be parsed by different threads (xevdm_dec_slice hands tiles to its thread pool the same way,
+// src_main/xevdm.c:2640-2690).  The references name the state of the Stream the coder belongs to.
+struct TileCoder {
+    const Sps &sps;
+    const Pps &pps;
+    const Slice &sh;
+    Picture &pic;
+    const std::vector<const RefPic *> (&refp)[2];
+    const int &poc;
+    const std::vector<uint16_t> (&scan)[6][6];
+    Models models;
+    int qp_prev = 0;
+    explicit TileCoder(Stream &s) : sps(s.sps), pps(s.pps), sh(s.sh), pic(s.pic), refp(s.refp), poc(s.poc), scan(s.scan) { history_reset(); }
 
     // motion vector predictor candidates of one list (xevd_get_motion, xevd_util.c:469-515; availability xevd_get_avail_inter :632-687):
     // left, up, up-right neighbour SCU (1,1 when not available) and the co-located list-0 motion of reference 0 of that list
@@ -1307,14 +1327,113 @@ static void write_nal(std::vector<uint8_t> &out, int nut, int tid, const BitWrit
 }   // namespace
 
 // =============================================================================================================== parser
+// One tile of a picture being parsed: its coder state, its share of the batch, its scratch blocks.  Objects are kept between pictures (the vectors keep
+// their capacity); with several tiles and xhost_parser_set_threads() > 1 they run on different threads.
+struct TileParser {
+    Stream &st;
+    TileCoder tc;
+    Batch batch;
+    std::vector<int16_t> blk[3];
+    std::string err;
+    size_t n_coef = 0;
+    explicit TileParser(Stream &s) : st(s), tc(s) { for (int k = 0; k < 3; k++) blk[k].assign(64 * 64, 0); }
+    int fail(const char *m) { err = m; return XHOST_ERR_MALFORMED; }
+    // xevd_tile_eco (src_main/xevdm.c:2363-2461) for tile (tc_, tr) of the grid, from bit position `pos` of the slice NAL
+    int parse_tile(const BitReader &br0, size_t pos, int tcol, int trow)
+    {
+        BitReader br = br0;
+        br.pos = pos;
+        if (br.pos > br.size * 8) return fail("tile entry point past the end of the slice");
+        const Slice &sh = st.sh;
+        const int w_ctu = (st.sps.width + 63) >> 6;
+        batch.clear();
+        n_coef = 0;
+        tc.models.reset();
+        tc.qp_prev = sh.qp;
+        Dec dec;
+        dec.br = &br;
+        dec.start();
+        for (int cy = st.grid.row_bd[trow]; cy < st.grid.row_bd[trow + 1]; cy++) for (int cx = st.grid.col_bd[tcol]; cx < st.grid.col_bd[tcol + 1]; cx++) {
+            if (cx == st.grid.col_bd[tcol]) tc.history_reset();
+            batch.ctu_start.push_back((uint32_t)batch.x.size());
+            if (sh.alf_on && sh.alf_ctb_map) st.alf_ctb_flag[(size_t)cy * w_ctu + cx] = (uint8_t)dec.bin(0, tc.models.alf_ctb[0]);      // xevdm.c:2411-2418
+            const int rc = parse_tree(dec, cx << 6, cy << 6, 6);
+            if (rc != XGPU_OK) return rc;
+            if (br.overrun) return fail("slice data ends early");
+        }
+        if (dec.tile_end() != 1) return fail("missing end-of-tile flag");
+        return XGPU_OK;
+    }
+    int parse_tree(Dec &dec, int x, int y, int log2s)
+    {
+        const int s = 1 << log2s;
+        int split = 0;
+        if (s > 4 && !(s < 8)) split = dec.bin(0, tc.models.split[0]);
+        if (split) {
+            const int h = s >> 1;
+            for (int i = 0; i < 4; i++) {
+                const int nx = x + (i & 1) * h, ny = y + (i >> 1) * h;
+                if (nx < st.sps.width && ny < st.sps.height) { const int rc = parse_tree(dec, nx, ny, log2s - 1); if (rc != XGPU_OK) return rc; }
+            }
+            return XGPU_OK;
+        }
+        if (x + s > st.sps.width || y + s > st.sps.height) return fail("a CU crosses the picture border");
+        Cu cu;
+        memset(&cu, 0, sizeof(cu));
+        cu.x = x; cu.y = y; cu.log2w = cu.log2h = log2s;
+        int16_t *coef[3] = { blk[0].data(), blk[1].data(), blk[2].data() };
+        memset(coef[0], 0, sizeof(int16_t) << (2 * log2s));
+        memset(coef[1], 0, sizeof(int16_t) << (2 * log2s - 2));
+        memset(coef[2], 0, sizeof(int16_t) << (2 * log2s - 2));
+        tc.code_cu(dec, cu, coef, false);
+        tc.commit(cu);
+        // append to the batch
+        if (batch.x.empty()) n_coef = 0;
+        batch.x.push_back((uint16_t)x); batch.y.push_back((uint16_t)y); batch.log2w.push_back((uint8_t)log2s); batch.log2h.push_back((uint8_t)log2s);
+        batch.pred_mode.push_back((uint8_t)cu.mode);
+        batch.refi.push_back((int8_t)cu.refi[0]); batch.refi.push_back((int8_t)cu.refi[1]);
+        for (int l = 0; l < 2; l++) { batch.mv.push_back(cu.mv[l][0]); batch.mv.push_back(cu.mv[l][1]); }
+        int qp_u, qp_v;
+        tc.chroma_qps(cu.qp, qp_u, qp_v);
+        batch.qp.push_back((uint8_t)(cu.qp + 6 * (st.sps.bd_l - 8))); batch.qp.push_back((uint8_t)qp_u); batch.qp.push_back((uint8_t)qp_v);
+        batch.cbf.push_back((uint8_t)(cu.cbf[0] | (cu.cbf[1] << 1) | (cu.cbf[2] << 2)));
+        batch.ipm.push_back((uint8_t)cu.ipm); batch.ipm.push_back((uint8_t)(st.sps.tool_eipd ? cu.ipm_c : cu.ipm));      // Baseline: chroma mode = luma mode, xevd_eco.c:1154
+        batch.ats.push_back((uint8_t)cu.ats); batch.ats_inter.push_back((uint8_t)cu.ats_inter); batch.dmvr.push_back((uint8_t)cu.dmvr);
+        batch.coef_off.push_back((uint32_t)n_coef);
+        const int tu_shift = (cu.ats_inter & 15) == 0 ? 0 : (((cu.ats_inter & 15) >= 3) ? 2 : 1);      // the TU is 1/2 or 1/4 of the CU
+        for (int k = 0; k < 3; k++)
+            if (cu.cbf[k]) {
+                const size_t n = (size_t)1 << (2 * log2s - (k ? 2 : 0) - tu_shift);
+                batch.coef.insert(batch.coef.end(), coef[k], coef[k] + n);
+                n_coef += n;
+            }
+        return XGPU_OK;
+    }
+};
+
 struct xhost_parser {
     std::vector<uint8_t> data;
     size_t pos = 0;
     Stream st;
-    Batch batch;
+    std::vector<std::unique_ptr<TileParser>> tiles;      // one per tile of the current picture (kept between pictures)
+    Batch merged;                                        // several tiles: their batches, tile by tile
+    Batch *cur = &merged;                                // the batch of the picture handed out last
+    size_t n_coef = 0;
+    int n_threads = 1;                                   // xhost_parser_set_threads
     std::string err;
-    std::vector<int16_t> blk[3];
     int fail(const char *m) { err = m; return XHOST_ERR_MALFORMED; }
+    // runs fn(0 .. n-1) on up to n_threads threads (the calling one included)
+    template <class F> void parallel_for(int n, F fn)
+    {
+        const int nt = std::min(n_threads, n);
+        if (nt <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
+        std::atomic<int> next(0);
+        auto work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back(work);
+        work();
+        for (std::thread &t : th) t.join();
+    }
 
     // A picture-signature SEI directly after the slice NAL belongs to that picture (xevd_dec_nalu checks it against ctx->pic,
     // src_base/xevd.c:2010-2026).  Payload (xevd_eco_sei, xevd_eco.c:1617-1678): type 0x10, size 16, then 16 bytes PER PLANE.
@@ -1512,32 +1631,44 @@ struct xhost_parser {
         if (!st.setup_tiles()) return fail("the tile grid of the PPS does not fit the picture");
 
         // ---- tile data (xevdm_dec_slice + xevd_tile_eco, src_main/xevdm.c:2363-2461, 2614-2718): every tile is its own arithmetic-coder
-        //      run - contexts, QP predictor and motion history start afresh - at the byte offset the slice header gave ----
-        batch.clear();
+        //      run - contexts, QP predictor and motion history start afresh - at the byte offset the slice header gave; tiles share nothing but
+        //      the picture maps (disjoint regions), so they are parsed in parallel when the caller allows threads ----
         const int W = st.sps.width, H = st.sps.height, w_ctu = (W + 63) >> 6, h_ctu = (H + 63) >> 6;
         st.alf_ctb_flag.assign((size_t)w_ctu * h_ctu, 1);
-        for (int k = 0; k < 3; k++) blk[k].assign(64 * 64, 0);
-        size_t tile_pos = br.pos;
-        for (int t = 0; t < n_tiles; t++) {
-            const int tc = t % st.grid.n_cols, tr = t / st.grid.n_cols;
-            br.pos = tile_pos;
-            if (br.pos > br.size * 8) return fail("tile entry point past the end of the slice");
-            st.models.reset();
-            st.qp_prev = sh.qp;
-            Dec dec;
-            dec.br = &br;
-            dec.start();
-            for (int cy = st.grid.row_bd[tr]; cy < st.grid.row_bd[tr + 1]; cy++) for (int cx = st.grid.col_bd[tc]; cx < st.grid.col_bd[tc + 1]; cx++) {
-                if (cx == st.grid.col_bd[tc]) st.history_reset();
-                batch.ctu_start.push_back((uint32_t)batch.x.size());
-                if (sh.alf_on && sh.alf_ctb_map) st.alf_ctb_flag[(size_t)cy * w_ctu + cx] = (uint8_t)dec.bin(0, st.models.alf_ctb[0]);      // xevdm.c:2411-2418
-                const int rc = parse_tree(dec, cx << 6, cy << 6, 6);
-                if (rc != XGPU_OK) return rc;
-                if (br.overrun) return fail("slice data ends early");
+        while ((int)tiles.size() < n_tiles) tiles.emplace_back(new TileParser(st));
+        std::vector<size_t> tile_pos((size_t)n_tiles, br.pos);
+        for (int t = 1; t < n_tiles; t++) tile_pos[(size_t)t] = tile_pos[(size_t)t - 1] + tile_size[(size_t)t - 1] * 8;
+        std::vector<int> tile_rc((size_t)n_tiles, XGPU_OK);
+        parallel_for(n_tiles, [&](int t) { tile_rc[(size_t)t] = tiles[(size_t)t]->parse_tile(br, tile_pos[(size_t)t], t % st.grid.n_cols, t / st.grid.n_cols); });
+        for (int t = 0; t < n_tiles; t++) if (tile_rc[(size_t)t] != XGPU_OK) { err = tiles[(size_t)t]->err; return tile_rc[(size_t)t]; }
+        if (n_tiles == 1) { cur = &tiles[0]->batch; n_coef = tiles[0]->n_coef; }
+        else {
+            // one batch for the backend: the tiles' arrays one after the other, coefficient offsets and CTU starts moved along
+            std::vector<size_t> cu0((size_t)n_tiles + 1, 0), cf0((size_t)n_tiles + 1, 0), ct0((size_t)n_tiles + 1, 0);
+            for (int t = 0; t < n_tiles; t++) {
+                cu0[(size_t)t + 1] = cu0[(size_t)t] + tiles[(size_t)t]->batch.x.size();
+                cf0[(size_t)t + 1] = cf0[(size_t)t] + tiles[(size_t)t]->n_coef;
+                ct0[(size_t)t + 1] = ct0[(size_t)t] + tiles[(size_t)t]->batch.ctu_start.size();
             }
-            if (dec.tile_end() != 1) return fail("missing end-of-tile flag");
-            tile_pos += tile_size[(size_t)t] * 8;
+            if (cf0[(size_t)n_tiles] > 0xFFFFFFFFull) return fail("coefficient arena beyond 32-bit offsets");
+            Batch &m = merged;
+            const size_t n = cu0[(size_t)n_tiles];
+            m.x.resize(n); m.y.resize(n); m.log2w.resize(n); m.log2h.resize(n); m.pred_mode.resize(n); m.qp.resize(n * 3); m.cbf.resize(n); m.ipm.resize(n * 2);
+            m.ats.resize(n); m.ats_inter.resize(n); m.dmvr.resize(n); m.refi.resize(n * 2); m.mv.resize(n * 4); m.coef_off.resize(n);
+            m.coef.resize(cf0[(size_t)n_tiles]); m.ctu_start.resize(ct0[(size_t)n_tiles]);
+            parallel_for(n_tiles, [&](int t) {
+                const Batch &b = tiles[(size_t)t]->batch;
+                const size_t o = cu0[(size_t)t], k = b.x.size();
+                auto put = [&](auto &dst, const auto &src, size_t per) { if (k) memcpy(dst.data() + o * per, src.data(), k * per * sizeof(src[0])); };
+                put(m.x, b.x, 1); put(m.y, b.y, 1); put(m.log2w, b.log2w, 1); put(m.log2h, b.log2h, 1); put(m.pred_mode, b.pred_mode, 1); put(m.qp, b.qp, 3);
+                put(m.cbf, b.cbf, 1); put(m.ipm, b.ipm, 2); put(m.ats, b.ats, 1); put(m.ats_inter, b.ats_inter, 1); put(m.dmvr, b.dmvr, 1); put(m.refi, b.refi, 2); put(m.mv, b.mv, 4);
+                for (size_t i = 0; i < k; i++) m.coef_off[o + i] = b.coef_off[i] + (uint32_t)cf0[(size_t)t];
+                if (tiles[(size_t)t]->n_coef) memcpy(m.coef.data() + cf0[(size_t)t], b.coef.data(), tiles[(size_t)t]->n_coef * sizeof(int16_t));
+                for (size_t i = 0; i < b.ctu_start.size(); i++) m.ctu_start[ct0[(size_t)t] + i] = b.ctu_start[i] + (uint32_t)o;
+            });
+            cur = &merged; n_coef = cf0[(size_t)n_tiles];
         }
+        Batch &batch = *cur;
         batch.ctu_start.push_back((uint32_t)batch.x.size());
 
         // ---- hand-over ----
@@ -1616,6 +1747,7 @@ struct xhost_parser {
         for (RefPic &q : st.dpb) if (q.poc == last_poc) r = &q;
         if (!r || r->mv.empty()) return 0;
         const int ws = st.sps.width >> 2;
+        const Batch &batch = *cur;
         for (size_t i = 0; i < batch.x.size(); i++) {
             if (!(batch.dmvr[i] && batch.refi[i * 2] >= 0 && batch.refi[i * 2 + 1] >= 0 && batch.log2w[i] >= 3 && batch.log2h[i] >= 3)) continue;
             const int w = 1 << batch.log2w[i], h = 1 << batch.log2h[i], dx = std::min(w, 16), dy = std::min(h, 16);
@@ -1624,55 +1756,6 @@ struct xhost_parser {
                     memcpy(&r->mv[((size_t)((batch.y[i] + sy) >> 2) + v) * ws * 4 + ((size_t)((batch.x[i] + sx) >> 2) + u) * 4], mv, sizeof(int16_t) * 4);
         }
         return 0;
-    }
-    size_t n_coef = 0;
-
-    // quad tree of one CTU (xevd_entropy_decode_tree, xevd.c:928-999; xevd_eco_split_mode, xevd_eco.c:985-999): a split flag for
-    // every node above 4x4 whose top-left corner is inside the picture, also when the node crosses the picture border
-    int parse_tree(Dec &dec, int x, int y, int log2s)
-    {
-        const int s = 1 << log2s;
-        int split = 0;
-        if (s > 4 && !(s < 8)) split = dec.bin(0, st.models.split[0]);
-        if (split) {
-            const int h = s >> 1;
-            for (int i = 0; i < 4; i++) {
-                const int nx = x + (i & 1) * h, ny = y + (i >> 1) * h;
-                if (nx < st.sps.width && ny < st.sps.height) { const int rc = parse_tree(dec, nx, ny, log2s - 1); if (rc != XGPU_OK) return rc; }
-            }
-            return XGPU_OK;
-        }
-        if (x + s > st.sps.width || y + s > st.sps.height) return fail("a CU crosses the picture border");
-        Cu cu;
-        memset(&cu, 0, sizeof(cu));
-        cu.x = x; cu.y = y; cu.log2w = cu.log2h = log2s;
-        int16_t *coef[3] = { blk[0].data(), blk[1].data(), blk[2].data() };
-        memset(coef[0], 0, sizeof(int16_t) << (2 * log2s));
-        memset(coef[1], 0, sizeof(int16_t) << (2 * log2s - 2));
-        memset(coef[2], 0, sizeof(int16_t) << (2 * log2s - 2));
-        st.code_cu(dec, cu, coef, false);
-        st.commit(cu);
-        // append to the batch
-        if (batch.x.empty()) n_coef = 0;
-        batch.x.push_back((uint16_t)x); batch.y.push_back((uint16_t)y); batch.log2w.push_back((uint8_t)log2s); batch.log2h.push_back((uint8_t)log2s);
-        batch.pred_mode.push_back((uint8_t)cu.mode);
-        batch.refi.push_back((int8_t)cu.refi[0]); batch.refi.push_back((int8_t)cu.refi[1]);
-        for (int l = 0; l < 2; l++) { batch.mv.push_back(cu.mv[l][0]); batch.mv.push_back(cu.mv[l][1]); }
-        int qp_u, qp_v;
-        st.chroma_qps(cu.qp, qp_u, qp_v);
-        batch.qp.push_back((uint8_t)(cu.qp + 6 * (st.sps.bd_l - 8))); batch.qp.push_back((uint8_t)qp_u); batch.qp.push_back((uint8_t)qp_v);
-        batch.cbf.push_back((uint8_t)(cu.cbf[0] | (cu.cbf[1] << 1) | (cu.cbf[2] << 2)));
-        batch.ipm.push_back((uint8_t)cu.ipm); batch.ipm.push_back((uint8_t)(st.sps.tool_eipd ? cu.ipm_c : cu.ipm));      // Baseline: chroma mode = luma mode, xevd_eco.c:1154
-        batch.ats.push_back((uint8_t)cu.ats); batch.ats_inter.push_back((uint8_t)cu.ats_inter); batch.dmvr.push_back((uint8_t)cu.dmvr);
-        batch.coef_off.push_back((uint32_t)n_coef);
-        const int tu_shift = (cu.ats_inter & 15) == 0 ? 0 : (((cu.ats_inter & 15) >= 3) ? 2 : 1);      // the TU is 1/2 or 1/4 of the CU
-        for (int k = 0; k < 3; k++)
-            if (cu.cbf[k]) {
-                const size_t n = (size_t)1 << (2 * log2s - (k ? 2 : 0) - tu_shift);
-                batch.coef.insert(batch.coef.end(), coef[k], coef[k] + n);
-                n_coef += n;
-            }
-        return XGPU_OK;
     }
 };
 
@@ -1683,6 +1766,7 @@ extern "C" xhost_parser *xhost_parser_open(const uint8_t *bytes, size_t size)
     p->data.assign(bytes, bytes + size);
     return p;
 }
+extern "C" int xhost_parser_set_threads(xhost_parser *p, int n) { if (!p || n < 1) return XGPU_ERR_INVALID_ARGUMENT; p->n_threads = std::min(n, 64); return XGPU_OK; }
 extern "C" int xhost_parser_set_dmvr_mvs(xhost_parser *p, const int16_t *mv, int n_sub) { return p ? p->set_dmvr_mvs(mv, n_sub) : XHOST_ERR_MALFORMED; }
 extern "C" const char *xhost_parser_error(const xhost_parser *p) { return p ? p->err.c_str() : "null parser"; }
 extern "C" void xhost_parser_close(xhost_parser *p) { delete p; }
@@ -1762,6 +1846,7 @@ extern "C" int xhost_parser_nal(xhost_parser *p, const uint8_t *nal, size_t size
 struct xhost_writer {
     xhost_stream_params sp;
     Stream st;
+    TileCoder coder{st};          // the tiles are written one after the other
     std::vector<uint8_t> out;
     int n_pics = 0, last_tid = 0;
     bool headers_done = false;
@@ -1963,10 +2048,11 @@ struct TreeWriter {
     void node(int x, int y, int log2s)
     {
         Stream &st = w->st;
+        TileCoder &tcd = w->coder;
         const int s = 1 << log2s, ws = st.pic.w_scu;
         const int i = (x < st.sps.width && y < st.sps.height) ? leaf[(size_t)(y >> 2) * ws + (x >> 2)] : -1;
         const bool is_leaf = i >= 0 && b->log2w[i] == log2s;
-        if (s >= 8) enc->bin(!is_leaf, st.models.split[0]);
+        if (s >= 8) enc->bin(!is_leaf, tcd.models.split[0]);
         else if (!is_leaf) { error = 1; return; }
         if (!is_leaf) {
             const int h = s >> 1;
@@ -2027,8 +2113,8 @@ struct TreeWriter {
         if (cbf_all_path && !(cu.cbf[0] | cu.cbf[1] | cu.cbf[2])) { /* all-zero flag path */ }
         else if (cbf_all_path && cu.cbf[1] + cu.cbf[2] == 0) cu.cbf[0] = 1;      // implied luma cbf needs a luma coefficient
         if (cbf_all_path && cu.cbf[0]) { bool nz = false; for (int16_t v : blk[0]) nz |= v != 0; if (!nz) blk[0][0] = 1; }
-        st.code_cu(*enc, cu, coef, true);
-        st.commit(cu);
+        tcd.code_cu(*enc, cu, coef, true);
+        tcd.commit(cu);
     }
 };
 }
@@ -2091,20 +2177,21 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
         tw.leaf[(size_t)(b->y[i] >> 2) * st.pic.w_scu + (b->x[i] >> 2)] = i;
     }
     // every tile is its own arithmetic-coder run (contexts, QP predictor, motion history); the header carries the byte sizes of all but the last
+    TileCoder &tcd = w->coder;
     std::vector<BitWriter> tile_bits((size_t)n_tiles);
     for (int t = 0; t < n_tiles; t++) {
         const int tc = t % st.grid.n_cols, tr = t / st.grid.n_cols;
-        st.models.reset();
-        st.qp_prev = slice_qp;
+        tcd.models.reset();
+        tcd.qp_prev = slice_qp;
         Enc enc;
         enc.bw = &tile_bits[(size_t)t];
         enc.start();
         tw.enc = &enc;
         for (int cy = st.grid.row_bd[tr]; cy < st.grid.row_bd[tr + 1]; cy++) for (int cx = st.grid.col_bd[tc]; cx < st.grid.col_bd[tc + 1]; cx++) {
-            if (cx == st.grid.col_bd[tc]) st.history_reset();
+            if (cx == st.grid.col_bd[tc]) tcd.history_reset();
             if (st.sh.alf_on && st.sh.alf_ctb_map) {
                 const int f = w->next_alf_ctb.empty() ? 1 : (w->next_alf_ctb[(size_t)cy * w_ctu + cx] != 0);
-                enc.bin(f, st.models.alf_ctb[0]);
+                enc.bin(f, tcd.models.alf_ctb[0]);
                 st.alf_ctb_flag[(size_t)cy * w_ctu + cx] = (uint8_t)f;
             }
             tw.node(cx << 6, cy << 6, 6);

@@ -10,11 +10,12 @@ from .decoder import XgpuDecoder
 
 
 class StreamDecoder:
-    def __init__(self, data, device=0, prefetch=2, verify_md5=False, apply_crop=False):
+    def __init__(self, data, device=0, prefetch=2, verify_md5=False, apply_crop=False, parser_threads=1):
         """verify_md5: check downloaded pictures against the stream's picture-signature SEIs (the reference's
         XEVD_CFG_SET_USE_PIC_SIGNATURE), raising on a mismatch"""
         self.data, self.device, self.prefetch, self.verify_md5 = data, device, prefetch, verify_md5
         self._lock, self._dec, self._abort = threading.Lock(), None, False
+        self.parser_threads = parser_threads      # host threads for the tiles of one picture (xhost_parser_set_threads)
         self.apply_crop = apply_crop      # packed output: cut the SPS conformance window (the reference application writes uncropped pictures)
 
     N_SLOTS = 33      # the parser keeps at most 32 reference pictures (+ the current one): a slot is always free
@@ -29,7 +30,7 @@ class StreamDecoder:
                                             eipd=p["eipd"], max_pics=34, chroma_qp_tables=p["chroma_qp_tables"], bit_depth_chroma=p["bit_depth_chroma"])
                 return self._dec.batch_create_from_struct(cu_batch)
         try:
-            for p in stream.iter_stream(self.data, consume_batch=to_device):
+            for p in stream.iter_stream(self.data, consume_batch=to_device, threads=self.parser_threads):
                 if p["n_dmvr_sub"]:
                     p["_dmvr"] = [threading.Event(), None]
                 q.put(p)

@@ -71,6 +71,7 @@ def load():
         lib.xhost_parser_error.argtypes = [C.c_void_p]
         lib.xhost_parser_close.argtypes = [C.c_void_p]
         lib.xhost_parser_set_dmvr_mvs.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.xhost_parser_set_threads.argtypes = [C.c_void_p, C.c_int]
         lib.xhost_writer_open.restype = C.c_void_p
         lib.xhost_writer_open.argtypes = [C.POINTER(StreamParams)]
         lib.xhost_writer_add_picture.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(abi.CuBatch)]
@@ -208,7 +209,7 @@ def _feedback(lib, h):
     return feed
 
 
-def iter_stream(data, consume_batch=None):
+def iter_stream(data, consume_batch=None, threads=1):
     """generator over the pictures of a .evc byte string in decoding order: dict(params..., batch=dict of numpy arrays in the
     layout of synth.gen_frame).  The C parser runs inside each next() with the GIL released (ctypes).
     consume_batch(params, cu_batch_struct): zero-copy hand-over - called while the parser's arrays are valid (before the next picture
@@ -216,6 +217,8 @@ def iter_stream(data, consume_batch=None):
     lib = load()
     buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
     h = lib.xhost_parser_open(buf, len(data))
+    if threads > 1:      # the tiles of a picture on parallel host threads (xhost_parser_set_threads)
+        lib.xhost_parser_set_threads(h, int(threads))
     try:
         while True:
             hp = HostPicture()
@@ -262,6 +265,6 @@ def iter_stream(data, consume_batch=None):
         lib.xhost_parser_close(h)
 
 
-def parse_stream(data):
+def parse_stream(data, threads=1):
     """-> list of the pictures of iter_stream(data)"""
-    return list(iter_stream(data))
+    return list(iter_stream(data, threads=threads))
