@@ -20,7 +20,8 @@
  * src_main/xevdm_alf.c:700-794), and tool_admvp with its sub-tools tool_amvr, tool_hmvp, tool_mmvd and tool_dmvr: merge_idx / merge_mode_flag / mvr_idx /
  * bi_idx / mmvd_flag + mmvd data syntax (xevdm_eco.c:767-812,1519-1726), merge with vector difference (src_main/xevdm_util.c:191-592,4682-4716), merge candidates incl. the temporal and history ones (src_main/xevdm_util.c:594-1391,3729-3818), the resolution-indexed
  * predictor (:750-951), intra-only 4x4 CUs; tool_dmvr needs the backend's refined vectors back per picture (xhost_parser_set_dmvr_mvs) and is refused
- * together with tool_hmvp or tool_mmvd.  Not parsed: sps_btt_flag / sps_suco_flag (split syntax), tool_affine, tool_cm_init (and ADCC),
+ * together with tool_hmvp or tool_mmvd.  tool_affine (affine merge / affine inter CUs, xevdm_util.c:2145-3187) is parsed too.
+ * Not parsed: sps_btt_flag / sps_suco_flag (split syntax), tool_cm_init (and ADCC),
  * tool_rpl / tool_pocs, dquant.  SPS chroma QP mapping tables and cropping offsets are parsed, a VUI is skipped; 4:2:0, one slice per picture (with all of its
  * tiles - uniform or explicit PPS tile grids, entry points in the slice header; explicit tile ids and arbitrary slices are refused), I / P / B slices incl. temporal layers (hierarchical sub-GOPs).
  * Conventions as xevd_hip.h: 0 / negative XEVD_ERR_* codes, nothing throws, one object per stream.
@@ -130,6 +131,9 @@ typedef struct xhost_stream_params {
     int tile_cols, tile_rows;
     int tile_col_w[XGPU_MAX_TILE_COLS], tile_row_h[XGPU_MAX_TILE_ROWS];
     int loop_filter_across_tiles;          /* pps.loop_filter_across_tiles_enabled_flag */
+    int tool_affine;                       /* sub-tool of tool_admvp: sps->tool_affine - a CU of the batch with `affine` 2 / 3 is written as an affine CU: skip / merge-mode
+                                              CUs of 8x8 and larger take one of the five affine merge candidates (the batch's control points are not used), inter CUs
+                                              of 16x16 and larger code their control-point vectors `affine_mv` against one of two predictors (xevdm_eco.c:1528-1537, 1649-1682) */
 } xhost_stream_params;
 
 /* ALF parameter set as it is coded in an APS NAL unit (XEVD_ALF_SLICE_PARAM after xevdm_eco_alf_aps_param) */

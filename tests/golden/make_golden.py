@@ -172,6 +172,13 @@ def golden_streams(only=()):
                                                                                inter_frac=0.9, max_refs=3, log2_sub_gop=3, bit_depth=10, skip_frac=0.3, direct_frac=0.3)),
                                 "main_mmvd_all_tools_10b": (264, 136, 17, dict(main=True, admvp=True, mmvd=True, amvr=True, hmvp=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True,
                                                                                ibc_log_max=5, inter_frac=0.9, skip_frac=0.35, direct_frac=0.3, max_refs=3, log2_sub_gop=3, bit_depth=10)),
+                                # sps->tool_affine: affine merge and affine inter CUs from the bitstream
+                                "main_affine_p_8b": (392, 264, 6, dict(main=True, admvp=True, affine=True, inter_frac=0.95, split_prob=0.35, skip_frac=0.3, direct_frac=0.3, max_refs=2)),
+                                "main_affine_all_tools_10b": (328, 264, 17, dict(main=True, admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, iqt=True, ats=True, addb=True, alf=True,
+                                                                                eipd=True, htdf=True, inter_frac=0.9, split_prob=0.4, skip_frac=0.3, direct_frac=0.3, max_refs=3, log2_sub_gop=3,
+                                                                                bit_depth=10)),
+                                "main_affine_dmvr_tiles_8b": (392, 264, 9, dict(main=True, admvp=True, affine=True, affine_frac=0.6, dmvr=True, addb=True, alf=True, inter_frac=0.95, split_prob=0.35,
+                                                                                skip_frac=0.3, direct_frac=0.3, max_refs=2, log2_sub_gop=2, tiles=(2, 2, 0))),
                                 # several tiles per picture: without / with filtering across the tile borders, uniform and explicit grids
                                 "main_tiles_2x2_dbk_8b": (256, 192, 4, dict(main=True, tiles=(2, 2, 0), max_refs=2)),
                                 "main_tiles_3x2_all_tools_10b": (320, 200, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, alf_fixed=True, eipd=True, htdf=True, admvp=True, amvr=True, hmvp=True,

@@ -397,7 +397,7 @@ def test_gpu_decoder_survives_mutated_streams():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["hier_b_gop4", "main_eipd_all_tools_10b", "cqt_crop_10b", "idr_period_skip", "main_dra_10b", "main_htdf_all_tools_10b", "main_tiles_explicit_10b"])
+@pytest.mark.parametrize("name", ["hier_b_gop4", "main_eipd_all_tools_10b", "cqt_crop_10b", "idr_period_skip", "main_dra_10b", "main_htdf_all_tools_10b", "main_tiles_explicit_10b", "main_affine_all_tools_10b"])
 def test_gpu_plain_c_decoder(name, tmp_path):
     """examples/evc_decode - a decoder in plain C on the two C ABIs, no Python in the loop - writes the reference decoder's pictures"""
     import subprocess
@@ -423,7 +423,8 @@ APP_ON_HIP = os.path.normpath(os.path.join(golden_io.GOLDEN, "..", "..", "oracle
                                        ("main_all_tools_10b", []), ("signed_main_alf_10b", ["-s", "--output-bit-depth", "10"]),
                                        ("main_dra_10b", ["--output-bit-depth", "10"]), ("main_htdf_all_tools_10b", ["--output-bit-depth", "10"]),
                                        ("main_ibc_all_tools_10b", ["--output-bit-depth", "10"]), ("main_admvp_all_tools_10b", ["--output-bit-depth", "10"]), ("main_dmvr_all_tools_10b", ["--output-bit-depth", "10"]),
-                                       ("main_tiles_3x2_all_tools_10b", ["--output-bit-depth", "10"]), ("main_tiles_explicit_10b", [])])
+                                       ("main_tiles_3x2_all_tools_10b", ["--output-bit-depth", "10"]), ("main_tiles_explicit_10b", []),
+                                       ("main_affine_all_tools_10b", ["--output-bit-depth", "10"])])
 def test_gpu_reference_application_on_our_api(name, args, tmp_path):
     """The reference's OWN sample application (app/xevd_app.c, compiled from its source where it lies) linked against libxevd_amd_api.so - this
     repository's implementation of the public xevd_create / xevd_decode / xevd_pull API - instead of libxevd: it decodes the golden streams on

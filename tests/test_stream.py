@@ -86,6 +86,16 @@ CONFIGS = [
     (136, 72, 3, dict(main=True, eipd=True, ibc_log_max=4, idr_period=1)),
     (264, 136, 6, dict(main=True, eipd=True, addb=True, ibc_log_max=3, ibc_frac=0.6, inter_frac=0.5)),
     (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=6, inter_frac=0.5, log2_sub_gop=3, max_refs=2, bit_depth=10)),
+    # sps->tool_affine: affine merge CUs (model inherited from affine neighbours, constructed from corner vectors incl. the co-located ones, zero
+    # candidates) and affine inter CUs (two predictors per list, 2 or 3 coded control points), sub-block vectors in the motion maps (merge / predictor
+    # candidates of later CUs, temporal candidates of later pictures, history), with every other tool, tiles and DMVR
+    (200, 136, 3, dict(main=True, admvp=True, affine=True, inter_frac=0.9, split_prob=0.3)),
+    (392, 264, 6, dict(main=True, admvp=True, affine=True, inter_frac=0.95, split_prob=0.35, skip_frac=0.3, direct_frac=0.3, max_refs=2)),
+    (392, 264, 9, dict(main=True, admvp=True, affine=True, affine_frac=0.7, inter_frac=0.95, split_prob=0.35, skip_frac=0.3, direct_frac=0.3, max_refs=2, log2_sub_gop=2)),
+    (328, 264, 17, dict(main=True, admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, inter_frac=0.9, split_prob=0.4,
+                        skip_frac=0.3, direct_frac=0.3, max_refs=3, log2_sub_gop=3, bit_depth=10)),
+    (392, 264, 9, dict(main=True, admvp=True, affine=True, dmvr=True, addb=True, inter_frac=0.95, split_prob=0.35, skip_frac=0.3, direct_frac=0.3, max_refs=2, log2_sub_gop=2, tiles=(2, 2, 0))),
+    (264, 264, 8, dict(main=True, admvp=True, affine=True, affine_frac=0.9, inter_frac=1.0, split_prob=0.25, skip_frac=0.3, direct_frac=0.3, max_refs=4)),
     # several tiles per picture (PPS grid uniform / explicit, one slice with entry points): every tile its own arithmetic-coder run, no neighbour
     # across a tile border (intra samples, HTDF border, motion candidates, most probable modes), the history reset per tile CTU row, deblocking with
     # and without loop_filter_across_tiles, the ALF windows ending at the tile (mirrored / replicated)

@@ -1,7 +1,12 @@
 // affine_model.h - the affine motion model's scalar arithmetic, shared by the host batch builder (which sorts the tiles of affine CUs into the
 // EIF and the sub-block-translation work lists) and k_affine.hip (which re-derives it per tile): deltas, sub-block size, EIF decision.
 #pragma once
+#ifdef __HIPCC__
 #include <hip/hip_runtime.h>
+#else                    // the host front end (plain C++) derives the sub-block vectors of affine CUs for its motion maps with the same arithmetic
+#define __host__
+#define __device__
+#endif
 #include <stdint.h>
 
 static __host__ __device__ inline int aff_imax(int a, int b) { return a > b ? a : b; }
@@ -46,7 +51,6 @@ static __host__ __device__ inline void aff_subblock(const AffModel m[2], const b
     sub_w = 1 << lw; sub_h = 1 << lh;
     bool apply = true;
     mem_band = true;
-#pragma unroll
     for (int l = 0; l < 2; l++) {
         if (!use[l]) continue;
         const int wx = aff_imax(aff_iabs(m[l].dh[0]), aff_iabs(m[l].dh[1])), wy = aff_imax(aff_iabs(m[l].dv[0]), aff_iabs(m[l].dv[1]));
@@ -54,7 +58,6 @@ static __host__ __device__ inline void aff_subblock(const AffModel m[2], const b
         const int h = wy > 4 ? 4 : (wy == 0 ? 1 << lh : (wy == 1 ? 32 : (wy == 2 ? 16 : 8)));
         sub_w = aff_imin(sub_w, w); sub_h = aff_imin(sub_h, h);
     }
-#pragma unroll
     for (int l = 0; l < 2; l++) {
         if (!use[l] || !apply) continue;             // the reference stops at the first list that fails
         bool mb;

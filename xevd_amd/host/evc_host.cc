@@ -9,6 +9,7 @@
 // see the same neighbour state because both walk the CUs in the same order and "reconstructed" (COD) == "already parsed".
 #include "../../include/xevd_host.h"
 #include "alf_fixed_tables.h"
+#include "../csrc/affine_model.h"
 
 #include <algorithm>
 #include <atomic>
@@ -188,6 +189,7 @@ struct Models {
           mvr_idx[4],                                                                                // tool_amvr: xevd_def.h:493
           merge_mode[1], merge_idx[5], bi_idx[2],                                                      // tool_admvp: xevd_def.h:461-465
           ibc_flag[2],                                                                               // sps->ibc_flag: xevd_def.h:485
+          affine_flag[2], affine_mode[1], affine_mrg[5], affine_mvp_idx[1], affine_mvd_flag[2],       // tool_affine: xevd_def.h:483-498
           ipm_mpm_flag[1], ipm_mpm_idx[1], ipm_chroma[1];                                            // tool_eipd: xevd_def.h intra_luma_pred_mpm_flag / _idx, intra_chroma_pred_mode
     void reset() { Model *p = (Model *)this; for (size_t i = 0; i < sizeof(Models) / sizeof(Model); i++) p[i] = 512; }     // PROB_INIT, xevd_eco.c:769-803
 };
@@ -229,6 +231,7 @@ struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, lo
              int tool_mmvd = 0;                      // sps->tool_mmvd: merge with vector difference (a base candidate plus one of 32 offsets)
              int tool_dmvr = 0;                      // sps->tool_dmvr: merge-mode motion is refined by the backend (no syntax of its own)
              int tool_amvr = 0, tool_hmvp = 0;       // sub-tools of tool_admvp: adaptive vector resolution (mvr_idx), history-based candidates
+             int tool_affine = 0;                    // sps->tool_affine: affine merge / affine inter CUs (4- or 6-parameter models from 2 / 3 control points)
              int tool_admvp = 0;                     // sps->tool_admvp: merge / resolution-indexed predictors instead of the Baseline candidate lists, 8-tap MC tables
              int ibc = 0, ibc_log_max = 0;            // sps->ibc_flag, sps->ibc_log_max_size (log2 of the largest IBC CU; xevdm_eco.c:1890-1898)
              int crop[4] = { 0, 0, 0, 0 };            // picture_crop_left / right / top / bottom_offset (xevd_eco.c:1349-1357), as xevd_pull reports them
@@ -297,6 +300,10 @@ struct Cu {
     int ats_inter;                   // ats_inter_info: idx | pos << 4
     int mmvd, mmvd_idx;              // mmvd_flag; group << 7 | base candidate << 5 | distance << 2 | direction
     int dmvr;                        // tool_dmvr and a skip / merge-mode CU: mcore->dmvr_enable (xevdm.c:1272-1288)
+    int affine;                      // mcore->affine_flag: 0 translational, 1 / 2 = 2 / 3 control points (4- / 6-parameter model)
+    int16_t aff_mv[2][3][2];         // mcore->affine_mv[list][vertex][x/y]: top-left, top-right, bottom-left control-point vectors
+    int aff_idx[2];                  // affine merge index ([0]) / affine predictor index per list
+    int16_t aff_mvd[2][3][2];        // coded control-point differences of an affine inter CU
 };
 
 struct Picture {         // SCU maps of the picture being parsed / written (ctx->map_scu, map_ipm, map_mv, map_refi; cod_eco)
@@ -304,6 +311,8 @@ struct Picture {         // SCU maps of the picture being parsed / written (ctx-
     std::vector<uint8_t> cod, intra, ibc;      // ibc: MCU_GET_IBC
     std::vector<uint8_t> tidx;       // ctx->map_tidx: the tile of every SCU (empty: one tile) - neighbours in another tile are not available
     bool same_tile(int a, int b) const { return tidx.empty() || tidx[(size_t)a] == tidx[(size_t)b]; }
+    std::vector<uint8_t> aff;        // sps->tool_affine: 0, or affine_flag | log2w << 2 | log2h << 5 of the affine CU the SCU belongs to (MCU_GET_AFF + map_affine)
+    std::vector<uint32_t> aff_tl;    //   ... and the SCU address of that CU's top-left corner (MCU_GET_AFF_XOFF / _YOFF)
     std::vector<int8_t> ipm;
     std::vector<int16_t> mv;         // [f_scu][2][2]
     std::vector<int8_t> refi;        // [f_scu][2]
@@ -311,17 +320,17 @@ struct Picture {         // SCU maps of the picture being parsed / written (ctx-
     {
         w_scu = w >> 2; h_scu = h >> 2;
         const size_t f = (size_t)w_scu * h_scu;
-        cod.assign(f, 0); intra.assign(f, 0); ibc.assign(f, 0); ipm.assign(f, 0); mv.assign(f * 4, 0); refi.assign(f * 2, -1); tidx.clear();
+        cod.assign(f, 0); intra.assign(f, 0); ibc.assign(f, 0); ipm.assign(f, 0); mv.assign(f * 4, 0); refi.assign(f * 2, -1); tidx.clear(); aff.clear();
     }
 };
 
 struct Batch {           // the xgpu_cu_batch under construction
     std::vector<uint16_t> x, y;
-    std::vector<uint8_t> log2w, log2h, pred_mode, qp, cbf, ipm, ats, ats_inter, dmvr;
+    std::vector<uint8_t> log2w, log2h, pred_mode, qp, cbf, ipm, ats, ats_inter, dmvr, affine;
     std::vector<int8_t> refi;
-    std::vector<int16_t> mv, coef;
+    std::vector<int16_t> mv, coef, affine_mv;
     std::vector<uint32_t> coef_off, ctu_start;
-    void clear() { x.clear(); y.clear(); log2w.clear(); log2h.clear(); pred_mode.clear(); qp.clear(); cbf.clear(); ipm.clear(); ats.clear(); ats_inter.clear(); dmvr.clear(); refi.clear(); mv.clear(); coef.clear(); coef_off.clear(); ctu_start.clear(); }
+    void clear() { x.clear(); y.clear(); log2w.clear(); log2h.clear(); pred_mode.clear(); qp.clear(); cbf.clear(); ipm.clear(); ats.clear(); ats_inter.clear(); dmvr.clear(); affine.clear(); affine_mv.clear(); refi.clear(); mv.clear(); coef.clear(); coef_off.clear(); ctu_start.clear(); }
 };
 
 // ---- DRA parameter sets (APS type 1, SIG_PARAM_DRA) and the inverse-mapping tables the output stage applies (src_main/xevdm_dra.c) ----
@@ -437,6 +446,7 @@ struct Stream {          // everything both directions share
             grid.row_bd[j + 1] = grid.row_bd[j] + ht;
         }
         if (grid.col_bd[grid.n_cols] != w_ctu || grid.row_bd[grid.n_rows] != h_ctu) return false;
+        if (sps.tool_affine) { pic.aff.assign((size_t)pic.w_scu * pic.h_scu, 0); pic.aff_tl.resize((size_t)pic.w_scu * pic.h_scu); }
         pic.tidx.clear();
         if (grid.n_cols * grid.n_rows > 1) {
             pic.tidx.assign((size_t)pic.w_scu * pic.h_scu, 0);
@@ -668,6 +678,7 @@ struct TileCoder {
         if (hist_cnt == 23) { for (int i = 1; i < 23; i++) hist[i - 1] = hist[i]; hist_cnt = 22; }
         Motion &m = hist[hist_cnt++];
         for (int l = 0; l < 2; l++) { m.refi[l] = (int8_t)cu.refi[l]; m.mv[l][0] = cu.mv[l][0]; m.mv[l][1] = cu.mv[l][1]; }
+        if (cu.affine) for (int l = 0; l < 2; l++) { m.mv[l][0] = m.mv[l][1] = 0; if (cu.refi[l] >= 0) aff_centre(cu, l, m.mv[l]); }      // an affine CU leaves the vector at its centre
     }
     bool bi_applicable(const Cu &cu) const { return sh.type == XHOST_SLICE_B && (1 << cu.log2w) + (1 << cu.log2h) > 12; }      // xevdm_check_bi_applicability, xevdm_util.c:1083-1096
     // the five spatial neighbours H, D, E, I, A (xevdm_check_motion_availability, xevdm_util.c:594-748, last branch): decoded, inter, not IBC
@@ -1005,6 +1016,257 @@ struct TileCoder {
         qp_u = (iu >= 0 ? tbl[iu] : 0) + off;                 // entries below 0 of the default table are zero-initialised storage
         qp_v = (iv >= 0 ? tbl[iv] : 0) + off;
     }
+
+    // ------------------------------------------------------------------------------------------------------------------------------
+    // sps->tool_affine: control-point vectors of affine merge / affine inter CUs (xevd_get_affine_motion, src_main/xevdm.c:937-1013;
+    // candidates src_main/xevdm_util.c:2145-3187).  Without SUCO the right-hand neighbours are never decoded before the CU: avail_lr is
+    // LR_10 or LR_00, and the branches the reference keeps for LR_01 / LR_11 are not restated.
+    // ------------------------------------------------------------------------------------------------------------------------------
+    static int aff_rnd(int v, int shift) { return (v + (1 << (shift - 1)) - (v >= 0)) >> shift; }      // xevdm_mv_rounding_s32, xevdm_util.c:1856-1861
+    static int16_t clip16(int v) { return (int16_t)std::min(std::max(v, -32768), 32767); }
+    // neighbour SCU n of the CU at scup: decoded, inter, same tile - and affine (model-based candidates) or not IBC (corner vectors)
+    bool aff_nb(int scup, int n, bool inside, bool need_affine) const
+    {
+        if (!inside || !pic.cod[n] || pic.intra[n] || !pic.same_tile(scup, n)) return false;
+        return need_affine ? pic.aff[n] != 0 : !pic.ibc[n];
+    }
+    // the model of the affine CU that covers SCU scun, evaluated at this CU's corners (xevdm_derive_affine_model_mv, xevdm_util.c:2270-2363)
+    void aff_inherit(const Cu &cu, int scun, int l, int cp_num, int16_t mvp[3][2]) const
+    {
+        const int ws = pic.w_scu, a = pic.aff[(size_t)scun], nlw = (a >> 2) & 7, nlh = (a >> 5) & 7, nw = 1 << nlw, nh = 1 << nlh, tl = (int)pic.aff_tl[(size_t)scun];
+        const int addr[4] = { tl, tl + (nw >> 2) - 1, tl + ((nh >> 2) - 1) * ws, tl + ((nh >> 2) - 1) * ws + (nw >> 2) - 1 };
+        int nmv[4][2];
+        for (int i = 0; i < 4; i++) { nmv[i][0] = pic.mv[(size_t)addr[i] * 4 + l * 2]; nmv[i][1] = pic.mv[(size_t)addr[i] * 4 + l * 2 + 1]; }
+        const int nx = (tl % ws) << 2;
+        int ny = (tl / ws) << 2;
+        bool top = false;
+        if ((ny + nh) % 64 == 0 && ny + nh == cu.y) {          // the neighbour sits in the CTU row above: only its bottom row of vectors is used (line buffer)
+            top = true; ny += nh;
+            nmv[0][0] = nmv[2][0]; nmv[0][1] = nmv[2][1]; nmv[1][0] = nmv[3][0]; nmv[1][1] = nmv[3][1];
+        }
+        const int dhx = (nmv[1][0] - nmv[0][0]) * (1 << (7 - nlw)), dhy = (nmv[1][1] - nmv[0][1]) * (1 << (7 - nlw));
+        int dvx = -dhy, dvy = dhx;
+        if (cp_num == 3 && !top) { dvx = (nmv[2][0] - nmv[0][0]) * (1 << (7 - nlh)); dvy = (nmv[2][1] - nmv[0][1]) * (1 << (7 - nlh)); }
+        const int hb = nmv[0][0] * 128, vb = nmv[0][1] * 128;
+        auto at = [&](int px, int py, int16_t out[2]) {
+            out[0] = clip16(aff_rnd(dhx * px + dvx * py + hb, 7)); out[1] = clip16(aff_rnd(dhy * px + dvy * py + vb, 7));
+        };
+        at(cu.x - nx, cu.y - ny, mvp[0]);
+        at(cu.x - nx + (1 << cu.log2w), cu.y - ny, mvp[1]);
+        if (cp_num == 3) at(cu.x - nx, cu.y - ny + (1 << cu.log2h), mvp[2]);
+    }
+    // the two predictor candidates of an affine inter CU for list l / reference cur_refi (xevdm_get_affine_motion_scaling, xevdm_util.c:2367-2761)
+    void aff_amvp(const Cu &cu, int l, int cur_refi, int vn, int16_t mvp[2][3][2]) const
+    {
+        const int ws = pic.w_scu, hs = pic.h_scu, xs = cu.x >> 2, ys = cu.y >> 2, scuw = (1 << cu.log2w) >> 2, scuh = (1 << cu.log2h) >> 2, scup = ys * ws + xs;
+        memset(mvp, 0, sizeof(int16_t) * 2 * 3 * 2);
+        int cnt = 0;
+        auto model = [&](const int *nb, const bool *in, int n) {          // the first neighbour of a group that is affine and uses this reference
+            for (int k = 0; k < n; k++)
+                if (aff_nb(scup, nb[k], in[k], true) && pic.refi[(size_t)nb[k] * 2 + l] >= 0 && pic.refi[(size_t)nb[k] * 2 + l] == cur_refi) {
+                    int16_t t[3][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 } };
+                    aff_inherit(cu, nb[k], l, vn, t);
+                    memcpy(mvp[cnt++], t, sizeof(t));
+                    return;
+                }
+        };
+        { const int nb[2] = { scup + ws * scuh - 1, scup + ws * (scuh - 1) - 1 }; const bool in[2] = { xs > 0 && ys + scuh < hs, xs > 0 }; model(nb, in, 2); }      // A0, A1
+        if (cnt >= 2) return;
+        { const int nb[3] = { scup - ws + scuw, scup - ws + scuw - 1, scup - ws - 1 }; const bool in[3] = { ys > 0 && xs + scuw < ws, ys > 0, xs > 0 && ys > 0 }; model(nb, in, 3); }      // B0, B1, B2
+        if (cnt >= 2) return;
+        { const int nb[2] = { scup + ws * scuh + scuw, scup + ws * (scuh - 1) + scuw }; const bool in[2] = { xs + scuw < ws && ys + scuh < hs, xs + scuw < ws }; model(nb, in, 2); }      // C0, C1
+        if (cnt >= 2) return;
+        // corner vectors: the first neighbour of each corner that uses this reference
+        auto corner = [&](const int *nb, const bool *in, int n, int16_t out[2]) -> bool {
+            out[0] = out[1] = 0;
+            for (int k = 0; k < n; k++)
+                if (aff_nb(scup, nb[k], in[k], false) && pic.refi[(size_t)nb[k] * 2 + l] == cur_refi && cur_refi >= 0) {
+                    out[0] = pic.mv[(size_t)nb[k] * 4 + l * 2]; out[1] = pic.mv[(size_t)nb[k] * 4 + l * 2 + 1];
+                    return true;
+                }
+            return false;
+        };
+        int16_t lt[2], rt[2], lb[2], rb[2];
+        const int nlt[3] = { scup - ws - 1, scup - ws, scup - 1 }; const bool ilt[3] = { xs > 0 && ys > 0, ys > 0, xs > 0 };
+        const int nrt[3] = { scup - ws + scuw, scup - ws + scuw - 1, scup + scuw }; const bool irt[3] = { ys > 0 && xs + scuw < ws, ys > 0, xs + scuw < ws };
+        const int nlb[2] = { scup + ws * scuh - 1, scup + ws * (scuh - 1) - 1 }; const bool ilb[2] = { xs > 0 && ys + scuh < hs, xs > 0 };
+        const int nrb[2] = { scup + ws * scuh + scuw, scup + ws * (scuh - 1) + scuw }; const bool irb[2] = { xs + scuw < ws && ys + scuh < hs, xs + scuw < ws };
+        const bool c_lt = corner(nlt, ilt, 3, lt), c_rt = corner(nrt, irt, 3, rt), c_lb = corner(nlb, ilb, 2, lb), c_rb = corner(nrb, irb, 2, rb);
+        auto put = [&](const int16_t a[2], const int16_t b[2], const int16_t c2[2]) { memcpy(mvp[cnt][0], a, 4); memcpy(mvp[cnt][1], b, 4); memcpy(mvp[cnt][2], c2, 4); cnt++; };
+        if (c_lt && c_rt && (vn == 2 || c_lb || c_rb)) {
+            int16_t third[2] = { lb[0], lb[1] };
+            if (!c_lb && c_rb) { third[0] = clip16(rb[0] + lt[0] - rt[0]); third[1] = clip16(rb[1] + lt[1] - rt[1]); }
+            put(lt, rt, third);
+        }
+        if (cnt == 2) return;
+        if (c_lb) put(lb, lb, lb); else if (c_rb) put(rb, rb, rb);        // translational candidates: left, (right,) above, above-left
+        if (cnt == 2) return;
+        if (c_rt) put(rt, rt, rt);
+        if (cnt == 2) return;
+        if (c_lt) put(lt, lt, lt);
+    }
+    // one constructed candidate from corner vectors (xevdm_derive_affine_constructed_candidate, xevdm_util.c:2145-2268)
+    void aff_constructed(const Cu &cu, const int cp_valid[4], const int16_t cp_mv[2][4][2], const int cp_refi[2][4], const int *idx, int model, int vn,
+                         int8_t refi[5][2], int16_t cpmv[5][2][3][2], int cpn[5], int &cnt) const
+    {
+        if (cnt >= 5) return;
+        for (int i = 0; i < vn; i++) if (!cp_valid[idx[i]]) return;
+        bool ok[2];
+        for (int l = 0; l < 2; l++) {
+            ok[l] = true;
+            for (int i = 0; i < vn; i++) ok[l] = ok[l] && cp_refi[l][idx[i]] >= 0 && cp_refi[l][idx[i]] == cp_refi[l][idx[0]];
+        }
+        if (!ok[0] && !ok[1]) return;
+        cpn[cnt] = vn;
+        const int sh_hw = 7 + cu.log2w - cu.log2h;
+        for (int l = 0; l < 2; l++) {
+            memset(cpmv[cnt][l], 0, sizeof(cpmv[cnt][l]));
+            refi[cnt][l] = -1;
+            if (!ok[l]) continue;
+            refi[cnt][l] = (int8_t)cp_refi[l][idx[0]];
+            int t[4][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
+            for (int i = 0; i < vn; i++) { t[idx[i]][0] = cp_mv[l][idx[i]][0]; t[idx[i]][1] = cp_mv[l][idx[i]][1]; }
+            switch (model) {      // to top-left, top-right (, bottom-left)
+            case 1: t[2][0] = t[3][0] + t[0][0] - t[1][0]; t[2][1] = t[3][1] + t[0][1] - t[1][1]; break;
+            case 2: t[1][0] = t[3][0] + t[0][0] - t[2][0]; t[1][1] = t[3][1] + t[0][1] - t[2][1]; break;
+            case 3: t[0][0] = t[1][0] + t[2][0] - t[3][0]; t[0][1] = t[1][1] + t[2][1] - t[3][1]; break;
+            case 5: {
+                const int h = (t[2][1] - t[0][1]) * (1 << sh_hw) + t[0][0] * 128, v = -((t[2][0] - t[0][0]) * (1 << sh_hw)) + t[0][1] * 128;
+                t[1][0] = aff_rnd(h, 7); t[1][1] = aff_rnd(v, 7);
+                break; }
+            default: break;
+            }
+            for (int i = 0; i < vn; i++) { cpmv[cnt][l][i][0] = clip16(t[i][0]); cpmv[cnt][l][i][1] = clip16(t[i][1]); }
+        }
+        cnt++;
+    }
+    // the five affine merge candidates (xevdm_get_affine_merge_candidate, xevdm_util.c:2763-3187)
+    void aff_merge(const Cu &cu, int8_t refi[5][2], int16_t cpmv[5][2][3][2], int cpn[5]) const
+    {
+        const int ws = pic.w_scu, hs = pic.h_scu, xs = cu.x >> 2, ys = cu.y >> 2, scuw = (1 << cu.log2w) >> 2, scuh = (1 << cu.log2h) >> 2, scup = ys * ws + xs;
+        const bool left_avail = xs > 0 && pic.cod[(size_t)scup - 1] && pic.same_tile(scup, scup - 1);      // avail_lr LR_10 (xevd_check_nev_avail, xevd_util.c:1156-1174)
+        int cnt = 0;
+        memset(cpmv, 0, sizeof(int16_t) * 5 * 2 * 3 * 2);
+        {   // model based: A1, B1, B0, A0, B2 - one candidate per distinct affine neighbour CU
+            const int nb[5] = { scup + ws * (scuh - 1) - 1, scup - ws + scuw - 1, scup - ws + scuw, scup + ws * scuh - 1, scup - ws - 1 };
+            const bool in[5] = { xs > 0, ys > 0, ys > 0 && xs + scuw < ws, xs > 0 && ys + scuh < hs, xs > 0 && ys > 0 };
+            bool valid[5];
+            uint32_t tl[5] = { 0, 0, 0, 0, 0 };
+            for (int k = 0; k < 5; k++) { valid[k] = aff_nb(scup, nb[k], in[k], true); if (valid[k]) tl[k] = pic.aff_tl[(size_t)nb[k]]; }
+            if (valid[2] && valid[1] && tl[1] == tl[2]) valid[2] = false;
+            if (valid[3] && valid[0] && tl[0] == tl[3]) valid[3] = false;
+            if ((valid[4] && valid[0] && tl[4] == tl[0]) || (valid[4] && valid[1] && tl[4] == tl[1])) valid[4] = false;
+            for (int k = 0; k < 5 && cnt < 5; k++) {
+                if (!valid[k]) continue;
+                cpn[cnt] = (pic.aff[(size_t)nb[k]] & 3) == 1 ? 2 : 3;
+                for (int l = 0; l < 2; l++) {
+                    refi[cnt][l] = pic.refi[(size_t)nb[k] * 2 + l];
+                    if (refi[cnt][l] >= 0) aff_inherit(cu, nb[k], l, cpn[cnt], cpmv[cnt][l]); else refi[cnt][l] = -1;
+                }
+                cnt++;
+            }
+        }
+        {   // constructed from the vectors at the four corners
+            int16_t cp_mv[2][4][2];
+            int cp_refi[2][4], cp_valid[4] = { 0, 0, 0, 0 };
+            memset(cp_mv, 0, sizeof(cp_mv));
+            for (int l = 0; l < 2; l++) for (int i = 0; i < 4; i++) cp_refi[l][i] = -1;
+            auto spatial = [&](const int *nb, const bool *in, int n, int v) {
+                for (int k = 0; k < n; k++)
+                    if (aff_nb(scup, nb[k], in[k], false)) {
+                        for (int l = 0; l < 2; l++) {
+                            cp_refi[l][v] = pic.refi[(size_t)nb[k] * 2 + l];
+                            cp_mv[l][v][0] = pic.mv[(size_t)nb[k] * 4 + l * 2]; cp_mv[l][v][1] = pic.mv[(size_t)nb[k] * 4 + l * 2 + 1];
+                        }
+                        cp_valid[v] = 1;
+                        return;
+                    }
+            };
+            auto temporal = [&](int scu_col, int v) {          // the co-located vectors at an 8x8-aligned position, reference 0 of each list
+                int16_t t[2][2];
+                const int have = collocated(cu, scu_col, t);
+                for (int l = 0; l < 2; l++) {
+                    const bool on = (have >> l) & 1 && (l == 0 || sh.type == XHOST_SLICE_B);
+                    cp_refi[l][v] = on ? 0 : -1;
+                    cp_mv[l][v][0] = on ? t[l][0] : (int16_t)0; cp_mv[l][v][1] = on ? t[l][1] : (int16_t)0;
+                }
+            };
+            const bool same_ctu_row = (((ys + scuh) << 2) >> 6) == ((ys << 2) >> 6);
+            { const int nb[3] = { scup - ws - 1, scup - ws, scup - 1 }; const bool in[3] = { xs > 0 && ys > 0, ys > 0, xs > 0 }; spatial(nb, in, 3, 0); }
+            { const int nb[3] = { scup - ws + scuw, scup - ws + scuw - 1, scup + scuw }; const bool in[3] = { ys > 0 && xs + scuw < ws, ys > 0, xs + scuw < ws }; spatial(nb, in, 3, 1); }
+            if (left_avail) { const int nb[2] = { scup + ws * scuh - 1, scup + ws * (scuh - 1) - 1 }; const bool in[2] = { xs > 0 && ys + scuh < hs, xs > 0 }; spatial(nb, in, 2, 2); }
+            else {
+                if (xs > 0 && ys + scuh < hs && same_ctu_row && pic.same_tile(scup, scup + ws * scuh - 1) && pic.same_tile(scup, scup - 1))
+                    temporal(((xs - 1) >> 1 << 1) + ((ys + scuh) >> 1 << 1) * ws, 2);
+                if (cp_refi[0][2] >= 0 || cp_refi[1][2] >= 0) cp_valid[2] = 1;
+            }
+            {
+                const int col = ((xs + scuw) >> 1 << 1) + ((ys + scuh) >> 1 << 1) * ws;
+                if (xs + scuw < ws && ys + scuh < hs && same_ctu_row && pic.same_tile(scup, col)) temporal(col, 3);
+                if (cp_refi[0][3] >= 0 || cp_refi[1][3] >= 0) cp_valid[3] = 1;
+            }
+            static const int models[6][3] = { { 0, 1, 2 }, { 0, 1, 3 }, { 0, 2, 3 }, { 1, 2, 3 }, { 0, 1, 0 }, { 0, 2, 0 } };
+            static const int vns[6] = { 3, 3, 3, 3, 2, 2 };
+            for (int m = 0; m < 6; m++) aff_constructed(cu, cp_valid, cp_mv, cp_refi, models[m], m, vns[m], refi, cpmv, cpn, cnt);
+        }
+        for (; cnt < 5; cnt++) { cpn[cnt] = 2; refi[cnt][0] = 0; refi[cnt][1] = sh.type == XHOST_SLICE_B ? 0 : -1; }      // zero candidates
+    }
+    // affine merge: candidate idx decides the model and the references
+    void aff_merge_motion(Cu &cu, int idx) const
+    {
+        int8_t refi[5][2]; int16_t cpmv[5][2][3][2]; int cpn[5];
+        aff_merge(cu, refi, cpmv, cpn);
+        cu.affine = cpn[idx] - 1;
+        memset(cu.aff_mv, 0, sizeof(cu.aff_mv));
+        for (int l = 0; l < 2; l++) {
+            cu.refi[l] = refi[idx][l] >= 0 ? refi[idx][l] : -1;
+            cu.mv[l][0] = cu.mv[l][1] = 0;
+            if (cu.refi[l] >= 0) for (int v = 0; v < cpn[idx]; v++) { cu.aff_mv[l][v][0] = cpmv[idx][l][v][0]; cu.aff_mv[l][v][1] = cpmv[idx][l][v][1]; }
+        }
+    }
+    // what the history keeps of an affine CU: the model's vector at the CU centre (update_history_buffer_parse_affine, xevdm.c:657-796)
+    void aff_centre(const Cu &cu, int l, int16_t out[2]) const
+    {
+        const int16_t (*m)[2] = cu.aff_mv[l];
+        const int dhx = (m[1][0] - m[0][0]) * (1 << (7 - cu.log2w)), dhy = (m[1][1] - m[0][1]) * (1 << (7 - cu.log2w));
+        int dvx = -dhy, dvy = dhx;
+        if (cu.affine == 2) { dvx = (m[2][0] - m[0][0]) * (1 << (7 - cu.log2h)); dvy = (m[2][1] - m[0][1]) * (1 << (7 - cu.log2h)); }
+        const int px = 1 << (cu.log2w - 1), py = 1 << (cu.log2h - 1);
+        out[0] = clip16(aff_rnd(m[0][0] * 128 + dhx * px + dvx * py, 7)); out[1] = clip16(aff_rnd(m[0][1] * 128 + dhy * px + dvy * py, 7));
+    }
+    // the vectors later CUs and pictures see of an affine CU: one per sub-block, the control-point vectors themselves at the corners
+    // (xevdm_set_affine_mvf, xevdm_util.c:4095-4195; sub-block size xevdm_derive_affine_subblock_size_bi :1870-1945)
+    void aff_store(const Cu &cu)
+    {
+        const int ws = pic.w_scu, w_cu = (1 << cu.log2w) >> 2, h_cu = (1 << cu.log2h) >> 2, scup = (cu.y >> 2) * ws + (cu.x >> 2), vn = cu.affine + 1;
+        AffModel m[2];
+        const bool use[2] = { cu.refi[0] >= 0, cu.refi[1] >= 0 };
+        for (int l = 0; l < 2; l++) if (use[l]) m[l] = aff_model(&cu.aff_mv[l][0][0], cu.log2w, cu.log2h, vn);
+        int sub_w, sub_h; bool mem_band;
+        aff_subblock(m, use, cu.log2w, cu.log2h, sub_w, sub_h, mem_band);
+        const int sw = sub_w >> 2, shh = sub_h >> 2;
+        for (int l = 0; l < 2; l++) {
+            if (!use[l]) continue;
+            const int16_t (*mv)[2] = cu.aff_mv[l];
+            for (int h = 0; h < h_cu; h += shh) for (int w = 0; w < w_cu; w += sw) {
+                int vx, vy;
+                if (w == 0 && h == 0) { vx = mv[0][0]; vy = mv[0][1]; }
+                else if (w + sw == w_cu && h == 0) { vx = mv[1][0]; vy = mv[1][1]; }
+                else if (w == 0 && h + shh == h_cu && vn == 3) { vx = mv[2][0]; vy = mv[2][1]; }
+                else {
+                    const int px = (w << 2) + (sub_w >> 1), py = (h << 2) + (sub_h >> 1);
+                    vx = aff_clip18(aff_round(mv[0][0] * 128 + m[l].dh[0] * px + m[l].dv[0] * py, 5)) >> 2;
+                    vy = aff_clip18(aff_round(mv[0][1] * 128 + m[l].dh[1] * px + m[l].dv[1] * py, 5)) >> 2;
+                }
+                for (int y = h; y < h + shh; y++) for (int x = w; x < w + sw; x++) {
+                    const size_t k = (size_t)scup + (size_t)y * ws + x;
+                    pic.mv[k * 4 + l * 2] = (int16_t)vx; pic.mv[k * 4 + l * 2 + 1] = (int16_t)vy;
+                }
+            }
+        }
+        const uint8_t tag = (uint8_t)(cu.affine | (cu.log2w << 2) | (cu.log2h << 5));
+        for (int y = 0; y < h_cu; y++) for (int x = 0; x < w_cu; x++) { pic.aff[(size_t)scup + (size_t)y * ws + x] = tag; pic.aff_tl[(size_t)scup + (size_t)y * ws + x] = (uint32_t)scup; }
+    }
     // SCU maps after a CU (xevd_set_dec_info, xevd_util.c:1574-1660; cod_eco xevd.c:797-803)
     void commit(const Cu &cu)
     {
@@ -1015,6 +1277,7 @@ struct TileCoder {
             pic.cod[k] = 1; pic.intra[k] = cu.mode == MODE_INTRA; pic.ibc[k] = cu.mode == MODE_IBC; pic.ipm[k] = (int8_t)cu.ipm;
             for (int l = 0; l < 2; l++) { pic.refi[k * 2 + l] = (int8_t)cu.refi[l]; pic.mv[k * 4 + l * 2] = cu.mv[l][0]; pic.mv[k * 4 + l * 2 + 1] = cu.mv[l][1]; }
         }
+        if (cu.affine && cu.mode != MODE_INTRA && cu.mode != MODE_IBC) aff_store(cu);
     }
 
     // ---- coefficient block, run-length coding in zig-zag order (xevd_eco_run_length_cc, xevd_eco.c:343-395) ----
@@ -1048,6 +1311,40 @@ struct TileCoder {
     // ---- one CU: syntax (xevd_eco_cu, xevd_eco.c:1048-1176; cbf :260-341; coefficients/QP :593-767) + derivations ----
     // enc: `cu` and `coef` carry the wanted values (mv of an INTER CU is met through mvd, a SKIP CU takes its predictor's motion);
     // dec: they are filled.  coef[c]: w*h (w/2*h/2) values of component c, zero-initialised by the caller when decoding.
+    template <class C> int code_refi(C &c, int want, int nref)      // xevd_eco_refi, xevd_eco.c:409-436
+    {
+        if (nref <= 1) return 0;
+        const int r = std::min(std::max(want, 0), nref - 1);
+        int v = 0;
+        if (c.bin(r > 0, models.refi[0])) {
+            v = 1;
+            if (nref > 2 && c.bin(r > 1, models.refi[1])) {
+                v = 2;
+                for (; v < nref - 1; v++) if (!c.ep(r > v)) break;
+            }
+        }
+        return v;
+    }
+    template <class C> void code_mvd(C &c, int16_t mvd[2])          // xevd_eco_get_mvd, xevd_eco.c:491-536
+    {
+        for (int d = 0; d < 2; d++) {
+            const int v = mvd[d], a = sym_abs_mvd(c, v < 0 ? -v : v, models.mvd[0]);
+            int sg = v < 0;
+            if (a) sg = c.ep(sg);
+            mvd[d] = (int16_t)(sg ? -a : a);
+        }
+    }
+    // affine_flag + affine merge index of a skip / merge-mode CU of at least 8x8 (xevdm_eco.c:1528-1537, 1622-1632); true: the CU is affine
+    template <class C> bool code_affine_merge(C &c, Cu &cu)
+    {
+        int aff = 0;
+        if (sps.tool_affine && cu.log2w >= 3 && cu.log2h >= 3) aff = c.bin(cu.affine != 0, models.affine_flag[0]);
+        if (!aff) { cu.affine = 0; return false; }
+        cu.aff_idx[0] = sym_trunc_unary(c, cu.aff_idx[0], models.affine_mrg, 5, 5);
+        aff_merge_motion(cu, cu.aff_idx[0]);
+        cu.dmvr = 0;
+        return true;
+    }
     template <class C> void code_cu(C &c, Cu &cu, int16_t *coef[3], bool enc)
     {
         // mode constraint eOnlyIntra: I slices, and with tool_admvp every 4x4 CU (xevdm.c:1838-1843) - no skip flag, no pred_mode_flag
@@ -1055,13 +1352,14 @@ struct TileCoder {
         int skip = 0;
         if (inter_slice) skip = c.bin(cu.mode == MODE_SKIP, models.skip[0]);
         if (!enc) { cu.mode = skip ? MODE_SKIP : MODE_INTRA; cu.refi[0] = cu.refi[1] = -1; memset(cu.mv, 0, sizeof(cu.mv)); memset(cu.mvd, 0, sizeof(cu.mvd));
-                    cu.mvp_idx[0] = cu.mvp_idx[1] = 0; cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0; cu.ipm = cu.ipm_c = 0; cu.ats = cu.ats_inter = 0; cu.dmvr = 0; cu.mmvd = cu.mmvd_idx = 0; }
+                    cu.mvp_idx[0] = cu.mvp_idx[1] = 0; cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0; cu.ipm = cu.ipm_c = 0; cu.ats = cu.ats_inter = 0; cu.dmvr = 0; cu.mmvd = cu.mmvd_idx = 0; cu.affine = 0; memset(cu.aff_mv, 0, sizeof(cu.aff_mv)); memset(cu.aff_mvd, 0, sizeof(cu.aff_mvd)); cu.aff_idx[0] = cu.aff_idx[1] = 0; }
         int16_t cand[4][2];
         const int n_lists = sh.type == XHOST_SLICE_B ? 2 : 1;
         if (skip && sps.tool_admvp) {
             // Main: one merge index, truncated unary over five contexts (xevdm_eco_merge_idx, xevdm_eco.c:731-744; call site :1550-1551)
             if (sps.tool_mmvd) cu.mmvd = c.bin(cu.mmvd, models.mmvd_flag[0]);
-            if (cu.mmvd) { code_mmvd_idx(c, cu); mmvd_motion(cu); }
+            if (cu.mmvd) { cu.affine = 0; code_mmvd_idx(c, cu); mmvd_motion(cu); }
+            else if (code_affine_merge(c, cu)) { }
             else {
                 cu.mvp_idx[0] = cu.mvp_idx[1] = sym_trunc_unary(c, cu.mvp_idx[0], models.merge_idx, 5, 6);
                 merge_motion(cu, cu.mvp_idx[0]);
@@ -1108,13 +1406,14 @@ struct TileCoder {
             // The predictor is the resolution-indexed one (index 0 without AMVR): mv = predictor + mvd (xevd_get_inter_motion, xevdm.c:885-932)
             int mvr = 0;                                             // xevdm_eco_mvr_idx (xevdm_eco.c:814-817): quarter, half, 1, 2, 4 samples
             if (sps.tool_amvr) {
-                if (enc) mvr = cu.direct ? 0 : ((cu.x >> 3) * 5 + (cu.y >> 3) * 3) % 11 % 5 * (((cu.x ^ cu.y) >> 2) & 1);      // about every second coded vector on a coarser grid
+                if (enc) mvr = (cu.direct || cu.affine) ? 0 : ((cu.x >> 3) * 5 + (cu.y >> 3) * 3) % 11 % 5 * (((cu.x ^ cu.y) >> 2) & 1);      // about every second coded vector on a coarser grid
                 mvr = sym_trunc_unary(c, mvr, models.mvr_idx, 4, 5);
             }
             cu.direct = mvr == 0 ? c.bin(cu.direct, models.merge_mode[0]) : 0;
             if (cu.direct) {
                 if (sps.tool_mmvd) cu.mmvd = c.bin(cu.mmvd, models.mmvd_flag[0]);
-                if (cu.mmvd) { code_mmvd_idx(c, cu); mmvd_motion(cu); }
+                if (cu.mmvd) { cu.affine = 0; code_mmvd_idx(c, cu); mmvd_motion(cu); }
+                else if (code_affine_merge(c, cu)) { }
                 else {
                     cu.mvp_idx[0] = cu.mvp_idx[1] = sym_trunc_unary(c, cu.mvp_idx[0], models.merge_idx, 5, 6);
                     merge_motion(cu, cu.mvp_idx[0]);
@@ -1129,14 +1428,46 @@ struct TileCoder {
                     if (!not_bi) dir = 2;
                     else dir = c.bin(dir == 1, models.inter_dir[1]) ? 1 : 0;
                 }
+                // affine inter CU (xevdm_eco.c:1649-1682): 16x16 and larger, quarter-sample vectors only; affine_mode picks 2 or 3 control points, then
+                // per list the reference, one of two predictors, and the control-point differences (all zero with affine_mvd_flag)
+                int aff = 0;
+                if (sps.tool_affine && cu.log2w >= 4 && cu.log2h >= 4 && mvr == 0) aff = c.bin(cu.affine != 0, models.affine_flag[0]);
+                if (!aff) cu.affine = 0;
+                else {
+                    cu.affine = 1 + c.bin(cu.affine == 2, models.affine_mode[0]);
+                    const int vn = cu.affine + 1;
+                    for (int l = 0; l < 2; l++) {
+                        cu.mv[l][0] = cu.mv[l][1] = 0;
+                        if (!(((dir + 1) >> l) & 1)) { cu.refi[l] = -1; memset(cu.aff_mv[l], 0, sizeof(cu.aff_mv[l])); continue; }
+                        cu.refi[l] = code_refi(c, cu.refi[l], (int)refp[l].size());
+                        cu.aff_idx[l] = c.bin(cu.aff_idx[l] != 0, models.affine_mvp_idx[0]);
+                        int16_t mvp[2][3][2];
+                        aff_amvp(cu, l, cu.refi[l], vn, mvp);
+                        int16_t (*pp)[2] = mvp[cu.aff_idx[l]];
+                        if (enc) {      // differences that reproduce the requested control points: the first one also moves the other predictors
+                            for (int d = 0; d < 2; d++) {
+                                cu.aff_mvd[l][0][d] = (int16_t)(cu.aff_mv[l][0][d] - pp[0][d]);
+                                for (int v = 1; v < vn; v++) cu.aff_mvd[l][v][d] = (int16_t)(cu.aff_mv[l][v][d] - (int16_t)(pp[v][d] + cu.aff_mvd[l][0][d]));
+                            }
+                        }
+                        int zero = 1;
+                        for (int v = 0; v < vn; v++) zero &= cu.aff_mvd[l][v][0] == 0 && cu.aff_mvd[l][v][1] == 0;
+                        zero = c.bin(zero, models.affine_mvd_flag[l]);
+                        for (int v = 0; v < vn; v++) {
+                            if (zero) cu.aff_mvd[l][v][0] = cu.aff_mvd[l][v][1] = 0; else code_mvd(c, cu.aff_mvd[l][v]);
+                            for (int d = 0; d < 2; d++) cu.aff_mv[l][v][d] = (int16_t)(pp[v][d] + cu.aff_mvd[l][v][d]);
+                            if (v == 0) for (int d = 0; d < 2; d++) { pp[1][d] = (int16_t)(pp[1][d] + cu.aff_mvd[l][0][d]); pp[2][d] = (int16_t)(pp[2][d] + cu.aff_mvd[l][0][d]); }
+                        }
+                    }
+                }
                 int bi_idx = 0;                                      // BI_NON 0, BI_NORMAL 1, BI_FL0 2, BI_FL1 3
-                if (dir == 2) {
+                if (dir == 2 && !aff) {
                     if (enc) bi_idx = 1 + ((cu.x >> 2) + (cu.y >> 2) * 3) % 7 % 3;      // a spread of the three kinds over the picture
                     const int v = bi_idx - 1;
                     if (c.bin(v == 0, models.bi_idx[0])) bi_idx = 1;
                     else bi_idx = c.bin(v == 1, models.bi_idx[1]) ? 2 : 3;
                 }
-                for (int l = 0; l < 2; l++) {
+                for (int l = 0; l < 2 && !aff; l++) {
                     if (!(((dir + 1) >> l) & 1)) { cu.refi[l] = -1; cu.mv[l][0] = cu.mv[l][1] = 0; continue; }
                     const int nref = (int)refp[l].size();
                     if (bi_idx != 2 && bi_idx != 3) {
@@ -1399,6 +1730,10 @@ struct TileParser {
         batch.cbf.push_back((uint8_t)(cu.cbf[0] | (cu.cbf[1] << 1) | (cu.cbf[2] << 2)));
         batch.ipm.push_back((uint8_t)cu.ipm); batch.ipm.push_back((uint8_t)(st.sps.tool_eipd ? cu.ipm_c : cu.ipm));      // Baseline: chroma mode = luma mode, xevd_eco.c:1154
         batch.ats.push_back((uint8_t)cu.ats); batch.ats_inter.push_back((uint8_t)cu.ats_inter); batch.dmvr.push_back((uint8_t)cu.dmvr);
+        if (st.sps.tool_affine) {      // xgpu_cu_batch.affine: 0 / 2 / 3 control points, .affine_mv[list][vertex][x/y]
+            batch.affine.push_back((uint8_t)(cu.affine ? cu.affine + 1 : 0));
+            batch.affine_mv.insert(batch.affine_mv.end(), &cu.aff_mv[0][0][0], &cu.aff_mv[0][0][0] + 12);
+        }
         batch.coef_off.push_back((uint32_t)n_coef);
         const int tu_shift = (cu.ats_inter & 15) == 0 ? 0 : (((cu.ats_inter & 15) >= 3) ? 2 : 1);      // the TU is 1/2 or 1/4 of the CU
         for (int k = 0; k < 3; k++)
@@ -1474,8 +1809,8 @@ struct xhost_parser {
             unsupported |= br.get1();                    // sps_btt_flag
             unsupported |= br.get1();                    // sps_suco_flag
             s.tool_admvp = br.get1();
-            s.tool_amvr = s.tool_hmvp = s.tool_dmvr = s.tool_mmvd = 0;
-            if (s.tool_admvp) { unsupported |= br.get1(); s.tool_amvr = br.get1(); s.tool_dmvr = br.get1(); s.tool_mmvd = br.get1(); s.tool_hmvp = br.get1(); }      // tool_affine, tool_amvr, tool_dmvr, tool_mmvd, tool_hmvp
+            s.tool_amvr = s.tool_hmvp = s.tool_dmvr = s.tool_mmvd = s.tool_affine = 0;
+            if (s.tool_admvp) { s.tool_affine = br.get1(); s.tool_amvr = br.get1(); s.tool_dmvr = br.get1(); s.tool_mmvd = br.get1(); s.tool_hmvp = br.get1(); }      // tool_affine, tool_amvr, tool_dmvr, tool_mmvd, tool_hmvp
             s.tool_eipd = br.get1();
             s.ibc = s.ibc_log_max = 0;
             if (s.tool_eipd && (s.ibc = br.get1())) { s.ibc_log_max = (int)br.ue() + 2; if (s.ibc_log_max > 7) return fail("bad SPS"); }
@@ -1654,7 +1989,7 @@ struct xhost_parser {
             Batch &m = merged;
             const size_t n = cu0[(size_t)n_tiles];
             m.x.resize(n); m.y.resize(n); m.log2w.resize(n); m.log2h.resize(n); m.pred_mode.resize(n); m.qp.resize(n * 3); m.cbf.resize(n); m.ipm.resize(n * 2);
-            m.ats.resize(n); m.ats_inter.resize(n); m.dmvr.resize(n); m.refi.resize(n * 2); m.mv.resize(n * 4); m.coef_off.resize(n);
+            m.ats.resize(n); m.ats_inter.resize(n); m.dmvr.resize(n); m.affine.resize(st.sps.tool_affine ? n : 0); m.affine_mv.resize(st.sps.tool_affine ? n * 12 : 0); m.refi.resize(n * 2); m.mv.resize(n * 4); m.coef_off.resize(n);
             m.coef.resize(cf0[(size_t)n_tiles]); m.ctu_start.resize(ct0[(size_t)n_tiles]);
             parallel_for(n_tiles, [&](int t) {
                 const Batch &b = tiles[(size_t)t]->batch;
@@ -1662,6 +1997,7 @@ struct xhost_parser {
                 auto put = [&](auto &dst, const auto &src, size_t per) { if (k) memcpy(dst.data() + o * per, src.data(), k * per * sizeof(src[0])); };
                 put(m.x, b.x, 1); put(m.y, b.y, 1); put(m.log2w, b.log2w, 1); put(m.log2h, b.log2h, 1); put(m.pred_mode, b.pred_mode, 1); put(m.qp, b.qp, 3);
                 put(m.cbf, b.cbf, 1); put(m.ipm, b.ipm, 2); put(m.ats, b.ats, 1); put(m.ats_inter, b.ats_inter, 1); put(m.dmvr, b.dmvr, 1); put(m.refi, b.refi, 2); put(m.mv, b.mv, 4);
+                if (st.sps.tool_affine) { put(m.affine, b.affine, 1); put(m.affine_mv, b.affine_mv, 12); }
                 for (size_t i = 0; i < k; i++) m.coef_off[o + i] = b.coef_off[i] + (uint32_t)cf0[(size_t)t];
                 if (tiles[(size_t)t]->n_coef) memcpy(m.coef.data() + cf0[(size_t)t], b.coef.data(), tiles[(size_t)t]->n_coef * sizeof(int16_t));
                 for (size_t i = 0; i < b.ctu_start.size(); i++) m.ctu_start[ct0[(size_t)t] + i] = b.ctu_start[i] + (uint32_t)o;
@@ -1716,6 +2052,7 @@ struct xhost_parser {
         b.pred_mode = batch.pred_mode.data(); b.refi = batch.refi.data(); b.mv = batch.mv.data(); b.qp = batch.qp.data();
         b.cbf = batch.cbf.data(); b.ipm = batch.ipm.data(); b.coef_off = batch.coef_off.data();
         if (st.sps.tool_ats) { b.ats = batch.ats.data(); b.ats_inter = batch.ats_inter.data(); }
+        if (st.sps.tool_affine) { b.affine = batch.affine.data(); b.affine_mv = batch.affine_mv.data(); }
         if (batch.coef.empty()) batch.coef.push_back(0);
         b.coef = batch.coef.data(); b.n_coef = batch.x.empty() ? 0 : n_coef;
         b.n_ctu = w_ctu * h_ctu; b.ctu_cu_start = batch.ctu_start.data();
@@ -1847,6 +2184,7 @@ struct xhost_writer {
     xhost_stream_params sp;
     Stream st;
     TileCoder coder{st};          // the tiles are written one after the other
+    bool plain_inter_seen = false; // a translational inter CU has been written (see the affine CUs in TreeWriter::node)
     std::vector<uint8_t> out;
     int n_pics = 0, last_tid = 0;
     bool headers_done = false;
@@ -1863,7 +2201,7 @@ struct xhost_writer {
         else {
             bw.put1(0); bw.put1(0);                      // btt suco
             bw.put1(sp.tool_admvp ? 1 : 0);
-            if (sp.tool_admvp) { bw.put1(0); bw.put1(sp.tool_amvr ? 1 : 0); bw.put1(sp.tool_dmvr ? 1 : 0); bw.put1(sp.tool_mmvd ? 1 : 0); bw.put1(sp.tool_hmvp ? 1 : 0); }      // affine amvr dmvr mmvd hmvp
+            if (sp.tool_admvp) { bw.put1(sp.tool_affine ? 1 : 0); bw.put1(sp.tool_amvr ? 1 : 0); bw.put1(sp.tool_dmvr ? 1 : 0); bw.put1(sp.tool_mmvd ? 1 : 0); bw.put1(sp.tool_hmvp ? 1 : 0); }      // affine amvr dmvr mmvd hmvp
             bw.put1(sp.tool_eipd ? 1 : 0);
             if (sp.tool_eipd) { bw.put1(sp.ibc_log_max_size ? 1 : 0); if (sp.ibc_log_max_size) bw.ue((uint32_t)(sp.ibc_log_max_size - 2)); }      // ibc_flag, ibc_log_max_size - 2
             bw.put1(0);                                  // cm_init
@@ -1939,6 +2277,7 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     w->sp.tool_admvp = s.profile_main && sp->tool_admvp; s.tool_admvp = w->sp.tool_admvp;
     w->sp.tool_amvr = s.tool_admvp && sp->tool_amvr; s.tool_amvr = w->sp.tool_amvr;
     w->sp.tool_hmvp = s.tool_admvp && sp->tool_hmvp; s.tool_hmvp = w->sp.tool_hmvp;
+    w->sp.tool_affine = s.tool_admvp && sp->tool_affine; s.tool_affine = w->sp.tool_affine;
     w->sp.tool_mmvd = s.tool_admvp && sp->tool_mmvd; s.tool_mmvd = w->sp.tool_mmvd;
     w->sp.tool_dmvr = s.tool_admvp && sp->tool_dmvr && !s.tool_hmvp && !s.tool_mmvd; s.tool_dmvr = w->sp.tool_dmvr;      // not with tool_hmvp (see the parser)
     w->sp.ibc_log_max_size = (s.tool_eipd && sp->ibc_log_max_size >= 2 && sp->ibc_log_max_size <= 7) ? sp->ibc_log_max_size : 0;
@@ -2081,6 +2420,19 @@ struct TreeWriter {
         cu.mvp_idx[0] = (x >> 2) & 3; cu.mvp_idx[1] = (y >> 2) & 3;   // a SKIP CU: some predictor per list
         if (st.sps.tool_admvp) cu.mvp_idx[0] = cu.mvp_idx[1] = ((x >> 2) + 2 * (y >> 2)) % 6;
         if (st.sps.tool_mmvd && ((x >> 3) + (y >> 2)) % 3 == 0) { cu.mmvd = 1; cu.mmvd_idx = ((x >> 2) * 37 + (y >> 2) * 101 + i) % 384; }      // a third of the skip / merge-mode CUs: any group, base, distance, direction      // ... or one of the six merge candidates (also of a merge-mode CU)
+        if (st.sps.tool_affine && b->affine && b->affine[i] >= 2 && (cu.mode == MODE_SKIP || cu.mode == MODE_INTER) && !cu.mmvd) {
+            // an affine CU: merge candidates of a skip / merge-mode CU (8x8 and larger), or the batch's control points coded against a predictor (16x16 and larger)
+            // (not before the stream's first translational inter CU: the reference's sub-block affine prediction reads its interpolation taps through a
+            //  process-global pointer that only the translational path switches from the Baseline table - zeros at the sixteenth-sample phases - to the
+            //  Main one, src_main/xevdm_mc.c:1914-1924; an affine CU decoded before that predicts zeros.  A decoder state, not a stream property: avoided)
+            const bool merge = cu.mode == MODE_SKIP || cu.direct;
+            if (log2s >= (merge ? 3 : 4) && w->plain_inter_seen) {
+                cu.affine = b->affine[i] - 1;
+                cu.aff_idx[0] = merge ? ((x >> 3) + (y >> 3) * 3) % 5 : (x >> 4) & 1; cu.aff_idx[1] = (y >> 4) & 1;
+                if (b->affine_mv) memcpy(cu.aff_mv, b->affine_mv + (size_t)i * 12, sizeof(cu.aff_mv));
+            }
+        }
+        if ((cu.mode == MODE_SKIP || cu.mode == MODE_INTER) && !cu.affine) w->plain_inter_seen = true;
         cu.ipm = b->ipm ? b->ipm[i * 2] % (st.sps.tool_eipd ? 33 : 5) : 0;
         cu.ipm_c = (b->ipm && st.sps.tool_eipd) ? b->ipm[i * 2 + 1] % 5 : 0;
         cu.qp = std::min(std::max((int)b->qp[i * 3] - bd_off, 0), 51);
