@@ -172,6 +172,8 @@ def golden_streams(only=()):
                                                                                inter_frac=0.9, max_refs=3, log2_sub_gop=3, bit_depth=10, skip_frac=0.3, direct_frac=0.3)),
                                 "main_mmvd_all_tools_10b": (264, 136, 17, dict(main=True, admvp=True, mmvd=True, amvr=True, hmvp=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True,
                                                                                ibc_log_max=5, inter_frac=0.9, skip_frac=0.35, direct_frac=0.3, max_refs=3, log2_sub_gop=3, bit_depth=10)),
+                                "main_dquant_area8_10b": (264, 200, 9, dict(main=True, admvp=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, inter_frac=0.8, split_prob=0.65, max_refs=2,
+                                                                            log2_sub_gop=2, bit_depth=10, qp_delta_area=8)),
                                 # sps->tool_affine: affine merge and affine inter CUs from the bitstream
                                 "main_affine_p_8b": (392, 264, 6, dict(main=True, admvp=True, affine=True, inter_frac=0.95, split_prob=0.35, skip_frac=0.3, direct_frac=0.3, max_refs=2)),
                                 "main_affine_all_tools_10b": (328, 264, 17, dict(main=True, admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, iqt=True, ats=True, addb=True, alf=True,

@@ -96,6 +96,13 @@ CONFIGS = [
                         skip_frac=0.3, direct_frac=0.3, max_refs=3, log2_sub_gop=3, bit_depth=10)),
     (392, 264, 9, dict(main=True, admvp=True, affine=True, dmvr=True, addb=True, inter_frac=0.95, split_prob=0.35, skip_frac=0.3, direct_frac=0.3, max_refs=2, log2_sub_gop=2, tiles=(2, 2, 0))),
     (264, 264, 8, dict(main=True, admvp=True, affine=True, affine_frac=0.9, inter_frac=1.0, split_prob=0.25, skip_frac=0.3, direct_frac=0.3, max_refs=4)),
+    # sps->dquant_flag: one QP delta per quantisation group of pps.cu_qp_delta_area samples (8x8 ... 64x64; an odd area never matches a square node)
+    (264, 200, 5, dict(main=True, iqt=True, qp_delta_area=6, split_prob=0.7, inter_frac=0.7)),
+    (264, 200, 5, dict(main=True, iqt=True, qp_delta_area=10, split_prob=0.7, inter_frac=0.7)),
+    (264, 200, 5, dict(main=True, iqt=True, qp_delta_area=7, split_prob=0.7, inter_frac=0.7)),
+    (328, 264, 9, dict(main=True, admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, inter_frac=0.9, split_prob=0.6,
+                       skip_frac=0.3, direct_frac=0.3, max_refs=3, log2_sub_gop=2, bit_depth=10, qp_delta_area=8)),
+    (392, 264, 5, dict(main=True, iqt=True, addb=True, tiles=(2, 2, 0), qp_delta_area=12, split_prob=0.7)),
     # several tiles per picture (PPS grid uniform / explicit, one slice with entry points): every tile its own arithmetic-coder run, no neighbour
     # across a tile border (intra samples, HTDF border, motion candidates, most probable modes), the history reset per tile CTU row, deblocking with
     # and without loop_filter_across_tiles, the ALF windows ending at the tile (mirrored / replicated)

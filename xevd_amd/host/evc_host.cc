@@ -231,12 +231,13 @@ struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, lo
              int tool_mmvd = 0;                      // sps->tool_mmvd: merge with vector difference (a base candidate plus one of 32 offsets)
              int tool_dmvr = 0;                      // sps->tool_dmvr: merge-mode motion is refined by the backend (no syntax of its own)
              int tool_amvr = 0, tool_hmvp = 0;       // sub-tools of tool_admvp: adaptive vector resolution (mvr_idx), history-based candidates
+             int dquant = 0;                         // sps->dquant_flag (Main): QP deltas per quantisation group of pps.cu_qp_delta_area instead of per coded CU
              int tool_affine = 0;                    // sps->tool_affine: affine merge / affine inter CUs (4- or 6-parameter models from 2 / 3 control points)
              int tool_admvp = 0;                     // sps->tool_admvp: merge / resolution-indexed predictors instead of the Baseline candidate lists, 8-tap MC tables
              int ibc = 0, ibc_log_max = 0;            // sps->ibc_flag, sps->ibc_log_max_size (log2 of the largest IBC CU; xevdm_eco.c:1890-1898)
              int crop[4] = { 0, 0, 0, 0 };            // picture_crop_left / right / top / bottom_offset (xevd_eco.c:1349-1357), as xevd_pull reports them
              bool cqt = false; int8_t cq[2][96] = { { 0 } }; };      // chroma QP mapping tables signalled in the SPS: [c][qp + 6*(bd_c-8)], qp = -6*(bd_c-8) .. 57
-struct Pps { int constrained_intra = 0, cu_qp_delta = 0, dra_on = 0, dra_aps_id = 0;
+struct Pps { int constrained_intra = 0, cu_qp_delta = 0, qp_delta_area = 6, dra_on = 0, dra_aps_id = 0;      // qp_delta_area: log2 of the group's sample count (6 = 8x8)
              // tiles (xevdm_eco_pps, xevdm_eco.c:2019-2052): a grid of CTU columns x rows, uniform or with explicit sizes
              int tile_cols = 1, tile_rows = 1, tile_uniform = 1, across_tiles = 0, offset_bits = 1, id_bits = 1, arbitrary_slices = 0;
              int tile_col_w[XGPU_MAX_TILE_COLS] = { 0 }, tile_row_h[XGPU_MAX_TILE_ROWS] = { 0 }; };
@@ -300,6 +301,7 @@ struct Cu {
     int ats_inter;                   // ats_inter_info: idx | pos << 4
     int mmvd, mmvd_idx;              // mmvd_flag; group << 7 | base candidate << 5 | distance << 2 | direction
     int dmvr;                        // tool_dmvr and a skip / merge-mode CU: mcore->dmvr_enable (xevdm.c:1272-1288)
+    int qp_code;                     // core->cu_qp_delta_code (sps->dquant_flag): 0 - , 1 a CU of at least a quantisation group, 2 a CU inside a group
     int affine;                      // mcore->affine_flag: 0 translational, 1 / 2 = 2 / 3 control points (4- / 6-parameter model)
     int16_t aff_mv[2][3][2];         // mcore->affine_mv[list][vertex][x/y]: top-left, top-right, bottom-left control-point vectors
     int aff_idx[2];                  // affine merge index ([0]) / affine predictor index per list
@@ -642,6 +644,7 @@ struct TileCoder {
     const std::vector<uint16_t> (&scan)[6][6];
     Models models;
     int qp_prev = 0;
+    int qp_coded = 0;                // core->cu_qp_delta_is_coded: the current quantisation group has sent its delta
     explicit TileCoder(Stream &s) : sps(s.sps), pps(s.pps), sh(s.sh), pic(s.pic), refp(s.refp), poc(s.poc), scan(s.scan) { history_reset(); }
 
     // motion vector predictor candidates of one list (xevd_get_motion, xevd_util.c:469-515; availability xevd_get_avail_inter :632-687):
@@ -1597,7 +1600,11 @@ struct TileCoder {
             cu.cbf[0] = c.bin(cu.cbf[0], models.cbf_luma[0]);
         }
         // QP (xevd_eco.c:640-668, xevd_eco_dqp :460-479): a delta only when the CU has coefficients
-        if (!all_zero && pps.cu_qp_delta && (cu.cbf[0] || cu.cbf[1] || cu.cbf[2])) {
+        // sps->dquant_flag (Main; xevdm_eco.c:882-897): one delta per quantisation group - a CU of at least the group size sends it when it has
+        // coefficients (code 1), the first CU that gets this far inside a group of smaller CUs sends it in any case (code 2), the others take the predictor
+        const bool any_cbf = cu.cbf[0] || cu.cbf[1] || cu.cbf[2];
+        const bool qp_here = sps.profile_main && sps.dquant ? ((cu.qp_code == 1 && !qp_coded && any_cbf) || (cu.qp_code == 2 && !qp_coded)) : any_cbf;
+        if (!all_zero && pps.cu_qp_delta && qp_here) {
             int dqp = 0;
             if (enc) { dqp = cu.qp - qp_prev; while (dqp > 25) dqp -= 52; while (dqp < -26) dqp += 52; }
             const int a = sym_unary(c, dqp < 0 ? -dqp : dqp, models.dqp, 1);
@@ -1606,6 +1613,7 @@ struct TileCoder {
             dqp = s ? -a : a;
             cu.qp = (qp_prev + dqp + 52) % 52;
             qp_prev = cu.qp;
+            qp_coded = 1;
         } else cu.qp = qp_prev;
         if (all_zero) return;
         // Main, tool_ats (xevdm_eco_coef, xevdm_eco.c:902-934): transform selection of intra luma blocks up to 32x32, sub-block
@@ -1658,6 +1666,17 @@ static void write_nal(std::vector<uint8_t> &out, int nut, int tid, const BitWrit
 }   // namespace
 
 // =============================================================================================================== parser
+// sps->dquant_flag: where a quantisation group starts in the split tree (xevd_entropy_decode_tree, src_main/xevdm.c:1739-1759) - at a leaf of at least
+// pps.cu_qp_delta_area samples (code 1: the delta goes with the CU's coefficients), or at the split node of exactly that size (code 2: the first CU below it
+// that reaches its QP syntax sends the delta).  -> the code for the node's children / the leaf
+static int qp_group(const Stream &st, TileCoder &tc, int split, int log2s, int qp_code)
+{
+    if (!(st.pps.cu_qp_delta && st.sps.dquant && st.sps.profile_main)) return qp_code;
+    if (!split && 2 * log2s >= st.pps.qp_delta_area && qp_code != 2) { tc.qp_coded = 0; return log2s == 7 ? 2 : 1; }
+    if (2 * log2s == st.pps.qp_delta_area && qp_code != 2) { tc.qp_coded = 0; return 2; }
+    return qp_code;
+}
+
 // One tile of a picture being parsed: its coder state, its share of the batch, its scratch blocks.  Objects are kept between pictures (the vectors keep
 // their capacity); with several tiles and xhost_parser_set_threads() > 1 they run on different threads.
 struct TileParser {
@@ -1695,23 +1714,24 @@ struct TileParser {
         if (dec.tile_end() != 1) return fail("missing end-of-tile flag");
         return XGPU_OK;
     }
-    int parse_tree(Dec &dec, int x, int y, int log2s)
+    int parse_tree(Dec &dec, int x, int y, int log2s, int qp_code = 0)
     {
         const int s = 1 << log2s;
         int split = 0;
         if (s > 4 && !(s < 8)) split = dec.bin(0, tc.models.split[0]);
+        qp_code = qp_group(st, tc, split, log2s, qp_code);
         if (split) {
             const int h = s >> 1;
             for (int i = 0; i < 4; i++) {
                 const int nx = x + (i & 1) * h, ny = y + (i >> 1) * h;
-                if (nx < st.sps.width && ny < st.sps.height) { const int rc = parse_tree(dec, nx, ny, log2s - 1); if (rc != XGPU_OK) return rc; }
+                if (nx < st.sps.width && ny < st.sps.height) { const int rc = parse_tree(dec, nx, ny, log2s - 1, qp_code); if (rc != XGPU_OK) return rc; }
             }
             return XGPU_OK;
         }
         if (x + s > st.sps.width || y + s > st.sps.height) return fail("a CU crosses the picture border");
         Cu cu;
         memset(&cu, 0, sizeof(cu));
-        cu.x = x; cu.y = y; cu.log2w = cu.log2h = log2s;
+        cu.x = x; cu.y = y; cu.log2w = cu.log2h = log2s; cu.qp_code = qp_code;
         int16_t *coef[3] = { blk[0].data(), blk[1].data(), blk[2].data() };
         memset(coef[0], 0, sizeof(int16_t) << (2 * log2s));
         memset(coef[1], 0, sizeof(int16_t) << (2 * log2s - 2));
@@ -1822,7 +1842,7 @@ struct xhost_parser {
             s.tool_htdf = br.get1();                     // no syntax of its own: the backend filters with the slice QP (xevdm.c:1381-1392)
             rpl = br.get1(); pocs = br.get1();
             unsupported |= rpl | pocs;
-            unsupported |= br.get1();                    // dquant_flag: the Main decoder then codes QP deltas per cu_qp_delta_area (xevdm_eco.c), not per CU
+            s.dquant = br.get1();                        // dquant_flag: QP deltas per quantisation group of pps.cu_qp_delta_area (xevdm.c:1739-1759, xevdm_eco.c:882-897)
             s.tool_dra = br.get1();
         }
         // tool_dmvr with tool_hmvp: xevdm_set_dec_info ends by copying map_mv[first SCU] - the REFINED vector of the CU's first sub-block - back into
@@ -1905,7 +1925,8 @@ struct xhost_parser {
         q.arbitrary_slices = br.get1();                  // arbitrary_slice_present_flag
         st.pps.constrained_intra = br.get1();
         st.pps.cu_qp_delta = br.get1();
-        if (st.pps.cu_qp_delta) br.ue();                 // cu_qp_delta_area
+        st.pps.qp_delta_area = 6;
+        if (st.pps.cu_qp_delta) { st.pps.qp_delta_area = (int)br.ue() + 6; if (st.pps.qp_delta_area > 14) return fail("bad PPS: cu_qp_delta_area"); }
         if (br.overrun) return fail("bad PPS");
         st.have_pps = true;
         return XGPU_OK;
@@ -2210,7 +2231,7 @@ struct xhost_writer {
             bw.put1(sp.tool_addb ? 1 : 0);
             bw.put1(sp.tool_alf ? 1 : 0);
             bw.put1(sp.tool_htdf ? 1 : 0);
-            for (int i = 0; i < 3; i++) bw.put1(0);      // rpl pocs dquant
+            bw.put1(0); bw.put1(0); bw.put1(st.sps.dquant);      // rpl pocs dquant
             bw.put1(sp.tool_dra ? 1 : 0);
         }
         bw.ue((uint32_t)sp.log2_sub_gop_length);
@@ -2252,7 +2273,7 @@ struct xhost_writer {
         bw.put1(0);                                      // arbitrary_slice_present
         bw.put1(0);                                      // constrained_intra_pred_flag
         bw.put1(sp.cu_qp_delta ? 1 : 0);
-        if (sp.cu_qp_delta) bw.ue(0);
+        if (sp.cu_qp_delta) bw.ue((uint32_t)(st.pps.qp_delta_area - 6));      // cu_qp_delta_area - 6
         bw.align_zero();
         write_nal(out, NUT_PPS, 0, bw);
     }
@@ -2296,6 +2317,9 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
         w->sp.tile_cols = q.tile_cols; w->sp.tile_rows = q.tile_rows;
     }
     w->st.pps.cu_qp_delta = sp->cu_qp_delta;
+    // Main: sps->dquant_flag with quantisation groups of 2^cu_qp_delta_area samples (6 = 8x8 ... 12 = 64x64); 0 = off (a delta per coded CU)
+    s.dquant = (s.profile_main && sp->cu_qp_delta && sp->cu_qp_delta_area >= 6 && sp->cu_qp_delta_area <= 13) ? 1 : 0;
+    w->st.pps.qp_delta_area = s.dquant ? sp->cu_qp_delta_area : 6;
     return w;
 }
 extern "C" void xhost_writer_close(xhost_writer *w) { delete w; }
@@ -2384,7 +2408,7 @@ struct TreeWriter {
     std::vector<int> leaf;        // CU index by SCU position of its top-left corner, -1 elsewhere
     int bd_off;
     int error = 0;
-    void node(int x, int y, int log2s)
+    void node(int x, int y, int log2s, int qp_code = 0)
     {
         Stream &st = w->st;
         TileCoder &tcd = w->coder;
@@ -2393,17 +2417,18 @@ struct TreeWriter {
         const bool is_leaf = i >= 0 && b->log2w[i] == log2s;
         if (s >= 8) enc->bin(!is_leaf, tcd.models.split[0]);
         else if (!is_leaf) { error = 1; return; }
+        qp_code = qp_group(st, tcd, !is_leaf, log2s, qp_code);
         if (!is_leaf) {
             const int h = s >> 1;
             for (int q = 0; q < 4; q++) {
                 const int nx = x + (q & 1) * h, ny = y + (q >> 1) * h;
-                if (nx < st.sps.width && ny < st.sps.height) node(nx, ny, log2s - 1);
+                if (nx < st.sps.width && ny < st.sps.height) node(nx, ny, log2s - 1, qp_code);
             }
             return;
         }
         Cu cu;
         memset(&cu, 0, sizeof(cu));
-        cu.x = x; cu.y = y; cu.log2w = cu.log2h = log2s;
+        cu.x = x; cu.y = y; cu.log2w = cu.log2h = log2s; cu.qp_code = qp_code;
         cu.mode = b->pred_mode[i] == XGPU_MODE_INTRA ? MODE_INTRA : (b->pred_mode[i] == XGPU_MODE_SKIP ? MODE_SKIP : MODE_INTER);
         const bool ibc = b->pred_mode[i] == XGPU_MODE_IBC && st.sps.ibc && log2s <= st.sps.ibc_log_max;
         if (st.sh.type == XHOST_SLICE_I || (st.sps.tool_admvp && log2s == 2)) cu.mode = MODE_INTRA;
