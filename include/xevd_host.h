@@ -21,8 +21,9 @@
  * bi_idx / mmvd_flag + mmvd data syntax (xevdm_eco.c:767-812,1519-1726), merge with vector difference (src_main/xevdm_util.c:191-592,4682-4716), merge candidates incl. the temporal and history ones (src_main/xevdm_util.c:594-1391,3729-3818), the resolution-indexed
  * predictor (:750-951), intra-only 4x4 CUs; tool_dmvr needs the backend's refined vectors back per picture (xhost_parser_set_dmvr_mvs) and is refused
  * together with tool_hmvp or tool_mmvd.  tool_affine (affine merge / affine inter CUs, xevdm_util.c:2145-3187) is parsed too.
- * Not parsed: sps_btt_flag / sps_suco_flag (split syntax), tool_cm_init (and ADCC),
- * tool_rpl / tool_pocs.  dquant_flag (QP deltas per quantisation group) is parsed.  SPS chroma QP mapping tables and cropping offsets are parsed, a VUI is skipped; 4:2:0, one slice per picture (with all of its
+ * Not parsed: sps_btt_flag / sps_suco_flag (split syntax), tool_cm_init (and ADCC).
+ * dquant_flag (QP deltas per quantisation group), tool_rpl (reference picture lists in SPS / slice headers, RPL-based marking) and tool_pocs
+ * (POC from poc_lsb) are parsed.  SPS chroma QP mapping tables and cropping offsets are parsed, a VUI is skipped; 4:2:0, one slice per picture (with all of its
  * tiles - uniform or explicit PPS tile grids, entry points in the slice header; explicit tile ids and arbitrary slices are refused), I / P / B slices incl. temporal layers (hierarchical sub-GOPs).
  * Conventions as xevd_hip.h: 0 / negative XEVD_ERR_* codes, nothing throws, one object per stream.
  */
@@ -136,6 +137,9 @@ typedef struct xhost_stream_params {
                                               of 16x16 and larger code their control-point vectors `affine_mv` against one of two predictors (xevdm_eco.c:1528-1537, 1649-1682) */
     int cu_qp_delta_area;                  /* Main with cu_qp_delta: 0 = a QP delta per coded CU; 6..13 = sps->dquant_flag with quantisation groups of 2^n samples
                                               (pps.cu_qp_delta_area; 6 = 8x8): one delta per group (xevdm.c:1739-1759, xevdm_eco.c:882-897)                    */
+    int tool_rpl, tool_pocs;               /* Main: sps->tool_rpl - every slice header carries reference picture lists (leading entries = the lists the sub-GOP scheme
+                                              builds, tail = the other pictures that scheme still keeps) and the list sizes; sps->tool_pocs - poc_lsb (8 bits) per slice */
+    int rpl_in_sps;                        /* with tool_rpl, low delay and at least 2 references: RPL candidates in the SPS, picked by index where they match */
 } xhost_stream_params;
 
 /* ALF parameter set as it is coded in an APS NAL unit (XEVD_ALF_SLICE_PARAM after xevdm_eco_alf_aps_param) */

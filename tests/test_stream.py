@@ -96,6 +96,17 @@ CONFIGS = [
                         skip_frac=0.3, direct_frac=0.3, max_refs=3, log2_sub_gop=3, bit_depth=10)),
     (392, 264, 9, dict(main=True, admvp=True, affine=True, dmvr=True, addb=True, inter_frac=0.95, split_prob=0.35, skip_frac=0.3, direct_frac=0.3, max_refs=2, log2_sub_gop=2, tiles=(2, 2, 0))),
     (264, 264, 8, dict(main=True, admvp=True, affine=True, affine_frac=0.9, inter_frac=1.0, split_prob=0.25, skip_frac=0.3, direct_frac=0.3, max_refs=4)),
+    # sps->tool_rpl / tool_pocs: POC from poc_lsb, reference lists and marking from RPLs (explicit in the slice header or candidates of the SPS by index),
+    # list sizes from the override - low delay, hierarchical B, IDR periods, with the motion tools that read the lists (TMVP, merge, DMVR) and tiles
+    (136, 72, 5, dict(main=True, rpl=True, max_refs=2)),
+    (136, 72, 5, dict(main=True, pocs=True, max_refs=2)),
+    (136, 136, 11, dict(main=True, rpl=True, pocs=True, max_refs=4, idr_period=4, skip_frac=0.4)),
+    (200, 136, 17, dict(main=True, rpl=True, max_refs=3, log2_sub_gop=3)),
+    (200, 136, 10, dict(main=True, pocs=True, admvp=True, max_refs=2, log2_sub_gop=2, idr_period=5)),
+    (200, 136, 12, dict(main=True, rpl=True, pocs=True, admvp=True, hmvp=True, max_refs=4, rpl_in_sps=True, idr_period=7)),
+    (264, 136, 17, dict(main=True, rpl=True, pocs=True, admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, inter_frac=0.9,
+                        skip_frac=0.3, direct_frac=0.3, max_refs=3, log2_sub_gop=3, bit_depth=10, qp_delta_area=8)),
+    (392, 264, 9, dict(main=True, rpl=True, admvp=True, dmvr=True, addb=True, inter_frac=0.95, skip_frac=0.3, direct_frac=0.3, max_refs=2, log2_sub_gop=2, tiles=(2, 2, 0))),
     # sps->dquant_flag: one QP delta per quantisation group of pps.cu_qp_delta_area samples (8x8 ... 64x64; an odd area never matches a square node)
     (264, 200, 5, dict(main=True, iqt=True, qp_delta_area=6, split_prob=0.7, inter_frac=0.7)),
     (264, 200, 5, dict(main=True, iqt=True, qp_delta_area=10, split_prob=0.7, inter_frac=0.7)),

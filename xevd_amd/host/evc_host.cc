@@ -180,6 +180,31 @@ template <class C> static int sym_bits_ep(C &c, int v, int n)                   
     return r;
 }
 
+struct Rpl { int n = 0, active = 0; int ref[XGPU_MAX_REFS + 4] = { 0 }; };      // XEVD_RPL: POC differences cur - ref of the list's pictures (the first `active` are indexed by refi)
+// ref_pic_list_struct (xevdm_eco_rlp, src_main/xevdm_eco.c:1820-1844): entry count, then per entry the POC difference to the previous entry with a sign
+static bool read_rpl(BitReader &br, Rpl &r)
+{
+    r = Rpl();
+    r.n = (int)br.ue();
+    if (br.overrun || r.n > XGPU_MAX_REFS) return false;
+    int sign = 0;                                             // the reference keeps the last sign flag across entries whose difference is zero
+    for (int i = 0; i < r.n; i++) {
+        const int d = (int)br.ue();
+        if (d != 0) sign = br.get1();
+        r.ref[i] = (i ? r.ref[i - 1] : 0) + d * (1 - 2 * sign);
+    }
+    return !br.overrun;
+}
+static void write_rpl(BitWriter &bw, const Rpl &r)
+{
+    bw.ue((uint32_t)r.n);
+    for (int i = 0; i < r.n; i++) {
+        const int d = r.ref[i] - (i ? r.ref[i - 1] : 0);
+        bw.ue((uint32_t)(d < 0 ? -d : d));
+        if (d != 0) bw.put1(d < 0);
+    }
+}
+
 struct Models {
     Model split[1], run[24], last[2], level[24], cbf_luma[1], cbf_cb[1], cbf_cr[1], cbf_all[1], pred_mode[3], direct[1], inter_dir[2],
           intra_dir[2], mvp_idx[3], mvd[1], refi[2], dqp[1], skip[2],
@@ -231,18 +256,21 @@ struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, lo
              int tool_mmvd = 0;                      // sps->tool_mmvd: merge with vector difference (a base candidate plus one of 32 offsets)
              int tool_dmvr = 0;                      // sps->tool_dmvr: merge-mode motion is refined by the backend (no syntax of its own)
              int tool_amvr = 0, tool_hmvp = 0;       // sub-tools of tool_admvp: adaptive vector resolution (mvr_idx), history-based candidates
+             int tool_rpl = 0, tool_pocs = 0, poc_lsb_bits = 4;      // sps->tool_rpl: reference lists and marking from signalled RPLs; tool_pocs: POC from poc_lsb in the slice header
+             int n_rpl[2] = { 0, 0 }; Rpl rpls[2][32];               // RPL candidates of the SPS (sps->rpls_l0 / rpls_l1)
              int dquant = 0;                         // sps->dquant_flag (Main): QP deltas per quantisation group of pps.cu_qp_delta_area instead of per coded CU
              int tool_affine = 0;                    // sps->tool_affine: affine merge / affine inter CUs (4- or 6-parameter models from 2 / 3 control points)
              int tool_admvp = 0;                     // sps->tool_admvp: merge / resolution-indexed predictors instead of the Baseline candidate lists, 8-tap MC tables
              int ibc = 0, ibc_log_max = 0;            // sps->ibc_flag, sps->ibc_log_max_size (log2 of the largest IBC CU; xevdm_eco.c:1890-1898)
              int crop[4] = { 0, 0, 0, 0 };            // picture_crop_left / right / top / bottom_offset (xevd_eco.c:1349-1357), as xevd_pull reports them
              bool cqt = false; int8_t cq[2][96] = { { 0 } }; };      // chroma QP mapping tables signalled in the SPS: [c][qp + 6*(bd_c-8)], qp = -6*(bd_c-8) .. 57
-struct Pps { int constrained_intra = 0, cu_qp_delta = 0, qp_delta_area = 6, dra_on = 0, dra_aps_id = 0;      // qp_delta_area: log2 of the group's sample count (6 = 8x8)
+struct Pps { int rpl1_idx_present = 0, default_active[2] = { 1, 1 }; int constrained_intra = 0, cu_qp_delta = 0, qp_delta_area = 6, dra_on = 0, dra_aps_id = 0;      // qp_delta_area: log2 of the group's sample count (6 = 8x8)
              // tiles (xevdm_eco_pps, xevdm_eco.c:2019-2052): a grid of CTU columns x rows, uniform or with explicit sizes
              int tile_cols = 1, tile_rows = 1, tile_uniform = 1, across_tiles = 0, offset_bits = 1, id_bits = 1, arbitrary_slices = 0;
              int tile_col_w[XGPU_MAX_TILE_COLS] = { 0 }, tile_row_h[XGPU_MAX_TILE_ROWS] = { 0 }; };
 struct Slice { int type = XHOST_SLICE_I, qp = 32, qp_u_offset = 0, qp_v_offset = 0, deblock = 1, alpha_off = 0, beta_off = 0;
                int alf_on = 0, aps_id_y = 0, aps_id_ch = 0, alf_chroma_idc = 0, alf_ctb_map = 0;
+               int poc_lsb = 0; Rpl rpl[2];                                                // tool_pocs / tool_rpl (xevdm_eco.c:2658-2733)
                int mmvd_group = 0;                                                         // mmvd_group_enable_flag (tool_mmvd, xevdm_eco.c:2592-2599)
                int tmvp_assigned = 0, col_list = 0, col_src_list = 0, col_ref = 0; };      // temporal_mvp_asigned_flag + collocated_* (tool_admvp, xevdm_eco.c:2748-2760)
 
@@ -549,6 +577,17 @@ struct Stream {          // everything both directions share
     void derive_poc(bool idr, int t)
     {
         tid = t;
+        if (sps.tool_pocs && !enc_side) {
+            // POC from the slice header's poc_lsb (xevdm.c:3044-3074): msb from the previous temporal-layer-0 picture (an IDR picture does not reset that one)
+            if (idr) { poc = 0; return; }
+            const int max_lsb = 1 << sps.poc_lsb_bits, prev_lsb = prev_poc & (max_lsb - 1), prev_msb = prev_poc - prev_lsb;
+            int msb = prev_msb;
+            if (sh.poc_lsb < prev_lsb && prev_lsb - sh.poc_lsb >= max_lsb / 2) msb = prev_msb + max_lsb;
+            else if (sh.poc_lsb > prev_lsb && sh.poc_lsb - prev_lsb > max_lsb / 2) msb = prev_msb - max_lsb;
+            poc = msb + sh.poc_lsb;
+            if (t == 0) prev_poc = poc;
+            return;
+        }
         if (idr) { poc = 0; prev_doc_offset = -1; prev_poc = 0; return; }
         const int sub = 1 << sps.log2_sub_gop;
         if (t == 0) { poc = prev_poc + sub; prev_doc_offset = 0; prev_poc = poc; return; }
@@ -559,13 +598,36 @@ struct Stream {          // everything both directions share
         poc = prev_poc + (int)(sub * ((2.0 * doc + 1) / (double)(1 << t) - 2));
         prev_doc_offset = doc;
     }
-    bool is_ref_picture() const { return tid == 0 || tid < sps.log2_sub_gop; }      // ctx->slice_ref_flag, xevd.c:1853
+    bool enc_side = false;               // the writer: POCs, marking and lists by the sub-GOP scheme (it then DESCRIBES them with poc_lsb / RPLs when those tools are on)
+    bool is_ref_picture() const { return (sps.tool_pocs && !enc_side) || tid == 0 || tid < sps.log2_sub_gop; }      // ctx->slice_ref_flag, xevd.c:1853 (tool_pocs: every picture, xevdm.c:3076)
+    std::vector<int> rpl_released;       // POCs the current slice's RPLs dropped from the DPB (reported with the picture)
 
     // reference lists without RPL (xevd_picman_refp_init, xevd_picman.c:291-437) over the reference pictures by descending POC
-    void build_ref_lists()
+    bool build_ref_lists(bool idr)
     {
         refp[0].clear(); refp[1].clear();
-        if (sh.type == XHOST_SLICE_I) return;
+        rpl_released.clear();
+        if (sps.tool_rpl && !enc_side) {
+            // marking (xevdm_picman_refpic_marking, xevdm_picman.c:542-588): a reference picture that neither list of THIS slice names (active or not) is
+            // dropped; lists (xevdm_picman_refp_rpl_based_init :315-368): entry i = the picture with POC cur - ref[i], which must be there
+            if (!idr)
+                for (size_t i = 0; i < dpb.size();) {
+                    bool named = false;
+                    for (int l = 0; l < 2 && !named; l++) for (int j = 0; j < sh.rpl[l].n && !named; j++) named = dpb[i].poc == poc - sh.rpl[l].ref[j];
+                    if (named) i++; else { rpl_released.push_back(dpb[i].poc); dpb.erase(dpb.begin() + (long)i); }
+                }
+            if (sh.type == XHOST_SLICE_I) return true;
+            for (int l = 0; l < (sh.type == XHOST_SLICE_B ? 2 : 1); l++)
+                for (int i = 0; i < sh.rpl[l].active; i++) {
+                    if (i >= sh.rpl[l].n || i >= XGPU_MAX_REFS) return false;
+                    const RefPic *hit = nullptr;
+                    for (const RefPic &r : dpb) if (r.poc == poc - sh.rpl[l].ref[i]) { hit = &r; break; }
+                    if (!hit) return false;
+                    refp[l].push_back(hit);
+                }
+            return true;
+        }
+        if (sh.type == XHOST_SLICE_I) return true;
         std::vector<const RefPic *> ref;
         for (const RefPic &r : dpb) ref.push_back(&r);
         std::stable_sort(ref.begin(), ref.end(), [](const RefPic *a, const RefPic *b) { return a->poc > b->poc; });
@@ -583,7 +645,7 @@ struct Stream {          // everything both directions share
                     if (r->poc < poc) refp[0].push_back(r);
                 }
             }
-            return;
+            return true;
         }
         // B: nearest pictures first, each step allowed one temporal layer further down than the picture just taken
         for (int l = 0; l < 2; l++) {
@@ -597,6 +659,7 @@ struct Stream {          // everything both directions share
                 }
             }
         }
+        return true;
     }
     // picture marking + insertion (xevd_picman_put_pic / pic_marking_no_rpl, xevd_picman.c:68-110,462-509); released POCs reported
     void store_picture(bool idr, std::vector<int> &released)
@@ -607,8 +670,10 @@ struct Stream {          // everything both directions share
             stale_list0_poc = refp[0].empty() ? 0 : refp[0][0]->poc;
             for (size_t i = 0; i < refp[0].size() && i < 16; i++) stale_list_poc[i] = refp[0][i]->poc;
         }
+        released.insert(released.end(), rpl_released.begin(), rpl_released.end());
+        rpl_released.clear();
         if (idr) { for (const RefPic &r : dpb) released.push_back(r.poc); dpb.clear(); }
-        else if (tid == 0) {
+        else if (tid == 0 && (!sps.tool_rpl || enc_side)) {            // sliding-window marking only without RPLs (xevdm_picman_put_pic, xevdm_picman.c:595-606)
             const int gap = 1 << sps.log2_ref_gap;
             for (size_t i = 0; i < dpb.size();) {
                 if (dpb[i].tid > 0 || (i > 0 && gap > 0 && dpb[i].poc % gap != 0)) { released.push_back(dpb[i].poc); dpb.erase(dpb.begin() + (long)i); }
@@ -1841,7 +1906,6 @@ struct xhost_parser {
             s.tool_alf = br.get1();
             s.tool_htdf = br.get1();                     // no syntax of its own: the backend filters with the slice QP (xevdm.c:1381-1392)
             rpl = br.get1(); pocs = br.get1();
-            unsupported |= rpl | pocs;
             s.dquant = br.get1();                        // dquant_flag: QP deltas per quantisation group of pps.cu_qp_delta_area (xevdm.c:1739-1759, xevdm_eco.c:882-897)
             s.tool_dra = br.get1();
         }
@@ -1852,11 +1916,27 @@ struct xhost_parser {
         // unrefined map, xevdm_util.c:246-247): the same dependency
         if (s.tool_dmvr && s.tool_mmvd) return fail("tool_dmvr together with tool_mmvd: the base candidates depend on refined vectors inside the picture (not supported)");
         if (s.tool_dmvr && s.tool_hmvp) return fail("tool_dmvr together with tool_hmvp: the history candidates depend on refined vectors inside the picture (not supported)");
-        if (unsupported) return fail("the stream uses tools this front end does not parse (btt, suco, affine, cm_init, rpl, pocs, dquant in Main)");
-        s.log2_sub_gop = (int)br.ue();                   // tool_rpl = tool_pocs = 0
-        if (s.log2_sub_gop == 0) s.log2_ref_gap = (int)br.ue();
-        if (s.log2_sub_gop > 5) return fail("bad SPS");
-        s.max_num_ref_pics = (int)br.ue();
+        if (unsupported) return fail("the stream uses tools this front end does not parse (sps_btt_flag, sps_suco_flag, tool_cm_init)");
+        // xevdm_eco.c:1920-1961: POC lsb width (tool_pocs), the sub-GOP description unless both tools are on, and either the sliding-window size or the RPL candidates
+        s.tool_rpl = rpl; s.tool_pocs = pocs;
+        s.log2_sub_gop = s.log2_ref_gap = 0;
+        if (pocs) { s.poc_lsb_bits = (int)br.ue() + 4; if (s.poc_lsb_bits > 16) return fail("bad SPS: log2_max_pic_order_cnt_lsb"); }
+        if (!rpl || !pocs) {
+            s.log2_sub_gop = (int)br.ue();
+            if (s.log2_sub_gop == 0) s.log2_ref_gap = (int)br.ue();
+            if (s.log2_sub_gop > 5) return fail("bad SPS");
+        }
+        if (!rpl) s.max_num_ref_pics = (int)br.ue();
+        else {
+            s.max_num_ref_pics = std::min((int)br.ue() + 1, XGPU_MAX_REFS);      // sps_max_dec_pic_buffering_minus1
+            br.get1();                                                          // long_term_ref_pics_flag (no syntax of its own in this decoder)
+            if (br.get1()) return fail("rpl1_same_as_rpl0_flag is not supported (nor by the reference)");
+            for (int l = 0; l < 2; l++) {
+                s.n_rpl[l] = (int)br.ue();
+                if (br.overrun || s.n_rpl[l] > 32) return fail("bad SPS: num_ref_pic_lists_in_sps");
+                for (int i = 0; i < s.n_rpl[l]; i++) if (!read_rpl(br, s.rpls[l][i])) return fail("bad SPS: reference picture list");
+            }
+        }
         s.crop[0] = s.crop[1] = s.crop[2] = s.crop[3] = 0;
         if (br.get1()) for (int i = 0; i < 4; i++) s.crop[i] = (int)br.ue();      // left, right, top, bottom (handed to the caller's output stage)
         s.cqt = br.get1() != 0;
@@ -1901,8 +1981,10 @@ struct xhost_parser {
     }
     int parse_pps(BitReader &br)
     {
-        br.ue(); br.ue(); br.ue(); br.ue(); br.ue();     // pps id, sps id, num_ref_idx_default_active_minus1[2], additional_lt_poc_lsb_len
-        br.get1();                                       // rpl1_idx_present_flag
+        br.ue(); br.ue();                                // pps id, sps id
+        st.pps.default_active[0] = (int)br.ue() + 1; st.pps.default_active[1] = (int)br.ue() + 1;      // num_ref_idx_default_active_minus1
+        br.ue();                                         // additional_lt_poc_lsb_len
+        st.pps.rpl1_idx_present = br.get1();
         Pps &q = st.pps;
         q.tile_cols = q.tile_rows = q.tile_uniform = 1; q.across_tiles = 0;      // one tile: the flag is not sent and reads as 0
         if (!br.get1()) {                                // single_tile_in_pic_flag == 0 (xevdm_eco.c:2021-2039)
@@ -1960,7 +2042,26 @@ struct xhost_parser {
                 if (sh.alf_chroma_idc) sh.aps_id_ch = (int)br.get(5);
             }
         }
-        if (sh.type != XHOST_SLICE_I && br.get1()) { br.ue(); if (sh.type == XHOST_SLICE_B) br.ue(); }      // num_ref_idx_active override (unused by the Baseline decoder, xevd_eco.c:409)
+        sh.poc_lsb = 0; sh.rpl[0] = Rpl(); sh.rpl[1] = Rpl();
+        if (nut != NUT_IDR) {                            // xevdm_eco.c:2658-2733
+            if (st.sps.tool_pocs) sh.poc_lsb = (int)br.get(st.sps.poc_lsb_bits);
+            if (st.sps.tool_rpl) {
+                int from_sps[2] = { 0, 0 }, idx[2] = { 0, 0 };
+                for (int l = 0; l < 2; l++) {
+                    if (l == 0 || st.pps.rpl1_idx_present) from_sps[l] = st.sps.n_rpl[l] > 0 ? br.get1() : 0;
+                    else from_sps[1] = from_sps[0];
+                    if (from_sps[l]) {
+                        if (l == 0 || st.pps.rpl1_idx_present) { if (st.sps.n_rpl[l] > 1) idx[l] = (int)br.ue(); }
+                        else idx[1] = idx[0];
+                        // (the reference copies list 0 only when the SPS holds more than one candidate - with exactly one it keeps the previous slice's list)
+                        if (idx[l] >= st.sps.n_rpl[l] || (l == 0 && st.sps.n_rpl[0] == 1)) return fail("reference picture list index");
+                        sh.rpl[l] = st.sps.rpls[l][idx[l]];
+                    } else if (!read_rpl(br, sh.rpl[l])) return fail("bad slice header: reference picture list");
+                }
+            }
+        }
+        sh.rpl[0].active = st.pps.default_active[0]; sh.rpl[1].active = st.pps.default_active[1];
+        if (sh.type != XHOST_SLICE_I && br.get1()) { sh.rpl[0].active = (int)br.ue() + 1; if (sh.type == XHOST_SLICE_B) sh.rpl[1].active = (int)br.ue() + 1; }      // num_ref_idx_active override (only used with tool_rpl)
         sh.tmvp_assigned = sh.col_list = sh.col_src_list = sh.col_ref = 0;
         if (sh.type != XHOST_SLICE_I && st.sps.tool_admvp && (sh.tmvp_assigned = br.get1())) {                // xevdm_eco.c:2748-2760
             if (sh.type == XHOST_SLICE_B) { sh.col_list = br.get1(); sh.col_src_list = br.get1(); }
@@ -1977,7 +2078,7 @@ struct xhost_parser {
         if (br.overrun || sh.qp > 51) return fail("bad slice header");
         st.derive_poc(nut == NUT_IDR, tid);
         if (sh.type == XHOST_SLICE_I) st.last_intra_poc = st.poc;
-        st.build_ref_lists();
+        if (!st.build_ref_lists(nut == NUT_IDR)) return fail("a reference picture list names a picture that is not in the DPB");
         if (sh.type != XHOST_SLICE_I && st.refp[0].empty()) return fail("P/B slice without a reference picture");
         if (sh.type == XHOST_SLICE_B && st.refp[1].empty()) return fail("B slice without a list-1 reference picture");
         for (int l = 0; l < 2; l++)
@@ -2231,12 +2332,19 @@ struct xhost_writer {
             bw.put1(sp.tool_addb ? 1 : 0);
             bw.put1(sp.tool_alf ? 1 : 0);
             bw.put1(sp.tool_htdf ? 1 : 0);
-            bw.put1(0); bw.put1(0); bw.put1(st.sps.dquant);      // rpl pocs dquant
+            bw.put1(st.sps.tool_rpl); bw.put1(st.sps.tool_pocs); bw.put1(st.sps.dquant);      // rpl pocs dquant
             bw.put1(sp.tool_dra ? 1 : 0);
         }
-        bw.ue((uint32_t)sp.log2_sub_gop_length);
-        if (sp.log2_sub_gop_length == 0) bw.ue(0);      // log2_ref_pic_gap_length
-        bw.ue((uint32_t)sp.max_num_ref_pics);
+        if (st.sps.tool_pocs) bw.ue((uint32_t)st.sps.poc_lsb_bits - 4);      // log2_max_pic_order_cnt_lsb_minus4
+        if (!st.sps.tool_rpl || !st.sps.tool_pocs) {
+            bw.ue((uint32_t)sp.log2_sub_gop_length);
+            if (sp.log2_sub_gop_length == 0) bw.ue(0);      // log2_ref_pic_gap_length
+        }
+        if (!st.sps.tool_rpl) bw.ue((uint32_t)sp.max_num_ref_pics);
+        else {
+            bw.ue(15); bw.put1(0); bw.put1(0);           // sps_max_dec_pic_buffering_minus1, long_term_ref_pics_flag, rpl1_same_as_rpl0_flag
+            for (int l = 0; l < 2; l++) { bw.ue((uint32_t)st.sps.n_rpl[l]); for (int i = 0; i < st.sps.n_rpl[l]; i++) write_rpl(bw, st.sps.rpls[l][i]); }
+        }
         const bool crop = sp.crop[0] | sp.crop[1] | sp.crop[2] | sp.crop[3];
         bw.put1(crop);
         if (crop) for (int i = 0; i < 4; i++) bw.ue((uint32_t)sp.crop[i]);
@@ -2256,7 +2364,7 @@ struct xhost_writer {
     {
         BitWriter bw;
         bw.ue(0); bw.ue(0); bw.ue(0); bw.ue(0); bw.ue(0);
-        bw.put1(0);                                      // rpl1_idx_present_flag
+        bw.put1(st.sps.tool_rpl);                        // rpl1_idx_present_flag
         const Pps &q = st.pps;
         bw.put1(q.tile_cols * q.tile_rows == 1);         // single_tile_in_pic_flag
         if (q.tile_cols * q.tile_rows > 1) {
@@ -2299,6 +2407,15 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     w->sp.tool_amvr = s.tool_admvp && sp->tool_amvr; s.tool_amvr = w->sp.tool_amvr;
     w->sp.tool_hmvp = s.tool_admvp && sp->tool_hmvp; s.tool_hmvp = w->sp.tool_hmvp;
     w->sp.tool_affine = s.tool_admvp && sp->tool_affine; s.tool_affine = w->sp.tool_affine;
+    w->st.enc_side = true;
+    s.tool_rpl = s.profile_main && sp->tool_rpl; s.tool_pocs = s.profile_main && sp->tool_pocs; s.poc_lsb_bits = 8;
+    if (s.tool_rpl && sp->rpl_in_sps && sp->log2_sub_gop_length == 0 && sp->max_num_ref_pics >= 2) {
+        // low delay: list 0 of a picture with k references is { 1 .. k } - as candidates of the SPS (both lists), picked by index in the slice headers
+        for (int l = 0; l < 2; l++) {
+            s.n_rpl[l] = std::min(sp->max_num_ref_pics, 5);
+            for (int k = 0; k < s.n_rpl[l]; k++) { s.rpls[l][k] = Rpl(); s.rpls[l][k].n = k + 1; for (int j = 0; j <= k; j++) s.rpls[l][k].ref[j] = j + 1; }
+        }
+    }
     w->sp.tool_mmvd = s.tool_admvp && sp->tool_mmvd; s.tool_mmvd = w->sp.tool_mmvd;
     w->sp.tool_dmvr = s.tool_admvp && sp->tool_dmvr && !s.tool_hmvp && !s.tool_mmvd; s.tool_dmvr = w->sp.tool_dmvr;      // not with tool_hmvp (see the parser)
     w->sp.ibc_log_max_size = (s.tool_eipd && sp->ibc_log_max_size >= 2 && sp->ibc_log_max_size <= 7) ? sp->ibc_log_max_size : 0;
@@ -2507,8 +2624,22 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
     st.sh.deblock = w->sp.deblock_on ? 1 : 0;
     st.derive_poc(idr != 0, temporal_id);
     if (slice_type == XHOST_SLICE_I) st.last_intra_poc = st.poc;
-    st.build_ref_lists();
+    st.build_ref_lists(idr != 0);
     if (slice_type != XHOST_SLICE_I && st.refp[0].empty()) return XGPU_ERR_INVALID_ARGUMENT;
+    // tool_pocs / tool_rpl: the same pictures and lists, described to the decoder - poc_lsb, and RPLs whose leading entries are the lists above and whose
+    // tail (list 0) names every other picture the sub-GOP scheme still keeps, so that the decoder's marking drops exactly what that scheme drops
+    st.sh.poc_lsb = st.poc & ((1 << st.sps.poc_lsb_bits) - 1);
+    for (int l = 0; l < 2; l++) {
+        Rpl &r = st.sh.rpl[l];
+        r = Rpl();
+        for (const RefPic *q : st.refp[l]) r.ref[r.n++] = st.poc - q->poc;
+        r.active = r.n;
+    }
+    for (const RefPic &q : st.dpb) {
+        bool named = false;
+        for (int l = 0; l < 2; l++) for (int j = 0; j < st.sh.rpl[l].n; j++) named |= st.sh.rpl[l].ref[j] == st.poc - q.poc;
+        if (!named && st.sh.rpl[0].n < XGPU_MAX_REFS) st.sh.rpl[0].ref[st.sh.rpl[0].n++] = st.poc - q.poc;
+    }
     if (slice_type == XHOST_SLICE_B && st.refp[1].empty()) return XGPU_ERR_INVALID_ARGUMENT;
 
     BitWriter bw;
@@ -2533,7 +2664,21 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
             if (st.sh.alf_chroma_idc) bw.put((uint32_t)st.sh.aps_id_ch, 5);
         }
     } else st.sh.alf_on = 0;
-    if (slice_type != XHOST_SLICE_I) bw.put1(0);         // num_ref_idx_active_override_flag
+    if (!idr) {                                          // xevdm_eco.c:2658-2733
+        if (st.sps.tool_pocs) bw.put((uint32_t)st.sh.poc_lsb, st.sps.poc_lsb_bits);
+        if (st.sps.tool_rpl)
+            for (int l = 0; l < 2; l++) {
+                int hit = -1;                            // a candidate of the SPS with these entries (the index is only sent when there are at least two)
+                for (int i = 0; i < st.sps.n_rpl[l] && st.sps.n_rpl[l] > 1 && hit < 0; i++)
+                    if (st.sps.rpls[l][i].n == st.sh.rpl[l].n && !memcmp(st.sps.rpls[l][i].ref, st.sh.rpl[l].ref, sizeof(int) * (size_t)st.sh.rpl[l].n)) hit = i;
+                if (st.sps.n_rpl[l] > 0) bw.put1(hit >= 0);
+                if (hit >= 0) bw.ue((uint32_t)hit); else write_rpl(bw, st.sh.rpl[l]);
+            }
+    }
+    if (slice_type != XHOST_SLICE_I) {                   // num_ref_idx_active_override_flag (+ the list sizes, which the decoder only uses with tool_rpl)
+        bw.put1(st.sps.tool_rpl);
+        if (st.sps.tool_rpl) { bw.ue((uint32_t)st.sh.rpl[0].active - 1); if (slice_type == XHOST_SLICE_B) bw.ue((uint32_t)st.sh.rpl[1].active - 1); }
+    }
     st.sh.tmvp_assigned = st.sh.col_list = st.sh.col_src_list = st.sh.col_ref = 0;
     if (slice_type != XHOST_SLICE_I && st.sps.tool_admvp) bw.put1(0);      // temporal_mvp_asigned_flag: the collocated picture is reference 0 of list 1 (P: list 0)
     bw.put1(st.sh.deblock);
