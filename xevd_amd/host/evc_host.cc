@@ -9,6 +9,7 @@
 // see the same neighbour state because both walk the CUs in the same order and "reconstructed" (COD) == "already parsed".
 #include "../../include/xevd_host.h"
 #include "alf_fixed_tables.h"
+#include "cm_init_tables.h"
 #include "../csrc/affine_model.h"
 
 #include <algorithm>
@@ -215,8 +216,33 @@ struct Models {
           merge_mode[1], merge_idx[5], bi_idx[2],                                                      // tool_admvp: xevd_def.h:461-465
           ibc_flag[2],                                                                               // sps->ibc_flag: xevd_def.h:485
           affine_flag[2], affine_mode[1], affine_mrg[5], affine_mvp_idx[1], affine_mvd_flag[2],       // tool_affine: xevd_def.h:483-498
-          ipm_mpm_flag[1], ipm_mpm_idx[1], ipm_chroma[1];                                            // tool_eipd: xevd_def.h intra_luma_pred_mpm_flag / _idx, intra_chroma_pred_mode
+          ipm_mpm_flag[1], ipm_mpm_idx[1], ipm_chroma[1],                                            // tool_eipd: xevd_def.h intra_luma_pred_mpm_flag / _idx, intra_chroma_pred_mode
+          sig_coeff[47], gt_ab[18], last_x[21], last_y[21];                                          // tool_adcc: xevd_def.h sig_coeff_flag, coeff_abs_level_greaterAB_flag, last_sig_coeff_{x,y}_prefix
     void reset() { Model *p = (Model *)this; for (size_t i = 0; i < sizeof(Models) / sizeof(Model); i++) p[i] = 512; }     // PROB_INIT, xevd_eco.c:769-803
+    // sps->tool_cm_init: every context starts from its initValue, the slice kind and the slice QP (xevd_eco_sbac_ctx_initialize, src_base/xevd_util.c:1243-1274;
+    // the list of xevdm_eco_sbac_reset, src_main/xevdm_eco.c:1012-1065)
+    template <int N> static void init(Model (&m)[N], const int16_t (&tbl)[2][N], int b_slice, int qp)
+    {
+        for (int i = 0; i < N; i++) {
+            const int v = tbl[b_slice][i];
+            int slope = (v & 14) << 4, offset = ((v >> 4) & 62) << 7;
+            if (v & 1) slope = -slope;
+            if ((v >> 4) & 1) offset = -offset;
+            int state = std::min(std::max((slope * qp + offset + 4096) >> 4, 1), 511), mps = 1;
+            if (state > 256) { state = 512 - state; mps = 0; }
+            m[i] = (Model)((state << 1) + mps);
+        }
+    }
+    void reset_cm(int b_slice, int qp)
+    {
+        qp = std::min(std::max(qp, 0), 51);
+#define CM(name) init(name, k_cm_##name, b_slice, qp)
+        CM(split); CM(run); CM(last); CM(level); CM(cbf_luma); CM(cbf_cb); CM(cbf_cr); CM(cbf_all); CM(pred_mode); CM(direct); CM(inter_dir); CM(intra_dir); CM(mvp_idx);
+        CM(mvd); CM(refi); CM(dqp); CM(skip); CM(ats_mode); CM(ats_inter_flag); CM(ats_inter_quad); CM(ats_inter_hor); CM(ats_inter_pos); CM(alf_ctb); CM(mmvd_flag);
+        CM(mmvd_merge_idx); CM(mmvd_dist_idx); CM(mmvd_dir_idx); CM(mmvd_group_idx); CM(mvr_idx); CM(merge_mode); CM(merge_idx); CM(bi_idx); CM(ibc_flag); CM(affine_flag);
+        CM(affine_mode); CM(affine_mrg); CM(affine_mvp_idx); CM(affine_mvd_flag); CM(ipm_mpm_flag); CM(ipm_mpm_idx); CM(ipm_chroma); CM(sig_coeff); CM(gt_ab); CM(last_x); CM(last_y);
+#undef CM
+    }
 };
 
 // ------------------------------------------------------------------------------------------------ constants of the standard
@@ -258,6 +284,7 @@ struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, lo
              int tool_amvr = 0, tool_hmvp = 0;       // sub-tools of tool_admvp: adaptive vector resolution (mvr_idx), history-based candidates
              int tool_rpl = 0, tool_pocs = 0, poc_lsb_bits = 4;      // sps->tool_rpl: reference lists and marking from signalled RPLs; tool_pocs: POC from poc_lsb in the slice header
              int n_rpl[2] = { 0, 0 }; Rpl rpls[2][32];               // RPL candidates of the SPS (sps->rpls_l0 / rpls_l1)
+             int tool_cm_init = 0, tool_adcc = 0;     // sps->tool_cm_init: contexts start from tables (slice kind, QP) and several flags pick theirs from the neighbours; tool_adcc
              int dquant = 0;                         // sps->dquant_flag (Main): QP deltas per quantisation group of pps.cu_qp_delta_area instead of per coded CU
              int tool_affine = 0;                    // sps->tool_affine: affine merge / affine inter CUs (4- or 6-parameter models from 2 / 3 control points)
              int tool_admvp = 0;                     // sps->tool_admvp: merge / resolution-indexed predictors instead of the Baseline candidate lists, 8-tap MC tables
@@ -339,6 +366,7 @@ struct Cu {
 struct Picture {         // SCU maps of the picture being parsed / written (ctx->map_scu, map_ipm, map_mv, map_refi; cod_eco)
     int w_scu = 0, h_scu = 0;
     std::vector<uint8_t> cod, intra, ibc;      // ibc: MCU_GET_IBC
+    std::vector<uint8_t> skip;       // MCU_GET_SF (only kept with sps->tool_cm_init: the skip flag's context counts skipped neighbours)
     std::vector<uint8_t> tidx;       // ctx->map_tidx: the tile of every SCU (empty: one tile) - neighbours in another tile are not available
     bool same_tile(int a, int b) const { return tidx.empty() || tidx[(size_t)a] == tidx[(size_t)b]; }
     std::vector<uint8_t> aff;        // sps->tool_affine: 0, or affine_flag | log2w << 2 | log2h << 5 of the affine CU the SCU belongs to (MCU_GET_AFF + map_affine)
@@ -350,7 +378,7 @@ struct Picture {         // SCU maps of the picture being parsed / written (ctx-
     {
         w_scu = w >> 2; h_scu = h >> 2;
         const size_t f = (size_t)w_scu * h_scu;
-        cod.assign(f, 0); intra.assign(f, 0); ibc.assign(f, 0); ipm.assign(f, 0); mv.assign(f * 4, 0); refi.assign(f * 2, -1); tidx.clear(); aff.clear();
+        cod.assign(f, 0); intra.assign(f, 0); ibc.assign(f, 0); ipm.assign(f, 0); mv.assign(f * 4, 0); refi.assign(f * 2, -1); tidx.clear(); aff.clear(); skip.clear();
     }
 };
 
@@ -477,6 +505,7 @@ struct Stream {          // everything both directions share
         }
         if (grid.col_bd[grid.n_cols] != w_ctu || grid.row_bd[grid.n_rows] != h_ctu) return false;
         if (sps.tool_affine) { pic.aff.assign((size_t)pic.w_scu * pic.h_scu, 0); pic.aff_tl.resize((size_t)pic.w_scu * pic.h_scu); }
+        if (sps.tool_cm_init) pic.skip.assign((size_t)pic.w_scu * pic.h_scu, 0);
         pic.tidx.clear();
         if (grid.n_cols * grid.n_rows > 1) {
             pic.tidx.assign((size_t)pic.w_scu * pic.h_scu, 0);
@@ -1343,6 +1372,7 @@ struct TileCoder {
         for (int r = 0; r < h; r++) for (int c = 0; c < w; c++) {
             const size_t k = (size_t)(ys + r) * pic.w_scu + xs + c;
             pic.cod[k] = 1; pic.intra[k] = cu.mode == MODE_INTRA; pic.ibc[k] = cu.mode == MODE_IBC; pic.ipm[k] = (int8_t)cu.ipm;
+            if (!pic.skip.empty()) pic.skip[k] = cu.mode == MODE_SKIP;
             for (int l = 0; l < 2; l++) { pic.refi[k * 2 + l] = (int8_t)cu.refi[l]; pic.mv[k * 4 + l * 2] = cu.mv[l][0]; pic.mv[k * 4 + l * 2 + 1] = cu.mv[l][1]; }
         }
         if (cu.affine && cu.mode != MODE_INTRA && cu.mode != MODE_IBC) aff_store(cu);
@@ -1352,10 +1382,12 @@ struct TileCoder {
     template <class C> void code_coefs(C &c, int16_t *coef, int log2w, int log2h, int chroma, bool enc)
     {
         const std::vector<uint16_t> &sc = scan[log2w - 1][log2h - 1];
-        const int n = 1 << (log2w + log2h), t0 = chroma ? 2 : 0;
-        int pos = 0;
+        const int n = 1 << (log2w + log2h);
+        int pos = 0, prev_level = 6;
         for (;;) {
             int run = 0, level = 1, sign = 0, last = 1;
+            // context pair of run and level: with sps->tool_cm_init by the level before (xevdm_eco.c:319)
+            const int t0 = sps.tool_cm_init ? (std::min(prev_level - 1, 5) << 1) + (chroma ? 12 : 0) : (chroma ? 2 : 0);
             if (enc) {
                 while (pos + run < n && coef[sc[pos + run]] == 0) run++;
                 const int v = coef[sc[pos + run]];
@@ -1367,6 +1399,7 @@ struct TileCoder {
             pos += run;
             if (pos >= n) return;                                   // malformed input; the caller checks the reader's overrun flag
             level = sym_unary(c, level - 1, models.level + t0, 2) + 1;
+            prev_level = level;
             sign = c.ep(sign);
             if (!enc) coef[sc[pos]] = (int16_t)(sign ? -level : level);
             if (pos >= n - 1) break;
@@ -1379,6 +1412,23 @@ struct TileCoder {
     // ---- one CU: syntax (xevd_eco_cu, xevd_eco.c:1048-1176; cbf :260-341; coefficients/QP :593-767) + derivations ----
     // enc: `cu` and `coef` carry the wanted values (mv of an INTER CU is met through mvd, a SKIP CU takes its predictor's motion);
     // dec: they are filled.  coef[c]: w*h (w/2*h/2) values of component c, zero-initialised by the caller when decoding.
+    // sps->tool_cm_init: the contexts of skip_flag / pred_mode_flag / ibc_flag / affine_flag count the neighbours that have the property - above the top-left
+    // SCU, left of the bottom-left one (and right of the bottom-right one, never parsed before the CU without SUCO) - in the same tile and already parsed
+    // (xevdm_get_ctx_some_flags, src_main/xevdm_util.c:1729-1853)
+    enum { CTX_SKIP, CTX_PRED, CTX_IBC, CTX_AFF };
+    int nb_ctx(const Cu &cu, int what) const
+    {
+        if (!sps.tool_cm_init) return 0;
+        const int ws = pic.w_scu, xs = cu.x >> 2, ys = cu.y >> 2, scuh = (1 << cu.log2h) >> 2, scup = ys * ws + xs;
+        const int nb[2] = { scup - ws, scup - 1 + (scuh - 1) * ws };
+        const bool in[2] = { ys > 0, xs > 0 };
+        int n = 0;
+        for (int k = 0; k < 2; k++) {
+            if (!in[k] || !pic.cod[(size_t)nb[k]] || !pic.same_tile(scup, nb[k])) continue;
+            n += what == CTX_SKIP ? pic.skip[(size_t)nb[k]] : what == CTX_PRED ? pic.intra[(size_t)nb[k]] : what == CTX_IBC ? pic.ibc[(size_t)nb[k]] : (!pic.aff.empty() && pic.aff[(size_t)nb[k]] != 0);
+        }
+        return std::min(n, what == CTX_PRED ? 2 : 1);
+    }
     template <class C> int code_refi(C &c, int want, int nref)      // xevd_eco_refi, xevd_eco.c:409-436
     {
         if (nref <= 1) return 0;
@@ -1406,7 +1456,7 @@ struct TileCoder {
     template <class C> bool code_affine_merge(C &c, Cu &cu)
     {
         int aff = 0;
-        if (sps.tool_affine && cu.log2w >= 3 && cu.log2h >= 3) aff = c.bin(cu.affine != 0, models.affine_flag[0]);
+        if (sps.tool_affine && cu.log2w >= 3 && cu.log2h >= 3) aff = c.bin(cu.affine != 0, models.affine_flag[nb_ctx(cu, CTX_AFF)]);
         if (!aff) { cu.affine = 0; return false; }
         cu.aff_idx[0] = sym_trunc_unary(c, cu.aff_idx[0], models.affine_mrg, 5, 5);
         aff_merge_motion(cu, cu.aff_idx[0]);
@@ -1418,7 +1468,7 @@ struct TileCoder {
         // mode constraint eOnlyIntra: I slices, and with tool_admvp every 4x4 CU (xevdm.c:1838-1843) - no skip flag, no pred_mode_flag
         const bool inter_slice = sh.type != XHOST_SLICE_I && !(sps.tool_admvp && cu.log2w == 2 && cu.log2h == 2);
         int skip = 0;
-        if (inter_slice) skip = c.bin(cu.mode == MODE_SKIP, models.skip[0]);
+        if (inter_slice) skip = c.bin(cu.mode == MODE_SKIP, models.skip[nb_ctx(cu, CTX_SKIP)]);
         if (!enc) { cu.mode = skip ? MODE_SKIP : MODE_INTRA; cu.refi[0] = cu.refi[1] = -1; memset(cu.mv, 0, sizeof(cu.mv)); memset(cu.mvd, 0, sizeof(cu.mvd));
                     cu.mvp_idx[0] = cu.mvp_idx[1] = 0; cu.cbf[0] = cu.cbf[1] = cu.cbf[2] = 0; cu.ipm = cu.ipm_c = 0; cu.ats = cu.ats_inter = 0; cu.dmvr = 0; cu.mmvd = cu.mmvd_idx = 0; cu.affine = 0; memset(cu.aff_mv, 0, sizeof(cu.aff_mv)); memset(cu.aff_mvd, 0, sizeof(cu.aff_mvd)); cu.aff_idx[0] = cu.aff_idx[1] = 0; }
         int16_t cand[4][2];
@@ -1450,12 +1500,12 @@ struct TileCoder {
             return;
         }
         int intra = 1;
-        if (inter_slice) intra = c.bin(cu.mode == MODE_INTRA, models.pred_mode[0]);
+        if (inter_slice) intra = c.bin(cu.mode == MODE_INTRA, models.pred_mode[nb_ctx(cu, CTX_PRED)]);
         // xevdm_eco_pred_mode (xevdm_eco.c:1401-1438): with sps->ibc_flag every CU up to the IBC size limit that is not already known to be
         // intra-predicted carries ibc_flag - in I slices all of them (mode constraint eOnlyIntra: no pred_mode_flag); context 0 without cm_init
         int ibc = 0;
         if (sps.ibc && cu.log2w <= sps.ibc_log_max && cu.log2h <= sps.ibc_log_max && !(inter_slice && intra))
-            ibc = c.bin(cu.mode == MODE_IBC, models.ibc_flag[0]);
+            ibc = c.bin(cu.mode == MODE_IBC, models.ibc_flag[nb_ctx(cu, CTX_IBC)]);
         if (!enc) { cu.mode = ibc ? MODE_IBC : intra ? MODE_INTRA : MODE_INTER; cu.direct = 0; }
         if (ibc) {
             // the block vector itself is sent as a motion vector difference (xevdm_eco.c:1789-1800); no references, no predictor
@@ -1499,7 +1549,7 @@ struct TileCoder {
                 // affine inter CU (xevdm_eco.c:1649-1682): 16x16 and larger, quarter-sample vectors only; affine_mode picks 2 or 3 control points, then
                 // per list the reference, one of two predictors, and the control-point differences (all zero with affine_mvd_flag)
                 int aff = 0;
-                if (sps.tool_affine && cu.log2w >= 4 && cu.log2h >= 4 && mvr == 0) aff = c.bin(cu.affine != 0, models.affine_flag[0]);
+                if (sps.tool_affine && cu.log2w >= 4 && cu.log2h >= 4 && mvr == 0) aff = c.bin(cu.affine != 0, models.affine_flag[nb_ctx(cu, CTX_AFF)]);
                 if (!aff) cu.affine = 0;
                 else {
                     cu.affine = 1 + c.bin(cu.affine == 2, models.affine_mode[0]);
@@ -1692,7 +1742,7 @@ struct TileCoder {
             } else cu.ats = 0;
             const int w = 1 << cu.log2w, h = 1 << cu.log2h;
             const int avail = (intra || ibc || w > 64 || h > 64) ? 0 : ((w >= 8) | ((h >= 8) << 1) | ((w >= 16) << 2) | ((h >= 16) << 3));      // xevdm_util.c:3565-3583
-            cu.ats_inter = avail ? code_ats_inter(c, cu.ats_inter, avail) : 0;
+            cu.ats_inter = avail ? code_ats_inter(c, cu.ats_inter, avail, cu.log2w, cu.log2h) : 0;
             const int idx = cu.ats_inter & 15;
             if (idx == 1 || idx == 3) tlw -= idx == 3 ? 2 : 1;
             if (idx == 2 || idx == 4) tlh -= idx == 4 ? 2 : 1;
@@ -1701,15 +1751,16 @@ struct TileCoder {
             if (cu.cbf[k]) code_coefs(c, coef[k], tlw - (k ? 1 : 0), tlh - (k ? 1 : 0), k != 0, enc);
     }
 
-    // ats_inter_info syntax (xevdm_eco_ats_inter_info, xevdm_eco.c:128-190; contexts 0 without cm_init)
-    template <class C> int code_ats_inter(C &c, int info, int avail)
+    // ats_inter_info syntax (xevdm_eco_ats_inter_info, xevdm_eco.c:128-190; with cm_init the flag's context goes by the CU's area, the direction's by its shape)
+    template <class C> int code_ats_inter(C &c, int info, int avail, int log2w, int log2h)
     {
         const int mv_ = avail & 1, mh_ = (avail >> 1) & 1, vq = (avail >> 2) & 1, hq = (avail >> 3) & 1;
-        if (!c.bin(info != 0, models.ats_inter_flag[0])) return 0;
+        const int ctx_flag = sps.tool_cm_init ? (log2w + log2h >= 8 ? 0 : 1) : 0, ctx_hor = sps.tool_cm_init ? (log2w == log2h ? 0 : log2w < log2h ? 1 : 2) : 0;
+        if (!c.bin(info != 0, models.ats_inter_flag[ctx_flag])) return 0;
         const int idx = info & 15;
         int quad = idx >= 3, hor = idx == 2 || idx == 4, pos = (info >> 4) & 1;
         if ((vq || hq) && (mv_ || mh_)) quad = c.bin(quad, models.ats_inter_quad[0]); else quad = 0;
-        if ((quad && vq && hq) || (!quad && mv_ && mh_)) hor = c.bin(hor, models.ats_inter_hor[0]);
+        if ((quad && vq && hq) || (!quad && mv_ && mh_)) hor = c.bin(hor, models.ats_inter_hor[ctx_hor]);
         else hor = (quad && hq) || (!quad && mh_);
         pos = c.bin(pos, models.ats_inter_pos[0]);
         return ((quad ? 2 : 0) + (hor ? 1 : 0) + 1) | (pos << 4);
@@ -1763,7 +1814,7 @@ struct TileParser {
         const int w_ctu = (st.sps.width + 63) >> 6;
         batch.clear();
         n_coef = 0;
-        tc.models.reset();
+        if (st.sps.tool_cm_init) tc.models.reset_cm(sh.type == XHOST_SLICE_B, sh.qp); else tc.models.reset();
         tc.qp_prev = sh.qp;
         Dec dec;
         dec.br = &br;
@@ -1899,7 +1950,8 @@ struct xhost_parser {
             s.tool_eipd = br.get1();
             s.ibc = s.ibc_log_max = 0;
             if (s.tool_eipd && (s.ibc = br.get1())) { s.ibc_log_max = (int)br.ue() + 2; if (s.ibc_log_max > 7) return fail("bad SPS"); }
-            unsupported |= br.get1();                    // tool_cm_init
+            s.tool_cm_init = br.get1(); s.tool_adcc = s.tool_cm_init ? br.get1() : 0;      // tool_cm_init, tool_adcc (xevdm_eco.c:1900-1904)
+            unsupported |= s.tool_adcc;
             s.tool_iqt = br.get1();
             if (s.tool_iqt) s.tool_ats = br.get1();
             s.tool_addb = br.get1();
@@ -1916,7 +1968,7 @@ struct xhost_parser {
         // unrefined map, xevdm_util.c:246-247): the same dependency
         if (s.tool_dmvr && s.tool_mmvd) return fail("tool_dmvr together with tool_mmvd: the base candidates depend on refined vectors inside the picture (not supported)");
         if (s.tool_dmvr && s.tool_hmvp) return fail("tool_dmvr together with tool_hmvp: the history candidates depend on refined vectors inside the picture (not supported)");
-        if (unsupported) return fail("the stream uses tools this front end does not parse (sps_btt_flag, sps_suco_flag, tool_cm_init)");
+        if (unsupported) return fail("the stream uses tools this front end does not parse (sps_btt_flag, sps_suco_flag, tool_adcc)");
         // xevdm_eco.c:1920-1961: POC lsb width (tool_pocs), the sub-GOP description unless both tools are on, and either the sliding-window size or the RPL candidates
         s.tool_rpl = rpl; s.tool_pocs = pocs;
         s.log2_sub_gop = s.log2_ref_gap = 0;
@@ -2326,7 +2378,7 @@ struct xhost_writer {
             if (sp.tool_admvp) { bw.put1(sp.tool_affine ? 1 : 0); bw.put1(sp.tool_amvr ? 1 : 0); bw.put1(sp.tool_dmvr ? 1 : 0); bw.put1(sp.tool_mmvd ? 1 : 0); bw.put1(sp.tool_hmvp ? 1 : 0); }      // affine amvr dmvr mmvd hmvp
             bw.put1(sp.tool_eipd ? 1 : 0);
             if (sp.tool_eipd) { bw.put1(sp.ibc_log_max_size ? 1 : 0); if (sp.ibc_log_max_size) bw.ue((uint32_t)(sp.ibc_log_max_size - 2)); }      // ibc_flag, ibc_log_max_size - 2
-            bw.put1(0);                                  // cm_init
+            bw.put1(st.sps.tool_cm_init); if (st.sps.tool_cm_init) bw.put1(st.sps.tool_adcc);      // cm_init (+ adcc)
             bw.put1(sp.tool_iqt ? 1 : 0);
             if (sp.tool_iqt) bw.put1(sp.tool_ats ? 1 : 0);
             bw.put1(sp.tool_addb ? 1 : 0);
@@ -2408,6 +2460,7 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     w->sp.tool_hmvp = s.tool_admvp && sp->tool_hmvp; s.tool_hmvp = w->sp.tool_hmvp;
     w->sp.tool_affine = s.tool_admvp && sp->tool_affine; s.tool_affine = w->sp.tool_affine;
     w->st.enc_side = true;
+    s.tool_cm_init = s.profile_main && sp->tool_cm_init; s.tool_adcc = 0;
     s.tool_rpl = s.profile_main && sp->tool_rpl; s.tool_pocs = s.profile_main && sp->tool_pocs; s.poc_lsb_bits = 8;
     if (s.tool_rpl && sp->rpl_in_sps && sp->log2_sub_gop_length == 0 && sp->max_num_ref_pics >= 2) {
         // low delay: list 0 of a picture with k references is { 1 .. k } - as candidates of the SPS (both lists), picked by index in the slice headers
@@ -2703,7 +2756,7 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
     std::vector<BitWriter> tile_bits((size_t)n_tiles);
     for (int t = 0; t < n_tiles; t++) {
         const int tc = t % st.grid.n_cols, tr = t / st.grid.n_cols;
-        tcd.models.reset();
+        if (st.sps.tool_cm_init) tcd.models.reset_cm(slice_type == XHOST_SLICE_B, slice_qp); else tcd.models.reset();
         tcd.qp_prev = slice_qp;
         Enc enc;
         enc.bw = &tile_bits[(size_t)t];
