@@ -21,7 +21,8 @@
  * bi_idx / mmvd_flag + mmvd data syntax (xevdm_eco.c:767-812,1519-1726), merge with vector difference (src_main/xevdm_util.c:191-592,4682-4716), merge candidates incl. the temporal and history ones (src_main/xevdm_util.c:594-1391,3729-3818), the resolution-indexed
  * predictor (:750-951), intra-only 4x4 CUs; tool_dmvr needs the backend's refined vectors back per picture (xhost_parser_set_dmvr_mvs) and is refused
  * together with tool_hmvp or tool_mmvd.  tool_affine (affine merge / affine inter CUs, xevdm_util.c:2145-3187) is parsed too.
- * Not parsed: sps_btt_flag / sps_suco_flag (split syntax), tool_adcc.  tool_cm_init (context initialisation tables, neighbour-dependent contexts) is parsed.
+ * Not parsed: sps_btt_flag / sps_suco_flag (the split syntax).  tool_cm_init (context initialisation tables, neighbour-dependent contexts) and tool_adcc
+ * (advanced coefficient coding) are parsed.
  * dquant_flag (QP deltas per quantisation group), tool_rpl (reference picture lists in SPS / slice headers, RPL-based marking) and tool_pocs
  * (POC from poc_lsb) are parsed.  SPS chroma QP mapping tables and cropping offsets are parsed, a VUI is skipped; 4:2:0, one slice per picture (with all of its
  * tiles - uniform or explicit PPS tile grids, entry points in the slice header; explicit tile ids and arbitrary slices are refused), I / P / B slices incl. temporal layers (hierarchical sub-GOPs).
@@ -141,6 +142,8 @@ typedef struct xhost_stream_params {
                                               builds, tail = the other pictures that scheme still keeps) and the list sizes; sps->tool_pocs - poc_lsb (8 bits) per slice */
     int tool_cm_init;                      /* Main: sps->tool_cm_init - context variables start from the standard's tables (slice kind, QP); skip / pred_mode / ibc /
                                               affine flags, the run / level pair and the ATS-inter flags pick their contexts from neighbours, levels and CU shapes */
+    int tool_adcc;                         /* Main, switches tool_cm_init on: sps->tool_adcc - coefficient blocks as last position + significance / greater-than flags /
+                                              Golomb-Rice remainders per group of 16 (xevdm_eco_adcc) instead of run-level pairs */
     int rpl_in_sps;                        /* with tool_rpl, low delay and at least 2 references: RPL candidates in the SPS, picked by index where they match */
 } xhost_stream_params;
 

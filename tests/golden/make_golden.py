@@ -178,6 +178,10 @@ def golden_streams(only=()):
                                 "main_cm_init_all_tools_10b": (264, 136, 17, dict(main=True, cm_init=True, rpl=True, pocs=True, admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, iqt=True, ats=True,
                                                                                   addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=5, inter_frac=0.9, skip_frac=0.3, direct_frac=0.3, max_refs=3,
                                                                                   log2_sub_gop=3, bit_depth=10, qp_delta_area=8)),
+                                "main_adcc_all_tools_10b": (264, 136, 17, dict(main=True, adcc=True, rpl=True, pocs=True, admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, iqt=True, ats=True,
+                                                                               addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=5, inter_frac=0.9, skip_frac=0.3, direct_frac=0.3, max_refs=3,
+                                                                               log2_sub_gop=3, bit_depth=10, qp_delta_area=8)),
+                                "main_adcc_low_qp_8b": (200, 136, 5, dict(main=True, adcc=True, iqt=True, max_refs=2, max_level=3000, qp_range=(0, 8))),
                                 "main_dquant_area8_10b": (264, 200, 9, dict(main=True, admvp=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, inter_frac=0.8, split_prob=0.65, max_refs=2,
                                                                             log2_sub_gop=2, bit_depth=10, qp_delta_area=8)),
                                 # sps->tool_affine: affine merge and affine inter CUs from the bitstream

@@ -114,6 +114,14 @@ CONFIGS = [
     (264, 136, 17, dict(main=True, cm_init=True, rpl=True, pocs=True, admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True,
                         ibc_log_max=5, inter_frac=0.9, skip_frac=0.3, direct_frac=0.3, max_refs=3, log2_sub_gop=3, bit_depth=10, qp_delta_area=8)),
     (392, 264, 9, dict(main=True, cm_init=True, admvp=True, dmvr=True, addb=True, inter_frac=0.95, skip_frac=0.3, direct_frac=0.3, max_refs=2, log2_sub_gop=2, tiles=(2, 2, 0))),
+    # sps->tool_adcc: coefficient blocks as last position + significance / greater-than-1 / greater-than-2 flags + Golomb-Rice remainders + signs per group
+    # of 16 scan positions, contexts from the coded neighbours; all block sizes 2x2 .. 64x64, small and large levels (low QPs)
+    (64, 64, 1, dict(main=True, adcc=True, idr_period=1, split_prob=0.9)),
+    (136, 72, 4, dict(main=True, adcc=True, max_refs=2)),
+    (200, 136, 5, dict(main=True, adcc=True, iqt=True, max_refs=2, max_level=3000, qp_range=(0, 8))),
+    (200, 136, 9, dict(main=True, adcc=True, iqt=True, ats=True, max_refs=2, log2_sub_gop=2)),
+    (264, 136, 17, dict(main=True, adcc=True, rpl=True, pocs=True, admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True,
+                        ibc_log_max=5, inter_frac=0.9, skip_frac=0.3, direct_frac=0.3, max_refs=3, log2_sub_gop=3, bit_depth=10, qp_delta_area=8)),
     # sps->dquant_flag: one QP delta per quantisation group of pps.cu_qp_delta_area samples (8x8 ... 64x64; an odd area never matches a square node)
     (264, 200, 5, dict(main=True, iqt=True, qp_delta_area=6, split_prob=0.7, inter_frac=0.7)),
     (264, 200, 5, dict(main=True, iqt=True, qp_delta_area=10, split_prob=0.7, inter_frac=0.7)),

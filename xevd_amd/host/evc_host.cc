@@ -479,6 +479,7 @@ struct Stream {          // everything both directions share
     int stale_list_poc[16] = { 0 };      // list_poc[] entries past a picture's own list keep what earlier pictures wrote
     bool have_sps = false, have_pps = false, need_idr = false;
     std::vector<uint16_t> scan[6][6];      // zig-zag tables by log2 size - 1
+    std::vector<uint16_t> scan_inv[6][6];  // raster position -> scan position (tool_adcc)
     AlfAps alf_aps[32];
     DraAps dra_aps[32];
     int32_t dra_luts[3 * 1024];            // of the current picture (when the PPS switches DRA on)
@@ -600,7 +601,14 @@ struct Stream {          // everything both directions share
     }
     int alf_kmin_minus1 = 0;
 
-    Stream() { for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) make_zigzag(scan[a][b], 2 << a, 2 << b); }
+    Stream()
+    {
+        for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) {
+            make_zigzag(scan[a][b], 2 << a, 2 << b);
+            scan_inv[a][b].resize(scan[a][b].size());
+            for (size_t i = 0; i < scan[a][b].size(); i++) scan_inv[a][b][scan[a][b][i]] = (uint16_t)i;
+        }
+    }
 
     // POC of the next picture (xevd.c:1846-1861, xevd_poc_derivation xevd_util.c:429-467)
     void derive_poc(bool idr, int t)
@@ -735,11 +743,11 @@ struct TileCoder {
     Picture &pic;
     const std::vector<const RefPic *> (&refp)[2];
     const int &poc;
-    const std::vector<uint16_t> (&scan)[6][6];
+    const std::vector<uint16_t> (&scan)[6][6], (&scan_inv)[6][6];
     Models models;
     int qp_prev = 0;
     int qp_coded = 0;                // core->cu_qp_delta_is_coded: the current quantisation group has sent its delta
-    explicit TileCoder(Stream &s) : sps(s.sps), pps(s.pps), sh(s.sh), pic(s.pic), refp(s.refp), poc(s.poc), scan(s.scan) { history_reset(); }
+    explicit TileCoder(Stream &s) : sps(s.sps), pps(s.pps), sh(s.sh), pic(s.pic), refp(s.refp), poc(s.poc), scan(s.scan), scan_inv(s.scan_inv) { history_reset(); }
 
     // motion vector predictor candidates of one list (xevd_get_motion, xevd_util.c:469-515; availability xevd_get_avail_inter :632-687):
     // left, up, up-right neighbour SCU (1,1 when not available) and the co-located list-0 motion of reference 0 of that list
@@ -1409,6 +1417,142 @@ struct TileCoder {
         }
     }
 
+
+    // ---- coefficient block with sps->tool_adcc (xevdm_eco_adcc, src_main/xevdm_eco.c:482-689): position of the last coefficient in scan order, then per
+    //      group of 16 scan positions (last group first): significance flags, greater-than-1 flags of the first 8 coefficients, one greater-than-2 flag,
+    //      Golomb-Rice remainders, signs.  Contexts from the five already-coded neighbours to the right and below; the block itself is the working state ----
+    static int adcc_nb(const int16_t *coef, int blkpos, int width, int height, int log2w, int what, int base = 0)
+    {
+        const int16_t *p = coef + blkpos;
+        const int py = blkpos >> log2w, px = blkpos - (py << log2w);
+        int n = 0;
+        auto take = [&](int v) { const int a = v < 0 ? -v : v; n += what == 0 ? v != 0 : what == 1 ? a > 1 : what == 2 ? a > 2 : a; };
+        if (px < width - 1) { take(p[1]); if (px < width - 2) take(p[2]); if (py < height - 1) take(p[width + 1]); }
+        if (py < height - 1) { take(p[width]); if (py < height - 2) take(p[2 * width]); }
+        (void)base;
+        return n;
+    }
+    template <class C> void code_adcc(C &c, int16_t *coef, int log2w, int log2h, int chroma, bool enc)
+    {
+        static const int group_idx[64] = { 0, 1, 2, 3, 4, 4, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 8, 8, 8, 8, 9, 9, 9, 9, 9, 9, 9, 9, 10, 10, 10, 10, 10, 10, 10, 10, 10, 10, 10, 10, 10,
+                                           10, 10, 10, 11, 11, 11, 11, 11, 11, 11, 11, 11, 11, 11, 11, 11, 11, 11, 11 };      // g_group_idx, xevdm_tbl.c:390
+        static const int min_in_group[14] = { 0, 1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96 };
+        static const int rice_range[10] = { 6, 5, 6, 3, 3, 3, 3, 3, 3, 3 };
+        static const int rice_para[32] = { 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 3, 3, 3 };
+        const int width = 1 << log2w, height = 1 << log2h, n = width * height;
+        const std::vector<uint16_t> &sc = scan[log2w - 1][log2h - 1], &inv = scan_inv[log2w - 1][log2h - 1];
+        std::vector<int16_t> want;
+        int last_x = 0, last_y = 0;
+        if (enc) {
+            want.assign(coef, coef + n);
+            int last = 0;
+            for (int i = 0; i < n; i++) if (want[sc[(size_t)i]]) last = i;
+            last_x = sc[(size_t)last] & (width - 1); last_y = sc[(size_t)last] >> log2w;
+            memset(coef, 0, sizeof(int16_t) * (size_t)n);
+        }
+        {   // last_sig_coeff_{x,y}_prefix / _suffix (xevdm_parse_positionLastXY :395-457; context sets by block size, xevd_get_ctx_last_pos_xy_para)
+            auto para = [&](int size, int log2s, int &off, int &shift) {
+                const int cv = std::max(log2s - 2, 0);
+                if (chroma) { off = 0; shift = cv - (size >= 16 ? log2s - 4 : 0); }      // cv - log2(size >> 4), the reference's log2 table maps 0 to 0
+                else { off = cv * 3 + ((cv + 1) >> 2); shift = (cv + 3) >> 2; if (cv >= 4) { off += ((size >> 6) << 1) + (size >> 7); shift = 2; } }
+            };
+            int off[2], shift[2], pos[2] = { last_x, last_y };
+            para(width, log2w, off[0], shift[0]); para(height, log2h, off[1], shift[1]);
+            Model *cm[2] = { models.last_x + (chroma ? 18 : 0), models.last_y + (chroma ? 18 : 0) };
+            int grp[2];
+            for (int d = 0; d < 2; d++) {
+                const int gmax = group_idx[(d ? height : width) - 1], g = enc ? group_idx[pos[d]] : 0;
+                int k = 0;
+                for (; k < gmax; k++) if (!c.bin(enc ? k < g : 0, cm[d][off[d] + (k >> shift[d])])) break;
+                grp[d] = k;
+            }
+            for (int d = 0; d < 2; d++) {
+                if (grp[d] > 3) { const int cnt = (grp[d] - 2) >> 1; pos[d] = min_in_group[grp[d]] + sym_bits_ep(c, enc ? pos[d] - min_in_group[grp[d]] : 0, cnt); }
+                else pos[d] = grp[d];
+            }
+            last_x = std::min(pos[0], width - 1); last_y = std::min(pos[1], height - 1);
+        }
+        const int num_coeff = inv[(size_t)(last_x + last_y * width)] + 1, scan_pos_last = num_coeff - 1;
+        const int log2_min = std::min(log2w, log2h);
+        Model *cm_sig = chroma ? models.sig_coeff + 39 : models.sig_coeff + (log2_min <= 2 ? 0 : 13 << std::min(1, log2_min - 3));
+        Model *cm_gt = chroma ? models.gt_ab + 13 : models.gt_ab;
+        int ipos = scan_pos_last, pos_last = -1, ctx_gta = 0, ctx_gtb = 0;
+        for (int sub = scan_pos_last >> 4; sub >= 0; sub--) {
+            int num_nz = 0, pos[16], abs_coef[16];
+            for (; ipos >= (sub << 4); ipos--) {
+                const int blk = sc[(size_t)ipos];
+                int sig = 1;
+                if (ipos != scan_pos_last) {
+                    const int py = blk >> log2w, px = blk - (py << log2w), diag = px + py;
+                    int idx = std::min(adcc_nb(coef, blk, width, height, log2w, 0), 4) + 1;
+                    if (diag < 2) idx = std::min(idx, 2);
+                    const int ofs = chroma ? (diag < 2 ? 0 : 2) : (diag < 2 ? 0 : diag < 5 ? 2 : 7);
+                    sig = c.bin(enc ? want[(size_t)blk] != 0 : 0, cm_sig[ofs + idx]);
+                }
+                coef[blk] = (int16_t)sig;
+                if (sig) { pos[num_nz++] = blk; if (pos_last < 0) pos_last = blk; }
+            }
+            if (!num_nz) continue;
+            auto gt_ctx = [&](int blk, int what) {
+                const int py = blk >> log2w, px = blk - (py << log2w), diag = px + py;
+                int v = std::min(adcc_nb(coef, blk, width, height, log2w, what), 3) + 1;
+                if (!chroma) v += diag < 3 ? 0 : diag < 10 ? 4 : 8;
+                return v;
+            };
+            auto true_abs = [&](int blk) { const int v = want[(size_t)blk]; return v < 0 ? -v : v; };
+            bool escape = false;
+            int first_c2 = -1;
+            for (int i = 0; i < num_nz; i++) abs_coef[i] = 1;
+            for (int i = 0; i < std::min(num_nz, 8); i++) {
+                if (pos[i] != pos_last) ctx_gta = gt_ctx(pos[i], 1);
+                const int f = c.bin(enc ? true_abs(pos[i]) > 1 : 0, cm_gt[ctx_gta]);
+                coef[pos[i]] = (int16_t)(coef[pos[i]] + f);
+                abs_coef[i] = f + 1;
+                if (f) { if (first_c2 < 0) first_c2 = i; else escape = true; }
+            }
+            if (first_c2 >= 0) {
+                if (pos[first_c2] != pos_last) ctx_gtb = gt_ctx(pos[first_c2], 2);
+                const int f = c.bin(enc ? true_abs(pos[first_c2]) > 2 : 0, cm_gt[ctx_gtb]);
+                coef[pos[first_c2]] = (int16_t)(coef[pos[first_c2]] + f);
+                abs_coef[first_c2] = f + 2;
+                if (f) escape = true;
+            }
+            escape = escape || num_nz > 8;
+            int first_coeff2 = 1;
+            if (escape)
+                for (int i = 0; i < num_nz; i++) {
+                    const int base = i < 8 ? 2 + first_coeff2 : 1;
+                    if (abs_coef[i] >= base) {
+                        const int r = rice_para[std::max(std::min(adcc_nb(coef, pos[i], width, height, log2w, 3) - 5 * base, 31), 0)];
+                        // xevdm_parse_coef_remain_exgolomb (:458-481): unary prefix, then r bins - or, past the prefix limit of r, an escape with growing suffix
+                        int sym = enc ? true_abs(pos[i]) - base : 0, prefix = 0;
+                        if (enc) {
+                            if (sym < (rice_range[r] << r)) prefix = sym >> r;
+                            else { int k = 0; while ((((1 << (k + 1)) + rice_range[r] - 1) << r) <= sym) k++; prefix = rice_range[r] + k; }
+                        }
+                        int k = 0;
+                        while (c.ep(enc ? k < prefix : 0)) { if (++k > 32) break; }
+                        prefix = k;
+                        if (prefix < rice_range[r]) sym = (prefix << r) + sym_bits_ep(c, sym & ((1 << r) - 1), r);
+                        else {
+                            const int e = prefix - rice_range[r], b0 = ((1 << e) + rice_range[r] - 1) << r;
+                            sym = b0 + sym_bits_ep(c, sym - b0, std::min(e + r, 30));
+                        }
+                        abs_coef[i] = sym + base;
+                        coef[pos[i]] = (int16_t)std::min(abs_coef[i], 32767);
+                    }
+                    if (abs_coef[i] >= 2) first_coeff2 = 0;
+                }
+            uint32_t signs = 0;
+            if (enc) for (int i = 0; i < num_nz; i++) signs = (signs << 1) | (want[(size_t)pos[i]] < 0);
+            signs = (uint32_t)sym_bits_ep(c, (int)signs, num_nz);
+            for (int i = 0; i < num_nz; i++) {
+                const int neg = (signs >> (num_nz - 1 - i)) & 1, a = std::min(abs_coef[i], 32767);
+                coef[pos[i]] = (int16_t)(neg ? -a : a);
+            }
+        }
+    }
+
     // ---- one CU: syntax (xevd_eco_cu, xevd_eco.c:1048-1176; cbf :260-341; coefficients/QP :593-767) + derivations ----
     // enc: `cu` and `coef` carry the wanted values (mv of an INTER CU is met through mvd, a SKIP CU takes its predictor's motion);
     // dec: they are filled.  coef[c]: w*h (w/2*h/2) values of component c, zero-initialised by the caller when decoding.
@@ -1748,7 +1892,7 @@ struct TileCoder {
             if (idx == 2 || idx == 4) tlh -= idx == 4 ? 2 : 1;
         }
         for (int k = 0; k < 3; k++)
-            if (cu.cbf[k]) code_coefs(c, coef[k], tlw - (k ? 1 : 0), tlh - (k ? 1 : 0), k != 0, enc);
+            if (cu.cbf[k]) { if (sps.tool_adcc) code_adcc(c, coef[k], tlw - (k ? 1 : 0), tlh - (k ? 1 : 0), k != 0, enc); else code_coefs(c, coef[k], tlw - (k ? 1 : 0), tlh - (k ? 1 : 0), k != 0, enc); }
     }
 
     // ats_inter_info syntax (xevdm_eco_ats_inter_info, xevdm_eco.c:128-190; with cm_init the flag's context goes by the CU's area, the direction's by its shape)
@@ -1951,7 +2095,6 @@ struct xhost_parser {
             s.ibc = s.ibc_log_max = 0;
             if (s.tool_eipd && (s.ibc = br.get1())) { s.ibc_log_max = (int)br.ue() + 2; if (s.ibc_log_max > 7) return fail("bad SPS"); }
             s.tool_cm_init = br.get1(); s.tool_adcc = s.tool_cm_init ? br.get1() : 0;      // tool_cm_init, tool_adcc (xevdm_eco.c:1900-1904)
-            unsupported |= s.tool_adcc;
             s.tool_iqt = br.get1();
             if (s.tool_iqt) s.tool_ats = br.get1();
             s.tool_addb = br.get1();
@@ -1968,7 +2111,7 @@ struct xhost_parser {
         // unrefined map, xevdm_util.c:246-247): the same dependency
         if (s.tool_dmvr && s.tool_mmvd) return fail("tool_dmvr together with tool_mmvd: the base candidates depend on refined vectors inside the picture (not supported)");
         if (s.tool_dmvr && s.tool_hmvp) return fail("tool_dmvr together with tool_hmvp: the history candidates depend on refined vectors inside the picture (not supported)");
-        if (unsupported) return fail("the stream uses tools this front end does not parse (sps_btt_flag, sps_suco_flag, tool_adcc)");
+        if (unsupported) return fail("the stream uses tools this front end does not parse (sps_btt_flag, sps_suco_flag)");
         // xevdm_eco.c:1920-1961: POC lsb width (tool_pocs), the sub-GOP description unless both tools are on, and either the sliding-window size or the RPL candidates
         s.tool_rpl = rpl; s.tool_pocs = pocs;
         s.log2_sub_gop = s.log2_ref_gap = 0;
@@ -2460,7 +2603,7 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     w->sp.tool_hmvp = s.tool_admvp && sp->tool_hmvp; s.tool_hmvp = w->sp.tool_hmvp;
     w->sp.tool_affine = s.tool_admvp && sp->tool_affine; s.tool_affine = w->sp.tool_affine;
     w->st.enc_side = true;
-    s.tool_cm_init = s.profile_main && sp->tool_cm_init; s.tool_adcc = 0;
+    s.tool_cm_init = s.profile_main && (sp->tool_cm_init || sp->tool_adcc); s.tool_adcc = s.tool_cm_init && sp->tool_adcc;      // tool_adcc is a sub-flag of tool_cm_init
     s.tool_rpl = s.profile_main && sp->tool_rpl; s.tool_pocs = s.profile_main && sp->tool_pocs; s.poc_lsb_bits = 8;
     if (s.tool_rpl && sp->rpl_in_sps && sp->log2_sub_gop_length == 0 && sp->max_num_ref_pics >= 2) {
         // low delay: list 0 of a picture with k references is { 1 .. k } - as candidates of the SPS (both lists), picked by index in the slice headers

@@ -21,7 +21,7 @@ class StreamParams(C.Structure):
                 ("crop", C.c_int * 4), ("tool_dra", C.c_int), ("dra_aps_id", C.c_int), ("cqt_present", C.c_int), ("cqt_same", C.c_int), ("cqt_global_offset", C.c_int),
                 ("cqt_num_points", C.c_int * 2), ("cqt_delta_in", (C.c_int * 16) * 2), ("cqt_delta_out", (C.c_int * 16) * 2), ("tool_htdf", C.c_int), ("tool_admvp", C.c_int), ("tool_mmvd", C.c_int), ("tool_dmvr", C.c_int), ("tool_amvr", C.c_int), ("tool_hmvp", C.c_int), ("ibc_log_max_size", C.c_int),
                 ("tile_cols", C.c_int), ("tile_rows", C.c_int), ("tile_col_w", C.c_int * abi.XGPU_MAX_TILE_COLS), ("tile_row_h", C.c_int * abi.XGPU_MAX_TILE_ROWS),
-                ("loop_filter_across_tiles", C.c_int), ("tool_affine", C.c_int), ("cu_qp_delta_area", C.c_int), ("tool_rpl", C.c_int), ("tool_pocs", C.c_int), ("tool_cm_init", C.c_int), ("rpl_in_sps", C.c_int)]
+                ("loop_filter_across_tiles", C.c_int), ("tool_affine", C.c_int), ("cu_qp_delta_area", C.c_int), ("tool_rpl", C.c_int), ("tool_pocs", C.c_int), ("tool_cm_init", C.c_int), ("tool_adcc", C.c_int), ("rpl_in_sps", C.c_int)]
 
 
 class AlfAps(C.Structure):
@@ -89,7 +89,7 @@ class StreamWriter:
     def __init__(self, width, height, bit_depth=8, max_num_ref_pics=1, qp_u_offset=0, qp_v_offset=0, deblock=True, cu_qp_delta=True,
                  log2_sub_gop=0, main=False, iqt=False, ats=False, addb=False, alpha_off=0, beta_off=0, alf=False, eipd=False, crop=(0, 0, 0, 0),
                  chroma_qp_points=None, dra_aps_id=None, htdf=False, ibc_log_max=0, admvp=False, amvr=False, hmvp=False, dmvr=False, mmvd=False,
-                 tiles=None, affine=False, qp_delta_area=0, rpl=False, pocs=False, rpl_in_sps=False, cm_init=False):
+                 tiles=None, affine=False, qp_delta_area=0, rpl=False, pocs=False, rpl_in_sps=False, cm_init=False, adcc=False):
         """chroma_qp_points: None, or (global_offset_flag, [table, ...]) with 1 (same for Cb and Cr) or 2 tables of (delta_in_minus1, delta_out) pairs"""
         self.lib = load()
         sp = StreamParams(width, height, bit_depth, max_num_ref_pics, log2_sub_gop, qp_u_offset, qp_v_offset, int(deblock), int(cu_qp_delta),
@@ -110,7 +110,7 @@ class StreamWriter:
         sp.tool_affine = int(affine)
         sp.cu_qp_delta_area = int(qp_delta_area)
         sp.tool_rpl, sp.tool_pocs, sp.rpl_in_sps = int(rpl), int(pocs), int(rpl_in_sps)
-        sp.tool_cm_init = int(cm_init)
+        sp.tool_cm_init, sp.tool_adcc = int(cm_init), int(adcc)
         if dra_aps_id is not None:
             sp.tool_dra, sp.dra_aps_id = 1, int(dra_aps_id)
         if chroma_qp_points is not None:
