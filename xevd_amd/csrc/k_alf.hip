@@ -123,7 +123,8 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
     const int ctu = 1 << a.log2_ctu;
     k.x0 = tx0 & ~(ctu - 1); k.y0 = ty0 & ~(ctu - 1);
     k.cw = min(ctu, a.pic_w - k.x0); k.ch = min(ctu, a.pic_h - k.y0);
-    {
+    k.tx0 = 0; k.tx1 = a.pic_w; k.ty0 = 0; k.ty1 = a.pic_h;
+    if (a.multi_tile) {
         const int cx = k.x0 >> a.log2_ctu, cy = k.y0 >> a.log2_ctu, h_ctu = (a.pic_h + ctu - 1) >> a.log2_ctu;
         k.tx0 = TileMask::tile_first(a.tiles.vb, cx) << a.log2_ctu; k.tx1 = min(TileMask::tile_end(a.tiles.vb, cx, a.w_ctu) << a.log2_ctu, a.pic_w);
         k.ty0 = TileMask::tile_first(a.tiles.hb, cy) << a.log2_ctu; k.ty1 = min(TileMask::tile_end(a.tiles.hb, cy, h_ctu) << a.log2_ctu, a.pic_h);

@@ -1082,6 +1082,7 @@ int xgpu_alf(xgpu_ctx *c, const xgpu_alf_params *ap)
     a.bd = c->sp.bit_depth_luma;           // one bit depth for classification and all clip ranges (xevd_alf_init, xevdm_alf.c:431-437)
     a.log2_ctu = c->sp.log2_ctu; a.w_ctu = c->w_ctu; a.across_tiles = ap->across_tiles ? 1 : 0;
     ARGCHK(c, tile_mask(c, ap->tiles, a.tiles));
+    a.multi_tile = ap->tiles && ap->tiles->n_cols * ap->tiles->n_rows > 1;
     ARGCHK(c, !ap->tiles || (ap->tiles->loop_filter_across_tiles != 0) == (ap->across_tiles != 0));
     for (int i = 0; i < 3; i++) a.enable[i] = ap->enable[i] ? 1 : 0;
     if (ap->luma_coef) memcpy(a.coef, ap->luma_coef, sizeof(int16_t) * 325);

@@ -224,6 +224,7 @@ struct AddbArgs {
 struct AlfArgs {
     int      s_l, s_c, pic_w, pic_h, bd, log2_ctu, w_ctu, across_tiles;
     TileMask tiles;                    // tile starts: a CTU's windows end at its tile (alf_process_tile)
+    int      multi_tile;               // 0: one tile - the masks are not looked at
     int      enable[3];
     const uint8_t *ctb_flag;           // device, [n_ctu] or null
     int16_t  coef[25 * 13 + 7];        // coef_final followed by the chroma filter
