@@ -761,9 +761,9 @@ struct TileCoder {
         };
         // an intra-block-copy neighbour does not count on the left and above - but does above-right, where the Main library's availability test
         // only asks "coded and not intra" (xevdm_get_avail_inter, xevdm_util.c:1468-1503): its stored vector is the block vector (list 1: zero)
-        take(0, xs > 0 && !pic.intra[scup - 1] && pic.cod[scup - 1] && !pic.ibc[scup - 1] && pic.same_tile(scup, scup - 1), scup - 1);
-        take(1, ys > 0 && !pic.intra[scup - ws] && !pic.ibc[scup - ws] && pic.same_tile(scup, scup - ws), scup - ws);
-        take(2, ys > 0 && xs + scuw < ws && pic.cod[scup - ws + scuw] && !pic.intra[scup - ws + scuw] && pic.same_tile(scup, scup - ws + scuw), scup - ws + scuw);
+        take(0, xs > 0 && pic.same_tile(scup, scup - 1) && !pic.intra[scup - 1] && pic.cod[scup - 1] && !pic.ibc[scup - 1], scup - 1);
+        take(1, ys > 0 && pic.same_tile(scup, scup - ws) && !pic.intra[scup - ws] && !pic.ibc[scup - ws], scup - ws);
+        take(2, ys > 0 && xs + scuw < ws && pic.same_tile(scup, scup - ws + scuw) && pic.cod[scup - ws + scuw] && !pic.intra[scup - ws + scuw], scup - ws + scuw);
         const RefPic *col = refp[lidx].empty() ? nullptr : refp[lidx][0];
         cand[3][0] = col ? col->mv0[(size_t)scup * 2] : (int16_t)0;
         cand[3][1] = col ? col->mv0[(size_t)scup * 2 + 1] : (int16_t)0;
@@ -792,7 +792,7 @@ struct TileCoder {
         const int ws = pic.w_scu, hs = pic.h_scu, xs = cu.x >> 2, ys = cu.y >> 2, scuw = (1 << cu.log2w) >> 2, scuh = (1 << cu.log2h) >> 2, scup = ys * ws + xs;
         neb[0] = scup + (scuh - 1) * ws - 1; neb[1] = scup - ws + scuw - 1; neb[2] = scup - ws + scuw; neb[3] = scup + scuh * ws - 1; neb[4] = scup - ws - 1;
         const bool in[5] = { xs > 0, ys > 0, ys > 0 && xs + scuw < ws, ys + scuh < hs && xs > 0, ys > 0 && xs > 0 };
-        for (int k = 0; k < 5; k++) valid[k] = in[k] && pic.cod[neb[k]] && !pic.intra[neb[k]] && !pic.ibc[neb[k]] && pic.same_tile(scup, neb[k]);
+        for (int k = 0; k < 5; k++) valid[k] = in[k] && pic.same_tile(scup, neb[k]) && pic.cod[neb[k]] && !pic.intra[neb[k]] && !pic.ibc[neb[k]];      // the tile test first: another tile's maps may be written right now
     }
     static void scale_mv(int ratio, const int16_t in[2], int16_t out[2])      // scaling_mv, xevdm_util.c:180-190 (MVP_SCALING_PRECISION 5)
     {
@@ -1028,7 +1028,7 @@ struct TileCoder {
         adm_neighbours(cu, neb, valid);
         default_motion(neb, valid, cur_refi, l, dref, dmv);
         const int n = (int)refp[l].size(), pc = refp[l][std::min(std::max(cur_refi, 0), n - 1)]->poc;
-        auto ratio = [&](int r) -> int { const int t0 = poc - refp[l][std::min(std::max(r, 0), n - 1)]->poc; return t0 ? ((poc - pc) << 5) / t0 : 0; };
+        auto ratio = [&](int r) -> int { const int t0 = poc - refp[l][std::min(std::max(r, 0), n - 1)]->poc; return t0 ? ((poc - pc) * 32) / t0 : 0; };
         int r = valid[mvr] ? (int)pic.refi[(size_t)neb[mvr] * 2 + l] : -1;
         if (r >= 0) {
             const int16_t *m = &pic.mv[(size_t)neb[mvr] * 4 + l * 2];
@@ -1059,8 +1059,8 @@ struct TileCoder {
     {
         const int xs = cu.x >> 2, ys = cu.y >> 2, ws = pic.w_scu, scup = ys * ws + xs;
         int l = 0, u = 0;
-        if (xs > 0 && pic.intra[scup - 1] && pic.cod[scup - 1] && pic.same_tile(scup, scup - 1)) l = pic.ipm[scup - 1] + 1;
-        if (ys > 0 && pic.intra[scup - ws] && pic.cod[scup - ws] && pic.same_tile(scup, scup - ws)) u = pic.ipm[scup - ws] + 1;
+        if (xs > 0 && pic.same_tile(scup, scup - 1) && pic.intra[scup - 1] && pic.cod[scup - 1]) l = pic.ipm[scup - 1] + 1;
+        if (ys > 0 && pic.same_tile(scup, scup - ws) && pic.intra[scup - ws] && pic.cod[scup - ws]) u = pic.ipm[scup - ws] + 1;
         return k_mpm[l][u];
     }
     // tool_eipd: the two most probable modes, eight "extended" ones and the ordering of all 33 (xevdm_get_mpm, src_main/xevdm_ipred.c:
@@ -1070,8 +1070,8 @@ struct TileCoder {
         enum { DC = 0, PLN = 1, BI = 2, VER = 12, HOR = 24, DIA_R = 18, DIA_L = 6, DIA_U = 30, CNT = 33 };
         const int xs = cu.x >> 2, ys = cu.y >> 2, ws = pic.w_scu, scup = ys * ws + xs;
         int l = DC, u = DC;
-        if (xs > 0 && pic.intra[scup - 1] && pic.cod[scup - 1] && pic.same_tile(scup, scup - 1)) l = pic.ipm[scup - 1];
-        if (ys > 0 && pic.intra[scup - ws] && pic.cod[scup - ws] && pic.same_tile(scup, scup - ws)) u = pic.ipm[scup - ws];
+        if (xs > 0 && pic.same_tile(scup, scup - 1) && pic.intra[scup - 1] && pic.cod[scup - 1]) l = pic.ipm[scup - 1];
+        if (ys > 0 && pic.same_tile(scup, scup - ws) && pic.intra[scup - ws] && pic.cod[scup - ws]) u = pic.ipm[scup - ws];
         mpm[0] = std::min(l, u); mpm[1] = std::max(l, u);
         if (mpm[0] == mpm[1]) { mpm[0] = DC; mpm[1] = mpm[1] == DC ? BI : mpm[1]; }
         const int m0 = mpm[0], m1 = mpm[1];
@@ -1132,7 +1132,7 @@ struct TileCoder {
     // neighbour SCU n of the CU at scup: decoded, inter, same tile - and affine (model-based candidates) or not IBC (corner vectors)
     bool aff_nb(int scup, int n, bool inside, bool need_affine) const
     {
-        if (!inside || !pic.cod[n] || pic.intra[n] || !pic.same_tile(scup, n)) return false;
+        if (!inside || !pic.same_tile(scup, n) || !pic.cod[n] || pic.intra[n]) return false;
         return need_affine ? pic.aff[n] != 0 : !pic.ibc[n];
     }
     // the model of the affine CU that covers SCU scun, evaluated at this CU's corners (xevdm_derive_affine_model_mv, xevdm_util.c:2270-2363)
@@ -1249,7 +1249,7 @@ struct TileCoder {
     void aff_merge(const Cu &cu, int8_t refi[5][2], int16_t cpmv[5][2][3][2], int cpn[5]) const
     {
         const int ws = pic.w_scu, hs = pic.h_scu, xs = cu.x >> 2, ys = cu.y >> 2, scuw = (1 << cu.log2w) >> 2, scuh = (1 << cu.log2h) >> 2, scup = ys * ws + xs;
-        const bool left_avail = xs > 0 && pic.cod[(size_t)scup - 1] && pic.same_tile(scup, scup - 1);      // avail_lr LR_10 (xevd_check_nev_avail, xevd_util.c:1156-1174)
+        const bool left_avail = xs > 0 && pic.same_tile(scup, scup - 1) && pic.cod[(size_t)scup - 1];      // avail_lr LR_10 (xevd_check_nev_avail, xevd_util.c:1156-1174)
         int cnt = 0;
         memset(cpmv, 0, sizeof(int16_t) * 5 * 2 * 3 * 2);
         {   // model based: A1, B1, B0, A0, B2 - one candidate per distinct affine neighbour CU
@@ -1568,7 +1568,7 @@ struct TileCoder {
         const bool in[2] = { ys > 0, xs > 0 };
         int n = 0;
         for (int k = 0; k < 2; k++) {
-            if (!in[k] || !pic.cod[(size_t)nb[k]] || !pic.same_tile(scup, nb[k])) continue;
+            if (!in[k] || !pic.same_tile(scup, nb[k]) || !pic.cod[(size_t)nb[k]]) continue;
             n += what == CTX_SKIP ? pic.skip[(size_t)nb[k]] : what == CTX_PRED ? pic.intra[(size_t)nb[k]] : what == CTX_IBC ? pic.ibc[(size_t)nb[k]] : (!pic.aff.empty() && pic.aff[(size_t)nb[k]] != 0);
         }
         return std::min(n, what == CTX_PRED ? 2 : 1);
@@ -1758,7 +1758,7 @@ struct TileCoder {
                             cu.mvd[l][d] = (int16_t)(sg ? -a : a);
                         }
                     }
-                    cu.mv[l][0] = (int16_t)(mvp[0] + (cu.mvd[l][0] << mvr)); cu.mv[l][1] = (int16_t)(mvp[1] + (cu.mvd[l][1] << mvr));
+                    cu.mv[l][0] = (int16_t)(mvp[0] + cu.mvd[l][0] * (1 << mvr)); cu.mv[l][1] = (int16_t)(mvp[1] + cu.mvd[l][1] * (1 << mvr));
                 }
             }
         } else if (!intra) {
