@@ -21,7 +21,8 @@
  * bi_idx / mmvd_flag + mmvd data syntax (xevdm_eco.c:767-812,1519-1726), merge with vector difference (src_main/xevdm_util.c:191-592,4682-4716), merge candidates incl. the temporal and history ones (src_main/xevdm_util.c:594-1391,3729-3818), the resolution-indexed
  * predictor (:750-951), intra-only 4x4 CUs; tool_dmvr needs the backend's refined vectors back per picture (xhost_parser_set_dmvr_mvs) and is refused
  * together with tool_hmvp or tool_mmvd.  tool_affine (affine merge / affine inter CUs, xevdm_util.c:2145-3187) is parsed too.
- * Not parsed: sps_btt_flag / sps_suco_flag (the split syntax).  tool_cm_init (context initialisation tables, neighbour-dependent contexts) and tool_adcc
+ * sps_btt_flag (binary / ternary split trees with CTU 64, "inter only" mode constraints) is parsed; refused: sps_suco_flag, and the local dual tree ("intra only"
+ * constraint: luma-only / chroma-only CUs) when a BTT + ADMVP stream uses it.  tool_cm_init (context initialisation tables, neighbour-dependent contexts) and tool_adcc
  * (advanced coefficient coding) are parsed.
  * dquant_flag (QP deltas per quantisation group), tool_rpl (reference picture lists in SPS / slice headers, RPL-based marking) and tool_pocs
  * (POC from poc_lsb) are parsed.  SPS chroma QP mapping tables and cropping offsets are parsed, a VUI is skipped; 4:2:0, one slice per picture (with all of its
@@ -144,6 +145,10 @@ typedef struct xhost_stream_params {
                                               affine flags, the run / level pair and the ATS-inter flags pick their contexts from neighbours, levels and CU shapes */
     int tool_adcc;                         /* Main, switches tool_cm_init on: sps->tool_adcc - coefficient blocks as last position + significance / greater-than flags /
                                               Golomb-Rice remainders per group of 16 (xevdm_eco_adcc) instead of run-level pairs */
+    int btt;                               /* Main: sps_btt_flag (CTU 64) - the batch's CUs are the leaves of a binary / ternary split tree (non-square CUs 4x8 .. 64x16);
+                                              the writer finds the tree from the leaves.  Limits of the tree: smallest CU side 2^btt_log2_min_cb (2..6), and the SPS fields
+                                              log2_diff_ctu_max_14_cb_size / log2_diff_ctu_max_tt_cb_size / log2_diff_min_cb_min_tt_cb_size_minus2 (xevdm_util.c:4393-4400) */
+    int btt_log2_min_cb, btt_diff_max_14, btt_diff_max_tt, btt_diff_min_tt;
     int rpl_in_sps;                        /* with tool_rpl, low delay and at least 2 references: RPL candidates in the SPS, picked by index where they match */
 } xhost_stream_params;
 
@@ -190,6 +195,9 @@ int  xhost_writer_set_slice_alf(xhost_writer *w, const xhost_slice_alf *sa);    
    and with tool_ats: ats (intra CUs up to 32x32 with luma coefficients) and ats_inter (inter CUs; dropped when the shape does
    not allow the split; the coefficient blocks then have the TU size).
    idr != 0 forces an IDR picture with an I slice.  temporal_id: nuh_temporal_id (0 for low-delay streams). */
+/* sps_btt_flag: which splits the stream allows for the node (x, y, 2^log2w x 2^log2h) - allow[0] none, [1] / [2] binary with a vertical / horizontal cut, [3] / [4]
+   ternary; 2 instead of 1: only below which every CU is an inter CU of a P / B picture (the children get the "inter only" mode constraint) */
+int  xhost_writer_split_allowed(xhost_writer *w, int x, int y, int log2w, int log2h, int allow[5]);
 int  xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type, int slice_qp, int temporal_id, const xgpu_cu_batch *b);
 /* Appends a picture-signature SEI NAL unit (payload type 0x10) for the picture added last: the MD5 digests of its decoded Y, U, V
    planes (16-bit little-endian samples, rows without padding).  The reference decoder verifies them when

@@ -182,6 +182,11 @@ def golden_streams(only=()):
                                                                                addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=5, inter_frac=0.9, skip_frac=0.3, direct_frac=0.3, max_refs=3,
                                                                                log2_sub_gop=3, bit_depth=10, qp_delta_area=8)),
                                 "main_adcc_low_qp_8b": (200, 136, 5, dict(main=True, adcc=True, iqt=True, max_refs=2, max_level=3000, qp_range=(0, 8))),
+                                "main_btt_p_8b": (136, 72, 4, dict(main=True, btt=(2, 0, 0, 0), max_refs=2, split_prob=0.7)),
+                                "main_btt_all_tools_10b": (264, 200, 9, dict(main=True, btt=(2, 0, 0, 0), admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, iqt=True, ats=True, addb=True, alf=True,
+                                                                             eipd=True, htdf=True, cm_init=True, adcc=True, rpl=True, pocs=True, qp_delta_area=8, max_refs=2, log2_sub_gop=2, split_prob=0.7,
+                                                                             bit_depth=10, inter_frac=0.9, skip_frac=0.3, direct_frac=0.3)),
+                                "main_btt_tiles_8b": (392, 264, 5, dict(main=True, btt=(3, 1, 1, 1), iqt=True, addb=True, alf=True, tiles=(2, 2, 0), max_refs=2, split_prob=0.8)),
                                 "main_dquant_area8_10b": (264, 200, 9, dict(main=True, admvp=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, inter_frac=0.8, split_prob=0.65, max_refs=2,
                                                                             log2_sub_gop=2, bit_depth=10, qp_delta_area=8)),
                                 # sps->tool_affine: affine merge and affine inter CUs from the bitstream

@@ -27,14 +27,14 @@ def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_fra
                 cu_qp_delta=True, split_prob=0.5, idr_period=0, log2_sub_gop=0, bi_frac=0.5, direct_frac=0.1,
                 main=False, iqt=False, ats=False, addb=False, addb_offsets=(0, 0), alf=False, sign=False, eipd=False, crop=(0, 0, 0, 0),
                 chroma_qp_points=None, dra=None, htdf=False, ibc_log_max=0, ibc_frac=0.25, alf_fixed=False, admvp=False, amvr=False, hmvp=False, dmvr=False, mmvd=False,
-                tiles=None, affine=False, affine_frac=0.4, qp_delta_area=0, rpl=False, pocs=False, rpl_in_sps=False, cm_init=False, adcc=False, max_level=6, qp_range=(22, 37)):
+                tiles=None, affine=False, affine_frac=0.4, qp_delta_area=0, rpl=False, pocs=False, rpl_in_sps=False, cm_init=False, adcc=False, max_level=6, qp_range=(22, 37), btt=None):
     """-> bytes.  Picture 0 is an IDR.  log2_sub_gop = 0: IPPP; n: hierarchical sub-GOPs of 2^n pictures, the layer-0 picture of
     each a P picture, the others B pictures (bi-prediction, temporal direct and two-list skip CUs).
     sign: every picture is followed by a picture-signature SEI with the MD5s of the ORACLE's reconstruction of the stream so far."""
     rng = np.random.default_rng(seed)
     w = stream.StreamWriter(width, height, bit_depth, max_refs, qp_offsets[0], qp_offsets[1], deblock, cu_qp_delta, log2_sub_gop,
                             main=main, iqt=iqt, ats=ats, addb=addb, alpha_off=addb_offsets[0], beta_off=addb_offsets[1], alf=alf, eipd=eipd, crop=crop, chroma_qp_points=chroma_qp_points,
-                            dra_aps_id=None if dra is None else 3, htdf=htdf, ibc_log_max=ibc_log_max, admvp=admvp, amvr=amvr, hmvp=hmvp, dmvr=dmvr, mmvd=mmvd, tiles=tiles, affine=affine, qp_delta_area=qp_delta_area, rpl=rpl, pocs=pocs, rpl_in_sps=rpl_in_sps, cm_init=cm_init, adcc=adcc)
+                            dra_aps_id=None if dra is None else 3, htdf=htdf, ibc_log_max=ibc_log_max, admvp=admvp, amvr=amvr, hmvp=hmvp, dmvr=dmvr, mmvd=mmvd, tiles=tiles, affine=affine, qp_delta_area=qp_delta_area, rpl=rpl, pocs=pocs, rpl_in_sps=rpl_in_sps, cm_init=cm_init, adcc=adcc, btt=btt)
     n_ctu = ((width + 63) // 64) * ((height + 63) // 64)
     tids = gop_tids(log2_sub_gop)
     try:
@@ -48,9 +48,18 @@ def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_fra
                 since_idr = 0
             tid = 0 if idr else tids[(since_idr - 1) % len(tids)]
             is_b = (not idr) and tid > 0
-            b = synth.gen_frame(rng, width, height, bit_depth, inter_frac=0.0 if idr else inter_frac, n_refs=(max_refs, max_refs if is_b else 0),
+            only_inter = None if idr else []      # P / B pictures: also splits whose children get the "inter only" mode constraint (sps_btt_flag with tool_admvp)
+            part = None if btt is None else synth.gen_partition_tree(rng, width, height, w.split_allowed, split_prob, inter_only=only_inter)      # sps_btt_flag: a legal binary / ternary tree
+            b = synth.gen_frame(rng, width, height, bit_depth, partition=part, inter_frac=0.0 if idr else inter_frac, n_refs=(max_refs, max_refs if is_b else 0),
                                 bi_frac=bi_frac if is_b else 0.0, split_prob=split_prob, coded_frac=0.6, max_level=max_level, amp=1.0, qp_range=qp_range,
                                 ats_frac=0.5 if ats else 0.0, ats_inter_frac=0.5 if ats else 0.0, eipd=eipd)
+            if only_inter:      # CUs below a mode-constrained split: inter CUs (an intra one becomes a list-0 CU with a small vector)
+                sel = np.array(only_inter)
+                fix = sel[b["pred_mode"][sel] == 0]
+                b["pred_mode"][fix] = 1
+                b["refi"][fix, 0] = 0; b["refi"][fix, 1] = -1
+                b["mv"][fix] = 0
+                b["mv"][fix, 0, :] = rng.integers(-20, 21, (len(fix), 2))
             if not idr:
                 inter = b["pred_mode"] == 1
                 r = rng.random(len(inter))

@@ -122,6 +122,18 @@ CONFIGS = [
     (200, 136, 9, dict(main=True, adcc=True, iqt=True, ats=True, max_refs=2, log2_sub_gop=2)),
     (264, 136, 17, dict(main=True, adcc=True, rpl=True, pocs=True, admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True,
                         ibc_log_max=5, inter_frac=0.9, skip_frac=0.3, direct_frac=0.3, max_refs=3, log2_sub_gop=3, bit_depth=10, qp_delta_area=8)),
+    # sps_btt_flag: binary / ternary split trees (no quad split), non-square CUs 4x8 .. 64x16 through every CU-level derivation, the SPS limits of the tree,
+    # implicit splits at the picture border, split-flag contexts from the neighbours' sizes (cm_init), "inter only" mode constraints (admvp), QP groups of TT nodes
+    (64, 64, 1, dict(main=True, btt=(2, 0, 0, 0), idr_period=1, split_prob=0.6)),
+    (136, 72, 4, dict(main=True, btt=(2, 0, 0, 0), max_refs=2, split_prob=0.7)),
+    (264, 200, 4, dict(main=True, btt=(3, 1, 1, 1), max_refs=2, split_prob=0.8)),
+    (200, 136, 9, dict(main=True, btt=(2, 0, 0, 0), max_refs=2, log2_sub_gop=2, split_prob=0.7)),
+    (200, 136, 5, dict(main=True, btt=(2, 0, 1, 0), adcc=True, max_refs=2, split_prob=0.75)),
+    (200, 136, 5, dict(main=True, btt=(2, 0, 0, 0), eipd=True, htdf=True, qp_delta_area=8, max_refs=2, split_prob=0.7)),
+    (200, 136, 5, dict(main=True, btt=(2, 0, 0, 0), admvp=True, max_refs=2, split_prob=0.7)),
+    (264, 200, 9, dict(main=True, btt=(2, 0, 0, 0), admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, cm_init=True, adcc=True,
+                       rpl=True, pocs=True, qp_delta_area=8, max_refs=2, log2_sub_gop=2, split_prob=0.7, bit_depth=10, inter_frac=0.9, skip_frac=0.3, direct_frac=0.3)),
+    (392, 264, 5, dict(main=True, btt=(2, 0, 0, 0), iqt=True, addb=True, tiles=(2, 2, 0), max_refs=2, split_prob=0.7)),
     # sps->dquant_flag: one QP delta per quantisation group of pps.cu_qp_delta_area samples (8x8 ... 64x64; an odd area never matches a square node)
     (264, 200, 5, dict(main=True, iqt=True, qp_delta_area=6, split_prob=0.7, inter_frac=0.7)),
     (264, 200, 5, dict(main=True, iqt=True, qp_delta_area=10, split_prob=0.7, inter_frac=0.7)),

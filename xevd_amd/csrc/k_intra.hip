@@ -444,14 +444,16 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 ol[r][0] = pack2i(pl[r][0], pl[r][1]); ol[r][1] = pack2i(pl[r][2], pl[r][3]);
-                if (cbf & 1) { ol[r][0] = recon2i(ol[r][0], rl[r].x, maxv); ol[r][1] = recon2i(ol[r][1], rl[r].y, maxv); }
+                // also without coefficients: the reference clips the prediction (xevd_recon.c:44-51) - the DC of a 4x8 / 8x4 block next to an unavailable side
+                // (mid-grey neighbours, sum of 12 samples shifted by 3) leaves the sample range
+                ol[r][0] = recon2i(ol[r][0], (cbf & 1) ? rl[r].x : 0u, maxv); ol[r][1] = recon2i(ol[r][1], (cbf & 1) ? rl[r].y : 0u, maxv);
             }
 #pragma unroll
             for (int c = 1; c < 3; c++)
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
                     oc[c - 1][r] = pack2i(pc[c - 1][r][0], pc[c - 1][r][1]);
-                    if ((cbf >> c) & 1) oc[c - 1][r] = recon2i(oc[c - 1][r], rc[c - 1][r], maxv);   // the luma depth clips chroma too (xevd_recon.c:75-90)
+                    oc[c - 1][r] = recon2i(oc[c - 1][r], ((cbf >> c) & 1) ? rc[c - 1][r] : 0u, maxv);   // the luma depth clips chroma too (xevd_recon.c:75-90)
                 }
             const int coff = (y >> 1) * a.s_c + (x >> 1);
 #pragma unroll

@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <map>
 #include <memory>
 #include <thread>
 #include <cstdio>
@@ -217,6 +218,7 @@ struct Models {
           ibc_flag[2],                                                                               // sps->ibc_flag: xevd_def.h:485
           affine_flag[2], affine_mode[1], affine_mrg[5], affine_mvp_idx[1], affine_mvd_flag[2],       // tool_affine: xevd_def.h:483-498
           ipm_mpm_flag[1], ipm_mpm_idx[1], ipm_chroma[1],                                            // tool_eipd: xevd_def.h intra_luma_pred_mpm_flag / _idx, intra_chroma_pred_mode
+          btt_split_flag[15], btt_split_dir[5], btt_split_type[1], mode_cons[3],                        // sps_btt_flag: xevd_def.h:486-491
           sig_coeff[47], gt_ab[18], last_x[21], last_y[21];                                          // tool_adcc: xevd_def.h sig_coeff_flag, coeff_abs_level_greaterAB_flag, last_sig_coeff_{x,y}_prefix
     void reset() { Model *p = (Model *)this; for (size_t i = 0; i < sizeof(Models) / sizeof(Model); i++) p[i] = 512; }     // PROB_INIT, xevd_eco.c:769-803
     // sps->tool_cm_init: every context starts from its initValue, the slice kind and the slice QP (xevd_eco_sbac_ctx_initialize, src_base/xevd_util.c:1243-1274;
@@ -240,7 +242,7 @@ struct Models {
         CM(split); CM(run); CM(last); CM(level); CM(cbf_luma); CM(cbf_cb); CM(cbf_cr); CM(cbf_all); CM(pred_mode); CM(direct); CM(inter_dir); CM(intra_dir); CM(mvp_idx);
         CM(mvd); CM(refi); CM(dqp); CM(skip); CM(ats_mode); CM(ats_inter_flag); CM(ats_inter_quad); CM(ats_inter_hor); CM(ats_inter_pos); CM(alf_ctb); CM(mmvd_flag);
         CM(mmvd_merge_idx); CM(mmvd_dist_idx); CM(mmvd_dir_idx); CM(mmvd_group_idx); CM(mvr_idx); CM(merge_mode); CM(merge_idx); CM(bi_idx); CM(ibc_flag); CM(affine_flag);
-        CM(affine_mode); CM(affine_mrg); CM(affine_mvp_idx); CM(affine_mvd_flag); CM(ipm_mpm_flag); CM(ipm_mpm_idx); CM(ipm_chroma); CM(sig_coeff); CM(gt_ab); CM(last_x); CM(last_y);
+        CM(affine_mode); CM(affine_mrg); CM(affine_mvp_idx); CM(affine_mvd_flag); CM(ipm_mpm_flag); CM(ipm_mpm_idx); CM(ipm_chroma); CM(btt_split_flag); CM(btt_split_dir); CM(btt_split_type); CM(mode_cons); CM(sig_coeff); CM(gt_ab); CM(last_x); CM(last_y);
 #undef CM
     }
 };
@@ -284,6 +286,8 @@ struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, lo
              int tool_amvr = 0, tool_hmvp = 0;       // sub-tools of tool_admvp: adaptive vector resolution (mvr_idx), history-based candidates
              int tool_rpl = 0, tool_pocs = 0, poc_lsb_bits = 4;      // sps->tool_rpl: reference lists and marking from signalled RPLs; tool_pocs: POC from poc_lsb in the slice header
              int n_rpl[2] = { 0, 0 }; Rpl rpls[2][32];               // RPL candidates of the SPS (sps->rpls_l0 / rpls_l1)
+             int btt = 0, log2_min_cb = 2, split_tbl[4][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };      // sps_btt_flag: binary / ternary splits; allowed long sides (min, max) per shape 1:1, 1:2, 1:4, TT
+             int btt_raw[4] = { 0, 0, 0, 0 };         // the SPS fields behind split_tbl (min cb - 2, diff max 1:4, diff max TT, diff min TT - 2)
              int tool_cm_init = 0, tool_adcc = 0;     // sps->tool_cm_init: contexts start from tables (slice kind, QP) and several flags pick theirs from the neighbours; tool_adcc
              int dquant = 0;                         // sps->dquant_flag (Main): QP deltas per quantisation group of pps.cu_qp_delta_area instead of per coded CU
              int tool_affine = 0;                    // sps->tool_affine: affine merge / affine inter CUs (4- or 6-parameter models from 2 / 3 control points)
@@ -356,6 +360,7 @@ struct Cu {
     int ats_inter;                   // ats_inter_info: idx | pos << 4
     int mmvd, mmvd_idx;              // mmvd_flag; group << 7 | base candidate << 5 | distance << 2 | direction
     int dmvr;                        // tool_dmvr and a skip / merge-mode CU: mcore->dmvr_enable (xevdm.c:1272-1288)
+    int only_inter;                  // mode constraint eOnlyInter of a local tree (sps_btt_flag with tool_admvp): no pred_mode_flag, no IBC
     int qp_code;                     // core->cu_qp_delta_code (sps->dquant_flag): 0 - , 1 a CU of at least a quantisation group, 2 a CU inside a group
     int affine;                      // mcore->affine_flag: 0 translational, 1 / 2 = 2 / 3 control points (4- / 6-parameter model)
     int16_t aff_mv[2][3][2];         // mcore->affine_mv[list][vertex][x/y]: top-left, top-right, bottom-left control-point vectors
@@ -366,6 +371,7 @@ struct Cu {
 struct Picture {         // SCU maps of the picture being parsed / written (ctx->map_scu, map_ipm, map_mv, map_refi; cod_eco)
     int w_scu = 0, h_scu = 0;
     std::vector<uint8_t> cod, intra, ibc;      // ibc: MCU_GET_IBC
+    std::vector<uint8_t> cu_size;    // log2w | log2h << 4 of the CU over the SCU (map_cu_mode; only kept for the split-flag contexts: sps_btt_flag with tool_cm_init)
     std::vector<uint8_t> skip;       // MCU_GET_SF (only kept with sps->tool_cm_init: the skip flag's context counts skipped neighbours)
     std::vector<uint8_t> tidx;       // ctx->map_tidx: the tile of every SCU (empty: one tile) - neighbours in another tile are not available
     bool same_tile(int a, int b) const { return tidx.empty() || tidx[(size_t)a] == tidx[(size_t)b]; }
@@ -378,7 +384,7 @@ struct Picture {         // SCU maps of the picture being parsed / written (ctx-
     {
         w_scu = w >> 2; h_scu = h >> 2;
         const size_t f = (size_t)w_scu * h_scu;
-        cod.assign(f, 0); intra.assign(f, 0); ibc.assign(f, 0); ipm.assign(f, 0); mv.assign(f * 4, 0); refi.assign(f * 2, -1); tidx.clear(); aff.clear(); skip.clear();
+        cod.assign(f, 0); intra.assign(f, 0); ibc.assign(f, 0); ipm.assign(f, 0); mv.assign(f * 4, 0); refi.assign(f * 2, -1); tidx.clear(); aff.clear(); skip.clear(); cu_size.clear();
     }
 };
 
@@ -507,6 +513,7 @@ struct Stream {          // everything both directions share
         if (grid.col_bd[grid.n_cols] != w_ctu || grid.row_bd[grid.n_rows] != h_ctu) return false;
         if (sps.tool_affine) { pic.aff.assign((size_t)pic.w_scu * pic.h_scu, 0); pic.aff_tl.resize((size_t)pic.w_scu * pic.h_scu); }
         if (sps.tool_cm_init) pic.skip.assign((size_t)pic.w_scu * pic.h_scu, 0);
+        if (sps.tool_cm_init && sps.btt) pic.cu_size.assign((size_t)pic.w_scu * pic.h_scu, 0);
         pic.tidx.clear();
         if (grid.n_cols * grid.n_rows > 1) {
             pic.tidx.assign((size_t)pic.w_scu * pic.h_scu, 0);
@@ -1381,6 +1388,7 @@ struct TileCoder {
             const size_t k = (size_t)(ys + r) * pic.w_scu + xs + c;
             pic.cod[k] = 1; pic.intra[k] = cu.mode == MODE_INTRA; pic.ibc[k] = cu.mode == MODE_IBC; pic.ipm[k] = (int8_t)cu.ipm;
             if (!pic.skip.empty()) pic.skip[k] = cu.mode == MODE_SKIP;
+            if (!pic.cu_size.empty()) pic.cu_size[k] = (uint8_t)(cu.log2w | (cu.log2h << 4));
             for (int l = 0; l < 2; l++) { pic.refi[k * 2 + l] = (int8_t)cu.refi[l]; pic.mv[k * 4 + l * 2] = cu.mv[l][0]; pic.mv[k * 4 + l * 2 + 1] = cu.mv[l][1]; }
         }
         if (cu.affine && cu.mode != MODE_INTRA && cu.mode != MODE_IBC) aff_store(cu);
@@ -1556,6 +1564,90 @@ struct TileCoder {
     // ---- one CU: syntax (xevd_eco_cu, xevd_eco.c:1048-1176; cbf :260-341; coefficients/QP :593-767) + derivations ----
     // enc: `cu` and `coef` carry the wanted values (mv of an INTER CU is met through mvd, a SKIP CU takes its predictor's motion);
     // dec: they are filled.  coef[c]: w*h (w/2*h/2) values of component c, zero-initialised by the caller when decoding.
+    // ---- sps_btt_flag: which splits a node may take (xevdm_check_split_mode, src_main/xevdm_util.c:1575-1680).  Index = split mode: 0 none, 1 binary with a
+    //      vertical cut, 2 binary horizontal, 3 ternary vertical (1/4, 1/2, 1/4), 4 ternary horizontal; there is no quad split with BTT.  Shapes are limited
+    //      through the SPS table of long sides per aspect ratio; a node crossing the picture border takes a binary split towards it ----
+    enum { NO_SPLIT = 0, BI_VER = 1, BI_HOR = 2, TRI_VER = 3, TRI_HOR = 4, QUAD = 5 };
+    bool ratio_ok(int long_side, int ratio) const { return ratio <= 2 && long_side <= sps.split_tbl[ratio][1] && long_side >= sps.split_tbl[ratio][0]; }
+    bool tri_ok(int long_side) const { return long_side <= sps.split_tbl[3][1] && long_side >= sps.split_tbl[3][0]; }
+    static bool small_child_is_4x4(int split, int w, int h) { if (split == BI_HOR) h >>= 1; else if (split == BI_VER) w >>= 1; else if (split == TRI_HOR) h >>= 2; else w >>= 2; return w == 4 && h == 4; }
+    static bool chroma_split_ok(int split, int w, int h) { if (split == BI_HOR) h >>= 1; else if (split == BI_VER) w >>= 1; else if (split == TRI_HOR) h >>= 2; else w >>= 2; return w * h >= 64; }
+    void split_allowed(int allow[6], int lw, int lh, int x, int y, bool only_inter) const
+    {
+        const int W = sps.width, H = sps.height, w = 1 << lw, h = 1 << lh;
+        const bool boundary = !(x + w <= W && y + h <= H), boundary_r = boundary && x + w > W && !(y + h > H);
+        const bool from_boundary_b = y >= H - H % 32 && !(x >= W - W % 32);      // cu_max = half a CTU
+        for (int i = 0; i < 6; i++) allow[i] = 0;
+        allow[NO_SPLIT] = 1;                     // (the reference leaves this entry unset and never reads it for a node inside the picture)
+        const bool tv = tri_ok(lw) && (lw > lh || (lw == lh && ratio_ok(lw, 2))), th = tri_ok(lh) && (lh > lw || (lw == lh && ratio_ok(lh, 2)));
+        if (lw == lh) { allow[BI_HOR] = allow[BI_VER] = ratio_ok(lw, 1); }
+        else if (lw > lh) {
+            allow[BI_HOR] = ratio_ok(lw, lw - lh + 1);
+            const int sw = lw - 1, ratio = sw > lh ? sw - lh : lh - sw;
+            allow[BI_VER] = ratio_ok(std::max(sw, lh), ratio) || (from_boundary_b && (ratio == 3 || ratio == 4));
+        } else {
+            const int sh_ = lh - 1, ratio = lw > sh_ ? lw - sh_ : sh_ - lw;
+            allow[BI_HOR] = ratio_ok(std::max(lw, sh_), ratio);
+            allow[BI_VER] = ratio_ok(lh, lh - lw + 1);
+        }
+        allow[TRI_VER] = tv; allow[TRI_HOR] = th;
+        if (boundary) {
+            allow[NO_SPLIT] = allow[TRI_VER] = allow[TRI_HOR] = 0;
+            if (boundary_r) allow[BI_HOR] = !allow[BI_VER]; else allow[BI_VER] = !allow[BI_HOR];
+        }
+        if (only_inter) for (int m = BI_VER; m <= TRI_HOR; m++) allow[m] = allow[m] && !small_child_is_4x4(m, w, h);
+    }
+    // split syntax of a node inside the picture (xevdm_eco_split_mode, src_main/xevdm_eco.c:1173-1296): btt_split_flag, direction, type - each only when
+    // both alternatives are allowed; with tool_cm_init the flag's context counts the neighbours (above / left) that are narrower / lower than the node
+    template <class C> int code_split(C &c, int want, int x, int y, int lw, int lh, bool only_inter)
+    {
+        if (lw < 3 && lh < 3) return NO_SPLIT;
+        int allow[6];
+        split_allowed(allow, lw, lh, x, y, only_inter);
+        if (!(allow[BI_VER] || allow[BI_HOR] || allow[TRI_VER] || allow[TRI_HOR])) return NO_SPLIT;
+        int ctx = 0;
+        if (sps.tool_cm_init) {
+            static const uint8_t shape_ctx[6][6] = { { 255, 4, 4, 14, 15, 15 }, { 4, 4, 3, 3, 2, 2 }, { 4, 3, 3, 2, 2, 1 }, { 14, 3, 2, 2, 1, 1 }, { 15, 2, 2, 1, 1, 0 }, { 15, 2, 1, 1, 0, 0 } };      // xevd_tbl_split_flag_ctx
+            const int ws = pic.w_scu, xs = x >> 2, ys = y >> 2, scup = ys * ws + xs;
+            int smaller = 0;
+            if (ys > 0 && pic.same_tile(scup, scup - ws)) smaller += (1 << (pic.cu_size[(size_t)scup - ws] & 15)) < (1 << lw);                                  // above: parsed whenever it is in the tile
+            if (xs > 0 && pic.same_tile(scup, scup - 1) && pic.cod[(size_t)scup - 1]) smaller += (1 << (pic.cu_size[(size_t)scup - 1] >> 4)) < (1 << lh);
+            ctx = std::min(smaller, 2) + 3 * shape_ctx[lw - 2][lh - 2];
+            if (ctx > 14) ctx = 14;
+        }
+        if (!c.bin(want != NO_SPLIT, models.btt_split_flag[ctx])) return NO_SPLIT;
+        const bool ver_ok = allow[BI_VER] || allow[TRI_VER], hor_ok = allow[BI_HOR] || allow[TRI_HOR];
+        int dir = want == BI_VER || want == TRI_VER;
+        if (ver_ok && hor_ok) dir = c.bin(dir, models.btt_split_dir[sps.tool_cm_init ? lw - lh + 2 : 0]); else dir = ver_ok;
+        int tri = want == TRI_VER || want == TRI_HOR;
+        if ((dir && allow[BI_VER] && allow[TRI_VER]) || (!dir && allow[BI_HOR] && allow[TRI_HOR])) tri = c.bin(tri, models.btt_split_type[0]);
+        else tri = (dir && allow[TRI_VER]) || (!dir && allow[TRI_HOR]);
+        return tri ? (dir ? TRI_VER : TRI_HOR) : (dir ? BI_VER : BI_HOR);
+    }
+    // children of a split node: position and size
+    static int split_parts(int split, int x, int y, int lw, int lh, int px[3], int py[3], int plw[3], int plh[3])
+    {
+        const int n = split == BI_VER || split == BI_HOR ? 2 : 3, ver = split == BI_VER || split == TRI_VER;
+        int off = 0;
+        for (int i = 0; i < n; i++) {
+            const int shrink = n == 2 ? 1 : (i == 1 ? 1 : 2);
+            plw[i] = ver ? lw - shrink : lw; plh[i] = ver ? lh : lh - shrink;
+            px[i] = ver ? x + off : x; py[i] = ver ? y : y + off;
+            off += 1 << (ver ? plw[i] : plh[i]);
+        }
+        return n;
+    }
+    // the mode constraint a split node hands to its children with sps_btt_flag and tool_admvp (xevd_entropy_decode_tree, src_main/xevdm.c:1775-1802):
+    // 0 none, 1 inter only (signalled), -1 intra only = a local dual tree (luma CUs, then one chroma CU), which the batch format cannot express
+    template <class C> int code_mode_cons(C &c, int split, int lw, int lh, bool only_inter, int want_only_inter)
+    {
+        if (!(sps.btt && sps.tool_admvp) || only_inter) return only_inter ? 1 : 0;
+        const int w = 1 << lw, h = 1 << lh;
+        if (chroma_split_ok(split, w, h)) return 0;
+        if (sh.type == XHOST_SLICE_I || small_child_is_4x4(split, w, h)) return -1;
+        return c.bin(!want_only_inter, models.mode_cons[0]) ? -1 : 1;      // the flag says "intra only"; its context counts nothing (always 0)
+    }
+
     // sps->tool_cm_init: the contexts of skip_flag / pred_mode_flag / ibc_flag / affine_flag count the neighbours that have the property - above the top-left
     // SCU, left of the bottom-left one (and right of the bottom-right one, never parsed before the CU without SUCO) - in the same tile and already parsed
     // (xevdm_get_ctx_some_flags, src_main/xevdm_util.c:1729-1853)
@@ -1611,6 +1703,7 @@ struct TileCoder {
     {
         // mode constraint eOnlyIntra: I slices, and with tool_admvp every 4x4 CU (xevdm.c:1838-1843) - no skip flag, no pred_mode_flag
         const bool inter_slice = sh.type != XHOST_SLICE_I && !(sps.tool_admvp && cu.log2w == 2 && cu.log2h == 2);
+        const int keep_only_inter = cu.only_inter;
         int skip = 0;
         if (inter_slice) skip = c.bin(cu.mode == MODE_SKIP, models.skip[nb_ctx(cu, CTX_SKIP)]);
         if (!enc) { cu.mode = skip ? MODE_SKIP : MODE_INTRA; cu.refi[0] = cu.refi[1] = -1; memset(cu.mv, 0, sizeof(cu.mv)); memset(cu.mvd, 0, sizeof(cu.mvd));
@@ -1644,11 +1737,12 @@ struct TileCoder {
             return;
         }
         int intra = 1;
-        if (inter_slice) intra = c.bin(cu.mode == MODE_INTRA, models.pred_mode[nb_ctx(cu, CTX_PRED)]);
+        if (inter_slice && keep_only_inter) intra = 0;                 // eOnlyInter: no pred_mode_flag (xevdm_eco_pred_mode, xevdm_eco.c:1401-1438)
+        else if (inter_slice) intra = c.bin(cu.mode == MODE_INTRA, models.pred_mode[nb_ctx(cu, CTX_PRED)]);
         // xevdm_eco_pred_mode (xevdm_eco.c:1401-1438): with sps->ibc_flag every CU up to the IBC size limit that is not already known to be
         // intra-predicted carries ibc_flag - in I slices all of them (mode constraint eOnlyIntra: no pred_mode_flag); context 0 without cm_init
         int ibc = 0;
-        if (sps.ibc && cu.log2w <= sps.ibc_log_max && cu.log2h <= sps.ibc_log_max && !(inter_slice && intra))
+        if (sps.ibc && cu.log2w <= sps.ibc_log_max && cu.log2h <= sps.ibc_log_max && !(inter_slice && intra) && !keep_only_inter)
             ibc = c.bin(cu.mode == MODE_IBC, models.ibc_flag[nb_ctx(cu, CTX_IBC)]);
         if (!enc) { cu.mode = ibc ? MODE_IBC : intra ? MODE_INTRA : MODE_INTER; cu.direct = 0; }
         if (ibc) {
@@ -1929,11 +2023,12 @@ static void write_nal(std::vector<uint8_t> &out, int nut, int tid, const BitWrit
 // sps->dquant_flag: where a quantisation group starts in the split tree (xevd_entropy_decode_tree, src_main/xevdm.c:1739-1759) - at a leaf of at least
 // pps.cu_qp_delta_area samples (code 1: the delta goes with the CU's coefficients), or at the split node of exactly that size (code 2: the first CU below it
 // that reaches its QP syntax sends the delta).  -> the code for the node's children / the leaf
-static int qp_group(const Stream &st, TileCoder &tc, int split, int log2s, int qp_code)
+static int qp_group(const Stream &st, TileCoder &tc, int split, int lw, int lh, int qp_code)
 {
     if (!(st.pps.cu_qp_delta && st.sps.dquant && st.sps.profile_main)) return qp_code;
-    if (!split && 2 * log2s >= st.pps.qp_delta_area && qp_code != 2) { tc.qp_coded = 0; return log2s == 7 ? 2 : 1; }
-    if (2 * log2s == st.pps.qp_delta_area && qp_code != 2) { tc.qp_coded = 0; return 2; }
+    if (!split && lw + lh >= st.pps.qp_delta_area && qp_code != 2) { tc.qp_coded = 0; return (lw == 7 || lh == 7) ? 2 : 1; }
+    const bool tri = split == TileCoder::TRI_VER || split == TileCoder::TRI_HOR;
+    if ((tri && lw + lh == st.pps.qp_delta_area + 1) || (lw + lh == st.pps.qp_delta_area && qp_code != 2)) { tc.qp_coded = 0; return 2; }
     return qp_code;
 }
 
@@ -1967,7 +2062,7 @@ struct TileParser {
             if (cx == st.grid.col_bd[tcol]) tc.history_reset();
             batch.ctu_start.push_back((uint32_t)batch.x.size());
             if (sh.alf_on && sh.alf_ctb_map) st.alf_ctb_flag[(size_t)cy * w_ctu + cx] = (uint8_t)dec.bin(0, tc.models.alf_ctb[0]);      // xevdm.c:2411-2418
-            const int rc = parse_tree(dec, cx << 6, cy << 6, 6);
+            const int rc = st.sps.btt ? parse_node(dec, cx << 6, cy << 6, 6, 6, 0, false) : parse_tree(dec, cx << 6, cy << 6, 6);
             if (rc != XGPU_OK) return rc;
             if (br.overrun) return fail("slice data ends early");
         }
@@ -1979,7 +2074,7 @@ struct TileParser {
         const int s = 1 << log2s;
         int split = 0;
         if (s > 4 && !(s < 8)) split = dec.bin(0, tc.models.split[0]);
-        qp_code = qp_group(st, tc, split, log2s, qp_code);
+        qp_code = qp_group(st, tc, split ? TileCoder::QUAD : 0, log2s, log2s, qp_code);
         if (split) {
             const int h = s >> 1;
             for (int i = 0; i < 4; i++) {
@@ -1988,19 +2083,47 @@ struct TileParser {
             }
             return XGPU_OK;
         }
-        if (x + s > st.sps.width || y + s > st.sps.height) return fail("a CU crosses the picture border");
+        return leaf(dec, x, y, log2s, log2s, qp_code, 0);
+    }
+    // sps_btt_flag: a node of the binary / ternary split tree (xevd_entropy_decode_tree, src_main/xevdm.c:1644-1850, without SUCO)
+    int parse_node(Dec &dec, int x, int y, int lw, int lh, int qp_code, bool only_inter)
+    {
+        const int W = st.sps.width, H = st.sps.height, w = 1 << lw, h = 1 << lh, mn = 1 << st.sps.log2_min_cb;
+        int split = TileCoder::NO_SPLIT;
+        if (w > mn || h > mn) {
+            if (x + w <= W && y + h <= H) split = tc.code_split(dec, 0, x, y, lw, lh, only_inter);
+            else {      // across the picture border: the binary split towards it, no syntax (:1687-1713)
+                int allow[6];
+                tc.split_allowed(allow, lw, lh, x, y, only_inter);
+                split = allow[TileCoder::BI_VER] ? TileCoder::BI_VER : allow[TileCoder::BI_HOR] ? TileCoder::BI_HOR : -1;
+                if (split < 0) return fail("a node across the picture border cannot be split");
+            }
+        }
+        qp_code = qp_group(st, tc, split, lw, lh, qp_code);
+        if (split == TileCoder::NO_SPLIT) return leaf(dec, x, y, lw, lh, qp_code, only_inter);
+        const int mc = tc.code_mode_cons(dec, split, lw, lh, only_inter, 0);
+        if (mc < 0) return fail("local dual tree (luma-only / chroma-only CUs below this split) is not supported");
+        int px[3], py[3], plw[3], plh[3];
+        const int n = TileCoder::split_parts(split, x, y, lw, lh, px, py, plw, plh);
+        for (int i = 0; i < n; i++)
+            if (px[i] < W && py[i] < H) { const int rc = parse_node(dec, px[i], py[i], plw[i], plh[i], qp_code, mc == 1); if (rc != XGPU_OK) return rc; }
+        return XGPU_OK;
+    }
+    int leaf(Dec &dec, int x, int y, int lw, int lh, int qp_code, int only_inter)
+    {
+        if (x + (1 << lw) > st.sps.width || y + (1 << lh) > st.sps.height) return fail("a CU crosses the picture border");
         Cu cu;
         memset(&cu, 0, sizeof(cu));
-        cu.x = x; cu.y = y; cu.log2w = cu.log2h = log2s; cu.qp_code = qp_code;
+        cu.x = x; cu.y = y; cu.log2w = lw; cu.log2h = lh; cu.qp_code = qp_code; cu.only_inter = only_inter;
         int16_t *coef[3] = { blk[0].data(), blk[1].data(), blk[2].data() };
-        memset(coef[0], 0, sizeof(int16_t) << (2 * log2s));
-        memset(coef[1], 0, sizeof(int16_t) << (2 * log2s - 2));
-        memset(coef[2], 0, sizeof(int16_t) << (2 * log2s - 2));
+        memset(coef[0], 0, sizeof(int16_t) << (lw + lh));
+        memset(coef[1], 0, sizeof(int16_t) << (lw + lh - 2));
+        memset(coef[2], 0, sizeof(int16_t) << (lw + lh - 2));
         tc.code_cu(dec, cu, coef, false);
         tc.commit(cu);
         // append to the batch
         if (batch.x.empty()) n_coef = 0;
-        batch.x.push_back((uint16_t)x); batch.y.push_back((uint16_t)y); batch.log2w.push_back((uint8_t)log2s); batch.log2h.push_back((uint8_t)log2s);
+        batch.x.push_back((uint16_t)x); batch.y.push_back((uint16_t)y); batch.log2w.push_back((uint8_t)lw); batch.log2h.push_back((uint8_t)lh);
         batch.pred_mode.push_back((uint8_t)cu.mode);
         batch.refi.push_back((int8_t)cu.refi[0]); batch.refi.push_back((int8_t)cu.refi[1]);
         for (int l = 0; l < 2; l++) { batch.mv.push_back(cu.mv[l][0]); batch.mv.push_back(cu.mv[l][1]); }
@@ -2018,7 +2141,7 @@ struct TileParser {
         const int tu_shift = (cu.ats_inter & 15) == 0 ? 0 : (((cu.ats_inter & 15) >= 3) ? 2 : 1);      // the TU is 1/2 or 1/4 of the CU
         for (int k = 0; k < 3; k++)
             if (cu.cbf[k]) {
-                const size_t n = (size_t)1 << (2 * log2s - (k ? 2 : 0) - tu_shift);
+                const size_t n = (size_t)1 << (lw + lh - (k ? 2 : 0) - tu_shift);
                 batch.coef.insert(batch.coef.end(), coef[k], coef[k] + n);
                 n_coef += n;
             }
@@ -2086,7 +2209,17 @@ struct xhost_parser {
         if (!s.profile_main) {
             for (int i = 0; i < 13; i++) { const int f = br.get1(); if (i != 11) unsupported |= f; }      // btt suco admvp eipd cm_init iqt addb alf htdf rpl pocs dquant dra
         } else {                                          // xevdm_eco_sps, xevdm_eco.c:1863-1937: sub-flags follow their tool flag
-            unsupported |= br.get1();                    // sps_btt_flag
+            s.btt = br.get1();                           // sps_btt_flag + the limits of the split tree (xevdm_eco.c:1863-1871; table xevdm_util.c:4393-4400)
+            if (s.btt) {
+                if (br.ue() != 1) return fail("sps_btt_flag with a CTU size other than 64 is not supported");      // log2_ctu_size_minus5
+                for (int i = 0; i < 4; i++) s.btt_raw[i] = (int)br.ue();
+                if (br.overrun || s.btt_raw[0] > 4 || s.btt_raw[1] > 6 || s.btt_raw[2] > 6 || s.btt_raw[3] > 6) return fail("bad SPS: split limits");
+                s.log2_min_cb = s.btt_raw[0] + 2;
+                s.split_tbl[0][1] = 6; s.split_tbl[0][0] = s.log2_min_cb;
+                s.split_tbl[1][1] = 6; s.split_tbl[1][0] = s.log2_min_cb + 1;
+                s.split_tbl[2][1] = std::min(6 - s.btt_raw[1], 6); s.split_tbl[2][0] = s.log2_min_cb + 2;
+                s.split_tbl[3][1] = std::min(6 - s.btt_raw[2], 6); s.split_tbl[3][0] = s.log2_min_cb + s.btt_raw[3] + 2;
+            }
             unsupported |= br.get1();                    // sps_suco_flag
             s.tool_admvp = br.get1();
             s.tool_amvr = s.tool_hmvp = s.tool_dmvr = s.tool_mmvd = s.tool_affine = 0;
@@ -2111,7 +2244,7 @@ struct xhost_parser {
         // unrefined map, xevdm_util.c:246-247): the same dependency
         if (s.tool_dmvr && s.tool_mmvd) return fail("tool_dmvr together with tool_mmvd: the base candidates depend on refined vectors inside the picture (not supported)");
         if (s.tool_dmvr && s.tool_hmvp) return fail("tool_dmvr together with tool_hmvp: the history candidates depend on refined vectors inside the picture (not supported)");
-        if (unsupported) return fail("the stream uses tools this front end does not parse (sps_btt_flag, sps_suco_flag)");
+        if (unsupported) return fail("the stream uses tools this front end does not parse (sps_suco_flag)");
         // xevdm_eco.c:1920-1961: POC lsb width (tool_pocs), the sub-GOP description unless both tools are on, and either the sliding-window size or the RPL candidates
         s.tool_rpl = rpl; s.tool_pocs = pocs;
         s.log2_sub_gop = s.log2_ref_gap = 0;
@@ -2516,7 +2649,9 @@ struct xhost_writer {
         bw.ue((uint32_t)(sp.bit_depth - 8)); bw.ue((uint32_t)(sp.bit_depth - 8));
         if (!sp.profile_main) for (int i = 0; i < 13; i++) bw.put1(i == 11 ? (sp.cu_qp_delta ? 1 : 0) : 0);       // all tools off; dquant_flag with cu_qp_delta
         else {
-            bw.put1(0); bw.put1(0);                      // btt suco
+            bw.put1(st.sps.btt);                         // sps_btt_flag: log2_ctu_size_minus5 (1 = 64), log2_min_cb_size_minus2, the three limits of the split table
+            if (st.sps.btt) { bw.ue(1); for (int i = 0; i < 4; i++) bw.ue((uint32_t)st.sps.btt_raw[i]); }
+            bw.put1(0);                                  // sps_suco_flag
             bw.put1(sp.tool_admvp ? 1 : 0);
             if (sp.tool_admvp) { bw.put1(sp.tool_affine ? 1 : 0); bw.put1(sp.tool_amvr ? 1 : 0); bw.put1(sp.tool_dmvr ? 1 : 0); bw.put1(sp.tool_mmvd ? 1 : 0); bw.put1(sp.tool_hmvp ? 1 : 0); }      // affine amvr dmvr mmvd hmvp
             bw.put1(sp.tool_eipd ? 1 : 0);
@@ -2603,6 +2738,15 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     w->sp.tool_hmvp = s.tool_admvp && sp->tool_hmvp; s.tool_hmvp = w->sp.tool_hmvp;
     w->sp.tool_affine = s.tool_admvp && sp->tool_affine; s.tool_affine = w->sp.tool_affine;
     w->st.enc_side = true;
+    s.btt = s.profile_main && sp->btt;
+    if (s.btt) {
+        s.btt_raw[0] = std::min(std::max(sp->btt_log2_min_cb - 2, 0), 4); s.btt_raw[1] = std::min(std::max(sp->btt_diff_max_14, 0), 6);
+        s.btt_raw[2] = std::min(std::max(sp->btt_diff_max_tt, 0), 6); s.btt_raw[3] = std::min(std::max(sp->btt_diff_min_tt, 0), 6);
+        s.log2_min_cb = s.btt_raw[0] + 2;
+        s.split_tbl[0][1] = 6; s.split_tbl[0][0] = s.log2_min_cb; s.split_tbl[1][1] = 6; s.split_tbl[1][0] = s.log2_min_cb + 1;
+        s.split_tbl[2][1] = std::min(6 - s.btt_raw[1], 6); s.split_tbl[2][0] = s.log2_min_cb + 2;
+        s.split_tbl[3][1] = std::min(6 - s.btt_raw[2], 6); s.split_tbl[3][0] = s.log2_min_cb + s.btt_raw[3] + 2;
+    }
     s.tool_cm_init = s.profile_main && (sp->tool_cm_init || sp->tool_adcc); s.tool_adcc = s.tool_cm_init && sp->tool_adcc;      // tool_adcc is a sub-flag of tool_cm_init
     s.tool_rpl = s.profile_main && sp->tool_rpl; s.tool_pocs = s.profile_main && sp->tool_pocs; s.poc_lsb_bits = 8;
     if (s.tool_rpl && sp->rpl_in_sps && sp->log2_sub_gop_length == 0 && sp->max_num_ref_pics >= 2) {
@@ -2730,7 +2874,7 @@ struct TreeWriter {
         const bool is_leaf = i >= 0 && b->log2w[i] == log2s;
         if (s >= 8) enc->bin(!is_leaf, tcd.models.split[0]);
         else if (!is_leaf) { error = 1; return; }
-        qp_code = qp_group(st, tcd, !is_leaf, log2s, qp_code);
+        qp_code = qp_group(st, tcd, is_leaf ? 0 : TileCoder::QUAD, log2s, log2s, qp_code);
         if (!is_leaf) {
             const int h = s >> 1;
             for (int q = 0; q < 4; q++) {
@@ -2739,12 +2883,83 @@ struct TreeWriter {
             }
             return;
         }
+        write_leaf(i, qp_code, 0);
+    }
+    // ---- sps_btt_flag: the split tree is found from the leaves - at every node the first allowed split whose cuts no CU crosses and below which the
+    //      same search succeeds (plan), then coded (node_btt) ----
+    std::vector<int> owner;                              // CU index of every SCU
+    std::map<uint64_t, int> chosen;                      // node -> split mode
+    static uint64_t node_key(int x, int y, int lw, int lh, bool oi) { return ((uint64_t)x << 40) | ((uint64_t)y << 16) | ((uint64_t)lw << 8) | ((uint64_t)lh << 4) | (oi ? 1 : 0); }
+    bool whole_cus(int x, int y, int wd, int ht, bool &any_non_inter) const      // the rectangle (clipped to the picture) is a union of whole CUs
+    {
+        const Stream &st = w->st;
+        for (int yy = y; yy < std::min(y + ht, st.sps.height); yy += 4) for (int xx = x; xx < std::min(x + wd, st.sps.width); xx += 4) {
+            const int i = owner[(size_t)(yy >> 2) * st.pic.w_scu + (xx >> 2)];
+            if (i < 0 || b->x[i] < x || b->y[i] < y || b->x[i] + (1 << b->log2w[i]) > x + wd || b->y[i] + (1 << b->log2h[i]) > y + ht) return false;
+            if (b->pred_mode[i] == XGPU_MODE_INTRA || b->pred_mode[i] == XGPU_MODE_IBC || st.sh.type == XHOST_SLICE_I) any_non_inter = true;
+        }
+        return true;
+    }
+    bool plan(int x, int y, int lw, int lh, bool only_inter)
+    {
+        Stream &st = w->st;
+        TileCoder &tcd = w->coder;
+        const uint64_t key = node_key(x, y, lw, lh, only_inter);
+        if (chosen.count(key)) return chosen[key] >= 0;
+        const int W = st.sps.width, H = st.sps.height, wd = 1 << lw, ht = 1 << lh;
+        const bool inside = x + wd <= W && y + ht <= H;
+        if (inside) {
+            const int i = leaf[(size_t)(y >> 2) * st.pic.w_scu + (x >> 2)];
+            if (i >= 0 && b->log2w[i] == lw && b->log2h[i] == lh) { chosen[key] = TileCoder::NO_SPLIT; return true; }
+        }
+        chosen[key] = -1;
+        if (!(wd > (1 << st.sps.log2_min_cb) || ht > (1 << st.sps.log2_min_cb)) || (lw < 3 && lh < 3)) return false;
+        int allow[6];
+        tcd.split_allowed(allow, lw, lh, x, y, only_inter);
+        for (int sp = TileCoder::BI_VER; sp <= TileCoder::TRI_HOR; sp++) {
+            if (!allow[sp]) continue;
+            if (!inside && sp != (allow[TileCoder::BI_VER] ? TileCoder::BI_VER : TileCoder::BI_HOR)) continue;      // the forced split
+            int px[3], py[3], plw[3], plh[3];
+            const int n = TileCoder::split_parts(sp, x, y, lw, lh, px, py, plw, plh);
+            bool ok = true, non_inter = false;
+            for (int k = 0; k < n && ok; k++) if (px[k] < W && py[k] < H) ok = whole_cus(px[k], py[k], 1 << plw[k], 1 << plh[k], non_inter);
+            if (!ok) continue;
+            bool child_oi = only_inter;
+            if (st.sps.btt && st.sps.tool_admvp && !only_inter && !TileCoder::chroma_split_ok(sp, wd, ht)) {
+                // the children would need a mode constraint: only "inter only" can be written (the other one is the local dual tree)
+                if (st.sh.type == XHOST_SLICE_I || TileCoder::small_child_is_4x4(sp, wd, ht) || non_inter) continue;
+                child_oi = true;
+            }
+            for (int k = 0; k < n && ok; k++) if (px[k] < W && py[k] < H) ok = plan(px[k], py[k], plw[k], plh[k], child_oi);
+            if (ok) { chosen[key] = sp; return true; }
+        }
+        return false;
+    }
+    void node_btt(int x, int y, int lw, int lh, int qp_code, bool only_inter)
+    {
+        Stream &st = w->st;
+        TileCoder &tcd = w->coder;
+        const int W = st.sps.width, H = st.sps.height, wd = 1 << lw, ht = 1 << lh, mn = 1 << st.sps.log2_min_cb;
+        const int split = chosen[node_key(x, y, lw, lh, only_inter)];
+        if ((wd > mn || ht > mn) && x + wd <= W && y + ht <= H) tcd.code_split(*enc, split, x, y, lw, lh, only_inter);
+        qp_code = qp_group(st, tcd, split, lw, lh, qp_code);
+        if (split == TileCoder::NO_SPLIT) { write_leaf(leaf[(size_t)(y >> 2) * st.pic.w_scu + (x >> 2)], qp_code, only_inter); return; }
+        const int mc = tcd.code_mode_cons(*enc, split, lw, lh, only_inter, 1);
+        int px[3], py[3], plw[3], plh[3];
+        const int n = TileCoder::split_parts(split, x, y, lw, lh, px, py, plw, plh);
+        for (int k = 0; k < n; k++) if (px[k] < W && py[k] < H) node_btt(px[k], py[k], plw[k], plh[k], qp_code, mc == 1);
+    }
+    void write_leaf(int i, int qp_code, int only_inter)
+    {
+        Stream &st = w->st;
+        TileCoder &tcd = w->coder;
+        const int x = b->x[i], y = b->y[i], lw = b->log2w[i], lh = b->log2h[i], log2s = std::min(lw, lh);
         Cu cu;
         memset(&cu, 0, sizeof(cu));
-        cu.x = x; cu.y = y; cu.log2w = cu.log2h = log2s; cu.qp_code = qp_code;
+        cu.x = x; cu.y = y; cu.log2w = lw; cu.log2h = lh; cu.qp_code = qp_code; cu.only_inter = only_inter;
         cu.mode = b->pred_mode[i] == XGPU_MODE_INTRA ? MODE_INTRA : (b->pred_mode[i] == XGPU_MODE_SKIP ? MODE_SKIP : MODE_INTER);
-        const bool ibc = b->pred_mode[i] == XGPU_MODE_IBC && st.sps.ibc && log2s <= st.sps.ibc_log_max;
-        if (st.sh.type == XHOST_SLICE_I || (st.sps.tool_admvp && log2s == 2)) cu.mode = MODE_INTRA;
+        const bool ibc = b->pred_mode[i] == XGPU_MODE_IBC && st.sps.ibc && std::max(lw, lh) <= st.sps.ibc_log_max && !only_inter;
+        if (st.sh.type == XHOST_SLICE_I || (st.sps.tool_admvp && lw == 2 && lh == 2)) cu.mode = MODE_INTRA;
         if (ibc) cu.mode = MODE_IBC;
         cu.direct = (st.sh.type == XHOST_SLICE_B || (st.sps.tool_admvp && st.sh.type == XHOST_SLICE_P)) && b->pred_mode[i] == XGPU_MODE_DIR;
         for (int l = 0; l < 2; l++) {
@@ -2757,7 +2972,9 @@ struct TreeWriter {
         if (ibc) { cu.refi[0] = cu.refi[1] = -1; cu.mv[1][0] = cu.mv[1][1] = 0; }
         cu.mvp_idx[0] = (x >> 2) & 3; cu.mvp_idx[1] = (y >> 2) & 3;   // a SKIP CU: some predictor per list
         if (st.sps.tool_admvp) cu.mvp_idx[0] = cu.mvp_idx[1] = ((x >> 2) + 2 * (y >> 2)) % 6;
-        if (st.sps.tool_mmvd && ((x >> 3) + (y >> 2)) % 3 == 0) { cu.mmvd = 1; cu.mmvd_idx = ((x >> 2) * 37 + (y >> 2) * 101 + i) % 384; }      // a third of the skip / merge-mode CUs: any group, base, distance, direction      // ... or one of the six merge candidates (also of a merge-mode CU)
+        // (not for CUs of up to 32 samples - 4x8 / 8x4 with sps_btt_flag: the reference's candidate list for them comes out with uninitialised entries in P slices,
+        //  refi 85 / vector 13235 seen in xevdm_get_mmvd_mvp_list's output; decoder behaviour on them is undefined, so the streams stay away)
+        if (st.sps.tool_mmvd && ((x >> 3) + (y >> 2)) % 3 == 0 && (1 << (lw + lh)) > 32) { cu.mmvd = 1; cu.mmvd_idx = ((x >> 2) * 37 + (y >> 2) * 101 + i) % 384; }      // a third of the skip / merge-mode CUs: any group, base, distance, direction      // ... or one of the six merge candidates (also of a merge-mode CU)
         if (st.sps.tool_affine && b->affine && b->affine[i] >= 2 && (cu.mode == MODE_SKIP || cu.mode == MODE_INTER) && !cu.mmvd) {
             // an affine CU: merge candidates of a skip / merge-mode CU (8x8 and larger), or the batch's control points coded against a predictor (16x16 and larger)
             // (not before the stream's first translational inter CU: the reference's sub-block affine prediction reads its interpolation taps through a
@@ -2778,8 +2995,8 @@ struct TreeWriter {
         cu.ats = (st.sps.tool_ats && b->ats && cu.mode == MODE_INTRA) ? b->ats[i] & 7 : 0;
         cu.ats_inter = 0;
         if (st.sps.tool_ats && b->ats_inter && cu.mode == MODE_INTER && !cu.direct) {
-            const int info = b->ats_inter[i], idx = info & 15, dim = (idx == 1 || idx == 3) ? s : s;      // square CUs: both dimensions = s
-            if (idx >= 1 && idx <= 4 && dim >= (idx >= 3 ? 16 : 8) && s <= 64) cu.ats_inter = info & 0x1F;
+            const int info = b->ats_inter[i], idx = info & 15, dim = (idx == 1 || idx == 3) ? 1 << lw : 1 << lh;      // the side the TU split cuts
+            if (idx >= 1 && idx <= 4 && dim >= (idx >= 3 ? 16 : 8) && std::max(lw, lh) <= 6) cu.ats_inter = info & 0x1F;
         }
         const int tu_shift = (cu.ats_inter & 15) == 0 ? 0 : (((cu.ats_inter & 15) >= 3) ? 2 : 1);
         // coefficient blocks: a coded component needs at least one non-zero value to be representable
@@ -2787,7 +3004,7 @@ struct TreeWriter {
         int16_t *coef[3];
         size_t off = b->coef_off[i];
         for (int k = 0; k < 3; k++) {
-            const size_t n = (size_t)1 << (2 * log2s - (k ? 2 : 0) - tu_shift);
+            const size_t n = (size_t)1 << (lw + lh - (k ? 2 : 0) - tu_shift);
             blk[k].assign(n, 0);
             if ((b->cbf[i] >> k) & 1) {
                 blk[k].assign(b->coef + off, b->coef + off + n);
@@ -2803,10 +3020,46 @@ struct TreeWriter {
         if (cbf_all_path && !(cu.cbf[0] | cu.cbf[1] | cu.cbf[2])) { /* all-zero flag path */ }
         else if (cbf_all_path && cu.cbf[1] + cu.cbf[2] == 0) cu.cbf[0] = 1;      // implied luma cbf needs a luma coefficient
         if (cbf_all_path && cu.cbf[0]) { bool nz = false; for (int16_t v : blk[0]) nz |= v != 0; if (!nz) blk[0][0] = 1; }
+        if (cu.mmvd && (cu.mode == MODE_SKIP || cu.direct)) {
+            // an index whose candidate has no reference in either list (P slices: prediction type "none" of a group, xevdm_util.c:499-503) would leave the
+            // decoder without a prediction - its buffer keeps what the last CU left: not a stream to compare decoders with
+            Cu t = cu;
+            if (!(st.sh.mmvd_group && (1 << (lw + lh)) > 32)) t.mmvd_idx &= 127;
+            tcd.mmvd_motion(t);
+            if (t.refi[0] < 0 && t.refi[1] < 0) cu.mmvd = 0;
+        }
+        if (st.sps.tool_admvp && !cu.mmvd && !cu.affine && (cu.mode == MODE_SKIP || cu.direct)) {
+            // ... and the same for a merge candidate (e.g. a temporal one that only has list-1 motion, in a P slice): take the next index that predicts from something
+            const int n_cand = (1 << (lw + lh)) <= 32 ? 4 : 6;      // CUs of up to 32 samples have four candidates (MAX_NUM_MVP_SMALL_CU)
+            cu.mvp_idx[0] = cu.mvp_idx[1] = cu.mvp_idx[0] % n_cand;
+            for (int tries = 0; tries < n_cand; tries++) {
+                Cu t = cu;
+                tcd.merge_motion(t, cu.mvp_idx[0]);
+                if (t.refi[0] >= 0 || t.refi[1] >= 0) break;
+                cu.mvp_idx[0] = cu.mvp_idx[1] = (cu.mvp_idx[0] + 1) % n_cand;
+            }
+        }
         tcd.code_cu(*enc, cu, coef, true);
         tcd.commit(cu);
     }
 };
+}
+
+// which splits the writer's stream allows at a node (for generators of CU batches): allow[0..4] = none, binary vertical / horizontal cut, ternary vertical / horizontal
+extern "C" int xhost_writer_split_allowed(xhost_writer *w, int x, int y, int log2w, int log2h, int allow[5])
+{
+    if (!w || !allow || log2w < 2 || log2w > 6 || log2h < 2 || log2h > 6) return XGPU_ERR_INVALID_ARGUMENT;
+    for (int i = 0; i < 5; i++) allow[i] = i == 0;
+    if (!w->st.sps.btt) return XGPU_OK;
+    const int wd = 1 << log2w, ht = 1 << log2h, mn = 1 << w->st.sps.log2_min_cb;
+    if (!(wd > mn || ht > mn) || (log2w < 3 && log2h < 3)) { allow[0] = x + wd <= w->st.sps.width && y + ht <= w->st.sps.height; return XGPU_OK; }
+    int a[6];
+    w->coder.split_allowed(a, log2w, log2h, x, y, false);
+    for (int i = 0; i < 5; i++) allow[i] = a[i];
+    // splits whose children would need a mode constraint (sps_btt_flag with tool_admvp, smallest child under 64 luma samples): the writer can only send
+    // "inter only" - reported as 2 (allowed in P / B pictures when every CU below is an inter CU)
+    if (w->st.sps.tool_admvp) for (int i = 1; i < 5; i++) if (allow[i] && !TileCoder::chroma_split_ok(i, wd, ht)) allow[i] = TileCoder::small_child_is_4x4(i, wd, ht) ? 0 : 2;
+    return XGPU_OK;
 }
 
 extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type, int slice_qp, int temporal_id, const xgpu_cu_batch *b)
@@ -2888,12 +3141,17 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
     TreeWriter tw;
     tw.w = w; tw.b = b; tw.bd_off = 6 * (st.sps.bd_l - 8);
     tw.leaf.assign((size_t)st.pic.w_scu * st.pic.h_scu, -1);
+    if (st.sps.btt) tw.owner.assign((size_t)st.pic.w_scu * st.pic.h_scu, -1);
     for (int i = 0; i < b->n_cu; i++) {
-        if (b->log2w[i] != b->log2h[i] || b->log2w[i] < 2 || b->log2w[i] > 6 || b->x[i] + (1 << b->log2w[i]) > st.sps.width ||
-            b->y[i] + (1 << b->log2h[i]) > st.sps.height || (b->x[i] & ((1 << b->log2w[i]) - 1)) || (b->y[i] & ((1 << b->log2h[i]) - 1)))
+        if ((!st.sps.btt && b->log2w[i] != b->log2h[i]) || b->log2w[i] < 2 || b->log2w[i] > 6 || b->log2h[i] < 2 || b->log2h[i] > 6 || b->x[i] + (1 << b->log2w[i]) > st.sps.width ||
+            b->y[i] + (1 << b->log2h[i]) > st.sps.height || (b->x[i] & 3) || (b->y[i] & 3) || (!st.sps.btt && ((b->x[i] & ((1 << b->log2w[i]) - 1)) || (b->y[i] & ((1 << b->log2h[i]) - 1)))))
             return XGPU_ERR_INVALID_ARGUMENT;
         tw.leaf[(size_t)(b->y[i] >> 2) * st.pic.w_scu + (b->x[i] >> 2)] = i;
+        if (st.sps.btt)
+            for (int r = 0; r < (1 << b->log2h[i]) >> 2; r++) for (int c2 = 0; c2 < (1 << b->log2w[i]) >> 2; c2++) tw.owner[(size_t)((b->y[i] >> 2) + r) * st.pic.w_scu + (b->x[i] >> 2) + c2] = i;
     }
+    if (st.sps.btt)      // the split tree of every CTU must exist before anything is written
+        for (int cy = 0; cy < h_ctu; cy++) for (int cx = 0; cx < w_ctu; cx++) if (!tw.plan(cx << 6, cy << 6, 6, 6, false)) return XGPU_ERR_INVALID_ARGUMENT;
     // every tile is its own arithmetic-coder run (contexts, QP predictor, motion history); the header carries the byte sizes of all but the last
     TileCoder &tcd = w->coder;
     std::vector<BitWriter> tile_bits((size_t)n_tiles);
@@ -2912,7 +3170,7 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
                 enc.bin(f, tcd.models.alf_ctb[0]);
                 st.alf_ctb_flag[(size_t)cy * w_ctu + cx] = (uint8_t)f;
             }
-            tw.node(cx << 6, cy << 6, 6);
+            if (st.sps.btt) tw.node_btt(cx << 6, cy << 6, 6, 6, 0, false); else tw.node(cx << 6, cy << 6, 6);
         }
         if (tw.error) return XGPU_ERR_INVALID_ARGUMENT;
         enc.tile_end();

@@ -135,9 +135,11 @@ def gen_partition_btt(rng, width, height, log2_ctu=6, split_prob=0.5, btt_frac=0
 
 def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_frac=0.0, coded_frac=0.6,
               n_refs=(1, 0), qp_range=(22, 37), mv_sigma_px=8.0, oob_frac=0.05, split_prob=0.5,
-              chroma_qp_table=None, max_level=24, amp=2.0, ats_frac=0.0, ats_inter_frac=0.0, btt_frac=0.0, min_log2=2, eipd=False):
+              chroma_qp_table=None, max_level=24, amp=2.0, ats_frac=0.0, ats_inter_frac=0.0, btt_frac=0.0, min_log2=2, eipd=False, partition=None):
     """One picture's CU batch as a dict of numpy arrays (layout of xgpu_cu_batch, include/xevd_hip.h)."""
-    if btt_frac > 0:
+    if partition is not None:      # leaf CUs given by the caller (x, y, log2w, log2h, ctu_cu_start)
+        x, y, l2w, l2h, start = partition
+    elif btt_frac > 0:
         x, y, l2w, l2h, start = gen_partition_btt(rng, width, height, log2_ctu, split_prob, btt_frac)
     else:
         x, y, l2w, l2h, start = gen_partition(rng, width, height, log2_ctu, split_prob, min_log2)
@@ -299,6 +301,44 @@ DEFAULT_CHROMA_QP_BASE = [
     0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19,
     20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 29, 29, 30, 31, 32, 32, 33, 33, 34, 34,
     35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 39, 39, 40, 40, 40, 41, 41, 41]
+
+
+def gen_partition_tree(rng, width, height, allowed, split_prob=0.5, log2_ctu=6, inter_only=None):
+    """Leaf CUs (decode order) of a split tree whose nodes only take the splits `allowed(x, y, log2w, log2h)` reports - [none, binary with a vertical cut,
+    binary horizontal, ternary vertical, ternary horizontal], entries 0 / 1 / 2 - e.g. StreamWriter.split_allowed for a stream with sps_btt_flag.  A split
+    reported as 2 is only taken when `inter_only` is a list: the leaves below it must then be inter CUs, their indices are appended to that list.
+    -> x, y, log2w, log2h, ctu_cu_start like gen_partition"""
+    ctu = 1 << log2_ctu
+    w_ctu, h_ctu = (width + ctu - 1) // ctu, (height + ctu - 1) // ctu
+    xs, ys, lws, lhs, start = [], [], [], [], []
+
+    def node(x, y, lw, lh, forced=False):
+        if x >= width or y >= height:
+            return
+        raw = allowed(x, y, lw, lh)
+        a = [int(v == 1 or (v == 2 and (inter_only is not None or forced))) for v in raw]
+        inside = x + (1 << lw) <= width and y + (1 << lh) <= height
+        opts = [m for m in range(1, 5) if a[m]]
+        if inside and a[0] and (not opts or rng.random() >= split_prob):
+            if forced:
+                inter_only.append(len(xs))
+            xs.append(x); ys.append(y); lws.append(lw); lhs.append(lh)
+            return
+        assert opts, f"no way to split the node {x},{y} {1 << lw}x{1 << lh}"
+        m = opts[int(rng.integers(0, len(opts)))] if inside else opts[0]
+        ver = m in (1, 3)
+        sizes = [1, 1] if m < 3 else [2, 1, 2]
+        off = 0
+        for sh in sizes:
+            clw, clh = (lw - sh, lh) if ver else (lw, lh - sh)
+            node(x + off if ver else x, y if ver else y + off, clw, clh, forced or raw[m] == 2)
+            off += 1 << (clw if ver else clh)
+    for cy in range(h_ctu):
+        for cx in range(w_ctu):
+            start.append(len(xs))
+            node(cx * ctu, cy * ctu, log2_ctu, log2_ctu)
+    start.append(len(xs))
+    return np.array(xs, np.uint16), np.array(ys, np.uint16), np.array(lws, np.uint8), np.array(lhs, np.uint8), np.array(start, np.uint32)
 
 
 def add_affine(rng, batch, frac=0.5):
