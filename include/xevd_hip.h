@@ -170,6 +170,11 @@ typedef struct xgpu_cu_batch {
                                      the CUs reconstructed before it (xevdm.c:1381-1392; a slice QP up to 17 switches it off)          */
     const xgpu_tile_grid *tiles;  /* NULL = one tile.  Else the CUs come tile by tile (tiles in raster order, CTUs in raster order inside a
                                      tile - xevdm_dec_slice, src_main/xevdm.c:2614-2718) and neighbours in another tile are unavailable   */
+    const uint8_t  *tree;         /* [n_cu] or NULL: local dual tree of Main streams with sps_btt_flag and tool_admvp (mode constraint eOnlyIntra below a split that
+                                     would leave chroma blocks under 16 samples, src_main/xevdm.c:1775-1833): 0 = the CU has luma and chroma, 1 = luma only
+                                     (TREE_L: intra or IBC; cbf bits 1-2 clear; writes the SCU maps as usual), 2 = chroma only (TREE_C: the split node's
+                                     chroma block, intra, ipm[0] = the luma mode its DM refers to, cbf bit 0 clear; follows its luma CUs in decoding order,
+                                     leaves the SCU maps alone; chroma edges are deblocked at ITS border, not at those of the luma CUs inside)          */
 } xgpu_cu_batch;
 
 /* ------------------------------------------------------------------ lifetime ---------------------- */

@@ -21,8 +21,8 @@
  * bi_idx / mmvd_flag + mmvd data syntax (xevdm_eco.c:767-812,1519-1726), merge with vector difference (src_main/xevdm_util.c:191-592,4682-4716), merge candidates incl. the temporal and history ones (src_main/xevdm_util.c:594-1391,3729-3818), the resolution-indexed
  * predictor (:750-951), intra-only 4x4 CUs; tool_dmvr needs the backend's refined vectors back per picture (xhost_parser_set_dmvr_mvs) and is refused
  * together with tool_hmvp or tool_mmvd.  tool_affine (affine merge / affine inter CUs, xevdm_util.c:2145-3187) is parsed too.
- * sps_btt_flag (binary / ternary split trees with CTU 64, "inter only" mode constraints) is parsed; refused: sps_suco_flag, and the local dual tree ("intra only"
- * constraint: luma-only / chroma-only CUs) when a BTT + ADMVP stream uses it.  tool_cm_init (context initialisation tables, neighbour-dependent contexts) and tool_adcc
+ * sps_btt_flag (binary / ternary split trees with CTU 64, "inter only" mode constraints, local dual trees: xgpu_cu_batch.tree) is parsed; refused: sps_suco_flag.
+ * tool_cm_init (context initialisation tables, neighbour-dependent contexts) and tool_adcc
  * (advanced coefficient coding) are parsed.
  * dquant_flag (QP deltas per quantisation group), tool_rpl (reference picture lists in SPS / slice headers, RPL-based marking) and tool_pocs
  * (POC from poc_lsb) are parsed.  SPS chroma QP mapping tables and cropping offsets are parsed, a VUI is skipped; 4:2:0, one slice per picture (with all of its
@@ -196,7 +196,8 @@ int  xhost_writer_set_slice_alf(xhost_writer *w, const xhost_slice_alf *sa);    
    not allow the split; the coefficient blocks then have the TU size).
    idr != 0 forces an IDR picture with an I slice.  temporal_id: nuh_temporal_id (0 for low-delay streams). */
 /* sps_btt_flag: which splits the stream allows for the node (x, y, 2^log2w x 2^log2h) - allow[0] none, [1] / [2] binary with a vertical / horizontal cut, [3] / [4]
-   ternary; 2 instead of 1: only below which every CU is an inter CU of a P / B picture (the children get the "inter only" mode constraint) */
+   ternary; 2 instead of 1: the children get a mode constraint - either every CU below is an inter CU of a P / B picture ("inter only"), or the node starts a local dual
+   tree: luma-only intra / IBC CUs below (xgpu_cu_batch.tree 1), then the node's chroma-only CU (tree 2) in the batch; 3: the dual tree only (a child would be 4x4) */
 int  xhost_writer_split_allowed(xhost_writer *w, int x, int y, int log2w, int log2h, int allow[5]);
 int  xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type, int slice_qp, int temporal_id, const xgpu_cu_batch *b);
 /* Appends a picture-signature SEI NAL unit (payload type 0x10) for the picture added last: the MD5 digests of its decoded Y, U, V

@@ -24,7 +24,7 @@
  * objects in the link, oracle/Makefile.ref: libxevd_ref_hip.so) - the way ref_harness.c reaches static helpers; no reference source is copied.
  * The recursion over the split tree below is OUR walk over the reference's exported helpers (xevd_get_split_mode,
  * xevd_split_get_part_structure, xevdm_get_suco_flag, xevdm_split_get_suco_order, xevd_derive_mode_cons).
- * Limits (asserted): one slice per picture (any tile grid), 4:2:0, no local dual tree, not tool_dmvr together with tool_hmvp (the history would need refined vectors
+ * Limits (asserted): one slice per picture (any tile grid), 4:2:0, not tool_dmvr together with tool_hmvp (the history would need refined vectors
  * while the picture is still being parsed).
  */
 #include "xevdm.c"
@@ -50,12 +50,12 @@ typedef struct {
     /* the batch of the picture being decoded */
     int n_cu, cap_cu;
     uint16_t *x, *y, *cbf_sub;
-    uint8_t *log2w, *log2h, *pred_mode, *qp, *cbf, *ipm, *ats, *ats_inter, *affine, *dmvr;
+    uint8_t *log2w, *log2h, *pred_mode, *qp, *cbf, *ipm, *ats, *ats_inter, *affine, *dmvr, *tree;
     int8_t *refi;
     int16_t *mv, *affine_mv;
     uint32_t *coef_off, *ctu_start;
     void *coef; rb_vec coef_v;
-    int any_affine, any_dmvr, any_ats, any_ats_inter;
+    int any_affine, any_dmvr, any_ats, any_ats_inter, any_tree;
     int failed;
     xgpu_tile_grid grid;
 } rb_state;
@@ -78,7 +78,7 @@ static void rb_reserve(rb_state *s)
     s->cap_cu = s->cap_cu ? s->cap_cu * 2 : 4096;
 #define G(f, k) s->f = realloc(s->f, sizeof(*s->f) * (size_t)s->cap_cu * (k))
     G(x, 1); G(y, 1); G(cbf_sub, 1); G(log2w, 1); G(log2h, 1); G(pred_mode, 1); G(qp, 3); G(cbf, 1); G(ipm, 2); G(ats, 1); G(ats_inter, 1);
-    G(affine, 1); G(dmvr, 1); G(refi, 2); G(mv, 4); G(affine_mv, 12); G(coef_off, 1);
+    G(affine, 1); G(dmvr, 1); G(tree, 1); G(refi, 2); G(mv, 4); G(affine_mv, 12); G(coef_off, 1);
 #undef G
 }
 
@@ -95,7 +95,6 @@ static void hip_recon_unit(XEVD_CTX *ctx, XEVD_CORE *core, int x, int y, int log
     core->x_scu = PEL2SCU(x); core->y_scu = PEL2SCU(y);
     core->scup = core->x_scu + core->y_scu * ctx->w_scu;
     cu_init(ctx, core, x, y, cuw, cuh);
-    if (!xevd_check_luma(ctx, core) || !xevd_check_chroma(ctx, core)) { s->failed = 1; return; }      /* local dual tree (separate luma / chroma CUs): not in the batch format */
     core->avail_lr = xevd_check_nev_avail(core->x_scu, core->y_scu, cuw, cuh, ctx->w_scu, ctx->h_scu, ctx->map_scu, ctx->map_tidx);
     xevdm_get_ctx_some_flags(core->x_scu, core->y_scu, cuw, cuh, ctx->w_scu, ctx->map_scu, ctx->cod_eco, ctx->map_cu_mode, core->ctx_flags, ctx->sh.slice_type,
                              ctx->sps->tool_cm_init, ctx->sps->ibc_flag, ctx->sps->ibc_log_max_size, ctx->map_tidx, 0);
@@ -152,6 +151,8 @@ static void hip_recon_unit(XEVD_CTX *ctx, XEVD_CORE *core, int x, int y, int log
     s->ats_inter[i] = (uint8_t)((mode != MODE_INTRA && mode != MODE_IBC) ? mcore->ats_inter_info : 0);
     s->affine[i] = (uint8_t)((mode != MODE_INTRA && mode != MODE_IBC && mcore->affine_flag) ? mcore->affine_flag + 1 : 0);
     s->dmvr[i] = (uint8_t)(mcore->dmvr_enable && ctx->sps->tool_dmvr);
+    s->tree[i] = (uint8_t)(tree_cons.tree_type == TREE_L ? 1 : tree_cons.tree_type == TREE_C ? 2 : 0);      /* local dual tree: xgpu_cu_batch.tree */
+    s->any_tree |= s->tree[i] != 0;
     memset(&s->affine_mv[i * 12], 0, sizeof(int16_t) * 12);
     if (s->affine[i]) {
         int l, v;
@@ -166,7 +167,7 @@ static void hip_recon_unit(XEVD_CTX *ctx, XEVD_CORE *core, int x, int y, int log
         if (s->ats_inter[i]) xevdm_get_tu_size(s->ats_inter[i], log2_cuw, log2_cuh, &lt_w, &lt_h);
         for (c = 0; c < N_C; c++) {
             const size_t n = ((size_t)1 << (lt_w + lt_h)) >> (c ? 2 : 0);
-            if (!core->is_coef[c]) continue;
+            if (!core->is_coef[c] || (c == 0 ? !xevd_check_luma(ctx, core) : !xevd_check_chroma(ctx, core))) continue;
             s->cbf[i] |= (uint8_t)(1 << c);
             for (sb = 0; sb < MAX_SUB_TB_NUM; sb++) if (core->is_coef_sub[c][sb]) s->cbf_sub[i] |= (uint16_t)(1 << (4 * c + sb));
             memcpy(rb_push(&s->coef_v, &s->coef, sizeof(int16_t), n), core->coef[c], sizeof(int16_t) * n);
@@ -196,7 +197,6 @@ static void hip_recon_tree(XEVD_CTX *ctx, XEVD_CORE *core, int x, int y, int cuw
             if (tree_cons.mode_cons == eAll && !xevd_is_chroma_split_allowed(cuw, cuh, split_mode)) {
                 child.mode_cons = xevd_derive_mode_cons(ctx, PEL2SCU(x) + PEL2SCU(y) * ctx->w_scu);
                 child.tree_type = child.mode_cons == eOnlyIntra ? TREE_L : TREE_LC;
-                if (child.mode_cons == eOnlyIntra) { rb_of(ctx)->failed = 1; return; }      /* local dual tree */
             }
         }
         xevdm_split_get_suco_order(xevd_split_is_vertical(split_mode) ? suco_flag : 0, split_mode, order);
@@ -205,6 +205,9 @@ static void hip_recon_tree(XEVD_CTX *ctx, XEVD_CORE *core, int x, int y, int cuw
             if (st.x_pos[p] < ctx->w && st.y_pos[p] < ctx->h)
                 hip_recon_tree(ctx, core, st.x_pos[p], st.y_pos[p], st.width[p], st.height[p], st.cud[p], st.cup[p], child);
         }
+        /* a local dual tree started at this node: its chroma block follows the luma CUs as one CU (xevd_recon_tree, src_main/xevdm.c:1910-1917) */
+        if (tree_cons.mode_cons == eAll && child.mode_cons == eOnlyIntra && child.tree_type == TREE_L)
+            hip_recon_unit(ctx, core, x, y, XEVD_CONV_LOG2(cuw), XEVD_CONV_LOG2(cuh), cup, (TREE_CONS_NEW) { TREE_C, eOnlyIntra });
         return;
     }
     if (ctx->sh.slice_type == SLICE_I || (ctx->sps->tool_admvp && XEVD_CONV_LOG2(cuw) == 2 && XEVD_CONV_LOG2(cuh) == 2)) tree_cons.mode_cons = eOnlyIntra;
@@ -262,7 +265,7 @@ static int hip_dec_slice(XEVD_CTX *ctx, XEVD_CORE *core)
     if (ctx->sps->tool_dmvr && ctx->sps->tool_hmvp) return XEVD_ERR_UNSUPPORTED;
     if (!s->g && (ret = hip_open(ctx)) < 0) return ret;
 
-    s->n_cu = 0; s->coef_v.n = 0; s->any_affine = s->any_dmvr = s->any_ats = s->any_ats_inter = 0; s->failed = 0; s->deblocked = 0;
+    s->n_cu = 0; s->coef_v.n = 0; s->any_affine = s->any_dmvr = s->any_ats = s->any_ats_inter = s->any_tree = 0; s->failed = 0; s->deblocked = 0;
     s->ctu_start = realloc(s->ctu_start, sizeof(uint32_t) * (size_t)(ctx->f_lcu + 1));
     ctx->sh.qp_prev_eco = ctx->sh.qp;
     xevd_mcpy(&bs0, &ctx->bs, sizeof(XEVD_BSR));                        /* the reader right behind the slice header: where the first tile starts */
@@ -314,6 +317,7 @@ static int hip_dec_slice(XEVD_CTX *ctx, XEVD_CORE *core)
     b.constrained_intra_pred = ctx->pps.constrained_intra_pred_flag;
     if (s->any_affine) { b.affine = s->affine; b.affine_mv = s->affine_mv; }
     if (s->any_dmvr) b.dmvr = s->dmvr;
+    if (s->any_tree) b.tree = s->tree;
     b.htdf_slice_qp = ctx->sps->tool_htdf ? ctx->sh.qp : 0;
     b.tiles = hip_tile_grid(ctx, &s->grid);
 

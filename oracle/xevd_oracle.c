@@ -442,6 +442,7 @@ static void ats_inter_tu(int info, int w, int h, int *tx, int *ty, int *tw, int 
 
 /* xevd_set_dec_info (src_base/xevd_util.c:1574-1660): every SCU of the CU receives intra flag (bit 15), QP
    (bits 16-22, core->qp = qp_y - 6*(bd-8)), skip flag (23), luma cbf (24), COD (31), refi and mv. */
+#define CU_PLANES(b, i) ((b)->tree ? ((b)->tree[i] == 1 ? 1 : (b)->tree[i] == 2 ? 2 : 3) : 3)
 static void set_dec_info(const xgpu_seq_params *sp, const xgpu_cu_batch *b, int i, orc_maps *m)
 {
     const int xs = b->x[i] >> 2, ys = b->y[i] >> 2, ws = (1 << b->log2w[i]) >> 2, hs = (1 << b->log2h[i]) >> 2;
@@ -1152,6 +1153,10 @@ int orc_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xgp
         const int x = b->x[i], y = b->y[i], lw = b->log2w[i], lh = b->log2h[i], w = 1 << lw, h = 1 << lh;
         size_t off = b->coef_off[i];
         const int inter = b->pred_mode[i] != XGPU_MODE_INTRA;
+        /* local dual tree: a luma-only (intra / IBC) or chroma-only (intra) CU - prediction, residual, HTDF and the map update per plane it has (xevd_check_luma /
+           xevd_check_chroma in xevd_recon_unit, src_main/xevdm.c:1230-1405; a chroma-only CU leaves the maps alone, xevdm_set_dec_info xevdm_util.c:4241) */
+        const int planes = CU_PLANES(b, i);
+#define HAS_PLANE(c) ((planes >> ((c) ? 1 : 0)) & 1)
         if (b->pred_mode[i] == XGPU_MODE_IBC) {
             /* xevdm_IBC_mc, xevdm_mc.c:2040-2106: a copy out of the CURRENT picture (reconstructed, not yet filtered) at the whole-sample block
                vector mv[0]; chroma at the halved vector */
@@ -1183,6 +1188,7 @@ int orc_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xgp
             for (c = 0; c < 3; c++) {
                 const int cw = c ? w >> 1 : w, ch = c ? h >> 1 : h, s = c ? fr->cur.s_c : fr->cur.s_l;
                 const int16_t *plane = c == 0 ? fr->cur.y : (c == 1 ? fr->cur.u : fr->cur.v);
+                if (!HAS_PLANE(c)) continue;
                 if (sp->tool_eipd) {
                     const int ml = b->ipm ? b->ipm[i * 2] : 0, mc = b->ipm ? b->ipm[i * 2 + 1] : 0;
                     intra_neighbours_eipd(sp, maps, plane + (c ? (y >> 1) * s + (x >> 1) : y * s + x), s, x >> 2, y >> 2, cw, ch, c ? 2 : 4,
@@ -1230,7 +1236,7 @@ int orc_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xgp
         }
         for (c = 0; c < 3 && !ai; c++) {
             const int cw = c ? w >> 1 : w, ch = c ? h >> 1 : h, clw = c ? lw - 1 : lw, clh = c ? lh - 1 : lh;
-            const int coded = (b->cbf[i] >> c) & 1;
+            const int coded = HAS_PLANE(c) && ((b->cbf[i] >> c) & 1);
             int16_t *plane = c == 0 ? fr->cur.y : (c == 1 ? fr->cur.u : fr->cur.v);
             const int s = c ? fr->cur.s_c : fr->cur.s_l;
             if (coded) {
@@ -1264,13 +1270,14 @@ int orc_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xgp
                 if (resid_out) memcpy(resid_out + off, res, sizeof(int16_t) * cw * ch);
                 off += (size_t)cw * ch;
             }
-            if (inter || maps)      /* xevd_recon_yuv passes the luma bit depth for chroma too, xevd_recon.c:75-90 */
+            if ((inter || maps) && HAS_PLANE(c))      /* xevd_recon_yuv passes the luma bit depth for chroma too, xevd_recon.c:75-90 */
                 orc_recon(res, pred[0][c], coded, cw, ch, s, plane + (c ? (y >> 1) * s + (x >> 1) : y * s + x), sp->bit_depth_luma);
         }
-        if (maps && b->htdf_slice_qp && b->pred_mode[i] != XGPU_MODE_IBC && ((b->cbf[i] & 1) || !inter))      /* xevdm.c:1381-1392 */
+        if (maps && b->htdf_slice_qp && b->pred_mode[i] != XGPU_MODE_IBC && ((b->cbf[i] & 1) || !inter) && (planes & 1))      /* xevdm.c:1381-1392 */
             orc_htdf(fr->cur.y + y * fr->cur.s_l + x, fr->cur.s_l, w, h, b->htdf_slice_qp, !inter, maps, x >> 2, y >> 2, !inter && b->constrained_intra_pred,
                      sp->bit_depth_luma);
-        if (maps) set_dec_info(sp, b, i, maps);
+        if (maps && (planes & 1)) set_dec_info(sp, b, i, maps);
+#undef HAS_PLANE
         if (maps && inter && dmvr_done && !sp->tool_addb) {
             /* The SCU map after a refined CU.  xevdm_set_dec_info keeps both sets of vectors (map_mv refined, map_unrefined_mv not, xevdm_util.c:
                4327-4338); the ADDB filter is handed the unrefined ones (xevdm.c:2009-2041) - but the Main library's copy of the BASELINE filter reads
@@ -1346,6 +1353,8 @@ static int chroma_qp(const xgpu_seq_params *sp, int c, int qp)
 
 /* one 4-sample luma edge segment + its chroma, between SCU kq (right/below, supplies the QP) and SCU kp.
    xevd_df.c:343-371 (hor) / :442-476 (ver) */
+/* which planes the CU whose edge is being filtered has (local dual tree, xevd_check_luma_fn / xevd_check_chroma_fn in xevdm_df.c:155-160, 916-920): bit 0 luma, bit 1 chroma */
+static int g_dbk_planes = 3;
 static void dbk_segment(const xgpu_seq_params *sp, const orc_frame *fr, const orc_maps *m, int kq, int kp,
                         int x_pel, int y_pel, int is_ver)
 {
@@ -1354,10 +1363,10 @@ static void dbk_segment(const xgpu_seq_params *sp, const orc_frame *fr, const or
     const int bdl = sp->bit_depth_luma, bdc = sp->bit_depth_chroma;
     const int st = k_df_st[cls][qp] << (bdl - 8);
     int st_u, st_v;
-    if (st) orc_dbk_luma(fr->cur.y + y_pel * fr->cur.s_l + x_pel, st, fr->cur.s_l, bdl, is_ver);
+    if (st && (g_dbk_planes & 1)) orc_dbk_luma(fr->cur.y + y_pel * fr->cur.s_l + x_pel, st, fr->cur.s_l, bdl, is_ver);
     st_u = k_df_st[cls][chroma_qp(sp, 0, qp + fr->qp_u_offset)] << (bdc - 8);
     st_v = k_df_st[cls][chroma_qp(sp, 1, qp + fr->qp_v_offset)] << (bdc - 8);
-    if (st_u || st_v) {
+    if ((st_u || st_v) && (g_dbk_planes & 2)) {
         const int off = (y_pel >> 1) * fr->cur.s_c + (x_pel >> 1);
         orc_dbk_chroma(fr->cur.u + off, fr->cur.v + off, st_u, st_v, fr->cur.s_c, bdc, is_ver);
     }
@@ -1378,6 +1387,7 @@ int orc_deblock_baseline(const xgpu_seq_params *sp, const orc_frame *fr, const x
         /* a CU wider than 64 is filtered as two halves, each like a CU of its own (deblock_tree, src_main/xevdm.c:2017-2037) */
         const int cw = 1 << b->log2w[i], y = b->y[i], w = cw > 64 ? 64 : cw, h = 1 << b->log2h[i];
         int x;
+        g_dbk_planes = CU_PLANES(b, i);
         for (x = b->x[i]; x < b->x[i] + cw; x += 64) {
             const int t = (x >> 2) + (y >> 2) * ws;
             if (x > 0 && MCU_COD(m->map_scu[t - 1]) && TB_OK(t, t - 1))
@@ -1391,6 +1401,7 @@ int orc_deblock_baseline(const xgpu_seq_params *sp, const orc_frame *fr, const x
     for (i = 0; i < b->n_cu; i++) {
         const int x = b->x[i], w = 1 << b->log2w[i], ch = 1 << b->log2h[i];
         int y;
+        g_dbk_planes = CU_PLANES(b, i);
         for (y = b->y[i]; y < b->y[i] + ch; y += 64) {
             const int t = (x >> 2) + (y >> 2) * ws;
             if (y > 0 && TB_OK(t, t - ws))
@@ -1517,9 +1528,9 @@ static void addb_segment(const xgpu_seq_params *sp, const orc_frame *fr, const o
     int c1 = (uint8_t)(k_addb_clip[ia][bs] << (bdl - 9 > 0 ? bdl - 9 : 0));
     int i, c;
     int16_t *y = fr->cur.y + y_pel * fr->cur.s_l + x_pel;
-    for (i = 0; i < 4; i++)
+    for (i = 0; i < 4 && (g_dbk_planes & 1); i++)
         addb_line_luma(is_ver ? y + i * fr->cur.s_l : y + i, is_ver ? 1 : fr->cur.s_l, bs, alpha, beta, c1, bdl);
-    for (c = 0; c < 2; c++) {
+    for (c = 0; c < 2 && (g_dbk_planes & 2); c++) {
         int16_t *pl = (c ? fr->cur.v : fr->cur.u) + (y_pel >> 1) * fr->cur.s_c + (x_pel >> 1);
         const int boff = 6 * (bdc - 8);
         int q = CLIP3(-boff, 57, qp + (c ? fr->qp_v_offset : fr->qp_u_offset));
@@ -1546,6 +1557,7 @@ int orc_deblock_addb(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
     for (i = 0; i < b->n_cu; i++) {
         const int cx = b->x[i], y = b->y[i], cw = 1 << b->log2w[i], h = 1 << b->log2h[i];
         int hx;
+        g_dbk_planes = CU_PLANES(b, i);
         for (hx = 0; hx < cw; hx += 64) {
             const int x = cx + hx, w = cw > 64 ? 64 : cw;
             const int t = (x >> 2) + (y >> 2) * ws;
@@ -1559,6 +1571,7 @@ int orc_deblock_addb(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
     for (i = 0; i < b->n_cu; i++) {
         const int x = b->x[i], cy = b->y[i], w = 1 << b->log2w[i], ch = 1 << b->log2h[i];
         int hy;
+        g_dbk_planes = CU_PLANES(b, i);
         for (hy = 0; hy < ch; hy += 64) {
             const int y = cy + hy;
             const int t = (x >> 2) + (y >> 2) * ws;
@@ -1566,6 +1579,7 @@ int orc_deblock_addb(const xgpu_seq_params *sp, const orc_frame *fr, const xgpu_
                 for (c = 0; c < w >> 2; c++) addb_segment(sp, fr, m, t + c, t + c - ws, x + 4 * c, y, 0, alpha_off, beta_off);
         }
     }
+    g_dbk_planes = 3;
     free(tmap);
     return 0;
 #undef TB_OK

@@ -187,6 +187,12 @@ def golden_streams(only=()):
                                                                              eipd=True, htdf=True, cm_init=True, adcc=True, rpl=True, pocs=True, qp_delta_area=8, max_refs=2, log2_sub_gop=2, split_prob=0.7,
                                                                              bit_depth=10, inter_frac=0.9, skip_frac=0.3, direct_frac=0.3)),
                                 "main_btt_tiles_8b": (392, 264, 5, dict(main=True, btt=(3, 1, 1, 1), iqt=True, addb=True, alf=True, tiles=(2, 2, 0), max_refs=2, split_prob=0.8)),
+                                # local dual trees of BTT + ADMVP streams: luma-only intra / IBC CUs followed by their node's chroma-only CU
+                                "main_dual_tree_i_8b": (200, 136, 2, dict(main=True, btt=(2, 0, 0, 0), admvp=True, dual_tree=True, split_prob=0.8, idr_period=1)),
+                                "main_dual_tree_all_tools_10b": (264, 200, 9, dict(main=True, btt=(2, 0, 0, 0), admvp=True, dual_tree=True, affine=True, amvr=True, hmvp=True, mmvd=True, iqt=True,
+                                                                                   ats=True, addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=4, cm_init=True, adcc=True, qp_delta_area=8,
+                                                                                   max_refs=2, log2_sub_gop=2, split_prob=0.7, bit_depth=10, inter_frac=0.7, skip_frac=0.3, direct_frac=0.3)),
+                                "main_dual_tree_tiles_8b": (392, 264, 4, dict(main=True, btt=(2, 0, 0, 0), admvp=True, dual_tree=True, split_prob=0.7, inter_frac=0.6, tiles=(2, 2, 0), addb=True)),
                                 "main_dquant_area8_10b": (264, 200, 9, dict(main=True, admvp=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, inter_frac=0.8, split_prob=0.65, max_refs=2,
                                                                             log2_sub_gop=2, bit_depth=10, qp_delta_area=8)),
                                 # sps->tool_affine: affine merge and affine inter CUs from the bitstream

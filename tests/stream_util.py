@@ -27,7 +27,7 @@ def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_fra
                 cu_qp_delta=True, split_prob=0.5, idr_period=0, log2_sub_gop=0, bi_frac=0.5, direct_frac=0.1,
                 main=False, iqt=False, ats=False, addb=False, addb_offsets=(0, 0), alf=False, sign=False, eipd=False, crop=(0, 0, 0, 0),
                 chroma_qp_points=None, dra=None, htdf=False, ibc_log_max=0, ibc_frac=0.25, alf_fixed=False, admvp=False, amvr=False, hmvp=False, dmvr=False, mmvd=False,
-                tiles=None, affine=False, affine_frac=0.4, qp_delta_area=0, rpl=False, pocs=False, rpl_in_sps=False, cm_init=False, adcc=False, max_level=6, qp_range=(22, 37), btt=None):
+                tiles=None, affine=False, affine_frac=0.4, qp_delta_area=0, rpl=False, pocs=False, rpl_in_sps=False, cm_init=False, adcc=False, max_level=6, qp_range=(22, 37), btt=None, dual_tree=False):
     """-> bytes.  Picture 0 is an IDR.  log2_sub_gop = 0: IPPP; n: hierarchical sub-GOPs of 2^n pictures, the layer-0 picture of
     each a P picture, the others B pictures (bi-prediction, temporal direct and two-list skip CUs).
     sign: every picture is followed by a picture-signature SEI with the MD5s of the ORACLE's reconstruction of the stream so far."""
@@ -49,7 +49,7 @@ def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_fra
             tid = 0 if idr else tids[(since_idr - 1) % len(tids)]
             is_b = (not idr) and tid > 0
             only_inter = None if idr else []      # P / B pictures: also splits whose children get the "inter only" mode constraint (sps_btt_flag with tool_admvp)
-            part = None if btt is None else synth.gen_partition_tree(rng, width, height, w.split_allowed, split_prob, inter_only=only_inter)      # sps_btt_flag: a legal binary / ternary tree
+            part = None if btt is None else synth.gen_partition_tree(rng, width, height, w.split_allowed, split_prob, inter_only=only_inter, dual_tree=dual_tree)      # sps_btt_flag: a legal binary / ternary tree
             b = synth.gen_frame(rng, width, height, bit_depth, partition=part, inter_frac=0.0 if idr else inter_frac, n_refs=(max_refs, max_refs if is_b else 0),
                                 bi_frac=bi_frac if is_b else 0.0, split_prob=split_prob, coded_frac=0.6, max_level=max_level, amp=1.0, qp_range=qp_range,
                                 ats_frac=0.5 if ats else 0.0, ats_inter_frac=0.5 if ats else 0.0, eipd=eipd)
@@ -74,6 +74,15 @@ def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_fra
                 synth.add_affine(rng, b, affine_frac)
             if ibc_log_max:      # sps->ibc_flag: intra block copy CUs in every slice type (I slices included), up to the signalled size
                 synth.add_ibc(rng, b, width, height, 6, ibc_frac, max_log2=ibc_log_max)
+                if b.get("tree") is not None:      # the chroma block of a local dual tree is always intra-predicted
+                    b["pred_mode"][b["tree"] == 2] = 0
+                if only_inter:      # ... and no IBC below an "inter only" split
+                    sel = np.array(only_inter)
+                    fix = sel[b["pred_mode"][sel] == 6]
+                    b["pred_mode"][fix] = 1
+                    b["refi"][fix, 0] = 0; b["refi"][fix, 1] = -1
+                    b["mv"][fix] = 0
+                    b["mv"][fix, 0, :] = rng.integers(-20, 21, (len(fix), 2))
             if alf:      # a fresh parameter set every other picture (different shapes of the syntax), per-CTU flags, some pictures without ALF / map
                 if k % 2 == 0:
                     nf = int(rng.integers(1, 6))

@@ -46,7 +46,7 @@ def test_struct_sizes_match_header():
     # computed by hand from include/xevd_hip.h (LP64)
     assert C.sizeof(abi.SeqParams) == 12 * 4 + 2 * 8 + 8          # ... + tool_eipd + tail padding
     assert C.sizeof(abi.FrameParams) == (4 + 2 * 17 * 2 + 4 + 2) * 4
-    assert C.sizeof(abi.CuBatch) == 8 + 15 * 8 + 8 + 8 + 8 + 8 + 16 + 8 + 8 + 8      # ... + dmvr, htdf_slice_qp (padded), tiles
+    assert C.sizeof(abi.CuBatch) == 8 + 15 * 8 + 8 + 8 + 8 + 8 + 16 + 8 + 8 + 8 + 8  # ... + dmvr, htdf_slice_qp (padded), tiles, tree
     assert C.sizeof(abi.TileGrid) == (2 + 21 + 23 + 1) * 4
     assert C.sizeof(abi.AlfParams) == 3 * 4 + 4 + 3 * 8 + 8 + 8                      # enable, pad, three pointers, across_tiles (padded), tiles
 

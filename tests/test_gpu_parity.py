@@ -205,6 +205,9 @@ def test_gpu_batch_rejects_malformed_tool_fields():
         variant(lambda b: b["affine"].__setitem__(np.nonzero(b["pred_mode"] == 0)[0][0], 2)),     # affine intra CU
         variant(lambda b: b.__setitem__("htdf_slice_qp", 77)),                                    # slice QP range
         variant(lambda b: b["pred_mode"].__setitem__(aff[0], 5)),                                 # unknown prediction mode
+        variant(lambda b: b.__setitem__("tree", np.where(np.arange(len(b["x"])) == aff[0], 2, 0).astype(np.uint8))),      # a chroma-only CU of a dual tree that is an inter CU
+        variant(lambda b: b.__setitem__("tree", np.where(np.arange(len(b["x"])) == np.nonzero((b["pred_mode"] == 0) & ((b["cbf"] & 6) == 0))[0][0], 1, 0).astype(np.uint8))),  # luma-only CU, no chroma-only CU after it
+        variant(lambda b: b.__setitem__("tree", np.full(len(b["x"]), 3, np.uint8))),               # unknown tree type
     ]
     dec = XgpuDecoder(cs["w"], cs["h"], cs["bd"], iqt=1, admvp=1, addb=1)
     for k, b in enumerate(bad):

@@ -78,7 +78,7 @@ class CuBatch(C.Structure):
         ("coef_off", C.POINTER(C.c_uint32)), ("coef", C.POINTER(C.c_int16)), ("n_coef", C.c_size_t),
         ("n_ctu", C.c_int), ("ctu_cu_start", C.POINTER(C.c_uint32)), ("constrained_intra_pred", C.c_int),
         ("affine", C.POINTER(C.c_uint8)), ("affine_mv", C.POINTER(C.c_int16)), ("dmvr", C.POINTER(C.c_uint8)), ("htdf_slice_qp", C.c_int),
-        ("tiles", C.POINTER(TileGrid)),
+        ("tiles", C.POINTER(TileGrid)), ("tree", C.POINTER(C.c_uint8)),
     ]
 
 
@@ -125,6 +125,7 @@ def make_cu_batch(b):
         "affine": None if b.get("affine") is None else np.ascontiguousarray(b["affine"], np.uint8),
         "affine_mv": None if b.get("affine") is None else np.ascontiguousarray(b["affine_mv"], np.int16),
         "dmvr": None if b.get("dmvr") is None else np.ascontiguousarray(b["dmvr"], np.uint8),
+        "tree": None if b.get("tree") is None else np.ascontiguousarray(b["tree"], np.uint8),
         "coef_off": np.ascontiguousarray(b["coef_off"], np.uint32),
         "coef": np.ascontiguousarray(b["coef"], np.int16),
         "ctu_cu_start": np.ascontiguousarray(b["ctu_cu_start"], np.uint32),
@@ -146,6 +147,8 @@ def make_cu_batch(b):
         cb.affine, cb.affine_mv = _ptr(keep["affine"], C.c_uint8), _ptr(keep["affine_mv"], C.c_int16)
     if keep["dmvr"] is not None:
         cb.dmvr = _ptr(keep["dmvr"], C.c_uint8)
+    if keep["tree"] is not None:
+        cb.tree = _ptr(keep["tree"], C.c_uint8)
     cb.coef_off, cb.coef = _ptr(keep["coef_off"], C.c_uint32), _ptr(keep["coef"], C.c_int16)
     cb.n_coef = len(keep["coef"])
     cb.n_ctu = len(keep["ctu_cu_start"]) - 1

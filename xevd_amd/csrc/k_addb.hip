@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void k_addb(const AddbArgs a, const int16_t *_
     const int step = DIR == 0 ? 1 : a.w_scu;
     const int eq = DIR == 0 ? sx : sy, npos = DIR == 0 ? a.w_scu : a.h_scu;
     const uint32_t eflag = DIR == 0 ? SCU_EDGE_L : SCU_EDGE_T;
+    const uint32_t nflag = DIR == 0 ? SCU_NOCH_L : SCU_NOCH_T;      // a luma CU's edge inside the chroma block of a local dual tree: luma only (xevdm_df.c:916-920, 986-997)
     const uint4 *maps = (const uint4 *)a.maps;
     const bool has_p = eq > 0, has_q = eq < npos, in_range = has_p && has_q;
     const int kq = in_range ? sy * a.w_scu + sx : 0, kp = in_range ? kq - step : 0;
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(256) void k_addb(const AddbArgs a, const int16_t *_
             for (int r = 0; r < 4; r++) addb_line_luma(L[r], bs, alpha, beta, c1, a.bd_l, maxl);
         }
         const int boff = 6 * (a.bd_c - 8);
+        if (!(rq.x & nflag))
 #pragma unroll
         for (int pl = 0; pl < 2; pl++) {
             const int q = clip3a(-boff, 57, qp + (pl ? a.qp_v_off : a.qp_u_off));

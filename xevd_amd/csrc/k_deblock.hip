@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
     const int step = DIR == 0 ? 1 : a.w_scu;                 // SCU-map step along the filtering axis
     const int pos = DIR == 0 ? sx : sy, npos = DIR == 0 ? a.w_scu : a.h_scu;
     const uint32_t eflag = DIR == 0 ? SCU_EDGE_L : SCU_EDGE_T;
+    const uint32_t nflag = DIR == 0 ? SCU_NOCH_L : SCU_NOCH_T;      // a luma CU's edge inside the chroma block of a local dual tree: luma only (xevdm_df.c:155-160)
     const uint4 *maps = (const uint4 *)a.maps;
     const bool has_p = pos > 0, has_q = pos < npos, in_range = has_p && has_q;
     const int k0 = in_range ? sy * a.w_scu + sx : 0;
@@ -150,6 +151,7 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
         const int cls = edge_class(rq, rp), qp = (rq.x >> 16) & 0x7F;
 #pragma unroll
         for (int c = 0; c < 3; c++) st[c] = s_st[(c * 4 + cls) * 64 + (qp & 63)];
+        if (rq.x & nflag) st[1] = st[2] = 0;
     }
 
     // ------------------------------------------------ luma -----------------------------------------------
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
             int kk = k0;
             uint4 cur = rp;                                  // record of SCU head-1
             while (head - 1 > 0) {
-                if (!(cur.x & eflag) || on_tile_border(head - 1)) break;
+                if (!(cur.x & eflag) || (cur.x & nflag) || on_tile_border(head - 1)) break;
                 const uint4 prv = kk == k0 ? rpp : maps[kk - 2 * step];
                 const int cls = edge_class(cur, prv), qp = (cur.x >> 16) & 0x7F;
                 if (s_st[((1 + pl) * 4 + cls) * 64 + (qp & 63)] == 0) break;

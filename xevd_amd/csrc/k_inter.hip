@@ -209,7 +209,7 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
         r1.x = __builtin_amdgcn_readfirstlane(r1.x); r1.y = __builtin_amdgcn_readfirstlane(r1.y); r1.z = __builtin_amdgcn_readfirstlane(r1.z); r1.w = __builtin_amdgcn_readfirstlane(r1.w);
     } else if (!lane_ok) return false;
     const int cu_x = r0.x & 0xFFFF, cu_y = r0.x >> 16;
-    const int lw = r0.y & 0xFF, lh = (r0.y >> 8) & 0xFF, pred_mode = (r0.y >> 16) & 0xFF, cbf = r0.y >> 24;
+    const int lw = r0.y & 0xFF, lh = (r0.y >> 8) & 0xFF, pred_mode = (r0.y >> 16) & 0xF, cbf = r0.y >> 24;
     const int refi0 = (int)(int8_t)(r0.z & 0xFF), refi1 = (int)(int8_t)((r0.z >> 8) & 0xFF), qp_map = (r0.z >> 16) & 0xFF;
     const uint32_t coef_off = r0.w;
     const int cw = 1 << lw, chh = 1 << lh;
@@ -237,6 +237,8 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
         // CU boundary, or the 64-sample transform boundary inside a wider CU (deblock_tree splits those, xevdm.c:1989-2037)
         if (((x - cu_x) & 63) == 0) m |= SCU_EDGE_L;
         if (((y - cu_y) & 63) == 0) m |= SCU_EDGE_T;
+        if (x == cu_x && ((r0.y >> 16) & CU_NOCH_L)) m |= SCU_NOCH_L;          // luma-only CU of a local dual tree: no chroma edge inside the chroma block
+        if (y == cu_y && ((r0.y >> 16) & CU_NOCH_T)) m |= SCU_NOCH_T;
         uint4 rec;
         rec.x = m;
         rec.y = (intra || ibc) ? 0x0000FFFFu : ((r0.z & 0xFFFFu) | ((uint32_t)ai << 16));

@@ -456,9 +456,12 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
                     oc[c - 1][r] = recon2i(oc[c - 1][r], ((cbf >> c) & 1) ? rc[c - 1][r] : 0u, maxv);   // the luma depth clips chroma too (xevd_recon.c:75-90)
                 }
             const int coff = (y >> 1) * a.s_c + (x >> 1);
+            // local dual tree: a chroma-only CU (flag 32) leaves luma alone, a luma-only one (64) chroma - what was computed for the missing plane is dropped
+            if (!(nflags & 32u))
 #pragma unroll
             for (int r = 0; r < 4; r++)
                 if (DEP) st_coherent2(dy + r * a.s_l, ol[r][0], ol[r][1]); else *(uint2 *)(dy + r * a.s_l) = make_uint2(ol[r][0], ol[r][1]);
+            if (!(nflags & 64u))
 #pragma unroll
             for (int c = 1; c < 3; c++) {
                 int16_t *d = (c == 1 ? a.cur_u : a.cur_v) + coff;

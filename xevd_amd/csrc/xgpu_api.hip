@@ -433,9 +433,10 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     // which of the five tables.  Such a CU - inter ones included - reads the final samples of the CUs before it and is read by the ones after it:
     // it becomes a node of the dependency graph next to the intra and IBC CUs
     const int hqp = b->htdf_slice_qp;
+    auto tree_of = [&](uint32_t j) -> int { return b->tree ? b->tree[j] : 0; };      // local dual tree: 1 luma-only, 2 chroma-only CU
     auto htdf_idx = [&](uint32_t j) -> int {       // -1: not filtered
         const bool intra = b->pred_mode[j] == XGPU_MODE_INTRA;
-        if (hqp <= 17 || b->pred_mode[j] == XGPU_MODE_IBC || !((b->cbf[j] & 1) || intra)) return -1;
+        if (hqp <= 17 || tree_of(j) == 2 || b->pred_mode[j] == XGPU_MODE_IBC || !((b->cbf[j] & 1) || intra)) return -1;
         const int w = 1 << b->log2w[j], h = 1 << b->log2h[j], mn = std::min(w, h), mx = std::max(w, h);
         if (w * h < 64 || mx >= 128 || (!intra && mn >= 32)) return -1;
         const int qp = hqp - ((intra && w == h && mn >= 32) ? 8 : 0);
@@ -446,10 +447,12 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     const uint32_t NONE = 0xFFFFFFFFu;
     std::vector<uint32_t> owner((size_t)ws * hs, NONE);
     std::vector<int> level((size_t)n, 0);
-    for (int i = 0; i < n; i++) {
+    // painted CU by CU as the loop below reaches them ("reconstructed before CU i" = painted): inside a local dual tree the node's chroma-only CU follows its
+    // luma CUs and covers them again
+    auto paint = [&](int i) {
         const int xs = b->x[i] >> 2, ys = b->y[i] >> 2, w = (1 << b->log2w[i]) >> 2, h = (1 << b->log2h[i]) >> 2;
         for (int r = 0; r < h; r++) std::fill_n(owner.begin() + (size_t)(ys + r) * ws + xs, w, (uint32_t)i);
-    }
+    };
     // tiles: a neighbour in another tile is not available (map_tidx[curr] == map_tidx[neighbour] in xevd_get_avail_intra, xevd_get_nbr_b, xevdm_get_nbr)
     const int ctu_sh = c->sp.log2_ctu - 2;
     std::vector<uint8_t> ctu_tile;
@@ -464,7 +467,7 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     std::vector<IntraRec> recs;                 // decode order; dep lists hold CU indices until the sort below
     std::vector<uint32_t> deps;
     int max_level = 0;
-    for (int i = 0; i < n; i++) {
+    for (int i = 0; i < n; paint(i), i++) {
         if (!ordered((uint32_t)i)) continue;
         const int xs = b->x[i] >> 2, ys = b->y[i] >> 2, units = ((1 << b->log2w[i]) + (1 << b->log2h[i])) >> 2;
         IntraRec r;
@@ -537,7 +540,7 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
             const int bvx = b->mv[i * 4], bvy = b->mv[i * 4 + 1], w = 1 << b->log2w[i], h = 1 << b->log2h[i];
             const int x0 = b->x[i] + (bvx & ~1), x1 = b->x[i] + bvx + w - 1, y0 = b->y[i] + (bvy & ~1), y1 = b->y[i] + bvy + h - 1;
             r.ipm[0] = r.ipm[1] = 0;
-            r.flags = 2u; r.le = (uint64_t)(uint16_t)bvx | ((uint64_t)(uint16_t)bvy << 16);
+            r.flags = 2u | (tree_of((uint32_t)i) == 1 ? 64u : 0u); r.le = (uint64_t)(uint16_t)bvx | ((uint64_t)(uint16_t)bvy << 16);
             for (int sy = y0 >> 2; sy <= y1 >> 2; sy++)
                 for (int sx = x0 >> 2; sx <= x1 >> 2; sx++) {
                     const uint32_t j = owner[(size_t)sy * ws + sx];
@@ -570,6 +573,22 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
             else if (m == 2) need_up = std::max(need_up, wu);
             else if (m == 3) { need_up = std::max(need_up, wu); need_le = std::max(need_le, hu); need_ul = true; }
             else { need_up = units; need_le = units; }
+        }
+        if (tree_of((uint32_t)i) == 1) r.flags |= 64u;              // luma only: the chroma samples stay as they are
+        if (tree_of((uint32_t)i) == 2) {
+            // chroma only: after the luma CUs of its block (the CUs that read this block later wait for this one CU)
+            r.flags |= 32u;
+            for (int sy = ys; sy < ys + hu; sy++) for (int sx = xs; sx < xs + wu; sx++) {
+                const uint32_t j = owner[(size_t)sy * ws + sx];
+                if (j >= (uint32_t)i) continue;
+                if (ordered(j) && j != last) {
+                    bool seen = false;
+                    for (size_t d = r.dep_first; d < deps.size() && !seen; d++) seen = deps[d] == j;
+                    if (!seen) deps.push_back(j);
+                    last = j;
+                }
+                lv = std::max(lv, level[j]);
+            }
         }
         bool used = true;
         auto ok = [&](int sx, int sy) -> bool {
@@ -704,6 +723,10 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         ARGCHK(c, lw >= 2 && lw <= 7 && lh >= 2 && lh <= 7 && lw <= c->sp.log2_ctu && lh <= c->sp.log2_ctu);
         ARGCHK(c, b->x[i] + (1 << lw) <= c->sp.width && b->y[i] + (1 << lh) <= c->sp.height && !(b->x[i] & 3) && !(b->y[i] & 3));
         ARGCHK(c, b->pred_mode[i] <= XGPU_MODE_DIR || b->pred_mode[i] == XGPU_MODE_IBC);
+        if (b->tree && b->tree[i]) {      // local dual tree: luma-only intra / IBC CUs, chroma-only intra CUs, only the coefficients of the planes they have
+            ARGCHK(c, b->tree[i] <= 2 && (b->pred_mode[i] == XGPU_MODE_INTRA || (b->tree[i] == 1 && b->pred_mode[i] == XGPU_MODE_IBC)));
+            ARGCHK(c, (b->cbf[i] & (b->tree[i] == 1 ? 6 : 1)) == 0);
+        }
         if (b->pred_mode[i] == XGPU_MODE_IBC) {
             // the source block (and the chroma block at the halved vector) inside the active picture; that it is reconstructed before the CU is
             // checked by the dependency plan below
@@ -827,9 +850,10 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         static thread_local std::vector<uint32_t> own;
         own.resize((size_t)c->w_scu * c->h_scu);
         size_t covered = 0;
-        for (int i = 0; i < n; i++) covered += (size_t)1 << (b->log2w[i] + b->log2h[i] - 4);
+        for (int i = 0; i < n; i++) if (!(b->tree && b->tree[i] == 2)) covered += (size_t)1 << (b->log2w[i] + b->log2h[i] - 4);
         if (covered != own.size()) std::fill(own.begin(), own.end(), 0xFFFFFFFFu);
         for (int i = 0; i < n; i++) {
+            if (b->tree && b->tree[i] == 2) continue;               // the SCU maps of a dual-tree block belong to its luma CUs
             const int ws = (1 << b->log2w[i]) >> 2, hh = (1 << b->log2h[i]) >> 2;
             uint32_t *o = own.data() + (size_t)(b->y[i] >> 2) * c->w_scu + (b->x[i] >> 2);
             for (int r = 0; r < hh; r++, o += c->w_scu) std::fill_n(o, ws, (uint32_t)i);
@@ -857,6 +881,14 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         }
         r.x = b->x[i]; r.y = b->y[i]; r.log2w = b->log2w[i]; r.log2h = b->log2h[i];
         r.pred_mode = b->pred_mode[i]; r.cbf = b->cbf[i] & 7;
+        if (b->tree && b->tree[i] == 1) {
+            // a luma-only CU: its left / top edge is an edge of the chroma block (the chroma-only CU that follows) only on that block's border
+            int j = i + 1;
+            while (j < n && b->tree[j] != 2) j++;
+            ARGCHK(c, j < n && b->x[j] <= b->x[i] && b->y[j] <= b->y[i] && b->x[i] + (1 << b->log2w[i]) <= b->x[j] + (1 << b->log2w[j]) && b->y[i] + (1 << b->log2h[i]) <= b->y[j] + (1 << b->log2h[j]));
+            if (b->x[i] != b->x[j]) r.pred_mode |= CU_NOCH_L;
+            if (b->y[i] != b->y[j]) r.pred_mode |= CU_NOCH_T;
+        }
         r.refi[0] = b->refi[i * 2]; r.refi[1] = b->refi[i * 2 + 1];
         r.qp_map = (uint8_t)((b->qp[i * 3] - bdoff) & 0x7F);
         r.map_cbf = (uint8_t)((r.cbf & 1) && (!(r.log2w > 6 || r.log2h > 6) || !b->cbf_sub || (b->cbf_sub[i] & 1)));

@@ -56,6 +56,10 @@ struct __attribute__((aligned(16))) ScuRec {
 static_assert(sizeof(ScuRec) == 16, "ScuRec must be 16 bytes");
 #define SCU_EDGE_L (1u << 8)      // the SCU's left edge is a CU boundary  (free bits 7:14 of map_scu)
 #define SCU_EDGE_T (1u << 9)      // the SCU's top edge is a CU boundary
+#define SCU_NOCH_L (1u << 10)     // ... but not an edge of the chroma block (a luma-only CU inside a local dual tree): the filters leave chroma alone there
+#define SCU_NOCH_T (1u << 11)
+#define CU_NOCH_L 0x40            // CuRec.pred_mode bits 6 / 7 carry the two flags to k_inter's map pass (bits 0-3: XGPU_MODE_*)
+#define CU_NOCH_T 0x80
 
 // One coded transform block for the dequant + inverse-transform kernel.
 struct TbRec {

@@ -361,6 +361,8 @@ struct Cu {
     int mmvd, mmvd_idx;              // mmvd_flag; group << 7 | base candidate << 5 | distance << 2 | direction
     int dmvr;                        // tool_dmvr and a skip / merge-mode CU: mcore->dmvr_enable (xevdm.c:1272-1288)
     int only_inter;                  // mode constraint eOnlyInter of a local tree (sps_btt_flag with tool_admvp): no pred_mode_flag, no IBC
+    int tree;                        // local dual tree (mode constraint eOnlyIntra below a split whose chroma blocks would get too small): 0 = luma + chroma,
+                                     // 1 = luma only (TREE_L; intra or IBC), 2 = chroma only (TREE_C: the split node's chroma block, intra, after its luma CUs)
     int qp_code;                     // core->cu_qp_delta_code (sps->dquant_flag): 0 - , 1 a CU of at least a quantisation group, 2 a CU inside a group
     int affine;                      // mcore->affine_flag: 0 translational, 1 / 2 = 2 / 3 control points (4- / 6-parameter model)
     int16_t aff_mv[2][3][2];         // mcore->affine_mv[list][vertex][x/y]: top-left, top-right, bottom-left control-point vectors
@@ -390,11 +392,12 @@ struct Picture {         // SCU maps of the picture being parsed / written (ctx-
 
 struct Batch {           // the xgpu_cu_batch under construction
     std::vector<uint16_t> x, y;
-    std::vector<uint8_t> log2w, log2h, pred_mode, qp, cbf, ipm, ats, ats_inter, dmvr, affine;
+    std::vector<uint8_t> log2w, log2h, pred_mode, qp, cbf, ipm, ats, ats_inter, dmvr, affine, tree;
+    bool has_tree = false;
     std::vector<int8_t> refi;
     std::vector<int16_t> mv, coef, affine_mv;
     std::vector<uint32_t> coef_off, ctu_start;
-    void clear() { x.clear(); y.clear(); log2w.clear(); log2h.clear(); pred_mode.clear(); qp.clear(); cbf.clear(); ipm.clear(); ats.clear(); ats_inter.clear(); dmvr.clear(); affine.clear(); affine_mv.clear(); refi.clear(); mv.clear(); coef.clear(); coef_off.clear(); ctu_start.clear(); }
+    void clear() { x.clear(); y.clear(); log2w.clear(); log2h.clear(); pred_mode.clear(); qp.clear(); cbf.clear(); ipm.clear(); ats.clear(); ats_inter.clear(); dmvr.clear(); affine.clear(); tree.clear(); has_tree = false; affine_mv.clear(); refi.clear(); mv.clear(); coef.clear(); coef_off.clear(); ctu_start.clear(); }
 };
 
 // ---- DRA parameter sets (APS type 1, SIG_PARAM_DRA) and the inverse-mapping tables the output stage applies (src_main/xevdm_dra.c) ----
@@ -1382,6 +1385,7 @@ struct TileCoder {
     // SCU maps after a CU (xevd_set_dec_info, xevd_util.c:1574-1660; cod_eco xevd.c:797-803)
     void commit(const Cu &cu)
     {
+        if (cu.tree == 2) return;                        // a chroma-only CU leaves every map as its luma CUs wrote it (xevdm_set_dec_info, xevdm_util.c:4241)
         if (sps.tool_hmvp && (cu.mode == MODE_INTER || cu.mode == MODE_SKIP)) history_push(cu);
         const int xs = cu.x >> 2, ys = cu.y >> 2, w = (1 << cu.log2w) >> 2, h = (1 << cu.log2h) >> 2;
         for (int r = 0; r < h; r++) for (int c = 0; c < w; c++) {
@@ -1699,10 +1703,18 @@ struct TileCoder {
         cu.dmvr = 0;
         return true;
     }
+    // the luma intra mode a chroma-only CU refers to: the one stored at the centre of its block (xevd_get_luma_cup, xevd_util.c:1481); Baseline modes: that CU is intra
+    // by constraint; EIPD: DC when it is not (an IBC CU)
+    int luma_mode_of(const Cu &cu) const
+    {
+        const size_t k = (size_t)((cu.y >> 2) + ((1 << cu.log2h) >> 3)) * pic.w_scu + (cu.x >> 2) + ((1 << cu.log2w) >> 3);
+        return pic.intra[k] ? pic.ipm[k] : 0;
+    }
     template <class C> void code_cu(C &c, Cu &cu, int16_t *coef[3], bool enc)
     {
         // mode constraint eOnlyIntra: I slices, and with tool_admvp every 4x4 CU (xevdm.c:1838-1843) - no skip flag, no pred_mode_flag
-        const bool inter_slice = sh.type != XHOST_SLICE_I && !(sps.tool_admvp && cu.log2w == 2 && cu.log2h == 2);
+        // ... and the CUs of a local dual tree (TREE_L / TREE_C)
+        const bool inter_slice = sh.type != XHOST_SLICE_I && !(sps.tool_admvp && cu.log2w == 2 && cu.log2h == 2) && cu.tree == 0;
         const int keep_only_inter = cu.only_inter;
         int skip = 0;
         if (inter_slice) skip = c.bin(cu.mode == MODE_SKIP, models.skip[nb_ctx(cu, CTX_SKIP)]);
@@ -1742,7 +1754,7 @@ struct TileCoder {
         // xevdm_eco_pred_mode (xevdm_eco.c:1401-1438): with sps->ibc_flag every CU up to the IBC size limit that is not already known to be
         // intra-predicted carries ibc_flag - in I slices all of them (mode constraint eOnlyIntra: no pred_mode_flag); context 0 without cm_init
         int ibc = 0;
-        if (sps.ibc && cu.log2w <= sps.ibc_log_max && cu.log2h <= sps.ibc_log_max && !(inter_slice && intra) && !keep_only_inter)
+        if (sps.ibc && cu.log2w <= sps.ibc_log_max && cu.log2h <= sps.ibc_log_max && !(inter_slice && intra) && !keep_only_inter && cu.tree != 2)
             ibc = c.bin(cu.mode == MODE_IBC, models.ibc_flag[nb_ctx(cu, CTX_IBC)]);
         if (!enc) { cu.mode = ibc ? MODE_IBC : intra ? MODE_INTRA : MODE_INTER; cu.direct = 0; }
         if (ibc) {
@@ -1898,10 +1910,14 @@ struct TileCoder {
                     cu.mv[l][0] = (int16_t)(cand[cu.mvp_idx[l]][0] + cu.mvd[l][0]); cu.mv[l][1] = (int16_t)(cand[cu.mvp_idx[l]][1] + cu.mvd[l][1]);
                 }
             }
+        } else if (cu.tree == 2 && !sps.tool_eipd) {
+            cu.ipm_c = cu.ipm = luma_mode_of(cu);                  // no syntax: the chroma block takes the luma mode at its centre (xevdm_eco.c:1763-1781)
         } else if (sps.tool_eipd) {
             // xevd_eco_intra_dir (xevd_eco.c:842-879): one of the 2 most probable modes, one of the 8 extended ones (bypass), or the index
             // among the remaining 23 in truncated binary (4 or 5 bypass bins)
             int mpm[2], ext[8], pims[33];
+            if (cu.tree == 2) cu.ipm = luma_mode_of(cu);           // chroma-only CU: DM refers to the luma mode at the block's centre, DC when that CU is not intra (xevdm_eco.c:1738-1752)
+            else {
             eipd_mpm(cu, mpm, ext, pims);
             int pos = 0;
             while (enc && pos < 33 && pims[pos] != cu.ipm) pos++;
@@ -1920,6 +1936,9 @@ struct TileCoder {
                     cu.ipm = pims[10 + std::min(v, 22)];
                 }
             }
+            }
+            if (cu.tree == 1) cu.ipm_c = 0;
+            else {
             // xevd_eco_intra_dir_c (:881-910): DM, or one of the other modes - the one DM stands for (a luma DC / BI / HOR / VER) is skipped
             const int lc = cu.ipm == 12 ? 4 : cu.ipm == 24 ? 3 : cu.ipm == 0 ? 2 : cu.ipm == 2 ? 1 : 0;
             if (enc && lc && cu.ipm_c == lc) cu.ipm_c = 0;
@@ -1929,6 +1948,7 @@ struct TileCoder {
                 if (lc && v >= lc) v++;
                 cu.ipm_c = std::min(v, 4);
             }
+            }
         } else {
             const uint8_t *mpm = mpm_list(cu);                       // xevd_eco_intra_dir_b, xevd_eco.c:826-846: the code number is sent
             const int code = sym_unary(c, mpm[cu.ipm], models.intra_dir, 2);
@@ -1936,7 +1956,7 @@ struct TileCoder {
         }
         // coded block flags (eco_cbf, xevd_eco.c:260-341), CU <= 64: no sub-blocks
         bool all_zero = false;
-        if (!intra) {
+        if (!intra && cu.tree == 0) {
             // a merge-mode CU (MODE_DIR with tool_admvp) has coefficients by definition - without them it would be a skip CU: no cbf_all (xevdm_eco.c:831)
             const bool merge_cu = sps.tool_admvp && cu.direct && cu.mode == MODE_INTER;
             const int any = merge_cu ? 1 : c.bin((cu.cbf[0] | cu.cbf[1] | cu.cbf[2]) != 0, models.cbf_all[0]);
@@ -1947,10 +1967,10 @@ struct TileCoder {
                 if (cu.cbf[1] + cu.cbf[2] == 0) cu.cbf[0] = 1;
                 else cu.cbf[0] = c.bin(cu.cbf[0], models.cbf_luma[0]);
             }
-        } else {
-            cu.cbf[1] = c.bin(cu.cbf[1], models.cbf_cb[0]);
-            cu.cbf[2] = c.bin(cu.cbf[2], models.cbf_cr[0]);
-            cu.cbf[0] = c.bin(cu.cbf[0], models.cbf_luma[0]);
+        } else {                                                     // intra CUs, and every CU of a dual tree (an IBC luma CU too): one flag per component it has (xevdm_eco_cbf, xevdm_eco.c:266-296)
+            cu.cbf[1] = cu.tree == 1 ? 0 : c.bin(cu.cbf[1], models.cbf_cb[0]);
+            cu.cbf[2] = cu.tree == 1 ? 0 : c.bin(cu.cbf[2], models.cbf_cr[0]);
+            cu.cbf[0] = cu.tree == 2 ? 0 : c.bin(cu.cbf[0], models.cbf_luma[0]);
         }
         // QP (xevd_eco.c:640-668, xevd_eco_dqp :460-479): a delta only when the CU has coefficients
         // sps->dquant_flag (Main; xevdm_eco.c:882-897): one delta per quantisation group - a CU of at least the group size sends it when it has
@@ -2086,7 +2106,7 @@ struct TileParser {
         return leaf(dec, x, y, log2s, log2s, qp_code, 0);
     }
     // sps_btt_flag: a node of the binary / ternary split tree (xevd_entropy_decode_tree, src_main/xevdm.c:1644-1850, without SUCO)
-    int parse_node(Dec &dec, int x, int y, int lw, int lh, int qp_code, bool only_inter)
+    int parse_node(Dec &dec, int x, int y, int lw, int lh, int qp_code, bool only_inter, bool only_intra = false)
     {
         const int W = st.sps.width, H = st.sps.height, w = 1 << lw, h = 1 << lh, mn = 1 << st.sps.log2_min_cb;
         int split = TileCoder::NO_SPLIT;
@@ -2100,21 +2120,23 @@ struct TileParser {
             }
         }
         qp_code = qp_group(st, tc, split, lw, lh, qp_code);
-        if (split == TileCoder::NO_SPLIT) return leaf(dec, x, y, lw, lh, qp_code, only_inter);
-        const int mc = tc.code_mode_cons(dec, split, lw, lh, only_inter, 0);
-        if (mc < 0) return fail("local dual tree (luma-only / chroma-only CUs below this split) is not supported");
+        if (split == TileCoder::NO_SPLIT) { last_qp_code = qp_code; return leaf(dec, x, y, lw, lh, qp_code, only_inter, only_intra ? 1 : 0); }
+        const int mc = only_intra ? 0 : tc.code_mode_cons(dec, split, lw, lh, only_inter, 0);
         int px[3], py[3], plw[3], plh[3];
         const int n = TileCoder::split_parts(split, x, y, lw, lh, px, py, plw, plh);
         for (int i = 0; i < n; i++)
-            if (px[i] < W && py[i] < H) { const int rc = parse_node(dec, px[i], py[i], plw[i], plh[i], qp_code, mc == 1); if (rc != XGPU_OK) return rc; }
+            if (px[i] < W && py[i] < H) { const int rc = parse_node(dec, px[i], py[i], plw[i], plh[i], qp_code, mc == 1, only_intra || mc < 0); if (rc != XGPU_OK) return rc; }
+        // local dual tree: the luma CUs above, now the node's chroma block as one CU (xevdm.c:1828-1833; core->cu_qp_delta_code keeps the last leaf's value)
+        if (mc < 0) return leaf(dec, x, y, lw, lh, last_qp_code, 0, 2);
         return XGPU_OK;
     }
-    int leaf(Dec &dec, int x, int y, int lw, int lh, int qp_code, int only_inter)
+    int last_qp_code = 0;
+    int leaf(Dec &dec, int x, int y, int lw, int lh, int qp_code, int only_inter, int tree = 0)
     {
         if (x + (1 << lw) > st.sps.width || y + (1 << lh) > st.sps.height) return fail("a CU crosses the picture border");
         Cu cu;
         memset(&cu, 0, sizeof(cu));
-        cu.x = x; cu.y = y; cu.log2w = lw; cu.log2h = lh; cu.qp_code = qp_code; cu.only_inter = only_inter;
+        cu.x = x; cu.y = y; cu.log2w = lw; cu.log2h = lh; cu.qp_code = qp_code; cu.only_inter = only_inter; cu.tree = tree;
         int16_t *coef[3] = { blk[0].data(), blk[1].data(), blk[2].data() };
         memset(coef[0], 0, sizeof(int16_t) << (lw + lh));
         memset(coef[1], 0, sizeof(int16_t) << (lw + lh - 2));
@@ -2133,6 +2155,7 @@ struct TileParser {
         batch.cbf.push_back((uint8_t)(cu.cbf[0] | (cu.cbf[1] << 1) | (cu.cbf[2] << 2)));
         batch.ipm.push_back((uint8_t)cu.ipm); batch.ipm.push_back((uint8_t)(st.sps.tool_eipd ? cu.ipm_c : cu.ipm));      // Baseline: chroma mode = luma mode, xevd_eco.c:1154
         batch.ats.push_back((uint8_t)cu.ats); batch.ats_inter.push_back((uint8_t)cu.ats_inter); batch.dmvr.push_back((uint8_t)cu.dmvr);
+        batch.tree.push_back((uint8_t)tree); batch.has_tree |= tree != 0;
         if (st.sps.tool_affine) {      // xgpu_cu_batch.affine: 0 / 2 / 3 control points, .affine_mv[list][vertex][x/y]
             batch.affine.push_back((uint8_t)(cu.affine ? cu.affine + 1 : 0));
             batch.affine_mv.insert(batch.affine_mv.end(), &cu.aff_mv[0][0][0], &cu.aff_mv[0][0][0] + 12);
@@ -2439,14 +2462,16 @@ struct xhost_parser {
             Batch &m = merged;
             const size_t n = cu0[(size_t)n_tiles];
             m.x.resize(n); m.y.resize(n); m.log2w.resize(n); m.log2h.resize(n); m.pred_mode.resize(n); m.qp.resize(n * 3); m.cbf.resize(n); m.ipm.resize(n * 2);
-            m.ats.resize(n); m.ats_inter.resize(n); m.dmvr.resize(n); m.affine.resize(st.sps.tool_affine ? n : 0); m.affine_mv.resize(st.sps.tool_affine ? n * 12 : 0); m.refi.resize(n * 2); m.mv.resize(n * 4); m.coef_off.resize(n);
+            m.ats.resize(n); m.ats_inter.resize(n); m.dmvr.resize(n); m.tree.resize(n); m.has_tree = false;
+            for (int t = 0; t < n_tiles; t++) m.has_tree |= tiles[(size_t)t]->batch.has_tree;
+            m.affine.resize(st.sps.tool_affine ? n : 0); m.affine_mv.resize(st.sps.tool_affine ? n * 12 : 0); m.refi.resize(n * 2); m.mv.resize(n * 4); m.coef_off.resize(n);
             m.coef.resize(cf0[(size_t)n_tiles]); m.ctu_start.resize(ct0[(size_t)n_tiles]);
             parallel_for(n_tiles, [&](int t) {
                 const Batch &b = tiles[(size_t)t]->batch;
                 const size_t o = cu0[(size_t)t], k = b.x.size();
                 auto put = [&](auto &dst, const auto &src, size_t per) { if (k) memcpy(dst.data() + o * per, src.data(), k * per * sizeof(src[0])); };
                 put(m.x, b.x, 1); put(m.y, b.y, 1); put(m.log2w, b.log2w, 1); put(m.log2h, b.log2h, 1); put(m.pred_mode, b.pred_mode, 1); put(m.qp, b.qp, 3);
-                put(m.cbf, b.cbf, 1); put(m.ipm, b.ipm, 2); put(m.ats, b.ats, 1); put(m.ats_inter, b.ats_inter, 1); put(m.dmvr, b.dmvr, 1); put(m.refi, b.refi, 2); put(m.mv, b.mv, 4);
+                put(m.cbf, b.cbf, 1); put(m.ipm, b.ipm, 2); put(m.ats, b.ats, 1); put(m.ats_inter, b.ats_inter, 1); put(m.dmvr, b.dmvr, 1); put(m.tree, b.tree, 1); put(m.refi, b.refi, 2); put(m.mv, b.mv, 4);
                 if (st.sps.tool_affine) { put(m.affine, b.affine, 1); put(m.affine_mv, b.affine_mv, 12); }
                 for (size_t i = 0; i < k; i++) m.coef_off[o + i] = b.coef_off[i] + (uint32_t)cf0[(size_t)t];
                 if (tiles[(size_t)t]->n_coef) memcpy(m.coef.data() + cf0[(size_t)t], b.coef.data(), tiles[(size_t)t]->n_coef * sizeof(int16_t));
@@ -2503,6 +2528,7 @@ struct xhost_parser {
         b.cbf = batch.cbf.data(); b.ipm = batch.ipm.data(); b.coef_off = batch.coef_off.data();
         if (st.sps.tool_ats) { b.ats = batch.ats.data(); b.ats_inter = batch.ats_inter.data(); }
         if (st.sps.tool_affine) { b.affine = batch.affine.data(); b.affine_mv = batch.affine_mv.data(); }
+        if (batch.has_tree) b.tree = batch.tree.data();
         if (batch.coef.empty()) batch.coef.push_back(0);
         b.coef = batch.coef.data(); b.n_coef = batch.x.empty() ? 0 : n_coef;
         b.n_ctu = w_ctu * h_ctu; b.ctu_cu_start = batch.ctu_start.data();
@@ -2889,7 +2915,9 @@ struct TreeWriter {
     //      same search succeeds (plan), then coded (node_btt) ----
     std::vector<int> owner;                              // CU index of every SCU
     std::map<uint64_t, int> chosen;                      // node -> split mode
-    static uint64_t node_key(int x, int y, int lw, int lh, bool oi) { return ((uint64_t)x << 40) | ((uint64_t)y << 16) | ((uint64_t)lw << 8) | ((uint64_t)lh << 4) | (oi ? 1 : 0); }
+    static uint64_t node_key(int x, int y, int lw, int lh, int cons) { return ((uint64_t)x << 40) | ((uint64_t)y << 16) | ((uint64_t)lw << 8) | ((uint64_t)lh << 4) | (uint64_t)cons; }      // cons: 0 none, 1 inter only, 2 intra only (dual tree)
+    std::map<uint64_t, int> chroma_cu;                   // node -> its chroma-only CU (xgpu_cu_batch.tree == 2): the local dual tree starts at that node
+    int last_qp_code = 0;
     bool whole_cus(int x, int y, int wd, int ht, bool &any_non_inter) const      // the rectangle (clipped to the picture) is a union of whole CUs
     {
         const Stream &st = w->st;
@@ -2900,17 +2928,21 @@ struct TreeWriter {
         }
         return true;
     }
-    bool plan(int x, int y, int lw, int lh, bool only_inter)
+    bool plan(int x, int y, int lw, int lh, bool only_inter, bool only_intra = false)
     {
         Stream &st = w->st;
         TileCoder &tcd = w->coder;
-        const uint64_t key = node_key(x, y, lw, lh, only_inter);
+        const uint64_t key = node_key(x, y, lw, lh, only_inter ? 1 : only_intra ? 2 : 0);
         if (chosen.count(key)) return chosen[key] >= 0;
         const int W = st.sps.width, H = st.sps.height, wd = 1 << lw, ht = 1 << lh;
         const bool inside = x + wd <= W && y + ht <= H;
         if (inside) {
             const int i = leaf[(size_t)(y >> 2) * st.pic.w_scu + (x >> 2)];
-            if (i >= 0 && b->log2w[i] == lw && b->log2h[i] == lh) { chosen[key] = TileCoder::NO_SPLIT; return true; }
+            if (i >= 0 && b->log2w[i] == lw && b->log2h[i] == lh) {
+                // a luma-only CU is a leaf of a dual tree and nothing else
+                if (((b->tree ? b->tree[i] : 0) == 1) != only_intra) { chosen[key] = -1; return false; }
+                chosen[key] = TileCoder::NO_SPLIT; return true;
+            }
         }
         chosen[key] = -1;
         if (!(wd > (1 << st.sps.log2_min_cb) || ht > (1 << st.sps.log2_min_cb)) || (lw < 3 && lh < 3)) return false;
@@ -2924,42 +2956,56 @@ struct TreeWriter {
             bool ok = true, non_inter = false;
             for (int k = 0; k < n && ok; k++) if (px[k] < W && py[k] < H) ok = whole_cus(px[k], py[k], 1 << plw[k], 1 << plh[k], non_inter);
             if (!ok) continue;
-            bool child_oi = only_inter;
-            if (st.sps.btt && st.sps.tool_admvp && !only_inter && !TileCoder::chroma_split_ok(sp, wd, ht)) {
-                // the children would need a mode constraint: only "inter only" can be written (the other one is the local dual tree)
-                if (st.sh.type == XHOST_SLICE_I || TileCoder::small_child_is_4x4(sp, wd, ht) || non_inter) continue;
-                child_oi = true;
-            }
-            for (int k = 0; k < n && ok; k++) if (px[k] < W && py[k] < H) ok = plan(px[k], py[k], plw[k], plh[k], child_oi);
+            bool child_oi = only_inter, child_intra = only_intra;
+            if (st.sps.btt && st.sps.tool_admvp && !only_inter && !only_intra && !TileCoder::chroma_split_ok(sp, wd, ht)) {
+                // the children need a mode constraint: a local dual tree when the batch has the node's chroma-only CU (inferred in I slices and for 4x4 children,
+                // else signalled), "inter only" when every CU below is an inter CU
+                if (chroma_cu.count(node_key(x, y, lw, lh, 0))) child_intra = true;
+                else if (st.sh.type == XHOST_SLICE_I || TileCoder::small_child_is_4x4(sp, wd, ht) || non_inter) continue;
+                else child_oi = true;
+            } else if (!only_intra && chroma_cu.count(node_key(x, y, lw, lh, 0))) continue;      // a chroma-only CU where no dual tree can start
+            for (int k = 0; k < n && ok; k++) if (px[k] < W && py[k] < H) ok = plan(px[k], py[k], plw[k], plh[k], child_oi, child_intra);
             if (ok) { chosen[key] = sp; return true; }
         }
         return false;
     }
-    void node_btt(int x, int y, int lw, int lh, int qp_code, bool only_inter)
+    void node_btt(int x, int y, int lw, int lh, int qp_code, bool only_inter, bool only_intra = false)
     {
         Stream &st = w->st;
         TileCoder &tcd = w->coder;
         const int W = st.sps.width, H = st.sps.height, wd = 1 << lw, ht = 1 << lh, mn = 1 << st.sps.log2_min_cb;
-        const int split = chosen[node_key(x, y, lw, lh, only_inter)];
+        const int split = chosen[node_key(x, y, lw, lh, only_inter ? 1 : only_intra ? 2 : 0)];
         if ((wd > mn || ht > mn) && x + wd <= W && y + ht <= H) tcd.code_split(*enc, split, x, y, lw, lh, only_inter);
         qp_code = qp_group(st, tcd, split, lw, lh, qp_code);
-        if (split == TileCoder::NO_SPLIT) { write_leaf(leaf[(size_t)(y >> 2) * st.pic.w_scu + (x >> 2)], qp_code, only_inter); return; }
-        const int mc = tcd.code_mode_cons(*enc, split, lw, lh, only_inter, 1);
+        if (split == TileCoder::NO_SPLIT) { last_qp_code = qp_code; write_leaf(leaf[(size_t)(y >> 2) * st.pic.w_scu + (x >> 2)], qp_code, only_inter, only_intra ? 1 : 0); return; }
+        const auto cc = chroma_cu.find(node_key(x, y, lw, lh, 0));
+        const bool dual = !only_inter && !only_intra && cc != chroma_cu.end();
+        const int mc = only_intra ? 0 : tcd.code_mode_cons(*enc, split, lw, lh, only_inter, dual ? 0 : 1);
         int px[3], py[3], plw[3], plh[3];
         const int n = TileCoder::split_parts(split, x, y, lw, lh, px, py, plw, plh);
-        for (int k = 0; k < n; k++) if (px[k] < W && py[k] < H) node_btt(px[k], py[k], plw[k], plh[k], qp_code, mc == 1);
+        for (int k = 0; k < n; k++) if (px[k] < W && py[k] < H) node_btt(px[k], py[k], plw[k], plh[k], qp_code, mc == 1, only_intra || mc < 0);
+        if (mc < 0) { if (cc == chroma_cu.end()) { error = 1; return; } write_leaf(cc->second, last_qp_code, 0, 2); }
     }
-    void write_leaf(int i, int qp_code, int only_inter)
+    void write_leaf(int i, int qp_code, int only_inter, int tree = 0)
     {
         Stream &st = w->st;
         TileCoder &tcd = w->coder;
         const int x = b->x[i], y = b->y[i], lw = b->log2w[i], lh = b->log2h[i], log2s = std::min(lw, lh);
         Cu cu;
         memset(&cu, 0, sizeof(cu));
-        cu.x = x; cu.y = y; cu.log2w = lw; cu.log2h = lh; cu.qp_code = qp_code; cu.only_inter = only_inter;
+        cu.x = x; cu.y = y; cu.log2w = lw; cu.log2h = lh; cu.qp_code = qp_code; cu.only_inter = only_inter; cu.tree = tree;
         cu.mode = b->pred_mode[i] == XGPU_MODE_INTRA ? MODE_INTRA : (b->pred_mode[i] == XGPU_MODE_SKIP ? MODE_SKIP : MODE_INTER);
-        const bool ibc = b->pred_mode[i] == XGPU_MODE_IBC && st.sps.ibc && std::max(lw, lh) <= st.sps.ibc_log_max && !only_inter;
-        if (st.sh.type == XHOST_SLICE_I || (st.sps.tool_admvp && lw == 2 && lh == 2)) cu.mode = MODE_INTRA;
+        // (a luma-only IBC CU only with EIPD: a Baseline-mode chroma CU must find an intra mode at its centre, xevdm_eco.c:1771-1775)
+        bool ibc = b->pred_mode[i] == XGPU_MODE_IBC && st.sps.ibc && std::max(lw, lh) <= st.sps.ibc_log_max && !only_inter && tree != 2 && !(tree == 1 && !st.sps.tool_eipd);
+        if (ibc) {
+            // the source block must lie in what THIS stream has coded before the CU: the writer's split tree may order the leaves differently from the
+            // batch (several trees have the same leaves), and a block copied from samples that do not exist yet is whatever the decoder's buffer held
+            const int bvx = b->mv[i * 4], bvy = b->mv[i * 4 + 1];
+            const int x0 = x + (bvx & ~1), y0 = y + (bvy & ~1), x1 = x + bvx + (1 << lw) - 1, y1 = y + bvy + (1 << lh) - 1;
+            if (x0 < 0 || y0 < 0 || x1 >= st.sps.width || y1 >= st.sps.height) ibc = false;
+            for (int sy = y0 >> 2; ibc && sy <= y1 >> 2; sy++) for (int sx = x0 >> 2; sx <= x1 >> 2; sx++) if (!st.pic.cod[(size_t)sy * st.pic.w_scu + sx]) { ibc = false; break; }
+        }
+        if (st.sh.type == XHOST_SLICE_I || (st.sps.tool_admvp && lw == 2 && lh == 2) || tree) cu.mode = MODE_INTRA;
         if (ibc) cu.mode = MODE_IBC;
         cu.direct = (st.sh.type == XHOST_SLICE_B || (st.sps.tool_admvp && st.sh.type == XHOST_SLICE_P)) && b->pred_mode[i] == XGPU_MODE_DIR;
         for (int l = 0; l < 2; l++) {
@@ -2991,7 +3037,7 @@ struct TreeWriter {
         cu.ipm = b->ipm ? b->ipm[i * 2] % (st.sps.tool_eipd ? 33 : 5) : 0;
         cu.ipm_c = (b->ipm && st.sps.tool_eipd) ? b->ipm[i * 2 + 1] % 5 : 0;
         cu.qp = std::min(std::max((int)b->qp[i * 3] - bd_off, 0), 51);
-        for (int k = 0; k < 3; k++) cu.cbf[k] = cu.mode == MODE_SKIP ? 0 : (b->cbf[i] >> k) & 1;
+        for (int k = 0; k < 3; k++) cu.cbf[k] = (cu.mode == MODE_SKIP || (tree == 1 && k > 0) || (tree == 2 && k == 0)) ? 0 : (b->cbf[i] >> k) & 1;
         cu.ats = (st.sps.tool_ats && b->ats && cu.mode == MODE_INTRA) ? b->ats[i] & 7 : 0;
         cu.ats_inter = 0;
         if (st.sps.tool_ats && b->ats_inter && cu.mode == MODE_INTER && !cu.direct) {
@@ -3016,7 +3062,7 @@ struct TreeWriter {
             coef[k] = blk[k].data();
         }
         if (st.sps.tool_admvp && cu.mode == MODE_INTER && cu.direct && !(cu.cbf[0] | cu.cbf[1] | cu.cbf[2])) { cu.mode = MODE_SKIP; cu.direct = 0; }      // merge mode without coefficients IS skip
-        const bool cbf_all_path = cu.mode == MODE_INTER || cu.mode == MODE_IBC;          // eco_cbf's non-intra branch
+        const bool cbf_all_path = (cu.mode == MODE_INTER || cu.mode == MODE_IBC) && tree == 0;          // eco_cbf's non-intra branch
         if (cbf_all_path && !(cu.cbf[0] | cu.cbf[1] | cu.cbf[2])) { /* all-zero flag path */ }
         else if (cbf_all_path && cu.cbf[1] + cu.cbf[2] == 0) cu.cbf[0] = 1;      // implied luma cbf needs a luma coefficient
         if (cbf_all_path && cu.cbf[0]) { bool nz = false; for (int16_t v : blk[0]) nz |= v != 0; if (!nz) blk[0][0] = 1; }
@@ -3056,9 +3102,9 @@ extern "C" int xhost_writer_split_allowed(xhost_writer *w, int x, int y, int log
     int a[6];
     w->coder.split_allowed(a, log2w, log2h, x, y, false);
     for (int i = 0; i < 5; i++) allow[i] = a[i];
-    // splits whose children would need a mode constraint (sps_btt_flag with tool_admvp, smallest child under 64 luma samples): the writer can only send
-    // "inter only" - reported as 2 (allowed in P / B pictures when every CU below is an inter CU)
-    if (w->st.sps.tool_admvp) for (int i = 1; i < 5; i++) if (allow[i] && !TileCoder::chroma_split_ok(i, wd, ht)) allow[i] = TileCoder::small_child_is_4x4(i, wd, ht) ? 0 : 2;
+    // splits whose children need a mode constraint (sps_btt_flag with tool_admvp, smallest child under 64 luma samples): 2 = either every CU below is an inter CU
+    // (P / B pictures) or the node starts a local dual tree - luma-only intra / IBC CUs below, then the node's chroma-only CU; 3 = the dual tree only (4x4 children)
+    if (w->st.sps.tool_admvp) for (int i = 1; i < 5; i++) if (allow[i] && !TileCoder::chroma_split_ok(i, wd, ht)) allow[i] = TileCoder::small_child_is_4x4(i, wd, ht) ? 3 : 2;
     return XGPU_OK;
 }
 
@@ -3146,6 +3192,12 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
         if ((!st.sps.btt && b->log2w[i] != b->log2h[i]) || b->log2w[i] < 2 || b->log2w[i] > 6 || b->log2h[i] < 2 || b->log2h[i] > 6 || b->x[i] + (1 << b->log2w[i]) > st.sps.width ||
             b->y[i] + (1 << b->log2h[i]) > st.sps.height || (b->x[i] & 3) || (b->y[i] & 3) || (!st.sps.btt && ((b->x[i] & ((1 << b->log2w[i]) - 1)) || (b->y[i] & ((1 << b->log2h[i]) - 1)))))
             return XGPU_ERR_INVALID_ARGUMENT;
+        if (b->tree && b->tree[i] == 2) {      // the chroma block of a local dual tree: found again through its node
+            if (!(st.sps.btt && st.sps.tool_admvp) || b->pred_mode[i] != XGPU_MODE_INTRA) return XGPU_ERR_INVALID_ARGUMENT;
+            tw.chroma_cu[TreeWriter::node_key(b->x[i], b->y[i], b->log2w[i], b->log2h[i], 0)] = i;
+            continue;
+        }
+        if (b->tree && b->tree[i] > 2) return XGPU_ERR_INVALID_ARGUMENT;
         tw.leaf[(size_t)(b->y[i] >> 2) * st.pic.w_scu + (b->x[i] >> 2)] = i;
         if (st.sps.btt)
             for (int r = 0; r < (1 << b->log2h[i]) >> 2; r++) for (int c2 = 0; c2 < (1 << b->log2w[i]) >> 2; c2++) tw.owner[(size_t)((b->y[i] >> 2) + r) * st.pic.w_scu + (b->x[i] >> 2) + c2] = i;

@@ -251,6 +251,7 @@ def iter_stream(data, consume_batch=None, threads=1):
                 "coef_off": _arr(b.coef_off, n, np.uint32), "coef": _arr(b.coef, max(b.n_coef, 1), np.int16), "n_coef": int(b.n_coef),
                 "ctu_cu_start": _arr(b.ctu_cu_start, b.n_ctu + 1, np.uint32), "constrained_intra_pred": int(b.constrained_intra_pred), "htdf_slice_qp": int(b.htdf_slice_qp),
                 "dmvr": _arr(b.dmvr, n, np.uint8) if b.dmvr else None,
+                "tree": _arr(b.tree, n, np.uint8) if b.tree else None,
                 "affine": _arr(b.affine, n, np.uint8) if b.affine else None,
                 "affine_mv": _arr(b.affine_mv, n * 12, np.int16).reshape(n, 2, 3, 2) if b.affine else None,
                 "tiles": abi.tile_grid_dict(b.tiles.contents) if b.tiles else None,

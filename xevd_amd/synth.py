@@ -137,8 +137,10 @@ def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_fr
               n_refs=(1, 0), qp_range=(22, 37), mv_sigma_px=8.0, oob_frac=0.05, split_prob=0.5,
               chroma_qp_table=None, max_level=24, amp=2.0, ats_frac=0.0, ats_inter_frac=0.0, btt_frac=0.0, min_log2=2, eipd=False, partition=None):
     """One picture's CU batch as a dict of numpy arrays (layout of xgpu_cu_batch, include/xevd_hip.h)."""
-    if partition is not None:      # leaf CUs given by the caller (x, y, log2w, log2h, ctu_cu_start)
-        x, y, l2w, l2h, start = partition
+    tree = None
+    if partition is not None:      # leaf CUs given by the caller (x, y, log2w, log2h, ctu_cu_start[, tree: 0 / 1 luma-only / 2 chroma-only CUs of local dual trees])
+        x, y, l2w, l2h, start = partition[:5]
+        tree = partition[5] if len(partition) > 5 else None
     elif btt_frac > 0:
         x, y, l2w, l2h, start = gen_partition_btt(rng, width, height, log2_ctu, split_prob, btt_frac)
     else:
@@ -148,6 +150,8 @@ def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_fr
     h = (1 << l2h.astype(np.int64))
 
     pred_mode = np.where(rng.random(n) < inter_frac, MODE_INTER, MODE_INTRA).astype(np.uint8)
+    if tree is not None:
+        pred_mode[tree != 0] = MODE_INTRA
     inter = pred_mode != MODE_INTRA
 
     # reference indices: uni L0, uni L1 or bi
@@ -189,6 +193,8 @@ def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_fr
     cbf |= (coded & (rng.random(n) < 0.9)).astype(np.uint8)
     cbf |= (coded & (rng.random(n) < 0.5)).astype(np.uint8) << 1
     cbf |= (coded & (rng.random(n) < 0.5)).astype(np.uint8) << 2
+    if tree is not None:
+        cbf = np.where(tree == 1, cbf & 1, np.where(tree == 2, cbf & 6, cbf)).astype(np.uint8)
 
     # ATS-inter (Main): a coded inter CU of 8..64 may code one half/quarter TU (xevdm_check_ats_inter_info_coded,
     # src_main/xevdm_util.c:3565-3583); ats_inter_info = idx | pos << 4, idx 1/3 vertical split, 2/4 horizontal split
@@ -290,7 +296,7 @@ def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_fr
         ipm[:, 1] = rng.integers(0, 5, n)
     return {
         "x": x, "y": y, "log2w": l2w, "log2h": l2h, "pred_mode": pred_mode, "refi": refi, "mv": mv, "qp": qp,
-        "cbf": cbf, "cbf_sub": cbf_sub if big.any() else None, "ats": ats, "ats_inter": ats_inter, "ipm": ipm, "coef_off": coef_off.astype(np.uint32), "coef": coef[:max(n_coef, 1)],
+        "tree": tree if tree is not None and tree.any() else None, "cbf": cbf, "cbf_sub": cbf_sub if big.any() else None, "ats": ats, "ats_inter": ats_inter, "ipm": ipm, "coef_off": coef_off.astype(np.uint32), "coef": coef[:max(n_coef, 1)],
         "ctu_cu_start": start, "n_coef": n_coef,
     }
 
@@ -303,42 +309,51 @@ DEFAULT_CHROMA_QP_BASE = [
     35, 35, 36, 36, 36, 37, 37, 37, 38, 38, 39, 39, 40, 40, 40, 41, 41, 41]
 
 
-def gen_partition_tree(rng, width, height, allowed, split_prob=0.5, log2_ctu=6, inter_only=None):
+def gen_partition_tree(rng, width, height, allowed, split_prob=0.5, log2_ctu=6, inter_only=None, dual_tree=False):
     """Leaf CUs (decode order) of a split tree whose nodes only take the splits `allowed(x, y, log2w, log2h)` reports - [none, binary with a vertical cut,
     binary horizontal, ternary vertical, ternary horizontal], entries 0 / 1 / 2 - e.g. StreamWriter.split_allowed for a stream with sps_btt_flag.  A split
     reported as 2 is only taken when `inter_only` is a list: the leaves below it must then be inter CUs, their indices are appended to that list.
-    -> x, y, log2w, log2h, ctu_cu_start like gen_partition"""
+    With `dual_tree` a split reported as 2 or 3 may also start a local dual tree: the leaves below it become luma-only CUs (tree 1) and the node's chroma-only CU
+    (tree 2) follows them; a sixth array `tree` is then returned.
+    -> x, y, log2w, log2h, ctu_cu_start like gen_partition [, tree]"""
     ctu = 1 << log2_ctu
     w_ctu, h_ctu = (width + ctu - 1) // ctu, (height + ctu - 1) // ctu
-    xs, ys, lws, lhs, start = [], [], [], [], []
+    xs, ys, lws, lhs, start, trees = [], [], [], [], [], []
 
-    def node(x, y, lw, lh, forced=False):
+    def node(x, y, lw, lh, forced=False, dual=False):
         if x >= width or y >= height:
             return
         raw = allowed(x, y, lw, lh)
-        a = [int(v == 1 or (v == 2 and (inter_only is not None or forced))) for v in raw]
+        a = [int(v == 1 or (v == 2 and (inter_only is not None or forced or dual or dual_tree)) or (v == 3 and (dual or (dual_tree and not forced)))) for v in raw]
         inside = x + (1 << lw) <= width and y + (1 << lh) <= height
         opts = [m for m in range(1, 5) if a[m]]
         if inside and a[0] and (not opts or rng.random() >= split_prob):
             if forced:
                 inter_only.append(len(xs))
-            xs.append(x); ys.append(y); lws.append(lw); lhs.append(lh)
+            xs.append(x); ys.append(y); lws.append(lw); lhs.append(lh); trees.append(1 if dual else 0)
             return
         assert opts, f"no way to split the node {x},{y} {1 << lw}x{1 << lh}"
         m = opts[int(rng.integers(0, len(opts)))] if inside else opts[0]
         ver = m in (1, 3)
         sizes = [1, 1] if m < 3 else [2, 1, 2]
         off = 0
+        # a split that constrains its children: inter CUs only (P / B pictures), or a local dual tree
+        starts_dual = False
+        if raw[m] >= 2 and not forced and not dual:
+            starts_dual = raw[m] == 3 or inter_only is None or (dual_tree and rng.random() < 0.5)
         for sh in sizes:
             clw, clh = (lw - sh, lh) if ver else (lw, lh - sh)
-            node(x + off if ver else x, y if ver else y + off, clw, clh, forced or raw[m] == 2)
+            node(x + off if ver else x, y if ver else y + off, clw, clh, forced or (raw[m] == 2 and not starts_dual and not dual), dual or starts_dual)
             off += 1 << (clw if ver else clh)
+        if starts_dual:
+            xs.append(x); ys.append(y); lws.append(lw); lhs.append(lh); trees.append(2)
     for cy in range(h_ctu):
         for cx in range(w_ctu):
             start.append(len(xs))
             node(cx * ctu, cy * ctu, log2_ctu, log2_ctu)
     start.append(len(xs))
-    return np.array(xs, np.uint16), np.array(ys, np.uint16), np.array(lws, np.uint8), np.array(lhs, np.uint8), np.array(start, np.uint32)
+    out = (np.array(xs, np.uint16), np.array(ys, np.uint16), np.array(lws, np.uint8), np.array(lhs, np.uint8), np.array(start, np.uint32))
+    return out + (np.array(trees, np.uint8),) if dual_tree else out
 
 
 def add_affine(rng, batch, frac=0.5):
