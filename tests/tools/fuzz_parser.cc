@@ -4,6 +4,7 @@
 //   ./fuzz <mutations per stream> <parser threads> a.evc b.evc ...             (golden streams: np.load(tests/golden/stream_*.npz)["bytes"])
 // Round 2: 8250 mutations of the 55 golden streams under ASan + UBSan and the tiled ones under TSan with 4 threads - clean after the tile test was moved in
 // front of every neighbour read (another tile's maps may be written at that moment).
+// Repeated after BTT and the local dual tree went in: 1200 + 1200 mutations of their six golden streams (ASan + UBSan), 300 of the tiled ones under TSan with 4 threads - clean.
 #include "../../include/xevd_host.h"
 #include <cstdio>
 #include <cstdlib>
