@@ -288,6 +288,26 @@ def end_to_end_leg(dec, wl, batches, alf, slots, steps, warmup, builders=int(os.
                     "xgpu_pic_output_async (conversion, packing, download stream) -> host YUV; all of it inside the timed region"}
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N child processes of this command line, RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set
+    (127.0.0.1 and a free port), stdout / stderr shared with the parent; returns the worst exit status."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = rc or p.returncode
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -297,7 +317,13 @@ def main():
                     help=f"default: {DEFAULT_WORKLOAD} on one GPU, {DEFAULT_WORKLOAD_MULTI} with --gpus N > 1")
     ap.add_argument("--batches", type=int, default=4, help="distinct pictures' CU batches kept resident and cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the batches-in -> YUV-out leg")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # launched plainly (`python bench.py --gpus N`): this process becomes the launcher of N ranks, one per GPU, each running this
+        # file with the rendezvous variables torch.distributed.run would have set; rank 0 prints the JSON line
+        sys.exit(spawn_ranks(args.gpus))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -313,9 +339,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
     local_rank %= max(torch.cuda.device_count(), 1)       # more ranks than devices (a one-GPU box exercising the N > 1 path): they share
-    torch.cuda.set_device(local_rank)
+    # XEVD_BENCH_DECODER names another module with an XgpuDecoder class: tests/stub_decoder.py, with which the CPU suite runs the launcher,
+    # the work queue and the accounting of the N > 1 path (the line then says "decoder": "stub_decoder"; no measurement comes out of it)
+    dec_mod = os.environ.get("XEVD_BENCH_DECODER", "xevd_amd.decoder")
+    if dec_mod == "xevd_amd.decoder":
+        torch.cuda.set_device(local_rank)
 
-    from xevd_amd.decoder import XgpuDecoder
+    import importlib
+    XgpuDecoder = importlib.import_module(dec_mod).XgpuDecoder
     wl = WORKLOADS[args.workload]
     first, batches, alf = make_stream(wl, 1000 + rank, args.batches)
     dec = XgpuDecoder(wl["w"], wl["h"], wl["bd"], device=local_rank, iqt=wl["iqt"], admvp=wl["admvp"], addb=wl["addb"],
@@ -359,7 +390,8 @@ def main():
     def barrier():
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         dec.sync()
 
     for k in range(args.warmup):
@@ -389,7 +421,8 @@ def main():
                 step(k)
                 k += 1
             mine += n
-        torch.cuda.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
         dec.sync()
         my_dt = time.perf_counter() - t0
         barrier()
@@ -412,8 +445,11 @@ def main():
     for hb in handles:
         dec.batch_destroy(hb)
     handles = []
-    e2e = end_to_end_leg(dec, wl, batches, alf, slots, max(args.steps // 2, 10), 4)
-    if dist is not None:
+    if args.no_end_to_end:
+        e2e = {"fps": None, "ms_per_picture": 0.0, "skipped": True}
+    else:
+        e2e = end_to_end_leg(dec, wl, batches, alf, slots, max(args.steps // 2, 10), 4)
+    if dist is not None and not args.no_end_to_end:
         t = torch.tensor([e2e["ms_per_picture"]], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         e2e["fps"] = round(world * 1e3 / float(t.item()), 2)
@@ -429,7 +465,7 @@ def main():
         # `kernels` but not priced against the HBM roofline
         dom = max(("itdq", "inter", "dbk_v", "dbk_h", "alf"), key=lambda k: tim[k][0])
         bytes_per_launch = float(np.mean([a[dom] for a in ab]))
-        avg_s = tim[dom][0] / max(tim[dom][1], 1) * 1e-3
+        avg_s = max(tim[dom][0] / max(tim[dom][1], 1) * 1e-3, 1e-12)
         achieved = bytes_per_launch / avg_s / 1e9
         try:
             copy_bw = dec.measure_copy_bw(1 << 30, 10)
@@ -443,7 +479,7 @@ def main():
         except Exception:
             traffic = None
         total_alg = float(np.mean([sum(v for k, v in a.items() if k != "alf" or wl["alf"]) for a in ab]))
-        kern_s = sum(tim[k][0] for k in ("itdq", "inter", "dmvr", "affine", "intra", "dbk_v", "dbk_h", "alf", "pad")) * 1e-3 / args.steps
+        kern_s = max(sum(tim[k][0] for k in ("itdq", "inter", "dmvr", "affine", "intra", "dbk_v", "dbk_h", "alf", "pad")) * 1e-3 / args.steps, 1e-12)
         out = {
             "metric": "frames/sec (bit-exact YUV) + achieved HBM GB/s",
             "value": round(world * args.steps / dt, 2),
@@ -470,6 +506,7 @@ def main():
             # `value` above is the rate with the CU batches resident in HBM (the benchmark contract's definition); the rate of the whole
             # span host batches -> host YUV, transfers and the host batch builder inside the timed region, is end_to_end_fps
             "per_rank": per_rank,
+            "decoder": dec_mod,
             "kernel_only_fps": round(world * args.steps / dt, 2),
             "end_to_end_fps": e2e["fps"],
             "end_to_end": e2e,

@@ -267,6 +267,7 @@ int main(int argc, char **argv)
         if (streams[s].fd < 0) { perror(argv[a + 2 * s + 1]); return 2; }
         /* one job per closed GOP: the unit of the queue, and the bound on the pinned output buffer of a worker */
         int n = xwq_split_gops(bytes, (size_t)size, s, jobs, MAX_GOPS);
+        if (n == -203) { fprintf(stderr, "%s: more than %d closed GOPs\n", argv[a + 2 * s], MAX_GOPS); return 1; }
         if (n < 0) { fprintf(stderr, "%s: damaged NAL length prefix\n", argv[a + 2 * s]); return 1; }
         if (n == 0) continue;                                       /* no picture: an empty output file */
         for (int k = 0; k < n; k++) { xwq_push(q, &jobs[k]); total_pictures += jobs[k].n_pictures; }

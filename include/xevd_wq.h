@@ -44,7 +44,8 @@ int  xwq_run(xwq *q, const int *devices, int n_devices, xwq_init_fn init, xwq_jo
 
 /* Cut a length-prefixed EVC stream (4-byte big-endian NAL size, app/xevd_app.c:52-107) into closed GOPs: a unit starts at every IDR slice NAL
    and takes everything up to the next one.  Parameter sets / APS NAL units before a unit stay where they are - xwq_unit_bytes() prepends
-   them.  Returns the number of units (<= max_jobs), or < 0 for a damaged length prefix. */
+   them.  Returns the number of units (<= max_jobs), -202 for a damaged length prefix, -203 when the stream has more units than max_jobs
+   (the array then holds no usable split: call again with a larger one). */
 int  xwq_split_gops(const uint8_t *data, size_t size, int stream, xwq_job *jobs, int max_jobs);
 /* The bytes a worker decodes for one unit: every SPS / PPS / APS NAL unit of the stream before job->offset (later ones replace earlier
    ones in the parser exactly as they would in a sequential decode), then the unit itself.  Returns the size written, 0 if cap is too small. */

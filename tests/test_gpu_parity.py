@@ -59,7 +59,9 @@ def test_gpu_fine_grained_recon_and_deblock_shims(decs):
     for bd in (8, 10):
         for is_coef in (0, 1):
             for (w, h) in ((16, 8), (4, 4), (64, 32), (2, 2)):
-                pred = rng.integers(0, 1 << bd, (h, w)).astype(np.int16)
+                # predictions outside the sample range too: without coefficients the reference clips them (xevd_recon.c:41-48), e.g. the
+                # Baseline DC of a non-square block next to an unavailable side
+                pred = rng.integers(-300, (1 << bd) + 300, (h, w)).astype(np.int16)
                 coef = rng.integers(-32768, 32768, (h, w)).astype(np.int16)
                 exp = rng.integers(0, 100, (h, w + 24)).astype(np.int16)
                 got = dec.test_recon(coef, pred, is_coef, exp, bd)

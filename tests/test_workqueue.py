@@ -3,6 +3,7 @@ a fake backend, and the cross-process ticket queue of bench.py with world_size 2
 import glob
 import os
 import socket
+import sys
 import threading
 import time
 
@@ -121,3 +122,24 @@ def test_two_ranks_draw_from_one_ticket_queue_over_gloo():
     assert res[0][2] == res[1][2] and res[0][2] > 0                # and the same max-over-ranks time
     assert sorted(res[0][4] + res[1][4]) == [5 + i for i in range(12)]   # each job decoded exactly once
     assert res[0][3] + res[1][3] == total and len(res[0][4]) > len(res[1][4])      # dynamic: the fast rank took more jobs
+
+
+def test_bench_gpus_n_spawns_n_ranks():
+    """`python bench.py --gpus 2` launched plainly (no torchrun, WORLD_SIZE unset) must run TWO ranks that share the job queue and print one
+    line with n_gpus == 2.  The decoder is tests/stub_decoder.py: this checks launcher + queue + accounting."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env["XEVD_BENCH_DECODER"] = "stub_decoder"
+    env["PYTHONPATH"] = os.path.join(root, "tests") + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "1", "--batches", "1",
+                        "--workload", "cfg2_base_1080p_8b_ippp", "--no-cpu-baseline", "--no-end-to-end"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["decoder"] == "stub_decoder"
+    assert sorted(p["rank"] for p in out["per_rank"]) == [0, 1]
+    assert sum(p["pictures"] for p in out["per_rank"]) == 2 * 12          # weak scaling: world x steps pictures, drawn from one queue

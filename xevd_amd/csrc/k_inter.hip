@@ -8,8 +8,8 @@
 //     a per-sample function of the covering CU's motion, so an SCU can be predicted independently of the CU it
 //     belongs to: every lane runs the same straight-line code whatever the CU sizes are (no size classes, no
 //     divergence on block shape), and the 16 lanes of an SCU row store 128 contiguous bytes per picture row.
-//   * the covering CU comes from a per-picture SCU -> CU owner map that k_paint (one thread per CU) writes first; the CTU's CU records, the
-//     reference table and the tap tables are staged once per workgroup in LDS, so a lane's chain is owner -> LDS -> reference samples;
+//   * the covering CU comes from a per-picture SCU -> CU owner map that the host paints in xgpu_batch_create; the reference table and the tap
+//     tables are staged once per workgroup in LDS, so a lane's chain is owner -> CU record -> reference samples;
 //   * a wave whose 32x32 tile lies inside ONE CU takes the tile path instead: window fetched once into the wave's own LDS, shared
 //     horizontal pass, vertical pass from LDS (mc_luma_tile / mc_chroma_tile below);
 //   * the 11x11 (luma) / 5x5 (chroma) reference windows are read straight from HBM/L2 with 16-byte loads at the
@@ -516,14 +516,15 @@ void launch_test_mc(xgpu_ctx *c, const int16_t *plane, int stride, int ref_x, in
 }
 
 // fn_recon's call shape (src_base/xevd_def.h:1466, xevd_recon, xevd_recon.c:35-71) on the kernels' packed residual add: rec = clip(pred + coef)
-// with the 16-bit wrap of the reference's s16 sum, or the prediction itself when the block has no coefficients.  One lane per sample pair.
+// with the 16-bit wrap of the reference's s16 sum, or the clipped prediction when the block has no coefficients.  One lane per sample pair.
 __global__ void k_test_recon(const int16_t *coef, const int16_t *pred, int is_coef, int cuw, int cuh, int16_t *rec, int s_rec, int bd)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x, pw = cuw >> 1;
     if (i >= pw * cuh) return;
     const int y = i / pw, x = (i - y * pw) * 2;
     const uint32_t p = *(const uint32_t *)(pred + y * cuw + x);
-    const uint32_t r = is_coef ? recon2(p, *(const uint32_t *)(coef + y * cuw + x), (1 << bd) - 1) : p;
+    // without coefficients the reference still clips the prediction (xevd_recon.c:41-48)
+    const uint32_t r = recon2(p, is_coef ? *(const uint32_t *)(coef + y * cuw + x) : 0u, (1 << bd) - 1);
     rec[y * s_rec + x] = (int16_t)(r & 0xFFFF); rec[y * s_rec + x + 1] = (int16_t)(r >> 16);
 }
 void launch_test_recon(xgpu_ctx *c, const int16_t *coef, const int16_t *pred, int is_coef, int cuw, int cuh, int16_t *rec, int s_rec, int bd)

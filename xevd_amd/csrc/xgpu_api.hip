@@ -726,6 +726,11 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         if (b->tree && b->tree[i]) {      // local dual tree: luma-only intra / IBC CUs, chroma-only intra CUs, only the coefficients of the planes they have
             ARGCHK(c, b->tree[i] <= 2 && (b->pred_mode[i] == XGPU_MODE_INTRA || (b->tree[i] == 1 && b->pred_mode[i] == XGPU_MODE_IBC)));
             ARGCHK(c, (b->cbf[i] & (b->tree[i] == 1 ? 6 : 1)) == 0);
+            if (b->tree[i] == 1) {        // a luma-only CU lies inside the chroma-only CU that closes its tree (checked here: nothing is allocated yet)
+                int j = i + 1;
+                while (j < n && b->tree[j] != 2) j++;
+                ARGCHK(c, j < n && b->x[j] <= b->x[i] && b->y[j] <= b->y[i] && b->x[i] + (1 << lw) <= b->x[j] + (1 << b->log2w[j]) && b->y[i] + (1 << lh) <= b->y[j] + (1 << b->log2h[j]));
+            }
         }
         if (b->pred_mode[i] == XGPU_MODE_IBC) {
             // the source block (and the chroma block at the halved vector) inside the active picture; that it is reconstructed before the CU is
@@ -885,8 +890,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
             // a luma-only CU: its left / top edge is an edge of the chroma block (the chroma-only CU that follows) only on that block's border
             int j = i + 1;
             while (j < n && b->tree[j] != 2) j++;
-            ARGCHK(c, j < n && b->x[j] <= b->x[i] && b->y[j] <= b->y[i] && b->x[i] + (1 << b->log2w[i]) <= b->x[j] + (1 << b->log2w[j]) && b->y[i] + (1 << b->log2h[i]) <= b->y[j] + (1 << b->log2h[j]));
-            if (b->x[i] != b->x[j]) r.pred_mode |= CU_NOCH_L;
+            if (b->x[i] != b->x[j]) r.pred_mode |= CU_NOCH_L;          // (containment was validated in pass 1)
             if (b->y[i] != b->y[j]) r.pred_mode |= CU_NOCH_T;
         }
         r.refi[0] = b->refi[i * 2]; r.refi[1] = b->refi[i * 2 + 1];

@@ -669,7 +669,9 @@ struct Stream {          // everything both directions share
                     if (i >= sh.rpl[l].n || i >= XGPU_MAX_REFS) return false;
                     const RefPic *hit = nullptr;
                     for (const RefPic &r : dpb) if (r.poc == poc - sh.rpl[l].ref[i]) { hit = &r; break; }
-                    if (!hit) return false;
+                    // a reference with the current picture's own POC (an RPL delta of 0, or tool_pocs repeating a poc_lsb) would put a zero POC distance
+                    // into every scaling of mmvd_motion / the temporal candidates: not a stream a conformant encoder writes - refused, not divided by
+                    if (!hit || hit->poc == poc) return false;
                     refp[l].push_back(hit);
                 }
             return true;
@@ -936,6 +938,8 @@ struct TileCoder {
         const int grp = cu.mmvd_idx >> 7, base = (cu.mmvd_idx >> 5) & 3, kk = cu.mmvd_idx & 31;
         const bool is_b = sh.type == XHOST_SLICE_B, small = (1 << (cu.log2w + cu.log2h)) <= 32;
         auto rpoc = [&](int l, int r) -> int { return (r >= 0 && r < (int)refp[l].size()) ? refp[l][(size_t)r]->poc : 0; };      // REF_SET
+        // POC distances are non-zero for the lists build_ref_lists accepts; a REF_SET miss (rpoc = 0 at POC 0) must still not trap in the parser
+        auto sdiv = [](int a, int b) -> int { return b ? a / b : 0; };
         auto scaled = [&](int w, int v, int sg) -> int { return std::min(std::max(sg * ((abs(w * v) + 16) >> 5), -32768), 32767); };
         // base_mv_t: the candidate (P slices take list 1 of candidate 0: unused), types per group
         int t[2][3] = { { cand[base].mv[0][0], cand[base].mv[0][1], cand[base].refi[0] },
@@ -954,7 +958,7 @@ struct TileCoder {
                 if (n0 == 1) { pm[1][0] = t[0][0] + 3; pm[1][1] = t[0][1]; pm[2][0] = t[0][0] - 3; pm[2][1] = t[0][1]; }
                 else {
                     for (int g = 1; g <= (n0 == 2 ? 1 : 2); g++) {
-                        const int w = ((poc - rpoc(0, pm[0][2])) << 5) / (poc - rpoc(0, pm[g][2]));
+                        const int w = sdiv((poc - rpoc(0, pm[0][2])) << 5, poc - rpoc(0, pm[g][2]));
                         pm[g][0] = scaled(w, t[0][0], 1); pm[g][1] = scaled(w, t[0][1], 1);
                     }
                     if (n0 == 2) { pm[2][0] = t[0][0] - 3; pm[2][1] = t[0][1]; }
@@ -963,14 +967,14 @@ struct TileCoder {
                 type[0] = 1; type[1] = 0; type[2] = 2;
                 const int p0 = rpoc(0, t[0][2]);
                 t[1][2] = (n1 > 1 && rpoc(1, 1) - poc == poc - p0) ? 1 : 0;
-                const int w = ((poc - rpoc(1, t[1][2])) << 5) / (poc - p0);
+                const int w = sdiv((poc - rpoc(1, t[1][2])) << 5, poc - p0);
                 t[1][0] = scaled(w, t[0][0], w * t[0][0] < 0 ? -1 : 1); t[1][1] = scaled(w, t[0][1], w * t[0][1] < 0 ? -1 : 1);
             }
         } else if (t[1][2] >= 0) {
             type[0] = 2; type[1] = 0; type[2] = 1;
             const int p1 = rpoc(1, t[1][2]);
             t[0][2] = (n0 > 1 && rpoc(0, 1) - poc == poc - p1) ? 1 : 0;
-            const int w = ((poc - rpoc(0, t[0][2])) << 5) / (poc - p1);
+            const int w = sdiv((poc - rpoc(0, t[0][2])) << 5, poc - p1);
             t[0][0] = scaled(w, t[1][0], w * t[1][0] < 0 ? -1 : 1); t[0][1] = scaled(w, t[1][1], w * t[1][1] < 0 ? -1 : 1);
         } else type[0] = type[1] = type[2] = 3;
         if (small) type[0] = 1;
@@ -985,8 +989,8 @@ struct TileCoder {
         if (r0 != -1 && r1 != -1) {
             const int p0 = rpoc(0, r0), p1 = rpoc(1, r1);
             if (is_b && (p0 - poc) * (poc - p1) > 0) sign = -1;
-            if (abs(p1 - poc) >= abs(p0 - poc)) d0 = std::min(std::max((((abs(p0 - poc) << 5) / abs(p1 - poc)) * step + 16) >> 5, -32768), 32767);
-            else d1 = std::min(std::max((((abs(p1 - poc) << 5) / abs(p0 - poc)) * step + 16) >> 5, -32768), 32767);
+            if (abs(p1 - poc) >= abs(p0 - poc)) d0 = std::min(std::max((sdiv(abs(p0 - poc) << 5, abs(p1 - poc)) * step + 16) >> 5, -32768), 32767);
+            else d1 = std::min(std::max((sdiv(abs(p1 - poc) << 5, abs(p0 - poc)) * step + 16) >> 5, -32768), 32767);
         }
         const int dir = kk & 3, s0 = (dir & 1) ? -d0 : d0, s1 = ((dir & 1) ? -d1 : d1) * sign;
         const int real[2][2] = { { b[0][0] + (dir < 2 ? s0 : 0), b[0][1] + (dir < 2 ? 0 : s0) }, { b[1][0] + (dir < 2 ? s1 : 0), b[1][1] + (dir < 2 ? 0 : s1) } };
@@ -2332,11 +2336,11 @@ struct xhost_parser {
     }
     int parse_pps(BitReader &br)
     {
+        Pps q = st.pps;                                  // parsed into a copy: a damaged PPS leaves the active one untouched (as parse_sps does)
         br.ue(); br.ue();                                // pps id, sps id
-        st.pps.default_active[0] = (int)br.ue() + 1; st.pps.default_active[1] = (int)br.ue() + 1;      // num_ref_idx_default_active_minus1
+        q.default_active[0] = (int)br.ue() + 1; q.default_active[1] = (int)br.ue() + 1;      // num_ref_idx_default_active_minus1
         br.ue();                                         // additional_lt_poc_lsb_len
-        st.pps.rpl1_idx_present = br.get1();
-        Pps &q = st.pps;
+        q.rpl1_idx_present = br.get1();
         q.tile_cols = q.tile_rows = q.tile_uniform = 1; q.across_tiles = 0;      // one tile: the flag is not sent and reads as 0
         if (!br.get1()) {                                // single_tile_in_pic_flag == 0 (xevdm_eco.c:2021-2039)
             q.tile_cols = (int)br.ue() + 1; q.tile_rows = (int)br.ue() + 1;
@@ -2353,14 +2357,15 @@ struct xhost_parser {
         q.id_bits = (int)br.ue() + 1;                    // tile_id_len_minus1
         if (q.id_bits > 15) return fail("bad PPS: tile_id_len_minus1");
         if (br.get1()) return fail("explicit tile ids are not supported");
-        st.pps.dra_on = br.get1();                       // pic_dra_enabled_flag, pic_dra_aps_id (xevdm_eco.c:2054-2060)
-        if (st.pps.dra_on) st.pps.dra_aps_id = (int)br.get(5);
+        q.dra_on = br.get1();                       // pic_dra_enabled_flag, pic_dra_aps_id (xevdm_eco.c:2054-2060)
+        if (q.dra_on) q.dra_aps_id = (int)br.get(5);
         q.arbitrary_slices = br.get1();                  // arbitrary_slice_present_flag
-        st.pps.constrained_intra = br.get1();
-        st.pps.cu_qp_delta = br.get1();
-        st.pps.qp_delta_area = 6;
-        if (st.pps.cu_qp_delta) { st.pps.qp_delta_area = (int)br.ue() + 6; if (st.pps.qp_delta_area > 14) return fail("bad PPS: cu_qp_delta_area"); }
+        q.constrained_intra = br.get1();
+        q.cu_qp_delta = br.get1();
+        q.qp_delta_area = 6;
+        if (q.cu_qp_delta) { q.qp_delta_area = (int)br.ue() + 6; if (q.qp_delta_area > 14) return fail("bad PPS: cu_qp_delta_area"); }
         if (br.overrun) return fail("bad PPS");
+        st.pps = q;
         st.have_pps = true;
         return XGPU_OK;
     }

@@ -92,7 +92,7 @@ int xwq_split_gops(const uint8_t *data, size_t size, int stream, xwq_job *jobs, 
         if (len < 2 || pos + 4 + len > size) return -202;
         const int t = nal_type(data + pos + 4);
         if (t == NUT_IDR) {
-            if (n == max_jobs) return n;
+            if (n == max_jobs) return -203;          // more units than the caller's array holds: nothing is dropped silently - grow and call again
             if (n) jobs[n - 1].size = pos - jobs[n - 1].offset;
             memset(&jobs[n], 0, sizeof(jobs[n]));
             jobs[n].stream = stream; jobs[n].unit = n; jobs[n].offset = pos; jobs[n].first_picture = pictures;

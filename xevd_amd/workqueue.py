@@ -43,8 +43,12 @@ def lib():
 
 def split_gops(data, stream=0, max_jobs=4096):
     """closed GOPs (IDR to IDR) of a length-prefixed EVC stream -> list of Job"""
-    jobs = (Job * max_jobs)()
-    n = lib().xwq_split_gops(data, len(data), stream, jobs, max_jobs)
+    while True:
+        jobs = (Job * max_jobs)()
+        n = lib().xwq_split_gops(data, len(data), stream, jobs, max_jobs)
+        if n != -203:
+            break
+        max_jobs *= 4              # more closed GOPs than the array held
     if n < 0:
         raise ValueError(f"damaged NAL length prefix ({n})")
     return [Job.from_buffer_copy(bytes(jobs[i])) for i in range(n)]
