@@ -53,7 +53,7 @@ GOP_PICTURES = 8            # pictures per job of the multi-GPU work queue (one 
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def algorithmic_bytes(batch, w, h):
+def algorithmic_bytes(batch, w, h, addb=False):
     """SURVEY 8(d) per-sample byte counts applied to the actual batch (2 B/sample, halo re-reads not credited)."""
     cw = (1 << batch["log2w"].astype(np.int64))
     ch = (1 << batch["log2h"].astype(np.int64))
@@ -67,7 +67,9 @@ def algorithmic_bytes(batch, w, h):
     b_itdq = int(4 * coded.sum())
     b_intra = int((2 * samples[~inter]).sum() + 2 * coded[~inter].sum())
     s_pic = w * h * 3 // 2
-    return {"inter": b_inter, "itdq": b_itdq, "intra": b_intra, "dbk_v": 4 * s_pic, "dbk_h": 4 * s_pic, "alf": 4 * s_pic}
+    # deblocking: SURVEY 8(d) prices two passes of 4 B/sample.  ADDB runs as ONE fused kernel (k_addb_fused: one read + one write), timed as
+    # "dbk_v" - it is credited with the 4 B/sample it has to move, not with the second pass it no longer makes
+    return {"inter": b_inter, "itdq": b_itdq, "intra": b_intra, "dbk_v": 4 * s_pic, "dbk_h": 0 if addb else 4 * s_pic, "alf": 4 * s_pic}
 
 
 def make_stream(wl, seed, n_batches):
@@ -455,7 +457,7 @@ def main():
         e2e["fps"] = round(world * 1e3 / float(t.item()), 2)
 
     if rank == 0:
-        ab = [algorithmic_bytes(b, wl["w"], wl["h"]) for b in batches]
+        ab = [algorithmic_bytes(b, wl["w"], wl["h"], bool(wl["addb"])) for b in batches]
         kernels = {}
         for name in ("itdq", "inter", "dmvr", "affine", "intra", "dbk_v", "dbk_h", "alf", "pad"):
             ms, n = tim[name]
@@ -502,7 +504,10 @@ def main():
                          "frac_of_measured_copy_bw": None if not copy_bw else round(achieved / copy_bw, 4)},
             "kernels": kernels,
             "whole_frame": {"algorithmic_bytes": int(total_alg), "kernel_us": round(kern_s * 1e6, 2),
-                            "achieved_gbps": round(total_alg / kern_s / 1e9, 1)},
+                            "achieved_gbps": round(total_alg / kern_s / 1e9, 1),
+                            # the same kernel time against SURVEY 8(d)'s own accounting (deblocking as two passes of 4 B/sample), for comparison across rounds
+                            "algorithmic_bytes_survey_two_pass_deblock": int(total_alg + (4 * wl["w"] * wl["h"] * 3 // 2 if wl["addb"] else 0)),
+                            "achieved_gbps_survey_accounting": round((total_alg + (4 * wl["w"] * wl["h"] * 3 // 2 if wl["addb"] else 0)) / kern_s / 1e9, 1)},
             # `value` above is the rate with the CU batches resident in HBM (the benchmark contract's definition); the rate of the whole
             # span host batches -> host YUV, transfers and the host batch builder inside the timed region, is end_to_end_fps
             "per_rank": per_rank,

@@ -6,13 +6,11 @@
 // average of both sides; alpha/beta/clip tables indexed through get_index()'s u8 arguments; luma strong (bS 4)
 // and normal filters over 3 samples per side, chroma over 1; all vertical edges before all horizontal ones.
 //
-// MI355X mapping - order-free and out of place like the baseline filter (k_deblock.hip): each pass reads SRC and writes
-// DST.  Grid edges are 8 samples apart and touch 3 samples per side, so edges never interact and the 8-sample windows
-// centred on the grid lines tile the picture: one LANE per 4-sample edge SEGMENT owns the SCU on either side (P = left /
-// above, Q = right / below), loads the aligned 8x4 (4x8) luma and 4x2 (2x4) chroma windows once, filters and writes both
-// halves - every sample is read once and written once, no filter is evaluated twice.  The columns (rows) of SCUs next to
-// the picture border belong to "edges" 0 and w_scu (h_scu), which only copy their inner half.  All loads (two SCU
-// records, luma and chroma windows) are issued before any decision; decisions are lane-local integer tests, tables in LDS.
+// MI355X mapping - out of place (SRC -> DST) and order-free: grid edges are 8 samples apart and touch 3 samples per side, so edges never interact and
+// the 8-sample windows centred on the grid lines tile the picture in both directions: one LANE per 4-sample edge SEGMENT owns the SCU on either side
+// (P = left / above, Q = right / below), filters once and writes both halves - every sample is read once and written once, no filter is evaluated
+// twice.  Both edge directions run in ONE kernel (k_addb_fused below; round 2 had a kernel per direction: two reads and two writes of the picture).
+// All loads are issued before any decision; decisions are lane-local integer tests, tables in LDS.
 #include "xgpu_internal.h"
 
 struct __attribute__((packed, aligned(8))) U32x4a8 { uint32_t a, b, c, d; };
@@ -106,122 +104,159 @@ __device__ __forceinline__ void addb_line_chroma(int s[4], int bs, int alpha, in
 
 __device__ __forceinline__ int addb_index(int qp, int offset) { return clip3a(0, 51, (qp & 0xFF) + (offset & 0xFF)); }   // u8 arguments
 
+// The decisions and filters of one 4-sample edge segment (deblock_addb_cu_hor :893-944 / deblock_addb_cu_ver_yuv :947-1034): rq / rp = the SCU records
+// after / before the grid line, eq = the Q side's SCU position along the filtered axis, L / Cc = the windows (filtered in place).
 template <int DIR>
-__global__ __launch_bounds__(256) void k_addb(const AddbArgs a, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
-                                              const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_,
-                                              int16_t *__restrict__ dv_)
+__device__ __forceinline__ void addb_edge(const AddbArgs &a, const uint4 rq, const uint4 rp, int eq, int L[4][8], int Cc[2][2][4],
+                                          const uint8_t *s_alpha, const uint8_t *s_beta, const uint8_t *s_clip, const int8_t *s_cqp, const uint8_t *s_pic)
+{
+    const uint32_t eflag = DIR == 0 ? SCU_EDGE_L : SCU_EDGE_T;
+    const uint32_t nflag = DIR == 0 ? SCU_NOCH_L : SCU_NOCH_T;      // a luma CU's edge inside the chroma block of a local dual tree: luma only (xevdm_df.c:916-920, 986-997)
+    const int maxl = (1 << a.bd_l) - 1, maxc = (1 << a.bd_c) - 1;
+    // an edge on a tile border stays as it is unless the PPS filters across tiles (no_boundary, src_main/xevdm_df.c:877, 1088, 1106)
+    const int ctu_sh = a.log2_ctu - 2;
+    const bool tile_edge = (eq & ((1 << ctu_sh) - 1)) == 0 && (DIR == 0 ? a.no_filter.col_start((eq >> ctu_sh) & 255) : a.no_filter.row_start((eq >> ctu_sh) & 255));
+    if (!(rq.x & eflag) || tile_edge) return;
+    const int epos = eq << 2;
+    const bool cross = (epos & ((1 << a.log2_ctu) - 1)) == 0;
+    const int bs = addb_bs(rq, rp, cross, s_pic);
+    const int qp = (((rq.x >> 16) & 0x7F) + ((rp.x >> 16) & 0x7F) + 1) >> 1;
+    const int scale = a.bd_l - 8;
+    {
+        const int ia = addb_index(qp, a.alpha_off), ib = addb_index(qp, a.beta_off);
+        const int alpha = s_alpha[ia] << scale, beta = (s_beta[ib] << scale) & 0xFF;
+        const int c1 = (s_clip[ia * 5 + bs] << max(0, a.bd_l - 9)) & 0xFF;
+#pragma unroll
+        for (int r = 0; r < 4; r++) addb_line_luma(L[r], bs, alpha, beta, c1, a.bd_l, maxl);
+    }
+    const int boff = 6 * (a.bd_c - 8);
+    if (!(rq.x & nflag))
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++) {
+        const int q = clip3a(-boff, 57, qp + (pl ? a.qp_v_off : a.qp_u_off));
+        const int qc = s_cqp[pl * 96 + q + boff];
+        const int ia = addb_index(qc, a.alpha_off), ib = addb_index(qc, a.beta_off);
+        const int alpha = s_alpha[ia] << scale, beta = (s_beta[ib] << scale) & 0xFF;      // luma depth scales chroma too (:926-927)
+        const int c0 = ((s_clip[ia * 5 + bs] + 1) << max(0, a.bd_c - 9)) & 0xFF;
+#pragma unroll
+        for (int r = 0; r < 2; r++) addb_line_chroma(Cc[pl][r], bs, alpha, beta, c0, maxc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_addb_fused - both edge directions in ONE kernel: one read and one write of the picture instead of two of each.
+//
+// Grid edges are 8 samples apart and a filter touches at most 4 samples on either side (3 written), so the 8-sample windows centred on the grid lines
+// tile the picture in BOTH directions.  A workgroup therefore owns the tile [X0 - 4, X0 + 252) x [Y0 - 4, Y0 + 28) - shifted by half a window against
+// the 8x8 grid - which holds 32 x 8 complete vertical-edge windows (8 samples x 4 rows) and, at the same time, 64 x 4 complete horizontal-edge windows
+// (4 samples x 8 rows): no halo in either direction, nothing is read or filtered twice.
+//   phase V: lane = one vertical-edge segment: SCU records + its luma / chroma windows from HBM (a wave's loads are two 512-byte runs per
+//            row), filter, windows -> LDS, the two SCU records -> LDS (the horizontal phase needs the same 64 x 8 records);
+//   barrier;
+//   phase H: lane = one horizontal-edge segment: windows and records from LDS, filter, stores to DST (512-byte runs per row).
+// All vertical edges of the picture before all horizontal ones (xevdm_deblock, src_main/xevdm.c:2048-2103) holds per sample: a horizontal filter reads
+// only its own window, which phase V of the same workgroup has completed.
+// ---------------------------------------------------------------------------------------------------------
+#define AF_LS 264                 // LDS luma row stride in samples: 256 + 8 (rows 4 apart land 16 banks apart; rows stay 16-byte aligned)
+#define AF_CS 136                 // chroma: 128 + 8
+__global__ __launch_bounds__(256) void k_addb_fused(const AddbArgs a, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
+                                                    const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_,
+                                                    int16_t *__restrict__ dv_, int tiles_x)
 {
     __shared__ uint8_t s_alpha[52], s_beta[52], s_clip[52 * 5], s_pic[XGPU_MAX_REFS * 2];
     __shared__ int8_t s_cqp[2 * 96];
-    for (int i = threadIdx.x; i < 52; i += 256) { s_alpha[i] = k_alpha[i]; s_beta[i] = k_beta[i]; }
-    for (int i = threadIdx.x; i < 260; i += 256) s_clip[i] = ((const uint8_t *)k_clip)[i];
-    for (int i = threadIdx.x; i < XGPU_MAX_REFS * 2; i += 256) s_pic[i] = a.pic_id[i];
-    for (int i = threadIdx.x; i < 192; i += 256) s_cqp[i] = a.chroma_qp[i];
-    __syncthreads();
-
-    // lane -> edge segment: along the filtered axis the lane index counts grid lines (every second SCU position), across it SCUs
-    const int n_ex = DIR == 0 ? (a.w_scu >> 1) + 1 : a.w_scu, n_ey = DIR == 0 ? a.h_scu : (a.h_scu >> 1) + 1;
-    // a wave = 64 neighbouring segments of one grid row: its loads and stores are 512-byte to 1-KB runs of a picture row (a 16 x 16 lane
-    // tile made them 128-byte pieces of 16 rows: 17 % slower at 8K)
-    const int tiles_x = (n_ex + 63) >> 6;
+    __shared__ __attribute__((aligned(16))) int16_t s_y[32 * AF_LS];
+    __shared__ __attribute__((aligned(16))) int16_t s_c[2][16 * AF_CS];
+    __shared__ uint4 s_map[8][64];
+    const int t = threadIdx.x;
+    for (int i = t; i < 52; i += 256) { s_alpha[i] = k_alpha[i]; s_beta[i] = k_beta[i]; }
+    for (int i = t; i < 260; i += 256) s_clip[i] = ((const uint8_t *)k_clip)[i];
+    for (int i = t; i < XGPU_MAX_REFS * 2; i += 256) s_pic[i] = a.pic_id[i];
+    for (int i = t; i < 192; i += 256) s_cqp[i] = a.chroma_qp[i];
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
-    const int ex = (tx << 6) + (threadIdx.x & 63), ey = (ty << 2) + (threadIdx.x >> 6);
-    if (ex >= n_ex || ey >= n_ey) return;
-    const int sx = DIR == 0 ? ex << 1 : ex, sy = DIR == 0 ? ey : ey << 1;                 // the Q-side SCU (may lie one past the picture)
-    const int step = DIR == 0 ? 1 : a.w_scu;
-    const int eq = DIR == 0 ? sx : sy, npos = DIR == 0 ? a.w_scu : a.h_scu;
-    const uint32_t eflag = DIR == 0 ? SCU_EDGE_L : SCU_EDGE_T;
-    const uint32_t nflag = DIR == 0 ? SCU_NOCH_L : SCU_NOCH_T;      // a luma CU's edge inside the chroma block of a local dual tree: luma only (xevdm_df.c:916-920, 986-997)
-    const uint4 *maps = (const uint4 *)a.maps;
-    const bool has_p = eq > 0, has_q = eq < npos, in_range = has_p && has_q;
-    const int kq = in_range ? sy * a.w_scu + sx : 0, kp = in_range ? kq - step : 0;
-    const int maxl = (1 << a.bd_l) - 1, maxc = (1 << a.bd_c) - 1;
+    const int n_ex = (a.w_scu >> 1) + 1, n_ey = (a.h_scu >> 1) + 1;     // grid lines incl. the picture borders (which only copy their inner half)
+#define PK2(lo, hi) ((uint32_t)(uint16_t)(lo) | ((uint32_t)(uint16_t)(hi) << 16))
 
-    // ---- all loads first ----
-    const uint4 rq = maps[kq], rp = maps[kp];
-    const int x = sx << 2, y = sy << 2, cx = sx << 1, cy = sy << 1;
-    const int xe = x, ye = y;                          // luma position of the edge segment (Q side origin)
-    int L[4][8];          // 4 lines x (p3 p2 p1 p0 q0 q1 q2 q3)
-    int Cc[2][2][4];      // [plane][line][p1 p0 q0 q1]
-    if (DIR == 0) {
+    // ---------------------------------------------------------------- phase V: vertical edges
+    {
+        const int wx = t & 31, sr = t >> 5;                  // window along x, SCU row of the tile
+        const int ex = (tx << 5) + wx;                       // grid line x = 8 * ex
+        const int srow = (ty << 3) - 1 + sr;                 // SCU row in the picture
+        const int sxq = ex << 1;                             // the Q-side SCU column
+        const bool ok = ex < n_ex && srow >= 0 && srow < a.h_scu;
+        const bool has_p = ok && ex > 0, has_q = ok && sxq < a.w_scu;
+        const uint4 *maps = (const uint4 *)a.maps;
+        uint4 rq = make_uint4(0, 0, 0, 0), rp = rq;
+        int L[4][8], Cc[2][2][4];
+        if (ok) {
+            const int kq = srow * a.w_scu + sxq;
+            if (has_q) rq = maps[kq];
+            if (has_p) rp = maps[kq - 1];
+            const int x = sxq << 2, y = srow << 2, cy = srow << 1;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const U32x4a8 v = *(const U32x4a8 *)(sy_ + (y + r) * a.s_l + xe - 4);
-            L[r][0] = (int16_t)(v.a & 0xFFFF); L[r][1] = (int16_t)(v.a >> 16); L[r][2] = (int16_t)(v.b & 0xFFFF); L[r][3] = (int16_t)(v.b >> 16);
-            L[r][4] = (int16_t)(v.c & 0xFFFF); L[r][5] = (int16_t)(v.c >> 16); L[r][6] = (int16_t)(v.d & 0xFFFF); L[r][7] = (int16_t)(v.d >> 16);
+            for (int r = 0; r < 4; r++) {
+                const U32x4a8 v = *(const U32x4a8 *)(sy_ + (y + r) * a.s_l + x - 4);
+                L[r][0] = (int16_t)(v.a & 0xFFFF); L[r][1] = (int16_t)(v.a >> 16); L[r][2] = (int16_t)(v.b & 0xFFFF); L[r][3] = (int16_t)(v.b >> 16);
+                L[r][4] = (int16_t)(v.c & 0xFFFF); L[r][5] = (int16_t)(v.c >> 16); L[r][6] = (int16_t)(v.d & 0xFFFF); L[r][7] = (int16_t)(v.d >> 16);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const U32x2a4 v = *(const U32x2a4 *)((pl ? sv_ : su_) + (cy + r) * a.s_c + (x >> 1) - 2);
+                    Cc[pl][r][0] = (int16_t)(v.a & 0xFFFF); Cc[pl][r][1] = (int16_t)(v.a >> 16);
+                    Cc[pl][r][2] = (int16_t)(v.b & 0xFFFF); Cc[pl][r][3] = (int16_t)(v.b >> 16);
+                }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int k = 0; k < 8; k++) L[r][k] = 0;
+#pragma unroll
+            for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) Cc[pl][r][k] = 0;
         }
+        __syncthreads();                                     // the tables (the loads above are in flight across it)
+        if (has_p && has_q) addb_edge<0>(a, rq, rp, sxq, L, Cc, s_alpha, s_beta, s_clip, s_cqp, s_pic);
+        s_map[sr][2 * wx] = rp; s_map[sr][2 * wx + 1] = rq;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            *(uint4 *)(s_y + (4 * sr + r) * AF_LS + 8 * wx) = make_uint4(PK2(L[r][0], L[r][1]), PK2(L[r][2], L[r][3]), PK2(L[r][4], L[r][5]), PK2(L[r][6], L[r][7]));
 #pragma unroll
         for (int pl = 0; pl < 2; pl++)
 #pragma unroll
-            for (int r = 0; r < 2; r++) {
-                const U32x2a4 v = *(const U32x2a4 *)((pl ? sv_ : su_) + (cy + r) * a.s_c + (xe >> 1) - 2);
-                Cc[pl][r][0] = (int16_t)(v.a & 0xFFFF); Cc[pl][r][1] = (int16_t)(v.a >> 16);
-                Cc[pl][r][2] = (int16_t)(v.b & 0xFFFF); Cc[pl][r][3] = (int16_t)(v.b >> 16);
-            }
-    } else {
+            for (int r = 0; r < 2; r++)
+                *(uint2 *)(s_c[pl] + (2 * sr + r) * AF_CS + 4 * wx) = make_uint2(PK2(Cc[pl][r][0], Cc[pl][r][1]), PK2(Cc[pl][r][2], Cc[pl][r][3]));
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- phase H: horizontal edges
+    {
+        const int sx = t & 63, g = t >> 6;                   // SCU column of the tile, grid line of the tile
+        const int scol = (tx << 6) - 1 + sx;                 // SCU column in the picture
+        const int ey = (ty << 2) + g;                        // grid line y = 8 * ey
+        if (scol < 0 || scol >= a.w_scu || ey >= n_ey) return;
+        const int syq = ey << 1;                             // the Q-side SCU row
+        const bool has_p = ey > 0, has_q = syq < a.h_scu;
+        const uint4 rq = s_map[2 * g + 1][sx], rp = s_map[2 * g][sx];
+        int L[4][8], Cc[2][2][4];
 #pragma unroll
         for (int r = 0; r < 8; r++) {
-            const uint2 v = *(const uint2 *)(sy_ + (ye - 4 + r) * a.s_l + x);
+            const uint2 v = *(const uint2 *)(s_y + (8 * g + r) * AF_LS + 4 * sx);
             L[0][r] = (int16_t)(v.x & 0xFFFF); L[1][r] = (int16_t)(v.x >> 16); L[2][r] = (int16_t)(v.y & 0xFFFF); L[3][r] = (int16_t)(v.y >> 16);
         }
 #pragma unroll
         for (int pl = 0; pl < 2; pl++)
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint32_t v = *(const uint32_t *)((pl ? sv_ : su_) + ((ye >> 1) - 2 + r) * a.s_c + cx);
+                const uint32_t v = *(const uint32_t *)(s_c[pl] + (4 * g + r) * AF_CS + 2 * sx);
                 Cc[pl][0][r] = (int16_t)(v & 0xFFFF); Cc[pl][1][r] = (int16_t)(v >> 16);
             }
-    }
-
-    // ---- decisions (deblock_addb_cu_hor :893-944 / deblock_addb_cu_ver_yuv :947-1034) ----
-    // an edge on a tile border stays as it is unless the PPS filters across tiles (no_boundary, src_main/xevdm_df.c:877, 1088, 1106)
-    const int ctu_sh = a.log2_ctu - 2;
-    const bool tile_edge = (eq & ((1 << ctu_sh) - 1)) == 0 && (DIR == 0 ? a.no_filter.col_start((eq >> ctu_sh) & 255) : a.no_filter.row_start((eq >> ctu_sh) & 255));
-    if (in_range && (rq.x & eflag) && !tile_edge) {
-        const int epos = eq << 2;
-        const bool cross = (epos & ((1 << a.log2_ctu) - 1)) == 0;
-        const int bs = addb_bs(rq, rp, cross, s_pic);
-        const int qp = (((rq.x >> 16) & 0x7F) + ((rp.x >> 16) & 0x7F) + 1) >> 1;
-        const int scale = a.bd_l - 8;
-        {
-            const int ia = addb_index(qp, a.alpha_off), ib = addb_index(qp, a.beta_off);
-            const int alpha = s_alpha[ia] << scale, beta = (s_beta[ib] << scale) & 0xFF;
-            const int c1 = (s_clip[ia * 5 + bs] << max(0, a.bd_l - 9)) & 0xFF;
-#pragma unroll
-            for (int r = 0; r < 4; r++) addb_line_luma(L[r], bs, alpha, beta, c1, a.bd_l, maxl);
-        }
-        const int boff = 6 * (a.bd_c - 8);
-        if (!(rq.x & nflag))
-#pragma unroll
-        for (int pl = 0; pl < 2; pl++) {
-            const int q = clip3a(-boff, 57, qp + (pl ? a.qp_v_off : a.qp_u_off));
-            const int qc = s_cqp[pl * 96 + q + boff];
-            const int ia = addb_index(qc, a.alpha_off), ib = addb_index(qc, a.beta_off);
-            const int alpha = s_alpha[ia] << scale, beta = (s_beta[ib] << scale) & 0xFF;      // luma depth scales chroma too (:926-927)
-            const int c0 = ((s_clip[ia * 5 + bs] + 1) << max(0, a.bd_c - 9)) & 0xFF;
-#pragma unroll
-            for (int r = 0; r < 2; r++) addb_line_chroma(Cc[pl][r], bs, alpha, beta, c0, maxc);
-        }
-    }
-
-    // ---- both halves of the window: P (the SCU before the grid line) and Q, each if inside the picture ----
-#define PK2(lo, hi) ((uint32_t)(uint16_t)(lo) | ((uint32_t)(uint16_t)(hi) << 16))
-    if (DIR == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-            int16_t *d = dy_ + (y + r) * a.s_l + x;
-            if (has_p) *(uint2 *)(d - 4) = make_uint2(PK2(L[r][0], L[r][1]), PK2(L[r][2], L[r][3]));
-            if (has_q) *(uint2 *)d = make_uint2(PK2(L[r][4], L[r][5]), PK2(L[r][6], L[r][7]));
-        }
-#pragma unroll
-        for (int pl = 0; pl < 2; pl++)
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                int16_t *d = (pl ? dv_ : du_) + (cy + r) * a.s_c + cx;
-                if (has_p) *(uint32_t *)(d - 2) = PK2(Cc[pl][r][0], Cc[pl][r][1]);
-                if (has_q) *(uint32_t *)d = PK2(Cc[pl][r][2], Cc[pl][r][3]);
-            }
-    } else {
+        if (has_p && has_q) addb_edge<1>(a, rq, rp, syq, L, Cc, s_alpha, s_beta, s_clip, s_cqp, s_pic);
+        const int x = scol << 2, y = syq << 2, cx = scol << 1, cy = syq << 1;
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             if (r < 4 ? !has_p : !has_q) continue;
@@ -238,12 +273,10 @@ __global__ __launch_bounds__(256) void k_addb(const AddbArgs a, const int16_t *_
 #undef PK2
 }
 
-void launch_addb(xgpu_ctx *c, const AddbArgs &a, int dir, const DevPic &src, const DevPic &dst)
+void launch_addb_fused(xgpu_ctx *c, const AddbArgs &a, const DevPic &src, const DevPic &dst)
 {
-    const int n_ex = dir == 0 ? (a.w_scu >> 1) + 1 : a.w_scu, n_ey = dir == 0 ? a.h_scu : (a.h_scu >> 1) + 1;
-    const int tiles = ((n_ex + 63) >> 6) * ((n_ey + 3) >> 2);
-    if (dir == 0)
-        hipLaunchKernelGGL(k_addb<0>, dim3(tiles), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
-    else
-        hipLaunchKernelGGL(k_addb<1>, dim3(tiles), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
+    const int n_ex = (a.w_scu >> 1) + 1, n_ey = (a.h_scu >> 1) + 1;
+    const int tiles_x = (n_ex + 31) >> 5, tiles_y = (n_ey + 3) >> 2;
+    hipLaunchKernelGGL(k_addb_fused, dim3(tiles_x * tiles_y), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v, tiles_x);
 }
+

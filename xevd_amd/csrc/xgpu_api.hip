@@ -991,9 +991,9 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
 
     InterArgs a;
     memset(&a, 0, sizeof(a));
-    // out-of-place filter chain: 2 passes of deblocking + 1 of ALF must end in the DPB slot -> start in the scratch
-    // picture when the number of passes is odd
-    c->where = (2 * (c->fp.deblock_on ? 1 : 0) + (c->fp.alf_on ? 1 : 0)) & 1;
+    // out-of-place filter chain: the deblocking passes (ADDB: one fused kernel; baseline filter: two) + one of ALF must end in the DPB slot ->
+    // start in the scratch picture when the number of passes is odd
+    c->where = ((c->fp.deblock_on ? (c->sp.tool_addb ? 1 : 2) : 0) + (c->fp.alf_on ? 1 : 0)) & 1;
     DevPic &cur = c->where ? c->pics[0] : dpic(c, c->fp.pic);
     a.cur_y = cur.y; a.cur_u = cur.u; a.cur_v = cur.v;
     a.s_l = c->s_l; a.s_c = c->s_c; a.pic_w = c->sp.width; a.pic_h = c->sp.height;
@@ -1084,8 +1084,8 @@ int xgpu_deblock(xgpu_ctx *c)
         memcpy(a.chroma_qp, c->chroma_qp, sizeof(a.chroma_qp));
         for (int l = 0; l < 2; l++)
             for (int i = 0; i < XGPU_MAX_REFS; i++) a.pic_id[i * 2 + l] = i < c->fp.num_refp[l] ? (uint8_t)c->fp.refp_pic[i][l] : 255;
-        TIMED(c, XGPU_K_DBK_V, launch_addb(c, a, 0, first, second));
-        TIMED(c, XGPU_K_DBK_H, launch_addb(c, a, 1, second, first));
+        TIMED(c, XGPU_K_DBK_V, launch_addb_fused(c, a, first, second));      // both edge directions: one read + one write of the picture (timed as "dbk_v")
+        c->where ^= 1;
     } else {
         DbkArgs a;
         memset(&a, 0, sizeof(a));

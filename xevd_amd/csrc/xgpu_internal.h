@@ -312,7 +312,7 @@ void launch_dmvr(xgpu_ctx *c, const DmvrArgs &a);
 void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst);
 void upload_transform_tables(const int *tm, const int16_t *ats, hipStream_t s);
 int  itdq_group_size(int log2w, int log2h);     // TBs of one size class per 256-thread work item
-void launch_addb(xgpu_ctx *c, const AddbArgs &a, int dir, const DevPic &src, const DevPic &dst);
+void launch_addb_fused(xgpu_ctx *c, const AddbArgs &a, const DevPic &src, const DevPic &dst);      // both passes, one read + one write of the picture
 void launch_alf(xgpu_ctx *c, const AlfArgs &a, const DevPic &src, const DevPic &dst);
 void launch_pad(xgpu_ctx *c, const DevPic &p);
 void launch_copy_bw(xgpu_ctx *c, const void *src, void *dst, size_t bytes);
