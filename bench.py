@@ -368,6 +368,7 @@ def main():
     handles = [dec.batch_create(b) for b in batches]
     dec.sync()
     t_up = (time.perf_counter() - t_up) / len(batches)
+    batch_info = dec.batch_info(handles[0])
 
     two_lists = wl["n_refs"][1] > 0
 
@@ -494,7 +495,7 @@ def main():
                        "profile": "Main (admvp 8-tap MC, IQT, ADDB, ALF on every CTU)" if wl["addb"] else "Baseline",
                        "stream": ("2 reference lists, 50% bi-predicted CUs" if two_lists else "IPPP, 1 reference")
                                  + ", 90% inter / 10% intra CUs (5 Baseline modes), 60% coded, deblock on, quad-tree 64..4",
-                       "batches_resident": len(batches),
+                       "batches_resident": len(batches), "batch": batch_info,
                        "parallelism": (f"{world} ranks, one GPU each, drawing jobs of {GOP_PICTURES} pictures (closed GOPs of independent streams) from one host work "
                                        "queue; no collective on the data path" if world > 1 else "1 stream on 1 GPU")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

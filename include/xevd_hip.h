@@ -237,6 +237,11 @@ int  xgpu_batch_wait_upload(xgpu_ctx *ctx, xgpu_dbatch *db);
    sub-blocks in raster order - mv[list][x/y] in quarter samples: refined where the refinement ran, the CU's own otherwise.  `n` = capacity of
    `mv` in sub-blocks; returns the number of sub-blocks (also with mv = NULL), or a negative error.  Blocking.                                 */
 int  xgpu_batch_dmvr_mvs(xgpu_ctx *ctx, xgpu_dbatch *db, int16_t *mv, int n);
+/* what the batch builder made of the batch (measurement / diagnostics): info[0] CUs, [1] transform blocks, [2] work items of the transform kernel,
+   [3] nodes of the order-dependent kernel (intra / IBC CUs, HTDF nodes), [4] of them without a node among their neighbours, [5] depth of the
+   dependency graph (levels), [6] DMVR sub-blocks, [7] affine tiles.                                                                            */
+#define XGPU_BATCH_INFO_COUNT 8
+int  xgpu_batch_info(xgpu_ctx *ctx, const xgpu_dbatch *db, int info[XGPU_BATCH_INFO_COUNT]);
 /* returns the batch's blocks to the pool.  Does not wait for the device: it may follow xgpu_batch_recon immediately (kernels already
    queued keep their data - later batches of this context are written through the same HIP stream, behind them). */
 void xgpu_batch_destroy(xgpu_ctx *ctx, xgpu_dbatch *db);

@@ -96,7 +96,26 @@ __device__ __forceinline__ v2s vabs(v2s x) { const v2s z = {0, 0}; const v2s n =
 // D = S0.i16 * S1.i16 + S2.i32 on the low / high half of a packed pair: two neighbouring output samples share every packed pair sum
 __device__ __forceinline__ int mad_lo(uint32_t ps, int f, int acc) { int r; asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(ps), "v"(f), "v"(acc)); return r; }
 __device__ __forceinline__ int mad_hi(uint32_t ps, int f, int acc) { int r; asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(ps), "v"(f), "v"(acc)); return r; }
-__device__ __forceinline__ int hsum(v2s x, int acc) { const v2s one = {1, 1}; return __builtin_amdgcn_sdot2(x, one, acc, false); }
+typedef unsigned short v2us __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t padd(uint32_t x, uint32_t y) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2us, x) + __builtin_bit_cast(v2us, y)); }
+// (x.lo + y.hi, x.hi + y.lo): the pair sums of two horizontally adjacent taps of ONE output - their mirrored samples sit in a packed pair in reverse order
+__device__ __forceinline__ uint32_t padd_x(uint32_t x, uint32_t y) { uint32_t r; asm("v_pk_add_u16 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v"(r) : "v"(x), "v"(y)); return r; }
+__device__ __forceinline__ uint32_t pack_f(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
+__device__ __forceinline__ int dot2s(uint32_t f, uint32_t x, int acc) { return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, f), __builtin_bit_cast(v2s, x), acc, false); }
+// |Laplacian| of two neighbouring positions in four directions, accumulated: |2c - a - b| = |2c - (a + b)| on packed u16 pairs is one v_pk_add_u16 and one
+// v_sad_u16 (sum of the two absolute differences + accumulator) per direction.  up / mid / dn: three dwords of the rows above, at and below the pair
+// (the pair itself = dword 1; dwords 0 / 2 supply its left / right neighbours).  acc = V, H, D0, D1 (alf_derive_classification_blk :83-86)
+__device__ __forceinline__ void lap_pair(const uint32_t up[3], const uint32_t mid[3], const uint32_t dn[3], uint32_t acc[4])
+{
+    const uint32_t c2 = padd(mid[1], mid[1]);
+    const uint32_t l0 = __builtin_amdgcn_alignbit(mid[1], mid[0], 16), r0 = __builtin_amdgcn_alignbit(mid[2], mid[1], 16);
+    const uint32_t lu = __builtin_amdgcn_alignbit(up[1], up[0], 16), ru = __builtin_amdgcn_alignbit(up[2], up[1], 16);
+    const uint32_t ld = __builtin_amdgcn_alignbit(dn[1], dn[0], 16), rd = __builtin_amdgcn_alignbit(dn[2], dn[1], 16);
+    acc[0] = __builtin_amdgcn_sad_u16(c2, padd(up[1], dn[1]), acc[0]);
+    acc[1] = __builtin_amdgcn_sad_u16(c2, padd(l0, r0), acc[1]);
+    acc[2] = __builtin_amdgcn_sad_u16(c2, padd(lu, rd), acc[2]);
+    acc[3] = __builtin_amdgcn_sad_u16(c2, padd(ld, ru), acc[3]);
+}
 
 __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
                                              const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_,
@@ -167,44 +186,30 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
         // is then 16 sub-block sums (phase 2).  Packed-s16 arithmetic; a sub-block sum is at most 4 * 2 * (2^bd - 1): fits u16 up to 12 bit.
 #pragma unroll
         for (int sr = 0; sr < 2; sr++) {
-            int acc[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+            uint32_t acc[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
 #pragma unroll
             for (int rr = 0; rr < 2; rr++) {
                 const int i = 3 + sr * 2 + rr;
 #pragma unroll
-                for (int sc = 0; sc < 2; sc++) {
-                    const int d = 2 + sc;
-                    const v2s c2 = asv(W[i][d]) + asv(W[i][d]);
-                    const v2s up = asv(W[i - 1][d]), dn = asv(W[i + 1][d]);
-                    const v2s l0 = asv(__builtin_amdgcn_alignbit(W[i][d], W[i][d - 1], 16)), r0 = asv(__builtin_amdgcn_alignbit(W[i][d + 1], W[i][d], 16));
-                    const v2s lu = asv(__builtin_amdgcn_alignbit(W[i - 1][d], W[i - 1][d - 1], 16)), ru = asv(__builtin_amdgcn_alignbit(W[i - 1][d + 1], W[i - 1][d], 16));
-                    const v2s ld = asv(__builtin_amdgcn_alignbit(W[i + 1][d], W[i + 1][d - 1], 16)), rd = asv(__builtin_amdgcn_alignbit(W[i + 1][d + 1], W[i + 1][d], 16));
-                    acc[sc][0] = hsum(vabs(c2 - up - dn), acc[sc][0]);
-                    acc[sc][1] = hsum(vabs(c2 - l0 - r0), acc[sc][1]);
-                    acc[sc][2] = hsum(vabs(c2 - lu - rd), acc[sc][2]);
-                    acc[sc][3] = hsum(vabs(c2 - ld - ru), acc[sc][3]);
-                }
+                for (int sc = 0; sc < 2; sc++) lap_pair(&W[i - 1][1 + sc], &W[i][1 + sc], &W[i + 1][1 + sc], acc[sc]);
             }
 #pragma unroll
             for (int dir = 0; dir < 4; dir++)
-                *(uint32_t *)&l_lap[dir][(ly << 1) + sr + 1][(lx << 1) + 2] = (uint32_t)acc[0][dir] | ((uint32_t)acc[1][dir] << 16);
+                *(uint32_t *)&l_lap[dir][(ly << 1) + sr + 1][(lx << 1) + 2] = acc[0][dir] | (acc[1][dir] << 16);
         }
         // the ring of sub-blocks around the tile (window rows/cols -2..-1 and 64..65): 132 of them, one per lane
         if (t < 132) {
             int sr, sc;                                           // sub-block coordinates -1..32
             if (t < 34) { sr = -1; sc = t - 1; } else if (t < 68) { sr = 32; sc = t - 35; } else if (t < 100) { sr = t - 68; sc = -1; } else { sr = t - 100; sc = 32; }
-            int acc[4] = { 0, 0, 0, 0 };
+            // sample rows 2 sr - 1 .. 2 sr + 2 (LDS rows + 3), samples 2 sc - 2 .. 2 sc + 3 = three aligned dwords from LDS column index 2 sc + 2
+            uint32_t R[4][3], acc[4] = { 0, 0, 0, 0 };
 #pragma unroll
-            for (int rr = 0; rr < 2; rr++)
-#pragma unroll
-                for (int cc = 0; cc < 2; cc++) {
-                    const int16_t *p = l_y + (sr * 2 + rr + 3) * LSTR + sc * 2 + cc + 4;
-                    const int c2 = 2 * p[0];
-                    acc[0] += abs(c2 - p[-LSTR] - p[LSTR]);
-                    acc[1] += abs(c2 - p[-1] - p[1]);
-                    acc[2] += abs(c2 - p[-LSTR - 1] - p[LSTR + 1]);
-                    acc[3] += abs(c2 - p[LSTR - 1] - p[-LSTR + 1]);
-                }
+            for (int r = 0; r < 4; r++) {
+                const uint32_t *row = (const uint32_t *)(l_y + (sr * 2 + 2 + r) * LSTR + sc * 2 + 2);
+                R[r][0] = row[0]; R[r][1] = row[1]; R[r][2] = row[2];
+            }
+            lap_pair(R[0], R[1], R[2], acc);
+            lap_pair(R[1], R[2], R[3], acc);
 #pragma unroll
             for (int dir = 0; dir < 4; dir++) l_lap[dir][sr + 1][sc + 2] = (uint16_t)acc[dir];
         }
@@ -255,27 +260,36 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
         // S(i, c+1)), a window dword or one v_alignbit - so one v_pk_add_i16 makes both pair sums (<= 2 * 4095, exact in s16) and two
         // v_mad_i32_i16 (low / high half) accumulate them: 38 VALU per output pair instead of ~100 with scalar extracts.
 #define P(i, c) ((((c) + 4) & 1) ? __builtin_amdgcn_alignbit(W[(i) + 3][(((c) + 4) >> 1) + 1], W[(i) + 3][((c) + 4) >> 1], 16) : W[(i) + 3][((c) + 4) >> 1])
-#define TAP(k, i1, c1, i2, c2) do { const uint32_t ps_ = __builtin_bit_cast(uint32_t, asv(P(i1, c1)) + asv(P(i2, c2))); a0 = mad_lo(ps_, f[k], a0); a1 = mad_hi(ps_, f[k], a1); } while (0)
+        // Round 3: ten of the twelve symmetric taps come in horizontally adjacent couples (3,2) (8,7) (6,5) (10,9) + (centre,11).  For ONE output the two
+        // first samples of a couple are a packed pair of the window and the two mirrored samples are a packed pair in reverse order, so one
+        // v_pk_add_u16 with swapped halves forms both pair sums and one v_dot2_i32_i16 against the packed coefficient couple accumulates them: 2
+        // instructions per output and couple (was 3 per output PAIR and tap = 3 per output and couple).  The taps without a neighbour (0, 1, 4) stay
+        // on the two-outputs-per-register form: one v_pk_add_u16 + two v_mad_i32_i16 per output pair.
+        const uint32_t F32 = pack_f(f[3], f[2]), F87 = pack_f(f[8], f[7]), F65 = pack_f(f[6], f[5]), FA9 = pack_f(f[10], f[9]), FCB = pack_f(f[12], f[11]);
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) {
             int o[4];
 #pragma unroll
+            for (int jj = 0; jj < 4; jj++) {
+                int acc = 256;
+                acc = dot2s(F32, padd_x(P(ii + 2, jj - 1), P(ii - 2, jj)), acc);
+                acc = dot2s(F87, padd_x(P(ii + 1, jj - 2), P(ii - 1, jj + 1)), acc);
+                acc = dot2s(F65, padd_x(P(ii + 1, jj), P(ii - 1, jj - 1)), acc);
+                acc = dot2s(FA9, padd_x(P(ii, jj + 2), P(ii, jj - 3)), acc);
+                acc = dot2s(FCB, P(ii, jj), acc);
+                o[jj] = mad_lo(P(ii, jj - 1), f[11], acc);
+            }
+#pragma unroll
             for (int jj = 0; jj < 4; jj += 2) {
-                int a0 = 256, a1 = 256;
-                TAP(0, ii + 3, jj, ii - 3, jj);
-                TAP(1, ii + 2, jj + 1, ii - 2, jj - 1); TAP(2, ii + 2, jj, ii - 2, jj); TAP(3, ii + 2, jj - 1, ii - 2, jj + 1);
-                TAP(4, ii + 1, jj + 2, ii - 1, jj - 2); TAP(5, ii + 1, jj + 1, ii - 1, jj - 1); TAP(6, ii + 1, jj, ii - 1, jj);
-                TAP(7, ii + 1, jj - 1, ii - 1, jj + 1); TAP(8, ii + 1, jj - 2, ii - 1, jj + 2);
-                TAP(9, ii, jj + 3, ii, jj - 3); TAP(10, ii, jj + 2, ii, jj - 2); TAP(11, ii, jj + 1, ii, jj - 1);
-                { const uint32_t c_ = P(ii, jj); a0 = mad_lo(c_, f[12], a0); a1 = mad_hi(c_, f[12], a1); }
-                o[jj] = min(max(a0 >> 9, 0), maxv); o[jj + 1] = min(max(a1 >> 9, 0), maxv);
+                const uint32_t p0 = padd(P(ii + 3, jj), P(ii - 3, jj)), p1 = padd(P(ii + 2, jj + 1), P(ii - 2, jj - 1)), p4 = padd(P(ii + 1, jj + 2), P(ii - 1, jj - 2));
+                o[jj] = mad_lo(p4, f[4], mad_lo(p1, f[1], mad_lo(p0, f[0], o[jj])));
+                o[jj + 1] = mad_hi(p4, f[4], mad_hi(p1, f[1], mad_hi(p0, f[0], o[jj + 1])));
             }
             uint2 w;
-            w.x = (uint32_t)(uint16_t)o[0] | ((uint32_t)(uint16_t)o[1] << 16);
-            w.y = (uint32_t)(uint16_t)o[2] | ((uint32_t)(uint16_t)o[3] << 16);
+            w.x = (uint32_t)(uint16_t)min(max(o[0] >> 9, 0), maxv) | ((uint32_t)(uint16_t)min(max(o[1] >> 9, 0), maxv) << 16);
+            w.y = (uint32_t)(uint16_t)min(max(o[2] >> 9, 0), maxv) | ((uint32_t)(uint16_t)min(max(o[3] >> 9, 0), maxv) << 16);
             *(uint2 *)(dy_ + (y + ii) * a.s_l + x) = w;
         }
-#undef TAP
 #undef P
     } else {
 #pragma unroll
@@ -303,16 +317,22 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
         const int16_t *f = l_coef + 325;
         // alf_filter_blk_5 (xevdm_alf.c:339-429), the same way: the SCU's two outputs of a row are one packed pair
 #define PC(i, c) ((((c) + 2) & 1) ? __builtin_amdgcn_alignbit(C[(i) + 2][(((c) + 2) >> 1) + 1], C[(i) + 2][((c) + 2) >> 1], 16) : C[(i) + 2][((c) + 2) >> 1])
-#define TAPC(k, i1, c1, i2, c2) do { const uint32_t ps_ = __builtin_bit_cast(uint32_t, asv(PC(i1, c1)) + asv(PC(i2, c2))); a0 = mad_lo(ps_, f[k], a0); a1 = mad_hi(ps_, f[k], a1); } while (0)
+        const uint32_t G32 = pack_f(f[3], f[2]), G54 = pack_f(f[5], f[4]);      // the couples of the 5x5 diamond: taps (3,2) and (5,4)
 #pragma unroll
         for (int ii = 0; ii < 2; ii++) {
-            int a0 = 256, a1 = 256;
-            TAPC(0, ii + 2, 0, ii - 2, 0); TAPC(1, ii + 1, 1, ii - 1, -1); TAPC(2, ii + 1, 0, ii - 1, 0); TAPC(3, ii + 1, -1, ii - 1, 1);
-            TAPC(4, ii, 2, ii, -2); TAPC(5, ii, 1, ii, -1);
-            { const uint32_t c_ = PC(ii, 0); a0 = mad_lo(c_, f[6], a0); a1 = mad_hi(c_, f[6], a1); }
-            *(uint32_t *)(dst + (cy + ii) * a.s_c + cx) = (uint32_t)(uint16_t)min(max(a0 >> 9, 0), maxv) | ((uint32_t)(uint16_t)min(max(a1 >> 9, 0), maxv) << 16);
+            int o[2];
+#pragma unroll
+            for (int jj = 0; jj < 2; jj++) {
+                int acc = 256;
+                acc = dot2s(G32, padd_x(PC(ii + 1, jj - 1), PC(ii - 1, jj)), acc);
+                acc = dot2s(G54, padd_x(PC(ii, jj + 1), PC(ii, jj - 2)), acc);
+                o[jj] = mad_lo(PC(ii, jj), f[6], acc);
+            }
+            const uint32_t p0 = padd(PC(ii + 2, 0), PC(ii - 2, 0)), p1 = padd(PC(ii + 1, 1), PC(ii - 1, -1));
+            o[0] = mad_lo(p1, f[1], mad_lo(p0, f[0], o[0]));
+            o[1] = mad_hi(p1, f[1], mad_hi(p0, f[0], o[1]));
+            *(uint32_t *)(dst + (cy + ii) * a.s_c + cx) = (uint32_t)(uint16_t)min(max(o[0] >> 9, 0), maxv) | ((uint32_t)(uint16_t)min(max(o[1] >> 9, 0), maxv) << 16);
         }
-#undef TAPC
 #undef PC
     }
 }

@@ -83,9 +83,23 @@ int itdq_group_size(int lw, int lh) { return itdq_group(lw, lh); }
 
 #define ITDQ_PLANES_DWORDS 4608  // max over size classes of 2 planes x G*H*(W/2+1) dwords (16x16: 2*2304)
 #define ITDQ_LDS_DWORDS (ITDQ_PLANES_DWORDS + 2048)   // + 4096 dequantised s16 coefficients
+#define ITDQ_MAX_G 128           // TBs per work item (2x2 chroma blocks)
 
+// OR over the 64 lanes of the wave (every lane must take part)
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v |= (uint32_t)__shfl_xor((int)v, m, 64);
+    return v;
+}
+
+// Sparsity masks (round 3): a coded block of a real stream holds a handful of non-zero coefficients at low frequencies.  Stage 0 records, per TB, which
+// coefficient ROW pairs and COLUMN pairs hold a non-zero value (LDS atomic OR, only for the few non-zero dwords); stage 1 then walks only the set row
+// pairs (union over the wave's TBs, a scalar bit loop - the matrix rows stay wave-uniform SGPR loads) and stage 2 only the set column pairs: a column
+// without coefficients stays zero through the vertical transform.  The round-2 loop tested every row pair with an LDS read + ballot + branch - 32
+// dependent LDS round trips per stage for a 64-point transform, which is what the kernel's time was (the arithmetic itself is a few dozen dot2).
 template <int LW, int LH>
-__device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, uint32_t *lds)
+__device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, uint32_t *lds, uint32_t *s_rm, uint32_t *s_cm)
 {
     constexpr int W = 1 << LW, H = 1 << LH;
     constexpr int N1 = H > 16 ? 16 : H, C1 = H / N1;          // stage-1 outputs per lane, chunks
@@ -94,8 +108,13 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
     constexpr int RS = W / 2 + 1;                              // LDS row stride in dwords (s16 pairs), odd
     constexpr int PLANE = G * H * RS;                          // dwords per intermediate plane
     constexpr bool UNI1 = (G * W) % 64 == 0, UNI2 = (G * H) % 64 == 0;
-    static_assert(2 * PLANE <= ITDQ_PLANES_DWORDS && G * W * H <= 4096, "LDS budget");
+    static_assert(2 * PLANE <= ITDQ_PLANES_DWORDS && G * W * H <= 4096 && G <= ITDQ_MAX_G, "LDS budget");
+    constexpr bool RMASK = H >= 16, CMASK = W >= 16;          // shorter transforms: the masks would cost more than the 2..4 loop rounds they can save
     const int t = threadIdx.x;
+    if (RMASK || CMASK) {
+        if (t < G) { s_rm[t] = 0; s_cm[t] = 0; }
+        __syncthreads();
+    }
     // wave-uniform matrix choice: DCT-II, or for ATS work items (4..32 only) DST-VII / DCT-VIII
     const uint32_t *tmh = (wv.tr_v == TR_DCT2 || LH < 2 || LH > 5) ? k_tmp + tmp_base(LH) : k_atsp[wv.tr_v - 1] + atsp_base(LH);
     const uint32_t *tmw = (wv.tr_h == TR_DCT2 || LW < 2 || LW > 5) ? k_tmp + tmp_base(LW) : k_atsp[wv.tr_h - 1] + atsp_base(LW);
@@ -132,6 +151,8 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
                 const long long l0 = ((long long)c0 * mul + offset) >> shift, l1 = ((long long)c1 * mul + offset) >> shift;
                 const int v0 = (int)min(max(l0, -32768ll), 32767ll), v1 = (int)min(max(l1, -32768ll), 32767ll);
                 raw[i] = (uint32_t)(uint16_t)v0 | ((uint32_t)(uint16_t)v1 << 16);
+                if (RMASK) atomicOr(&s_rm[p], 1u << ((o + 2 * i) >> (LW + 1)));                  // row pair of this dword
+                if (CMASK) atomicOr(&s_cm[p], 1u << (((o + 2 * i) & (W - 1)) >> 1));              // column pair
             }
 #pragma unroll
             for (int i = 0; i < UN / 2; i++) ldsc[(p * S + o) / 2 + i] = raw[i];
@@ -140,6 +161,11 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
     __syncthreads();
 
     // ------------------------------------------------ stage 1: columns ------------------------------------
+    uint32_t rows1 = 0;
+    if (RMASK) {
+        const int p1 = (t % (G * W)) >> LW;
+        rows1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_or((t < G * W * C1 && p1 < wv.count) ? s_rm[p1] : 0u));
+    }
     if (t < G * W * C1) {
         const int idx = t % (G * W);
         int chunk = t / (G * W);
@@ -151,16 +177,27 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
         int acc[N1];
 #pragma unroll
         for (int n = 0; n < N1; n++) acc[n] = 0;
-        for (int k2 = 0; k2 < H / 2; k2++) {
-            const uint32_t vp = valid ? ((uint32_t)(uint16_t)src[(2 * k2) * W] | ((uint32_t)(uint16_t)src[(2 * k2 + 1) * W] << 16)) : 0u;
-            if (__ballot(vp != 0) == 0) continue;              // both coefficient rows zero across this wave
-            const uint32_t *row = tmh + k2 * H + chunk * N1;
+        if (RMASK) {
+            for (uint32_t m = rows1; m; m &= m - 1) {          // the row pairs that hold a coefficient in one of this wave's TBs
+                const int k2 = __builtin_ctz(m);
+                const uint32_t vp = valid ? ((uint32_t)(uint16_t)src[(2 * k2) * W] | ((uint32_t)(uint16_t)src[(2 * k2 + 1) * W] << 16)) : 0u;
+                const uint32_t *row = tmh + k2 * H + chunk * N1;
 #pragma unroll
-            for (int n = 0; n < N1; n++) acc[n] = dot2(row[n], vp, acc[n]);
+                for (int n = 0; n < N1; n++) acc[n] = dot2(row[n], vp, acc[n]);
+            }
+        } else {
+            for (int k2 = 0; k2 < H / 2; k2++) {
+                const uint32_t vp = valid ? ((uint32_t)(uint16_t)src[(2 * k2) * W] | ((uint32_t)(uint16_t)src[(2 * k2 + 1) * W] << 16)) : 0u;
+                if (__ballot(vp != 0) == 0) continue;              // both coefficient rows zero across this wave
+                const uint32_t *row = tmh + k2 * H + chunk * N1;
+#pragma unroll
+                for (int n = 0; n < N1; n++) acc[n] = dot2(row[n], vp, acc[n]);
+            }
         }
-        // transposed store: element [p][row = chunk*N1+n][col = j]
+        // transposed store: element [p][row = chunk*N1+n][col = j] - only columns stage 2 will read (its column pair holds a coefficient)
         const int base = (p * H + chunk * N1) * (2 * RS) + j;
-        if (s16_mid) {
+        if (CMASK && !(valid && ((s_cm[p] >> (j >> 1)) & 1))) {
+        } else if (s16_mid) {
 #pragma unroll
             for (int n = 0; n < N1; n++) ldsh[base + n * (2 * RS)] = (int16_t)clip16((acc[n] + 64) >> 7);   // xevdm_itdq.c ITX_SHIFT1 = 7
         } else {
@@ -174,12 +211,19 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
     __syncthreads();
 
     // ------------------------------------------------ stage 2: rows ---------------------------------------
+    uint32_t cols2 = 0;
+    if (CMASK) {
+        const int p2 = (t % (G * H)) >> LH;
+        cols2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_or((t < G * H * C2 && p2 < wv.count) ? s_cm[p2] : 0u));
+    }
     if (t < G * H * C2) {
         const int idx = t % (G * H);
         int chunk = t / (G * H);
         if (UNI2) chunk = __builtin_amdgcn_readfirstlane(chunk);
         const int p = idx >> LH, r = idx & (H - 1);
         if (p >= wv.count) return;
+        // a column pair outside this TB's own mask was not written by stage 1 (it may be set for another TB of the wave): reads as zero
+        const uint32_t own = CMASK ? s_cm[p] : 0xFFFFFFFFu;
         const TbRec tb = a.tbs[wv.first + p];
         const int shift2 = s16_mid ? 12 - (a.bd - 8) : 7 + 12 - (a.bd - 8);
         const uint32_t *inh = lds + (p * H + r) * RS;
@@ -189,12 +233,22 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
             int s[N2];
 #pragma unroll
             for (int n = 0; n < N2; n++) s[n] = 1 << (shift2 - 1);
-            for (int k2 = 0; k2 < W / 2; k2++) {
-                const uint32_t vp = inh[k2];
-                if (__ballot(vp != 0) == 0) continue;
-                const uint32_t *row = tmw + k2 * W + chunk * N2;
+            if (CMASK) {
+                for (uint32_t m = cols2; m; m &= m - 1) {
+                    const int k2 = __builtin_ctz(m);
+                    const uint32_t vp = ((own >> k2) & 1) ? inh[k2] : 0u;
+                    const uint32_t *row = tmw + k2 * W + chunk * N2;
 #pragma unroll
-                for (int n = 0; n < N2; n++) s[n] = dot2(row[n], vp, s[n]);
+                    for (int n = 0; n < N2; n++) s[n] = dot2(row[n], vp, s[n]);
+                }
+            } else {
+                for (int k2 = 0; k2 < W / 2; k2++) {
+                    const uint32_t vp = inh[k2];
+                    if (__ballot(vp != 0) == 0) continue;
+                    const uint32_t *row = tmw + k2 * W + chunk * N2;
+#pragma unroll
+                    for (int n = 0; n < N2; n++) s[n] = dot2(row[n], vp, s[n]);
+                }
             }
 #pragma unroll
             for (int n = 0; n < N2; n++) res[n] = clip16(s[n] >> shift2);
@@ -202,12 +256,23 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
             int sh[N2], sl[N2];
 #pragma unroll
             for (int n = 0; n < N2; n++) { sh[n] = 0; sl[n] = 0; }
-            for (int k2 = 0; k2 < W / 2; k2++) {
-                const uint32_t vh = inh[k2], vl = inl[k2];
-                if (__ballot((vh | vl) != 0) == 0) continue;
-                const uint32_t *row = tmw + k2 * W + chunk * N2;
+            if (CMASK) {
+                for (uint32_t m = cols2; m; m &= m - 1) {
+                    const int k2 = __builtin_ctz(m);
+                    const bool mine = (own >> k2) & 1;
+                    const uint32_t vh = mine ? inh[k2] : 0u, vl = mine ? inl[k2] : 0u;
+                    const uint32_t *row = tmw + k2 * W + chunk * N2;
 #pragma unroll
-                for (int n = 0; n < N2; n++) { sh[n] = dot2(row[n], vh, sh[n]); sl[n] = dot2(row[n], vl, sl[n]); }
+                    for (int n = 0; n < N2; n++) { sh[n] = dot2(row[n], vh, sh[n]); sl[n] = dot2(row[n], vl, sl[n]); }
+                }
+            } else {
+                for (int k2 = 0; k2 < W / 2; k2++) {
+                    const uint32_t vh = inh[k2], vl = inl[k2];
+                    if (__ballot((vh | vl) != 0) == 0) continue;
+                    const uint32_t *row = tmw + k2 * W + chunk * N2;
+#pragma unroll
+                    for (int n = 0; n < N2; n++) { sh[n] = dot2(row[n], vh, sh[n]); sl[n] = dot2(row[n], vl, sl[n]); }
+                }
             }
             const long long add = 1ll << (shift2 - 1);
 #pragma unroll
@@ -241,10 +306,11 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
 __global__ __launch_bounds__(256) void k_itdq(const ItdqArgs a)
 {
     __shared__ uint32_t lds[ITDQ_LDS_DWORDS];
+    __shared__ uint32_t s_rm[ITDQ_MAX_G], s_cm[ITDQ_MAX_G];      // per TB: coefficient row pairs / column pairs that are not all zero
     const int wi = blockIdx.x;
     if (wi >= a.n_waves) return;
     const TbWave wv = a.waves[wi];
-#define CASE(lw, lh) case (lw) * 8 + (lh): itdq_item<lw, lh>(a, wv, lds); break;
+#define CASE(lw, lh) case (lw) * 8 + (lh): itdq_item<lw, lh>(a, wv, lds, s_rm, s_cm); break;
 #define ROW(lw) CASE(lw, 1) CASE(lw, 2) CASE(lw, 3) CASE(lw, 4) CASE(lw, 5) CASE(lw, 6)
     switch (wv.log2w * 8 + wv.log2h) {
         ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6)

@@ -1061,6 +1061,14 @@ int xgpu_batch_dmvr_mvs(xgpu_ctx *c, xgpu_dbatch *db, int16_t *mv, int n)
     return db->n_dmvr;
 }
 
+int xgpu_batch_info(xgpu_ctx *c, const xgpu_dbatch *db, int info[XGPU_BATCH_INFO_COUNT])
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, db != NULL && info != NULL);
+    info[0] = db->n_cu; info[1] = db->n_tb; info[2] = db->n_waves; info[3] = db->n_intra; info[4] = db->n_intra_l1; info[5] = db->n_levels;
+    info[6] = db->n_dmvr; info[7] = db->n_aff_eif + db->n_aff_sub;
+    return XGPU_OK;
+}
+
 int xgpu_batch_wait_upload(xgpu_ctx *c, xgpu_dbatch *db)
 {
     ARGCHK(c, c != NULL); ARGCHK(c, db != NULL);

@@ -119,6 +119,12 @@ class XgpuDecoder:
         self._chk(self.lib.xgpu_batch_dmvr_mvs(self.ctx, h, out.ctypes.data, n), "xgpu_batch_dmvr_mvs")
         return out[:n]
 
+    def batch_info(self, h):
+        """what the batch builder made of the batch: CU / TB / work-item counts, nodes and depth of the dependency graph (xgpu_batch_info)"""
+        v = (C.c_int * 8)()
+        self._chk(self.lib.xgpu_batch_info(self.ctx, h, v), "xgpu_batch_info")
+        return dict(zip(("n_cu", "n_tb", "itdq_items", "dep_nodes", "dep_nodes_level1", "dep_levels", "dmvr_sub_blocks", "affine_tiles"), list(v)))
+
     def batch_wait_upload(self, h):
         self._chk(self.lib.xgpu_batch_wait_upload(self.ctx, h), "xgpu_batch_wait_upload")
 
