@@ -14,7 +14,9 @@
  * chain on one host core (an 8K picture takes tens of milliseconds to parse, its kernels half a millisecond), so a GPU is fed by parsing
  * several GOPs at once.
  * --tile-threads T lets every worker's parser use T threads for the tiles of one picture (xhost_parser_set_threads).
- * usage: evc_decode [--gpus N] [--workers W] [--tile-threads T] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
+ * Every worker runs its parser on a thread of its own, one picture ahead of the thread that builds the device batch and launches the kernels
+ * (--no-pipeline: back to back on one thread, as xevd_dec_nalu does it).
+ * usage: evc_decode [--gpus N] [--workers W] [--tile-threads T] [--no-pipeline] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
  *        evc_decode in.evc out.yuv D                                               (the round-1 form)
  * build: oracle-free; see examples/Makefile.
  */
@@ -25,6 +27,7 @@
 #include <time.h>
 #include <unistd.h>
 #include <fcntl.h>
+#include <pthread.h>
 #include "xevd_host.h"
 #include "xevd_wq.h"
 
@@ -32,6 +35,7 @@
 #define MAX_STREAMS 64
 #define MAX_GOPS 4096
 #define CHECK(call) do { int rc_ = (call); if (rc_ < 0) { fprintf(stderr, "%s -> %d (%s)\n", #call, rc_, w->g ? xgpu_last_error(w->g) : ""); return rc_; } } while (0)
+static double now_s(void);
 
 typedef struct { int poc, pic, in_use; } slot_t;                 /* DPB: POC -> device picture slot */
 typedef struct { int epoch, poc; size_t off; } out_t;              /* one output picture: position in the unit's buffer */
@@ -44,6 +48,8 @@ typedef struct {                                                    /* one worke
     const stream_t *streams;
     long pictures;
     double busy_s, setup_s;                                         /* time inside the units / inside context creation and picture allocation */
+    int16_t *ref_luma[MAX_SLOTS + 2];                               /* host copies of decoded luma planes, by device picture (only for streams whose parser asks) */
+    double parse_s, build_s;                                        /* inside xhost_parser_next (its own thread with the pipeline) / inside xgpu_batch_create */
 } worker_t;
 
 static double now_s(void)
@@ -71,6 +77,7 @@ static int worker_context(worker_t *w, const xhost_picture *p)
     if (w->g && !p->chroma_qp_table[0] && !memcmp(&sp, &w->sp, sizeof(sp))) return 0;
     const double t0 = now_s();
     if (w->g) { xgpu_close(w->g); w->g = NULL; }
+    for (int i = 0; i < MAX_SLOTS + 2; i++) { free(w->ref_luma[i]); w->ref_luma[i] = NULL; }      /* sized for the old sequence */
     w->sp = sp;                                                     /* compared without the table pointers */
     w->n_slots = 0;
     sp.chroma_qp_table[0] = p->chroma_qp_table[0]; sp.chroma_qp_table[1] = p->chroma_qp_table[1];
@@ -80,29 +87,99 @@ static int worker_context(worker_t *w, const xhost_picture *p)
 }
 
 static int g_tile_threads = 1;
-/* Decode `bytes` (parameter sets + one or more GOPs) on the worker's device -> packed pictures in output order (malloc'ed) */
+static int g_pipeline = 1;          /* --no-pipeline: parse and reconstruct every picture back to back on the worker's thread (the round-2 loop) */
+
+/* ---- the parser of a unit on its own thread, one picture ahead of the thread that drives the device ------------------------------------------------
+ * xevd_dec_nalu runs entropy decoding and reconstruction of a picture back to back (src_base/xevd.c:1905-1983).  Here they are two stages of a
+ * pipeline: while this worker turns picture k into a device batch and launches its kernels, the parser thread is already inside xhost_parser_next
+ * for picture k + 1 (xhost_parser_set_depth(2): the arrays of two pictures stay valid).  Pictures with DMVR candidates break the overlap for one
+ * step: the parser needs their refined vectors from the device before it goes on (xhost_parser_set_dmvr_mvs). */
+typedef struct {
+    xhost_parser *ps;
+    xhost_picture pic[2];
+    int rc[2];
+    long produced, released;        /* pictures handed over by the parser thread / given back by the consumer */
+    int stop;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    double parse_s;
+} pipe_t;
+
+static void *parser_thread(void *arg)
+{
+    pipe_t *q = (pipe_t *)arg;
+    for (long k = 0;; k++) {
+        pthread_mutex_lock(&q->mu);
+        while (!q->stop && q->released < k - 1) pthread_cond_wait(&q->cv, &q->mu);      /* slot k & 1 is free once picture k - 2 has been given back */
+        const int stop = q->stop;
+        pthread_mutex_unlock(&q->mu);
+        if (stop) break;
+        const double t0 = now_s();
+        const int rc = xhost_parser_next(q->ps, &q->pic[k & 1]);
+        q->parse_s += now_s() - t0;
+        pthread_mutex_lock(&q->mu);
+        q->rc[k & 1] = rc;
+        q->produced = k + 1;
+        pthread_cond_broadcast(&q->cv);
+        /* DMVR feedback: picture k's refined vectors - or, when the parser refines itself (tool_dmvr with tool_hmvp / tool_mmvd), picture k's decoded
+           luma samples - reach the parser (from the consumer, while this thread waits here) before picture k + 1 is parsed */
+        if (rc == 1 && (q->pic[k & 1].n_dmvr_sub > 0 || q->pic[k & 1].needs_ref_luma)) while (!q->stop && q->released < k + 1) pthread_cond_wait(&q->cv, &q->mu);
+        pthread_mutex_unlock(&q->mu);
+        if (rc != 1) break;
+    }
+    return NULL;
+}
+
+/* Decode `bytes` (parameter sets + one or more GOPs) on the worker's device -> packed pictures in output order */
 static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_bd_arg, int expected, uint8_t **frames_out, out_t **outs_out, int *n_out, size_t *frame_bytes_out, int *pinned_out)
 {
-    xhost_parser *ps = xhost_parser_open(bytes, size);
     slot_t dpb[MAX_SLOTS];
-    if (ps && g_tile_threads > 1) xhost_parser_set_threads(ps, g_tile_threads);      /* the tiles of a picture on parallel host threads */
-    int free_pic[MAX_SLOTS], n_free = 0, n_pics = 0, epoch = -1, rc, have_ctx = 0, ticket = -1, pinned = 0;
-    out_t *outs = (out_t *)malloc(sizeof(out_t) * (size_t)(expected > 0 ? expected : 1));
+    int free_pic[MAX_SLOTS], n_free = 0, n_pics = 0, epoch = -1, rc = 0, have_ctx = 0, ticket = -1, pinned = 0, thread_on = 0;
     uint8_t *frames = NULL;                                         /* decoded pictures in decoding order, packed: pinned memory, so that the */
     size_t frame_bytes = 0;                                         /* download of picture k runs while picture k + 1 is parsed and launched     */
-    if (!outs) return -1;
-    xhost_picture p;
+    xgpu_dbatch *db = NULL;
+    int16_t *mv = NULL;
+    pthread_t th;
+    pipe_t q;
+    memset(&q, 0, sizeof(q));
     memset(dpb, 0, sizeof(dpb));
+    out_t *outs = (out_t *)malloc(sizeof(out_t) * (size_t)(expected > 0 ? expected : 1));
+    q.ps = xhost_parser_open(bytes, size);
+    if (!outs || !q.ps) { rc = -1; goto done; }
+    if (g_tile_threads > 1) xhost_parser_set_threads(q.ps, g_tile_threads);      /* the tiles of a picture on parallel host threads */
+    pthread_mutex_init(&q.mu, NULL); pthread_cond_init(&q.cv, NULL);
+    if (g_pipeline) {
+        xhost_parser_set_depth(q.ps, 2);
+        if (pthread_create(&th, NULL, parser_thread, &q) != 0) { rc = -1; goto done; }
+        thread_on = 1;
+    }
+#define FAIL(code) do { rc = (code); goto done; } while (0)
+#define TRY(call) do { int rc_ = (call); if (rc_ < 0) { fprintf(stderr, "%s -> %d (%s)\n", #call, rc_, w->g ? xgpu_last_error(w->g) : ""); FAIL(rc_); } } while (0)
 
-    while ((rc = xhost_parser_next(ps, &p)) == 1) {
+    for (long k = 0;; k++) {
+        xhost_picture *pp = &q.pic[k & 1];
+        int prc;
+        if (thread_on) {
+            pthread_mutex_lock(&q.mu);
+            while (q.produced <= k) pthread_cond_wait(&q.cv, &q.mu);
+            prc = q.rc[k & 1];
+            pthread_mutex_unlock(&q.mu);
+        } else {
+            const double t0 = now_s();
+            prc = xhost_parser_next(q.ps, pp);
+            q.parse_s += now_s() - t0;
+        }
+        if (prc < 0) { fprintf(stderr, "parser: %s\n", xhost_parser_error(q.ps)); FAIL(prc); }
+        if (prc == 0) break;
+        const xhost_picture p = *pp;                                 /* the arrays it points at stay valid until picture k is given back below */
         if (!have_ctx) {                                             /* first picture: the sequence parameters are known */
-            CHECK(worker_context(w, &p));
+            TRY(worker_context(w, &p));
             for (int i = 0; i < w->n_slots; i++) free_pic[n_free++] = w->slots[i];
             frame_bytes = xgpu_pic_output_size(w->g, out_bd_arg ? out_bd_arg : p.bit_depth_luma, 0, 0, 0, 0);
             void *pin = NULL;
             if (xgpu_host_alloc(w->g, (size_t)(expected > 0 ? expected : 1) * frame_bytes, &pin) == 0) { frames = (uint8_t *)pin; pinned = 1; }
             else frames = (uint8_t *)malloc((size_t)(expected > 0 ? expected : 1) * frame_bytes);       /* pageable: the copies block, the result is the same */
-            if (!frames) return -1;
+            if (!frames) FAIL(-1);
             have_ctx = 1;
         }
         if (p.is_idr) {                                              /* an IDR empties the DPB */
@@ -110,10 +187,10 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
             epoch++;
         }
         if (n_free == 0) {                                           /* device pictures are allocated when the stream first needs them */
-            if (w->n_slots == MAX_SLOTS) { fprintf(stderr, "DPB overflow\n"); return -1; }
+            if (w->n_slots == MAX_SLOTS) { fprintf(stderr, "DPB overflow\n"); FAIL(-1); }
             const double t0 = now_s();
             const int id = xgpu_pic_alloc(w->g);
-            if (id < 0) return id;
+            if (id < 0) FAIL(id);
             w->setup_s += now_s() - t0;
             w->slots[w->n_slots++] = id; free_pic[n_free++] = id;
         }
@@ -126,8 +203,8 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
             fp.num_refp[l] = p.num_refp[l];
             for (int i = 0; i < p.num_refp[l]; i++) {
                 int s = -1;
-                for (int k = 0; k < MAX_SLOTS; k++) if (dpb[k].in_use && dpb[k].poc == p.refp_poc[i][l]) s = dpb[k].pic;
-                if (s < 0) { fprintf(stderr, "reference POC %d is not in the DPB\n", p.refp_poc[i][l]); return -1; }
+                for (int j = 0; j < MAX_SLOTS; j++) if (dpb[j].in_use && dpb[j].poc == p.refp_poc[i][l]) s = dpb[j].pic;
+                if (s < 0) { fprintf(stderr, "reference POC %d is not in the DPB\n", p.refp_poc[i][l]); FAIL(-1); }
                 fp.refp_pic[i][l] = s; fp.refp_poc[i][l] = p.refp_poc[i][l];
             }
         }
@@ -135,47 +212,82 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
         fp.deblock_alpha_offset = p.deblock_alpha_offset; fp.deblock_beta_offset = p.deblock_beta_offset;
         fp.deblock_on = p.deblock_on; fp.alf_on = p.alf_on;
 
-        xgpu_dbatch *db = NULL;
-        CHECK(xgpu_batch_create(w->g, &p.batch, &db));              /* the parser's arrays are consumed before the call returns */
-        CHECK(xgpu_frame_begin(w->g, &fp));
-        CHECK(xgpu_batch_recon(w->g, db));
-        if (p.deblock_on) CHECK(xgpu_deblock(w->g));
-        if (p.alf_on) CHECK(xgpu_alf(w->g, &p.alf));
-        CHECK(xgpu_pad(w->g));
-        CHECK(xgpu_frame_end(w->g));
+        const double tb = now_s();
+        TRY(xgpu_batch_create(w->g, &p.batch, &db));                /* the parser's arrays are consumed before the call returns */
+        w->build_s += now_s() - tb;
+        TRY(xgpu_frame_begin(w->g, &fp));
+        TRY(xgpu_batch_recon(w->g, db));
+        if (p.deblock_on) TRY(xgpu_deblock(w->g));
+        if (p.alf_on) TRY(xgpu_alf(w->g, &p.alf));
+        TRY(xgpu_pad(w->g));
+        TRY(xgpu_frame_end(w->g));
         if (p.n_dmvr_sub > 0) {
-            /* sps->tool_dmvr: the refined vectors of this picture go back to the parser before it parses the next one (temporal merge candidates) */
-            int16_t *mv = (int16_t *)malloc(sizeof(int16_t) * 4 * (size_t)p.n_dmvr_sub);
+            /* sps->tool_dmvr: the refined vectors of this picture go back to the parser before it parses the next one (temporal merge candidates);
+               the parser thread is parked until this picture is given back */
+            mv = (int16_t *)malloc(sizeof(int16_t) * 4 * (size_t)p.n_dmvr_sub);
             const int got = mv ? xgpu_batch_dmvr_mvs(w->g, db, mv, p.n_dmvr_sub) : -1;
-            const int fed = got == p.n_dmvr_sub ? xhost_parser_set_dmvr_mvs(ps, mv, got) : -1;
-            free(mv);
-            if (fed < 0) { fprintf(stderr, "DMVR vectors: backend %d, parser %d (%s)\n", got, fed, xhost_parser_error(ps)); xgpu_batch_destroy(w->g, db); return -1; }
+            const int fed = got == p.n_dmvr_sub ? xhost_parser_set_dmvr_mvs(q.ps, mv, got) : -1;
+            free(mv); mv = NULL;
+            if (fed < 0) { fprintf(stderr, "DMVR vectors: backend %d, parser %d (%s)\n", got, fed, xhost_parser_error(q.ps)); FAIL(-1); }
         }
-        xgpu_batch_destroy(w->g, db);
+        if (p.needs_ref_luma) {
+            /* tool_dmvr with tool_hmvp / tool_mmvd: the syntax of later pictures depends on refined vectors, so the parser runs the refinement search
+               itself (xevd_amd/host/dmvr_search.h) on this picture's decoded luma: one padded plane per device picture, downloaded behind the kernels */
+            const int stride = p.width + 2 * XGPU_PAD_L, slot = cur;                  /* device picture ids are 0 .. max_pics - 1 = MAX_SLOTS */
+            if (!w->ref_luma[slot]) w->ref_luma[slot] = (int16_t *)malloc(sizeof(int16_t) * (size_t)stride * (size_t)(p.height + 2 * XGPU_PAD_L));
+            if (!w->ref_luma[slot]) FAIL(-1);
+            TRY(xgpu_pic_download_padded(w->g, cur, w->ref_luma[slot], NULL, NULL));
+            TRY(xhost_parser_set_ref_luma(q.ps, p.poc, w->ref_luma[slot] + (size_t)XGPU_PAD_L * stride + XGPU_PAD_L, stride));
+        }
+        xgpu_batch_destroy(w->g, db); db = NULL;
 
-        if (n_pics >= expected) { fprintf(stderr, "more pictures than slice NAL units\n"); return -1; }
+        if (n_pics >= expected) { fprintf(stderr, "more pictures than slice NAL units\n"); FAIL(-1); }
         /* output of this picture behind its kernels, overlapping the parsing and the kernels of the next one; the DRA post-filter, when the
            PPS switches it on, is part of it */
         xgpu_dra_luts dra = { p.dra_lut[0], { p.dra_lut[1], p.dra_lut[2] } };
         const int prev = ticket;
-        CHECK(xgpu_pic_output_async(w->g, cur, p.dra_lut[0] ? &dra : NULL, out_bd_arg ? out_bd_arg : p.bit_depth_luma, 0, 0, 0, 0,
-                                    frames + (size_t)n_pics * frame_bytes, frame_bytes, &ticket));
-        if (prev >= 0 && prev != ticket) CHECK(xgpu_pic_output_wait(w->g, prev));
+        TRY(xgpu_pic_output_async(w->g, cur, p.dra_lut[0] ? &dra : NULL, out_bd_arg ? out_bd_arg : p.bit_depth_luma, 0, 0, 0, 0,
+                                  frames + (size_t)n_pics * frame_bytes, frame_bytes, &ticket));
+        if (prev >= 0 && prev != ticket) TRY(xgpu_pic_output_wait(w->g, prev));
         outs[n_pics].epoch = epoch; outs[n_pics].poc = p.poc; outs[n_pics].off = (size_t)n_pics * frame_bytes;
         n_pics++;
 
         for (int r = 0; r < p.n_release; r++)                        /* pictures the stream unmarked when this one was stored */
-            for (int k = 0; k < MAX_SLOTS; k++)
-                if (dpb[k].in_use && dpb[k].poc == p.release_poc[r]) { free_pic[n_free++] = dpb[k].pic; dpb[k].in_use = 0; }
+            for (int j = 0; j < MAX_SLOTS; j++)
+                if (dpb[j].in_use && dpb[j].poc == p.release_poc[r]) { free_pic[n_free++] = dpb[j].pic; dpb[j].in_use = 0; }
         if (p.is_ref) {
-            for (int k = 0; k < MAX_SLOTS; k++) if (!dpb[k].in_use) { dpb[k].in_use = 1; dpb[k].poc = p.poc; dpb[k].pic = cur; break; }
+            for (int j = 0; j < MAX_SLOTS; j++) if (!dpb[j].in_use) { dpb[j].in_use = 1; dpb[j].poc = p.poc; dpb[j].pic = cur; break; }
         } else free_pic[n_free++] = cur;
-    }
-    if (rc < 0) { fprintf(stderr, "parser: %s\n", xhost_parser_error(ps)); xhost_parser_close(ps); return rc; }
-    xhost_parser_close(ps);
-    if (w->g) CHECK(xgpu_sync(w->g));                               /* the last outputs have landed */
 
+        if (thread_on) {                                             /* picture k's arrays go back to the parser */
+            pthread_mutex_lock(&q.mu);
+            q.released = k + 1;
+            pthread_cond_broadcast(&q.cv);
+            pthread_mutex_unlock(&q.mu);
+        }
+    }
+    if (w->g) TRY(xgpu_sync(w->g));                                 /* the last outputs have landed */
     qsort(outs, (size_t)n_pics, sizeof(out_t), cmp_out);            /* output order: ascending POC inside every IDR period */
+#undef TRY
+#undef FAIL
+done:
+    if (thread_on) {                                                /* every path: stop and join the parser thread before its parser goes away */
+        pthread_mutex_lock(&q.mu);
+        q.stop = 1;
+        pthread_cond_broadcast(&q.cv);
+        pthread_mutex_unlock(&q.mu);
+        pthread_join(th, NULL);
+    }
+    if (q.ps) { pthread_mutex_destroy(&q.mu); pthread_cond_destroy(&q.cv); xhost_parser_close(q.ps); }
+    w->parse_s += q.parse_s;
+    free(mv);
+    if (db) xgpu_batch_destroy(w->g, db);
+    if (rc < 0) {                                                   /* nothing is handed out on failure */
+        if (w->g) (void)xgpu_sync(w->g);                            /* queued downloads still write into `frames` */
+        if (frames) { if (pinned) xgpu_host_free(w->g, frames); else free(frames); }
+        free(outs);
+        return rc;
+    }
     *frames_out = frames; *outs_out = outs; *n_out = n_pics; *frame_bytes_out = frame_bytes; *pinned_out = pinned;
     return 0;
 }
@@ -220,13 +332,14 @@ static int worker_job(void *state, const xwq_job *job)
     w->pictures += n;
     return rc;
 }
-static double g_busy[64], g_setup[64];
+static double g_busy[64], g_setup[64], g_parse[64], g_build[64];
 static int g_workers;
 static void worker_fini(void *state)
 {
     worker_t *w = (worker_t *)state;
-    { const int k = __sync_fetch_and_add(&g_workers, 1); g_busy[k & 63] = w->busy_s - w->setup_s; g_setup[k & 63] = w->setup_s; }
+    { const int k = __sync_fetch_and_add(&g_workers, 1); g_busy[k & 63] = w->busy_s - w->setup_s; g_setup[k & 63] = w->setup_s; g_parse[k & 63] = w->parse_s; g_build[k & 63] = w->build_s; }
     if (w->g) xgpu_close(w->g);
+    for (int i = 0; i < MAX_SLOTS + 2; i++) free(w->ref_luma[i]);
     free(w);
 }
 
@@ -238,6 +351,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[a], "--workers") && a + 1 < argc) { workers = atoi(argv[a + 1]); a += 2; }
         else if (!strcmp(argv[a], "--bd") && a + 1 < argc) { out_bd = atoi(argv[a + 1]); a += 2; }
         else if (!strcmp(argv[a], "--tile-threads") && a + 1 < argc) { g_tile_threads = atoi(argv[a + 1]); a += 2; }
+        else if (!strcmp(argv[a], "--no-pipeline")) { g_pipeline = 0; a += 1; }
         else break;
     }
     int n_pos = argc - a;
@@ -288,10 +402,12 @@ int main(int argc, char **argv)
     fprintf(stderr, "%ld pictures\n", total_pictures);
     fprintf(stderr, "%d stream(s), %d job(s) on %d worker(s), %d per device:", n_streams, n_jobs, gpus, workers);
     for (int i = 0; i < gpus; i++) fprintf(stderr, " %d", done[i]);
-    double busy = 0, setup = 0;
-    for (int i = 0; i < g_workers && i < 64; i++) { if (g_busy[i] > busy) busy = g_busy[i]; if (g_setup[i] > setup) setup = g_setup[i]; }
+    double busy = 0, setup = 0, parse = 0, build = 0;
+    for (int i = 0; i < g_workers && i < 64; i++) { if (g_busy[i] > busy) busy = g_busy[i]; if (g_setup[i] > setup) setup = g_setup[i]; parse += g_parse[i]; build += g_build[i]; }
     fprintf(stderr, " jobs; %.3f s wall (device start-up included), %.2f pictures/s; decoding alone (parsing + kernels + output, the span xevd_app times: "
             "app/xevd_app.c:492-501,612-624; slowest worker) %.3f s, %.2f pictures/s; context + picture allocation %.3f s\n",
             secs, secs > 0 ? (double)total_pictures / secs : 0.0, busy, busy > 0 ? (double)total_pictures / busy : 0.0, setup);
+    fprintf(stderr, "stages per picture: parse %.2f ms (%s), batch build %.2f ms\n", total_pictures ? 1e3 * parse / (double)total_pictures : 0.0,
+            g_pipeline ? "own thread, one picture ahead" : "same thread", total_pictures ? 1e3 * build / (double)total_pictures : 0.0);
     return 0;
 }

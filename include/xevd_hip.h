@@ -219,7 +219,8 @@ int  xgpu_pic_output(xgpu_ctx *ctx, int pic, const xgpu_dra_luts *dra, int out_b
 int  xgpu_pic_output_async(xgpu_ctx *ctx, int pic, const xgpu_dra_luts *dra, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b,
                            void *dst, size_t dst_size, int *ticket);
 int  xgpu_pic_output_wait(xgpu_ctx *ctx, int ticket);
-/* whole padded buffers (XEVD_PIC.buf_y/u/v layout: stride = w + 2*pad, rows = h + 2*pad), for tests.     */
+/* whole padded buffers (XEVD_PIC.buf_y/u/v layout: stride = w + 2*pad, rows = h + 2*pad): for tests, and - luma alone, buf_u = buf_v = NULL - for a
+   front end that refines merge vectors itself on the reference samples (xhost_parser_set_ref_luma, include/xevd_host.h).  Blocking.                 */
 int  xgpu_pic_download_padded(xgpu_ctx *ctx, int pic, int16_t *buf_y, int16_t *buf_u, int16_t *buf_v);
 int  xgpu_pic_upload_padded(xgpu_ctx *ctx, int pic, const int16_t *buf_y, const int16_t *buf_u, const int16_t *buf_v);
 

@@ -19,8 +19,8 @@
  * filter sets, coefficient syntax :2154-2318, slice-level parameters :2479-2657, per-CTU flags src_main/xevdm.c:2411-2418, alf_recon_coef
  * src_main/xevdm_alf.c:700-794), and tool_admvp with its sub-tools tool_amvr, tool_hmvp, tool_mmvd and tool_dmvr: merge_idx / merge_mode_flag / mvr_idx /
  * bi_idx / mmvd_flag + mmvd data syntax (xevdm_eco.c:767-812,1519-1726), merge with vector difference (src_main/xevdm_util.c:191-592,4682-4716), merge candidates incl. the temporal and history ones (src_main/xevdm_util.c:594-1391,3729-3818), the resolution-indexed
- * predictor (:750-951), intra-only 4x4 CUs; tool_dmvr needs the backend's refined vectors back per picture (xhost_parser_set_dmvr_mvs) and is refused
- * together with tool_hmvp or tool_mmvd.  tool_affine (affine merge / affine inter CUs, xevdm_util.c:2145-3187) is parsed too.
+ * predictor (:750-951), intra-only 4x4 CUs; tool_dmvr needs the backend's refined vectors back per picture (xhost_parser_set_dmvr_mvs) - or, together with
+ * tool_hmvp or tool_mmvd, the decoded luma samples of the reference pictures (xhost_parser_set_ref_luma: the front end then refines itself).  tool_affine (affine merge / affine inter CUs, xevdm_util.c:2145-3187) is parsed too.
  * sps_btt_flag (binary / ternary split trees with CTU 64, "inter only" mode constraints, local dual trees: xgpu_cu_batch.tree) is parsed; refused: sps_suco_flag.
  * tool_cm_init (context initialisation tables, neighbour-dependent contexts) and tool_adcc
  * (advanced coefficient coding) are parsed.
@@ -48,7 +48,8 @@ typedef struct xhost_parser xhost_parser;
 typedef struct xhost_writer xhost_writer;
 
 /* One decoded-syntax picture: everything xgpu_frame_begin + xgpu_batch_create need, plus DPB bookkeeping by POC.
-   The arrays behind `batch` belong to the parser and stay valid until the next xhost_parser_next / close. */
+   The arrays behind `batch`, `alf` and `dra_lut` belong to the parser and stay valid until the next xhost_parser_next / close - or, after
+   xhost_parser_set_depth(p, d), until the call that hands out the d-th picture after this one. */
 typedef struct xhost_picture {
     int width, height, bit_depth_luma, bit_depth_chroma;
     int poc, temporal_id, slice_type, is_idr;
@@ -73,6 +74,9 @@ typedef struct xhost_picture {
     uint8_t md5[3][16];                    /*   (xevd_eco_sei xevd_eco.c:1617-1678, xevd_md5_imgb xevd_util.c:985-1002)          */
     int n_dmvr_sub;                        /* sps->tool_dmvr: the number of sub-blocks xgpu_batch_dmvr_mvs reports for this picture's batch (batch.dmvr flags the
                                               merge-mode CUs); their vectors must come back through xhost_parser_set_dmvr_mvs before the next picture is parsed */
+    int needs_ref_luma;                    /* sps->tool_dmvr together with tool_hmvp or tool_mmvd, and this picture is kept as a reference: the front end refines merge-mode
+                                              vectors itself while it parses LATER pictures (their syntax depends on the refined vectors) and reads this picture's
+                                              decoded luma samples for that - register them with xhost_parser_set_ref_luma before the next xhost_parser_next */
     int n_release;                         /* reference pictures unmarked before this one was stored (pic_marking_no_rpl) */
     int release_poc[32];
     xgpu_cu_batch batch;
@@ -85,6 +89,10 @@ int  xhost_parser_next(xhost_parser *p, xhost_picture *out);
    parser stores them with the picture, where the temporal merge candidates of later pictures read them (the reference's map_mv holds the REFINED
    vectors, src_main/xevdm_util.c:4327-4338).  0, or < 0 on a count mismatch.  Not needed for pictures with n_dmvr_sub == 0. */
 int  xhost_parser_set_dmvr_mvs(xhost_parser *p, const int16_t *mv, int n_sub);
+/* The decoded luma plane of the picture with POC `poc` (handed out with needs_ref_luma): `plane` = sample (0, 0), rows `stride` samples apart, with at least
+   144 samples of replicated border on every side (what xgpu_pic_download_padded delivers); it must stay valid and unchanged while the picture is a
+   reference.  Streams that need it and do not get it fail with an error that says so.  Why the front end reads samples at all: xevd_amd/host/dmvr_search.h. */
+int  xhost_parser_set_ref_luma(xhost_parser *p, int poc, const int16_t *plane, int stride);
 /* The same parser fed one NAL unit at a time (2-byte NAL header + payload, no length prefix - what xevd_decode receives):
    1: `out` holds a picture (has_md5 is 0: a signature SEI arrives as its own NAL unit); 0: consumed; < 0: error */
 xhost_parser *xhost_parser_open_nal(void);
@@ -94,6 +102,12 @@ const char *xhost_parser_error(const xhost_parser *p);
    in parallel, tile by tile off a shared counter - what xevdm_dec_slice does with the reference's thread pool (src_main/xevdm.c:2640-2690).
    Pictures with one tile are not affected.  The batch handed out is the same for every thread count. */
 int  xhost_parser_set_threads(xhost_parser *p, int n_threads);
+/* How many handed-out pictures stay valid at once (1..8, default 1; before the first picture).  With 2, picture k can be turned into a device
+   batch and launched on one thread while another thread is inside xhost_parser_next for picture k + 1 (examples/evc_decode.c): the stages
+   xevd_dec_nalu runs back to back per picture - entropy decoding, then reconstruction - overlap across pictures.  The parser itself is not
+   re-entrant: one thread at a time inside its functions.  (Not for streams with sps->tool_dmvr feedback pending: xhost_parser_set_dmvr_mvs of
+   picture k has to come before xhost_parser_next for k + 1 - the caller serialises those.) */
+int  xhost_parser_set_depth(xhost_parser *p, int depth);
 void xhost_parser_close(xhost_parser *p);
 
 typedef struct xhost_stream_params {
@@ -204,6 +218,9 @@ int  xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type, int slic
    planes (16-bit little-endian samples, rows without padding).  The reference decoder verifies them when
    XEVD_CFG_SET_USE_PIC_SIGNATURE is set (src_base/xevd.c:2010-2026) - the MD5 round trip of SURVEY 8c. */
 int  xhost_writer_add_md5_sei(xhost_writer *w, const uint8_t md5[3][16]);
+/* tool_dmvr together with tool_hmvp / tool_mmvd: the writer derives the same motion as a decoder, refined vectors included, so it needs the decoded luma
+   samples of every reference picture it has written (a test harness decodes the stream so far); same contract as xhost_parser_set_ref_luma */
+int  xhost_writer_set_ref_luma(xhost_writer *w, int poc, const int16_t *plane, int stride);
 int  xhost_writer_bytes(xhost_writer *w, const uint8_t **bytes, size_t *size);
 void xhost_writer_close(xhost_writer *w);
 

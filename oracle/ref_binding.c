@@ -262,7 +262,7 @@ static int hip_dec_slice(XEVD_CTX *ctx, XEVD_CORE *core)
     for (t = 0; t < ctx->num_tiles_in_slice; t++) if (ctx->tile_in_slice[t] != t) return XEVD_ERR_UNSUPPORTED;
     /* DMVR + HMVP: xevdm_set_dec_info leaves the refined vector of the first sub-block in core->mv (xevdm_util.c:4384-4387), which the history buffer then
        takes (xevdm.c:1335-1342) - the next CUs' candidates would need the refinement result before the batch has run */
-    if (ctx->sps->tool_dmvr && ctx->sps->tool_hmvp) return XEVD_ERR_UNSUPPORTED;
+    if (ctx->sps->tool_dmvr && (ctx->sps->tool_hmvp || ctx->sps->tool_mmvd)) return XEVD_ERR_UNSUPPORTED;
     if (!s->g && (ret = hip_open(ctx)) < 0) return ret;
 
     s->n_cu = 0; s->coef_v.n = 0; s->any_affine = s->any_dmvr = s->any_ats = s->any_ats_inter = s->any_tree = 0; s->failed = 0; s->deblocked = 0;

@@ -170,6 +170,13 @@ def golden_streams(only=()):
                                 "main_dmvr_b_8b": (200, 136, 9, dict(main=True, admvp=True, dmvr=True, inter_frac=0.9, max_refs=2, log2_sub_gop=2, skip_frac=0.3, direct_frac=0.3)),
                                 "main_dmvr_all_tools_10b": (264, 136, 17, dict(main=True, admvp=True, dmvr=True, amvr=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=4,
                                                                                inter_frac=0.9, max_refs=3, log2_sub_gop=3, bit_depth=10, skip_frac=0.3, direct_frac=0.3)),
+                                # tool_dmvr with tool_hmvp / tool_mmvd: the front end refines vectors itself (reference samples through xhost_parser_set_ref_luma)
+                                "main_dmvr_hmvp_mmvd_b_8b": (200, 136, 9, dict(main=True, admvp=True, dmvr=True, hmvp=True, mmvd=True, amvr=True, log2_sub_gop=2, max_refs=4, skip_frac=0.3, direct_frac=0.4)),
+                                "main_every_tool_10b": (264, 200, 17, dict(main=True, btt=(2, 0, 0, 0), admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, dmvr=True, iqt=True, ats=True, addb=True,
+                                                                           alf=True, eipd=True, htdf=True, cm_init=True, adcc=True, rpl=True, pocs=True, qp_delta_area=8, max_refs=2, log2_sub_gop=3,
+                                                                           split_prob=0.7, bit_depth=10, inter_frac=0.9, skip_frac=0.3, direct_frac=0.3)),
+                                "main_every_tool_tiles_8b": (392, 264, 9, dict(main=True, admvp=True, amvr=True, hmvp=True, mmvd=True, dmvr=True, affine=True, iqt=True, addb=True, alf=True, inter_frac=0.95,
+                                                                               skip_frac=0.3, direct_frac=0.3, max_refs=2, log2_sub_gop=2, tiles=(2, 2, 0))),
                                 "main_mmvd_all_tools_10b": (264, 136, 17, dict(main=True, admvp=True, mmvd=True, amvr=True, hmvp=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True,
                                                                                ibc_log_max=5, inter_frac=0.9, skip_frac=0.35, direct_frac=0.3, max_refs=3, log2_sub_gop=3, bit_depth=10)),
                                 "main_rpl_pocs_gop8_10b": (264, 136, 17, dict(main=True, rpl=True, pocs=True, admvp=True, amvr=True, hmvp=True, iqt=True, addb=True, alf=True, inter_frac=0.9,

@@ -99,6 +99,11 @@ def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_fra
                           temporal_id=tid)
             if sign:
                 w.add_md5_sei(decode_oracle(w.bytes(), order="decoding")[-1])
+            if dmvr and (hmvp or mmvd) and k + 1 < n_pics:
+                # the writer derives motion like a decoder, refined vectors included: it needs the decoded samples of what it has written so far
+                lumas = []
+                decode_oracle(w.bytes(), order="decoding", keep_luma=lumas)
+                w.set_ref_luma(lumas[-1][0], lumas[-1][1], abi.PAD_L)
             since_idr += 1
         return w.bytes()
     finally:
@@ -139,8 +144,10 @@ def _output_order(pics):
     return [v for _, v in sorted(out, key=lambda kv: kv[0])]
 
 
-def decode_oracle(data, order="output"):
-    """Our parser + the CPU oracle (oracle/liboracle.so). -> pictures in output (or decoding) order."""
+def decode_oracle(data, order="output", keep_luma=None, keep_params=None):
+    """Our parser + the CPU oracle (oracle/liboracle.so). -> pictures in output (or decoding) order.
+    keep_luma: a list that receives (poc, padded luma plane) of every picture in decoding order; keep_params: one that receives the parser's picture
+    dicts (streams whose parser needs the decoded reference samples cannot be parsed without decoding them)."""
     o = ol.oracle()
     dpb, out = {}, []
     for p in stream.iter_stream(data):      # a generator: with tool_dmvr the parser needs this picture's refined vectors before it parses the next one
@@ -170,6 +177,12 @@ def decode_oracle(data, order="output"):
             ap, keep_ap = abi.make_alf_params(p["alf"])
             o.orc_alf(C.byref(sp), C.byref(fr.cur), C.byref(ap))
         o.orc_pad(C.byref(sp), C.byref(fr.cur))
+        if p["needs_ref_luma"]:      # tool_dmvr with tool_hmvp / tool_mmvd: the parser refines vectors itself on the decoded reference samples
+            p["set_ref_luma"](p["poc"], cur.bufs[0], abi.PAD_L)
+        if keep_luma is not None:
+            keep_luma.append((p["poc"], cur.bufs[0]))
+        if keep_params is not None:
+            keep_params.append(p)
         if p["is_idr"]:
             dpb.clear()
         for poc in p["release"]:

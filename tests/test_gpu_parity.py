@@ -402,7 +402,8 @@ def test_gpu_decoder_survives_mutated_streams():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["hier_b_gop4", "main_eipd_all_tools_10b", "cqt_crop_10b", "idr_period_skip", "main_dra_10b", "main_htdf_all_tools_10b", "main_tiles_explicit_10b", "main_affine_all_tools_10b"])
+@pytest.mark.parametrize("name", ["hier_b_gop4", "main_eipd_all_tools_10b", "cqt_crop_10b", "idr_period_skip", "main_dra_10b", "main_htdf_all_tools_10b", "main_tiles_explicit_10b", "main_affine_all_tools_10b",
+                                  "main_dmvr_hmvp_mmvd_b_8b", "main_every_tool_10b", "main_every_tool_tiles_8b"])
 def test_gpu_plain_c_decoder(name, tmp_path):
     """examples/evc_decode - a decoder in plain C on the two C ABIs, no Python in the loop - writes the reference decoder's pictures"""
     import subprocess
@@ -429,7 +430,8 @@ APP_ON_HIP = os.path.normpath(os.path.join(golden_io.GOLDEN, "..", "..", "oracle
                                        ("main_dra_10b", ["--output-bit-depth", "10"]), ("main_htdf_all_tools_10b", ["--output-bit-depth", "10"]),
                                        ("main_ibc_all_tools_10b", ["--output-bit-depth", "10"]), ("main_admvp_all_tools_10b", ["--output-bit-depth", "10"]), ("main_dmvr_all_tools_10b", ["--output-bit-depth", "10"]),
                                        ("main_tiles_3x2_all_tools_10b", ["--output-bit-depth", "10"]), ("main_tiles_explicit_10b", []),
-                                       ("main_affine_all_tools_10b", ["--output-bit-depth", "10"])])
+                                       ("main_affine_all_tools_10b", ["--output-bit-depth", "10"]), ("main_every_tool_10b", ["--output-bit-depth", "10"]),
+                                       ("main_dmvr_hmvp_mmvd_b_8b", [])])
 def test_gpu_reference_application_on_our_api(name, args, tmp_path):
     """The reference's OWN sample application (app/xevd_app.c, compiled from its source where it lies) linked against libxevd_amd_api.so - this
     repository's implementation of the public xevd_create / xevd_decode / xevd_pull API - instead of libxevd: it decodes the golden streams on
@@ -456,7 +458,12 @@ def test_gpu_reference_application_on_our_api(name, args, tmp_path):
 REF_DECODE_HIP = os.path.normpath(os.path.join(golden_io.GOLDEN, "..", "..", "oracle", "_ref", "ref_decode_hip"))
 # the Main-profile streams: the reference's Main library itself does not survive the Baseline ones (its entropy pass writes past ctx->cod_eco,
 # src_main/xevdm.c:1450-1455, on CTU rows that cross the picture's bottom edge) - those are the Baseline library's, tests/test_stream.py
-STREAM_NAMES = sorted(f[len("stream_"):-len(".npz")] for f in os.listdir(golden_io.GOLDEN) if f.startswith("stream_") and f.endswith(".npz") and "main_" in f)
+# ... and not the streams with tool_dmvr together with tool_hmvp / tool_mmvd: the refined vectors steer the reference parser's own candidate lists CU by CU, and a backend
+# behind the picture-granular slots (fn_dec_slice ...) reconstructs after the picture is parsed - our own front end runs the refinement search itself for those
+# (xevd_amd/host/dmvr_search.h); they are decoded by every other path below
+HOST_DMVR_STREAMS = {"main_dmvr_hmvp_mmvd_b_8b", "main_every_tool_10b", "main_every_tool_tiles_8b"}
+STREAM_NAMES = sorted(f[len("stream_"):-len(".npz")] for f in os.listdir(golden_io.GOLDEN)
+                      if f.startswith("stream_") and f.endswith(".npz") and "main_" in f and f[len("stream_"):-len(".npz")] not in HOST_DMVR_STREAMS)
 
 
 @pytest.mark.gpu
@@ -531,3 +538,38 @@ def test_gpu_plain_c_decoder_work_queue(tmp_path):
     for dst, want in expect:
         got = np.fromfile(dst, np.uint8)
         assert got.size == want.size and np.array_equal(got.astype(np.int32), want.astype(np.int32)), dst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("args", [["--workers", "1", "--tile-threads", "8"], ["--workers", "1", "--tile-threads", "8", "--no-pipeline"], ["--workers", "3", "--tile-threads", "2"]],
+                         ids=["pipelined", "back_to_back", "gop_parallel"])
+def test_gpu_bench_stream_plain_c_decoder(args, tmp_path):
+    """the real-bitstream leg of bench.py at 1920x1088: random-access Main (hierarchical B, two lists of two references, tool_admvp, IQT, ADDB, ALF, 4x4 tiles),
+    three IDR periods, decoded by examples/evc_decode - parser thread one picture ahead of the device thread, back to back, and GOP-parallel - must be the
+    pictures parser + oracle reconstruct (which tests/test_stream.py pins to the reference decoder for this stream shape)"""
+    import subprocess
+    import sys
+    import stream_util as su
+    root = os.path.normpath(os.path.join(golden_io.GOLDEN, "..", ".."))
+    sys.path.insert(0, root)
+    import bench
+    wl = dict(bench.WORKLOADS["cfg4_main_8k_10b_ra"])
+    wl["w"], wl["h"] = 1920, 1088
+    one, data, _ = bench.write_bench_stream(wl, 17, 3, seed=9)
+    exe = os.path.join(root, "examples", "evc_decode")
+    src, dst = tmp_path / "s.evc", tmp_path / "s.yuv"
+    src.write_bytes(data)
+    r = subprocess.run([exe] + args + [str(src), str(dst)], stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode == 0, r.stderr.decode()[-300:]
+    ref = su.decode_oracle(one)
+    expect = np.concatenate([ref[k][c].ravel() for k in range(17) for c in range(3)]).astype(np.int32)
+    got = np.fromfile(dst, "<u2").astype(np.int32)
+    assert got.size == 3 * expect.size
+    for period in range(3):
+        g = got[period * expect.size:(period + 1) * expect.size]
+        if not np.array_equal(g, expect):
+            el = 1920 * 1088 * 3 // 2
+            bad = [k for k in range(17) if not np.array_equal(g[k * el:(k + 1) * el], expect[k * el:(k + 1) * el])]
+            k = bad[0]
+            d = np.flatnonzero(g[k * el:k * el + 1920 * 1088] != expect[k * el:k * el + 1920 * 1088])
+            assert False, f"IDR period {period}: pictures {bad} differ; first luma differences of picture {k} at (y, x) {[(int(i) // 1920, int(i) % 1920) for i in d[:6]]} ({len(d)} samples)"

@@ -153,6 +153,20 @@ CONFIGS = [
     (512, 320, 5, dict(main=True, iqt=True, addb=True, alf=True, eipd=True, admvp=True, bit_depth=10, tiles=(3, 3, 0, (1, 5), (2, 1)))),
     (712, 72, 4, dict(main=True, iqt=True, alf=True, addb=True, tiles=(7, 1, 0))),
     (200, 328, 4, dict(main=True, iqt=True, alf=True, tiles=(1, 5, 1))),
+    # tool_dmvr TOGETHER with tool_hmvp / tool_mmvd (what Main-profile encoders switch on): the refined vectors are state of the picture's own parse (history
+    # buffer, merge list of MMVD CUs), so the front end runs the refinement search itself on the decoded reference samples (xevd_amd/host/dmvr_search.h;
+    # decode_oracle registers them with xhost_parser_set_ref_luma, the stream writer gets them through xhost_writer_set_ref_luma)
+    (136, 136, 9, dict(main=True, admvp=True, dmvr=True, hmvp=True, iqt=True, addb=True, log2_sub_gop=2, max_refs=2)),
+    (264, 200, 17, dict(main=True, admvp=True, dmvr=True, mmvd=True, iqt=True, addb=True, log2_sub_gop=3, max_refs=2, bit_depth=10)),
+    (200, 136, 9, dict(main=True, admvp=True, dmvr=True, hmvp=True, mmvd=True, amvr=True, log2_sub_gop=2, max_refs=4, skip_frac=0.3, direct_frac=0.4)),
+    (200, 136, 8, dict(main=True, admvp=True, dmvr=True, hmvp=True, mmvd=True, inter_frac=0.9, max_refs=4, skip_frac=0.3, direct_frac=0.3)),
+    (392, 264, 9, dict(main=True, admvp=True, amvr=True, hmvp=True, mmvd=True, dmvr=True, affine=True, iqt=True, addb=True, alf=True, inter_frac=0.95, skip_frac=0.3, direct_frac=0.3,
+                       max_refs=2, log2_sub_gop=2, tiles=(2, 2, 0))),
+    # every Main tool the front end knows at once - the shape of a real Main-profile encode
+    (264, 200, 17, dict(main=True, btt=(2, 0, 0, 0), admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, dmvr=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True,
+                        cm_init=True, adcc=True, rpl=True, pocs=True, qp_delta_area=8, max_refs=2, log2_sub_gop=3, split_prob=0.7, bit_depth=10, inter_frac=0.9, skip_frac=0.3, direct_frac=0.3)),
+    (264, 200, 9, dict(main=True, btt=(2, 0, 0, 0), admvp=True, dual_tree=True, affine=True, amvr=True, hmvp=True, mmvd=True, dmvr=True, iqt=True, ats=True, addb=True, alf=True, eipd=True,
+                       htdf=True, ibc_log_max=4, cm_init=True, adcc=True, qp_delta_area=8, max_refs=2, log2_sub_gop=2, split_prob=0.7, bit_depth=10, inter_frac=0.7, skip_frac=0.3, direct_frac=0.3)),
 ]
 
 
@@ -164,13 +178,14 @@ def test_stream_reference_decoder_equals_parser_plus_oracle(cfg):
     w, h, n, kw = cfg
     data = su.make_stream(w, h, n, seed=w * 7 + n, **kw)
     ref = su.decode_reference(data, w, h, main=bool(kw.get("main")))
-    ours = su.decode_oracle(data)
+    pics = []
+    ours = su.decode_oracle(data, keep_params=pics)
     assert len(ref) == n and len(ours) == n
+    if kw.get("dmvr") and (kw.get("hmvp") or kw.get("mmvd")) and kw.get("log2_sub_gop"):      # refinement candidates exist: merge-mode CUs with two references, 8x8 and up
+        assert sum(int(((p["batch"]["dmvr"] > 0) & (p["batch"]["refi"].min(1) >= 0) & (p["batch"]["log2w"] >= 3) & (p["batch"]["log2h"] >= 3)).sum()) for p in pics if p["batch"]["dmvr"] is not None) >= 10
     if kw.get("ats"):      # the stream really carries both kinds of ATS CUs
-        pics = stream.parse_stream(data)
         assert sum(int((p["batch"]["ats"] & 1).sum()) for p in pics) > 0 and sum(int((p["batch"]["ats_inter"] != 0).sum()) for p in pics) > 0
     if kw.get("eipd"):     # angular luma modes and all five chroma modes occur
-        pics = stream.parse_stream(data)
         intra = np.concatenate([p["batch"]["ipm"][p["batch"]["pred_mode"] == 0] for p in pics])
         assert len(set(intra[:, 0].tolist())) > 20 and set(intra[:, 1].tolist()) == {0, 1, 2, 3, 4}
     for k in range(n):
@@ -287,3 +302,28 @@ def test_parser_survives_mutated_streams():
         except RuntimeError:
             outcomes["error"] += 1
     assert outcomes["error"] > 100 and outcomes["pictures"] > 100
+
+
+@pytest.mark.ref
+def test_bench_stream_reference_decoder_equals_parser_plus_oracle():
+    """the stream bench.py decodes in its real-bitstream leg (write_bench_stream: random-access Main, two lists of two references, tool_admvp, IQT, ADDB,
+    ALF, 4x4 tiles; one closed GOP repeated): at a small size, the reference decoder == parser + oracle, and every repeated IDR period decodes to the
+    same pictures - which is what lets the bench compare all periods against ONE period of the reference decoder"""
+    if not su.have_ref_decoder():
+        pytest.skip("oracle/_ref is not built")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    wl = dict(bench.WORKLOADS["cfg4_main_8k_10b_ra"])
+    wl["w"], wl["h"] = 328, 264
+    one, data, what = bench.write_bench_stream(wl, 17, 2, seed=5)
+    assert "random access" in what
+    pics = stream.parse_stream(data)
+    assert len(pics) == 34 and sum(p["slice_type"] == stream.SLICE_B for p in pics) == 2 * 14 and all(p["batch"]["tiles"] is not None for p in pics)
+    ref = su.decode_reference(data, wl["w"], wl["h"], main=True)
+    ours = su.decode_oracle(data)
+    assert len(ref) == 34 and len(ours) == 34
+    for k in range(34):
+        for c in range(3):
+            assert np.array_equal(ref[k][c], ours[k][c]), f"picture {k} plane {c}"
+            assert np.array_equal(ours[k][c], ours[k % 17][c]), f"IDR period 2, picture {k % 17}, plane {c}"

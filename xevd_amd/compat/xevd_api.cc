@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <vector>
 #include "xevd_host.h"
 
@@ -93,6 +94,7 @@ struct Decoder {
     int epoch = -1, last_key_poc = -1, pic_cnt = 0;
     bool decoded_since_pull = false, use_sig = false;
     Image *last = nullptr;                 // the picture a signature SEI refers to (it stays in `pending` or with the caller)
+    std::map<int, std::vector<int16_t>> ref_luma;      // by device picture slot: host copies of decoded luma planes for the parser's own DMVR search
     int w = 0, h = 0, bd = 8;
     Decoder() { memset(dpb, 0, sizeof(dpb)); }
 };
@@ -151,6 +153,13 @@ int decode_picture(Decoder *d, const xhost_picture &p, Image **out)
         rc = xgpu_batch_dmvr_mvs(d->g, db, mv.data(), p.n_dmvr_sub);
         if (rc == p.n_dmvr_sub) rc = xhost_parser_set_dmvr_mvs(d->ps, mv.data(), p.n_dmvr_sub);
         else if (rc >= 0) rc = XGPU_ERR_UNEXPECTED;
+    }
+    if (rc >= 0 && p.needs_ref_luma) {      // tool_dmvr with tool_hmvp / tool_mmvd: the parser refines vectors itself and reads this picture's decoded luma for it
+        std::vector<int16_t> &buf = d->ref_luma[cur];
+        const int stride = p.width + 2 * XGPU_PAD_L;
+        buf.resize((size_t)stride * (p.height + 2 * XGPU_PAD_L));
+        rc = xgpu_pic_download_padded(d->g, cur, buf.data(), nullptr, nullptr);
+        if (rc >= 0) rc = xhost_parser_set_ref_luma(d->ps, p.poc, buf.data() + (size_t)XGPU_PAD_L * stride + XGPU_PAD_L, stride);
     }
     if (db) xgpu_batch_destroy(d->g, db);
     if (rc < 0) return rc;

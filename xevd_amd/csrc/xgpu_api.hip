@@ -305,6 +305,7 @@ static int copy_planes(xgpu_ctx *c, int pic, int16_t *y, int s_y, int16_t *u, in
     int16_t *host[3] = { y, u, v };
     int16_t *dev[3] = { p.y, p.u, p.v };
     for (int i = 0; i < 3; i++) {
+        if (!host[i]) continue;                           // a plane the caller did not ask for (xgpu_pic_download_padded with luma only)
         const int e = i ? ext_c : ext_l, hs = i ? s_c : s_y, ds = i ? p.s_c : p.s_l;
         const int w = (i ? c->sp.width >> 1 : c->sp.width) + 2 * e, h = (i ? c->sp.height >> 1 : c->sp.height) + 2 * e;
         int16_t *d = dev[i] - (size_t)e * ds - e;
@@ -327,7 +328,7 @@ int xgpu_pic_download(xgpu_ctx *c, int pic, int16_t *y, int s_y, int16_t *u, int
 }
 int xgpu_pic_download_padded(xgpu_ctx *c, int pic, int16_t *by, int16_t *bu, int16_t *bv)
 {
-    ARGCHK(c, c != NULL); ARGCHK(c, valid_pic(c, pic)); ARGCHK(c, by && bu && bv);
+    ARGCHK(c, c != NULL); ARGCHK(c, valid_pic(c, pic)); ARGCHK(c, by && (bu != NULL) == (bv != NULL));
     return copy_planes(c, pic, by, c->sp.width + 2 * XGPU_PAD_L, bu, bv, (c->sp.width >> 1) + 2 * XGPU_PAD_C, XGPU_PAD_L, XGPU_PAD_C, false);
 }
 int xgpu_pic_upload_padded(xgpu_ctx *c, int pic, const int16_t *by, const int16_t *bu, const int16_t *bv)

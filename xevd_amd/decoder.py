@@ -139,6 +139,12 @@ class XgpuDecoder:
         self._chk(self.lib.xgpu_pic_download_padded(self.ctx, pic, y.ctypes.data, u.ctypes.data, v.ctypes.data), "xgpu_pic_download_padded")
         return [y, u, v]
 
+    def pic_download_padded_luma(self, pic):
+        """the padded luma plane alone (what a front end that refines vectors itself registers with xhost_parser_set_ref_luma)"""
+        y = np.zeros((self.height + 2 * abi.PAD_L, self.width + 2 * abi.PAD_L), np.int16)
+        self._chk(self.lib.xgpu_pic_download_padded(self.ctx, pic, y.ctypes.data, None, None), "xgpu_pic_download_padded")
+        return y
+
     # -- per picture ---------------------------------------------------------------------------------
     def frame_begin(self, pic, poc, refs, qp_u_offset=0, qp_v_offset=0, deblock_on=0, alf_on=0, alpha_off=0, beta_off=0):
         """refs: {(idx, list): (pic_slot, poc)}"""

@@ -9,6 +9,7 @@
 // see the same neighbour state because both walk the CUs in the same order and "reconstructed" (COD) == "already parsed".
 #include "../../include/xevd_host.h"
 #include "alf_fixed_tables.h"
+#include "dmvr_search.h"
 #include "cm_init_tables.h"
 #include "../csrc/affine_model.h"
 
@@ -283,6 +284,9 @@ struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, lo
              int profile_main = 0, tool_iqt = 0, tool_ats = 0, tool_addb = 0, tool_alf = 0, tool_eipd = 0, tool_dra = 0, tool_htdf = 0;
              int tool_mmvd = 0;                      // sps->tool_mmvd: merge with vector difference (a base candidate plus one of 32 offsets)
              int tool_dmvr = 0;                      // sps->tool_dmvr: merge-mode motion is refined by the backend (no syntax of its own)
+             // ... and by the front end itself when refined vectors are decoder state inside the picture: the history buffer (tool_hmvp) and the merge
+             // list of MMVD CUs (tool_mmvd) read them (dmvr_search.h)
+             bool host_dmvr() const { return tool_dmvr && (tool_hmvp || tool_mmvd); }
              int tool_amvr = 0, tool_hmvp = 0;       // sub-tools of tool_admvp: adaptive vector resolution (mvr_idx), history-based candidates
              int tool_rpl = 0, tool_pocs = 0, poc_lsb_bits = 4;      // sps->tool_rpl: reference lists and marking from signalled RPLs; tool_pocs: POC from poc_lsb in the slice header
              int n_rpl[2] = { 0, 0 }; Rpl rpls[2][32];               // RPL candidates of the SPS (sps->rpls_l0 / rpls_l1)
@@ -347,6 +351,8 @@ struct RefPic {          // what a decoded picture leaves behind for later pictu
     std::vector<int16_t> mv;         // [f_scu][2][2] and
     std::vector<int8_t> refi;        // [f_scu][2]: both lists (tool_admvp's temporal candidates read them)
     int list_poc[16] = { 0 };        // pic->list_poc[]: POCs of ITS list-0 references (indexed by reference indices of EITHER list, xevdm_util.c:3760-3761)
+    const int16_t *luma = nullptr;   // the decoded picture's luma samples on the host (sample (0, 0), >= 144 samples of replicated border), registered by the caller
+    int luma_stride = 0;             //   when the front end refines vectors itself (xhost_parser_set_ref_luma; dmvr_search.h)
 };
 
 struct Cu {
@@ -380,12 +386,14 @@ struct Picture {         // SCU maps of the picture being parsed / written (ctx-
     std::vector<uint8_t> aff;        // sps->tool_affine: 0, or affine_flag | log2w << 2 | log2h << 5 of the affine CU the SCU belongs to (MCU_GET_AFF + map_affine)
     std::vector<uint32_t> aff_tl;    //   ... and the SCU address of that CU's top-left corner (MCU_GET_AFF_XOFF / _YOFF)
     std::vector<int8_t> ipm;
-    std::vector<int16_t> mv;         // [f_scu][2][2]
+    std::vector<int16_t> mv;         // [f_scu][2][2]: the CUs' own vectors (mctx->map_unrefined_mv)
+    std::vector<int16_t> mv_ref;     // host-side DMVR (Sps::host_dmvr): ctx->map_mv - the refined vectors of refined sub-blocks, the CU's own elsewhere; else empty
     std::vector<int8_t> refi;        // [f_scu][2]
-    void reset(int w, int h)
+    void reset(int w, int h, bool refined_map = false)
     {
         w_scu = w >> 2; h_scu = h >> 2;
         const size_t f = (size_t)w_scu * h_scu;
+        if (refined_map) mv_ref.assign(f * 4, 0); else mv_ref.clear();
         cod.assign(f, 0); intra.assign(f, 0); ibc.assign(f, 0); ipm.assign(f, 0); mv.assign(f * 4, 0); refi.assign(f * 2, -1); tidx.clear(); aff.clear(); skip.clear(); cu_size.clear();
     }
 };
@@ -736,9 +744,10 @@ struct Stream {          // everything both directions share
         RefPic r;
         r.poc = poc; r.tid = tid; r.list0_poc = stale_list0_poc;
         const size_t f = (size_t)pic.w_scu * pic.h_scu;
+        const std::vector<int16_t> &kept = pic.mv_ref.empty() ? pic.mv : pic.mv_ref;      // ctx->map_mv: with host-side DMVR the refined vectors
         r.mv0.resize(f * 2);
-        for (size_t k = 0; k < f; k++) { r.mv0[k * 2] = pic.mv[k * 4]; r.mv0[k * 2 + 1] = pic.mv[k * 4 + 1]; }
-        if (sps.tool_admvp) { r.mv = pic.mv; r.refi = pic.refi; memcpy(r.list_poc, stale_list_poc, sizeof(r.list_poc)); }
+        for (size_t k = 0; k < f; k++) { r.mv0[k * 2] = kept[k * 4]; r.mv0[k * 2 + 1] = kept[k * 4 + 1]; }
+        if (sps.tool_admvp) { r.mv = kept; r.refi = pic.refi; memcpy(r.list_poc, stale_list_poc, sizeof(r.list_poc)); }
         dpb.push_back(std::move(r));
     }
 
@@ -851,8 +860,11 @@ struct TileCoder {
         return have[0] | (have[1] << 1);
     }
     // xevdm_get_motion_merge_main (xevdm_util.c:1169-1391) without the history candidates (sps->tool_hmvp off): up to 6 candidates (4 for CUs of 32 samples)
-    void merge_candidates(const Cu &cu, Motion cand[6]) const
+    // refined: the spatial candidates come from the refined map (ctx->map_mv) - the list xevdm_get_mmvd_mvp_list builds for an MMVD CU (xevdm_util.c:246-247);
+    // the ordinary merge list reads the CUs' own vectors (map_unrefined_mv for refined neighbours, :1212-1216)
+    void merge_candidates(const Cu &cu, Motion cand[6], bool refined = false) const
     {
+        const std::vector<int16_t> &map_mv = (refined && !pic.mv_ref.empty()) ? pic.mv_ref : pic.mv;
         const int ws = pic.w_scu, hs = pic.h_scu, xs = cu.x >> 2, ys = cu.y >> 2, cuw = 1 << cu.log2w, cuh = 1 << cu.log2h, scup = ys * ws + xs;
         const int max_n = cuw * cuh <= 32 ? 4 : 6;
         const bool is_b = sh.type == XHOST_SLICE_B, bi = bi_applicable(cu);
@@ -875,7 +887,7 @@ struct TileCoder {
         int neb[5]; bool valid[5];
         adm_neighbours(cu, neb, valid);
         for (int k = 0; k < 5; k++) {
-            if (valid[k]) insert(&pic.refi[(size_t)neb[k] * 2], &pic.mv[(size_t)neb[k] * 4]);
+            if (valid[k]) insert(&pic.refi[(size_t)neb[k] * 2], &map_mv[(size_t)neb[k] * 4]);
             if (cnt == max_n - 1) break;
         }
         // temporal: the centre of the CU on the 8x8 grid, else below, else to the right (inside the CTU row / column)
@@ -934,7 +946,7 @@ struct TileCoder {
     void mmvd_motion(Cu &cu) const
     {
         Motion cand[6];
-        merge_candidates(cu, cand);
+        merge_candidates(cu, cand, true);
         const int grp = cu.mmvd_idx >> 7, base = (cu.mmvd_idx >> 5) & 3, kk = cu.mmvd_idx & 31;
         const bool is_b = sh.type == XHOST_SLICE_B, small = (1 << (cu.log2w + cu.log2h)) <= 32;
         auto rpoc = [&](int l, int r) -> int { return (r >= 0 && r < (int)refp[l].size()) ? refp[l][(size_t)r]->poc : 0; };      // REF_SET
@@ -1380,6 +1392,7 @@ struct TileCoder {
                 for (int y = h; y < h + shh; y++) for (int x = w; x < w + sw; x++) {
                     const size_t k = (size_t)scup + (size_t)y * ws + x;
                     pic.mv[k * 4 + l * 2] = (int16_t)vx; pic.mv[k * 4 + l * 2 + 1] = (int16_t)vy;
+                    if (!pic.mv_ref.empty()) { pic.mv_ref[k * 4 + l * 2] = (int16_t)vx; pic.mv_ref[k * 4 + l * 2 + 1] = (int16_t)vy; }      // map_mv and map_unrefined_mv agree outside refined CUs
                 }
             }
         }
@@ -1387,11 +1400,43 @@ struct TileCoder {
         for (int y = 0; y < h_cu; y++) for (int x = 0; x < w_cu; x++) { pic.aff[(size_t)scup + (size_t)y * ws + x] = tag; pic.aff_tl[(size_t)scup + (size_t)y * ws + x] = (uint32_t)scup; }
     }
     // SCU maps after a CU (xevd_set_dec_info, xevd_util.c:1574-1660; cod_eco xevd.c:797-803)
+    std::vector<int16_t> dmvr_scratch;
+    bool missing_ref = false;                            // host-side DMVR needed the samples of a reference picture the caller has not registered
     void commit(const Cu &cu)
     {
         if (cu.tree == 2) return;                        // a chroma-only CU leaves every map as its luma CUs wrote it (xevdm_set_dec_info, xevdm_util.c:4241)
-        if (sps.tool_hmvp && (cu.mode == MODE_INTER || cu.mode == MODE_SKIP)) history_push(cu);
         const int xs = cu.x >> 2, ys = cu.y >> 2, w = (1 << cu.log2w) >> 2, h = (1 << cu.log2h) >> 2;
+        // Host-side DMVR (Sps::host_dmvr): the refinement search of a merge-mode bi-predicted CU runs HERE, because the refined vectors are state of this
+        // picture's parse - the refined map below (MMVD merge lists, temporal candidates of later pictures) and the history buffer
+        int16_t refined[64][2][2];
+        bool is_refined = false;
+        if (sps.host_dmvr() && cu.dmvr && (cu.mode == MODE_INTER || cu.mode == MODE_SKIP) && !cu.affine && cu.refi[0] >= 0 && cu.refi[1] >= 0 &&
+            cu.refi[0] < (int)refp[0].size() && cu.refi[1] < (int)refp[1].size()) {
+            const RefPic *r0 = refp[0][(size_t)cu.refi[0]], *r1 = refp[1][(size_t)cu.refi[1]];
+            if (dmvr_search_applies(poc, r0->poc, r1->poc, 1 << cu.log2w, 1 << cu.log2h)) {
+                if (!r0->luma || !r1->luma) missing_ref = true;
+                else {
+                    const DmvrRefPlane rp[2] = { { r0->luma, r0->luma_stride, r0->poc }, { r1->luma, r1->luma_stride, r1->poc } };
+                    dmvr_search_cu(pic.w_scu << 2, pic.h_scu << 2, sps.bd_l, cu.x, cu.y, 1 << cu.log2w, 1 << cu.log2h, cu.mv, rp, refined, dmvr_scratch);
+                    is_refined = true;
+                }
+            }
+        }
+        if (sps.tool_hmvp && (cu.mode == MODE_INTER || cu.mode == MODE_SKIP)) {
+            if (is_refined) {                            // core->mv = map_mv[first SCU] before the history update (xevdm_util.c:4384-4387, xevdm.c:1335-1342)
+                Cu first = cu;
+                memcpy(first.mv, refined[0], sizeof(first.mv));
+                history_push(first);
+            } else history_push(cu);
+        }
+        if (!pic.mv_ref.empty()) {
+            const int sbw = std::min(w, 4), sbh = std::min(h, 4), per_row = w / sbw;      // 16x16 sub-blocks in SCUs
+            for (int r = 0; r < h; r++) for (int c = 0; c < w; c++) {
+                const size_t k = (size_t)(ys + r) * pic.w_scu + xs + c;
+                const int16_t (*v)[2] = is_refined ? refined[(r / sbh) * per_row + c / sbw] : cu.mv;
+                for (int l = 0; l < 2; l++) { pic.mv_ref[k * 4 + l * 2] = v[l][0]; pic.mv_ref[k * 4 + l * 2 + 1] = v[l][1]; }
+            }
+        }
         for (int r = 0; r < h; r++) for (int c = 0; c < w; c++) {
             const size_t k = (size_t)(ys + r) * pic.w_scu + xs + c;
             pic.cod[k] = 1; pic.intra[k] = cu.mode == MODE_INTRA; pic.ibc[k] = cu.mode == MODE_IBC; pic.ipm[k] = (int8_t)cu.ipm;
@@ -2077,6 +2122,7 @@ struct TileParser {
         const int w_ctu = (st.sps.width + 63) >> 6;
         batch.clear();
         n_coef = 0;
+        tc.missing_ref = false;
         if (st.sps.tool_cm_init) tc.models.reset_cm(sh.type == XHOST_SLICE_B, sh.qp); else tc.models.reset();
         tc.qp_prev = sh.qp;
         Dec dec;
@@ -2089,6 +2135,7 @@ struct TileParser {
             const int rc = st.sps.btt ? parse_node(dec, cx << 6, cy << 6, 6, 6, 0, false) : parse_tree(dec, cx << 6, cy << 6, 6);
             if (rc != XGPU_OK) return rc;
             if (br.overrun) return fail("slice data ends early");
+            if (tc.missing_ref) return fail("tool_dmvr with tool_hmvp / tool_mmvd: the samples of a reference picture are needed (xhost_parser_set_ref_luma)");
         }
         if (dec.tile_end() != 1) return fail("missing end-of-tile flag");
         return XGPU_OK;
@@ -2182,7 +2229,19 @@ struct xhost_parser {
     Stream st;
     std::vector<std::unique_ptr<TileParser>> tiles;      // one per tile of the current picture (kept between pictures)
     Batch merged;                                        // several tiles: their batches, tile by tile
-    Batch *cur = &merged;                                // the batch of the picture handed out last
+    // What a handed-out xhost_picture points at lives in a ring of `held.size()` slots (xhost_parser_set_depth, default 1): the arrays of picture k
+    // stay untouched until the call that hands out picture k + depth - so a caller can build and launch picture k on one thread while another
+    // one is inside xhost_parser_next for picture k + 1 (depth 2).  The batch arrays are swapped into the slot (no copy), the small tables copied.
+    struct Held {
+        Batch batch;
+        int16_t alf_luma[25][13], alf_chroma[7];
+        std::vector<uint8_t> ctb;
+        std::vector<int32_t> dra;
+        xgpu_tile_grid grid;
+    };
+    std::vector<Held> held = std::vector<Held>(1);
+    size_t n_handed = 0;
+    Batch *cur = &merged;                                // the batch of the picture handed out last (in its ring slot)
     size_t n_coef = 0;
     int n_threads = 1;                                   // xhost_parser_set_threads
     std::string err;
@@ -2264,13 +2323,10 @@ struct xhost_parser {
             s.dquant = br.get1();                        // dquant_flag: QP deltas per quantisation group of pps.cu_qp_delta_area (xevdm.c:1739-1759, xevdm_eco.c:882-897)
             s.tool_dra = br.get1();
         }
-        // tool_dmvr with tool_hmvp: xevdm_set_dec_info ends by copying map_mv[first SCU] - the REFINED vector of the CU's first sub-block - back into
-        // core->mv (xevdm_util.c:4384-4387), and that is what the history buffer then receives (xevdm.c:1335-1342): the merge candidates of the NEXT CUs of
-        // the same picture depend on the refinement search, i.e. on reference SAMPLES.  A front end that hands whole pictures to the backend cannot follow that.
-        // ... and tool_mmvd builds its base candidates from ctx->map_mv, the REFINED vectors of refined neighbours (xevdm_get_mmvd_mvp_list passes no
-        // unrefined map, xevdm_util.c:246-247): the same dependency
-        if (s.tool_dmvr && s.tool_mmvd) return fail("tool_dmvr together with tool_mmvd: the base candidates depend on refined vectors inside the picture (not supported)");
-        if (s.tool_dmvr && s.tool_hmvp) return fail("tool_dmvr together with tool_hmvp: the history candidates depend on refined vectors inside the picture (not supported)");
+        // tool_dmvr with tool_hmvp / tool_mmvd: xevdm_set_dec_info ends by copying map_mv[first SCU] - the REFINED vector of the CU's first sub-block - back into
+        // core->mv (xevdm_util.c:4384-4387), which is what the history buffer then receives (xevdm.c:1335-1342), and an MMVD CU builds its merge list from
+        // ctx->map_mv, the refined vectors (xevdm_util.c:246-247): the syntax of later CUs of the SAME picture depends on the refinement search.  The
+        // front end then searches itself (TileCoder::commit, dmvr_search.h) on the reference samples the caller registers (xhost_parser_set_ref_luma)
         if (unsupported) return fail("the stream uses tools this front end does not parse (sps_suco_flag)");
         // xevdm_eco.c:1920-1961: POC lsb width (tool_pocs), the sub-GOP description unless both tools are on, and either the sliding-window size or the RPL candidates
         s.tool_rpl = rpl; s.tool_pocs = pocs;
@@ -2440,7 +2496,7 @@ struct xhost_parser {
         for (int l = 0; l < 2; l++)
             for (const RefPic *r : st.refp[l])
                 if (r->mv0.size() != (size_t)(st.sps.width >> 2) * (st.sps.height >> 2) * 2) return fail("reference picture of another geometry");
-        st.pic.reset(st.sps.width, st.sps.height);
+        st.pic.reset(st.sps.width, st.sps.height, st.sps.host_dmvr());
         if (!st.setup_tiles()) return fail("the tile grid of the PPS does not fit the picture");
 
         // ---- tile data (xevdm_dec_slice + xevd_tile_eco, src_main/xevdm.c:2363-2461, 2614-2718): every tile is its own arithmetic-coder
@@ -2484,8 +2540,11 @@ struct xhost_parser {
             });
             cur = &merged; n_coef = cf0[(size_t)n_tiles];
         }
+        cur->ctu_start.push_back((uint32_t)cur->x.size());
+        Held &hd = held[n_handed++ % held.size()];
+        std::swap(hd.batch, *cur);                       // the parser's working vectors take over the slot's old storage (cleared / resized at their next use)
+        cur = &hd.batch;
         Batch &batch = *cur;
-        batch.ctu_start.push_back((uint32_t)batch.x.size());
 
         // ---- hand-over ----
         memset(out, 0, sizeof(*out));
@@ -2511,16 +2570,19 @@ struct xhost_parser {
                 if (st.sps.cqt) cq[c] = st.sps.cq[c] + off;
                 else { for (int q = -off; q <= 57; q++) dflt[c][q + off] = q >= 0 ? (st.sps.tool_iqt ? k_chroma_qp_main : k_chroma_qp)[q] : 0; cq[c] = dflt[c] + off; }
             }
-            dra_build_luts(d, st.sps.bd_l, cq[0], cq[1], off, st.dra_luts);
-            for (int c = 0; c < 3; c++) out->dra_lut[c] = st.dra_luts + 1024 * c;
+            hd.dra.resize(3 * 1024);
+            dra_build_luts(d, st.sps.bd_l, cq[0], cq[1], off, hd.dra.data());
+            for (int c = 0; c < 3; c++) out->dra_lut[c] = hd.dra.data() + 1024 * c;
         }
         for (int i = 0; i < 4; i++) out->crop[i] = st.sps.crop[i];
         out->chroma_qp_table[0] = st.sps.cqt ? st.sps.cq[0] : nullptr; out->chroma_qp_table[1] = st.sps.cqt ? st.sps.cq[1] : nullptr;
         if (sh.alf_on) {
             if (!st.alf_finalise()) return fail("slice refers to an ALF parameter set that was not sent");
             out->alf.enable[0] = 1; out->alf.enable[1] = sh.alf_chroma_idc & 1; out->alf.enable[2] = (sh.alf_chroma_idc >> 1) & 1;
-            out->alf.luma_coef = &st.alf_luma_final[0][0]; out->alf.chroma_coef = st.alf_chroma_final;
-            out->alf.ctb_flag = st.alf_ctb_flag.data(); out->alf.across_tiles = st.pps.across_tiles; out->alf.tiles = n_tiles > 1 ? &st.grid : nullptr;
+            memcpy(hd.alf_luma, st.alf_luma_final, sizeof(hd.alf_luma)); memcpy(hd.alf_chroma, st.alf_chroma_final, sizeof(hd.alf_chroma));
+            hd.ctb = st.alf_ctb_flag;
+            out->alf.luma_coef = &hd.alf_luma[0][0]; out->alf.chroma_coef = hd.alf_chroma;
+            out->alf.ctb_flag = hd.ctb.data(); out->alf.across_tiles = st.pps.across_tiles; out->alf.tiles = n_tiles > 1 ? &hd.grid : nullptr;
         }
         std::vector<int> released;
         st.store_picture(nut == NUT_IDR, released);
@@ -2538,14 +2600,16 @@ struct xhost_parser {
         b.coef = batch.coef.data(); b.n_coef = batch.x.empty() ? 0 : n_coef;
         b.n_ctu = w_ctu * h_ctu; b.ctu_cu_start = batch.ctu_start.data();
         b.constrained_intra_pred = st.pps.constrained_intra;
-        b.tiles = n_tiles > 1 ? &st.grid : nullptr;
+        hd.grid = st.grid;
+        b.tiles = n_tiles > 1 ? &hd.grid : nullptr;
         b.htdf_slice_qp = st.sps.tool_htdf ? sh.qp : 0;
         // sps->tool_dmvr: the merge-mode flags, and how many 16x16 sub-blocks of candidates (flag, two references, at least 8x8 - the order of
         // xgpu_batch_dmvr_mvs) the backend will report vectors for; they go back in through xhost_parser_set_dmvr_mvs before the next picture
         out->n_dmvr_sub = 0;
         last_poc = st.poc; last_stored = st.is_ref_picture();
-        if (st.sps.tool_dmvr) {
-            b.dmvr = batch.dmvr.data();
+        out->needs_ref_luma = st.sps.host_dmvr() && st.is_ref_picture();
+        if (st.sps.tool_dmvr) b.dmvr = batch.dmvr.data();
+        if (st.sps.tool_dmvr && !st.sps.host_dmvr()) {      // (host-side refinement: nothing comes back from the backend)
             for (int i = 0; i < b.n_cu; i++)
                 if (batch.dmvr[(size_t)i] && batch.refi[(size_t)i * 2] >= 0 && batch.refi[(size_t)i * 2 + 1] >= 0 && batch.log2w[(size_t)i] >= 3 && batch.log2h[(size_t)i] >= 3)
                     out->n_dmvr_sub += (batch.log2w[(size_t)i] > 4 ? 1 << (batch.log2w[(size_t)i] - 4) : 1) * (batch.log2h[(size_t)i] > 4 ? 1 << (batch.log2h[(size_t)i] - 4) : 1);
@@ -2560,7 +2624,7 @@ struct xhost_parser {
     int set_dmvr_mvs(const int16_t *mv, int n)
     {
         if (n != last_n_dmvr || (n > 0 && !mv)) return fail("xhost_parser_set_dmvr_mvs: not the sub-block count of the last picture");
-        if (!last_stored || n == 0) return 0;
+        if (!last_stored || n == 0 || st.sps.host_dmvr()) return 0;
         RefPic *r = nullptr;
         for (RefPic &q : st.dpb) if (q.poc == last_poc) r = &q;
         if (!r || r->mv.empty()) return 0;
@@ -2583,6 +2647,20 @@ extern "C" xhost_parser *xhost_parser_open(const uint8_t *bytes, size_t size)
     xhost_parser *p = new xhost_parser();
     p->data.assign(bytes, bytes + size);
     return p;
+}
+// the decoded luma samples of the picture with this POC, for the front end's own refinement search (Sps::host_dmvr)
+static int set_ref_luma(Stream &st, int poc, const int16_t *plane, int stride)
+{
+    if (!plane || stride <= 0) return XGPU_ERR_INVALID_ARGUMENT;
+    for (RefPic &r : st.dpb) if (r.poc == poc) { r.luma = plane; r.luma_stride = stride; return XGPU_OK; }
+    return XGPU_OK;                                      // not kept as a reference: nothing will read it
+}
+extern "C" int xhost_parser_set_ref_luma(xhost_parser *p, int poc, const int16_t *plane, int stride) { return p ? set_ref_luma(p->st, poc, plane, stride) : XGPU_ERR_INVALID_ARGUMENT; }
+extern "C" int xhost_parser_set_depth(xhost_parser *p, int depth)
+{
+    if (!p || depth < 1 || depth > 8 || p->n_handed) return XGPU_ERR_INVALID_ARGUMENT;      // before the first picture
+    p->held = std::vector<xhost_parser::Held>((size_t)depth);
+    return XGPU_OK;
 }
 extern "C" int xhost_parser_set_threads(xhost_parser *p, int n) { if (!p || n < 1) return XGPU_ERR_INVALID_ARGUMENT; p->n_threads = std::min(n, 64); return XGPU_OK; }
 extern "C" int xhost_parser_set_dmvr_mvs(xhost_parser *p, const int16_t *mv, int n_sub) { return p ? p->set_dmvr_mvs(mv, n_sub) : XHOST_ERR_MALFORMED; }
@@ -2788,7 +2866,7 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
         }
     }
     w->sp.tool_mmvd = s.tool_admvp && sp->tool_mmvd; s.tool_mmvd = w->sp.tool_mmvd;
-    w->sp.tool_dmvr = s.tool_admvp && sp->tool_dmvr && !s.tool_hmvp && !s.tool_mmvd; s.tool_dmvr = w->sp.tool_dmvr;      // not with tool_hmvp (see the parser)
+    w->sp.tool_dmvr = s.tool_admvp && sp->tool_dmvr; s.tool_dmvr = w->sp.tool_dmvr;      // with tool_hmvp / tool_mmvd the writer needs the reference samples too (xhost_writer_set_ref_luma)
     w->sp.ibc_log_max_size = (s.tool_eipd && sp->ibc_log_max_size >= 2 && sp->ibc_log_max_size <= 7) ? sp->ibc_log_max_size : 0;
     s.ibc = w->sp.ibc_log_max_size != 0; s.ibc_log_max = w->sp.ibc_log_max_size;
     {
@@ -2870,6 +2948,7 @@ extern "C" int xhost_writer_add_alf_aps(xhost_writer *w, const xhost_alf_aps *in
     w->st.alf_aps[in->aps_id] = parsed;
     return XGPU_OK;
 }
+extern "C" int xhost_writer_set_ref_luma(xhost_writer *w, int poc, const int16_t *plane, int stride) { return w ? set_ref_luma(w->st, poc, plane, stride) : XGPU_ERR_INVALID_ARGUMENT; }
 extern "C" int xhost_writer_add_md5_sei(xhost_writer *w, const uint8_t md5[3][16])
 {
     if (!w || !md5 || w->n_pics == 0) return XGPU_ERR_INVALID_ARGUMENT;
@@ -3187,7 +3266,7 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
     bw.put((uint32_t)slice_qp, 6);
     bw.se(st.sh.qp_u_offset); bw.se(st.sh.qp_v_offset);
 
-    st.pic.reset(st.sps.width, st.sps.height);
+    st.pic.reset(st.sps.width, st.sps.height, st.sps.host_dmvr());
     if (!st.setup_tiles()) return XGPU_ERR_INVALID_ARGUMENT;
     TreeWriter tw;
     tw.w = w; tw.b = b; tw.bd_off = 6 * (st.sps.bd_l - 8);

@@ -33,7 +33,16 @@ class StreamDecoder:
             for p in stream.iter_stream(self.data, consume_batch=to_device, threads=self.parser_threads):
                 if p["n_dmvr_sub"]:
                     p["_dmvr"] = [threading.Event(), None]
+                if p["needs_ref_luma"]:
+                    p["_luma"] = [threading.Event(), None]
                 q.put(p)
+                if p["needs_ref_luma"]:
+                    # tool_dmvr with tool_hmvp / tool_mmvd: the parser refines merge vectors itself while it parses the NEXT pictures and reads this
+                    # picture's decoded luma for it - the consumer downloads it (padded) right behind the picture's kernels
+                    while not p["_luma"][0].wait(0.05):
+                        if self._abort:
+                            return
+                    p["set_ref_luma"](p["poc"], p["_luma"][1], abi.PAD_L)
                 if p["n_dmvr_sub"]:
                     # sps->tool_dmvr: the temporal candidates of later pictures read this picture's REFINED vectors - the parser waits for the
                     # backend's (xgpu_batch_dmvr_mvs, fetched by the consumer right after the picture's kernels were queued)
@@ -72,6 +81,9 @@ class StreamDecoder:
                 if p["n_dmvr_sub"]:
                     p["_dmvr"][1] = dec.batch_dmvr_mvs(hb)
                     p["_dmvr"][0].set()
+                if p["needs_ref_luma"]:
+                    p["_luma"][1] = dec.pic_download_padded_luma(cur)
+                    p["_luma"][0].set()
                 dec.batch_destroy(hb)          # back to the pool; queued kernels keep reading it (same HIP stream)
             planes = None
             if download and output_bit_depth is not None:

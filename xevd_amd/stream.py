@@ -53,7 +53,7 @@ class HostPicture(C.Structure):
                 ("dra_lut", C.POINTER(C.c_int32) * 3),
                 ("alf_on", C.c_int), ("alf", abi.AlfParams),
                 ("has_md5", C.c_int), ("md5", (C.c_uint8 * 16) * 3),
-                ("n_dmvr_sub", C.c_int), ("n_release", C.c_int), ("release_poc", C.c_int * 32), ("batch", abi.CuBatch)]
+                ("n_dmvr_sub", C.c_int), ("needs_ref_luma", C.c_int), ("n_release", C.c_int), ("release_poc", C.c_int * 32), ("batch", abi.CuBatch)]
 
 
 _lib = None
@@ -72,6 +72,8 @@ def load():
         lib.xhost_parser_error.argtypes = [C.c_void_p]
         lib.xhost_parser_close.argtypes = [C.c_void_p]
         lib.xhost_parser_set_dmvr_mvs.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+        lib.xhost_parser_set_ref_luma.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        lib.xhost_writer_set_ref_luma.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         lib.xhost_parser_set_threads.argtypes = [C.c_void_p, C.c_int]
         lib.xhost_writer_split_allowed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         lib.xhost_writer_open.restype = C.c_void_p
@@ -197,6 +199,12 @@ class StreamWriter:
         if rc != 0:
             raise RuntimeError(f"xhost_writer_add_md5_sei -> {rc}")
 
+    def set_ref_luma(self, poc, padded_plane, pad):
+        """tool_dmvr with tool_hmvp / tool_mmvd: the decoded luma of a picture already written (xhost_writer_set_ref_luma)"""
+        if not hasattr(self, "_luma_keep"):
+            self._luma_keep = {}
+        _ref_luma(self.lib.xhost_writer_set_ref_luma, self.h, self._luma_keep)(poc, padded_plane, pad)
+
     def bytes(self):
         p, n = C.c_void_p(), C.c_size_t()
         self.lib.xhost_writer_bytes(self.h, C.byref(p), C.byref(n))
@@ -223,6 +231,17 @@ def _feedback(lib, h):
     return feed
 
 
+def _ref_luma(fn, h, keep):
+    def give(poc, padded_plane, pad):
+        """padded_plane: int16 array [h + 2 pad][w + 2 pad] of the decoded picture with this POC (pad >= 144); kept alive with the parser / writer"""
+        a = np.ascontiguousarray(padded_plane, np.int16)
+        keep[poc] = a
+        rc = fn(h, int(poc), C.c_void_p(a.ctypes.data + 2 * (pad * a.shape[1] + pad)), int(a.shape[1]))
+        if rc < 0:
+            raise RuntimeError(f"set_ref_luma -> {rc}")
+    return give
+
+
 def iter_stream(data, consume_batch=None, threads=1):
     """generator over the pictures of a .evc byte string in decoding order: dict(params..., batch=dict of numpy arrays in the
     layout of synth.gen_frame).  The C parser runs inside each next() with the GIL released (ctypes).
@@ -233,6 +252,7 @@ def iter_stream(data, consume_batch=None, threads=1):
     h = lib.xhost_parser_open(buf, len(data))
     if threads > 1:      # the tiles of a picture on parallel host threads (xhost_parser_set_threads)
         lib.xhost_parser_set_threads(h, int(threads))
+    luma_keep = {}
     try:
         while True:
             hp = HostPicture()
@@ -274,7 +294,12 @@ def iter_stream(data, consume_batch=None, threads=1):
                 # sps->tool_dmvr: the number of sub-blocks whose vectors (xgpu_batch_dmvr_mvs / the oracle's dmvr_mv_out) must be handed to
                 # dmvr_feedback() before the generator is advanced - the temporal candidates of later pictures read them
                 "n_dmvr_sub": int(hp.n_dmvr_sub), "dmvr_feedback": _feedback(lib, h),
+                # tool_dmvr with tool_hmvp / tool_mmvd: the parser refines vectors itself while it parses later pictures and needs this picture's decoded
+                # luma (padded) for it: set_ref_luma(poc, padded_plane, pad) before the generator is advanced
+                "needs_ref_luma": bool(hp.needs_ref_luma), "set_ref_luma": _ref_luma(lib.xhost_parser_set_ref_luma, h, luma_keep),
             }
+            for gone in params["release"]:      # no longer in the parser's DPB: their registered luma planes can go
+                luma_keep.pop(gone, None)
             if consume_batch is not None:
                 params["batch"] = consume_batch(params, hp.batch)
             yield params
