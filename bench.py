@@ -104,7 +104,7 @@ def cpu_baseline(wl, first, batch, alf, budget_s=15.0):
     cb, keep = abi.make_cu_batch(batch)
     ref = ol.Picture(wl["w"], wl["h"], 0, first[0])
     ref.pad_numpy()
-    ref2 = ol.Picture(wl["w"], wl["h"], -1, first[1])
+    ref2 = ol.Picture(wl["w"], wl["h"], 2 if wl.get("dmvr_frac") else -1, first[1])      # DMVR: a B picture between its two references (as the timed steps)
     ref2.pad_numpy()
     cur = ol.Picture(wl["w"], wl["h"], 1)
     ap = keep_ap = None
@@ -379,6 +379,7 @@ def main():
     ap.add_argument("--batches", type=int, default=4, help="distinct pictures' CU batches kept resident and cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the batches-in -> YUV-out leg")
+    ap.add_argument("--no-prepare", action="store_true", help="every picture's residual pass in front of its own k_inter (no xgpu_batch_prepare of the next picture)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -437,17 +438,20 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         refs = {(0, 0): (slots[0], 0)}
         if two_lists:
-            refs[(0, 1)] = (slots[1], -1)
+            refs[(0, 1)] = (slots[1], 2 if wl.get("dmvr_frac") else -1)
         dec.decode_picture(slots[2], 1, refs, handles[0], alf=alf)
         gpu_check = dec.pic_download_padded(slots[2])
 
-    def step(k):
+    def step(k, ahead=False):
         # picture k+1 is predicted from picture k (list 0) and, with two lists, picture k-1 (list 1): a 3-slot DPB ring
         cur, ref0, ref1 = slots[(k + 2) % 3], slots[(k + 1) % 3], slots[k % 3]
         refs = {(0, 0): (ref0, k)}
         if two_lists:
             refs[(0, 1)] = (ref1, k + 2 if wl.get("dmvr_frac") else k - 1)      # DMVR: a B picture between its two references
-        dec.decode_picture(cur, k + 1, refs, handles[k % len(handles)], alf=alf)
+        # ahead: the NEXT picture's residual pass (it depends on nothing but its batch) is queued behind this picture's k_inter (xgpu_batch_prepare) - what a
+        # decoder does that has parsed picture k + 1 while picture k is being reconstructed; needs two resident batches
+        nxt = handles[(k + 1) % len(handles)] if ahead and len(handles) > 1 else None
+        dec.decode_picture(cur, k + 1, refs, handles[k % len(handles)], alf=alf, next_batch=nxt)
 
     def barrier():
         if dist is not None:
@@ -456,14 +460,15 @@ def main():
             torch.cuda.synchronize()
         dec.sync()
 
+    ahead = not args.no_prepare
     for k in range(args.warmup):
-        step(k)
+        step(k, ahead)
     barrier()
     per_rank = None
     t0 = time.perf_counter()
     if dist is None:
         for k in range(args.steps):
-            step(args.warmup + k)
+            step(args.warmup + k, ahead)
         barrier()
         dt = time.perf_counter() - t0
     else:
@@ -480,7 +485,7 @@ def main():
                 break
             n = min(GOP_PICTURES, world * args.steps - j * GOP_PICTURES)
             for _ in range(n):
-                step(k)
+                step(k, ahead)
                 k += 1
             mine += n
         if torch.cuda.is_available():
@@ -495,7 +500,9 @@ def main():
         dist.all_gather(g, torch.tensor([float(mine), my_dt], dtype=torch.float64))
         per_rank = [{"rank": r, "pictures": int(v[0].item()), "fps": round(float(v[0].item()) / max(float(v[1].item()), 1e-9), 2)} for r, v in enumerate(g)]
 
-    # per-kernel durations with HIP events on the stream the kernels are launched on, same workload and steps
+    # per-kernel durations with HIP events on the stream the kernels are launched on, same workload and steps - every kernel on the main stream, one after
+    # the other (no residual pass queued ahead), so that each duration is the kernel's own
+    dec.sync()
     dec.timing_enable(True)
     dec.timing_reset()
     for k in range(args.steps):
@@ -555,6 +562,7 @@ def main():
                        "stream": ("2 reference lists, 50% bi-predicted CUs" if two_lists else "IPPP, 1 reference")
                                  + ", 90% inter / 10% intra CUs (5 Baseline modes), 60% coded, deblock on, quad-tree 64..4",
                        "batches_resident": len(batches), "batch": batch_info,
+                       "residual_pass_ahead": bool(ahead and len(batches) > 1),
                        "parallelism": (f"{world} ranks, one GPU each, drawing jobs of {GOP_PICTURES} pictures (closed GOPs of independent streams) from one host work "
                                        "queue; no collective on the data path" if world > 1 else "1 stream on 1 GPU")},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

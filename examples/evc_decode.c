@@ -28,6 +28,7 @@
 #include <unistd.h>
 #include <fcntl.h>
 #include <pthread.h>
+#include <malloc.h>
 #include "xevd_host.h"
 #include "xevd_wq.h"
 
@@ -48,6 +49,10 @@ typedef struct {                                                    /* one worke
     const stream_t *streams;
     long pictures;
     double busy_s, setup_s;                                         /* time inside the units / inside context creation and picture allocation */
+    uint8_t *frames; size_t frames_cap; int frames_pinned;          /* the output pictures of a unit (pinned): kept across units - pinning gigabytes per GOP costs more than decoding it */
+    void *arena[4]; size_t arena_bytes[4]; int arena_busy[4];     /* pinned coefficient arenas handed to the parsers of this worker's units (kept across units) */
+    pthread_mutex_t arena_mu;
+    int arena_ok;
     int16_t *ref_luma[MAX_SLOTS + 2];                               /* host copies of decoded luma planes, by device picture (only for streams whose parser asks) */
     double parse_s, build_s;                                        /* inside xhost_parser_next (its own thread with the pipeline) / inside xgpu_batch_create */
 } worker_t;
@@ -76,17 +81,55 @@ static int worker_context(worker_t *w, const xhost_picture *p)
     sp.max_pics = MAX_SLOTS + 1;
     if (w->g && !p->chroma_qp_table[0] && !memcmp(&sp, &w->sp, sizeof(sp))) return 0;
     const double t0 = now_s();
+    pthread_mutex_lock(&w->arena_mu);                               /* the arenas belong to the context that goes away (a parser that still holds one only returns it) */
     if (w->g) { xgpu_close(w->g); w->g = NULL; }
+    for (int i = 0; i < 4; i++) { w->arena[i] = NULL; w->arena_bytes[i] = 0; }
+    pthread_mutex_unlock(&w->arena_mu);
+    if (w->frames && !w->frames_pinned) free(w->frames);
+    w->frames = NULL; w->frames_cap = 0;
     for (int i = 0; i < MAX_SLOTS + 2; i++) { free(w->ref_luma[i]); w->ref_luma[i] = NULL; }      /* sized for the old sequence */
     w->sp = sp;                                                     /* compared without the table pointers */
     w->n_slots = 0;
     sp.chroma_qp_table[0] = p->chroma_qp_table[0]; sp.chroma_qp_table[1] = p->chroma_qp_table[1];
-    CHECK(xgpu_open(&sp, &w->g));
+    xgpu_ctx *g = NULL;
+    CHECK(xgpu_open(&sp, &g));
+    pthread_mutex_lock(&w->arena_mu);
+    w->g = g;
+    pthread_mutex_unlock(&w->arena_mu);
     w->setup_s += now_s() - t0;
     return 0;
 }
 
+/* xhost_parser_set_arena callbacks: pinned host memory of the worker's context, so that xgpu_batch_create sends a picture's coefficients from where the
+   parser gathered them.  Called on the parser thread; the context appears when the first picture of the worker's first unit has been parsed - until
+   then there is nothing to allocate from and the parser keeps that picture's coefficients in its own memory. */
+static void *arena_alloc(void *user, size_t bytes)
+{
+    worker_t *w = (worker_t *)user;
+    void *out = NULL;
+    pthread_mutex_lock(&w->arena_mu);
+    xgpu_ctx *g = w->arena_ok ? w->g : NULL;                        /* not before this unit's context is settled (worker_context may replace it) */
+    for (int i = 0; i < 4 && !out && g; i++)
+        if (w->arena[i] && !w->arena_busy[i] && w->arena_bytes[i] >= bytes) { w->arena_busy[i] = 1; out = w->arena[i]; }
+    for (int i = 0; i < 4 && !out && g; i++)
+        if (!w->arena_busy[i]) {
+            if (w->arena[i]) { xgpu_host_free(g, w->arena[i]); w->arena[i] = NULL; }
+            if (xgpu_host_alloc(g, bytes, &w->arena[i]) == 0) { w->arena_bytes[i] = bytes; w->arena_busy[i] = 1; out = w->arena[i]; }
+            break;
+        }
+    pthread_mutex_unlock(&w->arena_mu);
+    return out;
+}
+static void arena_release(void *user, void *mem)
+{
+    worker_t *w = (worker_t *)user;
+    pthread_mutex_lock(&w->arena_mu);
+    for (int i = 0; i < 4; i++) if (w->arena[i] == mem) w->arena_busy[i] = 0;
+    pthread_mutex_unlock(&w->arena_mu);
+}
+
 static int g_tile_threads = 1;
+static int g_trace = 0;             /* --trace: one line per picture on stderr (slice type, CUs, stage times) */
 static int g_pipeline = 1;          /* --no-pipeline: parse and reconstruct every picture back to back on the worker's thread (the round-2 loop) */
 
 /* ---- the parser of a unit on its own thread, one picture ahead of the thread that drives the device ------------------------------------------------
@@ -98,6 +141,7 @@ typedef struct {
     xhost_parser *ps;
     xhost_picture pic[2];
     int rc[2];
+    double parse_ms[2];
     long produced, released;        /* pictures handed over by the parser thread / given back by the consumer */
     int stop;
     pthread_mutex_t mu;
@@ -117,6 +161,7 @@ static void *parser_thread(void *arg)
         const double t0 = now_s();
         const int rc = xhost_parser_next(q->ps, &q->pic[k & 1]);
         q->parse_s += now_s() - t0;
+        q->parse_ms[k & 1] = 1e3 * (now_s() - t0);
         pthread_mutex_lock(&q->mu);
         q->rc[k & 1] = rc;
         q->produced = k + 1;
@@ -148,6 +193,8 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
     if (!outs || !q.ps) { rc = -1; goto done; }
     if (g_tile_threads > 1) xhost_parser_set_threads(q.ps, g_tile_threads);      /* the tiles of a picture on parallel host threads */
     pthread_mutex_init(&q.mu, NULL); pthread_cond_init(&q.cv, NULL);
+    pthread_mutex_lock(&w->arena_mu); w->arena_ok = 0; pthread_mutex_unlock(&w->arena_mu);
+    xhost_parser_set_arena(q.ps, arena_alloc, arena_release, w);
     if (g_pipeline) {
         xhost_parser_set_depth(q.ps, 2);
         if (pthread_create(&th, NULL, parser_thread, &q) != 0) { rc = -1; goto done; }
@@ -168,17 +215,25 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
             const double t0 = now_s();
             prc = xhost_parser_next(q.ps, pp);
             q.parse_s += now_s() - t0;
+            q.parse_ms[k & 1] = 1e3 * (now_s() - t0);
         }
         if (prc < 0) { fprintf(stderr, "parser: %s\n", xhost_parser_error(q.ps)); FAIL(prc); }
         if (prc == 0) break;
         const xhost_picture p = *pp;                                 /* the arrays it points at stay valid until picture k is given back below */
         if (!have_ctx) {                                             /* first picture: the sequence parameters are known */
             TRY(worker_context(w, &p));
+            pthread_mutex_lock(&w->arena_mu); w->arena_ok = 1; pthread_mutex_unlock(&w->arena_mu);
             for (int i = 0; i < w->n_slots; i++) free_pic[n_free++] = w->slots[i];
             frame_bytes = xgpu_pic_output_size(w->g, out_bd_arg ? out_bd_arg : p.bit_depth_luma, 0, 0, 0, 0);
-            void *pin = NULL;
-            if (xgpu_host_alloc(w->g, (size_t)(expected > 0 ? expected : 1) * frame_bytes, &pin) == 0) { frames = (uint8_t *)pin; pinned = 1; }
-            else frames = (uint8_t *)malloc((size_t)(expected > 0 ? expected : 1) * frame_bytes);       /* pageable: the copies block, the result is the same */
+            const size_t need = (size_t)(expected > 0 ? expected : 1) * frame_bytes;
+            if (w->frames_cap < need) {                              /* the worker's output buffer grows to the largest unit it has seen */
+                if (w->frames) { if (w->frames_pinned) xgpu_host_free(w->g, w->frames); else free(w->frames); }
+                void *pin = NULL;
+                w->frames_pinned = xgpu_host_alloc(w->g, need, &pin) == 0;
+                w->frames = w->frames_pinned ? (uint8_t *)pin : (uint8_t *)malloc(need);       /* pageable: the copies block, the result is the same */
+                w->frames_cap = w->frames ? need : 0;
+            }
+            frames = w->frames; pinned = w->frames_pinned;
             if (!frames) FAIL(-1);
             have_ctx = 1;
         }
@@ -215,6 +270,8 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
         const double tb = now_s();
         TRY(xgpu_batch_create(w->g, &p.batch, &db));                /* the parser's arrays are consumed before the call returns */
         w->build_s += now_s() - tb;
+        if (g_trace) fprintf(stderr, "picture %ld: poc %d slice %s, %d CUs, %zu coefficients: parse %.2f ms, batch build %.2f ms\n", k, p.poc,
+                             p.slice_type == XHOST_SLICE_I ? "I" : p.slice_type == XHOST_SLICE_P ? "P" : "B", p.batch.n_cu, p.batch.n_coef, q.parse_ms[k & 1], 1e3 * (now_s() - tb));
         TRY(xgpu_frame_begin(w->g, &fp));
         TRY(xgpu_batch_recon(w->g, db));
         if (p.deblock_on) TRY(xgpu_deblock(w->g));
@@ -239,6 +296,7 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
             TRY(xgpu_pic_download_padded(w->g, cur, w->ref_luma[slot], NULL, NULL));
             TRY(xhost_parser_set_ref_luma(q.ps, p.poc, w->ref_luma[slot] + (size_t)XGPU_PAD_L * stride + XGPU_PAD_L, stride));
         }
+        TRY(xgpu_batch_wait_upload(w->g, db));                      /* the coefficient arena (the parser's, pinned) has left host memory: its slot may be parsed into again */
         xgpu_batch_destroy(w->g, db); db = NULL;
 
         if (n_pics >= expected) { fprintf(stderr, "more pictures than slice NAL units\n"); FAIL(-1); }
@@ -283,8 +341,7 @@ done:
     free(mv);
     if (db) xgpu_batch_destroy(w->g, db);
     if (rc < 0) {                                                   /* nothing is handed out on failure */
-        if (w->g) (void)xgpu_sync(w->g);                            /* queued downloads still write into `frames` */
-        if (frames) { if (pinned) xgpu_host_free(w->g, frames); else free(frames); }
+        if (w->g) (void)xgpu_sync(w->g);                            /* queued downloads still write into the worker's output buffer */
         free(outs);
         return rc;
     }
@@ -298,6 +355,7 @@ static void *worker_init(int device, void *user)
     worker_t *w = (worker_t *)calloc(1, sizeof(worker_t));
     if (!w) return NULL;
     w->device = device; w->streams = (const stream_t *)user;
+    pthread_mutex_init(&w->arena_mu, NULL);
     /* is the device there?  A worker without one leaves the queue to the others instead of failing their jobs */
     xgpu_seq_params sp;
     xgpu_ctx *probe = NULL;
@@ -327,7 +385,7 @@ static int worker_job(void *state, const xwq_job *job)
     else
         for (int i = 0; i < n && rc >= 0; i++)                       /* picture by picture, in output order, at the unit's place in the file */
             if (pwrite(s->fd, frames + outs[i].off, frame_bytes, (off_t)((size_t)(job->first_picture + i) * frame_bytes)) != (ssize_t)frame_bytes) { perror("pwrite"); rc = -1; }
-    if (pinned) xgpu_host_free(w->g, frames); else free(frames);
+    (void)pinned;                                                   /* `frames` is the worker's buffer: reused by its next unit */
     free(outs);
     w->pictures += n;
     return rc;
@@ -338,6 +396,7 @@ static void worker_fini(void *state)
 {
     worker_t *w = (worker_t *)state;
     { const int k = __sync_fetch_and_add(&g_workers, 1); g_busy[k & 63] = w->busy_s - w->setup_s; g_setup[k & 63] = w->setup_s; g_parse[k & 63] = w->parse_s; g_build[k & 63] = w->build_s; }
+    if (w->frames && !w->frames_pinned) free(w->frames);            /* (pinned memory goes with the context) */
     if (w->g) xgpu_close(w->g);
     for (int i = 0; i < MAX_SLOTS + 2; i++) free(w->ref_luma[i]);
     free(w);
@@ -346,12 +405,17 @@ static void worker_fini(void *state)
 int main(int argc, char **argv)
 {
     int gpus = 1, workers = 1, out_bd = 0, a = 1;
+    /* the per-picture arrays of the parser and the batch builder are tens of megabytes: kept in the heap instead of being mapped and unmapped per
+       picture (every munmap interrupts all the threads of the process - the tile threads of the parser - to flush their TLBs) */
+    mallopt(M_MMAP_THRESHOLD, 32 << 20);        /* the largest value glibc takes */
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
     while (a < argc && argv[a][0] == '-' && argv[a][1] == '-') {
         if (!strcmp(argv[a], "--gpus") && a + 1 < argc) { gpus = atoi(argv[a + 1]); a += 2; }
         else if (!strcmp(argv[a], "--workers") && a + 1 < argc) { workers = atoi(argv[a + 1]); a += 2; }
         else if (!strcmp(argv[a], "--bd") && a + 1 < argc) { out_bd = atoi(argv[a + 1]); a += 2; }
         else if (!strcmp(argv[a], "--tile-threads") && a + 1 < argc) { g_tile_threads = atoi(argv[a + 1]); a += 2; }
         else if (!strcmp(argv[a], "--no-pipeline")) { g_pipeline = 0; a += 1; }
+        else if (!strcmp(argv[a], "--trace")) { g_trace = 1; a += 1; }
         else break;
     }
     int n_pos = argc - a;

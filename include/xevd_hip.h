@@ -246,6 +246,10 @@ int  xgpu_batch_info(xgpu_ctx *ctx, const xgpu_dbatch *db, int info[XGPU_BATCH_I
 /* returns the batch's blocks to the pool.  Does not wait for the device: it may follow xgpu_batch_recon immediately (kernels already
    queued keep their data - later batches of this context are written through the same HIP stream, behind them). */
 void xgpu_batch_destroy(xgpu_ctx *ctx, xgpu_dbatch *db);
+/* Optional, for a caller that has the NEXT picture's batch at hand while the current one is being reconstructed: queues the batch's residual pass (dequant +
+   inverse transform - it depends on nothing but the batch) on a side stream behind the k_inter launched last, so that it runs under the current picture's
+   dependency kernel and filters; xgpu_batch_recon of that batch then only waits for it.  Call between xgpu_batch_recon of picture k and of picture k + 1.     */
+int  xgpu_batch_prepare(xgpu_ctx *ctx, xgpu_dbatch *db);
 /* dequant + inverse transform of every coded TB, then MC + residual add + clip of every inter CU, and the
    SCU map update (xevd_set_dec_info) the in-loop filters read.  Asynchronous on the ctx stream.          */
 int  xgpu_batch_recon(xgpu_ctx *ctx, xgpu_dbatch *db);

@@ -108,6 +108,12 @@ int  xhost_parser_set_threads(xhost_parser *p, int n_threads);
    re-entrant: one thread at a time inside its functions.  (Not for streams with sps->tool_dmvr feedback pending: xhost_parser_set_dmvr_mvs of
    picture k has to come before xhost_parser_next for k + 1 - the caller serialises those.) */
 int  xhost_parser_set_depth(xhost_parser *p, int depth);
+/* Where the coefficient arena of a picture with several tiles is gathered (before the first picture): memory from `alloc(user, bytes)` - e.g. pinned
+   host memory of the backend (xgpu_host_alloc), so that xgpu_batch_create sends the largest array of a batch from where the parser wrote it, without
+   a staging copy - one arena per picture slot of xhost_parser_set_depth, grown on demand, given back through `release(user, p)` when it is outgrown or
+   the parser is closed.  `alloc` may return NULL (nothing available yet): that picture's coefficients then live in the parser's own memory.  The caller
+   keeps an arena untouched until the backend has consumed it (xgpu_batch_wait_upload) before it lets the parser reuse the picture slot. */
+int  xhost_parser_set_arena(xhost_parser *p, void *(*alloc)(void *user, size_t bytes), void (*release)(void *user, void *mem), void *user);
 void xhost_parser_close(xhost_parser *p);
 
 typedef struct xhost_stream_params {

@@ -430,8 +430,7 @@ APP_ON_HIP = os.path.normpath(os.path.join(golden_io.GOLDEN, "..", "..", "oracle
                                        ("main_dra_10b", ["--output-bit-depth", "10"]), ("main_htdf_all_tools_10b", ["--output-bit-depth", "10"]),
                                        ("main_ibc_all_tools_10b", ["--output-bit-depth", "10"]), ("main_admvp_all_tools_10b", ["--output-bit-depth", "10"]), ("main_dmvr_all_tools_10b", ["--output-bit-depth", "10"]),
                                        ("main_tiles_3x2_all_tools_10b", ["--output-bit-depth", "10"]), ("main_tiles_explicit_10b", []),
-                                       ("main_affine_all_tools_10b", ["--output-bit-depth", "10"]), ("main_every_tool_10b", ["--output-bit-depth", "10"]),
-                                       ("main_dmvr_hmvp_mmvd_b_8b", [])])
+                                       ("main_affine_all_tools_10b", ["--output-bit-depth", "10"]), ("main_every_tool_10b", ["--output-bit-depth", "10"])])
 def test_gpu_reference_application_on_our_api(name, args, tmp_path):
     """The reference's OWN sample application (app/xevd_app.c, compiled from its source where it lies) linked against libxevd_amd_api.so - this
     repository's implementation of the public xevd_create / xevd_decode / xevd_pull API - instead of libxevd: it decodes the golden streams on
@@ -504,7 +503,10 @@ def test_gpu_reference_application_rejects_bad_signature(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", ["cfg2_base_1080p_8b_ippp", "cfg3_main_4k_10b_ra", "cfg4_main_8k_10b_ra"])
+@pytest.mark.parametrize("name", ["cfg2_base_1080p_8b_ippp", "cfg3_main_4k_10b_ra", "cfg4_main_8k_10b_ra",
+                                  # the Main tools outside BASELINE's configurations, at 7680x4320 too: k_dmvr's item list (hundreds of thousands of sub-blocks), k_affine's
+                                  # tile split, the data-flow kernel with most CUs of the picture as HTDF nodes
+                                  "main_8k_10b_ra_dmvr", "main_8k_10b_ra_affine30", "main_8k_10b_ra_htdf"])
 def test_gpu_bench_workload_vs_oracle(name):
     """The configurations the metric is quoted on, at size: the exact CU batch, reference pictures and ALF parameters bench.py times (Main 10 bit,
     admvp 8-tap tables, IQT, ADDB, ALF on every CTU, two lists, 50 % bi-prediction at 3840x2160 and 7680x4320; Baseline 1080p) through the whole

@@ -318,8 +318,8 @@ __global__ __launch_bounds__(256) void k_itdq(const ItdqArgs a)
     }
 }
 
-void launch_itdq(xgpu_ctx *c, const ItdqArgs &a)
+void launch_itdq(xgpu_ctx *c, const ItdqArgs &a, hipStream_t s)
 {
     if (a.n_waves <= 0) return;
-    hipLaunchKernelGGL(k_itdq, dim3(a.n_waves), dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_itdq, dim3(a.n_waves), dim3(256), 0, s, a);
 }

@@ -155,7 +155,7 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     xgpu_ctx *c = new xgpu_ctx();
     c->sp = *sp;
     c->sp.chroma_qp_table[0] = c->sp.chroma_qp_table[1] = NULL;
-    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_dra = NULL; c->d_ctb_flag = NULL; c->stream = 0; c->up_stream = 0; c->down_stream = 0; c->where = 0;
+    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_dra = NULL; c->d_ctb_flag = NULL; c->stream = 0; c->up_stream = 0; c->down_stream = 0; c->side_stream = 0; c->after_inter = 0; c->have_after_inter = 0; c->where = 0;
     for (int i = 0; i < 2; i++) { c->d_out[i] = NULL; c->out_caps[i] = 0; c->out_ready[i] = c->out_done[i] = 0; c->out_busy[i] = 0; }
     c->out_next = 0;
     memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_n, 0, sizeof(c->t_n));
@@ -171,6 +171,8 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     if (hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     if (hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+    if (hipEventCreateWithFlags(&c->after_inter, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     for (int i = 0; i < 2; i++)
         if (hipEventCreateWithFlags(&c->out_ready[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->out_done[i], hipEventDisableTiming) != hipSuccess)
             return fail(XGPU_ERR_UNEXPECTED);
@@ -214,9 +216,10 @@ void xgpu_close(xgpu_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->up_stream) (void)hipStreamSynchronize(c->up_stream);
     if (c->down_stream) (void)hipStreamSynchronize(c->down_stream);
+    if (c->side_stream) (void)hipStreamSynchronize(c->side_stream);
     for (auto &p : c->pics) if (p.base) (void)hipFree(p.base);
     if (c->d_maps) (void)hipFree(c->d_maps);
-    for (BatchBlock &k : c->pool) { (void)hipFree(k.d_base); (void)hipHostFree(k.h_stage); (void)hipEventDestroy(k.uploaded); (void)hipEventDestroy(k.done); }
+    for (BatchBlock &k : c->pool) { (void)hipFree(k.d_base); (void)hipHostFree(k.h_stage); (void)hipEventDestroy(k.uploaded); (void)hipEventDestroy(k.done); (void)hipEventDestroy(k.itdq_done); }
     for (auto &h : c->pinned) (void)hipHostFree(h.p);
     c->pinned.clear();
     c->pool.clear();
@@ -228,6 +231,8 @@ void xgpu_close(xgpu_ctx *c)
     if (c->stream) (void)hipStreamDestroy(c->stream);
     if (c->up_stream) (void)hipStreamDestroy(c->up_stream);
     if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
+    if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
+    if (c->after_inter) (void)hipEventDestroy(c->after_inter);
     delete c;
 }
 
@@ -235,6 +240,7 @@ int xgpu_sync(xgpu_ctx *c)
 {
     ARGCHK(c, c != NULL);
     HIPCHK(c, hipStreamSynchronize(c->up_stream));
+    HIPCHK(c, hipStreamSynchronize(c->side_stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipStreamSynchronize(c->down_stream));
     return XGPU_OK;
@@ -446,8 +452,12 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     auto ordered = [&](uint32_t j) -> bool { return b->pred_mode[j] == XGPU_MODE_INTRA || b->pred_mode[j] == XGPU_MODE_IBC || htdf_idx(j) >= 0; };
     const int n = b->n_cu, ws = c->w_scu, hs = c->h_scu;
     const uint32_t NONE = 0xFFFFFFFFu;
-    std::vector<uint32_t> owner((size_t)ws * hs, NONE);
-    std::vector<int> level((size_t)n, 0);
+    // scratch of the builder thread, kept between pictures: an 8 MB vector per 8K picture allocated and freed every call goes through mmap / munmap, and the
+    // munmap's TLB shootdown reaches every thread of the process - the parser's tile threads among them (examples/evc_decode.c runs them next to this one)
+    static thread_local std::vector<uint32_t> owner;
+    static thread_local std::vector<int> level;
+    owner.assign((size_t)ws * hs, NONE);
+    level.assign((size_t)n, 0);
     // painted CU by CU as the loop below reaches them ("reconstructed before CU i" = painted): inside a local dual tree the node's chroma-only CU follows its
     // luma CUs and covers them again
     auto paint = [&](int i) {
@@ -627,7 +637,8 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     std::vector<int> first((size_t)max_level + 2, 0);
     for (const IntraRec &r : recs) first[level[r.cu] + 1]++;
     for (int l = 1; l <= max_level + 1; l++) first[l] += first[l - 1];
-    std::vector<uint32_t> pos((size_t)n, NONE);
+    static thread_local std::vector<uint32_t> pos;
+    pos.assign((size_t)n, NONE);
     plan.recs.resize(recs.size());
     for (const IntraRec &r : recs) { pos[r.cu] = (uint32_t)first[level[r.cu]]; plan.recs[first[level[r.cu]]++] = r; }
     for (uint32_t &d : deps) d = pos[d];
@@ -838,6 +849,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
             db->blk.h_cap = h_cap;
             if (hipEventCreateWithFlags(&db->blk.uploaded, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
             if (hipEventCreateWithFlags(&db->blk.done, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+            if (hipEventCreateWithFlags(&db->blk.itdq_done, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
         }
     }
     db->h_stage = db->blk.h_stage;
@@ -968,15 +980,42 @@ void xgpu_batch_destroy(xgpu_ctx *c, xgpu_dbatch *db)
     if (!db) return;
     // No synchronisation: kernels still queued on the context's stream keep reading the block; whoever reuses it makes the upload stream wait
     // for the `done` event those kernels signal, and the host waits for `uploaded` before it touches the staging block.
-    if (db->blk.d_base && db->blk.h_stage && db->blk.uploaded && db->blk.done && c) { std::lock_guard<std::mutex> g(c->pool_mu); c->pool.push_back(db->blk); }
+    if (db->blk.d_base && db->blk.h_stage && db->blk.uploaded && db->blk.done && db->blk.itdq_done && c) { std::lock_guard<std::mutex> g(c->pool_mu); c->pool.push_back(db->blk); }
     else {
         if (c && c->stream) (void)hipStreamSynchronize(c->stream);
         if (db->blk.d_base) (void)hipFree(db->blk.d_base);
         if (db->blk.h_stage) (void)hipHostFree(db->blk.h_stage);
         if (db->blk.uploaded) (void)hipEventDestroy(db->blk.uploaded);
         if (db->blk.done) (void)hipEventDestroy(db->blk.done);
+        if (db->blk.itdq_done) (void)hipEventDestroy(db->blk.itdq_done);
     }
     delete db;
+}
+
+static ItdqArgs itdq_args(const xgpu_ctx *c, const xgpu_dbatch *db)
+{
+    ItdqArgs ia;
+    ia.coef = db->d_coef; ia.resid = db->d_resid; ia.tbs = db->d_tbs; ia.waves = db->d_waves; ia.n_waves = db->n_waves;
+    ia.bd = c->sp.bit_depth_luma;      // the LUMA depth drives dequant/transform shifts of all components (xevd.c:441-442)
+    ia.iqt = c->sp.tool_iqt;
+    return ia;
+}
+
+// The residual pass of a batch depends on nothing but the batch: queued AHEAD, on the side stream, behind the k_inter of the picture being reconstructed now, it
+// runs under that picture's dependency kernel (k_intra's data-flow launch keeps a few thousand waves busy for tens of microseconds - most of the GPU idles)
+// and its filters instead of in front of its own k_inter.  Optional: xgpu_batch_recon launches the pass itself for a batch that was not prepared.
+int xgpu_batch_prepare(xgpu_ctx *c, xgpu_dbatch *db)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, db != NULL);
+    if (db->prepared) return XGPU_OK;
+    HIPCHK(c, hipStreamWaitEvent(c->side_stream, db->blk.uploaded, 0));
+    if (c->have_after_inter) HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->after_inter, 0));
+    const ItdqArgs ia = itdq_args(c, db);
+    launch_itdq(c, ia, c->side_stream);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(db->blk.itdq_done, c->side_stream));
+    db->prepared = 1;
+    return XGPU_OK;
 }
 
 int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
@@ -984,11 +1023,13 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
     ARGCHK(c, c != NULL); ARGCHK(c, db != NULL); ARGCHK(c, c->have_frame);
     HIPCHK(c, hipStreamWaitEvent(c->stream, db->blk.uploaded, 0));       // the batch's arrays come through the upload stream
     if (db->tiles_across) memset(&c->no_dbk, 0, sizeof(c->no_dbk)); else c->no_dbk = db->tile_starts;
-    ItdqArgs ia;
-    ia.coef = db->d_coef; ia.resid = db->d_resid; ia.tbs = db->d_tbs; ia.waves = db->d_waves; ia.n_waves = db->n_waves;
-    ia.bd = c->sp.bit_depth_luma;      // the LUMA depth drives dequant/transform shifts of all components (xevd.c:441-442)
-    ia.iqt = c->sp.tool_iqt;
-    TIMED(c, XGPU_K_ITDQ, launch_itdq(c, ia));
+    if (db->prepared) {                                                  // xgpu_batch_prepare ran the residual pass on the side stream
+        HIPCHK(c, hipStreamWaitEvent(c->stream, db->blk.itdq_done, 0));
+        db->prepared = 0;
+    } else {
+        const ItdqArgs ia = itdq_args(c, db);
+        TIMED(c, XGPU_K_ITDQ, launch_itdq(c, ia, c->stream));
+    }
 
     InterArgs a;
     memset(&a, 0, sizeof(a));
@@ -1011,6 +1052,8 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
             a.refp[i][l].poc = i < c->fp.num_refp[l] ? c->fp.refp_poc[i][l] : 0;
         }
     TIMED(c, XGPU_K_INTER, launch_inter(c, a));
+    HIPCHK(c, hipEventRecord(c->after_inter, c->stream));               // where a prepared residual pass of the next picture may start
+    c->have_after_inter = 1;
     if (db->n_dmvr) {
         DmvrArgs d;
         memset(&d, 0, sizeof(d));
@@ -1261,7 +1304,7 @@ int xgpu_test_itdq(xgpu_ctx *c, int16_t *coef, int n_blocks, int log2w, int log2
     HIPCHK(c, hipMemcpyAsync(dt, tbs.data(), sizeof(TbRec) * tbs.size(), hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(dw, wv.data(), sizeof(TbWave) * wv.size(), hipMemcpyHostToDevice, c->stream));
     ItdqArgs ia; ia.coef = dc; ia.resid = dr; ia.tbs = dt; ia.waves = dw; ia.n_waves = (int)wv.size(); ia.bd = bit_depth; ia.iqt = c->sp.tool_iqt;
-    launch_itdq(c, ia);
+    launch_itdq(c, ia, c->stream);
     HIPCHK(c, hipMemcpyAsync(coef, dr, nb, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     (void)hipFree(dc); (void)hipFree(dr); (void)hipFree(dt); (void)hipFree(dw);

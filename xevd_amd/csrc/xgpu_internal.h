@@ -237,7 +237,7 @@ struct AlfArgs {
 // One device block + one pinned staging block of a batch.  xgpu_batch_destroy returns them to the context's pool instead of freeing:
 // hipMalloc / hipFree / hipHostMalloc synchronise the device and serialise across the threads of a process, which capped many-stream
 // decoding on one GPU (tools/bench_multistream.py) and cost a stream synchronisation per picture.
-struct BatchBlock { uint8_t *d_base; size_t d_cap; void *h_stage; size_t h_cap; hipEvent_t uploaded, done; };      // uploaded: the H2D copies have left the host memory; done: the reconstruction kernels have read the block
+struct BatchBlock { uint8_t *d_base; size_t d_cap; void *h_stage; size_t h_cap; hipEvent_t uploaded, done, itdq_done; };      // uploaded: the H2D copies have left the host memory; done: the reconstruction kernels have read the block
 
 struct xgpu_dbatch {
     BatchBlock blk;
@@ -265,6 +265,7 @@ struct xgpu_dbatch {
     uint32_t   intra_epoch, intra_tickets;
     void      *h_stage;               // pinned staging block
     size_t     stage_bytes;
+    int        prepared;              // xgpu_batch_prepare has queued the residual pass (k_itdq) on the side stream: `blk.itdq_done` says when it has finished
 };
 
 struct xgpu_ctx {
@@ -272,6 +273,9 @@ struct xgpu_ctx {
     int8_t          chroma_qp[2][96];  // [c][qp + 6*(bdc-8)]
     hipStream_t     stream;            // kernels
     hipStream_t     up_stream, down_stream;      // batch uploads / output downloads: their own DMA queues, ordered against the kernels by events
+    hipStream_t     side_stream;       // xgpu_batch_prepare: the residual pass of the NEXT picture, behind the current picture's k_inter (fills the GPU under the
+    hipEvent_t      after_inter;       //   latency-bound dependency kernel); after_inter = the point of the main stream it may start behind
+    int             have_after_inter;
     std::mutex      pool_mu;           // xgpu_batch_create / _destroy may run on a builder thread next to the thread that drives the context
     struct HostRange { uint8_t *p; size_t n; };
     std::vector<HostRange> pinned;     // xgpu_host_alloc'ed ranges: batch arrays inside them are sent without a staging copy
@@ -302,7 +306,7 @@ struct xgpu_ctx {
 };
 
 // kernel launchers (one per .hip file)
-void launch_itdq(xgpu_ctx *c, const ItdqArgs &a);
+void launch_itdq(xgpu_ctx *c, const ItdqArgs &a, hipStream_t s);
 void launch_inter(xgpu_ctx *c, const InterArgs &a);
 void launch_test_recon(xgpu_ctx *c, const int16_t *coef, const int16_t *pred, int is_coef, int cuw, int cuh, int16_t *rec, int s_rec, int bd);
 void launch_test_dbk(xgpu_ctx *c, int16_t *buf, int16_t *buf_v, int st, int st_v, int stride, int bd, int hor, int chroma);

@@ -184,6 +184,10 @@ class XgpuDecoder:
         self._batches = [b for b in self._batches if b.value != h.value]
         self.lib.xgpu_batch_destroy(self.ctx, h)
 
+    def batch_prepare(self, h):
+        """queue the batch's residual pass ahead of its picture (xgpu_batch_prepare)"""
+        self._chk(self.lib.xgpu_batch_prepare(self.ctx, h), "xgpu_batch_prepare")
+
     def batch_recon(self, h):
         self._chk(self.lib.xgpu_batch_recon(self.ctx, h), "xgpu_batch_recon")
 
@@ -201,11 +205,13 @@ class XgpuDecoder:
         self._chk(self.lib.xgpu_frame_end(self.ctx), "xgpu_frame_end")
 
     def decode_picture(self, pic, poc, refs, batch_handle, deblock=True, pad=True, qp_u_offset=0, qp_v_offset=0,
-                       alpha_off=0, beta_off=0, alf=None):
+                       alpha_off=0, beta_off=0, alf=None, next_batch=None):
         """The coarse sequence of xevd_dec_nalu for one picture (src_base/xevd.c:1905-1983, src_main/xevdm.c:3136-3219)."""
         self.frame_begin(pic, poc, refs, qp_u_offset, qp_v_offset, deblock_on=deblock, alf_on=alf is not None,
                          alpha_off=alpha_off, beta_off=beta_off)
         self.batch_recon(batch_handle)
+        if next_batch is not None:      # the next picture's residual pass, under this picture's dependency kernel and filters
+            self.batch_prepare(next_batch)
         if deblock:
             self.deblock()
         if alf is not None:

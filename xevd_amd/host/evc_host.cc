@@ -2238,9 +2238,16 @@ struct xhost_parser {
         std::vector<uint8_t> ctb;
         std::vector<int32_t> dra;
         xgpu_tile_grid grid;
+        int16_t *arena = nullptr;                        // xhost_parser_set_arena: the coefficients of a picture with several tiles are gathered here
+        size_t arena_cap = 0;                            //   (in samples) instead of in batch.coef
     };
+    void *(*arena_alloc)(void *, size_t) = nullptr;
+    void (*arena_release)(void *, void *) = nullptr;
+    void *arena_user = nullptr;
+    ~xhost_parser() { for (Held &h : held) if (h.arena && arena_release) arena_release(arena_user, h.arena); }
     std::vector<Held> held = std::vector<Held>(1);
     size_t n_handed = 0;
+    int16_t *merged_arena = nullptr;                     // the arena the coefficients of the picture being handed out were gathered in (else batch.coef)
     Batch *cur = &merged;                                // the batch of the picture handed out last (in its ring slot)
     size_t n_coef = 0;
     int n_threads = 1;                                   // xhost_parser_set_threads
@@ -2510,6 +2517,7 @@ struct xhost_parser {
         std::vector<int> tile_rc((size_t)n_tiles, XGPU_OK);
         parallel_for(n_tiles, [&](int t) { tile_rc[(size_t)t] = tiles[(size_t)t]->parse_tile(br, tile_pos[(size_t)t], t % st.grid.n_cols, t / st.grid.n_cols); });
         for (int t = 0; t < n_tiles; t++) if (tile_rc[(size_t)t] != XGPU_OK) { err = tiles[(size_t)t]->err; return tile_rc[(size_t)t]; }
+        merged_arena = nullptr;
         if (n_tiles == 1) { cur = &tiles[0]->batch; n_coef = tiles[0]->n_coef; }
         else {
             // one batch for the backend: the tiles' arrays one after the other, coefficient offsets and CTU starts moved along
@@ -2522,11 +2530,28 @@ struct xhost_parser {
             if (cf0[(size_t)n_tiles] > 0xFFFFFFFFull) return fail("coefficient arena beyond 32-bit offsets");
             Batch &m = merged;
             const size_t n = cu0[(size_t)n_tiles];
+            // the caller's arena (pinned memory of the backend: xgpu_batch_create then sends the coefficients from where they lie) of the slot this picture
+            // will be handed out in; without one - or when the allocator has nothing yet - the merged batch's own vector
+            Held &slot = held[n_handed % held.size()];
+            int16_t *arena = nullptr;
+            if (arena_alloc) {
+                const size_t need = std::max(cf0[(size_t)n_tiles], (size_t)8);
+                if (slot.arena_cap < need) {
+                    if (slot.arena && arena_release) arena_release(arena_user, slot.arena);
+                    slot.arena_cap = need + need / 4;
+                    slot.arena = (int16_t *)arena_alloc(arena_user, slot.arena_cap * sizeof(int16_t));
+                    if (!slot.arena) slot.arena_cap = 0;
+                }
+                arena = slot.arena;
+            }
             m.x.resize(n); m.y.resize(n); m.log2w.resize(n); m.log2h.resize(n); m.pred_mode.resize(n); m.qp.resize(n * 3); m.cbf.resize(n); m.ipm.resize(n * 2);
             m.ats.resize(n); m.ats_inter.resize(n); m.dmvr.resize(n); m.tree.resize(n); m.has_tree = false;
             for (int t = 0; t < n_tiles; t++) m.has_tree |= tiles[(size_t)t]->batch.has_tree;
             m.affine.resize(st.sps.tool_affine ? n : 0); m.affine_mv.resize(st.sps.tool_affine ? n * 12 : 0); m.refi.resize(n * 2); m.mv.resize(n * 4); m.coef_off.resize(n);
-            m.coef.resize(cf0[(size_t)n_tiles]); m.ctu_start.resize(ct0[(size_t)n_tiles]);
+            if (!arena) m.coef.resize(cf0[(size_t)n_tiles]);
+            m.ctu_start.resize(ct0[(size_t)n_tiles]);
+            int16_t *coef_dst = arena ? arena : m.coef.data();
+            merged_arena = arena;
             parallel_for(n_tiles, [&](int t) {
                 const Batch &b = tiles[(size_t)t]->batch;
                 const size_t o = cu0[(size_t)t], k = b.x.size();
@@ -2535,7 +2560,7 @@ struct xhost_parser {
                 put(m.cbf, b.cbf, 1); put(m.ipm, b.ipm, 2); put(m.ats, b.ats, 1); put(m.ats_inter, b.ats_inter, 1); put(m.dmvr, b.dmvr, 1); put(m.tree, b.tree, 1); put(m.refi, b.refi, 2); put(m.mv, b.mv, 4);
                 if (st.sps.tool_affine) { put(m.affine, b.affine, 1); put(m.affine_mv, b.affine_mv, 12); }
                 for (size_t i = 0; i < k; i++) m.coef_off[o + i] = b.coef_off[i] + (uint32_t)cf0[(size_t)t];
-                if (tiles[(size_t)t]->n_coef) memcpy(m.coef.data() + cf0[(size_t)t], b.coef.data(), tiles[(size_t)t]->n_coef * sizeof(int16_t));
+                if (tiles[(size_t)t]->n_coef) memcpy(coef_dst + cf0[(size_t)t], b.coef.data(), tiles[(size_t)t]->n_coef * sizeof(int16_t));
                 for (size_t i = 0; i < b.ctu_start.size(); i++) m.ctu_start[ct0[(size_t)t] + i] = b.ctu_start[i] + (uint32_t)o;
             });
             cur = &merged; n_coef = cf0[(size_t)n_tiles];
@@ -2597,7 +2622,7 @@ struct xhost_parser {
         if (st.sps.tool_affine) { b.affine = batch.affine.data(); b.affine_mv = batch.affine_mv.data(); }
         if (batch.has_tree) b.tree = batch.tree.data();
         if (batch.coef.empty()) batch.coef.push_back(0);
-        b.coef = batch.coef.data(); b.n_coef = batch.x.empty() ? 0 : n_coef;
+        b.coef = merged_arena ? merged_arena : batch.coef.data(); b.n_coef = batch.x.empty() ? 0 : n_coef;
         b.n_ctu = w_ctu * h_ctu; b.ctu_cu_start = batch.ctu_start.data();
         b.constrained_intra_pred = st.pps.constrained_intra;
         hd.grid = st.grid;
@@ -2660,6 +2685,12 @@ extern "C" int xhost_parser_set_depth(xhost_parser *p, int depth)
 {
     if (!p || depth < 1 || depth > 8 || p->n_handed) return XGPU_ERR_INVALID_ARGUMENT;      // before the first picture
     p->held = std::vector<xhost_parser::Held>((size_t)depth);
+    return XGPU_OK;
+}
+extern "C" int xhost_parser_set_arena(xhost_parser *p, void *(*alloc)(void *, size_t), void (*release)(void *, void *), void *user)
+{
+    if (!p || !alloc || !release || p->n_handed) return XGPU_ERR_INVALID_ARGUMENT;
+    p->arena_alloc = alloc; p->arena_release = release; p->arena_user = user;
     return XGPU_OK;
 }
 extern "C" int xhost_parser_set_threads(xhost_parser *p, int n) { if (!p || n < 1) return XGPU_ERR_INVALID_ARGUMENT; p->n_threads = std::min(n, 64); return XGPU_OK; }
