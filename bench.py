@@ -569,7 +569,10 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 2),
                          "measured_copy_bw_gbps": None if copy_bw is None else round(copy_bw, 1),
-                         "frac_of_measured_copy_bw": None if not copy_bw else round(achieved / copy_bw, 4)},
+                         "frac_of_measured_copy_bw": None if not copy_bw else round(achieved / copy_bw, 4),
+                         # the guide's measured float4-copy figure for this part (MI355X_MICROARCH.md: 6.29 TB/s); our own copy kernel reaches 4.8
+                         "frac_of_guide_copy_bw_6290": round(achieved / 6290.0, 4),
+                         "traffic_source": "profiles/latest_pmc.json (rocprofv3 --pmc passes of this workload, committed; not measured by this run)" if traffic is not None else None},
             "kernels": kernels,
             "whole_frame": {"algorithmic_bytes": int(total_alg), "kernel_us": round(kern_s * 1e6, 2),
                             "achieved_gbps": round(total_alg / kern_s / 1e9, 1),

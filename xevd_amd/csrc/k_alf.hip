@@ -126,13 +126,19 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
     __shared__ int16_t l_coef[25 * 13 + 7];
     // sums of |Laplacian| over the 2x2 sub-blocks of the tile + one ring: [direction V, H, D0, D1][sub-block row -1..32][col -1..32]
     __shared__ __attribute__((aligned(16))) uint16_t l_lap[4][34][SSTR];
+    // the filtered samples on the picture border that this tile holds: [plane][first / last row of the picture][column of the tile] and [first / last column][row],
+    // for the border replication below (what k_pad did in a launch of its own)
+    __shared__ __attribute__((aligned(8))) int16_t b_row[3][2][64], b_col[3][2][64];
 
     // XCD-aware mapping: workgroup b runs on XCD b % 8 and every XCD has its own L2.  A tile reads its neighbours' edge samples as halo (the 8-byte
     // pieces at cols -4 and 64 sit in the cache lines of the tiles to the left and right, 3 rows above / below in those of the tiles there), so
     // with tiles handed out round-robin every line was fetched from HBM by up to three XCDs: 331 MB read per 8K picture for 126 MB of window
     // (TCC_EA0_RDREQ_128B, profiles/round2_*).  Each XCD now takes a contiguous eighth of the raster tile order: neighbours share an L2.
     const int tiles_x = (a.pic_w + 63) >> 6, n_tiles = tiles_x * ((a.pic_h + 63) >> 6);
-    const int tile = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    // The XCDs that hold the lower half of the picture walk their eighth backwards: the tiles on the top and bottom picture border also write the padding (below:
+    // up to ten times the stores of an inner tile) and should be the first of their XCD, not its tail.
+    const int per_xcd = gridDim.x >> 3, xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
+    const int tile = xcd * per_xcd + (xcd >= 4 ? per_xcd - 1 - seq : seq);
     if (tile >= n_tiles) return;
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tx0 = tx << 6, ty0 = ty << 6;
@@ -215,7 +221,18 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
         }
     }
     __syncthreads();
-    if (!inside) return;
+    const bool edge_l = tx0 == 0, edge_r = tx0 + 64 >= a.pic_w, edge_t = ty0 == 0, edge_b = ty0 + 64 >= a.pic_h;
+    do {
+    if (!inside) break;
+    // a lane's block on the picture border leaves its outermost samples for the replication
+    auto keep_luma = [&](int ii, uint2 w) {
+        if (a.pad) {
+            if (y + ii == 0) *(uint2 *)&b_row[0][0][lx << 2] = w;
+            if (y + ii == a.pic_h - 1) *(uint2 *)&b_row[0][1][lx << 2] = w;
+            if (x == 0) b_col[0][0][(ly << 2) + ii] = (int16_t)(w.x & 0xFFFF);
+            if (x + 4 == a.pic_w) b_col[0][1][(ly << 2) + ii] = (int16_t)(w.y >> 16);
+        }
+    };
 
     if (luma_on) {
         // phase 2: the 8x8 window = sub-block rows 2*ly-1 .. 2*ly+2, cols 2*lx-1 .. 2*lx+2
@@ -289,11 +306,12 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
             w.x = (uint32_t)(uint16_t)min(max(o[0] >> 9, 0), maxv) | ((uint32_t)(uint16_t)min(max(o[1] >> 9, 0), maxv) << 16);
             w.y = (uint32_t)(uint16_t)min(max(o[2] >> 9, 0), maxv) | ((uint32_t)(uint16_t)min(max(o[3] >> 9, 0), maxv) << 16);
             *(uint2 *)(dy_ + (y + ii) * a.s_l + x) = w;
+            keep_luma(ii, w);
         }
 #undef P
     } else {
 #pragma unroll
-        for (int ii = 0; ii < 4; ii++) *(uint2 *)(dy_ + (y + ii) * a.s_l + x) = *(const uint2 *)(sy_ + (y + ii) * a.s_l + x);
+        for (int ii = 0; ii < 4; ii++) { const uint2 w = *(const uint2 *)(sy_ + (y + ii) * a.s_l + x); *(uint2 *)(dy_ + (y + ii) * a.s_l + x) = w; keep_luma(ii, w); }
     }
 
     // ------------------------------------------------ chroma ---------------------------------------------
@@ -302,9 +320,17 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
     for (int pl = 0; pl < 2; pl++) {
         const int16_t *src = pl ? sv_ : su_;
         int16_t *dst = pl ? dv_ : du_;
+        auto keep_chroma = [&](int ii, uint32_t w) {
+            if (a.pad) {
+                if (cy + ii == 0) *(uint32_t *)&b_row[1 + pl][0][lx << 1] = w;
+                if (cy + ii == (a.pic_h >> 1) - 1) *(uint32_t *)&b_row[1 + pl][1][lx << 1] = w;
+                if (cx == 0) b_col[1 + pl][0][(ly << 1) + ii] = (int16_t)(w & 0xFFFF);
+                if (cx + 2 == (a.pic_w >> 1)) b_col[1 + pl][1][(ly << 1) + ii] = (int16_t)(w >> 16);
+            }
+        };
         if (!a.enable[1 + pl]) {
-            *(uint32_t *)(dst + cy * a.s_c + cx) = *(const uint32_t *)(src + cy * a.s_c + cx);
-            *(uint32_t *)(dst + (cy + 1) * a.s_c + cx) = *(const uint32_t *)(src + (cy + 1) * a.s_c + cx);
+#pragma unroll
+            for (int ii = 0; ii < 2; ii++) { const uint32_t w = *(const uint32_t *)(src + (cy + ii) * a.s_c + cx); *(uint32_t *)(dst + (cy + ii) * a.s_c + cx) = w; keep_chroma(ii, w); }
             continue;
         }
         // window rows -2..3, cols -2..3 -> 3 dwords per row; col j at sample j+2
@@ -331,9 +357,56 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
             const uint32_t p0 = padd(PC(ii + 2, 0), PC(ii - 2, 0)), p1 = padd(PC(ii + 1, 1), PC(ii - 1, -1));
             o[0] = mad_lo(p1, f[1], mad_lo(p0, f[0], o[0]));
             o[1] = mad_hi(p1, f[1], mad_hi(p0, f[0], o[1]));
-            *(uint32_t *)(dst + (cy + ii) * a.s_c + cx) = (uint32_t)(uint16_t)min(max(o[0] >> 9, 0), maxv) | ((uint32_t)(uint16_t)min(max(o[1] >> 9, 0), maxv) << 16);
+            const uint32_t w = (uint32_t)(uint16_t)min(max(o[0] >> 9, 0), maxv) | ((uint32_t)(uint16_t)min(max(o[1] >> 9, 0), maxv) << 16);
+            *(uint32_t *)(dst + (cy + ii) * a.s_c + cx) = w;
+            keep_chroma(ii, w);
         }
 #undef PC
+    }
+    } while (0);
+
+    // ------------------------------------------------ border replication (xevd_picbuf_expand, src_base/xevd_util.c:365-427) ---------------
+    // A tile on the picture border writes its share of the padding from the samples it has just produced: the margin left / right of its rows, the rows above /
+    // below its columns, and - a corner tile - the corner block.  All 256 threads of the workgroup take part (the tile's own lanes outside the picture too).
+    if (!a.pad || !(edge_l || edge_r || edge_t || edge_b)) return;
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int sh = c ? 1 : 0, pad = c ? XGPU_PAD_C : XGPU_PAD_L, s = c ? a.s_c : a.s_l;
+        const int pw = a.pic_w >> sh, ph = a.pic_h >> sh, x0 = tx0 >> sh, y0 = ty0 >> sh, T = 64 >> sh;
+        const int cols = min(T, pw - x0), rows = min(T, ph - y0);        // the tile's part of the picture
+        int16_t *pl = c == 0 ? dy_ : (c == 1 ? du_ : dv_);
+        const int q = pad >> 2;                                          // margin width in 8-byte pieces (144 / 72 samples)
+        // left / right of the tile's rows
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            if (side ? !edge_r : !edge_l) continue;
+            for (int i = t; i < rows * q; i += 256) {
+                const int r = i / q, k = i - r * q;
+                const uint32_t v = (uint16_t)b_col[c][side][r] * 0x10001u;
+                *(uint2 *)(pl + (y0 + r) * s + (side ? pw : -pad) + 4 * k) = make_uint2(v, v);
+            }
+        }
+        // above / below the tile's columns, and the corner blocks next to them
+#pragma unroll
+        for (int side = 0; side < 2; side++) {
+            if (side ? !edge_b : !edge_t) continue;
+            int16_t *base = pl + (side ? ph : -pad) * s;
+            const int cq = cols >> 2;
+            for (int i = t; i < pad * cq; i += 256) {
+                const int r = i / cq, k = i - r * cq;
+                *(uint2 *)(base + r * s + x0 + 4 * k) = *(const uint2 *)&b_row[c][side][4 * k];
+            }
+#pragma unroll
+            for (int cs = 0; cs < 2; cs++) {
+                if (cs ? !edge_r : !edge_l) continue;
+                const uint32_t v = (uint16_t)b_row[c][side][cs ? cols - 1 : 0] * 0x10001u;
+                for (int i = t; i < pad * q; i += 256) {
+                    const int r = i / q, k = i - r * q;
+                    *(uint2 *)(base + r * s + (cs ? pw : -pad) + 4 * k) = make_uint2(v, v);
+                }
+            }
+        }
     }
 }
 

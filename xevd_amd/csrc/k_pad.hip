@@ -47,19 +47,15 @@ void launch_pad(xgpu_ctx *c, const DevPic &pic)
     hipLaunchKernelGGL(k_pad, dim3(rows), dim3(256), 0, c->stream, p);
 }
 
-// The bandwidth yardstick of bench.py (roofline.measured_copy_bw_gbps): a float4 grid-stride copy with four independent 16-byte loads in flight per lane
-// before the first store (one load per iteration reached 4.8 TB/s in rounds 1-2; the guide's figure for this part is 6.29 TB/s)
+// The bandwidth yardstick of bench.py (roofline.measured_copy_bw_gbps): a float4 grid-stride copy, one 16-byte load in flight per lane and iteration, 2048
+// workgroups: 4.8 TB/s on a 1 GiB buffer.  (Round 3 tried four independent loads per lane before the first store with 4096 workgroups: 4.3-4.5 TB/s - slower.
+// The guide's 6.29 TB/s for this part is not reached by either form; bench.py reports the fraction against both.)
 __global__ __launch_bounds__(256) void k_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n)
 {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
-        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
-    }
-    for (; i < n; i += stride) dst[i] = src[i];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
 }
 void launch_copy_bw(xgpu_ctx *c, const void *src, void *dst, size_t bytes)
 {
-    hipLaunchKernelGGL(k_copy, dim3(256 * 16), dim3(256), 0, c->stream, (const uint4 *)src, (uint4 *)dst, bytes / 16);
+    hipLaunchKernelGGL(k_copy, dim3(256 * 8), dim3(256), 0, c->stream, (const uint4 *)src, (uint4 *)dst, bytes / 16);
 }

@@ -413,6 +413,7 @@ int xgpu_frame_begin(xgpu_ctx *c, const xgpu_frame_params *fp)
     c->fp = *fp;
     c->have_frame = 1;
     c->where = 0;
+    c->pad_done = 0;
     return XGPU_OK;
 }
 
@@ -1180,8 +1181,10 @@ int xgpu_alf(xgpu_ctx *c, const xgpu_alf_params *ap)
         a.ctb_flag = c->d_ctb_flag;
     }
     // the filter chain is planned so that ALF reads the scratch picture and lands in the DPB slot
+    a.pad = 1;                              // the border tiles replicate their samples into the padding: xgpu_pad has nothing left to do for this picture
     TIMED(c, XGPU_K_ALF, launch_alf(c, a, c->pics[0], dpic(c, c->fp.pic)));
     c->where = 0;
+    c->pad_done = 1;
     HIPCHK(c, hipGetLastError());
     return XGPU_OK;
 }
@@ -1189,6 +1192,7 @@ int xgpu_alf(xgpu_ctx *c, const xgpu_alf_params *ap)
 int xgpu_pad(xgpu_ctx *c)
 {
     ARGCHK(c, c != NULL); ARGCHK(c, c->have_frame); ARGCHK(c, c->where == 0);
+    if (c->pad_done) return XGPU_OK;        // k_alf wrote the padding with its border tiles
     TIMED(c, XGPU_K_PAD, launch_pad(c, dpic(c, c->fp.pic)));
     HIPCHK(c, hipGetLastError());
     return XGPU_OK;

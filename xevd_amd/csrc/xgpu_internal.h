@@ -229,6 +229,7 @@ struct AlfArgs {
     int      s_l, s_c, pic_w, pic_h, bd, log2_ctu, w_ctu, across_tiles;
     TileMask tiles;                    // tile starts: a CTU's windows end at its tile (alf_process_tile)
     int      multi_tile;               // 0: one tile - the masks are not looked at
+    int      pad;                      // 1: the tiles on the picture border also write the 144 / 72-sample padding of the output picture (no k_pad launch)
     int      enable[3];
     const uint8_t *ctb_flag;           // device, [n_ctu] or null
     int16_t  coef[25 * 13 + 7];        // coef_final followed by the chroma filter
@@ -294,6 +295,7 @@ struct xgpu_ctx {
     xgpu_frame_params fp;
     int             have_frame;
     TileMask        no_dbk;            // tile borders the deblocking of the current picture leaves alone (set by xgpu_batch_recon)
+    int             pad_done;          // the padding of the current picture has been written (by k_alf's border tiles): xgpu_pad launches nothing
     int             where;             // 0: the picture being built lives in its DPB slot, 1: in the scratch picture
     // timing
     int             timing;
