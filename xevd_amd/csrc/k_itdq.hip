@@ -98,7 +98,10 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 // pairs (union over the wave's TBs, a scalar bit loop - the matrix rows stay wave-uniform SGPR loads) and stage 2 only the set column pairs: a column
 // without coefficients stays zero through the vertical transform.  The round-2 loop tested every row pair with an LDS read + ballot + branch - 32
 // dependent LDS round trips per stage for a 64-point transform, which is what the kernel's time was (the arithmetic itself is a few dozen dot2).
-template <int LW, int LH>
+// IQT: the sequence uses the 16-bit two-stage transforms (sps->tool_iqt) - every work item keeps a clipped s16 intermediate, so only ONE intermediate plane
+// exists in LDS (17 KB instead of 27 KB per workgroup) and the 32-bit split path is not compiled in: more workgroups per CU for a kernel that is bound by the
+// latency of its dependent loads, not by arithmetic.
+template <int LW, int LH, bool IQT>
 __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, uint32_t *lds, uint32_t *s_rm, uint32_t *s_cm)
 {
     constexpr int W = 1 << LW, H = 1 << LH;
@@ -109,6 +112,7 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
     constexpr int PLANE = G * H * RS;                          // dwords per intermediate plane
     constexpr bool UNI1 = (G * W) % 64 == 0, UNI2 = (G * H) % 64 == 0;
     static_assert(2 * PLANE <= ITDQ_PLANES_DWORDS && G * W * H <= 4096 && G <= ITDQ_MAX_G, "LDS budget");
+    constexpr int PLANES_DWORDS = IQT ? ITDQ_PLANES_DWORDS / 2 : ITDQ_PLANES_DWORDS;
     constexpr bool RMASK = H >= 16, CMASK = W >= 16;          // shorter transforms: the masks would cost more than the 2..4 loop rounds they can save
     const int t = threadIdx.x;
     if (RMASK || CMASK) {
@@ -118,10 +122,10 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
     // wave-uniform matrix choice: DCT-II, or for ATS work items (4..32 only) DST-VII / DCT-VIII
     const uint32_t *tmh = (wv.tr_v == TR_DCT2 || LH < 2 || LH > 5) ? k_tmp + tmp_base(LH) : k_atsp[wv.tr_v - 1] + atsp_base(LH);
     const uint32_t *tmw = (wv.tr_h == TR_DCT2 || LW < 2 || LW > 5) ? k_tmp + tmp_base(LW) : k_atsp[wv.tr_h - 1] + atsp_base(LW);
-    const bool s16_mid = a.iqt || wv.tr_v != TR_DCT2 || wv.tr_h != TR_DCT2;    // ATS keeps a clipped s16 intermediate like IQT (:406-421)
+    const bool s16_mid = IQT || wv.tr_v != TR_DCT2 || wv.tr_h != TR_DCT2;     // ATS keeps a clipped s16 intermediate like IQT (:406-421)
     int16_t *ldsh = (int16_t *)lds;                            // plane 0: hi (or the IQT intermediate), plane 1: lo
     int16_t *ldsl = (int16_t *)(lds + PLANE);
-    uint32_t *ldsc = lds + ITDQ_PLANES_DWORDS;                 // dequantised coefficients, [p][row][col] s16
+    uint32_t *ldsc = lds + PLANES_DWORDS;                      // dequantised coefficients, [p][row][col] s16
 
     // ------------------------------------------------ stage 0: load + dequantise ---------------------------
     // all coefficients of the G blocks in one coalesced sweep (one memory round trip for the whole work item),
@@ -137,7 +141,7 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
             if (p >= wv.count) break;
             const TbRec tb = a.tbs[wv.first + p];
             const int qp = tb.qp, sidx = qp % 6;
-            const int sbase = sidx == 0 ? 40 : sidx == 1 ? 45 : sidx == 2 ? 51 : sidx == 3 ? 57 : sidx == 4 ? 64 : (a.iqt ? 72 : 71);
+            const int sbase = sidx == 0 ? 40 : sidx == 1 ? 45 : sidx == 2 ? 51 : sidx == 3 ? 57 : sidx == 4 ? 64 : (IQT ? 72 : 71);
             const long long mul = (long long)(sbase << (qp / 6)) * (odd ? 181 : 1);
             // row-major TB with row stride 2^log2s (a sub-block of a >64 CU keeps the CU's stride, xevd_itdq.c:573-584)
             const int16_t *src = a.coef + tb.off + ((o >> LW) << tb.log2s) + (o & (W - 1));
@@ -303,14 +307,15 @@ __device__ __forceinline__ void itdq_item(const ItdqArgs &a, const TbWave wv, ui
     }
 }
 
+template <bool IQT>
 __global__ __launch_bounds__(256) void k_itdq(const ItdqArgs a)
 {
-    __shared__ uint32_t lds[ITDQ_LDS_DWORDS];
+    __shared__ uint32_t lds[IQT ? ITDQ_LDS_DWORDS - ITDQ_PLANES_DWORDS / 2 : ITDQ_LDS_DWORDS];
     __shared__ uint32_t s_rm[ITDQ_MAX_G], s_cm[ITDQ_MAX_G];      // per TB: coefficient row pairs / column pairs that are not all zero
     const int wi = blockIdx.x;
     if (wi >= a.n_waves) return;
     const TbWave wv = a.waves[wi];
-#define CASE(lw, lh) case (lw) * 8 + (lh): itdq_item<lw, lh>(a, wv, lds, s_rm, s_cm); break;
+#define CASE(lw, lh) case (lw) * 8 + (lh): itdq_item<lw, lh, IQT>(a, wv, lds, s_rm, s_cm); break;
 #define ROW(lw) CASE(lw, 1) CASE(lw, 2) CASE(lw, 3) CASE(lw, 4) CASE(lw, 5) CASE(lw, 6)
     switch (wv.log2w * 8 + wv.log2h) {
         ROW(1) ROW(2) ROW(3) ROW(4) ROW(5) ROW(6)
@@ -321,5 +326,6 @@ __global__ __launch_bounds__(256) void k_itdq(const ItdqArgs a)
 void launch_itdq(xgpu_ctx *c, const ItdqArgs &a, hipStream_t s)
 {
     if (a.n_waves <= 0) return;
-    hipLaunchKernelGGL(k_itdq, dim3(a.n_waves), dim3(256), 0, s, a);
+    if (a.iqt) hipLaunchKernelGGL(k_itdq<true>, dim3(a.n_waves), dim3(256), 0, s, a);
+    else       hipLaunchKernelGGL(k_itdq<false>, dim3(a.n_waves), dim3(256), 0, s, a);
 }
