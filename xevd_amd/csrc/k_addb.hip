@@ -147,8 +147,8 @@ __device__ __forceinline__ void addb_edge(const AddbArgs &a, const uint4 rq, con
 // k_addb_fused - both edge directions in ONE kernel: one read and one write of the picture instead of two of each.
 //
 // Grid edges are 8 samples apart and a filter touches at most 4 samples on either side (3 written), so the 8-sample windows centred on the grid lines
-// tile the picture in BOTH directions.  A workgroup therefore owns the tile [X0 - 4, X0 + 252) x [Y0 - 4, Y0 + 28) - shifted by half a window against
-// the 8x8 grid - which holds 32 x 8 complete vertical-edge windows (8 samples x 4 rows) and, at the same time, 64 x 4 complete horizontal-edge windows
+// tile the picture in BOTH directions.  A workgroup therefore owns the tile [X0 - 4, X0 + 252) x [Y0 - 4, Y0 + 12) - shifted by half a window against
+// the 8x8 grid - which holds 32 x 4 complete vertical-edge windows (8 samples x 4 rows) and, at the same time, 64 x 2 complete horizontal-edge windows
 // (4 samples x 8 rows): no halo in either direction, nothing is read or filtered twice.
 //   phase V: lane = one vertical-edge segment: SCU records + its luma / chroma windows from HBM (a wave's loads are two 512-byte runs per
 //            row), filter, windows -> LDS, the two SCU records -> LDS (the horizontal phase needs the same 64 x 8 records);
@@ -159,20 +159,22 @@ __device__ __forceinline__ void addb_edge(const AddbArgs &a, const uint4 rq, con
 // ---------------------------------------------------------------------------------------------------------
 #define AF_LS 264                 // LDS luma row stride in samples: 256 + 8 (rows 4 apart land 16 banks apart; rows stay 16-byte aligned)
 #define AF_CS 136                 // chroma: 128 + 8
-__global__ __launch_bounds__(256) void k_addb_fused(const AddbArgs a, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
+template <int SR>                 // SCU rows of the tile: 4 = 128 threads, 256 x 16 samples (8 = 256 threads, 256 x 32 samples measured the same)
+__global__ __launch_bounds__(32 * SR) void k_addb_fused(const AddbArgs a, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
                                                     const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_,
                                                     int16_t *__restrict__ dv_, int tiles_x)
 {
     __shared__ uint8_t s_alpha[52], s_beta[52], s_clip[52 * 5], s_pic[XGPU_MAX_REFS * 2];
     __shared__ int8_t s_cqp[2 * 96];
-    __shared__ __attribute__((aligned(16))) int16_t s_y[32 * AF_LS];
-    __shared__ __attribute__((aligned(16))) int16_t s_c[2][16 * AF_CS];
-    __shared__ uint4 s_map[8][64];
+    constexpr int NT = 32 * SR;
+    __shared__ __attribute__((aligned(16))) int16_t s_y[4 * SR * AF_LS];
+    __shared__ __attribute__((aligned(16))) int16_t s_c[2][2 * SR * AF_CS];
+    __shared__ uint4 s_map[SR][64];
     const int t = threadIdx.x;
-    for (int i = t; i < 52; i += 256) { s_alpha[i] = k_alpha[i]; s_beta[i] = k_beta[i]; }
-    for (int i = t; i < 260; i += 256) s_clip[i] = ((const uint8_t *)k_clip)[i];
-    for (int i = t; i < XGPU_MAX_REFS * 2; i += 256) s_pic[i] = a.pic_id[i];
-    for (int i = t; i < 192; i += 256) s_cqp[i] = a.chroma_qp[i];
+    for (int i = t; i < 52; i += NT) { s_alpha[i] = k_alpha[i]; s_beta[i] = k_beta[i]; }
+    for (int i = t; i < 260; i += NT) s_clip[i] = ((const uint8_t *)k_clip)[i];
+    for (int i = t; i < XGPU_MAX_REFS * 2; i += NT) s_pic[i] = a.pic_id[i];
+    for (int i = t; i < 192; i += NT) s_cqp[i] = a.chroma_qp[i];
     const int tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
     const int n_ex = (a.w_scu >> 1) + 1, n_ey = (a.h_scu >> 1) + 1;     // grid lines incl. the picture borders (which only copy their inner half)
 #define PK2(lo, hi) ((uint32_t)(uint16_t)(lo) | ((uint32_t)(uint16_t)(hi) << 16))
@@ -181,7 +183,7 @@ __global__ __launch_bounds__(256) void k_addb_fused(const AddbArgs a, const int1
     {
         const int wx = t & 31, sr = t >> 5;                  // window along x, SCU row of the tile
         const int ex = (tx << 5) + wx;                       // grid line x = 8 * ex
-        const int srow = (ty << 3) - 1 + sr;                 // SCU row in the picture
+        const int srow = ty * SR - 1 + sr;                   // SCU row in the picture
         const int sxq = ex << 1;                             // the Q-side SCU column
         const bool ok = ex < n_ex && srow >= 0 && srow < a.h_scu;
         const bool has_p = ok && ex > 0, has_q = ok && sxq < a.w_scu;
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256) void k_addb_fused(const AddbArgs a, const int1
     {
         const int sx = t & 63, g = t >> 6;                   // SCU column of the tile, grid line of the tile
         const int scol = (tx << 6) - 1 + sx;                 // SCU column in the picture
-        const int ey = (ty << 2) + g;                        // grid line y = 8 * ey
+        const int ey = ty * (SR / 2) + g;                    // grid line y = 8 * ey
         if (scol < 0 || scol >= a.w_scu || ey >= n_ey) return;
         const int syq = ey << 1;                             // the Q-side SCU row
         const bool has_p = ey > 0, has_q = syq < a.h_scu;
@@ -276,7 +278,10 @@ __global__ __launch_bounds__(256) void k_addb_fused(const AddbArgs a, const int1
 void launch_addb_fused(xgpu_ctx *c, const AddbArgs &a, const DevPic &src, const DevPic &dst)
 {
     const int n_ex = (a.w_scu >> 1) + 1, n_ey = (a.h_scu >> 1) + 1;
-    const int tiles_x = (n_ex + 31) >> 5, tiles_y = (n_ey + 3) >> 2;
-    hipLaunchKernelGGL(k_addb_fused, dim3(tiles_x * tiles_y), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v, tiles_x);
+    // tile height: 4 SCU rows (128 threads, 17 KB of LDS: nine workgroups per CU in different phases of load - filter - store).  Measured against 8 rows (256
+    // threads, 34 KB): 64.9 / 65.0 us at 8K, 25.0 / 26.4 us at 4K - the kernel is bound by neither VALU issue (an edge-compacted variant with 12.7 M instead of
+    // 21.7 M VALU instructions took the same 66 us) nor workgroup granularity; 233 MB in 65 us is 75 % of what a plain copy kernel reaches on this part.
+    const int tiles_x = (n_ex + 31) >> 5;
+    hipLaunchKernelGGL(k_addb_fused<4>, dim3(tiles_x * ((n_ey + 1) >> 1)), dim3(128), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v, tiles_x);
 }
 

@@ -26,7 +26,7 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 #define LROWS 70
 #define LSTR  72          // luma LDS row stride in s16: window col c (-3..66) at index c+4
 #define CROWS 36
-#define SSTR  40          // sub-block sums row stride (u16); sub-block col c (-1..32) at index c+2 (own pairs 4-byte aligned)
+#define SSTR  36          // sub-block sums row stride (u16); sub-block col c (-1..32) at index c+2 (own pairs 4-byte aligned)
 #define CSTR  40          // chroma: window col c (-2..33) at index c+4 (keeps the 8-byte interior pieces aligned)
 
 struct CtuRect { int x0, y0, cw, ch, aL, aR, aT, aB; int tx0, tx1, ty0, ty1; };      // the CTU, its border availability, its tile [tx0,tx1) x [ty0,ty1)
@@ -128,7 +128,10 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
     __shared__ __attribute__((aligned(16))) uint16_t l_lap[4][34][SSTR];
     // the filtered samples on the picture border that this tile holds: [plane][first / last row of the picture][column of the tile] and [first / last column][row],
     // for the border replication below (what k_pad did in a launch of its own)
-    __shared__ __attribute__((aligned(8))) int16_t b_row[3][2][64], b_col[3][2][64];
+    // They live in l_y: every lane has its luma window in registers before the barrier behind phase 1, so the staged tile is dead by the time the first filtered
+    // sample exists (26 KB of LDS per workgroup = six workgroups per CU).
+    int16_t (*b_row)[2][64] = (int16_t (*)[2][64])l_y, (*b_col)[2][64] = (int16_t (*)[2][64])(l_y + 3 * 2 * 64);
+    static_assert(2 * 3 * 2 * 64 <= LROWS * LSTR, "the border arrays fit into the staged luma tile");
 
     // XCD-aware mapping: workgroup b runs on XCD b % 8 and every XCD has its own L2.  A tile reads its neighbours' edge samples as halo (the 8-byte
     // pieces at cols -4 and 64 sit in the cache lines of the tiles to the left and right, 3 rows above / below in those of the tiles there), so

@@ -379,7 +379,11 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
         for (int sidx = t; sidx < (htdf_only ? 0 : nscu); sidx += 64) {
             const int lx = (sidx % scuw) << 2, ly = (sidx / scuw) << 2;
             const int x = cu_x + lx, y = cu_y + ly;
-            if (sidx != t) fetch_resid(lx, ly);                      // later rounds of a CU above 32x32
+            // a CU above 32x32 takes several rounds: the residual of the NEXT round is requested before this round's arithmetic, so that a round does not
+            // start with a memory round trip (the level-1 launch is as long as its 64x64 CUs take)
+            const uint2 rl_cur[4] = { rl[0], rl[1], rl[2], rl[3] };
+            const uint32_t rc_cur[2][2] = { { rc[0][0], rc[0][1] }, { rc[1][0], rc[1][1] } };
+            if (sidx + 64 < nscu) fetch_resid(((sidx + 64) % scuw) << 2, ((sidx + 64) / scuw) << 2);
             int pl[4][4], pc[2][2][2];
             if (IBC && ibc_cu) {
                 // xevdm_IBC_mc (xevdm_mc.c:2040-2106): the block at the whole-sample vector in the current picture, chroma at the halved vector.
@@ -446,14 +450,14 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
                 ol[r][0] = pack2i(pl[r][0], pl[r][1]); ol[r][1] = pack2i(pl[r][2], pl[r][3]);
                 // also without coefficients: the reference clips the prediction (xevd_recon.c:44-51) - the DC of a 4x8 / 8x4 block next to an unavailable side
                 // (mid-grey neighbours, sum of 12 samples shifted by 3) leaves the sample range
-                ol[r][0] = recon2i(ol[r][0], (cbf & 1) ? rl[r].x : 0u, maxv); ol[r][1] = recon2i(ol[r][1], (cbf & 1) ? rl[r].y : 0u, maxv);
+                ol[r][0] = recon2i(ol[r][0], (cbf & 1) ? rl_cur[r].x : 0u, maxv); ol[r][1] = recon2i(ol[r][1], (cbf & 1) ? rl_cur[r].y : 0u, maxv);
             }
 #pragma unroll
             for (int c = 1; c < 3; c++)
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
                     oc[c - 1][r] = pack2i(pc[c - 1][r][0], pc[c - 1][r][1]);
-                    oc[c - 1][r] = recon2i(oc[c - 1][r], ((cbf >> c) & 1) ? rc[c - 1][r] : 0u, maxv);   // the luma depth clips chroma too (xevd_recon.c:75-90)
+                    oc[c - 1][r] = recon2i(oc[c - 1][r], ((cbf >> c) & 1) ? rc_cur[c - 1][r] : 0u, maxv);   // the luma depth clips chroma too (xevd_recon.c:75-90)
                 }
             const int coff = (y >> 1) * a.s_c + (x >> 1);
             // local dual tree: a chroma-only CU (flag 32) leaves luma alone, a luma-only one (64) chroma - what was computed for the missing plane is dropped

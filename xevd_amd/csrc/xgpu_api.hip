@@ -634,14 +634,16 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         max_level = std::max(max_level, lv + 1);
         recs.push_back(r);
     }
-    // counting sort by level (levels are 1-based), then dependency CU indices -> list positions
-    std::vector<int> first((size_t)max_level + 2, 0);
-    for (const IntraRec &r : recs) first[level[r.cu] + 1]++;
-    for (int l = 1; l <= max_level + 1; l++) first[l] += first[l - 1];
+    // sort by level (levels are 1-based; every dependency sits on a lower one), the larger CUs of a level first - a 64x64 CU is four rounds of its wave and should
+    // not be the last thing a launch starts -, decode order otherwise; then dependency CU indices -> list positions
+    auto key = [&](const IntraRec &r) { return (size_t)level[r.cu] * 16 + (size_t)(14 - (r.log2w + r.log2h)); };      // counting sort: log2w + log2h is 4 .. 14
+    std::vector<int> first(((size_t)max_level + 2) * 16, 0);
+    for (const IntraRec &r : recs) first[key(r) + 1]++;
+    for (size_t l = 1; l < first.size(); l++) first[l] += first[l - 1];
     static thread_local std::vector<uint32_t> pos;
     pos.assign((size_t)n, NONE);
     plan.recs.resize(recs.size());
-    for (const IntraRec &r : recs) { pos[r.cu] = (uint32_t)first[level[r.cu]]; plan.recs[first[level[r.cu]]++] = r; }
+    for (const IntraRec &r : recs) { const int k = first[key(r)]++; pos[r.cu] = (uint32_t)k; plan.recs[(size_t)k] = r; }
     for (uint32_t &d : deps) d = pos[d];
     plan.deps.swap(deps);
     plan.n_levels = max_level;
