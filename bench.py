@@ -300,6 +300,7 @@ def end_to_end_leg(dec, wl, batches, alf, slots, steps, warmup, builders=int(os.
         bb = dict(b)
         bb["coef"] = arena[:len(b["coef"])]
         prepared.append(abi.make_cu_batch(bb))
+    dec.lib.xgpu_set_builder_threads(dec.ctx, int(os.environ.get("XEVD_BENCH_BUILD_THREADS", "4")))      # every xgpu_batch_create spreads its per-CU passes
     out_size = dec.lib.xgpu_pic_output_size(dec.ctx, wl["bd"], 0, 0, 0, 0)
     outs = [dec.host_alloc(out_size) for _ in range(2)]
     two_lists = wl["n_refs"][1] > 0
@@ -342,7 +343,7 @@ def end_to_end_leg(dec, wl, batches, alf, slots, steps, warmup, builders=int(os.
     d2h_ms = (time.perf_counter() - t1) / 5 * 1e3
     h2d = float(np.mean([b["coef"].nbytes for b in batches]))
     return {"fps": round(steps / dt, 2), "ms_per_picture": round(1e3 * dt / steps, 3), "steps": steps,
-            "builder_threads": builders, "pictures_in_flight": depth,
+            "builder_threads": builders, "threads_per_builder": int(os.environ.get("XEVD_BENCH_BUILD_THREADS", "4")), "pictures_in_flight": depth,
             "stage_ms": {"batch_build_per_thread": round(1e3 * float(np.mean(build_s)), 3), "output_kernel_plus_d2h_alone": round(d2h_ms, 3)},
             "h2d_coef_bytes_per_picture": int(h2d), "d2h_bytes_per_picture": int(out_size),
             "what": "host CU batches -> xgpu_batch_create (builder threads, pinned coefficient arena) -> upload stream -> kernels -> "

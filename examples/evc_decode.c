@@ -16,7 +16,7 @@
  * --tile-threads T lets every worker's parser use T threads for the tiles of one picture (xhost_parser_set_threads).
  * Every worker runs its parser on a thread of its own, one picture ahead of the thread that builds the device batch and launches the kernels
  * (--no-pipeline: back to back on one thread, as xevd_dec_nalu does it).
- * usage: evc_decode [--gpus N] [--workers W] [--tile-threads T] [--no-pipeline] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
+ * usage: evc_decode [--gpus N] [--workers W] [--tile-threads T] [--build-threads B] [--no-pipeline] [--trace] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
  *        evc_decode in.evc out.yuv D                                               (the round-1 form)
  * build: oracle-free; see examples/Makefile.
  */
@@ -37,6 +37,7 @@
 #define MAX_GOPS 4096
 #define CHECK(call) do { int rc_ = (call); if (rc_ < 0) { fprintf(stderr, "%s -> %d (%s)\n", #call, rc_, w->g ? xgpu_last_error(w->g) : ""); return rc_; } } while (0)
 static double now_s(void);
+static int g_build_threads = 4;     /* --build-threads B: host threads xgpu_batch_create spreads its per-CU passes over */
 
 typedef struct { int poc, pic, in_use; } slot_t;                 /* DPB: POC -> device picture slot */
 typedef struct { int epoch, poc; size_t off; } out_t;              /* one output picture: position in the unit's buffer */
@@ -93,6 +94,7 @@ static int worker_context(worker_t *w, const xhost_picture *p)
     sp.chroma_qp_table[0] = p->chroma_qp_table[0]; sp.chroma_qp_table[1] = p->chroma_qp_table[1];
     xgpu_ctx *g = NULL;
     CHECK(xgpu_open(&sp, &g));
+    if (g_build_threads > 1) (void)xgpu_set_builder_threads(g, g_build_threads > 64 ? 64 : g_build_threads);
     pthread_mutex_lock(&w->arena_mu);
     w->g = g;
     pthread_mutex_unlock(&w->arena_mu);
@@ -416,6 +418,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[a], "--tile-threads") && a + 1 < argc) { g_tile_threads = atoi(argv[a + 1]); a += 2; }
         else if (!strcmp(argv[a], "--no-pipeline")) { g_pipeline = 0; a += 1; }
         else if (!strcmp(argv[a], "--trace")) { g_trace = 1; a += 1; }
+        else if (!strcmp(argv[a], "--build-threads") && a + 1 < argc) { g_build_threads = atoi(argv[a + 1]); a += 2; }
         else break;
     }
     int n_pos = argc - a;

@@ -238,6 +238,9 @@ int  xgpu_batch_wait_upload(xgpu_ctx *ctx, xgpu_dbatch *db);
    sub-blocks in raster order - mv[list][x/y] in quarter samples: refined where the refinement ran, the CU's own otherwise.  `n` = capacity of
    `mv` in sub-blocks; returns the number of sub-blocks (also with mv = NULL), or a negative error.  Blocking.                                 */
 int  xgpu_batch_dmvr_mvs(xgpu_ctx *ctx, xgpu_dbatch *db, int16_t *mv, int n);
+/* Host threads xgpu_batch_create may spread its per-CU passes over (validation + counting, record / TB-list construction, the owner map); 1..64, default 1.
+   The device arrays it builds do not depend on the count. */
+int  xgpu_set_builder_threads(xgpu_ctx *ctx, int n);
 /* what the batch builder made of the batch (measurement / diagnostics): info[0] CUs, [1] transform blocks, [2] work items of the transform kernel,
    [3] nodes of the order-dependent kernel (intra / IBC CUs, HTDF nodes), [4] of them without a node among their neighbours, [5] depth of the
    dependency graph (levels), [6] DMVR sub-blocks, [7] affine tiles.                                                                            */

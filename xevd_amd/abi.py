@@ -193,6 +193,7 @@ _EXPORTS = {
     "xgpu_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "xgpu_host_free": (None, [C.c_void_p, C.c_void_p]),
     "xgpu_batch_wait_upload": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "xgpu_set_builder_threads": (C.c_int, [C.c_void_p, C.c_int]),
     "xgpu_batch_prepare": (C.c_int, [C.c_void_p, C.c_void_p]),
     "xgpu_batch_info": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "xgpu_batch_dmvr_mvs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),

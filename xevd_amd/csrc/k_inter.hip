@@ -406,9 +406,7 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
 // CU record -> reference windows.  The host paints the owner map (xgpu_batch_create), so there is no k_paint and no per-CTU staging of CU records.
 // (A persistent variant that kept the first links of the next tiles in flight was measured slower: the prefetch registers pushed the kernel into
 // scratch and its 53 KB of code out of the instruction cache; DESIGN.md.)
-#ifdef INTER_WAVES_PER_SIMD       // experiment switch of the build (tools/run_exp_waves.sh): force the register allocator to an occupancy
-__attribute__((amdgpu_waves_per_eu(INTER_WAVES_PER_SIMD, INTER_WAVES_PER_SIMD)))
-#endif
+// (Round 3: forcing the register allocator to five waves per SIMD - amdgpu_waves_per_eu(5, 5): 96 VGPRs + 192 bytes of scratch per lane - took 286 us instead of 152.)
 __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
 {
     __shared__ uint4    s_ref[XGPU_MAX_REFS * 2][2];        // RefEntry [idx][list]

@@ -155,6 +155,7 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     xgpu_ctx *c = new xgpu_ctx();
     c->sp = *sp;
     c->sp.chroma_qp_table[0] = c->sp.chroma_qp_table[1] = NULL;
+    c->builder_threads = 1;
     c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_dra = NULL; c->d_ctb_flag = NULL; c->stream = 0; c->up_stream = 0; c->down_stream = 0; c->side_stream = 0; c->after_inter = 0; c->have_after_inter = 0; c->where = 0;
     for (int i = 0; i < 2; i++) { c->d_out[i] = NULL; c->out_caps[i] = 0; c->out_ready[i] = c->out_done[i] = 0; c->out_busy[i] = 0; }
     c->out_next = 0;
@@ -695,7 +696,6 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     // pass 1: validate + count TBs per size class
     // size class = (log2w, log2h) x (vertical, horizontal) transform kind; ATS kinds only occur for intra luma TBs
     enum { NCLS = 64 * 9 };
-    int cls_count[NCLS] = { 0 };
     auto ats_inter_of = [&](int i) -> int { return (b->ats_inter && b->pred_mode[i] != XGPU_MODE_INTRA && b->pred_mode[i] != XGPU_MODE_IBC) ? b->ats_inter[i] : 0; };
     auto tr_code = [&](int i, int k) -> int {
         if (k != 0) return 0;
@@ -718,7 +718,6 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         if (idx == 1 || idx == 3) bw -= idx == 3 ? 2 : 1;
         if (idx == 2 || idx == 4) bh -= idx == 4 ? 2 : 1;
     };
-    int n_aff = 0, n_aff_eif = 0, n_aff_sub = 0, n_dmvr = 0;
     // DMVR candidates the backend can refine: flagged, plain inter, two references, at least 8x8 (the POC test happens on the device)
     auto dmvr_cand = [&](int i) -> bool {
         return b->dmvr && b->dmvr[i] && b->pred_mode[i] != XGPU_MODE_INTRA && b->pred_mode[i] != XGPU_MODE_IBC && !(b->affine && b->affine[i]) &&
@@ -733,43 +732,58 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         aff_subblock(md, use, bb->log2w[i], bb->log2h[i], sw, sh, mb);
         return sw < 8 || sh < 8;
     };
-    for (int i = 0; i < n; i++) {
+    // The builder's per-CU passes run on `builder_threads` host threads (xgpu_set_builder_threads; default 1), each over a contiguous range of CUs: pass 1
+    // validates and counts per range, a prefix over the ranges gives every thread its own start in each output list, pass 2 and the owner map then write
+    // disjoint parts - the lists come out exactly as the sequential passes build them.
+    struct Part { int cls[NCLS]; int n_aff, n_eif, n_sub, n_dmvr; };
+    const int nthr = std::max(1, std::min(c->builder_threads, std::max(1, n / 4096)));
+    std::vector<Part> parts((size_t)nthr);
+    for (Part &P : parts) memset(&P, 0, sizeof(P));
+    auto run_parts = [&](auto fn) {                       // fn(thread, first CU, one past the last)
+        std::vector<std::thread> th;
+        for (int k = 1; k < nthr; k++) th.emplace_back(fn, k, (int)((long long)n * k / nthr), (int)((long long)n * (k + 1) / nthr));
+        fn(0, 0, (int)((long long)n / nthr));
+        for (std::thread &t : th) t.join();
+    };
+#define CUCHK(cond) do { if (!(cond)) return #cond; } while (0)
+    auto pass1 = [&](int i0, int i1, Part &P) -> const char * {
+    for (int i = i0; i < i1; i++) {
         const int lw = b->log2w[i], lh = b->log2h[i];
-        ARGCHK(c, lw >= 2 && lw <= 7 && lh >= 2 && lh <= 7 && lw <= c->sp.log2_ctu && lh <= c->sp.log2_ctu);
-        ARGCHK(c, b->x[i] + (1 << lw) <= c->sp.width && b->y[i] + (1 << lh) <= c->sp.height && !(b->x[i] & 3) && !(b->y[i] & 3));
-        ARGCHK(c, b->pred_mode[i] <= XGPU_MODE_DIR || b->pred_mode[i] == XGPU_MODE_IBC);
+        CUCHK(lw >= 2 && lw <= 7 && lh >= 2 && lh <= 7 && lw <= c->sp.log2_ctu && lh <= c->sp.log2_ctu);
+        CUCHK(b->x[i] + (1 << lw) <= c->sp.width && b->y[i] + (1 << lh) <= c->sp.height && !(b->x[i] & 3) && !(b->y[i] & 3));
+        CUCHK(b->pred_mode[i] <= XGPU_MODE_DIR || b->pred_mode[i] == XGPU_MODE_IBC);
         if (b->tree && b->tree[i]) {      // local dual tree: luma-only intra / IBC CUs, chroma-only intra CUs, only the coefficients of the planes they have
-            ARGCHK(c, b->tree[i] <= 2 && (b->pred_mode[i] == XGPU_MODE_INTRA || (b->tree[i] == 1 && b->pred_mode[i] == XGPU_MODE_IBC)));
-            ARGCHK(c, (b->cbf[i] & (b->tree[i] == 1 ? 6 : 1)) == 0);
+            CUCHK(b->tree[i] <= 2 && (b->pred_mode[i] == XGPU_MODE_INTRA || (b->tree[i] == 1 && b->pred_mode[i] == XGPU_MODE_IBC)));
+            CUCHK((b->cbf[i] & (b->tree[i] == 1 ? 6 : 1)) == 0);
             if (b->tree[i] == 1) {        // a luma-only CU lies inside the chroma-only CU that closes its tree (checked here: nothing is allocated yet)
                 int j = i + 1;
                 while (j < n && b->tree[j] != 2) j++;
-                ARGCHK(c, j < n && b->x[j] <= b->x[i] && b->y[j] <= b->y[i] && b->x[i] + (1 << lw) <= b->x[j] + (1 << b->log2w[j]) && b->y[i] + (1 << lh) <= b->y[j] + (1 << b->log2h[j]));
+                CUCHK(j < n && b->x[j] <= b->x[i] && b->y[j] <= b->y[i] && b->x[i] + (1 << lw) <= b->x[j] + (1 << b->log2w[j]) && b->y[i] + (1 << lh) <= b->y[j] + (1 << b->log2h[j]));
             }
         }
         if (b->pred_mode[i] == XGPU_MODE_IBC) {
             // the source block (and the chroma block at the halved vector) inside the active picture; that it is reconstructed before the CU is
             // checked by the dependency plan below
             const int bvx = b->mv[i * 4], bvy = b->mv[i * 4 + 1];
-            ARGCHK(c, b->x[i] + (bvx & ~1) >= 0 && b->y[i] + (bvy & ~1) >= 0 && b->x[i] + bvx + (1 << lw) <= c->sp.width && b->y[i] + bvy + (1 << lh) <= c->sp.height);
-            ARGCHK(c, !(b->affine && b->affine[i]));
-        } else if (b->pred_mode[i] != XGPU_MODE_INTRA) ARGCHK(c, b->refi[i * 2] < XGPU_MAX_REFS && b->refi[i * 2 + 1] < XGPU_MAX_REFS);
-        ARGCHK(c, b->qp[i * 3] < 96 && b->qp[i * 3 + 1] < 96 && b->qp[i * 3 + 2] < 96);                     // 0..51 + 6 * (bit depth - 8)
+            CUCHK(b->x[i] + (bvx & ~1) >= 0 && b->y[i] + (bvy & ~1) >= 0 && b->x[i] + bvx + (1 << lw) <= c->sp.width && b->y[i] + bvy + (1 << lh) <= c->sp.height);
+            CUCHK(!(b->affine && b->affine[i]));
+        } else if (b->pred_mode[i] != XGPU_MODE_INTRA) CUCHK(b->refi[i * 2] < XGPU_MAX_REFS && b->refi[i * 2 + 1] < XGPU_MAX_REFS);
+        CUCHK(b->qp[i * 3] < 96 && b->qp[i * 3 + 1] < 96 && b->qp[i * 3 + 2] < 96);                     // 0..51 + 6 * (bit depth - 8)
         if (const int ai = ats_inter_of(i)) {
             // availability as xevdm_check_ats_inter_info_coded (xevdm_util.c:3565-3583): CU <= 64, split dimension >= 8 (>= 16 for quarters)
             const int idx = ai & 15, pos = ai >> 4;
-            ARGCHK(c, idx >= 1 && idx <= 4 && pos <= 1 && lw <= 6 && lh <= 6);
-            ARGCHK(c, ((idx == 1 || idx == 3) ? lw : lh) >= (idx >= 3 ? 4 : 3));
+            CUCHK(idx >= 1 && idx <= 4 && pos <= 1 && lw <= 6 && lh <= 6);
+            CUCHK(((idx == 1 || idx == 3) ? lw : lh) >= (idx >= 3 ? 4 : 3));
         }
         if (b->affine && b->affine[i]) {
             // affine CUs exist from 8x8 (xevdm_eco.c:1529), with 2 or 3 control points and at least one reference
-            ARGCHK(c, b->affine_mv != NULL && (b->affine[i] == 2 || b->affine[i] == 3) && b->pred_mode[i] != XGPU_MODE_INTRA);
-            ARGCHK(c, lw >= 3 && lh >= 3 && (b->refi[i * 2] >= 0 || b->refi[i * 2 + 1] >= 0));
-            n_aff++;
-            if (affine_is_eif(b, i)) n_aff_eif += ((1 << lw) + 15) / 16 * (((1 << lh) + 15) / 16);
-            else                     n_aff_sub += ((1 << lw) + 31) / 32 * (((1 << lh) + 31) / 32);
+            CUCHK(b->affine_mv != NULL && (b->affine[i] == 2 || b->affine[i] == 3) && b->pred_mode[i] != XGPU_MODE_INTRA);
+            CUCHK(lw >= 3 && lh >= 3 && (b->refi[i * 2] >= 0 || b->refi[i * 2 + 1] >= 0));
+            P.n_aff++;
+            if (affine_is_eif(b, i)) P.n_eif += ((1 << lw) + 15) / 16 * (((1 << lh) + 15) / 16);
+            else                     P.n_sub += ((1 << lw) + 31) / 32 * (((1 << lh) + 31) / 32);
         }
-        if (dmvr_cand(i)) n_dmvr += (lw > 4 ? 1 << (lw - 4) : 1) * (lh > 4 ? 1 << (lh - 4) : 1);
+        if (dmvr_cand(i)) P.n_dmvr += (lw > 4 ? 1 << (lw - 4) : 1) * (lh > 4 ? 1 << (lh - 4) : 1);
         size_t need = 0;
         int bw, bh;
         blk_log2(i, bw, bh);
@@ -781,13 +795,24 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
             for (int sb = 0; sb < 4; sb++) {
                 if ((sb & 1) >= nsx || (sb >> 1) >= nsy) continue;
                 if (nsx * nsy > 1 && b->cbf_sub && !((b->cbf_sub[i] >> (4 * k + sb)) & 1)) continue;
-                ARGCHK(c, tr_code(i, k) == 0 || (tw >= 2 && tw <= 5 && th >= 2 && th <= 5));      // ATS exists for 4..32 only (checked before anything is allocated)
-                cls_count[tr_code(i, k) * 64 + tw * 8 + th]++;
+                CUCHK(tr_code(i, k) == 0 || (tw >= 2 && tw <= 5 && th >= 2 && th <= 5));      // ATS exists for 4..32 only (checked before anything is allocated)
+                P.cls[tr_code(i, k) * 64 + tw * 8 + th]++;
             }
             need += (size_t)(1 << (bw + bh)) >> (k ? 2 : 0);
         }
-        ARGCHK(c, (size_t)b->coef_off[i] + need <= b->n_coef);
+        CUCHK((size_t)b->coef_off[i] + need <= b->n_coef);
     }
+    return nullptr;
+    };
+#undef CUCHK
+    {
+        std::vector<const char *> bad((size_t)nthr, nullptr);
+        run_parts([&](int k, int i0, int i1) { bad[(size_t)k] = pass1(i0, i1, parts[(size_t)k]); });
+        for (const char *m : bad)
+            if (m) { snprintf(c->err, sizeof(c->err), "%s: invalid argument: %s", __FILE__, m); return XGPU_ERR_INVALID_ARGUMENT; }
+    }
+    int cls_count[NCLS] = { 0 }, n_aff = 0, n_aff_eif = 0, n_aff_sub = 0, n_dmvr = 0;
+    for (const Part &P : parts) { for (int k = 0; k < NCLS; k++) cls_count[k] += P.cls[k]; n_aff += P.n_aff; n_aff_eif += P.n_eif; n_aff_sub += P.n_sub; n_dmvr += P.n_dmvr; }
     int cls_first[NCLS], n_tb = 0, n_waves = 0;
     for (int k = 0; k < NCLS; k++) {
         cls_first[k] = n_tb; n_tb += cls_count[k];
@@ -863,7 +888,6 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
 
     AffItem *aff_items = (AffItem *)(hs + o_aff);
     int16_t *cpmv = (int16_t *)(hs + o_cpmv);
-    int aff_fill = 0, eif_fill = 0, sub_fill = n_aff_eif, dmvr_fill = 0;
     DmvrItem *dmvr_items = (DmvrItem *)(hs + o_dmvr);
     // SCU -> CU map of the picture (k_inter's lanes find their CU through it); SCUs outside the batch - another tile's - stay unowned.  Painted in
     // ordinary memory (short row fills) and copied into the pinned block in one piece
@@ -873,19 +897,29 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         size_t covered = 0;
         for (int i = 0; i < n; i++) if (!(b->tree && b->tree[i] == 2)) covered += (size_t)1 << (b->log2w[i] + b->log2h[i] - 4);
         if (covered != own.size()) std::fill(own.begin(), own.end(), 0xFFFFFFFFu);
-        for (int i = 0; i < n; i++) {
-            if (b->tree && b->tree[i] == 2) continue;               // the SCU maps of a dual-tree block belong to its luma CUs
-            const int ws = (1 << b->log2w[i]) >> 2, hh = (1 << b->log2h[i]) >> 2;
-            uint32_t *o = own.data() + (size_t)(b->y[i] >> 2) * c->w_scu + (b->x[i] >> 2);
-            for (int r = 0; r < hh; r++, o += c->w_scu) std::fill_n(o, ws, (uint32_t)i);
-        }
+        uint32_t *const own_p = own.data();                     // (`own` is thread_local: inside another thread the NAME would mean that thread's empty vector)
+        run_parts([&, own_p](int, int i0, int i1) {             // CUs do not overlap: the ranges paint disjoint SCUs
+            for (int i = i0; i < i1; i++) {
+                if (b->tree && b->tree[i] == 2) continue;           // the SCU maps of a dual-tree block belong to its luma CUs
+                const int ws = (1 << b->log2w[i]) >> 2, hh = (1 << b->log2h[i]) >> 2;
+                uint32_t *o = own_p + (size_t)(b->y[i] >> 2) * c->w_scu + (b->x[i] >> 2);
+                for (int r = 0; r < hh; r++, o += c->w_scu) std::fill_n(o, ws, (uint32_t)i);
+            }
+        });
         memcpy(hs + o_own, own.data(), sz_own);
     }
 
-    // pass 2: records + TB scatter into class order
+    // pass 2: records + TB scatter into class order; every thread starts where the ranges before it end in each list
+    run_parts([&](int part, int i0, int i1) {
     int cls_fill[NCLS];
     memcpy(cls_fill, cls_first, sizeof(cls_fill));
-    for (int i = 0; i < n; i++) {
+    int aff_fill = 0, eif_fill = 0, sub_fill = n_aff_eif, dmvr_fill = 0;
+    for (int q = 0; q < part; q++) {
+        const Part &P = parts[(size_t)q];
+        for (int k = 0; k < NCLS; k++) cls_fill[k] += P.cls[k];
+        aff_fill += P.n_aff; eif_fill += P.n_eif; sub_fill += P.n_sub; dmvr_fill += P.n_dmvr;
+    }
+    for (int i = i0; i < i1; i++) {
         CuRec &r = cus[i];
         memset(&r, 0, sizeof(r));
         if (b->affine && b->affine[i]) {
@@ -945,6 +979,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
             off += 1u << (cl + chh);
         }
     }
+    });
     int w = 0;
     for (int k = 0; k < NCLS; k++) {
         if (!cls_count[k]) continue;
@@ -956,7 +991,14 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         }
     }
     memcpy(hs + o_ctu, b->ctu_cu_start, sz_ctu);
-    if (b->n_coef && !coef_pinned) memcpy(hs + o_coef, b->coef, sizeof(int16_t) * b->n_coef);
+    if (b->n_coef && !coef_pinned) {                                   // the largest array (45 MB at 8K): in slices on the builder's threads
+        const size_t bytes = sizeof(int16_t) * b->n_coef;
+        std::vector<std::thread> th;
+        for (int k = 1; k < nthr; k++) th.emplace_back([&, k]() { const size_t a0 = bytes * k / nthr & ~(size_t)63, a1 = k + 1 == nthr ? bytes : (bytes * (k + 1) / nthr & ~(size_t)63);
+                                                                   memcpy(hs + o_coef + a0, (const uint8_t *)b->coef + a0, a1 - a0); });
+        memcpy(hs + o_coef, b->coef, nthr > 1 ? (bytes / nthr & ~(size_t)63) : bytes);
+        for (std::thread &t : th) t.join();
+    }
     if (n_intra) memcpy(hs + o_intra, plan.recs.data(), sizeof(IntraRec) * (size_t)n_intra);
     if (n_deps) memcpy(hs + o_deps, plan.deps.data(), sizeof(uint32_t) * (size_t)n_deps);
 
@@ -1106,6 +1148,13 @@ int xgpu_batch_dmvr_mvs(xgpu_ctx *c, xgpu_dbatch *db, int16_t *mv, int n)
         HIPCHK(c, hipStreamSynchronize(c->stream));
     }
     return db->n_dmvr;
+}
+
+int xgpu_set_builder_threads(xgpu_ctx *c, int n)
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, n >= 1 && n <= 64);
+    c->builder_threads = n;
+    return XGPU_OK;
 }
 
 int xgpu_batch_info(xgpu_ctx *c, const xgpu_dbatch *db, int info[XGPU_BATCH_INFO_COUNT])

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include "../../include/xevd_hip.h"
 
@@ -295,6 +296,7 @@ struct xgpu_ctx {
     xgpu_frame_params fp;
     int             have_frame;
     TileMask        no_dbk;            // tile borders the deblocking of the current picture leaves alone (set by xgpu_batch_recon)
+    int             builder_threads;   // xgpu_set_builder_threads: host threads xgpu_batch_create spreads its per-CU passes over (default 1)
     int             pad_done;          // the padding of the current picture has been written (by k_alf's border tiles): xgpu_pad launches nothing
     int             where;             // 0: the picture being built lives in its DPB slot, 1: in the scratch picture
     // timing
