@@ -20,10 +20,11 @@
 // v_pk_* op, row sums via v_dot2 with a ones vector), fetches its 13 coefficients from an LDS copy of the filter
 // set and filters its 16 luma + 2x4 chroma samples.  LDS rows are read as aligned 8-byte pieces.
 #include "xgpu_internal.h"
+#include "addb_filter.h"
 
 typedef short v2s __attribute__((ext_vector_type(2)));
 
-#define LROWS 70
+#define LROWS 72          // 70 window rows (-3..66); the fused form keeps the deblocking filter's 72 (-4..67)
 #define LSTR  72          // luma LDS row stride in s16: window col c (-3..66) at index c+4
 #define CROWS 36
 #define SSTR  36          // sub-block sums row stride (u16); sub-block col c (-1..32) at index c+2 (own pairs 4-byte aligned)
@@ -32,9 +33,9 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 struct CtuRect { int x0, y0, cw, ch, aL, aR, aT, aB; int tx0, tx1, ty0, ty1; };      // the CTU, its border availability, its tile [tx0,tx1) x [ty0,ty1)
 
 // sample of the reference's per-CTU window at absolute plane position (y,x)  (alf_process_tile :1000-1052)
-__device__ __forceinline__ int alf_fetch(const int16_t *__restrict__ p, int s, const CtuRect k, int y, int x)
+__device__ __forceinline__ void alf_pos(const CtuRect k, int y, int x, int &yy, int &xx)
 {
-    int yy = y, xx = x;
+    yy = y; xx = x;
     if (y < k.y0 && !k.aT) yy = 2 * k.y0 - y;
     else if (y >= k.y0 + k.ch && !k.aB) yy = 2 * (k.y0 + k.ch - 1) - y;
     if (yy >= k.y0 && yy < k.y0 + k.ch) {
@@ -42,6 +43,11 @@ __device__ __forceinline__ int alf_fetch(const int16_t *__restrict__ p, int s, c
         else if (x >= k.x0 + k.cw && !k.aR) xx = 2 * (k.x0 + k.cw - 1) - x;
     }
     yy = min(max(yy, k.ty0), k.ty1 - 1); xx = min(max(xx, k.tx0), k.tx1 - 1);           // the replicate extension of the tile's copy
+}
+__device__ __forceinline__ int alf_fetch(const int16_t *__restrict__ p, int s, const CtuRect k, int y, int x)
+{
+    int yy, xx;
+    alf_pos(k, y, x, yy, xx);
     return p[yy * s + xx];
 }
 
@@ -117,10 +123,18 @@ __device__ __forceinline__ void lap_pair(const uint32_t up[3], const uint32_t mi
     acc[3] = __builtin_amdgcn_sad_u16(c2, padd(ld, ru), acc[3]);
 }
 
-__global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
-                                             const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_,
-                                             int16_t *__restrict__ dv_)
+// FUSED: the ADDB deblocking filter runs in front of ALF inside the same kernel.  ALF filters a 64x64 tile from the DEBLOCKED samples of the 70x70 window around
+// it; the deblocking filter's 8-sample windows (centred on the grid lines, independent of each other, see k_addb.hip) that cover this window are the 72x72 region
+// [x0 - 4, x0 + 68) x [y0 - 4, y0 + 68): 9 x 18 vertical-edge segments and 18 x 9 horizontal-edge segments - 162 lanes each - filtered in place in the LDS tile that
+// ALF then reads.  The deblocked picture never goes to memory (k_addb_fused writes 100 MB that k_alf reads back: 433 MB of traffic for the two become 270 MB); the
+// price is 27 % more deblocking arithmetic (72^2 / 64^2: the halo is filtered by both neighbours).  LDS layout: window row r at row r + RO, luma column c at c + 4,
+// chroma column c at c + CO.
+template <bool FUSED>
+__device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
+                                           const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_,
+                                           int16_t *__restrict__ dv_)
 {
+    constexpr int RO = FUSED ? 4 : 3, CO = FUSED ? 2 : 4;
     __shared__ __attribute__((aligned(16))) int16_t l_y[LROWS * LSTR];
     __shared__ __attribute__((aligned(16))) int16_t l_c[2][CROWS * CSTR];
     __shared__ int16_t l_coef[25 * 13 + 7];
@@ -165,14 +179,127 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
     const bool luma_on = a.enable[0] && (a.ctb_flag == nullptr || a.ctb_flag[ctu_idx] != 0);
 
     for (int i = t; i < 25 * 13 + 7; i += 256) l_coef[i] = a.coef[i];
-    if (luma_on) alf_stage<64, 3, LSTR, 4>(l_y, sy_, a.s_l, k, tx0, ty0, t, 256);
-    {
-        CtuRect kc = k;
-        kc.x0 >>= 1; kc.y0 >>= 1; kc.cw >>= 1; kc.ch >>= 1; kc.tx0 >>= 1; kc.tx1 >>= 1; kc.ty0 >>= 1; kc.ty1 >>= 1;
+    CtuRect kc = k;
+    kc.x0 >>= 1; kc.y0 >>= 1; kc.cw >>= 1; kc.ch >>= 1; kc.tx0 >>= 1; kc.tx1 >>= 1; kc.ty0 >>= 1; kc.ty1 >>= 1;
+    if (!FUSED) {
+        if (luma_on) alf_stage<64, 3, LSTR, 4>(l_y, sy_, a.s_l, k, tx0, ty0, t, 256);
         if (a.enable[1]) alf_stage<32, 2, CSTR, 4>(l_c[0], su_, a.s_c, kc, tx0 >> 1, ty0 >> 1, t, 256);
         if (a.enable[2]) alf_stage<32, 2, CSTR, 4>(l_c[1], sv_, a.s_c, kc, tx0 >> 1, ty0 >> 1, t, 256);
+        __syncthreads();
+    } else {
+        // ---- the deblocking filter on the 72 x 72 region around the tile; its SCU records and tables borrow l_lap (written by ALF's classification afterwards) ----
+        const AddbArgs &da = *d;
+        uint4 (*s_map)[18] = (uint4 (*)[18])&l_lap[0][0][0];
+        uint8_t *s_alpha = (uint8_t *)&l_lap[0][0][0] + 18 * 18 * 16, *s_beta = s_alpha + 52, *s_clip = s_beta + 52, *s_pic = s_clip + 260;
+        int8_t *s_cqp = (int8_t *)(s_pic + XGPU_MAX_REFS * 2);
+        static_assert(18 * 18 * 16 + 52 + 52 + 260 + XGPU_MAX_REFS * 2 + 192 <= (int)sizeof(uint16_t) * 4 * 34 * SSTR, "the deblocking state fits into l_lap");
+        for (int i = t; i < 52; i += 256) { s_alpha[i] = k_alpha[i]; s_beta[i] = k_beta[i]; }
+        for (int i = t; i < 260; i += 256) s_clip[i] = ((const uint8_t *)k_clip)[i];
+        for (int i = t; i < XGPU_MAX_REFS * 2; i += 256) s_pic[i] = da.pic_id[i];
+        for (int i = t; i < 192; i += 256) s_cqp[i] = da.chroma_qp[i];
+#define PK2(lo, hi) ((uint32_t)(uint16_t)(lo) | ((uint32_t)(uint16_t)(hi) << 16))
+        {   // vertical edges: lane = window wx (grid line x0 + 8 wx) x SCU row sr of the region; windows and records from memory, filtered, into LDS
+            const int wx = t % 9, sr = t / 9;
+            const int gx = tx0 + 8 * wx, sxq = gx >> 2, srow = (ty0 >> 2) - 1 + sr;
+            const bool ok = t < 162 && gx <= a.pic_w && srow >= 0 && srow < da.h_scu;
+            const bool has_p = ok && gx > 0, has_q = ok && gx < a.pic_w;
+            const uint4 *maps = (const uint4 *)da.maps;
+            uint4 rq = make_uint4(0, 0, 0, 0), rp = rq;
+            int L[4][8], Cc[2][2][4];
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int q = 0; q < 8; q++) L[r][q] = 0;
+#pragma unroll
+            for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int q = 0; q < 4; q++) Cc[pl][r][q] = 0;
+            if (ok) {
+                const int kq = srow * da.w_scu + sxq;
+                if (has_q) rq = maps[kq];
+                if (has_p) rp = maps[kq - 1];
+                const int y = srow << 2, cy = srow << 1;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const U32x4a8 v = *(const U32x4a8 *)(sy_ + (y + r) * a.s_l + gx - 4);
+                    L[r][0] = (int16_t)(v.a & 0xFFFF); L[r][1] = (int16_t)(v.a >> 16); L[r][2] = (int16_t)(v.b & 0xFFFF); L[r][3] = (int16_t)(v.b >> 16);
+                    L[r][4] = (int16_t)(v.c & 0xFFFF); L[r][5] = (int16_t)(v.c >> 16); L[r][6] = (int16_t)(v.d & 0xFFFF); L[r][7] = (int16_t)(v.d >> 16);
+                }
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const U32x2a4 v = *(const U32x2a4 *)((pl ? sv_ : su_) + (cy + r) * a.s_c + (gx >> 1) - 2);
+                        Cc[pl][r][0] = (int16_t)(v.a & 0xFFFF); Cc[pl][r][1] = (int16_t)(v.a >> 16); Cc[pl][r][2] = (int16_t)(v.b & 0xFFFF); Cc[pl][r][3] = (int16_t)(v.b >> 16);
+                    }
+            }
+            __syncthreads();                                 // the tables (the loads above are in flight across it)
+            if (has_p && has_q) addb_edge<0>(da, rq, rp, sxq, L, Cc, s_alpha, s_beta, s_clip, s_cqp, s_pic);
+            if (t < 162) {
+                s_map[sr][2 * wx] = rp; s_map[sr][2 * wx + 1] = rq;
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    *(uint4 *)(l_y + (4 * sr + r) * LSTR + 8 * wx) = make_uint4(PK2(L[r][0], L[r][1]), PK2(L[r][2], L[r][3]), PK2(L[r][4], L[r][5]), PK2(L[r][6], L[r][7]));
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+                    for (int r = 0; r < 2; r++)
+                        *(uint2 *)(l_c[pl] + (2 * sr + r) * CSTR + 4 * wx) = make_uint2(PK2(Cc[pl][r][0], Cc[pl][r][1]), PK2(Cc[pl][r][2], Cc[pl][r][3]));
+            }
+        }
+        __syncthreads();
+        if (t < 162) {   // horizontal edges: lane = SCU column sx x grid line y0 + 8 g of the region, in place in LDS
+            const int sx = t % 18, g = t / 18;
+            const int scol = (tx0 >> 2) - 1 + sx, gy = ty0 + 8 * g, syq = gy >> 2;
+            const bool okh = scol >= 0 && scol < da.w_scu && gy <= a.pic_h;
+            if (okh && gy > 0 && gy < a.pic_h) {
+                const uint4 rq = s_map[2 * g + 1][sx], rp = s_map[2 * g][sx];
+                int L[4][8], Cc[2][2][4];
+#pragma unroll
+                for (int r = 0; r < 8; r++) {
+                    const uint2 v = *(const uint2 *)(l_y + (8 * g + r) * LSTR + 4 * sx);
+                    L[0][r] = (int16_t)(v.x & 0xFFFF); L[1][r] = (int16_t)(v.x >> 16); L[2][r] = (int16_t)(v.y & 0xFFFF); L[3][r] = (int16_t)(v.y >> 16);
+                }
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const uint32_t v = *(const uint32_t *)(l_c[pl] + (4 * g + r) * CSTR + 2 * sx);
+                        Cc[pl][0][r] = (int16_t)(v & 0xFFFF); Cc[pl][1][r] = (int16_t)(v >> 16);
+                    }
+                addb_edge<1>(da, rq, rp, syq, L, Cc, s_alpha, s_beta, s_clip, s_cqp, s_pic);
+#pragma unroll
+                for (int r = 0; r < 8; r++) *(uint2 *)(l_y + (8 * g + r) * LSTR + 4 * sx) = make_uint2(PK2(L[0][r], L[1][r]), PK2(L[2][r], L[3][r]));
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) *(uint32_t *)(l_c[pl] + (4 * g + r) * CSTR + 2 * sx) = PK2(Cc[pl][0][r], Cc[pl][1][r]);
+            }
+        }
+#undef PK2
+        __syncthreads();
+        // ---- ALF's window rule on the tiles that touch a picture / tile border or an unavailable CTU side: every window position takes the sample the rule names
+        //      (alf_fetch's position mapping is idempotent - a position it names maps to itself - so the pass runs in place) ----
+        const bool plain = (k.aL || tx0 > k.x0) && (k.aR || tx0 + 64 < k.x0 + k.cw) && (k.aT || ty0 > k.y0) && (k.aB || ty0 + 64 < k.y0 + k.ch) &&
+                           tx0 - 3 >= k.tx0 && tx0 + 67 <= k.tx1 && ty0 - 3 >= k.ty0 && ty0 + 67 <= k.ty1;
+        if (!plain) {
+            for (int i = t; i < 70 * 70; i += 256) {
+                const int r = i / 70 - 3, cc = i % 70 - 3;
+                int yy, xx;
+                alf_pos(k, ty0 + r, tx0 + cc, yy, xx);
+                l_y[(r + RO) * LSTR + cc + 4] = l_y[(yy - ty0 + RO) * LSTR + xx - tx0 + 4];
+            }
+            for (int i = t; i < 2 * 36 * 36; i += 256) {
+                const int pl = i / (36 * 36), j = i - pl * 36 * 36, r = j / 36 - 2, cc = j % 36 - 2;
+                int yy, xx;
+                alf_pos(kc, (ty0 >> 1) + r, (tx0 >> 1) + cc, yy, xx);
+                l_c[pl][(r + 2) * CSTR + cc + CO] = l_c[pl][(yy - (ty0 >> 1) + 2) * CSTR + xx - (tx0 >> 1) + CO];
+            }
+            __syncthreads();
+        }
     }
-    __syncthreads();
 
     const int lx = t & 15, ly = t >> 4;
     const int x = tx0 + (lx << 2), y = ty0 + (ly << 2);
@@ -182,10 +309,15 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
     // ------------------------------------------------ luma -----------------------------------------------
     // window rows -3..6, each 12 samples (cols -4..7) as 6 dwords; col j sits at sample j+4
     uint32_t W[10][6];
+    uint2 keep_w[4];                  // fused, luma filter off in this CTU: the lane's deblocked block, read before b_row / b_col reuse the staged tile
+    if (FUSED && !luma_on) {
+#pragma unroll
+        for (int ii = 0; ii < 4; ii++) keep_w[ii] = *(const uint2 *)(l_y + ((ly << 2) + ii + RO) * LSTR + (lx << 2) + 4);
+    }
     if (luma_on) {
 #pragma unroll
         for (int i = 0; i < 10; i++) {
-            const uint2 *row = (const uint2 *)(l_y + ((ly << 2) + i) * LSTR + (lx << 2));
+            const uint2 *row = (const uint2 *)(l_y + ((ly << 2) + i + RO - 3) * LSTR + (lx << 2));
             const uint2 v0 = row[0], v1 = row[1], v2 = row[2];
             W[i][0] = v0.x; W[i][1] = v0.y; W[i][2] = v1.x; W[i][3] = v1.y; W[i][4] = v2.x; W[i][5] = v2.y;
         }
@@ -214,7 +346,7 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
             uint32_t R[4][3], acc[4] = { 0, 0, 0, 0 };
 #pragma unroll
             for (int r = 0; r < 4; r++) {
-                const uint32_t *row = (const uint32_t *)(l_y + (sr * 2 + 2 + r) * LSTR + sc * 2 + 2);
+                const uint32_t *row = (const uint32_t *)(l_y + (sr * 2 + 2 + r + RO - 3) * LSTR + sc * 2 + 2);
                 R[r][0] = row[0]; R[r][1] = row[1]; R[r][2] = row[2];
             }
             lap_pair(R[0], R[1], R[2], acc);
@@ -314,7 +446,10 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
 #undef P
     } else {
 #pragma unroll
-        for (int ii = 0; ii < 4; ii++) { const uint2 w = *(const uint2 *)(sy_ + (y + ii) * a.s_l + x); *(uint2 *)(dy_ + (y + ii) * a.s_l + x) = w; keep_luma(ii, w); }
+        for (int ii = 0; ii < 4; ii++) {
+            const uint2 w = FUSED ? keep_w[ii] : *(const uint2 *)(sy_ + (y + ii) * a.s_l + x);      // (fused: the deblocked samples only exist in LDS)
+            *(uint2 *)(dy_ + (y + ii) * a.s_l + x) = w; keep_luma(ii, w);
+        }
     }
 
     // ------------------------------------------------ chroma ---------------------------------------------
@@ -333,14 +468,17 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
         };
         if (!a.enable[1 + pl]) {
 #pragma unroll
-            for (int ii = 0; ii < 2; ii++) { const uint32_t w = *(const uint32_t *)(src + (cy + ii) * a.s_c + cx); *(uint32_t *)(dst + (cy + ii) * a.s_c + cx) = w; keep_chroma(ii, w); }
+            for (int ii = 0; ii < 2; ii++) {
+                const uint32_t w = FUSED ? *(const uint32_t *)(l_c[pl] + ((ly << 1) + ii + 2) * CSTR + (lx << 1) + CO) : *(const uint32_t *)(src + (cy + ii) * a.s_c + cx);
+                *(uint32_t *)(dst + (cy + ii) * a.s_c + cx) = w; keep_chroma(ii, w);
+            }
             continue;
         }
         // window rows -2..3, cols -2..3 -> 3 dwords per row; col j at sample j+2
         uint32_t C[6][3];
 #pragma unroll
         for (int i = 0; i < 6; i++) {
-            const uint32_t *row = (const uint32_t *)(l_c[pl] + ((ly << 1) + i) * CSTR + (lx << 1) + 2);
+            const uint32_t *row = (const uint32_t *)(l_c[pl] + ((ly << 1) + i) * CSTR + (lx << 1) + CO - 2);
             C[i][0] = row[0]; C[i][1] = row[1]; C[i][2] = row[2];
         }
         const int16_t *f = l_coef + 325;
@@ -413,8 +551,23 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
     }
 }
 
-void launch_alf(xgpu_ctx *c, const AlfArgs &a, const DevPic &src, const DevPic &dst)
+__global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_, const int16_t *__restrict__ sv_,
+                                             int16_t *__restrict__ dy_, int16_t *__restrict__ du_, int16_t *__restrict__ dv_)
+{
+    alf_kernel<false>(a, nullptr, sy_, su_, sv_, dy_, du_, dv_);
+}
+
+// ADDB deblocking + ALF of a picture in one pass: SRC = the reconstruction, DST = the output picture
+__global__ __launch_bounds__(256) void k_addb_alf(const AlfArgs a, const AddbArgs d, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
+                                                  const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_, int16_t *__restrict__ dv_)
+{
+    alf_kernel<true>(a, &d, sy_, su_, sv_, dy_, du_, dv_);
+}
+
+void launch_alf(xgpu_ctx *c, const AlfArgs &a, const AddbArgs *deblock, const DevPic &src, const DevPic &dst)
 {
     const int tiles = ((a.pic_w + 63) >> 6) * ((a.pic_h + 63) >> 6);
-    hipLaunchKernelGGL(k_alf, dim3(((tiles + 7) >> 3) << 3), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
+    const dim3 grid(((tiles + 7) >> 3) << 3);
+    if (deblock) hipLaunchKernelGGL(k_addb_alf, grid, dim3(256), 0, c->stream, a, *deblock, src.y, src.u, src.v, dst.y, dst.u, dst.v);
+    else hipLaunchKernelGGL(k_alf, grid, dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
 }

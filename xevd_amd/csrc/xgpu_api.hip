@@ -156,7 +156,8 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     c->sp = *sp;
     c->sp.chroma_qp_table[0] = c->sp.chroma_qp_table[1] = NULL;
     c->builder_threads = 1;
-    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_dra = NULL; c->d_ctb_flag = NULL; c->stream = 0; c->up_stream = 0; c->down_stream = 0; c->side_stream = 0; c->after_inter = 0; c->have_after_inter = 0; c->where = 0;
+    c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_dra = NULL; c->d_ctb_flag = NULL; c->stream = 0; c->up_stream = 0; c->down_stream = 0; c->side_stream = 0; c->after_inter = 0; c->have_after_inter = 0; c->where = 0; c->addb_pending = 0;
+    c->split_addb_alf = getenv("XEVD_HIP_SPLIT_ADDB_ALF") != NULL;      // measurement knob: ADDB and ALF as two kernels (the round-2 chain) instead of k_addb_alf
     for (int i = 0; i < 2; i++) { c->d_out[i] = NULL; c->out_caps[i] = 0; c->out_ready[i] = c->out_done[i] = 0; c->out_busy[i] = 0; }
     c->out_next = 0;
     memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_n, 0, sizeof(c->t_n));
@@ -404,6 +405,10 @@ int xgpu_pic_output(xgpu_ctx *c, int pic, const xgpu_dra_luts *dra, int out_bit_
 }
 
 // ------------------------------------------------------------------------------------------------ per picture
+// ADDB deblocking directly followed by ALF: xgpu_deblock only prepares its arguments and xgpu_alf launches k_addb_alf, which deblocks the 72 x 72 region around
+// each of its 64 x 64 tiles in LDS - the deblocked picture is never written to or read from memory.
+static bool addb_alf_fused(const xgpu_ctx *c) { return c->fp.deblock_on && c->sp.tool_addb && c->fp.alf_on && !c->split_addb_alf; }
+
 int xgpu_frame_begin(xgpu_ctx *c, const xgpu_frame_params *fp)
 {
     ARGCHK(c, c != NULL); ARGCHK(c, fp != NULL); ARGCHK(c, valid_pic(c, fp->pic));
@@ -415,6 +420,7 @@ int xgpu_frame_begin(xgpu_ctx *c, const xgpu_frame_params *fp)
     c->have_frame = 1;
     c->where = 0;
     c->pad_done = 0;
+    c->addb_pending = 0;
     return XGPU_OK;
 }
 
@@ -422,7 +428,8 @@ int xgpu_frame_end(xgpu_ctx *c)
 {
     ARGCHK(c, c != NULL);
     c->have_frame = 0;
-    if (c->where != 0) {
+    if (c->where != 0 || c->addb_pending) {
+        c->addb_pending = 0;
         snprintf(c->err, sizeof(c->err), "frame_end: the in-loop filters announced in xgpu_frame_params (deblock_on=%d alf_on=%d) were not all run",
                  c->fp.deblock_on, c->fp.alf_on);
         c->where = 0;
@@ -462,9 +469,16 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     level.assign((size_t)n, 0);
     // painted CU by CU as the loop below reaches them ("reconstructed before CU i" = painted): inside a local dual tree the node's chroma-only CU follows its
     // luma CUs and covers them again
+    // constrained intra prediction inside local dual trees: "is the neighbour intra-coded" is a property of the LUMA CU over the SCU (map_scu is written by the
+    // luma CUs only) - an IBC luma CU under a chroma-only intra CU is not an intra neighbour.  The luma owners are kept apart from the repainted map for that test.
+    const bool constrained_tree = b->constrained_intra_pred != 0 && b->tree != NULL;
+    static thread_local std::vector<uint32_t> luma_owner;
+    if (constrained_tree) luma_owner.assign((size_t)ws * hs, NONE);
     auto paint = [&](int i) {
         const int xs = b->x[i] >> 2, ys = b->y[i] >> 2, w = (1 << b->log2w[i]) >> 2, h = (1 << b->log2h[i]) >> 2;
         for (int r = 0; r < h; r++) std::fill_n(owner.begin() + (size_t)(ys + r) * ws + xs, w, (uint32_t)i);
+        if (constrained_tree && b->tree[i] != 2)
+            for (int r = 0; r < h; r++) std::fill_n(luma_owner.begin() + (size_t)(ys + r) * ws + xs, w, (uint32_t)i);
     };
     // tiles: a neighbour in another tile is not available (map_tidx[curr] == map_tidx[neighbour] in xevd_get_avail_intra, xevd_get_nbr_b, xevdm_get_nbr)
     const int ctu_sh = c->sp.log2_ctu - 2;
@@ -607,7 +621,8 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         auto ok = [&](int sx, int sy) -> bool {
             const uint32_t j = owner[(size_t)sy * ws + sx];
             if (j >= (uint32_t)i || tile_of(sx, sy) != my_tile) return false;              // not reconstructed yet (or nothing there), or in another tile
-            const bool j_intra = b->pred_mode[j] == XGPU_MODE_INTRA;
+            const uint32_t jl = constrained_tree ? luma_owner[(size_t)sy * ws + sx] : j;
+            const bool j_intra = b->pred_mode[jl < (uint32_t)i ? jl : j] == XGPU_MODE_INTRA;
             if (constrained && !j_intra) return false;                                     // constrained_intra_pred: intra neighbours only
             if (!used) return true;
             if (ordered(j) && j != last) {                                                 // inter CUs are complete before the intra kernel starts
@@ -1079,8 +1094,8 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
     InterArgs a;
     memset(&a, 0, sizeof(a));
     // out-of-place filter chain: the deblocking passes (ADDB: one fused kernel; baseline filter: two) + one of ALF must end in the DPB slot ->
-    // start in the scratch picture when the number of passes is odd
-    c->where = ((c->fp.deblock_on ? (c->sp.tool_addb ? 1 : 2) : 0) + (c->fp.alf_on ? 1 : 0)) & 1;
+    // start in the scratch picture when the number of passes is odd.  ADDB followed by ALF is ONE pass (k_addb_alf).
+    c->where = (addb_alf_fused(c) ? 1 : (c->fp.deblock_on ? (c->sp.tool_addb ? 1 : 2) : 0) + (c->fp.alf_on ? 1 : 0)) & 1;
     DevPic &cur = c->where ? c->pics[0] : dpic(c, c->fp.pic);
     a.cur_y = cur.y; a.cur_u = cur.u; a.cur_v = cur.v;
     a.s_l = c->s_l; a.s_c = c->s_c; a.pic_w = c->sp.width; a.pic_h = c->sp.height;
@@ -1188,6 +1203,11 @@ int xgpu_deblock(xgpu_ctx *c)
         memcpy(a.chroma_qp, c->chroma_qp, sizeof(a.chroma_qp));
         for (int l = 0; l < 2; l++)
             for (int i = 0; i < XGPU_MAX_REFS; i++) a.pic_id[i * 2 + l] = i < c->fp.num_refp[l] ? (uint8_t)c->fp.refp_pic[i][l] : 255;
+        if (addb_alf_fused(c)) {
+            ARGCHK(c, c->where == 1 && !c->addb_pending);
+            c->addb_args = a; c->addb_pending = 1;      // runs inside xgpu_alf's kernel
+            return XGPU_OK;
+        }
         TIMED(c, XGPU_K_DBK_V, launch_addb_fused(c, a, first, second));      // both edge directions: one read + one write of the picture (timed as "dbk_v")
         c->where ^= 1;
     } else {
@@ -1215,6 +1235,7 @@ int xgpu_deblock(xgpu_ctx *c)
 int xgpu_alf(xgpu_ctx *c, const xgpu_alf_params *ap)
 {
     ARGCHK(c, c != NULL); ARGCHK(c, c->have_frame); ARGCHK(c, c->fp.alf_on); ARGCHK(c, ap != NULL && c->where == 1);
+    ARGCHK(c, !addb_alf_fused(c) || c->addb_pending);      // deblock_on was announced: xgpu_deblock comes first
     ARGCHK(c, (!ap->enable[0] || ap->luma_coef) && ((!ap->enable[1] && !ap->enable[2]) || ap->chroma_coef));
     AlfArgs a;
     memset(&a, 0, sizeof(a));
@@ -1233,8 +1254,9 @@ int xgpu_alf(xgpu_ctx *c, const xgpu_alf_params *ap)
     }
     // the filter chain is planned so that ALF reads the scratch picture and lands in the DPB slot
     a.pad = 1;                              // the border tiles replicate their samples into the padding: xgpu_pad has nothing left to do for this picture
-    TIMED(c, XGPU_K_ALF, launch_alf(c, a, c->pics[0], dpic(c, c->fp.pic)));
+    TIMED(c, XGPU_K_ALF, launch_alf(c, a, c->addb_pending ? &c->addb_args : NULL, c->pics[0], dpic(c, c->fp.pic)));
     c->where = 0;
+    c->addb_pending = 0;
     c->pad_done = 1;
     HIPCHK(c, hipGetLastError());
     return XGPU_OK;

@@ -299,6 +299,8 @@ struct xgpu_ctx {
     int             builder_threads;   // xgpu_set_builder_threads: host threads xgpu_batch_create spreads its per-CU passes over (default 1)
     int             pad_done;          // the padding of the current picture has been written (by k_alf's border tiles): xgpu_pad launches nothing
     int             where;             // 0: the picture being built lives in its DPB slot, 1: in the scratch picture
+    int             addb_pending, split_addb_alf;      // ADDB + ALF in one kernel: xgpu_deblock left its arguments in addb_args for xgpu_alf
+    AddbArgs        addb_args;
     // timing
     int             timing;
     struct Ev { hipEvent_t a, b; int k; };
@@ -321,7 +323,7 @@ void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const
 void upload_transform_tables(const int *tm, const int16_t *ats, hipStream_t s);
 int  itdq_group_size(int log2w, int log2h);     // TBs of one size class per 256-thread work item
 void launch_addb_fused(xgpu_ctx *c, const AddbArgs &a, const DevPic &src, const DevPic &dst);      // both passes, one read + one write of the picture
-void launch_alf(xgpu_ctx *c, const AlfArgs &a, const DevPic &src, const DevPic &dst);
+void launch_alf(xgpu_ctx *c, const AlfArgs &a, const AddbArgs *deblock, const DevPic &src, const DevPic &dst);      // deblock != NULL: ADDB on SRC first, inside the same kernel
 void launch_pad(xgpu_ctx *c, const DevPic &p);
 void launch_copy_bw(xgpu_ctx *c, const void *src, void *dst, size_t bytes);
 void launch_output(xgpu_ctx *c, const DevPic &pic, const int32_t *d_dra, int out_bd, int crop_l, int crop_r, int crop_t, int crop_b, uint8_t *d_dst);
