@@ -256,6 +256,11 @@ int  xgpu_batch_prepare(xgpu_ctx *ctx, xgpu_dbatch *db);
 /* dequant + inverse transform of every coded TB, then MC + residual add + clip of every inter CU, and the
    SCU map update (xevd_set_dec_info) the in-loop filters read.  Asynchronous on the ctx stream.          */
 int  xgpu_batch_recon(xgpu_ctx *ctx, xgpu_dbatch *db);
+/* xgpu_batch_recon of `db`, with the residual pass of the NEXT picture's batch (`next`, may be NULL; its upload may still be in flight) queued on the
+   same stream: inside this picture's data-flow intra launch when it has one - that launch is a chain of memory round trips that leaves most of the GPU
+   idle - or behind this picture's last kernel.  xgpu_batch_recon(_ahead) of `next` then starts with its MC kernel.  The preferred form of
+   xgpu_batch_prepare: no second stream, no cross-stream event.                                                                                    */
+int  xgpu_batch_recon_ahead(xgpu_ctx *ctx, xgpu_dbatch *db, xgpu_dbatch *next);
 /* both deblocking passes over the current picture (vertical edges, then horizontal edges)               */
 int  xgpu_deblock(xgpu_ctx *ctx);
 /* adaptive loop filter: 4x4 block classification + 7x7 luma / 5x5 chroma diamond filters (ctx->fn_alf)    */

@@ -187,8 +187,10 @@ def dmvr_mvs(engine, case):
     return out[:int((out[:, 0, 0] != -32768).sum())].copy()
 
 
-def run_gpu(case, deblock=True, pad=True, alf=True, resid=False, repeat=1, dmvr=False):
-    """The HIP backend through the C ABI. -> list of padded planes (reference buffer geometry)"""
+def run_gpu(case, deblock=True, pad=True, alf=True, resid=False, repeat=1, dmvr=False, ahead=False):
+    """The HIP backend through the C ABI. -> list of padded planes (reference buffer geometry).
+    ahead: the picture is decoded twice from two batch objects; the second one's residual pass is queued with the first picture's kernels
+    (xgpu_batch_recon_ahead) and its picture is the one returned"""
     from xevd_amd.decoder import XgpuDecoder
     with XgpuDecoder(case["w"], case["h"], case["bd"], log2_ctu=case.get("log2_ctu", 6), iqt=case["iqt"], admvp=case["admvp"],
                      addb=case.get("addb", 0), alf=case.get("alf", 0), eipd=case.get("eipd", 0), max_pics=8) as dec:
@@ -201,6 +203,13 @@ def run_gpu(case, deblock=True, pad=True, alf=True, resid=False, repeat=1, dmvr=
         cur = dec.pic_alloc()
         dec.pic_upload_padded(cur, _start_picture(case).bufs)
         hb = dec.batch_create(case["batch"])
+        if ahead:
+            hb2 = dec.batch_create(case["batch"])
+            dec.decode_picture(cur, CUR_POC, slots, hb, deblock=deblock and not case.get("no_deblock"), pad=pad, qp_u_offset=QP_OFFSETS[0], qp_v_offset=QP_OFFSETS[1],
+                               alpha_off=case.get("alpha_off", 0), beta_off=case.get("beta_off", 0), alf=case.get("alf_params") if alf else None, next_batch=hb2)
+            dec.sync()
+            dec.pic_upload_padded(cur, _start_picture(case).bufs)
+            hb = hb2
         for _ in range(repeat - 1):      # the same resident batch decoded again into the same slot (exercises per-batch device state)
             dec.decode_picture(cur, CUR_POC, slots, hb, deblock=deblock and not case.get("no_deblock"), pad=pad,
                                qp_u_offset=QP_OFFSETS[0], qp_v_offset=QP_OFFSETS[1],

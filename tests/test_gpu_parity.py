@@ -110,6 +110,18 @@ def test_gpu_pictures_golden(name):
         assert np.array_equal(mvs, exp["dmvr_mv"]), f"DMVR vectors: {np.argwhere(mvs != exp['dmvr_mv'])[:4]}"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", golden_io.PICTURE_CASES)
+def test_gpu_pictures_golden_residual_pass_ahead(name):
+    """xgpu_batch_recon_ahead: the residual pass of a batch queued with the PREVIOUS picture's kernels (inside its data-flow intra launch, k_intra_itdq, when it
+    has one and the sequence uses IQT; as a plain launch otherwise) leaves the same residuals and the same picture"""
+    case, exp = golden_io.load_picture_case(name)
+    out, resid = cases.run_gpu(case, resid=True, ahead=True)
+    assert np.array_equal(resid[:len(exp["resid"])], exp["resid"])
+    for c in range(3):
+        assert np.array_equal(out[c], exp["out"][c]), f"final plane {c}: {np.argwhere(out[c] != exp['out'][c])[:4]}"
+
+
 RANDOM = [
     # name, w, h, bd, admvp, iqt, n_refs, bi_frac, kwargs
     ("rnd_a", 264, 136, 8, 0, 0, (2, 1), 0.3, {}),
@@ -517,6 +529,9 @@ def test_gpu_bench_workload_vs_oracle(name):
     out = cases.run_gpu(cs)
     for c in range(3):
         assert np.array_equal(out[c], ref.bufs[c]), f"{name} plane {c}: {np.argwhere(out[c] != ref.bufs[c])[:4]}"
+    out = cases.run_gpu(cs, ahead=True)      # as bench.py's timed loop runs it: the residual pass inside the previous picture's data-flow launch
+    for c in range(3):
+        assert np.array_equal(out[c], ref.bufs[c]), f"{name} (residual pass ahead) plane {c}: {np.argwhere(out[c] != ref.bufs[c])[:4]}"
 
 
 @pytest.mark.gpu

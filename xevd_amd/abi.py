@@ -203,6 +203,7 @@ _EXPORTS = {
     "xgpu_batch_create": (C.c_int, [C.c_void_p, C.POINTER(CuBatch), C.POINTER(C.c_void_p)]),
     "xgpu_batch_destroy": (None, [C.c_void_p, C.c_void_p]),
     "xgpu_batch_recon": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "xgpu_batch_recon_ahead": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "xgpu_deblock": (C.c_int, [C.c_void_p]),
     "xgpu_alf": (C.c_int, [C.c_void_p, C.POINTER(AlfParams)]),
     "xgpu_pad": (C.c_int, [C.c_void_p]),

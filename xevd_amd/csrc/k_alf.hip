@@ -176,7 +176,7 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
     k.aR = a.across_tiles ? 1 : (k.x0 + k.cw != k.tx1);
     k.aB = a.across_tiles ? 1 : (k.y0 + k.ch != k.ty1);
     const int ctu_idx = (k.y0 >> a.log2_ctu) * a.w_ctu + (k.x0 >> a.log2_ctu);
-    const bool luma_on = a.enable[0] && (a.ctb_flag == nullptr || a.ctb_flag[ctu_idx] != 0);
+    const bool luma_on = a.enable[0] && (a.ctb_in_args ? ((a.ctb_bits[ctu_idx >> 5] >> (ctu_idx & 31)) & 1) != 0 : (a.ctb_flag == nullptr || a.ctb_flag[ctu_idx] != 0));
 
     for (int i = t; i < 25 * 13 + 7; i += 256) l_coef[i] = a.coef[i];
     CtuRect kc = k;

@@ -24,6 +24,7 @@
 // reductions, then every lane predicts whole 4x4 SCUs (+ their 2x2 chroma blocks) exactly like k_inter's lanes
 // reconstruct theirs, so residual addressing and stores are shared idioms.  HBM-bound integer work: no MFMA.
 #include "xgpu_internal.h"
+#include "itdq_body.h"
 
 #define NB_MAX 264      // up to 128 + 128 + 1 neighbour samples per side (luma of a 128x128 CU)
 
@@ -204,30 +205,31 @@ __constant__ uint8_t k_htdf_tbl[5][16] = {
 };
 #define HTDF_EXT (66 * 66)           // a filtered CU is at most 64 x 64 (xevdm_htdf_skip_condition): the block plus one sample of border
 
-template <bool DEP, bool EIPD, bool IBC, bool HTDF>
-__global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
+// per wave: the neighbour arrays of the prediction pass; the HTDF instantiation lays its 66 x 66 block over them afterwards (70 KB per 8-wave workgroup:
+// two workgroups per CU)
+template <bool HTDF> struct IntraLds { static constexpr int WAVE = (HTDF && HTDF_EXT > 3 * NB_LEN) ? HTDF_EXT : 3 * NB_LEN; };
+
+// The work of one workgroup of WAVES waves; `block` = its position in the launch (static assignment, DEP = false).  s_nb = WAVES x IntraLds<HTDF>::WAVE samples,
+// s_lut = WAVES x 16 (HTDF only), s_chunk = one dword.
+template <bool DEP, bool EIPD, bool IBC, bool HTDF, int WAVES>
+__device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, int16_t *s_nb_, int (*s_lut)[16], uint32_t *s_chunk)
 {
-    __shared__ int     s_lut[HTDF ? INTRA_WAVES : 1][16];
-    // per wave: the neighbour arrays of the prediction pass; the HTDF instantiation lays its 66 x 66 block over them afterwards (70 KB per workgroup:
-    // two workgroups per CU)
-    constexpr int WAVE_LDS = (HTDF && HTDF_EXT > 3 * NB_LEN) ? HTDF_EXT : 3 * NB_LEN;
-    __shared__ __attribute__((aligned(16))) int16_t s_nb[INTRA_WAVES][WAVE_LDS];
-    __shared__ uint32_t s_chunk;
+    constexpr int WAVE_LDS = IntraLds<HTDF>::WAVE;
+    int16_t (*s_nb)[WAVE_LDS] = (int16_t (*)[WAVE_LDS])s_nb_;
     const int t = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    uint32_t chunk = blockIdx.x;
+    uint32_t chunk = block;
     if (DEP) {
-        if (threadIdx.x == 0) s_chunk = atomicAdd(&a.done[a.n_intra], 1u) - a.ticket_base;
+        if (threadIdx.x == 0) *s_chunk = atomicAdd(&a.done[a.n_intra], 1u) - a.ticket_base;
         __syncthreads();                                             // the only workgroup barrier, before any wave can wait
-        chunk = s_chunk;
+        chunk = *s_chunk;
     }
     int16_t (*nb)[NB_LEN] = (int16_t (*)[NB_LEN])s_nb[wv];
     const int mid = 1 << (a.bd_l - 1);
     const int maxv = (1 << a.bd_l) - 1;
 
-    constexpr int PER_WG = DEP ? INTRA_CHUNK : INTRA_WAVES;         // independent CUs: one per wave, as many workgroups as it takes
-    for (int it = 0; it < PER_WG / INTRA_WAVES; it++) {
-        const uint32_t item = a.first + chunk * PER_WG + it * INTRA_WAVES + wv;
-        if (item >= (uint32_t)(a.first + a.count)) break;
+    {   // one CU per wave and workgroup pass: a ticket (DEP) covers WAVES list positions
+        const uint32_t item = a.first + chunk * WAVES + wv;
+        if (item >= (uint32_t)(a.first + a.count)) return;
         const uint4 *rec = (const uint4 *)&a.list[item];
         const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
         const uint32_t avail_ul = uni(q0.y) & 1;
@@ -556,9 +558,54 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
     }
 }
 
-void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf)
+template <bool DEP, bool EIPD, bool IBC, bool HTDF>
+__global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 {
-    const int per = dep ? INTRA_CHUNK : INTRA_WAVES;
+    __shared__ int     s_lut[HTDF ? INTRA_WAVES : 1][16];
+    __shared__ __attribute__((aligned(16))) int16_t s_nb[INTRA_WAVES * IntraLds<HTDF>::WAVE];
+    __shared__ uint32_t s_chunk;
+    intra_body<DEP, EIPD, IBC, HTDF, INTRA_WAVES>(a, blockIdx.x, s_nb, s_lut, &s_chunk);
+}
+
+// k_intra_itdq - the data-flow launch of this picture and the residual pass of the NEXT picture in one grid.  The data-flow kernel is a chain of
+// dependent memory round trips (4 K waves at 8K, the SIMDs idle most of its 45 us) and the residual pass depends on nothing but its batch, so its
+// work items fill the machine under the chain: workgroups [0, n_intra_wg) run intra_body (tickets order them, whatever the dispatcher does), the rest
+// one residual work item each.  256 threads: the residual pass's workgroup shape; four CUs in flight per intra workgroup (18.6 KB of LDS either way).
+// Measured at 8K (profiles/round3_*): 45 us + 39 us as two launches (43 + 55 when the residual pass ran beside the level-1 launch on a second stream,
+// with two cross-stream event waits of 6 us each), [see DESIGN 5] as one.
+#define FUSED_WAVES 4
+template <bool EIPD, bool IBC>
+__global__ __launch_bounds__(64 * FUSED_WAVES) void k_intra_itdq(const IntraArgs a, const ItdqArgs r, uint32_t n_intra_wg)
+{
+    constexpr int ITDQ_DW = ITDQ_LDS_DWORDS - ITDQ_PLANES_DWORDS / 2 + 2 * ITDQ_MAX_G, INTRA_DW = (FUSED_WAVES * IntraLds<false>::WAVE + 1) / 2 + 4;
+    __shared__ __attribute__((aligned(16))) uint32_t raw[ITDQ_DW > INTRA_DW ? ITDQ_DW : INTRA_DW];
+    if (blockIdx.x < n_intra_wg) {
+        intra_body<true, EIPD, IBC, false, FUSED_WAVES>(a, blockIdx.x, (int16_t *)raw, nullptr, raw + INTRA_DW - 1);
+    } else {
+        const int wi = (int)(blockIdx.x - n_intra_wg);
+        if (wi >= r.n_waves) return;
+        uint32_t *s_rm = raw + ITDQ_LDS_DWORDS - ITDQ_PLANES_DWORDS / 2;
+        itdq_dispatch<true>(r, wi, raw, s_rm, s_rm + ITDQ_MAX_G);
+    }
+}
+
+void upload_transform_tables_intra(const int *tm, const int16_t *ats, hipStream_t s) { upload_transform_tables_tu(tm, ats, s); }
+
+int intra_chunk(bool with_itdq) { return with_itdq ? FUSED_WAVES : INTRA_WAVES; }
+
+// dep launch with `next` != NULL: k_intra_itdq (callers check intra_itdq_fusable first)
+void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf, const ItdqArgs *next)
+{
+    if (next) {
+        const uint32_t n_wg = (uint32_t)((a.count + FUSED_WAVES - 1) / FUSED_WAVES);
+        const dim3 g(n_wg + (uint32_t)next->n_waves), b(64 * FUSED_WAVES);
+#define LAUNCHF(E, I) hipLaunchKernelGGL((k_intra_itdq<E, I>), g, b, 0, c->stream, a, *next, n_wg)
+        if (c->sp.tool_eipd) { if (ibc) LAUNCHF(true, true); else LAUNCHF(true, false); }
+        else                 { if (ibc) LAUNCHF(false, true); else LAUNCHF(false, false); }
+#undef LAUNCHF
+        return;
+    }
+    const int per = INTRA_WAVES;
     const int blocks = (a.count + per - 1) / per;
     const dim3 g(blocks), b(64 * INTRA_WAVES);
 #define LAUNCH(D, E, I, H) hipLaunchKernelGGL((k_intra<D, E, I, H>), g, b, 0, c->stream, a)

@@ -1040,7 +1040,13 @@ void xgpu_batch_destroy(xgpu_ctx *c, xgpu_dbatch *db)
     if (!db) return;
     // No synchronisation: kernels still queued on the context's stream keep reading the block; whoever reuses it makes the upload stream wait
     // for the `done` event those kernels signal, and the host waits for `uploaded` before it touches the staging block.
-    if (db->blk.d_base && db->blk.h_stage && db->blk.uploaded && db->blk.done && db->blk.itdq_done && c) { std::lock_guard<std::mutex> g(c->pool_mu); c->pool.push_back(db->blk); }
+    // The event is recorded here, not behind the batch's kernels: a marker between two kernels of a picture idles the device for ~6 us (profiles/round3_trace_window.txt),
+    // and a batch that stays resident (decoded again and again) never needs it.
+    if (db->blk.d_base && db->blk.h_stage && db->blk.uploaded && db->blk.done && db->blk.itdq_done && c) {
+        if (db->prepared == 1) (void)hipStreamWaitEvent(c->stream, db->blk.itdq_done, 0);      // a residual pass on the side stream that nobody consumed
+        if (db->used || db->prepared) (void)hipEventRecord(db->blk.done, c->stream);
+        std::lock_guard<std::mutex> g(c->pool_mu); c->pool.push_back(db->blk);
+    }
     else {
         if (c && c->stream) (void)hipStreamSynchronize(c->stream);
         if (db->blk.d_base) (void)hipFree(db->blk.d_base);
@@ -1078,12 +1084,24 @@ int xgpu_batch_prepare(xgpu_ctx *c, xgpu_dbatch *db)
     return XGPU_OK;
 }
 
-int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
+int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db) { return xgpu_batch_recon_ahead(c, db, NULL); }
+
+// next != NULL: the residual pass of the NEXT picture's batch is queued with this picture's kernels, on the same stream - inside the data-flow intra launch
+// when the picture has one (k_intra_itdq), behind the last kernel otherwise.  No second stream and no event between streams is involved (the side-stream form,
+// xgpu_batch_prepare, pays two cross-stream waits of ~6 us per picture and overlaps with the wrong kernel; profiles/round3_trace_window.txt).
+int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
 {
-    ARGCHK(c, c != NULL); ARGCHK(c, db != NULL); ARGCHK(c, c->have_frame);
-    HIPCHK(c, hipStreamWaitEvent(c->stream, db->blk.uploaded, 0));       // the batch's arrays come through the upload stream
+    ARGCHK(c, c != NULL); ARGCHK(c, db != NULL); ARGCHK(c, c->have_frame); ARGCHK(c, next != db);
+    if (!db->upload_waited) HIPCHK(c, hipStreamWaitEvent(c->stream, db->blk.uploaded, 0));       // the batch's arrays come through the upload stream
+    db->upload_waited = 0;
+    db->used = 1;                                                        // xgpu_batch_destroy records blk.done: the block may be overwritten behind the kernels queued until then
+    if (next && next->prepared) next = NULL;
+    const bool ahead = next != NULL;
+    if (next) { HIPCHK(c, hipStreamWaitEvent(c->stream, next->blk.uploaded, 0)); next->upload_waited = 1; }
     if (db->tiles_across) memset(&c->no_dbk, 0, sizeof(c->no_dbk)); else c->no_dbk = db->tile_starts;
-    if (db->prepared) {                                                  // xgpu_batch_prepare ran the residual pass on the side stream
+    if (db->prepared == 2) {                                             // the residual pass ran on this stream with the previous picture
+        db->prepared = 0;
+    } else if (db->prepared) {                                           // xgpu_batch_prepare ran the residual pass on the side stream
         HIPCHK(c, hipStreamWaitEvent(c->stream, db->blk.itdq_done, 0));
         db->prepared = 0;
     } else {
@@ -1112,7 +1130,7 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
             a.refp[i][l].poc = i < c->fp.num_refp[l] ? c->fp.refp_poc[i][l] : 0;
         }
     TIMED(c, XGPU_K_INTER, launch_inter(c, a));
-    HIPCHK(c, hipEventRecord(c->after_inter, c->stream));               // where a prepared residual pass of the next picture may start
+    if (!ahead) HIPCHK(c, hipEventRecord(c->after_inter, c->stream));   // where a residual pass prepared on the side stream (xgpu_batch_prepare) may start
     c->have_after_inter = 1;
     if (db->n_dmvr) {
         DmvrArgs d;
@@ -1143,14 +1161,26 @@ int xgpu_batch_recon(xgpu_ctx *c, xgpu_dbatch *db)
         ta.ticket_base = db->intra_tickets;                // the counter keeps running: a launch draws one ticket per workgroup
         const int n_dep = db->n_intra - db->n_intra_l1;
         TIMED(c, XGPU_K_INTRA, {
+            // the next picture's residual pass rides in the data-flow launch (not while single kernels are being timed; HTDF's workgroups are a different shape)
+            ItdqArgs na;
+            const bool ride = next && n_dep > 0 && !c->timing && !db->has_htdf && (na = itdq_args(c, next), na.iqt && na.n_waves > 0);
             ta.first = 0; ta.count = db->n_intra_l1;
-            if (ta.count) launch_intra(c, ta, false, db->has_ibc != 0, db->has_htdf != 0);
+            if (ta.count) launch_intra(c, ta, false, db->has_ibc != 0, db->has_htdf != 0, NULL);
             ta.first = db->n_intra_l1; ta.count = n_dep;
-            if (ta.count) { launch_intra(c, ta, true, db->has_ibc != 0, db->has_htdf != 0); db->intra_tickets += (uint32_t)((n_dep + INTRA_CHUNK - 1) / INTRA_CHUNK); }
+            if (n_dep) {
+                launch_intra(c, ta, true, db->has_ibc != 0, db->has_htdf != 0, ride ? &na : NULL);
+                const int chunk = intra_chunk(ride);
+                db->intra_tickets += (uint32_t)((ta.count + chunk - 1) / chunk);
+                if (ride) { next->prepared = 2; next->used = 1; next = NULL; }
+            }
         });
     }
+    if (next) {
+        const ItdqArgs na = itdq_args(c, next);
+        TIMED(c, XGPU_K_ITDQ, launch_itdq(c, na, c->stream));
+        next->prepared = 2; next->used = 1;
+    }
     HIPCHK(c, hipGetLastError());
-    HIPCHK(c, hipEventRecord(db->blk.done, c->stream));                  // the block may be overwritten by a later batch after this point
     return XGPU_OK;
 }
 
@@ -1249,8 +1279,14 @@ int xgpu_alf(xgpu_ctx *c, const xgpu_alf_params *ap)
     if (ap->luma_coef) memcpy(a.coef, ap->luma_coef, sizeof(int16_t) * 325);
     if (ap->chroma_coef) memcpy(a.coef + 325, ap->chroma_coef, sizeof(int16_t) * 7);
     if (ap->ctb_flag && ap->enable[0]) {
-        HIPCHK(c, hipMemcpyAsync(c->d_ctb_flag, ap->ctb_flag, (size_t)c->w_ctu * c->h_ctu, hipMemcpyHostToDevice, c->stream));
-        a.ctb_flag = c->d_ctb_flag;
+        const int n_ctu = c->w_ctu * c->h_ctu;
+        if (n_ctu <= ALF_CTB_BITS) {        // as kernel arguments: a copy engine transfer between two kernels costs ~12 us of idle device (profiles/round3_trace_window.txt)
+            a.ctb_in_args = 1;
+            for (int i = 0; i < n_ctu; i++) if (ap->ctb_flag[i]) a.ctb_bits[i >> 5] |= 1u << (i & 31);
+        } else {
+            HIPCHK(c, hipMemcpyAsync(c->d_ctb_flag, ap->ctb_flag, (size_t)n_ctu, hipMemcpyHostToDevice, c->stream));
+            a.ctb_flag = c->d_ctb_flag;
+        }
     }
     // the filter chain is planned so that ALF reads the scratch picture and lands in the DPB slot
     a.pad = 1;                              // the border tiles replicate their samples into the padding: xgpu_pad has nothing left to do for this picture

@@ -154,7 +154,6 @@ struct __attribute__((aligned(16))) IntraRec {
     uint32_t coef_off;
 };
 static_assert(sizeof(IntraRec) == 48, "IntraRec must be 48 bytes");
-#define INTRA_CHUNK 8         // list positions one workgroup of the data-flow intra kernel handles = its 8 waves, one CU each
 struct IntraArgs {
     int16_t *cur_y, *cur_u, *cur_v;
     int      s_l, s_c;
@@ -226,6 +225,7 @@ struct AddbArgs {
     uint8_t  pic_id[XGPU_MAX_REFS * 2];// picture slot of refp[idx][list], 255 = none
 };
 
+#define ALF_CTB_BITS 8704           // 8192 x 4320 in 64 x 64 CTUs
 struct AlfArgs {
     int      s_l, s_c, pic_w, pic_h, bd, log2_ctu, w_ctu, across_tiles;
     TileMask tiles;                    // tile starts: a CTU's windows end at its tile (alf_process_tile)
@@ -233,6 +233,8 @@ struct AlfArgs {
     int      pad;                      // 1: the tiles on the picture border also write the 144 / 72-sample padding of the output picture (no k_pad launch)
     int      enable[3];
     const uint8_t *ctb_flag;           // device, [n_ctu] or null
+    int      ctb_in_args;              // 1: the per-CTU luma flags travel in ctb_bits (pictures up to ALF_CTB_BITS CTUs): no H2D copy between the kernels
+    uint32_t ctb_bits[ALF_CTB_BITS / 32];
     int16_t  coef[25 * 13 + 7];        // coef_final followed by the chroma filter
 };
 
@@ -267,7 +269,10 @@ struct xgpu_dbatch {
     uint32_t   intra_epoch, intra_tickets;
     void      *h_stage;               // pinned staging block
     size_t     stage_bytes;
-    int        prepared;              // xgpu_batch_prepare has queued the residual pass (k_itdq) on the side stream: `blk.itdq_done` says when it has finished
+    int        prepared;              // 1: xgpu_batch_prepare has queued the residual pass (k_itdq) on the side stream: `blk.itdq_done` says when it has finished;
+                                      // 2: it ran on the main stream with the previous picture (xgpu_batch_recon_ahead)
+    int        upload_waited;         // the main stream already waits for blk.uploaded
+    int        used;                  // kernels that read the block have been queued (xgpu_batch_recon, or a residual pass ahead)
 };
 
 struct xgpu_ctx {
@@ -316,7 +321,8 @@ void launch_itdq(xgpu_ctx *c, const ItdqArgs &a, hipStream_t s);
 void launch_inter(xgpu_ctx *c, const InterArgs &a);
 void launch_test_recon(xgpu_ctx *c, const int16_t *coef, const int16_t *pred, int is_coef, int cuw, int cuh, int16_t *rec, int s_rec, int bd);
 void launch_test_dbk(xgpu_ctx *c, int16_t *buf, int16_t *buf_v, int st, int st_v, int stride, int bd, int hor, int chroma);
-void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf);
+void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf, const ItdqArgs *next);      // next != NULL (dep launches): k_intra_itdq
+int  intra_chunk(bool with_itdq);                // list positions per ticket of the data-flow launch (= waves per workgroup: 8, with the residual pass riding 4)
 void launch_affine(xgpu_ctx *c, const AffineArgs &a);
 void launch_dmvr(xgpu_ctx *c, const DmvrArgs &a);
 void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst);

@@ -188,8 +188,12 @@ class XgpuDecoder:
         """queue the batch's residual pass ahead of its picture (xgpu_batch_prepare)"""
         self._chk(self.lib.xgpu_batch_prepare(self.ctx, h), "xgpu_batch_prepare")
 
-    def batch_recon(self, h):
-        self._chk(self.lib.xgpu_batch_recon(self.ctx, h), "xgpu_batch_recon")
+    def batch_recon(self, h, next_batch=None):
+        """next_batch: the NEXT picture's batch - its residual pass is queued with this picture's kernels (xgpu_batch_recon_ahead)"""
+        if next_batch is None:
+            self._chk(self.lib.xgpu_batch_recon(self.ctx, h), "xgpu_batch_recon")
+        else:
+            self._chk(self.lib.xgpu_batch_recon_ahead(self.ctx, h, next_batch), "xgpu_batch_recon_ahead")
 
     def deblock(self):
         self._chk(self.lib.xgpu_deblock(self.ctx), "xgpu_deblock")
@@ -209,9 +213,7 @@ class XgpuDecoder:
         """The coarse sequence of xevd_dec_nalu for one picture (src_base/xevd.c:1905-1983, src_main/xevdm.c:3136-3219)."""
         self.frame_begin(pic, poc, refs, qp_u_offset, qp_v_offset, deblock_on=deblock, alf_on=alf is not None,
                          alpha_off=alpha_off, beta_off=beta_off)
-        self.batch_recon(batch_handle)
-        if next_batch is not None:      # the next picture's residual pass, under this picture's dependency kernel and filters
-            self.batch_prepare(next_batch)
+        self.batch_recon(batch_handle, next_batch)      # with the next picture's residual pass under this picture's dependency kernel
         if deblock:
             self.deblock()
         if alf is not None:
