@@ -97,20 +97,27 @@ __device__ __forceinline__ int addb_index(int qp, int offset) { return clip3a(0,
 
 // The decisions and filters of one 4-sample edge segment (deblock_addb_cu_hor :893-944 / deblock_addb_cu_ver_yuv :947-1034): rq / rp = the SCU records
 // after / before the grid line, eq = the Q side's SCU position along the filtered axis, L / Cc = the windows (filtered in place).
+// decision half: the boundary strength of the segment, 0 = nothing to filter (not a CU / transform boundary, a tile border the PPS keeps, or strength 0)
 template <int DIR>
-__device__ __forceinline__ void addb_edge(const AddbArgs &a, const uint4 rq, const uint4 rp, int eq, int L[4][8], int Cc[2][2][4],
-                                          const uint8_t *s_alpha, const uint8_t *s_beta, const uint8_t *s_clip, const int8_t *s_cqp, const uint8_t *s_pic)
+__device__ __forceinline__ int addb_edge_strength(const AddbArgs &a, const uint4 rq, const uint4 rp, int eq, const uint8_t *s_pic)
 {
     const uint32_t eflag = DIR == 0 ? SCU_EDGE_L : SCU_EDGE_T;
-    const uint32_t nflag = DIR == 0 ? SCU_NOCH_L : SCU_NOCH_T;      // a luma CU's edge inside the chroma block of a local dual tree: luma only (xevdm_df.c:916-920, 986-997)
-    const int maxl = (1 << a.bd_l) - 1, maxc = (1 << a.bd_c) - 1;
     // an edge on a tile border stays as it is unless the PPS filters across tiles (no_boundary, src_main/xevdm_df.c:877, 1088, 1106)
     const int ctu_sh = a.log2_ctu - 2;
     const bool tile_edge = (eq & ((1 << ctu_sh) - 1)) == 0 && (DIR == 0 ? a.no_filter.col_start((eq >> ctu_sh) & 255) : a.no_filter.row_start((eq >> ctu_sh) & 255));
-    if (!(rq.x & eflag) || tile_edge) return;
+    if (!(rq.x & eflag) || tile_edge) return 0;
     const int epos = eq << 2;
     const bool cross = (epos & ((1 << a.log2_ctu) - 1)) == 0;
-    const int bs = addb_bs(rq, rp, cross, s_pic);
+    return addb_bs(rq, rp, cross, s_pic);
+}
+
+// filter half: bs > 0
+template <int DIR>
+__device__ __forceinline__ void addb_edge_filter(const AddbArgs &a, const uint4 rq, const uint4 rp, int bs, int L[4][8], int Cc[2][2][4],
+                                                 const uint8_t *s_alpha, const uint8_t *s_beta, const uint8_t *s_clip, const int8_t *s_cqp)
+{
+    const uint32_t nflag = DIR == 0 ? SCU_NOCH_L : SCU_NOCH_T;      // a luma CU's edge inside the chroma block of a local dual tree: luma only (xevdm_df.c:916-920, 986-997)
+    const int maxl = (1 << a.bd_l) - 1, maxc = (1 << a.bd_c) - 1;
     const int qp = (((rq.x >> 16) & 0x7F) + ((rp.x >> 16) & 0x7F) + 1) >> 1;
     const int scale = a.bd_l - 8;
     {
@@ -134,3 +141,10 @@ __device__ __forceinline__ void addb_edge(const AddbArgs &a, const uint4 rq, con
     }
 }
 
+template <int DIR>
+__device__ __forceinline__ void addb_edge(const AddbArgs &a, const uint4 rq, const uint4 rp, int eq, int L[4][8], int Cc[2][2][4],
+                                          const uint8_t *s_alpha, const uint8_t *s_beta, const uint8_t *s_clip, const int8_t *s_cqp, const uint8_t *s_pic)
+{
+    const int bs = addb_edge_strength<DIR>(a, rq, rp, eq, s_pic);
+    if (bs) addb_edge_filter<DIR>(a, rq, rp, bs, L, Cc, s_alpha, s_beta, s_clip, s_cqp);
+}

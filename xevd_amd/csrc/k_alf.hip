@@ -187,96 +187,121 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
         if (a.enable[2]) alf_stage<32, 2, CSTR, 4>(l_c[1], sv_, a.s_c, kc, tx0 >> 1, ty0 >> 1, t, 256);
         __syncthreads();
     } else {
-        // ---- the deblocking filter on the 72 x 72 region around the tile; its SCU records and tables borrow l_lap (written by ALF's classification afterwards) ----
+        // ---- the deblocking filter on the 72 x 72 region around the tile; its SCU records, tables and edge lists borrow l_lap (written by ALF's classification afterwards) ----
+        // Edge segments with something to filter are a minority (one grid line in eight inside a 64x64 CU; strength 0 between CUs that move alike) and a wave pays for
+        // the whole filter code whenever ONE of its lanes has such an edge.  So the region is moved into LDS unfiltered, every segment decides its strength, the ones
+        // to filter are compacted into a list (LDS atomic counter) and as many lanes as the list is long filter them in place: one wave pass instead of three per direction
+        // where CUs are large.  This kernel is bound by VALU issue, unlike k_addb_fused, where the same compaction changed nothing.
         const AddbArgs &da = *d;
         uint4 (*s_map)[18] = (uint4 (*)[18])&l_lap[0][0][0];
         uint8_t *s_alpha = (uint8_t *)&l_lap[0][0][0] + 18 * 18 * 16, *s_beta = s_alpha + 52, *s_clip = s_beta + 52, *s_pic = s_clip + 260;
         int8_t *s_cqp = (int8_t *)(s_pic + XGPU_MAX_REFS * 2);
-        static_assert(18 * 18 * 16 + 52 + 52 + 260 + XGPU_MAX_REFS * 2 + 192 <= (int)sizeof(uint16_t) * 4 * 34 * SSTR, "the deblocking state fits into l_lap");
+        constexpr int LIST_OFF = (18 * 18 * 16 + 52 + 52 + 260 + XGPU_MAX_REFS * 2 + 192 + 3) & ~3;
+        uint32_t *s_cnt = (uint32_t *)((uint8_t *)&l_lap[0][0][0] + LIST_OFF);
+        uint16_t (*s_list)[164] = (uint16_t (*)[164])(s_cnt + 2);            // entry = lane | strength << 8
+        static_assert(LIST_OFF + 8 + 2 * 164 * 2 <= (int)sizeof(uint16_t) * 4 * 34 * SSTR, "the deblocking state fits into l_lap");
         for (int i = t; i < 52; i += 256) { s_alpha[i] = k_alpha[i]; s_beta[i] = k_beta[i]; }
         for (int i = t; i < 260; i += 256) s_clip[i] = ((const uint8_t *)k_clip)[i];
         for (int i = t; i < XGPU_MAX_REFS * 2; i += 256) s_pic[i] = da.pic_id[i];
         for (int i = t; i < 192; i += 256) s_cqp[i] = da.chroma_qp[i];
+        if (t < 2) s_cnt[t] = 0;
 #define PK2(lo, hi) ((uint32_t)(uint16_t)(lo) | ((uint32_t)(uint16_t)(hi) << 16))
-        {   // vertical edges: lane = window wx (grid line x0 + 8 wx) x SCU row sr of the region; windows and records from memory, filtered, into LDS
+        {   // phase A: lane = vertical-edge window wx (grid line x0 + 8 wx) x SCU row sr of the region: window and SCU records from memory to LDS
             const int wx = t % 9, sr = t / 9;
             const int gx = tx0 + 8 * wx, sxq = gx >> 2, srow = (ty0 >> 2) - 1 + sr;
             const bool ok = t < 162 && gx <= a.pic_w && srow >= 0 && srow < da.h_scu;
             const bool has_p = ok && gx > 0, has_q = ok && gx < a.pic_w;
             const uint4 *maps = (const uint4 *)da.maps;
             uint4 rq = make_uint4(0, 0, 0, 0), rp = rq;
-            int L[4][8], Cc[2][2][4];
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-#pragma unroll
-                for (int q = 0; q < 8; q++) L[r][q] = 0;
-#pragma unroll
-            for (int pl = 0; pl < 2; pl++)
-#pragma unroll
-                for (int r = 0; r < 2; r++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) Cc[pl][r][q] = 0;
+            uint4 L[4] = { rq, rq, rq, rq };
+            uint2 C[2][2] = { { make_uint2(0, 0), make_uint2(0, 0) }, { make_uint2(0, 0), make_uint2(0, 0) } };
             if (ok) {
                 const int kq = srow * da.w_scu + sxq;
                 if (has_q) rq = maps[kq];
                 if (has_p) rp = maps[kq - 1];
                 const int y = srow << 2, cy = srow << 1;
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const U32x4a8 v = *(const U32x4a8 *)(sy_ + (y + r) * a.s_l + gx - 4);
-                    L[r][0] = (int16_t)(v.a & 0xFFFF); L[r][1] = (int16_t)(v.a >> 16); L[r][2] = (int16_t)(v.b & 0xFFFF); L[r][3] = (int16_t)(v.b >> 16);
-                    L[r][4] = (int16_t)(v.c & 0xFFFF); L[r][5] = (int16_t)(v.c >> 16); L[r][6] = (int16_t)(v.d & 0xFFFF); L[r][7] = (int16_t)(v.d >> 16);
-                }
+                for (int r = 0; r < 4; r++) { const U32x4a8 v = *(const U32x4a8 *)(sy_ + (y + r) * a.s_l + gx - 4); L[r] = make_uint4(v.a, v.b, v.c, v.d); }
 #pragma unroll
                 for (int pl = 0; pl < 2; pl++)
 #pragma unroll
-                    for (int r = 0; r < 2; r++) {
-                        const U32x2a4 v = *(const U32x2a4 *)((pl ? sv_ : su_) + (cy + r) * a.s_c + (gx >> 1) - 2);
-                        Cc[pl][r][0] = (int16_t)(v.a & 0xFFFF); Cc[pl][r][1] = (int16_t)(v.a >> 16); Cc[pl][r][2] = (int16_t)(v.b & 0xFFFF); Cc[pl][r][3] = (int16_t)(v.b >> 16);
-                    }
+                    for (int r = 0; r < 2; r++) { const U32x2a4 v = *(const U32x2a4 *)((pl ? sv_ : su_) + (cy + r) * a.s_c + (gx >> 1) - 2); C[pl][r] = make_uint2(v.a, v.b); }
             }
-            __syncthreads();                                 // the tables (the loads above are in flight across it)
-            if (has_p && has_q) addb_edge<0>(da, rq, rp, sxq, L, Cc, s_alpha, s_beta, s_clip, s_cqp, s_pic);
+            __syncthreads();                                 // the tables and the counters (the loads above are in flight across it)
             if (t < 162) {
                 s_map[sr][2 * wx] = rp; s_map[sr][2 * wx + 1] = rq;
 #pragma unroll
-                for (int r = 0; r < 4; r++)
-                    *(uint4 *)(l_y + (4 * sr + r) * LSTR + 8 * wx) = make_uint4(PK2(L[r][0], L[r][1]), PK2(L[r][2], L[r][3]), PK2(L[r][4], L[r][5]), PK2(L[r][6], L[r][7]));
+                for (int r = 0; r < 4; r++) *(uint4 *)(l_y + (4 * sr + r) * LSTR + 8 * wx) = L[r];
 #pragma unroll
                 for (int pl = 0; pl < 2; pl++)
 #pragma unroll
-                    for (int r = 0; r < 2; r++)
-                        *(uint2 *)(l_c[pl] + (2 * sr + r) * CSTR + 4 * wx) = make_uint2(PK2(Cc[pl][r][0], Cc[pl][r][1]), PK2(Cc[pl][r][2], Cc[pl][r][3]));
+                    for (int r = 0; r < 2; r++) *(uint2 *)(l_c[pl] + (2 * sr + r) * CSTR + 4 * wx) = C[pl][r];
+                const int bs = has_p && has_q ? addb_edge_strength<0>(da, rq, rp, sxq, s_pic) : 0;
+                if (bs) s_list[0][atomicAdd(&s_cnt[0], 1u)] = (uint16_t)(t | (bs << 8));
             }
         }
         __syncthreads();
-        if (t < 162) {   // horizontal edges: lane = SCU column sx x grid line y0 + 8 g of the region, in place in LDS
-            const int sx = t % 18, g = t / 18;
-            const int scol = (tx0 >> 2) - 1 + sx, gy = ty0 + 8 * g, syq = gy >> 2;
-            const bool okh = scol >= 0 && scol < da.w_scu && gy <= a.pic_h;
-            if (okh && gy > 0 && gy < a.pic_h) {
-                const uint4 rq = s_map[2 * g + 1][sx], rp = s_map[2 * g][sx];
-                int L[4][8], Cc[2][2][4];
+        // phase B: the vertical edges to filter, in place
+        for (int i = t; i < (int)s_cnt[0]; i += 256) {
+            const int e = s_list[0][i], seg = e & 255, bs = e >> 8, wx = seg % 9, sr = seg / 9;
+            const uint4 rp = s_map[sr][2 * wx], rq = s_map[sr][2 * wx + 1];
+            int L[4][8], Cc[2][2][4];
 #pragma unroll
-                for (int r = 0; r < 8; r++) {
-                    const uint2 v = *(const uint2 *)(l_y + (8 * g + r) * LSTR + 4 * sx);
-                    L[0][r] = (int16_t)(v.x & 0xFFFF); L[1][r] = (int16_t)(v.x >> 16); L[2][r] = (int16_t)(v.y & 0xFFFF); L[3][r] = (int16_t)(v.y >> 16);
-                }
-#pragma unroll
-                for (int pl = 0; pl < 2; pl++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) {
-                        const uint32_t v = *(const uint32_t *)(l_c[pl] + (4 * g + r) * CSTR + 2 * sx);
-                        Cc[pl][0][r] = (int16_t)(v & 0xFFFF); Cc[pl][1][r] = (int16_t)(v >> 16);
-                    }
-                addb_edge<1>(da, rq, rp, syq, L, Cc, s_alpha, s_beta, s_clip, s_cqp, s_pic);
-#pragma unroll
-                for (int r = 0; r < 8; r++) *(uint2 *)(l_y + (8 * g + r) * LSTR + 4 * sx) = make_uint2(PK2(L[0][r], L[1][r]), PK2(L[2][r], L[3][r]));
-#pragma unroll
-                for (int pl = 0; pl < 2; pl++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) *(uint32_t *)(l_c[pl] + (4 * g + r) * CSTR + 2 * sx) = PK2(Cc[pl][0][r], Cc[pl][1][r]);
+            for (int r = 0; r < 4; r++) {
+                const uint4 v = *(const uint4 *)(l_y + (4 * sr + r) * LSTR + 8 * wx);
+                L[r][0] = (int16_t)(v.x & 0xFFFF); L[r][1] = (int16_t)(v.x >> 16); L[r][2] = (int16_t)(v.y & 0xFFFF); L[r][3] = (int16_t)(v.y >> 16);
+                L[r][4] = (int16_t)(v.z & 0xFFFF); L[r][5] = (int16_t)(v.z >> 16); L[r][6] = (int16_t)(v.w & 0xFFFF); L[r][7] = (int16_t)(v.w >> 16);
             }
+#pragma unroll
+            for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const uint2 v = *(const uint2 *)(l_c[pl] + (2 * sr + r) * CSTR + 4 * wx);
+                    Cc[pl][r][0] = (int16_t)(v.x & 0xFFFF); Cc[pl][r][1] = (int16_t)(v.x >> 16); Cc[pl][r][2] = (int16_t)(v.y & 0xFFFF); Cc[pl][r][3] = (int16_t)(v.y >> 16);
+                }
+            addb_edge_filter<0>(da, rq, rp, bs, L, Cc, s_alpha, s_beta, s_clip, s_cqp);
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+                *(uint4 *)(l_y + (4 * sr + r) * LSTR + 8 * wx) = make_uint4(PK2(L[r][0], L[r][1]), PK2(L[r][2], L[r][3]), PK2(L[r][4], L[r][5]), PK2(L[r][6], L[r][7]));
+#pragma unroll
+            for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+                    *(uint2 *)(l_c[pl] + (2 * sr + r) * CSTR + 4 * wx) = make_uint2(PK2(Cc[pl][r][0], Cc[pl][r][1]), PK2(Cc[pl][r][2], Cc[pl][r][3]));
+        }
+        if (t < 162) {   // the horizontal edges to filter (the records are complete since the barrier): lane = SCU column sx x grid line y0 + 8 g of the region
+            const int sx = t % 18, g = t / 18;
+            const int scol = (tx0 >> 2) - 1 + sx, gy = ty0 + 8 * g;
+            if (scol >= 0 && scol < da.w_scu && gy > 0 && gy < a.pic_h) {
+                const int bs = addb_edge_strength<1>(da, s_map[2 * g + 1][sx], s_map[2 * g][sx], gy >> 2, s_pic);
+                if (bs) s_list[1][atomicAdd(&s_cnt[1], 1u)] = (uint16_t)(t | (bs << 8));
+            }
+        }
+        __syncthreads();
+        // phase C: the horizontal edges, in place
+        for (int i = t; i < (int)s_cnt[1]; i += 256) {
+            const int e = s_list[1][i], seg = e & 255, bs = e >> 8, sx = seg % 18, g = seg / 18;
+            const uint4 rq = s_map[2 * g + 1][sx], rp = s_map[2 * g][sx];
+            int L[4][8], Cc[2][2][4];
+#pragma unroll
+            for (int r = 0; r < 8; r++) {
+                const uint2 v = *(const uint2 *)(l_y + (8 * g + r) * LSTR + 4 * sx);
+                L[0][r] = (int16_t)(v.x & 0xFFFF); L[1][r] = (int16_t)(v.x >> 16); L[2][r] = (int16_t)(v.y & 0xFFFF); L[3][r] = (int16_t)(v.y >> 16);
+            }
+#pragma unroll
+            for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const uint32_t v = *(const uint32_t *)(l_c[pl] + (4 * g + r) * CSTR + 2 * sx);
+                    Cc[pl][0][r] = (int16_t)(v & 0xFFFF); Cc[pl][1][r] = (int16_t)(v >> 16);
+                }
+            addb_edge_filter<1>(da, rq, rp, bs, L, Cc, s_alpha, s_beta, s_clip, s_cqp);
+#pragma unroll
+            for (int r = 0; r < 8; r++) *(uint2 *)(l_y + (8 * g + r) * LSTR + 4 * sx) = make_uint2(PK2(L[0][r], L[1][r]), PK2(L[2][r], L[3][r]));
+#pragma unroll
+            for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) *(uint32_t *)(l_c[pl] + (4 * g + r) * CSTR + 2 * sx) = PK2(Cc[pl][0][r], Cc[pl][1][r]);
         }
 #undef PK2
         __syncthreads();
