@@ -407,6 +407,8 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
 // (A persistent variant that kept the first links of the next tiles in flight was measured slower: the prefetch registers pushed the kernel into
 // scratch and its 53 KB of code out of the instruction cache; DESIGN.md.)
 // (Round 3: forcing the register allocator to five waves per SIMD - amdgpu_waves_per_eu(5, 5): 96 VGPRs + 192 bytes of scratch per lane - took 286 us instead of 152.)
+// (Round 3, occupancy sweep with dynamic LDS padding at 8K: 4 workgroups per CU 147 us, 3 per CU 153 us, 2 per CU 176 us - the kernel is not bound by the latency of
+//  its chains any more; its 507 MB of measured traffic in 147 us are 3.45 TB/s, 72 % of what this part's plain copy kernel reaches.)
 __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
 {
     __shared__ uint4    s_ref[XGPU_MAX_REFS * 2][2];        // RefEntry [idx][list]
