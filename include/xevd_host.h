@@ -93,6 +93,13 @@ int  xhost_parser_set_dmvr_mvs(xhost_parser *p, const int16_t *mv, int n_sub);
    144 samples of replicated border on every side (what xgpu_pic_download_padded delivers); it must stay valid and unchanged while the picture is a
    reference.  Streams that need it and do not get it fail with an error that says so.  Why the front end reads samples at all: xevd_amd/host/dmvr_search.h. */
 int  xhost_parser_set_ref_luma(xhost_parser *p, int poc, const int16_t *plane, int stride);
+/* Picture boundaries of a NAL stream without decoding it (what the GOP splitter xwq_split_gops uses): feed every NAL unit (without its length prefix);
+   -> 0 not a slice, 1 the first slice of a picture, 2 a further slice of the same picture (several slices per picture), < 0 malformed.               */
+typedef struct xhost_scan xhost_scan;
+xhost_scan *xhost_scan_open(void);
+int  xhost_scan_nal(xhost_scan *s, const uint8_t *nal, size_t size);
+void xhost_scan_close(xhost_scan *s);
+
 /* The same parser fed one NAL unit at a time (2-byte NAL header + payload, no length prefix - what xevd_decode receives):
    1: `out` holds a picture (has_md5 is 0: a signature SEI arrives as its own NAL unit); 0: consumed; < 0: error */
 xhost_parser *xhost_parser_open_nal(void);
@@ -208,6 +215,15 @@ xhost_writer *xhost_writer_open(const xhost_stream_params *sp);
 int  xhost_writer_add_dra_aps(xhost_writer *w, const xhost_dra_aps *aps);       /* appends a DRA APS NAL unit (needs tool_dra), before the pictures */
 int  xhost_writer_add_alf_aps(xhost_writer *w, const xhost_alf_aps *aps);       /* appends an APS NAL unit (needs tool_alf)    */
 int  xhost_writer_set_slice_alf(xhost_writer *w, const xhost_slice_alf *sa);    /* for the next xhost_writer_add_picture       */
+/* Several slices per picture (Main profile with tiles and sps_pocs_flag): every following picture is written as n slice NAL units, slice k holding the
+   rectangle of tiles first_tile .. last_tile (tile ids in raster order of the PPS's grid; the rectangles must partition the grid).  slice_qp / deblock_on:
+   -1 = what xhost_writer_add_picture / the stream parameters say.  n = 0: back to one slice with every tile.  The decoders run the in-loop filters of
+   the whole picture with the LAST slice's header (src_main/xevdm.c:3138-3199).                                                                       */
+typedef struct xhost_slice_desc { int first_tile, last_tile, slice_qp, deblock_on; } xhost_slice_desc;
+int  xhost_writer_set_slices(xhost_writer *w, int n, const xhost_slice_desc *slices);
+/* before the first picture: the PPS announces arbitrary slices and every slice of several tiles lists its tiles (arbitrary_slice_flag, ascending tile ids)
+   instead of naming the rectangle's corners - the same slices in the other syntax                                                                  */
+int  xhost_writer_set_arbitrary_slices(xhost_writer *w, int on);
 /* Appends one picture (SPS + PPS first when it is the first).  `b`: leaf CUs of a quad tree (64..4) in decode order with the
    fields of xgpu_cu_batch; per CU the writer keeps pred_mode (INTRA / INTER / SKIP / DIR), refi and mv of the lists in use
    (INTER: refi[l] >= 0 selects the lists, indices are clamped to the actual list sizes; SKIP / DIR CUs take derived motion),

@@ -216,6 +216,12 @@ def golden_streams(only=()):
                                 "main_tiles_across_dmvr_8b": (392, 264, 9, dict(main=True, iqt=True, addb=True, alf=True, eipd=True, htdf=True, admvp=True, dmvr=True, log2_sub_gop=2, max_refs=2,
                                                                                 tiles=(2, 3, 1))),
                                 "main_tiles_explicit_10b": (512, 320, 5, dict(main=True, iqt=True, addb=True, alf=True, eipd=True, admvp=True, bit_depth=10, tiles=(3, 3, 0, (1, 5), (2, 1)))),
+                                # several slice NAL units per picture (tile rectangles; own slice QPs; the in-loop filters follow the LAST slice's header)
+                                "main_slices_4rows_all_tools_10b": (256, 256, 9, dict(main=True, pocs=True, rpl=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, admvp=True, amvr=True,
+                                                                                      hmvp=True, mmvd=True, max_refs=2, log2_sub_gop=2, bit_depth=10, tiles=(4, 4, 0),
+                                                                                      slices=[(0, 3, 28, 1), (4, 7, 33, 0), (8, 11, -1, 1), (12, 15, 35, 1)])),
+                                "main_slices_columns_arbitrary_8b": (384, 256, 5, dict(main=True, pocs=True, iqt=True, addb=True, alf=True, admvp=True, affine=True, dmvr=True, max_refs=2,
+                                                                                       tiles=(3, 2, 1), slices=[(0, 3, 31), (1, 5, 25)], arbitrary_slices=True)),
                                 "main_alf_fixed_8b": (264, 136, 8, dict(main=True, alf=True, addb=True, alf_fixed=True)),
                                 "main_ibc_i_8b": (136, 72, 3, dict(main=True, eipd=True, ibc_log_max=4, ibc_frac=0.4, idr_period=1)),
                                 "main_ibc_all_tools_10b": (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=5, inter_frac=0.5, log2_sub_gop=2, max_refs=2, bit_depth=10))}.items():

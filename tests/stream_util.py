@@ -27,7 +27,7 @@ def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_fra
                 cu_qp_delta=True, split_prob=0.5, idr_period=0, log2_sub_gop=0, bi_frac=0.5, direct_frac=0.1,
                 main=False, iqt=False, ats=False, addb=False, addb_offsets=(0, 0), alf=False, sign=False, eipd=False, crop=(0, 0, 0, 0),
                 chroma_qp_points=None, dra=None, htdf=False, ibc_log_max=0, ibc_frac=0.25, alf_fixed=False, admvp=False, amvr=False, hmvp=False, dmvr=False, mmvd=False,
-                tiles=None, affine=False, affine_frac=0.4, qp_delta_area=0, rpl=False, pocs=False, rpl_in_sps=False, cm_init=False, adcc=False, max_level=6, qp_range=(22, 37), btt=None, dual_tree=False):
+                tiles=None, affine=False, affine_frac=0.4, qp_delta_area=0, rpl=False, pocs=False, rpl_in_sps=False, cm_init=False, adcc=False, max_level=6, qp_range=(22, 37), btt=None, dual_tree=False, slices=None, arbitrary_slices=False):
     """-> bytes.  Picture 0 is an IDR.  log2_sub_gop = 0: IPPP; n: hierarchical sub-GOPs of 2^n pictures, the layer-0 picture of
     each a P picture, the others B pictures (bi-prediction, temporal direct and two-list skip CUs).
     sign: every picture is followed by a picture-signature SEI with the MD5s of the ORACLE's reconstruction of the stream so far."""
@@ -38,6 +38,10 @@ def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_fra
     n_ctu = ((width + 63) // 64) * ((height + 63) // 64)
     tids = gop_tids(log2_sub_gop)
     try:
+        if slices:      # several slice NAL units per picture: tile rectangles (first, last[, slice_qp[, deblock_on]])
+            if arbitrary_slices:
+                w.set_arbitrary_slices(True)
+            w.set_slices(slices)
         if dra is not None:      # one of oracle_lib.DRA_SETS: the PPS switches DRA on for every picture with parameter set 3
             d = ol.DRA_SETS[dra]
             w.add_dra_aps(3, d["in_ranges"], d["scales"], d["cb"], d["cr"], d["table_idx"])

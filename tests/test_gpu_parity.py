@@ -415,7 +415,7 @@ def test_gpu_decoder_survives_mutated_streams():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["hier_b_gop4", "main_eipd_all_tools_10b", "cqt_crop_10b", "idr_period_skip", "main_dra_10b", "main_htdf_all_tools_10b", "main_tiles_explicit_10b", "main_affine_all_tools_10b",
-                                  "main_dmvr_hmvp_mmvd_b_8b", "main_every_tool_10b", "main_every_tool_tiles_8b"])
+                                  "main_dmvr_hmvp_mmvd_b_8b", "main_every_tool_10b", "main_every_tool_tiles_8b", "main_slices_4rows_all_tools_10b", "main_slices_columns_arbitrary_8b"])
 def test_gpu_plain_c_decoder(name, tmp_path):
     """examples/evc_decode - a decoder in plain C on the two C ABIs, no Python in the loop - writes the reference decoder's pictures"""
     import subprocess
@@ -442,7 +442,8 @@ APP_ON_HIP = os.path.normpath(os.path.join(golden_io.GOLDEN, "..", "..", "oracle
                                        ("main_dra_10b", ["--output-bit-depth", "10"]), ("main_htdf_all_tools_10b", ["--output-bit-depth", "10"]),
                                        ("main_ibc_all_tools_10b", ["--output-bit-depth", "10"]), ("main_admvp_all_tools_10b", ["--output-bit-depth", "10"]), ("main_dmvr_all_tools_10b", ["--output-bit-depth", "10"]),
                                        ("main_tiles_3x2_all_tools_10b", ["--output-bit-depth", "10"]), ("main_tiles_explicit_10b", []),
-                                       ("main_affine_all_tools_10b", ["--output-bit-depth", "10"]), ("main_every_tool_10b", ["--output-bit-depth", "10"])])
+                                       ("main_affine_all_tools_10b", ["--output-bit-depth", "10"]), ("main_every_tool_10b", ["--output-bit-depth", "10"]),
+                                       ("main_slices_4rows_all_tools_10b", ["--output-bit-depth", "10"])])
 def test_gpu_reference_application_on_our_api(name, args, tmp_path):
     """The reference's OWN sample application (app/xevd_app.c, compiled from its source where it lies) linked against libxevd_amd_api.so - this
     repository's implementation of the public xevd_create / xevd_decode / xevd_pull API - instead of libxevd: it decodes the golden streams on
@@ -473,8 +474,10 @@ REF_DECODE_HIP = os.path.normpath(os.path.join(golden_io.GOLDEN, "..", "..", "or
 # behind the picture-granular slots (fn_dec_slice ...) reconstructs after the picture is parsed - our own front end runs the refinement search itself for those
 # (xevd_amd/host/dmvr_search.h); they are decoded by every other path below
 HOST_DMVR_STREAMS = {"main_dmvr_hmvp_mmvd_b_8b", "main_every_tool_10b", "main_every_tool_tiles_8b"}
+# ... and not the streams with several slices per picture: oracle/ref_binding.c's fn_dec_slice stand-in builds and launches one batch per call (one slice = one picture)
+MULTI_SLICE_STREAMS = {"main_slices_4rows_all_tools_10b", "main_slices_columns_arbitrary_8b"}
 STREAM_NAMES = sorted(f[len("stream_"):-len(".npz")] for f in os.listdir(golden_io.GOLDEN)
-                      if f.startswith("stream_") and f.endswith(".npz") and "main_" in f and f[len("stream_"):-len(".npz")] not in HOST_DMVR_STREAMS)
+                      if f.startswith("stream_") and f.endswith(".npz") and "main_" in f and f[len("stream_"):-len(".npz")] not in HOST_DMVR_STREAMS | MULTI_SLICE_STREAMS)
 
 
 @pytest.mark.gpu

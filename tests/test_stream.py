@@ -152,6 +152,15 @@ CONFIGS = [
     (384, 256, 9, dict(main=True, iqt=True, addb=True, alf=True, eipd=True, admvp=True, dmvr=True, log2_sub_gop=2, max_refs=2, bit_depth=10, tiles=(2, 2, 0))),
     (512, 320, 5, dict(main=True, iqt=True, addb=True, alf=True, eipd=True, admvp=True, bit_depth=10, tiles=(3, 3, 0, (1, 5), (2, 1)))),
     (712, 72, 4, dict(main=True, iqt=True, alf=True, addb=True, tiles=(7, 1, 0))),
+    # several slices per picture (slice NAL units of tile rectangles, sps_pocs_flag): own slice QP per slice (the tiles' QP predictors start there), the in-loop
+    # filters of the whole picture with the LAST slice's header - deblocking switched off there switches it off everywhere (src_main/xevdm.c:3138-3199)
+    (256, 256, 4, dict(main=True, pocs=True, tiles=(4, 4, 0), slices=[(0, 7), (8, 15)])),
+    (256, 256, 5, dict(main=True, pocs=True, rpl=True, iqt=True, addb=True, alf=True, admvp=True, hmvp=True, max_refs=2, log2_sub_gop=2, bit_depth=10, tiles=(4, 4, 0),
+                       slices=[(0, 3, 28, 1), (4, 7, 33, 0), (8, 11, -1, 1), (12, 15, 35, 1)])),
+    (256, 192, 3, dict(main=True, pocs=True, iqt=True, addb=True, tiles=(2, 2, 1), slices=[(0, 1, 30, 1), (2, 2, 26, 1), (3, 3, 38, 0)])),
+    (384, 256, 4, dict(main=True, pocs=True, rpl=True, iqt=True, addb=True, alf=True, eipd=True, admvp=True, max_refs=2, tiles=(3, 2, 0), slices=[(0, 3, 31), (1, 5, 25)])),
+    (384, 256, 3, dict(main=True, pocs=True, iqt=True, addb=True, admvp=True, max_refs=2, tiles=(3, 2, 0), slices=[(0, 3, 31), (1, 5, 25)], arbitrary_slices=True)),
+    (256, 256, 3, dict(main=True, pocs=True, tiles=(4, 4, 0), slices=[(0, 7), (8, 11, 35), (12, 15, 24)], arbitrary_slices=True)),
     (200, 328, 4, dict(main=True, iqt=True, alf=True, tiles=(1, 5, 1))),
     # tool_dmvr TOGETHER with tool_hmvp / tool_mmvd (what Main-profile encoders switch on): the refined vectors are state of the picture's own parse (history
     # buffer, merge list of MMVD CUs), so the front end runs the refinement search itself on the decoded reference samples (xevd_amd/host/dmvr_search.h;

@@ -658,10 +658,13 @@ struct Stream {          // everything both directions share
     std::vector<int> rpl_released;       // POCs the current slice's RPLs dropped from the DPB (reported with the picture)
 
     // reference lists without RPL (xevd_picman_refp_init, xevd_picman.c:291-437) over the reference pictures by descending POC
-    bool build_ref_lists(bool idr)
+    // later_slice: a further slice of the picture being parsed - what the earlier slices' marking released is kept, and an I slice leaves the lists alone
+    // (xevdm_picman_refp_rpl_based_init / xevdm_picman_refp_init return before touching refp for SLICE_I: the lists of an earlier P / B slice stay)
+    bool build_ref_lists(bool idr, bool later_slice = false)
     {
-        refp[0].clear(); refp[1].clear();
-        rpl_released.clear();
+        const bool keep_lists = later_slice && sh.type == XHOST_SLICE_I;
+        if (!keep_lists) { refp[0].clear(); refp[1].clear(); }
+        if (!later_slice) rpl_released.clear();
         if (sps.tool_rpl && !enc_side) {
             // marking (xevdm_picman_refpic_marking, xevdm_picman.c:542-588): a reference picture that neither list of THIS slice names (active or not) is
             // dropped; lists (xevdm_picman_refp_rpl_based_init :315-368): entry i = the picture with POC cur - ref[i], which must be there
@@ -719,11 +722,11 @@ struct Stream {          // everything both directions share
         return true;
     }
     // picture marking + insertion (xevd_picman_put_pic / pic_marking_no_rpl, xevd_picman.c:68-110,462-509); released POCs reported
-    void store_picture(bool idr, std::vector<int> &released)
+    void store_picture(bool idr, std::vector<int> &released, int any_inter_slice = -1)
     {
         // pic->list_poc[i] = POC of refp[i][REFP_0] (xevd_picman.c:213-221); an I slice leaves num_refp untouched, so the previous picture's values stay.
-        // Taken BEFORE the DPB below is edited: refp[] points into it
-        if (sh.type != XHOST_SLICE_I) {
+        // Taken BEFORE the DPB below is edited: refp[] points into it.  (Several slices: the lists of the picture's P / B slices, whichever slice came last.)
+        if (any_inter_slice < 0 ? sh.type != XHOST_SLICE_I : any_inter_slice != 0) {
             stale_list0_poc = refp[0].empty() ? 0 : refp[0][0]->poc;
             for (size_t i = 0; i < refp[0].size() && i < 16; i++) stale_list_poc[i] = refp[0][i]->poc;
         }
@@ -2252,7 +2255,7 @@ struct xhost_parser {
     size_t n_coef = 0;
     int n_threads = 1;                                   // xhost_parser_set_threads
     std::string err;
-    int fail(const char *m) { err = m; return XHOST_ERR_MALFORMED; }
+    int fail(const char *m) { err = m; pic_tiles_left = 0; return XHOST_ERR_MALFORMED; }      // (a picture half assembled from slices is dropped)
     // runs fn(0 .. n-1) on up to n_threads threads (the calling one included)
     template <class F> void parallel_for(int n, F fn)
     {
@@ -2432,6 +2435,42 @@ struct xhost_parser {
         st.have_pps = true;
         return XGPU_OK;
     }
+    // the tiles of a slice, in the order of their entry points (xevdm_eco.c:2520-2550, set_tile_info src_main/xevdm.c:2185-2236): one tile, the rectangle of
+    // tiles between first_tile_id and last_tile_id (it may wrap around the picture's right / bottom border), or an arbitrary ascending list.  br stands behind
+    // slice_pic_parameter_set_id
+    int slice_tile_list(BitReader &br, std::vector<int> &tl)
+    {
+        const int n_tiles = st.pps.tile_cols * st.pps.tile_rows;
+        tl.assign(1, 0);
+        if (n_tiles > 1) {
+            const int single = br.get1(), first = (int)br.get(st.pps.id_bits);
+            if (first >= n_tiles) return fail("bad slice header: first_tile_id");
+            tl[0] = first;
+            if (!single) {
+                const int arbitrary = st.pps.arbitrary_slices ? br.get1() : 0;
+                if (!arbitrary) {
+                    const int last = (int)br.get(st.pps.id_bits), wt = st.pps.tile_cols, ht = st.pps.tile_rows;
+                    if (last >= n_tiles) return fail("bad slice header: last_tile_id");
+                    int delta = last - first;
+                    if (last < first) delta += first % wt > last % wt ? n_tiles + wt : n_tiles;
+                    else if (first % wt > last % wt) delta += wt;
+                    const int ws = delta % wt + 1, hs = delta / wt + 1;
+                    if (ws > wt || hs > ht) return fail("bad slice header: tile rectangle");
+                    tl.clear();
+                    for (int r = 0; r < hs; r++) for (int c2 = 0; c2 < ws; c2++) tl.push_back(((first / wt + r) % ht) * wt + (first % wt + c2) % wt);
+                } else {
+                    const uint32_t more = br.ue() + 1;             // num_remaining_tiles_in_slice_minus1 + 1
+                    if (br.overrun || more >= (uint32_t)n_tiles) return fail("bad slice header: arbitrary slice");
+                    for (uint32_t i = 0; i < more; i++) {
+                        const uint32_t d = br.ue();
+                        if (br.overrun || d >= (uint32_t)n_tiles || tl.back() + (int)d + 1 >= n_tiles) return fail("bad slice header: delta_tile_id");
+                        tl.push_back(tl.back() + (int)d + 1);
+                    }
+                }
+            }
+        }
+        return XGPU_OK;
+    }
     int parse_slice(BitReader &br, int nut, int tid, xhost_picture *out)
     {
         if (!st.have_sps || !st.have_pps) return fail("slice before SPS/PPS");
@@ -2441,12 +2480,18 @@ struct xhost_parser {
         br.ue();                                         // slice_pic_parameter_set_id
         const int n_tiles = st.pps.tile_cols * st.pps.tile_rows;
         if (n_tiles > 1 && !st.sps.profile_main) return fail("tiles in a Baseline stream are not supported");
-        if (n_tiles > 1) {                               // xevdm_eco.c:2520-2550: this front end takes ONE slice per picture, all tiles in raster order
-            const int single = br.get1(), first = (int)br.get(st.pps.id_bits);
-            if (single || first != 0) return fail("several slices per picture are not supported");
-            if (st.pps.arbitrary_slices && br.get1()) return fail("arbitrary slices are not supported");
-            if ((int)br.get(st.pps.id_bits) != n_tiles - 1) return fail("several slices per picture are not supported");
+        std::vector<int> tl;
+        { const int rc = slice_tile_list(br, tl); if (rc != XGPU_OK) return rc; }
+        const int n_slice_tiles = (int)tl.size();
+        const bool first_slice = pic_tiles_left == 0;
+        if (!first_slice) {
+            // The reference decoder takes slice NALs as parts of one picture until every CTU is covered (ctx->num_ctb, src_main/xevdm.c:2995-2999, 3106, 3138); without
+            // sps_pocs_flag it derives a NEW picture order count for every slice NAL (xevd_poc_derivation is called per NAL, :3030-3040), so such streams need the flag
+            if (!st.sps.tool_pocs) return fail("several slices per picture need sps_pocs_flag (the reference decoder counts a picture per slice NAL otherwise)");
+            if (nut != pic_nut || tid != pic_tid) return fail("the slices of a picture differ in NAL unit type or temporal id");
         }
+        for (int t : tl) if (!first_slice && tile_done[(size_t)t]) return fail("a tile is coded twice in one picture");
+        if (!first_slice && n_slice_tiles > pic_tiles_left) return fail("a tile is coded twice in one picture");
         sh.type = (int)br.ue();
         if (sh.type < 0 || sh.type > 2) return fail("bad slice type");
         if (nut == NUT_IDR) br.get1();                   // no_output_of_prior_pics_flag
@@ -2491,32 +2536,51 @@ struct xhost_parser {
         if (sh.deblock && st.sps.tool_addb) { sh.alpha_off = br.se(); sh.beta_off = br.se(); }      // xevdm_eco.c:2767-2772
         sh.qp = (int)br.get(6);
         sh.qp_u_offset = br.se(); sh.qp_v_offset = br.se();
-        std::vector<size_t> tile_size((size_t)n_tiles, 0);      // entry_point_offset_minus1 + 1: bytes of every tile but the last (xevdm_eco.c:2789-2795)
-        for (int i = 0; i + 1 < n_tiles; i++) tile_size[(size_t)i] = (size_t)br.get(st.pps.offset_bits) + 1;
+        std::vector<size_t> tile_size((size_t)n_slice_tiles, 0);      // entry_point_offset_minus1 + 1: bytes of every tile of the slice but the last (xevdm_eco.c:2789-2795)
+        for (int i = 0; i + 1 < n_slice_tiles; i++) tile_size[(size_t)i] = (size_t)br.get(st.pps.offset_bits) + 1;
         while (!br.aligned()) if (br.get1()) return fail("slice header alignment");
         if (br.overrun || sh.qp > 51) return fail("bad slice header");
         st.derive_poc(nut == NUT_IDR, tid);
+        if (!first_slice && st.poc != pic_poc) return fail("a slice of another picture before every tile of the picture was coded");
         if (sh.type == XHOST_SLICE_I) st.last_intra_poc = st.poc;
-        if (!st.build_ref_lists(nut == NUT_IDR)) return fail("a reference picture list names a picture that is not in the DPB");
+        if (!st.build_ref_lists(nut == NUT_IDR, !first_slice)) return fail("a reference picture list names a picture that is not in the DPB");
         if (sh.type != XHOST_SLICE_I && st.refp[0].empty()) return fail("P/B slice without a reference picture");
         if (sh.type == XHOST_SLICE_B && st.refp[1].empty()) return fail("B slice without a list-1 reference picture");
         for (int l = 0; l < 2; l++)
             for (const RefPic *r : st.refp[l])
                 if (r->mv0.size() != (size_t)(st.sps.width >> 2) * (st.sps.height >> 2) * 2) return fail("reference picture of another geometry");
-        st.pic.reset(st.sps.width, st.sps.height, st.sps.host_dmvr());
-        if (!st.setup_tiles()) return fail("the tile grid of the PPS does not fit the picture");
+        const int W = st.sps.width, H = st.sps.height, w_ctu = (W + 63) >> 6, h_ctu = (H + 63) >> 6;
+        if (first_slice) {
+            st.pic.reset(st.sps.width, st.sps.height, st.sps.host_dmvr());
+            if (!st.setup_tiles()) return fail("the tile grid of the PPS does not fit the picture");
+            st.alf_ctb_flag.assign((size_t)w_ctu * h_ctu, 1);
+            tile_done.assign((size_t)n_tiles, 0);
+            pic_nut = nut; pic_tid = tid; pic_poc = st.poc; pic_inter = 0; pic_qp = sh.qp;
+        }
+        // The backend takes ONE pair of reference lists per picture (and the reference decoder deblocks the whole picture with the lists of its last P / B slice,
+        // ctx->refp at src_main/xevdm.c:3138-3199): the P / B slices of a picture must name the same pictures; I slices may be mixed in
+        if (sh.type != XHOST_SLICE_I) {
+            std::vector<int> lp;
+            for (int l = 0; l < 2; l++) { lp.push_back(-1 - l); for (const RefPic *r : st.refp[l]) lp.push_back(r->poc); }
+            if (pic_inter && lp != pic_lists) return fail("slices of one picture with different reference picture lists are not supported");
+            pic_lists = lp; pic_inter = 1;
+        }
+        if (st.sps.tool_htdf && sh.qp != pic_qp) return fail("slices of one picture with different slice QPs together with HTDF are not supported");
 
         // ---- tile data (xevdm_dec_slice + xevd_tile_eco, src_main/xevdm.c:2363-2461, 2614-2718): every tile is its own arithmetic-coder
         //      run - contexts, QP predictor and motion history start afresh - at the byte offset the slice header gave; tiles share nothing but
         //      the picture maps (disjoint regions), so they are parsed in parallel when the caller allows threads ----
-        const int W = st.sps.width, H = st.sps.height, w_ctu = (W + 63) >> 6, h_ctu = (H + 63) >> 6;
-        st.alf_ctb_flag.assign((size_t)w_ctu * h_ctu, 1);
         while ((int)tiles.size() < n_tiles) tiles.emplace_back(new TileParser(st));
-        std::vector<size_t> tile_pos((size_t)n_tiles, br.pos);
-        for (int t = 1; t < n_tiles; t++) tile_pos[(size_t)t] = tile_pos[(size_t)t - 1] + tile_size[(size_t)t - 1] * 8;
-        std::vector<int> tile_rc((size_t)n_tiles, XGPU_OK);
-        parallel_for(n_tiles, [&](int t) { tile_rc[(size_t)t] = tiles[(size_t)t]->parse_tile(br, tile_pos[(size_t)t], t % st.grid.n_cols, t / st.grid.n_cols); });
-        for (int t = 0; t < n_tiles; t++) if (tile_rc[(size_t)t] != XGPU_OK) { err = tiles[(size_t)t]->err; return tile_rc[(size_t)t]; }
+        std::vector<size_t> tile_pos((size_t)n_slice_tiles, br.pos);
+        for (int t = 1; t < n_slice_tiles; t++) tile_pos[(size_t)t] = tile_pos[(size_t)t - 1] + tile_size[(size_t)t - 1] * 8;
+        std::vector<int> tile_rc((size_t)n_slice_tiles, XGPU_OK);
+        parallel_for(n_slice_tiles, [&](int i) { const int t = tl[(size_t)i]; tile_rc[(size_t)i] = tiles[(size_t)t]->parse_tile(br, tile_pos[(size_t)i], t % st.grid.n_cols, t / st.grid.n_cols); });
+        for (int i = 0; i < n_slice_tiles; i++) if (tile_rc[(size_t)i] != XGPU_OK) { err = tiles[(size_t)tl[(size_t)i]]->err; pic_tiles_left = 0; return tile_rc[(size_t)i]; }
+        if (first_slice) pic_tiles_left = n_tiles;
+        for (int t : tl) tile_done[(size_t)t] = 1;
+        pic_tiles_left -= n_slice_tiles;
+        if (pic_tiles_left > 0) return XGPU_OK;                // more slices of this picture follow; the in-loop filters run with the LAST slice's header, as in the
+                                                                 // reference decoder (ctx->sh at src_main/xevdm.c:3138-3199: deblocking switch and offsets, chroma QP offsets, ALF)
         merged_arena = nullptr;
         if (n_tiles == 1) { cur = &tiles[0]->batch; n_coef = tiles[0]->n_coef; }
         else {
@@ -2610,7 +2674,7 @@ struct xhost_parser {
             out->alf.ctb_flag = hd.ctb.data(); out->alf.across_tiles = st.pps.across_tiles; out->alf.tiles = n_tiles > 1 ? &hd.grid : nullptr;
         }
         std::vector<int> released;
-        st.store_picture(nut == NUT_IDR, released);
+        st.store_picture(nut == NUT_IDR, released, pic_inter);
         out->n_release = (int)std::min(released.size(), (size_t)32);
         for (int i = 0; i < out->n_release; i++) out->release_poc[i] = released[(size_t)i];
         xgpu_cu_batch &b = out->batch;
@@ -2644,6 +2708,10 @@ struct xhost_parser {
     }
     int last_poc = 0, last_n_dmvr = 0;
     bool last_stored = false;
+    // the picture being assembled from several slice NALs: tiles still to come, and what its slices must agree on
+    int pic_tiles_left = 0, pic_nut = 0, pic_tid = 0, pic_poc = 0, pic_inter = 0, pic_qp = 0;
+    std::vector<uint8_t> tile_done;
+    std::vector<int> pic_lists;
     // the refined vectors of the picture just handed out: what the reference keeps in map_mv for the temporal candidates of later pictures
     // (dmvr_mv -> map_mv, src_main/xevdm_util.c:4327-4338); the picture's own CUs, the history and the deblocking filter use the unrefined ones
     int set_dmvr_mvs(const int16_t *mv, int n)
@@ -2761,6 +2829,32 @@ extern "C" int xhost_parser_next(xhost_parser *p, xhost_picture *out)
     return 0;
 }
 
+// Picture boundaries without decoding anything (the GOP splitter of the work queue, xwq.cc): a slice NAL belongs to the picture of the slice before it until
+// the PPS's tiles are all covered (ctx->num_ctb, src_main/xevdm.c:2995-2999).  The scanner reads PPS NALs (tile grid) and the first fields of slice headers.
+struct xhost_scan { xhost_parser p; int tiles_left = 0; };
+extern "C" xhost_scan *xhost_scan_open(void) { return new xhost_scan(); }
+extern "C" void xhost_scan_close(xhost_scan *s) { delete s; }
+// -> 0: not a slice NAL, 1: the first (or only) slice of a picture, 2: a further slice of the picture, < 0: malformed
+extern "C" int xhost_scan_nal(xhost_scan *s, const uint8_t *nal, size_t len)
+{
+    if (!s || !nal || len < 2) return XGPU_ERR_INVALID_ARGUMENT;
+    BitReader br;
+    br.p = nal; br.size = len;
+    br.get1();
+    const int nut = (int)br.get(6) - 1;
+    br.get(3); br.get(5); br.get1();
+    if (nut == NUT_PPS) { const int rc = s->p.parse_pps(br); return rc < 0 ? rc : 0; }
+    if (nut != NUT_IDR && nut != NUT_NONIDR) return 0;
+    br.ue();                                             // slice_pic_parameter_set_id
+    std::vector<int> tl;
+    const int rc = s->p.slice_tile_list(br, tl);
+    if (rc != XGPU_OK || br.overrun) return XHOST_ERR_MALFORMED;
+    const bool first = s->tiles_left <= 0;
+    if (first) s->tiles_left = s->p.st.pps.tile_cols * s->p.st.pps.tile_rows;
+    s->tiles_left -= (int)tl.size();
+    return first ? 1 : 2;
+}
+
 // NAL-at-a-time interface (what xevd_decode takes: one NAL unit without its length prefix, src_base/xevd.c:1786-2024)
 extern "C" xhost_parser *xhost_parser_open_nal(void) { return new xhost_parser(); }
 extern "C" int xhost_parser_nal(xhost_parser *p, const uint8_t *nal, size_t size, xhost_picture *out)
@@ -2780,6 +2874,8 @@ struct xhost_writer {
     bool headers_done = false;
     xhost_slice_alf next_alf = { 0, 0, 0, 0, 0, nullptr };
     std::vector<uint8_t> next_alf_ctb;
+    std::vector<xhost_slice_desc> slices;      // xhost_writer_set_slices; empty = one slice with every tile
+    bool arbitrary_slices = false;             // xhost_writer_set_arbitrary_slices: slices of several tiles list their tiles (arbitrary_slice_flag) instead of naming a rectangle
 
     void write_sps()
     {
@@ -2848,7 +2944,8 @@ struct xhost_writer {
         bw.ue((uint32_t)q.id_bits - 1); bw.put1(0);      // tile_id_len_minus1, explicit_tile_id_flag
         bw.put1(sp.tool_dra ? 1 : 0);                    // pic_dra_enabled_flag
         if (sp.tool_dra) bw.put((uint32_t)sp.dra_aps_id, 5);
-        bw.put1(0);                                      // arbitrary_slice_present
+        st.pps.arbitrary_slices = arbitrary_slices ? 1 : 0;
+        bw.put1(st.pps.arbitrary_slices);                // arbitrary_slice_present_flag
         bw.put1(0);                                      // constrained_intra_pred_flag
         bw.put1(sp.cu_qp_delta ? 1 : 0);
         if (sp.cu_qp_delta) bw.ue((uint32_t)(st.pps.qp_delta_area - 6));      // cu_qp_delta_area - 6
@@ -2928,6 +3025,18 @@ extern "C" int xhost_writer_set_slice_alf(xhost_writer *w, const xhost_slice_alf
     const size_t n_ctu = (size_t)((w->sp.width + 63) >> 6) * (size_t)((w->sp.height + 63) >> 6);
     if (sa->ctb_flag) w->next_alf_ctb.assign(sa->ctb_flag, sa->ctb_flag + n_ctu);
     w->next_alf.ctb_flag = nullptr;
+    return XGPU_OK;
+}
+extern "C" int xhost_writer_set_slices(xhost_writer *w, int n, const xhost_slice_desc *d)
+{
+    if (!w || n < 0 || n > XGPU_MAX_TILE_COLS * XGPU_MAX_TILE_ROWS || (n > 0 && !d)) return XGPU_ERR_INVALID_ARGUMENT;
+    w->slices.assign(d, d + n);
+    return XGPU_OK;
+}
+extern "C" int xhost_writer_set_arbitrary_slices(xhost_writer *w, int on)
+{
+    if (!w || w->headers_done) return XGPU_ERR_INVALID_ARGUMENT;      // the PPS carries arbitrary_slice_present_flag
+    w->arbitrary_slices = on != 0;
     return XGPU_OK;
 }
 extern "C" int xhost_writer_add_dra_aps(xhost_writer *w, const xhost_dra_aps *in)
@@ -3252,14 +3361,24 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
     }
     if (slice_type == XHOST_SLICE_B && st.refp[1].empty()) return XGPU_ERR_INVALID_ARGUMENT;
 
-    BitWriter bw;
-    bw.ue(0);                                            // slice_pic_parameter_set_id
     const int n_tiles = st.pps.tile_cols * st.pps.tile_rows;
-    if (n_tiles > 1) { bw.put1(0); bw.put(0, st.pps.id_bits); bw.put((uint32_t)n_tiles - 1, st.pps.id_bits); }      // one slice with every tile: first / last_tile_id
-    bw.ue((uint32_t)slice_type);
-    if (idr) bw.put1(0);                                 // no_output_of_prior_pics_flag
+    // the slices of this picture (xhost_writer_set_slices; default: one slice with every tile) and, per tile, the slice it belongs to
+    std::vector<xhost_slice_desc> slices = w->slices;
+    if (slices.empty()) { xhost_slice_desc d; d.first_tile = 0; d.last_tile = n_tiles - 1; d.slice_qp = -1; d.deblock_on = -1; slices.push_back(d); }
+    std::vector<std::vector<int>> slice_tiles(slices.size());
+    std::vector<int> tile_slice((size_t)n_tiles, -1);
+    for (size_t k = 0; k < slices.size(); k++) {
+        const int first = slices[k].first_tile, last = slices[k].last_tile, wt = st.pps.tile_cols;
+        if (first < 0 || last < first || last >= n_tiles || first % wt > last % wt) return XGPU_ERR_INVALID_ARGUMENT;      // rectangles inside the grid (no wrap-around)
+        for (int r = first / wt; r <= last / wt; r++) for (int c2 = first % wt; c2 <= last % wt; c2++) {
+            if (tile_slice[(size_t)r * wt + c2] >= 0) return XGPU_ERR_INVALID_ARGUMENT;
+            tile_slice[(size_t)r * wt + c2] = (int)k; slice_tiles[k].push_back(r * wt + c2);
+        }
+        if (slices[k].slice_qp > 51) return XGPU_ERR_INVALID_ARGUMENT;
+    }
+    for (int t = 0; t < n_tiles; t++) if (tile_slice[(size_t)t] < 0) return XGPU_ERR_INVALID_ARGUMENT;
+    if (slices.size() > 1 && !st.sps.tool_pocs) return XGPU_ERR_INVALID_ARGUMENT;      // the reference decoder counts a picture per slice NAL without poc_lsb (see the parser)
     st.sh.mmvd_group = (st.sps.tool_mmvd && slice_type != XHOST_SLICE_I) ? (w->n_pics & 1) : 0;      // every other picture with the candidate groups
-    if (st.sps.tool_mmvd && slice_type != XHOST_SLICE_I) bw.put1(st.sh.mmvd_group);
     const int w_ctu = (st.sps.width + 63) >> 6, h_ctu = (st.sps.height + 63) >> 6;
     st.alf_ctb_flag.assign((size_t)w_ctu * h_ctu, 1);
     if (st.sps.tool_alf) {
@@ -3268,34 +3387,55 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
         if (st.sh.alf_on && (!st.alf_aps[st.sh.aps_id_y].valid || !st.alf_aps[st.sh.aps_id_y].luma_present ||
                              (st.sh.alf_chroma_idc && (!st.alf_aps[st.sh.aps_id_ch].valid || !st.alf_aps[st.sh.aps_id_ch].chroma_present))))
             return XGPU_ERR_INVALID_ARGUMENT;
-        bw.put1(st.sh.alf_on);
-        if (st.sh.alf_on) {
-            bw.put((uint32_t)st.sh.aps_id_y, 5); bw.put1(st.sh.alf_ctb_map); bw.put((uint32_t)st.sh.alf_chroma_idc, 2);
-            if (st.sh.alf_chroma_idc) bw.put((uint32_t)st.sh.aps_id_ch, 5);
-        }
     } else st.sh.alf_on = 0;
-    if (!idr) {                                          // xevdm_eco.c:2658-2733
-        if (st.sps.tool_pocs) bw.put((uint32_t)st.sh.poc_lsb, st.sps.poc_lsb_bits);
-        if (st.sps.tool_rpl)
-            for (int l = 0; l < 2; l++) {
-                int hit = -1;                            // a candidate of the SPS with these entries (the index is only sent when there are at least two)
-                for (int i = 0; i < st.sps.n_rpl[l] && st.sps.n_rpl[l] > 1 && hit < 0; i++)
-                    if (st.sps.rpls[l][i].n == st.sh.rpl[l].n && !memcmp(st.sps.rpls[l][i].ref, st.sh.rpl[l].ref, sizeof(int) * (size_t)st.sh.rpl[l].n)) hit = i;
-                if (st.sps.n_rpl[l] > 0) bw.put1(hit >= 0);
-                if (hit >= 0) bw.ue((uint32_t)hit); else write_rpl(bw, st.sh.rpl[l]);
-            }
-    }
-    if (slice_type != XHOST_SLICE_I) {                   // num_ref_idx_active_override_flag (+ the list sizes, which the decoder only uses with tool_rpl)
-        bw.put1(st.sps.tool_rpl);
-        if (st.sps.tool_rpl) { bw.ue((uint32_t)st.sh.rpl[0].active - 1); if (slice_type == XHOST_SLICE_B) bw.ue((uint32_t)st.sh.rpl[1].active - 1); }
-    }
     st.sh.tmvp_assigned = st.sh.col_list = st.sh.col_src_list = st.sh.col_ref = 0;
-    if (slice_type != XHOST_SLICE_I && st.sps.tool_admvp) bw.put1(0);      // temporal_mvp_asigned_flag: the collocated picture is reference 0 of list 1 (P: list 0)
-    bw.put1(st.sh.deblock);
     st.sh.alpha_off = st.sps.tool_addb ? w->sp.deblock_alpha_offset : 0; st.sh.beta_off = st.sps.tool_addb ? w->sp.deblock_beta_offset : 0;
-    if (st.sh.deblock && st.sps.tool_addb) { bw.se(st.sh.alpha_off); bw.se(st.sh.beta_off); }
-    bw.put((uint32_t)slice_qp, 6);
-    bw.se(st.sh.qp_u_offset); bw.se(st.sh.qp_v_offset);
+    // the slice header of slice k up to the entry points (xevdm_eco_sh, src_main/xevdm_eco.c:2510-2797)
+    auto slice_header = [&](BitWriter &bw, size_t k, int qp, int deblock) {
+        bw.ue(0);                                        // slice_pic_parameter_set_id
+        if (n_tiles > 1) {
+            // single_tile_in_slice_flag stays 0 also for a slice of one tile: the reference decoder does not reset last_tile_id for such a header and computes the
+            // slice's rectangle from the PREVIOUS slice's value (set_tile_info, src_main/xevdm.c:2185-2210 after xevdm_eco_sh :2519-2538)
+            bw.put1(0); bw.put((uint32_t)slices[k].first_tile, st.pps.id_bits);
+            if (st.pps.arbitrary_slices && slice_tiles[k].size() > 1) {      // the same tiles as an ascending list (xevdm_eco.c:2540-2548)
+                bw.put1(1); bw.ue((uint32_t)slice_tiles[k].size() - 2);
+                for (size_t i = 1; i < slice_tiles[k].size(); i++) bw.ue((uint32_t)(slice_tiles[k][i] - slice_tiles[k][i - 1] - 1));
+            } else {
+                if (st.pps.arbitrary_slices) bw.put1(0);
+                bw.put((uint32_t)slices[k].last_tile, st.pps.id_bits);
+            }
+        }
+        bw.ue((uint32_t)slice_type);
+        if (idr) bw.put1(0);                             // no_output_of_prior_pics_flag
+        if (st.sps.tool_mmvd && slice_type != XHOST_SLICE_I) bw.put1(st.sh.mmvd_group);
+        if (st.sps.tool_alf) {
+            bw.put1(st.sh.alf_on);
+            if (st.sh.alf_on) {
+                bw.put((uint32_t)st.sh.aps_id_y, 5); bw.put1(st.sh.alf_ctb_map); bw.put((uint32_t)st.sh.alf_chroma_idc, 2);
+                if (st.sh.alf_chroma_idc) bw.put((uint32_t)st.sh.aps_id_ch, 5);
+            }
+        }
+        if (!idr) {                                      // xevdm_eco.c:2658-2733
+            if (st.sps.tool_pocs) bw.put((uint32_t)st.sh.poc_lsb, st.sps.poc_lsb_bits);
+            if (st.sps.tool_rpl)
+                for (int l = 0; l < 2; l++) {
+                    int hit = -1;                        // a candidate of the SPS with these entries (the index is only sent when there are at least two)
+                    for (int i = 0; i < st.sps.n_rpl[l] && st.sps.n_rpl[l] > 1 && hit < 0; i++)
+                        if (st.sps.rpls[l][i].n == st.sh.rpl[l].n && !memcmp(st.sps.rpls[l][i].ref, st.sh.rpl[l].ref, sizeof(int) * (size_t)st.sh.rpl[l].n)) hit = i;
+                    if (st.sps.n_rpl[l] > 0) bw.put1(hit >= 0);
+                    if (hit >= 0) bw.ue((uint32_t)hit); else write_rpl(bw, st.sh.rpl[l]);
+                }
+        }
+        if (slice_type != XHOST_SLICE_I) {               // num_ref_idx_active_override_flag (+ the list sizes, which the decoder only uses with tool_rpl)
+            bw.put1(st.sps.tool_rpl);
+            if (st.sps.tool_rpl) { bw.ue((uint32_t)st.sh.rpl[0].active - 1); if (slice_type == XHOST_SLICE_B) bw.ue((uint32_t)st.sh.rpl[1].active - 1); }
+        }
+        if (slice_type != XHOST_SLICE_I && st.sps.tool_admvp) bw.put1(0);      // temporal_mvp_asigned_flag: the collocated picture is reference 0 of list 1 (P: list 0)
+        bw.put1(deblock);
+        if (deblock && st.sps.tool_addb) { bw.se(st.sh.alpha_off); bw.se(st.sh.beta_off); }
+        bw.put((uint32_t)qp, 6);
+        bw.se(st.sh.qp_u_offset); bw.se(st.sh.qp_v_offset);
+    };
 
     st.pic.reset(st.sps.width, st.sps.height, st.sps.host_dmvr());
     if (!st.setup_tiles()) return XGPU_ERR_INVALID_ARGUMENT;
@@ -3324,8 +3464,10 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
     std::vector<BitWriter> tile_bits((size_t)n_tiles);
     for (int t = 0; t < n_tiles; t++) {
         const int tc = t % st.grid.n_cols, tr = t / st.grid.n_cols;
-        if (st.sps.tool_cm_init) tcd.models.reset_cm(slice_type == XHOST_SLICE_B, slice_qp); else tcd.models.reset();
-        tcd.qp_prev = slice_qp;
+        const int tile_qp = slices[(size_t)tile_slice[(size_t)t]].slice_qp >= 0 ? slices[(size_t)tile_slice[(size_t)t]].slice_qp : slice_qp;
+        st.sh.qp = tile_qp;                              // (the coder of a CU reads the slice QP of ITS slice)
+        if (st.sps.tool_cm_init) tcd.models.reset_cm(slice_type == XHOST_SLICE_B, tile_qp); else tcd.models.reset();
+        tcd.qp_prev = tile_qp;
         Enc enc;
         enc.bw = &tile_bits[(size_t)t];
         enc.start();
@@ -3342,15 +3484,23 @@ extern "C" int xhost_writer_add_picture(xhost_writer *w, int idr, int slice_type
         if (tw.error) return XGPU_ERR_INVALID_ARGUMENT;
         enc.tile_end();
         // the reference steps to a tile in 4-byte words from the word its reader stands in (xevdm.c:2665-2678): an entry offset shorter than that breaks it
-        while (t + 1 < n_tiles && tile_bits[(size_t)t].buf.size() < 8) tile_bits[(size_t)t].buf.push_back(0);
+        while (t != slice_tiles[(size_t)tile_slice[(size_t)t]].back() && tile_bits[(size_t)t].buf.size() < 8) tile_bits[(size_t)t].buf.push_back(0);
     }
-    for (int t = 0; t + 1 < n_tiles; t++) {
-        if (st.pps.offset_bits < 32 && (tile_bits[(size_t)t].buf.size() - 1) >> st.pps.offset_bits) return XGPU_ERR_UNSUPPORTED;
-        bw.put((uint32_t)tile_bits[(size_t)t].buf.size() - 1, st.pps.offset_bits);      // entry_point_offset_minus1
+    for (size_t k = 0; k < slices.size(); k++) {         // one NAL unit per slice: header, entry points of its tiles, the tiles
+        const int qp = slices[k].slice_qp >= 0 ? slices[k].slice_qp : slice_qp, deblock = slices[k].deblock_on >= 0 ? (slices[k].deblock_on != 0) : (w->sp.deblock_on ? 1 : 0);
+        st.sh.qp = qp; st.sh.deblock = deblock;          // what stays in st.sh is the LAST slice's header: the one the decoders run the in-loop filters with
+        BitWriter bw;
+        slice_header(bw, k, qp, deblock);
+        const std::vector<int> &tl = slice_tiles[k];
+        for (size_t i = 0; i + 1 < tl.size(); i++) {
+            const size_t sz = tile_bits[(size_t)tl[i]].buf.size();
+            if (st.pps.offset_bits < 32 && (sz - 1) >> st.pps.offset_bits) return XGPU_ERR_UNSUPPORTED;
+            bw.put((uint32_t)sz - 1, st.pps.offset_bits);      // entry_point_offset_minus1
+        }
+        bw.align_zero();
+        for (int t : tl) bw.buf.insert(bw.buf.end(), tile_bits[(size_t)t].buf.begin(), tile_bits[(size_t)t].buf.end());
+        write_nal(w->out, idr ? NUT_IDR : NUT_NONIDR, temporal_id, bw);
     }
-    bw.align_zero();
-    for (int t = 0; t < n_tiles; t++) bw.buf.insert(bw.buf.end(), tile_bits[(size_t)t].buf.begin(), tile_bits[(size_t)t].buf.end());
-    write_nal(w->out, idr ? NUT_IDR : NUT_NONIDR, temporal_id, bw);
     w->last_tid = temporal_id;
     std::vector<int> released;
     st.store_picture(idr != 0, released);

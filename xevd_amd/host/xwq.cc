@@ -1,5 +1,6 @@
 // xwq.cc - host work queue for multi-GPU decoding (include/xevd_wq.h): a mutex + condition variable FIFO, one worker thread per device.
 #include "../../include/xevd_wq.h"
+#include "../../include/xevd_host.h"
 
 #include <condition_variable>
 #include <cstring>
@@ -87,20 +88,25 @@ int xwq_split_gops(const uint8_t *data, size_t size, int stream, xwq_job *jobs, 
     if (!data || !jobs || max_jobs <= 0) return -101;
     int n = 0, pictures = 0;
     size_t pos = 0;
+    xhost_scan *scan = xhost_scan_open();                // picture boundaries: a picture may come as several slice NAL units
+    if (!scan) return -101;
     while (pos + 4 <= size) {
         const size_t len = ((size_t)data[pos] << 24) | ((size_t)data[pos + 1] << 16) | ((size_t)data[pos + 2] << 8) | data[pos + 3];
-        if (len < 2 || pos + 4 + len > size) return -202;
+        if (len < 2 || pos + 4 + len > size) { xhost_scan_close(scan); return -202; }
         const int t = nal_type(data + pos + 4);
-        if (t == NUT_IDR) {
-            if (n == max_jobs) return -203;          // more units than the caller's array holds: nothing is dropped silently - grow and call again
+        const int kind = xhost_scan_nal(scan, data + pos + 4, len);      // 1: first slice of a picture, 2: a further slice
+        if (kind < 0) { xhost_scan_close(scan); return -202; }
+        if (t == NUT_IDR && kind == 1) {
+            if (n == max_jobs) { xhost_scan_close(scan); return -203; }          // more units than the caller's array holds: nothing is dropped silently - grow and call again
             if (n) jobs[n - 1].size = pos - jobs[n - 1].offset;
             memset(&jobs[n], 0, sizeof(jobs[n]));
             jobs[n].stream = stream; jobs[n].unit = n; jobs[n].offset = pos; jobs[n].first_picture = pictures;
             n++;
         }
-        if ((t == NUT_IDR || t == NUT_NONIDR) && n) { jobs[n - 1].n_pictures++; pictures++; }
+        if (kind == 1 && n) { jobs[n - 1].n_pictures++; pictures++; }
         pos += 4 + len;
     }
+    xhost_scan_close(scan);
     if (n) jobs[n - 1].size = pos - jobs[n - 1].offset;
     return n;
 }

@@ -37,6 +37,10 @@ class SliceAlf(C.Structure):
                 ("ctb_flag", C.POINTER(C.c_uint8))]
 
 
+class SliceDesc(C.Structure):
+    _fields_ = [("first_tile", C.c_int), ("last_tile", C.c_int), ("slice_qp", C.c_int), ("deblock_on", C.c_int)]
+
+
 class DraAps(C.Structure):
     _fields_ = [("aps_id", C.c_int), ("num_ranges", C.c_int), ("in_ranges", C.c_int * 33), ("scale", C.c_int * 32), ("cb_scale", C.c_int),
                 ("cr_scale", C.c_int), ("table_idx", C.c_int)]
@@ -85,6 +89,8 @@ def load():
         lib.xhost_writer_add_dra_aps.argtypes = [C.c_void_p, C.POINTER(DraAps)]
         lib.xhost_writer_add_md5_sei.argtypes = [C.c_void_p, C.c_void_p]
         lib.xhost_writer_set_slice_alf.argtypes = [C.c_void_p, C.POINTER(SliceAlf)]
+        lib.xhost_writer_set_slices.argtypes = [C.c_void_p, C.c_int, C.POINTER(SliceDesc)]
+        lib.xhost_writer_set_arbitrary_slices.argtypes = [C.c_void_p, C.c_int]
         _lib = lib
     return _lib
 
@@ -187,6 +193,22 @@ class StreamWriter:
         rc = self.lib.xhost_writer_set_slice_alf(self.h, C.byref(sa))
         if rc != 0:
             raise RuntimeError(f"xhost_writer_set_slice_alf -> {rc}")
+
+    def set_arbitrary_slices(self, on=True):
+        rc = self.lib.xhost_writer_set_arbitrary_slices(self.h, int(on))
+        if rc != 0:
+            raise RuntimeError(f"xhost_writer_set_arbitrary_slices -> {rc}")
+
+    def set_slices(self, slices):
+        """the following pictures as len(slices) slice NAL units: (first_tile, last_tile[, slice_qp[, deblock_on]]) per slice, tile rectangles that
+        partition the PPS's grid; -1 / missing = what add_picture / the stream parameters say.  [] = one slice with every tile"""
+        arr = (SliceDesc * max(len(slices), 1))()
+        for i, sd in enumerate(slices):
+            sd = tuple(sd) + (-1,) * (4 - len(sd))
+            arr[i] = SliceDesc(int(sd[0]), int(sd[1]), int(sd[2]), int(sd[3]))
+        rc = self.lib.xhost_writer_set_slices(self.h, len(slices), arr)
+        if rc != 0:
+            raise RuntimeError(f"xhost_writer_set_slices -> {rc}")
 
     def add_md5_sei(self, planes):
         """picture-signature SEI for the picture added last; planes = its decoded [Y, U, V] (the MD5 runs over 16-bit LE samples)"""
