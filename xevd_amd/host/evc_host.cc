@@ -2422,7 +2422,8 @@ struct xhost_parser {
         }
         q.id_bits = (int)br.ue() + 1;                    // tile_id_len_minus1
         if (q.id_bits > 15) return fail("bad PPS: tile_id_len_minus1");
-        if (br.get1()) return fail("explicit tile ids are not supported");
+        if (br.get1())                                   // explicit_tile_id_flag: tile_id_val[row][col] (xevdm_eco.c:2042-2052).  The reference decoder reads the values and never
+            for (int i = 0; i < q.tile_cols * q.tile_rows; i++) br.get(q.id_bits);      // looks at them again - first / last_tile_id stay raster indices (set_tile_info) - so neither do we
         q.dra_on = br.get1();                       // pic_dra_enabled_flag, pic_dra_aps_id (xevdm_eco.c:2054-2060)
         if (q.dra_on) q.dra_aps_id = (int)br.get(5);
         q.arbitrary_slices = br.get1();                  // arbitrary_slice_present_flag
