@@ -37,7 +37,7 @@
 #define MAX_GOPS 4096
 #define CHECK(call) do { int rc_ = (call); if (rc_ < 0) { fprintf(stderr, "%s -> %d (%s)\n", #call, rc_, w->g ? xgpu_last_error(w->g) : ""); return rc_; } } while (0)
 static double now_s(void);
-static int g_build_threads = 4;     /* --build-threads B: host threads xgpu_batch_create spreads its per-CU passes over */
+static int g_build_threads = 8;     /* --build-threads B: host threads xgpu_batch_create spreads its per-CU passes over */
 
 typedef struct { int poc, pic, in_use; } slot_t;                 /* DPB: POC -> device picture slot */
 typedef struct { int epoch, poc; size_t off; } out_t;              /* one output picture: position in the unit's buffer */

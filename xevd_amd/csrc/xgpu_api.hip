@@ -443,7 +443,7 @@ int xgpu_frame_end(xgpu_ctx *c)
 // sets COD CU by CU, xevd.c:744-754; xevd_get_avail_intra, xevd_util.c:689-745; single tile/slice).  The list is sorted by
 // level (1 + the highest level among the intra CUs read), which is a topological order: every dependency sits earlier.
 struct IntraPlan { std::vector<IntraRec> recs; std::vector<uint32_t> deps; int n_levels, n_level1; bool has_ibc, has_htdf; };
-static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &plan)
+static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &plan, const uint32_t *final_owner, int nthr)
 {
     // HTDF (xevdm.c:1381-1392 with xevdm_htdf_skip_condition, xevdm_recon.c:270-297): which CUs are filtered right after their reconstruction, and with
     // which of the five tables.  Such a CU - inter ones included - reads the final samples of the CUs before it and is read by the ones after it:
@@ -463,10 +463,19 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     const uint32_t NONE = 0xFFFFFFFFu;
     // scratch of the builder thread, kept between pictures: an 8 MB vector per 8K picture allocated and freed every call goes through mmap / munmap, and the
     // munmap's TLB shootdown reaches every thread of the process - the parser's tile threads among them (examples/evc_decode.c runs them next to this one)
-    static thread_local std::vector<uint32_t> owner;
+    // Batches without local dual trees (everything but BTT + ADMVP streams) take the FINAL SCU -> CU map the caller has already painted (in parallel, for k_inter):
+    // "reconstructed before CU i" is then "owner index below i", no painting in step with the loop, and the nodes are independent of each other - built on the
+    // builder's threads, levels assigned afterwards.  (At 8K this function was 11 of the builder's 15 ms, whatever the thread count.)
+    const bool fast = final_owner != NULL && b->tree == NULL;
+    static const bool pt_on = getenv("XEVD_HIP_BUILD_TRACE") != NULL;
+    auto pt_t0 = std::chrono::steady_clock::now();
+    auto PT = [&](const char *what) { if (pt_on) { const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "    intra plan: %-12s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - pt_t0).count()); pt_t0 = t; } };
+    static thread_local std::vector<uint32_t> owner_own;
     static thread_local std::vector<int> level;
-    owner.assign((size_t)ws * hs, NONE);
+    if (!fast) owner_own.assign((size_t)ws * hs, NONE);
+    const uint32_t *const owner = fast ? final_owner : owner_own.data();
     level.assign((size_t)n, 0);
+    int *const level_p = level.data();
     // painted CU by CU as the loop below reaches them ("reconstructed before CU i" = painted): inside a local dual tree the node's chroma-only CU follows its
     // luma CUs and covers them again
     // constrained intra prediction inside local dual trees: "is the neighbour intra-coded" is a property of the LUMA CU over the SCU (map_scu is written by the
@@ -476,7 +485,7 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     if (constrained_tree) luma_owner.assign((size_t)ws * hs, NONE);
     auto paint = [&](int i) {
         const int xs = b->x[i] >> 2, ys = b->y[i] >> 2, w = (1 << b->log2w[i]) >> 2, h = (1 << b->log2h[i]) >> 2;
-        for (int r = 0; r < h; r++) std::fill_n(owner.begin() + (size_t)(ys + r) * ws + xs, w, (uint32_t)i);
+        for (int r = 0; r < h; r++) std::fill_n(owner_own.begin() + (size_t)(ys + r) * ws + xs, w, (uint32_t)i);
         if (constrained_tree && b->tree[i] != 2)
             for (int r = 0; r < h; r++) std::fill_n(luma_owner.begin() + (size_t)(ys + r) * ws + xs, w, (uint32_t)i);
     };
@@ -494,8 +503,9 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     std::vector<IntraRec> recs;                 // decode order; dep lists hold CU indices until the sort below
     std::vector<uint32_t> deps;
     int max_level = 0;
-    for (int i = 0; i < n; paint(i), i++) {
-        if (!ordered((uint32_t)i)) continue;
+    // one CU: 0 = not a node, 1 = node appended to recs / deps (lv_out = its level when the levels of its dependencies are known: sequential mode), -1 = invalid batch
+    auto make_node = [&](const int i, std::vector<IntraRec> &recs, std::vector<uint32_t> &deps, bool &has_ibc, bool &has_htdf, int &lv_out) -> int {
+        if (!ordered((uint32_t)i)) return 0;
         const int xs = b->x[i] >> 2, ys = b->y[i] >> 2, units = ((1 << b->log2w[i]) + (1 << b->log2h[i])) >> 2;
         IntraRec r;
         memset(&r, 0, sizeof(r));
@@ -521,7 +531,7 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
                     for (size_t d = r.dep_first; d < deps.size() && !seen; d++) seen = deps[d] == j;
                     if (!seen) deps.push_back(j);
                 }
-                lv = std::max(lv, level[j]);
+                lv = std::max(lv, level_p[j]);
             };
             uint32_t av = 0;
             if (xs > 0 && cod(xs - 1, ys)) {
@@ -552,14 +562,13 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
             // an inter CU that is only here for its filter: k_inter / k_affine have reconstructed it, the node filters it in place
             r.cbf = 0; r.ipm[0] = r.ipm[1] = 0;
             r.flags = 8u;
-            if (!add_htdf(r)) return false;
+            if (!add_htdf(r)) return -1;
             r.dep_count = (uint32_t)deps.size() - r.dep_first;
-            level[i] = lv + 1;
-            max_level = std::max(max_level, lv + 1);
+            lv_out = lv + 1;
             recs.push_back(r);
-            plan.has_ibc = true;                 // the instantiation with the extra node kinds
-            plan.has_htdf = true;
-            continue;
+            has_ibc = true;                      // the instantiation with the extra node kinds
+            has_htdf = true;
+            return 1;
         }
         if (b->pred_mode[i] == XGPU_MODE_IBC) {
             // intra block copy: the CU waits for the intra / IBC CUs under its source block - the luma block at the vector plus, for an odd
@@ -571,21 +580,20 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
             for (int sy = y0 >> 2; sy <= y1 >> 2; sy++)
                 for (int sx = x0 >> 2; sx <= x1 >> 2; sx++) {
                     const uint32_t j = owner[(size_t)sy * ws + sx];
-                    if (j >= (uint32_t)i) return false;
+                    if (j >= (uint32_t)i) return -1;
                     if (ordered(j) && j != last) {
                         bool seen = false;
                         for (size_t d = r.dep_first; d < deps.size() && !seen; d++) seen = deps[d] == j;
                         if (!seen) deps.push_back(j);
                         last = j;
                     }
-                    lv = std::max(lv, level[j]);
+                    lv = std::max(lv, level_p[j]);
                 }
             r.dep_count = (uint32_t)deps.size() - r.dep_first;
-            level[i] = lv + 1;
-            max_level = std::max(max_level, lv + 1);
+            lv_out = lv + 1;
             recs.push_back(r);
-            plan.has_ibc = true;
-            continue;
+            has_ibc = true;
+            return 1;
         }
         // which neighbour units the CU's predictors actually read (xevd_ipred.c:96-164,587-622): only those create a dependency;
         // the others are still fetched by the kernel (availability is about COD flags, not about use) but their values are ignored
@@ -614,7 +622,7 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
                     if (!seen) deps.push_back(j);
                     last = j;
                 }
-                lv = std::max(lv, level[j]);
+                lv = std::max(lv, level_p[j]);
             }
         }
         bool used = true;
@@ -631,7 +639,7 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
                 if (!seen) deps.push_back(j);
                 last = j;
             }
-            lv = std::max(lv, level[j]);
+            lv = std::max(lv, level_p[j]);
             return true;
         };
         used = need_ul;
@@ -644,12 +652,51 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
             used = k < need_le;
             if (xs > 0 && ys + k < hs && ok(xs - 1, ys + k)) r.le |= 1ull << k;
         }
-        if (hidx >= 0) { used = true; if (!add_htdf(r)) return false; plan.has_htdf = true; plan.has_ibc = true; }
+        if (hidx >= 0) { used = true; if (!add_htdf(r)) return -1; has_htdf = true; has_ibc = true; }
         r.dep_count = (uint32_t)deps.size() - r.dep_first;
-        level[i] = lv + 1;
-        max_level = std::max(max_level, lv + 1);
+        lv_out = lv + 1;
         recs.push_back(r);
+        return 1;
+    };
+    PT("setup");
+    if (!fast) {
+        for (int i = 0; i < n; paint(i), i++) {
+            int lv = 0;
+            const int rc = make_node(i, recs, deps, plan.has_ibc, plan.has_htdf, lv);
+            if (rc < 0) return false;
+            if (rc) { level[(size_t)i] = lv; max_level = std::max(max_level, lv); }
+        }
+    } else {
+        const int K = std::max(1, std::min(nthr, std::max(1, n / 4096)));
+        struct Out { std::vector<IntraRec> recs; std::vector<uint32_t> deps; bool ibc = false, htdf = false, bad = false; };
+        std::vector<Out> outs((size_t)K);
+        auto work = [&](int k) {
+            Out &o = outs[(size_t)k];
+            int lv = 0;
+            for (int i = (int)((long long)n * k / K), i1 = (int)((long long)n * (k + 1) / K); i < i1 && !o.bad; i++) o.bad = make_node(i, o.recs, o.deps, o.ibc, o.htdf, lv) < 0;
+        };
+        std::vector<std::thread> th;
+        for (int k = 1; k < K; k++) th.emplace_back(work, k);
+        work(0);
+        for (std::thread &t : th) t.join();
+        PT("nodes");
+        size_t nr = 0, nd = 0;
+        for (const Out &o : outs) { if (o.bad) return false; nr += o.recs.size(); nd += o.deps.size(); plan.has_ibc |= o.ibc; plan.has_htdf |= o.htdf; }
+        recs.reserve(nr); deps.reserve(nd);
+        for (Out &o : outs) {
+            const uint32_t base = (uint32_t)deps.size();
+            for (IntraRec &r : o.recs) { r.dep_first += base; recs.push_back(r); }
+            deps.insert(deps.end(), o.deps.begin(), o.deps.end());
+        }
+        // levels, in decoding order: 1 + the highest level among the nodes read (CUs that are no nodes - complete before the intra kernels start - count as level 0)
+        for (const IntraRec &r : recs) {
+            int lv = 0;
+            for (uint32_t d = r.dep_first; d < r.dep_first + r.dep_count; d++) lv = std::max(lv, level[deps[d]]);
+            level[r.cu] = lv + 1;
+            max_level = std::max(max_level, lv + 1);
+        }
     }
+    PT("levels");
     // sort by level (levels are 1-based; every dependency sits on a lower one), the larger CUs of a level first - a 64x64 CU is four rounds of its wave and should
     // not be the last thing a launch starts -, decode order otherwise; then dependency CU indices -> list positions
     auto key = [&](const IntraRec &r) { return (size_t)level[r.cu] * 16 + (size_t)(14 - (r.log2w + r.log2h)); };      // counting sort: log2w + log2h is 4 .. 14
@@ -665,6 +712,7 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     plan.n_levels = max_level;
     plan.n_level1 = 0;
     for (const IntraRec &r : plan.recs) plan.n_level1 += level[r.cu] == 1;
+    PT("sort");
     // level-1 CUs are finished by their own launch before the data-flow launch starts: drop them from the waiting lists
     for (IntraRec &r : plan.recs) {
         uint32_t k = r.dep_first;
@@ -707,6 +755,9 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     HIPCHK(c, hipSetDevice(c->sp.device));
     const int n = b->n_cu;
     const int bdoff = 6 * (c->sp.bit_depth_luma - 8);
+    static const bool bt_on = getenv("XEVD_HIP_BUILD_TRACE") != NULL;      // phase times of the builder on stderr
+    auto bt_t0 = std::chrono::steady_clock::now();
+    auto BT = [&](const char *what) { if (bt_on) { const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  batch build: %-14s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - bt_t0).count()); bt_t0 = t; } };
 
     // pass 1: validate + count TBs per size class
     // size class = (log2w, log2h) x (vertical, horizontal) transform kind; ATS kinds only occur for intra luma TBs
@@ -826,6 +877,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         for (const char *m : bad)
             if (m) { snprintf(c->err, sizeof(c->err), "%s: invalid argument: %s", __FILE__, m); return XGPU_ERR_INVALID_ARGUMENT; }
     }
+    BT("pass 1");
     int cls_count[NCLS] = { 0 }, n_aff = 0, n_aff_eif = 0, n_aff_sub = 0, n_dmvr = 0;
     for (const Part &P : parts) { for (int k = 0; k < NCLS; k++) cls_count[k] += P.cls[k]; n_aff += P.n_aff; n_aff_eif += P.n_eif; n_aff_sub += P.n_sub; n_dmvr += P.n_dmvr; }
     int cls_first[NCLS], n_tb = 0, n_waves = 0;
@@ -838,9 +890,29 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     plan.n_levels = 0; plan.n_level1 = 0;
     bool any_intra = false;
     plan.has_ibc = false; plan.has_htdf = false;
+    // SCU -> CU map of the picture (k_inter's lanes find their CU through it; the dependency plan reads "reconstructed before" off it); SCUs outside the batch -
+    // another tile's - stay unowned.  Painted in ordinary memory (short row fills) and copied into the pinned block in one piece further down
+    static thread_local std::vector<uint32_t> own;
+    {
+        own.resize((size_t)c->w_scu * c->h_scu);
+        size_t covered = 0;
+        for (int i = 0; i < n; i++) if (!(b->tree && b->tree[i] == 2)) covered += (size_t)1 << (b->log2w[i] + b->log2h[i] - 4);
+        if (covered != own.size()) std::fill(own.begin(), own.end(), 0xFFFFFFFFu);
+        uint32_t *const own_p = own.data();                     // (`own` is thread_local: inside another thread the NAME would mean that thread's empty vector)
+        run_parts([&, own_p](int, int i0, int i1) {             // CUs do not overlap: the ranges paint disjoint SCUs
+            for (int i = i0; i < i1; i++) {
+                if (b->tree && b->tree[i] == 2) continue;           // the SCU maps of a dual-tree block belong to its luma CUs
+                const int ws = (1 << b->log2w[i]) >> 2, hh = (1 << b->log2h[i]) >> 2;
+                uint32_t *o = own_p + (size_t)(b->y[i] >> 2) * c->w_scu + (b->x[i] >> 2);
+                for (int r = 0; r < hh; r++, o += c->w_scu) std::fill_n(o, ws, (uint32_t)i);
+            }
+        });
+    }
+    BT("owner map");
     for (int i = 0; i < n && !any_intra; i++) any_intra = b->pred_mode[i] == XGPU_MODE_INTRA || b->pred_mode[i] == XGPU_MODE_IBC || (b->htdf_slice_qp > 17 && (b->cbf[i] & 1));
-    if (any_intra) ARGCHK(c, build_intra_plan(c, b, plan));      // false: an IBC source block that is not reconstructed before its CU
+    if (any_intra) ARGCHK(c, build_intra_plan(c, b, plan, own.data(), nthr));      // false: an IBC source block that is not reconstructed before its CU
     const int n_intra = (int)plan.recs.size(), n_deps = (int)plan.deps.size();
+    BT("intra plan");
 
     xgpu_dbatch *db = new xgpu_dbatch();
     memset(db, 0, sizeof(*db));
@@ -895,6 +967,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
             if (hipEventCreateWithFlags(&db->blk.itdq_done, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
         }
     }
+    BT("block");
     db->h_stage = db->blk.h_stage;
     uint8_t *hs = (uint8_t *)db->h_stage;
     CuRec *cus = (CuRec *)(hs + o_cus);
@@ -904,25 +977,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     AffItem *aff_items = (AffItem *)(hs + o_aff);
     int16_t *cpmv = (int16_t *)(hs + o_cpmv);
     DmvrItem *dmvr_items = (DmvrItem *)(hs + o_dmvr);
-    // SCU -> CU map of the picture (k_inter's lanes find their CU through it); SCUs outside the batch - another tile's - stay unowned.  Painted in
-    // ordinary memory (short row fills) and copied into the pinned block in one piece
-    {
-        static thread_local std::vector<uint32_t> own;
-        own.resize((size_t)c->w_scu * c->h_scu);
-        size_t covered = 0;
-        for (int i = 0; i < n; i++) if (!(b->tree && b->tree[i] == 2)) covered += (size_t)1 << (b->log2w[i] + b->log2h[i] - 4);
-        if (covered != own.size()) std::fill(own.begin(), own.end(), 0xFFFFFFFFu);
-        uint32_t *const own_p = own.data();                     // (`own` is thread_local: inside another thread the NAME would mean that thread's empty vector)
-        run_parts([&, own_p](int, int i0, int i1) {             // CUs do not overlap: the ranges paint disjoint SCUs
-            for (int i = i0; i < i1; i++) {
-                if (b->tree && b->tree[i] == 2) continue;           // the SCU maps of a dual-tree block belong to its luma CUs
-                const int ws = (1 << b->log2w[i]) >> 2, hh = (1 << b->log2h[i]) >> 2;
-                uint32_t *o = own_p + (size_t)(b->y[i] >> 2) * c->w_scu + (b->x[i] >> 2);
-                for (int r = 0; r < hh; r++, o += c->w_scu) std::fill_n(o, ws, (uint32_t)i);
-            }
-        });
-        memcpy(hs + o_own, own.data(), sz_own);
-    }
+    memcpy(hs + o_own, own.data(), sz_own);
 
     // pass 2: records + TB scatter into class order; every thread starts where the ranges before it end in each list
     run_parts([&](int part, int i0, int i1) {
@@ -1025,12 +1080,14 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     db->d_coef = (int16_t *)(dbase + o_coef); db->d_resid = (int16_t *)(dbase + o_resid); db->d_intra_done = (uint32_t *)(dbase + o_done);
     // one copy: the staging block has the device layout (a pinned coefficient arena goes from the caller's buffer).  On the upload stream: the
     // copy overlaps the kernels of the pictures before; xgpu_batch_recon makes the kernel stream wait for `uploaded`
+    BT("stage filled");
     hipError_t e = hipMemcpyAsync(dbase, hs, coef_pinned ? o_coef : db->stage_bytes, hipMemcpyHostToDevice, c->up_stream);
     if (e == hipSuccess && coef_pinned) e = hipMemcpyAsync(dbase + o_coef, b->coef, sizeof(int16_t) * b->n_coef, hipMemcpyHostToDevice, c->up_stream);
     if (e == hipSuccess) e = hipMemsetAsync(db->d_intra_done, 0, sz_done, c->up_stream);
     if (e == hipSuccess) e = hipMemsetAsync(db->d_resid, 0, sz_coef, c->up_stream);
     if (e == hipSuccess) e = hipEventRecord(db->blk.uploaded, c->up_stream);
     if (e != hipSuccess) { snprintf(c->err, sizeof(c->err), "batch upload: %s", hipGetErrorString(e)); return fail(XGPU_ERR_UNEXPECTED); }
+    BT("uploads queued");
     *out = db;
     return XGPU_OK;
 }
