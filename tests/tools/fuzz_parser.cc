@@ -1,5 +1,5 @@
 // Parser fuzz (development tool): mutated .evc streams (bit flips, overwritten bytes, truncations, garbage runs) through xhost_parser, for sanitizer builds:
-//   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize=shift-base -pthread -o fuzz tests/tools/fuzz_parser.cc xevd_amd/host/evc_host.cc xevd_amd/host/xwq.cc
+//   g++ -O1 -g -std=c++17 -fsanitize=address,undefined -fno-sanitize=shift-base -pthread -o fuzz tests/tools/fuzz_parser.cc xevd_amd/host/evc_parser.cc xevd_amd/host/evc_writer.cc xevd_amd/host/xwq.cc
 //   g++ -O1 -g -std=c++17 -fsanitize=thread -pthread -o fuzz_tsan ...        (tile streams with threads > 1: the tiles of a picture parse in parallel)
 //   ./fuzz <mutations per stream> <parser threads> a.evc b.evc ...             (golden streams: np.load(tests/golden/stream_*.npz)["bytes"])
 // Round 2: 8250 mutations of the 55 golden streams under ASan + UBSan and the tiled ones under TSan with 4 threads - clean after the tile test was moved in
