@@ -572,7 +572,8 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 // work items fill the machine under the chain: workgroups [0, n_intra_wg) run intra_body (tickets order them, whatever the dispatcher does), the rest
 // one residual work item each.  256 threads: the residual pass's workgroup shape; four CUs in flight per intra workgroup (18.6 KB of LDS either way).
 // Measured at 8K (profiles/round3_*): 45 us + 39 us as two launches (43 + 55 when the residual pass ran beside the level-1 launch on a second stream,
-// with two cross-stream event waits of 6 us each), [see DESIGN 5] as one.
+// with two cross-stream event waits of 6 us each), 64 us as one.  (Letting the level-1 launch carry a share of the work items too - it is 23 us of memory latency
+// as well - measured nothing at 25 % and 1 - 3 % slower at 35 - 70 %: that launch is short and dense enough to be slowed down by the company.)
 #define FUSED_WAVES 4
 template <bool EIPD, bool IBC>
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_intra_itdq(const IntraArgs a, const ItdqArgs r, uint32_t n_intra_wg)
