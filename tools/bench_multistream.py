@@ -49,18 +49,34 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--profile", default="base", choices=["base", "main"])
+    ap.add_argument("--processes", action="store_true", help="one evc_decode PROCESS per stream instead of one worker thread per stream in one process (own HIP runtime each)")
     args = ap.parse_args()
     exe = os.path.join(ROOT, "examples", "evc_decode")
     is_main = args.profile == "main"
     pics = args.pics if not is_main else (args.pics + 24) // 25 * 25
     data = [write_stream(args.width, args.height, pics, 100 + i, is_main) for i in range(4)]      # 4 distinct streams, reused round-robin
     out = {"stream": f"{'Main random-access (hierarchical B, admvp, IQT, ADDB, ALF) 10-bit' if is_main else 'Baseline 8-bit IPPP'} {args.width}x{args.height}, {pics} pictures per stream, "
-                     f"{len(data[0])} bytes", "host_cores": os.cpu_count(), "decoder": "examples/evc_decode (C): one worker = parser thread + device thread + xgpu context per stream",
+                     f"{len(data[0])} bytes", "host_cores": os.cpu_count(), "decoder": "examples/evc_decode (C): one worker = parser thread + device thread + xgpu context per stream" + (", one PROCESS per stream" if args.processes else ", all workers in one process"),
            "pictures_per_s": {}}
     with tempfile.TemporaryDirectory() as td:
         for i, d in enumerate(data):
             open(os.path.join(td, f"s{i}.evc"), "wb").write(d)
         for k in [int(v) for v in args.streams.split(",")]:
+            if args.processes:
+                import time
+                t0 = time.perf_counter()
+                ps = [subprocess.Popen([exe, "--workers", "1", os.path.join(td, f"s{i % len(data)}.evc"), os.path.join(td, f"o{i}.yuv")], stderr=subprocess.PIPE) for i in range(k)]
+                errs = [p.communicate()[1].decode() for p in ps]
+                wall = time.perf_counter() - t0
+                if any(p.returncode != 0 for p in ps):
+                    out["pictures_per_s"][str(k)] = "error: " + errs[0][-200:]
+                    continue
+                # every process reports its own decode-only span; the aggregate is K streams over the slowest of them (they run side by side)
+                spans = [float(e.split("slowest worker)")[1].split("s,")[0]) for e in errs]
+                out["pictures_per_s"][str(k)] = {"decode_only": round(k * pics / max(spans), 2), "wall_incl_start_up": round(k * pics / wall, 2)}
+                for i in range(k):
+                    os.remove(os.path.join(td, f"o{i}.yuv"))
+                continue
             cmd = [exe, "--workers", str(k)]
             for i in range(k):
                 cmd += [os.path.join(td, f"s{i % len(data)}.evc"), os.path.join(td, f"o{i}.yuv")]
