@@ -395,7 +395,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
                 const int16_t *src = a.cur_y + syl * a.s_l + (sxl - ol_);
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const uint32_t d0 = ldw(src + r * a.s_l), d1 = ldw(src + r * a.s_l + 2), d2 = ol_ ? ldw(src + r * a.s_l + 4) : 0u;
+                    const uint32_t d0 = ldw(src + r * a.s_l), d1 = ldw(src + r * a.s_l + 2), d2 = ldw(src + r * a.s_l + 4);      // (the third dword is only used for an odd vector; loading it unconditionally keeps the four rows' loads in flight together - it lies inside the padded picture)
                     const uint32_t o0 = ol_ ? (d0 >> 16) | (d1 << 16) : d0, o1 = ol_ ? (d1 >> 16) | (d2 << 16) : d1;
                     pl[r][0] = (int)(o0 & 0xFFFF); pl[r][1] = (int)(o0 >> 16); pl[r][2] = (int)(o1 & 0xFFFF); pl[r][3] = (int)(o1 >> 16);
                 }
@@ -405,7 +405,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
                     const int16_t *sc = (c == 0 ? a.cur_u : a.cur_v) + syc * a.s_c + (sxc - oc_);
 #pragma unroll
                     for (int r = 0; r < 2; r++) {
-                        const uint32_t d0 = ldw(sc + r * a.s_c), d1 = oc_ ? ldw(sc + r * a.s_c + 2) : 0u;
+                        const uint32_t d0 = ldw(sc + r * a.s_c), d1 = ldw(sc + r * a.s_c + 2);
                         const uint32_t o0 = oc_ ? (d0 >> 16) | (d1 << 16) : d0;
                         pc[c][r][0] = (int)(o0 & 0xFFFF); pc[c][r][1] = (int)(o0 >> 16);
                     }
@@ -489,31 +489,47 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
             int16_t *org = a.cur_y + cu_y * a.s_l + cu_x;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the wave's own stores of the prediction pass
             auto ldw = [&](const int16_t *p) -> uint32_t { return DEP ? ld_coherent(p) : *(const uint32_t *)p; };
-            auto ld1s = [&](const int16_t *p) -> int {
-                const uintptr_t q = (uintptr_t)p;
-                const uint32_t d = ldw((const int16_t *)(q & ~(uintptr_t)3));
-                return (int)((q & 2) ? d >> 16 : d & 0xFFFFu);
-            };
             if (t < 16) s_lut[wv][t] = k_htdf_tbl[tidx][t];
-            for (int i = t; i < (cw >> 1) * chh; i += 64) {
-                const int r = i >> (lw - 1), c = (i & ((cw >> 1) - 1)) << 1;
-                const uint32_t d = ldw(org + r * a.s_l + c);
-                tb[(r + 1) * we + c + 1] = (int16_t)(d & 0xFFFF); tb[(r + 1) * we + c + 2] = (int16_t)(d >> 16);
+            // Every global load of the stage is issued before the first LDS store that needs one: the loop this replaces waited for each round of 64 dwords before it
+            // asked for the next one - a 32x32 block was eight memory round trips (~2 us each for the coherent loads of the data-flow launch), the border four more,
+            // which is what a level of the HTDF workload cost (15 us; 26 levels at 8K).  A filtered CU is at most 64 samples wide and high: one lane per border sample.
+            auto ldr = [&](const int16_t *p) -> uint32_t { return ldw((const int16_t *)((uintptr_t)p & ~(uintptr_t)3)); };      // the dword that holds the sample
+            auto pick = [&](const int16_t *p, uint32_t d) -> int16_t { return (int16_t)(((uintptr_t)p & 2) ? d >> 16 : d & 0xFFFFu); };
+            const int16_t *p_l = nullptr, *p_r = nullptr, *p_u = nullptr, *p_d = nullptr, *p_c = nullptr;
+            uint32_t d_l = 0, d_r = 0, d_u = 0, d_d = 0, d_c = 0;
+            if (t < chh) {
+                const bool ok_l = ((av >> 1) & 1) && (!cmask || ((avail_le_raw >> (t >> 2)) & 1));
+                p_l = org + t * a.s_l + (ok_l ? -1 : 0); p_r = org + t * a.s_l + (((av >> 3) & 1) ? cw : cw - 1);
+                d_l = ldr(p_l); d_r = ldr(p_r);
             }
-            for (int i = t; i < chh; i += 64) {
-                const bool ok_l = ((av >> 1) & 1) && (!cmask || ((avail_le_raw >> (i >> 2)) & 1));
-                tb[(i + 1) * we] = (int16_t)ld1s(org + i * a.s_l + (ok_l ? -1 : 0));
-                tb[(i + 1) * we + we - 1] = (int16_t)ld1s(org + i * a.s_l + (((av >> 3) & 1) ? cw : cw - 1));
+            if (t < cw) {
+                const bool ok_u = (av & 1) && (!cmask || ((avail_up >> (t >> 2)) & 1));
+                p_u = org + t - (ok_u ? a.s_l : 0); p_d = org + (chh - 1) * a.s_l + t;
+                d_u = ldr(p_u); d_d = ldr(p_d);
             }
-            for (int i = t; i < cw; i += 64) {
-                const bool ok_u = (av & 1) && (!cmask || ((avail_up >> (i >> 2)) & 1));
-                tb[i + 1] = (int16_t)ld1s(org + i - (ok_u ? a.s_l : 0));
-                tb[(he - 1) * we + i + 1] = (int16_t)ld1s(org + (chh - 1) * a.s_l + i);
+            if (t < 4) {
+                p_c = t == 0 ? (((av >> 5) & 1) ? org - 1 - a.s_l : org) : t == 1 ? (((av >> 6) & 1) ? org + cw - a.s_l : org + cw - 1)
+                    : t == 2 ? (((av >> 7) & 1) ? org - 1 + chh * a.s_l : org + (chh - 1) * a.s_l) : (((av >> 8) & 1) ? org + cw + chh * a.s_l : org + cw - 1 + (chh - 1) * a.s_l);
+                d_c = ldr(p_c);
             }
-            if (t == 0) tb[0] = (int16_t)ld1s(((av >> 5) & 1) ? org - 1 - a.s_l : org);
-            if (t == 1) tb[we - 1] = (int16_t)ld1s(((av >> 6) & 1) ? org + cw - a.s_l : org + cw - 1);
-            if (t == 2) tb[we * (he - 1)] = (int16_t)ld1s(((av >> 7) & 1) ? org - 1 + chh * a.s_l : org + (chh - 1) * a.s_l);
-            if (t == 3) tb[we - 1 + we * (he - 1)] = (int16_t)ld1s(((av >> 8) & 1) ? org + cw + chh * a.s_l : org + cw - 1 + (chh - 1) * a.s_l);
+            const int n2 = (cw >> 1) * chh;
+            for (int i0 = 0; i0 < n2; i0 += 64 * 8) {
+                uint32_t d[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int i = i0 + q * 64 + t;
+                    d[q] = 0;
+                    if (i < n2) d[q] = ldw(org + (i >> (lw - 1)) * a.s_l + ((i & ((cw >> 1) - 1)) << 1));
+                }
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int i = i0 + q * 64 + t, r = i >> (lw - 1), c = (i & ((cw >> 1) - 1)) << 1;
+                    if (i < n2) { tb[(r + 1) * we + c + 1] = (int16_t)(d[q] & 0xFFFF); tb[(r + 1) * we + c + 2] = (int16_t)(d[q] >> 16); }
+                }
+            }
+            if (t < chh) { tb[(t + 1) * we] = pick(p_l, d_l); tb[(t + 1) * we + we - 1] = pick(p_r, d_r); }
+            if (t < cw) { tb[t + 1] = pick(p_u, d_u); tb[(he - 1) * we + t + 1] = pick(p_d, d_d); }
+            if (t < 4) tb[t == 0 ? 0 : t == 1 ? we - 1 : t == 2 ? we * (he - 1) : we - 1 + we * (he - 1)] = pick(p_c, d_c);
             wave_lds_sync();
             const int *lut = s_lut[wv];
             auto lutf = [&](int z) -> int {                           // read_table (:176-189)
