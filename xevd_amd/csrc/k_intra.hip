@@ -283,37 +283,56 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
         if (EIPD) {
             // xevdm_get_nbr: an unavailable unit repeats the last sample of the nearest available unit before it (the mid value when
             // there is none above; the corner when there is none to the left); every element is one load at a computed position
-            auto ld1 = [&](const int16_t *p) -> int {
-                if (!DEP) return (int)(uint16_t)*p;
-                const uintptr_t q = (uintptr_t)p;
-                const uint32_t d = ld_coherent((const int16_t *)(q & ~(uintptr_t)3));
-                return (int)((q & 2) ? d >> 16 : d & 0xFFFFu);
+            // every element is one load at a computed position: the dword that holds it is requested for all elements of a component first (up to four rounds of 64
+            // lanes per side), the halves are picked afterwards - a select right behind a load would make every load its own memory round trip
+            auto ldd = [&](const int16_t *p) -> uint32_t {
+                const uintptr_t q = (uintptr_t)p & ~(uintptr_t)3;
+                return DEP ? ld_coherent((const int16_t *)q) : *(const uint32_t *)q;
             };
+            auto half = [&](const int16_t *p, uint32_t d) -> int { return (int)(((uintptr_t)p & 2) ? d >> 16 : d & 0xFFFFu); };
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 const int16_t *plane = c == 0 ? a.cur_y : (c == 1 ? a.cur_u : a.cur_v);
                 const int s = c ? a.s_c : a.s_l, sh = c ? 1 : 0, ush = c ? 1 : 2, usz = c ? 2 : 4;
                 const int16_t *org = plane + (cu_y >> sh) * s + (cu_x >> sh);
                 const int n = (cw + chh) >> sh;
-                const int corner_pre = avail_ul ? ld1(org - s - 1) : mid;
-                const int corner = avail_ul ? corner_pre : ((avail_up & 1) ? ld1(org - s) : mid);
-                for (int e = t; e < n; e += 64) {
-                    const int u = e >> ush;
-                    const uint64_t below_up = avail_up & ((1ull << u) - 1), below_le = avail_le & ((1ull << u) - 1);
-                    int v;
-                    if ((avail_up >> u) & 1) v = ld1(org - s + e);
-                    else if (below_up)       v = ld1(org - s + (63 - __clzll((long long)below_up)) * usz + usz - 1);
-                    else                     v = corner_pre;
-                    nb[c][NB_C0 + 1 + e] = (int16_t)v;
-                    if ((avail_le >> u) & 1) v = ld1(org + e * s - 1);
-                    else if (below_le)       v = ld1(org + ((63 - __clzll((long long)below_le)) * usz + usz - 1) * s - 1);
-                    else                     v = corner;
-                    nb[c][NB_C0 - 1 - e] = (int16_t)v;
+                const int16_t *pc0 = avail_ul ? org - s - 1 : nullptr, *pc1 = (!avail_ul && (avail_up & 1)) ? org - s : nullptr;
+                const uint32_t dc0 = pc0 ? ldd(pc0) : 0u, dc1 = pc1 ? ldd(pc1) : 0u;
+                const int16_t *pu[4], *ple[4];
+                uint32_t du[4], dle[4];
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const int e = t + 64 * it, u = e >> ush;
+                    pu[it] = ple[it] = nullptr; du[it] = dle[it] = 0;
+                    if (e < n) {
+                        const uint64_t below_up = avail_up & ((1ull << u) - 1), below_le = avail_le & ((1ull << u) - 1);
+                        if ((avail_up >> u) & 1) pu[it] = org - s + e;
+                        else if (below_up)       pu[it] = org - s + (63 - __clzll((long long)below_up)) * usz + usz - 1;
+                        if ((avail_le >> u) & 1) ple[it] = org + e * s - 1;
+                        else if (below_le)       ple[it] = org + ((63 - __clzll((long long)below_le)) * usz + usz - 1) * s - 1;
+                        if (pu[it]) du[it] = ldd(pu[it]);
+                        if (ple[it]) dle[it] = ldd(ple[it]);
+                    }
+                }
+                uint32_t dc0_ = dc0, dc1_ = dc1;
+                asm volatile("" : "+v"(dc0_), "+v"(dc1_), "+v"(du[0]), "+v"(du[1]), "+v"(du[2]), "+v"(du[3]), "+v"(dle[0]), "+v"(dle[1]), "+v"(dle[2]), "+v"(dle[3]));      // (keeps the selects out of the loads' branches)
+                const int corner_pre = pc0 ? half(pc0, dc0_) : mid;
+                const int corner = pc0 ? corner_pre : (pc1 ? half(pc1, dc1_) : mid);
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+                    const int e = t + 64 * it;
+                    if (e < n) {
+                        nb[c][NB_C0 + 1 + e] = (int16_t)(pu[it] ? half(pu[it], du[it]) : corner_pre);
+                        nb[c][NB_C0 - 1 - e] = (int16_t)(ple[it] ? half(ple[it], dle[it]) : corner);
+                    }
                 }
                 if (t == 0) nb[c][NB_C0] = (int16_t)corner;
             }
         } else {
+        // (In the data-flow launch the loads are coherent dword loads whose wanted half is picked AFTER every load of the round is out: a shift or select right
+        //  behind a load makes the compiler wait for it on the spot, and these loads are memory round trips - nine in a row was most of a dependency hop.)
         uint32_t v_up[3], v_le[3][2], v_ul[3];
+        bool h_le[3][2], h_ul[3];
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const int16_t *plane = c == 0 ? a.cur_y : (c == 1 ? a.cur_u : a.cur_v);
@@ -326,19 +345,24 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
 #pragma unroll
             for (int k = 0; k < 2; k++) {
                 const int el = t + 64 * k;
-                v_le[c][k] = (uint32_t)mid;
-                if (el < n && ((avail_le >> (el >> ush)) & 1)) v_le[c][k] = DEP ? (ld_coherent(org + el * s - 2) >> 16) : (uint32_t)(uint16_t)org[el * s - 1];
+                v_le[c][k] = 0;
+                h_le[c][k] = el < n && ((avail_le >> (el >> ush)) & 1);
+                if (h_le[c][k]) v_le[c][k] = DEP ? ld_coherent(org + el * s - 2) : ((uint32_t)(uint16_t)org[el * s - 1] << 16);      // the sample = the dword's high half
             }
-            v_ul[c] = (uint32_t)mid;
-            if (t == 0 && avail_ul) v_ul[c] = DEP ? (ld_coherent(org - s - 2) >> 16) : (uint32_t)(uint16_t)org[-s - 1];
+            v_ul[c] = 0;
+            h_ul[c] = t == 0 && avail_ul;
+            if (h_ul[c]) v_ul[c] = DEP ? ld_coherent(org - s - 2) : ((uint32_t)(uint16_t)org[-s - 1] << 16);
         }
+        // (opaque to the optimiser: without it the shifts below are sunk back into the branches of the loads - one wait per load again)
+#pragma unroll
+        for (int c = 0; c < 3; c++) asm volatile("" : "+v"(v_up[c]), "+v"(v_le[c][0]), "+v"(v_le[c][1]), "+v"(v_ul[c]));
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const int sh = c ? 1 : 0, n = (cw + chh) >> sh;
             if (2 * t < n) *(uint32_t *)&nb[c][NB_C0 + 1 + 2 * t] = v_up[c];
-            if (t < n) nb[c][NB_C0 - 1 - t] = (int16_t)v_le[c][0];
-            if (t + 64 < n) nb[c][NB_C0 - 1 - (t + 64)] = (int16_t)v_le[c][1];
-            if (t == 0) nb[c][NB_C0] = (int16_t)v_ul[c];
+            if (t < n) nb[c][NB_C0 - 1 - t] = (int16_t)(h_le[c][0] ? v_le[c][0] >> 16 : (uint32_t)mid);
+            if (t + 64 < n) nb[c][NB_C0 - 1 - (t + 64)] = (int16_t)(h_le[c][1] ? v_le[c][1] >> 16 : (uint32_t)mid);
+            if (t == 0) nb[c][NB_C0] = (int16_t)(h_ul[c] ? v_ul[c] >> 16 : (uint32_t)mid);
         }
         if (cw + chh > 128) {                                        // the rest of the largest CUs (luma only can exceed one round)
             const int16_t *org = a.cur_y + cu_y * a.s_l + cu_x;
@@ -527,6 +551,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
                     if (i < n2) { tb[(r + 1) * we + c + 1] = (int16_t)(d[q] & 0xFFFF); tb[(r + 1) * we + c + 2] = (int16_t)(d[q] >> 16); }
                 }
             }
+            asm volatile("" : "+v"(d_l), "+v"(d_r), "+v"(d_u), "+v"(d_d), "+v"(d_c));      // (keeps the picks out of the loads' branches)
             if (t < chh) { tb[(t + 1) * we] = pick(p_l, d_l); tb[(t + 1) * we + we - 1] = pick(p_r, d_r); }
             if (t < cw) { tb[t + 1] = pick(p_u, d_u); tb[(he - 1) * we + t + 1] = pick(p_d, d_d); }
             if (t < 4) tb[t == 0 ? 0 : t == 1 ? we - 1 : t == 2 ? we * (he - 1) : we - 1 + we * (he - 1)] = pick(p_c, d_c);
