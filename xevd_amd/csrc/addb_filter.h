@@ -99,12 +99,12 @@ __device__ __forceinline__ int addb_index(int qp, int offset) { return clip3a(0,
 // after / before the grid line, eq = the Q side's SCU position along the filtered axis, L / Cc = the windows (filtered in place).
 // decision half: the boundary strength of the segment, 0 = nothing to filter (not a CU / transform boundary, a tile border the PPS keeps, or strength 0)
 template <int DIR>
-__device__ __forceinline__ int addb_edge_strength(const AddbArgs &a, const uint4 rq, const uint4 rp, int eq, const uint8_t *s_pic)
+__device__ __forceinline__ int addb_edge_strength(const AddbArgs &a, const TileMask &no_filter, const uint4 rq, const uint4 rp, int eq, const uint8_t *s_pic)
 {
     const uint32_t eflag = DIR == 0 ? SCU_EDGE_L : SCU_EDGE_T;
     // an edge on a tile border stays as it is unless the PPS filters across tiles (no_boundary, src_main/xevdm_df.c:877, 1088, 1106)
     const int ctu_sh = a.log2_ctu - 2;
-    const bool tile_edge = (eq & ((1 << ctu_sh) - 1)) == 0 && (DIR == 0 ? a.no_filter.col_start((eq >> ctu_sh) & 255) : a.no_filter.row_start((eq >> ctu_sh) & 255));
+    const bool tile_edge = (eq & ((1 << ctu_sh) - 1)) == 0 && (DIR == 0 ? no_filter.col_start((eq >> ctu_sh) & 255) : no_filter.row_start((eq >> ctu_sh) & 255));
     if (!(rq.x & eflag) || tile_edge) return 0;
     const int epos = eq << 2;
     const bool cross = (epos & ((1 << a.log2_ctu) - 1)) == 0;
@@ -145,6 +145,6 @@ template <int DIR>
 __device__ __forceinline__ void addb_edge(const AddbArgs &a, const uint4 rq, const uint4 rp, int eq, int L[4][8], int Cc[2][2][4],
                                           const uint8_t *s_alpha, const uint8_t *s_beta, const uint8_t *s_clip, const int8_t *s_cqp, const uint8_t *s_pic)
 {
-    const int bs = addb_edge_strength<DIR>(a, rq, rp, eq, s_pic);
+    const int bs = addb_edge_strength<DIR>(a, a.no_filter, rq, rp, eq, s_pic);
     if (bs) addb_edge_filter<DIR>(a, rq, rp, bs, L, Cc, s_alpha, s_beta, s_clip, s_cqp);
 }

@@ -178,7 +178,7 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
     const int ctu_idx = (k.y0 >> a.log2_ctu) * a.w_ctu + (k.x0 >> a.log2_ctu);
     const bool luma_on = a.enable[0] && (a.ctb_in_args ? ((a.ctb_bits[ctu_idx >> 5] >> (ctu_idx & 31)) & 1) != 0 : (a.ctb_flag == nullptr || a.ctb_flag[ctu_idx] != 0));
 
-    for (int i = t; i < 25 * 13 + 7; i += 256) l_coef[i] = a.coef[i];
+    if (!FUSED) for (int i = t; i < 25 * 13 + 7; i += 256) l_coef[i] = a.coef[i];      // (fused: behind the window loads, with the deblocking tables)
     CtuRect kc = k;
     kc.x0 >>= 1; kc.y0 >>= 1; kc.cw >>= 1; kc.ch >>= 1; kc.tx0 >>= 1; kc.tx1 >>= 1; kc.ty0 >>= 1; kc.ty1 >>= 1;
     if (!FUSED) {
@@ -199,12 +199,8 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
         constexpr int LIST_OFF = (18 * 18 * 16 + 52 + 52 + 260 + XGPU_MAX_REFS * 2 + 192 + 3) & ~3;
         uint32_t *s_cnt = (uint32_t *)((uint8_t *)&l_lap[0][0][0] + LIST_OFF);
         uint16_t (*s_list)[164] = (uint16_t (*)[164])(s_cnt + 2);            // entry = lane | strength << 8
-        static_assert(LIST_OFF + 8 + 2 * 164 * 2 <= (int)sizeof(uint16_t) * 4 * 34 * SSTR, "the deblocking state fits into l_lap");
-        for (int i = t; i < 52; i += 256) { s_alpha[i] = k_alpha[i]; s_beta[i] = k_beta[i]; }
-        for (int i = t; i < 260; i += 256) s_clip[i] = ((const uint8_t *)k_clip)[i];
-        for (int i = t; i < XGPU_MAX_REFS * 2; i += 256) s_pic[i] = da.pic_id[i];
-        for (int i = t; i < 192; i += 256) s_cqp[i] = da.chroma_qp[i];
-        if (t < 2) s_cnt[t] = 0;
+        TileMask *s_tm = (TileMask *)((uint8_t *)&l_lap[0][0][0] + LIST_OFF + 8 + ((2 * 164 * 2 + 3) & ~3));      // the tile-border masks: a lane-indexed read of the kernel arguments is a global load
+        static_assert(LIST_OFF + 8 + ((2 * 164 * 2 + 3) & ~3) + (int)sizeof(TileMask) <= (int)sizeof(uint16_t) * 4 * 34 * SSTR, "the deblocking state fits into l_lap");
 #define PK2(lo, hi) ((uint32_t)(uint16_t)(lo) | ((uint32_t)(uint16_t)(hi) << 16))
         {   // phase A: lane = vertical-edge window wx (grid line x0 + 8 wx) x SCU row sr of the region: window and SCU records from memory to LDS
             const int wx = t % 9, sr = t / 9;
@@ -227,6 +223,30 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
 #pragma unroll
                     for (int r = 0; r < 2; r++) { const U32x2a4 v = *(const U32x2a4 *)((pl ? sv_ : su_) + (cy + r) * a.s_c + (gx >> 1) - 2); C[pl][r] = make_uint2(v.a, v.b); }
             }
+            // the small tables into LDS only now: each of these copies waits for its own loads, and in front of the window loads they were four memory round trips
+            // in a row before the first window load of the tile had even been issued
+            // (and all of their loads before the first of their stores: one more round trip, not six)
+            {
+                static_assert(XGPU_MAX_REFS * 2 <= 256 && 260 <= 512 && 25 * 13 + 7 <= 512, "one or two table entries per thread");
+                const uint8_t *clip = (const uint8_t *)k_clip;
+                uint8_t va = 0, vb = 0, vc0 = clip[t], vc1 = 0, vp = 0;
+                int8_t vq = 0;
+                int16_t vf0 = a.coef[t], vf1 = 0;
+                if (t < 52) { va = k_alpha[t]; vb = k_beta[t]; }
+                if (t + 256 < 260) vc1 = clip[t + 256];
+                if (t < XGPU_MAX_REFS * 2) vp = da.pic_id[t];
+                if (t < 192) vq = da.chroma_qp[t];
+                if (t + 256 < 25 * 13 + 7) vf1 = a.coef[t + 256];
+                if (t < 52) { s_alpha[t] = va; s_beta[t] = vb; }
+                s_clip[t] = vc0;
+                if (t + 256 < 260) s_clip[t + 256] = vc1;
+                if (t < XGPU_MAX_REFS * 2) s_pic[t] = vp;
+                if (t < 192) s_cqp[t] = vq;
+                l_coef[t] = vf0;
+                if (t + 256 < 25 * 13 + 7) l_coef[t + 256] = vf1;
+                if (t < 2) s_cnt[t] = 0;
+                if (t < 16) ((uint32_t *)s_tm)[t] = t < 8 ? da.no_filter.vb[t] : da.no_filter.hb[t - 8];
+            }
             __syncthreads();                                 // the tables and the counters (the loads above are in flight across it)
             if (t < 162) {
                 s_map[sr][2 * wx] = rp; s_map[sr][2 * wx + 1] = rq;
@@ -236,7 +256,7 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
                 for (int pl = 0; pl < 2; pl++)
 #pragma unroll
                     for (int r = 0; r < 2; r++) *(uint2 *)(l_c[pl] + (2 * sr + r) * CSTR + 4 * wx) = C[pl][r];
-                const int bs = has_p && has_q ? addb_edge_strength<0>(da, rq, rp, sxq, s_pic) : 0;
+                const int bs = has_p && has_q ? addb_edge_strength<0>(da, *s_tm, rq, rp, sxq, s_pic) : 0;
                 if (bs) s_list[0][atomicAdd(&s_cnt[0], 1u)] = (uint16_t)(t | (bs << 8));
             }
         }
@@ -273,7 +293,7 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
             const int sx = t % 18, g = t / 18;
             const int scol = (tx0 >> 2) - 1 + sx, gy = ty0 + 8 * g;
             if (scol >= 0 && scol < da.w_scu && gy > 0 && gy < a.pic_h) {
-                const int bs = addb_edge_strength<1>(da, s_map[2 * g + 1][sx], s_map[2 * g][sx], gy >> 2, s_pic);
+                const int bs = addb_edge_strength<1>(da, *s_tm, s_map[2 * g + 1][sx], s_map[2 * g][sx], gy >> 2, s_pic);
                 if (bs) s_list[1][atomicAdd(&s_cnt[1], 1u)] = (uint16_t)(t | (bs << 8));
             }
         }

@@ -266,13 +266,20 @@ __device__ __forceinline__ void dmvr_predict_packed(const DmvrArgs &a, const Dmv
         const int q16x = ((u.px << 2) + u.st[l][0]) << 2, q16y = ((u.py << 2) + u.st[l][1]) << 2;
         {
             const gs16 sy_ = (gs16)u.ry[l] + ((q16y >> 4) - 3) * a.s_l + (q16x >> 4) - 3;
-            for (int i = lane; i < (DY + 7) * CH; i += 64) { const int r = i / CH, k = i - r * CH; *(uint4 *)(W + r * DM_LWS + 8 + 8 * k) = gload16(sy_ + r * a.s_l + 8 * k); }
+            // all loads of the list first, then the LDS stores (a loop of load + store waits for every round on its own: three memory round trips instead of one)
+            constexpr int NLW = (DY + 7) * CH, NCW = 2 * WCH * 2;      // 16-byte chunks of the luma window (at most 69: two per lane) and of the two chroma windows (at most 44)
+            static_assert(NLW <= 128 && NCW <= 64, "one or two chunks per lane");
             const int co = ((q16y >> 5) - 1) * a.s_c + (q16x >> 5) - 1;
             const gs16 su_ = (gs16)u.ru[l] + co, sv_ = (gs16)u.rv[l] + co;
-            for (int i = lane; i < 2 * WCH * 2; i += 64) {          // two planes x rows x two chunks
-                const int p = i >= WCH * 2, j = i - p * WCH * 2, r = j >> 1, k = j & 1;
-                *(uint4 *)(Wc + p * WCH * DM_CWS + r * DM_CWS + 8 + 8 * k) = gload16((p ? sv_ : su_) + r * a.s_c + 8 * k);
-            }
+            const int r0 = lane / CH, k0 = lane - r0 * CH, r1 = (lane + 64) / CH, k1 = (lane + 64) - r1 * CH;
+            const int cp = lane >= WCH * 2, cj = lane - cp * WCH * 2, cr_ = cj >> 1, ck = cj & 1;
+            uint4 v0 = make_uint4(0, 0, 0, 0), v1 = v0, vc = v0;
+            if (lane < NLW) v0 = gload16(sy_ + r0 * a.s_l + 8 * k0);
+            if (lane + 64 < NLW) v1 = gload16(sy_ + r1 * a.s_l + 8 * k1);
+            if (lane < NCW) vc = gload16((cp ? sv_ : su_) + cr_ * a.s_c + 8 * ck);
+            if (lane < NLW) *(uint4 *)(W + r0 * DM_LWS + 8 + 8 * k0) = v0;
+            if (lane + 64 < NLW) *(uint4 *)(W + r1 * DM_LWS + 8 + 8 * k1) = v1;
+            if (lane < NCW) *(uint4 *)(Wc + cp * WCH * DM_CWS + cr_ * DM_CWS + 8 + 8 * ck) = vc;
         }
         dm_sync();
         for (int i = lane; i < 2 * (DY + 7) + 4 * WCH; i += 64) {
@@ -452,16 +459,18 @@ __device__ __forceinline__ void dmvr_block(const DmvrArgs &a, const uint4 r0, co
 
     // ---- search windows: (DY + 5) rows x (DX + 5) samples of both lists at the (clipped) starting vector, then the bilinear blocks ----
     int bfx[2], bfy[2];
+    uint4 sw[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) };
 #pragma unroll
     for (int l = 0; l < 2; l++) {
         const int gx = ((u.cu_x << 2) + u.st[l][0] - 8) << 2, gy = ((u.cu_y << 2) + u.st[l][1] - 8) << 2;      // sixteenth samples of the CU block's corner
         bfx[l] = gx & 15; bfy[l] = gy & 15;
         const gs16 src = (gs16)u.ry[l] + ((gy >> 4) + (u.py - u.cu_y)) * a.s_l + (gx >> 4) + (u.px - u.cu_x);
-        for (int i = lane; i < (DY + 5) * CH; i += 64) {
-            const int r = i / CH, k = i - r * CH;
-            *(uint4 *)(W + l * 21 * DM_RS + r * DM_RS + 8 * k) = gload16(src + r * a.s_l + 8 * k);
-        }
+        static_assert((DY + 5) * CH <= 64, "one chunk of a search window per lane");
+        if (lane < (DY + 5) * CH) sw[l] = gload16(src + (lane / CH) * a.s_l + 8 * (lane % CH));      // both lists' loads go out before either is stored
     }
+#pragma unroll
+    for (int l = 0; l < 2; l++)
+        if (lane < (DY + 5) * CH) *(uint4 *)(W + l * 21 * DM_RS + (lane / CH) * DM_RS + 8 * (lane % CH)) = sw[l];
     dm_sync();
 #pragma unroll
     for (int l = 0; l < 2; l++) {
@@ -573,7 +582,7 @@ __device__ __forceinline__ void dmvr_block(const DmvrArgs &a, const uint4 r0, co
     else        dmvr_predict_scalar<DX, DY>(a, u, r16, W, T, lane);
 }
 
-__global__ __launch_bounds__(256) void k_dmvr(const DmvrArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_dmvr(const DmvrArgs a)      // (64 VGPRs: eight waves per SIMD - the LDS footprint allows as many)
 {
     __shared__ __attribute__((aligned(16))) int16_t s_bl[4][2 * DM_BL * DM_BL];
     __shared__ __attribute__((aligned(16))) int16_t s_win[4][DM_STAGE];
