@@ -315,7 +315,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
                     }
                 }
                 uint32_t dc0_ = dc0, dc1_ = dc1;
-                asm volatile("" : "+v"(dc0_), "+v"(dc1_), "+v"(du[0]), "+v"(du[1]), "+v"(du[2]), "+v"(du[3]), "+v"(dle[0]), "+v"(dle[1]), "+v"(dle[2]), "+v"(dle[3]));      // (keeps the selects out of the loads' branches)
+                if (DEP) asm volatile("" : "+v"(dc0_), "+v"(dc1_), "+v"(du[0]), "+v"(du[1]), "+v"(du[2]), "+v"(du[3]), "+v"(dle[0]), "+v"(dle[1]), "+v"(dle[2]), "+v"(dle[3]));      // (keeps the selects out of the loads' branches)
                 const int corner_pre = pc0 ? half(pc0, dc0_) : mid;
                 const int corner = pc0 ? corner_pre : (pc1 ? half(pc1, dc1_) : mid);
 #pragma unroll
@@ -355,7 +355,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
         }
         // (opaque to the optimiser: without it the shifts below are sunk back into the branches of the loads - one wait per load again)
 #pragma unroll
-        for (int c = 0; c < 3; c++) asm volatile("" : "+v"(v_up[c]), "+v"(v_le[c][0]), "+v"(v_le[c][1]), "+v"(v_ul[c]));
+        for (int c = 0; c < 3; c++) if (DEP) asm volatile("" : "+v"(v_up[c]), "+v"(v_le[c][0]), "+v"(v_le[c][1]), "+v"(v_ul[c]));      // (the plain loads of the level-1 launch are the compiler's to schedule: 23.5 us without, 27.8 with the fence)
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             const int sh = c ? 1 : 0, n = (cw + chh) >> sh;
