@@ -17,6 +17,7 @@
 //     the control points - cheaper than another host-built table.
 // Integer arithmetic and intermediate widths follow the reference exactly (its intermediates are s16 `pel`).
 #include "mc_filters.h"
+#include <type_traits>
 
 #include "affine_model.h"
 
@@ -133,36 +134,55 @@ __global__ __launch_bounds__(256) void k_affine_eif(const AffineArgs a)
 #pragma unroll
     for (int l = 0; l < 2; l++) {
         if (!k.use[l]) continue;
-        const RefEntry &re = a.refp[k.refi[l]][l];
+        const RefEntry &re = a.refp[__builtin_amdgcn_readfirstlane(k.refi[l])][l];      // (wave-uniform: scalar loads of the kernel arguments instead of a vector load per plane)
         const AffModel &m = k.md[l];
         const int mv_scale[2] = { k.cp[l][0] * (1 << AFF_BIT), k.cp[l][1] * (1 << AFF_BIT) };
         int mx[2], mn[2];
         aff_eif_range(k.cu_x, k.cu_y, k.lw, k.lh, m, mv_scale, a.pic_w, a.pic_h, !k.mem_band, mx, mn);
-        int base = 0;
+        // Every gather of the list - three components: six + two + two rounds of 64 lanes - goes out before the first sample is computed (a loop of gather +
+        // arithmetic + LDS store waited for its four loads in every round: ten memory round trips per list, now one).  The two samples of a row are one dword
+        // load at the 2-byte-aligned address.
+        constexpr int RL = ((EIF_TILE + 2) * (EIF_TILE + 2) + 63) / 64, RC = ((EIF_TILE / 2 + 2) * (EIF_TILE / 2 + 2) + 63) / 64;
+        uint32_t top[RL + 2 * RC], bot[RL + 2 * RC];
+        int frac[RL + 2 * RC];
 #pragma unroll
-        for (int comp = 0; comp < 3; comp++) {
-            const int cs = comp ? 1 : 0;                                     // 4:2:0
-            const int bw = tw >> cs, bh = th >> cs, ox = tx >> cs, oy = ty >> cs, bd = comp ? a.bd_c : a.bd_l;
-            const int s_ref = comp ? a.s_c : a.s_l;
-            const int16_t *ref = (comp == 0 ? re.y : comp == 1 ? re.u : re.v) + (k.cu_y >> cs) * s_ref + (k.cu_x >> cs);
-            const int m0x = mv_scale[0] >> cs, m0y = mv_scale[1] >> cs;
-            const int hx = mx[0] >> cs, hy = mx[1] >> cs, lx_ = mn[0] >> cs, ly_ = mn[1] >> cs;
-            const int shift1 = min(4, bd - 8), shift2 = max(8, 20 - bd), off2 = 1 << (shift2 - 1);
-            const int ts = bw + 2, inv = (65536 + ts - 1) / ts;              // i / ts == (i * inv) >> 16 for the few hundred i of a window
-            int16_t *dst = s_bl_[wv][l] + base;
-#pragma unroll 2
-            for (int i = t; i < ts * (bh + 2); i += 64) {
-                const int row = (i * inv) >> 16, col = i - row * ts;
-                const int py = row - 1 + oy, px = col - 1 + ox;
-                int vx = (m0x + px * m.dh[0] + py * m.dv[0]) >> 4, vy = (m0y + px * m.dh[1] + py * m.dv[1]) >> 4;
-                vx = min(hx, max(lx_, vx)); vy = min(hy, max(ly_, vy));
-                const int16_t *r = ref + (py + (vy >> 5)) * s_ref + px + (vx >> 5);
-                const int fx = vx & 31, fy = vy & 31;
-                const int s1 = (int)(int16_t)(((64 - 2 * fx) * r[0] + 2 * fx * r[1]) >> shift1);
-                const int s2 = (int)(int16_t)(((64 - 2 * fx) * r[s_ref] + 2 * fx * r[s_ref + 1]) >> shift1);
-                dst[i] = (int16_t)(((64 - 2 * fy) * s1 + 2 * fy * s2 + off2) >> shift2);
+        for (int pass = 0; pass < 2; pass++) {
+            int base = 0;
+#pragma unroll
+            for (int comp = 0; comp < 3; comp++) {
+                const int cs = comp ? 1 : 0;                                     // 4:2:0
+                const int bw = tw >> cs, bh = th >> cs, ox = tx >> cs, oy = ty >> cs, bd = comp ? a.bd_c : a.bd_l;
+                const int s_ref = comp ? a.s_c : a.s_l;
+                const int16_t *ref = (comp == 0 ? re.y : comp == 1 ? re.u : re.v) + (k.cu_y >> cs) * s_ref + (k.cu_x >> cs);
+                const int m0x = mv_scale[0] >> cs, m0y = mv_scale[1] >> cs;
+                const int hx = mx[0] >> cs, hy = mx[1] >> cs, lx_ = mn[0] >> cs, ly_ = mn[1] >> cs;
+                const int shift1 = min(4, bd - 8), shift2 = max(8, 20 - bd), off2 = 1 << (shift2 - 1);
+                const int ts = bw + 2, inv = (65536 + ts - 1) / ts;              // i / ts == (i * inv) >> 16 for the few hundred i of a window
+                int16_t *dst = s_bl_[wv][l] + base;
+#pragma unroll
+                for (int it = 0; it < RL; it++) {
+                    if (it >= (comp ? RC : RL)) continue;
+                    const int q = (comp == 0 ? 0 : comp == 1 ? RL : RL + RC) + it, i = t + 64 * it;
+                    if (pass == 0) {
+                        top[q] = bot[q] = 0; frac[q] = 0;
+                        if (i < ts * (bh + 2)) {
+                            const int row = (i * inv) >> 16, col = i - row * ts;
+                            const int py = row - 1 + oy, px = col - 1 + ox;
+                            int vx = (m0x + px * m.dh[0] + py * m.dv[0]) >> 4, vy = (m0y + px * m.dh[1] + py * m.dv[1]) >> 4;
+                            vx = min(hx, max(lx_, vx)); vy = min(hy, max(ly_, vy));
+                            const gs16 r = (gs16)ref + (py + (vy >> 5)) * s_ref + px + (vx >> 5);
+                            top[q] = gload4(r); bot[q] = gload4(r + s_ref);
+                            frac[q] = (vx & 31) | ((vy & 31) << 8);
+                        }
+                    } else if (i < ts * (bh + 2)) {
+                        const int fx = frac[q] & 31, fy = frac[q] >> 8;
+                        const int s1 = (int)(int16_t)(((64 - 2 * fx) * (int)(int16_t)(top[q] & 0xFFFF) + 2 * fx * (int)(int16_t)(top[q] >> 16)) >> shift1);
+                        const int s2 = (int)(int16_t)(((64 - 2 * fx) * (int)(int16_t)(bot[q] & 0xFFFF) + 2 * fx * (int)(int16_t)(bot[q] >> 16)) >> shift1);
+                        dst[i] = (int16_t)(((64 - 2 * fy) * s1 + 2 * fy * s2 + off2) >> shift2);
+                    }
+                }
+                base += ts * (bh + 2);
             }
-            base += ts * (bh + 2);
         }
     }
     aff_wave_sync();
@@ -256,7 +276,7 @@ __global__ __launch_bounds__(256) void k_affine_sub(const AffineArgs a)
 #pragma unroll
     for (int l = 0; l < 2; l++) {
         if (!k.use[l]) continue;
-        const RefEntry &re = a.refp[k.refi[l]][l];
+        const RefEntry &re = a.refp[__builtin_amdgcn_readfirstlane(k.refi[l])][l];      // (wave-uniform: scalar loads of the kernel arguments instead of a vector load per plane)
         const AffModel &m = k.md[l];
         // filter variant from the unclipped vector like xevd_mc_l / xevd_mc_c (xevd_mc.h:66-74)
         const int ox = aff_clip18(aff_round(k.cp[l][0] * (1 << AFF_BIT) + m.dh[0] * (k.sub_w >> 1) + m.dv[0] * (k.sub_h >> 1), 5));
