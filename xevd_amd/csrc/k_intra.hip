@@ -616,18 +616,18 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 // with two cross-stream event waits of 6 us each), 64 us as one.  (Letting the level-1 launch carry a share of the work items too - it is 23 us of memory latency
 // as well - measured nothing at 25 % and 1 - 3 % slower at 35 - 70 %: that launch is short and dense enough to be slowed down by the company.)
 #define FUSED_WAVES 4
-template <bool EIPD, bool IBC>
+template <bool EIPD, bool IBC, bool IQT>
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_intra_itdq(const IntraArgs a, const ItdqArgs r, uint32_t n_intra_wg)
 {
-    constexpr int ITDQ_DW = ITDQ_LDS_DWORDS - ITDQ_PLANES_DWORDS / 2 + 2 * ITDQ_MAX_G, INTRA_DW = (FUSED_WAVES * IntraLds<false>::WAVE + 1) / 2 + 4;
+    constexpr int ITDQ_DW = (IQT ? ITDQ_LDS_DWORDS - ITDQ_PLANES_DWORDS / 2 : ITDQ_LDS_DWORDS) + 2 * ITDQ_MAX_G, INTRA_DW = (FUSED_WAVES * IntraLds<false>::WAVE + 1) / 2 + 4;
     __shared__ __attribute__((aligned(16))) uint32_t raw[ITDQ_DW > INTRA_DW ? ITDQ_DW : INTRA_DW];
     if (blockIdx.x < n_intra_wg) {
         intra_body<true, EIPD, IBC, false, FUSED_WAVES>(a, blockIdx.x, (int16_t *)raw, nullptr, raw + INTRA_DW - 1);
     } else {
         const int wi = (int)(blockIdx.x - n_intra_wg);
         if (wi >= r.n_waves) return;
-        uint32_t *s_rm = raw + ITDQ_LDS_DWORDS - ITDQ_PLANES_DWORDS / 2;
-        itdq_dispatch<true>(r, wi, raw, s_rm, s_rm + ITDQ_MAX_G);
+        uint32_t *s_rm = raw + ITDQ_DW - 2 * ITDQ_MAX_G;
+        itdq_dispatch<IQT>(r, wi, raw, s_rm, s_rm + ITDQ_MAX_G);
     }
 }
 
@@ -641,7 +641,7 @@ void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf
     if (next) {
         const uint32_t n_wg = (uint32_t)((a.count + FUSED_WAVES - 1) / FUSED_WAVES);
         const dim3 g(n_wg + (uint32_t)next->n_waves), b(64 * FUSED_WAVES);
-#define LAUNCHF(E, I) hipLaunchKernelGGL((k_intra_itdq<E, I>), g, b, 0, c->stream, a, *next, n_wg)
+#define LAUNCHF(E, I) do { if (next->iqt) hipLaunchKernelGGL((k_intra_itdq<E, I, true>), g, b, 0, c->stream, a, *next, n_wg); else hipLaunchKernelGGL((k_intra_itdq<E, I, false>), g, b, 0, c->stream, a, *next, n_wg); } while (0)
         if (c->sp.tool_eipd) { if (ibc) LAUNCHF(true, true); else LAUNCHF(true, false); }
         else                 { if (ibc) LAUNCHF(false, true); else LAUNCHF(false, false); }
 #undef LAUNCHF

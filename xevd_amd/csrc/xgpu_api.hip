@@ -1220,7 +1220,7 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
         TIMED(c, XGPU_K_INTRA, {
             // the next picture's residual pass rides in the data-flow launch (not while single kernels are being timed; HTDF's workgroups are a different shape)
             ItdqArgs na;
-            const bool ride = next && n_dep > 0 && !c->timing && !db->has_htdf && (na = itdq_args(c, next), na.iqt && na.n_waves > 0);
+            const bool ride = next && n_dep > 0 && !c->timing && !db->has_htdf && (na = itdq_args(c, next), na.n_waves > 0);
             ta.first = 0; ta.count = db->n_intra_l1;
             if (ta.count) launch_intra(c, ta, false, db->has_ibc != 0, db->has_htdf != 0, NULL);
             ta.first = db->n_intra_l1; ta.count = n_dep;
