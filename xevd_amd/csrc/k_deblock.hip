@@ -183,6 +183,9 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
     // Edges 2 chroma samples apart are applied in increasing coordinate order (xevd_df.c:238-289): this edge's A is the C' of the previous
     // edge when that one is active.  The lane walks back to the head of the chain of consecutive active edges and recomputes it forward
     // from the ORIGINAL samples (chains are as long as a run of 4-wide CUs; every lane stays independent).
+    // (Round 3: a variant that loaded the records of three more edges with the first loads, walked over them in registers and fetched a chain's samples in one batch
+    //  was bit-exact and SLOWER - 30.6 / 27.7 us instead of 28 / 25 at 1080p, 90 / 81 instead of 83 / 71 at 8K: chains are rare enough that the dependent loads below
+    //  are seldom executed, and the 30 extra registers cost more than they saved.)
     const int alongc = DIR == 0 ? 1 : a.s_c, acrossc = DIR == 0 ? a.s_c : 1;
 #pragma unroll
     for (int pl = 0; pl < 2; pl++) {
