@@ -252,6 +252,41 @@ def test_parser_rejects_garbage():
         stream.parse_stream(bytes(data))
 
 
+def _nals(data):
+    pos, out = 0, []
+    while pos + 4 <= len(data):
+        n = int.from_bytes(data[pos:pos + 4], "big")
+        out.append(data[pos:pos + 4 + n])
+        pos += 4 + n
+    return out
+
+
+def test_several_slices_per_picture_boundaries_and_refusals():
+    """a picture in several slice NAL units: the NAL scanner (what the GOP splitter uses) tells first slices from further ones; a picture that loses one of
+    its slices is refused when the next picture starts (not assembled from another picture's tiles); the writer refuses such pictures without sps_pocs_flag
+    (the reference decoder would count a picture per slice NAL, src_main/xevdm.c:3030-3040)"""
+    import ctypes as C
+    kw = dict(main=True, pocs=True, tiles=(4, 4, 0), slices=[(0, 7), (8, 11, 35), (12, 15, 24)])
+    data = su.make_stream(256, 256, 3, seed=11, **kw)
+    lib = stream.load()
+    lib.xhost_scan_open.restype = C.c_void_p
+    lib.xhost_scan_nal.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    lib.xhost_scan_close.argtypes = [C.c_void_p]
+    sc = lib.xhost_scan_open()
+    kinds = [lib.xhost_scan_nal(sc, bytes(n[4:]), len(n) - 4) for n in _nals(data)]
+    lib.xhost_scan_close(sc)
+    assert [k for k in kinds if k] == [1, 2, 2] * 3
+    assert len(stream.parse_stream(data)) == 3
+    nals = _nals(data)
+    slices = [i for i, k in enumerate(kinds) if k]
+    with pytest.raises(RuntimeError, match="another picture|twice"):      # picture 1 without its last slice: picture 2's first slice must not complete it
+        stream.parse_stream(b"".join(n for i, n in enumerate(nals) if i != slices[5]))
+    with pytest.raises(RuntimeError):
+        su.make_stream(256, 256, 2, seed=11, main=True, tiles=(4, 4, 0), slices=[(0, 7), (8, 15)])      # no sps_pocs_flag
+    with pytest.raises(RuntimeError):
+        su.make_stream(256, 256, 2, seed=11, main=True, pocs=True, tiles=(4, 4, 0), slices=[(0, 7), (4, 15)])      # overlapping tile rectangles
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(golden_io.GOLDEN, "stream_*.npz"))), ids=os.path.basename)
 def test_golden_streams_parser_plus_oracle(path):
     """committed streams + the reference decoder's pictures (made by tests/golden/make_golden.py with oracle/_ref)"""
