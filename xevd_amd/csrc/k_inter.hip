@@ -430,17 +430,19 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     const bool active = sx < (a.pic_w >> 2) && sy < (a.pic_h >> 2);
     // the first link of the chain goes out before the tables are staged
     const uint32_t own = active ? a.owner[sy * a.w_scu + sx] : OWNER_NONE;
-    if (t < XGPU_MAX_REFS * 2) {
-        const uint4 *re = (const uint4 *)&a.refp[t >> 1][t & 1];
-        s_ref[t][0] = re[0]; s_ref[t][1] = re[1];
-    } else if (t >= 64 && t < 64 + 17) {
-        s_ltap[t - 64] = *(const uint4 *)k_luma_taps[a.admvp][t - 64];
-    } else if (t >= 128 && t < 128 + 33) {
-        s_ctap[t - 128] = *(const uint2 *)k_chroma_taps[a.admvp][t - 128];
-    }
+    // ... and so do the table loads, ONE per lane, all before the first wait: three branches of "load, store to LDS" were three more round trips in a row in
+    // front of the CU record loads (the ISA had load + s_waitcnt vmcnt(0) three times between the owner load and the record loads)
+    static_assert(XGPU_MAX_REFS * 4 <= 96 && sizeof(RefEntry) == 32, "one 16-byte half of a reference entry per lane, in front of the tap tables' lanes");
+    uint4 tab = make_uint4(0, 0, 0, 0);
+    if (t < XGPU_MAX_REFS * 4) tab = ((const uint4 *)&a.refp[0][0])[t];
+    else if (t >= 96 && t < 96 + 17) tab = *(const uint4 *)k_luma_taps[a.admvp][t - 96];
+    else if (t >= 128 && t < 128 + 33) { const uint2 v = *(const uint2 *)k_chroma_taps[a.admvp][t - 128]; tab.x = v.x; tab.y = v.y; }
     uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
     const bool ok = own < (uint32_t)a.n_cu;                    // unowned (another tile's SCU) or not an index of this batch
     if (ok) { c0 = ((const uint4 *)&a.cus[own])[0]; c1 = ((const uint4 *)&a.cus[own])[1]; }
+    if (t < XGPU_MAX_REFS * 4) s_ref[t >> 1][t & 1] = tab;
+    else if (t >= 96 && t < 96 + 17) s_ltap[t - 96] = tab;
+    else if (t >= 128 && t < 128 + 33) s_ctap[t - 128] = make_uint2(tab.x, tab.y);
     __syncthreads();
 
     int16_t *W = s_tile[t >> 6];
