@@ -409,6 +409,10 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
 // (Round 3: forcing the register allocator to five waves per SIMD - amdgpu_waves_per_eu(5, 5): 96 VGPRs + 192 bytes of scratch per lane - took 286 us instead of 152.)
 // (Round 3, occupancy sweep with dynamic LDS padding at 8K: 4 workgroups per CU 147 us, 3 per CU 153 us, 2 per CU 176 us - the kernel is not bound by the latency of
 //  its chains any more; its 507 MB of measured traffic in 147 us are 3.45 TB/s, 72 % of what this part's plain copy kernel reaches.)
+// (Round 3, non-temporal hints on the streaming accesses - residual loads, sample and SCU-record stores - so that they would not push reference lines out of L2:
+//  reads 2.83 M -> 2.70 M lines, but the stores no longer combine into 64-byte writes (2.05 M of 2.37 M requests -> 1.77 M of 2.63 M) and the kernel took 154 us
+//  instead of 140; on the loads alone 143 us.  Every read request of this kernel is a whole 128-byte line: the 39 x 78-byte rows of a window at an arbitrary offset
+//  touch 1.6 lines each, which is where the 2.2x between the windows' 134 MB and the 293 MB fetched for them comes from.)
 __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
 {
     __shared__ uint4    s_ref[XGPU_MAX_REFS * 2][2];        // RefEntry [idx][list]
