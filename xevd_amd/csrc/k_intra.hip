@@ -227,9 +227,13 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
     const int mid = 1 << (a.bd_l - 1);
     const int maxv = (1 << a.bd_l) - 1;
 
-    {   // one CU per wave and workgroup pass: a ticket (DEP) covers WAVES list positions
-        const uint32_t item = a.first + chunk * WAVES + wv;
-        if (item >= (uint32_t)(a.first + a.count)) return;
+    // one CU per wave and workgroup pass: a ticket (DEP) covers WAVES list positions.  In the data-flow launch a wave then follows its CU's STRAND: the host links a CU
+    // whose only unfinished dependency is one CU to that CU (IntraRec.cu = list position of the successor), and the wave that has just published the parent goes on
+    // with the child - no flag store to become visible, no poll to see it: a link of a strand costs the store acknowledgement and the neighbour loads (two coherent
+    // round trips) instead of four.  Strand members behind the head lie behind the launch's range of the list: no ticket reaches them.
+    uint32_t item = a.first + chunk * WAVES + wv;
+    if (item >= (uint32_t)(a.first + a.count)) return;
+    for (;;) {
         const uint4 *rec = (const uint4 *)&a.list[item];
         const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
         const uint32_t avail_ul = uni(q0.y) & 1;
@@ -596,6 +600,9 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
             if (t == 0) __hip_atomic_store(&a.done[item], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         wave_lds_sync();                                             // the next CU of this wave reuses the LDS arrays
+        if (!DEP) break;
+        item = uni(q0.x);                                            // the strand's next CU
+        if (item == 0xFFFFFFFFu) break;
     }
 }
 

@@ -442,7 +442,7 @@ int xgpu_frame_end(xgpu_ctx *c)
 // reference's COD flags: a neighbouring SCU is reconstructed at CU i's turn iff its CU index is below i (xevd_recon_unit
 // sets COD CU by CU, xevd.c:744-754; xevd_get_avail_intra, xevd_util.c:689-745; single tile/slice).  The list is sorted by
 // level (1 + the highest level among the intra CUs read), which is a topological order: every dependency sits earlier.
-struct IntraPlan { std::vector<IntraRec> recs; std::vector<uint32_t> deps; int n_levels, n_level1; bool has_ibc, has_htdf; };
+struct IntraPlan { std::vector<IntraRec> recs; std::vector<uint32_t> deps; int n_levels, n_level1, n_heads; bool has_ibc, has_htdf; };      // n_heads: level-1 CUs + strand heads = the part of the list the launches range over
 static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &plan, const uint32_t *final_owner, int nthr)
 {
     // HTDF (xevdm.c:1381-1392 with xevdm_htdf_skip_condition, xevdm_recon.c:270-297): which CUs are filtered right after their reconstruction, and with
@@ -697,29 +697,51 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         }
     }
     PT("levels");
+    // Strands (k_intra.hip): a CU of level 2 and up whose dependency list holds exactly ONE CU of level 2 and up (the others are level-1 CUs, complete before the
+    // data-flow launch) is linked to that CU when it has no successor yet; the wave that reconstructs the parent continues with it.
+    std::vector<int32_t> rec_of_cu((size_t)n, -1);
+    for (size_t ri = 0; ri < recs.size(); ri++) rec_of_cu[recs[ri].cu] = (int32_t)ri;
+    std::vector<uint32_t> succ(recs.size(), NONE);
+    std::vector<uint8_t> member(recs.size(), 0);             // 1: reached through its parent, not through a ticket
+    for (size_t ri = 0; ri < recs.size(); ri++) {
+        const IntraRec &r = recs[ri];
+        if (level[r.cu] < 2) continue;
+        int cnt = 0;
+        uint32_t parent = NONE;
+        for (uint32_t d = r.dep_first; d < r.dep_first + r.dep_count; d++) if (level[deps[d]] >= 2) { cnt++; parent = deps[d]; }
+        static const bool no_strands = getenv("XEVD_HIP_NO_STRANDS") != NULL;      // A/B measurements
+        if (cnt != 1 || no_strands) continue;
+        const size_t pr = (size_t)rec_of_cu[parent];
+        if (succ[pr] == NONE) { succ[pr] = (uint32_t)ri; member[ri] = 1; }
+    }
     // sort by level (levels are 1-based; every dependency sits on a lower one), the larger CUs of a level first - a 64x64 CU is four rounds of its wave and should
-    // not be the last thing a launch starts -, decode order otherwise; then dependency CU indices -> list positions
-    auto key = [&](const IntraRec &r) { return (size_t)level[r.cu] * 16 + (size_t)(14 - (r.log2w + r.log2h)); };      // counting sort: log2w + log2h is 4 .. 14
-    std::vector<int> first(((size_t)max_level + 2) * 16, 0);
-    for (const IntraRec &r : recs) first[key(r) + 1]++;
+    // not be the last thing a launch starts -, decode order otherwise, the strand members behind everything else; then dependency CU indices -> list positions
+    auto key = [&](size_t ri) { return member[ri] ? ((size_t)max_level + 1) * 16 : (size_t)level[recs[ri].cu] * 16 + (size_t)(14 - (recs[ri].log2w + recs[ri].log2h)); };      // counting sort: log2w + log2h is 4 .. 14
+    std::vector<int> first(((size_t)max_level + 3) * 16, 0);
+    for (size_t ri = 0; ri < recs.size(); ri++) first[key(ri) + 1]++;
     for (size_t l = 1; l < first.size(); l++) first[l] += first[l - 1];
     static thread_local std::vector<uint32_t> pos;
     pos.assign((size_t)n, NONE);
     plan.recs.resize(recs.size());
-    for (const IntraRec &r : recs) { const int k = first[key(r)]++; pos[r.cu] = (uint32_t)k; plan.recs[(size_t)k] = r; }
+    for (size_t ri = 0; ri < recs.size(); ri++) { const int k = first[key(ri)]++; pos[recs[ri].cu] = (uint32_t)k; plan.recs[(size_t)k] = recs[ri]; }
     for (uint32_t &d : deps) d = pos[d];
     plan.deps.swap(deps);
     plan.n_levels = max_level;
-    plan.n_level1 = 0;
-    for (const IntraRec &r : plan.recs) plan.n_level1 += level[r.cu] == 1;
+    plan.n_level1 = 0; plan.n_heads = 0;
+    for (size_t ri = 0; ri < recs.size(); ri++) { plan.n_level1 += level[recs[ri].cu] == 1; plan.n_heads += !member[ri]; }
     PT("sort");
-    // level-1 CUs are finished by their own launch before the data-flow launch starts: drop them from the waiting lists
-    for (IntraRec &r : plan.recs) {
+    // level-1 CUs are finished by their own launch before the data-flow launch starts: drop them from the waiting lists; a strand member waits for nobody (its one
+    // dependency of the launch is the CU its wave has just finished)
+    for (size_t ri = 0; ri < recs.size(); ri++) {
+        IntraRec &r = plan.recs[pos[recs[ri].cu]];
         uint32_t k = r.dep_first;
-        for (uint32_t d = r.dep_first; d < r.dep_first + r.dep_count; d++)
-            if (plan.deps[d] >= (uint32_t)plan.n_level1) plan.deps[k++] = plan.deps[d];
+        if (!member[ri])
+            for (uint32_t d = r.dep_first; d < r.dep_first + r.dep_count; d++)
+                if (plan.deps[d] >= (uint32_t)plan.n_level1) plan.deps[k++] = plan.deps[d];
         r.dep_count = k - r.dep_first;
     }
+    // the device reads the successor's list position where the host kept the CU index
+    for (size_t ri = 0; ri < recs.size(); ri++) plan.recs[pos[recs[ri].cu]].cu = succ[ri] == NONE ? NONE : pos[recs[succ[ri]].cu];
     return true;
 }
 
@@ -887,7 +909,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     }
 
     IntraPlan plan;
-    plan.n_levels = 0; plan.n_level1 = 0;
+    plan.n_levels = 0; plan.n_level1 = 0; plan.n_heads = 0;
     bool any_intra = false;
     plan.has_ibc = false; plan.has_htdf = false;
     // SCU -> CU map of the picture (k_inter's lanes find their CU through it; the dependency plan reads "reconstructed before" off it); SCUs outside the batch -
@@ -916,7 +938,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
 
     xgpu_dbatch *db = new xgpu_dbatch();
     memset(db, 0, sizeof(*db));
-    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->n_dmvr = n_dmvr; db->has_ibc = plan.has_ibc ? 1 : 0; db->has_htdf = plan.has_htdf ? 1 : 0;
+    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_intra_heads = plan.n_heads; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->n_dmvr = n_dmvr; db->has_ibc = plan.has_ibc ? 1 : 0; db->has_htdf = plan.has_htdf ? 1 : 0;
     db->tile_starts = tmask; db->tiles_across = b->tiles ? (b->tiles->loop_filter_across_tiles ? 1 : 0) : 1;
     const size_t sz_cus = sizeof(CuRec) * (size_t)std::max(n, 1), sz_ctu = sizeof(uint32_t) * (size_t)(b->n_ctu + 1);
     const size_t sz_tbs = sizeof(TbRec) * (size_t)std::max(n_tb, 1), sz_wv = sizeof(TbWave) * (size_t)std::max(n_waves, 1);
@@ -1216,7 +1238,7 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
         ta.done = db->d_intra_done; ta.n_intra = db->n_intra;
         ta.epoch = ++db->intra_epoch;                      // flags are compared against the epoch: no reset between pictures
         ta.ticket_base = db->intra_tickets;                // the counter keeps running: a launch draws one ticket per workgroup
-        const int n_dep = db->n_intra - db->n_intra_l1;
+        const int n_dep = db->n_intra_heads - db->n_intra_l1;      // strand heads: the members behind them in the list are reached through their parents
         TIMED(c, XGPU_K_INTRA, {
             // the next picture's residual pass rides in the data-flow launch (not while single kernels are being timed; HTDF's workgroups are a different shape)
             ItdqArgs na;

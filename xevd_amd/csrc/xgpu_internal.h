@@ -265,7 +265,7 @@ struct xgpu_dbatch {
     int        has_ibc, has_htdf;     // the intra list holds intra-block-copy CUs / HTDF nodes
     TileMask   tile_starts;           // of the batch's tile grid (zero: one tile)
     int        tiles_across;          // its loop_filter_across_tiles
-    int        n_intra, n_levels, n_intra_deps, n_intra_l1;      // n_intra_l1: CUs of level 1 (head of the list)
+    int        n_intra, n_levels, n_intra_deps, n_intra_l1, n_intra_heads;      // n_intra_l1: CUs of level 1 (head of the list); n_intra_heads: + the strand heads of the data-flow launch (the strand members follow)
     uint32_t   intra_epoch, intra_tickets;
     void      *h_stage;               // pinned staging block
     size_t     stage_bytes;
