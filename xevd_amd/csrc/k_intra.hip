@@ -89,11 +89,15 @@ __device__ __forceinline__ void st_coherent2(int16_t *p, uint32_t lo, uint32_t h
 // ---------------------------------------------------------------------------------------------------------
 struct EipdPlan { int mode, p0, p1, p2; };      // wave-uniform: DC p0 = value; planar p0 = base, p1 = b, p2 = c; bilinear p0 = a, p1 = b, p2 = wt; angular p0 = dx, p1 = dy
 
+// sum over the 64 lanes, the same value in every lane: two quad permutes and two mirrors in DPP leave every lane of a row of 16 with the row's sum, the four row
+// sums meet on the scalar unit (six rounds of __shfl_xor were six LDS-crossbar round trips on the critical path of every DC / planar CU of a dependency chain)
 __device__ __forceinline__ int wave_sum(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);     // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);     // row_mirror
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
 }
 __device__ __forceinline__ void ang_slopes(int mode, int &dx, int &dy)      // xevd_tbl_ipred_dxdy (xevd_tbl.c:294-304): slopes in 1/1024
 {
@@ -396,8 +400,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
             if (mode == 0) {
                 int acc = 0;
                 for (int e = t; e < w + h; e += 64) acc += e < h ? nb[c][NB_C0 - 1 - e] : nb[c][NB_C0 + 1 + e - h];
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+                acc = wave_sum(acc);
                 if (t == 0) nb[c][NB_DC] = (int16_t)((acc + w) >> ((c ? lw - 1 : lw) + 1));
             } else if (mode == 4) {
                 for (int e = t; e < w + h; e += 64) nb[c][NB_UR + e] = (int16_t)((nb[c][NB_C0 + 1 + e] + nb[c][NB_C0 - 1 - e]) >> 1);
