@@ -20,9 +20,13 @@ def main():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--main", action="store_true", help="Main profile: EIPD predictors, IQT, ADDB, ALF")
     ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--mode", type=int, default=-1, help="every CU with this luma mode (chroma: derived mode) - isolates the cost of a predictor from the cost of the chain")
     a = ap.parse_args()
     tools = {"eipd": 1, "addb": 1, "alf": 1} if a.main else None
     cs = cases.build_case("all_intra", a.width, a.height, 10 if a.main else 8, 1 if a.main else 0, 1 if a.main else 0, (1, 0), 0.0, tools=tools, inter_frac=0.0)
+    if a.mode >= 0:
+        cs["batch"]["ipm"][:, 0] = a.mode
+        cs["batch"]["ipm"][:, 1] = 0
     with XgpuDecoder(cs["w"], cs["h"], cs["bd"], iqt=cs["iqt"], admvp=cs["admvp"], addb=cs.get("addb", 0), alf=cs.get("alf", 0), eipd=cs.get("eipd", 0), max_pics=4) as dec:
         cur = dec.pic_alloc()
         hb = dec.batch_create(cs["batch"])

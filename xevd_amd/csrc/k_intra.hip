@@ -275,7 +275,27 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
 #pragma unroll
                     for (int r = 0; r < 2; r++) rc[c - 1][r] = *(const uint32_t *)(a.resid + (c == 1 ? off_u : off_v) + ((ly >> 1) + r) * cwc + (lx >> 1));
         };
-        if (t < nscu) fetch_resid((t % scuw) << 2, (t / scuw) << 2);
+        // EIPD instantiations work in UNITS instead of SCUs: unit u = the row of four luma samples at (4 * (u % scuw), u / scuw) and one pair of chroma samples
+        // (4:2:0: as many pairs as luma rows - U in the first half of the units, V in the second, row-major).  A lane of the SCU mapping evaluates 24 predictor
+        // samples one after another - at the ~35 instructions of an angular sample 1.5 us in which a 4x4 CU keeps one lane busy and a 16x16 CU sixteen; a chain of
+        // small CUs (an all-intra picture is one) pays that per link.  With units a CU up to 16x16 is one step of six samples per lane, and the loop body holds six
+        // inlined predictors instead of 24.  The residual of a unit is contiguous (luma at 4 u, chroma at 2 v): up to four units per lane are requested at once.
+        const int nunit = nscu << 2, uhalf = nscu << 1;
+        uint2 ul[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
+        uint32_t uc[4] = { 0, 0, 0, 0 };
+        auto fetch_units = [&](int u0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int u = u0 + 64 * k, c = u >= uhalf ? 1 : 0;
+                ul[k] = make_uint2(0, 0); uc[k] = 0;
+                if (u < nunit) {
+                    if (cbf & 1) ul[k] = *(const uint2 *)(a.resid + coef_off + 4 * u);
+                    if ((cbf >> (1 + c)) & 1) uc[k] = *(const uint32_t *)(a.resid + (c ? off_v : off_u) + 2 * (u - (c ? uhalf : 0)));
+                }
+            }
+        };
+        if (EIPD) fetch_units(t);
+        else if (t < nscu) fetch_resid((t % scuw) << 2, (t / scuw) << 2);
 
         if (DEP) {      // wait until the intra CUs this one reads from have published their samples
             for (uint32_t d = t; d < dep_count; d += 64) {
@@ -409,6 +429,50 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
         }
         wave_lds_sync();
         // ---- prediction + reconstruction, one 4x4 SCU per lane and step ----
+        if (EIPD) {
+        const int maxc = (1 << a.bd_c) - 1, lsw = lw - 2;
+        for (int u0 = t; u0 - t < (htdf_only ? 0 : nunit); u0 += 256) {
+            uint2 cl[4] = { ul[0], ul[1], ul[2], ul[3] };
+            uint32_t cc[4] = { uc[0], uc[1], uc[2], uc[3] };
+            if (u0 - t + 256 < nunit) fetch_units(u0 + 256);
+            const int steps = min(4, (nunit - (u0 - t) + 63) >> 6);
+#pragma unroll 1
+            for (int k = 0; k < steps; k++) {
+                const int u = u0 + 64 * k;
+                if (u < nunit) {
+                    const int c = u >= uhalf ? 1 : 0, v = u - (c ? uhalf : 0);
+                    const int lx = (u & (scuw - 1)) << 2, ly = u >> lsw, cx = (v & (scuw - 1)) << 1, cy = v >> lsw;
+                    int pl[4], pc[2];
+                    if (IBC && ibc_cu) {
+                        // xevdm_IBC_mc (xevdm_mc.c:2040-2106): the block at the whole-sample vector in the current picture, chroma at the halved vector
+                        auto ldw = [&](const int16_t *p) -> uint32_t { return DEP ? ld_coherent(p) : *(const uint32_t *)p; };
+                        const int sxl = cu_x + lx + bvx, ol_ = sxl & 1, sxc = (cu_x >> 1) + cx + (bvx >> 1), oc_ = sxc & 1;
+                        const int16_t *src = a.cur_y + (cu_y + ly + bvy) * a.s_l + (sxl - ol_);
+                        const int16_t *sc = (c ? a.cur_v : a.cur_u) + ((cu_y >> 1) + cy + (bvy >> 1)) * a.s_c + (sxc - oc_);
+                        const uint32_t d0 = ldw(src), d1 = ldw(src + 2), d2 = ldw(src + 4), e0 = ldw(sc), e1 = ldw(sc + 2);      // (the third dword only serves an odd vector; it lies inside the padded picture)
+                        const uint32_t o0 = ol_ ? (d0 >> 16) | (d1 << 16) : d0, o1 = ol_ ? (d1 >> 16) | (d2 << 16) : d1, oc0 = oc_ ? (e0 >> 16) | (e1 << 16) : e0;
+                        pl[0] = (int)(o0 & 0xFFFF); pl[1] = (int)(o0 >> 16); pl[2] = (int)(o1 & 0xFFFF); pl[3] = (int)(o1 >> 16);
+                        pc[0] = (int)(oc0 & 0xFFFF); pc[1] = (int)(oc0 >> 16);
+                    } else {
+                        const EipdPlan kc = { plan[1].mode, c ? plan[2].p0 : plan[1].p0, c ? plan[2].p1 : plan[1].p1, c ? plan[2].p2 : plan[1].p2 };
+#pragma unroll
+                        for (int q = 0; q < 4; q++) pl[q] = eipd_sample(nb[0], plan[0], lx + q, ly, cw, chh, lw, lh, maxv);
+#pragma unroll
+                        for (int q = 0; q < 2; q++) pc[q] = eipd_sample(nb[1 + c], kc, cx + q, cy, cw >> 1, chh >> 1, lw - 1, lh - 1, maxc);
+                    }
+                    // also without coefficients: the reference clips the prediction (xevd_recon.c:44-51); the luma depth clips chroma too (:75-90)
+                    const uint32_t o0 = recon2i(pack2i(pl[0], pl[1]), (cbf & 1) ? cl[0].x : 0u, maxv), o1 = recon2i(pack2i(pl[2], pl[3]), (cbf & 1) ? cl[0].y : 0u, maxv);
+                    const uint32_t o2 = recon2i(pack2i(pc[0], pc[1]), ((cbf >> (1 + c)) & 1) ? cc[0] : 0u, maxv);
+                    int16_t *dy = a.cur_y + (cu_y + ly) * a.s_l + cu_x + lx, *dc = (c ? a.cur_v : a.cur_u) + ((cu_y >> 1) + cy) * a.s_c + (cu_x >> 1) + cx;
+                    // local dual tree: a chroma-only CU (flag 32) leaves luma alone, a luma-only one (64) chroma
+                    if (!(nflags & 32u)) { if (DEP) st_coherent2(dy, o0, o1); else *(uint2 *)dy = make_uint2(o0, o1); }
+                    if (!(nflags & 64u)) { if (DEP) st_coherent(dc, o2); else *(uint32_t *)dc = o2; }
+                }
+                cl[0] = cl[1]; cl[1] = cl[2]; cl[2] = cl[3];
+                cc[0] = cc[1]; cc[1] = cc[2]; cc[2] = cc[3];
+            }
+        }
+        } else
         for (int sidx = t; sidx < (htdf_only ? 0 : nscu); sidx += 64) {
             const int lx = (sidx % scuw) << 2, ly = (sidx / scuw) << 2;
             const int x = cu_x + lx, y = cu_y + ly;
@@ -441,19 +505,6 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
                         pc[c][r][0] = (int)(o0 & 0xFFFF); pc[c][r][1] = (int)(o0 >> 16);
                     }
                 }
-            } else if (EIPD) {
-                const int maxc = (1 << a.bd_c) - 1;
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-#pragma unroll
-                    for (int q = 0; q < 4; q++) pl[r][q] = eipd_sample(nb[0], plan[0], lx + q, ly + r, cw, chh, lw, lh, maxv);
-#pragma unroll
-                for (int c = 0; c < 2; c++)
-#pragma unroll
-                    for (int r = 0; r < 2; r++)
-#pragma unroll
-                        for (int q = 0; q < 2; q++)
-                            pc[c][r][q] = eipd_sample(nb[1 + c], plan[1 + c], (lx >> 1) + q, (ly >> 1) + r, cw >> 1, chh >> 1, lw - 1, lh - 1, maxc);
             } else {
             // all LDS reads of the SCU first (one wait), then the arithmetic, then the stores
             int vl[7], vc[2][3];
