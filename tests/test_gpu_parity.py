@@ -186,6 +186,20 @@ def test_gpu_all_intra_1080p_vs_oracle():
         assert np.array_equal(out[c], ref.bufs[c]), f"plane {c}"
 
 
+def test_gpu_intra_per_ctu_launch_option():
+    """XEVD_HIP_INTRA_CTU=1: graphs without IBC / HTDF nodes go through k_intra_ctu (one workgroup per CTU, the CTU in LDS) instead of the level-1 + data-flow
+    launches - an option (measured slower), same pictures.  The knob is read once per process: the golden pictures (Baseline and EIPD predictors, local
+    dual trees, constrained intra prediction, CTU 128, tiles) and the 1080p all-intra picture (three times from the resident batch) run in a child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, XEVD_HIP_INTRA_CTU="1")
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(here, "test_gpu_parity.py"),
+                        "-k", "test_gpu_pictures_golden or test_gpu_all_intra_1080p_vs_oracle or test_gpu_vs_oracle_random"],
+                       env=env, cwd=os.path.dirname(here), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-3000:]
+
+
 def test_gpu_ibc_intra_1080p_vs_oracle():
     """a 1080p picture of intra and intra-block-copy CUs only (Main, EIPD, ADDB): IBC CUs wait for the CUs under their source block, intra CUs for
     their neighbours - one dependency graph through the data-flow kernel; decoded three times from the resident batch"""
