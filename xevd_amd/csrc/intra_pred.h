@@ -157,6 +157,63 @@ __device__ __forceinline__ int eipd_sample(const int16_t *A, const EipdPlan &k, 
     return clip3i(0, maxv, (r0 * (32 - o) + r1 * (64 - o) + r2 * (32 + o) + r3 * o + 64) >> 7);
 }
 
+// N consecutive samples of row j from column i0: eipd_sample for each of them with the mode looked at once (eipd_sample's chain of uniform branches per sample
+// was most of a prediction step: a lone wave pays every taken branch in full), and for the vertical angular modes (3 .. 11) one offset / one filter phase per row
+// and N + 3 reference reads instead of 4 N.  Same arithmetic, sample for sample.
+template <int N>
+__device__ __forceinline__ void eipd_row(const int16_t *A, const EipdPlan &k, int i0, int j, int w, int h, int lw, int lh, int maxv, int out[N])
+{
+    const int mode = k.mode, hi = w + h - 1;
+    if (mode == 12) {
+#pragma unroll
+        for (int q = 0; q < N; q++) out[q] = A[NB_C0 + 1 + i0 + q];
+    } else if (mode == 24) {
+        const int v = A[NB_C0 - 1 - j];
+#pragma unroll
+        for (int q = 0; q < N; q++) out[q] = v;
+    } else if (mode == 0) {
+#pragma unroll
+        for (int q = 0; q < N; q++) out[q] = k.p0;
+    } else if (mode == 1) {
+        const int base = k.p0 + j * k.p2 + i0 * k.p1;
+#pragma unroll
+        for (int q = 0; q < N; q++) out[q] = clip3i(0, maxv, (base + q * k.p1) >> 5);
+    } else if (mode == 2) {
+        const int le = A[NB_C0 - 1 - j];
+#pragma unroll
+        for (int q = 0; q < N; q++) {
+            const int i = i0 + q, u = A[NB_C0 + 1 + i];
+            const int px = (le << lw) + (i + 1) * (k.p0 - le), py = (u << lh) + (j + 1) * (k.p1 - u);
+            out[q] = clip3i(0, maxv, ((px << lh) + (py << lw) + i * j * k.p2 + (1 << (lw + lh))) >> (lw + lh + 1));
+        }
+    } else if (mode < 12) {
+        const int tt = (j + 1) * k.p0, o = (tt >> 5) & 31, p0 = i0 + (tt >> 10) - 1;
+        int r[N + 3];
+#pragma unroll
+        for (int m = 0; m < N + 3; m++) r[m] = A[NB_C0 + 1 + clip3i(-1, hi, p0 + m)];
+#pragma unroll
+        for (int q = 0; q < N; q++) out[q] = clip3i(0, maxv, (r[q] * (32 - o) + r[q + 1] * (64 - o) + r[q + 2] * (32 + o) + r[q + 3] * o + 64) >> 7);
+    } else if (mode > 24) {
+#pragma unroll
+        for (int q = 0; q < N; q++) {
+            const int tt = (i0 + q + 1) * k.p1, p = j + (tt >> 10), o = (tt >> 5) & 31;
+            const int r0 = A[NB_C0 - 1 - clip3i(-1, hi, p - 1)], r1 = A[NB_C0 - 1 - clip3i(-1, hi, p)], r2 = A[NB_C0 - 1 - clip3i(-1, hi, p + 1)], r3 = A[NB_C0 - 1 - clip3i(-1, hi, p + 2)];
+            out[q] = clip3i(0, maxv, (r0 * (32 - o) + r1 * (64 - o) + r2 * (32 + o) + r3 * o + 64) >> 7);
+        }
+    } else {
+        const int tx = (j + 1) * k.p0;
+#pragma unroll
+        for (int q = 0; q < N; q++) {
+            const int i = i0 + q, ty = (i + 1) * k.p1;
+            const bool from_up = j < (ty >> 10);
+            const int p = from_up ? i - (tx >> 10) : j - (ty >> 10), o = ((from_up ? tx : ty) >> 5) & 31, sgn = from_up ? 1 : -1;
+            const int r0 = A[NB_C0 + sgn * (1 + clip3i(-1, hi, p + 1))], r1 = A[NB_C0 + sgn * (1 + clip3i(-1, hi, p))];
+            const int r2 = A[NB_C0 + sgn * (1 + clip3i(-1, hi, p - 1))], r3 = A[NB_C0 + sgn * (1 + clip3i(-1, hi, p - 2))];
+            out[q] = clip3i(0, maxv, (r0 * (32 - o) + r1 * (64 - o) + r2 * (32 + o) + r3 * o + 64) >> 7);
+        }
+    }
+}
+
 __device__ __forceinline__ void wave_lds_sync()      // LDS traffic of one wave is processed in order: only the compiler needs the fence
 {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

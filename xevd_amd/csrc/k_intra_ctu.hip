@@ -312,10 +312,8 @@ __global__ __launch_bounds__(64 * CTU_WAVES) void k_intra_ctu(const IntraArgs a,
                         const int lx = (u & (scuw - 1)) << 2, ly = u >> lsw, cx = (v & (scuw - 1)) << 1, cy = v >> lsw;
                         const EipdPlan kc = { plan[1].mode, c ? plan[2].p0 : plan[1].p0, c ? plan[2].p1 : plan[1].p1, c ? plan[2].p2 : plan[1].p2 };
                         int pl[4], pc[2];
-#pragma unroll
-                        for (int q = 0; q < 4; q++) pl[q] = eipd_sample(nb[0], plan[0], lx + q, ly, cw, chh, lw, lh, maxv);
-#pragma unroll
-                        for (int q = 0; q < 2; q++) pc[q] = eipd_sample(nb[1 + c], kc, cx + q, cy, cw >> 1, chh >> 1, lw - 1, lh - 1, maxc);
+                        eipd_row<4>(nb[0], plan[0], lx, ly, cw, chh, lw, lh, maxv, pl);
+                        eipd_row<2>(nb[1 + c], kc, cx, cy, cw >> 1, chh >> 1, lw - 1, lh - 1, maxc, pc);
                         // also without coefficients: the reference clips the prediction (xevd_recon.c:44-51); the luma depth clips chroma too (:75-90)
                         const uint32_t o0 = recon2i(pack2i(pl[0], pl[1]), (cbf & 1) ? cl[0].x : 0u, maxv), o1 = recon2i(pack2i(pl[2], pl[3]), (cbf & 1) ? cl[0].y : 0u, maxv);
                         const uint32_t o2 = recon2i(pack2i(pc[0], pc[1]), ((cbf >> (1 + c)) & 1) ? cq[0] : 0u, maxv);
