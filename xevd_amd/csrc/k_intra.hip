@@ -122,6 +122,10 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
         // small CUs (an all-intra picture is one) pays that per link.  With units a CU up to 16x16 is one step of six samples per lane, and the loop body holds six
         // inlined predictors instead of 24.  The residual of a unit is contiguous (luma at 4 u, chroma at 2 v): up to four units per lane are requested at once.
         const int nunit = nscu << 2, uhalf = nscu << 1;
+        // parts: a large CU sits in the list several times (the host's plan, xgpu_api.hip: one entry per step of 64 units / SCUs, each with its own done flag); every part
+        // stages the neighbours and derives the plan, and reconstructs the units [u_lo, u_hi) / the SCUs [s_lo, s_hi)
+        const int part = (int)(m >> 24), nparts = max(1, (int)((ipm >> 16) & 0xFF));
+        const int u_lo = part * (nunit / nparts), u_hi = u_lo + nunit / nparts, s_lo = part * (nscu / nparts), s_hi = s_lo + nscu / nparts;
         uint2 ul[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
         uint32_t uc[4] = { 0, 0, 0, 0 };
         auto fetch_units = [&](int u0) {
@@ -129,14 +133,14 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
             for (int k = 0; k < 4; k++) {
                 const int u = u0 + 64 * k, c = u >= uhalf ? 1 : 0;
                 ul[k] = make_uint2(0, 0); uc[k] = 0;
-                if (u < nunit) {
+                if (u < u_hi) {
                     if (cbf & 1) ul[k] = *(const uint2 *)(a.resid + coef_off + 4 * u);
                     if ((cbf >> (1 + c)) & 1) uc[k] = *(const uint32_t *)(a.resid + (c ? off_v : off_u) + 2 * (u - (c ? uhalf : 0)));
                 }
             }
         };
-        if (EIPD) fetch_units(t);
-        else if (t < nscu) fetch_resid((t % scuw) << 2, (t / scuw) << 2);
+        if (EIPD) fetch_units(u_lo + t);
+        else if (s_lo + t < s_hi) fetch_resid(((s_lo + t) % scuw) << 2, ((s_lo + t) / scuw) << 2);
 
         if (DEP) {      // wait until the intra CUs this one reads from have published their samples
             for (uint32_t d = t; d < dep_count; d += 64) {
@@ -272,16 +276,16 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
         // ---- prediction + reconstruction, one 4x4 SCU per lane and step ----
         if (EIPD) {
         const int maxc = (1 << a.bd_c) - 1, lsw = lw - 2;
-        for (int ub = 0; ub < (htdf_only ? 0 : nunit); ub += 256) {      // (a scalar loop counter: the trip counts below stay on the scalar unit)
+        for (int ub = u_lo; ub < (htdf_only ? 0 : u_hi); ub += 256) {      // (a scalar loop counter: the trip counts below stay on the scalar unit)
             const int u0 = ub + t;
             uint2 cl[4] = { ul[0], ul[1], ul[2], ul[3] };
             uint32_t cc[4] = { uc[0], uc[1], uc[2], uc[3] };
-            if (ub + 256 < nunit) fetch_units(u0 + 256);
-            const int steps = min(4, (nunit - ub + 63) >> 6);
+            if (ub + 256 < u_hi) fetch_units(u0 + 256);
+            const int steps = min(4, (u_hi - ub + 63) >> 6);
 #pragma unroll 1
             for (int k = 0; k < steps; k++) {
                 const int u = u0 + 64 * k;
-                if (u < nunit) {
+                if (u < u_hi) {
                     const int c = u >= uhalf ? 1 : 0, v = u - (c ? uhalf : 0);
                     const int lx = (u & (scuw - 1)) << 2, ly = u >> lsw, cx = (v & (scuw - 1)) << 1, cy = v >> lsw;
                     int pl[4], pc[2];
@@ -313,14 +317,14 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
             }
         }
         } else
-        for (int sidx = t; sidx < (htdf_only ? 0 : nscu); sidx += 64) {
+        for (int sidx = s_lo + t; sidx < (htdf_only ? 0 : s_hi); sidx += 64) {
             const int lx = (sidx % scuw) << 2, ly = (sidx / scuw) << 2;
             const int x = cu_x + lx, y = cu_y + ly;
             // a CU above 32x32 takes several rounds: the residual of the NEXT round is requested before this round's arithmetic, so that a round does not
             // start with a memory round trip (the level-1 launch is as long as its 64x64 CUs take)
             const uint2 rl_cur[4] = { rl[0], rl[1], rl[2], rl[3] };
             const uint32_t rc_cur[2][2] = { { rc[0][0], rc[0][1] }, { rc[1][0], rc[1][1] } };
-            if (sidx + 64 < nscu) fetch_resid(((sidx + 64) % scuw) << 2, ((sidx + 64) / scuw) << 2);
+            if (sidx + 64 < s_hi) fetch_resid(((sidx + 64) % scuw) << 2, ((sidx + 64) / scuw) << 2);
             int pl[4][4], pc[2][2][2];
             if (IBC && ibc_cu) {
                 // xevdm_IBC_mc (xevdm_mc.c:2040-2106): the block at the whole-sample vector in the current picture, chroma at the halved vector.

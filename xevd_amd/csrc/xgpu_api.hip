@@ -756,6 +756,16 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     }
     // Strands (k_intra.hip): a CU of level 2 and up whose dependency list holds exactly ONE CU of level 2 and up (the others are level-1 CUs, complete before the
     // data-flow launch) is linked to that CU when it has no successor yet; the wave that reconstructs the parent continues with it.
+    // Parts (k_intra.hip): a wave takes 64 units (EIPD: rows of four luma samples + a chroma pair) or 64 SCUs (Baseline predictors) of its CU per step, a 64x64 CU is 16 (4) steps
+    // of one wave - on the critical path of every chain through it, and the level-1 launch is as long as its largest CUs take.  Such a CU goes into the list as several entries,
+    // one per step (at most 16), each with its own done flag: every part stages the neighbours and derives the plan itself and reconstructs its share; whoever reads the CU waits
+    // for all parts.  Not for HTDF / IBC nodes (the filter stage works on the whole block).  XEVD_HIP_NO_PARTS=1: A/B measurements.
+    static const bool no_parts = getenv("XEVD_HIP_NO_PARTS") != NULL;
+    auto parts_of = [&](const IntraRec &r) -> int {
+        if (no_parts || (r.flags & (2u | 4u | 8u))) return 1;
+        const int nscu = 1 << (r.log2w + r.log2h - 4), steps = (c->sp.tool_eipd ? nscu * 4 : nscu) / 64;
+        return std::max(1, std::min(steps, 16));
+    };
     std::vector<int32_t> rec_of_cu((size_t)n, -1);
     for (size_t ri = 0; ri < recs.size(); ri++) rec_of_cu[recs[ri].cu] = (int32_t)ri;
     std::vector<uint32_t> succ(recs.size(), NONE);
@@ -769,36 +779,53 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         static const bool no_strands = getenv("XEVD_HIP_NO_STRANDS") != NULL;      // A/B measurements
         if (cnt != 1 || no_strands) continue;
         const size_t pr = (size_t)rec_of_cu[parent];
+        if (parts_of(r) > 1 || parts_of(recs[pr]) > 1) continue;
         if (succ[pr] == NONE) { succ[pr] = (uint32_t)ri; member[ri] = 1; }
     }
     // sort by level (levels are 1-based; every dependency sits on a lower one), the larger CUs of a level first - a 64x64 CU is four rounds of its wave and should
     // not be the last thing a launch starts -, decode order otherwise, the strand members behind everything else; then dependency CU indices -> list positions
     auto key = [&](size_t ri) { return member[ri] ? ((size_t)max_level + 1) * 16 : (size_t)level[recs[ri].cu] * 16 + (size_t)(14 - (recs[ri].log2w + recs[ri].log2h)); };      // counting sort: log2w + log2h is 4 .. 14
     std::vector<int> first(((size_t)max_level + 3) * 16, 0);
-    for (size_t ri = 0; ri < recs.size(); ri++) first[key(ri) + 1]++;
+    size_t n_entries = 0;
+    for (size_t ri = 0; ri < recs.size(); ri++) { const int np = parts_of(recs[ri]); first[key(ri) + 1] += np; n_entries += (size_t)np; }
     for (size_t l = 1; l < first.size(); l++) first[l] += first[l - 1];
-    static thread_local std::vector<uint32_t> pos;
+    static thread_local std::vector<uint32_t> pos;                    // CU index -> list position of its first part
     pos.assign((size_t)n, NONE);
-    plan.recs.resize(recs.size());
-    for (size_t ri = 0; ri < recs.size(); ri++) { const int k = first[key(ri)]++; pos[recs[ri].cu] = (uint32_t)k; plan.recs[(size_t)k] = recs[ri]; }
-    for (uint32_t &d : deps) d = pos[d];
-    plan.deps.swap(deps);
-    plan.n_levels = max_level;
+    plan.recs.resize(n_entries);
     plan.n_level1 = 0; plan.n_heads = 0;
-    for (size_t ri = 0; ri < recs.size(); ri++) { plan.n_level1 += level[recs[ri].cu] == 1; plan.n_heads += !member[ri]; }
-    PT("sort");
-    // level-1 CUs are finished by their own launch before the data-flow launch starts: drop them from the waiting lists; a strand member waits for nobody (its one
-    // dependency of the launch is the CU its wave has just finished)
     for (size_t ri = 0; ri < recs.size(); ri++) {
-        IntraRec &r = plan.recs[pos[recs[ri].cu]];
-        uint32_t k = r.dep_first;
-        if (!member[ri])
-            for (uint32_t d = r.dep_first; d < r.dep_first + r.dep_count; d++)
-                if (plan.deps[d] >= (uint32_t)plan.n_level1) plan.deps[k++] = plan.deps[d];
-        r.dep_count = k - r.dep_first;
+        const int np = parts_of(recs[ri]), k = first[key(ri)];
+        first[key(ri)] += np;
+        pos[recs[ri].cu] = (uint32_t)k;
+        for (int q = 0; q < np; q++) { IntraRec &o = plan.recs[(size_t)k + q]; o = recs[ri]; o.pad0 = (uint8_t)q; o.pad1[0] = (uint8_t)np; }
+        if (level[recs[ri].cu] == 1) plan.n_level1 += np;
+        if (!member[ri]) plan.n_heads += np;
     }
-    // the device reads the successor's list position where the host kept the CU index
-    for (size_t ri = 0; ri < recs.size(); ri++) plan.recs[pos[recs[ri].cu]].cu = succ[ri] == NONE ? NONE : pos[recs[succ[ri]].cu];
+    plan.n_levels = max_level;
+    PT("sort");
+    // dependency CU indices -> list positions, every part of a CU that has parts.  Level-1 CUs are finished by their own launch before the data-flow launch starts: they drop
+    // out of the waiting lists; a strand member waits for nobody (its one dependency of the launch is the CU its wave has just finished)
+    std::vector<uint32_t> ndeps;
+    ndeps.reserve(deps.size() + deps.size() / 4);
+    for (size_t ri = 0; ri < recs.size(); ri++) {
+        const IntraRec &r = recs[ri];
+        const uint32_t nf = (uint32_t)ndeps.size();
+        if (!member[ri])
+            for (uint32_t d = r.dep_first; d < r.dep_first + r.dep_count; d++) {
+                const uint32_t j = deps[d], pj = pos[j];
+                if (pj < (uint32_t)plan.n_level1) continue;
+                const int np = parts_of(recs[(size_t)rec_of_cu[j]]);
+                for (int q = 0; q < np; q++) ndeps.push_back(pj + (uint32_t)q);
+            }
+        const int np = parts_of(r);
+        for (int q = 0; q < np; q++) {
+            IntraRec &o = plan.recs[(size_t)pos[r.cu] + q];
+            o.dep_first = nf; o.dep_count = (uint32_t)ndeps.size() - nf;
+            // the device reads the successor's list position where the host kept the CU index
+            o.cu = succ[ri] == NONE ? NONE : pos[recs[succ[ri]].cu];
+        }
+    }
+    plan.deps.swap(ndeps);
     return true;
 }
 
