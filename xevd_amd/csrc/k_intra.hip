@@ -56,6 +56,16 @@ template <bool HTDF> struct IntraLds { static constexpr int WAVE = (HTDF && HTDF
 
 // The work of one workgroup of WAVES waves; `block` = its position in the launch (static assignment, DEP = false).  s_nb = WAVES x IntraLds<HTDF>::WAVE samples,
 // s_lut = WAVES x 16 (HTDF only), s_chunk = one dword.
+#ifdef INTRA_PROFILE      // cycle stamps of 64 consecutive list positions of the data-flow launch (make EXTRA=-DINTRA_PROFILE=<first position>; printed by launch_intra)
+// Measured with them (all-intra 1080p Main, 2.43 GHz): per CU ~4 400 clocks of staging (per component ~1 000 of address arithmetic and load issue, 400 - 1 000 until the loads are
+// back, 150 of LDS stores), 1 100 - 1 900 of plan, 2 000 - 3 500 for a step of six samples, 270 - 800 until the stores are acknowledged: a link of a chain is ~9 000 clocks of one
+// wave's instruction latency plus ~0.7 us of flag hand-over, not memory round trips.  Tried on top and measured slower: the three components' loads in one batch (bits instead of
+// pointers kept alive: stage 5 000 - 7 000), 32-bit availability masks for CUs up to w + h = 128 (issue 1 000 -> 1 200).
+__device__ uint32_t g_intra_prof[8 * 64];
+#define ISTAMP(k) do { if (DEP && t == 0 && item >= INTRA_PROFILE && item < INTRA_PROFILE + 64) g_intra_prof[8 * (item - INTRA_PROFILE) + (k)] = (uint32_t)clock64(); } while (0)
+#else
+#define ISTAMP(k)
+#endif
 template <bool DEP, bool EIPD, bool IBC, bool HTDF, int WAVES>
 __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, int16_t *s_nb_, int (*s_lut)[16], uint32_t *s_chunk)
 {
@@ -142,6 +152,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
         if (EIPD) fetch_units(u_lo + t);
         else if (s_lo + t < s_hi) fetch_resid(((s_lo + t) % scuw) << 2, ((s_lo + t) / scuw) << 2);
 
+        ISTAMP(0);
         if (DEP) {      // wait until the intra CUs this one reads from have published their samples
             for (uint32_t d = t; d < dep_count; d += 64) {
                 const uint32_t j = a.deps[dep_first + d];
@@ -151,6 +162,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
             asm volatile("" ::: "memory");
         }
 
+        ISTAMP(1);
         // ---- neighbour staging (xevd_get_nbr_b): sample e of a side belongs to unit e / unit_size.  All loads of the first round
         //      (covers CUs up to w + h = 128) are issued before any LDS store so that they overlap ----
         if (EIPD) {
@@ -188,9 +200,13 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
                     }
                 }
                 uint32_t dc0_ = dc0, dc1_ = dc1;
+                if (c == 0) ISTAMP(6);
                 if (DEP) asm volatile("" : "+v"(dc0_), "+v"(dc1_), "+v"(du[0]), "+v"(du[1]), "+v"(du[2]), "+v"(du[3]), "+v"(dle[0]), "+v"(dle[1]), "+v"(dle[2]), "+v"(dle[3]));      // (keeps the selects out of the loads' branches)
                 const int corner_pre = pc0 ? half(pc0, dc0_) : mid;
                 const int corner = pc0 ? corner_pre : (pc1 ? half(pc1, dc1_) : mid);
+#ifdef INTRA_PROFILE
+                if (c == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ISTAMP(7); }
+#endif
 #pragma unroll
                 for (int it = 0; it < 4; it++) {
                     const int e = t + 64 * it;
@@ -248,6 +264,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
         }
         }
         wave_lds_sync();
+        ISTAMP(2);
 
         EipdPlan plan[3];
         if (EIPD) {
@@ -273,6 +290,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
         }
         }
         wave_lds_sync();
+        ISTAMP(3);
         // ---- prediction + reconstruction, one 4x4 SCU per lane and step ----
         if (EIPD) {
         const int maxc = (1 << a.bd_c) - 1, lsw = lw - 2;
@@ -493,8 +511,10 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
                 if (DEP) st_coherent(org + r * a.s_l + c, pack2i(o0, o1)); else *(uint32_t *)(org + r * a.s_l + c) = pack2i(o0, o1);
             }
         }
+        ISTAMP(4);
         if (DEP) {      // publish: the wave's sc1 stores have reached the coherence point once vmcnt drains; then the done flag
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            ISTAMP(5);
             if (t == 0) __hip_atomic_store(&a.done[item], a.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         wave_lds_sync();                                             // the next CU of this wave reuses the LDS arrays
@@ -567,4 +587,15 @@ void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf
         else                 { if (dep) LAUNCH(true, false, false, false); else LAUNCH(false, false, false, false); }
     }
 #undef LAUNCH
+#ifdef INTRA_PROFILE
+    static int shots = 0;
+    if (dep && ++shots == 5) {
+        hipStreamSynchronize(c->stream);
+        uint32_t h[8 * 64];
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_intra_prof), sizeof(h));
+        for (int i = 0; i < 64; i++)
+            fprintf(stderr, "  pos %d start %10u  wait %6u stage %5u (EIPD luma: issue %5u, return %5u) plan %5u predict %5u ack %5u\n", INTRA_PROFILE + i, h[8 * i], h[8 * i + 1] - h[8 * i],
+                    h[8 * i + 2] - h[8 * i + 1], h[8 * i + 6] - h[8 * i + 1], h[8 * i + 7] - h[8 * i + 6], h[8 * i + 3] - h[8 * i + 2], h[8 * i + 4] - h[8 * i + 3], h[8 * i + 5] - h[8 * i + 4]);
+    }
+#endif
 }
