@@ -603,6 +603,10 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
 }
 
 // ADDB deblocking + ALF of a picture in one pass: SRC = the reconstruction, DST = the output picture
+// (Round 3, measured and not kept: the NEXT picture's residual pass in this kernel's grid instead of the data-flow intra launch's - the pass's work items in groups of
+//  eight spread evenly between the groups of tiles, its LDS laid over the tile's, 78 VGPRs and six workgroups per CU as before.  The idea: this kernel is bound by VALU issue
+//  with 2 TB/s of traffic, the pass moves 107 MB with 19 us of VALU work.  Same box, ride in the intra launch / here: 8K 2679, 2718 / 2708, 2748 frames/s (+1 %),
+//  4K 8155, 8165 / 7725, 7849 (-4.5 %).)
 __global__ __launch_bounds__(256) void k_addb_alf(const AlfArgs a, const AddbArgs d, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
                                                   const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_, int16_t *__restrict__ dv_)
 {
