@@ -542,14 +542,20 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 // as well - measured nothing at 25 % and 1 - 3 % slower at 35 - 70 %: that launch is short and dense enough to be slowed down by the company.)
 #define FUSED_WAVES 4
 template <bool EIPD, bool IBC, bool IQT>
-__global__ __launch_bounds__(64 * FUSED_WAVES) void k_intra_itdq(const IntraArgs a, const ItdqArgs r, uint32_t n_intra_wg)
+__global__ __launch_bounds__(64 * FUSED_WAVES) void k_intra_itdq(const IntraArgs a, const ItdqArgs r, uint32_t n_intra_wg, uint32_t span)
 {
     constexpr int ITDQ_DW = (IQT ? ITDQ_LDS_DWORDS - ITDQ_PLANES_DWORDS / 2 : ITDQ_LDS_DWORDS) + 2 * ITDQ_MAX_G, INTRA_DW = (FUSED_WAVES * IntraLds<false>::WAVE + 1) / 2 + 4;
     __shared__ __attribute__((aligned(16))) uint32_t raw[ITDQ_DW > INTRA_DW ? ITDQ_DW : INTRA_DW];
-    if (blockIdx.x < n_intra_wg) {
+    // The chain's workgroups are spread evenly over the first `span` blocks of the grid (the host passes half of it) instead of all in front: the list is sorted by
+    // level and tickets are drawn in the order the workgroups start, so a level's CUs arrive about when the level before them is done - in front, 4 400 waves that
+    // mostly wait took half the machine's wave slots from the residual pass for the whole length of the chain, and the pass was the long pole of the launch.
+    // One box, share of the grid the chain is spread over 0 (all in front) / 25 / 50 / 75 / 100 %: 8K 2697 / 2772 / 2790 / 2792 / 2735 frames/s, 4K 8183 / 8066 / 8194 /
+    // 8068 / 7795.
+    const uint32_t before = min(n_intra_wg, (uint32_t)(((uint64_t)blockIdx.x * n_intra_wg) / span)), after = min(n_intra_wg, (uint32_t)(((uint64_t)(blockIdx.x + 1) * n_intra_wg) / span));
+    if (after > before) {
         intra_body<true, EIPD, IBC, false, FUSED_WAVES>(a, blockIdx.x, (int16_t *)raw, nullptr, raw + INTRA_DW - 1);
     } else {
-        const int wi = (int)(blockIdx.x - n_intra_wg);
+        const int wi = (int)(blockIdx.x - before);
         if (wi >= r.n_waves) return;
         uint32_t *s_rm = raw + ITDQ_DW - 2 * ITDQ_MAX_G;
         itdq_dispatch<IQT>(r, wi, raw, s_rm, s_rm + ITDQ_MAX_G);
@@ -566,7 +572,9 @@ void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf
     if (next) {
         const uint32_t n_wg = (uint32_t)((a.count + FUSED_WAVES - 1) / FUSED_WAVES);
         const dim3 g(n_wg + (uint32_t)next->n_waves), b(64 * FUSED_WAVES);
-#define LAUNCHF(E, I) do { if (next->iqt) hipLaunchKernelGGL((k_intra_itdq<E, I, true>), g, b, 0, c->stream, a, *next, n_wg); else hipLaunchKernelGGL((k_intra_itdq<E, I, false>), g, b, 0, c->stream, a, *next, n_wg); } while (0)
+        // the chain's workgroups spread evenly over the first half of the grid (k_intra_itdq)
+        const uint32_t span = std::max(n_wg, g.x / 2);
+#define LAUNCHF(E, I) do { if (next->iqt) hipLaunchKernelGGL((k_intra_itdq<E, I, true>), g, b, 0, c->stream, a, *next, n_wg, span); else hipLaunchKernelGGL((k_intra_itdq<E, I, false>), g, b, 0, c->stream, a, *next, n_wg, span); } while (0)
         if (c->sp.tool_eipd) { if (ibc) LAUNCHF(true, true); else LAUNCHF(true, false); }
         else                 { if (ibc) LAUNCHF(false, true); else LAUNCHF(false, false); }
 #undef LAUNCHF
