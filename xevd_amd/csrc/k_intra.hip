@@ -540,6 +540,8 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 // Measured at 8K (profiles/round3_*): 45 us + 39 us as two launches (43 + 55 when the residual pass ran beside the level-1 launch on a second stream,
 // with two cross-stream event waits of 6 us each), 64 us as one.  (Letting the level-1 launch carry a share of the work items too - it is 23 us of memory latency
 // as well - measured nothing at 25 % and 1 - 3 % slower at 35 - 70 %: that launch is short and dense enough to be slowed down by the company.)
+// (Round 3, measured and dropped: ONE launch for all levels - the level-1 CUs at the head of this launch's list, publishing flags like everybody else, strand
+// members waiting for their level-1 CUs - instead of the plain level-1 launch in front: bit-exact, 8K 2764 -> 2587 frames/s, 4K 8172 -> 7860, 1080p 10996 -> 11163.)
 #define FUSED_WAVES 4
 template <bool EIPD, bool IBC, bool IQT>
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_intra_itdq(const IntraArgs a, const ItdqArgs r, uint32_t n_intra_wg, uint32_t span)
