@@ -1156,9 +1156,11 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         }
     }
     });
+    // work items of the largest blocks first: an item of 64x64 blocks runs longest (two 64-point passes over 4096 samples), and what is launched last is the tail
     int w = 0;
+    for (int sz = 12; sz >= 2; sz--)
     for (int k = 0; k < NCLS; k++) {
-        if (!cls_count[k]) continue;
+        if (!cls_count[k] || ((k & 63) >> 3) + (k & 7) != sz) continue;
         const int per = itdq_group_size((k & 63) >> 3, k & 7);
         for (int f = 0; f < cls_count[k]; f += per) {
             wv[w].first = cls_first[k] + f; wv[w].count = (uint16_t)std::min(per, cls_count[k] - f);
