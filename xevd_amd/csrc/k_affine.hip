@@ -340,8 +340,8 @@ __global__ __launch_bounds__(256) void k_affine_sub(const AffineArgs a)
     aff_store_mvf(a, k, bx >> 2, by >> 2);
 }
 
-void launch_affine(xgpu_ctx *c, const AffineArgs &a)
+void launch_affine(xgpu_ctx *c, const AffineArgs &a, hipStream_t st)
 {
-    if (a.n_eif) hipLaunchKernelGGL(k_affine_eif, dim3((a.n_eif + 3) / 4), dim3(256), 0, c->stream, a);
-    if (a.n_sub) hipLaunchKernelGGL(k_affine_sub, dim3((a.n_sub + 3) / 4), dim3(256), 0, c->stream, a);
+    if (a.n_eif) hipLaunchKernelGGL(k_affine_eif, dim3((a.n_eif + 3) / 4), dim3(256), 0, st, a);
+    if (a.n_sub) hipLaunchKernelGGL(k_affine_sub, dim3((a.n_sub + 3) / 4), dim3(256), 0, st, a);
 }

@@ -609,7 +609,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(8, 8))) voi
     else     { if (h16) dmvr_block<8, 16>(a, r0, r1, isx, isy, BL, W, T, out_mv, lane);  else dmvr_block<8, 8>(a, r0, r1, isx, isy, BL, W, T, out_mv, lane); }
 }
 
-void launch_dmvr(xgpu_ctx *c, const DmvrArgs &a)
+void launch_dmvr(xgpu_ctx *c, const DmvrArgs &a, hipStream_t st)
 {
-    if (a.n_items > 0) hipLaunchKernelGGL(k_dmvr, dim3((a.n_items + 3) / 4), dim3(256), 0, c->stream, a);
+    if (a.n_items > 0) hipLaunchKernelGGL(k_dmvr, dim3((a.n_items + 3) / 4), dim3(256), 0, st, a);
 }

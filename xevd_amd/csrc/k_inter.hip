@@ -244,7 +244,24 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
         rec.y = (intra || ibc) ? 0x0000FFFFu : ((r0.z & 0xFFFFu) | ((uint32_t)ai << 16));
         rec.z = intra ? 0u : r1.x;                               // IBC keeps its block vector in list 0 (xevdm.c:1098-1110)
         rec.w = (intra || ibc) ? 0u : r1.y;
-        *(uint4 *)&a.maps[sy * a.w_scu + sx] = rec;
+        // k_affine and k_dmvr run BESIDE this kernel on another stream (xgpu_batch_recon): the vector words they write - the sub-block vectors of an affine CU's used
+        // lists, the refined vectors of a DMVR CU when the baseline filter is to see them - are theirs alone, this kernel leaves them out (the other bytes of the
+        // record are written here only)
+        bool other0 = false, other1 = false;
+        if (!intra && !ibc) {
+            if ((r1.w >> 16) & 0xFF) { other0 = refi0 >= 0; other1 = refi1 >= 0; }
+            else if (a.dmvr_to_map && (r1.w >> 24)) {
+                const int q0 = refi0 >= 0 ? (int)s_ref[refi0 * 2][1].z : 0, q1 = refi1 >= 0 ? (int)s_ref[refi1 * 2 + 1][1].z : 0;
+                other0 = other1 = dmvr_applies(a.cur_poc, q0, q1);
+            }
+        }
+        ScuRec *const mp = &a.maps[sy * a.w_scu + sx];
+        if (!other0 && !other1) *(uint4 *)mp = rec;
+        else {
+            *(uint2 *)mp = make_uint2(rec.x, rec.y);
+            if (!other0) ((uint32_t *)mp)[2] = rec.z;
+            if (!other1) ((uint32_t *)mp)[3] = rec.w;
+        }
     }
     if (intra || pred_mode == XGPU_MODE_IBC || ((r1.w >> 16) & 0xFF)) return false;   // IBC CUs are reconstructed with the intra CUs (k_intra); affine CUs: samples and sub-block vectors come from k_affine
 

@@ -175,6 +175,7 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     if (hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     if (hipEventCreateWithFlags(&c->after_inter, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+    if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     for (int i = 0; i < 2; i++)
         if (hipEventCreateWithFlags(&c->out_ready[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->out_done[i], hipEventDisableTiming) != hipSuccess)
             return fail(XGPU_ERR_UNEXPECTED);
@@ -235,6 +236,8 @@ void xgpu_close(xgpu_ctx *c)
     if (c->down_stream) (void)hipStreamDestroy(c->down_stream);
     if (c->side_stream) (void)hipStreamDestroy(c->side_stream);
     if (c->after_inter) (void)hipEventDestroy(c->after_inter);
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    if (c->join_ev) (void)hipEventDestroy(c->join_ev);
     delete c;
 }
 
@@ -1294,6 +1297,17 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
             a.refp[i][l].y = rp.y; a.refp[i][l].u = rp.u; a.refp[i][l].v = rp.v;
             a.refp[i][l].poc = i < c->fp.num_refp[l] ? c->fp.refp_poc[i][l] : 0;
         }
+    // k_dmvr and k_affine reconstruct CUs that k_inter skips, from the same references: on the side stream beside it (not while single kernels are timed).  The map records
+    // are shared: k_inter leaves the vector words those kernels write alone (k_inter.hip)
+    static const bool serial_knob = getenv("XEVD_HIP_TOOLS_SERIAL") != NULL;      // A/B measurements
+    const bool beside = !c->timing && !serial_knob && (db->n_dmvr || db->n_aff_eif + db->n_aff_sub);
+    hipStream_t tool_stream = c->stream;
+    a.dmvr_to_map = c->sp.tool_addb ? 0 : 1;
+    if (beside) {
+        HIPCHK(c, hipEventRecord(c->fork_ev, c->stream));
+        HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->fork_ev, 0));
+        tool_stream = c->side_stream;
+    }
     TIMED(c, XGPU_K_INTER, launch_inter(c, a));
     if (!ahead) HIPCHK(c, hipEventRecord(c->after_inter, c->stream));   // where a residual pass prepared on the side stream (xgpu_batch_prepare) may start
     c->have_after_inter = 1;
@@ -1304,7 +1318,7 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
         d.bd_l = c->sp.bit_depth_luma; d.bd_c = c->sp.bit_depth_chroma; d.admvp = a.admvp; d.cur_poc = c->fp.poc;
         d.cus = db->d_cus; d.items = db->d_dmvr_items; d.n_items = db->n_dmvr; d.resid = db->d_resid; d.out_mv = db->d_dmvr_mv; d.maps = c->d_maps; d.w_scu = c->w_scu; d.refined_to_map = c->sp.tool_addb ? 0 : 1;
         memcpy(d.refp, a.refp, sizeof(d.refp));
-        TIMED(c, XGPU_K_DMVR, launch_dmvr(c, d));
+        TIMED(c, XGPU_K_DMVR, launch_dmvr(c, d, tool_stream));
     }
     if (db->n_aff_eif + db->n_aff_sub) {
         AffineArgs f;
@@ -1314,7 +1328,11 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
         f.cus = db->d_cus; f.cpmv = db->d_cpmv; f.items = db->d_aff_items; f.n_eif = db->n_aff_eif; f.n_sub = db->n_aff_sub;
         f.resid = db->d_resid; f.maps = c->d_maps; f.w_scu = c->w_scu;
         memcpy(f.refp, a.refp, sizeof(f.refp));
-        TIMED(c, XGPU_K_AFFINE, launch_affine(c, f));
+        TIMED(c, XGPU_K_AFFINE, launch_affine(c, f, tool_stream));
+    }
+    if (beside) {
+        HIPCHK(c, hipEventRecord(c->join_ev, c->side_stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->join_ev, 0));
     }
     if (db->n_intra) {
         // intra CUs: level 1 as a plain launch, all deeper levels as one data-flow launch (k_intra.hip)

@@ -98,6 +98,7 @@ struct InterArgs {
     const uint32_t *owner;             // [w_scu * h_scu] batch index of the CU covering each SCU (0xFFFFFFFF: none), painted by xgpu_batch_create
     int      n_cu;
     int      cur_poc;                  // POC of the picture being decoded (DMVR's distance test)
+    int      dmvr_to_map;              // k_dmvr writes its refined vectors into the map records (DmvrArgs.refined_to_map): k_inter leaves those words alone
     RefEntry refp[XGPU_MAX_REFS][2];
 };
 
@@ -307,6 +308,7 @@ struct xgpu_ctx {
     xgpu_frame_params fp;
     int             have_frame;
     TileMask        no_dbk;            // tile borders the deblocking of the current picture leaves alone (set by xgpu_batch_recon)
+    hipEvent_t      fork_ev, join_ev;  // k_dmvr / k_affine on the side stream beside k_inter: where they may start, where the kernel stream takes them back
     int             ctu_attr[2];       // k_intra_ctu's LDS size attribute set (Baseline / EIPD instantiation)
     int             builder_threads;   // xgpu_set_builder_threads: host threads xgpu_batch_create spreads its per-CU passes over (default 1)
     int             pad_done;          // the padding of the current picture has been written (by k_alf's border tiles): xgpu_pad launches nothing
@@ -332,8 +334,8 @@ void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf
 int  launch_intra_ctu(xgpu_ctx *c, const IntraArgs &a, const IntraCtu *ctus, int n_ctus);      // -1: the LDS attribute could not be set
 int  intra_ctu_lds_bytes(int log2_ctu);
 int  intra_chunk(bool with_itdq);                // list positions per ticket of the data-flow launch (= waves per workgroup: 8, with the residual pass riding 4)
-void launch_affine(xgpu_ctx *c, const AffineArgs &a);
-void launch_dmvr(xgpu_ctx *c, const DmvrArgs &a);
+void launch_affine(xgpu_ctx *c, const AffineArgs &a, hipStream_t s);
+void launch_dmvr(xgpu_ctx *c, const DmvrArgs &a, hipStream_t s);
 void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst);
 void upload_transform_tables(const int *tm, const int16_t *ats, hipStream_t s);
 int  itdq_group_size(int log2w, int log2h);     // TBs of one size class per 256-thread work item
