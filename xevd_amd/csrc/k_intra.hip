@@ -165,6 +165,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
         ISTAMP(1);
         // ---- neighbour staging (xevd_get_nbr_b): sample e of a side belongs to unit e / unit_size.  All loads of the first round
         //      (covers CUs up to w + h = 128) are issued before any LDS store so that they overlap ----
+        if (!htdf_only) {      // (a filter-only node - an inter CU that HTDF runs on - predicts nothing: no neighbour arrays, no plan; cycle stamps on the HTDF workload: 3 400 of a node's 12 500 clocks)
         if (EIPD) {
             // xevdm_get_nbr: an unavailable unit repeats the last sample of the nearest available unit before it (the mid value when
             // there is none above; the corner when there is none to the left); every element is one load at a computed position
@@ -263,10 +264,12 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
                 nb[0][NB_C0 - 1 - e] = ((avail_le >> (e >> 2)) & 1) ? (DEP ? (int16_t)(ld_coherent(org + e * a.s_l - 2) >> 16) : org[e * a.s_l - 1]) : (int16_t)mid;
         }
         }
+        }
         wave_lds_sync();
         ISTAMP(2);
 
         EipdPlan plan[3];
+        if (!htdf_only) {
         if (EIPD) {
             // chroma mode -> the luma-numbered predictor (xevdm_ipred_uv :267-305): DM follows the luma mode, then BI / DC / HOR / VER
             const int mc = mode_c == 0 ? mode_l : (mode_c == 1 ? 2 : mode_c == 2 ? 0 : mode_c == 3 ? 24 : 12);
@@ -287,6 +290,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
             } else if (mode == 4) {
                 for (int e = t; e < w + h; e += 64) nb[c][NB_UR + e] = (int16_t)((nb[c][NB_C0 + 1 + e] + nb[c][NB_C0 - 1 - e]) >> 1);
             }
+        }
         }
         }
         wave_lds_sync();
