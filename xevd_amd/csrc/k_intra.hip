@@ -437,7 +437,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
             int16_t *org = a.cur_y + cu_y * a.s_l + cu_x;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the wave's own stores of the prediction pass
             auto ldw = [&](const int16_t *p) -> uint32_t { return DEP ? ld_coherent(p) : *(const uint32_t *)p; };
-            if (t < 16) s_lut[wv][t] = k_htdf_tbl[tidx][t];
+            const int lut_v = k_htdf_tbl[tidx][t & 15];              // (requested here, stored to LDS behind the block's loads: the store needs the value, and a wait in front of those loads made the table a round trip of its own - 2 500 clocks from the end of the prediction pass to the first block load, cycle stamps)
             // Every global load of the stage is issued before the first LDS store that needs one: the loop this replaces waited for each round of 64 dwords before it
             // asked for the next one - a 32x32 block was eight memory round trips (~2 us each for the coherent loads of the data-flow launch), the border four more,
             // which is what a level of the HTDF workload cost (15 us; 26 levels at 8K).  A filtered CU is at most 64 samples wide and high: one lane per border sample.
@@ -461,6 +461,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
                 d_c = ldr(p_c);
             }
             const int n2 = (cw >> 1) * chh;
+            ISTAMP(6);
             for (int i0 = 0; i0 < n2; i0 += 64 * 8) {
                 uint32_t d[8];
 #pragma unroll
@@ -475,11 +476,13 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
                     if (i < n2) { tb[(r + 1) * we + c + 1] = (int16_t)(d[q] & 0xFFFF); tb[(r + 1) * we + c + 2] = (int16_t)(d[q] >> 16); }
                 }
             }
+            if (t < 16) s_lut[wv][t] = lut_v;
             asm volatile("" : "+v"(d_l), "+v"(d_r), "+v"(d_u), "+v"(d_d), "+v"(d_c));      // (keeps the picks out of the loads' branches)
             if (t < chh) { tb[(t + 1) * we] = pick(p_l, d_l); tb[(t + 1) * we + we - 1] = pick(p_r, d_r); }
             if (t < cw) { tb[t + 1] = pick(p_u, d_u); tb[(he - 1) * we + t + 1] = pick(p_d, d_d); }
             if (t < 4) tb[t == 0 ? 0 : t == 1 ? we - 1 : t == 2 ? we * (he - 1) : we - 1 + we * (he - 1)] = pick(p_c, d_c);
             wave_lds_sync();
+            ISTAMP(7);
             const int *lut = s_lut[wv];
             auto lutf = [&](int z) -> int {                           // read_table (:176-189)
                 const int ab = z < 0 ? -z : z;
@@ -608,8 +611,8 @@ void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf
         uint32_t h[8 * 64];
         hipMemcpyFromSymbol(h, HIP_SYMBOL(g_intra_prof), sizeof(h));
         for (int i = 0; i < 64; i++)
-            fprintf(stderr, "  pos %d start %10u  wait %6u stage %5u (EIPD luma: issue %5u, return %5u) plan %5u predict %5u ack %5u\n", INTRA_PROFILE + i, h[8 * i], h[8 * i + 1] - h[8 * i],
-                    h[8 * i + 2] - h[8 * i + 1], h[8 * i + 6] - h[8 * i + 1], h[8 * i + 7] - h[8 * i + 6], h[8 * i + 3] - h[8 * i + 2], h[8 * i + 4] - h[8 * i + 3], h[8 * i + 5] - h[8 * i + 4]);
+            fprintf(stderr, "  pos %d start %10u  wait %6u stage %5u (EIPD luma: issue %5u, return %5u | HTDF: to the block loads %5u from stamp 3, block in LDS %5u) plan %5u predict %5u ack %5u\n", INTRA_PROFILE + i, h[8 * i], h[8 * i + 1] - h[8 * i],
+                    h[8 * i + 2] - h[8 * i + 1], h[8 * i + 6] - h[8 * i + 1], h[8 * i + 7] - h[8 * i + 6], h[8 * i + 6] - h[8 * i + 3], h[8 * i + 7] - h[8 * i + 6], h[8 * i + 3] - h[8 * i + 2], h[8 * i + 4] - h[8 * i + 3], h[8 * i + 5] - h[8 * i + 4]);
     }
 #endif
 }
