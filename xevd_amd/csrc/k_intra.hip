@@ -22,7 +22,9 @@
 // MI355X mapping: one wavefront per CU, eight independent waves per workgroup.  The neighbour arrays of the three components
 // are staged once in LDS (unavailable units -> mid grey of the LUMA bit depth, xevd.c:455-473), DC sums are wave
 // reductions, then every lane predicts whole 4x4 SCUs (+ their 2x2 chroma blocks) exactly like k_inter's lanes
-// reconstruct theirs, so residual addressing and stores are shared idioms.  HBM-bound integer work: no MFMA.
+// reconstruct theirs, so residual addressing and stores are shared idioms (Baseline predictors; the EIPD instantiations work in
+// units of one luma row of four + one chroma pair, see intra_body).  A CU of several 64-unit steps sits in the list once per step
+// (parts, xgpu_api.hip).  Integer work bound by the latency of dependent instructions and memory round trips: no MFMA.
 #include "xgpu_internal.h"
 #include "itdq_body.h"
 
