@@ -454,7 +454,7 @@ __device__ __forceinline__ void dmvr_block(const DmvrArgs &a, const uint4 r0, co
     DmvrCu u;
     dmvr_unpack(a, r0, r1, isx, isy, u);
     constexpr int CH = DX == 16 ? 3 : 2;                       // 16-byte chunks per staged luma row
-    const int bd = a.bd_l, maxl = (1 << a.bd_l) - 1, maxc = (1 << a.bd_c) - 1;
+    const int bd = a.bd_l, maxl = (1 << a.bd_l) - 1;
     const int sh1 = min(4, bd - 8), sh2 = max(8, 20 - bd), off2 = 1 << (sh2 - 1);
 
     // ---- search windows: (DY + 5) rows x (DX + 5) samples of both lists at the (clipped) starting vector, then the bilinear blocks ----

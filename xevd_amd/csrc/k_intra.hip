@@ -415,8 +415,9 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
             // local dual tree: a chroma-only CU (flag 32) leaves luma alone, a luma-only one (64) chroma - what was computed for the missing plane is dropped
             if (!(nflags & 32u))
 #pragma unroll
-            for (int r = 0; r < 4; r++)
+            for (int r = 0; r < 4; r++) {
                 if (DEP) st_coherent2(dy + r * a.s_l, ol[r][0], ol[r][1]); else *(uint2 *)(dy + r * a.s_l) = make_uint2(ol[r][0], ol[r][1]);
+            }
             if (!(nflags & 64u))
 #pragma unroll
             for (int c = 1; c < 3; c++) {
