@@ -57,7 +57,7 @@ __constant__ uint8_t k_htdf_tbl[5][16] = {
 template <bool HTDF> struct IntraLds { static constexpr int WAVE = (HTDF && HTDF_EXT > 3 * NB_LEN) ? HTDF_EXT : 3 * NB_LEN; };
 
 // The work of one workgroup of WAVES waves; `block` = its position in the launch (static assignment, DEP = false).  s_nb = WAVES x IntraLds<HTDF>::WAVE samples,
-// s_lut = WAVES x 16 (HTDF only), s_chunk = one dword.
+// s_chunk = one dword.
 #ifdef INTRA_PROFILE      // cycle stamps of 64 consecutive list positions of the data-flow launch (make EXTRA=-DINTRA_PROFILE=<first position>; printed by launch_intra)
 // Measured with them (all-intra 1080p Main, 2.43 GHz): per CU ~4 400 clocks of staging (per component ~1 000 of address arithmetic and load issue, 400 - 1 000 until the loads are
 // back, 150 of LDS stores), 1 100 - 1 900 of plan, 2 000 - 3 500 for a step of six samples, 270 - 800 until the stores are acknowledged: a link of a chain is ~9 000 clocks of one
@@ -69,7 +69,7 @@ __device__ uint32_t g_intra_prof[8 * 64];
 #define ISTAMP(k)
 #endif
 template <bool DEP, bool EIPD, bool IBC, bool HTDF, int WAVES>
-__device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, int16_t *s_nb_, int (*s_lut)[16], uint32_t *s_chunk)
+__device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, int16_t *s_nb_, uint32_t *s_chunk)
 {
     constexpr int WAVE_LDS = IntraLds<HTDF>::WAVE;
     int16_t (*s_nb)[WAVE_LDS] = (int16_t (*)[WAVE_LDS])s_nb_;
@@ -440,7 +440,6 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
             int16_t *org = a.cur_y + cu_y * a.s_l + cu_x;
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // the wave's own stores of the prediction pass
             auto ldw = [&](const int16_t *p) -> uint32_t { return DEP ? ld_coherent(p) : *(const uint32_t *)p; };
-            const int lut_v = k_htdf_tbl[tidx][t & 15];              // (requested here, stored to LDS behind the block's loads: the store needs the value, and a wait in front of those loads made the table a round trip of its own - 2 500 clocks from the end of the prediction pass to the first block load, cycle stamps)
             // Every global load of the stage is issued before the first LDS store that needs one: the loop this replaces waited for each round of 64 dwords before it
             // asked for the next one - a 32x32 block was eight memory round trips (~2 us each for the coherent loads of the data-flow launch), the border four more,
             // which is what a level of the HTDF workload cost (15 us; 26 levels at 8K).  A filtered CU is at most 64 samples wide and high: one lane per border sample.
@@ -479,17 +478,21 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
                     if (i < n2) { tb[(r + 1) * we + c + 1] = (int16_t)(d[q] & 0xFFFF); tb[(r + 1) * we + c + 2] = (int16_t)(d[q] >> 16); }
                 }
             }
-            if (t < 16) s_lut[wv][t] = lut_v;
             asm volatile("" : "+v"(d_l), "+v"(d_r), "+v"(d_u), "+v"(d_d), "+v"(d_c));      // (keeps the picks out of the loads' branches)
             if (t < chh) { tb[(t + 1) * we] = pick(p_l, d_l); tb[(t + 1) * we + we - 1] = pick(p_r, d_r); }
             if (t < cw) { tb[t + 1] = pick(p_u, d_u); tb[(he - 1) * we + t + 1] = pick(p_d, d_d); }
             if (t < 4) tb[t == 0 ? 0 : t == 1 ? we - 1 : t == 2 ? we * (he - 1) : we - 1 + we * (he - 1)] = pick(p_c, d_c);
             wave_lds_sync();
             ISTAMP(7);
-            const int *lut = s_lut[wv];
+            // the 16-byte table in four scalar registers, an entry picked with two byte permutes: 18 look-ups per pair of samples were 18 LDS reads in the dependent chain
+            // of a wave that mostly runs alone
+            const uint32_t *tb32 = (const uint32_t *)k_htdf_tbl[tidx];
+            const uint32_t tq0 = uni(tb32[0]), tq1 = uni(tb32[1]), tq2 = uni(tb32[2]), tq3 = uni(tb32[3]);
             auto lutf = [&](int z) -> int {                           // read_table (:176-189)
                 const int ab = z < 0 ? -z : z;
-                const int v = ab < thr ? lut[((ab + rnd) & thr) >> shift] : ab;
+                const uint32_t idx = (uint32_t)(((ab + rnd) & thr) >> shift), sel = (idx & 7u) | 0x0C0C0C00u;
+                const int e = (int)((idx & 8u) ? __builtin_amdgcn_perm(tq3, tq2, sel) : __builtin_amdgcn_perm(tq1, tq0, sel));
+                const int v = ab < thr ? e : ab;
                 return z < 0 ? -v : v;
             };
             for (int i = t; i < (cw >> 1) * chh; i += 64) {
@@ -537,10 +540,9 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
 template <bool DEP, bool EIPD, bool IBC, bool HTDF>
 __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 {
-    __shared__ int     s_lut[HTDF ? INTRA_WAVES : 1][16];
     __shared__ __attribute__((aligned(16))) int16_t s_nb[INTRA_WAVES * IntraLds<HTDF>::WAVE];
     __shared__ uint32_t s_chunk;
-    intra_body<DEP, EIPD, IBC, HTDF, INTRA_WAVES>(a, blockIdx.x, s_nb, s_lut, &s_chunk);
+    intra_body<DEP, EIPD, IBC, HTDF, INTRA_WAVES>(a, blockIdx.x, s_nb, &s_chunk);
 }
 
 // k_intra_itdq - the data-flow launch of this picture and the residual pass of the NEXT picture in one grid.  The data-flow kernel is a chain of
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_intra_itdq(const IntraArgs
     // 8068 / 7795.
     const uint32_t before = min(n_intra_wg, (uint32_t)(((uint64_t)blockIdx.x * n_intra_wg) / span)), after = min(n_intra_wg, (uint32_t)(((uint64_t)(blockIdx.x + 1) * n_intra_wg) / span));
     if (after > before) {
-        intra_body<true, EIPD, IBC, false, FUSED_WAVES>(a, blockIdx.x, (int16_t *)raw, nullptr, raw + INTRA_DW - 1);
+        intra_body<true, EIPD, IBC, false, FUSED_WAVES>(a, blockIdx.x, (int16_t *)raw, raw + INTRA_DW - 1);
     } else {
         const int wi = (int)(blockIdx.x - before);
         if (wi >= r.n_waves) return;
