@@ -495,33 +495,41 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
                 const int v = ab < thr ? e : ab;
                 return z < 0 ? -v : v;
             };
-            for (int i = t; i < (cw >> 1) * chh; i += 64) {
-                const int r = i >> (lw - 1), c = (i & ((cw >> 1) - 1)) << 1;          // output samples (r, c) and (r, c + 1) = ext (r + 1, c + 1), (r + 1, c + 2)
-                int p[3][4];
+            // a lane filters 2 x 2 samples: the nine windows over the 4 x 4 samples around them (a sample lies in four windows; one pair of samples per lane needed six
+            // windows, i.e. three per sample instead of 2.25)
+            for (int i = t; i < (cw >> 1) * (chh >> 1); i += 64) {
+                const int r = (i >> (lw - 1)) << 1, c = (i & ((cw >> 1) - 1)) << 1;          // output samples (r .. r + 1, c .. c + 1) = ext (r + 1 .. r + 2, c + 1 .. c + 2)
+                int p[4][4];
 #pragma unroll
-                for (int rr = 0; rr < 3; rr++)
+                for (int rr = 0; rr < 4; rr++) {
+                    const uint32_t d0 = *(const uint32_t *)&tb[(r + rr) * we + c], d1 = *(const uint32_t *)&tb[(r + rr) * we + c + 2];
+                    p[rr][0] = (int)(int16_t)(d0 & 0xFFFF); p[rr][1] = (int)(int16_t)(d0 >> 16); p[rr][2] = (int)(int16_t)(d1 & 0xFFFF); p[rr][3] = (int)(int16_t)(d1 >> 16);
+                }
+                int acc[2][2] = { { 0, 0 }, { 0, 0 } };
 #pragma unroll
-                    for (int cc = 0; cc < 4; cc++) p[rr][cc] = tb[(r + rr) * we + c + cc];
-                int acc[2] = { 0, 0 };
-#pragma unroll
-                for (int wr = 0; wr < 2; wr++)
+                for (int wr = 0; wr < 3; wr++)
 #pragma unroll
                     for (int wc = 0; wc < 3; wc++) {                   // window with its top-left sample at ext (r + wr, c + wc)
                         const int x0 = p[wr][wc], x1 = p[wr][wc + 1], x2 = p[wr + 1][wc], x3 = p[wr + 1][wc + 1];
                         const int y0 = x0 + x2, y1 = x1 + x3, y2 = x0 - x2, y3 = x1 - x3;
                         const int z0 = y0 + y1, z1 = lutf(y0 - y1), z2 = lutf(y2 + y3), z3 = lutf(y2 - y3);
-                        const int i0 = z0 + z2, i1 = z1 + z3, i2 = z0 - z2, i3 = z1 - z3;
-                        // the sample at ext (r + 1, c + 1 + e) sits in this window at row 1 - wr, column 1 + e - wc
+                        const int i0_ = z0 + z2, i1_ = z1 + z3, i2_ = z0 - z2, i3_ = z1 - z3;
+                        // the output sample (dr, dc) = ext (r + 1 + dr, c + 1 + dc) sits in this window at row 1 + dr - wr, column 1 + dc - wc
 #pragma unroll
-                        for (int e = 0; e < 2; e++) {
-                            const int col = 1 + e - wc;
-                            if (col < 0 || col > 1) continue;
-                            const int v = wr == 0 ? (col == 0 ? i2 + i3 : i2 - i3) : (col == 0 ? i0 + i1 : i0 - i1);
-                            acc[e] += v >> 2;
-                        }
+                        for (int dr = 0; dr < 2; dr++)
+#pragma unroll
+                            for (int dc = 0; dc < 2; dc++) {
+                                const int row = 1 + dr - wr, col = 1 + dc - wc;
+                                if (row < 0 || row > 1 || col < 0 || col > 1) continue;
+                                const int v = row == 1 ? (col == 0 ? i2_ + i3_ : i2_ - i3_) : (col == 0 ? i0_ + i1_ : i0_ - i1_);
+                                acc[dr][dc] += v >> 2;
+                            }
                     }
-                const int o0 = clip3i(0, maxv, ((int)(int16_t)acc[0] + 2) >> 2), o1 = clip3i(0, maxv, ((int)(int16_t)acc[1] + 2) >> 2);
-                if (DEP) st_coherent(org + r * a.s_l + c, pack2i(o0, o1)); else *(uint32_t *)(org + r * a.s_l + c) = pack2i(o0, o1);
+#pragma unroll
+                for (int dr = 0; dr < 2; dr++) {
+                    const int o0 = clip3i(0, maxv, ((int)(int16_t)acc[dr][0] + 2) >> 2), o1 = clip3i(0, maxv, ((int)(int16_t)acc[dr][1] + 2) >> 2);
+                    if (DEP) st_coherent(org + (r + dr) * a.s_l + c, pack2i(o0, o1)); else *(uint32_t *)(org + (r + dr) * a.s_l + c) = pack2i(o0, o1);
+                }
             }
         }
         ISTAMP(4);
