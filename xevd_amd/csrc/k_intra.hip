@@ -28,6 +28,7 @@
 #include "xgpu_internal.h"
 #include "itdq_body.h"
 
+#include <type_traits>
 #include "intra_pred.h"
 
 // waves (= CUs in flight) per workgroup = INTRA_CHUNK list positions per ticket.  Measured at 8K (chunk, waves): (8, 4) 81 us, (4, 4) 72, (2, 2) 83,
@@ -495,42 +496,57 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
                 const int v = ab < thr ? e : ab;
                 return z < 0 ? -v : v;
             };
-            // a lane filters 2 x 2 samples: the nine windows over the 4 x 4 samples around them (a sample lies in four windows; one pair of samples per lane needed six
-            // windows, i.e. three per sample instead of 2.25)
-            for (int i = t; i < (cw >> 1) * (chh >> 1); i += 64) {
-                const int r = (i >> (lw - 1)) << 1, c = (i & ((cw >> 1) - 1)) << 1;          // output samples (r .. r + 1, c .. c + 1) = ext (r + 1 .. r + 2, c + 1 .. c + 2)
-                int p[4][4];
+            // a lane filters a tile of TR x TC samples from the (TR + 1) x (TC + 1) windows over the (TR + 2) x (TC + 2) samples around them (a sample lies in four windows):
+            // 2 x 2 = 2.25 windows per sample (one pair per lane needed three), 4 x 4 = 1.56 - for the blocks of 1024 samples and more (32 x 32, 64 x 16 ...: four rounds of 2 x 2 tiles at ~390 instructions against one of 4 x 4 at ~1 100): their waves
+            // run several rounds, and a level of the graph lasts as long as its largest node
+            auto filter_tiles = [&](auto TRc, auto TCc) {
+                constexpr int TR = decltype(TRc)::value, TC = decltype(TCc)::value, LR = TR == 4 ? 2 : 1, LC = TC == 4 ? 2 : 1;
+                const int tiles_x = cw >> LC, ltx = lw - LC;
+                for (int i = t; i < tiles_x * (chh >> LR); i += 64) {
+                    const int r = (i >> ltx) << LR, c = (i & (tiles_x - 1)) << LC;          // output samples (r .. r + TR - 1, c .. c + TC - 1) = ext (r + 1 .., c + 1 ..)
+                    int p[TR + 2][TC + 2];
 #pragma unroll
-                for (int rr = 0; rr < 4; rr++) {
-                    const uint32_t d0 = *(const uint32_t *)&tb[(r + rr) * we + c], d1 = *(const uint32_t *)&tb[(r + rr) * we + c + 2];
-                    p[rr][0] = (int)(int16_t)(d0 & 0xFFFF); p[rr][1] = (int)(int16_t)(d0 >> 16); p[rr][2] = (int)(int16_t)(d1 & 0xFFFF); p[rr][3] = (int)(int16_t)(d1 >> 16);
+                    for (int rr = 0; rr < TR + 2; rr++)
+#pragma unroll
+                        for (int cc = 0; cc < TC + 2; cc += 2) {
+                            const uint32_t d = *(const uint32_t *)&tb[(r + rr) * we + c + cc];
+                            p[rr][cc] = (int)(int16_t)(d & 0xFFFF); p[rr][cc + 1] = (int)(int16_t)(d >> 16);
+                        }
+                    int acc[TR][TC];
+#pragma unroll
+                    for (int dr = 0; dr < TR; dr++)
+#pragma unroll
+                        for (int dc = 0; dc < TC; dc++) acc[dr][dc] = 0;
+#pragma unroll
+                    for (int wr = 0; wr < TR + 1; wr++)
+#pragma unroll
+                        for (int wc = 0; wc < TC + 1; wc++) {              // window with its top-left sample at ext (r + wr, c + wc)
+                            const int x0 = p[wr][wc], x1 = p[wr][wc + 1], x2 = p[wr + 1][wc], x3 = p[wr + 1][wc + 1];
+                            const int y0 = x0 + x2, y1 = x1 + x3, y2 = x0 - x2, y3 = x1 - x3;
+                            const int z0 = y0 + y1, z1 = lutf(y0 - y1), z2 = lutf(y2 + y3), z3 = lutf(y2 - y3);
+                            const int i0_ = z0 + z2, i1_ = z1 + z3, i2_ = z0 - z2, i3_ = z1 - z3;
+                            // the output sample (dr, dc) = ext (r + 1 + dr, c + 1 + dc) sits in this window at row 1 + dr - wr, column 1 + dc - wc
+#pragma unroll
+                            for (int row = 0; row < 2; row++)
+#pragma unroll
+                                for (int col = 0; col < 2; col++) {
+                                    const int dr = wr - 1 + row, dc = wc - 1 + col;
+                                    if (dr < 0 || dr >= TR || dc < 0 || dc >= TC) continue;
+                                    const int v = row == 1 ? (col == 0 ? i2_ + i3_ : i2_ - i3_) : (col == 0 ? i0_ + i1_ : i0_ - i1_);
+                                    acc[dr][dc] += v >> 2;
+                                }
+                        }
+#pragma unroll
+                    for (int dr = 0; dr < TR; dr++)
+#pragma unroll
+                        for (int dc = 0; dc < TC; dc += 2) {
+                            const int o0 = clip3i(0, maxv, ((int)(int16_t)acc[dr][dc] + 2) >> 2), o1 = clip3i(0, maxv, ((int)(int16_t)acc[dr][dc + 1] + 2) >> 2);
+                            if (DEP) st_coherent(org + (r + dr) * a.s_l + c + dc, pack2i(o0, o1)); else *(uint32_t *)(org + (r + dr) * a.s_l + c + dc) = pack2i(o0, o1);
+                        }
                 }
-                int acc[2][2] = { { 0, 0 }, { 0, 0 } };
-#pragma unroll
-                for (int wr = 0; wr < 3; wr++)
-#pragma unroll
-                    for (int wc = 0; wc < 3; wc++) {                   // window with its top-left sample at ext (r + wr, c + wc)
-                        const int x0 = p[wr][wc], x1 = p[wr][wc + 1], x2 = p[wr + 1][wc], x3 = p[wr + 1][wc + 1];
-                        const int y0 = x0 + x2, y1 = x1 + x3, y2 = x0 - x2, y3 = x1 - x3;
-                        const int z0 = y0 + y1, z1 = lutf(y0 - y1), z2 = lutf(y2 + y3), z3 = lutf(y2 - y3);
-                        const int i0_ = z0 + z2, i1_ = z1 + z3, i2_ = z0 - z2, i3_ = z1 - z3;
-                        // the output sample (dr, dc) = ext (r + 1 + dr, c + 1 + dc) sits in this window at row 1 + dr - wr, column 1 + dc - wc
-#pragma unroll
-                        for (int dr = 0; dr < 2; dr++)
-#pragma unroll
-                            for (int dc = 0; dc < 2; dc++) {
-                                const int row = 1 + dr - wr, col = 1 + dc - wc;
-                                if (row < 0 || row > 1 || col < 0 || col > 1) continue;
-                                const int v = row == 1 ? (col == 0 ? i2_ + i3_ : i2_ - i3_) : (col == 0 ? i0_ + i1_ : i0_ - i1_);
-                                acc[dr][dc] += v >> 2;
-                            }
-                    }
-#pragma unroll
-                for (int dr = 0; dr < 2; dr++) {
-                    const int o0 = clip3i(0, maxv, ((int)(int16_t)acc[dr][0] + 2) >> 2), o1 = clip3i(0, maxv, ((int)(int16_t)acc[dr][1] + 2) >> 2);
-                    if (DEP) st_coherent(org + (r + dr) * a.s_l + c, pack2i(o0, o1)); else *(uint32_t *)(org + (r + dr) * a.s_l + c) = pack2i(o0, o1);
-                }
-            }
+            };
+            if (cw * chh >= 1024) filter_tiles(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{});
+            else                 filter_tiles(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
         }
         ISTAMP(4);
         if (DEP) {      // publish: the wave's sc1 stores have reached the coherence point once vmcnt drains; then the done flag
