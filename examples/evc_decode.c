@@ -191,10 +191,10 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
     memset(&q, 0, sizeof(q));
     memset(dpb, 0, sizeof(dpb));
     out_t *outs = (out_t *)malloc(sizeof(out_t) * (size_t)(expected > 0 ? expected : 1));
+    pthread_mutex_init(&q.mu, NULL); pthread_cond_init(&q.cv, NULL);      /* before the first goto done, which destroys them */
     q.ps = xhost_parser_open(bytes, size);
     if (!outs || !q.ps) { rc = -1; goto done; }
     if (g_tile_threads > 1) xhost_parser_set_threads(q.ps, g_tile_threads);      /* the tiles of a picture on parallel host threads */
-    pthread_mutex_init(&q.mu, NULL); pthread_cond_init(&q.cv, NULL);
     pthread_mutex_lock(&w->arena_mu); w->arena_ok = 0; pthread_mutex_unlock(&w->arena_mu);
     xhost_parser_set_arena(q.ps, arena_alloc, arena_release, w);
     if (g_pipeline) {
@@ -338,7 +338,8 @@ done:
         pthread_mutex_unlock(&q.mu);
         pthread_join(th, NULL);
     }
-    if (q.ps) { pthread_mutex_destroy(&q.mu); pthread_cond_destroy(&q.cv); xhost_parser_close(q.ps); }
+    pthread_mutex_destroy(&q.mu); pthread_cond_destroy(&q.cv);
+    if (q.ps) xhost_parser_close(q.ps);
     w->parse_s += q.parse_s;
     free(mv);
     if (db) xgpu_batch_destroy(w->g, db);

@@ -84,11 +84,40 @@ def test_plain_c_example_is_built():
     assert r.returncode == 2 and b"usage" in r.stderr
 
 
-def test_public_api_library_exports_the_reference_entry_points():
-    """libxevd_amd_api.so (xevd_amd/compat, built where the reference's public header is) exports the six functions of inc/xevd.h:369-374"""
+def _build_api_lib():
+    import subprocess
     lib_path = os.path.join(ROOT, "xevd_amd", "libxevd_amd_api.so")
     if not os.path.exists(lib_path):
-        pytest.skip("libxevd_amd_api.so is built only in the development container")
-    lib = C.CDLL(lib_path)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "xevd_amd", "compat")])
+    return lib_path
+
+
+def test_public_api_library_exports_the_reference_entry_points():
+    """libxevd_amd_api.so (xevd_amd/compat, compiled against include/xevd_api.h - no reference tree needed) exports the six functions of inc/xevd.h:369-374"""
+    lib = C.CDLL(_build_api_lib())
     for name in ("xevd_create", "xevd_delete", "xevd_decode", "xevd_pull", "xevd_config", "xevd_info"):
         assert hasattr(lib, name), name
+
+
+def _probe(header_flag, includes, tmp_path, tag):
+    import subprocess
+    exe = str(tmp_path / f"probe_{tag}")
+    subprocess.check_call(["gcc", "-Wall", "-Werror", f"-DPROBE_HEADER={header_flag}"] + [f"-I{i}" for i in includes]
+                          + [os.path.join(ROOT, "tests", "tools", "api_layout_probe.c"), "-L" + os.path.join(ROOT, "xevd_amd"), "-lxevd_amd_api",
+                             "-Wl,-rpath," + os.path.join(ROOT, "xevd_amd"), "-o", exe])
+    return subprocess.run([exe], stdout=subprocess.PIPE, check=True).stdout.decode()
+
+
+def test_public_api_header_matches_reference_layout(tmp_path):
+    """include/xevd_api.h is this repository's restatement of the reference's public ABI (inc/xevd.h:48-374): every constant's value, every struct's size and
+    every field's offset and size - printed by one probe program - equal the committed fixture that the same probe produced from the reference's header
+    (tests/golden/api_layout.txt), and, where the reference tree is present, the reference's header itself; the probe also assigns the six entry points to
+    pointers of the reference's prototypes"""
+    _build_api_lib()
+    ours = _probe('"xevd_api.h"', [os.path.join(ROOT, "include")], tmp_path, "ours")
+    golden = open(os.path.join(ROOT, "tests", "golden", "api_layout.txt")).read()
+    assert ours == golden
+    assert ours.count("\n") >= 150 and "prototypes 1" in ours
+    gen = os.path.join(ROOT, "oracle", "_ref", "gen")
+    if os.path.isdir("/root/reference/inc") and os.path.exists(os.path.join(gen, "xevd_exports.h")):
+        assert _probe("<xevd.h>", ["/root/reference/inc", gen], tmp_path, "ref") == ours

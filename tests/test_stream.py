@@ -281,6 +281,20 @@ def test_several_slices_per_picture_boundaries_and_refusals():
     slices = [i for i, k in enumerate(kinds) if k]
     with pytest.raises(RuntimeError, match="another picture|twice"):      # picture 1 without its last slice: picture 2's first slice must not complete it
         stream.parse_stream(b"".join(n for i, n in enumerate(nals) if i != slices[5]))
+    # a parameter set between two slices of one picture would change the geometry under the open picture's maps / tile state: refused, the
+    # partial picture dropped; so is a stream that ends inside a picture
+    is_ps = [i for i, n in enumerate(nals) if ((n[4] << 8 | n[5]) >> 9 & 63) - 1 in (24, 25)]
+    assert len(is_ps) >= 2
+    for ps in is_ps[:2]:
+        with pytest.raises(RuntimeError, match="parameter set between"):
+            stream.parse_stream(b"".join(nals[:slices[1]] + [nals[ps]] + nals[slices[1]:]))
+    with pytest.raises(RuntimeError, match="ends inside a picture"):
+        stream.parse_stream(b"".join(nals[:slices[7] + 1]))
+    # the scanner resynchronises behind a lost slice: the next picture's first slice brings tiles the open picture already has -> kind 1 again
+    sc = lib.xhost_scan_open()
+    kinds2 = [lib.xhost_scan_nal(sc, bytes(n[4:]), len(n) - 4) for i, n in enumerate(nals) if i != slices[5]]
+    lib.xhost_scan_close(sc)
+    assert [k for k in kinds2 if k] == [1, 2, 2, 1, 2, 1, 2, 2]
     with pytest.raises(RuntimeError):
         su.make_stream(256, 256, 2, seed=11, main=True, tiles=(4, 4, 0), slices=[(0, 7), (8, 15)])      # no sps_pocs_flag
     with pytest.raises(RuntimeError):

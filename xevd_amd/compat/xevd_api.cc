@@ -1,8 +1,8 @@
 // xevd_api.cc - the reference's PUBLIC decoder API (inc/xevd.h:369-374: xevd_create / xevd_decode / xevd_pull / xevd_config / xevd_delete /
 // xevd_info) implemented on this repository's two C ABIs: an application written for libxevd - the reference's own xevd_app included - links
-// against libxevd_amd_api.so instead and decodes on the MI355X.  No reference source is part of this file; it is compiled against the
-// reference's public header WHERE IT LIES (-I $(REF)/inc), so it is built only where that header exists (build() does it in the development
-// container; the .so travels).  Streams: what include/xevd_host.h parses.
+// against libxevd_amd_api.so instead and decodes on the MI355X.  No reference source is part of this file; it is compiled against this repository's own
+// restatement of that ABI (include/xevd_api.h: the reference's constants and struct layouts, pinned by tests/test_abi.py), so it builds anywhere.
+// Streams: what include/xevd_host.h parses.
 //
 //   xevd_decode(one NAL unit)  -> xhost_parser_nal; a picture: map reference POCs to device slots, reconstruct + filter + pad on the GPU,
 //                                 download it into a host XEVD_IMGB (16-bit planes, what the reference's pictures are) and queue it for output
@@ -11,7 +11,7 @@
 //                                 application's bumping phase: everything left, then XEVD_ERR_UNEXPECTED (src_base/xevd.c:2042-2071 behaviour)
 //   picture-signature SEI      -> with XEVD_CFG_SET_USE_PIC_SIGNATURE the MD5 of every plane is checked (XEVD_ERR_BAD_CRC), else
 //                                 XEVD_WARN_CRC_IGNORED, as xevd.c:2010-2026
-#include <xevd.h>
+#include "xevd_api.h"
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>

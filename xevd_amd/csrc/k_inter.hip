@@ -441,10 +441,19 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     // form a compact patch whose vertical halos are still in its L2 when the row below is processed, and all XCDs get the same number of regions.
     const int idx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
     if (idx >= a.n_regions) return;
-    const int regions_y = a.n_regions / a.regions_x, per_strip = INTER_STRIP * regions_y;
-    const int strip = idx / per_strip, ks = idx - strip * per_strip;
-    const int sw = min(INTER_STRIP, a.regions_x - strip * INTER_STRIP);       // the last strip may be narrower
-    const int ry = ks / sw, rx = strip * INTER_STRIP + (ks - ry * sw);
+    const int regions_y = a.n_regions / a.regions_x;
+    int rx, ry;
+    if (a.order == 0) {
+        const int per_strip = a.strip * regions_y;
+        const int strip = idx / per_strip, ks = idx - strip * per_strip;
+        const int sw = min(a.strip, a.regions_x - strip * a.strip);       // the last strip may be narrower
+        ry = ks / sw; rx = strip * a.strip + (ks - ry * sw);
+    } else {                                                              // horizontal bands a.strip regions high, column by column inside a band
+        const int per_band = a.strip * a.regions_x;
+        const int band = idx / per_band, ks = idx - band * per_band;
+        const int bh = min(a.strip, regions_y - band * a.strip);
+        rx = ks / bh; ry = band * a.strip + (ks - rx * bh);
+    }
     const int t = threadIdx.x, lane = t & 63;
     // SCU coordinates in the picture: a wave covers 8x8 SCUs (32x32 samples), so that CUs of 32x32 and above fill whole waves
     const int sx = (rx << 4) + ((t >> 6 & 1) << 3) + (lane & 7), sy = (ry << 4) + ((t >> 7) << 3) + (lane >> 3);
@@ -494,7 +503,8 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
 
 void launch_inter(xgpu_ctx *c, const InterArgs &a)
 {
-    hipLaunchKernelGGL(k_inter, dim3(((a.n_regions + 7) >> 3) << 3), dim3(256), 0, c->stream, a);
+    const int lds_pad = getenv("XEVD_HIP_INTER_LDSPAD") ? atoi(getenv("XEVD_HIP_INTER_LDSPAD")) : 0;      // measurement knob: dynamic LDS that only lowers the occupancy
+    hipLaunchKernelGGL(k_inter, dim3(((a.n_regions + 7) >> 3) << 3), dim3(256), lds_pad, c->stream, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------

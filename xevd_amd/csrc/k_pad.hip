@@ -47,15 +47,16 @@ void launch_pad(xgpu_ctx *c, const DevPic &pic)
     hipLaunchKernelGGL(k_pad, dim3(rows), dim3(256), 0, c->stream, p);
 }
 
-// The bandwidth yardstick of bench.py (roofline.measured_copy_bw_gbps): a float4 grid-stride copy, one 16-byte load in flight per lane and iteration, 2048
-// workgroups: 4.8 TB/s on a 1 GiB buffer.  (Round 3 tried four independent loads per lane before the first store with 4096 workgroups: 4.3-4.5 TB/s - slower.
-// The guide's 6.29 TB/s for this part is not reached by either form; bench.py reports the fraction against both.)
+// The bandwidth yardstick of bench.py (roofline.measured_copy_bw_gbps): a float4 copy, ONE 16-byte element per lane, as many workgroups as the buffer has 4 KB
+// pieces.  tools/ubench/copy_bw.hip (round 4, 1 GiB): this form 6.18 TB/s - the guide's 6.29 TB/s figure for the part; a grid-stride loop over 2048 workgroups
+// (the yardstick of rounds 1-3) 4.8 TB/s, over 1024 workgroups 5.6, four loads per lane before the first store 4.3-5.3, non-temporal accesses 4.2-5.8;
+// read-only 6.39 TB/s, write-only 3.87 TB/s.
 __global__ __launch_bounds__(256) void k_copy(const uint4 *__restrict__ src, uint4 *__restrict__ dst, size_t n)
 {
-    const size_t stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
 }
 void launch_copy_bw(xgpu_ctx *c, const void *src, void *dst, size_t bytes)
 {
-    hipLaunchKernelGGL(k_copy, dim3(256 * 8), dim3(256), 0, c->stream, (const uint4 *)src, (uint4 *)dst, bytes / 16);
+    hipLaunchKernelGGL(k_copy, dim3((unsigned)((bytes / 16 + 255) / 256)), dim3(256), 0, c->stream, (const uint4 *)src, (uint4 *)dst, bytes / 16);
 }

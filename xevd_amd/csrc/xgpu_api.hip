@@ -1265,7 +1265,13 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
     db->used = 1;                                                        // xgpu_batch_destroy records blk.done: the block may be overwritten behind the kernels queued until then
     if (next && next->prepared) next = NULL;
     const bool ahead = next != NULL;
-    if (next) { HIPCHK(c, hipStreamWaitEvent(c->stream, next->blk.uploaded, 0)); next->upload_waited = 1; }
+    // (the stream waits for the NEXT batch's upload only in front of the launch that carries its residual pass - behind this picture's k_inter and tool kernels: a slow
+    //  upload of picture k + 1, 45 MB of coefficients at 8K, must not hold up picture k)
+    bool next_waited = false;
+    auto wait_next = [&]() -> int {
+        if (next && !next_waited) { HIPCHK(c, hipStreamWaitEvent(c->stream, next->blk.uploaded, 0)); next_waited = true; }
+        return XGPU_OK;
+    };
     if (db->tiles_across) memset(&c->no_dbk, 0, sizeof(c->no_dbk)); else c->no_dbk = db->tile_starts;
     if (db->prepared == 2) {                                             // the residual pass ran on this stream with the previous picture
         db->prepared = 0;
@@ -1289,6 +1295,9 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
     a.regions_x = (c->sp.width + 63) >> 6;
     a.n_regions = a.regions_x * ((c->sp.height + 63) >> 6);
     a.admvp = c->sp.tool_admvp ? 1 : 0;
+    const int strip_knob = getenv("XEVD_HIP_INTER_STRIP") ? atoi(getenv("XEVD_HIP_INTER_STRIP")) : 0;      // measurement knob
+    a.strip = strip_knob > 0 ? strip_knob : 16;
+    a.order = getenv("XEVD_HIP_INTER_ORDER") ? atoi(getenv("XEVD_HIP_INTER_ORDER")) : 0;
     a.cus = db->d_cus; a.resid = db->d_resid;
     a.maps = c->d_maps; a.w_scu = c->w_scu; a.owner = db->d_owner; a.n_cu = db->n_cu; a.cur_poc = c->fp.poc;
     for (int l = 0; l < 2; l++)
@@ -1350,25 +1359,30 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
             if (rc) { snprintf(c->err, sizeof(c->err), "k_intra_ctu: LDS size attribute"); return XGPU_ERR_UNEXPECTED; }
             db->intra_tickets += (uint32_t)db->n_intra_ctus;
         } else
-        TIMED(c, XGPU_K_INTRA, {
+        {
             // the next picture's residual pass rides in the data-flow launch (not while single kernels are being timed; HTDF's workgroups are a different shape)
             ItdqArgs na;
             const bool ride = next && n_dep > 0 && !c->timing && !db->has_htdf && (na = itdq_args(c, next), na.n_waves > 0);
-            ta.first = 0; ta.count = db->n_intra_l1;
-            if (ta.count) launch_intra(c, ta, false, db->has_ibc != 0, db->has_htdf != 0, NULL);
-            ta.first = db->n_intra_l1; ta.count = n_dep;
-            if (n_dep) {
-                launch_intra(c, ta, true, db->has_ibc != 0, db->has_htdf != 0, ride ? &na : NULL);
-                const int chunk = intra_chunk(ride);
-                db->intra_tickets += (uint32_t)((ta.count + chunk - 1) / chunk);
-                if (ride) { next->prepared = 2; next->used = 1; next = NULL; }
-            }
-        });
+            if (ride) { const int rc = wait_next(); if (rc != XGPU_OK) return rc; }
+            TIMED(c, XGPU_K_INTRA, {
+                ta.first = 0; ta.count = db->n_intra_l1;
+                if (ta.count) launch_intra(c, ta, false, db->has_ibc != 0, db->has_htdf != 0, NULL);
+                ta.first = db->n_intra_l1; ta.count = n_dep;
+                if (n_dep) {
+                    launch_intra(c, ta, true, db->has_ibc != 0, db->has_htdf != 0, ride ? &na : NULL);
+                    const int chunk = intra_chunk(ride);
+                    db->intra_tickets += (uint32_t)((ta.count + chunk - 1) / chunk);
+                    if (ride) { next->upload_waited = 1; next->prepared = 2; next->used = 1; next = NULL; }
+                }
+            });
+        }
     }
     if (next) {
+        const int rc = wait_next();
+        if (rc != XGPU_OK) return rc;
         const ItdqArgs na = itdq_args(c, next);
         TIMED(c, XGPU_K_ITDQ, launch_itdq(c, na, c->stream));
-        next->prepared = 2; next->used = 1;
+        next->upload_waited = 1; next->prepared = 2; next->used = 1;
     }
     HIPCHK(c, hipGetLastError());
     return XGPU_OK;

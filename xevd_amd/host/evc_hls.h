@@ -494,11 +494,25 @@ struct Stream {          // everything both directions share
         if (sps.tool_rpl && !enc_side) {
             // marking (xevdm_picman_refpic_marking, xevdm_picman.c:542-588): a reference picture that neither list of THIS slice names (active or not) is
             // dropped; lists (xevdm_picman_refp_rpl_based_init :315-368): entry i = the picture with POC cur - ref[i], which must be there
+            // refp[] holds pointers into dpb: the lists an I slice keeps from an earlier P / B slice of the picture are re-resolved by POC behind the marking
+            // (an erase shifts the elements behind it), and an I slice whose RPLs release one of those pictures is refused
+            std::vector<int> kept[2];
+            if (keep_lists) for (int l = 0; l < 2; l++) for (const RefPic *r : refp[l]) kept[l].push_back(r->poc);
             if (!idr)
                 for (size_t i = 0; i < dpb.size();) {
                     bool named = false;
                     for (int l = 0; l < 2 && !named; l++) for (int j = 0; j < sh.rpl[l].n && !named; j++) named = dpb[i].poc == poc - sh.rpl[l].ref[j];
                     if (named) i++; else { rpl_released.push_back(dpb[i].poc); dpb.erase(dpb.begin() + (long)i); }
+                }
+            if (keep_lists)
+                for (int l = 0; l < 2; l++) {
+                    refp[l].clear();
+                    for (int q : kept[l]) {
+                        const RefPic *hit = nullptr;
+                        for (const RefPic &r : dpb) if (r.poc == q) { hit = &r; break; }
+                        if (!hit) return false;
+                        refp[l].push_back(hit);
+                    }
                 }
             if (sh.type == XHOST_SLICE_I) return true;
             for (int l = 0; l < (sh.type == XHOST_SLICE_B ? 2 : 1); l++)

@@ -676,6 +676,9 @@ static int parser_nal(xhost_parser *p, const uint8_t *nal, size_t len, xhost_pic
     if (br.get1()) return p->fail("forbidden_zero_bit");
     const int nut = (int)br.get(6) - 1, tid = (int)br.get(3);
     if (br.get(5) != 0 || br.get1() != 0) return p->fail("reserved NAL header bits");
+    // a picture is open between its first and its last slice NAL: the picture maps, the tile grid and the per-tile state were sized by the parameter sets of its
+    // first slice, so a sequence or picture parameter set may not change under it (the partial picture is dropped with the error)
+    if ((nut == NUT_SPS || nut == NUT_PPS) && p->pic_tiles_left > 0) { p->pic_tiles_left = 0; return p->fail("parameter set between the slices of a picture"); }
     if (nut == NUT_SPS) return p->parse_sps(br);
     if (nut == NUT_PPS) return p->parse_pps(br);
     if (nut == NUT_IDR || nut == NUT_NONIDR) {
@@ -727,12 +730,13 @@ extern "C" int xhost_parser_next(xhost_parser *p, xhost_picture *out)
         const int rc = parser_nal(p, d + 4, len, out, true);
         if (rc != XGPU_OK) return rc;
     }
+    if (p->pic_tiles_left > 0) { p->pic_tiles_left = 0; return p->fail("the stream ends inside a picture (slices missing)"); }
     return 0;
 }
 
 // Picture boundaries without decoding anything (the GOP splitter of the work queue, xwq.cc): a slice NAL belongs to the picture of the slice before it until
 // the PPS's tiles are all covered (ctx->num_ctb, src_main/xevdm.c:2995-2999).  The scanner reads PPS NALs (tile grid) and the first fields of slice headers.
-struct xhost_scan { xhost_parser p; int tiles_left = 0; };
+struct xhost_scan { xhost_parser p; int tiles_left = 0, last_nut = -1; std::vector<uint8_t> seen; };
 extern "C" xhost_scan *xhost_scan_open(void) { return new xhost_scan(); }
 extern "C" void xhost_scan_close(xhost_scan *s) { delete s; }
 // -> 0: not a slice NAL, 1: the first (or only) slice of a picture, 2: a further slice of the picture, < 0: malformed
@@ -750,9 +754,14 @@ extern "C" int xhost_scan_nal(xhost_scan *s, const uint8_t *nal, size_t len)
     std::vector<int> tl;
     const int rc = s->p.slice_tile_list(br, tl);
     if (rc != XGPU_OK || br.overrun) return XHOST_ERR_MALFORMED;
-    const bool first = s->tiles_left <= 0;
-    if (first) s->tiles_left = s->p.st.pps.tile_cols * s->p.st.pps.tile_rows;
+    // resynchronise after a lost slice: a slice of the other NAL type, or one that brings a tile the open picture already has, starts a new picture
+    const int n_tiles = s->p.st.pps.tile_cols * s->p.st.pps.tile_rows;
+    bool first = s->tiles_left <= 0 || nut != s->last_nut || (int)s->seen.size() != n_tiles;
+    for (int t : tl) if (!first && (t < 0 || t >= n_tiles || s->seen[(size_t)t])) first = true;
+    if (first) { s->tiles_left = n_tiles; s->seen.assign((size_t)n_tiles, 0); }
+    for (int t : tl) if (t >= 0 && t < n_tiles) s->seen[(size_t)t] = 1;
     s->tiles_left -= (int)tl.size();
+    s->last_nut = nut;
     return first ? 1 : 2;
 }
 
