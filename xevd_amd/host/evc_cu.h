@@ -38,8 +38,8 @@ struct TileCoder {
         take(1, ys > 0 && pic.same_tile(scup, scup - ws) && !pic.intra[scup - ws] && !pic.ibc[scup - ws], scup - ws);
         take(2, ys > 0 && xs + scuw < ws && pic.same_tile(scup, scup - ws + scuw) && pic.cod[scup - ws + scuw] && !pic.intra[scup - ws + scuw], scup - ws + scuw);
         const RefPic *col = refp[lidx].empty() ? nullptr : refp[lidx][0];
-        cand[3][0] = col ? col->mv0[(size_t)scup * 2] : (int16_t)0;
-        cand[3][1] = col ? col->mv0[(size_t)scup * 2 + 1] : (int16_t)0;
+        cand[3][0] = col ? col->mv[(size_t)scup * 4] : (int16_t)0;
+        cand[3][1] = col ? col->mv[(size_t)scup * 4 + 1] : (int16_t)0;
     }
     // ------------------------------------------------------------------------------------------------------------------------------
     // Main profile, sps->tool_admvp: merge candidates (skip and merge-mode CUs) and the predictor of explicitly coded motion.
@@ -325,7 +325,7 @@ struct TileCoder {
         const int ws = pic.w_scu, scup = (cu.y >> 2) * ws + (cu.x >> 2);
         const int c_scu = scup + (((1 << cu.log2w) >> 2) - 1) + (((1 << cu.log2h) >> 2) - 1) * ws;
         const RefPic *r0 = refp[0][0], *col = refp[1][0];
-        const int mvx = col->mv0[(size_t)c_scu * 2], mvy = col->mv0[(size_t)c_scu * 2 + 1];
+        const int mvx = col->mv[(size_t)c_scu * 4], mvy = col->mv[(size_t)c_scu * 4 + 1];
         const int dco = col->poc - col->list0_poc, d0 = poc - r0->poc, d1 = col->poc - poc;
         cu.refi[0] = cu.refi[1] = 0;
         if (dco == 0) { memset(cu.mv, 0, sizeof(cu.mv)); return; }

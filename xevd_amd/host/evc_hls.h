@@ -173,9 +173,8 @@ static inline int ilog2i(int v) { int l = 0; while ((v >> (l + 1)) > 0) l++; ret
 struct RefPic {          // what a decoded picture leaves behind for later pictures (XEVD_PIC map_mv / list_poc, xevd_picman.c:213-221)
     int poc = 0, tid = 0;
     int list0_poc = 0;               // POC of reference 0 of ITS list 0 (pic->list_poc[0]); temporal direct mode scales by it
-    std::vector<int16_t> mv0;        // [f_scu][2]: list-0 motion of every SCU (refp.map_mv[scup][REFP_0])
-    std::vector<int16_t> mv;         // [f_scu][2][2] and
-    std::vector<int8_t> refi;        // [f_scu][2]: both lists (tool_admvp's temporal candidates read them)
+    std::vector<int16_t> mv;         // [f_scu][2][2]: the motion of every SCU, both lists (refp.map_mv; the Baseline temporal predictor reads list 0) and
+    std::vector<int8_t> refi;        // [f_scu][2]: the reference indices (tool_admvp's temporal candidates read them; empty otherwise)
     int list_poc[16] = { 0 };        // pic->list_poc[]: POCs of ITS list-0 references (indexed by reference indices of EITHER list, xevdm_util.c:3760-3761)
     const int16_t *luma = nullptr;   // the decoded picture's luma samples on the host (sample (0, 0), >= 144 samples of replicated border), registered by the caller
     int luma_stride = 0;             //   when the front end refines vectors itself (xhost_parser_set_ref_luma; dmvr_search.h)
@@ -215,13 +214,23 @@ struct Picture {         // SCU maps of the picture being parsed / written (ctx-
     std::vector<int16_t> mv;         // [f_scu][2][2]: the CUs' own vectors (mctx->map_unrefined_mv)
     std::vector<int16_t> mv_ref;     // host-side DMVR (Sps::host_dmvr): ctx->map_mv - the refined vectors of refined sub-blocks, the CU's own elsewhere; else empty
     std::vector<int8_t> refi;        // [f_scu][2]
-    void reset(int w, int h, bool refined_map = false)
+    // size(): the maps get the picture's geometry (contents undefined); clear_rows(): the state every picture starts from, for SCU rows [y0, y1) - the parser
+    // clears row bands on its tile threads (at 8K the maps are 29 MB: a serial 10 ms in front of every picture otherwise); reset() = both, serially
+    void size(int w, int h, bool refined_map = false)
     {
         w_scu = w >> 2; h_scu = h >> 2;
         const size_t f = (size_t)w_scu * h_scu;
-        if (refined_map) mv_ref.assign(f * 4, 0); else mv_ref.clear();
-        cod.assign(f, 0); intra.assign(f, 0); ibc.assign(f, 0); ipm.assign(f, 0); mv.assign(f * 4, 0); refi.assign(f * 2, -1); tidx.clear(); aff.clear(); skip.clear(); cu_size.clear();
+        if (refined_map) mv_ref.resize(f * 4); else mv_ref.clear();
+        cod.resize(f); intra.resize(f); ibc.resize(f); ipm.resize(f); mv.resize(f * 4); refi.resize(f * 2); tidx.clear(); aff.clear(); skip.clear(); cu_size.clear();
     }
+    void clear_rows(int y0, int y1)
+    {
+        const size_t a = (size_t)y0 * w_scu, n = (size_t)(y1 - y0) * w_scu;
+        if (!mv_ref.empty()) memset(mv_ref.data() + a * 4, 0, n * 4 * sizeof(int16_t));
+        memset(cod.data() + a, 0, n); memset(intra.data() + a, 0, n); memset(ibc.data() + a, 0, n); memset(ipm.data() + a, 0, n);
+        memset(mv.data() + a * 4, 0, n * 4 * sizeof(int16_t)); memset(refi.data() + a * 2, -1, n * 2);
+    }
+    void reset(int w, int h, bool refined_map = false) { size(w, h, refined_map); clear_rows(0, h_scu); }
 };
 
 struct Batch {           // the xgpu_cu_batch under construction
@@ -502,7 +511,7 @@ struct Stream {          // everything both directions share
                 for (size_t i = 0; i < dpb.size();) {
                     bool named = false;
                     for (int l = 0; l < 2 && !named; l++) for (int j = 0; j < sh.rpl[l].n && !named; j++) named = dpb[i].poc == poc - sh.rpl[l].ref[j];
-                    if (named) i++; else { rpl_released.push_back(dpb[i].poc); dpb.erase(dpb.begin() + (long)i); }
+                    if (named) i++; else { rpl_released.push_back(dpb[i].poc); drop_ref(i); }
                 }
             if (keep_lists)
                 for (int l = 0; l < 2; l++) {
@@ -572,26 +581,43 @@ struct Stream {          // everything both directions share
         }
         released.insert(released.end(), rpl_released.begin(), rpl_released.end());
         rpl_released.clear();
-        if (idr) { for (const RefPic &r : dpb) released.push_back(r.poc); dpb.clear(); }
+        if (idr) { for (const RefPic &r : dpb) released.push_back(r.poc); while (!dpb.empty()) drop_ref(dpb.size() - 1); }
         else if (tid == 0 && (!sps.tool_rpl || enc_side)) {            // sliding-window marking only without RPLs (xevdm_picman_put_pic, xevdm_picman.c:595-606)
             const int gap = 1 << sps.log2_ref_gap;
             for (size_t i = 0; i < dpb.size();) {
-                if (dpb[i].tid > 0 || (i > 0 && gap > 0 && dpb[i].poc % gap != 0)) { released.push_back(dpb[i].poc); dpb.erase(dpb.begin() + (long)i); }
+                if (dpb[i].tid > 0 || (i > 0 && gap > 0 && dpb[i].poc % gap != 0)) { released.push_back(dpb[i].poc); drop_ref(i); }
                 else i++;
             }
-            while (dpb.size() >= 5) { released.push_back(dpb[0].poc); dpb.erase(dpb.begin()); }      // XEVD_MAX_NUM_ACTIVE_REF_FRAME
+            while (dpb.size() >= 5) { released.push_back(dpb[0].poc); drop_ref(0); }      // XEVD_MAX_NUM_ACTIVE_REF_FRAME
         }
         if (!is_ref_picture()) return;
         // bound on a damaged stream that keeps sending tid > 0 reference pictures without a tid-0 picture between them
-        while (dpb.size() >= 32) { released.push_back(dpb[0].poc); dpb.erase(dpb.begin()); }
+        while (dpb.size() >= 32) { released.push_back(dpb[0].poc); drop_ref(0); }
         RefPic r;
         r.poc = poc; r.tid = tid; r.list0_poc = stale_list0_poc;
-        const size_t f = (size_t)pic.w_scu * pic.h_scu;
-        const std::vector<int16_t> &kept = pic.mv_ref.empty() ? pic.mv : pic.mv_ref;      // ctx->map_mv: with host-side DMVR the refined vectors
-        r.mv0.resize(f * 2);
-        for (size_t k = 0; k < f; k++) { r.mv0[k * 2] = kept[k * 4]; r.mv0[k * 2 + 1] = kept[k * 4 + 1]; }
-        if (sps.tool_admvp) { r.mv = kept; r.refi = pic.refi; memcpy(r.list_poc, stale_list_poc, sizeof(r.list_poc)); }
+        // The picture's motion field MOVES into the DPB entry (at 8K it is 16.6 MB + 4 MB of reference indices: copying them, and extracting a list-0 copy, was a
+        // serial 18 ms behind every reference picture); the maps of the next picture take the vectors of an entry that left the DPB (pool) - no allocation, no
+        // page faults in the steady state.  ctx->map_mv: with host-side DMVR the refined vectors
+        std::vector<int16_t> &kept = pic.mv_ref.empty() ? pic.mv : pic.mv_ref;
+        r.mv = std::move(kept);
+        kept.clear();
+        if (!mv_pool.empty()) { kept = std::move(mv_pool.back()); mv_pool.pop_back(); }
+        if (sps.tool_admvp) {
+            r.refi = std::move(pic.refi);
+            pic.refi.clear();
+            if (!refi_pool.empty()) { pic.refi = std::move(refi_pool.back()); refi_pool.pop_back(); }
+            memcpy(r.list_poc, stale_list_poc, sizeof(r.list_poc));
+        }
         dpb.push_back(std::move(r));
+    }
+    // a picture leaves the DPB: its motion vectors go back to the pool the picture maps draw from
+    std::vector<std::vector<int16_t>> mv_pool;
+    std::vector<std::vector<int8_t>> refi_pool;
+    void drop_ref(size_t i)
+    {
+        if (!dpb[i].mv.empty() && mv_pool.size() < 4) mv_pool.push_back(std::move(dpb[i].mv));
+        if (!dpb[i].refi.empty() && refi_pool.size() < 4) refi_pool.push_back(std::move(dpb[i].refi));
+        dpb.erase(dpb.begin() + (long)i);
     }
 
 };

@@ -8,6 +8,7 @@
 // batch that xgpu_batch_create takes; the reference's two passes over XEVD_CU_DATA (xevd_tile_eco, then xevd_ctu_row_rec_mt)
 // see the same neighbour state because both walk the CUs in the same order and "reconstructed" (COD) == "already parsed".
 #include "evc_cu.h"
+#include <chrono>
 
 // =============================================================================================================== parser
 // One tile of a picture being parsed: its coder state, its share of the batch, its scratch blocks.  Objects are kept between pictures (the vectors keep
@@ -16,10 +17,9 @@ struct TileParser {
     Stream &st;
     TileCoder tc;
     Batch batch;
-    std::vector<int16_t> blk[3];
     std::string err;
     size_t n_coef = 0;
-    explicit TileParser(Stream &s) : st(s), tc(s) { for (int k = 0; k < 3; k++) blk[k].assign(64 * 64, 0); }
+    explicit TileParser(Stream &s) : st(s), tc(s) {}
     int fail(const char *m) { err = m; return XHOST_ERR_MALFORMED; }
     // xevd_tile_eco (src_main/xevdm.c:2363-2461) for tile (tc_, tr) of the grid, from bit position `pos` of the slice NAL
     int parse_tile(const BitReader &br0, size_t pos, int tcol, int trow)
@@ -97,14 +97,15 @@ struct TileParser {
         Cu cu;
         memset(&cu, 0, sizeof(cu));
         cu.x = x; cu.y = y; cu.log2w = lw; cu.log2h = lh; cu.qp_code = qp_code; cu.only_inter = only_inter; cu.tree = tree;
-        int16_t *coef[3] = { blk[0].data(), blk[1].data(), blk[2].data() };
-        memset(coef[0], 0, sizeof(int16_t) << (lw + lh));
-        memset(coef[1], 0, sizeof(int16_t) << (lw + lh - 2));
-        memset(coef[2], 0, sizeof(int16_t) << (lw + lh - 2));
+        // the coefficient blocks are decoded where they stay: zeroed space for all three components at the end of the tile's arena, given back behind the
+        // blocks that turn out to be coded (they are packed together when one in front of them is not)
+        if (batch.x.empty()) n_coef = 0;
+        const size_t nl = (size_t)1 << (lw + lh), nc = nl >> 2;
+        batch.coef.resize(n_coef + nl + 2 * nc);
+        int16_t *coef[3] = { batch.coef.data() + n_coef, batch.coef.data() + n_coef + nl, batch.coef.data() + n_coef + nl + nc };
         tc.code_cu(dec, cu, coef, false);
         tc.commit(cu);
         // append to the batch
-        if (batch.x.empty()) n_coef = 0;
         batch.x.push_back((uint16_t)x); batch.y.push_back((uint16_t)y); batch.log2w.push_back((uint8_t)lw); batch.log2h.push_back((uint8_t)lh);
         batch.pred_mode.push_back((uint8_t)cu.mode);
         batch.refi.push_back((int8_t)cu.refi[0]); batch.refi.push_back((int8_t)cu.refi[1]);
@@ -125,9 +126,11 @@ struct TileParser {
         for (int k = 0; k < 3; k++)
             if (cu.cbf[k]) {
                 const size_t n = (size_t)1 << (lw + lh - (k ? 2 : 0) - tu_shift);
-                batch.coef.insert(batch.coef.end(), coef[k], coef[k] + n);
+                int16_t *dst = batch.coef.data() + n_coef;
+                if (dst != coef[k]) memmove(dst, coef[k], n * sizeof(int16_t));
                 n_coef += n;
             }
+        batch.coef.resize(n_coef);
         return XGPU_OK;
     }
 };
@@ -381,6 +384,9 @@ struct xhost_parser {
     int parse_slice(BitReader &br, int nut, int tid, xhost_picture *out)
     {
         if (!st.have_sps || !st.have_pps) return fail("slice before SPS/PPS");
+        static const bool tr_on = getenv("XEVD_HOST_TRACE") != NULL;      // phase times of the front end on stderr
+        auto tr_t0 = std::chrono::steady_clock::now();
+        auto TR = [&](const char *what) { if (tr_on) { const auto t = std::chrono::steady_clock::now(); fprintf(stderr, "  parse: %-14s %.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tr_t0).count()); tr_t0 = t; } };
         if (st.need_idr && nut != NUT_IDR) return fail("the sequence parameters changed: waiting for an IDR picture");
         st.need_idr = false;
         Slice &sh = st.sh;
@@ -455,15 +461,20 @@ struct xhost_parser {
         if (sh.type == XHOST_SLICE_B && st.refp[1].empty()) return fail("B slice without a list-1 reference picture");
         for (int l = 0; l < 2; l++)
             for (const RefPic *r : st.refp[l])
-                if (r->mv0.size() != (size_t)(st.sps.width >> 2) * (st.sps.height >> 2) * 2) return fail("reference picture of another geometry");
+                if (r->mv.size() != (size_t)(st.sps.width >> 2) * (st.sps.height >> 2) * 4) return fail("reference picture of another geometry");
         const int W = st.sps.width, H = st.sps.height, w_ctu = (W + 63) >> 6, h_ctu = (H + 63) >> 6;
         if (first_slice) {
-            st.pic.reset(st.sps.width, st.sps.height, st.sps.host_dmvr());
+            st.pic.size(st.sps.width, st.sps.height, st.sps.host_dmvr());
+            {       // the maps' start state, in row bands on the tile threads
+                const int bands = std::max(1, std::min(n_threads, st.pic.h_scu / 16));
+                parallel_for(bands, [&](int k) { st.pic.clear_rows((int)((long long)st.pic.h_scu * k / bands), (int)((long long)st.pic.h_scu * (k + 1) / bands)); });
+            }
             if (!st.setup_tiles()) return fail("the tile grid of the PPS does not fit the picture");
             st.alf_ctb_flag.assign((size_t)w_ctu * h_ctu, 1);
             tile_done.assign((size_t)n_tiles, 0);
             pic_nut = nut; pic_tid = tid; pic_poc = st.poc; pic_inter = 0; pic_qp = sh.qp;
         }
+        TR("header + reset");
         // The backend takes ONE pair of reference lists per picture (and the reference decoder deblocks the whole picture with the lists of its last P / B slice,
         // ctx->refp at src_main/xevdm.c:3138-3199): the P / B slices of a picture must name the same pictures; I slices may be mixed in
         if (sh.type != XHOST_SLICE_I) {
@@ -482,6 +493,7 @@ struct xhost_parser {
         for (int t = 1; t < n_slice_tiles; t++) tile_pos[(size_t)t] = tile_pos[(size_t)t - 1] + tile_size[(size_t)t - 1] * 8;
         std::vector<int> tile_rc((size_t)n_slice_tiles, XGPU_OK);
         parallel_for(n_slice_tiles, [&](int i) { const int t = tl[(size_t)i]; tile_rc[(size_t)i] = tiles[(size_t)t]->parse_tile(br, tile_pos[(size_t)i], t % st.grid.n_cols, t / st.grid.n_cols); });
+        TR("tiles");
         for (int i = 0; i < n_slice_tiles; i++) if (tile_rc[(size_t)i] != XGPU_OK) { err = tiles[(size_t)tl[(size_t)i]]->err; pic_tiles_left = 0; return tile_rc[(size_t)i]; }
         if (first_slice) pic_tiles_left = n_tiles;
         for (int t : tl) tile_done[(size_t)t] = 1;
@@ -536,6 +548,7 @@ struct xhost_parser {
             });
             cur = &merged; n_coef = cf0[(size_t)n_tiles];
         }
+        TR("merge");
         cur->ctu_start.push_back((uint32_t)cur->x.size());
         Held &hd = held[n_handed++ % held.size()];
         std::swap(hd.batch, *cur);                       // the parser's working vectors take over the slot's old storage (cleared / resized at their next use)
@@ -581,7 +594,9 @@ struct xhost_parser {
             out->alf.ctb_flag = hd.ctb.data(); out->alf.across_tiles = st.pps.across_tiles; out->alf.tiles = n_tiles > 1 ? &hd.grid : nullptr;
         }
         std::vector<int> released;
+        TR("hand-over");
         st.store_picture(nut == NUT_IDR, released, pic_inter);
+        TR("store picture");
         out->n_release = (int)std::min(released.size(), (size_t)32);
         for (int i = 0; i < out->n_release; i++) out->release_poc[i] = released[(size_t)i];
         xgpu_cu_batch &b = out->batch;
