@@ -14,9 +14,10 @@
  * chain on one host core (an 8K picture takes tens of milliseconds to parse, its kernels half a millisecond), so a GPU is fed by parsing
  * several GOPs at once.
  * --tile-threads T lets every worker's parser use T threads for the tiles of one picture (xhost_parser_set_threads).
- * Every worker runs its parser on a thread of its own, one picture ahead of the thread that builds the device batch and launches the kernels
- * (--no-pipeline: back to back on one thread, as xevd_dec_nalu does it).
- * usage: evc_decode [--gpus N] [--workers W] [--tile-threads T] [--build-threads B] [--no-pipeline] [--trace] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
+ * Every worker is a pipeline of three threads: the parser (entropy decoding, picture k + 2), the batch builder (xgpu_batch_create, picture k + 1) and the
+ * device thread (kernel launches and output of picture k); --no-pipeline: back to back on one thread, as xevd_dec_nalu does it.  A worker keeps its parser
+ * (xhost_parser_rebind), its context, its pinned buffers and its threads from unit to unit.
+ * usage: evc_decode [--gpus N] [--workers W] [--tile-threads T] [--build-threads B] [--keep-units K] [--no-pipeline] [--trace] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
  *        evc_decode in.evc out.yuv D                                               (the round-1 form)
  * build: oracle-free; see examples/Makefile.
  */
@@ -37,6 +38,7 @@
 #define MAX_GOPS 4096
 #define CHECK(call) do { int rc_ = (call); if (rc_ < 0) { fprintf(stderr, "%s -> %d (%s)\n", #call, rc_, w->g ? xgpu_last_error(w->g) : ""); return rc_; } } while (0)
 static double now_s(void);
+static int g_keep_units = -1;      /* --keep-units K: only the first K units (closed GOPs) of every input are written to its output file; the rest is decoded all the same (long timing runs) */
 static int g_build_threads = 8;     /* --build-threads B: host threads xgpu_batch_create spreads its per-CU passes over */
 
 typedef struct { int poc, pic, in_use; } slot_t;                 /* DPB: POC -> device picture slot */
@@ -56,6 +58,7 @@ typedef struct {                                                    /* one worke
     int arena_ok;
     int16_t *ref_luma[MAX_SLOTS + 2];                               /* host copies of decoded luma planes, by device picture (only for streams whose parser asks) */
     double parse_s, build_s;                                        /* inside xhost_parser_next (its own thread with the pipeline) / inside xgpu_batch_create */
+    xhost_parser *ps;                                               /* the worker's parser, rebound to every unit (xhost_parser_rebind): its memory and tile threads stay */
 } worker_t;
 
 static double now_s(void)
@@ -139,40 +142,79 @@ static int g_pipeline = 1;          /* --no-pipeline: parse and reconstruct ever
  * pipeline: while this worker turns picture k into a device batch and launches its kernels, the parser thread is already inside xhost_parser_next
  * for picture k + 1 (xhost_parser_set_depth(2): the arrays of two pictures stay valid).  Pictures with DMVR candidates break the overlap for one
  * step: the parser needs their refined vectors from the device before it goes on (xhost_parser_set_dmvr_mvs). */
+#define PIPE_DEPTH 3                 /* pictures in flight between the parser, the builder and the device thread */
 typedef struct {
     xhost_parser *ps;
-    xhost_picture pic[2];
-    int rc[2];
-    double parse_ms[2];
-    long produced, released;        /* pictures handed over by the parser thread / given back by the consumer */
+    xhost_picture pic[PIPE_DEPTH];
+    int rc[PIPE_DEPTH];
+    double parse_ms[PIPE_DEPTH];
+    xgpu_dbatch *db[PIPE_DEPTH];     /* built by the builder thread */
+    int build_rc[PIPE_DEPTH];
+    double build_ms[PIPE_DEPTH];
+    long produced, built, released;  /* pictures handed over by the parser thread / by the builder thread / given back by the consumer */
     int stop;
+    xgpu_ctx *g;                     /* the worker's context once the device thread has settled it for this unit (the builder thread waits for it) */
     pthread_mutex_t mu;
     pthread_cond_t cv;
-    double parse_s;
+    double parse_s, build_s;
 } pipe_t;
 
 static void *parser_thread(void *arg)
 {
     pipe_t *q = (pipe_t *)arg;
     for (long k = 0;; k++) {
+        const int s = (int)(k % PIPE_DEPTH);
         pthread_mutex_lock(&q->mu);
-        while (!q->stop && q->released < k - 1) pthread_cond_wait(&q->cv, &q->mu);      /* slot k & 1 is free once picture k - 2 has been given back */
+        while (!q->stop && q->released < k - (PIPE_DEPTH - 1)) pthread_cond_wait(&q->cv, &q->mu);      /* slot k % depth is free once picture k - depth has been given back */
         const int stop = q->stop;
         pthread_mutex_unlock(&q->mu);
         if (stop) break;
         const double t0 = now_s();
-        const int rc = xhost_parser_next(q->ps, &q->pic[k & 1]);
+        const int rc = xhost_parser_next(q->ps, &q->pic[s]);
         q->parse_s += now_s() - t0;
-        q->parse_ms[k & 1] = 1e3 * (now_s() - t0);
+        q->parse_ms[s] = 1e3 * (now_s() - t0);
         pthread_mutex_lock(&q->mu);
-        q->rc[k & 1] = rc;
+        q->rc[s] = rc;
         q->produced = k + 1;
         pthread_cond_broadcast(&q->cv);
         /* DMVR feedback: picture k's refined vectors - or, when the parser refines itself (tool_dmvr with tool_hmvp / tool_mmvd), picture k's decoded
            luma samples - reach the parser (from the consumer, while this thread waits here) before picture k + 1 is parsed */
-        if (rc == 1 && (q->pic[k & 1].n_dmvr_sub > 0 || q->pic[k & 1].needs_ref_luma)) while (!q->stop && q->released < k + 1) pthread_cond_wait(&q->cv, &q->mu);
+        if (rc == 1 && (q->pic[s].n_dmvr_sub > 0 || q->pic[s].needs_ref_luma)) while (!q->stop && q->released < k + 1) pthread_cond_wait(&q->cv, &q->mu);
         pthread_mutex_unlock(&q->mu);
         if (rc != 1) break;
+    }
+    return NULL;
+}
+
+/* The middle stage: picture k's device batch (xgpu_batch_create: records, transform-block lists, dependency plan, staging block, upload) is built here while the
+   device thread launches picture k - 1 and the parser is inside picture k + 1.  xgpu_batch_create may run next to the thread that drives the context. */
+static void *builder_thread(void *arg)
+{
+    pipe_t *q = (pipe_t *)arg;
+    for (long k = 0;; k++) {
+        const int s = (int)(k % PIPE_DEPTH);
+        pthread_mutex_lock(&q->mu);
+        while (!q->stop && q->produced <= k) pthread_cond_wait(&q->cv, &q->mu);
+        const int prc = q->stop ? 0 : q->rc[s];
+        while (!q->stop && prc == 1 && !q->g) pthread_cond_wait(&q->cv, &q->mu);       /* the device thread opens the context at the unit's first picture */
+        xgpu_ctx *g = q->g;
+        const int stop = q->stop;
+        pthread_mutex_unlock(&q->mu);
+        if (stop) break;
+        int brc = 0;
+        q->db[s] = NULL;
+        if (prc == 1) {
+            const double t0 = now_s();
+            brc = xgpu_batch_create(g, &q->pic[s].batch, &q->db[s]);
+            q->build_ms[s] = 1e3 * (now_s() - t0);
+            q->build_s += now_s() - t0;
+        }
+        pthread_mutex_lock(&q->mu);
+        q->build_rc[s] = brc;
+        q->built = k + 1;
+        pthread_cond_broadcast(&q->cv);
+        pthread_mutex_unlock(&q->mu);
+        if (prc != 1 || brc < 0) break;
     }
     return NULL;
 }
@@ -186,38 +228,48 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
     size_t frame_bytes = 0;                                         /* download of picture k runs while picture k + 1 is parsed and launched     */
     xgpu_dbatch *db = NULL;
     int16_t *mv = NULL;
-    pthread_t th;
+    pthread_t th, bth;
+    int builder_on = 0;
     pipe_t q;
     memset(&q, 0, sizeof(q));
     memset(dpb, 0, sizeof(dpb));
     out_t *outs = (out_t *)malloc(sizeof(out_t) * (size_t)(expected > 0 ? expected : 1));
     pthread_mutex_init(&q.mu, NULL); pthread_cond_init(&q.cv, NULL);      /* before the first goto done, which destroys them */
-    q.ps = xhost_parser_open(bytes, size);
-    if (!outs || !q.ps) { rc = -1; goto done; }
-    if (g_tile_threads > 1) xhost_parser_set_threads(q.ps, g_tile_threads);      /* the tiles of a picture on parallel host threads */
     pthread_mutex_lock(&w->arena_mu); w->arena_ok = 0; pthread_mutex_unlock(&w->arena_mu);
-    xhost_parser_set_arena(q.ps, arena_alloc, arena_release, w);
+    if (w->ps) { if (xhost_parser_rebind(w->ps, bytes, size) < 0) { rc = -1; goto done; } }
+    else {
+        w->ps = xhost_parser_open(bytes, size);
+        if (w->ps) {
+            if (g_tile_threads > 1) xhost_parser_set_threads(w->ps, g_tile_threads);      /* the tiles of a picture on parallel host threads */
+            xhost_parser_set_arena(w->ps, arena_alloc, arena_release, w);
+            if (g_pipeline) xhost_parser_set_depth(w->ps, PIPE_DEPTH);
+        }
+    }
+    q.ps = w->ps;
+    if (!outs || !q.ps) { rc = -1; goto done; }
     if (g_pipeline) {
-        xhost_parser_set_depth(q.ps, 2);
         if (pthread_create(&th, NULL, parser_thread, &q) != 0) { rc = -1; goto done; }
         thread_on = 1;
+        if (pthread_create(&bth, NULL, builder_thread, &q) != 0) { rc = -1; goto done; }
+        builder_on = 1;
     }
 #define FAIL(code) do { rc = (code); goto done; } while (0)
 #define TRY(call) do { int rc_ = (call); if (rc_ < 0) { fprintf(stderr, "%s -> %d (%s)\n", #call, rc_, w->g ? xgpu_last_error(w->g) : ""); FAIL(rc_); } } while (0)
 
     for (long k = 0;; k++) {
-        xhost_picture *pp = &q.pic[k & 1];
+        const int ks = (int)(k % PIPE_DEPTH);
+        xhost_picture *pp = &q.pic[ks];
         int prc;
         if (thread_on) {
             pthread_mutex_lock(&q.mu);
             while (q.produced <= k) pthread_cond_wait(&q.cv, &q.mu);
-            prc = q.rc[k & 1];
+            prc = q.rc[ks];
             pthread_mutex_unlock(&q.mu);
         } else {
             const double t0 = now_s();
             prc = xhost_parser_next(q.ps, pp);
             q.parse_s += now_s() - t0;
-            q.parse_ms[k & 1] = 1e3 * (now_s() - t0);
+            q.parse_ms[ks] = 1e3 * (now_s() - t0);
         }
         if (prc < 0) { fprintf(stderr, "parser: %s\n", xhost_parser_error(q.ps)); FAIL(prc); }
         if (prc == 0) break;
@@ -238,6 +290,7 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
             frames = w->frames; pinned = w->frames_pinned;
             if (!frames) FAIL(-1);
             have_ctx = 1;
+            pthread_mutex_lock(&q.mu); q.g = w->g; pthread_cond_broadcast(&q.cv); pthread_mutex_unlock(&q.mu);      /* the builder thread may start */
         }
         if (p.is_idr) {                                              /* an IDR empties the DPB */
             for (int i = 0; i < MAX_SLOTS; i++) if (dpb[i].in_use) { free_pic[n_free++] = dpb[i].pic; dpb[i].in_use = 0; }
@@ -269,11 +322,23 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
         fp.deblock_alpha_offset = p.deblock_alpha_offset; fp.deblock_beta_offset = p.deblock_beta_offset;
         fp.deblock_on = p.deblock_on; fp.alf_on = p.alf_on;
 
-        const double tb = now_s();
-        TRY(xgpu_batch_create(w->g, &p.batch, &db));                /* the parser's arrays are consumed before the call returns */
-        w->build_s += now_s() - tb;
+        double build_ms;
+        if (builder_on) {                                            /* built by the builder thread while picture k - 1 was being launched */
+            pthread_mutex_lock(&q.mu);
+            while (q.built <= k) pthread_cond_wait(&q.cv, &q.mu);
+            const int brc = q.build_rc[ks];
+            db = q.db[ks]; q.db[ks] = NULL;
+            build_ms = q.build_ms[ks];
+            pthread_mutex_unlock(&q.mu);
+            if (brc < 0) { fprintf(stderr, "xgpu_batch_create -> %d (%s)\n", brc, xgpu_last_error(w->g)); FAIL(brc); }
+        } else {
+            const double tb = now_s();
+            TRY(xgpu_batch_create(w->g, &p.batch, &db));            /* the parser's arrays are consumed before the call returns */
+            q.build_s += now_s() - tb;
+            build_ms = 1e3 * (now_s() - tb);
+        }
         if (g_trace) fprintf(stderr, "picture %ld: poc %d slice %s, %d CUs, %zu coefficients: parse %.2f ms, batch build %.2f ms\n", k, p.poc,
-                             p.slice_type == XHOST_SLICE_I ? "I" : p.slice_type == XHOST_SLICE_P ? "P" : "B", p.batch.n_cu, p.batch.n_coef, q.parse_ms[k & 1], 1e3 * (now_s() - tb));
+                             p.slice_type == XHOST_SLICE_I ? "I" : p.slice_type == XHOST_SLICE_P ? "P" : "B", p.batch.n_cu, p.batch.n_coef, q.parse_ms[ks], build_ms);
         TRY(xgpu_frame_begin(w->g, &fp));
         TRY(xgpu_batch_recon(w->g, db));
         if (p.deblock_on) TRY(xgpu_deblock(w->g));
@@ -337,10 +402,12 @@ done:
         pthread_cond_broadcast(&q.cv);
         pthread_mutex_unlock(&q.mu);
         pthread_join(th, NULL);
+        if (builder_on) pthread_join(bth, NULL);
+        for (int i = 0; i < PIPE_DEPTH; i++) if (q.db[i]) { xgpu_batch_destroy(w->g, q.db[i]); q.db[i] = NULL; }      /* built, never launched (an error further down the pipeline) */
     }
     pthread_mutex_destroy(&q.mu); pthread_cond_destroy(&q.cv);
-    if (q.ps) xhost_parser_close(q.ps);
-    w->parse_s += q.parse_s;
+    if (rc < 0 && w->ps) { xhost_parser_close(w->ps); w->ps = NULL; }      /* a failed unit: the next one starts with a new parser */
+    w->parse_s += q.parse_s; w->build_s += q.build_s;
     free(mv);
     if (db) xgpu_batch_destroy(w->g, db);
     if (rc < 0) {                                                   /* nothing is handed out on failure */
@@ -385,7 +452,7 @@ static int worker_job(void *state, const xwq_job *job)
     free(unit);
     if (rc < 0) return rc;
     if (n != job->n_pictures) { fprintf(stderr, "stream %d unit %d: %d pictures decoded, %d expected\n", job->stream, job->unit, n, job->n_pictures); rc = -1; }
-    else
+    else if (g_keep_units < 0 || job->unit < g_keep_units)
         for (int i = 0; i < n && rc >= 0; i++)                       /* picture by picture, in output order, at the unit's place in the file */
             if (pwrite(s->fd, frames + outs[i].off, frame_bytes, (off_t)((size_t)(job->first_picture + i) * frame_bytes)) != (ssize_t)frame_bytes) { perror("pwrite"); rc = -1; }
     (void)pinned;                                                   /* `frames` is the worker's buffer: reused by its next unit */
@@ -400,6 +467,7 @@ static void worker_fini(void *state)
     worker_t *w = (worker_t *)state;
     { const int k = __sync_fetch_and_add(&g_workers, 1); g_busy[k & 63] = w->busy_s - w->setup_s; g_setup[k & 63] = w->setup_s; g_parse[k & 63] = w->parse_s; g_build[k & 63] = w->build_s; }
     if (w->frames && !w->frames_pinned) free(w->frames);            /* (pinned memory goes with the context) */
+    if (w->ps) xhost_parser_close(w->ps);                           /* before the context: it gives its arenas back */
     if (w->g) xgpu_close(w->g);
     for (int i = 0; i < MAX_SLOTS + 2; i++) free(w->ref_luma[i]);
     free(w);
@@ -420,6 +488,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[a], "--no-pipeline")) { g_pipeline = 0; a += 1; }
         else if (!strcmp(argv[a], "--trace")) { g_trace = 1; a += 1; }
         else if (!strcmp(argv[a], "--build-threads") && a + 1 < argc) { g_build_threads = atoi(argv[a + 1]); a += 2; }
+        else if (!strcmp(argv[a], "--keep-units") && a + 1 < argc) { g_keep_units = atoi(argv[a + 1]); a += 2; }
         else break;
     }
     int n_pos = argc - a;

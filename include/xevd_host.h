@@ -83,6 +83,10 @@ typedef struct xhost_picture {
 } xhost_picture;
 
 xhost_parser *xhost_parser_open(const uint8_t *bytes, size_t size);
+/* The same parser object on another independent byte string (parameter sets + closed GOPs, e.g. the next unit of a work queue): every bit of stream state
+   starts afresh exactly as in a new parser, but the object keeps its memory (picture maps, motion fields, tile batches, the arenas of xhost_parser_set_arena)
+   and its tile threads - a new parser per GOP pays for ~300 MB of fresh pages at 8K.  Pictures handed out before are invalid afterwards.  0 or < 0. */
+int  xhost_parser_rebind(xhost_parser *p, const uint8_t *bytes, size_t size);
 /* 1: `out` holds the next picture in decoding order; 0: end of stream; < 0: error */
 int  xhost_parser_next(xhost_parser *p, xhost_picture *out);
 /* sps->tool_dmvr: the vectors xgpu_batch_dmvr_mvs returned for the picture the parser handed out last ([n_sub][list][x/y], n_sub = its n_dmvr_sub): the

@@ -1,0 +1,98 @@
+"""The host batch builder (xgpu_batch_create's host half) without a device: xgpu_test_build_batch builds the staging block of a batch in host memory and returns a digest
+per array (CU records, CTU starts, TB records, itdq work items, intra records, dependency lists, affine tiles, control points, DMVR sub-blocks, owner map).
+Pinned here: the arrays do not depend on the number of builder threads, and they equal the committed digests (tests/golden/builder_digests.json, written by this
+file's --write with the builder whose staging blocks the GPU suite decodes bit-exactly: a refactoring of the builder must reproduce them byte for byte)."""
+import ctypes as C
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import golden_io
+from xevd_amd import abi, stream
+
+GOLDEN_FILE = os.path.join(golden_io.GOLDEN, "builder_digests.json")
+
+
+def _lib():
+    lib = abi.load()
+    lib.xgpu_test_build_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_double)]
+    lib.xgpu_test_build_batch.restype = C.c_int
+    return lib
+
+
+def _build(lib, sp, cb, threads):
+    dg, info, ms = (C.c_uint64 * 11)(), (C.c_int * 8)(), C.c_double()
+    rc = lib.xgpu_test_build_batch(C.byref(sp), C.byref(cb), threads, dg, info, C.byref(ms))
+    assert rc == 0, rc
+    return [f"{int(v):016x}" for v in dg][:10] + [int(v) for v in info]      # (the coefficient array is the caller's, sent from where it lies: digest 10 is empty)
+
+
+def picture_digests(lib, name, threads):
+    case, _ = golden_io.load_picture_case(name)
+    sp = abi.make_seq_params(case["w"], case["h"], case["bd"], log2_ctu=case["log2_ctu"], iqt=case["iqt"], admvp=case["admvp"], addb=case["addb"], alf=case["alf"], eipd=case["eipd"])
+    cb, keep = abi.make_cu_batch(case["batch"])
+    return _build(lib, sp, cb, threads)
+
+
+def stream_digests(lib, path, threads):
+    data = np.load(path)["bytes"].tobytes()
+    out = []
+
+    def consume(params, cbs):
+        sp = abi.make_seq_params(params["width"], params["height"], params["bit_depth"], iqt=params["iqt"], admvp=params["admvp"], addb=params["addb"], alf=params["tool_alf"],
+                                 eipd=params["eipd"], bit_depth_chroma=params["bit_depth_chroma"])
+        out.append(_build(lib, sp, cbs, threads))
+    for p in stream.iter_stream(data, consume_batch=consume):
+        # streams with tool_dmvr expect the backend's refined vectors / decoded luma before the next picture: there is no backend here - fixed stand-ins (the
+        # vectors of later pictures then differ from a real decode, deterministically: the builder's input is still a valid batch)
+        if p["n_dmvr_sub"]:
+            p["dmvr_feedback"](np.zeros((p["n_dmvr_sub"], 2, 2), np.int16))
+        if p["needs_ref_luma"]:
+            p["set_ref_luma"](p["poc"], np.full((p["height"] + 288, p["width"] + 288), 1 << (p["bit_depth"] - 1), np.int16), 144)
+    return out
+
+
+STREAMS = sorted(glob.glob(os.path.join(golden_io.GOLDEN, "stream_*.npz")))
+
+
+@pytest.mark.parametrize("name", golden_io.PICTURE_CASES)
+def test_builder_picture_cases(name):
+    lib = _lib()
+    want = json.load(open(GOLDEN_FILE))["pic_" + name]
+    for threads in (1, 3):
+        assert picture_digests(lib, name, threads) == want, f"{threads} builder thread(s)"
+
+
+@pytest.mark.parametrize("path", STREAMS, ids=os.path.basename)
+def test_builder_stream_pictures(path):
+    lib = _lib()
+    want = json.load(open(GOLDEN_FILE))[os.path.basename(path)]
+    for threads in (1, 4):
+        assert stream_digests(lib, path, threads) == want, f"{threads} builder thread(s)"
+
+
+def test_builder_rejects_invalid_batches_without_a_device():
+    """the validation pass of the builder (geometry, reference indices, coefficient extents) answers before anything is allocated - also in the host-only shim"""
+    lib = _lib()
+    case, _ = golden_io.load_picture_case("base_p_8b")
+    sp = abi.make_seq_params(case["w"], case["h"], case["bd"])
+    for field, value in (("x", 60000), ("log2w", 9), ("coef_off", 1 << 30)):
+        b = dict(case["batch"])
+        b[field] = b[field].copy()
+        b[field][len(b[field]) // 2] = value
+        cb, keep = abi.make_cu_batch(b)
+        dg, info, ms = (C.c_uint64 * 11)(), (C.c_int * 8)(), C.c_double()
+        assert lib.xgpu_test_build_batch(C.byref(sp), C.byref(cb), 2, dg, info, C.byref(ms)) == -101, field
+
+
+if __name__ == "__main__" and "--write" in sys.argv:
+    lib = _lib()
+    out = {"pic_" + n: picture_digests(lib, n, 1) for n in golden_io.PICTURE_CASES}
+    for p in STREAMS:
+        out[os.path.basename(p)] = stream_digests(lib, p, 1)
+    json.dump(out, open(GOLDEN_FILE, "w"), indent=0)
+    print(len(out), "entries")

@@ -301,6 +301,53 @@ def test_several_slices_per_picture_boundaries_and_refusals():
         su.make_stream(256, 256, 2, seed=11, main=True, pocs=True, tiles=(4, 4, 0), slices=[(0, 7), (4, 15)])      # overlapping tile rectangles
 
 
+def test_parser_rebind_equals_a_new_parser():
+    """xhost_parser_rebind: one parser object (its picture maps, motion-field pool, tile batches and tile threads kept) on one independent byte string after the
+    other hands out exactly the pictures a new parser per string hands out - different geometries, profiles and tool sets in turn (what a work-queue worker
+    does with the GOP jobs it draws)"""
+    import ctypes as C
+    lib = stream.load()
+    lib.xhost_parser_rebind.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+    a = su.make_stream(256, 192, 5, seed=3, main=True, iqt=True, addb=True, alf=True, admvp=True, max_refs=2, tiles=(2, 2, 1))
+    b = su.make_stream(192, 128, 4, seed=4)
+
+    def parse_all(h):
+        out = []
+        while True:
+            hp = stream.HostPicture()
+            rc = lib.xhost_parser_next(h, C.byref(hp))
+            if rc <= 0:
+                assert rc == 0, lib.xhost_parser_error(h)
+                return out
+            n = hp.batch.n_cu
+            out.append((hp.poc, n, np.ctypeslib.as_array(hp.batch.mv, (n * 4,)).tobytes(), np.ctypeslib.as_array(hp.batch.pred_mode, (n,)).tobytes(), hp.batch.n_coef,
+                        np.ctypeslib.as_array(hp.batch.coef, (max(hp.batch.n_coef, 1),)).tobytes(), [hp.refp_poc[i][0] for i in range(hp.num_refp[0])]))
+
+    def fresh(d):
+        h = lib.xhost_parser_open(d, len(d))
+        lib.xhost_parser_set_threads(h, 3)
+        r = parse_all(h)
+        lib.xhost_parser_close(h)
+        return r
+    ra, rb = fresh(a), fresh(b)
+    assert len(ra) == 5 and len(rb) == 4
+    h = lib.xhost_parser_open(a, len(a))
+    lib.xhost_parser_set_threads(h, 3)
+    assert parse_all(h) == ra
+    for d, r in ((b, rb), (a, ra), (a, ra), (b, rb)):
+        assert lib.xhost_parser_rebind(h, d, len(d)) == 0
+        assert parse_all(h) == r
+    # a unit that ends in an error leaves a parser that can be rebound
+    assert lib.xhost_parser_rebind(h, a[:len(a) // 2], len(a) // 2) == 0
+    hp = stream.HostPicture()
+    while True:
+        rc = lib.xhost_parser_next(h, C.byref(hp))
+        if rc <= 0:
+            break
+    assert lib.xhost_parser_rebind(h, b, len(b)) == 0 and parse_all(h) == rb
+    lib.xhost_parser_close(h)
+
+
 @pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(golden_io.GOLDEN, "stream_*.npz"))), ids=os.path.basename)
 def test_golden_streams_parser_plus_oracle(path):
     """committed streams + the reference decoder's pictures (made by tests/golden/make_golden.py with oracle/_ref)"""

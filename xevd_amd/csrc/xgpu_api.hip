@@ -170,6 +170,12 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
 
     auto fail = [&](int code) { xgpu_close(c); return code; };
     if (hipSetDevice(sp->device) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+    // Host waits (hipEventSynchronize / hipStreamSynchronize) spin by default: a decoder thread that waits for a picture's download burns a whole CPU doing so, and on
+    // a host with a CPU quota (the GPU boxes of this pool: cgroup cpu.max = 16 CPUs under 256 hardware threads) the spinning of several workers throttles the
+    // parser threads next to them.  XEVD_HIP_BLOCKING_SYNC=1: the runtime sleeps on an interrupt instead (a few microseconds more latency per wait).
+    static const bool blocking = getenv("XEVD_HIP_BLOCKING_SYNC") != NULL && atoi(getenv("XEVD_HIP_BLOCKING_SYNC")) != 0;
+    if (blocking) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+    const unsigned ev_flags = hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0);
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     if (hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     if (hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
@@ -177,7 +183,7 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     if (hipEventCreateWithFlags(&c->after_inter, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     for (int i = 0; i < 2; i++)
-        if (hipEventCreateWithFlags(&c->out_ready[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->out_done[i], hipEventDisableTiming) != hipSuccess)
+        if (hipEventCreateWithFlags(&c->out_ready[i], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->out_done[i], ev_flags) != hipSuccess)
             return fail(XGPU_ERR_UNEXPECTED);
 
     c->w_scu = sp->width >> 2; c->h_scu = sp->height >> 2;
@@ -445,23 +451,29 @@ int xgpu_frame_end(xgpu_ctx *c)
 // reference's COD flags: a neighbouring SCU is reconstructed at CU i's turn iff its CU index is below i (xevd_recon_unit
 // sets COD CU by CU, xevd.c:744-754; xevd_get_avail_intra, xevd_util.c:689-745; single tile/slice).  The list is sorted by
 // level (1 + the highest level among the intra CUs read), which is a topological order: every dependency sits earlier.
-struct IntraPlan { std::vector<IntraRec> recs; std::vector<uint32_t> deps; int n_levels, n_level1, n_heads, n_ctus; bool has_ibc, has_htdf; };      // n_heads: level-1 CUs + strand heads = the part of the list the launches range over
-static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &plan, const uint32_t *final_owner, int nthr)
+// HTDF (xevdm.c:1381-1392 with xevdm_htdf_skip_condition, xevdm_recon.c:270-297): which CUs are filtered right after their reconstruction, and with which of the five
+// tables (-1: not filtered).  Such a CU - inter ones included - reads the final samples of the CUs before it and is read by the ones after it: it is a node of the
+// dependency graph next to the intra and IBC CUs
+static inline int plan_htdf_idx(const xgpu_cu_batch *b, uint32_t j)
 {
-    // HTDF (xevdm.c:1381-1392 with xevdm_htdf_skip_condition, xevdm_recon.c:270-297): which CUs are filtered right after their reconstruction, and with
-    // which of the five tables.  Such a CU - inter ones included - reads the final samples of the CUs before it and is read by the ones after it:
-    // it becomes a node of the dependency graph next to the intra and IBC CUs
+    const int hqp = b->htdf_slice_qp;
+    const bool intra = b->pred_mode[j] == XGPU_MODE_INTRA;
+    if (hqp <= 17 || (b->tree && b->tree[j] == 2) || b->pred_mode[j] == XGPU_MODE_IBC || !((b->cbf[j] & 1) || intra)) return -1;
+    const int w = 1 << b->log2w[j], h = 1 << b->log2h[j], mn = std::min(w, h), mx = std::max(w, h);
+    if (w * h < 64 || mx >= 128 || (!intra && mn >= 32)) return -1;
+    const int qp = hqp - ((intra && w == h && mn >= 32) ? 8 : 0);
+    return std::min(std::max((qp - 20 + 4) >> 3, 0), 4);
+}
+static inline bool plan_is_node(const xgpu_cu_batch *b, uint32_t j) { return b->pred_mode[j] == XGPU_MODE_INTRA || b->pred_mode[j] == XGPU_MODE_IBC || plan_htdf_idx(b, j) >= 0; }
+
+struct IntraPlan { std::vector<IntraRec> recs; std::vector<uint32_t> deps; int n_levels, n_level1, n_heads, n_ctus; bool has_ibc, has_htdf; };      // n_heads: level-1 CUs + strand heads = the part of the list the launches range over
+static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &plan, const uint32_t *final_owner, int nthr, WorkPool &pool, const std::vector<uint32_t> &nodes)
+{
     const int hqp = b->htdf_slice_qp;
     auto tree_of = [&](uint32_t j) -> int { return b->tree ? b->tree[j] : 0; };      // local dual tree: 1 luma-only, 2 chroma-only CU
-    auto htdf_idx = [&](uint32_t j) -> int {       // -1: not filtered
-        const bool intra = b->pred_mode[j] == XGPU_MODE_INTRA;
-        if (hqp <= 17 || tree_of(j) == 2 || b->pred_mode[j] == XGPU_MODE_IBC || !((b->cbf[j] & 1) || intra)) return -1;
-        const int w = 1 << b->log2w[j], h = 1 << b->log2h[j], mn = std::min(w, h), mx = std::max(w, h);
-        if (w * h < 64 || mx >= 128 || (!intra && mn >= 32)) return -1;
-        const int qp = hqp - ((intra && w == h && mn >= 32) ? 8 : 0);
-        return std::min(std::max((qp - 20 + 4) >> 3, 0), 4);
-    };
-    auto ordered = [&](uint32_t j) -> bool { return b->pred_mode[j] == XGPU_MODE_INTRA || b->pred_mode[j] == XGPU_MODE_IBC || htdf_idx(j) >= 0; };
+    auto htdf_idx = [&](uint32_t j) -> int { return plan_htdf_idx(b, j); };
+    auto ordered = [&](uint32_t j) -> bool { return plan_is_node(b, j); };
+    (void)hqp;
     const int n = b->n_cu, ws = c->w_scu, hs = c->h_scu;
     const uint32_t NONE = 0xFFFFFFFFu;
     // scratch of the builder thread, kept between pictures: an 8 MB vector per 8K picture allocated and freed every call goes through mmap / munmap, and the
@@ -670,18 +682,19 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
             if (rc) { level[(size_t)i] = lv; max_level = std::max(max_level, lv); }
         }
     } else {
-        const int K = std::max(1, std::min(nthr, std::max(1, n / 4096)));
+        // `nodes` = the CUs that are nodes, in decoding order (collected by the caller's validation pass): the ranges of this list go to the threads
+        const int nn = (int)nodes.size();
+        const int K = std::max(1, std::min(nthr, std::max(1, nn / 2048)));
         struct Out { std::vector<IntraRec> recs; std::vector<uint32_t> deps; bool ibc = false, htdf = false, bad = false; };
         std::vector<Out> outs((size_t)K);
         auto work = [&](int k) {
             Out &o = outs[(size_t)k];
             int lv = 0;
-            for (int i = (int)((long long)n * k / K), i1 = (int)((long long)n * (k + 1) / K); i < i1 && !o.bad; i++) o.bad = make_node(i, o.recs, o.deps, o.ibc, o.htdf, lv) < 0;
+            const int q0 = (int)((long long)nn * k / K), q1 = (int)((long long)nn * (k + 1) / K);
+            o.recs.reserve((size_t)(q1 - q0)); o.deps.reserve((size_t)(q1 - q0) * 3);
+            for (int q = q0; q < q1 && !o.bad; q++) o.bad = make_node((int)nodes[(size_t)q], o.recs, o.deps, o.ibc, o.htdf, lv) < 0;
         };
-        std::vector<std::thread> th;
-        for (int k = 1; k < K; k++) th.emplace_back(work, k);
-        work(0);
-        for (std::thread &t : th) t.join();
+        pool.run(K, work);
         PT("nodes");
         size_t nr = 0, nd = 0;
         for (const Out &o : outs) { if (o.bad) return false; nr += o.recs.size(); nd += o.deps.size(); plan.has_ibc |= o.ibc; plan.has_htdf |= o.htdf; }
@@ -849,7 +862,10 @@ static bool tile_mask(const xgpu_ctx *c, const xgpu_tile_grid *g, TileMask &m)
 // The batch builder: SoA batch of the ABI -> 32-byte CU records, the TB list sorted by size class and the
 // wave work items of the itdq kernel, written into ONE pinned staging block and sent with one async copy per
 // array.  (xevd_ctu_row_rec_mt's per-CU cu_init + coef_rect_to_series, xevd.c:567-676, become this pass.)
-int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
+// host_only (xgpu_test_build_batch): everything but the device - the staging block comes from malloc, nothing is uploaded; `segs` receives (offset, bytes) of
+// every array in the staging block.  The CPU suite pins the builder's output with it (digests, thread-count independence).
+struct StageSeg { size_t off, bytes; };
+static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, bool host_only, std::vector<StageSeg> *segs)
 {
     ARGCHK(c, c != NULL); ARGCHK(c, b != NULL && out != NULL);
     *out = NULL;
@@ -861,7 +877,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     for (int k = 0; k < b->n_ctu; k++) ARGCHK(c, b->ctu_cu_start[k] <= b->ctu_cu_start[k + 1]);
     TileMask tmask;
     ARGCHK(c, tile_mask(c, b->tiles, tmask));
-    HIPCHK(c, hipSetDevice(c->sp.device));
+    if (!host_only) HIPCHK(c, hipSetDevice(c->sp.device));
     const int n = b->n_cu;
     const int bdoff = 6 * (c->sp.bit_depth_luma - 8);
     static const bool bt_on = getenv("XEVD_HIP_BUILD_TRACE") != NULL;      // phase times of the builder on stderr
@@ -910,15 +926,13 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     // The builder's per-CU passes run on `builder_threads` host threads (xgpu_set_builder_threads; default 1), each over a contiguous range of CUs: pass 1
     // validates and counts per range, a prefix over the ranges gives every thread its own start in each output list, pass 2 and the owner map then write
     // disjoint parts - the lists come out exactly as the sequential passes build them.
-    struct Part { int cls[NCLS]; int n_aff, n_eif, n_sub, n_dmvr; };
+    struct Part { int cls[NCLS]; int n_aff, n_eif, n_sub, n_dmvr; std::vector<uint32_t> nodes; };      // nodes: the CUs of the range that enter the dependency plan (intra, IBC, HTDF)
     const int nthr = std::max(1, std::min(c->builder_threads, std::max(1, n / 4096)));
     std::vector<Part> parts((size_t)nthr);
-    for (Part &P : parts) memset(&P, 0, sizeof(P));
+    for (Part &P : parts) { memset(P.cls, 0, sizeof(P.cls)); P.n_aff = P.n_eif = P.n_sub = P.n_dmvr = 0; }
+    static thread_local WorkPool pool;                     // this caller's worker threads, kept between pictures
     auto run_parts = [&](auto fn) {                       // fn(thread, first CU, one past the last)
-        std::vector<std::thread> th;
-        for (int k = 1; k < nthr; k++) th.emplace_back(fn, k, (int)((long long)n * k / nthr), (int)((long long)n * (k + 1) / nthr));
-        fn(0, 0, (int)((long long)n / nthr));
-        for (std::thread &t : th) t.join();
+        pool.run(nthr, [&](int k) { fn(k, (int)((long long)n * k / nthr), (int)((long long)n * (k + 1) / nthr)); });
     };
 #define CUCHK(cond) do { if (!(cond)) return #cond; } while (0)
     auto pass1 = [&](int i0, int i1, Part &P) -> const char * {
@@ -976,6 +990,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
             need += (size_t)(1 << (bw + bh)) >> (k ? 2 : 0);
         }
         CUCHK((size_t)b->coef_off[i] + need <= b->n_coef);
+        if (plan_is_node(b, (uint32_t)i)) P.nodes.push_back((uint32_t)i);
     }
     return nullptr;
     };
@@ -1018,8 +1033,11 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
         });
     }
     BT("owner map");
-    for (int i = 0; i < n && !any_intra; i++) any_intra = b->pred_mode[i] == XGPU_MODE_INTRA || b->pred_mode[i] == XGPU_MODE_IBC || (b->htdf_slice_qp > 17 && (b->cbf[i] & 1));
-    if (any_intra) ARGCHK(c, build_intra_plan(c, b, plan, own.data(), nthr));      // false: an IBC source block that is not reconstructed before its CU
+    static thread_local std::vector<uint32_t> node_list;
+    node_list.clear();
+    for (const Part &P : parts) node_list.insert(node_list.end(), P.nodes.begin(), P.nodes.end());
+    any_intra = !node_list.empty();
+    if (any_intra) ARGCHK(c, build_intra_plan(c, b, plan, own.data(), nthr, pool, node_list));      // false: an IBC source block that is not reconstructed before its CU
     const int n_intra = (int)plan.recs.size(), n_deps = (int)plan.deps.size();
     BT("intra plan");
 
@@ -1048,7 +1066,7 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     const size_t o_dmv = o_done + align_up((int)sz_done, 256);
     const size_t d_need = o_dmv + align_up((int)(sizeof(int16_t) * 4 * (size_t)std::max(n_dmvr, 1)), 256);
     // is the coefficient arena inside a range from xgpu_host_alloc?  Then it is sent from where it lies (no staging copy of the largest array)
-    bool coef_pinned = false;
+    bool coef_pinned = host_only && b->n_coef != 0;      // (the builder alone: the coefficient copy - a plain memcpy, skipped for pinned arenas - stays out of the measurement)
     {
         // a pooled block that is large enough (the smallest such), else a new one
         int best = -1;
@@ -1060,7 +1078,13 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
                 if (c->pool[k].d_cap >= d_need && c->pool[k].h_cap >= db->stage_bytes && (best < 0 || c->pool[k].d_cap < c->pool[best].d_cap)) best = (int)k;
             if (best >= 0) { db->blk = c->pool[best]; c->pool.erase(c->pool.begin() + best); }
         }
-        if (best >= 0) {
+        if (host_only) {
+            memset(&db->blk, 0, sizeof(db->blk));
+            // (kept between calls like a pooled block: a fresh 60 MB malloc per call would time the kernel's page zeroing)
+            static thread_local std::vector<uint8_t> host_stage;
+            if (host_stage.size() < db->stage_bytes) host_stage.resize(db->stage_bytes);
+            db->blk.h_stage = host_stage.data(); db->blk.h_cap = db->stage_bytes;
+        } else if (best >= 0) {
             if (hipEventSynchronize(db->blk.uploaded) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);      // its staging block may still feed an upload
             // ... and its device block the kernels of the batch that had it before: the upload stream waits for them
             if (hipStreamWaitEvent(c->up_stream, db->blk.done, 0) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
@@ -1071,7 +1095,8 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
             db->blk.d_cap = d_cap;
             if (hipHostMalloc(&db->blk.h_stage, h_cap, hipHostMallocDefault) != hipSuccess) return fail(XGPU_ERR_OUT_OF_MEMORY);
             db->blk.h_cap = h_cap;
-            if (hipEventCreateWithFlags(&db->blk.uploaded, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+            static const bool blocking = getenv("XEVD_HIP_BLOCKING_SYNC") != NULL && atoi(getenv("XEVD_HIP_BLOCKING_SYNC")) != 0;      // see xgpu_open
+            if (hipEventCreateWithFlags(&db->blk.uploaded, hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0)) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
             if (hipEventCreateWithFlags(&db->blk.done, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
             if (hipEventCreateWithFlags(&db->blk.itdq_done, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
         }
@@ -1086,7 +1111,10 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     AffItem *aff_items = (AffItem *)(hs + o_aff);
     int16_t *cpmv = (int16_t *)(hs + o_cpmv);
     DmvrItem *dmvr_items = (DmvrItem *)(hs + o_dmvr);
-    memcpy(hs + o_own, own.data(), sz_own);
+    {
+        const uint8_t *const own_b = (const uint8_t *)own.data();      // (`own` is thread_local: the workers must not name it)
+        pool.run(nthr, [&](int k) { const size_t a0 = sz_own * (size_t)k / nthr & ~(size_t)63, a1 = k + 1 == nthr ? sz_own : (sz_own * (size_t)(k + 1) / nthr & ~(size_t)63); memcpy(hs + o_own + a0, own_b + a0, a1 - a0); });
+    }
 
     // pass 2: records + TB scatter into class order; every thread starts where the ranges before it end in each list
     run_parts([&](int part, int i0, int i1) {
@@ -1174,11 +1202,8 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     memcpy(hs + o_ctu, b->ctu_cu_start, sz_ctu);
     if (b->n_coef && !coef_pinned) {                                   // the largest array (45 MB at 8K): in slices on the builder's threads
         const size_t bytes = sizeof(int16_t) * b->n_coef;
-        std::vector<std::thread> th;
-        for (int k = 1; k < nthr; k++) th.emplace_back([&, k]() { const size_t a0 = bytes * k / nthr & ~(size_t)63, a1 = k + 1 == nthr ? bytes : (bytes * (k + 1) / nthr & ~(size_t)63);
-                                                                   memcpy(hs + o_coef + a0, (const uint8_t *)b->coef + a0, a1 - a0); });
-        memcpy(hs + o_coef, b->coef, nthr > 1 ? (bytes / nthr & ~(size_t)63) : bytes);
-        for (std::thread &t : th) t.join();
+        pool.run(nthr, [&](int k) { const size_t a0 = k == 0 ? 0 : (bytes * k / nthr & ~(size_t)63), a1 = k + 1 == nthr ? bytes : (bytes * (k + 1) / nthr & ~(size_t)63);
+                                    memcpy(hs + o_coef + a0, (const uint8_t *)b->coef + a0, a1 - a0); });
     }
     if (n_intra) memcpy(hs + o_intra, plan.recs.data(), sizeof(IntraRec) * (size_t)n_intra);
     if (n_deps) memcpy(hs + o_deps, plan.deps.data(), sizeof(uint32_t) * (size_t)n_deps);
@@ -1192,6 +1217,10 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     // one copy: the staging block has the device layout (a pinned coefficient arena goes from the caller's buffer).  On the upload stream: the
     // copy overlaps the kernels of the pictures before; xgpu_batch_recon makes the kernel stream wait for `uploaded`
     BT("stage filled");
+    if (segs) *segs = { { o_cus, sizeof(CuRec) * (size_t)n }, { o_ctu, sz_ctu }, { o_tbs, sizeof(TbRec) * (size_t)n_tb }, { o_wv, sizeof(TbWave) * (size_t)n_waves }, { o_intra, sizeof(IntraRec) * (size_t)n_intra },
+                        { o_deps, sizeof(uint32_t) * (size_t)n_deps }, { o_aff, sizeof(AffItem) * (size_t)(n_aff_eif + n_aff_sub) }, { o_cpmv, sizeof(int16_t) * 12 * (size_t)n_aff },
+                        { o_dmvr, sizeof(DmvrItem) * (size_t)n_dmvr }, { o_own, sz_own }, { o_coef, coef_pinned ? 0 : sizeof(int16_t) * b->n_coef } };
+    if (host_only) { *out = db; return XGPU_OK; }
     hipError_t e = hipMemcpyAsync(dbase, hs, coef_pinned ? o_coef : db->stage_bytes, hipMemcpyHostToDevice, c->up_stream);
     if (e == hipSuccess && coef_pinned) e = hipMemcpyAsync(dbase + o_coef, b->coef, sizeof(int16_t) * b->n_coef, hipMemcpyHostToDevice, c->up_stream);
     if (e == hipSuccess) e = hipMemsetAsync(db->d_intra_done, 0, sz_done, c->up_stream);
@@ -1203,9 +1232,44 @@ int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out)
     return XGPU_OK;
 }
 
+int xgpu_batch_create(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out) { return batch_build(c, b, out, false, NULL); }
+
+// Test shim (no device, no HIP call): the host batch builder alone on `threads` builder threads -> digest[k] = FNV-1a of array k of the staging block (CU records, CTU
+// starts, TB records, work items, intra records, dependency lists, affine tiles, control points, DMVR sub-blocks, owner map, coefficients), info as xgpu_batch_info,
+// *ms = the builder's wall time.  What the CPU suite uses to pin the builder (goldens of the digests, independence of the thread count).
+int xgpu_test_build_batch(const xgpu_seq_params *sp, const xgpu_cu_batch *b, int threads, uint64_t digest[XGPU_TEST_BUILD_DIGESTS], int info[XGPU_BATCH_INFO_COUNT], double *ms)
+{
+    if (!sp || !b || !digest || threads < 1 || threads > 64) return XGPU_ERR_INVALID_ARGUMENT;
+    if (sp->width <= 0 || sp->height <= 0 || (sp->width & 7) || (sp->height & 7) || sp->log2_ctu < 5 || sp->log2_ctu > 7) return XGPU_ERR_INVALID_ARGUMENT;
+    xgpu_ctx *c = new xgpu_ctx();
+    c->sp = *sp; c->sp.chroma_qp_table[0] = c->sp.chroma_qp_table[1] = NULL;
+    c->builder_threads = threads; c->err[0] = 0;
+    c->stream = c->up_stream = c->down_stream = c->side_stream = 0;
+    c->w_scu = sp->width >> 2; c->h_scu = sp->height >> 2;
+    const int ctu = 1 << sp->log2_ctu;
+    c->w_ctu = (sp->width + ctu - 1) / ctu; c->h_ctu = (sp->height + ctu - 1) / ctu;
+    xgpu_dbatch *db = NULL;
+    std::vector<StageSeg> segs;
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = batch_build(c, b, &db, true, &segs);
+    if (ms) *ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (rc == XGPU_OK) {
+        for (int k = 0; k < XGPU_TEST_BUILD_DIGESTS; k++) {
+            uint64_t h = 1469598103934665603ull;
+            if (k < (int)segs.size()) { const uint8_t *p = (const uint8_t *)db->h_stage + segs[(size_t)k].off; for (size_t i = 0; i < segs[(size_t)k].bytes; i++) { h ^= p[i]; h *= 1099511628211ull; } }
+            digest[k] = h;
+        }
+        if (info) { info[0] = db->n_cu; info[1] = db->n_tb; info[2] = db->n_waves; info[3] = db->n_intra; info[4] = db->n_intra_l1; info[5] = db->n_levels; info[6] = db->n_dmvr; info[7] = db->n_aff_eif + db->n_aff_sub; }
+        delete db;
+    }
+    delete c;
+    return rc;
+}
+
 void xgpu_batch_destroy(xgpu_ctx *c, xgpu_dbatch *db)
 {
     if (!db) return;
+    if (db->blk.h_stage && !db->blk.d_base && !db->blk.uploaded) { delete db; return; }      // a host-only build (xgpu_test_build_batch) that failed half way: the block is the shim's own
     // No synchronisation: kernels still queued on the context's stream keep reading the block; whoever reuses it makes the upload stream wait
     // for the `done` event those kernels signal, and the host waits for `uploaded` before it touches the staging block.
     // The event is recorded here, not behind the batch's kernels: a marker between two kernels of a picture idles the device for ~6 us (profiles/round3_trace_window.txt),

@@ -5,6 +5,8 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -325,6 +327,52 @@ struct xgpu_ctx {
     double          t_ms[XGPU_K_COUNT];
     long long       t_n[XGPU_K_COUNT];
     char            err[256];
+};
+
+// The host threads of a batch builder: workers that stay alive between pictures (a std::thread per phase and picture cost ~0.1 ms each - more than a phase of
+// the builder takes).  One pool per CALLING thread (xgpu_batch_create may run on several builder threads of one context at once): static thread_local in
+// xgpu_api.hip.  run(n, f): f(0) on the caller, f(1) .. f(n - 1) on workers, returns when all are done.
+class WorkPool {
+public:
+    ~WorkPool() { { std::lock_guard<std::mutex> g(mu); stop = true; } cv.notify_all(); for (std::thread &t : th) t.join(); }
+    template <class F> void run(int n, F &&f)
+    {
+        if (n <= 1) { f(0); return; }
+        while ((int)th.size() < n - 1) { const int idx = (int)th.size(); th.emplace_back([this, idx]() { worker(idx); }); }
+        const std::function<void(int)> fn = [&f](int k) { f(k); };
+        { std::lock_guard<std::mutex> g(mu); job = &fn; want = n - 1; left = n - 1; gen++; }
+        cv.notify_all();
+        f(0);
+        std::unique_lock<std::mutex> g(mu);
+        done_cv.wait(g, [this]() { return left == 0; });
+        job = nullptr;
+    }
+private:
+    void worker(int idx)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)> *fn = nullptr;
+            {
+                std::unique_lock<std::mutex> g(mu);
+                cv.wait(g, [&]() { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+                if (idx < want) fn = job;
+            }
+            if (!fn) continue;
+            (*fn)(idx + 1);
+            std::lock_guard<std::mutex> g(mu);
+            if (--left == 0) done_cv.notify_one();
+        }
+    }
+    std::vector<std::thread> th;
+    std::mutex mu;
+    std::condition_variable cv, done_cv;
+    const std::function<void(int)> *job = nullptr;
+    int want = 0, left = 0;
+    uint64_t gen = 0;
+    bool stop = false;
 };
 
 // kernel launchers (one per .hip file)

@@ -9,6 +9,9 @@
 // see the same neighbour state because both walk the CUs in the same order and "reconstructed" (COD) == "already parsed".
 #include "evc_cu.h"
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 
 // =============================================================================================================== parser
 // One tile of a picture being parsed: its coder state, its share of the batch, its scratch blocks.  Objects are kept between pictures (the vectors keep
@@ -165,17 +168,56 @@ struct xhost_parser {
     int n_threads = 1;                                   // xhost_parser_set_threads
     std::string err;
     int fail(const char *m) { err = m; pic_tiles_left = 0; return XHOST_ERR_MALFORMED; }      // (a picture half assembled from slices is dropped)
-    // runs fn(0 .. n-1) on up to n_threads threads (the calling one included)
+    // runs fn(0 .. n-1) on up to n_threads threads (the calling one included).  The helper threads live as long as the parser: creating and joining 15 threads
+    // three times per picture cost milliseconds of a 9 ms picture - more when another thread of the process (a decoder's device thread inside the GPU
+    // driver) holds the address-space lock that every thread creation needs.
+    struct Pool {
+        std::vector<std::thread> th;
+        std::mutex mu;
+        std::condition_variable cv, done_cv;
+        const std::function<void()> *job = nullptr;
+        int want = 0, left = 0;
+        uint64_t gen = 0;
+        bool stop = false;
+        ~Pool() { { std::lock_guard<std::mutex> g(mu); stop = true; } cv.notify_all(); for (std::thread &t : th) t.join(); }
+        void worker(int idx)
+        {
+            uint64_t seen = 0;
+            for (;;) {
+                const std::function<void()> *fn = nullptr;
+                {
+                    std::unique_lock<std::mutex> g(mu);
+                    cv.wait(g, [&]() { return stop || gen != seen; });
+                    if (stop) return;
+                    seen = gen;
+                    if (idx < want) fn = job;
+                }
+                if (!fn) continue;
+                (*fn)();
+                std::lock_guard<std::mutex> g(mu);
+                if (--left == 0) done_cv.notify_one();
+            }
+        }
+        void run(int helpers, const std::function<void()> &fn)      // fn on `helpers` pool threads and on the caller
+        {
+            while ((int)th.size() < helpers) { const int idx = (int)th.size(); th.emplace_back([this, idx]() { worker(idx); }); }
+            { std::lock_guard<std::mutex> g(mu); job = &fn; want = helpers; left = helpers; gen++; }
+            cv.notify_all();
+            fn();
+            std::unique_lock<std::mutex> g(mu);
+            done_cv.wait(g, [this]() { return left == 0; });
+            job = nullptr;
+        }
+    };
+    std::unique_ptr<Pool> pool;
     template <class F> void parallel_for(int n, F fn)
     {
         const int nt = std::min(n_threads, n);
         if (nt <= 1) { for (int i = 0; i < n; i++) fn(i); return; }
         std::atomic<int> next(0);
-        auto work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; t++) th.emplace_back(work);
-        work();
-        for (std::thread &t : th) t.join();
+        const std::function<void()> work = [&]() { for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) fn(i); };
+        if (!pool) pool.reset(new Pool());
+        pool->run(nt - 1, work);
     }
 
     // A picture-signature SEI directly after the slice NAL belongs to that picture (xevd_dec_nalu checks it against ctx->pic,
@@ -662,6 +704,26 @@ extern "C" xhost_parser *xhost_parser_open(const uint8_t *bytes, size_t size)
     xhost_parser *p = new xhost_parser();
     p->data.assign(bytes, bytes + size);
     return p;
+}
+extern "C" int xhost_parser_rebind(xhost_parser *p, const uint8_t *bytes, size_t size)
+{
+    if (!p || !bytes) return XGPU_ERR_INVALID_ARGUMENT;
+    Stream &st = p->st;
+    while (!st.dpb.empty()) st.drop_ref(st.dpb.size() - 1);      // the motion fields go to the pools
+    Picture pic = std::move(st.pic);
+    std::vector<std::vector<int16_t>> mvp = std::move(st.mv_pool);
+    std::vector<std::vector<int8_t>> rfp = std::move(st.refi_pool);
+    st.~Stream();                                                // every parameter set, POC / reference-list / ALF / DRA state: as in a new parser
+    new (&st) Stream();
+    st.pic = std::move(pic); st.mv_pool = std::move(mvp); st.refi_pool = std::move(rfp);
+    // the arenas go back to the caller (who may hand the same memory out again, or replace what it was allocated from before the next unit's pictures need one)
+    for (xhost_parser::Held &h : p->held) { if (h.arena && p->arena_release) p->arena_release(p->arena_user, h.arena); h.arena = nullptr; h.arena_cap = 0; }
+    p->merged_arena = nullptr;
+    p->data.assign(bytes, bytes + size);
+    p->pos = 0; p->err.clear();
+    p->pic_tiles_left = 0; p->last_poc = 0; p->last_n_dmvr = 0; p->last_stored = false;
+    p->tile_done.clear(); p->pic_lists.clear();
+    return XGPU_OK;
 }
 // the decoded luma samples of the picture with this POC, for the front end's own refinement search (Sps::host_dmvr)
 extern "C" int xhost_parser_set_ref_luma(xhost_parser *p, int poc, const int16_t *plane, int stride) { return p ? set_ref_luma(p->st, poc, plane, stride) : XGPU_ERR_INVALID_ARGUMENT; }
