@@ -207,13 +207,107 @@ def write_bench_stream(wl, gop_pictures, repeats, seed=77):
     return prefix + gop, prefix + gop * repeats, what
 
 
+def host_cpu_quota():
+    """CPUs this process may use at once: the cgroup's cpu.max quota (the GPU boxes of this pool: 16 CPUs under 256 hardware threads) or the CPU count"""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            return max(1, int(round(int(q) / int(per))))
+    except Exception:
+        pass
+    return os.cpu_count() or 1
+
+
+def run_evc_decode(args, timeout=900):
+    """examples/evc_decode --json ... -> its report (dict) or {"error": ...}"""
+    import subprocess
+    ours = os.path.join(ROOT, "examples", "evc_decode")
+    r = subprocess.run([ours, "--json"] + args, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout)
+    if r.returncode != 0:
+        return {"error": r.stderr.decode()[-300:]}
+    return json.loads(r.stdout.decode().strip().splitlines()[-1])
+
+
+def file_md5s(path, period_bytes, limit=None):
+    """one MD5 per `period_bytes` of a file (the output pictures of one IDR period), the first `limit` periods"""
+    import hashlib
+    out = []
+    with open(path, "rb") as f:
+        while limit is None or len(out) < limit:
+            hh, left = hashlib.md5(), period_bytes
+            while left:
+                blk = f.read(min(left, 1 << 24))
+                if not blk:
+                    break
+                hh.update(blk)
+                left -= len(blk)
+            if left == period_bytes:
+                break
+            out.append(hh.hexdigest())
+    return out
+
+
+def streams_leg(n_gpus, n_streams=8, gop_pictures=17, repeats=4, wl=None):
+    """BASELINE.json configs[4], literally: `n_streams` independent 4K Main random-access streams (different seeds; one closed GOP of `gop_pictures` pictures each,
+    sent `repeats` times) decoded by examples/evc_decode --gpus N - the C work queue (include/xevd_wq.h) hands the closed GOPs of all streams to one worker set
+    per device - with parsing, batch building, kernels and output inside the timed region (the span app/xevd_app.c:492-501,612-624 times).  The first IDR period of
+    every output is compared with the reference decoder's pictures (oracle/_ref/ref_decode_main, one thread), where that was built."""
+    import subprocess
+    import tempfile
+    import torch
+    wl = wl or WORKLOADS["cfg3_main_4k_10b_ra"]      # (the GPU suite runs the leg on a small picture size)
+    w, h, bd = wl["w"], wl["h"], wl["bd"]
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_decode_main")
+    n_dev = min(n_gpus, max(torch.cuda.device_count(), 1))
+    quota = host_cpu_quota()
+    workers = max(1, min(8, quota // 2) // n_dev) if n_dev < 8 else 1
+    tile_threads = max(1, min(16, quota // (workers * n_dev)) - 1)
+    period_bytes = gop_pictures * (w * h * 3 // 2) * 2
+    out = {"workload": "cfg5: %d independent %dx%d %d-bit Main random-access streams (seeds differ), closed GOPs of %d pictures x %d" % (n_streams, w, h, bd, gop_pictures, repeats),
+           "devices_asked": n_gpus, "devices_used": n_dev, "host_cpu_quota": quota, "host_hardware_threads": os.cpu_count(),
+           "workers_per_device": workers, "tile_threads_per_worker": tile_threads, "build_threads_per_worker": 1}
+    with tempfile.TemporaryDirectory() as td:
+        args, refs, t_ref = [], {}, time.perf_counter()
+        for k in range(n_streams):
+            one, data, what = write_bench_stream(wl, gop_pictures, repeats, seed=100 + k)
+            open(os.path.join(td, f"s{k}.evc"), "wb").write(data)
+            open(os.path.join(td, f"s{k}_one.evc"), "wb").write(one)
+            args += [os.path.join(td, f"s{k}.evc"), os.path.join(td, f"o{k}.yuv")]
+        out["stream"] = what
+        procs = []
+        if os.path.exists(exe):       # the reference decoder on one IDR period of every stream, all at once (one thread each)
+            for k in range(n_streams):
+                procs.append(subprocess.Popen([exe, os.path.join(td, f"s{k}_one.evc"), os.path.join(td, f"r{k}.raw"), str(w), str(h), "1"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE))
+            ref_fps = []
+            for k, pr in enumerate(procs):
+                err = pr.communicate()[1].decode()
+                if pr.returncode == 0:
+                    pics, secs = err.split()[-2:]
+                    ref_fps.append(int(pics) / float(secs))
+                    refs[k] = file_md5s(os.path.join(td, f"r{k}.raw"), period_bytes, 1)
+            out["reference_decoder_fps_one_thread_each_all_streams_at_once"] = round(float(np.sum(ref_fps)), 2) if ref_fps else None
+        rep = run_evc_decode(["--gpus", str(n_dev), "--workers", str(workers), "--tile-threads", str(tile_threads), "--build-threads", "1", "--keep-units", "1"] + args)
+        out["evc_decode"] = rep
+        if "error" not in rep:
+            out["fps_decode_only"] = rep["fps_decode_only"]
+            out["fps_wall_incl_device_startup"] = rep["fps_wall"]
+            out["pictures"] = rep["pictures"]
+            out["pictures_per_device"] = rep["pictures_per_device"]
+            out["host_threads"] = n_dev * workers * (tile_threads + 2)
+            out["cpu_seconds"] = round(rep["cpu_user_s"] + rep["cpu_sys_s"], 2)
+            if refs:
+                ok = [file_md5s(os.path.join(td, f"o{k}.yuv"), period_bytes, 1) == refs.get(k) for k in range(n_streams)]
+                out["bit_exact"] = bool(all(ok))
+                out["bit_exact_what"] = "the first IDR period of every stream's output == the reference decoder's pictures (single-threaded run)"
+    return out
+
+
 def reference_decoder_leg(wl, budget_s=60.0):
     """Real-bitstream decode, .evc -> .yuv (write_bench_stream): the reference DECODER itself (its public API through oracle/_ref/ref_decode, -m 1 and
     -m 8 threads, entropy decoding included - what a user of xevd_app runs on this host) next to examples/evc_decode (plain C on this repository's
-    C ABIs) in three shapes: ONE stream on one worker (parser thread with 16 tile threads one picture ahead of the device thread), the same without
-    the pipeline, and GOP-parallel (4 workers x 8 tile threads through the work queue).  Every IDR period of evc_decode's output is compared byte
-    for byte with the reference decoder's output of that period."""
-    import hashlib
+    C ABIs) in four shapes: ONE stream on one worker (parser with its tile threads -> batch builder -> device thread, three pictures in flight), the same
+    back to back on one thread, and GOP-parallel through the work queue (2 workers x 8 tile threads, 4 x 4).  12 IDR periods per run; the first two of every
+    run are written out and compared byte for byte with the reference decoder's output of that period.  The host's CPU quota (cgroup cpu.max) is in the line."""
     import subprocess
     import tempfile
     main_profile = bool(wl["addb"] or wl["iqt"] or wl["alf"])
@@ -222,46 +316,32 @@ def reference_decoder_leg(wl, budget_s=60.0):
     if not os.path.exists(exe) or not os.path.exists(ours):
         return None
     w, h, bd = wl["w"], wl["h"], wl["bd"]
-    gop_pictures, repeats = 17, 4
+    gop_pictures, repeats = 17, 12
     one, data, what = write_bench_stream(wl, gop_pictures, repeats)
     period_bytes = gop_pictures * (w * h * 3 // 2) * (2 if bd > 8 else 1)
-
-    def md5s(path):      # one digest per IDR period
-        out = []
-        with open(path, "rb") as f:
-            while True:
-                hh, left = hashlib.md5(), period_bytes
-                while left:
-                    blk = f.read(min(left, 1 << 24))
-                    if not blk:
-                        break
-                    hh.update(blk)
-                    left -= len(blk)
-                if left == period_bytes:
-                    break
-                out.append(hh.hexdigest())
-        return out
+    keep = 2                 # IDR periods of every run that are written out and compared (the others are decoded all the same: --keep-units)
+    quota = host_cpu_quota()
     fps, ref_sum, t0, gpu = {}, {}, time.perf_counter(), {}
     with tempfile.TemporaryDirectory() as td:
         p_one, p_all = os.path.join(td, "one.evc"), os.path.join(td, "all.evc")
         open(p_one, "wb").write(one)
         open(p_all, "wb").write(data)
         ok = True
-        for name, args in (("one_stream_pipelined", ["--workers", "1", "--tile-threads", "16"]),
-                           ("one_stream_back_to_back", ["--workers", "1", "--tile-threads", "16", "--no-pipeline"]),
-                           ("gop_parallel_4x8", ["--workers", "4", "--tile-threads", "8"])):
+        shapes = (("one_stream_pipelined", ["--workers", "1", "--tile-threads", str(min(16, quota)), "--build-threads", "4"]),
+                  ("one_stream_back_to_back", ["--workers", "1", "--tile-threads", str(min(16, quota)), "--build-threads", "4", "--no-pipeline"]),
+                  ("gop_parallel_2x8", ["--workers", "2", "--tile-threads", str(max(1, min(8, quota // 2))), "--build-threads", "2"]),
+                  ("gop_parallel_4x4", ["--workers", "4", "--tile-threads", str(max(1, min(4, quota // 4))), "--build-threads", "1"]))
+        for name, args in shapes:
             dst = os.path.join(td, "ours.yuv")
-            r = subprocess.run([ours] + args + [p_all, dst], stderr=subprocess.PIPE, timeout=600)
-            txt = r.stderr.decode()
-            if r.returncode != 0:
-                gpu[name] = {"error": txt[-200:]}
+            rep = run_evc_decode(args + ["--keep-units", str(keep), p_all, dst])
+            if "error" in rep:
+                gpu[name] = rep
                 ok = False
                 continue
-            gpu[name] = {"decode_only_fps": float(txt.split("slowest worker)")[1].split("s,")[1].split("pictures/s")[0]),
-                         "parse_ms_per_picture": float(txt.split("stages per picture: parse")[1].split("ms")[0]),
-                         "batch_build_ms_per_picture": float(txt.split("batch build")[1].split("ms")[0])}
+            gpu[name] = {"decode_only_fps": rep["fps_decode_only"], "parse_ms_per_picture": rep["parse_ms_per_picture"], "batch_build_ms_per_picture": rep["build_ms_per_picture"],
+                         "host_threads": rep["workers_per_device"] * (rep["tile_threads"] + 2), "cpu_seconds_per_picture": round((rep["cpu_user_s"] + rep["cpu_sys_s"]) / max(rep["pictures"], 1), 4)}
             if bd > 8:          # 16-bit samples like the reference driver's output
-                gpu[name]["periods"] = md5s(dst)
+                gpu[name]["periods"] = file_md5s(dst, period_bytes, keep)
         for threads in (1, 8):
             if time.perf_counter() - t0 > budget_s and fps:
                 break
@@ -272,19 +352,19 @@ def reference_decoder_leg(wl, budget_s=60.0):
             pics, secs = r.stderr.decode().split()[-2:]
             fps[str(threads)] = round(int(pics) / float(secs), 2)
             if bd > 8:
-                ref_sum[threads] = md5s(dst)
+                ref_sum[threads] = file_md5s(dst, period_bytes)
     # the yardstick is the reference decoder with ONE thread; whether its own threaded run agrees with it is reported, not required (it does not on every
     # tiled stream: DESIGN 5b)
     bit_exact = None
     if bd > 8 and ok and 1 in ref_sum and len(ref_sum[1]) == 1:
         for g in gpu.values():
-            g["bit_exact"] = len(g["periods"]) == repeats and all(m == ref_sum[1][0] for m in g["periods"])
+            g["bit_exact"] = len(g.get("periods", [])) == keep and all(m == ref_sum[1][0] for m in g["periods"])
         bit_exact = all(g["bit_exact"] for g in gpu.values())
     for g in gpu.values():
         g.pop("periods", None)
-    return {"frames_per_s_by_threads": fps, "host_cores": os.cpu_count(), "evc_decode_on_gpu": gpu, "bit_exact": bit_exact,
+    return {"frames_per_s_by_threads": fps, "host_cores": os.cpu_count(), "host_cpu_quota": quota, "evc_decode_on_gpu": gpu, "bit_exact": bit_exact,
             "reference_threads_8_equals_1": (ref_sum[8] == ref_sum[1]) if (1 in ref_sum and 8 in ref_sum) else None, "stream": what,
-            "pictures": {"evc_decode": gop_pictures * repeats, "reference_decoder": gop_pictures},
+            "pictures": {"evc_decode": gop_pictures * repeats, "reference_decoder": gop_pictures, "compared_idr_periods_per_run": keep},
             "what": "xevd_create / xevd_decode / xevd_pull of the reference library built in oracle/_ref (entropy decoding + reconstruction), threads = "
                     "XEVD_CDSC.threads, on one IDR period; evc_decode_on_gpu: examples/evc_decode on the whole stream, decode-only rate of the slowest worker "
                     "(parsing + batch build + kernels + output, the span the reference application times, app/xevd_app.c:492-501,612-624); bit_exact: every IDR "
@@ -532,6 +612,18 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         e2e["fps"] = round(world * 1e3 / float(t.item()), 2)
 
+    # BASELINE configs[4] literally (N > 1): independent 4K streams -> examples/evc_decode --gpus N, one process with a worker set per device and the C work queue
+    # between them.  Rank 0 runs it (the other ranks hold no stream work and wait at the barrier); reported next to `value`, not instead of it.
+    streams = None
+    if world > 1:
+        barrier()
+        if rank == 0 and dec_mod == "xevd_amd.decoder":
+            try:
+                streams = streams_leg(world)
+            except Exception as e:
+                streams = {"error": repr(e)[:300]}
+        barrier()
+
     if rank == 0:
         ab = [algorithmic_bytes(b, wl["w"], wl["h"], bool(wl["addb"])) for b in batches]
         # ADDB directly followed by ALF runs as ONE kernel (k_addb_alf, timed as "alf"): it is credited with the one read + one write of the picture it has to
@@ -557,11 +649,12 @@ def main():
             copy_bw = dec.measure_copy_bw(1 << 30, 10)
         except Exception:
             copy_bw = None
-        traffic = None
+        traffic, pmc_commit = None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
             if pmc["workload"] == args.workload:
                 traffic = pmc["kernels"][dom]["traffic_bytes"]       # from the committed rocprofv3 --pmc passes
+                pmc_commit = pmc.get("commit")
         except Exception:
             traffic = None
         total_alg = float(np.mean([sum(v for k, v in a.items() if k != "alf" or wl["alf"]) for a in ab]))
@@ -587,9 +680,10 @@ def main():
                          "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 2),
                          "measured_copy_bw_gbps": None if copy_bw is None else round(copy_bw, 1),
                          "frac_of_measured_copy_bw": None if not copy_bw else round(achieved / copy_bw, 4),
-                         # the guide's measured float4-copy figure for this part (MI355X_MICROARCH.md: 6.29 TB/s); our own copy kernel reaches 4.8
+                         # the guide's measured float4-copy figure for this part (MI355X_MICROARCH.md: 6.29 TB/s); k_copy (one 16-byte element per lane) reaches 6.2
                          "frac_of_guide_copy_bw_6290": round(achieved / 6290.0, 4),
-                         "traffic_source": "profiles/latest_pmc.json (rocprofv3 --pmc passes of this workload, committed; not measured by this run)" if traffic is not None else None},
+                         "traffic_source": (f"profiles/latest_pmc.json (rocprofv3 --pmc passes of this workload at commit {pmc_commit}, committed; not measured by this run: "
+                                            "counter passes cannot run inside a timed benchmark)") if traffic is not None else None},
             "kernels": kernels,
             "whole_frame": {"algorithmic_bytes": int(total_alg), "kernel_us": round(kern_s * 1e6, 2),
                             "achieved_gbps": round(total_alg / kern_s / 1e9, 1),
@@ -599,6 +693,7 @@ def main():
             # `value` above is the rate with the CU batches resident in HBM (the benchmark contract's definition); the rate of the whole
             # span host batches -> host YUV, transfers and the host batch builder inside the timed region, is end_to_end_fps
             "per_rank": per_rank,
+            "streams": streams,
             "decoder": dec_mod,
             "kernel_only_fps": round(world * args.steps / dt, 2),
             "end_to_end_fps": e2e["fps"],

@@ -30,6 +30,7 @@
 #include <fcntl.h>
 #include <pthread.h>
 #include <malloc.h>
+#include <sys/resource.h>
 #include "xevd_host.h"
 #include "xevd_wq.h"
 
@@ -461,11 +462,14 @@ static int worker_job(void *state, const xwq_job *job)
     return rc;
 }
 static double g_busy[64], g_setup[64], g_parse[64], g_build[64];
+static long g_pics[64];
+static int g_dev[64];
+static int g_json = 0;              /* --json: one JSON line with the run's figures on stdout (bench.py's multi-GPU leg reads it) */
 static int g_workers;
 static void worker_fini(void *state)
 {
     worker_t *w = (worker_t *)state;
-    { const int k = __sync_fetch_and_add(&g_workers, 1); g_busy[k & 63] = w->busy_s - w->setup_s; g_setup[k & 63] = w->setup_s; g_parse[k & 63] = w->parse_s; g_build[k & 63] = w->build_s; }
+    { const int k = __sync_fetch_and_add(&g_workers, 1); g_busy[k & 63] = w->busy_s - w->setup_s; g_setup[k & 63] = w->setup_s; g_parse[k & 63] = w->parse_s; g_build[k & 63] = w->build_s; g_pics[k & 63] = w->pictures; g_dev[k & 63] = w->device; }
     if (w->frames && !w->frames_pinned) free(w->frames);            /* (pinned memory goes with the context) */
     if (w->ps) xhost_parser_close(w->ps);                           /* before the context: it gives its arenas back */
     if (w->g) xgpu_close(w->g);
@@ -489,6 +493,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[a], "--trace")) { g_trace = 1; a += 1; }
         else if (!strcmp(argv[a], "--build-threads") && a + 1 < argc) { g_build_threads = atoi(argv[a + 1]); a += 2; }
         else if (!strcmp(argv[a], "--keep-units") && a + 1 < argc) { g_keep_units = atoi(argv[a + 1]); a += 2; }
+        else if (!strcmp(argv[a], "--json")) { g_json = 1; a++; }
         else break;
     }
     int n_pos = argc - a;
@@ -546,5 +551,20 @@ int main(int argc, char **argv)
             secs, secs > 0 ? (double)total_pictures / secs : 0.0, busy, busy > 0 ? (double)total_pictures / busy : 0.0, setup);
     fprintf(stderr, "stages per picture: parse %.2f ms (%s), batch build %.2f ms\n", total_pictures ? 1e3 * parse / (double)total_pictures : 0.0,
             g_pipeline ? "own thread, one picture ahead" : "same thread", total_pictures ? 1e3 * build / (double)total_pictures : 0.0);
+    if (g_json) {
+        struct rusage ru;
+        getrusage(RUSAGE_SELF, &ru);
+        long per_dev[64];
+        memset(per_dev, 0, sizeof(per_dev));
+        for (int i = 0; i < g_workers && i < 64; i++) if (g_dev[i] >= 0 && g_dev[i] < 64) per_dev[g_dev[i]] += g_pics[i];
+        printf("{\"pictures\": %ld, \"streams\": %d, \"jobs\": %d, \"devices\": %d, \"workers_per_device\": %d, \"tile_threads\": %d, \"build_threads\": %d, \"pipeline\": %d, "
+               "\"wall_s\": %.4f, \"decode_only_s\": %.4f, \"fps_wall\": %.2f, \"fps_decode_only\": %.2f, \"setup_s\": %.3f, \"parse_ms_per_picture\": %.3f, \"build_ms_per_picture\": %.3f, "
+               "\"cpu_user_s\": %.3f, \"cpu_sys_s\": %.3f, \"pictures_per_device\": [",
+               total_pictures, n_streams, n_jobs, gpus / workers, workers, g_tile_threads, g_build_threads, g_pipeline, secs, busy, secs > 0 ? (double)total_pictures / secs : 0.0,
+               busy > 0 ? (double)total_pictures / busy : 0.0, setup, total_pictures ? 1e3 * parse / (double)total_pictures : 0.0, total_pictures ? 1e3 * build / (double)total_pictures : 0.0,
+               (double)ru.ru_utime.tv_sec + 1e-6 * (double)ru.ru_utime.tv_usec, (double)ru.ru_stime.tv_sec + 1e-6 * (double)ru.ru_stime.tv_usec);
+        for (int d = 0; d < gpus / workers; d++) printf("%s%ld", d ? ", " : "", per_dev[d]);
+        printf("]}\n");
+    }
     return 0;
 }

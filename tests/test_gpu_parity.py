@@ -607,3 +607,17 @@ def test_gpu_bench_stream_plain_c_decoder(args, tmp_path):
             k = bad[0]
             d = np.flatnonzero(g[k * el:k * el + 1920 * 1088] != expect[k * el:k * el + 1920 * 1088])
             assert False, f"IDR period {period}: pictures {bad} differ; first luma differences of picture {k} at (y, x) {[(int(i) // 1920, int(i) % 1920) for i in d[:6]]} ({len(d)} samples)"
+
+
+@pytest.mark.gpu
+def test_gpu_bench_streams_leg_configs4():
+    """bench.py's multi-GPU leg (BASELINE configs[4] literally: independent Main streams -> examples/evc_decode --gpus N through the C work queue, compared with
+    the reference decoder) on a small picture size and however many devices the box has: every stream's first IDR period bit-exact, every picture accounted for"""
+    import bench
+    wl = dict(bench.WORKLOADS["cfg3_main_4k_10b_ra"], w=512, h=256)
+    out = bench.streams_leg(2, n_streams=3, gop_pictures=9, repeats=3, wl=wl)
+    assert "error" not in out.get("evc_decode", {}), out
+    assert out["pictures"] == 3 * 9 * 3 and sum(out["pictures_per_device"]) == out["pictures"]
+    assert out["devices_used"] >= 1 and out["host_cpu_quota"] >= 1
+    if os.path.exists(os.path.join(os.path.dirname(bench.__file__), "oracle", "_ref", "ref_decode_main")):
+        assert out["bit_exact"] is True, out

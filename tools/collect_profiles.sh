@@ -1,5 +1,6 @@
 # Round evidence on the GPU box: bench lines (with cpu_baseline), rocprofv3 kernel stats, HBM traffic counters (separate --pmc passes).
-# usage (through gpurun): bash tools/collect_profiles.sh <tag>      -> gpurun_out/<tag>_*
+# usage (through gpurun): XEVD_COMMIT=$(git rev-parse --short HEAD) ... bash tools/collect_profiles.sh <tag> [commit]     -> gpurun_out/<tag>_*
+[ -n "$2" ] && export XEVD_COMMIT=$2
 R=$GRAFT_REPO_ROOT; T=$1
 mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/latest_pmc.json from rocprofv3 --pmc passes (one pass per counter group, no tracing).
-usage: make_pmc_json.py <workload> <rdreq.csv> <wrreq.csv> <out.json> [<fetch_size.csv> <write_size.csv>]
+usage: make_pmc_json.py <workload> <rdreq.csv> <wrreq.csv> <out.json> [<fetch_size.csv> <write_size.csv>]      (XEVD_COMMIT in the environment: recorded as the code's commit)
 
 HBM traffic per dispatch from the L2 <-> fabric REQUEST counters, which carry their size:
     read bytes  = 128 * TCC_EA0_RDREQ_128B + 64 * TCC_EA0_RDREQ_64B + 32 * TCC_EA0_RDREQ_32B      (the three classes partition TCC_EA0_RDREQ)
@@ -11,6 +11,7 @@ tallied at 64) are kept next to it when their passes are given: FETCH_SIZE x 2 o
 too), which is where round 1's "2.16x" ALF traffic came from."""
 import csv
 import json
+import os
 import sys
 
 NAMES = {"k_inter(": "inter", "k_alf(": "alf", "k_addb<0>(": "dbk_v", "k_addb<1>(": "dbk_h", "k_addb_fused<": "dbk_v", "k_dbk<0>(": "dbk_v", "k_dbk<1>(": "dbk_h",
@@ -43,7 +44,7 @@ def main():
             kern[k]["fetch_size_kb"] = round(f, 1)
             kern[k]["write_size_kb"] = round(wv, 1)
             kern[k]["traffic_bytes_fetch_size_method"] = int((2.0 * f + wv) * 1024)
-    json.dump({"workload": wl, "source": f"{rpath} + {wpath} (rocprofv3 --pmc, separate passes, no tracing)",
+    json.dump({"workload": wl, "commit": os.environ.get("XEVD_COMMIT"), "source": f"{rpath} + {wpath} (rocprofv3 --pmc, separate passes, no tracing)",
                "method": "read = 128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B, write = 64*WRREQ_64B + 32*(WRREQ - WRREQ_64B); traffic_bytes_fetch_size_method = "
                          "(2*FETCH_SIZE + WRITE_SIZE) KB, the guide's gfx950 correction, for comparison",
                "kernels": kern}, open(opath, "w"), indent=1)

@@ -52,7 +52,31 @@ static inline uint32_t lps_range(Model m, uint32_t range) { const uint32_t l = (
 struct Dec {      // xevd_sbac_decode_bin / sbac_decode_bin_ep / xevd_sbac_decode_bin_trm, xevd_eco.c:35-165
     BitReader *br;
     uint32_t range, value;
-    void start() { range = 16384; value = 0; for (int i = 0; i < 14; i++) value = ((value << 1) | (uint32_t)br->get1()) & 0xFFFF; }
+    // The bits of the tile come through a 64-bit window (the reference shifts the stream in bit by bit, and so did round 1-3's get1() per renormalisation step: a
+    // bounds check, a byte index and a shift for every bit): refilled a byte at a time, zeros past the end of the data - reading one of THOSE sets br->overrun, as
+    // BitReader::get1 does.  br->pos is brought up to date by sync() (tile_end, and whoever looks at the reader after the tile).
+    uint64_t win = 0;
+    int avail = 0;                   // unread bits in `win`
+    size_t byte_pos = 0;             // next byte of br->p to load
+    void refill()
+    {
+        while (avail <= 56) { win = (win << 8) | (uint64_t)(byte_pos < br->size ? br->p[byte_pos] : 0); byte_pos++; avail += 8; }
+    }
+    uint32_t take(int n)             // 1 <= n <= 16 bits, first bit in the most significant place
+    {
+        if (avail < n) refill();
+        avail -= n;
+        if (byte_pos > br->size && byte_pos * 8 - (size_t)avail > br->size * 8) br->overrun = true;
+        return (uint32_t)(win >> avail) & ((1u << n) - 1u);
+    }
+    void sync() { br->pos = byte_pos * 8 - (size_t)avail; }
+    void start()
+    {
+        byte_pos = br->pos >> 3; win = 0; avail = 0;
+        refill();
+        avail -= (int)(br->pos & 7);                                 // a tile starts at a byte boundary in every stream; kept general
+        range = 16384; value = take(14);
+    }
     int bin(int, Model &m)
     {
         const int mps = m & 1;
@@ -61,7 +85,11 @@ struct Dec {      // xevd_sbac_decode_bin / sbac_decode_bin_ep / xevd_sbac_decod
         range -= lps;
         if (value >= range) { b = 1 - mps; value -= range; range = lps; model_update(m, true); }
         else model_update(m, false);
-        while (range < 8192) { range <<= 1; value = ((value << 1) | (uint32_t)br->get1()) & 0xFFFF; }
+        if (range < 8192) {                                          // renormalise: all the missing bits at once
+            const int sh = __builtin_clz(range) - 18;                // range < 2^13: bring its top bit to bit 13
+            range <<= sh;
+            value = ((value << sh) | take(sh)) & 0xFFFF;
+        }
         return b;
     }
     int ep(int)
@@ -70,12 +98,13 @@ struct Dec {      // xevd_sbac_decode_bin / sbac_decode_bin_ep / xevd_sbac_decod
         range >>= 1;
         if (value >= range) { b = 1; value -= range; }
         range <<= 1;
-        value = ((value << 1) | (uint32_t)br->get1()) & 0xFFFF;
+        value = ((value << 1) | take(1)) & 0xFFFF;
         return b;
     }
     int tile_end()      // terminating bin, then zero bits up to the byte boundary and zero words up to the end (xevd_eco.c:100-140,1683-1695)
     {
         range--;
+        sync();
         if (value < range) return 0;
         while (!br->aligned()) if (br->get1()) return -1;
         return 1;
