@@ -75,6 +75,30 @@ def test_builder_stream_pictures(path):
         assert stream_digests(lib, path, threads) == want, f"{threads} builder thread(s)"
 
 
+LARGE = (("intra1080", 1920, 1080, dict(inter_frac=0.0), {}), ("mix1080", 1920, 1080, dict(inter_frac=0.5, bi_frac=0.3, n_refs=(1, 1)), dict(admvp=1)),
+         ("eipd4k", 3840, 2160, dict(inter_frac=0.2, eipd=True), dict(eipd=1)), ("htdf1080", 1920, 1080, dict(inter_frac=0.7, n_refs=(1, 0)), {}))
+
+
+def large_digests(lib, case, threads):
+    from xevd_amd import synth
+    name, w, h, kw, spkw = case
+    b = synth.gen_frame(np.random.default_rng(11), w, h, 10, coded_frac=0.6, qp_range=(22, 37), **kw)
+    if name.startswith("htdf"):
+        b["htdf_slice_qp"] = 32
+    cb, keep = abi.make_cu_batch(b)
+    return _build(lib, abi.make_seq_params(w, h, 10, **spkw), cb, threads)
+
+
+@pytest.mark.parametrize("case", LARGE, ids=[c[0] for c in LARGE])
+def test_builder_large_pictures_on_several_threads(case):
+    """pictures with enough CUs and dependency nodes (14 k - 58 k) that every parallel section of the builder really runs on several threads: validation and counting,
+    owner map, node construction, record scatter and dependency rewrite - same arrays whatever the thread count, equal to the committed digests"""
+    lib = _lib()
+    want = json.load(open(GOLDEN_FILE))["large_" + case[0]]
+    for threads in (1, 4, 7):
+        assert large_digests(lib, case, threads) == want, f"{threads} builder thread(s)"
+
+
 def test_builder_rejects_invalid_batches_without_a_device():
     """the validation pass of the builder (geometry, reference indices, coefficient extents) answers before anything is allocated - also in the host-only shim"""
     lib = _lib()
@@ -94,5 +118,7 @@ if __name__ == "__main__" and "--write" in sys.argv:
     out = {"pic_" + n: picture_digests(lib, n, 1) for n in golden_io.PICTURE_CASES}
     for p in STREAMS:
         out[os.path.basename(p)] = stream_digests(lib, p, 1)
+    for c in LARGE:
+        out["large_" + c[0]] = large_digests(lib, c, 1)
     json.dump(out, open(GOLDEN_FILE, "w"), indent=0)
     print(len(out), "entries")

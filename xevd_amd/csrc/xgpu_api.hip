@@ -519,10 +519,10 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     std::vector<uint32_t> deps;
     int max_level = 0;
     // one CU: 0 = not a node, 1 = node appended to recs / deps (lv_out = its level when the levels of its dependencies are known: sequential mode), -1 = invalid batch
-    auto make_node = [&](const int i, std::vector<IntraRec> &recs, std::vector<uint32_t> &deps, bool &has_ibc, bool &has_htdf, int &lv_out) -> int {
+    // (r = where the node's record goes: a slot of the final list in the parallel mode, a temporary in the sequential one)
+    auto make_node = [&](const int i, IntraRec &r, std::vector<uint32_t> &deps, bool &has_ibc, bool &has_htdf, int &lv_out) -> int {
         if (!ordered((uint32_t)i)) return 0;
         const int xs = b->x[i] >> 2, ys = b->y[i] >> 2, units = ((1 << b->log2w[i]) + (1 << b->log2h[i])) >> 2;
-        IntraRec r;
         memset(&r, 0, sizeof(r));
         r.cu = (uint32_t)i; r.dep_first = (uint32_t)deps.size();
         r.x = b->x[i]; r.y = b->y[i]; r.log2w = b->log2w[i]; r.log2h = b->log2h[i]; r.cbf = b->cbf[i] & 7;
@@ -580,7 +580,6 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
             if (!add_htdf(r)) return -1;
             r.dep_count = (uint32_t)deps.size() - r.dep_first;
             lv_out = lv + 1;
-            recs.push_back(r);
             has_ibc = true;                      // the instantiation with the extra node kinds
             has_htdf = true;
             return 1;
@@ -606,7 +605,6 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
                 }
             r.dep_count = (uint32_t)deps.size() - r.dep_first;
             lv_out = lv + 1;
-            recs.push_back(r);
             has_ibc = true;
             return 1;
         }
@@ -641,20 +639,25 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
             }
         }
         bool used = true;
+        uint32_t last_used = NONE;                                                         // the neighbour CU the unit before this one was looked up for
         auto ok = [&](int sx, int sy) -> bool {
             const uint32_t j = owner[(size_t)sy * ws + sx];
             if (j >= (uint32_t)i || tile_of(sx, sy) != my_tile) return false;              // not reconstructed yet (or nothing there), or in another tile
-            const uint32_t jl = constrained_tree ? luma_owner[(size_t)sy * ws + sx] : j;
-            const bool j_intra = b->pred_mode[jl < (uint32_t)i ? jl : j] == XGPU_MODE_INTRA;
-            if (constrained && !j_intra) return false;                                     // constrained_intra_pred: intra neighbours only
-            if (!used) return true;
-            if (ordered(j) && j != last) {                                                 // inter CUs are complete before the intra kernel starts
-                bool seen = false;
-                for (size_t d = r.dep_first; d < deps.size() && !seen; d++) seen = deps[d] == j;
-                if (!seen) deps.push_back(j);
-                last = j;
+            if (constrained) {                                                             // constrained_intra_pred: intra neighbours only
+                const uint32_t jl = constrained_tree ? luma_owner[(size_t)sy * ws + sx] : j;
+                if (b->pred_mode[jl < (uint32_t)i ? jl : j] != XGPU_MODE_INTRA) return false;
             }
-            lv = std::max(lv, level_p[j]);
+            if (!used) return true;
+            if (j != last_used) {                                                          // (a wide neighbour covers several units: looked at once)
+                last_used = j;
+                if (j != last && ordered(j)) {                                             // inter CUs are complete before the intra kernel starts
+                    bool seen = false;
+                    for (size_t d = r.dep_first; d < deps.size() && !seen; d++) seen = deps[d] == j;
+                    if (!seen) deps.push_back(j);
+                    last = j;
+                }
+                if (!fast) lv = std::max(lv, level_p[j]);                                  // (parallel mode: the levels are assigned afterwards)
+            }
             return true;
         };
         used = need_ul;
@@ -670,46 +673,51 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         if (hidx >= 0) { used = true; if (!add_htdf(r)) return -1; has_htdf = true; has_ibc = true; }
         r.dep_count = (uint32_t)deps.size() - r.dep_first;
         lv_out = lv + 1;
-        recs.push_back(r);
         return 1;
     };
     PT("setup");
     if (!fast) {
         for (int i = 0; i < n; paint(i), i++) {
             int lv = 0;
-            const int rc = make_node(i, recs, deps, plan.has_ibc, plan.has_htdf, lv);
+            IntraRec r;
+            const int rc = make_node(i, r, deps, plan.has_ibc, plan.has_htdf, lv);
             if (rc < 0) return false;
-            if (rc) { level[(size_t)i] = lv; max_level = std::max(max_level, lv); }
+            if (rc) { recs.push_back(r); level[(size_t)i] = lv; max_level = std::max(max_level, lv); }
         }
     } else {
         // `nodes` = the CUs that are nodes, in decoding order (collected by the caller's validation pass): the ranges of this list go to the threads
         const int nn = (int)nodes.size();
         const int K = std::max(1, std::min(nthr, std::max(1, nn / 2048)));
-        struct Out { std::vector<IntraRec> recs; std::vector<uint32_t> deps; bool ibc = false, htdf = false, bad = false; };
+        // every entry of `nodes` becomes exactly one record: the threads write their ranges of the final list; the dependency lists are per thread and
+        // concatenated afterwards (dep_first moved along while the levels are assigned)
+        struct Out { std::vector<uint32_t> deps; bool ibc = false, htdf = false, bad = false; };
         std::vector<Out> outs((size_t)K);
+        recs.resize((size_t)nn);
+        IntraRec *const recs_p = recs.data();
         auto work = [&](int k) {
             Out &o = outs[(size_t)k];
             int lv = 0;
             const int q0 = (int)((long long)nn * k / K), q1 = (int)((long long)nn * (k + 1) / K);
-            o.recs.reserve((size_t)(q1 - q0)); o.deps.reserve((size_t)(q1 - q0) * 3);
-            for (int q = q0; q < q1 && !o.bad; q++) o.bad = make_node((int)nodes[(size_t)q], o.recs, o.deps, o.ibc, o.htdf, lv) < 0;
+            o.deps.reserve((size_t)(q1 - q0) * 3);
+            for (int q = q0; q < q1 && !o.bad; q++) o.bad = make_node((int)nodes[(size_t)q], recs_p[q], o.deps, o.ibc, o.htdf, lv) != 1;
         };
         pool.run(K, work);
         PT("nodes");
-        size_t nr = 0, nd = 0;
-        for (const Out &o : outs) { if (o.bad) return false; nr += o.recs.size(); nd += o.deps.size(); plan.has_ibc |= o.ibc; plan.has_htdf |= o.htdf; }
-        recs.reserve(nr); deps.reserve(nd);
-        for (Out &o : outs) {
-            const uint32_t base = (uint32_t)deps.size();
-            for (IntraRec &r : o.recs) { r.dep_first += base; recs.push_back(r); }
-            deps.insert(deps.end(), o.deps.begin(), o.deps.end());
-        }
+        size_t nd = 0;
+        for (const Out &o : outs) { if (o.bad) return false; nd += o.deps.size(); plan.has_ibc |= o.ibc; plan.has_htdf |= o.htdf; }
+        deps.reserve(nd);
         // levels, in decoding order: 1 + the highest level among the nodes read (CUs that are no nodes - complete before the intra kernels start - count as level 0)
-        for (const IntraRec &r : recs) {
-            int lv = 0;
-            for (uint32_t d = r.dep_first; d < r.dep_first + r.dep_count; d++) lv = std::max(lv, level[deps[d]]);
-            level[r.cu] = lv + 1;
-            max_level = std::max(max_level, lv + 1);
+        for (int k = 0; k < K; k++) {
+            const uint32_t base = (uint32_t)deps.size();
+            deps.insert(deps.end(), outs[(size_t)k].deps.begin(), outs[(size_t)k].deps.end());
+            for (int q = (int)((long long)nn * k / K), q1 = (int)((long long)nn * (k + 1) / K); q < q1; q++) {
+                IntraRec &r = recs_p[q];
+                r.dep_first += base;
+                int lv = 0;
+                for (uint32_t d = r.dep_first; d < r.dep_first + r.dep_count; d++) lv = std::max(lv, level[deps[d]]);
+                level[r.cu] = lv + 1;
+                max_level = std::max(max_level, lv + 1);
+            }
         }
     }
     PT("levels");
@@ -809,38 +817,72 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     pos.assign((size_t)n, NONE);
     plan.recs.resize(n_entries);
     plan.n_level1 = 0; plan.n_heads = 0;
-    for (size_t ri = 0; ri < recs.size(); ri++) {
+    uint32_t *const pos_p = pos.data();
+    for (size_t ri = 0; ri < recs.size(); ri++) {                     // positions (serial: a running counter per key) ...
         const int np = parts_of(recs[ri]), k = first[key(ri)];
         first[key(ri)] += np;
-        pos[recs[ri].cu] = (uint32_t)k;
-        for (int q = 0; q < np; q++) { IntraRec &o = plan.recs[(size_t)k + q]; o = recs[ri]; o.pad0 = (uint8_t)q; o.pad1[0] = (uint8_t)np; }
+        pos_p[recs[ri].cu] = (uint32_t)k;
         if (level[recs[ri].cu] == 1) plan.n_level1 += np;
         if (!member[ri]) plan.n_heads += np;
     }
     plan.n_levels = max_level;
-    PT("sort");
     // dependency CU indices -> list positions, every part of a CU that has parts.  Level-1 CUs are finished by their own launch before the data-flow launch starts: they drop
-    // out of the waiting lists; a strand member waits for nobody (its one dependency of the launch is the CU its wave has just finished)
-    std::vector<uint32_t> ndeps;
-    ndeps.reserve(deps.size() + deps.size() / 4);
-    for (size_t ri = 0; ri < recs.size(); ri++) {
-        const IntraRec &r = recs[ri];
-        const uint32_t nf = (uint32_t)ndeps.size();
-        if (!member[ri])
-            for (uint32_t d = r.dep_first; d < r.dep_first + r.dep_count; d++) {
-                const uint32_t j = deps[d], pj = pos[j];
-                if (pj < (uint32_t)plan.n_level1) continue;
-                const int np = parts_of(recs[(size_t)rec_of_cu[j]]);
-                for (int q = 0; q < np; q++) ndeps.push_back(pj + (uint32_t)q);
-            }
-        const int np = parts_of(r);
-        for (int q = 0; q < np; q++) {
-            IntraRec &o = plan.recs[(size_t)pos[r.cu] + q];
-            o.dep_first = nf; o.dep_count = (uint32_t)ndeps.size() - nf;
-            // the device reads the successor's list position where the host kept the CU index
-            o.cu = succ[ri] == NONE ? NONE : pos[recs[succ[ri]].cu];
+    // out of the waiting lists; a strand member waits for nobody (its one dependency of the launch is the CU its wave has just finished).  Counted per record first, so that
+    // the records and their lists can be written by the builder's threads
+    static thread_local std::vector<uint32_t> nfirst;
+    nfirst.resize(recs.size() + 1);
+    uint32_t *const nf_p = nfirst.data();
+    const IntraRec *const rc_p = recs.data();
+    const uint32_t *const dp_p = deps.data();
+    const int32_t *const roc_p = rec_of_cu.data();
+    const uint32_t *const succ_p = succ.data();
+    const uint8_t *const mem_p = member.data();
+    const uint32_t n_l1 = (uint32_t)plan.n_level1;
+    const int KS = std::max(1, std::min(nthr, std::max(1, (int)recs.size() / 2048)));
+    auto range = [&](int k, size_t &a0, size_t &a1) { a0 = recs.size() * (size_t)k / KS; a1 = recs.size() * (size_t)(k + 1) / KS; };
+    pool.run(KS, [&](int k) {
+        size_t a0, a1;
+        range(k, a0, a1);
+        for (size_t ri = a0; ri < a1; ri++) {
+            uint32_t c = 0;
+            if (!mem_p[ri])
+                for (uint32_t d = rc_p[ri].dep_first; d < rc_p[ri].dep_first + rc_p[ri].dep_count; d++) {
+                    const uint32_t j = dp_p[d];
+                    if (pos_p[j] >= n_l1) c += (uint32_t)parts_of(rc_p[(size_t)roc_p[j]]);
+                }
+            nf_p[ri + 1] = c;
         }
-    }
+    });
+    nf_p[0] = 0;
+    for (size_t ri = 0; ri < recs.size(); ri++) nf_p[ri + 1] += nf_p[ri];
+    PT("sort");
+    std::vector<uint32_t> ndeps((size_t)nf_p[recs.size()]);
+    uint32_t *const nd_p = ndeps.data();
+    IntraRec *const out_p = plan.recs.data();
+    pool.run(KS, [&](int k) {                                         // ... records and lists (parallel: every record knows where it goes)
+        size_t a0, a1;
+        range(k, a0, a1);
+        for (size_t ri = a0; ri < a1; ri++) {
+            const IntraRec &r = rc_p[ri];
+            uint32_t w = nf_p[ri];
+            if (!mem_p[ri])
+                for (uint32_t d = r.dep_first; d < r.dep_first + r.dep_count; d++) {
+                    const uint32_t j = dp_p[d], pj = pos_p[j];
+                    if (pj < n_l1) continue;
+                    const int npj = parts_of(rc_p[(size_t)roc_p[j]]);
+                    for (int q = 0; q < npj; q++) nd_p[w++] = pj + (uint32_t)q;
+                }
+            const int np = parts_of(r);
+            for (int q = 0; q < np; q++) {
+                IntraRec &o = out_p[(size_t)pos_p[r.cu] + q];
+                o = r;
+                o.pad0 = (uint8_t)q; o.pad1[0] = (uint8_t)np;
+                o.dep_first = nf_p[ri]; o.dep_count = nf_p[ri + 1] - nf_p[ri];
+                // the device reads the successor's list position where the host kept the CU index
+                o.cu = succ_p[ri] == NONE ? NONE : pos_p[rc_p[succ_p[ri]].cu];
+            }
+        }
+    });
     plan.deps.swap(ndeps);
     return true;
 }
