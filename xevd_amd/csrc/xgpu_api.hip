@@ -515,8 +515,13 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     }
     auto tile_of = [&](int sx, int sy) -> int { return ctu_tile.empty() ? 0 : ctu_tile[(size_t)(sy >> ctu_sh) * c->w_ctu + (sx >> ctu_sh)]; };
     const bool constrained = b->constrained_intra_pred != 0;
-    std::vector<IntraRec> recs;                 // decode order; dep lists hold CU indices until the sort below
-    std::vector<uint32_t> deps;
+    // (the working arrays of the plan are the builder thread's own, kept between pictures: at 8K they are 6 - 7 MB each, and a fresh vector per call is an mmap, a
+    //  page fault per 4 KB and a munmap whose TLB shootdown interrupts the parser's tile threads)
+    static thread_local std::vector<IntraRec> recs_tl;      // decode order; dep lists hold CU indices until the sort below
+    static thread_local std::vector<uint32_t> deps_tl;
+    std::vector<IntraRec> &recs = recs_tl;
+    std::vector<uint32_t> &deps = deps_tl;
+    deps.clear();      // (recs: cleared by the sequential mode; the parallel mode resizes it - no re-initialisation of records that are overwritten anyway)
     int max_level = 0;
     // one CU: 0 = not a node, 1 = node appended to recs / deps (lv_out = its level when the levels of its dependencies are known: sequential mode), -1 = invalid batch
     // (r = where the node's record goes: a slot of the final list in the parallel mode, a temporary in the sequential one)
@@ -677,6 +682,7 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     };
     PT("setup");
     if (!fast) {
+        recs.clear();
         for (int i = 0; i < n; paint(i), i++) {
             int lv = 0;
             IntraRec r;
@@ -691,7 +697,10 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         // every entry of `nodes` becomes exactly one record: the threads write their ranges of the final list; the dependency lists are per thread and
         // concatenated afterwards (dep_first moved along while the levels are assigned)
         struct Out { std::vector<uint32_t> deps; bool ibc = false, htdf = false, bad = false; };
-        std::vector<Out> outs((size_t)K);
+        static thread_local std::vector<Out> outs_tl;
+        std::vector<Out> &outs = outs_tl;
+        if ((int)outs.size() < K) outs.resize((size_t)K);
+        for (Out &o : outs) { o.deps.clear(); o.ibc = o.htdf = o.bad = false; }
         recs.resize((size_t)nn);
         IntraRec *const recs_p = recs.data();
         auto work = [&](int k) {
@@ -704,7 +713,7 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         pool.run(K, work);
         PT("nodes");
         size_t nd = 0;
-        for (const Out &o : outs) { if (o.bad) return false; nd += o.deps.size(); plan.has_ibc |= o.ibc; plan.has_htdf |= o.htdf; }
+        for (int k = 0; k < K; k++) { const Out &o = outs[(size_t)k]; if (o.bad) return false; nd += o.deps.size(); plan.has_ibc |= o.ibc; plan.has_htdf |= o.htdf; }
         deps.reserve(nd);
         // levels, in decoding order: 1 + the highest level among the nodes read (CUs that are no nodes - complete before the intra kernels start - count as level 0)
         for (int k = 0; k < K; k++) {
@@ -790,10 +799,15 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         const int nscu = 1 << (r.log2w + r.log2h - 4), steps = (c->sp.tool_eipd ? nscu * 4 : nscu) / 64;
         return std::max(1, std::min(steps, 16));
     };
-    std::vector<int32_t> rec_of_cu((size_t)n, -1);
+    static thread_local std::vector<int32_t> rec_of_cu_tl;
+    std::vector<int32_t> &rec_of_cu = rec_of_cu_tl;
+    rec_of_cu.assign((size_t)n, -1);
     for (size_t ri = 0; ri < recs.size(); ri++) rec_of_cu[recs[ri].cu] = (int32_t)ri;
-    std::vector<uint32_t> succ(recs.size(), NONE);
-    std::vector<uint8_t> member(recs.size(), 0);             // 1: reached through its parent, not through a ticket
+    static thread_local std::vector<uint32_t> succ_tl;
+    static thread_local std::vector<uint8_t> member_tl;
+    std::vector<uint32_t> &succ = succ_tl;
+    std::vector<uint8_t> &member = member_tl;                // 1: reached through its parent, not through a ticket
+    succ.assign(recs.size(), NONE); member.assign(recs.size(), 0);
     for (size_t ri = 0; ri < recs.size(); ri++) {
         const IntraRec &r = recs[ri];
         if (level[r.cu] < 2) continue;
@@ -856,7 +870,8 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     nf_p[0] = 0;
     for (size_t ri = 0; ri < recs.size(); ri++) nf_p[ri + 1] += nf_p[ri];
     PT("sort");
-    std::vector<uint32_t> ndeps((size_t)nf_p[recs.size()]);
+    std::vector<uint32_t> &ndeps = plan.deps;                         // (the caller's plan object keeps its capacity between pictures)
+    ndeps.resize((size_t)nf_p[recs.size()]);
     uint32_t *const nd_p = ndeps.data();
     IntraRec *const out_p = plan.recs.data();
     pool.run(KS, [&](int k) {                                         // ... records and lists (parallel: every record knows where it goes)
@@ -883,7 +898,6 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
             }
         }
     });
-    plan.deps.swap(ndeps);
     return true;
 }
 
@@ -1052,7 +1066,9 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
         if (cls_count[k]) { const int per = itdq_group_size((k & 63) >> 3, k & 7); n_waves += (cls_count[k] + per - 1) / per; }
     }
 
-    IntraPlan plan;
+    static thread_local IntraPlan plan_tl;                 // (kept between pictures: see build_intra_plan)
+    IntraPlan &plan = plan_tl;
+    plan.recs.clear(); plan.deps.clear();
     plan.n_levels = 0; plan.n_level1 = 0; plan.n_heads = 0; plan.n_ctus = 0;
     bool any_intra = false;
     plan.has_ibc = false; plan.has_htdf = false;
