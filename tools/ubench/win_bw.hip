@@ -17,7 +17,7 @@ __device__ __forceinline__ uint32_t hash(uint32_t x) { x ^= x >> 16; x *= 0x7feb
 
 // one wave per TW x TH tile, 4 waves (2 x 2 tiles) per workgroup; REFS reference windows; WR: write the tile; sigma: vector range +- sigma samples (uniform)
 template <int TW, int TH, int REFS, bool WR, int AX = 2>
-__global__ __launch_bounds__(256) void k_win(const int16_t *r0, const int16_t *r1, int16_t *dst, int tiles_x, int tiles_y, int sigma, int strip, int xcd_map)
+__global__ __launch_bounds__(256) void k_win(const int16_t *r0, const int16_t *r1, int16_t *dst, int tiles_x, int tiles_y, int sigma, int strip, int xcd_map, int aln = 0)
 {
     constexpr int AY = 4 / AX;                              // the workgroup's four waves as AX x AY tiles
     const int wg_x = tiles_x / AX, wg_y = tiles_y / AY, n_wg = wg_x * wg_y;
@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void k_win(const int16_t *r0, const int16_t *r
     for (int r = 0; r < REFS; r++) {
         const uint32_t h = hash((uint32_t)(ty * tiles_x + tx) * 2 + r);
         const int mx = sigma ? (int)(h % (2 * sigma + 1)) - sigma : 0, my = sigma ? (int)((h >> 12) % (2 * sigma + 1)) - sigma : 0;
-        const int16_t *p = (r ? r1 : r0) + (size_t)(y0 + my - 3) * STRIDE + x0 + mx - 3;
+        // aln: the window's chunks start at the 16-byte boundary below its first sample (one more chunk per row would cover it: same count here, the last one clipped)
+        const int16_t *p = (r ? r1 : r0) + (size_t)(y0 + my - 3) * STRIDE + (aln ? ((x0 + mx - 3) & ~7) : x0 + mx - 3);
 #pragma unroll
         for (int i = lane; i < WH * CH; i += 64) {
             const int row = i / CH, c = i - row * CH;
@@ -54,20 +55,21 @@ __global__ __launch_bounds__(256) void k_win(const int16_t *r0, const int16_t *r
 }
 
 template <int TW, int TH, int REFS, bool WR, int AX = 2>
-static void run(const char *name, const int16_t *r0, const int16_t *r1, int16_t *dst, int sigma, int strip_px, int xcd)
+static void run(const char *name, const int16_t *r0, const int16_t *r1, int16_t *dst, int sigma, int strip_px, int xcd, int aln = 0)
 {
     const int tiles_x = PW / TW, tiles_y = PH / TH, n_wg = (tiles_x / AX) * (tiles_y / (4 / AX));
     const int strip = strip_px / (AX * TW) > 0 ? strip_px / (AX * TW) : 1;
     hipEvent_t a, b;
     hipEventCreate(&a); hipEventCreate(&b);
     const int grid = ((n_wg + 7) >> 3) << 3;
-    for (int i = 0; i < 2; i++) hipLaunchKernelGGL((k_win<TW, TH, REFS, WR, AX>), dim3(grid), dim3(256), 0, 0, r0, r1, dst, tiles_x, tiles_y, sigma, strip, xcd);
+    for (int i = 0; i < 2; i++) hipLaunchKernelGGL((k_win<TW, TH, REFS, WR, AX>), dim3(grid), dim3(256), 0, 0, r0, r1, dst, tiles_x, tiles_y, sigma, strip, xcd, aln);
     hipEventRecord(a, 0);
     const int reps = 8;
-    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_win<TW, TH, REFS, WR, AX>), dim3(grid), dim3(256), 0, 0, r0, r1, dst, tiles_x, tiles_y, sigma, strip, xcd);
+    for (int i = 0; i < reps; i++) hipLaunchKernelGGL((k_win<TW, TH, REFS, WR, AX>), dim3(grid), dim3(256), 0, 0, r0, r1, dst, tiles_x, tiles_y, sigma, strip, xcd, aln);
     hipEventRecord(b, 0); hipEventSynchronize(b);
     float ms = 0; hipEventElapsedTime(&ms, a, b);
     const double us = ms * 1e3 / reps, bytes = (double)PW * PH * 2 * (REFS + (WR ? 1 : 0));
+    if (aln) name = "rw aligned";
     printf("%-10s wg %dx%d tile %3dx%-3d refs %d write %d sigma %2d strip %4dpx xcd %d : %7.1f us  %7.1f GB/s (compulsory bytes)\n", name, AX, 4 / AX, TW, TH, REFS, (int)WR, sigma, strip_px, xcd, us, bytes / us / 1e3);
     fflush(stdout);
 }
@@ -176,6 +178,10 @@ int main(int argc, char **argv)
     run<32, 32, 2, true>("rw", r0, r1, d, 16, 7680, 1);
     run<32, 32, 2, true>("rw", r0, r1, d, 16, 256, 1);
     }
+    run<32, 32, 2, true, 2>("rw", r0, r1, d, 16, 1024, 1, 1);
+    run<64, 32, 2, true, 2>("rw", r0, r1, d, 16, 1024, 1, 1);
+    run<32, 32, 2, false, 2>("read", r0, r1, d, 16, 1024, 1, 0);
+    run<32, 32, 2, false, 2>("read", r0, r1, d, 16, 1024, 1, 1);
     // the workgroup's shape with k_inter's 32x32 wave tile, and the wider wave tiles
     run<32, 32, 2, true, 2>("rw", r0, r1, d, 16, 1024, 1);
     run<32, 32, 2, true, 4>("rw", r0, r1, d, 16, 1024, 1);

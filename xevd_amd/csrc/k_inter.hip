@@ -60,19 +60,16 @@ __device__ __forceinline__ void tile_fetch(gs16 p, int s, gs16 pu, gs16 pv, int 
     if (lane < 57) { f.c[0] = gload16(pu + fm.gc); f.c[1] = gload16(pv + fm.gc); }
 }
 
-template <bool H, bool V>
-__device__ __forceinline__ void mc_luma_tile(const uint4 v[4], const uint32_t ch[4], const uint32_t cv[4], Regime rg, int maxv,
-                                             int16_t *W, int16_t *I, int lane, const LaneMap fm, uint32_t o[8])
+// the two passes over a 39x39 window in LDS: Wn = the window's first sample, WS = its row stride in samples (UW_STRIDE: the wave's own window; REG_W_STRIDE: the
+// wave's part of the 71x71 window its workgroup shares, see inter_tile<2>)
+template <bool H, bool V, int WS>
+__device__ __forceinline__ void luma_tile_filter(const int16_t *Wn, const uint32_t ch[4], const uint32_t cv[4], Regime rg, int maxv, int16_t *I, int lane, uint32_t o[8])
 {
-#pragma unroll
-    for (int it = 0; it < 4; it++)
-        if (lane < (it < 3 ? 60 : 15)) *(uint4 *)(W + fm.ly + 12 * it * UW_STRIDE) = v[it];
-    wave_lds_sync();
 #pragma unroll
     for (int it = 0; it < 5; it++) {                                // horizontal pass: 39 rows x 8 groups of 4 columns
         const int idx = lane + 64 * it, row = idx >> 3, g = idx & 7;
         if (idx < 312) {
-            const uint2 *w = (const uint2 *)(W + row * UW_STRIDE + 4 * g);
+            const uint2 *w = (const uint2 *)(Wn + row * WS + 4 * g);
             const uint2 a = w[0], b = w[1], c = w[2];
             const uint32_t D0 = a.x, D1 = a.y, D2 = b.x, D3 = b.y, D4 = c.x, D5 = c.y;
             uint2 r;
@@ -126,19 +123,27 @@ __device__ __forceinline__ void mc_luma_tile(const uint4 v[4], const uint32_t ch
     }
     wave_lds_sync();
 }
-
-// Both chroma planes of the tile (16x16 each).  pu / pv = reference sample at (tile x - 1, tile y - 1) of the plane.
 template <bool H, bool V>
-__device__ __forceinline__ void mc_chroma_tile(const uint4 v[2], const uint32_t ch[2], const uint32_t cv[2],
-                                               Regime rg, int maxv, int16_t *W, int16_t *I, int lane, const LaneMap fm, uint32_t ou[2], uint32_t ov[2])
+__device__ __forceinline__ void mc_luma_tile(const uint4 v[4], const uint32_t ch[4], const uint32_t cv[4], Regime rg, int maxv,
+                                             int16_t *W, int16_t *I, int lane, const LaneMap fm, uint32_t o[8])
 {
-    if (lane < 57) { *(uint4 *)(W + fm.lc) = v[0]; *(uint4 *)(W + 19 * UC_STRIDE + fm.lc) = v[1]; }
+#pragma unroll
+    for (int it = 0; it < 4; it++)
+        if (lane < (it < 3 ? 60 : 15)) *(uint4 *)(W + fm.ly + 12 * it * UW_STRIDE) = v[it];
     wave_lds_sync();
+    luma_tile_filter<H, V, UW_STRIDE>(W, ch, cv, rg, maxv, I, lane, o);
+}
+
+// Both chroma planes of the tile (16x16 each): the passes over the two 19x19 windows Wu / Wv (row stride WS) in LDS
+template <bool H, bool V, int WS>
+__device__ __forceinline__ void chroma_tile_filter(const int16_t *Wu, const int16_t *Wv, const uint32_t ch[2], const uint32_t cv[2],
+                                                   Regime rg, int maxv, int16_t *I, int lane, uint32_t ou[2], uint32_t ov[2])
+{
 #pragma unroll
     for (int it = 0; it < 3; it++) {                                // horizontal pass: 2 x 19 rows x 4 groups of 4 columns
         const int idx = lane + 64 * it, prow = idx >> 2, g = idx & 3;
         if (idx < 152) {
-            const uint2 *w = (const uint2 *)(W + prow * UC_STRIDE + 4 * g);
+            const uint2 *w = (const uint2 *)((prow >= 19 ? Wv + (prow - 19) * WS : Wu + prow * WS) + 4 * g);
             const uint2 a = w[0], b = w[1];
             const uint32_t D0 = a.x, D1 = a.y, D2 = b.x, D3 = b.y;
             const uint32_t Q0 = hi_lo(D1, D0), Q1 = hi_lo(D2, D1);
@@ -190,8 +195,62 @@ __device__ __forceinline__ void mc_chroma_tile(const uint4 v[2], const uint32_t 
     }
     wave_lds_sync();
 }
+// pu / pv = reference sample at (tile x - 1, tile y - 1) of the plane.
+template <bool H, bool V>
+__device__ __forceinline__ void mc_chroma_tile(const uint4 v[2], const uint32_t ch[2], const uint32_t cv[2],
+                                               Regime rg, int maxv, int16_t *W, int16_t *I, int lane, const LaneMap fm, uint32_t ou[2], uint32_t ov[2])
+{
+    if (lane < 57) { *(uint4 *)(W + fm.lc) = v[0]; *(uint4 *)(W + 19 * UC_STRIDE + fm.lc) = v[1]; }
+    wave_lds_sync();
+    chroma_tile_filter<H, V, UC_STRIDE>(W, W + 19 * UC_STRIDE, ch, cv, rg, maxv, I, lane, ou, ov);
+}
 
-#define INTER_STRIP 16
+// ---------------------------------------------------------------------------------------------------------
+// A 64x64 region inside ONE CU (half of the samples of a typical picture lie in CUs of 64x64 and above): its four waves would each fetch their own 39x39 window -
+// 78-byte rows that touch 1.44 cache lines, and the 7-sample halos between the four tiles twice.  The workgroup fetches the region's 71x71 window (+ 2 x 35x35 chroma)
+// ONCE into LDS it shares - rows of 142 bytes: 2.1 lines - and every wave filters its own 39x39 part of it with the tile passes above.  Per region and list 149 + 104
+// line requests instead of 225 + 198 (round 4: the kernel is bound by the rate of L1 -> L2 line requests, ~70 G/s of the ~85 G/s this access pattern reaches with no
+// arithmetic at all - tools/ubench/win_bw.hip).  Two workgroup barriers per list.
+// ---------------------------------------------------------------------------------------------------------
+#define REG_W_STRIDE 80              // 71 columns in 9 chunks of 8 samples
+#define REG_C_STRIDE 40              // 35 columns in 5 chunks
+#define REG_W_SAMPLES (71 * REG_W_STRIDE)
+#define REG_C_SAMPLES (35 * REG_C_STRIDE)
+#define REG_I_SAMPLES (39 * UI_STRIDE)
+#define REG_SAMPLES   (REG_W_SAMPLES + 2 * REG_C_SAMPLES + 4 * REG_I_SAMPLES)
+struct RegionFetch { uint4 y[3]; uint4 c[2]; };
+// a thread's chunks of the region windows: luma 71 rows x 9 chunks in three rounds of 256 threads, chroma 2 planes x 35 rows x 5 chunks in two; offsets < 0: none
+struct RegionMap { int y[3], c[2]; };      // row << 8 | chunk (chroma: | plane << 7); < 0: none.  The offsets are formed where they are used: five registers, not ten
+__device__ __forceinline__ RegionMap region_map(int t)
+{
+    RegionMap m;
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+        const int idx = t + 256 * it, row = idx / 9, k = idx - row * 9;
+        m.y[it] = idx < 71 * 9 ? (row << 8) | k : -1;
+    }
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const int idx = t + 256 * it, pl = idx >= 175, j = idx - 175 * pl, row = j / 5, k = j - row * 5;
+        m.c[it] = idx < 350 ? (row << 8) | (pl << 7) | k : -1;
+    }
+    return m;
+}
+__device__ __forceinline__ void region_fetch(gs16 p, int s_l, gs16 pu, gs16 pv, int s_c, const RegionMap m, RegionFetch &f)
+{
+#pragma unroll
+    for (int it = 0; it < 3; it++) if (m.y[it] >= 0) f.y[it] = gload16(p + (m.y[it] >> 8) * s_l + 8 * (m.y[it] & 127));
+#pragma unroll
+    for (int it = 0; it < 2; it++) if (m.c[it] >= 0) f.c[it] = gload16(((m.c[it] & 128) ? pv : pu) + (m.c[it] >> 8) * s_c + 8 * (m.c[it] & 127));
+}
+__device__ __forceinline__ void region_store(const RegionFetch &f, const RegionMap m, int16_t *SH)
+{
+#pragma unroll
+    for (int it = 0; it < 3; it++) if (m.y[it] >= 0) *(uint4 *)(SH + (m.y[it] >> 8) * REG_W_STRIDE + 8 * (m.y[it] & 127)) = f.y[it];
+#pragma unroll
+    for (int it = 0; it < 2; it++) if (m.c[it] >= 0) *(uint4 *)(SH + REG_W_SAMPLES + ((m.c[it] & 128) ? REG_C_SAMPLES : 0) + (m.c[it] >> 8) * REG_C_STRIDE + 8 * (m.c[it] & 127)) = f.c[it];
+}
+
 #define OWNER_NONE 0xFFFFFFFFu
 
 // One 32x32 tile (one wave): the SCU map records, and for plain inter CUs prediction + residual + store.  UNI: the whole tile lies in one CU -
@@ -200,10 +259,14 @@ __device__ __forceinline__ void mc_chroma_tile(const uint4 v[2], const uint32_t 
 // Returns whether the lane has samples to store: pl / pu / pv = its 4x4 luma and 2x2 + 2x2 chroma samples (the caller stores them AFTER it has taken
 // the prefetched records of the next tile out of their registers: stores and loads share one counter, and a wait behind the stores would be a
 // wait for their acknowledgement - a memory round trip per tile).
-template <bool UNI>
+// MODE 0: per lane; 1: the wave's tile inside one CU (UNI above); 2: the workgroup's whole 64x64 region inside one CU - the reference windows are fetched once per
+// workgroup into LDS the four waves share (W = that block, rm = the thread's chunks of it, wave = the tile's place in the region), everything else as in mode 1
+template <int MODE>
 __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r1, bool lane_ok, int sx, int sy, int lane, int16_t *W, const LaneMap fm,
-                                           const uint4 (*s_ref)[2], const uint4 *s_ltap, const uint2 *s_ctap, uint32_t pl[8], uint32_t pu[2], uint32_t pv[2])
+                                           const uint4 (*s_ref)[2], const uint4 *s_ltap, const uint2 *s_ctap, uint32_t pl[8], uint32_t pu[2], uint32_t pv[2],
+                                           const RegionMap *rm = nullptr, int wave = 0)
 {
+    constexpr bool UNI = MODE != 0;
     if (UNI) {
         r0.x = __builtin_amdgcn_readfirstlane(r0.x); r0.y = __builtin_amdgcn_readfirstlane(r0.y); r0.z = __builtin_amdgcn_readfirstlane(r0.z); r0.w = __builtin_amdgcn_readfirstlane(r0.w);
         r1.x = __builtin_amdgcn_readfirstlane(r1.x); r1.y = __builtin_amdgcn_readfirstlane(r1.y); r1.z = __builtin_amdgcn_readfirstlane(r1.z); r1.w = __builtin_amdgcn_readfirstlane(r1.w);
@@ -313,7 +376,60 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
             rv[0] = *(const uint32_t *)r; rv[1] = *(const uint32_t *)(r + cwc);
         }
     };
-    if (UNI) {
+    if (MODE == 2) {
+        // the region's windows: requested by all 256 threads for both lists (and the residual) before anything is filtered; then, list by list, into the shared
+        // block, a barrier, every wave's passes over its part, a barrier before the block is written again
+        const int wx = __builtin_amdgcn_readfirstlane(x) & ~63, wy = __builtin_amdgcn_readfirstlane(y) & ~63;      // the region's first sample
+        int16_t *const I = W + REG_W_SAMPLES + 2 * REG_C_SAMPLES + wave * REG_I_SAMPLES;
+        const int16_t *const Wy = W + ((wave >> 1) << 5) * REG_W_STRIDE + ((wave & 1) << 5);
+        const int16_t *const Wu = W + REG_W_SAMPLES + ((wave >> 1) << 4) * REG_C_STRIDE + ((wave & 1) << 4), *const Wv = Wu + REG_C_SAMPLES;
+        RegionFetch rf[2];
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+            if (!use[l]) continue;
+            const uint4 e0 = s_ref[refis[l] * 2 + l][0], e1 = s_ref[refis[l] * 2 + l][1];
+            const gs16 ry_ = (gs16)(((uint64_t)e0.y << 32) | e0.x), ru_ = (gs16)(((uint64_t)e0.w << 32) | e0.z), rv_ = (gs16)(((uint64_t)e1.y << 32) | e1.x);
+            const int px = (wx << 2) + mvt[l][0], py = (wy << 2) + mvt[l][1];
+            const int off = ((py >> 3) - 1) * a.s_c + (px >> 3) - 1;
+            region_fetch(ry_ + ((py >> 2) - 3) * a.s_l + (px >> 2) - 3, a.s_l, ru_ + off, rv_ + off, a.s_c, *rm, rf[l]);
+        }
+        load_resid();
+#pragma unroll
+        for (int l = 0; l < 2; l++) {
+            if (!use[l]) continue;                                  // (the same CU in all four waves: every wave takes the same turns)
+            const int mvx = mvs[l][0], mvy = mvs[l][1], px = (wx << 2) + mvt[l][0], py = (wy << 2) + mvt[l][1];
+            const int ldx = (mvx & 3) != 0, ldy = (mvy & 3) != 0, cdx = (mvx & 7) != 0, cdy = (mvy & 7) != 0;
+            uint32_t o[8], ou[2], ov[2];
+            if (nl) __syncthreads();                                // the waves are done with the first list's windows
+            region_store(rf[l], *rm, W);
+            __syncthreads();
+            {
+                const uint4 th = s_ltap[ldx ? ((px & 3) << 2) : 16], tv = s_ltap[ldy ? ((py & 3) << 2) : 16];
+                const uint32_t ch[4] = { th.x, th.y, th.z, th.w }, cv[4] = { tv.x, tv.y, tv.z, tv.w };
+                const Regime rg = regime(ldx, ldy, a.bd_l);
+                if (ldx) { if (ldy) luma_tile_filter<true, true, REG_W_STRIDE>(Wy, ch, cv, rg, maxl, I, lane, o); else luma_tile_filter<true, false, REG_W_STRIDE>(Wy, ch, cv, rg, maxl, I, lane, o); }
+                else     { if (ldy) luma_tile_filter<false, true, REG_W_STRIDE>(Wy, ch, cv, rg, maxl, I, lane, o); else luma_tile_filter<false, false, REG_W_STRIDE>(Wy, ch, cv, rg, maxl, I, lane, o); }
+            }
+            {
+                const uint2 th = s_ctap[cdx ? ((px & 7) << 2) : 32], tv = s_ctap[cdy ? ((py & 7) << 2) : 32];
+                const uint32_t c2h[2] = { th.x, th.y }, c2v[2] = { tv.x, tv.y };
+                const Regime rg = regime(cdx, cdy, a.bd_c);
+                if (cdx) { if (cdy) chroma_tile_filter<true, true, REG_C_STRIDE>(Wu, Wv, c2h, c2v, rg, maxc, I, lane, ou, ov); else chroma_tile_filter<true, false, REG_C_STRIDE>(Wu, Wv, c2h, c2v, rg, maxc, I, lane, ou, ov); }
+                else     { if (cdy) chroma_tile_filter<false, true, REG_C_STRIDE>(Wu, Wv, c2h, c2v, rg, maxc, I, lane, ou, ov); else chroma_tile_filter<false, false, REG_C_STRIDE>(Wu, Wv, c2h, c2v, rg, maxc, I, lane, ou, ov); }
+            }
+            if (nl == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; k++) pl[k] = o[k];
+                pu[0] = ou[0]; pu[1] = ou[1]; pv[0] = ov[0]; pv[1] = ov[1];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; k++) pl[k] = avg2(pl[k], o[k]);
+                pu[0] = avg2(pu[0], ou[0]); pu[1] = avg2(pu[1], ou[1]);
+                pv[0] = avg2(pv[0], ov[0]); pv[1] = avg2(pv[1], ov[1]);
+            }
+            nl++;
+        }
+    } else if (UNI) {
         int16_t *I = W + UNI_W_SAMPLES;
         const int wx = __builtin_amdgcn_readfirstlane(x), wy = __builtin_amdgcn_readfirstlane(y);
         TileFetch tf[2];
@@ -435,7 +551,9 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     __shared__ uint4    s_ref[XGPU_MAX_REFS * 2][2];        // RefEntry [idx][list]
     __shared__ uint4    s_ltap[17];                         // luma taps of this sequence's table, [16] = identity
     __shared__ uint2    s_ctap[33];
-    __shared__ __attribute__((aligned(16))) int16_t s_tile[4][UNI_SAMPLES];      // per wave: window + intermediate of the tile path
+    static_assert(REG_SAMPLES >= 4 * UNI_SAMPLES, "the shared region block holds the four waves' own blocks");
+    __shared__ __attribute__((aligned(16))) int16_t s_tile[REG_SAMPLES];          // per wave: window + intermediate of the tile path; or the region's shared windows + four intermediates
+    __shared__ uint32_t s_own[4];                               // the CU every wave's tile lies in (OWNER_NONE: several): all four the same -> the region path
     // XCD-aware mapping: workgroup b runs on XCD b % 8 and every XCD has its own L2.  The regions are ordered in vertical strips INTER_STRIP wide
     // (row-major inside a strip) and every XCD takes a contiguous eighth of that order - about one strip: the ~100 workgroups it has in flight
     // form a compact patch whose vertical halos are still in its L2 when the row below is processed, and all XCDs get the same number of regions.
@@ -473,9 +591,12 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     if (t < XGPU_MAX_REFS * 4) s_ref[t >> 1][t & 1] = tab;
     else if (t >= 96 && t < 96 + 17) s_ltap[t - 96] = tab;
     else if (t >= 128 && t < 128 + 33) s_ctap[t - 128] = make_uint2(tab.x, tab.y);
+    const bool uni = __ballot(ok) == ~0ull && __ballot(own == __builtin_amdgcn_readfirstlane(own)) == ~0ull;
+    if (lane == 0) s_own[t >> 6] = uni ? own : OWNER_NONE;
     __syncthreads();
+    const bool region = !a.no_region && s_own[0] != OWNER_NONE && s_own[0] == s_own[1] && s_own[0] == s_own[2] && s_own[0] == s_own[3];
 
-    int16_t *W = s_tile[t >> 6];
+    int16_t *W = s_tile + (t >> 6) * UNI_SAMPLES;
     LaneMap fm;
     {
         const int row0 = (lane * 205) >> 10, k = lane - row0 * 5;         // luma window: 12 rows x 5 chunks of 8 samples per pass (lanes 60..63 idle)
@@ -483,12 +604,8 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
         const int cr = (lane * 171) >> 9, ck = lane - cr * 3;              // chroma windows: 19 rows x 3 chunks of 8 samples per plane (lanes 57..63 idle)
         fm.gc = cr * a.s_c + 8 * ck; fm.lc = cr * UC_STRIDE + 8 * ck;
     }
-    const bool uni = __ballot(ok) == ~0ull && __ballot(own == __builtin_amdgcn_readfirstlane(own)) == ~0ull;
-    uint32_t pl[8], pu[2], pv[2];
-    bool st;
-    if (uni) st = inter_tile<true>(a, c0, c1, true, sx, sy, lane, W, fm, s_ref, s_ltap, s_ctap, pl, pu, pv);
-    else     st = inter_tile<false>(a, c0, c1, ok, sx, sy, lane, W, fm, s_ref, s_ltap, s_ctap, pl, pu, pv);
-    if (st) {
+    // every path stores on its own and leaves (one common tail would make the register allocator keep the three paths' results in the same registers)
+    auto store_tile = [&](const uint32_t pl[8], const uint32_t pu[2], const uint32_t pv[2]) {
         const int x = sx << 2, y = sy << 2;
         int16_t *dy = a.cur_y + y * a.s_l + x;
 #pragma unroll
@@ -498,7 +615,20 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
         *(uint32_t *)(a.cur_u + coff + a.s_c) = pu[1];
         *(uint32_t *)(a.cur_v + coff) = pv[0];
         *(uint32_t *)(a.cur_v + coff + a.s_c) = pv[1];
+    };
+    if (region) {
+        uint32_t pl[8], pu[2], pv[2];
+        const RegionMap rmap = region_map(t);
+        if (inter_tile<2>(a, c0, c1, true, sx, sy, lane, s_tile, fm, s_ref, s_ltap, s_ctap, pl, pu, pv, &rmap, t >> 6)) store_tile(pl, pu, pv);
+        return;
     }
+    if (uni) {
+        uint32_t pl[8], pu[2], pv[2];
+        if (inter_tile<1>(a, c0, c1, true, sx, sy, lane, W, fm, s_ref, s_ltap, s_ctap, pl, pu, pv)) store_tile(pl, pu, pv);
+        return;
+    }
+    uint32_t pl[8], pu[2], pv[2];
+    if (inter_tile<0>(a, c0, c1, ok, sx, sy, lane, W, fm, s_ref, s_ltap, s_ctap, pl, pu, pv)) store_tile(pl, pu, pv);
 }
 
 void launch_inter(xgpu_ctx *c, const InterArgs &a)

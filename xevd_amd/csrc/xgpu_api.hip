@@ -1420,6 +1420,7 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
     const int strip_knob = getenv("XEVD_HIP_INTER_STRIP") ? atoi(getenv("XEVD_HIP_INTER_STRIP")) : 0;      // measurement knob
     a.strip = strip_knob > 0 ? strip_knob : 16;
     a.order = getenv("XEVD_HIP_INTER_ORDER") ? atoi(getenv("XEVD_HIP_INTER_ORDER")) : 0;
+    a.no_region = getenv("XEVD_HIP_INTER_NO_REGION") != NULL;
     a.cus = db->d_cus; a.resid = db->d_resid;
     a.maps = c->d_maps; a.w_scu = c->w_scu; a.owner = db->d_owner; a.n_cu = db->n_cu; a.cur_poc = c->fp.poc;
     for (int l = 0; l < 2; l++)

@@ -101,6 +101,7 @@ struct InterArgs {
     int      n_cu;
     int      cur_poc;                  // POC of the picture being decoded (DMVR's distance test)
     int      dmvr_to_map;              // k_dmvr writes its refined vectors into the map records (DmvrArgs.refined_to_map): k_inter leaves those words alone
+    int      no_region;                // 1: no workgroup-shared windows for 64x64 regions inside one CU (measurement knob XEVD_HIP_INTER_NO_REGION)
     int      order;                    // 0: vertical strips, row by row inside a strip; 1: horizontal bands, column by column (measurement knob)
     int      strip;                    // width of the vertical strips of the region order, in 64x64 regions (k_inter.hip)
     RefEntry refp[XGPU_MAX_REFS][2];
