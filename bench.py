@@ -327,10 +327,10 @@ def reference_decoder_leg(wl, budget_s=60.0):
         open(p_one, "wb").write(one)
         open(p_all, "wb").write(data)
         ok = True
-        shapes = (("one_stream_pipelined", ["--workers", "1", "--tile-threads", str(min(16, quota)), "--build-threads", "4"]),
-                  ("one_stream_back_to_back", ["--workers", "1", "--tile-threads", str(min(16, quota)), "--build-threads", "4", "--no-pipeline"]),
-                  ("gop_parallel_2x8", ["--workers", "2", "--tile-threads", str(max(1, min(8, quota // 2))), "--build-threads", "2"]),
-                  ("gop_parallel_4x4", ["--workers", "4", "--tile-threads", str(max(1, min(4, quota // 4))), "--build-threads", "1"]))
+        shapes = (("one_stream_pipelined", ["--workers", "1", "--tile-threads", str(min(16, quota)), "--build-threads", "8"]),
+                  ("one_stream_back_to_back", ["--workers", "1", "--tile-threads", str(min(16, quota)), "--build-threads", "8", "--no-pipeline"]),
+                  ("gop_parallel_2x8", ["--workers", "2", "--tile-threads", str(max(1, min(8, quota // 2))), "--build-threads", "4"]),
+                  ("gop_parallel_4x4", ["--workers", "4", "--tile-threads", str(max(1, min(4, quota // 4))), "--build-threads", "2"]))
         for name, args in shapes:
             dst = os.path.join(td, "ours.yuv")
             rep = run_evc_decode(args + ["--keep-units", str(keep), p_all, dst])
@@ -339,7 +339,7 @@ def reference_decoder_leg(wl, budget_s=60.0):
                 ok = False
                 continue
             gpu[name] = {"decode_only_fps": rep["fps_decode_only"], "parse_ms_per_picture": rep["parse_ms_per_picture"], "batch_build_ms_per_picture": rep["build_ms_per_picture"],
-                         "host_threads": rep["workers_per_device"] * (rep["tile_threads"] + 2), "cpu_seconds_per_picture": round((rep["cpu_user_s"] + rep["cpu_sys_s"]) / max(rep["pictures"], 1), 4)}
+                         "host_threads": rep["workers_per_device"] * (rep["tile_threads"] + rep["build_threads"] + 1), "cpu_seconds_per_picture": round((rep["cpu_user_s"] + rep["cpu_sys_s"]) / max(rep["pictures"], 1), 4)}
             if bd > 8:          # 16-bit samples like the reference driver's output
                 gpu[name]["periods"] = file_md5s(dst, period_bytes, keep)
         for threads in (1, 8):

@@ -689,12 +689,19 @@ struct TileCoder {
                 for (int l = 0; l < 2; l++) { pic.mv_ref[k * 4 + l * 2] = v[l][0]; pic.mv_ref[k * 4 + l * 2 + 1] = v[l][1]; }
             }
         }
-        for (int r = 0; r < h; r++) for (int c = 0; c < w; c++) {
-            const size_t k = (size_t)(ys + r) * pic.w_scu + xs + c;
-            pic.cod[k] = 1; pic.intra[k] = cu.mode == MODE_INTRA; pic.ibc[k] = cu.mode == MODE_IBC; pic.ipm[k] = (int8_t)cu.ipm;
-            if (!pic.skip.empty()) pic.skip[k] = cu.mode == MODE_SKIP;
-            if (!pic.cu_size.empty()) pic.cu_size[k] = (uint8_t)(cu.log2w | (cu.log2h << 4));
-            for (int l = 0; l < 2; l++) { pic.refi[k * 2 + l] = (int8_t)cu.refi[l]; pic.mv[k * 4 + l * 2] = cu.mv[l][0]; pic.mv[k * 4 + l * 2 + 1] = cu.mv[l][1]; }
+        {   // the CU's rows of the SCU maps, row by row as fills (a 64x64 CU is 256 SCUs x 6 maps: element-wise stores were a tenth of the parse time)
+            const int8_t rf[2] = { (int8_t)cu.refi[0], (int8_t)cu.refi[1] };
+            const int16_t mvq[4] = { cu.mv[0][0], cu.mv[0][1], cu.mv[1][0], cu.mv[1][1] };
+            const uint8_t is_intra = cu.mode == MODE_INTRA, is_ibc = cu.mode == MODE_IBC, is_skip = cu.mode == MODE_SKIP, size = (uint8_t)(cu.log2w | (cu.log2h << 4));
+            for (int r = 0; r < h; r++) {
+                const size_t k = (size_t)(ys + r) * pic.w_scu + xs;
+                memset(&pic.cod[k], 1, (size_t)w); memset(&pic.intra[k], is_intra, (size_t)w); memset(&pic.ibc[k], is_ibc, (size_t)w); memset(&pic.ipm[k], (int8_t)cu.ipm, (size_t)w);
+                if (!pic.skip.empty()) memset(&pic.skip[k], is_skip, (size_t)w);
+                if (!pic.cu_size.empty()) memset(&pic.cu_size[k], size, (size_t)w);
+                int8_t *rp = &pic.refi[k * 2];
+                int16_t *mp = &pic.mv[k * 4];
+                for (int c = 0; c < w; c++) { memcpy(rp + 2 * c, rf, 2); memcpy(mp + 4 * c, mvq, 8); }
+            }
         }
         if (cu.affine && cu.mode != MODE_INTRA && cu.mode != MODE_IBC) aff_store(cu);
     }
