@@ -215,6 +215,7 @@ _EXPORTS = {
     "xgpu_test_mc_l": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p] + [C.c_int] * 3),
     "xgpu_test_mc_c": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 8 + [C.c_void_p] + [C.c_int] * 3),
     "xgpu_test_batch_resid": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "xgpu_test_build_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_int), C.POINTER(C.c_double)]),
     "xgpu_test_recon": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 4 + [C.c_void_p, C.c_int]),
     "xgpu_test_dbk": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 7),
     "xgpu_test_dbk_chroma": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p] + [C.c_int] * 8),
