@@ -57,6 +57,7 @@ typedef struct {
     void *coef; rb_vec coef_v;
     int any_affine, any_dmvr, any_ats, any_ats_inter, any_tree;
     int failed;
+    int n_ctu, pic_inter;         /* CTUs of the picture in the batch so far (several slices: one fn_dec_slice call each); a P / B slice among them */
     xgpu_tile_grid grid;
 } rb_state;
 
@@ -256,17 +257,23 @@ static int hip_dec_slice(XEVD_CTX *ctx, XEVD_CORE *core)
     int ret, l, i, cx, cy;
     XEVD_BSR bs0;
     XEVD_SBAC sbac0;
-    int t, n_ctu = 0;
-    /* one slice per picture with all of its tiles in raster order (what set_tile_info derives for first_tile_id 0 / last_tile_id count - 1) */
-    if (ctx->num_tiles_in_slice != ctx->w_tile * ctx->h_tile || ctx->sh.arbitrary_slice_flag || ctx->sps->chroma_format_idc != 1) return XEVD_ERR_UNSUPPORTED;
-    for (t = 0; t < ctx->num_tiles_in_slice; t++) if (ctx->tile_in_slice[t] != t) return XEVD_ERR_UNSUPPORTED;
+    int t;
+    /* A picture may come as several slices - one call each, every slice with its own tiles (ctx->tile_in_slice, set_tile_info xevdm.c:2185-2236): the CUs of all
+       of them are gathered into ONE batch, which is launched when the last CTU of the picture has been parsed (ctx->num_ctb == 0, the test xevd_dec_nalu itself
+       makes before it runs the in-loop filters, :3139) - with that last slice's header for everything picture-level, as the reference decoder filters */
+    const int first_slice = ctx->num_ctb == (u32)ctx->f_lcu;
+    if (ctx->sps->chroma_format_idc != 1) return XEVD_ERR_UNSUPPORTED;
     /* DMVR + HMVP: xevdm_set_dec_info leaves the refined vector of the first sub-block in core->mv (xevdm_util.c:4384-4387), which the history buffer then
        takes (xevdm.c:1335-1342) - the next CUs' candidates would need the refinement result before the batch has run */
     if (ctx->sps->tool_dmvr && (ctx->sps->tool_hmvp || ctx->sps->tool_mmvd)) return XEVD_ERR_UNSUPPORTED;
     if (!s->g && (ret = hip_open(ctx)) < 0) return ret;
 
-    s->n_cu = 0; s->coef_v.n = 0; s->any_affine = s->any_dmvr = s->any_ats = s->any_ats_inter = s->any_tree = 0; s->failed = 0; s->deblocked = 0;
-    s->ctu_start = realloc(s->ctu_start, sizeof(uint32_t) * (size_t)(ctx->f_lcu + 1));
+    if (first_slice) {
+        s->n_cu = 0; s->coef_v.n = 0; s->any_affine = s->any_dmvr = s->any_ats = s->any_ats_inter = s->any_tree = 0; s->failed = 0; s->deblocked = 0;
+        s->n_ctu = 0; s->pic_inter = 0;
+        s->ctu_start = realloc(s->ctu_start, sizeof(uint32_t) * (size_t)(ctx->f_lcu + 1));
+    }
+    if (ctx->sh.slice_type != SLICE_I) s->pic_inter = 1;
     ctx->sh.qp_prev_eco = ctx->sh.qp;
     xevd_mcpy(&bs0, &ctx->bs, sizeof(XEVD_BSR));                        /* the reader right behind the slice header: where the first tile starts */
     xevd_mcpy(&sbac0, GET_SBAC_DEC(&ctx->bs), sizeof(XEVD_SBAC));
@@ -274,9 +281,10 @@ static int hip_dec_slice(XEVD_CTX *ctx, XEVD_CORE *core)
         /* entropy decoding of one tile, as xevdm_dec_slice sets its worker up (xevdm.c:2640-2680): own reader + arithmetic decoder at the tile's
            entry point - the sum of the slice header's entry_point_offset_minus1 + 1 of the tiles before it, in bytes from the first tile */
         int x0, x1, y1;
+        const int tile_idx = ctx->tile_in_slice[t];
         xevd_mcpy(cm, core, sizeof(XEVD_CORE));
-        cm->ctx = ctx; cm->bs = &ctx->bs_mt[0]; cm->sbac = &ctx->sbac_dec_mt[0]; cm->tile_num = t; cm->thread_idx = 0;
-        tile = &ctx->tile[t];
+        cm->ctx = ctx; cm->bs = &ctx->bs_mt[0]; cm->sbac = &ctx->sbac_dec_mt[0]; cm->tile_num = tile_idx; cm->thread_idx = 0;
+        tile = &ctx->tile[tile_idx];
         tile->qp_prev_eco = ctx->sh.qp; tile->qp = ctx->sh.qp;
         xevd_mcpy(cm->bs, &bs0, sizeof(XEVD_BSR));
         xevd_mcpy(cm->sbac, &sbac0, sizeof(XEVD_SBAC));
@@ -298,15 +306,18 @@ static int hip_dec_slice(XEVD_CTX *ctx, XEVD_CORE *core)
             cm->x_lcu = cx; cm->y_lcu = cy; cm->lcu_num = cy * ctx->w_lcu + cx;
             cm->x_pel = cx << ctx->log2_max_cuwh; cm->y_pel = cy << ctx->log2_max_cuwh;
             if (ctx->sps->tool_hmvp && cx == x0 && xevdm_hmvp_init(cm) != XEVD_OK) return XEVD_ERR;      /* xevdm.c:2499-2503 */
-            s->ctu_start[n_ctu++] = (uint32_t)s->n_cu;
+            if (s->n_ctu >= (int)ctx->f_lcu) return XEVD_ERR_MALFORMED_BITSTREAM;
+            s->ctu_start[s->n_ctu++] = (uint32_t)s->n_cu;
             hip_recon_tree(ctx, cm, cm->x_pel, cm->y_pel, ctx->max_cuwh, ctx->max_cuwh, 0, 0, (TREE_CONS_NEW) { TREE_LC, eAll });
             if (s->failed) return XEVD_ERR_UNSUPPORTED;
         }
         ctx->num_ctb -= tile->w_ctb * tile->h_ctb;                    /* xevdm.c:2693-2697 */
     }
-    s->ctu_start[ctx->f_lcu] = (uint32_t)s->n_cu;
     xevd_mcpy(&ctx->bs, cm->bs, sizeof(XEVD_BSR));                      /* :2707-2711 */
     xevd_mcpy(&ctx->sbac_dec, cm->sbac, sizeof(XEVD_SBAC));
+    if (ctx->num_ctb > 0) return XEVD_OK;                              /* further slices of this picture follow */
+    if (s->n_ctu != (int)ctx->f_lcu) return XEVD_ERR_MALFORMED_BITSTREAM;
+    s->ctu_start[ctx->f_lcu] = (uint32_t)s->n_cu;
 
     memset(&b, 0, sizeof(b));
     b.n_cu = s->n_cu; b.x = s->x; b.y = s->y; b.log2w = s->log2w; b.log2h = s->log2h; b.pred_mode = s->pred_mode; b.refi = s->refi; b.mv = s->mv;
@@ -324,7 +335,7 @@ static int hip_dec_slice(XEVD_CTX *ctx, XEVD_CORE *core)
     memset(&fp, 0, sizeof(fp));
     fp.pic = rb_slot(s, ctx->pic); fp.poc = ctx->poc.poc_val;
     for (l = 0; l < 2; l++) {
-        fp.num_refp[l] = ctx->sh.slice_type == SLICE_I ? 0 : mctx->dpm.num_refp[l];
+        fp.num_refp[l] = s->pic_inter ? mctx->dpm.num_refp[l] : 0;      /* (an I slice leaves the lists of the picture's P / B slices alone) */
         for (i = 0; i < fp.num_refp[l]; i++) { fp.refp_pic[i][l] = rb_slot(s, ctx->refp[i][l].pic); fp.refp_poc[i][l] = ctx->refp[i][l].poc; }
     }
     fp.qp_u_offset = ctx->sh.qp_u_offset; fp.qp_v_offset = ctx->sh.qp_v_offset;

@@ -488,10 +488,8 @@ REF_DECODE_HIP = os.path.normpath(os.path.join(golden_io.GOLDEN, "..", "..", "or
 # behind the picture-granular slots (fn_dec_slice ...) reconstructs after the picture is parsed - our own front end runs the refinement search itself for those
 # (xevd_amd/host/dmvr_search.h); they are decoded by every other path below
 HOST_DMVR_STREAMS = {"main_dmvr_hmvp_mmvd_b_8b", "main_every_tool_10b", "main_every_tool_tiles_8b"}
-# ... and not the streams with several slices per picture: oracle/ref_binding.c's fn_dec_slice stand-in builds and launches one batch per call (one slice = one picture)
-MULTI_SLICE_STREAMS = {"main_slices_4rows_all_tools_10b", "main_slices_columns_arbitrary_8b"}
 STREAM_NAMES = sorted(f[len("stream_"):-len(".npz")] for f in os.listdir(golden_io.GOLDEN)
-                      if f.startswith("stream_") and f.endswith(".npz") and "main_" in f and f[len("stream_"):-len(".npz")] not in HOST_DMVR_STREAMS | MULTI_SLICE_STREAMS)
+                      if f.startswith("stream_") and f.endswith(".npz") and "main_" in f and f[len("stream_"):-len(".npz")] not in HOST_DMVR_STREAMS)
 
 
 @pytest.mark.gpu
