@@ -4,6 +4,8 @@
 //   ./fuzz <mutations per stream> <parser threads> a.evc b.evc ...             (golden streams: np.load(tests/golden/stream_*.npz)["bytes"])
 // Round 2: 8250 mutations of the 55 golden streams under ASan + UBSan and the tiled ones under TSan with 4 threads - clean after the tile test was moved in
 // front of every neighbour read (another tile's maps may be written at that moment).
+// Round 4 (persistent parser + rebind, windowed bit reader, coefficients decoded in place, pooled tile threads): 120 mutations of each of the 51 golden streams under ASan + UBSan,
+// 40 of each tiled one under TSan with 4 threads - see DESIGN 5b.
 // Repeated after BTT and the local dual tree went in: 1200 + 1200 mutations of their six golden streams (ASan + UBSan), 300 of the tiled ones under TSan with 4 threads - clean.
 #include "../../include/xevd_host.h"
 #include <cstdio>
@@ -17,6 +19,10 @@ int main(int argc, char **argv)
 {
     int iters = atoi(argv[1]), threads = atoi(argv[2]);
     long pics = 0, errs = 0;
+    // round 4: ONE parser object for the whole run, rebound to every mutated stream (xhost_parser_rebind: what a work-queue worker does from GOP to GOP) - a parser that
+    // has just failed in the middle of a picture, or decoded a stream of another geometry / tool set, must behave like a new one; every fourth stream a new parser
+    xhost_parser *p = nullptr;
+    long n_streams = 0;
     for (int f = 3; f < argc; f++) {
         FILE *fp = fopen(argv[f], "rb"); if (!fp) continue;
         std::vector<uint8_t> d; uint8_t buf[65536]; size_t n;
@@ -32,8 +38,9 @@ int main(int argc, char **argv)
                 else if (kind == 2) { m.resize(pos + 1); break; }
                 else { const size_t len = 1 + rnd() % 8; for (size_t q = pos; q < pos + len && q < m.size(); q++) m[q] = (uint8_t)rnd(); }
             }
-            xhost_parser *p = xhost_parser_open(m.data(), m.size());
-            if (threads > 1) xhost_parser_set_threads(p, threads);
+            if (p && (n_streams++ & 3) == 3) { xhost_parser_close(p); p = nullptr; }
+            if (p) { if (xhost_parser_rebind(p, m.data(), m.size()) < 0) return 1; }
+            else { p = xhost_parser_open(m.data(), m.size()); if (threads > 1) xhost_parser_set_threads(p, threads); }
             xhost_picture pic;
             for (;;) {
                 const int rc = xhost_parser_next(p, &pic);
@@ -42,9 +49,9 @@ int main(int argc, char **argv)
                 pics++;
                 if (pic.n_dmvr_sub) { std::vector<int16_t> mv((size_t)pic.n_dmvr_sub * 4, 0); xhost_parser_set_dmvr_mvs(p, mv.data(), pic.n_dmvr_sub); }
             }
-            xhost_parser_close(p);
         }
     }
+    if (p) xhost_parser_close(p);
     printf("pictures %ld, failed streams %ld\n", pics, errs);
     return 0;
 }
