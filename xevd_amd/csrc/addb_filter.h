@@ -148,3 +148,100 @@ __device__ __forceinline__ void addb_edge(const AddbArgs &a, const uint4 rq, con
     const int bs = addb_edge_strength<DIR>(a, a.no_filter, rq, rp, eq, s_pic);
     if (bs) addb_edge_filter<DIR>(a, rq, rp, bs, L, Cc, s_alpha, s_beta, s_clip, s_cqp);
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------------------------
+// Two lines of an edge segment at once (round 4): the same filters on PACKED pairs - the low half of every dword belongs to one line of the segment, the high half
+// to the next - with v_pk_* arithmetic; every condition is a 0 / 0xFFFF mask per half and every "if" a v_bfi select between the variants (a wave whose lanes take
+// different branches executes all of them in the scalar form too).  k_addb_alf is bound by VALU issue and the scalar line filters were a third of its
+// instructions.  Exact for bit depths up to 10: the largest intermediate, 3 (p2 + p0 + q0) - 8 p1 - q1, stays inside s16 (9 x 1023); deeper pictures take the
+// scalar form.  s[] as above: p3 p2 p1 p0 q0 q1 q2 q3.
+typedef short pk_s __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pk_s pks(uint32_t x) { return __builtin_bit_cast(pk_s, x); }
+__device__ __forceinline__ uint32_t pku(pk_s x) { return __builtin_bit_cast(uint32_t, x); }
+__device__ __forceinline__ uint32_t pk_rep(int v) { return ((uint32_t)v & 0xFFFFu) * 0x00010001u; }
+__device__ __forceinline__ pk_s pk_abs(pk_s x) { return __builtin_elementwise_max(x, (pk_s){0, 0} - x); }
+__device__ __forceinline__ uint32_t pk_lt(pk_s x, pk_s thr) { return pku((x - thr) >> (pk_s){15, 15}); }      // 0xFFFF where x < thr (no overflow at these ranges)
+__device__ __forceinline__ uint32_t pk_sel(uint32_t m, uint32_t a, uint32_t b) { return (a & m) | (b & ~m); }  // -> v_bfi_b32
+__device__ __forceinline__ pk_s pk_clip(pk_s lo, pk_s hi, pk_s v) { return __builtin_elementwise_min(__builtin_elementwise_max(v, lo), hi); }
+
+__device__ __forceinline__ void addb_line_luma_pk(uint32_t s[8], int bs, int alpha, int beta, int c1, int bd, int maxv)
+{
+    const pk_s p3 = pks(s[0]), p2 = pks(s[1]), p1 = pks(s[2]), p0 = pks(s[3]), q0 = pks(s[4]), q1 = pks(s[5]), q2 = pks(s[6]), q3 = pks(s[7]);
+    const pk_s A = pks(pk_rep(alpha)), B = pks(pk_rep(beta)), Z = { 0, 0 }, MX = pks(pk_rep(maxv));
+    const pk_s dpq = pk_abs(p0 - q0);
+    const uint32_t on = pk_lt(dpq, A) & pk_lt(pk_abs(p1 - p0), B) & pk_lt(pk_abs(q1 - q0), B);      // (bs != 0: the caller's)
+    if (!on) return;
+    const uint32_t ap = pk_lt(pk_abs(p0 - p2), B), aq = pk_lt(pk_abs(q0 - q2), B);
+    pk_s po0, po1 = p1, po2 = p2, qo0, qo1 = q1, qo2 = q2;
+    if (bs == 4) {
+        const uint32_t strong = pk_lt(dpq, pks(pk_rep((alpha >> 2) + 2)));
+        const pk_s two = { 2, 2 }, four = { 4, 4 }, sh2 = { 2, 2 }, sh3 = { 3, 3 };
+        const pk_s mid = p0 + q0, pw0 = (2 * p1 + p0 + q1 + two) >> sh2, qw0 = (2 * q1 + q0 + p1 + two) >> sh2;
+        const pk_s ps0 = (p2 + 2 * (p1 + mid) + q1 + four) >> sh3, ps1 = (p2 + p1 + mid + two) >> sh2, ps2 = (2 * p3 + 3 * p2 + p1 + mid + four) >> sh3;
+        const pk_s qs0 = (q2 + 2 * (q1 + mid) + p1 + four) >> sh3, qs1 = (q2 + q1 + mid + two) >> sh2, qs2 = (2 * q3 + 3 * q2 + q1 + mid + four) >> sh3;
+        const uint32_t mp = ap & strong, mq = aq & strong;
+        po0 = pks(pk_sel(mp, pku(ps0), pku(pw0))); po1 = pks(pk_sel(mp, pku(ps1), pku(p1))); po2 = pks(pk_sel(mp, pku(ps2), pku(p2)));
+        qo0 = pks(pk_sel(mq, pku(qs0), pku(qw0))); qo1 = pks(pk_sel(mq, pku(qs1), pku(q1))); qo2 = pks(pk_sel(mq, pku(qs2), pku(q2)));
+    } else {
+        const int sh = max(0, bd - 9);
+        const pk_s C1 = pks(pk_rep(c1));
+        const pk_s c0 = pks((pku(C1) + ((((ap & 0x00010001u) + (aq & 0x00010001u))) << sh)) & 0x00FF00FFu);          // u8 c0, xevdm_df.c:650
+        const pk_s d0 = pk_clip(Z - c0, c0, (4 * (q0 - p0) + p1 - q1 + (pk_s){4, 4}) >> (pk_s){3, 3});
+        po0 = pk_clip(Z, MX, p0 + d0);
+        qo0 = pk_clip(Z, MX, q0 - d0);
+        const pk_s dp = pk_clip(Z - C1, C1, ((p2 + p0 + q0) * (pk_s){3, 3} - 8 * p1 - q1) >> (pk_s){4, 4});
+        const pk_s dq = pk_clip(Z - C1, C1, ((q2 + q0 + p0) * (pk_s){3, 3} - 8 * q1 - p1) >> (pk_s){4, 4});
+        po1 = pks(pk_sel(ap, pku(p1 + dp), pku(p1)));
+        qo1 = pks(pk_sel(aq, pku(q1 + dq), pku(q1)));
+    }
+    s[3] = pk_sel(on, pku(pk_clip(Z, MX, po0)), s[3]); s[2] = pk_sel(on, pku(pk_clip(Z, MX, po1)), s[2]); s[1] = pk_sel(on, pku(pk_clip(Z, MX, po2)), s[1]);
+    s[4] = pk_sel(on, pku(pk_clip(Z, MX, qo0)), s[4]); s[5] = pk_sel(on, pku(pk_clip(Z, MX, qo1)), s[5]); s[6] = pk_sel(on, pku(pk_clip(Z, MX, qo2)), s[6]);
+}
+// chroma, two lines: s = p1 p0 q0 q1
+__device__ __forceinline__ void addb_line_chroma_pk(uint32_t s[4], int bs, int alpha, int beta, int c0v, int maxv)
+{
+    const pk_s p1 = pks(s[0]), p0 = pks(s[1]), q0 = pks(s[2]), q1 = pks(s[3]);
+    const pk_s A = pks(pk_rep(alpha)), B = pks(pk_rep(beta)), Z = { 0, 0 }, MX = pks(pk_rep(maxv));
+    const uint32_t on = pk_lt(pk_abs(p0 - q0), A) & pk_lt(pk_abs(p1 - p0), B) & pk_lt(pk_abs(q1 - q0), B);
+    if (!on) return;
+    pk_s po, qo;
+    if (bs == 4) {
+        po = pk_clip(Z, MX, (2 * p1 + p0 + q1 + (pk_s){2, 2}) >> (pk_s){2, 2});
+        qo = pk_clip(Z, MX, (2 * q1 + q0 + p1 + (pk_s){2, 2}) >> (pk_s){2, 2});
+    } else {
+        const pk_s C0 = pks(pk_rep(c0v));
+        const pk_s d0 = pk_clip(Z - C0, C0, (4 * (q0 - p0) + p1 - q1 + (pk_s){4, 4}) >> (pk_s){3, 3});
+        po = pk_clip(Z, MX, p0 + d0);
+        qo = pk_clip(Z, MX, q0 - d0);
+    }
+    s[1] = pk_sel(on, pku(po), s[1]); s[2] = pk_sel(on, pku(qo), s[2]);
+}
+// filter half of an edge segment on packed line pairs: LP[0] = lines 0 / 1, LP[1] = lines 2 / 3 of the luma segment (8 positions across the edge each),
+// CP[plane] = the two chroma lines (4 positions).  bs > 0, bit depths <= 10.
+template <int DIR>
+__device__ __forceinline__ void addb_edge_filter_pk(const AddbArgs &a, const uint4 rq, const uint4 rp, int bs, uint32_t LP[2][8], uint32_t CP[2][4],
+                                                    const uint8_t *s_alpha, const uint8_t *s_beta, const uint8_t *s_clip, const int8_t *s_cqp)
+{
+    const uint32_t nflag = DIR == 0 ? SCU_NOCH_L : SCU_NOCH_T;
+    const int maxl = (1 << a.bd_l) - 1, maxc = (1 << a.bd_c) - 1;
+    const int qp = (((rq.x >> 16) & 0x7F) + ((rp.x >> 16) & 0x7F) + 1) >> 1;
+    const int scale = a.bd_l - 8;
+    {
+        const int ia = addb_index(qp, a.alpha_off), ib = addb_index(qp, a.beta_off);
+        const int alpha = s_alpha[ia] << scale, beta = (s_beta[ib] << scale) & 0xFF;
+        const int c1 = (s_clip[ia * 5 + bs] << max(0, a.bd_l - 9)) & 0xFF;
+        addb_line_luma_pk(LP[0], bs, alpha, beta, c1, a.bd_l, maxl);
+        addb_line_luma_pk(LP[1], bs, alpha, beta, c1, a.bd_l, maxl);
+    }
+    const int boff = 6 * (a.bd_c - 8);
+    if (!(rq.x & nflag))
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++) {
+        const int q = clip3a(-boff, 57, qp + (pl ? a.qp_v_off : a.qp_u_off));
+        const int qc = s_cqp[pl * 96 + q + boff];
+        const int ia = addb_index(qc, a.alpha_off), ib = addb_index(qc, a.beta_off);
+        const int alpha = s_alpha[ia] << scale, beta = (s_beta[ib] << scale) & 0xFF;
+        const int c0 = ((s_clip[ia * 5 + bs] + 1) << max(0, a.bd_c - 9)) & 0xFF;
+        addb_line_chroma_pk(CP[pl], bs, alpha, beta, c0, maxc);
+    }
+}

@@ -129,7 +129,8 @@ __device__ __forceinline__ void lap_pair(const uint32_t up[3], const uint32_t mi
 // ALF then reads.  The deblocked picture never goes to memory (k_addb_fused writes 100 MB that k_alf reads back: 433 MB of traffic for the two become 270 MB); the
 // price is 27 % more deblocking arithmetic (72^2 / 64^2: the halo is filtered by both neighbours).  LDS layout: window row r at row r + RO, luma column c at c + 4,
 // chroma column c at c + CO.
-template <bool FUSED>
+// PK (fused form): the deblocking line filters on packed pairs of lines (addb_filter.h; bit depths up to 10)
+template <bool FUSED, bool PK = false>
 __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
                                            const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_,
                                            int16_t *__restrict__ dv_)
@@ -265,6 +266,40 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
         for (int i = t; i < (int)s_cnt[0]; i += 256) {
             const int e = s_list[0][i], seg = e & 255, bs = e >> 8, wx = seg % 9, sr = seg / 9;
             const uint4 rp = s_map[sr][2 * wx], rq = s_map[sr][2 * wx + 1];
+            if (PK) {
+                // lines = rows here: the pairs (row 0, row 1) and (row 2, row 3) are formed with byte permutes, sample by sample across the edge
+                uint32_t LP[2][8], CP[2][4];
+                uint4 R[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) R[r] = *(const uint4 *)(l_y + (4 * sr + r) * LSTR + 8 * wx);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    const uint32_t a0[4] = { R[2 * h].x, R[2 * h].y, R[2 * h].z, R[2 * h].w }, a1[4] = { R[2 * h + 1].x, R[2 * h + 1].y, R[2 * h + 1].z, R[2 * h + 1].w };
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { LP[h][2 * j] = __builtin_amdgcn_perm(a1[j], a0[j], 0x05040100u); LP[h][2 * j + 1] = __builtin_amdgcn_perm(a1[j], a0[j], 0x07060302u); }
+                }
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) {
+                    const uint2 c0 = *(const uint2 *)(l_c[pl] + (2 * sr) * CSTR + 4 * wx), c1 = *(const uint2 *)(l_c[pl] + (2 * sr + 1) * CSTR + 4 * wx);
+                    CP[pl][0] = __builtin_amdgcn_perm(c1.x, c0.x, 0x05040100u); CP[pl][1] = __builtin_amdgcn_perm(c1.x, c0.x, 0x07060302u);
+                    CP[pl][2] = __builtin_amdgcn_perm(c1.y, c0.y, 0x05040100u); CP[pl][3] = __builtin_amdgcn_perm(c1.y, c0.y, 0x07060302u);
+                }
+                addb_edge_filter_pk<0>(da, rq, rp, bs, LP, CP, s_alpha, s_beta, s_clip, s_cqp);
+#pragma unroll
+                for (int h = 0; h < 2; h++) {
+                    uint32_t b0[4], b1[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { b0[j] = __builtin_amdgcn_perm(LP[h][2 * j + 1], LP[h][2 * j], 0x05040100u); b1[j] = __builtin_amdgcn_perm(LP[h][2 * j + 1], LP[h][2 * j], 0x07060302u); }
+                    *(uint4 *)(l_y + (4 * sr + 2 * h) * LSTR + 8 * wx) = make_uint4(b0[0], b0[1], b0[2], b0[3]);
+                    *(uint4 *)(l_y + (4 * sr + 2 * h + 1) * LSTR + 8 * wx) = make_uint4(b1[0], b1[1], b1[2], b1[3]);
+                }
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++) {
+                    *(uint2 *)(l_c[pl] + (2 * sr) * CSTR + 4 * wx) = make_uint2(__builtin_amdgcn_perm(CP[pl][1], CP[pl][0], 0x05040100u), __builtin_amdgcn_perm(CP[pl][3], CP[pl][2], 0x05040100u));
+                    *(uint2 *)(l_c[pl] + (2 * sr + 1) * CSTR + 4 * wx) = make_uint2(__builtin_amdgcn_perm(CP[pl][1], CP[pl][0], 0x07060302u), __builtin_amdgcn_perm(CP[pl][3], CP[pl][2], 0x07060302u));
+                }
+                continue;
+            }
             int L[4][8], Cc[2][2][4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -302,6 +337,24 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
         for (int i = t; i < (int)s_cnt[1]; i += 256) {
             const int e = s_list[1][i], seg = e & 255, bs = e >> 8, sx = seg % 18, g = seg / 18;
             const uint4 rq = s_map[2 * g + 1][sx], rp = s_map[2 * g][sx];
+            if (PK) {
+                // lines = columns here: a row's dwords ARE the pairs (line 0, line 1) and (line 2, line 3) - no unpacking at all
+                uint32_t LP[2][8], CP[2][4];
+#pragma unroll
+                for (int r = 0; r < 8; r++) { const uint2 v = *(const uint2 *)(l_y + (8 * g + r) * LSTR + 4 * sx); LP[0][r] = v.x; LP[1][r] = v.y; }
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) CP[pl][r] = *(const uint32_t *)(l_c[pl] + (4 * g + r) * CSTR + 2 * sx);
+                addb_edge_filter_pk<1>(da, rq, rp, bs, LP, CP, s_alpha, s_beta, s_clip, s_cqp);
+#pragma unroll
+                for (int r = 0; r < 8; r++) *(uint2 *)(l_y + (8 * g + r) * LSTR + 4 * sx) = make_uint2(LP[0][r], LP[1][r]);
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) *(uint32_t *)(l_c[pl] + (4 * g + r) * CSTR + 2 * sx) = CP[pl][r];
+                continue;
+            }
             int L[4][8], Cc[2][2][4];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
@@ -607,16 +660,20 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
 //  eight spread evenly between the groups of tiles, its LDS laid over the tile's, 78 VGPRs and six workgroups per CU as before.  The idea: this kernel is bound by VALU issue
 //  with 2 TB/s of traffic, the pass moves 107 MB with 19 us of VALU work.  Same box, ride in the intra launch / here: 8K 2679, 2718 / 2708, 2748 frames/s (+1 %),
 //  4K 8155, 8165 / 7725, 7849 (-4.5 %).)
+// PK: the deblocking line filters on packed pairs of lines (bit depths up to 10; XEVD_HIP_ADDB_SCALAR=1 keeps the scalar form for A/B runs)
+template <bool PK>
 __global__ __launch_bounds__(256) void k_addb_alf(const AlfArgs a, const AddbArgs d, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
                                                   const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_, int16_t *__restrict__ dv_)
 {
-    alf_kernel<true>(a, &d, sy_, su_, sv_, dy_, du_, dv_);
+    alf_kernel<true, PK>(a, &d, sy_, su_, sv_, dy_, du_, dv_);
 }
 
 void launch_alf(xgpu_ctx *c, const AlfArgs &a, const AddbArgs *deblock, const DevPic &src, const DevPic &dst)
 {
     const int tiles = ((a.pic_w + 63) >> 6) * ((a.pic_h + 63) >> 6);
     const dim3 grid(((tiles + 7) >> 3) << 3);
-    if (deblock) hipLaunchKernelGGL(k_addb_alf, grid, dim3(256), 0, c->stream, a, *deblock, src.y, src.u, src.v, dst.y, dst.u, dst.v);
+    static const bool scalar_knob = getenv("XEVD_HIP_ADDB_SCALAR") != NULL;
+    if (deblock && !scalar_knob && deblock->bd_l <= 10 && deblock->bd_c <= 10) hipLaunchKernelGGL(k_addb_alf<true>, grid, dim3(256), 0, c->stream, a, *deblock, src.y, src.u, src.v, dst.y, dst.u, dst.v);
+    else if (deblock) hipLaunchKernelGGL(k_addb_alf<false>, grid, dim3(256), 0, c->stream, a, *deblock, src.y, src.u, src.v, dst.y, dst.u, dst.v);
     else hipLaunchKernelGGL(k_alf, grid, dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
 }
