@@ -247,7 +247,7 @@ def file_md5s(path, period_bytes, limit=None):
     return out
 
 
-def streams_leg(n_gpus, n_streams=8, gop_pictures=17, repeats=4, wl=None):
+def streams_leg(n_gpus, n_streams=8, gop_pictures=17, repeats=6, wl=None):
     """BASELINE.json configs[4], literally: `n_streams` independent 4K Main random-access streams (different seeds; one closed GOP of `gop_pictures` pictures each,
     sent `repeats` times) decoded by examples/evc_decode --gpus N - the C work queue (include/xevd_wq.h) hands the closed GOPs of all streams to one worker set
     per device - with parsing, batch building, kernels and output inside the timed region (the span app/xevd_app.c:492-501,612-624 times).  The first IDR period of
@@ -260,8 +260,11 @@ def streams_leg(n_gpus, n_streams=8, gop_pictures=17, repeats=4, wl=None):
     exe = os.path.join(ROOT, "oracle", "_ref", "ref_decode_main")
     n_dev = min(n_gpus, max(torch.cuda.device_count(), 1))
     quota = host_cpu_quota()
-    workers = max(1, min(8, quota // 2) // n_dev) if n_dev < 8 else 1
-    tile_threads = max(1, min(16, quota // (workers * n_dev)) - 1)
+    # workers: ~3/4 of the CPUs the host gives (a worker is a parser thread + a builder thread + a device thread: ~1.4 CPUs at 4K), at least one per device; measured on the
+    # 16-CPU boxes, 8 streams on one device: 8 / 12 / 16 workers x 1 tile thread = 304 / 400 / 297 pictures/s, 8 x 2 tile threads 384
+    total = max(n_dev, min(16, quota * 3 // 4))
+    workers = max(1, total // n_dev)
+    tile_threads = max(1, min(16, quota // (workers * n_dev)))
     period_bytes = gop_pictures * (w * h * 3 // 2) * 2
     out = {"workload": "cfg5: %d independent %dx%d %d-bit Main random-access streams (seeds differ), closed GOPs of %d pictures x %d" % (n_streams, w, h, bd, gop_pictures, repeats),
            "devices_asked": n_gpus, "devices_used": n_dev, "host_cpu_quota": quota, "host_hardware_threads": os.cpu_count(),
@@ -293,7 +296,7 @@ def streams_leg(n_gpus, n_streams=8, gop_pictures=17, repeats=4, wl=None):
             out["fps_wall_incl_device_startup"] = rep["fps_wall"]
             out["pictures"] = rep["pictures"]
             out["pictures_per_device"] = rep["pictures_per_device"]
-            out["host_threads"] = n_dev * workers * (tile_threads + 2)
+            out["host_threads"] = n_dev * workers * (tile_threads + 2)      # per worker: the parser with its tile threads, the builder, the device thread
             out["cpu_seconds"] = round(rep["cpu_user_s"] + rep["cpu_sys_s"], 2)
             if refs:
                 ok = [file_md5s(os.path.join(td, f"o{k}.yuv"), period_bytes, 1) == refs.get(k) for k in range(n_streams)]
