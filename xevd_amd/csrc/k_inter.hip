@@ -62,16 +62,26 @@ __device__ __forceinline__ void tile_fetch(gs16 p, int s, gs16 pu, gs16 pv, int 
 
 // the two passes over a 39x39 window in LDS: Wn = the window's first sample, WS = its row stride in samples (UW_STRIDE: the wave's own window; REG_W_STRIDE: the
 // wave's part of the 71x71 window its workgroup shares, see inter_tile<2>)
-template <bool H, bool V, int WS>
-__device__ __forceinline__ void luma_tile_filter(const int16_t *Wn, const uint32_t ch[4], const uint32_t cv[4], Regime rg, int maxv, int16_t *I, int lane, uint32_t o[8])
+// SH: the window was fetched in 16-byte ALIGNED chunks, so its first sample sits at an arbitrary sample of the LDS row: Wn = that sample rounded down to a dword,
+// odd = whether it is the dword's high half (wave-uniform: the rows are read dword-wise and shifted by 16 bits then)
+template <bool H, bool V, int WS, bool SH = false>
+__device__ __forceinline__ void luma_tile_filter(const int16_t *Wn, const uint32_t ch[4], const uint32_t cv[4], Regime rg, int maxv, int16_t *I, int lane, uint32_t o[8], int odd = 0)
 {
 #pragma unroll
     for (int it = 0; it < 5; it++) {                                // horizontal pass: 39 rows x 8 groups of 4 columns
         const int idx = lane + 64 * it, row = idx >> 3, g = idx & 7;
         if (idx < 312) {
-            const uint2 *w = (const uint2 *)(Wn + row * WS + 4 * g);
-            const uint2 a = w[0], b = w[1], c = w[2];
-            const uint32_t D0 = a.x, D1 = a.y, D2 = b.x, D3 = b.y, D4 = c.x, D5 = c.y;
+            uint32_t D0, D1, D2, D3, D4, D5;
+            if (SH) {
+                const uint32_t *w = (const uint32_t *)(Wn + row * WS + 4 * g);
+                const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4], d5 = w[5], d6 = w[6];
+                if (odd) { D0 = hi_lo(d1, d0); D1 = hi_lo(d2, d1); D2 = hi_lo(d3, d2); D3 = hi_lo(d4, d3); D4 = hi_lo(d5, d4); D5 = hi_lo(d6, d5); }
+                else { D0 = d0; D1 = d1; D2 = d2; D3 = d3; D4 = d4; D5 = d5; }
+            } else {
+                const uint2 *w = (const uint2 *)(Wn + row * WS + 4 * g);
+                const uint2 a = w[0], b = w[1], c = w[2];
+                D0 = a.x; D1 = a.y; D2 = b.x; D3 = b.y; D4 = c.x; D5 = c.y;
+            }
             uint2 r;
             if (H) {
                 const uint32_t Q0 = hi_lo(D1, D0), Q1 = hi_lo(D2, D1), Q2 = hi_lo(D3, D2), Q3 = hi_lo(D4, D3), Q4 = hi_lo(D5, D4);
@@ -135,17 +145,25 @@ __device__ __forceinline__ void mc_luma_tile(const uint4 v[4], const uint32_t ch
 }
 
 // Both chroma planes of the tile (16x16 each): the passes over the two 19x19 windows Wu / Wv (row stride WS) in LDS
-template <bool H, bool V, int WS>
+template <bool H, bool V, int WS, bool SH = false>
 __device__ __forceinline__ void chroma_tile_filter(const int16_t *Wu, const int16_t *Wv, const uint32_t ch[2], const uint32_t cv[2],
-                                                   Regime rg, int maxv, int16_t *I, int lane, uint32_t ou[2], uint32_t ov[2])
+                                                   Regime rg, int maxv, int16_t *I, int lane, uint32_t ou[2], uint32_t ov[2], int odd = 0)
 {
 #pragma unroll
     for (int it = 0; it < 3; it++) {                                // horizontal pass: 2 x 19 rows x 4 groups of 4 columns
         const int idx = lane + 64 * it, prow = idx >> 2, g = idx & 3;
         if (idx < 152) {
-            const uint2 *w = (const uint2 *)((prow >= 19 ? Wv + (prow - 19) * WS : Wu + prow * WS) + 4 * g);
-            const uint2 a = w[0], b = w[1];
-            const uint32_t D0 = a.x, D1 = a.y, D2 = b.x, D3 = b.y;
+            uint32_t D0, D1, D2, D3;
+            if (SH) {
+                const uint32_t *w = (const uint32_t *)((prow >= 19 ? Wv + (prow - 19) * WS : Wu + prow * WS) + 4 * g);
+                const uint32_t d0 = w[0], d1 = w[1], d2 = w[2], d3 = w[3], d4 = w[4];
+                if (odd) { D0 = hi_lo(d1, d0); D1 = hi_lo(d2, d1); D2 = hi_lo(d3, d2); D3 = hi_lo(d4, d3); }
+                else { D0 = d0; D1 = d1; D2 = d2; D3 = d3; }
+            } else {
+                const uint2 *w = (const uint2 *)((prow >= 19 ? Wv + (prow - 19) * WS : Wu + prow * WS) + 4 * g);
+                const uint2 a = w[0], b = w[1];
+                D0 = a.x; D1 = a.y; D2 = b.x; D3 = b.y;
+            }
             const uint32_t Q0 = hi_lo(D1, D0), Q1 = hi_lo(D2, D1);
             uint2 r;
             if (H) {
@@ -212,27 +230,27 @@ __device__ __forceinline__ void mc_chroma_tile(const uint4 v[2], const uint32_t 
 // line requests instead of 225 + 198 (round 4: the kernel is bound by the rate of L1 -> L2 line requests, ~70 G/s of the ~85 G/s this access pattern reaches with no
 // arithmetic at all - tools/ubench/win_bw.hip).  Two workgroup barriers per list.
 // ---------------------------------------------------------------------------------------------------------
-#define REG_W_STRIDE 80              // 71 columns in 9 chunks of 8 samples
-#define REG_C_STRIDE 40              // 35 columns in 5 chunks
+#define REG_W_STRIDE 80              // up to 7 + 71 columns in 10 chunks of 8 samples, every chunk 16-byte aligned in the reference picture
+#define REG_C_STRIDE 48              // up to 7 + 35 columns in 6 chunks
 #define REG_W_SAMPLES (71 * REG_W_STRIDE)
 #define REG_C_SAMPLES (35 * REG_C_STRIDE)
 #define REG_I_SAMPLES (39 * UI_STRIDE)
 #define REG_SAMPLES   (REG_W_SAMPLES + 2 * REG_C_SAMPLES + 4 * REG_I_SAMPLES)
 struct RegionFetch { uint4 y[3]; uint4 c[2]; };
-// a thread's chunks of the region windows: luma 71 rows x 9 chunks in three rounds of 256 threads, chroma 2 planes x 35 rows x 5 chunks in two; offsets < 0: none
+// a thread's chunks of the region windows: luma 71 rows x 10 chunks in three rounds of 256 threads, chroma 2 planes x 35 rows x 6 chunks in two; offsets < 0: none
 struct RegionMap { int y[3], c[2]; };      // row << 8 | chunk (chroma: | plane << 7); < 0: none.  The offsets are formed where they are used: five registers, not ten
 __device__ __forceinline__ RegionMap region_map(int t)
 {
     RegionMap m;
 #pragma unroll
     for (int it = 0; it < 3; it++) {
-        const int idx = t + 256 * it, row = idx / 9, k = idx - row * 9;
-        m.y[it] = idx < 71 * 9 ? (row << 8) | k : -1;
+        const int idx = t + 256 * it, row = idx / 10, k = idx - row * 10;
+        m.y[it] = idx < 71 * 10 ? (row << 8) | k : -1;
     }
 #pragma unroll
     for (int it = 0; it < 2; it++) {
-        const int idx = t + 256 * it, pl = idx >= 175, j = idx - 175 * pl, row = j / 5, k = j - row * 5;
-        m.c[it] = idx < 350 ? (row << 8) | (pl << 7) | k : -1;
+        const int idx = t + 256 * it, pl = idx >= 210, j = idx - 210 * pl, row = j / 6, k = j - row * 6;
+        m.c[it] = idx < 420 ? (row << 8) | (pl << 7) | k : -1;
     }
     return m;
 }
@@ -381,8 +399,8 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
         // block, a barrier, every wave's passes over its part, a barrier before the block is written again
         const int wx = __builtin_amdgcn_readfirstlane(x) & ~63, wy = __builtin_amdgcn_readfirstlane(y) & ~63;      // the region's first sample
         int16_t *const I = W + REG_W_SAMPLES + 2 * REG_C_SAMPLES + wave * REG_I_SAMPLES;
-        const int16_t *const Wy = W + ((wave >> 1) << 5) * REG_W_STRIDE + ((wave & 1) << 5);
-        const int16_t *const Wu = W + REG_W_SAMPLES + ((wave >> 1) << 4) * REG_C_STRIDE + ((wave & 1) << 4), *const Wv = Wu + REG_C_SAMPLES;
+        const int16_t *const Wy0 = W + ((wave >> 1) << 5) * REG_W_STRIDE + ((wave & 1) << 5);
+        const int16_t *const Wu0 = W + REG_W_SAMPLES + ((wave >> 1) << 4) * REG_C_STRIDE + ((wave & 1) << 4);
         RegionFetch rf[2];
 #pragma unroll
         for (int l = 0; l < 2; l++) {
@@ -390,8 +408,11 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
             const uint4 e0 = s_ref[refis[l] * 2 + l][0], e1 = s_ref[refis[l] * 2 + l][1];
             const gs16 ry_ = (gs16)(((uint64_t)e0.y << 32) | e0.x), ru_ = (gs16)(((uint64_t)e0.w << 32) | e0.z), rv_ = (gs16)(((uint64_t)e1.y << 32) | e1.x);
             const int px = (wx << 2) + mvt[l][0], py = (wy << 2) + mvt[l][1];
-            const int off = ((py >> 3) - 1) * a.s_c + (px >> 3) - 1;
-            region_fetch(ry_ + ((py >> 2) - 3) * a.s_l + (px >> 2) - 3, a.s_l, ru_ + off, rv_ + off, a.s_c, *rm, rf[l]);
+            // every chunk at a 16-byte aligned address (rows start 256-byte aligned): the window's first sample is then `& 7` samples into the first chunk - an
+            // unaligned 16-byte load costs the vector L1 2.4x the accesses of an aligned one (tools/ubench/win_bw.hip)
+            const int xi = (px >> 2) - 3, xc = (px >> 3) - 1;
+            const int off = ((py >> 3) - 1) * a.s_c + (xc & ~7);
+            region_fetch(ry_ + ((py >> 2) - 3) * a.s_l + (xi & ~7), a.s_l, ru_ + off, rv_ + off, a.s_c, *rm, rf[l]);
         }
         load_resid();
 #pragma unroll
@@ -407,15 +428,19 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
                 const uint4 th = s_ltap[ldx ? ((px & 3) << 2) : 16], tv = s_ltap[ldy ? ((py & 3) << 2) : 16];
                 const uint32_t ch[4] = { th.x, th.y, th.z, th.w }, cv[4] = { tv.x, tv.y, tv.z, tv.w };
                 const Regime rg = regime(ldx, ldy, a.bd_l);
-                if (ldx) { if (ldy) luma_tile_filter<true, true, REG_W_STRIDE>(Wy, ch, cv, rg, maxl, I, lane, o); else luma_tile_filter<true, false, REG_W_STRIDE>(Wy, ch, cv, rg, maxl, I, lane, o); }
-                else     { if (ldy) luma_tile_filter<false, true, REG_W_STRIDE>(Wy, ch, cv, rg, maxl, I, lane, o); else luma_tile_filter<false, false, REG_W_STRIDE>(Wy, ch, cv, rg, maxl, I, lane, o); }
+                const int mis = ((px >> 2) - 3) & 7, odd = mis & 1;
+                const int16_t *const Wy = Wy0 + (mis & ~1);
+                if (ldx) { if (ldy) luma_tile_filter<true, true, REG_W_STRIDE, true>(Wy, ch, cv, rg, maxl, I, lane, o, odd); else luma_tile_filter<true, false, REG_W_STRIDE, true>(Wy, ch, cv, rg, maxl, I, lane, o, odd); }
+                else     { if (ldy) luma_tile_filter<false, true, REG_W_STRIDE, true>(Wy, ch, cv, rg, maxl, I, lane, o, odd); else luma_tile_filter<false, false, REG_W_STRIDE, true>(Wy, ch, cv, rg, maxl, I, lane, o, odd); }
             }
             {
                 const uint2 th = s_ctap[cdx ? ((px & 7) << 2) : 32], tv = s_ctap[cdy ? ((py & 7) << 2) : 32];
                 const uint32_t c2h[2] = { th.x, th.y }, c2v[2] = { tv.x, tv.y };
                 const Regime rg = regime(cdx, cdy, a.bd_c);
-                if (cdx) { if (cdy) chroma_tile_filter<true, true, REG_C_STRIDE>(Wu, Wv, c2h, c2v, rg, maxc, I, lane, ou, ov); else chroma_tile_filter<true, false, REG_C_STRIDE>(Wu, Wv, c2h, c2v, rg, maxc, I, lane, ou, ov); }
-                else     { if (cdy) chroma_tile_filter<false, true, REG_C_STRIDE>(Wu, Wv, c2h, c2v, rg, maxc, I, lane, ou, ov); else chroma_tile_filter<false, false, REG_C_STRIDE>(Wu, Wv, c2h, c2v, rg, maxc, I, lane, ou, ov); }
+                const int mis = ((px >> 3) - 1) & 7, odd = mis & 1;
+                const int16_t *const Wu = Wu0 + (mis & ~1), *const Wv = Wu + REG_C_SAMPLES;
+                if (cdx) { if (cdy) chroma_tile_filter<true, true, REG_C_STRIDE, true>(Wu, Wv, c2h, c2v, rg, maxc, I, lane, ou, ov, odd); else chroma_tile_filter<true, false, REG_C_STRIDE, true>(Wu, Wv, c2h, c2v, rg, maxc, I, lane, ou, ov, odd); }
+                else     { if (cdy) chroma_tile_filter<false, true, REG_C_STRIDE, true>(Wu, Wv, c2h, c2v, rg, maxc, I, lane, ou, ov, odd); else chroma_tile_filter<false, false, REG_C_STRIDE, true>(Wu, Wv, c2h, c2v, rg, maxc, I, lane, ou, ov, odd); }
             }
             if (nl == 0) {
 #pragma unroll
