@@ -47,17 +47,25 @@ __device__ __forceinline__ void wave_lds_sync()
 
 // p = reference sample at (tile x - 3, tile y - 3); lane l owns the SCU (l & 7, l >> 3) of the tile.  o[] as mc_luma_4x4.
 // The fetch is split from the filtering so that a wave has the windows of both lists (and its residual) in flight at once.
-struct TileFetch { uint4 y[4]; uint4 c[2]; };
+struct TileFetch { uint4 y[4]; uint4 c[3]; };
 // a lane's chunk of the tile windows: offsets into the reference plane (samples) and into the wave's LDS window.  Luma: 12 rows x 5 chunks of
 // 8 samples per pass (lanes 60..63 idle), four passes cover the 39 rows; chroma: 19 rows x 3 chunks per plane (lanes 57..63 idle).  The offsets
 // depend on the lane alone: computed once per kernel, every pass adds a constant.
-struct LaneMap { int gy, ly, gc, lc; };
-__device__ __forceinline__ void tile_fetch(gs16 p, int s, gs16 pu, gs16 pv, int lane, const LaneMap fm, TileFetch &f)
+struct LaneMap { int gy, ly; };
+// The chunks are 16-byte ALIGNED pieces of the reference rows (p / pu / pv = the chunk that holds the window's first sample; rows start 256-byte aligned): an unaligned
+// 16-byte load costs the vector L1 2.4x the accesses (round 4).  Luma: up to 7 + 39 samples = 6 chunks per row, 10 rows x 6 chunks per pass (lanes 60..63 idle), four
+// passes; chroma: up to 7 + 19 samples = 4 chunks, 2 planes x 19 rows x 4 chunks = 152 loads in three passes of 64 lanes.
+#define UCW_STRIDE 32                // chroma window rows (the intermediate rows keep UC_STRIDE)
+__device__ __forceinline__ void tile_fetch(gs16 p, int s, gs16 pu, gs16 pv, int sc, int lane, const LaneMap fm, TileFetch &f)
 {
 #pragma unroll
     for (int it = 0; it < 4; it++)
-        if (lane < (it < 3 ? 60 : 15)) f.y[it] = gload16(p + fm.gy + 12 * it * s);
-    if (lane < 57) { f.c[0] = gload16(pu + fm.gc); f.c[1] = gload16(pv + fm.gc); }
+        if (lane < (it < 3 ? 60 : 54)) f.y[it] = gload16(p + fm.gy + 10 * it * s);
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+        const int idx = lane + 64 * it, plane = idx >= 76, j = idx - 76 * plane;
+        if (idx < 152) f.c[it] = gload16((plane ? pv : pu) + (j >> 2) * sc + 8 * (j & 3));
+    }
 }
 
 // the two passes over a 39x39 window in LDS: Wn = the window's first sample, WS = its row stride in samples (UW_STRIDE: the wave's own window; REG_W_STRIDE: the
@@ -135,13 +143,13 @@ __device__ __forceinline__ void luma_tile_filter(const int16_t *Wn, const uint32
 }
 template <bool H, bool V>
 __device__ __forceinline__ void mc_luma_tile(const uint4 v[4], const uint32_t ch[4], const uint32_t cv[4], Regime rg, int maxv,
-                                             int16_t *W, int16_t *I, int lane, const LaneMap fm, uint32_t o[8])
+                                             int16_t *W, int16_t *I, int lane, const LaneMap fm, uint32_t o[8], int mis)      // mis: the window's first sample inside its first chunk
 {
 #pragma unroll
     for (int it = 0; it < 4; it++)
-        if (lane < (it < 3 ? 60 : 15)) *(uint4 *)(W + fm.ly + 12 * it * UW_STRIDE) = v[it];
+        if (lane < (it < 3 ? 60 : 54)) *(uint4 *)(W + fm.ly + 10 * it * UW_STRIDE) = v[it];
     wave_lds_sync();
-    luma_tile_filter<H, V, UW_STRIDE>(W, ch, cv, rg, maxv, I, lane, o);
+    luma_tile_filter<H, V, UW_STRIDE, true>(W + (mis & ~1), ch, cv, rg, maxv, I, lane, o, mis & 1);
 }
 
 // Both chroma planes of the tile (16x16 each): the passes over the two 19x19 windows Wu / Wv (row stride WS) in LDS
@@ -215,12 +223,16 @@ __device__ __forceinline__ void chroma_tile_filter(const int16_t *Wu, const int1
 }
 // pu / pv = reference sample at (tile x - 1, tile y - 1) of the plane.
 template <bool H, bool V>
-__device__ __forceinline__ void mc_chroma_tile(const uint4 v[2], const uint32_t ch[2], const uint32_t cv[2],
-                                               Regime rg, int maxv, int16_t *W, int16_t *I, int lane, const LaneMap fm, uint32_t ou[2], uint32_t ov[2])
+__device__ __forceinline__ void mc_chroma_tile(const uint4 v[3], const uint32_t ch[2], const uint32_t cv[2],
+                                               Regime rg, int maxv, int16_t *W, int16_t *I, int lane, uint32_t ou[2], uint32_t ov[2], int mis)
 {
-    if (lane < 57) { *(uint4 *)(W + fm.lc) = v[0]; *(uint4 *)(W + 19 * UC_STRIDE + fm.lc) = v[1]; }
+#pragma unroll
+    for (int it = 0; it < 3; it++) {
+        const int idx = lane + 64 * it, plane = idx >= 76, j = idx - 76 * plane;
+        if (idx < 152) *(uint4 *)(W + (plane ? 19 * UCW_STRIDE : 0) + (j >> 2) * UCW_STRIDE + 8 * (j & 3)) = v[it];
+    }
     wave_lds_sync();
-    chroma_tile_filter<H, V, UC_STRIDE>(W, W + 19 * UC_STRIDE, ch, cv, rg, maxv, I, lane, ou, ov);
+    chroma_tile_filter<H, V, UCW_STRIDE, true>(W + (mis & ~1), W + 19 * UCW_STRIDE + (mis & ~1), ch, cv, rg, maxv, I, lane, ou, ov, mis & 1);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -464,8 +476,8 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
             const uint4 e0 = s_ref[refis[l] * 2 + l][0], e1 = s_ref[refis[l] * 2 + l][1];
             const gs16 ry_ = (gs16)(((uint64_t)e0.y << 32) | e0.x), ru_ = (gs16)(((uint64_t)e0.w << 32) | e0.z), rv_ = (gs16)(((uint64_t)e1.y << 32) | e1.x);
             const int px = (wx << 2) + mvt[l][0], py = (wy << 2) + mvt[l][1];
-            const int off = ((py >> 3) - 1) * a.s_c + (px >> 3) - 1;
-            tile_fetch(ry_ + ((py >> 2) - 3) * a.s_l + (px >> 2) - 3, a.s_l, ru_ + off, rv_ + off, lane, fm, tf[l]);
+            const int off = ((py >> 3) - 1) * a.s_c + (((px >> 3) - 1) & ~7);
+            tile_fetch(ry_ + ((py >> 2) - 3) * a.s_l + (((px >> 2) - 3) & ~7), a.s_l, ru_ + off, rv_ + off, a.s_c, lane, fm, tf[l]);
         }
         load_resid();                                               // ... and the residual, then the filtering
 #pragma unroll
@@ -478,15 +490,17 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
                 const uint4 th = s_ltap[ldx ? ((px & 3) << 2) : 16], tv = s_ltap[ldy ? ((py & 3) << 2) : 16];
                 const uint32_t ch[4] = { th.x, th.y, th.z, th.w }, cv[4] = { tv.x, tv.y, tv.z, tv.w };
                 const Regime rg = regime(ldx, ldy, a.bd_l);
-                if (ldx) { if (ldy) mc_luma_tile<true, true>(tf[l].y, ch, cv, rg, maxl, W, I, lane, fm, o); else mc_luma_tile<true, false>(tf[l].y, ch, cv, rg, maxl, W, I, lane, fm, o); }
-                else     { if (ldy) mc_luma_tile<false, true>(tf[l].y, ch, cv, rg, maxl, W, I, lane, fm, o); else mc_luma_tile<false, false>(tf[l].y, ch, cv, rg, maxl, W, I, lane, fm, o); }
+                const int mis = ((px >> 2) - 3) & 7;
+                if (ldx) { if (ldy) mc_luma_tile<true, true>(tf[l].y, ch, cv, rg, maxl, W, I, lane, fm, o, mis); else mc_luma_tile<true, false>(tf[l].y, ch, cv, rg, maxl, W, I, lane, fm, o, mis); }
+                else     { if (ldy) mc_luma_tile<false, true>(tf[l].y, ch, cv, rg, maxl, W, I, lane, fm, o, mis); else mc_luma_tile<false, false>(tf[l].y, ch, cv, rg, maxl, W, I, lane, fm, o, mis); }
             }
             {
                 const uint2 th = s_ctap[cdx ? ((px & 7) << 2) : 32], tv = s_ctap[cdy ? ((py & 7) << 2) : 32];
                 const uint32_t c2h[2] = { th.x, th.y }, c2v[2] = { tv.x, tv.y };
                 const Regime rg = regime(cdx, cdy, a.bd_c);
-                if (cdx) { if (cdy) mc_chroma_tile<true, true>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, fm, ou, ov); else mc_chroma_tile<true, false>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, fm, ou, ov); }
-                else     { if (cdy) mc_chroma_tile<false, true>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, fm, ou, ov); else mc_chroma_tile<false, false>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, fm, ou, ov); }
+                const int mis = ((px >> 3) - 1) & 7;
+                if (cdx) { if (cdy) mc_chroma_tile<true, true>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, ou, ov, mis); else mc_chroma_tile<true, false>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, ou, ov, mis); }
+                else     { if (cdy) mc_chroma_tile<false, true>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, ou, ov, mis); else mc_chroma_tile<false, false>(tf[l].c, c2h, c2v, rg, maxc, W, I, lane, ou, ov, mis); }
             }
             if (nl == 0) {
 #pragma unroll
@@ -624,10 +638,8 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     int16_t *W = s_tile + (t >> 6) * UNI_SAMPLES;
     LaneMap fm;
     {
-        const int row0 = (lane * 205) >> 10, k = lane - row0 * 5;         // luma window: 12 rows x 5 chunks of 8 samples per pass (lanes 60..63 idle)
+        const int row0 = (lane * 171) >> 10, k = lane - row0 * 6;         // luma window: 10 rows x 6 aligned chunks of 8 samples per pass (lanes 60..63 idle)
         fm.gy = row0 * a.s_l + 8 * k; fm.ly = row0 * UW_STRIDE + 8 * k;
-        const int cr = (lane * 171) >> 9, ck = lane - cr * 3;              // chroma windows: 19 rows x 3 chunks of 8 samples per plane (lanes 57..63 idle)
-        fm.gc = cr * a.s_c + 8 * ck; fm.lc = cr * UC_STRIDE + 8 * ck;
     }
     // every path stores on its own and leaves (one common tail would make the register allocator keep the three paths' results in the same registers)
     auto store_tile = [&](const uint32_t pl[8], const uint32_t pu[2], const uint32_t pv[2]) {
