@@ -455,11 +455,12 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
     }
     __syncthreads();
     const bool edge_l = tx0 == 0, edge_r = tx0 + 64 >= a.pic_w, edge_t = ty0 == 0, edge_b = ty0 + 64 >= a.pic_h;
+    const bool keep_border = a.pad && (edge_l || edge_r || edge_t || edge_b);      // workgroup-uniform: an inner tile's lanes do not test their rows against the picture borders
     do {
     if (!inside) break;
     // a lane's block on the picture border leaves its outermost samples for the replication
     auto keep_luma = [&](int ii, uint2 w) {
-        if (a.pad) {
+        if (keep_border) {
             if (y + ii == 0) *(uint2 *)&b_row[0][0][lx << 2] = w;
             if (y + ii == a.pic_h - 1) *(uint2 *)&b_row[0][1][lx << 2] = w;
             if (x == 0) b_col[0][0][(ly << 2) + ii] = (int16_t)(w.x & 0xFFFF);
@@ -557,7 +558,7 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
         const int16_t *src = pl ? sv_ : su_;
         int16_t *dst = pl ? dv_ : du_;
         auto keep_chroma = [&](int ii, uint32_t w) {
-            if (a.pad) {
+            if (keep_border) {
                 if (cy + ii == 0) *(uint32_t *)&b_row[1 + pl][0][lx << 1] = w;
                 if (cy + ii == (a.pic_h >> 1) - 1) *(uint32_t *)&b_row[1 + pl][1][lx << 1] = w;
                 if (cx == 0) b_col[1 + pl][0][(ly << 1) + ii] = (int16_t)(w & 0xFFFF);
