@@ -21,7 +21,7 @@
  * bi_idx / mmvd_flag + mmvd data syntax (xevdm_eco.c:767-812,1519-1726), merge with vector difference (src_main/xevdm_util.c:191-592,4682-4716), merge candidates incl. the temporal and history ones (src_main/xevdm_util.c:594-1391,3729-3818), the resolution-indexed
  * predictor (:750-951), intra-only 4x4 CUs; tool_dmvr needs the backend's refined vectors back per picture (xhost_parser_set_dmvr_mvs) - or, together with
  * tool_hmvp or tool_mmvd, the decoded luma samples of the reference pictures (xhost_parser_set_ref_luma: the front end then refines itself).  tool_affine (affine merge / affine inter CUs, xevdm_util.c:2145-3187) is parsed too.
- * sps_btt_flag (binary / ternary split trees with CTU 64, "inter only" mode constraints, local dual trees: xgpu_cu_batch.tree) is parsed; refused: sps_suco_flag.
+ * sps_btt_flag (binary / ternary split trees with CTU 64, "inter only" mode constraints, local dual trees: xgpu_cu_batch.tree) and sps_suco_flag (parts of a split coded right to left, right-hand neighbours) are parsed.
  * tool_cm_init (context initialisation tables, neighbour-dependent contexts) and tool_adcc
  * (advanced coefficient coding) are parsed.
  * dquant_flag (QP deltas per quantisation group), tool_rpl (reference picture lists in SPS / slice headers, RPL-based marking) and tool_pocs
@@ -181,6 +181,11 @@ typedef struct xhost_stream_params {
                                               log2_diff_ctu_max_14_cb_size / log2_diff_ctu_max_tt_cb_size / log2_diff_min_cb_min_tt_cb_size_minus2 (xevdm_util.c:4393-4400) */
     int btt_log2_min_cb, btt_diff_max_14, btt_diff_max_tt, btt_diff_min_tt;
     int rpl_in_sps;                        /* with tool_rpl, low delay and at least 2 references: RPL candidates in the SPS, picked by index where they match */
+    int suco;                              /* Main: sps_suco_flag - split nodes with a vertical cut may code their parts right to left (the writer lets about half of the
+                                              nodes that may choose do so); the CUs of such a part see their RIGHT neighbours as decoded.  suco_diff_max / suco_diff_min:
+                                              log2_diff_ctu_size_max_suco_cb_size / log2_diff_max_suco_min_suco_cb_size (xevdm_util.c:1702-1727: the flag is sent for
+                                              nodes with sides between 2^max(6 - max - min, 4) and 2^(6 - max))                                                       */
+    int suco_diff_max, suco_diff_min;
 } xhost_stream_params;
 
 /* ALF parameter set as it is coded in an APS NAL unit (XEVD_ALF_SLICE_PARAM after xevdm_eco_alf_aps_param) */

@@ -703,12 +703,12 @@ static void intra_predict(const int16_t *left, const int16_t *up, int16_t *dst, 
 
 /* ------------------------------------------------------------------------------------------------
  * Intra prediction with sps->tool_eipd (Main): 33 luma modes (DC 0, planar 1, bilinear 2, 30 angular with VER 12 / HOR 24) and
- * 5 chroma modes (DM 0, BI 1, DC 2, HOR 3, VER 4), for blocks without right-hand neighbours (SUCO off: avail_lr LR_00 / LR_10).
+ * 5 chroma modes (DM 0, BI 1, DC 2, HOR 3, VER 4); avail_lr says which of the left / right columns next to the block are reconstructed (the right one only with SUCO).
  * ---------------------------------------------------------------------------------------------- */
 /* xevdm_get_nbr (src_main/xevdm_ipred.c:39-148): as intra_neighbours, but an unavailable unit REPEATS the sample before it
    (towards the corner) instead of the mid value, and an unavailable corner takes up[0]. */
 static void intra_neighbours_eipd(const xgpu_seq_params *sp, const orc_maps *m, const int16_t *src, int s, int x_scu, int y_scu,
-                                  int cw, int ch, int unit, int constrained, int16_t *up, int16_t *left)
+                                  int cw, int ch, int unit, int constrained, int16_t *up, int16_t *left, int16_t *right)
 {
     const int scuw = cw / unit, scuh = ch / unit, ws = m->w_scu, scup = x_scu + y_scu * ws;
     int i, j;
@@ -725,7 +725,22 @@ static void intra_neighbours_eipd(const xgpu_seq_params *sp, const orc_maps *m, 
         const int ok = x_scu > 0 && y_scu + i < m->h_scu && NB_OK(scup - 1 + i * ws);
         for (j = 0; j < unit; j++) left[i * unit + j] = ok ? src[(i * unit + j) * s - 1] : left[i * unit - 1];
     }
+    /* the column right of the block (:123-147): decoded before the block only where SUCO runs a split right to left; starts from the sample above it */
+    right[-1] = up[cw];
+    for (i = 0; i < scuh + scuw; i++) {
+        const int ok = x_scu + scuw < ws && y_scu + i < m->h_scu && NB_OK(scup + scuw + i * ws);
+        for (j = 0; j < unit; j++) right[i * unit + j] = ok ? src[(i * unit + j) * s + cw] : right[i * unit - 1];
+    }
 #undef NB_OK
+}
+/* xevd_check_nev_avail (src_base/xevd_util.c:1156-1174): bit 0 - the SCU left of the block's first one is reconstructed, bit 1 - the one right of its first row */
+static int avail_lr_of(const orc_maps *m, int xs, int ys, int scuw)
+{
+    const int ws = m->w_scu, scup = xs + ys * ws;
+    int lr = 0;
+    if (xs > 0 && MCU_COD(m->map_scu[scup - 1]) && TILE_SAME(m, scup, scup - 1)) lr |= 1;
+    if (xs + scuw < ws && MCU_COD(m->map_scu[scup + scuw]) && TILE_SAME(m, scup, scup + scuw)) lr |= 2;
+    return lr;
 }
 
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
@@ -742,50 +757,62 @@ static void ang_slopes(int mode, int *dx, int *dy)
     else                               { *dx = 0; *dy = 0; }
 }
 
-/* ipred_ang_val (xevd_ipred.c:377-569) without the right-neighbour branches: a 4-tap interpolation { 32-o, 64-o, 32+o, o } / 128
-   between reference positions clamped to [-1, w+h-1] */
-static int ang_sample(const int16_t *left, const int16_t *up, int mode, int i, int j, int w, int h, int maxv)
+/* ipred_ang_val (xevd_ipred.c:377-569): a 4-tap interpolation { 32-o, 64-o, 32+o, o } / 128 between reference positions clamped to [-1, w+h-1] on the row
+   above, the left column or - where it is reconstructed (lr & 2) - the right column */
+static int ang_sample(const int16_t *left, const int16_t *up, const int16_t *right, int lr, int mode, int i, int j, int w, int h, int maxv)
 {
     int dx, dy, o, p, dir;
     const int16_t *ref;
+    const int ri = (lr & 2) != 0;
     ang_slopes(mode, &dx, &dy);
-    if (mode < 12) {                       /* from the row above, leaning right */
-        const int t = (j + 1) * dx;
-        p = i + (t >> 10); o = (t >> 5) - ((t >> 10) << 5); ref = up; dir = 1;
-    } else if (mode > 24) {                /* from the left column, leaning down */
-        const int t = (i + 1) * dy;
-        p = j + (t >> 10); o = (t >> 5) - ((t >> 10) << 5); ref = left; dir = 1;
-    } else {                               /* between vertical and horizontal: from above or from the left, leaning back */
-        const int ty = (i + 1) * dy;
-        if (j < (ty >> 10)) {
-            const int tx = (j + 1) * dx;
-            p = i - (tx >> 10); o = (tx >> 5) - ((tx >> 10) << 5); ref = up;
-        } else {
-            p = j - (ty >> 10); o = (ty >> 5) - ((ty >> 10) << 5); ref = left;
-        }
-        dir = -1;
+#define POS(mt, d, q, off) do { (q) = ((d) * (mt)) >> 10; (off) = (((d) * (mt)) >> 5) - ((q) << 5); } while (0)
+    if (mode < 12) {                       /* from the row above, leaning right - past the block's right edge from the right column */
+        int t;
+        POS(dx, j + 1, t, o);
+        if (ri && i >= w - t) { POS(dy, w - i, t, o); p = j - t; ref = right; dir = -1; }
+        else { p = i + t; ref = up; dir = 1; }
+    } else if (mode > 24) {                /* from the left column, leaning down; with a right column: from above or from the right instead */
+        int t;
+        if (ri) {
+            POS(dy, w - i, t, o);
+            if (j < t) { POS(dx, w - i, t, o); p = i + t; ref = up; dir = 1; }
+            else { p = j - t; ref = right; dir = -1; }
+        } else { POS(dy, i + 1, t, o); p = j + t; ref = left; dir = 1; }
+    } else {                               /* between vertical and horizontal: from above or from the left, leaning back (only a right column: from it, leaning down) */
+        int ty, t;
+        POS(dy, i + 1, ty, o);
+        if (j < ty) { POS(dx, j + 1, t, o); p = i - t; ref = up; dir = -1; }
+        else if (lr == 2) { POS(dy, w - i, t, o); p = j + t; ref = right; dir = 1; }
+        else { p = j - ty; ref = left; dir = -1; }
     }
+#undef POS
     {
         const int hi = w + h - 1;
 #define CL(v) ((v) < -1 ? -1 : ((v) > hi ? hi : (v)))
-        const int v = (ref[CL(p - dir)] * (32 - o) + ref[CL(p)] * (64 - o) + ref[CL(p + dir)] * (32 + o) + ref[CL(p + 2 * dir)] * o + 64) >> 7;
+        const int v = (int16_t)((ref[CL(p - dir)] * (32 - o) + ref[CL(p)] * (64 - o) + ref[CL(p + dir)] * (32 + o) + ref[CL(p + 2 * dir)] * o + 64) >> 7);
 #undef CL
         return v < 0 ? 0 : (v > maxv ? maxv : v);
     }
 }
 
-/* xevdm_ipred / xevdm_ipred_uv (src_main/xevdm_ipred.c:241-305) for avail_lr without a right side.  `mode` is a LUMA mode number. */
-static void intra_predict_eipd(const int16_t *left, const int16_t *up, int16_t *dst, int mode, int w, int h, int bit_depth)
+/* xevdm_ipred / xevdm_ipred_uv (src_main/xevdm_ipred.c:241-305).  `mode` is a LUMA mode number; lr = avail_lr (bit 0 left, bit 1 right column reconstructed). */
+static void intra_predict_eipd(const int16_t *left, const int16_t *up, const int16_t *right, int lr, int16_t *dst, int mode, int w, int h, int bit_depth)
 {
     const int lw = ilog2(w), lh = ilog2(h), maxv = (1 << bit_depth) - 1;
     int i, j;
     if (mode == 12) { for (j = 0; j < h; j++) for (i = 0; i < w; i++) dst[j * w + i] = up[i]; return; }            /* xevd_ipred_vert */
-    if (mode == 24) { for (j = 0; j < h; j++) for (i = 0; i < w; i++) dst[j * w + i] = left[j]; return; }          /* xevdm_ipred_hor :153-196 */
+    if (mode == 24) {                                                                                           /* xevdm_ipred_hor :153-196 */
+        for (j = 0; j < h; j++) for (i = 0; i < w; i++)
+            dst[j * w + i] = lr == 3 ? (int16_t)(((left[j] * (w - i) + right[j] * (i + 1) + (w >> 1)) * k_inv_size[lw]) >> 12) : (lr == 2 ? right[j] : left[j]);
+        return;
+    }
     if (mode == 0) {                                                                                            /* xevdm_ipred_dc :198-229, xevd_get_dc */
-        int dc = 0;
-        for (j = 0; j < h; j++) dc += left[j];
+        int dc = 0, hh = h, lhh = lh;
+        if (lr != 2) for (j = 0; j < h; j++) dc += left[j];
+        if (lr & 2) for (j = 0; j < h; j++) dc += right[j];
         for (i = 0; i < w; i++) dc += up[i];
-        dc = ((dc + ((w + h) >> 1)) * k_inv_size[lw > lh ? lw - lh : lh - lw]) >> ((lw < lh ? lw : lh) + 12);
+        if (lr == 3) { hh = h << 1; lhh = lh + 1; }                       /* both columns: the mean over w + 2h samples */
+        dc = ((dc + ((w + hh) >> 1)) * k_inv_size[lw > lhh ? lw - lhh : lhh - lw]) >> ((lw < lhh ? lw : lhh) + 12);
         for (i = 0; i < w * h; i++) dst[i] = (int16_t)dc;
         return;
     }
@@ -793,32 +820,52 @@ static void intra_predict_eipd(const int16_t *left, const int16_t *up, int16_t *
         static const int mult[6] = { 13, 17, 5, 11, 23, 47 }, shift[6] = { 7, 10, 11, 15, 19, 23 };
         const int w2 = w >> 1, h2 = h >> 1, iw = lw < 2 ? 0 : lw - 2, ih = lh < 2 ? 0 : lh - 2;
         int ch_ = 0, cv = 0, a, b, c, base;
-        for (i = 1; i <= w2; i++) ch_ += i * (up[w2 - 1 + i] - up[w2 - 1 - i]);
-        for (j = 1; j <= h2; j++) cv += j * (left[h2 - 1 + j] - left[h2 - 1 - j]);
-        a = (left[h - 1] + up[w - 1]) << 4;
+        if (lr & 2) {                                /* a right column: the mirror image - gradients towards the left, anchored at the bottom-right and top-left samples */
+            for (i = 1; i <= w2; i++) ch_ += i * (up[w2 - i] - up[w2 + i]);
+            for (j = 1; j <= h2; j++) cv += j * (right[h2 - 1 + j] - right[h2 - 1 - j]);
+            a = (right[h - 1] + up[0]) << 4;
+        } else {
+            for (i = 1; i <= w2; i++) ch_ += i * (up[w2 - 1 + i] - up[w2 - 1 - i]);
+            for (j = 1; j <= h2; j++) cv += j * (left[h2 - 1 + j] - left[h2 - 1 - j]);
+            a = (left[h - 1] + up[w - 1]) << 4;
+        }
         b = ((ch_ << 5) * mult[iw] + (1 << (shift[iw] - 1))) >> shift[iw];
         c = ((cv << 5) * mult[ih] + (1 << (shift[ih] - 1))) >> shift[ih];
         base = a - (h2 - 1) * c - (w2 - 1) * b + 16;
         for (j = 0; j < h; j++) for (i = 0; i < w; i++) {
-            const int v = (base + j * c + i * b) >> 5;
+            const int v = (base + j * c + ((lr & 2) ? w - 1 - i : i) * b) >> 5;
             dst[j * w + i] = (int16_t)(v < 0 ? 0 : (v > maxv ? maxv : v));
         }
         return;
     }
-    if (mode == 2) {                                                                                            /* xevd_ipred_bi :251-369, last branch */
+    if (mode == 2) {                                                                                            /* xevd_ipred_bi :251-369 */
         static const int wc_tbl[6] = { -1, 341, 205, 114, 60, 31 };
-        const int a = up[w], b = left[h], ms = lw < lh ? lw : lh;
-        const int c = w == h ? (a + b + 1) >> 1 : (((a << lw) + (b << lh)) * wc_tbl[lw > lh ? lw - lh : lh - lw] + (1 << (ms + 9))) >> (ms + 10);
-        const int wt = (c << 1) - a - b;
-        for (j = 0; j < h; j++) for (i = 0; i < w; i++) {
-            const int px = (left[j] << lw) + (i + 1) * (a - left[j]);
-            const int py = (up[i] << lh) + (j + 1) * (b - up[i]);
-            const int v = ((px << lh) + (py << lw) + i * j * wt + (1 << (lw + lh))) >> (lw + lh + 1);
-            dst[j * w + i] = (int16_t)(v < 0 ? 0 : (v > maxv ? maxv : v));
+        if (lr == 3) {                               /* both columns: rows interpolated between them, then towards the bottom row of that from the row above */
+            for (j = 0; j < h; j++) for (i = 0; i < w; i++) {
+                const int row = ((left[j] * (w - i) + right[j] * (i + 1) + (w >> 1)) * k_inv_size[lw]) >> 12;
+                const int bot = ((left[h - 1] * (w - i) + right[h - 1] * (i + 1) + (w >> 1)) * k_inv_size[lw]) >> 12;
+                const int t = (up[i] * (h - 1 - j) + bot * (j + 1) + (h >> 1)) >> lh;
+                dst[j * w + i] = (int16_t)((row + t + 1) >> 1);
+            }
+            return;
+        }
+        {
+            /* one column (the right one: the mirror image): corner values a (beyond the row above) and b (below the column) */
+            const int16_t *col = lr == 2 ? right : left;
+            const int a = lr == 2 ? up[-1] : up[w], b = col[h], ms = lw < lh ? lw : lh;
+            const int c = w == h ? (a + b + 1) >> 1 : (((a << lw) + (b << lh)) * wc_tbl[lw > lh ? lw - lh : lh - lw] + (1 << (ms + 9))) >> (ms + 10);
+            const int wt = (c << 1) - a - b;
+            for (j = 0; j < h; j++) for (i = 0; i < w; i++) {
+                const int k = lr == 2 ? w - 1 - i : i;          /* distance from the column */
+                const int px = (col[j] << lw) + (k + 1) * (a - col[j]);
+                const int py = (up[i] << lh) + (j + 1) * (b - up[i]);
+                const int v = ((px << lh) + (py << lw) + k * j * wt + (1 << (lw + lh))) >> (lw + lh + 1);
+                dst[j * w + i] = (int16_t)(v < 0 ? 0 : (v > maxv ? maxv : v));
+            }
         }
         return;
     }
-    for (j = 0; j < h; j++) for (i = 0; i < w; i++) dst[j * w + i] = (int16_t)ang_sample(left, up, mode, i, j, w, h, maxv);
+    for (j = 0; j < h; j++) for (i = 0; i < w; i++) dst[j * w + i] = (int16_t)ang_sample(left, up, right, lr, mode, i, j, w, h, maxv);
 }
 /* chroma mode -> the luma-numbered predictor to run (xevdm_ipred_uv :267-305; DM follows the luma mode) */
 static int eipd_chroma_mode(int ipm_c, int ipm_l)
@@ -1184,7 +1231,8 @@ int orc_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xgp
             if (!done) orc_mc_cu(sp, fr, x, y, w, h, &b->refi[i * 2], (const int16_t (*)[2])&b->mv[i * 4], pred[0], pred[1]);
         }
         else if (maps) {      /* xevd_recon_unit's intra branch, xevd.c:731-741 (availability needs the SCU map) */
-            int16_t nb_up[2 * MAX_CU + 8], nb_le[2 * MAX_CU + 8];
+            int16_t nb_up[2 * MAX_CU + 8], nb_le[2 * MAX_CU + 8], nb_ri[2 * MAX_CU + 8];
+            const int lr = avail_lr_of(maps, x >> 2, y >> 2, w >> 2);
             for (c = 0; c < 3; c++) {
                 const int cw = c ? w >> 1 : w, ch = c ? h >> 1 : h, s = c ? fr->cur.s_c : fr->cur.s_l;
                 const int16_t *plane = c == 0 ? fr->cur.y : (c == 1 ? fr->cur.u : fr->cur.v);
@@ -1192,8 +1240,8 @@ int orc_recon_batch_ex(const xgpu_seq_params *sp, const orc_frame *fr, const xgp
                 if (sp->tool_eipd) {
                     const int ml = b->ipm ? b->ipm[i * 2] : 0, mc = b->ipm ? b->ipm[i * 2 + 1] : 0;
                     intra_neighbours_eipd(sp, maps, plane + (c ? (y >> 1) * s + (x >> 1) : y * s + x), s, x >> 2, y >> 2, cw, ch, c ? 2 : 4,
-                                          b->constrained_intra_pred, nb_up + 4, nb_le + 4);
-                    intra_predict_eipd(nb_le + 4, nb_up + 4, pred[0][c], c ? eipd_chroma_mode(mc, ml) : ml, cw, ch,
+                                          b->constrained_intra_pred, nb_up + 4, nb_le + 4, nb_ri + 4);
+                    intra_predict_eipd(nb_le + 4, nb_up + 4, nb_ri + 4, lr, pred[0][c], c ? eipd_chroma_mode(mc, ml) : ml, cw, ch,
                                        c ? sp->bit_depth_chroma : sp->bit_depth_luma);
                     continue;
                 }

@@ -27,14 +27,14 @@ def make_stream(width, height, n_pics, bit_depth=8, seed=0, max_refs=1, skip_fra
                 cu_qp_delta=True, split_prob=0.5, idr_period=0, log2_sub_gop=0, bi_frac=0.5, direct_frac=0.1,
                 main=False, iqt=False, ats=False, addb=False, addb_offsets=(0, 0), alf=False, sign=False, eipd=False, crop=(0, 0, 0, 0),
                 chroma_qp_points=None, dra=None, htdf=False, ibc_log_max=0, ibc_frac=0.25, alf_fixed=False, admvp=False, amvr=False, hmvp=False, dmvr=False, mmvd=False,
-                tiles=None, affine=False, affine_frac=0.4, qp_delta_area=0, rpl=False, pocs=False, rpl_in_sps=False, cm_init=False, adcc=False, max_level=6, qp_range=(22, 37), btt=None, dual_tree=False, slices=None, arbitrary_slices=False):
+                tiles=None, affine=False, affine_frac=0.4, qp_delta_area=0, rpl=False, pocs=False, rpl_in_sps=False, cm_init=False, adcc=False, max_level=6, qp_range=(22, 37), btt=None, dual_tree=False, slices=None, arbitrary_slices=False, suco=None):
     """-> bytes.  Picture 0 is an IDR.  log2_sub_gop = 0: IPPP; n: hierarchical sub-GOPs of 2^n pictures, the layer-0 picture of
     each a P picture, the others B pictures (bi-prediction, temporal direct and two-list skip CUs).
     sign: every picture is followed by a picture-signature SEI with the MD5s of the ORACLE's reconstruction of the stream so far."""
     rng = np.random.default_rng(seed)
     w = stream.StreamWriter(width, height, bit_depth, max_refs, qp_offsets[0], qp_offsets[1], deblock, cu_qp_delta, log2_sub_gop,
                             main=main, iqt=iqt, ats=ats, addb=addb, alpha_off=addb_offsets[0], beta_off=addb_offsets[1], alf=alf, eipd=eipd, crop=crop, chroma_qp_points=chroma_qp_points,
-                            dra_aps_id=None if dra is None else 3, htdf=htdf, ibc_log_max=ibc_log_max, admvp=admvp, amvr=amvr, hmvp=hmvp, dmvr=dmvr, mmvd=mmvd, tiles=tiles, affine=affine, qp_delta_area=qp_delta_area, rpl=rpl, pocs=pocs, rpl_in_sps=rpl_in_sps, cm_init=cm_init, adcc=adcc, btt=btt)
+                            dra_aps_id=None if dra is None else 3, htdf=htdf, ibc_log_max=ibc_log_max, admvp=admvp, amvr=amvr, hmvp=hmvp, dmvr=dmvr, mmvd=mmvd, tiles=tiles, affine=affine, qp_delta_area=qp_delta_area, rpl=rpl, pocs=pocs, rpl_in_sps=rpl_in_sps, cm_init=cm_init, adcc=adcc, btt=btt, suco=suco)
     n_ctu = ((width + 63) // 64) * ((height + 63) // 64)
     tids = gop_tids(log2_sub_gop)
     try:

@@ -48,6 +48,7 @@ static const int16_t k_cm_btt_split_flag[2][15] = { { 145, 560, 528, 308, 594, 5
 static const int16_t k_cm_btt_split_dir[2][5] = { { 0, 417, 389, 99, 0 }, { 0, 128, 81, 49, 0 } };
 static const int16_t k_cm_btt_split_type[2][1] = { { 257 }, { 225 } };
 static const int16_t k_cm_mode_cons[2][3] = { { 64, 0, 0 }, { 481, 16, 368 } };
+static const int16_t k_cm_suco_flag[2][14] = { { 0, 0, 0, 0, 0, 0, 545, 0, 481, 515, 0, 32, 0, 0 }, { 0, 0, 0, 0, 0, 0, 577, 0, 481, 2, 0, 97, 0, 0 } };      // init_suco_flag, xevdm_tbl.c:328-332
 static const int16_t k_cm_sig_coeff[2][47] = { { 387, 98, 233, 346, 717, 306, 233, 37, 321, 293, 244, 37, 329, 645, 408, 493, 164, 781, 101, 179, 369, 871, 585, 244, 361, 147, 416, 408, 628, 352, 406, 502, 566, 466, 54, 97, 521, 113, 147, 519, 36, 297, 132, 457, 308, 231, 534 }, { 66, 34, 241, 321, 293, 113, 35, 83, 226, 519, 553, 229, 751, 224, 129, 133, 162, 227, 178, 165, 532, 417, 357, 33, 489, 199, 387, 939, 133, 515, 32, 131, 3, 305, 579, 323, 65, 99, 425, 453, 291, 329, 679, 683, 391, 751, 51 } };
 static const int16_t k_cm_gt_ab[2][18] = { { 40, 225, 306, 272, 85, 120, 389, 664, 209, 322, 291, 536, 338, 709, 54, 244, 19, 566 }, { 38, 352, 340, 19, 305, 258, 18, 33, 209, 773, 517, 406, 719, 741, 613, 295, 37, 498 } };
 static const int16_t k_cm_last_x[2][21] = { { 762, 310, 288, 828, 342, 451, 502, 51, 97, 416, 662, 890, 340, 146, 20, 337, 468, 975, 216, 66, 54 }, { 892, 84, 581, 600, 278, 419, 372, 568, 408, 485, 338, 632, 666, 732, 17, 178, 180, 585, 581, 34, 257 } };

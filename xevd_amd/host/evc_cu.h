@@ -59,12 +59,35 @@ struct TileCoder {
         if (cu.affine) for (int l = 0; l < 2; l++) { m.mv[l][0] = m.mv[l][1] = 0; if (cu.refi[l] >= 0) aff_centre(cu, l, m.mv[l]); }      // an affine CU leaves the vector at its centre
     }
     bool bi_applicable(const Cu &cu) const { return sh.type == XHOST_SLICE_B && (1 << cu.log2w) + (1 << cu.log2h) > 12; }      // xevdm_check_bi_applicability, xevdm_util.c:1083-1096
-    // the five spatial neighbours H, D, E, I, A (xevdm_check_motion_availability, xevdm_util.c:594-748, last branch): decoded, inter, not IBC
+    // Which sides of the CU are parsed already: bit 0 the SCU left of its first SCU, bit 1 the one right of its first row (xevd_check_eco_nev_avail /
+    // xevd_check_nev_avail, xevd_util.c:1139-1174: LR_00 0, LR_10 1, LR_01 2, LR_11 3).  The right side only ever is with sps_suco_flag.
+    enum { LR_00 = 0, LR_10 = 1, LR_01 = 2, LR_11 = 3 };
+    int avail_lr(const Cu &cu) const
+    {
+        const int ws = pic.w_scu, xs = cu.x >> 2, ys = cu.y >> 2, scuw = (1 << cu.log2w) >> 2, scup = ys * ws + xs;
+        int lr = 0;
+        if (xs > 0 && pic.same_tile(scup, scup - 1) && pic.cod[(size_t)scup - 1]) lr |= 1;
+        if (sps.suco && xs + scuw < ws && pic.same_tile(scup, scup + scuw) && pic.cod[(size_t)scup + scuw]) lr |= 2;
+        return lr;
+    }
+    // the five spatial neighbours (xevdm_check_motion_availability, xevdm_util.c:594-748): decoded, inter, not IBC.  LR_10 / LR_00: H, D, E, I, A (left of the
+    // bottom-left SCU, above the top-right one, above-right, below-left, above-left); LR_01: their mirror images; LR_11: left, right, above, above-right, above-left
     void adm_neighbours(const Cu &cu, int neb[5], bool valid[5]) const
     {
         const int ws = pic.w_scu, hs = pic.h_scu, xs = cu.x >> 2, ys = cu.y >> 2, scuw = (1 << cu.log2w) >> 2, scuh = (1 << cu.log2h) >> 2, scup = ys * ws + xs;
-        neb[0] = scup + (scuh - 1) * ws - 1; neb[1] = scup - ws + scuw - 1; neb[2] = scup - ws + scuw; neb[3] = scup + scuh * ws - 1; neb[4] = scup - ws - 1;
-        const bool in[5] = { xs > 0, ys > 0, ys > 0 && xs + scuw < ws, ys + scuh < hs && xs > 0, ys > 0 && xs > 0 };
+        const int lr = avail_lr(cu);
+        const bool le = xs > 0, ri = xs + scuw < ws, up = ys > 0, dn = ys + scuh < hs;
+        bool in[5];
+        if (lr == LR_11) {
+            neb[0] = scup + (scuh - 1) * ws - 1; neb[1] = scup + (scuh - 1) * ws + scuw; neb[2] = scup - ws; neb[3] = scup - ws + scuw; neb[4] = scup - ws - 1;
+            in[0] = le; in[1] = ri; in[2] = up; in[3] = up && ri; in[4] = le && up;
+        } else if (lr == LR_01) {
+            neb[0] = scup + (scuh - 1) * ws + scuw; neb[1] = scup - ws; neb[2] = scup - ws - 1; neb[3] = scup + scuh * ws + scuw; neb[4] = scup - ws + scuw;
+            in[0] = ri; in[1] = up; in[2] = up && le; in[3] = dn && ri; in[4] = up && ri;
+        } else {
+            neb[0] = scup + (scuh - 1) * ws - 1; neb[1] = scup - ws + scuw - 1; neb[2] = scup - ws + scuw; neb[3] = scup + scuh * ws - 1; neb[4] = scup - ws - 1;
+            in[0] = le; in[1] = up; in[2] = up && ri; in[3] = dn && le; in[4] = up && le;
+        }
         for (int k = 0; k < 5; k++) valid[k] = in[k] && pic.same_tile(scup, neb[k]) && pic.cod[neb[k]] && !pic.intra[neb[k]] && !pic.ibc[neb[k]];      // the tile test first: another tile's maps may be written right now
     }
     static void scale_mv(int ratio, const int16_t in[2], int16_t out[2])      // scaling_mv, xevdm_util.c:180-190 (MVP_SCALING_PRECISION 5)
@@ -153,11 +176,20 @@ struct TileCoder {
             return cnt >= max_n;
         };
         if (temporal(((xs + (cuw >> 3)) >> 1 << 1) + ((ys + (cuh >> 3)) >> 1 << 1) * ws)) return;
-        const int xe = xs + (cuw >> 2) - 1, ye = ys + (cuh >> 2) - 1;
-        if (!tmvp_added && ye + 1 < hs && ((ye + 1) << 2 >> 6) == (ye << 2 >> 6))
-            if (temporal(((ye + 1) >> 1 << 1) * ws + (xe >> 1 << 1))) return;
-        if (!tmvp_added && xe + 1 < ws && ((xe + 1) << 2 >> 6) == (xe << 2 >> 6))
-            if (temporal((ye >> 1 << 1) * ws + ((xe + 1) >> 1 << 1))) return;
+        const int ye = ys + (cuh >> 2) - 1, ctu = 6;
+        if (avail_lr(cu) == LR_01) {        // the right side is there, the left one is not: below the bottom-left SCU, then left of it (xevd_get_right_below_scup_merge_suco, :1030-1057)
+            const int xl = xs - 1;
+            if (!tmvp_added && ye + 1 < hs && ((ye + 1) << 2 >> ctu) == (ye << 2 >> ctu))
+                if (temporal(((ye + 1) >> 1 << 1) * ws + ((xl + 1) >> 1 << 1))) return;
+            if (!tmvp_added && xl >= 0 && ((xl + 1) << 2 >> ctu) == (xl << 2 >> ctu))
+                if (temporal((ye >> 1 << 1) * ws + (xl >> 1 << 1))) return;
+        } else {
+            const int xe = xs + (cuw >> 2) - 1;
+            if (!tmvp_added && ye + 1 < hs && ((ye + 1) << 2 >> ctu) == (ye << 2 >> ctu))
+                if (temporal(((ye + 1) >> 1 << 1) * ws + (xe >> 1 << 1))) return;
+            if (!tmvp_added && xe + 1 < ws && ((xe + 1) << 2 >> ctu) == (xe << 2 >> ctu))
+                if (temporal((ye >> 1 << 1) * ws + ((xe + 1) >> 1 << 1))) return;
+        }
         // every fourth entry of the history, newest first (with tool_hmvp off the buffer is empty)
         for (int k = 3; k <= std::min(hist_cnt, max_n == 4 ? 15 : 23); k += 4) {
             insert(hist[hist_cnt - k].refi, &hist[hist_cnt - k].mv[0][0]);
@@ -342,18 +374,76 @@ struct TileCoder {
         return k_mpm[l][u];
     }
     // tool_eipd: the two most probable modes, eight "extended" ones and the ordering of all 33 (xevdm_get_mpm, src_main/xevdm_ipred.c:
-    // 320-767) for a CU whose right-hand neighbour is not coded yet - always the case without SUCO, which this front end rejects.
+    // 320-767)
     void eipd_mpm(const Cu &cu, int mpm[2], int ext[8], int pims[33]) const
     {
         enum { DC = 0, PLN = 1, BI = 2, VER = 12, HOR = 24, DIA_R = 18, DIA_L = 6, DIA_U = 30, CNT = 33 };
         const int xs = cu.x >> 2, ys = cu.y >> 2, ws = pic.w_scu, scup = ys * ws + xs;
-        int l = DC, u = DC;
-        if (xs > 0 && pic.same_tile(scup, scup - 1) && pic.intra[scup - 1] && pic.cod[scup - 1]) l = pic.ipm[scup - 1];
-        if (ys > 0 && pic.same_tile(scup, scup - ws) && pic.intra[scup - ws] && pic.cod[scup - ws]) u = pic.ipm[scup - ws];
+        int l = DC, u = DC, r = DC;
+        bool vl = false, vu = false, vr = false;
+        if (xs > 0 && pic.same_tile(scup, scup - 1) && pic.intra[scup - 1] && pic.cod[scup - 1]) { l = pic.ipm[scup - 1]; vl = true; }
+        if (ys > 0 && pic.same_tile(scup, scup - ws) && pic.intra[scup - ws] && pic.cod[scup - ws]) { u = pic.ipm[scup - ws]; vu = true; }
+        const int scuw = (1 << cu.log2w) >> 2;
+        if (sps.suco && xs + scuw < ws && pic.same_tile(scup, scup + scuw) && pic.intra[scup + scuw] && pic.cod[scup + scuw]) {
+            // a right-hand neighbour decoded before the CU (SUCO) stands in for a missing / repeated one, or joins as a third mode (:348-377)
+            r = pic.ipm[scup + scuw];
+            if (vl && vu) { if (l == u) u = r; else vr = true; }
+            else if (!vl) l = r;
+            else u = r;
+            if (vr && (l == r || u == r)) vr = false;
+        }
         mpm[0] = std::min(l, u); mpm[1] = std::max(l, u);
         if (mpm[0] == mpm[1]) { mpm[0] = DC; mpm[1] = mpm[1] == DC ? BI : mpm[1]; }
         const int m0 = mpm[0], m1 = mpm[1];
-        if (m1 < 3) {                                         // two non-angular modes: the third one, then the main directions
+        // candidates of a list in order, those equal to a most probable mode or an earlier entry dropped, until eight are there
+        auto fill = [&](int n, const int *list, int cnt) {
+            for (int i = 0; i < cnt && n < 8; i++) {
+                bool dup = list[i] == m0 || list[i] == m1;
+                for (int j = 0; j < n && !dup; j++) dup = list[i] == ext[j];
+                if (!dup) ext[n++] = list[i];
+            }
+        };
+        auto below = [](int m) { return (m == 3 || m == 4) ? m + 1 : m - 2; };
+        auto above = [](int m) { return (m == CNT - 1 || m == CNT - 2) ? m - 1 : m + 2; };
+        if (vr) {                                             // three different modes around the CU (xevdm_ipred.c:388-625)
+            if (m1 < 3) {
+                ext[0] = m0 == DC ? (m1 == BI ? PLN : BI) : DC;
+                if (r < 3) { const int e[7] = { VER, HOR, DIA_R, DIA_L, DIA_U, VER + 4, HOR - 4 }; memcpy(ext + 1, e, sizeof(e)); }
+                else {
+                    const int list[10] = { VER, HOR, DIA_R, PLN, DIA_L, DIA_U, VER + 4, HOR - 4, VER - 4, HOR + 4 };
+                    ext[1] = r; ext[2] = below(r); ext[3] = above(r);
+                    fill(4, list, 10);
+                }
+            } else if (m0 < 3) {
+                ext[0] = m0 == PLN ? BI : (m0 == BI ? DC : BI);
+                ext[1] = m0 == PLN ? DC : PLN;
+                if (r < 3) {
+                    if (m1 > CNT - 3)  { const int e[6] = { m1 == CNT - 1 ? CNT - 2 : CNT - 1, CNT - 3, CNT - 4, CNT - 5, HOR, DIA_R }; memcpy(ext + 2, e, sizeof(e)); }
+                    else if (m1 < 5)   { const int e[6] = { m1 == 3 ? 4 : 3, 5, 6, 7, VER, DIA_R }; memcpy(ext + 2, e, sizeof(e)); }
+                    else {
+                        ext[2] = m1 + 2; ext[3] = m1 - 2; ext[4] = m1 + 1; ext[5] = m1 - 1;
+                        if (m1 <= 23 && m1 >= 13) { ext[6] = m1 - 5; ext[7] = m1 + 5; }
+                        else { ext[6] = m1 > 23 ? m1 - 5 : m1 + 5; ext[7] = m1 > 23 ? m1 - 10 : m1 + 10; }
+                    }
+                } else {
+                    int list[15] = { below(r), above(r), below(m1), above(m1), (r + m1 + 1) >> 1, 0, 0, VER, HOR, DIA_R, PLN, DIA_L, DIA_U, VER + 4, HOR - 4 };
+                    list[5] = (list[4] + r + 1) >> 1; list[6] = (list[4] + m1 + 1) >> 1;
+                    ext[2] = r;
+                    fill(3, list, 15);
+                }
+            } else if (r < 3) {
+                int list[15] = { below(m0), m0 == CNT - 2 ? m0 - 1 : m0 + 2, m1 == 4 ? m1 + 1 : m1 - 2, above(m1), (m0 + m1 + 1) >> 1, 0, 0, VER, HOR, DIA_R, PLN, DIA_L, DIA_U, VER + 4, HOR - 4 };
+                list[5] = (list[4] + m0 + 1) >> 1; list[6] = (list[4] + m1 + 1) >> 1;
+                ext[0] = r; ext[1] = r == BI ? DC : BI;
+                fill(2, list, 15);
+            } else {
+                const int list[16] = { below(m0), m0 == CNT - 2 ? m0 - 1 : m0 + 2, m1 == 4 ? m1 + 1 : m1 - 2, above(m1), below(r), above(r),
+                                       r < m1 ? (m0 + r + 1) >> 1 : (m0 + m1 + 1) >> 1, r < m0 ? (m0 + m1 + 1) >> 1 : (m1 + r + 1) >> 1,
+                                       VER, HOR, DIA_R, PLN, DIA_L, DIA_U, VER + 4, HOR - 4 };
+                ext[0] = BI; ext[1] = DC; ext[2] = r;
+                fill(3, list, 16);
+            }
+        } else if (m1 < 3) {                                         // two non-angular modes: the third one, then the main directions
             const int e[8] = { m0 == DC ? (m1 == BI ? PLN : BI) : DC, VER, HOR, DIA_R, DIA_L, DIA_U, VER + 4, HOR - 4 };
             memcpy(ext, e, sizeof(e));
         } else if (m0 < 3) {                                  // one angular mode: the other non-angular ones, then its neighbourhood
@@ -402,8 +492,7 @@ struct TileCoder {
 
     // ------------------------------------------------------------------------------------------------------------------------------
     // sps->tool_affine: control-point vectors of affine merge / affine inter CUs (xevd_get_affine_motion, src_main/xevdm.c:937-1013;
-    // candidates src_main/xevdm_util.c:2145-3187).  Without SUCO the right-hand neighbours are never decoded before the CU: avail_lr is
-    // LR_10 or LR_00, and the branches the reference keeps for LR_01 / LR_11 are not restated.
+    // candidates src_main/xevdm_util.c:2145-3187).  The right-hand neighbours count where SUCO has them decoded before the CU (avail_lr LR_01 / LR_11).
     // ------------------------------------------------------------------------------------------------------------------------------
     static int aff_rnd(int v, int shift) { return (v + (1 << (shift - 1)) - (v >= 0)) >> shift; }      // xevdm_mv_rounding_s32, xevdm_util.c:1856-1861
     static int16_t clip16(int v) { return (int16_t)std::min(std::max(v, -32768), 32767); }
@@ -527,12 +616,16 @@ struct TileCoder {
     void aff_merge(const Cu &cu, int8_t refi[5][2], int16_t cpmv[5][2][3][2], int cpn[5]) const
     {
         const int ws = pic.w_scu, hs = pic.h_scu, xs = cu.x >> 2, ys = cu.y >> 2, scuw = (1 << cu.log2w) >> 2, scuh = (1 << cu.log2h) >> 2, scup = ys * ws + xs;
-        const bool left_avail = xs > 0 && pic.same_tile(scup, scup - 1) && pic.cod[(size_t)scup - 1];      // avail_lr LR_10 (xevd_check_nev_avail, xevd_util.c:1156-1174)
+        const int lr = avail_lr(cu);
+        const bool left_avail = (lr & 1) != 0, right_avail = (lr & 2) != 0;
         int cnt = 0;
         memset(cpmv, 0, sizeof(int16_t) * 5 * 2 * 3 * 2);
-        {   // model based: A1, B1, B0, A0, B2 - one candidate per distinct affine neighbour CU
-            const int nb[5] = { scup + ws * (scuh - 1) - 1, scup - ws + scuw - 1, scup - ws + scuw, scup + ws * scuh - 1, scup - ws - 1 };
-            const bool in[5] = { xs > 0, ys > 0, ys > 0 && xs + scuw < ws, xs > 0 && ys + scuh < hs, xs > 0 && ys > 0 };
+        {   // model based: A1, B1, B0, A0, B2 - one candidate per distinct affine neighbour CU; with only the right side decoded (LR_01) their mirror images
+            const bool mir = lr == LR_01;
+            const int nb[5] = { mir ? scup + ws * (scuh - 1) + scuw : scup + ws * (scuh - 1) - 1, mir ? scup - ws : scup - ws + scuw - 1, mir ? scup - ws - 1 : scup - ws + scuw,
+                                mir ? scup + ws * scuh + scuw : scup + ws * scuh - 1, mir ? scup - ws + scuw : scup - ws - 1 };
+            const bool le = xs > 0, ri = xs + scuw < ws, up = ys > 0, dn = ys + scuh < hs;
+            const bool in[5] = { mir ? ri : le, up, up && (mir ? le : ri), dn && (mir ? ri : le), up && (mir ? ri : le) };
             bool valid[5];
             uint32_t tl[5] = { 0, 0, 0, 0, 0 };
             for (int k = 0; k < 5; k++) { valid[k] = aff_nb(scup, nb[k], in[k], true); if (valid[k]) tl[k] = pic.aff_tl[(size_t)nb[k]]; }
@@ -583,11 +676,16 @@ struct TileCoder {
                     temporal(((xs - 1) >> 1 << 1) + ((ys + scuh) >> 1 << 1) * ws, 2);
                 if (cp_refi[0][2] >= 0 || cp_refi[1][2] >= 0) cp_valid[2] = 1;
             }
-            {
+            if (right_avail) {      // the corner takes the neighbour's vectors; it counts when one of them uses a reference (cp_valid[3] is only set from cp_refi, :3132-3135)
+                const int nb[2] = { scup + ws * scuh + scuw, scup + ws * (scuh - 1) + scuw }; const bool in[2] = { xs + scuw < ws && ys + scuh < hs, xs + scuw < ws };
+                const int keep = cp_valid[3];
+                spatial(nb, in, 2, 3);
+                cp_valid[3] = keep;
+            } else {
                 const int col = ((xs + scuw) >> 1 << 1) + ((ys + scuh) >> 1 << 1) * ws;
                 if (xs + scuw < ws && ys + scuh < hs && same_ctu_row && pic.same_tile(scup, col)) temporal(col, 3);
-                if (cp_refi[0][3] >= 0 || cp_refi[1][3] >= 0) cp_valid[3] = 1;
             }
+            if (cp_refi[0][3] >= 0 || cp_refi[1][3] >= 0) cp_valid[3] = 1;
             static const int models[6][3] = { { 0, 1, 2 }, { 0, 1, 3 }, { 0, 2, 3 }, { 1, 2, 3 }, { 0, 1, 0 }, { 0, 2, 0 } };
             static const int vns[6] = { 3, 3, 3, 3, 2, 2 };
             for (int m = 0; m < 6; m++) aff_constructed(cu, cp_valid, cp_mv, cp_refi, models[m], m, vns[m], refi, cpmv, cpn, cnt);
@@ -924,6 +1022,8 @@ struct TileCoder {
             int smaller = 0;
             if (ys > 0 && pic.same_tile(scup, scup - ws)) smaller += (1 << (pic.cu_size[(size_t)scup - ws] & 15)) < (1 << lw);                                  // above: parsed whenever it is in the tile
             if (xs > 0 && pic.same_tile(scup, scup - 1) && pic.cod[(size_t)scup - 1]) smaller += (1 << (pic.cu_size[(size_t)scup - 1] >> 4)) < (1 << lh);
+            const int scuw = (1 << lw) >> 2;                                                                                                                  // the right-hand neighbour: only SUCO lets it be parsed first
+            if (sps.suco && xs + scuw < ws && pic.same_tile(scup, scup + scuw) && pic.cod[(size_t)scup + scuw]) smaller += (1 << (pic.cu_size[(size_t)scup + scuw] >> 4)) < (1 << lh);
             ctx = std::min(smaller, 2) + 3 * shape_ctx[lw - 2][lh - 2];
             if (ctx > 14) ctx = 14;
         }
@@ -935,6 +1035,25 @@ struct TileCoder {
         if ((dir && allow[BI_VER] && allow[TRI_VER]) || (!dir && allow[BI_HOR] && allow[TRI_HOR])) tri = c.bin(tri, models.btt_split_type[0]);
         else tri = (dir && allow[TRI_VER]) || (!dir && allow[TRI_HOR]);
         return tri ? (dir ? TRI_VER : TRI_HOR) : (dir ? BI_VER : BI_HOR);
+    }
+    // suco_flag of a split node (xevdm_eco_suco_flag, src_main/xevdm_eco.c:1303-1331; xevdm_check_suco_cond, xevdm_util.c:1702-1727): sent by a node inside the picture whose
+    // split has a vertical cut (quad, or binary / ternary vertical of a node wider than high) and whose sides lie in the SPS range; every other node INHERITS its
+    // parent's flag - and a vertical split below it then runs right to left as well (xevdm.c:1805: only the direction of the split is asked there)
+    template <class C> int code_suco(C &c, int want, int split, int lw, int lh, bool boundary, int parent)
+    {
+        if (!sps.suco) return parent;
+        const int mx = std::min(6 - sps.suco_raw[0], 6), mn = std::max(mx - sps.suco_raw[1], std::max(4, sps.log2_min_cb));
+        if (std::min(lw, lh) < mn || std::max(lw, lh) > mx || boundary) return parent;
+        if (split == NO_SPLIT || split == BI_HOR || split == TRI_HOR || (split != QUAD && lw <= lh)) return parent;
+        int ctx = 0;
+        if (sps.tool_cm_init) { ctx = std::max(lw, lh) - 2; ctx = lw == lh ? ctx * 2 : ctx * 2 + 1; }
+        return c.bin(want != 0, models.suco_flag[ctx]);
+    }
+    // the order a split node's n parts are coded in (xevdm_split_get_suco_order, xevdm_util.c:3482-3512): right to left with the flag - the quad split row by row
+    static void part_order(int split, int suco, int n, int order[4])
+    {
+        const bool rev = suco && split != BI_HOR && split != TRI_HOR;
+        for (int i = 0; i < n; i++) order[i] = !rev ? i : split == QUAD ? (i ^ 1) : n - 1 - i;
     }
     // children of a split node: position and size
     static int split_parts(int split, int x, int y, int lw, int lh, int px[3], int py[3], int plw[3], int plh[3])
@@ -961,17 +1080,17 @@ struct TileCoder {
     }
 
     // sps->tool_cm_init: the contexts of skip_flag / pred_mode_flag / ibc_flag / affine_flag count the neighbours that have the property - above the top-left
-    // SCU, left of the bottom-left one (and right of the bottom-right one, never parsed before the CU without SUCO) - in the same tile and already parsed
+    // SCU, left of the bottom-left one and right of the bottom-right one (parsed before the CU only in a part that SUCO runs right to left) - in the same tile and already parsed
     // (xevdm_get_ctx_some_flags, src_main/xevdm_util.c:1729-1853)
     enum { CTX_SKIP, CTX_PRED, CTX_IBC, CTX_AFF };
     int nb_ctx(const Cu &cu, int what) const
     {
         if (!sps.tool_cm_init) return 0;
-        const int ws = pic.w_scu, xs = cu.x >> 2, ys = cu.y >> 2, scuh = (1 << cu.log2h) >> 2, scup = ys * ws + xs;
-        const int nb[2] = { scup - ws, scup - 1 + (scuh - 1) * ws };
-        const bool in[2] = { ys > 0, xs > 0 };
+        const int ws = pic.w_scu, xs = cu.x >> 2, ys = cu.y >> 2, scuw = (1 << cu.log2w) >> 2, scuh = (1 << cu.log2h) >> 2, scup = ys * ws + xs;
+        const int nb[3] = { scup - ws, scup - 1 + (scuh - 1) * ws, scup + scuw + (scuh - 1) * ws };
+        const bool in[3] = { ys > 0, xs > 0, sps.suco && xs + scuw < ws };
         int n = 0;
-        for (int k = 0; k < 2; k++) {
+        for (int k = 0; k < 3; k++) {
             if (!in[k] || !pic.same_tile(scup, nb[k]) || !pic.cod[(size_t)nb[k]]) continue;
             n += what == CTX_SKIP ? pic.skip[(size_t)nb[k]] : what == CTX_PRED ? pic.intra[(size_t)nb[k]] : what == CTX_IBC ? pic.ibc[(size_t)nb[k]] : (!pic.aff.empty() && pic.aff[(size_t)nb[k]] != 0);
         }

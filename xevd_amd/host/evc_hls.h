@@ -46,6 +46,7 @@ struct Models {
           affine_flag[2], affine_mode[1], affine_mrg[5], affine_mvp_idx[1], affine_mvd_flag[2],       // tool_affine: xevd_def.h:483-498
           ipm_mpm_flag[1], ipm_mpm_idx[1], ipm_chroma[1],                                            // tool_eipd: xevd_def.h intra_luma_pred_mpm_flag / _idx, intra_chroma_pred_mode
           btt_split_flag[15], btt_split_dir[5], btt_split_type[1], mode_cons[3],                        // sps_btt_flag: xevd_def.h:486-491
+          suco_flag[14],                                                                             // sps_suco_flag: xevd_def.h:489
           sig_coeff[47], gt_ab[18], last_x[21], last_y[21];                                          // tool_adcc: xevd_def.h sig_coeff_flag, coeff_abs_level_greaterAB_flag, last_sig_coeff_{x,y}_prefix
     void reset() { Model *p = (Model *)this; for (size_t i = 0; i < sizeof(Models) / sizeof(Model); i++) p[i] = 512; }     // PROB_INIT, xevd_eco.c:769-803
     // sps->tool_cm_init: every context starts from its initValue, the slice kind and the slice QP (xevd_eco_sbac_ctx_initialize, src_base/xevd_util.c:1243-1274;
@@ -69,7 +70,7 @@ struct Models {
         CM(split); CM(run); CM(last); CM(level); CM(cbf_luma); CM(cbf_cb); CM(cbf_cr); CM(cbf_all); CM(pred_mode); CM(direct); CM(inter_dir); CM(intra_dir); CM(mvp_idx);
         CM(mvd); CM(refi); CM(dqp); CM(skip); CM(ats_mode); CM(ats_inter_flag); CM(ats_inter_quad); CM(ats_inter_hor); CM(ats_inter_pos); CM(alf_ctb); CM(mmvd_flag);
         CM(mmvd_merge_idx); CM(mmvd_dist_idx); CM(mmvd_dir_idx); CM(mmvd_group_idx); CM(mvr_idx); CM(merge_mode); CM(merge_idx); CM(bi_idx); CM(ibc_flag); CM(affine_flag);
-        CM(affine_mode); CM(affine_mrg); CM(affine_mvp_idx); CM(affine_mvd_flag); CM(ipm_mpm_flag); CM(ipm_mpm_idx); CM(ipm_chroma); CM(btt_split_flag); CM(btt_split_dir); CM(btt_split_type); CM(mode_cons); CM(sig_coeff); CM(gt_ab); CM(last_x); CM(last_y);
+        CM(affine_mode); CM(affine_mrg); CM(affine_mvp_idx); CM(affine_mvd_flag); CM(ipm_mpm_flag); CM(ipm_mpm_idx); CM(ipm_chroma); CM(btt_split_flag); CM(btt_split_dir); CM(btt_split_type); CM(mode_cons); CM(suco_flag); CM(sig_coeff); CM(gt_ab); CM(last_x); CM(last_y);
 #undef CM
     }
 };
@@ -117,6 +118,7 @@ struct Sps { int width = 0, height = 0, bd_l = 8, bd_c = 8, log2_sub_gop = 0, lo
              int tool_rpl = 0, tool_pocs = 0, poc_lsb_bits = 4;      // sps->tool_rpl: reference lists and marking from signalled RPLs; tool_pocs: POC from poc_lsb in the slice header
              int n_rpl[2] = { 0, 0 }; Rpl rpls[2][32];               // RPL candidates of the SPS (sps->rpls_l0 / rpls_l1)
              int btt = 0, log2_min_cb = 2, split_tbl[4][2] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };      // sps_btt_flag: binary / ternary splits; allowed long sides (min, max) per shape 1:1, 1:2, 1:4, TT
+             int suco = 0, suco_raw[2] = { 0, 0 };     // sps_suco_flag: a split node may code its parts right to left; log2_diff_ctu_size_max_suco_cb_size, log2_diff_max_suco_min_suco_cb_size
              int btt_raw[4] = { 0, 0, 0, 0 };         // the SPS fields behind split_tbl (min cb - 2, diff max 1:4, diff max TT, diff min TT - 2)
              int tool_cm_init = 0, tool_adcc = 0;     // sps->tool_cm_init: contexts start from tables (slice kind, QP) and several flags pick theirs from the neighbours; tool_adcc
              int dquant = 0;                         // sps->dquant_flag (Main): QP deltas per quantisation group of pps.cu_qp_delta_area instead of per coded CU

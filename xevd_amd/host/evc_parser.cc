@@ -52,7 +52,7 @@ struct TileParser {
         if (dec.tile_end() != 1) return fail("missing end-of-tile flag");
         return XGPU_OK;
     }
-    int parse_tree(Dec &dec, int x, int y, int log2s, int qp_code = 0)
+    int parse_tree(Dec &dec, int x, int y, int log2s, int qp_code = 0, int suco = 0)
     {
         const int s = 1 << log2s;
         int split = 0;
@@ -60,16 +60,19 @@ struct TileParser {
         qp_code = qp_group(st, tc, split ? TileCoder::QUAD : 0, log2s, log2s, qp_code);
         if (split) {
             const int h = s >> 1;
-            for (int i = 0; i < 4; i++) {
-                const int nx = x + (i & 1) * h, ny = y + (i >> 1) * h;
-                if (nx < st.sps.width && ny < st.sps.height) { const int rc = parse_tree(dec, nx, ny, log2s - 1, qp_code); if (rc != XGPU_OK) return rc; }
+            suco = tc.code_suco(dec, 0, TileCoder::QUAD, log2s, log2s, !(x + s <= st.sps.width && y + s <= st.sps.height), suco);
+            int order[4];
+            TileCoder::part_order(TileCoder::QUAD, suco, 4, order);
+            for (int k = 0; k < 4; k++) {
+                const int i = order[k], nx = x + (i & 1) * h, ny = y + (i >> 1) * h;
+                if (nx < st.sps.width && ny < st.sps.height) { const int rc = parse_tree(dec, nx, ny, log2s - 1, qp_code, suco); if (rc != XGPU_OK) return rc; }
             }
             return XGPU_OK;
         }
         return leaf(dec, x, y, log2s, log2s, qp_code, 0);
     }
-    // sps_btt_flag: a node of the binary / ternary split tree (xevd_entropy_decode_tree, src_main/xevdm.c:1644-1850, without SUCO)
-    int parse_node(Dec &dec, int x, int y, int lw, int lh, int qp_code, bool only_inter, bool only_intra = false)
+    // sps_btt_flag: a node of the binary / ternary split tree (xevd_entropy_decode_tree, src_main/xevdm.c:1644-1850)
+    int parse_node(Dec &dec, int x, int y, int lw, int lh, int qp_code, bool only_inter, bool only_intra = false, int suco = 0)
     {
         const int W = st.sps.width, H = st.sps.height, w = 1 << lw, h = 1 << lh, mn = 1 << st.sps.log2_min_cb;
         int split = TileCoder::NO_SPLIT;
@@ -84,11 +87,15 @@ struct TileParser {
         }
         qp_code = qp_group(st, tc, split, lw, lh, qp_code);
         if (split == TileCoder::NO_SPLIT) { last_qp_code = qp_code; return leaf(dec, x, y, lw, lh, qp_code, only_inter, only_intra ? 1 : 0); }
+        suco = tc.code_suco(dec, 0, split, lw, lh, !(x + w <= W && y + h <= H), suco);
         const int mc = only_intra ? 0 : tc.code_mode_cons(dec, split, lw, lh, only_inter, 0);
-        int px[3], py[3], plw[3], plh[3];
+        int px[3], py[3], plw[3], plh[3], order[4];
         const int n = TileCoder::split_parts(split, x, y, lw, lh, px, py, plw, plh);
-        for (int i = 0; i < n; i++)
-            if (px[i] < W && py[i] < H) { const int rc = parse_node(dec, px[i], py[i], plw[i], plh[i], qp_code, mc == 1, only_intra || mc < 0); if (rc != XGPU_OK) return rc; }
+        TileCoder::part_order(split, suco, n, order);
+        for (int k = 0; k < n; k++) {
+            const int i = order[k];
+            if (px[i] < W && py[i] < H) { const int rc = parse_node(dec, px[i], py[i], plw[i], plh[i], qp_code, mc == 1, only_intra || mc < 0, suco); if (rc != XGPU_OK) return rc; }
+        }
         // local dual tree: the luma CUs above, now the node's chroma block as one CU (xevdm.c:1828-1833; core->cu_qp_delta_code keeps the last leaf's value)
         if (mc < 0) return leaf(dec, x, y, lw, lh, last_qp_code, 0, 2);
         return XGPU_OK;
@@ -266,8 +273,10 @@ struct xhost_parser {
                 s.split_tbl[1][1] = 6; s.split_tbl[1][0] = s.log2_min_cb + 1;
                 s.split_tbl[2][1] = std::min(6 - s.btt_raw[1], 6); s.split_tbl[2][0] = s.log2_min_cb + 2;
                 s.split_tbl[3][1] = std::min(6 - s.btt_raw[2], 6); s.split_tbl[3][0] = s.log2_min_cb + s.btt_raw[3] + 2;
-            }
-            unsupported |= br.get1();                    // sps_suco_flag
+            } else s.log2_min_cb = 2;
+            s.suco = br.get1();                          // sps_suco_flag + the CU sizes that may choose (xevdm_eco.c:1872-1877)
+            s.suco_raw[0] = s.suco_raw[1] = 0;
+            if (s.suco) { s.suco_raw[0] = (int)br.ue(); s.suco_raw[1] = (int)br.ue(); if (br.overrun || s.suco_raw[0] > 6 || s.suco_raw[1] > 6) return fail("bad SPS: SUCO sizes"); }
             s.tool_admvp = br.get1();
             s.tool_amvr = s.tool_hmvp = s.tool_dmvr = s.tool_mmvd = s.tool_affine = 0;
             if (s.tool_admvp) { s.tool_affine = br.get1(); s.tool_amvr = br.get1(); s.tool_dmvr = br.get1(); s.tool_mmvd = br.get1(); s.tool_hmvp = br.get1(); }      // tool_affine, tool_amvr, tool_dmvr, tool_mmvd, tool_hmvp
@@ -288,7 +297,7 @@ struct xhost_parser {
         // core->mv (xevdm_util.c:4384-4387), which is what the history buffer then receives (xevdm.c:1335-1342), and an MMVD CU builds its merge list from
         // ctx->map_mv, the refined vectors (xevdm_util.c:246-247): the syntax of later CUs of the SAME picture depends on the refinement search.  The
         // front end then searches itself (TileCoder::commit, dmvr_search.h) on the reference samples the caller registers (xhost_parser_set_ref_luma)
-        if (unsupported) return fail("the stream uses tools this front end does not parse (sps_suco_flag)");
+        if (unsupported) return fail("a Baseline SPS with a Main profile tool flag");
         // xevdm_eco.c:1920-1961: POC lsb width (tool_pocs), the sub-GOP description unless both tools are on, and either the sliding-window size or the RPL candidates
         s.tool_rpl = rpl; s.tool_pocs = pocs;
         s.log2_sub_gop = s.log2_ref_gap = 0;

@@ -26,7 +26,8 @@ struct xhost_writer {
         else {
             bw.put1(st.sps.btt);                         // sps_btt_flag: log2_ctu_size_minus5 (1 = 64), log2_min_cb_size_minus2, the three limits of the split table
             if (st.sps.btt) { bw.ue(1); for (int i = 0; i < 4; i++) bw.ue((uint32_t)st.sps.btt_raw[i]); }
-            bw.put1(0);                                  // sps_suco_flag
+            bw.put1(st.sps.suco);                        // sps_suco_flag + the two size limits
+            if (st.sps.suco) { bw.ue((uint32_t)st.sps.suco_raw[0]); bw.ue((uint32_t)st.sps.suco_raw[1]); }
             bw.put1(sp.tool_admvp ? 1 : 0);
             if (sp.tool_admvp) { bw.put1(sp.tool_affine ? 1 : 0); bw.put1(sp.tool_amvr ? 1 : 0); bw.put1(sp.tool_dmvr ? 1 : 0); bw.put1(sp.tool_mmvd ? 1 : 0); bw.put1(sp.tool_hmvp ? 1 : 0); }      // affine amvr dmvr mmvd hmvp
             bw.put1(sp.tool_eipd ? 1 : 0);
@@ -114,6 +115,8 @@ extern "C" xhost_writer *xhost_writer_open(const xhost_stream_params *sp)
     w->sp.tool_hmvp = s.tool_admvp && sp->tool_hmvp; s.tool_hmvp = w->sp.tool_hmvp;
     w->sp.tool_affine = s.tool_admvp && sp->tool_affine; s.tool_affine = w->sp.tool_affine;
     w->st.enc_side = true;
+    s.suco = s.profile_main && sp->suco;
+    s.suco_raw[0] = s.suco ? std::min(std::max(sp->suco_diff_max, 0), 6) : 0; s.suco_raw[1] = s.suco ? std::min(std::max(sp->suco_diff_min, 0), 6) : 0;
     s.btt = s.profile_main && sp->btt;
     if (s.btt) {
         s.btt_raw[0] = std::min(std::max(sp->btt_log2_min_cb - 2, 0), 4); s.btt_raw[1] = std::min(std::max(sp->btt_diff_max_14, 0), 6);
@@ -254,7 +257,9 @@ struct TreeWriter {
     std::vector<int> leaf;        // CU index by SCU position of its top-left corner, -1 elsewhere
     int bd_off;
     int error = 0;
-    void node(int x, int y, int log2s, int qp_code = 0)
+    // sps_suco_flag: the writer's choice for a node that may choose - a hash of its position, so about half of them run right to left
+    static int suco_want(int x, int y, int lw, int lh) { return (((x >> 3) * 5 + (y >> 3) * 3 + lw + 2 * lh) >> 1) & 1; }
+    void node(int x, int y, int log2s, int qp_code = 0, int suco = 0)
     {
         Stream &st = w->st;
         TileCoder &tcd = w->coder;
@@ -266,9 +271,12 @@ struct TreeWriter {
         qp_code = qp_group(st, tcd, is_leaf ? 0 : TileCoder::QUAD, log2s, log2s, qp_code);
         if (!is_leaf) {
             const int h = s >> 1;
-            for (int q = 0; q < 4; q++) {
-                const int nx = x + (q & 1) * h, ny = y + (q >> 1) * h;
-                if (nx < st.sps.width && ny < st.sps.height) node(nx, ny, log2s - 1, qp_code);
+            suco = tcd.code_suco(*enc, suco_want(x, y, log2s, log2s), TileCoder::QUAD, log2s, log2s, !(x + s <= st.sps.width && y + s <= st.sps.height), suco);
+            int order[4];
+            TileCoder::part_order(TileCoder::QUAD, suco, 4, order);
+            for (int k = 0; k < 4; k++) {
+                const int q = order[k], nx = x + (q & 1) * h, ny = y + (q >> 1) * h;
+                if (nx < st.sps.width && ny < st.sps.height) node(nx, ny, log2s - 1, qp_code, suco);
             }
             return;
         }
@@ -332,7 +340,7 @@ struct TreeWriter {
         }
         return false;
     }
-    void node_btt(int x, int y, int lw, int lh, int qp_code, bool only_inter, bool only_intra = false)
+    void node_btt(int x, int y, int lw, int lh, int qp_code, bool only_inter, bool only_intra = false, int suco = 0)
     {
         Stream &st = w->st;
         TileCoder &tcd = w->coder;
@@ -343,10 +351,12 @@ struct TreeWriter {
         if (split == TileCoder::NO_SPLIT) { last_qp_code = qp_code; write_leaf(leaf[(size_t)(y >> 2) * st.pic.w_scu + (x >> 2)], qp_code, only_inter, only_intra ? 1 : 0); return; }
         const auto cc = chroma_cu.find(node_key(x, y, lw, lh, 0));
         const bool dual = !only_inter && !only_intra && cc != chroma_cu.end();
+        suco = tcd.code_suco(*enc, suco_want(x, y, lw, lh), split, lw, lh, !(x + wd <= W && y + ht <= H), suco);
         const int mc = only_intra ? 0 : tcd.code_mode_cons(*enc, split, lw, lh, only_inter, dual ? 0 : 1);
-        int px[3], py[3], plw[3], plh[3];
+        int px[3], py[3], plw[3], plh[3], order[4];
         const int n = TileCoder::split_parts(split, x, y, lw, lh, px, py, plw, plh);
-        for (int k = 0; k < n; k++) if (px[k] < W && py[k] < H) node_btt(px[k], py[k], plw[k], plh[k], qp_code, mc == 1, only_intra || mc < 0);
+        TileCoder::part_order(split, suco, n, order);
+        for (int j = 0; j < n; j++) { const int k = order[j]; if (px[k] < W && py[k] < H) node_btt(px[k], py[k], plw[k], plh[k], qp_code, mc == 1, only_intra || mc < 0, suco); }
         if (mc < 0) { if (cc == chroma_cu.end()) { error = 1; return; } write_leaf(cc->second, last_qp_code, 0, 2); }
     }
     void write_leaf(int i, int qp_code, int only_inter, int tree = 0)

@@ -22,7 +22,8 @@ class StreamParams(C.Structure):
                 ("cqt_num_points", C.c_int * 2), ("cqt_delta_in", (C.c_int * 16) * 2), ("cqt_delta_out", (C.c_int * 16) * 2), ("tool_htdf", C.c_int), ("tool_admvp", C.c_int), ("tool_mmvd", C.c_int), ("tool_dmvr", C.c_int), ("tool_amvr", C.c_int), ("tool_hmvp", C.c_int), ("ibc_log_max_size", C.c_int),
                 ("tile_cols", C.c_int), ("tile_rows", C.c_int), ("tile_col_w", C.c_int * abi.XGPU_MAX_TILE_COLS), ("tile_row_h", C.c_int * abi.XGPU_MAX_TILE_ROWS),
                 ("loop_filter_across_tiles", C.c_int), ("tool_affine", C.c_int), ("cu_qp_delta_area", C.c_int), ("tool_rpl", C.c_int), ("tool_pocs", C.c_int), ("tool_cm_init", C.c_int), ("tool_adcc", C.c_int),
-                ("btt", C.c_int), ("btt_log2_min_cb", C.c_int), ("btt_diff_max_14", C.c_int), ("btt_diff_max_tt", C.c_int), ("btt_diff_min_tt", C.c_int), ("rpl_in_sps", C.c_int)]
+                ("btt", C.c_int), ("btt_log2_min_cb", C.c_int), ("btt_diff_max_14", C.c_int), ("btt_diff_max_tt", C.c_int), ("btt_diff_min_tt", C.c_int), ("rpl_in_sps", C.c_int),
+                ("suco", C.c_int), ("suco_diff_max", C.c_int), ("suco_diff_min", C.c_int)]
 
 
 class AlfAps(C.Structure):
@@ -99,7 +100,7 @@ class StreamWriter:
     def __init__(self, width, height, bit_depth=8, max_num_ref_pics=1, qp_u_offset=0, qp_v_offset=0, deblock=True, cu_qp_delta=True,
                  log2_sub_gop=0, main=False, iqt=False, ats=False, addb=False, alpha_off=0, beta_off=0, alf=False, eipd=False, crop=(0, 0, 0, 0),
                  chroma_qp_points=None, dra_aps_id=None, htdf=False, ibc_log_max=0, admvp=False, amvr=False, hmvp=False, dmvr=False, mmvd=False,
-                 tiles=None, affine=False, qp_delta_area=0, rpl=False, pocs=False, rpl_in_sps=False, cm_init=False, adcc=False, btt=None):
+                 tiles=None, affine=False, qp_delta_area=0, rpl=False, pocs=False, rpl_in_sps=False, cm_init=False, adcc=False, btt=None, suco=None):
         """chroma_qp_points: None, or (global_offset_flag, [table, ...]) with 1 (same for Cb and Cr) or 2 tables of (delta_in_minus1, delta_out) pairs"""
         self.lib = load()
         sp = StreamParams(width, height, bit_depth, max_num_ref_pics, log2_sub_gop, qp_u_offset, qp_v_offset, int(deblock), int(cu_qp_delta),
@@ -123,6 +124,8 @@ class StreamWriter:
         sp.tool_cm_init, sp.tool_adcc = int(cm_init), int(adcc)
         if btt is not None:      # (log2 of the smallest CU side, log2_diff_ctu_max_14_cb_size, log2_diff_ctu_max_tt_cb_size, log2_diff_min_cb_min_tt_cb_size_minus2)
             sp.btt, sp.btt_log2_min_cb, sp.btt_diff_max_14, sp.btt_diff_max_tt, sp.btt_diff_min_tt = 1, int(btt[0]), int(btt[1]), int(btt[2]), int(btt[3])
+        if suco is not None:     # (log2_diff_ctu_size_max_suco_cb_size, log2_diff_max_suco_min_suco_cb_size)
+            sp.suco, sp.suco_diff_max, sp.suco_diff_min = 1, int(suco[0]), int(suco[1])
         if dra_aps_id is not None:
             sp.tool_dra, sp.dra_aps_id = 1, int(dra_aps_id)
         if chroma_qp_points is not None:
