@@ -222,6 +222,16 @@ def golden_streams(only=()):
                                                                                       slices=[(0, 3, 28, 1), (4, 7, 33, 0), (8, 11, -1, 1), (12, 15, 35, 1)])),
                                 "main_slices_columns_arbitrary_8b": (384, 256, 5, dict(main=True, pocs=True, iqt=True, addb=True, alf=True, admvp=True, affine=True, dmvr=True, max_refs=2,
                                                                                        tiles=(3, 2, 1), slices=[(0, 3, 31), (1, 5, 25)], arbitrary_slices=True)),
+                                # sps_suco_flag: split nodes coded right to left - right-hand neighbours in candidate lists, contexts, most probable modes and intra prediction
+                                "main_suco_eipd_i_8b": (136, 120, 2, dict(main=True, suco=(0, 2), eipd=True, idr_period=1, split_prob=0.7)),
+                                "main_suco_p_8b": (136, 72, 4, dict(main=True, suco=(0, 2), max_refs=2)),
+                                "main_suco_quad_all_tools_10b": (264, 136, 9, dict(main=True, suco=(0, 2), admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, iqt=True, ats=True, addb=True, alf=True,
+                                                                                   eipd=True, htdf=True, ibc_log_max=4, cm_init=True, adcc=True, qp_delta_area=8, max_refs=2, log2_sub_gop=2, split_prob=0.6,
+                                                                                   bit_depth=10, inter_frac=0.6, skip_frac=0.3, direct_frac=0.3)),
+                                "main_suco_btt_all_tools_10b": (264, 200, 9, dict(main=True, suco=(0, 2), btt=(2, 0, 0, 0), admvp=True, dual_tree=True, affine=True, amvr=True, hmvp=True, mmvd=True, dmvr=True,
+                                                                                  iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=4, cm_init=True, adcc=True, qp_delta_area=8,
+                                                                                  max_refs=2, log2_sub_gop=2, split_prob=0.7, bit_depth=10, inter_frac=0.7, skip_frac=0.3, direct_frac=0.3)),
+                                "main_suco_tiles_dbk_8b": (392, 264, 5, dict(main=True, suco=(0, 3), eipd=True, htdf=True, tiles=(2, 2, 0), max_refs=2, split_prob=0.7, inter_frac=0.6)),
                                 "main_alf_fixed_8b": (264, 136, 8, dict(main=True, alf=True, addb=True, alf_fixed=True)),
                                 "main_ibc_i_8b": (136, 72, 3, dict(main=True, eipd=True, ibc_log_max=4, ibc_frac=0.4, idr_period=1)),
                                 "main_ibc_all_tools_10b": (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=5, inter_frac=0.5, log2_sub_gop=2, max_refs=2, bit_depth=10))}.items():

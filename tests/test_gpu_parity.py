@@ -487,7 +487,7 @@ REF_DECODE_HIP = os.path.normpath(os.path.join(golden_io.GOLDEN, "..", "..", "or
 # ... and not the streams with tool_dmvr together with tool_hmvp / tool_mmvd: the refined vectors steer the reference parser's own candidate lists CU by CU, and a backend
 # behind the picture-granular slots (fn_dec_slice ...) reconstructs after the picture is parsed - our own front end runs the refinement search itself for those
 # (xevd_amd/host/dmvr_search.h); they are decoded by every other path below
-HOST_DMVR_STREAMS = {"main_dmvr_hmvp_mmvd_b_8b", "main_every_tool_10b", "main_every_tool_tiles_8b"}
+HOST_DMVR_STREAMS = {"main_dmvr_hmvp_mmvd_b_8b", "main_every_tool_10b", "main_every_tool_tiles_8b", "main_suco_btt_all_tools_10b"}
 STREAM_NAMES = sorted(f[len("stream_"):-len(".npz")] for f in os.listdir(golden_io.GOLDEN)
                       if f.startswith("stream_") and f.endswith(".npz") and "main_" in f and f[len("stream_"):-len(".npz")] not in HOST_DMVR_STREAMS)
 

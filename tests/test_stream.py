@@ -171,12 +171,40 @@ CONFIGS = [
     (200, 136, 8, dict(main=True, admvp=True, dmvr=True, hmvp=True, mmvd=True, inter_frac=0.9, max_refs=4, skip_frac=0.3, direct_frac=0.3)),
     (392, 264, 9, dict(main=True, admvp=True, amvr=True, hmvp=True, mmvd=True, dmvr=True, affine=True, iqt=True, addb=True, alf=True, inter_frac=0.95, skip_frac=0.3, direct_frac=0.3,
                        max_refs=2, log2_sub_gop=2, tiles=(2, 2, 0))),
+    # sps_suco_flag: split nodes coded right to left (the flag's syntax and inheritance, quad / binary / ternary order) - right-hand neighbours in the flag and split contexts,
+    # the most probable intra modes (a third neighbour mode), merge / AMVP / affine candidates and their temporal positions, EIPD prediction from a right reference column
+    # (LR_01 / LR_11 forms of DC, horizontal, planar, bilinear, angular), HTDF borders; with quad trees (many reversed nodes) and BTT
+    (136, 72, 2, dict(main=True, suco=(0, 2), idr_period=1, split_prob=0.8)),
+    (136, 72, 2, dict(main=True, suco=(0, 2), eipd=True, idr_period=1, split_prob=0.8)),
+    (200, 136, 5, dict(main=True, suco=(0, 2), eipd=True, inter_frac=0.4, max_refs=2)),
+    (200, 136, 9, dict(main=True, suco=(0, 2), cm_init=True, max_refs=2, log2_sub_gop=2)),
+    (136, 72, 3, dict(main=True, suco=(0, 2), htdf=True, inter_frac=0.6)),
+    (200, 136, 9, dict(main=True, suco=(0, 2), admvp=True, hmvp=True, amvr=True, inter_frac=0.9, max_refs=2, log2_sub_gop=2)),
+    (200, 136, 4, dict(main=True, suco=(0, 2), admvp=True, mmvd=True, inter_frac=0.9, skip_frac=0.35, direct_frac=0.3, max_refs=1)),
+    (392, 264, 6, dict(main=True, suco=(0, 2), admvp=True, affine=True, inter_frac=0.95, split_prob=0.35, skip_frac=0.3, direct_frac=0.3, max_refs=2)),
+    (264, 200, 4, dict(main=True, suco=(1, 1), btt=(3, 1, 1, 1), max_refs=2, split_prob=0.8)),
+    (264, 136, 6, dict(main=True, suco=(0, 2), eipd=True, addb=True, ibc_log_max=3, ibc_frac=0.6, inter_frac=0.5)),
+    (264, 200, 9, dict(main=True, suco=(0, 2), btt=(2, 0, 0, 0), admvp=True, dual_tree=True, affine=True, amvr=True, hmvp=True, mmvd=True, dmvr=True, iqt=True, ats=True, addb=True, alf=True, eipd=True,
+                       htdf=True, ibc_log_max=4, cm_init=True, adcc=True, qp_delta_area=8, max_refs=2, log2_sub_gop=2, split_prob=0.7, bit_depth=10, inter_frac=0.7, skip_frac=0.3, direct_frac=0.3)),
+    (392, 264, 9, dict(main=True, suco=(0, 3), cm_init=True, admvp=True, dmvr=True, addb=True, inter_frac=0.95, skip_frac=0.3, direct_frac=0.3, max_refs=2, log2_sub_gop=2, tiles=(2, 2, 0))),
     # every Main tool the front end knows at once - the shape of a real Main-profile encode
     (264, 200, 17, dict(main=True, btt=(2, 0, 0, 0), admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, dmvr=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True,
                         cm_init=True, adcc=True, rpl=True, pocs=True, qp_delta_area=8, max_refs=2, log2_sub_gop=3, split_prob=0.7, bit_depth=10, inter_frac=0.9, skip_frac=0.3, direct_frac=0.3)),
     (264, 200, 9, dict(main=True, btt=(2, 0, 0, 0), admvp=True, dual_tree=True, affine=True, amvr=True, hmvp=True, mmvd=True, dmvr=True, iqt=True, ats=True, addb=True, alf=True, eipd=True,
                        htdf=True, ibc_log_max=4, cm_init=True, adcc=True, qp_delta_area=8, max_refs=2, log2_sub_gop=2, split_prob=0.7, bit_depth=10, inter_frac=0.7, skip_frac=0.3, direct_frac=0.3)),
 ]
+
+
+def _right_first(b, w, h):
+    """number of CUs of a parsed batch whose right-hand neighbour SCU belongs to a CU that comes before them in decoding order"""
+    ws, hs = (w + 3) // 4, (h + 3) // 4
+    own = -np.ones((hs, ws), np.int64)
+    n = 0
+    for i, (x, y, lw, lh) in enumerate(zip(b["x"], b["y"], b["log2w"], b["log2h"])):
+        xs, ys, sw, sh = int(x) // 4, int(y) // 4, (1 << int(lw)) // 4, (1 << int(lh)) // 4
+        n += int(xs + sw < ws and own[ys, xs + sw] >= 0)
+        own[ys:ys + sh, xs:xs + sw] = i
+    return n
 
 
 @pytest.mark.ref
@@ -194,6 +222,8 @@ def test_stream_reference_decoder_equals_parser_plus_oracle(cfg):
         assert sum(int(((p["batch"]["dmvr"] > 0) & (p["batch"]["refi"].min(1) >= 0) & (p["batch"]["log2w"] >= 3) & (p["batch"]["log2h"] >= 3)).sum()) for p in pics if p["batch"]["dmvr"] is not None) >= 10
     if kw.get("ats"):      # the stream really carries both kinds of ATS CUs
         assert sum(int((p["batch"]["ats"] & 1).sum()) for p in pics) > 0 and sum(int((p["batch"]["ats_inter"] != 0).sum()) for p in pics) > 0
+    if kw.get("suco"):     # CUs with their right-hand neighbour decoded first exist
+        assert sum(_right_first(p["batch"], w, h) for p in pics) >= 20
     if kw.get("eipd"):     # angular luma modes and all five chroma modes occur
         intra = np.concatenate([p["batch"]["ipm"][p["batch"]["pred_mode"] == 0] for p in pics])
         assert len(set(intra[:, 0].tolist())) > 20 and set(intra[:, 1].tolist()) == {0, 1, 2, 3, 4}

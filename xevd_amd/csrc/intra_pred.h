@@ -59,12 +59,15 @@ __device__ __forceinline__ void st_coherent2(int16_t *p, uint32_t lo, uint32_t h
 
 // ---------------------------------------------------------------------------------------------------------
 // sps->tool_eipd (Main): 33 luma modes - DC 0, planar 1, bilinear 2, angular 3..32 with VER 12 / HOR 24 - and chroma DM / BI / DC /
-// HOR / VER (xevdm_ipred / xevdm_ipred_uv, src_main/xevdm_ipred.c:241-305; predictors src_base/xevd_ipred.c:110-585), for blocks
-// without right-hand neighbours (SUCO off).  The neighbour arrays follow xevdm_get_nbr (xevdm_ipred.c:39-148): an unavailable
+// HOR / VER (xevdm_ipred / xevdm_ipred_uv, src_main/xevdm_ipred.c:241-305; predictors src_base/xevd_ipred.c:110-585).  The neighbour arrays follow xevdm_get_nbr (xevdm_ipred.c:39-148): an unavailable
 // unit REPEATS the sample before it (towards the corner; the mid value only where nothing precedes), an unavailable corner takes
 // up[0].  Every predictor is a function of (i, j) and the arrays, so a lane evaluates its 4x4 (2x2) samples independently.
 // ---------------------------------------------------------------------------------------------------------
-struct EipdPlan { int mode, p0, p1, p2; };      // wave-uniform: DC p0 = value; planar p0 = base, p1 = b, p2 = c; bilinear p0 = a, p1 = b, p2 = wt; angular p0 = dx, p1 = dy
+struct EipdPlan { int mode, p0, p1, p2, lr; };  // wave-uniform: DC p0 = value; planar p0 = base, p1 = b, p2 = c; bilinear p0 = a, p1 = b, p2 = wt; angular p0 = dx, p1 = dy
+                                                // lr = avail_lr (xevd_check_nev_avail): bit 0 the column left of the block is reconstructed, bit 1 the one to its right (SUCO)
+// The right column (sps_suco_flag: a split coded right to left leaves a block with its RIGHT neighbours reconstructed; xevdm_get_nbr :123-147) takes the place of the
+// Baseline-only arrays: right[p] = A[NB_UR + 1 + p], p = -1 .. w+h-1, right[-1] = up[w].  It is staged, and the LR_01 / LR_11 forms of the predictors run, only
+// for blocks with lr & 2; everything else takes the paths below unchanged.
 
 // sum over the 64 lanes, the same value in every lane: two quad permutes and two mirrors in DPP leave every lane of a row of 16 with the row's sum, the four row
 // sums meet on the scalar unit (six rounds of __shfl_xor were six LDS-crossbar round trips on the critical path of every DC / planar CU of a dependency chain)
@@ -88,9 +91,99 @@ __device__ __forceinline__ void ang_slopes(int mode, int &dx, int &dy)      // x
     for (int k = 0; k < 11; k++) { if (k == a) dx = u[k]; if (k == b) dy = u[k]; }
 }
 // mode: a LUMA mode number (chroma modes are mapped by the caller); A = the component's neighbour array; all lanes take part
-__device__ __forceinline__ EipdPlan eipd_plan(const int16_t *A, int mode, int w, int h, int lw, int lh, int t)
+// ... with a reconstructed right column (lr 2: only that one, lr 3: both): xevdm_ipred_dc / xevdm_ipred_hor (xevdm_ipred.c:153-229), xevd_ipred_plane / xevd_ipred_bi (xevd_ipred.c:
+// 163-369), first branches
+__device__ __forceinline__ EipdPlan eipd_plan_lr(const int16_t *A, int mode, int w, int h, int lw, int lh, int t, int lr)
 {
-    EipdPlan k = { mode, 0, 0, 0 };
+    EipdPlan k = { mode, 0, 0, 0, lr };
+    const int16_t *up = A + NB_C0 + 1, *ri = A + NB_UR + 1;
+    const int inv[8] = { 2048, 1365, 819, 455, 241, 124, 63, 32 };
+    int inv_w = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) if (q == lw) inv_w = inv[q];
+    if (mode == 0) {
+        int acc = 0;
+        for (int e = t; e < w + h; e += 64) acc += e < h ? ((lr & 1) ? A[NB_C0 - 1 - e] : 0) + ri[e] : up[e - h];
+        const int lhh = lr == 3 ? lh + 1 : lh, hh = lr == 3 ? h << 1 : h, asp = lw > lhh ? lw - lhh : lhh - lw;
+        int m = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) if (q == asp) m = inv[q];
+        k.p0 = ((wave_sum(acc) + ((w + hh) >> 1)) * m) >> (min(lw, lhh) + 12);
+    } else if (mode == 1) {                            // the mirror image: gradients towards the left, anchored at the bottom-right and top-left samples
+        const int mult[6] = { 13, 17, 5, 11, 23, 47 }, shift[6] = { 7, 10, 11, 15, 19, 23 };
+        const int w2 = w >> 1, h2 = h >> 1, iw = max(lw - 2, 0), ih = max(lh - 2, 0);
+        int ch = 0, cv = 0;
+        for (int x = 1 + t; x <= w2; x += 64) ch += x * (up[w2 - x] - up[w2 + x]);
+        for (int y = 1 + t; y <= h2; y += 64) cv += y * (ri[h2 - 1 + y] - ri[h2 - 1 - y]);
+        ch = wave_sum(ch); cv = wave_sum(cv);
+        int mh = 0, sh = 0, mv = 0, sv = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) { if (q == iw) { mh = mult[q]; sh = shift[q]; } if (q == ih) { mv = mult[q]; sv = shift[q]; } }
+        const int a = (ri[h - 1] + up[0]) << 4;
+        k.p1 = ((ch << 5) * mh + (1 << (sh - 1))) >> sh;
+        k.p2 = ((cv << 5) * mv + (1 << (sv - 1))) >> sv;
+        k.p0 = a - (h2 - 1) * k.p2 - (w2 - 1) * k.p1 + 16;
+    } else if (mode == 2 && lr == 2) {
+        const int wc_tbl[6] = { -1, 341, 205, 114, 60, 31 };
+        const int a = up[-1], b = ri[h], ms = min(lw, lh), asp = lw > lh ? lw - lh : lh - lw;
+        int wc = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) if (q == asp) wc = wc_tbl[q];
+        const int c = w == h ? (a + b + 1) >> 1 : (((a << lw) + (b << lh)) * wc + (1 << (ms + 9))) >> (ms + 10);
+        k.p0 = a; k.p1 = b; k.p2 = (c << 1) - a - b;
+    } else if (mode == 2 || mode == 24) {
+        k.p0 = inv_w;                                  // both columns: rows interpolated between them with 4096 / (w + 1)
+    } else if (mode != 12) {
+        ang_slopes(mode, k.p0, k.p1);
+    }
+    return k;
+}
+// ... and the sample at column i, row j of such a block (ipred_ang_val's right-column branches, xevd_ipred.c:377-569)
+__device__ __forceinline__ int eipd_sample_lr(const int16_t *A, const EipdPlan &k, int i, int j, int w, int h, int lw, int lh, int maxv)
+{
+    const int mode = k.mode, lr = k.lr;
+    const int16_t *up = A + NB_C0 + 1, *ri = A + NB_UR + 1;
+    auto le = [&](int p) -> int { return A[NB_C0 - 1 - p]; };
+    if (mode == 12) return up[i];
+    if (mode == 24) return lr == 3 ? ((le(j) * (w - i) + ri[j] * (i + 1) + (w >> 1)) * k.p0) >> 12 : ri[j];
+    if (mode == 0) return k.p0;
+    if (mode == 1) return clip3i(0, maxv, (k.p0 + j * k.p2 + (w - 1 - i) * k.p1) >> 5);
+    if (mode == 2) {
+        if (lr == 3) {
+            const int row = ((le(j) * (w - i) + ri[j] * (i + 1) + (w >> 1)) * k.p0) >> 12, bot = ((le(h - 1) * (w - i) + ri[h - 1] * (i + 1) + (w >> 1)) * k.p0) >> 12;
+            return (row + ((up[i] * (h - 1 - j) + bot * (j + 1) + (h >> 1)) >> lh) + 1) >> 1;
+        }
+        const int d = w - 1 - i, col = ri[j], u = up[i];
+        const int px = (col << lw) + (d + 1) * (k.p0 - col), py = (u << lh) + (j + 1) * (k.p1 - u);
+        return clip3i(0, maxv, ((px << lh) + (py << lw) + d * j * k.p2 + (1 << (lw + lh))) >> (lw + lh + 1));
+    }
+    int p, o, dir, src;                                // src 0 up, 1 left, 2 right
+    auto pos = [&](int mt, int d, int &q) { q = (d * mt) >> 10; o = ((d * mt) >> 5) & 31; };
+    if (mode < 12) {
+        int tq;
+        pos(k.p0, j + 1, tq);
+        if (i >= w - tq) { pos(k.p1, w - i, tq); p = j - tq; src = 2; dir = -1; }
+        else { p = i + tq; src = 0; dir = 1; }
+    } else if (mode > 24) {
+        int tq;
+        pos(k.p1, w - i, tq);
+        if (j < tq) { pos(k.p0, w - i, tq); p = i + tq; src = 0; dir = 1; }
+        else { p = j - tq; src = 2; dir = -1; }
+    } else {
+        int ty, tq;
+        pos(k.p1, i + 1, ty);
+        if (j < ty) { pos(k.p0, j + 1, tq); p = i - tq; src = 0; dir = -1; }
+        else if (lr == 2) { pos(k.p1, w - i, tq); p = j + tq; src = 2; dir = 1; }
+        else { p = j - ty; src = 1; dir = -1; }
+    }
+    const int hi = w + h - 1;
+    auto ref = [&](int q) -> int { q = clip3i(-1, hi, q); return src == 0 ? up[q] : src == 1 ? le(q) : ri[q]; };
+    return clip3i(0, maxv, (int)(int16_t)((ref(p - dir) * (32 - o) + ref(p) * (64 - o) + ref(p + dir) * (32 + o) + ref(p + 2 * dir) * o + 64) >> 7));
+}
+__device__ __forceinline__ EipdPlan eipd_plan(const int16_t *A, int mode, int w, int h, int lw, int lh, int t, int lr = 0)
+{
+    if (lr & 2) return eipd_plan_lr(A, mode, w, h, lw, lh, t, lr);
+    EipdPlan k = { mode, 0, 0, 0, 0 };
     const int16_t *up = A + NB_C0 + 1;
     if (mode == 0) {                                   // xevdm_ipred_dc + xevd_get_dc (xevd_ipred.c:124-144): 4096 / (2^k + 1) scaling of non-square sums
         const int inv[8] = { 2048, 1365, 819, 455, 241, 124, 63, 32 };
@@ -164,6 +257,15 @@ template <int N>
 __device__ __forceinline__ void eipd_row(const int16_t *A, const EipdPlan &k, int i0, int j, int w, int h, int lw, int lh, int maxv, int out[N])
 {
     const int mode = k.mode, hi = w + h - 1;
+    if (k.lr & 2) {                                    // (wave-uniform) a block with a reconstructed right column
+#pragma unroll 1
+        for (int q = 0; q < N; q++) {                  // (one copy of the sample function per row form: this path is rare, the kernel's size is not)
+            const int v = eipd_sample_lr(A, k, i0 + q, j, w, h, lw, lh, maxv);
+#pragma unroll
+            for (int m = 0; m < N; m++) if (m == q) out[m] = v;
+        }
+        return;
+    }
     if (mode == 12) {
 #pragma unroll
         for (int q = 0; q < N; q++) out[q] = A[NB_C0 + 1 + i0 + q];

@@ -186,26 +186,67 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
     // (Round 3: a variant that loaded the records of three more edges with the first loads, walked over them in registers and fetched a chain's samples in one batch
     //  was bit-exact and SLOWER - 30.6 / 27.7 us instead of 28 / 25 at 1080p, 90 / 81 instead of 83 / 71 at 8K: chains are rare enough that the dependent loads below
     //  are seldom executed, and the 30 extra registers cost more than they saved.)
+    // sps_suco_flag (Main library, xevdm_df.c:186-330): a vertical CU edge is reached with the LATER of its two CUs - as the left edge of the right CU or as the right
+    // edge of the left one, a CU filtering its left edge first - so a split coded right to left applies its edges right to left.  before(k): edge k - 1 is applied
+    // before edge k, from the places in decoding order (SCU_RANK) of the SCUs k - 2, k - 1, k; the CTUs themselves follow each other left to right.  An edge then
+    // reads what its EARLIER neighbours wrote: the chain to the left (below), and with SUCO possibly one to the right.
     const int alongc = DIR == 0 ? 1 : a.s_c, acrossc = DIR == 0 ? a.s_c : 1;
+    auto before = [&](uint32_t ma, uint32_t mb, uint32_t mc, int k) -> bool {
+        if (DIR != 0) return true;
+        const int cm = (1 << a.ctu_sh) - 1;
+        int da = ((SCU_RANK_OF(ma) - SCU_RANK_OF(mb)) << 21) >> 21, dc = ((SCU_RANK_OF(mc) - SCU_RANK_OF(mb)) << 21) >> 21;
+        if (((k - 1) & cm) == 0) da = -4096;                 // SCU k - 2 lies in the CTU before
+        if ((k & cm) == 0) dc = 4096;                        // SCU k starts the next CTU
+        return max(da, 0) <= max(dc, 0);
+    };
 #pragma unroll
     for (int pl = 0; pl < 2; pl++) {
         const int stt = st[1 + pl];
-        int head = pos;
+        int head = pos, tail = pos;
         if (stt) {
             int kk = k0;
-            uint4 cur = rp;                                  // record of SCU head-1
+            uint4 cur = rp, nxt = rq;                        // records of SCU head-1, head
             while (head - 1 > 0) {
                 if (!(cur.x & eflag) || (cur.x & nflag) || on_tile_border(head - 1)) break;
                 const uint4 prv = kk == k0 ? rpp : maps[kk - 2 * step];
                 const int cls = edge_class(cur, prv), qp = (cur.x >> 16) & 0x7F;
                 if (s_st[((1 + pl) * 4 + cls) * 64 + (qp & 63)] == 0) break;
-                head--; kk -= step; cur = prv;
+                if (!before(prv.x, cur.x, nxt.x, head)) break;      // that edge comes later: this one reads the original sample
+                head--; kk -= step; nxt = cur; cur = prv;
+            }
+            // a chain to the RIGHT starts only where the CU to the left of this edge comes after the CU to its right (never without SUCO)
+            if (DIR == 0 && (pos & ((1 << a.ctu_sh) - 1)) != 0 && (((SCU_RANK_OF(rp.x) - SCU_RANK_OF(rq.x)) << 21) >> 21) > 0) {
+                uint4 lft = rp, mid = rq;                    // records of SCU tail-1, tail
+                while (tail + 1 < npos) {
+                    const uint4 rgt = maps[k0 + (tail + 1 - pos)];      // SCU tail+1: its left edge is edge tail+1
+                    if (!(rgt.x & eflag) || (rgt.x & nflag) || on_tile_border(tail + 1)) break;
+                    const int cls = edge_class(rgt, mid), qp = (rgt.x >> 16) & 0x7F;
+                    if (s_st[((1 + pl) * 4 + cls) * 64 + (qp & 63)] == 0) break;
+                    if (before(lft.x, mid.x, rgt.x, tail + 1)) break;  // edge tail is applied before edge tail+1
+                    tail++; lft = mid; mid = rgt;
+                }
             }
         }
 #pragma unroll
         for (int ln = 0; ln < 2; ln++) {
             int *s = Cw[pl][ln];
             if (!stt) continue;
+            if (tail > pos) {                                // the edges to the right that come first, from the far end: each hands its B' to the one before it
+                const int16_t *p = (pl ? sv_ : su_) + cy * a.s_c + cx + ln * acrossc;
+                int prevB = 0;
+                for (int e = tail; e > pos; e--) {
+                    const int rel = (e - pos) * 2;
+                    const int ke = k0 + (e - pos) * step;
+                    const uint4 q = maps[ke], pp = maps[ke - step];
+                    const int cls = edge_class(q, pp), qp = (q.x >> 16) & 0x7F;
+                    const int ste = s_st[((1 + pl) * 4 + cls) * 64 + (qp & 63)];
+                    const int D = (e == tail) ? p[(rel + 1) * alongc] : prevB;
+                    int Bo, Co;
+                    filt_chroma(p[(rel - 2) * alongc], p[(rel - 1) * alongc], p[rel * alongc], D, ste, maxc, Bo, Co);
+                    prevB = Bo;
+                }
+                s[3] = prevB;
+            }
             int a_in = s[0];
             if (head < pos) {
                 const int16_t *p = (pl ? sv_ : su_) + cy * a.s_c + cx + ln * acrossc;

@@ -294,10 +294,11 @@ __device__ __forceinline__ void region_store(const RegionFetch &f, const RegionM
 template <int MODE>
 __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r1, bool lane_ok, int sx, int sy, int lane, int16_t *W, const LaneMap fm,
                                            const uint4 (*s_ref)[2], const uint4 *s_ltap, const uint2 *s_ctap, uint32_t pl[8], uint32_t pu[2], uint32_t pv[2],
-                                           const RegionMap *rm = nullptr, int wave = 0)
+                                           const RegionMap *rm = nullptr, int wave = 0, uint32_t own = 0)
 {
     constexpr bool UNI = MODE != 0;
     if (UNI) {
+        own = (uint32_t)__builtin_amdgcn_readfirstlane((int)own);
         r0.x = __builtin_amdgcn_readfirstlane(r0.x); r0.y = __builtin_amdgcn_readfirstlane(r0.y); r0.z = __builtin_amdgcn_readfirstlane(r0.z); r0.w = __builtin_amdgcn_readfirstlane(r0.w);
         r1.x = __builtin_amdgcn_readfirstlane(r1.x); r1.y = __builtin_amdgcn_readfirstlane(r1.y); r1.z = __builtin_amdgcn_readfirstlane(r1.z); r1.w = __builtin_amdgcn_readfirstlane(r1.w);
     } else if (!lane_ok) return false;
@@ -323,6 +324,7 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
     // ---- SCU map update (xevd_set_dec_info): intra flag, QP, skip flag, luma cbf, COD + CU-edge flags ----
     {
         uint32_t m = ((uint32_t)qp_map << 16) | ((uint32_t)intra << 15) | (1u << 31);
+        m |= SCU_RANK(own);                                      // the CU's place in decoding order: which of two neighbouring CUs the baseline deblocking filter reaches later (k_deblock.hip)
         if (pred_mode == XGPU_MODE_SKIP) m |= 1u << 23;
         const bool ibc = pred_mode == XGPU_MODE_IBC;
         if (ibc) m |= 1u << 26;                                  // MCU_SET_IBC (xevdm_def.h:325)
@@ -656,16 +658,16 @@ __global__ __launch_bounds__(256) void k_inter(const InterArgs a)
     if (region) {
         uint32_t pl[8], pu[2], pv[2];
         const RegionMap rmap = region_map(t);
-        if (inter_tile<2>(a, c0, c1, true, sx, sy, lane, s_tile, fm, s_ref, s_ltap, s_ctap, pl, pu, pv, &rmap, t >> 6)) store_tile(pl, pu, pv);
+        if (inter_tile<2>(a, c0, c1, true, sx, sy, lane, s_tile, fm, s_ref, s_ltap, s_ctap, pl, pu, pv, &rmap, t >> 6, own)) store_tile(pl, pu, pv);
         return;
     }
     if (uni) {
         uint32_t pl[8], pu[2], pv[2];
-        if (inter_tile<1>(a, c0, c1, true, sx, sy, lane, W, fm, s_ref, s_ltap, s_ctap, pl, pu, pv)) store_tile(pl, pu, pv);
+        if (inter_tile<1>(a, c0, c1, true, sx, sy, lane, W, fm, s_ref, s_ltap, s_ctap, pl, pu, pv, nullptr, 0, own)) store_tile(pl, pu, pv);
         return;
     }
     uint32_t pl[8], pu[2], pv[2];
-    if (inter_tile<0>(a, c0, c1, ok, sx, sy, lane, W, fm, s_ref, s_ltap, s_ctap, pl, pu, pv)) store_tile(pl, pu, pv);
+    if (inter_tile<0>(a, c0, c1, ok, sx, sy, lane, W, fm, s_ref, s_ltap, s_ctap, pl, pu, pv, nullptr, 0, own)) store_tile(pl, pu, pv);
 }
 
 void launch_inter(xgpu_ctx *c, const InterArgs &a)

@@ -69,7 +69,9 @@ __device__ uint32_t g_intra_prof[8 * 64];
 #else
 #define ISTAMP(k)
 #endif
-template <bool DEP, bool EIPD, bool IBC, bool HTDF, int WAVES>
+// EIPD: 0 Baseline modes, 1 sps->tool_eipd, 2 tool_eipd in a picture with CUs whose RIGHT neighbours are reconstructed first (sps_suco_flag: the right reference
+// column and the LR_01 / LR_11 predictor forms; pictures without such CUs keep the smaller instantiation)
+template <bool DEP, int EIPD, bool IBC, bool HTDF, int WAVES>
 __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, int16_t *s_nb_, uint32_t *s_chunk)
 {
     constexpr int WAVE_LDS = IntraLds<HTDF>::WAVE;
@@ -95,7 +97,11 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
         const uint4 *rec = (const uint4 *)&a.list[item];
         const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
         const uint32_t avail_ul = uni(q0.y) & 1;
-        const uint64_t avail_up = (uint64_t)uni(q0.z) | ((uint64_t)uni(q0.w) << 32);
+        // sps_suco_flag: a CU whose RIGHT neighbours are reconstructed first (flag bit 24; bit 23: so is its left side - the two bits are avail_lr) keeps the mask of the
+        // right column's units in the upper half of `up` - such a CU lies inside a node of at most 64x64, its masks have at most 24 bits (xgpu_internal.h)
+        const int lrf = (int)((uni(q0.y) >> 23) & 3), lr = EIPD == 2 ? lrf : 0;      // (the Baseline predictors have no right-hand form, xevd_ipred.c:95-164,587-622)
+        const uint32_t avail_ri = (lrf & 2) ? uni(q0.w) : 0u;
+        const uint64_t avail_up = (uint64_t)uni(q0.z) | ((lrf & 2) ? 0ull : (uint64_t)uni(q0.w) << 32);
         uint64_t avail_le = (uint64_t)uni(q1.x) | ((uint64_t)uni(q1.y) << 32);
         const uint64_t avail_le_raw = avail_le;
         // intra block copy (batches that have such CUs run the IBC instantiation): the record's `le` word carries the block vector, there are no
@@ -220,6 +226,24 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
                     }
                 }
                 if (t == 0) nb[c][NB_C0] = (int16_t)corner;
+                if (lr & 2) {
+                    // the right column (xevdm_get_nbr :123-147): unit by unit from the picture where it is reconstructed, else the sample before it; it starts from up[w],
+                    // the sample above it - itself a picture sample or a repetition.  (Not on the critical path of ordinary streams: plain code.)
+                    const int wc_ = cw >> sh, ue = wc_ >> ush;
+                    const uint64_t below_e = avail_up & ((1ull << ue) - 1);
+                    const int16_t *pe = ((avail_up >> ue) & 1) ? org - s + wc_ : below_e ? org - s + (63 - __clzll((long long)below_e)) * usz + usz - 1 : nullptr;
+                    const int first = pe ? half(pe, ldd(pe)) : corner_pre;
+#pragma unroll
+                    for (int it = 0; it < 2; it++) {
+                        const int e = t + 64 * it, u = e >> ush;
+                        if (e < n) {
+                            const uint32_t below = avail_ri & ((1u << u) - 1u);
+                            const int16_t *pr = ((avail_ri >> u) & 1) ? org + e * s + wc_ : below ? org + ((31 - __clz((int)below)) * usz + usz - 1) * s + wc_ : nullptr;
+                            nb[c][NB_UR + 1 + e] = (int16_t)(pr ? half(pr, ldd(pr)) : first);
+                        }
+                    }
+                    if (t == 0) nb[c][NB_UR] = (int16_t)first;
+                }
             }
         } else {
         // (In the data-flow launch the loads are coherent dword loads whose wanted half is picked AFTER every load of the round is out: a shift or select right
@@ -276,9 +300,9 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
         if (EIPD) {
             // chroma mode -> the luma-numbered predictor (xevdm_ipred_uv :267-305): DM follows the luma mode, then BI / DC / HOR / VER
             const int mc = mode_c == 0 ? mode_l : (mode_c == 1 ? 2 : mode_c == 2 ? 0 : mode_c == 3 ? 24 : 12);
-            plan[0] = eipd_plan(nb[0], mode_l, cw, chh, lw, lh, t);
-            plan[1] = eipd_plan(nb[1], mc, cw >> 1, chh >> 1, lw - 1, lh - 1, t);
-            plan[2] = eipd_plan(nb[2], mc, cw >> 1, chh >> 1, lw - 1, lh - 1, t);
+            plan[0] = eipd_plan(nb[0], mode_l, cw, chh, lw, lh, t, lr);
+            plan[1] = eipd_plan(nb[1], mc, cw >> 1, chh >> 1, lw - 1, lh - 1, t, lr);
+            plan[2] = eipd_plan(nb[2], mc, cw >> 1, chh >> 1, lw - 1, lh - 1, t, lr);
         } else {
         // ---- DC values (ipred_dc_b): (sum of h left + w up samples + w) >> (log2 w + 1) ----
 #pragma unroll
@@ -325,7 +349,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
                         pl[0] = (int)(o0 & 0xFFFF); pl[1] = (int)(o0 >> 16); pl[2] = (int)(o1 & 0xFFFF); pl[3] = (int)(o1 >> 16);
                         pc[0] = (int)(oc0 & 0xFFFF); pc[1] = (int)(oc0 >> 16);
                     } else {
-                        const EipdPlan kc = { plan[1].mode, c ? plan[2].p0 : plan[1].p0, c ? plan[2].p1 : plan[1].p1, c ? plan[2].p2 : plan[1].p2 };
+                        const EipdPlan kc = { plan[1].mode, c ? plan[2].p0 : plan[1].p0, c ? plan[2].p1 : plan[1].p1, c ? plan[2].p2 : plan[1].p2, plan[1].lr };
                         eipd_row<4>(nb[0], plan[0], lx, ly, cw, chh, lw, lh, maxv, pl);
                         eipd_row<2>(nb[1 + c], kc, cx, cy, cw >> 1, chh >> 1, lw - 1, lh - 1, maxc, pc);
                     }
@@ -450,7 +474,8 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
             uint32_t d_l = 0, d_r = 0, d_u = 0, d_d = 0, d_c = 0;
             if (t < chh) {
                 const bool ok_l = ((av >> 1) & 1) && (!cmask || ((avail_le_raw >> (t >> 2)) & 1));
-                p_l = org + t * a.s_l + (ok_l ? -1 : 0); p_r = org + t * a.s_l + (((av >> 3) & 1) ? cw : cw - 1);
+                const bool ok_r = ((av >> 3) & 1) && (!cmask || ((avail_ri >> (t >> 2)) & 1));
+                p_l = org + t * a.s_l + (ok_l ? -1 : 0); p_r = org + t * a.s_l + (ok_r ? cw : cw - 1);
                 d_l = ldr(p_l); d_r = ldr(p_r);
             }
             if (t < cw) {
@@ -561,7 +586,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
     }
 }
 
-template <bool DEP, bool EIPD, bool IBC, bool HTDF>
+template <bool DEP, int EIPD, bool IBC, bool HTDF>
 __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 {
     __shared__ __attribute__((aligned(16))) int16_t s_nb[INTRA_WAVES * IntraLds<HTDF>::WAVE];
@@ -579,7 +604,7 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 // (Round 3, measured and dropped: ONE launch for all levels - the level-1 CUs at the head of this launch's list, publishing flags like everybody else, strand
 // members waiting for their level-1 CUs - instead of the plain level-1 launch in front: bit-exact, 8K 2764 -> 2587 frames/s, 4K 8172 -> 7860, 1080p 10996 -> 11163.)
 #define FUSED_WAVES 4
-template <bool EIPD, bool IBC, bool IQT>
+template <int EIPD, bool IBC, bool IQT>
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_intra_itdq(const IntraArgs a, const ItdqArgs r, uint32_t n_intra_wg, uint32_t span)
 {
     constexpr int ITDQ_DW = (IQT ? ITDQ_LDS_DWORDS - ITDQ_PLANES_DWORDS / 2 : ITDQ_LDS_DWORDS) + 2 * ITDQ_MAX_G, INTRA_DW = (FUSED_WAVES * IntraLds<false>::WAVE + 1) / 2 + 4;
@@ -605,16 +630,18 @@ void upload_transform_tables_intra(const int *tm, const int16_t *ats, hipStream_
 int intra_chunk(bool with_itdq) { return with_itdq ? FUSED_WAVES : INTRA_WAVES; }
 
 // dep launch with `next` != NULL: k_intra_itdq (callers check intra_itdq_fusable first)
-void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf, const ItdqArgs *next)
+void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf, const ItdqArgs *next, bool right)
 {
+    right = right && c->sp.tool_eipd;                   // (the Baseline predictors have no right-hand form)
     if (next) {
         const uint32_t n_wg = (uint32_t)((a.count + FUSED_WAVES - 1) / FUSED_WAVES);
         const dim3 g(n_wg + (uint32_t)next->n_waves), b(64 * FUSED_WAVES);
         // the chain's workgroups spread evenly over the first half of the grid (k_intra_itdq)
         const uint32_t span = std::max(n_wg, g.x / 2);
 #define LAUNCHF(E, I) do { if (next->iqt) hipLaunchKernelGGL((k_intra_itdq<E, I, true>), g, b, 0, c->stream, a, *next, n_wg, span); else hipLaunchKernelGGL((k_intra_itdq<E, I, false>), g, b, 0, c->stream, a, *next, n_wg, span); } while (0)
-        if (c->sp.tool_eipd) { if (ibc) LAUNCHF(true, true); else LAUNCHF(true, false); }
-        else                 { if (ibc) LAUNCHF(false, true); else LAUNCHF(false, false); }
+        if (right) LAUNCHF(2, true);
+        else if (c->sp.tool_eipd) { if (ibc) LAUNCHF(1, true); else LAUNCHF(1, false); }
+        else                 { if (ibc) LAUNCHF(0, true); else LAUNCHF(0, false); }
 #undef LAUNCHF
         return;
     }
@@ -622,15 +649,16 @@ void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf
     const int blocks = (a.count + per - 1) / per;
     const dim3 g(blocks), b(64 * INTRA_WAVES);
 #define LAUNCH(D, E, I, H) hipLaunchKernelGGL((k_intra<D, E, I, H>), g, b, 0, c->stream, a)
-    if (htdf) {     // pictures with HTDF nodes (they use the IBC-capable instantiation)
-        if (c->sp.tool_eipd) { if (dep) LAUNCH(true, true, true, true); else LAUNCH(false, true, true, true); }
-        else                 { if (dep) LAUNCH(true, false, true, true); else LAUNCH(false, false, true, true); }
+    if (right) { if (dep) LAUNCH(true, 2, true, true); else LAUNCH(false, 2, true, true); }      // SUCO pictures: one instantiation that knows everything
+    else if (htdf) {     // pictures with HTDF nodes (they use the IBC-capable instantiation)
+        if (c->sp.tool_eipd) { if (dep) LAUNCH(true, 1, true, true); else LAUNCH(false, 1, true, true); }
+        else                 { if (dep) LAUNCH(true, 0, true, true); else LAUNCH(false, 0, true, true); }
     } else if (ibc) {      // pictures with intra-block-copy CUs: the instantiation that knows the copy path
-        if (c->sp.tool_eipd) { if (dep) LAUNCH(true, true, true, false); else LAUNCH(false, true, true, false); }
-        else                 { if (dep) LAUNCH(true, false, true, false); else LAUNCH(false, false, true, false); }
+        if (c->sp.tool_eipd) { if (dep) LAUNCH(true, 1, true, false); else LAUNCH(false, 1, true, false); }
+        else                 { if (dep) LAUNCH(true, 0, true, false); else LAUNCH(false, 0, true, false); }
     } else {
-        if (c->sp.tool_eipd) { if (dep) LAUNCH(true, true, false, false); else LAUNCH(false, true, false, false); }
-        else                 { if (dep) LAUNCH(true, false, false, false); else LAUNCH(false, false, false, false); }
+        if (c->sp.tool_eipd) { if (dep) LAUNCH(true, 1, false, false); else LAUNCH(false, 1, false, false); }
+        else                 { if (dep) LAUNCH(true, 0, false, false); else LAUNCH(false, 0, false, false); }
     }
 #undef LAUNCH
 #ifdef INTRA_PROFILE

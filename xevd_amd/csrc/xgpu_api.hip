@@ -466,7 +466,7 @@ static inline int plan_htdf_idx(const xgpu_cu_batch *b, uint32_t j)
 }
 static inline bool plan_is_node(const xgpu_cu_batch *b, uint32_t j) { return b->pred_mode[j] == XGPU_MODE_INTRA || b->pred_mode[j] == XGPU_MODE_IBC || plan_htdf_idx(b, j) >= 0; }
 
-struct IntraPlan { std::vector<IntraRec> recs; std::vector<uint32_t> deps; int n_levels, n_level1, n_heads, n_ctus; bool has_ibc, has_htdf; };      // n_heads: level-1 CUs + strand heads = the part of the list the launches range over
+struct IntraPlan { std::vector<IntraRec> recs; std::vector<uint32_t> deps; int n_levels, n_level1, n_heads, n_ctus; bool has_ibc, has_htdf, has_right; };      // n_heads: level-1 CUs + strand heads = the part of the list the launches range over
 static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &plan, const uint32_t *final_owner, int nthr, WorkPool &pool, const std::vector<uint32_t> &nodes)
 {
     const int hqp = b->htdf_slice_qp;
@@ -525,7 +525,7 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     int max_level = 0;
     // one CU: 0 = not a node, 1 = node appended to recs / deps (lv_out = its level when the levels of its dependencies are known: sequential mode), -1 = invalid batch
     // (r = where the node's record goes: a slot of the final list in the parallel mode, a temporary in the sequential one)
-    auto make_node = [&](const int i, IntraRec &r, std::vector<uint32_t> &deps, bool &has_ibc, bool &has_htdf, int &lv_out) -> int {
+    auto make_node = [&](const int i, IntraRec &r, std::vector<uint32_t> &deps, bool &has_ibc, bool &has_htdf, bool &has_right, int &lv_out) -> int {
         if (!ordered((uint32_t)i)) return 0;
         const int xs = b->x[i] >> 2, ys = b->y[i] >> 2, units = ((1 << b->log2w[i]) + (1 << b->log2h[i])) >> 2;
         memset(&r, 0, sizeof(r));
@@ -567,7 +567,6 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
                 av |= 1u << 3;
                 if (ys + scuh + scuw - 1 < hs && cod(xs + scuw, ys + scuh + scuw - 1)) av |= 1u << 8;
             }
-            if ((av & 8u) && h_intra && constrained) return false;      // a right neighbour under constrained intra prediction: no per-unit mask for it
             if (av & 2u)  for (int k = 0; k < scuh; k++) dep(xs - 1, ys + k);
             if (av & 1u)  for (int k = 0; k < scuw; k++) dep(xs + k, ys - 1);
             if (av & 8u)  for (int k = 0; k < scuh; k++) dep(xs + scuw, ys + k);
@@ -675,6 +674,24 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
             used = k < need_le;
             if (xs > 0 && ys + k < hs && ok(xs - 1, ys + k)) r.le |= 1ull << k;
         }
+        // sps_suco_flag: a split coded right to left leaves the CU with its RIGHT neighbours reconstructed.  avail_lr (xevd_check_nev_avail, xevd_util.c:1156-1174: the
+        // SCU left of / right of the CU's first row is reconstructed, whatever its mode) goes into flag bits 23 / 24; the units of the right column the predictors may
+        // read (xevdm_get_nbr :123-147) into the upper half of `up`: such a CU lies in a node of at most 64x64 that was split vertically, so its masks are short
+        {
+            const uint32_t jl = xs > 0 ? owner[(size_t)ys * ws + xs - 1] : NONE, jr = xs + wu < ws ? owner[(size_t)ys * ws + xs + wu] : NONE;
+            if (jr < (uint32_t)i && tile_of(xs + wu, ys) == my_tile) {
+                if (units > 32) return -1;
+                r.flags |= 1u << 24;
+                has_right = true;
+                if (jl < (uint32_t)i && tile_of(xs - 1, ys) == my_tile) r.flags |= 1u << 23;      // (only matters next to bit 24: LR_11 against LR_01)
+                uint32_t ri = 0;
+                for (int k = 0; k < units; k++) {
+                    used = c->sp.tool_eipd != 0;                    // (the Baseline predictors never read the right column; HTDF lists its own dependencies)
+                    if (ys + k < hs && ok(xs + wu, ys + k)) ri |= 1u << k;
+                }
+                r.up |= (uint64_t)ri << 32;
+            }
+        }
         if (hidx >= 0) { used = true; if (!add_htdf(r)) return -1; has_htdf = true; has_ibc = true; }
         r.dep_count = (uint32_t)deps.size() - r.dep_first;
         lv_out = lv + 1;
@@ -686,7 +703,7 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         for (int i = 0; i < n; paint(i), i++) {
             int lv = 0;
             IntraRec r;
-            const int rc = make_node(i, r, deps, plan.has_ibc, plan.has_htdf, lv);
+            const int rc = make_node(i, r, deps, plan.has_ibc, plan.has_htdf, plan.has_right, lv);
             if (rc < 0) return false;
             if (rc) { recs.push_back(r); level[(size_t)i] = lv; max_level = std::max(max_level, lv); }
         }
@@ -696,11 +713,11 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         const int K = std::max(1, std::min(nthr, std::max(1, nn / 2048)));
         // every entry of `nodes` becomes exactly one record: the threads write their ranges of the final list; the dependency lists are per thread and
         // concatenated afterwards (dep_first moved along while the levels are assigned)
-        struct Out { std::vector<uint32_t> deps; bool ibc = false, htdf = false, bad = false; };
+        struct Out { std::vector<uint32_t> deps; bool ibc = false, htdf = false, right = false, bad = false; };
         static thread_local std::vector<Out> outs_tl;
         std::vector<Out> &outs = outs_tl;
         if ((int)outs.size() < K) outs.resize((size_t)K);
-        for (Out &o : outs) { o.deps.clear(); o.ibc = o.htdf = o.bad = false; }
+        for (Out &o : outs) { o.deps.clear(); o.ibc = o.htdf = o.right = o.bad = false; }
         recs.resize((size_t)nn);
         IntraRec *const recs_p = recs.data();
         auto work = [&](int k) {
@@ -708,12 +725,12 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
             int lv = 0;
             const int q0 = (int)((long long)nn * k / K), q1 = (int)((long long)nn * (k + 1) / K);
             o.deps.reserve((size_t)(q1 - q0) * 3);
-            for (int q = q0; q < q1 && !o.bad; q++) o.bad = make_node((int)nodes[(size_t)q], recs_p[q], o.deps, o.ibc, o.htdf, lv) != 1;
+            for (int q = q0; q < q1 && !o.bad; q++) o.bad = make_node((int)nodes[(size_t)q], recs_p[q], o.deps, o.ibc, o.htdf, o.right, lv) != 1;
         };
         pool.run(K, work);
         PT("nodes");
         size_t nd = 0;
-        for (int k = 0; k < K; k++) { const Out &o = outs[(size_t)k]; if (o.bad) return false; nd += o.deps.size(); plan.has_ibc |= o.ibc; plan.has_htdf |= o.htdf; }
+        for (int k = 0; k < K; k++) { const Out &o = outs[(size_t)k]; if (o.bad) return false; nd += o.deps.size(); plan.has_ibc |= o.ibc; plan.has_htdf |= o.htdf; plan.has_right |= o.right; }
         deps.reserve(nd);
         // levels, in decoding order: 1 + the highest level among the nodes read (CUs that are no nodes - complete before the intra kernels start - count as level 0)
         for (int k = 0; k < K; k++) {
@@ -740,7 +757,7 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         static const char *const knob = getenv("XEVD_HIP_INTRA_CTU");
         const int min_levels = (knob && atoi(knob) > 0) ? 1 : (1 << 30);
         const int lc = c->sp.log2_ctu, wc = c->w_ctu;
-        if (max_level >= min_levels && !plan.has_ibc && !plan.has_htdf && intra_ctu_lds_bytes(lc) <= 160 * 1024) {
+        if (max_level >= min_levels && !plan.has_ibc && !plan.has_htdf && intra_ctu_lds_bytes(lc) <= 160 * 1024 && !plan.has_right) {      // (the per-CTU launch has no right-hand neighbours: SUCO pictures take the default)
             auto ctu_of = [&](uint32_t cu) -> int { return (b->y[cu] >> lc) * wc + (b->x[cu] >> lc); };
             std::vector<int> ent_of((size_t)wc * c->h_ctu + 1, 0);                         // counts, then first list positions
             for (const IntraRec &r : recs) ent_of[(size_t)ctu_of(r.cu) + 1]++;
@@ -1071,7 +1088,7 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     plan.recs.clear(); plan.deps.clear();
     plan.n_levels = 0; plan.n_level1 = 0; plan.n_heads = 0; plan.n_ctus = 0;
     bool any_intra = false;
-    plan.has_ibc = false; plan.has_htdf = false;
+    plan.has_ibc = false; plan.has_htdf = false; plan.has_right = false;
     // SCU -> CU map of the picture (k_inter's lanes find their CU through it; the dependency plan reads "reconstructed before" off it); SCUs outside the batch -
     // another tile's - stay unowned.  Painted in ordinary memory (short row fills) and copied into the pinned block in one piece further down
     static thread_local std::vector<uint32_t> own;
@@ -1101,7 +1118,7 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
 
     xgpu_dbatch *db = new xgpu_dbatch();
     memset(db, 0, sizeof(*db));
-    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_intra_heads = plan.n_heads; db->n_intra_ctus = plan.n_ctus; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->n_dmvr = n_dmvr; db->has_ibc = plan.has_ibc ? 1 : 0; db->has_htdf = plan.has_htdf ? 1 : 0;
+    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_intra_heads = plan.n_heads; db->n_intra_ctus = plan.n_ctus; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->n_dmvr = n_dmvr; db->has_ibc = plan.has_ibc ? 1 : 0; db->has_htdf = plan.has_htdf ? 1 : 0; db->has_right = plan.has_right ? 1 : 0;
     db->tile_starts = tmask; db->tiles_across = b->tiles ? (b->tiles->loop_filter_across_tiles ? 1 : 0) : 1;
     const size_t sz_cus = sizeof(CuRec) * (size_t)std::max(n, 1), sz_ctu = sizeof(uint32_t) * (size_t)(b->n_ctu + 1);
     const size_t sz_tbs = sizeof(TbRec) * (size_t)std::max(n_tb, 1), sz_wv = sizeof(TbWave) * (size_t)std::max(n_waves, 1);
@@ -1489,10 +1506,10 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
             if (ride) { const int rc = wait_next(); if (rc != XGPU_OK) return rc; }
             TIMED(c, XGPU_K_INTRA, {
                 ta.first = 0; ta.count = db->n_intra_l1;
-                if (ta.count) launch_intra(c, ta, false, db->has_ibc != 0, db->has_htdf != 0, NULL);
+                if (ta.count) launch_intra(c, ta, false, db->has_ibc != 0, db->has_htdf != 0, NULL, db->has_right != 0);
                 ta.first = db->n_intra_l1; ta.count = n_dep;
                 if (n_dep) {
-                    launch_intra(c, ta, true, db->has_ibc != 0, db->has_htdf != 0, ride ? &na : NULL);
+                    launch_intra(c, ta, true, db->has_ibc != 0, db->has_htdf != 0, ride ? &na : NULL, db->has_right != 0);
                     const int chunk = intra_chunk(ride);
                     db->intra_tickets += (uint32_t)((ta.count + chunk - 1) / chunk);
                     if (ride) { next->upload_waited = 1; next->prepared = 2; next->used = 1; next = NULL; }

@@ -51,7 +51,7 @@ static_assert(sizeof(CuRec) == 32, "CuRec must be 32 bytes");
 // SCU map record: the reference's map_scu / map_refi / map_mv (xevd_def.h:372-438) fused into one 16-byte
 // element so that a deblocking lane fetches a neighbour with one load.
 struct __attribute__((aligned(16))) ScuRec {
-    uint32_t scu;             // bit 15 intra, 16-22 QP, 23 skip, 24 luma cbf, 31 COD; bits 8/9: left/top CU edge
+    uint32_t scu;             // bit 15 intra, 16-22 QP, 23 skip, 24 luma cbf, 31 COD; bits 8/9: left/top CU edge; bits 0-7, 12-14: SCU_RANK
     int8_t   refi[2];
     uint16_t ats_inter;       // mctx->map_ats_inter of the SCU (ADDB: non-zero on either side of an edge -> bS 2)
     int16_t  mv[2][2];
@@ -61,6 +61,11 @@ static_assert(sizeof(ScuRec) == 16, "ScuRec must be 16 bytes");
 #define SCU_EDGE_T (1u << 9)      // the SCU's top edge is a CU boundary
 #define SCU_NOCH_L (1u << 10)     // ... but not an edge of the chroma block (a luma-only CU inside a local dual tree): the filters leave chroma alone there
 #define SCU_NOCH_T (1u << 11)
+// bits 0-7 and 12-14: the low 11 bits of the CU's index in the batch = its place in decoding order.  The baseline deblocking filter of the Main library reaches a
+// vertical CU edge with the LATER of the two CUs (xevdm_df.c:186-330: left edge when the left neighbour is done, right edge when the right one is), so with
+// sps_suco_flag chroma edges 2 samples apart are not always applied left to right; two CUs of one CTU are at most 320 places apart, CTUs follow each other
+#define SCU_RANK(idx)  (((uint32_t)(idx) & 0xFFu) | ((((uint32_t)(idx) >> 8) & 7u) << 12))
+#define SCU_RANK_OF(m) ((int)(((m) & 0xFFu) | (((m) >> 4) & 0x700u)))
 #define CU_NOCH_L 0x40            // CuRec.pred_mode bits 6 / 7 carry the two flags to k_inter's map pass (bits 0-3: XGPU_MODE_*)
 #define CU_NOCH_T 0x80
 
@@ -152,6 +157,8 @@ struct __attribute__((aligned(16))) IntraRec {
     uint32_t flags;           // bit 0: the up-left sample is available; bit 1: an intra-block-copy CU (then `le` = block vector x | y << 16, `up` = 0);
                               // bit 2: HTDF runs on the CU, bit 3: and nothing else (an inter CU), bit 4: under constrained intra prediction (the up / le masks
                               // pick the border units), bits 8-16: xevd_get_avail_intra's bits 0-8, bits 20-22: table
+                              // bits 23 / 24: avail_lr - the SCU left / right of the CU's first row is reconstructed before it (the right one only where
+                              // sps_suco_flag reversed a split); with bit 24 the upper half of `up` is the mask of the RIGHT column's units
     uint64_t up, le;
     uint32_t dep_first, dep_count;   // range of the dependency list: positions (in this list) of the intra CUs it reads from
     uint16_t x, y;            // the CU fields the kernel needs, copied here so that one record fetch starts the work
@@ -274,6 +281,7 @@ struct xgpu_dbatch {
     uint32_t  *d_intra_deps;          // dependency lists (positions in d_intra)
     uint32_t  *d_intra_done;          // [n_intra] done epochs + [1] ticket counter
     int        has_ibc, has_htdf;     // the intra list holds intra-block-copy CUs / HTDF nodes
+    int        has_right;             // ... CUs whose right-hand neighbours are reconstructed first (sps_suco_flag): the instantiations that know the right reference column
     int        n_intra_ctus;          // > 0: the list is in CTU order and d_intra_deps holds the CTU table (k_intra_ctu.hip) instead of dependency lists
     TileMask   tile_starts;           // of the batch's tile grid (zero: one tile)
     int        tiles_across;          // its loop_filter_across_tiles
@@ -381,7 +389,7 @@ void launch_itdq(xgpu_ctx *c, const ItdqArgs &a, hipStream_t s);
 void launch_inter(xgpu_ctx *c, const InterArgs &a);
 void launch_test_recon(xgpu_ctx *c, const int16_t *coef, const int16_t *pred, int is_coef, int cuw, int cuh, int16_t *rec, int s_rec, int bd);
 void launch_test_dbk(xgpu_ctx *c, int16_t *buf, int16_t *buf_v, int st, int st_v, int stride, int bd, int hor, int chroma);
-void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf, const ItdqArgs *next);      // next != NULL (dep launches): k_intra_itdq
+void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf, const ItdqArgs *next, bool right = false);      // next != NULL (dep launches): k_intra_itdq
 int  launch_intra_ctu(xgpu_ctx *c, const IntraArgs &a, const IntraCtu *ctus, int n_ctus);      // -1: the LDS attribute could not be set
 int  intra_ctu_lds_bytes(int log2_ctu);
 int  intra_chunk(bool with_itdq);                // list positions per ticket of the data-flow launch (= waves per workgroup: 8, with the residual pass riding 4)
