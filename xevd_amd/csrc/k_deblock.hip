@@ -81,7 +81,8 @@ __device__ __forceinline__ void filt_chroma(int A, int B, int C, int D, int st, 
 // One lane per 4-sample edge segment - the left / top edge of SCU (sx, sy), grid lines one past the picture included.  The lane owns what its
 // edge can change: luma [e-2, e+2) and chroma [e/2-1, e/2+1) along the filtered axis, 4 (2) lines across; these windows tile the picture, so
 // every sample is written exactly once, each filter is evaluated once, and the window is a single 8-byte (4-byte) load per line.
-template <int DIR>
+// ORD: the picture has CUs decoded after their right-hand neighbours (sps_suco_flag) - vertical chroma edges in the order the reference reaches them
+template <int DIR, bool ORD>
 __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
                                              const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_,
                                              int16_t *__restrict__ dv_)
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
     // reads what its EARLIER neighbours wrote: the chain to the left (below), and with SUCO possibly one to the right.
     const int alongc = DIR == 0 ? 1 : a.s_c, acrossc = DIR == 0 ? a.s_c : 1;
     auto before = [&](uint32_t ma, uint32_t mb, uint32_t mc, int k) -> bool {
-        if (DIR != 0) return true;
+        if (DIR != 0 || !ORD) return true;
         const int cm = (1 << a.ctu_sh) - 1;
         int da = ((SCU_RANK_OF(ma) - SCU_RANK_OF(mb)) << 21) >> 21, dc = ((SCU_RANK_OF(mc) - SCU_RANK_OF(mb)) << 21) >> 21;
         if (((k - 1) & cm) == 0) da = -4096;                 // SCU k - 2 lies in the CTU before
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
                 head--; kk -= step; nxt = cur; cur = prv;
             }
             // a chain to the RIGHT starts only where the CU to the left of this edge comes after the CU to its right (never without SUCO)
-            if (DIR == 0 && (pos & ((1 << a.ctu_sh) - 1)) != 0 && (((SCU_RANK_OF(rp.x) - SCU_RANK_OF(rq.x)) << 21) >> 21) > 0) {
+            if (DIR == 0 && ORD && (pos & ((1 << a.ctu_sh) - 1)) != 0 && (((SCU_RANK_OF(rp.x) - SCU_RANK_OF(rq.x)) << 21) >> 21) > 0) {
                 uint4 lft = rp, mid = rq;                    // records of SCU tail-1, tail
                 while (tail + 1 < npos) {
                     const uint4 rgt = maps[k0 + (tail + 1 - pos)];      // SCU tail+1: its left edge is edge tail+1
@@ -284,14 +285,16 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
 #undef PK2
 }
 
-void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst)
+void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst, bool order_rl)
 {
     const int n_ex = dir == 0 ? a.w_scu + 1 : a.w_scu, n_ey = dir == 0 ? a.h_scu : a.h_scu + 1;
     const int tiles = dir == 0 ? ((n_ex + 63) >> 6) * ((n_ey + 3) >> 2) : ((n_ex + 15) >> 4) * ((n_ey + 15) >> 4);
-    if (dir == 0)
-        hipLaunchKernelGGL(k_dbk<0>, dim3(tiles), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
+    if (dir == 0 && order_rl)
+        hipLaunchKernelGGL((k_dbk<0, true>), dim3(tiles), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
+    else if (dir == 0)
+        hipLaunchKernelGGL((k_dbk<0, false>), dim3(tiles), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
     else
-        hipLaunchKernelGGL(k_dbk<1>, dim3(tiles), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
+        hipLaunchKernelGGL((k_dbk<1, false>), dim3(tiles), dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
 }
 
 // ---------------------------------------------------------------------------------------------------------

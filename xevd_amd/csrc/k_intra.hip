@@ -100,8 +100,11 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
         // sps_suco_flag: a CU whose RIGHT neighbours are reconstructed first (flag bit 24; bit 23: so is its left side - the two bits are avail_lr) keeps the mask of the
         // right column's units in the upper half of `up` - such a CU lies inside a node of at most 64x64, its masks have at most 24 bits (xgpu_internal.h)
         const int lrf = (int)((uni(q0.y) >> 23) & 3), lr = EIPD == 2 ? lrf : 0;      // (the Baseline predictors have no right-hand form, xevd_ipred.c:95-164,587-622)
-        const uint32_t avail_ri = (lrf & 2) ? uni(q0.w) : 0u;
-        const uint64_t avail_up = (uint64_t)uni(q0.z) | ((lrf & 2) ? 0ull : (uint64_t)uni(q0.w) << 32);
+        uint32_t up_hi = q0.w;
+        asm volatile("" : "+v"(up_hi));                             // (the word is wanted whatever the flags say: left to itself the compiler loads it behind a test of the flags - a second memory round trip in front of every CU of a chain)
+        up_hi = uni(up_hi);
+        const uint32_t avail_ri = (lrf & 2) ? up_hi : 0u;
+        const uint64_t avail_up = (uint64_t)uni(q0.z) | ((lrf & 2) ? 0ull : (uint64_t)up_hi << 32);
         uint64_t avail_le = (uint64_t)uni(q1.x) | ((uint64_t)uni(q1.y) << 32);
         const uint64_t avail_le_raw = avail_le;
         // intra block copy (batches that have such CUs run the IBC instantiation): the record's `le` word carries the block vector, there are no

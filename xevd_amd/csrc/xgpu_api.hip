@@ -3,6 +3,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <atomic>
 #include "xgpu_internal.h"
 #include "affine_model.h"
 
@@ -430,6 +431,7 @@ int xgpu_frame_begin(xgpu_ctx *c, const xgpu_frame_params *fp)
     c->where = 0;
     c->pad_done = 0;
     c->addb_pending = 0;
+    c->order_rl = 0;
     return XGPU_OK;
 }
 
@@ -1108,6 +1110,21 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
         });
     }
     BT("owner map");
+    // sps_suco_flag: is any CU decoded AFTER its right-hand neighbour?  (All right-hand neighbours of a CU lie in the other part of one vertical split: the first one
+    // tells.)  Only the baseline deblocking filter wants to know beforehand - it applies chroma edges 2 samples apart in the order the reference's tree walk reaches
+    // them (k_deblock.hip) and takes its left-to-right instantiation otherwise; ADDB is order-free, the intra plan finds its right-hand neighbours itself
+    bool order_rl = false;
+    if (!c->sp.tool_addb) {
+        std::atomic<int> found(0);
+        const uint32_t *const own_p = own.data();
+        run_parts([&, own_p](int, int i0, int i1) {
+            for (int i = i0; i < i1 && !found.load(std::memory_order_relaxed); i++) {
+                const int xr = b->x[i] + (1 << b->log2w[i]);
+                if (xr < c->sp.width && own_p[(size_t)(b->y[i] >> 2) * c->w_scu + (xr >> 2)] < (uint32_t)i) found.store(1, std::memory_order_relaxed);
+            }
+        });
+        order_rl = found.load() != 0;
+    }
     static thread_local std::vector<uint32_t> node_list;
     node_list.clear();
     for (const Part &P : parts) node_list.insert(node_list.end(), P.nodes.begin(), P.nodes.end());
@@ -1118,7 +1135,7 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
 
     xgpu_dbatch *db = new xgpu_dbatch();
     memset(db, 0, sizeof(*db));
-    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_intra_heads = plan.n_heads; db->n_intra_ctus = plan.n_ctus; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->n_dmvr = n_dmvr; db->has_ibc = plan.has_ibc ? 1 : 0; db->has_htdf = plan.has_htdf ? 1 : 0; db->has_right = plan.has_right ? 1 : 0;
+    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_intra_heads = plan.n_heads; db->n_intra_ctus = plan.n_ctus; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->n_dmvr = n_dmvr; db->has_ibc = plan.has_ibc ? 1 : 0; db->has_htdf = plan.has_htdf ? 1 : 0; db->has_right = plan.has_right ? 1 : 0; db->order_rl = order_rl ? 1 : 0;
     db->tile_starts = tmask; db->tiles_across = b->tiles ? (b->tiles->loop_filter_across_tiles ? 1 : 0) : 1;
     const size_t sz_cus = sizeof(CuRec) * (size_t)std::max(n, 1), sz_ctu = sizeof(uint32_t) * (size_t)(b->n_ctu + 1);
     const size_t sz_tbs = sizeof(TbRec) * (size_t)std::max(n_tb, 1), sz_wv = sizeof(TbWave) * (size_t)std::max(n_waves, 1);
@@ -1440,6 +1457,7 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
     a.no_region = getenv("XEVD_HIP_INTER_NO_REGION") != NULL;
     a.cus = db->d_cus; a.resid = db->d_resid;
     a.maps = c->d_maps; a.w_scu = c->w_scu; a.owner = db->d_owner; a.n_cu = db->n_cu; a.cur_poc = c->fp.poc;
+    c->order_rl |= db->order_rl;                            // (the pictures' batches - one per slice - say it for the deblocking pass behind them)
     for (int l = 0; l < 2; l++)
         for (int i = 0; i < XGPU_MAX_REFS; i++) {
             const DevPic &rp = i < c->fp.num_refp[l] ? dpic(c, c->fp.refp_pic[i][l]) : dpic(c, c->fp.pic);
@@ -1599,7 +1617,7 @@ int xgpu_deblock(xgpu_ctx *c)
                     a.st[1 + t][cls][qp] = (uint8_t)(k_df_st[cls][v] << (c->sp.bit_depth_chroma - 8));
                 }
             }
-        TIMED(c, XGPU_K_DBK_V, launch_dbk(c, a, 0, first, second));
+        TIMED(c, XGPU_K_DBK_V, launch_dbk(c, a, 0, first, second, c->order_rl != 0));
         TIMED(c, XGPU_K_DBK_H, launch_dbk(c, a, 1, second, first));
     }
     HIPCHK(c, hipGetLastError());

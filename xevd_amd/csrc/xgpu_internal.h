@@ -281,6 +281,7 @@ struct xgpu_dbatch {
     uint32_t  *d_intra_deps;          // dependency lists (positions in d_intra)
     uint32_t  *d_intra_done;          // [n_intra] done epochs + [1] ticket counter
     int        has_ibc, has_htdf;     // the intra list holds intra-block-copy CUs / HTDF nodes
+    int        order_rl;              // some CU is decoded after its right-hand neighbour (sps_suco_flag; only looked for when the baseline deblocking filter is the one that runs)
     int        has_right;             // ... CUs whose right-hand neighbours are reconstructed first (sps_suco_flag): the instantiations that know the right reference column
     int        n_intra_ctus;          // > 0: the list is in CTU order and d_intra_deps holds the CTU table (k_intra_ctu.hip) instead of dependency lists
     TileMask   tile_starts;           // of the batch's tile grid (zero: one tile)
@@ -326,6 +327,7 @@ struct xgpu_ctx {
     int             builder_threads;   // xgpu_set_builder_threads: host threads xgpu_batch_create spreads its per-CU passes over (default 1)
     int             pad_done;          // the padding of the current picture has been written (by k_alf's border tiles): xgpu_pad launches nothing
     int             where;             // 0: the picture being built lives in its DPB slot, 1: in the scratch picture
+    int             order_rl;          // a batch of the picture has CUs decoded after their right-hand neighbours (xgpu_dbatch.order_rl): k_dbk's order-aware instantiation
     int             addb_pending, split_addb_alf;      // ADDB + ALF in one kernel: xgpu_deblock left its arguments in addb_args for xgpu_alf
     AddbArgs        addb_args;
     // timing
@@ -395,7 +397,7 @@ int  intra_ctu_lds_bytes(int log2_ctu);
 int  intra_chunk(bool with_itdq);                // list positions per ticket of the data-flow launch (= waves per workgroup: 8, with the residual pass riding 4)
 void launch_affine(xgpu_ctx *c, const AffineArgs &a, hipStream_t s);
 void launch_dmvr(xgpu_ctx *c, const DmvrArgs &a, hipStream_t s);
-void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst);
+void launch_dbk(xgpu_ctx *c, const DbkArgs &a, int dir, const DevPic &src, const DevPic &dst, bool order_rl = false);
 void upload_transform_tables(const int *tm, const int16_t *ats, hipStream_t s);
 int  itdq_group_size(int log2w, int log2h);     // TBs of one size class per 256-thread work item
 void launch_addb_fused(xgpu_ctx *c, const AddbArgs &a, const DevPic &src, const DevPic &dst);      // both passes, one read + one write of the picture
