@@ -292,6 +292,28 @@ def test_gpu_stream_1080p_vs_oracle():
             assert np.array_equal(ours[k][c], ref[k][c]), f"picture {k} plane {c}"
 
 
+SUCO_CONFIGS = [
+    # sps_suco_flag beyond the golden streams, GPU against parser + oracle (the oracle is pinned to the reference decoder on such streams, tests/test_stream.py):
+    # local dual trees under the BASELINE deblocking filter (order-aware chroma edges), every intra tool at once, a 1080p all-intra picture pair
+    (264, 200, 5, dict(main=True, suco=(0, 2), btt=(2, 0, 0, 0), admvp=True, dual_tree=True, eipd=True, split_prob=0.7, inter_frac=0.6, max_refs=2)),
+    (392, 264, 4, dict(main=True, suco=(0, 3), eipd=True, htdf=True, ibc_log_max=4, cm_init=True, adcc=True, iqt=True, ats=True, inter_frac=0.4, split_prob=0.7, bit_depth=10)),
+    (392, 264, 5, dict(main=True, suco=(1, 2), admvp=True, affine=True, hmvp=True, eipd=True, addb=True, alf=True, inter_frac=0.8, split_prob=0.5, max_refs=2, log2_sub_gop=2, tiles=(2, 2, 1))),
+    (1920, 1080, 2, dict(main=True, suco=(0, 2), eipd=True, idr_period=1, split_prob=0.75)),
+]
+
+
+@pytest.mark.parametrize("cfg", SUCO_CONFIGS, ids=[f"{c[0]}x{c[1]}x{c[2]}_{i}" for i, c in enumerate(SUCO_CONFIGS)])
+def test_gpu_suco_streams_vs_oracle(cfg):
+    import stream_util as su
+    w, h, n, kw = cfg
+    data = su.make_stream(w, h, n, seed=w + 3 * n, **kw)
+    ours, ref = su.decode_gpu(data), su.decode_oracle(data)
+    assert len(ours) == n and len(ref) == n
+    for k in range(n):
+        for c in range(3):
+            assert np.array_equal(ours[k][c], ref[k][c]), f"picture {k} plane {c}: {np.argwhere(ours[k][c] != ref[k][c])[:4].tolist()}"
+
+
 def test_gpu_8k_properties():
     """8K (7680x4320): identity property - zero motion, no residual, deblocking off: the picture equals its
     reference, padding included; and the run is deterministic."""
