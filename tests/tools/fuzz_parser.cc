@@ -6,6 +6,7 @@
 // front of every neighbour read (another tile's maps may be written at that moment).
 // Round 4 (persistent parser + rebind, windowed bit reader, coefficients decoded in place, pooled tile threads): 120 mutations of each of the 51 golden streams under ASan + UBSan,
 // 40 of each tiled one under TSan with 4 threads - see DESIGN 5b.
+// Repeated after sps_suco_flag went in (right-hand neighbour reads in every derivation): 1500 mutations of each of the five SUCO golden streams under ASan + UBSan, 300 of the tiled one under TSan with 4 threads - clean.
 // Repeated after BTT and the local dual tree went in: 1200 + 1200 mutations of their six golden streams (ASan + UBSan), 300 of the tiled ones under TSan with 4 threads - clean.
 #include "../../include/xevd_host.h"
 #include <cstdio>
