@@ -1,8 +1,18 @@
-R=$GRAFT_REPO_ROOT
-cd $R
-echo "== current (143 VGPRs, residual early)"; timeout -k 5 300 python tools/exp_inter_order.py 16:0 16:0 2>&1 | grep inter_us | cut -c1-60
-for v in tmp_k_late tmp_k_late_f; do
-  cp tools/$v.hip xevd_amd/csrc/k_inter.hip; (cd xevd_amd/csrc && make >/dev/null 2>&1)
-  echo "== $v"; timeout -k 5 300 python tools/exp_inter_order.py 16:0 16:0 2>&1 | grep inter_us | cut -c1-60
-done
-timeout -k 5 600 python -m pytest tests -m gpu -x -q -k "golden or bench_workload" 2>&1 | tail -2
+#!/bin/bash
+cd /root/repo
+mkdir -p gpurun_out
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -k "golden_streams or workload_vs_oracle or golden_pic or pictures" 2>&1 | tail -4
+WL=cfg4_main_8k_10b_ra
+for rep in 1 2 3; do
+  for v in old new noq; do
+    if [ $v = old ]; then cp tools/ab/libxevd_hip_old.so xevd_amd/libxevd_hip.so; else cp tools/ab/libxevd_hip_new.so xevd_amd/libxevd_hip.so; fi
+    if [ $v = noq ]; then export XEVD_HIP_INTER_NO_QUAD=1; else unset XEVD_HIP_INTER_NO_QUAD; fi
+    timeout 600 python bench.py --steps 60 --workload $WL --no-cpu-baseline --no-end-to-end 2>/dev/null | python -c "
+import sys, json
+d = json.loads([l for l in sys.stdin if l.startswith('{')][-1])
+print('$v', d['value'], d['ms_per_step'], {k: v['avg_us'] for k, v in d['kernels'].items()})"
+  done
+done > gpurun_out/ab_quad.log 2>&1
+unset XEVD_HIP_INTER_NO_QUAD
+cp tools/ab/libxevd_hip_new.so xevd_amd/libxevd_hip.so
+cat gpurun_out/ab_quad.log
