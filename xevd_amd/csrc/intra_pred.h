@@ -1,4 +1,4 @@
-// intra_pred.h - what the intra kernels share (k_intra.hip: one wave per CU, global done flags; k_intra_ctu.hip: one workgroup per CTU, the CTU in LDS):
+// intra_pred.h - what the intra kernels share (k_intra.hip: one wave per CU, global done flags; and, until round 4, a per-CTU formulation):
 // the neighbour-array layout in LDS, the Baseline and EIPD predictors as functions of (column, row) over those arrays, packed reconstruction, coherent accesses.
 #pragma once
 #include "xgpu_internal.h"

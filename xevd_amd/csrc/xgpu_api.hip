@@ -468,7 +468,7 @@ static inline int plan_htdf_idx(const xgpu_cu_batch *b, uint32_t j)
 }
 static inline bool plan_is_node(const xgpu_cu_batch *b, uint32_t j) { return b->pred_mode[j] == XGPU_MODE_INTRA || b->pred_mode[j] == XGPU_MODE_IBC || plan_htdf_idx(b, j) >= 0; }
 
-struct IntraPlan { std::vector<IntraRec> recs; std::vector<uint32_t> deps; int n_levels, n_level1, n_heads, n_ctus; bool has_ibc, has_htdf, has_right; };      // n_heads: level-1 CUs + strand heads = the part of the list the launches range over
+struct IntraPlan { std::vector<IntraRec> recs; std::vector<uint32_t> deps; int n_levels, n_level1, n_heads; bool has_ibc, has_htdf, has_right; };      // n_heads: level-1 CUs + strand heads = the part of the list the launches range over
 static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &plan, const uint32_t *final_owner, int nthr, WorkPool &pool, const std::vector<uint32_t> &nodes)
 {
     const int hqp = b->htdf_slice_qp;
@@ -749,63 +749,9 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
         }
     }
     PT("levels");
-    // The per-CTU launch (k_intra_ctu.hip: one workgroup per CTU, the chain of a CTU through LDS) takes the list in CTU raster order, decoding order inside a CTU;
-    // the dependency lists shrink to "which neighbour CTUs hold a CU that a CU of this CTU reads" (the CUs of one CTU synchronise per SCU in LDS, from the
-    // availability masks).  It is an OPTION (XEVD_HIP_INTRA_CTU=1, graphs without IBC / HTDF nodes), not the default: measured on all-intra pictures it is
-    // slower than the data-flow launch (1080p Baseline 3.3 ms against 2.3, Main 8.9 against 8.0) - a link of a chain costs ~2-4 us of single-wave instruction
-    // latency either way (cycle stamps: staging 2 100 clocks, plan 1 000 - 1 700, 4 400 per step of six angular samples), the memory round trips the LDS tile
-    // saves are the smaller part, and ordering whole CTUs (a CTU starts when the one above-right has finished) gives up the overlap the CU-granular graph has.
-    {
-        static const char *const knob = getenv("XEVD_HIP_INTRA_CTU");
-        const int min_levels = (knob && atoi(knob) > 0) ? 1 : (1 << 30);
-        const int lc = c->sp.log2_ctu, wc = c->w_ctu;
-        if (max_level >= min_levels && !plan.has_ibc && !plan.has_htdf && intra_ctu_lds_bytes(lc) <= 160 * 1024 && !plan.has_right) {      // (the per-CTU launch has no right-hand neighbours: SUCO pictures take the default)
-            auto ctu_of = [&](uint32_t cu) -> int { return (b->y[cu] >> lc) * wc + (b->x[cu] >> lc); };
-            std::vector<int> ent_of((size_t)wc * c->h_ctu + 1, 0);                         // counts, then first list positions
-            for (const IntraRec &r : recs) ent_of[(size_t)ctu_of(r.cu) + 1]++;
-            std::vector<uint32_t> table_idx((size_t)wc * c->h_ctu, NONE);
-            std::vector<IntraCtu> tab;
-            for (size_t k = 0; k + 1 < ent_of.size(); k++) {
-                if (ent_of[k + 1]) {
-                    IntraCtu e;
-                    e.first = 0; e.count = (uint32_t)ent_of[k + 1]; e.pad = 0;
-                    e.xy = (uint32_t)(((int)k % wc) << lc) | ((uint32_t)(((int)k / wc) << lc) << 16);
-                    e.nbr[0] = e.nbr[1] = e.nbr[2] = e.nbr[3] = NONE;
-                    table_idx[k] = (uint32_t)tab.size();
-                    tab.push_back(e);
-                }
-                ent_of[k + 1] += ent_of[k];
-            }
-            bool ok_ctu = true;
-            plan.recs.resize(recs.size());
-            for (size_t ri = 0; ri < recs.size() && ok_ctu; ri++) {
-                const IntraRec &r = recs[ri];
-                const int k = ctu_of(r.cu);
-                IntraCtu &e = tab[table_idx[(size_t)k]];
-                for (uint32_t d = r.dep_first; d < r.dep_first + r.dep_count && ok_ctu; d++) {
-                    const int kd = ctu_of(deps[d]);
-                    if (kd == k) continue;
-                    const uint32_t td = table_idx[(size_t)kd];
-                    int q = 0;
-                    while (q < 4 && e.nbr[q] != NONE && e.nbr[q] != td) q++;
-                    if (q == 4 || kd > k) ok_ctu = false;                                  // (cannot happen without IBC: left, above-left, above, above-right)
-                    else if (!(knob && atoi(knob) == 2)) e.nbr[q] = td;                   // (2: a timing experiment - no CTU waits for another, wrong pictures)
-                }
-                IntraRec &o = plan.recs[(size_t)ent_of[(size_t)k]++];
-                o = r;
-                o.cu = NONE; o.dep_first = 0; o.dep_count = 0;
-            }
-            if (ok_ctu) {
-                uint32_t at = 0;
-                for (IntraCtu &e : tab) { e.first = at; at += e.count; }
-                plan.deps.resize(tab.size() * (sizeof(IntraCtu) / sizeof(uint32_t)));
-                memcpy(plan.deps.data(), tab.data(), tab.size() * sizeof(IntraCtu));
-                plan.n_levels = max_level; plan.n_level1 = 0; plan.n_heads = (int)recs.size(); plan.n_ctus = (int)tab.size();
-                PT("ctu order");
-                return true;
-            }
-        }
-    }
+    // (Rounds 2 - 4 kept a second formulation beside this one - one workgroup per CTU with the CTU's chain in LDS, k_intra_ctu.hip, XEVD_HIP_INTRA_CTU=1 - bit-exact and measured
+    //  slower on every all-intra picture (1080p Baseline 3.3 ms against 2.3, Main 8.9 against 8.0: a link of a chain is ~2 - 4 us of single-wave instruction latency either way,
+    //  and ordering whole CTUs gives up the overlap of the CU-granular graph).  Removed in round 4; `git show ac993a5:xevd_amd/csrc/k_intra_ctu.hip` has it.)
     // Strands (k_intra.hip): a CU of level 2 and up whose dependency list holds exactly ONE CU of level 2 and up (the others are level-1 CUs, complete before the
     // data-flow launch) is linked to that CU when it has no successor yet; the wave that reconstructs the parent continues with it.
     // Parts (k_intra.hip): a wave takes 64 units (EIPD: rows of four luma samples + a chroma pair) or 64 SCUs (Baseline predictors) of its CU per step, a 64x64 CU is 16 (4) steps
@@ -1088,7 +1034,7 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     static thread_local IntraPlan plan_tl;                 // (kept between pictures: see build_intra_plan)
     IntraPlan &plan = plan_tl;
     plan.recs.clear(); plan.deps.clear();
-    plan.n_levels = 0; plan.n_level1 = 0; plan.n_heads = 0; plan.n_ctus = 0;
+    plan.n_levels = 0; plan.n_level1 = 0; plan.n_heads = 0;
     bool any_intra = false;
     plan.has_ibc = false; plan.has_htdf = false; plan.has_right = false;
     // SCU -> CU map of the picture (k_inter's lanes find their CU through it; the dependency plan reads "reconstructed before" off it); SCUs outside the batch -
@@ -1135,7 +1081,7 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
 
     xgpu_dbatch *db = new xgpu_dbatch();
     memset(db, 0, sizeof(*db));
-    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_intra_heads = plan.n_heads; db->n_intra_ctus = plan.n_ctus; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->n_dmvr = n_dmvr; db->has_ibc = plan.has_ibc ? 1 : 0; db->has_htdf = plan.has_htdf ? 1 : 0; db->has_right = plan.has_right ? 1 : 0; db->order_rl = order_rl ? 1 : 0;
+    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_intra_heads = plan.n_heads; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->n_dmvr = n_dmvr; db->has_ibc = plan.has_ibc ? 1 : 0; db->has_htdf = plan.has_htdf ? 1 : 0; db->has_right = plan.has_right ? 1 : 0; db->order_rl = order_rl ? 1 : 0;
     db->tile_starts = tmask; db->tiles_across = b->tiles ? (b->tiles->loop_filter_across_tiles ? 1 : 0) : 1;
     const size_t sz_cus = sizeof(CuRec) * (size_t)std::max(n, 1), sz_ctu = sizeof(uint32_t) * (size_t)(b->n_ctu + 1);
     const size_t sz_tbs = sizeof(TbRec) * (size_t)std::max(n_tb, 1), sz_wv = sizeof(TbWave) * (size_t)std::max(n_waves, 1);
@@ -1510,13 +1456,6 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
         ta.epoch = ++db->intra_epoch;                      // flags are compared against the epoch: no reset between pictures
         ta.ticket_base = db->intra_tickets;                // the counter keeps running: a launch draws one ticket per workgroup
         const int n_dep = db->n_intra_heads - db->n_intra_l1;      // strand heads: the members behind them in the list are reached through their parents
-        if (db->n_intra_ctus) {
-            // a deep graph: one workgroup per CTU, the chain of a CTU in LDS (k_intra_ctu.hip); the table sits where the dependency lists would
-            int rc = 0;
-            TIMED(c, XGPU_K_INTRA, rc = launch_intra_ctu(c, ta, (const IntraCtu *)db->d_intra_deps, db->n_intra_ctus));
-            if (rc) { snprintf(c->err, sizeof(c->err), "k_intra_ctu: LDS size attribute"); return XGPU_ERR_UNEXPECTED; }
-            db->intra_tickets += (uint32_t)db->n_intra_ctus;
-        } else
         {
             // the next picture's residual pass rides in the data-flow launch (not while single kernels are being timed; HTDF's workgroups are a different shape)
             ItdqArgs na;

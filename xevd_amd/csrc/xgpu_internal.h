@@ -181,11 +181,6 @@ struct IntraArgs {
     int       first, count;   // the list range this launch covers
 };
 
-// One CTU of the per-CTU intra launch (k_intra_ctu.hip): its CUs are list positions [first, first + count) in decoding order; nbr = the table entries of the
-// CTUs (left, above-left, above, above-right) that hold CUs this CTU's CUs read from, 0xFFFFFFFF = none.  The table travels in the dependency array.
-struct IntraCtu { uint32_t first, count, xy, nbr[4], pad; };
-static_assert(sizeof(IntraCtu) == 32, "IntraCtu must be 32 bytes");
-
 struct ItdqArgs {
     const int16_t *coef;
     int16_t       *resid;
@@ -283,7 +278,6 @@ struct xgpu_dbatch {
     int        has_ibc, has_htdf;     // the intra list holds intra-block-copy CUs / HTDF nodes
     int        order_rl;              // some CU is decoded after its right-hand neighbour (sps_suco_flag; only looked for when the baseline deblocking filter is the one that runs)
     int        has_right;             // ... CUs whose right-hand neighbours are reconstructed first (sps_suco_flag): the instantiations that know the right reference column
-    int        n_intra_ctus;          // > 0: the list is in CTU order and d_intra_deps holds the CTU table (k_intra_ctu.hip) instead of dependency lists
     TileMask   tile_starts;           // of the batch's tile grid (zero: one tile)
     int        tiles_across;          // its loop_filter_across_tiles
     int        n_intra, n_levels, n_intra_deps, n_intra_l1, n_intra_heads;      // n_intra_l1: CUs of level 1 (head of the list); n_intra_heads: + the strand heads of the data-flow launch (the strand members follow)
@@ -323,7 +317,6 @@ struct xgpu_ctx {
     int             have_frame;
     TileMask        no_dbk;            // tile borders the deblocking of the current picture leaves alone (set by xgpu_batch_recon)
     hipEvent_t      fork_ev, join_ev;  // k_dmvr / k_affine on the side stream beside k_inter: where they may start, where the kernel stream takes them back
-    int             ctu_attr[2];       // k_intra_ctu's LDS size attribute set (Baseline / EIPD instantiation)
     int             builder_threads;   // xgpu_set_builder_threads: host threads xgpu_batch_create spreads its per-CU passes over (default 1)
     int             pad_done;          // the padding of the current picture has been written (by k_alf's border tiles): xgpu_pad launches nothing
     int             where;             // 0: the picture being built lives in its DPB slot, 1: in the scratch picture
@@ -392,8 +385,6 @@ void launch_inter(xgpu_ctx *c, const InterArgs &a);
 void launch_test_recon(xgpu_ctx *c, const int16_t *coef, const int16_t *pred, int is_coef, int cuw, int cuh, int16_t *rec, int s_rec, int bd);
 void launch_test_dbk(xgpu_ctx *c, int16_t *buf, int16_t *buf_v, int st, int st_v, int stride, int bd, int hor, int chroma);
 void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf, const ItdqArgs *next, bool right = false);      // next != NULL (dep launches): k_intra_itdq
-int  launch_intra_ctu(xgpu_ctx *c, const IntraArgs &a, const IntraCtu *ctus, int n_ctus);      // -1: the LDS attribute could not be set
-int  intra_ctu_lds_bytes(int log2_ctu);
 int  intra_chunk(bool with_itdq);                // list positions per ticket of the data-flow launch (= waves per workgroup: 8, with the residual pass riding 4)
 void launch_affine(xgpu_ctx *c, const AffineArgs &a, hipStream_t s);
 void launch_dmvr(xgpu_ctx *c, const DmvrArgs &a, hipStream_t s);
