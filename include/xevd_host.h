@@ -97,6 +97,13 @@ int  xhost_parser_set_dmvr_mvs(xhost_parser *p, const int16_t *mv, int n_sub);
    144 samples of replicated border on every side (what xgpu_pic_download_padded delivers); it must stay valid and unchanged while the picture is a
    reference.  Streams that need it and do not get it fail with an error that says so.  Why the front end reads samples at all: xevd_amd/host/dmvr_search.h. */
 int  xhost_parser_set_ref_luma(xhost_parser *p, int poc, const int16_t *plane, int stride);
+/* The refinement search of decoder-side motion vector refinement on its own (xevd_amd/host/dmvr_search.h: what processDMVR decides, src_main/xevdm_mc.c:1647-1829), for a
+   binding whose OWN parser derives candidates CU by CU from refined vectors (sps->tool_dmvr with tool_hmvp / tool_mmvd: oracle/ref_binding.c is the worked example).  The CU
+   (x, y, w x h) with the unrefined quarter-sample vectors mv = { l0x, l0y, l1x, l1y } between two references at equal POC distances on either side; ref0 / ref1 = luma sample
+   (0, 0) of the reference planes, each with at least 144 samples of replicated border.  refined[k * 4 ..] = the vectors of sub-block k (16x16, or the CU when smaller; raster
+   order inside the CU) = mcore->dmvr_mv.  Returns the number of sub-blocks. */
+int  xhost_dmvr_search(int pic_w, int pic_h, int bit_depth, int x, int y, int w, int h, const int16_t mv[4],
+                       const int16_t *ref0, int stride0, const int16_t *ref1, int stride1, int16_t *refined);
 /* Picture boundaries of a NAL stream without decoding it (what the GOP splitter xwq_split_gops uses): feed every NAL unit (without its length prefix);
    -> 0 not a slice, 1 the first slice of a picture, 2 a further slice of the same picture (several slices per picture), < 0 malformed.               */
 typedef struct xhost_scan xhost_scan;

@@ -24,12 +24,14 @@
  * objects in the link, oracle/Makefile.ref: libxevd_ref_hip.so) - the way ref_harness.c reaches static helpers; no reference source is copied.
  * The recursion over the split tree below is OUR walk over the reference's exported helpers (xevd_get_split_mode,
  * xevd_split_get_part_structure, xevdm_get_suco_flag, xevdm_split_get_suco_order, xevd_derive_mode_cons).
- * Limits (asserted): one slice per picture (any tile grid), 4:2:0, not tool_dmvr together with tool_hmvp (the history would need refined vectors
- * while the picture is still being parsed).
+ * Limits (asserted): 4:2:0.  Several slices per picture are gathered into one batch; with tool_dmvr next to tool_hmvp / tool_mmvd - later CUs of the picture derive
+ * their candidates from refined vectors while the picture is still being parsed - the refinement SEARCH runs on the host (xhost_dmvr_search of libxevd_host.so, on luma
+ * planes downloaded from the backend's picture slots), the backend repeats it for the prediction.
  */
 #include "xevdm.c"
 #include "xevdm_alf.c"
 #include "../include/xevd_hip.h"
+#include "../include/xevd_host.h"
 
 typedef struct { void **p; size_t elem, n, cap; } rb_vec;          /* growable array of a batch field */
 static void *rb_push(rb_vec *v, void **base, size_t elem, size_t count)
@@ -57,6 +59,10 @@ typedef struct {
     void *coef; rb_vec coef_v;
     int any_affine, any_dmvr, any_ats, any_ats_inter, any_tree;
     int failed;
+    /* sps->tool_dmvr with tool_hmvp / tool_mmvd: the refined vectors steer this parser's own candidate lists CU by CU, so the refinement SEARCH runs here, on host
+       copies of the two references' luma planes (xhost_dmvr_search; the backend repeats it for the prediction) - fetched once per picture and reference */
+    struct { int slot; int16_t *y; } luma[64];
+    int n_luma;
     int n_ctu, pic_inter;         /* CTUs of the picture in the batch so far (several slices: one fn_dec_slice call each); a P / B slice among them */
     xgpu_tile_grid grid;
 } rb_state;
@@ -71,6 +77,26 @@ static int rb_slot(rb_state *s, const XEVD_PIC *pic)
     s->slots[s->n_slots].pic = pic;
     s->slots[s->n_slots].slot = xgpu_pic_alloc(s->g);
     return s->slots[s->n_slots++].slot;
+}
+
+/* the padded luma plane of the picture in `slot` on the host (sample (0, 0); stride = width + 2 * 144) */
+static const int16_t *rb_luma(rb_state *s, XEVD_CTX *ctx, int slot, int *stride)
+{
+    const int pad = 144, w = ctx->w + 2 * pad, h = ctx->h + 2 * pad;
+    int i;
+    *stride = w;
+    for (i = 0; i < s->n_luma; i++) if (s->luma[i].slot == slot) return s->luma[i].y + pad * w + pad;
+    if (s->n_luma == 64) return NULL;
+    s->luma[s->n_luma].slot = slot;
+    s->luma[s->n_luma].y = (int16_t *)malloc(sizeof(int16_t) * (size_t)w * h);
+    if (xgpu_pic_download_padded(s->g, slot, s->luma[s->n_luma].y, NULL, NULL) < 0) { free(s->luma[s->n_luma].y); return NULL; }
+    return s->luma[s->n_luma++].y + pad * w + pad;
+}
+static void rb_luma_drop(rb_state *s)
+{
+    int i;
+    for (i = 0; i < s->n_luma; i++) free(s->luma[i].y);
+    s->n_luma = 0;
 }
 
 static void rb_reserve(rb_state *s)
@@ -91,6 +117,8 @@ static void hip_recon_unit(XEVD_CTX *ctx, XEVD_CORE *core, int x, int y, int log
     XEVD_CU_DATA *cu_data = &ctx->map_cu_data[core->lcu_num];
     const int cuw = 1 << log2_cuw, cuh = 1 << log2_cuh;
     int i, c, sb, mode;
+    s16 mv_unrefined[REFP_NUM][MV_D];
+    int refined_cu = 0;
     mcore->tree_cons = (TREE_CONS) { FALSE, tree_cons.tree_type, tree_cons.mode_cons };
     core->log2_cuw = log2_cuw; core->log2_cuh = log2_cuh;
     core->x_scu = PEL2SCU(x); core->y_scu = PEL2SCU(y);
@@ -130,8 +158,25 @@ static void hip_recon_unit(XEVD_CTX *ctx, XEVD_CORE *core, int x, int y, int log
                 int k;
                 mcore->dmvr_flag = 1;
                 for (k = 0; k < (cuw >> MIN_CU_LOG2) * (cuh >> MIN_CU_LOG2); k++) memcpy(mcore->dmvr_mv[k], core->mv, sizeof(s16) * 4);
+                if (ctx->sps->tool_hmvp || ctx->sps->tool_mmvd) {
+                    /* ... unless later CUs of this picture derive their candidates from the refined vectors (history buffer, the MMVD base list): then the
+                       search runs now, and mcore->dmvr_mv is what processDMVR would have left (src_main/xevdm_mc.c:1783-1797) */
+                    int16_t sub[64 * 4], in[4];
+                    const int dx = cuw < 16 ? cuw : 16, dy = cuh < 16 ? cuh : 16;
+                    int st0 = 0, st1 = 0, sx, sy, u, v, n = 0;
+                    const int16_t *r0 = rb_luma(s, ctx, rb_slot(s, ctx->refp[core->refi[0]][REFP_0].pic), &st0);
+                    const int16_t *r1 = rb_luma(s, ctx, rb_slot(s, ctx->refp[core->refi[1]][REFP_1].pic), &st1);
+                    memcpy(in, core->mv, sizeof(in));
+                    if (!r0 || !r1 || xhost_dmvr_search(ctx->w, ctx->h, ctx->sps->bit_depth_luma_minus8 + 8, x, y, cuw, cuh, in, r0, st0, r1, st1, sub) < 0) s->failed = 1;
+                    else
+                        for (sy = 0; sy < cuh; sy += dy) for (sx = 0; sx < cuw; sx += dx, n++)
+                            for (v = 0; v < dy >> MIN_CU_LOG2; v++) for (u = 0; u < dx >> MIN_CU_LOG2; u++)
+                                memcpy(mcore->dmvr_mv[((sy >> MIN_CU_LOG2) + v) * (cuw >> MIN_CU_LOG2) + (sx >> MIN_CU_LOG2) + u], &sub[n * 4], sizeof(s16) * 4);
+                    refined_cu = 1;
+                }
             }
         }
+        memcpy(mv_unrefined, core->mv, sizeof(mv_unrefined));
         xevdm_set_dec_info(ctx, core);
         mcore->dmvr_flag = 0;
         if (ctx->sps->tool_hmvp) update_history_buffer_parse_affine(core, ctx->sh.slice_type);
@@ -145,7 +190,7 @@ static void hip_recon_unit(XEVD_CTX *ctx, XEVD_CORE *core, int x, int y, int log
     s->pred_mode[i] = (uint8_t)(mode == MODE_INTRA ? XGPU_MODE_INTRA : mode == MODE_IBC ? XGPU_MODE_IBC :
                                 (mode == MODE_SKIP || mode == MODE_SKIP_MMVD) ? XGPU_MODE_SKIP : (mode == MODE_DIR || mode == MODE_DIR_MMVD) ? XGPU_MODE_DIR : XGPU_MODE_INTER);
     s->refi[i * 2] = core->refi[0]; s->refi[i * 2 + 1] = core->refi[1];
-    memcpy(&s->mv[i * 4], core->mv, sizeof(s16) * 4);
+    memcpy(&s->mv[i * 4], (refined_cu && mode != MODE_INTRA && mode != MODE_IBC) ? mv_unrefined : core->mv, sizeof(s16) * 4);      /* (the backend refines for itself: xevdm_set_dec_info has put the first sub-block's refined vector into core->mv) */
     s->qp[i * 3] = core->qp_y; s->qp[i * 3 + 1] = core->qp_u; s->qp[i * 3 + 2] = core->qp_v;
     s->ipm[i * 2] = (uint8_t)core->ipm[0]; s->ipm[i * 2 + 1] = (uint8_t)core->ipm[1];
     s->ats[i] = (uint8_t)((mode == MODE_INTRA && mcore->ats_intra_cu) ? (1 | (mcore->ats_intra_mode_v << 1) | (mcore->ats_intra_mode_h << 2)) : 0);
@@ -263,14 +308,12 @@ static int hip_dec_slice(XEVD_CTX *ctx, XEVD_CORE *core)
        makes before it runs the in-loop filters, :3139) - with that last slice's header for everything picture-level, as the reference decoder filters */
     const int first_slice = ctx->num_ctb == (u32)ctx->f_lcu;
     if (ctx->sps->chroma_format_idc != 1) return XEVD_ERR_UNSUPPORTED;
-    /* DMVR + HMVP: xevdm_set_dec_info leaves the refined vector of the first sub-block in core->mv (xevdm_util.c:4384-4387), which the history buffer then
-       takes (xevdm.c:1335-1342) - the next CUs' candidates would need the refinement result before the batch has run */
-    if (ctx->sps->tool_dmvr && (ctx->sps->tool_hmvp || ctx->sps->tool_mmvd)) return XEVD_ERR_UNSUPPORTED;
     if (!s->g && (ret = hip_open(ctx)) < 0) return ret;
 
     if (first_slice) {
         s->n_cu = 0; s->coef_v.n = 0; s->any_affine = s->any_dmvr = s->any_ats = s->any_ats_inter = s->any_tree = 0; s->failed = 0; s->deblocked = 0;
         s->n_ctu = 0; s->pic_inter = 0;
+        rb_luma_drop(s);                                               /* picture slots are reused: the host copies are per picture */
         s->ctu_start = realloc(s->ctu_start, sizeof(uint32_t) * (size_t)(ctx->f_lcu + 1));
     }
     if (ctx->sh.slice_type != SLICE_I) s->pic_inter = 1;

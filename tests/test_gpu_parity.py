@@ -506,10 +506,9 @@ def test_gpu_reference_application_on_our_api(name, args, tmp_path):
 REF_DECODE_HIP = os.path.normpath(os.path.join(golden_io.GOLDEN, "..", "..", "oracle", "_ref", "ref_decode_hip"))
 # the Main-profile streams: the reference's Main library itself does not survive the Baseline ones (its entropy pass writes past ctx->cod_eco,
 # src_main/xevdm.c:1450-1455, on CTU rows that cross the picture's bottom edge) - those are the Baseline library's, tests/test_stream.py
-# ... and not the streams with tool_dmvr together with tool_hmvp / tool_mmvd: the refined vectors steer the reference parser's own candidate lists CU by CU, and a backend
-# behind the picture-granular slots (fn_dec_slice ...) reconstructs after the picture is parsed - our own front end runs the refinement search itself for those
-# (xevd_amd/host/dmvr_search.h); they are decoded by every other path below
-HOST_DMVR_STREAMS = {"main_dmvr_hmvp_mmvd_b_8b", "main_every_tool_10b", "main_every_tool_tiles_8b", "main_suco_btt_all_tools_10b"}
+# Streams with tool_dmvr together with tool_hmvp / tool_mmvd - the refined vectors steer the reference parser's own candidate lists CU by CU - run too: the binding
+# calls the refinement search on the host (xhost_dmvr_search) at every such CU and the backend repeats it for the prediction (round 4)
+HOST_DMVR_STREAMS = set()
 STREAM_NAMES = sorted(f[len("stream_"):-len(".npz")] for f in os.listdir(golden_io.GOLDEN)
                       if f.startswith("stream_") and f.endswith(".npz") and "main_" in f and f[len("stream_"):-len(".npz")] not in HOST_DMVR_STREAMS)
 

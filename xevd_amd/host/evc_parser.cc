@@ -736,6 +736,17 @@ extern "C" int xhost_parser_rebind(xhost_parser *p, const uint8_t *bytes, size_t
 }
 // the decoded luma samples of the picture with this POC, for the front end's own refinement search (Sps::host_dmvr)
 extern "C" int xhost_parser_set_ref_luma(xhost_parser *p, int poc, const int16_t *plane, int stride) { return p ? set_ref_luma(p->st, poc, plane, stride) : XGPU_ERR_INVALID_ARGUMENT; }
+extern "C" int xhost_dmvr_search(int pic_w, int pic_h, int bit_depth, int x, int y, int w, int h, const int16_t mv[4],
+                                 const int16_t *ref0, int stride0, const int16_t *ref1, int stride1, int16_t *refined)
+{
+    if (!mv || !ref0 || !ref1 || !refined || w < 8 || h < 8 || w > 128 || h > 128) return XGPU_ERR_INVALID_ARGUMENT;
+    const int16_t m[2][2] = { { mv[0], mv[1] }, { mv[2], mv[3] } };
+    const DmvrRefPlane rp[2] = { { ref0, stride0, 0 }, { ref1, stride1, 0 } };
+    const int n = (w > 16 ? w / 16 : 1) * (h > 16 ? h / 16 : 1);
+    static thread_local std::vector<int16_t> scratch;
+    dmvr_search_cu(pic_w, pic_h, bit_depth, x, y, w, h, m, rp, (int16_t (*)[2][2])refined, scratch);
+    return n;
+}
 extern "C" int xhost_parser_set_depth(xhost_parser *p, int depth)
 {
     if (!p || depth < 1 || depth > 8 || p->n_handed) return XGPU_ERR_INVALID_ARGUMENT;      // before the first picture
