@@ -374,6 +374,52 @@ def reference_decoder_leg(wl, budget_s=60.0):
                     "period of every evc_decode run == the reference decoder's pictures (its single-threaded run)"}
 
 
+def contexts_leg(XgpuDecoder, device, wl, first, batches, alf, steps, warmup, n_ctx=2):
+    """What the GPU does when it is fed by SEVERAL decoders at once (the streams of configs[4] on one device; the pictures of one temporal layer of a random-access
+    stream): n_ctx contexts on one device, each with its own stream, picture slots and resident batches, cycling them from its own host thread - the resident-batch
+    rate of `value` with the idle stretches of one picture (the dependency chain of its intra CUs, the gaps between its kernels) filled by another.  A secondary
+    figure: `value` stays one context."""
+    import threading
+    two_lists = wl["n_refs"][1] > 0
+    ctxs = []
+    for i in range(n_ctx):
+        d = XgpuDecoder(wl["w"], wl["h"], wl["bd"], device=device, iqt=wl["iqt"], admvp=wl["admvp"], addb=wl["addb"], alf=wl["alf"], max_pics=4)
+        sl = [d.pic_alloc(), d.pic_alloc(), d.pic_alloc()]
+        for k in range(2):
+            d.pic_upload(sl[k], first[k])
+            d.frame_begin(sl[k], k - 1, {})
+            d.pad()
+            d.frame_end()
+        hs = [d.batch_create(b) for b in batches]
+        d.sync()
+        ctxs.append((d, sl, hs))
+
+    def run(d, sl, hs, k0, n):
+        for k in range(k0, k0 + n):
+            refs = {(0, 0): (sl[(k + 1) % 3], k)}
+            if two_lists:
+                refs[(0, 1)] = (sl[k % 3], k + 2 if wl.get("dmvr_frac") else k - 1)
+            d.decode_picture(sl[(k + 2) % 3], k + 1, refs, hs[k % len(hs)], alf=alf, next_batch=hs[(k + 1) % len(hs)] if len(hs) > 1 else None)
+        d.sync()
+
+    def all_of(k0, n):
+        th = [threading.Thread(target=run, args=(d, sl, hs, k0, n)) for d, sl, hs in ctxs]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
+    all_of(0, warmup)
+    dt = all_of(warmup, steps)
+    for d, sl, hs in ctxs:
+        for h in hs:
+            d.batch_destroy(h)
+        d.close()
+    return {"contexts": n_ctx, "fps": round(n_ctx * steps / dt, 2), "ms_per_picture": round(dt * 1e3 / (n_ctx * steps), 4),
+            "what": "resident batches as in `value`, but from %d decoder contexts at once on this device (own HIP streams, own host threads): the GPU's rate when independent pictures overlap" % n_ctx}
+
+
 def end_to_end_leg(dec, wl, batches, alf, slots, steps, warmup, builders=int(os.environ.get('XEVD_BENCH_BUILDERS', '4')), depth=int(os.environ.get('XEVD_BENCH_DEPTH', '5'))):
     """CU batches in host memory -> packed YUV pictures in host memory, everything inside the timed region: the host batch builder
     (xgpu_batch_create on `builders` threads, `depth` pictures ahead), the upload of every batch (coefficient arena straight from pinned
@@ -610,6 +656,12 @@ def main():
         e2e = {"fps": None, "ms_per_picture": 0.0, "skipped": True}
     else:
         e2e = end_to_end_leg(dec, wl, batches, alf, slots, max(args.steps // 2, 10), 4)
+    two_ctx = None
+    if world == 1 and not args.no_end_to_end and dec_mod == "xevd_amd.decoder":
+        try:
+            two_ctx = contexts_leg(XgpuDecoder, local_rank, wl, first, batches, alf, args.steps, args.warmup)
+        except Exception as e:      # (a secondary figure must not cost the line)
+            two_ctx = {"error": str(e)[:200]}
     if dist is not None and not args.no_end_to_end:
         t = torch.tensor([e2e["ms_per_picture"]], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -701,6 +753,7 @@ def main():
             "kernel_only_fps": round(world * args.steps / dt, 2),
             "end_to_end_fps": e2e["fps"],
             "end_to_end": e2e,
+            "two_contexts": two_ctx,
         }
         if not args.no_cpu_baseline and world == 1:      # the CPU leg runs on rank 0 of the single-GPU run only
             cpu_pic, out["cpu_baseline"] = cpu_baseline(wl, first, batches[0], alf)

@@ -1,14 +1,14 @@
-R=$GRAFT_REPO_ROOT
-cd $R
-bash tools/collect_profiles.sh round4_a bb3828d
-cd $R
-timeout -k 5 600 python tools/bench_multistream.py --streams 1,4,16,32 --pics 48 --profile base > gpurun_out/round4_a_multistream_base1080p.json 2> /dev/null; tail -c 1200 gpurun_out/round4_a_multistream_base1080p.json
-timeout -k 5 600 python tools/bench_multistream.py --streams 1,4,16,32 --pics 50 --profile main > gpurun_out/round4_a_multistream_main1080p.json 2> /dev/null; tail -c 1200 gpurun_out/round4_a_multistream_main1080p.json
-gcc -O2 -I include -o /tmp/parse_time tools/parse_time.c -L xevd_amd -lxevd_host -Wl,-rpath,$R/xevd_amd
-python - <<'PY'
-import bench
-wl = bench.WORKLOADS["cfg4_main_8k_10b_ra"]
-one, data, _ = bench.write_bench_stream(wl, 17, 1)
-open("/tmp/s8k1.evc", "wb").write(one)
-PY
-for t in 1 16; do /tmp/parse_time /tmp/s8k1.evc $t 2 | tail -1; done
+#!/bin/bash
+# how much of the frame time is GPU idle that a second, independent picture could fill: two processes on one device, each cycling its own resident batches
+cd /root/repo
+mkdir -p gpurun_out
+one() { timeout 600 python bench.py --steps 6000 --warmup 50 --workload $1 --no-cpu-baseline --no-end-to-end 2>/dev/null | python -c "
+import sys, json
+d = json.loads([l for l in sys.stdin if l.startswith('{')][-1]); print('$2', d['value'], d['ms_per_step'])"; }
+for WL in cfg4_main_8k_10b_ra cfg3_main_4k_10b_ra; do
+  echo "== $WL"
+  one $WL alone
+  one $WL A & one $WL B & wait
+  one $WL A & one $WL B & one $WL C & wait
+done > gpurun_out/two_procs.log 2>&1
+cat gpurun_out/two_procs.log

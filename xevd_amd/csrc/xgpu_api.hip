@@ -177,10 +177,17 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     static const bool blocking = getenv("XEVD_HIP_BLOCKING_SYNC") != NULL && atoi(getenv("XEVD_HIP_BLOCKING_SYNC")) != 0;
     if (blocking) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
     const unsigned ev_flags = hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0);
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
-    if (hipStreamCreateWithFlags(&c->up_stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
-    if (hipStreamCreateWithFlags(&c->down_stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
-    if (hipStreamCreateWithFlags(&c->side_stream, hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+    {
+        // The runtime hands its hardware queues (four by default, GPU_MAX_HW_QUEUES) to the streams of a process in the order they are created.  Every context creates
+        // four streams, so created in one fixed order the KERNEL streams of all contexts of a process would share one hardware queue, and the pictures of independent
+        // decoders would run strictly one after the other (measured: two contexts in one process 2814 pictures/s at 8K against 2841 for one; 3087 with the queues apart,
+        // 4K 7865 -> 11397).  Context k creates its kernel stream k-th of its four.
+        static std::atomic<int> n_ctx(0);
+        const int rot = n_ctx.fetch_add(1) & 3;
+        hipStream_t *const order[4] = { &c->stream, &c->up_stream, &c->down_stream, &c->side_stream };
+        for (int i = 0; i < 4; i++)
+            if (hipStreamCreateWithFlags(order[(i - rot + 4) & 3], hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+    }
     if (hipEventCreateWithFlags(&c->after_inter, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     for (int i = 0; i < 2; i++)
