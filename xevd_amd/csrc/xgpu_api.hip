@@ -179,14 +179,18 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     const unsigned ev_flags = hipEventDisableTiming | (blocking ? hipEventBlockingSync : 0);
     {
         // The runtime hands its hardware queues (four by default, GPU_MAX_HW_QUEUES) to the streams of a process in the order they are created.  Every context creates
-        // four streams, so created in one fixed order the KERNEL streams of all contexts of a process would share one hardware queue, and the pictures of independent
-        // decoders would run strictly one after the other (measured: two contexts in one process 2814 pictures/s at 8K against 2841 for one; 3087 with the queues apart,
-        // 4K 7865 -> 11397).  Context k creates its kernel stream k-th of its four.
+        // four streams, so created in one fixed order the KERNEL streams of all contexts of a process shared one hardware queue, and the pictures of independent decoders ran
+        // strictly one after the other (two contexts in one process: 2814 pictures/s at 8K against 2841 for one; 3087 - 3118 with the queues apart, 4K 7865 -> 11 300).  Every
+        // other context creates its kernel stream LAST instead of first: the kernel streams alternate between the first and the fourth queue, the upload and download streams
+        // of all contexts stay on the second and third - a picture's output copy never queues behind another decoder's kernels (rotating all four positions cost the host-bound
+        // many-stream decode 4 %; stream priority classes changed nothing) -, and the rarely used side stream shares with the other parity's kernels.
+        // XEVD_HIP_NO_QUEUE_ROTATION=1: the fixed order (A/B measurements).
         static std::atomic<int> n_ctx(0);
-        const int rot = n_ctx.fetch_add(1) & 3;
-        hipStream_t *const order[4] = { &c->stream, &c->up_stream, &c->down_stream, &c->side_stream };
+        static const bool no_rot = getenv("XEVD_HIP_NO_QUEUE_ROTATION") != NULL;
+        const bool swap = !no_rot && (n_ctx.fetch_add(1) & 1);
+        hipStream_t *const order[4] = { swap ? &c->side_stream : &c->stream, &c->up_stream, &c->down_stream, swap ? &c->stream : &c->side_stream };
         for (int i = 0; i < 4; i++)
-            if (hipStreamCreateWithFlags(order[(i - rot + 4) & 3], hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
+            if (hipStreamCreateWithFlags(order[i], hipStreamNonBlocking) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     }
     if (hipEventCreateWithFlags(&c->after_inter, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
     if (hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) return fail(XGPU_ERR_UNEXPECTED);
