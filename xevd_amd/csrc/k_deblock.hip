@@ -219,18 +219,19 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
             sp[0] = s_st[(1 * 4 + cls) * 64 + (qp & 63)]; sp[1] = s_st[(2 * 4 + cls) * 64 + (qp & 63)];
         }
         bool pend[2];
+        int rc[2][2] = { { 0, 0 }, { 0, 0 } }, rok[2] = { 0, 0 };      // vertical edges: what the thread has published stays in registers (the lane to the right fetches it with a wave shift)
         auto finish = [&](int pl, int a0, int a1) {          // this edge's two lines with A' = a0 / a1; publishes the C' values
 #pragma unroll
             for (int ln = 0; ln < 2; ln++) {
                 int *w = Cw[pl][ln];
                 if (st[1 + pl]) { int Bo, Co; filt_chroma(ln ? a1 : a0, w[1], w[2], w[3], st[1 + pl], maxc, Bo, Co); w[1] = Bo; w[2] = Co; }
-                s_cp[pl][ln][tid] = w[2];
+                if (DIR == 0) rc[pl][ln] = w[2]; else s_cp[pl][ln][tid] = w[2];
             }
-            s_ok[pl][tid] = 1;
+            if (DIR == 0) rok[pl] = 1; else s_ok[pl][tid] = 1;
         };
         const bool l0 = st[1] && sp[0], l1 = st[2] && sp[1];
         pend[0] = l0 && has_pred; pend[1] = l1 && has_pred;
-        s_ok[0][tid] = 0; s_ok[1][tid] = 0;
+        if (DIR != 0) { s_ok[0][tid] = 0; s_ok[1][tid] = 0; }
         if (!l0) finish(0, Cw[0][0][0], Cw[0][1][0]);
         if (!l1) finish(1, Cw[1][0][0], Cw[1][1][0]);
         if ((l0 || l1) && !has_pred) {
@@ -280,22 +281,30 @@ __global__ __launch_bounds__(256) void k_dbk(const DbkArgs a, const int16_t *__r
             if (l1) finish(1, prevC[1][0], prevC[1][1]);
         }
         // A round: every waiting thread looks at the flag and the C' values of the thread before it; who finds them filters and publishes its own.  Vertical edges: a chain
-        // stays inside its row = one wave, and a wave's LDS reads of a round are served before its writes: no barrier.  Horizontal edges: a chain crosses the workgroup's
-        // waves: a barrier before the looks, one between looks and publications (one barrier with fenced flag-then-value reads measured slower: 20.3 against 17.5 us).
+        // stays inside its row = one wave - the values stay in registers and move one lane to the right per round (DPP wave_shr:1; through LDS a round was two LDS round
+        // trips, and a run of 4x4 CUs is 16 - 32 rounds).  Horizontal edges: a chain crosses the workgroup's waves - LDS, a barrier before the looks, one between looks and
+        // publications (one barrier with fenced flag-then-value reads measured slower: 20.3 against 17.5 us).
         for (;;) {
             const bool waiting = pend[0] || pend[1];
             if (DIR == 0) { if (__ballot(waiting) == 0) break; }
             else if (!__syncthreads_or(waiting)) break;
             int ok[2] = { 0, 0 }, c[2][2] = { { 0, 0 }, { 0, 0 } };
+            if (DIR == 0) {
 #pragma unroll
-            for (int pl = 0; pl < 2; pl++)
-                if (pend[pl]) { ok[pl] = s_ok[pl][pred]; c[pl][0] = s_cp[pl][0][pred]; c[pl][1] = s_cp[pl][1][pred]; }
-            if (DIR == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
-            else __syncthreads();                            // everybody has looked before anybody publishes
+                for (int pl = 0; pl < 2; pl++) {
+                    ok[pl] = __builtin_amdgcn_update_dpp(0, rok[pl], 0x138, 0xF, 0xF, false);          // wave_shr:1 - lane i receives lane i - 1's value
+                    c[pl][0] = __builtin_amdgcn_update_dpp(0, rc[pl][0], 0x138, 0xF, 0xF, false);
+                    c[pl][1] = __builtin_amdgcn_update_dpp(0, rc[pl][1], 0x138, 0xF, 0xF, false);
+                }
+            } else {
+#pragma unroll
+                for (int pl = 0; pl < 2; pl++)
+                    if (pend[pl]) { ok[pl] = s_ok[pl][pred]; c[pl][0] = s_cp[pl][0][pred]; c[pl][1] = s_cp[pl][1][pred]; }
+                __syncthreads();                             // everybody has looked before anybody publishes
+            }
 #pragma unroll
             for (int pl = 0; pl < 2; pl++)
                 if (pend[pl] && ok[pl]) { finish(pl, c[pl][0], c[pl][1]); pend[pl] = false; }
-            if (DIR == 0) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
         }
         coop_done = true;
     }
