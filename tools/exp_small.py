@@ -5,7 +5,7 @@ import bench
 from xevd_amd.decoder import XgpuDecoder
 from xevd_amd import abi
 for (w, h) in [(int(a.split("x")[0]), int(a.split("x")[1])) for a in (sys.argv[1:] or ["320x184", "640x360", "1280x720", "1920x1080", "3840x2160"])]:
-    wl = dict(bench.WORKLOADS["cfg2_base_1080p_8b_ippp"]); wl["w"], wl["h"] = w, h
+    wl = dict(bench.WORKLOADS[os.environ.get("EXP_WL", "cfg2_base_1080p_8b_ippp")]); wl["w"], wl["h"] = w, h
     first, batches, alf = bench.make_stream(wl, 1000, 2)
     dec = XgpuDecoder(w, h, wl["bd"], device=0, iqt=wl["iqt"], admvp=wl["admvp"], addb=wl["addb"], alf=wl["alf"], max_pics=4)
     sl = [dec.pic_alloc(), dec.pic_alloc(), dec.pic_alloc()]

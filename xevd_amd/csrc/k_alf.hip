@@ -674,7 +674,8 @@ void launch_alf(xgpu_ctx *c, const AlfArgs &a, const AddbArgs *deblock, const De
     const int tiles = ((a.pic_w + 63) >> 6) * ((a.pic_h + 63) >> 6);
     const dim3 grid(((tiles + 7) >> 3) << 3);
     static const bool scalar_knob = getenv("XEVD_HIP_ADDB_SCALAR") != NULL;
-    if (deblock && !scalar_knob && deblock->bd_l <= 10 && deblock->bd_c <= 10) hipLaunchKernelGGL(k_addb_alf<true>, grid, dim3(256), 0, c->stream, a, *deblock, src.y, src.u, src.v, dst.y, dst.u, dst.v);
+    static const int lds_pad = getenv("XEVD_HIP_ALF_LDSPAD") ? atoi(getenv("XEVD_HIP_ALF_LDSPAD")) : 0;      // measurement knob: dynamic LDS that only lowers the occupancy
+    if (deblock && !scalar_knob && deblock->bd_l <= 10 && deblock->bd_c <= 10) hipLaunchKernelGGL(k_addb_alf<true>, grid, dim3(256), lds_pad, c->stream, a, *deblock, src.y, src.u, src.v, dst.y, dst.u, dst.v);
     else if (deblock) hipLaunchKernelGGL(k_addb_alf<false>, grid, dim3(256), 0, c->stream, a, *deblock, src.y, src.u, src.v, dst.y, dst.u, dst.v);
     else hipLaunchKernelGGL(k_alf, grid, dim3(256), 0, c->stream, a, src.y, src.u, src.v, dst.y, dst.u, dst.v);
 }
