@@ -122,3 +122,30 @@ if __name__ == "__main__" and "--write" in sys.argv:
         out["large_" + c[0]] = large_digests(lib, c, 1)
     json.dump(out, open(GOLDEN_FILE, "w"), indent=0)
     print(len(out), "entries")
+
+
+@pytest.mark.parametrize("name", ["base_i_8b", "main_eipd_b_ctu128_constrained_10b", "main_btt_10b", "main_b_ctu128_intra_mix_8b"])
+def test_builder_arbitrary_cu_order_inside_ctus(name):
+    """The ORDER of a batch carries meaning (a neighbour counts as reconstructed when it comes earlier; with sps_suco_flag also right-hand neighbours): the CUs of every
+    CTU in a random order - orders no split tree produces - must build the same arrays on 1 and 4 threads or be refused alike (a right-hand neighbour next to a CU with more
+    than 32 units has no place in the record, an intra block copy source may come later), and never crash."""
+    lib = _lib()
+    case, _ = golden_io.load_picture_case(name)
+    b = dict(case["batch"])
+    rng = np.random.default_rng(5)
+    start = np.asarray(b["ctu_cu_start"])
+    perm = np.concatenate([rng.permutation(np.arange(start[k], start[k + 1])) for k in range(len(start) - 1)]).astype(np.int64)
+    per_cu = {"x": 1, "y": 1, "log2w": 1, "log2h": 1, "pred_mode": 1, "refi": 2, "mv": 4, "qp": 3, "cbf": 1, "coef_off": 1, "ipm": 2, "ats": 1, "ats_inter": 1, "affine": 1,
+              "affine_mv": 12, "dmvr": 1, "tree": 1, "cbf_sub": 1}
+    n = len(b["x"])
+    for k, width in per_cu.items():
+        if b.get(k) is not None and hasattr(b[k], "shape") and b[k].size == n * width:
+            b[k] = np.ascontiguousarray(np.asarray(b[k]).reshape(n, -1)[perm].reshape(np.asarray(b[k]).shape))
+    sp = abi.make_seq_params(case["w"], case["h"], case["bd"], log2_ctu=case["log2_ctu"], iqt=case["iqt"], admvp=case["admvp"], addb=case["addb"], alf=case["alf"], eipd=case["eipd"])
+    cb, keep = abi.make_cu_batch(b)
+    out = []
+    for threads in (1, 4):
+        dg, info, ms = (C.c_uint64 * 11)(), (C.c_int * 8)(), C.c_double()
+        rc = lib.xgpu_test_build_batch(C.byref(sp), C.byref(cb), threads, dg, info, C.byref(ms))
+        out.append((rc, [int(v) for v in dg][:10] if rc == 0 else None))
+    assert out[0] == out[1] and out[0][0] in (0, -101)
