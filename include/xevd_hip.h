@@ -123,6 +123,8 @@ typedef struct xgpu_alf_params {
  * One batch of decoded CUs (one tile or one picture), structure-of-arrays, in decode order, grouped by CTU.
  * The ORDER carries meaning: a neighbouring CU counts as reconstructed before CU i when its index is below i (xevd_get_avail_intra / xevdm_get_nbr / xevd_check_nev_avail read the
  * COD flags the reference sets CU by CU) - left, above, and with sps_suco_flag also right-hand neighbours.  Nothing else tells the backend about split order.
+ * It must be the order of a walk over the split tree (any node's parts left to right or right to left): all neighbours along one side of a CU are then decoded before it or all
+ * after it, which the reference's deblocking walk relies on (xevdm_df.c:237,280) and the backend's filters take for granted.
  * It is the post-entropy-decode record set of XEVD_CU_DATA (src_base/xevd_def.h:1145-1190) after MV
  * derivation (xevd.c:705-728), flattened per leaf CU.  Coefficients are stored CU-contiguous exactly as
  * coef_rect_to_series produces them (xevd.c:640-676): for a CU, the coded components in the order Y, U, V,

@@ -640,3 +640,60 @@ def test_gpu_bench_streams_leg_configs4():
     assert out["devices_used"] >= 1 and out["host_cpu_quota"] >= 1
     if os.path.exists(os.path.join(os.path.dirname(bench.__file__), "oracle", "_ref", "ref_decode_main")):
         assert out["bit_exact"] is True, out
+
+
+def _permute_inside_ctus(batch, seed, log2_ctu=6):
+    """the CUs of every CTU (quad-tree partitions) in the order of a tree walk that takes the two columns of ANY split node right to left at random - SUCO without the
+    SPS limits on which nodes may choose (sizes 8 .. 64).  Still a tree order: all neighbours along one side of a CU lie in one sibling subtree, so they are all decoded
+    before the CU or all after it, which the reference takes for granted (its deblocking walk filters a CU's whole side when the FIRST neighbouring SCU is done; a side
+    that is half done would be filtered twice).  The order is what tells the backend which neighbours are reconstructed first."""
+    b = dict(batch)
+    rng = np.random.default_rng(seed)
+    start = np.asarray(b["ctu_cu_start"])
+    x, y, lw = np.asarray(b["x"]).astype(np.int64), np.asarray(b["y"]).astype(np.int64), np.asarray(b["log2w"]).astype(np.int64)
+    perm = []
+
+    def walk(idx, x0, y0, ls, out):
+        if len(idx) == 0:
+            return
+        if len(idx) == 1 and lw[idx[0]] == ls:
+            out.append(int(idx[0]))
+            return
+        h = 1 << (ls - 1)
+        for q in ([1, 0, 3, 2] if rng.random() < 0.6 else [0, 1, 2, 3]):
+            qx, qy = x0 + (q & 1) * h, y0 + (q >> 1) * h
+            walk(idx[(x[idx] >= qx) & (x[idx] < qx + h) & (y[idx] >= qy) & (y[idx] < qy + h)], qx, qy, ls - 1, out)
+    for k in range(len(start) - 1):
+        idx = np.arange(start[k], start[k + 1])
+        if len(idx) == 0:
+            continue
+        out = []
+        walk(idx, int(x[idx].min()) >> log2_ctu << log2_ctu, int(y[idx].min()) >> log2_ctu << log2_ctu, log2_ctu, out)
+        assert sorted(out) == list(idx)
+        perm += out
+    perm = np.asarray(perm, np.int64)
+    n = len(b["x"])
+    for k, v in list(b.items()):
+        if isinstance(v, np.ndarray) and k != "ctu_cu_start" and k != "coef" and v.ndim >= 1 and v.shape[0] == n:
+            b[k] = np.ascontiguousarray(v[perm])
+    return b
+
+
+@pytest.mark.parametrize("cfg", [
+    ("perm_eipd_htdf_constrained", 200, 136, 10, 1, 1, (1, 1), 0.3, {"addb": 1, "alf": 1, "eipd": 1, "inter_frac": 0.5, "htdf_qp": 30, "constrained_intra": 1, "split_prob": 0.6, "coded_frac": 0.8}),
+    ("perm_eipd_noaddb_i", 136, 136, 8, 1, 1, (1, 0), 0.0, {"eipd": 1, "inter_frac": 0.0, "split_prob": 0.7}),
+    ("perm_eipd_noaddb_p", 264, 200, 10, 1, 0, (2, 0), 0.0, {"eipd": 1, "inter_frac": 0.6, "split_prob": 0.7}),
+    ("perm_base_modes_b", 200, 136, 8, 0, 0, (1, 1), 0.4, {"inter_frac": 0.6, "split_prob": 0.7}),
+], ids=lambda c: c[0])
+def test_gpu_reversed_tree_orders_vs_oracle(cfg):
+    """Right-hand neighbours in every shape: the CUs of each CTU in a tree order with reversed nodes of every size through the whole pipeline against the oracle (which sets its COD flags CU by CU like
+    the reference) - EIPD prediction from left / right / both columns for every CU size, constrained intra prediction, HTDF borders, and the baseline deblocking filter's
+    order-aware chroma chains, far beyond what SUCO split trees produce."""
+    name, w, h, bd, admvp, iqt, n_refs, bi_frac, tools = cfg
+    for seed in (1, 2):
+        cs = cases.build_case(name, w, h, bd, admvp, iqt, n_refs, bi_frac, tools, seed=seed)
+        cs["batch"] = _permute_inside_ctus(cs["batch"], 40 + seed)
+        ref, _, _, _ = cases.run_cpu("oracle", cs)
+        out = cases.run_gpu(cs)
+        for c in range(3):
+            assert np.array_equal(out[c], ref.bufs[c]), f"{name} seed {seed} plane {c}: {np.argwhere(out[c] != ref.bufs[c])[:4].tolist()}"
