@@ -330,7 +330,7 @@ def reference_decoder_leg(wl, budget_s=60.0):
         open(p_one, "wb").write(one)
         open(p_all, "wb").write(data)
         ok = True
-        shapes = (("one_stream_pipelined", ["--workers", "1", "--tile-threads", str(min(16, quota)), "--build-threads", "8"]),
+        shapes = (("one_stream_pipelined", ["--workers", "1", "--tile-threads", str(min(16, quota)), "--build-threads", "8", "--builders", "2"]),
                   ("one_stream_back_to_back", ["--workers", "1", "--tile-threads", str(min(16, quota)), "--build-threads", "8", "--no-pipeline"]),
                   ("gop_parallel_2x8", ["--workers", "2", "--tile-threads", str(max(1, min(8, quota // 2))), "--build-threads", "4"]),
                   ("gop_parallel_4x4", ["--workers", "4", "--tile-threads", str(max(1, min(4, quota // 4))), "--build-threads", "2"]))

@@ -17,7 +17,7 @@
  * Every worker is a pipeline of three threads: the parser (entropy decoding, picture k + 2), the batch builder (xgpu_batch_create, picture k + 1) and the
  * device thread (kernel launches and output of picture k); --no-pipeline: back to back on one thread, as xevd_dec_nalu does it.  A worker keeps its parser
  * (xhost_parser_rebind), its context, its pinned buffers and its threads from unit to unit.
- * usage: evc_decode [--gpus N] [--workers W] [--tile-threads T] [--build-threads B] [--keep-units K] [--no-pipeline] [--trace] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
+ * usage: evc_decode [--gpus N] [--workers W] [--tile-threads T] [--build-threads B] [--builders N] [--keep-units K] [--no-pipeline] [--trace] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
  *        evc_decode in.evc out.yuv D                                               (the round-1 form)
  * build: oracle-free; see examples/Makefile.
  */
@@ -40,6 +40,8 @@
 #define CHECK(call) do { int rc_ = (call); if (rc_ < 0) { fprintf(stderr, "%s -> %d (%s)\n", #call, rc_, w->g ? xgpu_last_error(w->g) : ""); return rc_; } } while (0)
 static double now_s(void);
 static int g_keep_units = -1;      /* --keep-units K: only the first K units (closed GOPs) of every input are written to its output file; the rest is decoded all the same (long timing runs) */
+static int g_builders = 2;          /* --builders N: builder threads per worker (pictures built side by side) */
+static int g_depth = 4;             /* 2 + g_builders */
 static int g_build_threads = 8;     /* --build-threads B: host threads xgpu_batch_create spreads its per-CU passes over */
 
 typedef struct { int poc, pic, in_use; } slot_t;                 /* DPB: POC -> device picture slot */
@@ -143,7 +145,8 @@ static int g_pipeline = 1;          /* --no-pipeline: parse and reconstruct ever
  * pipeline: while this worker turns picture k into a device batch and launches its kernels, the parser thread is already inside xhost_parser_next
  * for picture k + 1 (xhost_parser_set_depth(2): the arrays of two pictures stay valid).  Pictures with DMVR candidates break the overlap for one
  * step: the parser needs their refined vectors from the device before it goes on (xhost_parser_set_dmvr_mvs). */
-#define PIPE_DEPTH 3                 /* pictures in flight between the parser, the builder and the device thread */
+#define MAX_BUILDERS 4
+#define PIPE_DEPTH (2 + MAX_BUILDERS)  /* most pictures in flight between the parser, the builders and the device thread; in use: 2 + --builders (g_depth) */
 typedef struct {
     xhost_parser *ps;
     xhost_picture pic[PIPE_DEPTH];
@@ -152,7 +155,9 @@ typedef struct {
     xgpu_dbatch *db[PIPE_DEPTH];     /* built by the builder thread */
     int build_rc[PIPE_DEPTH];
     double build_ms[PIPE_DEPTH];
-    long produced, built, released;  /* pictures handed over by the parser thread / by the builder thread / given back by the consumer */
+    long built_k[PIPE_DEPTH];        /* k + 1 once picture k (in slot k % depth) has been built */
+    int n_builders;
+    long produced, released;         /* pictures handed over by the parser thread / given back by the consumer */
     int stop;
     xgpu_ctx *g;                     /* the worker's context once the device thread has settled it for this unit (the builder thread waits for it) */
     pthread_mutex_t mu;
@@ -164,9 +169,9 @@ static void *parser_thread(void *arg)
 {
     pipe_t *q = (pipe_t *)arg;
     for (long k = 0;; k++) {
-        const int s = (int)(k % PIPE_DEPTH);
+        const int s = (int)(k % g_depth);
         pthread_mutex_lock(&q->mu);
-        while (!q->stop && q->released < k - (PIPE_DEPTH - 1)) pthread_cond_wait(&q->cv, &q->mu);      /* slot k % depth is free once picture k - depth has been given back */
+        while (!q->stop && q->released < k - (g_depth - 1)) pthread_cond_wait(&q->cv, &q->mu);      /* slot k % depth is free once picture k - depth has been given back */
         const int stop = q->stop;
         pthread_mutex_unlock(&q->mu);
         if (stop) break;
@@ -189,11 +194,14 @@ static void *parser_thread(void *arg)
 
 /* The middle stage: picture k's device batch (xgpu_batch_create: records, transform-block lists, dependency plan, staging block, upload) is built here while the
    device thread launches picture k - 1 and the parser is inside picture k + 1.  xgpu_batch_create may run next to the thread that drives the context. */
+typedef struct { void *q; int id; } builder_arg_t;
 static void *builder_thread(void *arg)
 {
-    pipe_t *q = (pipe_t *)arg;
-    for (long k = 0;; k++) {
-        const int s = (int)(k % PIPE_DEPTH);
+    pipe_t *q = (pipe_t *)((builder_arg_t *)arg)->q;
+    /* --builders N: N of these threads, thread i on pictures i, i + N, ... - a picture's batch does not depend on the one before it, and at 8K the build
+       (13 ms on 4 threads, largely its dependency plan) was the longest stage of the pipeline */
+    for (long k = ((builder_arg_t *)arg)->id;; k += q->n_builders) {
+        const int s = (int)(k % g_depth);
         pthread_mutex_lock(&q->mu);
         while (!q->stop && q->produced <= k) pthread_cond_wait(&q->cv, &q->mu);
         const int prc = q->stop ? 0 : q->rc[s];
@@ -212,7 +220,7 @@ static void *builder_thread(void *arg)
         }
         pthread_mutex_lock(&q->mu);
         q->build_rc[s] = brc;
-        q->built = k + 1;
+        q->built_k[s] = k + 1;
         pthread_cond_broadcast(&q->cv);
         pthread_mutex_unlock(&q->mu);
         if (prc != 1 || brc < 0) break;
@@ -229,7 +237,8 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
     size_t frame_bytes = 0;                                         /* download of picture k runs while picture k + 1 is parsed and launched     */
     xgpu_dbatch *db = NULL;
     int16_t *mv = NULL;
-    pthread_t th, bth;
+    pthread_t th, bth[MAX_BUILDERS];
+    builder_arg_t barg[MAX_BUILDERS];
     int builder_on = 0;
     pipe_t q;
     memset(&q, 0, sizeof(q));
@@ -243,7 +252,7 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
         if (w->ps) {
             if (g_tile_threads > 1) xhost_parser_set_threads(w->ps, g_tile_threads);      /* the tiles of a picture on parallel host threads */
             xhost_parser_set_arena(w->ps, arena_alloc, arena_release, w);
-            if (g_pipeline) xhost_parser_set_depth(w->ps, PIPE_DEPTH);
+            if (g_pipeline) xhost_parser_set_depth(w->ps, g_depth);
         }
     }
     q.ps = w->ps;
@@ -251,14 +260,17 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
     if (g_pipeline) {
         if (pthread_create(&th, NULL, parser_thread, &q) != 0) { rc = -1; goto done; }
         thread_on = 1;
-        if (pthread_create(&bth, NULL, builder_thread, &q) != 0) { rc = -1; goto done; }
-        builder_on = 1;
+        q.n_builders = g_builders;
+        for (; builder_on < g_builders; builder_on++) {
+            barg[builder_on].q = &q; barg[builder_on].id = builder_on;
+            if (pthread_create(&bth[builder_on], NULL, builder_thread, &barg[builder_on]) != 0) { rc = -1; goto done; }
+        }
     }
 #define FAIL(code) do { rc = (code); goto done; } while (0)
 #define TRY(call) do { int rc_ = (call); if (rc_ < 0) { fprintf(stderr, "%s -> %d (%s)\n", #call, rc_, w->g ? xgpu_last_error(w->g) : ""); FAIL(rc_); } } while (0)
 
     for (long k = 0;; k++) {
-        const int ks = (int)(k % PIPE_DEPTH);
+        const int ks = (int)(k % g_depth);
         xhost_picture *pp = &q.pic[ks];
         int prc;
         if (thread_on) {
@@ -326,7 +338,7 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
         double build_ms;
         if (builder_on) {                                            /* built by the builder thread while picture k - 1 was being launched */
             pthread_mutex_lock(&q.mu);
-            while (q.built <= k) pthread_cond_wait(&q.cv, &q.mu);
+            while (q.built_k[ks] != k + 1) pthread_cond_wait(&q.cv, &q.mu);
             const int brc = q.build_rc[ks];
             db = q.db[ks]; q.db[ks] = NULL;
             build_ms = q.build_ms[ks];
@@ -403,7 +415,7 @@ done:
         pthread_cond_broadcast(&q.cv);
         pthread_mutex_unlock(&q.mu);
         pthread_join(th, NULL);
-        if (builder_on) pthread_join(bth, NULL);
+        for (int i = 0; i < builder_on; i++) pthread_join(bth[i], NULL);
         for (int i = 0; i < PIPE_DEPTH; i++) if (q.db[i]) { xgpu_batch_destroy(w->g, q.db[i]); q.db[i] = NULL; }      /* built, never launched (an error further down the pipeline) */
     }
     pthread_mutex_destroy(&q.mu); pthread_cond_destroy(&q.cv);
@@ -492,6 +504,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[a], "--no-pipeline")) { g_pipeline = 0; a += 1; }
         else if (!strcmp(argv[a], "--trace")) { g_trace = 1; a += 1; }
         else if (!strcmp(argv[a], "--build-threads") && a + 1 < argc) { g_build_threads = atoi(argv[a + 1]); a += 2; }
+        else if (!strcmp(argv[a], "--builders") && a + 1 < argc) { g_builders = atoi(argv[a + 1]); if (g_builders < 1) g_builders = 1; if (g_builders > MAX_BUILDERS) g_builders = MAX_BUILDERS; g_depth = 2 + g_builders; a += 2; }
         else if (!strcmp(argv[a], "--keep-units") && a + 1 < argc) { g_keep_units = atoi(argv[a + 1]); a += 2; }
         else if (!strcmp(argv[a], "--json")) { g_json = 1; a++; }
         else break;
@@ -499,7 +512,7 @@ int main(int argc, char **argv)
     int n_pos = argc - a;
     if (n_pos == 3 && strspn(argv[a + 2], "0123456789") == strlen(argv[a + 2])) { out_bd = atoi(argv[a + 2]); n_pos = 2; }      /* in out D */
     if (n_pos < 2 || (n_pos & 1) || gpus < 1 || workers < 1 || gpus * workers > 64 || n_pos / 2 > MAX_STREAMS) {
-        fprintf(stderr, "usage: %s [--gpus N] [--workers W] [--tile-threads T] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]\n", argv[0]);
+        fprintf(stderr, "usage: %s [--gpus N] [--workers W] [--tile-threads T] [--build-threads B] [--builders N] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]\n", argv[0]);
         return 2;
     }
     static stream_t streams[MAX_STREAMS];
@@ -557,10 +570,10 @@ int main(int argc, char **argv)
         long per_dev[64];
         memset(per_dev, 0, sizeof(per_dev));
         for (int i = 0; i < g_workers && i < 64; i++) if (g_dev[i] >= 0 && g_dev[i] < 64) per_dev[g_dev[i]] += g_pics[i];
-        printf("{\"pictures\": %ld, \"streams\": %d, \"jobs\": %d, \"devices\": %d, \"workers_per_device\": %d, \"tile_threads\": %d, \"build_threads\": %d, \"pipeline\": %d, "
+        printf("{\"pictures\": %ld, \"streams\": %d, \"jobs\": %d, \"devices\": %d, \"workers_per_device\": %d, \"tile_threads\": %d, \"build_threads\": %d, \"builders\": %d, \"pipeline\": %d, "
                "\"wall_s\": %.4f, \"decode_only_s\": %.4f, \"fps_wall\": %.2f, \"fps_decode_only\": %.2f, \"setup_s\": %.3f, \"parse_ms_per_picture\": %.3f, \"build_ms_per_picture\": %.3f, "
                "\"cpu_user_s\": %.3f, \"cpu_sys_s\": %.3f, \"pictures_per_device\": [",
-               total_pictures, n_streams, n_jobs, gpus / workers, workers, g_tile_threads, g_build_threads, g_pipeline, secs, busy, secs > 0 ? (double)total_pictures / secs : 0.0,
+               total_pictures, n_streams, n_jobs, gpus / workers, workers, g_tile_threads, g_build_threads, g_builders, g_pipeline, secs, busy, secs > 0 ? (double)total_pictures / secs : 0.0,
                busy > 0 ? (double)total_pictures / busy : 0.0, setup, total_pictures ? 1e3 * parse / (double)total_pictures : 0.0, total_pictures ? 1e3 * build / (double)total_pictures : 0.0,
                (double)ru.ru_utime.tv_sec + 1e-6 * (double)ru.ru_utime.tv_usec, (double)ru.ru_stime.tv_sec + 1e-6 * (double)ru.ru_stime.tv_usec);
         for (int d = 0; d < gpus / workers; d++) printf("%s%ld", d ? ", " : "", per_dev[d]);

@@ -1385,6 +1385,18 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
         if (next && !next_waited) { HIPCHK(c, hipStreamWaitEvent(c->stream, next->blk.uploaded, 0)); next_waited = true; }
         return XGPU_OK;
     };
+    // XEVD_HIP_RIDE (measurement knob): where the next picture's residual pass goes.  0 (default): into this picture's data-flow intra launch; 1: onto the side stream - its
+    // own hardware queue since round 4 - next to this picture's k_inter; 2: onto the side stream behind k_inter, next to the intra launches
+    static const int ride_mode = getenv("XEVD_HIP_RIDE") ? atoi(getenv("XEVD_HIP_RIDE")) : 0;
+    auto ride_side = [&]() -> int {
+        HIPCHK(c, hipEventRecord(c->after_inter, c->stream));              // everything queued so far - the batch's previous use among it - is behind the pass
+        HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->after_inter, 0));
+        HIPCHK(c, hipStreamWaitEvent(c->side_stream, next->blk.uploaded, 0));
+        launch_itdq(c, itdq_args(c, next), c->side_stream);
+        HIPCHK(c, hipEventRecord(next->blk.itdq_done, c->side_stream));
+        next->upload_waited = 1; next->prepared = 1; next->used = 1; next = NULL;
+        return XGPU_OK;
+    };
     if (db->tiles_across) memset(&c->no_dbk, 0, sizeof(c->no_dbk)); else c->no_dbk = db->tile_starts;
     if (db->prepared == 2) {                                             // the residual pass ran on this stream with the previous picture
         db->prepared = 0;
@@ -1432,7 +1444,9 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
         HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->fork_ev, 0));
         tool_stream = c->side_stream;
     }
+    if (next && ride_mode == 1 && !c->timing && db->prepared == 0) { const int rc = ride_side(); if (rc != XGPU_OK) return rc; }
     TIMED(c, XGPU_K_INTER, launch_inter(c, a));
+    if (next && ride_mode == 2 && !c->timing) { const int rc = ride_side(); if (rc != XGPU_OK) return rc; }
     if (!ahead) HIPCHK(c, hipEventRecord(c->after_inter, c->stream));   // where a residual pass prepared on the side stream (xgpu_batch_prepare) may start
     c->have_after_inter = 1;
     if (db->n_dmvr) {
