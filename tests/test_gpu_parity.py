@@ -594,8 +594,10 @@ def test_gpu_plain_c_decoder_work_queue(tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("args", [["--workers", "1", "--tile-threads", "8"], ["--workers", "1", "--tile-threads", "8", "--no-pipeline"], ["--workers", "3", "--tile-threads", "2"]],
-                         ids=["pipelined", "back_to_back", "gop_parallel"])
+@pytest.mark.parametrize("args", [["--workers", "1", "--tile-threads", "8"], ["--workers", "1", "--tile-threads", "8", "--no-pipeline"], ["--workers", "3", "--tile-threads", "2"],
+                                  ["--workers", "1", "--tile-threads", "8", "--builders", "1"], ["--workers", "1", "--tile-threads", "4", "--builders", "4", "--build-threads", "2"],
+                                  ["--workers", "2", "--tile-threads", "4", "--builders", "3", "--build-threads", "2"]],
+                         ids=["pipelined", "back_to_back", "gop_parallel", "one_builder", "four_builders", "gop_parallel_three_builders"])
 def test_gpu_bench_stream_plain_c_decoder(args, tmp_path):
     """the real-bitstream leg of bench.py at 1920x1088: random-access Main (hierarchical B, two lists of two references, tool_admvp, IQT, ADDB, ALF, 4x4 tiles),
     three IDR periods, decoded by examples/evc_decode - parser thread one picture ahead of the device thread, back to back, and GOP-parallel - must be the
