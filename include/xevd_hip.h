@@ -235,7 +235,9 @@ int  xgpu_frame_begin(xgpu_ctx *ctx, const xgpu_frame_params *fp);
 int  xgpu_batch_create(xgpu_ctx *ctx, const xgpu_cu_batch *b, xgpu_dbatch **out);
 /* xgpu_batch_create / xgpu_batch_destroy are the two entry points that may run on ANOTHER thread than the one driving the context (a builder
    thread preparing picture k+1 while picture k is being launched): the upload goes through the context's own upload stream, and
-   xgpu_batch_recon makes the kernels wait for it.  xgpu_batch_wait_upload blocks until the batch's arrays have left host memory.        */
+   xgpu_batch_recon makes the kernels wait for it.  Several threads may be inside xgpu_batch_create of ONE context at a time (pictures built side
+   by side: examples/evc_decode --builders, bench.py's end-to-end leg); the staging-block pool is locked, every thread has its own scratch and
+   worker pool.  xgpu_batch_wait_upload blocks until the batch's arrays have left host memory.                                             */
 int  xgpu_batch_wait_upload(xgpu_ctx *ctx, xgpu_dbatch *db);
 /* DMVR: the vectors the decoder stores for temporal prediction (map_mv / dmvr_mv, src_main/xevdm_mc.c:1783-1797, xevdm.c:1553-1563) after
    xgpu_batch_recon: for every CU of the batch with the dmvr flag, two references and at least 8x8 samples - in batch order, its 16x16

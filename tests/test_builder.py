@@ -149,3 +149,34 @@ def test_builder_arbitrary_cu_order_inside_ctus(name):
         rc = lib.xgpu_test_build_batch(C.byref(sp), C.byref(cb), threads, dg, info, C.byref(ms))
         out.append((rc, [int(v) for v in dg][:10] if rc == 0 else None))
     assert out[0] == out[1] and out[0][0] in (0, -101)
+
+
+def test_builder_several_callers_at_once():
+    """pictures built side by side (examples/evc_decode --builders, bench.py's end-to-end leg): four caller threads, each with its own pool of builder threads, inside
+    the builder at the same time - every call returns the committed digests of its picture"""
+    import threading
+    from xevd_amd import synth
+    lib = _lib()
+    goldens = json.load(open(GOLDEN_FILE))
+    jobs = []
+    for case in LARGE[:2]:
+        name, w, h, kw, spkw = case
+        b = synth.gen_frame(np.random.default_rng(11), w, h, 10, coded_frac=0.6, qp_range=(22, 37), **kw)
+        cb, keep = abi.make_cu_batch(b)
+        jobs.append((goldens["large_" + name], abi.make_seq_params(w, h, 10, **spkw), cb, keep))
+    errors = []
+
+    def caller(k):
+        try:
+            for rep in range(4):
+                want, sp, cb, _ = jobs[(k + rep) % len(jobs)]
+                if _build(lib, sp, cb, 1 + k % 3) != want:
+                    errors.append(f"caller {k}, call {rep}")
+        except Exception as e:      # noqa: BLE001 - reported below
+            errors.append(f"caller {k}: {e!r}")
+    threads = [threading.Thread(target=caller, args=(k,)) for k in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
