@@ -122,6 +122,19 @@ def test_gpu_pictures_golden_residual_pass_ahead(name):
         assert np.array_equal(out[c], exp["out"][c]), f"final plane {c}: {np.argwhere(out[c] != exp['out'][c])[:4]}"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_gpu_residual_pass_ahead_on_the_side_stream(mode):
+    """XEVD_HIP_RIDE=1 / 2 (measurement knob, read once per process): the next picture's residual pass on the context's side stream - next to this picture's k_inter, or
+    behind it - instead of inside the data-flow intra launch: the picture goldens through xgpu_batch_recon_ahead again, in a process of their own"""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_gpu_pictures_golden_residual_pass_ahead", "-p", "no:cacheprovider"],
+                       env=dict(os.environ, XEVD_HIP_RIDE=mode), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0, r.stdout.decode()[-1500:]
+    assert b" passed" in r.stdout
+
+
 RANDOM = [
     # name, w, h, bd, admvp, iqt, n_refs, bi_frac, kwargs
     ("rnd_a", 264, 136, 8, 0, 0, (2, 1), 0.3, {}),
