@@ -180,3 +180,11 @@ def test_builder_several_callers_at_once():
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_builder_survives_mutated_batches():
+    """tests/tools/fuzz_builder.py (a process of its own: a crash must not take the suite along): picture goldens with a few elements of their arrays overwritten -
+    out-of-range geometry, modes, reference indices, offsets - are built or refused, nothing else"""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "fuzz_builder.py"), "5", "150"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and b"done:" in r.stdout, r.stdout.decode()[-800:]
