@@ -14,8 +14,8 @@
  * chain on one host core (an 8K picture takes tens of milliseconds to parse, its kernels half a millisecond), so a GPU is fed by parsing
  * several GOPs at once.
  * --tile-threads T lets every worker's parser use T threads for the tiles of one picture (xhost_parser_set_threads).
- * Every worker is a pipeline of three threads: the parser (entropy decoding, picture k + 2), the batch builder (xgpu_batch_create, picture k + 1) and the
- * device thread (kernel launches and output of picture k); --no-pipeline: back to back on one thread, as xevd_dec_nalu does it.  A worker keeps its parser
+ * Every worker is a pipeline of three stages: the parser thread (entropy decoding, picture k + 1 + N), N batch-builder threads (--builders, default 2: xgpu_batch_create of
+ * pictures k + 1 .. k + N side by side, picture j on thread j mod N) and the device thread (kernel launches and output of picture k); --no-pipeline: back to back on one thread, as xevd_dec_nalu does it.  A worker keeps its parser
  * (xhost_parser_rebind), its context, its pinned buffers and its threads from unit to unit.
  * usage: evc_decode [--gpus N] [--workers W] [--tile-threads T] [--build-threads B] [--builders N] [--keep-units K] [--no-pipeline] [--trace] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
  *        evc_decode in.evc out.yuv D                                               (the round-1 form)
