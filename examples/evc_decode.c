@@ -14,7 +14,7 @@
  * chain on one host core (an 8K picture takes tens of milliseconds to parse, its kernels half a millisecond), so a GPU is fed by parsing
  * several GOPs at once.
  * --tile-threads T lets every worker's parser use T threads for the tiles of one picture (xhost_parser_set_threads).
- * Every worker is a pipeline of three stages: the parser thread (entropy decoding, picture k + 1 + N), N batch-builder threads (--builders, default 2: xgpu_batch_create of
+ * Every worker is a pipeline of three stages: the parser thread (entropy decoding, picture k + 1 + N), N batch-builder threads (--builders; default 2 for one or two workers, 1 for more: xgpu_batch_create of
  * pictures k + 1 .. k + N side by side, picture j on thread j mod N) and the device thread (kernel launches and output of picture k); --no-pipeline: back to back on one thread, as xevd_dec_nalu does it.  A worker keeps its parser
  * (xhost_parser_rebind), its context, its pinned buffers and its threads from unit to unit.
  * usage: evc_decode [--gpus N] [--workers W] [--tile-threads T] [--build-threads B] [--builders N] [--keep-units K] [--no-pipeline] [--trace] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
@@ -40,8 +40,8 @@
 #define CHECK(call) do { int rc_ = (call); if (rc_ < 0) { fprintf(stderr, "%s -> %d (%s)\n", #call, rc_, w->g ? xgpu_last_error(w->g) : ""); return rc_; } } while (0)
 static double now_s(void);
 static int g_keep_units = -1;      /* --keep-units K: only the first K units (closed GOPs) of every input are written to its output file; the rest is decoded all the same (long timing runs) */
-static int g_builders = 2;          /* --builders N: builder threads per worker (pictures built side by side) */
-static int g_depth = 4;             /* 2 + g_builders */
+static int g_builders = 0;          /* --builders N: builder threads per worker (pictures built side by side); 0 = not given: 2 for one or two workers, 1 for more (the host's CPUs are the workers' to share) */
+static int g_depth = 3;             /* 2 + g_builders */
 static int g_build_threads = 8;     /* --build-threads B: host threads xgpu_batch_create spreads its per-CU passes over */
 
 typedef struct { int poc, pic, in_use; } slot_t;                 /* DPB: POC -> device picture slot */
@@ -544,6 +544,7 @@ int main(int argc, char **argv)
     }
     xwq_close(q);
     int devices[64], done[64];
+    if (g_builders == 0) { g_builders = gpus * workers <= 2 ? 2 : 1; g_depth = 2 + g_builders; }
     gpus *= workers;                                                /* worker i runs on device i / workers */
     for (int i = 0; i < gpus; i++) devices[i] = i / workers;
     struct timespec t0, t1;

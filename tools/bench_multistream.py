@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--profile", default="base", choices=["base", "main"])
+    ap.add_argument("--extra", default="", help="more evc_decode options, e.g. \"--builders 1\"")
     ap.add_argument("--processes", action="store_true", help="one evc_decode PROCESS per stream instead of one worker thread per stream in one process (own HIP runtime each)")
     args = ap.parse_args()
     exe = os.path.join(ROOT, "examples", "evc_decode")
@@ -77,7 +78,7 @@ def main():
                 for i in range(k):
                     os.remove(os.path.join(td, f"o{i}.yuv"))
                 continue
-            cmd = [exe, "--workers", str(k)]
+            cmd = [exe, "--workers", str(k)] + args.extra.split()
             for i in range(k):
                 cmd += [os.path.join(td, f"s{i % len(data)}.evc"), os.path.join(td, f"o{i}.yuv")]
             r = subprocess.run(cmd, stderr=subprocess.PIPE, timeout=900)
