@@ -12,6 +12,9 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#define XWQ_ERR_INVALID_ARGUMENT (-101)  /* XEVD_ERR_INVALID_ARGUMENT (inc/xevd.h:61)                                          */
+#define XWQ_ERR_UNEXPECTED       (-105)  /* XEVD_ERR_UNEXPECTED (inc/xevd.h:65): push into a closed queue; a worker that did not come up */
+
 #ifdef __cplusplus
 extern "C" {
 #endif

@@ -51,6 +51,43 @@ def test_struct_sizes_match_header():
     assert C.sizeof(abi.AlfParams) == 3 * 4 + 4 + 3 * 8 + 8 + 8                      # enable, pad, three pointers, across_tiles (padded), tiles
 
 
+def _ref_codes():
+    """XEVD_* constants as the reference's own header defines them: tests/golden/api_layout.txt, printed by tests/tools/api_layout_probe.c compiled against
+    /root/reference/inc/xevd.h (tests/golden/make_golden.py) - NOT this repository's restatement of them"""
+    out = {}
+    for ln in open(os.path.join(ROOT, "tests", "golden", "api_layout.txt")):
+        f = ln.split()
+        if len(f) == 2 and f[0].startswith("XEVD_") and f[1].lstrip("-").isdigit():
+            out[f[0]] = int(f[1])
+    return out
+
+
+def _header_defines(path, prefix):
+    import re
+    txt = open(path).read()
+    return {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(" + prefix + r"\w+)\s+\(?(-?\d+)\)?", txt)}
+
+
+def test_error_codes_equal_the_reference_headers():
+    """Every XGPU_ERR_* / XHOST_ERR_* / XWQ_ERR_* code of the C ABI is the reference's XEVD_ERR_* code of the same name (inc/xevd.h:48-77): a binding forwards them
+    unchanged.  Pinned against the values printed from the reference's header, and xevd_api.h's own enum against the same list."""
+    ref = _ref_codes()
+    assert ref["XEVD_ERR_UNSUPPORTED"] == -104 and ref["XEVD_ERR_UNEXPECTED"] == -105      # (what the reference header says today)
+    seen = 0
+    for hdr, prefix in (("xevd_hip.h", "XGPU_"), ("xevd_host.h", "XHOST_"), ("xevd_wq.h", "XWQ_")):
+        for name, val in _header_defines(os.path.join(ROOT, "include", hdr), prefix + "ERR").items():
+            suffix = name[len(prefix):]
+            want = {"ERR_MALFORMED": "XEVD_ERR_MALFORMED_BITSTREAM"}.get(suffix, "XEVD_" + suffix)
+            assert ref[want] == val, (name, val, want, ref[want])
+            seen += 1
+    assert seen >= 8
+    assert _header_defines(os.path.join(ROOT, "include", "xevd_hip.h"), "XGPU_OK")["XGPU_OK"] == ref["XEVD_OK"]
+    import re
+    api = open(os.path.join(ROOT, "include", "xevd_api.h")).read()
+    for name, val in re.findall(r"(XEVD_(?:ERR|OK|WARN)\w*)\s*=\s*(-?\d+)", api):
+        assert ref[name] == int(val), name
+
+
 def test_argument_errors_without_gpu():
     lib = abi.load()
     assert lib.xgpu_open(None, None) == -101
@@ -59,7 +96,7 @@ def test_argument_errors_without_gpu():
     assert lib.xgpu_open(C.byref(sp), C.byref(out)) == -101 and not out.value
     sp = abi.make_seq_params(128, 64)
     sp.chroma_format_idc = 3
-    assert lib.xgpu_open(C.byref(sp), C.byref(out)) == -105
+    assert lib.xgpu_open(C.byref(sp), C.byref(out)) == _ref_codes()["XEVD_ERR_UNSUPPORTED"]
     assert lib.xgpu_version().startswith(b"xevd_amd")
 
 

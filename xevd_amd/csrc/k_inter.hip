@@ -21,6 +21,7 @@
 //   * no MFMA: these are 4/8-tap integer FIRs, bounded by load/issue rate and HBM, not by dense contraction.
 #include "xgpu_internal.h"
 
+#include <hip/hip_ext.h>
 #include "mc_filters.h"
 
 // ---------------------------------------------------------------------------------------------------------
@@ -576,104 +577,118 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
     return true;
 }
 
-// One workgroup per 64x64 region, one wave per 32x32 tile, no barrier after the tables are staged: every wave walks its own chain owner entry ->
-// CU record -> reference windows.  The host paints the owner map (xgpu_batch_create), so there is no k_paint and no per-CTU staging of CU records.
-// (A persistent variant that kept the first links of the next tiles in flight was measured slower: the prefetch registers pushed the kernel into
-// scratch and its 53 KB of code out of the instruction cache; DESIGN.md.)
-// (Round 3: forcing the register allocator to five waves per SIMD - amdgpu_waves_per_eu(5, 5): 96 VGPRs + 192 bytes of scratch per lane - took 286 us instead of 152.)
-// (Round 3, occupancy sweep with dynamic LDS padding at 8K: 4 workgroups per CU 147 us, 3 per CU 153 us, 2 per CU 176 us - the kernel is not bound by the latency of
-//  its chains any more; its 507 MB of measured traffic in 147 us are 3.45 TB/s, 72 % of what this part's plain copy kernel reaches.)
-// (Round 3, non-temporal hints on the streaming accesses - residual loads, sample and SCU-record stores - so that they would not push reference lines out of L2:
-//  reads 2.83 M -> 2.70 M lines, but the stores no longer combine into 64-byte writes (2.05 M of 2.37 M requests -> 1.77 M of 2.63 M) and the kernel took 154 us
-//  instead of 140; on the loads alone 143 us.  Every read request of this kernel is a whole 128-byte line: the 39 x 78-byte rows of a window at an arbitrary offset
-//  touch 1.6 lines each, which is where the 2.2x between the windows' 134 MB and the 293 MB fetched for them comes from.)
-__global__ __launch_bounds__(256) void k_inter(const InterArgs a)
+// ---------------------------------------------------------------------------------------------------------
+// Three launches per picture, one per CLASS of 32x32 tile, each with its own register budget (round 5: as three paths of one kernel every path paid the registers of
+// the others - 128 -> 143 -> 156 VGPRs over the rounds, three waves per SIMD).  xgpu_batch_create sorts the picture into three work lists in ONE spatial order (vertical
+// strips XGPU_INTER_STRIP regions wide, row by row inside a strip):
+//   k_inter_region  64x64 regions inside one CU: one workgroup per region, the reference windows fetched once per workgroup into LDS the four waves share;
+//   k_inter_tile    32x32 tiles inside one CU (whose region is not): one wave per tile, the window in the wave's own LDS;
+//   k_inter_split   every other tile: one wave per tile, one lane per SCU, every lane on the CU that covers its SCU (owner map).
+// The classes are disjoint sets of whole 32x32 tiles, so the launches write disjoint 64-byte row segments and disjoint SCU-map records: the second and third are
+// launched without the barrier bit and overlap the tail of the one before (launch_inter).  The first two know their CU from the list entry: the CU record, the reference table (kernel arguments) and the tap tables
+// (constant memory) are read with wave-uniform addresses - no owner-map link in the chain, no LDS tables, no barrier in front of the work.
+// XCD-aware mapping (all three): workgroup b runs on XCD b % 8 and every XCD has its own L2; XCD k takes the k-th contiguous eighth of the list - a compact patch of
+// the picture whose vertical halos are still in its L2 when the row below is processed.
+// History of the single-kernel form (rounds 1-4: persistent waves, class-sorted pieces, occupancy sweeps, non-temporal hints, region order) is in DESIGN.md 3.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int xcd_slice(int block, int grid) { return (block & 7) * (grid >> 3) + (block >> 3); }
+
+__device__ __forceinline__ void store_scu(const InterArgs &a, int sx, int sy, const uint32_t pl[8], const uint32_t pu[2], const uint32_t pv[2])
+{
+    const int x = sx << 2, y = sy << 2;
+    int16_t *dy = a.cur_y + y * a.s_l + x;
+#pragma unroll
+    for (int k = 0; k < 4; k++) *(uint2 *)(dy + k * a.s_l) = make_uint2(pl[k * 2], pl[k * 2 + 1]);
+    const int coff = (y >> 1) * a.s_c + (x >> 1);
+    *(uint32_t *)(a.cur_u + coff) = pu[0];
+    *(uint32_t *)(a.cur_u + coff + a.s_c) = pu[1];
+    *(uint32_t *)(a.cur_v + coff) = pv[0];
+    *(uint32_t *)(a.cur_v + coff + a.s_c) = pv[1];
+}
+// the reference table as inter_tile reads it ([index * 2 + list][2 halves]) and the tap tables, where they lie for wave-uniform indices
+#define ARG_REFS(a)  ((const uint4 (*)[2])&(a).refp[0][0])
+#define ARG_LTAPS(a) ((const uint4 *)&k_luma_taps[(a).admvp][0][0])
+#define ARG_CTAPS(a) ((const uint2 *)&k_chroma_taps[(a).admvp][0][0])
+static_assert(sizeof(RefEntry) == 32, "a reference entry is two 16-byte halves");
+
+__global__ __launch_bounds__(256) void k_inter_region(const InterArgs a)
+{
+    __shared__ __attribute__((aligned(16))) int16_t s_win[REG_SAMPLES];      // the region's shared windows + the four waves' intermediates
+    const int idx = xcd_slice(blockIdx.x, gridDim.x);
+    if (idx >= a.n_regions) return;
+    const uint2 e = a.regions[idx];
+    const int rx = e.x & 0xFFFF, ry = e.x >> 16;
+    const int t = threadIdx.x, lane = t & 63;
+    const int sx = (rx << 4) + ((t >> 6 & 1) << 3) + (lane & 7), sy = (ry << 4) + ((t >> 7) << 3) + (lane >> 3);
+    const uint4 c0 = ((const uint4 *)&a.cus[e.y])[0], c1 = ((const uint4 *)&a.cus[e.y])[1];
+    const RegionMap rmap = region_map(t);
+    const LaneMap fm = { 0, 0 };
+    uint32_t pl[8], pu[2], pv[2];
+    if (inter_tile<2>(a, c0, c1, true, sx, sy, lane, s_win, fm, ARG_REFS(a), ARG_LTAPS(a), ARG_CTAPS(a), pl, pu, pv, &rmap, t >> 6, e.y)) store_scu(a, sx, sy, pl, pu, pv);
+}
+
+__global__ __launch_bounds__(256) void k_inter_tile(const InterArgs a)
+{
+    __shared__ __attribute__((aligned(16))) int16_t s_win[4 * UNI_SAMPLES];  // per wave: window + intermediate
+    const int t = threadIdx.x, lane = t & 63;
+    const int idx = xcd_slice(blockIdx.x, gridDim.x) * 4 + (t >> 6);
+    if (idx >= a.n_tiles) return;                                            // (no barrier in this kernel)
+    const uint2 e = a.tiles[idx];
+    const int sx = ((e.x & 0xFFFF) << 3) + (lane & 7), sy = ((e.x >> 16) << 3) + (lane >> 3);
+    const uint4 c0 = ((const uint4 *)&a.cus[e.y])[0], c1 = ((const uint4 *)&a.cus[e.y])[1];
+    LaneMap fm;
+    {
+        const int row0 = (lane * 171) >> 10, k = lane - row0 * 6;            // luma window: 10 rows x 6 aligned chunks of 8 samples per pass (lanes 60..63 idle)
+        fm.gy = row0 * a.s_l + 8 * k; fm.ly = row0 * UW_STRIDE + 8 * k;
+    }
+    uint32_t pl[8], pu[2], pv[2];
+    if (inter_tile<1>(a, c0, c1, true, sx, sy, lane, s_win + (t >> 6) * UNI_SAMPLES, fm, ARG_REFS(a), ARG_LTAPS(a), ARG_CTAPS(a), pl, pu, pv, nullptr, 0, e.y)) store_scu(a, sx, sy, pl, pu, pv);
+}
+
+__global__ __launch_bounds__(256) void k_inter_split(const InterArgs a)
 {
     __shared__ uint4    s_ref[XGPU_MAX_REFS * 2][2];        // RefEntry [idx][list]
     __shared__ uint4    s_ltap[17];                         // luma taps of this sequence's table, [16] = identity
     __shared__ uint2    s_ctap[33];
-    static_assert(REG_SAMPLES >= 4 * UNI_SAMPLES, "the shared region block holds the four waves' own blocks");
-    __shared__ __attribute__((aligned(16))) int16_t s_tile[REG_SAMPLES];          // per wave: window + intermediate of the tile path; or the region's shared windows + four intermediates
-    __shared__ uint32_t s_own[4];                               // the CU every wave's tile lies in (OWNER_NONE: several): all four the same -> the region path
-    // XCD-aware mapping: workgroup b runs on XCD b % 8 and every XCD has its own L2.  The regions are ordered in vertical strips INTER_STRIP wide
-    // (row-major inside a strip) and every XCD takes a contiguous eighth of that order - about one strip: the ~100 workgroups it has in flight
-    // form a compact patch whose vertical halos are still in its L2 when the row below is processed, and all XCDs get the same number of regions.
-    const int idx = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    if (idx >= a.n_regions) return;
-    const int regions_y = a.n_regions / a.regions_x;
-    int rx, ry;
-    if (a.order == 0) {
-        const int per_strip = a.strip * regions_y;
-        const int strip = idx / per_strip, ks = idx - strip * per_strip;
-        const int sw = min(a.strip, a.regions_x - strip * a.strip);       // the last strip may be narrower
-        ry = ks / sw; rx = strip * a.strip + (ks - ry * sw);
-    } else {                                                              // horizontal bands a.strip regions high, column by column inside a band
-        const int per_band = a.strip * a.regions_x;
-        const int band = idx / per_band, ks = idx - band * per_band;
-        const int bh = min(a.strip, regions_y - band * a.strip);
-        rx = ks / bh; ry = band * a.strip + (ks - rx * bh);
-    }
     const int t = threadIdx.x, lane = t & 63;
-    // SCU coordinates in the picture: a wave covers 8x8 SCUs (32x32 samples), so that CUs of 32x32 and above fill whole waves
-    const int sx = (rx << 4) + ((t >> 6 & 1) << 3) + (lane & 7), sy = (ry << 4) + ((t >> 7) << 3) + (lane >> 3);
-    const bool active = sx < (a.pic_w >> 2) && sy < (a.pic_h >> 2);
+    const int idx = xcd_slice(blockIdx.x, gridDim.x) * 4 + (t >> 6);
+    const bool have = idx < a.n_splits;
+    const uint32_t e = have ? a.splits[idx] : 0u;
+    const int sx = ((e & 0xFFFF) << 3) + (lane & 7), sy = ((e >> 16) << 3) + (lane >> 3);
+    const bool active = have && sx < (a.pic_w >> 2) && sy < (a.pic_h >> 2);
     // the first link of the chain goes out before the tables are staged
     const uint32_t own = active ? a.owner[sy * a.w_scu + sx] : OWNER_NONE;
-    // ... and so do the table loads, ONE per lane, all before the first wait: three branches of "load, store to LDS" were three more round trips in a row in
-    // front of the CU record loads (the ISA had load + s_waitcnt vmcnt(0) three times between the owner load and the record loads)
-    static_assert(XGPU_MAX_REFS * 4 <= 96 && sizeof(RefEntry) == 32, "one 16-byte half of a reference entry per lane, in front of the tap tables' lanes");
+    // ... and so do the table loads, ONE per lane, all before the first wait
+    static_assert(XGPU_MAX_REFS * 4 <= 96, "one 16-byte half of a reference entry per lane, in front of the tap tables' lanes");
     uint4 tab = make_uint4(0, 0, 0, 0);
     if (t < XGPU_MAX_REFS * 4) tab = ((const uint4 *)&a.refp[0][0])[t];
     else if (t >= 96 && t < 96 + 17) tab = *(const uint4 *)k_luma_taps[a.admvp][t - 96];
     else if (t >= 128 && t < 128 + 33) { const uint2 v = *(const uint2 *)k_chroma_taps[a.admvp][t - 128]; tab.x = v.x; tab.y = v.y; }
     uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
-    const bool ok = own < (uint32_t)a.n_cu;                    // unowned (another tile's SCU) or not an index of this batch
+    const bool ok = own < (uint32_t)a.n_cu;                    // unowned (another batch's SCU) or not an index of this batch
     if (ok) { c0 = ((const uint4 *)&a.cus[own])[0]; c1 = ((const uint4 *)&a.cus[own])[1]; }
     if (t < XGPU_MAX_REFS * 4) s_ref[t >> 1][t & 1] = tab;
     else if (t >= 96 && t < 96 + 17) s_ltap[t - 96] = tab;
     else if (t >= 128 && t < 128 + 33) s_ctap[t - 128] = make_uint2(tab.x, tab.y);
-    const bool uni = __ballot(ok) == ~0ull && __ballot(own == __builtin_amdgcn_readfirstlane(own)) == ~0ull;
-    if (lane == 0) s_own[t >> 6] = uni ? own : OWNER_NONE;
     __syncthreads();
-    const bool region = !a.no_region && s_own[0] != OWNER_NONE && s_own[0] == s_own[1] && s_own[0] == s_own[2] && s_own[0] == s_own[3];
-
-    int16_t *W = s_tile + (t >> 6) * UNI_SAMPLES;
-    LaneMap fm;
-    {
-        const int row0 = (lane * 171) >> 10, k = lane - row0 * 6;         // luma window: 10 rows x 6 aligned chunks of 8 samples per pass (lanes 60..63 idle)
-        fm.gy = row0 * a.s_l + 8 * k; fm.ly = row0 * UW_STRIDE + 8 * k;
-    }
-    // every path stores on its own and leaves (one common tail would make the register allocator keep the three paths' results in the same registers)
-    auto store_tile = [&](const uint32_t pl[8], const uint32_t pu[2], const uint32_t pv[2]) {
-        const int x = sx << 2, y = sy << 2;
-        int16_t *dy = a.cur_y + y * a.s_l + x;
-#pragma unroll
-        for (int k = 0; k < 4; k++) *(uint2 *)(dy + k * a.s_l) = make_uint2(pl[k * 2], pl[k * 2 + 1]);
-        const int coff = (y >> 1) * a.s_c + (x >> 1);
-        *(uint32_t *)(a.cur_u + coff) = pu[0];
-        *(uint32_t *)(a.cur_u + coff + a.s_c) = pu[1];
-        *(uint32_t *)(a.cur_v + coff) = pv[0];
-        *(uint32_t *)(a.cur_v + coff + a.s_c) = pv[1];
-    };
-    if (region) {
-        uint32_t pl[8], pu[2], pv[2];
-        const RegionMap rmap = region_map(t);
-        if (inter_tile<2>(a, c0, c1, true, sx, sy, lane, s_tile, fm, s_ref, s_ltap, s_ctap, pl, pu, pv, &rmap, t >> 6, own)) store_tile(pl, pu, pv);
-        return;
-    }
-    if (uni) {
-        uint32_t pl[8], pu[2], pv[2];
-        if (inter_tile<1>(a, c0, c1, true, sx, sy, lane, W, fm, s_ref, s_ltap, s_ctap, pl, pu, pv, nullptr, 0, own)) store_tile(pl, pu, pv);
-        return;
-    }
+    const LaneMap fm = { 0, 0 };
     uint32_t pl[8], pu[2], pv[2];
-    if (inter_tile<0>(a, c0, c1, ok, sx, sy, lane, W, fm, s_ref, s_ltap, s_ctap, pl, pu, pv, nullptr, 0, own)) store_tile(pl, pu, pv);
+    if (inter_tile<0>(a, c0, c1, ok, sx, sy, lane, nullptr, fm, s_ref, s_ltap, s_ctap, pl, pu, pv, nullptr, 0, own)) store_scu(a, sx, sy, pl, pu, pv);
 }
 
-void launch_inter(xgpu_ctx *c, const InterArgs &a)
+void launch_inter(xgpu_ctx *c, const InterArgs &a, bool any_order)
 {
-    const int lds_pad = getenv("XEVD_HIP_INTER_LDSPAD") ? atoi(getenv("XEVD_HIP_INTER_LDSPAD")) : 0;      // measurement knob: dynamic LDS that only lowers the occupancy
-    hipLaunchKernelGGL(k_inter, dim3(((a.n_regions + 7) >> 3) << 3), dim3(256), lds_pad, c->stream, a);
+    auto grid = [](int n, int per) { return dim3((unsigned)((((n + per - 1) / per + 7) >> 3) << 3)); };
+    // the split tiles first: their per-lane chains run longest.  any_order: all three on one stream, the second and third without the barrier bit (hipExtAnyOrderLaunch)
+    bool first = true;
+    auto go = [&](auto kernel, dim3 g) {
+        if (any_order && !first) hipExtLaunchKernelGGL(kernel, g, dim3(256), 0, c->stream, nullptr, nullptr, hipExtAnyOrderLaunch, a);
+        else hipLaunchKernelGGL(kernel, g, dim3(256), 0, c->stream, a);
+        first = false;
+    };
+    if (a.n_splits) go(k_inter_split, grid(a.n_splits, 4));
+    if (a.n_regions) go(k_inter_region, grid(a.n_regions, 1));
+    if (a.n_tiles) go(k_inter_tile, grid(a.n_tiles, 4));
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -158,6 +158,7 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     c->sp.chroma_qp_table[0] = c->sp.chroma_qp_table[1] = NULL;
     c->builder_threads = 1;
     c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_dra = NULL; c->d_ctb_flag = NULL; c->stream = 0; c->up_stream = 0; c->down_stream = 0; c->side_stream = 0; c->after_inter = 0; c->have_after_inter = 0; c->where = 0; c->addb_pending = 0;
+    c->fork_ev = c->join_ev = 0;
     c->split_addb_alf = getenv("XEVD_HIP_SPLIT_ADDB_ALF") != NULL;      // measurement knob: ADDB and ALF as two kernels (the round-2 chain) instead of k_addb_alf
     for (int i = 0; i < 2; i++) { c->d_out[i] = NULL; c->out_caps[i] = 0; c->out_ready[i] = c->out_done[i] = 0; c->out_busy[i] = 0; }
     c->out_next = 0;
@@ -1067,6 +1068,53 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
         });
     }
     BT("owner map");
+    // Work lists of the three inter launches (k_inter.hip): 64x64 regions inside one CU, 32x32 tiles inside one CU, the other tiles that hold SCUs of the batch.  A tile /
+    // region counts as "inside one CU" only when it lies inside the picture as a whole (the kernels' shared-window paths have no partial form).  The CUs mark the tiles
+    // (disjoint CUs: disjoint full tiles; `any` is a relaxed flag several CUs of one tile may set), one sequential sweep in the kernels' spatial order - vertical strips
+    // INTER_STRIP regions wide, row by row inside a strip - emits the lists.
+    static thread_local std::vector<uint32_t> tile_cu;
+    static thread_local std::vector<uint8_t> tile_any;
+    static thread_local std::vector<uint2> inter_regions, inter_tiles;
+    static thread_local std::vector<uint32_t> inter_splits;
+    {
+        const int tiles_x = (c->sp.width + 31) >> 5, tiles_y = (c->sp.height + 31) >> 5, full_x = c->sp.width >> 5, full_y = c->sp.height >> 5;
+        tile_cu.assign((size_t)tiles_x * tiles_y, 0xFFFFFFFFu);
+        tile_any.assign((size_t)tiles_x * tiles_y, 0);
+        uint32_t *const tcu = tile_cu.data();
+        uint8_t *const tany = tile_any.data();
+        run_parts([&, tcu, tany](int, int i0, int i1) {
+            for (int i = i0; i < i1; i++) {
+                if (b->tree && b->tree[i] == 2) continue;
+                const int x0 = b->x[i], y0 = b->y[i], x1 = x0 + (1 << b->log2w[i]), y1 = y0 + (1 << b->log2h[i]);
+                for (int ty = y0 >> 5; ty <= (y1 - 1) >> 5; ty++)
+                    for (int tx = x0 >> 5; tx <= (x1 - 1) >> 5; tx++) {
+                        __atomic_store_n(&tany[(size_t)ty * tiles_x + tx], (uint8_t)1, __ATOMIC_RELAXED);
+                        if (tx < full_x && ty < full_y && (tx << 5) >= x0 && (tx << 5) + 32 <= x1 && (ty << 5) >= y0 && (ty << 5) + 32 <= y1) tcu[(size_t)ty * tiles_x + tx] = (uint32_t)i;
+                    }
+            }
+        });
+        inter_regions.clear(); inter_tiles.clear(); inter_splits.clear();
+        const int regions_x = (c->sp.width + 63) >> 6, regions_y = (c->sp.height + 63) >> 6;
+        for (int s0 = 0; s0 < regions_x; s0 += XGPU_INTER_STRIP)
+            for (int ry = 0; ry < regions_y; ry++)
+                for (int rx = s0; rx < std::min(s0 + XGPU_INTER_STRIP, regions_x); rx++) {
+                    const int tx = rx * 2, ty = ry * 2;
+                    const bool whole = tx + 1 < tiles_x && ty + 1 < tiles_y;
+                    const uint32_t o = tcu[(size_t)ty * tiles_x + tx];
+                    if (whole && o != 0xFFFFFFFFu && tcu[(size_t)ty * tiles_x + tx + 1] == o && tcu[(size_t)(ty + 1) * tiles_x + tx] == o && tcu[(size_t)(ty + 1) * tiles_x + tx + 1] == o) {
+                        inter_regions.push_back(make_uint2((uint32_t)rx | ((uint32_t)ry << 16), o));
+                        continue;
+                    }
+                    for (int q = 0; q < 4; q++) {
+                        const int qx = tx + (q & 1), qy = ty + (q >> 1);
+                        if (qx >= tiles_x || qy >= tiles_y) continue;
+                        const uint32_t oq = tcu[(size_t)qy * tiles_x + qx];
+                        if (oq != 0xFFFFFFFFu) inter_tiles.push_back(make_uint2((uint32_t)qx | ((uint32_t)qy << 16), oq));
+                        else if (tany[(size_t)qy * tiles_x + qx]) inter_splits.push_back((uint32_t)qx | ((uint32_t)qy << 16));
+                    }
+                }
+    }
+    BT("inter lists");
     // sps_suco_flag: is any CU decoded AFTER its right-hand neighbour?  (All right-hand neighbours of a CU lie in the other part of one vertical split: the first one
     // tells.)  Only the baseline deblocking filter wants to know beforehand - it applies chroma edges 2 samples apart in the order the reference's tree walk reaches
     // them (k_deblock.hip) and takes its left-to-right instantiation otherwise; ADDB is order-free, the intra plan finds its right-hand neighbours itself
@@ -1106,7 +1154,9 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     const size_t sz_dmvr = sizeof(DmvrItem) * (size_t)std::max(n_dmvr, 1);
     const size_t sz_own = sizeof(uint32_t) * (size_t)c->w_scu * c->h_scu;
     const size_t o_cpmv = o_aff + align_up((int)sz_aff, 256), o_dmvr = o_cpmv + align_up((int)sz_cpmv, 256), o_own = o_dmvr + align_up((int)sz_dmvr, 256);
-    const size_t o_coef = o_own + align_up((int)sz_own, 256);
+    const size_t sz_ireg = sizeof(uint2) * std::max(inter_regions.size(), (size_t)1), sz_itile = sizeof(uint2) * std::max(inter_tiles.size(), (size_t)1), sz_isplit = sizeof(uint32_t) * std::max(inter_splits.size(), (size_t)1);
+    const size_t o_ireg = o_own + align_up((int)sz_own, 256), o_itile = o_ireg + align_up((int)sz_ireg, 256), o_isplit = o_itile + align_up((int)sz_itile, 256);
+    const size_t o_coef = o_isplit + align_up((int)sz_isplit, 256);
     db->stage_bytes = o_coef + sz_coef;
     auto fail = [&](int code) { xgpu_batch_destroy(c, db); return code; };
     // device layout: the uploaded arrays at the staging offsets, then the residual arena and the intra done flags
@@ -1249,6 +1299,9 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
         }
     }
     memcpy(hs + o_ctu, b->ctu_cu_start, sz_ctu);
+    if (!inter_regions.empty()) memcpy(hs + o_ireg, inter_regions.data(), sizeof(uint2) * inter_regions.size());
+    if (!inter_tiles.empty()) memcpy(hs + o_itile, inter_tiles.data(), sizeof(uint2) * inter_tiles.size());
+    if (!inter_splits.empty()) memcpy(hs + o_isplit, inter_splits.data(), sizeof(uint32_t) * inter_splits.size());
     if (b->n_coef && !coef_pinned) {                                   // the largest array (45 MB at 8K): in slices on the builder's threads
         const size_t bytes = sizeof(int16_t) * b->n_coef;
         pool.run(nthr, [&](int k) { const size_t a0 = k == 0 ? 0 : (bytes * k / nthr & ~(size_t)63), a1 = k + 1 == nthr ? bytes : (bytes * (k + 1) / nthr & ~(size_t)63);
@@ -1262,13 +1315,16 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     db->d_waves = (TbWave *)(dbase + o_wv); db->d_intra = (IntraRec *)(dbase + o_intra); db->d_intra_deps = (uint32_t *)(dbase + o_deps);
     db->d_aff_items = (AffItem *)(dbase + o_aff); db->d_cpmv = (int16_t *)(dbase + o_cpmv);
     db->d_dmvr_items = (DmvrItem *)(dbase + o_dmvr); db->d_dmvr_mv = (int16_t *)(dbase + o_dmv); db->d_owner = (uint32_t *)(dbase + o_own);
+    db->d_inter_regions = (uint2 *)(dbase + o_ireg); db->d_inter_tiles = (uint2 *)(dbase + o_itile); db->d_inter_splits = (uint32_t *)(dbase + o_isplit);
+    db->n_inter_regions = (int)inter_regions.size(); db->n_inter_tiles = (int)inter_tiles.size(); db->n_inter_splits = (int)inter_splits.size();
     db->d_coef = (int16_t *)(dbase + o_coef); db->d_resid = (int16_t *)(dbase + o_resid); db->d_intra_done = (uint32_t *)(dbase + o_done);
     // one copy: the staging block has the device layout (a pinned coefficient arena goes from the caller's buffer).  On the upload stream: the
     // copy overlaps the kernels of the pictures before; xgpu_batch_recon makes the kernel stream wait for `uploaded`
     BT("stage filled");
     if (segs) *segs = { { o_cus, sizeof(CuRec) * (size_t)n }, { o_ctu, sz_ctu }, { o_tbs, sizeof(TbRec) * (size_t)n_tb }, { o_wv, sizeof(TbWave) * (size_t)n_waves }, { o_intra, sizeof(IntraRec) * (size_t)n_intra },
                         { o_deps, sizeof(uint32_t) * (size_t)n_deps }, { o_aff, sizeof(AffItem) * (size_t)(n_aff_eif + n_aff_sub) }, { o_cpmv, sizeof(int16_t) * 12 * (size_t)n_aff },
-                        { o_dmvr, sizeof(DmvrItem) * (size_t)n_dmvr }, { o_own, sz_own }, { o_coef, coef_pinned ? 0 : sizeof(int16_t) * b->n_coef } };
+                        { o_dmvr, sizeof(DmvrItem) * (size_t)n_dmvr }, { o_own, sz_own }, { o_coef, coef_pinned ? 0 : sizeof(int16_t) * b->n_coef },
+                        { o_ireg, sizeof(uint2) * inter_regions.size() }, { o_itile, sizeof(uint2) * inter_tiles.size() }, { o_isplit, sizeof(uint32_t) * inter_splits.size() } };
     if (host_only) { *out = db; return XGPU_OK; }
     hipError_t e = hipMemcpyAsync(dbase, hs, coef_pinned ? o_coef : db->stage_bytes, hipMemcpyHostToDevice, c->up_stream);
     if (e == hipSuccess && coef_pinned) e = hipMemcpyAsync(dbase + o_coef, b->coef, sizeof(int16_t) * b->n_coef, hipMemcpyHostToDevice, c->up_stream);
@@ -1417,13 +1473,9 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
     a.cur_y = cur.y; a.cur_u = cur.u; a.cur_v = cur.v;
     a.s_l = c->s_l; a.s_c = c->s_c; a.pic_w = c->sp.width; a.pic_h = c->sp.height;
     a.bd_l = c->sp.bit_depth_luma; a.bd_c = c->sp.bit_depth_chroma;
-    a.regions_x = (c->sp.width + 63) >> 6;
-    a.n_regions = a.regions_x * ((c->sp.height + 63) >> 6);
     a.admvp = c->sp.tool_admvp ? 1 : 0;
-    const int strip_knob = getenv("XEVD_HIP_INTER_STRIP") ? atoi(getenv("XEVD_HIP_INTER_STRIP")) : 0;      // measurement knob
-    a.strip = strip_knob > 0 ? strip_knob : 16;
-    a.order = getenv("XEVD_HIP_INTER_ORDER") ? atoi(getenv("XEVD_HIP_INTER_ORDER")) : 0;
-    a.no_region = getenv("XEVD_HIP_INTER_NO_REGION") != NULL;
+    a.regions = db->d_inter_regions; a.tiles = db->d_inter_tiles; a.splits = db->d_inter_splits;
+    a.n_regions = db->n_inter_regions; a.n_tiles = db->n_inter_tiles; a.n_splits = db->n_inter_splits;
     a.cus = db->d_cus; a.resid = db->d_resid;
     a.maps = c->d_maps; a.w_scu = c->w_scu; a.owner = db->d_owner; a.n_cu = db->n_cu; a.cur_poc = c->fp.poc;
     c->order_rl |= db->order_rl;                            // (the pictures' batches - one per slice - say it for the deblocking pass behind them)
@@ -1445,7 +1497,11 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
         tool_stream = c->side_stream;
     }
     if (next && ride_mode == 1 && !c->timing && db->prepared == 0) { const int rc = ride_side(); if (rc != XGPU_OK) return rc; }
-    TIMED(c, XGPU_K_INTER, launch_inter(c, a));
+    // the three inter launches (k_inter.hip) write disjoint tiles: the second and third are launched without the barrier bit (hipExtAnyOrderLaunch) and may start while
+    // the first still runs - not while single kernels are timed, where XGPU_K_INTER is the sum of the three.  (Round 5, 8K: one after the other 0.360 ms per picture,
+    // any-order 0.354 - 0.357, on three streams of the default class 0.362 - 0.365, on streams of the high-priority class 0.638: their waves preempt the kernel stream's.)
+    static const bool inter_in_order = getenv("XEVD_HIP_INTER_IN_ORDER") != NULL;      // A/B measurements (read once)
+    TIMED(c, XGPU_K_INTER, launch_inter(c, a, !c->timing && !inter_in_order));
     if (next && ride_mode == 2 && !c->timing) { const int rc = ride_side(); if (rc != XGPU_OK) return rc; }
     if (!ahead) HIPCHK(c, hipEventRecord(c->after_inter, c->stream));   // where a residual pass prepared on the side stream (xgpu_batch_prepare) may start
     c->have_after_inter = 1;

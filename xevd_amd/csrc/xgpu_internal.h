@@ -88,6 +88,7 @@ struct TbWave {
     uint8_t  pad[2];
 };
 
+#define XGPU_INTER_STRIP 16       // width, in 64x64 regions, of the vertical strips the inter work lists are ordered in (xgpu_batch_create, k_inter.hip)
 struct RefEntry { const int16_t *y, *u, *v; int poc; int pad; };
 
 // Kernel arguments of the inter reconstruction kernel (passed by value).
@@ -96,8 +97,13 @@ struct InterArgs {
     int      s_l, s_c;                 // all pictures of a ctx share the geometry
     int      pic_w, pic_h;
     int      bd_l, bd_c;
-    int      n_regions, regions_x;     // 64x64 luma regions
     int      admvp;
+    // Work lists of the three launches (built by xgpu_batch_create in one spatial order - vertical strips of 64x64 regions, row by row inside a strip - so that
+    // every XCD, which takes a contiguous eighth of each list, works on a compact patch of the picture):
+    const uint2    *regions;           // k_inter_region: 64x64 regions inside ONE CU: x = region column | row << 16, y = the CU's index in the batch
+    const uint2    *tiles;             // k_inter_tile: 32x32 tiles inside one CU (whose region is not): x = tile column | row << 16, y = the CU's index
+    const uint32_t *splits;            // k_inter_split: every other tile that holds SCUs of the batch: tile column | row << 16
+    int      n_regions, n_tiles, n_splits;
     const CuRec    *cus;
     const int16_t  *resid;
     ScuRec  *maps;
@@ -106,9 +112,6 @@ struct InterArgs {
     int      n_cu;
     int      cur_poc;                  // POC of the picture being decoded (DMVR's distance test)
     int      dmvr_to_map;              // k_dmvr writes its refined vectors into the map records (DmvrArgs.refined_to_map): k_inter leaves those words alone
-    int      no_region;                // 1: no workgroup-shared windows for 64x64 regions inside one CU (measurement knob XEVD_HIP_INTER_NO_REGION)
-    int      order;                    // 0: vertical strips, row by row inside a strip; 1: horizontal bands, column by column (measurement knob)
-    int      strip;                    // width of the vertical strips of the region order, in 64x64 regions (k_inter.hip)
     RefEntry refp[XGPU_MAX_REFS][2];
 };
 
@@ -263,6 +266,9 @@ struct xgpu_dbatch {
     CuRec     *d_cus;
     uint32_t  *d_ctu_start;
     uint32_t  *d_owner;               // SCU -> CU index of the batch, over the whole picture
+    uint2     *d_inter_regions, *d_inter_tiles;      // work lists of the three inter launches (InterArgs)
+    uint32_t  *d_inter_splits;
+    int        n_inter_regions, n_inter_tiles, n_inter_splits;
     int16_t   *d_coef, *d_resid;
     TbRec     *d_tbs;
     TbWave    *d_waves;
@@ -381,7 +387,7 @@ private:
 
 // kernel launchers (one per .hip file)
 void launch_itdq(xgpu_ctx *c, const ItdqArgs &a, hipStream_t s);
-void launch_inter(xgpu_ctx *c, const InterArgs &a);
+void launch_inter(xgpu_ctx *c, const InterArgs &a, bool any_order);      // the three launches on the ctx stream; any_order: the second and third without the barrier bit      // the three launches: regions on the ctx stream, tiles / split tiles on the given ones
 void launch_test_recon(xgpu_ctx *c, const int16_t *coef, const int16_t *pred, int is_coef, int cuw, int cuh, int16_t *rec, int s_rec, int bd);
 void launch_test_dbk(xgpu_ctx *c, int16_t *buf, int16_t *buf_v, int st, int st_v, int stride, int bd, int hor, int chroma);
 void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf, const ItdqArgs *next, bool right = false);      // next != NULL (dep launches): k_intra_itdq

@@ -23,10 +23,10 @@ void xwq_destroy(xwq *q) { delete q; }
 
 int xwq_push(xwq *q, const xwq_job *job)
 {
-    if (!q || !job) return -101;
+    if (!q || !job) return XWQ_ERR_INVALID_ARGUMENT;
     {
         std::lock_guard<std::mutex> g(q->mu);
-        if (q->closed) return -106;
+        if (q->closed) return XWQ_ERR_UNEXPECTED;
         q->jobs.push_back(*job);
     }
     q->cv.notify_one();
@@ -42,7 +42,7 @@ void xwq_close(xwq *q)
 
 int xwq_pop(xwq *q, xwq_job *out)
 {
-    if (!q || !out) return -101;
+    if (!q || !out) return XWQ_ERR_INVALID_ARGUMENT;
     std::unique_lock<std::mutex> g(q->mu);
     q->cv.wait(g, [&] { return !q->jobs.empty() || q->closed; });
     if (q->jobs.empty()) return 0;
@@ -53,13 +53,13 @@ int xwq_pop(xwq *q, xwq_job *out)
 
 int xwq_run(xwq *q, const int *devices, int n_devices, xwq_init_fn init, xwq_job_fn job, xwq_fini_fn fini, void *user, int *jobs_done)
 {
-    if (!q || !devices || n_devices <= 0 || !job) return -101;
+    if (!q || !devices || n_devices <= 0 || !job) return XWQ_ERR_INVALID_ARGUMENT;
     std::vector<std::thread> th;
     std::vector<int> done((size_t)n_devices, 0), rc((size_t)n_devices, 0);
     for (int i = 0; i < n_devices; i++)
         th.emplace_back([&, i] {
             void *st = init ? init(devices[i], user) : nullptr;
-            if (init && !st) { rc[(size_t)i] = -106; return; }              // this device is out; the others take its share
+            if (init && !st) { rc[(size_t)i] = XWQ_ERR_UNEXPECTED; return; }              // this device is out; the others take its share
             xwq_job j;
             while (xwq_pop(q, &j) == 1) {
                 const int r = job(st, &j);
@@ -72,10 +72,10 @@ int xwq_run(xwq *q, const int *devices, int n_devices, xwq_init_fn init, xwq_job
     int first = 0, usable = 0;
     for (int i = 0; i < n_devices; i++) {
         if (jobs_done) jobs_done[i] = done[(size_t)i];
-        if (rc[(size_t)i] != -106 || done[(size_t)i]) usable++;
-        if (rc[(size_t)i] < 0 && rc[(size_t)i] != -106 && first == 0) first = rc[(size_t)i];
+        if (rc[(size_t)i] != XWQ_ERR_UNEXPECTED || done[(size_t)i]) usable++;
+        if (rc[(size_t)i] < 0 && rc[(size_t)i] != XWQ_ERR_UNEXPECTED && first == 0) first = rc[(size_t)i];
     }
-    if (!usable) return -106;                                                // no worker came up: nothing was decoded
+    if (!usable) return XWQ_ERR_UNEXPECTED;                                                // no worker came up: nothing was decoded
     return first;
 }
 
@@ -85,11 +85,11 @@ enum { NUT_NONIDR = 0, NUT_IDR = 1, NUT_SPS = 24, NUT_PPS = 25, NUT_APS = 26 };
 
 int xwq_split_gops(const uint8_t *data, size_t size, int stream, xwq_job *jobs, int max_jobs)
 {
-    if (!data || !jobs || max_jobs <= 0) return -101;
+    if (!data || !jobs || max_jobs <= 0) return XWQ_ERR_INVALID_ARGUMENT;
     int n = 0, pictures = 0;
     size_t pos = 0;
     xhost_scan *scan = xhost_scan_open();                // picture boundaries: a picture may come as several slice NAL units
-    if (!scan) return -101;
+    if (!scan) return XWQ_ERR_INVALID_ARGUMENT;
     while (pos + 4 <= size) {
         const size_t len = ((size_t)data[pos] << 24) | ((size_t)data[pos + 1] << 16) | ((size_t)data[pos + 2] << 8) | data[pos + 3];
         if (len < 2 || pos + 4 + len > size) { xhost_scan_close(scan); return -202; }
