@@ -1,13 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py - frames/s of the MI355X reconstruction backend on BASELINE.json's workload, with the roofline of the
-dominant kernel and a CPU baseline.
+"""bench.py - frames/s of the MI355X reconstruction backend on BASELINE.json's workload, with the roofline of the dominant kernel and a CPU baseline.
 
-A "step" is one picture through the whole hot path: dequant + inverse transform of every coded TB, MC + residual
-add + clip of every CU, both deblocking passes and border padding - i.e. everything xevd_dec_nalu does after
-entropy decoding (src_base/xevd.c:1905-1983).  Pictures chain like an IPPP stream: picture k is predicted from
-picture k-1 (DPB ping-pong), so steps are serially dependent exactly like a real decode.  The CU batches (the
-post-entropy records) are resident in HBM before the timed region starts; H2D of the batches is reported
-separately as `pcie_inclusive_fps`.
+A "step" is one picture through the whole hot path - everything xevdm_dec_nalu does after entropy decoding (src_main/xevdm.c:3136-3219): dequant + inverse
+transform of every coded TB (k_itdq), MC + residual add + clip + SCU-map update of every inter CU (the three k_inter_* launches), intra CUs in dependency order
+(k_intra), ADDB + ALF + border padding in one pass (k_addb_alf).  Pictures chain like a stream: picture k is predicted from pictures k-1 and k-2 (a 3-slot DPB
+ring), so steps are serially dependent exactly like a real decode.
+
+What the JSON line's figures are, all at the command line the driver uses (`--steps 20 --warmup 5` included):
+  value / kernel_only_fps   the benchmark contract's number: the CU batches (the post-entropy records) are resident in HBM when the timed region starts; W warm-up
+                            pictures, then exactly K timed ones between two barrier + synchronize pairs.
+  roofline                  the dominant kernel family by HIP-event time (the three k_inter_* launches are ONE pass over the picture and are priced as one: their
+                            summed duration against SURVEY 8(d)'s bytes of that pass), timed in a second loop of K pictures with every kernel alone on the stream.
+  end_to_end_fps            host CU batches -> host YUV (builder + H2D + kernels + conversion + D2H inside the timed region).  Its OWN fixed length
+  two_contexts              (E2E_PICTURES after E2E_WARMUP; CTX_PICTURES per context after CTX_WARMUP), independent of --steps: a secondary figure that moved with
+                            the step count was the round-4 review's finding.
+  cpu_baseline              the same batch through the reference's functions (oracle/_ref) or the CPU oracle on a bounded sample, + the reference decoder on a
+                            real stream of the workload's shape.
 
     python bench.py --gpus 1 --steps 200 --warmup 20            # single GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...   # one rank per GPU
@@ -49,6 +57,8 @@ WORKLOADS = {
 }
 DEFAULT_WORKLOAD = "cfg4_main_8k_10b_ra"
 DEFAULT_WORKLOAD_MULTI = "cfg5_main_4k_10b_ra_streams"
+E2E_PICTURES, E2E_WARMUP = 256, 16     # the end-to-end leg's own length (pictures), whatever --steps says
+CTX_PICTURES, CTX_WARMUP = 512, 32     # per context, the several-contexts leg
 GOP_PICTURES = 8            # pictures per job of the multi-GPU work queue (one closed GOP)
 HBM_PEAK_GBPS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
@@ -655,11 +665,11 @@ def main():
     if args.no_end_to_end:
         e2e = {"fps": None, "ms_per_picture": 0.0, "skipped": True}
     else:
-        e2e = end_to_end_leg(dec, wl, batches, alf, slots, max(args.steps // 2, 10), 4)
+        e2e = end_to_end_leg(dec, wl, batches, alf, slots, E2E_PICTURES, E2E_WARMUP)
     two_ctx = None
     if world == 1 and not args.no_end_to_end and dec_mod == "xevd_amd.decoder":
         try:
-            two_ctx = contexts_leg(XgpuDecoder, local_rank, wl, first, batches, alf, args.steps, args.warmup)
+            two_ctx = contexts_leg(XgpuDecoder, local_rank, wl, first, batches, alf, CTX_PICTURES, CTX_WARMUP)
         except Exception as e:      # (a secondary figure must not cost the line)
             two_ctx = {"error": str(e)[:200]}
     if dist is not None and not args.no_end_to_end:

@@ -80,7 +80,7 @@ def test_error_codes_equal_the_reference_headers():
             want = {"ERR_MALFORMED": "XEVD_ERR_MALFORMED_BITSTREAM"}.get(suffix, "XEVD_" + suffix)
             assert ref[want] == val, (name, val, want, ref[want])
             seen += 1
-    assert seen >= 8
+    assert seen >= 7      # XGPU_ERR, _INVALID_ARGUMENT, _OUT_OF_MEMORY, _UNSUPPORTED, _UNEXPECTED; XHOST_ERR_MALFORMED; XWQ_ERR_INVALID_ARGUMENT, _UNEXPECTED
     assert _header_defines(os.path.join(ROOT, "include", "xevd_hip.h"), "XGPU_OK")["XGPU_OK"] == ref["XEVD_OK"]
     import re
     api = open(os.path.join(ROOT, "include", "xevd_api.h")).read()

@@ -122,19 +122,6 @@ def test_gpu_pictures_golden_residual_pass_ahead(name):
         assert np.array_equal(out[c], exp["out"][c]), f"final plane {c}: {np.argwhere(out[c] != exp['out'][c])[:4]}"
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["1", "2"])
-def test_gpu_residual_pass_ahead_on_the_side_stream(mode):
-    """XEVD_HIP_RIDE=1 / 2 (measurement knob, read once per process): the next picture's residual pass on the context's side stream - next to this picture's k_inter, or
-    behind it - instead of inside the data-flow intra launch: the picture goldens through xgpu_batch_recon_ahead again, in a process of their own"""
-    import subprocess
-    import sys
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_gpu_pictures_golden_residual_pass_ahead", "-p", "no:cacheprovider"],
-                       env=dict(os.environ, XEVD_HIP_RIDE=mode), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-    assert r.returncode == 0, r.stdout.decode()[-1500:]
-    assert b" passed" in r.stdout
-
-
 RANDOM = [
     # name, w, h, bd, admvp, iqt, n_refs, bi_frac, kwargs
     ("rnd_a", 264, 136, 8, 0, 0, (2, 1), 0.3, {}),
@@ -197,20 +184,6 @@ def test_gpu_all_intra_1080p_vs_oracle():
     out = cases.run_gpu(cs, repeat=3)
     for c in range(3):
         assert np.array_equal(out[c], ref.bufs[c]), f"plane {c}"
-
-
-def test_gpu_intra_per_ctu_launch_option():
-    """XEVD_HIP_INTRA_CTU=1: graphs without IBC / HTDF nodes go through k_intra_ctu (one workgroup per CTU, the CTU in LDS) instead of the level-1 + data-flow
-    launches - an option (measured slower), same pictures.  The knob is read once per process: the golden pictures (Baseline and EIPD predictors, local
-    dual trees, constrained intra prediction, CTU 128, tiles) and the 1080p all-intra picture (three times from the resident batch) run in a child process."""
-    import subprocess
-    import sys
-    env = dict(os.environ, XEVD_HIP_INTRA_CTU="1")
-    here = os.path.dirname(os.path.abspath(__file__))
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", os.path.join(here, "test_gpu_parity.py"),
-                        "-k", "test_gpu_pictures_golden or test_gpu_all_intra_1080p_vs_oracle or test_gpu_vs_oracle_random"],
-                       env=env, cwd=os.path.dirname(here), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
-    assert r.returncode == 0, r.stdout.decode()[-3000:]
 
 
 def test_gpu_ibc_intra_1080p_vs_oracle():
