@@ -65,7 +65,7 @@ def _ref_codes():
 def _header_defines(path, prefix):
     import re
     txt = open(path).read()
-    return {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(" + prefix + r"\w+)\s+\(?(-?\d+)\)?", txt)}
+    return {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(" + prefix + r"\w*)\s+\(?(-?\d+)\)?", txt)}
 
 
 def test_error_codes_equal_the_reference_headers():

@@ -24,6 +24,8 @@
 #include <hip/hip_ext.h>
 #include "mc_filters.h"
 
+#define LDS_AS __attribute__((address_space(3)))
+
 // ---------------------------------------------------------------------------------------------------------
 // Wave-uniform motion (every SCU of a wave's 32x32 tile belongs to one CU - three quarters of the samples of a typical
 // picture): the separable filter runs as a tile through the wave's own LDS instead of per lane.  The 39x39 reference window
@@ -50,27 +52,11 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// p = reference sample at (tile x - 3, tile y - 3); lane l owns the SCU (l & 7, l >> 3) of the tile.  o[] as mc_luma_4x4.
-// The fetch is split from the filtering so that a wave has the windows of both lists (and its residual) in flight at once.
-struct TileFetch { uint4 y[4]; uint4 c[3]; };
-// a lane's chunk of the tile windows: offsets into the reference plane (samples) and into the wave's LDS window.  Luma: 12 rows x 5 chunks of
-// 8 samples per pass (lanes 60..63 idle), four passes cover the 39 rows; chroma: 19 rows x 3 chunks per plane (lanes 57..63 idle).  The offsets
-// depend on the lane alone: computed once per kernel, every pass adds a constant.
+// a lane's chunk of the tile's luma window: offsets into the reference plane (samples) and into the wave's LDS window - 10 rows x 6 chunks of 8 samples per request
+// (lanes 60..63 idle), four requests cover the 39 rows.  The offsets depend on the lane alone: computed once per kernel, every request adds a constant.
+// The chunks are 16-byte ALIGNED pieces of the reference rows (rows start 256-byte aligned): an unaligned 16-byte load costs the vector L1 2.4x the accesses (round 4).
+// Luma: up to 7 + 39 samples = 6 chunks per row; chroma: up to 7 + 19 samples = 4 chunks, 2 planes x 19 rows x 4 chunks = 152 chunks in three requests of 64 lanes.
 struct LaneMap { int gy, ly; };
-// The chunks are 16-byte ALIGNED pieces of the reference rows (p / pu / pv = the chunk that holds the window's first sample; rows start 256-byte aligned): an unaligned
-// 16-byte load costs the vector L1 2.4x the accesses (round 4).  Luma: up to 7 + 39 samples = 6 chunks per row, 10 rows x 6 chunks per pass (lanes 60..63 idle), four
-// passes; chroma: up to 7 + 19 samples = 4 chunks, 2 planes x 19 rows x 4 chunks = 152 loads in three passes of 64 lanes.
-__device__ __forceinline__ void tile_fetch(gs16 p, int s, gs16 pu, gs16 pv, int sc, int lane, const LaneMap fm, TileFetch &f)
-{
-#pragma unroll
-    for (int it = 0; it < 4; it++)
-        if (lane < (it < 3 ? 60 : 54)) f.y[it] = gload16(p + fm.gy + 10 * it * s);
-#pragma unroll
-    for (int it = 0; it < 3; it++) {
-        const int idx = lane + 64 * it, plane = idx >= 76, j = idx - 76 * plane;
-        if (idx < 152) f.c[it] = gload16((plane ? pv : pu) + (j >> 2) * sc + 8 * (j & 3));
-    }
-}
 
 // the two passes over a 39x39 window in LDS: Wn = the window's first sample, WS = its row stride in samples (UW_STRIDE: the wave's own window; REG_W_STRIDE: the
 // wave's part of the 71x71 window its workgroup shares, see inter_tile<2>)
@@ -155,17 +141,6 @@ __device__ __forceinline__ void luma_tile_filter(const int16_t *Wn, const uint32
     }
     wave_lds_sync();
 }
-template <bool H, bool V>
-__device__ __forceinline__ void mc_luma_tile(const uint4 v[4], const uint32_t ch[4], const uint32_t cv[4], Regime rg, int maxv,
-                                             int16_t *W, int16_t *I, int lane, const LaneMap fm, uint32_t o[8], int mis)      // mis: the window's first sample inside its first chunk
-{
-#pragma unroll
-    for (int it = 0; it < 4; it++)
-        if (lane < (it < 3 ? 60 : 54)) *(uint4 *)(W + fm.ly + 10 * it * UW_STRIDE) = v[it];
-    wave_lds_sync();
-    luma_tile_filter<H, V, UW_STRIDE, true>(W + (mis & ~1), ch, cv, rg, maxv, I, lane, o, mis & 1);
-}
-
 // Both chroma planes of the tile (16x16 each): the passes over the two 19x19 windows Wu / Wv (row stride WS) in LDS
 template <bool H, bool V, int WS, bool SH = false>
 __device__ __forceinline__ void chroma_tile_filter(const int16_t *Wu, const int16_t *Wv, const uint32_t ch[2], const uint32_t cv[2],
@@ -241,20 +216,6 @@ __device__ __forceinline__ void chroma_tile_filter(const int16_t *Wu, const int1
     }
     wave_lds_sync();
 }
-// pu / pv = reference sample at (tile x - 1, tile y - 1) of the plane.
-template <bool H, bool V>
-__device__ __forceinline__ void mc_chroma_tile(const uint4 v[3], const uint32_t ch[2], const uint32_t cv[2],
-                                               Regime rg, int maxv, int16_t *W, int16_t *I, int lane, uint32_t ou[2], uint32_t ov[2], int mis)
-{
-#pragma unroll
-    for (int it = 0; it < 3; it++) {
-        const int idx = lane + 64 * it, plane = idx >= 76, j = idx - 76 * plane;
-        if (idx < 152) *(uint4 *)(W + (plane ? 19 * UCW_STRIDE : 0) + (j >> 2) * UCW_STRIDE + 8 * (j & 3)) = v[it];
-    }
-    wave_lds_sync();
-    chroma_tile_filter<H, V, UCW_STRIDE, true>(W + (mis & ~1), W + 19 * UCW_STRIDE + (mis & ~1), ch, cv, rg, maxv, I, lane, ou, ov, mis & 1);
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // A 64x64 region inside ONE CU (half of the samples of a typical picture lie in CUs of 64x64 and above): its four waves would each fetch their own 39x39 window -
 // 78-byte rows that touch 1.44 cache lines, and the 7-sample halos between the four tiles twice.  The workgroup fetches the region's 71x71 window (+ 2 x 35x35 chroma)
@@ -268,7 +229,6 @@ __device__ __forceinline__ void mc_chroma_tile(const uint4 v[3], const uint32_t 
 #define REG_C_SAMPLES (35 * REG_C_STRIDE)
 #define REG_I_SAMPLES (39 * UI_STRIDE)
 #define REG_SAMPLES   (REG_W_SAMPLES + 2 * REG_C_SAMPLES + 4 * REG_I_SAMPLES)
-struct RegionFetch { uint4 y[3]; uint4 c[2]; };
 // a thread's chunks of the region windows: luma 71 rows x 10 chunks in three rounds of 256 threads, chroma 2 planes x 35 rows x 6 chunks in two; offsets < 0: none
 struct RegionMap { int y[3], c[2]; };      // row << 8 | chunk (chroma: | plane << 7); < 0: none.  The offsets are formed where they are used: five registers, not ten
 __device__ __forceinline__ RegionMap region_map(int t)
@@ -286,138 +246,6 @@ __device__ __forceinline__ RegionMap region_map(int t)
     }
     return m;
 }
-__device__ __forceinline__ void region_fetch(gs16 p, int s_l, gs16 pu, gs16 pv, int s_c, const RegionMap m, RegionFetch &f)
-{
-#pragma unroll
-    for (int it = 0; it < 3; it++) if (m.y[it] >= 0) f.y[it] = gload16(p + (m.y[it] >> 8) * s_l + 8 * (m.y[it] & 127));
-#pragma unroll
-    for (int it = 0; it < 2; it++) if (m.c[it] >= 0) f.c[it] = gload16(((m.c[it] & 128) ? pv : pu) + (m.c[it] >> 8) * s_c + 8 * (m.c[it] & 127));
-}
-__device__ __forceinline__ void region_store(const RegionFetch &f, const RegionMap m, int16_t *SH)
-{
-#pragma unroll
-    for (int it = 0; it < 3; it++) if (m.y[it] >= 0) *(uint4 *)(SH + (m.y[it] >> 8) * REG_W_STRIDE + 8 * (m.y[it] & 127)) = f.y[it];
-#pragma unroll
-    for (int it = 0; it < 2; it++) if (m.c[it] >= 0) *(uint4 *)(SH + REG_W_SAMPLES + ((m.c[it] & 128) ? REG_C_SAMPLES : 0) + (m.c[it] >> 8) * REG_C_STRIDE + 8 * (m.c[it] & 127)) = f.c[it];
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// k_inter_split's shared quadrant windows.  A request (global_load_lds, 16 bytes per lane) writes 64 x 16 = 1024 consecutive bytes: lane (q, rs, col) - quadrant, row
-// slot, column chunk - lands at q * 256 + rs * 64 + col * 16, i.e. the block of request k holds rows 4k .. 4k + 3 of the four quadrants' windows as 64-byte rows
-// (luma: 32 samples from the 16-byte aligned chunk that holds the window's first sample; chroma: 16 samples of U from the even sample at or below the window's
-// first, then 16 of V).  Blocks start SQ_BLK_B = 1024 + 16 bytes apart, so that rows 4 apart - the lanes jy, jy + 1 of a quadrant read them at the same moment -
-// start 4 banks apart.  Row r of quadrant q: q * 256 + sq_row(r).  (tools/ubench/glds_probe.hip: a 12-byte request also strides 16 bytes per lane - its rows would
-// have holes; inactive lanes write nothing.)
-// ---------------------------------------------------------------------------------------------------------
-#define LDS_AS __attribute__((address_space(3)))
-#define SQ_BLK_B   1040
-#define SQ_L_BYTES (6 * SQ_BLK_B)         // 23 luma rows (24 slots)
-#define SQ_C_BYTES (3 * SQ_BLK_B)         // 11 chroma rows (12 slots)
-#define SQ_BYTES   (SQ_L_BYTES + SQ_C_BYTES)
-__device__ __forceinline__ int sq_row(int r) { return (r >> 2) * SQ_BLK_B + (r & 3) * 64; }
-
-// mc_luma_4x4 / mc_chroma_2x2 (mc_filters.h) with the window read from the shared block instead of the reference picture: w = the dword of row 0 that holds the
-// lane's first window sample (the sample is the dword's high half when `odd`), r0 = the lane's first row in the quadrant's window.
-template <bool H, bool V>
-__device__ __forceinline__ void mc_luma_4x4_w(const char LDS_AS *w, int r0, int odd, const uint32_t ch[4], const uint32_t cv[4], Regime rg, int maxv, uint32_t o[8])
-{
-    int acc[4][4];
-    int tp[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int j = V ? 0 : 3; j < (V ? 11 : 7); j++) {
-        int t[4];
-        const uint32_t LDS_AS *r = (const uint32_t LDS_AS *)(w + sq_row(r0 + j));
-        if (H) {
-            const uint32_t R[6] = { r[0], r[1], r[2], r[3], r[4], r[5] };
-            uint32_t D[6];
-#pragma unroll
-            for (int k = 0; k < 5; k++) D[k] = odd ? hi_lo(R[k + 1], R[k]) : R[k];
-            D[5] = odd ? R[5] >> 16 : R[5];                          // (only its low half is a tap's sample)
-            const uint32_t Q0 = hi_lo(D[1], D[0]), Q1 = hi_lo(D[2], D[1]), Q2 = hi_lo(D[3], D[2]), Q3 = hi_lo(D[4], D[3]), Q4 = hi_lo(D[5], D[4]);
-            t[0] = dot2(ch[3], D[3], dot2(ch[2], D[2], dot2(ch[1], D[1], dot2z(ch[0], D[0]))));
-            t[2] = dot2(ch[3], D[4], dot2(ch[2], D[3], dot2(ch[1], D[2], dot2z(ch[0], D[1]))));
-            t[1] = dot2(ch[3], Q3, dot2(ch[2], Q2, dot2(ch[1], Q1, dot2z(ch[0], Q0))));
-            t[3] = dot2(ch[3], Q4, dot2(ch[2], Q3, dot2(ch[1], Q2, dot2z(ch[0], Q1))));
-#pragma unroll
-            for (int c_ = 0; c_ < 4; c_++) t[c_] = clip3(rg.lo1, rg.hi1, t[c_] >> rg.sh1);
-        } else {
-            // samples 3..6 of the window: dwords 1..3 (shifted) when the window starts on an even sample, dwords 2..3 when it starts on an odd one
-            const uint32_t d1 = r[1], d2 = r[2], d3 = r[3];
-            const uint32_t a0 = odd ? d2 : hi_lo(d2, d1), a1 = odd ? d3 : hi_lo(d3, d2);
-            t[0] = (int)(int16_t)(a0 & 0xFFFF); t[1] = (int)(int16_t)(a0 >> 16);
-            t[2] = (int)(int16_t)(a1 & 0xFFFF); t[3] = (int)(int16_t)(a1 >> 16);
-        }
-        if (!V) {
-#pragma unroll
-            for (int c_ = 0; c_ < 4; c_++) acc[j - 3][c_] = t[c_];
-            continue;
-        }
-        if (j > 0) {
-#pragma unroll
-            for (int c_ = 0; c_ < 4; c_++) {
-                const uint32_t pr = pack2(tp[c_], t[c_]);
-#pragma unroll
-                for (int r_ = 0; r_ < 4; r_++) {
-                    const int d = j - 1 - r_;
-                    if (d == 0) acc[r_][c_] = dot2a(cv[0], pr, rg.off2);
-                    else if (d > 0 && d <= 6 && (d & 1) == 0) acc[r_][c_] = dot2(cv[d >> 1], pr, acc[r_][c_]);
-                }
-            }
-        }
-#pragma unroll
-        for (int c_ = 0; c_ < 4; c_++) tp[c_] = t[c_];
-        if (j & 1) __builtin_amdgcn_sched_barrier(0);      // two rows at a time: the scheduler otherwise fetches all eleven rows first (66 registers: 160 VGPRs for the kernel)
-    }
-#pragma unroll
-    for (int r_ = 0; r_ < 4; r_++) {
-        int v[4];
-#pragma unroll
-        for (int c_ = 0; c_ < 4; c_++) v[c_] = clip3(0, maxv, V ? acc[r_][c_] >> rg.sh2 : acc[r_][c_]);
-        o[r_ * 2 + 0] = pack2(v[0], v[1]);
-        o[r_ * 2 + 1] = pack2(v[2], v[3]);
-    }
-}
-template <bool H, bool V>
-__device__ __forceinline__ void mc_chroma_2x2_w(const char LDS_AS *w, int r0, int odd, const uint32_t ch[2], const uint32_t cv[2], Regime rg, int maxv, uint32_t o[2])
-{
-    int acc[2][2];
-    int tp[2] = {0, 0};
-#pragma unroll
-    for (int j = V ? 0 : 1; j < (V ? 5 : 3); j++) {
-        int t[2];
-        const uint32_t LDS_AS *r = (const uint32_t LDS_AS *)(w + sq_row(r0 + j));
-        if (H) {
-            const uint32_t R0 = r[0], R1 = r[1], R2 = r[2];
-            const uint32_t D0 = odd ? hi_lo(R1, R0) : R0, D1 = odd ? hi_lo(R2, R1) : R1, D2 = odd ? R2 >> 16 : R2;      // (D2: only its low half is a tap's sample)
-            const uint32_t Q0 = hi_lo(D1, D0), Q1 = hi_lo(D2, D1);
-            t[0] = dot2(ch[1], D1, dot2z(ch[0], D0));
-            t[1] = dot2(ch[1], Q1, dot2z(ch[0], Q0));
-#pragma unroll
-            for (int c_ = 0; c_ < 2; c_++) t[c_] = clip3(rg.lo1, rg.hi1, t[c_] >> rg.sh1);
-        } else {
-            const uint32_t R0 = r[0], R1 = r[1];
-            const uint32_t a0 = odd ? R1 : hi_lo(R1, R0);          // samples 1..2 of the window
-            t[0] = (int)(int16_t)(a0 & 0xFFFF); t[1] = (int)(int16_t)(a0 >> 16);
-        }
-        if (!V) { acc[j - 1][0] = t[0]; acc[j - 1][1] = t[1]; continue; }
-        if (j > 0) {
-#pragma unroll
-            for (int c_ = 0; c_ < 2; c_++) {
-                const uint32_t pr = pack2(tp[c_], t[c_]);
-#pragma unroll
-                for (int r_ = 0; r_ < 2; r_++) {
-                    const int d = j - 1 - r_;
-                    if (d == 0) acc[r_][c_] = dot2a(cv[0], pr, rg.off2);
-                    else if (d == 2) acc[r_][c_] = dot2(cv[1], pr, acc[r_][c_]);
-                }
-            }
-        }
-        tp[0] = t[0]; tp[1] = t[1];
-    }
-#pragma unroll
-    for (int r_ = 0; r_ < 2; r_++)
-        o[r_] = pack2(clip3(0, maxv, V ? acc[r_][0] >> rg.sh2 : acc[r_][0]), clip3(0, maxv, V ? acc[r_][1] >> rg.sh2 : acc[r_][1]));
-}
 
 #define OWNER_NONE 0xFFFFFFFFu
 
@@ -429,8 +257,7 @@ __device__ __forceinline__ void mc_chroma_2x2_w(const char LDS_AS *w, int r0, in
 // wait for their acknowledgement - a memory round trip per tile).
 // MODE 0: per lane; 1: the wave's tile inside one CU (UNI above); 2: the workgroup's whole 64x64 region inside one CU - the reference windows are fetched once per
 // workgroup into LDS the four waves share (W = that block, rm = the thread's chunks of it, wave = the tile's place in the region), everything else as in mode 1
-// Q16 (MODE 0): the wave holds four 16x16 blocks inside one CU each - 16 consecutive lanes share a window (k_inter_quad) - else every lane fetches its own (k_inter_small)
-template <int MODE, bool Q16 = false>
+template <int MODE>
 __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r1, bool lane_ok, int sx, int sy, int lane, int16_t *W, const LaneMap fm,
                                            const uint4 (*s_ref)[2], const uint4 *s_ltap, const uint2 *s_ctap, uint32_t pl[8], uint32_t pu[2], uint32_t pv[2],
                                            const RegionMap *rm = nullptr, int wave = 0, uint32_t own = 0)
@@ -663,9 +490,6 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
         (void)tid;
     } else {
         load_resid();
-        // quadrant-major lanes (k_inter_split): q = lane >> 4 is the SCU's 16x16 quadrant of the tile, (jx, jy) its place in the quadrant
-        const int jx = lane & 3, jy = (lane >> 2) & 3;
-        char LDS_AS *const Wb = (char LDS_AS *)W;                          // the wave's window block (SQ_BYTES)
 #pragma unroll
         for (int l = 0; l < 2; l++) {
             if (!use[l]) continue;
@@ -677,79 +501,26 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
             const int ldx = (mvx & 3) != 0, ldy = (mvy & 3) != 0;
             const int cdx = (mvx & 7) != 0, cdy = (mvy & 7) != 0;
             uint32_t ch[4], cv[4], o[8], ou[2], ov[2];
-            const uint4 lth = s_ltap[ldx ? ((px & 3) << 2) : 16], ltv = s_ltap[ldy ? ((py & 3) << 2) : 16];
-            ch[0] = lth.x; ch[1] = lth.y; ch[2] = lth.z; ch[3] = lth.w; cv[0] = ltv.x; cv[1] = ltv.y; cv[2] = ltv.z; cv[3] = ltv.w;
-            // chroma: 1/8-pel position (x<<2)+mv in luma quarter-pel == chroma eighth-pel; phase in 1/32 = (pos&7)<<2
-            const uint2 cth = s_ctap[cdx ? ((px & 7) << 2) : 32], ctv = s_ctap[cdy ? ((py & 7) << 2) : 32];
-            uint32_t c2h[2] = { cth.x, cth.y }, c2v[2] = { ctv.x, ctv.y };
-            const Regime rgl = regime(ldx, ldy, a.bd_l), rgc = regime(cdx, cdy, a.bd_c);
-            // ---- quadrants inside ONE CU (a 16x16 CU, or a 16x16 part of a 32x16 / 16x64 ... one): the 16 lanes want overlapping 11x11 windows of one 23x23 window
-            //      (+ two 11x11 chroma windows).  They fetch it ONCE, straight into the wave's LDS block (global_load_lds, 16 bytes per lane and instruction: no staging
-            //      registers, all nine requests of the list in flight together), 6 + 3 requests per lane instead of 22 + 20; the other lanes' per-lane loads and
-            //      filtering run while those are in flight, then every quadrant lane filters its part of the shared window - the per-lane predictors' arithmetic,
-            //      sample for sample (mc_luma_4x4_w / mc_chroma_2x2_w).  All 16 lanes of such a quadrant are here together: they share the CU, hence every test above.
-            constexpr bool any_q = Q16;
-            int misl = 0, oddc = 0;
-            if (any_q) {
-                if (Q16) {
-                    const int pxq = px - (jx << 4), pyq = py - (jy << 4);          // the quadrant's first sample, quarter samples
-                    const int rs = lane >> 2 & 3;                                  // this lane's row slot / column chunk inside a request
-                    {
-                        const int xi = (pxq >> 2) - 3, col = lane & 3;
-                        misl = xi & 7;
-                        const gs16 src = ry_ + ((pyq >> 2) - 3 + rs) * a.s_l + (xi & ~7) + col * 8;
-#pragma unroll
-                        for (int k = 0; k < 6; k++)
-                            if (k < 5 || rs < 3) __builtin_amdgcn_global_load_lds((const GAS void *)(src + 4 * k * a.s_l), (LDS_AS void *)(Wb + k * SQ_BLK_B), 16, 0, 0);
-                    }
-                    {
-                        const int xc = (pxq >> 3) - 1, plane = lane >> 1 & 1, col = lane & 1;
-                        oddc = xc & 1;
-                        const gs16 src = (plane ? rv_ : ru_) + ((pyq >> 3) - 1 + rs) * a.s_c + (xc & ~1) + col * 8;
-#pragma unroll
-                        for (int k = 0; k < 3; k++)
-                            if (k < 2 || rs < 3) __builtin_amdgcn_global_load_lds((const GAS void *)(src + 4 * k * a.s_c), (LDS_AS void *)(Wb + SQ_L_BYTES + k * SQ_BLK_B), 16, 0, 0);
-                    }
-                }
+            {
+                const uint4 th = s_ltap[ldx ? ((px & 3) << 2) : 16], tv = s_ltap[ldy ? ((py & 3) << 2) : 16];
+                ch[0] = th.x; ch[1] = th.y; ch[2] = th.z; ch[3] = th.w; cv[0] = tv.x; cv[1] = tv.y; cv[2] = tv.z; cv[3] = tv.w;
+                const gs16 p = ry_ + ((py >> 2) - 3) * a.s_l + (px >> 2) - 3;
+                const Regime rg = regime(ldx, ldy, a.bd_l);
+                const bool wh = __ballot(ldx) != 0, wvv = __ballot(ldy) != 0;      // over the lanes that run this list
+                if (wh) { if (wvv) mc_luma_4x4<true, true>(p, a.s_l, ch, cv, rg, maxl, o); else mc_luma_4x4<true, false>(p, a.s_l, ch, cv, rg, maxl, o); }
+                else    { if (wvv) mc_luma_4x4<false, true>(p, a.s_l, ch, cv, rg, maxl, o); else mc_luma_4x4<false, false>(p, a.s_l, ch, cv, rg, maxl, o); }
             }
-            if (!Q16) {
-                {
-                    const gs16 p = ry_ + ((py >> 2) - 3) * a.s_l + (px >> 2) - 3;
-                    const bool wh = __ballot(ldx) != 0, wvv = __ballot(ldy) != 0;      // over the lanes that run this list per lane
-                    if (wh) { if (wvv) mc_luma_4x4<true, true>(p, a.s_l, ch, cv, rgl, maxl, o); else mc_luma_4x4<true, false>(p, a.s_l, ch, cv, rgl, maxl, o); }
-                    else    { if (wvv) mc_luma_4x4<false, true>(p, a.s_l, ch, cv, rgl, maxl, o); else mc_luma_4x4<false, false>(p, a.s_l, ch, cv, rgl, maxl, o); }
-                }
-                {
-                    const int off = ((py >> 3) - 1) * a.s_c + (px >> 3) - 1;
-                    const bool wh = __ballot(cdx) != 0, wvv = __ballot(cdy) != 0;
-#define MC_C(H, V) do { mc_chroma_2x2<H, V>(ru_ + off, a.s_c, c2h, c2v, rgc, maxc, ou); mc_chroma_2x2<H, V>(rv_ + off, a.s_c, c2h, c2v, rgc, maxc, ov); } while (0)
-                    if (wh) { if (wvv) MC_C(true, true); else MC_C(true, false); }
-                    else    { if (wvv) MC_C(false, true); else MC_C(false, false); }
+            {
+                // chroma: 1/8-pel position (x<<2)+mv in luma quarter-pel == chroma eighth-pel; phase in 1/32 = (pos&7)<<2
+                const uint2 th = s_ctap[cdx ? ((px & 7) << 2) : 32], tv = s_ctap[cdy ? ((py & 7) << 2) : 32];
+                uint32_t c2h[2] = { th.x, th.y }, c2v[2] = { tv.x, tv.y };
+                const int off = ((py >> 3) - 1) * a.s_c + (px >> 3) - 1;
+                const Regime rg = regime(cdx, cdy, a.bd_c);
+                const bool wh = __ballot(cdx) != 0, wvv = __ballot(cdy) != 0;
+#define MC_C(H, V) do { mc_chroma_2x2<H, V>(ru_ + off, a.s_c, c2h, c2v, rg, maxc, ou); mc_chroma_2x2<H, V>(rv_ + off, a.s_c, c2h, c2v, rg, maxc, ov); } while (0)
+                if (wh) { if (wvv) MC_C(true, true); else MC_C(true, false); }
+                else    { if (wvv) MC_C(false, true); else MC_C(false, false); }
 #undef MC_C
-                }
-            }
-            if (any_q) {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // the window requests have landed (nothing else orders an LDS read behind them)
-                wave_lds_sync();
-                if (Q16) {
-                    const char LDS_AS *const wq = Wb + (lane >> 4) * 256;
-                    {
-                        const char LDS_AS *const w = wq + (((misl >> 1) + (jx << 1)) << 2);      // the dword of the row that holds the lane's first window sample
-                        const int oddl = misl & 1;
-                        const bool wh = __ballot(ldx) != 0, wvv = __ballot(ldy) != 0;
-                        if (wh) { if (wvv) mc_luma_4x4_w<true, true>(w, jy << 2, oddl, ch, cv, rgl, maxl, o); else mc_luma_4x4_w<true, false>(w, jy << 2, oddl, ch, cv, rgl, maxl, o); }
-                        else    { if (wvv) mc_luma_4x4_w<false, true>(w, jy << 2, oddl, ch, cv, rgl, maxl, o); else mc_luma_4x4_w<false, false>(w, jy << 2, oddl, ch, cv, rgl, maxl, o); }
-                    }
-                    {
-                        const char LDS_AS *const w = wq + SQ_L_BYTES + (jx << 2);
-                        const bool wh = __ballot(cdx) != 0, wvv = __ballot(cdy) != 0;
-#define MC_CW(H, V) do { mc_chroma_2x2_w<H, V>(w, jy << 1, oddc, c2h, c2v, rgc, maxc, ou); mc_chroma_2x2_w<H, V>(w + 32, jy << 1, oddc, c2h, c2v, rgc, maxc, ov); } while (0)
-                        if (wh) { if (wvv) MC_CW(true, true); else MC_CW(true, false); }
-                        else    { if (wvv) MC_CW(false, true); else MC_CW(false, false); }
-#undef MC_CW
-                    }
-                }
-                wave_lds_sync();                                               // the block is written again by the second list's requests
             }
             if (nl == 0) {
 #pragma unroll
@@ -778,20 +549,21 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Four launches per picture, one per CLASS of block, each with its own register budget (rounds 2 - 4: as paths of one kernel every path paid the registers of the
-// others - 128 -> 143 -> 156 VGPRs, three waves per SIMD - and a wave that held two kinds of block ran both instruction streams).  xgpu_batch_create sorts the picture
-// into four work lists in ONE spatial order (vertical strips XGPU_INTER_STRIP regions wide, row by row inside a strip):
+// Three launches per picture, one per CLASS of 32x32 tile, each with its own register budget (rounds 2 - 4: as three paths of one kernel every path paid the registers of
+// the others - 128 -> 143 -> 156 VGPRs, three waves per SIMD).  xgpu_batch_create sorts the picture into three work lists in ONE spatial order (vertical strips
+// XGPU_INTER_STRIP regions wide, row by row inside a strip):
 //   k_inter_region  64x64 regions inside one CU: one workgroup per region, the reference windows requested once per workgroup into LDS the four waves share;
 //   k_inter_tile    32x32 tiles inside one CU (whose region is not): one wave per tile, the window in the wave's own LDS;
-//   k_inter_quad    16x16 blocks inside one CU (whose tile is not): four per wave, 16 lanes share a block's window;
-//   k_inter_small   every other 16x16 block: four per wave, one lane per SCU, every lane on the CU that covers its SCU (owner map) with windows of its own.
-// The classes are disjoint sets of whole 16x16 blocks, so the launches write disjoint 32-byte row segments and disjoint SCU-map records: the second to fourth are
-// launched without the barrier bit and overlap the tail of the one before (launch_inter).  The first three know their CU from the list item, which carries the CU's
-// record: the chain of a wave is list item -> reference windows; the reference table (kernel arguments) and the tap tables (constant memory) are read with wave-uniform
-// addresses in the first two - no owner-map link, no LDS tables, no barrier in front of the work.
-// XCD-aware mapping (all four): workgroup b runs on XCD b % 8 and every XCD has its own L2; XCD k takes the k-th contiguous eighth of the list - a compact patch of
+//   k_inter_split   every other tile: one wave per tile, one lane per SCU, every lane on the CU that covers its SCU (owner map) with windows of its own.
+// The classes are disjoint sets of whole 32x32 tiles, so the launches write disjoint 64-byte row segments and disjoint SCU-map records: the second and third are
+// launched without the barrier bit and overlap the tail of the one before (launch_inter).  The first two know their CU from the list item, which carries the CU's
+// record: the chain of a wave is list item -> reference windows; the reference table (kernel arguments) and the tap tables (constant memory) are read with
+// wave-uniform addresses - no owner-map link, no LDS tables, no barrier in front of the work.
+// XCD-aware mapping (all three): workgroup b runs on XCD b % 8 and every XCD has its own L2; XCD k takes the k-th contiguous eighth of the list - a compact patch of
 // the picture whose vertical halos are still in its L2 when the row below is processed.
-// History of the single-kernel form (rounds 1-4: persistent waves, class-sorted pieces, occupancy sweeps, non-temporal hints, region order) is in DESIGN.md 3.
+// Round 5 also built, measured bit-exact and dropped finer classes for the split tiles (16x16 blocks inside one CU sharing a 23x23 window by global_load_lds, as a path
+// of this kernel, as tasks sorted inside the workgroup, and as a fourth and fifth launch): DESIGN.md 3 has the numbers and what they say about the bound.
+// History of the single-kernel form (rounds 1-4: persistent waves, class-sorted pieces, occupancy sweeps, non-temporal hints, region order) is in DESIGN.md 3 too.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int xcd_slice(int block, int grid) { return (block & 7) * (grid >> 3) + (block >> 3); }
 
@@ -847,80 +619,52 @@ __global__ __launch_bounds__(256) void k_inter_tile(const InterArgs a)
     if (inter_tile<1>(a, c0, c1, true, sx, sy, lane, s_win + (t >> 6) * UNI_SAMPLES, fm, ARG_REFS(a), ARG_LTAPS(a), ARG_CTAPS(a), pl, pu, pv, nullptr, 0, e.y)) store_scu(a, sx, sy, pl, pu, pv);
 }
 
-// the reference table and the tap tables in LDS, for lanes that look them up with indices of their own; one load per lane, all before the first wait
-struct SplitTables { uint4 ref[XGPU_MAX_REFS * 2][2]; uint4 ltap[17]; uint2 ctap[33]; };
-__device__ __forceinline__ uint4 tables_load(const InterArgs &a, int t)
+// one wave per split tile, one lane per SCU, every lane on the CU that covers its SCU: owner entry -> CU record -> windows of its own (inter_tile<0>); the reference
+// table and the tap tables in LDS, for lanes that look them up with indices of their own
+__global__ __launch_bounds__(256) void k_inter_split(const InterArgs a)
 {
+    __shared__ uint4    s_ref[XGPU_MAX_REFS * 2][2];        // RefEntry [idx][list]
+    __shared__ uint4    s_ltap[17];                         // luma taps of this sequence's table, [16] = identity
+    __shared__ uint2    s_ctap[33];
+    const int t = threadIdx.x, lane = t & 63;
+    const int idx = xcd_slice(blockIdx.x, gridDim.x) * 4 + (t >> 6);
+    const bool have = idx < a.n_splits;
+    const uint32_t e = have ? a.splits[idx] : 0u;
+    const int sx = ((e & 0xFFFF) << 3) + (lane & 7), sy = ((e >> 16) << 3) + (lane >> 3);
+    const bool active = have && sx < (a.pic_w >> 2) && sy < (a.pic_h >> 2);
+    // the first link of the chain goes out before the tables are staged
+    const uint32_t own = active ? a.owner[sy * a.w_scu + sx] : OWNER_NONE;
+    // ... and so do the table loads, ONE per lane, all before the first wait
     static_assert(XGPU_MAX_REFS * 4 <= 96, "one 16-byte half of a reference entry per lane, in front of the tap tables' lanes");
     uint4 tab = make_uint4(0, 0, 0, 0);
     if (t < XGPU_MAX_REFS * 4) tab = ((const uint4 *)&a.refp[0][0])[t];
     else if (t >= 96 && t < 96 + 17) tab = *(const uint4 *)k_luma_taps[a.admvp][t - 96];
     else if (t >= 128 && t < 128 + 33) { const uint2 v = *(const uint2 *)k_chroma_taps[a.admvp][t - 128]; tab.x = v.x; tab.y = v.y; }
-    return tab;
-}
-__device__ __forceinline__ void tables_store(SplitTables &s, int t, uint4 tab)
-{
-    if (t < XGPU_MAX_REFS * 4) s.ref[t >> 1][t & 1] = tab;
-    else if (t >= 96 && t < 96 + 17) s.ltap[t - 96] = tab;
-    else if (t >= 128 && t < 128 + 33) s.ctap[t - 128] = make_uint2(tab.x, tab.y);
-}
-
-// four 16x16 blocks per wave, each inside one CU: lanes 16 q .. 16 q + 15 are block q's 4 x 4 SCUs and share its windows (inter_tile<0, true>)
-__global__ __launch_bounds__(256) void k_inter_quad(const InterArgs a)
-{
-    __shared__ SplitTables s_tab;
-    __shared__ __attribute__((aligned(16))) char s_win[4 * SQ_BYTES];      // per wave: the shared windows of its four blocks
-    const int t = threadIdx.x, lane = t & 63;
-    const int idx = (xcd_slice(blockIdx.x, gridDim.x) * 4 + (t >> 6)) * 4 + (lane >> 4);
-    const bool have = idx < a.n_quads;
-    uint4 e = make_uint4(0, 0, 0, 0), c0 = e, c1 = e;
-    if (have) { const uint4 *const item = (const uint4 *)&a.quads[idx]; e = item[0]; c0 = item[1]; c1 = item[2]; }
-    const uint4 tab = tables_load(a, t);
-    const int sx = ((e.x & 0xFFFF) << 2) + (lane & 3), sy = ((e.x >> 16) << 2) + (lane >> 2 & 3);
-    tables_store(s_tab, t, tab);
-    __syncthreads();
-    const LaneMap fm = { 0, 0 };
-    uint32_t pl[8], pu[2], pv[2];
-    if (inter_tile<0, true>(a, c0, c1, have, sx, sy, lane, (int16_t *)(s_win + (t >> 6) * SQ_BYTES), fm, s_tab.ref, s_tab.ltap, s_tab.ctap, pl, pu, pv, nullptr, 0, e.y)) store_scu(a, sx, sy, pl, pu, pv);
-}
-
-// four 16x16 blocks per wave, one lane per SCU, every lane on the CU that covers its SCU: owner entry -> CU record -> windows of its own (inter_tile<0, false>)
-__global__ __launch_bounds__(256) void k_inter_small(const InterArgs a)
-{
-    __shared__ SplitTables s_tab;
-    const int t = threadIdx.x, lane = t & 63;
-    const int idx = (xcd_slice(blockIdx.x, gridDim.x) * 4 + (t >> 6)) * 4 + (lane >> 4);
-    const bool have = idx < a.n_smalls;
-    const uint32_t e = have ? a.smalls[idx] : 0u;
-    const int sx = ((e & 0xFFFF) << 2) + (lane & 3), sy = ((e >> 16) << 2) + (lane >> 2 & 3);
-    const bool active = have && sx < (a.pic_w >> 2) && sy < (a.pic_h >> 2);
-    // the first link of the chain goes out before the tables are staged
-    const uint32_t own = active ? a.owner[sy * a.w_scu + sx] : OWNER_NONE;
-    const uint4 tab = tables_load(a, t);
     uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
     const bool ok = own < (uint32_t)a.n_cu;                    // unowned (another batch's SCU) or not an index of this batch
     if (ok) { c0 = ((const uint4 *)&a.cus[own])[0]; c1 = ((const uint4 *)&a.cus[own])[1]; }
-    tables_store(s_tab, t, tab);
+    if (t < XGPU_MAX_REFS * 4) s_ref[t >> 1][t & 1] = tab;
+    else if (t >= 96 && t < 96 + 17) s_ltap[t - 96] = tab;
+    else if (t >= 128 && t < 128 + 33) s_ctap[t - 128] = make_uint2(tab.x, tab.y);
     __syncthreads();
     const LaneMap fm = { 0, 0 };
     uint32_t pl[8], pu[2], pv[2];
-    if (inter_tile<0, false>(a, c0, c1, ok, sx, sy, lane, nullptr, fm, s_tab.ref, s_tab.ltap, s_tab.ctap, pl, pu, pv, nullptr, 0, own)) store_scu(a, sx, sy, pl, pu, pv);
+    if (inter_tile<0>(a, c0, c1, ok, sx, sy, lane, nullptr, fm, s_ref, s_ltap, s_ctap, pl, pu, pv, nullptr, 0, own)) store_scu(a, sx, sy, pl, pu, pv);
 }
 
 void launch_inter(xgpu_ctx *c, const InterArgs &a, bool any_order)
 {
     auto grid = [](int n, int per) { return dim3((unsigned)((((n + per - 1) / per + 7) >> 3) << 3)); };
-    // the single-SCU blocks first: their per-lane chains run longest.  any_order: the later launches without the barrier bit (hipExtAnyOrderLaunch)
+    // the split tiles first: their per-lane chains run longest.  any_order: the second and third launch without the barrier bit (hipExtAnyOrderLaunch)
     bool first = true;
     auto go = [&](auto kernel, dim3 g) {
         if (any_order && !first) hipExtLaunchKernelGGL(kernel, g, dim3(256), 0, c->stream, nullptr, nullptr, hipExtAnyOrderLaunch, a);
         else hipLaunchKernelGGL(kernel, g, dim3(256), 0, c->stream, a);
         first = false;
     };
-    if (a.n_smalls) go(k_inter_small, grid(a.n_smalls, 16));
+    if (a.n_splits) go(k_inter_split, grid(a.n_splits, 4));
     if (a.n_regions) go(k_inter_region, grid(a.n_regions, 1));
     if (a.n_tiles) go(k_inter_tile, grid(a.n_tiles, 4));
-    if (a.n_quads) go(k_inter_quad, grid(a.n_quads, 16));
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -1068,37 +1068,32 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
         });
     }
     BT("owner map");
-    // Work lists of the four inter launches (k_inter.hip): 64x64 regions inside one CU, 32x32 tiles inside one CU, 16x16 blocks inside one CU, and the other 16x16 blocks
-    // that hold SCUs of the batch.  A region / tile / block counts as "inside one CU" only when it lies inside the picture as a whole (the kernels' shared-window paths
-    // have no partial form).  The CUs mark the tiles and blocks (disjoint CUs: disjoint full tiles; `any` is a relaxed flag several CUs of one block may set), one
-    // sequential sweep in the kernels' spatial order - vertical strips XGPU_INTER_STRIP regions wide, row by row inside a strip - emits the lists.
-    static thread_local std::vector<uint32_t> tile_cu, quad_cu;
-    static thread_local std::vector<uint8_t> quad_any;
-    static thread_local std::vector<uint2> inter_regions, inter_tiles, inter_quads;      // (position, CU index); the staging copy adds the CU record
-    static thread_local std::vector<uint32_t> inter_smalls;
+    // Work lists of the three inter launches (k_inter.hip): 64x64 regions inside one CU, 32x32 tiles inside one CU, the other tiles that hold SCUs of the batch.  A tile /
+    // region counts as "inside one CU" only when it lies inside the picture as a whole (the kernels' shared-window paths have no partial form).  The CUs mark the tiles
+    // (disjoint CUs: disjoint full tiles; `any` is a relaxed flag several CUs of one tile may set), one sequential sweep in the kernels' spatial order - vertical strips
+    // XGPU_INTER_STRIP regions wide, row by row inside a strip - emits the lists.
+    static thread_local std::vector<uint32_t> tile_cu;
+    static thread_local std::vector<uint8_t> tile_any;
+    static thread_local std::vector<uint2> inter_regions, inter_tiles;      // (position, CU index); the staging copy adds the CU record
+    static thread_local std::vector<uint32_t> inter_splits;
     {
         const int tiles_x = (c->sp.width + 31) >> 5, tiles_y = (c->sp.height + 31) >> 5, full_x = c->sp.width >> 5, full_y = c->sp.height >> 5;
-        const int quads_x = (c->sp.width + 15) >> 4, quads_y = (c->sp.height + 15) >> 4, qfull_x = c->sp.width >> 4, qfull_y = c->sp.height >> 4;
         tile_cu.assign((size_t)tiles_x * tiles_y, 0xFFFFFFFFu);
-        quad_cu.assign((size_t)quads_x * quads_y, 0xFFFFFFFFu);
-        quad_any.assign((size_t)quads_x * quads_y, 0);
-        uint32_t *const tcu = tile_cu.data(), *const qcu = quad_cu.data();
-        uint8_t *const qany = quad_any.data();
-        run_parts([&, tcu, qcu, qany](int, int i0, int i1) {
+        tile_any.assign((size_t)tiles_x * tiles_y, 0);
+        uint32_t *const tcu = tile_cu.data();
+        uint8_t *const tany = tile_any.data();
+        run_parts([&, tcu, tany](int, int i0, int i1) {
             for (int i = i0; i < i1; i++) {
                 if (b->tree && b->tree[i] == 2) continue;
                 const int x0 = b->x[i], y0 = b->y[i], x1 = x0 + (1 << b->log2w[i]), y1 = y0 + (1 << b->log2h[i]);
-                for (int qy = y0 >> 4; qy <= (y1 - 1) >> 4; qy++)
-                    for (int qx = x0 >> 4; qx <= (x1 - 1) >> 4; qx++) {
-                        if (qx < qfull_x && qy < qfull_y && (qx << 4) >= x0 && (qx << 4) + 16 <= x1 && (qy << 4) >= y0 && (qy << 4) + 16 <= y1) qcu[(size_t)qy * quads_x + qx] = (uint32_t)i;
-                        else __atomic_store_n(&qany[(size_t)qy * quads_x + qx], (uint8_t)1, __ATOMIC_RELAXED);
+                for (int ty = y0 >> 5; ty <= (y1 - 1) >> 5; ty++)
+                    for (int tx = x0 >> 5; tx <= (x1 - 1) >> 5; tx++) {
+                        if (tx < full_x && ty < full_y && (tx << 5) >= x0 && (tx << 5) + 32 <= x1 && (ty << 5) >= y0 && (ty << 5) + 32 <= y1) tcu[(size_t)ty * tiles_x + tx] = (uint32_t)i;
+                        else __atomic_store_n(&tany[(size_t)ty * tiles_x + tx], (uint8_t)1, __ATOMIC_RELAXED);
                     }
-                if (b->log2w[i] >= 5 && b->log2h[i] >= 5)
-                    for (int ty = (y0 + 31) >> 5; ty < full_y && (ty << 5) + 32 <= y1; ty++)
-                        for (int tx = (x0 + 31) >> 5; tx < full_x && (tx << 5) + 32 <= x1; tx++) tcu[(size_t)ty * tiles_x + tx] = (uint32_t)i;
             }
         });
-        inter_regions.clear(); inter_tiles.clear(); inter_quads.clear(); inter_smalls.clear();
+        inter_regions.clear(); inter_tiles.clear(); inter_splits.clear();
         const int regions_x = (c->sp.width + 63) >> 6, regions_y = (c->sp.height + 63) >> 6;
         for (int s0 = 0; s0 < regions_x; s0 += XGPU_INTER_STRIP)
             for (int ry = 0; ry < regions_y; ry++)
@@ -1114,14 +1109,8 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
                         const int ux = tx + (q & 1), uy = ty + (q >> 1);
                         if (ux >= tiles_x || uy >= tiles_y) continue;
                         const uint32_t oq = tcu[(size_t)uy * tiles_x + ux];
-                        if (oq != 0xFFFFFFFFu) { inter_tiles.push_back(make_uint2((uint32_t)ux | ((uint32_t)uy << 16), oq)); continue; }
-                        for (int k = 0; k < 4; k++) {
-                            const int qx = ux * 2 + (k & 1), qy = uy * 2 + (k >> 1);
-                            if (qx >= quads_x || qy >= quads_y) continue;
-                            const uint32_t ok_ = qcu[(size_t)qy * quads_x + qx];
-                            if (ok_ != 0xFFFFFFFFu) inter_quads.push_back(make_uint2((uint32_t)qx | ((uint32_t)qy << 16), ok_));
-                            else if (qany[(size_t)qy * quads_x + qx]) inter_smalls.push_back((uint32_t)qx | ((uint32_t)qy << 16));
-                        }
+                        if (oq != 0xFFFFFFFFu) inter_tiles.push_back(make_uint2((uint32_t)ux | ((uint32_t)uy << 16), oq));
+                        else if (tany[(size_t)uy * tiles_x + ux]) inter_splits.push_back((uint32_t)ux | ((uint32_t)uy << 16));
                     }
                 }
     }
@@ -1166,10 +1155,9 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     const size_t sz_own = sizeof(uint32_t) * (size_t)c->w_scu * c->h_scu;
     const size_t o_cpmv = o_aff + align_up((int)sz_aff, 256), o_dmvr = o_cpmv + align_up((int)sz_cpmv, 256), o_own = o_dmvr + align_up((int)sz_dmvr, 256);
     const size_t sz_ireg = sizeof(InterItem) * std::max(inter_regions.size(), (size_t)1), sz_itile = sizeof(InterItem) * std::max(inter_tiles.size(), (size_t)1);
-    const size_t sz_iquad = sizeof(InterItem) * std::max(inter_quads.size(), (size_t)1), sz_ismall = sizeof(uint32_t) * std::max(inter_smalls.size(), (size_t)1);
-    const size_t o_ireg = o_own + align_up((int)sz_own, 256), o_itile = o_ireg + align_up((int)sz_ireg, 256), o_iquad = o_itile + align_up((int)sz_itile, 256);
-    const size_t o_ismall = o_iquad + align_up((int)sz_iquad, 256);
-    const size_t o_coef = o_ismall + align_up((int)sz_ismall, 256);
+    const size_t sz_isplit = sizeof(uint32_t) * std::max(inter_splits.size(), (size_t)1);
+    const size_t o_ireg = o_own + align_up((int)sz_own, 256), o_itile = o_ireg + align_up((int)sz_ireg, 256), o_isplit = o_itile + align_up((int)sz_itile, 256);
+    const size_t o_coef = o_isplit + align_up((int)sz_isplit, 256);
     db->stage_bytes = o_coef + sz_coef;
     auto fail = [&](int code) { xgpu_batch_destroy(c, db); return code; };
     // device layout: the uploaded arrays at the staging offsets, then the residual arena and the intra done flags
@@ -1313,13 +1301,13 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     }
     memcpy(hs + o_ctu, b->ctu_cu_start, sz_ctu);
     {
-        // the items of the three uniform classes carry their CU's record: the kernels' chain is list entry -> reference windows, no CU-record fetch in between
+        // the items of the two uniform classes carry their CU's record: the kernels' chain is list entry -> reference windows, no CU-record fetch in between
         auto fill = [&](size_t off, const std::vector<uint2> &v) {
             InterItem *it = (InterItem *)(hs + off);
             for (size_t k = 0; k < v.size(); k++) { it[k].pos = v[k].x; it[k].cu = v[k].y; it[k].pad[0] = it[k].pad[1] = 0; it[k].rec = cus[v[k].y]; }
         };
-        fill(o_ireg, inter_regions); fill(o_itile, inter_tiles); fill(o_iquad, inter_quads);
-        if (!inter_smalls.empty()) memcpy(hs + o_ismall, inter_smalls.data(), sizeof(uint32_t) * inter_smalls.size());
+        fill(o_ireg, inter_regions); fill(o_itile, inter_tiles);
+        if (!inter_splits.empty()) memcpy(hs + o_isplit, inter_splits.data(), sizeof(uint32_t) * inter_splits.size());
     }
     if (b->n_coef && !coef_pinned) {                                   // the largest array (45 MB at 8K): in slices on the builder's threads
         const size_t bytes = sizeof(int16_t) * b->n_coef;
@@ -1334,8 +1322,8 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     db->d_waves = (TbWave *)(dbase + o_wv); db->d_intra = (IntraRec *)(dbase + o_intra); db->d_intra_deps = (uint32_t *)(dbase + o_deps);
     db->d_aff_items = (AffItem *)(dbase + o_aff); db->d_cpmv = (int16_t *)(dbase + o_cpmv);
     db->d_dmvr_items = (DmvrItem *)(dbase + o_dmvr); db->d_dmvr_mv = (int16_t *)(dbase + o_dmv); db->d_owner = (uint32_t *)(dbase + o_own);
-    db->d_inter_regions = (InterItem *)(dbase + o_ireg); db->d_inter_tiles = (InterItem *)(dbase + o_itile); db->d_inter_quads = (InterItem *)(dbase + o_iquad); db->d_inter_smalls = (uint32_t *)(dbase + o_ismall);
-    db->n_inter_regions = (int)inter_regions.size(); db->n_inter_tiles = (int)inter_tiles.size(); db->n_inter_quads = (int)inter_quads.size(); db->n_inter_smalls = (int)inter_smalls.size();
+    db->d_inter_regions = (InterItem *)(dbase + o_ireg); db->d_inter_tiles = (InterItem *)(dbase + o_itile); db->d_inter_splits = (uint32_t *)(dbase + o_isplit);
+    db->n_inter_regions = (int)inter_regions.size(); db->n_inter_tiles = (int)inter_tiles.size(); db->n_inter_splits = (int)inter_splits.size();
     db->d_coef = (int16_t *)(dbase + o_coef); db->d_resid = (int16_t *)(dbase + o_resid); db->d_intra_done = (uint32_t *)(dbase + o_done);
     // one copy: the staging block has the device layout (a pinned coefficient arena goes from the caller's buffer).  On the upload stream: the
     // copy overlaps the kernels of the pictures before; xgpu_batch_recon makes the kernel stream wait for `uploaded`
@@ -1343,7 +1331,7 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     if (segs) *segs = { { o_cus, sizeof(CuRec) * (size_t)n }, { o_ctu, sz_ctu }, { o_tbs, sizeof(TbRec) * (size_t)n_tb }, { o_wv, sizeof(TbWave) * (size_t)n_waves }, { o_intra, sizeof(IntraRec) * (size_t)n_intra },
                         { o_deps, sizeof(uint32_t) * (size_t)n_deps }, { o_aff, sizeof(AffItem) * (size_t)(n_aff_eif + n_aff_sub) }, { o_cpmv, sizeof(int16_t) * 12 * (size_t)n_aff },
                         { o_dmvr, sizeof(DmvrItem) * (size_t)n_dmvr }, { o_own, sz_own }, { o_coef, coef_pinned ? 0 : sizeof(int16_t) * b->n_coef },
-                        { o_ireg, sizeof(InterItem) * inter_regions.size() }, { o_itile, sizeof(InterItem) * inter_tiles.size() }, { o_iquad, sizeof(InterItem) * inter_quads.size() }, { o_ismall, sizeof(uint32_t) * inter_smalls.size() } };
+                        { o_ireg, sizeof(InterItem) * inter_regions.size() }, { o_itile, sizeof(InterItem) * inter_tiles.size() }, { o_isplit, sizeof(uint32_t) * inter_splits.size() } };
     if (host_only) { *out = db; return XGPU_OK; }
     hipError_t e = hipMemcpyAsync(dbase, hs, coef_pinned ? o_coef : db->stage_bytes, hipMemcpyHostToDevice, c->up_stream);
     if (e == hipSuccess && coef_pinned) e = hipMemcpyAsync(dbase + o_coef, b->coef, sizeof(int16_t) * b->n_coef, hipMemcpyHostToDevice, c->up_stream);
@@ -1481,8 +1469,8 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
     a.s_l = c->s_l; a.s_c = c->s_c; a.pic_w = c->sp.width; a.pic_h = c->sp.height;
     a.bd_l = c->sp.bit_depth_luma; a.bd_c = c->sp.bit_depth_chroma;
     a.admvp = c->sp.tool_admvp ? 1 : 0;
-    a.regions = db->d_inter_regions; a.tiles = db->d_inter_tiles; a.quads = db->d_inter_quads; a.smalls = db->d_inter_smalls;
-    a.n_regions = db->n_inter_regions; a.n_tiles = db->n_inter_tiles; a.n_quads = db->n_inter_quads; a.n_smalls = db->n_inter_smalls;
+    a.regions = db->d_inter_regions; a.tiles = db->d_inter_tiles; a.splits = db->d_inter_splits;
+    a.n_regions = db->n_inter_regions; a.n_tiles = db->n_inter_tiles; a.n_splits = db->n_inter_splits;
     a.cus = db->d_cus; a.resid = db->d_resid;
     a.maps = c->d_maps; a.w_scu = c->w_scu; a.owner = db->d_owner; a.n_cu = db->n_cu; a.cur_poc = c->fp.poc;
     c->order_rl |= db->order_rl;                            // (the pictures' batches - one per slice - say it for the deblocking pass behind them)

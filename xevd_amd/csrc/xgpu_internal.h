@@ -89,7 +89,7 @@ struct TbWave {
 };
 
 #define XGPU_INTER_STRIP 16       // width, in 64x64 regions, of the vertical strips the inter work lists are ordered in (xgpu_batch_create, k_inter.hip)
-// One item of the uniform work lists: where, which CU, and the CU's record (the kernels need no second fetch to start their window requests)
+// One item of the two uniform work lists: where, which CU, and the CU's record (the kernels need no second fetch to start their window requests)
 struct __attribute__((aligned(16))) InterItem { uint32_t pos, cu, pad[2]; CuRec rec; };
 static_assert(sizeof(InterItem) == 48, "InterItem must be 48 bytes");
 struct RefEntry { const int16_t *y, *u, *v; int poc; int pad; };
@@ -101,13 +101,12 @@ struct InterArgs {
     int      pic_w, pic_h;
     int      bd_l, bd_c;
     int      admvp;
-    // Work lists of the four launches (built by xgpu_batch_create in one spatial order - vertical strips of 64x64 regions, row by row inside a strip - so that
+    // Work lists of the three launches (built by xgpu_batch_create in one spatial order - vertical strips of 64x64 regions, row by row inside a strip - so that
     // every XCD, which takes a contiguous eighth of each list, works on a compact patch of the picture):
     const InterItem *regions;          // k_inter_region: 64x64 regions inside ONE CU (pos = region column | row << 16)
     const InterItem *tiles;            // k_inter_tile: 32x32 tiles inside one CU whose region is not (pos in tiles)
-    const InterItem *quads;            // k_inter_quad: 16x16 blocks inside one CU whose tile is not (pos in blocks)
-    const uint32_t  *smalls;           // k_inter_small: every other 16x16 block that holds SCUs of the batch: block column | row << 16
-    int      n_regions, n_tiles, n_quads, n_smalls;
+    const uint32_t  *splits;           // k_inter_split: every other tile that holds SCUs of the batch: tile column | row << 16
+    int      n_regions, n_tiles, n_splits;
     const CuRec    *cus;
     const int16_t  *resid;
     ScuRec  *maps;
@@ -270,9 +269,9 @@ struct xgpu_dbatch {
     CuRec     *d_cus;
     uint32_t  *d_ctu_start;
     uint32_t  *d_owner;               // SCU -> CU index of the batch, over the whole picture
-    InterItem *d_inter_regions, *d_inter_tiles, *d_inter_quads;      // work lists of the four inter launches (InterArgs)
-    uint32_t  *d_inter_smalls;
-    int        n_inter_regions, n_inter_tiles, n_inter_quads, n_inter_smalls;
+    InterItem *d_inter_regions, *d_inter_tiles;      // work lists of the three inter launches (InterArgs)
+    uint32_t  *d_inter_splits;
+    int        n_inter_regions, n_inter_tiles, n_inter_splits;
     int16_t   *d_coef, *d_resid;
     TbRec     *d_tbs;
     TbWave    *d_waves;
