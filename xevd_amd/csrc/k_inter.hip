@@ -22,6 +22,7 @@
 #include "xgpu_internal.h"
 
 #include <hip/hip_ext.h>
+#include <type_traits>
 #include "mc_filters.h"
 
 #define LDS_AS __attribute__((address_space(3)))
@@ -245,6 +246,130 @@ __device__ __forceinline__ RegionMap region_map(int t)
         m.c[it] = idx < 420 ? (row << 8) | (pl << 7) | k : -1;
     }
     return m;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// k_inter_split: one SCU per lane, one list.  mc_luma_4x4 + 2 x mc_chroma_2x2 (mc_filters.h) with ALL the list's requests in front of the arithmetic.
+// Left to itself the compiler - holding the kernel at four waves per SIMD - fetched the luma window in four instalments (five rows, two, one, three) and each chroma
+// plane on its own, every instalment a wait for the round trip before the next is requested: six memory round trips per list in a row, ~11 per wave with the owner
+// entry and the CU record in front, at ~2 us each under load - the wave's 25-30 us life, of which the SIMD saw ~3 (round 5: why nothing that changed the NUMBER or the
+// SIZE of the requests moved this kernel).  Here the eleven luma rows are requested at once (66 registers - the kernel takes three waves per SIMD instead of four),
+// the first six are filtered, the ten chroma rows are requested into the registers those freed, the last five luma rows are filtered while they travel: two round
+// trips per list, the second under arithmetic.
+// H / V: does ANY lane of the wave filter luma in that direction (wave-uniform, as mc_luma_4x4); chroma is fetched as for the full filter and its variant chosen after.
+// ---------------------------------------------------------------------------------------------------------
+template <bool H, bool V>
+__device__ __forceinline__ void mc_scu_list(gs16 pl_, int s_l, gs16 pu_, gs16 pv_, int s_c, const uint32_t ch[4], const uint32_t cv[4], Regime rgl, int maxl,
+                                            const uint32_t c2h[2], const uint32_t c2v[2], Regime rgc, int maxc, bool cwh, bool cwv, uint32_t o[8], uint32_t ou[2], uint32_t ov[2])
+{
+    constexpr int J0 = V ? 0 : 3, J1 = V ? 11 : 7;
+    uint4 A[11]; uint2 B[11];
+#pragma unroll
+    for (int j = J0; j < J1; j++) {
+        if (H) { A[j] = gload16(pl_ + j * s_l); B[j] = gload8(pl_ + j * s_l + 8); }
+        else B[j] = gload8(pl_ + j * s_l + 3);                 // no lane filters horizontally: samples 3..6 of the window
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    int acc[4][4];
+    int tp[4] = {0, 0, 0, 0};
+    auto row = [&](int j) {
+        int t[4];
+        if (H) {
+            const uint32_t D0 = A[j].x, D1 = A[j].y, D2 = A[j].z, D3 = A[j].w, D4 = B[j].x, D5 = B[j].y;
+            const uint32_t Q0 = hi_lo(D1, D0), Q1 = hi_lo(D2, D1), Q2 = hi_lo(D3, D2), Q3 = hi_lo(D4, D3), Q4 = hi_lo(D5, D4);
+            t[0] = dot2(ch[3], D3, dot2(ch[2], D2, dot2(ch[1], D1, dot2z(ch[0], D0))));
+            t[2] = dot2(ch[3], D4, dot2(ch[2], D3, dot2(ch[1], D2, dot2z(ch[0], D1))));
+            t[1] = dot2(ch[3], Q3, dot2(ch[2], Q2, dot2(ch[1], Q1, dot2z(ch[0], Q0))));
+            t[3] = dot2(ch[3], Q4, dot2(ch[2], Q3, dot2(ch[1], Q2, dot2z(ch[0], Q1))));
+#pragma unroll
+            for (int c = 0; c < 4; c++) t[c] = clip3(rgl.lo1, rgl.hi1, t[c] >> rgl.sh1);
+        } else {
+            t[0] = (int)(int16_t)(B[j].x & 0xFFFF); t[1] = (int)(int16_t)(B[j].x >> 16);
+            t[2] = (int)(int16_t)(B[j].y & 0xFFFF); t[3] = (int)(int16_t)(B[j].y >> 16);
+        }
+        if (!V) {
+#pragma unroll
+            for (int c = 0; c < 4; c++) acc[j - 3][c] = t[c];
+            return;
+        }
+        if (j > 0) {
+            // row pair (j-1, j) feeds output row r with tap pair (j-1-r)/2 when j-1-r is even and in 0..6
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const uint32_t pr = pack2(tp[c], t[c]);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int d = j - 1 - r;
+                    if (d == 0) acc[r][c] = dot2a(cv[0], pr, rgl.off2);          // first tap pair carries the rounding offset
+                    else if (d > 0 && d <= 6 && (d & 1) == 0) acc[r][c] = dot2(cv[d >> 1], pr, acc[r][c]);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; c++) tp[c] = t[c];
+    };
+    constexpr int JM = V ? 6 : 5;                               // the rows filtered before the chroma requests go out
+#pragma unroll
+    for (int j = J0; j < JM; j++) row(j);
+    __builtin_amdgcn_sched_barrier(0);
+    // both chroma windows: five rows of 8 + 4 bytes per plane (the full filter's; the variants below read what they need)
+    uint2 CA[2][5]; uint32_t CB[2][5];
+#pragma unroll
+    for (int pl = 0; pl < 2; pl++)
+#pragma unroll
+        for (int j = 0; j < 5; j++) { const gs16 q = (pl ? pv_ : pu_) + j * s_c; CA[pl][j] = gload8(q); CB[pl][j] = gload4(q + 4); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = JM; j < J1; j++) row(j);
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        int v[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) v[c] = clip3(0, maxl, V ? acc[r][c] >> rgl.sh2 : acc[r][c]);
+        o[r * 2 + 0] = pack2(v[0], v[1]);
+        o[r * 2 + 1] = pack2(v[2], v[3]);
+    }
+    // chroma, from the registers: mc_chroma_2x2's arithmetic on window row j = dwords (CA[j].x, CA[j].y, CB[j]) = samples 0..5
+    auto chroma = [&](auto hc, auto vc, int pl, uint32_t oo[2]) {
+        constexpr bool CH = decltype(hc)::value, CV = decltype(vc)::value;
+        int a2[2][2];
+        int tq[2] = {0, 0};
+#pragma unroll
+        for (int j = CV ? 0 : 1; j < (CV ? 5 : 3); j++) {
+            int t[2];
+            const uint32_t D0 = CA[pl][j].x, D1 = CA[pl][j].y, D2 = CB[pl][j];
+            if (CH) {
+                const uint32_t Q0 = hi_lo(D1, D0), Q1 = hi_lo(D2, D1);
+                t[0] = dot2(c2h[1], D1, dot2z(c2h[0], D0));
+                t[1] = dot2(c2h[1], Q1, dot2z(c2h[0], Q0));
+#pragma unroll
+                for (int c = 0; c < 2; c++) t[c] = clip3(rgc.lo1, rgc.hi1, t[c] >> rgc.sh1);
+            } else {
+                const uint32_t q = hi_lo(D1, D0);                                 // samples 1..2
+                t[0] = (int)(int16_t)(q & 0xFFFF); t[1] = (int)(int16_t)(q >> 16);
+            }
+            if (!CV) { a2[j - 1][0] = t[0]; a2[j - 1][1] = t[1]; continue; }
+            if (j > 0) {
+#pragma unroll
+                for (int c = 0; c < 2; c++) {
+                    const uint32_t pr = pack2(tq[c], t[c]);
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const int d = j - 1 - r;
+                        if (d == 0) a2[r][c] = dot2a(c2v[0], pr, rgc.off2);
+                        else if (d == 2) a2[r][c] = dot2(c2v[1], pr, a2[r][c]);
+                    }
+                }
+            }
+            tq[0] = t[0]; tq[1] = t[1];
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+            oo[r] = pack2(clip3(0, maxc, CV ? a2[r][0] >> rgc.sh2 : a2[r][0]), clip3(0, maxc, CV ? a2[r][1] >> rgc.sh2 : a2[r][1]));
+    };
+    using T = std::true_type; using F = std::false_type;
+    if (cwh) { if (cwv) { chroma(T{}, T{}, 0, ou); chroma(T{}, T{}, 1, ov); } else { chroma(T{}, F{}, 0, ou); chroma(T{}, F{}, 1, ov); } }
+    else     { if (cwv) { chroma(F{}, T{}, 0, ou); chroma(F{}, T{}, 1, ov); } else { chroma(F{}, F{}, 0, ou); chroma(F{}, F{}, 1, ov); } }
 }
 
 #define OWNER_NONE 0xFFFFFFFFu
@@ -504,23 +629,18 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
             {
                 const uint4 th = s_ltap[ldx ? ((px & 3) << 2) : 16], tv = s_ltap[ldy ? ((py & 3) << 2) : 16];
                 ch[0] = th.x; ch[1] = th.y; ch[2] = th.z; ch[3] = th.w; cv[0] = tv.x; cv[1] = tv.y; cv[2] = tv.z; cv[3] = tv.w;
-                const gs16 p = ry_ + ((py >> 2) - 3) * a.s_l + (px >> 2) - 3;
-                const Regime rg = regime(ldx, ldy, a.bd_l);
-                const bool wh = __ballot(ldx) != 0, wvv = __ballot(ldy) != 0;      // over the lanes that run this list
-                if (wh) { if (wvv) mc_luma_4x4<true, true>(p, a.s_l, ch, cv, rg, maxl, o); else mc_luma_4x4<true, false>(p, a.s_l, ch, cv, rg, maxl, o); }
-                else    { if (wvv) mc_luma_4x4<false, true>(p, a.s_l, ch, cv, rg, maxl, o); else mc_luma_4x4<false, false>(p, a.s_l, ch, cv, rg, maxl, o); }
-            }
-            {
                 // chroma: 1/8-pel position (x<<2)+mv in luma quarter-pel == chroma eighth-pel; phase in 1/32 = (pos&7)<<2
-                const uint2 th = s_ctap[cdx ? ((px & 7) << 2) : 32], tv = s_ctap[cdy ? ((py & 7) << 2) : 32];
-                uint32_t c2h[2] = { th.x, th.y }, c2v[2] = { tv.x, tv.y };
+                const uint2 cth = s_ctap[cdx ? ((px & 7) << 2) : 32], ctv = s_ctap[cdy ? ((py & 7) << 2) : 32];
+                const uint32_t c2h[2] = { cth.x, cth.y }, c2v[2] = { ctv.x, ctv.y };
+                const gs16 p = ry_ + ((py >> 2) - 3) * a.s_l + (px >> 2) - 3;
                 const int off = ((py >> 3) - 1) * a.s_c + (px >> 3) - 1;
-                const Regime rg = regime(cdx, cdy, a.bd_c);
-                const bool wh = __ballot(cdx) != 0, wvv = __ballot(cdy) != 0;
-#define MC_C(H, V) do { mc_chroma_2x2<H, V>(ru_ + off, a.s_c, c2h, c2v, rg, maxc, ou); mc_chroma_2x2<H, V>(rv_ + off, a.s_c, c2h, c2v, rg, maxc, ov); } while (0)
-                if (wh) { if (wvv) MC_C(true, true); else MC_C(true, false); }
-                else    { if (wvv) MC_C(false, true); else MC_C(false, false); }
-#undef MC_C
+                const Regime rgl = regime(ldx, ldy, a.bd_l), rgc = regime(cdx, cdy, a.bd_c);
+                const bool wh = __ballot(ldx) != 0, wvv = __ballot(ldy) != 0;      // over the lanes that run this list
+                const bool cwh = __ballot(cdx) != 0, cwv = __ballot(cdy) != 0;
+#define MC_S(H, V) mc_scu_list<H, V>(p, a.s_l, ru_ + off, rv_ + off, a.s_c, ch, cv, rgl, maxl, c2h, c2v, rgc, maxc, cwh, cwv, o, ou, ov)
+                if (wh) { if (wvv) MC_S(true, true); else MC_S(true, false); }
+                else    { if (wvv) MC_S(false, true); else MC_S(false, false); }
+#undef MC_S
             }
             if (nl == 0) {
 #pragma unroll

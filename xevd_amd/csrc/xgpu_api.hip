@@ -1492,10 +1492,10 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
         tool_stream = c->side_stream;
     }
     // the three inter launches (k_inter.hip) write disjoint tiles: the second and third are launched without the barrier bit (hipExtAnyOrderLaunch) and may start while
-    // the first still runs - not while single kernels are timed, where XGPU_K_INTER is the sum of the three.  (Round 5, 8K: one after the other 0.360 ms per picture,
+    // the first still runs; XGPU_K_INTER times the three as the one pass over the picture they are (first start to last end).  (Round 5, 8K: one after the other 0.360 ms per picture,
     // any-order 0.354 - 0.357, on three streams of the default class 0.362 - 0.365, on streams of the high-priority class 0.638: their waves preempt the kernel stream's.)
     static const bool inter_in_order = getenv("XEVD_HIP_INTER_IN_ORDER") != NULL;      // A/B measurements (read once)
-    TIMED(c, XGPU_K_INTER, launch_inter(c, a, !c->timing && !inter_in_order));
+    TIMED(c, XGPU_K_INTER, launch_inter(c, a, !inter_in_order));
     if (!ahead) HIPCHK(c, hipEventRecord(c->after_inter, c->stream));   // where a residual pass prepared on the side stream (xgpu_batch_prepare) may start
     c->have_after_inter = 1;
     if (db->n_dmvr) {
