@@ -40,10 +40,12 @@
 #define UI_STRIDE 40                 // intermediate rows: 80 B = 20 banks, so the 8 x 4 SCUs of a half wave hit 64 different banks
 #define UC_STRIDE 24                 // chroma rows (window and intermediate): 12 banks, conflict-free for the 64 lanes' dword reads
 #define UCW_STRIDE 32                // chroma window rows (the intermediate rows keep UC_STRIDE)
-// k_inter_tile's block per wave: luma window (4 requests x 60 chunks = 40 rows), the two chroma windows (152 chunks; 3 requests x 64 slots), intermediate rows
+// k_inter_tile's block per wave: luma window (4 requests x 60 chunks = 40 rows), the two chroma windows (152 chunks; 3 requests x 64 slots); the intermediate rows
+// of the passes are written over the window rows they come from (inter_tile)
+static_assert(UI_STRIDE <= UW_STRIDE && UC_STRIDE <= UCW_STRIDE, "an intermediate row is not longer than the window row it replaces");
 #define UT_L_SAMPLES (40 * UW_STRIDE)
 #define UT_C_SAMPLES (3 * 64 * 8)
-#define UNI_SAMPLES   (UT_L_SAMPLES + UT_C_SAMPLES + 39 * UI_STRIDE)
+#define UNI_SAMPLES   (UT_L_SAMPLES + UT_C_SAMPLES)
 static_assert(2 * 19 * UCW_STRIDE <= UT_C_SAMPLES, "both chroma windows fit");
 
 __device__ __forceinline__ void wave_lds_sync()
@@ -509,7 +511,11 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
         constexpr bool REGION = MODE == 2;
         constexpr int WS_L = REGION ? REG_W_STRIDE : UW_STRIDE, WS_C = REGION ? REG_C_STRIDE : UCW_STRIDE;
         constexpr int L_SAMPLES = REGION ? REG_W_SAMPLES : UT_L_SAMPLES, C_SAMPLES = REGION ? REG_C_SAMPLES : 19 * UCW_STRIDE;
-        int16_t *const I = W + L_SAMPLES + 2 * C_SAMPLES + (REGION ? wave * REG_I_SAMPLES : 0);
+        // the intermediate rows of the two passes.  MODE 2: a block per wave behind the windows.  MODE 1: IN the window they come from - intermediate row r (80 bytes) lies in
+        // window rows <= r (96 bytes each) and a pass of the wave reads all its window rows before it writes (LDS executes a wave's instructions in order), so a row
+        // is overwritten only after it has been read: 6.9 KB of LDS per wave instead of 10
+        int16_t *const I = REGION ? W + L_SAMPLES + 2 * C_SAMPLES + wave * REG_I_SAMPLES : W;
+        int16_t *const IC = REGION ? I : W + L_SAMPLES;
         // the wave's 39x39 (19x19) part of the window block
         const int16_t *const Wy0 = W + (REGION ? ((wave >> 1) << 5) * REG_W_STRIDE + ((wave & 1) << 5) : 0);
         const int16_t *const Wu0 = W + L_SAMPLES + (REGION ? ((wave >> 1) << 4) * REG_C_STRIDE + ((wave & 1) << 4) : 0);
@@ -593,8 +599,8 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
                 const Regime rg = regime(cdx, cdy, a.bd_c);
                 const int mis = ((px >> 3) - 1) & 7, odd = mis & 1;
                 const int16_t *const Wu = Wu0 + (mis & ~1), *const Wv = Wu + C_SAMPLES;
-                if (cdx) { if (cdy) chroma_tile_filter<true, true, WS_C, true>(Wu, Wv, c2h, c2v, rg, maxc, I, lane, ou, ov, odd); else chroma_tile_filter<true, false, WS_C, true>(Wu, Wv, c2h, c2v, rg, maxc, I, lane, ou, ov, odd); }
-                else     { if (cdy) chroma_tile_filter<false, true, WS_C, true>(Wu, Wv, c2h, c2v, rg, maxc, I, lane, ou, ov, odd); else chroma_tile_filter<false, false, WS_C, true>(Wu, Wv, c2h, c2v, rg, maxc, I, lane, ou, ov, odd); }
+                if (cdx) { if (cdy) chroma_tile_filter<true, true, WS_C, true>(Wu, Wv, c2h, c2v, rg, maxc, IC, lane, ou, ov, odd); else chroma_tile_filter<true, false, WS_C, true>(Wu, Wv, c2h, c2v, rg, maxc, IC, lane, ou, ov, odd); }
+                else     { if (cdy) chroma_tile_filter<false, true, WS_C, true>(Wu, Wv, c2h, c2v, rg, maxc, IC, lane, ou, ov, odd); else chroma_tile_filter<false, false, WS_C, true>(Wu, Wv, c2h, c2v, rg, maxc, IC, lane, ou, ov, odd); }
             }
             if (more) {
                 if (REGION) __syncthreads(); else wave_lds_sync();
