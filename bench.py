@@ -740,7 +740,7 @@ def main():
                        "residual_pass_ahead": bool(ahead and len(batches) > 1),
                        "parallelism": (f"{world} ranks, one GPU each, drawing jobs of {GOP_PICTURES} pictures (closed GOPs of independent streams) from one host work "
                                        "queue; no collective on the data path" if world > 1 else "1 stream on 1 GPU")},
-            "roofline": {"bound": "hbm", "kernel": "addb_alf" if dom == "alf" and addb_alf else ("inter = k_inter_region + k_inter_tile + k_inter_split, one pass over the picture in three launches" if dom == "inter" else dom), "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "roofline": {"bound": "hbm", "kernel": "addb_alf" if dom == "alf" and addb_alf else dom, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                          "algorithmic_bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 2),
                          "measured_copy_bw_gbps": None if copy_bw is None else round(copy_bw, 1),

@@ -122,6 +122,23 @@ def test_gpu_pictures_golden_residual_pass_ahead(name):
         assert np.array_equal(out[c], exp["out"][c]), f"final plane {c}: {np.argwhere(out[c] != exp['out'][c])[:4]}"
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("knob", ["XEVD_HIP_INTER_LAUNCHES=3", "XEVD_HIP_INTER_ALL_FIRST=1"])
+def test_gpu_inter_launch_options(knob, monkeypatch):
+    """The inter pass's measurement options (read per context by xgpu_open): the three class kernels as launches of their own instead of the one launch, and the one
+    launch with the split role's requests all in front - the same pictures (every golden picture with inter CUs, small pictures: all three classes occur in the
+    CTU-128 and B-picture cases)"""
+    name, value = knob.split("=")
+    monkeypatch.setenv(name, value)
+    for case_name in golden_io.PICTURE_CASES:
+        case, exp = golden_io.load_picture_case(case_name)
+        if not (case["batch"]["pred_mode"] != 0).any():
+            continue
+        out = cases.run_gpu(case)
+        for c in range(3):
+            assert np.array_equal(out[c], exp["out"][c]), f"{case_name}: final plane {c}"
+
+
 RANDOM = [
     # name, w, h, bd, admvp, iqt, n_refs, bi_frac, kwargs
     ("rnd_a", 264, 136, 8, 0, 0, (2, 1), 0.3, {}),

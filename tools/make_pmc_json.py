@@ -14,7 +14,7 @@ import json
 import os
 import sys
 
-NAMES = {"k_inter(": "inter", "k_inter_region(": "inter", "k_inter_tile(": "inter", "k_inter_split(": "inter",      # (the three inter launches are one pass: summed)
+NAMES = {"k_inter(": "inter", "k_inter_af(": "inter", "k_inter_region(": "inter", "k_inter_tile(": "inter", "k_inter_split(": "inter",      # (the three inter launches are one pass: summed)
           "k_alf(": "alf", "k_addb<0>(": "dbk_v", "k_addb<1>(": "dbk_h", "k_addb_fused<": "dbk_v", "k_dbk<0>(": "dbk_v", "k_dbk<1>(": "dbk_h",
          "k_itdq": "itdq", "k_intra<": "intra", "k_intra_itdq<": "intra_itdq", "k_addb_alf(": "alf", "k_addb_alf<": "alf", "k_affine_": "affine", "k_pad(": "pad", "k_dmvr(": "dmvr"}
 

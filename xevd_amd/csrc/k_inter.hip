@@ -384,7 +384,8 @@ __device__ __forceinline__ void mc_scu_list(gs16 pl_, int s_l, gs16 pu_, gs16 pv
 // wait for their acknowledgement - a memory round trip per tile).
 // MODE 0: per lane; 1: the wave's tile inside one CU (UNI above); 2: the workgroup's whole 64x64 region inside one CU - the reference windows are fetched once per
 // workgroup into LDS the four waves share (W = that block, rm = the thread's chunks of it, wave = the tile's place in the region), everything else as in mode 1
-template <int MODE>
+// ALL_FIRST (MODE 0): mc_scu_list (all requests of a list in front of its arithmetic, 145 VGPRs) or mc_luma_4x4 + mc_chroma_2x2 (requests in instalments, 123 VGPRs)
+template <int MODE, bool ALL_FIRST = true>
 __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r1, bool lane_ok, int sx, int sy, int lane, int16_t *W, const LaneMap fm,
                                            const uint4 (*s_ref)[2], const uint4 *s_ltap, const uint2 *s_ctap, uint32_t pl[8], uint32_t pu[2], uint32_t pv[2],
                                            const RegionMap *rm = nullptr, int wave = 0, uint32_t own = 0)
@@ -644,8 +645,17 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
                 const bool wh = __ballot(ldx) != 0, wvv = __ballot(ldy) != 0;      // over the lanes that run this list
                 const bool cwh = __ballot(cdx) != 0, cwv = __ballot(cdy) != 0;
 #define MC_S(H, V) mc_scu_list<H, V>(p, a.s_l, ru_ + off, rv_ + off, a.s_c, ch, cv, rgl, maxl, c2h, c2v, rgc, maxc, cwh, cwv, o, ou, ov)
-                if (wh) { if (wvv) MC_S(true, true); else MC_S(true, false); }
-                else    { if (wvv) MC_S(false, true); else MC_S(false, false); }
+#define MC_C(H, V) do { mc_chroma_2x2<H, V>(ru_ + off, a.s_c, c2h, c2v, rgc, maxc, ou); mc_chroma_2x2<H, V>(rv_ + off, a.s_c, c2h, c2v, rgc, maxc, ov); } while (0)
+                if (ALL_FIRST) {
+                    if (wh) { if (wvv) MC_S(true, true); else MC_S(true, false); }
+                    else    { if (wvv) MC_S(false, true); else MC_S(false, false); }
+                } else {
+                    if (wh) { if (wvv) mc_luma_4x4<true, true>(p, a.s_l, ch, cv, rgl, maxl, o); else mc_luma_4x4<true, false>(p, a.s_l, ch, cv, rgl, maxl, o); }
+                    else    { if (wvv) mc_luma_4x4<false, true>(p, a.s_l, ch, cv, rgl, maxl, o); else mc_luma_4x4<false, false>(p, a.s_l, ch, cv, rgl, maxl, o); }
+                    if (cwh) { if (cwv) MC_C(true, true); else MC_C(true, false); }
+                    else     { if (cwv) MC_C(false, true); else MC_C(false, false); }
+                }
+#undef MC_C
 #undef MC_S
             }
             if (nl == 0) {
@@ -778,10 +788,92 @@ __global__ __launch_bounds__(256) void k_inter_split(const InterArgs a)
     if (inter_tile<0>(a, c0, c1, ok, sx, sy, lane, nullptr, fm, s_ref, s_ltap, s_ctap, pl, pu, pv, nullptr, 0, own)) store_scu(a, sx, sy, pl, pu, pv);
 }
 
+// k_inter - ONE launch over the three lists (the default): a workgroup per 64x64 region in the lists' spatial order - the region's four waves take the
+// region role together, or every wave the role of its tile (inside one CU / split).  Same role code as the three kernels above; what changes is WHEN a piece of the
+// picture is worked on: neighbouring tiles of different classes run at the same time on the same XCD and share the reference lines of their halos in its L2 - as three
+// launches every class swept the whole picture on its own and the pass read 505 MB from HBM instead of 337 (profiles/round5_a_pmc.json).
+template <bool ALL_FIRST>
+__device__ __forceinline__ void inter_fused_body(const InterArgs &a)
+{
+    __shared__ __attribute__((aligned(16))) int16_t s_win[REG_SAMPLES];      // region role: the shared windows + intermediates; tile role: four wave blocks
+    static_assert(4 * UNI_SAMPLES <= REG_SAMPLES, "the four waves' tile blocks fit into the region block");
+    __shared__ uint4    s_ref[XGPU_MAX_REFS * 2][2];
+    __shared__ uint4    s_ltap[17];
+    __shared__ uint2    s_ctap[33];
+    const int idx = xcd_slice(blockIdx.x, gridDim.x);
+    if (idx >= a.n_work) return;
+    const uint4 w = a.work[idx];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const LaneMap fm0 = { 0, 0 };
+    uint32_t pl[8], pu[2], pv[2];
+    if (w.x == XGPU_WORK_REGION) {
+        const uint4 *const item = (const uint4 *)&a.regions[w.y];
+        const uint4 e = item[0], c0 = item[1], c1 = item[2];
+        const int rx = e.x & 0xFFFF, ry = e.x >> 16;
+        const int sx = (rx << 4) + ((wave & 1) << 3) + (lane & 7), sy = (ry << 4) + ((wave >> 1) << 3) + (lane >> 3);
+        const RegionMap rmap = region_map(t);
+        if (inter_tile<2>(a, c0, c1, true, sx, sy, lane, s_win, fm0, ARG_REFS(a), ARG_LTAPS(a), ARG_CTAPS(a), pl, pu, pv, &rmap, wave, e.y)) store_scu(a, sx, sy, pl, pu, pv);
+        return;
+    }
+    const uint32_t kinds = w.x;
+    const bool any_split = (kinds & 0xAAu) != 0;                       // workgroup-uniform: the tables and the barrier only where a wave looks them up per lane
+    const uint32_t kind = (kinds >> (2 * wave)) & 3u, below = kinds & ((1u << (2 * wave)) - 1u);
+    const int n_tile_below = __popc(below & 0x55u), n_split_below = __popc(below & 0xAAu);
+    uint4 tab = make_uint4(0, 0, 0, 0);
+    uint32_t own = OWNER_NONE;
+    int sx = 0, sy = 0;
+    bool ok = false;
+    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+    if (kind == 2) {
+        const uint32_t e = a.splits[w.z + n_split_below];
+        sx = ((e & 0xFFFF) << 3) + (lane & 7); sy = ((e >> 16) << 3) + (lane >> 3);
+        if (sx < (a.pic_w >> 2) && sy < (a.pic_h >> 2)) own = a.owner[sy * a.w_scu + sx];
+    }
+    if (any_split) {
+        static_assert(XGPU_MAX_REFS * 4 <= 96, "one 16-byte half of a reference entry per lane, in front of the tap tables' lanes");
+        if (t < XGPU_MAX_REFS * 4) tab = ((const uint4 *)&a.refp[0][0])[t];
+        else if (t >= 96 && t < 96 + 17) tab = *(const uint4 *)k_luma_taps[a.admvp][t - 96];
+        else if (t >= 128 && t < 128 + 33) { const uint2 v = *(const uint2 *)k_chroma_taps[a.admvp][t - 128]; tab.x = v.x; tab.y = v.y; }
+    }
+    if (kind == 2) {
+        ok = own < (uint32_t)a.n_cu;
+        if (ok) { c0 = ((const uint4 *)&a.cus[own])[0]; c1 = ((const uint4 *)&a.cus[own])[1]; }
+    }
+    if (any_split) {
+        if (t < XGPU_MAX_REFS * 4) s_ref[t >> 1][t & 1] = tab;
+        else if (t >= 96 && t < 96 + 17) s_ltap[t - 96] = tab;
+        else if (t >= 128 && t < 128 + 33) s_ctap[t - 128] = make_uint2(tab.x, tab.y);
+        __syncthreads();
+    }
+    if (kind == 1) {
+        const uint4 *const item = (const uint4 *)&a.tiles[w.y + n_tile_below];
+        const uint4 e = item[0];
+        c0 = item[1]; c1 = item[2];
+        sx = ((e.x & 0xFFFF) << 3) + (lane & 7); sy = ((e.x >> 16) << 3) + (lane >> 3);
+        LaneMap fm;
+        {
+            const int row0 = (lane * 171) >> 10, k = lane - row0 * 6;
+            fm.gy = row0 * a.s_l + 8 * k; fm.ly = row0 * UW_STRIDE + 8 * k;
+        }
+        if (inter_tile<1>(a, c0, c1, true, sx, sy, lane, s_win + wave * UNI_SAMPLES, fm, ARG_REFS(a), ARG_LTAPS(a), ARG_CTAPS(a), pl, pu, pv, nullptr, 0, e.y)) store_scu(a, sx, sy, pl, pu, pv);
+    } else if (kind == 2) {
+        if (inter_tile<0, ALL_FIRST>(a, c0, c1, ok, sx, sy, lane, nullptr, fm0, s_ref, s_ltap, s_ctap, pl, pu, pv, nullptr, 0, own)) store_scu(a, sx, sy, pl, pu, pv);
+    }
+}
+__global__ __launch_bounds__(256) void k_inter(const InterArgs a) { inter_fused_body<false>(a); }
+__global__ __launch_bounds__(256) void k_inter_af(const InterArgs a) { inter_fused_body<true>(a); }
+
+// c->inter_launches (XEVD_HIP_INTER_LAUNCHES, read by xgpu_open): 1 (default) = k_inter, the one launch; 3 = the three class kernels one after the other (per-class
+// durations under rocprofv3; A/B measurements), the second and third without the barrier bit when any_order.  c->inter_all_first (XEVD_HIP_INTER_ALL_FIRST): the one
+// launch with the split role's requests all in front (148 VGPRs instead of 127).
 void launch_inter(xgpu_ctx *c, const InterArgs &a, bool any_order)
 {
     auto grid = [](int n, int per) { return dim3((unsigned)((((n + per - 1) / per + 7) >> 3) << 3)); };
-    // the split tiles first: their per-lane chains run longest.  any_order: the second and third launch without the barrier bit (hipExtAnyOrderLaunch)
+    if (c->inter_launches != 3) {
+        if (a.n_work) { if (c->inter_all_first) hipLaunchKernelGGL(k_inter_af, grid(a.n_work, 1), dim3(256), 0, c->stream, a); else hipLaunchKernelGGL(k_inter, grid(a.n_work, 1), dim3(256), 0, c->stream, a); }
+        return;
+    }
+    // the split tiles first: their per-lane chains run longest
     bool first = true;
     auto go = [&](auto kernel, dim3 g) {
         if (any_order && !first) hipExtLaunchKernelGGL(kernel, g, dim3(256), 0, c->stream, nullptr, nullptr, hipExtAnyOrderLaunch, a);

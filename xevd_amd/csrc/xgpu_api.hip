@@ -159,6 +159,8 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     c->builder_threads = 1;
     c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_dra = NULL; c->d_ctb_flag = NULL; c->stream = 0; c->up_stream = 0; c->down_stream = 0; c->side_stream = 0; c->after_inter = 0; c->have_after_inter = 0; c->where = 0; c->addb_pending = 0;
     c->fork_ev = c->join_ev = 0;
+    c->inter_launches = getenv("XEVD_HIP_INTER_LAUNCHES") && atoi(getenv("XEVD_HIP_INTER_LAUNCHES")) == 3 ? 3 : 1;      // measurement knobs (k_inter.hip: launch_inter), per context
+    c->inter_all_first = getenv("XEVD_HIP_INTER_ALL_FIRST") != NULL;
     c->split_addb_alf = getenv("XEVD_HIP_SPLIT_ADDB_ALF") != NULL;      // measurement knob: ADDB and ALF as two kernels (the round-2 chain) instead of k_addb_alf
     for (int i = 0; i < 2; i++) { c->d_out[i] = NULL; c->out_caps[i] = 0; c->out_ready[i] = c->out_done[i] = 0; c->out_busy[i] = 0; }
     c->out_next = 0;
@@ -1076,6 +1078,7 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     static thread_local std::vector<uint8_t> tile_any;
     static thread_local std::vector<uint2> inter_regions, inter_tiles;      // (position, CU index); the staging copy adds the CU record
     static thread_local std::vector<uint32_t> inter_splits;
+    static thread_local std::vector<uint4> inter_work;            // one entry per 64x64 region that holds SCUs of the batch (k_inter.hip: InterArgs.work)
     {
         const int tiles_x = (c->sp.width + 31) >> 5, tiles_y = (c->sp.height + 31) >> 5, full_x = c->sp.width >> 5, full_y = c->sp.height >> 5;
         tile_cu.assign((size_t)tiles_x * tiles_y, 0xFFFFFFFFu);
@@ -1093,7 +1096,7 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
                     }
             }
         });
-        inter_regions.clear(); inter_tiles.clear(); inter_splits.clear();
+        inter_regions.clear(); inter_tiles.clear(); inter_splits.clear(); inter_work.clear();
         const int regions_x = (c->sp.width + 63) >> 6, regions_y = (c->sp.height + 63) >> 6;
         for (int s0 = 0; s0 < regions_x; s0 += XGPU_INTER_STRIP)
             for (int ry = 0; ry < regions_y; ry++)
@@ -1102,16 +1105,20 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
                     const bool whole = tx + 1 < tiles_x && ty + 1 < tiles_y;
                     const uint32_t o = tcu[(size_t)ty * tiles_x + tx];
                     if (whole && o != 0xFFFFFFFFu && tcu[(size_t)ty * tiles_x + tx + 1] == o && tcu[(size_t)(ty + 1) * tiles_x + tx] == o && tcu[(size_t)(ty + 1) * tiles_x + tx + 1] == o) {
+                        inter_work.push_back(make_uint4(XGPU_WORK_REGION, (uint32_t)inter_regions.size(), 0, 0));
                         inter_regions.push_back(make_uint2((uint32_t)rx | ((uint32_t)ry << 16), o));
                         continue;
                     }
+                    uint32_t kinds = 0;
+                    const uint32_t t0 = (uint32_t)inter_tiles.size(), s0_ = (uint32_t)inter_splits.size();
                     for (int q = 0; q < 4; q++) {
                         const int ux = tx + (q & 1), uy = ty + (q >> 1);
                         if (ux >= tiles_x || uy >= tiles_y) continue;
                         const uint32_t oq = tcu[(size_t)uy * tiles_x + ux];
-                        if (oq != 0xFFFFFFFFu) inter_tiles.push_back(make_uint2((uint32_t)ux | ((uint32_t)uy << 16), oq));
-                        else if (tany[(size_t)uy * tiles_x + ux]) inter_splits.push_back((uint32_t)ux | ((uint32_t)uy << 16));
+                        if (oq != 0xFFFFFFFFu) { inter_tiles.push_back(make_uint2((uint32_t)ux | ((uint32_t)uy << 16), oq)); kinds |= 1u << (2 * q); }
+                        else if (tany[(size_t)uy * tiles_x + ux]) { inter_splits.push_back((uint32_t)ux | ((uint32_t)uy << 16)); kinds |= 2u << (2 * q); }
                     }
+                    if (kinds) inter_work.push_back(make_uint4(kinds, t0, s0_, 0));
                 }
     }
     BT("inter lists");
@@ -1157,7 +1164,9 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     const size_t sz_ireg = sizeof(InterItem) * std::max(inter_regions.size(), (size_t)1), sz_itile = sizeof(InterItem) * std::max(inter_tiles.size(), (size_t)1);
     const size_t sz_isplit = sizeof(uint32_t) * std::max(inter_splits.size(), (size_t)1);
     const size_t o_ireg = o_own + align_up((int)sz_own, 256), o_itile = o_ireg + align_up((int)sz_ireg, 256), o_isplit = o_itile + align_up((int)sz_itile, 256);
-    const size_t o_coef = o_isplit + align_up((int)sz_isplit, 256);
+    const size_t sz_iwork = sizeof(uint4) * std::max(inter_work.size(), (size_t)1);
+    const size_t o_iwork = o_isplit + align_up((int)sz_isplit, 256);
+    const size_t o_coef = o_iwork + align_up((int)sz_iwork, 256);
     db->stage_bytes = o_coef + sz_coef;
     auto fail = [&](int code) { xgpu_batch_destroy(c, db); return code; };
     // device layout: the uploaded arrays at the staging offsets, then the residual arena and the intra done flags
@@ -1308,6 +1317,7 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
         };
         fill(o_ireg, inter_regions); fill(o_itile, inter_tiles);
         if (!inter_splits.empty()) memcpy(hs + o_isplit, inter_splits.data(), sizeof(uint32_t) * inter_splits.size());
+        if (!inter_work.empty()) memcpy(hs + o_iwork, inter_work.data(), sizeof(uint4) * inter_work.size());
     }
     if (b->n_coef && !coef_pinned) {                                   // the largest array (45 MB at 8K): in slices on the builder's threads
         const size_t bytes = sizeof(int16_t) * b->n_coef;
@@ -1322,7 +1332,7 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     db->d_waves = (TbWave *)(dbase + o_wv); db->d_intra = (IntraRec *)(dbase + o_intra); db->d_intra_deps = (uint32_t *)(dbase + o_deps);
     db->d_aff_items = (AffItem *)(dbase + o_aff); db->d_cpmv = (int16_t *)(dbase + o_cpmv);
     db->d_dmvr_items = (DmvrItem *)(dbase + o_dmvr); db->d_dmvr_mv = (int16_t *)(dbase + o_dmv); db->d_owner = (uint32_t *)(dbase + o_own);
-    db->d_inter_regions = (InterItem *)(dbase + o_ireg); db->d_inter_tiles = (InterItem *)(dbase + o_itile); db->d_inter_splits = (uint32_t *)(dbase + o_isplit);
+    db->d_inter_regions = (InterItem *)(dbase + o_ireg); db->d_inter_tiles = (InterItem *)(dbase + o_itile); db->d_inter_splits = (uint32_t *)(dbase + o_isplit); db->d_inter_work = (uint4 *)(dbase + o_iwork); db->n_inter_work = (int)inter_work.size();
     db->n_inter_regions = (int)inter_regions.size(); db->n_inter_tiles = (int)inter_tiles.size(); db->n_inter_splits = (int)inter_splits.size();
     db->d_coef = (int16_t *)(dbase + o_coef); db->d_resid = (int16_t *)(dbase + o_resid); db->d_intra_done = (uint32_t *)(dbase + o_done);
     // one copy: the staging block has the device layout (a pinned coefficient arena goes from the caller's buffer).  On the upload stream: the
@@ -1331,7 +1341,7 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     if (segs) *segs = { { o_cus, sizeof(CuRec) * (size_t)n }, { o_ctu, sz_ctu }, { o_tbs, sizeof(TbRec) * (size_t)n_tb }, { o_wv, sizeof(TbWave) * (size_t)n_waves }, { o_intra, sizeof(IntraRec) * (size_t)n_intra },
                         { o_deps, sizeof(uint32_t) * (size_t)n_deps }, { o_aff, sizeof(AffItem) * (size_t)(n_aff_eif + n_aff_sub) }, { o_cpmv, sizeof(int16_t) * 12 * (size_t)n_aff },
                         { o_dmvr, sizeof(DmvrItem) * (size_t)n_dmvr }, { o_own, sz_own }, { o_coef, coef_pinned ? 0 : sizeof(int16_t) * b->n_coef },
-                        { o_ireg, sizeof(InterItem) * inter_regions.size() }, { o_itile, sizeof(InterItem) * inter_tiles.size() }, { o_isplit, sizeof(uint32_t) * inter_splits.size() } };
+                        { o_ireg, sizeof(InterItem) * inter_regions.size() }, { o_itile, sizeof(InterItem) * inter_tiles.size() }, { o_isplit, sizeof(uint32_t) * inter_splits.size() }, { o_iwork, sizeof(uint4) * inter_work.size() } };
     if (host_only) { *out = db; return XGPU_OK; }
     hipError_t e = hipMemcpyAsync(dbase, hs, coef_pinned ? o_coef : db->stage_bytes, hipMemcpyHostToDevice, c->up_stream);
     if (e == hipSuccess && coef_pinned) e = hipMemcpyAsync(dbase + o_coef, b->coef, sizeof(int16_t) * b->n_coef, hipMemcpyHostToDevice, c->up_stream);
@@ -1469,7 +1479,7 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
     a.s_l = c->s_l; a.s_c = c->s_c; a.pic_w = c->sp.width; a.pic_h = c->sp.height;
     a.bd_l = c->sp.bit_depth_luma; a.bd_c = c->sp.bit_depth_chroma;
     a.admvp = c->sp.tool_admvp ? 1 : 0;
-    a.regions = db->d_inter_regions; a.tiles = db->d_inter_tiles; a.splits = db->d_inter_splits;
+    a.regions = db->d_inter_regions; a.tiles = db->d_inter_tiles; a.splits = db->d_inter_splits; a.work = db->d_inter_work; a.n_work = db->n_inter_work;
     a.n_regions = db->n_inter_regions; a.n_tiles = db->n_inter_tiles; a.n_splits = db->n_inter_splits;
     a.cus = db->d_cus; a.resid = db->d_resid;
     a.maps = c->d_maps; a.w_scu = c->w_scu; a.owner = db->d_owner; a.n_cu = db->n_cu; a.cur_poc = c->fp.poc;
@@ -1491,10 +1501,8 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
         HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->fork_ev, 0));
         tool_stream = c->side_stream;
     }
-    // the three inter launches (k_inter.hip) write disjoint tiles: the second and third are launched without the barrier bit (hipExtAnyOrderLaunch) and may start while
-    // the first still runs; XGPU_K_INTER times the three as the one pass over the picture they are (first start to last end).  (Round 5, 8K: one after the other 0.360 ms per picture,
-    // any-order 0.354 - 0.357, on three streams of the default class 0.362 - 0.365, on streams of the high-priority class 0.638: their waves preempt the kernel stream's.)
-    static const bool inter_in_order = getenv("XEVD_HIP_INTER_IN_ORDER") != NULL;      // A/B measurements (read once)
+    // the inter pass (k_inter.hip): one launch over the batch's work lists (or, as a measurement option, one launch per class)
+    static const bool inter_in_order = getenv("XEVD_HIP_INTER_IN_ORDER") != NULL;      // A/B measurements (read once): the three class launches strictly one after the other
     TIMED(c, XGPU_K_INTER, launch_inter(c, a, !inter_in_order));
     if (!ahead) HIPCHK(c, hipEventRecord(c->after_inter, c->stream));   // where a residual pass prepared on the side stream (xgpu_batch_prepare) may start
     c->have_after_inter = 1;

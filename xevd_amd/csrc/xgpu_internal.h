@@ -88,6 +88,7 @@ struct TbWave {
     uint8_t  pad[2];
 };
 
+#define XGPU_WORK_REGION 0x100u
 #define XGPU_INTER_STRIP 16       // width, in 64x64 regions, of the vertical strips the inter work lists are ordered in (xgpu_batch_create, k_inter.hip)
 // One item of the two uniform work lists: where, which CU, and the CU's record (the kernels need no second fetch to start their window requests)
 struct __attribute__((aligned(16))) InterItem { uint32_t pos, cu, pad[2]; CuRec rec; };
@@ -107,6 +108,10 @@ struct InterArgs {
     const InterItem *tiles;            // k_inter_tile: 32x32 tiles inside one CU whose region is not (pos in tiles)
     const uint32_t  *splits;           // k_inter_split: every other tile that holds SCUs of the batch: tile column | row << 16
     int      n_regions, n_tiles, n_splits;
+    // ... and the one launch's order over them: one entry per 64x64 region that holds SCUs of the batch, in the same spatial order.  x = XGPU_WORK_REGION: the region
+    // is regions[y]; else x = two bits per tile of the region (0: no SCU of the batch, 1: the next entry of `tiles` from y on, 2: the next of `splits` from z on)
+    const uint4 *work;
+    int      n_work;
     const CuRec    *cus;
     const int16_t  *resid;
     ScuRec  *maps;
@@ -271,7 +276,8 @@ struct xgpu_dbatch {
     uint32_t  *d_owner;               // SCU -> CU index of the batch, over the whole picture
     InterItem *d_inter_regions, *d_inter_tiles;      // work lists of the three inter launches (InterArgs)
     uint32_t  *d_inter_splits;
-    int        n_inter_regions, n_inter_tiles, n_inter_splits;
+    uint4     *d_inter_work;
+    int        n_inter_regions, n_inter_tiles, n_inter_splits, n_inter_work;
     int16_t   *d_coef, *d_resid;
     TbRec     *d_tbs;
     TbWave    *d_waves;
@@ -326,6 +332,7 @@ struct xgpu_ctx {
     int             have_frame;
     TileMask        no_dbk;            // tile borders the deblocking of the current picture leaves alone (set by xgpu_batch_recon)
     hipEvent_t      fork_ev, join_ev;  // k_dmvr / k_affine on the side stream beside k_inter: where they may start, where the kernel stream takes them back
+    int             inter_launches, inter_all_first;      // measurement knobs of launch_inter (k_inter.hip), read from the environment by xgpu_open
     int             builder_threads;   // xgpu_set_builder_threads: host threads xgpu_batch_create spreads its per-CU passes over (default 1)
     int             pad_done;          // the padding of the current picture has been written (by k_alf's border tiles): xgpu_pad launches nothing
     int             where;             // 0: the picture being built lives in its DPB slot, 1: in the scratch picture
