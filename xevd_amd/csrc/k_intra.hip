@@ -597,6 +597,15 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
     intra_body<DEP, EIPD, IBC, HTDF, INTRA_WAVES>(a, blockIdx.x, s_nb, &s_chunk);
 }
 
+// The level-1 launch of pictures without EIPD / IBC / HTDF nodes, held to 64 VGPRs: eight waves per SIMD instead of six (the launch is a chain of memory round trips
+// per wave - 15.7 k independent CUs at cfg4 - and the CU's LDS holds four 8-wave workgroups either way)
+__global__ __launch_bounds__(64 * INTRA_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_intra_l1(const IntraArgs a)
+{
+    __shared__ __attribute__((aligned(16))) int16_t s_nb[INTRA_WAVES * IntraLds<false>::WAVE];
+    __shared__ uint32_t s_chunk;
+    intra_body<false, 0, false, false, INTRA_WAVES>(a, blockIdx.x, s_nb, &s_chunk);
+}
+
 // k_intra_itdq - the data-flow launch of this picture and the residual pass of the NEXT picture in one grid.  The data-flow kernel is a chain of
 // dependent memory round trips (4 K waves at 8K, the SIMDs idle most of its 45 us) and the residual pass depends on nothing but its batch, so its
 // work items fill the machine under the chain: workgroups [0, n_intra_wg) run intra_body (tickets order them, whatever the dispatcher does), the rest
@@ -661,7 +670,7 @@ void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf
         else                 { if (dep) LAUNCH(true, 0, true, false); else LAUNCH(false, 0, true, false); }
     } else {
         if (c->sp.tool_eipd) { if (dep) LAUNCH(true, 1, false, false); else LAUNCH(false, 1, false, false); }
-        else                 { if (dep) LAUNCH(true, 0, false, false); else LAUNCH(false, 0, false, false); }
+        else                 { if (dep) LAUNCH(true, 0, false, false); else if (getenv("XEVD_HIP_INTRA_L1_W6")) LAUNCH(false, 0, false, false); else hipLaunchKernelGGL(k_intra_l1, g, b, 0, c->stream, a); }
     }
 #undef LAUNCH
 #ifdef INTRA_PROFILE
