@@ -597,15 +597,6 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
     intra_body<DEP, EIPD, IBC, HTDF, INTRA_WAVES>(a, blockIdx.x, s_nb, &s_chunk);
 }
 
-// The level-1 launch of pictures without EIPD / IBC / HTDF nodes, held to 64 VGPRs: eight waves per SIMD instead of six (the launch is a chain of memory round trips
-// per wave - 15.7 k independent CUs at cfg4 - and the CU's LDS holds four 8-wave workgroups either way)
-__global__ __launch_bounds__(64 * INTRA_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_intra_l1(const IntraArgs a)
-{
-    __shared__ __attribute__((aligned(16))) int16_t s_nb[INTRA_WAVES * IntraLds<false>::WAVE];
-    __shared__ uint32_t s_chunk;
-    intra_body<false, 0, false, false, INTRA_WAVES>(a, blockIdx.x, s_nb, &s_chunk);
-}
-
 // k_intra_itdq - the data-flow launch of this picture and the residual pass of the NEXT picture in one grid.  The data-flow kernel is a chain of
 // dependent memory round trips (4 K waves at 8K, the SIMDs idle most of its 45 us) and the residual pass depends on nothing but its batch, so its
 // work items fill the machine under the chain: workgroups [0, n_intra_wg) run intra_body (tickets order them, whatever the dispatcher does), the rest
@@ -613,6 +604,8 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) __attribute__((amdgpu_waves_per_e
 // Measured at 8K (profiles/round3_*): 45 us + 39 us as two launches (43 + 55 when the residual pass ran beside the level-1 launch on a second stream,
 // with two cross-stream event waits of 6 us each), 64 us as one.  (Letting the level-1 launch carry a share of the work items too - it is 23 us of memory latency
 // as well - measured nothing at 25 % and 1 - 3 % slower at 35 - 70 %: that launch is short and dense enough to be slowed down by the company.)
+// (Round 5, measured and dropped: the level-1 launch held to 64 VGPRs - eight waves per SIMD instead of six, 92 bytes of scratch per lane: 41 us instead of 24 at cfg4, 31.6 instead of
+//  28.8 at 1080p.)
 // (Round 3, measured and dropped: ONE launch for all levels - the level-1 CUs at the head of this launch's list, publishing flags like everybody else, strand
 // members waiting for their level-1 CUs - instead of the plain level-1 launch in front: bit-exact, 8K 2764 -> 2587 frames/s, 4K 8172 -> 7860, 1080p 10996 -> 11163.)
 #define FUSED_WAVES 4
@@ -670,7 +663,7 @@ void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf
         else                 { if (dep) LAUNCH(true, 0, true, false); else LAUNCH(false, 0, true, false); }
     } else {
         if (c->sp.tool_eipd) { if (dep) LAUNCH(true, 1, false, false); else LAUNCH(false, 1, false, false); }
-        else                 { if (dep) LAUNCH(true, 0, false, false); else if (getenv("XEVD_HIP_INTRA_L1_W6")) LAUNCH(false, 0, false, false); else hipLaunchKernelGGL(k_intra_l1, g, b, 0, c->stream, a); }
+        else                 { if (dep) LAUNCH(true, 0, false, false); else LAUNCH(false, 0, false, false); }
     }
 #undef LAUNCH
 #ifdef INTRA_PROFILE
