@@ -539,6 +539,33 @@ def test_gpu_reference_parser_feeds_hip_backend(name, tmp_path):
     assert got.size == expect.size and np.array_equal(got, expect)
 
 
+REF_DECODE_HIP_BASE = os.path.normpath(os.path.join(golden_io.GOLDEN, "..", "..", "oracle", "_ref", "ref_decode_hip_base"))
+BASE_STREAM_NAMES = sorted(f[len("stream_"):-len(".npz")] for f in os.listdir(golden_io.GOLDEN)
+                           if f.startswith("stream_") and f.endswith(".npz") and "main_" not in f)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", BASE_STREAM_NAMES)
+def test_gpu_reference_baseline_parser_feeds_hip_backend(name, tmp_path):
+    """The same for the reference's BASELINE library (libxevdb: src_base/xevd.c; oracle/ref_binding_base.c compiles it with the backend in ctx->fn_dec_slice /
+    fn_deblock / fn_picbuf_expand): its own Baseline parser, motion derivation, DPB and xevd_pull, every picture reconstructed by libxevd_hip.so - the golden
+    Baseline streams, the reference's pictures sample for sample."""
+    import subprocess
+    if not os.path.exists(REF_DECODE_HIP_BASE):
+        pytest.skip("oracle/_ref/ref_decode_hip_base is built only where the reference sources are (development container)")
+    d = np.load(os.path.join(golden_io.GOLDEN, f"stream_{name}.npz"))
+    src, dst = tmp_path / "s.evc", tmp_path / "s.raw"
+    src.write_bytes(d["bytes"].tobytes())
+    h, w = d["p0_0"].shape
+    r = subprocess.run([REF_DECODE_HIP_BASE, str(src), str(dst), str(w), str(h), "1"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert r.returncode == 0, r.stdout.decode()[-400:]
+    n = int(d["n"])
+    assert int(r.stdout.split()[-2]) == n
+    got = np.fromfile(dst, "<i2")
+    expect = np.concatenate([d[f"p{k}_{c}"].ravel() for k in range(min(n, 64)) for c in range(3)]).astype(np.int16)
+    assert got.size == expect.size and np.array_equal(got, expect)
+
+
 @pytest.mark.gpu
 def test_gpu_reference_application_rejects_bad_signature(tmp_path):
     import subprocess
