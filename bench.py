@@ -346,13 +346,16 @@ def reference_decoder_leg(wl, budget_s=60.0):
                   ("gop_parallel_4x4", ["--workers", "4", "--tile-threads", str(max(1, min(4, quota // 4))), "--build-threads", "2"]))
         for name, args in shapes:
             dst = os.path.join(td, "ours.yuv")
-            rep = run_evc_decode(args + ["--keep-units", str(keep), p_all, dst])
+            rep = run_evc_decode(args + ["--keep-units", str(keep), "--hash-units", p_all, dst])
             if "error" in rep:
                 gpu[name] = rep
                 ok = False
                 continue
             gpu[name] = {"decode_only_fps": rep["fps_decode_only"], "parse_ms_per_picture": rep["parse_ms_per_picture"], "batch_build_ms_per_picture": rep["build_ms_per_picture"],
                          "host_threads": rep["workers_per_device"] * (rep["tile_threads"] + rep["build_threads"] + 1), "cpu_seconds_per_picture": round((rep["cpu_user_s"] + rep["cpu_sys_s"]) / max(rep["pictures"], 1), 4)}
+            # every IDR period of the run repeats the same GOP: all their hashes must equal the first period's, whose pictures are compared with the reference decoder's below
+            hashes = (rep.get("unit_hashes") or [[]])[0]
+            gpu[name]["all_periods_equal_the_first"] = len(hashes) == repeats and len(set(hashes)) == 1
             if bd > 8:          # 16-bit samples like the reference driver's output
                 gpu[name]["periods"] = file_md5s(dst, period_bytes, keep)
         for threads in (1, 8):
@@ -371,7 +374,7 @@ def reference_decoder_leg(wl, budget_s=60.0):
     bit_exact = None
     if bd > 8 and ok and 1 in ref_sum and len(ref_sum[1]) == 1:
         for g in gpu.values():
-            g["bit_exact"] = len(g.get("periods", [])) == keep and all(m == ref_sum[1][0] for m in g["periods"])
+            g["bit_exact"] = len(g.get("periods", [])) == keep and all(m == ref_sum[1][0] for m in g["periods"]) and bool(g.get("all_periods_equal_the_first"))
         bit_exact = all(g["bit_exact"] for g in gpu.values())
     for g in gpu.values():
         g.pop("periods", None)

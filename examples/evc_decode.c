@@ -17,7 +17,7 @@
  * Every worker is a pipeline of three stages: the parser thread (entropy decoding, picture k + 1 + N), N batch-builder threads (--builders; default 2 for one or two workers, 1 for more: xgpu_batch_create of
  * pictures k + 1 .. k + N side by side, picture j on thread j mod N) and the device thread (kernel launches and output of picture k); --no-pipeline: back to back on one thread, as xevd_dec_nalu does it.  A worker keeps its parser
  * (xhost_parser_rebind), its context, its pinned buffers and its threads from unit to unit.
- * usage: evc_decode [--gpus N] [--workers W] [--tile-threads T] [--build-threads B] [--builders N] [--keep-units K] [--no-pipeline] [--trace] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
+ * usage: evc_decode [--gpus N] [--workers W] [--tile-threads T] [--build-threads B] [--builders N] [--keep-units K] [--hash-units] [--no-pipeline] [--trace] [--bd D] in.evc out.yuv [in2.evc out2.yuv ...]      (--bd 0 / omitted: the coding bit depth; 8: one byte per sample)
  *        evc_decode in.evc out.yuv D                                               (the round-1 form)
  * build: oracle-free; see examples/Makefile.
  */
@@ -39,6 +39,8 @@
 #define MAX_GOPS 4096
 #define CHECK(call) do { int rc_ = (call); if (rc_ < 0) { fprintf(stderr, "%s -> %d (%s)\n", #call, rc_, w->g ? xgpu_last_error(w->g) : ""); return rc_; } } while (0)
 static double now_s(void);
+static int g_hash_units = 0;       /* --hash-units: a 64-bit hash of every unit's pictures (output order) in the --json line: units that are not kept (--keep-units) are checked all the same */
+static uint64_t g_unit_hash[64][256];
 static int g_keep_units = -1;      /* --keep-units K: only the first K units (closed GOPs) of every input are written to its output file; the rest is decoded all the same (long timing runs) */
 static int g_builders = 0;          /* --builders N: builder threads per worker (pictures built side by side); 0 = not given: 2 for one or two workers, 1 for more (the host's CPUs are the workers' to share) */
 static int g_depth = 3;             /* 2 + g_builders */
@@ -468,6 +470,16 @@ static int worker_job(void *state, const xwq_job *job)
     else if (g_keep_units < 0 || job->unit < g_keep_units)
         for (int i = 0; i < n && rc >= 0; i++)                       /* picture by picture, in output order, at the unit's place in the file */
             if (pwrite(s->fd, frames + outs[i].off, frame_bytes, (off_t)((size_t)(job->first_picture + i) * frame_bytes)) != (ssize_t)frame_bytes) { perror("pwrite"); rc = -1; }
+    if (rc >= 0 && g_hash_units && job->stream < 64 && job->unit < 256) {
+        /* word-wise multiply-xorshift over the unit's pictures in output order (not a cryptographic hash: equal units of a repeated GOP must agree, and the
+           first unit's pictures are compared with the reference decoder's by the caller) */
+        uint64_t h = 0x9E3779B97F4A7C15ull;
+        for (int i = 0; i < n; i++) {
+            const uint64_t *p = (const uint64_t *)(frames + outs[i].off);
+            for (size_t k = 0; k < frame_bytes / 8; k++) { h = (h ^ p[k]) * 0xD6E8FEB86659FD93ull; h ^= h >> 32; }
+        }
+        g_unit_hash[job->stream][job->unit] = h;
+    }
     (void)pinned;                                                   /* `frames` is the worker's buffer: reused by its next unit */
     free(outs);
     w->pictures += n;
@@ -506,6 +518,7 @@ int main(int argc, char **argv)
         else if (!strcmp(argv[a], "--build-threads") && a + 1 < argc) { g_build_threads = atoi(argv[a + 1]); a += 2; }
         else if (!strcmp(argv[a], "--builders") && a + 1 < argc) { g_builders = atoi(argv[a + 1]); if (g_builders < 1) g_builders = 1; if (g_builders > MAX_BUILDERS) g_builders = MAX_BUILDERS; g_depth = 2 + g_builders; a += 2; }
         else if (!strcmp(argv[a], "--keep-units") && a + 1 < argc) { g_keep_units = atoi(argv[a + 1]); a += 2; }
+        else if (!strcmp(argv[a], "--hash-units")) { g_hash_units = 1; a += 1; }
         else if (!strcmp(argv[a], "--json")) { g_json = 1; a++; }
         else break;
     }
@@ -578,7 +591,19 @@ int main(int argc, char **argv)
                busy > 0 ? (double)total_pictures / busy : 0.0, setup, total_pictures ? 1e3 * parse / (double)total_pictures : 0.0, total_pictures ? 1e3 * build / (double)total_pictures : 0.0,
                (double)ru.ru_utime.tv_sec + 1e-6 * (double)ru.ru_utime.tv_usec, (double)ru.ru_stime.tv_sec + 1e-6 * (double)ru.ru_stime.tv_usec);
         for (int d = 0; d < gpus / workers; d++) printf("%s%ld", d ? ", " : "", per_dev[d]);
-        printf("]}\n");
+        printf("]");
+        if (g_hash_units) {
+            printf(", \"unit_hashes\": [");
+            for (int st = 0; st < n_streams && st < 64; st++) {
+                int units = 0;
+                for (int u = 0; u < 256; u++) if (g_unit_hash[st][u]) units = u + 1;
+                printf("%s[", st ? ", " : "");
+                for (int u = 0; u < units; u++) printf("%s\"%016llx\"", u ? ", " : "", (unsigned long long)g_unit_hash[st][u]);
+                printf("]");
+            }
+            printf("]");
+        }
+        printf("}\n");
     }
     return 0;
 }

@@ -23,6 +23,12 @@
 //     are staged in LDS.
 #include "xgpu_internal.h"
 
+// The vertical pass resolves its chroma chains with the DPP control wave_shr:1, which exists on the 64-lane wave of GFX9 / CDNA only (gfx10+ has no wave_shr and runs
+// 32-lane waves): this file is written for gfx950 and refuses to build device code for anything else instead of filtering wrongly there.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#error "k_deblock.hip: the chroma chain exchange uses DPP wave_shr:1 (GFX9 / CDNA, wave64) - build with --offload-arch=gfx950"
+#endif
+
 struct __attribute__((packed, aligned(4))) U32x4a4 { uint32_t a, b, c, d; };   // 16-byte load at 4-byte alignment
 struct __attribute__((packed, aligned(4))) U32x2a4 { uint32_t a, b; };         // 8 bytes at 4-byte alignment
 struct __attribute__((packed, aligned(2))) U32x1a2 { uint32_t a; };            // 4 bytes at 2-byte alignment (gfx950: unaligned-access mode)
