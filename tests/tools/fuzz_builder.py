@@ -2,8 +2,9 @@
 hands the backend arrays it made itself, the validation pass is what stands between them and the kernels.
 usage: fuzz_builder.py <seed> [iterations] [picture golden ...]      env FZ_MAXMUT: most mutated elements per batch + 1 (default 4), FZ_LIB: the library to load
 Under AddressSanitizer (round 4: 1600 batches with up to 3 and 800 with up to 23 mutated elements, clean):
-  hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=address -fno-gpu-sanitize -Ixevd_amd/csrc -c xevd_amd/csrc/xgpu_api.hip -o /tmp/api_asan.o
-  hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address -shared-libsan -o /tmp/libxevd_hip_asan.so /tmp/api_asan.o xevd_amd/csrc/k_*.o
+  hipcc --offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=address -fno-gpu-sanitize -Ixevd_amd/csrc -c xevd_amd/csrc/xgpu_builder.hip -o /tmp/builder_asan.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -fsanitize=address -shared-libsan -o /tmp/libxevd_hip_asan.so /tmp/builder_asan.o xevd_amd/csrc/xgpu_api.o xevd_amd/csrc/xgpu_launch.o xevd_amd/csrc/xgpu_shims.o xevd_amd/csrc/k_*.o
+  (round 5, with the work lists of k_inter in the builder: 600 batches with up to 3 and 300 with up to 23 mutated elements, clean)
   FZ_LIB=/tmp/libxevd_hip_asan.so LD_PRELOAD=$(find /opt/rocm/lib/llvm -name 'libclang_rt.asan-x86_64.so') ASAN_OPTIONS=detect_leaks=0 python tests/tools/fuzz_builder.py 1"""
 import ctypes as C
 import os

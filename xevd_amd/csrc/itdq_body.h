@@ -8,7 +8,7 @@
 typedef short v2s __attribute__((ext_vector_type(2)));
 
 // transform matrices xevd_tbl_tm2..64 packed as row pairs: entry [k2][n] = (tm[2*k2][n], tm[2*k2+1][n]) as two s16;
-// filled by the host from the closed form (xgpu_api.hip:init_transform_tables).  Offsets: N*N/2 dwords per size.
+// filled by the host from the closed form (xgpu_api.hip: init_transform_tables).  Offsets: N*N/2 dwords per size.
 static __constant__ uint32_t k_tmp[2730];
 __host__ __device__ constexpr int tmp_base(int log2n) { return log2n == 1 ? 0 : log2n == 2 ? 2 : log2n == 3 ? 10 : log2n == 4 ? 42 : log2n == 5 ? 170 : 682; }
 
@@ -54,7 +54,7 @@ __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
     return __builtin_amdgcn_sdot2(__builtin_bit_cast(v2s, a), __builtin_bit_cast(v2s, b), c, false);
 }
 
-// geometry of a size class, shared with the host-side batch builder (xgpu_api.hip)
+// geometry of a size class, shared with the host-side batch builder (xgpu_builder.hip)
 __host__ __device__ constexpr int itdq_group(int lw, int lh)
 {
     const int W = 1 << lw, H = 1 << lh;

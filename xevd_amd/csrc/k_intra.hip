@@ -24,7 +24,7 @@
 // reductions, then every lane predicts whole 4x4 SCUs (+ their 2x2 chroma blocks) exactly like k_inter's lanes
 // reconstruct theirs, so residual addressing and stores are shared idioms (Baseline predictors; the EIPD instantiations work in
 // units of one luma row of four + one chroma pair, see intra_body).  A CU of several 64-unit steps sits in the list once per step
-// (parts, xgpu_api.hip).  Integer work bound by the latency of dependent instructions and memory round trips: no MFMA.
+// (parts, xgpu_builder.hip).  Integer work bound by the latency of dependent instructions and memory round trips: no MFMA.
 #include "xgpu_internal.h"
 #include "itdq_body.h"
 
@@ -144,7 +144,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
         // small CUs (an all-intra picture is one) pays that per link.  With units a CU up to 16x16 is one step of six samples per lane, and the loop body holds six
         // inlined predictors instead of 24.  The residual of a unit is contiguous (luma at 4 u, chroma at 2 v): up to four units per lane are requested at once.
         const int nunit = nscu << 2, uhalf = nscu << 1;
-        // parts: a large CU sits in the list several times (the host's plan, xgpu_api.hip: one entry per step of 64 units / SCUs, each with its own done flag); every part
+        // parts: a large CU sits in the list several times (the host's plan, xgpu_builder.hip: one entry per step of 64 units / SCUs, each with its own done flag); every part
         // stages the neighbours and derives the plan, and reconstructs the units [u_lo, u_hi) / the SCUs [s_lo, s_hi)
         const int part = (int)(m >> 24), nparts = max(1, (int)((ipm >> 16) & 0xFF));
         const int u_lo = part * (nunit / nparts), u_hi = u_lo + nunit / nparts, s_lo = part * (nscu / nparts), s_hi = s_lo + nscu / nparts;

@@ -351,7 +351,7 @@ struct xgpu_ctx {
 
 // The host threads of a batch builder: workers that stay alive between pictures (a std::thread per phase and picture cost ~0.1 ms each - more than a phase of
 // the builder takes).  One pool per CALLING thread (xgpu_batch_create may run on several builder threads of one context at once): static thread_local in
-// xgpu_api.hip.  run(n, f): f(0) on the caller, f(1) .. f(n - 1) on workers, returns when all are done.
+// xgpu_builder.hip.  run(n, f): f(0) on the caller, f(1) .. f(n - 1) on workers, returns when all are done.
 class WorkPool {
 public:
     ~WorkPool() { { std::lock_guard<std::mutex> g(mu); stop = true; } cv.notify_all(); for (std::thread &t : th) t.join(); }
