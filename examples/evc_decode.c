@@ -46,6 +46,7 @@ static int g_builders = 0;          /* --builders N: builder threads per worker 
 static int g_depth = 3;             /* 2 + g_builders */
 static int g_build_threads = 8;     /* --build-threads B: host threads xgpu_batch_create spreads its per-CU passes over */
 
+#define MAX_BUILDERS 4
 typedef struct { int poc, pic, in_use; } slot_t;                 /* DPB: POC -> device picture slot */
 typedef struct { int epoch, poc; size_t off; } out_t;              /* one output picture: position in the unit's buffer */
 typedef struct { const uint8_t *bytes; size_t size; int fd; int out_bd; } stream_t;
@@ -64,6 +65,15 @@ typedef struct {                                                    /* one worke
     int16_t *ref_luma[MAX_SLOTS + 2];                               /* host copies of decoded luma planes, by device picture (only for streams whose parser asks) */
     double parse_s, build_s;                                        /* inside xhost_parser_next (its own thread with the pipeline) / inside xgpu_batch_create */
     xhost_parser *ps;                                               /* the worker's parser, rebound to every unit (xhost_parser_rebind): its memory and tile threads stay */
+    /* the worker's builder threads live as long as the worker: xgpu_batch_create keeps its worker pool and its scratch (owner map, records, dependency plan: tens of
+       megabytes at 8K) per calling thread, and threads created per unit threw both away at every GOP */
+    pthread_t bth[MAX_BUILDERS];
+    int n_bth;
+    pthread_mutex_t b_mu;
+    pthread_cond_t b_cv;
+    void *b_unit;                                                   /* the pipe_t of the unit being decoded (NULL between units) */
+    long b_gen;                                                     /* a new unit: the builders leave their wait */
+    int b_left, b_quit;                                             /* builders still inside the unit; the worker goes away */
 } worker_t;
 
 static double now_s(void)
@@ -147,7 +157,6 @@ static int g_pipeline = 1;          /* --no-pipeline: parse and reconstruct ever
  * pipeline: while this worker turns picture k into a device batch and launches its kernels, the parser thread is already inside xhost_parser_next
  * for picture k + 1 (xhost_parser_set_depth(2): the arrays of two pictures stay valid).  Pictures with DMVR candidates break the overlap for one
  * step: the parser needs their refined vectors from the device before it goes on (xhost_parser_set_dmvr_mvs). */
-#define MAX_BUILDERS 4
 #define PIPE_DEPTH (2 + MAX_BUILDERS)  /* most pictures in flight between the parser, the builders and the device thread; in use: 2 + --builders (g_depth) */
 typedef struct {
     xhost_parser *ps;
@@ -196,13 +205,12 @@ static void *parser_thread(void *arg)
 
 /* The middle stage: picture k's device batch (xgpu_batch_create: records, transform-block lists, dependency plan, staging block, upload) is built here while the
    device thread launches picture k - 1 and the parser is inside picture k + 1.  xgpu_batch_create may run next to the thread that drives the context. */
-typedef struct { void *q; int id; } builder_arg_t;
-static void *builder_thread(void *arg)
+typedef struct { void *w; int id; } builder_arg_t;
+static void builder_unit(pipe_t *q, int id)
 {
-    pipe_t *q = (pipe_t *)((builder_arg_t *)arg)->q;
     /* --builders N: N of these threads, thread i on pictures i, i + N, ... - a picture's batch does not depend on the one before it, and at 8K the build
        (13 ms on 4 threads, largely its dependency plan) was the longest stage of the pipeline */
-    for (long k = ((builder_arg_t *)arg)->id;; k += q->n_builders) {
+    for (long k = id;; k += q->n_builders) {
         const int s = (int)(k % g_depth);
         pthread_mutex_lock(&q->mu);
         while (!q->stop && q->produced <= k) pthread_cond_wait(&q->cv, &q->mu);
@@ -227,6 +235,25 @@ static void *builder_thread(void *arg)
         pthread_mutex_unlock(&q->mu);
         if (prc != 1 || brc < 0) break;
     }
+}
+static void *builder_thread(void *arg)
+{
+    worker_t *w = (worker_t *)((builder_arg_t *)arg)->w;
+    const int id = ((builder_arg_t *)arg)->id;
+    long seen = 0;
+    free(arg);
+    for (;;) {
+        pthread_mutex_lock(&w->b_mu);
+        while (!w->b_quit && w->b_gen == seen) pthread_cond_wait(&w->b_cv, &w->b_mu);
+        if (w->b_quit) { pthread_mutex_unlock(&w->b_mu); break; }
+        seen = w->b_gen;
+        pipe_t *q = (pipe_t *)w->b_unit;
+        pthread_mutex_unlock(&w->b_mu);
+        if (q && id < q->n_builders) builder_unit(q, id);
+        pthread_mutex_lock(&w->b_mu);
+        if (--w->b_left == 0) pthread_cond_broadcast(&w->b_cv);
+        pthread_mutex_unlock(&w->b_mu);
+    }
     return NULL;
 }
 
@@ -239,8 +266,7 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
     size_t frame_bytes = 0;                                         /* download of picture k runs while picture k + 1 is parsed and launched     */
     xgpu_dbatch *db = NULL;
     int16_t *mv = NULL;
-    pthread_t th, bth[MAX_BUILDERS];
-    builder_arg_t barg[MAX_BUILDERS];
+    pthread_t th;
     int builder_on = 0;
     pipe_t q;
     memset(&q, 0, sizeof(q));
@@ -263,10 +289,17 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
         if (pthread_create(&th, NULL, parser_thread, &q) != 0) { rc = -1; goto done; }
         thread_on = 1;
         q.n_builders = g_builders;
-        for (; builder_on < g_builders; builder_on++) {
-            barg[builder_on].q = &q; barg[builder_on].id = builder_on;
-            if (pthread_create(&bth[builder_on], NULL, builder_thread, &barg[builder_on]) != 0) { rc = -1; goto done; }
+        for (; w->n_bth < g_builders; w->n_bth++) {                  /* (first unit of the worker) */
+            builder_arg_t *ba = (builder_arg_t *)malloc(sizeof(builder_arg_t));
+            if (!ba) { rc = -1; goto done; }
+            ba->w = w; ba->id = w->n_bth;
+            if (pthread_create(&w->bth[w->n_bth], NULL, builder_thread, ba) != 0) { free(ba); rc = -1; goto done; }
         }
+        pthread_mutex_lock(&w->b_mu);                                 /* the unit goes to the worker's builder threads */
+        w->b_unit = &q; w->b_left = w->n_bth; w->b_gen++;
+        pthread_cond_broadcast(&w->b_cv);
+        pthread_mutex_unlock(&w->b_mu);
+        builder_on = g_builders;
     }
 #define FAIL(code) do { rc = (code); goto done; } while (0)
 #define TRY(call) do { int rc_ = (call); if (rc_ < 0) { fprintf(stderr, "%s -> %d (%s)\n", #call, rc_, w->g ? xgpu_last_error(w->g) : ""); FAIL(rc_); } } while (0)
@@ -417,7 +450,12 @@ done:
         pthread_cond_broadcast(&q.cv);
         pthread_mutex_unlock(&q.mu);
         pthread_join(th, NULL);
-        for (int i = 0; i < builder_on; i++) pthread_join(bth[i], NULL);
+        if (builder_on) {                                           /* the builders have left the unit (its pipe_t lives on this stack frame) */
+            pthread_mutex_lock(&w->b_mu);
+            while (w->b_left) pthread_cond_wait(&w->b_cv, &w->b_mu);
+            w->b_unit = NULL;
+            pthread_mutex_unlock(&w->b_mu);
+        }
         for (int i = 0; i < PIPE_DEPTH; i++) if (q.db[i]) { xgpu_batch_destroy(w->g, q.db[i]); q.db[i] = NULL; }      /* built, never launched (an error further down the pipeline) */
     }
     pthread_mutex_destroy(&q.mu); pthread_cond_destroy(&q.cv);
@@ -441,6 +479,7 @@ static void *worker_init(int device, void *user)
     if (!w) return NULL;
     w->device = device; w->streams = (const stream_t *)user;
     pthread_mutex_init(&w->arena_mu, NULL);
+    pthread_mutex_init(&w->b_mu, NULL); pthread_cond_init(&w->b_cv, NULL);
     /* is the device there?  A worker without one leaves the queue to the others instead of failing their jobs */
     xgpu_seq_params sp;
     xgpu_ctx *probe = NULL;
@@ -494,6 +533,10 @@ static void worker_fini(void *state)
 {
     worker_t *w = (worker_t *)state;
     { const int k = __sync_fetch_and_add(&g_workers, 1); g_busy[k & 63] = w->busy_s - w->setup_s; g_setup[k & 63] = w->setup_s; g_parse[k & 63] = w->parse_s; g_build[k & 63] = w->build_s; g_pics[k & 63] = w->pictures; g_dev[k & 63] = w->device; }
+    if (w->n_bth) {                                                 /* the builder threads go first: they use the context */
+        pthread_mutex_lock(&w->b_mu); w->b_quit = 1; pthread_cond_broadcast(&w->b_cv); pthread_mutex_unlock(&w->b_mu);
+        for (int i = 0; i < w->n_bth; i++) pthread_join(w->bth[i], NULL);
+    }
     if (w->frames && !w->frames_pinned) free(w->frames);            /* (pinned memory goes with the context) */
     if (w->ps) xhost_parser_close(w->ps);                           /* before the context: it gives its arenas back */
     if (w->g) xgpu_close(w->g);
