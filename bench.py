@@ -169,7 +169,7 @@ def cpu_baseline(wl, first, batch, alf, budget_s=15.0):
                          if kind == "reference" else "plain-C oracle port")}
 
 
-def write_bench_stream(wl, gop_pictures, repeats, seed=77):
+def write_bench_stream(wl, gop_pictures, repeats, seed=77, refine_tools=False, device=0):
     """A real bitstream of the workload's shape, written by this repository's front end (xevd_amd/host): Main workloads -> random-access coding -
     hierarchical-B sub-GOPs of 8 (temporal layers 0..3), two reference lists with two pictures each, tool_admvp (merge / skip candidates, 8-tap
     interpolation), IQT, ADDB, ALF, a 4x4 tile grid; Baseline workloads -> IPPP with one reference.  ONE closed GOP (an IDR + gop_pictures - 1
@@ -181,7 +181,7 @@ def write_bench_stream(wl, gop_pictures, repeats, seed=77):
     rng = np.random.default_rng(seed)
     tids = [0, 1, 2, 2, 3, 3, 3, 3]
     wr = stream.StreamWriter(w, h, bd, 2 if main else 1, main=main, iqt=bool(wl["iqt"]), addb=bool(wl["addb"]), alf=bool(wl["alf"]), admvp=bool(wl["admvp"]),
-                             log2_sub_gop=3 if main else 0, tiles=(4, 4, 1) if main else None)
+                             log2_sub_gop=3 if main else 0, tiles=(4, 4, 1) if main else None, dmvr=refine_tools, hmvp=refine_tools, mmvd=refine_tools, amvr=refine_tools)
     try:
         if wl["alf"]:       # one parameter set for the whole stream: the repeated IDR periods must not see a later one
             wr.add_alf_aps(0, luma=rng.integers(-12, 13, (5, 12)), chroma=rng.integers(-10, 11, 6), type7=True, delta_idx=rng.integers(0, 5, 25))
@@ -200,6 +200,13 @@ def write_bench_stream(wl, gop_pictures, repeats, seed=77):
             if wl["alf"]:
                 wr.set_slice_alf(True, 0, 0, chroma_idc=3)
             wr.add_picture(b, stream.SLICE_I if idr else (stream.SLICE_B if is_b else stream.SLICE_P), slice_qp=30, idr=idr, temporal_id=tid)
+            if refine_tools and k + 1 < gop_pictures:
+                from xevd_amd import abi, player
+                last = None
+                for p, _ in player.StreamDecoder(wr.bytes(), device=device, parser_threads=8).pictures(download=False):
+                    last = p
+                if last is not None and last.get("_luma") is not None:      # (a picture that is kept as a reference)
+                    wr.set_ref_luma(last["poc"], last["_luma"][1], abi.PAD_L)
         data = wr.bytes()
     finally:
         wr.close()
@@ -213,7 +220,8 @@ def write_bench_stream(wl, gop_pictures, repeats, seed=77):
     prefix, gop = data[:pos], data[pos:]
     what = (f"{w}x{h} {bd}-bit, closed GOPs of {gop_pictures} pictures x {repeats}, " +
             ("Main profile, random access: hierarchical-B sub-GOPs of 8, two lists of two references, tool_admvp (merge / skip, 8-tap tables), IQT, ADDB, ALF, "
-             "4x4 tiles" if main else "Baseline profile, IPPP, one reference") + f"; {len(gop) * 8 / gop_pictures / 1e6:.2f} Mbit per picture; written by xevd_amd/host")
+             "4x4 tiles" + (", tool_dmvr + tool_hmvp + tool_mmvd + tool_amvr (the parser refines merge vectors itself on decoded reference luma)" if refine_tools else "")
+             if main else "Baseline profile, IPPP, one reference") + f"; {len(gop) * 8 / gop_pictures / 1e6:.2f} Mbit per picture; written by xevd_amd/host")
     return prefix + gop, prefix + gop * repeats, what
 
 
@@ -369,6 +377,31 @@ def reference_decoder_leg(wl, budget_s=60.0):
             fps[str(threads)] = round(int(pics) / float(secs), 2)
             if bd > 8:
                 ref_sum[threads] = file_md5s(dst, period_bytes)
+        # The same stream shape with tool_dmvr + tool_hmvp + tool_mmvd: the parser needs every reference picture's decoded luma before it parses the next picture (a blocking
+        # 66 MB download per 8K reference picture in the decode loop) and runs the refinement search itself - what that configuration costs against the plain stream
+        refine = None
+        if wl.get("admvp") and wl.get("addb") and not os.environ.get("XEVD_BENCH_NO_REFINE_LEG"):
+            try:
+                r_one, r_all, r_what = write_bench_stream(wl, gop_pictures, 4, refine_tools=True)
+                p_r1, p_ra = os.path.join(td, "r_one.evc"), os.path.join(td, "r_all.evc")
+                open(p_r1, "wb").write(r_one)
+                open(p_ra, "wb").write(r_all)
+                dst = os.path.join(td, "r_ours.yuv")
+                rep = run_evc_decode(shapes[0][1] + ["--keep-units", "1", "--hash-units", p_ra, dst])
+                if "error" in rep:
+                    refine = rep
+                else:
+                    hashes = (rep.get("unit_hashes") or [[]])[0]
+                    refine = {"decode_only_fps": rep["fps_decode_only"], "parse_ms_per_picture": rep["parse_ms_per_picture"], "batch_build_ms_per_picture": rep["build_ms_per_picture"],
+                              "all_periods_equal_the_first": len(hashes) == 4 and len(set(hashes)) == 1, "stream": r_what,
+                              "ratio_to_the_plain_stream": round(rep["fps_decode_only"] / max(gpu.get("one_stream_pipelined", {}).get("decode_only_fps", 0.0), 1e-9), 3)}
+                    if bd > 8:
+                        ours = file_md5s(dst, period_bytes, 1)
+                        dst_r = os.path.join(td, "r_ref.raw")
+                        rr = subprocess.run([exe, p_r1, dst_r, str(w), str(h), "1"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=600)
+                        refine["bit_exact"] = rr.returncode == 0 and file_md5s(dst_r, period_bytes) == ours and refine["all_periods_equal_the_first"]
+            except Exception as e:
+                refine = {"error": repr(e)[:300]}
     # the yardstick is the reference decoder with ONE thread; whether its own threaded run agrees with it is reported, not required (it does not on every
     # tiled stream: DESIGN 5b)
     bit_exact = None
@@ -379,6 +412,7 @@ def reference_decoder_leg(wl, budget_s=60.0):
     for g in gpu.values():
         g.pop("periods", None)
     return {"frames_per_s_by_threads": fps, "host_cores": os.cpu_count(), "host_cpu_quota": quota, "evc_decode_on_gpu": gpu, "bit_exact": bit_exact,
+            "evc_decode_dmvr_hmvp_mmvd": refine,
             "reference_threads_8_equals_1": (ref_sum[8] == ref_sum[1]) if (1 in ref_sum and 8 in ref_sum) else None, "stream": what,
             "pictures": {"evc_decode": gop_pictures * repeats, "reference_decoder": gop_pictures, "compared_idr_periods_per_run": keep},
             "what": "xevd_create / xevd_decode / xevd_pull of the reference library built in oracle/_ref (entropy decoding + reconstruction), threads = "
