@@ -62,6 +62,7 @@ typedef struct {                                                    /* one worke
     void *arena[4]; size_t arena_bytes[4]; int arena_busy[4];     /* pinned coefficient arenas handed to the parsers of this worker's units (kept across units) */
     pthread_mutex_t arena_mu;
     int arena_ok;
+    int ref_luma_pinned[MAX_SLOTS + 2];                             /* from xgpu_host_alloc: freed with the context */
     int16_t *ref_luma[MAX_SLOTS + 2];                               /* host copies of decoded luma planes, by device picture (only for streams whose parser asks) */
     double parse_s, build_s;                                        /* inside xhost_parser_next (its own thread with the pipeline) / inside xgpu_batch_create */
     xhost_parser *ps;                                               /* the worker's parser, rebound to every unit (xhost_parser_rebind): its memory and tile threads stay */
@@ -106,7 +107,7 @@ static int worker_context(worker_t *w, const xhost_picture *p)
     pthread_mutex_unlock(&w->arena_mu);
     if (w->frames && !w->frames_pinned) free(w->frames);
     w->frames = NULL; w->frames_cap = 0;
-    for (int i = 0; i < MAX_SLOTS + 2; i++) { free(w->ref_luma[i]); w->ref_luma[i] = NULL; }      /* sized for the old sequence */
+    for (int i = 0; i < MAX_SLOTS + 2; i++) { if (!w->ref_luma_pinned[i]) free(w->ref_luma[i]); w->ref_luma[i] = NULL; w->ref_luma_pinned[i] = 0; }      /* sized for the old sequence (pinned ones went with the context) */
     w->sp = sp;                                                     /* compared without the table pointers */
     w->n_slots = 0;
     sp.chroma_qp_table[0] = p->chroma_qp_table[0]; sp.chroma_qp_table[1] = p->chroma_qp_table[1];
@@ -194,9 +195,10 @@ static void *parser_thread(void *arg)
         q->rc[s] = rc;
         q->produced = k + 1;
         pthread_cond_broadcast(&q->cv);
-        /* DMVR feedback: picture k's refined vectors - or, when the parser refines itself (tool_dmvr with tool_hmvp / tool_mmvd), picture k's decoded
-           luma samples - reach the parser (from the consumer, while this thread waits here) before picture k + 1 is parsed */
-        if (rc == 1 && (q->pic[s].n_dmvr_sub > 0 || q->pic[s].needs_ref_luma)) while (!q->stop && q->released < k + 1) pthread_cond_wait(&q->cv, &q->mu);
+        /* DMVR feedback: picture k's refined vectors reach the parser (from the consumer, while this thread waits here) before picture k + 1 is parsed.
+           (When the parser refines itself - tool_dmvr with tool_hmvp / tool_mmvd, needs_ref_luma - it goes on: xhost_parser_next waits inside the first
+           CU that searches in a plane the consumer has not registered yet, xhost_parser_set_ref_luma_wait.) */
+        if (rc == 1 && q->pic[s].n_dmvr_sub > 0) while (!q->stop && q->released < k + 1) pthread_cond_wait(&q->cv, &q->mu);
         pthread_mutex_unlock(&q->mu);
         if (rc != 1) break;
     }
@@ -281,6 +283,7 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
             if (g_tile_threads > 1) xhost_parser_set_threads(w->ps, g_tile_threads);      /* the tiles of a picture on parallel host threads */
             xhost_parser_set_arena(w->ps, arena_alloc, arena_release, w);
             if (g_pipeline) xhost_parser_set_depth(w->ps, g_depth);
+            if (g_pipeline) xhost_parser_set_ref_luma_wait(w->ps, 1);    /* luma planes (needs_ref_luma) are registered by this thread while the parser thread runs ahead */
         }
     }
     q.ps = w->ps;
@@ -406,7 +409,12 @@ static int decode_unit(worker_t *w, const uint8_t *bytes, size_t size, int out_b
             /* tool_dmvr with tool_hmvp / tool_mmvd: the syntax of later pictures depends on refined vectors, so the parser runs the refinement search
                itself (xevd_amd/host/dmvr_search.h) on this picture's decoded luma: one padded plane per device picture, downloaded behind the kernels */
             const int stride = p.width + 2 * XGPU_PAD_L, slot = cur;                  /* device picture ids are 0 .. max_pics - 1 = MAX_SLOTS */
-            if (!w->ref_luma[slot]) w->ref_luma[slot] = (int16_t *)malloc(sizeof(int16_t) * (size_t)stride * (size_t)(p.height + 2 * XGPU_PAD_L));
+            if (!w->ref_luma[slot]) {                                /* pinned: the parser may be waiting for this plane, and a pageable download takes three times as long */
+                const size_t bytes = sizeof(int16_t) * (size_t)stride * (size_t)(p.height + 2 * XGPU_PAD_L);
+                void *m = NULL;
+                if (xgpu_host_alloc(w->g, bytes, &m) >= 0 && m) { w->ref_luma[slot] = (int16_t *)m; w->ref_luma_pinned[slot] = 1; }
+                else w->ref_luma[slot] = (int16_t *)malloc(bytes);
+            }
             if (!w->ref_luma[slot]) FAIL(-1);
             TRY(xgpu_pic_download_padded(w->g, cur, w->ref_luma[slot], NULL, NULL));
             TRY(xhost_parser_set_ref_luma(q.ps, p.poc, w->ref_luma[slot] + (size_t)XGPU_PAD_L * stride + XGPU_PAD_L, stride));
@@ -449,6 +457,7 @@ done:
         q.stop = 1;
         pthread_cond_broadcast(&q.cv);
         pthread_mutex_unlock(&q.mu);
+        if (rc < 0) xhost_parser_cancel_wait(q.ps);                 /* a parser waiting for a luma plane that will not come any more */
         pthread_join(th, NULL);
         if (builder_on) {                                           /* the builders have left the unit (its pipe_t lives on this stack frame) */
             pthread_mutex_lock(&w->b_mu);
@@ -540,7 +549,7 @@ static void worker_fini(void *state)
     if (w->frames && !w->frames_pinned) free(w->frames);            /* (pinned memory goes with the context) */
     if (w->ps) xhost_parser_close(w->ps);                           /* before the context: it gives its arenas back */
     if (w->g) xgpu_close(w->g);
-    for (int i = 0; i < MAX_SLOTS + 2; i++) free(w->ref_luma[i]);
+    for (int i = 0; i < MAX_SLOTS + 2; i++) if (!w->ref_luma_pinned[i]) free(w->ref_luma[i]);
     free(w);
 }
 

@@ -97,6 +97,13 @@ int  xhost_parser_set_dmvr_mvs(xhost_parser *p, const int16_t *mv, int n_sub);
    144 samples of replicated border on every side (what xgpu_pic_download_padded delivers); it must stay valid and unchanged while the picture is a
    reference.  Streams that need it and do not get it fail with an error that says so.  Why the front end reads samples at all: xevd_amd/host/dmvr_search.h. */
 int  xhost_parser_set_ref_luma(xhost_parser *p, int poc, const int16_t *plane, int stride);
+/* The same hand-over without parking the parser behind every reference picture: after xhost_parser_set_ref_luma_wait(p, 1) (before the first picture)
+   xhost_parser_set_ref_luma may be called from ANOTHER thread while xhost_parser_next runs on later pictures - in the order the pictures were handed out - and
+   a CU whose refinement search needs a plane that has not been registered yet waits for it inside xhost_parser_next.  The caller must therefore register the
+   plane of every picture handed out with needs_ref_luma, or call xhost_parser_cancel_wait (any thread): a waiting xhost_parser_next then fails with
+   XHOST_ERR_MALFORMED, as does every later one until xhost_parser_rebind. */
+int  xhost_parser_set_ref_luma_wait(xhost_parser *p, int on);
+void xhost_parser_cancel_wait(xhost_parser *p);
 /* The refinement search of decoder-side motion vector refinement on its own (xevd_amd/host/dmvr_search.h: what processDMVR decides, src_main/xevdm_mc.c:1647-1829), for a
    binding whose OWN parser derives candidates CU by CU from refined vectors (sps->tool_dmvr with tool_hmvp / tool_mmvd: oracle/ref_binding.c is the worked example).  The CU
    (x, y, w x h) with the unrefined quarter-sample vectors mv = { l0x, l0y, l1x, l1y } between two references at equal POC distances on either side; ref0 / ref1 = luma sample

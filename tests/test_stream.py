@@ -9,7 +9,7 @@ import pytest
 
 import golden_io
 import stream_util as su
-from xevd_amd import stream
+from xevd_amd import abi, stream
 
 CONFIGS = [
     # w, h, pictures, kwargs
@@ -329,6 +329,75 @@ def test_several_slices_per_picture_boundaries_and_refusals():
         su.make_stream(256, 256, 2, seed=11, main=True, tiles=(4, 4, 0), slices=[(0, 7), (8, 15)])      # no sps_pocs_flag
     with pytest.raises(RuntimeError):
         su.make_stream(256, 256, 2, seed=11, main=True, pocs=True, tiles=(4, 4, 0), slices=[(0, 7), (4, 15)])      # overlapping tile rectangles
+
+
+def test_ref_luma_registered_late_from_another_thread():
+    """xhost_parser_set_ref_luma_wait: the luma planes of a tool_dmvr + tool_hmvp / tool_mmvd stream are registered from a second thread, each one only after
+    the parser has been inside later pictures for a while (or, for a picture nothing refers to soon, pictures later) - every picture parses to what the
+    picture-by-picture hand-over gives; a cancelled wait fails the parser instead of hanging it"""
+    import queue
+    import threading
+    import time
+    w, h, n = 264, 200, 17
+    data = su.make_stream(w, h, n, seed=21, main=True, admvp=True, dmvr=True, hmvp=True, mmvd=True, amvr=True, iqt=True, addb=True, log2_sub_gop=3, max_refs=2, tiles=(2, 2, 0),
+                          inter_frac=0.95, skip_frac=0.3, direct_frac=0.3)
+    lumas, want = [], []
+    su.decode_oracle(data, order="decoding", keep_luma=lumas, keep_params=want)
+    assert len(want) == n and sum(int(p["needs_ref_luma"]) for p in want) >= 8
+    assert sum(int(((p["batch"]["dmvr"] > 0) & (p["batch"]["refi"].min(1) >= 0)).sum()) for p in want if p["batch"]["dmvr"] is not None) >= 10
+
+    def run(delay_s, lag, cancel_at=None, threads=1):
+        handed, got, err = queue.Queue(), [], []
+
+        def parse():
+            try:
+                for p in stream.iter_stream(data, threads=threads, luma_wait=True):
+                    got.append(p)
+                    handed.put(p)
+            except RuntimeError as e:
+                err.append(str(e))
+            handed.put(None)
+        t = threading.Thread(target=parse)
+        t.start()
+        pending, k = [], 0
+        while True:
+            p = handed.get()
+            if p is None:
+                break
+            pending.append((k, p))
+            k += 1
+            while len(pending) > lag:                    # `lag` pictures behind the parser, and late
+                j, q = pending.pop(0)
+                if cancel_at is not None and j == cancel_at:
+                    q["cancel_wait"]()
+                    pending = []
+                    break
+                time.sleep(delay_s)
+                if q["needs_ref_luma"]:
+                    assert lumas[j][0] == q["poc"]
+                    q["set_ref_luma"](q["poc"], lumas[j][1], abi.PAD_L)
+            if cancel_at is None and handed.empty() and pending and not t.is_alive():
+                break
+            # nothing handed out for a while: the parser waits for a plane - give it the oldest one
+            while cancel_at is None and pending and handed.empty() and t.is_alive():
+                time.sleep(0.002)
+                if handed.empty() and t.is_alive():
+                    j, q = pending.pop(0)
+                    if q["needs_ref_luma"]:
+                        q["set_ref_luma"](q["poc"], lumas[j][1], abi.PAD_L)
+        t.join(60)
+        assert not t.is_alive()
+        return got, err
+
+    for delay, lag, threads in ((0.004, 0, 1), (0.0, 2, 1), (0.002, 1, 4)):
+        got, err = run(delay, lag, threads=threads)
+        assert not err and len(got) == n
+        for p, q in zip(want, got):
+            assert p["poc"] == q["poc"]
+            for k, v in p["batch"].items():
+                assert np.array_equal(v, q["batch"][k]) if isinstance(v, np.ndarray) else (v == q["batch"][k] or k == "tiles"), (p["poc"], k)
+    got, err = run(0.0, 0, cancel_at=3)
+    assert len(err) == 1 and "reference picture" in err[0] and len(got) < n
 
 
 def test_parser_rebind_equals_a_new_parser():

@@ -752,6 +752,10 @@ struct TileCoder {
     // SCU maps after a CU (xevd_set_dec_info, xevd_util.c:1574-1660; cod_eco xevd.c:797-803)
     std::vector<int16_t> dmvr_scratch;
     bool missing_ref = false;                            // host-side DMVR needed the samples of a reference picture the caller has not registered
+    LumaBoard *board = nullptr;                          // xhost_parser_set_ref_luma_wait: where a plane that is not in the DPB entry yet is waited for
+    long posted_serial[2] = { 0, 0 };                    // the last two planes taken from the board (a CU has two references; serials start at 1)
+    const int16_t *posted_plane[2] = { nullptr, nullptr };
+    int posted_stride[2] = { 0, 0 }, posted_next = 0;
     void commit(const Cu &cu)
     {
         if (cu.tree == 2) return;                        // a chroma-only CU leaves every map as its luma CUs wrote it (xevdm_set_dec_info, xevdm_util.c:4241)
@@ -764,9 +768,21 @@ struct TileCoder {
             cu.refi[0] < (int)refp[0].size() && cu.refi[1] < (int)refp[1].size()) {
             const RefPic *r0 = refp[0][(size_t)cu.refi[0]], *r1 = refp[1][(size_t)cu.refi[1]];
             if (dmvr_search_applies(poc, r0->poc, r1->poc, 1 << cu.log2w, 1 << cu.log2h)) {
-                if (!r0->luma || !r1->luma) missing_ref = true;
+                const int16_t *plane[2] = { r0->luma, r1->luma };
+                int stride[2] = { r0->luma_stride, r1->luma_stride };
+                const RefPic *rr[2] = { r0, r1 };
+                for (int l = 0; l < 2; l++) if (!plane[l] && board) {      // decoded, but its plane may still be on its way from the device (LumaBoard)
+                    int k = 0;
+                    while (k < 2 && posted_serial[k] != rr[l]->serial) k++;
+                    if (k == 2) {
+                        k = posted_next; posted_next ^= 1;
+                        posted_serial[k] = board->wait(rr[l]->serial, &posted_plane[k], &posted_stride[k]) ? rr[l]->serial : 0;
+                    }
+                    if (posted_serial[k]) { plane[l] = posted_plane[k]; stride[l] = posted_stride[k]; }
+                }
+                if (!plane[0] || !plane[1]) missing_ref = true;
                 else {
-                    const DmvrRefPlane rp[2] = { { r0->luma, r0->luma_stride, r0->poc }, { r1->luma, r1->luma_stride, r1->poc } };
+                    const DmvrRefPlane rp[2] = { { plane[0], stride[0], r0->poc }, { plane[1], stride[1], r1->poc } };
                     dmvr_search_cu(pic.w_scu << 2, pic.h_scu << 2, sps.bd_l, cu.x, cu.y, 1 << cu.log2w, 1 << cu.log2h, cu.mv, rp, refined, dmvr_scratch);
                     is_refined = true;
                 }

@@ -2,6 +2,9 @@
 // DRA parameter sets, the SCU maps of the picture in work and of the reference pictures, the CU batch under construction, and `Stream`: POC derivation,
 // reference list construction and marking, the tile grid, ALF coefficient reconstruction, the DPB.
 #pragma once
+#include <condition_variable>
+#include <deque>
+#include <mutex>
 #include "evc_bits.h"
 #include "alf_fixed_tables.h"
 #include "dmvr_search.h"
@@ -180,6 +183,39 @@ struct RefPic {          // what a decoded picture leaves behind for later pictu
     int list_poc[16] = { 0 };        // pic->list_poc[]: POCs of ITS list-0 references (indexed by reference indices of EITHER list, xevdm_util.c:3760-3761)
     const int16_t *luma = nullptr;   // the decoded picture's luma samples on the host (sample (0, 0), >= 144 samples of replicated border), registered by the caller
     int luma_stride = 0;             //   when the front end refines vectors itself (xhost_parser_set_ref_luma; dmvr_search.h)
+    long serial = 0;                 // count of reference pictures stored so far in this stream (POCs repeat across IDR periods): names the picture on the LumaBoard
+};
+
+// xhost_parser_set_ref_luma_wait: luma planes registered from ANOTHER thread while the parser is already inside a later picture.  The planes of the pictures
+// handed out with needs_ref_luma are posted here; the parser thread moves the posted ones into the DPB at the start of every picture, and a CU whose
+// refinement search needs a plane that has not been posted yet waits for it (TileCoder::commit) instead of the whole parser parking behind every
+// reference picture.  Entries are added and removed on the parser thread only; the registering thread fills in plane / stride.
+struct LumaBoard {
+    struct Entry { long serial; int poc; const int16_t *plane; int stride; };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Entry> e;             // oldest first
+    bool cancelled = false;
+    void expect(long serial, int poc) { std::lock_guard<std::mutex> g(mu); e.push_back({ serial, poc, nullptr, 0 }); }
+    int post(int poc, const int16_t *plane, int stride)      // the oldest picture with this POC that still waits for its plane
+    {
+        std::lock_guard<std::mutex> g(mu);
+        for (Entry &x : e) if (x.poc == poc && !x.plane) { x.plane = plane; x.stride = stride; cv.notify_all(); return XGPU_OK; }
+        return XGPU_OK;              // not kept as a reference, or already gone from the DPB: nothing will read it
+    }
+    bool wait(long serial, const int16_t **plane, int *stride)
+    {
+        std::unique_lock<std::mutex> g(mu);
+        for (;;) {
+            const Entry *hit = nullptr;
+            for (const Entry &x : e) if (x.serial == serial) { hit = &x; break; }
+            if (!hit || cancelled) return false;
+            if (hit->plane) { *plane = hit->plane; *stride = hit->stride; return true; }
+            cv.wait(g);
+        }
+    }
+    void cancel() { std::lock_guard<std::mutex> g(mu); cancelled = true; cv.notify_all(); }
+    void reset() { std::lock_guard<std::mutex> g(mu); e.clear(); cancelled = false; }
 };
 
 struct Cu {
@@ -597,6 +633,7 @@ struct Stream {          // everything both directions share
         while (dpb.size() >= 32) { released.push_back(dpb[0].poc); drop_ref(0); }
         RefPic r;
         r.poc = poc; r.tid = tid; r.list0_poc = stale_list0_poc;
+        r.serial = ++pic_serial;
         // The picture's motion field MOVES into the DPB entry (at 8K it is 16.6 MB + 4 MB of reference indices: copying them, and extracting a list-0 copy, was a
         // serial 18 ms behind every reference picture); the maps of the next picture take the vectors of an entry that left the DPB (pool) - no allocation, no
         // page faults in the steady state.  ctx->map_mv: with host-side DMVR the refined vectors
@@ -611,6 +648,19 @@ struct Stream {          // everything both directions share
             memcpy(r.list_poc, stale_list_poc, sizeof(r.list_poc));
         }
         dpb.push_back(std::move(r));
+    }
+    long pic_serial = 0;
+    // the planes posted on the board so far go to their DPB entries (parser thread, between pictures); posted entries of pictures that left the DPB are dropped
+    void take_posted_luma(LumaBoard &b)
+    {
+        std::lock_guard<std::mutex> g(b.mu);
+        for (size_t i = 0; i < b.e.size();) {
+            RefPic *r = nullptr;
+            for (RefPic &d : dpb) if (d.serial == b.e[i].serial) { r = &d; break; }
+            if (!b.e[i].plane) { i++; continue; }        // (also when the picture has left the DPB: its entry waits for its post, so that the post cannot land on a later picture with the same POC)
+            if (r) { r->luma = b.e[i].plane; r->luma_stride = b.e[i].stride; }
+            b.e.erase(b.e.begin() + (long)i);
+        }
     }
     // a picture leaves the DPB: its motion vectors go back to the pool the picture maps draw from
     std::vector<std::vector<int16_t>> mv_pool;

@@ -169,6 +169,8 @@ struct xhost_parser {
     ~xhost_parser() { for (Held &h : held) if (h.arena && arena_release) arena_release(arena_user, h.arena); }
     std::vector<Held> held = std::vector<Held>(1);
     size_t n_handed = 0;
+    LumaBoard board;                                     // xhost_parser_set_ref_luma_wait
+    bool luma_wait = false;
     int16_t *merged_arena = nullptr;                     // the arena the coefficients of the picture being handed out were gathered in (else batch.coef)
     Batch *cur = &merged;                                // the batch of the picture handed out last (in its ring slot)
     size_t n_coef = 0;
@@ -540,6 +542,10 @@ struct xhost_parser {
         //      run - contexts, QP predictor and motion history start afresh - at the byte offset the slice header gave; tiles share nothing but
         //      the picture maps (disjoint regions), so they are parsed in parallel when the caller allows threads ----
         while ((int)tiles.size() < n_tiles) tiles.emplace_back(new TileParser(st));
+        if (luma_wait) {                                     // planes posted since the last slice go to their DPB entries; the others are waited for where a CU needs them
+            st.take_posted_luma(board);
+            for (auto &t : tiles) { t->tc.board = &board; t->tc.posted_serial[0] = t->tc.posted_serial[1] = 0; }
+        }
         std::vector<size_t> tile_pos((size_t)n_slice_tiles, br.pos);
         for (int t = 1; t < n_slice_tiles; t++) tile_pos[(size_t)t] = tile_pos[(size_t)t - 1] + tile_size[(size_t)t - 1] * 8;
         std::vector<int> tile_rc((size_t)n_slice_tiles, XGPU_OK);
@@ -670,6 +676,7 @@ struct xhost_parser {
         out->n_dmvr_sub = 0;
         last_poc = st.poc; last_stored = st.is_ref_picture();
         out->needs_ref_luma = st.sps.host_dmvr() && st.is_ref_picture();
+        if (out->needs_ref_luma && luma_wait) board.expect(st.pic_serial, st.poc);
         if (st.sps.tool_dmvr) b.dmvr = batch.dmvr.data();
         if (st.sps.tool_dmvr && !st.sps.host_dmvr()) {      // (host-side refinement: nothing comes back from the backend)
             for (int i = 0; i < b.n_cu; i++)
@@ -732,10 +739,24 @@ extern "C" int xhost_parser_rebind(xhost_parser *p, const uint8_t *bytes, size_t
     p->pos = 0; p->err.clear();
     p->pic_tiles_left = 0; p->last_poc = 0; p->last_n_dmvr = 0; p->last_stored = false;
     p->tile_done.clear(); p->pic_lists.clear();
+    p->board.reset();
     return XGPU_OK;
 }
 // the decoded luma samples of the picture with this POC, for the front end's own refinement search (Sps::host_dmvr)
-extern "C" int xhost_parser_set_ref_luma(xhost_parser *p, int poc, const int16_t *plane, int stride) { return p ? set_ref_luma(p->st, poc, plane, stride) : XGPU_ERR_INVALID_ARGUMENT; }
+extern "C" int xhost_parser_set_ref_luma(xhost_parser *p, int poc, const int16_t *plane, int stride)
+{
+    if (!p) return XGPU_ERR_INVALID_ARGUMENT;
+    if (!p->luma_wait) return set_ref_luma(p->st, poc, plane, stride);
+    if (!plane || stride <= 0) return XGPU_ERR_INVALID_ARGUMENT;
+    return p->board.post(poc, plane, stride);            // possibly from another thread, while xhost_parser_next runs
+}
+extern "C" int xhost_parser_set_ref_luma_wait(xhost_parser *p, int on)
+{
+    if (!p || p->n_handed) return XGPU_ERR_INVALID_ARGUMENT;      // before the first picture
+    p->luma_wait = on != 0;
+    return XGPU_OK;
+}
+extern "C" void xhost_parser_cancel_wait(xhost_parser *p) { if (p) p->board.cancel(); }
 extern "C" int xhost_dmvr_search(int pic_w, int pic_h, int bit_depth, int x, int y, int w, int h, const int16_t mv[4],
                                  const int16_t *ref0, int stride0, const int16_t *ref1, int stride1, int16_t *refined)
 {

@@ -79,6 +79,9 @@ def load():
         lib.xhost_parser_set_dmvr_mvs.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
         lib.xhost_parser_set_ref_luma.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
         lib.xhost_writer_set_ref_luma.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        lib.xhost_parser_set_ref_luma_wait.argtypes = [C.c_void_p, C.c_int]
+        lib.xhost_parser_cancel_wait.argtypes = [C.c_void_p]
+        lib.xhost_parser_cancel_wait.restype = None
         lib.xhost_parser_set_threads.argtypes = [C.c_void_p, C.c_int]
         lib.xhost_writer_split_allowed.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int)]
         lib.xhost_writer_open.restype = C.c_void_p
@@ -267,16 +270,20 @@ def _ref_luma(fn, h, keep):
     return give
 
 
-def iter_stream(data, consume_batch=None, threads=1):
+def iter_stream(data, consume_batch=None, threads=1, luma_wait=False):
     """generator over the pictures of a .evc byte string in decoding order: dict(params..., batch=dict of numpy arrays in the
     layout of synth.gen_frame).  The C parser runs inside each next() with the GIL released (ctypes).
     consume_batch(params, cu_batch_struct): zero-copy hand-over - called while the parser's arrays are valid (before the next picture
-    is parsed) with the xgpu_cu_batch the parser filled; its return value becomes params["batch"] (e.g. a device batch handle)."""
+    is parsed) with the xgpu_cu_batch the parser filled; its return value becomes params["batch"] (e.g. a device batch handle).
+    luma_wait: xhost_parser_set_ref_luma_wait - params["set_ref_luma"] may then be called from another thread while this generator is inside a later
+    picture (which waits where it needs the plane); params["cancel_wait"]() lets a waiting parser fail instead."""
     lib = load()
     buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
     h = lib.xhost_parser_open(buf, len(data))
     if threads > 1:      # the tiles of a picture on parallel host threads (xhost_parser_set_threads)
         lib.xhost_parser_set_threads(h, int(threads))
+    if luma_wait:
+        lib.xhost_parser_set_ref_luma_wait(h, 1)
     luma_keep = {}
     try:
         while True:
@@ -322,6 +329,7 @@ def iter_stream(data, consume_batch=None, threads=1):
                 # tool_dmvr with tool_hmvp / tool_mmvd: the parser refines vectors itself while it parses later pictures and needs this picture's decoded
                 # luma (padded) for it: set_ref_luma(poc, padded_plane, pad) before the generator is advanced
                 "needs_ref_luma": bool(hp.needs_ref_luma), "set_ref_luma": _ref_luma(lib.xhost_parser_set_ref_luma, h, luma_keep),
+                "cancel_wait": (lambda: lib.xhost_parser_cancel_wait(h)),
             }
             for gone in params["release"]:      # no longer in the parser's DPB: their registered luma planes can go
                 luma_keep.pop(gone, None)
