@@ -304,9 +304,9 @@ int xgpu_test_dbk_chroma(xgpu_ctx *ctx, int16_t *u, int16_t *v, int pw, int ph, 
 int xgpu_test_batch_resid(xgpu_ctx *ctx, xgpu_dbatch *db, int16_t *resid);
 /* The host batch builder alone - no device, no HIP call (runs on a machine without a GPU): builds the staging block of `b` for a sequence `sp` on `threads`
    builder threads and returns an FNV-1a digest per array of the block (CU records, CTU starts, TB records, itdq work items, intra records, dependency lists,
-   affine tiles, control points, DMVR sub-blocks, owner map, coefficients, and the work lists of the three inter launches: regions, tiles, split tiles, and the one launch's order over them), the counts of xgpu_batch_info and the builder's wall time in milliseconds.  The CPU
+   affine tiles, control points, DMVR sub-blocks, owner map, coefficients, and k_inter's two arrays: the items of the whole tiles and the roles per region), the counts of xgpu_batch_info and the builder's wall time in milliseconds.  The CPU
    suite pins the builder with it: the arrays do not depend on the thread count, and their digests are golden values. */
-#define XGPU_TEST_BUILD_DIGESTS 15
+#define XGPU_TEST_BUILD_DIGESTS 13
 int xgpu_test_build_batch(const xgpu_seq_params *sp, const xgpu_cu_batch *b, int threads, uint64_t digest[XGPU_TEST_BUILD_DIGESTS], int info[XGPU_BATCH_INFO_COUNT], double *ms);
 /* dequant + 2-D inverse transform of n blocks of one size, in place (xevd_itdq, src_base/xevd_itdq.c:494) */
 int xgpu_test_itdq(xgpu_ctx *ctx, int16_t *coef, int n_blocks, int log2w, int log2h, const uint8_t *qp, int bit_depth);

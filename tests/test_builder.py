@@ -25,12 +25,12 @@ def _lib():
 
 
 def _build(lib, sp, cb, threads):
-    dg, info, ms = (C.c_uint64 * 15)(), (C.c_int * 8)(), C.c_double()
+    dg, info, ms = (C.c_uint64 * 13)(), (C.c_int * 8)(), C.c_double()
     rc = lib.xgpu_test_build_batch(C.byref(sp), C.byref(cb), threads, dg, info, C.byref(ms))
     assert rc == 0, rc
     # (the coefficient array is the caller's, sent from where it lies: digest 10 is empty; 11..13: the work lists of the three inter launches)
     h = [f"{int(v):016x}" for v in dg]
-    return h[:10] + [int(v) for v in info] + h[11:15]
+    return h[:10] + [int(v) for v in info] + h[11:13]
 
 
 def picture_digests(lib, name, threads):
@@ -111,7 +111,7 @@ def test_builder_rejects_invalid_batches_without_a_device():
         b[field] = b[field].copy()
         b[field][len(b[field]) // 2] = value
         cb, keep = abi.make_cu_batch(b)
-        dg, info, ms = (C.c_uint64 * 15)(), (C.c_int * 8)(), C.c_double()
+        dg, info, ms = (C.c_uint64 * 13)(), (C.c_int * 8)(), C.c_double()
         assert lib.xgpu_test_build_batch(C.byref(sp), C.byref(cb), 2, dg, info, C.byref(ms)) == -101, field
 
 
@@ -147,7 +147,7 @@ def test_builder_arbitrary_cu_order_inside_ctus(name):
     cb, keep = abi.make_cu_batch(b)
     out = []
     for threads in (1, 4):
-        dg, info, ms = (C.c_uint64 * 15)(), (C.c_int * 8)(), C.c_double()
+        dg, info, ms = (C.c_uint64 * 13)(), (C.c_int * 8)(), C.c_double()
         rc = lib.xgpu_test_build_batch(C.byref(sp), C.byref(cb), threads, dg, info, C.byref(ms))
         out.append((rc, [int(v) for v in dg][:10] if rc == 0 else None))
     assert out[0] == out[1] and out[0][0] in (0, -101)

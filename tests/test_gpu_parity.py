@@ -123,13 +123,10 @@ def test_gpu_pictures_golden_residual_pass_ahead(name):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knob", ["XEVD_HIP_INTER_LAUNCHES=3", "XEVD_HIP_INTER_ALL_FIRST=1"])
-def test_gpu_inter_launch_options(knob, monkeypatch):
-    """The inter pass's measurement options (read per context by xgpu_open): the three class kernels as launches of their own instead of the one launch, and the one
-    launch with the split role's requests all in front - the same pictures (every golden picture with inter CUs, small pictures: all three classes occur in the
-    CTU-128 and B-picture cases)"""
-    name, value = knob.split("=")
-    monkeypatch.setenv(name, value)
+def test_gpu_inter_all_first_option(monkeypatch):
+    """The inter pass's measurement option (read per context by xgpu_open): the split role's requests all in front of its arithmetic - the same pictures (every
+    golden picture with inter CUs, small pictures: all three roles occur in the CTU-128 and B-picture cases)"""
+    monkeypatch.setenv("XEVD_HIP_INTER_ALL_FIRST", "1")
     for case_name in golden_io.PICTURE_CASES:
         case, exp = golden_io.load_picture_case(case_name)
         if not (case["batch"]["pred_mode"] != 0).any():

@@ -47,7 +47,7 @@ def main():
             cb, keep = abi.make_cu_batch(b)
         except Exception:      # noqa: BLE001 - the Python plumbing refused the arrays before the library saw them
             continue
-        dg, info, ms = (C.c_uint64 * 15)(), (C.c_int * 8)(), C.c_double()
+        dg, info, ms = (C.c_uint64 * 13)(), (C.c_int * 8)(), C.c_double()
         rc = lib.xgpu_test_build_batch(C.byref(sp), C.byref(cb), int(rng.integers(1, 4)), dg, info, C.byref(ms))
         if rc == 0:
             n_ok += 1

@@ -13,7 +13,7 @@ lib.xgpu_test_build_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER
 
 
 def build(sp, cb, threads):
-    dg, info, ms = (C.c_uint64 * 15)(), (C.c_int * 8)(), C.c_double()
+    dg, info, ms = (C.c_uint64 * 13)(), (C.c_int * 8)(), C.c_double()
     rc = lib.xgpu_test_build_batch(C.byref(sp), C.byref(cb), threads, dg, info, C.byref(ms))
     if rc:
         raise RuntimeError(f"xgpu_test_build_batch -> {rc}")

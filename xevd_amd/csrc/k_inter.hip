@@ -385,10 +385,30 @@ __device__ __forceinline__ void mc_scu_list(gs16 pl_, int s_l, gs16 pu_, gs16 pv
 // MODE 0: per lane; 1: the wave's tile inside one CU (UNI above); 2: the workgroup's whole 64x64 region inside one CU - the reference windows are fetched once per
 // workgroup into LDS the four waves share (W = that block, rm = the thread's chunks of it, wave = the tile's place in the region), everything else as in mode 1
 // ALL_FIRST (MODE 0): mc_scu_list (all requests of a list in front of its arithmetic, 145 VGPRs) or mc_luma_4x4 + mc_chroma_2x2 (requests in instalments, 123 VGPRs)
+#ifdef XGPU_INTER_TRACE
+// measurement build (make EXTRA=-DXGPU_INTER_TRACE): where the life of a wave goes, per role - shader cycles between marks, summed over the waves' lane 0
+__device__ unsigned long long g_inter_trace[3][16];
+struct InterTrace { unsigned long long prev; int role; bool on; };
+#define TRACE_MARK(tr, p) do { if ((tr).on) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_inter_trace[(tr).role][p], now_ - (tr).prev); (tr).prev = __builtin_amdgcn_s_memtime(); } } while (0)
+#define TRACE_ARG , InterTrace &tr
+#define TRACE_PASS , tr
+#define TRACE_OFF InterTrace tr = { 0, 0, false };
+extern "C" int xgpu_test_inter_trace(unsigned long long out[48], int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_inter_trace), sizeof(g_inter_trace)) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[48]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_inter_trace), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define TRACE_MARK(tr, p) do { } while (0)
+#define TRACE_ARG
+#define TRACE_PASS
+#define TRACE_OFF
+#endif
 template <int MODE, bool ALL_FIRST = true>
 __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r1, bool lane_ok, int sx, int sy, int lane, int16_t *W, const LaneMap fm,
                                            const uint4 (*s_ref)[2], const uint4 *s_ltap, const uint2 *s_ctap, uint32_t pl[8], uint32_t pu[2], uint32_t pv[2],
-                                           const RegionMap *rm = nullptr, int wave = 0, uint32_t own = 0)
+                                           const RegionMap *rm, int wave, uint32_t own TRACE_ARG)
 {
     constexpr bool UNI = MODE != 0;
     if (UNI) {
@@ -564,8 +584,10 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
         };
         constexpr int N_LUMA_REQ = REGION ? 3 : 4, N_CHROMA_REQ = REGION ? 2 : 3;
         const int l_first = use[0] ? 0 : 1, n_lists = (int)use[0] + (int)use[1];
+        TRACE_MARK(tr, 2);                                     // records decoded, map written
         load_resid();
         if (n_lists) { request_luma(l_first); __builtin_amdgcn_sched_barrier(0); request_chroma(l_first); }
+        TRACE_MARK(tr, 3);                                     // first requests issued
 #pragma unroll 1
         for (int i = 0; i < n_lists; i++) {
             const int l = i ? 1 : l_first;
@@ -577,6 +599,7 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
             uint32_t o[8], ou[2], ov[2];
             if (REGION) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }      // this list's windows have landed, all four waves' requests
             else { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N_CHROMA_REQ) : "memory"); wave_lds_sync(); }      // the luma window has (the chroma requests may still be out)
+            TRACE_MARK(tr, i ? 8 : 4);                         // waited for the list's luma window
             {
                 const uint4 th = s_ltap[ldx ? ((px & 3) << 2) : 16], tv = s_ltap[ldy ? ((py & 3) << 2) : 16];
                 const uint32_t ch[4] = { th.x, th.y, th.z, th.w }, cv[4] = { tv.x, tv.y, tv.z, tv.w };
@@ -586,6 +609,7 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
                 if (ldx) { if (ldy) luma_tile_filter<true, true, WS_L, true>(Wy, ch, cv, rg, maxl, I, lane, o, odd); else luma_tile_filter<true, false, WS_L, true>(Wy, ch, cv, rg, maxl, I, lane, o, odd); }
                 else     { if (ldy) luma_tile_filter<false, true, WS_L, true>(Wy, ch, cv, rg, maxl, I, lane, o, odd); else luma_tile_filter<false, false, WS_L, true>(Wy, ch, cv, rg, maxl, I, lane, o, odd); }
             }
+            TRACE_MARK(tr, 5);                                 // luma passes
             if (more) {                                             // the luma window block is free: the second list's goes there while the chroma passes run
                 if (REGION) __syncthreads(); else wave_lds_sync();
                 request_luma(1);
@@ -594,6 +618,7 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
                 if (more) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N_LUMA_REQ) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 wave_lds_sync();
             }
+            TRACE_MARK(tr, 6);                                 // barrier / chroma window wait
             {
                 const uint2 th = s_ctap[cdx ? ((px & 7) << 2) : 32], tv = s_ctap[cdy ? ((py & 7) << 2) : 32];
                 const uint32_t c2h[2] = { th.x, th.y }, c2v[2] = { tv.x, tv.y };
@@ -603,6 +628,7 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
                 if (cdx) { if (cdy) chroma_tile_filter<true, true, WS_C, true>(Wu, Wv, c2h, c2v, rg, maxc, IC, lane, ou, ov, odd); else chroma_tile_filter<true, false, WS_C, true>(Wu, Wv, c2h, c2v, rg, maxc, IC, lane, ou, ov, odd); }
                 else     { if (cdy) chroma_tile_filter<false, true, WS_C, true>(Wu, Wv, c2h, c2v, rg, maxc, IC, lane, ou, ov, odd); else chroma_tile_filter<false, false, WS_C, true>(Wu, Wv, c2h, c2v, rg, maxc, IC, lane, ou, ov, odd); }
             }
+            TRACE_MARK(tr, 7);                                 // chroma passes
             if (more) {
                 if (REGION) __syncthreads(); else wave_lds_sync();
                 request_chroma(1);
@@ -621,6 +647,7 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
         }
         (void)tid;
     } else {
+        TRACE_MARK(tr, 2);
         load_resid();
 #pragma unroll
         for (int l = 0; l < 2; l++) {
@@ -671,6 +698,7 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
             nl++;
         }
     }
+    TRACE_MARK(tr, 9);             // (split role: both lists' requests and arithmetic)
     if (nl == 0) return false;     // inter CU without a valid reference: nothing predicted (does not occur in valid streams)
 
     // ---- residual add + clip (xevd_recon.c:35-71; the LUMA bit depth clips all three components, :75-90) ----
@@ -685,20 +713,26 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Three launches per picture, one per CLASS of 32x32 tile, each with its own register budget (rounds 2 - 4: as three paths of one kernel every path paid the registers of
-// the others - 128 -> 143 -> 156 VGPRs, three waves per SIMD).  xgpu_batch_create sorts the picture into three work lists in ONE spatial order (vertical strips
-// XGPU_INTER_STRIP regions wide, row by row inside a strip):
-//   k_inter_region  64x64 regions inside one CU: one workgroup per region, the reference windows requested once per workgroup into LDS the four waves share;
-//   k_inter_tile    32x32 tiles inside one CU (whose region is not): one wave per tile, the window in the wave's own LDS;
-//   k_inter_split   every other tile: one wave per tile, one lane per SCU, every lane on the CU that covers its SCU (owner map) with windows of its own.
-// The classes are disjoint sets of whole 32x32 tiles, so the launches write disjoint 64-byte row segments and disjoint SCU-map records: the second and third are
-// launched without the barrier bit and overlap the tail of the one before (launch_inter).  The first two know their CU from the list item, which carries the CU's
-// record: the chain of a wave is list item -> reference windows; the reference table (kernel arguments) and the tap tables (constant memory) are read with
-// wave-uniform addresses - no owner-map link, no LDS tables, no barrier in front of the work.
-// XCD-aware mapping (all three): workgroup b runs on XCD b % 8 and every XCD has its own L2; XCD k takes the k-th contiguous eighth of the list - a compact patch of
+// k_inter - ONE launch per picture: a workgroup per 64x64 region of the picture, in vertical strips XGPU_INTER_STRIP regions wide, row by row inside a strip; its four
+// waves take one of three ROLES, which xgpu_batch_create has written into the region's entry of InterArgs.work:
+//   region role  the region lies inside ONE CU: the four waves together, the reference windows requested once per workgroup into LDS they share (inter_tile<2>);
+//   tile role    the wave's 32x32 tile lies inside one CU (whose region does not): the window in the wave's own LDS block (inter_tile<1>);
+//   split role   every other tile: one lane per SCU, every lane on the CU that covers its SCU (owner map), with windows of its own (inter_tile<0>).
+// Neighbouring tiles of different roles run at the same time on the same XCD and share the reference lines of their halos in its L2: as three launches, one per role
+// (round 5's first form, each with its own register budget: 110 / 101 / 123 VGPRs), every class swept the whole picture on its own and the pass read 505 MB from HBM
+// instead of 337 (profiles/round5_a_pmc.json), 156 us instead of 145.
+// What a wave must know before it can ask for reference samples is ONE round trip away: the region's position follows from the workgroup's number, and the entry of
+// `work`, the wave's item (region and tile role: position-indexed, with the CU's record in it) and the owner-map entries of its SCUs (split role) are all requested
+// at once, whatever the role turns out to be.  (With the role-specific lists of the first form - work entry, then list item or list entry, owner entry, CU record -
+// the chain in front of the first request was 2 - 4 dependent loads at ~2000 cycles each under load: 40 - 50 % of the life of a region- or tile-role wave, tools/r5_n.sh,
+// profiles/round5_exp_inter_wave_life.txt.)  The split role's tables (reference entries, filter taps: looked up per lane) are staged per WAVE: no workgroup barrier
+// outside the region role, a tile-role wave does not wait for its neighbours' table loads.
+// XCD-aware mapping: workgroup b runs on XCD b % 8 and every XCD has its own L2; XCD k takes the k-th contiguous eighth of the strip order - a compact patch of
 // the picture whose vertical halos are still in its L2 when the row below is processed.
 // Round 5 also built, measured bit-exact and dropped finer classes for the split tiles (16x16 blocks inside one CU sharing a 23x23 window by global_load_lds, as a path
-// of this kernel, as tasks sorted inside the workgroup, and as a fourth and fifth launch): DESIGN.md 3 has the numbers and what they say about the bound.
+// of this kernel, as tasks sorted inside the workgroup, and as a fourth and fifth launch), and several entries per workgroup with the next entry's chain loaded
+// during the current one (tools/patches/k_inter_items_loop_r5.diff: the loop keeps the scalar state of all three roles alive side by side - 165 - 170 VGPRs for
+// constants the scalar registers no longer hold, three waves per SIMD): DESIGN.md 3 has the numbers and what they say about the bound.
 // History of the single-kernel form (rounds 1-4: persistent waves, class-sorted pieces, occupancy sweeps, non-temporal hints, region order) is in DESIGN.md 3 too.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int xcd_slice(int block, int grid) { return (block & 7) * (grid >> 3) + (block >> 3); }
@@ -720,169 +754,103 @@ __device__ __forceinline__ void store_scu(const InterArgs &a, int sx, int sy, co
 #define ARG_LTAPS(a) ((const uint4 *)&k_luma_taps[(a).admvp][0][0])
 #define ARG_CTAPS(a) ((const uint2 *)&k_chroma_taps[(a).admvp][0][0])
 static_assert(sizeof(RefEntry) == 32, "a reference entry is two 16-byte halves");
+static_assert(XGPU_INTER_STRIP == 16, "the strip arithmetic below shifts by four");
 
-__global__ __launch_bounds__(256) void k_inter_region(const InterArgs a)
-{
-    __shared__ __attribute__((aligned(16))) int16_t s_win[REG_SAMPLES];      // the region's shared windows + the four waves' intermediates
-    const int idx = xcd_slice(blockIdx.x, gridDim.x);
-    if (idx >= a.n_regions) return;
-    const uint4 *const item = (const uint4 *)&a.regions[idx];
-    const uint4 e = item[0], c0 = item[1], c1 = item[2];
-    const int rx = e.x & 0xFFFF, ry = e.x >> 16;
-    const int t = threadIdx.x, lane = t & 63;
-    const int sx = (rx << 4) + ((t >> 6 & 1) << 3) + (lane & 7), sy = (ry << 4) + ((t >> 7) << 3) + (lane >> 3);
-    const RegionMap rmap = region_map(t);
-    const LaneMap fm = { 0, 0 };
-    uint32_t pl[8], pu[2], pv[2];
-    if (inter_tile<2>(a, c0, c1, true, sx, sy, lane, s_win, fm, ARG_REFS(a), ARG_LTAPS(a), ARG_CTAPS(a), pl, pu, pv, &rmap, t >> 6, e.y)) store_scu(a, sx, sy, pl, pu, pv);
-}
+struct SplitTables { uint4 ref[XGPU_MAX_REFS * 2][2]; uint4 ltap[17]; uint2 ctap[33]; uint2 pad; };      // RefEntry [idx][list]; luma taps of this sequence's table, [16] = identity; chroma taps
 
-__global__ __launch_bounds__(256) void k_inter_tile(const InterArgs a)
-{
-    __shared__ __attribute__((aligned(16))) int16_t s_win[4 * UNI_SAMPLES];  // per wave: window + intermediate
-    const int t = threadIdx.x, lane = t & 63;
-    const int idx = xcd_slice(blockIdx.x, gridDim.x) * 4 + (t >> 6);
-    if (idx >= a.n_tiles) return;                                            // (no barrier in this kernel)
-    const uint4 *const item = (const uint4 *)&a.tiles[idx];
-    const uint4 e = item[0], c0 = item[1], c1 = item[2];
-    const int sx = ((e.x & 0xFFFF) << 3) + (lane & 7), sy = ((e.x >> 16) << 3) + (lane >> 3);
-    LaneMap fm;
-    {
-        const int row0 = (lane * 171) >> 10, k = lane - row0 * 6;            // luma window: 10 rows x 6 aligned chunks of 8 samples per request (lanes 60..63 idle)
-        fm.gy = row0 * a.s_l + 8 * k; fm.ly = row0 * UW_STRIDE + 8 * k;
-    }
-    uint32_t pl[8], pu[2], pv[2];
-    if (inter_tile<1>(a, c0, c1, true, sx, sy, lane, s_win + (t >> 6) * UNI_SAMPLES, fm, ARG_REFS(a), ARG_LTAPS(a), ARG_CTAPS(a), pl, pu, pv, nullptr, 0, e.y)) store_scu(a, sx, sy, pl, pu, pv);
-}
-
-// one wave per split tile, one lane per SCU, every lane on the CU that covers its SCU: owner entry -> CU record -> windows of its own (inter_tile<0>); the reference
-// table and the tap tables in LDS, for lanes that look them up with indices of their own
-__global__ __launch_bounds__(256) void k_inter_split(const InterArgs a)
-{
-    __shared__ uint4    s_ref[XGPU_MAX_REFS * 2][2];        // RefEntry [idx][list]
-    __shared__ uint4    s_ltap[17];                         // luma taps of this sequence's table, [16] = identity
-    __shared__ uint2    s_ctap[33];
-    const int t = threadIdx.x, lane = t & 63;
-    const int idx = xcd_slice(blockIdx.x, gridDim.x) * 4 + (t >> 6);
-    const bool have = idx < a.n_splits;
-    const uint32_t e = have ? a.splits[idx] : 0u;
-    const int sx = ((e & 0xFFFF) << 3) + (lane & 7), sy = ((e >> 16) << 3) + (lane >> 3);
-    const bool active = have && sx < (a.pic_w >> 2) && sy < (a.pic_h >> 2);
-    // the first link of the chain goes out before the tables are staged
-    const uint32_t own = active ? a.owner[sy * a.w_scu + sx] : OWNER_NONE;
-    // ... and so do the table loads, ONE per lane, all before the first wait
-    static_assert(XGPU_MAX_REFS * 4 <= 96, "one 16-byte half of a reference entry per lane, in front of the tap tables' lanes");
-    uint4 tab = make_uint4(0, 0, 0, 0);
-    if (t < XGPU_MAX_REFS * 4) tab = ((const uint4 *)&a.refp[0][0])[t];
-    else if (t >= 96 && t < 96 + 17) tab = *(const uint4 *)k_luma_taps[a.admvp][t - 96];
-    else if (t >= 128 && t < 128 + 33) { const uint2 v = *(const uint2 *)k_chroma_taps[a.admvp][t - 128]; tab.x = v.x; tab.y = v.y; }
-    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
-    const bool ok = own < (uint32_t)a.n_cu;                    // unowned (another batch's SCU) or not an index of this batch
-    if (ok) { c0 = ((const uint4 *)&a.cus[own])[0]; c1 = ((const uint4 *)&a.cus[own])[1]; }
-    if (t < XGPU_MAX_REFS * 4) s_ref[t >> 1][t & 1] = tab;
-    else if (t >= 96 && t < 96 + 17) s_ltap[t - 96] = tab;
-    else if (t >= 128 && t < 128 + 33) s_ctap[t - 128] = make_uint2(tab.x, tab.y);
-    __syncthreads();
-    const LaneMap fm = { 0, 0 };
-    uint32_t pl[8], pu[2], pv[2];
-    if (inter_tile<0>(a, c0, c1, ok, sx, sy, lane, nullptr, fm, s_ref, s_ltap, s_ctap, pl, pu, pv, nullptr, 0, own)) store_scu(a, sx, sy, pl, pu, pv);
-}
-
-// k_inter - ONE launch over the three lists (the default): a workgroup per 64x64 region in the lists' spatial order - the region's four waves take the
-// region role together, or every wave the role of its tile (inside one CU / split).  Same role code as the three kernels above; what changes is WHEN a piece of the
-// picture is worked on: neighbouring tiles of different classes run at the same time on the same XCD and share the reference lines of their halos in its L2 - as three
-// launches every class swept the whole picture on its own and the pass read 505 MB from HBM instead of 337 (profiles/round5_a_pmc.json).
 template <bool ALL_FIRST>
 __device__ __forceinline__ void inter_fused_body(const InterArgs &a)
 {
     __shared__ __attribute__((aligned(16))) int16_t s_win[REG_SAMPLES];      // region role: the shared windows + intermediates; tile role: four wave blocks
     static_assert(4 * UNI_SAMPLES <= REG_SAMPLES, "the four waves' tile blocks fit into the region block");
-    __shared__ uint4    s_ref[XGPU_MAX_REFS * 2][2];
-    __shared__ uint4    s_ltap[17];
-    __shared__ uint2    s_ctap[33];
+    __shared__ SplitTables s_tab[4];                                         // split role: per wave
     const int idx = xcd_slice(blockIdx.x, gridDim.x);
     if (idx >= a.n_work) return;
-    const uint4 w = a.work[idx];
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+#ifdef XGPU_INTER_TRACE
+    InterTrace tr = { __builtin_amdgcn_s_memtime(), 0, lane == 0 && (idx % 61) == 7 };      // a sample of the workgroups: the atomics of all of them on 33 addresses stretched the kernel sixfold
+#endif
+    // the region's place in the strip order (xgpu_batch_create's): full strips of 16 x regions_y entries, then the narrower last strip
+    int rx, ry;
+    if (idx < a.full_entries) {
+        const int s = (int)__umulhi((uint32_t)idx, a.magic_strip), r = idx - s * a.strip_entries;
+        ry = r >> 4; rx = (s << 4) + (r & 15);
+    } else {
+        const int r = idx - a.full_entries;
+        ry = (int)__umulhi((uint32_t)r, a.magic_last); rx = (a.regions_x & ~15) + r - ry * (a.regions_x & 15);
+    }
+    const int sx = (rx << 4) + ((wave & 1) << 3) + (lane & 7), sy = (ry << 4) + ((wave >> 1) << 3) + (lane >> 3);
+    // everything a role needs first, requested at once
+    const uint32_t kinds = a.work[idx];
+    const uint4 *const item = (const uint4 *)&a.items[idx * 4 + wave];
+    const uint4 e = item[0], i0 = item[1], i1 = item[2];
+    const uint32_t own = (sx < (a.pic_w >> 2) && sy < (a.pic_h >> 2)) ? a.owner[sy * a.w_scu + sx] : OWNER_NONE;
     const LaneMap fm0 = { 0, 0 };
     uint32_t pl[8], pu[2], pv[2];
-    if (w.x == XGPU_WORK_REGION) {
-        const uint4 *const item = (const uint4 *)&a.regions[w.y];
-        const uint4 e = item[0], c0 = item[1], c1 = item[2];
-        const int rx = e.x & 0xFFFF, ry = e.x >> 16;
-        const int sx = (rx << 4) + ((wave & 1) << 3) + (lane & 7), sy = (ry << 4) + ((wave >> 1) << 3) + (lane >> 3);
+    if (kinds == XGPU_WORK_REGION) {
+#ifdef XGPU_INTER_TRACE
+        tr.role = 0;
+        if (e.y == 0xFFFFFFFFu) tr.on = false;                 // (uses the item: the mark stands behind its arrival)
+        if (tr.on) atomicAdd(&g_inter_trace[0][15], 1ull);
+        TRACE_MARK(tr, 0);
+#endif
         const RegionMap rmap = region_map(t);
-        if (inter_tile<2>(a, c0, c1, true, sx, sy, lane, s_win, fm0, ARG_REFS(a), ARG_LTAPS(a), ARG_CTAPS(a), pl, pu, pv, &rmap, wave, e.y)) store_scu(a, sx, sy, pl, pu, pv);
+        if (inter_tile<2>(a, i0, i1, true, sx, sy, lane, s_win, fm0, ARG_REFS(a), ARG_LTAPS(a), ARG_CTAPS(a), pl, pu, pv, &rmap, wave, e.y TRACE_PASS)) store_scu(a, sx, sy, pl, pu, pv);
+        TRACE_MARK(tr, 10);
         return;
     }
-    const uint32_t kinds = w.x;
-    const bool any_split = (kinds & 0xAAu) != 0;                       // workgroup-uniform: the tables and the barrier only where a wave looks them up per lane
-    const uint32_t kind = (kinds >> (2 * wave)) & 3u, below = kinds & ((1u << (2 * wave)) - 1u);
-    const int n_tile_below = __popc(below & 0x55u), n_split_below = __popc(below & 0xAAu);
-    uint4 tab = make_uint4(0, 0, 0, 0);
-    uint32_t own = OWNER_NONE;
-    int sx = 0, sy = 0;
-    bool ok = false;
-    uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
-    if (kind == 2) {
-        const uint32_t e = a.splits[w.z + n_split_below];
-        sx = ((e & 0xFFFF) << 3) + (lane & 7); sy = ((e >> 16) << 3) + (lane >> 3);
-        if (sx < (a.pic_w >> 2) && sy < (a.pic_h >> 2)) own = a.owner[sy * a.w_scu + sx];
-    }
-    if (any_split) {
-        static_assert(XGPU_MAX_REFS * 4 <= 96, "one 16-byte half of a reference entry per lane, in front of the tap tables' lanes");
-        if (t < XGPU_MAX_REFS * 4) tab = ((const uint4 *)&a.refp[0][0])[t];
-        else if (t >= 96 && t < 96 + 17) tab = *(const uint4 *)k_luma_taps[a.admvp][t - 96];
-        else if (t >= 128 && t < 128 + 33) { const uint2 v = *(const uint2 *)k_chroma_taps[a.admvp][t - 128]; tab.x = v.x; tab.y = v.y; }
-    }
-    if (kind == 2) {
-        ok = own < (uint32_t)a.n_cu;
-        if (ok) { c0 = ((const uint4 *)&a.cus[own])[0]; c1 = ((const uint4 *)&a.cus[own])[1]; }
-    }
-    if (any_split) {
-        if (t < XGPU_MAX_REFS * 4) s_ref[t >> 1][t & 1] = tab;
-        else if (t >= 96 && t < 96 + 17) s_ltap[t - 96] = tab;
-        else if (t >= 128 && t < 128 + 33) s_ctap[t - 128] = make_uint2(tab.x, tab.y);
-        __syncthreads();
-    }
+    const uint32_t kind = (kinds >> (2 * wave)) & 3u;
     if (kind == 1) {
-        const uint4 *const item = (const uint4 *)&a.tiles[w.y + n_tile_below];
-        const uint4 e = item[0];
-        c0 = item[1]; c1 = item[2];
-        sx = ((e.x & 0xFFFF) << 3) + (lane & 7); sy = ((e.x >> 16) << 3) + (lane >> 3);
+#ifdef XGPU_INTER_TRACE
+        tr.role = 1;
+        if (e.y == 0xFFFFFFFFu) tr.on = false;
+        if (tr.on) atomicAdd(&g_inter_trace[1][15], 1ull);
+        TRACE_MARK(tr, 0);
+#endif
         LaneMap fm;
         {
-            const int row0 = (lane * 171) >> 10, k = lane - row0 * 6;
+            const int row0 = (lane * 171) >> 10, k = lane - row0 * 6;            // luma window: 10 rows x 6 aligned chunks of 8 samples per request (lanes 60..63 idle)
             fm.gy = row0 * a.s_l + 8 * k; fm.ly = row0 * UW_STRIDE + 8 * k;
         }
-        if (inter_tile<1>(a, c0, c1, true, sx, sy, lane, s_win + wave * UNI_SAMPLES, fm, ARG_REFS(a), ARG_LTAPS(a), ARG_CTAPS(a), pl, pu, pv, nullptr, 0, e.y)) store_scu(a, sx, sy, pl, pu, pv);
+        if (inter_tile<1>(a, i0, i1, true, sx, sy, lane, s_win + wave * UNI_SAMPLES, fm, ARG_REFS(a), ARG_LTAPS(a), ARG_CTAPS(a), pl, pu, pv, nullptr, 0, e.y TRACE_PASS)) store_scu(a, sx, sy, pl, pu, pv);
+        TRACE_MARK(tr, 10);
     } else if (kind == 2) {
-        if (inter_tile<0, ALL_FIRST>(a, c0, c1, ok, sx, sy, lane, nullptr, fm0, s_ref, s_ltap, s_ctap, pl, pu, pv, nullptr, 0, own)) store_scu(a, sx, sy, pl, pu, pv);
+#ifdef XGPU_INTER_TRACE
+        tr.role = 2;
+        if (tr.on) atomicAdd(&g_inter_trace[2][15], 1ull);
+        TRACE_MARK(tr, 0);
+#endif
+        // second (and last) link of the chain: the CU records of the lanes' owners, and beside them the wave's copy of the tables: 68 + 17 + 33 entries, two per lane
+        SplitTables &tb = s_tab[wave];
+        static_assert(XGPU_MAX_REFS * 4 == 68, "lanes 0..63 and 0..3 of the second round take the reference entries' halves");
+        const uint4 tab0 = ((const uint4 *)&a.refp[0][0])[lane];
+        uint4 tab1 = make_uint4(0, 0, 0, 0);
+        if (lane < 4) tab1 = ((const uint4 *)&a.refp[0][0])[64 + lane];
+        else if (lane < 4 + 17) tab1 = *(const uint4 *)k_luma_taps[a.admvp][lane - 4];
+        else if (lane < 4 + 17 + 33) { const uint2 v = *(const uint2 *)k_chroma_taps[a.admvp][lane - 21]; tab1.x = v.x; tab1.y = v.y; }
+        const bool ok = own < (uint32_t)a.n_cu;                    // unowned (another batch's SCU) or not an index of this batch
+        uint4 c0 = make_uint4(0, 0, 0, 0), c1 = c0;
+        if (ok) { c0 = ((const uint4 *)&a.cus[own])[0]; c1 = ((const uint4 *)&a.cus[own])[1]; }
+        tb.ref[lane >> 1][lane & 1] = tab0;
+        if (lane < 4) tb.ref[32 + (lane >> 1)][lane & 1] = tab1;
+        else if (lane < 4 + 17) tb.ltap[lane - 4] = tab1;
+        else if (lane < 4 + 17 + 33) tb.ctap[lane - 21] = make_uint2(tab1.x, tab1.y);
+        wave_lds_sync();
+        TRACE_MARK(tr, 1);
+        if (inter_tile<0, ALL_FIRST>(a, c0, c1, ok, sx, sy, lane, nullptr, fm0, tb.ref, tb.ltap, tb.ctap, pl, pu, pv, nullptr, 0, own TRACE_PASS)) store_scu(a, sx, sy, pl, pu, pv);
+        TRACE_MARK(tr, 10);
     }
 }
 __global__ __launch_bounds__(256) void k_inter(const InterArgs a) { inter_fused_body<false>(a); }
 __global__ __launch_bounds__(256) void k_inter_af(const InterArgs a) { inter_fused_body<true>(a); }
 
-// c->inter_launches (XEVD_HIP_INTER_LAUNCHES, read by xgpu_open): 1 (default) = k_inter, the one launch; 3 = the three class kernels one after the other (per-class
-// durations under rocprofv3; A/B measurements), the second and third without the barrier bit when any_order.  c->inter_all_first (XEVD_HIP_INTER_ALL_FIRST): the one
-// launch with the split role's requests all in front (148 VGPRs instead of 127).
-void launch_inter(xgpu_ctx *c, const InterArgs &a, bool any_order)
+// c->inter_all_first (XEVD_HIP_INTER_ALL_FIRST, read by xgpu_open; A/B measurements): the split role's requests all in front of its arithmetic (148 VGPRs instead of 127)
+void launch_inter(xgpu_ctx *c, const InterArgs &a)
 {
-    auto grid = [](int n, int per) { return dim3((unsigned)((((n + per - 1) / per + 7) >> 3) << 3)); };
-    if (c->inter_launches != 3) {
-        if (a.n_work) { if (c->inter_all_first) hipLaunchKernelGGL(k_inter_af, grid(a.n_work, 1), dim3(256), 0, c->stream, a); else hipLaunchKernelGGL(k_inter, grid(a.n_work, 1), dim3(256), 0, c->stream, a); }
-        return;
-    }
-    // the split tiles first: their per-lane chains run longest
-    bool first = true;
-    auto go = [&](auto kernel, dim3 g) {
-        if (any_order && !first) hipExtLaunchKernelGGL(kernel, g, dim3(256), 0, c->stream, nullptr, nullptr, hipExtAnyOrderLaunch, a);
-        else hipLaunchKernelGGL(kernel, g, dim3(256), 0, c->stream, a);
-        first = false;
-    };
-    if (a.n_splits) go(k_inter_split, grid(a.n_splits, 4));
-    if (a.n_regions) go(k_inter_region, grid(a.n_regions, 1));
-    if (a.n_tiles) go(k_inter_tile, grid(a.n_tiles, 4));
+    if (!a.n_work) return;
+    const dim3 grid((unsigned)(((a.n_work + 7) >> 3) << 3));
+    if (c->inter_all_first) hipLaunchKernelGGL(k_inter_af, grid, dim3(256), 0, c->stream, a);
+    else hipLaunchKernelGGL(k_inter, grid, dim3(256), 0, c->stream, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------

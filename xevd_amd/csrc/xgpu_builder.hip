@@ -599,9 +599,8 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     // XGPU_INTER_STRIP regions wide, row by row inside a strip - emits the lists.
     static thread_local std::vector<uint32_t> tile_cu;
     static thread_local std::vector<uint8_t> tile_any;
-    static thread_local std::vector<uint2> inter_regions, inter_tiles;      // (position, CU index); the staging copy adds the CU record
-    static thread_local std::vector<uint32_t> inter_splits;
-    static thread_local std::vector<uint4> inter_work;            // one entry per 64x64 region that holds SCUs of the batch (k_inter.hip: InterArgs.work)
+    static thread_local std::vector<uint32_t> inter_items;        // [entry * 4 + tile]: the CU a whole tile lies in (the staging copy adds the CU's record), else none
+    static thread_local std::vector<uint32_t> inter_work;         // one entry per 64x64 region of the picture (k_inter.hip: InterArgs.work)
     {
         const int tiles_x = (c->sp.width + 31) >> 5, tiles_y = (c->sp.height + 31) >> 5, full_x = c->sp.width >> 5, full_y = c->sp.height >> 5;
         tile_cu.assign((size_t)tiles_x * tiles_y, 0xFFFFFFFFu);
@@ -619,7 +618,7 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
                     }
             }
         });
-        inter_regions.clear(); inter_tiles.clear(); inter_splits.clear(); inter_work.clear();
+        inter_items.clear(); inter_work.clear();
         const int regions_x = (c->sp.width + 63) >> 6, regions_y = (c->sp.height + 63) >> 6;
         for (int s0 = 0; s0 < regions_x; s0 += XGPU_INTER_STRIP)
             for (int ry = 0; ry < regions_y; ry++)
@@ -628,20 +627,22 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
                     const bool whole = tx + 1 < tiles_x && ty + 1 < tiles_y;
                     const uint32_t o = tcu[(size_t)ty * tiles_x + tx];
                     if (whole && o != 0xFFFFFFFFu && tcu[(size_t)ty * tiles_x + tx + 1] == o && tcu[(size_t)(ty + 1) * tiles_x + tx] == o && tcu[(size_t)(ty + 1) * tiles_x + tx + 1] == o) {
-                        inter_work.push_back(make_uint4(XGPU_WORK_REGION, (uint32_t)inter_regions.size(), 0, 0));
-                        inter_regions.push_back(make_uint2((uint32_t)rx | ((uint32_t)ry << 16), o));
+                        inter_work.push_back(XGPU_WORK_REGION);
+                        for (int q = 0; q < 4; q++) inter_items.push_back(o);      // every wave of the region role reads the item of its own tile's place
                         continue;
                     }
                     uint32_t kinds = 0;
-                    const uint32_t t0 = (uint32_t)inter_tiles.size(), s0_ = (uint32_t)inter_splits.size();
                     for (int q = 0; q < 4; q++) {
                         const int ux = tx + (q & 1), uy = ty + (q >> 1);
-                        if (ux >= tiles_x || uy >= tiles_y) continue;
-                        const uint32_t oq = tcu[(size_t)uy * tiles_x + ux];
-                        if (oq != 0xFFFFFFFFu) { inter_tiles.push_back(make_uint2((uint32_t)ux | ((uint32_t)uy << 16), oq)); kinds |= 1u << (2 * q); }
-                        else if (tany[(size_t)uy * tiles_x + ux]) { inter_splits.push_back((uint32_t)ux | ((uint32_t)uy << 16)); kinds |= 2u << (2 * q); }
+                        uint32_t oq = 0xFFFFFFFFu;
+                        if (ux < tiles_x && uy < tiles_y) {
+                            oq = tcu[(size_t)uy * tiles_x + ux];
+                            if (oq != 0xFFFFFFFFu) kinds |= 1u << (2 * q);
+                            else if (tany[(size_t)uy * tiles_x + ux]) kinds |= 2u << (2 * q);
+                        }
+                        inter_items.push_back(oq);
                     }
-                    if (kinds) inter_work.push_back(make_uint4(kinds, t0, s0_, 0));
+                    inter_work.push_back(kinds);
                 }
     }
     BT("inter lists");
@@ -684,11 +685,8 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     const size_t sz_dmvr = sizeof(DmvrItem) * (size_t)std::max(n_dmvr, 1);
     const size_t sz_own = sizeof(uint32_t) * (size_t)c->w_scu * c->h_scu;
     const size_t o_cpmv = o_aff + align_up((int)sz_aff, 256), o_dmvr = o_cpmv + align_up((int)sz_cpmv, 256), o_own = o_dmvr + align_up((int)sz_dmvr, 256);
-    const size_t sz_ireg = sizeof(InterItem) * std::max(inter_regions.size(), (size_t)1), sz_itile = sizeof(InterItem) * std::max(inter_tiles.size(), (size_t)1);
-    const size_t sz_isplit = sizeof(uint32_t) * std::max(inter_splits.size(), (size_t)1);
-    const size_t o_ireg = o_own + align_up((int)sz_own, 256), o_itile = o_ireg + align_up((int)sz_ireg, 256), o_isplit = o_itile + align_up((int)sz_itile, 256);
-    const size_t sz_iwork = sizeof(uint4) * std::max(inter_work.size(), (size_t)1);
-    const size_t o_iwork = o_isplit + align_up((int)sz_isplit, 256);
+    const size_t sz_iitem = sizeof(InterItem) * std::max(inter_items.size(), (size_t)1), sz_iwork = sizeof(uint32_t) * std::max(inter_work.size(), (size_t)1);
+    const size_t o_iitem = o_own + align_up((int)sz_own, 256), o_iwork = o_iitem + align_up((int)sz_iitem, 256);
     const size_t o_coef = o_iwork + align_up((int)sz_iwork, 256);
     db->stage_bytes = o_coef + sz_coef;
     auto fail = [&](int code) { xgpu_batch_destroy(c, db); return code; };
@@ -833,14 +831,17 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     }
     memcpy(hs + o_ctu, b->ctu_cu_start, sz_ctu);
     {
-        // the items of the two uniform classes carry their CU's record: the kernels' chain is list entry -> reference windows, no CU-record fetch in between
-        auto fill = [&](size_t off, const std::vector<uint2> &v) {
-            InterItem *it = (InterItem *)(hs + off);
-            for (size_t k = 0; k < v.size(); k++) { it[k].pos = v[k].x; it[k].cu = v[k].y; it[k].pad[0] = it[k].pad[1] = 0; it[k].rec = cus[v[k].y]; }
-        };
-        fill(o_ireg, inter_regions); fill(o_itile, inter_tiles);
-        if (!inter_splits.empty()) memcpy(hs + o_isplit, inter_splits.data(), sizeof(uint32_t) * inter_splits.size());
-        if (!inter_work.empty()) memcpy(hs + o_iwork, inter_work.data(), sizeof(uint4) * inter_work.size());
+        // the items carry their CU's record: the chain of a region- or tile-role wave is item -> reference windows, no CU-record fetch in between
+        InterItem *const it = (InterItem *)(hs + o_iitem);
+        const uint32_t *const ii = inter_items.data();
+        const size_t n_items = inter_items.size();
+        pool.run(nthr, [&, it, ii](int part) {
+            for (size_t k = n_items * (size_t)part / nthr; k < n_items * (size_t)(part + 1) / nthr; k++) {
+                if (ii[k] == 0xFFFFFFFFu) memset(&it[k], 0, sizeof(InterItem));
+                else { it[k].pos = 0; it[k].cu = ii[k]; it[k].pad[0] = it[k].pad[1] = 0; it[k].rec = cus[ii[k]]; }
+            }
+        });
+        if (!inter_work.empty()) memcpy(hs + o_iwork, inter_work.data(), sizeof(uint32_t) * inter_work.size());
     }
     if (b->n_coef && !coef_pinned) {                                   // the largest array (45 MB at 8K): in slices on the builder's threads
         const size_t bytes = sizeof(int16_t) * b->n_coef;
@@ -855,8 +856,7 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     db->d_waves = (TbWave *)(dbase + o_wv); db->d_intra = (IntraRec *)(dbase + o_intra); db->d_intra_deps = (uint32_t *)(dbase + o_deps);
     db->d_aff_items = (AffItem *)(dbase + o_aff); db->d_cpmv = (int16_t *)(dbase + o_cpmv);
     db->d_dmvr_items = (DmvrItem *)(dbase + o_dmvr); db->d_dmvr_mv = (int16_t *)(dbase + o_dmv); db->d_owner = (uint32_t *)(dbase + o_own);
-    db->d_inter_regions = (InterItem *)(dbase + o_ireg); db->d_inter_tiles = (InterItem *)(dbase + o_itile); db->d_inter_splits = (uint32_t *)(dbase + o_isplit); db->d_inter_work = (uint4 *)(dbase + o_iwork); db->n_inter_work = (int)inter_work.size();
-    db->n_inter_regions = (int)inter_regions.size(); db->n_inter_tiles = (int)inter_tiles.size(); db->n_inter_splits = (int)inter_splits.size();
+    db->d_inter_items = (InterItem *)(dbase + o_iitem); db->d_inter_work = (uint32_t *)(dbase + o_iwork); db->n_inter_work = (int)inter_work.size();
     db->d_coef = (int16_t *)(dbase + o_coef); db->d_resid = (int16_t *)(dbase + o_resid); db->d_intra_done = (uint32_t *)(dbase + o_done);
     // one copy: the staging block has the device layout (a pinned coefficient arena goes from the caller's buffer).  On the upload stream: the
     // copy overlaps the kernels of the pictures before; xgpu_batch_recon makes the kernel stream wait for `uploaded`
@@ -864,7 +864,7 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     if (segs) *segs = { { o_cus, sizeof(CuRec) * (size_t)n }, { o_ctu, sz_ctu }, { o_tbs, sizeof(TbRec) * (size_t)n_tb }, { o_wv, sizeof(TbWave) * (size_t)n_waves }, { o_intra, sizeof(IntraRec) * (size_t)n_intra },
                         { o_deps, sizeof(uint32_t) * (size_t)n_deps }, { o_aff, sizeof(AffItem) * (size_t)(n_aff_eif + n_aff_sub) }, { o_cpmv, sizeof(int16_t) * 12 * (size_t)n_aff },
                         { o_dmvr, sizeof(DmvrItem) * (size_t)n_dmvr }, { o_own, sz_own }, { o_coef, coef_pinned ? 0 : sizeof(int16_t) * b->n_coef },
-                        { o_ireg, sizeof(InterItem) * inter_regions.size() }, { o_itile, sizeof(InterItem) * inter_tiles.size() }, { o_isplit, sizeof(uint32_t) * inter_splits.size() }, { o_iwork, sizeof(uint4) * inter_work.size() } };
+                        { o_iitem, sizeof(InterItem) * inter_items.size() }, { o_iwork, sizeof(uint32_t) * inter_work.size() } };
     if (host_only) { *out = db; return XGPU_OK; }
     hipError_t e = hipMemcpyAsync(dbase, hs, coef_pinned ? o_coef : db->stage_bytes, hipMemcpyHostToDevice, c->up_stream);
     if (e == hipSuccess && coef_pinned) e = hipMemcpyAsync(dbase + o_coef, b->coef, sizeof(int16_t) * b->n_coef, hipMemcpyHostToDevice, c->up_stream);

@@ -102,16 +102,15 @@ struct InterArgs {
     int      pic_w, pic_h;
     int      bd_l, bd_c;
     int      admvp;
-    // Work lists of the three launches (built by xgpu_batch_create in one spatial order - vertical strips of 64x64 regions, row by row inside a strip - so that
-    // every XCD, which takes a contiguous eighth of each list, works on a compact patch of the picture):
-    const InterItem *regions;          // k_inter_region: 64x64 regions inside ONE CU (pos = region column | row << 16)
-    const InterItem *tiles;            // k_inter_tile: 32x32 tiles inside one CU whose region is not (pos in tiles)
-    const uint32_t  *splits;           // k_inter_split: every other tile that holds SCUs of the batch: tile column | row << 16
-    int      n_regions, n_tiles, n_splits;
-    // ... and the one launch's order over them: one entry per 64x64 region that holds SCUs of the batch, in the same spatial order.  x = XGPU_WORK_REGION: the region
-    // is regions[y]; else x = two bits per tile of the region (0: no SCU of the batch, 1: the next entry of `tiles` from y on, 2: the next of `splits` from z on)
-    const uint4 *work;
+    // One entry of `work` per 64x64 region of the PICTURE, in vertical strips XGPU_INTER_STRIP regions wide, row by row inside a strip (every XCD takes a contiguous
+    // eighth of that order: a compact patch of the picture): XGPU_WORK_REGION = the region lies inside one CU of the batch; else two bits per 32x32 tile of the
+    // region (bits 2q.. for tile q = column | row << 1): 0 no SCU of the batch, 1 the tile lies inside one CU, 2 every other tile with SCUs of the batch.
+    // items[entry * 4 + q]: the CU (index and record) of tile q where it lies inside one CU (all four the same for a region entry), zero elsewhere.
+    const uint32_t  *work;
+    const InterItem *items;
     int      n_work;
+    int      regions_x, strip_entries, full_entries;      // 16 x regions_y; entries in front of the last, narrower strip
+    uint32_t magic_strip, magic_last;                     // floor(2^32 / d) + 1 for d = strip_entries and the last strip's width: n / d = mulhi(n, magic) for n x d < 2^32
     const CuRec    *cus;
     const int16_t  *resid;
     ScuRec  *maps;
@@ -274,10 +273,9 @@ struct xgpu_dbatch {
     CuRec     *d_cus;
     uint32_t  *d_ctu_start;
     uint32_t  *d_owner;               // SCU -> CU index of the batch, over the whole picture
-    InterItem *d_inter_regions, *d_inter_tiles;      // work lists of the three inter launches (InterArgs)
-    uint32_t  *d_inter_splits;
-    uint4     *d_inter_work;
-    int        n_inter_regions, n_inter_tiles, n_inter_splits, n_inter_work;
+    InterItem *d_inter_items;                        // k_inter's roles per region of the picture and the CUs of its whole tiles (InterArgs)
+    uint32_t  *d_inter_work;
+    int        n_inter_work;
     int16_t   *d_coef, *d_resid;
     TbRec     *d_tbs;
     TbWave    *d_waves;
@@ -332,7 +330,7 @@ struct xgpu_ctx {
     int             have_frame;
     TileMask        no_dbk;            // tile borders the deblocking of the current picture leaves alone (set by xgpu_batch_recon)
     hipEvent_t      fork_ev, join_ev;  // k_dmvr / k_affine on the side stream beside k_inter: where they may start, where the kernel stream takes them back
-    int             inter_launches, inter_all_first;      // measurement knobs of launch_inter (k_inter.hip), read from the environment by xgpu_open
+    int             inter_all_first;      // measurement knobs of launch_inter (k_inter.hip), read from the environment by xgpu_open
     int             builder_threads;   // xgpu_set_builder_threads: host threads xgpu_batch_create spreads its per-CU passes over (default 1)
     int             pad_done;          // the padding of the current picture has been written (by k_alf's border tiles): xgpu_pad launches nothing
     int             where;             // 0: the picture being built lives in its DPB slot, 1: in the scratch picture
@@ -397,7 +395,7 @@ private:
 
 // kernel launchers (one per .hip file)
 void launch_itdq(xgpu_ctx *c, const ItdqArgs &a, hipStream_t s);
-void launch_inter(xgpu_ctx *c, const InterArgs &a, bool any_order);      // the three launches on the ctx stream; any_order: the second and third without the barrier bit      // the three launches: regions on the ctx stream, tiles / split tiles on the given ones
+void launch_inter(xgpu_ctx *c, const InterArgs &a);      // k_inter on the ctx stream
 void launch_test_recon(xgpu_ctx *c, const int16_t *coef, const int16_t *pred, int is_coef, int cuw, int cuh, int16_t *rec, int s_rec, int bd);
 void launch_test_dbk(xgpu_ctx *c, int16_t *buf, int16_t *buf_v, int st, int st_v, int stride, int bd, int hor, int chroma);
 void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf, const ItdqArgs *next, bool right = false);      // next != NULL (dep launches): k_intra_itdq

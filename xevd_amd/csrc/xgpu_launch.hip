@@ -78,8 +78,13 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
     a.s_l = c->s_l; a.s_c = c->s_c; a.pic_w = c->sp.width; a.pic_h = c->sp.height;
     a.bd_l = c->sp.bit_depth_luma; a.bd_c = c->sp.bit_depth_chroma;
     a.admvp = c->sp.tool_admvp ? 1 : 0;
-    a.regions = db->d_inter_regions; a.tiles = db->d_inter_tiles; a.splits = db->d_inter_splits; a.work = db->d_inter_work; a.n_work = db->n_inter_work;
-    a.n_regions = db->n_inter_regions; a.n_tiles = db->n_inter_tiles; a.n_splits = db->n_inter_splits;
+    a.work = db->d_inter_work; a.items = db->d_inter_items; a.n_work = db->n_inter_work;
+    {
+        const int regions_x = (c->sp.width + 63) >> 6, regions_y = (c->sp.height + 63) >> 6;
+        a.regions_x = regions_x; a.strip_entries = XGPU_INTER_STRIP * regions_y; a.full_entries = (regions_x / XGPU_INTER_STRIP) * a.strip_entries;
+        a.magic_strip = (uint32_t)((1ull << 32) / (uint64_t)a.strip_entries) + 1u;
+        a.magic_last = (regions_x % XGPU_INTER_STRIP) ? (uint32_t)((1ull << 32) / (uint64_t)(regions_x % XGPU_INTER_STRIP)) + 1u : 0u;
+    }
     a.cus = db->d_cus; a.resid = db->d_resid;
     a.maps = c->d_maps; a.w_scu = c->w_scu; a.owner = db->d_owner; a.n_cu = db->n_cu; a.cur_poc = c->fp.poc;
     c->order_rl |= db->order_rl;                            // (the pictures' batches - one per slice - say it for the deblocking pass behind them)
@@ -100,9 +105,8 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
         HIPCHK(c, hipStreamWaitEvent(c->side_stream, c->fork_ev, 0));
         tool_stream = c->side_stream;
     }
-    // the inter pass (k_inter.hip): one launch over the batch's work lists (or, as a measurement option, one launch per class)
-    static const bool inter_in_order = getenv("XEVD_HIP_INTER_IN_ORDER") != NULL;      // A/B measurements (read once): the three class launches strictly one after the other
-    TIMED(c, XGPU_K_INTER, launch_inter(c, a, !inter_in_order));
+    // the inter pass (k_inter.hip): one launch, a workgroup per 64x64 region of the picture
+    TIMED(c, XGPU_K_INTER, launch_inter(c, a));
     if (!ahead) HIPCHK(c, hipEventRecord(c->after_inter, c->stream));   // where a residual pass prepared on the side stream (xgpu_batch_prepare) may start
     c->have_after_inter = 1;
     if (db->n_dmvr) {
