@@ -837,7 +837,6 @@ struct TileCoder {
                 for (int q = pos + run + 1; q < n; q++) if (coef[sc[q]]) { last = 0; break; }
             }
             run = sym_unary(c, run, models.run + t0, 2);
-            if (!enc) for (int i = pos; i < pos + run && i < n; i++) coef[sc[i]] = 0;
             pos += run;
             if (pos >= n) return;                                   // malformed input; the caller checks the reader's overrun flag
             level = sym_unary(c, level - 1, models.level + t0, 2) + 1;
@@ -1449,7 +1448,10 @@ struct TileCoder {
             if (idx == 2 || idx == 4) tlh -= idx == 4 ? 2 : 1;
         }
         for (int k = 0; k < 3; k++)
-            if (cu.cbf[k]) { if (sps.tool_adcc) code_adcc(c, coef[k], tlw - (k ? 1 : 0), tlh - (k ? 1 : 0), k != 0, enc); else code_coefs(c, coef[k], tlw - (k ? 1 : 0), tlh - (k ? 1 : 0), k != 0, enc); }
+            if (cu.cbf[k]) {
+                if (!enc) memset(coef[k], 0, sizeof(int16_t) << (tlw + tlh - (k ? 2 : 0)));      // the decoder writes the coded levels into a cleared block (the arena itself is not: Batch)
+                if (sps.tool_adcc) code_adcc(c, coef[k], tlw - (k ? 1 : 0), tlh - (k ? 1 : 0), k != 0, enc); else code_coefs(c, coef[k], tlw - (k ? 1 : 0), tlh - (k ? 1 : 0), k != 0, enc);
+            }
     }
 
     // ats_inter_info syntax (xevdm_eco_ats_inter_info, xevdm_eco.c:128-190; with cm_init the flag's context goes by the CU's area, the direction's by its shape)

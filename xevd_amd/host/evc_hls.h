@@ -271,12 +271,21 @@ struct Picture {         // SCU maps of the picture being parsed / written (ctx-
     void reset(int w, int h, bool refined_map = false) { size(w, h, refined_map); clear_rows(0, h_scu); }
 };
 
+// the coefficient arena of a batch grows without being zeroed (a resize of a plain vector value-initialises: 3 bytes per SAMPLE of every CU - 100 MB per 8K picture -
+// when the space of a CU's three blocks was taken and given back CU by CU); a coded block is cleared where it is decoded (TileCoder::code_cu)
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { typedef NoInitAlloc<U> other; };
+    template <class U> void construct(U *p) noexcept { ::new ((void *)p) U; }
+    template <class U, class... A> void construct(U *p, A &&... a) { ::new ((void *)p) U(std::forward<A>(a)...); }
+};
+typedef std::vector<int16_t, NoInitAlloc<int16_t>> CoefVec;
 struct Batch {           // the xgpu_cu_batch under construction
     std::vector<uint16_t> x, y;
     std::vector<uint8_t> log2w, log2h, pred_mode, qp, cbf, ipm, ats, ats_inter, dmvr, affine, tree;
     bool has_tree = false;
     std::vector<int8_t> refi;
-    std::vector<int16_t> mv, coef, affine_mv;
+    std::vector<int16_t> mv, affine_mv;
+    CoefVec coef;
     std::vector<uint32_t> coef_off, ctu_start;
     void clear() { x.clear(); y.clear(); log2w.clear(); log2h.clear(); pred_mode.clear(); qp.clear(); cbf.clear(); ipm.clear(); ats.clear(); ats_inter.clear(); dmvr.clear(); affine.clear(); tree.clear(); has_tree = false; affine_mv.clear(); refi.clear(); mv.clear(); coef.clear(); coef_off.clear(); ctu_start.clear(); }
 };

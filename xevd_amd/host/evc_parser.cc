@@ -107,11 +107,11 @@ struct TileParser {
         Cu cu;
         memset(&cu, 0, sizeof(cu));
         cu.x = x; cu.y = y; cu.log2w = lw; cu.log2h = lh; cu.qp_code = qp_code; cu.only_inter = only_inter; cu.tree = tree;
-        // the coefficient blocks are decoded where they stay: zeroed space for all three components at the end of the tile's arena, given back behind the
+        // the coefficient blocks are decoded where they stay: space for all three components at the end of the tile's arena (cleared block by block, where one is coded), given back behind the
         // blocks that turn out to be coded (they are packed together when one in front of them is not)
         if (batch.x.empty()) n_coef = 0;
         const size_t nl = (size_t)1 << (lw + lh), nc = nl >> 2;
-        batch.coef.resize(n_coef + nl + 2 * nc);
+        if (batch.coef.size() < n_coef + nl + 2 * nc) batch.coef.resize(std::max(n_coef + nl + 2 * nc, batch.coef.size() * 2));      // (not zeroed: NoInitAlloc)
         int16_t *coef[3] = { batch.coef.data() + n_coef, batch.coef.data() + n_coef + nl, batch.coef.data() + n_coef + nl + nc };
         tc.code_cu(dec, cu, coef, false);
         tc.commit(cu);
@@ -140,7 +140,6 @@ struct TileParser {
                 if (dst != coef[k]) memmove(dst, coef[k], n * sizeof(int16_t));
                 n_coef += n;
             }
-        batch.coef.resize(n_coef);
         return XGPU_OK;
     }
 };
