@@ -130,6 +130,19 @@ __device__ __forceinline__ void lap_pair(const uint32_t up[3], const uint32_t mi
 // price is 27 % more deblocking arithmetic (72^2 / 64^2: the halo is filtered by both neighbours).  LDS layout: window row r at row r + RO, luma column c at c + 4,
 // chroma column c at c + CO.
 // PK (fused form): the deblocking line filters on packed pairs of lines (addb_filter.h; bit depths up to 10)
+#ifdef XGPU_ALF_TRACE
+// measurement build (make EXTRA=-DXGPU_ALF_TRACE): shader cycles between the marks of alf_kernel, summed over lane 0 of the waves of every 61st workgroup
+__device__ unsigned long long g_alf_trace[16];
+#define ATR(p) do { if (atr_on) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_alf_trace[p], now_ - atr_prev); atr_prev = __builtin_amdgcn_s_memtime(); } } while (0)
+extern "C" int xgpu_test_alf_trace(unsigned long long out[16], int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_alf_trace), sizeof(g_alf_trace)) != hipSuccess) return -1;
+    if (reset) { static unsigned long long z[16]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_alf_trace), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#else
+#define ATR(p) do { } while (0)
+#endif
 template <bool FUSED, bool PK = false>
 __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
                                            const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_,
@@ -161,6 +174,11 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
     const int tx = tile % tiles_x, ty = tile / tiles_x;
     const int tx0 = tx << 6, ty0 = ty << 6;
     const int t = threadIdx.x;
+#ifdef XGPU_ALF_TRACE
+    unsigned long long atr_prev = __builtin_amdgcn_s_memtime();
+    const bool atr_on = (t & 63) == 0 && tile % 61 == 7;
+    if (atr_on) atomicAdd(&g_alf_trace[15], 1ull);
+#endif
     // the CTU this tile belongs to and its border availability (alf_process_tile :984-999)
     CtuRect k;
     const int ctu = 1 << a.log2_ctu;
@@ -248,7 +266,9 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
                 if (t < 2) s_cnt[t] = 0;
                 if (t < 16) ((uint32_t *)s_tm)[t] = t < 8 ? da.no_filter.vb[t] : da.no_filter.hb[t - 8];
             }
+            ATR(1);
             __syncthreads();                                 // the tables and the counters (the loads above are in flight across it)
+            ATR(2);
             if (t < 162) {
                 s_map[sr][2 * wx] = rp; s_map[sr][2 * wx + 1] = rq;
 #pragma unroll
@@ -261,7 +281,9 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
                 if (bs) s_list[0][atomicAdd(&s_cnt[0], 1u)] = (uint16_t)(t | (bs << 8));
             }
         }
+        ATR(3);
         __syncthreads();
+        ATR(4);
         // phase B: the vertical edges to filter, in place
         for (int i = t; i < (int)s_cnt[0]; i += 256) {
             const int e = s_list[0][i], seg = e & 255, bs = e >> 8, wx = seg % 9, sr = seg / 9;
@@ -332,7 +354,9 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
                 if (bs) s_list[1][atomicAdd(&s_cnt[1], 1u)] = (uint16_t)(t | (bs << 8));
             }
         }
+        ATR(5);
         __syncthreads();
+        ATR(6);
         // phase C: the horizontal edges, in place
         for (int i = t; i < (int)s_cnt[1]; i += 256) {
             const int e = s_list[1][i], seg = e & 255, bs = e >> 8, sx = seg % 18, g = seg / 18;
@@ -377,7 +401,9 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
                 for (int r = 0; r < 4; r++) *(uint32_t *)(l_c[pl] + (4 * g + r) * CSTR + 2 * sx) = PK2(Cc[pl][0][r], Cc[pl][1][r]);
         }
 #undef PK2
+        ATR(7);
         __syncthreads();
+        ATR(8);
         // ---- ALF's window rule on the tiles that touch a picture / tile border or an unavailable CTU side: every window position takes the sample the rule names
         //      (alf_fetch's position mapping is idempotent - a position it names maps to itself - so the pass runs in place) ----
         const bool plain = (k.aL || tx0 > k.x0) && (k.aR || tx0 + 64 < k.x0 + k.cw) && (k.aT || ty0 > k.y0) && (k.aB || ty0 + 64 < k.y0 + k.ch) &&
@@ -453,7 +479,9 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
             for (int dir = 0; dir < 4; dir++) l_lap[dir][sr + 1][sc + 2] = (uint16_t)acc[dir];
         }
     }
+    ATR(9);
     __syncthreads();
+    ATR(10);
     const bool edge_l = tx0 == 0, edge_r = tx0 + 64 >= a.pic_w, edge_t = ty0 == 0, edge_b = ty0 + 64 >= a.pic_h;
     const bool keep_border = a.pad && (edge_l || edge_r || edge_t || edge_b);      // workgroup-uniform: an inner tile's lanes do not test their rows against the picture borders
     do {
@@ -608,6 +636,7 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
     // ------------------------------------------------ border replication (xevd_picbuf_expand, src_base/xevd_util.c:365-427) ---------------
     // A tile on the picture border writes its share of the padding from the samples it has just produced: the margin left / right of its rows, the rows above /
     // below its columns, and - a corner tile - the corner block.  All 256 threads of the workgroup take part (the tile's own lanes outside the picture too).
+    ATR(11);
     if (!a.pad || !(edge_l || edge_r || edge_t || edge_b)) return;
     __syncthreads();
 #pragma unroll
