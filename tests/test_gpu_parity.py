@@ -123,17 +123,25 @@ def test_gpu_pictures_golden_residual_pass_ahead(name):
 
 
 @pytest.mark.gpu
-def test_gpu_inter_all_first_option(monkeypatch):
-    """The inter pass's measurement option (read per context by xgpu_open): the split role's requests all in front of its arithmetic - the same pictures (every
-    golden picture with inter CUs, small pictures: all three roles occur in the CTU-128 and B-picture cases)"""
-    monkeypatch.setenv("XEVD_HIP_INTER_ALL_FIRST", "1")
-    for case_name in golden_io.PICTURE_CASES:
-        case, exp = golden_io.load_picture_case(case_name)
-        if not (case["batch"]["pred_mode"] != 0).any():
-            continue
-        out = cases.run_gpu(case)
+@pytest.mark.parametrize("admvp,bd", [(0, 8), (1, 10)], ids=["base_taps_8b", "main_taps_10b"])
+def test_gpu_split_role_whole_sample_vectors(admvp, bd):
+    """k_inter's split role: a lane whose vector has a whole-sample component sits out of the window rows / samples its identity taps multiply by zero
+    (mc_scu_list).  Pictures of small CUs (4x4 .. 16x16, mixed inside every 32x32 tile) whose vectors are forced, CU by CU, through every combination of
+    whole / fractional luma and chroma phases in x and y, both lists, against the oracle (xevd_mc.c:469-557, xevdm_mc.c:1860-2038)."""
+    for seed in range(3):
+        cs = cases.build_case(f"split_phases_{admvp}", 200, 136, bd, admvp, 0, (2, 2), 0.5, {"inter_frac": 1.0, "split_prob": 0.85 if seed else 1.0, "coded_frac": 0.3}, seed=seed, oob_frac=0.2)
+        mv = cs["batch"]["mv"]                                   # [n_cu][list][x / y], quarter samples
+        k = np.arange(mv.shape[0])
+        for l in range(2):
+            for d in range(2):
+                sel = (k >> (2 * l + d + seed)) % 4              # 0: as drawn, 1: whole luma sample, 2: whole chroma sample (multiple of 8), 3: half a luma sample
+                v = mv[:, l, d].astype(np.int32)
+                v = np.where(sel == 1, v & ~3, np.where(sel == 2, v & ~7, np.where(sel == 3, (v & ~3) | 2, v)))
+                mv[:, l, d] = v.astype(mv.dtype)
+        ref, _, _, _ = cases.run_cpu("oracle", cs)
+        out = cases.run_gpu(cs)
         for c in range(3):
-            assert np.array_equal(out[c], exp["out"][c]), f"{case_name}: final plane {c}"
+            assert np.array_equal(out[c], ref.bufs[c]), f"seed {seed} plane {c}: {np.argwhere(out[c] != ref.bufs[c])[:4]}"
 
 
 RANDOM = [

@@ -251,27 +251,58 @@ __device__ __forceinline__ RegionMap region_map(int t)
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// k_inter_split: one SCU per lane, one list.  mc_luma_4x4 + 2 x mc_chroma_2x2 (mc_filters.h) with ALL the list's requests in front of the arithmetic.
-// Left to itself the compiler - holding the kernel at four waves per SIMD - fetched the luma window in four instalments (five rows, two, one, three) and each chroma
-// plane on its own, every instalment a wait for the round trip before the next is requested: six memory round trips per list in a row, ~11 per wave with the owner
-// entry and the CU record in front, at ~2 us each under load - the wave's 25-30 us life, of which the SIMD saw ~3 (round 5: why nothing that changed the NUMBER or the
-// SIZE of the requests moved this kernel).  Here the eleven luma rows are requested at once (66 registers - the kernel takes three waves per SIMD instead of four),
-// the first six are filtered, the ten chroma rows are requested into the registers those freed, the last five luma rows are filtered while they travel: two round
-// trips per list, the second under arithmetic.
+// k_inter_split: one SCU per lane, one list.  The arithmetic of mc_luma_4x4 + 2 x mc_chroma_2x2 (mc_filters.h) with the list's requests in two instalments in front
+// of it: a memory round trip for the luma window, one for both chroma windows.  (Left to itself the compiler fetched the luma window in four instalments and each
+// chroma plane on its own - six dependent round trips per list.)
+// Round 5, second half: the pass runs at what the memory path delivers for its requests, so the requests were cut - lanes sit out of the rows and samples their
+// identity taps multiply by zero, a chroma row is one 12-byte request instead of 8 + 4 bytes: 42 -> 25.5 requests per lane and list, k_inter 143.7 -> 135.6 us on one
+// box (tools/r5_u.sh, profiles/round5_exp_split_requests.txt; the same structure with every lane requesting everything: 141.0).  The number of round trips does not
+// show: luma in instalments of 6 + 5 rows with the chroma planes one after the other (five round trips per list), 6 + 5 rows and both planes (three), 9 + 2 rows,
+// all eleven (two) measured 138.2 / 135.6 / 135.3 / 136.0 us - what shows is the fourth wave per SIMD (133 VGPRs: 144.9 us).  Also measured and dropped: a lane whose
+// SCU has one of the same CU under it (lane + 8) taking its rows 4..10 from that lane's registers (ds_bpermute) instead of requesting them - 23 rows instead of 44
+// per column of a 16x16 CU, bit-exact, and no faster (133.1 against 132.3 us): the requests that cost are those of the 4x4 CUs.
 // H / V: does ANY lane of the wave filter luma in that direction (wave-uniform, as mc_luma_4x4); chroma is fetched as for the full filter and its variant chosen after.
 // ---------------------------------------------------------------------------------------------------------
 template <bool H, bool V>
 __device__ __forceinline__ void mc_scu_list(gs16 pl_, int s_l, gs16 pu_, gs16 pv_, int s_c, const uint32_t ch[4], const uint32_t cv[4], Regime rgl, int maxl,
-                                            const uint32_t c2h[2], const uint32_t c2v[2], Regime rgc, int maxc, bool cwh, bool cwv, uint32_t o[8], uint32_t ou[2], uint32_t ov[2])
+                                            const uint32_t c2h[2], const uint32_t c2v[2], Regime rgc, int maxc, bool cwh, bool cwv, uint32_t o[8], uint32_t ou[2], uint32_t ov[2],
+                                            bool fx, bool fy, bool cfx, bool cfy)
 {
     constexpr int J0 = V ? 0 : 3, J1 = V ? 11 : 7;
-    uint4 A[11]; uint2 B[11];
+#ifdef XGPU_NO_LANE_PRED
+    fx = fy = cfx = cfy = true;                                  // (measurement build: every lane requests the whole window)
+#endif
+    // fx / fy (cfx / cfy): does THIS lane filter luma (chroma) horizontally / vertically.  A lane whose vector has a whole-sample component carries the identity
+    // taps in that direction (mc_filters.h: one tap of 1, zeros around it): the rows above and below its block and the samples right of sample 7 are multiplied by
+    // zero, so the lane does not request them - it sits out of those load instructions and the registers hold whatever they held.  With quarter-sample vectors a
+    // quarter of the lanes has a whole-sample component in each direction: 16.2 requests per lane and luma window instead of 22.  A chroma row is ONE 12-byte request
+    // (six samples, of which the filters use five; the round-4 form asked for 8 + 4 bytes): 10 per list instead of 20, 9.3 with the rows a lane sits out of.
+    // A conditional load is a branch of its own, and what consumes the loaded value next is moved INTO that branch by the compiler - a wait for the round trip per
+    // row.  `fence` (an empty asm that takes the rows' registers in and out) sits behind all requests of an instalment and in front of their consumers, and the
+    // loaded value stays one register tuple until then (mc_filters.h: any_value, gload*_if).
+    // Two instalments per list: all luma rows (66 registers), then - the luma block finished - both chroma windows (30); the kernel stays at four waves per SIMD.
+    v4u32 A[11]; v2u32 B[11];
+    auto request = [&](int ja, int jb) {
 #pragma unroll
-    for (int j = J0; j < J1; j++) {
-        if (H) { A[j] = gload16(pl_ + j * s_l); B[j] = gload8(pl_ + j * s_l + 8); }
-        else B[j] = gload8(pl_ + j * s_l + 3);                 // no lane filters horizontally: samples 3..6 of the window
-    }
-    __builtin_amdgcn_sched_barrier(0);
+        for (int j = ja; j < jb; j++) {
+            const bool row_on = !V || fy || (j >= 3 && j < 7);
+            if (H) {
+                A[j] = any_value<v4u32>(); B[j] = any_value<v2u32>();
+                gload16_if(A[j], pl_ + j * s_l, row_on);
+                gload8_if(B[j], pl_ + j * s_l + 8, row_on && fx);
+            } else {
+                B[j] = any_value<v2u32>();
+                gload8_if(B[j], pl_ + j * s_l + 3, row_on);     // no lane filters horizontally: samples 3..6 of the window
+            }
+        }
+    };
+    auto fence = [&](int ja, int jb) {
+#pragma unroll
+        for (int j = ja; j < jb; j++) {
+            if (H) asm volatile("" : "+v"(A[j]), "+v"(B[j]));
+            else   asm volatile("" : "+v"(B[j]));
+        }
+    };
     int acc[4][4];
     int tp[4] = {0, 0, 0, 0};
     auto row = [&](int j) {
@@ -310,28 +341,34 @@ __device__ __forceinline__ void mc_scu_list(gs16 pl_, int s_l, gs16 pu_, gs16 pv
 #pragma unroll
         for (int c = 0; c < 4; c++) tp[c] = t[c];
     };
-    constexpr int JM = V ? 6 : 5;                               // the rows filtered before the chroma requests go out
+    auto rows = [&](int ja, int jb) {
 #pragma unroll
-    for (int j = J0; j < JM; j++) row(j);
-    __builtin_amdgcn_sched_barrier(0);
-    // both chroma windows: five rows of 8 + 4 bytes per plane (the full filter's; the variants below read what they need)
-    uint2 CA[2][5]; uint32_t CB[2][5];
+        for (int j = ja; j < jb; j++) row(j);
+    };
+    auto luma_out = [&]() {
 #pragma unroll
-    for (int pl = 0; pl < 2; pl++)
+        for (int r = 0; r < 4; r++) {
+            int v[4];
 #pragma unroll
-        for (int j = 0; j < 5; j++) { const gs16 q = (pl ? pv_ : pu_) + j * s_c; CA[pl][j] = gload8(q); CB[pl][j] = gload4(q + 4); }
-    __builtin_amdgcn_sched_barrier(0);
+            for (int c = 0; c < 4; c++) v[c] = clip3(0, maxl, V ? acc[r][c] >> rgl.sh2 : acc[r][c]);
+            o[r * 2 + 0] = pack2(v[0], v[1]);
+            o[r * 2 + 1] = pack2(v[2], v[3]);
+        }
+    };
+    v3u32 CW[2][5];
+    auto request_c = [&](int pl) {
 #pragma unroll
-    for (int j = JM; j < J1; j++) row(j);
+        for (int j = 0; j < 5; j++) {
+            const bool row_on = cfy || j == 1 || j == 2;      // (as for luma: identity taps select row 1 + r and sample 1 + c)
+            CW[pl][j] = any_value<v3u32>();
+            gload12_if(CW[pl][j], (pl ? pv_ : pu_) + j * s_c, row_on);
+        }
+    };
+    auto fence_c = [&](int pl) {
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-        int v[4];
-#pragma unroll
-        for (int c = 0; c < 4; c++) v[c] = clip3(0, maxl, V ? acc[r][c] >> rgl.sh2 : acc[r][c]);
-        o[r * 2 + 0] = pack2(v[0], v[1]);
-        o[r * 2 + 1] = pack2(v[2], v[3]);
-    }
-    // chroma, from the registers: mc_chroma_2x2's arithmetic on window row j = dwords (CA[j].x, CA[j].y, CB[j]) = samples 0..5
+        for (int j = 0; j < 5; j++) asm volatile("" : "+v"(CW[pl][j]));
+    };
+    // chroma, from the registers: mc_chroma_2x2's arithmetic on window row j = the dwords of CW[j] = samples 0..5
     auto chroma = [&](auto hc, auto vc, int pl, uint32_t oo[2]) {
         constexpr bool CH = decltype(hc)::value, CV = decltype(vc)::value;
         int a2[2][2];
@@ -339,7 +376,7 @@ __device__ __forceinline__ void mc_scu_list(gs16 pl_, int s_l, gs16 pu_, gs16 pv
 #pragma unroll
         for (int j = CV ? 0 : 1; j < (CV ? 5 : 3); j++) {
             int t[2];
-            const uint32_t D0 = CA[pl][j].x, D1 = CA[pl][j].y, D2 = CB[pl][j];
+            const uint32_t D0 = CW[pl][j].x, D1 = CW[pl][j].y, D2 = CW[pl][j].z;
             if (CH) {
                 const uint32_t Q0 = hi_lo(D1, D0), Q1 = hi_lo(D2, D1);
                 t[0] = dot2(c2h[1], D1, dot2z(c2h[0], D0));
@@ -370,8 +407,17 @@ __device__ __forceinline__ void mc_scu_list(gs16 pl_, int s_l, gs16 pu_, gs16 pv
             oo[r] = pack2(clip3(0, maxc, CV ? a2[r][0] >> rgc.sh2 : a2[r][0]), clip3(0, maxc, CV ? a2[r][1] >> rgc.sh2 : a2[r][1]));
     };
     using T = std::true_type; using F = std::false_type;
-    if (cwh) { if (cwv) { chroma(T{}, T{}, 0, ou); chroma(T{}, T{}, 1, ov); } else { chroma(T{}, F{}, 0, ou); chroma(T{}, F{}, 1, ov); } }
-    else     { if (cwv) { chroma(F{}, T{}, 0, ou); chroma(F{}, T{}, 1, ov); } else { chroma(F{}, F{}, 0, ou); chroma(F{}, F{}, 1, ov); } }
+    auto chroma_pl = [&](int pl, uint32_t oo[2]) {
+        fence_c(pl);
+        if (cwh) { if (cwv) chroma(T{}, T{}, pl, oo); else chroma(T{}, F{}, pl, oo); }
+        else     { if (cwv) chroma(F{}, T{}, pl, oo); else chroma(F{}, F{}, pl, oo); }
+    };
+    request(J0, J1); fence(J0, J1);
+    rows(J0, J1);
+    luma_out();
+    __builtin_amdgcn_sched_barrier(0);
+    request_c(0); request_c(1);
+    chroma_pl(0, ou); chroma_pl(1, ov);
 }
 
 #define OWNER_NONE 0xFFFFFFFFu
@@ -384,7 +430,7 @@ __device__ __forceinline__ void mc_scu_list(gs16 pl_, int s_l, gs16 pu_, gs16 pv
 // wait for their acknowledgement - a memory round trip per tile).
 // MODE 0: per lane; 1: the wave's tile inside one CU (UNI above); 2: the workgroup's whole 64x64 region inside one CU - the reference windows are fetched once per
 // workgroup into LDS the four waves share (W = that block, rm = the thread's chunks of it, wave = the tile's place in the region), everything else as in mode 1
-// ALL_FIRST (MODE 0): mc_scu_list (all requests of a list in front of its arithmetic, 145 VGPRs) or mc_luma_4x4 + mc_chroma_2x2 (requests in instalments, 123 VGPRs)
+// MODE 0 filters through mc_scu_list: the list's luma window requested at once, then both chroma windows, every lane only what its taps do not multiply by zero
 #ifdef XGPU_INTER_TRACE
 // measurement build (make EXTRA=-DXGPU_INTER_TRACE): where the life of a wave goes, per role - shader cycles between marks, summed over the waves' lane 0
 __device__ unsigned long long g_inter_trace[3][16];
@@ -405,7 +451,7 @@ extern "C" int xgpu_test_inter_trace(unsigned long long out[48], int reset)
 #define TRACE_PASS
 #define TRACE_OFF
 #endif
-template <int MODE, bool ALL_FIRST = true>
+template <int MODE>
 __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r1, bool lane_ok, int sx, int sy, int lane, int16_t *W, const LaneMap fm,
                                            const uint4 (*s_ref)[2], const uint4 *s_ltap, const uint2 *s_ctap, uint32_t pl[8], uint32_t pu[2], uint32_t pv[2],
                                            const RegionMap *rm, int wave, uint32_t own TRACE_ARG)
@@ -648,7 +694,6 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
         (void)tid;
     } else {
         TRACE_MARK(tr, 2);
-        load_resid();
 #pragma unroll
         for (int l = 0; l < 2; l++) {
             if (!use[l]) continue;
@@ -671,18 +716,9 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
                 const Regime rgl = regime(ldx, ldy, a.bd_l), rgc = regime(cdx, cdy, a.bd_c);
                 const bool wh = __ballot(ldx) != 0, wvv = __ballot(ldy) != 0;      // over the lanes that run this list
                 const bool cwh = __ballot(cdx) != 0, cwv = __ballot(cdy) != 0;
-#define MC_S(H, V) mc_scu_list<H, V>(p, a.s_l, ru_ + off, rv_ + off, a.s_c, ch, cv, rgl, maxl, c2h, c2v, rgc, maxc, cwh, cwv, o, ou, ov)
-#define MC_C(H, V) do { mc_chroma_2x2<H, V>(ru_ + off, a.s_c, c2h, c2v, rgc, maxc, ou); mc_chroma_2x2<H, V>(rv_ + off, a.s_c, c2h, c2v, rgc, maxc, ov); } while (0)
-                if (ALL_FIRST) {
-                    if (wh) { if (wvv) MC_S(true, true); else MC_S(true, false); }
-                    else    { if (wvv) MC_S(false, true); else MC_S(false, false); }
-                } else {
-                    if (wh) { if (wvv) mc_luma_4x4<true, true>(p, a.s_l, ch, cv, rgl, maxl, o); else mc_luma_4x4<true, false>(p, a.s_l, ch, cv, rgl, maxl, o); }
-                    else    { if (wvv) mc_luma_4x4<false, true>(p, a.s_l, ch, cv, rgl, maxl, o); else mc_luma_4x4<false, false>(p, a.s_l, ch, cv, rgl, maxl, o); }
-                    if (cwh) { if (cwv) MC_C(true, true); else MC_C(true, false); }
-                    else     { if (cwv) MC_C(false, true); else MC_C(false, false); }
-                }
-#undef MC_C
+#define MC_S(H, V) mc_scu_list<H, V>(p, a.s_l, ru_ + off, rv_ + off, a.s_c, ch, cv, rgl, maxl, c2h, c2v, rgc, maxc, cwh, cwv, o, ou, ov, ldx != 0, ldy != 0, cdx != 0, cdy != 0)
+                if (wh) { if (wvv) MC_S(true, true); else MC_S(true, false); }
+                else    { if (wvv) MC_S(false, true); else MC_S(false, false); }
 #undef MC_S
             }
             if (nl == 0) {
@@ -699,6 +735,7 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
         }
     }
     TRACE_MARK(tr, 9);             // (split role: both lists' requests and arithmetic)
+    if (MODE == 0) load_resid();      // (split role: requested behind the lists - its twelve registers in front of them were the kernel's fourth wave per SIMD)
     if (nl == 0) return false;     // inter CU without a valid reference: nothing predicted (does not occur in valid streams)
 
     // ---- residual add + clip (xevd_recon.c:35-71; the LUMA bit depth clips all three components, :75-90) ----
@@ -758,7 +795,6 @@ static_assert(XGPU_INTER_STRIP == 16, "the strip arithmetic below shifts by four
 
 struct SplitTables { uint4 ref[XGPU_MAX_REFS * 2][2]; uint4 ltap[17]; uint2 ctap[33]; uint2 pad; };      // RefEntry [idx][list]; luma taps of this sequence's table, [16] = identity; chroma taps
 
-template <bool ALL_FIRST>
 __device__ __forceinline__ void inter_fused_body(const InterArgs &a)
 {
     __shared__ __attribute__((aligned(16))) int16_t s_win[REG_SAMPLES];      // region role: the shared windows + intermediates; tile role: four wave blocks
@@ -837,20 +873,18 @@ __device__ __forceinline__ void inter_fused_body(const InterArgs &a)
         else if (lane < 4 + 17 + 33) tb.ctap[lane - 21] = make_uint2(tab1.x, tab1.y);
         wave_lds_sync();
         TRACE_MARK(tr, 1);
-        if (inter_tile<0, ALL_FIRST>(a, c0, c1, ok, sx, sy, lane, nullptr, fm0, tb.ref, tb.ltap, tb.ctap, pl, pu, pv, nullptr, 0, own TRACE_PASS)) store_scu(a, sx, sy, pl, pu, pv);
+        if (inter_tile<0>(a, c0, c1, ok, sx, sy, lane, nullptr, fm0, tb.ref, tb.ltap, tb.ctap, pl, pu, pv, nullptr, 0, own TRACE_PASS)) store_scu(a, sx, sy, pl, pu, pv);
         TRACE_MARK(tr, 10);
     }
 }
-__global__ __launch_bounds__(256) void k_inter(const InterArgs a) { inter_fused_body<false>(a); }
-__global__ __launch_bounds__(256) void k_inter_af(const InterArgs a) { inter_fused_body<true>(a); }
+__global__ __launch_bounds__(256) void k_inter(const InterArgs a) { inter_fused_body(a); }
 
-// c->inter_all_first (XEVD_HIP_INTER_ALL_FIRST, read by xgpu_open; A/B measurements): the split role's requests all in front of its arithmetic (148 VGPRs instead of 127)
+// (the measurement knob XEVD_HIP_INTER_ALL_FIRST and its second kernel are gone: mc_scu_list's one form requests a list's luma window at once at four waves per SIMD)
 void launch_inter(xgpu_ctx *c, const InterArgs &a)
 {
     if (!a.n_work) return;
     const dim3 grid((unsigned)(((a.n_work + 7) >> 3) << 3));
-    if (c->inter_all_first) hipLaunchKernelGGL(k_inter_af, grid, dim3(256), 0, c->stream, a);
-    else hipLaunchKernelGGL(k_inter, grid, dim3(256), 0, c->stream, a);
+    hipLaunchKernelGGL(k_inter, grid, dim3(256), 0, c->stream, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -14,12 +14,22 @@ struct __attribute__((packed, aligned(2))) U32x1u { uint32_t a; };
 typedef const GAS int16_t *gs16;
 typedef uint32_t v4u32 __attribute__((ext_vector_type(4)));
 typedef uint32_t v2u32 __attribute__((ext_vector_type(2)));
+typedef uint32_t v3u32 __attribute__((ext_vector_type(3)));
 typedef v4u32 __attribute__((aligned(2))) v4u32_u;          // 16 / 8 / 4 bytes at a 2-byte aligned sample address (gfx950 unaligned-access mode)
 typedef v2u32 __attribute__((aligned(2))) v2u32_u;
+typedef v3u32 __attribute__((aligned(2))) v3u32_u;
 typedef uint32_t __attribute__((aligned(2))) u32_u;
 __device__ __forceinline__ uint4 gload16(gs16 p) { const v4u32 v = *(const GAS v4u32_u *)p; return make_uint4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ uint2 gload8(gs16 p) { const v2u32 v = *(const GAS v2u32_u *)p; return make_uint2(v.x, v.y); }
 __device__ __forceinline__ uint32_t gload4(gs16 p) { return *(const GAS u32_u *)p; }
+// Loads a lane may sit out of (its result is multiplied by zero then): the value stays ONE vector register tuple from the load to the fence behind the requests,
+// so that the place where the lane's branch joins the wave again needs no copy (a copy there waits for the load: one memory round trip per window row); a lane that
+// sat out keeps whatever the registers held (`any`: a definition without an instruction).
+template <typename T> __device__ __forceinline__ T any_value() { T v; asm volatile("" : "=v"(v)); return v; }
+__device__ __forceinline__ void gload16_if(v4u32 &v, gs16 p, bool on) { if (on) v = *(const GAS v4u32_u *)p; }
+__device__ __forceinline__ void gload8_if(v2u32 &v, gs16 p, bool on) { if (on) v = *(const GAS v2u32_u *)p; }
+__device__ __forceinline__ void gload12_if(v3u32 &v, gs16 p, bool on) { if (on) v = *(const GAS v3u32_u *)p; }
+__device__ __forceinline__ void gload4_if(uint32_t &v, gs16 p, bool on) { if (on) v = *(const GAS u32_u *)p; }
 
 __device__ __forceinline__ int dot2(uint32_t a, uint32_t b, int c)
 {

@@ -330,7 +330,6 @@ struct xgpu_ctx {
     int             have_frame;
     TileMask        no_dbk;            // tile borders the deblocking of the current picture leaves alone (set by xgpu_batch_recon)
     hipEvent_t      fork_ev, join_ev;  // k_dmvr / k_affine on the side stream beside k_inter: where they may start, where the kernel stream takes them back
-    int             inter_all_first;      // measurement knobs of launch_inter (k_inter.hip), read from the environment by xgpu_open
     int             builder_threads;   // xgpu_set_builder_threads: host threads xgpu_batch_create spreads its per-CU passes over (default 1)
     int             pad_done;          // the padding of the current picture has been written (by k_alf's border tiles): xgpu_pad launches nothing
     int             where;             // 0: the picture being built lives in its DPB slot, 1: in the scratch picture
