@@ -144,6 +144,31 @@ def test_gpu_split_role_whole_sample_vectors(admvp, bd):
             assert np.array_equal(out[c], ref.bufs[c]), f"seed {seed} plane {c}: {np.argwhere(out[c] != ref.bufs[c])[:4]}"
 
 
+@pytest.mark.gpu
+def test_gpu_intra_level1_sixteen_lanes_per_cu(monkeypatch):
+    """k_intra_l1: level-1 CUs of at most 16 SCUs reconstructed by 16 lanes each, four per wave (Baseline predictors; xevd_ipred.c:95-161, 587-676).  Large pictures take
+    that launch by themselves (cfg3 / cfg4 workloads, the 4K and 8K tests); here XEVD_HIP_INTRA_SMALL_MIN=1 (read per context) sends every picture golden without EIPD
+    / IBC / HTDF through it, and random pictures of small and oddly shaped CUs (binary / ternary splits: 32x8, 64x4, 4x16 ...) next to unavailable picture borders."""
+    monkeypatch.setenv("XEVD_HIP_INTRA_SMALL_MIN", "1")
+    n = 0
+    for case_name in golden_io.PICTURE_CASES:
+        case, exp = golden_io.load_picture_case(case_name)
+        if case.get("eipd") or not (case["batch"]["pred_mode"] == 0).any():
+            continue
+        out = cases.run_gpu(case)
+        n += 1
+        for c in range(3):
+            assert np.array_equal(out[c], exp["out"][c]), f"{case_name}: final plane {c}"
+    assert n >= 5
+    for seed, (w, h, bd, kw) in enumerate([(264, 136, 8, {"split_prob": 0.9, "inter_frac": 0.6}), (200, 328, 10, {"split_prob": 0.7, "inter_frac": 0.5, "btt_frac": 0.8}),
+                                            (136, 72, 8, {"split_prob": 1.0, "inter_frac": 0.3}), (328, 200, 10, {"split_prob": 0.5, "inter_frac": 0.8, "btt_frac": 0.6, "log2_ctu": 7})]):
+        cs = cases.build_case(f"l1_small_{seed}", w, h, bd, 1 if bd == 10 else 0, 0, (1, 1), 0.3, kw, seed=seed)
+        ref, _, _, _ = cases.run_cpu("oracle", cs)
+        out = cases.run_gpu(cs)
+        for c in range(3):
+            assert np.array_equal(out[c], ref.bufs[c]), f"random {seed} plane {c}: {np.argwhere(out[c] != ref.bufs[c])[:4]}"
+
+
 RANDOM = [
     # name, w, h, bd, admvp, iqt, n_refs, bi_frac, kwargs
     ("rnd_a", 264, 136, 8, 0, 0, (2, 1), 0.3, {}),

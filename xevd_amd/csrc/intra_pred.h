@@ -26,14 +26,14 @@ __device__ __forceinline__ uint32_t recon2i(uint32_t pred, uint32_t res, int max
 #define NB_LEN (NB_UR + 256)
 
 // N consecutive neighbour entries for the block at (lx, ly): v[k]; the sample at row r, column q is v[sel(mode, r, q)]
-template <int N>
+template <int N, int C0 = NB_C0, int UR = NB_UR>
 __device__ __forceinline__ void nb_fetch(const int16_t *nb, int mode, int lx, int ly, int v[N])
 {
     int base = NB_DC, step = 0;
-    if (mode == 1) { base = NB_C0 - 1 - ly; step = -1; }
-    if (mode == 2) { base = NB_C0 + 1 + lx; step = 1; }
-    if (mode == 3) { base = NB_C0 + lx - ly - (N >> 1); step = 1; }
-    if (mode == 4) { base = NB_UR + lx + ly + 1; step = 1; }
+    if (mode == 1) { base = C0 - 1 - ly; step = -1; }
+    if (mode == 2) { base = C0 + 1 + lx; step = 1; }
+    if (mode == 3) { base = C0 + lx - ly - (N >> 1); step = 1; }
+    if (mode == 4) { base = UR + lx + ly + 1; step = 1; }
 #pragma unroll
     for (int k = 0; k < N; k++) v[k] = (uint16_t)nb[base + step * k];
 }
@@ -71,6 +71,14 @@ struct EipdPlan { int mode, p0, p1, p2, lr; };  // wave-uniform: DC p0 = value; 
 
 // sum over the 64 lanes, the same value in every lane: two quad permutes and two mirrors in DPP leave every lane of a row of 16 with the row's sum, the four row
 // sums meet on the scalar unit (six rounds of __shfl_xor were six LDS-crossbar round trips on the critical path of every DC / planar CU of a dependency chain)
+__device__ __forceinline__ int row_sum16(int v)      // the sum over a row of 16 lanes, in every lane of the row
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);      // quad_perm [2, 3, 0, 1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);     // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);     // row_mirror
+    return v;
+}
 __device__ __forceinline__ int wave_sum(int v)
 {
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);      // quad_perm [1, 0, 3, 2]

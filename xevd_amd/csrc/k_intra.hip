@@ -589,6 +589,151 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Level 1, Baseline predictors, CUs of at most 16 SCUs (any shape from 4x4 to 16x16, 32x8, 64x4): SIXTEEN LANES per CU, four CUs per wave.
+// With a wave per CU the level-1 launch of an 8K P/B picture was 15.7 thousand waves for CUs of which most use one to four lanes - 2.6 rounds of the machine's wave
+// slots, each the length of a wave's three dependent memory round trips (record -> neighbours + residual -> stores).  The list is sorted by size inside a level, so
+// these CUs are the END of the level's range (IntraArgs.n_small, counted by the host's plan): the launch gives the large CUs a wave each as before and the small ones a
+// row of 16 lanes each.  Everything that is wave-uniform in intra_body is uniform per row here; the DC sum is a DPP row reduction; the neighbour arrays are the
+// same diagonal-axis layout in a compact form (at most 68 samples per side).  No lane of a row waits for another row: LDS traffic of a wave is in order.
+// ---------------------------------------------------------------------------------------------------------
+#define SB_C0 71             // odd, like NB_C0: pairs of up[] are 4-byte aligned
+#define SB_UR 144
+#define SB_LEN (SB_UR + 72)
+#define SMALL_GROUPS (4 * INTRA_WAVES)      // CUs per workgroup
+__device__ __forceinline__ void intra_small_body(const IntraArgs &a, uint32_t block, int16_t *s_nb_)
+{
+    int16_t (*s_nb)[3][SB_LEN] = (int16_t (*)[3][SB_LEN])s_nb_;
+    const int g = threadIdx.x >> 4, t = threadIdx.x & 15;
+    const uint32_t k = block * SMALL_GROUPS + (uint32_t)g;
+    if (k >= (uint32_t)a.n_small) return;
+    const uint32_t item = (uint32_t)(a.first + a.count - a.n_small) + k;
+    int16_t (*nb)[SB_LEN] = s_nb[g];
+    const int mid = 1 << (a.bd_l - 1), maxv = (1 << a.bd_l) - 1;
+    const uint4 *rec = (const uint4 *)&a.list[item];
+    const uint4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+    const uint32_t nflags = q0.y, avail_ul = nflags & 1;
+    const int lrf = (int)((nflags >> 23) & 3);
+    const uint64_t avail_up = (uint64_t)q0.z | ((lrf & 2) ? 0ull : (uint64_t)q0.w << 32);      // (the Baseline predictors have no right-hand form: a right mask in the word is not the up mask's upper half)
+    const uint64_t avail_le = (uint64_t)q1.x | ((uint64_t)q1.y << 32);
+    const uint32_t gg = q2.x, m = q2.y, ipm = q2.z, coef_off = q2.w;
+    const int cu_x = gg & 0xFFFF, cu_y = gg >> 16;
+    const int lw = m & 0xFF, lh = (m >> 8) & 0xFF, cbf = (m >> 16) & 0xFF;
+    const int mode_l = ipm & 0xFF, mode_c = (ipm >> 8) & 0xFF;
+    const int cw = 1 << lw, chh = 1 << lh, scuw = cw >> 2, nscu = scuw * (chh >> 2), cwc = cw >> 1;
+    const uint32_t off_u = coef_off + ((cbf & 1) ? (uint32_t)(cw * chh) : 0u);
+    const uint32_t off_v = off_u + ((cbf & 2) ? (uint32_t)(cwc * (chh >> 1)) : 0u);
+    const bool has = t < nscu;
+    const int lx = (t & (scuw - 1)) << 2, ly = (t >> (lw - 2)) << 2;
+
+    // the residual of the lane's SCU depends on no neighbour: requested first
+    uint2 rl[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
+    uint32_t rc[2][2] = { { 0, 0 }, { 0, 0 } };
+    if (has) {
+        if (cbf & 1)
+#pragma unroll
+            for (int r = 0; r < 4; r++) rl[r] = *(const uint2 *)(a.resid + coef_off + (ly + r) * cw + lx);
+#pragma unroll
+        for (int c = 1; c < 3; c++)
+            if ((cbf >> c) & 1)
+#pragma unroll
+                for (int r = 0; r < 2; r++) rc[c - 1][r] = *(const uint32_t *)(a.resid + (c == 1 ? off_u : off_v) + ((ly >> 1) + r) * cwc + (lx >> 1));
+    }
+
+    // ---- neighbour staging (xevd_get_nbr_b): every position of the arrays lies inside the padded picture, so the loads are unconditional (an element beyond the
+    //      side's length repeats its last one: same address, same request) and availability is a select afterwards - no branch around a load, all of them in flight
+    //      together.  One round covers a side of 32 samples (up: a dword per lane; left: two samples per lane); the wide shapes (32x8, 64x4) take a second pass. ----
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int16_t *plane = c == 0 ? a.cur_y : (c == 1 ? a.cur_u : a.cur_v);
+        const int s = c ? a.s_c : a.s_l, sh = c ? 1 : 0, ush = c ? 1 : 2;
+        const int16_t *org = plane + (cu_y >> sh) * s + (cu_x >> sh);
+        const int n = (cw + chh) >> sh;
+        const int eu = min(2 * t, n - 2), e0 = min(t, n - 1), e1 = min(t + 16, n - 1);
+        const uint32_t vu = *(const uint32_t *)(org - s + eu);
+        const uint32_t v0 = (uint16_t)org[e0 * s - 1], v1 = (uint16_t)org[e1 * s - 1], vc = (uint16_t)org[-s - 1];
+        const uint32_t midp = (uint32_t)mid * 0x10001u;
+        if (2 * t < n) *(uint32_t *)&nb[c][SB_C0 + 1 + 2 * t] = ((avail_up >> (eu >> ush)) & 1) ? vu : midp;
+        if (t < n) nb[c][SB_C0 - 1 - t] = (int16_t)(((avail_le >> (e0 >> ush)) & 1) ? v0 : (uint32_t)mid);
+        if (t + 16 < n) nb[c][SB_C0 - 1 - (t + 16)] = (int16_t)(((avail_le >> (e1 >> ush)) & 1) ? v1 : (uint32_t)mid);
+        if (t == 0) nb[c][SB_C0] = (int16_t)(avail_ul ? vc : (uint32_t)mid);
+        if (n > 32) {
+            for (int e = 2 * t + 32; e < n; e += 32)
+                *(uint32_t *)&nb[c][SB_C0 + 1 + e] = ((avail_up >> (e >> ush)) & 1) ? *(const uint32_t *)(org - s + e) : midp;
+            for (int e = t + 32; e < n; e += 16)
+                nb[c][SB_C0 - 1 - e] = ((avail_le >> (e >> ush)) & 1) ? org[e * s - 1] : (int16_t)mid;
+        }
+    }
+    wave_lds_sync();
+    // ---- DC values (ipred_dc_b): (sum of h left + w up samples + w) >> (log2 w + 1); IPD_UR_B: the averaged diagonal ----
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int mode = c ? mode_c : mode_l;
+        const int w = c ? cw >> 1 : cw, h = c ? chh >> 1 : chh;
+        if (mode == 0) {
+            int acc = 0;
+            for (int e = t; e < w + h; e += 16) acc += e < h ? nb[c][SB_C0 - 1 - e] : nb[c][SB_C0 + 1 + e - h];
+            acc = row_sum16(acc);                                // (rows whose CU has another mode run the instruction with a zero: DPP reads active lanes only)
+            if (t == 0) nb[c][NB_DC] = (int16_t)((acc + w) >> ((c ? lw - 1 : lw) + 1));
+        } else if (mode == 4) {
+            for (int e = t; e < w + h; e += 16) nb[c][SB_UR + e] = (int16_t)((nb[c][SB_C0 + 1 + e] + nb[c][SB_C0 - 1 - e]) >> 1);
+        }
+    }
+    wave_lds_sync();
+    if (!has) return;
+    // ---- prediction + reconstruction of the lane's SCU (as intra_body's Baseline pass) ----
+    const int x = cu_x + lx, y = cu_y + ly;
+    int pl[4][4], pc[2][2][2];
+    int vl[7], vc[2][3];
+    nb_fetch<7, SB_C0, SB_UR>(nb[0], mode_l, lx, ly, vl);
+    nb_fetch<3, SB_C0, SB_UR>(nb[1], mode_c, lx >> 1, ly >> 1, vc[0]);
+    nb_fetch<3, SB_C0, SB_UR>(nb[2], mode_c, lx >> 1, ly >> 1, vc[1]);
+#pragma unroll
+    for (int md = 0; md < 5; md++) {
+        if (md == mode_l)
+#pragma unroll
+            for (int r = 0; r < 4; r++)
+#pragma unroll
+                for (int q = 0; q < 4; q++) pl[r][q] = vl[nb_sel(md, r, q, 3)];
+        if (md == mode_c)
+#pragma unroll
+            for (int c = 0; c < 2; c++)
+#pragma unroll
+                for (int r = 0; r < 2; r++)
+#pragma unroll
+                    for (int q = 0; q < 2; q++) pc[c][r][q] = vc[c][nb_sel(md, r, q, 1)];
+    }
+    int16_t *dy = a.cur_y + y * a.s_l + x;
+    const int coff = (y >> 1) * a.s_c + (x >> 1);
+    if (!(nflags & 32u))                                         // (local dual tree: a chroma-only CU leaves luma alone, a luma-only one chroma)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            // also without coefficients: the reference clips the prediction (xevd_recon.c:44-51)
+            const uint32_t o0 = recon2i(pack2i(pl[r][0], pl[r][1]), (cbf & 1) ? rl[r].x : 0u, maxv), o1 = recon2i(pack2i(pl[r][2], pl[r][3]), (cbf & 1) ? rl[r].y : 0u, maxv);
+            *(uint2 *)(dy + r * a.s_l) = make_uint2(o0, o1);
+        }
+    if (!(nflags & 64u))
+#pragma unroll
+        for (int c = 1; c < 3; c++) {
+            int16_t *d = (c == 1 ? a.cur_u : a.cur_v) + coff;
+#pragma unroll
+            for (int r = 0; r < 2; r++)
+                *(uint32_t *)(d + r * a.s_c) = recon2i(pack2i(pc[c - 1][r][0], pc[c - 1][r][1]), ((cbf >> c) & 1) ? rc[c - 1][r] : 0u, maxv);      // the luma depth clips chroma too (xevd_recon.c:75-90)
+        }
+}
+
+// the level-1 launch of pictures with the Baseline predictors and none of the other node kinds: workgroups [0, big) take a large CU per wave, the rest 32 small CUs each
+__global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra_l1(const IntraArgs a, uint32_t big)
+{
+    constexpr int BIG_LDS = INTRA_WAVES * IntraLds<false>::WAVE, SMALL_LDS = SMALL_GROUPS * 3 * SB_LEN;
+    __shared__ __attribute__((aligned(16))) int16_t s_nb[BIG_LDS > SMALL_LDS ? BIG_LDS : SMALL_LDS];
+    if (blockIdx.x < big) {
+        IntraArgs b = a;
+        b.count = a.count - a.n_small;
+        intra_body<false, 0, false, false, INTRA_WAVES>(b, blockIdx.x, s_nb, nullptr);
+    } else intra_small_body(a, blockIdx.x - big, s_nb);
+}
+
 template <bool DEP, int EIPD, bool IBC, bool HTDF>
 __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 {
@@ -651,6 +796,13 @@ void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf
         return;
     }
     const int per = INTRA_WAVES;
+    // (pictures whose level 1 fits into the machine's wave slots a few times over keep the wave per CU: 1080p, 1059 CUs: 28.9 us against 29.6; 4K, 4129: 35.5 -> 34.8;
+    //  8K, 15727: 58.1 -> 51.9 - both intra launches, tools/r5_v.sh; XEVD_HIP_INTRA_SMALL_MIN moves the limit - the GPU tests run the small pictures with 1)
+    if (!dep && !right && !htdf && !ibc && !c->sp.tool_eipd && a.n_small >= c->intra_small_min) {
+        const uint32_t big = (uint32_t)((a.count - a.n_small + per - 1) / per), small_blocks = (uint32_t)((a.n_small + SMALL_GROUPS - 1) / SMALL_GROUPS);
+        hipLaunchKernelGGL(k_intra_l1, dim3(big + small_blocks), dim3(64 * INTRA_WAVES), 0, c->stream, a, big);
+        return;
+    }
     const int blocks = (a.count + per - 1) / per;
     const dim3 g(blocks), b(64 * INTRA_WAVES);
 #define LAUNCH(D, E, I, H) hipLaunchKernelGGL((k_intra<D, E, I, H>), g, b, 0, c->stream, a)

@@ -121,6 +121,7 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     c->builder_threads = 1;
     c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_dra = NULL; c->d_ctb_flag = NULL; c->stream = 0; c->up_stream = 0; c->down_stream = 0; c->side_stream = 0; c->after_inter = 0; c->have_after_inter = 0; c->where = 0; c->addb_pending = 0;
     c->fork_ev = c->join_ev = 0;
+    c->intra_small_min = getenv("XEVD_HIP_INTRA_SMALL_MIN") ? std::max(1, atoi(getenv("XEVD_HIP_INTRA_SMALL_MIN"))) : 2048;      // (k_intra.hip: launch_intra; read per context, tests set 1)
     c->split_addb_alf = getenv("XEVD_HIP_SPLIT_ADDB_ALF") != NULL;      // measurement knob: ADDB and ALF as two kernels (the round-2 chain) instead of k_addb_alf
     for (int i = 0; i < 2; i++) { c->d_out[i] = NULL; c->out_caps[i] = 0; c->out_ready[i] = c->out_done[i] = 0; c->out_busy[i] = 0; }
     c->out_next = 0;

@@ -24,7 +24,7 @@ static inline int plan_htdf_idx(const xgpu_cu_batch *b, uint32_t j)
 }
 static inline bool plan_is_node(const xgpu_cu_batch *b, uint32_t j) { return b->pred_mode[j] == XGPU_MODE_INTRA || b->pred_mode[j] == XGPU_MODE_IBC || plan_htdf_idx(b, j) >= 0; }
 
-struct IntraPlan { std::vector<IntraRec> recs; std::vector<uint32_t> deps; int n_levels, n_level1, n_heads; bool has_ibc, has_htdf, has_right; };      // n_heads: level-1 CUs + strand heads = the part of the list the launches range over
+struct IntraPlan { std::vector<IntraRec> recs; std::vector<uint32_t> deps; int n_levels, n_level1, n_level1_small, n_heads; bool has_ibc, has_htdf, has_right; };      // n_heads: level-1 CUs + strand heads = the part of the list the launches range over
 static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &plan, const uint32_t *final_owner, int nthr, WorkPool &pool, const std::vector<uint32_t> &nodes)
 {
     const int hqp = b->htdf_slice_qp;
@@ -348,6 +348,8 @@ static bool build_intra_plan(xgpu_ctx *c, const xgpu_cu_batch *b, IntraPlan &pla
     size_t n_entries = 0;
     for (size_t ri = 0; ri < recs.size(); ri++) { const int np = parts_of(recs[ri]); first[key(ri) + 1] += np; n_entries += (size_t)np; }
     for (size_t l = 1; l < first.size(); l++) first[l] += first[l - 1];
+    // the level-1 entries of at most 16 SCUs (log2 w + log2 h <= 8: key 16 + 6 and up) end the level's part of the list: k_intra gives them 16 lanes each
+    plan.n_level1_small = max_level >= 1 ? first[2 * 16] - first[16 + 6] : 0;
     static thread_local std::vector<uint32_t> pos;                    // CU index -> list position of its first part
     pos.assign((size_t)n, NONE);
     plan.recs.resize(n_entries);
@@ -571,7 +573,7 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
     static thread_local IntraPlan plan_tl;                 // (kept between pictures: see build_intra_plan)
     IntraPlan &plan = plan_tl;
     plan.recs.clear(); plan.deps.clear();
-    plan.n_levels = 0; plan.n_level1 = 0; plan.n_heads = 0;
+    plan.n_levels = 0; plan.n_level1 = 0; plan.n_level1_small = 0; plan.n_heads = 0;
     bool any_intra = false;
     plan.has_ibc = false; plan.has_htdf = false; plan.has_right = false;
     // SCU -> CU map of the picture (k_inter's lanes find their CU through it; the dependency plan reads "reconstructed before" off it); SCUs outside the batch -
@@ -671,7 +673,7 @@ static int batch_build(xgpu_ctx *c, const xgpu_cu_batch *b, xgpu_dbatch **out, b
 
     xgpu_dbatch *db = new xgpu_dbatch();
     memset(db, 0, sizeof(*db));
-    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_intra_heads = plan.n_heads; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->n_dmvr = n_dmvr; db->has_ibc = plan.has_ibc ? 1 : 0; db->has_htdf = plan.has_htdf ? 1 : 0; db->has_right = plan.has_right ? 1 : 0; db->order_rl = order_rl ? 1 : 0;
+    db->n_cu = n; db->n_ctu = b->n_ctu; db->n_tb = n_tb; db->n_waves = n_waves; db->n_coef = b->n_coef; db->n_intra = n_intra; db->n_intra_deps = n_deps; db->n_levels = plan.n_levels; db->n_intra_l1 = plan.n_level1; db->n_intra_l1_small = plan.n_level1_small; db->n_intra_heads = plan.n_heads; db->n_aff_eif = n_aff_eif; db->n_aff_sub = n_aff_sub; db->n_dmvr = n_dmvr; db->has_ibc = plan.has_ibc ? 1 : 0; db->has_htdf = plan.has_htdf ? 1 : 0; db->has_right = plan.has_right ? 1 : 0; db->order_rl = order_rl ? 1 : 0;
     db->tile_starts = tmask; db->tiles_across = b->tiles ? (b->tiles->loop_filter_across_tiles ? 1 : 0) : 1;
     const size_t sz_cus = sizeof(CuRec) * (size_t)std::max(n, 1), sz_ctu = sizeof(uint32_t) * (size_t)(b->n_ctu + 1);
     const size_t sz_tbs = sizeof(TbRec) * (size_t)std::max(n_tb, 1), sz_wv = sizeof(TbWave) * (size_t)std::max(n_waves, 1);

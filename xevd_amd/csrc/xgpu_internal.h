@@ -189,6 +189,7 @@ struct IntraArgs {
     uint32_t  epoch, ticket_base;
     int       n_intra;        // list length (the ticket counter sits at done[n_intra])
     int       first, count;   // the list range this launch covers
+    int       n_small;        // level-1 launch: the LAST n_small entries of the range are CUs of at most 16 SCUs (the list is sorted by size inside a level): 16 lanes per CU (k_intra.hip)
 };
 
 struct ItdqArgs {
@@ -293,6 +294,7 @@ struct xgpu_dbatch {
     int        has_right;             // ... CUs whose right-hand neighbours are reconstructed first (sps_suco_flag): the instantiations that know the right reference column
     TileMask   tile_starts;           // of the batch's tile grid (zero: one tile)
     int        tiles_across;          // its loop_filter_across_tiles
+    int        n_intra_l1_small;      // of the level-1 entries, the ones with at most 16 SCUs (log2 w + log2 h <= 8): they end the level's part of the list
     int        n_intra, n_levels, n_intra_deps, n_intra_l1, n_intra_heads;      // n_intra_l1: CUs of level 1 (head of the list); n_intra_heads: + the strand heads of the data-flow launch (the strand members follow)
     uint32_t   intra_epoch, intra_tickets;
     void      *h_stage;               // pinned staging block
@@ -334,6 +336,7 @@ struct xgpu_ctx {
     int             pad_done;          // the padding of the current picture has been written (by k_alf's border tiles): xgpu_pad launches nothing
     int             where;             // 0: the picture being built lives in its DPB slot, 1: in the scratch picture
     int             order_rl;          // a batch of the picture has CUs decoded after their right-hand neighbours (xgpu_dbatch.order_rl): k_dbk's order-aware instantiation
+    int             intra_small_min;   // level-1 launches with at least this many CUs of at most 16 SCUs give those 16 lanes each (k_intra_l1; XEVD_HIP_INTRA_SMALL_MIN, default 2048)
     int             addb_pending, split_addb_alf;      // ADDB + ALF in one kernel: xgpu_deblock left its arguments in addb_args for xgpu_alf
     AddbArgs        addb_args;
     // timing

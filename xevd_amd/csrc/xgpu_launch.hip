@@ -147,9 +147,9 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
             const bool ride = next && n_dep > 0 && !c->timing && !db->has_htdf && (na = itdq_args(c, next), na.n_waves > 0);
             if (ride) { const int rc = wait_next(); if (rc != XGPU_OK) return rc; }
             TIMED(c, XGPU_K_INTRA, {
-                ta.first = 0; ta.count = db->n_intra_l1;
+                ta.first = 0; ta.count = db->n_intra_l1; ta.n_small = db->n_intra_l1_small;
                 if (ta.count) launch_intra(c, ta, false, db->has_ibc != 0, db->has_htdf != 0, NULL, db->has_right != 0);
-                ta.first = db->n_intra_l1; ta.count = n_dep;
+                ta.first = db->n_intra_l1; ta.count = n_dep; ta.n_small = 0;
                 if (n_dep) {
                     launch_intra(c, ta, true, db->has_ibc != 0, db->has_htdf != 0, ride ? &na : NULL, db->has_right != 0);
                     const int chunk = intra_chunk(ride);
