@@ -754,6 +754,9 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 // (Round 3, measured and dropped: ONE launch for all levels - the level-1 CUs at the head of this launch's list, publishing flags like everybody else, strand
 // members waiting for their level-1 CUs - instead of the plain level-1 launch in front: bit-exact, 8K 2764 -> 2587 frames/s, 4K 8172 -> 7860, 1080p 10996 -> 11163.)
 #define FUSED_WAVES 4
+// (Round 5: the residual pass alone needs 44 VGPRs, this kernel 121 - 145 because of the chain's side, so the pass rides at half its own occupancy.  Holding the kernel to
+//  96 / 80 / 64 VGPRs (amdgpu_waves_per_eu 5 / 6 / 8: 72 / 172 / 236 bytes of scratch, all in the chain's side) measured 3035 / 2740 / 2602 frames/s against 3052 at 8K, 8050 /
+//  6820 / 6300 against 8600 at 4K: the launch is as long as its chain, and spills lengthen every link of it.  tools/r5_w.sh)
 template <int EIPD, bool IBC, bool IQT>
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_intra_itdq(const IntraArgs a, const ItdqArgs r, uint32_t n_intra_wg, uint32_t span)
 {
