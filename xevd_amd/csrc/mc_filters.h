@@ -191,8 +191,8 @@ __device__ __forceinline__ void mc_chroma_2x2(gs16 p, int s, const uint32_t ch[2
     for (int j = V ? 0 : 1; j < (V ? 5 : 3); j++) {
         int t[2];
         if (H) {
-            const uint2 a = gload8(p + j * s);
-            const uint32_t D0 = a.x, D1 = a.y, D2 = gload4(p + j * s + 4);
+            const v3u32 a = *(const GAS v3u32_u *)(p + j * s);      // six samples in ONE 12-byte request (rounds 1 - 4: 8 + 4 bytes)
+            const uint32_t D0 = a.x, D1 = a.y, D2 = a.z;
             const uint32_t Q0 = hi_lo(D1, D0), Q1 = hi_lo(D2, D1);
             t[0] = dot2(ch[1], D1, dot2z(ch[0], D0));
             t[1] = dot2(ch[1], Q1, dot2z(ch[0], Q0));
