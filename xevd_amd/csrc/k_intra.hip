@@ -147,7 +147,10 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
         // parts: a large CU sits in the list several times (the host's plan, xgpu_builder.hip: one entry per step of 64 units / SCUs, each with its own done flag); every part
         // stages the neighbours and derives the plan, and reconstructs the units [u_lo, u_hi) / the SCUs [s_lo, s_hi)
         const int part = (int)(m >> 24), nparts = max(1, (int)((ipm >> 16) & 0xFF));
-        const int u_lo = part * (nunit / nparts), u_hi = u_lo + nunit / nparts, s_lo = part * (nscu / nparts), s_hi = s_lo + nscu / nparts;
+        // (shifts and masks: widths, SCU counts and part counts are powers of two - left as divisions by values only known at run time they were three
+        //  reciprocal sequences of ~30 dependent instructions each on the critical path of every link of a chain)
+        const int lparts = 31 - __builtin_clz((unsigned)nparts), lscuw = lw - 2;
+        const int u_lo = part * (nunit >> lparts), u_hi = u_lo + (nunit >> lparts), s_lo = part * (nscu >> lparts), s_hi = s_lo + (nscu >> lparts);
         uint2 ul[4] = { { 0, 0 }, { 0, 0 }, { 0, 0 }, { 0, 0 } };
         uint32_t uc[4] = { 0, 0, 0, 0 };
         auto fetch_units = [&](int u0) {
@@ -162,7 +165,7 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
             }
         };
         if (EIPD) fetch_units(u_lo + t);
-        else if (s_lo + t < s_hi) fetch_resid(((s_lo + t) % scuw) << 2, ((s_lo + t) / scuw) << 2);
+        else if (s_lo + t < s_hi) fetch_resid(((s_lo + t) & (scuw - 1)) << 2, ((s_lo + t) >> lscuw) << 2);
 
         ISTAMP(0);
         if (DEP) {      // wait until the intra CUs this one reads from have published their samples
@@ -370,13 +373,13 @@ __device__ __forceinline__ void intra_body(const IntraArgs &a, uint32_t block, i
         }
         } else
         for (int sidx = s_lo + t; sidx < (htdf_only ? 0 : s_hi); sidx += 64) {
-            const int lx = (sidx % scuw) << 2, ly = (sidx / scuw) << 2;
+            const int lx = (sidx & (scuw - 1)) << 2, ly = (sidx >> lscuw) << 2;
             const int x = cu_x + lx, y = cu_y + ly;
             // a CU above 32x32 takes several rounds: the residual of the NEXT round is requested before this round's arithmetic, so that a round does not
             // start with a memory round trip (the level-1 launch is as long as its 64x64 CUs take)
             const uint2 rl_cur[4] = { rl[0], rl[1], rl[2], rl[3] };
             const uint32_t rc_cur[2][2] = { { rc[0][0], rc[0][1] }, { rc[1][0], rc[1][1] } };
-            if (sidx + 64 < s_hi) fetch_resid(((sidx + 64) % scuw) << 2, ((sidx + 64) / scuw) << 2);
+            if (sidx + 64 < s_hi) fetch_resid(((sidx + 64) & (scuw - 1)) << 2, ((sidx + 64) >> lscuw) << 2);
             int pl[4][4], pc[2][2][2];
             if (IBC && ibc_cu) {
                 // xevdm_IBC_mc (xevdm_mc.c:2040-2106): the block at the whole-sample vector in the current picture, chroma at the halved vector.
