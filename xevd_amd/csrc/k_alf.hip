@@ -171,7 +171,9 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
     const int per_xcd = gridDim.x >> 3, xcd = blockIdx.x & 7, seq = blockIdx.x >> 3;
     const int tile = xcd * per_xcd + (xcd >= 4 ? per_xcd - 1 - seq : seq);
     if (tile >= n_tiles) return;
-    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    // (tile / tiles_x by a multiplication: tiles_x is only known at run time, and the division was a reciprocal sequence of ~30 instructions in front of every tile of a
+    //  kernel that is bound by instruction issue; floor(2^32 / d) + 1 is exact for n x d < 2^32)
+    const int ty = (int)__umulhi((uint32_t)tile, a.magic_tiles_x), tx = tile - ty * tiles_x;
     const int tx0 = tx << 6, ty0 = ty << 6;
     const int t = threadIdx.x;
 #ifdef XGPU_ALF_TRACE
@@ -698,9 +700,11 @@ __global__ __launch_bounds__(256) void k_addb_alf(const AlfArgs a, const AddbArg
     alf_kernel<true, PK>(a, &d, sy_, su_, sv_, dy_, du_, dv_);
 }
 
-void launch_alf(xgpu_ctx *c, const AlfArgs &a, const AddbArgs *deblock, const DevPic &src, const DevPic &dst)
+void launch_alf(xgpu_ctx *c, const AlfArgs &a_, const AddbArgs *deblock, const DevPic &src, const DevPic &dst)
 {
+    AlfArgs a = a_;
     const int tiles = ((a.pic_w + 63) >> 6) * ((a.pic_h + 63) >> 6);
+    a.magic_tiles_x = (uint32_t)((1ull << 32) / (uint64_t)((a.pic_w + 63) >> 6)) + 1u;
     const dim3 grid(((tiles + 7) >> 3) << 3);
     static const bool scalar_knob = getenv("XEVD_HIP_ADDB_SCALAR") != NULL;
     static const int lds_pad = getenv("XEVD_HIP_ALF_LDSPAD") ? atoi(getenv("XEVD_HIP_ALF_LDSPAD")) : 0;      // measurement knob: dynamic LDS that only lowers the occupancy

@@ -761,7 +761,7 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 //  96 / 80 / 64 VGPRs (amdgpu_waves_per_eu 5 / 6 / 8: 72 / 172 / 236 bytes of scratch, all in the chain's side) measured 3035 / 2740 / 2602 frames/s against 3052 at 8K, 8050 /
 //  6820 / 6300 against 8600 at 4K: the launch is as long as its chain, and spills lengthen every link of it.  tools/r5_w.sh)
 template <int EIPD, bool IBC, bool IQT>
-__global__ __launch_bounds__(64 * FUSED_WAVES) void k_intra_itdq(const IntraArgs a, const ItdqArgs r, uint32_t n_intra_wg, uint32_t span)
+__global__ __launch_bounds__(64 * FUSED_WAVES) void k_intra_itdq(const IntraArgs a, const ItdqArgs r, uint32_t n_intra_wg, uint64_t rate)
 {
     constexpr int ITDQ_DW = (IQT ? ITDQ_LDS_DWORDS - ITDQ_PLANES_DWORDS / 2 : ITDQ_LDS_DWORDS) + 2 * ITDQ_MAX_G, INTRA_DW = (FUSED_WAVES * IntraLds<false>::WAVE + 1) / 2 + 4;
     __shared__ __attribute__((aligned(16))) uint32_t raw[ITDQ_DW > INTRA_DW ? ITDQ_DW : INTRA_DW];
@@ -770,7 +770,9 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_intra_itdq(const IntraArgs
     // mostly wait took half the machine's wave slots from the residual pass for the whole length of the chain, and the pass was the long pole of the launch.
     // One box, share of the grid the chain is spread over 0 (all in front) / 25 / 50 / 75 / 100 %: 8K 2697 / 2772 / 2790 / 2792 / 2735 frames/s, 4K 8183 / 8066 / 8194 /
     // 8068 / 7795.
-    const uint32_t before = min(n_intra_wg, (uint32_t)(((uint64_t)blockIdx.x * n_intra_wg) / span)), after = min(n_intra_wg, (uint32_t)(((uint64_t)(blockIdx.x + 1) * n_intra_wg) / span));
+    // (`rate` = ceil(2^32 n_intra_wg / span), from the host: the chain's share of the blocks before this one is a multiplication - the two 64-bit divisions that stood here
+    //  were in front of every work item of the residual pass too)
+    const uint32_t before = min(n_intra_wg, (uint32_t)(((uint64_t)blockIdx.x * rate) >> 32)), after = min(n_intra_wg, (uint32_t)(((uint64_t)(blockIdx.x + 1) * rate) >> 32));
     if (after > before) {
         // (s_setprio 3 for the chain's waves, so that a wave whose flags have arrived is not kept waiting by the residual pass's: measured, nothing - 8K 3053 / 3100 / 3054
         //  frames/s without, 3040 / 3059 / 3117 with, tools/r5_w.sh)
@@ -796,7 +798,8 @@ void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf
         const dim3 g(n_wg + (uint32_t)next->n_waves), b(64 * FUSED_WAVES);
         // the chain's workgroups spread evenly over the first half of the grid (k_intra_itdq)
         const uint32_t span = std::max(n_wg, g.x / 2);
-#define LAUNCHF(E, I) do { if (next->iqt) hipLaunchKernelGGL((k_intra_itdq<E, I, true>), g, b, 0, c->stream, a, *next, n_wg, span); else hipLaunchKernelGGL((k_intra_itdq<E, I, false>), g, b, 0, c->stream, a, *next, n_wg, span); } while (0)
+        const uint64_t rate = (((uint64_t)n_wg << 32) + span - 1) / span;      // <= 2^32: every chain workgroup 0 .. n_wg - 1 is some block's, in order, inside the first `span` blocks
+#define LAUNCHF(E, I) do { if (next->iqt) hipLaunchKernelGGL((k_intra_itdq<E, I, true>), g, b, 0, c->stream, a, *next, n_wg, rate); else hipLaunchKernelGGL((k_intra_itdq<E, I, false>), g, b, 0, c->stream, a, *next, n_wg, rate); } while (0)
         if (right) LAUNCHF(2, true);
         else if (c->sp.tool_eipd) { if (ibc) LAUNCHF(1, true); else LAUNCHF(1, false); }
         else                 { if (ibc) LAUNCHF(0, true); else LAUNCHF(0, false); }

@@ -253,6 +253,7 @@ struct AddbArgs {
 struct AlfArgs {
     int      s_l, s_c, pic_w, pic_h, bd, log2_ctu, w_ctu, across_tiles;
     TileMask tiles;                    // tile starts: a CTU's windows end at its tile (alf_process_tile)
+    uint32_t magic_tiles_x;            // floor(2^32 / tiles per row) + 1, set by launch_alf: tile / tiles_x as a multiplication
     int      multi_tile;               // 0: one tile - the masks are not looked at
     int      pad;                      // 1: the tiles on the picture border also write the 144 / 72-sample padding of the output picture (no k_pad launch)
     int      enable[3];
