@@ -8,11 +8,14 @@
 __device__ __forceinline__ uint32_t pack2i(int lo, int hi) { return ((uint32_t)lo & 0xFFFFu) | ((uint32_t)hi << 16); }
 __device__ __forceinline__ int clip3i(int lo, int hi, int v) { return min(max(v, lo), hi); }
 // rec = clip(0, max, (s16)(res + pred)) on packed pairs: the 16-bit sum wraps (xevd_recon.c:39,60)
+// (packed 16-bit instructions - v_pk_add_u16, v_pk_max_i16, v_pk_min_i16: three for the pair; the halves taken apart, sign-extended, clipped and packed again were ten,
+//  twelve pairs per SCU on the path of every link of a dependency chain)
 __device__ __forceinline__ uint32_t recon2i(uint32_t pred, uint32_t res, int maxv)
 {
-    const int lo = (int)(int16_t)((pred & 0xFFFFu) + (res & 0xFFFFu));
-    const int hi = (int)(int16_t)((pred >> 16) + (res >> 16));
-    return pack2i(clip3i(0, maxv, lo), clip3i(0, maxv, hi));
+    typedef short v2s_ __attribute__((ext_vector_type(2)));
+    const v2s_ sum = __builtin_bit_cast(v2s_, pred) + __builtin_bit_cast(v2s_, res);
+    const v2s_ r = __builtin_elementwise_min(__builtin_elementwise_max(sum, (v2s_)(0)), (v2s_)((short)maxv));
+    return __builtin_bit_cast(uint32_t, r);
 }
 
 // Neighbour samples of one component in LDS, laid out along the block's "diagonal axis":
