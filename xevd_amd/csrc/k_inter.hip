@@ -12,8 +12,9 @@
 //     tables are staged once per workgroup in LDS, so a lane's chain is owner -> CU record -> reference samples;
 //   * a wave whose 32x32 tile lies inside ONE CU takes the tile path instead: window fetched once into the wave's own LDS, shared
 //     horizontal pass, vertical pass from LDS (mc_luma_tile / mc_chroma_tile below);
-//   * the 11x11 (luma) / 5x5 (chroma) reference windows are read straight from HBM/L2 with 16-byte loads at the
-//     2-byte-aligned sample address (gfx950 runs in unaligned-access mode); neighbouring lanes share the halo
+//   * the 11x11 (luma) / 5x5 (chroma) reference windows are read straight from HBM/L2 at the 2-byte-aligned sample
+//     address (16 + 8 bytes per luma row, 12 per chroma row; gfx950 runs in unaligned-access mode) - by every lane only
+//     the rows and samples its taps do not multiply by zero (mc_scu_list); neighbouring lanes share the halo
 //     through the vector L1, workgroups are mapped to XCDs in contiguous bands so vertical halos share an L2.
 //   * FIRs run on packed s16 pairs with v_dot2c_i32_i16 (two taps per instruction); the four rounding regimes of
 //     the reference (copy / H-only / V-only / 2-D) are one code path with per-lane tap vectors, shifts and
