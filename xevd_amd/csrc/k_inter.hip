@@ -257,7 +257,7 @@ __device__ __forceinline__ RegionMap region_map(int t)
 // chroma plane on its own - six dependent round trips per list.)
 // Round 5, second half: the pass runs at what the memory path delivers for its requests, so the requests were cut - lanes sit out of the rows and samples their
 // identity taps multiply by zero, a chroma row is one 12-byte request instead of 8 + 4 bytes: 42 -> 25.5 requests per lane and list, k_inter 143.7 -> 135.6 us on one
-// box (tools/r5_u.sh, profiles/round5_exp_split_requests.txt; the same structure with every lane requesting everything: 141.0).  The number of round trips does not
+// box (tools/archive/r5_u.sh, profiles/round5_exp_split_requests.txt; the same structure with every lane requesting everything: 141.0).  The number of round trips does not
 // show: luma in instalments of 6 + 5 rows with the chroma planes one after the other (five round trips per list), 6 + 5 rows and both planes (three), 9 + 2 rows,
 // all eleven (two) measured 138.2 / 135.6 / 135.3 / 136.0 us - what shows is the fourth wave per SIMD (133 VGPRs: 144.9 us).  Also measured and dropped: a lane whose
 // SCU has one of the same CU under it (lane + 8) taking its rows 4..10 from that lane's registers (ds_bpermute) instead of requesting them - 23 rows instead of 44
@@ -762,7 +762,7 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
 // What a wave must know before it can ask for reference samples is ONE round trip away: the region's position follows from the workgroup's number, and the entry of
 // `work`, the wave's item (region and tile role: position-indexed, with the CU's record in it) and the owner-map entries of its SCUs (split role) are all requested
 // at once, whatever the role turns out to be.  (With the role-specific lists of the first form - work entry, then list item or list entry, owner entry, CU record -
-// the chain in front of the first request was 2 - 4 dependent loads at ~2000 cycles each under load: 40 - 50 % of the life of a region- or tile-role wave, tools/r5_n.sh,
+// the chain in front of the first request was 2 - 4 dependent loads at ~2000 cycles each under load: 40 - 50 % of the life of a region- or tile-role wave, tools/archive/r5_n.sh,
 // profiles/round5_exp_inter_wave_life.txt.)  The split role's tables (reference entries, filter taps: looked up per lane) are staged per WAVE: no workgroup barrier
 // outside the region role, a tile-role wave does not wait for its neighbours' table loads.
 // XCD-aware mapping: workgroup b runs on XCD b % 8 and every XCD has its own L2; XCD k takes the k-th contiguous eighth of the strip order - a compact patch of

@@ -759,7 +759,7 @@ __global__ __launch_bounds__(64 * INTRA_WAVES) void k_intra(const IntraArgs a)
 #define FUSED_WAVES 4
 // (Round 5: the residual pass alone needs 44 VGPRs, this kernel 121 - 145 because of the chain's side, so the pass rides at half its own occupancy.  Holding the kernel to
 //  96 / 80 / 64 VGPRs (amdgpu_waves_per_eu 5 / 6 / 8: 72 / 172 / 236 bytes of scratch, all in the chain's side) measured 3035 / 2740 / 2602 frames/s against 3052 at 8K, 8050 /
-//  6820 / 6300 against 8600 at 4K: the launch is as long as its chain, and spills lengthen every link of it.  tools/r5_w.sh)
+//  6820 / 6300 against 8600 at 4K: the launch is as long as its chain, and spills lengthen every link of it.  tools/archive/r5_w.sh)
 template <int EIPD, bool IBC, bool IQT>
 __global__ __launch_bounds__(64 * FUSED_WAVES) void k_intra_itdq(const IntraArgs a, const ItdqArgs r, uint32_t n_intra_wg, uint64_t rate)
 {
@@ -775,7 +775,7 @@ __global__ __launch_bounds__(64 * FUSED_WAVES) void k_intra_itdq(const IntraArgs
     const uint32_t before = min(n_intra_wg, (uint32_t)(((uint64_t)blockIdx.x * rate) >> 32)), after = min(n_intra_wg, (uint32_t)(((uint64_t)(blockIdx.x + 1) * rate) >> 32));
     if (after > before) {
         // (s_setprio 3 for the chain's waves, so that a wave whose flags have arrived is not kept waiting by the residual pass's: measured, nothing - 8K 3053 / 3100 / 3054
-        //  frames/s without, 3040 / 3059 / 3117 with, tools/r5_w.sh)
+        //  frames/s without, 3040 / 3059 / 3117 with, tools/archive/r5_w.sh)
         intra_body<true, EIPD, IBC, false, FUSED_WAVES>(a, blockIdx.x, (int16_t *)raw, raw + INTRA_DW - 1);
     } else {
         const int wi = (int)(blockIdx.x - before);
@@ -810,7 +810,7 @@ void launch_intra(xgpu_ctx *c, const IntraArgs &a, bool dep, bool ibc, bool htdf
     }
     const int per = INTRA_WAVES;
     // (pictures whose level 1 fits into the machine's wave slots a few times over keep the wave per CU: 1080p, 1059 CUs: 28.9 us against 29.6; 4K, 4129: 35.5 -> 34.8;
-    //  8K, 15727: 58.1 -> 51.9 - both intra launches, tools/r5_v.sh; XEVD_HIP_INTRA_SMALL_MIN moves the limit - the GPU tests run the small pictures with 1)
+    //  8K, 15727: 58.1 -> 51.9 - both intra launches, tools/archive/r5_v.sh; XEVD_HIP_INTRA_SMALL_MIN moves the limit - the GPU tests run the small pictures with 1)
     if (!dep && !right && !htdf && !ibc && !c->sp.tool_eipd && a.n_small >= c->intra_small_min) {
         const uint32_t big = (uint32_t)((a.count - a.n_small + per - 1) / per), small_blocks = (uint32_t)((a.n_small + SMALL_GROUPS - 1) / SMALL_GROUPS);
         hipLaunchKernelGGL(k_intra_l1, dim3(big + small_blocks), dim3(64 * INTRA_WAVES), 0, c->stream, a, big);
