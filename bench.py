@@ -584,7 +584,18 @@ def main():
         # the work queue (rendezvous store), the barriers and the final accounting - gloo on the host, no RCCL communicator is created
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
+        # gloo reports its connections on the C-level stdout ("[Gloo] Rank 0 is connected to ..."): stdout carries the ONE JSON line and nothing else, so the
+        # descriptor points at stderr while the process group comes up
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("gloo")
+            dist.barrier()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
     local_rank %= max(torch.cuda.device_count(), 1)       # more ranks than devices (a one-GPU box exercising the N > 1 path): they share
     # XEVD_BENCH_DECODER names another module with an XgpuDecoder class: tests/stub_decoder.py, with which the CPU suite runs the launcher,
     # the work queue and the accounting of the N > 1 path (the line then says "decoder": "stub_decoder"; no measurement comes out of it)
