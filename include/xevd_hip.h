@@ -16,6 +16,7 @@
  *   xgpu_alf                      <- mctx->fn_alf (xevd_alf -> alf_process)      src_main/xevdm.c:2105, xevdm_alf.c:901-1249
  *   xgpu_pad                      <- ctx->fn_picbuf_expand                       src_base/xevd_util.c:365-427
  *   xgpu_pic_download             <- xevd_pull (picture hand-off)                src_base/xevd.c:2042-2071
+ *   xgpu_pic_md5                  <- xevd_picbuf_signature / xevd_md5_imgb (picture signature)       src_base/xevd_util.c:985-1002, 1557-1572
  *   xgpu_pic_output               <- xevd_pull + the application's imgb_cpy_codec_to_out (crop fields xevd.c:2058-2069,
  *                                    bit-depth conversions app/xevd_app_util.h:441-552,656-700)
  *
@@ -223,6 +224,13 @@ int  xgpu_pic_output(xgpu_ctx *ctx, int pic, const xgpu_dra_luts *dra, int out_b
 int  xgpu_pic_output_async(xgpu_ctx *ctx, int pic, const xgpu_dra_luts *dra, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b,
                            void *dst, size_t dst_size, int *ticket);
 int  xgpu_pic_output_wait(xgpu_ctx *ctx, int ticket);
+/* The picture signature on the device: the MD5 of every plane over its rows of width x 2 bytes of 16-bit samples (8-bit pictures too), as xevd_md5_imgb makes it
+   (src_base/xevd_util.c:985-1002) and xevd_picbuf_check_signature compares it with the SEI (:1557-1572) - of the DRA-mapped picture when `dra` is given, which is
+   what the Main decoder signs when the PPS names a DRA parameter set (src_main/xevdm.c:3256-3287).  digest[plane] = the 16 bytes of the SEI payload.  Blocking; the
+   picture's own kernels need not have finished when it is called.  An MD5 is one serial chain per plane: the device walks the three chains in three lanes of one
+   wave at ~80 MB/s each (measured: 48 ms for a 1080p picture, 0.22 s at 4K, 0.87 s at 8K; a host core hashes at ~700 MB/s) - it takes the hashing off a CPU-bound
+   host, it does not make it faster. */
+int  xgpu_pic_md5(xgpu_ctx *ctx, int pic, const xgpu_dra_luts *dra, uint8_t digest[3][16]);
 /* whole padded buffers (XEVD_PIC.buf_y/u/v layout: stride = w + 2*pad, rows = h + 2*pad): for tests, and - luma alone, buf_u = buf_v = NULL - for a
    front end that refines merge vectors itself on the reference samples (xhost_parser_set_ref_luma, include/xevd_host.h).  Blocking.                 */
 int  xgpu_pic_download_padded(xgpu_ctx *ctx, int pic, int16_t *buf_y, int16_t *buf_u, int16_t *buf_v);

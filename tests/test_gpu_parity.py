@@ -438,6 +438,39 @@ def test_gpu_dra_output(name):
 
 
 @pytest.mark.gpu
+def test_gpu_picture_md5():
+    """xgpu_pic_md5 (k_md5.hip: the three chains of a picture in three lanes of one wave) == the reference's own xevd_md5_imgb on the same pictures
+    (tests/golden/md5_pictures.json, made by tests/golden/make_md5_golden.py from oracle/_ref) - message lengths with and without a partial last block,
+    8- and 10-bit pictures (two bytes per sample either way), a 1080p picture; and of the DRA-mapped picture == MD5 of what xgpu_pic_output hands out with
+    the same tables (the copy the Main decoder signs, src_main/xevdm.c:3256-3287)."""
+    import hashlib
+    import json
+    import sys
+    from xevd_amd.decoder import XgpuDecoder
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_md5_golden as g
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "md5_pictures.json")))
+    for seed, w, h, bd in g.CASES:
+        planes = g.md5_picture(seed, w, h, bd)
+        with XgpuDecoder(w, h, bd, device=0) as dec:
+            pic = dec.pic_alloc()
+            dec.pic_upload(pic, planes)
+            got = [d.hex() for d in dec.pic_md5(pic)]
+            again = [d.hex() for d in dec.pic_md5(pic)]
+        assert got == gold[f"{seed}_{w}x{h}_{bd}b"] == again, (seed, w, h, bd, got)
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dra.npz"))
+    planes, luts = [d[f"in_{c}"] for c in range(3)], d["three_ranges_idx58_luts"]
+    hh, ww = planes[0].shape
+    with XgpuDecoder(ww, hh, 10, device=0) as dec:
+        pic = dec.pic_alloc()
+        dec.pic_upload(pic, planes)
+        mapped = dec.pic_output(pic, 10, dra=luts)
+        got = dec.pic_md5(pic, dra=luts)
+    n_y, n_c = ww * hh * 2, (ww // 2) * (hh // 2) * 2
+    assert got == [hashlib.md5(mapped[:n_y].tobytes()).digest(), hashlib.md5(mapped[n_y:n_y + n_c].tobytes()).digest(), hashlib.md5(mapped[n_y + n_c:].tobytes()).digest()]
+
+
+@pytest.mark.gpu
 def test_gpu_stream_cropped_8bit_output():
     """a stream with SPS chroma QP tables and a conformance window: player output with the crop applied and 10 -> 8 bit conversion on
     the device == oracle pictures through the oracle's conversion"""
@@ -597,16 +630,27 @@ def test_gpu_reference_baseline_parser_feeds_hip_backend(name, tmp_path):
 
 
 @pytest.mark.gpu
-def test_gpu_reference_application_rejects_bad_signature(tmp_path):
+@pytest.mark.parametrize("md5_on_device", [False, True], ids=["host_md5", "device_md5"])
+def test_gpu_reference_application_rejects_bad_signature(md5_on_device, tmp_path):
+    """the reference's application with -s on the public API: the intact stream passes, a flipped digest bit is XEVD_ERR_BAD_CRC - with the signatures made by the
+    host's MD5, and (XEVD_AMD_MD5_ON_DEVICE=1) by xgpu_pic_md5 on the device picture"""
     import subprocess
     if not os.path.exists(APP_ON_HIP):
         pytest.skip("oracle/_ref/xevd_app_on_hip is not built")
+    env = dict(os.environ)
+    env.pop("XEVD_AMD_MD5_ON_DEVICE", None)
+    if md5_on_device:
+        env["XEVD_AMD_MD5_ON_DEVICE"] = "1"
     d = np.load(os.path.join(golden_io.GOLDEN, "stream_signed_main_alf_10b.npz"))
+    good = tmp_path / "g.evc"
+    good.write_bytes(d["bytes"].tobytes())
+    r = subprocess.run([APP_ON_HIP, "-i", str(good), "-s"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120, env=env)
+    assert r.returncode == 0 and b"MD5 check mismatch" not in r.stdout, r.stdout.decode()[-400:]
     bad = bytearray(d["bytes"].tobytes())
     bad[len(bad) - 3] ^= 0x40                          # inside the last SEI's V-plane digest
     src = tmp_path / "s.evc"
     src.write_bytes(bytes(bad))
-    r = subprocess.run([APP_ON_HIP, "-i", str(src), "-s"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    r = subprocess.run([APP_ON_HIP, "-i", str(src), "-s"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120, env=env)
     assert r.returncode != 0 and b"MD5 check mismatch" in r.stdout
 
 

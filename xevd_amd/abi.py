@@ -190,6 +190,7 @@ _EXPORTS = {
     "xgpu_pic_output": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t]),
     "xgpu_pic_output_async": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
     "xgpu_pic_output_wait": (C.c_int, [C.c_void_p, C.c_int]),
+    "xgpu_pic_md5": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "xgpu_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "xgpu_host_free": (None, [C.c_void_p, C.c_void_p]),
     "xgpu_batch_wait_upload": (C.c_int, [C.c_void_p, C.c_void_p]),

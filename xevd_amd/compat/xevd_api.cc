@@ -72,6 +72,8 @@ struct Image {                      // an XEVD_IMGB that owns three tight 16-bit
     std::vector<int16_t> mem;
     int epoch, poc;
     bool ready;                     // may leave through xevd_pull (the next temporal-layer-0 picture has arrived)
+    bool have_dig = false;          // XEVD_AMD_MD5_ON_DEVICE: the picture's signature was made on the device (xgpu_pic_md5) when it was decoded
+    uint8_t dig[3][16];
 };
 int img_addref(XEVD_IMGB *i) { return ++i->refcnt; }
 int img_getref(XEVD_IMGB *i) { return i->refcnt; }
@@ -93,6 +95,7 @@ struct Decoder {
     std::vector<Image *> pending;          // decoded, not yet pulled
     int epoch = -1, last_key_poc = -1, pic_cnt = 0;
     bool decoded_since_pull = false, use_sig = false;
+    bool md5_on_device = getenv("XEVD_AMD_MD5_ON_DEVICE") != nullptr;      // picture signatures by xgpu_pic_md5 instead of the host's MD5 (read per decoder)
     Image *last = nullptr;                 // the picture a signature SEI refers to (it stays in `pending` or with the caller)
     std::map<int, std::vector<int16_t>> ref_luma;      // by device picture slot: host copies of decoded luma planes for the parser's own DMVR search
     int w = 0, h = 0, bd = 8;
@@ -189,6 +192,13 @@ int decode_picture(Decoder *d, const xhost_picture &p, Image **out)
         rc = xgpu_pic_output(d->g, cur, &dra, p.bit_depth_luma, 0, 0, 0, 0, im->mem.data(), im->mem.size() * sizeof(int16_t));
     } else
         rc = xgpu_pic_download(d->g, cur, pl[0], w, pl[1], pl[2], w / 2);
+    if (rc >= 0 && d->use_sig && d->md5_on_device) {
+        // the signature of the picture the application gets - the DRA-mapped copy when there is one (src_main/xevdm.c:3256-3287) - made by three lanes of the device
+        // instead of a host pass over the planes (k_md5.hip; slower than a host core per picture, but it is not the host's time)
+        const xgpu_dra_luts dra = { p.dra_lut[0], { p.dra_lut[1], p.dra_lut[2] } };
+        rc = xgpu_pic_md5(d->g, cur, (p.dra_lut[0] && p.bit_depth_luma > 8) ? &dra : nullptr, im->dig);
+        im->have_dig = rc >= 0;
+    }
     if (rc < 0) { delete im; return rc; }
 
     for (int r = 0; r < p.n_release; r++)
@@ -270,8 +280,8 @@ int xevd_decode(XEVD id, XEVD_BITB *bitb, XEVD_STAT *stat)
             for (int c = 0; c < 3; c++) {
                 Md5 m;
                 uint8_t dig[16];
-                m.update((const uint8_t *)g.a[c], (size_t)g.s[c] * g.h[c]);
-                m.finish(dig);
+                if (d->last->have_dig) memcpy(dig, d->last->dig[c], 16);
+                else { m.update((const uint8_t *)g.a[c], (size_t)g.s[c] * g.h[c]); m.finish(dig); }
                 if (memcmp(dig, nal + 4 + 16 * c, 16) != 0) return XEVD_ERR_BAD_CRC;
             }
         }

@@ -80,11 +80,13 @@ __global__ __launch_bounds__(256) void k_output(const OutArgs p)
     }
 }
 
-void launch_output(xgpu_ctx *c, const DevPic &pic, const int32_t *d_dra, int out_bd, int crop_l, int crop_r, int crop_t, int crop_b, uint8_t *d_dst)
+// raw16: the samples as they are, two bytes each whatever the coding depth (the bytes the picture signature is made of: xevd_md5_imgb hashes w x 2 bytes per row)
+void launch_output(xgpu_ctx *c, const DevPic &pic, const int32_t *d_dra, int out_bd, int crop_l, int crop_r, int crop_t, int crop_b, uint8_t *d_dst, bool raw16)
 {
+    if (raw16) out_bd = c->sp.bit_depth_luma;
     OutArgs p;
     const int16_t *pl[3] = { pic.y, pic.u, pic.v };
-    const int bps = out_bd == 8 ? 1 : 2;
+    const int bps = (out_bd == 8 && !raw16) ? 1 : 2;
     int rows = 0;
     size_t off = 0;
     for (int i = 0; i < 3; i++) {
@@ -102,7 +104,7 @@ void launch_output(xgpu_ctx *c, const DevPic &pic, const int32_t *d_dra, int out
     p.dst = d_dst;
     const int src_bd = c->sp.bit_depth_luma;
     p.shift = src_bd - out_bd;
-    p.out8 = out_bd == 8;
+    p.out8 = out_bd == 8 && !raw16;
     p.maxv = (1 << out_bd) - 1;
     p.dra = d_dra;
     hipLaunchKernelGGL(k_output, dim3(rows), dim3(256), 0, c->stream, p);

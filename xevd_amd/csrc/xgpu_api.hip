@@ -124,6 +124,7 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     c->intra_small_min = getenv("XEVD_HIP_INTRA_SMALL_MIN") ? std::max(1, atoi(getenv("XEVD_HIP_INTRA_SMALL_MIN"))) : 2048;      // (k_intra.hip: launch_intra; read per context, tests set 1)
     c->split_addb_alf = getenv("XEVD_HIP_SPLIT_ADDB_ALF") != NULL;      // measurement knob: ADDB and ALF as two kernels (the round-2 chain) instead of k_addb_alf
     for (int i = 0; i < 2; i++) { c->d_out[i] = NULL; c->out_caps[i] = 0; c->out_ready[i] = c->out_done[i] = 0; c->out_busy[i] = 0; }
+    c->d_md5 = NULL; c->md5_ready = 0;
     c->out_next = 0;
     memset(c->t_ms, 0, sizeof(c->t_ms)); memset(c->t_n, 0, sizeof(c->t_n));
     // chroma QP mapping: caller table starts at qp = -6*(bdc-8); default = Baseline static table with the
@@ -208,6 +209,8 @@ void xgpu_close(xgpu_ctx *c)
     for (auto &h : c->pinned) (void)hipHostFree(h.p);
     c->pinned.clear();
     c->pool.clear();
+    if (c->d_md5) (void)hipFree(c->d_md5);
+    if (c->md5_ready) (void)hipEventDestroy(c->md5_ready);
     for (int i = 0; i < 2; i++) { if (c->d_out[i]) (void)hipFree(c->d_out[i]); if (c->out_ready[i]) (void)hipEventDestroy(c->out_ready[i]); if (c->out_done[i]) (void)hipEventDestroy(c->out_done[i]); }
     if (c->d_dra) (void)hipFree(c->d_dra);
     if (c->d_ctb_flag) (void)hipFree(c->d_ctb_flag);
@@ -340,6 +343,15 @@ size_t xgpu_pic_output_size(const xgpu_ctx *c, int out_bit_depth, int crop_l, in
     const size_t w = c->sp.width - crop_l - crop_r, h = c->sp.height - crop_t - crop_b;
     return (w * h + 2 * (w >> 1) * (h >> 1)) * (out_bit_depth == 8 ? 1 : 2);
 }
+static int upload_dra(xgpu_ctx *c, const xgpu_dra_luts *dra)      // the inverse-mapping tables behind the picture's kernels on their stream
+{
+    ARGCHK(c, dra->luma_inv_scale_lut && dra->chroma_inv_scale_lut[0] && dra->chroma_inv_scale_lut[1]);
+    ARGCHK(c, c->sp.bit_depth_luma <= 10);                         // the tables have 1024 entries (DRA_LUT_MAXSIZE)
+    if (!c->d_dra && hipMalloc((void **)&c->d_dra, sizeof(int32_t) * 3 * 1024) != hipSuccess) { snprintf(c->err, sizeof(c->err), "pic_output: cannot allocate the DRA tables"); return XGPU_ERR_OUT_OF_MEMORY; }
+    const int32_t *src[3] = { dra->luma_inv_scale_lut, dra->chroma_inv_scale_lut[0], dra->chroma_inv_scale_lut[1] };
+    for (int i = 0; i < 3; i++) HIPCHK(c, hipMemcpyAsync(c->d_dra + 1024 * i, src[i], sizeof(int32_t) * 1024, hipMemcpyHostToDevice, c->stream));
+    return XGPU_OK;
+}
 int xgpu_pic_output_async(xgpu_ctx *c, int pic, const xgpu_dra_luts *dra, int out_bit_depth, int crop_l, int crop_r, int crop_t, int crop_b, void *dst, size_t dst_size,
                           int *ticket)
 {
@@ -354,13 +366,7 @@ int xgpu_pic_output_async(xgpu_ctx *c, int pic, const xgpu_dra_luts *dra, int ou
         if (hipMalloc((void **)&c->d_out[k], need) != hipSuccess) { snprintf(c->err, sizeof(c->err), "pic_output: cannot allocate the %zu-byte staging buffer", need); return XGPU_ERR_OUT_OF_MEMORY; }
         c->out_caps[k] = need;
     }
-    if (dra) {
-        ARGCHK(c, dra->luma_inv_scale_lut && dra->chroma_inv_scale_lut[0] && dra->chroma_inv_scale_lut[1]);
-        ARGCHK(c, c->sp.bit_depth_luma <= 10);                         // the tables have 1024 entries (DRA_LUT_MAXSIZE)
-        if (!c->d_dra && hipMalloc((void **)&c->d_dra, sizeof(int32_t) * 3 * 1024) != hipSuccess) { snprintf(c->err, sizeof(c->err), "pic_output: cannot allocate the DRA tables"); return XGPU_ERR_OUT_OF_MEMORY; }
-        const int32_t *src[3] = { dra->luma_inv_scale_lut, dra->chroma_inv_scale_lut[0], dra->chroma_inv_scale_lut[1] };
-        for (int i = 0; i < 3; i++) HIPCHK(c, hipMemcpyAsync(c->d_dra + 1024 * i, src[i], sizeof(int32_t) * 1024, hipMemcpyHostToDevice, c->stream));
-    }
+    if (dra) { const int rc = upload_dra(c, dra); if (rc < 0) return rc; }
     // conversion + packing behind the picture's kernels on their stream; the copy to the host on the download stream behind an event, so it
     // overlaps the kernels of the next picture
     launch_output(c, dpic(c, pic), dra ? c->d_dra : NULL, out_bit_depth, crop_l, crop_r, crop_t, crop_b, c->d_out[k]);
@@ -385,6 +391,30 @@ int xgpu_pic_output(xgpu_ctx *c, int pic, const xgpu_dra_luts *dra, int out_bit_
     int ticket = 0;
     const int rc = xgpu_pic_output_async(c, pic, dra, out_bit_depth, crop_l, crop_r, crop_t, crop_b, dst, dst_size, &ticket);
     return rc < 0 ? rc : xgpu_pic_output_wait(c, ticket);
+}
+
+// The picture signature on the device (k_md5.hip): the planes packed as the signature's message behind the picture's kernels (k_output, samples as they are), the three
+// chains on the transfer stream - the kernel stream is free for the next picture while they run -, 48 bytes to the host.  Blocking.
+int xgpu_pic_md5(xgpu_ctx *c, int pic, const xgpu_dra_luts *dra, uint8_t digest[3][16])
+{
+    ARGCHK(c, c != NULL); ARGCHK(c, valid_pic(c, pic)); ARGCHK(c, digest != NULL);
+    const int w = c->sp.width, h = c->sp.height;
+    const size_t need = ((size_t)w * h + 2 * (size_t)(w >> 1) * (h >> 1)) * 2;
+    if (!c->d_md5) {
+        if (hipMalloc((void **)&c->d_md5, need + 64) != hipSuccess) { snprintf(c->err, sizeof(c->err), "pic_md5: cannot allocate the %zu-byte message buffer", need + 64); return XGPU_ERR_OUT_OF_MEMORY; }
+        HIPCHK(c, hipEventCreateWithFlags(&c->md5_ready, hipEventDisableTiming));
+    }
+    if (dra) { const int rc = upload_dra(c, dra); if (rc < 0) return rc; }
+    uint32_t *d_digest = (uint32_t *)(c->d_md5 + ((need + 15) & ~(size_t)15));
+    launch_output(c, dpic(c, pic), dra ? c->d_dra : NULL, c->sp.bit_depth_luma, 0, 0, 0, 0, c->d_md5, true);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipEventRecord(c->md5_ready, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->down_stream, c->md5_ready, 0));
+    launch_md5(c, c->down_stream, c->d_md5, w, h, d_digest);
+    HIPCHK(c, hipGetLastError());
+    HIPCHK(c, hipMemcpyAsync(digest, d_digest, 48, hipMemcpyDeviceToHost, c->down_stream));
+    HIPCHK(c, hipStreamSynchronize(c->down_stream));
+    return XGPU_OK;
 }
 
 // ------------------------------------------------------------------------------------------------ per picture

@@ -325,6 +325,8 @@ struct xgpu_ctx {
     uint8_t        *d_ctb_flag;       // ALF luma CTB flags of the current picture
     std::vector<BatchBlock> pool;     // blocks of destroyed batches, reused by later ones of the same stream (same HIP stream -> ordered)
     uint8_t        *d_out[2];         // packed output pictures (xgpu_pic_output): two in flight, grown on demand
+    uint8_t        *d_md5;            // xgpu_pic_md5: the picture's planes as the signature's message (+ 48 bytes of digest behind it), allocated at the first call
+    hipEvent_t      md5_ready;
     size_t          out_caps[2];
     hipEvent_t      out_ready[2], out_done[2];      // conversion kernel finished (kernel stream) / copy to the host finished (download stream)
     int             out_busy[2], out_next;
@@ -412,6 +414,7 @@ void launch_addb_fused(xgpu_ctx *c, const AddbArgs &a, const DevPic &src, const 
 void launch_alf(xgpu_ctx *c, const AlfArgs &a, const AddbArgs *deblock, const DevPic &src, const DevPic &dst);      // deblock != NULL: ADDB on SRC first, inside the same kernel
 void launch_pad(xgpu_ctx *c, const DevPic &p);
 void launch_copy_bw(xgpu_ctx *c, const void *src, void *dst, size_t bytes);
-void launch_output(xgpu_ctx *c, const DevPic &pic, const int32_t *d_dra, int out_bd, int crop_l, int crop_r, int crop_t, int crop_b, uint8_t *d_dst);
+void launch_output(xgpu_ctx *c, const DevPic &pic, const int32_t *d_dra, int out_bd, int crop_l, int crop_r, int crop_t, int crop_b, uint8_t *d_dst, bool raw16 = false);
+void launch_md5(xgpu_ctx *c, hipStream_t s, const uint8_t *d_msg, int w, int h, uint32_t *d_digest);      // k_md5.hip: the three planes packed back to back at d_msg -> d_digest[3][4]
 void launch_test_mc(xgpu_ctx *c, const int16_t *plane, int stride, int ref_x, int ref_y, int has_dx, int has_dy,
                     int gmv_x, int gmv_y, int16_t *pred, int w, int h, int bd, int luma);

@@ -96,6 +96,21 @@ class XgpuDecoder:
         self._chk(self.lib.xgpu_pic_output(self.ctx, pic, dl, bd, *crop, out.ctypes.data, n), "xgpu_pic_output")
         return out
 
+    def pic_md5(self, pic, dra=None):
+        """the picture signature made on the device (xgpu_pic_md5): [Y, U, V] digests of 16 bytes - the MD5 of every plane's 16-bit samples as the reference's
+        xevd_md5_imgb makes it; with `dra` tables (as pic_output takes them) of the DRA-mapped picture"""
+        dl, keep = None, None
+        if dra is not None:
+            keep = [np.ascontiguousarray(t, np.int32) for t in dra]
+            assert all(t.size == 1024 for t in keep)
+            d = abi.DraLuts()
+            d.luma_inv_scale_lut = keep[0].ctypes.data
+            d.chroma_inv_scale_lut[0], d.chroma_inv_scale_lut[1] = keep[1].ctypes.data, keep[2].ctypes.data
+            dl = C.byref(d)
+        out = np.zeros((3, 16), np.uint8)
+        self._chk(self.lib.xgpu_pic_md5(self.ctx, pic, dl, out.ctypes.data), "xgpu_pic_md5")
+        return [bytes(out[c]) for c in range(3)]
+
     def host_alloc(self, nbytes, dtype=np.uint8):
         """pinned host memory from the backend as a numpy array (freed with the decoder): for coefficient arenas and output buffers"""
         p = C.c_void_p()
