@@ -602,14 +602,26 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
             list_refs(l, ry_, ru_, rv_); list_pos(l, px, py);
             const gs16 p = ry_ + ((py >> 2) - 3) * a.s_l + (((px >> 2) - 3) & ~7);
             char LDS_AS *const d = (char LDS_AS *)W;
+            // A vector with a whole-sample component needs neither the three rows above and four below the block (the vertical pass only copies rows 3 .. 3 + size) nor
+            // the samples left of sample 3 and right of sample 3 + size of a row (the horizontal pass only picks them): those chunks are not requested (wave- /
+            // workgroup-uniform here, the CU is one; the slots keep what they held and nothing reads it).  Same idea as the split role's lanes (mc_scu_list).
+#ifdef XGPU_NO_LANE_PRED
+            const bool fy = true, fx = true;
+#else
+            const bool fy = ((l ? mvs[1][1] : mvs[0][1]) & 3) != 0, fx = ((l ? mvs[1][0] : mvs[0][0]) & 3) != 0;
+#endif
+            constexpr int SIZE = REGION ? 64 : 32;
+            const int s0 = (((px >> 2) - 3) & 7) + 3, s1 = s0 + SIZE;      // the samples of a row (counted from its first chunk) that a copy needs
+            auto wanted = [&](int row, int k) { return (fy || (row >= 3 && row < 3 + SIZE)) && (fx || (8 * k + 8 > s0 && 8 * k < s1)); };
             if (REGION) {
 #pragma unroll
                 for (int it = 0; it < 3; it++)       // 71 rows x 10 chunks, thread t takes chunks t, t + 256, t + 512: LDS offset = chunk * 16
-                    if (rm->y[it] >= 0) __builtin_amdgcn_global_load_lds((const GAS void *)(p + (rm->y[it] >> 8) * a.s_l + 8 * (rm->y[it] & 127)), (LDS_AS void *)(d + (256 * it + 64 * wave) * 16), 16, 0, 0);
+                    if (rm->y[it] >= 0 && wanted(rm->y[it] >> 8, rm->y[it] & 127)) __builtin_amdgcn_global_load_lds((const GAS void *)(p + (rm->y[it] >> 8) * a.s_l + 8 * (rm->y[it] & 127)), (LDS_AS void *)(d + (256 * it + 64 * wave) * 16), 16, 0, 0);
             } else {
+                const int row0 = (lane * 171) >> 10, k = lane - row0 * 6;
 #pragma unroll
                 for (int it = 0; it < 4; it++)       // 39 rows x 6 chunks, 10 rows per request (lanes 60..63 idle)
-                    if (lane < (it < 3 ? 60 : 54)) __builtin_amdgcn_global_load_lds((const GAS void *)(p + fm.gy + 10 * it * a.s_l), (LDS_AS void *)(d + it * 960), 16, 0, 0);
+                    if (lane < (it < 3 ? 60 : 54) && wanted(row0 + 10 * it, k)) __builtin_amdgcn_global_load_lds((const GAS void *)(p + fm.gy + 10 * it * a.s_l), (LDS_AS void *)(d + it * 960), 16, 0, 0);
             }
         };
         auto request_chroma = [&](int l) {
