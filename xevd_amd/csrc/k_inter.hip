@@ -611,8 +611,10 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
             const bool fy = ((l ? mvs[1][1] : mvs[0][1]) & 3) != 0, fx = ((l ? mvs[1][0] : mvs[0][0]) & 3) != 0;
 #endif
             constexpr int SIZE = REGION ? 64 : 32;
-            const int s0 = (((px >> 2) - 3) & 7) + 3, s1 = s0 + SIZE;      // the samples of a row (counted from its first chunk) that a copy needs
-            auto wanted = [&](int row, int k) { return (fy || (row >= 3 && row < 3 + SIZE)) && (fx || (8 * k + 8 > s0 && 8 * k < s1)); };
+            // the samples of a row, counted from its first chunk, that the list needs: the window's SIZE + 7 from where it starts inside that chunk - the last chunk of
+            // a row is only there for windows that start at its sample 2 and beyond -, or the SIZE of a copy
+            const int mis = ((px >> 2) - 3) & 7, s0 = fx ? mis : mis + 3, s1 = fx ? mis + SIZE + 7 : mis + 3 + SIZE;
+            auto wanted = [&](int row, int k) { return (fy || (row >= 3 && row < 3 + SIZE)) && 8 * k + 8 > s0 && 8 * k < s1; };
             if (REGION) {
 #pragma unroll
                 for (int it = 0; it < 3; it++)       // 71 rows x 10 chunks, thread t takes chunks t, t + 256, t + 512: LDS offset = chunk * 16
@@ -629,15 +631,25 @@ __device__ __forceinline__ bool inter_tile(const InterArgs &a, uint4 r0, uint4 r
             list_refs(l, ry_, ru_, rv_); list_pos(l, px, py);
             const int off = ((py >> 3) - 1) * a.s_c + (((px >> 3) - 1) & ~7);
             char LDS_AS *const d = (char LDS_AS *)(W + L_SAMPLES);
+            // (as request_luma: the chroma windows are SIZE / 2 + 3 samples from sample `cmis` of the first chunk - three times out of four they end before the row's
+            //  last chunk -, a whole-sample component needs SIZE / 2 rows / samples from 1)
+#ifdef XGPU_NO_LANE_PRED
+            const bool fy = true, fx = true;
+#else
+            const bool fy = ((l ? mvs[1][1] : mvs[0][1]) & 7) != 0, fx = ((l ? mvs[1][0] : mvs[0][0]) & 7) != 0;
+#endif
+            constexpr int CSIZE = REGION ? 32 : 16;
+            const int cmis = ((px >> 3) - 1) & 7, s0 = fx ? cmis : cmis + 1, s1 = fx ? cmis + CSIZE + 3 : cmis + 1 + CSIZE;
+            auto wanted = [&](int row, int k) { return (fy || (row >= 1 && row < 1 + CSIZE)) && 8 * k + 8 > s0 && 8 * k < s1; };
             if (REGION) {
 #pragma unroll
                 for (int it = 0; it < 2; it++)       // 2 planes x 35 rows x 6 chunks
-                    if (rm->c[it] >= 0) __builtin_amdgcn_global_load_lds((const GAS void *)(((rm->c[it] & 128) ? rv_ : ru_) + off + (rm->c[it] >> 8) * a.s_c + 8 * (rm->c[it] & 127)), (LDS_AS void *)(d + (256 * it + 64 * wave) * 16), 16, 0, 0);
+                    if (rm->c[it] >= 0 && wanted(rm->c[it] >> 8, rm->c[it] & 127)) __builtin_amdgcn_global_load_lds((const GAS void *)(((rm->c[it] & 128) ? rv_ : ru_) + off + (rm->c[it] >> 8) * a.s_c + 8 * (rm->c[it] & 127)), (LDS_AS void *)(d + (256 * it + 64 * wave) * 16), 16, 0, 0);
             } else {
 #pragma unroll
                 for (int it = 0; it < 3; it++) {     // 2 planes x 19 rows x 4 chunks
                     const int idx = lane + 64 * it, plane = idx >= 76, j = idx - 76 * plane;
-                    if (idx < 152) __builtin_amdgcn_global_load_lds((const GAS void *)((plane ? rv_ : ru_) + off + (j >> 2) * a.s_c + 8 * (j & 3)), (LDS_AS void *)(d + it * 1024), 16, 0, 0);
+                    if (idx < 152 && wanted(j >> 2, j & 3)) __builtin_amdgcn_global_load_lds((const GAS void *)((plane ? rv_ : ru_) + off + (j >> 2) * a.s_c + 8 * (j & 3)), (LDS_AS void *)(d + it * 1024), 16, 0, 0);
                 }
             }
         };
