@@ -2,15 +2,16 @@
 """bench.py - frames/s of the MI355X reconstruction backend on BASELINE.json's workload, with the roofline of the dominant kernel and a CPU baseline.
 
 A "step" is one picture through the whole hot path - everything xevdm_dec_nalu does after entropy decoding (src_main/xevdm.c:3136-3219): dequant + inverse
-transform of every coded TB (k_itdq), MC + residual add + clip + SCU-map update of every inter CU (the three k_inter_* launches), intra CUs in dependency order
-(k_intra), ADDB + ALF + border padding in one pass (k_addb_alf).  Pictures chain like a stream: picture k is predicted from pictures k-1 and k-2 (a 3-slot DPB
+transform of every coded TB (k_itdq), MC + residual add + clip + SCU-map update of every inter CU (k_inter: one launch, a workgroup per 64x64 region), intra CUs in
+dependency order (k_intra_l1 + the data-flow launch k_intra, which also carries the NEXT picture's residual pass), ADDB + ALF + border padding in one pass (k_addb_alf).  Pictures chain like a stream: picture k is predicted from pictures k-1 and k-2 (a 3-slot DPB
 ring), so steps are serially dependent exactly like a real decode.
 
 What the JSON line's figures are, all at the command line the driver uses (`--steps 20 --warmup 5` included):
   value / kernel_only_fps   the benchmark contract's number: the CU batches (the post-entropy records) are resident in HBM when the timed region starts; W warm-up
                             pictures, then exactly K timed ones between two barrier + synchronize pairs.
-  roofline                  the dominant kernel family by HIP-event time (the three k_inter_* launches are ONE pass over the picture and are priced as one: their
-                            summed duration against SURVEY 8(d)'s bytes of that pass), timed in a second loop of K pictures with every kernel alone on the stream.
+  roofline                  the dominant kernel by HIP-event time against SURVEY 8(d)'s bytes of its pass, timed in a second loop of K pictures with every kernel alone
+                            on the stream.  `traffic` comes from the committed counter passes (profiles/latest_pmc.json) and is dropped (null) when the kernel's sources
+                            no longer hash to what those passes measured.
   end_to_end_fps            host CU batches -> host YUV (builder + H2D + kernels + conversion + D2H inside the timed region).  Its OWN fixed length
   two_contexts              (E2E_PICTURES after E2E_WARMUP; CTX_PICTURES per context after CTX_WARMUP), independent of --steps: a secondary figure that moved with
                             the step count was the round-4 review's finding.
@@ -34,6 +35,20 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+# the files a kernel family is compiled from (xevd_amd/csrc): profiles/latest_pmc.json records their hash at the commit its counter passes ran on
+KERNEL_SOURCES = {"inter": ("k_inter.hip", "mc_filters.h"), "alf": ("k_alf.hip", "addb_filter.h"), "itdq": ("k_itdq.hip", "itdq_body.h"),
+                  "dbk_v": ("k_addb.hip", "k_deblock.hip", "addb_filter.h"), "dbk_h": ("k_addb.hip", "k_deblock.hip", "addb_filter.h"),
+                  "intra": ("k_intra.hip", "intra_pred.h", "itdq_body.h"), "intra_itdq": ("k_intra.hip", "intra_pred.h", "itdq_body.h")}
+
+
+def kernel_sources_sha256(kernel):
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES.get(kernel, ()):
+        h.update(open(os.path.join(ROOT, "xevd_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
 
 WORKLOADS = {
     # BASELINE.json configs[1]: Baseline profile, 1080p, 8 bit, IPPP, one reference
@@ -762,12 +777,16 @@ def main():
             copy_bw = dec.measure_copy_bw(1 << 30, 10)
         except Exception:
             copy_bw = None
-        traffic, pmc_commit = None, None
+        traffic, pmc_commit, traffic_note = None, None, None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "latest_pmc.json")))
             if pmc["workload"] == args.workload:
-                traffic = pmc["kernels"][dom]["traffic_bytes"]       # from the committed rocprofv3 --pmc passes
                 pmc_commit = pmc.get("commit")
+                # the counter passes are a committed record, not part of this run: they only describe this run's kernel while its sources are the ones measured
+                if pmc.get("sources_sha256", {}).get(dom) == kernel_sources_sha256(dom):
+                    traffic = pmc["kernels"][dom]["traffic_bytes"]       # from the committed rocprofv3 --pmc passes
+                else:
+                    traffic_note = f"dropped: the sources of the {dom} kernel changed since the counter passes of commit {pmc_commit}"
         except Exception:
             traffic = None
         total_alg = float(np.mean([sum(v for k, v in a.items() if k != "alf" or wl["alf"]) for a in ab]))
@@ -796,7 +815,7 @@ def main():
                          # the guide's measured float4-copy figure for this part (MI355X_MICROARCH.md: 6.29 TB/s); k_copy (one 16-byte element per lane) reaches 6.2
                          "frac_of_guide_copy_bw_6290": round(achieved / 6290.0, 4),
                          "traffic_source": (f"profiles/latest_pmc.json (rocprofv3 --pmc passes of this workload at commit {pmc_commit}, committed; not measured by this run: "
-                                            "counter passes cannot run inside a timed benchmark)") if traffic is not None else None},
+                                            "counter passes cannot run inside a timed benchmark)") if traffic is not None else traffic_note},
             "kernels": kernels,
             "whole_frame": {"algorithmic_bytes": int(total_alg), "kernel_us": round(kern_s * 1e6, 2),
                             "achieved_gbps": round(total_alg / kern_s / 1e9, 1),

@@ -68,6 +68,15 @@ CASES = [
                                                                      "ats_inter_frac": 0.3, "affine_frac": 0.2}),
     # CTU 128 without ADDB: the Main library's copy of the Baseline filter, CUs above 64 filtered as two halves
     ("main_ctu128_noaddb_8b", 264, 264, 8, 1, 0, (1, 1), 0.3, {"log2_ctu": 7, "btt_frac": 0.6, "ats_inter_frac": 0.5, "split_prob": 0.3}),
+    # 12 bit: the reference is generic in bit depth (src_main/xevdm.c:351-352, src_base/xevd_mc.c:253-286 shift from bit_depth) and xgpu_open accepts 8..12 - Base taps with the
+    # baseline filter, Main with every pixel tool (the packed-s16 paths of the kernels are for <= 10 bit; above that the scalar instantiations run)
+    ("base_p_12b", 144, 88, 12, 0, 0, (2, 0), 0.0),
+    ("base_b_12b", 136, 72, 12, 0, 0, (2, 2), 0.5, {"inter_frac": 0.8}),
+    ("main_addb_alf_12b", 200, 136, 12, 1, 1, (2, 2), 0.5, {"addb": 1, "alf": 1, "inter_frac": 1.0}),
+    ("main_all_tools_b_12b", 264, 200, 12, 1, 1, (2, 2), 0.6, {"addb": 1, "alf": 1, "inter_frac": 0.7, "eipd": 1, "htdf_qp": 32, "dmvr_frac": 0.6, "ats_frac": 0.4, "ats_inter_frac": 0.4,
+                                                              "btt_frac": 0.5, "split_prob": 0.4, "affine_frac": 0.3, "coded_frac": 0.8}),
+    ("main_i_eipd_ibc_htdf_ctu128_12b", 264, 136, 12, 1, 1, (1, 0), 0.0, {"addb": 1, "alf": 1, "inter_frac": 0.0, "eipd": 1, "htdf_qp": 28, "ibc_frac": 0.3, "log2_ctu": 7, "ats_frac": 0.5,
+                                                                         "btt_frac": 0.5, "split_prob": 0.5}),
 ]
 POCS = [[4, 0, 2], [12, 16, 4]]      # L1 idx 2 has the POC of L0 idx 0 -> identical-motion candidates exist
 CUR_POC = 8

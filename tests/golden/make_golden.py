@@ -26,12 +26,12 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def golden_mc(lib):
+def golden_mc(lib, bds=(8, 10), fname="blocks_mc.npz", seed=2024):
     names = {(0, 0): "00", (1, 0): "n0", (0, 1): "0n", (1, 1): "nn"}
-    rng = np.random.default_rng(2024)
+    rng = np.random.default_rng(seed)
     out = {}
     recs, preds = [], []
-    for bd in (8, 10):
+    for bd in bds:
         plane = rng.integers(0, 1 << bd, (96, 160)).astype(np.int16)
         out[f"plane_bd{bd}"] = plane
         for admvp in (0, 1):
@@ -59,12 +59,12 @@ def golden_mc(lib):
                             preds.append(a.ravel())
     out["recs"] = np.array(recs, np.int64)
     out["pred"] = np.concatenate(preds)
-    np.savez_compressed(os.path.join(HERE, "blocks_mc.npz"), **out)
-    print("blocks_mc.npz:", len(recs), "blocks")
+    np.savez_compressed(os.path.join(HERE, fname), **out)
+    print(fname + ":", len(recs), "blocks")
 
 
-def golden_itdq(lib):
-    rng = np.random.default_rng(77)
+def golden_itdq(lib, bds=(8, 10), fname="blocks_itdq.npz", seed=77):
+    rng = np.random.default_rng(seed)
     itxb = (C.c_void_p * 6).in_dll(lib, "xevd_tbl_itxb")
     itx = (C.c_void_p * 6).in_dll(lib, "xevdm_tbl_itx")
     f_itxb = C.CFUNCTYPE(None, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int)
@@ -72,7 +72,7 @@ def golden_itdq(lib):
     lib.xevd_dquant.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_uint8]
     recs, cin, cout = [], [], []
     for iqt in (0, 1):
-        for bd in (8, 10):
+        for bd in bds:
             for log2w in range(1, 7):
                 for log2h in range(1, 7):
                     w, h = 1 << log2w, 1 << log2h
@@ -102,9 +102,9 @@ def golden_itdq(lib):
                         recs.append((iqt, bd, log2w, log2h, qp, sum(c.size for c in cin)))
                         cin.append(coef.ravel())
                         cout.append(a.ravel())
-    np.savez_compressed(os.path.join(HERE, "blocks_itdq.npz"), recs=np.array(recs, np.int64), coef=np.concatenate(cin),
+    np.savez_compressed(os.path.join(HERE, fname), recs=np.array(recs, np.int64), coef=np.concatenate(cin),
                         resid=np.concatenate(cout))
-    print("blocks_itdq.npz:", len(recs), "blocks")
+    print(fname + ":", len(recs), "blocks")
 
 
 def golden_pictures(only=None):
@@ -233,6 +233,10 @@ def golden_streams(only=()):
                                                                                   max_refs=2, log2_sub_gop=2, split_prob=0.7, bit_depth=10, inter_frac=0.7, skip_frac=0.3, direct_frac=0.3)),
                                 "main_suco_tiles_dbk_8b": (392, 264, 5, dict(main=True, suco=(0, 3), eipd=True, htdf=True, tiles=(2, 2, 0), max_refs=2, split_prob=0.7, inter_frac=0.6)),
                                 "main_alf_fixed_8b": (264, 136, 8, dict(main=True, alf=True, addb=True, alf_fixed=True)),
+                                # 12 bit (bit_depth_luma_minus8 = bit_depth_chroma_minus8 = 4): Baseline hierarchical B; Main with every pixel tool
+                                "hier_b_gop4_12b": (208, 120, 9, dict(log2_sub_gop=2, max_refs=2, bit_depth=12)),
+                                "main_all_tools_12b": (264, 200, 9, dict(main=True, admvp=True, affine=True, amvr=True, hmvp=True, mmvd=True, dmvr=True, iqt=True, ats=True, addb=True, alf=True,
+                                                                         eipd=True, htdf=True, ibc_log_max=4, max_refs=2, log2_sub_gop=2, bit_depth=12, inter_frac=0.8, skip_frac=0.3, direct_frac=0.3)),
                                 "main_ibc_i_8b": (136, 72, 3, dict(main=True, eipd=True, ibc_log_max=4, ibc_frac=0.4, idr_period=1)),
                                 "main_ibc_all_tools_10b": (200, 136, 9, dict(main=True, iqt=True, ats=True, addb=True, alf=True, eipd=True, htdf=True, ibc_log_max=5, inter_frac=0.5, log2_sub_gop=2, max_refs=2, bit_depth=10))}.items():
         if only and name not in only:
@@ -274,6 +278,10 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "dra":
         golden_dra()
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "blocks12":       # the 12-bit block vectors (added in round 6; the 8 / 10-bit files keep their bytes)
+        golden_mc(lib, (12,), "blocks_mc_12b.npz", 2025)
+        golden_itdq(lib, (12,), "blocks_itdq_12b.npz", 78)
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "streams":
         golden_streams(sys.argv[2:])
     elif len(sys.argv) > 1:               # python make_golden.py <picture case> ... : only (re)generate those
@@ -281,5 +289,7 @@ if __name__ == "__main__":
     else:
         golden_mc(lib)
         golden_itdq(lib)
+        golden_mc(lib, (12,), "blocks_mc_12b.npz", 2025)
+        golden_itdq(lib, (12,), "blocks_itdq_12b.npz", 78)
         golden_pictures()
         golden_streams()

@@ -15,7 +15,8 @@ PICTURE_CASES = ["base_p_8b", "base_b_8b", "base_p_10b", "main_b_10b", "main_adm
                  "main_eipd_i_10b", "main_eipd_i_btt_8b", "main_eipd_b_ctu128_constrained_10b",
                  "main_affine_b_10b", "main_affine_p_8b_atsinter", "main_affine_b_ctu128_10b",
                  "main_ibc_i_10b", "main_ibc_b_8b_noaddb", "main_ibc_p_ctu128_eipd_10b",
-                 "main_htdf_b_10b", "main_htdf_i_8b_constrained", "main_htdf_p_ctu128_10b", "main_dmvr_b_10b", "main_dmvr_b_8b_ctu128_mixed"]
+                 "main_htdf_b_10b", "main_htdf_i_8b_constrained", "main_htdf_p_ctu128_10b", "main_dmvr_b_10b", "main_dmvr_b_8b_ctu128_mixed",
+                 "base_p_12b", "base_b_12b", "main_addb_alf_12b", "main_all_tools_b_12b", "main_i_eipd_ibc_htdf_ctu128_12b"]
 
 
 def load_picture_case(name):

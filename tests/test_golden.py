@@ -14,8 +14,9 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p)
 
 
-def test_golden_mc_blocks_oracle():
-    d = np.load(os.path.join(golden_io.GOLDEN, "blocks_mc.npz"))
+@pytest.mark.parametrize("fname", ["blocks_mc.npz", "blocks_mc_12b.npz"])
+def test_golden_mc_blocks_oracle(fname):
+    d = np.load(os.path.join(golden_io.GOLDEN, fname))
     orc = ol.oracle()
     for bd, admvp, luma, has_dx, has_dy, w, h, gx, gy, off in d["recs"]:
         plane = d[f"plane_bd{bd}"]
@@ -25,8 +26,9 @@ def test_golden_mc_blocks_oracle():
         assert np.array_equal(out.ravel(), d["pred"][off:off + w * h]), (bd, admvp, luma, has_dx, has_dy, w, h)
 
 
-def test_golden_itdq_blocks_oracle():
-    d = np.load(os.path.join(golden_io.GOLDEN, "blocks_itdq.npz"))
+@pytest.mark.parametrize("fname", ["blocks_itdq.npz", "blocks_itdq_12b.npz"])
+def test_golden_itdq_blocks_oracle(fname):
+    d = np.load(os.path.join(golden_io.GOLDEN, fname))
     orc = ol.oracle()
     for iqt, bd, log2w, log2h, qp, off in d["recs"]:
         n = 1 << (log2w + log2h)

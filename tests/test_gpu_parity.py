@@ -31,16 +31,18 @@ def test_native_library_is_loaded():
     assert "libxevd_hip.so" in maps
 
 
-def test_gpu_mc_blocks_golden(decs):
-    d = np.load(os.path.join(golden_io.GOLDEN, "blocks_mc.npz"))
+@pytest.mark.parametrize("fname", ["blocks_mc.npz", "blocks_mc_12b.npz"])
+def test_gpu_mc_blocks_golden(decs, fname):
+    d = np.load(os.path.join(golden_io.GOLDEN, fname))
     for bd, admvp, luma, has_dx, has_dy, w, h, gx, gy, off in d["recs"]:
         plane = d[f"plane_bd{bd}"]
         out = decs[(int(admvp), 0)].test_mc(plane, 0, 0, int(has_dx), int(has_dy), int(gx), int(gy), int(w), int(h), int(bd), bool(luma))
         assert np.array_equal(out.ravel(), d["pred"][off:off + w * h]), (bd, admvp, luma, has_dx, has_dy, w, h, gx, gy)
 
 
-def test_gpu_itdq_blocks_golden(decs):
-    d = np.load(os.path.join(golden_io.GOLDEN, "blocks_itdq.npz"))
+@pytest.mark.parametrize("fname", ["blocks_itdq.npz", "blocks_itdq_12b.npz"])
+def test_gpu_itdq_blocks_golden(decs, fname):
+    d = np.load(os.path.join(golden_io.GOLDEN, fname))
     for iqt, bd, log2w, log2h, qp, off in d["recs"]:
         n = 1 << (log2w + log2h)
         out = decs[(0, int(iqt))].test_itdq(d["coef"][off:off + n], int(log2w), int(log2h), [int(qp)], int(bd))
@@ -56,7 +58,7 @@ def test_gpu_fine_grained_recon_and_deblock_shims(decs):
     orc = ol.oracle()
     dec = decs[(0, 0)]
     rng = np.random.default_rng(31)
-    for bd in (8, 10):
+    for bd in (8, 10, 12):
         for is_coef in (0, 1):
             for (w, h) in ((16, 8), (4, 4), (64, 32), (2, 2)):
                 # predictions outside the sample range too: without coefficients the reference clips them (xevd_recon.c:41-48), e.g. the
@@ -108,6 +110,31 @@ def test_gpu_pictures_golden(name):
     if exp["dmvr_mv"] is not None:      # the vectors the reference keeps for temporal prediction (refined where DMVR ran)
         _, mvs = cases.run_gpu(case, dmvr=True)
         assert np.array_equal(mvs, exp["dmvr_mv"]), f"DMVR vectors: {np.argwhere(mvs != exp['dmvr_mv'])[:4]}"
+
+
+@pytest.mark.parametrize("name", [n for n in golden_io.PICTURE_CASES if "addb" in n or "alf" in n or "all_tools" in n or "ctu128_10b" in n or "12b" in n])
+def test_gpu_pictures_golden_scalar_deblocking(name, monkeypatch):
+    """k_addb_alf<false>: the scalar ADDB line filters - the instantiation every picture above 10 bits takes - on the ADDB / ALF goldens of every bit depth
+    (XEVD_HIP_ADDB_SCALAR is read when a context opens)"""
+    monkeypatch.setenv("XEVD_HIP_ADDB_SCALAR", "1")
+    case, exp = golden_io.load_picture_case(name)
+    out = cases.run_gpu(case)
+    for c in range(3):
+        assert np.array_equal(out[c], exp["out"][c]), f"final plane {c}: {np.argwhere(out[c] != exp['out'][c])[:4]}"
+
+
+@pytest.mark.parametrize("w,h,bd,tools", [(64, 192, 8, {}), (1088, 256, 10, {"addb": 1, "alf": 1}), (64, 128, 10, {"addb": 1, "alf": 1}), (2112, 128, 8, {"addb": 1, "alf": 1}),
+                                          (8, 264, 8, {}), (1032, 72, 10, {"addb": 1, "alf": 1, "log2_ctu": 7})],
+                         ids=["64x192", "1088x256", "64x128_filters", "2112x128", "8x264", "1032x72_ctu128"])
+def test_gpu_one_region_wide_last_strip(w, h, bd, tools):
+    """pictures whose last strip of 64x64 regions is ONE region wide (regions_x % 16 == 1: widths 1..64, 1025..1088, 2049..2112 - e.g. portrait 1080 x 1920) and pictures
+    one filter tile wide: the index -> (row, column) maps of k_inter and k_addb_alf divide by that width with a multiplication, and floor(2^32 / 1) + 1 does not fit"""
+    main = 1 if tools else 0
+    cs = cases.build_case(f"strip_{w}x{h}", w, h, bd, main, main, (1, 1), 0.4, dict(tools, inter_frac=0.8))
+    ref, _, _, _ = cases.run_cpu("oracle", cs)
+    out = cases.run_gpu(cs)
+    for c in range(3):
+        assert np.array_equal(out[c], ref.bufs[c]), f"{w}x{h} plane {c}: {np.argwhere(out[c] != ref.bufs[c])[:4]}"
 
 
 @pytest.mark.gpu

@@ -52,7 +52,7 @@ def _set_mc_tables(lib, admvp):
 
 
 @pytest.mark.parametrize("admvp", [0, 1])
-@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("bd", [8, 10, 12])
 def test_mc_blocks(admvp, bd):
     lib, orc = ol.ref(), ol.oracle()
     rng = np.random.default_rng(100 + admvp * 2 + bd)
@@ -100,7 +100,7 @@ def _dq_params(log2w, log2h, qp, bd, iqt):
 
 
 @pytest.mark.parametrize("iqt", [0, 1])
-@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("bd", [8, 10, 12])
 def test_itdq_all_sizes(iqt, bd):
     lib, orc = ol.ref(), ol.oracle()
     rng = np.random.default_rng(7 + iqt + bd)
@@ -151,7 +151,7 @@ def test_itdq_all_sizes(iqt, bd):
 def test_recon_wraps_like_reference():
     lib, orc = ol.ref(), ol.oracle()
     rng = np.random.default_rng(3)
-    for bd in (8, 10):
+    for bd in (8, 10, 12):
         for is_coef in (0, 1):
             w, h = 16, 8
             pred = rng.integers(0, 1 << bd, (h, w)).astype(np.int16)
@@ -166,7 +166,7 @@ def test_recon_wraps_like_reference():
 def test_deblock_segments():
     lib, orc = ol.ref(), ol.oracle()
     rng = np.random.default_rng(11)
-    for bd in (8, 10):
+    for bd in (8, 10, 12):
         for trial in range(400):
             st = int(rng.integers(1, 13)) << (bd - 8)
             base = rng.integers(0, 1 << bd)

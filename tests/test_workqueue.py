@@ -96,6 +96,30 @@ def test_c_queue_reports_a_failing_job_and_still_drains():
     assert q.push(jobs[0]) != 0 if q.q else True
 
 
+def test_c_queue_reports_a_job_failing_with_the_unexpected_code():
+    """-105 (XGPU_ERR_UNEXPECTED: every HIP error and frame_end failure) is a job's failure like any other: reported even when other jobs of the worker succeeded
+    and another worker never came up - "worker down" is a flag of its own, not that code"""
+    jobs = workqueue.split_gops(_streams()[0][1])
+    q = workqueue.WorkQueue()
+    for j in jobs * 3:
+        q.push(j)
+    q.close()
+    calls = []
+
+    def decode(device, job):
+        calls.append(job.unit)
+        return -105 if len(calls) == 2 else 0
+    rc, done = q.run([0, 7], decode, init_ok=lambda d: d != 7)
+    q.destroy()
+    assert rc == -105 and done == [3 * len(jobs) - 1, 0]
+    q = workqueue.WorkQueue()
+    q.push(jobs[0])
+    q.close()
+    rc, done = q.run([7, 9], decode, init_ok=lambda d: False)          # no worker at all
+    q.destroy()
+    assert rc == -105 and done == [0, 0]
+
+
 def _worker(rank, world, port, out_q):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"

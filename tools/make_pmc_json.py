@@ -45,7 +45,9 @@ def main():
             kern[k]["fetch_size_kb"] = round(f, 1)
             kern[k]["write_size_kb"] = round(wv, 1)
             kern[k]["traffic_bytes_fetch_size_method"] = int((2.0 * f + wv) * 1024)
-    json.dump({"workload": wl, "commit": os.environ.get("XEVD_COMMIT"), "source": f"{rpath} + {wpath} (rocprofv3 --pmc, separate passes, no tracing)",
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    json.dump({"workload": wl, "commit": os.environ.get("XEVD_COMMIT"), "sources_sha256": {k: bench.kernel_sources_sha256(k) for k in kern if k in bench.KERNEL_SOURCES}, "source": f"{rpath} + {wpath} (rocprofv3 --pmc, separate passes, no tracing)",
                "method": "read = 128*RDREQ_128B + 64*RDREQ_64B + 32*RDREQ_32B, write = 64*WRREQ_64B + 32*(WRREQ - WRREQ_64B); traffic_bytes_fetch_size_method = "
                          "(2*FETCH_SIZE + WRITE_SIZE) KB, the guide's gfx950 correction, for comparison",
                "kernels": kern}, open(opath, "w"), indent=1)

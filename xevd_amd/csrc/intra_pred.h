@@ -13,7 +13,9 @@ __device__ __forceinline__ int clip3i(int lo, int hi, int v) { return min(max(v,
 __device__ __forceinline__ uint32_t recon2i(uint32_t pred, uint32_t res, int maxv)
 {
     typedef short v2s_ __attribute__((ext_vector_type(2)));
-    const v2s_ sum = __builtin_bit_cast(v2s_, pred) + __builtin_bit_cast(v2s_, res);
+    typedef unsigned short v2u_ __attribute__((ext_vector_type(2)));
+    // (the sum as UNSIGNED halves: pred + res may pass 32767 and has to wrap like the reference's (s16) cast - signed vector overflow would be undefined)
+    const v2s_ sum = __builtin_bit_cast(v2s_, __builtin_bit_cast(v2u_, pred) + __builtin_bit_cast(v2u_, res));
     const v2s_ r = __builtin_elementwise_min(__builtin_elementwise_max(sum, (v2s_)(0)), (v2s_)((short)maxv));
     return __builtin_bit_cast(uint32_t, r);
 }

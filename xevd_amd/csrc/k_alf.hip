@@ -173,7 +173,7 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
     if (tile >= n_tiles) return;
     // (tile / tiles_x by a multiplication: tiles_x is only known at run time, and the division was a reciprocal sequence of ~30 instructions in front of every tile of a
     //  kernel that is bound by instruction issue; floor(2^32 / d) + 1 is exact for n x d < 2^32)
-    const int ty = (int)__umulhi((uint32_t)tile, a.magic_tiles_x), tx = tile - ty * tiles_x;
+    const int ty = a.magic_tiles_x ? (int)__umulhi((uint32_t)tile, a.magic_tiles_x) : tile, tx = tile - ty * tiles_x;      // (magic 0: one tile per row)
     const int tx0 = tx << 6, ty0 = ty << 6;
     const int t = threadIdx.x;
 #ifdef XGPU_ALF_TRACE
@@ -704,9 +704,9 @@ void launch_alf(xgpu_ctx *c, const AlfArgs &a_, const AddbArgs *deblock, const D
 {
     AlfArgs a = a_;
     const int tiles = ((a.pic_w + 63) >> 6) * ((a.pic_h + 63) >> 6);
-    a.magic_tiles_x = (uint32_t)((1ull << 32) / (uint64_t)((a.pic_w + 63) >> 6)) + 1u;
+    a.magic_tiles_x = a.pic_w > 64 ? (uint32_t)((1ull << 32) / (uint64_t)((a.pic_w + 63) >> 6)) + 1u : 0u;      // floor(2^32 / 1) + 1 does not fit: 0 = one tile per row
     const dim3 grid(((tiles + 7) >> 3) << 3);
-    static const bool scalar_knob = getenv("XEVD_HIP_ADDB_SCALAR") != NULL;
+    const bool scalar_knob = c->addb_scalar != 0;
     static const int lds_pad = getenv("XEVD_HIP_ALF_LDSPAD") ? atoi(getenv("XEVD_HIP_ALF_LDSPAD")) : 0;      // measurement knob: dynamic LDS that only lowers the occupancy
     if (deblock && !scalar_knob && deblock->bd_l <= 10 && deblock->bd_c <= 10) hipLaunchKernelGGL(k_addb_alf<true>, grid, dim3(256), lds_pad, c->stream, a, *deblock, src.y, src.u, src.v, dst.y, dst.u, dst.v);
     else if (deblock) hipLaunchKernelGGL(k_addb_alf<false>, grid, dim3(256), 0, c->stream, a, *deblock, src.y, src.u, src.v, dst.y, dst.u, dst.v);

@@ -838,7 +838,7 @@ __device__ __forceinline__ void inter_fused_body(const InterArgs &a)
         ry = r >> 4; rx = (s << 4) + (r & 15);
     } else {
         const int r = idx - a.full_entries;
-        ry = (int)__umulhi((uint32_t)r, a.magic_last); rx = (a.regions_x & ~15) + r - ry * (a.regions_x & 15);
+        ry = a.magic_last ? (int)__umulhi((uint32_t)r, a.magic_last) : r; rx = (a.regions_x & ~15) + r - ry * (a.regions_x & 15);
     }
     const int sx = (rx << 4) + ((wave & 1) << 3) + (lane & 7), sy = (ry << 4) + ((wave >> 1) << 3) + (lane >> 3);
     // everything a role needs first, requested at once

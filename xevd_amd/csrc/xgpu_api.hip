@@ -122,6 +122,7 @@ int xgpu_open(const xgpu_seq_params *sp, xgpu_ctx **out)
     c->err[0] = 0; c->timing = 0; c->have_frame = 0; c->d_maps = NULL; c->d_dra = NULL; c->d_ctb_flag = NULL; c->stream = 0; c->up_stream = 0; c->down_stream = 0; c->side_stream = 0; c->after_inter = 0; c->have_after_inter = 0; c->where = 0; c->addb_pending = 0;
     c->fork_ev = c->join_ev = 0;
     c->intra_small_min = getenv("XEVD_HIP_INTRA_SMALL_MIN") ? std::max(1, atoi(getenv("XEVD_HIP_INTRA_SMALL_MIN"))) : 2048;      // (k_intra.hip: launch_intra; read per context, tests set 1)
+    c->addb_scalar = getenv("XEVD_HIP_ADDB_SCALAR") != NULL;
     c->split_addb_alf = getenv("XEVD_HIP_SPLIT_ADDB_ALF") != NULL;      // measurement knob: ADDB and ALF as two kernels (the round-2 chain) instead of k_addb_alf
     for (int i = 0; i < 2; i++) { c->d_out[i] = NULL; c->out_caps[i] = 0; c->out_ready[i] = c->out_done[i] = 0; c->out_busy[i] = 0; }
     c->d_md5 = NULL; c->md5_ready = 0;
@@ -401,8 +402,8 @@ int xgpu_pic_md5(xgpu_ctx *c, int pic, const xgpu_dra_luts *dra, uint8_t digest[
     const int w = c->sp.width, h = c->sp.height;
     const size_t need = ((size_t)w * h + 2 * (size_t)(w >> 1) * (h >> 1)) * 2;
     if (!c->d_md5) {
-        if (hipMalloc((void **)&c->d_md5, need + 64) != hipSuccess) { snprintf(c->err, sizeof(c->err), "pic_md5: cannot allocate the %zu-byte message buffer", need + 64); return XGPU_ERR_OUT_OF_MEMORY; }
-        HIPCHK(c, hipEventCreateWithFlags(&c->md5_ready, hipEventDisableTiming));
+        if (!c->md5_ready) HIPCHK(c, hipEventCreateWithFlags(&c->md5_ready, hipEventDisableTiming));      // the event first: d_md5 != NULL means both exist
+        if (hipMalloc((void **)&c->d_md5, need + 64) != hipSuccess) { c->d_md5 = NULL; snprintf(c->err, sizeof(c->err), "pic_md5: cannot allocate the %zu-byte message buffer", need + 64); return XGPU_ERR_OUT_OF_MEMORY; }
     }
     if (dra) { const int rc = upload_dra(c, dra); if (rc < 0) return rc; }
     uint32_t *d_digest = (uint32_t *)(c->d_md5 + ((need + 15) & ~(size_t)15));

@@ -110,7 +110,7 @@ struct InterArgs {
     const InterItem *items;
     int      n_work;
     int      regions_x, strip_entries, full_entries;      // 16 x regions_y; entries in front of the last, narrower strip
-    uint32_t magic_strip, magic_last;                     // floor(2^32 / d) + 1 for d = strip_entries and the last strip's width: n / d = mulhi(n, magic) for n x d < 2^32
+    uint32_t magic_strip, magic_last;                     // floor(2^32 / d) + 1 for d = strip_entries and the last strip's width: n / d = mulhi(n, magic) for n x d < 2^32; magic_last 0 = width 1 (or no last strip)
     const CuRec    *cus;
     const int16_t  *resid;
     ScuRec  *maps;
@@ -253,7 +253,7 @@ struct AddbArgs {
 struct AlfArgs {
     int      s_l, s_c, pic_w, pic_h, bd, log2_ctu, w_ctu, across_tiles;
     TileMask tiles;                    // tile starts: a CTU's windows end at its tile (alf_process_tile)
-    uint32_t magic_tiles_x;            // floor(2^32 / tiles per row) + 1, set by launch_alf: tile / tiles_x as a multiplication
+    uint32_t magic_tiles_x;            // floor(2^32 / tiles per row) + 1, set by launch_alf: tile / tiles_x as a multiplication; 0 = one tile per row
     int      multi_tile;               // 0: one tile - the masks are not looked at
     int      pad;                      // 1: the tiles on the picture border also write the 144 / 72-sample padding of the output picture (no k_pad launch)
     int      enable[3];
@@ -340,6 +340,7 @@ struct xgpu_ctx {
     int             where;             // 0: the picture being built lives in its DPB slot, 1: in the scratch picture
     int             order_rl;          // a batch of the picture has CUs decoded after their right-hand neighbours (xgpu_dbatch.order_rl): k_dbk's order-aware instantiation
     int             intra_small_min;   // level-1 launches with at least this many CUs of at most 16 SCUs give those 16 lanes each (k_intra_l1; XEVD_HIP_INTRA_SMALL_MIN, default 2048)
+    int             addb_scalar;                       // XEVD_HIP_ADDB_SCALAR: the scalar line filters (the > 10-bit instantiation) at every bit depth - read per context, tests set it
     int             addb_pending, split_addb_alf;      // ADDB + ALF in one kernel: xgpu_deblock left its arguments in addb_args for xgpu_alf
     AddbArgs        addb_args;
     // timing

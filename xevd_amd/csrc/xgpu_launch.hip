@@ -83,7 +83,8 @@ int xgpu_batch_recon_ahead(xgpu_ctx *c, xgpu_dbatch *db, xgpu_dbatch *next)
         const int regions_x = (c->sp.width + 63) >> 6, regions_y = (c->sp.height + 63) >> 6;
         a.regions_x = regions_x; a.strip_entries = XGPU_INTER_STRIP * regions_y; a.full_entries = (regions_x / XGPU_INTER_STRIP) * a.strip_entries;
         a.magic_strip = (uint32_t)((1ull << 32) / (uint64_t)a.strip_entries) + 1u;
-        a.magic_last = (regions_x % XGPU_INTER_STRIP) ? (uint32_t)((1ull << 32) / (uint64_t)(regions_x % XGPU_INTER_STRIP)) + 1u : 0u;
+        // (a last strip ONE region wide: floor(2^32 / 1) + 1 wraps to 1 - magic 0 tells the kernel that the quotient is the index itself)
+        a.magic_last = (regions_x % XGPU_INTER_STRIP) > 1 ? (uint32_t)((1ull << 32) / (uint64_t)(regions_x % XGPU_INTER_STRIP)) + 1u : 0u;
     }
     a.cus = db->d_cus; a.resid = db->d_resid;
     a.maps = c->d_maps; a.w_scu = c->w_scu; a.owner = db->d_owner; a.n_cu = db->n_cu; a.cur_poc = c->fp.poc;

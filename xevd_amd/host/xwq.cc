@@ -55,11 +55,11 @@ int xwq_run(xwq *q, const int *devices, int n_devices, xwq_init_fn init, xwq_job
 {
     if (!q || !devices || n_devices <= 0 || !job) return XWQ_ERR_INVALID_ARGUMENT;
     std::vector<std::thread> th;
-    std::vector<int> done((size_t)n_devices, 0), rc((size_t)n_devices, 0);
+    std::vector<int> done((size_t)n_devices, 0), rc((size_t)n_devices, 0), down((size_t)n_devices, 0);      // down: the worker never came up (its own flag: a job may fail with any code, -105 included)
     for (int i = 0; i < n_devices; i++)
         th.emplace_back([&, i] {
             void *st = init ? init(devices[i], user) : nullptr;
-            if (init && !st) { rc[(size_t)i] = XWQ_ERR_UNEXPECTED; return; }              // this device is out; the others take its share
+            if (init && !st) { down[(size_t)i] = 1; return; }                             // this device is out; the others take its share
             xwq_job j;
             while (xwq_pop(q, &j) == 1) {
                 const int r = job(st, &j);
@@ -72,8 +72,8 @@ int xwq_run(xwq *q, const int *devices, int n_devices, xwq_init_fn init, xwq_job
     int first = 0, usable = 0;
     for (int i = 0; i < n_devices; i++) {
         if (jobs_done) jobs_done[i] = done[(size_t)i];
-        if (rc[(size_t)i] != XWQ_ERR_UNEXPECTED || done[(size_t)i]) usable++;
-        if (rc[(size_t)i] < 0 && rc[(size_t)i] != XWQ_ERR_UNEXPECTED && first == 0) first = rc[(size_t)i];
+        if (!down[(size_t)i]) usable++;
+        if (rc[(size_t)i] < 0 && first == 0) first = rc[(size_t)i];                       // every failed job is reported, whatever its code
     }
     if (!usable) return XWQ_ERR_UNEXPECTED;                                                // no worker came up: nothing was decoded
     return first;
