@@ -23,7 +23,19 @@ static __constant__ uint8_t k_clip[52][5] = {
     {0,4,5,7,7},{0,4,5,8,8},{0,4,6,9,9},{0,5,7,10,10},{0,6,8,11,11},{0,6,8,13,13},{0,7,10,14,14},{0,8,11,16,16},
     {0,9,12,18,18},{0,10,13,20,20},{0,11,15,23,23},{0,13,17,25,25} };
 
-// get_bs, xevdm_df.c:361-513.  q = record of the right/below SCU, p = left/above; cross_ctu: the edge lies on a CTU boundary.
+// |a - b| < 4 in both components of two packed (x, y) vectors.  The reference subtracts in int (abs(a - b) of two s16 never wraps); here the packed difference
+// SATURATES (v_pk_sub_i16 ... clamp), so a difference beyond s16 stays large instead of wrapping into (-4, 4), and the test is one mask: |d| < 4 <=> no bit above bit 1
+__device__ __forceinline__ bool mv_same(uint32_t a, uint32_t b)
+{
+    uint32_t d, e, m;
+    asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
+    asm("v_pk_sub_i16 %0, %1, %2 clamp" : "=v"(e) : "v"(b), "v"(a));
+    asm("v_pk_max_i16 %0, %1, %2" : "=v"(m) : "v"(d), "v"(e));
+    return (m & 0xFFFCFFFCu) == 0;
+}
+// get_bs, xevdm_df.c:361-513.  q = record of the right/below SCU, p = left/above; cross_ctu: the edge lies on a CU boundary that is a CTU boundary.
+// (Round 6: the vector comparisons on packed pairs - four v_pk_* per pair of vectors instead of two subtractions, two negations, two maxima and two compares per
+//  component; the kernel this runs in, k_addb_alf, is bound by instruction issue and every one of its 324 edge segments per tile computes a strength.)
 __device__ __forceinline__ int addb_bs(const uint4 q, const uint4 p, bool cross_ctu, const uint8_t *pic_id)
 {
     const bool intra = ((q.x | p.x) >> 15) & 1;
@@ -34,18 +46,14 @@ __device__ __forceinline__ int addb_bs(const uint4 q, const uint4 p, bool cross_
     // reference pictures by identity (XEVD_PIC pointers in the reference): device picture slot, 255 = none
     const int Q0 = q0 >= 0 ? pic_id[q0 * 2] : 255, Q1 = q1 >= 0 ? pic_id[q1 * 2 + 1] : 255;
     const int P0 = p0 >= 0 ? pic_id[p0 * 2] : 255, P1 = p1 >= 0 ? pic_id[p1 * 2 + 1] : 255;
-    const int qm[2][2] = { { q0 >= 0 ? (int16_t)(q.z & 0xFFFF) : 0, q0 >= 0 ? (int16_t)(q.z >> 16) : 0 },
-                           { q1 >= 0 ? (int16_t)(q.w & 0xFFFF) : 0, q1 >= 0 ? (int16_t)(q.w >> 16) : 0 } };
-    const int pm[2][2] = { { p0 >= 0 ? (int16_t)(p.z & 0xFFFF) : 0, p0 >= 0 ? (int16_t)(p.z >> 16) : 0 },
-                           { p1 >= 0 ? (int16_t)(p.w & 0xFFFF) : 0, p1 >= 0 ? (int16_t)(p.w >> 16) : 0 } };
-#define MVSAME(a, b) (abs((a)[0] - (b)[0]) < 4 && abs((a)[1] - (b)[1]) < 4)
-    if ((Q0 == P0 && Q1 == P1) || (Q0 == P1 && Q1 == P0)) {
-        if (Q0 == Q1) return (MVSAME(qm[0], pm[0]) && MVSAME(qm[1], pm[1]) && MVSAME(qm[0], pm[1]) && MVSAME(qm[1], pm[0])) ? 0 : 1;
-        if (Q0 == P0 && Q1 == P1) return (MVSAME(qm[0], pm[0]) && MVSAME(qm[1], pm[1])) ? 0 : 1;
-        return (MVSAME(qm[0], pm[1]) && MVSAME(qm[1], pm[0])) ? 0 : 1;
-    }
-    return 1;
-#undef MVSAME
+    // the vector of an unused list counts as (0, 0) (xevdm_df.c:437-452)
+    const uint32_t qm0 = q0 >= 0 ? q.z : 0u, qm1 = q1 >= 0 ? q.w : 0u, pm0 = p0 >= 0 ? p.z : 0u, pm1 = p1 >= 0 ? p.w : 0u;
+    const bool straight = Q0 == P0 && Q1 == P1, crossed = Q0 == P1 && Q1 == P0;
+    if (!straight && !crossed) return 1;
+    const bool s_ok = mv_same(qm0, pm0) && mv_same(qm1, pm1), c_ok = mv_same(qm0, pm1) && mv_same(qm1, pm0);
+    if (Q0 == Q1) return (s_ok && c_ok) ? 0 : 1;
+    if (straight) return s_ok ? 0 : 1;
+    return c_ok ? 0 : 1;
 }
 
 // deblock_scu_line_luma, xevdm_df.c:584-709.  s[0..3] = p3 p2 p1 p0, s[4..7] = q0 q1 q2 q3; in place.
@@ -108,6 +116,18 @@ __device__ __forceinline__ int addb_edge_strength(const AddbArgs &a, const TileM
     if (!(rq.x & eflag) || tile_edge) return 0;
     const int epos = eq << 2;
     const bool cross = (epos & ((1 << a.log2_ctu) - 1)) == 0;
+    return addb_bs(rq, rp, cross, s_pic);
+}
+
+// ... with the direction per lane (k_alf.hip's interior tiles decide the vertical and the horizontal segments of a tile in one pass of all lanes)
+__device__ __forceinline__ int addb_edge_strength_rt(const AddbArgs &a, const TileMask &no_filter, const uint4 rq, const uint4 rp, int eq, bool hor, const uint8_t *s_pic)
+{
+    const uint32_t eflag = hor ? SCU_EDGE_T : SCU_EDGE_L;
+    const int ctu_sh = a.log2_ctu - 2, ctu_i = (eq >> ctu_sh) & 255;
+    const uint32_t starts = hor ? no_filter.hb[ctu_i >> 5] : no_filter.vb[ctu_i >> 5];
+    const bool tile_edge = (eq & ((1 << ctu_sh) - 1)) == 0 && ((starts >> (ctu_i & 31)) & 1);
+    if (!(rq.x & eflag) || tile_edge) return 0;
+    const bool cross = ((eq << 2) & ((1 << a.log2_ctu) - 1)) == 0;
     return addb_bs(rq, rp, cross, s_pic);
 }
 
@@ -216,6 +236,30 @@ __device__ __forceinline__ void addb_line_chroma_pk(uint32_t s[4], int bs, int a
     }
     s[1] = pk_sel(on, pku(po), s[1]); s[2] = pk_sel(on, pku(qo), s[2]);
 }
+// The parameters of a segment's luma filter and of one chroma plane's filter (the front halves of addb_edge_filter above), for callers that give the line pairs and
+// the planes of a segment to different waves (k_alf.hip, round 6).  chroma: false = a luma-only edge (local dual tree), nothing to filter in the planes
+__device__ __forceinline__ void addb_luma_params(const AddbArgs &a, uint32_t rqx, uint32_t rpx, int bs, const uint8_t *s_alpha, const uint8_t *s_beta, const uint8_t *s_clip,
+                                                 int &alpha, int &beta, int &c1)
+{
+    const int qp = (((rqx >> 16) & 0x7F) + ((rpx >> 16) & 0x7F) + 1) >> 1, scale = a.bd_l - 8;
+    const int ia = addb_index(qp, a.alpha_off), ib = addb_index(qp, a.beta_off);
+    alpha = s_alpha[ia] << scale; beta = (s_beta[ib] << scale) & 0xFF;
+    c1 = (s_clip[ia * 5 + bs] << max(0, a.bd_l - 9)) & 0xFF;
+}
+template <int DIR>
+__device__ __forceinline__ bool addb_chroma_params(const AddbArgs &a, uint32_t rqx, uint32_t rpx, int bs, int pl, const uint8_t *s_alpha, const uint8_t *s_beta, const uint8_t *s_clip,
+                                                   const int8_t *s_cqp, int &alpha, int &beta, int &c0)
+{
+    if (rqx & (DIR == 0 ? SCU_NOCH_L : SCU_NOCH_T)) return false;
+    const int qp = (((rqx >> 16) & 0x7F) + ((rpx >> 16) & 0x7F) + 1) >> 1, scale = a.bd_l - 8, boff = 6 * (a.bd_c - 8);
+    const int q = clip3a(-boff, 57, qp + (pl ? a.qp_v_off : a.qp_u_off));
+    const int qc = s_cqp[pl * 96 + q + boff];
+    const int ia = addb_index(qc, a.alpha_off), ib = addb_index(qc, a.beta_off);
+    alpha = s_alpha[ia] << scale; beta = (s_beta[ib] << scale) & 0xFF;      // luma depth scales chroma too (:926-927)
+    c0 = ((s_clip[ia * 5 + bs] + 1) << max(0, a.bd_c - 9)) & 0xFF;
+    return true;
+}
+
 // filter half of an edge segment on packed line pairs: LP[0] = lines 0 / 1, LP[1] = lines 2 / 3 of the luma segment (8 positions across the edge each),
 // CP[plane] = the two chroma lines (4 positions).  bs > 0, bit depths <= 10.
 template <int DIR>

@@ -27,7 +27,6 @@ typedef short v2s __attribute__((ext_vector_type(2)));
 #define LROWS 72          // 70 window rows (-3..66); the fused form keeps the deblocking filter's 72 (-4..67)
 #define LSTR  72          // luma LDS row stride in s16: window col c (-3..66) at index c+4
 #define CROWS 36
-#define SSTR  36          // sub-block sums row stride (u16); sub-block col c (-1..32) at index c+2 (own pairs 4-byte aligned)
 #define CSTR  40          // chroma: window col c (-2..33) at index c+4 (keeps the 8-byte interior pieces aligned)
 
 struct CtuRect { int x0, y0, cw, ch, aL, aR, aT, aB; int tx0, tx1, ty0, ty1; };      // the CTU, its border availability, its tile [tx0,tx1) x [ty0,ty1)
@@ -92,16 +91,32 @@ __device__ __forceinline__ void alf_stage(int16_t *lds, const int16_t *__restric
     }
 }
 
-__constant__ uint8_t k_alf_perm[4][13] = {      // coefficient order per transpose index, xevdm_alf.c:268-273
-    { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12 }, { 9, 4, 10, 8, 1, 5, 11, 7, 3, 0, 2, 6, 12 },
-    { 0, 3, 2, 1, 8, 7, 6, 5, 4, 9, 10, 11, 12 }, { 9, 8, 10, 4, 3, 7, 11, 5, 1, 0, 2, 6, 12 } };
-
 __device__ __forceinline__ v2s asv(uint32_t x) { return __builtin_bit_cast(v2s, x); }
 __device__ __forceinline__ uint32_t asu(v2s x) { return __builtin_bit_cast(uint32_t, x); }
 __device__ __forceinline__ v2s vabs(v2s x) { const v2s z = {0, 0}; const v2s n = z - x; return __builtin_elementwise_max(x, n); }
 // D = S0.i16 * S1.i16 + S2.i32 on the low / high half of a packed pair: two neighbouring output samples share every packed pair sum
 __device__ __forceinline__ int mad_lo(uint32_t ps, int f, int acc) { int r; asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(ps), "v"(f), "v"(acc)); return r; }
 __device__ __forceinline__ int mad_hi(uint32_t ps, int f, int acc) { int r; asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(ps), "v"(f), "v"(acc)); return r; }
+// ... with the coefficient in the HIGH half of its register (the packed table's pairs)
+__device__ __forceinline__ int mad_lo_fh(uint32_t ps, uint32_t f, int acc) { int r; asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[0,1,0,0]" : "=v"(r) : "v"(ps), "v"(f), "v"(acc)); return r; }
+__device__ __forceinline__ int mad_hi_fh(uint32_t ps, uint32_t f, int acc) { int r; asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(r) : "v"(ps), "v"(f), "v"(acc)); return r; }
+// ... with a UNIFORM coefficient register (the chroma filter: kernel arguments) as the instruction's scalar operand - an "v" constraint made a v_mov per use
+#define SC_ "s"
+__device__ __forceinline__ int smad_lo(uint32_t ps, uint32_t f, int acc) { int r; asm("v_mad_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(ps), SC_(f), "v"(acc)); return r; }
+__device__ __forceinline__ int smad_hi(uint32_t ps, uint32_t f, int acc) { int r; asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,0,0,0]" : "=v"(r) : "v"(ps), SC_(f), "v"(acc)); return r; }
+__device__ __forceinline__ int smad_lo_fh(uint32_t ps, uint32_t f, int acc) { int r; asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[0,1,0,0]" : "=v"(r) : "v"(ps), SC_(f), "v"(acc)); return r; }
+__device__ __forceinline__ int smad_hi_fh(uint32_t ps, uint32_t f, int acc) { int r; asm("v_mad_i32_i16 %0, %1, %2, %3 op_sel:[1,1,0,0]" : "=v"(r) : "v"(ps), SC_(f), "v"(acc)); return r; }
+// the first term of a filter sum: f . x + 256 with the rounding constant as the scalar operand of the three-source form (the accumulating v_dot2c needed a v_mov of 256 per sum)
+__device__ __forceinline__ int dot2s_first(uint32_t f, uint32_t x) { int r; asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : "v"(f), "v"(x), SC_(256)); return r; }
+__device__ __forceinline__ int sdot2s(uint32_t f, uint32_t x, int acc) { int r; asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(r) : SC_(f), "v"(x), "v"(acc)); return r; }
+// two filter sums -> two samples: >> 9, clip to [0, maxv] (one v_med3_i32 each: the compiler cannot know 0 <= maxv and made a max and a min), packed by one byte permute
+__device__ __forceinline__ uint32_t clip_pack(int o0, int o1, int maxv)
+{
+    int a, b;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(a) : "v"(o0 >> 9), SC_(maxv));
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(b) : "v"(o1 >> 9), SC_(maxv));
+    return __builtin_amdgcn_perm((uint32_t)b, (uint32_t)a, 0x05040100u);
+}
 typedef unsigned short v2us __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t padd(uint32_t x, uint32_t y) { return __builtin_bit_cast(uint32_t, __builtin_bit_cast(v2us, x) + __builtin_bit_cast(v2us, y)); }
 // (x.lo + y.hi, x.hi + y.lo): the pair sums of two horizontally adjacent taps of ONE output - their mirrored samples sit in a packed pair in reverse order
@@ -143,6 +158,9 @@ extern "C" int xgpu_test_alf_trace(unsigned long long out[16], int reset)
 #else
 #define ATR(p) do { } while (0)
 #endif
+#ifndef XGPU_ALF_WAVES
+#define XGPU_ALF_WAVES 6          // waves per SIMD the fused kernel is compiled for (its registers); the workgroup's LDS allows seven workgroups per CU
+#endif
 template <bool FUSED, bool PK = false>
 __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
                                            const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_,
@@ -151,9 +169,12 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
     constexpr int RO = FUSED ? 4 : 3, CO = FUSED ? 2 : 4;
     __shared__ __attribute__((aligned(16))) int16_t l_y[LROWS * LSTR];
     __shared__ __attribute__((aligned(16))) int16_t l_c[2][CROWS * CSTR];
-    __shared__ int16_t l_coef[25 * 13 + 7];
-    // sums of |Laplacian| over the 2x2 sub-blocks of the tile + one ring: [direction V, H, D0, D1][sub-block row -1..32][col -1..32]
-    __shared__ __attribute__((aligned(16))) uint16_t l_lap[4][34][SSTR];
+    // sums of |Laplacian| (V, H, D0, D1 as one uint4) over the 4x4 blocks of the lattice OFFSET by two samples from the tile's 4x4 blocks - block (m, n) = samples
+    // [4m - 2, 4m + 2) x [4n - 2, 4n + 2), m, n = 0..16 - see phase 1 below; the fused form's deblocking state (records, tables, lists: 6.4 KB) lies in the same bytes
+    constexpr int LAP_BYTES = 6512;
+    static_assert(17 * 17 * 16 <= LAP_BYTES, "the offset-lattice sums fit");
+    __shared__ __attribute__((aligned(16))) uint8_t l_lap[LAP_BYTES];
+    uint4 (*const l_o)[17] = (uint4 (*)[17])l_lap;
     // the filtered samples on the picture border that this tile holds: [plane][first / last row of the picture][column of the tile] and [first / last column][row],
     // for the border replication below (what k_pad did in a launch of its own)
     // They live in l_y: every lane has its luma window in registers before the barrier behind phase 1, so the staged tile is dead by the time the first filtered
@@ -181,8 +202,12 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
     const bool atr_on = (t & 63) == 0 && tile % 61 == 7;
     if (atr_on) atomicAdd(&g_alf_trace[15], 1ull);
 #endif
-    // the CTU this tile belongs to and its border availability (alf_process_tile :984-999)
-    CtuRect k;
+    // the CTU this tile belongs to and its border availability (alf_process_tile :984-999).  A chain of dependent scalar loads (kernel arguments, the tile masks, the
+    // CTU's luma flag): the fused form runs it BEHIND the requests for the tile's region (round 5 ran it in front: a dozen scalar round trips before the first sample
+    // was asked for - the "setup" fifth of a wave's life in profiles/round5_exp_addb_alf_wave_life.txt)
+    CtuRect k, kc;
+    bool luma_on;
+    auto ctu_setup = [&]() {
     const int ctu = 1 << a.log2_ctu;
     k.x0 = tx0 & ~(ctu - 1); k.y0 = ty0 & ~(ctu - 1);
     k.cw = min(ctu, a.pic_w - k.x0); k.ch = min(ctu, a.pic_h - k.y0);
@@ -197,11 +222,11 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
     k.aR = a.across_tiles ? 1 : (k.x0 + k.cw != k.tx1);
     k.aB = a.across_tiles ? 1 : (k.y0 + k.ch != k.ty1);
     const int ctu_idx = (k.y0 >> a.log2_ctu) * a.w_ctu + (k.x0 >> a.log2_ctu);
-    const bool luma_on = a.enable[0] && (a.ctb_in_args ? ((a.ctb_bits[ctu_idx >> 5] >> (ctu_idx & 31)) & 1) != 0 : (a.ctb_flag == nullptr || a.ctb_flag[ctu_idx] != 0));
-
-    if (!FUSED) for (int i = t; i < 25 * 13 + 7; i += 256) l_coef[i] = a.coef[i];      // (fused: behind the window loads, with the deblocking tables)
-    CtuRect kc = k;
+    luma_on = a.enable[0] && (a.ctb_in_args ? ((a.ctb_bits[ctu_idx >> 5] >> (ctu_idx & 31)) & 1) != 0 : (a.ctb_flag == nullptr || a.ctb_flag[ctu_idx] != 0));
+    kc = k;
     kc.x0 >>= 1; kc.y0 >>= 1; kc.cw >>= 1; kc.ch >>= 1; kc.tx0 >>= 1; kc.tx1 >>= 1; kc.ty0 >>= 1; kc.ty1 >>= 1;
+    };
+    if (!FUSED) ctu_setup();
     if (!FUSED) {
         if (luma_on) alf_stage<64, 3, LSTR, 4>(l_y, sy_, a.s_l, k, tx0, ty0, t, 256);
         if (a.enable[1]) alf_stage<32, 2, CSTR, 4>(l_c[0], su_, a.s_c, kc, tx0 >> 1, ty0 >> 1, t, 256);
@@ -214,15 +239,89 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
         // to filter are compacted into a list (LDS atomic counter) and as many lanes as the list is long filter them in place: one wave pass instead of three per direction
         // where CUs are large.  This kernel is bound by VALU issue, unlike k_addb_fused, where the same compaction changed nothing.
         const AddbArgs &da = *d;
-        uint4 (*s_map)[18] = (uint4 (*)[18])&l_lap[0][0][0];
-        uint8_t *s_alpha = (uint8_t *)&l_lap[0][0][0] + 18 * 18 * 16, *s_beta = s_alpha + 52, *s_clip = s_beta + 52, *s_pic = s_clip + 260;
+        uint4 (*s_map)[18] = (uint4 (*)[18])l_lap;
+        uint8_t *s_alpha = (uint8_t *)l_lap + 18 * 18 * 16, *s_beta = s_alpha + 52, *s_clip = s_beta + 52, *s_pic = s_clip + 260;
         int8_t *s_cqp = (int8_t *)(s_pic + XGPU_MAX_REFS * 2);
         constexpr int LIST_OFF = (18 * 18 * 16 + 52 + 52 + 260 + XGPU_MAX_REFS * 2 + 192 + 3) & ~3;
-        uint32_t *s_cnt = (uint32_t *)((uint8_t *)&l_lap[0][0][0] + LIST_OFF);
+        uint32_t *s_cnt = (uint32_t *)((uint8_t *)l_lap + LIST_OFF);
         uint16_t (*s_list)[164] = (uint16_t (*)[164])(s_cnt + 2);            // entry = lane | strength << 8
-        TileMask *s_tm = (TileMask *)((uint8_t *)&l_lap[0][0][0] + LIST_OFF + 8 + ((2 * 164 * 2 + 3) & ~3));      // the tile-border masks: a lane-indexed read of the kernel arguments is a global load
-        static_assert(LIST_OFF + 8 + ((2 * 164 * 2 + 3) & ~3) + (int)sizeof(TileMask) <= (int)sizeof(uint16_t) * 4 * 34 * SSTR, "the deblocking state fits into l_lap");
+        TileMask *s_tm = (TileMask *)((uint8_t *)l_lap + LIST_OFF + 8 + ((2 * 164 * 2 + 3) & ~3));      // the tile-border masks: a lane-indexed read of the kernel arguments is a global load
+        static_assert(LIST_OFF + 8 + ((2 * 164 * 2 + 3) & ~3) + (int)sizeof(TileMask) <= LAP_BYTES, "the deblocking state fits into l_lap");
 #define PK2(lo, hi) ((uint32_t)(uint16_t)(lo) | ((uint32_t)(uint16_t)(hi) << 16))
+        // An INTERIOR tile (its 72 x 72 region and the 18 x 18 records around it lie inside the picture: all but the tiles on the picture border) brings region and records
+        // straight into LDS (global_load_lds, 16 bytes per lane and request: no staging registers, no LDS store pass - k_inter's region role does the same): l_y is 72 rows of
+        // nine chunks, the chroma tiles 2 x 36 rows of five, the records 324 chunks, each array contiguous, chunk c of an array requested by thread c mod 256.  Both
+        // directions' strengths are then decided in ONE pass of all lanes (324 segments) instead of the vertical ones behind the store pass and the horizontal ones behind
+        // the vertical filters.
+        const bool interior = tx0 > 0 && ty0 > 0 && tx0 + 68 <= a.pic_w && ty0 + 68 <= a.pic_h;
+        if (interior) {
+            const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+            typedef __attribute__((address_space(3))) char lds_char;
+            typedef const __attribute__((address_space(1))) char glb_char;
+            {
+                const int r0 = (t * 57) >> 9, c0 = t - r0 * 9;                        // t / 9, t % 9 (t < 256)
+                glb_char *const g0 = (glb_char *)(sy_ + (ty0 - 4) * a.s_l + tx0 - 4);
+                lds_char *const d0 = (lds_char *)l_y + wave * 1024;
+                const uint32_t rs = (uint32_t)a.s_l << 1;
+                // chunk t + 256 it: 256 = 28 rows + 4 chunks, 512 = 56 rows + 8 chunks
+                const int c1 = c0 + 4 >= 9 ? c0 - 5 : c0 + 4, r1 = r0 + 28 + (c0 + 4 >= 9), c2 = c0 + 8 >= 9 ? c0 - 1 : c0 + 8, r2 = r0 + 56 + (c0 + 8 >= 9);
+                __builtin_amdgcn_global_load_lds((glb_char *)(g0 + r0 * rs + c0 * 16), (lds_char *)d0, 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((glb_char *)(g0 + r1 * rs + c1 * 16), (lds_char *)(d0 + 4096), 16, 0, 0);
+                if (t < 648 - 512) __builtin_amdgcn_global_load_lds((glb_char *)(g0 + r2 * rs + c2 * 16), (lds_char *)(d0 + 8192), 16, 0, 0);
+            }
+            {
+                const uint32_t rs = (uint32_t)a.s_c << 1;
+                const uint32_t cbase = (uint32_t)(((ty0 >> 1) - 2) * a.s_c + (tx0 >> 1) - 2) << 1;
+                lds_char *const d0 = (lds_char *)&l_c[0][0] + wave * 1024;
+#pragma unroll
+                for (int it = 0; it < 2; it++) {
+                    const int idx = t + 256 * it, pl = idx >= 180, j = idx - 180 * pl, r = (j * 205) >> 10, c = j - r * 5;      // j / 5 (j < 180)
+                    if (it == 0 || t < 360 - 256)
+                        __builtin_amdgcn_global_load_lds((glb_char *)((glb_char *)(pl ? sv_ : su_) + cbase + r * rs + c * 16), (lds_char *)(d0 + 4096 * it), 16, 0, 0);
+                }
+            }
+            {
+                glb_char *const g0 = (glb_char *)(da.maps + ((ty0 >> 2) - 1) * da.w_scu + (tx0 >> 2) - 1);
+                lds_char *const d0 = (lds_char *)l_lap + wave * 1024;
+                const uint32_t rs = (uint32_t)da.w_scu << 4;
+#pragma unroll
+                for (int it = 0; it < 2; it++) {
+                    const int idx = t + 256 * it, r = (idx * 57) >> 10, c = idx - r * 18;      // idx / 18 (idx < 324)
+                    if (it == 0 || t < 324 - 256) __builtin_amdgcn_global_load_lds((glb_char *)(g0 + r * rs + c * 16), (lds_char *)(d0 + 4096 * it), 16, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                static_assert(XGPU_MAX_REFS * 2 <= 256 && 260 <= 512, "one or two table entries per thread");
+                const uint8_t *clip = (const uint8_t *)k_clip;
+                uint8_t va = 0, vb = 0, vc0 = clip[t], vc1 = 0, vp = 0;
+                int8_t vq = 0;
+                if (t < 52) { va = k_alpha[t]; vb = k_beta[t]; }
+                if (t + 256 < 260) vc1 = clip[t + 256];
+                if (t < XGPU_MAX_REFS * 2) vp = da.pic_id[t];
+                if (t < 192) vq = da.chroma_qp[t];
+                if (t < 52) { s_alpha[t] = va; s_beta[t] = vb; }
+                s_clip[t] = vc0;
+                if (t + 256 < 260) s_clip[t + 256] = vc1;
+                if (t < XGPU_MAX_REFS * 2) s_pic[t] = vp;
+                if (t < 192) s_cqp[t] = vq;
+                if (t < 2) s_cnt[t] = 0;
+                if (t < 16) ((uint32_t *)s_tm)[t] = t < 8 ? da.no_filter.vb[t] : da.no_filter.hb[t - 8];
+            }
+            ctu_setup();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's chunks have landed (the compiler does not know that the requests write LDS)
+            ATR(1);
+            __syncthreads();
+            ATR(2);
+            for (int it = t; it < 324; it += 256) {
+                const bool hor = it >= 162;
+                const int j = hor ? it - 162 : it;
+                int bs;
+                if (!hor) { const int wx = j % 9, sr = j / 9; bs = addb_edge_strength_rt(da, *s_tm, s_map[sr][2 * wx + 1], s_map[sr][2 * wx], (tx0 >> 2) + 2 * wx, false, s_pic); }
+                else      { const int sx = j % 18, g = j / 18; bs = addb_edge_strength_rt(da, *s_tm, s_map[2 * g + 1][sx], s_map[2 * g][sx], (ty0 >> 2) + 2 * g, true, s_pic); }
+                if (bs) s_list[hor][atomicAdd(&s_cnt[hor], 1u)] = (uint16_t)(j | (bs << 8));
+            }
+        } else
         {   // phase A: lane = vertical-edge window wx (grid line x0 + 8 wx) x SCU row sr of the region: window and SCU records from memory to LDS
             const int wx = t % 9, sr = t / 9;
             const int gx = tx0 + 8 * wx, sxq = gx >> 2, srow = (ty0 >> 2) - 1 + sr;
@@ -248,26 +347,23 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
             // in a row before the first window load of the tile had even been issued
             // (and all of their loads before the first of their stores: one more round trip, not six)
             {
-                static_assert(XGPU_MAX_REFS * 2 <= 256 && 260 <= 512 && 25 * 13 + 7 <= 512, "one or two table entries per thread");
+                static_assert(XGPU_MAX_REFS * 2 <= 256 && 260 <= 512, "one or two table entries per thread");
                 const uint8_t *clip = (const uint8_t *)k_clip;
                 uint8_t va = 0, vb = 0, vc0 = clip[t], vc1 = 0, vp = 0;
                 int8_t vq = 0;
-                int16_t vf0 = a.coef[t], vf1 = 0;
                 if (t < 52) { va = k_alpha[t]; vb = k_beta[t]; }
                 if (t + 256 < 260) vc1 = clip[t + 256];
                 if (t < XGPU_MAX_REFS * 2) vp = da.pic_id[t];
                 if (t < 192) vq = da.chroma_qp[t];
-                if (t + 256 < 25 * 13 + 7) vf1 = a.coef[t + 256];
                 if (t < 52) { s_alpha[t] = va; s_beta[t] = vb; }
                 s_clip[t] = vc0;
                 if (t + 256 < 260) s_clip[t + 256] = vc1;
                 if (t < XGPU_MAX_REFS * 2) s_pic[t] = vp;
                 if (t < 192) s_cqp[t] = vq;
-                l_coef[t] = vf0;
-                if (t + 256 < 25 * 13 + 7) l_coef[t + 256] = vf1;
                 if (t < 2) s_cnt[t] = 0;
                 if (t < 16) ((uint32_t *)s_tm)[t] = t < 8 ? da.no_filter.vb[t] : da.no_filter.hb[t - 8];
             }
+            ctu_setup();
             ATR(1);
             __syncthreads();                                 // the tables and the counters (the loads above are in flight across it)
             ATR(2);
@@ -286,44 +382,50 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
         ATR(3);
         __syncthreads();
         ATR(4);
-        // phase B: the vertical edges to filter, in place
-        for (int i = t; i < (int)s_cnt[0]; i += 256) {
+        // phase B: the vertical edges to filter, in place.
+        // PK form (round 6): the four WAVES of the workgroup take the four parts of a listed segment - luma lines 0 / 1, luma lines 2 / 3, the U lines, the V lines - and lane
+        // l of each wave takes list entry l.  Round 5 gave a whole segment to one lane: with the usual 20 .. 60 entries one wave ran all ~580 instructions of the filter code
+        // while the other three waited at the barrier - two such phases were 40 % of a workgroup's life (profiles/round5_exp_addb_alf_wave_life.txt), during which it held its
+        // sixth of the CU's LDS with a quarter of its lanes.  The parts touch disjoint samples; the instructions issued are about the same, the phase is a quarter as long.
+        if (PK) {
+            const int role = __builtin_amdgcn_readfirstlane(t >> 6);
+            const int maxl = (1 << da.bd_l) - 1, maxc = (1 << da.bd_c) - 1;
+            for (int i = t & 63; i < (int)s_cnt[0]; i += 64) {
+                const int e = s_list[0][i], seg = e & 255, bs = e >> 8, wx = seg % 9, sr = seg / 9;
+                const uint32_t rpx = s_map[sr][2 * wx].x, rqx = s_map[sr][2 * wx + 1].x;
+                if (role < 2) {
+                    // lines = rows here: the pair (row 2 role, row 2 role + 1) is formed with byte permutes, sample by sample across the edge
+                    int alpha, beta, c1;
+                    addb_luma_params(da, rqx, rpx, bs, s_alpha, s_beta, s_clip, alpha, beta, c1);
+                    int16_t *const w0 = l_y + (4 * sr + 2 * role) * LSTR + 8 * wx;
+                    const uint4 R0 = *(const uint4 *)w0, R1 = *(const uint4 *)(w0 + LSTR);
+                    const uint32_t a0[4] = { R0.x, R0.y, R0.z, R0.w }, a1[4] = { R1.x, R1.y, R1.z, R1.w };
+                    uint32_t LP[8], b0[4], b1[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { LP[2 * j] = __builtin_amdgcn_perm(a1[j], a0[j], 0x05040100u); LP[2 * j + 1] = __builtin_amdgcn_perm(a1[j], a0[j], 0x07060302u); }
+                    addb_line_luma_pk(LP, bs, alpha, beta, c1, da.bd_l, maxl);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) { b0[j] = __builtin_amdgcn_perm(LP[2 * j + 1], LP[2 * j], 0x05040100u); b1[j] = __builtin_amdgcn_perm(LP[2 * j + 1], LP[2 * j], 0x07060302u); }
+                    *(uint4 *)w0 = make_uint4(b0[0], b0[1], b0[2], b0[3]);
+                    *(uint4 *)(w0 + LSTR) = make_uint4(b1[0], b1[1], b1[2], b1[3]);
+                } else {
+                    const int pl = role - 2;
+                    int alpha, beta, c0v;
+                    if (addb_chroma_params<0>(da, rqx, rpx, bs, pl, s_alpha, s_beta, s_clip, s_cqp, alpha, beta, c0v)) {
+                        int16_t *const w0 = l_c[pl] + (2 * sr) * CSTR + 4 * wx;
+                        const uint2 c0 = *(const uint2 *)w0, c1 = *(const uint2 *)(w0 + CSTR);
+                        uint32_t CP[4] = { __builtin_amdgcn_perm(c1.x, c0.x, 0x05040100u), __builtin_amdgcn_perm(c1.x, c0.x, 0x07060302u),
+                                           __builtin_amdgcn_perm(c1.y, c0.y, 0x05040100u), __builtin_amdgcn_perm(c1.y, c0.y, 0x07060302u) };
+                        addb_line_chroma_pk(CP, bs, alpha, beta, c0v, maxc);
+                        *(uint2 *)w0 = make_uint2(__builtin_amdgcn_perm(CP[1], CP[0], 0x05040100u), __builtin_amdgcn_perm(CP[3], CP[2], 0x05040100u));
+                        *(uint2 *)(w0 + CSTR) = make_uint2(__builtin_amdgcn_perm(CP[1], CP[0], 0x07060302u), __builtin_amdgcn_perm(CP[3], CP[2], 0x07060302u));
+                    }
+                }
+            }
+        }
+        for (int i = t; !PK && i < (int)s_cnt[0]; i += 256) {
             const int e = s_list[0][i], seg = e & 255, bs = e >> 8, wx = seg % 9, sr = seg / 9;
             const uint4 rp = s_map[sr][2 * wx], rq = s_map[sr][2 * wx + 1];
-            if (PK) {
-                // lines = rows here: the pairs (row 0, row 1) and (row 2, row 3) are formed with byte permutes, sample by sample across the edge
-                uint32_t LP[2][8], CP[2][4];
-                uint4 R[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) R[r] = *(const uint4 *)(l_y + (4 * sr + r) * LSTR + 8 * wx);
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    const uint32_t a0[4] = { R[2 * h].x, R[2 * h].y, R[2 * h].z, R[2 * h].w }, a1[4] = { R[2 * h + 1].x, R[2 * h + 1].y, R[2 * h + 1].z, R[2 * h + 1].w };
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { LP[h][2 * j] = __builtin_amdgcn_perm(a1[j], a0[j], 0x05040100u); LP[h][2 * j + 1] = __builtin_amdgcn_perm(a1[j], a0[j], 0x07060302u); }
-                }
-#pragma unroll
-                for (int pl = 0; pl < 2; pl++) {
-                    const uint2 c0 = *(const uint2 *)(l_c[pl] + (2 * sr) * CSTR + 4 * wx), c1 = *(const uint2 *)(l_c[pl] + (2 * sr + 1) * CSTR + 4 * wx);
-                    CP[pl][0] = __builtin_amdgcn_perm(c1.x, c0.x, 0x05040100u); CP[pl][1] = __builtin_amdgcn_perm(c1.x, c0.x, 0x07060302u);
-                    CP[pl][2] = __builtin_amdgcn_perm(c1.y, c0.y, 0x05040100u); CP[pl][3] = __builtin_amdgcn_perm(c1.y, c0.y, 0x07060302u);
-                }
-                addb_edge_filter_pk<0>(da, rq, rp, bs, LP, CP, s_alpha, s_beta, s_clip, s_cqp);
-#pragma unroll
-                for (int h = 0; h < 2; h++) {
-                    uint32_t b0[4], b1[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) { b0[j] = __builtin_amdgcn_perm(LP[h][2 * j + 1], LP[h][2 * j], 0x05040100u); b1[j] = __builtin_amdgcn_perm(LP[h][2 * j + 1], LP[h][2 * j], 0x07060302u); }
-                    *(uint4 *)(l_y + (4 * sr + 2 * h) * LSTR + 8 * wx) = make_uint4(b0[0], b0[1], b0[2], b0[3]);
-                    *(uint4 *)(l_y + (4 * sr + 2 * h + 1) * LSTR + 8 * wx) = make_uint4(b1[0], b1[1], b1[2], b1[3]);
-                }
-#pragma unroll
-                for (int pl = 0; pl < 2; pl++) {
-                    *(uint2 *)(l_c[pl] + (2 * sr) * CSTR + 4 * wx) = make_uint2(__builtin_amdgcn_perm(CP[pl][1], CP[pl][0], 0x05040100u), __builtin_amdgcn_perm(CP[pl][3], CP[pl][2], 0x05040100u));
-                    *(uint2 *)(l_c[pl] + (2 * sr + 1) * CSTR + 4 * wx) = make_uint2(__builtin_amdgcn_perm(CP[pl][1], CP[pl][0], 0x07060302u), __builtin_amdgcn_perm(CP[pl][3], CP[pl][2], 0x07060302u));
-                }
-                continue;
-            }
             int L[4][8], Cc[2][2][4];
 #pragma unroll
             for (int r = 0; r < 4; r++) {
@@ -348,7 +450,7 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
                 for (int r = 0; r < 2; r++)
                     *(uint2 *)(l_c[pl] + (2 * sr + r) * CSTR + 4 * wx) = make_uint2(PK2(Cc[pl][r][0], Cc[pl][r][1]), PK2(Cc[pl][r][2], Cc[pl][r][3]));
         }
-        if (t < 162) {   // the horizontal edges to filter (the records are complete since the barrier): lane = SCU column sx x grid line y0 + 8 g of the region
+        if (!interior && t < 162) {   // (border tiles) the horizontal edges to filter (the records are complete since the barrier): lane = SCU column sx x grid line y0 + 8 g of the region
             const int sx = t % 18, g = t / 18;
             const int scol = (tx0 >> 2) - 1 + sx, gy = ty0 + 8 * g;
             if (scol >= 0 && scol < da.w_scu && gy > 0 && gy < a.pic_h) {
@@ -359,28 +461,42 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
         ATR(5);
         __syncthreads();
         ATR(6);
-        // phase C: the horizontal edges, in place
-        for (int i = t; i < (int)s_cnt[1]; i += 256) {
+        // phase C: the horizontal edges, in place (PK: the four parts of a segment on the four waves, as in phase B)
+        if (PK) {
+            const int role = __builtin_amdgcn_readfirstlane(t >> 6);
+            const int maxl = (1 << da.bd_l) - 1, maxc = (1 << da.bd_c) - 1;
+            for (int i = t & 63; i < (int)s_cnt[1]; i += 64) {
+                const int e = s_list[1][i], seg = e & 255, bs = e >> 8, sx = seg % 18, g = seg / 18;
+                const uint32_t rqx = s_map[2 * g + 1][sx].x, rpx = s_map[2 * g][sx].x;
+                if (role < 2) {
+                    // lines = columns here: a row's dwords ARE the pairs (column 0, column 1) and (column 2, column 3) of the segment - no unpacking at all
+                    int alpha, beta, c1;
+                    addb_luma_params(da, rqx, rpx, bs, s_alpha, s_beta, s_clip, alpha, beta, c1);
+                    int16_t *const w0 = l_y + (8 * g) * LSTR + 4 * sx + 2 * role;
+                    uint32_t LP[8];
+#pragma unroll
+                    for (int r = 0; r < 8; r++) LP[r] = *(const uint32_t *)(w0 + r * LSTR);
+                    addb_line_luma_pk(LP, bs, alpha, beta, c1, da.bd_l, maxl);
+#pragma unroll
+                    for (int r = 0; r < 8; r++) *(uint32_t *)(w0 + r * LSTR) = LP[r];
+                } else {
+                    const int pl = role - 2;
+                    int alpha, beta, c0v;
+                    if (addb_chroma_params<1>(da, rqx, rpx, bs, pl, s_alpha, s_beta, s_clip, s_cqp, alpha, beta, c0v)) {
+                        int16_t *const w0 = l_c[pl] + (4 * g) * CSTR + 2 * sx;
+                        uint32_t CP[4];
+#pragma unroll
+                        for (int r = 0; r < 4; r++) CP[r] = *(const uint32_t *)(w0 + r * CSTR);
+                        addb_line_chroma_pk(CP, bs, alpha, beta, c0v, maxc);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) *(uint32_t *)(w0 + r * CSTR) = CP[r];
+                    }
+                }
+            }
+        }
+        for (int i = t; !PK && i < (int)s_cnt[1]; i += 256) {
             const int e = s_list[1][i], seg = e & 255, bs = e >> 8, sx = seg % 18, g = seg / 18;
             const uint4 rq = s_map[2 * g + 1][sx], rp = s_map[2 * g][sx];
-            if (PK) {
-                // lines = columns here: a row's dwords ARE the pairs (line 0, line 1) and (line 2, line 3) - no unpacking at all
-                uint32_t LP[2][8], CP[2][4];
-#pragma unroll
-                for (int r = 0; r < 8; r++) { const uint2 v = *(const uint2 *)(l_y + (8 * g + r) * LSTR + 4 * sx); LP[0][r] = v.x; LP[1][r] = v.y; }
-#pragma unroll
-                for (int pl = 0; pl < 2; pl++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) CP[pl][r] = *(const uint32_t *)(l_c[pl] + (4 * g + r) * CSTR + 2 * sx);
-                addb_edge_filter_pk<1>(da, rq, rp, bs, LP, CP, s_alpha, s_beta, s_clip, s_cqp);
-#pragma unroll
-                for (int r = 0; r < 8; r++) *(uint2 *)(l_y + (8 * g + r) * LSTR + 4 * sx) = make_uint2(LP[0][r], LP[1][r]);
-#pragma unroll
-                for (int pl = 0; pl < 2; pl++)
-#pragma unroll
-                    for (int r = 0; r < 4; r++) *(uint32_t *)(l_c[pl] + (4 * g + r) * CSTR + 2 * sx) = CP[pl][r];
-                continue;
-            }
             int L[4][8], Cc[2][2][4];
 #pragma unroll
             for (int r = 0; r < 8; r++) {
@@ -427,7 +543,11 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
         }
     }
 
-    const int lx = t & 15, ly = t >> 4;
+    // lane -> 4x4 block: a wave takes an 8 x 8 quarter of the tile's 16 x 16 blocks (round 5: 16 x 4).  A lane reads window rows as 8-byte pieces at
+    // (4 ly + i) * 144 + 8 lx bytes: with eight blocks per row a half-wave covers banks 16 ly + 2 lx + {0, 1} exactly once - sixteen blocks per row put two lanes
+    // on every bank (SQ_LDS_BANK_CONFLICT 41 % of the LDS cycles, profiles/round5_exp_inter_counters.txt); the sub-block sums (72-byte rows) and the chroma tile (80-byte
+    // rows) spread the same way
+    const int lx = (t & 7) | ((t >> 3) & 8), ly = ((t >> 3) & 7) | ((t >> 4) & 8);
     const int x = tx0 + (lx << 2), y = ty0 + (ly << 2);
     const bool inside = x < a.pic_w && y < a.pic_h;
     const int maxv = (1 << a.bd) - 1;
@@ -447,43 +567,52 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
             const uint2 v0 = row[0], v1 = row[1], v2 = row[2];
             W[i][0] = v0.x; W[i][1] = v0.y; W[i][2] = v1.x; W[i][3] = v1.y; W[i][4] = v2.x; W[i][5] = v2.y;
         }
-        // Classification, phase 1 (alf_derive_classification_blk :38-208): the reference sums |Laplacian| (vertical, horizontal, two
-        // diagonals) over the 8x8 window around a 4x4 block.  Windows of neighbouring blocks overlap, so every lane computes the
-        // Laplacians of its OWN 16 positions once, reduced to its four 2x2 sub-blocks, and shares them through LDS; the window sum
-        // is then 16 sub-block sums (phase 2).  Packed-s16 arithmetic; a sub-block sum is at most 4 * 2 * (2^bd - 1): fits u16 up to 12 bit.
+        // Classification, phase 1 (alf_derive_classification_blk :38-208): the reference sums |Laplacian| (vertical, horizontal, two diagonals) over the 8x8 window around a
+        // 4x4 block - the block and two samples on every side.  That window is exactly four blocks of the lattice shifted by (-2, -2): with O(m, n) = the sums over samples
+        // [4m - 2, 4m + 2) x [4n - 2, 4n + 2), window(lx, ly) = O(lx, ly) + O(lx + 1, ly) + O(lx, ly + 1) + O(lx + 1, ly + 1).  So a lane computes the sixteen Laplacians
+        // of ITS offset block (rows / columns -2 .. 1 of its window: the same work as its own sixteen positions), keeps the four sums and shares them as one 16-byte store;
+        // phase 2 is three 16-byte loads and eight additions.  (Rounds 1-5 shared 2x2 sub-block sums: eight stores, 24 two-dword loads and 48 dot products per lane, and
+        // the array was 9.8 KB.)  The 33 blocks with m = 16 or n = 16 belong to no lane: the first 33 threads take them from the staged tile.  Sums as u32 (a block's sum
+        // reaches 16 x 2 x 4095 at 12 bits).
+        {
+            uint32_t acc[4] = { 0, 0, 0, 0 };
 #pragma unroll
-        for (int sr = 0; sr < 2; sr++) {
-            uint32_t acc[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+            for (int i = 1; i < 5; i++)
 #pragma unroll
-            for (int rr = 0; rr < 2; rr++) {
-                const int i = 3 + sr * 2 + rr;
-#pragma unroll
-                for (int sc = 0; sc < 2; sc++) lap_pair(&W[i - 1][1 + sc], &W[i][1 + sc], &W[i + 1][1 + sc], acc[sc]);
-            }
-#pragma unroll
-            for (int dir = 0; dir < 4; dir++)
-                *(uint32_t *)&l_lap[dir][(ly << 1) + sr + 1][(lx << 1) + 2] = acc[0][dir] | (acc[1][dir] << 16);
+                for (int sc = 0; sc < 2; sc++) lap_pair(&W[i - 1][sc], &W[i][sc], &W[i + 1][sc], acc);
+            l_o[ly][lx] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
         }
-        // the ring of sub-blocks around the tile (window rows/cols -2..-1 and 64..65): 132 of them, one per lane
-        if (t < 132) {
-            int sr, sc;                                           // sub-block coordinates -1..32
-            if (t < 34) { sr = -1; sc = t - 1; } else if (t < 68) { sr = 32; sc = t - 35; } else if (t < 100) { sr = t - 68; sc = -1; } else { sr = t - 100; sc = 32; }
-            // sample rows 2 sr - 1 .. 2 sr + 2 (LDS rows + 3), samples 2 sc - 2 .. 2 sc + 3 = three aligned dwords from LDS column index 2 sc + 2
-            uint32_t R[4][3], acc[4] = { 0, 0, 0, 0 };
+        if (t < 33) {
+            const int m = t < 17 ? 16 : t - 17, n = t < 17 ? t : 16;
+            // sample rows 4n - 3 .. 4n + 2, samples 4m - 4 .. 4m + 3 = four aligned dwords from LDS column index 4m
+            uint32_t R[6][4], acc[4] = { 0, 0, 0, 0 };
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const uint32_t *row = (const uint32_t *)(l_y + (sr * 2 + 2 + r + RO - 3) * LSTR + sc * 2 + 2);
-                R[r][0] = row[0]; R[r][1] = row[1]; R[r][2] = row[2];
+            for (int r = 0; r < 6; r++) {
+                const uint2 *row = (const uint2 *)(l_y + (4 * n - 3 + r + RO) * LSTR + 4 * m);
+                const uint2 v0 = row[0], v1 = row[1];
+                R[r][0] = v0.x; R[r][1] = v0.y; R[r][2] = v1.x; R[r][3] = v1.y;
             }
-            lap_pair(R[0], R[1], R[2], acc);
-            lap_pair(R[1], R[2], R[3], acc);
 #pragma unroll
-            for (int dir = 0; dir < 4; dir++) l_lap[dir][sr + 1][sc + 2] = (uint16_t)acc[dir];
+            for (int i = 1; i < 5; i++)
+#pragma unroll
+                for (int sc = 0; sc < 2; sc++) lap_pair(&R[i - 1][sc], &R[i][sc], &R[i + 1][sc], acc);
+            l_o[n][m] = make_uint4(acc[0], acc[1], acc[2], acc[3]);
         }
     }
     ATR(9);
     __syncthreads();
     ATR(10);
+    // output addresses as unsigned byte offsets from the (uniform) plane pointers: one scalar base + a 32-bit lane offset per store, one add per row (the 64-bit
+    // form was a multiply, a sign extension and a 64-bit shift-add per row)
+    const uint32_t ol0 = (uint32_t)(y * a.s_l + x) << 1, oc0 = (uint32_t)((y >> 1) * a.s_c + (x >> 1)) << 1, sl2 = (uint32_t)a.s_l << 1, sc2 = (uint32_t)a.s_c << 1;
+#ifdef XGPU_EXP_PAD_VALU
+    {   // measurement: what does one more VALU instruction per wave cost this kernel?  N dependent byte permutes on a value that ends up in an (always false) store condition
+        uint32_t pv = (uint32_t)t;
+#pragma unroll
+        for (int k_ = 0; k_ < XGPU_EXP_PAD_VALU; k_++) asm volatile("v_perm_b32 %0, %0, %1, %2" : "+v"(pv) : "v"(x), "v"(y));
+        if (pv == 0x12345678u && x < 0) l_lap[0] = 1;
+    }
+#endif
     const bool edge_l = tx0 == 0, edge_r = tx0 + 64 >= a.pic_w, edge_t = ty0 == 0, edge_b = ty0 + 64 >= a.pic_h;
     const bool keep_border = a.pad && (edge_l || edge_r || edge_t || edge_b);      // workgroup-uniform: an inner tile's lanes do not test their rows against the picture borders
     do {
@@ -499,21 +628,10 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
     };
 
     if (luma_on) {
-        // phase 2: the 8x8 window = sub-block rows 2*ly-1 .. 2*ly+2, cols 2*lx-1 .. 2*lx+2
-        int sum[4] = { 0, 0, 0, 0 };
-#pragma unroll
-        for (int dir = 0; dir < 4; dir++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                // cols 2*lx-1 .. 2*lx+2 sit at u16 index 2*lx+1 .. 2*lx+4: three aligned pairs, the outer ones half used
-                typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-                const uint32_t *row = (const uint32_t *)&l_lap[dir][(ly << 1) + r][lx << 1];
-                uint32_t acc = (uint32_t)sum[dir];
-                acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, row[0]), (us2){0, 1}, acc, false);
-                acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, row[1]), (us2){1, 1}, acc, false);
-                acc = __builtin_amdgcn_udot2(__builtin_bit_cast(us2, row[2]), (us2){1, 0}, acc, false);
-                sum[dir] = (int)acc;
-            }
+        // phase 2: the 8x8 window = the lane's offset block and its right, lower and lower-right neighbours
+        const uint4 own_lap = l_o[ly][lx], o10 = l_o[ly][lx + 1], o01 = l_o[ly + 1][lx], o11 = l_o[ly + 1][lx + 1];      // (the lane's own sums too: four registers less across the barrier)
+        const int sum[4] = { (int)(own_lap.x + o10.x + o01.x + o11.x), (int)(own_lap.y + o10.y + o01.y + o11.y), (int)(own_lap.z + o10.z + o01.z + o11.z),
+                             (int)(own_lap.w + o10.w + o01.w + o11.w) };
         const int sv = sum[0], sh = sum[1], sd0 = sum[2], sd1 = sum[3];
         int cls, tr;
         {
@@ -530,12 +648,9 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
             if (strength) cls += (((main_dir & 1) << 1) + strength) * 5;
             tr = (0x31322010u >> ((main_dir * 2 + (sec_dir >> 1)) * 4)) & 0xF;  // trans_tbl = {0,1,0,2,2,3,1,3}
         }
-        // coefficient order of the block's transpose index (k_alf_perm) as 13 nibbles of one constant: selects instead of per-lane table loads
-        const uint64_t pk = tr == 0 ? 0xcba9876543210ull : tr == 1 ? 0xc62037b518a49ull : tr == 2 ? 0xcba9456781230ull : 0xc62015b734a89ull;
-        int f[13];
-#pragma unroll
-        for (int i = 0; i < 13; i++) f[i] = l_coef[cls * 13 + (int)((pk >> (4 * i)) & 15)];
-
+        // the block's filter: two 16-byte loads from the packed class x transpose table in the kernel arguments (L1 / L2 resident: 3.2 KB for the whole picture)
+        const uint4 *const fe = (const uint4 *)a.ctab[(cls << 2) + tr];
+        const uint4 fe0 = fe[0], fe1 = fe[1];
         // The filter of alf_filter_blk_7 (xevdm_alf.c:210-337): sum_k f[k] * (S(i+dy_k, j+dx_k) + S(i-dy_k, j-dx_k)) + f[12] * S(i, j), + 256 >> 9.
         // Two neighbouring outputs (j, j+1) at a time: their symmetric sample pairs are PACKED pairs of the window - P(i, c) = (S(i, c),
         // S(i, c+1)), a window dword or one v_alignbit - so one v_pk_add_i16 makes both pair sums (<= 2 * 4095, exact in s16) and two
@@ -546,30 +661,28 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
         // v_pk_add_u16 with swapped halves forms both pair sums and one v_dot2_i32_i16 against the packed coefficient couple accumulates them: 2
         // instructions per output and couple (was 3 per output PAIR and tap = 3 per output and couple).  The taps without a neighbour (0, 1, 4) stay
         // on the two-outputs-per-register form: one v_pk_add_u16 + two v_mad_i32_i16 per output pair.
-        const uint32_t F32 = pack_f(f[3], f[2]), F87 = pack_f(f[8], f[7]), F65 = pack_f(f[6], f[5]), FA9 = pack_f(f[10], f[9]), FCB = pack_f(f[12], f[11]);
+        const uint32_t F32 = fe0.x, F87 = fe0.y, F65 = fe0.z, FA9 = fe0.w, FCB = fe1.x, F10 = fe1.y, F4 = fe1.z;
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) {
             int o[4];
 #pragma unroll
             for (int jj = 0; jj < 4; jj++) {
-                int acc = 256;
-                acc = dot2s(F32, padd_x(P(ii + 2, jj - 1), P(ii - 2, jj)), acc);
+                int acc = dot2s_first(F32, padd_x(P(ii + 2, jj - 1), P(ii - 2, jj)));
                 acc = dot2s(F87, padd_x(P(ii + 1, jj - 2), P(ii - 1, jj + 1)), acc);
                 acc = dot2s(F65, padd_x(P(ii + 1, jj), P(ii - 1, jj - 1)), acc);
                 acc = dot2s(FA9, padd_x(P(ii, jj + 2), P(ii, jj - 3)), acc);
                 acc = dot2s(FCB, P(ii, jj), acc);
-                o[jj] = mad_lo(P(ii, jj - 1), f[11], acc);
+                o[jj] = mad_lo_fh(P(ii, jj - 1), FCB, acc);
             }
 #pragma unroll
             for (int jj = 0; jj < 4; jj += 2) {
                 const uint32_t p0 = padd(P(ii + 3, jj), P(ii - 3, jj)), p1 = padd(P(ii + 2, jj + 1), P(ii - 2, jj - 1)), p4 = padd(P(ii + 1, jj + 2), P(ii - 1, jj - 2));
-                o[jj] = mad_lo(p4, f[4], mad_lo(p1, f[1], mad_lo(p0, f[0], o[jj])));
-                o[jj + 1] = mad_hi(p4, f[4], mad_hi(p1, f[1], mad_hi(p0, f[0], o[jj + 1])));
+                o[jj] = mad_lo(p4, F4, mad_lo_fh(p1, F10, mad_lo(p0, F10, o[jj])));
+                o[jj + 1] = mad_hi(p4, F4, mad_hi_fh(p1, F10, mad_hi(p0, F10, o[jj + 1])));
             }
             uint2 w;
-            w.x = (uint32_t)(uint16_t)min(max(o[0] >> 9, 0), maxv) | ((uint32_t)(uint16_t)min(max(o[1] >> 9, 0), maxv) << 16);
-            w.y = (uint32_t)(uint16_t)min(max(o[2] >> 9, 0), maxv) | ((uint32_t)(uint16_t)min(max(o[3] >> 9, 0), maxv) << 16);
-            *(uint2 *)(dy_ + (y + ii) * a.s_l + x) = w;
+            w.x = clip_pack(o[0], o[1], maxv); w.y = clip_pack(o[2], o[3], maxv);
+            *(uint2 *)((char *)dy_ + (ol0 + ii * sl2)) = w;
             keep_luma(ii, w);
         }
 #undef P
@@ -577,7 +690,7 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
 #pragma unroll
         for (int ii = 0; ii < 4; ii++) {
             const uint2 w = FUSED ? keep_w[ii] : *(const uint2 *)(sy_ + (y + ii) * a.s_l + x);      // (fused: the deblocked samples only exist in LDS)
-            *(uint2 *)(dy_ + (y + ii) * a.s_l + x) = w; keep_luma(ii, w);
+            *(uint2 *)((char *)dy_ + (ol0 + ii * sl2)) = w; keep_luma(ii, w);
         }
     }
 
@@ -599,7 +712,7 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
 #pragma unroll
             for (int ii = 0; ii < 2; ii++) {
                 const uint32_t w = FUSED ? *(const uint32_t *)(l_c[pl] + ((ly << 1) + ii + 2) * CSTR + (lx << 1) + CO) : *(const uint32_t *)(src + (cy + ii) * a.s_c + cx);
-                *(uint32_t *)(dst + (cy + ii) * a.s_c + cx) = w; keep_chroma(ii, w);
+                *(uint32_t *)((char *)dst + (oc0 + ii * sc2)) = w; keep_chroma(ii, w);
             }
             continue;
         }
@@ -610,25 +723,23 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
             const uint32_t *row = (const uint32_t *)(l_c[pl] + ((ly << 1) + i) * CSTR + (lx << 1) + CO - 2);
             C[i][0] = row[0]; C[i][1] = row[1]; C[i][2] = row[2];
         }
-        const int16_t *f = l_coef + 325;
         // alf_filter_blk_5 (xevdm_alf.c:339-429), the same way: the SCU's two outputs of a row are one packed pair
 #define PC(i, c) ((((c) + 2) & 1) ? __builtin_amdgcn_alignbit(C[(i) + 2][(((c) + 2) >> 1) + 1], C[(i) + 2][((c) + 2) >> 1], 16) : C[(i) + 2][((c) + 2) >> 1])
-        const uint32_t G32 = pack_f(f[3], f[2]), G54 = pack_f(f[5], f[4]);      // the couples of the 5x5 diamond: taps (3,2) and (5,4)
+        const uint32_t G32 = a.cchroma[0], G54 = a.cchroma[1], G10 = a.cchroma[2], G6 = a.cchroma[3];      // the couples of the 5x5 diamond: taps (3,2) and (5,4); scalars of the kernel arguments
+        const uint32_t G32v = G32;      // (one vector copy: the first sum's scalar operand is the rounding constant - an instruction takes one scalar register)
 #pragma unroll
         for (int ii = 0; ii < 2; ii++) {
             int o[2];
 #pragma unroll
             for (int jj = 0; jj < 2; jj++) {
-                int acc = 256;
-                acc = dot2s(G32, padd_x(PC(ii + 1, jj - 1), PC(ii - 1, jj)), acc);
-                acc = dot2s(G54, padd_x(PC(ii, jj + 1), PC(ii, jj - 2)), acc);
-                o[jj] = mad_lo(PC(ii, jj), f[6], acc);
+                int acc = sdot2s(G54, padd_x(PC(ii, jj + 1), PC(ii, jj - 2)), dot2s_first(G32v, padd_x(PC(ii + 1, jj - 1), PC(ii - 1, jj))));
+                o[jj] = smad_lo(PC(ii, jj), G6, acc);
             }
             const uint32_t p0 = padd(PC(ii + 2, 0), PC(ii - 2, 0)), p1 = padd(PC(ii + 1, 1), PC(ii - 1, -1));
-            o[0] = mad_lo(p1, f[1], mad_lo(p0, f[0], o[0]));
-            o[1] = mad_hi(p1, f[1], mad_hi(p0, f[0], o[1]));
-            const uint32_t w = (uint32_t)(uint16_t)min(max(o[0] >> 9, 0), maxv) | ((uint32_t)(uint16_t)min(max(o[1] >> 9, 0), maxv) << 16);
-            *(uint32_t *)(dst + (cy + ii) * a.s_c + cx) = w;
+            o[0] = smad_lo_fh(p1, G10, smad_lo(p0, G10, o[0]));
+            o[1] = smad_hi_fh(p1, G10, smad_hi(p0, G10, o[1]));
+            const uint32_t w = clip_pack(o[0], o[1], maxv);
+            *(uint32_t *)((char *)dst + (oc0 + ii * sc2)) = w;
             keep_chroma(ii, w);
         }
 #undef PC
@@ -694,7 +805,7 @@ __global__ __launch_bounds__(256) void k_alf(const AlfArgs a, const int16_t *__r
 //  4K 8155, 8165 / 7725, 7849 (-4.5 %).)
 // PK: the deblocking line filters on packed pairs of lines (bit depths up to 10; XEVD_HIP_ADDB_SCALAR=1 keeps the scalar form for A/B runs)
 template <bool PK>
-__global__ __launch_bounds__(256) void k_addb_alf(const AlfArgs a, const AddbArgs d, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(XGPU_ALF_WAVES, XGPU_ALF_WAVES))) void k_addb_alf(const AlfArgs a, const AddbArgs d, const int16_t *__restrict__ sy_, const int16_t *__restrict__ su_,
                                                   const int16_t *__restrict__ sv_, int16_t *__restrict__ dy_, int16_t *__restrict__ du_, int16_t *__restrict__ dv_)
 {
     alf_kernel<true, PK>(a, &d, sy_, su_, sv_, dy_, du_, dv_);

@@ -260,7 +260,13 @@ struct AlfArgs {
     const uint8_t *ctb_flag;           // device, [n_ctu] or null
     int      ctb_in_args;              // 1: the per-CTU luma flags travel in ctb_bits (pictures up to ALF_CTB_BITS CTUs): no H2D copy between the kernels
     uint32_t ctb_bits[ALF_CTB_BITS / 32];
-    int16_t  coef[25 * 13 + 7];        // coef_final followed by the chroma filter
+    // The luma filter set as the filter loop wants it: for each of the 25 classes and the 4 transpose indices (xevdm_alf.c:268-273) the thirteen coefficients in the
+    // block's orientation, packed in the pairs the v_dot2 / v_mad_i32_i16 forms take - (f3,f2) (f8,f7) (f6,f5) (f10,f9) (f12,f11) (f1,f0) (-,f4), high half first - so a
+    // lane fetches its filter with two 16-byte loads at (class * 4 + transpose) (xgpu_alf builds it; round 5 read thirteen s16 from an LDS copy of coef_final through a
+    // nibble permutation and packed them with run-time shifts, ~70 instructions per lane of a kernel bound by instruction issue).  Argument blocks above 4 KB launch on
+    // this runtime (tools/ubench/kernarg_probe.hip: 8 KB tested)
+    uint32_t ctab[25 * 4][8];
+    uint32_t cchroma[4];               // the chroma filter: (f3,f2) (f5,f4) (f1,f0) (-,f6)
 };
 
 // One device block + one pinned staging block of a batch.  xgpu_batch_destroy returns them to the context's pool instead of freeing:

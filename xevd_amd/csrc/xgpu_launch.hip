@@ -242,8 +242,24 @@ int xgpu_alf(xgpu_ctx *c, const xgpu_alf_params *ap)
     a.multi_tile = ap->tiles && ap->tiles->n_cols * ap->tiles->n_rows > 1;
     ARGCHK(c, !ap->tiles || (ap->tiles->loop_filter_across_tiles != 0) == (ap->across_tiles != 0));
     for (int i = 0; i < 3; i++) a.enable[i] = ap->enable[i] ? 1 : 0;
-    if (ap->luma_coef) memcpy(a.coef, ap->luma_coef, sizeof(int16_t) * 325);
-    if (ap->chroma_coef) memcpy(a.coef + 325, ap->chroma_coef, sizeof(int16_t) * 7);
+    if (ap->luma_coef) {
+        static const uint8_t perm[4][13] = {      // coefficient order per transpose index, xevdm_alf.c:268-273
+            { 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12 }, { 9, 4, 10, 8, 1, 5, 11, 7, 3, 0, 2, 6, 12 },
+            { 0, 3, 2, 1, 8, 7, 6, 5, 4, 9, 10, 11, 12 }, { 9, 8, 10, 4, 3, 7, 11, 5, 1, 0, 2, 6, 12 } };
+        auto pk = [](int hi, int lo) { return ((uint32_t)(uint16_t)(int16_t)hi << 16) | (uint16_t)(int16_t)lo; };
+        for (int cls = 0; cls < 25; cls++)
+            for (int tr = 0; tr < 4; tr++) {
+                int f[13];
+                for (int i = 0; i < 13; i++) f[i] = ap->luma_coef[cls * 13 + perm[tr][i]];
+                uint32_t *e = a.ctab[cls * 4 + tr];
+                e[0] = pk(f[2], f[3]); e[1] = pk(f[7], f[8]); e[2] = pk(f[5], f[6]); e[3] = pk(f[9], f[10]); e[4] = pk(f[11], f[12]); e[5] = pk(f[1], f[0]); e[6] = pk(0, f[4]); e[7] = 0;
+            }
+    }
+    if (ap->chroma_coef) {
+        const int16_t *g = ap->chroma_coef;
+        a.cchroma[0] = ((uint32_t)(uint16_t)g[2] << 16) | (uint16_t)g[3]; a.cchroma[1] = ((uint32_t)(uint16_t)g[4] << 16) | (uint16_t)g[5];
+        a.cchroma[2] = ((uint32_t)(uint16_t)g[1] << 16) | (uint16_t)g[0]; a.cchroma[3] = (uint16_t)g[6];
+    }
     if (ap->ctb_flag && ap->enable[0]) {
         const int n_ctu = c->w_ctu * c->h_ctu;
         if (n_ctu <= ALF_CTB_BITS) {        // as kernel arguments: a copy engine transfer between two kernels costs ~12 us of idle device (profiles/round3_trace_window.txt)
