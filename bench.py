@@ -110,7 +110,7 @@ def make_stream(wl, seed, n_batches):
     rng = np.random.default_rng(seed)
     first = [synth.gen_picture(rng, wl["w"], wl["h"], wl["bd"]) for _ in range(2)]
     batches = [synth.gen_frame(rng, wl["w"], wl["h"], wl["bd"], inter_frac=0.9, bi_frac=wl["bi_frac"], coded_frac=0.6,
-                               n_refs=wl["n_refs"], qp_range=(22, 37), mv_sigma_px=8.0, oob_frac=0.05)
+                               n_refs=wl["n_refs"], qp_range=(22, 37), mv_sigma_px=8.0, oob_frac=0.05, admvp=bool(wl["admvp"]))
                for _ in range(n_batches)]
     if wl.get("htdf_qp"):
         for b in batches:
@@ -205,7 +205,7 @@ def write_bench_stream(wl, gop_pictures, repeats, seed=77, refine_tools=False, d
             tid = 0 if idr or not main else tids[(k - 1) % 8]
             is_b = main and not idr and tid > 0
             b = synth.gen_frame(rng, w, h, bd, inter_frac=0.0 if idr else 0.9, n_refs=(2 if main else 1, 2 if is_b else 0), bi_frac=wl["bi_frac"] if is_b else 0.0,
-                                coded_frac=0.6, max_level=6, amp=1.0)
+                                coded_frac=0.6, max_level=6, amp=1.0, admvp=bool(wl["admvp"]))
             if not idr:      # a share of skip and (B pictures / tool_admvp) merge-mode CUs, like the streams of tests/test_stream.py
                 inter = b["pred_mode"] == 1
                 r = rng.random(len(inter))

@@ -178,7 +178,9 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
     // the filtered samples on the picture border that this tile holds: [plane][first / last row of the picture][column of the tile] and [first / last column][row],
     // for the border replication below (what k_pad did in a launch of its own)
     // They live in l_y: every lane has its luma window in registers before the barrier behind phase 1, so the staged tile is dead by the time the first filtered
-    // sample exists (26 KB of LDS per workgroup = six workgroups per CU).
+    // sample exists.  (Round 6, measured and not kept: the window in three instalments - rows -3..2 for the Laplacians, 3..4 behind them, 5..6 behind output row 1 -
+    // to fit 72 registers = seven waves per SIMD, which the 22.6 KB of LDS would allow: 108.5 us against 104.0 with six; the instalments alone at six waves 105.3.
+    // The kernel is bound by instruction issue, a seventh wave only adds contention - tools/exp_variants.sh "lattice new w7".)
     int16_t (*b_row)[2][64] = (int16_t (*)[2][64])l_y, (*b_col)[2][64] = (int16_t (*)[2][64])(l_y + 3 * 2 * 64);
     static_assert(2 * 3 * 2 * 64 <= LROWS * LSTR, "the border arrays fit into the staged luma tile");
 

@@ -135,7 +135,7 @@ def gen_partition_btt(rng, width, height, log2_ctu=6, split_prob=0.5, btt_frac=0
 
 def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_frac=0.0, coded_frac=0.6,
               n_refs=(1, 0), qp_range=(22, 37), mv_sigma_px=8.0, oob_frac=0.05, split_prob=0.5,
-              chroma_qp_table=None, max_level=24, amp=2.0, ats_frac=0.0, ats_inter_frac=0.0, btt_frac=0.0, min_log2=2, eipd=False, partition=None):
+              chroma_qp_table=None, max_level=24, amp=2.0, ats_frac=0.0, ats_inter_frac=0.0, btt_frac=0.0, min_log2=2, eipd=False, partition=None, admvp=False):
     """One picture's CU batch as a dict of numpy arrays (layout of xgpu_cu_batch, include/xevd_hip.h)."""
     tree = None
     if partition is not None:      # leaf CUs given by the caller (x, y, log2w, log2h, ctu_cu_start[, tree: 0 / 1 luma-only / 2 chroma-only CUs of local dual trees])
@@ -158,6 +158,8 @@ def gen_frame(rng, width, height, bit_depth=8, log2_ctu=6, inter_frac=1.0, bi_fr
     refi = np.full((n, 2), -1, np.int8)
     has_l1 = n_refs[1] > 0
     bi = inter & has_l1 & (rng.random(n) < bi_frac)
+    if admvp:      # with sps->tool_admvp a CU of width + height <= 12 (4x4, 4x8, 8x4) cannot be bi-predicted (xevdm_check_bi_applicability, src_main/xevdm_util.c:1086-1098):
+        bi &= (w + h) > 12      # the parser never hands such a CU over, so the benchmark's batches do not hold one either
     use_l1_only = inter & has_l1 & ~bi & (rng.random(n) < 0.3)
     l0 = inter & ~use_l1_only
     refi[l0, 0] = rng.integers(0, max(n_refs[0], 1), l0.sum())
