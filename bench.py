@@ -105,6 +105,41 @@ def algorithmic_bytes(batch, w, h, addb=False):
     return {"inter": b_inter, "affine": b_aff, "dmvr": b_dmvr, "itdq": b_itdq, "intra": b_intra, "dbk_v": 4 * s_pic, "dbk_h": 0 if addb else 4 * s_pic, "alf": 4 * s_pic}
 
 
+INTER_CLASS_PICTURES = 6      # timed pictures per CU-size class of inter_by_cu_size_leg (after 2 untimed ones); fixed, like the other secondary legs
+
+
+def inter_by_cu_size_leg(dec, wl, slots, alf):
+    """k_inter's duration (HIP events, every kernel alone on the stream) on pictures of ONE CU size each - 64x64 .. 4x4, all inter, otherwise the workload's statistics
+    (vectors N(0, 8 px) per CU, sub-sample classes, share of bi-predicted CUs, 60 % coded) - next to the workload's own mix: which CU sizes the inter pass pays for.
+    64 / 32: the region and tile roles (windows shared through LDS); 16 / 8 / 4: the split role, one lane per 4x4 unit with its own 11x11 window."""
+    from xevd_amd import synth
+    rng = np.random.default_rng(77)
+    two_lists = wl["n_refs"][1] > 0
+    out = {}
+    for name, sp, ml in (("64x64", 0.0, 2), ("32x32", 1.0, 5), ("16x16", 1.0, 4), ("8x8", 1.0, 3), ("4x4", 1.0, 2)):
+        b = synth.gen_frame(rng, wl["w"], wl["h"], wl["bd"], inter_frac=1.0, bi_frac=wl["bi_frac"], coded_frac=0.6, n_refs=wl["n_refs"], qp_range=(22, 37), mv_sigma_px=8.0,
+                            oob_frac=0.05, split_prob=sp, min_log2=ml, admvp=bool(wl["admvp"]))
+        h = dec.batch_create(b)
+
+        def step(k):
+            cur, r0, r1 = slots[(k + 2) % 3], slots[(k + 1) % 3], slots[k % 3]
+            refs = {(0, 0): (r0, k)}
+            if two_lists:
+                refs[(0, 1)] = (r1, k - 1)
+            dec.decode_picture(cur, k + 1, refs, h, alf=alf)
+        for k in range(2):
+            step(k)
+        dec.sync(); dec.timing_enable(True); dec.timing_reset()
+        for k in range(INTER_CLASS_PICTURES):
+            step(2 + k)
+        tim = dec.timing_get(); dec.timing_enable(False)
+        ab = algorithmic_bytes(b, wl["w"], wl["h"], bool(wl["addb"]))["inter"]
+        us = 1e3 * tim["inter"][0] / max(tim["inter"][1], 1)
+        out[name] = {"avg_us": round(us, 1), "cus": int(len(b["x"])), "algorithmic_gbps": round(ab / us / 1e3, 1)}
+        dec.batch_destroy(h)
+    return out
+
+
 def make_stream(wl, seed, n_batches):
     from xevd_amd import synth
     rng = np.random.default_rng(seed)
@@ -579,6 +614,7 @@ def main():
     ap.add_argument("--batches", type=int, default=4, help="distinct pictures' CU batches kept resident and cycled")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the batches-in -> YUV-out leg")
+    ap.add_argument("--no-inter-classes", action="store_true", help="skip the k_inter-by-CU-size leg")
     ap.add_argument("--no-prepare", action="store_true", help="every picture's residual pass in front of its own k_inter (no xgpu_batch_prepare of the next picture)")
     args = ap.parse_args()
 
@@ -729,6 +765,12 @@ def main():
         e2e = {"fps": None, "ms_per_picture": 0.0, "skipped": True}
     else:
         e2e = end_to_end_leg(dec, wl, batches, alf, slots, E2E_PICTURES, E2E_WARMUP)
+    inter_classes = None
+    if world == 1 and rank == 0 and not args.no_inter_classes and not args.no_end_to_end and dec_mod == "xevd_amd.decoder" and wl["w"] >= 3840:
+        try:
+            inter_classes = inter_by_cu_size_leg(dec, wl, slots, alf)
+        except Exception as e:
+            inter_classes = {"error": repr(e)[:200]}
     two_ctx = None
     if world == 1 and not args.no_end_to_end and dec_mod == "xevd_amd.decoder":
         try:
@@ -817,6 +859,7 @@ def main():
                          "traffic_source": (f"profiles/latest_pmc.json (rocprofv3 --pmc passes of this workload at commit {pmc_commit}, committed; not measured by this run: "
                                             "counter passes cannot run inside a timed benchmark)") if traffic is not None else traffic_note},
             "kernels": kernels,
+            "inter_by_cu_size": inter_classes,
             "whole_frame": {"algorithmic_bytes": int(total_alg), "kernel_us": round(kern_s * 1e6, 2),
                             "achieved_gbps": round(total_alg / kern_s / 1e9, 1),
                             # the same kernel time against SURVEY 8(d)'s own accounting (deblocking as two passes of 4 B/sample), for comparison across rounds
