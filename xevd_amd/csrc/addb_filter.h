@@ -10,18 +10,26 @@ struct __attribute__((packed, aligned(4))) U32x2a4 { uint32_t a, b; };
 __device__ __forceinline__ int clip3a(int lo, int hi, int v) { return min(max(v, lo), hi); }
 
 // ALPHA_TABLE / BETA_TABLE / CLIP_TAB (src_main/xevdm_tbl.c:377-379) - tables of the EVC specification
-static __constant__ uint8_t k_alpha[52] = { 0,0,0,0,0,0,0,0,0,0,0,0, 0,0,0,0,4,4,5,6, 7,8,9,10,12,13,15,17, 20,22,25,28,32,36,40,45,
-    50,56,63,71,80,90,101,113, 127,144,162,182,203,226,255,255 };
-static __constant__ uint8_t k_beta[52] = { 0,0,0,0,0,0,0,0,0,0,0,0, 0,0,0,0,2,2,2,3, 3,3,3,4,4,4,6,6, 7,7,8,8,9,9,10,10,
-    11,11,12,12,13,13,14,14, 15,15,16,16,17,17,18,18 };
-static __constant__ uint8_t k_clip[52][5] = {
-    {0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},
-    {0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},
-    {0,0,0,0,0},{0,0,0,1,1},{0,0,0,1,1},{0,0,0,1,1},{0,0,0,1,1},{0,0,1,1,1},{0,0,1,1,1},{0,1,1,1,1},
-    {0,1,1,1,1},{0,1,1,1,1},{0,1,1,1,1},{0,1,1,2,2},{0,1,1,2,2},{0,1,1,2,2},{0,1,1,2,2},{0,1,2,3,3},
-    {0,1,2,3,3},{0,2,2,3,3},{0,2,2,4,4},{0,2,3,4,4},{0,2,3,4,4},{0,3,3,5,5},{0,3,4,6,6},{0,3,4,6,6},
-    {0,4,5,7,7},{0,4,5,8,8},{0,4,6,9,9},{0,5,7,10,10},{0,6,8,11,11},{0,6,8,13,13},{0,7,10,14,14},{0,8,11,16,16},
-    {0,9,12,18,18},{0,10,13,20,20},{0,11,15,23,23},{0,13,17,25,25} };
+#define ADDB_ALPHA_INIT { 0,0,0,0,0,0,0,0,0,0,0,0, 0,0,0,0,4,4,5,6, 7,8,9,10,12,13,15,17, 20,22,25,28,32,36,40,45, \
+    50,56,63,71,80,90,101,113, 127,144,162,182,203,226,255,255 }
+#define ADDB_BETA_INIT { 0,0,0,0,0,0,0,0,0,0,0,0, 0,0,0,0,2,2,2,3, 3,3,3,4,4,4,6,6, 7,7,8,8,9,9,10,10, \
+    11,11,12,12,13,13,14,14, 15,15,16,16,17,17,18,18 }
+#define ADDB_CLIP_INIT { \
+    {0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}, \
+    {0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0},{0,0,0,0,0}, \
+    {0,0,0,0,0},{0,0,0,1,1},{0,0,0,1,1},{0,0,0,1,1},{0,0,0,1,1},{0,0,1,1,1},{0,0,1,1,1},{0,1,1,1,1}, \
+    {0,1,1,1,1},{0,1,1,1,1},{0,1,1,1,1},{0,1,1,2,2},{0,1,1,2,2},{0,1,1,2,2},{0,1,1,2,2},{0,1,2,3,3}, \
+    {0,1,2,3,3},{0,2,2,3,3},{0,2,2,4,4},{0,2,3,4,4},{0,2,3,4,4},{0,3,3,5,5},{0,3,4,6,6},{0,3,4,6,6}, \
+    {0,4,5,7,7},{0,4,5,8,8},{0,4,6,9,9},{0,5,7,10,10},{0,6,8,11,11},{0,6,8,13,13},{0,7,10,14,14},{0,8,11,16,16}, \
+    {0,9,12,18,18},{0,10,13,20,20},{0,11,15,23,23},{0,13,17,25,25} }
+static __constant__ uint8_t k_alpha[52] = ADDB_ALPHA_INIT;
+static __constant__ uint8_t k_beta[52] = ADDB_BETA_INIT;
+static __constant__ uint8_t k_clip[52][5] = ADDB_CLIP_INIT;
+// the same tables on the host: xgpu_deblock lays them out, with the picture's reference identities and chroma QP mapping, as the block k_addb_alf copies into LDS
+// dword by dword (AddbArgs.lds_tables; round 6 - byte stores into LDS cost ~35 LDS cycles per wave-instruction)
+static const uint8_t h_addb_alpha[52] = ADDB_ALPHA_INIT;
+static const uint8_t h_addb_beta[52] = ADDB_BETA_INIT;
+static const uint8_t h_addb_clip[52][5] = ADDB_CLIP_INIT;
 
 // |a - b| < 4 in both components of two packed (x, y) vectors.  The reference subtracts in int (abs(a - b) of two s16 never wraps); here the packed difference
 // SATURATES (v_pk_sub_i16 ... clamp), so a difference beyond s16 stays large instead of wrapping into (-4, 4), and the test is one mask: |d| < 4 <=> no bit above bit 1

@@ -170,8 +170,8 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
     __shared__ __attribute__((aligned(16))) int16_t l_y[LROWS * LSTR];
     __shared__ __attribute__((aligned(16))) int16_t l_c[2][CROWS * CSTR];
     // sums of |Laplacian| (V, H, D0, D1 as one uint4) over the 4x4 blocks of the lattice OFFSET by two samples from the tile's 4x4 blocks - block (m, n) = samples
-    // [4m - 2, 4m + 2) x [4n - 2, 4n + 2), m, n = 0..16 - see phase 1 below; the fused form's deblocking state (records, tables, lists: 6.4 KB) lies in the same bytes
-    constexpr int LAP_BYTES = 6512;
+    // [4m - 2, 4m + 2) x [4n - 2, 4n + 2), m, n = 0..16 - see phase 1 below; the fused form's deblocking state (records, tables, lists: 7.0 KB) lies in the same bytes
+    constexpr int LAP_BYTES = 7168;
     static_assert(17 * 17 * 16 <= LAP_BYTES, "the offset-lattice sums fit");
     __shared__ __attribute__((aligned(16))) uint8_t l_lap[LAP_BYTES];
     uint4 (*const l_o)[17] = (uint4 (*)[17])l_lap;
@@ -244,11 +244,12 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
         uint4 (*s_map)[18] = (uint4 (*)[18])l_lap;
         uint8_t *s_alpha = (uint8_t *)l_lap + 18 * 18 * 16, *s_beta = s_alpha + 52, *s_clip = s_beta + 52, *s_pic = s_clip + 260;
         int8_t *s_cqp = (int8_t *)(s_pic + XGPU_MAX_REFS * 2);
-        constexpr int LIST_OFF = (18 * 18 * 16 + 52 + 52 + 260 + XGPU_MAX_REFS * 2 + 192 + 3) & ~3;
+        static_assert(52 + 52 + 260 + XGPU_MAX_REFS * 2 + 192 == ADDB_LDS_TABLE_BYTES, "the LDS tables are AddbArgs.lds_tables");
+        constexpr int LIST_OFF = (18 * 18 * 16 + ADDB_LDS_TABLE_BYTES + 3) & ~3;
         uint32_t *s_cnt = (uint32_t *)((uint8_t *)l_lap + LIST_OFF);
-        uint16_t (*s_list)[164] = (uint16_t (*)[164])(s_cnt + 2);            // entry = lane | strength << 8
-        TileMask *s_tm = (TileMask *)((uint8_t *)l_lap + LIST_OFF + 8 + ((2 * 164 * 2 + 3) & ~3));      // the tile-border masks: a lane-indexed read of the kernel arguments is a global load
-        static_assert(LIST_OFF + 8 + ((2 * 164 * 2 + 3) & ~3) + (int)sizeof(TileMask) <= LAP_BYTES, "the deblocking state fits into l_lap");
+        uint32_t (*s_list)[164] = (uint32_t (*)[164])(s_cnt + 2);            // entry = segment | strength << 8 (dwords: a 16-bit LDS store costs several times a 32-bit one)
+        TileMask *s_tm = (TileMask *)((uint8_t *)l_lap + LIST_OFF + 8 + 2 * 164 * 4);      // the tile-border masks: a lane-indexed read of the kernel arguments is a global load
+        static_assert(LIST_OFF + 8 + 2 * 164 * 4 + (int)sizeof(TileMask) <= LAP_BYTES, "the deblocking state fits into l_lap");
 #define PK2(lo, hi) ((uint32_t)(uint16_t)(lo) | ((uint32_t)(uint16_t)(hi) << 16))
         // An INTERIOR tile (its 72 x 72 region and the 18 x 18 records around it lie inside the picture: all but the tiles on the picture border) brings region and records
         // straight into LDS (global_load_lds, 16 bytes per lane and request: no staging registers, no LDS store pass - k_inter's region role does the same): l_y is 72 rows of
@@ -294,21 +295,12 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
             }
             __builtin_amdgcn_sched_barrier(0);
             {
-                static_assert(XGPU_MAX_REFS * 2 <= 256 && 260 <= 512, "one or two table entries per thread");
-                const uint8_t *clip = (const uint8_t *)k_clip;
-                uint8_t va = 0, vb = 0, vc0 = clip[t], vc1 = 0, vp = 0;
-                int8_t vq = 0;
-                if (t < 52) { va = k_alpha[t]; vb = k_beta[t]; }
-                if (t + 256 < 260) vc1 = clip[t + 256];
-                if (t < XGPU_MAX_REFS * 2) vp = da.pic_id[t];
-                if (t < 192) vq = da.chroma_qp[t];
-                if (t < 52) { s_alpha[t] = va; s_beta[t] = vb; }
-                s_clip[t] = vc0;
-                if (t + 256 < 260) s_clip[t + 256] = vc1;
-                if (t < XGPU_MAX_REFS * 2) s_pic[t] = vp;
-                if (t < 192) s_cqp[t] = vq;
+                // the deblocking tables (alpha, beta, clip, reference identities, chroma QP mapping: one block the host lays out, AddbArgs.lds_tables) and the tile masks, a
+                // dword per thread (round 5 copied them byte by byte from five places: six sub-dword LDS stores per wave)
+                static_assert(ADDB_LDS_TABLE_DWORDS + 16 <= 256, "one table dword per thread");
+                if (t < ADDB_LDS_TABLE_DWORDS) ((uint32_t *)s_alpha)[t] = da.lds_tables[t];
+                else if (t < ADDB_LDS_TABLE_DWORDS + 16) { const int k_ = t - ADDB_LDS_TABLE_DWORDS; ((uint32_t *)s_tm)[k_] = k_ < 8 ? da.no_filter.vb[k_] : da.no_filter.hb[k_ - 8]; }
                 if (t < 2) s_cnt[t] = 0;
-                if (t < 16) ((uint32_t *)s_tm)[t] = t < 8 ? da.no_filter.vb[t] : da.no_filter.hb[t - 8];
             }
             ctu_setup();
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's chunks have landed (the compiler does not know that the requests write LDS)
@@ -321,7 +313,7 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
                 int bs;
                 if (!hor) { const int wx = j % 9, sr = j / 9; bs = addb_edge_strength_rt(da, *s_tm, s_map[sr][2 * wx + 1], s_map[sr][2 * wx], (tx0 >> 2) + 2 * wx, false, s_pic); }
                 else      { const int sx = j % 18, g = j / 18; bs = addb_edge_strength_rt(da, *s_tm, s_map[2 * g + 1][sx], s_map[2 * g][sx], (ty0 >> 2) + 2 * g, true, s_pic); }
-                if (bs) s_list[hor][atomicAdd(&s_cnt[hor], 1u)] = (uint16_t)(j | (bs << 8));
+                if (bs) s_list[hor][atomicAdd(&s_cnt[hor], 1u)] = (uint32_t)(j | (bs << 8));
             }
         } else
         {   // phase A: lane = vertical-edge window wx (grid line x0 + 8 wx) x SCU row sr of the region: window and SCU records from memory to LDS
@@ -349,21 +341,12 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
             // in a row before the first window load of the tile had even been issued
             // (and all of their loads before the first of their stores: one more round trip, not six)
             {
-                static_assert(XGPU_MAX_REFS * 2 <= 256 && 260 <= 512, "one or two table entries per thread");
-                const uint8_t *clip = (const uint8_t *)k_clip;
-                uint8_t va = 0, vb = 0, vc0 = clip[t], vc1 = 0, vp = 0;
-                int8_t vq = 0;
-                if (t < 52) { va = k_alpha[t]; vb = k_beta[t]; }
-                if (t + 256 < 260) vc1 = clip[t + 256];
-                if (t < XGPU_MAX_REFS * 2) vp = da.pic_id[t];
-                if (t < 192) vq = da.chroma_qp[t];
-                if (t < 52) { s_alpha[t] = va; s_beta[t] = vb; }
-                s_clip[t] = vc0;
-                if (t + 256 < 260) s_clip[t + 256] = vc1;
-                if (t < XGPU_MAX_REFS * 2) s_pic[t] = vp;
-                if (t < 192) s_cqp[t] = vq;
+                // the deblocking tables (alpha, beta, clip, reference identities, chroma QP mapping: one block the host lays out, AddbArgs.lds_tables) and the tile masks, a
+                // dword per thread (round 5 copied them byte by byte from five places: six sub-dword LDS stores per wave)
+                static_assert(ADDB_LDS_TABLE_DWORDS + 16 <= 256, "one table dword per thread");
+                if (t < ADDB_LDS_TABLE_DWORDS) ((uint32_t *)s_alpha)[t] = da.lds_tables[t];
+                else if (t < ADDB_LDS_TABLE_DWORDS + 16) { const int k_ = t - ADDB_LDS_TABLE_DWORDS; ((uint32_t *)s_tm)[k_] = k_ < 8 ? da.no_filter.vb[k_] : da.no_filter.hb[k_ - 8]; }
                 if (t < 2) s_cnt[t] = 0;
-                if (t < 16) ((uint32_t *)s_tm)[t] = t < 8 ? da.no_filter.vb[t] : da.no_filter.hb[t - 8];
             }
             ctu_setup();
             ATR(1);
@@ -378,7 +361,7 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
 #pragma unroll
                     for (int r = 0; r < 2; r++) *(uint2 *)(l_c[pl] + (2 * sr + r) * CSTR + 4 * wx) = C[pl][r];
                 const int bs = has_p && has_q ? addb_edge_strength<0>(da, *s_tm, rq, rp, sxq, s_pic) : 0;
-                if (bs) s_list[0][atomicAdd(&s_cnt[0], 1u)] = (uint16_t)(t | (bs << 8));
+                if (bs) s_list[0][atomicAdd(&s_cnt[0], 1u)] = (uint32_t)(t | (bs << 8));
             }
         }
         ATR(3);
@@ -457,7 +440,7 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
             const int scol = (tx0 >> 2) - 1 + sx, gy = ty0 + 8 * g;
             if (scol >= 0 && scol < da.w_scu && gy > 0 && gy < a.pic_h) {
                 const int bs = addb_edge_strength<1>(da, *s_tm, s_map[2 * g + 1][sx], s_map[2 * g][sx], gy >> 2, s_pic);
-                if (bs) s_list[1][atomicAdd(&s_cnt[1], 1u)] = (uint16_t)(t | (bs << 8));
+                if (bs) s_list[1][atomicAdd(&s_cnt[1], 1u)] = (uint32_t)(t | (bs << 8));
             }
         }
         ATR(5);

@@ -238,6 +238,8 @@ struct DbkArgs {
     uint8_t  st[3][4][64];             // strength by component, edge class, map QP (host-built from xevd_tbl_df_st)
 };
 
+#define ADDB_LDS_TABLE_BYTES (52 + 52 + 260 + XGPU_MAX_REFS * 2 + 192)
+#define ADDB_LDS_TABLE_DWORDS ((ADDB_LDS_TABLE_BYTES + 3) / 4)
 struct AddbArgs {
     int      s_l, s_c;
     int      w_scu, h_scu;
@@ -247,6 +249,8 @@ struct AddbArgs {
     const ScuRec *maps;
     int8_t   chroma_qp[2 * 96];        // [c][qp + 6*(bdc-8)]
     uint8_t  pic_id[XGPU_MAX_REFS * 2];// picture slot of refp[idx][list], 255 = none
+    // alpha[52] beta[52] clip[260] pic_id[2 * XGPU_MAX_REFS] chroma_qp[192] in the order and at the offsets of k_addb_alf's LDS copy, as dwords
+    uint32_t lds_tables[ADDB_LDS_TABLE_DWORDS];
 };
 
 #define ALF_CTB_BITS 8704           // 8192 x 4320 in 64 x 64 CTUs

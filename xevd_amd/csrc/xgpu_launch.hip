@@ -1,6 +1,7 @@
 // xgpu_launch.hip - the per-picture launch sequencing behind xgpu_batch_prepare / _recon / _recon_ahead, xgpu_deblock, xgpu_alf, xgpu_pad: which kernels, on which
 // stream, in which order, with which arguments.  The kernels live in k_*.hip.
 #include "xgpu_host.h"
+#include "addb_filter.h"
 
 // xevd_tbl_df_st (src_base/xevd_tbl.c:306-324): deblocking strength by edge class and QP - a table of the
 // MPEG-5 EVC specification.
@@ -199,6 +200,11 @@ int xgpu_deblock(xgpu_ctx *c)
         memcpy(a.chroma_qp, c->chroma_qp, sizeof(a.chroma_qp));
         for (int l = 0; l < 2; l++)
             for (int i = 0; i < XGPU_MAX_REFS; i++) a.pic_id[i * 2 + l] = i < c->fp.num_refp[l] ? (uint8_t)c->fp.refp_pic[i][l] : 255;
+        {
+            uint8_t *tb = (uint8_t *)a.lds_tables;
+            memcpy(tb, h_addb_alpha, 52); memcpy(tb + 52, h_addb_beta, 52); memcpy(tb + 104, h_addb_clip, 260);
+            memcpy(tb + 364, a.pic_id, XGPU_MAX_REFS * 2); memcpy(tb + 364 + XGPU_MAX_REFS * 2, a.chroma_qp, 192);
+        }
         if (addb_alf_fused(c)) {
             ARGCHK(c, c->where == 1 && !c->addb_pending);
             c->addb_args = a; c->addb_pending = 1;      // runs inside xgpu_alf's kernel
