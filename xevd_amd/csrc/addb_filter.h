@@ -26,7 +26,7 @@ static __constant__ uint8_t k_alpha[52] = ADDB_ALPHA_INIT;
 static __constant__ uint8_t k_beta[52] = ADDB_BETA_INIT;
 static __constant__ uint8_t k_clip[52][5] = ADDB_CLIP_INIT;
 // the same tables on the host: xgpu_deblock lays them out, with the picture's reference identities and chroma QP mapping, as the block k_addb_alf copies into LDS
-// dword by dword (AddbArgs.lds_tables; round 6 - byte stores into LDS cost ~35 LDS cycles per wave-instruction)
+// dword by dword (AddbArgs.lds_tables; round 6: one load and one store per thread instead of six byte copies from five places)
 static const uint8_t h_addb_alpha[52] = ADDB_ALPHA_INIT;
 static const uint8_t h_addb_beta[52] = ADDB_BETA_INIT;
 static const uint8_t h_addb_clip[52][5] = ADDB_CLIP_INIT;

@@ -247,7 +247,7 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
         static_assert(52 + 52 + 260 + XGPU_MAX_REFS * 2 + 192 == ADDB_LDS_TABLE_BYTES, "the LDS tables are AddbArgs.lds_tables");
         constexpr int LIST_OFF = (18 * 18 * 16 + ADDB_LDS_TABLE_BYTES + 3) & ~3;
         uint32_t *s_cnt = (uint32_t *)((uint8_t *)l_lap + LIST_OFF);
-        uint32_t (*s_list)[164] = (uint32_t (*)[164])(s_cnt + 2);            // entry = segment | strength << 8 (dwords: a 16-bit LDS store costs several times a 32-bit one)
+        uint32_t (*s_list)[164] = (uint32_t (*)[164])(s_cnt + 2);            // entry = segment | strength << 8 (dwords, like everything else the strength pass stores)
         TileMask *s_tm = (TileMask *)((uint8_t *)l_lap + LIST_OFF + 8 + 2 * 164 * 4);      // the tile-border masks: a lane-indexed read of the kernel arguments is a global load
         static_assert(LIST_OFF + 8 + 2 * 164 * 4 + (int)sizeof(TileMask) <= LAP_BYTES, "the deblocking state fits into l_lap");
 #define PK2(lo, hi) ((uint32_t)(uint16_t)(lo) | ((uint32_t)(uint16_t)(hi) << 16))
@@ -296,7 +296,7 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
             __builtin_amdgcn_sched_barrier(0);
             {
                 // the deblocking tables (alpha, beta, clip, reference identities, chroma QP mapping: one block the host lays out, AddbArgs.lds_tables) and the tile masks, a
-                // dword per thread (round 5 copied them byte by byte from five places: six sub-dword LDS stores per wave)
+                // dword per thread (round 5 copied them byte by byte from five places: six loads and six byte stores per wave)
                 static_assert(ADDB_LDS_TABLE_DWORDS + 16 <= 256, "one table dword per thread");
                 if (t < ADDB_LDS_TABLE_DWORDS) ((uint32_t *)s_alpha)[t] = da.lds_tables[t];
                 else if (t < ADDB_LDS_TABLE_DWORDS + 16) { const int k_ = t - ADDB_LDS_TABLE_DWORDS; ((uint32_t *)s_tm)[k_] = k_ < 8 ? da.no_filter.vb[k_] : da.no_filter.hb[k_ - 8]; }
@@ -342,7 +342,7 @@ __device__ __forceinline__ void alf_kernel(const AlfArgs &a, const AddbArgs *d, 
             // (and all of their loads before the first of their stores: one more round trip, not six)
             {
                 // the deblocking tables (alpha, beta, clip, reference identities, chroma QP mapping: one block the host lays out, AddbArgs.lds_tables) and the tile masks, a
-                // dword per thread (round 5 copied them byte by byte from five places: six sub-dword LDS stores per wave)
+                // dword per thread (round 5 copied them byte by byte from five places: six loads and six byte stores per wave)
                 static_assert(ADDB_LDS_TABLE_DWORDS + 16 <= 256, "one table dword per thread");
                 if (t < ADDB_LDS_TABLE_DWORDS) ((uint32_t *)s_alpha)[t] = da.lds_tables[t];
                 else if (t < ADDB_LDS_TABLE_DWORDS + 16) { const int k_ = t - ADDB_LDS_TABLE_DWORDS; ((uint32_t *)s_tm)[k_] = k_ < 8 ? da.no_filter.vb[k_] : da.no_filter.hb[k_ - 8]; }
