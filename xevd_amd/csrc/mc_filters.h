@@ -232,7 +232,8 @@ __device__ __forceinline__ uint32_t avg2(uint32_t a, uint32_t b)
 // rec = clip(0, max, (s16)(res + pred)) on packed pairs: the 16-bit sum wraps (xevd_recon.c:39,60)
 __device__ __forceinline__ uint32_t recon2(uint32_t pred, uint32_t res, int maxv)
 {
-    const v2s sum = __builtin_bit_cast(v2s, pred) + __builtin_bit_cast(v2s, res);
+    // (the sum as UNSIGNED halves: it has to wrap like the reference's (s16) cast, and signed vector overflow would be undefined - as recon2i, intra_pred.h)
+    const v2s sum = __builtin_bit_cast(v2s, __builtin_bit_cast(v2us, pred) + __builtin_bit_cast(v2us, res));
     const v2s r = __builtin_elementwise_min(__builtin_elementwise_max(sum, (v2s)(0)), (v2s)((short)maxv));
     return __builtin_bit_cast(uint32_t, r);
 }
